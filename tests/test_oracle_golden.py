@@ -1,0 +1,155 @@
+"""CPU: the oracle (oracle/tante_oracle.py) against golden vectors produced by the reference itself
+(tests/golden/make_golden.py).  This is what PINS the oracle."""
+import glob
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, load_golden, split_prefix, rel_err, max_rel
+from oracle import tante_oracle as O
+
+TOL = 2e-6   # fp32 re-association noise between two CPU evaluation orders (hard part 3)
+
+
+def names(pattern):
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, pattern + ".npz")))
+
+
+def test_g1_tiny_end_to_end():
+    g = load_golden("g1_tante_tiny")
+    cfg = O.TanteCfg(4, 1, (64, 64), taylor_order=2, attn_axes="TL-TL", n_head=4, embed_dim=64, patch_scale=8)
+    y = O.tante_forward(split_prefix(g, "w."), cfg, g["x"])
+    assert y.shape == g["y"].shape
+    assert max_rel(y, g["y"]) < TOL
+
+
+@pytest.mark.parametrize("name", names("g2_encdec_*"))
+def test_g2_encdec(name):
+    g = load_golden(name)
+    ps, ov = int(g["meta"][0]), float(g["meta"][1]) / 100
+    z = O.enc_cnn(split_prefix(g, "enc."), g["x"], ps, ov)
+    assert z.shape == g["z"].shape and max_rel(z, g["z"]) < TOL
+    r = O.dec_cnn(split_prefix(g, "dec."), g["zz"], ps, ov)
+    assert r.shape == g["r"].shape and max_rel(r, g["r"]) < TOL
+
+
+@pytest.mark.parametrize("name", names("g3_block_*"))
+def test_g3_block(name):
+    g = load_golden(name)
+    C, nh, L, causal, _ = (int(v) for v in g["meta"])
+    y = O.transformer_block(split_prefix(g, "w."), g["x"], nh, bool(causal))
+    assert max_rel(y, g["y"]) < TOL
+
+
+@pytest.mark.parametrize("name", names("g4_backbone_*"))
+def test_g4_backbone(name):
+    g = load_golden(name)
+    axes = name.split("_")[-1]
+    y = O.attn_backbone(split_prefix(g, "w."), g["x"], axes, int(g["meta"][5]))
+    assert max_rel(y, g["y"]) < TOL
+
+
+def test_g5_film_and_t_series():
+    g = load_golden("g5_film")
+    w = split_prefix(g, "w.")
+    assert torch.equal(O.t_series(4, 1.0), g["t_series_4_1"])
+    assert torch.equal(O.t_series(5, 0.5), g["t_series_5_05"])
+    assert O.t_series(4, 1.0).tolist() == [-2.0, -1.0, 0.0, 0.0]   # the duplicated-zero quirk
+    assert max_rel(O.film(w, g["x5"], g["t_series_4_1"]), g["y5"]) < TOL
+    assert max_rel(O.film(w, g["x3"], g["rt"]), g["y3"]) < TOL
+
+
+def test_g6_interprator():
+    g = load_golden("g6_interp")
+    w = split_prefix(g, "w.")
+    raw = g["raw"]
+    assert (raw < 0).any() and (raw > 0.5).any()    # both clamps are exercised
+    for out_T, key in ((1.5, "rt_1p5"), (8, "rt_8"), (1, "rt_1")):
+        assert max_rel(O.interprator(w, g["x"], out_T), g[key]) < TOL
+
+
+@pytest.mark.parametrize("tag,axes,nf", [("o1", "TH", 2), ("o2", "T-W", 2), ("o3", "T-H-W", 2)])
+def test_g7_taylor(tag, axes, nf):
+    g = load_golden("g7_taylor_" + tag)
+    order, fi, ol = int(g["meta"][0]), float(g["meta"][1]) / 100, int(g["meta"][2])
+    cfg = O.TanteCfg(3, nf, (16, 32), taylor_order=order, frame_interval=fi, output_length=ol, attn_axes=axes,
+                     n_head=2, embed_dim=32, patch_scale=8)
+    y = O.tante_forward(split_prefix(g, "w."), cfg, g["x"])
+    assert y.shape == g["y"].shape and max_rel(y, g["y"]) < TOL
+
+
+@pytest.mark.parametrize("name", names("g8_rollout_*"))
+def test_g8_rollout(name):
+    g = load_golden(name)
+    ol, n_roll = int(g["meta"][0]), int(g["meta"][1])
+    cfg = O.TanteCfg(4, 2, (16, 16), taylor_order=2, output_length=ol, attn_axes="T-L", n_head=2, embed_dim=32,
+                     patch_scale=8)
+    w = split_prefix(g, "w.")
+    assert torch.isnan(g["inp"]).any()
+    y, y_ref = O.rollout(w, cfg, {"input": g["inp"], "output": g["out"]}, n_roll)
+    assert y.shape == g["y_eval"].shape and max_rel(y, g["y_eval"]) < 5 * TOL
+    assert torch.equal(y_ref, g["y_ref"])
+    yt, _ = O.rollout(w, cfg, {"input": g["inp"], "output": g["out"][:, :4]}, 4)
+    assert yt.shape == g["y_train"].shape and max_rel(yt, g["y_train"]) < 5 * TOL
+
+
+def test_g9_train_step():
+    g = load_golden("g9_trainstep")
+    lr, wd, b1, b2, eps, max_norm = (float(v) for v in g["hyper"])
+    cfg = O.TanteCfg(4, 2, (16, 16), taylor_order=2, attn_axes="TH-WL", n_head=2, embed_dim=32, patch_scale=8)
+    w = {k: v.clone().requires_grad_(True) for k, v in split_prefix(g, "w0.").items()}
+    m = {k: torch.zeros_like(v) for k, v in w.items()}
+    v2 = {k: torch.zeros_like(v) for k, v in w.items()}
+    batch = {"input": g["inp"], "output": g["out"]}
+    for step in range(2):
+        y, y_ref = O.rollout(w, cfg, batch, 4)
+        loss = O.mse(y, y_ref).mean()
+        ks = list(w.keys())
+        grads = torch.autograd.grad(loss, [w[k] for k in ks])
+        assert abs(float(loss.detach()) - float(g[f"loss{step}"])) < 1e-5 * abs(float(g[f"loss{step}"]))
+        if step == 0:
+            assert max_rel(y, g["y_pred"]) < 5 * TOL
+            for k, gr in zip(ks, grads):
+                assert max_rel(gr, g["g0." + k]) < 2e-4, k
+        clipped, total = O.clip_grad_norm(grads, max_norm)
+        assert abs(float(total) - float(g[f"gnorm{step}"])) < 1e-4 * float(g[f"gnorm{step}"])
+        with torch.no_grad():
+            for k, gr in zip(ks, clipped):
+                p, m[k], v2[k] = O.adamw_step(w[k].detach(), gr, m[k], v2[k], step + 1, lr, wd, b1, b2, eps)
+                w[k] = p.requires_grad_(True)
+        for k in ks:
+            # Adam's first steps are sign-like (|update| ~ lr): compare on the update scale
+            assert float((w[k].detach() - g[f"w{step + 1}." + k]).abs().max()) < 2e-2 * lr, k
+
+
+def test_g10_metrics_and_lr():
+    g = load_golden("g10_metrics")
+    x, y = g["x"], g["y"]
+    assert max_rel(O.mse(x, y), g["MSE"]) < TOL
+    assert max_rel(O.l2re(x, y), g["L2RE"]) < TOL
+    assert max_rel(O.nnmse(x, y), g["NNMSE"]) < TOL
+    assert max_rel(O.vrmse(x, y), g["VRMSE"]) < TOL
+    assert max_rel(O.nmse(x, y), g["NMSE"]) < TOL
+    for k in ("below", "inside", "above"):
+        assert abs(float(O.eval_rt(g["rt_" + k])) - float(g["eval_rt_" + k])) < 1e-7
+        assert abs(float(O.mse_with_rt(x, y, g["rt_" + k])) - float(g["mse_rt_" + k])) < 1e-5
+    assert float(g["eval_rt_below"]) > 0 and float(g["eval_rt_inside"]) == 0 and float(g["eval_rt_above"]) > 0
+    lrs = g["lr_schedule"].numpy()
+    for e in range(35):
+        mine = O.warmup_cosine_lr(e, 5e-5, 2, 34, 5e-6, 5e-6)
+        assert abs(mine - lrs[e]) < 1e-10, (e, mine, lrs[e])
+
+
+def test_g13_adaptive_dt():
+    g = load_golden("g13_deg_false")
+    cfg = O.TanteCfg(4, 1, (32, 32), taylor_order=2, attn_axes="TH-TW", n_head=2, embed_dim=32, patch_scale=8,
+                     deg=False)
+    w = split_prefix(g, "w.")
+    for out_T, tag in ((1.5, "1p5"), (6, "6")):
+        y, rt = O.tante_forward(w, cfg, g["x"], out_T)
+        assert y.shape == g["y_" + tag].shape
+        assert max_rel(rt, g["rt_" + tag]) < TOL and max_rel(y, g["y_" + tag]) < TOL
+    assert g["y_6"].shape[1] > 1      # the multi-frame branch is exercised
