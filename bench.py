@@ -1,0 +1,169 @@
+#!/usr/bin/env python3
+"""Headline benchmark: autoregressive rollout frames/sec of TANTE on Active-Matter-shaped fields
+(BASELINE.json configs[1]: configs/tante_am.yaml -- 256x256x11, order-3 Taylor, bf16).
+
+A "step" is one full rollout of one batch: B samples x n_steps_rollout frames through the
+Evaler.rollout_model loop (trainer/evaler.py:121-138) with the window already resident in HBM.
+`value` = frames produced by all ranks / wall time of the K timed steps (max over ranks).
+Multi-GPU: the rollout shards over batch (independent samples, no data-path collective) -> weak scaling.
+
+Also reported on the same JSON line:
+  roofline      dominant kernel (LayerNorm-fused projection GEMM, bf16 MFMA) algorithmic FLOP/s vs the dense
+                bf16 peak, timed with HIP events around each of its launches in an instrumented pass
+  cpu_baseline  the CPU oracle (oracle/tante_oracle.py, kind "port") timed on this box's host cores on a bounded
+                sample of the same workload (rank 0, N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}      # dense MFMA peaks, MI355X_MICROARCH.md
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=10)
+    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--config", default=os.path.join(ROOT, "configs", "tante_am.yaml"))
+    p.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: workload.batch_size)")
+    p.add_argument("--dtype", default=None, choices=["bf16", "fp32"])
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-roofline", action="store_true")
+    return p.parse_args()
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import tante_amd
+    from tante_amd import kernels as K
+    cfg = tante_amd.load_config(args.config)
+    wl = cfg["workload"]
+    B = args.batch or wl["batch_size"]
+    n_steps = wl["n_steps_rollout"]
+    T_in = wl["n_steps_input"]
+    res = tuple(wl["spatial_resolution"])
+    D = wl["n_fields"]
+    dtype = args.dtype or {"bfloat16": "bf16", "float32": "fp32"}[wl.get("amp", "bfloat16")]
+    md = tante_amd.TanteMetadata(n_fields=D, spatial_resolution=res)
+    torch.manual_seed(cfg.get("seed", 211))
+    model = tante_amd.build_model(cfg, md).to(dev).eval().set_compute(dtype)
+    gen = torch.Generator().manual_seed(cfg.get("seed", 211) + rank)
+    batch = {"input": torch.randn(B, T_in, *res, D, generator=gen).to(dev),          # channels-last, like the dataset
+             "output": torch.randn(B, n_steps, *res, D, generator=gen).to(dev)}
+    fmt = tante_amd.DefaultChannelsFirstFormatter(md)
+
+    def step():
+        with torch.inference_mode():
+            y, _ = tante_amd.rollout_model(model, batch, fmt, n_steps, device=dev)
+        return y
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    frames = B * n_steps * args.steps * world
+    value = frames / elapsed
+
+    roofline = None
+    if not args.no_roofline and rank == 0:
+        # instrumented pass: HIP events (on the launch stream) around every launch of the dominant kernel
+        K_prof = []
+        orig = K.linear
+
+        def timed_linear(a, pw, out, **kw):
+            if kw.get("ln"):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                r = orig(a, pw, out, **kw)
+                e1.record()
+                M = kw.get("M") or (a.numel() // pw.K)
+                K_prof.append((e0, e1, 2.0 * M * pw.N * pw.K))
+                return r
+            return orig(a, pw, out, **kw)
+        K.linear = timed_linear
+        import tante_amd.attn_backbone as AB
+        AB.K.linear = timed_linear
+        try:
+            step()
+            torch.cuda.synchronize()
+        finally:
+            K.linear = orig
+            AB.K.linear = orig
+        tot_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in K_prof)
+        tot_fl = sum(f for _, _, f in K_prof)
+        ach = tot_fl / (tot_ms * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "kernel": "gemm_kernel<bf16,K=256,LN> (LayerNorm+QKV / LayerNorm+fc1+GELU)" if dtype == "bf16"
+                    else "gemm_kernel<fp32,K=256,LN>", "achieved": round(ach, 2), "peak": PEAK_TFLOPS[dtype],
+                    "unit": "TFLOP/s", "frac": round(ach / PEAK_TFLOPS[dtype], 4), "traffic": None,
+                    "launches": len(K_prof), "avg_launch_us": round(1e3 * tot_ms / max(1, len(K_prof)), 2)}
+
+    cpu = None
+    if not args.no_cpu_baseline and rank == 0 and world == 1:
+        from oracle import tante_oracle as O
+        mk = cfg["model"]
+        ocfg = O.TanteCfg(mk["in_T"], D, res, taylor_order=mk.get("taylor_order", 1), frame_interval=mk.get("frame_interval", 1.0),
+                          attn_axes=mk.get("attn_axes", "THWTHWTHW"), n_head=mk.get("n_head", 8), mlp_ratio=mk.get("mlp_ratio", 1.0),
+                          embed_dim=mk.get("embed_dim", 256), patch_scale=mk.get("patch_scale", 32))
+        w = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+        cores = os.cpu_count() or 1
+        torch.set_num_threads(cores)
+        Bc, nc = min(B, 4), 2
+        cb = {"input": batch["input"][:Bc].cpu(), "output": batch["output"][:Bc, :nc].cpu()}
+        with torch.no_grad():
+            O.rollout(w, ocfg, {"input": cb["input"][:1], "output": cb["output"][:1, :1]}, 1)      # warm-up
+            t0 = time.perf_counter()
+            O.rollout(w, ocfg, cb, nc)
+            tc = time.perf_counter() - t0
+        cpu = {"value": round(Bc * nc / tc, 3), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+               "sample": f"oracle rollout, {Bc} samples x {nc} frames of the same workload, fp32, {tc:.1f} s"}
+
+    if rank == 0:
+        out = {"metric": "rollout frames/sec (fwd), TANTE on 256x256 Active Matter", "value": round(value, 2), "unit": "frames/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+               "config": {"workload": os.path.basename(args.config), "fields": D, "resolution": list(res), "batch_per_gpu": B,
+                          "n_steps_input": T_in, "n_steps_rollout": n_steps, "taylor_order": cfg["model"].get("taylor_order", 1),
+                          "attn_axes": cfg["model"].get("attn_axes"), "parallelism": f"batch-sharded x{world} (no collective)"},
+               "roofline": roofline, "cpu_baseline": cpu}
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

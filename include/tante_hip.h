@@ -1,0 +1,162 @@
+/*
+ * tante_hip.h -- C ABI of libtante_hip.so, the MI355X (gfx950) kernel library behind the TANTE
+ * Taylor-rollout hot path.
+ *
+ * The reference (zwu88/TANTE) is 100 % Python and has NO existing FFI: every "kernel" on its path is
+ * an ATen op reached through nn.Module.forward().  This header therefore declares the boundary a
+ * maintainer would bind instead of those ATen calls; each entry point cites the reference lines whose
+ * arithmetic it replaces.  INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions
+ *  - plain C: pointers are DEVICE pointers owned by the caller (torch tensors' data_ptr()); the
+ *    library never allocates, frees or synchronises, and keeps no global state besides a
+ *    thread-local last-error string.  All launches go to the caller's hipStream_t (passed as void*),
+ *    so the calls are HIP-graph capturable.
+ *  - return value: 0 on success, negative on error (-1 bad argument, -2 unsupported shape,
+ *    -3 HIP launch error); tante_last_error() returns a description.  No exceptions cross the ABI.
+ *  - dtype codes: TANTE_F32 = 0, TANTE_BF16 = 1.  "compute" selects the matrix-core path:
+ *    TANTE_F32 -> v_mfma_f32_16x16x4_f32 (exact fp32), TANTE_BF16 -> v_mfma_f32_16x16x32_bf16
+ *    (fp32 accumulate).  LayerNorm statistics, softmax and GELU are always evaluated in fp32.
+ *  - token tensors are (B,T,Hp,Wp,C) row-major, C innermost ("tokens x C").
+ */
+#ifndef TANTE_HIP_H
+#define TANTE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TANTE_F32 0
+#define TANTE_BF16 1
+
+/* activation codes */
+#define TANTE_ACT_NONE 0
+#define TANTE_ACT_GELU_ERF 1  /* nn.GELU()                      enc_dec_cnn.py:215, attn_backbone.py:113 */
+#define TANTE_ACT_GELU_TANH 2 /* nn.GELU(approximate="tanh")    attn_backbone.py:54 */
+#define TANTE_ACT_RELU 3      /* nn.ReLU()                      tante.py:185,208 */
+
+/* how the rows of the left operand are gathered */
+#define TANTE_A_LINEAR 0     /* row r at ((r / n0) * s1 + (r % n0) * s0 + off) elements, K contiguous */
+#define TANTE_A_PATCH_NHWC 1 /* row = (img, ho, wo): P x P patch of a channels-last image, k = (kh, kw, ci) */
+#define TANTE_A_PATCH_NCHW 2 /* row = (img, ho, wo): P x P patch of a channels-first image, k = (ci, kh, kw) */
+
+/* what the epilogue does with a finished (row, 4 consecutive columns) group */
+#define TANTE_E_LINEAR 0      /* out[r * ld + n] = act(v + bias[n]) (+ residual[r * res_ld + n]) */
+#define TANTE_E_FILM 1        /* out = (v + bias) * film_a[t][n] + film_b[t][n] + s_emb[hw][n],  r = (b, t, hw) */
+#define TANTE_E_DECONV_NHWC 2 /* r = (img, hi, wi), n = (kh, kw, co): out[img][hi*P+kh][wi*P+kw][co] */
+#define TANTE_E_DECONV_NCHW 3 /* r = (img, hi, wi), n = (co, kh, kw): out[img][co][hi*P+kh][wi*P+kw]  (fp32) */
+
+/* source layouts understood by tante_pack_weight */
+#define TANTE_W_LINEAR 0      /* nn.Linear weight (N, K);  also Conv2d (Cout, Cin, P, P) with k = (ci, kh, kw) */
+#define TANTE_W_CONV_NHWC 1   /* Conv2d weight (Cout, Cin, P, P), k re-ordered to (kh, kw, ci) */
+#define TANTE_W_DECONV_NHWC 2 /* ConvTranspose2d weight (Cin, Cout, P, P): k = ci, n = (kh, kw, co) */
+#define TANTE_W_DECONV_NCHW 3 /* ConvTranspose2d weight (Cin, Cout, P, P): k = ci, n = (co, kh, kw) */
+
+/* Geometry of a packed weight for (N, K) under a compute dtype.  The packed image is
+ * [n_pad / nt tiles][nt rows][k_pad / chunk 16-byte chunks, XOR-swizzled], i.e. exactly the LDS
+ * tile image the GEMM streams.  bytes = n_pad * k_pad * sizeof(compute dtype). */
+typedef struct TantePackGeom {
+  int32_t n_pad, k_pad, nt, cb; /* cb = k_pad / (16 for f32 | 32 for bf16) "chunk blocks" */
+  int64_t bytes;
+} TantePackGeom;
+
+int tante_pack_geom(int N, int K, int compute, TantePackGeom* out);
+
+/* Pack (and optionally LayerNorm-fold) a weight.  If gamma != NULL the packed matrix is
+ * W * diag(gamma) and bias_out[n] = bias[n] + sum_k W[n][k] * beta[k], which turns
+ * LayerNorm(x) @ W^T + b (attn_backbone.py:68,74 and :82) into normalise(x) @ W'^T + b'.
+ * bias_out has n_pad floats; bias may be NULL (zeros).  P / C_other describe conv layouts:
+ * CONV_NHWC: C_other = Cin; DECONV_*: C_other = Cout; bias is indexed by co. */
+int tante_pack_weight(const float* w, const float* bias, const float* gamma, const float* beta, int layout, int N,
+                      int K, int P, int C_other, int compute, void* w_out, float* bias_out, void* stream);
+
+typedef struct TanteGemm {
+  /* left operand */
+  const void* a;
+  int32_t a_dtype, a_mode;
+  int32_t M, K;            /* rows, logical K (<= k_pad) */
+  int64_t a_s1, a_s0, a_off; /* LINEAR addressing (elements) */
+  int32_t a_n0;
+  int32_t Hin, Win, Cin, P; /* PATCH_*: input image (per img) and patch size; rows = imgs*(Hin/P)*(Win/P) */
+  int32_t ln;               /* 1: normalise each row over K (biased variance, eps) before the product */
+  float ln_eps;
+  /* packed right operand */
+  const void* w;
+  const float* bias; /* n_pad floats */
+  int32_t N;
+  int32_t compute; /* TANTE_F32 | TANTE_BF16, must match the packing */
+  /* epilogue */
+  int32_t act, e_mode;
+  void* out;
+  int32_t out_dtype;
+  int64_t out_ld;
+  const float* residual; /* LINEAR only, may alias out */
+  int64_t res_ld;
+  const float *film_a, *film_b, *s_emb; /* FILM: (T, N), (T, N), (HW, N) */
+  int32_t T, HW;
+  int32_t Hi, Wi, Po, Cout; /* DECONV_*: input grid per img, upsampling factor, output channels */
+} TanteGemm;
+
+/* out = epilogue(gather(a) @ W^T).  Replaces, depending on the descriptor:
+ *   F.linear inside nn.MultiheadAttention in/out projection          attn_backbone.py:74-80
+ *   LayerNorm + Linear (+GELU) of the block MLP                      attn_backbone.py:50-56,82
+ *   RealConv2d with kernel = stride (patch embed) + GELU             enc_dec_cnn.py:97-110,221-225
+ *   film(t_seq) + s_emb + t_emb epilogue                             tante.py:136-141,218-230
+ *   RealTransConv2d with kernel = stride (derivative head) + GELU    enc_dec_cnn.py:164-184,269-273 */
+int tante_gemm(const TanteGemm* g, void* stream);
+
+/* Sequence regrouping of the (B,T,Hp,Wp) token grid for one axis letter (attn_backbone.py:148-182):
+ * token(s, l) = (s / n_s0) * S1 + (s % n_s0) * S0 + (l / n_l0) * P1 + (l % n_l0) * P0. */
+typedef struct TanteSeq {
+  int32_t nseq, L;
+  int32_t n_s0;
+  int64_t S1, S0;
+  int32_t n_l0;
+  int64_t P1, P0;
+} TanteSeq;
+
+/* o[token, h*d : (h+1)*d] = softmax(q k^T / sqrt(d) [+ causal mask]) v  per (sequence, head);
+ * qkv is (tokens, 3C) as produced by the packed in-projection.  Replaces the scaled-dot-product
+ * core of nn.MultiheadAttention (attn_backbone.py:74-80) and causal_mask (l.35-36). */
+int tante_attention(const void* qkv, void* o, int dtype, int C, int n_head, const TanteSeq* seq, int causal,
+                    void* stream);
+
+/* x += W2 gelu_erf(W1 x_line + b1) + b2 along one axis of an fp32 (outer, n, inner) tensor, in place
+ * (the vertical / horizontal / temporal propagators, attn_backbone.py:111-119,140-146). */
+int tante_axis_mlp(float* x, int64_t outer, int n, int64_t inner, const float* w1, const float* b1, const float* w2,
+                   const float* b2, void* stream);
+
+/* film tables (tante.py:218-230): a[r][c] = 1 + scale(t[r])[c], b[r][c] = shift(t[r])[c] (+ add[r][c]).
+ * scale/shift = Linear(1, C/2) -> ReLU -> Linear(C/2, C).  rows = len(t). */
+int tante_film_table(const float* t, int rows, int C, const float* sc_w0, const float* sc_b0, const float* sc_w2,
+                     const float* sc_b2, const float* sh_w0, const float* sh_b0, const float* sh_w2,
+                     const float* sh_b2, const float* add, float* a_out, float* b_out, void* stream);
+
+/* y[r][c] = x_row(r)[c] * a[g][c] + b[g][c], g = r / rows_per, x_row(r) = x + g * x_bstride + (r % rows_per) * C
+ * (film on (B, L, C) tokens, tante.py:222-224,229-230; tables hold 1+scale and shift). */
+int tante_film_apply(const float* x, int64_t x_bstride, float* y, int64_t rows, int C, int64_t rows_per, const float* a,
+                     const float* b, void* stream);
+
+/* out[i] = z[i * E + E - 1]: the "[..., -1]" of the channel-attention letter 'C' (attn_backbone.py:188). */
+int tante_gather_last(const float* z, int64_t n, int E, float* out, void* stream);
+
+/* Taylor sum (tante.py:165-171): out[b][i-1] = last[b] + sum_k derivs[k][b] * (i * dt)^k / k!,
+ * i = 1..n_out.  last = input[:, -1] given as base pointer + batch stride (elements);
+ * derivs = n_order device pointers, each (B, frame) contiguous. */
+int tante_taylor(const float* last, int64_t last_bstride, const float* const* derivs, int n_order, double dt,
+                 int n_out, float* out, int64_t B, int64_t frame, void* stream);
+
+/* interprator head reduction (tante.py:194-201): t (B, L) raw per-token scalars ->
+ * rt[b] = mean_l clamp(t[b][l], 0, out_T - 1) + ep. */
+int tante_rt_reduce(const float* t, int B, int L, float out_T, float ep, float* rt, void* stream);
+
+const char* tante_last_error(void);
+int tante_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TANTE_HIP_H */

@@ -1,0 +1,15 @@
+"""tante_amd -- MI355X-native implementation of the TANTE Taylor-expansion rollout path.
+
+Host code mirrors the reference's operator surface (models.TANTE, models.attn_backbone.*,
+models.enc_dec_cnn.*, trainer rollout semantics, configs/*.yaml); the arithmetic lives in
+libtante_hip.so (include/tante_hip.h, tante_amd/csrc/*.hip).  There is no CPU fallback.
+"""
+from .tante import TANTE, TanteMetadata, enc_CNN, dec_CNN, film, interprator, t_series, Patch_map  # noqa: F401
+from .attn_backbone import Attn_Backbone, TransformerBlock  # noqa: F401
+from .rollout import (DefaultChannelsFirstFormatter, DefaultChannelsLastFormatter, rollout_model,  # noqa: F401
+                      rollout_adaptive)
+from .config import instantiate, load_config, build_model  # noqa: F401
+
+__all__ = ["TANTE", "TanteMetadata", "enc_CNN", "dec_CNN", "film", "interprator", "t_series", "Attn_Backbone",
+           "TransformerBlock", "DefaultChannelsFirstFormatter", "DefaultChannelsLastFormatter", "rollout_model",
+           "rollout_adaptive", "instantiate", "load_config", "build_model"]

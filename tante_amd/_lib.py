@@ -1,0 +1,78 @@
+"""ctypes binding of libtante_hip.so (include/tante_hip.h).  There is NO fallback: if the library is
+missing or a call fails, the product path raises."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libtante_hip.so")
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_GELU_ERF, ACT_GELU_TANH, ACT_RELU = 0, 1, 2, 3
+A_LINEAR, A_PATCH_NHWC, A_PATCH_NCHW = 0, 1, 2
+E_LINEAR, E_FILM, E_DECONV_NHWC, E_DECONV_NCHW = 0, 1, 2, 3
+W_LINEAR, W_CONV_NHWC, W_DECONV_NHWC, W_DECONV_NCHW = 0, 1, 2, 3
+
+c_i32, c_i64, c_f32, c_vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
+
+
+class PackGeom(C.Structure):
+    _fields_ = [("n_pad", c_i32), ("k_pad", c_i32), ("nt", c_i32), ("cb", c_i32), ("bytes", c_i64)]
+
+
+class Gemm(C.Structure):
+    _fields_ = [
+        ("a", c_vp), ("a_dtype", c_i32), ("a_mode", c_i32), ("M", c_i32), ("K", c_i32),
+        ("a_s1", c_i64), ("a_s0", c_i64), ("a_off", c_i64), ("a_n0", c_i32),
+        ("Hin", c_i32), ("Win", c_i32), ("Cin", c_i32), ("P", c_i32), ("ln", c_i32), ("ln_eps", c_f32),
+        ("w", c_vp), ("bias", c_vp), ("N", c_i32), ("compute", c_i32),
+        ("act", c_i32), ("e_mode", c_i32), ("out", c_vp), ("out_dtype", c_i32), ("out_ld", c_i64),
+        ("residual", c_vp), ("res_ld", c_i64),
+        ("film_a", c_vp), ("film_b", c_vp), ("s_emb", c_vp), ("T", c_i32), ("HW", c_i32),
+        ("Hi", c_i32), ("Wi", c_i32), ("Po", c_i32), ("Cout", c_i32),
+    ]
+
+
+class Seq(C.Structure):
+    _fields_ = [("nseq", c_i32), ("L", c_i32), ("n_s0", c_i32), ("S1", c_i64), ("S0", c_i64),
+                ("n_l0", c_i32), ("P1", c_i64), ("P0", c_i64)]
+
+
+SIGNATURES = {
+    "tante_pack_geom": ([c_i32, c_i32, c_i32, C.POINTER(PackGeom)], c_i32),
+    "tante_pack_weight": ([c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp], c_i32),
+    "tante_gemm": ([C.POINTER(Gemm), c_vp], c_i32),
+    "tante_attention": ([c_vp, c_vp, c_i32, c_i32, c_i32, C.POINTER(Seq), c_i32, c_vp], c_i32),
+    "tante_axis_mlp": ([c_vp, c_i64, c_i32, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp], c_i32),
+    "tante_film_table": ([c_vp, c_i32, c_i32] + [c_vp] * 8 + [c_vp, c_vp, c_vp, c_vp], c_i32),
+    "tante_film_apply": ([c_vp, c_i64, c_vp, c_i64, c_i32, c_i64, c_vp, c_vp, c_vp], c_i32),
+    "tante_taylor": ([c_vp, c_i64, C.POINTER(c_vp), c_i32, C.c_double, c_i32, c_vp, c_i64, c_i64, c_vp], c_i32),
+    "tante_rt_reduce": ([c_vp, c_i32, c_i32, c_f32, c_f32, c_vp, c_vp], c_i32),
+    "tante_gather_last": ([c_vp, c_i64, c_i32, c_vp, c_vp], c_i32),
+    "tante_last_error": ([], C.c_char_p),
+    "tante_abi_version": ([], c_i32),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded library; raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -m tante_amd.build` "
+                "(or __graft_entry__.build()).  tante_amd has no CPU / eager fallback.")
+        L = C.CDLL(LIB_PATH)
+        for name, (argtypes, restype) in SIGNATURES.items():
+            fn = getattr(L, name)      # AttributeError here = header / library mismatch
+            fn.argtypes = argtypes
+            fn.restype = restype
+        _lib = L
+    return _lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = lib().tante_last_error().decode(errors="replace")
+        raise RuntimeError(f"libtante_hip {what} failed (rc={rc}): {msg}")

@@ -1,0 +1,197 @@
+"""Axis-factorised transformer backbone on MI355X -- host side.
+
+Mirrors the reference operator surface (models/attn_backbone.py): ``TransformerBlock(embed_dim, n_head,
+mlp_ratio, dropout).forward(x, key_padding_mask, attn_mask, causal)`` and ``Attn_Backbone(tensor_shape,
+attn_axes, expanded_channel, n_head, mlp_ratio, dropout).forward(x)``, with identical parameter names,
+shapes and default initialisation (the torch.nn modules below are PARAMETER CONTAINERS only -- their
+forward() is never called; all arithmetic goes through libtante_hip.so).
+
+MI355X-first differences from the reference's execution (results identical to rounding):
+  * the residual stream stays a flat (tokens, C) fp32 array for the whole backbone; the per-letter
+    ``rearrange`` copies (attn_backbone.py:150-182) do not exist -- only the attention kernel sees the
+    regrouping, as index arithmetic (kernels.make_seq);
+  * LayerNorm is fused into the projection that consumes it (gamma/beta folded into the packed weight);
+  * bias, GELU and the residual add are GEMM epilogues.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from . import kernels as K
+
+
+def resolve_compute(module_default: Optional[str] = None) -> int:
+    """fp32 unless the caller runs under torch.autocast(bfloat16) (the reference's AMP switch,
+    trainer/trainer.py:183) or the module was pinned with set_compute()."""
+    if module_default is not None:
+        return K.COMPUTE[module_default]
+    if torch.is_autocast_enabled("cuda"):
+        dt = torch.get_autocast_dtype("cuda")
+        if dt == torch.bfloat16:
+            return L.BF16
+        raise NotImplementedError(f"autocast dtype {dt} has no MFMA path here (use bfloat16 or fp32)")
+    return L.F32
+
+
+def _no_autograd(module: nn.Module):
+    if torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters()):
+        raise NotImplementedError(
+            "tante_amd forward kernels do not record an autograd graph yet: call under torch.no_grad() / "
+            "inference_mode (rollout path).")
+
+
+class _PackCache:
+    """Packed (bf16 / fp32, swizzled, LayerNorm-folded) copies of a module's weights, rebuilt when any
+    source parameter changed (optimizer step, load_state_dict, .to())."""
+
+    def __init__(self):
+        self._store = {}
+
+    def get(self, compute: int, params, build):
+        key = tuple((p.data_ptr(), p._version) for p in params)
+        hit = self._store.get(compute)
+        if hit is None or hit[0] != key:
+            hit = (key, build())
+            self._store[compute] = hit
+        return hit[1]
+
+
+class TransformerBlock(nn.Module):
+    """Pre-LN block: x += MHA(LN1 x); x += W2 gelu_tanh(W1 LN2 x)   (attn_backbone.py:38-83)."""
+
+    def __init__(self, embed_dim: int, n_head: int, mlp_ratio: float = 4.0, dropout: float = 0.1):
+        super().__init__()
+        self.embed_dim, self.n_head, self.p_drop = embed_dim, n_head, dropout
+        self.ln1 = nn.LayerNorm(embed_dim)
+        self.attn = nn.MultiheadAttention(embed_dim, n_head, batch_first=True, dropout=dropout, bias=True)
+        self.ln2 = nn.LayerNorm(embed_dim)
+        hidden = int(embed_dim * mlp_ratio)
+        self.hidden = hidden
+        self.mlp = nn.Sequential(nn.Linear(embed_dim, hidden, bias=True), nn.GELU(approximate="tanh"),
+                                 nn.Linear(hidden, embed_dim, bias=True))
+        self.drop = nn.Dropout(dropout)
+        self._cache = _PackCache()
+        self.compute: Optional[str] = None
+
+    def _packed(self, compute: int):
+        a, m = self.attn, self.mlp
+        params = [self.ln1.weight, self.ln1.bias, a.in_proj_weight, a.in_proj_bias, a.out_proj.weight, a.out_proj.bias,
+                  self.ln2.weight, self.ln2.bias, m[0].weight, m[0].bias, m[2].weight, m[2].bias]
+
+        def build():
+            return dict(
+                qkv=K.pack_weight(a.in_proj_weight, a.in_proj_bias, compute, gamma=self.ln1.weight, beta=self.ln1.bias),
+                out=K.pack_weight(a.out_proj.weight, a.out_proj.bias, compute),
+                fc1=K.pack_weight(m[0].weight, m[0].bias, compute, gamma=self.ln2.weight, beta=self.ln2.bias),
+                fc2=K.pack_weight(m[2].weight, m[2].bias, compute))
+        return self._cache.get(compute, params, build)
+
+    def forward_tokens(self, x: torch.Tensor, seq: L.Seq, causal: bool, compute: int) -> torch.Tensor:
+        """In place on the flat fp32 residual stream x (tokens, C); `seq` says which tokens attend to which."""
+        if self.training and self.p_drop > 0.0:
+            raise NotImplementedError("dropout > 0 in training mode is not implemented on the HIP path yet")
+        C_ = self.embed_dim
+        n_tok = x.numel() // C_
+        pk = self._packed(compute)
+        adt = K.act_torch_dtype(compute)
+        qkv = torch.empty(n_tok, 3 * C_, dtype=adt, device=x.device)
+        K.linear(x, pk["qkv"], qkv, M=n_tok, ln=True, ln_eps=self.ln1.eps)
+        o = torch.empty(n_tok, C_, dtype=adt, device=x.device)
+        K.attention(qkv, o, C_, self.n_head, seq, causal)
+        K.linear(o, pk["out"], x, M=n_tok, residual=x)
+        h = qkv.view(-1)[: n_tok * self.hidden].view(n_tok, self.hidden) if self.hidden <= 3 * C_ else \
+            torch.empty(n_tok, self.hidden, dtype=adt, device=x.device)
+        K.linear(x, pk["fc1"], h, M=n_tok, ln=True, ln_eps=self.ln2.eps, act=L.ACT_GELU_TANH)
+        K.linear(h, pk["fc2"], x, M=n_tok, residual=x)
+        return x
+
+    def forward(self, x: torch.Tensor, key_padding_mask=None, attn_mask=None, causal: bool = False) -> torch.Tensor:
+        if key_padding_mask is not None or attn_mask is not None:
+            raise NotImplementedError("only the causal flag is used on the TANTE path (attn_backbone.py:148-189)")
+        _no_autograd(self)
+        Bp, Lq, C_ = x.shape
+        y = x.detach().to(torch.float32).contiguous().clone()
+        self.forward_tokens(y.view(Bp * Lq, C_), K.dense_seq(Bp, Lq), causal, resolve_compute(self.compute))
+        return y
+
+
+class Attn_Backbone(nn.Module):
+    """Three residual axis propagators, then one TransformerBlock per axis letter (attn_backbone.py:88-191)."""
+
+    def __init__(self, tensor_shape=(10, 8, 4, 256), attn_axes: str = "L TT TT TT L", expanded_channel: int = 128,
+                 n_head: int = 8, mlp_ratio: float = 1.0, dropout: float = 0.0):
+        super().__init__()
+        self.T, self.H, self.W, self.C = tensor_shape
+        self.L = self.H * self.W
+        self.expanded_channel = expanded_channel
+        if attn_axes == "":
+            raise ValueError("Invalid block: empty segment.")
+        self.attn_axes = attn_axes
+        self.n_head = n_head
+        self.blocks = nn.ModuleList()
+
+        def prop(n):
+            return nn.Sequential(nn.Linear(n, n), nn.GELU(), nn.Linear(n, n))
+        self.vertical_propagator = prop(self.H)
+        self.horizontal_propagator = prop(self.W)
+        self.temporal_propagator = prop(self.T)
+        self.channel_blocks = nn.ModuleList()
+        for axis in self.attn_axes:
+            if axis in "LTHWAXY":
+                embed_dim = self.C
+            elif axis == "C":
+                embed_dim = self.expanded_channel
+                self.channel_blocks.append(nn.Sequential(nn.Linear(1, embed_dim // 4), nn.GELU(),
+                                                         nn.Linear(embed_dim // 4, embed_dim)))
+            else:
+                raise ValueError(f"invalid axis letter {axis!r}")
+            self.blocks.append(TransformerBlock(embed_dim=embed_dim, n_head=n_head, mlp_ratio=mlp_ratio, dropout=dropout))
+        self._cache = _PackCache()
+        self.compute: Optional[str] = None
+
+    def _packed_channel(self, compute: int):
+        params = [p for cb in self.channel_blocks for p in cb.parameters()]
+
+        def build():
+            return [(K.pack_weight(cb[0].weight, cb[0].bias, compute), K.pack_weight(cb[2].weight, cb[2].bias, compute))
+                    for cb in self.channel_blocks]
+        return self._cache.get(compute, params, build)
+
+    def forward_tokens(self, x: torch.Tensor, B: int, compute: int) -> torch.Tensor:
+        """In place on x = (B,T,H,W,C) fp32 contiguous."""
+        T, H, W, C_ = self.T, self.H, self.W, self.C
+        vp, hp, tp = self.vertical_propagator, self.horizontal_propagator, self.temporal_propagator
+        K.axis_mlp(x, B * T, H, W * C_, vp[0].weight, vp[0].bias, vp[2].weight, vp[2].bias)          # l.140-141
+        K.axis_mlp(x, B * T * H, W, C_, hp[0].weight, hp[0].bias, hp[2].weight, hp[2].bias)          # l.142-143
+        K.axis_mlp(x, B, T, H * W * C_, tp[0].weight, tp[0].bias, tp[2].weight, tp[2].bias)          # l.144-145
+        ci = 0
+        for i, axis in enumerate(self.attn_axes):
+            blk = self.blocks[i]
+            if axis == "C":                                                                          # l.184-189
+                E = self.expanded_channel
+                lift1, lift2 = self._packed_channel(compute)[ci]
+                ci += 1
+                n = x.numel()
+                adt = K.act_torch_dtype(compute)
+                z1 = torch.empty(n, E // 4, dtype=adt, device=x.device)
+                K.linear(x, lift1, z1, M=n, act=L.ACT_GELU_ERF, a_s0=1)
+                z = torch.empty(n, E, dtype=torch.float32, device=x.device)
+                K.linear(z1, lift2, z, M=n)
+                blk.forward_tokens(z, K.dense_seq(n // C_, C_), False, compute)
+                K.gather_last(z, n, E, x)
+            else:
+                blk.forward_tokens(x, K.make_seq(axis, B, T, H, W), axis == "T", compute)
+        return x
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        _no_autograd(self)
+        B, T, H, W, C_ = x.shape
+        if (T, H, W, C_) != (self.T, self.H, self.W, self.C):
+            raise ValueError(f"expected (B,{self.T},{self.H},{self.W},{self.C}), got {tuple(x.shape)}")
+        y = x.detach().to(torch.float32).contiguous().clone()
+        return self.forward_tokens(y, B, resolve_compute(self.compute))

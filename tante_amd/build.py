@@ -1,0 +1,51 @@
+"""Build libtante_hip.so (gfx950) in-tree with hipcc.  No torch dependency: the library is a plain
+C-ABI shared object (include/tante_hip.h)."""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libtante_hip.so")
+SOURCES = ["gemm.hip", "attention.hip", "pointwise.hip"]
+HEADERS = [os.path.join(CSRC, "common.cuh"), os.path.join(os.path.dirname(HERE), "include", "tante_hip.h")]
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=fast"]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    os.makedirs(LIBDIR, exist_ok=True)
+    objs, jobs = [], []
+    for src in SOURCES:
+        sp = os.path.join(CSRC, src)
+        op = os.path.join(LIBDIR, src.replace(".hip", ".o"))
+        objs.append(op)
+        if force or _stale(op, [sp] + HEADERS):
+            jobs.append([HIPCC, *FLAGS, "-c", sp, "-o", op])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed: {' '.join(cmd)}\n{r.stdout}\n{r.stderr}")
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
+            list(ex.map(run, jobs))
+    if jobs or force or _stale(LIB, objs):
+        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs])
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,63 @@
+// Shared device helpers for the TANTE gfx950 kernels (CDNA4, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/tante_hip.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+#define TANTE_WAVE 64
+
+// ---- error plumbing (host) -------------------------------------------------------------------
+void tante_set_error(const char* fmt, ...);
+#define TANTE_FAIL(code, ...)      \
+  do {                             \
+    tante_set_error(__VA_ARGS__);  \
+    return (code);                 \
+  } while (0)
+#define TANTE_CHECK_LAUNCH()                                                        \
+  do {                                                                              \
+    hipError_t e__ = hipGetLastError();                                             \
+    if (e__ != hipSuccess) TANTE_FAIL(-3, "%s: %s", __func__, hipGetErrorString(e__)); \
+  } while (0)
+
+// ---- bf16 pack / unpack (round-to-nearest-even via v_cvt_pk_bf16_f32, NaN-preserving) ---------
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+  bf16x2 p;
+  p[0] = (__bf16)lo;
+  p[1] = (__bf16)hi;
+  return __builtin_bit_cast(unsigned, p);
+}
+__device__ __forceinline__ float bf16_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+
+// ---- activations (always evaluated in fp32) ---------------------------------------------------
+__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_tanh_f(float x) {
+  const float c = 0.79788456080286535588f;  // sqrt(2/pi)
+  return 0.5f * x * (1.0f + tanhf(c * (x + 0.044715f * x * x * x)));
+}
+__device__ __forceinline__ float apply_act(float x, int act) {
+  switch (act) {
+    case TANTE_ACT_GELU_ERF: return gelu_erf_f(x);
+    case TANTE_ACT_GELU_TANH: return gelu_tanh_f(x);
+    case TANTE_ACT_RELU: return fmaxf(x, 0.0f);
+    default: return x;
+  }
+}
+
+// ---- LDS weight-tile swizzle -------------------------------------------------------------------
+// A packed weight tile is [nt rows][cpr 16-byte chunks].  MFMA operand reads are ds_read_b128 with
+// lane l -> (row l&15, chunk 4*cb + (l>>4)).  XOR-ing the chunk index with the row makes every
+// 16-lane ds_read_b128 service group hit 16 distinct 16-byte slots of the 256-byte bank row
+// (cdna_hip_programming.md 5.5 T2; group lists in MI355X_MICROARCH.md "LDS").
+__host__ __device__ __forceinline__ int swz_chunk(int r, int c, int cpr) {
+  return (cpr >= 16) ? (c ^ (r & 15)) : (c ^ ((r >> 1) & 7));  // cpr == 8 -> two rows per bank row
+}

@@ -1,0 +1,612 @@
+// Token-stationary MFMA GEMM for the TANTE path:  out = epilogue(gather(A)[M,K] @ W[N,K]^T).
+//
+// Every dense contraction on the path has a huge M (tokens / patches), a small K (<= 512) and a
+// small N (<= 768), with weights of a few hundred KB that every workgroup needs in full.  So the
+// roles are the reverse of a classic tiled GEMM:
+//   * each wave keeps its 16 or 32 token rows as MFMA fragments IN REGISTERS for the whole K
+//     (loaded once from HBM, normalised there when a LayerNorm is fused, converted to bf16 there);
+//   * the packed weight streams through LDS in [NT rows][K_pad] tiles, double buffered, shared by
+//     the 4 waves; its global image is already the swizzled LDS image, so staging is a linear copy;
+//   * the MFMA "A" operand is the weight tile (rows = output features) and the "B" operand the
+//     tokens, so a lane's 4 accumulator registers are 4 CONSECUTIVE output features of ONE token:
+//     the epilogue (bias, GELU, residual, FiLM, pixel-shuffle scatter) stores 16 B (fp32) or 8 B
+//     (bf16) per lane with no cross-lane traffic.
+//
+// fp32 compute uses v_mfma_f32_16x16x4_f32 (exact fp32 products, fp32 accumulate); a lane's 16-byte
+// chunk holds k = 16*blk + 4*(lane>>4) + s, s = 0..3, and MFMA step s consumes element s of both
+// operands -- a fixed permutation of the k order inside each 16-wide block, which a dot product does
+// not care about.  bf16 compute uses v_mfma_f32_16x16x32_bf16 whose natural operand layout is
+// already one 16-byte chunk (8 consecutive k) per lane.
+#include "common.cuh"
+
+namespace {
+
+constexpr int nt_for_cb(int CB) { return (512 / CB) < 64 ? (512 / CB) : 64; }
+
+struct RowInfo {
+  long a_base;  // element offset of the row's first gathered element
+  bool ok;
+};
+
+__device__ __forceinline__ float ld_elem(const void* a, int dtype, long idx) {
+  if (dtype == TANTE_BF16) return __uint_as_float(((unsigned)((const unsigned short*)a)[idx]) << 16);
+  return ((const float*)a)[idx];
+}
+
+template <int E>
+__device__ __forceinline__ void ld_vec(const void* a, int dtype, long idx, float (&v)[E]) {
+  if (dtype == TANTE_BF16) {
+    if constexpr (E == 8) {
+      u32x4 u = *(const u32x4*)((const unsigned short*)a + idx);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        v[2 * i] = bf16_lo(u[i]);
+        v[2 * i + 1] = bf16_hi(u[i]);
+      }
+    } else {
+      u32x2 u = *(const u32x2*)((const unsigned short*)a + idx);
+      v[0] = bf16_lo(u[0]); v[1] = bf16_hi(u[0]); v[2] = bf16_lo(u[1]); v[3] = bf16_hi(u[1]);
+    }
+  } else {
+    const float* p = (const float*)a + idx;
+#pragma unroll
+    for (int i = 0; i < E / 4; ++i) {
+      f32x4 f = *(const f32x4*)(p + 4 * i);
+      v[4 * i] = f[0]; v[4 * i + 1] = f[1]; v[4 * i + 2] = f[2]; v[4 * i + 3] = f[3];
+    }
+  }
+}
+
+__device__ __forceinline__ RowInfo row_info(const TanteGemm& g, int row) {
+  RowInfo ri;
+  ri.ok = row < g.M;
+  const int r = ri.ok ? row : 0;
+  if (g.a_mode == TANTE_A_LINEAR) {
+    ri.a_base = (long)(r / g.a_n0) * g.a_s1 + (long)(r % g.a_n0) * g.a_s0 + g.a_off;
+  } else {
+    const int Wo = g.Win / g.P, Ho = g.Hin / g.P;
+    const int img = r / (Ho * Wo), rem = r % (Ho * Wo);
+    const int ho = rem / Wo, wo = rem % Wo;
+    if (g.a_mode == TANTE_A_PATCH_NHWC)
+      ri.a_base = (((long)img * g.Hin + (long)ho * g.P) * g.Win + (long)wo * g.P) * g.Cin;
+    else
+      ri.a_base = ((long)img * g.Cin * g.Hin + (long)ho * g.P) * g.Win + (long)wo * g.P;
+  }
+  return ri;
+}
+
+// E consecutive k of one gathered row (k0 = first k of the chunk); zero beyond K / beyond M.
+template <int E>
+__device__ __forceinline__ void load_chunk(const TanteGemm& g, const RowInfo& ri, int k0, bool a_vec, float (&v)[E]) {
+#pragma unroll
+  for (int i = 0; i < E; ++i) v[i] = 0.0f;
+  if (!ri.ok || k0 >= g.K) return;
+  const bool full = (k0 + E <= g.K);
+  if (g.a_mode == TANTE_A_LINEAR) {
+    if (a_vec && full) {
+      ld_vec<E>(g.a, g.a_dtype, ri.a_base + k0, v);
+    } else {
+#pragma unroll
+      for (int i = 0; i < E; ++i)
+        if (k0 + i < g.K) v[i] = ld_elem(g.a, g.a_dtype, ri.a_base + k0 + i);
+    }
+  } else if (g.a_mode == TANTE_A_PATCH_NHWC) {
+    const int seg = g.P * g.Cin;  // one kernel row = P*Cin contiguous elements
+    if (a_vec && full) {
+      const int kh = k0 / seg, rem = k0 % seg;
+      ld_vec<E>(g.a, g.a_dtype, ri.a_base + (long)kh * g.Win * g.Cin + rem, v);
+    } else {
+#pragma unroll
+      for (int i = 0; i < E; ++i) {
+        const int k = k0 + i;
+        if (k < g.K) v[i] = ld_elem(g.a, g.a_dtype, ri.a_base + (long)(k / seg) * g.Win * g.Cin + (k % seg));
+      }
+    }
+  } else {  // PATCH_NCHW: k = (ci, kh, kw)
+    const int pp = g.P * g.P;
+#pragma unroll
+    for (int i = 0; i < E; ++i) {
+      const int k = k0 + i;
+      if (k < g.K) {
+        const int ci = k / pp, kh = (k % pp) / g.P, kw = k % g.P;
+        v[i] = ld_elem(g.a, g.a_dtype, ri.a_base + ((long)ci * g.Hin + kh) * g.Win + kw);
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ void store4(void* out, int dtype, long idx, const float (&v)[4]) {
+  if (dtype == TANTE_BF16) {
+    u32x2 u;
+    u[0] = pack_bf16x2(v[0], v[1]);
+    u[1] = pack_bf16x2(v[2], v[3]);
+    *(u32x2*)((unsigned short*)out + idx) = u;
+  } else {
+    f32x4 f = {v[0], v[1], v[2], v[3]};
+    *(f32x4*)((float*)out + idx) = f;
+  }
+}
+__device__ __forceinline__ void store1(void* out, int dtype, long idx, float v) {
+  if (dtype == TANTE_BF16) {
+    ((__bf16*)out)[idx] = (__bf16)v;
+  } else {
+    ((float*)out)[idx] = v;
+  }
+}
+
+struct EpiRow {  // per token row, computed once
+  long o_base, r_base;
+  int t, hw;  // FILM
+  bool ok;
+};
+
+__device__ __forceinline__ EpiRow epi_row(const TanteGemm& g, int row) {
+  EpiRow e;
+  e.ok = row < g.M;
+  const int r = e.ok ? row : 0;
+  e.o_base = 0; e.r_base = 0; e.t = 0; e.hw = 0;
+  switch (g.e_mode) {
+    case TANTE_E_LINEAR:
+      e.o_base = (long)r * g.out_ld;
+      e.r_base = (long)r * g.res_ld;
+      break;
+    case TANTE_E_FILM:
+      e.o_base = (long)r * g.out_ld;
+      e.hw = r % g.HW;
+      e.t = (r / g.HW) % g.T;
+      break;
+    case TANTE_E_DECONV_NHWC: {
+      const int img = r / (g.Hi * g.Wi), rem = r % (g.Hi * g.Wi);
+      const int hi = rem / g.Wi, wi = rem % g.Wi;
+      e.o_base = ((long)img * g.Hi * g.Po + (long)hi * g.Po) * (g.Wi * g.Po) + (long)wi * g.Po;  // pixel index
+    } break;
+    default: {  // DECONV_NCHW
+      const int img = r / (g.Hi * g.Wi), rem = r % (g.Hi * g.Wi);
+      const int hi = rem / g.Wi, wi = rem % g.Wi;
+      const long Ho = (long)g.Hi * g.Po, Wo = (long)g.Wi * g.Po;
+      e.o_base = (long)img * g.Cout * Ho * Wo + (long)hi * g.Po * Wo + (long)wi * g.Po;
+    } break;
+  }
+  return e;
+}
+
+// finished group: token row (EpiRow), output features n0 .. n0+3 (pre-bias accumulators in v)
+__device__ __forceinline__ void epilogue4(const TanteGemm& g, const EpiRow& e, int n0, float (&v)[4], bool out_vec) {
+  if (!e.ok || n0 >= g.N) return;
+  {
+    const f32x4 b = *(const f32x4*)(g.bias + n0);  // bias is padded to n_pad
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = apply_act(v[j] + b[j], g.act);
+  }
+  switch (g.e_mode) {
+    case TANTE_E_LINEAR: {
+      if (out_vec) {
+        if (g.residual) {
+          const f32x4 r = *(const f32x4*)(g.residual + e.r_base + n0);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] += r[j];
+        }
+        store4(g.out, g.out_dtype, e.o_base + n0, v);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (n0 + j < g.N) {
+            float x = v[j];
+            if (g.residual) x += g.residual[e.r_base + n0 + j];
+            store1(g.out, g.out_dtype, e.o_base + n0 + j, x);
+          }
+      }
+    } break;
+    case TANTE_E_FILM: {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (n0 + j < g.N) {
+          const int n = n0 + j;
+          v[j] = v[j] * g.film_a[(long)e.t * g.N + n] + g.film_b[(long)e.t * g.N + n] + g.s_emb[(long)e.hw * g.N + n];
+        }
+      if (out_vec) {
+        store4(g.out, g.out_dtype, e.o_base + n0, v);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (n0 + j < g.N) store1(g.out, g.out_dtype, e.o_base + n0 + j, v[j]);
+      }
+    } break;
+    case TANTE_E_DECONV_NHWC: {
+      const int Wo = g.Wi * g.Po;
+      if (out_vec) {  // Cout % 4 == 0: the 4 features share (kh, kw)
+        const int khw = n0 / g.Cout, co = n0 % g.Cout;
+        const int kh = khw / g.Po, kw = khw % g.Po;
+        store4(g.out, g.out_dtype, (e.o_base + (long)kh * Wo + kw) * g.Cout + co, v);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (n0 + j < g.N) {
+            const int khw = (n0 + j) / g.Cout, co = (n0 + j) % g.Cout;
+            store1(g.out, g.out_dtype, (e.o_base + (long)(khw / g.Po) * Wo + (khw % g.Po)) * g.Cout + co, v[j]);
+          }
+      }
+    } break;
+    default: {  // DECONV_NCHW, n = (co, kh, kw)
+      const long Ho = (long)g.Hi * g.Po, Wo = (long)g.Wi * g.Po;
+      const int pp = g.Po * g.Po;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (n0 + j < g.N) {
+          const int n = n0 + j, co = n / pp, kh = (n % pp) / g.Po, kw = n % g.Po;
+          store1(g.out, g.out_dtype, e.o_base + (long)co * Ho * Wo + (long)kh * Wo + kw, v[j]);
+        }
+    } break;
+  }
+}
+
+template <bool BF16>
+__device__ __forceinline__ u32x4 to_frag(const float (&v)[BF16 ? 8 : 4]) {
+  u32x4 f;
+  if constexpr (BF16) {
+    f[0] = pack_bf16x2(v[0], v[1]);
+    f[1] = pack_bf16x2(v[2], v[3]);
+    f[2] = pack_bf16x2(v[4], v[5]);
+    f[3] = pack_bf16x2(v[6], v[7]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) f[i] = __float_as_uint(v[i]);
+  }
+  return f;
+}
+
+template <bool BF16, int CB, int TT, bool LN>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const TanteGemm g, int n_tiles, int tiles_per_split, int flags) {
+  constexpr int E = BF16 ? 8 : 4;       // elements per 16-byte chunk
+  constexpr int CPR = CB * 4;           // chunks per packed weight row
+  constexpr int NT = nt_for_cb(CB);     // weight rows (output features) per LDS tile
+  constexpr int NSUB = NT / 16;
+  constexpr int TILE_U = NT * CPR;      // 16-byte units per tile
+  constexpr int UPT = TILE_U / 256;     // units staged per thread
+  constexpr bool PREFETCH = (CB < 32);  // K = 512 fp32: no registers left to hold a tile across the MFMAs
+  static_assert(TILE_U % 256 == 0, "tile must split evenly over 256 threads");
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 tiles
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int kk = lane >> 4, l15 = lane & 15;
+  const int row0 = (blockIdx.x * 4 + wave) * (TT * 16);
+  const int t_begin = blockIdx.y * tiles_per_split;
+  const int t_end = min(n_tiles, t_begin + tiles_per_split);
+  const bool a_vec = flags & 1, out_vec = flags & 2;
+
+  // ---- first weight tile: issue the loads before anything else -------------------------------
+  const u32x4* wsrc = (const u32x4*)g.w;
+  u32x4 st[UPT];
+  {
+    const u32x4* p = wsrc + (size_t)t_begin * TILE_U;
+#pragma unroll
+    for (int u = 0; u < UPT; ++u) st[u] = p[tid + u * 256];
+  }
+
+  // ---- token fragments: this wave's TT*16 rows, whole K, kept in registers --------------------
+  u32x4 xf[TT][CB];
+#pragma unroll
+  for (int tt = 0; tt < TT; ++tt) {
+    const RowInfo ri = row_info(g, row0 + tt * 16 + l15);
+    if constexpr (LN) {  // LayerNorm without affine (gamma/beta are folded into the packed weight / bias)
+      float v[CB][E];
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) load_chunk<E>(g, ri, (cb * 4 + kk) * E, a_vec, v[cb]);
+      float s = 0.0f;
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+        for (int i = 0; i < E; ++i) s += v[cb][i];
+      s += __shfl_xor(s, 16);
+      s += __shfl_xor(s, 32);
+      const float mean = s / (float)g.K;
+      float q = 0.0f;
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+        for (int i = 0; i < E; ++i) {
+          const float d = ((cb * 4 + kk) * E + i < g.K) ? v[cb][i] - mean : 0.0f;
+          v[cb][i] = d;
+          q += d * d;
+        }
+      q += __shfl_xor(q, 16);
+      q += __shfl_xor(q, 32);
+      const float rstd = rsqrtf(q / (float)g.K + g.ln_eps);
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) {
+#pragma unroll
+        for (int i = 0; i < E; ++i) v[cb][i] *= rstd;
+        xf[tt][cb] = to_frag<BF16>(v[cb]);
+      }
+    } else {
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) {
+        float v[E];
+        load_chunk<E>(g, ri, (cb * 4 + kk) * E, a_vec, v);
+        xf[tt][cb] = to_frag<BF16>(v);
+      }
+    }
+  }
+
+  EpiRow er[TT];
+#pragma unroll
+  for (int tt = 0; tt < TT; ++tt) er[tt] = epi_row(g, row0 + tt * 16 + l15);
+
+  {
+    u32x4* d = (u32x4*)smem;
+#pragma unroll
+    for (int u = 0; u < UPT; ++u) d[tid + u * 256] = st[u];
+  }
+  __syncthreads();
+
+  int cur = 0;
+  for (int t = t_begin; t < t_end; ++t) {
+    const bool more = (t + 1 < t_end);
+    if (PREFETCH && more) {  // next tile's global loads fly under this tile's MFMAs
+      const u32x4* p = wsrc + (size_t)(t + 1) * TILE_U;
+#pragma unroll
+      for (int u = 0; u < UPT; ++u) st[u] = p[tid + u * 256];
+    }
+    const char* wt = smem + cur * (TILE_U * 16);
+    f32x4 acc[NSUB][TT];
+#pragma unroll
+    for (int ns = 0; ns < NSUB; ++ns)
+#pragma unroll
+      for (int tt = 0; tt < TT; ++tt) acc[ns][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+    for (int ns = 0; ns < NSUB; ++ns) {
+      const int r = ns * 16 + l15;
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) {
+        const int phys = swz_chunk(r, cb * 4 + kk, CPR);
+        const u32x4 wf = *(const u32x4*)(wt + ((r * CPR + phys) << 4));
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt) {
+          if constexpr (BF16) {
+            acc[ns][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf),
+                                                                  __builtin_bit_cast(bf16x8, xf[tt][cb]), acc[ns][tt], 0, 0, 0);
+          } else {
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+              acc[ns][tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wf[s]), __uint_as_float(xf[tt][cb][s]),
+                                                                 acc[ns][tt], 0, 0, 0);
+          }
+        }
+      }
+    }
+
+#pragma unroll
+    for (int ns = 0; ns < NSUB; ++ns)
+#pragma unroll
+      for (int tt = 0; tt < TT; ++tt) {
+        float v[4] = {acc[ns][tt][0], acc[ns][tt][1], acc[ns][tt][2], acc[ns][tt][3]};
+        epilogue4(g, er[tt], t * NT + ns * 16 + kk * 4, v, out_vec);
+      }
+
+    if (more) {
+      if constexpr (!PREFETCH) {
+        const u32x4* p = wsrc + (size_t)(t + 1) * TILE_U;
+#pragma unroll
+        for (int u = 0; u < UPT; ++u) st[u] = p[tid + u * 256];
+      }
+      u32x4* d = (u32x4*)(smem + (cur ^ 1) * (TILE_U * 16));
+#pragma unroll
+      for (int u = 0; u < UPT; ++u) d[tid + u * 256] = st[u];
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+}
+
+// ---- weight packing ----------------------------------------------------------------------------
+__device__ __forceinline__ long w_src_index(int layout, int n, int k, int N, int K, int P, int Co) {
+  switch (layout) {
+    case TANTE_W_CONV_NHWC: {  // (Cout, Cin, P, P); k = (kh, kw, ci), Co = Cin
+      const int kh = k / (P * Co), kw = (k / Co) % P, ci = k % Co;
+      return (((long)n * Co + ci) * P + kh) * P + kw;
+    }
+    case TANTE_W_DECONV_NHWC: {  // (Cin, Cout, P, P); n = (kh, kw, co), Co = Cout
+      const int kh = n / (P * Co), kw = (n / Co) % P, co = n % Co;
+      return (((long)k * Co + co) * P + kh) * P + kw;
+    }
+    case TANTE_W_DECONV_NCHW:  // (Cin, Cout, P, P); n = (co, kh, kw)
+      return (long)k * N + n;
+    default:
+      return (long)n * K + k;
+  }
+}
+
+template <bool BF16>
+__global__ void pack_kernel(const float* __restrict__ w, const float* __restrict__ gamma, int layout, int N, int K, int P,
+                            int Co, int n_pad, int cpr, int nt, u32x4* __restrict__ out) {
+  constexpr int E = BF16 ? 8 : 4;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)n_pad * cpr) return;
+  const int n = (int)(idx / cpr), c = (int)(idx % cpr);
+  float v[E];
+#pragma unroll
+  for (int i = 0; i < E; ++i) {
+    const int k = c * E + i;
+    float x = 0.0f;
+    if (n < N && k < K) {
+      x = w[w_src_index(layout, n, k, N, K, P, Co)];
+      if (gamma) x *= gamma[k];
+    }
+    v[i] = x;
+  }
+  u32x4 o;
+  if constexpr (BF16) {
+    o[0] = pack_bf16x2(v[0], v[1]); o[1] = pack_bf16x2(v[2], v[3]);
+    o[2] = pack_bf16x2(v[4], v[5]); o[3] = pack_bf16x2(v[6], v[7]);
+  } else {
+    o[0] = __float_as_uint(v[0]); o[1] = __float_as_uint(v[1]); o[2] = __float_as_uint(v[2]); o[3] = __float_as_uint(v[3]);
+  }
+  const int tile = n / nt, r = n % nt;
+  out[((long)tile * nt + r) * cpr + swz_chunk(r, c, cpr)] = o;
+}
+
+__global__ void pack_bias_kernel(const float* __restrict__ w, const float* __restrict__ bias, const float* __restrict__ beta,
+                                 int layout, int N, int K, int P, int Co, int n_pad, float* __restrict__ out) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= n_pad) return;
+  float b = 0.0f;
+  if (n < N) {
+    if (bias) {
+      int bi = n;
+      if (layout == TANTE_W_DECONV_NHWC) bi = n % Co;
+      else if (layout == TANTE_W_DECONV_NCHW) bi = n / (P * P);
+      b = bias[bi];
+    }
+    if (beta) {
+      float s = 0.0f;
+      for (int k = 0; k < K; ++k) s += w[w_src_index(layout, n, k, N, K, P, Co)] * beta[k];
+      b += s;
+    }
+  }
+  out[n] = b;
+}
+
+template <bool BF16, int CB>
+int launch_gemm(const TanteGemm& g, int n_tiles, int flags, hipStream_t s) {
+  constexpr int TT = (CB <= 8) ? 2 : 1;
+  constexpr int NT = nt_for_cb(CB);
+  const int rows_per_wg = 4 * TT * 16;
+  const int gx = (g.M + rows_per_wg - 1) / rows_per_wg;
+  // split N over workgroups until the grid fills the 256 CUs a few times over
+  int nsplit = 1;
+  while (nsplit < n_tiles && (long)gx * nsplit < 1024 && (n_tiles % (nsplit * 2) == 0)) nsplit *= 2;
+  const int per = (n_tiles + nsplit - 1) / nsplit;
+  const size_t lds = 2 * (size_t)NT * CB * 4 * 16;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)gemm_kernel<BF16, CB, TT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute((const void*)gemm_kernel<BF16, CB, TT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  if (g.ln)
+    hipLaunchKernelGGL((gemm_kernel<BF16, CB, TT, true>), dim3(gx, nsplit), dim3(256), lds, s, g, n_tiles, per, flags);
+  else
+    hipLaunchKernelGGL((gemm_kernel<BF16, CB, TT, false>), dim3(gx, nsplit), dim3(256), lds, s, g, n_tiles, per, flags);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int tante_pack_geom(int N, int K, int compute, TantePackGeom* out) {
+  if (!out || N <= 0 || K <= 0) TANTE_FAIL(-1, "tante_pack_geom: bad argument");
+  const int kb = (compute == TANTE_BF16) ? 32 : 16;
+  const int need = (K + kb - 1) / kb;
+  int cb = 2;
+  while (cb < need) cb *= 2;
+  const int cb_max = (compute == TANTE_BF16) ? 16 : 32;
+  if (cb > cb_max) TANTE_FAIL(-2, "tante_pack_geom: K=%d exceeds the register-stationary limit (512)", K);
+  out->cb = cb;
+  out->k_pad = cb * kb;
+  out->nt = nt_for_cb(cb);
+  out->n_pad = (N + out->nt - 1) / out->nt * out->nt;
+  out->bytes = (int64_t)out->n_pad * out->k_pad * ((compute == TANTE_BF16) ? 2 : 4);
+  return 0;
+}
+
+extern "C" int tante_pack_weight(const float* w, const float* bias, const float* gamma, const float* beta, int layout,
+                                 int N, int K, int P, int C_other, int compute, void* w_out, float* bias_out,
+                                 void* stream) {
+  TantePackGeom geo;
+  int rc = tante_pack_geom(N, K, compute, &geo);
+  if (rc) return rc;
+  if (!w || !w_out || !bias_out) TANTE_FAIL(-1, "tante_pack_weight: null pointer");
+  if (layout != TANTE_W_LINEAR && (P <= 0 || C_other <= 0)) TANTE_FAIL(-1, "tante_pack_weight: conv layout needs P, C_other");
+  if ((gamma || beta) && layout != TANTE_W_LINEAR) TANTE_FAIL(-1, "tante_pack_weight: LayerNorm fold only for linear weights");
+  hipStream_t s = (hipStream_t)stream;
+  const int cpr = geo.cb * 4;
+  const long units = (long)geo.n_pad * cpr;
+  const int blocks = (int)((units + 255) / 256);
+  if (compute == TANTE_BF16)
+    hipLaunchKernelGGL(pack_kernel<true>, dim3(blocks), dim3(256), 0, s, w, gamma, layout, N, K, P, C_other, geo.n_pad, cpr,
+                       geo.nt, (u32x4*)w_out);
+  else
+    hipLaunchKernelGGL(pack_kernel<false>, dim3(blocks), dim3(256), 0, s, w, gamma, layout, N, K, P, C_other, geo.n_pad, cpr,
+                       geo.nt, (u32x4*)w_out);
+  hipLaunchKernelGGL(pack_bias_kernel, dim3((geo.n_pad + 63) / 64), dim3(64), 0, s, w, bias, beta, layout, N, K, P, C_other,
+                     geo.n_pad, bias_out);
+  TANTE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int tante_gemm(const TanteGemm* gp, void* stream) {
+  if (!gp) TANTE_FAIL(-1, "tante_gemm: null descriptor");
+  const TanteGemm& g = *gp;
+  if (!g.a || !g.w || !g.bias || !g.out) TANTE_FAIL(-1, "tante_gemm: null pointer");
+  if (g.M <= 0 || g.N <= 0 || g.K <= 0) TANTE_FAIL(-1, "tante_gemm: bad shape M=%d N=%d K=%d", g.M, g.N, g.K);
+  if (g.compute != TANTE_F32 && g.compute != TANTE_BF16) TANTE_FAIL(-1, "tante_gemm: bad compute dtype");
+  TantePackGeom geo;
+  int rc = tante_pack_geom(g.N, g.K, g.compute, &geo);
+  if (rc) return rc;
+  const int E = (g.compute == TANTE_BF16) ? 8 : 4;
+  const int al = (g.a_dtype == TANTE_BF16) ? E : 4;  // elements per aligned vector load
+  int flags = 0;
+  const bool a_ptr_ok = ((uintptr_t)g.a % 16) == 0;
+  switch (g.a_mode) {
+    case TANTE_A_LINEAR:
+      if (g.a_n0 <= 0) TANTE_FAIL(-1, "tante_gemm: a_n0 must be > 0");
+      if (a_ptr_ok && g.a_s1 % al == 0 && g.a_s0 % al == 0 && g.a_off % al == 0) flags |= 1;
+      break;
+    case TANTE_A_PATCH_NHWC:
+    case TANTE_A_PATCH_NCHW:
+      if (g.P <= 0 || g.Hin % g.P || g.Win % g.P || g.Cin <= 0) TANTE_FAIL(-1, "tante_gemm: bad patch geometry");
+      if (g.K != g.Cin * g.P * g.P) TANTE_FAIL(-1, "tante_gemm: K != Cin*P*P");
+      if (g.M % ((g.Hin / g.P) * (g.Win / g.P))) TANTE_FAIL(-1, "tante_gemm: M is not a whole number of images");
+      if (g.a_mode == TANTE_A_PATCH_NHWC && a_ptr_ok && (g.P * g.Cin) % E == 0 && g.Cin % al == 0) flags |= 1;
+      break;
+    default:
+      TANTE_FAIL(-1, "tante_gemm: bad a_mode %d", g.a_mode);
+  }
+  const int oal = 4;
+  const bool o_ptr_ok = ((uintptr_t)g.out % 16) == 0;
+  switch (g.e_mode) {
+    case TANTE_E_LINEAR:
+      if (o_ptr_ok && g.N % 4 == 0 && g.out_ld % oal == 0 &&
+          (!g.residual || (g.res_ld % 4 == 0 && ((uintptr_t)g.residual % 16) == 0)))
+        flags |= 2;
+      break;
+    case TANTE_E_FILM:
+      if (!g.film_a || !g.film_b || !g.s_emb || g.T <= 0 || g.HW <= 0) TANTE_FAIL(-1, "tante_gemm: FILM epilogue needs tables");
+      if (o_ptr_ok && g.N % 4 == 0 && g.out_ld % oal == 0) flags |= 2;
+      break;
+    case TANTE_E_DECONV_NHWC:
+    case TANTE_E_DECONV_NCHW:
+      if (g.Hi <= 0 || g.Wi <= 0 || g.Po <= 0 || g.Cout <= 0) TANTE_FAIL(-1, "tante_gemm: bad deconv geometry");
+      if (g.N != g.Cout * g.Po * g.Po) TANTE_FAIL(-1, "tante_gemm: N != Cout*P*P");
+      if (g.M % (g.Hi * g.Wi)) TANTE_FAIL(-1, "tante_gemm: M is not a whole number of images");
+      if (g.e_mode == TANTE_E_DECONV_NCHW && g.out_dtype != TANTE_F32) TANTE_FAIL(-1, "tante_gemm: NCHW output is fp32");
+      if (g.e_mode == TANTE_E_DECONV_NHWC && o_ptr_ok && g.Cout % 4 == 0) flags |= 2;
+      break;
+    default:
+      TANTE_FAIL(-1, "tante_gemm: bad e_mode %d", g.e_mode);
+  }
+  if (((uintptr_t)g.w % 16) || ((uintptr_t)g.bias % 16)) TANTE_FAIL(-1, "tante_gemm: packed weight/bias must be 16-byte aligned");
+  const int n_tiles = geo.n_pad / geo.nt;
+  hipStream_t s = (hipStream_t)stream;
+  const bool bf = g.compute == TANTE_BF16;
+#define TANTE_DISPATCH(CBV)                                          \
+  case CBV:                                                          \
+    if (bf) launch_gemm<true, CBV>(g, n_tiles, flags, s);            \
+    else launch_gemm<false, CBV>(g, n_tiles, flags, s);              \
+    break;
+  switch (geo.cb) {
+    TANTE_DISPATCH(2)
+    TANTE_DISPATCH(4)
+    TANTE_DISPATCH(8)
+    TANTE_DISPATCH(16)
+    case 32:
+      if (bf) TANTE_FAIL(-2, "tante_gemm: K too large for bf16 path");
+      launch_gemm<false, 32>(g, n_tiles, flags, s);
+      break;
+    default:
+      TANTE_FAIL(-2, "tante_gemm: unsupported K");
+  }
+#undef TANTE_DISPATCH
+  TANTE_CHECK_LAUNCH();
+  return 0;
+}

@@ -1,0 +1,281 @@
+// HBM-bound stages of the TANTE path: axis propagators, FiLM tables, Taylor sum, step-size reduction.
+#include "common.cuh"
+
+namespace {
+
+// ---- axis propagator:  x += W2 gelu_erf(W1 x_line + b1) + b2  along a strided axis -------------------
+// x is viewed as (outer, n, inner) fp32; one lane owns one (outer, inner) column, i.e. a line of n
+// values with stride `inner`; consecutive lanes own consecutive inner indices, so every load/store
+// instruction of a wave covers 256 contiguous bytes.  The line, the hidden vector and both n x n
+// weight matrices are small: the line lives in registers (N is a template parameter so the register
+// arrays are statically indexed) and the weights are read with wave-uniform addresses (scalar loads).
+template <int N>
+__global__ __launch_bounds__(256) void axis_mlp_kernel(float* __restrict__ x, long outer, int n, long inner,
+                                                       const float* __restrict__ w1, const float* __restrict__ b1,
+                                                       const float* __restrict__ w2, const float* __restrict__ b2) {
+  // weights zero-padded to N x N in LDS; w2 stored transposed so that both inner loops read one
+  // contiguous row per hidden unit j with a wave-uniform address (ds_read_b128 broadcast)
+  __shared__ __attribute__((aligned(16))) float w1s[N * N];
+  __shared__ __attribute__((aligned(16))) float w2ts[N * N];
+  __shared__ __attribute__((aligned(16))) float b1s[N];
+  __shared__ __attribute__((aligned(16))) float b2s[N];
+  for (int idx = threadIdx.x; idx < N * N; idx += 256) {
+    const int j = idx / N, a = idx % N;
+    const bool in = (j < n) && (a < n);
+    w1s[idx] = in ? w1[j * n + a] : 0.0f;
+    w2ts[idx] = in ? w2[a * n + j] : 0.0f;
+  }
+  if (threadIdx.x < N) {
+    b1s[threadIdx.x] = (threadIdx.x < n) ? b1[threadIdx.x] : 0.0f;
+    b2s[threadIdx.x] = (threadIdx.x < n) ? b2[threadIdx.x] : 0.0f;
+  }
+  __syncthreads();
+  const long col = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= outer * inner) return;
+  const long o = col / inner, i = col - o * inner;
+  float* p = x + o * (long)n * inner + i;
+  float v[N], acc[N];
+#pragma unroll
+  for (int a = 0; a < N; ++a) {
+    v[a] = (a < n) ? p[(long)a * inner] : 0.0f;
+    acc[a] = b2s[a];
+  }
+  for (int j = 0; j < n; ++j) {
+    float s = b1s[j];
+#pragma unroll
+    for (int a4 = 0; a4 < N / 4; ++a4) {
+      const f32x4 w = *(const f32x4*)(w1s + j * N + 4 * a4);
+      s += w[0] * v[4 * a4] + w[1] * v[4 * a4 + 1] + w[2] * v[4 * a4 + 2] + w[3] * v[4 * a4 + 3];
+    }
+    const float h = gelu_erf_f(s);
+#pragma unroll
+    for (int a4 = 0; a4 < N / 4; ++a4) {
+      const f32x4 w = *(const f32x4*)(w2ts + j * N + 4 * a4);
+      acc[4 * a4] += w[0] * h;
+      acc[4 * a4 + 1] += w[1] * h;
+      acc[4 * a4 + 2] += w[2] * h;
+      acc[4 * a4 + 3] += w[3] * h;
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < N; ++a)
+    if (a < n) p[(long)a * inner] = v[a] + acc[a];
+}
+
+// generic fallback for long axes (n > 64): line and hidden vector live in LDS, [n][64 lanes]
+__global__ __launch_bounds__(64) void axis_mlp_lds_kernel(float* __restrict__ x, long outer, int n, long inner,
+                                                          const float* __restrict__ w1, const float* __restrict__ b1,
+                                                          const float* __restrict__ w2, const float* __restrict__ b2) {
+  extern __shared__ float sm[];  // v[n][64], h[n][64]
+  float* vs = sm;
+  float* hs = sm + (long)n * 64;
+  const int lane = threadIdx.x;
+  const long col = (long)blockIdx.x * 64 + lane;
+  const bool live = col < outer * inner;
+  const long o = live ? col / inner : 0, i = live ? col - o * inner : 0;
+  float* p = x + o * (long)n * inner + i;
+  for (int a = 0; a < n; ++a) vs[a * 64 + lane] = live ? p[(long)a * inner] : 0.0f;
+  for (int j = 0; j < n; ++j) {
+    float s = b1[j];
+    for (int a = 0; a < n; ++a) s += w1[j * n + a] * vs[a * 64 + lane];
+    hs[j * 64 + lane] = gelu_erf_f(s);
+  }
+  if (!live) return;
+  for (int a = 0; a < n; ++a) {
+    float s = b2[a];
+    for (int j = 0; j < n; ++j) s += w2[a * n + j] * hs[j * 64 + lane];
+    p[(long)a * inner] = vs[a * 64 + lane] + s;
+  }
+}
+
+// ---- FiLM tables ------------------------------------------------------------------------------------
+// a[r][c] = 1 + W2s relu(w0s * t[r] + b0s) + b2s ; b[r][c] = W2h relu(w0h * t[r] + b0h) + b2h (+ add[r][c])
+__global__ void film_table_kernel(const float* __restrict__ t, int rows, int C, const float* __restrict__ sc_w0,
+                                  const float* __restrict__ sc_b0, const float* __restrict__ sc_w2, const float* __restrict__ sc_b2,
+                                  const float* __restrict__ sh_w0, const float* __restrict__ sh_b0, const float* __restrict__ sh_w2,
+                                  const float* __restrict__ sh_b2, const float* __restrict__ add, float* __restrict__ a_out,
+                                  float* __restrict__ b_out) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * C) return;
+  const int r = idx / C, c = idx % C, Hd = C / 2;
+  const float tv = t[r];
+  float sa = sc_b2[c], sb = sh_b2[c];
+  for (int j = 0; j < Hd; ++j) {
+    sa += sc_w2[c * Hd + j] * fmaxf(sc_w0[j] * tv + sc_b0[j], 0.0f);
+    sb += sh_w2[c * Hd + j] * fmaxf(sh_w0[j] * tv + sh_b0[j], 0.0f);
+  }
+  a_out[idx] = 1.0f + sa;
+  b_out[idx] = sb + (add ? add[idx] : 0.0f);
+}
+
+__global__ void film_apply_kernel(const float* __restrict__ x, long x_bstride, float* __restrict__ y, long rows, int C4,
+                                  long rows_per, const float* __restrict__ a, const float* __restrict__ b) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;  // one float4 per thread
+  if (idx >= rows * C4) return;
+  const long r = idx / C4;
+  const int c4 = (int)(idx - r * C4);
+  const long g = r / rows_per, i = r - g * rows_per;
+  const f32x4 xv = *(const f32x4*)(x + g * x_bstride + (i * C4 + c4) * 4);
+  const f32x4 av = ((const f32x4*)a)[g * C4 + c4], bv = ((const f32x4*)b)[g * C4 + c4];
+  ((f32x4*)y)[idx] = xv * av + bv;
+}
+
+// out[i] = z[i * E + E - 1]  (letter 'C': keep the last lifted channel, attn_backbone.py:188)
+__global__ void gather_last_kernel(const float* __restrict__ z, long n, int E, float* __restrict__ out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = z[i * E + (E - 1)];
+}
+
+// ---- Taylor sum -------------------------------------------------------------------------------------
+struct TaylorArgs {
+  const float* d[8];
+  float coef[8][8];  // [out frame i-1][order k-1] = (i*dt)^k / k!
+};
+
+template <int NO>
+__global__ void taylor_kernel(const float* __restrict__ last, long last_bstride, const TaylorArgs ta, int n_out,
+                              float* __restrict__ out, long B, long frame4) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;  // float4 index within (B, frame)
+  if (idx >= B * frame4) return;
+  const long b = idx / frame4, f = idx - b * frame4;
+  const f32x4 base = *(const f32x4*)(last + b * last_bstride + 4 * f);
+  f32x4 dv[NO];
+#pragma unroll
+  for (int k = 0; k < NO; ++k) dv[k] = ((const f32x4*)ta.d[k])[idx];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {  // static indices only: a runtime index into the kernarg struct goes to scratch
+    if (i < n_out) {
+      f32x4 o = base;
+#pragma unroll
+      for (int k = 0; k < NO; ++k) o += dv[k] * ta.coef[i][k];
+      ((f32x4*)out)[(b * n_out + i) * frame4 + f] = o;
+    }
+  }
+}
+
+// rt[b] = mean_l clamp(t[b][l], 0, out_T - 1) + ep ; one wave per sample
+__global__ __launch_bounds__(64) void rt_reduce_kernel(const float* __restrict__ t, int L, float hi, float ep, float* __restrict__ rt) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  float s = 0.0f;
+  for (int l = lane; l < L; l += 64) {
+    const float v = t[(long)b * L + l];
+    // t + relu(-t) - relu(t - hi): forward value of the straight-through clamp (tante.py:196-198)
+    s += v + fmaxf(-v, 0.0f) - fmaxf(v - hi, 0.0f);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if (lane == 0) rt[b] = s / (float)L + ep;
+}
+
+template <int N>
+void launch_axis(float* x, long outer, int n, long inner, const float* w1, const float* b1, const float* w2, const float* b2,
+                 hipStream_t s) {
+  const long cols = outer * inner;
+  hipLaunchKernelGGL(axis_mlp_kernel<N>, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, s, x, outer, n, inner, w1, b1, w2, b2);
+}
+
+}  // namespace
+
+extern "C" int tante_axis_mlp(float* x, int64_t outer, int n, int64_t inner, const float* w1, const float* b1,
+                              const float* w2, const float* b2, void* stream) {
+  if (!x || !w1 || !b1 || !w2 || !b2) TANTE_FAIL(-1, "tante_axis_mlp: null pointer");
+  if (outer <= 0 || n <= 0 || inner <= 0) TANTE_FAIL(-1, "tante_axis_mlp: bad shape");
+  hipStream_t s = (hipStream_t)stream;
+  if (n <= 4) launch_axis<4>(x, outer, n, inner, w1, b1, w2, b2, s);
+  else if (n <= 8) launch_axis<8>(x, outer, n, inner, w1, b1, w2, b2, s);
+  else if (n <= 16) launch_axis<16>(x, outer, n, inner, w1, b1, w2, b2, s);
+  else if (n <= 32) launch_axis<32>(x, outer, n, inner, w1, b1, w2, b2, s);
+  else if (n <= 48) launch_axis<48>(x, outer, n, inner, w1, b1, w2, b2, s);
+  else if (n <= 64) launch_axis<64>(x, outer, n, inner, w1, b1, w2, b2, s);
+  else {
+    const size_t lds = 2 * (size_t)n * 64 * sizeof(float);
+    if (lds > 160 * 1024) TANTE_FAIL(-2, "tante_axis_mlp: axis length %d too long", n);
+    if (lds > 64 * 1024)
+      hipFuncSetAttribute((const void*)axis_mlp_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const long cols = outer * inner;
+    hipLaunchKernelGGL(axis_mlp_lds_kernel, dim3((unsigned)((cols + 63) / 64)), dim3(64), lds, s, x, outer, n, inner, w1, b1, w2, b2);
+  }
+  TANTE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int tante_film_table(const float* t, int rows, int C, const float* sc_w0, const float* sc_b0, const float* sc_w2,
+                                const float* sc_b2, const float* sh_w0, const float* sh_b0, const float* sh_w2,
+                                const float* sh_b2, const float* add, float* a_out, float* b_out, void* stream) {
+  if (!t || !sc_w0 || !sc_b0 || !sc_w2 || !sc_b2 || !sh_w0 || !sh_b0 || !sh_w2 || !sh_b2 || !a_out || !b_out)
+    TANTE_FAIL(-1, "tante_film_table: null pointer");
+  if (rows <= 0 || C <= 0 || C % 2) TANTE_FAIL(-1, "tante_film_table: bad shape");
+  hipLaunchKernelGGL(film_table_kernel, dim3((rows * C + 255) / 256), dim3(256), 0, (hipStream_t)stream, t, rows, C, sc_w0, sc_b0,
+                     sc_w2, sc_b2, sh_w0, sh_b0, sh_w2, sh_b2, add, a_out, b_out);
+  TANTE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int tante_film_apply(const float* x, int64_t x_bstride, float* y, int64_t rows, int C, int64_t rows_per,
+                                const float* a, const float* b, void* stream) {
+  if (!x || !y || !a || !b) TANTE_FAIL(-1, "tante_film_apply: null pointer");
+  if (rows <= 0 || C <= 0 || C % 4 || rows_per <= 0 || x_bstride % 4)
+    TANTE_FAIL(-1, "tante_film_apply: bad shape (C and the batch stride must be multiples of 4)");
+  const long n4 = rows * (C / 4);
+  hipLaunchKernelGGL(film_apply_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x,
+                     (long)x_bstride, y, (long)rows, C / 4, (long)rows_per, a, b);
+  TANTE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int tante_gather_last(const float* z, int64_t n, int E, float* out, void* stream) {
+  if (!z || !out || n <= 0 || E <= 0) TANTE_FAIL(-1, "tante_gather_last: bad argument");
+  hipLaunchKernelGGL(gather_last_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, z, (long)n, E, out);
+  TANTE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int tante_taylor(const float* last, int64_t last_bstride, const float* const* derivs, int n_order, double dt,
+                            int n_out, float* out, int64_t B, int64_t frame, void* stream) {
+  if (!last || !derivs || !out) TANTE_FAIL(-1, "tante_taylor: null pointer");
+  if (n_order < 1 || n_order > 8 || n_out < 1 || n_out > 8) TANTE_FAIL(-2, "tante_taylor: order and n_out must be in 1..8");
+  if (frame % 4 || last_bstride % 4 || ((uintptr_t)last % 16) || ((uintptr_t)out % 16))
+    TANTE_FAIL(-2, "tante_taylor: frame size / stride must be multiples of 4 floats, 16-byte aligned");
+  TaylorArgs ta;
+  for (int k = 0; k < 8; ++k) ta.d[k] = (k < n_order) ? derivs[k] : nullptr;
+  for (int i = 0; i < 8; ++i) {
+    double fact = 1.0;
+    for (int k = 0; k < 8; ++k) {
+      fact *= (double)(k + 1);
+      // (i*dt)^k / k!  evaluated like the reference: python float pow, then divide (tante.py:168)
+      double p = 1.0;
+      for (int e = 0; e <= k; ++e) p *= (double)(i + 1) * (double)dt;
+      ta.coef[i][k] = (float)(p / fact);
+    }
+  }
+  const long n4 = B * (frame / 4);
+  const dim3 grid((unsigned)((n4 + 255) / 256));
+  hipStream_t s = (hipStream_t)stream;
+#define TANTE_TAYLOR(NO) \
+  case NO: hipLaunchKernelGGL(taylor_kernel<NO>, grid, dim3(256), 0, s, last, (long)last_bstride, ta, n_out, out, (long)B, (long)(frame / 4)); break;
+  switch (n_order) {
+    TANTE_TAYLOR(1) TANTE_TAYLOR(2) TANTE_TAYLOR(3) TANTE_TAYLOR(4)
+    TANTE_TAYLOR(5) TANTE_TAYLOR(6) TANTE_TAYLOR(7) TANTE_TAYLOR(8)
+  }
+#undef TANTE_TAYLOR
+  TANTE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int tante_rt_reduce(const float* t, int B, int L, float out_T, float ep, float* rt, void* stream) {
+  if (!t || !rt || B <= 0 || L <= 0) TANTE_FAIL(-1, "tante_rt_reduce: bad argument");
+  hipLaunchKernelGGL(rt_reduce_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, t, L, out_T - 1.0f, ep, rt);
+  TANTE_CHECK_LAUNCH();
+  return 0;
+}
+
+// ---- error string / version -----------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void tante_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* tante_last_error(void) { return g_err; }
+extern "C" int tante_abi_version(void) { return 1; }

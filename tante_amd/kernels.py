@@ -1,0 +1,234 @@
+"""Thin torch-tensor front end of the C ABI (include/tante_hip.h).
+
+PyTorch supplies device memory and the current stream only; every computation below is a call into
+libtante_hip.so.  Nothing here falls back to ATen arithmetic: CPU tensors or a missing library raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import torch
+
+from . import _lib as L
+
+_DT = {torch.float32: L.F32, torch.bfloat16: L.BF16}
+COMPUTE = {"fp32": L.F32, "float32": L.F32, "bf16": L.BF16, "bfloat16": L.BF16}
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("tante_amd kernels need CUDA/HIP tensors (no CPU fallback)")
+        if not t.is_contiguous():
+            raise RuntimeError("tante_amd kernels need contiguous tensors")
+
+
+def _p(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def act_torch_dtype(compute: int) -> torch.dtype:
+    return torch.bfloat16 if compute == L.BF16 else torch.float32
+
+
+class PackedWeight:
+    """A weight in the GEMM's streaming layout (+ its fp32 bias, LayerNorm shift folded in)."""
+    __slots__ = ("w", "bias", "N", "K", "compute", "geom")
+
+    def __init__(self, w, bias, N, K, compute, geom):
+        self.w, self.bias, self.N, self.K, self.compute, self.geom = w, bias, N, K, compute, geom
+
+
+def pack_geom(N: int, K: int, compute: int) -> L.PackGeom:
+    g = L.PackGeom()
+    L.check(L.lib().tante_pack_geom(N, K, compute, C.byref(g)), "tante_pack_geom")
+    return g
+
+
+def pack_weight(w: torch.Tensor, bias: Optional[torch.Tensor], compute: int, layout: int = L.W_LINEAR,
+                N: Optional[int] = None, K: Optional[int] = None, P: int = 0, C_other: int = 0,
+                gamma: Optional[torch.Tensor] = None, beta: Optional[torch.Tensor] = None) -> PackedWeight:
+    w = w.detach()
+    _dev(w, bias, gamma, beta)
+    if w.dtype != torch.float32:
+        raise RuntimeError("master weights are fp32")
+    if layout == L.W_LINEAR:
+        N = w.shape[0] if N is None else N
+        K = w[0].numel() if K is None else K
+    assert N is not None and K is not None
+    g = pack_geom(N, K, compute)
+    wp = torch.empty(g.bytes, dtype=torch.uint8, device=w.device)
+    bp = torch.empty(g.n_pad, dtype=torch.float32, device=w.device)
+    L.check(L.lib().tante_pack_weight(_p(w), _p(None if bias is None else bias.detach()),
+                                      _p(None if gamma is None else gamma.detach()),
+                                      _p(None if beta is None else beta.detach()), layout, N, K, P, C_other, compute,
+                                      _p(wp), _p(bp), _stream()), "tante_pack_weight")
+    return PackedWeight(wp, bp, N, K, compute, g)
+
+
+def _base(pw: PackedWeight, a: torch.Tensor, M: int, out: torch.Tensor, act: int) -> L.Gemm:
+    _dev(a, out)
+    g = L.Gemm()
+    g.a, g.a_dtype, g.M, g.K = _p(a), _DT[a.dtype], M, pw.K
+    g.w, g.bias, g.N, g.compute = _p(pw.w), _p(pw.bias), pw.N, pw.compute
+    g.act, g.out, g.out_dtype = act, _p(out), _DT[out.dtype]
+    g.a_n0 = 1
+    return g
+
+
+def _run(g: L.Gemm):
+    L.check(L.lib().tante_gemm(C.byref(g), _stream()), "tante_gemm")
+
+
+def linear(a: torch.Tensor, pw: PackedWeight, out: torch.Tensor, *, M: Optional[int] = None, act: int = L.ACT_NONE,
+           ln: bool = False, ln_eps: float = 1e-5, residual: Optional[torch.Tensor] = None,
+           a_n0: Optional[int] = None, a_s1: int = 0, a_s0: Optional[int] = None, a_off: int = 0,
+           out_ld: Optional[int] = None):
+    """out[M, N] = act(norm?(rows(a)) @ W^T + b) (+ residual).  Row r of `a` starts at element
+    (r // a_n0) * a_s1 + (r % a_n0) * a_s0 + a_off  (default: dense rows of length K)."""
+    K = pw.K
+    M = (a.numel() // K) if M is None else M
+    g = _base(pw, a, M, out, act)
+    g.a_mode = L.A_LINEAR
+    g.a_n0 = M if a_n0 is None else a_n0
+    g.a_s1, g.a_s0, g.a_off = a_s1, (K if a_s0 is None else a_s0), a_off
+    g.ln, g.ln_eps = int(ln), ln_eps
+    g.e_mode = L.E_LINEAR
+    g.out_ld = pw.N if out_ld is None else out_ld
+    if residual is not None:
+        _dev(residual)
+        if residual.dtype != torch.float32:
+            raise RuntimeError("residual stream is fp32")
+        g.residual, g.res_ld = _p(residual), pw.N
+    _run(g)
+    return out
+
+
+def patch_embed(a: torch.Tensor, pw: PackedWeight, out: torch.Tensor, *, n_img: int, Hin: int, Win: int, Cin: int, P: int,
+                nchw: bool, act: int, film: Optional[tuple] = None):
+    """Patch conv with kernel = stride = P as a GEMM over non-overlapping patches.  `a` is
+    (n_img, Cin, Hin, Win) when nchw else (n_img, Hin, Win, Cin); out is channels-last
+    (n_img, Hin/P, Win/P, N).  film = (film_a, film_b, s_emb, T, HW) selects the FiLM + positional epilogue."""
+    M = n_img * (Hin // P) * (Win // P)
+    g = _base(pw, a, M, out, act)
+    g.a_mode = L.A_PATCH_NCHW if nchw else L.A_PATCH_NHWC
+    g.Hin, g.Win, g.Cin, g.P = Hin, Win, Cin, P
+    g.out_ld = pw.N
+    if film is None:
+        g.e_mode = L.E_LINEAR
+    else:
+        fa, fb, se, T, HW = film
+        _dev(fa, fb, se)
+        g.e_mode = L.E_FILM
+        g.film_a, g.film_b, g.s_emb, g.T, g.HW = _p(fa), _p(fb), _p(se), T, HW
+    _run(g)
+    return out
+
+
+def deconv(a: torch.Tensor, pw: PackedWeight, out: torch.Tensor, *, n_img: int, Hi: int, Wi: int, P: int, Cout: int,
+           nchw_out: bool, act: int, a_n0: Optional[int] = None, a_s1: int = 0, a_s0: Optional[int] = None, a_off: int = 0):
+    """ConvTranspose2d with kernel = stride = P: one GEMM row per input pixel, N = Cout*P*P outputs
+    scattered (pixel-shuffle) into (n_img, Hi*P, Wi*P, Cout) [channels-last] or (n_img, Cout, Hi*P, Wi*P)."""
+    M = n_img * Hi * Wi
+    g = _base(pw, a, M, out, act)
+    g.a_mode = L.A_LINEAR
+    g.a_n0 = M if a_n0 is None else a_n0
+    g.a_s1, g.a_s0, g.a_off = a_s1, (pw.K if a_s0 is None else a_s0), a_off
+    g.e_mode = L.E_DECONV_NCHW if nchw_out else L.E_DECONV_NHWC
+    g.Hi, g.Wi, g.Po, g.Cout = Hi, Wi, P, Cout
+    _run(g)
+    return out
+
+
+def make_seq(letter: str, B: int, T: int, H: int, W: int) -> L.Seq:
+    """Token regrouping of one axis letter over a (B,T,H,W) grid (attn_backbone.py:148-182)."""
+    s = L.Seq()
+    HW, THW = H * W, T * H * W
+    if letter == "T":
+        s.nseq, s.L, s.n_s0, s.S1, s.S0, s.n_l0, s.P1, s.P0 = B * HW, T, HW, THW, 1, T, 0, HW
+    elif letter == "H":
+        s.nseq, s.L, s.n_s0, s.S1, s.S0, s.n_l0, s.P1, s.P0 = B * T * W, H, W, HW, 1, H, 0, W
+    elif letter == "W":
+        s.nseq, s.L, s.n_s0, s.S1, s.S0, s.n_l0, s.P1, s.P0 = B * T * H, W, 1, W, 0, W, 0, 1
+    elif letter == "L":
+        s.nseq, s.L, s.n_s0, s.S1, s.S0, s.n_l0, s.P1, s.P0 = B * T, HW, 1, HW, 0, HW, 0, 1
+    elif letter == "Y":   # (b w) (t h)
+        s.nseq, s.L, s.n_s0, s.S1, s.S0, s.n_l0, s.P1, s.P0 = B * W, T * H, W, THW, 1, H, HW, W
+    elif letter == "X":   # (b h) (t w)
+        s.nseq, s.L, s.n_s0, s.S1, s.S0, s.n_l0, s.P1, s.P0 = B * H, T * W, H, THW, W, W, HW, 1
+    elif letter == "A":
+        s.nseq, s.L, s.n_s0, s.S1, s.S0, s.n_l0, s.P1, s.P0 = B, THW, 1, THW, 0, THW, 0, 1
+    else:
+        raise ValueError(f"invalid axis letter {letter!r}")
+    return s
+
+
+def dense_seq(nseq: int, Lq: int) -> L.Seq:
+    s = L.Seq()
+    s.nseq, s.L, s.n_s0, s.S1, s.S0, s.n_l0, s.P1, s.P0 = nseq, Lq, 1, Lq, 0, Lq, 0, 1
+    return s
+
+
+def attention(qkv: torch.Tensor, o: torch.Tensor, C_: int, n_head: int, seq: L.Seq, causal: bool):
+    _dev(qkv, o)
+    if qkv.dtype != o.dtype:
+        raise RuntimeError("qkv and o must share a dtype")
+    L.check(L.lib().tante_attention(_p(qkv), _p(o), _DT[qkv.dtype], C_, n_head, C.byref(seq), int(causal), _stream()),
+            "tante_attention")
+    return o
+
+
+def axis_mlp(x: torch.Tensor, outer: int, n: int, inner: int, w1, b1, w2, b2):
+    _dev(x, w1, b1, w2, b2)
+    if x.dtype != torch.float32:
+        raise RuntimeError("axis propagators run on the fp32 residual stream")
+    L.check(L.lib().tante_axis_mlp(_p(x), outer, n, inner, _p(w1.detach()), _p(b1.detach()), _p(w2.detach()),
+                                   _p(b2.detach()), _stream()), "tante_axis_mlp")
+    return x
+
+
+def film_table(t: torch.Tensor, film_params: Sequence[torch.Tensor], C_: int, add: Optional[torch.Tensor]):
+    """film_params = (scale.0.weight, scale.0.bias, scale.2.weight, scale.2.bias, shift.0.weight, ...)."""
+    _dev(t, add, *film_params)
+    rows = t.numel()
+    a = torch.empty(rows, C_, dtype=torch.float32, device=t.device)
+    b = torch.empty(rows, C_, dtype=torch.float32, device=t.device)
+    L.check(L.lib().tante_film_table(_p(t), rows, C_, *[_p(p.detach()) for p in film_params],
+                                     _p(None if add is None else add.detach()), _p(a), _p(b), _stream()), "tante_film_table")
+    return a, b
+
+
+def film_apply(x: torch.Tensor, x_elem_off: int, x_bstride: int, y: torch.Tensor, rows: int, C_: int, rows_per: int, a, b):
+    _dev(x, y, a, b)
+    L.check(L.lib().tante_film_apply(x.data_ptr() + 4 * x_elem_off, x_bstride, _p(y), rows, C_, rows_per, _p(a), _p(b),
+                                     _stream()), "tante_film_apply")
+    return y
+
+
+def taylor(last: torch.Tensor, last_elem_off: int, last_bstride: int, derivs: Sequence[torch.Tensor], dt: float, n_out: int,
+           out: torch.Tensor, B: int, frame: int):
+    _dev(last, out, *derivs)
+    arr = (C.c_void_p * len(derivs))(*[d.data_ptr() for d in derivs])
+    L.check(L.lib().tante_taylor(last.data_ptr() + 4 * last_elem_off, last_bstride, arr, len(derivs), float(dt), n_out,
+                                 _p(out), B, frame, _stream()), "tante_taylor")
+    return out
+
+
+def rt_reduce(t: torch.Tensor, B: int, Lq: int, out_T: float, ep: float):
+    _dev(t)
+    rt = torch.empty(B, dtype=torch.float32, device=t.device)
+    L.check(L.lib().tante_rt_reduce(_p(t), B, Lq, float(out_T), float(ep), _p(rt), _stream()), "tante_rt_reduce")
+    return rt
+
+
+def gather_last(z: torch.Tensor, n: int, E: int, out: torch.Tensor):
+    _dev(z, out)
+    L.check(L.lib().tante_gather_last(_p(z), n, E, _p(out), _stream()), "tante_gather_last")
+    return out

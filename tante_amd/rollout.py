@@ -1,0 +1,73 @@
+"""Autoregressive rollout harness (host side) with the reference's semantics.
+
+Trainer.rollout_model / Evaler.rollout_model  (trainer/trainer.py:144-159, trainer/evaler.py:121-138)
+R_Trainer.rollout_model / R_Evaler.rollout_model (trainer/r_trainer.py:112-133, trainer/r_evaler.py:87-105)
+DefaultChannelsFirstFormatter / ...LastFormatter   (data/datamodule.py:184-202)
+"""
+from __future__ import annotations
+
+from typing import Dict, Tuple
+
+import torch
+
+
+class DefaultChannelsFirstFormatter:
+    """'b t h w c -> b t c h w' (+ nan_to_num) on the way in, the inverse on the way out."""
+
+    def __init__(self, metadata=None):
+        self.metadata = metadata
+
+    def process_input(self, data: Dict) -> Tuple:
+        x = data["input"]
+        x = x.permute(0, 1, x.dim() - 1, *range(2, x.dim() - 1))
+        return (torch.nan_to_num(x),), torch.nan_to_num(data["output"])
+
+    def process_output(self, output: torch.Tensor) -> torch.Tensor:
+        return output.permute(0, 1, *range(3, output.dim()), 2)
+
+
+class DefaultChannelsLastFormatter:
+    def __init__(self, metadata=None):
+        self.metadata = metadata
+
+    def process_input(self, data: Dict) -> Tuple:
+        return (torch.nan_to_num(data["input"]),), torch.nan_to_num(data["output"])
+
+    def process_output(self, output: torch.Tensor) -> torch.Tensor:
+        return output
+
+
+def rollout_model(model, batch: Dict, formatter, n_steps: int, device=None):
+    """Sliding-window re-feed until n_steps frames exist; returns (y_pred channels-last [:, :n_steps], y_ref)."""
+    device = device or next(model.parameters()).device
+    moving, y_ref = formatter.process_input(batch)
+    moving = moving[0].to(device)
+    preds, produced = [], 0
+    while produced < n_steps:
+        y = model(moving)
+        produced += y.shape[1]
+        if produced < n_steps:
+            moving = torch.cat([moving[:, y.shape[1]:], y], dim=1)
+        preds.append(formatter.process_output(y))
+    return torch.cat(preds, dim=1)[:, :n_steps], y_ref.to(device)
+
+
+def rollout_adaptive(model, batch: Dict, formatter, n_steps: int, out_T: float, per_sample: bool, device=None):
+    """deg=False rollouts: per_sample=True, out_T=1.5 is R_Trainer's loop; per_sample=False,
+    out_T=n_steps_rollout is R_Evaler's.  Returns (y_pred, y_ref, Rts)."""
+    device = device or next(model.parameters()).device
+    xs, y_ref = formatter.process_input(batch)
+    xs = xs[0].to(device)
+    chunks = [xs[i:i + 1] for i in range(xs.shape[0])] if per_sample else [xs]
+    rts, outs = [], []
+    for moving in chunks:
+        preds, produced = [], 0
+        while produced < n_steps:
+            y, rt = model(moving, out_T)
+            produced += y.shape[1]
+            if produced < n_steps:
+                moving = torch.cat([moving[:, y.shape[1]:], y], dim=1)
+            preds.append(formatter.process_output(y))
+            rts.append(rt)
+        outs.append(torch.cat(preds, dim=1)[:, :n_steps])
+    return torch.cat(outs, dim=0), y_ref.to(device), torch.cat(rts, dim=0)

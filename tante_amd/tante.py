@@ -1,0 +1,391 @@
+"""TANTE operator on MI355X -- host side of the Taylor-expansion rollout path.
+
+Mirrors ``models.TANTE`` (models/tante.py:37-176), ``enc_CNN`` / ``dec_CNN`` (models/enc_dec_cnn.py:187-277),
+``film`` and ``interprator`` (models/tante.py:178-230): same constructor arguments, same parameter names,
+shapes and default initialisation (``state_dict()`` is interchangeable with the reference's), same
+``forward(input[B,T,D,H,W], out_T=1)`` contract.  The torch.nn modules are parameter containers; the
+arithmetic runs in libtante_hip.so:
+
+  patch embed   3 x (kernel = stride conv as a GEMM over non-overlapping patches, GELU in the epilogue);
+                the third stage's epilogue applies FiLM(t_seq), + s_emb, + t_emb (tante.py:136-141) and
+                writes the fp32 token stream directly -- the encoder never materialises NCHW intermediates.
+  backbone      attn_backbone.Attn_Backbone.forward_tokens, in place on the token stream.
+  heads         per order: 3 x (ConvTranspose kernel = stride as GEMM + pixel-shuffle scatter epilogue),
+                reading the last time slot of the token stream by stride (no slice copy).
+  Taylor sum    one pass over (last frame, K derivative fields) -> n_out frames (tante.py:165-171).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from . import kernels as K
+from .attn_backbone import Attn_Backbone, _PackCache, _no_autograd, resolve_compute
+
+# models/enc_dec_cnn.py:39-46
+Patch_map = {64: (4, 4, 4), 32: (4, 4, 2), 16: (4, 2, 2), 8: (2, 2, 2), 4: (2, 2, 1), 2: (2, 1, 1)}
+
+
+@dataclass
+class TanteMetadata:
+    """The constructor-argument record of the reference (data/dataset.py:43-63); the operator reads
+    only n_fields and spatial_resolution (tante.py:64-66)."""
+    dataset_name: str = "synthetic"
+    n_spatial_dims: int = 2
+    spatial_resolution: Tuple[int, ...] = (128, 384)
+    field_names: Optional[Dict[int, List[str]]] = None
+    boundary_condition_types: Optional[List[str]] = None
+    n_files: int = 1
+    n_trajectories_per_file: Optional[List[int]] = None
+    n_steps_per_trajectory: Optional[List[int]] = None
+    n_fields: int = 4
+
+    @property
+    def sample_shapes(self):
+        return {"input_fields": [*self.spatial_resolution, self.n_fields],
+                "output_fields": [*self.spatial_resolution, self.n_fields],
+                "space_grid": [*self.spatial_resolution, self.n_spatial_dims]}
+
+
+def _check_patch_cfg(patch_scale, overlap_ratio):
+    P = Patch_map[patch_scale]
+    if overlap_ratio != 0.0:
+        raise NotImplementedError("overlap_ratio > 0 (strided-overlap conv + pooling, enc_dec_cnn.py:66-110) is not on the "
+                                  "HIP path yet; shipped configs use overlap_ratio = 0")
+    if any((p - 1) // 2 != 0 for p in P):
+        raise NotImplementedError(f"patch_scale {patch_scale} uses a 4x4 stage whose 'same' padding shifts the patch grid "
+                                  "(enc_dec_cnn.py:78-81); only 1x1 / 2x2 stages (patch_scale 2, 4, 8) are on the HIP path yet")
+    return P
+
+
+class _ConvHolder(nn.Module):
+    """Parameter container with the reference's attribute name (`conv` / `deconv`)."""
+
+    def __init__(self, name: str, mod: nn.Module):
+        super().__init__()
+        setattr(self, name, mod)
+
+
+class enc_CNN(nn.Module):
+    """3-stage patch embed, (B,T,D,H,W) -> (B,T,Hp,Wp,C)   (enc_dec_cnn.py:187-229)."""
+
+    def __init__(self, dset_metadata=None, embed_dim: int = 256, patch_scale=64, overlap_ratio=0.5):
+        super().__init__()
+        self.embed_dim = embed_dim
+        self.P = _check_patch_cfg(patch_scale, overlap_ratio)
+        cin = dset_metadata.n_fields if dset_metadata else 4
+        shape = dset_metadata.spatial_resolution if dset_metadata else (128, 384)
+        self.H, self.W = shape[0], shape[1]
+        self.chans = [cin, embed_dim // 4, embed_dim // 2, embed_dim]
+        for i in range(3):
+            p = self.P[i]
+            setattr(self, f"enc_conv_{i + 1}", _ConvHolder("conv", nn.Conv2d(self.chans[i], self.chans[i + 1], (p, p), stride=(p, p))))
+        tot = self.P[0] * self.P[1] * self.P[2]
+        self.patch_shape = (self.H // tot, self.W // tot)
+        self._cache = _PackCache()
+
+    def _packed(self, compute: int):
+        convs = [getattr(self, f"enc_conv_{i + 1}").conv for i in range(3)]
+        params = [p for c in convs for p in (c.weight, c.bias)]
+
+        def build():
+            out = []
+            for i, c in enumerate(convs):
+                p, ci, co = self.P[i], self.chans[i], self.chans[i + 1]
+                if i == 0:   # first stage reads the channels-first input: k = (ci, kh, kw) is the native weight order
+                    out.append(K.pack_weight(c.weight, c.bias, compute, L.W_LINEAR, N=co, K=ci * p * p))
+                else:        # later stages read channels-last intermediates: k = (kh, kw, ci)
+                    out.append(K.pack_weight(c.weight, c.bias, compute, L.W_CONV_NHWC, N=co, K=ci * p * p, P=p, C_other=ci))
+            return out
+        return self._cache.get(compute, params, build)
+
+    def forward_tokens(self, inp: torch.Tensor, compute: int, film: Optional[tuple]) -> torch.Tensor:
+        """inp (B,T,D,H,W) fp32 contiguous -> tokens (B*T*Hp*Wp, C) fp32; `film` = (a, b, s_emb, T, HW) is
+        applied in the last stage's epilogue (None: plain encoder output)."""
+        B, T, D, H, W = inp.shape
+        if (H, W) != (self.H, self.W) or D != self.chans[0]:
+            raise ValueError(f"encoder built for {self.chans[0]} fields at {(self.H, self.W)}, got {tuple(inp.shape)}")
+        pk = self._packed(compute)
+        adt = K.act_torch_dtype(compute)
+        n_img, h, w = B * T, H, W
+        x = inp
+        for i in range(3):
+            p, ci, co = self.P[i], self.chans[i], self.chans[i + 1]
+            last = i == 2
+            out = torch.empty(n_img * (h // p) * (w // p), co, dtype=torch.float32 if last else adt, device=inp.device)
+            K.patch_embed(x, pk[i], out, n_img=n_img, Hin=h, Win=w, Cin=ci, P=p, nchw=(i == 0),
+                          act=L.ACT_NONE if last else L.ACT_GELU_ERF, film=film if last else None)
+            x, h, w = out, h // p, w // p
+        return x
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        _no_autograd(self)
+        B, T = x.shape[:2]
+        tok = self.forward_tokens(x.detach().float().contiguous(), resolve_compute(None), None)
+        return tok.view(B, T, self.patch_shape[0], self.patch_shape[1], self.embed_dim)
+
+
+class dec_CNN(nn.Module):
+    """3-stage derivative head, (B,T,Hp,Wp,C) -> (B,T,D,H,W)   (enc_dec_cnn.py:232-277)."""
+
+    def __init__(self, dset_metadata=None, embed_dim: int = 256, patch_scale=64, overlap_ratio=0.5):
+        super().__init__()
+        self.embed_dim = embed_dim
+        Pm = _check_patch_cfg(patch_scale, overlap_ratio)
+        self.P = (Pm[2], Pm[1], Pm[0])           # enc_dec_cnn.py:251-253: kernel sizes in reverse order
+        cout = dset_metadata.n_fields if dset_metadata else 4
+        shape = dset_metadata.spatial_resolution if dset_metadata else (128, 384)
+        self.H, self.W = shape[0], shape[1]
+        self.chans = [embed_dim, embed_dim // 2, embed_dim // 4, cout]
+        for i in range(3):
+            p = self.P[i]
+            setattr(self, f"dec_conv_{i + 1}", _ConvHolder("deconv", nn.ConvTranspose2d(self.chans[i], self.chans[i + 1], (p, p), stride=(p, p))))
+        tot = Pm[0] * Pm[1] * Pm[2]
+        self.patch_shape = (self.H // tot, self.W // tot)
+        self._cache = _PackCache()
+
+    def _packed(self, compute: int):
+        convs = [getattr(self, f"dec_conv_{i + 1}").deconv for i in range(3)]
+        params = [p for c in convs for p in (c.weight, c.bias)]
+
+        def build():
+            out = []
+            for i, c in enumerate(convs):
+                p, ci, co = self.P[i], self.chans[i], self.chans[i + 1]
+                lay = L.W_DECONV_NCHW if i == 2 else L.W_DECONV_NHWC
+                out.append(K.pack_weight(c.weight, c.bias, compute, lay, N=co * p * p, K=ci, P=p, C_other=co))
+            return out
+        return self._cache.get(compute, params, build)
+
+    def forward_tokens(self, src: torch.Tensor, n_img: int, compute: int, a_n0: int, a_s1: int, a_s0: int, a_off: int) -> torch.Tensor:
+        """Rows (img, hp, wp) of `src` (gathered by the given strides, in elements) -> (n_img, D, H, W) fp32."""
+        pk = self._packed(compute)
+        adt = K.act_torch_dtype(compute)
+        h, w = self.patch_shape
+        x = src
+        for i in range(3):
+            p, co = self.P[i], self.chans[i + 1]
+            last = i == 2
+            if last:
+                out = torch.empty(n_img, co, h * p, w * p, dtype=torch.float32, device=src.device)
+            else:
+                out = torch.empty(n_img, h * p, w * p, co, dtype=adt, device=src.device)
+            if i == 0:
+                K.deconv(x, pk[i], out, n_img=n_img, Hi=h, Wi=w, P=p, Cout=co, nchw_out=last,
+                         act=L.ACT_NONE if last else L.ACT_GELU_ERF, a_n0=a_n0, a_s1=a_s1, a_s0=a_s0, a_off=a_off)
+            else:
+                K.deconv(x, pk[i], out, n_img=n_img, Hi=h, Wi=w, P=p, Cout=co, nchw_out=last,
+                         act=L.ACT_NONE if last else L.ACT_GELU_ERF)
+            x, h, w = out, h * p, w * p
+        return x
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        _no_autograd(self)
+        B, T, Hp, Wp, C_ = x.shape
+        src = x.detach().float().contiguous()
+        y = self.forward_tokens(src, B * T, resolve_compute(None), B * T * Hp * Wp, 0, C_, 0)
+        return y.view(B, T, *y.shape[1:])
+
+
+class film(nn.Module):
+    """x + (x * scale(t) + shift(t))   (tante.py:203-230).  Parameter container + table builder."""
+
+    def __init__(self, h_dim=768, in_dim=1):
+        super().__init__()
+        self.h_dim = h_dim
+        self.condition_to_scale = nn.Sequential(nn.Linear(in_dim, h_dim // 2), nn.ReLU(), nn.Linear(h_dim // 2, h_dim))
+        self.condition_to_shift = nn.Sequential(nn.Linear(in_dim, h_dim // 2), nn.ReLU(), nn.Linear(h_dim // 2, h_dim))
+
+    def tables(self, t: torch.Tensor, add: Optional[torch.Tensor] = None):
+        """-> (a, b) with a = 1 + scale(t), b = shift(t) (+ add); film(x, t) = x * a + b."""
+        s, h = self.condition_to_scale, self.condition_to_shift
+        return K.film_table(t, (s[0].weight, s[0].bias, s[2].weight, s[2].bias, h[0].weight, h[0].bias, h[2].weight, h[2].bias),
+                            self.h_dim, add)
+
+    def forward(self, x: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
+        _no_autograd(self)
+        x = x.detach().float().contiguous()
+        a, b = self.tables(t.detach().float().contiguous().to(x.device))
+        C_ = x.shape[-1]
+        y = torch.empty_like(x)
+        if x.dim() == 5:      # (B,T,H,W,C), t (T,): one table row per time slot
+            B, T = x.shape[:2]
+            hw = x.shape[2] * x.shape[3]
+            for bi in range(B):
+                K.film_apply(x, bi * T * hw * C_, hw * C_, y[bi], T * hw, C_, hw, a, b)
+        elif x.dim() == 3:    # (B,L,C), t (B,)
+            B, Lq = x.shape[:2]
+            K.film_apply(x, 0, Lq * C_, y, B * Lq, C_, Lq, a, b)
+        else:
+            raise ValueError("film expects a 3-D or 5-D tensor")
+        return y
+
+
+class interprator(nn.Module):
+    """Adaptive step-size head (tante.py:178-201): per-token MLP C -> C/2 -> C/4 -> 1, clamp, mean, + ep."""
+
+    def __init__(self, h_dim=768, sp_dim=16, ep=1.001):
+        super().__init__()
+        self.sp_dim, self.ep, self.h_dim = sp_dim, ep, h_dim
+        self.interprete = nn.Sequential(nn.Linear(h_dim, h_dim // 2), nn.ReLU(), nn.Linear(h_dim // 2, h_dim // 4), nn.ReLU(),
+                                        nn.Linear(h_dim // 4, 1))
+        self._cache = _PackCache()
+
+    def _packed(self, compute):
+        lin = [self.interprete[0], self.interprete[2], self.interprete[4]]
+        return self._cache.get(compute, [p for l in lin for p in (l.weight, l.bias)],
+                               lambda: [K.pack_weight(l.weight, l.bias, compute) for l in lin])
+
+    def forward_tokens(self, src: torch.Tensor, B: int, out_T: float, compute: int, a_n0: int, a_s1: int, a_s0: int, a_off: int):
+        pk = self._packed(compute)
+        n = B * self.sp_dim
+        adt = K.act_torch_dtype(compute)
+        h1 = torch.empty(n, self.h_dim // 2, dtype=adt, device=src.device)
+        K.linear(src, pk[0], h1, M=n, act=L.ACT_RELU, a_n0=a_n0, a_s1=a_s1, a_s0=a_s0, a_off=a_off)
+        h2 = torch.empty(n, self.h_dim // 4, dtype=adt, device=src.device)
+        K.linear(h1, pk[1], h2, M=n, act=L.ACT_RELU)
+        t = torch.empty(n, 1, dtype=torch.float32, device=src.device)
+        K.linear(h2, pk[2], t, M=n)
+        return K.rt_reduce(t, B, self.sp_dim, out_T, self.ep)
+
+    def forward(self, x: torch.Tensor, out_T) -> torch.Tensor:
+        _no_autograd(self)
+        B, Lq, C_ = x.shape
+        src = x.detach().float().contiguous()
+        return self.forward_tokens(src, B, out_T, resolve_compute(None), B * Lq, 0, C_, 0)
+
+
+def get_1d_sincos_pos_embed_from_grid(embed_dim, pos):
+    """tante.py:232-242 (initial value of a learned parameter; checkpoints override it)."""
+    omega = torch.arange(embed_dim // 2, dtype=torch.float32) / (embed_dim / 2.0)
+    omega = 1.0 / 10000 ** omega
+    out = pos.reshape(-1)[:, None] * omega[None, :]
+    return torch.cat([torch.sin(out), torch.cos(out)], dim=1)
+
+
+def t_emb_init(embed_dim, length):
+    return get_1d_sincos_pos_embed_from_grid(embed_dim, torch.arange(length, dtype=torch.float32)).unsqueeze(0)
+
+
+def s_emb_init(embed_dim, grid_size, *, flatten: bool = False):
+    """tante.py:251-276, including its meshgrid('ij') of (w, h) reshaped to (2,1,H,W)."""
+    H, W = grid_size
+    gw, gh = torch.meshgrid(torch.arange(W, dtype=torch.float32), torch.arange(H, dtype=torch.float32), indexing="ij")
+    grid = torch.stack([gh, gw], dim=0).reshape(2, 1, H, W)
+    emb = torch.cat([get_1d_sincos_pos_embed_from_grid(embed_dim // 2, grid[0]),
+                     get_1d_sincos_pos_embed_from_grid(embed_dim // 2, grid[1])], dim=1)
+    return emb.unsqueeze(0) if flatten else emb.view(H, W, embed_dim).unsqueeze(0)
+
+
+def t_series(IP, frame_interval):
+    """tante.py:279-285: [.., -2dt, -dt, 0, 0] -- the duplicated zero is the reference's behaviour."""
+    seq = [0.0] + [-i * frame_interval for i in range(IP - 1)]
+    seq.reverse()
+    return torch.tensor(seq)
+
+
+class TANTE(nn.Module):
+    def __init__(self, in_T, dset_metadata: TanteMetadata = None, taylor_order: int = 1, frame_interval: float = 1.0,
+                 output_length=1, attn_axes: str = "THWTHWTHW", expanded_channel: int = 128, n_head: int = 8,
+                 mlp_ratio: float = 1.0, dropout: float = 0.0, enc_dec_type: str = "cnn", embed_dim: int = 256,
+                 modes1: int = 32, modes2: int = 32, patch_scale: int = 32, overlap_ratio: float = 0.0, deg: bool = True):
+        super().__init__()
+        n_channel = dset_metadata.n_fields if dset_metadata else 4
+        shape = dset_metadata.spatial_resolution if dset_metadata else (128, 384)
+        self.T = in_T
+        self.D, self.H, self.W = n_channel, shape[0], shape[1]
+        self.H_p, self.W_p = shape[0] // patch_scale, shape[1] // patch_scale
+        self.C = embed_dim
+        self.taylor_order, self.frame_interval, self.output_length, self.deg = taylor_order, frame_interval, output_length, deg
+        self.attn_axes = attn_axes.replace(" ", "")
+        if set(self.attn_axes) - {"T", "H", "W", "L", "A", "C", "X", "Y", "-"}:   # the reference's set has the typo 'X,'
+            raise ValueError("There are invalid letters")
+        self.blocks_axes = [p.strip() for p in self.attn_axes.split("-")]
+        if len(self.blocks_axes) != taylor_order:
+            raise ValueError(f"Block allocation doesn't match expansion order: expected {taylor_order} parts, "
+                             f"got {len(self.blocks_axes)} (input='{self.attn_axes}').")
+        if enc_dec_type != "cnn":
+            raise NotImplementedError("enc_dec_type='fno' (spectral encoder) is a later tier (SURVEY 8f rank 2)")
+        self.decoders = nn.ModuleList()
+        self.encoder = enc_CNN(dset_metadata=dset_metadata, embed_dim=embed_dim, patch_scale=patch_scale, overlap_ratio=overlap_ratio)
+        for _ in range(taylor_order):
+            self.decoders.append(dec_CNN(dset_metadata=dset_metadata, embed_dim=embed_dim, patch_scale=patch_scale,
+                                         overlap_ratio=overlap_ratio))
+        self.blocks = nn.ModuleList()
+        for block_axes in self.blocks_axes:
+            self.blocks.append(Attn_Backbone(tensor_shape=(self.T, self.H_p, self.W_p, self.C), attn_axes=block_axes,
+                                             expanded_channel=expanded_channel, n_head=n_head, mlp_ratio=mlp_ratio, dropout=dropout))
+        self.t_emb = nn.Parameter(t_emb_init(self.C, self.T))
+        self.s_emb = nn.Parameter(s_emb_init(self.C, (self.H_p, self.W_p), flatten=False))
+        self.t_seq = t_series(self.T, frame_interval)      # plain attribute, not in the state_dict (tante.py:118)
+        self.t_encode = film(self.C, in_dim=1)
+        if not self.deg:
+            self.interprators = nn.ModuleList([interprator(self.C, self.H_p * self.W_p) for _ in range(taylor_order)])
+            self.modifiers = nn.ModuleList([film(self.C, in_dim=1) for _ in range(taylor_order)])
+        self.compute: Optional[str] = None       # None: follow torch.autocast; "fp32" / "bf16": pinned
+        self._film_cache = _PackCache()
+
+    def set_compute(self, mode: Optional[str]):
+        if mode is not None and mode not in K.COMPUTE:
+            raise ValueError("compute must be None, 'fp32' or 'bf16'")
+        self.compute = mode
+        return self
+
+    def _apply(self, fn, *a, **k):               # keep t_seq with the parameters on .to()/.cuda()
+        super()._apply(fn, *a, **k)
+        self.t_seq = fn(self.t_seq)
+        return self
+
+    def _time_tables(self):
+        """FiLM(t_seq) scale/shift with t_emb folded into the shift: input independent, rebuilt only when
+        the weights change."""
+        te = self.t_encode
+        params = list(te.parameters()) + [self.t_emb]
+        return self._film_cache.get(0, params, lambda: te.tables(self.t_seq.to(self.t_emb.device, torch.float32).contiguous(),
+                                                                 self.t_emb.view(self.T, self.C)))
+
+    def forward(self, input: torch.Tensor, out_T=1):
+        _no_autograd(self)
+        if not input.is_cuda:
+            raise RuntimeError("tante_amd.TANTE runs on the GPU only (no CPU fallback); move the input to cuda")
+        if input.shape[1] != self.T:
+            input = input[:, -self.T:]
+        inp = input.detach().to(torch.float32).contiguous()
+        B, T, D, H, W = inp.shape
+        compute = resolve_compute(self.compute)
+        Hp, Wp, C_ = self.H_p, self.W_p, self.C
+        HW = Hp * Wp
+        fa, fb = self._time_tables()
+        x = self.encoder.forward_tokens(inp, compute, (fa, fb, self.s_emb.view(HW, C_), T, HW))     # tante.py:132-141
+        last_slot = dict(a_n0=HW, a_s1=T * HW * C_, a_s0=C_, a_off=(T - 1) * HW * C_)               # x[:, -1:] by stride
+        derivs, r_t = [], []
+        for i in range(self.taylor_order):
+            self.blocks[i].forward_tokens(x, B, compute)                                            # l.146 (chained)
+            if self.deg:
+                derivs.append(self.decoders[i].forward_tokens(x, B, compute, **last_slot))          # l.147,153
+            else:
+                # intended semantics of l.148-152 (the shipped glue raises): d3 = last slot as (B, L, C);
+                # rt = interprator(d3, out_T); d3 = film3d(d3, rt); decode
+                rt = self.interprators[i].forward_tokens(x, B, out_T, compute, **last_slot)
+                r_t.append(rt)
+                ma, mb = self.modifiers[i].tables(rt)
+                d3 = torch.empty(B * HW, C_, dtype=torch.float32, device=x.device)
+                K.film_apply(x, (T - 1) * HW * C_, T * HW * C_, d3, B * HW, C_, HW, ma, mb)
+                derivs.append(self.decoders[i].forward_tokens(d3, B, compute, B * HW, 0, C_, 0))
+        if self.deg:
+            n_out, R_t = self.output_length, None
+        else:
+            R_t = torch.stack(r_t, dim=1).mean(dim=1)
+            n_out = math.floor(float(R_t[0]))         # l.163: sample 0 decides for the batch (host sync, as in the reference)
+        frame = D * H * W
+        if n_out < 1:
+            out = torch.empty(B, 0, D, H, W, dtype=torch.float32, device=x.device)
+        else:
+            out = torch.empty(B, n_out, D, H, W, dtype=torch.float32, device=x.device)
+            K.taylor(inp, (T - 1) * frame, T * frame, derivs, self.frame_interval, n_out, out, B, frame)   # l.165-171
+        return out if self.deg else (out, R_t)

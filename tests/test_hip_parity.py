@@ -1,0 +1,417 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle and the committed golden vectors.
+
+Bars (BASELINE.json north_star): fp32 compute within 1e-5 relative, bf16 compute within 1e-2 relative,
+of the reference's fp32 CPU path.  `rel` below is ||a-b||_2 / ||b||_2 and `mx` is max|a-b| / max|b|.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import load_golden, split_prefix, rel_err, max_rel
+
+pytestmark = pytest.mark.gpu
+
+TOL = {"fp32": 1e-5, "bf16": 1e-2}
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+def _ops():
+    from tante_amd import kernels as K, _lib as L
+    return K, L
+
+
+def close(a, b, mode, scale=1.0):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    assert torch.isfinite(a).all()
+    r, m = rel_err(a, b), max_rel(a, b)
+    assert r < TOL[mode] * scale and m < TOL[mode] * scale * 2, f"rel={r:.3e} max={m:.3e} (tol {TOL[mode] * scale:.1e})"
+
+
+def bf16_round(t):
+    return t.to(torch.bfloat16).float()
+
+
+# ---------------------------------------------------------------------------------------------------
+# GEMM core: layouts, K/N/M tails, epilogues
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+@pytest.mark.parametrize("M,N,K", [(200, 768, 256), (64, 64, 64), (37, 20, 44), (130, 256, 128), (70, 12, 512),
+                                   (129, 1, 16), (16, 96, 32), (300, 130, 100)])
+def test_gemm_linear(dev, mode, M, N, K):
+    Kk, L = _ops()
+    comp = Kk.COMPUTE[mode]
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    a = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b = torch.randn(N, generator=g)
+    ref = a @ w.t() + b
+    pw = Kk.pack_weight(w.to(dev), b.to(dev), comp)
+    out = torch.full((M, N), float("nan"), device=dev)
+    Kk.linear(a.to(dev), pw, out, M=M)
+    close(out, ref, mode)
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_gemm_layout_asymmetric(dev, mode):
+    """A = identity-like rows against an asymmetric integer W: catches transposed / permuted fragments exactly."""
+    Kk, L = _ops()
+    comp = Kk.COMPUTE[mode]
+    M = N = K = 64
+    a = torch.eye(M, K)
+    w = (torch.arange(N)[:, None] * 3 + torch.arange(K)[None, :] * 1).float() % 61      # exact in bf16
+    pw = Kk.pack_weight(w.to(dev), None, comp)
+    out = torch.empty(M, N, device=dev)
+    Kk.linear(a.to(dev), pw, out, M=M)
+    assert torch.equal(out.cpu(), w.t().contiguous())
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+@pytest.mark.parametrize("act", ["none", "gelu_erf", "gelu_tanh", "relu"])
+def test_gemm_ln_act_residual(dev, mode, act):
+    from oracle import tante_oracle as O
+    Kk, L = _ops()
+    comp = Kk.COMPUTE[mode]
+    M, N, K = 150, 128, 256
+    g = torch.Generator().manual_seed(5)
+    a = torch.randn(M, K, generator=g) * 2 + 0.5
+    w = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b = torch.randn(N, generator=g)
+    gamma = 1 + 0.2 * torch.randn(K, generator=g)
+    beta = 0.2 * torch.randn(K, generator=g)
+    res = torch.randn(M, N, generator=g)
+    f = {"none": lambda x: x, "gelu_erf": O.gelu_erf, "gelu_tanh": O.gelu_tanh, "relu": torch.relu}[act]
+    code = {"none": L.ACT_NONE, "gelu_erf": L.ACT_GELU_ERF, "gelu_tanh": L.ACT_GELU_TANH, "relu": L.ACT_RELU}[act]
+    ref = f(O.layer_norm(a, gamma, beta) @ w.t() + b) + res
+    pw = Kk.pack_weight(w.to(dev), b.to(dev), comp, gamma=gamma.to(dev), beta=beta.to(dev))
+    out = res.to(dev).clone()
+    Kk.linear(a.to(dev), pw, out, M=M, ln=True, act=code, residual=out)     # in place on the residual stream
+    close(out, ref, mode)
+    # bf16 activations as source and destination
+    if mode == "bf16":
+        a16 = a.to(torch.bfloat16)
+        ref16 = f(a16.float() @ w.t() + b)
+        pw2 = Kk.pack_weight(w.to(dev), b.to(dev), comp)
+        o16 = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+        Kk.linear(a16.to(dev), pw2, o16, M=M, act=code)
+        close(o16, ref16, mode)
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+@pytest.mark.parametrize("nchw,Cin,Cout,P,H,W", [(True, 11, 64, 2, 16, 32), (False, 64, 128, 2, 8, 12), (True, 1, 16, 2, 8, 8),
+                                                 (False, 6, 20, 2, 4, 6), (True, 3, 8, 1, 4, 4)])
+def test_gemm_patch_embed(dev, mode, nchw, Cin, Cout, P, H, W):
+    from oracle import tante_oracle as O
+    Kk, L = _ops()
+    comp = Kk.COMPUTE[mode]
+    g = torch.Generator().manual_seed(Cin * 11 + Cout)
+    n_img = 3
+    x = torch.randn(n_img, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, P, P, generator=g) / math.sqrt(Cin * P * P)
+    b = torch.randn(Cout, generator=g)
+    ref = O.gelu_erf(O.real_conv2d(x, w, b, P, 0.0)).permute(0, 2, 3, 1).contiguous()      # channels-last
+    if nchw:
+        pw = Kk.pack_weight(w.to(dev), b.to(dev), comp, L.W_LINEAR, N=Cout, K=Cin * P * P)
+        src = x.to(dev)
+    else:
+        pw = Kk.pack_weight(w.to(dev), b.to(dev), comp, L.W_CONV_NHWC, N=Cout, K=Cin * P * P, P=P, C_other=Cin)
+        src = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    out = torch.empty(n_img, H // P, W // P, Cout, device=dev)
+    Kk.patch_embed(src, pw, out, n_img=n_img, Hin=H, Win=W, Cin=Cin, P=P, nchw=nchw, act=L.ACT_GELU_ERF)
+    close(out, ref, mode)
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+@pytest.mark.parametrize("nchw_out,Cin,Cout,P,H,W", [(False, 64, 32, 2, 4, 6), (True, 16, 11, 2, 8, 8), (True, 8, 3, 1, 4, 4),
+                                                      (False, 12, 6, 2, 3, 5), (True, 32, 1, 2, 8, 8)])
+def test_gemm_deconv(dev, mode, nchw_out, Cin, Cout, P, H, W):
+    from oracle import tante_oracle as O
+    Kk, L = _ops()
+    comp = Kk.COMPUTE[mode]
+    g = torch.Generator().manual_seed(Cin * 5 + Cout)
+    n_img = 2
+    x = torch.randn(n_img, Cin, H, W, generator=g)
+    w = torch.randn(Cin, Cout, P, P, generator=g) / math.sqrt(Cin)
+    b = torch.randn(Cout, generator=g)
+    ref = O.real_transconv2d(x, w, b, P, 0.0)
+    src = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    lay = L.W_DECONV_NCHW if nchw_out else L.W_DECONV_NHWC
+    pw = Kk.pack_weight(w.to(dev), b.to(dev), comp, lay, N=Cout * P * P, K=Cin, P=P, C_other=Cout)
+    if nchw_out:
+        out = torch.empty(n_img, Cout, H * P, W * P, device=dev)
+    else:
+        out = torch.empty(n_img, H * P, W * P, Cout, device=dev)
+        ref = ref.permute(0, 2, 3, 1).contiguous()
+    Kk.deconv(src, pw, out, n_img=n_img, Hi=H, Wi=W, P=P, Cout=Cout, nchw_out=nchw_out, act=L.ACT_NONE)
+    close(out, ref, mode)
+
+
+# ---------------------------------------------------------------------------------------------------
+# attention core per axis letter
+# ---------------------------------------------------------------------------------------------------
+def _attn_ref(qkv, n_head, causal):
+    Bp, Lq, C3 = qkv.shape
+    C_ = C3 // 3
+    d = C_ // n_head
+    q, k, v = (t.reshape(Bp, Lq, n_head, d).transpose(1, 2) for t in qkv.split(C_, dim=-1))
+    s = q @ k.transpose(-1, -2) / math.sqrt(d)
+    if causal:
+        s = s.masked_fill(torch.triu(torch.ones(Lq, Lq, dtype=torch.bool), 1), float("-inf"))
+    return (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(Bp, Lq, C_)
+
+
+_PERM = {  # (permutation to (batch', L, C) view of (B,T,H,W,C), inverse)
+    "T": ((0, 2, 3, 1, 4), lambda B, T, H, W: (B * H * W, T)),
+    "H": ((0, 1, 3, 2, 4), lambda B, T, H, W: (B * T * W, H)),
+    "W": ((0, 1, 2, 3, 4), lambda B, T, H, W: (B * T * H, W)),
+    "L": ((0, 1, 2, 3, 4), lambda B, T, H, W: (B * T, H * W)),
+    "Y": ((0, 3, 1, 2, 4), lambda B, T, H, W: (B * W, T * H)),
+    "X": ((0, 2, 1, 3, 4), lambda B, T, H, W: (B * H, T * W)),
+    "A": ((0, 1, 2, 3, 4), lambda B, T, H, W: (B, T * H * W)),
+}
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("letter,B,T,H,W,C,nh", [("T", 2, 4, 3, 5, 32, 4), ("H", 2, 3, 32, 4, 64, 2), ("W", 1, 2, 3, 48, 64, 8),
+                                                  ("L", 2, 2, 6, 7, 32, 2), ("Y", 2, 3, 5, 4, 16, 2), ("X", 2, 3, 4, 6, 32, 4),
+                                                  ("A", 2, 4, 9, 10, 32, 1), ("L", 1, 1, 20, 30, 64, 8), ("T", 3, 7, 2, 2, 128, 2)])
+def test_attention_letters(dev, dtype, letter, B, T, H, W, C, nh):
+    Kk, L = _ops()
+    g = torch.Generator().manual_seed(ord(letter) + T * H * W)
+    qkv = torch.randn(B, T, H, W, 3 * C, generator=g)
+    if dtype == torch.bfloat16:
+        qkv = bf16_round(qkv)
+    perm, shp = _PERM[letter]
+    Bp, Lq = shp(B, T, H, W)
+    causal = letter == "T"
+    ref_seq = _attn_ref(qkv.permute(*perm).reshape(Bp, Lq, 3 * C), nh, causal)
+    inv = [perm.index(i) for i in range(5)]
+    if letter == "T":
+        ref = ref_seq.reshape(B, H, W, T, C).permute(*inv)
+    elif letter == "H":
+        ref = ref_seq.reshape(B, T, W, H, C).permute(*inv)
+    elif letter == "Y":
+        ref = ref_seq.reshape(B, W, T, H, C).permute(*inv)
+    elif letter == "X":
+        ref = ref_seq.reshape(B, H, T, W, C).permute(*inv)
+    else:
+        ref = ref_seq.reshape(B, T, H, W, C)
+    o = torch.full((B * T * H * W, C), float("nan"), dtype=dtype, device=dev)
+    Kk.attention(qkv.reshape(-1, 3 * C).to(dev, dtype), o, C, nh, Kk.make_seq(letter, B, T, H, W), causal)
+    close(o.view(B, T, H, W, C), ref.contiguous(), "fp32" if dtype == torch.float32 else "bf16")
+
+
+# ---------------------------------------------------------------------------------------------------
+# pointwise stages
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("outer,n,inner", [(6, 32, 64), (3, 4, 1000), (2, 48, 33), (5, 7, 16), (2, 100, 40), (4, 64, 70)])
+def test_axis_mlp(dev, outer, n, inner):
+    from oracle import tante_oracle as O
+    Kk, L = _ops()
+    g = torch.Generator().manual_seed(n)
+    x = torch.randn(outer, n, inner, generator=g)
+    w = {"p.0.weight": torch.randn(n, n, generator=g) / math.sqrt(n), "p.0.bias": torch.randn(n, generator=g),
+         "p.2.weight": torch.randn(n, n, generator=g) / math.sqrt(n), "p.2.bias": torch.randn(n, generator=g)}
+    ref = x + O._axis_mlp(w, "p", x.transpose(1, 2)).transpose(1, 2)
+    xd = x.to(dev)
+    Kk.axis_mlp(xd, outer, n, inner, *(w[k].to(dev) for k in ("p.0.weight", "p.0.bias", "p.2.weight", "p.2.bias")))
+    close(xd, ref, "fp32")
+
+
+def test_film_taylor_rt(dev):
+    from oracle import tante_oracle as O
+    import tante_amd
+    Kk, L = _ops()
+    g = load_golden("g5_film")
+    f = tante_amd.film(32).to(dev)
+    f.load_state_dict(split_prefix(g, "w."))
+    with torch.no_grad():
+        close(f(g["x5"].to(dev), g["t_series_4_1"].to(dev)), g["y5"], "fp32")
+        close(f(g["x3"].to(dev), g["rt"].to(dev)), g["y3"], "fp32")
+    assert torch.equal(tante_amd.t_series(4, 1.0), g["t_series_4_1"]) and torch.equal(tante_amd.t_series(5, 0.5), g["t_series_5_05"])
+    # Taylor sum against the literal loop of tante.py:165-171
+    gen = torch.Generator().manual_seed(1)
+    B, T, frame = 3, 4, 2 * 8 * 12
+    inp = torch.randn(B, T, frame, generator=gen)
+    ders = [torch.randn(B, frame, generator=gen) for _ in range(3)]
+    for dt, n_out in ((1.0, 1), (0.5, 3), (2.0, 8), (0.1, 2)):
+        ref = torch.stack([inp[:, -1] + sum(ders[k - 1] * (i * dt) ** k / math.factorial(k) for k in (1, 2, 3))
+                           for i in range(1, n_out + 1)], 1)
+        out = torch.empty(B, n_out, frame, device=dev)
+        Kk.taylor(inp.to(dev), (T - 1) * frame, T * frame, [d.to(dev) for d in ders], dt, n_out, out, B, frame)
+        close(out, ref, "fp32")
+    # interprator (both clamps exercised by the fixture)
+    g6 = load_golden("g6_interp")
+    it = tante_amd.interprator(32, 12).to(dev)
+    it.load_state_dict(split_prefix(g6, "w."))
+    with torch.no_grad():
+        for out_T, key in ((1.5, "rt_1p5"), (8, "rt_8"), (1, "rt_1")):
+            close(it(g6["x"].to(dev), out_T), g6[key], "fp32")
+
+
+# ---------------------------------------------------------------------------------------------------
+# modules against the golden vectors (weights loaded from the reference's state_dict)
+# ---------------------------------------------------------------------------------------------------
+import glob
+import os
+from conftest import GOLDEN
+
+
+def names(pattern):
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, pattern + ".npz")))
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+@pytest.mark.parametrize("name", names("g3_block_*"))
+def test_g3_block(dev, name, mode):
+    import tante_amd
+    g = load_golden(name)
+    C, nh, Lq, causal, ratio = (int(v) for v in g["meta"])
+    blk = tante_amd.TransformerBlock(C, nh, mlp_ratio=ratio / 100, dropout=0.0).to(dev).eval()
+    blk.load_state_dict(split_prefix(g, "w."))
+    blk.compute = mode
+    with torch.no_grad():
+        y = blk(g["x"].to(dev), causal=bool(causal))
+    close(y, g["y"], mode)
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+@pytest.mark.parametrize("name", names("g4_backbone_*"))
+def test_g4_backbone(dev, name, mode):
+    import tante_amd
+    g = load_golden(name)
+    axes = name.split("_")[-1]
+    T, H, W, C, E, nh = (int(v) for v in g["meta"])
+    bb = tante_amd.Attn_Backbone((T, H, W, C), axes, expanded_channel=E, n_head=nh, mlp_ratio=1.0, dropout=0.0).to(dev).eval()
+    bb.load_state_dict(split_prefix(g, "w."))
+    bb.compute = mode
+    with torch.no_grad():
+        y = bb(g["x"].to(dev))
+    close(y, g["y"], mode, scale=2.0 if mode == "bf16" else 1.0)
+
+
+@pytest.mark.parametrize("name", names("g2_encdec_*"))
+def test_g2_encdec(dev, name):
+    import tante_amd
+    g = load_golden(name)
+    ps, ov, H, W, nf, C = (int(v) for v in g["meta"])
+    md = tante_amd.TanteMetadata(n_fields=nf, spatial_resolution=(H, W))
+    if ov != 0 or ps not in (2, 4, 8):
+        with pytest.raises(NotImplementedError):       # fails loudly, never silently approximates
+            tante_amd.enc_CNN(md, embed_dim=C, patch_scale=ps, overlap_ratio=ov / 100)
+        return
+    e = tante_amd.enc_CNN(md, embed_dim=C, patch_scale=ps, overlap_ratio=0.0).to(dev)
+    d = tante_amd.dec_CNN(md, embed_dim=C, patch_scale=ps, overlap_ratio=0.0).to(dev)
+    e.load_state_dict(split_prefix(g, "enc."))
+    d.load_state_dict(split_prefix(g, "dec."))
+    with torch.no_grad():
+        close(e(g["x"].to(dev)), g["z"], "fp32")
+        close(d(g["zz"].to(dev)), g["r"], "fp32")
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            close(e(g["x"].to(dev)), g["z"], "bf16")
+            close(d(g["zz"].to(dev)), g["r"], "bf16")
+
+
+def _tante_from(g, dev, **kw):
+    import tante_amd
+    m = tante_amd.TANTE(**kw).to(dev).eval()
+    missing = m.load_state_dict(split_prefix(g, "w."), strict=True)
+    return m
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_g1_tiny_end_to_end(dev, mode):
+    import tante_amd
+    g = load_golden("g1_tante_tiny")
+    m = _tante_from(g, dev, in_T=4, dset_metadata=tante_amd.TanteMetadata(n_fields=1, spatial_resolution=(64, 64)),
+                    taylor_order=2, attn_axes="TL-TL", n_head=4, embed_dim=64, patch_scale=8, dropout=0.0)
+    m.set_compute(mode)
+    with torch.no_grad():
+        y = m(g["x"].to(dev))
+    close(y, g["y"], mode)
+    # the derivative part alone (output minus the last input frame) must also agree
+    d, dref = y.cpu() - g["x"][:, -1:], g["y"] - g["x"][:, -1:]
+    assert rel_err(d, dref) < (2e-5 if mode == "fp32" else 3e-2)
+
+
+@pytest.mark.parametrize("tag,axes", [("o1", "TH"), ("o2", "T-W"), ("o3", "T-H-W")])
+def test_g7_taylor_orders(dev, tag, axes):
+    import tante_amd
+    g = load_golden("g7_taylor_" + tag)
+    order, fi, ol = int(g["meta"][0]), float(g["meta"][1]) / 100, int(g["meta"][2])
+    m = _tante_from(g, dev, in_T=3, dset_metadata=tante_amd.TanteMetadata(n_fields=2, spatial_resolution=(16, 32)),
+                    taylor_order=order, frame_interval=fi, output_length=ol, attn_axes=axes, n_head=2, embed_dim=32,
+                    patch_scale=8, dropout=0.0)
+    with torch.no_grad():
+        y = m(g["x"].to(dev))          # T=5 > in_T: window slice
+    close(y, g["y"], "fp32")
+
+
+@pytest.mark.parametrize("name", names("g8_rollout_*"))
+def test_g8_rollout(dev, name):
+    import tante_amd
+    g = load_golden(name)
+    ol, n_roll = int(g["meta"][0]), int(g["meta"][1])
+    md = tante_amd.TanteMetadata(n_fields=2, spatial_resolution=(16, 16))
+    m = _tante_from(g, dev, in_T=4, dset_metadata=md, taylor_order=2, output_length=ol, attn_axes="T-L", n_head=2,
+                    embed_dim=32, patch_scale=8, dropout=0.0)
+    fmt = tante_amd.DefaultChannelsFirstFormatter(md)
+    with torch.no_grad():
+        y, y_ref = tante_amd.rollout_model(m, {"input": g["inp"], "output": g["out"]}, fmt, n_roll)
+        yt, _ = tante_amd.rollout_model(m, {"input": g["inp"], "output": g["out"][:, :4]}, fmt, 4)
+    close(y, g["y_eval"], "fp32", scale=3.0)
+    close(yt, g["y_train"], "fp32", scale=3.0)
+    assert torch.equal(y_ref.cpu(), g["y_ref"])
+
+
+def test_g13_adaptive_dt(dev):
+    import tante_amd
+    g = load_golden("g13_deg_false")
+    m = _tante_from(g, dev, in_T=4, dset_metadata=tante_amd.TanteMetadata(n_fields=1, spatial_resolution=(32, 32)),
+                    taylor_order=2, attn_axes="TH-TW", n_head=2, embed_dim=32, patch_scale=8, dropout=0.0, deg=False)
+    with torch.no_grad():
+        for out_T, tag in ((1.5, "1p5"), (6, "6")):
+            y, rt = m(g["x"].to(dev), out_T)
+            close(rt, g["rt_" + tag], "fp32")
+            close(y, g["y_" + tag], "fp32")
+
+
+# ---------------------------------------------------------------------------------------------------
+# full-size configuration (BASELINE cfg2): oracle on one sample + size-independent properties
+# ---------------------------------------------------------------------------------------------------
+def _cfg2_model(dev, order3=True):
+    import tante_amd
+    torch.manual_seed(211)
+    md = tante_amd.TanteMetadata(n_fields=11, spatial_resolution=(256, 256))
+    kw = dict(taylor_order=3, attn_axes="THW-THW-THW") if order3 else dict(taylor_order=1, attn_axes="THWTHWTHW")
+    m = tante_amd.TANTE(in_T=4, dset_metadata=md, n_head=8, mlp_ratio=1.0, dropout=0.1, embed_dim=256, patch_scale=8, **kw)
+    return m.to(dev).eval()
+
+
+def test_cfg2_full_size_against_oracle(dev):
+    from oracle import tante_oracle as O
+    m = _cfg2_model(dev)
+    w = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    cfg = O.TanteCfg(4, 11, (256, 256), taylor_order=3, attn_axes="THW-THW-THW", n_head=8, embed_dim=256, patch_scale=8)
+    x = torch.randn(2, 4, 11, 256, 256, generator=torch.Generator().manual_seed(211))
+    ref = O.tante_forward(w, cfg, x[:1])
+    with torch.no_grad():
+        y32 = m.set_compute("fp32")(x.to(dev))
+        y16 = m.set_compute("bf16")(x.to(dev))
+        y32_b = m.set_compute("fp32")(x[1:].to(dev))
+    close(y32[:1], ref, "fp32")
+    close(y16[:1], ref, "bf16")
+    # derivative part (what the network actually computes) under the same bars, slightly widened
+    d32, d16, dref = y32[:1].cpu() - x[:1, -1:], y16[:1].cpu() - x[:1, -1:], ref - x[:1, -1:]
+    assert rel_err(d32, dref) < 5e-5 and rel_err(d16, dref) < 5e-2
+    # batch independence: sample 1 computed alone == computed inside the batch (bitwise: same kernels, same tiles)
+    assert torch.equal(y32[1:], y32_b)
