@@ -140,7 +140,8 @@ def main():
                           attn_axes=mk.get("attn_axes", "THWTHWTHW"), n_head=mk.get("n_head", 8), mlp_ratio=mk.get("mlp_ratio", 1.0),
                           embed_dim=mk.get("embed_dim", 256), patch_scale=mk.get("patch_scale", 32))
         w = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
-        cores = os.cpu_count() or 1
+        # the GPU box gives one job a share of the host (16 cores per GPU), whatever os.cpu_count() says
+        cores = min(len(os.sched_getaffinity(0)), int(os.environ.get("TANTE_CPU_THREADS", "16")))
         torch.set_num_threads(cores)
         Bc, nc = min(B, 4), 2
         cb = {"input": batch["input"][:Bc].cpu(), "output": batch["output"][:Bc, :nc].cpu()}

@@ -22,6 +22,10 @@ template <int D>
 __device__ __forceinline__ void load_row(const void* base, int dtype, long elem, float (&v)[D]) {
   if (dtype == TANTE_BF16) {
     const unsigned short* p = (const unsigned short*)base + elem;
+    if constexpr (D == 4) {
+      const u32x2 u = *(const u32x2*)p;
+      v[0] = bf16_lo(u[0]); v[1] = bf16_hi(u[0]); v[2] = bf16_lo(u[1]); v[3] = bf16_hi(u[1]);
+    }
 #pragma unroll
     for (int i = 0; i < D / 8; ++i) {
       const u32x4 u = *(const u32x4*)(p + 8 * i);
@@ -45,6 +49,12 @@ template <int D>
 __device__ __forceinline__ void store_row(void* base, int dtype, long elem, const float (&v)[D]) {
   if (dtype == TANTE_BF16) {
     unsigned short* p = (unsigned short*)base + elem;
+    if constexpr (D == 4) {
+      u32x2 u;
+      u[0] = pack_bf16x2(v[0], v[1]);
+      u[1] = pack_bf16x2(v[2], v[3]);
+      *(u32x2*)p = u;
+    }
 #pragma unroll
     for (int i = 0; i < D / 8; ++i) {
       u32x4 u;
@@ -214,11 +224,12 @@ extern "C" int tante_attention(const void* qkv, void* o, int dtype, int C, int n
   if (seq->nseq > 65535 && seq->L > 256) TANTE_FAIL(-2, "tante_attention: too many long sequences for one launch");
   hipStream_t s = (hipStream_t)stream;
   switch (d) {
+    case 4: launch_attn<4>(qkv, o, dtype, C, n_head, *seq, causal, s); break;
     case 8: launch_attn<8>(qkv, o, dtype, C, n_head, *seq, causal, s); break;
     case 16: launch_attn<16>(qkv, o, dtype, C, n_head, *seq, causal, s); break;
     case 32: launch_attn<32>(qkv, o, dtype, C, n_head, *seq, causal, s); break;
     case 64: launch_attn<64>(qkv, o, dtype, C, n_head, *seq, causal, s); break;
-    default: TANTE_FAIL(-2, "tante_attention: head dim %d unsupported (8, 16, 32, 64)", d);
+    default: TANTE_FAIL(-2, "tante_attention: head dim %d unsupported (4, 8, 16, 32, 64)", d);
   }
   TANTE_CHECK_LAUNCH();
   return 0;

@@ -18,6 +18,7 @@
 // not care about.  bf16 compute uses v_mfma_f32_16x16x32_bf16 whose natural operand layout is
 // already one 16-byte chunk (8 consecutive k) per lane.
 #include "common.cuh"
+#include <stdlib.h>
 
 namespace {
 
@@ -170,7 +171,43 @@ __device__ __forceinline__ EpiRow epi_row(const TanteGemm& g, int row) {
   return e;
 }
 
-// finished group: token row (EpiRow), output features n0 .. n0+3 (pre-bias accumulators in v)
+// ---- compile-time variants ------------------------------------------------------------------------
+// The row gather (AM), the activation and the epilogue kind (EP) are template parameters so that the
+// tile loop is one short straight-line path: a first version that switched on them at run time inlined
+// every combination 8x per tile (170 KB of code per kernel, instruction-fetch bound at ~5 % of MFMA peak).
+enum { AM_LIN = 0, AM_NHWC = 1, AM_GEN = 2 };
+enum { EP_LIN_NONE = 0, EP_LIN_RELU, EP_LIN_GELU_TANH, EP_LIN_GELU_ERF, EP_FILM, EP_DNHWC_GELU_ERF, EP_DNCHW_NONE, EP_GEN };
+
+template <bool FAST>
+__device__ __forceinline__ float gelu_tanh_v(float x) {
+  // 0.5 x (1 + tanh u) = x / (1 + exp(-2u)),  u = sqrt(2/pi) (x + 0.044715 x^3)
+  const float u2 = 1.59576912160573071176f * (x + 0.044715f * x * x * x);
+  const float e = FAST ? __expf(-u2) : expf(-u2);
+  return x / (1.0f + e);
+}
+
+template <int E>
+__device__ __forceinline__ void load_chunk_fast_lin(const TanteGemm& g, const RowInfo& ri, int k0, float (&v)[E]) {
+  if (ri.ok && k0 < g.K) {
+    ld_vec<E>(g.a, g.a_dtype, ri.a_base + k0, v);
+  } else {
+#pragma unroll
+    for (int i = 0; i < E; ++i) v[i] = 0.0f;
+  }
+}
+template <int E>
+__device__ __forceinline__ void load_chunk_fast_nhwc(const TanteGemm& g, const RowInfo& ri, int k0, float (&v)[E]) {
+  if (ri.ok && k0 < g.K) {
+    const int seg = g.P * g.Cin;
+    const int kh = k0 / seg, rem = k0 - kh * seg;
+    ld_vec<E>(g.a, g.a_dtype, ri.a_base + (long)kh * g.Win * g.Cin + rem, v);
+  } else {
+#pragma unroll
+    for (int i = 0; i < E; ++i) v[i] = 0.0f;
+  }
+}
+
+// generic epilogue: every mode, scalar stores allowed (slow variant for odd shapes)
 __device__ __forceinline__ void epilogue4(const TanteGemm& g, const EpiRow& e, int n0, float (&v)[4], bool out_vec) {
   if (!e.ok || n0 >= g.N) return;
   {
@@ -240,6 +277,48 @@ __device__ __forceinline__ void epilogue4(const TanteGemm& g, const EpiRow& e, i
   }
 }
 
+// fast epilogues: vector stores only, one mode each
+template <int EP, bool BF16>
+__device__ __forceinline__ void epilogue4_fast(const TanteGemm& g, const EpiRow& e, int n0, float (&v)[4]) {
+  if (!e.ok || n0 >= g.N) return;
+  const f32x4 b = *(const f32x4*)(g.bias + n0);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float x = v[j] + b[j];
+    if constexpr (EP == EP_LIN_RELU) x = fmaxf(x, 0.0f);
+    if constexpr (EP == EP_LIN_GELU_TANH) x = gelu_tanh_v<BF16>(x);
+    if constexpr (EP == EP_LIN_GELU_ERF || EP == EP_DNHWC_GELU_ERF) x = gelu_erf_f(x);
+    v[j] = x;
+  }
+  if constexpr (EP <= EP_LIN_GELU_ERF) {
+    if (g.residual) {
+      const f32x4 r = *(const f32x4*)(g.residual + e.r_base + n0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] += r[j];
+    }
+    store4(g.out, g.out_dtype, e.o_base + n0, v);
+  } else if constexpr (EP == EP_FILM) {
+    const f32x4 fa = *(const f32x4*)(g.film_a + (long)e.t * g.N + n0), fb = *(const f32x4*)(g.film_b + (long)e.t * g.N + n0);
+    const f32x4 se = *(const f32x4*)(g.s_emb + (long)e.hw * g.N + n0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = v[j] * fa[j] + fb[j] + se[j];
+    store4(g.out, g.out_dtype, e.o_base + n0, v);
+  } else if constexpr (EP == EP_DNHWC_GELU_ERF) {
+    const int khw = n0 / g.Cout, co = n0 - khw * g.Cout;
+    const int kh = khw / g.Po, kw = khw - kh * g.Po;
+    store4(g.out, g.out_dtype, (e.o_base + (long)kh * (g.Wi * g.Po) + kw) * g.Cout + co, v);
+  } else {  // EP_DNCHW_NONE: n = (co, kh, kw); P*P consecutive n are one output pixel block of one channel
+    const long Ho = (long)g.Hi * g.Po, Wo = (long)g.Wi * g.Po;
+    const int pp = g.Po * g.Po;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (n0 + j < g.N) {
+        const int n = n0 + j, co = n / pp, rem = n - co * pp, kh = rem / g.Po, kw = rem - kh * g.Po;
+        ((float*)g.out)[e.o_base + (long)co * Ho * Wo + (long)kh * Wo + kw] = v[j];
+      }
+  }
+}
+
 template <bool BF16>
 __device__ __forceinline__ u32x4 to_frag(const float (&v)[BF16 ? 8 : 4]) {
   u32x4 f;
@@ -255,7 +334,14 @@ __device__ __forceinline__ u32x4 to_frag(const float (&v)[BF16 ? 8 : 4]) {
   return f;
 }
 
-template <bool BF16, int CB, int TT, bool LN>
+template <int AM, int E>
+__device__ __forceinline__ void load_chunk_any(const TanteGemm& g, const RowInfo& ri, int k0, bool a_vec, float (&v)[E]) {
+  if constexpr (AM == AM_LIN) load_chunk_fast_lin<E>(g, ri, k0, v);
+  else if constexpr (AM == AM_NHWC) load_chunk_fast_nhwc<E>(g, ri, k0, v);
+  else load_chunk<E>(g, ri, k0, a_vec, v);
+}
+
+template <bool BF16, int CB, int TT, bool LN, int AM, int EP>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const TanteGemm g, int n_tiles, int tiles_per_split, int flags) {
   constexpr int E = BF16 ? 8 : 4;       // elements per 16-byte chunk
   constexpr int CPR = CB * 4;           // chunks per packed weight row
@@ -291,7 +377,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const TanteGemm g, int n_t
     if constexpr (LN) {  // LayerNorm without affine (gamma/beta are folded into the packed weight / bias)
       float v[CB][E];
 #pragma unroll
-      for (int cb = 0; cb < CB; ++cb) load_chunk<E>(g, ri, (cb * 4 + kk) * E, a_vec, v[cb]);
+      for (int cb = 0; cb < CB; ++cb) load_chunk_any<AM, E>(g, ri, (cb * 4 + kk) * E, a_vec, v[cb]);
       float s = 0.0f;
 #pragma unroll
       for (int cb = 0; cb < CB; ++cb)
@@ -322,7 +408,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const TanteGemm g, int n_t
 #pragma unroll
       for (int cb = 0; cb < CB; ++cb) {
         float v[E];
-        load_chunk<E>(g, ri, (cb * 4 + kk) * E, a_vec, v);
+        load_chunk_any<AM, E>(g, ri, (cb * 4 + kk) * E, a_vec, v);
         xf[tt][cb] = to_frag<BF16>(v);
       }
     }
@@ -381,7 +467,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const TanteGemm g, int n_t
 #pragma unroll
       for (int tt = 0; tt < TT; ++tt) {
         float v[4] = {acc[ns][tt][0], acc[ns][tt][1], acc[ns][tt][2], acc[ns][tt][3]};
-        epilogue4(g, er[tt], t * NT + ns * 16 + kk * 4, v, out_vec);
+        if constexpr (EP == EP_GEN) epilogue4(g, er[tt], t * NT + ns * 16 + kk * 4, v, out_vec);
+        else epilogue4_fast<EP, BF16>(g, er[tt], t * NT + ns * 16 + kk * 4, v);
       }
 
     if (more) {
@@ -467,28 +554,61 @@ __global__ void pack_bias_kernel(const float* __restrict__ w, const float* __res
   out[n] = b;
 }
 
-template <bool BF16, int CB>
-int launch_gemm(const TanteGemm& g, int n_tiles, int flags, hipStream_t s) {
+template <bool BF16, int CB, bool LN, int AM, int EP>
+void launch_variant(const TanteGemm& g, int n_tiles, int flags, hipStream_t s) {
   constexpr int TT = (CB <= 8) ? 2 : 1;
   constexpr int NT = nt_for_cb(CB);
   const int rows_per_wg = 4 * TT * 16;
   const int gx = (g.M + rows_per_wg - 1) / rows_per_wg;
-  // split N over workgroups until the grid fills the 256 CUs a few times over
   int nsplit = 1;
-  while (nsplit < n_tiles && (long)gx * nsplit < 1024 && (n_tiles % (nsplit * 2) == 0)) nsplit *= 2;
+  static const int target = getenv("TANTE_GEMM_WGS") ? atoi(getenv("TANTE_GEMM_WGS")) : 512;
+  // every N-split re-loads (and re-normalises) the token rows, so split only while the grid is short of WGs
+  while (nsplit < n_tiles && (long)gx * nsplit < target && (n_tiles % (nsplit * 2) == 0)) nsplit *= 2;
   const int per = (n_tiles + nsplit - 1) / nsplit;
   const size_t lds = 2 * (size_t)NT * CB * 4 * 16;
+  auto kern = gemm_kernel<BF16, CB, TT, LN, AM, EP>;
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute((const void*)gemm_kernel<BF16, CB, TT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipFuncSetAttribute((const void*)gemm_kernel<BF16, CB, TT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  if (g.ln)
-    hipLaunchKernelGGL((gemm_kernel<BF16, CB, TT, true>), dim3(gx, nsplit), dim3(256), lds, s, g, n_tiles, per, flags);
-  else
-    hipLaunchKernelGGL((gemm_kernel<BF16, CB, TT, false>), dim3(gx, nsplit), dim3(256), lds, s, g, n_tiles, per, flags);
-  return 0;
+  hipLaunchKernelGGL(kern, dim3(gx, nsplit), dim3(256), lds, s, g, n_tiles, per, flags);
+}
+
+// the variants the TANTE path uses get a dedicated straight-line kernel; anything else runs the generic one
+template <bool BF16, int CB>
+void launch_gemm(const TanteGemm& g, int n_tiles, int flags, hipStream_t s) {
+  const bool a_vec = flags & 1, out_vec = flags & 2;
+  const int E = BF16 ? 8 : 4;
+  const bool k_ok = (g.K % E) == 0;
+  int am = AM_GEN;
+  if (a_vec && k_ok && g.a_mode == TANTE_A_LINEAR) am = AM_LIN;
+  if (a_vec && k_ok && g.a_mode == TANTE_A_PATCH_NHWC) am = AM_NHWC;
+  int ep = EP_GEN;
+  if (out_vec && g.e_mode == TANTE_E_LINEAR) {
+    ep = g.act == TANTE_ACT_NONE ? EP_LIN_NONE : g.act == TANTE_ACT_RELU ? EP_LIN_RELU
+       : g.act == TANTE_ACT_GELU_TANH ? EP_LIN_GELU_TANH : EP_LIN_GELU_ERF;
+  } else if (out_vec && g.e_mode == TANTE_E_FILM && g.act == TANTE_ACT_NONE) {
+    ep = EP_FILM;
+  } else if (out_vec && g.e_mode == TANTE_E_DECONV_NHWC && g.act == TANTE_ACT_GELU_ERF) {
+    ep = EP_DNHWC_GELU_ERF;
+  } else if (g.e_mode == TANTE_E_DECONV_NCHW && g.act == TANTE_ACT_NONE) {
+    ep = EP_DNCHW_NONE;
+  }
+  const bool ln = g.ln != 0;
+#define TANTE_V(LNV, AMV, EPV) launch_variant<BF16, CB, LNV, AMV, EPV>(g, n_tiles, flags, s)
+  if (ln && am == AM_LIN && ep == EP_LIN_NONE) return TANTE_V(true, AM_LIN, EP_LIN_NONE);            // LN + QKV
+  if (ln && am == AM_LIN && ep == EP_LIN_GELU_TANH) return TANTE_V(true, AM_LIN, EP_LIN_GELU_TANH);  // LN + fc1 + GELU
+  if (!ln && am == AM_LIN && ep == EP_LIN_NONE) return TANTE_V(false, AM_LIN, EP_LIN_NONE);          // out-proj / fc2 (+res)
+  if (!ln && am == AM_LIN && ep == EP_LIN_RELU) return TANTE_V(false, AM_LIN, EP_LIN_RELU);          // interprator
+  if (!ln && am == AM_GEN && ep == EP_LIN_GELU_ERF) return TANTE_V(false, AM_GEN, EP_LIN_GELU_ERF);  // patch embed 1 (NCHW)
+  if (!ln && am == AM_NHWC && ep == EP_LIN_GELU_ERF) return TANTE_V(false, AM_NHWC, EP_LIN_GELU_ERF);  // patch embed 2
+  if (!ln && am == AM_NHWC && ep == EP_FILM) return TANTE_V(false, AM_NHWC, EP_FILM);                // patch embed 3 + FiLM
+  if (!ln && am == AM_LIN && ep == EP_DNHWC_GELU_ERF) return TANTE_V(false, AM_LIN, EP_DNHWC_GELU_ERF);  // heads 1, 2
+  if (!ln && am == AM_LIN && ep == EP_DNCHW_NONE) return TANTE_V(false, AM_LIN, EP_DNCHW_NONE);      // head 3
+  if (ln) return TANTE_V(true, AM_GEN, EP_GEN);
+  return TANTE_V(false, AM_GEN, EP_GEN);
+#undef TANTE_V
 }
 
 }  // namespace
