@@ -153,6 +153,23 @@ int tante_taylor(const float* last, int64_t last_bstride, const float* const* de
  * rt[b] = mean_l clamp(t[b][l], 0, out_T - 1) + ep. */
 int tante_rt_reduce(const float* t, int B, int L, float out_T, float ep, float* rt, void* stream);
 
+/* ---- fused TransformerBlock (bf16 MFMA path) ----------------------------------------------------
+ * tante_block_fused: x (tokens, C) fp32, in place, ONE launch for the whole block
+ *     x += out_proj(MHA(LayerNorm1(x)));  x += W2 gelu_tanh(W1 LayerNorm2(x) + b1) + b2   attn_backbone.py:59-83
+ * The residual rows are read once, stay in registers and are written once; q, k, v, scores, per-head
+ * outputs and the MLP hidden layer never leave the CU.  It consumes the "weight stream" built by
+ * tante_pack_block from the block's 12 fp32 parameters (LayerNorm affine folded, 1/sqrt(d) folded into q,
+ * bf16, k-permuted LDS tile images in consumption order).
+ * Supported: head dim 32, C in {64,128,256}, hidden in {C, 2C} (C = 256: hidden = 256), sequence length L
+ * dividing 32 (tante_block_fused_supported); anything else goes through tante_gemm + tante_attention. */
+int tante_block_fused_supported(int C, int n_head, int hidden, int L);
+int64_t tante_block_stream_bytes(int C, int hidden);
+int tante_pack_block(const float* ln1_w, const float* ln1_b, const float* in_w, const float* in_b, const float* out_w,
+                     const float* out_b, const float* ln2_w, const float* ln2_b, const float* fc1_w, const float* fc1_b,
+                     const float* fc2_w, const float* fc2_b, int C, int hidden, void* block_stream, void* stream);
+int tante_block_fused(float* x, const void* block_stream, int C, int n_head, int hidden, const TanteSeq* seq, int causal,
+                      float eps, void* stream);
+
 const char* tante_last_error(void);
 int tante_abi_version(void);
 

@@ -48,6 +48,10 @@ SIGNATURES = {
     "tante_taylor": ([c_vp, c_i64, C.POINTER(c_vp), c_i32, C.c_double, c_i32, c_vp, c_i64, c_i64, c_vp], c_i32),
     "tante_rt_reduce": ([c_vp, c_i32, c_i32, c_f32, c_f32, c_vp, c_vp], c_i32),
     "tante_gather_last": ([c_vp, c_i64, c_i32, c_vp, c_vp], c_i32),
+    "tante_block_fused_supported": ([c_i32, c_i32, c_i32, c_i32], c_i32),
+    "tante_block_stream_bytes": ([c_i32, c_i32], c_i64),
+    "tante_pack_block": ([c_vp] * 12 + [c_i32, c_i32, c_vp, c_vp], c_i32),
+    "tante_block_fused": ([c_vp, c_vp, c_i32, c_i32, c_i32, C.POINTER(Seq), c_i32, c_f32, c_vp], c_i32),
     "tante_last_error": ([], C.c_char_p),
     "tante_abi_version": ([], c_i32),
 }

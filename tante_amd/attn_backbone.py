@@ -77,6 +77,7 @@ class TransformerBlock(nn.Module):
         self.drop = nn.Dropout(dropout)
         self._cache = _PackCache()
         self.compute: Optional[str] = None
+        self.fused = True        # bf16: use the fused block kernels whenever the shape allows
 
     def _packed(self, compute: int):
         a, m = self.attn, self.mlp
@@ -91,12 +92,22 @@ class TransformerBlock(nn.Module):
                 fc2=K.pack_weight(m[2].weight, m[2].bias, compute))
         return self._cache.get(compute, params, build)
 
+    def _packed_fused(self):
+        a, m = self.attn, self.mlp
+        params = [self.ln1.weight, self.ln1.bias, a.in_proj_weight, a.in_proj_bias, a.out_proj.weight, a.out_proj.bias,
+                  self.ln2.weight, self.ln2.bias, m[0].weight, m[0].bias, m[2].weight, m[2].bias]
+        return self._cache.get(-1, params, lambda: K.pack_block(params, self.embed_dim, self.hidden))
+
     def forward_tokens(self, x: torch.Tensor, seq: L.Seq, causal: bool, compute: int) -> torch.Tensor:
         """In place on the flat fp32 residual stream x (tokens, C); `seq` says which tokens attend to which."""
         if self.training and self.p_drop > 0.0:
             raise NotImplementedError("dropout > 0 in training mode is not implemented on the HIP path yet")
         C_ = self.embed_dim
         n_tok = x.numel() // C_
+        if (compute == L.BF16 and self.fused and self.ln1.eps == self.ln2.eps
+                and K.block_fused_supported(C_, self.n_head, self.hidden, seq.L)):
+            # one launch per block: the residual rows are read once and written once
+            return K.block_fused(x, self._packed_fused(), C_, self.n_head, self.hidden, seq, causal, self.ln1.eps)
         pk = self._packed(compute)
         adt = K.act_torch_dtype(compute)
         qkv = torch.empty(n_tok, 3 * C_, dtype=adt, device=x.device)

@@ -232,3 +232,26 @@ def gather_last(z: torch.Tensor, n: int, E: int, out: torch.Tensor):
     _dev(z, out)
     L.check(L.lib().tante_gather_last(_p(z), n, E, _p(out), _stream()), "tante_gather_last")
     return out
+
+
+# ---- fused TransformerBlock halves (bf16) ----------------------------------------------------------------
+def block_fused_supported(C_: int, n_head: int, hidden: int, Lq: int) -> bool:
+    return bool(L.lib().tante_block_fused_supported(C_, n_head, hidden, Lq))
+
+
+def pack_block(params: Sequence[torch.Tensor], C_: int, hidden: int) -> torch.Tensor:
+    """params = (ln1.w, ln1.b, in_proj_w, in_proj_b, out_proj.w, out_proj.b, ln2.w, ln2.b, fc1.w, fc1.b, fc2.w, fc2.b)
+    -> the block's weight stream (uint8 device buffer)."""
+    ps = [p.detach() for p in params]
+    _dev(*ps)
+    st = torch.empty(L.lib().tante_block_stream_bytes(C_, hidden), dtype=torch.uint8, device=ps[0].device)
+    L.check(L.lib().tante_pack_block(*[_p(p) for p in ps], C_, hidden, _p(st), _stream()), "tante_pack_block")
+    return st
+
+
+def block_fused(x: torch.Tensor, block_stream: torch.Tensor, C_: int, n_head: int, hidden: int, seq: L.Seq, causal: bool,
+                eps: float):
+    _dev(x, block_stream)
+    L.check(L.lib().tante_block_fused(_p(x), _p(block_stream), C_, n_head, hidden, C.byref(seq), int(causal), eps, _stream()),
+            "tante_block_fused")
+    return x

@@ -415,3 +415,53 @@ def test_cfg2_full_size_against_oracle(dev):
     assert rel_err(d32, dref) < 5e-5 and rel_err(d16, dref) < 5e-2
     # batch independence: sample 1 computed alone == computed inside the batch (bitwise: same kernels, same tiles)
     assert torch.equal(y32[1:], y32_b)
+
+
+# ---------------------------------------------------------------------------------------------------
+# fused block kernels (bf16): every supported shape against the oracle and against the unfused path
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("C,nh,Lq,Bp,causal,ratio", [(256, 8, 32, 5, False, 1.0), (256, 8, 4, 37, True, 1.0), (256, 8, 16, 3, False, 1.0),
+                                                      (256, 8, 8, 9, True, 1.0), (256, 8, 1, 70, False, 1.0), (256, 8, 2, 33, True, 1.0),
+                                                      (128, 4, 32, 2, False, 2.0), (64, 2, 4, 50, True, 1.0), (64, 2, 32, 3, False, 2.0),
+                                                      (128, 4, 8, 20, False, 1.0), (256, 8, 32, 130, False, 1.0)])
+def test_fused_block(dev, C, nh, Lq, Bp, causal, ratio):
+    import tante_amd
+    from oracle import tante_oracle as O
+    from tante_amd import kernels as Kk
+    torch.manual_seed(C + Lq + Bp)
+    blk = tante_amd.TransformerBlock(C, nh, mlp_ratio=ratio, dropout=0.0).to(dev).eval()
+    with torch.no_grad():
+        for ln in (blk.ln1, blk.ln2):
+            ln.weight.add_(0.2 * torch.randn_like(ln.weight))
+            ln.bias.add_(0.2 * torch.randn_like(ln.bias))
+        blk.attn.in_proj_bias.add_(0.1 * torch.randn_like(blk.attn.in_proj_bias))
+        blk.attn.out_proj.bias.add_(0.1 * torch.randn_like(blk.attn.out_proj.bias))
+    assert Kk.block_fused_supported(C, nh, blk.hidden, Lq)
+    x = torch.randn(Bp, Lq, C) * 1.5 + 0.3
+    ref = O.transformer_block({k: v.detach().cpu() for k, v in blk.state_dict().items()}, x, nh, causal)
+    blk.compute = "bf16"
+    with torch.no_grad():
+        blk.fused = True
+        y_f = blk(x.to(dev), causal=causal)
+        blk.fused = False
+        y_u = blk(x.to(dev), causal=causal)
+    close(y_f, ref, "bf16")
+    close(y_u, ref, "bf16")
+    # the block's own contribution (output minus the residual input) must also hold the bar
+    d_f, d_ref = y_f.cpu() - x, ref - x
+    assert rel_err(d_f, d_ref) < 2e-2, rel_err(d_f, d_ref)
+
+
+def test_fused_backbone_strided_letters(dev):
+    """T/H/W letters through the fused kernels on a (B,T,H,W,C) grid: the strided gather inside the kernel."""
+    import tante_amd
+    from oracle import tante_oracle as O
+    torch.manual_seed(3)
+    T, H, W, C = 4, 8, 16, 64
+    bb = tante_amd.Attn_Backbone((T, H, W, C), "THW", n_head=2, mlp_ratio=1.0, dropout=0.0).to(dev).eval()
+    x = torch.randn(3, T, H, W, C)
+    ref = O.attn_backbone({k: v.detach().cpu() for k, v in bb.state_dict().items()}, x, "THW", 2)
+    bb.compute = "bf16"
+    with torch.no_grad():
+        y = bb(x.to(dev))
+    close(y, ref, "bf16")
