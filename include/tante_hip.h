@@ -129,6 +129,14 @@ int tante_attention(const void* qkv, void* o, int dtype, int C, int n_head, cons
 int tante_axis_mlp(float* x, int64_t outer, int n, int64_t inner, const float* w1, const float* b1, const float* w2,
                    const float* b2, void* stream);
 
+/* Vertical then horizontal propagator in ONE pass over x (BT, nH, nW, C) fp32, in place (attn_backbone.py:140-143):
+ * x += MLP_H(x) along h; x += MLP_W(x) along w.  The n x n contractions run on MFMA in the compute dtype
+ * (bf16: operands rounded to bf16, fp32 accumulate, A&S erf; fp32: exact fp32 MFMA, erff).  Needs nH, nW <= 64,
+ * C % 16 == 0 and nH * (nW * 16 + 2) * 4 bytes of LDS <= 160 KiB; otherwise call tante_axis_mlp twice. */
+int tante_axis_hw(float* x, int64_t BT, int nH, int nW, int C, const float* wh1, const float* bh1, const float* wh2,
+                  const float* bh2, const float* ww1, const float* bw1, const float* ww2, const float* bw2, int compute,
+                  void* stream);
+
 /* film tables (tante.py:218-230): a[r][c] = 1 + scale(t[r])[c], b[r][c] = shift(t[r])[c] (+ add[r][c]).
  * scale/shift = Linear(1, C/2) -> ReLU -> Linear(C/2, C).  rows = len(t). */
 int tante_film_table(const float* t, int rows, int C, const float* sc_w0, const float* sc_b0, const float* sc_w2,

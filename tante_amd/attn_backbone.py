@@ -177,8 +177,12 @@ class Attn_Backbone(nn.Module):
         """In place on x = (B,T,H,W,C) fp32 contiguous."""
         T, H, W, C_ = self.T, self.H, self.W, self.C
         vp, hp, tp = self.vertical_propagator, self.horizontal_propagator, self.temporal_propagator
-        K.axis_mlp(x, B * T, H, W * C_, vp[0].weight, vp[0].bias, vp[2].weight, vp[2].bias)          # l.140-141
-        K.axis_mlp(x, B * T * H, W, C_, hp[0].weight, hp[0].bias, hp[2].weight, hp[2].bias)          # l.142-143
+        if K.axis_hw_supported(H, W, C_):      # both axes in one pass over x, contractions on MFMA     l.140-143
+            K.axis_hw(x, B * T, H, W, C_, (vp[0].weight, vp[0].bias, vp[2].weight, vp[2].bias),
+                      (hp[0].weight, hp[0].bias, hp[2].weight, hp[2].bias), compute)
+        else:
+            K.axis_mlp(x, B * T, H, W * C_, vp[0].weight, vp[0].bias, vp[2].weight, vp[2].bias)      # l.140-141
+            K.axis_mlp(x, B * T * H, W, C_, hp[0].weight, hp[0].bias, hp[2].weight, hp[2].bias)      # l.142-143
         K.axis_mlp(x, B, T, H * W * C_, tp[0].weight, tp[0].bias, tp[2].weight, tp[2].bias)          # l.144-145
         ci = 0
         for i, axis in enumerate(self.attn_axes):

@@ -40,6 +40,15 @@ __device__ __forceinline__ float bf16_hi(unsigned u) { return __uint_as_float(u 
 
 // ---- activations (always evaluated in fp32) ---------------------------------------------------
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7): one v_exp, one v_rcp, 6 fma -- a third of ocml erff.
+// Used by the bf16 path only; the fp32 parity path keeps erff.
+__device__ __forceinline__ float gelu_erf_fast(float x) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float erf_abs = 1.0f - poly * __expf(-z * z);
+  return 0.5f * x * (1.0f + copysignf(erf_abs, x));
+}
 __device__ __forceinline__ float gelu_tanh_f(float x) {
   const float c = 0.79788456080286535588f;  // sqrt(2/pi)
   return 0.5f * x * (1.0f + tanhf(c * (x + 0.044715f * x * x * x)));

@@ -175,15 +175,15 @@ __device__ __forceinline__ EpiRow epi_row(const TanteGemm& g, int row) {
 // The row gather (AM), the activation and the epilogue kind (EP) are template parameters so that the
 // tile loop is one short straight-line path: a first version that switched on them at run time inlined
 // every combination 8x per tile (170 KB of code per kernel, instruction-fetch bound at ~5 % of MFMA peak).
-enum { AM_LIN = 0, AM_NHWC = 1, AM_GEN = 2 };
+enum { AM_LIN = 0, AM_NHWC = 1, AM_GEN = 2, AM_NCHW2 = 3 };
 enum { EP_LIN_NONE = 0, EP_LIN_RELU, EP_LIN_GELU_TANH, EP_LIN_GELU_ERF, EP_FILM, EP_DNHWC_GELU_ERF, EP_DNCHW_NONE, EP_GEN };
 
 template <bool FAST>
 __device__ __forceinline__ float gelu_tanh_v(float x) {
   // 0.5 x (1 + tanh u) = x / (1 + exp(-2u)),  u = sqrt(2/pi) (x + 0.044715 x^3)
   const float u2 = 1.59576912160573071176f * (x + 0.044715f * x * x * x);
-  const float e = FAST ? __expf(-u2) : expf(-u2);
-  return x / (1.0f + e);
+  if constexpr (FAST) return x * __builtin_amdgcn_rcpf(1.0f + __expf(-u2));
+  return x / (1.0f + expf(-u2));
 }
 
 template <int E>
@@ -204,6 +204,25 @@ __device__ __forceinline__ void load_chunk_fast_nhwc(const TanteGemm& g, const R
   } else {
 #pragma unroll
     for (int i = 0; i < E; ++i) v[i] = 0.0f;
+  }
+}
+
+// channels-first fp32 image, 2x2 patches: k = 4*ci + 2*kh + kw, so a chunk is E/4 channels x 2 rows x one
+// 8-byte (kw = 0,1) load; the 16 lanes of a token group read 128 contiguous bytes per (ci, kh)
+template <int E>
+__device__ __forceinline__ void load_chunk_fast_nchw2(const TanteGemm& g, const RowInfo& ri, int k0, float (&v)[E]) {
+#pragma unroll
+  for (int i = 0; i < E; ++i) v[i] = 0.0f;
+  if (!ri.ok) return;
+  const float* base = (const float*)g.a + ri.a_base;
+#pragma unroll
+  for (int e = 0; e < E / 4; ++e) {
+    const int ci = k0 / 4 + e;
+    if (ci < g.Cin) {
+      const float2 r0 = *(const float2*)(base + (long)ci * g.Hin * g.Win);
+      const float2 r1 = *(const float2*)(base + (long)ci * g.Hin * g.Win + g.Win);
+      v[4 * e] = r0.x; v[4 * e + 1] = r0.y; v[4 * e + 2] = r1.x; v[4 * e + 3] = r1.y;
+    }
   }
 }
 
@@ -287,7 +306,7 @@ __device__ __forceinline__ void epilogue4_fast(const TanteGemm& g, const EpiRow&
     float x = v[j] + b[j];
     if constexpr (EP == EP_LIN_RELU) x = fmaxf(x, 0.0f);
     if constexpr (EP == EP_LIN_GELU_TANH) x = gelu_tanh_v<BF16>(x);
-    if constexpr (EP == EP_LIN_GELU_ERF || EP == EP_DNHWC_GELU_ERF) x = gelu_erf_f(x);
+    if constexpr (EP == EP_LIN_GELU_ERF || EP == EP_DNHWC_GELU_ERF) x = BF16 ? gelu_erf_fast(x) : gelu_erf_f(x);
     v[j] = x;
   }
   if constexpr (EP <= EP_LIN_GELU_ERF) {
@@ -338,6 +357,7 @@ template <int AM, int E>
 __device__ __forceinline__ void load_chunk_any(const TanteGemm& g, const RowInfo& ri, int k0, bool a_vec, float (&v)[E]) {
   if constexpr (AM == AM_LIN) load_chunk_fast_lin<E>(g, ri, k0, v);
   else if constexpr (AM == AM_NHWC) load_chunk_fast_nhwc<E>(g, ri, k0, v);
+  else if constexpr (AM == AM_NCHW2) load_chunk_fast_nchw2<E>(g, ri, k0, v);
   else load_chunk<E>(g, ri, k0, a_vec, v);
 }
 
@@ -584,6 +604,7 @@ void launch_gemm(const TanteGemm& g, int n_tiles, int flags, hipStream_t s) {
   int am = AM_GEN;
   if (a_vec && k_ok && g.a_mode == TANTE_A_LINEAR) am = AM_LIN;
   if (a_vec && k_ok && g.a_mode == TANTE_A_PATCH_NHWC) am = AM_NHWC;
+  if (g.a_mode == TANTE_A_PATCH_NCHW && g.P == 2 && g.a_dtype == TANTE_F32 && g.Win % 2 == 0 && ((uintptr_t)g.a % 8) == 0) am = AM_NCHW2;
   int ep = EP_GEN;
   if (out_vec && g.e_mode == TANTE_E_LINEAR) {
     ep = g.act == TANTE_ACT_NONE ? EP_LIN_NONE : g.act == TANTE_ACT_RELU ? EP_LIN_RELU
@@ -601,7 +622,8 @@ void launch_gemm(const TanteGemm& g, int n_tiles, int flags, hipStream_t s) {
   if (ln && am == AM_LIN && ep == EP_LIN_GELU_TANH) return TANTE_V(true, AM_LIN, EP_LIN_GELU_TANH);  // LN + fc1 + GELU
   if (!ln && am == AM_LIN && ep == EP_LIN_NONE) return TANTE_V(false, AM_LIN, EP_LIN_NONE);          // out-proj / fc2 (+res)
   if (!ln && am == AM_LIN && ep == EP_LIN_RELU) return TANTE_V(false, AM_LIN, EP_LIN_RELU);          // interprator
-  if (!ln && am == AM_GEN && ep == EP_LIN_GELU_ERF) return TANTE_V(false, AM_GEN, EP_LIN_GELU_ERF);  // patch embed 1 (NCHW)
+  if (!ln && am == AM_NCHW2 && ep == EP_LIN_GELU_ERF) return TANTE_V(false, AM_NCHW2, EP_LIN_GELU_ERF);  // patch embed 1 (NCHW)
+  if (am == AM_NCHW2) am = AM_GEN;
   if (!ln && am == AM_NHWC && ep == EP_LIN_GELU_ERF) return TANTE_V(false, AM_NHWC, EP_LIN_GELU_ERF);  // patch embed 2
   if (!ln && am == AM_NHWC && ep == EP_FILM) return TANTE_V(false, AM_NHWC, EP_FILM);                // patch embed 3 + FiLM
   if (!ln && am == AM_LIN && ep == EP_DNHWC_GELU_ERF) return TANTE_V(false, AM_LIN, EP_DNHWC_GELU_ERF);  // heads 1, 2

@@ -88,6 +88,184 @@ __global__ __launch_bounds__(64) void axis_mlp_lds_kernel(float* __restrict__ x,
   }
 }
 
+// ---- fused vertical + horizontal propagators on MFMA -------------------------------------------------------
+// x (BT, nH, nW, C) fp32, in place:  x += MLP_H(x) along h, then x += MLP_W(x) along w  (attn_backbone.py:140-143).
+// One workgroup owns one (bt, 16-channel tile): the nH x nW x 16 plane sits in LDS (64 B per token, so global
+// traffic is whole 64-byte segments), both axes are processed there and the plane is read and written ONCE.
+// The n x n contractions run on the matrix cores: for a fixed w (phase H) or h (phase W) the MFMA B operand is
+// the 16 channels x n line, D = W1 . line, GELU on the accumulators, and -- as in the fused block kernel -- the
+// accumulator tiles are re-used directly as the next MFMA's B operand with the k order permuted (W2's columns
+// are loaded in that order), so the hidden layer never leaves registers.
+// bf16 compute: v_mfma_f32_16x16x32_bf16; fp32 compute: v_mfma_f32_16x16x4_f32 (exact fp32).  n <= 64.
+template <bool BF16, int MT>
+struct AxisW {  // A-operand fragments of one n x n weight (n <= 16 * MT), zero padded
+  static constexpr int KB = BF16 ? (MT + 1) / 2 : MT;   // k-blocks: 32 wide (bf16) / 16 wide (fp32)
+  u32x4 f[MT][KB];
+};
+
+// build the fragments from the weight staged in LDS (ws: n x n floats, row-major)
+template <bool BF16, int MT, bool KPERM>
+__device__ __forceinline__ void load_axis_weight(const float* ws, int n, int l15, int kk, AxisW<BF16, MT>& aw) {
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int row = mt * 16 + l15;
+#pragma unroll
+    for (int kb = 0; kb < AxisW<BF16, MT>::KB; ++kb) {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < (BF16 ? 8 : 4); ++e) {
+        int k;
+        if constexpr (BF16) k = KPERM ? (kb * 32 + (e < 4 ? 4 * kk + e : 16 + 4 * kk + (e - 4))) : (kb * 32 + 8 * kk + e);
+        else k = KPERM ? (kb * 16 + 4 * kk + e) : (kb * 16 + 4 * e + kk);
+        v[e] = (row < n && k < n) ? ws[row * n + k] : 0.0f;
+      }
+      if constexpr (BF16) {
+        aw.f[mt][kb][0] = pack_bf16x2(v[0], v[1]); aw.f[mt][kb][1] = pack_bf16x2(v[2], v[3]);
+        aw.f[mt][kb][2] = pack_bf16x2(v[4], v[5]); aw.f[mt][kb][3] = pack_bf16x2(v[6], v[7]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) aw.f[mt][kb][e] = __float_as_uint(v[e]);
+      }
+    }
+  }
+}
+
+// one line group: xin = this lane's k elements of the line (operand order), out = W2 gelu(W1 x + b1) + b2
+template <bool BF16, int MT>
+__device__ __forceinline__ void axis_mlp_mfma(const AxisW<BF16, MT>& w1, const AxisW<BF16, MT>& w2, const float (&b1)[MT][4],
+                                              const float (&b2)[MT][4], const float (&xin)[16 * ((MT + 1) / 2)], f32x4 (&out)[MT]) {
+  constexpr int KB = AxisW<BF16, MT>::KB;
+  f32x4 d1[MT + 1];  // +1: the bf16 pack below reads tile MT when MT is odd (zeros)
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) d1[mt] = f32x4{b1[mt][0], b1[mt][1], b1[mt][2], b1[mt][3]};
+  d1[MT] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if constexpr (BF16) {
+    u32x4 xb[KB];
+#pragma unroll
+    for (int ks = 0; ks < KB; ++ks) {
+      xb[ks][0] = pack_bf16x2(xin[8 * ks], xin[8 * ks + 1]); xb[ks][1] = pack_bf16x2(xin[8 * ks + 2], xin[8 * ks + 3]);
+      xb[ks][2] = pack_bf16x2(xin[8 * ks + 4], xin[8 * ks + 5]); xb[ks][3] = pack_bf16x2(xin[8 * ks + 6], xin[8 * ks + 7]);
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int ks = 0; ks < KB; ++ks)
+        d1[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w1.f[mt][ks]), __builtin_bit_cast(bf16x8, xb[ks]), d1[mt], 0, 0, 0);
+  } else {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          d1[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w1.f[mt][kb][e]), xin[4 * kb + e], d1[mt], 0, 0, 0);
+  }
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) d1[mt][j] = BF16 ? gelu_erf_fast(d1[mt][j]) : gelu_erf_f(d1[mt][j]);
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) out[mt] = f32x4{b2[mt][0], b2[mt][1], b2[mt][2], b2[mt][3]};
+  if constexpr (BF16) {  // the hidden accumulators ARE the B operand (k order = accumulator order, matched by w2)
+    u32x4 hb[KB];
+#pragma unroll
+    for (int ks = 0; ks < KB; ++ks) {
+      const f32x4 lo = d1[2 * ks], hi = d1[2 * ks + 1];
+      hb[ks][0] = pack_bf16x2(lo[0], lo[1]); hb[ks][1] = pack_bf16x2(lo[2], lo[3]);
+      hb[ks][2] = pack_bf16x2(hi[0], hi[1]); hb[ks][3] = pack_bf16x2(hi[2], hi[3]);
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int ks = 0; ks < KB; ++ks)
+        out[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w2.f[mt][ks]), __builtin_bit_cast(bf16x8, hb[ks]), out[mt], 0, 0, 0);
+  } else {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          out[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w2.f[mt][kb][e]), d1[kb][e], out[mt], 0, 0, 0);
+  }
+}
+
+// one phase: lines of length n along an axis with element stride `ls` floats; line group g starts at g * gs
+template <bool BF16, int MT>
+__device__ __forceinline__ void axis_phase(float* plane, float* wst, const float* __restrict__ gw1, const float* __restrict__ gb1,
+                                           const float* __restrict__ gw2, const float* __restrict__ gb2, int n, int ngroups, int ls,
+                                           int gs, int tid) {
+  const int lane = tid & 63, wave = tid >> 6, kk = lane >> 4, l15 = lane & 15;
+  // stage this axis' weights in LDS: w1 | w2 | b1 | b2
+  for (int i = tid; i < n * n; i += 256) { wst[i] = gw1[i]; wst[n * n + i] = gw2[i]; }
+  if (tid < n) { wst[2 * n * n + tid] = gb1[tid]; wst[2 * n * n + n + tid] = gb2[tid]; }
+  __syncthreads();
+  AxisW<BF16, MT> w1, w2;
+  load_axis_weight<BF16, MT, false>(wst, n, l15, kk, w1);
+  load_axis_weight<BF16, MT, true>(wst + n * n, n, l15, kk, w2);
+  float b1[MT][4], b2[MT][4];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = mt * 16 + kk * 4 + j;
+      b1[mt][j] = r < n ? wst[2 * n * n + r] : 0.0f;
+      b2[mt][j] = r < n ? wst[2 * n * n + n + r] : 0.0f;
+    }
+  constexpr int NX = 16 * ((MT + 1) / 2);
+  for (int g = wave; g < ngroups; g += 4) {
+    float* base = plane + g * gs + l15;
+    float xin[NX];
+#pragma unroll
+    for (int j = 0; j < NX; ++j) {
+      const int p = BF16 ? ((j >> 3) * 32 + kk * 8 + (j & 7)) : ((j >> 2) * 16 + (j & 3) * 4 + kk);
+      xin[j] = p < n ? base[p * ls] : 0.0f;
+    }
+    f32x4 out[MT];
+    axis_mlp_mfma<BF16, MT>(w1, w2, b1, b2, xin, out);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int p = mt * 16 + kk * 4 + j;
+        if (p < n) base[p * ls] += out[mt][j];   // this line group is owned by this wave
+      }
+  }
+  __syncthreads();
+}
+
+template <bool BF16, int MT>
+__global__ __launch_bounds__(256, 2) void axis_hw_kernel(float* __restrict__ x, int nH, int nW, int C, const float* __restrict__ wh1,
+                                                         const float* __restrict__ bh1, const float* __restrict__ wh2,
+                                                         const float* __restrict__ bh2, const float* __restrict__ ww1,
+                                                         const float* __restrict__ bw1, const float* __restrict__ ww2,
+                                                         const float* __restrict__ bw2) {
+  extern __shared__ __attribute__((aligned(16))) float plane[];  // [nH][nW*16 + 2] then the weight staging area
+  const int tid = threadIdx.x;
+  const int ctiles = C / 16;
+  const long bt = blockIdx.x / ctiles;
+  const int c0 = (blockIdx.x % ctiles) * 16;
+  float* gx = x + bt * (long)nH * nW * C + c0;
+  const int rs = nW * 16 + 2;  // LDS row (h) stride in floats: +2 spreads the h-strided reads over the banks
+  float* wst = plane + nH * rs;
+  // ---- load the plane: 4 threads x 16 B per token ---------------------------------------------------------
+  for (int i = tid; i < nH * nW * 4; i += 256) {
+    const int tokn = i >> 2, q = i & 3, h = tokn / nW, w = tokn - h * nW;
+    const f32x4 v = *(const f32x4*)(gx + (long)tokn * C + q * 4);
+    float* d = plane + h * rs + w * 16 + q * 4;
+    d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+  }
+  // phase H: lines along h (stride rs), one group per w;  phase W: lines along w (stride 16), one group per h
+  axis_phase<BF16, MT>(plane, wst, wh1, bh1, wh2, bh2, nH, nW, rs, 16, tid);
+  axis_phase<BF16, MT>(plane, wst, ww1, bw1, ww2, bw2, nW, nH, 16, rs, tid);
+  // ---- store the plane -----------------------------------------------------------------------------------------
+  for (int i = tid; i < nH * nW * 4; i += 256) {
+    const int tokn = i >> 2, q = i & 3, h = tokn / nW, w = tokn - h * nW;
+    const float* sp = plane + h * rs + w * 16 + q * 4;
+    *(f32x4*)(gx + (long)tokn * C + q * 4) = f32x4{sp[0], sp[1], sp[2], sp[3]};
+  }
+}
+
 // ---- FiLM tables ------------------------------------------------------------------------------------
 // a[r][c] = 1 + W2s relu(w0s * t[r] + b0s) + b2s ; b[r][c] = W2h relu(w0h * t[r] + b0h) + b2h (+ add[r][c])
 __global__ void film_table_kernel(const float* __restrict__ t, int rows, int C, const float* __restrict__ sc_w0,
@@ -195,6 +373,41 @@ extern "C" int tante_axis_mlp(float* x, int64_t outer, int n, int64_t inner, con
     const long cols = outer * inner;
     hipLaunchKernelGGL(axis_mlp_lds_kernel, dim3((unsigned)((cols + 63) / 64)), dim3(64), lds, s, x, outer, n, inner, w1, b1, w2, b2);
   }
+  TANTE_CHECK_LAUNCH();
+  return 0;
+}
+
+template <bool BF16, int MT>
+static void launch_axis_hw(float* x, long BT, int nH, int nW, int C, const float* wh1, const float* bh1, const float* wh2,
+                           const float* bh2, const float* ww1, const float* bw1, const float* ww2, const float* bw2, size_t lds,
+                           hipStream_t s) {
+  static size_t attr = 0;
+  if (lds > attr) {
+    hipFuncSetAttribute((const void*)axis_hw_kernel<BF16, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr = lds;
+  }
+  hipLaunchKernelGGL((axis_hw_kernel<BF16, MT>), dim3((unsigned)(BT * (C / 16))), dim3(256), lds, s, x, nH, nW, C, wh1, bh1, wh2, bh2,
+                     ww1, bw1, ww2, bw2);
+}
+
+extern "C" int tante_axis_hw(float* x, int64_t BT, int nH, int nW, int C, const float* wh1, const float* bh1, const float* wh2,
+                             const float* bh2, const float* ww1, const float* bw1, const float* ww2, const float* bw2,
+                             int compute, void* stream) {
+  if (!x || !wh1 || !bh1 || !wh2 || !bh2 || !ww1 || !bw1 || !ww2 || !bw2) TANTE_FAIL(-1, "tante_axis_hw: null pointer");
+  if (BT <= 0 || nH <= 0 || nW <= 0 || C <= 0) TANTE_FAIL(-1, "tante_axis_hw: bad shape");
+  const int nmax = nH > nW ? nH : nW;
+  const size_t lds = ((size_t)nH * (nW * 16 + 2) + 2 * (size_t)nmax * nmax + 2 * nmax) * sizeof(float);
+  if (nmax > 64 || C % 16 || lds > 160 * 1024 || ((uintptr_t)x % 16))
+    TANTE_FAIL(-2, "tante_axis_hw: needs nH, nW <= 64, C %% 16 == 0 and the plane to fit LDS (use tante_axis_mlp)");
+  hipStream_t s = (hipStream_t)stream;
+  const int mt = (nmax + 15) / 16;
+#define TANTE_AHW(BF, MTV) launch_axis_hw<BF, MTV>(x, (long)BT, nH, nW, C, wh1, bh1, wh2, bh2, ww1, bw1, ww2, bw2, lds, s)
+  if (compute == TANTE_BF16) {
+    switch (mt) { case 1: TANTE_AHW(true, 1); break; case 2: TANTE_AHW(true, 2); break; case 3: TANTE_AHW(true, 3); break; default: TANTE_AHW(true, 4); }
+  } else {
+    switch (mt) { case 1: TANTE_AHW(false, 1); break; case 2: TANTE_AHW(false, 2); break; case 3: TANTE_AHW(false, 3); break; default: TANTE_AHW(false, 4); }
+  }
+#undef TANTE_AHW
   TANTE_CHECK_LAUNCH();
   return 0;
 }

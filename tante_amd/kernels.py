@@ -194,6 +194,19 @@ def axis_mlp(x: torch.Tensor, outer: int, n: int, inner: int, w1, b1, w2, b2):
     return x
 
 
+def axis_hw_supported(nH: int, nW: int, C_: int) -> bool:
+    n = max(nH, nW)
+    return n <= 64 and C_ % 16 == 0 and (nH * (nW * 16 + 2) + 2 * n * n + 2 * n) * 4 <= 160 * 1024
+
+
+def axis_hw(x: torch.Tensor, BT: int, nH: int, nW: int, C_: int, vp, hp, compute: int):
+    """Fused vertical + horizontal propagators; vp / hp = (w1, b1, w2, b2) of the H / W axis MLPs."""
+    ws = [p.detach() for p in (*vp, *hp)]
+    _dev(x, *ws)
+    L.check(L.lib().tante_axis_hw(_p(x), BT, nH, nW, C_, *[_p(w) for w in ws], compute, _stream()), "tante_axis_hw")
+    return x
+
+
 def film_table(t: torch.Tensor, film_params: Sequence[torch.Tensor], C_: int, add: Optional[torch.Tensor]):
     """film_params = (scale.0.weight, scale.0.bias, scale.2.weight, scale.2.bias, shift.0.weight, ...)."""
     _dev(t, add, *film_params)

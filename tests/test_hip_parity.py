@@ -465,3 +465,24 @@ def test_fused_backbone_strided_letters(dev):
     with torch.no_grad():
         y = bb(x.to(dev))
     close(y, ref, "bf16")
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+@pytest.mark.parametrize("BT,nH,nW,C", [(3, 32, 32, 64), (2, 16, 48, 32), (5, 4, 6, 16), (1, 64, 16, 48), (2, 33, 7, 16), (1, 8, 64, 16)])
+def test_axis_hw_fused(dev, mode, BT, nH, nW, C):
+    """Fused vertical+horizontal propagators (MFMA) against the oracle's two sequential axis MLPs."""
+    from oracle import tante_oracle as O
+    Kk, L = _ops()
+    g = torch.Generator().manual_seed(nH * 100 + nW)
+    x = torch.randn(BT, nH, nW, C, generator=g)
+
+    def mk(n):
+        return {"p.0.weight": torch.randn(n, n, generator=g) / math.sqrt(n), "p.0.bias": 0.3 * torch.randn(n, generator=g),
+                "p.2.weight": torch.randn(n, n, generator=g) / math.sqrt(n), "p.2.bias": 0.3 * torch.randn(n, generator=g)}
+    wh, ww = mk(nH), mk(nW)
+    ref = x + O._axis_mlp(wh, "p", x.permute(0, 2, 3, 1)).permute(0, 3, 1, 2)        # along h
+    ref = ref + O._axis_mlp(ww, "p", ref.permute(0, 1, 3, 2)).permute(0, 1, 3, 2)    # along w
+    xd = x.to(dev)
+    keys = ("p.0.weight", "p.0.bias", "p.2.weight", "p.2.bias")
+    Kk.axis_hw(xd, BT, nH, nW, C, [wh[k].to(dev) for k in keys], [ww[k].to(dev) for k in keys], Kk.COMPUTE[mode])
+    close(xd, ref, mode)

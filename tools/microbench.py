@@ -58,6 +58,8 @@ def main():
             x = torch.randn(B, T, H, W, C, device=dev)
             vp, hp, tp = bb.vertical_propagator, bb.horizontal_propagator, bb.temporal_propagator
             by = 2.0 * x.numel() * 4
+            timeit(lambda: K.axis_hw(x, B * T, H, W, C, (vp[0].weight, vp[0].bias, vp[2].weight, vp[2].bias),
+                                     (hp[0].weight, hp[0].bias, hp[2].weight, hp[2].bias), comp), "axis H+W fused", None, by)
             timeit(lambda: K.axis_mlp(x, B * T, H, W * C, vp[0].weight, vp[0].bias, vp[2].weight, vp[2].bias), "axis H", None, by)
             timeit(lambda: K.axis_mlp(x, B * T * H, W, C, hp[0].weight, hp[0].bias, hp[2].weight, hp[2].bias), "axis W", None, by)
             timeit(lambda: K.axis_mlp(x, B, T, H * W * C, tp[0].weight, tp[0].bias, tp[2].weight, tp[2].bias), "axis T", None, by)
