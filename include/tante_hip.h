@@ -80,7 +80,9 @@ typedef struct TanteGemm {
   int32_t M, K;            /* rows, logical K (<= k_pad) */
   int64_t a_s1, a_s0, a_off; /* LINEAR addressing (elements) */
   int32_t a_n0;
-  int32_t Hin, Win, Cin, P; /* PATCH_*: input image (per img) and patch size; rows = imgs*(Hin/P)*(Win/P) */
+  int32_t Hin, Win, Cin, P; /* PATCH_*: input image (per img) and patch size; rows = imgs*(Hin/P)*(Win/P);
+                             * image i starts at (i / a_n0) * a_s1 + (i % a_n0) * Cin*Hin*Win + a_off  (a sliding
+                             * window over a longer (B, T_total, ...) buffer needs no copy) */
   int32_t ln;               /* 1: normalise each row over K (biased variance, eps) before the product */
   float ln_eps;
   /* packed right operand */
@@ -153,9 +155,10 @@ int tante_gather_last(const float* z, int64_t n, int E, float* out, void* stream
 
 /* Taylor sum (tante.py:165-171): out[b][i-1] = last[b] + sum_k derivs[k][b] * (i * dt)^k / k!,
  * i = 1..n_out.  last = input[:, -1] given as base pointer + batch stride (elements);
- * derivs = n_order device pointers, each (B, frame) contiguous. */
+ * derivs = n_order device pointers, each (B, frame) contiguous; out[b] starts at out + b * out_bstride (elements),
+ * so the prediction can be written straight into the next window of a rollout buffer. */
 int tante_taylor(const float* last, int64_t last_bstride, const float* const* derivs, int n_order, double dt,
-                 int n_out, float* out, int64_t B, int64_t frame, void* stream);
+                 int n_out, float* out, int64_t out_bstride, int64_t B, int64_t frame, void* stream);
 
 /* interprator head reduction (tante.py:194-201): t (B, L) raw per-token scalars ->
  * rt[b] = mean_l clamp(t[b][l], 0, out_T - 1) + ep. */

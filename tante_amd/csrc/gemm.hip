@@ -68,10 +68,12 @@ __device__ __forceinline__ RowInfo row_info(const TanteGemm& g, int row) {
     const int Wo = g.Win / g.P, Ho = g.Hin / g.P;
     const int img = r / (Ho * Wo), rem = r % (Ho * Wo);
     const int ho = rem / Wo, wo = rem % Wo;
+    // images may sit in a sliding window of a longer buffer: a_n0 images per batch item, a_s1 elements between items
+    const long img_off = (long)(img / g.a_n0) * g.a_s1 + (long)(img % g.a_n0) * g.Cin * g.Hin * g.Win + g.a_off;
     if (g.a_mode == TANTE_A_PATCH_NHWC)
-      ri.a_base = (((long)img * g.Hin + (long)ho * g.P) * g.Win + (long)wo * g.P) * g.Cin;
+      ri.a_base = img_off + (((long)ho * g.P) * g.Win + (long)wo * g.P) * g.Cin;
     else
-      ri.a_base = ((long)img * g.Cin * g.Hin + (long)ho * g.P) * g.Win + (long)wo * g.P;
+      ri.a_base = img_off + ((long)ho * g.P) * g.Win + (long)wo * g.P;
   }
   return ri;
 }
@@ -699,6 +701,8 @@ extern "C" int tante_gemm(const TanteGemm* gp, void* stream) {
       if (g.P <= 0 || g.Hin % g.P || g.Win % g.P || g.Cin <= 0) TANTE_FAIL(-1, "tante_gemm: bad patch geometry");
       if (g.K != g.Cin * g.P * g.P) TANTE_FAIL(-1, "tante_gemm: K != Cin*P*P");
       if (g.M % ((g.Hin / g.P) * (g.Win / g.P))) TANTE_FAIL(-1, "tante_gemm: M is not a whole number of images");
+      if (g.a_n0 <= 0) TANTE_FAIL(-1, "tante_gemm: a_n0 (images per batch item) must be > 0");
+      if (g.a_s1 % 4 || g.a_off % 4) TANTE_FAIL(-1, "tante_gemm: image strides must be multiples of 4 elements");
       if (g.a_mode == TANTE_A_PATCH_NHWC && a_ptr_ok && (g.P * g.Cin) % E == 0 && g.Cin % al == 0) flags |= 1;
       break;
     default:

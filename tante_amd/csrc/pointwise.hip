@@ -312,7 +312,7 @@ struct TaylorArgs {
 
 template <int NO>
 __global__ void taylor_kernel(const float* __restrict__ last, long last_bstride, const TaylorArgs ta, int n_out,
-                              float* __restrict__ out, long B, long frame4) {
+                              float* __restrict__ out, long out_bstride, long B, long frame4) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;  // float4 index within (B, frame)
   if (idx >= B * frame4) return;
   const long b = idx / frame4, f = idx - b * frame4;
@@ -326,7 +326,7 @@ __global__ void taylor_kernel(const float* __restrict__ last, long last_bstride,
       f32x4 o = base;
 #pragma unroll
       for (int k = 0; k < NO; ++k) o += dv[k] * ta.coef[i][k];
-      ((f32x4*)out)[(b * n_out + i) * frame4 + f] = o;
+      *(f32x4*)(out + b * out_bstride + ((long)i * frame4 + f) * 4) = o;
     }
   }
 }
@@ -444,10 +444,10 @@ extern "C" int tante_gather_last(const float* z, int64_t n, int E, float* out, v
 }
 
 extern "C" int tante_taylor(const float* last, int64_t last_bstride, const float* const* derivs, int n_order, double dt,
-                            int n_out, float* out, int64_t B, int64_t frame, void* stream) {
+                            int n_out, float* out, int64_t out_bstride, int64_t B, int64_t frame, void* stream) {
   if (!last || !derivs || !out) TANTE_FAIL(-1, "tante_taylor: null pointer");
   if (n_order < 1 || n_order > 8 || n_out < 1 || n_out > 8) TANTE_FAIL(-2, "tante_taylor: order and n_out must be in 1..8");
-  if (frame % 4 || last_bstride % 4 || ((uintptr_t)last % 16) || ((uintptr_t)out % 16))
+  if (frame % 4 || last_bstride % 4 || out_bstride % 4 || ((uintptr_t)last % 16) || ((uintptr_t)out % 16))
     TANTE_FAIL(-2, "tante_taylor: frame size / stride must be multiples of 4 floats, 16-byte aligned");
   TaylorArgs ta;
   for (int k = 0; k < 8; ++k) ta.d[k] = (k < n_order) ? derivs[k] : nullptr;
@@ -465,7 +465,7 @@ extern "C" int tante_taylor(const float* last, int64_t last_bstride, const float
   const dim3 grid((unsigned)((n4 + 255) / 256));
   hipStream_t s = (hipStream_t)stream;
 #define TANTE_TAYLOR(NO) \
-  case NO: hipLaunchKernelGGL(taylor_kernel<NO>, grid, dim3(256), 0, s, last, (long)last_bstride, ta, n_out, out, (long)B, (long)(frame / 4)); break;
+  case NO: hipLaunchKernelGGL(taylor_kernel<NO>, grid, dim3(256), 0, s, last, (long)last_bstride, ta, n_out, out, (long)out_bstride, (long)B, (long)(frame / 4)); break;
   switch (n_order) {
     TANTE_TAYLOR(1) TANTE_TAYLOR(2) TANTE_TAYLOR(3) TANTE_TAYLOR(4)
     TANTE_TAYLOR(5) TANTE_TAYLOR(6) TANTE_TAYLOR(7) TANTE_TAYLOR(8)

@@ -112,14 +112,20 @@ def linear(a: torch.Tensor, pw: PackedWeight, out: torch.Tensor, *, M: Optional[
 
 
 def patch_embed(a: torch.Tensor, pw: PackedWeight, out: torch.Tensor, *, n_img: int, Hin: int, Win: int, Cin: int, P: int,
-                nchw: bool, act: int, film: Optional[tuple] = None):
+                nchw: bool, act: int, film: Optional[tuple] = None, imgs_per_item: Optional[int] = None, item_stride: int = 0,
+                elem_off: int = 0):
     """Patch conv with kernel = stride = P as a GEMM over non-overlapping patches.  `a` is
     (n_img, Cin, Hin, Win) when nchw else (n_img, Hin, Win, Cin); out is channels-last
     (n_img, Hin/P, Win/P, N).  film = (film_a, film_b, s_emb, T, HW) selects the FiLM + positional epilogue."""
     M = n_img * (Hin // P) * (Win // P)
-    g = _base(pw, a, M, out, act)
+    if not a.is_cuda:
+        raise RuntimeError("tante_amd kernels need CUDA/HIP tensors (no CPU fallback)")
+    g = _base(pw, a if a.is_contiguous() else a.new_empty(0), M, out, act)
+    g.a = a.data_ptr()        # may be a strided window view: addressing is explicit below
     g.a_mode = L.A_PATCH_NCHW if nchw else L.A_PATCH_NHWC
     g.Hin, g.Win, g.Cin, g.P = Hin, Win, Cin, P
+    g.a_n0 = n_img if imgs_per_item is None else imgs_per_item
+    g.a_s1, g.a_off = item_stride, elem_off
     g.out_ld = pw.N
     if film is None:
         g.e_mode = L.E_LINEAR
@@ -226,11 +232,15 @@ def film_apply(x: torch.Tensor, x_elem_off: int, x_bstride: int, y: torch.Tensor
 
 
 def taylor(last: torch.Tensor, last_elem_off: int, last_bstride: int, derivs: Sequence[torch.Tensor], dt: float, n_out: int,
-           out: torch.Tensor, B: int, frame: int):
-    _dev(last, out, *derivs)
+           out: torch.Tensor, B: int, frame: int, out_elem_off: int = 0, out_bstride: Optional[int] = None):
+    """`last` / `out` are base tensors addressed by (element offset, batch stride): they may be views into a rollout buffer."""
+    if not (last.is_cuda and out.is_cuda):
+        raise RuntimeError("tante_amd kernels need CUDA/HIP tensors (no CPU fallback)")
+    _dev(*derivs)
     arr = (C.c_void_p * len(derivs))(*[d.data_ptr() for d in derivs])
     L.check(L.lib().tante_taylor(last.data_ptr() + 4 * last_elem_off, last_bstride, arr, len(derivs), float(dt), n_out,
-                                 _p(out), B, frame, _stream()), "tante_taylor")
+                                 out.data_ptr() + 4 * out_elem_off, n_out * frame if out_bstride is None else out_bstride, B, frame,
+                                 _stream()), "tante_taylor")
     return out
 
 

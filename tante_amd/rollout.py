@@ -37,11 +37,29 @@ class DefaultChannelsLastFormatter:
         return output
 
 
+def _rollout_in_place(model, x: torch.Tensor, n_steps: int) -> torch.Tensor:
+    """The reference's loop without its copies: one (B, T + frames, D, H, W) buffer holds the input window and every
+    predicted frame; each model call reads its window in place (strided view) and writes its prediction into the next
+    slots, so `torch.cat([moving[:, k:], y])` and the per-step output concatenation disappear."""
+    B, T = x.shape[:2]
+    ol = model.output_length
+    n_calls = -(-n_steps // ol)
+    buf = torch.empty(B, T + n_calls * ol, *x.shape[2:], dtype=torch.float32, device=x.device)
+    buf[:, :T].copy_(x)           # the formatter's 'b t h w c -> b t c h w' is materialised here, once
+    for s in range(n_calls):
+        model(buf[:, s * ol: s * ol + T], out=buf[:, T + s * ol: T + (s + 1) * ol])
+    return buf[:, T: T + n_steps]
+
+
 def rollout_model(model, batch: Dict, formatter, n_steps: int, device=None):
     """Sliding-window re-feed until n_steps frames exist; returns (y_pred channels-last [:, :n_steps], y_ref)."""
     device = device or next(model.parameters()).device
     moving, y_ref = formatter.process_input(batch)
     moving = moving[0].to(device)
+    from .tante import TANTE
+    if isinstance(model, TANTE) and model.deg and not torch.is_grad_enabled() and moving.shape[1] == model.T \
+            and moving.dtype == torch.float32:
+        return formatter.process_output(_rollout_in_place(model, moving, n_steps)), y_ref.to(device)
     preds, produced = [], 0
     while produced < n_steps:
         y = model(moving)

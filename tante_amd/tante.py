@@ -104,9 +104,10 @@ class enc_CNN(nn.Module):
             return out
         return self._cache.get(compute, params, build)
 
-    def forward_tokens(self, inp: torch.Tensor, compute: int, film: Optional[tuple]) -> torch.Tensor:
-        """inp (B,T,D,H,W) fp32 contiguous -> tokens (B*T*Hp*Wp, C) fp32; `film` = (a, b, s_emb, T, HW) is
-        applied in the last stage's epilogue (None: plain encoder output)."""
+    def forward_tokens(self, inp: torch.Tensor, compute: int, film: Optional[tuple], item_stride: Optional[int] = None) -> torch.Tensor:
+        """inp (B,T,D,H,W) fp32 -> tokens (B*T*Hp*Wp, C) fp32; `film` = (a, b, s_emb, T, HW) is applied in the
+        last stage's epilogue (None: plain encoder output).  inp may be a window view of a longer rollout buffer:
+        frames contiguous, `item_stride` elements between batch items."""
         B, T, D, H, W = inp.shape
         if (H, W) != (self.H, self.W) or D != self.chans[0]:
             raise ValueError(f"encoder built for {self.chans[0]} fields at {(self.H, self.W)}, got {tuple(inp.shape)}")
@@ -119,7 +120,8 @@ class enc_CNN(nn.Module):
             last = i == 2
             out = torch.empty(n_img * (h // p) * (w // p), co, dtype=torch.float32 if last else adt, device=inp.device)
             K.patch_embed(x, pk[i], out, n_img=n_img, Hin=h, Win=w, Cin=ci, P=p, nchw=(i == 0),
-                          act=L.ACT_NONE if last else L.ACT_GELU_ERF, film=film if last else None)
+                          act=L.ACT_NONE if last else L.ACT_GELU_ERF, film=film if last else None,
+                          imgs_per_item=T if i == 0 else None, item_stride=(item_stride or T * D * H * W) if i == 0 else 0)
             x, h, w = out, h // p, w // p
         return x
 
@@ -349,19 +351,25 @@ class TANTE(nn.Module):
         return self._film_cache.get(0, params, lambda: te.tables(self.t_seq.to(self.t_emb.device, torch.float32).contiguous(),
                                                                  self.t_emb.view(self.T, self.C)))
 
-    def forward(self, input: torch.Tensor, out_T=1):
+    def forward(self, input: torch.Tensor, out_T=1, out: Optional[torch.Tensor] = None):
+        """`out` (optional, deg=True only): a (B, output_length, D, H, W) fp32 view with contiguous frames (e.g. the next
+        slots of a rollout buffer) that receives the prediction instead of a fresh tensor."""
         _no_autograd(self)
         if not input.is_cuda:
             raise RuntimeError("tante_amd.TANTE runs on the GPU only (no CPU fallback); move the input to cuda")
         if input.shape[1] != self.T:
             input = input[:, -self.T:]
-        inp = input.detach().to(torch.float32).contiguous()
+        inp = input.detach().to(torch.float32)
         B, T, D, H, W = inp.shape
+        frame = D * H * W
+        if inp.stride()[1:] != (frame, H * W, W, 1) or inp.stride(0) % 4 or inp.data_ptr() % 16:
+            inp = inp.contiguous()      # only a (B, T_total, D, H, W) time window is read in place
+        bstride = inp.stride(0)
         compute = resolve_compute(self.compute)
         Hp, Wp, C_ = self.H_p, self.W_p, self.C
         HW = Hp * Wp
         fa, fb = self._time_tables()
-        x = self.encoder.forward_tokens(inp, compute, (fa, fb, self.s_emb.view(HW, C_), T, HW))     # tante.py:132-141
+        x = self.encoder.forward_tokens(inp, compute, (fa, fb, self.s_emb.view(HW, C_), T, HW), bstride)   # tante.py:132-141
         last_slot = dict(a_n0=HW, a_s1=T * HW * C_, a_s0=C_, a_off=(T - 1) * HW * C_)               # x[:, -1:] by stride
         derivs, r_t = [], []
         for i in range(self.taylor_order):
@@ -382,10 +390,17 @@ class TANTE(nn.Module):
         else:
             R_t = torch.stack(r_t, dim=1).mean(dim=1)
             n_out = math.floor(float(R_t[0]))         # l.163: sample 0 decides for the batch (host sync, as in the reference)
-        frame = D * H * W
+        if out is not None:
+            if not self.deg:
+                raise ValueError("out= is only meaningful with a fixed output length (deg=True)")
+            if tuple(out.shape) != (B, n_out, D, H, W) or out.dtype != torch.float32 or not out.is_cuda \
+                    or out.stride()[1:] != (frame, H * W, W, 1) or out.stride(0) % 4 or out.data_ptr() % 16:
+                raise ValueError("out must be a (B, output_length, D, H, W) fp32 CUDA view with contiguous frames")
         if n_out < 1:
             out = torch.empty(B, 0, D, H, W, dtype=torch.float32, device=x.device)
         else:
-            out = torch.empty(B, n_out, D, H, W, dtype=torch.float32, device=x.device)
-            K.taylor(inp, (T - 1) * frame, T * frame, derivs, self.frame_interval, n_out, out, B, frame)   # l.165-171
+            if out is None:
+                out = torch.empty(B, n_out, D, H, W, dtype=torch.float32, device=x.device)
+            K.taylor(inp, (T - 1) * frame, bstride, derivs, self.frame_interval, n_out, out, B, frame,
+                     out_bstride=out.stride(0))                                                     # l.165-171
         return out if self.deg else (out, R_t)
