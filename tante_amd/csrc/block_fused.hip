@@ -26,6 +26,7 @@
 #include "common.cuh"
 
 #include <utility>
+#include <stdlib.h>
 
 namespace {
 
@@ -346,6 +347,243 @@ __global__ __launch_bounds__(256, 1) void fused_block_kernel(float* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------------
+// Same block, 16 tokens per wave, 8 waves per workgroup (two waves per SIMD).
+//
+// The 32-token-per-wave kernel above needs the whole 512-entry register file per wave, i.e. one wave per SIMD:
+// with nothing to switch to, every LDS / LDS-DMA latency and every non-MFMA instruction is exposed (measured:
+// MFMA busy 18 % of wave cycles, 44 % parked in waits).  Here a wave owns 16 tokens (residual 64 regs, fragments
+// 32 + 32), fits 256 registers, and two waves share each SIMD.  A 32-long sequence then spans a PAIR of waves
+// (2p, 2p+1: positions 0-15 / 16-31); per head the pair swaps its K fragments and packed V^T halves through a
+// 2 KiB-per-wave LDS mailbox.  The attention of head h-1 runs after the projections of head h, so the mailbox
+// written in iteration h-1 is covered by the tile barrier that is there anyway (no extra barrier per head).
+// Sequences with L | 16 stay inside one wave (16/L per wave) and use no mailbox.
+// ------------------------------------------------------------------------------------------------------
+template <int CB>
+__device__ __forceinline__ void norm_frags16(const f32x4 (&res)[2 * CB], bool live, int C, float eps, u32x4 (&xn)[CB]) {
+  float s = 0.0f;
+#pragma unroll
+  for (int g = 0; g < 2 * CB; ++g) s += res[g][0] + res[g][1] + res[g][2] + res[g][3];
+  s += __shfl_xor(s, 16);
+  s += __shfl_xor(s, 32);
+  const float mean = s / (float)C;
+  float q = 0.0f;
+#pragma unroll
+  for (int g = 0; g < 2 * CB; ++g)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float d = res[g][j] - mean;
+      q += d * d;
+    }
+  q += __shfl_xor(q, 16);
+  q += __shfl_xor(q, 32);
+  const float rstd = live ? rsqrtf(q / (float)C + eps) : 0.0f;
+#pragma unroll
+  for (int b = 0; b < CB; ++b) xn[b] = pack8((res[2 * b] - mean) * rstd, (res[2 * b + 1] - mean) * rstd);
+}
+
+// LDS-DMA copy by a 512-thread workgroup (8 waves x 1 KiB per pass)
+__device__ __forceinline__ void glds_copy8(const char* __restrict__ g, char* l, int bytes, int tid) {
+  const int wave = tid >> 6, lane = tid & 63;
+  for (int off = wave * 1024; off < bytes; off += 8192) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + off + lane * 16),
+                                     (__attribute__((address_space(3))) void*)(l + off), 16, 0, 0);
+  }
+}
+
+template <int CB, int HB>
+__global__ __launch_bounds__(512, 2) void fused_block16_kernel(float* __restrict__ x, const char* __restrict__ stream, TanteSeq sq,
+                                                              int causal, float eps) {
+  constexpr int C = CB * 32, HID = HB * 32, NH = CB;
+  constexpr int CPR = CB * 4, CPRH = HB * 4;
+  constexpr int TO = C / 64, T1 = HID / 64;
+  constexpr int TILEH = 96 * CPR * 16 + BIAS_BYTES, TILEO = 64 * CPR * 16 + BIAS_BYTES, TILE2 = 64 * CPRH * 16 + BIAS_BYTES;
+  constexpr int SLOT = (TILEH > TILE2 ? TILEH : TILE2);
+  constexpr int NT = NH + TO + T1 + TO;
+  constexpr int MAXB = (HB > CB ? HB : CB);
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 weight slots, then 2 mailbox sets of 8 x 2 KiB
+  char* mbox = smem + 2 * SLOT;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kk = lane >> 4, l15 = lane & 15;
+  auto tile_bytes = [](int u) constexpr { return u < NH ? TILEH : (u < NH + TO + T1 ? TILEO : TILE2); };
+  auto tile_off = [](int u) constexpr {
+    long o = 0;
+    for (int i = 0; i < u; ++i) o += (i < NH ? TILEH : (i < NH + TO + T1 ? TILEO : TILE2));
+    return o;
+  };
+  glds_copy8(stream, smem, TILEH, tid);  // tile 0 in flight while the tokens load
+
+  const int L = sq.L;
+  const bool paired = (L == 32);
+  const int half = wave & 1;  // paired: which 16 positions of the sequence this wave holds
+  int seq, pos;
+  if (paired) {
+    seq = blockIdx.x * 4 + (wave >> 1);
+    pos = half * 16 + l15;
+  } else {
+    const int spw = 16 / L, sl = l15 / L;
+    seq = (blockIdx.x * 8 + wave) * spw + sl;
+    pos = l15 - sl * L;
+  }
+  const bool live = seq < sq.nseq;
+  const long tok = live ? seq_token(sq, seq, pos) * C : 0;
+  f32x4 res[2 * CB];
+#pragma unroll
+  for (int g = 0; g < 2 * CB; ++g) res[g] = *(const f32x4*)(x + tok + 16 * g + 4 * kk);
+
+  // which keys (own wave: slot 4*kk+r; partner wave: its slot 4*kk+r) the query of this lane may see
+  unsigned allow_own = 0u, allow_par = 0u;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int j = kk * 4 + r;
+    bool ok_o, ok_p = false;
+    if (paired) {
+      ok_o = live && (!causal || j <= l15);
+      ok_p = live && (!causal || half == 1);  // the partner holds the other half of the same sequence
+    } else {
+      const int sj = j / L, pj = j - sj * L, si = l15 / L;
+      const bool live_j = ((int)(blockIdx.x * 8 + wave) * (16 / L) + sj) < sq.nseq;
+      ok_o = (sj == si) && (!causal || pj <= pos) && live_j;
+    }
+    allow_own |= (ok_o ? 1u : 0u) << r;
+    allow_par |= (ok_p ? 1u : 0u) << r;
+  }
+
+  int xo_c[CB], xo_h[HB];
+#pragma unroll
+  for (int kb = 0; kb < CB; ++kb) xo_c[kb] = swz_chunk(l15, kb * 4 + kk, CPR) << 4;
+#pragma unroll
+  for (int kb = 0; kb < HB; ++kb) xo_h[kb] = swz_chunk(l15, kb * 4 + kk, CPRH) << 4;
+  const int row_c = l15 * CPR * 16, row_h = l15 * CPRH * 16;
+
+  u32x4 xn[CB];
+  norm_frags16<CB>(res, live, C, eps, xn);
+  u32x4 of[MAXB];
+  u32x4 qf_p, kf_p, vpk_p;  // head h-1: this wave's q / k fragments and packed V^T halves ({dt0.xy, dt1.xy})
+  qf_p = kf_p = vpk_p = u32x4{0u, 0u, 0u, 0u};
+
+  // attention of head h for this wave's 16 queries; keys/values: own 16 tokens (+ the partner's 16 when paired)
+  auto attend = [&](int h) {
+    u32x4 kf_o = kf_p, vpk_o = vpk_p, kf_q = u32x4{0u, 0u, 0u, 0u}, vpk_q = u32x4{0u, 0u, 0u, 0u};
+    if (paired) {
+      const char* pb = mbox + (h & 1) * 16384 + (wave ^ 1) * 2048 + lane * 16;
+      kf_q = *(const u32x4*)pb;
+      vpk_q = *(const u32x4*)(pb + 1024);
+    }
+    f32x4 so = mfma_bf16(kf_o, qf_p, f32x4{0.f, 0.f, 0.f, 0.f});  // rows = own keys, column = query
+    f32x4 sp = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (paired) sp = mfma_bf16(kf_q, qf_p, sp);
+    float m = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if ((allow_own >> r) & 1u) m = fmaxf(m, so[r]);
+      if ((allow_par >> r) & 1u) m = fmaxf(m, sp[r]);
+    }
+    m = fmaxf(m, __shfl_xor(m, 16));
+    m = fmaxf(m, __shfl_xor(m, 32));
+    float sum = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      so[r] = ((allow_own >> r) & 1u) ? __expf(so[r] - m) : 0.0f;
+      sp[r] = ((allow_par >> r) & 1u) ? __expf(sp[r] - m) : 0.0f;
+      sum += so[r] + sp[r];
+    }
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+    const float inv = sum > 0.0f ? __builtin_amdgcn_rcpf(sum) : 0.0f;
+    const u32x4 pf = pack8(so * inv, sp * inv);  // k order: own keys then partner keys -- the same order as vt below
+    const u32x4 vt0 = u32x4{vpk_o[0], vpk_o[1], vpk_q[0], vpk_q[1]}, vt1 = u32x4{vpk_o[2], vpk_o[3], vpk_q[2], vpk_q[3]};
+    const f32x4 o0 = mfma_bf16(vt0, pf, f32x4{0.f, 0.f, 0.f, 0.f});  // O^T = V^T P^T
+    const f32x4 o1 = mfma_bf16(vt1, pf, f32x4{0.f, 0.f, 0.f, 0.f});
+    return pack8(o0, o1);
+  };
+
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  static_for<NT>([&](auto t_c) {
+    constexpr int t = decltype(t_c)::value;
+    if constexpr (t + 1 < NT) glds_copy8(stream + tile_off(t + 1), smem + ((t + 1) & 1) * SLOT, tile_bytes(t + 1), tid);
+    const char* wt = smem + (t & 1) * SLOT;
+    if constexpr (t < NH) {
+      // =============================== projections of head t, attention of head t-1 ======================
+      const float* bias = (const float*)(wt + 96 * CPR * 16);
+      f32x4 aqk[4];
+#pragma unroll
+      for (int ns = 0; ns < 4; ++ns) aqk[ns] = *(const f32x4*)(bias + ns * 16 + kk * 4);  // start from the bias
+#pragma unroll
+      for (int ns = 0; ns < 4; ++ns)
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) {
+          const u32x4 wf = *(const u32x4*)(wt + ns * 16 * CPR * 16 + row_c + xo_c[cb]);
+          aqk[ns] = mfma_bf16(wf, xn[cb], aqk[ns]);
+        }
+      f32x4 av[2];
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        const float bv = bias[64 + dt * 16 + l15];
+        av[dt] = f32x4{bv, bv, bv, bv};
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) {
+          const u32x4 wf = *(const u32x4*)(wt + (64 + dt * 16) * CPR * 16 + row_c + xo_c[cb]);
+          av[dt] = mfma_bf16(xn[cb], wf, av[dt]);  // roles swapped: D[token][feature]
+        }
+      }
+      const u32x4 qf_n = pack8(aqk[0], aqk[1]), kf_n = pack8(aqk[2], aqk[3]);
+      u32x4 vpk_n;
+      vpk_n[0] = pack_bf16x2(av[0][0], av[0][1]); vpk_n[1] = pack_bf16x2(av[0][2], av[0][3]);
+      vpk_n[2] = pack_bf16x2(av[1][0], av[1][1]); vpk_n[3] = pack_bf16x2(av[1][2], av[1][3]);
+      if (paired) {  // publish this head's keys / values for the partner wave (read after this iteration's barrier)
+        char* mb = mbox + (t & 1) * 16384 + wave * 2048 + lane * 16;
+        *(u32x4*)mb = kf_n;
+        *(u32x4*)(mb + 1024) = vpk_n;
+      }
+      if constexpr (t > 0) of[t - 1] = attend(t - 1);
+      qf_p = qf_n; kf_p = kf_n; vpk_p = vpk_n;
+    } else {
+      if constexpr (t == NH) of[NH - 1] = attend(NH - 1);
+      // =============================== 64 output features of a dense layer ==============================
+      constexpr bool is_out = t < NH + TO, is_fc1 = !is_out && t < NH + TO + T1;
+      constexpr int KB = is_fc1 ? CB : (is_out ? CB : HB);
+      constexpr int cpr = KB * 4;
+      const float* bias = (const float*)(wt + 64 * cpr * 16);
+      constexpr int tb = is_fc1 ? t - NH - TO : (is_out ? t - NH : t - NH - TO - T1);
+      f32x4 acc[4];
+#pragma unroll
+      for (int ns = 0; ns < 4; ++ns) {
+        const f32x4 b = *(const f32x4*)(bias + ns * 16 + kk * 4);
+        if constexpr (is_fc1) acc[ns] = b;
+        else acc[ns] = res[4 * tb + ns] + b;  // the residual rides the accumulator
+      }
+#pragma unroll
+      for (int ns = 0; ns < 4; ++ns)
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+          const u32x4 wf = *(const u32x4*)(wt + ns * 16 * cpr * 16 + ((KB == CB) ? row_c + xo_c[kb < CB ? kb : 0] : row_h + xo_h[kb < HB ? kb : 0]));
+          if constexpr (is_fc1) acc[ns] = mfma_bf16(wf, xn[kb < CB ? kb : 0], acc[ns]);
+          else acc[ns] = mfma_bf16(wf, of[kb], acc[ns]);
+        }
+      if constexpr (is_fc1) {
+#pragma unroll
+        for (int ns = 0; ns < 4; ++ns)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[ns][j] = gelu_tanh_fast(acc[ns][j]);
+        of[2 * tb] = pack8(acc[0], acc[1]);
+        of[2 * tb + 1] = pack8(acc[2], acc[3]);
+      } else {
+#pragma unroll
+        for (int ns = 0; ns < 4; ++ns) res[4 * tb + ns] = acc[ns];
+        if constexpr (is_out && tb == TO - 1) norm_frags16<CB>(res, live, C, eps, xn);  // x1 complete: LayerNorm2
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  });
+  if (live) {
+#pragma unroll
+    for (int g = 0; g < 2 * CB; ++g) *(f32x4*)(x + tok + 16 * g + 4 * kk) = res[g];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
 // Stream packing.  One thread per 16-byte chunk (8 bf16) of one tile row, or per bias float.
 // ------------------------------------------------------------------------------------------------------
 // position p inside a 32-block of a k-permuted row holds source feature c:  p = 8*kk + 4*dt + r
@@ -433,7 +671,23 @@ __global__ void pack_block_stream_kernel(const float* __restrict__ w_in, const f
 }
 
 template <int CB, int HB>
+void launch_block16(float* x, const char* stream, const TanteSeq& sq, int causal, float eps, hipStream_t s) {
+  constexpr int TH = 96 * CB * 4 * 16 + BIAS_BYTES, T2 = 64 * HB * 4 * 16 + BIAS_BYTES;
+  constexpr int SLOT = TH > T2 ? TH : T2;
+  constexpr int LDS = 2 * SLOT + 2 * 16384;
+  const int per_wg = sq.L == 32 ? 4 : 8 * (16 / sq.L);  // sequences per workgroup
+  static bool set = false;
+  if (!set) {
+    hipFuncSetAttribute((const void*)fused_block16_kernel<CB, HB>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    set = true;
+  }
+  hipLaunchKernelGGL((fused_block16_kernel<CB, HB>), dim3((sq.nseq + per_wg - 1) / per_wg), dim3(512), LDS, s, x, stream, sq, causal, eps);
+}
+
+template <int CB, int HB>
 void launch_block(float* x, const char* stream, const TanteSeq& sq, int causal, float eps, hipStream_t s) {
+  static const int which = getenv("TANTE_BLOCK_KERNEL") ? atoi(getenv("TANTE_BLOCK_KERNEL")) : 16;
+  if (which == 16 && (sq.L == 32 || 16 % sq.L == 0)) return launch_block16<CB, HB>(x, stream, sq, causal, eps, s);
   constexpr int TH = 96 * CB * 4 * 16 + BIAS_BYTES, T2 = 64 * HB * 4 * 16 + BIAS_BYTES;
   constexpr int SLOT = TH > T2 ? TH : T2;
   const int spw = 32 / sq.L;
