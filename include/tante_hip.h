@@ -181,6 +181,25 @@ int tante_pack_block(const float* ln1_w, const float* ln1_b, const float* in_w, 
 int tante_block_fused(float* x, const void* block_stream, int C, int n_head, int hidden, const TanteSeq* seq, int causal,
                       float eps, void* stream);
 
+/* ---- losses / metrics / optimiser step of the harness ------------------------------------------------
+ * pred is addressed as pred[b*pb + t*pt + s*ps + c*pc] (so the channels-first rollout buffer needs no permute copy),
+ * ref and grad are contiguous channels-last (B, T, HW, C).
+ * tante_metric_sums: sums[(b*T + t)*C + c][0..2] = { sum_s (pred-ref)^2, sum_s ref^2, sum_s ref } -- every metric of
+ *   trainer/metrics.py (MSE l.53-60, NMSE l.82-98, L2RE l.100-111, NNMSE l.114-130, VRMSE l.158-164) is a closed form of them.
+ * tante_mse_grad: grad = scale * (pred - ref), the gradient of  MSE(...).mean()  with scale = 2 / (B*T*HW*C)  (trainer.py:189). */
+int tante_metric_sums(const float* pred, int64_t pb, int64_t pt, int64_t ps, int64_t pc, const float* ref, int B, int T, int64_t HW,
+                      int C, float* sums, void* stream);
+int tante_mse_grad(const float* pred, int64_t pb, int64_t pt, int64_t ps, int64_t pc, const float* ref, int B, int T, int64_t HW,
+                   int C, float scale, float* grad, void* stream);
+/* out (one double) = sum g[i]^2 over a flat fp32 gradient bucket: the square of clip_grad_norm_'s total norm (trainer.py:193). */
+int tante_sumsq(const float* g, int64_t n, double* out, void* stream);
+/* Fused clip + AdamW over flat fp32 buckets (params, exp_avg, exp_avg_sq, grads), torch.optim.AdamW semantics
+ * (decoupled decay, bias correction with `step` counted from 1).  g is first multiplied by grad_scale (1/world for a
+ * summed all-reduce) and, if max_norm > 0, by min(1, max_norm / (sqrt(*sumsq) * grad_scale + 1e-6)) -- computed on the
+ * device, so the train step has no host synchronisation. */
+int tante_adamw_step(float* p, float* m, float* v, const float* g, int64_t n, const double* sumsq, float max_norm, float lr,
+                     float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream);
+
 const char* tante_last_error(void);
 int tante_abi_version(void);
 

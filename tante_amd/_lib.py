@@ -53,6 +53,10 @@ SIGNATURES = {
     "tante_block_stream_bytes": ([c_i32, c_i32], c_i64),
     "tante_pack_block": ([c_vp] * 12 + [c_i32, c_i32, c_vp, c_vp], c_i32),
     "tante_block_fused": ([c_vp, c_vp, c_i32, c_i32, c_i32, C.POINTER(Seq), c_i32, c_f32, c_vp], c_i32),
+    "tante_metric_sums": ([c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_i32, c_i32, c_i64, c_i32, c_vp, c_vp], c_i32),
+    "tante_mse_grad": ([c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_i32, c_i32, c_i64, c_i32, c_f32, c_vp, c_vp], c_i32),
+    "tante_sumsq": ([c_vp, c_i64, c_vp, c_vp], c_i32),
+    "tante_adamw_step": ([c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_f32, c_f32, c_f32, c_f32, c_f32, c_f32, c_i32, c_f32, c_vp], c_i32),
     "tante_last_error": ([], C.c_char_p),
     "tante_abi_version": ([], c_i32),
 }

@@ -45,6 +45,14 @@ def _no_autograd(module: nn.Module):
             "inference_mode (rollout path).")
 
 
+_WEIGHT_EPOCH = [0]
+
+
+def bump_weight_epoch():
+    """Called by optimisers that update parameters through raw pointers (optim.FlatAdamW): invalidates every packed copy."""
+    _WEIGHT_EPOCH[0] += 1
+
+
 class _PackCache:
     """Packed (bf16 / fp32, swizzled, LayerNorm-folded) copies of a module's weights, rebuilt when any
     source parameter changed (optimizer step, load_state_dict, .to())."""
@@ -53,7 +61,7 @@ class _PackCache:
         self._store = {}
 
     def get(self, compute: int, params, build):
-        key = tuple((p.data_ptr(), p._version) for p in params)
+        key = (_WEIGHT_EPOCH[0],) + tuple((p.data_ptr(), p._version) for p in params)
         hit = self._store.get(compute)
         if hit is None or hit[0] != key:
             hit = (key, build())

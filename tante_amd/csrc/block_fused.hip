@@ -392,7 +392,7 @@ __device__ __forceinline__ void glds_copy8(const char* __restrict__ g, char* l, 
 
 template <int CB, int HB>
 __global__ __launch_bounds__(512, 2) void fused_block16_kernel(float* __restrict__ x, const char* __restrict__ stream, TanteSeq sq,
-                                                              int causal, float eps) {
+                                                              int causal, float eps, int dbg) {
   constexpr int C = CB * 32, HID = HB * 32, NH = CB;
   constexpr int CPR = CB * 4, CPRH = HB * 4;
   constexpr int TO = C / 64, T1 = HID / 64;
@@ -501,9 +501,10 @@ __global__ __launch_bounds__(512, 2) void fused_block16_kernel(float* __restrict
 
   static_for<NT>([&](auto t_c) {
     constexpr int t = decltype(t_c)::value;
-    if constexpr (t + 1 < NT) glds_copy8(stream + tile_off(t + 1), smem + ((t + 1) & 1) * SLOT, tile_bytes(t + 1), tid);
+    if constexpr (t + 1 < NT) { if (dbg != 2) glds_copy8(stream + tile_off(t + 1), smem + ((t + 1) & 1) * SLOT, tile_bytes(t + 1), tid); }
     const char* wt = smem + (t & 1) * SLOT;
-    if constexpr (t < NH) {
+    if (dbg == 1) {  // ablation: weight stream only
+    } else if constexpr (t < NH) {
       // =============================== projections of head t, attention of head t-1 ======================
       const float* bias = (const float*)(wt + 96 * CPR * 16);
       f32x4 aqk[4];
@@ -681,7 +682,8 @@ void launch_block16(float* x, const char* stream, const TanteSeq& sq, int causal
     hipFuncSetAttribute((const void*)fused_block16_kernel<CB, HB>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     set = true;
   }
-  hipLaunchKernelGGL((fused_block16_kernel<CB, HB>), dim3((sq.nseq + per_wg - 1) / per_wg), dim3(512), LDS, s, x, stream, sq, causal, eps);
+  static const int dbg = getenv("TANTE_BLOCK_DEBUG") ? atoi(getenv("TANTE_BLOCK_DEBUG")) : 0;  // timing ablations only
+  hipLaunchKernelGGL((fused_block16_kernel<CB, HB>), dim3((sq.nseq + per_wg - 1) / per_wg), dim3(512), LDS, s, x, stream, sq, causal, eps, dbg);
 }
 
 template <int CB, int HB>

@@ -1,0 +1,152 @@
+// Loss / metric reductions and the optimiser step of the TANTE train / eval harness.
+//   tante_metric_sums     one pass over (pred, ref) -> per (b, t, c) sums over the spatial axes; every metric of
+//                         trainer/metrics.py (MSE, NMSE, NNMSE, L2RE, RMSE, NRMSE, VMSE, VRMSE) is a closed form of them
+//   tante_mse_grad        d mean(MSE) / d pred  (trainer/trainer.py:189: loss = MSE(y_pred, y_ref).mean())
+//   tante_sumsq           sum of squares of a flat fp32 bucket (the global gradient norm of clip_grad_norm_, trainer.py:193)
+//   tante_adamw_step      clip-scale + AdamW update over the flat parameter bucket (torch.optim.AdamW, configs/tante.yaml:38-41)
+#include "common.cuh"
+
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// pred / ref: (B, T, HW, C) channels-last; pred may be a strided view: element (b,t,s,c) at b*pb + t*pt + s*ps + c*pc.
+// One workgroup per (b, t, spatial chunk): lanes own channels (c = lane % C when C <= 64 ...) -- generic: thread i
+// walks elements i, i+256, ... of its chunk so that consecutive lanes read consecutive (s, c) of the contiguous ref.
+// sums[(b*T + t)*C + c][0..2] += { sum (x-y)^2, sum y^2, sum y }  (fp32 atomics; tiny output)
+__global__ __launch_bounds__(256) void metric_sums_kernel(const float* __restrict__ pred, long pb, long pt, long ps, long pc,
+                                                          const float* __restrict__ ref, int T, long HW, int C, long chunk,
+                                                          float* __restrict__ sums) {
+  extern __shared__ float acc[];  // [C][3]
+  const long bt = blockIdx.y;
+  const long b = bt / T, t = bt - b * T;
+  for (int i = threadIdx.x; i < 3 * C; i += 256) acc[i] = 0.0f;
+  __syncthreads();
+  const long s0 = (long)blockIdx.x * chunk, s1 = min(HW, s0 + chunk);
+  const float* rp = ref + (bt * HW) * C;
+  const float* pp = pred + b * pb + t * pt;
+  // element index e in [s0*C, s1*C): s = e / C, c = e % C; 256 threads stride by 256 elements; if 256 % C == 0 a thread
+  // always sees the same channel and can keep its partial sums in registers
+  const bool fixed_c = (256 % C) == 0;
+  if (fixed_c) {
+    const int c = threadIdx.x % C;
+    float d2 = 0.f, y2 = 0.f, y1 = 0.f;
+    for (long e = s0 * C + threadIdx.x; e < s1 * C; e += 256) {
+      const long s = e / C;
+      const float y = rp[e], xv = pp[s * ps + (long)c * pc];
+      const float d = xv - y;
+      d2 += d * d; y2 += y * y; y1 += y;
+    }
+    atomicAdd(&acc[3 * c], d2); atomicAdd(&acc[3 * c + 1], y2); atomicAdd(&acc[3 * c + 2], y1);
+  } else {
+    for (long e = s0 * C + threadIdx.x; e < s1 * C; e += 256) {
+      const long s = e / C;
+      const int c = (int)(e - s * C);
+      const float y = rp[e], xv = pp[s * ps + (long)c * pc];
+      const float d = xv - y;
+      atomicAdd(&acc[3 * c], d * d); atomicAdd(&acc[3 * c + 1], y * y); atomicAdd(&acc[3 * c + 2], y);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 3 * C; i += 256) atomicAdd(&sums[bt * C * 3 + i], acc[i]);
+}
+
+// grad[b,t,s,c] (contiguous channels-last) = scale * (pred - ref)
+__global__ void mse_grad_kernel(const float* __restrict__ pred, long pb, long pt, long ps, long pc, const float* __restrict__ ref,
+                                int T, long HW, int C, float scale, float* __restrict__ grad, long n) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  const int c = (int)(e % C);
+  const long r = e / C, s = r % HW, bt = r / HW, b = bt / T, t = bt - b * T;
+  grad[e] = scale * (pred[b * pb + t * pt + s * ps + (long)c * pc] - ref[e]);
+}
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long n, double* __restrict__ out) {
+  double s = 0.0;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float v = g[i];
+    s += (double)v * v;
+  }
+  __shared__ double part[4];
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, part[0] + part[1] + part[2] + part[3]);
+}
+
+// p, m, v, g: flat fp32 buckets.  coef = min(1, max_norm / (||g|| + 1e-6)) is computed on the device from the
+// sum of squares so that the step needs no host synchronisation (max_norm <= 0: no clipping).
+__global__ void adamw_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v, const float* __restrict__ g,
+                             long n, const double* __restrict__ sumsq, float max_norm, float lr, float b1, float b2, float eps,
+                             float wd, float bc1, float bc2_sqrt, float grad_scale) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float coef = grad_scale;
+  if (max_norm > 0.0f) {
+    const float total = (float)sqrt(*sumsq) * grad_scale;
+    coef *= fminf(max_norm / (total + 1e-6f), 1.0f);
+  }
+  const float gi = g[i] * coef;
+  float pi = p[i] * (1.0f - lr * wd);            // decoupled weight decay
+  const float mi = b1 * m[i] + (1.0f - b1) * gi;
+  const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+  m[i] = mi;
+  v[i] = vi;
+  const float denom = sqrtf(vi) / bc2_sqrt + eps;
+  p[i] = pi - (lr / bc1) * (mi / denom);
+}
+
+}  // namespace
+
+extern "C" int tante_metric_sums(const float* pred, int64_t pb, int64_t pt, int64_t ps, int64_t pc, const float* ref, int B, int T,
+                                 int64_t HW, int C, float* sums, void* stream) {
+  if (!pred || !ref || !sums || B <= 0 || T <= 0 || HW <= 0 || C <= 0) TANTE_FAIL(-1, "tante_metric_sums: bad argument");
+  if (C > 1024) TANTE_FAIL(-2, "tante_metric_sums: too many channels");
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(sums, 0, (size_t)B * T * C * 3 * sizeof(float), s) != hipSuccess) TANTE_FAIL(-3, "tante_metric_sums: memset failed");
+  long chunks = (HW * C + 256 * 64 - 1) / (256 * 64);  // ~64 elements per thread
+  if (chunks < 1) chunks = 1;
+  const long chunk = (HW + chunks - 1) / chunks;
+  hipLaunchKernelGGL(metric_sums_kernel, dim3((unsigned)((HW + chunk - 1) / chunk), (unsigned)(B * T)), dim3(256), 3 * C * sizeof(float), s,
+                     pred, (long)pb, (long)pt, (long)ps, (long)pc, ref, T, (long)HW, C, chunk, sums);
+  TANTE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int tante_mse_grad(const float* pred, int64_t pb, int64_t pt, int64_t ps, int64_t pc, const float* ref, int B, int T,
+                              int64_t HW, int C, float scale, float* grad, void* stream) {
+  if (!pred || !ref || !grad || B <= 0 || T <= 0 || HW <= 0 || C <= 0) TANTE_FAIL(-1, "tante_mse_grad: bad argument");
+  const long n = (long)B * T * HW * C;
+  hipLaunchKernelGGL(mse_grad_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pred, (long)pb, (long)pt,
+                     (long)ps, (long)pc, ref, T, (long)HW, C, scale, grad, n);
+  TANTE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int tante_sumsq(const float* g, int64_t n, double* out, void* stream) {
+  if (!g || !out || n <= 0) TANTE_FAIL(-1, "tante_sumsq: bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(out, 0, sizeof(double), s) != hipSuccess) TANTE_FAIL(-3, "tante_sumsq: memset failed");
+  long blocks = (n + 256 * 16 - 1) / (256 * 16);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, s, g, (long)n, out);
+  TANTE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int tante_adamw_step(float* p, float* m, float* v, const float* g, int64_t n, const double* sumsq, float max_norm,
+                                float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
+                                void* stream) {
+  if (!p || !m || !v || !g || n <= 0 || step < 1) TANTE_FAIL(-1, "tante_adamw_step: bad argument");
+  if (max_norm > 0.0f && !sumsq) TANTE_FAIL(-1, "tante_adamw_step: clipping needs the gradient sum of squares");
+  const float bc1 = 1.0f - powf(beta1, (float)step);
+  const float bc2s = sqrtf(1.0f - powf(beta2, (float)step));
+  hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p, m, v, g, (long)n, sumsq,
+                     max_norm, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale);
+  TANTE_CHECK_LAUNCH();
+  return 0;
+}

@@ -1,0 +1,77 @@
+"""Optimiser step of the train harness on flat buckets.
+
+FlatAdamW re-homes a model's parameters into ONE contiguous fp32 bucket (each nn.Parameter becomes a view) with a
+matching gradient bucket, so that (i) data-parallel training needs a single all-reduce over xGMI per step
+(tante_amd.dist) and (ii) clip_grad_norm_ + AdamW (trainer/trainer.py:193-196, configs/tante.yaml:38-41) are two HIP
+launches with no host synchronisation: tante_sumsq (global gradient norm) and tante_adamw_step (clip scale computed on
+the device from that sum, decoupled weight decay, bias-corrected moments).  LR schedule: optim.warmup_cosine_lr
+(LinearWarmupCosineAnnealingLR, optim/schedulers.py:17-123, stepped per epoch by the reference).
+"""
+from __future__ import annotations
+
+import math
+from typing import Iterable, Optional
+
+import torch
+
+from . import _lib as L
+
+
+class FlatAdamW:
+    def __init__(self, params: Iterable[torch.nn.Parameter], lr: float = 5e-5, weight_decay: float = 1e-5,
+                 betas=(0.9, 0.999), eps: float = 1e-8, max_norm: float = 1.0):
+        self.params = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("no trainable parameters")
+        dev = self.params[0].device
+        if dev.type != "cuda":
+            raise RuntimeError("FlatAdamW runs on the GPU only (no CPU fallback)")
+        self.lr, self.weight_decay, self.betas, self.eps, self.max_norm = lr, weight_decay, betas, eps, max_norm
+        sizes = [p.numel() for p in self.params]
+        offs, n = [], 0
+        for sz in sizes:
+            offs.append(n)
+            n += (sz + 3) // 4 * 4            # keep every view 16-byte aligned
+        self.numel = n
+        self.flat_p = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.flat_g = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
+        self._sumsq = torch.zeros(1, dtype=torch.float64, device=dev)
+        with torch.no_grad():
+            for p, o, sz in zip(self.params, offs, sizes):
+                self.flat_p[o:o + sz].copy_(p.detach().reshape(-1))
+                p.data = self.flat_p[o:o + sz].view(p.shape)          # the parameter now lives in the bucket
+                p.grad = self.flat_g[o:o + sz].view(p.shape)
+        self.step_count = 0
+
+    def zero_grad(self):
+        self.flat_g.zero_()
+
+    def grad_norm(self) -> torch.Tensor:
+        """Total 2-norm of the gradient bucket (device tensor; reading it synchronises)."""
+        L.check(L.lib().tante_sumsq(self.flat_g.data_ptr(), self.numel, self._sumsq.data_ptr(),
+                                    torch.cuda.current_stream().cuda_stream), "tante_sumsq")
+        return torch.sqrt(self._sumsq)[0].float()
+
+    def step(self, grad_scale: float = 1.0, lr: Optional[float] = None):
+        """clip_grad_norm_(max_norm) + AdamW.  grad_scale multiplies the gradients first (1/world after a summed all-reduce)."""
+        self.step_count += 1
+        s = torch.cuda.current_stream().cuda_stream
+        if self.max_norm and self.max_norm > 0:
+            L.check(L.lib().tante_sumsq(self.flat_g.data_ptr(), self.numel, self._sumsq.data_ptr(), s), "tante_sumsq")
+        L.check(L.lib().tante_adamw_step(self.flat_p.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
+                                         self.flat_g.data_ptr(), self.numel, self._sumsq.data_ptr(), float(self.max_norm or 0.0),
+                                         float(self.lr if lr is None else lr), self.betas[0], self.betas[1], self.eps,
+                                         self.weight_decay, self.step_count, float(grad_scale), s), "tante_adamw_step")
+        # the kernel wrote through raw pointers: invalidate the packed-weight caches (attn_backbone._PackCache)
+        from .attn_backbone import bump_weight_epoch
+        bump_weight_epoch()
+
+
+def warmup_cosine_lr(epoch: int, base_lr: float, warmup_epochs: int, max_epochs: int, warmup_start_lr: float = 0.0,
+                     eta_min: float = 0.0) -> float:
+    """LinearWarmupCosineAnnealingLR in closed form (optim/schedulers.py:97-123)."""
+    if epoch < warmup_epochs:
+        return warmup_start_lr + epoch * (base_lr - warmup_start_lr) / max(1, warmup_epochs - 1)
+    return eta_min + 0.5 * (base_lr - eta_min) * (1 + math.cos(math.pi * (epoch - warmup_epochs) / (max_epochs - warmup_epochs)))

@@ -486,3 +486,55 @@ def test_axis_hw_fused(dev, mode, BT, nH, nW, C):
     keys = ("p.0.weight", "p.0.bias", "p.2.weight", "p.2.bias")
     Kk.axis_hw(xd, BT, nH, nW, C, [wh[k].to(dev) for k in keys], [ww[k].to(dev) for k in keys], Kk.COMPUTE[mode])
     close(xd, ref, mode)
+
+
+# ---------------------------------------------------------------------------------------------------
+# harness: metrics, loss gradient, clip + AdamW on the flat bucket
+# ---------------------------------------------------------------------------------------------------
+def test_metrics_golden_and_strided(dev):
+    import tante_amd
+    from oracle import tante_oracle as O
+    g = load_golden("g10_metrics")
+    x, y = g["x"].to(dev), g["y"].to(dev)
+    for name in ("MSE", "L2RE", "NNMSE", "VRMSE", "NMSE", "RMSE", "NRMSE", "VMSE"):
+        out = getattr(tante_amd, name)()(x, y, None)
+        close(out, g[name], "fp32", scale=3.0)
+    for k in ("below", "inside", "above"):
+        v = tante_amd.MSE()(x, y, g["rt_" + k].to(dev), 0.5, 2)
+        assert abs(float(v) - float(g["mse_rt_" + k])) < 1e-5
+    # prediction given as the channels-last VIEW of a channels-first rollout buffer (no copy), larger and ragged sizes
+    gen = torch.Generator().manual_seed(4)
+    buf = torch.randn(3, 5, 7, 33, 20, generator=gen)                 # (B, T, C, H, W)
+    ref = torch.randn(3, 5, 33, 20, 7, generator=gen)
+    pred_view = buf.to(dev).permute(0, 1, 3, 4, 2)
+    assert not pred_view.is_contiguous()
+    close(tante_amd.MSE.eval(pred_view, ref.to(dev)), O.mse(buf.permute(0, 1, 3, 4, 2), ref), "fp32", scale=3.0)
+    close(tante_amd.L2RE.eval(pred_view, ref.to(dev)), O.l2re(buf.permute(0, 1, 3, 4, 2), ref), "fp32", scale=3.0)
+    close(tante_amd.VRMSE.eval(pred_view, ref.to(dev)), O.vrmse(buf.permute(0, 1, 3, 4, 2), ref), "fp32", scale=30.0)
+    # gradient of the train loss MSE(...).mean()
+    xx = buf.permute(0, 1, 3, 4, 2).clone().requires_grad_(True)
+    O.mse(xx, ref).mean().backward()
+    close(tante_amd.metrics.mse_mean_grad(pred_view, ref.to(dev)), xx.grad, "fp32")
+
+
+def test_clip_adamw_against_reference_step(dev):
+    """g9: the reference's gradients of step 0 -> clip_grad_norm_(1.0) + AdamW -> its weights after step 1."""
+    import tante_amd
+    g = load_golden("g9_trainstep")
+    lr, wd, b1, b2, eps, max_norm = (float(v) for v in g["hyper"])
+    md = tante_amd.TanteMetadata(n_fields=2, spatial_resolution=(16, 16))
+    m = tante_amd.TANTE(in_T=4, dset_metadata=md, taylor_order=2, attn_axes="TH-WL", n_head=2, embed_dim=32, patch_scale=8,
+                        dropout=0.0).to(dev)
+    m.load_state_dict(split_prefix(g, "w0."))
+    opt = tante_amd.FlatAdamW(m.parameters(), lr=lr, weight_decay=wd, betas=(b1, b2), eps=eps, max_norm=max_norm)
+    for k, p in m.named_parameters():                                 # parameters now live in the flat bucket
+        assert p.data_ptr() >= opt.flat_p.data_ptr() and torch.equal(p.detach().cpu(), g["w0." + k])
+        p.grad.copy_(g["g0." + k].to(dev))
+    gn = opt.grad_norm()
+    assert abs(float(gn) - float(g["gnorm0"])) < 1e-5 * float(g["gnorm0"])
+    opt.step()
+    for k, p in m.named_parameters():
+        assert float((p.detach().cpu() - g["w1." + k]).abs().max()) < 2e-3 * lr, k      # vs |update| ~ lr
+    # the packed-weight caches notice the raw-pointer update
+    from tante_amd.attn_backbone import _WEIGHT_EPOCH
+    assert _WEIGHT_EPOCH[0] >= 1

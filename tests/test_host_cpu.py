@@ -142,3 +142,43 @@ def test_formatter_matches_oracle():
     xo, yo = O.format_input(batch)
     assert torch.equal(x, xo) and torch.equal(y, yo)
     assert torch.equal(fmt.process_output(x), torch.nan_to_num(batch["input"]))
+
+
+def _dp_worker(rank, world, port, q):
+    import os
+    import torch
+    import torch.distributed as dist
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from tante_amd import dist as D
+    r, w, _ = D.init("gloo")
+    g = torch.Generator().manual_seed(0)
+    batch = {"input": torch.randn(4, 3, 2, generator=g), "output": torch.randn(4, 1, 2, generator=g)}
+    mine = D.shard_batch(batch, r, w)
+    # a "gradient" that is linear in the samples: the summed all-reduce divided by world == full-batch mean
+    flat = mine["input"].sum(dim=0).reshape(-1).clone()
+    D.allreduce_sum_(flat)
+    t = D.max_over_ranks(1.0 + r)
+    D.barrier()
+    q.put((r, mine["input"].shape[0], flat, t))
+    dist.destroy_process_group()
+
+
+def test_dp_shard_and_allreduce_gloo_world2():
+    """The N > 1 path on CPU: batch sharding, the single summed gradient all-reduce, max-over-ranks timing (gloo)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 1000
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    g = torch.Generator().manual_seed(0)
+    full = torch.randn(4, 3, 2, generator=g)
+    for r, nb, flat, t in res:
+        assert nb == 2
+        assert torch.allclose(flat, full.sum(dim=0).reshape(-1), atol=1e-6)      # sum over ranks == full-batch sum
+        assert t == 2.0                                                          # slowest rank
