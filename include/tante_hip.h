@@ -54,6 +54,11 @@ extern "C" {
 #define TANTE_W_CONV_NHWC 1   /* Conv2d weight (Cout, Cin, P, P), k re-ordered to (kh, kw, ci) */
 #define TANTE_W_DECONV_NHWC 2 /* ConvTranspose2d weight (Cin, Cout, P, P): k = ci, n = (kh, kw, co) */
 #define TANTE_W_DECONV_NCHW 3 /* ConvTranspose2d weight (Cin, Cout, P, P): k = ci, n = (co, kh, kw) */
+/* transposed packings: the data-gradient GEMM of each forward layout (dX = dY . W), N and K are those of the dgrad GEMM */
+#define TANTE_W_LINEAR_T 4      /* source (K, N) row-major: Linear weight (N_fwd = K, K_fwd = N); Conv2d read as (ci,kh,kw) */
+#define TANTE_W_CONV_NHWC_T 5   /* Conv2d (Cout, Cin, P, P): n = (kh, kw, ci), k = co;  C_other = Cin */
+#define TANTE_W_DECONV_NHWC_T 6 /* ConvTranspose2d (Cin, Cout, P, P): n = ci, k = (kh, kw, co);  C_other = Cout */
+#define TANTE_W_DECONV_NCHW_T 7 /* ConvTranspose2d (Cin, Cout, P, P): n = ci, k = (co, kh, kw) */
 
 /* Geometry of a packed weight for (N, K) under a compute dtype.  The packed image is
  * [n_pad / nt tiles][nt rows][k_pad / chunk 16-byte chunks, XOR-swizzled], i.e. exactly the LDS
@@ -199,6 +204,55 @@ int tante_sumsq(const float* g, int64_t n, double* out, void* stream);
  * device, so the train step has no host synchronisation. */
 int tante_adamw_step(float* p, float* m, float* v, const float* g, int64_t n, const double* sumsq, float max_norm, float lr,
                      float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream);
+
+/* ---- backward kernels of the train step (trainer/trainer.py:191 loss.backward() through the whole rollout) ----------
+ * Data gradients of every dense / conv layer are tante_gemm calls with the TANTE_W_*_T packings (dX = dY . W, with the
+ * scatter / gather modes of the forward layer swapped); the rest: */
+
+/* xhat = (x - mean) * rstd per row (no affine: the host folds gamma/beta into the consumer's weight), stats[row] = {mean, rstd};
+ * backward: dx = dskip + rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = d xhat  (dskip = gradient of the residual branch, may be NULL) */
+int tante_layernorm_fwd(const float* x, int64_t M, int C, float eps, void* xhat, int out_dtype, float* stats, void* stream);
+int tante_layernorm_bwd(const void* dxhat, int g_dtype, const float* x, const float* stats, const float* dskip, int64_t M, int C,
+                        float* dx, void* stream);
+/* post = act(pre);  dpre = dpost * act'(pre)   (act codes above) */
+int tante_act_fwd(const void* pre, int in_dtype, void* post, int out_dtype, int64_t n, int act, void* stream);
+int tante_act_bwd(const void* dpost, int d_dtype, const void* pre, int pre_dtype, void* dpre, int out_dtype, int64_t n, int act,
+                  void* stream);
+/* out[c] (+)= sum over (o, i) of x[(o*C + c)*inner + i]: bias gradients of channels-last (inner = 1) / channels-first tensors */
+int tante_colsum(const void* x, int dtype, int64_t outer, int C, int64_t inner, float* out, int accumulate, void* stream);
+/* y = v * a[t] + b[t] + s_emb[hw] over rows r = (b, t, hw) (the FiLM + positional epilogue as an op of its own) and its backward:
+ * dv = dy * a[t], da / db (T, C) and ds (HW, C) reduced over the other indices */
+int tante_film_pos_fwd(const float* v, const float* a, const float* b, const float* s_emb, int64_t rows, int C, int T, int64_t HW,
+                       float* y, void* stream);
+int tante_film_pos_bwd(const float* dy, const float* v, const float* a, int64_t BT, int64_t HW, int C, int T, float* dv, float* da,
+                       float* db, float* ds, void* stream);
+/* Taylor sum backward: dderivs[k] = sum_i (i dt)^k / k! * dout_i,  dlast (+)= sum_i dout_i (dlast may be the last frame of the
+ * input-window gradient, addressed by base pointer + batch stride) */
+int tante_taylor_bwd(const float* dout, int64_t dout_bstride, float* const* dderivs, int n_order, double dt, int n_out, float* dlast,
+                     int64_t dlast_bstride, int accumulate, int64_t B, int64_t frame, void* stream);
+/* dqkv from (qkv, dO) for per-(sequence, head) softmax attention, probabilities recomputed (sequences up to 128 tokens) */
+int tante_attention_bwd(const void* qkv, const void* dO, void* dqkv, int dtype, int C, int n_head, const TanteSeq* seq, int causal,
+                        void* stream);
+/* axis propagator backward: dx = dy + W1^T (gelu'(pre) * (W2^T dy)); also writes h = gelu(pre) and dpre (same layout as x) for
+ * the weight-gradient GEMMs */
+int tante_axis_mlp_bwd(const float* x, const float* dy, int64_t outer, int n, int64_t inner, const float* w1, const float* b1,
+                       const float* w2, float* dx, float* h, float* dpre, void* stream);
+
+/* A gathered row matrix (rows r, `cols` columns): LINEAR rows at (r/n0)*s1 + (r%n0)*s0 + off with element stride es, or the
+ * k = s patches of an image batch exactly as in TanteGemm (n0 images per batch item, s1 elements between items). */
+typedef struct TanteRowMat {
+  const void* p;
+  int32_t dtype, mode;
+  int64_t s1, s0, off, es;
+  int32_t n0;
+  int32_t Hin, Win, Cin, P;
+} TanteRowMat;
+
+/* dW[i][j] (+)= sum_r U[r][i] * V[r][j], written at the parameter's own index: layout is a TANTE_W_* source layout of
+ * tante_pack_weight and (n, k) = (i, j), or (j, i) when swap != 0 (transposed-conv weights: U = input pixels, V = output-gradient
+ * patches).  MFMA in `compute`, fp32 atomics across the row split. */
+int tante_wgrad(const TanteRowMat* U, const TanteRowMat* V, int64_t R, int I, int J, float* dW, int layout, int P, int C_other, int swap,
+                int compute, int accumulate, void* stream);
 
 const char* tante_last_error(void);
 int tante_abi_version(void);

@@ -11,6 +11,7 @@ ACT_NONE, ACT_GELU_ERF, ACT_GELU_TANH, ACT_RELU = 0, 1, 2, 3
 A_LINEAR, A_PATCH_NHWC, A_PATCH_NCHW = 0, 1, 2
 E_LINEAR, E_FILM, E_DECONV_NHWC, E_DECONV_NCHW = 0, 1, 2, 3
 W_LINEAR, W_CONV_NHWC, W_DECONV_NHWC, W_DECONV_NCHW = 0, 1, 2, 3
+W_LINEAR_T, W_CONV_NHWC_T, W_DECONV_NHWC_T, W_DECONV_NCHW_T = 4, 5, 6, 7
 
 c_i32, c_i64, c_f32, c_vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 
@@ -30,6 +31,11 @@ class Gemm(C.Structure):
         ("film_a", c_vp), ("film_b", c_vp), ("s_emb", c_vp), ("T", c_i32), ("HW", c_i32),
         ("Hi", c_i32), ("Wi", c_i32), ("Po", c_i32), ("Cout", c_i32),
     ]
+
+
+class RowMat(C.Structure):
+    _fields_ = [("p", c_vp), ("dtype", c_i32), ("mode", c_i32), ("s1", c_i64), ("s0", c_i64), ("off", c_i64), ("es", c_i64),
+                ("n0", c_i32), ("Hin", c_i32), ("Win", c_i32), ("Cin", c_i32), ("P", c_i32)]
 
 
 class Seq(C.Structure):
@@ -57,6 +63,17 @@ SIGNATURES = {
     "tante_mse_grad": ([c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_i32, c_i32, c_i64, c_i32, c_f32, c_vp, c_vp], c_i32),
     "tante_sumsq": ([c_vp, c_i64, c_vp, c_vp], c_i32),
     "tante_adamw_step": ([c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_f32, c_f32, c_f32, c_f32, c_f32, c_f32, c_i32, c_f32, c_vp], c_i32),
+    "tante_layernorm_fwd": ([c_vp, c_i64, c_i32, c_f32, c_vp, c_i32, c_vp, c_vp], c_i32),
+    "tante_layernorm_bwd": ([c_vp, c_i32, c_vp, c_vp, c_vp, c_i64, c_i32, c_vp, c_vp], c_i32),
+    "tante_act_fwd": ([c_vp, c_i32, c_vp, c_i32, c_i64, c_i32, c_vp], c_i32),
+    "tante_act_bwd": ([c_vp, c_i32, c_vp, c_i32, c_vp, c_i32, c_i64, c_i32, c_vp], c_i32),
+    "tante_colsum": ([c_vp, c_i32, c_i64, c_i32, c_i64, c_vp, c_i32, c_vp], c_i32),
+    "tante_film_pos_fwd": ([c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i64, c_vp, c_vp], c_i32),
+    "tante_film_pos_bwd": ([c_vp, c_vp, c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp], c_i32),
+    "tante_taylor_bwd": ([c_vp, c_i64, C.POINTER(c_vp), c_i32, C.c_double, c_i32, c_vp, c_i64, c_i32, c_i64, c_i64, c_vp], c_i32),
+    "tante_attention_bwd": ([c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, C.POINTER(Seq), c_i32, c_vp], c_i32),
+    "tante_axis_mlp_bwd": ([c_vp, c_vp, c_i64, c_i32, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp], c_i32),
+    "tante_wgrad": ([C.POINTER(RowMat), C.POINTER(RowMat), c_i64, c_i32, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp], c_i32),
     "tante_last_error": ([], C.c_char_p),
     "tante_abi_version": ([], c_i32),
 }

@@ -1,0 +1,340 @@
+"""Differentiable HIP ops: each torch.autograd.Function below runs a HIP kernel forward and HIP kernels backward.
+
+torch.autograd is used as the tape (which op ran on which tensors, in which order -- including back-propagation through
+the autoregressive re-feed) and for gradient accumulation at fan-out points; every per-token computation is in
+libtante_hip.so.  LayerNorm's affine and the FiLM tables are tiny parameter-sized expressions (C values) that the host
+evaluates with torch so that their gradients come for free.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+from torch.autograd import Function
+
+from . import _lib as L
+from . import kernels as K
+
+_DT = {torch.float32: L.F32, torch.bfloat16: L.BF16}
+
+
+def _s():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _rm_linear(t: torch.Tensor, n0: Optional[int] = None, s1: int = 0, s0: Optional[int] = None, off: int = 0, es: int = 1,
+               rows: Optional[int] = None, cols: Optional[int] = None) -> L.RowMat:
+    m = L.RowMat()
+    m.p, m.dtype, m.mode = t.data_ptr(), _DT[t.dtype], L.A_LINEAR
+    cols = t.shape[-1] if cols is None else cols
+    m.n0 = (rows if rows is not None else t.numel() // cols) if n0 is None else n0
+    m.s1, m.s0, m.off, m.es = s1, (cols if s0 is None else s0), off, es
+    return m
+
+
+def _rm_patch(t: torch.Tensor, nhwc: bool, n_img: int, Hin: int, Win: int, Cin: int, P: int) -> L.RowMat:
+    m = L.RowMat()
+    m.p, m.dtype, m.mode = t.data_ptr(), _DT[t.dtype], (L.A_PATCH_NHWC if nhwc else L.A_PATCH_NCHW)
+    m.n0, m.s1, m.s0, m.off, m.es = n_img, 0, 0, 0, 1
+    m.Hin, m.Win, m.Cin, m.P = Hin, Win, Cin, P
+    return m
+
+
+def wgrad(U: L.RowMat, V: L.RowMat, R: int, I: int, J: int, out_shape, compute: int, layout: int = L.W_LINEAR, P: int = 0,
+          C_other: int = 0, swap: bool = False, device=None) -> torch.Tensor:
+    dW = torch.empty(out_shape, dtype=torch.float32, device=device)
+    L.check(L.lib().tante_wgrad(C.byref(U), C.byref(V), R, I, J, dW.data_ptr(), layout, P, C_other, int(swap), compute, 0, _s()),
+            "tante_wgrad")
+    return dW
+
+
+def colsum(x: torch.Tensor, outer: int, Cc: int, inner: int) -> torch.Tensor:
+    out = torch.empty(Cc, dtype=torch.float32, device=x.device)
+    L.check(L.lib().tante_colsum(x.data_ptr(), _DT[x.dtype], outer, Cc, inner, out.data_ptr(), 0, _s()), "tante_colsum")
+    return out
+
+
+class LayerNormFn(Function):
+    """xhat = (x - mean) / sqrt(var + eps) per row, no affine."""
+
+    @staticmethod
+    def forward(ctx, x, eps, out_dtype):
+        M, Cc = x.shape
+        xh = torch.empty(M, Cc, dtype=out_dtype, device=x.device)
+        st = torch.empty(M, 2, dtype=torch.float32, device=x.device)
+        L.check(L.lib().tante_layernorm_fwd(x.data_ptr(), M, Cc, eps, xh.data_ptr(), _DT[out_dtype], st.data_ptr(), _s()), "ln_fwd")
+        ctx.save_for_backward(x, st)
+        return xh
+
+    @staticmethod
+    def backward(ctx, g):
+        x, st = ctx.saved_tensors
+        g = g.contiguous()
+        dx = torch.empty_like(x)
+        L.check(L.lib().tante_layernorm_bwd(g.data_ptr(), _DT[g.dtype], x.data_ptr(), st.data_ptr(), None, x.shape[0], x.shape[1],
+                                            dx.data_ptr(), _s()), "ln_bwd")
+        return dx, None, None
+
+
+class LinearFn(Function):
+    """y = a @ W^T + b (+ residual).  a (M, K) fp32 / bf16, W (N, K) fp32 master, y in out_dtype (fp32 when a residual is added)."""
+
+    @staticmethod
+    def forward(ctx, a, W, b, residual, compute, out_dtype):
+        M, Kk = a.shape
+        N = W.shape[0]
+        pw = K.pack_weight(W, b, compute)
+        out = torch.empty(M, N, dtype=torch.float32 if residual is not None else out_dtype, device=a.device)
+        K.linear(a, pw, out, M=M, residual=residual)
+        ctx.save_for_backward(a, W)
+        ctx.compute, ctx.has_bias, ctx.has_res = compute, b is not None, residual is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        a, W = ctx.saved_tensors
+        dy = dy.contiguous()
+        M, Kk = a.shape
+        N = W.shape[0]
+        comp = ctx.compute
+        da = dW = db = None
+        if ctx.needs_input_grad[0]:
+            pwt = K.pack_weight(W, None, comp, L.W_LINEAR_T, N=Kk, K=N)        # dgrad GEMM: (M, N) x (N, K)
+            da = torch.empty(M, Kk, dtype=a.dtype, device=a.device)
+            K.linear(dy, pwt, da, M=M)
+        if ctx.needs_input_grad[1]:
+            dW = wgrad(_rm_linear(dy), _rm_linear(a), M, N, Kk, (N, Kk), comp, device=a.device)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = colsum(dy, M, N, 1)
+        dres = dy if ctx.has_res else None
+        return da, dW, db, dres, None, None
+
+
+class ActFn(Function):
+    @staticmethod
+    def forward(ctx, pre, act, out_dtype):
+        post = torch.empty(pre.shape, dtype=out_dtype, device=pre.device)
+        L.check(L.lib().tante_act_fwd(pre.data_ptr(), _DT[pre.dtype], post.data_ptr(), _DT[out_dtype], pre.numel(), act, _s()), "act_fwd")
+        ctx.save_for_backward(pre)
+        ctx.act = act
+        return post
+
+    @staticmethod
+    def backward(ctx, g):
+        (pre,) = ctx.saved_tensors
+        g = g.contiguous()
+        d = torch.empty_like(pre)
+        L.check(L.lib().tante_act_bwd(g.data_ptr(), _DT[g.dtype], pre.data_ptr(), _DT[pre.dtype], d.data_ptr(), _DT[d.dtype], pre.numel(),
+                                      ctx.act, _s()), "act_bwd")
+        return d, None, None
+
+
+class AttentionFn(Function):
+    """o = softmax(q k^T / sqrt(d) [+causal]) v per (sequence, head) on the packed (tokens, 3C) projection."""
+
+    @staticmethod
+    def forward(ctx, qkv, seq, Cc, n_head, causal):
+        o = torch.empty(qkv.shape[0], Cc, dtype=qkv.dtype, device=qkv.device)
+        K.attention(qkv, o, Cc, n_head, seq, causal)
+        ctx.save_for_backward(qkv)
+        ctx.seq, ctx.C, ctx.nh, ctx.causal = seq, Cc, n_head, causal
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        (qkv,) = ctx.saved_tensors
+        do = do.contiguous().to(qkv.dtype)
+        dqkv = torch.empty_like(qkv)
+        L.check(L.lib().tante_attention_bwd(qkv.data_ptr(), do.data_ptr(), dqkv.data_ptr(), _DT[qkv.dtype], ctx.C, ctx.nh, C.byref(ctx.seq),
+                                            int(ctx.causal), _s()), "attention_bwd")
+        return dqkv, None, None, None, None
+
+
+class AxisMlpFn(Function):
+    """y = x + W2 gelu_erf(W1 x + b1) + b2 along one axis of (outer, n, inner)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, outer, n, inner, compute):
+        y = x.clone()
+        K.axis_mlp(y, outer, n, inner, w1, b1, w2, b2)
+        ctx.save_for_backward(x, w1, b1, w2)
+        ctx.dims, ctx.compute = (outer, n, inner), compute
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w1, b1, w2 = ctx.saved_tensors
+        outer, n, inner = ctx.dims
+        dy = dy.contiguous()
+        dx, h, dpre = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+        L.check(L.lib().tante_axis_mlp_bwd(x.data_ptr(), dy.data_ptr(), outer, n, inner, w1.data_ptr(), b1.data_ptr(), w2.data_ptr(),
+                                           dx.data_ptr(), h.data_ptr(), dpre.data_ptr(), _s()), "axis_mlp_bwd")
+        R = outer * inner
+
+        def lines(t):     # one row per (outer, inner) column, n elements with stride `inner`
+            return _rm_linear(t, n0=inner, s1=n * inner, s0=1, es=inner, cols=n)
+        comp = L.F32      # the propagators run in fp32 on the residual stream
+        dw2 = wgrad(lines(dy), lines(h), R, n, n, (n, n), comp, device=x.device)
+        dw1 = wgrad(lines(dpre), lines(x), R, n, n, (n, n), comp, device=x.device)
+        db2 = colsum(dy, outer, n, inner)
+        db1 = colsum(dpre, outer, n, inner)
+        return dx, dw1, db1, dw2, db2, None, None, None, None
+
+
+class PatchEmbedFn(Function):
+    """Kernel = stride = P convolution as a patch GEMM; x (n_img, Cin, H, W) [nchw] or (n_img, H, W, Cin); out (rows, Cout) channels-last,
+    PRE-activation."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, n_img, Hin, Win, Cin, P, nchw, compute, out_dtype):
+        Cout = W.shape[0]
+        if nchw:
+            pw = K.pack_weight(W, b, compute, L.W_LINEAR, N=Cout, K=Cin * P * P)
+        else:
+            pw = K.pack_weight(W, b, compute, L.W_CONV_NHWC, N=Cout, K=Cin * P * P, P=P, C_other=Cin)
+        M = n_img * (Hin // P) * (Win // P)
+        out = torch.empty(M, Cout, dtype=out_dtype, device=x.device)
+        K.patch_embed(x, pw, out, n_img=n_img, Hin=Hin, Win=Win, Cin=Cin, P=P, nchw=nchw, act=L.ACT_NONE)
+        ctx.save_for_backward(x, W)
+        ctx.geo, ctx.compute = (n_img, Hin, Win, Cin, P, nchw), compute
+        return out
+
+    @staticmethod
+    def backward(ctx, d):
+        x, W = ctx.saved_tensors
+        n_img, Hin, Win, Cin, P, nchw = ctx.geo
+        comp = ctx.compute
+        d = d.contiguous()
+        M, Cout = d.shape
+        Kk = Cin * P * P
+        dx = dW = db = None
+        if ctx.needs_input_grad[0]:     # col2im of non-overlapping patches = the pixel-shuffle scatter of a transposed conv
+            if nchw:
+                pwt = K.pack_weight(W, None, comp, L.W_LINEAR_T, N=Kk, K=Cout)
+                dx = torch.empty(n_img, Cin, Hin, Win, dtype=torch.float32, device=x.device)
+            else:
+                pwt = K.pack_weight(W, None, comp, L.W_CONV_NHWC_T, N=Kk, K=Cout, P=P, C_other=Cin)
+                dx = torch.empty(n_img, Hin, Win, Cin, dtype=x.dtype, device=x.device)
+            K.deconv(d, pwt, dx, n_img=n_img, Hi=Hin // P, Wi=Win // P, P=P, Cout=Cin, nchw_out=nchw, act=L.ACT_NONE)
+            dx = dx.view(x.shape)
+        if ctx.needs_input_grad[1]:
+            V = _rm_patch(x, not nchw, n_img, Hin, Win, Cin, P)
+            dW = wgrad(_rm_linear(d), V, M, Cout, Kk, tuple(W.shape), comp, layout=L.W_LINEAR if nchw else L.W_CONV_NHWC, P=P,
+                       C_other=Cin, device=x.device)
+        if ctx.needs_input_grad[2]:
+            db = colsum(d, M, Cout, 1)
+        return dx, dW, db, None, None, None, None, None, None, None, None
+
+
+class DeconvFn(Function):
+    """Kernel = stride = P transposed convolution: a (rows, Cin) pixels -> (n_img, Hi*P, Wi*P, Cout) channels-last, or (n_img, Cout, .., ..)
+    fp32 when nchw_out; PRE-activation."""
+
+    @staticmethod
+    def forward(ctx, a, W, b, n_img, Hi, Wi, P, nchw_out, compute, out_dtype):
+        Cin, Cout = W.shape[0], W.shape[1]
+        lay = L.W_DECONV_NCHW if nchw_out else L.W_DECONV_NHWC
+        pw = K.pack_weight(W, b, compute, lay, N=Cout * P * P, K=Cin, P=P, C_other=Cout)
+        if nchw_out:
+            out = torch.empty(n_img, Cout, Hi * P, Wi * P, dtype=torch.float32, device=a.device)
+        else:
+            out = torch.empty(n_img, Hi * P, Wi * P, Cout, dtype=out_dtype, device=a.device)
+        K.deconv(a, pw, out, n_img=n_img, Hi=Hi, Wi=Wi, P=P, Cout=Cout, nchw_out=nchw_out, act=L.ACT_NONE)
+        ctx.save_for_backward(a, W)
+        ctx.geo, ctx.compute = (n_img, Hi, Wi, P, nchw_out), compute
+        return out
+
+    @staticmethod
+    def backward(ctx, d):
+        a, W = ctx.saved_tensors
+        n_img, Hi, Wi, P, nchw_out = ctx.geo
+        comp = ctx.compute
+        Cin, Cout = W.shape[0], W.shape[1]
+        d = d.contiguous()
+        M, N = n_img * Hi * Wi, Cout * P * P
+        da = dW = db = None
+        if ctx.needs_input_grad[0]:      # gather the P x P output-gradient patch of every input pixel
+            lay = L.W_DECONV_NCHW_T if nchw_out else L.W_DECONV_NHWC_T
+            pwt = K.pack_weight(W, None, comp, lay, N=Cin, K=N, P=P, C_other=Cout)
+            da = torch.empty(M, Cin, dtype=a.dtype, device=a.device)
+            K.patch_embed(d, pwt, da, n_img=n_img, Hin=Hi * P, Win=Wi * P, Cin=Cout, P=P, nchw=nchw_out, act=L.ACT_NONE)
+            da = da.view(a.shape)
+        if ctx.needs_input_grad[1]:
+            V = _rm_patch(d, not nchw_out, n_img, Hi * P, Wi * P, Cout, P)
+            dW = wgrad(_rm_linear(a), V, M, Cin, N, tuple(W.shape), comp, layout=L.W_DECONV_NCHW if nchw_out else L.W_DECONV_NHWC, P=P,
+                       C_other=Cout, swap=True, device=a.device)
+        if ctx.needs_input_grad[2]:
+            db = colsum(d, n_img, Cout, Hi * P * Wi * P) if nchw_out else colsum(d, n_img * Hi * P * Wi * P, Cout, 1)
+        return da, dW, db, None, None, None, None, None, None, None
+
+
+class FilmPosFn(Function):
+    """y[r] = v[r] * a[t] + b[t] + s_emb[hw],  r = (b, t, hw)   (tante.py:136-141 with t_emb folded into b)."""
+
+    @staticmethod
+    def forward(ctx, v, a, b, s_emb, T, HW):
+        rows, Cc = v.shape
+        y = torch.empty_like(v)
+        L.check(L.lib().tante_film_pos_fwd(v.data_ptr(), a.data_ptr(), b.data_ptr(), s_emb.data_ptr(), rows, Cc, T, HW, y.data_ptr(), _s()),
+                "film_pos_fwd")
+        ctx.save_for_backward(v, a)
+        ctx.dims = (T, HW)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        v, a = ctx.saved_tensors
+        T, HW = ctx.dims
+        rows, Cc = v.shape
+        dy = dy.contiguous()
+        dv = torch.empty_like(v)
+        da = torch.empty(T, Cc, dtype=torch.float32, device=v.device)
+        db = torch.empty(T, Cc, dtype=torch.float32, device=v.device)
+        ds = torch.empty(HW, Cc, dtype=torch.float32, device=v.device)
+        L.check(L.lib().tante_film_pos_bwd(dy.data_ptr(), v.data_ptr(), a.data_ptr(), rows // HW, HW, Cc, T, dv.data_ptr(), da.data_ptr(),
+                                           db.data_ptr(), ds.data_ptr(), _s()), "film_pos_bwd")
+        return dv, da, db, ds, None, None
+
+
+class TaylorFn(Function):
+    """out_i = inp[:, -1] + sum_k derivs[k] (i dt)^k / k!   (tante.py:165-171)."""
+
+    @staticmethod
+    def forward(ctx, inp, dt, n_out, *derivs):
+        B, T = inp.shape[:2]
+        frame = inp[0, 0].numel()
+        out = torch.empty(B, n_out, *inp.shape[2:], dtype=torch.float32, device=inp.device)
+        K.taylor(inp, (T - 1) * frame, T * frame, [d.contiguous() for d in derivs], dt, n_out, out, B, frame)
+        ctx.dims = (B, T, frame, dt, n_out, len(derivs), tuple(inp.shape))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        B, T, frame, dt, n_out, n_order, ishape = ctx.dims
+        dout = dout.contiguous()
+        dinp = torch.zeros(ishape, dtype=torch.float32, device=dout.device)
+        dds = [torch.empty(B, frame, dtype=torch.float32, device=dout.device) for _ in range(n_order)]
+        arr = (C.c_void_p * n_order)(*[d.data_ptr() for d in dds])
+        L.check(L.lib().tante_taylor_bwd(dout.data_ptr(), n_out * frame, arr, n_order, float(dt), n_out,
+                                         dinp.data_ptr() + 4 * (T - 1) * frame, T * frame, 0, B, frame, _s()), "taylor_bwd")
+        return (dinp, None, None) + tuple(d.view(B, 1, *ishape[2:]) for d in dds)
+
+
+class MseMeanFn(Function):
+    """MSE(pred, ref).mean() of channels-last tensors (trainer/trainer.py:189)."""
+
+    @staticmethod
+    def forward(ctx, pred, ref):
+        from . import metrics
+        s = metrics.metric_sums(pred, ref)
+        ctx.save_for_backward(pred, ref)
+        n = pred.numel()
+        return s[..., 0].sum() / n
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import metrics
+        pred, ref = ctx.saved_tensors
+        grad = metrics.mse_mean_grad(pred, ref)
+        return grad * g, None

@@ -1,0 +1,469 @@
+// Backward kernels of the TANTE train step (everything that is not a GEMM; the data-gradient GEMMs are tante_gemm with
+// the *_T packings, the weight-gradient GEMM is wgrad.hip).
+#include "common.cuh"
+
+namespace {
+
+__device__ __forceinline__ float ldx(const void* p, int dtype, long i) {
+  return dtype == TANTE_BF16 ? __uint_as_float(((unsigned)((const unsigned short*)p)[i]) << 16) : ((const float*)p)[i];
+}
+__device__ __forceinline__ void stx(void* p, int dtype, long i, float v) {
+  if (dtype == TANTE_BF16) ((__bf16*)p)[i] = (__bf16)v;
+  else ((float*)p)[i] = v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// ---- LayerNorm without affine (gamma / beta are folded into the consumer's weight by the host) -------------------
+// one wave per row; stats[row] = {mean, rstd}
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, long M, int C, float eps, void* __restrict__ xhat,
+                                                     int out_dtype, float* __restrict__ stats) {
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= M) return;
+  const float* xr = x + row * C;
+  float s = 0.f;
+  for (int c = lane; c < C; c += 64) s += xr[c];
+  const float mean = wave_sum(s) / C;
+  float q = 0.f;
+  for (int c = lane; c < C; c += 64) { const float d = xr[c] - mean; q += d * d; }
+  const float rstd = rsqrtf(wave_sum(q) / C + eps);
+  for (int c = lane; c < C; c += 64) stx(xhat, out_dtype, row * C + c, (xr[c] - mean) * rstd);
+  if (lane == 0) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
+}
+
+// dx = dskip + rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = d xhat
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ g, int g_dtype, const float* __restrict__ x,
+                                                     const float* __restrict__ stats, const float* __restrict__ dskip, long M, int C,
+                                                     float* __restrict__ dx) {
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= M) return;
+  const float mean = stats[2 * row], rstd = stats[2 * row + 1];
+  float s1 = 0.f, s2 = 0.f;
+  for (int c = lane; c < C; c += 64) {
+    const float gv = ldx(g, g_dtype, row * C + c), xh = (x[row * C + c] - mean) * rstd;
+    s1 += gv; s2 += gv * xh;
+  }
+  s1 = wave_sum(s1) / C; s2 = wave_sum(s2) / C;
+  for (int c = lane; c < C; c += 64) {
+    const float gv = ldx(g, g_dtype, row * C + c), xh = (x[row * C + c] - mean) * rstd;
+    const float d = rstd * (gv - s1 - xh * s2);
+    dx[row * C + c] = (dskip ? dskip[row * C + c] : 0.f) + d;
+  }
+}
+
+// ---- activations ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float act_f(float x, int act) { return apply_act(x, act); }
+__device__ __forceinline__ float act_df(float x, int act) {
+  switch (act) {
+    case TANTE_ACT_GELU_ERF: {  // Phi(x) + x phi(x)
+      const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+      return cdf + x * 0.39894228040143267794f * expf(-0.5f * x * x);
+    }
+    case TANTE_ACT_GELU_TANH: {
+      const float c = 0.79788456080286535588f, u = c * (x + 0.044715f * x * x * x), t = tanhf(u);
+      return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * c * (1.0f + 3.0f * 0.044715f * x * x);
+    }
+    case TANTE_ACT_RELU: return x > 0.f ? 1.0f : 0.f;
+    default: return 1.0f;
+  }
+}
+__global__ void act_fwd_kernel(const void* __restrict__ pre, int in_dtype, void* __restrict__ post, int out_dtype, long n, int act) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) stx(post, out_dtype, i, act_f(ldx(pre, in_dtype, i), act));
+}
+__global__ void act_bwd_kernel(const void* __restrict__ dpost, int d_dtype, const void* __restrict__ pre, int pre_dtype,
+                               void* __restrict__ dpre, int out_dtype, long n, int act) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) stx(dpre, out_dtype, i, ldx(dpost, d_dtype, i) * act_df(ldx(pre, pre_dtype, i), act));
+}
+
+// ---- out[c] = sum over (o, i) of x[(o*C + c)*inner + i]  (bias gradients) -------------------------------------------
+__global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ x, int dtype, long outer, int C, long inner, long chunk,
+                                                     float* __restrict__ out) {
+  // grid.x: chunks of the (outer x inner) reduction, grid.y: channel groups of 64 (inner == 1) or single channels
+  if (inner == 1) {
+    const int c = blockIdx.y * 64 + (threadIdx.x & 63);
+    const int sub = threadIdx.x >> 6;
+    float s = 0.f;
+    if (c < C) {
+      const long o0 = (long)blockIdx.x * chunk, o1 = min(outer, o0 + chunk);
+      for (long o = o0 + sub; o < o1; o += 4) s += ldx(x, dtype, o * C + c);
+    }
+    __shared__ float part[256];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (sub == 0 && c < C) atomicAdd(&out[c], part[threadIdx.x] + part[threadIdx.x + 64] + part[threadIdx.x + 128] + part[threadIdx.x + 192]);
+  } else {
+    const int c = blockIdx.y;
+    const long o = blockIdx.x;  // one (o, c) slab of `inner` contiguous elements per workgroup
+    float s = 0.f;
+    const long base = (o * C + c) * inner;
+    for (long i = threadIdx.x; i < inner; i += 256) s += ldx(x, dtype, base + i);
+    s = wave_sum(s);
+    __shared__ float part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(&out[c], part[0] + part[1] + part[2] + part[3]);
+  }
+}
+
+// ---- FiLM + positional epilogue as a stand-alone op (train path): y = v * a[t] + b[t] + s[hw], rows r = (b, t, hw) --
+__global__ void film_pos_fwd_kernel(const float* __restrict__ v, const float* __restrict__ a, const float* __restrict__ b,
+                                    const float* __restrict__ s, long rows, int C4, int T, long HW, float* __restrict__ y) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * C4) return;
+  const long r = idx / C4;
+  const int c4 = (int)(idx - r * C4);
+  const long hw = r % HW;
+  const int t = (int)((r / HW) % T);
+  const f32x4 vv = ((const f32x4*)v)[idx];
+  ((f32x4*)y)[idx] = vv * ((const f32x4*)a)[t * C4 + c4] + ((const f32x4*)b)[t * C4 + c4] + ((const f32x4*)s)[hw * C4 + c4];
+}
+// dv = dy * a[t];  da[t][c] += sum dy * v;  db[t][c] += sum dy   (one workgroup per (bt, hw chunk); thread = channel)
+__global__ __launch_bounds__(256) void film_pos_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ v,
+                                                           const float* __restrict__ a, long HW, int C, int T, long chunk,
+                                                           float* __restrict__ dv, float* __restrict__ da, float* __restrict__ db) {
+  const long bt = blockIdx.y;
+  const int t = (int)(bt % T);
+  const long h0 = (long)blockIdx.x * chunk, h1 = min(HW, h0 + chunk);
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const float av = a[t * C + c];
+    float sa = 0.f, sb = 0.f;
+    for (long hw = h0; hw < h1; ++hw) {
+      const long i = (bt * HW + hw) * C + c;
+      const float g = dy[i];
+      dv[i] = g * av;
+      sa += g * v[i];
+      sb += g;
+    }
+    atomicAdd(&da[t * C + c], sa);
+    atomicAdd(&db[t * C + c], sb);
+  }
+}
+// ds[hw][c] = sum over bt of dy[(bt*HW + hw)*C + c]
+__global__ void film_pos_ds_kernel(const float* __restrict__ dy, long BT, long HW, int C, float* __restrict__ ds) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= HW * C) return;
+  float s = 0.f;
+  for (long bt = 0; bt < BT; ++bt) s += dy[bt * HW * C + idx];
+  ds[idx] = s;
+}
+
+// ---- Taylor sum backward: dd_k = sum_i c_ik dout_i;  dlast (+)= sum_i dout_i -----------------------------------------
+struct TaylorBArgs {
+  float* dd[8];
+  float coef[8][8];
+};
+template <int NO>
+__global__ void taylor_bwd_kernel(const float* __restrict__ dout, long dout_bstride, TaylorBArgs ta, int n_out, float* __restrict__ dlast,
+                                  long dlast_bstride, int accumulate, long B, long frame4) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * frame4) return;
+  const long b = idx / frame4, f = idx - b * frame4;
+  f32x4 acc[NO], sl = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < NO; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+    if (i < n_out) {
+      const f32x4 g = *(const f32x4*)(dout + b * dout_bstride + ((long)i * frame4 + f) * 4);
+      sl += g;
+#pragma unroll
+      for (int k = 0; k < NO; ++k) acc[k] += g * ta.coef[i][k];
+    }
+#pragma unroll
+  for (int k = 0; k < NO; ++k) ((f32x4*)ta.dd[k])[idx] = acc[k];
+  f32x4* dl = (f32x4*)(dlast + b * dlast_bstride + 4 * f);
+  *dl = accumulate ? (*dl + sl) : sl;
+}
+
+// ---- attention backward (small sequences: L <= 128): one lane per token, two phases ----------------------------------
+// phase A (lane = query i): softmax stats m_i, l_i over its keys, delta_i = do_i . o_i, dq_i
+// phase B (lane = key j):   dk_j = scale * sum_i ds_ij q_i,  dv_j = sum_i p_ij do_i,  ds_ij = p_ij (do_i . v_j - delta_i)
+template <int D>
+__global__ __launch_bounds__(128) void attn_bwd_small_kernel(const void* __restrict__ qkv, const void* __restrict__ dO, void* __restrict__ dqkv,
+                                                             int dtype, int C, TanteSeq sq, int G, int causal, float scale) {
+  constexpr int ST = D + 4;
+  extern __shared__ __attribute__((aligned(16))) float sm[];  // Q, K, V, dO rows [128][ST] each, then m, l, delta [128]
+  float* Qs = sm;
+  float* Ks = Qs + 128 * ST;
+  float* Vs = Ks + 128 * ST;
+  float* Gs = Vs + 128 * ST;
+  float* Ms = Gs + 128 * ST;
+  float* Ls = Ms + 128;
+  float* Ds = Ls + 128;
+  const int tid = threadIdx.x, h = blockIdx.y, L = sq.L;
+  const int g = tid / L, l = tid - g * L, s = blockIdx.x * G + g;
+  const bool live = (g < G) && (s < sq.nseq);
+  long tok = 0;
+  if (live) {
+    tok = (long)(s / sq.n_s0) * sq.S1 + (long)(s % sq.n_s0) * sq.S0 + (long)(l / sq.n_l0) * sq.P1 + (long)(l % sq.n_l0) * sq.P0;
+    const long e = tok * 3L * C + (long)h * D;
+    for (int i = 0; i < D; ++i) {
+      Qs[tid * ST + i] = ldx(qkv, dtype, e + i);
+      Ks[tid * ST + i] = ldx(qkv, dtype, e + C + i);
+      Vs[tid * ST + i] = ldx(qkv, dtype, e + 2L * C + i);
+      Gs[tid * ST + i] = ldx(dO, dtype, tok * (long)C + (long)h * D + i);
+    }
+  }
+  __syncthreads();
+  const int r0 = g * L;
+  float dq[D];
+  if (live) {
+    // ---- phase A ----
+    const int nk = causal ? l + 1 : L;
+    float m = -INFINITY;
+    for (int j = 0; j < nk; ++j) {
+      float sc = 0.f;
+      for (int i = 0; i < D; ++i) sc += Qs[tid * ST + i] * Ks[(r0 + j) * ST + i];
+      m = fmaxf(m, sc * scale);
+    }
+    float lsum = 0.f, o[D];
+    for (int i = 0; i < D; ++i) o[i] = 0.f;
+    for (int j = 0; j < nk; ++j) {
+      float sc = 0.f;
+      for (int i = 0; i < D; ++i) sc += Qs[tid * ST + i] * Ks[(r0 + j) * ST + i];
+      const float p = expf(sc * scale - m);
+      lsum += p;
+      for (int i = 0; i < D; ++i) o[i] += p * Vs[(r0 + j) * ST + i];
+    }
+    float delta = 0.f;
+    for (int i = 0; i < D; ++i) delta += Gs[tid * ST + i] * o[i] / lsum;
+    Ms[tid] = m; Ls[tid] = lsum; Ds[tid] = delta;
+    for (int i = 0; i < D; ++i) dq[i] = 0.f;
+    for (int j = 0; j < nk; ++j) {
+      float sc = 0.f, dp = 0.f;
+      for (int i = 0; i < D; ++i) {
+        sc += Qs[tid * ST + i] * Ks[(r0 + j) * ST + i];
+        dp += Gs[tid * ST + i] * Vs[(r0 + j) * ST + i];
+      }
+      const float p = expf(sc * scale - m) / lsum;
+      const float ds = p * (dp - delta) * scale;
+      for (int i = 0; i < D; ++i) dq[i] += ds * Ks[(r0 + j) * ST + i];
+    }
+  }
+  __syncthreads();
+  if (!live) return;
+  // ---- phase B: this lane is key l of its sequence; queries i that see it: i >= l (causal) or all ----
+  float dk[D], dv[D];
+  for (int i = 0; i < D; ++i) { dk[i] = 0.f; dv[i] = 0.f; }
+  for (int i = causal ? l : 0; i < L; ++i) {
+    const int qi = r0 + i;
+    float sc = 0.f, dp = 0.f;
+    for (int e = 0; e < D; ++e) {
+      sc += Qs[qi * ST + e] * Ks[tid * ST + e];
+      dp += Gs[qi * ST + e] * Vs[tid * ST + e];
+    }
+    const float p = expf(sc * scale - Ms[qi]) / Ls[qi];
+    const float ds = p * (dp - Ds[qi]) * scale;
+    for (int e = 0; e < D; ++e) {
+      dk[e] += ds * Qs[qi * ST + e];
+      dv[e] += p * Gs[qi * ST + e];
+    }
+  }
+  const long e = tok * 3L * C + (long)h * D;
+  for (int i = 0; i < D; ++i) {
+    stx(dqkv, dtype, e + i, dq[i]);
+    stx(dqkv, dtype, e + C + i, dk[i]);
+    stx(dqkv, dtype, e + 2L * C + i, dv[i]);
+  }
+}
+
+// ---- axis propagator backward: y = x + W2 gelu(W1 x + b1) + b2 along an axis of (outer, n, inner) -----------------------
+// one lane per column; writes dx = dy + W1^T (gelu'(pre) * (W2^T dy)), and materialises h = gelu(pre) and dpre for the
+// weight-gradient GEMMs (same (outer, n, inner) layout, fp32)
+template <int N>
+__global__ __launch_bounds__(256) void axis_mlp_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, long outer, int n,
+                                                           long inner, const float* __restrict__ w1, const float* __restrict__ b1,
+                                                           const float* __restrict__ w2, float* __restrict__ dx, float* __restrict__ hbuf,
+                                                           float* __restrict__ dpre) {
+  __shared__ float w1s[N * N], w2s[N * N], b1s[N];
+  for (int idx = threadIdx.x; idx < N * N; idx += 256) {
+    const int j = idx / N, a = idx % N;
+    const bool in = j < n && a < n;
+    w1s[idx] = in ? w1[j * n + a] : 0.f;   // [j][a]
+    w2s[idx] = in ? w2[j * n + a] : 0.f;   // [a_out][j_hidden] stored as [row][col]
+  }
+  if (threadIdx.x < N) b1s[threadIdx.x] = threadIdx.x < n ? b1[threadIdx.x] : 0.f;
+  __syncthreads();
+  const long col = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= outer * inner) return;
+  const long o = col / inner, i = col - o * inner;
+  const long base = o * (long)n * inner + i;
+  float xv[N], gy[N];
+#pragma unroll
+  for (int a = 0; a < N; ++a) {
+    xv[a] = a < n ? x[base + (long)a * inner] : 0.f;
+    gy[a] = a < n ? dy[base + (long)a * inner] : 0.f;
+  }
+  float gx[N];
+#pragma unroll
+  for (int a = 0; a < N; ++a) gx[a] = gy[a];
+  for (int j = 0; j < n; ++j) {
+    float pre = b1s[j];
+#pragma unroll
+    for (int a = 0; a < N; ++a) pre += w1s[j * N + a] * xv[a];
+    float dh = 0.f;  // (W2^T dy)_j = sum_a W2[a][j] dy_a
+#pragma unroll
+    for (int a = 0; a < N; ++a) dh += w2s[a * N + j] * gy[a];
+    const float dp = dh * act_df(pre, TANTE_ACT_GELU_ERF);
+    hbuf[base + (long)j * inner] = gelu_erf_f(pre);
+    dpre[base + (long)j * inner] = dp;
+#pragma unroll
+    for (int a = 0; a < N; ++a) gx[a] += w1s[j * N + a] * dp;
+  }
+#pragma unroll
+  for (int a = 0; a < N; ++a)
+    if (a < n) dx[base + (long)a * inner] = gx[a];
+}
+
+template <int N>
+void launch_axis_bwd(const float* x, const float* dy, long outer, int n, long inner, const float* w1, const float* b1, const float* w2,
+                     float* dx, float* h, float* dpre, hipStream_t s) {
+  const long cols = outer * inner;
+  hipLaunchKernelGGL(axis_mlp_bwd_kernel<N>, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, s, x, dy, outer, n, inner, w1, b1, w2, dx, h, dpre);
+}
+
+template <int D>
+void launch_attn_bwd(const void* qkv, const void* dO, void* dqkv, int dtype, int C, int n_head, const TanteSeq& sq, int causal, hipStream_t s) {
+  const int G = 128 / sq.L;
+  const size_t lds = (4 * 128 * (D + 4) + 3 * 128) * sizeof(float);
+  static bool set = false;
+  if (!set && lds > 64 * 1024) {
+    hipFuncSetAttribute((const void*)attn_bwd_small_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    set = true;
+  }
+  hipLaunchKernelGGL(attn_bwd_small_kernel<D>, dim3((sq.nseq + G - 1) / G, n_head), dim3(128), lds, s, qkv, dO, dqkv, dtype, C, sq, G, causal,
+                     1.0f / sqrtf((float)D));
+}
+
+}  // namespace
+
+extern "C" int tante_layernorm_fwd(const float* x, int64_t M, int C, float eps, void* xhat, int out_dtype, float* stats, void* stream) {
+  if (!x || !xhat || !stats || M <= 0 || C <= 0) TANTE_FAIL(-1, "tante_layernorm_fwd: bad argument");
+  hipLaunchKernelGGL(ln_fwd_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, (long)M, C, eps, xhat, out_dtype, stats);
+  TANTE_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int tante_layernorm_bwd(const void* dxhat, int g_dtype, const float* x, const float* stats, const float* dskip, int64_t M, int C,
+                                   float* dx, void* stream) {
+  if (!dxhat || !x || !stats || !dx || M <= 0 || C <= 0) TANTE_FAIL(-1, "tante_layernorm_bwd: bad argument");
+  hipLaunchKernelGGL(ln_bwd_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, (hipStream_t)stream, dxhat, g_dtype, x, stats, dskip, (long)M, C, dx);
+  TANTE_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int tante_act_fwd(const void* pre, int in_dtype, void* post, int out_dtype, int64_t n, int act, void* stream) {
+  if (!pre || !post || n <= 0) TANTE_FAIL(-1, "tante_act_fwd: bad argument");
+  hipLaunchKernelGGL(act_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pre, in_dtype, post, out_dtype, (long)n, act);
+  TANTE_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int tante_act_bwd(const void* dpost, int d_dtype, const void* pre, int pre_dtype, void* dpre, int out_dtype, int64_t n, int act,
+                             void* stream) {
+  if (!dpost || !pre || !dpre || n <= 0) TANTE_FAIL(-1, "tante_act_bwd: bad argument");
+  hipLaunchKernelGGL(act_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dpost, d_dtype, pre, pre_dtype, dpre,
+                     out_dtype, (long)n, act);
+  TANTE_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int tante_colsum(const void* x, int dtype, int64_t outer, int C, int64_t inner, float* out, int accumulate, void* stream) {
+  if (!x || !out || outer <= 0 || C <= 0 || inner <= 0) TANTE_FAIL(-1, "tante_colsum: bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  if (!accumulate && hipMemsetAsync(out, 0, (size_t)C * sizeof(float), s) != hipSuccess) TANTE_FAIL(-3, "tante_colsum: memset failed");
+  if (inner == 1) {
+    long chunks = (outer + 1023) / 1024;
+    if (chunks > 1024) chunks = 1024;
+    const long chunk = (outer + chunks - 1) / chunks;
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((outer + chunk - 1) / chunk), (unsigned)((C + 63) / 64)), dim3(256), 0, s, x, dtype,
+                       (long)outer, C, (long)inner, chunk, out);
+  } else {
+    if (outer > 65535 * 16L) TANTE_FAIL(-2, "tante_colsum: outer too large");
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)outer, (unsigned)C), dim3(256), 0, s, x, dtype, (long)outer, C, (long)inner, 0L, out);
+  }
+  TANTE_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int tante_film_pos_fwd(const float* v, const float* a, const float* b, const float* s_emb, int64_t rows, int C, int T, int64_t HW,
+                                  float* y, void* stream) {
+  if (!v || !a || !b || !s_emb || !y || rows <= 0 || C <= 0 || C % 4 || T <= 0 || HW <= 0) TANTE_FAIL(-1, "tante_film_pos_fwd: bad argument");
+  const long n4 = rows * (C / 4);
+  hipLaunchKernelGGL(film_pos_fwd_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, v, a, b, s_emb, (long)rows, C / 4,
+                     T, (long)HW, y);
+  TANTE_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int tante_film_pos_bwd(const float* dy, const float* v, const float* a, int64_t BT, int64_t HW, int C, int T, float* dv, float* da,
+                                  float* db, float* ds, void* stream) {
+  if (!dy || !v || !a || !dv || !da || !db || !ds || BT <= 0 || HW <= 0 || C <= 0 || T <= 0) TANTE_FAIL(-1, "tante_film_pos_bwd: bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(da, 0, (size_t)T * C * sizeof(float), s) != hipSuccess || hipMemsetAsync(db, 0, (size_t)T * C * sizeof(float), s) != hipSuccess)
+    TANTE_FAIL(-3, "tante_film_pos_bwd: memset failed");
+  const long chunk = 64;
+  hipLaunchKernelGGL(film_pos_bwd_kernel, dim3((unsigned)((HW + chunk - 1) / chunk), (unsigned)BT), dim3(256), 0, s, dy, v, a, (long)HW, C, T, chunk,
+                     dv, da, db);
+  hipLaunchKernelGGL(film_pos_ds_kernel, dim3((unsigned)((HW * C + 255) / 256)), dim3(256), 0, s, dy, (long)BT, (long)HW, C, ds);
+  TANTE_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int tante_taylor_bwd(const float* dout, int64_t dout_bstride, float* const* dderivs, int n_order, double dt, int n_out, float* dlast,
+                                int64_t dlast_bstride, int accumulate, int64_t B, int64_t frame, void* stream) {
+  if (!dout || !dderivs || !dlast) TANTE_FAIL(-1, "tante_taylor_bwd: null pointer");
+  if (n_order < 1 || n_order > 8 || n_out < 1 || n_out > 8) TANTE_FAIL(-2, "tante_taylor_bwd: order and n_out must be in 1..8");
+  if (frame % 4 || dout_bstride % 4 || dlast_bstride % 4) TANTE_FAIL(-2, "tante_taylor_bwd: sizes must be multiples of 4 floats");
+  TaylorBArgs ta;
+  for (int k = 0; k < 8; ++k) ta.dd[k] = k < n_order ? dderivs[k] : nullptr;
+  for (int i = 0; i < 8; ++i) {
+    double fact = 1.0;
+    for (int k = 0; k < 8; ++k) {
+      fact *= (double)(k + 1);
+      double p = 1.0;
+      for (int e = 0; e <= k; ++e) p *= (double)(i + 1) * dt;
+      ta.coef[i][k] = (float)(p / fact);
+    }
+  }
+  const long n4 = B * (frame / 4);
+  const dim3 grid((unsigned)((n4 + 255) / 256));
+  hipStream_t s = (hipStream_t)stream;
+#define TANTE_TB(NO) \
+  case NO: hipLaunchKernelGGL(taylor_bwd_kernel<NO>, grid, dim3(256), 0, s, dout, (long)dout_bstride, ta, n_out, dlast, (long)dlast_bstride, accumulate, (long)B, (long)(frame / 4)); break;
+  switch (n_order) { TANTE_TB(1) TANTE_TB(2) TANTE_TB(3) TANTE_TB(4) TANTE_TB(5) TANTE_TB(6) TANTE_TB(7) TANTE_TB(8) }
+#undef TANTE_TB
+  TANTE_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int tante_attention_bwd(const void* qkv, const void* dO, void* dqkv, int dtype, int C, int n_head, const TanteSeq* seq, int causal,
+                                   void* stream) {
+  if (!qkv || !dO || !dqkv || !seq) TANTE_FAIL(-1, "tante_attention_bwd: null pointer");
+  if (n_head <= 0 || C % n_head) TANTE_FAIL(-1, "tante_attention_bwd: bad heads");
+  if (seq->L > 128) TANTE_FAIL(-2, "tante_attention_bwd: sequences longer than 128 are not on the train path yet (L=%d)", seq->L);
+  hipStream_t s = (hipStream_t)stream;
+  switch (C / n_head) {
+    case 4: launch_attn_bwd<4>(qkv, dO, dqkv, dtype, C, n_head, *seq, causal, s); break;
+    case 8: launch_attn_bwd<8>(qkv, dO, dqkv, dtype, C, n_head, *seq, causal, s); break;
+    case 16: launch_attn_bwd<16>(qkv, dO, dqkv, dtype, C, n_head, *seq, causal, s); break;
+    case 32: launch_attn_bwd<32>(qkv, dO, dqkv, dtype, C, n_head, *seq, causal, s); break;
+    case 64: launch_attn_bwd<64>(qkv, dO, dqkv, dtype, C, n_head, *seq, causal, s); break;
+    default: TANTE_FAIL(-2, "tante_attention_bwd: head dim %d unsupported", C / n_head);
+  }
+  TANTE_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int tante_axis_mlp_bwd(const float* x, const float* dy, int64_t outer, int n, int64_t inner, const float* w1, const float* b1,
+                                  const float* w2, float* dx, float* h, float* dpre, void* stream) {
+  if (!x || !dy || !w1 || !b1 || !w2 || !dx || !h || !dpre || outer <= 0 || n <= 0 || inner <= 0) TANTE_FAIL(-1, "tante_axis_mlp_bwd: bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  if (n <= 4) launch_axis_bwd<4>(x, dy, outer, n, inner, w1, b1, w2, dx, h, dpre, s);
+  else if (n <= 8) launch_axis_bwd<8>(x, dy, outer, n, inner, w1, b1, w2, dx, h, dpre, s);
+  else if (n <= 16) launch_axis_bwd<16>(x, dy, outer, n, inner, w1, b1, w2, dx, h, dpre, s);
+  else if (n <= 32) launch_axis_bwd<32>(x, dy, outer, n, inner, w1, b1, w2, dx, h, dpre, s);
+  else if (n <= 48) launch_axis_bwd<48>(x, dy, outer, n, inner, w1, b1, w2, dx, h, dpre, s);
+  else if (n <= 64) launch_axis_bwd<64>(x, dy, outer, n, inner, w1, b1, w2, dx, h, dpre, s);
+  else TANTE_FAIL(-2, "tante_axis_mlp_bwd: axis length %d > 64 is not on the train path yet", n);
+  TANTE_CHECK_LAUNCH();
+  return 0;
+}

@@ -521,6 +521,18 @@ __device__ __forceinline__ long w_src_index(int layout, int n, int k, int N, int
     }
     case TANTE_W_DECONV_NCHW:  // (Cin, Cout, P, P); n = (co, kh, kw)
       return (long)k * N + n;
+    case TANTE_W_LINEAR_T:  // dgrad of a linear / of a conv read as (ci,kh,kw): packed[n'][k'] = W[k'][n'], W is (K, N)
+      return (long)k * N + n;
+    case TANTE_W_CONV_NHWC_T: {  // dgrad of a CONV_NHWC stage: packed[n' = (kh,kw,ci)][k' = co] = W[co][ci][kh][kw], Co = Cin
+      const int kh = n / (P * Co), kw = (n / Co) % P, ci = n % Co;
+      return (((long)k * Co + ci) * P + kh) * P + kw;
+    }
+    case TANTE_W_DECONV_NHWC_T: {  // dgrad of a DECONV_NHWC stage: packed[n' = ci][k' = (kh,kw,co)] = W[ci][co][kh][kw], Co = Cout
+      const int kh = k / (P * Co), kw = (k / Co) % P, co = k % Co;
+      return (((long)n * Co + co) * P + kh) * P + kw;
+    }
+    case TANTE_W_DECONV_NCHW_T:  // dgrad of the DECONV_NCHW stage: packed[n' = ci][k' = (co,kh,kw)] = W[ci][k']  (native order)
+      return (long)n * K + k;
     default:
       return (long)n * K + k;
   }
@@ -660,7 +672,11 @@ extern "C" int tante_pack_weight(const float* w, const float* bias, const float*
   int rc = tante_pack_geom(N, K, compute, &geo);
   if (rc) return rc;
   if (!w || !w_out || !bias_out) TANTE_FAIL(-1, "tante_pack_weight: null pointer");
-  if (layout != TANTE_W_LINEAR && (P <= 0 || C_other <= 0)) TANTE_FAIL(-1, "tante_pack_weight: conv layout needs P, C_other");
+  const bool needs_geom = layout == TANTE_W_CONV_NHWC || layout == TANTE_W_DECONV_NHWC || layout == TANTE_W_DECONV_NCHW ||
+                          layout == TANTE_W_CONV_NHWC_T || layout == TANTE_W_DECONV_NHWC_T;
+  if (layout < 0 || layout > TANTE_W_DECONV_NCHW_T) TANTE_FAIL(-1, "tante_pack_weight: bad layout %d", layout);
+  if (needs_geom && (P <= 0 || C_other <= 0)) TANTE_FAIL(-1, "tante_pack_weight: conv layout needs P, C_other");
+  if (layout >= TANTE_W_LINEAR_T && bias) TANTE_FAIL(-1, "tante_pack_weight: a data-gradient packing has no bias");
   if ((gamma || beta) && layout != TANTE_W_LINEAR) TANTE_FAIL(-1, "tante_pack_weight: LayerNorm fold only for linear weights");
   hipStream_t s = (hipStream_t)stream;
   const int cpr = geo.cb * 4;

@@ -353,12 +353,17 @@ class TANTE(nn.Module):
 
     def forward(self, input: torch.Tensor, out_T=1, out: Optional[torch.Tensor] = None):
         """`out` (optional, deg=True only): a (B, output_length, D, H, W) fp32 view with contiguous frames (e.g. the next
-        slots of a rollout buffer) that receives the prediction instead of a fresh tensor."""
-        _no_autograd(self)
+        slots of a rollout buffer) that receives the prediction instead of a fresh tensor.
+        With autograd enabled the differentiable path (train_forward.py: HIP forward + HIP backward kernels) runs."""
         if not input.is_cuda:
             raise RuntimeError("tante_amd.TANTE runs on the GPU only (no CPU fallback); move the input to cuda")
         if input.shape[1] != self.T:
             input = input[:, -self.T:]
+        if torch.is_grad_enabled() and (input.requires_grad or any(p.requires_grad for p in self.parameters())):
+            from .train_forward import tante_train_forward
+            if out is not None:
+                raise ValueError("out= is an inference-path option")
+            return tante_train_forward(self, input.to(torch.float32).contiguous(), resolve_compute(self.compute))
         inp = input.detach().to(torch.float32)
         B, T, D, H, W = inp.shape
         frame = D * H * W

@@ -1,0 +1,102 @@
+"""Differentiable (training) forward of TANTE, composed from tante_amd.autograd ops.
+
+Same arithmetic as the inference path, one HIP launch per layer instead of the fused block kernel, because the
+backward pass needs the intermediate activations (normalised tokens, packed q/k/v, attention output, MLP pre-activation).
+The rollout harness back-propagates through every re-fed frame exactly like the reference (trainer/trainer.py:154: no
+detach), the tape being torch.autograd's.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib as L
+from . import kernels as K
+from .autograd import (ActFn, AttentionFn, AxisMlpFn, DeconvFn, FilmPosFn, LayerNormFn, LinearFn, PatchEmbedFn, TaylorFn)
+
+
+def _folded(lin_w, lin_b, ln):
+    """LayerNorm affine folded into the consumer: (W diag(gamma), b + W beta) -- parameter-sized torch expressions whose
+    autograd distributes the gradients back to W, b, gamma, beta."""
+    return lin_w * ln.weight[None, :], lin_b + lin_w @ ln.bias
+
+
+def block_train(blk, x: torch.Tensor, seq, causal: bool, compute: int) -> torch.Tensor:
+    if blk.training and blk.p_drop > 0.0:
+        raise NotImplementedError("dropout > 0 is not implemented on the HIP train path yet (use dropout=0.0)")
+    adt = K.act_torch_dtype(compute)
+    a, m = blk.attn, blk.mlp
+    w_in, b_in = _folded(a.in_proj_weight, a.in_proj_bias, blk.ln1)
+    xh = LayerNormFn.apply(x, blk.ln1.eps, adt)
+    qkv = LinearFn.apply(xh, w_in, b_in, None, compute, adt)
+    o = AttentionFn.apply(qkv, seq, blk.embed_dim, blk.n_head, causal)
+    x = LinearFn.apply(o, a.out_proj.weight, a.out_proj.bias, x, compute, torch.float32)
+    w1, b1 = _folded(m[0].weight, m[0].bias, blk.ln2)
+    xh2 = LayerNormFn.apply(x, blk.ln2.eps, adt)
+    hpre = LinearFn.apply(xh2, w1, b1, None, compute, adt)
+    h = ActFn.apply(hpre, L.ACT_GELU_TANH, adt)
+    return LinearFn.apply(h, m[2].weight, m[2].bias, x, compute, torch.float32)
+
+
+def backbone_train(bb, x: torch.Tensor, B: int, compute: int) -> torch.Tensor:
+    T, H, W, C_ = bb.T, bb.H, bb.W, bb.C
+    vp, hp, tp = bb.vertical_propagator, bb.horizontal_propagator, bb.temporal_propagator
+    x = AxisMlpFn.apply(x, vp[0].weight, vp[0].bias, vp[2].weight, vp[2].bias, B * T, H, W * C_, compute)
+    x = AxisMlpFn.apply(x, hp[0].weight, hp[0].bias, hp[2].weight, hp[2].bias, B * T * H, W, C_, compute)
+    x = AxisMlpFn.apply(x, tp[0].weight, tp[0].bias, tp[2].weight, tp[2].bias, B, T, H * W * C_, compute)
+    for i, axis in enumerate(bb.attn_axes):
+        if axis == "C":
+            raise NotImplementedError("the channel-attention letter 'C' is not on the HIP train path yet")
+        x = block_train(bb.blocks[i], x, K.make_seq(axis, B, T, H, W), axis == "T", compute)
+    return x
+
+
+def encoder_train(enc, inp: torch.Tensor, compute: int) -> torch.Tensor:
+    B, T, D, H, W = inp.shape
+    adt = K.act_torch_dtype(compute)
+    n_img, h, w = B * T, H, W
+    z = inp.reshape(n_img, D, H, W)
+    for i in range(3):
+        conv = getattr(enc, f"enc_conv_{i + 1}").conv
+        p, ci = enc.P[i], enc.chans[i]
+        last = i == 2
+        z = PatchEmbedFn.apply(z, conv.weight, conv.bias, n_img, h, w, ci, p, i == 0, compute, torch.float32 if last else adt)
+        if not last:
+            z = ActFn.apply(z, L.ACT_GELU_ERF, adt)
+        h, w = h // p, w // p
+    return z                                   # (B*T*Hp*Wp, C) fp32, before FiLM / positional embeddings
+
+
+def decoder_train(dec, a: torch.Tensor, n_img: int, compute: int) -> torch.Tensor:
+    adt = K.act_torch_dtype(compute)
+    h, w = dec.patch_shape
+    x = a
+    for i in range(3):
+        dc = getattr(dec, f"dec_conv_{i + 1}").deconv
+        p, co = dec.P[i], dec.chans[i + 1]
+        last = i == 2
+        x = DeconvFn.apply(x.reshape(-1, dec.chans[i]), dc.weight, dc.bias, n_img, h, w, p, last, compute, adt)
+        if not last:
+            x = ActFn.apply(x, L.ACT_GELU_ERF, adt)
+        h, w = h * p, w * p
+    return x                                   # (n_img, D, H, W) fp32
+
+
+def tante_train_forward(model, inp: torch.Tensor, compute: int) -> torch.Tensor:
+    if not model.deg:
+        raise NotImplementedError("the adaptive-dt variant (deg=False) is not on the HIP train path yet")
+    B, T, D, H, W = inp.shape
+    Hp, Wp, C_ = model.H_p, model.W_p, model.C
+    HW = Hp * Wp
+    z = encoder_train(model.encoder, inp, compute)
+    te = model.t_encode
+    t = model.t_seq.to(inp.device, torch.float32)[:, None]
+    fa = 1.0 + te.condition_to_scale(t)                                        # (T, C): film(x, t) = x * (1 + scale) + shift
+    fb = te.condition_to_shift(t) + model.t_emb.view(T, C_)
+    x = FilmPosFn.apply(z, fa.contiguous(), fb.contiguous(), model.s_emb.view(HW, C_), T, HW)
+    derivs = []
+    for i in range(model.taylor_order):
+        x = backbone_train(model.blocks[i], x, B, compute)
+        last = x.view(B, T, HW, C_)[:, -1].reshape(B * HW, C_)
+        d = decoder_train(model.decoders[i], last, B, compute)
+        derivs.append(d.view(B, 1, D, H, W))
+    return TaylorFn.apply(inp, model.frame_interval, model.output_length, *derivs)

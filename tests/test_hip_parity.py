@@ -538,3 +538,61 @@ def test_clip_adamw_against_reference_step(dev):
     # the packed-weight caches notice the raw-pointer update
     from tante_amd.attn_backbone import _WEIGHT_EPOCH
     assert _WEIGHT_EPOCH[0] >= 1
+
+
+# ---------------------------------------------------------------------------------------------------
+# train path: HIP forward + HIP backward against the reference's full gradient fixture (g9)
+# ---------------------------------------------------------------------------------------------------
+def _g9_model(dev):
+    import tante_amd
+    g = load_golden("g9_trainstep")
+    md = tante_amd.TanteMetadata(n_fields=2, spatial_resolution=(16, 16))
+    m = tante_amd.TANTE(in_T=4, dset_metadata=md, taylor_order=2, attn_axes="TH-WL", n_head=2, embed_dim=32, patch_scale=8,
+                        dropout=0.0).to(dev).train()
+    m.load_state_dict(split_prefix(g, "w0."))
+    return g, m, md
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_g9_train_step_gradients(dev, mode):
+    import tante_amd
+    from tante_amd.autograd import MseMeanFn
+    g, m, md = _g9_model(dev)
+    m.set_compute(mode)
+    fmt = tante_amd.DefaultChannelsFirstFormatter(md)
+    batch = {"input": g["inp"].to(dev), "output": g["out"].to(dev)}
+    y_pred, y_ref = tante_amd.rollout_model(m, batch, fmt, 4)            # BPTT through 4 re-fed steps
+    loss = MseMeanFn.apply(y_pred, y_ref)
+    loss.backward()
+    tol = 2e-4 if mode == "fp32" else 4e-2
+    assert abs(float(loss) - float(g["loss0"])) < (1e-5 if mode == "fp32" else 2e-3) * float(g["loss0"])
+    close(y_pred, g["y_pred"], mode, scale=3.0)
+    worst = 0.0
+    for k, p in m.named_parameters():
+        assert p.grad is not None, k
+        e = max_rel(p.grad.detach().cpu(), g["g0." + k])
+        worst = max(worst, e)
+        assert e < tol, (k, e)
+    # global gradient norm as clip_grad_norm_ sees it
+    gn = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in m.parameters()))
+    assert abs(float(gn) - float(g["gnorm0"])) < (1e-4 if mode == "fp32" else 2e-2) * float(g["gnorm0"])
+
+
+def test_g9_two_full_train_steps(dev):
+    """loss -> backward -> clip -> AdamW, twice, against the reference's weights after each step (fp32)."""
+    import tante_amd
+    from tante_amd.autograd import MseMeanFn
+    g, m, md = _g9_model(dev)
+    lr, wd, b1, b2, eps, max_norm = (float(v) for v in g["hyper"])
+    opt = tante_amd.FlatAdamW(m.parameters(), lr=lr, weight_decay=wd, betas=(b1, b2), eps=eps, max_norm=max_norm)
+    fmt = tante_amd.DefaultChannelsFirstFormatter(md)
+    batch = {"input": g["inp"].to(dev), "output": g["out"].to(dev)}
+    for step in range(2):
+        opt.zero_grad()
+        y_pred, y_ref = tante_amd.rollout_model(m, batch, fmt, 4)
+        loss = MseMeanFn.apply(y_pred, y_ref)
+        loss.backward()
+        assert abs(float(loss) - float(g[f"loss{step}"])) < 2e-4 * float(g[f"loss{step}"])
+        opt.step()
+        for k, p in m.named_parameters():
+            assert float((p.detach().cpu() - g[f"w{step + 1}." + k]).abs().max()) < 3e-2 * lr, (step, k)

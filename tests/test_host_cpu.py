@@ -56,8 +56,11 @@ def test_cpu_tensors_are_rejected():
     m = tante_amd.TANTE(in_T=2, dset_metadata=md, attn_axes="T", n_head=2, embed_dim=16, patch_scale=8).eval()
     with torch.no_grad(), pytest.raises(RuntimeError, match="no CPU fallback"):
         m(torch.zeros(1, 2, 1, 16, 16))
-    with pytest.raises(NotImplementedError):     # autograd graph is not recorded yet: refuse instead of silently detaching
+    with pytest.raises(RuntimeError, match="no CPU fallback"):     # the differentiable path is GPU-only as well
         m(torch.zeros(1, 2, 1, 16, 16))
+    blk = tante_amd.TransformerBlock(16, 2)
+    with pytest.raises(NotImplementedError):     # stand-alone modules do not record a graph: refuse instead of silently detaching
+        blk(torch.zeros(1, 2, 16))
 
 
 @pytest.mark.parametrize("letter", list("THWLYXA"))
