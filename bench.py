@@ -37,6 +37,8 @@ def parse():
     p.add_argument("--dtype", default=None, choices=["bf16", "fp32"])
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-roofline", action="store_true")
+    p.add_argument("--no-train", action="store_true", help="skip the train-step leg (configs/tante_trl.yaml)")
+    p.add_argument("--train-steps", type=int, default=3)
     return p.parse_args()
 
 
@@ -141,6 +143,40 @@ def main():
                     "others": {k: {"TFLOP/s": round(v[1] / (v[0] * 1e-3) / 1e12, 2), "avg_launch_us": round(1e3 * v[0] / v[2], 2),
                                    "launches": v[2]} for k, v in tot.items() if k != name}}
 
+    train = None
+    if not args.no_train:
+        # second leg of the metric: train-step samples/sec on cfg3 (TRL-2D shaped fields, batch 8 per GPU, 4-step BPTT,
+        # MSE + clip + AdamW, one summed gradient all-reduce per step when N > 1)
+        tcfg = tante_amd.load_config(os.path.join(ROOT, "configs", "tante_trl.yaml"))
+        twl = tcfg["workload"]
+        tmd = tante_amd.TanteMetadata(n_fields=twl["n_fields"], spatial_resolution=tuple(twl["spatial_resolution"]))
+        torch.manual_seed(tcfg.get("seed", 211))
+        drop = float(os.environ.get("TANTE_TRAIN_DROPOUT", tcfg["model"].get("dropout", 0.0)))
+        tmodel = tante_amd.build_model(tcfg, tmd, dropout=drop).to(dev).train().set_compute(dtype)
+        oc = tcfg["optimizer"]
+        opt = tante_amd.FlatAdamW(tmodel.parameters(), lr=oc["lr"], weight_decay=oc["weight_decay"], max_norm=1.0)
+        tB, tn = twl["batch_size"], twl["n_steps_output"]
+        tgen = torch.Generator().manual_seed(1000 + rank)
+        tbatch = {"input": torch.randn(tB, twl["n_steps_input"], *twl["spatial_resolution"], twl["n_fields"], generator=tgen).to(dev),
+                  "output": torch.randn(tB, tn, *twl["spatial_resolution"], twl["n_fields"], generator=tgen).to(dev)}
+        tfmt = tante_amd.DefaultChannelsFirstFormatter(tmd)
+        tante_amd.train_step(tmodel, opt, tbatch, tfmt, tn, world)          # warm-up (packs, allocator)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.train_steps):
+            tante_amd.train_step(tmodel, opt, tbatch, tfmt, tn, world)
+        sync()
+        tel = time.perf_counter() - t0
+        if dist is not None:
+            tt = torch.tensor([tel], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            tel = float(tt.item())
+        train = {"metric": "train-step samples/sec, TANTE on 128x384 TRL-2D (4-step BPTT, MSE, clip, AdamW)",
+                 "value": round(tB * world * args.train_steps / tel, 2), "unit": "samples/s", "ms_per_step": round(1e3 * tel / args.train_steps, 2),
+                 "global_batch": tB * world, "dropout": drop, "steps": args.train_steps,
+                 "collective": "one summed all-reduce of the flat fp32 gradient bucket (%d params)" % opt.numel if world > 1 else None}
+        del tmodel, opt, tbatch
+
     cpu = None
     if not args.no_cpu_baseline and rank == 0 and world == 1:
         from oracle import tante_oracle as O
@@ -169,7 +205,7 @@ def main():
                "config": {"workload": os.path.basename(args.config), "fields": D, "resolution": list(res), "batch_per_gpu": B,
                           "n_steps_input": T_in, "n_steps_rollout": n_steps, "taylor_order": cfg["model"].get("taylor_order", 1),
                           "attn_axes": cfg["model"].get("attn_axes"), "parallelism": f"batch-sharded x{world} (no collective)"},
-               "roofline": roofline, "cpu_baseline": cpu}
+               "roofline": roofline, "cpu_baseline": cpu, "train": train}
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

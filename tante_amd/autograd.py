@@ -99,10 +99,16 @@ class LinearFn(Function):
         N = W.shape[0]
         comp = ctx.compute
         da = dW = db = None
-        if ctx.needs_input_grad[0]:
-            pwt = K.pack_weight(W, None, comp, L.W_LINEAR_T, N=Kk, K=N)        # dgrad GEMM: (M, N) x (N, K)
+        if ctx.needs_input_grad[0]:       # dgrad GEMM: (M, N) x (N, K); the contraction (N) is chunked to the kernel's K limit
+            chunks = [(c0, min(512, N - c0)) for c0 in range(0, N, 512)]
             da = torch.empty(M, Kk, dtype=a.dtype, device=a.device)
-            K.linear(dy, pwt, da, M=M)
+            acc = None
+            for ci, (c0, ck) in enumerate(chunks):
+                pwt = K.pack_weight(W[c0:c0 + ck], None, comp, L.W_LINEAR_T, N=Kk, K=ck)
+                last = ci == len(chunks) - 1
+                out = da if last else (acc if acc is not None else torch.empty(M, Kk, dtype=torch.float32, device=a.device))
+                K.linear(dy, pw=pwt, out=out, M=M, a_n0=M, a_s0=N, a_off=c0, residual=acc)
+                acc = out
         if ctx.needs_input_grad[1]:
             dW = wgrad(_rm_linear(dy), _rm_linear(a), M, N, Kk, (N, Kk), comp, device=a.device)
         if ctx.has_bias and ctx.needs_input_grad[2]:

@@ -87,7 +87,7 @@ def _run(g: L.Gemm):
     L.check(L.lib().tante_gemm(C.byref(g), _stream()), "tante_gemm")
 
 
-def linear(a: torch.Tensor, pw: PackedWeight, out: torch.Tensor, *, M: Optional[int] = None, act: int = L.ACT_NONE,
+def linear(a: torch.Tensor, pw: PackedWeight = None, out: torch.Tensor = None, *, M: Optional[int] = None, act: int = L.ACT_NONE,
            ln: bool = False, ln_eps: float = 1e-5, residual: Optional[torch.Tensor] = None,
            a_n0: Optional[int] = None, a_s1: int = 0, a_s0: Optional[int] = None, a_off: int = 0,
            out_ld: Optional[int] = None):

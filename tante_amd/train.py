@@ -1,0 +1,32 @@
+"""One optimisation step of the reference's Trainer.train_one_epoch (trainer/trainer.py:174-207) on the HIP path:
+
+    y_pred, y_ref = rollout_model(model, batch, "train")          # BPTT through n_steps_output re-fed frames
+    loss = MSE(y_pred, y_ref).mean()
+    loss.backward(); clip_grad_norm_(1.0); AdamW.step(); zero_grad()
+
+Data parallel: the batch is sharded over ranks (one process per GPU); the ONLY collective is a summed all-reduce of the flat
+gradient bucket (RCCL over xGMI through torch.distributed), and the division by the world size is folded into the clip + AdamW
+launch.  The clip therefore uses the norm of the AVERAGED gradient, exactly as a single process would on the full batch.
+"""
+from __future__ import annotations
+
+from typing import Dict
+
+import torch
+
+from . import dist as D
+from .autograd import MseMeanFn
+from .optim import FlatAdamW
+from .rollout import rollout_model
+
+
+def train_step(model, opt: FlatAdamW, batch: Dict[str, torch.Tensor], formatter, n_steps_output: int, world: int = 1,
+               lr: float = None) -> torch.Tensor:
+    opt.zero_grad()
+    y_pred, y_ref = rollout_model(model, batch, formatter, n_steps_output)
+    loss = MseMeanFn.apply(y_pred, y_ref)
+    loss.backward()
+    if world > 1:
+        D.allreduce_sum_(opt.flat_g)
+    opt.step(grad_scale=1.0 / world, lr=lr)
+    return loss.detach()
