@@ -250,9 +250,10 @@ typedef struct TanteRowMat {
 
 /* dW[i][j] (+)= sum_r U[r][i] * V[r][j], written at the parameter's own index: layout is a TANTE_W_* source layout of
  * tante_pack_weight and (n, k) = (i, j), or (j, i) when swap != 0 (transposed-conv weights: U = input pixels, V = output-gradient
- * patches).  MFMA in `compute`, fp32 atomics across the row split. */
-int tante_wgrad(const TanteRowMat* U, const TanteRowMat* V, int64_t R, int I, int J, float* dW, int layout, int P, int C_other, int swap,
-                int compute, int accumulate, void* stream);
+ * patches).  dbias (may be NULL): dbias[i] (+)= sum_r U[r][i], the bias gradient of a Linear / patch-embed layer, computed from
+ * the tiles that are staged anyway.  MFMA in `compute`, fp32 atomics across the row split. */
+int tante_wgrad(const TanteRowMat* U, const TanteRowMat* V, int64_t R, int I, int J, float* dW, float* dbias, int layout, int P,
+                int C_other, int swap, int compute, int accumulate, void* stream);
 
 const char* tante_last_error(void);
 int tante_abi_version(void);

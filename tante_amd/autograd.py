@@ -18,6 +18,25 @@ from . import kernels as K
 
 _DT = {torch.float32: L.F32, torch.bfloat16: L.BF16}
 
+# Packed copies of a weight are valid until the weight changes; within one train step (4 BPTT calls x forward + backward) the
+# same (tensor, layout) is needed many times.  Keyed by the source tensor's identity and version; cleared by the optimiser.
+_PACKS = {}
+
+
+def clear_pack_cache():
+    _PACKS.clear()
+
+
+def _packed(W, b, compute, layout=L.W_LINEAR, **kw):
+    key = (W.data_ptr(), W._version, tuple(W.shape), None if b is None else (b.data_ptr(), b._version), compute, layout,
+           tuple(sorted(kw.items())))
+    hit = _PACKS.get(key)
+    if hit is None:
+        hit = K.pack_weight(W, b, compute, layout, **kw)
+        _PACKS[key] = (hit, W, b)        # keep the sources alive so that data_ptr stays unique
+        return hit
+    return hit[0]
+
 
 def _s():
     return torch.cuda.current_stream().cuda_stream
@@ -42,11 +61,13 @@ def _rm_patch(t: torch.Tensor, nhwc: bool, n_img: int, Hin: int, Win: int, Cin: 
 
 
 def wgrad(U: L.RowMat, V: L.RowMat, R: int, I: int, J: int, out_shape, compute: int, layout: int = L.W_LINEAR, P: int = 0,
-          C_other: int = 0, swap: bool = False, device=None) -> torch.Tensor:
+          C_other: int = 0, swap: bool = False, device=None, with_bias: bool = False):
+    """dW (and, with_bias, db[i] = sum_r U[r][i] from the same staged tiles)."""
     dW = torch.empty(out_shape, dtype=torch.float32, device=device)
-    L.check(L.lib().tante_wgrad(C.byref(U), C.byref(V), R, I, J, dW.data_ptr(), layout, P, C_other, int(swap), compute, 0, _s()),
-            "tante_wgrad")
-    return dW
+    db = torch.empty(I, dtype=torch.float32, device=device) if with_bias else None
+    L.check(L.lib().tante_wgrad(C.byref(U), C.byref(V), R, I, J, dW.data_ptr(), None if db is None else db.data_ptr(), layout, P,
+                                C_other, int(swap), compute, 0, _s()), "tante_wgrad")
+    return (dW, db) if with_bias else dW
 
 
 def colsum(x: torch.Tensor, outer: int, Cc: int, inner: int) -> torch.Tensor:
@@ -84,7 +105,7 @@ class LinearFn(Function):
     def forward(ctx, a, W, b, residual, compute, out_dtype):
         M, Kk = a.shape
         N = W.shape[0]
-        pw = K.pack_weight(W, b, compute)
+        pw = _packed(W, b, compute)
         out = torch.empty(M, N, dtype=torch.float32 if residual is not None else out_dtype, device=a.device)
         K.linear(a, pw, out, M=M, residual=residual)
         ctx.save_for_backward(a, W)
@@ -104,14 +125,16 @@ class LinearFn(Function):
             da = torch.empty(M, Kk, dtype=a.dtype, device=a.device)
             acc = None
             for ci, (c0, ck) in enumerate(chunks):
-                pwt = K.pack_weight(W[c0:c0 + ck], None, comp, L.W_LINEAR_T, N=Kk, K=ck)
+                pwt = _packed(W[c0:c0 + ck], None, comp, L.W_LINEAR_T, N=Kk, K=ck)
                 last = ci == len(chunks) - 1
                 out = da if last else (acc if acc is not None else torch.empty(M, Kk, dtype=torch.float32, device=a.device))
                 K.linear(dy, pw=pwt, out=out, M=M, a_n0=M, a_s0=N, a_off=c0, residual=acc)
                 acc = out
         if ctx.needs_input_grad[1]:
-            dW = wgrad(_rm_linear(dy), _rm_linear(a), M, N, Kk, (N, Kk), comp, device=a.device)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+            dW, db = wgrad(_rm_linear(dy), _rm_linear(a), M, N, Kk, (N, Kk), comp, device=a.device, with_bias=True)
+            if not (ctx.has_bias and ctx.needs_input_grad[2]):
+                db = None
+        elif ctx.has_bias and ctx.needs_input_grad[2]:
             db = colsum(dy, M, N, 1)
         dres = dy if ctx.has_res else None
         return da, dW, db, dres, None, None
@@ -196,9 +219,9 @@ class PatchEmbedFn(Function):
     def forward(ctx, x, W, b, n_img, Hin, Win, Cin, P, nchw, compute, out_dtype):
         Cout = W.shape[0]
         if nchw:
-            pw = K.pack_weight(W, b, compute, L.W_LINEAR, N=Cout, K=Cin * P * P)
+            pw = _packed(W, b, compute, L.W_LINEAR, N=Cout, K=Cin * P * P)
         else:
-            pw = K.pack_weight(W, b, compute, L.W_CONV_NHWC, N=Cout, K=Cin * P * P, P=P, C_other=Cin)
+            pw = _packed(W, b, compute, L.W_CONV_NHWC, N=Cout, K=Cin * P * P, P=P, C_other=Cin)
         M = n_img * (Hin // P) * (Win // P)
         out = torch.empty(M, Cout, dtype=out_dtype, device=x.device)
         K.patch_embed(x, pw, out, n_img=n_img, Hin=Hin, Win=Win, Cin=Cin, P=P, nchw=nchw, act=L.ACT_NONE)
@@ -217,18 +240,18 @@ class PatchEmbedFn(Function):
         dx = dW = db = None
         if ctx.needs_input_grad[0]:     # col2im of non-overlapping patches = the pixel-shuffle scatter of a transposed conv
             if nchw:
-                pwt = K.pack_weight(W, None, comp, L.W_LINEAR_T, N=Kk, K=Cout)
+                pwt = _packed(W, None, comp, L.W_LINEAR_T, N=Kk, K=Cout)
                 dx = torch.empty(n_img, Cin, Hin, Win, dtype=torch.float32, device=x.device)
             else:
-                pwt = K.pack_weight(W, None, comp, L.W_CONV_NHWC_T, N=Kk, K=Cout, P=P, C_other=Cin)
+                pwt = _packed(W, None, comp, L.W_CONV_NHWC_T, N=Kk, K=Cout, P=P, C_other=Cin)
                 dx = torch.empty(n_img, Hin, Win, Cin, dtype=x.dtype, device=x.device)
             K.deconv(d, pwt, dx, n_img=n_img, Hi=Hin // P, Wi=Win // P, P=P, Cout=Cin, nchw_out=nchw, act=L.ACT_NONE)
             dx = dx.view(x.shape)
         if ctx.needs_input_grad[1]:
             V = _rm_patch(x, not nchw, n_img, Hin, Win, Cin, P)
-            dW = wgrad(_rm_linear(d), V, M, Cout, Kk, tuple(W.shape), comp, layout=L.W_LINEAR if nchw else L.W_CONV_NHWC, P=P,
-                       C_other=Cin, device=x.device)
-        if ctx.needs_input_grad[2]:
+            dW, db = wgrad(_rm_linear(d), V, M, Cout, Kk, tuple(W.shape), comp, layout=L.W_LINEAR if nchw else L.W_CONV_NHWC, P=P,
+                           C_other=Cin, device=x.device, with_bias=True)
+        elif ctx.needs_input_grad[2]:
             db = colsum(d, M, Cout, 1)
         return dx, dW, db, None, None, None, None, None, None, None, None
 
@@ -241,7 +264,7 @@ class DeconvFn(Function):
     def forward(ctx, a, W, b, n_img, Hi, Wi, P, nchw_out, compute, out_dtype):
         Cin, Cout = W.shape[0], W.shape[1]
         lay = L.W_DECONV_NCHW if nchw_out else L.W_DECONV_NHWC
-        pw = K.pack_weight(W, b, compute, lay, N=Cout * P * P, K=Cin, P=P, C_other=Cout)
+        pw = _packed(W, b, compute, lay, N=Cout * P * P, K=Cin, P=P, C_other=Cout)
         if nchw_out:
             out = torch.empty(n_img, Cout, Hi * P, Wi * P, dtype=torch.float32, device=a.device)
         else:
@@ -262,7 +285,7 @@ class DeconvFn(Function):
         da = dW = db = None
         if ctx.needs_input_grad[0]:      # gather the P x P output-gradient patch of every input pixel
             lay = L.W_DECONV_NCHW_T if nchw_out else L.W_DECONV_NHWC_T
-            pwt = K.pack_weight(W, None, comp, lay, N=Cin, K=N, P=P, C_other=Cout)
+            pwt = _packed(W, None, comp, lay, N=Cin, K=N, P=P, C_other=Cout)
             da = torch.empty(M, Cin, dtype=a.dtype, device=a.device)
             K.patch_embed(d, pwt, da, n_img=n_img, Hin=Hi * P, Win=Wi * P, Cin=Cout, P=P, nchw=nchw_out, act=L.ACT_NONE)
             da = da.view(a.shape)

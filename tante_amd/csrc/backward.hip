@@ -376,8 +376,11 @@ extern "C" int tante_colsum(const void* x, int dtype, int64_t outer, int C, int6
   hipStream_t s = (hipStream_t)stream;
   if (!accumulate && hipMemsetAsync(out, 0, (size_t)C * sizeof(float), s) != hipSuccess) TANTE_FAIL(-3, "tante_colsum: memset failed");
   if (inner == 1) {
-    long chunks = (outer + 1023) / 1024;
-    if (chunks > 1024) chunks = 1024;
+    // enough workgroups to fill the chip: (row chunks) x (64-channel groups) ~ 2048, at least 64 rows per chunk
+    const long groups = (C + 63) / 64;
+    long chunks = 2048 / groups;
+    if (chunks < 1) chunks = 1;
+    if (chunks > (outer + 63) / 64) chunks = (outer + 63) / 64;
     const long chunk = (outer + chunks - 1) / chunks;
     hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((outer + chunk - 1) / chunk), (unsigned)((C + 63) / 64)), dim3(256), 0, s, x, dtype,
                        (long)outer, C, (long)inner, chunk, out);

@@ -46,78 +46,182 @@ __device__ __forceinline__ long out_index(int layout, int i, int j, int I, int J
   }
 }
 
-constexpr int TI = 64, TJ = 64, RC = 32;
+constexpr int RC = 64;  // rows (contraction index) per staged chunk
 
-template <bool BF16>
-__global__ __launch_bounds__(256) void wgrad_kernel(const TanteRowMat U, const TanteRowMat V, long R, int I, int J, long rows_per_split,
-                                                    float* __restrict__ dW, int layout, int P, int Co, int swap) {
-  using elem_t = typename std::conditional<BF16, unsigned short, float>::type;
-  constexpr int STRIDE = RC + (BF16 ? 8 : 4);  // elements per LDS row (one column of the operand, 32 r values + pad)
-  __shared__ __attribute__((aligned(16))) elem_t Ut[TI * STRIDE];
-  __shared__ __attribute__((aligned(16))) elem_t Vt[TJ * STRIDE];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kk = lane >> 4, l15 = lane & 15;
-  const int i0 = blockIdx.x * TI, j0 = blockIdx.y * TJ;
-  const long r_begin = (long)blockIdx.z * rows_per_split, r_end = min(R, r_begin + rows_per_split);
-  const int wi = wave >> 1, wj = wave & 1;  // this wave's 32 x 32 part of the 64 x 64 tile
-  f32x4 acc[2][2];
+// staging modes of an operand
+enum { ST_GENERIC = 0, ST_ROWMAJOR = 1, ST_COLMAJOR = 2 };
+
+// Stage a [RC rows][T columns] chunk of a row matrix into LDS transposed ([column][row], row contiguous).
+// Every thread owns 4 x 4 (row x column) blocks; the 4 values of one column over 4 consecutive rows are written
+// with one 8-byte (bf16) / 16-byte (fp32) LDS store.
+template <bool BF16, int T>
+struct Stager {
+  static constexpr int COLG = T / 4, NBLK = COLG * (RC / 4) / 256;  // blocks per thread
+  float v[NBLK][4][4];                                              // [block][col e][row q]
+
+  __device__ __forceinline__ void blk_pos(int tid, int k, int mode, int& cg, int& rg) const {
+    const int id = tid + k * 256;
+    if (mode == ST_COLMAJOR) { rg = id % (RC / 4); cg = id / (RC / 4); }   // lanes run along rows: contiguous source
+    else { cg = id % COLG; rg = id / COLG; }                               // lanes run along columns
+  }
+
+  __device__ __forceinline__ void load(const TanteRowMat& m, int mode, long r0, long r_end, int c0, int ncols, int tid) {
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+    for (int k = 0; k < NBLK; ++k) {
+      int cg, rg;
+      blk_pos(tid, k, mode, cg, rg);
+      const int c = c0 + cg * 4;
+      const long r = r0 + rg * 4;
 #pragma unroll
-    for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int srow = tid >> 3, scol = (tid & 7) * 8;  // staging: 8 consecutive columns of one of the 32 rows
-  const bool fastU = U.mode == TANTE_A_LINEAR && U.es == 1, fastV = V.mode == TANTE_A_LINEAR && V.es == 1;
-  for (long r0 = r_begin; r0 < r_end; r0 += RC) {
-    float u[8], v[8];
-    const long r = r0 + srow;
-    const bool rok = r < r_end;
+      for (int e = 0; e < 4; ++e)
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int ci = i0 + scol + e, cj = j0 + scol + e;
-      u[e] = (rok && ci < I) ? (fastU ? ldg(U.p, U.dtype, (r / U.n0) * U.s1 + (r % U.n0) * U.s0 + U.off + ci) : rm_elem(U, r, ci)) : 0.f;
-      v[e] = (rok && cj < J) ? (fastV ? ldg(V.p, V.dtype, (r / V.n0) * V.s1 + (r % V.n0) * V.s0 + V.off + cj) : rm_elem(V, r, cj)) : 0.f;
-    }
-    __syncthreads();  // the previous chunk's fragments have been consumed
+        for (int q = 0; q < 4; ++q) v[k][e][q] = 0.f;
+      if (mode == ST_ROWMAJOR && c + 4 <= ncols) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      if constexpr (BF16) {
-        Ut[(scol + e) * STRIDE + srow] = (unsigned short)(pack_bf16x2(u[e], 0.f) & 0xffff);
-        Vt[(scol + e) * STRIDE + srow] = (unsigned short)(pack_bf16x2(v[e], 0.f) & 0xffff);
+        for (int q = 0; q < 4; ++q)
+          if (r + q < r_end) {
+            const long base = ((r + q) / m.n0) * m.s1 + ((r + q) % m.n0) * m.s0 + m.off + c;
+            if (m.dtype == TANTE_BF16) {
+              const u32x2 u = *(const u32x2*)((const unsigned short*)m.p + base);
+              v[k][0][q] = bf16_lo(u[0]); v[k][1][q] = bf16_hi(u[0]); v[k][2][q] = bf16_lo(u[1]); v[k][3][q] = bf16_hi(u[1]);
+            } else {
+              const f32x4 f = *(const f32x4*)((const float*)m.p + base);
+              v[k][0][q] = f[0]; v[k][1][q] = f[1]; v[k][2][q] = f[2]; v[k][3][q] = f[3];
+            }
+          }
+      } else if (mode == ST_COLMAJOR && r + 4 <= r_end) {   // 4 consecutive rows of one column are contiguous (fp32 source)
+        const long base = (r / m.n0) * m.s1 + (r % m.n0) * m.s0 + m.off;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (c + e < ncols) {
+            const f32x4 f = *(const f32x4*)((const float*)m.p + base + (long)(c + e) * m.es);
+            v[k][e][0] = f[0]; v[k][e][1] = f[1]; v[k][e][2] = f[2]; v[k][e][3] = f[3];
+          }
       } else {
-        Ut[(scol + e) * STRIDE + srow] = u[e];
-        Vt[(scol + e) * STRIDE + srow] = v[e];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (r + q < r_end && c + e < ncols) v[k][e][q] = rm_elem(m, r + q, c + e);
       }
     }
-    __syncthreads();
+  }
+
+  template <class E>
+  __device__ __forceinline__ void store(E* lds, int stride, int mode, int tid) const {
 #pragma unroll
-    for (int a = 0; a < 2; ++a) {
-      const elem_t* up = Ut + (wi * 32 + a * 16 + l15) * STRIDE;
+    for (int k = 0; k < NBLK; ++k) {
+      int cg, rg;
+      blk_pos(tid, k, mode, cg, rg);
 #pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        const elem_t* vp = Vt + (wj * 32 + b * 16 + l15) * STRIDE;
-        if constexpr (BF16) {  // one k-step of 32 rows: lane chunk = rows 8*kk .. 8*kk+7
-          const u32x4 af = *(const u32x4*)(up + kk * 8), bf = *(const u32x4*)(vp + kk * 8);
-          acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af), __builtin_bit_cast(bf16x8, bf), acc[a][b], 0, 0, 0);
-        } else {  // two blocks of 16 rows, 4 MFMA steps each; lane chunk = rows 16*blk + 4*kk .. +3 (same order for both operands)
-#pragma unroll
-          for (int blk = 0; blk < 2; ++blk) {
-            const f32x4 af = *(const f32x4*)(up + blk * 16 + kk * 4), bf = *(const f32x4*)(vp + blk * 16 + kk * 4);
-#pragma unroll
-            for (int s = 0; s < 4; ++s) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s], bf[s], acc[a][b], 0, 0, 0);
-          }
+      for (int e = 0; e < 4; ++e) {
+        E* d = lds + (cg * 4 + e) * stride + rg * 4;
+        if constexpr (BF16) {
+          u32x2 w;
+          w[0] = pack_bf16x2(v[k][e][0], v[k][e][1]);
+          w[1] = pack_bf16x2(v[k][e][2], v[k][e][3]);
+          *(u32x2*)d = w;
+        } else {
+          *(f32x4*)d = f32x4{v[k][e][0], v[k][e][1], v[k][e][2], v[k][e][3]};
         }
       }
     }
   }
+};
+
+template <bool BF16, int T>   // T x T output tile; wave (wi, wj) of the 2 x 2 wave grid owns a (T/2) x (T/2) part
+__global__ __launch_bounds__(256) void wgrad_kernel(const TanteRowMat U, const TanteRowMat V, long R, int I, int J, long rows_per_split,
+                                                    float* __restrict__ dW, float* __restrict__ dbias, int layout, int P, int Co, int swap,
+                                                    int modeU, int modeV) {
+  using elem_t = typename std::conditional<BF16, unsigned short, float>::type;
+  constexpr int STRIDE = RC + (BF16 ? 8 : 4);  // elements per LDS row (one operand column, RC rows + pad; multiple of 16 bytes)
+  constexpr int NT = T / 32;                   // 16 x 16 MFMA tiles per wave per side
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  elem_t* Ut = (elem_t*)smem_raw;
+  elem_t* Vt = Ut + T * STRIDE;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kk = lane >> 4, l15 = lane & 15;
+  const int i0 = blockIdx.x * T, j0 = blockIdx.y * T;
+  const long r_begin = (long)blockIdx.z * rows_per_split, r_end = min(R, r_begin + rows_per_split);
+  const int wi = wave >> 1, wj = wave & 1;
+  f32x4 acc[NT][NT];
+#pragma unroll
+  for (int a = 0; a < NT; ++a)
+#pragma unroll
+    for (int b = 0; b < NT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bsum = 0.f;  // bias gradient: column sums of U (threads 0..T-1 of the j-tile-0 workgroups)
+  const bool do_bias = dbias != nullptr && blockIdx.y == 0;
+  Stager<BF16, T> su, sv;
+  su.load(U, modeU, r_begin, r_end, i0, I, tid);
+  sv.load(V, modeV, r_begin, r_end, j0, J, tid);
+  for (long r0 = r_begin; r0 < r_end; r0 += RC) {
+    __syncthreads();  // the previous chunk's fragments have been consumed
+    su.store(Ut, STRIDE, modeU, tid);
+    sv.store(Vt, STRIDE, modeV, tid);
+    __syncthreads();
+    if (r0 + RC < r_end) {  // next chunk's global loads fly under the MFMAs
+      su.load(U, modeU, r0 + RC, r_end, i0, I, tid);
+      sv.load(V, modeV, r0 + RC, r_end, j0, J, tid);
+    }
+    if (do_bias && tid < T) {
+      float sacc = 0.f;
+#pragma unroll
+      for (int q = 0; q < RC; ++q) {
+        if constexpr (BF16) sacc += __uint_as_float(((unsigned)Ut[tid * STRIDE + q]) << 16);
+        else sacc += Ut[tid * STRIDE + q];
+      }
+      bsum += sacc;
+    }
+#pragma unroll
+    for (int ks = 0; ks < (BF16 ? 2 : 4); ++ks) {
+      u32x4 af[NT], bf[NT];
+#pragma unroll
+      for (int a = 0; a < NT; ++a)
+        af[a] = *(const u32x4*)(Ut + (wi * (T / 2) + a * 16 + l15) * STRIDE + ks * (BF16 ? 32 : 16) + kk * (BF16 ? 8 : 4));
+#pragma unroll
+      for (int b = 0; b < NT; ++b)
+        bf[b] = *(const u32x4*)(Vt + (wj * (T / 2) + b * 16 + l15) * STRIDE + ks * (BF16 ? 32 : 16) + kk * (BF16 ? 8 : 4));
+#pragma unroll
+      for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b) {
+          if constexpr (BF16) {
+            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[a]), __builtin_bit_cast(bf16x8, bf[b]), acc[a][b], 0, 0, 0);
+          } else {  // lane chunk = rows 16*ks + 4*kk .. +3, the same order for both operands
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+              acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(af[a][s]), __uint_as_float(bf[b][s]), acc[a][b], 0, 0, 0);
+          }
+        }
+    }
+  }
   // D[row = i][col = j]: lane holds j = l15, i = 4*kk + reg
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < NT; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < NT; ++b)
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {
-        const int i = i0 + wi * 32 + a * 16 + kk * 4 + rg, j = j0 + wj * 32 + b * 16 + l15;
+        const int i = i0 + wi * (T / 2) + a * 16 + kk * 4 + rg, j = j0 + wj * (T / 2) + b * 16 + l15;
         if (i < I && j < J) atomicAdd(&dW[out_index(layout, i, j, I, J, P, Co, swap)], acc[a][b][rg]);
       }
+  if (do_bias && tid < T && i0 + tid < I) atomicAdd(&dbias[i0 + tid], bsum);
+}
+
+template <bool BF16, int T>
+void launch_wgrad(const TanteRowMat& U, const TanteRowMat& V, long R, int I, int J, float* dW, float* dbias, int layout, int P, int Co, int swap,
+                  int mu, int mv, hipStream_t s) {
+  const int ti = (I + T - 1) / T, tj = (J + T - 1) / T;
+  long split = 384 / ((long)ti * tj);   // enough workgroups to fill the chip, few enough to keep the atomic traffic small
+  if (split < 1) split = 1;
+  const long max_split = (R + 4 * RC - 1) / (4 * RC);
+  if (split > max_split) split = max_split;
+  if (split > 65535) split = 65535;
+  long per = (R + split - 1) / split;
+  per = (per + RC - 1) / RC * RC;
+  split = (R + per - 1) / per;
+  const size_t lds = 2 * (size_t)T * (RC + (BF16 ? 8 : 4)) * (BF16 ? 2 : 4);
+  hipLaunchKernelGGL((wgrad_kernel<BF16, T>), dim3(ti, tj, (unsigned)split), dim3(256), lds, s, U, V, R, I, J, per, dW, dbias, layout, P, Co, swap,
+                     mu, mv);
 }
 
 }  // namespace
@@ -134,8 +238,17 @@ static int check_rowmat(const TanteRowMat& m, const char* name) {
   return 0;
 }
 
-extern "C" int tante_wgrad(const TanteRowMat* U, const TanteRowMat* V, int64_t R, int I, int J, float* dW, int layout, int P, int C_other,
-                           int swap, int compute, int accumulate, void* stream) {
+static int rm_stage_mode(const TanteRowMat& m, int ncols) {
+  if (m.mode != TANTE_A_LINEAR || ((uintptr_t)m.p % 16)) return ST_GENERIC;
+  const int al = m.dtype == TANTE_BF16 ? 4 : 4;
+  if (m.es == 1 && m.s1 % al == 0 && m.s0 % al == 0 && m.off % al == 0 && ncols % 4 == 0) return ST_ROWMAJOR;
+  // lines: consecutive rows are consecutive addresses (s0 == 1) inside blocks of n0 rows
+  if (m.dtype == TANTE_F32 && m.s0 == 1 && m.es % 4 == 0 && m.n0 % 4 == 0 && m.s1 % 4 == 0 && m.off % 4 == 0) return ST_COLMAJOR;
+  return ST_GENERIC;
+}
+
+extern "C" int tante_wgrad(const TanteRowMat* U, const TanteRowMat* V, int64_t R, int I, int J, float* dW, float* dbias, int layout, int P,
+                           int C_other, int swap, int compute, int accumulate, void* stream) {
   if (!U || !V || !dW || R <= 0 || I <= 0 || J <= 0) TANTE_FAIL(-1, "tante_wgrad: bad argument");
   int rc = check_rowmat(*U, "U");
   if (rc) return rc;
@@ -144,20 +257,14 @@ extern "C" int tante_wgrad(const TanteRowMat* U, const TanteRowMat* V, int64_t R
   if (layout < TANTE_W_LINEAR || layout > TANTE_W_DECONV_NCHW) TANTE_FAIL(-1, "tante_wgrad: bad output layout");
   hipStream_t s = (hipStream_t)stream;
   if (!accumulate && hipMemsetAsync(dW, 0, (size_t)I * J * sizeof(float), s) != hipSuccess) TANTE_FAIL(-3, "tante_wgrad: memset failed");
-  const int ti = (I + TI - 1) / TI, tj = (J + TJ - 1) / TJ;
-  long split = 1024 / ((long)ti * tj);
-  if (split < 1) split = 1;
-  const long max_split = (R + 255) / 256;
-  if (split > max_split) split = max_split;
-  if (split > 65535) split = 65535;
-  long per = (R + split - 1) / split;
-  per = (per + RC - 1) / RC * RC;
-  split = (R + per - 1) / per;
-  const dim3 grid(ti, tj, (unsigned)split);
-  if (compute == TANTE_BF16)
-    hipLaunchKernelGGL(wgrad_kernel<true>, grid, dim3(256), 0, s, *U, *V, (long)R, I, J, per, dW, layout, P, C_other, swap);
-  else
-    hipLaunchKernelGGL(wgrad_kernel<false>, grid, dim3(256), 0, s, *U, *V, (long)R, I, J, per, dW, layout, P, C_other, swap);
+  if (!accumulate && dbias && hipMemsetAsync(dbias, 0, (size_t)I * sizeof(float), s) != hipSuccess) TANTE_FAIL(-3, "tante_wgrad: memset failed");
+  const int mu = rm_stage_mode(*U, I), mv = rm_stage_mode(*V, J);
+  if (compute == TANTE_BF16) {
+    if (I > 64 || J > 64) launch_wgrad<true, 128>(*U, *V, (long)R, I, J, dW, dbias, layout, P, C_other, swap, mu, mv, s);
+    else launch_wgrad<true, 64>(*U, *V, (long)R, I, J, dW, dbias, layout, P, C_other, swap, mu, mv, s);
+  } else {
+    launch_wgrad<false, 64>(*U, *V, (long)R, I, J, dW, dbias, layout, P, C_other, swap, mu, mv, s);
+  }
   TANTE_CHECK_LAUNCH();
   return 0;
 }

@@ -66,7 +66,9 @@ class FlatAdamW:
                                          self.weight_decay, self.step_count, float(grad_scale), s), "tante_adamw_step")
         # the kernel wrote through raw pointers: invalidate the packed-weight caches (attn_backbone._PackCache)
         from .attn_backbone import bump_weight_epoch
+        from .autograd import clear_pack_cache
         bump_weight_epoch()
+        clear_pack_cache()
 
 
 def warmup_cosine_lr(epoch: int, base_lr: float, warmup_epochs: int, max_epochs: int, warmup_start_lr: float = 0.0,

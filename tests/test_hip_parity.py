@@ -596,3 +596,52 @@ def test_g9_two_full_train_steps(dev):
         opt.step()
         for k, p in m.named_parameters():
             assert float((p.detach().cpu() - g[f"w{step + 1}." + k]).abs().max()) < 3e-2 * lr, (step, k)
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+@pytest.mark.parametrize("R,I,J", [(1000, 96, 64), (300, 768, 256), (77, 20, 44), (4096, 130, 70), (513, 8, 8)])
+def test_wgrad_linear_with_bias(dev, mode, R, I, J):
+    """dW = U^T V and db = column sums of U, dense row matrices (odd sizes exercise the generic loader and tile edges)."""
+    from tante_amd.autograd import wgrad, _rm_linear
+    from tante_amd import kernels as Kk
+    g = torch.Generator().manual_seed(R + I)
+    dt = torch.float32 if mode == "fp32" else torch.bfloat16
+    U = torch.randn(R, I, generator=g).to(dt)
+    V = torch.randn(R, J, generator=g).to(dt)
+    ref, refb = U.float().t() @ V.float(), U.float().sum(0)
+    Ud, Vd = U.to(dev), V.to(dev)
+    dW, db = wgrad(_rm_linear(Ud), _rm_linear(Vd), R, I, J, (I, J), Kk.COMPUTE[mode], device=dev, with_bias=True)
+    close(dW, ref, mode, scale=2.0)
+    close(db, refb, mode, scale=2.0)
+
+
+def test_wgrad_lines_and_patches(dev):
+    """the other operand shapes: axis lines (element stride = inner) and k = s patches, against autograd of torch ops"""
+    from tante_amd.autograd import wgrad, _rm_linear, _rm_patch
+    from tante_amd import _lib as L
+    g = torch.Generator().manual_seed(0)
+    outer, n, inner = 3, 24, 40
+    dy, h = torch.randn(outer, n, inner, generator=g), torch.randn(outer, n, inner, generator=g)
+    ref = torch.einsum("oai,obi->ab", dy, h)
+    dyd, hd = dy.to(dev), h.to(dev)
+
+    def lines(t):
+        return _rm_linear(t, n0=inner, s1=n * inner, s0=1, es=inner, cols=n)
+    close(wgrad(lines(dyd), lines(hd), outer * inner, n, n, (n, n), L.F32, device=dev), ref, "fp32")
+    # conv weight gradient: patches of a channels-last / channels-first image
+    n_img, Cin, Cout, P, H, W = 2, 6, 10, 2, 8, 12
+    x = torch.randn(n_img, Cin, H, W, generator=g, requires_grad=True)
+    w = torch.randn(Cout, Cin, P, P, generator=g, requires_grad=True)
+    y = torch.nn.functional.conv2d(x, w, stride=P)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    d = gy.permute(0, 2, 3, 1).reshape(-1, Cout).contiguous().to(dev)
+    M = d.shape[0]
+    xn = x.detach().to(dev)
+    dW = wgrad(_rm_linear(d), _rm_patch(xn, False, n_img, H, W, Cin, P), M, Cout, Cin * P * P, tuple(w.shape), L.F32, layout=L.W_LINEAR,
+               P=P, C_other=Cin, device=dev)
+    close(dW, w.grad, "fp32")
+    xl = x.detach().permute(0, 2, 3, 1).contiguous().to(dev)
+    dW = wgrad(_rm_linear(d), _rm_patch(xl, True, n_img, H, W, Cin, P), M, Cout, Cin * P * P, tuple(w.shape), L.F32, layout=L.W_CONV_NHWC,
+               P=P, C_other=Cin, device=dev)
+    close(dW, w.grad, "fp32")
