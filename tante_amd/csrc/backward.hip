@@ -100,10 +100,11 @@ __global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ x,
     if (sub == 0 && c < C) atomicAdd(&out[c], part[threadIdx.x] + part[threadIdx.x + 64] + part[threadIdx.x + 128] + part[threadIdx.x + 192]);
   } else {
     const int c = blockIdx.y;
-    const long o = blockIdx.x;  // one (o, c) slab of `inner` contiguous elements per workgroup
+    const long nch = (inner + chunk - 1) / chunk;           // `chunk` contiguous elements of one (o, c) slab per workgroup
+    const long o = blockIdx.x / nch, i0 = (blockIdx.x % nch) * chunk, i1 = min(inner, i0 + chunk);
     float s = 0.f;
     const long base = (o * C + c) * inner;
-    for (long i = threadIdx.x; i < inner; i += 256) s += ldx(x, dtype, base + i);
+    for (long i = i0 + threadIdx.x; i < i1; i += 256) s += ldx(x, dtype, base + i);
     s = wave_sum(s);
     __shared__ float part[4];
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
@@ -385,8 +386,10 @@ extern "C" int tante_colsum(const void* x, int dtype, int64_t outer, int C, int6
     hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((outer + chunk - 1) / chunk), (unsigned)((C + 63) / 64)), dim3(256), 0, s, x, dtype,
                        (long)outer, C, (long)inner, chunk, out);
   } else {
-    if (outer > 65535 * 16L) TANTE_FAIL(-2, "tante_colsum: outer too large");
-    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)outer, (unsigned)C), dim3(256), 0, s, x, dtype, (long)outer, C, (long)inner, 0L, out);
+    const long chunk = 4096;
+    const long nch = (inner + chunk - 1) / chunk;
+    if (outer * nch > 2000000000L) TANTE_FAIL(-2, "tante_colsum: too large");
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)(outer * nch), (unsigned)C), dim3(256), 0, s, x, dtype, (long)outer, C, (long)inner, chunk, out);
   }
   TANTE_CHECK_LAUNCH();
   return 0;

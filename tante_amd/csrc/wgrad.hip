@@ -10,6 +10,7 @@
 // ([column][32 rows], r contiguous): one 16-byte ds_read per lane is then an MFMA operand fragment.  The result tile is
 // added with fp32 atomics at the parameter's own index (TANTE_W_* layouts), r is split over workgroups.
 #include "common.cuh"
+#include <stdlib.h>
 
 namespace {
 
@@ -54,33 +55,44 @@ enum { ST_GENERIC = 0, ST_ROWMAJOR = 1, ST_COLMAJOR = 2 };
 // Stage a [RC rows][T columns] chunk of a row matrix into LDS transposed ([column][row], row contiguous).
 // Every thread owns 4 x 4 (row x column) blocks; the 4 values of one column over 4 consecutive rows are written
 // with one 8-byte (bf16) / 16-byte (fp32) LDS store.
-template <bool BF16, int T>
+template <bool BF16, int T, int MODE>
 struct Stager {
   static constexpr int COLG = T / 4, NBLK = COLG * (RC / 4) / 256;  // blocks per thread
   float v[NBLK][4][4];                                              // [block][col e][row q]
 
-  __device__ __forceinline__ void blk_pos(int tid, int k, int mode, int& cg, int& rg) const {
+  __device__ __forceinline__ void blk_pos(int tid, int k, int& cg, int& rg) const {
     const int id = tid + k * 256;
-    if (mode == ST_COLMAJOR) { rg = id % (RC / 4); cg = id / (RC / 4); }   // lanes run along rows: contiguous source
-    else { cg = id % COLG; rg = id / COLG; }                               // lanes run along columns
+    if constexpr (MODE == ST_COLMAJOR) { rg = id % (RC / 4); cg = id / (RC / 4); }   // lanes run along rows: contiguous source
+    else {
+      // a wave covers 8 column groups x 8 row groups: 64-byte global segments, and its 8-byte LDS stores
+      // ((4cg+e) * STRIDE + 4 rg elements) then touch 32 distinct banks
+      const int g = id >> 6;
+      cg = (id & 7) + 8 * (g % (COLG / 8));
+      rg = ((id >> 3) & 7) + 8 * (g / (COLG / 8));
+    }
   }
 
-  __device__ __forceinline__ void load(const TanteRowMat& m, int mode, long r0, long r_end, int c0, int ncols, int tid) {
+  __device__ __forceinline__ void load(const TanteRowMat& m, long r0, long r_end, int c0, int ncols, int tid) {
 #pragma unroll
     for (int k = 0; k < NBLK; ++k) {
       int cg, rg;
-      blk_pos(tid, k, mode, cg, rg);
+      blk_pos(tid, k, cg, rg);
       const int c = c0 + cg * 4;
       const long r = r0 + rg * 4;
 #pragma unroll
       for (int e = 0; e < 4; ++e)
 #pragma unroll
         for (int q = 0; q < 4; ++q) v[k][e][q] = 0.f;
-      if (mode == ST_ROWMAJOR && c + 4 <= ncols) {
+      if constexpr (MODE == ST_ROWMAJOR) {
+        if (c + 4 <= ncols) {
+        // one (64-bit) divide per 4-row block, none for dense matrices; a block never straddles two n0-groups when n0 % 4 == 0
+        const bool dense = m.s1 == 0;
+        const long blk = dense ? 0 : r / m.n0, rin = dense ? r : r - blk * m.n0;
+        const bool same = dense || (rin + 3 < m.n0);
 #pragma unroll
         for (int q = 0; q < 4; ++q)
           if (r + q < r_end) {
-            const long base = ((r + q) / m.n0) * m.s1 + ((r + q) % m.n0) * m.s0 + m.off + c;
+            const long base = (same ? blk * m.s1 + (rin + q) * m.s0 : ((r + q) / m.n0) * m.s1 + ((r + q) % m.n0) * m.s0) + m.off + c;
             if (m.dtype == TANTE_BF16) {
               const u32x2 u = *(const u32x2*)((const unsigned short*)m.p + base);
               v[k][0][q] = bf16_lo(u[0]); v[k][1][q] = bf16_hi(u[0]); v[k][2][q] = bf16_lo(u[1]); v[k][3][q] = bf16_hi(u[1]);
@@ -89,14 +101,23 @@ struct Stager {
               v[k][0][q] = f[0]; v[k][1][q] = f[1]; v[k][2][q] = f[2]; v[k][3][q] = f[3];
             }
           }
-      } else if (mode == ST_COLMAJOR && r + 4 <= r_end) {   // 4 consecutive rows of one column are contiguous (fp32 source)
-        const long base = (r / m.n0) * m.s1 + (r % m.n0) * m.s0 + m.off;
+        }
+      } else if constexpr (MODE == ST_COLMAJOR) {   // 4 consecutive rows of one column are contiguous (fp32 source)
+        if (r + 4 <= r_end) {
+          const long base = (r / m.n0) * m.s1 + (r % m.n0) * m.s0 + m.off;
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (c + e < ncols) {
-            const f32x4 f = *(const f32x4*)((const float*)m.p + base + (long)(c + e) * m.es);
-            v[k][e][0] = f[0]; v[k][e][1] = f[1]; v[k][e][2] = f[2]; v[k][e][3] = f[3];
-          }
+          for (int e = 0; e < 4; ++e)
+            if (c + e < ncols) {
+              const f32x4 f = *(const f32x4*)((const float*)m.p + base + (long)(c + e) * m.es);
+              v[k][e][0] = f[0]; v[k][e][1] = f[1]; v[k][e][2] = f[2]; v[k][e][3] = f[3];
+            }
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (r + q < r_end && c + e < ncols) v[k][e][q] = ((const float*)m.p)[((r + q) / m.n0) * m.s1 + ((r + q) % m.n0) * m.s0 + m.off + (long)(c + e) * m.es];
+        }
       } else {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
@@ -108,11 +129,11 @@ struct Stager {
   }
 
   template <class E>
-  __device__ __forceinline__ void store(E* lds, int stride, int mode, int tid) const {
+  __device__ __forceinline__ void store(E* lds, int stride, int tid) const {
 #pragma unroll
     for (int k = 0; k < NBLK; ++k) {
       int cg, rg;
-      blk_pos(tid, k, mode, cg, rg);
+      blk_pos(tid, k, cg, rg);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         E* d = lds + (cg * 4 + e) * stride + rg * 4;
@@ -129,10 +150,11 @@ struct Stager {
   }
 };
 
-template <bool BF16, int T>   // T x T output tile; wave (wi, wj) of the 2 x 2 wave grid owns a (T/2) x (T/2) part
+// T x T output tile; wave (wi, wj) of the 2 x 2 wave grid owns a (T/2) x (T/2) part.  The staging modes are template
+// parameters: inlining the generic gather (integer divisions) at all 64 element sites made a 125k-instruction kernel.
+template <bool BF16, int T, int MU, int MV>
 __global__ __launch_bounds__(256) void wgrad_kernel(const TanteRowMat U, const TanteRowMat V, long R, int I, int J, long rows_per_split,
-                                                    float* __restrict__ dW, float* __restrict__ dbias, int layout, int P, int Co, int swap,
-                                                    int modeU, int modeV) {
+                                                    float* __restrict__ dW, float* __restrict__ dbias, int layout, int P, int Co, int swap) {
   using elem_t = typename std::conditional<BF16, unsigned short, float>::type;
   constexpr int STRIDE = RC + (BF16 ? 8 : 4);  // elements per LDS row (one operand column, RC rows + pad; multiple of 16 bytes)
   constexpr int NT = T / 32;                   // 16 x 16 MFMA tiles per wave per side
@@ -150,17 +172,18 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const TanteRowMat U, const T
     for (int b = 0; b < NT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
   float bsum = 0.f;  // bias gradient: column sums of U (threads 0..T-1 of the j-tile-0 workgroups)
   const bool do_bias = dbias != nullptr && blockIdx.y == 0;
-  Stager<BF16, T> su, sv;
-  su.load(U, modeU, r_begin, r_end, i0, I, tid);
-  sv.load(V, modeV, r_begin, r_end, j0, J, tid);
+  Stager<BF16, T, MU> su;
+  Stager<BF16, T, MV> sv;
+  su.load(U, r_begin, r_end, i0, I, tid);
+  sv.load(V, r_begin, r_end, j0, J, tid);
   for (long r0 = r_begin; r0 < r_end; r0 += RC) {
     __syncthreads();  // the previous chunk's fragments have been consumed
-    su.store(Ut, STRIDE, modeU, tid);
-    sv.store(Vt, STRIDE, modeV, tid);
+    su.store(Ut, STRIDE, tid);
+    sv.store(Vt, STRIDE, tid);
     __syncthreads();
     if (r0 + RC < r_end) {  // next chunk's global loads fly under the MFMAs
-      su.load(U, modeU, r0 + RC, r_end, i0, I, tid);
-      sv.load(V, modeV, r0 + RC, r_end, j0, J, tid);
+      su.load(U, r0 + RC, r_end, i0, I, tid);
+      sv.load(V, r0 + RC, r_end, j0, J, tid);
     }
     if (do_bias && tid < T) {
       float sacc = 0.f;
@@ -211,7 +234,8 @@ template <bool BF16, int T>
 void launch_wgrad(const TanteRowMat& U, const TanteRowMat& V, long R, int I, int J, float* dW, float* dbias, int layout, int P, int Co, int swap,
                   int mu, int mv, hipStream_t s) {
   const int ti = (I + T - 1) / T, tj = (J + T - 1) / T;
-  long split = 384 / ((long)ti * tj);   // enough workgroups to fill the chip, few enough to keep the atomic traffic small
+  static const int wg_target = getenv("TANTE_WGRAD_WGS") ? atoi(getenv("TANTE_WGRAD_WGS")) : 512;
+  long split = wg_target / ((long)ti * tj);   // two workgroups per CU; fewer splits = less atomic traffic
   if (split < 1) split = 1;
   const long max_split = (R + 4 * RC - 1) / (4 * RC);
   if (split > max_split) split = max_split;
@@ -220,8 +244,13 @@ void launch_wgrad(const TanteRowMat& U, const TanteRowMat& V, long R, int I, int
   per = (per + RC - 1) / RC * RC;
   split = (R + per - 1) / per;
   const size_t lds = 2 * (size_t)T * (RC + (BF16 ? 8 : 4)) * (BF16 ? 2 : 4);
-  hipLaunchKernelGGL((wgrad_kernel<BF16, T>), dim3(ti, tj, (unsigned)split), dim3(256), lds, s, U, V, R, I, J, per, dW, dbias, layout, P, Co, swap,
-                     mu, mv);
+  const dim3 grid(ti, tj, (unsigned)split);
+#define TANTE_WG(MUV, MVV) hipLaunchKernelGGL((wgrad_kernel<BF16, T, MUV, MVV>), grid, dim3(256), lds, s, U, V, R, I, J, per, dW, dbias, layout, P, Co, swap)
+  if (mu == ST_ROWMAJOR && mv == ST_ROWMAJOR) TANTE_WG(ST_ROWMAJOR, ST_ROWMAJOR);        // linear layers
+  else if (mu == ST_COLMAJOR && mv == ST_COLMAJOR) TANTE_WG(ST_COLMAJOR, ST_COLMAJOR);   // axis propagators
+  else if (mu == ST_ROWMAJOR) TANTE_WG(ST_ROWMAJOR, ST_GENERIC);                         // conv / transposed-conv stages (V = patches)
+  else TANTE_WG(ST_GENERIC, ST_GENERIC);
+#undef TANTE_WG
 }
 
 }  // namespace

@@ -15,7 +15,7 @@ from tante_amd import kernels as K, _lib as L
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["block", "axis", "enc", "dec", "model"])
+    ap.add_argument("what", choices=["block", "axis", "enc", "dec", "model", "wgrad", "attnbwd"])
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--letter", default="H")
@@ -63,6 +63,28 @@ def main():
             timeit(lambda: K.axis_mlp(x, B * T, H, W * C, vp[0].weight, vp[0].bias, vp[2].weight, vp[2].bias), "axis H", None, by)
             timeit(lambda: K.axis_mlp(x, B * T * H, W, C, hp[0].weight, hp[0].bias, hp[2].weight, hp[2].bias), "axis W", None, by)
             timeit(lambda: K.axis_mlp(x, B, T, H * W * C, tp[0].weight, tp[0].bias, tp[2].weight, tp[2].bias), "axis T", None, by)
+        elif a.what == "wgrad":
+            from tante_amd.autograd import wgrad, _rm_linear
+            R = 24576
+            for (I, J) in ((256, 256), (768, 256)):
+                U = torch.randn(R, I, device=dev).to(torch.bfloat16)
+                V = torch.randn(R, J, device=dev).to(torch.bfloat16)
+                timeit(lambda: wgrad(_rm_linear(U), _rm_linear(V), R, I, J, (I, J), L.BF16, device=dev, with_bias=True),
+                       f"wgrad bf16 R={R} I={I} J={J}", 2.0 * R * I * J, 2.0 * R * (I + J))
+                timeit(lambda: wgrad(_rm_linear(U), _rm_linear(V), R, I, J, (I, J), L.BF16, device=dev, with_bias=False),
+                       f"wgrad bf16 no-bias R={R} I={I} J={J}", 2.0 * R * I * J, 2.0 * R * (I + J))
+        elif a.what == "attnbwd":
+            from tante_amd.autograd import AttentionFn
+            for letter, (T_, H_, W_) in (("W", (4, 16, 48)), ("H", (4, 16, 48)), ("T", (4, 16, 48))):
+                n = B * T_ * H_ * W_
+                qkv = torch.randn(n, 3 * C, device=dev).to(torch.bfloat16)
+                do = torch.randn(n, C, device=dev).to(torch.bfloat16)
+                dq = torch.empty_like(qkv)
+                seq = K.make_seq(letter, B, T_, H_, W_)
+                import ctypes as Ct
+                timeit(lambda: L.check(L.lib().tante_attention_bwd(qkv.data_ptr(), do.data_ptr(), dq.data_ptr(), L.BF16, C, 8, Ct.byref(seq),
+                                                                   int(letter == "T"), torch.cuda.current_stream().cuda_stream)),
+                       f"attn bwd {letter} L={seq.L}")
         elif a.what in ("enc", "dec", "model"):
             m = tante_amd.TANTE(in_T=4, dset_metadata=md, taylor_order=3, attn_axes="THW-THW-THW", n_head=8, embed_dim=256,
                                 patch_scale=8).to(dev).eval().set_compute(a.dtype)
