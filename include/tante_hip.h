@@ -232,7 +232,15 @@ int tante_taylor_bwd(const float* dout, int64_t dout_bstride, float* const* dder
                      int64_t dlast_bstride, int accumulate, int64_t B, int64_t frame, void* stream);
 /* dqkv from (qkv, dO) for per-(sequence, head) softmax attention, probabilities recomputed (sequences up to 128 tokens) */
 int tante_attention_bwd(const void* qkv, const void* dO, void* dqkv, int dtype, int C, int n_head, const TanteSeq* seq, int causal,
-                        void* stream);
+                        float p_drop, uint64_t seed, void* stream);
+/* Training-mode attention with dropout p on the softmax probabilities (nn.MultiheadAttention(dropout=p), attn_backbone.py:48).
+ * The mask is a pure function of (seed, sequence, head, query, key), so tante_attention_bwd regenerates it from the same seed. */
+int tante_attention_dropout(const void* qkv, void* o, int dtype, int C, int n_head, const TanteSeq* seq, int causal, float p_drop,
+                            uint64_t seed, void* stream);
+/* out = res + dropout(y) and dy = dropout'(dout): self.drop(.) on both residual branches (attn_backbone.py:57,81-82); the mask is
+ * a pure function of (seed, element index). */
+int tante_dropout_add(const void* y, int y_dtype, const float* res, float p, uint64_t seed, int64_t n, float* out, void* stream);
+int tante_dropout_bwd(const float* dout, float p, uint64_t seed, int64_t n, void* dy, int y_dtype, void* stream);
 /* axis propagator backward: dx = dy + W1^T (gelu'(pre) * (W2^T dy)); also writes h = gelu(pre) and dpre (same layout as x) for
  * the weight-gradient GEMMs */
 int tante_axis_mlp_bwd(const float* x, const float* dy, int64_t outer, int n, int64_t inner, const float* w1, const float* b1,

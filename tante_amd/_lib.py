@@ -71,7 +71,10 @@ SIGNATURES = {
     "tante_film_pos_fwd": ([c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i64, c_vp, c_vp], c_i32),
     "tante_film_pos_bwd": ([c_vp, c_vp, c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp], c_i32),
     "tante_taylor_bwd": ([c_vp, c_i64, C.POINTER(c_vp), c_i32, C.c_double, c_i32, c_vp, c_i64, c_i32, c_i64, c_i64, c_vp], c_i32),
-    "tante_attention_bwd": ([c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, C.POINTER(Seq), c_i32, c_vp], c_i32),
+    "tante_attention_bwd": ([c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, C.POINTER(Seq), c_i32, c_f32, C.c_uint64, c_vp], c_i32),
+    "tante_attention_dropout": ([c_vp, c_vp, c_i32, c_i32, c_i32, C.POINTER(Seq), c_i32, c_f32, C.c_uint64, c_vp], c_i32),
+    "tante_dropout_add": ([c_vp, c_i32, c_vp, c_f32, C.c_uint64, c_i64, c_vp, c_vp], c_i32),
+    "tante_dropout_bwd": ([c_vp, c_f32, C.c_uint64, c_i64, c_vp, c_i32, c_vp], c_i32),
     "tante_axis_mlp_bwd": ([c_vp, c_vp, c_i64, c_i32, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp], c_i32),
     "tante_wgrad": ([C.POINTER(RowMat), C.POINTER(RowMat), c_i64, c_i32, c_i32, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp], c_i32),
     "tante_last_error": ([], C.c_char_p),

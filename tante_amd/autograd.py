@@ -159,15 +159,29 @@ class ActFn(Function):
         return d, None, None
 
 
+_SEED = [0]
+
+
+def next_seed() -> int:
+    """A fresh 64-bit dropout seed per op, derived from torch's seed so that runs are reproducible."""
+    _SEED[0] += 1
+    return (torch.initial_seed() * 0x9E3779B97F4A7C15 + _SEED[0] * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+
+
 class AttentionFn(Function):
-    """o = softmax(q k^T / sqrt(d) [+causal]) v per (sequence, head) on the packed (tokens, 3C) projection."""
+    """o = dropout_p(softmax(q k^T / sqrt(d) [+causal])) v per (sequence, head) on the packed (tokens, 3C) projection."""
 
     @staticmethod
-    def forward(ctx, qkv, seq, Cc, n_head, causal):
+    def forward(ctx, qkv, seq, Cc, n_head, causal, p_drop=0.0):
         o = torch.empty(qkv.shape[0], Cc, dtype=qkv.dtype, device=qkv.device)
-        K.attention(qkv, o, Cc, n_head, seq, causal)
+        seed = next_seed() if p_drop > 0 else 0
+        if p_drop > 0:
+            L.check(L.lib().tante_attention_dropout(qkv.data_ptr(), o.data_ptr(), _DT[qkv.dtype], Cc, n_head, C.byref(seq), int(causal),
+                                                    float(p_drop), seed, _s()), "attention_dropout")
+        else:
+            K.attention(qkv, o, Cc, n_head, seq, causal)
         ctx.save_for_backward(qkv)
-        ctx.seq, ctx.C, ctx.nh, ctx.causal = seq, Cc, n_head, causal
+        ctx.seq, ctx.C, ctx.nh, ctx.causal, ctx.p, ctx.seed = seq, Cc, n_head, causal, float(p_drop), seed
         return o
 
     @staticmethod
@@ -176,8 +190,27 @@ class AttentionFn(Function):
         do = do.contiguous().to(qkv.dtype)
         dqkv = torch.empty_like(qkv)
         L.check(L.lib().tante_attention_bwd(qkv.data_ptr(), do.data_ptr(), dqkv.data_ptr(), _DT[qkv.dtype], ctx.C, ctx.nh, C.byref(ctx.seq),
-                                            int(ctx.causal), _s()), "attention_bwd")
-        return dqkv, None, None, None, None
+                                            int(ctx.causal), ctx.p, ctx.seed, _s()), "attention_bwd")
+        return dqkv, None, None, None, None, None
+
+
+class DropoutAddFn(Function):
+    """out = res + dropout_p(y)   (x + self.drop(y), attn_backbone.py:81-82)."""
+
+    @staticmethod
+    def forward(ctx, y, res, p):
+        seed = next_seed()
+        out = torch.empty_like(res)
+        L.check(L.lib().tante_dropout_add(y.data_ptr(), _DT[y.dtype], res.data_ptr(), float(p), seed, y.numel(), out.data_ptr(), _s()), "dropout_add")
+        ctx.p, ctx.seed, ctx.ydt = float(p), seed, y.dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        dout = dout.contiguous()
+        dy = torch.empty(dout.shape, dtype=ctx.ydt, device=dout.device)
+        L.check(L.lib().tante_dropout_bwd(dout.data_ptr(), ctx.p, ctx.seed, dout.numel(), dy.data_ptr(), _DT[ctx.ydt], _s()), "dropout_bwd")
+        return dy, dout, None
 
 
 class AxisMlpFn(Function):

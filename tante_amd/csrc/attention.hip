@@ -77,7 +77,7 @@ struct Lds {
 
 template <int D>
 __device__ __forceinline__ void online_step(const float* krow, const float* vrow, const float (&q)[D], float& m, float& ssum,
-                                            float (&o)[D]) {
+                                            float (&o)[D], float keep_scale = 1.0f) {
   float sc = 0.0f;
 #pragma unroll
   for (int i = 0; i < D / 4; ++i) {
@@ -87,14 +87,15 @@ __device__ __forceinline__ void online_step(const float* krow, const float* vrow
   const float mn = fmaxf(m, sc);
   const float corr = expf(m - mn);   // m = -inf on the first key -> 0
   const float p = expf(sc - mn);
-  ssum = ssum * corr + p;
+  ssum = ssum * corr + p;                 // the normaliser sees the un-dropped probabilities (dropout acts on softmax's output)
+  const float pd = p * keep_scale;        // keep_scale = 0 (dropped) or 1 / (1 - p_drop)
 #pragma unroll
   for (int i = 0; i < D / 4; ++i) {
     const f32x4 v4 = *(const f32x4*)(vrow + 4 * i);
-    o[4 * i] = o[4 * i] * corr + p * v4[0];
-    o[4 * i + 1] = o[4 * i + 1] * corr + p * v4[1];
-    o[4 * i + 2] = o[4 * i + 2] * corr + p * v4[2];
-    o[4 * i + 3] = o[4 * i + 3] * corr + p * v4[3];
+    o[4 * i] = o[4 * i] * corr + pd * v4[0];
+    o[4 * i + 1] = o[4 * i + 1] * corr + pd * v4[1];
+    o[4 * i + 2] = o[4 * i + 2] * corr + pd * v4[2];
+    o[4 * i + 3] = o[4 * i + 3] * corr + pd * v4[3];
   }
   m = mn;
 }
@@ -102,7 +103,8 @@ __device__ __forceinline__ void online_step(const float* krow, const float* vrow
 // SMALL: grid = (ceil(nseq / G), n_head); G = 256 / L sequences per workgroup
 template <int D>
 __global__ __launch_bounds__(256) void attn_small_kernel(const void* __restrict__ qkv, void* __restrict__ o, int dtype, int C,
-                                                         TanteSeq sq, int G, int causal, float scale) {
+                                                         TanteSeq sq, int G, int causal, float scale, float p_drop,
+                                                         unsigned long long seed) {
   constexpr int ST = Lds<D>::STRIDE;
   extern __shared__ __attribute__((aligned(16))) float sm[];  // K rows [256][ST] then V rows [256][ST]
   float* Ks = sm;
@@ -135,7 +137,14 @@ __global__ __launch_bounds__(256) void attn_small_kernel(const void* __restrict_
   for (int i = 0; i < D; ++i) acc[i] = 0.0f;
   const int nk = causal ? (l + 1) : L;
   const int r0 = g * L;
-  for (int j = 0; j < nk; ++j) online_step<D>(Ks + (r0 + j) * ST, Vs + (r0 + j) * ST, q, m, ssum, acc);
+  if (p_drop > 0.0f) {
+    const float ks = 1.0f / (1.0f - p_drop);
+    const unsigned long long base = (((unsigned long long)s * gridDim.y + h) * L + l) * L;   // (sequence, head, query) row of the mask
+    for (int j = 0; j < nk; ++j)
+      online_step<D>(Ks + (r0 + j) * ST, Vs + (r0 + j) * ST, q, m, ssum, acc, dropout_keep(seed, base + j, p_drop) ? ks : 0.0f);
+  } else {
+    for (int j = 0; j < nk; ++j) online_step<D>(Ks + (r0 + j) * ST, Vs + (r0 + j) * ST, q, m, ssum, acc);
+  }
   const float inv = 1.0f / ssum;
 #pragma unroll
   for (int i = 0; i < D; ++i) acc[i] *= inv;
@@ -194,7 +203,8 @@ __global__ __launch_bounds__(256) void attn_long_kernel(const void* __restrict__
 }
 
 template <int D>
-int launch_attn(const void* qkv, void* o, int dtype, int C, int n_head, const TanteSeq& sq, int causal, hipStream_t s) {
+int launch_attn(const void* qkv, void* o, int dtype, int C, int n_head, const TanteSeq& sq, int causal, float p_drop,
+                unsigned long long seed, hipStream_t s) {
   constexpr int ST = Lds<D>::STRIDE;
   const float scale = 1.0f / sqrtf((float)D);
   if (sq.L <= 256) {
@@ -203,7 +213,7 @@ int launch_attn(const void* qkv, void* o, int dtype, int C, int n_head, const Ta
     if (lds > 64 * 1024)
       hipFuncSetAttribute((const void*)attn_small_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(attn_small_kernel<D>, dim3((sq.nseq + G - 1) / G, n_head), dim3(256), lds, s, qkv, o, dtype, C, sq, G,
-                       causal, scale);
+                       causal, scale, p_drop, seed);
   } else {
     const size_t lds = 2 * 128 * ST * sizeof(float);
     hipLaunchKernelGGL(attn_long_kernel<D>, dim3((sq.L + 255) / 256, sq.nseq, n_head), dim3(256), lds, s, qkv, o, dtype, C, sq,
@@ -214,23 +224,35 @@ int launch_attn(const void* qkv, void* o, int dtype, int C, int n_head, const Ta
 
 }  // namespace
 
-extern "C" int tante_attention(const void* qkv, void* o, int dtype, int C, int n_head, const TanteSeq* seq, int causal,
-                               void* stream) {
+static int attention_impl(const void* qkv, void* o, int dtype, int C, int n_head, const TanteSeq* seq, int causal, float p_drop,
+                          unsigned long long seed, void* stream) {
   if (!qkv || !o || !seq) TANTE_FAIL(-1, "tante_attention: null pointer");
   if (n_head <= 0 || C % n_head) TANTE_FAIL(-1, "tante_attention: C=%d not divisible by n_head=%d", C, n_head);
   if (seq->nseq <= 0 || seq->L <= 0 || seq->n_s0 <= 0 || seq->n_l0 <= 0) TANTE_FAIL(-1, "tante_attention: bad sequence descriptor");
   if (((uintptr_t)qkv % 16) || ((uintptr_t)o % 16)) TANTE_FAIL(-1, "tante_attention: buffers must be 16-byte aligned");
   const int d = C / n_head;
   if (seq->nseq > 65535 && seq->L > 256) TANTE_FAIL(-2, "tante_attention: too many long sequences for one launch");
+  if (p_drop > 0.0f && seq->L > 256) TANTE_FAIL(-2, "tante_attention: attention dropout is implemented for sequences up to 256 tokens");
+  if (p_drop < 0.0f || p_drop >= 1.0f) TANTE_FAIL(-1, "tante_attention: dropout probability must be in [0, 1)");
   hipStream_t s = (hipStream_t)stream;
   switch (d) {
-    case 4: launch_attn<4>(qkv, o, dtype, C, n_head, *seq, causal, s); break;
-    case 8: launch_attn<8>(qkv, o, dtype, C, n_head, *seq, causal, s); break;
-    case 16: launch_attn<16>(qkv, o, dtype, C, n_head, *seq, causal, s); break;
-    case 32: launch_attn<32>(qkv, o, dtype, C, n_head, *seq, causal, s); break;
-    case 64: launch_attn<64>(qkv, o, dtype, C, n_head, *seq, causal, s); break;
+    case 4: launch_attn<4>(qkv, o, dtype, C, n_head, *seq, causal, p_drop, seed, s); break;
+    case 8: launch_attn<8>(qkv, o, dtype, C, n_head, *seq, causal, p_drop, seed, s); break;
+    case 16: launch_attn<16>(qkv, o, dtype, C, n_head, *seq, causal, p_drop, seed, s); break;
+    case 32: launch_attn<32>(qkv, o, dtype, C, n_head, *seq, causal, p_drop, seed, s); break;
+    case 64: launch_attn<64>(qkv, o, dtype, C, n_head, *seq, causal, p_drop, seed, s); break;
     default: TANTE_FAIL(-2, "tante_attention: head dim %d unsupported (4, 8, 16, 32, 64)", d);
   }
   TANTE_CHECK_LAUNCH();
   return 0;
+}
+
+extern "C" int tante_attention(const void* qkv, void* o, int dtype, int C, int n_head, const TanteSeq* seq, int causal,
+                               void* stream) {
+  return attention_impl(qkv, o, dtype, C, n_head, seq, causal, 0.0f, 0ull, stream);
+}
+
+extern "C" int tante_attention_dropout(const void* qkv, void* o, int dtype, int C, int n_head, const TanteSeq* seq, int causal,
+                                       float p_drop, uint64_t seed, void* stream) {
+  return attention_impl(qkv, o, dtype, C, n_head, seq, causal, p_drop, (unsigned long long)seed, stream);
 }

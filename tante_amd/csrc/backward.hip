@@ -188,7 +188,8 @@ __global__ void taylor_bwd_kernel(const float* __restrict__ dout, long dout_bstr
 // phase B (lane = key j):   dk_j = scale * sum_i ds_ij q_i,  dv_j = sum_i p_ij do_i,  ds_ij = p_ij (do_i . v_j - delta_i)
 template <int D>
 __global__ __launch_bounds__(128) void attn_bwd_small_kernel(const void* __restrict__ qkv, const void* __restrict__ dO, void* __restrict__ dqkv,
-                                                             int dtype, int C, TanteSeq sq, int G, int causal, float scale) {
+                                                             int dtype, int C, TanteSeq sq, int G, int causal, float scale, float p_drop,
+                                                             unsigned long long seed) {
   constexpr int ST = D + 4;
   extern __shared__ __attribute__((aligned(16))) float sm[];  // Q, K, V, dO rows [128][ST] each, then m, l, delta [128]
   float* Qs = sm;
@@ -224,6 +225,8 @@ __global__ __launch_bounds__(128) void attn_bwd_small_kernel(const void* __restr
       for (int i = 0; i < D; ++i) sc += Qs[tid * ST + i] * Ks[(r0 + j) * ST + i];
       m = fmaxf(m, sc * scale);
     }
+    const float kscale = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
+    const unsigned long long mrow = (((unsigned long long)s * gridDim.y + h) * L + l) * L;   // this query's row of the dropout mask
     float lsum = 0.f, o[D];
     for (int i = 0; i < D; ++i) o[i] = 0.f;
     for (int j = 0; j < nk; ++j) {
@@ -231,7 +234,8 @@ __global__ __launch_bounds__(128) void attn_bwd_small_kernel(const void* __restr
       for (int i = 0; i < D; ++i) sc += Qs[tid * ST + i] * Ks[(r0 + j) * ST + i];
       const float p = expf(sc * scale - m);
       lsum += p;
-      for (int i = 0; i < D; ++i) o[i] += p * Vs[(r0 + j) * ST + i];
+      const float pd = (p_drop > 0.f && !dropout_keep(seed, mrow + j, p_drop)) ? 0.f : p * kscale;
+      for (int i = 0; i < D; ++i) o[i] += pd * Vs[(r0 + j) * ST + i];
     }
     float delta = 0.f;
     for (int i = 0; i < D; ++i) delta += Gs[tid * ST + i] * o[i] / lsum;
@@ -244,6 +248,7 @@ __global__ __launch_bounds__(128) void attn_bwd_small_kernel(const void* __restr
         dp += Gs[tid * ST + i] * Vs[(r0 + j) * ST + i];
       }
       const float p = expf(sc * scale - m) / lsum;
+      if (p_drop > 0.f) dp = dropout_keep(seed, mrow + j, p_drop) ? dp * kscale : 0.f;   // d(dropped prob) -> d(prob)
       const float ds = p * (dp - delta) * scale;
       for (int i = 0; i < D; ++i) dq[i] += ds * Ks[(r0 + j) * ST + i];
     }
@@ -261,10 +266,17 @@ __global__ __launch_bounds__(128) void attn_bwd_small_kernel(const void* __restr
       dp += Gs[qi * ST + e] * Vs[tid * ST + e];
     }
     const float p = expf(sc * scale - Ms[qi]) / Ls[qi];
+    float pd = p;
+    if (p_drop > 0.f) {
+      const bool keep = dropout_keep(seed, (((unsigned long long)s * gridDim.y + h) * L + i) * L + l, p_drop);
+      const float ks2 = 1.0f / (1.0f - p_drop);
+      pd = keep ? p * ks2 : 0.f;
+      dp = keep ? dp * ks2 : 0.f;
+    }
     const float ds = p * (dp - Ds[qi]) * scale;
     for (int e = 0; e < D; ++e) {
       dk[e] += ds * Qs[qi * ST + e];
-      dv[e] += p * Gs[qi * ST + e];
+      dv[e] += pd * Gs[qi * ST + e];
     }
   }
   const long e = tok * 3L * C + (long)h * D;
@@ -323,6 +335,20 @@ __global__ __launch_bounds__(256) void axis_mlp_bwd_kernel(const float* __restri
     if (a < n) dx[base + (long)a * inner] = gx[a];
 }
 
+// ---- residual dropout: out = res + keep * y / (1 - p)  (self.drop(y) of attn_backbone.py:81-82) and its backward -----------------
+__global__ void dropout_add_kernel(const void* __restrict__ y, int y_dtype, const float* __restrict__ res, float p, unsigned long long seed,
+                                   long n, float* __restrict__ out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float v = dropout_keep(seed, (unsigned long long)i, p) ? ldx(y, y_dtype, i) / (1.0f - p) : 0.0f;
+  out[i] = res[i] + v;
+}
+__global__ void dropout_bwd_kernel(const float* __restrict__ dout, float p, unsigned long long seed, long n, void* __restrict__ dy, int y_dtype) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  stx(dy, y_dtype, i, dropout_keep(seed, (unsigned long long)i, p) ? dout[i] / (1.0f - p) : 0.0f);
+}
+
 template <int N>
 void launch_axis_bwd(const float* x, const float* dy, long outer, int n, long inner, const float* w1, const float* b1, const float* w2,
                      float* dx, float* h, float* dpre, hipStream_t s) {
@@ -331,7 +357,8 @@ void launch_axis_bwd(const float* x, const float* dy, long outer, int n, long in
 }
 
 template <int D>
-void launch_attn_bwd(const void* qkv, const void* dO, void* dqkv, int dtype, int C, int n_head, const TanteSeq& sq, int causal, hipStream_t s) {
+void launch_attn_bwd(const void* qkv, const void* dO, void* dqkv, int dtype, int C, int n_head, const TanteSeq& sq, int causal, float p_drop,
+                     unsigned long long seed, hipStream_t s) {
   const int G = 128 / sq.L;
   const size_t lds = (4 * 128 * (D + 4) + 3 * 128) * sizeof(float);
   static bool set = false;
@@ -340,7 +367,7 @@ void launch_attn_bwd(const void* qkv, const void* dO, void* dqkv, int dtype, int
     set = true;
   }
   hipLaunchKernelGGL(attn_bwd_small_kernel<D>, dim3((sq.nseq + G - 1) / G, n_head), dim3(128), lds, s, qkv, dO, dqkv, dtype, C, sq, G, causal,
-                     1.0f / sqrtf((float)D));
+                     1.0f / sqrtf((float)D), p_drop, seed);
 }
 
 }  // namespace
@@ -443,17 +470,18 @@ extern "C" int tante_taylor_bwd(const float* dout, int64_t dout_bstride, float* 
   return 0;
 }
 extern "C" int tante_attention_bwd(const void* qkv, const void* dO, void* dqkv, int dtype, int C, int n_head, const TanteSeq* seq, int causal,
-                                   void* stream) {
+                                   float p_drop, uint64_t seed_, void* stream) {
+  const unsigned long long seed = (unsigned long long)seed_;
   if (!qkv || !dO || !dqkv || !seq) TANTE_FAIL(-1, "tante_attention_bwd: null pointer");
   if (n_head <= 0 || C % n_head) TANTE_FAIL(-1, "tante_attention_bwd: bad heads");
   if (seq->L > 128) TANTE_FAIL(-2, "tante_attention_bwd: sequences longer than 128 are not on the train path yet (L=%d)", seq->L);
   hipStream_t s = (hipStream_t)stream;
   switch (C / n_head) {
-    case 4: launch_attn_bwd<4>(qkv, dO, dqkv, dtype, C, n_head, *seq, causal, s); break;
-    case 8: launch_attn_bwd<8>(qkv, dO, dqkv, dtype, C, n_head, *seq, causal, s); break;
-    case 16: launch_attn_bwd<16>(qkv, dO, dqkv, dtype, C, n_head, *seq, causal, s); break;
-    case 32: launch_attn_bwd<32>(qkv, dO, dqkv, dtype, C, n_head, *seq, causal, s); break;
-    case 64: launch_attn_bwd<64>(qkv, dO, dqkv, dtype, C, n_head, *seq, causal, s); break;
+    case 4: launch_attn_bwd<4>(qkv, dO, dqkv, dtype, C, n_head, *seq, causal, p_drop, seed, s); break;
+    case 8: launch_attn_bwd<8>(qkv, dO, dqkv, dtype, C, n_head, *seq, causal, p_drop, seed, s); break;
+    case 16: launch_attn_bwd<16>(qkv, dO, dqkv, dtype, C, n_head, *seq, causal, p_drop, seed, s); break;
+    case 32: launch_attn_bwd<32>(qkv, dO, dqkv, dtype, C, n_head, *seq, causal, p_drop, seed, s); break;
+    case 64: launch_attn_bwd<64>(qkv, dO, dqkv, dtype, C, n_head, *seq, causal, p_drop, seed, s); break;
     default: TANTE_FAIL(-2, "tante_attention_bwd: head dim %d unsupported", C / n_head);
   }
   TANTE_CHECK_LAUNCH();
@@ -470,6 +498,21 @@ extern "C" int tante_axis_mlp_bwd(const float* x, const float* dy, int64_t outer
   else if (n <= 48) launch_axis_bwd<48>(x, dy, outer, n, inner, w1, b1, w2, dx, h, dpre, s);
   else if (n <= 64) launch_axis_bwd<64>(x, dy, outer, n, inner, w1, b1, w2, dx, h, dpre, s);
   else TANTE_FAIL(-2, "tante_axis_mlp_bwd: axis length %d > 64 is not on the train path yet", n);
+  TANTE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int tante_dropout_add(const void* y, int y_dtype, const float* res, float p, uint64_t seed, int64_t n, float* out, void* stream) {
+  if (!y || !res || !out || n <= 0 || p < 0.0f || p >= 1.0f) TANTE_FAIL(-1, "tante_dropout_add: bad argument");
+  hipLaunchKernelGGL(dropout_add_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, y, y_dtype, res, p,
+                     (unsigned long long)seed, (long)n, out);
+  TANTE_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int tante_dropout_bwd(const float* dout, float p, uint64_t seed, int64_t n, void* dy, int y_dtype, void* stream) {
+  if (!dout || !dy || n <= 0 || p < 0.0f || p >= 1.0f) TANTE_FAIL(-1, "tante_dropout_bwd: bad argument");
+  hipLaunchKernelGGL(dropout_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dout, p, (unsigned long long)seed,
+                     (long)n, dy, y_dtype);
   TANTE_CHECK_LAUNCH();
   return 0;
 }

@@ -70,3 +70,12 @@ __device__ __forceinline__ float apply_act(float x, int act) {
 __host__ __device__ __forceinline__ int swz_chunk(int r, int c, int cpr) {
   return (cpr >= 16) ? (c ^ (r & 15)) : (c ^ ((r >> 1) & 7));  // cpr == 8 -> two rows per bank row
 }
+
+// ---- counter-based dropout mask: keep(seed, idx) is a pure function, so backward regenerates the forward's mask -------
+__device__ __forceinline__ bool dropout_keep(unsigned long long seed, unsigned long long idx, float p) {
+  unsigned long long z = seed + idx * 0x9E3779B97F4A7C15ull;   // splitmix64 finaliser
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return (float)(z >> 40) * (1.0f / 16777216.0f) >= p;       // 24 uniform bits
+}

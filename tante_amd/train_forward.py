@@ -11,7 +11,7 @@ import torch
 
 from . import _lib as L
 from . import kernels as K
-from .autograd import (ActFn, AttentionFn, AxisMlpFn, DeconvFn, FilmPosFn, LayerNormFn, LinearFn, PatchEmbedFn, TaylorFn)
+from .autograd import (ActFn, AttentionFn, AxisMlpFn, DeconvFn, DropoutAddFn, FilmPosFn, LayerNormFn, LinearFn, PatchEmbedFn, TaylorFn)
 
 
 def _folded(lin_w, lin_b, ln):
@@ -21,19 +21,23 @@ def _folded(lin_w, lin_b, ln):
 
 
 def block_train(blk, x: torch.Tensor, seq, causal: bool, compute: int) -> torch.Tensor:
-    if blk.training and blk.p_drop > 0.0:
-        raise NotImplementedError("dropout > 0 is not implemented on the HIP train path yet (use dropout=0.0)")
+    p = blk.p_drop if blk.training else 0.0     # nn.Dropout / MHA dropout are active in train() mode only
     adt = K.act_torch_dtype(compute)
     a, m = blk.attn, blk.mlp
     w_in, b_in = _folded(a.in_proj_weight, a.in_proj_bias, blk.ln1)
     xh = LayerNormFn.apply(x, blk.ln1.eps, adt)
     qkv = LinearFn.apply(xh, w_in, b_in, None, compute, adt)
-    o = AttentionFn.apply(qkv, seq, blk.embed_dim, blk.n_head, causal)
-    x = LinearFn.apply(o, a.out_proj.weight, a.out_proj.bias, x, compute, torch.float32)
+    o = AttentionFn.apply(qkv, seq, blk.embed_dim, blk.n_head, causal, p)
+    if p > 0.0:
+        x = DropoutAddFn.apply(LinearFn.apply(o, a.out_proj.weight, a.out_proj.bias, None, compute, adt), x, p)
+    else:
+        x = LinearFn.apply(o, a.out_proj.weight, a.out_proj.bias, x, compute, torch.float32)
     w1, b1 = _folded(m[0].weight, m[0].bias, blk.ln2)
     xh2 = LayerNormFn.apply(x, blk.ln2.eps, adt)
     hpre = LinearFn.apply(xh2, w1, b1, None, compute, adt)
     h = ActFn.apply(hpre, L.ACT_GELU_TANH, adt)
+    if p > 0.0:
+        return DropoutAddFn.apply(LinearFn.apply(h, m[2].weight, m[2].bias, None, compute, adt), x, p)
     return LinearFn.apply(h, m[2].weight, m[2].bias, x, compute, torch.float32)
 
 

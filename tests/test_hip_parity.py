@@ -645,3 +645,76 @@ def test_wgrad_lines_and_patches(dev):
     dW = wgrad(_rm_linear(d), _rm_patch(xl, True, n_img, H, W, Cin, P), M, Cout, Cin * P * P, tuple(w.shape), L.F32, layout=L.W_CONV_NHWC,
                P=P, C_other=Cin, device=dev)
     close(dW, w.grad, "fp32")
+
+
+# ---------------------------------------------------------------------------------------------------
+# dropout (train mode): statistics of the mask and exact consistency of forward / backward masks
+# ---------------------------------------------------------------------------------------------------
+def test_dropout_add_statistics_and_backward(dev):
+    from tante_amd import _lib as L
+    n, p, seed = 1 << 20, 0.1, 12345
+    y = torch.ones(n, device=dev)
+    res = torch.zeros(n, device=dev)
+    out = torch.empty(n, device=dev)
+    s = torch.cuda.current_stream().cuda_stream
+    L.check(L.lib().tante_dropout_add(y.data_ptr(), L.F32, res.data_ptr(), p, seed, n, out.data_ptr(), s))
+    kept = out != 0
+    rate = float(kept.float().mean())
+    assert abs(rate - (1 - p)) < 3e-3, rate                              # keep probability 1 - p (3 sigma ~ 9e-4)
+    assert torch.allclose(out[kept], torch.full_like(out[kept], 1 / (1 - p)))   # inverted-dropout scaling
+    assert abs(float(out.mean()) - 1.0) < 5e-3                            # expectation preserved
+    dy = torch.empty(n, device=dev)
+    L.check(L.lib().tante_dropout_bwd(torch.ones(n, device=dev).data_ptr(), p, seed, n, dy.data_ptr(), L.F32, s))
+    assert torch.equal(dy != 0, kept)                                     # backward regenerates exactly the forward's mask
+    out2 = torch.empty(n, device=dev)
+    L.check(L.lib().tante_dropout_add(y.data_ptr(), L.F32, res.data_ptr(), p, seed + 1, n, out2.data_ptr(), s))
+    assert float(((out2 != 0) != kept).float().mean()) > 0.1             # another seed, another mask
+
+
+@pytest.mark.parametrize("causal", [False, True])
+def test_attention_dropout_gradient_matches_finite_differences(dev, causal):
+    """fp32, fixed seed: d(sum(o * w)) / d(qkv) from the HIP backward against central differences of the HIP forward."""
+    import ctypes as Ct
+    from tante_amd import _lib as L, kernels as Kk
+    torch.manual_seed(0)
+    nseq, Lq, C, nh, p, seed = 3, 6, 16, 2, 0.3, 777
+    seq = Kk.dense_seq(nseq, Lq)
+    qkv = torch.randn(nseq * Lq, 3 * C, device=dev)
+    w = torch.randn(nseq * Lq, C, device=dev)
+    s = torch.cuda.current_stream().cuda_stream
+
+    def fwd(t):
+        o = torch.empty(nseq * Lq, C, device=dev)
+        L.check(L.lib().tante_attention_dropout(t.data_ptr(), o.data_ptr(), L.F32, C, nh, Ct.byref(seq), int(causal), p, seed, s))
+        return o
+    o = fwd(qkv)
+    # dropout really happened: o differs from the deterministic attention
+    o0 = torch.empty_like(o)
+    Kk.attention(qkv, o0, C, nh, seq, causal)
+    assert float((o - o0).abs().max()) > 1e-3
+    dq = torch.empty_like(qkv)
+    L.check(L.lib().tante_attention_bwd(qkv.data_ptr(), w.data_ptr(), dq.data_ptr(), L.F32, C, nh, Ct.byref(seq), int(causal), p, seed, s))
+    g = torch.Generator().manual_seed(1)
+    eps = 1e-2
+    for _ in range(12):
+        i, j = int(torch.randint(0, nseq * Lq, (1,), generator=g)), int(torch.randint(0, 3 * C, (1,), generator=g))
+        tp, tm = qkv.clone(), qkv.clone()
+        tp[i, j] += eps
+        tm[i, j] -= eps
+        num = float(((fwd(tp) - fwd(tm)) * w).sum()) / (2 * eps)
+        assert abs(num - float(dq[i, j])) < 2e-2 * max(1.0, abs(num)), (i, j, num, float(dq[i, j]))
+
+
+def test_train_step_with_dropout_runs(dev):
+    import tante_amd
+    g, m, md = _g9_model(dev)
+    for blk in (b for bb in m.blocks for b in bb.blocks):
+        blk.p_drop = 0.1
+    opt = tante_amd.FlatAdamW(m.parameters(), lr=1e-3)
+    fmt = tante_amd.DefaultChannelsFirstFormatter(md)
+    batch = {"input": g["inp"].to(dev), "output": g["out"].to(dev)}
+    l0 = float(tante_amd.train_step(m, opt, batch, fmt, 4))
+    l1 = float(tante_amd.train_step(m, opt, batch, fmt, 4))
+    assert math.isfinite(l0) and math.isfinite(l1)
+    assert abs(l0 - float(g["loss0"])) < 0.2 * float(g["loss0"])       # dropout perturbs, it does not wreck, the loss
+    assert all(torch.isfinite(p).all() for p in m.parameters())
