@@ -188,7 +188,7 @@ def main():
         # the GPU box gives one job a share of the host (16 cores per GPU), whatever os.cpu_count() says
         cores = min(len(os.sched_getaffinity(0)), int(os.environ.get("TANTE_CPU_THREADS", "16")))
         torch.set_num_threads(cores)
-        Bc, nc = min(B, 4), 2
+        Bc, nc = B, n_steps          # the full batch and rollout length: ~10-15 s of CPU work on 16 cores
         cb = {"input": batch["input"][:Bc].cpu(), "output": batch["output"][:Bc, :nc].cpu()}
         with torch.no_grad():
             O.rollout(w, ocfg, {"input": cb["input"][:1], "output": cb["output"][:1, :1]}, 1)      # warm-up
