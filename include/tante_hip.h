@@ -205,6 +205,11 @@ int tante_sumsq(const float* g, int64_t n, double* out, void* stream);
 int tante_adamw_step(float* p, float* m, float* v, const float* g, int64_t n, const double* sumsq, float max_norm, float lr,
                      float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream);
 
+/* g[i] = clamp(g[i], -clip, clip) over a flat gradient bucket: clip_grad_value_ of the adaptive-dt trainer (r_trainer.py:155) */
+int tante_clip_value(float* g, int64_t n, float clip, void* stream);
+/* backward of tante_rt_reduce: dt[b][l] = drt[b] / L (the clamp is straight-through in the reference, tante.py:195-198) */
+int tante_rt_reduce_bwd(const float* drt, int B, int L, float* dt, void* stream);
+
 /* ---- backward kernels of the train step (trainer/trainer.py:191 loss.backward() through the whole rollout) ----------
  * Data gradients of every dense / conv layer are tante_gemm calls with the TANTE_W_*_T packings (dX = dY . W, with the
  * scatter / gather modes of the forward layer swapped); the rest: */

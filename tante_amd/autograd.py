@@ -400,3 +400,21 @@ class MseMeanFn(Function):
         pred, ref = ctx.saved_tensors
         grad = metrics.mse_mean_grad(pred, ref)
         return grad * g, None
+
+
+class RtReduceFn(Function):
+    """rt[b] = mean_l clamp(t[b][l], 0, out_T - 1) + ep with a straight-through clamp (tante.py:194-201)."""
+
+    @staticmethod
+    def forward(ctx, t, B, Lq, out_T, ep):
+        rt = K.rt_reduce(t.contiguous(), B, Lq, out_T, ep)
+        ctx.dims = (B, Lq, tuple(t.shape))
+        return rt
+
+    @staticmethod
+    def backward(ctx, drt):
+        B, Lq, shape = ctx.dims
+        drt = drt.contiguous()
+        dt = torch.empty(shape, dtype=torch.float32, device=drt.device)
+        L.check(L.lib().tante_rt_reduce_bwd(drt.data_ptr(), B, Lq, dt.data_ptr(), _s()), "rt_reduce_bwd")
+        return dt, None, None, None, None

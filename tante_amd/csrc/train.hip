@@ -100,7 +100,33 @@ __global__ void adamw_kernel(float* __restrict__ p, float* __restrict__ m, float
   p[i] = pi - (lr / bc1) * (mi / denom);
 }
 
+__global__ void clip_value_kernel(float* __restrict__ g, long n, float c) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) g[i] = fminf(fmaxf(g[i], -c), c);
+}
+
+// dt[b][l] = drt[b] / L : backward of  rt[b] = mean_l clamp_ST(t[b][l]) + ep  (the clamp is straight-through, tante.py:195-198)
+__global__ void rt_bwd_kernel(const float* __restrict__ drt, int L, long n, float* __restrict__ dt) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dt[i] = drt[i / L] / (float)L;
+}
+
 }  // namespace
+
+extern "C" int tante_clip_value(float* g, int64_t n, float clip, void* stream) {
+  if (!g || n <= 0 || clip <= 0.0f) TANTE_FAIL(-1, "tante_clip_value: bad argument");
+  hipLaunchKernelGGL(clip_value_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g, (long)n, clip);
+  TANTE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int tante_rt_reduce_bwd(const float* drt, int B, int L, float* dt, void* stream) {
+  if (!drt || !dt || B <= 0 || L <= 0) TANTE_FAIL(-1, "tante_rt_reduce_bwd: bad argument");
+  const long n = (long)B * L;
+  hipLaunchKernelGGL(rt_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, drt, L, n, dt);
+  TANTE_CHECK_LAUNCH();
+  return 0;
+}
 
 extern "C" int tante_metric_sums(const float* pred, int64_t pb, int64_t pt, int64_t ps, int64_t pc, const float* ref, int B, int T,
                                  int64_t HW, int C, float* sums, void* stream) {

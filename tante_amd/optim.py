@@ -54,6 +54,11 @@ class FlatAdamW:
                                     torch.cuda.current_stream().cuda_stream), "tante_sumsq")
         return torch.sqrt(self._sumsq)[0].float()
 
+    def clip_grad_value_(self, clip: float):
+        """torch.nn.utils.clip_grad_value_ over the bucket (R_Trainer, trainer/r_trainer.py:155)."""
+        L.check(L.lib().tante_clip_value(self.flat_g.data_ptr(), self.numel, float(clip), torch.cuda.current_stream().cuda_stream),
+                "tante_clip_value")
+
     def step(self, grad_scale: float = 1.0, lr: Optional[float] = None):
         """clip_grad_norm_(max_norm) + AdamW.  grad_scale multiplies the gradients first (1/world after a summed all-reduce)."""
         self.step_count += 1

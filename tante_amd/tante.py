@@ -363,7 +363,7 @@ class TANTE(nn.Module):
             from .train_forward import tante_train_forward
             if out is not None:
                 raise ValueError("out= is an inference-path option")
-            return tante_train_forward(self, input.to(torch.float32).contiguous(), resolve_compute(self.compute))
+            return tante_train_forward(self, input.to(torch.float32).contiguous(), resolve_compute(self.compute), out_T)
         inp = input.detach().to(torch.float32)
         B, T, D, H, W = inp.shape
         frame = D * H * W

@@ -17,7 +17,8 @@ import torch
 from . import dist as D
 from .autograd import MseMeanFn
 from .optim import FlatAdamW
-from .rollout import rollout_model
+from .metrics import MSE
+from .rollout import rollout_adaptive, rollout_model
 
 
 def train_step(model, opt: FlatAdamW, batch: Dict[str, torch.Tensor], formatter, n_steps_output: int, world: int = 1,
@@ -30,3 +31,23 @@ def train_step(model, opt: FlatAdamW, batch: Dict[str, torch.Tensor], formatter,
         D.allreduce_sum_(opt.flat_g)
     opt.step(grad_scale=1.0 / world, lr=lr)
     return loss.detach()
+
+
+def train_step_adaptive(model, opt: FlatAdamW, batch: Dict[str, torch.Tensor], formatter, n_steps_output: int, rt_eps: float = 0.5,
+                        rt_n: float = 2.0, world: int = 1, lr: float = None):
+    """R_Trainer.train_one_epoch's step (trainer/r_trainer.py:135-179) for the adaptive-dt model (deg=False): per-sample rollouts
+    with out_T = 1.5, loss = MSE(...).mean() + eval_rt(Rts, eps, n), clip_grad_value_(1.0) instead of a norm clip, AdamW."""
+    opt.zero_grad()
+    y_pred, y_ref, rts = rollout_adaptive(model, batch, formatter, n_steps_output, 1.5, per_sample=True)
+    loss = MseMeanFn.apply(y_pred, y_ref) + MSE.eval_rt(rts, rt_eps, rt_n)
+    loss.backward()
+    if world > 1:
+        D.allreduce_sum_(opt.flat_g)
+        opt.flat_g.mul_(1.0 / world)
+    opt.clip_grad_value_(1.0)
+    saved, opt.max_norm = opt.max_norm, 0.0          # value clip replaces the norm clip in this trainer
+    try:
+        opt.step(lr=lr)
+    finally:
+        opt.max_norm = saved
+    return loss.detach(), rts.detach()

@@ -11,7 +11,8 @@ import torch
 
 from . import _lib as L
 from . import kernels as K
-from .autograd import (ActFn, AttentionFn, AxisMlpFn, DeconvFn, DropoutAddFn, FilmPosFn, LayerNormFn, LinearFn, PatchEmbedFn, TaylorFn)
+from .autograd import (ActFn, AttentionFn, AxisMlpFn, DeconvFn, DropoutAddFn, FilmPosFn, LayerNormFn, LinearFn, PatchEmbedFn, RtReduceFn,
+                       TaylorFn)
 
 
 def _folded(lin_w, lin_b, ln):
@@ -85,9 +86,17 @@ def decoder_train(dec, a: torch.Tensor, n_img: int, compute: int) -> torch.Tenso
     return x                                   # (n_img, D, H, W) fp32
 
 
-def tante_train_forward(model, inp: torch.Tensor, compute: int) -> torch.Tensor:
-    if not model.deg:
-        raise NotImplementedError("the adaptive-dt variant (deg=False) is not on the HIP train path yet")
+def interprator_train(it, d3: torch.Tensor, B: int, out_T: float, compute: int) -> torch.Tensor:
+    """tante.py:191-201 on (B*L, C) tokens -> rt (B,)."""
+    adt = K.act_torch_dtype(compute)
+    lin = it.interprete
+    h = ActFn.apply(LinearFn.apply(d3, lin[0].weight, lin[0].bias, None, compute, adt), L.ACT_RELU, adt)
+    h = ActFn.apply(LinearFn.apply(h, lin[2].weight, lin[2].bias, None, compute, adt), L.ACT_RELU, adt)
+    t = LinearFn.apply(h, lin[4].weight, lin[4].bias, None, compute, torch.float32)
+    return RtReduceFn.apply(t, B, it.sp_dim, float(out_T), float(it.ep))
+
+
+def tante_train_forward(model, inp: torch.Tensor, compute: int, out_T=1):
     B, T, D, H, W = inp.shape
     Hp, Wp, C_ = model.H_p, model.W_p, model.C
     HW = Hp * Wp
@@ -97,10 +106,25 @@ def tante_train_forward(model, inp: torch.Tensor, compute: int) -> torch.Tensor:
     fa = 1.0 + te.condition_to_scale(t)                                        # (T, C): film(x, t) = x * (1 + scale) + shift
     fb = te.condition_to_shift(t) + model.t_emb.view(T, C_)
     x = FilmPosFn.apply(z, fa.contiguous(), fb.contiguous(), model.s_emb.view(HW, C_), T, HW)
-    derivs = []
+    derivs, rts = [], []
     for i in range(model.taylor_order):
         x = backbone_train(model.blocks[i], x, B, compute)
         last = x.view(B, T, HW, C_)[:, -1].reshape(B * HW, C_)
+        if not model.deg:
+            # intended semantics of tante.py:148-152 (the shipped glue raises): rt from the last slot, 3-D film with rt, decode
+            rt = interprator_train(model.interprators[i], last, B, out_T, compute)
+            rts.append(rt)
+            mod = model.modifiers[i]
+            ma = 1.0 + mod.condition_to_scale(rt[:, None])                     # (B, C): film(x, rt) = x * (1 + scale) + shift
+            mb = mod.condition_to_shift(rt[:, None])
+            zero_pos = torch.zeros(HW, C_, dtype=torch.float32, device=inp.device)
+            last = FilmPosFn.apply(last, ma.contiguous(), mb.contiguous(), zero_pos, B, HW)    # rows (b, hw): table row = b
         d = decoder_train(model.decoders[i], last, B, compute)
         derivs.append(d.view(B, 1, D, H, W))
-    return TaylorFn.apply(inp, model.frame_interval, model.output_length, *derivs)
+    if model.deg:
+        return TaylorFn.apply(inp, model.frame_interval, model.output_length, *derivs)
+    R_t = torch.stack(rts, dim=1).mean(dim=1)
+    n_out = int(torch.floor(R_t[0].detach()))          # tante.py:163 -- sample 0 decides (host sync, as in the reference)
+    if n_out < 1:
+        return torch.empty(B, 0, D, H, W, dtype=torch.float32, device=inp.device), R_t
+    return TaylorFn.apply(inp, model.frame_interval, n_out, *derivs), R_t

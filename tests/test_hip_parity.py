@@ -718,3 +718,56 @@ def test_train_step_with_dropout_runs(dev):
     assert math.isfinite(l0) and math.isfinite(l1)
     assert abs(l0 - float(g["loss0"])) < 0.2 * float(g["loss0"])       # dropout perturbs, it does not wreck, the loss
     assert all(torch.isfinite(p).all() for p in m.parameters())
+
+
+# ---------------------------------------------------------------------------------------------------
+# adaptive-dt (deg=False) on the train path: gradients against autograd of the (g13-pinned) oracle
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("out_T", [1.5, 6])
+def test_adaptive_dt_gradients_against_oracle(dev, out_T):
+    import tante_amd
+    from oracle import tante_oracle as O
+    g = load_golden("g13_deg_false")
+    md = tante_amd.TanteMetadata(n_fields=1, spatial_resolution=(32, 32))
+    m = tante_amd.TANTE(in_T=4, dset_metadata=md, taylor_order=2, attn_axes="TH-TW", n_head=2, embed_dim=32, patch_scale=8,
+                        dropout=0.0, deg=False).to(dev).train()
+    m.load_state_dict(split_prefix(g, "w."))
+    cfg = O.TanteCfg(4, 1, (32, 32), taylor_order=2, attn_axes="TH-TW", n_head=2, embed_dim=32, patch_scale=8, deg=False)
+    w = {k: v.clone().requires_grad_(True) for k, v in split_prefix(g, "w.").items()}
+    x = g["x"]
+    y_o, rt_o = O.tante_forward(w, cfg, x, out_T)
+    tgt = torch.randn(y_o.shape, generator=torch.Generator().manual_seed(3))
+    loss_o = ((y_o - tgt) ** 2).mean() + 0.3 * (rt_o ** 2).sum()
+    ks = list(w)
+    grads_o = torch.autograd.grad(loss_o, [w[k] for k in ks], allow_unused=True)
+    y, rt = m(x.to(dev), out_T)
+    assert y.shape == y_o.shape
+    close(y, y_o, "fp32")
+    close(rt, rt_o, "fp32")
+    loss = ((y - tgt.to(dev)) ** 2).mean() + 0.3 * (rt ** 2).sum()
+    loss.backward()
+    named = dict(m.named_parameters())
+    for k, go in zip(ks, grads_o):
+        if go is None:
+            continue
+        assert named[k].grad is not None, k
+        assert max_rel(named[k].grad.cpu(), go) < 3e-4, (k, max_rel(named[k].grad.cpu(), go))
+
+
+def test_adaptive_train_step_runs(dev):
+    """R_Trainer-style step: per-sample rollouts with out_T = 1.5, MSE + eval_rt, clip_grad_value_, AdamW."""
+    import tante_amd
+    g = load_golden("g13_deg_false")
+    md = tante_amd.TanteMetadata(n_fields=1, spatial_resolution=(32, 32))
+    m = tante_amd.TANTE(in_T=4, dset_metadata=md, taylor_order=2, attn_axes="TH-TW", n_head=2, embed_dim=32, patch_scale=8,
+                        dropout=0.0, deg=False).to(dev).train()
+    m.load_state_dict(split_prefix(g, "w."))
+    opt = tante_amd.FlatAdamW(m.parameters(), lr=1e-3)
+    gen = torch.Generator().manual_seed(0)
+    batch = {"input": torch.randn(2, 4, 32, 32, 1, generator=gen).to(dev), "output": torch.randn(2, 3, 32, 32, 1, generator=gen).to(dev)}
+    fmt = tante_amd.DefaultChannelsFirstFormatter(md)
+    w_before = opt.flat_p.clone()
+    loss, rts = tante_amd.train_step_adaptive(m, opt, batch, fmt, 3)
+    assert math.isfinite(float(loss)) and rts.numel() >= 2 and bool(((rts >= 1.0) & (rts <= 1.502)).all())
+    assert float((opt.flat_p - w_before).abs().max()) > 0          # the step moved the weights
+    assert float(opt.flat_g.abs().max()) <= 1.0 + 1e-6              # clip_grad_value_(1.0) was applied
