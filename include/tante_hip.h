@@ -186,6 +186,20 @@ int tante_pack_block(const float* ln1_w, const float* ln1_b, const float* in_w, 
 int tante_block_fused(float* x, const void* block_stream, int C, int n_head, int hidden, const TanteSeq* seq, int causal,
                       float eps, void* stream);
 
+/* ---- fused derivative head (bf16 MFMA path) ----------------------------------------------------------
+ * One launch per Taylor order: rows r = (img, hp, wp) of the token stream (gathered like TANTE_A_LINEAR: the last time slot by
+ * stride) -> 3 x [ConvTranspose2d k = s = 2 (+GELU erf)] -> for i < n_out:  out_i (+)= coefs[i] * derivative, where out_i is frame i
+ * of out[img] (out + img * out_bstride + i * D*H*W, channels-first) and, when `last` != NULL, the sum starts from the last input
+ * frame (last + img * last_bstride) instead of accumulating.  Replaces dec_CNN.forward (enc_dec_cnn.py:263-277) and the Taylor sum
+ * (tante.py:165-171); the three intermediate images and the derivative fields never exist.  C in {128, 256}, D <= 16, patch_scale 8. */
+int tante_head_fused_supported(int C, int D);
+int64_t tante_head_stream_bytes(int C);
+int tante_pack_head(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3, const float* b3, int C, int D,
+                    void* head_stream, void* stream);
+int tante_head_fused(const float* x, int32_t a_n0, int64_t a_s1, int64_t a_s0, int64_t a_off, int n_img, int Hp, int Wp, int C, int D,
+                     const void* head_stream, float* out, int64_t out_bstride, int n_out, const float* coefs, const float* last,
+                     int64_t last_bstride, void* stream);
+
 /* ---- losses / metrics / optimiser step of the harness ------------------------------------------------
  * pred is addressed as pred[b*pb + t*pt + s*ps + c*pc] (so the channels-first rollout buffer needs no permute copy),
  * ref and grad are contiguous channels-last (B, T, HW, C).

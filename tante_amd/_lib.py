@@ -59,6 +59,10 @@ SIGNATURES = {
     "tante_block_stream_bytes": ([c_i32, c_i32], c_i64),
     "tante_pack_block": ([c_vp] * 12 + [c_i32, c_i32, c_vp, c_vp], c_i32),
     "tante_block_fused": ([c_vp, c_vp, c_i32, c_i32, c_i32, C.POINTER(Seq), c_i32, c_f32, c_vp], c_i32),
+    "tante_head_fused_supported": ([c_i32, c_i32], c_i32),
+    "tante_head_stream_bytes": ([c_i32], c_i64),
+    "tante_pack_head": ([c_vp] * 6 + [c_i32, c_i32, c_vp, c_vp], c_i32),
+    "tante_head_fused": ([c_vp, c_i32, c_i64, c_i64, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_i64, c_vp], c_i32),
     "tante_metric_sums": ([c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_i32, c_i32, c_i64, c_i32, c_vp, c_vp], c_i32),
     "tante_mse_grad": ([c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_i32, c_i32, c_i64, c_i32, c_f32, c_vp, c_vp], c_i32),
     "tante_sumsq": ([c_vp, c_i64, c_vp, c_vp], c_i32),

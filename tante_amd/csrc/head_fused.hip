@@ -1,0 +1,311 @@
+// Fused derivative head (bf16):  tokens of the last time slot -> 3 x [ConvTranspose2d k = s = 2 (+GELU)] -> Taylor accumulation
+// into the prediction frames, ONE launch per Taylor order  (enc_dec_cnn.py:263-277 + tante.py:165-171).
+//
+// A token's 8 x 8 x D output block depends on that token alone: stage 1 makes its 2 x 2 pixels (C/2 channels each), stage 2 the
+// 2 x 2 sub-pixels of each (C/4 channels), stage 3 the 2 x 2 x D values of each.  A wave owns 16 tokens; every intermediate is
+// an MFMA accumulator tile that is re-packed (bf16) into the next stage's B operand in registers (k order = accumulator order,
+// weights packed to match -- the same chaining as the fused block kernel).  The weights stream through LDS once per workgroup:
+// W3 (resident), W1 in 4 pixel tiles, W2 in 4 sub-pixel tiles.  The epilogue adds  coef_i * derivative  straight into the
+// output frames (out_i = last + sum_k coef_ik d_k: the first order starts from the last input frame, later orders accumulate),
+// so neither the three intermediate images nor the derivative fields nor a separate Taylor pass exist.
+#include "common.cuh"
+#include <stdlib.h>
+#include <utility>
+
+namespace {
+
+template <class F, int... Is>
+__device__ __forceinline__ void sfor_impl(F&& f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void sfor(F&& f) { sfor_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{}); }
+
+__device__ __forceinline__ u32x4 hpack8(const f32x4& a, const f32x4& b) {
+  u32x4 f;
+  f[0] = pack_bf16x2(a[0], a[1]); f[1] = pack_bf16x2(a[2], a[3]); f[2] = pack_bf16x2(b[0], b[1]); f[3] = pack_bf16x2(b[2], b[3]);
+  return f;
+}
+__device__ __forceinline__ f32x4 hmfma(const u32x4& a, const u32x4& b, const f32x4& c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 gelu4(const f32x4& v) {
+  return f32x4{gelu_erf_fast(v[0]), gelu_erf_fast(v[1]), gelu_erf_fast(v[2]), gelu_erf_fast(v[3])};
+}
+constexpr int HWAVES = 4;   // waves per workgroup (16 tokens each)
+__device__ __forceinline__ void hglds(const char* __restrict__ g, char* l, int bytes, int tid) {   // 1 KiB per wave pass
+  const int wave = tid >> 6, lane = tid & 63;
+  for (int off = wave * 1024; off < bytes; off += HWAVES * 1024)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + off + lane * 16),
+                                     (__attribute__((address_space(3))) void*)(l + off), 16, 0, 0);
+}
+
+struct HeadArgs {
+  const float* x;        // token stream
+  long a_s1, a_s0, a_off; int a_n0;   // row r = (img, hp, wp) -> (r / a_n0) * a_s1 + (r % a_n0) * a_s0 + a_off
+  int n_img, Hp, Wp, D;
+  const char* w;         // packed stream: [W3 | bias3] [W1 tile p | bias1 p] x4 [W2 tile q | bias2 q] x4
+  float* out; long out_bstride; int n_out;
+  const float* last; long last_bstride;   // NULL: accumulate into out; else out_i = last + coef_i * d
+  float coef[8];
+  int groups;            // 64-token groups
+  int debug;             // TANTE_HEAD_DEBUG ablation bits (timing only, results are wrong): 1 no epilogue memory, 2 no GELU, 4 no weight stream
+};
+
+constexpr int HB = 4096;   // bias block bytes per tile (whole LDS-DMA passes)
+
+// sizes for C = 32 * CB:  stage 1: K = C, 4 pixel tiles of C/2 rows;  stage 2: K = C/2, 4 tiles of C/4 rows;  stage 3: K = C/4, 64 rows
+template <int CB>
+struct HeadGeom {
+  static constexpr int C = 32 * CB, C1 = C / 2, C2 = C / 4;
+  static constexpr int CPR1 = CB * 4, CPR2 = CB * 2, CPR3 = CB;          // 16-byte chunks per row (K / 8)
+  static constexpr int NS1 = C1 / 16, NS2 = C2 / 16, NSH = NS1 / 2;      // 16-row sub-tiles (NSH: per half W1 tile)
+  static constexpr int KB2 = C1 / 32, KB3 = C2 / 32;                     // k-blocks of stages 2, 3
+  static constexpr int T1 = C1 * CPR1 * 16 + HB, T2 = C2 * CPR2 * 16 + HB, T3 = 64 * CPR3 * 16 + HB;
+  static constexpr int HALF1 = (C1 / 2) * CPR1 * 16;                     // half a W1 pixel tile (rows [0, C1/2) or [C1/2, C1))
+  static constexpr int SLOT = HALF1 > T2 ? HALF1 : T2;
+  static constexpr int B1S = 1024;                                       // stage-1 bias of this workgroup's pixel
+  static constexpr int LDS = T3 + B1S + 2 * SLOT;
+};
+
+// Work split: a workgroup owns 64 tokens AND one stage-1 pixel p; everything downstream of that pixel (its 4 sub-pixels, their
+// 2 x 2 x D values) depends on nothing else, so the four pixel workgroups of a token group never talk.  That quadruples the number
+// of waves over a token-only split (B = 8 has just 512 token groups of 16 for 1024 SIMDs) and shrinks the per-workgroup stream to
+// W1[p] + W2 + W3, small enough for two workgroups per CU -- the kernel is latency-bound per wave, so co-resident waves are what
+// hides the LDS / MFMA / epilogue-memory latencies.  blockIdx -> (group, p) keeps the four pixels of a group on one XCD (their
+// output sectors interleave, the L2 merges them).
+template <int CB>
+__global__ __launch_bounds__(HWAVES * 64, 2) void fused_head_kernel(const HeadArgs A) {
+  using G = HeadGeom<CB>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [W3 | bias3][bias1 p][slot 0][slot 1]
+  char* w3s = smem;
+  char* b1s = smem + G::T3;
+  char* slots = smem + G::T3 + G::B1S;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kk = lane >> 4, l15 = lane & 15;
+  const int p = (blockIdx.x & 31) >> 3;                          // stage-1 pixel (kh, kw) = (p >> 1, p & 1)
+  const int grp = (blockIdx.x >> 5) * 8 + (blockIdx.x & 7);
+  if (grp >= A.groups) return;
+  const char* w1p = A.w + G::T3 + (long)p * G::T1;
+  const char* w2 = A.w + G::T3 + 4L * G::T1;
+  hglds(A.w, w3s, G::T3, tid);
+  if (wave == 0)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w1p + G::C1 * G::CPR1 * 16 + lane * 16),
+                                     (__attribute__((address_space(3))) void*)b1s, 16, 0, 0);
+  hglds(w1p, slots, G::HALF1, tid);
+
+  const int HW = A.Hp * A.Wp;
+  const long row = ((long)grp * HWAVES + wave) * 16 + l15;
+  const bool live = row < (long)A.n_img * HW;
+  const long r = live ? row : 0;
+  const int img = (int)(r / HW), hw = (int)(r % HW), hp = hw / A.Wp, wp = hw % A.Wp;
+  const float* xr = A.x + (r / A.a_n0) * A.a_s1 + (r % A.a_n0) * A.a_s0 + A.a_off;
+  u32x4 xf[CB];   // the token as B-operand k-blocks, accumulator (k-permuted) order
+#pragma unroll
+  for (int b = 0; b < CB; ++b) {
+    const f32x4 lo = *(const f32x4*)(xr + 32 * b + 4 * kk), hi = *(const f32x4*)(xr + 32 * b + 16 + 4 * kk);
+    xf[b] = live ? hpack8(lo, hi) : u32x4{0u, 0u, 0u, 0u};
+  }
+  int xo1[CB], xo2[G::KB2], xo3[G::KB3];
+#pragma unroll
+  for (int b = 0; b < CB; ++b) xo1[b] = swz_chunk(l15, b * 4 + kk, G::CPR1) << 4;
+#pragma unroll
+  for (int b = 0; b < G::KB2; ++b) xo2[b] = swz_chunk(l15, b * 4 + kk, G::CPR2) << 4;
+#pragma unroll
+  for (int b = 0; b < G::KB3; ++b) xo3[b] = swz_chunk(l15, b * 4 + kk, G::CPR3) << 4;
+
+  // epilogue addressing: the values the epilogue adds to (frame 0) are `last` for the first order and `out` itself for the later
+  // ones; they are fetched one sub-pixel step ahead of their use so the read-modify-write never stalls the MFMA stream.
+  const long frame = (long)A.D * (A.Hp * 8) * (A.Wp * 8);
+  const int Wout = A.Wp * 8;
+  const float* rmw_src = A.last ? A.last + (long)img * A.last_bstride : A.out + (long)img * A.out_bstride;
+  auto pix_of = [&](int q, int ns) {
+    const int y0 = hp * 8 + (p >> 1) * 4 + (q >> 1) * 2, x0 = wp * 8 + (p & 1) * 4 + (q & 1) * 2;
+    return ((long)(4 * ns + kk) * (A.Hp * 8) + y0) * Wout + x0;
+  };
+  float2 pre[4][2], nxt[4][2];
+  auto prefetch = [&](int q, float2 (&dst)[4][2]) {
+#pragma unroll
+    for (int ns = 0; ns < 4; ++ns)
+      if (4 * ns < A.D && live && 4 * ns + kk < A.D && !(A.debug & 1)) {
+        const float* lp = rmw_src + pix_of(q, ns);
+        dst[ns][0] = *(const float2*)lp;
+        dst[ns][1] = *(const float2*)(lp + Wout);
+      }
+  };
+
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  // ---- stage 1: pixel p in two half tiles; h1[kb] = B-operand k-blocks (C/2 channels) for stage 2 ------------------------------
+  u32x4 h1[G::KB2];
+  const float* bias1 = (const float*)b1s;
+  sfor<2>([&](auto hc) {
+    constexpr int h = decltype(hc)::value;
+    if (!(A.debug & 4)) {
+      if constexpr (h == 0) hglds(w1p + G::HALF1, slots + G::SLOT, G::HALF1, tid);
+      else hglds(w2, slots, G::T2, tid);
+    }
+    if constexpr (h == 1) prefetch(0, pre);
+    const char* wt = slots + h * G::SLOT;
+    f32x4 acc[G::NSH];
+#pragma unroll
+    for (int ns = 0; ns < G::NSH; ++ns) acc[ns] = *(const f32x4*)(bias1 + (h * G::NSH + ns) * 16 + kk * 4);
+#pragma unroll
+    for (int b = 0; b < CB; ++b)
+#pragma unroll
+      for (int ns = 0; ns < G::NSH; ++ns) acc[ns] = hmfma(*(const u32x4*)(wt + (ns * 16 + l15) * G::CPR1 * 16 + xo1[b]), xf[b], acc[ns]);
+#pragma unroll
+    for (int b = 0; b < G::NSH / 2; ++b)
+      h1[h * (G::NSH / 2) + b] = (A.debug & 2) ? hpack8(acc[2 * b], acc[2 * b + 1]) : hpack8(gelu4(acc[2 * b]), gelu4(acc[2 * b + 1]));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  });
+
+  // ---- stages 2 + 3: sub-pixel tile q of W2 (continuing the ring), W3 resident ------------------------------------------------
+  const float* bias3 = (const float*)(w3s + 64 * G::CPR3 * 16);
+  sfor<4>([&](auto qc) {
+    constexpr int q = decltype(qc)::value;           // sub-pixel (kh2, kw2) = (q >> 1, q & 1)
+    if constexpr (q < 3) { if (!(A.debug & 4)) hglds(w2 + (long)(q + 1) * G::T2, slots + ((q + 1) & 1) * G::SLOT, G::T2, tid); }
+    if constexpr (q < 3) prefetch(q + 1, nxt);
+    const char* wt = slots + (q & 1) * G::SLOT;
+    const float* bias2 = (const float*)(wt + G::C2 * G::CPR2 * 16);
+    f32x4 acc2[G::NS2];
+#pragma unroll
+    for (int ns = 0; ns < G::NS2; ++ns) acc2[ns] = *(const f32x4*)(bias2 + ns * 16 + kk * 4);
+#pragma unroll
+    for (int b = 0; b < G::KB2; ++b)
+#pragma unroll
+      for (int ns = 0; ns < G::NS2; ++ns) acc2[ns] = hmfma(*(const u32x4*)(wt + (ns * 16 + l15) * G::CPR2 * 16 + xo2[b]), h1[b], acc2[ns]);
+    u32x4 h2[G::KB3];
+#pragma unroll
+    for (int b = 0; b < G::KB3; ++b) h2[b] = (A.debug & 2) ? hpack8(acc2[2 * b], acc2[2 * b + 1]) : hpack8(gelu4(acc2[2 * b]), gelu4(acc2[2 * b + 1]));
+    // stage 3: rows n3 = (co, kh3, kw3) = 16 ns + 4 kk + r  ->  channel co = 4 ns + kk, r = (kh3, kw3)
+#pragma unroll
+    for (int ns = 0; ns < 4; ++ns) {
+      if (4 * ns < A.D) {   // uniform: this 16-row tile holds real channels
+        f32x4 d = *(const f32x4*)(bias3 + ns * 16 + kk * 4);
+#pragma unroll
+        for (int b = 0; b < G::KB3; ++b) d = hmfma(*(const u32x4*)(w3s + (ns * 16 + l15) * G::CPR3 * 16 + xo3[b]), h2[b], d);
+        if ((A.debug & 1) && d[0] != 1.2345f) continue;
+        if (live && 4 * ns + kk < A.D) {
+          const long pix = pix_of(q, ns);
+          float* o0 = A.out + (long)img * A.out_bstride + pix;
+          const float c0 = A.coef[0];
+          *(float2*)o0 = make_float2(pre[ns][0].x + c0 * d[0], pre[ns][0].y + c0 * d[1]);
+          *(float2*)(o0 + Wout) = make_float2(pre[ns][1].x + c0 * d[2], pre[ns][1].y + c0 * d[3]);
+#pragma unroll
+          for (int i = 1; i < 8; ++i) {   // further output frames (output_length > 1 / adaptive dt): plain read-modify-write
+            if (i >= A.n_out) break;
+            float* o = o0 + (long)i * frame;
+            const float* bp = A.last ? A.last + (long)img * A.last_bstride + pix : o;
+            const float2 r0 = *(const float2*)bp, r1 = *(const float2*)(bp + Wout);
+            const float c = A.coef[i];
+            *(float2*)o = make_float2(r0.x + c * d[0], r0.y + c * d[1]);
+            *(float2*)(o + Wout) = make_float2(r1.x + c * d[2], r1.y + c * d[3]);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int ns = 0; ns < 4; ++ns) { pre[ns][0] = nxt[ns][0]; pre[ns][1] = nxt[ns][1]; }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  });
+}
+
+// ---- stream packing: one thread block per tile -------------------------------------------------------------------------------
+__device__ __forceinline__ int hkperm(int p) {   // position p of a k-permuted row holds source feature c
+  const int blk = p >> 5, qq = p & 31, kk = qq >> 3, dt = (qq >> 2) & 1, r = qq & 3;
+  return blk * 32 + dt * 16 + kk * 4 + r;
+}
+
+// ConvTranspose2d weights (Cin, Cout, 2, 2) of the three stages -> [W3][W1 x4][W2 x4] tiles, rows k-permuted
+__global__ void pack_head_stream_kernel(const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2,
+                                        const float* __restrict__ b2, const float* __restrict__ w3, const float* __restrict__ b3, int C, int D,
+                                        char* __restrict__ dst) {
+  const int C1 = C / 2, C2 = C / 4;
+  const int cpr1 = C / 8, cpr2 = C1 / 8, cpr3 = C2 / 8;
+  const long T1 = (long)C1 * cpr1 * 16 + HB, T2 = (long)C2 * cpr2 * 16 + HB, T3 = 64L * cpr3 * 16 + HB;
+  const int t = blockIdx.x;   // 0: W3, 1..4: W1 pixel tiles, 5..8: W2 sub-pixel tiles
+  const float* w; const float* b; int rows, cpr, K, Cout, pix; char* base;
+  if (t == 0) { w = w3; b = b3; rows = 64; cpr = cpr3; K = C2; Cout = D; pix = -1; base = dst; }
+  else if (t <= 4) { w = w1; b = b1; rows = C1; cpr = cpr1; K = C; Cout = C1; pix = t - 1; base = dst + T3 + (long)(t - 1) * T1; }
+  else { w = w2; b = b2; rows = C2; cpr = cpr2; K = C1; Cout = C2; pix = t - 5; base = dst + T3 + 4 * T1 + (long)(t - 5) * T2; }
+  for (int idx = threadIdx.x; idx < rows * cpr; idx += blockDim.x) {
+    const int r = idx / cpr, c = idx % cpr;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int k = hkperm(c * 8 + e);   // input channel ci
+      float xv = 0.f;
+      if (pix >= 0) {                    // row = output channel co of pixel (kh, kw) = pix
+        xv = w[(((long)k * Cout + r) * 2 + (pix >> 1)) * 2 + (pix & 1)];
+      } else if (r < 4 * D) {            // stage 3: row n3 = (co, kh3, kw3)
+        xv = w[(long)k * (D * 4) + r];
+      }
+      v[e] = xv;
+    }
+    u32x4 o;
+    o[0] = pack_bf16x2(v[0], v[1]); o[1] = pack_bf16x2(v[2], v[3]); o[2] = pack_bf16x2(v[4], v[5]); o[3] = pack_bf16x2(v[6], v[7]);
+    *((u32x4*)base + (long)r * cpr + swz_chunk(r, c, cpr)) = o;
+  }
+  float* bias = (float*)(base + (long)rows * cpr * 16);
+  for (int r = threadIdx.x; r < 256; r += blockDim.x) {
+    float v = 0.f;
+    if (pix >= 0) { if (r < rows) v = b[r]; }
+    else if (r < 4 * D) v = b[r / 4];
+    bias[r] = v;
+  }
+}
+
+template <int CB>
+void launch_head(HeadArgs A, hipStream_t s) {
+  using G = HeadGeom<CB>;
+  static bool set = false;
+  if (!set) {
+    hipFuncSetAttribute((const void*)fused_head_kernel<CB>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
+    set = true;
+  }
+  const long rows = (long)A.n_img * A.Hp * A.Wp;
+  A.groups = (int)((rows + HWAVES * 16 - 1) / (HWAVES * 16));
+  const unsigned grid = (unsigned)((A.groups + 7) / 8) * 32;   // 8 token groups x 4 pixels per 32 consecutive workgroups
+  hipLaunchKernelGGL(fused_head_kernel<CB>, dim3(grid), dim3(HWAVES * 64), G::LDS, s, A);
+}
+
+}  // namespace
+
+extern "C" int tante_head_fused_supported(int C, int D) { return (C == 128 || C == 256) && D >= 1 && D <= 16; }
+
+extern "C" int64_t tante_head_stream_bytes(int C) {
+  const long C1 = C / 2, C2 = C / 4;
+  return (64L * (C2 / 8) * 16 + HB) + 4 * (C1 * (long)(C / 8) * 16 + HB) + 4 * (C2 * (C1 / 8) * 16 + HB);
+}
+
+extern "C" int tante_pack_head(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3, const float* b3, int C, int D,
+                               void* head_stream, void* stream) {
+  if (!w1 || !b1 || !w2 || !b2 || !w3 || !b3 || !head_stream) TANTE_FAIL(-1, "tante_pack_head: null pointer");
+  if (!tante_head_fused_supported(C, D)) TANTE_FAIL(-2, "tante_pack_head: unsupported C=%d D=%d", C, D);
+  hipLaunchKernelGGL(pack_head_stream_kernel, dim3(9), dim3(256), 0, (hipStream_t)stream, w1, b1, w2, b2, w3, b3, C, D, (char*)head_stream);
+  TANTE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int tante_head_fused(const float* x, int32_t a_n0, int64_t a_s1, int64_t a_s0, int64_t a_off, int n_img, int Hp, int Wp, int C, int D,
+                                const void* head_stream, float* out, int64_t out_bstride, int n_out, const float* coefs, const float* last,
+                                int64_t last_bstride, void* stream) {
+  if (!x || !head_stream || !out || !coefs) TANTE_FAIL(-1, "tante_head_fused: null pointer");
+  if (!tante_head_fused_supported(C, D)) TANTE_FAIL(-2, "tante_head_fused: unsupported C=%d D=%d", C, D);
+  if (n_out < 1 || n_out > 8 || a_n0 <= 0 || n_img <= 0 || Hp <= 0 || Wp <= 0) TANTE_FAIL(-1, "tante_head_fused: bad shape");
+  if (a_s1 % 4 || a_s0 % 4 || a_off % 4 || out_bstride % 2 || last_bstride % 2 || ((uintptr_t)x % 16) || ((uintptr_t)out % 8) ||
+      (last && ((uintptr_t)last % 8)))
+    TANTE_FAIL(-1, "tante_head_fused: alignment");
+  HeadArgs A;
+  A.x = x; A.a_n0 = a_n0; A.a_s1 = a_s1; A.a_s0 = a_s0; A.a_off = a_off;
+  A.n_img = n_img; A.Hp = Hp; A.Wp = Wp; A.D = D;
+  A.w = (const char*)head_stream; A.out = out; A.out_bstride = out_bstride; A.n_out = n_out;
+  A.last = last; A.last_bstride = last_bstride;
+  for (int i = 0; i < 8; ++i) A.coef[i] = i < n_out ? coefs[i] : 0.f;
+  { const char* dbg = getenv("TANTE_HEAD_DEBUG"); A.debug = dbg ? atoi(dbg) : 0; }
+  if (C == 128) launch_head<4>(A, (hipStream_t)stream);
+  else launch_head<8>(A, (hipStream_t)stream);
+  TANTE_CHECK_LAUNCH();
+  return 0;
+}

@@ -278,3 +278,32 @@ def block_fused(x: torch.Tensor, block_stream: torch.Tensor, C_: int, n_head: in
     L.check(L.lib().tante_block_fused(_p(x), _p(block_stream), C_, n_head, hidden, C.byref(seq), int(causal), eps, _stream()),
             "tante_block_fused")
     return x
+
+
+# ---- fused derivative head (bf16) ---------------------------------------------------------------------------------------
+def head_fused_supported(C_: int, D: int) -> bool:
+    return bool(L.lib().tante_head_fused_supported(C_, D))
+
+
+def pack_head(params: Sequence[torch.Tensor], C_: int, D: int) -> torch.Tensor:
+    """params = (deconv1.w, deconv1.b, deconv2.w, deconv2.b, deconv3.w, deconv3.b) -> the head's weight stream."""
+    ps = [p.detach() for p in params]
+    _dev(*ps)
+    st = torch.empty(L.lib().tante_head_stream_bytes(C_), dtype=torch.uint8, device=ps[0].device)
+    L.check(L.lib().tante_pack_head(*[_p(p) for p in ps], C_, D, _p(st), _stream()), "tante_pack_head")
+    return st
+
+
+def head_fused(x: torch.Tensor, a_n0: int, a_s1: int, a_s0: int, a_off: int, n_img: int, Hp: int, Wp: int, C_: int, D: int,
+               head_stream: torch.Tensor, out: torch.Tensor, out_bstride: int, coefs: Sequence[float], last: Optional[torch.Tensor],
+               last_elem_off: int = 0, last_bstride: int = 0):
+    """out_i (+)= coefs[i] * head(x rows); `out` / `last` are base tensors addressed by data_ptr (+ offset) and a batch stride."""
+    _dev(x, head_stream)
+    if not out.is_cuda:
+        raise RuntimeError("tante_amd kernels need CUDA/HIP tensors (no CPU fallback)")
+    n_out = len(coefs)
+    arr = (C.c_float * n_out)(*[float(c) for c in coefs])
+    lp = None if last is None else last.data_ptr() + 4 * last_elem_off
+    L.check(L.lib().tante_head_fused(_p(x), a_n0, a_s1, a_s0, a_off, n_img, Hp, Wp, C_, D, _p(head_stream), out.data_ptr(), out_bstride,
+                                     n_out, arr, lp, last_bstride, _stream()), "tante_head_fused")
+    return out

@@ -164,6 +164,12 @@ class dec_CNN(nn.Module):
             return out
         return self._cache.get(compute, params, build)
 
+    def packed_head(self):
+        """Weight stream of the fused head kernel (kernels.head_fused), rebuilt when a deconv parameter changes."""
+        convs = [getattr(self, f"dec_conv_{i + 1}").deconv for i in range(3)]
+        params = [p for c in convs for p in (c.weight, c.bias)]
+        return self._cache.get(-2, params, lambda: K.pack_head(params, self.embed_dim, self.chans[3]))
+
     def forward_tokens(self, src: torch.Tensor, n_img: int, compute: int, a_n0: int, a_s1: int, a_s0: int, a_off: int) -> torch.Tensor:
         """Rows (img, hp, wp) of `src` (gathered by the given strides, in elements) -> (n_img, D, H, W) fp32."""
         pk = self._packed(compute)
@@ -330,6 +336,7 @@ class TANTE(nn.Module):
             self.interprators = nn.ModuleList([interprator(self.C, self.H_p * self.W_p) for _ in range(taylor_order)])
             self.modifiers = nn.ModuleList([film(self.C, in_dim=1) for _ in range(taylor_order)])
         self.compute: Optional[str] = None       # None: follow torch.autocast; "fp32" / "bf16": pinned
+        self.fused_head = True                   # bf16: fused derivative head + Taylor accumulation when the shape allows
         self._film_cache = _PackCache()
 
     def set_compute(self, mode: Optional[str]):
@@ -376,11 +383,26 @@ class TANTE(nn.Module):
         fa, fb = self._time_tables()
         x = self.encoder.forward_tokens(inp, compute, (fa, fb, self.s_emb.view(HW, C_), T, HW), bstride)   # tante.py:132-141
         last_slot = dict(a_n0=HW, a_s1=T * HW * C_, a_s0=C_, a_off=(T - 1) * HW * C_)               # x[:, -1:] by stride
-        derivs, r_t = [], []
+        fused_head = (compute == L.BF16 and self.fused_head and self.decoders[0].P == (2, 2, 2)
+                      and K.head_fused_supported(C_, D))
+        if out is not None:
+            if not self.deg:
+                raise ValueError("out= is only meaningful with a fixed output length (deg=True)")
+            if tuple(out.shape) != (B, self.output_length, D, H, W) or out.dtype != torch.float32 or not out.is_cuda \
+                    or out.stride()[1:] != (frame, H * W, W, 1) or out.stride(0) % 4 or out.data_ptr() % 16:
+                raise ValueError("out must be a (B, output_length, D, H, W) fp32 CUDA view with contiguous frames")
+        derivs, r_t, srcs = [], [], []
         for i in range(self.taylor_order):
             self.blocks[i].forward_tokens(x, B, compute)                                            # l.146 (chained)
             if self.deg:
-                derivs.append(self.decoders[i].forward_tokens(x, B, compute, **last_slot))          # l.147,153
+                if fused_head:
+                    if out is None:
+                        out = torch.empty(B, self.output_length, D, H, W, dtype=torch.float32, device=x.device)
+                    coefs = [(j * self.frame_interval) ** (i + 1) / math.factorial(i + 1) for j in range(1, self.output_length + 1)]
+                    K.head_fused(x, HW, T * HW * C_, C_, (T - 1) * HW * C_, B, Hp, Wp, C_, D, self.decoders[i].packed_head(), out,
+                                 out.stride(0), coefs, inp if i == 0 else None, (T - 1) * frame, bstride)     # l.147,153,165-171
+                else:
+                    derivs.append(self.decoders[i].forward_tokens(x, B, compute, **last_slot))      # l.147,153
             else:
                 # intended semantics of l.148-152 (the shipped glue raises): d3 = last slot as (B, L, C);
                 # rt = interprator(d3, out_T); d3 = film3d(d3, rt); decode
@@ -389,18 +411,22 @@ class TANTE(nn.Module):
                 ma, mb = self.modifiers[i].tables(rt)
                 d3 = torch.empty(B * HW, C_, dtype=torch.float32, device=x.device)
                 K.film_apply(x, (T - 1) * HW * C_, T * HW * C_, d3, B * HW, C_, HW, ma, mb)
-                derivs.append(self.decoders[i].forward_tokens(d3, B, compute, B * HW, 0, C_, 0))
+                srcs.append(d3)
         if self.deg:
             n_out, R_t = self.output_length, None
+            if fused_head:
+                return out
         else:
             R_t = torch.stack(r_t, dim=1).mean(dim=1)
             n_out = math.floor(float(R_t[0]))         # l.163: sample 0 decides for the batch (host sync, as in the reference)
-        if out is not None:
-            if not self.deg:
-                raise ValueError("out= is only meaningful with a fixed output length (deg=True)")
-            if tuple(out.shape) != (B, n_out, D, H, W) or out.dtype != torch.float32 or not out.is_cuda \
-                    or out.stride()[1:] != (frame, H * W, W, 1) or out.stride(0) % 4 or out.data_ptr() % 16:
-                raise ValueError("out must be a (B, output_length, D, H, W) fp32 CUDA view with contiguous frames")
+            if n_out >= 1 and fused_head and n_out <= 8:
+                out = torch.empty(B, n_out, D, H, W, dtype=torch.float32, device=x.device)
+                for i, d3 in enumerate(srcs):
+                    coefs = [(j * self.frame_interval) ** (i + 1) / math.factorial(i + 1) for j in range(1, n_out + 1)]
+                    K.head_fused(d3, B * HW, 0, C_, 0, B, Hp, Wp, C_, D, self.decoders[i].packed_head(), out, out.stride(0), coefs,
+                                 inp if i == 0 else None, (T - 1) * frame, bstride)
+                return out, R_t
+            derivs = [self.decoders[i].forward_tokens(d3, B, compute, B * HW, 0, C_, 0) for i, d3 in enumerate(srcs)]
         if n_out < 1:
             out = torch.empty(B, 0, D, H, W, dtype=torch.float32, device=x.device)
         else:

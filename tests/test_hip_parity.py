@@ -771,3 +771,35 @@ def test_adaptive_train_step_runs(dev):
     assert math.isfinite(float(loss)) and rts.numel() >= 2 and bool(((rts >= 1.0) & (rts <= 1.502)).all())
     assert float((opt.flat_p - w_before).abs().max()) > 0          # the step moved the weights
     assert float(opt.flat_g.abs().max()) <= 1.0 + 1e-6              # clip_grad_value_(1.0) was applied
+
+
+# ---------------------------------------------------------------------------------------------------
+# fused derivative head + Taylor accumulation (bf16)
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("C,D,B,Hp,Wp,n_out", [(256, 11, 2, 4, 6, 1), (128, 3, 3, 5, 3, 3), (256, 16, 1, 3, 7, 2), (128, 1, 2, 8, 8, 8)])
+def test_fused_head_against_oracle(dev, C, D, B, Hp, Wp, n_out):
+    import tante_amd
+    from oracle import tante_oracle as O
+    from tante_amd import kernels as Kk
+    torch.manual_seed(C + D)
+    md = tante_amd.TanteMetadata(n_fields=D, spatial_resolution=(Hp * 8, Wp * 8))
+    decs = [tante_amd.dec_CNN(md, embed_dim=C, patch_scale=8, overlap_ratio=0.0).to(dev) for _ in range(2)]
+    T, HW = 3, Hp * Wp
+    x = torch.randn(B, T, Hp, Wp, C)
+    last = torch.randn(B, 1, D, Hp * 8, Wp * 8)
+    dt = 0.5
+    ref = last.clone().repeat(1, n_out, 1, 1, 1)
+    for k, dec in enumerate(decs):
+        d = O.dec_cnn({n: v.detach().cpu() for n, v in dec.state_dict().items()}, x[:, -1:], 8, 0.0)
+        for i in range(n_out):
+            ref[:, i:i + 1] += d * O.taylor_coeff(i + 1, dt, k + 1)
+    xd, lastd = x.to(dev).contiguous(), last.to(dev).contiguous()
+    out = torch.full((B, n_out, D, Hp * 8, Wp * 8), float("nan"), device=dev)
+    frame = D * Hp * 8 * Wp * 8
+    for k, dec in enumerate(decs):
+        coefs = [O.taylor_coeff(i + 1, dt, k + 1) for i in range(n_out)]
+        Kk.head_fused(xd, HW, T * HW * C, C, (T - 1) * HW * C, B, Hp, Wp, C, D, dec.packed_head(), out, out.stride(0), coefs,
+                      lastd if k == 0 else None, 0, frame)
+    close(out, ref, "bf16")
+    # the derivative part alone (what the head computes) also holds the bf16 bar
+    assert rel_err((out.cpu() - last), (ref - last)) < 2e-2

@@ -15,7 +15,7 @@ from tante_amd import kernels as K, _lib as L
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["block", "axis", "enc", "dec", "model", "wgrad", "attnbwd"])
+    ap.add_argument("what", choices=["block", "axis", "enc", "dec", "head", "model", "wgrad", "attnbwd"])
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--letter", default="H")
@@ -85,7 +85,7 @@ def main():
                 timeit(lambda: L.check(L.lib().tante_attention_bwd(qkv.data_ptr(), do.data_ptr(), dq.data_ptr(), L.BF16, C, 8, Ct.byref(seq),
                                                                    int(letter == "T"), 0.0, 0, torch.cuda.current_stream().cuda_stream)),
                        f"attn bwd {letter} L={seq.L}")
-        elif a.what in ("enc", "dec", "model"):
+        elif a.what in ("enc", "dec", "head", "model"):
             m = tante_amd.TANTE(in_T=4, dset_metadata=md, taylor_order=3, attn_axes="THW-THW-THW", n_head=8, embed_dim=256,
                                 patch_scale=8).to(dev).eval().set_compute(a.dtype)
             inp = torch.randn(B, 4, 11, 256, 256, device=dev)
@@ -97,6 +97,12 @@ def main():
                 x = torch.randn(B * 4 * 1024, 256, device=dev)
                 timeit(lambda: m.decoders[0].forward_tokens(x, B, comp, a_n0=1024, a_s1=4 * 1024 * 256, a_s0=256, a_off=3 * 1024 * 256),
                        "head (3 stages)", B * 0.629e9)
+            elif a.what == "head":
+                x = torch.randn(B * 4 * 1024, 256, device=dev)
+                out = torch.zeros(B, 1, 11, 256, 256, device=dev)
+                ph = m.decoders[0].packed_head()
+                timeit(lambda: K.head_fused(x, 1024, 4 * 1024 * 256, 256, 3 * 1024 * 256, B, 32, 32, 256, 11, ph, out, out[0].numel(), [1.0],
+                                            None), "fused head", B * 0.629e9)
             else:
                 timeit(lambda: m(inp), "model forward", B * 35.1e9)
 
