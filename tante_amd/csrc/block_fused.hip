@@ -67,6 +67,38 @@ __device__ __forceinline__ void wait_vmcnt() {  // all but the N youngest vector
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// N weight-fragment MFMAs with a D-deep register ring of ds_read_b128s kept in flight.  Left to itself the compiler emits
+// "ds_read_b128; s_waitcnt lgkmcnt(0); v_mfma" per fragment -- one full LDS round trip (~120 cycles) per 16-cycle MFMA -- and
+// even with the reads hoisted in the source its waits stay lgkmcnt(0) for as long as an LDS-DMA is in flight (a FLAT-encoded
+// global_load_lds makes it flush both counters at every dependency).  So the ring is explicit: the reads are inline asm, fragment
+// i + D is issued before MFMA i runs, and the wait in front of MFMA i is a counted lgkmcnt(number of younger reads); LDS returns
+// in order, and an extra compiler-issued LDS read in between only makes the count conservative.  The stream starts from
+// lgkmcnt(0) so that no scalar load (out-of-order in the same counter) is pending while counts are relied on.
+// addr(ic) -> LDS pointer of fragment ic, use(ic, frag) issues the MFMA; ic is an integral_constant.
+__device__ __forceinline__ u32x4 lds_read128(const char* p) {
+  u32x4 r;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(r) : "v"((unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)p) : "memory");
+  return r;
+}
+template <int N>
+__device__ __forceinline__ void lds_wait(u32x4& frag) {  // all but the N youngest LDS operations have returned; ties `frag` to the wait
+  asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(frag) : "n"(N));
+}
+template <int N, int D, class AddrF, class UseF>
+__device__ __forceinline__ void mfma_stream(AddrF&& addr, UseF&& use) {
+  static_assert(D <= 15, "lgkmcnt is a 4-bit field");
+  u32x4 ring[D];
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  static_for<(D < N ? D : N)>([&](auto ic) { ring[decltype(ic)::value] = lds_read128(addr(ic)); });
+  static_for<N>([&](auto ic) {
+    constexpr int i = decltype(ic)::value;
+    u32x4 cur = ring[i % D];
+    if constexpr (i + D < N) ring[i % D] = lds_read128(addr(std::integral_constant<int, i + D>{}));
+    lds_wait<(N - 1 - i < D ? N - 1 - i : D)>(cur);
+    use(ic, cur);
+  });
+}
+
 __device__ __forceinline__ u32x4 pack8(const f32x4& a, const f32x4& b) {
   u32x4 f;
   f[0] = pack_bf16x2(a[0], a[1]);
@@ -314,8 +346,7 @@ __global__ __launch_bounds__(256, 1) void fused_block_kernel(float* __restrict__
         for (int ns = 0; ns < 4; ++ns)
 #pragma unroll
           for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[ns][tt][j] = gelu_tanh_fast(acc[ns][tt][j]);
+            acc[ns][tt] = gelu_poly4<true>(acc[ns][tt]);
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
           of[tt][2 * tb] = pack8(acc[0][tt], acc[1][tt]);
@@ -400,6 +431,7 @@ __global__ __launch_bounds__(512, 2) void fused_block16_kernel(float* __restrict
   constexpr int SLOT = (TILEH > TILE2 ? TILEH : TILE2);
   constexpr int NT = NH + TO + T1 + TO;
   constexpr int MAXB = (HB > CB ? HB : CB);
+  constexpr int RING = 4;  // weight fragments in flight per wave (mfma_stream)
   extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 weight slots, then 2 mailbox sets of 8 x 2 KiB
   char* mbox = smem + 2 * SLOT;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kk = lane >> 4, l15 = lane & 15;
@@ -507,27 +539,22 @@ __global__ __launch_bounds__(512, 2) void fused_block16_kernel(float* __restrict
     } else if constexpr (t < NH) {
       // =============================== projections of head t, attention of head t-1 ======================
       const float* bias = (const float*)(wt + 96 * CPR * 16);
-      f32x4 aqk[4];
+      f32x4 aqk[4], av[2];
 #pragma unroll
       for (int ns = 0; ns < 4; ++ns) aqk[ns] = *(const f32x4*)(bias + ns * 16 + kk * 4);  // start from the bias
-#pragma unroll
-      for (int ns = 0; ns < 4; ++ns)
-#pragma unroll
-        for (int cb = 0; cb < CB; ++cb) {
-          const u32x4 wf = *(const u32x4*)(wt + ns * 16 * CPR * 16 + row_c + xo_c[cb]);
-          aqk[ns] = mfma_bf16(wf, xn[cb], aqk[ns]);
-        }
-      f32x4 av[2];
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt) {
         const float bv = bias[64 + dt * 16 + l15];
         av[dt] = f32x4{bv, bv, bv, bv};
-#pragma unroll
-        for (int cb = 0; cb < CB; ++cb) {
-          const u32x4 wf = *(const u32x4*)(wt + (64 + dt * 16) * CPR * 16 + row_c + xo_c[cb]);
-          av[dt] = mfma_bf16(xn[cb], wf, av[dt]);  // roles swapped: D[token][feature]
-        }
       }
+      // 6 row tiles (q: 0-1, k: 2-3, v: 4-5) x CB k-blocks, k-block outer so consecutive MFMAs hit different accumulators
+      mfma_stream<6 * CB, RING>(
+          [&](auto ic) { constexpr int i = decltype(ic)::value; return wt + (i % 6) * 16 * CPR * 16 + row_c + xo_c[i / 6]; },
+          [&](auto ic, const u32x4& wf) {
+            constexpr int i = decltype(ic)::value, rt = i % 6, cb = i / 6;
+            if constexpr (rt < 4) aqk[rt] = mfma_bf16(wf, xn[cb], aqk[rt]);
+            else av[rt - 4] = mfma_bf16(xn[cb], wf, av[rt - 4]);  // roles swapped: D[token][feature]
+          });
       const u32x4 qf_n = pack8(aqk[0], aqk[1]), kf_n = pack8(aqk[2], aqk[3]);
       u32x4 vpk_n;
       vpk_n[0] = pack_bf16x2(av[0][0], av[0][1]); vpk_n[1] = pack_bf16x2(av[0][2], av[0][3]);
@@ -554,19 +581,20 @@ __global__ __launch_bounds__(512, 2) void fused_block16_kernel(float* __restrict
         if constexpr (is_fc1) acc[ns] = b;
         else acc[ns] = res[4 * tb + ns] + b;  // the residual rides the accumulator
       }
-#pragma unroll
-      for (int ns = 0; ns < 4; ++ns)
-#pragma unroll
-        for (int kb = 0; kb < KB; ++kb) {
-          const u32x4 wf = *(const u32x4*)(wt + ns * 16 * cpr * 16 + ((KB == CB) ? row_c + xo_c[kb < CB ? kb : 0] : row_h + xo_h[kb < HB ? kb : 0]));
-          if constexpr (is_fc1) acc[ns] = mfma_bf16(wf, xn[kb < CB ? kb : 0], acc[ns]);
-          else acc[ns] = mfma_bf16(wf, of[kb], acc[ns]);
-        }
+      mfma_stream<4 * KB, RING>(
+          [&](auto ic) {
+            constexpr int i = decltype(ic)::value, ns = i % 4, kb = i / 4;
+            return wt + ns * 16 * cpr * 16 + ((KB == CB) ? row_c + xo_c[kb < CB ? kb : 0] : row_h + xo_h[kb < HB ? kb : 0]);
+          },
+          [&](auto ic, const u32x4& wf) {
+            constexpr int i = decltype(ic)::value, ns = i % 4, kb = i / 4;
+            if constexpr (is_fc1) acc[ns] = mfma_bf16(wf, xn[kb < CB ? kb : 0], acc[ns]);
+            else acc[ns] = mfma_bf16(wf, of[kb], acc[ns]);
+          });
       if constexpr (is_fc1) {
 #pragma unroll
         for (int ns = 0; ns < 4; ++ns)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) acc[ns][j] = gelu_tanh_fast(acc[ns][j]);
+          acc[ns] = gelu_poly4<true>(acc[ns]);
         of[2 * tb] = pack8(acc[0], acc[1]);
         of[2 * tb + 1] = pack8(acc[2], acc[3]);
       } else {

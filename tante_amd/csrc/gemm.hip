@@ -308,7 +308,7 @@ __device__ __forceinline__ void epilogue4_fast(const TanteGemm& g, const EpiRow&
     float x = v[j] + b[j];
     if constexpr (EP == EP_LIN_RELU) x = fmaxf(x, 0.0f);
     if constexpr (EP == EP_LIN_GELU_TANH) x = gelu_tanh_v<BF16>(x);
-    if constexpr (EP == EP_LIN_GELU_ERF || EP == EP_DNHWC_GELU_ERF) x = BF16 ? gelu_erf_fast(x) : gelu_erf_f(x);
+    if constexpr (EP == EP_LIN_GELU_ERF || EP == EP_DNHWC_GELU_ERF) x = BF16 ? gelu_poly1<false>(x) : gelu_erf_f(x);
     v[j] = x;
   }
   if constexpr (EP <= EP_LIN_GELU_ERF) {

@@ -28,7 +28,7 @@ __device__ __forceinline__ f32x4 hmfma(const u32x4& a, const u32x4& b, const f32
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 __device__ __forceinline__ f32x4 gelu4(const f32x4& v) {
-  return f32x4{gelu_erf_fast(v[0]), gelu_erf_fast(v[1]), gelu_erf_fast(v[2]), gelu_erf_fast(v[3])};
+  return gelu_poly4<false>(v);
 }
 constexpr int HWAVES = 4;   // waves per workgroup (16 tokens each)
 __device__ __forceinline__ void hglds(const char* __restrict__ g, char* l, int bytes, int tid) {   // 1 KiB per wave pass

@@ -1,5 +1,6 @@
 // HBM-bound stages of the TANTE path: axis propagators, FiLM tables, Taylor sum, step-size reduction.
 #include "common.cuh"
+#include <stdlib.h>
 
 namespace {
 
@@ -161,9 +162,13 @@ __device__ __forceinline__ void axis_mlp_mfma(const AxisW<BF16, MT>& w1, const A
           d1[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w1.f[mt][kb][e]), xin[4 * kb + e], d1[mt], 0, 0, 0);
   }
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
+  for (int mt = 0; mt < MT; ++mt) {
+    if constexpr (BF16) d1[mt] = gelu_poly4<false>(d1[mt]);
+    else {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) d1[mt][j] = BF16 ? gelu_erf_fast(d1[mt][j]) : gelu_erf_f(d1[mt][j]);
+      for (int j = 0; j < 4; ++j) d1[mt][j] = gelu_erf_f(d1[mt][j]);
+    }
+  }
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) out[mt] = f32x4{b2[mt][0], b2[mt][1], b2[mt][2], b2[mt][3]};
   if constexpr (BF16) {  // the hidden accumulators ARE the B operand (k order = accumulator order, matched by w2)
@@ -239,7 +244,7 @@ __global__ __launch_bounds__(256, 2) void axis_hw_kernel(float* __restrict__ x, 
                                                          const float* __restrict__ bh1, const float* __restrict__ wh2,
                                                          const float* __restrict__ bh2, const float* __restrict__ ww1,
                                                          const float* __restrict__ bw1, const float* __restrict__ ww2,
-                                                         const float* __restrict__ bw2) {
+                                                         const float* __restrict__ bw2, int dbg) {
   extern __shared__ __attribute__((aligned(16))) float plane[];  // [nH][nW*16 + 2] then the weight staging area
   const int tid = threadIdx.x;
   const int ctiles = C / 16;
@@ -249,6 +254,7 @@ __global__ __launch_bounds__(256, 2) void axis_hw_kernel(float* __restrict__ x, 
   const int rs = nW * 16 + 2;  // LDS row (h) stride in floats: +2 spreads the h-strided reads over the banks
   float* wst = plane + nH * rs;
   // ---- load the plane: 4 threads x 16 B per token ---------------------------------------------------------
+  if (!(dbg & 1))
   for (int i = tid; i < nH * nW * 4; i += 256) {
     const int tokn = i >> 2, q = i & 3, h = tokn / nW, w = tokn - h * nW;
     const f32x4 v = *(const f32x4*)(gx + (long)tokn * C + q * 4);
@@ -256,9 +262,11 @@ __global__ __launch_bounds__(256, 2) void axis_hw_kernel(float* __restrict__ x, 
     d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
   }
   // phase H: lines along h (stride rs), one group per w;  phase W: lines along w (stride 16), one group per h
-  axis_phase<BF16, MT>(plane, wst, wh1, bh1, wh2, bh2, nH, nW, rs, 16, tid);
-  axis_phase<BF16, MT>(plane, wst, ww1, bw1, ww2, bw2, nW, nH, 16, rs, tid);
+  if (!(dbg & 2)) axis_phase<BF16, MT>(plane, wst, wh1, bh1, wh2, bh2, nH, nW, rs, 16, tid);
+  if (!(dbg & 4)) axis_phase<BF16, MT>(plane, wst, ww1, bw1, ww2, bw2, nW, nH, 16, rs, tid);
+  if (dbg & 6) __syncthreads();
   // ---- store the plane -----------------------------------------------------------------------------------------
+  if (!(dbg & 1))
   for (int i = tid; i < nH * nW * 4; i += 256) {
     const int tokn = i >> 2, q = i & 3, h = tokn / nW, w = tokn - h * nW;
     const float* sp = plane + h * rs + w * 16 + q * 4;
@@ -387,7 +395,7 @@ static void launch_axis_hw(float* x, long BT, int nH, int nW, int C, const float
     attr = lds;
   }
   hipLaunchKernelGGL((axis_hw_kernel<BF16, MT>), dim3((unsigned)(BT * (C / 16))), dim3(256), lds, s, x, nH, nW, C, wh1, bh1, wh2, bh2,
-                     ww1, bw1, ww2, bw2);
+                     ww1, bw1, ww2, bw2, getenv("TANTE_AXIS_DEBUG") ? atoi(getenv("TANTE_AXIS_DEBUG")) : 0);
 }
 
 extern "C" int tante_axis_hw(float* x, int64_t BT, int nH, int nW, int C, const float* wh1, const float* bh1, const float* wh2,
