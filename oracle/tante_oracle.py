@@ -274,7 +274,7 @@ class TanteCfg:
 
     def __init__(self, in_T, n_fields, resolution, taylor_order=1, frame_interval=1.0, output_length=1,
                  attn_axes="THWTHWTHW", expanded_channel=128, n_head=8, mlp_ratio=1.0, embed_dim=256,
-                 patch_scale=32, overlap_ratio=0.0, deg=True):
+                 patch_scale=32, overlap_ratio=0.0, deg=True, enc_dec_type="cnn", modes1=32, modes2=32):
         self.in_T, self.n_fields, self.resolution = in_T, n_fields, tuple(resolution)
         self.taylor_order, self.frame_interval, self.output_length = taylor_order, frame_interval, output_length
         self.attn_axes = attn_axes.replace(" ", "")
@@ -283,6 +283,7 @@ class TanteCfg:
             raise ValueError("Block allocation doesn't match expansion order")
         self.expanded_channel, self.n_head, self.mlp_ratio = expanded_channel, n_head, mlp_ratio
         self.embed_dim, self.patch_scale, self.overlap_ratio, self.deg = embed_dim, patch_scale, overlap_ratio, deg
+        self.enc_dec_type, self.modes = enc_dec_type, (modes1, modes2)   # tante.py:95-102: 'fno' swaps in enc_FNO / dec_FNO
 
 
 def taylor_coeff(i: int, frame_interval: float, order: int) -> float:
@@ -292,7 +293,11 @@ def taylor_coeff(i: int, frame_interval: float, order: int) -> float:
 
 def tante_embed(w: W, cfg: TanteCfg, inp: Tensor) -> Tensor:
     """tante.py:132-141: encoder -> FiLM(t_seq) -> + s_emb (1,Hp,Wp,C) -> + t_emb (1,T,C)."""
-    x = enc_cnn(sub(w, "encoder."), inp, cfg.patch_scale, cfg.overlap_ratio)
+    if cfg.enc_dec_type == "fno":
+        from .spectral_oracle import enc_fno
+        x = enc_fno(sub(w, "encoder."), inp, cfg.patch_scale, cfg.overlap_ratio, cfg.modes)
+    else:
+        x = enc_cnn(sub(w, "encoder."), inp, cfg.patch_scale, cfg.overlap_ratio)
     x = film(sub(w, "t_encode."), x, t_series(cfg.in_T, cfg.frame_interval).to(x.dtype))
     return x + w["s_emb"][:, None] + w["t_emb"][:, :, None, None, :]
 
@@ -318,7 +323,11 @@ def tante_forward(w: W, cfg: TanteCfg, inp: Tensor, out_T: float = 1):
             rt = interprator(sub(w, f"interprators.{i}."), d3, out_T)
             rts.append(rt)
             d = film(sub(w, f"modifiers.{i}."), d3, rt).reshape(B, 1, Hp, Wp, C)
-        ders.append(dec_cnn(sub(w, f"decoders.{i}."), d, cfg.patch_scale, cfg.overlap_ratio))
+        if cfg.enc_dec_type == "fno":
+            from .spectral_oracle import dec_fno
+            ders.append(dec_fno(sub(w, f"decoders.{i}."), d, cfg.patch_scale, cfg.overlap_ratio, cfg.modes))
+        else:
+            ders.append(dec_cnn(sub(w, f"decoders.{i}."), d, cfg.patch_scale, cfg.overlap_ratio))
     if cfg.deg:
         n_out, R_t = cfg.output_length, None
     else:

@@ -22,6 +22,8 @@ Fixture index:
   g8_rollout_*       Trainer / Evaler rollout_model window semantics
   g9_trainstep       loss, grads, clip, two AdamW steps
   g10_metrics        MSE / eval_rt / L2RE / NNMSE / VRMSE, LR schedule
+  g11_cvit_*         CViT tiny: grid / fourier / mlp coordinate embeddings, full-grid and query-point modes
+  g12_spectral_*     SpectralLayer (modes below / above the spectrum size) and TANTE(enc_dec_type='fno') tiny
   g13_deg_false      adaptive-dt forward composed from the reference's own sub-modules
 """
 import os
@@ -277,6 +279,60 @@ def g10():
     save("g10_metrics", **arrs)
 
 
+def g11():
+    """CViT (models/cvit.py): pins the double layer_norm2 of CrossAttnBlock, the eps-Gaussian grid embedding and both query modes."""
+    from models.cvit import CViT
+    cases = [
+        # name, embedding, ctor overrides, resolution, fields, query points (None = full grid)
+        ("grid", "grid", dict(grid_size=(16, 24), eps=1e5), (16, 24), 2, None),          # sharp kernel, queries on the nodes
+        ("gridwide", "grid", dict(grid_size=(6, 5), eps=40.0, dec_depth=2, num_mlp_layers=2), (16, 24), 2, 37),  # dense window
+        ("fourier", "fourier", dict(), (16, 16), 1, None),
+        ("mlp", "mlp", dict(mlp_ratio=2), (16, 24), 3, 50),
+    ]
+    for name, emb, kw, res, nf, nq in cases:
+        torch.manual_seed(zlib.crc32(("g11" + name).encode()))
+        base = dict(in_T=4, dset_metadata=md(nf, res), out_steps=3, patch_size=(1, 8, 8), grid_size=(8, 8), latent_dim=24, emb_dim=32,
+                    depth=2, num_heads=4, dec_emb_dim=48, dec_num_heads=4, dec_depth=1, num_mlp_layers=1, mlp_ratio=1,
+                    embedding_type=emb)
+        base.update(kw)
+        m = CViT(**base).eval()
+        x = torch.randn(2, 4, nf, *res)
+        coords = None if nq is None else torch.rand(nq, 2)
+        with torch.no_grad():
+            y = m(x) if coords is None else m(x, coords)
+        extra = {} if coords is None else {"coords": coords.numpy()}
+        save(f"g11_cvit_{name}", x=x.numpy(), y=y.numpy(), **extra, **sd_np(m))
+
+
+def g12():
+    """SpectralLayer (models/enc_dec_fno.py:184-222) and the TANTE(enc_dec_type='fno') path."""
+    from models.enc_dec_fno import SpectralLayer
+    for name, cin, cout, modes, shape in [("low", 3, 5, (4, 3), (2, 3, 16, 12)), ("clip", 2, 4, (40, 40), (3, 2, 8, 8)),
+                                          ("odd", 4, 2, (3, 5), (1, 4, 10, 14))]:
+        torch.manual_seed(zlib.crc32(("g12" + name).encode()))
+        m = SpectralLayer(cin, cout, *modes).eval()
+        x = torch.randn(*shape)
+        with torch.no_grad():
+            y = m(x)
+        w = {"w.weight_re": m.weight.detach().real.numpy().copy(), "w.weight_im": m.weight.detach().imag.numpy().copy(),
+             "w.w0.weight": m.w0.weight.detach().numpy().copy(), "w.w0.bias": m.w0.bias.detach().numpy().copy()}
+        save(f"g12_spectral_{name}", x=x.numpy(), y=y.numpy(), modes=np.array(modes), **w)
+    torch.manual_seed(zlib.crc32(b"g12fno"))
+    m = TANTE(in_T=4, dset_metadata=md(2, (32, 32)), taylor_order=2, attn_axes="TL-TL", n_head=4, embed_dim=64, patch_scale=8,
+              enc_dec_type="fno", modes1=8, modes2=8, dropout=0.0).eval()
+    x = torch.randn(2, 4, 2, 32, 32)
+    with torch.no_grad():
+        y = m(x)
+    sd = {}
+    for k, v in m.state_dict().items():   # complex weights travel as (re, im) pairs
+        if v.is_complex():
+            sd["w." + k + "_re"] = v.real.numpy().copy()
+            sd["w." + k + "_im"] = v.imag.numpy().copy()
+        else:
+            sd["w." + k] = v.numpy().copy()
+    save("g12_tante_fno", x=x.numpy(), y=y.numpy(), **sd)
+
+
 def g13():
     """deg=False: TANTE.forward raises in the reference (tante.py:149-152 applies a 3-D einops
     pattern to a 5-D tensor), so the adaptive-dt semantics are pinned by composing the reference's
@@ -324,6 +380,6 @@ def g13():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g13"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13"]
     for w in which:
         globals()[w]()

@@ -153,3 +153,46 @@ def test_g13_adaptive_dt():
         assert y.shape == g["y_" + tag].shape
         assert max_rel(rt, g["rt_" + tag]) < TOL and max_rel(y, g["y_" + tag]) < TOL
     assert g["y_6"].shape[1] > 1      # the multi-frame branch is exercised
+
+
+# ---- CViT (g11) and the spectral operator path (g12) ----------------------------------------------------------------------------
+from oracle import cvit_oracle as OC          # noqa: E402
+from oracle import spectral_oracle as OS      # noqa: E402
+
+CVIT_CASES = {   # name -> (CvitCfg kwargs, n_fields, resolution): the ctor arguments tests/golden/make_golden.py g11 used
+    "grid": (dict(grid_size=(16, 24), eps=1e5), 2, (16, 24)),
+    "gridwide": (dict(grid_size=(6, 5), eps=40.0, dec_depth=2, num_mlp_layers=2), 2, (16, 24)),
+    "fourier": (dict(embedding_type="fourier"), 1, (16, 16)),
+    "mlp": (dict(embedding_type="mlp", mlp_ratio=2), 3, (16, 24)),
+}
+
+
+def cvit_cfg(name, cls=OC.CvitCfg):
+    kw, nf, res = CVIT_CASES[name]
+    base = dict(out_steps=3, patch_size=(1, 8, 8), grid_size=(8, 8), latent_dim=24, emb_dim=32, depth=2, num_heads=4, dec_emb_dim=48,
+                dec_num_heads=4, dec_depth=1, num_mlp_layers=1, mlp_ratio=1)
+    base.update(kw)
+    return cls(4, nf, res, **base)
+
+
+@pytest.mark.parametrize("name", sorted(CVIT_CASES))
+def test_g11_cvit(name):
+    g = load_golden("g11_cvit_" + name)
+    y = OC.cvit_forward(split_prefix(g, "w."), cvit_cfg(name), g["x"], g.get("coords"))
+    assert y.shape == g["y"].shape and max_rel(y, g["y"]) < 5 * TOL
+
+
+@pytest.mark.parametrize("name", ["low", "clip", "odd"])
+def test_g12_spectral_layer(name):
+    g = load_golden("g12_spectral_" + name)
+    m1, m2 = (int(v) for v in g["modes"])
+    y = OS.spectral_layer(split_prefix(g, "w."), g["x"], m1, m2)
+    assert y.shape == g["y"].shape and max_rel(y, g["y"]) < TOL
+
+
+def test_g12_tante_fno():
+    g = load_golden("g12_tante_fno")
+    cfg = O.TanteCfg(4, 2, (32, 32), taylor_order=2, attn_axes="TL-TL", n_head=4, embed_dim=64, patch_scale=8, enc_dec_type="fno",
+                     modes1=8, modes2=8)
+    y = O.tante_forward(split_prefix(g, "w."), cfg, g["x"])
+    assert y.shape == g["y"].shape and max_rel(y, g["y"]) < 5 * TOL
