@@ -200,6 +200,45 @@ int tante_head_fused(const float* x, int32_t a_n0, int64_t a_s1, int64_t a_s0, i
                      const void* head_stream, float* out, int64_t out_bstride, int n_out, const float* coefs, const float* last,
                      int64_t last_bstride, void* stream);
 
+/* ---- general encoder / decoder stages, spectral operator path, CViT (operators.hip) ---------------------------------
+ * tante_im2col: rows = output positions (img, oh, ow) of a convolution with kernel (kh, kw), stride (sh, sw), zero padding (ph, pw)
+ *   over x (n_img, C, H, W) [nchw = 1] or (n_img, H, W, C) [nchw = 0]; columns ordered (c, kh, kw) [korder 0, the native
+ *   nn.Conv2d weight flatten] or (kh, kw, c) [korder 1].  With tante_gemm it is RealConv2d's conv for every patch_size /
+ *   overlap_ratio / 'same' padding (enc_dec_cnn.py:49-96) and CViT's Conv3d patch embed with kernel (1, p, p) (cvit.py:73-78). */
+int tante_im2col(const void* x, int x_dtype, int nchw, int64_t n_img, int C, int H, int W, int kh, int kw, int sh, int sw, int ph,
+                 int pw, int korder, void* cols, int cols_dtype, void* stream);
+/* F.adaptive_avg_pool2d to (Ht, Wt) on a channels-last image, then `act` (RealConv2d.forward, enc_dec_cnn.py:104-110). */
+int tante_avgpool_nhwc(const void* x, int x_dtype, int64_t n_img, int H, int W, int C, int Ht, int Wt, int act, void* y, int y_dtype,
+                       void* stream);
+/* F.interpolate(mode="bilinear", align_corners=False) of the (Hi, Wi) window at (crop_y, crop_x) of `in` to (Ho, Wo), then `act`
+ * (RealTransConv2d.forward, enc_dec_cnn.py:164-184: the padded transposed conv is the unpadded one cropped by the padding).
+ * Element (img, c, y, x) of in / out lives at img*sn + c*sc + y*sh + x*sw (elements). */
+int tante_resize_bilinear(const void* in, int in_dtype, int64_t n_img, int C, int Hi, int Wi, int crop_y, int crop_x, int64_t isn,
+                          int64_t isc, int64_t ish, int64_t isw, int Ho, int Wo, int64_t osn, int64_t osc, int64_t osh, int64_t osw,
+                          int act, void* out, int out_dtype, void* stream);
+/* y = LayerNorm(x) * gamma + beta per row (nn.LayerNorm; cvit.py:124-127, 228, 269, 412-414).  gamma / beta may be NULL. */
+int tante_layernorm_affine(const void* x, int x_dtype, int64_t M, int C, float eps, const float* gamma, const float* beta, void* y,
+                           int y_dtype, void* stream);
+/* SpectralLayer.forward (enc_dec_fno.py:184-222) on x (n, Cin, H, W) fp32:  out = act(irfft2(low-mode contraction of rfft2(x)) +
+ * conv1x1(x)), norm "ortho".  w_re / w_im: the complex weight (Cin, Cout, wm1, wm2) split into planes; modes clip to
+ * min(modes1, H) x min(modes2, W/2 + 1); the bottom band overwrites the top one where they overlap (l.203-210).  FFTs run through
+ * hipFFT plans cached per shape on the caller's stream; `work` holds the two spectra (tante_spectral_workspace_bytes). */
+int64_t tante_spectral_workspace_bytes(int64_t n, int Cin, int Cout, int H, int W);
+int tante_spectral_layer(const float* x, int64_t n, int Cin, int H, int W, const float* w_re, const float* w_im, int wm1, int wm2,
+                         int modes1, int modes2, const float* w0, const float* b0, int Cout, int act, float* out, void* work,
+                         int64_t work_bytes, void* stream);
+/* softmax(q k^T / sqrt(D)) v per (batch, head) with separate query and key/value sequences -- the core of
+ * nn.MultiheadAttention(q, kv, kv) in CViT's CrossAttnBlock / TimeAggregation / SelfAttnBlock (cvit.py:125, 162, 199-204).
+ * Rows: q (b, i) at (b*Lq + i)*ldq + h*D, k / v (b, j) at (b*Lk + j)*ldkv + h*D, o at (b*Lq + i)*ldo + h*D (elements). */
+int tante_cross_attention(const void* q, const void* k, const void* v, void* o, int dtype, int64_t n_batch, int n_head, int D, int Lq,
+                          int Lk, int64_t ldq, int64_t ldkv, int64_t ldo, void* stream);
+/* CViT grid embedding (cvit.py:434-438): out[n] = sum_g softmax_g(-eps |coords_n - grid_g|^2) latents[g];  coords (N, 2),
+ * grid (G, 2), latents (G, LD), LD <= 1024.  Exact: every grid point is evaluated, exact-zero weights are skipped. */
+int tante_grid_embed(const float* coords, const float* grid, const float* latents, int64_t N, int G, int LD, float eps, float* out,
+                     void* stream);
+/* FourierEmbs (cvit.py:308-331): out[n] = [cos(coords_n . K), sin(coords_n . K)], K (2, E/2). */
+int tante_fourier_embed(const float* coords, const float* kernel, int64_t N, int E, float* out, void* stream);
+
 /* ---- losses / metrics / optimiser step of the harness ------------------------------------------------
  * pred is addressed as pred[b*pb + t*pt + s*ps + c*pc] (so the channels-first rollout buffer needs no permute copy),
  * ref and grad are contiguous channels-last (B, T, HW, C).

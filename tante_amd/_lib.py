@@ -63,6 +63,17 @@ SIGNATURES = {
     "tante_head_stream_bytes": ([c_i32], c_i64),
     "tante_pack_head": ([c_vp] * 6 + [c_i32, c_i32, c_vp, c_vp], c_i32),
     "tante_head_fused": ([c_vp, c_i32, c_i64, c_i64, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_i64, c_vp], c_i32),
+    "tante_im2col": ([c_vp, c_i32, c_i32, c_i64] + [c_i32] * 10 + [c_vp, c_i32, c_vp], c_i32),
+    "tante_avgpool_nhwc": ([c_vp, c_i32, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp], c_i32),
+    "tante_resize_bilinear": ([c_vp, c_i32, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_i64, c_i64, c_i64, c_i64, c_i32, c_i32, c_i64, c_i64,
+                               c_i64, c_i64, c_i32, c_vp, c_i32, c_vp], c_i32),
+    "tante_layernorm_affine": ([c_vp, c_i32, c_i64, c_i32, c_f32, c_vp, c_vp, c_vp, c_i32, c_vp], c_i32),
+    "tante_spectral_workspace_bytes": ([c_i64, c_i32, c_i32, c_i32, c_i32], c_i64),
+    "tante_spectral_layer": ([c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp,
+                              c_i64, c_vp], c_i32),
+    "tante_cross_attention": ([c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_i32, c_i32, c_i32, c_i64, c_i64, c_i64, c_vp], c_i32),
+    "tante_grid_embed": ([c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_f32, c_vp, c_vp], c_i32),
+    "tante_fourier_embed": ([c_vp, c_vp, c_i64, c_i32, c_vp, c_vp], c_i32),
     "tante_metric_sums": ([c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_i32, c_i32, c_i64, c_i32, c_vp, c_vp], c_i32),
     "tante_mse_grad": ([c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_i32, c_i32, c_i64, c_i32, c_f32, c_vp, c_vp], c_i32),
     "tante_sumsq": ([c_vp, c_i64, c_vp, c_vp], c_i32),

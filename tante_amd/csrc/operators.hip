@@ -1,0 +1,435 @@
+// Operator kernels around the GEMM / attention core that the general encoder-decoder stages (padded or overlapping patch
+// convolutions, bilinear-resized transposed convolutions), the spectral operator path (enc_dec_fno.py) and CViT (cvit.py) need.
+// All of them are HBM-bound gather / pointwise / small-contraction kernels: coalesced on the innermost axis, fp32 arithmetic.
+#include "common.cuh"
+#include <hipfft/hipfft.h>
+#include <map>
+#include <mutex>
+#include <tuple>
+
+namespace {
+
+__device__ __forceinline__ float ldx(const void* p, int dtype, long i) {
+  return dtype == TANTE_BF16 ? __uint_as_float(((unsigned)((const unsigned short*)p)[i]) << 16) : ((const float*)p)[i];
+}
+__device__ __forceinline__ void stx(void* p, int dtype, long i, float v) {
+  if (dtype == TANTE_BF16) ((__bf16*)p)[i] = (__bf16)v;
+  else ((float*)p)[i] = v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+
+// ---- im2col: rows = output positions (img, oh, ow), columns = (c, kh, kw) [korder 0] or (kh, kw, c) [korder 1] ---------------
+__global__ void im2col_kernel(const void* __restrict__ x, int x_dtype, int nchw, long n_img, int C, int H, int W, int kh, int kw,
+                              int sh, int sw, int ph, int pw, int Ho, int Wo, int korder, void* __restrict__ cols, int cols_dtype) {
+  const int K = C * kh * kw;
+  const long total = n_img * Ho * Wo * K;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const long m = idx / K;
+    const int k = (int)(idx - m * K);
+    int c, i, j;
+    if (korder == 0) { c = k / (kh * kw); const int r = k - c * kh * kw; i = r / kw; j = r - i * kw; }
+    else { const int r = k / C; c = k - r * C; i = r / kw; j = r - i * kw; }
+    const long img = m / ((long)Ho * Wo);
+    const int o = (int)(m - img * Ho * Wo), oh = o / Wo, ow = o - oh * Wo;
+    const int y = oh * sh - ph + i, xx = ow * sw - pw + j;
+    float v = 0.0f;
+    if (y >= 0 && y < H && xx >= 0 && xx < W) {
+      const long src = nchw ? ((img * C + c) * H + y) * W + xx : ((img * H + y) * W + xx) * C + c;
+      v = ldx(x, x_dtype, src);
+    }
+    stx(cols, cols_dtype, idx, v);
+  }
+}
+
+// ---- adaptive average pooling (channels-last) + activation: cell o averages rows floor(o*H/Ht) .. ceil((o+1)*H/Ht) - 1 ---------
+__global__ void avgpool_kernel(const void* __restrict__ x, int x_dtype, long n_img, int H, int W, int C, int Ht, int Wt, int act,
+                               void* __restrict__ y, int y_dtype) {
+  const long total = n_img * Ht * Wt * C;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % C);
+    long r = idx / C;
+    const int ow = (int)(r % Wt); r /= Wt;
+    const int oh = (int)(r % Ht);
+    const long img = r / Ht;
+    const int y0 = (oh * H) / Ht, y1 = ((oh + 1) * H + Ht - 1) / Ht, x0 = (ow * W) / Wt, x1 = ((ow + 1) * W + Wt - 1) / Wt;
+    float s = 0.0f;
+    for (int yy = y0; yy < y1; ++yy)
+      for (int xx = x0; xx < x1; ++xx) s += ldx(x, x_dtype, ((img * H + yy) * W + xx) * C + c);
+    stx(y, y_dtype, idx, apply_act(s / (float)((y1 - y0) * (x1 - x0)), act));
+  }
+}
+
+// ---- bilinear resize (align_corners = False, F.interpolate semantics) of a cropped window + activation ------------------------
+// in element (img, c, y, x) at img*isn + c*isc + (y + cy)*ish + (x + cx)*isw, window Hi x Wi;  out likewise with its own strides.
+__global__ void resize_kernel(const void* __restrict__ in, int in_dtype, long n_img, int C, int Hi, int Wi, int cy, int cx, long isn,
+                              long isc, long ish, long isw, int Ho, int Wo, long osn, long osc, long osh, long osw, int act,
+                              void* __restrict__ out, int out_dtype, int c_fast) {
+  const long total = n_img * C * Ho * Wo;
+  const float sy = (float)Hi / (float)Ho, sx = (float)Wi / (float)Wo;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    int c, oy, ox;
+    long img;
+    if (c_fast) { c = (int)(idx % C); long r = idx / C; ox = (int)(r % Wo); r /= Wo; oy = (int)(r % Ho); img = r / Ho; }
+    else { ox = (int)(idx % Wo); long r = idx / Wo; oy = (int)(r % Ho); r /= Ho; c = (int)(r % C); img = r / C; }
+    float fy = sy * ((float)oy + 0.5f) - 0.5f, fx = sx * ((float)ox + 0.5f) - 0.5f;
+    fy = fy < 0.0f ? 0.0f : fy;
+    fx = fx < 0.0f ? 0.0f : fx;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + (y0 < Hi - 1 ? 1 : 0), x1 = x0 + (x0 < Wi - 1 ? 1 : 0);
+    const float ly = fy - (float)y0, lx = fx - (float)x0;
+    const long base = img * isn + c * isc;
+    const float v00 = ldx(in, in_dtype, base + (y0 + cy) * ish + (x0 + cx) * isw), v01 = ldx(in, in_dtype, base + (y0 + cy) * ish + (x1 + cx) * isw);
+    const float v10 = ldx(in, in_dtype, base + (y1 + cy) * ish + (x0 + cx) * isw), v11 = ldx(in, in_dtype, base + (y1 + cy) * ish + (x1 + cx) * isw);
+    const float v = (1.0f - ly) * ((1.0f - lx) * v00 + lx * v01) + ly * ((1.0f - lx) * v10 + lx * v11);
+    stx(out, out_dtype, img * osn + c * osc + oy * osh + ox * osw, apply_act(v, act));
+  }
+}
+
+// ---- LayerNorm with affine: one wave per row ----------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ln_affine_kernel(const void* __restrict__ x, int x_dtype, long M, int C, float eps,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        void* __restrict__ y, int y_dtype) {
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= M) return;
+  float s = 0.f;
+  for (int c = lane; c < C; c += 64) s += ldx(x, x_dtype, row * C + c);
+  const float mean = wave_sum(s) / C;
+  float q = 0.f;
+  for (int c = lane; c < C; c += 64) { const float d = ldx(x, x_dtype, row * C + c) - mean; q += d * d; }
+  const float rstd = rsqrtf(wave_sum(q) / C + eps);
+  for (int c = lane; c < C; c += 64)
+    stx(y, y_dtype, row * C + c, (ldx(x, x_dtype, row * C + c) - mean) * rstd * (gamma ? gamma[c] : 1.0f) + (beta ? beta[c] : 0.0f));
+}
+
+// ---- spectral layer: low-mode complex contraction (writes the WHOLE spectrum: zeros outside the two bands) --------------------
+// Y[b, o, i, j] = scale * sum_c X[b, c, i, j] * Wt[c, o, wi, j]; top band i < m1 (wi = i), bottom band i >= H - m1
+// (wi = i - (H - m1)); the bottom band wins where they overlap (it is written second at enc_dec_fno.py:207-210).
+__global__ void spectral_modes_kernel(const float2* __restrict__ X, const float* __restrict__ w_re, const float* __restrict__ w_im,
+                                      long n, int Cin, int Cout, int H, int Wf, int m1, int m2, int wm1, int wm2, float scale,
+                                      float2* __restrict__ Y) {
+  const long total = n * Cout * H * Wf;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int j = (int)(idx % Wf);
+    long r = idx / Wf;
+    const int i = (int)(r % H); r /= H;
+    const int o = (int)(r % Cout);
+    const long b = r / Cout;
+    float2 acc = make_float2(0.f, 0.f);
+    int wi = -1;
+    if (j < m2) {
+      if (i >= H - m1) wi = i - (H - m1);
+      else if (i < m1) wi = i;
+    }
+    if (wi >= 0) {
+      for (int c = 0; c < Cin; ++c) {
+        const float2 xv = X[((b * Cin + c) * H + i) * Wf + j];
+        const long wo = (((long)c * Cout + o) * wm1 + wi) * wm2 + j;
+        const float wr = w_re[wo], wim = w_im[wo];
+        acc.x += xv.x * wr - xv.y * wim;
+        acc.y += xv.x * wim + xv.y * wr;
+      }
+      acc.x *= scale; acc.y *= scale;
+    }
+    Y[idx] = acc;
+  }
+}
+
+// out[b, o, p] = act(y[b, o, p] + b0[o] + sum_c w0[o, c] x[b, c, p])   (channels-first 1x1 conv + the spectral branch)
+// block: 64 pixels x all outputs; x tile (Cin x 64) and w0 staged in LDS; thread (p = tid & 63, og = tid >> 6) owns outputs og, og+4, ...
+__global__ __launch_bounds__(256) void conv1x1_add_kernel(const float* __restrict__ x, const float* __restrict__ w0,
+                                                          const float* __restrict__ b0, const float* y, long HW, int Cin,
+                                                          int Cout, int act, float* out) {   // y may alias out
+  extern __shared__ float sm[];   // [Cin][64] x tile, then w0 [Cout][Cin]
+  float* xs = sm;
+  float* ws = sm + Cin * 64;
+  const long b = blockIdx.y;
+  const long p0 = (long)blockIdx.x * 64;
+  const int tid = threadIdx.x, p = tid & 63, og = tid >> 6;
+  for (int i = tid; i < Cin * 64; i += 256) {
+    const int c = i >> 6, pp = i & 63;
+    xs[i] = (p0 + pp < HW) ? x[(b * Cin + c) * HW + p0 + pp] : 0.0f;
+  }
+  for (int i = tid; i < Cout * Cin; i += 256) ws[i] = w0[i];
+  __syncthreads();
+  if (p0 + p >= HW) return;
+  for (int o = og; o < Cout; o += 4) {
+    float acc = b0 ? b0[o] : 0.0f;
+    const float* wr = ws + o * Cin;
+    for (int c = 0; c < Cin; ++c) acc += wr[c] * xs[c * 64 + p];
+    const long oi = (b * Cout + o) * HW + p0 + p;
+    out[oi] = apply_act(acc + (y ? y[oi] : 0.0f), act);
+  }
+}
+
+// ---- CViT: softmax attention with separate query and key/value sequences (fp32, exact; online softmax over key chunks) ---------
+// q row (b, i) at q + (b*Lq + i)*ldq + h*D, k / v rows (b, j) at k|v + (b*Lk + j)*ldkv + h*D, o row at o + (b*Lq + i)*ldo + h*D.
+// block = 256 queries of one (batch, head); keys/values staged in LDS 64 at a time (broadcast reads in the inner loops).
+template <int D>
+__global__ __launch_bounds__(256) void cross_attn_kernel(const void* __restrict__ q, const void* __restrict__ k, const void* __restrict__ v,
+                                                         void* __restrict__ o, int dtype, int n_head, int Lq, int Lk, long ldq, long ldkv,
+                                                         long ldo, float scale) {
+  __shared__ float ks[64][D];
+  __shared__ float vs[64][D];
+  const int bh = blockIdx.x, b = bh / n_head, h = bh - b * n_head;
+  const int i = blockIdx.y * 256 + threadIdx.x;
+  const bool live = i < Lq;
+  float qr[D], acc[D];
+  const long qoff = ((long)b * Lq + (live ? i : 0)) * ldq + (long)h * D;
+#pragma unroll
+  for (int d = 0; d < D; ++d) { qr[d] = ldx(q, dtype, qoff + d) * scale; acc[d] = 0.0f; }
+  float m = -INFINITY, l = 0.0f;
+  for (int j0 = 0; j0 < Lk; j0 += 64) {
+    const int nj = Lk - j0 < 64 ? Lk - j0 : 64;
+    __syncthreads();
+    for (int e = threadIdx.x; e < nj * D; e += 256) {
+      const int j = e / D, d = e - j * D;
+      const long off = ((long)b * Lk + j0 + j) * ldkv + (long)h * D + d;
+      ks[j][d] = ldx(k, dtype, off);
+      vs[j][d] = ldx(v, dtype, off);
+    }
+    __syncthreads();
+    for (int j = 0; j < nj; ++j) {
+      float s = 0.0f;
+#pragma unroll
+      for (int d = 0; d < D; ++d) s += qr[d] * ks[j][d];
+      const float mn = fmaxf(m, s);
+      const float corr = __expf(m - mn), pj = __expf(s - mn);   // first key: exp(-inf) = 0 rescales the empty sums
+      l = l * corr + pj;
+#pragma unroll
+      for (int d = 0; d < D; ++d) acc[d] = acc[d] * corr + pj * vs[j][d];
+      m = mn;
+    }
+  }
+  if (live) {
+    const float inv = 1.0f / l;
+    const long ooff = ((long)b * Lq + i) * ldo + (long)h * D;
+#pragma unroll
+    for (int d = 0; d < D; ++d) stx(o, dtype, ooff + d, acc[d] * inv);
+  }
+}
+
+// ---- CViT grid embedding: out[n, :] = sum_g w_ng latents[g, :],  w_ng = exp(-eps |x_n - g|^2) / sum_g' exp(...)  (cvit.py:435-438)
+// One workgroup per query point.  The weights are evaluated for EVERY grid point (the grid is a trainable parameter, no lattice is
+// assumed), 256 at a time; points whose weight is exactly 0 in fp32 (underflow, as in the reference) are dropped by an ordered
+// compaction -- wave ballot + prefix popcount, waves in fixed order -- so the summation order is the grid order, deterministic.
+// With eps = 1e5 on a 128 x 128 grid ~50 of 16384 points survive, which turns the dense N x G x latent_dim contraction
+// (1.1 PFLOP for cfg4) into ~0.2 GFLOP without changing a bit of the result's definition.
+__global__ __launch_bounds__(256) void grid_embed_kernel(const float* __restrict__ coords, const float* __restrict__ grid,
+                                                         const float* __restrict__ latents, long N, int G, int LD, float eps,
+                                                         float* __restrict__ out) {
+  constexpr int CAP = 1024;
+  __shared__ int l_idx[CAP];
+  __shared__ float l_w[CAP];
+  __shared__ int wave_cnt[4];
+  __shared__ float red[4];
+  const long n = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float cx = coords[2 * n], cy = coords[2 * n + 1];
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};   // latent dims tid, tid + 256, ... (LD <= 1024)
+  float wsum = 0.0f;
+  int cnt = 0;
+  auto flush = [&]() {
+    for (int e = 0; e < cnt; ++e) {
+      const float w = l_w[e];
+      const float* lr = latents + (long)l_idx[e] * LD;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+        if (tid + 256 * kk < LD) acc[kk] += w * lr[tid + 256 * kk];
+    }
+  };
+  for (int g0 = 0; g0 < G; g0 += 256) {
+    const int g = g0 + tid;
+    float w = 0.0f;
+    if (g < G) {
+      const float dx = cx - grid[2 * g], dy = cy - grid[2 * g + 1];
+      w = expf(-eps * (dx * dx + dy * dy));
+    }
+    wsum += w;
+    const unsigned long long bal = __ballot(w != 0.0f);
+    if (lane == 0) wave_cnt[wave] = __popcll(bal);
+    __syncthreads();
+    int base = cnt;
+    for (int ww = 0; ww < wave; ++ww) base += wave_cnt[ww];
+    const int tot = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+    if (cnt + tot > CAP) {   // uniform: the list would overflow -> fold what is there into the accumulators first
+      flush();
+      base -= cnt;
+      cnt = 0;
+      __syncthreads();
+    }
+    if (w != 0.0f) {
+      const int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
+      l_idx[pos] = g;
+      l_w[pos] = w;
+    }
+    cnt += tot;
+    __syncthreads();
+  }
+  flush();
+  wsum = wave_sum(wsum);
+  if (lane == 0) red[wave] = wsum;
+  __syncthreads();
+  const float inv = 1.0f / (red[0] + red[1] + red[2] + red[3]);
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk)
+    if (tid + 256 * kk < LD) out[n * LD + tid + 256 * kk] = acc[kk] * inv;
+}
+
+// FourierEmbs (cvit.py:308-331): out[n] = [cos(c . K[:, j]), sin(c . K[:, j])], K (2, E/2)
+__global__ void fourier_embed_kernel(const float* __restrict__ coords, const float* __restrict__ kern, long N, int half, float* __restrict__ out) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= N * half) return;
+  const long n = idx / half;
+  const int j = (int)(idx - n * half);
+  const float dp = coords[2 * n] * kern[j] + coords[2 * n + 1] * kern[half + j];
+  out[n * 2 * half + j] = cosf(dp);
+  out[n * 2 * half + half + j] = sinf(dp);
+}
+
+inline unsigned grid_for(long total, int block = 256) {
+  long g = (total + block - 1) / block;
+  return (unsigned)(g > 1048576 ? 1048576 : (g < 1 ? 1 : g));
+}
+
+// ---- hipFFT plans, cached per (H, W, batch, direction) ------------------------------------------------------------------------
+std::mutex plan_mu;
+std::map<std::tuple<int, int, long, int>, hipfftHandle> plans;
+int get_plan(int H, int W, long batch, int inverse, hipfftHandle* out) {
+  std::lock_guard<std::mutex> lk(plan_mu);
+  auto key = std::make_tuple(H, W, batch, inverse);
+  auto it = plans.find(key);
+  if (it != plans.end()) { *out = it->second; return 0; }
+  hipfftHandle p;
+  int n[2] = {H, W};
+  if (hipfftPlanMany(&p, 2, n, nullptr, 1, 0, nullptr, 1, 0, inverse ? HIPFFT_C2R : HIPFFT_R2C, (int)batch) != HIPFFT_SUCCESS) return -1;
+  plans[key] = p;
+  *out = p;
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int tante_im2col(const void* x, int x_dtype, int nchw, int64_t n_img, int C, int H, int W, int kh, int kw, int sh, int sw,
+                            int ph, int pw, int korder, void* cols, int cols_dtype, void* stream) {
+  if (!x || !cols || n_img <= 0 || C <= 0 || H <= 0 || W <= 0 || kh <= 0 || kw <= 0 || sh <= 0 || sw <= 0 || ph < 0 || pw < 0)
+    TANTE_FAIL(-1, "tante_im2col: bad argument");
+  const int Ho = (H + 2 * ph - kh) / sh + 1, Wo = (W + 2 * pw - kw) / sw + 1;
+  if (Ho <= 0 || Wo <= 0) TANTE_FAIL(-1, "tante_im2col: empty output");
+  const long total = (long)n_img * Ho * Wo * C * kh * kw;
+  hipLaunchKernelGGL(im2col_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, x_dtype, nchw, (long)n_img, C, H, W, kh, kw,
+                     sh, sw, ph, pw, Ho, Wo, korder, cols, cols_dtype);
+  TANTE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int tante_avgpool_nhwc(const void* x, int x_dtype, int64_t n_img, int H, int W, int C, int Ht, int Wt, int act, void* y,
+                                  int y_dtype, void* stream) {
+  if (!x || !y || n_img <= 0 || H <= 0 || W <= 0 || C <= 0 || Ht <= 0 || Wt <= 0) TANTE_FAIL(-1, "tante_avgpool_nhwc: bad argument");
+  hipLaunchKernelGGL(avgpool_kernel, dim3(grid_for((long)n_img * Ht * Wt * C)), dim3(256), 0, (hipStream_t)stream, x, x_dtype, (long)n_img, H, W,
+                     C, Ht, Wt, act, y, y_dtype);
+  TANTE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int tante_resize_bilinear(const void* in, int in_dtype, int64_t n_img, int C, int Hi, int Wi, int crop_y, int crop_x,
+                                     int64_t isn, int64_t isc, int64_t ish, int64_t isw, int Ho, int Wo, int64_t osn, int64_t osc,
+                                     int64_t osh, int64_t osw, int act, void* out, int out_dtype, void* stream) {
+  if (!in || !out || n_img <= 0 || C <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0) TANTE_FAIL(-1, "tante_resize_bilinear: bad argument");
+  hipLaunchKernelGGL(resize_kernel, dim3(grid_for((long)n_img * C * Ho * Wo)), dim3(256), 0, (hipStream_t)stream, in, in_dtype, (long)n_img, C,
+                     Hi, Wi, crop_y, crop_x, (long)isn, (long)isc, (long)ish, (long)isw, Ho, Wo, (long)osn, (long)osc, (long)osh, (long)osw, act,
+                     out, out_dtype, (int)(osc == 1));
+  TANTE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int tante_layernorm_affine(const void* x, int x_dtype, int64_t M, int C, float eps, const float* gamma, const float* beta, void* y,
+                                      int y_dtype, void* stream) {
+  if (!x || !y || M <= 0 || C <= 0) TANTE_FAIL(-1, "tante_layernorm_affine: bad argument");
+  hipLaunchKernelGGL(ln_affine_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, x_dtype, (long)M, C, eps, gamma, beta,
+                     y, y_dtype);
+  TANTE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int64_t tante_spectral_workspace_bytes(int64_t n, int Cin, int Cout, int H, int W) {
+  const long Wf = W / 2 + 1;
+  return (long)sizeof(float2) * n * H * Wf * ((long)Cin + Cout);
+}
+
+extern "C" int tante_spectral_layer(const float* x, int64_t n, int Cin, int H, int W, const float* w_re, const float* w_im, int wm1, int wm2,
+                                    int modes1, int modes2, const float* w0, const float* b0, int Cout, int act, float* out, void* work,
+                                    int64_t work_bytes, void* stream) {
+  if (!x || !w_re || !w_im || !w0 || !out || !work || n <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0)
+    TANTE_FAIL(-1, "tante_spectral_layer: bad argument");
+  if (work_bytes < tante_spectral_workspace_bytes(n, Cin, Cout, H, W)) TANTE_FAIL(-1, "tante_spectral_layer: workspace too small");
+  const int Wf = W / 2 + 1;
+  const int m1 = modes1 < H ? modes1 : H, m2 = modes2 < Wf ? modes2 : Wf;
+  if (m1 > wm1 || m2 > wm2) TANTE_FAIL(-1, "tante_spectral_layer: weight holds fewer modes (%d, %d) than used (%d, %d)", wm1, wm2, m1, m2);
+  hipStream_t s = (hipStream_t)stream;
+  float2* X = (float2*)work;
+  float2* Y = X + (long)n * Cin * H * Wf;
+  hipfftHandle fwd, inv;
+  if (get_plan(H, W, (long)n * Cin, 0, &fwd) || get_plan(H, W, (long)n * Cout, 1, &inv)) TANTE_FAIL(-3, "tante_spectral_layer: hipfftPlanMany failed");
+  if (hipfftSetStream(fwd, s) != HIPFFT_SUCCESS || hipfftSetStream(inv, s) != HIPFFT_SUCCESS) TANTE_FAIL(-3, "tante_spectral_layer: hipfftSetStream failed");
+  if (hipfftExecR2C(fwd, (hipfftReal*)x, (hipfftComplex*)X) != HIPFFT_SUCCESS) TANTE_FAIL(-3, "tante_spectral_layer: R2C failed");
+  // both 'ortho' factors (1/sqrt(HW) forward and inverse) ride the contraction
+  hipLaunchKernelGGL(spectral_modes_kernel, dim3(grid_for((long)n * Cout * H * Wf)), dim3(256), 0, s, X, w_re, w_im, (long)n, Cin, Cout, H, Wf,
+                     m1, m2, wm1, wm2, 1.0f / ((float)H * (float)W), Y);
+  TANTE_CHECK_LAUNCH();
+  if (hipfftExecC2R(inv, (hipfftComplex*)Y, (hipfftReal*)out) != HIPFFT_SUCCESS) TANTE_FAIL(-3, "tante_spectral_layer: C2R failed");
+  const size_t lds = ((size_t)Cin * 64 + (size_t)Cout * Cin) * sizeof(float);
+  if (lds > 160 * 1024) TANTE_FAIL(-2, "tante_spectral_layer: 1x1 weight %d x %d does not fit LDS", Cout, Cin);
+  if (lds > 64 * 1024) hipFuncSetAttribute((const void*)conv1x1_add_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const long HW = (long)H * W;
+  hipLaunchKernelGGL(conv1x1_add_kernel, dim3((unsigned)((HW + 63) / 64), (unsigned)n), dim3(256), lds, s, x, w0, b0, out, HW, Cin, Cout, act, out);
+  TANTE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int tante_cross_attention(const void* q, const void* k, const void* v, void* o, int dtype, int64_t n_batch, int n_head, int D, int Lq,
+                                     int Lk, int64_t ldq, int64_t ldkv, int64_t ldo, void* stream) {
+  if (!q || !k || !v || !o || n_batch <= 0 || n_head <= 0 || Lq <= 0 || Lk <= 0) TANTE_FAIL(-1, "tante_cross_attention: bad argument");
+  if ((Lq + 255) / 256 > 65535 || n_batch * n_head > 2147483647L) TANTE_FAIL(-2, "tante_cross_attention: grid too large");
+  const dim3 grid((unsigned)(n_batch * n_head), (unsigned)((Lq + 255) / 256));
+  const float scale = 1.0f / sqrtf((float)D);
+  hipStream_t s = (hipStream_t)stream;
+#define TANTE_XA(DD) hipLaunchKernelGGL(cross_attn_kernel<DD>, grid, dim3(256), 0, s, q, k, v, o, dtype, n_head, Lq, Lk, (long)ldq, (long)ldkv, (long)ldo, scale)
+  switch (D) {
+    case 4: TANTE_XA(4); break;
+    case 8: TANTE_XA(8); break;
+    case 12: TANTE_XA(12); break;
+    case 16: TANTE_XA(16); break;
+    case 32: TANTE_XA(32); break;
+    case 64: TANTE_XA(64); break;
+    default: TANTE_FAIL(-2, "tante_cross_attention: head dim %d not in {4, 8, 12, 16, 32, 64}", D);
+  }
+#undef TANTE_XA
+  TANTE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int tante_grid_embed(const float* coords, const float* grid, const float* latents, int64_t N, int G, int LD, float eps, float* out,
+                                void* stream) {
+  if (!coords || !grid || !latents || !out || N <= 0 || G <= 0 || LD <= 0) TANTE_FAIL(-1, "tante_grid_embed: bad argument");
+  if (LD > 1024) TANTE_FAIL(-2, "tante_grid_embed: latent_dim %d > 1024", LD);
+  hipLaunchKernelGGL(grid_embed_kernel, dim3((unsigned)N), dim3(256), 0, (hipStream_t)stream, coords, grid, latents, (long)N, G, LD, eps, out);
+  TANTE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int tante_fourier_embed(const float* coords, const float* kernel, int64_t N, int E, float* out, void* stream) {
+  if (!coords || !kernel || !out || N <= 0 || E <= 0 || E % 2) TANTE_FAIL(-1, "tante_fourier_embed: bad argument");
+  hipLaunchKernelGGL(fourier_embed_kernel, dim3(grid_for((long)N * (E / 2))), dim3(256), 0, (hipStream_t)stream, coords, kernel, (long)N, E / 2, out);
+  TANTE_CHECK_LAUNCH();
+  return 0;
+}

@@ -6,7 +6,7 @@ libtante_hip.so.  Nothing here falls back to ATen arithmetic: CPU tensors or a m
 from __future__ import annotations
 
 import ctypes as C
-from typing import Optional, Sequence
+from typing import Optional, Sequence, Tuple
 
 import torch
 
@@ -306,4 +306,85 @@ def head_fused(x: torch.Tensor, a_n0: int, a_s1: int, a_s0: int, a_off: int, n_i
     lp = None if last is None else last.data_ptr() + 4 * last_elem_off
     L.check(L.lib().tante_head_fused(_p(x), a_n0, a_s1, a_s0, a_off, n_img, Hp, Wp, C_, D, _p(head_stream), out.data_ptr(), out_bstride,
                                      n_out, arr, lp, last_bstride, _stream()), "tante_head_fused")
+    return out
+
+
+# ---- general conv stages, spectral layer, CViT operators (operators.hip) ---------------------------------------------------------
+def im2col(x: torch.Tensor, nchw: bool, n_img: int, C_: int, H: int, W: int, kh: int, kw: int, sh: int, sw: int, ph: int, pw: int,
+           korder: int, out_dtype: torch.dtype) -> torch.Tensor:
+    """-> (n_img * Ho * Wo, C * kh * kw) patch matrix (zero padded); korder 0 = (c, kh, kw), 1 = (kh, kw, c)."""
+    _dev(x)
+    Ho, Wo = (H + 2 * ph - kh) // sh + 1, (W + 2 * pw - kw) // sw + 1
+    cols = torch.empty(n_img * Ho * Wo, C_ * kh * kw, dtype=out_dtype, device=x.device)
+    L.check(L.lib().tante_im2col(_p(x), _DT[x.dtype], int(nchw), n_img, C_, H, W, kh, kw, sh, sw, ph, pw, korder, _p(cols), _DT[out_dtype],
+                                 _stream()), "tante_im2col")
+    return cols
+
+
+def avgpool_nhwc(x: torch.Tensor, n_img: int, H: int, W: int, C_: int, Ht: int, Wt: int, act: int, out_dtype: torch.dtype) -> torch.Tensor:
+    _dev(x)
+    y = torch.empty(n_img * Ht * Wt, C_, dtype=out_dtype, device=x.device)
+    L.check(L.lib().tante_avgpool_nhwc(_p(x), _DT[x.dtype], n_img, H, W, C_, Ht, Wt, act, _p(y), _DT[out_dtype], _stream()), "tante_avgpool_nhwc")
+    return y
+
+
+def resize_bilinear(x: torch.Tensor, n_img: int, C_: int, Hi: int, Wi: int, crop: Tuple[int, int], in_strides, Ho: int, Wo: int,
+                    out: torch.Tensor, out_strides, act: int):
+    """Bilinear resize (align_corners=False) of the (Hi, Wi) window at `crop` of x into out; strides = (sn, sc, sh, sw) in elements."""
+    _dev(x, out)
+    L.check(L.lib().tante_resize_bilinear(_p(x), _DT[x.dtype], n_img, C_, Hi, Wi, crop[0], crop[1], *in_strides, Ho, Wo, *out_strides, act,
+                                          _p(out), _DT[out.dtype], _stream()), "tante_resize_bilinear")
+    return out
+
+
+def layernorm_affine(x: torch.Tensor, gamma: Optional[torch.Tensor], beta: Optional[torch.Tensor], eps: float,
+                     out_dtype: torch.dtype = torch.float32) -> torch.Tensor:
+    _dev(x, gamma, beta)
+    x = x.contiguous()
+    Cc = x.shape[-1]
+    y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    L.check(L.lib().tante_layernorm_affine(_p(x), _DT[x.dtype], x.numel() // Cc, Cc, eps, _p(gamma), _p(beta), _p(y), _DT[out_dtype], _stream()),
+            "tante_layernorm_affine")
+    return y
+
+
+def spectral_layer(x: torch.Tensor, w_re: torch.Tensor, w_im: torch.Tensor, modes1: int, modes2: int, w0: torch.Tensor, b0: torch.Tensor,
+                   act: int) -> torch.Tensor:
+    """x (n, Cin, H, W) fp32 -> act(SpectralLayer(x)) (n, Cout, H, W) fp32."""
+    _dev(x, w_re, w_im, w0, b0)
+    n, Cin, H, W = x.shape
+    Cout = w_re.shape[1]
+    out = torch.empty(n, Cout, H, W, dtype=torch.float32, device=x.device)
+    nbytes = L.lib().tante_spectral_workspace_bytes(n, Cin, Cout, H, W)
+    work = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    L.check(L.lib().tante_spectral_layer(_p(x), n, Cin, H, W, _p(w_re), _p(w_im), w_re.shape[2], w_re.shape[3], modes1, modes2, _p(w0), _p(b0),
+                                         Cout, act, _p(out), _p(work), nbytes, _stream()), "tante_spectral_layer")
+    return out
+
+
+def cross_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, o: torch.Tensor, n_batch: int, n_head: int, D: int, Lq: int, Lk: int,
+                    ldq: int, ldkv: int, ldo: int):
+    """k and v may be views into one packed (…, 2C) buffer: rows are addressed by data_ptr + strides."""
+    if not (q.is_cuda and k.is_cuda and v.is_cuda and o.is_cuda):
+        raise RuntimeError("tante_amd kernels need CUDA/HIP tensors (no CPU fallback)")
+    if not (q.dtype == k.dtype == v.dtype == o.dtype):
+        raise RuntimeError("q, k, v, o must share a dtype")
+    L.check(L.lib().tante_cross_attention(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), _DT[q.dtype], n_batch, n_head, D, Lq, Lk, ldq,
+                                          ldkv, ldo, _stream()), "tante_cross_attention")
+    return o
+
+
+def grid_embed(coords: torch.Tensor, grid: torch.Tensor, latents: torch.Tensor, eps: float) -> torch.Tensor:
+    _dev(coords, grid, latents)
+    N, G, LD = coords.shape[0], grid.shape[0], latents.shape[1]
+    out = torch.empty(N, LD, dtype=torch.float32, device=coords.device)
+    L.check(L.lib().tante_grid_embed(_p(coords), _p(grid), _p(latents), N, G, LD, eps, _p(out), _stream()), "tante_grid_embed")
+    return out
+
+
+def fourier_embed(coords: torch.Tensor, kernel: torch.Tensor) -> torch.Tensor:
+    _dev(coords, kernel)
+    N, E = coords.shape[0], 2 * kernel.shape[1]
+    out = torch.empty(N, E, dtype=torch.float32, device=coords.device)
+    L.check(L.lib().tante_fourier_embed(_p(coords), _p(kernel), N, E, _p(out), _stream()), "tante_fourier_embed")
     return out

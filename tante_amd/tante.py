@@ -25,6 +25,7 @@ import torch.nn as nn
 
 from . import _lib as L
 from . import kernels as K
+from . import stages as S
 from .attn_backbone import Attn_Backbone, _PackCache, _no_autograd, resolve_compute
 
 # models/enc_dec_cnn.py:39-46
@@ -53,14 +54,19 @@ class TanteMetadata:
 
 
 def _check_patch_cfg(patch_scale, overlap_ratio):
-    P = Patch_map[patch_scale]
-    if overlap_ratio != 0.0:
-        raise NotImplementedError("overlap_ratio > 0 (strided-overlap conv + pooling, enc_dec_cnn.py:66-110) is not on the "
-                                  "HIP path yet; shipped configs use overlap_ratio = 0")
-    if any((p - 1) // 2 != 0 for p in P):
-        raise NotImplementedError(f"patch_scale {patch_scale} uses a 4x4 stage whose 'same' padding shifts the patch grid "
-                                  "(enc_dec_cnn.py:78-81); only 1x1 / 2x2 stages (patch_scale 2, 4, 8) are on the HIP path yet")
-    return P
+    """-> per-stage kernel sizes.  Stages with 'same' padding (4x4 kernels, enc_dec_cnn.py:78-81) or overlap (stride < kernel) take
+    the general im2col / crop+resize route of stages.py; 1x1 / 2x2 non-overlapping stages keep the dedicated patch GEMM."""
+    if not 0.0 <= overlap_ratio < 1.0:
+        raise AssertionError("overlap_ratio must be in [0, 1).")
+    return Patch_map[patch_scale]
+
+
+def _film_pos(v: torch.Tensor, film: tuple) -> torch.Tensor:
+    fa, fb, se, T, HW = film
+    y = torch.empty_like(v)
+    L.check(L.lib().tante_film_pos_fwd(v.data_ptr(), fa.data_ptr(), fb.data_ptr(), se.data_ptr(), v.shape[0], v.shape[1], T, HW, y.data_ptr(),
+                                       K._stream()), "tante_film_pos_fwd")
+    return y
 
 
 class _ConvHolder(nn.Module):
@@ -78,13 +84,16 @@ class enc_CNN(nn.Module):
         super().__init__()
         self.embed_dim = embed_dim
         self.P = _check_patch_cfg(patch_scale, overlap_ratio)
+        self.overlap = overlap_ratio
         cin = dset_metadata.n_fields if dset_metadata else 4
         shape = dset_metadata.spatial_resolution if dset_metadata else (128, 384)
         self.H, self.W = shape[0], shape[1]
         self.chans = [cin, embed_dim // 4, embed_dim // 2, embed_dim]
         for i in range(3):
             p = self.P[i]
-            setattr(self, f"enc_conv_{i + 1}", _ConvHolder("conv", nn.Conv2d(self.chans[i], self.chans[i + 1], (p, p), stride=(p, p))))
+            st, pd = S.stride_pad(p, overlap_ratio)
+            setattr(self, f"enc_conv_{i + 1}", _ConvHolder("conv", nn.Conv2d(self.chans[i], self.chans[i + 1], (p, p), stride=(st, st),
+                                                                             padding=(pd, pd))))
         tot = self.P[0] * self.P[1] * self.P[2]
         self.patch_shape = (self.H // tot, self.W // tot)
         self._cache = _PackCache()
@@ -97,12 +106,18 @@ class enc_CNN(nn.Module):
             out = []
             for i, c in enumerate(convs):
                 p, ci, co = self.P[i], self.chans[i], self.chans[i + 1]
-                if i == 0:   # first stage reads the channels-first input: k = (ci, kh, kw) is the native weight order
+                if self._general(i):   # im2col route: K-chunked dense weight in the gather's column order
+                    out.append(S.pack_linear_chunks(S.conv_weight_2d(c.weight, 0 if i == 0 else 1), c.bias, compute))
+                elif i == 0:   # first stage reads the channels-first input: k = (ci, kh, kw) is the native weight order
                     out.append(K.pack_weight(c.weight, c.bias, compute, L.W_LINEAR, N=co, K=ci * p * p))
                 else:        # later stages read channels-last intermediates: k = (kh, kw, ci)
                     out.append(K.pack_weight(c.weight, c.bias, compute, L.W_CONV_NHWC, N=co, K=ci * p * p, P=p, C_other=ci))
             return out
         return self._cache.get(compute, params, build)
+
+    def _general(self, i: int) -> bool:
+        s_, p_ = S.stride_pad(self.P[i], self.overlap)
+        return s_ != self.P[i] or p_ != 0 or self.chans[i] * self.P[i] ** 2 > S.KMAX
 
     def forward_tokens(self, inp: torch.Tensor, compute: int, film: Optional[tuple], item_stride: Optional[int] = None) -> torch.Tensor:
         """inp (B,T,D,H,W) fp32 -> tokens (B*T*Hp*Wp, C) fp32; `film` = (a, b, s_emb, T, HW) is applied in the
@@ -118,6 +133,15 @@ class enc_CNN(nn.Module):
         for i in range(3):
             p, ci, co = self.P[i], self.chans[i], self.chans[i + 1]
             last = i == 2
+            if self._general(i):
+                if i == 0:
+                    x = x.contiguous().view(n_img, D, H, W)
+                out, _, _ = S.conv_stage(x, i == 0, n_img, ci, h, w, p, self.overlap, pk[i], compute,
+                                         L.ACT_NONE if last else L.ACT_GELU_ERF, torch.float32 if last else adt)
+                if last and film is not None:
+                    out = _film_pos(out, film)
+                x, h, w = out, h // p, w // p
+                continue
             out = torch.empty(n_img * (h // p) * (w // p), co, dtype=torch.float32 if last else adt, device=inp.device)
             K.patch_embed(x, pk[i], out, n_img=n_img, Hin=h, Win=w, Cin=ci, P=p, nchw=(i == 0),
                           act=L.ACT_NONE if last else L.ACT_GELU_ERF, film=film if last else None,
@@ -140,13 +164,16 @@ class dec_CNN(nn.Module):
         self.embed_dim = embed_dim
         Pm = _check_patch_cfg(patch_scale, overlap_ratio)
         self.P = (Pm[2], Pm[1], Pm[0])           # enc_dec_cnn.py:251-253: kernel sizes in reverse order
+        self.overlap = overlap_ratio
         cout = dset_metadata.n_fields if dset_metadata else 4
         shape = dset_metadata.spatial_resolution if dset_metadata else (128, 384)
         self.H, self.W = shape[0], shape[1]
         self.chans = [embed_dim, embed_dim // 2, embed_dim // 4, cout]
         for i in range(3):
             p = self.P[i]
-            setattr(self, f"dec_conv_{i + 1}", _ConvHolder("deconv", nn.ConvTranspose2d(self.chans[i], self.chans[i + 1], (p, p), stride=(p, p))))
+            st, pd = S.stride_pad(p, overlap_ratio)
+            setattr(self, f"dec_conv_{i + 1}", _ConvHolder("deconv", nn.ConvTranspose2d(self.chans[i], self.chans[i + 1], (p, p),
+                                                                                         stride=(st, st), padding=(pd, pd))))
         tot = Pm[0] * Pm[1] * Pm[2]
         self.patch_shape = (self.H // tot, self.W // tot)
         self._cache = _PackCache()
@@ -159,7 +186,8 @@ class dec_CNN(nn.Module):
             out = []
             for i, c in enumerate(convs):
                 p, ci, co = self.P[i], self.chans[i], self.chans[i + 1]
-                lay = L.W_DECONV_NCHW if i == 2 else L.W_DECONV_NHWC
+                padded = S.stride_pad(p, self.overlap)[1] != 0    # padded stages scatter channels-last, then crop + resize
+                lay = L.W_DECONV_NCHW if (i == 2 and not padded) else L.W_DECONV_NHWC
                 out.append(K.pack_weight(c.weight, c.bias, compute, lay, N=co * p * p, K=ci, P=p, C_other=co))
             return out
         return self._cache.get(compute, params, build)
@@ -179,6 +207,12 @@ class dec_CNN(nn.Module):
         for i in range(3):
             p, co = self.P[i], self.chans[i + 1]
             last = i == 2
+            if S.stride_pad(p, self.overlap) != (p, 0):   # padded stage: unpadded deconv -> crop + bilinear resize -> act
+                rows = dict(a_n0=a_n0, a_s1=a_s1, a_s0=a_s0, a_off=a_off) if i == 0 else {}
+                x = S.deconv_stage(x, n_img, h, w, p, self.overlap, pk[i], co, compute, L.ACT_NONE if last else L.ACT_GELU_ERF, last,
+                                   torch.float32 if last else adt, **rows)
+                h, w = h * p, w * p
+                continue
             if last:
                 out = torch.empty(n_img, co, h * p, w * p, dtype=torch.float32, device=src.device)
             else:
@@ -317,13 +351,22 @@ class TANTE(nn.Module):
         if len(self.blocks_axes) != taylor_order:
             raise ValueError(f"Block allocation doesn't match expansion order: expected {taylor_order} parts, "
                              f"got {len(self.blocks_axes)} (input='{self.attn_axes}').")
-        if enc_dec_type != "cnn":
-            raise NotImplementedError("enc_dec_type='fno' (spectral encoder) is a later tier (SURVEY 8f rank 2)")
         self.decoders = nn.ModuleList()
-        self.encoder = enc_CNN(dset_metadata=dset_metadata, embed_dim=embed_dim, patch_scale=patch_scale, overlap_ratio=overlap_ratio)
-        for _ in range(taylor_order):
-            self.decoders.append(dec_CNN(dset_metadata=dset_metadata, embed_dim=embed_dim, patch_scale=patch_scale,
-                                         overlap_ratio=overlap_ratio))
+        if enc_dec_type == "cnn":                                                                    # tante.py:86-93
+            self.encoder = enc_CNN(dset_metadata=dset_metadata, embed_dim=embed_dim, patch_scale=patch_scale, overlap_ratio=overlap_ratio)
+            for _ in range(taylor_order):
+                self.decoders.append(dec_CNN(dset_metadata=dset_metadata, embed_dim=embed_dim, patch_scale=patch_scale,
+                                             overlap_ratio=overlap_ratio))
+        elif enc_dec_type == "fno":                                                                  # tante.py:94-101
+            from .spectral import enc_FNO, dec_FNO
+            self.encoder = enc_FNO(dset_metadata=dset_metadata, embed_dim=embed_dim, modes=(modes1, modes2), patch_scale=patch_scale,
+                                   overlap_ratio=overlap_ratio)
+            for _ in range(taylor_order):
+                self.decoders.append(dec_FNO(dset_metadata=dset_metadata, embed_dim=embed_dim, modes=(modes1, modes2),
+                                             patch_scale=patch_scale, overlap_ratio=overlap_ratio))
+        else:
+            raise ValueError(f"enc_dec_type must be 'cnn' or 'fno', got {enc_dec_type!r}")
+        self.enc_dec_type = enc_dec_type
         self.blocks = nn.ModuleList()
         for block_axes in self.blocks_axes:
             self.blocks.append(Attn_Backbone(tensor_shape=(self.T, self.H_p, self.W_p, self.C), attn_axes=block_axes,
@@ -367,6 +410,9 @@ class TANTE(nn.Module):
         if input.shape[1] != self.T:
             input = input[:, -self.T:]
         if torch.is_grad_enabled() and (input.requires_grad or any(p.requires_grad for p in self.parameters())):
+            if self.enc_dec_type != "cnn":
+                raise NotImplementedError("the spectral encoder / decoder run on the inference path only (no autograd graph): call "
+                                          "under torch.no_grad() / inference_mode")
             from .train_forward import tante_train_forward
             if out is not None:
                 raise ValueError("out= is an inference-path option")
@@ -383,7 +429,7 @@ class TANTE(nn.Module):
         fa, fb = self._time_tables()
         x = self.encoder.forward_tokens(inp, compute, (fa, fb, self.s_emb.view(HW, C_), T, HW), bstride)   # tante.py:132-141
         last_slot = dict(a_n0=HW, a_s1=T * HW * C_, a_s0=C_, a_off=(T - 1) * HW * C_)               # x[:, -1:] by stride
-        fused_head = (compute == L.BF16 and self.fused_head and self.decoders[0].P == (2, 2, 2)
+        fused_head = (compute == L.BF16 and self.fused_head and getattr(self.decoders[0], 'P', None) == (2, 2, 2) and self.decoders[0].overlap == 0.0
                       and K.head_fused_supported(C_, D))
         if out is not None:
             if not self.deg:

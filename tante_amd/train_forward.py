@@ -11,6 +11,7 @@ import torch
 
 from . import _lib as L
 from . import kernels as K
+from . import stages as S
 from .autograd import (ActFn, AttentionFn, AxisMlpFn, DeconvFn, DropoutAddFn, FilmPosFn, LayerNormFn, LinearFn, PatchEmbedFn, RtReduceFn,
                        TaylorFn)
 
@@ -56,6 +57,9 @@ def backbone_train(bb, x: torch.Tensor, B: int, compute: int) -> torch.Tensor:
 
 
 def encoder_train(enc, inp: torch.Tensor, compute: int) -> torch.Tensor:
+    if any(S.stride_pad(p, enc.overlap) != (p, 0) for p in enc.P):
+        raise NotImplementedError("the differentiable path covers non-overlapping, unpadded stages (patch_scale 2, 4, 8); padded / "
+                                  "overlapping stages run on the inference path only")
     B, T, D, H, W = inp.shape
     adt = K.act_torch_dtype(compute)
     n_img, h, w = B * T, H, W
@@ -72,6 +76,9 @@ def encoder_train(enc, inp: torch.Tensor, compute: int) -> torch.Tensor:
 
 
 def decoder_train(dec, a: torch.Tensor, n_img: int, compute: int) -> torch.Tensor:
+    if any(S.stride_pad(p, dec.overlap) != (p, 0) for p in dec.P):
+        raise NotImplementedError("the differentiable path covers non-overlapping, unpadded stages (patch_scale 2, 4, 8); padded / "
+                                  "overlapping stages run on the inference path only")
     adt = K.act_torch_dtype(compute)
     h, w = dec.patch_shape
     x = a

@@ -305,19 +305,21 @@ def test_g2_encdec(dev, name):
     g = load_golden(name)
     ps, ov, H, W, nf, C = (int(v) for v in g["meta"])
     md = tante_amd.TanteMetadata(n_fields=nf, spatial_resolution=(H, W))
-    if ov != 0 or ps not in (2, 4, 8):
-        with pytest.raises(NotImplementedError):       # fails loudly, never silently approximates
-            tante_amd.enc_CNN(md, embed_dim=C, patch_scale=ps, overlap_ratio=ov / 100)
-        return
-    e = tante_amd.enc_CNN(md, embed_dim=C, patch_scale=ps, overlap_ratio=0.0).to(dev)
-    d = tante_amd.dec_CNN(md, embed_dim=C, patch_scale=ps, overlap_ratio=0.0).to(dev)
+    ov = ov / 100
+    e = tante_amd.enc_CNN(md, embed_dim=C, patch_scale=ps, overlap_ratio=ov).to(dev)
+    d = tante_amd.dec_CNN(md, embed_dim=C, patch_scale=ps, overlap_ratio=ov).to(dev)
     e.load_state_dict(split_prefix(g, "enc."))
     d.load_state_dict(split_prefix(g, "dec."))
     with torch.no_grad():
-        close(e(g["x"].to(dev)), g["z"], "fp32")
-        close(d(g["zz"].to(dev)), g["r"], "fp32")
+        close(e(g["x"].to(dev)), g["z"], "fp32")     # every patch scale, 'same' padding and overlap (im2col + pool route)
         with torch.autocast("cuda", dtype=torch.bfloat16):
             close(e(g["x"].to(dev)), g["z"], "bf16")
+        if ov != 0:
+            with pytest.raises(NotImplementedError):   # overlapping transposed conv: fails loudly, never silently approximates
+                d(g["zz"].to(dev))
+            return
+        close(d(g["zz"].to(dev)), g["r"], "fp32")      # padded 4x4 stages: crop + bilinear resize route
+        with torch.autocast("cuda", dtype=torch.bfloat16):
             close(d(g["zz"].to(dev)), g["r"], "bf16")
 
 
@@ -803,3 +805,45 @@ def test_fused_head_against_oracle(dev, C, D, B, Hp, Wp, n_out):
     close(out, ref, "bf16")
     # the derivative part alone (what the head computes) also holds the bf16 bar
     assert rel_err((out.cpu() - last), (ref - last)) < 2e-2
+
+
+# ---- spectral operator path (fixtures g12) -----------------------------------------------------------------
+@pytest.mark.parametrize("name", ["low", "clip", "odd"])
+def test_g12_spectral_layer(dev, name):
+    from tante_amd.spectral import SpectralLayer
+    g = load_golden("g12_spectral_" + name)
+    m1, m2 = (int(v) for v in g["modes"])
+    cin, cout = g["w.weight_re"].shape[:2]
+    m = SpectralLayer(cin, cout, m1, m2).to(dev)
+    with torch.no_grad():
+        m.weight.copy_(torch.complex(g["w.weight_re"], g["w.weight_im"]))
+        m.w0.weight.copy_(g["w.w0.weight"])
+        m.w0.bias.copy_(g["w.w0.bias"])
+        y = m(g["x"].to(dev))
+    close(y, g["y"], "fp32")
+    # against the oracle on a fresh, larger random case (hipFFT vs the CPU FFT)
+    from oracle import spectral_oracle as OS
+    torch.manual_seed(5)
+    x = torch.randn(3, cin, 48, 40)
+    w = {"weight": m.weight.detach().cpu(), "w0.weight": m.w0.weight.detach().cpu(), "w0.bias": m.w0.bias.detach().cpu()}
+    with torch.no_grad():
+        close(m(x.to(dev)), OS.spectral_layer(w, x, m1, m2), "fp32")
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_g12_tante_fno(dev, mode):
+    import tante_amd
+    g = load_golden("g12_tante_fno")
+    md = tante_amd.TanteMetadata(n_fields=2, spatial_resolution=(32, 32))
+    m = tante_amd.TANTE(in_T=4, dset_metadata=md, taylor_order=2, attn_axes="TL-TL", n_head=4, embed_dim=64, patch_scale=8,
+                        enc_dec_type="fno", modes1=8, modes2=8).to(dev).eval()
+    sd = {}
+    for k, v in split_prefix(g, "w.").items():
+        if k.endswith("_re"):
+            sd[k[:-3]] = torch.complex(v, g["w." + k[:-3] + "_im"])
+        elif not k.endswith("_im"):
+            sd[k] = v
+    m.load_state_dict(sd, strict=True)
+    m.set_compute(mode)
+    with torch.no_grad():
+        close(m(g["x"].to(dev)), g["y"], mode)
