@@ -6,6 +6,8 @@ libtante_hip.so (include/tante_hip.h, tante_amd/csrc/*.hip).  There is no CPU fa
 """
 from .tante import TANTE, TanteMetadata, enc_CNN, dec_CNN, film, interprator, t_series, Patch_map  # noqa: F401
 from .attn_backbone import Attn_Backbone, TransformerBlock  # noqa: F401
+from .spectral import SpectralLayer, enc_FNO, dec_FNO  # noqa: F401
+from .cvit import CViT  # noqa: F401
 from .rollout import (DefaultChannelsFirstFormatter, DefaultChannelsLastFormatter, rollout_model,  # noqa: F401
                       rollout_adaptive)
 from .config import instantiate, load_config, build_model  # noqa: F401
@@ -16,4 +18,4 @@ from .train import train_step, train_step_adaptive  # noqa: F401
 
 __all__ = ["TANTE", "TanteMetadata", "enc_CNN", "dec_CNN", "film", "interprator", "t_series", "Attn_Backbone",
            "TransformerBlock", "DefaultChannelsFirstFormatter", "DefaultChannelsLastFormatter", "rollout_model",
-           "rollout_adaptive", "instantiate", "load_config", "build_model"]
+           "rollout_adaptive", "instantiate", "load_config", "build_model", "CViT", "SpectralLayer", "enc_FNO", "dec_FNO"]

@@ -1,0 +1,330 @@
+"""CViT on the HIP kernels  (reference models/cvit.py).
+
+Same constructor arguments, forward(x, input_coords=None) contract and state_dict keys as the reference's models.CViT.
+Every arithmetic step is a C-ABI call of libtante_hip: im2col + tante_gemm (Conv3d patch embed), tante_gemm with folded
+LayerNorm (all projections / MLPs), tante_cross_attention (self / cross / time-aggregation attention), tante_grid_embed (the
+eps-Gaussian latent-grid interpolation, evaluated exactly but sparsely), tante_layernorm_affine.  torch allocates and reshapes.
+
+Reference quirks kept on purpose (pinned by the g11 fixtures):
+  * CrossAttnBlock applies layer_norm2 twice -- to the keys/values and again to the post-attention stream (cvit.py:160,165);
+  * the decoder loop feeds each block's OUTPUT back as the next block's keys/values while the queries stay the coordinate
+    embedding (cvit.py:455-456);
+  * TimeAggregation depth is fixed to 2 with a single latent (cvit.py:262-269); the default eps is 1e5 (l.350).
+
+Inference path only (no autograd graph); no CPU fallback."""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from . import kernels as K
+from . import stages as S
+from .attn_backbone import _PackCache, _no_autograd, resolve_compute
+from .tante import TanteMetadata, s_emb_init, t_emb_init
+
+
+class MlpBlock(nn.Module):
+    """fc2(gelu_erf(fc1(x)))  (cvit.py:95-110)."""
+
+    def __init__(self, in_dim=256, dim=256, out_dim=256, kernel_init=True):
+        super().__init__()
+        self.fc1 = nn.Linear(in_dim, dim)
+        self.fc2 = nn.Linear(dim, out_dim)
+        if kernel_init:
+            nn.init.xavier_uniform_(self.fc1.weight)
+            nn.init.xavier_uniform_(self.fc2.weight)
+
+
+class _AttnBlock(nn.Module):
+    """Parameter layout shared by SelfAttnBlock / CrossAttnBlock (cvit.py:112-169)."""
+
+    def __init__(self, num_heads, emb_dim, mlp_ratio, layer_norm_eps=1e-5):
+        super().__init__()
+        self.num_heads, self.emb_dim, self.eps = num_heads, emb_dim, layer_norm_eps
+        self.attn = nn.MultiheadAttention(embed_dim=emb_dim, num_heads=num_heads, batch_first=True)
+        self.layer_norm1 = nn.LayerNorm(emb_dim, eps=layer_norm_eps)
+        self.layer_norm2 = nn.LayerNorm(emb_dim, eps=layer_norm_eps)
+        self.mlp = MlpBlock(emb_dim, emb_dim * mlp_ratio, emb_dim)
+        self._cache = _PackCache()
+
+    def _packed(self, compute: int):
+        a, m = self.attn, self.mlp
+        n1, n2 = self.layer_norm1, self.layer_norm2
+        params = [n1.weight, n1.bias, n2.weight, n2.bias, a.in_proj_weight, a.in_proj_bias, a.out_proj.weight, a.out_proj.bias,
+                  m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias]
+        C_ = self.emb_dim
+
+        def build():
+            Wi, bi = a.in_proj_weight.detach(), a.in_proj_bias.detach()
+            pw = K.pack_weight
+            return dict(
+                # LayerNorm affine folded into the consuming projection (gamma scales the columns, beta joins the bias)
+                q_ln1=pw(Wi[:C_].contiguous(), bi[:C_].contiguous(), compute, gamma=n1.weight, beta=n1.bias),
+                kv_ln2=pw(Wi[C_:].contiguous(), bi[C_:].contiguous(), compute, gamma=n2.weight, beta=n2.bias),
+                qkv_ln1=pw(Wi, bi, compute, gamma=n1.weight, beta=n1.bias),
+                out=pw(a.out_proj.weight, a.out_proj.bias, compute),
+                fc1_ln2=pw(m.fc1.weight, m.fc1.bias, compute, gamma=n2.weight, beta=n2.bias),
+                fc2=S.pack_linear_chunks(m.fc2.weight.detach(), m.fc2.bias, compute))
+        return self._cache.get(compute, params, build)
+
+    def _tail(self, attn_o: torch.Tensor, resid: torch.Tensor, pk, compute: int) -> torch.Tensor:
+        """x = out_proj(attn) + resid;  return x + fc2(gelu(fc1(LN2(x))))."""
+        adt = K.act_torch_dtype(compute)
+        M = attn_o.shape[0]
+        x = torch.empty(M, self.emb_dim, dtype=torch.float32, device=attn_o.device)
+        K.linear(attn_o, pk["out"], x, M=M, residual=resid)
+        h = torch.empty(M, pk["fc1_ln2"].N, dtype=adt, device=x.device)
+        K.linear(x, pk["fc1_ln2"], h, M=M, act=L.ACT_GELU_ERF, ln=True, ln_eps=self.eps)
+        if len(pk["fc2"]) == 1:
+            y = torch.empty_like(x)
+            return K.linear(h, pk["fc2"][0], y, M=M, residual=x)
+        return S.linear_chunks(h, pk["fc2"], torch.float32) + x    # hidden > 512: chunked accumulate, then the residual add
+
+
+class SelfAttnBlock(_AttnBlock):
+    def run(self, x: torch.Tensor, nb: int, Lq: int, compute: int) -> torch.Tensor:
+        """x (nb * Lq, C) fp32 -> block(x)   (cvit.py:129-139)."""
+        pk = self._packed(compute)
+        adt = K.act_torch_dtype(compute)
+        C_, nh = self.emb_dim, self.num_heads
+        M = nb * Lq
+        qkv = torch.empty(M, 3 * C_, dtype=adt, device=x.device)
+        K.linear(x, pk["qkv_ln1"], qkv, M=M, ln=True, ln_eps=self.eps)
+        o = torch.empty(M, C_, dtype=adt, device=x.device)
+        K.cross_attention(qkv, qkv[:, C_:], qkv[:, 2 * C_:], o, nb, nh, C_ // nh, Lq, Lq, 3 * C_, 3 * C_, C_)
+        return self._tail(o, x, pk, compute)
+
+
+class CrossAttnBlock(_AttnBlock):
+    def run(self, q_in: torch.Tensor, kv_in: torch.Tensor, nb: int, Lq: int, Lk: int, compute: int) -> torch.Tensor:
+        """q_in (nb * Lq, C), kv_in (nb * Lk, C) fp32 -> block(q_in, kv_in)   (cvit.py:158-169)."""
+        pk = self._packed(compute)
+        adt = K.act_torch_dtype(compute)
+        C_, nh = self.emb_dim, self.num_heads
+        q = torch.empty(nb * Lq, C_, dtype=adt, device=q_in.device)
+        K.linear(q_in, pk["q_ln1"], q, M=nb * Lq, ln=True, ln_eps=self.eps)
+        kv = torch.empty(nb * Lk, 2 * C_, dtype=adt, device=q_in.device)
+        K.linear(kv_in, pk["kv_ln2"], kv, M=nb * Lk, ln=True, ln_eps=self.eps)
+        o = torch.empty(nb * Lq, C_, dtype=adt, device=q_in.device)
+        K.cross_attention(q, kv, kv[:, C_:], o, nb, nh, C_ // nh, Lq, Lk, C_, 2 * C_, C_)
+        return self._tail(o, q_in, pk, compute)
+
+
+class TimeAggregation(nn.Module):
+    """Learned latents attend over the T frames of every spatial token  (cvit.py:171-211)."""
+
+    def __init__(self, emb_dim, depth, num_heads=8, num_latents=64, mlp_ratio=1, layer_norm_eps=1e-5):
+        super().__init__()
+        self.emb_dim, self.depth, self.num_latents = emb_dim, depth, num_latents
+        self.latents = nn.Parameter(torch.randn(num_latents, emb_dim))
+        self.CrossAttnBlocks = nn.ModuleList([CrossAttnBlock(num_heads, emb_dim, mlp_ratio, layer_norm_eps) for _ in range(depth)])
+
+    def run(self, x_bs_t: torch.Tensor, nbs: int, T: int, compute: int) -> torch.Tensor:
+        """x ((b s) t, d) fp32 -> latents ((b s) t', d)."""
+        lat = self.latents.detach().unsqueeze(0).expand(nbs, -1, -1).reshape(nbs * self.num_latents, self.emb_dim).contiguous()
+        for blk in self.CrossAttnBlocks:
+            lat = blk.run(lat, x_bs_t, nbs, self.num_latents, T, compute)
+        return lat
+
+
+class PatchEmbed(nn.Module):
+    """Conv3d with kernel = stride = (pt, ph, pw) as im2col + GEMM  (cvit.py:58-93)."""
+
+    def __init__(self, n_channel, patch_size=(1, 16, 16), emb_dim=768, use_norm=False, kernel_init=False, layer_norm_eps=1e-5):
+        super().__init__()
+        self.patch_size, self.use_norm = tuple(patch_size), use_norm
+        if self.patch_size[0] != 1:
+            raise NotImplementedError("temporal patches (patch_size[0] > 1) are not on the HIP path; every shipped config uses 1")
+        self.conv = nn.Conv3d(n_channel, emb_dim, kernel_size=self.patch_size, stride=self.patch_size)
+        if use_norm:
+            self.layer_norm = nn.LayerNorm(emb_dim, eps=layer_norm_eps)
+        self._cache = _PackCache()
+
+    def run(self, x: torch.Tensor, compute: int) -> torch.Tensor:
+        """x (b, t, c, h, w) fp32 contiguous -> (b * t * s, emb) fp32, s = (h / ph)(w / pw) row-major."""
+        b, t, c, h, w = x.shape
+        _, ph, pw = self.patch_size
+        chunks = self._cache.get(compute, [self.conv.weight, self.conv.bias],
+                                 lambda: S.pack_linear_chunks(self.conv.weight.detach().reshape(self.conv.weight.shape[0], -1),
+                                                              self.conv.bias, compute))
+        cols = K.im2col(x.view(b * t, c, h, w), True, b * t, c, h, w, ph, pw, ph, pw, 0, 0, 0, K.act_torch_dtype(compute))
+        y = S.linear_chunks(cols, chunks, torch.float32)
+        if self.use_norm:
+            y = K.layernorm_affine(y, self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps)
+        return y
+
+
+class Encoder(nn.Module):
+    """cvit.py:248-306."""
+
+    def __init__(self, n_channel, patch_size=(1, 16, 16), emb_dim=256, depth=3, num_heads=8, mlp_ratio=1, out_dim=1,
+                 layer_norm_eps=1e-5, THW_shape=(4, 128, 384)):
+        super().__init__()
+        self.depth, self.emb_dim = depth, emb_dim
+        self.patch_embed = PatchEmbed(n_channel, patch_size, emb_dim)
+        self.time_agg = TimeAggregation(num_latents=1, emb_dim=emb_dim, depth=2, num_heads=num_heads, mlp_ratio=mlp_ratio,
+                                        layer_norm_eps=layer_norm_eps)
+        self.layer_norm = nn.LayerNorm(emb_dim, eps=layer_norm_eps)
+        t, h, w = THW_shape
+        self.t_emb = nn.Parameter(t_emb_init(emb_dim, t // patch_size[0]))
+        self.s_emb = nn.Parameter(s_emb_init(emb_dim, (h // patch_size[1], w // patch_size[2]), flatten=True))   # (1, S, D)
+        self.SelfAttnBlocks = nn.ModuleList([SelfAttnBlock(num_heads, emb_dim, mlp_ratio, layer_norm_eps) for _ in range(depth)])
+
+    def run(self, x: torch.Tensor, compute: int):
+        """x (b, t, c, h, w) -> tokens (b * t' * s, d) fp32, (t' * s)."""
+        b, t = x.shape[:2]
+        d = self.emb_dim
+        y = self.patch_embed.run(x, compute)                       # rows (b, t, s)
+        s = y.shape[0] // (b * t)
+        # + t_emb[t] + s_emb[s]: the FiLM/positional kernel with scale 1 (a = 1, b = t_emb)
+        ones = torch.ones(t, d, dtype=torch.float32, device=y.device)
+        z = torch.empty_like(y)
+        L.check(L.lib().tante_film_pos_fwd(y.data_ptr(), ones.data_ptr(), self.t_emb.detach().view(t, d).contiguous().data_ptr(),
+                                           self.s_emb.detach().view(s, d).contiguous().data_ptr(), y.shape[0], d, t, s, z.data_ptr(),
+                                           K._stream()), "tante_film_pos_fwd")
+        kv = z.view(b, t, s, d).permute(0, 2, 1, 3).contiguous().view(b * s * t, d)     # 'b t s d -> (b s) t d' (layout change)
+        lat = self.time_agg.run(kv, b * s, t, compute)                                   # ((b s) t', d), t' = 1
+        tl = self.time_agg.num_latents
+        if tl != 1:
+            lat = lat.view(b, s, tl, d).permute(0, 2, 1, 3).contiguous().view(b * tl * s, d)
+        y = K.layernorm_affine(lat, self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps)
+        for blk in self.SelfAttnBlocks:
+            y = blk.run(y, b, tl * s, compute)
+        return y, tl * s
+
+
+class FourierEmbs(nn.Module):
+    """cvit.py:308-331."""
+
+    def __init__(self, embed_scale: float, embed_dim: int, D: int = 2):
+        super().__init__()
+        self.embed_scale, self.embed_dim = embed_scale, embed_dim
+        self.kernel = nn.Parameter(torch.randn(D, embed_dim // 2) * embed_scale)
+
+
+class Mlp(nn.Module):
+    """num_layers x [x = LN(x + gelu(dense(x)))] -> output layer  (cvit.py:213-242)."""
+
+    def __init__(self, in_dim, num_layers, hidden_dim, out_dim, kernel_init=True, layer_norm_eps=1e-5):
+        super().__init__()
+        self.num_layers = num_layers
+        self.dense_layers = nn.ModuleList([nn.Linear(hidden_dim if i > 0 else in_dim, hidden_dim) for i in range(num_layers)])
+        self.output_layer = nn.Linear(hidden_dim, out_dim)
+        self.layer_norms = nn.ModuleList([nn.LayerNorm(hidden_dim, eps=layer_norm_eps) for _ in range(num_layers)])
+        self._cache = _PackCache()
+
+    def run(self, x: torch.Tensor, compute: int) -> torch.Tensor:
+        params = [p for m in list(self.dense_layers) + [self.output_layer] for p in (m.weight, m.bias)]
+        pk = self._cache.get(compute, params, lambda: [K.pack_weight(m.weight, m.bias, compute)
+                                                       for m in list(self.dense_layers) + [self.output_layer]])
+        M = x.shape[0]
+        for i in range(self.num_layers):
+            y = torch.empty(M, pk[i].N, dtype=torch.float32, device=x.device)
+            K.linear(x, pk[i], y, M=M, act=L.ACT_GELU_ERF, residual=x)              # x + gelu(dense(x))
+            ln = self.layer_norms[i]
+            x = K.layernorm_affine(y, ln.weight, ln.bias, ln.eps)
+        out = torch.empty(M, pk[-1].N, dtype=torch.float32, device=x.device)
+        return K.linear(x, pk[-1], out, M=M)
+
+
+def generate_coords(h: int, w: int, device) -> torch.Tensor:
+    """The (h * w, 2) query grid on [0, 1]^2 in 'ij' order  (cvit.py:469-479)."""
+    xs, ys = torch.meshgrid(torch.linspace(0, 1, h, device=device), torch.linspace(0, 1, w, device=device), indexing="ij")
+    return torch.stack([xs.flatten(), ys.flatten()], dim=-1).contiguous()
+
+
+class CViT(nn.Module):
+    def __init__(self, in_T, dset_metadata: TanteMetadata = None, out_steps=4, patch_size: tuple = (1, 16, 16),
+                 grid_size: tuple = (128, 128), latent_dim: int = 256, emb_dim: int = 256, depth: int = 3, num_heads: int = 8,
+                 dec_emb_dim: int = 256, dec_num_heads: int = 8, dec_depth: int = 1, num_mlp_layers: int = 1, mlp_ratio: int = 1,
+                 eps: float = 1e5, layer_norm_eps: float = 1e-5, embedding_type: str = "grid"):
+        super().__init__()
+        n_channel = dset_metadata.n_fields if dset_metadata else 4
+        self.T = in_T
+        self.H, self.W = dset_metadata.spatial_resolution if dset_metadata else (128, 384)
+        self.embedding_type, self.eps, self.dec_depth, self.out_steps = embedding_type, eps, dec_depth, out_steps
+        self.dec_emb_dim, self.ln_eps = dec_emb_dim, layer_norm_eps
+        out_dim = n_channel * out_steps
+        if embedding_type == "grid":
+            n_x, n_y = grid_size
+            self.latents = nn.Parameter(torch.randn(n_x * n_y, latent_dim))
+            xx, yy = np.meshgrid(np.linspace(0, 1, n_x), np.linspace(0, 1, n_y), indexing="ij")
+            grid = torch.tensor(np.hstack([xx.flatten()[:, None], yy.flatten()[:, None]])).to(dtype=self.latents.dtype)
+            self.grid = nn.Parameter(grid)
+            self.embedding = nn.Sequential(nn.Linear(latent_dim, dec_emb_dim), nn.LayerNorm(dec_emb_dim, eps=layer_norm_eps))
+        elif embedding_type == "fourier":
+            self.embedding = nn.Sequential(FourierEmbs(embed_scale=2 * np.pi, embed_dim=dec_emb_dim))
+        elif embedding_type == "mlp":
+            self.embedding = nn.Sequential(MlpBlock(2, dec_emb_dim, dec_emb_dim), nn.LayerNorm(dec_emb_dim, eps=layer_norm_eps))
+        else:
+            raise ValueError(f"embedding_type must be 'grid', 'fourier' or 'mlp', got {embedding_type!r}")
+        self.Encoder = Encoder(n_channel=n_channel, patch_size=patch_size, emb_dim=emb_dim, depth=depth, num_heads=num_heads,
+                               mlp_ratio=mlp_ratio, layer_norm_eps=layer_norm_eps, THW_shape=(self.T, self.H, self.W))
+        self.E2D = nn.Linear(emb_dim, dec_emb_dim)
+        self.CrossAttnBlocks = nn.ModuleList([CrossAttnBlock(dec_num_heads, dec_emb_dim, mlp_ratio, layer_norm_eps) for _ in range(dec_depth)])
+        self.mlp = Mlp(in_dim=dec_emb_dim, num_layers=num_mlp_layers, hidden_dim=dec_emb_dim, out_dim=out_dim, layer_norm_eps=layer_norm_eps)
+        self.norm1 = nn.LayerNorm(emb_dim, eps=layer_norm_eps)
+        self.norm2 = nn.LayerNorm(dec_emb_dim, eps=layer_norm_eps)
+        self.compute: Optional[str] = None
+        self._cache = _PackCache()
+        self._coord_cache = _PackCache()
+
+    def set_compute(self, mode: Optional[str]):
+        if mode is not None and mode not in K.COMPUTE:
+            raise ValueError("compute must be None, 'fp32' or 'bf16'")
+        self.compute = mode
+        return self
+
+    # ---- coordinate embedding (cvit.py:434-446): input independent, so the default full-grid queries are cached per weight version
+    def _embed_coords(self, coords: torch.Tensor, compute: int) -> torch.Tensor:
+        n = coords.shape[0]
+        if self.embedding_type == "grid":
+            lin, ln = self.embedding[0], self.embedding[1]
+            c = K.grid_embed(coords, self.grid.detach().contiguous(), self.latents.detach().contiguous(), float(self.eps))
+            chunks = self._cache.get((compute, "emb"), [lin.weight, lin.bias], lambda: S.pack_linear_chunks(lin.weight.detach(), lin.bias, compute))
+            c = S.linear_chunks(c, chunks, torch.float32)
+            return K.layernorm_affine(c, ln.weight, ln.bias, ln.eps)
+        if self.embedding_type == "fourier":
+            return K.fourier_embed(coords, self.embedding[0].kernel.detach().contiguous())
+        blk, ln = self.embedding[0], self.embedding[1]
+        pk = self._cache.get((compute, "emb"), [blk.fc1.weight, blk.fc1.bias, blk.fc2.weight, blk.fc2.bias],
+                             lambda: (K.pack_weight(blk.fc1.weight, blk.fc1.bias, compute), S.pack_linear_chunks(blk.fc2.weight.detach(), blk.fc2.bias, compute)))
+        h = torch.empty(n, pk[0].N, dtype=K.act_torch_dtype(compute), device=coords.device)
+        K.linear(coords, pk[0], h, M=n, act=L.ACT_GELU_ERF)
+        c = S.linear_chunks(h, pk[1], torch.float32)
+        return K.layernorm_affine(c, ln.weight, ln.bias, ln.eps)
+
+    def forward(self, x: torch.Tensor, input_coords: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """x (b, t, c, h, w) -> (b, out_steps, c, h, w); with input_coords (n, 2): (b, out_steps, n, c)   (cvit.py:427-466)."""
+        if not x.is_cuda:
+            raise RuntimeError("tante_amd.CViT runs on the GPU only (no CPU fallback); move the input to cuda")
+        _no_autograd(self)
+        compute = resolve_compute(self.compute)
+        x = x.detach().to(torch.float32).contiguous()
+        b, t, c, h, w = x.shape
+        if input_coords is None:
+            params = [p for p in self.parameters()]
+            q1 = self._coord_cache.get((compute, h, w), params, lambda: self._embed_coords(generate_coords(h, w, x.device), compute))
+        else:
+            q1 = self._embed_coords(input_coords.detach().to(x.device, torch.float32).contiguous(), compute)
+        n = q1.shape[0]
+        d = self.dec_emb_dim
+        q = q1.unsqueeze(0).expand(b, n, d).reshape(b * n, d).contiguous()                     # 'n d -> b n d'
+        y, s = self.Encoder.run(x, compute)                                                    # (b * s, emb)
+        e2d = self._cache.get((compute, "e2d"), [self.norm1.weight, self.norm1.bias, self.E2D.weight, self.E2D.bias],
+                              lambda: K.pack_weight(self.E2D.weight, self.E2D.bias, compute, gamma=self.norm1.weight, beta=self.norm1.bias))
+        kv = torch.empty(b * s, d, dtype=torch.float32, device=x.device)
+        K.linear(y, e2d, kv, M=b * s, ln=True, ln_eps=self.norm1.eps)                          # E2D(norm1(x))
+        Lk = s
+        for blk in self.CrossAttnBlocks:                 # queries stay the coordinate embedding; the output becomes the next keys/values
+            kv = blk.run(q, kv, b, n, Lk, compute)
+            Lk = n
+        z = K.layernorm_affine(kv, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        o = self.mlp.run(z, compute).view(b, n, self.out_steps, c)
+        if input_coords is None:
+            return o.view(b, h, w, self.out_steps, c).permute(0, 3, 4, 1, 2)                   # 'b (h w) (t d) -> b t d h w'
+        return o.permute(0, 2, 1, 3)                                                           # 'b n (t d) -> b t n d'

@@ -847,3 +847,41 @@ def test_g12_tante_fno(dev, mode):
     m.set_compute(mode)
     with torch.no_grad():
         close(m(g["x"].to(dev)), g["y"], mode)
+
+
+# ---- CViT (fixtures g11) --------------------------------------------------------------------------------------
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+@pytest.mark.parametrize("name", ["grid", "gridwide", "fourier", "mlp"])
+def test_g11_cvit(dev, name, mode):
+    import tante_amd
+    from test_oracle_golden import CVIT_CASES
+    g = load_golden("g11_cvit_" + name)
+    kw, nf, res = CVIT_CASES[name]
+    base = dict(out_steps=3, patch_size=(1, 8, 8), grid_size=(8, 8), latent_dim=24, emb_dim=32, depth=2, num_heads=4, dec_emb_dim=48,
+                dec_num_heads=4, dec_depth=1, num_mlp_layers=1, mlp_ratio=1)
+    base.update(kw)
+    m = tante_amd.CViT(4, tante_amd.TanteMetadata(n_fields=nf, spatial_resolution=res), **base).to(dev).eval()
+    m.load_state_dict(split_prefix(g, "w."), strict=True)
+    m.set_compute(mode)
+    coords = g.get("coords")
+    with torch.no_grad():
+        y = m(g["x"].to(dev)) if coords is None else m(g["x"].to(dev), coords.to(dev))
+    close(y, g["y"], mode)
+
+
+def test_cvit_grid_embed_sparse_equals_dense(dev):
+    """The ordered-compaction grid embedding against the dense definition (oracle) at the shipped sharpness eps = 1e5 on a
+    64 x 64 latent grid with off-node queries, and with a wide kernel that overflows the compaction list."""
+    from tante_amd import kernels as K
+    torch.manual_seed(3)
+    n_x = n_y = 64
+    xs, ys = torch.meshgrid(torch.linspace(0, 1, n_x), torch.linspace(0, 1, n_y), indexing="ij")
+    grid = torch.stack([xs.flatten(), ys.flatten()], -1)
+    lat = torch.randn(n_x * n_y, 40)
+    coords = torch.rand(500, 2)
+    for eps in (1e5, 3.0):
+        d2 = ((coords[:, None, :] - grid[None]) ** 2).sum(2)
+        e = torch.exp(-eps * d2)
+        ref = (e / e.sum(1, keepdim=True)) @ lat
+        out = K.grid_embed(coords.to(dev), grid.to(dev), lat.to(dev), eps)
+        close(out, ref, "fp32", scale=3.0)
