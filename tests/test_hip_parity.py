@@ -885,3 +885,35 @@ def test_cvit_grid_embed_sparse_equals_dense(dev):
         ref = (e / e.sum(1, keepdim=True)) @ lat
         out = K.grid_embed(coords.to(dev), grid.to(dev), lat.to(dev), eps)
         close(out, ref, "fp32", scale=3.0)
+
+
+def test_cvit_cfg4_full_size_properties(dev):
+    """cfg4 at its full size (configs/cvit_rb.yaml: 512 x 128 queries, 128 x 128 latent grid, width 512, depth 10): too large for
+    the oracle in seconds, so check size-independent properties: (a) query-point mode at a subset of the grid nodes reproduces the
+    full-grid prediction at those pixels; (b) a smaller slice of the same model agrees with the oracle end to end."""
+    import tante_amd
+    from oracle import cvit_oracle as OC
+    cfg = tante_amd.load_config(os.path.join(os.path.dirname(GOLDEN), "..", "configs", "cvit_rb.yaml"))
+    wl = cfg["workload"]
+    H, W = wl["spatial_resolution"]
+    md = tante_amd.TanteMetadata(n_fields=wl["n_fields"], spatial_resolution=(H, W))
+    torch.manual_seed(211)
+    m = tante_amd.build_model(cfg, md).to(dev).eval().set_compute("bf16")
+    x = torch.randn(1, 4, wl["n_fields"], H, W, device=dev)
+    with torch.no_grad():
+        y = m(x)                                                     # (1, 4, 4, 512, 128)
+        assert y.shape == (1, 4, wl["n_fields"], H, W) and torch.isfinite(y).all()
+        idx = torch.randint(0, H * W, (777,), device=dev)
+        coords = tante_amd.cvit.generate_coords(H, W, dev)[idx]
+        yq = m(x, coords)                                            # (1, 4, 777, 4)
+    full = y.permute(0, 1, 3, 4, 2).reshape(1, 4, H * W, -1)[:, :, idx]
+    close(yq, full, "bf16")
+    # (b) fp32 against the oracle on a model of the same width at 64 x 32 with an 16 x 16 latent grid
+    torch.manual_seed(5)
+    kw = dict(out_steps=2, patch_size=(1, 16, 16), grid_size=(16, 16), latent_dim=64, emb_dim=128, depth=2, num_heads=8, dec_emb_dim=128,
+              dec_num_heads=8, dec_depth=1, num_mlp_layers=1, mlp_ratio=1, eps=300.0)   # (the default 1e5 underflows off the nodes)
+    ms = tante_amd.CViT(4, tante_amd.TanteMetadata(n_fields=4, spatial_resolution=(64, 32)), **kw).to(dev).eval().set_compute("fp32")
+    xs = torch.randn(2, 4, 4, 64, 32)
+    w = {k: v.detach().cpu() for k, v in ms.state_dict().items()}
+    with torch.no_grad():
+        close(ms(xs.to(dev)), OC.cvit_forward(w, OC.CvitCfg(4, 4, (64, 32), **kw), xs), "fp32", scale=2.0)
