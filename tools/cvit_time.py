@@ -1,7 +1,8 @@
 import os, sys, time, torch
-sys.path.insert(0, os.getcwd())
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 import tante_amd
-cfg = tante_amd.load_config("configs/cvit_rb.yaml"); wl = cfg["workload"]
+cfg = tante_amd.load_config(os.path.join(ROOT, "configs", "cvit_rb.yaml")); wl = cfg["workload"]
 H, W = wl["spatial_resolution"]
 md = tante_amd.TanteMetadata(n_fields=wl["n_fields"], spatial_resolution=(H, W))
 torch.manual_seed(211)
