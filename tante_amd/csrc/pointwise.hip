@@ -104,9 +104,23 @@ struct AxisW {  // A-operand fragments of one n x n weight (n <= 16 * MT), zero 
   u32x4 f[MT][KB];
 };
 
-// build the fragments from the weight staged in LDS (ws: n x n floats, row-major)
+// the staged n x n weight: bf16 in the bf16 path (it is rounded to bf16 for the MFMA anyway; halves the staging LDS), fp32 otherwise
+template <bool BF16> struct AxisStage { using T = float; };
+template <> struct AxisStage<true> { using T = unsigned short; };
+template <bool BF16>
+__device__ __forceinline__ float axis_wld(const typename AxisStage<BF16>::T* ws, int i) {
+  if constexpr (BF16) return __uint_as_float(((unsigned)ws[i]) << 16);
+  else return ws[i];
+}
+template <bool BF16>
+__device__ __forceinline__ void axis_wst(typename AxisStage<BF16>::T* ws, int i, float v) {
+  if constexpr (BF16) { __bf16 b = (__bf16)v; ws[i] = __builtin_bit_cast(unsigned short, b); }
+  else ws[i] = v;
+}
+
+// build the fragments from the weight staged in LDS (ws: n x n, row-major)
 template <bool BF16, int MT, bool KPERM>
-__device__ __forceinline__ void load_axis_weight(const float* ws, int n, int l15, int kk, AxisW<BF16, MT>& aw) {
+__device__ __forceinline__ void load_axis_weight(const typename AxisStage<BF16>::T* ws, int n, int l15, int kk, AxisW<BF16, MT>& aw) {
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int row = mt * 16 + l15;
@@ -118,7 +132,7 @@ __device__ __forceinline__ void load_axis_weight(const float* ws, int n, int l15
         int k;
         if constexpr (BF16) k = KPERM ? (kb * 32 + (e < 4 ? 4 * kk + e : 16 + 4 * kk + (e - 4))) : (kb * 32 + 8 * kk + e);
         else k = KPERM ? (kb * 16 + 4 * kk + e) : (kb * 16 + 4 * e + kk);
-        v[e] = (row < n && k < n) ? ws[row * n + k] : 0.0f;
+        v[e] = (row < n && k < n) ? axis_wld<BF16>(ws, row * n + k) : 0.0f;
       }
       if constexpr (BF16) {
         aw.f[mt][kb][0] = pack_bf16x2(v[0], v[1]); aw.f[mt][kb][1] = pack_bf16x2(v[2], v[3]);
@@ -196,14 +210,25 @@ __device__ __forceinline__ void axis_mlp_mfma(const AxisW<BF16, MT>& w1, const A
 }
 
 // one phase: lines of length n along an axis with element stride `ls` floats; line group g starts at g * gs
+constexpr int AXT = 512;      // threads per workgroup of the fused H+W kernel (8 waves share the line groups of a phase)
+constexpr int AXWS = 18;      // LDS floats per token (16 channels + 2): the w-strided reads of phase W hit 64 distinct banks
+__host__ __device__ inline int axis_row_stride(int nW) {   // LDS floats per h row: = 2 (mod 8) spreads the h-strided reads of phase H
+  int rs = nW * AXWS;
+  while (rs % 8 != 2) ++rs;
+  return rs;
+}
+
 template <bool BF16, int MT>
-__device__ __forceinline__ void axis_phase(float* plane, float* wst, const float* __restrict__ gw1, const float* __restrict__ gb1,
+__device__ __forceinline__ void axis_phase(float* plane, float* wst_raw, const float* __restrict__ gw1, const float* __restrict__ gb1,
                                            const float* __restrict__ gw2, const float* __restrict__ gb2, int n, int ngroups, int ls,
                                            int gs, int tid) {
+  using ST = typename AxisStage<BF16>::T;
   const int lane = tid & 63, wave = tid >> 6, kk = lane >> 4, l15 = lane & 15;
-  // stage this axis' weights in LDS: w1 | w2 | b1 | b2
-  for (int i = tid; i < n * n; i += 256) { wst[i] = gw1[i]; wst[n * n + i] = gw2[i]; }
-  if (tid < n) { wst[2 * n * n + tid] = gb1[tid]; wst[2 * n * n + n + tid] = gb2[tid]; }
+  // stage this axis' weights in LDS: [b1 | b2] fp32, then w1 | w2 in the staging type
+  float* bst = wst_raw;
+  ST* wst = (ST*)(wst_raw + 2 * n);
+  for (int i = tid; i < n * n; i += AXT) { axis_wst<BF16>(wst, i, gw1[i]); axis_wst<BF16>(wst, n * n + i, gw2[i]); }
+  if (tid < n) { bst[tid] = gb1[tid]; bst[n + tid] = gb2[tid]; }
   __syncthreads();
   AxisW<BF16, MT> w1, w2;
   load_axis_weight<BF16, MT, false>(wst, n, l15, kk, w1);
@@ -214,11 +239,11 @@ __device__ __forceinline__ void axis_phase(float* plane, float* wst, const float
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int r = mt * 16 + kk * 4 + j;
-      b1[mt][j] = r < n ? wst[2 * n * n + r] : 0.0f;
-      b2[mt][j] = r < n ? wst[2 * n * n + n + r] : 0.0f;
+      b1[mt][j] = r < n ? bst[r] : 0.0f;
+      b2[mt][j] = r < n ? bst[n + r] : 0.0f;
     }
   constexpr int NX = 16 * ((MT + 1) / 2);
-  for (int g = wave; g < ngroups; g += 4) {
+  for (int g = wave; g < ngroups; g += AXT / 64) {
     float* base = plane + g * gs + l15;
     float xin[NX];
 #pragma unroll
@@ -240,37 +265,39 @@ __device__ __forceinline__ void axis_phase(float* plane, float* wst, const float
 }
 
 template <bool BF16, int MT>
-__global__ __launch_bounds__(256, 2) void axis_hw_kernel(float* __restrict__ x, int nH, int nW, int C, const float* __restrict__ wh1,
-                                                         const float* __restrict__ bh1, const float* __restrict__ wh2,
-                                                         const float* __restrict__ bh2, const float* __restrict__ ww1,
-                                                         const float* __restrict__ bw1, const float* __restrict__ ww2,
-                                                         const float* __restrict__ bw2, int dbg) {
-  extern __shared__ __attribute__((aligned(16))) float plane[];  // [nH][nW*16 + 2] then the weight staging area
+__global__ __launch_bounds__(AXT) void axis_hw_kernel(float* __restrict__ x, int nH, int nW, int C, const float* __restrict__ wh1,
+                                                      const float* __restrict__ bh1, const float* __restrict__ wh2,
+                                                      const float* __restrict__ bh2, const float* __restrict__ ww1,
+                                                      const float* __restrict__ bw1, const float* __restrict__ ww2,
+                                                      const float* __restrict__ bw2, int dbg) {
+  extern __shared__ __attribute__((aligned(16))) float plane[];  // [nH][rs], token (h, w) at h * rs + w * AXWS; then the weight staging
   const int tid = threadIdx.x;
   const int ctiles = C / 16;
   const long bt = blockIdx.x / ctiles;
   const int c0 = (blockIdx.x % ctiles) * 16;
   float* gx = x + bt * (long)nH * nW * C + c0;
-  const int rs = nW * 16 + 2;  // LDS row (h) stride in floats: +2 spreads the h-strided reads over the banks
+  const int rs = axis_row_stride(nW);
   float* wst = plane + nH * rs;
   // ---- load the plane: 4 threads x 16 B per token ---------------------------------------------------------
   if (!(dbg & 1))
-  for (int i = tid; i < nH * nW * 4; i += 256) {
+  for (int i = tid; i < nH * nW * 4; i += AXT) {
     const int tokn = i >> 2, q = i & 3, h = tokn / nW, w = tokn - h * nW;
     const f32x4 v = *(const f32x4*)(gx + (long)tokn * C + q * 4);
-    float* d = plane + h * rs + w * 16 + q * 4;
-    d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+    float2* d = (float2*)(plane + h * rs + w * AXWS + q * 4);   // 8-byte aligned: rs, AXWS even
+    d[0] = make_float2(v[0], v[1]);
+    d[1] = make_float2(v[2], v[3]);
   }
-  // phase H: lines along h (stride rs), one group per w;  phase W: lines along w (stride 16), one group per h
-  if (!(dbg & 2)) axis_phase<BF16, MT>(plane, wst, wh1, bh1, wh2, bh2, nH, nW, rs, 16, tid);
-  if (!(dbg & 4)) axis_phase<BF16, MT>(plane, wst, ww1, bw1, ww2, bw2, nW, nH, 16, rs, tid);
-  if (dbg & 6) __syncthreads();
+  __syncthreads();
+  // phase H: lines along h (stride rs), one group per w;  phase W: lines along w (stride AXWS), one group per h
+  if (!(dbg & 2)) axis_phase<BF16, MT>(plane, wst, wh1, bh1, wh2, bh2, nH, nW, rs, AXWS, tid);
+  if (!(dbg & 4)) axis_phase<BF16, MT>(plane, wst, ww1, bw1, ww2, bw2, nW, nH, AXWS, rs, tid);
   // ---- store the plane -----------------------------------------------------------------------------------------
   if (!(dbg & 1))
-  for (int i = tid; i < nH * nW * 4; i += 256) {
+  for (int i = tid; i < nH * nW * 4; i += AXT) {
     const int tokn = i >> 2, q = i & 3, h = tokn / nW, w = tokn - h * nW;
-    const float* sp = plane + h * rs + w * 16 + q * 4;
-    *(f32x4*)(gx + (long)tokn * C + q * 4) = f32x4{sp[0], sp[1], sp[2], sp[3]};
+    const float2* sp = (const float2*)(plane + h * rs + w * AXWS + q * 4);
+    const float2 a = sp[0], b = sp[1];
+    *(f32x4*)(gx + (long)tokn * C + q * 4) = f32x4{a.x, a.y, b.x, b.y};
   }
 }
 
@@ -394,7 +421,7 @@ static void launch_axis_hw(float* x, long BT, int nH, int nW, int C, const float
     hipFuncSetAttribute((const void*)axis_hw_kernel<BF16, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr = lds;
   }
-  hipLaunchKernelGGL((axis_hw_kernel<BF16, MT>), dim3((unsigned)(BT * (C / 16))), dim3(256), lds, s, x, nH, nW, C, wh1, bh1, wh2, bh2,
+  hipLaunchKernelGGL((axis_hw_kernel<BF16, MT>), dim3((unsigned)(BT * (C / 16))), dim3(AXT), lds, s, x, nH, nW, C, wh1, bh1, wh2, bh2,
                      ww1, bw1, ww2, bw2, getenv("TANTE_AXIS_DEBUG") ? atoi(getenv("TANTE_AXIS_DEBUG")) : 0);
 }
 
@@ -404,7 +431,8 @@ extern "C" int tante_axis_hw(float* x, int64_t BT, int nH, int nW, int C, const 
   if (!x || !wh1 || !bh1 || !wh2 || !bh2 || !ww1 || !bw1 || !ww2 || !bw2) TANTE_FAIL(-1, "tante_axis_hw: null pointer");
   if (BT <= 0 || nH <= 0 || nW <= 0 || C <= 0) TANTE_FAIL(-1, "tante_axis_hw: bad shape");
   const int nmax = nH > nW ? nH : nW;
-  const size_t lds = ((size_t)nH * (nW * 16 + 2) + 2 * (size_t)nmax * nmax + 2 * nmax) * sizeof(float);
+  const size_t lds = (size_t)nH * axis_row_stride(nW) * sizeof(float) + 2 * (size_t)nmax * sizeof(float) +
+                     2 * (size_t)nmax * nmax * (compute == TANTE_BF16 ? 2 : 4);
   if (nmax > 64 || C % 16 || lds > 160 * 1024 || ((uintptr_t)x % 16))
     TANTE_FAIL(-2, "tante_axis_hw: needs nH, nW <= 64, C %% 16 == 0 and the plane to fit LDS (use tante_axis_mlp)");
   hipStream_t s = (hipStream_t)stream;

@@ -202,7 +202,10 @@ def axis_mlp(x: torch.Tensor, outer: int, n: int, inner: int, w1, b1, w2, b2):
 
 def axis_hw_supported(nH: int, nW: int, C_: int) -> bool:
     n = max(nH, nW)
-    return n <= 64 and C_ % 16 == 0 and (nH * (nW * 16 + 2) + 2 * n * n + 2 * n) * 4 <= 160 * 1024
+    rs = nW * 18
+    while rs % 8 != 2:       # axis_row_stride() of pointwise.hip
+        rs += 1
+    return n <= 64 and C_ % 16 == 0 and nH * rs * 4 + 8 * n + 8 * n * n <= 160 * 1024
 
 
 def axis_hw(x: torch.Tensor, BT: int, nH: int, nW: int, C_: int, vp, hp, compute: int):
