@@ -75,9 +75,17 @@ __device__ __forceinline__ void wait_vmcnt() {  // all but the N youngest vector
 // in order, and an extra compiler-issued LDS read in between only makes the count conservative.  The stream starts from
 // lgkmcnt(0) so that no scalar load (out-of-order in the same counter) is pending while counts are relied on.
 // addr(ic) -> LDS pointer of fragment ic, use(ic, frag) issues the MFMA; ic is an integral_constant.
-__device__ __forceinline__ u32x4 lds_read128(const char* p) {
+template <int OFF>
+struct LdsAddr {   // LDS byte address = base (a VGPR) + OFF (an instruction immediate, < 64 KiB): no VALU add per read
+  unsigned base;
+  static constexpr int off = OFF;
+};
+__device__ __forceinline__ unsigned lds_addr(const char* p) { return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)p; }
+template <int OFF>
+__device__ __forceinline__ u32x4 lds_read128(LdsAddr<OFF> a) {
+  static_assert(OFF >= 0 && OFF < 65536, "ds_read offset is a 16-bit immediate");
   u32x4 r;
-  asm volatile("ds_read_b128 %0, %1" : "=v"(r) : "v"((unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)p) : "memory");
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(a.base), "n"(OFF) : "memory");
   return r;
 }
 template <int N>
@@ -492,41 +500,52 @@ __global__ __launch_bounds__(512, 2) void fused_block16_kernel(float* __restrict
   u32x4 qf_p, kf_p, vpk_p;  // head h-1: this wave's q / k fragments and packed V^T halves ({dt0.xy, dt1.xy})
   qf_p = kf_p = vpk_p = u32x4{0u, 0u, 0u, 0u};
 
-  // attention of head h for this wave's 16 queries; keys/values: own 16 tokens (+ the partner's 16 when paired)
-  auto attend = [&](int h) {
-    u32x4 kf_o = kf_p, vpk_o = vpk_p, kf_q = u32x4{0u, 0u, 0u, 0u}, vpk_q = u32x4{0u, 0u, 0u, 0u};
+  // attention of head h for this wave's 16 queries; keys/values: own 16 tokens (+ the partner's 16 when paired).  It is cut into
+  // three stages so that the caller can drop them between the MFMAs of the NEXT weight tile: the softmax is VALU work (exp,
+  // cross-lane max / sum) that otherwise alternates with, instead of hiding under, the matrix pipe.
+  f32x4 at_so, at_sp;
+  u32x4 at_vo, at_vq, at_pf;
+  auto attend_qk = [&](int h) {
+    u32x4 kf_q = u32x4{0u, 0u, 0u, 0u};
+    at_vo = vpk_p;
+    at_vq = u32x4{0u, 0u, 0u, 0u};
     if (paired) {
       const char* pb = mbox + (h & 1) * 16384 + (wave ^ 1) * 2048 + lane * 16;
       kf_q = *(const u32x4*)pb;
-      vpk_q = *(const u32x4*)(pb + 1024);
+      at_vq = *(const u32x4*)(pb + 1024);
     }
-    f32x4 so = mfma_bf16(kf_o, qf_p, f32x4{0.f, 0.f, 0.f, 0.f});  // rows = own keys, column = query
-    f32x4 sp = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (paired) sp = mfma_bf16(kf_q, qf_p, sp);
+    at_so = mfma_bf16(kf_p, qf_p, f32x4{0.f, 0.f, 0.f, 0.f});  // rows = own keys, column = query
+    at_sp = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (paired) at_sp = mfma_bf16(kf_q, qf_p, at_sp);
+  };
+  auto attend_softmax = [&]() {
     float m = -INFINITY;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      if ((allow_own >> r) & 1u) m = fmaxf(m, so[r]);
-      if ((allow_par >> r) & 1u) m = fmaxf(m, sp[r]);
+      if ((allow_own >> r) & 1u) m = fmaxf(m, at_so[r]);
+      if ((allow_par >> r) & 1u) m = fmaxf(m, at_sp[r]);
     }
     m = fmaxf(m, __shfl_xor(m, 16));
     m = fmaxf(m, __shfl_xor(m, 32));
     float sum = 0.0f;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      so[r] = ((allow_own >> r) & 1u) ? __expf(so[r] - m) : 0.0f;
-      sp[r] = ((allow_par >> r) & 1u) ? __expf(sp[r] - m) : 0.0f;
-      sum += so[r] + sp[r];
+      at_so[r] = ((allow_own >> r) & 1u) ? __expf(at_so[r] - m) : 0.0f;
+      at_sp[r] = ((allow_par >> r) & 1u) ? __expf(at_sp[r] - m) : 0.0f;
+      sum += at_so[r] + at_sp[r];
     }
     sum += __shfl_xor(sum, 16);
     sum += __shfl_xor(sum, 32);
     const float inv = sum > 0.0f ? __builtin_amdgcn_rcpf(sum) : 0.0f;
-    const u32x4 pf = pack8(so * inv, sp * inv);  // k order: own keys then partner keys -- the same order as vt below
-    const u32x4 vt0 = u32x4{vpk_o[0], vpk_o[1], vpk_q[0], vpk_q[1]}, vt1 = u32x4{vpk_o[2], vpk_o[3], vpk_q[2], vpk_q[3]};
-    const f32x4 o0 = mfma_bf16(vt0, pf, f32x4{0.f, 0.f, 0.f, 0.f});  // O^T = V^T P^T
-    const f32x4 o1 = mfma_bf16(vt1, pf, f32x4{0.f, 0.f, 0.f, 0.f});
+    at_pf = pack8(at_so * inv, at_sp * inv);  // k order: own keys then partner keys -- the same order as vt below
+  };
+  auto attend_pv = [&]() {
+    const u32x4 vt0 = u32x4{at_vo[0], at_vo[1], at_vq[0], at_vq[1]}, vt1 = u32x4{at_vo[2], at_vo[3], at_vq[2], at_vq[3]};
+    const f32x4 o0 = mfma_bf16(vt0, at_pf, f32x4{0.f, 0.f, 0.f, 0.f});  // O^T = V^T P^T
+    const f32x4 o1 = mfma_bf16(vt1, at_pf, f32x4{0.f, 0.f, 0.f, 0.f});
     return pack8(o0, o1);
   };
+  f32x4 pend[4];   // fc1 accumulators whose GELU + pack is deferred into the next tile's MFMA stream
 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -548,12 +567,21 @@ __global__ __launch_bounds__(512, 2) void fused_block16_kernel(float* __restrict
         av[dt] = f32x4{bv, bv, bv, bv};
       }
       // 6 row tiles (q: 0-1, k: 2-3, v: 4-5) x CB k-blocks, k-block outer so consecutive MFMAs hit different accumulators
+      unsigned bt[CB];   // per-k-block LDS base of this tile: row + swizzled chunk; the row-tile offset is an immediate
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) bt[cb] = lds_addr(wt + row_c + xo_c[cb]);
       mfma_stream<6 * CB, RING>(
-          [&](auto ic) { constexpr int i = decltype(ic)::value; return wt + (i % 6) * 16 * CPR * 16 + row_c + xo_c[i / 6]; },
+          [&](auto ic) { constexpr int i = decltype(ic)::value; return LdsAddr<(i % 6) * 16 * CPR * 16>{bt[i / 6]}; },
           [&](auto ic, const u32x4& wf) {
             constexpr int i = decltype(ic)::value, rt = i % 6, cb = i / 6;
             if constexpr (rt < 4) aqk[rt] = mfma_bf16(wf, xn[cb], aqk[rt]);
             else av[rt - 4] = mfma_bf16(xn[cb], wf, av[rt - 4]);  // roles swapped: D[token][feature]
+            if constexpr (t > 0) {   // head t-1's attention rides this tile's MFMA stream
+              constexpr int N6 = 6 * CB;
+              if constexpr (i == N6 / 8) attend_qk(t - 1);
+              if constexpr (i == (3 * N6) / 8) attend_softmax();
+              if constexpr (i == (6 * N6) / 8) of[t - 1] = attend_pv();
+            }
           });
       const u32x4 qf_n = pack8(aqk[0], aqk[1]), kf_n = pack8(aqk[2], aqk[3]);
       u32x4 vpk_n;
@@ -564,16 +592,23 @@ __global__ __launch_bounds__(512, 2) void fused_block16_kernel(float* __restrict
         *(u32x4*)mb = kf_n;
         *(u32x4*)(mb + 1024) = vpk_n;
       }
-      if constexpr (t > 0) of[t - 1] = attend(t - 1);
       qf_p = qf_n; kf_p = kf_n; vpk_p = vpk_n;
     } else {
-      if constexpr (t == NH) of[NH - 1] = attend(NH - 1);
       // =============================== 64 output features of a dense layer ==============================
       constexpr bool is_out = t < NH + TO, is_fc1 = !is_out && t < NH + TO + T1;
       constexpr int KB = is_fc1 ? CB : (is_out ? CB : HB);
       constexpr int cpr = KB * 4;
       const float* bias = (const float*)(wt + 64 * cpr * 16);
       constexpr int tb = is_fc1 ? t - NH - TO : (is_out ? t - NH : t - NH - TO - T1);
+      // deferral needs room: the stream must be long enough, and an fc2 tile first reads of[2 (T1-1)] at MFMA 8 (T1-1)
+      constexpr bool DEFER = (CB >= 8 && T1 >= 3);
+      constexpr bool pend_gelu = DEFER && ((is_fc1 && tb > 0) || (!is_out && !is_fc1 && tb == 0));   // the previous tile was an fc1 tile
+      constexpr int pend_tb = is_fc1 ? tb - 1 : T1 - 1;
+      if constexpr (t == NH && CB < 8) {   // short stream: the last head's attention runs up front
+        attend_qk(NH - 1);
+        attend_softmax();
+        of[NH - 1] = attend_pv();
+      }
       f32x4 acc[4];
 #pragma unroll
       for (int ns = 0; ns < 4; ++ns) {
@@ -581,22 +616,35 @@ __global__ __launch_bounds__(512, 2) void fused_block16_kernel(float* __restrict
         if constexpr (is_fc1) acc[ns] = b;
         else acc[ns] = res[4 * tb + ns] + b;  // the residual rides the accumulator
       }
+      unsigned bt[KB];
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) bt[kb] = lds_addr(wt + ((KB == CB) ? row_c + xo_c[kb < CB ? kb : 0] : row_h + xo_h[kb < HB ? kb : 0]));
       mfma_stream<4 * KB, RING>(
-          [&](auto ic) {
-            constexpr int i = decltype(ic)::value, ns = i % 4, kb = i / 4;
-            return wt + ns * 16 * cpr * 16 + ((KB == CB) ? row_c + xo_c[kb < CB ? kb : 0] : row_h + xo_h[kb < HB ? kb : 0]);
-          },
+          [&](auto ic) { constexpr int i = decltype(ic)::value; return LdsAddr<(i % 4) * 16 * cpr * 16>{bt[i / 4]}; },
           [&](auto ic, const u32x4& wf) {
             constexpr int i = decltype(ic)::value, ns = i % 4, kb = i / 4;
             if constexpr (is_fc1) acc[ns] = mfma_bf16(wf, xn[kb < CB ? kb : 0], acc[ns]);
             else acc[ns] = mfma_bf16(wf, of[kb], acc[ns]);
+            if constexpr (t == NH && CB >= 8) {   // the last head's attention rides the first out-proj tile (of[NH-1] is consumed from i = 4 (NH-1))
+              if constexpr (i == 1) attend_qk(NH - 1);
+              if constexpr (i == 6) attend_softmax();
+              if constexpr (i == 12) of[NH - 1] = attend_pv();
+            }
+            if constexpr (pend_gelu) {  // GELU + pack of the previous fc1 tile under this tile's MFMAs; an fc2 tile reads of[2 pend_tb]
+              if constexpr (i == 2 || i == 5 || i == 8 || i == 11) pend[(i - 2) / 3] = gelu_poly4<true>(pend[(i - 2) / 3]);  // from i = 8 pend_tb
+              if constexpr (i == 13) { of[2 * pend_tb] = pack8(pend[0], pend[1]); of[2 * pend_tb + 1] = pack8(pend[2], pend[3]); }
+            }
           });
       if constexpr (is_fc1) {
+        if constexpr (DEFER) {
 #pragma unroll
-        for (int ns = 0; ns < 4; ++ns)
-          acc[ns] = gelu_poly4<true>(acc[ns]);
-        of[2 * tb] = pack8(acc[0], acc[1]);
-        of[2 * tb + 1] = pack8(acc[2], acc[3]);
+          for (int ns = 0; ns < 4; ++ns) pend[ns] = acc[ns];
+        } else {
+#pragma unroll
+          for (int ns = 0; ns < 4; ++ns) acc[ns] = gelu_poly4<true>(acc[ns]);
+          of[2 * tb] = pack8(acc[0], acc[1]);
+          of[2 * tb + 1] = pack8(acc[2], acc[3]);
+        }
       } else {
 #pragma unroll
         for (int ns = 0; ns < 4; ++ns) res[4 * tb + ns] = acc[ns];
