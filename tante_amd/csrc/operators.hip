@@ -3,6 +3,7 @@
 // All of them are HBM-bound gather / pointwise / small-contraction kernels: coalesced on the innermost axis, fp32 arithmetic.
 #include "common.cuh"
 #include <hipfft/hipfft.h>
+#include <stdlib.h>
 #include <map>
 #include <mutex>
 #include <tuple>
@@ -218,6 +219,159 @@ __global__ __launch_bounds__(256) void cross_attn_kernel(const void* __restrict_
   }
 }
 
+// ---- CViT attention on the matrix cores (bf16, head dim 64, up to 512 keys) ----------------------------------------------------
+// One workgroup = one (batch, head) and XQ_PER_WG queries.  K (rows = keys) and V^T (rows = head dims, keys k-permuted inside every
+// 32-block) are staged ONCE per workgroup in LDS as bf16 in the swizzled 16-byte-chunk image the MFMA A operand reads with
+// ds_read_b128; every wave then walks its queries 32 at a time (two B operands per fragment read, halving the LDS traffic):
+//   S^T tile (16 keys x 16 queries) = K_tile . Q^T            -- "rows = keys", so a lane holds 4 keys of ONE query column
+//   online softmax over 128-key chunks: per-lane max / partial sums, two __shfl_xor for the cross-lane max, exp2 with the
+//   1/sqrt(D) log2(e) factor applied to the fp32 scores
+//   O^T (16 dims x 16 queries) += V^T_tile . P^T              -- the probability tiles, packed to bf16, ARE the B operand
+// (key order inside a 32-block = accumulator order, matched by the V^T staging permutation).  Nothing but q, k, v, o touches HBM.
+__device__ __forceinline__ u32x4 xpack8(const f32x4& a, const f32x4& b) {
+  u32x4 f;
+  f[0] = pack_bf16x2(a[0], a[1]); f[1] = pack_bf16x2(a[2], a[3]); f[2] = pack_bf16x2(b[0], b[1]); f[3] = pack_bf16x2(b[2], b[3]);
+  return f;
+}
+__device__ __forceinline__ f32x4 xmfma(const u32x4& a, const u32x4& b, const f32x4& c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+constexpr int XD = 64;            // head dim
+constexpr int XGPW = 4;           // 32-query iterations per wave
+constexpr int XQ_PER_WG = 4 * XGPW * 32;
+
+__global__ __launch_bounds__(256, 2) void xattn_mfma_kernel(const unsigned short* __restrict__ q, const unsigned short* __restrict__ k,
+                                                            const unsigned short* __restrict__ v, unsigned short* __restrict__ o, int n_head,
+                                                            int Lq, int Lk, int Sp, long ldq, long ldkv, long ldo, float scale_log2e) {
+  extern __shared__ __attribute__((aligned(16))) char xsm[];   // K image [Sp][8 chunks], then V^T image [64][Sp / 8 chunks]
+  char* ks = xsm;
+  char* vt = xsm + (size_t)Sp * XD * 2;
+  const int cprV = Sp / 8;
+  const int bh = blockIdx.x, b = bh / n_head, h = bh - b * n_head;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kk = lane >> 4, l15 = lane & 15;
+  // ---- stage K and V^T (zero rows for padded keys) ----
+  for (int idx = tid; idx < Sp * 8; idx += 256) {
+    const int j = idx >> 3, c = idx & 7;
+    u32x4 kv = u32x4{0u, 0u, 0u, 0u}, vv = u32x4{0u, 0u, 0u, 0u};
+    if (j < Lk) {
+      const long off = ((long)b * Lk + j) * ldkv + (long)h * XD + c * 8;
+      kv = *(const u32x4*)(k + off);
+      vv = *(const u32x4*)(v + off);
+    }
+    *(u32x4*)(ks + ((j * 8 + swz_chunk(j, c, 8)) << 4)) = kv;
+    // key j sits at position 8 kk' + 4 dt + r of its 32-block (j = 32 blk + 16 dt + 4 kk' + r): chunk blk*4 + kk', element 4 dt + r
+    const int blk = j >> 5, jj = j & 31, dt = jj >> 4, kq = (jj >> 2) & 3, r = jj & 3;
+    const int cj = blk * 4 + kq, el = 4 * dt + r;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int d = c * 8 + e;
+      const unsigned short val = (unsigned short)((vv[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
+      *(unsigned short*)(vt + ((d * cprV + swz_chunk(d, cj, cprV)) << 4) + el * 2) = val;
+    }
+  }
+  __syncthreads();
+
+  int ko[2], vo[4];   // swizzled chunk offsets of this lane: K rows l15 (per 32-d block b), V^T rows l15 (per 32-key block, added later)
+#pragma unroll
+  for (int bb = 0; bb < 2; ++bb) ko[bb] = swz_chunk(l15, bb * 4 + kk, 8) << 4;
+
+  for (int it = 0; it < XGPW; ++it) {
+    const int q0 = blockIdx.y * XQ_PER_WG + (wave * XGPW + it) * 32;
+    if (q0 >= Lq) break;
+    u32x4 qf[2][2];
+    bool live[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const int qi = q0 + g * 16 + l15;
+      live[g] = qi < Lq;
+      const long qoff = ((long)b * Lq + (live[g] ? qi : 0)) * ldq + (long)h * XD;
+#pragma unroll
+      for (int bb = 0; bb < 2; ++bb) qf[g][bb] = live[g] ? *(const u32x4*)(q + qoff + bb * 32 + kk * 8) : u32x4{0u, 0u, 0u, 0u};
+    }
+    float m[2] = {-INFINITY, -INFINITY}, lsum[2] = {0.f, 0.f};
+    f32x4 oacc[2][4];
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) oacc[g][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int c0 = 0; c0 < Sp; c0 += 128) {
+      f32x4 s[2][8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const char* kr = ks + (((c0 + t * 16 + l15) * 8) << 4);
+        s[0][t] = s[1][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int bb = 0; bb < 2; ++bb) {
+          const u32x4 kf = *(const u32x4*)(kr + ko[bb]);
+          s[0][t] = xmfma(kf, qf[0][bb], s[0][t]);
+          s[1][t] = xmfma(kf, qf[1][bb], s[1][t]);
+        }
+      }
+      const bool tail = c0 + 128 > Lk;   // uniform: this chunk holds padded keys
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        float cm = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float sv = s[g][t][r] * scale_log2e;
+            if (tail && c0 + t * 16 + kk * 4 + r >= Lk) sv = -INFINITY;
+            s[g][t][r] = sv;
+            cm = fmaxf(cm, sv);
+          }
+        cm = fmaxf(cm, __shfl_xor(cm, 16));
+        cm = fmaxf(cm, __shfl_xor(cm, 32));
+        const float mn = fmaxf(m[g], cm);
+        const float corr = exp2f(m[g] - mn);
+        m[g] = mn;
+        float ps = 0.0f;
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float pv = exp2f(s[g][t][r] - mn);
+            s[g][t][r] = pv;
+            ps += pv;
+          }
+        lsum[g] = lsum[g] * corr + ps;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) oacc[g][dt] *= corr;
+      }
+#pragma unroll
+      for (int blk = 0; blk < 4; ++blk) {
+        const u32x4 p0 = xpack8(s[0][2 * blk], s[0][2 * blk + 1]), p1 = xpack8(s[1][2 * blk], s[1][2 * blk + 1]);
+        const int cj = (c0 >> 5) * 4 + blk * 4 + kk;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          const int d = dt * 16 + l15;
+          const u32x4 vf = *(const u32x4*)(vt + ((d * cprV + swz_chunk(d, cj, cprV)) << 4));
+          oacc[0][dt] = xmfma(vf, p0, oacc[0][dt]);
+          oacc[1][dt] = xmfma(vf, p1, oacc[1][dt]);
+        }
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      float l = lsum[g];
+      l += __shfl_xor(l, 16);
+      l += __shfl_xor(l, 32);
+      const float inv = 1.0f / l;
+      if (live[g]) {
+        const long ooff = ((long)b * Lq + q0 + g * 16 + l15) * ldo + (long)h * XD;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {   // lane holds dims 16 dt + 4 kk + r of its query
+          u32x2 w;
+          w[0] = pack_bf16x2(oacc[g][dt][0] * inv, oacc[g][dt][1] * inv);
+          w[1] = pack_bf16x2(oacc[g][dt][2] * inv, oacc[g][dt][3] * inv);
+          *(u32x2*)(o + ooff + dt * 16 + kk * 4) = w;
+        }
+      }
+    }
+  }
+}
+
 // ---- CViT grid embedding: out[n, :] = sum_g w_ng latents[g, :],  w_ng = exp(-eps |x_n - g|^2) / sum_g' exp(...)  (cvit.py:435-438)
 // One workgroup per query point.  The weights are evaluated for EVERY grid point (the grid is a trainable parameter, no lattice is
 // assumed), 256 at a time; points whose weight is exactly 0 in fp32 (underflow, as in the reference) are dropped by an ordered
@@ -400,9 +554,25 @@ extern "C" int tante_cross_attention(const void* q, const void* k, const void* v
                                      int Lk, int64_t ldq, int64_t ldkv, int64_t ldo, void* stream) {
   if (!q || !k || !v || !o || n_batch <= 0 || n_head <= 0 || Lq <= 0 || Lk <= 0) TANTE_FAIL(-1, "tante_cross_attention: bad argument");
   if ((Lq + 255) / 256 > 65535 || n_batch * n_head > 2147483647L) TANTE_FAIL(-2, "tante_cross_attention: grid too large");
-  const dim3 grid((unsigned)(n_batch * n_head), (unsigned)((Lq + 255) / 256));
   const float scale = 1.0f / sqrtf((float)D);
   hipStream_t s = (hipStream_t)stream;
+  static const bool force_valu = getenv("TANTE_XATTN_VALU") && atoi(getenv("TANTE_XATTN_VALU"));
+  if (dtype == TANTE_BF16 && D == XD && Lk <= 512 && !force_valu && ldq % 8 == 0 && ldkv % 8 == 0 && ldo % 4 == 0 &&
+      ((uintptr_t)q % 16) == 0 && ((uintptr_t)k % 16) == 0 && ((uintptr_t)v % 16) == 0 && ((uintptr_t)o % 8) == 0) {
+    const int Sp = ((Lk + 127) / 128) * 128;
+    const size_t lds = (size_t)Sp * XD * 2 * 2;
+    static size_t attr = 0;
+    if (lds > attr) {
+      hipFuncSetAttribute((const void*)xattn_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr = lds;
+    }
+    const dim3 mgrid((unsigned)(n_batch * n_head), (unsigned)((Lq + XQ_PER_WG - 1) / XQ_PER_WG));
+    hipLaunchKernelGGL(xattn_mfma_kernel, mgrid, dim3(256), lds, s, (const unsigned short*)q, (const unsigned short*)k, (const unsigned short*)v,
+                       (unsigned short*)o, n_head, Lq, Lk, Sp, (long)ldq, (long)ldkv, (long)ldo, scale * 1.44269504088896340736f);
+    TANTE_CHECK_LAUNCH();
+    return 0;
+  }
+  const dim3 grid((unsigned)(n_batch * n_head), (unsigned)((Lq + 255) / 256));
 #define TANTE_XA(DD) hipLaunchKernelGGL(cross_attn_kernel<DD>, grid, dim3(256), 0, s, q, k, v, o, dtype, n_head, Lq, Lk, (long)ldq, (long)ldkv, (long)ldo, scale)
   switch (D) {
     case 4: TANTE_XA(4); break;

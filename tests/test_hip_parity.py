@@ -917,3 +917,25 @@ def test_cvit_cfg4_full_size_properties(dev):
     w = {k: v.detach().cpu() for k, v in ms.state_dict().items()}
     with torch.no_grad():
         close(ms(xs.to(dev)), OC.cvit_forward(w, OC.CvitCfg(4, 4, (64, 32), **kw), xs), "fp32", scale=2.0)
+
+
+@pytest.mark.parametrize("nb,nh,Lq,Lk", [(2, 3, 777, 256), (1, 2, 40, 130), (1, 1, 1000, 512), (3, 2, 5, 4), (1, 8, 2048, 256)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_cross_attention_kernels(dev, nb, nh, Lq, Lk, dtype):
+    """tante_cross_attention, head dim 64: the exact VALU kernel (fp32) and the MFMA flash kernel (bf16), incl. key tails that are
+    not a multiple of the 128-key chunk, packed (k | v) buffers and query tails."""
+    from tante_amd import kernels as K
+    torch.manual_seed(Lq + Lk)
+    D = 64
+    C_ = nh * D
+    q = torch.randn(nb * Lq, C_)
+    kv = torch.randn(nb * Lk, 2 * C_)
+    qd, kvd = q.to(dev, dtype), kv.to(dev, dtype)
+    o = torch.empty(nb * Lq, C_, dtype=dtype, device=dev)
+    K.cross_attention(qd, kvd, kvd[:, C_:], o, nb, nh, D, Lq, Lk, C_, 2 * C_, C_)
+    qf, kvf = qd.float().cpu(), kvd.float().cpu()
+    qh = qf.view(nb, Lq, nh, D).transpose(1, 2)
+    kh = kvf[:, :C_].reshape(nb, Lk, nh, D).transpose(1, 2)
+    vh = kvf[:, C_:].reshape(nb, Lk, nh, D).transpose(1, 2)
+    ref = (torch.softmax(qh @ kh.transpose(-1, -2) / math.sqrt(D), -1) @ vh).transpose(1, 2).reshape(nb * Lq, C_)
+    close(o, ref, "fp32" if dtype == torch.float32 else "bf16")
