@@ -137,8 +137,19 @@ def main():
         name = max(tot, key=lambda k: tot[k][0])
         ms, fl, n = tot[name]
         ach = fl / (ms * 1e-3) / 1e12
+        # HBM bytes per launch of that kernel from the committed PMC passes (profiles/r01_pmc_rollout.json: separate
+        # `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this command, FETCH_SIZE doubled per the gfx950 note of
+        # MI355X_MICROARCH.md); bench.py itself cannot run the profiler, so the figure is null when the file is absent.
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_rollout.json")) as f:
+                pm = json.load(f)
+            if name.startswith("fused_block") and dtype == "bf16":
+                traffic = pm["fused_block16_kernel"]["hbm_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            pass
         roofline = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": PEAK_TFLOPS[dtype], "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_TFLOPS[dtype], 4), "traffic": None, "launches": n,
+                    "frac": round(ach / PEAK_TFLOPS[dtype], 4), "traffic": traffic, "launches": n,
                     "avg_launch_us": round(1e3 * ms / max(1, n), 2),
                     "others": {k: {"TFLOP/s": round(v[1] / (v[0] * 1e-3) / 1e12, 2), "avg_launch_us": round(1e3 * v[0] / v[2], 2),
                                    "launches": v[2]} for k, v in tot.items() if k != name}}
