@@ -15,6 +15,8 @@ from . import metrics, optim, dist  # noqa: F401
 from .metrics import MSE, NMSE, RMSE, NRMSE, VMSE, VRMSE, L2RE, NNMSE  # noqa: F401
 from .optim import FlatAdamW, warmup_cosine_lr  # noqa: F401
 from .train import train_step, train_step_adaptive  # noqa: F401
+from . import harness  # noqa: F401
+from .harness import LinearWarmupCosineAnnealingLR, SyntheticDataModule, save_checkpoint, load_checkpoint  # noqa: F401
 
 __all__ = ["TANTE", "TanteMetadata", "enc_CNN", "dec_CNN", "film", "interprator", "t_series", "Attn_Backbone",
            "TransformerBlock", "DefaultChannelsFirstFormatter", "DefaultChannelsLastFormatter", "rollout_model",

@@ -1,0 +1,149 @@
+"""Harness periphery around the hot path (host side only): the checkpoint dictionary of
+trainer/trainer.py:116-141, the per-epoch LR scheduler of optim/schedulers.py:17-123 as an object, CViT's query-point
+rollouts (trainer/trainer.py:36-69,161-172; trainer/evaler.py:37-76,140-165) and a synthetic stand-in for the datamodule that
+yields the `{"input", "output"}` dicts of data/dataset.py:224-227.  No arithmetic of the model lives here."""
+from __future__ import annotations
+
+from typing import Dict, Iterator, List, Optional, Tuple
+
+import torch
+
+from .optim import warmup_cosine_lr
+
+
+# ---- checkpoints: the reference's dictionary, key for key (including its 'optimizer_state_dit' spelling) -------------------------
+def save_checkpoint(path: str, model: torch.nn.Module, optimizer, epoch: int, validation_loss: float, best_validation_loss) -> None:
+    torch.save({"epoch": epoch, "model_state_dict": model.state_dict(),
+                "optimizer_state_dit": optimizer.state_dict() if optimizer is not None else None,
+                "validation_loss": validation_loss, "best_validation_loss": best_validation_loss}, path)
+
+
+def load_checkpoint(path: str, model: Optional[torch.nn.Module] = None, optimizer=None, lr_scheduler=None) -> Dict:
+    """-> {"starting_epoch", "starting_val_loss", "best_val_loss"}; replays the per-epoch scheduler like trainer.py:139-141."""
+    ck = torch.load(path, weights_only=False)
+    if model is not None:
+        model.load_state_dict(ck["model_state_dict"])
+    if optimizer is not None and ck.get("optimizer_state_dit") is not None:
+        optimizer.load_state_dict(ck["optimizer_state_dit"])
+    start = ck["epoch"] + 1
+    if lr_scheduler is not None:
+        for _ in range(start - 1):
+            lr_scheduler.step()
+    return {"starting_epoch": start, "starting_val_loss": ck["validation_loss"], "best_val_loss": ck["best_validation_loss"]}
+
+
+class LinearWarmupCosineAnnealingLR:
+    """Per-epoch schedule in closed form (optim/schedulers.py:97-123): the same `step()` / `get_last_lr()` surface, driving any
+    optimizer that exposes `.lr` (FlatAdamW) or `.param_groups` (torch.optim)."""
+
+    def __init__(self, optimizer, warmup_epochs: int, max_epochs: int, warmup_start_lr: float = 0.0, eta_min: float = 0.0,
+                 last_epoch: int = -1):
+        self.optimizer, self.warmup_epochs, self.max_epochs = optimizer, warmup_epochs, max_epochs
+        self.warmup_start_lr, self.eta_min = warmup_start_lr, eta_min
+        groups = getattr(optimizer, "param_groups", None)
+        self.base_lrs = [g["lr"] for g in groups] if groups else [optimizer.lr]
+        self.last_epoch = last_epoch
+        self.step()
+
+    def get_last_lr(self) -> List[float]:
+        return [warmup_cosine_lr(self.last_epoch, b, self.warmup_epochs, self.max_epochs, self.warmup_start_lr, self.eta_min)
+                for b in self.base_lrs]
+
+    def step(self) -> None:
+        self.last_epoch += 1
+        lrs = self.get_last_lr()
+        groups = getattr(self.optimizer, "param_groups", None)
+        if groups:
+            for g, lr in zip(groups, lrs):
+                g["lr"] = lr
+        else:
+            self.optimizer.lr = lrs[0]
+
+
+# ---- CViT query-point harness ---------------------------------------------------------------------------------------------------
+def generate_and_extract_coords(y_ref: torch.Tensor, M: int, generator: Optional[torch.Generator] = None):
+    """M random pixels of the (B, T, H, W, C) reference: their [0,1]^2 coordinates (M, 2) and values (B, T, M, C)
+    (trainer/trainer.py:36-69)."""
+    B, T, H, W, C = y_ref.shape
+    sel = torch.randperm(H * W, device=y_ref.device, generator=generator)[:M]
+    hi, wi = sel // W, sel % W
+    coords = torch.stack([hi.float() / (H - 1), wi.float() / (W - 1)], dim=-1)
+    return coords, y_ref[:, :, hi, wi, :]
+
+
+def generate_chunked_coords_with_indices(H: int, W: int, L: int, device="cuda"):
+    """All H * W pixels in row-major order, cut into chunks of L: normalised coordinates and integer (h, w) indices
+    (trainer/evaler.py:37-61)."""
+    idx = torch.arange(H * W, device=device)
+    hw = torch.stack([idx // W, idx % W], dim=-1)
+    xy = torch.stack([hw[:, 0].float() / (H - 1), hw[:, 1].float() / (W - 1)], dim=-1)
+    return list(xy.split(L)), list(hw.split(L))
+
+
+def reconstruct_full_field(chunks: List[torch.Tensor], indices: List[torch.Tensor], H: int, W: int) -> torch.Tensor:
+    """(B, T, n_i, C) predictions at the chunk pixels -> (B, T, C, H, W)  (trainer/evaler.py:63-76)."""
+    B, T, _, C = chunks[0].shape
+    full = torch.zeros(B, T, C, H, W, device=chunks[0].device, dtype=chunks[0].dtype)
+    for y, ij in zip(chunks, indices):
+        full[:, :, :, ij[:, 0], ij[:, 1]] = y.permute(0, 1, 3, 2)
+    return full
+
+
+def rollout_cvit_train(model, batch: Dict, formatter, num_query_points: int, device=None, generator=None):
+    """Trainer.rollout_cvit (trainer/trainer.py:161-172): one call at random query points."""
+    device = device or next(model.parameters()).device
+    moving, y_ref = formatter.process_input(batch)
+    coords, y_pts = generate_and_extract_coords(y_ref.to(device), num_query_points, generator)
+    return model(moving[0].to(device), coords), y_pts
+
+
+def rollout_cvit_eval(model, batch: Dict, formatter, n_steps: int, num_query_points: int, device=None):
+    """Evaler.rollout_cvit (trainer/evaler.py:140-165): the full field in query chunks, re-fed until n_steps frames exist."""
+    device = device or next(model.parameters()).device
+    moving, y_ref = formatter.process_input(batch)
+    moving = moving[0].to(device)
+    H, W = y_ref.shape[2], y_ref.shape[3]
+    preds, produced = [], 0
+    while produced < n_steps:
+        cc, ii = generate_chunked_coords_with_indices(H, W, num_query_points, device)
+        y = reconstruct_full_field([model(moving, c) for c in cc], ii, H, W)
+        produced += y.shape[1]
+        if produced < n_steps:
+            moving = torch.cat([moving[:, y.shape[1]:], y], dim=1)
+        preds.append(formatter.process_output(y))
+    return torch.cat(preds, dim=1)[:, :n_steps], y_ref.to(device)
+
+
+# ---- synthetic datamodule -------------------------------------------------------------------------------------------------------
+class SyntheticDataModule:
+    """Stand-in for data.TanteDataModule: standard-normal fields (the datasets are standardised per field, data/dataset.py:206-209)
+    in the `{"input": (B, n_in, H, W, C), "output": (B, n_out, H, W, C)}` layout of field_to_tensor (data/dataset.py:224-227),
+    sharded like DistributedSampler(num_replicas=world, rank=rank, drop_last=True) (data/datamodule.py:96-119)."""
+
+    def __init__(self, metadata, batch_size: int, n_steps_input: int = 4, n_steps_output: int = 4, n_samples: int = 64, seed: int = 211,
+                 world_size: int = 1, rank: int = 0, device="cpu"):
+        self.metadata, self.batch_size, self.n_in, self.n_out = metadata, batch_size, n_steps_input, n_steps_output
+        self.n_samples, self.seed, self.world, self.rank, self.device = n_samples, seed, world_size, rank, device
+        self.epoch = 0
+
+    def set_epoch(self, epoch: int) -> None:
+        self.epoch = epoch
+
+    def __len__(self) -> int:
+        return (self.n_samples // self.world) // self.batch_size
+
+    def _sample(self, i: int) -> torch.Tensor:
+        H, W = self.metadata.spatial_resolution
+        g = torch.Generator().manual_seed(self.seed * 1000003 + i)
+        return torch.randn(self.n_in + self.n_out, H, W, self.metadata.n_fields, generator=g)
+
+    def train_dataloader(self) -> Iterator[Dict[str, torch.Tensor]]:
+        g = torch.Generator().manual_seed(self.seed + self.epoch)
+        order = torch.randperm(self.n_samples, generator=g).tolist()
+        per = self.n_samples // self.world
+        mine = order[self.rank::self.world][:per]
+        for b in range(len(self)):
+            xs = torch.stack([self._sample(i) for i in mine[b * self.batch_size:(b + 1) * self.batch_size]]).to(self.device)
+            yield {"input": xs[:, :self.n_in], "output": xs[:, self.n_in:]}
+
+    val_dataloader = train_dataloader

@@ -48,6 +48,44 @@ class FlatAdamW:
     def zero_grad(self):
         self.flat_g.zero_()
 
+    # ---- checkpoint interchange with torch.optim.AdamW (the layout the reference's checkpoints hold, trainer/trainer.py:116-141) --
+    def _views(self, flat: torch.Tensor):
+        out, n = [], 0
+        for p in self.params:
+            out.append(flat[n:n + p.numel()].view(p.shape))
+            n += (p.numel() + 3) // 4 * 4
+        return out
+
+    def state_dict(self):
+        ea, es = self._views(self.exp_avg), self._views(self.exp_avg_sq)
+        state = {}
+        if self.step_count > 0:
+            state = {i: {"step": torch.tensor(float(self.step_count)), "exp_avg": ea[i].clone(), "exp_avg_sq": es[i].clone()}
+                     for i in range(len(self.params))}
+        group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.weight_decay, "amsgrad": False,
+                 "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                 "params": list(range(len(self.params)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_state_dict(self, sd):
+        g = sd["param_groups"][0]
+        self.lr, self.betas, self.eps, self.weight_decay = g["lr"], tuple(g["betas"]), g["eps"], g["weight_decay"]
+        ea, es = self._views(self.exp_avg), self._views(self.exp_avg_sq)
+        steps = set()
+        with torch.no_grad():
+            for i in range(len(self.params)):
+                st = sd["state"].get(i)
+                if st is None:
+                    ea[i].zero_()
+                    es[i].zero_()
+                    continue
+                ea[i].copy_(st["exp_avg"])
+                es[i].copy_(st["exp_avg_sq"])
+                steps.add(int(st["step"]))
+        if len(steps) > 1:
+            raise ValueError("FlatAdamW keeps one step counter; the checkpoint has per-parameter step counts " + str(sorted(steps)))
+        self.step_count = steps.pop() if steps else 0
+
     def grad_norm(self) -> torch.Tensor:
         """Total 2-norm of the gradient bucket (device tensor; reading it synchronises)."""
         L.check(L.lib().tante_sumsq(self.flat_g.data_ptr(), self.numel, self._sumsq.data_ptr(),

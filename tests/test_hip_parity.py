@@ -939,3 +939,49 @@ def test_cross_attention_kernels(dev, nb, nh, Lq, Lk, dtype):
     vh = kvf[:, C_:].reshape(nb, Lk, nh, D).transpose(1, 2)
     ref = (torch.softmax(qh @ kh.transpose(-1, -2) / math.sqrt(D), -1) @ vh).transpose(1, 2).reshape(nb * Lq, C_)
     close(o, ref, "fp32" if dtype == torch.float32 else "bf16")
+
+
+def test_flat_adamw_state_dict_interchanges_with_torch_adamw(dev):
+    """A checkpoint written after FlatAdamW steps resumes in torch.optim.AdamW (and back) with identical subsequent updates."""
+    import tante_amd
+    torch.manual_seed(1)
+    net = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.Linear(5, 3)).to(dev)
+    ref = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.Linear(5, 3)).to(dev)
+    ref.load_state_dict(net.state_dict())
+    opt = tante_amd.FlatAdamW(net.parameters(), lr=1e-2, weight_decay=1e-2, max_norm=0.0)
+    x = torch.randn(16, 7, device=dev)
+    for _ in range(2):
+        opt.zero_grad()
+        net(x).square().mean().backward()
+        opt.step()
+    topt = torch.optim.AdamW(ref.parameters(), lr=1e-2, weight_decay=1e-2)
+    ref.load_state_dict({k: v.clone() for k, v in net.state_dict().items()})
+    topt.load_state_dict(opt.state_dict())
+    opt2 = tante_amd.FlatAdamW(net.parameters(), lr=1e-2, weight_decay=1e-2, max_norm=0.0)
+    opt2.load_state_dict(topt.state_dict())
+    for o, mdl in ((topt, ref), (opt2, net)):
+        o.zero_grad()
+        mdl(x).square().mean().backward()
+        o.step()
+    for a, b in zip(net.parameters(), ref.parameters()):
+        close(a, b, "fp32", scale=10.0)
+
+
+def test_cvit_chunked_query_rollout_equals_full_grid(dev):
+    """Evaler.rollout_cvit semantics (query chunks + reassembly + re-feed) against the model's own full-grid forward."""
+    import tante_amd
+    from tante_amd import harness as Hn
+    torch.manual_seed(2)
+    md = tante_amd.TanteMetadata(n_fields=2, spatial_resolution=(16, 24))
+    m = tante_amd.CViT(4, md, out_steps=4, patch_size=(1, 8, 8), grid_size=(16, 24), latent_dim=24, emb_dim=32, depth=1, num_heads=4,
+                       dec_emb_dim=32, dec_num_heads=4).to(dev).eval()
+    fmt = tante_amd.DefaultChannelsFirstFormatter(md)
+    batch = {"input": torch.randn(2, 4, 16, 24, 2), "output": torch.randn(2, 6, 16, 24, 2)}
+    with torch.no_grad():
+        y, y_ref = Hn.rollout_cvit_eval(m, batch, fmt, n_steps=6, num_query_points=100, device=dev)
+        x0 = fmt.process_input(batch)[0][0].to(dev)
+        f1 = m(x0)
+        f2 = m(torch.cat([x0[:, 4:], f1], 1)[:, -4:])
+    want = fmt.process_output(torch.cat([f1, f2], 1))[:, :6]
+    assert y.shape == (2, 6, 16, 24, 2) and y_ref.shape == (2, 6, 16, 24, 2)
+    close(y, want, "fp32", scale=5.0)

@@ -185,3 +185,66 @@ def test_dp_shard_and_allreduce_gloo_world2():
         assert nb == 2
         assert torch.allclose(flat, full.sum(dim=0).reshape(-1), atol=1e-6)      # sum over ranks == full-batch sum
         assert t == 2.0                                                          # slowest rank
+
+
+# ---- harness periphery ------------------------------------------------------------------------------------
+def test_lr_scheduler_object_matches_reference_values():
+    """LinearWarmupCosineAnnealingLR driving an optimizer-like object: the 35 per-epoch values of fixture g10."""
+    import types
+    from tante_amd.harness import LinearWarmupCosineAnnealingLR
+    g = load_golden("g10_metrics")
+    opt = types.SimpleNamespace(lr=5e-5)
+    sch = LinearWarmupCosineAnnealingLR(opt, warmup_epochs=2, max_epochs=34, warmup_start_lr=5e-6, eta_min=5e-6)
+    lrs = g["lr_schedule"].numpy()
+    for e in range(35):
+        assert abs(opt.lr - lrs[e]) < 1e-10 and abs(sch.get_last_lr()[0] - lrs[e]) < 1e-10, (e, opt.lr, lrs[e])
+        sch.step()
+
+
+def test_cvit_query_chunks_roundtrip_and_extraction():
+    from tante_amd import harness as Hn
+    torch.manual_seed(0)
+    B, T, H, W, C = 2, 3, 6, 5, 4
+    y = torch.randn(B, T, H, W, C)
+    coords, pts = Hn.generate_and_extract_coords(y, 11)
+    assert coords.shape == (11, 2) and pts.shape == (B, T, 11, C)
+    hi = (coords[:, 0] * (H - 1)).round().long()
+    wi = (coords[:, 1] * (W - 1)).round().long()
+    assert torch.equal(pts, y[:, :, hi, wi, :]) and len({(int(a), int(b)) for a, b in zip(hi, wi)}) == 11
+    cc, ii = Hn.generate_chunked_coords_with_indices(H, W, 7, device="cpu")
+    assert sum(c.shape[0] for c in cc) == H * W and cc[0].shape == (7, 2)
+    chunks = [y[:, :, ij[:, 0], ij[:, 1], :] for ij in ii]                       # what a perfect model would return per chunk
+    assert torch.equal(Hn.reconstruct_full_field(chunks, ii, H, W), y.permute(0, 1, 4, 2, 3))
+
+
+def test_checkpoint_dict_has_the_reference_keys(tmp_path):
+    from tante_amd import harness as Hn
+    m = torch.nn.Linear(3, 2)
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-3)
+    m(torch.randn(4, 3)).sum().backward()
+    opt.step()
+    path = str(tmp_path / "recent.pt")
+    Hn.save_checkpoint(path, m, opt, epoch=3, validation_loss=0.5, best_validation_loss=0.25)
+    ck = torch.load(path, weights_only=False)
+    assert set(ck) == {"epoch", "model_state_dict", "optimizer_state_dit", "validation_loss", "best_validation_loss"}   # trainer.py:117-125
+    m2 = torch.nn.Linear(3, 2)
+    opt2 = torch.optim.AdamW(m2.parameters(), lr=1e-3)
+    info = Hn.load_checkpoint(path, m2, opt2)
+    assert info == {"starting_epoch": 4, "starting_val_loss": 0.5, "best_val_loss": 0.25}
+    assert all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), m2.state_dict().values()))
+
+
+def test_synthetic_datamodule_shards_like_distributed_sampler():
+    from tante_amd.harness import SyntheticDataModule
+    import tante_amd
+    md = tante_amd.TanteMetadata(n_fields=2, spatial_resolution=(8, 6))
+    seen = []
+    for r in range(2):
+        dm = SyntheticDataModule(md, batch_size=2, n_steps_input=4, n_steps_output=3, n_samples=12, world_size=2, rank=r)
+        batches = list(dm.train_dataloader())
+        assert len(batches) == len(dm) == 3
+        assert batches[0]["input"].shape == (2, 4, 8, 6, 2) and batches[0]["output"].shape == (2, 3, 8, 6, 2)
+        seen.append(torch.cat([b["input"] for b in batches]))
+    assert not torch.equal(seen[0], seen[1])                   # disjoint shards
+    full = SyntheticDataModule(md, batch_size=2, n_samples=12)
+    assert sum(b["input"].shape[0] for b in full.train_dataloader()) == 12
