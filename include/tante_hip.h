@@ -210,6 +210,11 @@ int tante_im2col(const void* x, int x_dtype, int nchw, int64_t n_img, int C, int
 /* F.adaptive_avg_pool2d to (Ht, Wt) on a channels-last image, then `act` (RealConv2d.forward, enc_dec_cnn.py:104-110). */
 int tante_avgpool_nhwc(const void* x, int x_dtype, int64_t n_img, int H, int W, int C, int Ht, int Wt, int act, void* y, int y_dtype,
                        void* stream);
+/* Gather half of a ConvTranspose2d whose taps overlap (stride < kernel P, padding `pad`; RealTransConv2d with overlap_ratio > 0,
+ * enc_dec_cnn.py:128-166): cols (n_img*Hi*Wi, P*P*Cout) with columns (kh, kw, co) is the tap matrix from one GEMM; out
+ * (n_img, Hf, Wf, Cout) channels-last, Hf = (Hi - 1) stride - 2 pad + P, gets the overlapping taps summed plus the bias. */
+int tante_col2im_nhwc(const void* cols, int cols_dtype, int64_t n_img, int Hi, int Wi, int P, int stride, int pad, int Cout,
+                      const float* bias, void* out, int out_dtype, void* stream);
 /* F.interpolate(mode="bilinear", align_corners=False) of the (Hi, Wi) window at (crop_y, crop_x) of `in` to (Ho, Wo), then `act`
  * (RealTransConv2d.forward, enc_dec_cnn.py:164-184: the padded transposed conv is the unpadded one cropped by the padding).
  * Element (img, c, y, x) of in / out lives at img*sn + c*sc + y*sh + x*sw (elements). */

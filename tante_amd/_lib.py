@@ -65,6 +65,7 @@ SIGNATURES = {
     "tante_head_fused": ([c_vp, c_i32, c_i64, c_i64, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_i64, c_vp], c_i32),
     "tante_im2col": ([c_vp, c_i32, c_i32, c_i64] + [c_i32] * 10 + [c_vp, c_i32, c_vp], c_i32),
     "tante_avgpool_nhwc": ([c_vp, c_i32, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp], c_i32),
+    "tante_col2im_nhwc": ([c_vp, c_i32, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_vp], c_i32),
     "tante_resize_bilinear": ([c_vp, c_i32, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_i64, c_i64, c_i64, c_i64, c_i32, c_i32, c_i64, c_i64,
                                c_i64, c_i64, c_i32, c_vp, c_i32, c_vp], c_i32),
     "tante_layernorm_affine": ([c_vp, c_i32, c_i64, c_i32, c_f32, c_vp, c_vp, c_vp, c_i32, c_vp], c_i32),

@@ -69,6 +69,37 @@ __global__ void avgpool_kernel(const void* __restrict__ x, int x_dtype, long n_i
   }
 }
 
+// ---- col2im for a transposed convolution with overlapping taps (stride < kernel): gather form, no atomics ----------------------
+// cols[(img, ih, iw)][(kh, kw, co)] = sum_ci x[img, ih, iw, ci] W[ci, co, kh, kw] (one GEMM); output pixel (y, x) sums the taps with
+// ih * s - p + kh = y, iw * s - p + kw = x, plus the bias; out is channels-last (img, Hf, Wf, Cout), Hf = (Hi - 1) s - 2 p + P.
+__global__ void col2im_kernel(const void* __restrict__ cols, int cols_dtype, long n_img, int Hi, int Wi, int P, int st, int pd, int Cout,
+                              const float* __restrict__ bias, int Hf, int Wf, void* __restrict__ out, int out_dtype) {
+  const long total = n_img * Hf * Wf * Cout;
+  const long ldc = (long)P * P * Cout;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int co = (int)(idx % Cout);
+    long r = idx / Cout;
+    const int x = (int)(r % Wf); r /= Wf;
+    const int y = (int)(r % Hf);
+    const long img = r / Hf;
+    float acc = bias ? bias[co] : 0.0f;
+    for (int kh = 0; kh < P; ++kh) {
+      const int ty = y + pd - kh;
+      if (ty < 0 || ty % st) continue;
+      const int ih = ty / st;
+      if (ih >= Hi) continue;
+      for (int kw = 0; kw < P; ++kw) {
+        const int tx = x + pd - kw;
+        if (tx < 0 || tx % st) continue;
+        const int iw = tx / st;
+        if (iw >= Wi) continue;
+        acc += ldx(cols, cols_dtype, ((img * Hi + ih) * Wi + iw) * ldc + ((long)kh * P + kw) * Cout + co);
+      }
+    }
+    stx(out, out_dtype, idx, acc);
+  }
+}
+
 // ---- bilinear resize (align_corners = False, F.interpolate semantics) of a cropped window + activation ------------------------
 // in element (img, c, y, x) at img*isn + c*isc + (y + cy)*ish + (x + cx)*isw, window Hi x Wi;  out likewise with its own strides.
 __global__ void resize_kernel(const void* __restrict__ in, int in_dtype, long n_img, int C, int Hi, int Wi, int cy, int cx, long isn,
@@ -491,6 +522,17 @@ extern "C" int tante_avgpool_nhwc(const void* x, int x_dtype, int64_t n_img, int
   if (!x || !y || n_img <= 0 || H <= 0 || W <= 0 || C <= 0 || Ht <= 0 || Wt <= 0) TANTE_FAIL(-1, "tante_avgpool_nhwc: bad argument");
   hipLaunchKernelGGL(avgpool_kernel, dim3(grid_for((long)n_img * Ht * Wt * C)), dim3(256), 0, (hipStream_t)stream, x, x_dtype, (long)n_img, H, W,
                      C, Ht, Wt, act, y, y_dtype);
+  TANTE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int tante_col2im_nhwc(const void* cols, int cols_dtype, int64_t n_img, int Hi, int Wi, int P, int stride, int pad, int Cout,
+                                 const float* bias, void* out, int out_dtype, void* stream) {
+  if (!cols || !out || n_img <= 0 || Hi <= 0 || Wi <= 0 || P <= 0 || stride <= 0 || pad < 0 || Cout <= 0) TANTE_FAIL(-1, "tante_col2im_nhwc: bad argument");
+  const int Hf = (Hi - 1) * stride - 2 * pad + P, Wf = (Wi - 1) * stride - 2 * pad + P;
+  if (Hf <= 0 || Wf <= 0) TANTE_FAIL(-1, "tante_col2im_nhwc: empty output");
+  hipLaunchKernelGGL(col2im_kernel, dim3(grid_for((long)n_img * Hf * Wf * Cout)), dim3(256), 0, (hipStream_t)stream, cols, cols_dtype, (long)n_img,
+                     Hi, Wi, P, stride, pad, Cout, bias, Hf, Wf, out, out_dtype);
   TANTE_CHECK_LAUNCH();
   return 0;
 }

@@ -331,6 +331,16 @@ def avgpool_nhwc(x: torch.Tensor, n_img: int, H: int, W: int, C_: int, Ht: int, 
     return y
 
 
+def col2im_nhwc(cols: torch.Tensor, n_img: int, Hi: int, Wi: int, P: int, stride: int, pad: int, Cout: int, bias: Optional[torch.Tensor],
+                out_dtype: torch.dtype) -> torch.Tensor:
+    _dev(cols, bias)
+    Hf, Wf = (Hi - 1) * stride - 2 * pad + P, (Wi - 1) * stride - 2 * pad + P
+    out = torch.empty(n_img, Hf, Wf, Cout, dtype=out_dtype, device=cols.device)
+    L.check(L.lib().tante_col2im_nhwc(_p(cols), _DT[cols.dtype], n_img, Hi, Wi, P, stride, pad, Cout, _p(bias), _p(out), _DT[out_dtype],
+                                      _stream()), "tante_col2im_nhwc")
+    return out
+
+
 def resize_bilinear(x: torch.Tensor, n_img: int, C_: int, Hi: int, Wi: int, crop: Tuple[int, int], in_strides, Ho: int, Wo: int,
                     out: torch.Tensor, out_strides, act: int):
     """Bilinear resize (align_corners=False) of the (Hi, Wi) window at `crop` of x into out; strides = (sn, sc, sh, sw) in elements."""

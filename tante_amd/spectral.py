@@ -145,8 +145,15 @@ class dec_FNO(nn.Module):
         params = [p for c, _ in dcs for p in (c.weight, c.bias)]
 
         def build():   # channels-first outputs: both stages feed a spectral layer
-            return [K.pack_weight(c.weight, c.bias, compute, L.W_DECONV_NCHW if S.stride_pad(p, self.overlap)[1] == 0 else L.W_DECONV_NHWC,
-                                  N=c.weight.shape[1] * p * p, K=c.weight.shape[0], P=p, C_other=c.weight.shape[1]) for c, p in dcs]
+            out = []
+            for c, p in dcs:
+                st_, pd_ = S.stride_pad(p, self.overlap)
+                if st_ != p:
+                    out.append(S.deconv_taps_pack(c.weight, c.bias, compute))
+                else:
+                    out.append(K.pack_weight(c.weight, c.bias, compute, L.W_DECONV_NCHW if pd_ == 0 else L.W_DECONV_NHWC,
+                                             N=c.weight.shape[1] * p * p, K=c.weight.shape[0], P=p, C_other=c.weight.shape[1]))
+            return out
         return self._cache.get(compute, params, build)
 
     def forward_tokens(self, src: torch.Tensor, n_img: int, compute: int, a_n0: int, a_s1: int, a_s0: int, a_off: int) -> torch.Tensor:

@@ -76,14 +76,36 @@ def conv_stage(x: torch.Tensor, nchw: bool, n_img: int, Cin: int, H: int, W: int
     return y, Ht, Wt
 
 
+def deconv_taps_pack(weight: torch.Tensor, bias: Optional[torch.Tensor], compute: int):
+    """ConvTranspose2d weight (Cin, Cout, P, P) -> (packed (P*P*Cout, Cin) tap GEMM weight without bias, bias) for overlapping stages."""
+    w = weight.detach()
+    w2 = w.permute(2, 3, 1, 0).reshape(-1, w.shape[0]).contiguous()
+    if w2.shape[1] > KMAX:
+        raise NotImplementedError("overlapping transposed conv with more than 512 input channels")
+    return K.pack_weight(w2, None, compute, L.W_LINEAR, N=w2.shape[0], K=w2.shape[1]), (None if bias is None else bias.detach())
+
+
 def deconv_stage(x: torch.Tensor, n_img: int, Hi: int, Wi: int, P: int, overlap: float, pw: K.PackedWeight, Cout: int, compute: int,
                  act: int, nchw_out: bool, out_dtype: torch.dtype, **rows) -> torch.Tensor:
     """RealTransConv2d.forward (enc_dec_cnn.py:164-184): ConvTranspose2d(kernel P, stride, padding) -> bilinear resize to
     (Hi * P, Wi * P) when the size differs -> act.  x: channels-last rows (n_img * Hi * Wi, Cin) (or gathered by **rows)."""
     s, p = stride_pad(P, overlap)
-    if s != P:
-        raise NotImplementedError("overlapping transposed convolution (overlap_ratio > 0 in a decoder stage) is not on the HIP path yet")
     Ho, Wo = Hi * P, Wi * P
+    if s != P:   # overlapping taps: tap matrix by one GEMM (pw = taps packing, see deconv_taps_chunks) -> gather-sum -> resize
+        M = n_img * Hi * Wi
+        if rows:
+            a_n0, a_s1, a_s0, a_off = rows["a_n0"], rows["a_s1"], rows["a_s0"], rows["a_off"]
+        else:
+            a_n0, a_s1, a_s0, a_off = M, 0, x.shape[-1], 0
+        taps, bias = pw
+        cols = torch.empty(M, taps.N, dtype=K.act_torch_dtype(compute), device=x.device)
+        K.linear(x, taps, cols, M=M, a_n0=a_n0, a_s1=a_s1, a_s0=a_s0, a_off=a_off)
+        full = K.col2im_nhwc(cols, n_img, Hi, Wi, P, s, p, Cout, bias, K.act_torch_dtype(compute))
+        Hf, Wf = full.shape[1], full.shape[2]
+        shape = (n_img, Cout, Ho, Wo) if nchw_out else (n_img, Ho, Wo, Cout)
+        out = torch.empty(shape, dtype=out_dtype, device=x.device)
+        ostr = (Cout * Ho * Wo, Ho * Wo, Wo, 1) if nchw_out else (Ho * Wo * Cout, 1, Wo * Cout, Cout)
+        return K.resize_bilinear(full, n_img, Cout, Hf, Wf, (0, 0), (Hf * Wf * Cout, 1, Wf * Cout, Cout), Ho, Wo, out, ostr, act)
     shape = (n_img, Cout, Ho, Wo) if nchw_out else (n_img, Ho, Wo, Cout)
     if p == 0:
         out = torch.empty(shape, dtype=out_dtype, device=x.device)

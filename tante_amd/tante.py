@@ -186,7 +186,11 @@ class dec_CNN(nn.Module):
             out = []
             for i, c in enumerate(convs):
                 p, ci, co = self.P[i], self.chans[i], self.chans[i + 1]
-                padded = S.stride_pad(p, self.overlap)[1] != 0    # padded stages scatter channels-last, then crop + resize
+                st_, pd_ = S.stride_pad(p, self.overlap)
+                if st_ != p:       # overlapping taps: tap GEMM + gather-sum (stages.deconv_stage)
+                    out.append(S.deconv_taps_pack(c.weight, c.bias, compute))
+                    continue
+                padded = pd_ != 0    # padded stages scatter channels-last, then crop + resize
                 lay = L.W_DECONV_NCHW if (i == 2 and not padded) else L.W_DECONV_NHWC
                 out.append(K.pack_weight(c.weight, c.bias, compute, lay, N=co * p * p, K=ci, P=p, C_other=co))
             return out
