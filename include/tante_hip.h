@@ -244,6 +244,16 @@ int tante_grid_embed(const float* coords, const float* grid, const float* latent
 /* FourierEmbs (cvit.py:308-331): out[n] = [cos(coords_n . K), sin(coords_n . K)], K (2, E/2). */
 int tante_fourier_embed(const float* coords, const float* kernel, int64_t N, int E, float* out, void* stream);
 
+/* ---- fused patch-embed stages 2 + 3 (bf16 MFMA path) -----------------------------------------------------
+ * h1: the stage-1 image, channels-last bf16 (n_img, 4 Hp, 4 Wp, C/4) as tante_gemm writes it.  One launch computes
+ * Conv2d(k = s = 2) -> GELU(erf) -> Conv2d(k = s = 2) -> x * film_a[t] + film_b[t] + s_emb[hw] into the fp32 token stream
+ * out (n_img * Hp * Wp, C), t = img % T  (enc_dec_cnn.py:221-229 stages 2-3 + tante.py:136-141).  C = 256, patch_scale 8. */
+int tante_enc23_supported(int C);
+int64_t tante_enc23_stream_bytes(int C);
+int tante_pack_enc23(const float* w2, const float* b2, const float* w3, const float* b3, int C, void* enc_stream, void* stream);
+int tante_enc23_fused(const void* h1, int n_img, int Hp, int Wp, int C, const void* enc_stream, const float* film_a,
+                      const float* film_b, const float* s_emb, int T, float* out, void* stream);
+
 /* ---- losses / metrics / optimiser step of the harness ------------------------------------------------
  * pred is addressed as pred[b*pb + t*pt + s*ps + c*pc] (so the channels-first rollout buffer needs no permute copy),
  * ref and grad are contiguous channels-last (B, T, HW, C).

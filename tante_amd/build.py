@@ -9,8 +9,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libtante_hip.so")
-SOURCES = ["gemm.hip", "attention.hip", "pointwise.hip", "block_fused.hip", "train.hip", "backward.hip", "wgrad.hip", "head_fused.hip", "operators.hip"]
-HEADERS = [os.path.join(CSRC, "common.cuh"), os.path.join(os.path.dirname(HERE), "include", "tante_hip.h")]
+SOURCES = ["gemm.hip", "attention.hip", "pointwise.hip", "block_fused.hip", "train.hip", "backward.hip", "wgrad.hip", "head_fused.hip", "operators.hip", "enc_fused.hip"]
+HEADERS = [os.path.join(CSRC, "common.cuh"), os.path.join(CSRC, "fused_common.cuh"), os.path.join(os.path.dirname(HERE), "include", "tante_hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=fast"]
 

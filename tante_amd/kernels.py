@@ -312,6 +312,29 @@ def head_fused(x: torch.Tensor, a_n0: int, a_s1: int, a_s0: int, a_off: int, n_i
     return out
 
 
+def enc23_supported(C_: int) -> bool:
+    return bool(L.lib().tante_enc23_supported(C_))
+
+
+def pack_enc23(params: Sequence[torch.Tensor], C_: int) -> torch.Tensor:
+    """params = (conv2.w, conv2.b, conv3.w, conv3.b) -> the fused stage-2+3 weight stream."""
+    ps = [p.detach() for p in params]
+    _dev(*ps)
+    st = torch.empty(L.lib().tante_enc23_stream_bytes(C_), dtype=torch.uint8, device=ps[0].device)
+    L.check(L.lib().tante_pack_enc23(*[_p(p) for p in ps], C_, _p(st), _stream()), "tante_pack_enc23")
+    return st
+
+
+def enc23_fused(h1: torch.Tensor, n_img: int, Hp: int, Wp: int, C_: int, enc_stream: torch.Tensor, film: tuple, out: torch.Tensor):
+    fa, fb, se, T, HW = film
+    _dev(h1, enc_stream, fa, fb, se, out)
+    if h1.dtype != torch.bfloat16 or HW != Hp * Wp:
+        raise RuntimeError("enc23_fused: bf16 stage-1 image and a (Hp*Wp, C) spatial embedding expected")
+    L.check(L.lib().tante_enc23_fused(_p(h1), n_img, Hp, Wp, C_, _p(enc_stream), _p(fa), _p(fb), _p(se), T, _p(out), _stream()),
+            "tante_enc23_fused")
+    return out
+
+
 # ---- general conv stages, spectral layer, CViT operators (operators.hip) ---------------------------------------------------------
 def im2col(x: torch.Tensor, nchw: bool, n_img: int, C_: int, H: int, W: int, kh: int, kw: int, sh: int, sw: int, ph: int, pw: int,
            korder: int, out_dtype: torch.dtype) -> torch.Tensor:

@@ -85,6 +85,7 @@ class enc_CNN(nn.Module):
         self.embed_dim = embed_dim
         self.P = _check_patch_cfg(patch_scale, overlap_ratio)
         self.overlap = overlap_ratio
+        self.fused = True          # bf16: stages 2 + 3 in one launch when the shape allows
         cin = dset_metadata.n_fields if dset_metadata else 4
         shape = dset_metadata.spatial_resolution if dset_metadata else (128, 384)
         self.H, self.W = shape[0], shape[1]
@@ -130,9 +131,17 @@ class enc_CNN(nn.Module):
         adt = K.act_torch_dtype(compute)
         n_img, h, w = B * T, H, W
         x = inp
+        fuse23 = (compute == L.BF16 and self.fused and film is not None and self.P == (2, 2, 2) and self.overlap == 0.0
+                  and K.enc23_supported(self.embed_dim))
         for i in range(3):
             p, ci, co = self.P[i], self.chans[i], self.chans[i + 1]
             last = i == 2
+            if fuse23 and i == 1:   # stages 2 + 3 + FiLM / positional epilogue in one launch; the C/2 intermediate never exists
+                convs = [self.enc_conv_2.conv, self.enc_conv_3.conv]
+                params = [q for c in convs for q in (c.weight, c.bias)]
+                st = self._cache.get(-3, params, lambda: K.pack_enc23(params, self.embed_dim))
+                out = torch.empty(n_img * (h // 4) * (w // 4), self.embed_dim, dtype=torch.float32, device=inp.device)
+                return K.enc23_fused(x, n_img, h // 4, w // 4, self.embed_dim, st, film, out)
             if self._general(i):
                 if i == 0:
                     x = x.contiguous().view(n_img, D, H, W)
