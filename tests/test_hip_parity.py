@@ -981,3 +981,26 @@ def test_cvit_chunked_query_rollout_equals_full_grid(dev):
     want = fmt.process_output(torch.cat([f1, f2], 1))[:, :6]
     assert y.shape == (2, 6, 16, 24, 2) and y_ref.shape == (2, 6, 16, 24, 2)
     close(y, want, "fp32", scale=5.0)
+
+
+def test_fused_encoder_stages_against_oracle_and_unfused(dev):
+    """enc23_kernel (stages 2 + 3 + FiLM / positional epilogue in one launch) against the oracle and against the three-GEMM route,
+    on a non-square token grid with a ragged last workgroup."""
+    import tante_amd
+    from tante_amd import _lib as L
+    from oracle import tante_oracle as O
+    torch.manual_seed(11)
+    md = tante_amd.TanteMetadata(n_fields=3, spatial_resolution=(40, 72))          # Hp, Wp = 5, 9 -> 45 tokens per frame
+    m = tante_amd.TANTE(in_T=3, dset_metadata=md, taylor_order=1, attn_axes="T", n_head=8, embed_dim=256, patch_scale=8).to(dev).eval()
+    x = torch.randn(2, 3, 3, 40, 72, device=dev)
+    fa, fb = m._time_tables()
+    film = (fa, fb, m.s_emb.view(45, 256), 3, 45)
+    with torch.no_grad():
+        fused = m.encoder.forward_tokens(x, L.BF16, film)
+        m.encoder.fused = False
+        plain = m.encoder.forward_tokens(x, L.BF16, film)
+    w = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    cfg = O.TanteCfg(3, 3, (40, 72), taylor_order=1, attn_axes="T", n_head=8, embed_dim=256, patch_scale=8)
+    want = O.tante_embed(w, cfg, x.cpu()).reshape(-1, 256)
+    close(fused, want, "bf16")
+    close(fused, plain, "bf16")
