@@ -136,6 +136,11 @@ int tante_attention(const void* qkv, void* o, int dtype, int C, int n_head, cons
 int tante_axis_mlp(float* x, int64_t outer, int n, int64_t inner, const float* w1, const float* b1, const float* w2,
                    const float* b2, void* stream);
 
+/* The same with the compute mode: TANTE_BF16 allows the polynomial GELU of the bf16 path, TANTE_F32 keeps erff; axes of up to 8
+ * positions with inner % 4 == 0 (the temporal propagator) take a float4-vectorised kernel. */
+int tante_axis_mlp_c(float* x, int64_t outer, int n, int64_t inner, const float* w1, const float* b1, const float* w2,
+                     const float* b2, int compute, void* stream);
+
 /* Vertical then horizontal propagator in ONE pass over x (BT, nH, nW, C) fp32, in place (attn_backbone.py:140-143):
  * x += MLP_H(x) along h; x += MLP_W(x) along w.  The n x n contractions run on MFMA in the compute dtype
  * (bf16: operands rounded to bf16, fp32 accumulate, A&S erf; fp32: exact fp32 MFMA, erff).  Needs nH, nW <= 64,

@@ -49,6 +49,7 @@ SIGNATURES = {
     "tante_gemm": ([C.POINTER(Gemm), c_vp], c_i32),
     "tante_attention": ([c_vp, c_vp, c_i32, c_i32, c_i32, C.POINTER(Seq), c_i32, c_vp], c_i32),
     "tante_axis_mlp": ([c_vp, c_i64, c_i32, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp], c_i32),
+    "tante_axis_mlp_c": ([c_vp, c_i64, c_i32, c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp], c_i32),
     "tante_axis_hw": ([c_vp, c_i64, c_i32, c_i32, c_i32] + [c_vp] * 8 + [c_i32, c_vp], c_i32),
     "tante_film_table": ([c_vp, c_i32, c_i32] + [c_vp] * 8 + [c_vp, c_vp, c_vp, c_vp], c_i32),
     "tante_film_apply": ([c_vp, c_i64, c_vp, c_i64, c_i32, c_i64, c_vp, c_vp, c_vp], c_i32),

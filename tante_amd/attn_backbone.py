@@ -189,9 +189,9 @@ class Attn_Backbone(nn.Module):
             K.axis_hw(x, B * T, H, W, C_, (vp[0].weight, vp[0].bias, vp[2].weight, vp[2].bias),
                       (hp[0].weight, hp[0].bias, hp[2].weight, hp[2].bias), compute)
         else:
-            K.axis_mlp(x, B * T, H, W * C_, vp[0].weight, vp[0].bias, vp[2].weight, vp[2].bias)      # l.140-141
-            K.axis_mlp(x, B * T * H, W, C_, hp[0].weight, hp[0].bias, hp[2].weight, hp[2].bias)      # l.142-143
-        K.axis_mlp(x, B, T, H * W * C_, tp[0].weight, tp[0].bias, tp[2].weight, tp[2].bias)          # l.144-145
+            K.axis_mlp(x, B * T, H, W * C_, vp[0].weight, vp[0].bias, vp[2].weight, vp[2].bias, compute)      # l.140-141
+            K.axis_mlp(x, B * T * H, W, C_, hp[0].weight, hp[0].bias, hp[2].weight, hp[2].bias, compute)      # l.142-143
+        K.axis_mlp(x, B, T, H * W * C_, tp[0].weight, tp[0].bias, tp[2].weight, tp[2].bias, compute)          # l.144-145
         ci = 0
         for i, axis in enumerate(self.attn_axes):
             blk = self.blocks[i]

@@ -63,6 +63,50 @@ __global__ __launch_bounds__(256) void axis_mlp_kernel(float* __restrict__ x, lo
     if (a < n) p[(long)a * inner] = v[a] + acc[a];
 }
 
+// Short axes (n <= 8, i.e. the temporal propagator): four adjacent columns per thread as float4 (16-byte loads / stores along the
+// contiguous inner axis), weights in registers via LDS broadcast.  FAST: polynomial GELU (bf16 compute mode), else erff.
+template <int N, bool FAST>
+__global__ __launch_bounds__(256) void axis_mlp_vec_kernel(float* __restrict__ x, long outer, int n, long inner4,
+                                                           const float* __restrict__ w1, const float* __restrict__ b1,
+                                                           const float* __restrict__ w2, const float* __restrict__ b2) {
+  __shared__ float w1s[N * N], w2s[N * N], b1s[N], b2s[N];
+  for (int idx = threadIdx.x; idx < N * N; idx += 256) {
+    const int j = idx / N, a = idx % N;
+    const bool in = (j < n) && (a < n);
+    w1s[idx] = in ? w1[j * n + a] : 0.0f;
+    w2s[idx] = in ? w2[j * n + a] : 0.0f;
+  }
+  if (threadIdx.x < N) {
+    b1s[threadIdx.x] = (threadIdx.x < n) ? b1[threadIdx.x] : 0.0f;
+    b2s[threadIdx.x] = (threadIdx.x < n) ? b2[threadIdx.x] : 0.0f;
+  }
+  __syncthreads();
+  const long col = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= outer * inner4) return;
+  const long o = col / inner4, i = col - o * inner4;
+  f32x4* p = (f32x4*)x + o * (long)n * inner4 + i;
+  f32x4 v[N], h[N];
+#pragma unroll
+  for (int a = 0; a < N; ++a) v[a] = (a < n) ? p[(long)a * inner4] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    f32x4 s = splat4(b1s[j]);
+#pragma unroll
+    for (int a = 0; a < N; ++a) s += splat4(w1s[j * N + a]) * v[a];
+    if constexpr (FAST) h[j] = gelu_poly4<false>(s);
+    else h[j] = f32x4{gelu_erf_f(s[0]), gelu_erf_f(s[1]), gelu_erf_f(s[2]), gelu_erf_f(s[3])};
+  }
+#pragma unroll
+  for (int a = 0; a < N; ++a) {
+    if (a < n) {
+      f32x4 acc = v[a] + splat4(b2s[a]);
+#pragma unroll
+      for (int j = 0; j < N; ++j) acc += splat4(w2s[a * N + j]) * h[j];
+      p[(long)a * inner4] = acc;
+    }
+  }
+}
+
 // generic fallback for long axes (n > 64): line and hidden vector live in LDS, [n][64 lanes]
 __global__ __launch_bounds__(64) void axis_mlp_lds_kernel(float* __restrict__ x, long outer, int n, long inner,
                                                           const float* __restrict__ w1, const float* __restrict__ b1,
@@ -388,6 +432,24 @@ void launch_axis(float* x, long outer, int n, long inner, const float* w1, const
 }
 
 }  // namespace
+
+extern "C" int tante_axis_mlp_c(float* x, int64_t outer, int n, int64_t inner, const float* w1, const float* b1, const float* w2,
+                                const float* b2, int compute, void* stream) {
+  if (!x || !w1 || !b1 || !w2 || !b2) TANTE_FAIL(-1, "tante_axis_mlp_c: null pointer");
+  if (outer <= 0 || n <= 0 || inner <= 0) TANTE_FAIL(-1, "tante_axis_mlp_c: bad shape");
+  if (n <= 8 && inner % 4 == 0 && ((uintptr_t)x % 16) == 0) {
+    hipStream_t s = (hipStream_t)stream;
+    const long cols = outer * (inner / 4);
+    const dim3 grid((unsigned)((cols + 255) / 256));
+#define TANTE_AV(NN, FF) hipLaunchKernelGGL((axis_mlp_vec_kernel<NN, FF>), grid, dim3(256), 0, s, x, (long)outer, n, (long)(inner / 4), w1, b1, w2, b2)
+    if (n <= 4) { if (compute == TANTE_BF16) TANTE_AV(4, true); else TANTE_AV(4, false); }
+    else { if (compute == TANTE_BF16) TANTE_AV(8, true); else TANTE_AV(8, false); }
+#undef TANTE_AV
+    TANTE_CHECK_LAUNCH();
+    return 0;
+  }
+  return tante_axis_mlp(x, outer, n, inner, w1, b1, w2, b2, stream);
+}
 
 extern "C" int tante_axis_mlp(float* x, int64_t outer, int n, int64_t inner, const float* w1, const float* b1,
                               const float* w2, const float* b2, void* stream) {

@@ -191,12 +191,12 @@ def attention(qkv: torch.Tensor, o: torch.Tensor, C_: int, n_head: int, seq: L.S
     return o
 
 
-def axis_mlp(x: torch.Tensor, outer: int, n: int, inner: int, w1, b1, w2, b2):
+def axis_mlp(x: torch.Tensor, outer: int, n: int, inner: int, w1, b1, w2, b2, compute: int = L.F32):
     _dev(x, w1, b1, w2, b2)
     if x.dtype != torch.float32:
-        raise RuntimeError("axis propagators run on the fp32 residual stream")
-    L.check(L.lib().tante_axis_mlp(_p(x), outer, n, inner, _p(w1.detach()), _p(b1.detach()), _p(w2.detach()),
-                                   _p(b2.detach()), _stream()), "tante_axis_mlp")
+        raise RuntimeError("the residual stream is fp32")
+    L.check(L.lib().tante_axis_mlp_c(_p(x), outer, n, inner, _p(w1.detach()), _p(b1.detach()), _p(w2.detach()), _p(b2.detach()), compute,
+                                     _stream()), "tante_axis_mlp")
     return x
 
 
