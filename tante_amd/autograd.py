@@ -60,19 +60,36 @@ def _rm_patch(t: torch.Tensor, nhwc: bool, n_img: int, Hin: int, Win: int, Cin: 
     return m
 
 
+ACCUMULATE_INTO_GRAD = True   # weight-gradient kernels add straight into a pre-allocated p.grad (FlatAdamW's bucket views)
+
+
+def _grad_slot(p) -> Optional[torch.Tensor]:
+    """The parameter's existing .grad when the weight-gradient kernels may accumulate into it directly.  With BPTT a weight is used
+    once per rollout step; letting autograd's AccumulateGrad add the per-use gradients costs an elementwise add (and a zero-filled
+    temporary) per use per parameter -- ~800 tiny launches per train step.  Backward then returns None for that input."""
+    if not ACCUMULATE_INTO_GRAD or not isinstance(p, torch.nn.Parameter) or p.grad is None:
+        return None
+    g = p.grad
+    return g if (g.dtype == torch.float32 and g.is_contiguous() and g.shape == p.shape and g.is_cuda) else None
+
+
 def wgrad(U: L.RowMat, V: L.RowMat, R: int, I: int, J: int, out_shape, compute: int, layout: int = L.W_LINEAR, P: int = 0,
-          C_other: int = 0, swap: bool = False, device=None, with_bias: bool = False):
-    """dW (and, with_bias, db[i] = sum_r U[r][i] from the same staged tiles)."""
-    dW = torch.empty(out_shape, dtype=torch.float32, device=device)
-    db = torch.empty(I, dtype=torch.float32, device=device) if with_bias else None
+          C_other: int = 0, swap: bool = False, device=None, with_bias: bool = False, into: Optional[torch.Tensor] = None,
+          db_into: Optional[torch.Tensor] = None):
+    """dW (and, with_bias, db[i] = sum_r U[r][i] from the same staged tiles).  `into` / `db_into`: accumulate onto existing tensors."""
+    acc = into is not None
+    dW = into if acc else torch.empty(out_shape, dtype=torch.float32, device=device)
+    db = None
+    if with_bias:
+        db = db_into if acc else torch.empty(I, dtype=torch.float32, device=device)
     L.check(L.lib().tante_wgrad(C.byref(U), C.byref(V), R, I, J, dW.data_ptr(), None if db is None else db.data_ptr(), layout, P,
-                                C_other, int(swap), compute, 0, _s()), "tante_wgrad")
+                                C_other, int(swap), compute, int(acc), _s()), "tante_wgrad")
     return (dW, db) if with_bias else dW
 
 
-def colsum(x: torch.Tensor, outer: int, Cc: int, inner: int) -> torch.Tensor:
-    out = torch.empty(Cc, dtype=torch.float32, device=x.device)
-    L.check(L.lib().tante_colsum(x.data_ptr(), _DT[x.dtype], outer, Cc, inner, out.data_ptr(), 0, _s()), "tante_colsum")
+def colsum(x: torch.Tensor, outer: int, Cc: int, inner: int, into: Optional[torch.Tensor] = None) -> torch.Tensor:
+    out = into if into is not None else torch.empty(Cc, dtype=torch.float32, device=x.device)
+    L.check(L.lib().tante_colsum(x.data_ptr(), _DT[x.dtype], outer, Cc, inner, out.data_ptr(), int(into is not None), _s()), "tante_colsum")
     return out
 
 
@@ -110,6 +127,7 @@ class LinearFn(Function):
         K.linear(a, pw, out, M=M, residual=residual)
         ctx.save_for_backward(a, W)
         ctx.compute, ctx.has_bias, ctx.has_res = compute, b is not None, residual is not None
+        ctx.params = (W, b)
         return out
 
     @staticmethod
@@ -131,9 +149,14 @@ class LinearFn(Function):
                 K.linear(dy, pw=pwt, out=out, M=M, a_n0=M, a_s0=N, a_off=c0, residual=acc)
                 acc = out
         if ctx.needs_input_grad[1]:
-            dW, db = wgrad(_rm_linear(dy), _rm_linear(a), M, N, Kk, (N, Kk), comp, device=a.device, with_bias=True)
-            if not (ctx.has_bias and ctx.needs_input_grad[2]):
-                db = None
+            gW, gb = _grad_slot(ctx.params[0]), _grad_slot(ctx.params[1])
+            if gW is not None and ctx.has_bias and ctx.needs_input_grad[2] and gb is not None:
+                wgrad(_rm_linear(dy), _rm_linear(a), M, N, Kk, (N, Kk), comp, device=a.device, with_bias=True, into=gW, db_into=gb)
+                dW = db = None
+            else:
+                dW, db = wgrad(_rm_linear(dy), _rm_linear(a), M, N, Kk, (N, Kk), comp, device=a.device, with_bias=True)
+                if not (ctx.has_bias and ctx.needs_input_grad[2]):
+                    db = None
         elif ctx.has_bias and ctx.needs_input_grad[2]:
             db = colsum(dy, M, N, 1)
         dres = dy if ctx.has_res else None
@@ -260,6 +283,7 @@ class PatchEmbedFn(Function):
         K.patch_embed(x, pw, out, n_img=n_img, Hin=Hin, Win=Win, Cin=Cin, P=P, nchw=nchw, act=L.ACT_NONE)
         ctx.save_for_backward(x, W)
         ctx.geo, ctx.compute = (n_img, Hin, Win, Cin, P, nchw), compute
+        ctx.params = (W, b)
         return out
 
     @staticmethod
@@ -282,8 +306,14 @@ class PatchEmbedFn(Function):
             dx = dx.view(x.shape)
         if ctx.needs_input_grad[1]:
             V = _rm_patch(x, not nchw, n_img, Hin, Win, Cin, P)
-            dW, db = wgrad(_rm_linear(d), V, M, Cout, Kk, tuple(W.shape), comp, layout=L.W_LINEAR if nchw else L.W_CONV_NHWC, P=P,
-                           C_other=Cin, device=x.device, with_bias=True)
+            gW, gb = _grad_slot(ctx.params[0]), _grad_slot(ctx.params[1])
+            lay = L.W_LINEAR if nchw else L.W_CONV_NHWC
+            if gW is not None and gb is not None and ctx.needs_input_grad[2]:
+                wgrad(_rm_linear(d), V, M, Cout, Kk, tuple(W.shape), comp, layout=lay, P=P, C_other=Cin, device=x.device, with_bias=True,
+                      into=gW, db_into=gb)
+            else:
+                dW, db = wgrad(_rm_linear(d), V, M, Cout, Kk, tuple(W.shape), comp, layout=lay, P=P, C_other=Cin, device=x.device,
+                               with_bias=True)
         elif ctx.needs_input_grad[2]:
             db = colsum(d, M, Cout, 1)
         return dx, dW, db, None, None, None, None, None, None, None, None
@@ -305,6 +335,7 @@ class DeconvFn(Function):
         K.deconv(a, pw, out, n_img=n_img, Hi=Hi, Wi=Wi, P=P, Cout=Cout, nchw_out=nchw_out, act=L.ACT_NONE)
         ctx.save_for_backward(a, W)
         ctx.geo, ctx.compute = (n_img, Hi, Wi, P, nchw_out), compute
+        ctx.params = (W, b)
         return out
 
     @staticmethod
@@ -324,10 +355,16 @@ class DeconvFn(Function):
             da = da.view(a.shape)
         if ctx.needs_input_grad[1]:
             V = _rm_patch(d, not nchw_out, n_img, Hi * P, Wi * P, Cout, P)
+            gW = _grad_slot(ctx.params[0])
             dW = wgrad(_rm_linear(a), V, M, Cin, N, tuple(W.shape), comp, layout=L.W_DECONV_NCHW if nchw_out else L.W_DECONV_NHWC, P=P,
-                       C_other=Cout, swap=True, device=a.device)
+                       C_other=Cout, swap=True, device=a.device, into=gW)
+            if gW is not None:
+                dW = None
         if ctx.needs_input_grad[2]:
-            db = colsum(d, n_img, Cout, Hi * P * Wi * P) if nchw_out else colsum(d, n_img * Hi * P * Wi * P, Cout, 1)
+            gb = _grad_slot(ctx.params[1])
+            db = colsum(d, n_img, Cout, Hi * P * Wi * P, gb) if nchw_out else colsum(d, n_img * Hi * P * Wi * P, Cout, 1, gb)
+            if gb is not None:
+                db = None
         return da, dW, db, None, None, None, None, None, None, None
 
 
