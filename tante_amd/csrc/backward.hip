@@ -186,104 +186,216 @@ __global__ void taylor_bwd_kernel(const float* __restrict__ dout, long dout_bstr
 // ---- attention backward (small sequences: L <= 128): one lane per token, two phases ----------------------------------
 // phase A (lane = query i): softmax stats m_i, l_i over its keys, delta_i = do_i . o_i, dq_i
 // phase B (lane = key j):   dk_j = scale * sum_i ds_ij q_i,  dv_j = sum_i p_ij do_i,  ds_ij = p_ij (do_i . v_j - delta_i)
-template <int D>
+// LDS rows hold the operands in their own dtype (bf16 rows halve the footprint: 4 workgroups per CU instead of 2)
+template <bool LB16> struct AbwT { using T = float; };
+template <> struct AbwT<true> { using T = unsigned short; };
+template <bool LB16>
+__device__ __forceinline__ f32x4 abw_ld4(const typename AbwT<LB16>::T* p) {
+  if constexpr (LB16) {
+    const u32x2 u = *(const u32x2*)p;
+    return f32x4{bf16_lo(u[0]), bf16_hi(u[0]), bf16_lo(u[1]), bf16_hi(u[1])};
+  } else {
+    return *(const f32x4*)p;
+  }
+}
+template <int D, bool LB16>
 __global__ __launch_bounds__(128) void attn_bwd_small_kernel(const void* __restrict__ qkv, const void* __restrict__ dO, void* __restrict__ dqkv,
                                                              int dtype, int C, TanteSeq sq, int G, int causal, float scale, float p_drop,
                                                              unsigned long long seed) {
-  constexpr int ST = D + 4;
-  extern __shared__ __attribute__((aligned(16))) float sm[];  // Q, K, V, dO rows [128][ST] each, then m, l, delta [128]
-  float* Qs = sm;
-  float* Ks = Qs + 128 * ST;
-  float* Vs = Ks + 128 * ST;
-  float* Gs = Vs + 128 * ST;
-  float* Ms = Gs + 128 * ST;
+  using ET = typename AbwT<LB16>::T;
+  constexpr int ST = D + (LB16 ? 8 : 4);   // row stride in elements: a multiple of 16 bytes
+  extern __shared__ __attribute__((aligned(16))) char sm_raw[];  // m, l, delta [128] floats, then Q, K, V, dO rows [128][ST]
+  float* Ms = (float*)sm_raw;
   float* Ls = Ms + 128;
   float* Ds = Ls + 128;
+  ET* Qs = (ET*)(Ds + 128);
+  ET* Ks = Qs + 128 * ST;
+  ET* Vs = Ks + 128 * ST;
+  ET* Gs = Vs + 128 * ST;
   const int tid = threadIdx.x, h = blockIdx.y, L = sq.L;
   const int g = tid / L, l = tid - g * L, s = blockIdx.x * G + g;
   const bool live = (g < G) && (s < sq.nseq);
-  long tok = 0;
-  if (live) {
-    tok = (long)(s / sq.n_s0) * sq.S1 + (long)(s % sq.n_s0) * sq.S0 + (long)(l / sq.n_l0) * sq.P1 + (long)(l % sq.n_l0) * sq.P0;
-    const long e = tok * 3L * C + (long)h * D;
-    for (int i = 0; i < D; ++i) {
-      Qs[tid * ST + i] = ldx(qkv, dtype, e + i);
-      Ks[tid * ST + i] = ldx(qkv, dtype, e + C + i);
-      Vs[tid * ST + i] = ldx(qkv, dtype, e + 2L * C + i);
-      Gs[tid * ST + i] = ldx(dO, dtype, tok * (long)C + (long)h * D + i);
+  auto token_of = [&](int t, bool& ok) -> long {   // token index of slot t of this workgroup (slots = G sequences x L positions)
+    const int gg = t / L, ll = t - gg * L, ss = blockIdx.x * G + gg;
+    ok = (gg < G) && (ss < sq.nseq);
+    return ok ? (long)(ss / sq.n_s0) * sq.S1 + (long)(ss % sq.n_s0) * sq.S0 + (long)(ll / sq.n_l0) * sq.P1 + (long)(ll % sq.n_l0) * sq.P0 : 0;
+  };
+  bool dummy;
+  const long tok = token_of(tid, dummy);
+  // cooperative, vectorised staging: 16-byte pieces of the q / k / v / dO rows (a lane-per-token copy issues 4 D scalar loads
+  // 3C elements apart -- that, not the arithmetic, was this kernel's time)
+  {
+    constexpr int EPC = 8;                         // elements per piece (bf16: 16 bytes; fp32: two 16-byte loads)
+    constexpr int PPR = D / EPC > 0 ? D / EPC : 1; // pieces per row
+    const int nslot = G * L;
+    for (int idx = tid; idx < nslot * 4 * PPR; idx += 128) {
+      const int pc = idx % PPR, mat = (idx / PPR) & 3, t = idx / (4 * PPR);
+      bool ok;
+      const long tk = token_of(t, ok);
+      ET* dst = (mat == 0 ? Qs : mat == 1 ? Ks : mat == 2 ? Vs : Gs) + t * ST + pc * EPC;
+      if (!ok) continue;
+      const long e = (mat < 3 ? tk * 3L * C + (long)mat * C : tk * (long)C) + (long)h * D + pc * EPC;
+      const void* src = mat < 3 ? qkv : dO;
+      if constexpr (D >= EPC) {
+        if constexpr (LB16) {
+          *(u32x4*)dst = *(const u32x4*)((const unsigned short*)src + e);
+        } else {
+          const f32x4 f0 = *(const f32x4*)((const float*)src + e), f1 = *(const f32x4*)((const float*)src + e + 4);
+          *(f32x4*)dst = f0;
+          *(f32x4*)(dst + 4) = f1;
+        }
+      } else {
+        for (int i = 0; i < D; ++i) {
+          const float v = ldx(src, dtype, e + i);
+          if constexpr (LB16) { __bf16 bb = (__bf16)v; dst[i] = __builtin_bit_cast(unsigned short, bb); }
+          else dst[i] = v;
+        }
+      }
     }
   }
   __syncthreads();
   const int r0 = g * L;
+  constexpr int D4 = D / 4;
+  // LDS rows are read as float4 (ST * 4 bytes is a multiple of 16) and a lane's own rows live in registers: an FMA costs a
+  // quarter of an LDS instruction instead of two.
+  auto dot = [&](const f32x4 (&a)[D4], const ET* row) {
+    float sacc = 0.f;
+#pragma unroll
+    for (int c = 0; c < D4; ++c) {
+      const f32x4 r = abw_ld4<LB16>(row + 4 * c);
+      sacc += a[c][0] * r[0] + a[c][1] * r[1] + a[c][2] * r[2] + a[c][3] * r[3];
+    }
+    return sacc;
+  };
   float dq[D];
+#pragma unroll
+  for (int i = 0; i < D; ++i) dq[i] = 0.f;
   if (live) {
-    // ---- phase A ----
+    // ---- phase A (lane = query): softmax statistics, then ONE pass that accumulates
+    //   delta = sum_j p_j dp'_j,  a1 = sum_j p_j dp'_j k_j,  a2 = sum_j p_j k_j   ->   dq = scale (a1 - delta a2)
+    // (dp'_j = do . v_j through the dropout mask, p_j the un-dropped probability)
+    f32x4 qv[D4], gv[D4];
+#pragma unroll
+    for (int c = 0; c < D4; ++c) { qv[c] = abw_ld4<LB16>(Qs + tid * ST + 4 * c); gv[c] = abw_ld4<LB16>(Gs + tid * ST + 4 * c); }
     const int nk = causal ? l + 1 : L;
-    float m = -INFINITY;
+    float m = -INFINITY, lsum = 0.f;
     for (int j = 0; j < nk; ++j) {
-      float sc = 0.f;
-      for (int i = 0; i < D; ++i) sc += Qs[tid * ST + i] * Ks[(r0 + j) * ST + i];
-      m = fmaxf(m, sc * scale);
+      const float sc = dot(qv, Ks + (r0 + j) * ST) * scale;
+      const float mn = fmaxf(m, sc);
+      lsum = lsum * expf(m - mn) + expf(sc - mn);
+      m = mn;
     }
     const float kscale = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
     const unsigned long long mrow = (((unsigned long long)s * gridDim.y + h) * L + l) * L;   // this query's row of the dropout mask
-    float lsum = 0.f, o[D];
-    for (int i = 0; i < D; ++i) o[i] = 0.f;
-    for (int j = 0; j < nk; ++j) {
-      float sc = 0.f;
-      for (int i = 0; i < D; ++i) sc += Qs[tid * ST + i] * Ks[(r0 + j) * ST + i];
-      const float p = expf(sc * scale - m);
-      lsum += p;
-      const float pd = (p_drop > 0.f && !dropout_keep(seed, mrow + j, p_drop)) ? 0.f : p * kscale;
-      for (int i = 0; i < D; ++i) o[i] += pd * Vs[(r0 + j) * ST + i];
-    }
+    const float inv_l = 1.0f / lsum;
     float delta = 0.f;
-    for (int i = 0; i < D; ++i) delta += Gs[tid * ST + i] * o[i] / lsum;
-    Ms[tid] = m; Ls[tid] = lsum; Ds[tid] = delta;
-    for (int i = 0; i < D; ++i) dq[i] = 0.f;
+    f32x4 a1[D4], a2[D4];
+#pragma unroll
+    for (int c = 0; c < D4; ++c) a1[c] = a2[c] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int j = 0; j < nk; ++j) {
-      float sc = 0.f, dp = 0.f;
-      for (int i = 0; i < D; ++i) {
-        sc += Qs[tid * ST + i] * Ks[(r0 + j) * ST + i];
-        dp += Gs[tid * ST + i] * Vs[(r0 + j) * ST + i];
-      }
-      const float p = expf(sc * scale - m) / lsum;
+      const ET* kr = Ks + (r0 + j) * ST;
+      const float sc = dot(qv, kr) * scale;
+      float dp = dot(gv, Vs + (r0 + j) * ST);
       if (p_drop > 0.f) dp = dropout_keep(seed, mrow + j, p_drop) ? dp * kscale : 0.f;   // d(dropped prob) -> d(prob)
-      const float ds = p * (dp - delta) * scale;
-      for (int i = 0; i < D; ++i) dq[i] += ds * Ks[(r0 + j) * ST + i];
+      const float p = expf(sc - m) * inv_l;
+      const float pdp = p * dp;
+      delta += pdp;
+#pragma unroll
+      for (int c = 0; c < D4; ++c) {
+        const f32x4 kv4 = abw_ld4<LB16>(kr + 4 * c);
+        a1[c] += kv4 * pdp;
+        a2[c] += kv4 * p;
+      }
+    }
+    Ms[tid] = m; Ls[tid] = inv_l; Ds[tid] = delta;
+#pragma unroll
+    for (int c = 0; c < D4; ++c)
+#pragma unroll
+      for (int e4 = 0; e4 < 4; ++e4) dq[4 * c + e4] = scale * (a1[c][e4] - delta * a2[c][e4]);
+  }
+  __syncthreads();
+  // ---- phase B: this lane is key l of its sequence; queries i that see it: i >= l (causal) or all ----
+  float dk[D], dv[D];
+  {
+    f32x4 kv[D4], vv[D4], dk4[D4], dv4[D4];
+#pragma unroll
+    for (int c = 0; c < D4; ++c) {
+      kv[c] = abw_ld4<LB16>(Ks + tid * ST + 4 * c);
+      vv[c] = abw_ld4<LB16>(Vs + tid * ST + 4 * c);
+      dk4[c] = dv4[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const float ks2 = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
+    for (int i = causal ? l : 0; live && i < L; ++i) {
+      const int qi = r0 + i;
+      const ET* qr = Qs + qi * ST;
+      const ET* gr = Gs + qi * ST;
+      f32x4 q4[D4], g4[D4];
+      float sc = 0.f, dp = 0.f;
+#pragma unroll
+      for (int c = 0; c < D4; ++c) {
+        q4[c] = abw_ld4<LB16>(qr + 4 * c);
+        g4[c] = abw_ld4<LB16>(gr + 4 * c);
+        sc += q4[c][0] * kv[c][0] + q4[c][1] * kv[c][1] + q4[c][2] * kv[c][2] + q4[c][3] * kv[c][3];
+        dp += g4[c][0] * vv[c][0] + g4[c][1] * vv[c][1] + g4[c][2] * vv[c][2] + g4[c][3] * vv[c][3];
+      }
+      const float p = expf(sc * scale - Ms[qi]) * Ls[qi];
+      float pd = p;
+      if (p_drop > 0.f) {
+        const bool keep = dropout_keep(seed, (((unsigned long long)s * gridDim.y + h) * L + i) * L + l, p_drop);
+        pd = keep ? p * ks2 : 0.f;
+        dp = keep ? dp * ks2 : 0.f;
+      }
+      const float ds = p * (dp - Ds[qi]) * scale;
+#pragma unroll
+      for (int c = 0; c < D4; ++c) {
+        dk4[c] += q4[c] * ds;
+        dv4[c] += g4[c] * pd;
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < D4; ++c)
+#pragma unroll
+      for (int e4 = 0; e4 < 4; ++e4) { dk[4 * c + e4] = dk4[c][e4]; dv[4 * c + e4] = dv4[c][e4]; }
+  }
+  // results -> LDS (the operand rows are dead once every lane has left phase B), then the same cooperative 16-byte pieces out
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < D; ++i) {
+    if constexpr (LB16) {
+      __bf16 a0 = (__bf16)dq[i], a1 = (__bf16)dk[i], a2 = (__bf16)dv[i];
+      Qs[tid * ST + i] = __builtin_bit_cast(unsigned short, a0);
+      Ks[tid * ST + i] = __builtin_bit_cast(unsigned short, a1);
+      Vs[tid * ST + i] = __builtin_bit_cast(unsigned short, a2);
+    } else {
+      Qs[tid * ST + i] = dq[i]; Ks[tid * ST + i] = dk[i]; Vs[tid * ST + i] = dv[i];
     }
   }
   __syncthreads();
-  if (!live) return;
-  // ---- phase B: this lane is key l of its sequence; queries i that see it: i >= l (causal) or all ----
-  float dk[D], dv[D];
-  for (int i = 0; i < D; ++i) { dk[i] = 0.f; dv[i] = 0.f; }
-  for (int i = causal ? l : 0; i < L; ++i) {
-    const int qi = r0 + i;
-    float sc = 0.f, dp = 0.f;
-    for (int e = 0; e < D; ++e) {
-      sc += Qs[qi * ST + e] * Ks[tid * ST + e];
-      dp += Gs[qi * ST + e] * Vs[tid * ST + e];
+  {
+    constexpr int EPC = 8;
+    constexpr int PPR = D / EPC > 0 ? D / EPC : 1;
+    const int nslot = G * L;
+    for (int idx = tid; idx < nslot * 3 * PPR; idx += 128) {
+      const int pc = idx % PPR, mat = (idx / PPR) % 3, t = idx / (3 * PPR);
+      bool ok;
+      const long tk = token_of(t, ok);
+      if (!ok) continue;
+      const ET* srcr = (mat == 0 ? Qs : mat == 1 ? Ks : Vs) + t * ST + pc * EPC;
+      const long e = tk * 3L * C + (long)mat * C + (long)h * D + pc * EPC;
+      if constexpr (D >= EPC) {
+        if constexpr (LB16) {
+          *(u32x4*)((unsigned short*)dqkv + e) = *(const u32x4*)srcr;
+        } else {
+          *(f32x4*)((float*)dqkv + e) = *(const f32x4*)srcr;
+          *(f32x4*)((float*)dqkv + e + 4) = *(const f32x4*)(srcr + 4);
+        }
+      } else {
+        for (int i = 0; i < D; ++i) {
+          if constexpr (LB16) ((unsigned short*)dqkv)[e + i] = srcr[i];
+          else stx(dqkv, dtype, e + i, srcr[i]);
+        }
+      }
     }
-    const float p = expf(sc * scale - Ms[qi]) / Ls[qi];
-    float pd = p;
-    if (p_drop > 0.f) {
-      const bool keep = dropout_keep(seed, (((unsigned long long)s * gridDim.y + h) * L + i) * L + l, p_drop);
-      const float ks2 = 1.0f / (1.0f - p_drop);
-      pd = keep ? p * ks2 : 0.f;
-      dp = keep ? dp * ks2 : 0.f;
-    }
-    const float ds = p * (dp - Ds[qi]) * scale;
-    for (int e = 0; e < D; ++e) {
-      dk[e] += ds * Qs[qi * ST + e];
-      dv[e] += pd * Gs[qi * ST + e];
-    }
-  }
-  const long e = tok * 3L * C + (long)h * D;
-  for (int i = 0; i < D; ++i) {
-    stx(dqkv, dtype, e + i, dq[i]);
-    stx(dqkv, dtype, e + C + i, dk[i]);
-    stx(dqkv, dtype, e + 2L * C + i, dv[i]);
   }
 }
 
@@ -356,18 +468,24 @@ void launch_axis_bwd(const float* x, const float* dy, long outer, int n, long in
   hipLaunchKernelGGL(axis_mlp_bwd_kernel<N>, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, s, x, dy, outer, n, inner, w1, b1, w2, dx, h, dpre);
 }
 
+template <int D, bool LB16>
+void launch_attn_bwd_t(const void* qkv, const void* dO, void* dqkv, int dtype, int C, int n_head, const TanteSeq& sq, int causal, float p_drop,
+                       unsigned long long seed, hipStream_t s) {
+  const int G = 128 / sq.L;
+  const size_t lds = 3 * 128 * sizeof(float) + 4 * 128 * (size_t)(D + (LB16 ? 8 : 4)) * (LB16 ? 2 : 4);
+  static bool set = false;
+  if (!set && lds > 64 * 1024) {
+    hipFuncSetAttribute((const void*)attn_bwd_small_kernel<D, LB16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    set = true;
+  }
+  hipLaunchKernelGGL((attn_bwd_small_kernel<D, LB16>), dim3((sq.nseq + G - 1) / G, n_head), dim3(128), lds, s, qkv, dO, dqkv, dtype, C, sq, G,
+                     causal, 1.0f / sqrtf((float)D), p_drop, seed);
+}
 template <int D>
 void launch_attn_bwd(const void* qkv, const void* dO, void* dqkv, int dtype, int C, int n_head, const TanteSeq& sq, int causal, float p_drop,
                      unsigned long long seed, hipStream_t s) {
-  const int G = 128 / sq.L;
-  const size_t lds = (4 * 128 * (D + 4) + 3 * 128) * sizeof(float);
-  static bool set = false;
-  if (!set && lds > 64 * 1024) {
-    hipFuncSetAttribute((const void*)attn_bwd_small_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    set = true;
-  }
-  hipLaunchKernelGGL(attn_bwd_small_kernel<D>, dim3((sq.nseq + G - 1) / G, n_head), dim3(128), lds, s, qkv, dO, dqkv, dtype, C, sq, G, causal,
-                     1.0f / sqrtf((float)D), p_drop, seed);
+  if (dtype == TANTE_BF16) launch_attn_bwd_t<D, true>(qkv, dO, dqkv, dtype, C, n_head, sq, causal, p_drop, seed, s);
+  else launch_attn_bwd_t<D, false>(qkv, dO, dqkv, dtype, C, n_head, sq, causal, p_drop, seed, s);
 }
 
 }  // namespace
