@@ -138,6 +138,13 @@ class LinearFn(Function):
         N = W.shape[0]
         comp = ctx.compute
         da = dW = db = None
+        dres = dy if ctx.has_res else None
+        if comp == L.BF16 and dy.dtype == torch.float32:
+            # the fp32 residual-stream gradient feeds two bf16 GEMMs (dgrad, wgrad): round it once -- both then read half the bytes
+            # and the weight gradient takes the LDS-DMA / transposed-read kernel, which wants bf16 rows
+            dyb = torch.empty(dy.shape, dtype=torch.bfloat16, device=dy.device)
+            L.check(L.lib().tante_act_fwd(dy.data_ptr(), L.F32, dyb.data_ptr(), L.BF16, dy.numel(), L.ACT_NONE, _s()), "tante_act_fwd")
+            dy = dyb
         if ctx.needs_input_grad[0]:       # dgrad GEMM: (M, N) x (N, K); the contraction (N) is chunked to the kernel's K limit
             chunks = [(c0, min(512, N - c0)) for c0 in range(0, N, 512)]
             da = torch.empty(M, Kk, dtype=a.dtype, device=a.device)
@@ -159,7 +166,6 @@ class LinearFn(Function):
                     db = None
         elif ctx.has_bias and ctx.needs_input_grad[2]:
             db = colsum(dy, M, N, 1)
-        dres = dy if ctx.has_res else None
         return da, dW, db, dres, None, None
 
 

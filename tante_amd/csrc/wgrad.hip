@@ -253,6 +253,126 @@ void launch_wgrad(const TanteRowMat& U, const TanteRowMat& V, long R, int I, int
 #undef TANTE_WG
 }
 
+// ---- fast path: both operands dense row-major bf16, I and J multiples of 128, R a multiple of 32 -------------------------------
+// The generic kernel above is LATENCY-bound: one chunk of global -> register -> (transposing) LDS staging in flight per
+// workgroup.  Here the rows go HBM -> LDS by LDS-DMA through a 4-deep ring of 32-row chunks with no register round trip, stored
+// row-major; the contraction index r is the slow axis of both operands, so the MFMA fragments (8 consecutive r of one column)
+// come out of `ds_read_b64_tr_b16`, gfx950's transposing LDS read (4 rows x 16 columns per 16-lane group, delivered column-major).
+// The image is the XOR-swizzled plain-row layout of cdna_hip_programming.md T10 (b): chunk' = chunk ^ (((row & 3) << 2) |
+// ((row >> 2) & 3)); LDS-DMA writes lane-linear, so the swizzle is applied to the global SOURCE chunk each lane fetches.
+// Bias gradient: one extra MFMA per A tile against an all-ones B fragment.
+constexpr int WT = 128, WRC = 32, WNBUF = 4;
+constexpr int WCHUNK = WRC * WT * 2;   // bytes of one operand chunk
+
+__device__ __forceinline__ int wg_swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+
+__device__ __forceinline__ u32x2 ds_read_tr16_b64(unsigned addr) {
+  u32x2 r;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r) : "v"(addr) : "memory");
+  return r;
+}
+
+__global__ __launch_bounds__(256, 2) void wgrad_tr_kernel(const unsigned short* __restrict__ U, long ldu, const unsigned short* __restrict__ V,
+                                                          long ldv, long R, int I, int J, long rows_per_split, float* __restrict__ dW,
+                                                          float* __restrict__ dbias, int layout, int P, int Co, int swap) {
+  extern __shared__ __attribute__((aligned(16))) char wsm[];   // ring: [buf][U chunk | V chunk]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kk = lane >> 4, l15 = lane & 15;
+  const int i0 = blockIdx.x * WT, j0 = blockIdx.y * WT;
+  const long r_begin = (long)blockIdx.z * rows_per_split, r_end = min(R, r_begin + rows_per_split);
+  const int nchunk = (int)((r_end - r_begin) / WRC);
+  const int wi = wave >> 1, wj = wave & 1;
+  // DMA: a wave instruction moves 4 rows (lanes 16 q .. 16 q + 15 = row q); wave w copies rows 8 w .. 8 w + 7 of the chunk
+  auto issue = [&](int c) {
+    char* buf = wsm + (c % WNBUF) * (2 * WCHUNK);
+    const long r0 = r_begin + (long)c * WRC;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int row = wave * 8 + h * 4 + (lane >> 4);
+      const int ch = (lane & 15) ^ wg_swz(row);                 // the logical chunk that belongs at this lane's LDS slot
+      const unsigned short* gu = U + (r0 + row) * ldu + i0 + ch * 8;
+      const unsigned short* gv = V + (r0 + row) * ldv + j0 + ch * 8;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gu,
+                                       (__attribute__((address_space(3))) void*)(buf + (wave * 8 + h * 4) * 256), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gv,
+                                       (__attribute__((address_space(3))) void*)(buf + WCHUNK + (wave * 8 + h * 4) * 256), 16, 0, 0);
+    }
+  };
+  f32x4 acc[4][4], bacc[4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    bacc[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const bool do_bias = dbias != nullptr && blockIdx.y == 0 && wj == 0;
+  const u32x4 ones = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};   // bf16 1.0 pairs
+  // transposed-read addressing: lane 4 q + p of a 16-lane group supplies row (rb + q), columns 4 p .. 4 p + 3 of the 16-column tile
+  const int q = l15 >> 2, p = l15 & 3;
+  unsigned trU[4][2], trV[4][2];   // byte offsets inside an operand chunk, per tile and per half (rows 8 kk + 4 h + q)
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int row = 8 * kk + 4 * h + q;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int cu = (wi * 64 + a * 16) / 8 + (p >> 1), cv = (wj * 64 + a * 16) / 8 + (p >> 1);
+      trU[a][h] = 256 * row + 16 * (cu ^ wg_swz(row)) + 8 * (p & 1);
+      trV[a][h] = 256 * row + 16 * (cv ^ wg_swz(row)) + 8 * (p & 1);
+    }
+  }
+  const unsigned lds0 = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)wsm;
+
+#pragma unroll
+  for (int c = 0; c < WNBUF - 1; ++c)
+    if (c < nchunk) issue(c);
+  for (int c = 0; c < nchunk; ++c) {
+    // chunk c was issued WNBUF - 1 chunks ago: all but the pieces of the chunks issued after it must have landed
+    const int later = min(nchunk - 1 - c, WNBUF - 2);
+    if (later >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (later == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                               // chunk c complete for every wave; chunk c - 1's buffer is free
+    if (c + WNBUF - 1 < nchunk) issue(c + WNBUF - 1);
+    const unsigned ub = lds0 + (c % WNBUF) * (2 * WCHUNK), vb = ub + WCHUNK;
+    u32x4 af[4], bf[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const u32x2 lo = ds_read_tr16_b64(ub + trU[a][0]), hi = ds_read_tr16_b64(ub + trU[a][1]);
+      af[a] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+      const u32x2 lo2 = ds_read_tr16_b64(vb + trV[a][0]), hi2 = ds_read_tr16_b64(vb + trV[a][1]);
+      bf[a] = u32x4{lo2[0], lo2[1], hi2[0], hi2[1]};
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[a]), __builtin_bit_cast(bf16x8, bf[b]), acc[a][b], 0, 0, 0);
+      if (do_bias) bacc[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[a]), __builtin_bit_cast(bf16x8, ones), bacc[a], 0, 0, 0);
+    }
+  }
+  // D[row = i][col = j]: lane holds j = l15, i = 4*kk + reg
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int i = i0 + wi * 64 + a * 16 + kk * 4 + rg, j = j0 + wj * 64 + b * 16 + l15;
+        atomicAdd(&dW[out_index(layout, i, j, I, J, P, Co, swap)], acc[a][b][rg]);
+      }
+  if (do_bias && l15 == 0) {
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) atomicAdd(&dbias[i0 + wi * 64 + a * 16 + kk * 4 + rg], bacc[a][rg]);
+  }
+}
+
+static bool wgrad_tr_ok(const TanteRowMat& m, long R, int ncols) {
+  return m.mode == TANTE_A_LINEAR && m.dtype == TANTE_BF16 && m.es == 1 && (m.s1 == 0 || m.n0 >= R) && m.s0 % 8 == 0 && m.off % 8 == 0 &&
+         ((uintptr_t)m.p % 16) == 0 && ncols % WT == 0 && m.s0 >= ncols;
+}
+
 }  // namespace
 
 static int check_rowmat(const TanteRowMat& m, const char* name) {
@@ -287,6 +407,28 @@ extern "C" int tante_wgrad(const TanteRowMat* U, const TanteRowMat* V, int64_t R
   hipStream_t s = (hipStream_t)stream;
   if (!accumulate && hipMemsetAsync(dW, 0, (size_t)I * J * sizeof(float), s) != hipSuccess) TANTE_FAIL(-3, "tante_wgrad: memset failed");
   if (!accumulate && dbias && hipMemsetAsync(dbias, 0, (size_t)I * sizeof(float), s) != hipSuccess) TANTE_FAIL(-3, "tante_wgrad: memset failed");
+  static const bool no_tr = getenv("TANTE_WGRAD_NO_TR") && atoi(getenv("TANTE_WGRAD_NO_TR"));
+  if (compute == TANTE_BF16 && !no_tr && R % WRC == 0 && wgrad_tr_ok(*U, (long)R, I) && wgrad_tr_ok(*V, (long)R, J)) {
+    const int ti = I / WT, tj = J / WT;
+    // every workgroup ends with 128 x 128 fp32 atomics: with the main loop at memory speed the split count is a trade between
+    // parallelism and atomic traffic (64 KiB per workgroup) -- measured best near 128 workgroups for <= 4 tiles, 256 otherwise
+    static const int wg_env = getenv("TANTE_WGRAD_WGS") ? atoi(getenv("TANTE_WGRAD_WGS")) : 0;
+    const int wg_target = wg_env > 0 ? wg_env : (ti * tj <= 4 ? 128 : 256);
+    long split = wg_target / ((long)ti * tj);
+    if (split < 1) split = 1;
+    const long nch = R / WRC;
+    if (split > nch / 4) split = nch / 4 > 0 ? nch / 4 : 1;
+    if (split > 65535) split = 65535;
+    long per = ((nch + split - 1) / split) * WRC;
+    split = (R + per - 1) / per;
+    const size_t lds = (size_t)WNBUF * 2 * WCHUNK;
+    static bool set = false;
+    if (!set) { hipFuncSetAttribute((const void*)wgrad_tr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set = true; }
+    hipLaunchKernelGGL(wgrad_tr_kernel, dim3(ti, tj, (unsigned)split), dim3(256), lds, s, (const unsigned short*)U->p + U->off, (long)U->s0,
+                       (const unsigned short*)V->p + V->off, (long)V->s0, (long)R, I, J, per, dW, dbias, layout, P, C_other, swap);
+    TANTE_CHECK_LAUNCH();
+    return 0;
+  }
   const int mu = rm_stage_mode(*U, I), mv = rm_stage_mode(*V, J);
   if (compute == TANTE_BF16) {
     if (I > 64 || J > 64) launch_wgrad<true, 128>(*U, *V, (long)R, I, J, dW, dbias, layout, P, C_other, swap, mu, mv, s);

@@ -1004,3 +1004,24 @@ def test_fused_encoder_stages_against_oracle_and_unfused(dev):
     want = O.tante_embed(w, cfg, x.cpu()).reshape(-1, 256)
     close(fused, want, "bf16")
     close(fused, plain, "bf16")
+
+
+@pytest.mark.parametrize("R,I,J", [(4096, 128, 128), (2080, 384, 256), (24576, 256, 768), (96, 128, 256)])
+def test_wgrad_dma_transposed_read_path(dev, R, I, J):
+    """wgrad_tr_kernel (LDS-DMA ring + ds_read_b64_tr_b16 operand reads): bf16 dense rows, I and J multiples of 128, R a multiple of 32;
+    incl. a row count that leaves a short last split, fused bias gradient, and accumulation onto an existing gradient."""
+    from tante_amd.autograd import wgrad, _rm_linear
+    from tante_amd import _lib as L
+    g = torch.Generator().manual_seed(R + I + J)
+    U = torch.randn(R, I, generator=g).to(torch.bfloat16)
+    V = torch.randn(R, J, generator=g).to(torch.bfloat16)
+    ref, refb = U.float().t() @ V.float(), U.float().sum(0)
+    Ud, Vd = U.to(dev), V.to(dev)
+    dW, db = wgrad(_rm_linear(Ud), _rm_linear(Vd), R, I, J, (I, J), L.BF16, device=dev, with_bias=True)
+    close(dW, ref, "bf16", scale=0.2)       # the products are exact in fp32: only the summation order differs
+    close(db, refb, "bf16", scale=0.2)
+    base, baseb = torch.randn(I, J, generator=g), torch.randn(I, generator=g)
+    accW, accb = base.to(dev).clone(), baseb.to(dev).clone()
+    wgrad(_rm_linear(Ud), _rm_linear(Vd), R, I, J, (I, J), L.BF16, device=dev, with_bias=True, into=accW, db_into=accb)
+    close(accW, ref + base, "bf16", scale=0.2)
+    close(accb, refb + baseb, "bf16", scale=0.2)
