@@ -237,7 +237,7 @@ __global__ __launch_bounds__(256, 1) void fused_block_kernel(float* __restrict__
         for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float p = ((allow[it] >> (jt * 4 + r)) & 1u) ? __expf(sc[jt][r] - m) : 0.0f;
+            const float p = ((allow[it] >> (jt * 4 + r)) & 1u) ? __builtin_amdgcn_exp2f(sc[jt][r] - m) : 0.0f;
             sc[jt][r] = p;
             sum += p;
           }
@@ -330,25 +330,31 @@ __global__ __launch_bounds__(256, 1) void fused_block_kernel(float* __restrict__
 // ------------------------------------------------------------------------------------------------------
 template <int CB>
 __device__ __forceinline__ void norm_frags16(const f32x4 (&res)[2 * CB], bool live, int C, float eps, u32x4 (&xn)[CB]) {
-  float s = 0.0f;
-#pragma unroll
-  for (int g = 0; g < 2 * CB; ++g) s += res[g][0] + res[g][1] + res[g][2] + res[g][3];
-  s += __shfl_xor(s, 16);
-  s += __shfl_xor(s, 32);
-  const float mean = s / (float)C;
-  float q = 0.0f;
+  // one pass: sum and sum of squares (E[x^2] - mean^2 in fp32 is ample for a stream that is rounded to bf16 next), then one fma per
+  // element -- this kernel is bound by VALU issue, every instruction per element counts
+  float s = 0.0f, q = 0.0f;
 #pragma unroll
   for (int g = 0; g < 2 * CB; ++g)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const float d = res[g][j] - mean;
-      q += d * d;
+      s += res[g][j];
+      q = fmaf(res[g][j], res[g][j], q);
     }
+  s += __shfl_xor(s, 16);
+  s += __shfl_xor(s, 32);
   q += __shfl_xor(q, 16);
   q += __shfl_xor(q, 32);
-  const float rstd = live ? rsqrtf(q / (float)C + eps) : 0.0f;
+  const float mean = s / (float)C;
+  const float var = fmaxf(q / (float)C - mean * mean, 0.0f);
+  const float rstd = live ? rsqrtf(var + eps) : 0.0f;
+  const float sh = -mean * rstd;
 #pragma unroll
-  for (int b = 0; b < CB; ++b) xn[b] = pack8((res[2 * b] - mean) * rstd, (res[2 * b + 1] - mean) * rstd);
+  for (int b = 0; b < CB; ++b) {
+    f32x4 lo, hi;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { lo[j] = fmaf(res[2 * b][j], rstd, sh); hi[j] = fmaf(res[2 * b + 1][j], rstd, sh); }
+    xn[b] = pack8(lo, hi);
+  }
 }
 
 // LDS-DMA copy by a 512-thread workgroup (8 waves x 1 KiB per pass)
@@ -449,21 +455,36 @@ __global__ __launch_bounds__(512, 2) void fused_block16_kernel(float* __restrict
     at_sp = f32x4{0.f, 0.f, 0.f, 0.f};
     if (paired) at_sp = mfma_bf16(kf_q, qf_p, at_sp);
   };
+  const bool all_visible = paired ? (__all(allow_own == 0xfu) && __all(allow_par == 0xfu)) : false;   // wave-uniform: no mask work at all
   auto attend_softmax = [&]() {
-    float m = -INFINITY;
+    float m, sum;
+    if (all_visible) {
+      m = fmaxf(fmaxf(fmaxf(at_so[0], at_so[1]), fmaxf(at_so[2], at_so[3])), fmaxf(fmaxf(at_sp[0], at_sp[1]), fmaxf(at_sp[2], at_sp[3])));
+      m = fmaxf(m, __shfl_xor(m, 16));
+      m = fmaxf(m, __shfl_xor(m, 32));
+      sum = 0.0f;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      if ((allow_own >> r) & 1u) m = fmaxf(m, at_so[r]);
-      if ((allow_par >> r) & 1u) m = fmaxf(m, at_sp[r]);
-    }
-    m = fmaxf(m, __shfl_xor(m, 16));
-    m = fmaxf(m, __shfl_xor(m, 32));
-    float sum = 0.0f;
+      for (int r = 0; r < 4; ++r) {
+        at_so[r] = __builtin_amdgcn_exp2f(at_so[r] - m);
+        at_sp[r] = __builtin_amdgcn_exp2f(at_sp[r] - m);
+        sum += at_so[r] + at_sp[r];
+      }
+    } else {
+      m = -INFINITY;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      at_so[r] = ((allow_own >> r) & 1u) ? __expf(at_so[r] - m) : 0.0f;
-      at_sp[r] = ((allow_par >> r) & 1u) ? __expf(at_sp[r] - m) : 0.0f;
-      sum += at_so[r] + at_sp[r];
+      for (int r = 0; r < 4; ++r) {
+        if ((allow_own >> r) & 1u) m = fmaxf(m, at_so[r]);
+        if ((allow_par >> r) & 1u) m = fmaxf(m, at_sp[r]);
+      }
+      m = fmaxf(m, __shfl_xor(m, 16));
+      m = fmaxf(m, __shfl_xor(m, 32));
+      sum = 0.0f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        at_so[r] = ((allow_own >> r) & 1u) ? __builtin_amdgcn_exp2f(at_so[r] - m) : 0.0f;
+        at_sp[r] = ((allow_par >> r) & 1u) ? __builtin_amdgcn_exp2f(at_sp[r] - m) : 0.0f;
+        sum += at_so[r] + at_sp[r];
+      }
     }
     sum += __shfl_xor(sum, 16);
     sum += __shfl_xor(sum, 32);
@@ -633,7 +654,7 @@ __global__ void pack_block_stream_kernel(const float* __restrict__ w_in, const f
                                          const float* __restrict__ b2, int C, int HID, char* __restrict__ dst) {
   const int NH = C / 32, CPR = C / 8, CPRH = HID / 8, TO = C / 64, T1 = HID / 64;
   const long tileh = 96 * CPR * 16 + BIAS_BYTES, tileo = 64 * CPR * 16 + BIAS_BYTES, tile2 = 64 * CPRH * 16 + BIAS_BYTES;
-  const float qscale = 0.17677669529663687f;  // 1/sqrt(32)
+  const float qscale = 0.17677669529663687f * 1.44269504088896340736f;  // log2(e) / sqrt(32): the kernels' softmax is exp2 of the scores
   const int t = blockIdx.x;
   int kind, tb;  // 0 head, 1 Wo, 2 W1, 3 W2
   long off;
