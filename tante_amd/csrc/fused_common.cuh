@@ -47,19 +47,32 @@ template <int N>
 __device__ __forceinline__ void lds_wait(u32x4& frag) {  // all but the N youngest LDS operations have returned; ties `frag` to the wait
   asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(frag) : "n"(N));
 }
+template <int N>
+__device__ __forceinline__ void lds_wait2(u32x4& f0, u32x4& f1) {  // one wait for two fragments
+  asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(f0), "+v"(f1) : "n"(N));
+}
 template <int N, int D, class AddrF, class UseF>
 __device__ __forceinline__ void mfma_stream(AddrF&& addr, UseF&& use) {
-  static_assert(D <= 15, "lgkmcnt is a 4-bit field");
+  static_assert(D <= 15 && D % 2 == 0, "lgkmcnt is a 4-bit field; fragments are consumed in pairs");
   u32x4 ring[D];
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   static_for<(D < N ? D : N)>([&](auto ic) { ring[decltype(ic)::value] = lds_read128(addr(ic)); });
-  static_for<N>([&](auto ic) {
-    constexpr int i = decltype(ic)::value;
-    u32x4 cur = ring[i % D];
+  // fragments are consumed in pairs behind ONE counted wait: the kernels that use this are bound by instruction issue, and an
+  // s_waitcnt per MFMA is an issue slot per MFMA
+  static_for<N / 2>([&](auto jc) {
+    constexpr int i = 2 * decltype(jc)::value;
+    u32x4 c0 = ring[i % D], c1 = ring[(i + 1) % D];
     if constexpr (i + D < N) ring[i % D] = lds_read128(addr(std::integral_constant<int, i + D>{}));
-    lds_wait<(N - 1 - i < D ? N - 1 - i : D)>(cur);
-    use(ic, cur);
+    if constexpr (i + 1 + D < N) ring[(i + 1) % D] = lds_read128(addr(std::integral_constant<int, i + 1 + D>{}));
+    lds_wait2<(N - 2 - i < D ? N - 2 - i : D)>(c0, c1);
+    use(std::integral_constant<int, i>{}, c0);
+    use(std::integral_constant<int, i + 1>{}, c1);
   });
+  if constexpr (N % 2 == 1) {
+    u32x4 c0 = ring[(N - 1) % D];
+    lds_wait<0>(c0);
+    use(std::integral_constant<int, N - 1>{}, c0);
+  }
 }
 
 __device__ __forceinline__ u32x4 pack8(const f32x4& a, const f32x4& b) {
