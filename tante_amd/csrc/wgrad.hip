@@ -50,7 +50,7 @@ __device__ __forceinline__ long out_index(int layout, int i, int j, int I, int J
 constexpr int RC = 64;  // rows (contraction index) per staged chunk
 
 // staging modes of an operand
-enum { ST_GENERIC = 0, ST_ROWMAJOR = 1, ST_COLMAJOR = 2 };
+enum { ST_GENERIC = 0, ST_ROWMAJOR = 1, ST_COLMAJOR = 2, ST_PATCH_NHWC = 3 };
 
 // Stage a [RC rows][T columns] chunk of a row matrix into LDS transposed ([column][row], row contiguous).
 // Every thread owns 4 x 4 (row x column) blocks; the 4 values of one column over 4 consecutive rows are written
@@ -101,6 +101,28 @@ struct Stager {
               v[k][0][q] = f[0]; v[k][1][q] = f[1]; v[k][2][q] = f[2]; v[k][3][q] = f[3];
             }
           }
+        }
+      } else if constexpr (MODE == ST_PATCH_NHWC) {
+        // k = s patches of a channels-last image: columns (kh, kw, ci) -- 4 consecutive columns are 4 contiguous elements of the
+        // run (kw, ci) of image row ho*P + kh (Cin % 4 == 0).  One index decomposition per ROW, not per element.
+        if (c + 4 <= ncols) {
+          const int seg = m.P * m.Cin, kh = c / seg, rest = c - kh * seg;
+          const int Wo = m.Win / m.P, Ho = m.Hin / m.P;
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (r + q < r_end) {
+              const long rr = r + q, img = rr / ((long)Ho * Wo);
+              const int rem = (int)(rr - img * Ho * Wo), ho = rem / Wo, wo = rem - ho * Wo;
+              const long base = (img / m.n0) * m.s1 + (img % m.n0) * (long)m.Cin * m.Hin * m.Win + m.off +
+                                ((long)(ho * m.P + kh) * m.Win + (long)wo * m.P) * m.Cin + rest;
+              if (m.dtype == TANTE_BF16) {
+                const u32x2 u = *(const u32x2*)((const unsigned short*)m.p + base);
+                v[k][0][q] = bf16_lo(u[0]); v[k][1][q] = bf16_hi(u[0]); v[k][2][q] = bf16_lo(u[1]); v[k][3][q] = bf16_hi(u[1]);
+              } else {
+                const f32x4 f = *(const f32x4*)((const float*)m.p + base);
+                v[k][0][q] = f[0]; v[k][1][q] = f[1]; v[k][2][q] = f[2]; v[k][3][q] = f[3];
+              }
+            }
         }
       } else if constexpr (MODE == ST_COLMAJOR) {   // 4 consecutive rows of one column are contiguous (fp32 source)
         if (r + 4 <= r_end) {
@@ -248,7 +270,8 @@ void launch_wgrad(const TanteRowMat& U, const TanteRowMat& V, long R, int I, int
 #define TANTE_WG(MUV, MVV) hipLaunchKernelGGL((wgrad_kernel<BF16, T, MUV, MVV>), grid, dim3(256), lds, s, U, V, R, I, J, per, dW, dbias, layout, P, Co, swap)
   if (mu == ST_ROWMAJOR && mv == ST_ROWMAJOR) TANTE_WG(ST_ROWMAJOR, ST_ROWMAJOR);        // linear layers
   else if (mu == ST_COLMAJOR && mv == ST_COLMAJOR) TANTE_WG(ST_COLMAJOR, ST_COLMAJOR);   // axis propagators
-  else if (mu == ST_ROWMAJOR) TANTE_WG(ST_ROWMAJOR, ST_GENERIC);                         // conv / transposed-conv stages (V = patches)
+  else if (mu == ST_ROWMAJOR && mv == ST_PATCH_NHWC) TANTE_WG(ST_ROWMAJOR, ST_PATCH_NHWC);   // conv / transposed-conv stages on channels-last images
+  else if (mu == ST_ROWMAJOR) TANTE_WG(ST_ROWMAJOR, ST_GENERIC);                         // V = patches of the channels-first input / output
   else TANTE_WG(ST_GENERIC, ST_GENERIC);
 #undef TANTE_WG
 }
@@ -388,6 +411,8 @@ static int check_rowmat(const TanteRowMat& m, const char* name) {
 }
 
 static int rm_stage_mode(const TanteRowMat& m, int ncols) {
+  if (m.mode == TANTE_A_PATCH_NHWC && ((uintptr_t)m.p % 16) == 0 && m.Cin % 4 == 0 && m.off % 4 == 0 && m.s1 % 4 == 0 && ncols % 4 == 0)
+    return ST_PATCH_NHWC;
   if (m.mode != TANTE_A_LINEAR || ((uintptr_t)m.p % 16)) return ST_GENERIC;
   const int al = m.dtype == TANTE_BF16 ? 4 : 4;
   if (m.es == 1 && m.s1 % al == 0 && m.s0 % al == 0 && m.off % al == 0 && ncols % 4 == 0) return ST_ROWMAJOR;
