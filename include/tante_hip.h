@@ -242,6 +242,18 @@ int tante_spectral_layer(const float* x, int64_t n, int Cin, int H, int W, const
  * Rows: q (b, i) at (b*Lq + i)*ldq + h*D, k / v (b, j) at (b*Lk + j)*ldkv + h*D, o at (b*Lq + i)*ldo + h*D (elements). */
 int tante_cross_attention(const void* q, const void* k, const void* v, void* o, int dtype, int64_t n_batch, int n_head, int D, int Lq,
                           int Lk, int64_t ldq, int64_t ldkv, int64_t ldo, void* stream);
+/* Backward of tante_cross_attention.  o is the forward output; dq gets the query gradient in the layout of q; the key / value gradients
+ * are ADDED (fp32 atomics) to dk / dv, rows (b, j) at (b*Lk + j)*ldg + h*D -- zero them first.  stats: n_batch*n_head*Lq*3 floats of
+ * scratch (softmax max, 1 / sum, dO . O per query). */
+int tante_cross_attention_bwd(const void* q, const void* k, const void* v, const void* o, const void* dO, void* dq, float* dk, float* dv,
+                              float* stats, int dtype, int64_t n_batch, int n_head, int D, int Lq, int Lk, int64_t ldq, int64_t ldkv,
+                              int64_t ldo, int64_t ldg, void* stream);
+/* Backward of tante_layernorm_affine: dx (fp32), and dgamma / dbeta ADDED to the given buffers (may be NULL). */
+int tante_layernorm_affine_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* gamma, int64_t M, int C, float eps,
+                               float* dx, float* dgamma, float* dbeta, void* stream);
+/* Backward of tante_grid_embed for the latents and the (trainable) grid positions; `out` is the forward result, wsum_work N floats. */
+int tante_grid_embed_bwd(const float* coords, const float* grid, const float* latents, const float* out, const float* dout, int64_t N,
+                         int G, int LD, float eps, float* wsum_work, float* dlatents, float* dgrid, void* stream);
 /* CViT grid embedding (cvit.py:434-438): out[n] = sum_g softmax_g(-eps |coords_n - grid_g|^2) latents[g];  coords (N, 2),
  * grid (G, 2), latents (G, LD), LD <= 1024.  Exact: every grid point is evaluated, exact-zero weights are skipped. */
 int tante_grid_embed(const float* coords, const float* grid, const float* latents, int64_t N, int G, int LD, float eps, float* out,

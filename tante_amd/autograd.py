@@ -122,9 +122,19 @@ class LinearFn(Function):
     def forward(ctx, a, W, b, residual, compute, out_dtype):
         M, Kk = a.shape
         N = W.shape[0]
-        pw = _packed(W, b, compute)
-        out = torch.empty(M, N, dtype=torch.float32 if residual is not None else out_dtype, device=a.device)
-        K.linear(a, pw, out, M=M, residual=residual)
+        if Kk <= 512:
+            pw = _packed(W, b, compute)
+            out = torch.empty(M, N, dtype=torch.float32 if residual is not None else out_dtype, device=a.device)
+            K.linear(a, pw, out, M=M, residual=residual)
+        else:   # contraction longer than the GEMM's register-stationary limit: K-chunks accumulate through the fp32 residual operand
+            acc = residual
+            for c0 in range(0, Kk, 512):
+                ck = min(512, Kk - c0)
+                pw = K.pack_weight(W.detach()[:, c0:c0 + ck].contiguous(), b if c0 == 0 else None, compute)
+                nxt = torch.empty(M, N, dtype=torch.float32, device=a.device)
+                K.linear(a, pw, nxt, M=M, a_n0=M, a_s0=Kk, a_off=c0, residual=acc)
+                acc = nxt
+            out = acc if (residual is not None or out_dtype == torch.float32) else acc.to(out_dtype)
         ctx.save_for_backward(a, W)
         ctx.compute, ctx.has_bias, ctx.has_res = compute, b is not None, residual is not None
         ctx.params = (W, b)
@@ -461,3 +471,109 @@ class RtReduceFn(Function):
         dt = torch.empty(shape, dtype=torch.float32, device=drt.device)
         L.check(L.lib().tante_rt_reduce_bwd(drt.data_ptr(), B, Lq, dt.data_ptr(), _s()), "rt_reduce_bwd")
         return dt, None, None, None, None
+
+
+# ---- CViT training ops (cvit.py) --------------------------------------------------------------------------------------------------
+class CrossAttentionFn(Function):
+    """o = softmax(q k^T / sqrt(D)) v per (batch, head); q lives in `qbuf` at column offset q_off (row stride = qbuf width), k / v in
+    `kvbuf` at k_off / v_off.  Self-attention passes the packed (M, 3C) projection as both buffers."""
+
+    @staticmethod
+    def forward(ctx, qbuf, kvbuf, q_off, k_off, v_off, nb, n_head, D, Lq, Lk):
+        C_ = n_head * D
+        o = torch.empty(nb * Lq, C_, dtype=qbuf.dtype, device=qbuf.device)
+        es = qbuf.element_size()
+        L.check(L.lib().tante_cross_attention(qbuf.data_ptr() + q_off * es, kvbuf.data_ptr() + k_off * es, kvbuf.data_ptr() + v_off * es,
+                                              o.data_ptr(), _DT[qbuf.dtype], nb, n_head, D, Lq, Lk, qbuf.shape[1], kvbuf.shape[1], C_, _s()),
+                "tante_cross_attention")
+        ctx.save_for_backward(qbuf, kvbuf, o)
+        ctx.geo = (q_off, k_off, v_off, nb, n_head, D, Lq, Lk)
+        return o
+
+    @staticmethod
+    def backward(ctx, dO):
+        qbuf, kvbuf, o = ctx.saved_tensors
+        q_off, k_off, v_off, nb, n_head, D, Lq, Lk = ctx.geo
+        dO = dO.contiguous().to(qbuf.dtype)
+        C_ = n_head * D
+        es = qbuf.element_size()
+        dq = torch.zeros_like(qbuf)
+        dkv32 = torch.zeros(kvbuf.shape, dtype=torch.float32, device=kvbuf.device)
+        stats = torch.empty(nb * n_head * Lq * 3, dtype=torch.float32, device=qbuf.device)
+        L.check(L.lib().tante_cross_attention_bwd(qbuf.data_ptr() + q_off * es, kvbuf.data_ptr() + k_off * es, kvbuf.data_ptr() + v_off * es,
+                                                  o.data_ptr(), dO.data_ptr(), dq.data_ptr() + q_off * es, dkv32.data_ptr() + 4 * k_off,
+                                                  dkv32.data_ptr() + 4 * v_off, stats.data_ptr(), _DT[qbuf.dtype], nb, n_head, D, Lq, Lk,
+                                                  qbuf.shape[1], kvbuf.shape[1], C_, kvbuf.shape[1], _s()), "tante_cross_attention_bwd")
+        if kvbuf.dtype == torch.float32:
+            dkv = dkv32
+        else:
+            dkv = torch.empty_like(kvbuf)
+            L.check(L.lib().tante_act_fwd(dkv32.data_ptr(), L.F32, dkv.data_ptr(), _DT[kvbuf.dtype], dkv32.numel(), L.ACT_NONE, _s()), "act_fwd")
+        return dq, dkv, None, None, None, None, None, None, None, None
+
+
+class LayerNormAffineFn(Function):
+    """y = LayerNorm(x) * gamma + beta (fp32 out): the LayerNorms of CViT whose output is itself a residual stream."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        x = x.contiguous()
+        y = K.layernorm_affine(x, gamma, beta, eps)
+        ctx.save_for_backward(x, gamma)
+        ctx.eps = eps
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma = ctx.saved_tensors
+        dy = dy.contiguous()
+        Cc = x.shape[-1]
+        M = x.numel() // Cc
+        dx = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+        dg = torch.zeros(Cc, dtype=torch.float32, device=x.device)
+        db = torch.zeros(Cc, dtype=torch.float32, device=x.device)
+        L.check(L.lib().tante_layernorm_affine_bwd(dy.data_ptr(), _DT[dy.dtype], x.data_ptr(), _DT[x.dtype], gamma.data_ptr(), M, Cc, ctx.eps,
+                                                   dx.data_ptr(), dg.data_ptr(), db.data_ptr(), _s()), "tante_layernorm_affine_bwd")
+        return dx.to(x.dtype), dg, db, None
+
+
+class GridEmbedFn(Function):
+    """out[n] = sum_g softmax_g(-eps |coords_n - grid_g|^2) latents[g]   (cvit.py:434-438); gradients for latents and grid."""
+
+    @staticmethod
+    def forward(ctx, coords, grid, latents, eps):
+        out = K.grid_embed(coords, grid.detach().contiguous(), latents.detach().contiguous(), eps)
+        ctx.save_for_backward(coords, grid, latents, out)
+        ctx.eps = eps
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        coords, grid, latents, out = ctx.saved_tensors
+        dout = dout.contiguous().float()
+        N, G, LD = coords.shape[0], grid.shape[0], latents.shape[1]
+        work = torch.empty(N, dtype=torch.float32, device=coords.device)
+        dl = torch.empty(G, LD, dtype=torch.float32, device=coords.device)
+        dg = torch.empty(G, 2, dtype=torch.float32, device=coords.device)
+        L.check(L.lib().tante_grid_embed_bwd(coords.data_ptr(), grid.detach().contiguous().data_ptr(), latents.detach().contiguous().data_ptr(),
+                                             out.data_ptr(), dout.data_ptr(), N, G, LD, ctx.eps, work.data_ptr(), dl.data_ptr(), dg.data_ptr(),
+                                             _s()), "tante_grid_embed_bwd")
+        return None, dg, dl, None
+
+
+class FourierEmbedFn(Function):
+    """[cos(c . K), sin(c . K)]  (cvit.py:308-331).  The gradient of the 2 x E/2 kernel is a parameter-sized reduction over the query
+    points, formed with torch expressions (like the LayerNorm-affine folding of the dense layers)."""
+
+    @staticmethod
+    def forward(ctx, coords, kernel):
+        out = K.fourier_embed(coords, kernel.detach().contiguous())
+        ctx.save_for_backward(coords, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        coords, out = ctx.saved_tensors
+        half = out.shape[1] // 2
+        ddp = dout[:, half:].float() * out[:, :half] - dout[:, :half].float() * out[:, half:]     # d/d(c.K): -sin dcos + cos dsin
+        return None, coords.t() @ ddp

@@ -481,6 +481,255 @@ __global__ void fourier_embed_kernel(const float* __restrict__ coords, const flo
   out[n * 2 * half + half + j] = sinf(dp);
 }
 
+// ---- CViT training: backward of softmax(q k^T / sqrt(D)) v with separate query / key sequences (fp32 arithmetic) ----------------
+// Kernel A (one lane per query): softmax statistics m, 1/l, delta = dO . O, and dq = scale sum_j p_j (dp_j - delta) k_j.
+// Kernel B (one lane per key, one workgroup per (batch, head, 256 keys, XB_QC queries)): dk_j = scale sum_i ds_ij q_i,
+// dv_j = sum_i p_ij dO_i with the query rows broadcast from LDS; partial sums are added to fp32 buffers with atomics.
+template <int D>
+__global__ __launch_bounds__(256) void xattn_bwd_dq_kernel(const void* __restrict__ q, const void* __restrict__ k, const void* __restrict__ v,
+                                                           const void* __restrict__ o, const void* __restrict__ dO, void* __restrict__ dq,
+                                                           float* __restrict__ stats, int dtype, int n_head, int Lq, int Lk, long ldq,
+                                                           long ldkv, long ldo, float scale) {
+  __shared__ float ks[64][D];
+  __shared__ float vs[64][D];
+  const int bh = blockIdx.x, b = bh / n_head, h = bh - b * n_head;
+  const int i = blockIdx.y * 256 + threadIdx.x;
+  const bool live = i < Lq;
+  const long qoff = ((long)b * Lq + (live ? i : 0)) * ldq + (long)h * D, ooff = ((long)b * Lq + (live ? i : 0)) * ldo + (long)h * D;
+  float qr[D], gr[D], acc[D];
+  float delta = 0.0f;
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    qr[d] = ldx(q, dtype, qoff + d) * scale;
+    gr[d] = ldx(dO, dtype, ooff + d);
+    delta += gr[d] * ldx(o, dtype, ooff + d);
+    acc[d] = 0.0f;
+  }
+  float m = -INFINITY, l = 0.0f;
+  for (int pass = 0; pass < 2; ++pass) {
+    const float inv_l = pass ? 1.0f / l : 0.0f;
+    for (int j0 = 0; j0 < Lk; j0 += 64) {
+      const int nj = Lk - j0 < 64 ? Lk - j0 : 64;
+      __syncthreads();
+      for (int e = threadIdx.x; e < nj * D; e += 256) {
+        const int j = e / D, d = e - j * D;
+        const long off = ((long)b * Lk + j0 + j) * ldkv + (long)h * D + d;
+        ks[j][d] = ldx(k, dtype, off);
+        if (pass) vs[j][d] = ldx(v, dtype, off);
+      }
+      __syncthreads();
+      for (int j = 0; j < nj; ++j) {
+        float sc = 0.0f;
+#pragma unroll
+        for (int d = 0; d < D; ++d) sc += qr[d] * ks[j][d];
+        if (!pass) {
+          const float mn = fmaxf(m, sc);
+          l = l * __expf(m - mn) + __expf(sc - mn);
+          m = mn;
+        } else {
+          float dp = 0.0f;
+#pragma unroll
+          for (int d = 0; d < D; ++d) dp += gr[d] * vs[j][d];
+          const float ds = __expf(sc - m) * inv_l * (dp - delta) * scale;
+#pragma unroll
+          for (int d = 0; d < D; ++d) acc[d] += ds * ks[j][d];
+        }
+      }
+    }
+  }
+  if (live) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) stx(dq, dtype, qoff + d, acc[d]);
+    float* st = stats + ((long)bh * Lq + i) * 3;
+    st[0] = m; st[1] = 1.0f / l; st[2] = delta;
+  }
+}
+
+constexpr int XB_QC = 512;   // queries per workgroup of the dk / dv kernel
+template <int D>
+__global__ __launch_bounds__(256) void xattn_bwd_dkv_kernel(const void* __restrict__ q, const void* __restrict__ k, const void* __restrict__ v,
+                                                            const void* __restrict__ dO, const float* __restrict__ stats,
+                                                            float* __restrict__ dk, float* __restrict__ dv, int dtype, int n_head, int Lq,
+                                                            int Lk, long ldq, long ldkv, long ldo, long ldg, float scale) {
+  __shared__ float qs[32][D];
+  __shared__ float gs[32][D];
+  __shared__ float sst[32][3];
+  const int bh = blockIdx.x, b = bh / n_head, h = bh - b * n_head;
+  const int j = blockIdx.y * 256 + threadIdx.x;
+  const bool live = j < Lk;
+  const long koff = ((long)b * Lk + (live ? j : 0)) * ldkv + (long)h * D;
+  float kr[D], vr[D], ak[D], av[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d) { kr[d] = ldx(k, dtype, koff + d); vr[d] = ldx(v, dtype, koff + d); ak[d] = 0.0f; av[d] = 0.0f; }
+  const int i_begin = blockIdx.z * XB_QC, i_end = min(Lq, i_begin + XB_QC);
+  for (int i0 = i_begin; i0 < i_end; i0 += 32) {
+    const int ni = i_end - i0 < 32 ? i_end - i0 : 32;
+    __syncthreads();
+    for (int e = threadIdx.x; e < ni * D; e += 256) {
+      const int ii = e / D, d = e - ii * D;
+      qs[ii][d] = ldx(q, dtype, ((long)b * Lq + i0 + ii) * ldq + (long)h * D + d);
+      gs[ii][d] = ldx(dO, dtype, ((long)b * Lq + i0 + ii) * ldo + (long)h * D + d);
+    }
+    if (threadIdx.x < ni * 3) sst[threadIdx.x / 3][threadIdx.x % 3] = stats[((long)bh * Lq + i0 + threadIdx.x / 3) * 3 + threadIdx.x % 3];
+    __syncthreads();
+    for (int ii = 0; ii < ni; ++ii) {
+      float sc = 0.0f, dp = 0.0f;
+#pragma unroll
+      for (int d = 0; d < D; ++d) { sc += qs[ii][d] * kr[d]; dp += gs[ii][d] * vr[d]; }
+      const float p = __expf(sc * scale - sst[ii][0]) * sst[ii][1];
+      const float ds = p * (dp - sst[ii][2]) * scale;
+#pragma unroll
+      for (int d = 0; d < D; ++d) { ak[d] += ds * qs[ii][d]; av[d] += p * gs[ii][d]; }
+    }
+  }
+  if (live) {
+    const long goff = ((long)b * Lk + j) * ldg + (long)h * D;
+#pragma unroll
+    for (int d = 0; d < D; ++d) { atomicAdd(dk + goff + d, ak[d]); atomicAdd(dv + goff + d, av[d]); }
+  }
+}
+
+// ---- LayerNorm with affine, backward: dx and the (accumulated) gamma / beta gradients; a wave walks LNB_RPW rows -----------------
+constexpr int LNB_RPW = 32;
+__global__ __launch_bounds__(256) void ln_affine_bwd_kernel(const void* __restrict__ dy, int dy_dtype, const void* __restrict__ x, int x_dtype,
+                                                            const float* __restrict__ gamma, long M, int C, float eps, float* __restrict__ dx,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long r0 = ((long)blockIdx.x * 4 + wave) * LNB_RPW;
+  float ag[16], ab[16];   // this lane's columns lane, lane + 64, ... (C <= 1024)
+#pragma unroll
+  for (int kq = 0; kq < 16; ++kq) { ag[kq] = 0.0f; ab[kq] = 0.0f; }
+  for (long row = r0; row < r0 + LNB_RPW && row < M; ++row) {
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += ldx(x, x_dtype, row * C + c);
+    const float mean = wave_sum(s) / C;
+    float qv = 0.f;
+    for (int c = lane; c < C; c += 64) { const float d = ldx(x, x_dtype, row * C + c) - mean; qv += d * d; }
+    const float rstd = rsqrtf(wave_sum(qv) / C + eps);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int kq = 0; kq < 16; ++kq) {
+      const int c = lane + 64 * kq;
+      if (c < C) {
+        const float xh = (ldx(x, x_dtype, row * C + c) - mean) * rstd, g = ldx(dy, dy_dtype, row * C + c);
+        ag[kq] += g * xh;
+        ab[kq] += g;
+        const float gg = g * (gamma ? gamma[c] : 1.0f);
+        s1 += gg;
+        s2 += gg * xh;
+      }
+    }
+    s1 = wave_sum(s1) / C;
+    s2 = wave_sum(s2) / C;
+#pragma unroll
+    for (int kq = 0; kq < 16; ++kq) {
+      const int c = lane + 64 * kq;
+      if (c < C) {
+        const float xh = (ldx(x, x_dtype, row * C + c) - mean) * rstd, gg = ldx(dy, dy_dtype, row * C + c) * (gamma ? gamma[c] : 1.0f);
+        dx[row * C + c] = rstd * (gg - s1 - xh * s2);
+      }
+    }
+  }
+#pragma unroll
+  for (int kq = 0; kq < 16; ++kq) {
+    const int c = lane + 64 * kq;
+    if (c < C) {
+      if (dgamma) atomicAdd(dgamma + c, ag[kq]);
+      if (dbeta) atomicAdd(dbeta + c, ab[kq]);
+    }
+  }
+}
+
+// ---- CViT grid embedding, backward: one workgroup per GRID POINT gathers from every query (no atomics, deterministic) -----------
+// w_ng = exp(-eps |x_n - g|^2) / wsum_n;  dlatents[g] = sum_n w_ng dout_n;  dgrid[g] = sum_n w_ng (dout_n . (latents_g - out_n)) 2 eps (x_n - g)
+__global__ __launch_bounds__(256) void grid_embed_wsum_kernel(const float* __restrict__ coords, const float* __restrict__ grid, long N, int G,
+                                                              float eps, float* __restrict__ wsum) {
+  __shared__ float red[4];
+  const long n = blockIdx.x;
+  const float cx = coords[2 * n], cy = coords[2 * n + 1];
+  float s = 0.0f;
+  for (int g = threadIdx.x; g < G; g += 256) {
+    const float dx = cx - grid[2 * g], dy = cy - grid[2 * g + 1];
+    s += expf(-eps * (dx * dx + dy * dy));
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) wsum[n] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void grid_embed_bwd_kernel(const float* __restrict__ coords, const float* __restrict__ grid,
+                                                             const float* __restrict__ latents, const float* __restrict__ out,
+                                                             const float* __restrict__ dout, const float* __restrict__ wsum, long N, int G,
+                                                             int LD, float eps, float* __restrict__ dlatents, float* __restrict__ dgrid) {
+  constexpr int CAP = 256;
+  __shared__ int l_idx[CAP];
+  __shared__ float l_w[CAP];
+  __shared__ int wave_cnt[4];
+  __shared__ float red[4];
+  const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float gx = grid[2 * g], gy = grid[2 * g + 1];
+  float lat[4], acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int kq = 0; kq < 4; ++kq) lat[kq] = (tid + 256 * kq < LD) ? latents[(long)g * LD + tid + 256 * kq] : 0.0f;
+  float dgx = 0.0f, dgy = 0.0f;
+  int cnt = 0;
+  auto flush = [&]() {
+    for (int e = 0; e < cnt; ++e) {
+      const float w = l_w[e];
+      const long n = l_idx[e];
+      float part = 0.0f;
+#pragma unroll
+      for (int kq = 0; kq < 4; ++kq)
+        if (tid + 256 * kq < LD) {
+          const float dv = dout[n * LD + tid + 256 * kq];
+          acc[kq] += w * dv;
+          part += dv * (lat[kq] - out[n * LD + tid + 256 * kq]);
+        }
+      part = wave_sum(part);
+      __syncthreads();
+      if (lane == 0) red[wave] = part;
+      __syncthreads();
+      const float dot = red[0] + red[1] + red[2] + red[3];
+      const float f = w * dot * 2.0f * eps;
+      dgx += f * (coords[2 * n] - gx);
+      dgy += f * (coords[2 * n + 1] - gy);
+    }
+  };
+  for (long n0 = 0; n0 < N; n0 += 256) {
+    const long n = n0 + tid;
+    float w = 0.0f;
+    if (n < N) {
+      const float dx = coords[2 * n] - gx, dy = coords[2 * n + 1] - gy;
+      w = expf(-eps * (dx * dx + dy * dy)) / wsum[n];
+    }
+    const unsigned long long bal = __ballot(w != 0.0f);
+    if (lane == 0) wave_cnt[wave] = __popcll(bal);
+    __syncthreads();
+    int base = cnt;
+    for (int ww = 0; ww < wave; ++ww) base += wave_cnt[ww];
+    const int tot = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+    if (cnt + tot > CAP) {
+      flush();
+      base -= cnt;
+      cnt = 0;
+      __syncthreads();
+    }
+    if (w != 0.0f) {
+      const int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
+      l_idx[pos] = (int)n;
+      l_w[pos] = w;
+    }
+    cnt += tot;
+    __syncthreads();
+  }
+  flush();
+#pragma unroll
+  for (int kq = 0; kq < 4; ++kq)
+    if (tid + 256 * kq < LD) dlatents[(long)g * LD + tid + 256 * kq] = acc[kq];
+  if (tid == 0) { dgrid[2 * g] = dgx; dgrid[2 * g + 1] = dgy; }
+}
+
 inline unsigned grid_for(long total, int block = 256) {
   long g = (total + block - 1) / block;
   return (unsigned)(g > 1048576 ? 1048576 : (g < 1 ? 1 : g));
@@ -626,6 +875,58 @@ extern "C" int tante_cross_attention(const void* q, const void* k, const void* v
     default: TANTE_FAIL(-2, "tante_cross_attention: head dim %d not in {4, 8, 12, 16, 32, 64}", D);
   }
 #undef TANTE_XA
+  TANTE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int tante_cross_attention_bwd(const void* q, const void* k, const void* v, const void* o, const void* dO, void* dq, float* dk,
+                                         float* dv, float* stats, int dtype, int64_t n_batch, int n_head, int D, int Lq, int Lk, int64_t ldq,
+                                         int64_t ldkv, int64_t ldo, int64_t ldg, void* stream) {
+  if (!q || !k || !v || !o || !dO || !dq || !dk || !dv || !stats || n_batch <= 0 || n_head <= 0 || Lq <= 0 || Lk <= 0)
+    TANTE_FAIL(-1, "tante_cross_attention_bwd: bad argument");
+  if ((Lq + 255) / 256 > 65535 || (Lk + 255) / 256 > 65535 || (Lq + XB_QC - 1) / XB_QC > 65535) TANTE_FAIL(-2, "tante_cross_attention_bwd: grid too large");
+  const float scale = 1.0f / sqrtf((float)D);
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 ga((unsigned)(n_batch * n_head), (unsigned)((Lq + 255) / 256));
+  const dim3 gb((unsigned)(n_batch * n_head), (unsigned)((Lk + 255) / 256), (unsigned)((Lq + XB_QC - 1) / XB_QC));
+#define TANTE_XB(DD)                                                                                                                         \
+  hipLaunchKernelGGL(xattn_bwd_dq_kernel<DD>, ga, dim3(256), 0, s, q, k, v, o, dO, dq, stats, dtype, n_head, Lq, Lk, (long)ldq, (long)ldkv,   \
+                     (long)ldo, scale);                                                                                                       \
+  hipLaunchKernelGGL(xattn_bwd_dkv_kernel<DD>, gb, dim3(256), 0, s, q, k, v, dO, stats, dk, dv, dtype, n_head, Lq, Lk, (long)ldq, (long)ldkv, \
+                     (long)ldo, (long)ldg, scale)
+  switch (D) {
+    case 4: TANTE_XB(4); break;
+    case 8: TANTE_XB(8); break;
+    case 12: TANTE_XB(12); break;
+    case 16: TANTE_XB(16); break;
+    case 32: TANTE_XB(32); break;
+    case 64: TANTE_XB(64); break;
+    default: TANTE_FAIL(-2, "tante_cross_attention_bwd: head dim %d not in {4, 8, 12, 16, 32, 64}", D);
+  }
+#undef TANTE_XB
+  TANTE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int tante_layernorm_affine_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* gamma, int64_t M, int C,
+                                          float eps, float* dx, float* dgamma, float* dbeta, void* stream) {
+  if (!dy || !x || !dx || M <= 0 || C <= 0) TANTE_FAIL(-1, "tante_layernorm_affine_bwd: bad argument");
+  if (C > 1024) TANTE_FAIL(-2, "tante_layernorm_affine_bwd: C = %d > 1024", C);
+  hipLaunchKernelGGL(ln_affine_bwd_kernel, dim3((unsigned)((M + 4 * LNB_RPW - 1) / (4 * LNB_RPW))), dim3(256), 0, (hipStream_t)stream, dy, dy_dtype,
+                     x, x_dtype, gamma, (long)M, C, eps, dx, dgamma, dbeta);
+  TANTE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int tante_grid_embed_bwd(const float* coords, const float* grid, const float* latents, const float* out, const float* dout,
+                                    int64_t N, int G, int LD, float eps, float* wsum_work, float* dlatents, float* dgrid, void* stream) {
+  if (!coords || !grid || !latents || !out || !dout || !wsum_work || !dlatents || !dgrid || N <= 0 || G <= 0 || LD <= 0)
+    TANTE_FAIL(-1, "tante_grid_embed_bwd: bad argument");
+  if (LD > 1024 || N > 2147483647L) TANTE_FAIL(-2, "tante_grid_embed_bwd: latent_dim %d > 1024 or too many queries", LD);
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(grid_embed_wsum_kernel, dim3((unsigned)N), dim3(256), 0, s, coords, grid, (long)N, G, eps, wsum_work);
+  hipLaunchKernelGGL(grid_embed_bwd_kernel, dim3((unsigned)G), dim3(256), 0, s, coords, grid, latents, out, dout, wsum_work, (long)N, G, LD, eps,
+                     dlatents, dgrid);
   TANTE_CHECK_LAUNCH();
   return 0;
 }

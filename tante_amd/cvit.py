@@ -302,8 +302,9 @@ class CViT(nn.Module):
         """x (b, t, c, h, w) -> (b, out_steps, c, h, w); with input_coords (n, 2): (b, out_steps, n, c)   (cvit.py:427-466)."""
         if not x.is_cuda:
             raise RuntimeError("tante_amd.CViT runs on the GPU only (no CPU fallback); move the input to cuda")
-        _no_autograd(self)
         compute = resolve_compute(self.compute)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            return cvit_train_forward(self, x.detach().to(torch.float32).contiguous(), input_coords, compute)
         x = x.detach().to(torch.float32).contiguous()
         b, t, c, h, w = x.shape
         if input_coords is None:
@@ -328,3 +329,106 @@ class CViT(nn.Module):
         if input_coords is None:
             return o.view(b, h, w, self.out_steps, c).permute(0, 3, 4, 1, 2)                   # 'b (h w) (t d) -> b t d h w'
         return o.permute(0, 2, 1, 3)                                                           # 'b n (t d) -> b t n d'
+
+
+# ---- differentiable (training) forward: the same arithmetic from tante_amd.autograd ops ---------------------------------------------
+def _fold(w, b, ln):
+    """LayerNorm affine folded into the consuming projection (parameter-sized torch expressions; autograd distributes the gradients)."""
+    return w * ln.weight[None, :], b + w @ ln.bias
+
+
+def _attn_tail_train(blk, o, resid, compute):
+    from .autograd import ActFn, LayerNormFn, LinearFn
+    adt = K.act_torch_dtype(compute)
+    a, m = blk.attn, blk.mlp
+    x = LinearFn.apply(o, a.out_proj.weight, a.out_proj.bias, resid, compute, torch.float32)
+    w1, b1 = _fold(m.fc1.weight, m.fc1.bias, blk.layer_norm2)
+    h = ActFn.apply(LinearFn.apply(LayerNormFn.apply(x, blk.eps, adt), w1, b1, None, compute, adt), L.ACT_GELU_ERF, adt)
+    return LinearFn.apply(h, m.fc2.weight, m.fc2.bias, x, compute, torch.float32)
+
+
+def _self_block_train(blk, x, nb, Lq, compute):
+    from .autograd import CrossAttentionFn, LayerNormFn, LinearFn
+    adt = K.act_torch_dtype(compute)
+    C_, nh = blk.emb_dim, blk.num_heads
+    w, b = _fold(blk.attn.in_proj_weight, blk.attn.in_proj_bias, blk.layer_norm1)
+    qkv = LinearFn.apply(LayerNormFn.apply(x, blk.eps, adt), w, b, None, compute, adt)
+    o = CrossAttentionFn.apply(qkv, qkv, 0, C_, 2 * C_, nb, nh, C_ // nh, Lq, Lq)
+    return _attn_tail_train(blk, o, x, compute)
+
+
+def _cross_block_train(blk, q_in, kv_in, nb, Lq, Lk, compute):
+    from .autograd import CrossAttentionFn, LayerNormFn, LinearFn
+    adt = K.act_torch_dtype(compute)
+    C_, nh = blk.emb_dim, blk.num_heads
+    Wi, bi = blk.attn.in_proj_weight, blk.attn.in_proj_bias
+    wq, bq = _fold(Wi[:C_], bi[:C_], blk.layer_norm1)
+    wkv, bkv = _fold(Wi[C_:], bi[C_:], blk.layer_norm2)
+    q = LinearFn.apply(LayerNormFn.apply(q_in, blk.eps, adt), wq, bq, None, compute, adt)
+    kv = LinearFn.apply(LayerNormFn.apply(kv_in, blk.eps, adt), wkv, bkv, None, compute, adt)
+    o = CrossAttentionFn.apply(q, kv, 0, 0, C_, nb, nh, C_ // nh, Lq, Lk)
+    return _attn_tail_train(blk, o, q_in, compute)
+
+
+def cvit_train_forward(m: CViT, x: torch.Tensor, input_coords, compute: int) -> torch.Tensor:
+    """CViT.forward with an autograd graph of HIP ops (one launch per layer; the backward kernels are tante_cross_attention_bwd,
+    tante_layernorm_affine_bwd, tante_grid_embed_bwd and the TANTE train path's dgrad / wgrad / LayerNorm / activation kernels)."""
+    from .autograd import (ActFn, DropoutAddFn, FilmPosFn, FourierEmbedFn, GridEmbedFn, LayerNormAffineFn, LayerNormFn, LinearFn)
+    adt = K.act_torch_dtype(compute)
+    b, t, c, h, w = x.shape
+    dev = x.device
+    coords = generate_coords(h, w, dev) if input_coords is None else input_coords.detach().to(dev, torch.float32).contiguous()
+    n, d = coords.shape[0], m.dec_emb_dim
+    # ---- coordinate embedding
+    if m.embedding_type == "grid":
+        lin, ln = m.embedding[0], m.embedding[1]
+        ce = GridEmbedFn.apply(coords, m.grid, m.latents, float(m.eps))
+        q1 = LayerNormAffineFn.apply(LinearFn.apply(ce, lin.weight, lin.bias, None, compute, torch.float32), ln.weight, ln.bias, ln.eps)
+    elif m.embedding_type == "fourier":
+        q1 = FourierEmbedFn.apply(coords, m.embedding[0].kernel)
+    else:
+        blk, ln = m.embedding[0], m.embedding[1]
+        hcoord = ActFn.apply(LinearFn.apply(coords, blk.fc1.weight, blk.fc1.bias, None, compute, adt), L.ACT_GELU_ERF, adt)
+        q1 = LayerNormAffineFn.apply(LinearFn.apply(hcoord, blk.fc2.weight, blk.fc2.bias, None, compute, torch.float32), ln.weight, ln.bias, ln.eps)
+    q = q1.unsqueeze(0).expand(b, n, d).reshape(b * n, d).contiguous()
+    # ---- encoder
+    enc = m.Encoder
+    pe = enc.patch_embed
+    _, ph, pw = pe.patch_size
+    cols = K.im2col(x.view(b * t, c, h, w), True, b * t, c, h, w, ph, pw, ph, pw, 0, 0, 0, adt)
+    y = LinearFn.apply(cols, pe.conv.weight.view(pe.conv.weight.shape[0], -1), pe.conv.bias, None, compute, torch.float32)
+    if pe.use_norm:
+        y = LayerNormAffineFn.apply(y, pe.layer_norm.weight, pe.layer_norm.bias, pe.layer_norm.eps)
+    s = y.shape[0] // (b * t)
+    e = enc.emb_dim
+    ones = torch.ones(t, e, dtype=torch.float32, device=dev)
+    y = FilmPosFn.apply(y, ones, enc.t_emb.view(t, e), enc.s_emb.view(s, e), t, s)
+    kv = y.view(b, t, s, e).permute(0, 2, 1, 3).reshape(b * s * t, e).contiguous()
+    ta = enc.time_agg
+    lat = ta.latents.unsqueeze(0).expand(b * s, -1, -1).reshape(b * s * ta.num_latents, e).contiguous()
+    for blk in ta.CrossAttnBlocks:
+        lat = _cross_block_train(blk, lat, kv, b * s, ta.num_latents, t, compute)
+    tl = ta.num_latents
+    if tl != 1:
+        lat = lat.view(b, s, tl, e).permute(0, 2, 1, 3).reshape(b * tl * s, e).contiguous()
+    y = LayerNormAffineFn.apply(lat, enc.layer_norm.weight, enc.layer_norm.bias, enc.layer_norm.eps)
+    for blk in enc.SelfAttnBlocks:
+        y = _self_block_train(blk, y, b, tl * s, compute)
+    # ---- decoder
+    we, be = _fold(m.E2D.weight, m.E2D.bias, m.norm1)
+    kvd = LinearFn.apply(LayerNormFn.apply(y, m.norm1.eps, adt), we, be, None, compute, torch.float32)
+    Lk = tl * s
+    for blk in m.CrossAttnBlocks:
+        kvd = _cross_block_train(blk, q, kvd, b, n, Lk, compute)
+        Lk = n
+    z = LayerNormAffineFn.apply(kvd, m.norm2.weight, m.norm2.bias, m.norm2.eps)
+    head = m.mlp
+    for i in range(head.num_layers):
+        hh = ActFn.apply(LinearFn.apply(z, head.dense_layers[i].weight, head.dense_layers[i].bias, None, compute, adt), L.ACT_GELU_ERF, adt)
+        z = DropoutAddFn.apply(hh, z, 0.0)                                   # x + gelu(dense(x))
+        ln = head.layer_norms[i]
+        z = LayerNormAffineFn.apply(z, ln.weight, ln.bias, ln.eps)
+    o = LinearFn.apply(z, head.output_layer.weight, head.output_layer.bias, None, compute, torch.float32).view(b, n, m.out_steps, c)
+    if input_coords is None:
+        return o.view(b, h, w, m.out_steps, c).permute(0, 3, 4, 1, 2)
+    return o.permute(0, 2, 1, 3)

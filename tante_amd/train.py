@@ -51,3 +51,28 @@ def train_step_adaptive(model, opt: FlatAdamW, batch: Dict[str, torch.Tensor], f
     finally:
         opt.max_norm = saved
     return loss.detach(), rts.detach()
+
+
+def train_step_cvit(model, opt: FlatAdamW, batch: Dict[str, torch.Tensor], formatter, num_query_points: int = 0, world: int = 1,
+                    lr: float = None, generator=None) -> torch.Tensor:
+    """The Trainer's step for a CViT model (trainer/trainer.py:174-207 with rollout_model / rollout_cvit, l.144-172): one model call
+    predicts all out_steps frames; num_query_points > 0 trains on that many random pixels (the `cvit: True` branch), 0 on the full
+    grid.  Loss = MSE(...).mean(); clip_grad_norm_(1.0) + AdamW through the flat buckets; one summed all-reduce when world > 1."""
+    from .harness import generate_and_extract_coords
+    opt.zero_grad()
+    device = next(model.parameters()).device
+    moving, y_ref = formatter.process_input(batch)
+    x = moving[0].to(device)
+    y_ref = y_ref.to(device)
+    if num_query_points > 0:
+        coords, y_pts = generate_and_extract_coords(y_ref, num_query_points, generator)
+        y_pred = model(x, coords)                                   # (b, t, n, d)
+        loss = MseMeanFn.apply(y_pred.unsqueeze(3), y_pts.unsqueeze(3).contiguous())
+    else:
+        y_pred = formatter.process_output(model(x))                 # (b, t, h, w, d) view of the prediction
+        loss = MseMeanFn.apply(y_pred, y_ref[:, :y_pred.shape[1]].contiguous())
+    loss.backward()
+    if world > 1:
+        D.allreduce_sum_(opt.flat_g)
+    opt.step(grad_scale=1.0 / world, lr=lr)
+    return loss.detach()

@@ -1025,3 +1025,114 @@ def test_wgrad_dma_transposed_read_path(dev, R, I, J):
     wgrad(_rm_linear(Ud), _rm_linear(Vd), R, I, J, (I, J), L.BF16, device=dev, with_bias=True, into=accW, db_into=accb)
     close(accW, ref + base, "bf16", scale=0.2)
     close(accb, refb + baseb, "bf16", scale=0.2)
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+@pytest.mark.parametrize("name", ["grid", "gridwide", "fourier", "mlp"])
+def test_cvit_gradients_against_oracle_autograd(dev, name, mode):
+    """CViT training path: every parameter's gradient of a random linear functional of the output, HIP backward kernels
+    (cross-attention, LayerNorm-affine, grid embedding, dgrad / wgrad GEMMs) against torch.autograd through the CPU oracle."""
+    import tante_amd
+    from test_oracle_golden import CVIT_CASES
+    from oracle import cvit_oracle as OC
+    g = load_golden("g11_cvit_" + name)
+    kw, nf, res = CVIT_CASES[name]
+    base = dict(out_steps=3, patch_size=(1, 8, 8), grid_size=(8, 8), latent_dim=24, emb_dim=32, depth=2, num_heads=4, dec_emb_dim=48,
+                dec_num_heads=4, dec_depth=1, num_mlp_layers=1, mlp_ratio=1)
+    base.update(kw)
+    m = tante_amd.CViT(4, tante_amd.TanteMetadata(n_fields=nf, spatial_resolution=res), **base).to(dev).train()
+    m.load_state_dict(split_prefix(g, "w."), strict=True)
+    m.set_compute(mode)
+    coords = g.get("coords")
+    x = g["x"]
+    torch.manual_seed(7)
+    proj = torch.randn(g["y"].shape)
+    y = m(x.to(dev)) if coords is None else m(x.to(dev), coords.to(dev))
+    close(y, g["y"], mode)
+    (y * proj.to(dev)).sum().backward()
+    w = {k: v.clone().requires_grad_(True) for k, v in split_prefix(g, "w.").items()}
+    yo = OC.cvit_forward(w, OC.CvitCfg(4, nf, res, **base), x, coords)
+    (yo * proj).sum().backward()
+    # fp32: every parameter to 2e-4.  bf16: matrices to 4e-2; vectors (biases, LayerNorm affine: sums with heavy cancellation over
+    # bf16-rounded activations) to 0.25 each, and the whole gradient (all parameters concatenated) to 4e-2.
+    tol = 2e-4 if mode == "fp32" else 4e-2
+    mine, refs = [], []
+    for k, p in m.named_parameters():
+        ref = w[k].grad
+        assert p.grad is not None and ref is not None, k
+        mine.append(p.grad.detach().cpu().flatten())
+        refs.append(ref.detach().flatten())
+        if float(ref.norm()) < 1e-6 * max(1.0, float(w[k].detach().norm())):   # identically ~0 in the reference (e.g. far grid nodes)
+            assert float(p.grad.norm()) < 1e-4, k
+            continue
+        r = rel_err(p.grad.detach().cpu(), ref.detach())
+        if mode == "fp32" or ref.dim() >= 2:
+            assert r < tol, f"{k}: rel {r:.3e}"
+        else:   # small vectors: relative to their own norm or to a sliver of the whole gradient's norm, whichever is larger
+            gn = float(torch.cat([t.flatten() for t in (v.grad for v in w.values()) if t is not None]).norm())
+            err = float((p.grad.detach().cpu() - ref.detach()).norm())
+            assert err < 0.25 * float(ref.norm()) + 2e-3 * gn, f"{k}: err {err:.3e} ref {float(ref.norm()):.3e} total {gn:.3e}"
+    assert rel_err(torch.cat(mine), torch.cat(refs)) < tol
+
+
+def test_linear_fn_long_contraction(dev):
+    """LinearFn with K > 512 (CViT's 16 x 16 patch embed at full size): forward chunks and gradients against torch."""
+    from tante_amd.autograd import LinearFn
+    from tante_amd import _lib as L
+    torch.manual_seed(9)
+    a = torch.randn(300, 1024)
+    W = (torch.randn(96, 1024) * 0.05).requires_grad_(True)
+    b = torch.randn(96).requires_grad_(True)
+    ref = a @ W.t() + b
+    ref.square().sum().backward()
+    Wd, bd = W.detach().to(dev).requires_grad_(True), b.detach().to(dev).requires_grad_(True)
+    out = LinearFn.apply(a.to(dev), Wd, bd, None, L.F32, torch.float32)
+    close(out, ref, "fp32")
+    out.square().sum().backward()
+    close(Wd.grad, W.grad, "fp32", scale=20.0)
+    close(bd.grad, b.grad, "fp32", scale=20.0)
+
+
+@pytest.mark.parametrize("nq", [0, 64])
+def test_cvit_train_steps_reduce_the_loss_and_match_torch_adamw(dev, nq):
+    """Two CViT optimisation steps on the HIP path against the same two steps through the oracle + torch.optim.AdamW (full grid and
+    random query points)."""
+    import tante_amd
+    from oracle import cvit_oracle as OC
+    kw = dict(out_steps=2, patch_size=(1, 8, 8), grid_size=(16, 16), latent_dim=24, emb_dim=32, depth=1, num_heads=4, dec_emb_dim=32,
+              dec_num_heads=4, dec_depth=1, num_mlp_layers=1, mlp_ratio=1, eps=200.0)
+    md = tante_amd.TanteMetadata(n_fields=2, spatial_resolution=(16, 16))
+    torch.manual_seed(21)
+    m = tante_amd.CViT(4, md, **kw).to(dev).train().set_compute("fp32")
+    w = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    fmt = tante_amd.DefaultChannelsFirstFormatter(md)
+    batch = {"input": torch.randn(2, 4, 16, 16, 2), "output": torch.randn(2, 2, 16, 16, 2)}
+    opt = tante_amd.FlatAdamW(m.parameters(), lr=1e-3, weight_decay=1e-5, max_norm=1.0)
+    ropt = torch.optim.AdamW(list(w.values()), lr=1e-3, weight_decay=1e-5)
+    cfg = OC.CvitCfg(4, 2, (16, 16), **kw)
+    losses = []
+    for step in range(2):
+        gen = torch.Generator(device=dev).manual_seed(100 + step) if nq else None
+        losses.append(float(tante_amd.train_step_cvit(m, opt, {k: v.to(dev) for k, v in batch.items()}, fmt, nq, generator=gen)))
+        # reference step
+        ropt.zero_grad()
+        x, y_ref = fmt.process_input(batch)
+        if nq:
+            gen2 = torch.Generator(device=dev).manual_seed(100 + step)
+            coords, y_pts = tante_amd.harness.generate_and_extract_coords(y_ref.to(dev), nq, gen2)
+            yo = OC.cvit_forward(w, cfg, x[0], coords.cpu())
+            lo = ((yo - y_pts.cpu()) ** 2).mean()
+        else:
+            yo = OC.cvit_forward(w, cfg, x[0])
+            lo = ((fmt.process_output(yo) - y_ref) ** 2).mean()
+        lo.backward()
+        torch.nn.utils.clip_grad_norm_(list(w.values()), 1.0)
+        ropt.step()
+        assert abs(losses[-1] - float(lo.detach())) < 1e-4 * max(1.0, float(lo.detach()))
+    # AdamW normalises each entry's step to ~lr whatever the gradient's size, so entries whose gradient is ~0 (latent-grid nodes no query
+    # reaches: exactly 0 here, 1e-40 through torch) may differ by a full step; everything else must agree closely
+    for k, p in m.named_parameters():
+        d = (p.detach().cpu() - w[k].detach()).abs()
+        assert float(d.max()) <= 2.2 * 1e-3 * 2, k
+        assert rel_err(p.detach().cpu(), w[k].detach()) < 1e-2, k
+    assert losses[1] < losses[0]
