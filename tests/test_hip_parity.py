@@ -1136,3 +1136,32 @@ def test_cvit_train_steps_reduce_the_loss_and_match_torch_adamw(dev, nq):
         assert float(d.max()) <= 2.2 * 1e-3 * 2, k
         assert rel_err(p.detach().cpu(), w[k].detach()) < 1e-2, k
     assert losses[1] < losses[0]
+
+
+def test_cfg5_spectral_path_full_size_properties(dev):
+    """cfg5 (configs/tante_fno.yaml, 512 x 512 x 8 fields, modes 20 x 20) at full size: too large for the oracle in seconds, so
+    size-independent properties -- (a) the spectral layer is linear: L(a x + b y) = a L(x) + b L(y) - (a + b - 1) L(0);
+    (b) a field whose spectrum lies outside the kept modes passes through the spectral branch as zero (only the 1x1 conv acts);
+    (c) the whole model runs a rollout step and agrees between fp32 and bf16 compute to the bf16 bar."""
+    import tante_amd
+    from tante_amd.spectral import SpectralLayer
+    torch.manual_seed(3)
+    lay = SpectralLayer(8, 32, 20, 20).to(dev)
+    x, y = torch.randn(2, 8, 512, 512, device=dev), torch.randn(2, 8, 512, 512, device=dev)
+    with torch.no_grad():
+        l0 = lay(torch.zeros_like(x))
+        close(lay(0.7 * x - 1.3 * y), 0.7 * lay(x) - 1.3 * lay(y) + 1.6 * l0, "fp32", scale=20.0)
+        ii, jj = torch.meshgrid(torch.arange(512, device=dev), torch.arange(512, device=dev), indexing="ij")
+        hf = torch.cos(2 * math.pi * (100 * ii + 37 * jj) / 512).expand(2, 8, 512, 512).contiguous()     # mode (100, 37): outside 20 x 20
+        conv_only = torch.nn.functional.conv2d(hf, lay.w0.weight, lay.w0.bias)
+        close(lay(hf), conv_only, "fp32", scale=20.0)
+    cfg = tante_amd.load_config(os.path.join(os.path.dirname(GOLDEN), "..", "configs", "tante_fno.yaml"))
+    wl = cfg["workload"]
+    md = tante_amd.TanteMetadata(n_fields=wl["n_fields"], spatial_resolution=tuple(wl["spatial_resolution"]))
+    m = tante_amd.build_model(cfg, md).to(dev).eval()
+    xin = torch.randn(1, 4, 8, 512, 512, device=dev)
+    with torch.no_grad():
+        y32 = m.set_compute("fp32")(xin)
+        y16 = m.set_compute("bf16")(xin)
+    assert y32.shape == (1, 1, 8, 512, 512) and torch.isfinite(y32).all()
+    close(y16, y32, "bf16")
