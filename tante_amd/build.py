@@ -13,6 +13,8 @@ SOURCES = ["gemm.hip", "attention.hip", "pointwise.hip", "block_fused.hip", "tra
 HEADERS = [os.path.join(CSRC, "common.cuh"), os.path.join(CSRC, "fused_common.cuh"), os.path.join(os.path.dirname(HERE), "include", "tante_hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=fast"]
+# the fused bf16 kernels are bound by VALU issue: without NaN-honouring every fmaxf / clamp loses its v_max canonicalisation
+EXTRA_FLAGS = {"block_fused.hip": ["-fno-honor-nans"], "head_fused.hip": ["-fno-honor-nans"], "enc_fused.hip": ["-fno-honor-nans"]}
 
 
 def _stale(target, deps):
@@ -30,7 +32,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         op = os.path.join(LIBDIR, src.replace(".hip", ".o"))
         objs.append(op)
         if force or _stale(op, [sp] + HEADERS):
-            jobs.append([HIPCC, *FLAGS, "-c", sp, "-o", op])
+            jobs.append([HIPCC, *FLAGS, *EXTRA_FLAGS.get(src, []), "-c", sp, "-o", op])
 
     def run(cmd):
         if verbose:
