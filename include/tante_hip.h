@@ -237,6 +237,21 @@ int64_t tante_spectral_workspace_bytes(int64_t n, int Cin, int Cout, int H, int 
 int tante_spectral_layer(const float* x, int64_t n, int Cin, int H, int W, const float* w_re, const float* w_im, int wm1, int wm2,
                          int modes1, int modes2, const float* w0, const float* b0, int Cout, int act, float* out, void* work,
                          int64_t work_bytes, void* stream);
+/* Backward of tante_spectral_layer (act none): dx (n, Cin, H, W) = irfft2(M^H rfft2(dy)) + W0^T dy, and the complex weight gradient
+ * dw_re / dw_im (Cin, Cout, wm1, wm2) in PyTorch's convention (dL/dRe + i dL/dIm).  w0t: the 1x1 weight transposed, (Cin, Cout).
+ * The 1x1 conv's own weight / bias gradients are ordinary reductions (tante_wgrad lines, tante_colsum). */
+int tante_spectral_layer_bwd(const float* x, const float* dy, int64_t n, int Cin, int H, int W, const float* w_re, const float* w_im, int wm1,
+                             int wm2, int modes1, int modes2, const float* w0t, int Cout, float* dx, float* dw_re, float* dw_im, void* work,
+                             int64_t work_bytes, void* stream);
+/* tante_col2im_nhwc with an explicit output size: the input gradient of a (padded / strided) convolution whose patch-matrix gradient is
+ * `cols` with columns (kh, kw, c) -- pixels no patch covers stay zero. */
+int tante_col2im_nhwc_sized(const void* cols, int cols_dtype, int64_t n_img, int Hi, int Wi, int P, int stride, int pad, int Cout,
+                            const float* bias, int Hf, int Wf, void* out, int out_dtype, void* stream);
+/* Backward of tante_resize_bilinear: the gradient of every output pixel is ADDED (fp32 atomics) to its source pixels in `din`
+ * (zero it first); same addressing convention as the forward. */
+int tante_resize_bilinear_bwd(const void* dout, int d_dtype, int64_t n_img, int C, int Hi, int Wi, int crop_y, int crop_x, int64_t isn,
+                              int64_t isc, int64_t ish, int64_t isw, int Ho, int Wo, int64_t osn, int64_t osc, int64_t osh, int64_t osw,
+                              float* din, void* stream);
 /* softmax(q k^T / sqrt(D)) v per (batch, head) with separate query and key/value sequences -- the core of
  * nn.MultiheadAttention(q, kv, kv) in CViT's CrossAttnBlock / TimeAggregation / SelfAttnBlock (cvit.py:125, 162, 199-204).
  * Rows: q (b, i) at (b*Lq + i)*ldq + h*D, k / v (b, j) at (b*Lk + j)*ldkv + h*D, o at (b*Lq + i)*ldo + h*D (elements). */

@@ -77,6 +77,11 @@ SIGNATURES = {
     "tante_spectral_workspace_bytes": ([c_i64, c_i32, c_i32, c_i32, c_i32], c_i64),
     "tante_spectral_layer": ([c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp,
                               c_i64, c_vp], c_i32),
+    "tante_spectral_layer_bwd": ([c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp,
+                                  c_vp, c_i64, c_vp], c_i32),
+    "tante_col2im_nhwc_sized": ([c_vp, c_i32, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_i32, c_vp, c_i32, c_vp], c_i32),
+    "tante_resize_bilinear_bwd": ([c_vp, c_i32, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_i64, c_i64, c_i64, c_i64, c_i32, c_i32, c_i64, c_i64,
+                                   c_i64, c_i64, c_vp, c_vp], c_i32),
     "tante_cross_attention": ([c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_i32, c_i32, c_i32, c_i64, c_i64, c_i64, c_vp], c_i32),
     "tante_cross_attention_bwd": ([c_vp] * 9 + [c_i32, c_i64, c_i32, c_i32, c_i32, c_i32, c_i64, c_i64, c_i64, c_i64, c_vp], c_i32),
     "tante_layernorm_affine_bwd": ([c_vp, c_i32, c_vp, c_i32, c_vp, c_i64, c_i32, c_f32, c_vp, c_vp, c_vp, c_vp], c_i32),

@@ -577,3 +577,88 @@ class FourierEmbedFn(Function):
         half = out.shape[1] // 2
         ddp = dout[:, half:].float() * out[:, :half] - dout[:, :half].float() * out[:, half:]     # d/d(c.K): -sin dcos + cos dsin
         return None, coords.t() @ ddp
+
+
+# ---- spectral operator path training ops (enc_dec_fno.py) -------------------------------------------------------------------------
+class SpectralLayerFn(Function):
+    """SpectralLayer.forward without activation; x (n, Cin, H, W) fp32 contiguous, weight complex (Cin, Cout, m1, m2), w0 (Cout, Cin, 1, 1)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, w0_w, w0_b, modes1, modes2):
+        x = x.contiguous()
+        wd = weight.detach()
+        re, im = wd.real.contiguous(), wd.imag.contiguous()
+        Cout, Cin = w0_w.shape[0], w0_w.shape[1]
+        y = K.spectral_layer(x, re, im, modes1, modes2, w0_w.detach().view(Cout, Cin), w0_b.detach(), L.ACT_NONE)
+        ctx.save_for_backward(x, re, im, w0_w)
+        ctx.modes = (modes1, modes2)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, re, im, w0_w = ctx.saved_tensors
+        m1, m2 = ctx.modes
+        dy = dy.contiguous().float()
+        n, Cin, H, W = x.shape
+        Cout = w0_w.shape[0]
+        w0t = w0_w.detach().view(Cout, Cin).t().contiguous()
+        dx = torch.empty_like(x)
+        dre, dim_ = torch.empty_like(re), torch.empty_like(im)
+        nbytes = L.lib().tante_spectral_workspace_bytes(n, Cin, Cout, H, W)
+        work = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        L.check(L.lib().tante_spectral_layer_bwd(x.data_ptr(), dy.data_ptr(), n, Cin, H, W, re.data_ptr(), im.data_ptr(), re.shape[2], re.shape[3],
+                                                 m1, m2, w0t.data_ptr(), Cout, dx.data_ptr(), dre.data_ptr(), dim_.data_ptr(), work.data_ptr(),
+                                                 nbytes, _s()), "tante_spectral_layer_bwd")
+        # the 1x1 conv's parameters: channels-first "lines" (rows = pixels, column stride = H W), like the axis propagators
+        HW = H * W
+
+        def lines(t, Cc):
+            return _rm_linear(t, n0=HW, s1=Cc * HW, s0=1, es=HW, cols=Cc)
+        dw0 = wgrad(lines(dy, Cout), lines(x, Cin), n * HW, Cout, Cin, (Cout, Cin), L.F32, device=x.device).view(w0_w.shape)
+        db0 = colsum(dy, n, Cout, HW)
+        return dx, torch.complex(dre, dim_), dw0, db0, None, None
+
+
+class Im2colFn(Function):
+    """Patch matrix of a channels-last image, columns (kh, kw, c); backward = gather-sum of the overlapping / padded patches."""
+
+    @staticmethod
+    def forward(ctx, x, n_img, C_, H, W, P, stride, pad, out_dtype):
+        cols = K.im2col(x.contiguous(), False, n_img, C_, H, W, P, P, stride, stride, pad, pad, 1, out_dtype)
+        ctx.geo = (n_img, C_, H, W, P, stride, pad, x.dtype)
+        return cols
+
+    @staticmethod
+    def backward(ctx, dcols):
+        n_img, C_, H, W, P, stride, pad, xdt = ctx.geo
+        dcols = dcols.contiguous()
+        Ho, Wo = (H + 2 * pad - P) // stride + 1, (W + 2 * pad - P) // stride + 1
+        dx = torch.empty(n_img, H, W, C_, dtype=xdt, device=dcols.device)
+        L.check(L.lib().tante_col2im_nhwc_sized(dcols.data_ptr(), _DT[dcols.dtype], n_img, Ho, Wo, P, stride, pad, C_, None, H, W, dx.data_ptr(),
+                                                _DT[xdt], _s()), "tante_col2im_nhwc_sized")
+        return dx, None, None, None, None, None, None, None, None
+
+
+class CropResizeFn(Function):
+    """Bilinear resize (align_corners=False) of the window (crop, Hi x Wi) of a channels-last image to (Ho, Wo), channels-last or -first out."""
+
+    @staticmethod
+    def forward(ctx, full, n_img, C_, Hi, Wi, crop, Ho, Wo, nchw_out, out_dtype):
+        full = full.contiguous()
+        Hf, Wf = full.shape[1], full.shape[2]
+        shape = (n_img, C_, Ho, Wo) if nchw_out else (n_img, Ho, Wo, C_)
+        out = torch.empty(shape, dtype=out_dtype, device=full.device)
+        istr = (Hf * Wf * C_, 1, Wf * C_, C_)
+        ostr = (C_ * Ho * Wo, Ho * Wo, Wo, 1) if nchw_out else (Ho * Wo * C_, 1, Wo * C_, C_)
+        K.resize_bilinear(full, n_img, C_, Hi, Wi, crop, istr, Ho, Wo, out, ostr, L.ACT_NONE)
+        ctx.geo = (n_img, C_, Hi, Wi, crop, Ho, Wo, istr, ostr, tuple(full.shape), full.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        n_img, C_, Hi, Wi, crop, Ho, Wo, istr, ostr, fshape, fdt = ctx.geo
+        dout = dout.contiguous()
+        din = torch.zeros(fshape, dtype=torch.float32, device=dout.device)
+        L.check(L.lib().tante_resize_bilinear_bwd(dout.data_ptr(), _DT[dout.dtype], n_img, C_, Hi, Wi, crop[0], crop[1], *istr, Ho, Wo, *ostr,
+                                                  din.data_ptr(), _s()), "tante_resize_bilinear_bwd")
+        return din.to(fdt), None, None, None, None, None, None, None, None, None

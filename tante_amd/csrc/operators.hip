@@ -730,6 +730,97 @@ __global__ __launch_bounds__(256) void grid_embed_bwd_kernel(const float* __rest
   if (tid == 0) { dgrid[2 * g] = dgx; dgrid[2 * g + 1] = dgy; }
 }
 
+// ---- spectral layer, backward ----------------------------------------------------------------------------------------------------
+// With 'ortho' transforms the layer's spectral branch is y = A(M(B(x))): B = rfft2, M the per-mode contraction, A = irfft2 (a real-linear
+// map that counts every interior half-spectrum column twice: D_j = 1 for j = 0 and j = W/2 (W even), 2 otherwise).  The adjoints are
+// A* = D . rfft2 and B* = irfft2 . (1/D); M is diagonal in (i, j), so the D factors cancel in the input gradient
+//     dx = irfft2(M^H rfft2(dy))
+// and survive in the weight gradient            dW[c, o, wi, j] = D_j sum_b sum_{rows i -> wi} conj(X[b, c, i, j]) R[b, o, i, j],  R = rfft2(dy).
+// Unnormalised hipFFT transforms are used throughout, so both carry the factor 1 / (H W).
+__global__ void spectral_adjoint_kernel(const float2* __restrict__ R, const float* __restrict__ w_re, const float* __restrict__ w_im, long n,
+                                        int Cin, int Cout, int H, int Wf, int m1, int m2, int wm1, int wm2, float scale, float2* __restrict__ dX) {
+  const long total = n * Cin * H * Wf;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int j = (int)(idx % Wf);
+    long r = idx / Wf;
+    const int i = (int)(r % H); r /= H;
+    const int c = (int)(r % Cin);
+    const long b = r / Cin;
+    float2 acc = make_float2(0.f, 0.f);
+    int wi = -1;
+    if (j < m2) {
+      if (i >= H - m1) wi = i - (H - m1);
+      else if (i < m1) wi = i;
+    }
+    if (wi >= 0) {
+      for (int o = 0; o < Cout; ++o) {
+        const float2 rv = R[((b * Cout + o) * H + i) * Wf + j];
+        const long wo = (((long)c * Cout + o) * wm1 + wi) * wm2 + j;
+        const float wr = w_re[wo], wim = w_im[wo];
+        acc.x += rv.x * wr + rv.y * wim;     // R * conj(W)
+        acc.y += rv.y * wr - rv.x * wim;
+      }
+      acc.x *= scale; acc.y *= scale;
+    }
+    dX[idx] = acc;
+  }
+}
+
+__global__ void spectral_wgrad_kernel(const float2* __restrict__ X, const float2* __restrict__ R, long n, int Cin, int Cout, int H, int W, int Wf,
+                                      int m1, int m2, int wm1, int wm2, float scale, float* __restrict__ dw_re, float* __restrict__ dw_im) {
+  const long total = (long)Cin * Cout * wm1 * wm2;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int j = (int)(idx % wm2);
+    long r = idx / wm2;
+    const int wi = (int)(r % wm1); r /= wm1;
+    const int o = (int)(r % Cout);
+    const int c = (int)(r / Cout);
+    float2 acc = make_float2(0.f, 0.f);
+    if (wi < m1 && j < m2) {
+      const int itop = wi, ibot = H - m1 + wi;
+      const bool use_top = itop < H - m1;            // a top row inside the bottom band was overwritten in the forward
+      for (long b = 0; b < n; ++b) {
+        for (int which = 0; which < 2; ++which) {
+          if (which == 0 && !use_top) continue;
+          const int i = which ? ibot : itop;
+          const float2 xv = X[((b * Cin + c) * H + i) * Wf + j], rv = R[((b * Cout + o) * H + i) * Wf + j];
+          acc.x += xv.x * rv.x + xv.y * rv.y;        // conj(X) * R
+          acc.y += xv.x * rv.y - xv.y * rv.x;
+        }
+      }
+      const float d = (j == 0 || ((W & 1) == 0 && j == W / 2)) ? 1.0f : 2.0f;
+      acc.x *= scale * d; acc.y *= scale * d;
+    }
+    dw_re[idx] = acc.x;
+    dw_im[idx] = acc.y;
+  }
+}
+
+// ---- bilinear resize (+ crop) backward: every output pixel hands its gradient to its (up to) four source pixels --------------------
+__global__ void resize_bwd_kernel(const void* __restrict__ dout, int d_dtype, long n_img, int C, int Hi, int Wi, int cy, int cx, long isn, long isc,
+                                  long ish, long isw, int Ho, int Wo, long osn, long osc, long osh, long osw, float* __restrict__ din, int c_fast) {
+  const long total = n_img * C * Ho * Wo;
+  const float sy = (float)Hi / (float)Ho, sx = (float)Wi / (float)Wo;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    int c, oy, ox;
+    long img;
+    if (c_fast) { c = (int)(idx % C); long r = idx / C; ox = (int)(r % Wo); r /= Wo; oy = (int)(r % Ho); img = r / Ho; }
+    else { ox = (int)(idx % Wo); long r = idx / Wo; oy = (int)(r % Ho); r /= Ho; c = (int)(r % C); img = r / C; }
+    float fy = sy * ((float)oy + 0.5f) - 0.5f, fx = sx * ((float)ox + 0.5f) - 0.5f;
+    fy = fy < 0.0f ? 0.0f : fy;
+    fx = fx < 0.0f ? 0.0f : fx;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + (y0 < Hi - 1 ? 1 : 0), x1 = x0 + (x0 < Wi - 1 ? 1 : 0);
+    const float ly = fy - (float)y0, lx = fx - (float)x0;
+    const float g = ldx(dout, d_dtype, img * osn + c * osc + oy * osh + ox * osw);
+    const long base = img * isn + c * isc;
+    atomicAdd(din + base + (y0 + cy) * ish + (x0 + cx) * isw, g * (1.0f - ly) * (1.0f - lx));
+    atomicAdd(din + base + (y0 + cy) * ish + (x1 + cx) * isw, g * (1.0f - ly) * lx);
+    atomicAdd(din + base + (y1 + cy) * ish + (x0 + cx) * isw, g * ly * (1.0f - lx));
+    atomicAdd(din + base + (y1 + cy) * ish + (x1 + cx) * isw, g * ly * lx);
+  }
+}
+
 inline unsigned grid_for(long total, int block = 256) {
   long g = (total + block - 1) / block;
   return (unsigned)(g > 1048576 ? 1048576 : (g < 1 ? 1 : g));
@@ -771,6 +862,16 @@ extern "C" int tante_avgpool_nhwc(const void* x, int x_dtype, int64_t n_img, int
   if (!x || !y || n_img <= 0 || H <= 0 || W <= 0 || C <= 0 || Ht <= 0 || Wt <= 0) TANTE_FAIL(-1, "tante_avgpool_nhwc: bad argument");
   hipLaunchKernelGGL(avgpool_kernel, dim3(grid_for((long)n_img * Ht * Wt * C)), dim3(256), 0, (hipStream_t)stream, x, x_dtype, (long)n_img, H, W,
                      C, Ht, Wt, act, y, y_dtype);
+  TANTE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int tante_col2im_nhwc_sized(const void* cols, int cols_dtype, int64_t n_img, int Hi, int Wi, int P, int stride, int pad, int Cout,
+                                       const float* bias, int Hf, int Wf, void* out, int out_dtype, void* stream) {
+  if (!cols || !out || n_img <= 0 || Hi <= 0 || Wi <= 0 || P <= 0 || stride <= 0 || pad < 0 || Cout <= 0 || Hf <= 0 || Wf <= 0)
+    TANTE_FAIL(-1, "tante_col2im_nhwc_sized: bad argument");
+  hipLaunchKernelGGL(col2im_kernel, dim3(grid_for((long)n_img * Hf * Wf * Cout)), dim3(256), 0, (hipStream_t)stream, cols, cols_dtype, (long)n_img,
+                     Hi, Wi, P, stride, pad, Cout, bias, Hf, Wf, out, out_dtype);
   TANTE_CHECK_LAUNCH();
   return 0;
 }
@@ -837,6 +938,55 @@ extern "C" int tante_spectral_layer(const float* x, int64_t n, int Cin, int H, i
   if (lds > 64 * 1024) hipFuncSetAttribute((const void*)conv1x1_add_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   const long HW = (long)H * W;
   hipLaunchKernelGGL(conv1x1_add_kernel, dim3((unsigned)((HW + 63) / 64), (unsigned)n), dim3(256), lds, s, x, w0, b0, out, HW, Cin, Cout, act, out);
+  TANTE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int tante_resize_bilinear_bwd(const void* dout, int d_dtype, int64_t n_img, int C, int Hi, int Wi, int crop_y, int crop_x, int64_t isn,
+                                         int64_t isc, int64_t ish, int64_t isw, int Ho, int Wo, int64_t osn, int64_t osc, int64_t osh,
+                                         int64_t osw, float* din, void* stream) {
+  if (!dout || !din || n_img <= 0 || C <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0) TANTE_FAIL(-1, "tante_resize_bilinear_bwd: bad argument");
+  hipLaunchKernelGGL(resize_bwd_kernel, dim3(grid_for((long)n_img * C * Ho * Wo)), dim3(256), 0, (hipStream_t)stream, dout, d_dtype, (long)n_img, C,
+                     Hi, Wi, crop_y, crop_x, (long)isn, (long)isc, (long)ish, (long)isw, Ho, Wo, (long)osn, (long)osc, (long)osh, (long)osw, din,
+                     (int)(osc == 1));
+  TANTE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int tante_spectral_layer_bwd(const float* x, const float* dy, int64_t n, int Cin, int H, int W, const float* w_re, const float* w_im,
+                                        int wm1, int wm2, int modes1, int modes2, const float* w0t, int Cout, float* dx, float* dw_re,
+                                        float* dw_im, void* work, int64_t work_bytes, void* stream) {
+  if (!x || !dy || !w_re || !w_im || !w0t || !dx || !dw_re || !dw_im || !work || n <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0)
+    TANTE_FAIL(-1, "tante_spectral_layer_bwd: bad argument");
+  if (work_bytes < tante_spectral_workspace_bytes(n, Cin, Cout, H, W)) TANTE_FAIL(-1, "tante_spectral_layer_bwd: workspace too small");
+  const int Wf = W / 2 + 1;
+  const int m1 = modes1 < H ? modes1 : H, m2 = modes2 < Wf ? modes2 : Wf;
+  if (m1 > wm1 || m2 > wm2) TANTE_FAIL(-1, "tante_spectral_layer_bwd: weight holds fewer modes than used");
+  hipStream_t s = (hipStream_t)stream;
+  float2* XS = (float2*)work;                       // Cin-sized spectrum: first dX, later X
+  float2* R = XS + (long)n * Cin * H * Wf;          // Cout-sized spectrum of dy
+  hipfftHandle fwd_in, fwd_out, inv_in;
+  if (get_plan(H, W, (long)n * Cin, 0, &fwd_in) || get_plan(H, W, (long)n * Cout, 0, &fwd_out) || get_plan(H, W, (long)n * Cin, 1, &inv_in))
+    TANTE_FAIL(-3, "tante_spectral_layer_bwd: hipfftPlanMany failed");
+  if (hipfftSetStream(fwd_in, s) != HIPFFT_SUCCESS || hipfftSetStream(fwd_out, s) != HIPFFT_SUCCESS || hipfftSetStream(inv_in, s) != HIPFFT_SUCCESS)
+    TANTE_FAIL(-3, "tante_spectral_layer_bwd: hipfftSetStream failed");
+  const float scale = 1.0f / ((float)H * (float)W);
+  if (hipfftExecR2C(fwd_out, (hipfftReal*)dy, (hipfftComplex*)R) != HIPFFT_SUCCESS) TANTE_FAIL(-3, "tante_spectral_layer_bwd: R2C(dy) failed");
+  hipLaunchKernelGGL(spectral_adjoint_kernel, dim3(grid_for((long)n * Cin * H * Wf)), dim3(256), 0, s, R, w_re, w_im, (long)n, Cin, Cout, H, Wf, m1,
+                     m2, wm1, wm2, scale, XS);
+  TANTE_CHECK_LAUNCH();
+  if (hipfftExecC2R(inv_in, (hipfftComplex*)XS, (hipfftReal*)dx) != HIPFFT_SUCCESS) TANTE_FAIL(-3, "tante_spectral_layer_bwd: C2R failed");
+  // + the 1x1 conv's input gradient: dx += W0^T dy  (same kernel as the forward, roles of Cin / Cout swapped)
+  const size_t lds = ((size_t)Cout * 64 + (size_t)Cin * Cout) * sizeof(float);
+  if (lds > 160 * 1024) TANTE_FAIL(-2, "tante_spectral_layer_bwd: 1x1 weight %d x %d does not fit LDS", Cout, Cin);
+  if (lds > 64 * 1024) hipFuncSetAttribute((const void*)conv1x1_add_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const long HW = (long)H * W;
+  hipLaunchKernelGGL(conv1x1_add_kernel, dim3((unsigned)((HW + 63) / 64), (unsigned)n), dim3(256), lds, s, dy, w0t, (const float*)nullptr, dx, HW, Cout,
+                     Cin, TANTE_ACT_NONE, dx);
+  TANTE_CHECK_LAUNCH();
+  if (hipfftExecR2C(fwd_in, (hipfftReal*)x, (hipfftComplex*)XS) != HIPFFT_SUCCESS) TANTE_FAIL(-3, "tante_spectral_layer_bwd: R2C(x) failed");
+  hipLaunchKernelGGL(spectral_wgrad_kernel, dim3(grid_for((long)Cin * Cout * wm1 * wm2)), dim3(256), 0, s, XS, R, (long)n, Cin, Cout, H, W, Wf, m1, m2,
+                     wm1, wm2, scale, dw_re, dw_im);
   TANTE_CHECK_LAUNCH();
   return 0;
 }

@@ -27,7 +27,9 @@ class FlatAdamW:
         if dev.type != "cuda":
             raise RuntimeError("FlatAdamW runs on the GPU only (no CPU fallback)")
         self.lr, self.weight_decay, self.betas, self.eps, self.max_norm = lr, weight_decay, betas, eps, max_norm
-        sizes = [p.numel() for p in self.params]
+        # complex parameters (the spectral layers' weights) live in the buckets as (re, im) pairs, which is also how torch.optim.AdamW
+        # treats them (view_as_real)
+        sizes = [p.numel() * (2 if p.is_complex() else 1) for p in self.params]
         offs, n = [], 0
         for sz in sizes:
             offs.append(n)
@@ -40,6 +42,11 @@ class FlatAdamW:
         self._sumsq = torch.zeros(1, dtype=torch.float64, device=dev)
         with torch.no_grad():
             for p, o, sz in zip(self.params, offs, sizes):
+                if p.is_complex():
+                    self.flat_p[o:o + sz].copy_(torch.view_as_real(p.detach()).reshape(-1))
+                    p.data = torch.view_as_complex(self.flat_p[o:o + sz].view(*p.shape, 2))
+                    p.grad = torch.view_as_complex(self.flat_g[o:o + sz].view(*p.shape, 2))
+                    continue
                 self.flat_p[o:o + sz].copy_(p.detach().reshape(-1))
                 p.data = self.flat_p[o:o + sz].view(p.shape)          # the parameter now lives in the bucket
                 p.grad = self.flat_g[o:o + sz].view(p.shape)
@@ -52,8 +59,9 @@ class FlatAdamW:
     def _views(self, flat: torch.Tensor):
         out, n = [], 0
         for p in self.params:
-            out.append(flat[n:n + p.numel()].view(p.shape))
-            n += (p.numel() + 3) // 4 * 4
+            sz = p.numel() * (2 if p.is_complex() else 1)
+            out.append(torch.view_as_complex(flat[n:n + sz].view(*p.shape, 2)) if p.is_complex() else flat[n:n + sz].view(p.shape))
+            n += (sz + 3) // 4 * 4
         return out
 
     def state_dict(self):

@@ -174,3 +174,60 @@ class dec_FNO(nn.Module):
         src = x.detach().float().contiguous()
         y = self.forward_tokens(src, B * T, resolve_compute(None), B * T * Hp * Wp, 0, C_, 0)
         return y.view(B, T, *y.shape[1:])
+
+
+# ---- differentiable (training) forward of the spectral encoder / decoder ---------------------------------------------------------------
+def _conv_stage_train(z_nchw: torch.Tensor, conv: nn.Conv2d, P: int, overlap: float, compute: int, out_dtype: torch.dtype):
+    """RealConv2d on the train path: channels-last im2col (its backward is the gather-sum col2im) + LinearFn; -> (rows, Cout), (h, w)."""
+    from .autograd import Im2colFn, LinearFn
+    n, C_, H, W = z_nchw.shape
+    st, pd = S.stride_pad(P, overlap)
+    Ho, Wo = (H + 2 * pd - P) // st + 1, (W + 2 * pd - P) // st + 1
+    if (Ho, Wo) != (H // P, W // P):
+        raise NotImplementedError("the differentiable path has no adaptive-average-pool backward (overlap_ratio > 0): inference path only")
+    cols = Im2colFn.apply(z_nchw.permute(0, 2, 3, 1).contiguous(), n, C_, H, W, P, st, pd, K.act_torch_dtype(compute))
+    w2d = conv.weight.permute(0, 2, 3, 1).reshape(conv.weight.shape[0], -1)           # columns (kh, kw, c), a parameter-sized re-layout
+    return LinearFn.apply(cols, w2d, conv.bias, None, compute, out_dtype), Ho, Wo
+
+
+def _deconv_stage_train(rows: torch.Tensor, dc: nn.ConvTranspose2d, n_img: int, h: int, w: int, P: int, overlap: float, compute: int):
+    """RealTransConv2d on the train path -> (n_img, Cout, h P, w P) fp32 pre-activation."""
+    from .autograd import CropResizeFn, DeconvFn
+    st, pd = S.stride_pad(P, overlap)
+    if st != P:
+        raise NotImplementedError("overlapping transposed convolutions run on the inference path only")
+    if pd == 0:
+        return DeconvFn.apply(rows, dc.weight, dc.bias, n_img, h, w, P, True, compute, torch.float32)
+    full = DeconvFn.apply(rows, dc.weight, dc.bias, n_img, h, w, P, False, compute, K.act_torch_dtype(compute))   # (n, hP, wP, Cout)
+    Cout = dc.weight.shape[1]
+    return CropResizeFn.apply(full, n_img, Cout, h * P - 2 * pd, w * P - 2 * pd, (pd, pd), h * P, w * P, True, torch.float32)
+
+
+def enc_fno_train(enc: enc_FNO, inp: torch.Tensor, compute: int) -> torch.Tensor:
+    """enc_FNO.forward with an autograd graph: (B, T, D, H, W) -> tokens (B*T*Hp*Wp, C) fp32 (before FiLM / positional terms)."""
+    from .autograd import ActFn, SpectralLayerFn
+    B, T, D, H, W = inp.shape
+    n = B * T
+    l1, l2 = enc.enc_spectral_1, enc.enc_spectral_2
+    z = ActFn.apply(SpectralLayerFn.apply(inp.reshape(n, D, H, W), l1.weight, l1.w0.weight, l1.w0.bias, l1.modes1, l1.modes2),
+                    L.ACT_GELU_ERF, torch.float32)
+    y, h, w = _conv_stage_train(z, enc.enc_conv_1.conv, enc.P[0], enc.overlap, compute, torch.float32)
+    y = ActFn.apply(y, L.ACT_GELU_ERF, torch.float32)
+    z = y.view(n, h, w, -1).permute(0, 3, 1, 2).contiguous()
+    z = ActFn.apply(SpectralLayerFn.apply(z, l2.weight, l2.w0.weight, l2.w0.bias, l2.modes1, l2.modes2), L.ACT_GELU_ERF, torch.float32)
+    y, h, w = _conv_stage_train(z, enc.enc_conv_2.conv, enc.P[1], enc.overlap, compute, torch.float32)
+    return y
+
+
+def dec_fno_train(dec: dec_FNO, rows: torch.Tensor, n_img: int, compute: int) -> torch.Tensor:
+    """dec_FNO.forward with an autograd graph: last-slot tokens (n_img*Hp*Wp, C) -> (n_img, D, H, W) fp32."""
+    from .autograd import ActFn, SpectralLayerFn
+    h, w = dec.patch_shape
+    p1, p0 = dec.Pf[1], dec.Pf[0]
+    l1, l2 = dec.dec_spectral_1, dec.dec_spectral_2
+    z = ActFn.apply(_deconv_stage_train(rows, dec.dec_conv_1.deconv, n_img, h, w, p1, dec.overlap, compute), L.ACT_GELU_ERF, torch.float32)
+    h, w = h * p1, w * p1
+    z = ActFn.apply(SpectralLayerFn.apply(z, l1.weight, l1.w0.weight, l1.w0.bias, l1.modes1, l1.modes2), L.ACT_GELU_ERF, torch.float32)
+    r2 = z.permute(0, 2, 3, 1).contiguous().view(n_img * h * w, -1)
+    z = ActFn.apply(_deconv_stage_train(r2, dec.dec_conv_2.deconv, n_img, h, w, p0, dec.overlap, compute), L.ACT_GELU_ERF, torch.float32)
+    return SpectralLayerFn.apply(z, l2.weight, l2.w0.weight, l2.w0.bias, l2.modes1, l2.modes2)

@@ -423,9 +423,6 @@ class TANTE(nn.Module):
         if input.shape[1] != self.T:
             input = input[:, -self.T:]
         if torch.is_grad_enabled() and (input.requires_grad or any(p.requires_grad for p in self.parameters())):
-            if self.enc_dec_type != "cnn":
-                raise NotImplementedError("the spectral encoder / decoder run on the inference path only (no autograd graph): call "
-                                          "under torch.no_grad() / inference_mode")
             from .train_forward import tante_train_forward
             if out is not None:
                 raise ValueError("out= is an inference-path option")

@@ -57,6 +57,9 @@ def backbone_train(bb, x: torch.Tensor, B: int, compute: int) -> torch.Tensor:
 
 
 def encoder_train(enc, inp: torch.Tensor, compute: int) -> torch.Tensor:
+    if type(enc).__name__ == "enc_FNO":
+        from .spectral import enc_fno_train
+        return enc_fno_train(enc, inp, compute)
     if any(S.stride_pad(p, enc.overlap) != (p, 0) for p in enc.P):
         raise NotImplementedError("the differentiable path covers non-overlapping, unpadded stages (patch_scale 2, 4, 8); padded / "
                                   "overlapping stages run on the inference path only")
@@ -76,6 +79,9 @@ def encoder_train(enc, inp: torch.Tensor, compute: int) -> torch.Tensor:
 
 
 def decoder_train(dec, a: torch.Tensor, n_img: int, compute: int) -> torch.Tensor:
+    if type(dec).__name__ == "dec_FNO":
+        from .spectral import dec_fno_train
+        return dec_fno_train(dec, a.reshape(-1, dec.chans[0]), n_img, compute)
     if any(S.stride_pad(p, dec.overlap) != (p, 0) for p in dec.P):
         raise NotImplementedError("the differentiable path covers non-overlapping, unpadded stages (patch_scale 2, 4, 8); padded / "
                                   "overlapping stages run on the inference path only")

@@ -1165,3 +1165,81 @@ def test_cfg5_spectral_path_full_size_properties(dev):
         y16 = m.set_compute("bf16")(xin)
     assert y32.shape == (1, 1, 8, 512, 512) and torch.isfinite(y32).all()
     close(y16, y32, "bf16")
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_g12_tante_fno_gradients_against_oracle_autograd(dev, mode):
+    """Training path of the spectral encoder / decoder (SpectralLayer backward through hipFFT, padded conv via im2col / col2im, padded
+    transposed conv via crop + bilinear-resize backward): every parameter's gradient -- incl. the complex spectral weights -- against
+    torch.autograd through the CPU oracle."""
+    import tante_amd
+    from oracle import tante_oracle as O
+    g = load_golden("g12_tante_fno")
+    md = tante_amd.TanteMetadata(n_fields=2, spatial_resolution=(32, 32))
+    m = tante_amd.TANTE(in_T=4, dset_metadata=md, taylor_order=2, attn_axes="TL-TL", n_head=4, embed_dim=64, patch_scale=8,
+                        enc_dec_type="fno", modes1=8, modes2=8).to(dev).train()
+    sd = {}
+    for k, v in split_prefix(g, "w.").items():
+        if k.endswith("_re"):
+            sd[k[:-3]] = torch.complex(v, g["w." + k[:-3] + "_im"])
+        elif not k.endswith("_im"):
+            sd[k] = v
+    m.load_state_dict(sd, strict=True)
+    m.set_compute(mode)
+    torch.manual_seed(17)
+    proj = torch.randn(g["y"].shape)
+    y = m(g["x"].to(dev))
+    close(y, g["y"], mode)
+    (y * proj.to(dev)).sum().backward()
+    w = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    cfg = O.TanteCfg(4, 2, (32, 32), taylor_order=2, attn_axes="TL-TL", n_head=4, embed_dim=64, patch_scale=8, enc_dec_type="fno",
+                     modes1=8, modes2=8)
+    yo = O.tante_forward(w, cfg, g["x"])
+    (yo * proj).sum().backward()
+    tol = 2e-4 if mode == "fp32" else 4e-2
+    mine, refs = [], []
+    for k, p in m.named_parameters():
+        ref = w[k].grad
+        assert p.grad is not None and ref is not None, k
+        a, b = p.grad.detach().cpu(), ref.detach()
+        if a.is_complex():
+            a, b = torch.view_as_real(a), torch.view_as_real(b)
+        mine.append(a.flatten())
+        refs.append(b.flatten())
+        if mode == "fp32" or b.dim() >= 2:
+            assert rel_err(a, b) < tol, f"{k}: rel {rel_err(a, b):.3e}"
+    assert rel_err(torch.cat(mine), torch.cat(refs)) < tol
+
+
+def test_tante_fno_two_train_steps_match_torch_adamw(dev):
+    """Two full optimisation steps of TANTE with the spectral encoder / decoder (BPTT over 2 re-fed frames, MSE, global-norm clip, AdamW
+    with the complex spectral weights in the flat buckets as (re, im) pairs) against the oracle + torch.optim.AdamW."""
+    import tante_amd
+    from oracle import tante_oracle as O
+    md = tante_amd.TanteMetadata(n_fields=2, spatial_resolution=(32, 32))
+    torch.manual_seed(33)
+    kw = dict(in_T=4, taylor_order=1, attn_axes="TL", n_head=4, embed_dim=64, patch_scale=8, enc_dec_type="fno", modes1=6, modes2=6)
+    m = tante_amd.TANTE(dset_metadata=md, **kw).to(dev).train().set_compute("fp32")
+    w = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    fmt = tante_amd.DefaultChannelsFirstFormatter(md)
+    batch = {"input": torch.randn(2, 4, 32, 32, 2), "output": torch.randn(2, 2, 32, 32, 2)}
+    opt = tante_amd.FlatAdamW(m.parameters(), lr=1e-3, weight_decay=1e-5, max_norm=1.0)
+    ropt = torch.optim.AdamW(list(w.values()), lr=1e-3, weight_decay=1e-5)
+    cfg = O.TanteCfg(4, 2, (32, 32), taylor_order=1, attn_axes="TL", n_head=4, embed_dim=64, patch_scale=8, enc_dec_type="fno", modes1=6, modes2=6)
+    losses = []
+    for _ in range(2):
+        losses.append(float(tante_amd.train_step(m, opt, {k: v.to(dev) for k, v in batch.items()}, fmt, 2)))
+        ropt.zero_grad()
+        yo, y_ref = O.rollout(w, cfg, batch, 2)
+        lo = ((yo - y_ref) ** 2).mean()
+        lo.backward()
+        torch.nn.utils.clip_grad_norm_(list(w.values()), 1.0)
+        ropt.step()
+        assert abs(losses[-1] - float(lo.detach())) < 1e-4 * max(1.0, float(lo.detach()))
+    for k, p in m.named_parameters():
+        a, b = p.detach().cpu(), w[k].detach()
+        if a.is_complex():
+            a, b = torch.view_as_real(a), torch.view_as_real(b)
+        assert float((a - b).abs().max()) <= 2.2 * 1e-3 * 2, k
+        assert rel_err(a, b) < 1e-2, k
+    assert losses[1] < losses[0]
