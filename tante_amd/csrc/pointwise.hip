@@ -287,16 +287,23 @@ __device__ __forceinline__ void axis_phase(float* plane, float* wst_raw, const f
       b2[mt][j] = r < n ? bst[n + r] : 0.0f;
     }
   constexpr int NX = 16 * ((MT + 1) / 2);
-  for (int g = wave; g < ngroups; g += AXT / 64) {
-    float* base = plane + g * gs + l15;
-    float xin[NX];
+  // software pipeline over this wave's line groups: the LDS gather of group g + 1 is in flight under the MFMAs / GELU of group g
+  auto gather = [&](int g, float (&xv)[NX]) {
+    const float* base = plane + g * gs + l15;
 #pragma unroll
     for (int j = 0; j < NX; ++j) {
       const int p = BF16 ? ((j >> 3) * 32 + kk * 8 + (j & 7)) : ((j >> 2) * 16 + (j & 3) * 4 + kk);
-      xin[j] = p < n ? base[p * ls] : 0.0f;
+      xv[j] = p < n ? base[p * ls] : 0.0f;
     }
+  };
+  float xa[NX], xb[NX];
+  if (wave < ngroups) gather(wave, xa);
+  for (int g = wave; g < ngroups; g += AXT / 64) {
+    const int gn = g + AXT / 64;
+    if (gn < ngroups) gather(gn, xb);
+    float* base = plane + g * gs + l15;
     f32x4 out[MT];
-    axis_mlp_mfma<BF16, MT>(w1, w2, b1, b2, xin, out);
+    axis_mlp_mfma<BF16, MT>(w1, w2, b1, b2, xa, out);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -304,6 +311,8 @@ __device__ __forceinline__ void axis_phase(float* plane, float* wst_raw, const f
         const int p = mt * 16 + kk * 4 + j;
         if (p < n) base[p * ls] += out[mt][j];   // this line group is owned by this wave
       }
+#pragma unroll
+    for (int j = 0; j < NX; ++j) xa[j] = xb[j];
   }
   __syncthreads();
 }
