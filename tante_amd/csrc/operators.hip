@@ -2,6 +2,7 @@
 // convolutions, bilinear-resized transposed convolutions), the spectral operator path (enc_dec_fno.py) and CViT (cvit.py) need.
 // All of them are HBM-bound gather / pointwise / small-contraction kernels: coalesced on the innermost axis, fp32 arithmetic.
 #include "common.cuh"
+#include "fused_common.cuh"
 #include <hipfft/hipfft.h>
 #include <stdlib.h>
 #include <map>
@@ -268,44 +269,73 @@ __device__ __forceinline__ f32x4 xmfma(const u32x4& a, const u32x4& b, const f32
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 constexpr int XD = 64;            // head dim
-constexpr int XGPW = 4;           // 32-query iterations per wave
+constexpr int XGPW = 8;           // 32-query iterations per wave
 constexpr int XQ_PER_WG = 4 * XGPW * 32;
+
+template <int OFF>
+__device__ __forceinline__ u32x2 x_tr_read_off(unsigned base) {   // base VGPR + 16-bit immediate offset
+  u32x2 r;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(base), "n"(OFF) : "memory");
+  return r;
+}
+__device__ __forceinline__ u32x2 x_tr_read(unsigned addr) {   // ds_read_b64_tr_b16: 4 rows x 16 columns per 16-lane group, column-major out
+  u32x2 r;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r) : "v"(addr) : "memory");
+  return r;
+}
+// V rows are 128 bytes (64 bf16): 16-byte chunk c of row r sits at chunk c ^ (((r >> 1) & 3) << 1), which makes the two 16-lane groups of
+// a half-wave (8 consecutive rows, one aligned chunk pair each) hit 16 distinct 16-byte slots of the 256-byte bank row
+__device__ __forceinline__ int xv_swz(int row) { return ((row >> 1) & 3) << 1; }
 
 __global__ __launch_bounds__(256, 2) void xattn_mfma_kernel(const unsigned short* __restrict__ q, const unsigned short* __restrict__ k,
                                                             const unsigned short* __restrict__ v, unsigned short* __restrict__ o, int n_head,
                                                             int Lq, int Lk, int Sp, long ldq, long ldkv, long ldo, float scale_log2e) {
-  extern __shared__ __attribute__((aligned(16))) char xsm[];   // K image [Sp][8 chunks], then V^T image [64][Sp / 8 chunks]
+  extern __shared__ __attribute__((aligned(16))) char xsm[];   // K image [Sp][8 chunks] (row reads), then V image [Sp][8 chunks] (transposed reads)
   char* ks = xsm;
-  char* vt = xsm + (size_t)Sp * XD * 2;
-  const int cprV = Sp / 8;
+  char* vs = xsm + (size_t)Sp * XD * 2;
   const int bh = blockIdx.x, b = bh / n_head, h = bh - b * n_head;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kk = lane >> 4, l15 = lane & 15;
-  // ---- stage K and V^T (zero rows for padded keys) ----
-  for (int idx = tid; idx < Sp * 8; idx += 256) {
-    const int j = idx >> 3, c = idx & 7;
-    u32x4 kv = u32x4{0u, 0u, 0u, 0u}, vv = u32x4{0u, 0u, 0u, 0u};
-    if (j < Lk) {
-      const long off = ((long)b * Lk + j) * ldkv + (long)h * XD + c * 8;
-      kv = *(const u32x4*)(k + off);
-      vv = *(const u32x4*)(v + off);
-    }
-    *(u32x4*)(ks + ((j * 8 + swz_chunk(j, c, 8)) << 4)) = kv;
-    // key j sits at position 8 kk' + 4 dt + r of its 32-block (j = 32 blk + 16 dt + 4 kk' + r): chunk blk*4 + kk', element 4 dt + r
-    const int blk = j >> 5, jj = j & 31, dt = jj >> 4, kq = (jj >> 2) & 3, r = jj & 3;
-    const int cj = blk * 4 + kq, el = 4 * dt + r;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int d = c * 8 + e;
-      const unsigned short val = (unsigned short)((vv[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
-      *(unsigned short*)(vt + ((d * cprV + swz_chunk(d, cj, cprV)) << 4) + el * 2) = val;
+  // ---- stage K and V row-major by LDS-DMA (no register round trip, no transposing stores): a wave instruction moves 8 rows of 128 bytes;
+  // the swizzles are applied to the SOURCE chunk each lane fetches.  Rows >= Lk re-read row Lk - 1 (their scores are masked below). ----
+  {
+    const int rl = lane >> 3, cs = lane & 7;
+    for (int r0 = wave * 8; r0 < Sp; r0 += 32) {
+      const int row = r0 + rl, src = row < Lk ? row : Lk - 1;
+      const unsigned short* gk = k + ((long)b * Lk + src) * ldkv + (long)h * XD + ((cs ^ ((row >> 1) & 7)) * 8);
+      const unsigned short* gv = v + ((long)b * Lk + src) * ldkv + (long)h * XD + ((cs ^ xv_swz(row)) * 8);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gk, (__attribute__((address_space(3))) void*)(ks + r0 * 128), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gv, (__attribute__((address_space(3))) void*)(vs + r0 * 128), 16, 0, 0);
     }
   }
+  // per-lane LDS byte addresses; everything that varies with the (compile-time) tile indices is an instruction immediate
+  unsigned kb[2];   // K row l15 of a 16-key tile, 32-dim block bb (row reads, ds_read_b128)
+#pragma unroll
+  for (int bb = 0; bb < 2; ++bb) kb[bb] = lds_addr(ks) + l15 * 128 + (swz_chunk(l15, bb * 4 + kk, 8) << 4);
+  // transposed V reads: lane 4 qq + pp of a 16-lane group supplies row (4 kk + qq), columns 4 pp .. 4 pp + 3 of the 16-dim tile dt; the
+  // swizzle only looks at row bits 1-2, which the 32-key block offset and the +16 of the second read leave alone
+  const int qq = l15 >> 2, pp = l15 & 3;
+  unsigned vb[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt)
+    vb[dt] = lds_addr(vs) + (4 * kk + qq) * 128 + (((dt * 2 + (pp >> 1)) ^ xv_swz(4 * kk + qq)) << 4) + 8 * (pp & 1);
+  const u32x4 ones = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
-  int ko[2], vo[4];   // swizzled chunk offsets of this lane: K rows l15 (per 32-d block b), V^T rows l15 (per 32-key block, added later)
+  // the next iteration's query fragments are fetched while this one computes
+  auto load_q = [&](int it, u32x4 (&dst)[2][2]) {
+    const int q0n = blockIdx.y * XQ_PER_WG + (wave * XGPW + it) * 32;
 #pragma unroll
-  for (int bb = 0; bb < 2; ++bb) ko[bb] = swz_chunk(l15, bb * 4 + kk, 8) << 4;
-
+    for (int g = 0; g < 2; ++g) {
+      const int qi = q0n + g * 16 + l15;
+      const bool lv = it < XGPW && qi < Lq;
+      const long qoff = ((long)b * Lq + (lv ? qi : 0)) * ldq + (long)h * XD;
+#pragma unroll
+      for (int bb = 0; bb < 2; ++bb) dst[g][bb] = lv ? *(const u32x4*)(q + qoff + bb * 32 + kk * 8) : u32x4{0u, 0u, 0u, 0u};
+    }
+  };
+  u32x4 qnext[2][2];
+  load_q(0, qnext);
   for (int it = 0; it < XGPW; ++it) {
     const int q0 = blockIdx.y * XQ_PER_WG + (wave * XGPW + it) * 32;
     if (q0 >= Lq) break;
@@ -313,82 +343,99 @@ __global__ __launch_bounds__(256, 2) void xattn_mfma_kernel(const unsigned short
     bool live[2];
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
-      const int qi = q0 + g * 16 + l15;
-      live[g] = qi < Lq;
-      const long qoff = ((long)b * Lq + (live[g] ? qi : 0)) * ldq + (long)h * XD;
+      live[g] = q0 + g * 16 + l15 < Lq;
 #pragma unroll
-      for (int bb = 0; bb < 2; ++bb) qf[g][bb] = live[g] ? *(const u32x4*)(q + qoff + bb * 32 + kk * 8) : u32x4{0u, 0u, 0u, 0u};
+      for (int bb = 0; bb < 2; ++bb) qf[g][bb] = qnext[g][bb];
     }
-    float m[2] = {-INFINITY, -INFINITY}, lsum[2] = {0.f, 0.f};
-    f32x4 oacc[2][4];
+    load_q(it + 1, qnext);
+    float m[2] = {-INFINITY, -INFINITY};   // running max of the RAW scores (the positive scale commutes with max)
+    f32x4 oacc[2][4], lacc[2];             // lacc: row sums of P by an all-ones MFMA (every row of the tile holds the same sum)
 #pragma unroll
-    for (int g = 0; g < 2; ++g)
+    for (int g = 0; g < 2; ++g) {
+      lacc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) oacc[g][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 
     for (int c0 = 0; c0 < Sp; c0 += 128) {
+      const unsigned kc[2] = {kb[0] + c0 * 128, kb[1] + c0 * 128};
       f32x4 s[2][8];
-#pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        const char* kr = ks + (((c0 + t * 16 + l15) * 8) << 4);
-        s[0][t] = s[1][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int bb = 0; bb < 2; ++bb) {
-          const u32x4 kf = *(const u32x4*)(kr + ko[bb]);
-          s[0][t] = xmfma(kf, qf[0][bb], s[0][t]);
-          s[1][t] = xmfma(kf, qf[1][bb], s[1][t]);
-        }
-      }
+      // S^T tiles: 16 K fragments (tile t, dim block bb), each feeding both query groups, through the counted LDS read ring
+      mfma_stream<16, 4>(
+          [&](auto ic) { constexpr int i = decltype(ic)::value; return LdsAddr<(i >> 1) * 2048>{kc[i & 1]}; },
+          [&](auto ic, const u32x4& kf) {
+            constexpr int i = decltype(ic)::value, t = i >> 1, bb = i & 1;
+            if constexpr (bb == 0) {
+              s[0][t] = xmfma(kf, qf[0][0], f32x4{0.f, 0.f, 0.f, 0.f});
+              s[1][t] = xmfma(kf, qf[1][0], f32x4{0.f, 0.f, 0.f, 0.f});
+            } else {
+              s[0][t] = xmfma(kf, qf[0][1], s[0][t]);
+              s[1][t] = xmfma(kf, qf[1][1], s[1][t]);
+            }
+          });
       const bool tail = c0 + 128 > Lk;   // uniform: this chunk holds padded keys
 #pragma unroll
       for (int g = 0; g < 2; ++g) {
+        if (tail) {
+#pragma unroll
+          for (int t = 0; t < 8; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (c0 + t * 16 + kk * 4 + r >= Lk) s[g][t][r] = -INFINITY;
+        }
         float cm = -INFINITY;
 #pragma unroll
-        for (int t = 0; t < 8; ++t)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float sv = s[g][t][r] * scale_log2e;
-            if (tail && c0 + t * 16 + kk * 4 + r >= Lk) sv = -INFINITY;
-            s[g][t][r] = sv;
-            cm = fmaxf(cm, sv);
-          }
+        for (int t = 0; t < 8; ++t) cm = fmaxf(cm, fmaxf(fmaxf(s[g][t][0], s[g][t][1]), fmaxf(s[g][t][2], s[g][t][3])));
         cm = fmaxf(cm, __shfl_xor(cm, 16));
         cm = fmaxf(cm, __shfl_xor(cm, 32));
         const float mn = fmaxf(m[g], cm);
-        const float corr = exp2f(m[g] - mn);
+        const float corr = __builtin_amdgcn_exp2f((m[g] - mn) * scale_log2e);
         m[g] = mn;
-        float ps = 0.0f;
+        const float nm = -mn * scale_log2e;
 #pragma unroll
         for (int t = 0; t < 8; ++t)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float pv = exp2f(s[g][t][r] - mn);
-            s[g][t][r] = pv;
-            ps += pv;
-          }
-        lsum[g] = lsum[g] * corr + ps;
+          for (int r = 0; r < 4; ++r) s[g][t][r] = __builtin_amdgcn_exp2f(fmaf(s[g][t][r], scale_log2e, nm));   // one fma + one exp per score
+        lacc[g] *= corr;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) oacc[g][dt] *= corr;
       }
+      // O^T += V^T P^T per 32-key block.  P's k order inside the block is the accumulator order (keys 16 h + 4 kk + r), so an A fragment
+      // is two transposed reads of 4 keys each; the reads of block blk + 1 are in flight under the MFMAs of block blk.
+      unsigned vc[4];
 #pragma unroll
-      for (int blk = 0; blk < 4; ++blk) {
+      for (int dt = 0; dt < 4; ++dt) vc[dt] = vb[dt] + c0 * 128;
+      u32x2 vlo[2][4], vhi[2][4];
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) { vlo[0][dt] = x_tr_read_off<0>(vc[dt]); vhi[0][dt] = x_tr_read_off<2048>(vc[dt]); }
+      static_for<4>([&](auto bc) {
+        constexpr int blk = decltype(bc)::value, cur = blk & 1;
         const u32x4 p0 = xpack8(s[0][2 * blk], s[0][2 * blk + 1]), p1 = xpack8(s[1][2 * blk], s[1][2 * blk + 1]);
-        const int cj = (c0 >> 5) * 4 + blk * 4 + kk;
+        if constexpr (blk < 3) {
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt) {
+            vlo[cur ^ 1][dt] = x_tr_read_off<(blk + 1) * 4096>(vc[dt]);
+            vhi[cur ^ 1][dt] = x_tr_read_off<(blk + 1) * 4096 + 2048>(vc[dt]);
+          }
+          asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(vlo[cur][0]), "+v"(vlo[cur][1]), "+v"(vlo[cur][2]), "+v"(vlo[cur][3]), "+v"(vhi[cur][0]),
+                       "+v"(vhi[cur][1]), "+v"(vhi[cur][2]), "+v"(vhi[cur][3]));
+        } else {
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vlo[cur][0]), "+v"(vlo[cur][1]), "+v"(vlo[cur][2]), "+v"(vlo[cur][3]), "+v"(vhi[cur][0]),
+                       "+v"(vhi[cur][1]), "+v"(vhi[cur][2]), "+v"(vhi[cur][3]));
+        }
+        lacc[0] = xmfma(ones, p0, lacc[0]);
+        lacc[1] = xmfma(ones, p1, lacc[1]);
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
-          const int d = dt * 16 + l15;
-          const u32x4 vf = *(const u32x4*)(vt + ((d * cprV + swz_chunk(d, cj, cprV)) << 4));
+          const u32x4 vf = u32x4{vlo[cur][dt][0], vlo[cur][dt][1], vhi[cur][dt][0], vhi[cur][dt][1]};
           oacc[0][dt] = xmfma(vf, p0, oacc[0][dt]);
           oacc[1][dt] = xmfma(vf, p1, oacc[1][dt]);
         }
-      }
+      });
     }
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
-      float l = lsum[g];
-      l += __shfl_xor(l, 16);
-      l += __shfl_xor(l, 32);
-      const float inv = 1.0f / l;
+      const float inv = 1.0f / lacc[g][0];
       if (live[g]) {
         const long ooff = ((long)b * Lq + q0 + g * 16 + l15) * ldo + (long)h * XD;
 #pragma unroll
