@@ -269,8 +269,10 @@ __device__ __forceinline__ f32x4 xmfma(const u32x4& a, const u32x4& b, const f32
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 constexpr int XD = 64;            // head dim
-constexpr int XGPW = 8;           // 32-query iterations per wave
-constexpr int XQ_PER_WG = 4 * XGPW * 32;
+constexpr int XQG = 2;            // 16-query groups a wave processes together (2: half the LDS reads per MFMA, but 50 more VGPRs)
+constexpr int XWAVES = 4;         // waves per workgroup (measured: XQG 1 with 6 waves = 3 waves/SIMD is 25 % slower than XQG 2 with 4)
+constexpr int XGPW = 8;           // iterations per wave
+constexpr int XQ_PER_WG = XWAVES * XGPW * 16 * XQG;
 
 template <int OFF>
 __device__ __forceinline__ u32x2 x_tr_read_off(unsigned base) {   // base VGPR + 16-bit immediate offset
@@ -287,7 +289,7 @@ __device__ __forceinline__ u32x2 x_tr_read(unsigned addr) {   // ds_read_b64_tr_
 // a half-wave (8 consecutive rows, one aligned chunk pair each) hit 16 distinct 16-byte slots of the 256-byte bank row
 __device__ __forceinline__ int xv_swz(int row) { return ((row >> 1) & 3) << 1; }
 
-__global__ __launch_bounds__(256, 2) void xattn_mfma_kernel(const unsigned short* __restrict__ q, const unsigned short* __restrict__ k,
+__global__ __launch_bounds__(XWAVES * 64, 2) void xattn_mfma_kernel(const unsigned short* __restrict__ q, const unsigned short* __restrict__ k,
                                                             const unsigned short* __restrict__ v, unsigned short* __restrict__ o, int n_head,
                                                             int Lq, int Lk, int Sp, long ldq, long ldkv, long ldo, float scale_log2e) {
   extern __shared__ __attribute__((aligned(16))) char xsm[];   // K image [Sp][8 chunks] (row reads), then V image [Sp][8 chunks] (transposed reads)
@@ -299,7 +301,7 @@ __global__ __launch_bounds__(256, 2) void xattn_mfma_kernel(const unsigned short
   // the swizzles are applied to the SOURCE chunk each lane fetches.  Rows >= Lk re-read row Lk - 1 (their scores are masked below). ----
   {
     const int rl = lane >> 3, cs = lane & 7;
-    for (int r0 = wave * 8; r0 < Sp; r0 += 32) {
+    for (int r0 = wave * 8; r0 < Sp; r0 += XWAVES * 8) {
       const int row = r0 + rl, src = row < Lk ? row : Lk - 1;
       const unsigned short* gk = k + ((long)b * Lk + src) * ldkv + (long)h * XD + ((cs ^ ((row >> 1) & 7)) * 8);
       const unsigned short* gv = v + ((long)b * Lk + src) * ldkv + (long)h * XD + ((cs ^ xv_swz(row)) * 8);
@@ -323,10 +325,10 @@ __global__ __launch_bounds__(256, 2) void xattn_mfma_kernel(const unsigned short
   __syncthreads();
 
   // the next iteration's query fragments are fetched while this one computes
-  auto load_q = [&](int it, u32x4 (&dst)[2][2]) {
-    const int q0n = blockIdx.y * XQ_PER_WG + (wave * XGPW + it) * 32;
+  auto load_q = [&](int it, u32x4 (&dst)[XQG][2]) {
+    const int q0n = blockIdx.y * XQ_PER_WG + (wave * XGPW + it) * 16 * XQG;
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {
+    for (int g = 0; g < XQG; ++g) {
       const int qi = q0n + g * 16 + l15;
       const bool lv = it < XGPW && qi < Lq;
       const long qoff = ((long)b * Lq + (lv ? qi : 0)) * ldq + (long)h * XD;
@@ -334,24 +336,25 @@ __global__ __launch_bounds__(256, 2) void xattn_mfma_kernel(const unsigned short
       for (int bb = 0; bb < 2; ++bb) dst[g][bb] = lv ? *(const u32x4*)(q + qoff + bb * 32 + kk * 8) : u32x4{0u, 0u, 0u, 0u};
     }
   };
-  u32x4 qnext[2][2];
+  u32x4 qnext[XQG][2];
   load_q(0, qnext);
   for (int it = 0; it < XGPW; ++it) {
-    const int q0 = blockIdx.y * XQ_PER_WG + (wave * XGPW + it) * 32;
+    const int q0 = blockIdx.y * XQ_PER_WG + (wave * XGPW + it) * 16 * XQG;
     if (q0 >= Lq) break;
-    u32x4 qf[2][2];
-    bool live[2];
+    u32x4 qf[XQG][2];
+    bool live[XQG];
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {
+    for (int g = 0; g < XQG; ++g) {
       live[g] = q0 + g * 16 + l15 < Lq;
 #pragma unroll
       for (int bb = 0; bb < 2; ++bb) qf[g][bb] = qnext[g][bb];
     }
     load_q(it + 1, qnext);
-    float m[2] = {-INFINITY, -INFINITY};   // running max of the RAW scores (the positive scale commutes with max)
-    f32x4 oacc[2][4], lacc[2];             // lacc: row sums of P by an all-ones MFMA (every row of the tile holds the same sum)
+    float m[XQG];                           // running max of the RAW scores (the positive scale commutes with max)
+    f32x4 oacc[XQG][4], lacc[XQG];          // lacc: row sums of P by an all-ones MFMA (every row of the tile holds the same sum)
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {
+    for (int g = 0; g < XQG; ++g) {
+      m[g] = -INFINITY;
       lacc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) oacc[g][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -359,23 +362,21 @@ __global__ __launch_bounds__(256, 2) void xattn_mfma_kernel(const unsigned short
 
     for (int c0 = 0; c0 < Sp; c0 += 128) {
       const unsigned kc[2] = {kb[0] + c0 * 128, kb[1] + c0 * 128};
-      f32x4 s[2][8];
+      f32x4 s[XQG][8];
       // S^T tiles: 16 K fragments (tile t, dim block bb), each feeding both query groups, through the counted LDS read ring
       mfma_stream<16, 4>(
           [&](auto ic) { constexpr int i = decltype(ic)::value; return LdsAddr<(i >> 1) * 2048>{kc[i & 1]}; },
           [&](auto ic, const u32x4& kf) {
             constexpr int i = decltype(ic)::value, t = i >> 1, bb = i & 1;
-            if constexpr (bb == 0) {
-              s[0][t] = xmfma(kf, qf[0][0], f32x4{0.f, 0.f, 0.f, 0.f});
-              s[1][t] = xmfma(kf, qf[1][0], f32x4{0.f, 0.f, 0.f, 0.f});
-            } else {
-              s[0][t] = xmfma(kf, qf[0][1], s[0][t]);
-              s[1][t] = xmfma(kf, qf[1][1], s[1][t]);
+#pragma unroll
+            for (int g = 0; g < XQG; ++g) {
+              if constexpr (bb == 0) s[g][t] = xmfma(kf, qf[g][0], f32x4{0.f, 0.f, 0.f, 0.f});
+              else s[g][t] = xmfma(kf, qf[g][1], s[g][t]);
             }
           });
       const bool tail = c0 + 128 > Lk;   // uniform: this chunk holds padded keys
 #pragma unroll
-      for (int g = 0; g < 2; ++g) {
+      for (int g = 0; g < XQG; ++g) {
         if (tail) {
 #pragma unroll
           for (int t = 0; t < 8; ++t)
@@ -410,7 +411,9 @@ __global__ __launch_bounds__(256, 2) void xattn_mfma_kernel(const unsigned short
       for (int dt = 0; dt < 4; ++dt) { vlo[0][dt] = x_tr_read_off<0>(vc[dt]); vhi[0][dt] = x_tr_read_off<2048>(vc[dt]); }
       static_for<4>([&](auto bc) {
         constexpr int blk = decltype(bc)::value, cur = blk & 1;
-        const u32x4 p0 = xpack8(s[0][2 * blk], s[0][2 * blk + 1]), p1 = xpack8(s[1][2 * blk], s[1][2 * blk + 1]);
+        u32x4 pf[XQG];
+#pragma unroll
+        for (int g = 0; g < XQG; ++g) pf[g] = xpack8(s[g][2 * blk], s[g][2 * blk + 1]);
         if constexpr (blk < 3) {
 #pragma unroll
           for (int dt = 0; dt < 4; ++dt) {
@@ -423,18 +426,18 @@ __global__ __launch_bounds__(256, 2) void xattn_mfma_kernel(const unsigned short
           asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vlo[cur][0]), "+v"(vlo[cur][1]), "+v"(vlo[cur][2]), "+v"(vlo[cur][3]), "+v"(vhi[cur][0]),
                        "+v"(vhi[cur][1]), "+v"(vhi[cur][2]), "+v"(vhi[cur][3]));
         }
-        lacc[0] = xmfma(ones, p0, lacc[0]);
-        lacc[1] = xmfma(ones, p1, lacc[1]);
+#pragma unroll
+        for (int g = 0; g < XQG; ++g) lacc[g] = xmfma(ones, pf[g], lacc[g]);
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
           const u32x4 vf = u32x4{vlo[cur][dt][0], vlo[cur][dt][1], vhi[cur][dt][0], vhi[cur][dt][1]};
-          oacc[0][dt] = xmfma(vf, p0, oacc[0][dt]);
-          oacc[1][dt] = xmfma(vf, p1, oacc[1][dt]);
+#pragma unroll
+          for (int g = 0; g < XQG; ++g) oacc[g][dt] = xmfma(vf, pf[g], oacc[g][dt]);
         }
       });
     }
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {
+    for (int g = 0; g < XQG; ++g) {
       const float inv = 1.0f / lacc[g][0];
       if (live[g]) {
         const long ooff = ((long)b * Lq + q0 + g * 16 + l15) * ldo + (long)h * XD;
@@ -1055,7 +1058,7 @@ extern "C" int tante_cross_attention(const void* q, const void* k, const void* v
       attr = lds;
     }
     const dim3 mgrid((unsigned)(n_batch * n_head), (unsigned)((Lq + XQ_PER_WG - 1) / XQ_PER_WG));
-    hipLaunchKernelGGL(xattn_mfma_kernel, mgrid, dim3(256), lds, s, (const unsigned short*)q, (const unsigned short*)k, (const unsigned short*)v,
+    hipLaunchKernelGGL(xattn_mfma_kernel, mgrid, dim3(XWAVES * 64), lds, s, (const unsigned short*)q, (const unsigned short*)k, (const unsigned short*)v,
                        (unsigned short*)o, n_head, Lq, Lk, Sp, (long)ldq, (long)ldkv, (long)ldo, scale * 1.44269504088896340736f);
     TANTE_CHECK_LAUNCH();
     return 0;

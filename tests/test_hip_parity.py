@@ -106,6 +106,32 @@ def test_gemm_ln_act_residual(dev, mode, act):
         close(o16, ref16, mode)
 
 
+@pytest.mark.parametrize("act", ["none", "gelu_erf", "gelu_tanh", "relu"])
+@pytest.mark.parametrize("M,N,K,odt,res", [(4096, 256, 256, "bf16", False), (5000, 200, 128, "f32", True), (4100, 768, 256, "bf16", False),
+                                           (4224, 96, 512, "f32", False), (8192, 512, 256, "bf16", True)])
+def test_gemm_training_shapes(dev, act, M, N, K, odt, res):
+    """bf16 rows x packed bf16 weight at training sizes (M >= 4096 tokens): the resident-round kernel (gemm_lite_kernel) with ragged M,
+    N that is not a whole tile, every activation, fp32 / bf16 destinations and the fp32 residual operand."""
+    from oracle import tante_oracle as O
+    Kk, L = _ops()
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g).to(torch.bfloat16)
+    w = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b = torch.randn(N, generator=g)
+    r = torch.randn(M, N, generator=g) if res else None
+    f = {"none": lambda x: x, "gelu_erf": O.gelu_erf, "gelu_tanh": O.gelu_tanh, "relu": torch.relu}[act]
+    code = {"none": L.ACT_NONE, "gelu_erf": L.ACT_GELU_ERF, "gelu_tanh": L.ACT_GELU_TANH, "relu": L.ACT_RELU}[act]
+    ref = f(a.float() @ w.to(torch.bfloat16).float().t() + b)
+    if res:
+        ref = ref + r
+    pw = Kk.pack_weight(w.to(dev), b.to(dev), L.BF16)
+    out = torch.full((M + 1, N), float("nan"), dtype=torch.bfloat16 if odt == "bf16" else torch.float32, device=dev)
+    Kk.linear(a.to(dev), pw, out, M=M, act=code, residual=None if r is None else r.to(dev))
+    assert torch.isnan(out[M].float()).all()                      # nothing written past row M
+    err = (out[:M].float().cpu() - ref).abs().max() / ref.abs().max()
+    assert err < (1e-2 if odt == "bf16" else 2e-3), err          # weights rounded identically on both sides: what is left is the output rounding (+ polynomial GELU)
+
+
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])
 @pytest.mark.parametrize("nchw,Cin,Cout,P,H,W", [(True, 11, 64, 2, 16, 32), (False, 64, 128, 2, 8, 12), (True, 1, 16, 2, 8, 8),
                                                  (False, 6, 20, 2, 4, 6), (True, 3, 8, 1, 4, 4)])
