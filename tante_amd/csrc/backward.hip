@@ -1,6 +1,7 @@
 // Backward kernels of the TANTE train step (everything that is not a GEMM; the data-gradient GEMMs are tante_gemm with
 // the *_T packings, the weight-gradient GEMM is wgrad.hip).
 #include "common.cuh"
+#include "fused_common.cuh"
 
 namespace {
 
@@ -399,6 +400,243 @@ __global__ __launch_bounds__(128) void attn_bwd_small_kernel(const void* __restr
   }
 }
 
+// ---- attention backward on the matrix cores: bf16, head dim 32, L <= 64 ------------------------------------------------------------
+// One wave per (unit, head); a unit is one sequence in NT = ceil(L / 16) tiles of 16 slots, or (L < 16) the 16 / L sequences that fit
+// one tile, kept apart by a block-diagonal mask.  v_mfma_f32_16x16x32_bf16 computes X Y^T from two "row, 8 consecutive k" fragments,
+// and head dim 32 is exactly one k step, so Q, K, V, dO fragments are plain 16-byte global loads and
+//   S^T = K Q^T, dP^T = V dO^T   (accumulator: 4 keys x 1 query per lane)  -> row statistics m, 1/l, delta and dS^T -> dQ^T = K^T-frag x dS
+//   S   = Q K^T, dP   = dO V^T   (accumulator: 4 queries x 1 key per lane) -> dS, dropped P                      -> dK^T, dV^T
+// each score tile is computed in both orientations (2 MFMAs) instead of being transposed.  An accumulator pair (two 16-slot tiles) packs
+// straight into the B operand of the second product with k order (tile a: 4 kk + r, tile b: 4 kk + r); the matching A operand - K^T, Q^T
+// or dO^T in that k order - is two ds_read_b64_tr_b16 of the row-major LDS image (MI355X_MICROARCH.md "LDS": 4 rows x 16 columns per
+// 16-lane group, column-major out).  The VALU kernel above spends ~260 FMAs per (query, key) pair; this one ~30 instructions.
+__device__ __forceinline__ u32x2 abm_tr(unsigned addr) {
+  u32x2 r;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r) : "v"(addr) : "memory");
+  return r;
+}
+template <int NT>
+__global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const unsigned short* __restrict__ qkv, const unsigned short* __restrict__ dO,
+                                                            unsigned short* __restrict__ dqkv, int C, int n_head, TanteSeq sq, int SPT, int causal,
+                                                            float scale, float p_drop, unsigned long long seed) {
+  constexpr int ROWS = NT * 16, NP = (NT + 1) / 2;
+  constexpr int WAVE_LDS = 3 * ROWS * 64 + 3 * ROWS * 4;
+  extern __shared__ __attribute__((aligned(16))) char sm_raw[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kk = lane >> 4, l15 = lane & 15, qq = l15 >> 2, pp = l15 & 3;
+  const int h = blockIdx.y * 4 + wave;
+  if (h >= n_head) return;                       // waves never meet at a barrier: each owns its slice of LDS
+  char* base = sm_raw + wave * WAVE_LDS;
+  unsigned short* Qs = (unsigned short*)base;
+  unsigned short* Ks = Qs + ROWS * 32;
+  unsigned short* Gs = Ks + ROWS * 32;
+  float* St = (float*)(Gs + ROWS * 32);          // m [ROWS], 1/l [ROWS], delta [ROWS]
+  const int L = sq.L, unit = blockIdx.x;
+  const bool big = L >= 16;
+  const unsigned rcpL = (65536u + L - 1) / L;    // floor(slot / L) for slot < 16
+  auto decode = [&](int slot, int& sl, int& pos, bool& live) {   // slot -> (sequence of the tile, position, exists)
+    sl = big ? 0 : (int)(((unsigned)slot * rcpL) >> 16);
+    pos = slot - sl * L;
+    const int seq = big ? unit : unit * SPT + sl;
+    live = (big ? pos < L : sl < SPT) && seq < sq.nseq;
+  };
+  long ctok[NT];
+  int csl[NT], cpos[NT];
+  bool clive[NT];
+  u32x4 qf[NT], kf[NT], vf[NT], gf[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    decode(t * 16 + l15, csl[t], cpos[t], clive[t]);
+    const int seq = big ? unit : unit * SPT + csl[t];
+    ctok[t] = clive[t] ? (long)(seq / sq.n_s0) * sq.S1 + (long)(seq % sq.n_s0) * sq.S0 + (long)(cpos[t] / sq.n_l0) * sq.P1 +
+                             (long)(cpos[t] % sq.n_l0) * sq.P0 : 0;
+    qf[t] = kf[t] = vf[t] = gf[t] = u32x4{0u, 0u, 0u, 0u};
+    if (clive[t]) {
+      const unsigned short* r = qkv + ctok[t] * 3L * C + h * 32 + kk * 8;
+      qf[t] = *(const u32x4*)r;
+      kf[t] = *(const u32x4*)(r + C);
+      vf[t] = *(const u32x4*)(r + 2 * C);
+      gf[t] = *(const u32x4*)(dO + ctok[t] * (long)C + h * 32 + kk * 8);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {   // row-major images (64-byte rows) for the transposing reads
+    *(u32x4*)(Qs + (t * 16 + l15) * 32 + kk * 8) = qf[t];
+    *(u32x4*)(Ks + (t * 16 + l15) * 32 + kk * 8) = kf[t];
+    *(u32x4*)(Gs + (t * 16 + l15) * 32 + kk * 8) = gf[t];
+  }
+  // transposed fragment of X (row tile rt, 16-dim tile dt): lane 4 qq + pp of a 16-lane group supplies row 4 kk + qq, columns 4 pp .. 4 pp + 3
+  const unsigned troff = (4 * kk + qq) * 64 + pp * 8;
+  auto tfrag = [&](const unsigned short* X, int rt0, int rt1, int dt) {
+    const unsigned a = lds_addr((const char*)X) + troff + dt * 32;
+    u32x2 lo = abm_tr(a + rt0 * 1024), hi = abm_tr(a + rt1 * 1024);
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo), "+v"(hi) : : "memory");
+    return u32x4{lo[0], lo[1], hi[0], hi[1]};
+  };
+  const float c2 = scale * 1.4426950408889634f;
+  const float ksc = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
+  const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto store4 = [&](int mat, int t, int dt, const f32x4& v) {
+    if (!clive[t]) return;
+    u32x2 u;
+    u[0] = pack_bf16x2(v[0], v[1]);
+    u[1] = pack_bf16x2(v[2], v[3]);
+    *(u32x2*)(dqkv + ctok[t] * 3L * C + (long)mat * C + h * 32 + dt * 16 + 4 * kk) = u;
+  };
+
+  // ---- pass 1: queries in the columns ------------------------------------------------------------------------------------------
+#pragma unroll
+  for (int it = 0; it < NT; ++it) {
+    const bool ilive = clive[it];
+    const int ipos = cpos[it], isl = csl[it];
+    const unsigned long long mrow = (((unsigned long long)(big ? unit : unit * SPT + isl) * n_head + h) * L + ipos) * L;
+    f32x4 st[NT], dpt[NT];
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt) {
+      st[jt] = mfma_bf16(kf[jt], qf[it], zero4);
+      dpt[jt] = mfma_bf16(vf[jt], gf[it], zero4);
+    }
+    unsigned vm = 0;
+    float mx = -INFINITY;
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int jsl, jpos; bool jlive;
+        decode(jt * 16 + 4 * kk + r, jsl, jpos, jlive);
+        const bool valid = ilive && jlive && jsl == isl && (!causal || jpos <= ipos);
+        vm |= (unsigned)valid << (jt * 4 + r);
+        if (valid) mx = fmaxf(mx, st[jt][r]);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float mm = (mx == -INFINITY) ? 0.f : mx;
+    float lsum = 0.f;
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float e = ((vm >> (jt * 4 + r)) & 1) ? __builtin_amdgcn_exp2f((st[jt][r] - mm) * c2) : 0.f;
+        st[jt][r] = e;
+        lsum += e;
+      }
+    lsum += __shfl_xor(lsum, 16);
+    lsum += __shfl_xor(lsum, 32);
+    const float inv_l = lsum > 0.f ? 1.0f / lsum : 0.f;
+    float delta = 0.f;
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = st[jt][r] * inv_l;
+        float dp = dpt[jt][r];
+        if (p_drop > 0.f) {
+          int jsl, jpos; bool jlive;
+          decode(jt * 16 + 4 * kk + r, jsl, jpos, jlive);
+          dp = dropout_keep(seed, mrow + jpos, p_drop) ? dp * ksc : 0.f;   // d(dropped prob) -> d(prob)
+        }
+        st[jt][r] = p;
+        dpt[jt][r] = dp;
+        delta += p * dp;
+      }
+    delta += __shfl_xor(delta, 16);
+    delta += __shfl_xor(delta, 32);
+    if (kk == 0) {
+      St[it * 16 + l15] = mm;
+      St[ROWS + it * 16 + l15] = inv_l;
+      St[2 * ROWS + it * 16 + l15] = delta;
+    }
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dpt[jt][r] = st[jt][r] * (dpt[jt][r] - delta) * scale;   // dS^T
+    f32x4 dq[2] = {zero4, zero4};
+#pragma unroll
+    for (int jp = 0; jp < NP; ++jp) {
+      constexpr int dummy = 0; (void)dummy;
+      const int j0 = 2 * jp, j1 = (2 * jp + 1 < NT) ? 2 * jp + 1 : 2 * jp;
+      const u32x4 pf = pack8(dpt[j0], (2 * jp + 1 < NT) ? dpt[j1] : zero4);
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) dq[dt] = mfma_bf16(tfrag(Ks, j0, j1, dt), pf, dq[dt]);
+    }
+    store4(0, it, 0, dq[0]);
+    store4(0, it, 1, dq[1]);
+  }
+
+  // ---- pass 2: keys in the columns ---------------------------------------------------------------------------------------------
+#pragma unroll
+  for (int jt = 0; jt < NT; ++jt) {
+    const bool jlive = clive[jt];
+    const int jpos = cpos[jt], jsl = csl[jt];
+    f32x4 sv[NT], dp[NT];
+#pragma unroll
+    for (int it = 0; it < NT; ++it) {
+      sv[it] = mfma_bf16(qf[it], kf[jt], zero4);
+      dp[it] = mfma_bf16(gf[it], vf[jt], zero4);
+    }
+#pragma unroll
+    for (int it = 0; it < NT; ++it) {
+      const f32x4 m4 = *(const f32x4*)(St + it * 16 + 4 * kk), il4 = *(const f32x4*)(St + ROWS + it * 16 + 4 * kk);
+      const f32x4 de4 = *(const f32x4*)(St + 2 * ROWS + it * 16 + 4 * kk);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int isl, ipos; bool ilive;
+        decode(it * 16 + 4 * kk + r, isl, ipos, ilive);
+        const bool valid = ilive && jlive && isl == jsl && (!causal || jpos <= ipos);
+        const float p = valid ? __builtin_amdgcn_exp2f((sv[it][r] - m4[r]) * c2) * il4[r] : 0.f;
+        float d = dp[it][r], pd = p;
+        if (p_drop > 0.f) {
+          const unsigned long long idx = ((((unsigned long long)(big ? unit : unit * SPT + isl) * n_head + h) * L + ipos) * L) + jpos;
+          const bool keep = dropout_keep(seed, idx, p_drop);
+          pd = keep ? p * ksc : 0.f;
+          d = keep ? d * ksc : 0.f;
+        }
+        sv[it][r] = pd;                              // dropped probabilities (dV)
+        dp[it][r] = p * (d - de4[r]) * scale;       // dS (dK)
+      }
+    }
+    f32x4 dk[2] = {zero4, zero4}, dv[2] = {zero4, zero4};
+#pragma unroll
+    for (int ip = 0; ip < NP; ++ip) {
+      const int i0 = 2 * ip, i1 = (2 * ip + 1 < NT) ? 2 * ip + 1 : 2 * ip;
+      const u32x4 pfs = pack8(dp[i0], (2 * ip + 1 < NT) ? dp[i1] : zero4);
+      const u32x4 pfp = pack8(sv[i0], (2 * ip + 1 < NT) ? sv[i1] : zero4);
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        dk[dt] = mfma_bf16(tfrag(Qs, i0, i1, dt), pfs, dk[dt]);
+        dv[dt] = mfma_bf16(tfrag(Gs, i0, i1, dt), pfp, dv[dt]);
+      }
+    }
+    store4(1, jt, 0, dk[0]);
+    store4(1, jt, 1, dk[1]);
+    store4(2, jt, 0, dv[0]);
+    store4(2, jt, 1, dv[1]);
+  }
+}
+
+template <int NT>
+void launch_attn_bwd_mfma(const void* qkv, const void* dO, void* dqkv, int C, int n_head, const TanteSeq& sq, int SPT, int units, int causal,
+                          float p_drop, unsigned long long seed, hipStream_t s) {
+  const size_t lds = 4 * (size_t)(3 * NT * 16 * 64 + 3 * NT * 16 * 4);
+  hipLaunchKernelGGL((attn_bwd_mfma_kernel<NT>), dim3(units, (n_head + 3) / 4), dim3(256), lds, s, (const unsigned short*)qkv,
+                     (const unsigned short*)dO, (unsigned short*)dqkv, C, n_head, sq, SPT, causal, 1.0f / sqrtf(32.0f), p_drop, seed);
+}
+bool try_attn_bwd_mfma(const void* qkv, const void* dO, void* dqkv, int dtype, int C, int n_head, const TanteSeq& sq, int causal, float p_drop,
+                       unsigned long long seed, hipStream_t s) {
+  static const bool off = getenv("TANTE_ATTN_BWD_VALU") != nullptr;
+  if (off || dtype != TANTE_BF16 || C != n_head * 32 || sq.L > 64 || sq.L < 1) return false;
+  if (((uintptr_t)qkv | (uintptr_t)dO | (uintptr_t)dqkv) & 15) return false;
+  const int L = sq.L;
+  const int SPT = L >= 16 ? 1 : 16 / L;
+  const int units = L >= 16 ? sq.nseq : (sq.nseq + SPT - 1) / SPT;
+  switch (L >= 16 ? (L + 15) / 16 : 1) {
+    case 1: launch_attn_bwd_mfma<1>(qkv, dO, dqkv, C, n_head, sq, SPT, units, causal, p_drop, seed, s); break;
+    case 2: launch_attn_bwd_mfma<2>(qkv, dO, dqkv, C, n_head, sq, SPT, units, causal, p_drop, seed, s); break;
+    case 3: launch_attn_bwd_mfma<3>(qkv, dO, dqkv, C, n_head, sq, SPT, units, causal, p_drop, seed, s); break;
+    default: launch_attn_bwd_mfma<4>(qkv, dO, dqkv, C, n_head, sq, SPT, units, causal, p_drop, seed, s); break;
+  }
+  return true;
+}
+
 // ---- axis propagator backward: y = x + W2 gelu(W1 x + b1) + b2 along an axis of (outer, n, inner) -----------------------
 // one lane per column; writes dx = dy + W1^T (gelu'(pre) * (W2^T dy)), and materialises h = gelu(pre) and dpre for the
 // weight-gradient GEMMs (same (outer, n, inner) layout, fp32)
@@ -594,6 +832,10 @@ extern "C" int tante_attention_bwd(const void* qkv, const void* dO, void* dqkv, 
   if (n_head <= 0 || C % n_head) TANTE_FAIL(-1, "tante_attention_bwd: bad heads");
   if (seq->L > 128) TANTE_FAIL(-2, "tante_attention_bwd: sequences longer than 128 are not on the train path yet (L=%d)", seq->L);
   hipStream_t s = (hipStream_t)stream;
+  if (try_attn_bwd_mfma(qkv, dO, dqkv, dtype, C, n_head, *seq, causal, p_drop, seed, s)) {
+    TANTE_CHECK_LAUNCH();
+    return 0;
+  }
   switch (C / n_head) {
     case 4: launch_attn_bwd<4>(qkv, dO, dqkv, dtype, C, n_head, *seq, causal, p_drop, seed, s); break;
     case 8: launch_attn_bwd<8>(qkv, dO, dqkv, dtype, C, n_head, *seq, causal, p_drop, seed, s); break;

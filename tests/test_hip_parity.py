@@ -729,6 +729,35 @@ def test_attention_dropout_gradient_matches_finite_differences(dev, causal):
         assert abs(num - float(dq[i, j])) < 2e-2 * max(1.0, abs(num)), (i, j, num, float(dq[i, j]))
 
 
+@pytest.mark.parametrize("p", [0.0, 0.25])
+@pytest.mark.parametrize("letter,B,T,H,W,causal", [("T", 2, 4, 6, 5, True), ("T", 1, 3, 4, 7, False), ("H", 2, 2, 16, 3, False),
+                                                    ("W", 1, 2, 3, 48, False), ("H", 1, 2, 20, 3, True), ("W", 2, 1, 2, 64, False),
+                                                    ("L", 3, 1, 6, 6, False), ("W", 1, 3, 5, 32, True), ("T", 3, 9, 2, 2, True)])
+def test_attention_bwd_mfma_matches_fp32_kernel(dev, letter, B, T, H, W, causal, p):
+    """bf16 attention backward with head dim 32 and L <= 64 runs on the matrix cores (attn_bwd_mfma_kernel): every axis letter's token
+    stride pattern, sequence lengths below / at / between / above 16-slot tiles, causal masks, 5 heads (a ragged group of four), with and
+    without attention dropout, against the fp32 lane-per-token kernel on the same bf16-rounded operands and the same seed."""
+    import ctypes as Ct
+    from tante_amd import _lib as L, kernels as Kk
+    nh, C = 5, 160
+    seq = Kk.make_seq(letter, B, T, H, W)
+    n = B * T * H * W
+    g = torch.Generator().manual_seed(n + seq.L)
+    qkv = torch.randn(n, 3 * C, generator=g).to(torch.bfloat16).to(dev)
+    do = torch.randn(n, C, generator=g).to(torch.bfloat16).to(dev)
+    s = torch.cuda.current_stream().cuda_stream
+    d16 = torch.full((n + 1, 3 * C), float("nan"), dtype=torch.bfloat16, device=dev)
+    L.check(L.lib().tante_attention_bwd(qkv.data_ptr(), do.data_ptr(), d16.data_ptr(), L.BF16, C, nh, Ct.byref(seq), int(causal), p, 99, s))
+    d32 = torch.empty(n, 3 * C, device=dev)
+    q32, g32 = qkv.float(), do.float()
+    L.check(L.lib().tante_attention_bwd(q32.data_ptr(), g32.data_ptr(), d32.data_ptr(), L.F32, C, nh, Ct.byref(seq), int(causal), p, 99, s))
+    assert torch.isnan(d16[n].float()).all() and torch.isfinite(d16[:n].float()).all()
+    for m, name in enumerate(("dq", "dk", "dv")):
+        a, b = d16[:n, m * C:(m + 1) * C].float(), d32[:, m * C:(m + 1) * C]
+        err = float((a - b).abs().max() / b.abs().max())
+        assert err < 1e-2, (name, err)                  # bf16 bar of the round: 1e-2 relative
+
+
 def test_train_step_with_dropout_runs(dev):
     import tante_amd
     g, m, md = _g9_model(dev)
