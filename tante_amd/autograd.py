@@ -115,6 +115,34 @@ class LayerNormFn(Function):
         return dx, None, None
 
 
+class LayerNormSkipFn(Function):
+    """(normalised x, x): the second output is the input itself, to be used as the skip operand of the residual add that closes the
+    pre-LN branch.  Its gradient then arrives HERE together with the branch's, and the LayerNorm backward kernel adds it while it writes
+    dx (its `dskip` operand) -- otherwise autograd sums the two with a stand-alone elementwise add over the residual stream per LayerNorm."""
+
+    @staticmethod
+    def forward(ctx, x, eps, out_dtype):
+        M, Cc = x.shape
+        xh = torch.empty(M, Cc, dtype=out_dtype, device=x.device)
+        st = torch.empty(M, 2, dtype=torch.float32, device=x.device)
+        L.check(L.lib().tante_layernorm_fwd(x.data_ptr(), M, Cc, eps, xh.data_ptr(), _DT[out_dtype], st.data_ptr(), _s()), "ln_fwd")
+        ctx.save_for_backward(x, st)
+        return xh, x.view(M, Cc)
+
+    @staticmethod
+    def backward(ctx, g, gskip):
+        x, st = ctx.saved_tensors
+        if g is None:
+            return gskip, None, None
+        g = g.contiguous()
+        if gskip is not None and (gskip.dtype != torch.float32 or not gskip.is_contiguous()):
+            gskip = gskip.float().contiguous()
+        dx = torch.empty_like(x)
+        L.check(L.lib().tante_layernorm_bwd(g.data_ptr(), _DT[g.dtype], x.data_ptr(), st.data_ptr(), None if gskip is None else gskip.data_ptr(),
+                                            x.shape[0], x.shape[1], dx.data_ptr(), _s()), "ln_bwd")
+        return dx, None, None
+
+
 class LinearFn(Function):
     """y = a @ W^T + b (+ residual).  a (M, K) fp32 / bf16, W (N, K) fp32 master, y in out_dtype (fp32 when a residual is added)."""
 

@@ -60,13 +60,15 @@ def rollout_model(model, batch: Dict, formatter, n_steps: int, device=None):
     if isinstance(model, TANTE) and model.deg and not torch.is_grad_enabled() and moving.shape[1] == model.T \
             and moving.dtype == torch.float32:
         return formatter.process_output(_rollout_in_place(model, moving, n_steps)), y_ref.to(device)
+    from .train_forward import fold_scope
     preds, produced = [], 0
-    while produced < n_steps:
-        y = model(moving)
-        produced += y.shape[1]
-        if produced < n_steps:
-            moving = torch.cat([moving[:, y.shape[1]:], y], dim=1)
-        preds.append(formatter.process_output(y))
+    with fold_scope():      # the re-fed calls of one rollout share one autograd graph (and one folded copy of every LayerNorm affine)
+        while produced < n_steps:
+            y = model(moving)
+            produced += y.shape[1]
+            if produced < n_steps:
+                moving = torch.cat([moving[:, y.shape[1]:], y], dim=1)
+            preds.append(formatter.process_output(y))
     return torch.cat(preds, dim=1)[:, :n_steps], y_ref.to(device)
 
 
@@ -77,15 +79,17 @@ def rollout_adaptive(model, batch: Dict, formatter, n_steps: int, out_T: float, 
     xs, y_ref = formatter.process_input(batch)
     xs = xs[0].to(device)
     chunks = [xs[i:i + 1] for i in range(xs.shape[0])] if per_sample else [xs]
+    from .train_forward import fold_scope
     rts, outs = [], []
-    for moving in chunks:
-        preds, produced = [], 0
-        while produced < n_steps:
-            y, rt = model(moving, out_T)
-            produced += y.shape[1]
-            if produced < n_steps:
-                moving = torch.cat([moving[:, y.shape[1]:], y], dim=1)
-            preds.append(formatter.process_output(y))
-            rts.append(rt)
-        outs.append(torch.cat(preds, dim=1)[:, :n_steps])
+    with fold_scope():
+        for moving in chunks:
+            preds, produced = [], 0
+            while produced < n_steps:
+                y, rt = model(moving, out_T)
+                produced += y.shape[1]
+                if produced < n_steps:
+                    moving = torch.cat([moving[:, y.shape[1]:], y], dim=1)
+                preds.append(formatter.process_output(y))
+                rts.append(rt)
+            outs.append(torch.cat(preds, dim=1)[:, :n_steps])
     return torch.cat(outs, dim=0), y_ref.to(device), torch.cat(rts, dim=0)

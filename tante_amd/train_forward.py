@@ -12,14 +12,41 @@ import torch
 from . import _lib as L
 from . import kernels as K
 from . import stages as S
-from .autograd import (ActFn, AttentionFn, AxisMlpFn, DeconvFn, DropoutAddFn, FilmPosFn, LayerNormFn, LinearFn, PatchEmbedFn, RtReduceFn,
+from .autograd import (ActFn, AttentionFn, AxisMlpFn, DeconvFn, DropoutAddFn, FilmPosFn, LayerNormFn, LayerNormSkipFn, LinearFn, PatchEmbedFn, RtReduceFn,
                        TaylorFn)
+
+
+_FOLDS = None   # (id(ln), id(W)) -> (W diag(gamma), b + W beta) while a fold_scope is open
+
+
+class fold_scope:
+    """One autograd graph's worth of folded LayerNorm affines.  A BPTT rollout calls every block n_steps times with the same weights;
+    folding (two torch ops), re-packing the folded weight for the forward and the dgrad GEMM, and back-propagating through the fold
+    once per CALL was ~10 % of the train step in ~2000 tiny launches.  Inside a scope the fold is built once and shared: autograd sums
+    the per-call gradients of the folded weight and runs the fold's backward once.  The scope must not outlive its graph (the fold's
+    saved tensors are freed by backward), so the rollouts open one per call."""
+
+    def __enter__(self):
+        global _FOLDS
+        self.prev, _FOLDS = _FOLDS, {}
+        return self
+
+    def __exit__(self, *exc):
+        global _FOLDS
+        _FOLDS = self.prev
+        return False
 
 
 def _folded(lin_w, lin_b, ln):
     """LayerNorm affine folded into the consumer: (W diag(gamma), b + W beta) -- parameter-sized torch expressions whose
     autograd distributes the gradients back to W, b, gamma, beta."""
-    return lin_w * ln.weight[None, :], lin_b + lin_w @ ln.bias
+    if _FOLDS is None or not torch.is_grad_enabled():
+        return lin_w * ln.weight[None, :], lin_b + lin_w @ ln.bias
+    key = (id(ln), id(lin_w))
+    hit = _FOLDS.get(key)
+    if hit is None:
+        hit = _FOLDS[key] = (lin_w * ln.weight[None, :], lin_b + lin_w @ ln.bias)
+    return hit
 
 
 def block_train(blk, x: torch.Tensor, seq, causal: bool, compute: int) -> torch.Tensor:
@@ -27,7 +54,7 @@ def block_train(blk, x: torch.Tensor, seq, causal: bool, compute: int) -> torch.
     adt = K.act_torch_dtype(compute)
     a, m = blk.attn, blk.mlp
     w_in, b_in = _folded(a.in_proj_weight, a.in_proj_bias, blk.ln1)
-    xh = LayerNormFn.apply(x, blk.ln1.eps, adt)
+    xh, x = LayerNormSkipFn.apply(x, blk.ln1.eps, adt)      # x: the same tokens, as the skip operand whose gradient LN's backward adds
     qkv = LinearFn.apply(xh, w_in, b_in, None, compute, adt)
     o = AttentionFn.apply(qkv, seq, blk.embed_dim, blk.n_head, causal, p)
     if p > 0.0:
@@ -35,7 +62,7 @@ def block_train(blk, x: torch.Tensor, seq, causal: bool, compute: int) -> torch.
     else:
         x = LinearFn.apply(o, a.out_proj.weight, a.out_proj.bias, x, compute, torch.float32)
     w1, b1 = _folded(m[0].weight, m[0].bias, blk.ln2)
-    xh2 = LayerNormFn.apply(x, blk.ln2.eps, adt)
+    xh2, x = LayerNormSkipFn.apply(x, blk.ln2.eps, adt)
     hpre = LinearFn.apply(xh2, w1, b1, None, compute, adt)
     h = ActFn.apply(hpre, L.ACT_GELU_TANH, adt)
     if p > 0.0:
