@@ -11,6 +11,7 @@
 //   LONG  (L  > 256): a workgroup owns 256 consecutive queries of one (sequence, head) and walks the
 //                     keys in chunks of KC through LDS (flash-style), causal chunks skipped.
 #include "common.cuh"
+#include "fused_common.cuh"
 
 namespace {
 
@@ -222,6 +223,149 @@ int launch_attn(const void* qkv, void* o, int dtype, int C, int n_head, const Ta
   return 0;
 }
 
+// ---- small-sequence attention on the matrix cores: bf16, head dim 32, L <= 64 (the train path's forward) ---------------------------
+// Same unit / tile scheme as attn_bwd_mfma_kernel (backward.hip): one wave per (unit, head), a unit being one sequence in NT 16-slot
+// tiles or the 16 / L sequences of one tile behind a block-diagonal mask.  S^T = K Q^T puts a query in each lane's column, so the row
+// statistics are two cross-group shuffles; the (dropped) probabilities of two key tiles pack straight into the B operand of
+// O^T = V^T P^T, whose A operand is two transposing LDS reads of the row-major V image.
+__device__ __forceinline__ u32x2 afm_tr(unsigned addr) {
+  u32x2 r;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r) : "v"(addr) : "memory");
+  return r;
+}
+template <int NT>
+__global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const unsigned short* __restrict__ qkv, unsigned short* __restrict__ o, int C, int n_head,
+                                                            TanteSeq sq, int SPT, int causal, float scale, float p_drop, unsigned long long seed) {
+  constexpr int ROWS = NT * 16, NP = (NT + 1) / 2;
+  extern __shared__ __attribute__((aligned(16))) char sm_raw[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kk = lane >> 4, l15 = lane & 15, qq = l15 >> 2, pp = l15 & 3;
+  const int h = blockIdx.y * 4 + wave;
+  if (h >= n_head) return;                       // no barriers: each wave owns its slice of LDS
+  unsigned short* Vs = (unsigned short*)(sm_raw + wave * ROWS * 64);
+  const int L = sq.L, unit = blockIdx.x;
+  const bool big = L >= 16;
+  const unsigned rcpL = (65536u + L - 1) / L;    // floor(slot / L) for slot < 16
+  auto decode = [&](int slot, int& sl, int& pos, bool& live) {
+    sl = big ? 0 : (int)(((unsigned)slot * rcpL) >> 16);
+    pos = slot - sl * L;
+    const int seq = big ? unit : unit * SPT + sl;
+    live = (big ? pos < L : sl < SPT) && seq < sq.nseq;
+  };
+  long ctok[NT];
+  int csl[NT], cpos[NT];
+  bool clive[NT];
+  u32x4 qf[NT], kf[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    decode(t * 16 + l15, csl[t], cpos[t], clive[t]);
+    const int seq = big ? unit : unit * SPT + csl[t];
+    ctok[t] = clive[t] ? (long)(seq / sq.n_s0) * sq.S1 + (long)(seq % sq.n_s0) * sq.S0 + (long)(cpos[t] / sq.n_l0) * sq.P1 +
+                             (long)(cpos[t] % sq.n_l0) * sq.P0 : 0;
+    u32x4 vf = u32x4{0u, 0u, 0u, 0u};
+    qf[t] = kf[t] = vf;
+    if (clive[t]) {
+      const unsigned short* r = qkv + ctok[t] * 3L * C + h * 32 + kk * 8;
+      qf[t] = *(const u32x4*)r;
+      kf[t] = *(const u32x4*)(r + C);
+      vf = *(const u32x4*)(r + 2 * C);
+    }
+    *(u32x4*)(Vs + (t * 16 + l15) * 32 + kk * 8) = vf;   // row-major image (64-byte rows) for the transposing reads
+  }
+  const unsigned troff = lds_addr((const char*)Vs) + (4 * kk + qq) * 64 + pp * 8;
+  const float c2 = scale * 1.4426950408889634f;
+  const float ksc = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
+  const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int it = 0; it < NT; ++it) {
+    const bool ilive = clive[it];
+    const int ipos = cpos[it], isl = csl[it];
+    const unsigned long long mrow = (((unsigned long long)(big ? unit : unit * SPT + isl) * n_head + h) * L + ipos) * L;
+    f32x4 st[NT];
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt) st[jt] = mfma_bf16(kf[jt], qf[it], zero4);
+    unsigned vm = 0;
+    float mx = -INFINITY;
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int jsl, jpos; bool jlive;
+        decode(jt * 16 + 4 * kk + r, jsl, jpos, jlive);
+        const bool valid = ilive && jlive && jsl == isl && (!causal || jpos <= ipos);
+        vm |= (unsigned)valid << (jt * 4 + r);
+        if (valid) mx = fmaxf(mx, st[jt][r]);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float mm = (mx == -INFINITY) ? 0.f : mx;
+    float lsum = 0.f;
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float e = ((vm >> (jt * 4 + r)) & 1) ? __builtin_amdgcn_exp2f((st[jt][r] - mm) * c2) : 0.f;
+        st[jt][r] = e;
+        lsum += e;
+      }
+    lsum += __shfl_xor(lsum, 16);
+    lsum += __shfl_xor(lsum, 32);
+    const float inv_l = lsum > 0.f ? 1.0f / lsum : 0.f;
+    if (p_drop > 0.f) {
+#pragma unroll
+      for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          int jsl, jpos; bool jlive;
+          decode(jt * 16 + 4 * kk + r, jsl, jpos, jlive);
+          st[jt][r] = dropout_keep(seed, mrow + jpos, p_drop) ? st[jt][r] * ksc : 0.f;
+        }
+    }
+    f32x4 oa[2] = {zero4, zero4};
+#pragma unroll
+    for (int jp = 0; jp < NP; ++jp) {
+      const int j0 = 2 * jp, j1 = (2 * jp + 1 < NT) ? 2 * jp + 1 : 2 * jp;
+      const u32x4 pf = pack8(st[j0], (2 * jp + 1 < NT) ? st[j1] : zero4);   // un-normalised: 1 / l scales the 8 outputs instead
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        u32x2 lo = afm_tr(troff + dt * 32 + j0 * 1024), hi = afm_tr(troff + dt * 32 + j1 * 1024);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo), "+v"(hi) : : "memory");
+        oa[dt] = mfma_bf16(u32x4{lo[0], lo[1], hi[0], hi[1]}, pf, oa[dt]);
+      }
+    }
+    if (ilive) {
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        u32x2 u;
+        u[0] = pack_bf16x2(oa[dt][0] * inv_l, oa[dt][1] * inv_l);
+        u[1] = pack_bf16x2(oa[dt][2] * inv_l, oa[dt][3] * inv_l);
+        *(u32x2*)(o + ctok[it] * (long)C + h * 32 + dt * 16 + 4 * kk) = u;
+      }
+    }
+  }
+}
+
+template <int NT>
+void launch_attn_fwd_mfma(const void* qkv, void* o, int C, int n_head, const TanteSeq& sq, int SPT, int units, int causal, float p_drop,
+                          unsigned long long seed, hipStream_t s) {
+  hipLaunchKernelGGL((attn_fwd_mfma_kernel<NT>), dim3(units, (n_head + 3) / 4), dim3(256), 4 * (size_t)NT * 16 * 64, s, (const unsigned short*)qkv,
+                     (unsigned short*)o, C, n_head, sq, SPT, causal, 1.0f / sqrtf(32.0f), p_drop, seed);
+}
+bool try_attn_fwd_mfma(const void* qkv, void* o, int dtype, int C, int n_head, const TanteSeq& sq, int causal, float p_drop, unsigned long long seed,
+                       hipStream_t s) {
+  static const bool off = getenv("TANTE_ATTN_FWD_VALU") != nullptr;
+  if (off || dtype != TANTE_BF16 || C != n_head * 32 || sq.L > 64 || sq.L < 1) return false;
+  const int L = sq.L;
+  const int SPT = L >= 16 ? 1 : 16 / L;
+  const int units = L >= 16 ? sq.nseq : (sq.nseq + SPT - 1) / SPT;
+  switch (L >= 16 ? (L + 15) / 16 : 1) {
+    case 1: launch_attn_fwd_mfma<1>(qkv, o, C, n_head, sq, SPT, units, causal, p_drop, seed, s); break;
+    case 2: launch_attn_fwd_mfma<2>(qkv, o, C, n_head, sq, SPT, units, causal, p_drop, seed, s); break;
+    case 3: launch_attn_fwd_mfma<3>(qkv, o, C, n_head, sq, SPT, units, causal, p_drop, seed, s); break;
+    default: launch_attn_fwd_mfma<4>(qkv, o, C, n_head, sq, SPT, units, causal, p_drop, seed, s); break;
+  }
+  return true;
+}
+
 }  // namespace
 
 static int attention_impl(const void* qkv, void* o, int dtype, int C, int n_head, const TanteSeq* seq, int causal, float p_drop,
@@ -235,6 +379,10 @@ static int attention_impl(const void* qkv, void* o, int dtype, int C, int n_head
   if (p_drop > 0.0f && seq->L > 256) TANTE_FAIL(-2, "tante_attention: attention dropout is implemented for sequences up to 256 tokens");
   if (p_drop < 0.0f || p_drop >= 1.0f) TANTE_FAIL(-1, "tante_attention: dropout probability must be in [0, 1)");
   hipStream_t s = (hipStream_t)stream;
+  if (try_attn_fwd_mfma(qkv, o, dtype, C, n_head, *seq, causal, p_drop, seed, s)) {
+    TANTE_CHECK_LAUNCH();
+    return 0;
+  }
   switch (d) {
     case 4: launch_attn<4>(qkv, o, dtype, C, n_head, *seq, causal, p_drop, seed, s); break;
     case 8: launch_attn<8>(qkv, o, dtype, C, n_head, *seq, causal, p_drop, seed, s); break;

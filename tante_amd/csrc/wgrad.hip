@@ -297,12 +297,12 @@ __device__ __forceinline__ u32x2 ds_read_tr16_b64(unsigned addr) {
 
 __global__ __launch_bounds__(256, 2) void wgrad_tr_kernel(const unsigned short* __restrict__ U, long ldu, const unsigned short* __restrict__ V,
                                                           long ldv, long R, int I, int J, long rows_per_split, float* __restrict__ dW,
-                                                          float* __restrict__ dbias, int layout, int P, int Co, int swap) {
+                                                          float* __restrict__ dbias, int layout, int P, int Co, int swap, int debug) {
   extern __shared__ __attribute__((aligned(16))) char wsm[];   // ring: [buf][U chunk | V chunk]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kk = lane >> 4, l15 = lane & 15;
   const int i0 = blockIdx.x * WT, j0 = blockIdx.y * WT;
   const long r_begin = (long)blockIdx.z * rows_per_split, r_end = min(R, r_begin + rows_per_split);
-  const int nchunk = (int)((r_end - r_begin) / WRC);
+  const int nchunk = (debug & 2) ? 0 : (int)((r_end - r_begin) / WRC);
   const int wi = wave >> 1, wj = wave & 1;
   // DMA: a wave instruction moves 4 rows (lanes 16 q .. 16 q + 15 = row q); wave w copies rows 8 w .. 8 w + 7 of the chunk
   auto issue = [&](int c) {
@@ -381,6 +381,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_tr_kernel(const unsigned short* 
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {
         const int i = i0 + wi * 64 + a * 16 + kk * 4 + rg, j = j0 + wj * 64 + b * 16 + l15;
+        if ((debug & 1) && acc[a][b][rg] != 12345.f) continue;
         atomicAdd(&dW[out_index(layout, i, j, I, J, P, Co, swap)], acc[a][b][rg]);
       }
   if (do_bias && l15 == 0) {
@@ -447,10 +448,11 @@ extern "C" int tante_wgrad(const TanteRowMat* U, const TanteRowMat* V, int64_t R
     long per = ((nch + split - 1) / split) * WRC;
     split = (R + per - 1) / per;
     const size_t lds = (size_t)WNBUF * 2 * WCHUNK;
+    static const int wdebug = getenv("TANTE_WGRAD_DEBUG") ? atoi(getenv("TANTE_WGRAD_DEBUG")) : 0;
     static bool set = false;
     if (!set) { hipFuncSetAttribute((const void*)wgrad_tr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set = true; }
     hipLaunchKernelGGL(wgrad_tr_kernel, dim3(ti, tj, (unsigned)split), dim3(256), lds, s, (const unsigned short*)U->p + U->off, (long)U->s0,
-                       (const unsigned short*)V->p + V->off, (long)V->s0, (long)R, I, J, per, dW, dbias, layout, P, C_other, swap);
+                       (const unsigned short*)V->p + V->off, (long)V->s0, (long)R, I, J, per, dW, dbias, layout, P, C_other, swap, wdebug);
     TANTE_CHECK_LAUNCH();
     return 0;
   }

@@ -758,6 +758,31 @@ def test_attention_bwd_mfma_matches_fp32_kernel(dev, letter, B, T, H, W, causal,
         assert err < 1e-2, (name, err)                  # bf16 bar of the round: 1e-2 relative
 
 
+@pytest.mark.parametrize("p", [0.0, 0.25])
+@pytest.mark.parametrize("letter,B,T,H,W,causal", [("T", 2, 4, 6, 5, True), ("T", 1, 3, 4, 7, False), ("H", 2, 2, 16, 3, False),
+                                                    ("W", 1, 2, 3, 48, False), ("H", 1, 2, 20, 3, True), ("W", 2, 1, 2, 64, False),
+                                                    ("L", 3, 1, 6, 6, False), ("W", 1, 3, 5, 32, True), ("T", 3, 9, 2, 2, True)])
+def test_attention_fwd_mfma_matches_fp32_kernel(dev, letter, B, T, H, W, causal, p):
+    """The forward counterpart (attn_fwd_mfma_kernel): bf16, head dim 32, L <= 64 on the matrix cores against the fp32 lane-per-token
+    kernel on the same bf16-rounded operands, same dropout seed."""
+    import ctypes as Ct
+    from tante_amd import _lib as L, kernels as Kk
+    nh, C = 5, 160
+    seq = Kk.make_seq(letter, B, T, H, W)
+    n = B * T * H * W
+    g = torch.Generator().manual_seed(n + seq.L + 1)
+    qkv = torch.randn(n, 3 * C, generator=g).to(torch.bfloat16).to(dev)
+    s = torch.cuda.current_stream().cuda_stream
+    o16 = torch.full((n + 1, C), float("nan"), dtype=torch.bfloat16, device=dev)
+    L.check(L.lib().tante_attention_dropout(qkv.data_ptr(), o16.data_ptr(), L.BF16, C, nh, Ct.byref(seq), int(causal), p, 99, s))
+    q32 = qkv.float()
+    o32 = torch.empty(n, C, device=dev)
+    L.check(L.lib().tante_attention_dropout(q32.data_ptr(), o32.data_ptr(), L.F32, C, nh, Ct.byref(seq), int(causal), p, 99, s))
+    assert torch.isnan(o16[n].float()).all() and torch.isfinite(o16[:n].float()).all()
+    err = float((o16[:n].float() - o32).abs().max() / o32.abs().max())
+    assert err < 1e-2, err
+
+
 def test_train_step_with_dropout_runs(dev):
     import tante_amd
     g, m, md = _g9_model(dev)
