@@ -317,6 +317,17 @@ class AxisMlpFn(Function):
         return dx, dw1, db1, dw2, db2, None, None, None, None
 
 
+def _tr_shape(M: int, I: int, J: int) -> bool:
+    """Shapes the LDS-DMA / transposed-read weight-gradient kernel takes (bf16 dense rows)."""
+    return M % 32 == 0 and I % 128 == 0 and J % 128 == 0
+
+
+def _to_bf16(t: torch.Tensor) -> torch.Tensor:
+    out = torch.empty(t.shape, dtype=torch.bfloat16, device=t.device)
+    L.check(L.lib().tante_act_fwd(t.data_ptr(), L.F32, out.data_ptr(), L.BF16, t.numel(), L.ACT_NONE, _s()), "tante_act_fwd")
+    return out
+
+
 class PatchEmbedFn(Function):
     """Kernel = stride = P convolution as a patch GEMM; x (n_img, Cin, H, W) [nchw] or (n_img, H, W, Cin); out (rows, Cout) channels-last,
     PRE-activation."""
@@ -355,14 +366,19 @@ class PatchEmbedFn(Function):
             K.deconv(d, pwt, dx, n_img=n_img, Hi=Hin // P, Wi=Win // P, P=P, Cout=Cin, nchw_out=nchw, act=L.ACT_NONE)
             dx = dx.view(x.shape)
         if ctx.needs_input_grad[1]:
-            V = _rm_patch(x, not nchw, n_img, Hin, Win, Cin, P)
+            U, V = _rm_linear(d), _rm_patch(x, not nchw, n_img, Hin, Win, Cin, P)
+            if comp == L.BF16 and not nchw and x.dtype == torch.bfloat16 and _tr_shape(M, Cout, Kk):
+                # a kernel = stride patch matrix is a permutation of the image: one 2 x 25 MB copy buys the dense-row weight-gradient
+                # kernel (~45 us) instead of the gathering one (~240 us at 24576 x 256 x 512)
+                cols = K.im2col(x, False, n_img, Cin, Hin, Win, P, P, P, P, 0, 0, 1, torch.bfloat16)
+                U, V = _rm_linear(d if d.dtype == torch.bfloat16 else _to_bf16(d)), _rm_linear(cols)
             gW, gb = _grad_slot(ctx.params[0]), _grad_slot(ctx.params[1])
             lay = L.W_LINEAR if nchw else L.W_CONV_NHWC
             if gW is not None and gb is not None and ctx.needs_input_grad[2]:
-                wgrad(_rm_linear(d), V, M, Cout, Kk, tuple(W.shape), comp, layout=lay, P=P, C_other=Cin, device=x.device, with_bias=True,
+                wgrad(U, V, M, Cout, Kk, tuple(W.shape), comp, layout=lay, P=P, C_other=Cin, device=x.device, with_bias=True,
                       into=gW, db_into=gb)
             else:
-                dW, db = wgrad(_rm_linear(d), V, M, Cout, Kk, tuple(W.shape), comp, layout=lay, P=P, C_other=Cin, device=x.device,
+                dW, db = wgrad(U, V, M, Cout, Kk, tuple(W.shape), comp, layout=lay, P=P, C_other=Cin, device=x.device,
                                with_bias=True)
         elif ctx.needs_input_grad[2]:
             db = colsum(d, M, Cout, 1)
@@ -397,15 +413,26 @@ class DeconvFn(Function):
         d = d.contiguous()
         M, N = n_img * Hi * Wi, Cout * P * P
         da = dW = db = None
-        if ctx.needs_input_grad[0]:      # gather the P x P output-gradient patch of every input pixel
+        # the P x P output-gradient patch of every input pixel, once, as dense bf16 rows: both the data-gradient GEMM and the
+        # weight-gradient kernel then run their dense-row variants instead of gathering
+        cols = None
+        if comp == L.BF16 and not nchw_out and d.dtype == torch.bfloat16 and N <= 512 and _tr_shape(M, Cin, N) \
+                and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]):
+            cols = K.im2col(d, False, n_img, Cout, Hi * P, Wi * P, P, P, P, P, 0, 0, 1, torch.bfloat16)
+        if ctx.needs_input_grad[0]:
             lay = L.W_DECONV_NCHW_T if nchw_out else L.W_DECONV_NHWC_T
             pwt = _packed(W, None, comp, lay, N=Cin, K=N, P=P, C_other=Cout)
             da = torch.empty(M, Cin, dtype=a.dtype, device=a.device)
-            K.patch_embed(d, pwt, da, n_img=n_img, Hin=Hi * P, Win=Wi * P, Cin=Cout, P=P, nchw=nchw_out, act=L.ACT_NONE)
+            if cols is not None:
+                K.linear(cols, pwt, da, M=M)
+            else:
+                K.patch_embed(d, pwt, da, n_img=n_img, Hin=Hi * P, Win=Wi * P, Cin=Cout, P=P, nchw=nchw_out, act=L.ACT_NONE)
             da = da.view(a.shape)
         if ctx.needs_input_grad[1]:
-            V = _rm_patch(d, not nchw_out, n_img, Hi * P, Wi * P, Cout, P)
+            V = _rm_linear(cols) if cols is not None else _rm_patch(d, not nchw_out, n_img, Hi * P, Wi * P, Cout, P)
             gW = _grad_slot(ctx.params[0])
+            if cols is not None and a.dtype != torch.bfloat16:     # the first stage reads the fp32 residual stream
+                a = _to_bf16(a)
             dW = wgrad(_rm_linear(a), V, M, Cin, N, tuple(W.shape), comp, layout=L.W_DECONV_NCHW if nchw_out else L.W_DECONV_NHWC, P=P,
                        C_other=Cout, swap=True, device=a.device, into=gW)
             if gW is not None:
