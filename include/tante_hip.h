@@ -350,6 +350,10 @@ int tante_dropout_bwd(const float* dout, float p, uint64_t seed, int64_t n, void
  * the weight-gradient GEMMs */
 int tante_axis_mlp_bwd(const float* x, const float* dy, int64_t outer, int n, int64_t inner, const float* w1, const float* b1,
                        const float* w2, float* dx, float* h, float* dpre, void* stream);
+/* weight / bias gradients of one propagator layer from two (outer, n, inner) fp32 tensors in the residual stream's layout:
+ * dW[a][j] (+)= sum_{o,i} U[o][a][i] V[o][j][i], db[a] (+)= sum_{o,i} U[o][a][i] (db may be NULL); n <= 64, inner % 16 == 0.
+ * (dW2 = <dy, h>, dW1 = <dpre, x> of attn_backbone.py:111-119's two Linear layers.) */
+int tante_axis_wgrad(const float* U, const float* V, int64_t outer, int n, int64_t inner, float* dW, float* db, int accumulate, void* stream);
 
 /* A gathered row matrix (rows r, `cols` columns): LINEAR rows at (r/n0)*s1 + (r%n0)*s0 + off with element stride es, or the
  * k = s patches of an image batch exactly as in TanteGemm (n0 images per batch item, s1 elements between items). */

@@ -308,6 +308,19 @@ class AxisMlpFn(Function):
         # the bias gradients are column sums of the wgrad kernels' first operand: they fall out of the tiles those already stage
         # (two stand-alone colsum passes over the residual stream cost 1.5 ms of a 41 ms step)
         slots = [_grad_slot(q) for q in ctx.params]
+        if n <= 64 and inner % 16 == 0:
+            # the contraction index (inner) is contiguous in this layout: a dedicated fp32-MFMA kernel streams both operands
+            def aw(U, V, gw, gb):
+                acc = gw is not None
+                dW = gw if acc else torch.empty(n, n, dtype=torch.float32, device=x.device)
+                dB = gb if acc else torch.empty(n, dtype=torch.float32, device=x.device)
+                L.check(L.lib().tante_axis_wgrad(U.data_ptr(), V.data_ptr(), outer, n, inner, dW.data_ptr(), dB.data_ptr(), int(acc), _s()),
+                        "tante_axis_wgrad")
+                return (None, None) if acc else (dW, dB)
+            both = all(g is not None for g in slots)
+            dw2, db2 = aw(dy, h, slots[2] if both else None, slots[3] if both else None)
+            dw1, db1 = aw(dpre, x, slots[0] if both else None, slots[1] if both else None)
+            return dx, dw1, db1, dw2, db2, None, None, None, None
         if all(g is not None for g in slots):
             wgrad(lines(dy), lines(h), R, n, n, (n, n), comp, device=x.device, with_bias=True, into=slots[2], db_into=slots[3])
             wgrad(lines(dpre), lines(x), R, n, n, (n, n), comp, device=x.device, with_bias=True, into=slots[0], db_into=slots[1])

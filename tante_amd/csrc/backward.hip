@@ -637,6 +637,79 @@ bool try_attn_bwd_mfma(const void* qkv, const void* dO, void* dqkv, int dtype, i
   return true;
 }
 
+// ---- axis propagator weight gradients: dW[a][j] (+)= sum_{o,i} U[o][a][i] V[o][j][i],  db[a] (+)= sum_{o,i} U[o][a][i] ---------------
+// U, V are (outer, n, inner) fp32 in the residual stream's own layout: the contraction index i is the contiguous one, so both MFMA
+// operands are natural "row, consecutive k" fragments read straight from global memory (a lane loads 4 consecutive i of row l15; MFMA s
+// of the four uses element s of every lane, i.e. k slot kk <-> i = i0 + 4 kk + s on both sides).  fp32 MFMA (16x16x4): the propagators
+// stay in fp32 in both compute modes.  The generic weight-gradient kernel gathers these operands element by element with stride
+// `inner` (85 us for 2 x 25 MB); this one streams them.
+template <int NT>
+__global__ __launch_bounds__(256) void axis_wgrad_kernel(const float* __restrict__ U, const float* __restrict__ V, long outer, int n, long inner,
+                                                         float* __restrict__ dW, float* __restrict__ db, long n_chunks) {
+  constexpr int NP = NT * 16;
+  __shared__ float red[NP * NP + NP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kk = lane >> 4, l15 = lane & 15;
+  for (int i = tid; i < NP * NP + NP; i += 256) red[i] = 0.f;
+  __syncthreads();
+  const long cpo = inner / 16;   // 16-wide chunks of the contraction per outer index
+  f32x4 acc[NT][NT], accb[NT];
+#pragma unroll
+  for (int a = 0; a < NT; ++a) {
+    accb[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int b = 0; b < NT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  auto load = [&](long c, f32x4 (&a)[NT], f32x4 (&b)[NT]) {
+    const long o = c / cpo;
+    const long base = o * n * inner + (c - o * cpo) * 16 + kk * 4;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int row = t * 16 + l15;
+      a[t] = b[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (row < n) {
+        a[t] = *(const f32x4*)(U + base + (long)row * inner);
+        b[t] = *(const f32x4*)(V + base + (long)row * inner);
+      }
+    }
+  };
+  auto fma_chunk = [&](const f32x4 (&a)[NT], const f32x4 (&b)[NT]) {
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+      for (int at = 0; at < NT; ++at) {
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt) acc[at][jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[at][s4], b[jt][s4], acc[at][jt], 0, 0, 0);
+        if (db) accb[at] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[at][s4], 1.0f, accb[at], 0, 0, 0);
+      }
+  };
+  const long stride = (long)gridDim.x * 4;
+  long c = (long)blockIdx.x * 4 + wave;
+  f32x4 a0[NT], b0[NT], a1[NT], b1[NT];
+  if (c < n_chunks) load(c, a0, b0);
+  while (c < n_chunks) {        // two chunks per trip: the next chunk's loads fly under this chunk's MFMAs
+    const long c1 = c + stride, c2 = c1 + stride;
+    if (c1 < n_chunks) load(c1, a1, b1);
+    fma_chunk(a0, b0);
+    if (c1 >= n_chunks) break;
+    if (c2 < n_chunks) load(c2, a0, b0);
+    fma_chunk(a1, b1);
+    c = c2;
+  }
+#pragma unroll
+  for (int at = 0; at < NT; ++at) {
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) atomicAdd(&red[(at * 16 + 4 * kk + r) * NP + jt * 16 + l15], acc[at][jt][r]);
+    if (db && l15 == 0)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) atomicAdd(&red[NP * NP + at * 16 + 4 * kk + r], accb[at][r]);
+  }
+  __syncthreads();
+  for (int i = tid; i < n * n; i += 256) atomicAdd(&dW[i], red[(i / n) * NP + (i % n)]);
+  if (db && tid < n) atomicAdd(&db[tid], red[NP * NP + tid]);
+}
+
 // ---- axis propagator backward: y = x + W2 gelu(W1 x + b1) + b2 along an axis of (outer, n, inner) -----------------------
 // one lane per column; writes dx = dy + W1^T (gelu'(pre) * (W2^T dy)), and materialises h = gelu(pre) and dpre for the
 // weight-gradient GEMMs (same (outer, n, inner) layout, fp32)
@@ -752,6 +825,31 @@ extern "C" int tante_act_bwd(const void* dpost, int d_dtype, const void* pre, in
   if (!dpost || !pre || !dpre || n <= 0) TANTE_FAIL(-1, "tante_act_bwd: bad argument");
   hipLaunchKernelGGL(act_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dpost, d_dtype, pre, pre_dtype, dpre,
                      out_dtype, (long)n, act);
+  TANTE_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int tante_axis_wgrad(const float* U, const float* V, int64_t outer, int n, int64_t inner, float* dW, float* db, int accumulate,
+                                void* stream) {
+  if (!U || !V || !dW || outer <= 0 || n <= 0 || inner <= 0) TANTE_FAIL(-1, "tante_axis_wgrad: bad argument");
+  if (n > 64) TANTE_FAIL(-2, "tante_axis_wgrad: axis length %d > 64", n);
+  if (inner % 16 || (((uintptr_t)U | (uintptr_t)V) & 15)) TANTE_FAIL(-2, "tante_axis_wgrad: inner must be a multiple of 16 and the operands 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  if (!accumulate) {
+    if (hipMemsetAsync(dW, 0, (size_t)n * n * sizeof(float), s) != hipSuccess) TANTE_FAIL(-3, "tante_axis_wgrad: memset failed");
+    if (db && hipMemsetAsync(db, 0, (size_t)n * sizeof(float), s) != hipSuccess) TANTE_FAIL(-3, "tante_axis_wgrad: memset failed");
+  }
+  const long n_chunks = (long)outer * (inner / 16);
+  long wgs = (n_chunks + 15) / 16;          // at least four chunks per wave
+  if (wgs > 512) wgs = 512;
+  if (wgs < 1) wgs = 1;
+#define TANTE_AW(NTV) hipLaunchKernelGGL(axis_wgrad_kernel<NTV>, dim3((unsigned)wgs), dim3(256), 0, s, U, V, (long)outer, n, (long)inner, dW, db, n_chunks)
+  switch ((n + 15) / 16) {
+    case 1: TANTE_AW(1); break;
+    case 2: TANTE_AW(2); break;
+    case 3: TANTE_AW(3); break;
+    default: TANTE_AW(4); break;
+  }
+#undef TANTE_AW
   TANTE_CHECK_LAUNCH();
   return 0;
 }

@@ -783,6 +783,29 @@ def test_attention_fwd_mfma_matches_fp32_kernel(dev, letter, B, T, H, W, causal,
     assert err < 1e-2, err
 
 
+@pytest.mark.parametrize("outer,n,inner", [(3, 4, 1024), (5, 16, 48), (7, 48, 32), (2, 33, 16), (1, 64, 80), (300, 6, 16)])
+def test_axis_wgrad_kernel(dev, outer, n, inner):
+    """tante_axis_wgrad: dW[a][j] = sum U[o][a][i] V[o][j][i], db[a] = sum U[o][a][i] on (outer, n, inner) fp32 tensors, fresh and
+    accumulating, against float64 einsums (fp32 MFMA: 1e-5 of the largest entry)."""
+    from tante_amd import _lib as L
+    g = torch.Generator().manual_seed(outer * 100 + n)
+    U = torch.randn(outer, n, inner, generator=g)
+    V = torch.randn(outer, n, inner, generator=g)
+    ref_w = torch.einsum("oai,oji->aj", U.double(), V.double())
+    ref_b = U.double().sum((0, 2))
+    Ud, Vd = U.to(dev), V.to(dev)
+    dW = torch.full((n, n), float("nan"), device=dev)
+    db = torch.full((n,), float("nan"), device=dev)
+    s = torch.cuda.current_stream().cuda_stream
+    L.check(L.lib().tante_axis_wgrad(Ud.data_ptr(), Vd.data_ptr(), outer, n, inner, dW.data_ptr(), db.data_ptr(), 0, s))
+    assert float((dW.cpu().double() - ref_w).abs().max()) < 1e-5 * float(ref_w.abs().max())
+    assert float((db.cpu().double() - ref_b).abs().max()) < 1e-5 * float(ref_b.abs().max()) + 1e-5
+    L.check(L.lib().tante_axis_wgrad(Ud.data_ptr(), Vd.data_ptr(), outer, n, inner, dW.data_ptr(), db.data_ptr(), 1, s))
+    assert float((dW.cpu().double() - 2 * ref_w).abs().max()) < 2e-5 * float(ref_w.abs().max())
+    L.check(L.lib().tante_axis_wgrad(Ud.data_ptr(), Vd.data_ptr(), outer, n, inner, dW.data_ptr(), None, 0, s))   # without the bias sum
+    assert float((dW.cpu().double() - ref_w).abs().max()) < 1e-5 * float(ref_w.abs().max())
+
+
 def test_train_step_with_dropout_runs(dev):
     import tante_amd
     g, m, md = _g9_model(dev)
