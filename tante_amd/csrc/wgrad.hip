@@ -297,11 +297,20 @@ __device__ __forceinline__ u32x2 ds_read_tr16_b64(unsigned addr) {
 
 __global__ __launch_bounds__(256, 2) void wgrad_tr_kernel(const unsigned short* __restrict__ U, long ldu, const unsigned short* __restrict__ V,
                                                           long ldv, long R, int I, int J, long rows_per_split, float* __restrict__ dW,
-                                                          float* __restrict__ dbias, int layout, int P, int Co, int swap, int debug) {
+                                                          float* __restrict__ dbias, int layout, int P, int Co, int swap, int debug, int n_split) {
   extern __shared__ __attribute__((aligned(16))) char wsm[];   // ring: [buf][U chunk | V chunk]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kk = lane >> 4, l15 = lane & 15;
-  const int i0 = blockIdx.x * WT, j0 = blockIdx.y * WT;
-  const long r_begin = (long)blockIdx.z * rows_per_split, r_end = min(R, r_begin + rows_per_split);
+  // XCD-aware mapping: workgroups are dealt round-robin to the 8 XCDs by linear id, and every output tile of one row range re-reads
+  // that range's operands, so the tiles of a split must share an XCD (one L2) -- with a (tile, tile, split) grid they land on different
+  // ones and every tile pulls its operand rows from HBM again.  id -> (xcd = id % 8, slot = id / 8); the slots of an XCD walk the tiles
+  // of split 8 * (slot / ntile) + xcd.
+  const int ti = I / WT, ntile = ti * (J / WT);
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int bz = (slot / ntile) * 8 + xcd, tile = slot % ntile;
+  if (bz >= n_split) return;
+  const int i0 = (tile % ti) * WT, j0 = (tile / ti) * WT;
+  const bool first_j = (tile / ti) == 0;
+  const long r_begin = (long)bz * rows_per_split, r_end = min(R, r_begin + rows_per_split);
   const int nchunk = (debug & 2) ? 0 : (int)((r_end - r_begin) / WRC);
   const int wi = wave >> 1, wj = wave & 1;
   // DMA: a wave instruction moves 4 rows (lanes 16 q .. 16 q + 15 = row q); wave w copies rows 8 w .. 8 w + 7 of the chunk
@@ -327,7 +336,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_tr_kernel(const unsigned short* 
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  const bool do_bias = dbias != nullptr && blockIdx.y == 0 && wj == 0;
+  const bool do_bias = dbias != nullptr && first_j && wj == 0;
   const u32x4 ones = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};   // bf16 1.0 pairs
   // transposed-read addressing: lane 4 q + p of a 16-lane group supplies row (rb + q), columns 4 p .. 4 p + 3 of the 16-column tile
   const int q = l15 >> 2, p = l15 & 3;
@@ -451,8 +460,9 @@ extern "C" int tante_wgrad(const TanteRowMat* U, const TanteRowMat* V, int64_t R
     static const int wdebug = getenv("TANTE_WGRAD_DEBUG") ? atoi(getenv("TANTE_WGRAD_DEBUG")) : 0;
     static bool set = false;
     if (!set) { hipFuncSetAttribute((const void*)wgrad_tr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set = true; }
-    hipLaunchKernelGGL(wgrad_tr_kernel, dim3(ti, tj, (unsigned)split), dim3(256), lds, s, (const unsigned short*)U->p + U->off, (long)U->s0,
-                       (const unsigned short*)V->p + V->off, (long)V->s0, (long)R, I, J, per, dW, dbias, layout, P, C_other, swap, wdebug);
+    const unsigned n_wg = 8u * (unsigned)((split + 7) / 8) * (unsigned)(ti * tj);
+    hipLaunchKernelGGL(wgrad_tr_kernel, dim3(n_wg), dim3(256), lds, s, (const unsigned short*)U->p + U->off, (long)U->s0,
+                       (const unsigned short*)V->p + V->off, (long)V->s0, (long)R, I, J, per, dW, dbias, layout, P, C_other, swap, wdebug, (int)split);
     TANTE_CHECK_LAUNCH();
     return 0;
   }
