@@ -284,7 +284,7 @@ void launch_wgrad(const TanteRowMat& U, const TanteRowMat& V, long R, int I, int
 // The image is the XOR-swizzled plain-row layout of cdna_hip_programming.md T10 (b): chunk' = chunk ^ (((row & 3) << 2) |
 // ((row >> 2) & 3)); LDS-DMA writes lane-linear, so the swizzle is applied to the global SOURCE chunk each lane fetches.
 // Bias gradient: one extra MFMA per A tile against an all-ones B fragment.
-constexpr int WT = 128, WRC = 32, WNBUF = 4;
+constexpr int WT = 128, WRC = 32;
 constexpr int WCHUNK = WRC * WT * 2;   // bytes of one operand chunk
 
 __device__ __forceinline__ int wg_swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
@@ -295,7 +295,8 @@ __device__ __forceinline__ u32x2 ds_read_tr16_b64(unsigned addr) {
   return r;
 }
 
-__global__ __launch_bounds__(256, 2) void wgrad_tr_kernel(const unsigned short* __restrict__ U, long ldu, const unsigned short* __restrict__ V,
+template <int WNBUF>   // ring depth: 4 (64 KB, two workgroups per CU) or 8 (128 KB: a lone workgroup keeps 7 chunks = 112 KB in flight)
+__global__ __launch_bounds__(256, WNBUF == 4 ? 2 : 1) void wgrad_tr_kernel(const unsigned short* __restrict__ U, long ldu, const unsigned short* __restrict__ V,
                                                           long ldv, long R, int I, int J, long rows_per_split, float* __restrict__ dW,
                                                           float* __restrict__ dbias, int layout, int P, int Co, int swap, int debug, int n_split) {
   extern __shared__ __attribute__((aligned(16))) char wsm[];   // ring: [buf][U chunk | V chunk]
@@ -358,8 +359,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_tr_kernel(const unsigned short* 
     if (c < nchunk) issue(c);
   for (int c = 0; c < nchunk; ++c) {
     // chunk c was issued WNBUF - 1 chunks ago: all but the pieces of the chunks issued after it must have landed
-    const int later = min(nchunk - 1 - c, WNBUF - 2);
-    if (later >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    const int later = min(nchunk - 1 - c, WNBUF - 2);   // 4 DMA instructions per lane and chunk
+    if (later >= 6) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    else if (later == 5) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+    else if (later == 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (later == 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if (later == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else if (later == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                               // chunk c complete for every wave; chunk c - 1's buffer is free
@@ -456,13 +461,24 @@ extern "C" int tante_wgrad(const TanteRowMat* U, const TanteRowMat* V, int64_t R
     if (split > 65535) split = 65535;
     long per = ((nch + split - 1) / split) * WRC;
     split = (R + per - 1) / per;
-    const size_t lds = (size_t)WNBUF * 2 * WCHUNK;
     static const int wdebug = getenv("TANTE_WGRAD_DEBUG") ? atoi(getenv("TANTE_WGRAD_DEBUG")) : 0;
+    static const int deep_env = getenv("TANTE_WGRAD_DEEP") ? atoi(getenv("TANTE_WGRAD_DEEP")) : -1;
     static bool set = false;
-    if (!set) { hipFuncSetAttribute((const void*)wgrad_tr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set = true; }
+    if (!set) {
+      hipFuncSetAttribute((const void*)wgrad_tr_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * WCHUNK);
+      hipFuncSetAttribute((const void*)wgrad_tr_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 2 * WCHUNK);
+      set = true;
+    }
     const unsigned n_wg = 8u * (unsigned)((split + 7) / 8) * (unsigned)(ti * tj);
-    hipLaunchKernelGGL(wgrad_tr_kernel, dim3(n_wg), dim3(256), lds, s, (const unsigned short*)U->p + U->off, (long)U->s0,
-                       (const unsigned short*)V->p + V->off, (long)V->s0, (long)R, I, J, per, dW, dbias, layout, P, C_other, swap, wdebug, (int)split);
+    // the 8-deep ring (one workgroup per CU with 112 KB in flight) is kept for experiments only: measured on the train step it LOSES to
+    // the 4-deep one (33.2 vs 31.0 ms when used for grids of <= 256 workgroups, 32.3 ms when forced everywhere)
+    const bool deep = deep_env > 0;
+    if (deep)
+      hipLaunchKernelGGL(wgrad_tr_kernel<8>, dim3(n_wg), dim3(256), (size_t)8 * 2 * WCHUNK, s, (const unsigned short*)U->p + U->off, (long)U->s0,
+                         (const unsigned short*)V->p + V->off, (long)V->s0, (long)R, I, J, per, dW, dbias, layout, P, C_other, swap, wdebug, (int)split);
+    else
+      hipLaunchKernelGGL(wgrad_tr_kernel<4>, dim3(n_wg), dim3(256), (size_t)4 * 2 * WCHUNK, s, (const unsigned short*)U->p + U->off, (long)U->s0,
+                         (const unsigned short*)V->p + V->off, (long)V->s0, (long)R, I, J, per, dW, dbias, layout, P, C_other, swap, wdebug, (int)split);
     TANTE_CHECK_LAUNCH();
     return 0;
   }
