@@ -105,6 +105,14 @@ typedef struct TanteGemm {
   const float *film_a, *film_b, *s_emb; /* FILM: (T, N), (T, N), (HW, N) */
   int32_t T, HW;
   int32_t Hi, Wi, Po, Cout; /* DECONV_*: input grid per img, upsampling factor, output channels */
+  /* training epilogues (LINEAR, dense bf16 rows, M >= 4096; zero = off):
+   *   drop_p > 0: out = residual + keep(drop_seed, row * N + n) * x / (1 - drop_p), the residual-branch dropout of
+   *               attn_backbone.py:57,81-82 applied to the product before the skip is added (same mask as tante_dropout_add);
+   *   dact != NULL: out = x * act'(dact[row * N + n]) with act = dact_kind -- the activation backward folded into the data-gradient GEMM. */
+  float drop_p;
+  uint64_t drop_seed;
+  const void* dact;
+  int32_t dact_dtype, dact_kind;
 } TanteGemm;
 
 /* out = epilogue(gather(a) @ W^T).  Replaces, depending on the descriptor:

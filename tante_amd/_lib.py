@@ -30,6 +30,7 @@ class Gemm(C.Structure):
         ("residual", c_vp), ("res_ld", c_i64),
         ("film_a", c_vp), ("film_b", c_vp), ("s_emb", c_vp), ("T", c_i32), ("HW", c_i32),
         ("Hi", c_i32), ("Wi", c_i32), ("Po", c_i32), ("Cout", c_i32),
+        ("drop_p", c_f32), ("drop_seed", C.c_uint64), ("dact", c_vp), ("dact_dtype", c_i32), ("dact_kind", c_i32),
     ]
 
 

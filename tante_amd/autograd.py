@@ -207,6 +207,89 @@ class LinearFn(Function):
         return da, dW, db, dres, None, None
 
 
+class BranchOutFn(Function):
+    """out = res + dropout_p(act(pre) @ W^T + b): the closing projection of a residual branch (attention out-proj: act = none; MLP fc2:
+    act = GELU on fc1's pre-activation) as ONE differentiable op, so that the GEMM epilogues carry what would otherwise be separate
+    passes over the token matrix: the dropout + skip add forward (tante_dropout_add) and the activation backward (tante_act_bwd)."""
+
+    @staticmethod
+    def forward(ctx, pre, W, b, res, act, p, compute):
+        M, Kk = pre.shape
+        N = W.shape[0]
+        adt = K.act_torch_dtype(compute)
+        if act != L.ACT_NONE:
+            a = torch.empty(M, Kk, dtype=adt, device=pre.device)
+            L.check(L.lib().tante_act_fwd(pre.data_ptr(), _DT[pre.dtype], a.data_ptr(), _DT[adt], pre.numel(), act, _s()), "act_fwd")
+        else:
+            a = pre
+        pw = _packed(W, b, compute)
+        seed = next_seed() if p > 0.0 else 0
+        fused = Kk <= 512 and K.linear_train_epilogue_ok(a, M, N, Kk, compute)
+        out = torch.empty(M, N, dtype=torch.float32, device=pre.device)
+        if p > 0.0 and fused:
+            K.linear(a, pw, out, M=M, residual=res, drop_p=p, drop_seed=seed)
+        elif p > 0.0:
+            y = torch.empty(M, N, dtype=adt, device=pre.device)
+            K.linear(a, pw, y, M=M)
+            L.check(L.lib().tante_dropout_add(y.data_ptr(), _DT[adt], res.data_ptr(), float(p), seed, y.numel(), out.data_ptr(), _s()), "dropout_add")
+        else:
+            K.linear(a, pw, out, M=M, residual=res)
+        ctx.save_for_backward(pre, a, W)
+        ctx.act, ctx.p, ctx.seed, ctx.compute, ctx.has_bias = act, float(p), seed, compute, b is not None
+        ctx.params = (W, b)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        pre, a, W = ctx.saved_tensors
+        dout = dout.contiguous()
+        M, Kk = a.shape
+        N = W.shape[0]
+        comp = ctx.compute
+        adt = K.act_torch_dtype(comp)
+        dy = torch.empty(M, N, dtype=adt, device=dout.device)   # gradient of the product, in the activation dtype (read by two GEMMs)
+        if ctx.p > 0.0:
+            L.check(L.lib().tante_dropout_bwd(dout.data_ptr(), ctx.p, ctx.seed, dout.numel(), dy.data_ptr(), _DT[adt], _s()), "dropout_bwd")
+        elif adt == torch.float32:
+            dy = dout
+        else:
+            L.check(L.lib().tante_act_fwd(dout.data_ptr(), L.F32, dy.data_ptr(), _DT[adt], dout.numel(), L.ACT_NONE, _s()), "tante_act_fwd")
+        dpre = dW = db = None
+        if ctx.needs_input_grad[0]:
+            dpre = torch.empty(M, Kk, dtype=pre.dtype, device=pre.device)
+            if N <= 512:
+                pwt = _packed(W, None, comp, L.W_LINEAR_T, N=Kk, K=N)
+                if ctx.act != L.ACT_NONE and K.linear_train_epilogue_ok(dy, M, Kk, N, comp):
+                    K.linear(dy, pwt, dpre, M=M, dact=pre, dact_kind=ctx.act)      # dgrad x act'(pre) in one pass
+                else:
+                    K.linear(dy, pwt, dpre, M=M)
+                    if ctx.act != L.ACT_NONE:
+                        L.check(L.lib().tante_act_bwd(dpre.data_ptr(), _DT[dpre.dtype], pre.data_ptr(), _DT[pre.dtype], dpre.data_ptr(),
+                                                      _DT[dpre.dtype], pre.numel(), ctx.act, _s()), "act_bwd")
+            else:
+                acc = None
+                for c0 in range(0, N, 512):
+                    ck = min(512, N - c0)
+                    pwt = _packed(W[c0:c0 + ck], None, comp, L.W_LINEAR_T, N=Kk, K=ck)
+                    nxt = torch.empty(M, Kk, dtype=torch.float32, device=a.device)
+                    K.linear(dy, pw=pwt, out=nxt, M=M, a_n0=M, a_s0=N, a_off=c0, residual=acc)
+                    acc = nxt
+                L.check(L.lib().tante_act_bwd(acc.data_ptr(), L.F32, pre.data_ptr(), _DT[pre.dtype], dpre.data_ptr(), _DT[dpre.dtype], pre.numel(),
+                                              ctx.act, _s()), "act_bwd")
+        if ctx.needs_input_grad[1]:
+            gW, gb = _grad_slot(ctx.params[0]), _grad_slot(ctx.params[1])
+            want_b = ctx.has_bias and ctx.needs_input_grad[2]
+            if gW is not None and want_b and gb is not None:
+                wgrad(_rm_linear(dy), _rm_linear(a), M, N, Kk, (N, Kk), comp, device=a.device, with_bias=True, into=gW, db_into=gb)
+            else:
+                dW, db = wgrad(_rm_linear(dy), _rm_linear(a), M, N, Kk, (N, Kk), comp, device=a.device, with_bias=True)
+                if not want_b:
+                    db = None
+        elif ctx.has_bias and ctx.needs_input_grad[2]:
+            db = colsum(dy, M, N, 1)
+        return dpre, dW, db, dout, None, None, None
+
+
 class ActFn(Function):
     @staticmethod
     def forward(ctx, pre, act, out_dtype):

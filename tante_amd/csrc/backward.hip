@@ -59,20 +59,6 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ g,
 
 // ---- activations ---------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float act_f(float x, int act) { return apply_act(x, act); }
-__device__ __forceinline__ float act_df(float x, int act) {
-  switch (act) {
-    case TANTE_ACT_GELU_ERF: {  // Phi(x) + x phi(x)
-      const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
-      return cdf + x * 0.39894228040143267794f * expf(-0.5f * x * x);
-    }
-    case TANTE_ACT_GELU_TANH: {
-      const float c = 0.79788456080286535588f, u = c * (x + 0.044715f * x * x * x), t = tanhf(u);
-      return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * c * (1.0f + 3.0f * 0.044715f * x * x);
-    }
-    case TANTE_ACT_RELU: return x > 0.f ? 1.0f : 0.f;
-    default: return 1.0f;
-  }
-}
 __global__ void act_fwd_kernel(const void* __restrict__ pre, int in_dtype, void* __restrict__ post, int out_dtype, long n, int act) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) stx(post, out_dtype, i, act_f(ldx(pre, in_dtype, i), act));

@@ -98,6 +98,22 @@ __host__ __device__ __forceinline__ int swz_chunk(int r, int c, int cpr) {
   return (cpr >= 16) ? (c ^ (r & 15)) : (c ^ ((r >> 1) & 7));  // cpr == 8 -> two rows per bank row
 }
 
+// derivative of an activation at its pre-activation value (training: act_bwd kernel and the data-gradient GEMM's epilogue)
+__device__ __forceinline__ float act_df(float x, int act) {
+  switch (act) {
+    case TANTE_ACT_GELU_ERF: {  // Phi(x) + x phi(x)
+      const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+      return cdf + x * 0.39894228040143267794f * expf(-0.5f * x * x);
+    }
+    case TANTE_ACT_GELU_TANH: {
+      const float c = 0.79788456080286535588f, u = c * (x + 0.044715f * x * x * x), t = tanhf(u);
+      return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * c * (1.0f + 3.0f * 0.044715f * x * x);
+    }
+    case TANTE_ACT_RELU: return x > 0.f ? 1.0f : 0.f;
+    default: return 1.0f;
+  }
+}
+
 // ---- counter-based dropout mask: keep(seed, idx) is a pure function, so backward regenerates the forward's mask -------
 __device__ __forceinline__ bool dropout_keep(unsigned long long seed, unsigned long long idx, float p) {
   unsigned long long z = seed + idx * 0x9E3779B97F4A7C15ull;   // splitmix64 finaliser

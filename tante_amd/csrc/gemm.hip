@@ -517,7 +517,39 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const TanteGemm g, int n_t
 // stores, so HBM reads never overlap HBM writes (24576 x 256 x 256, rocprofv3: 4.9 us empty kernel + 3.5 us loads + 1.4 us MFMA +
 // 4 us stores = 13.6 us).  A persistent variant (one resident tile per workgroup, row groups prefetched under the previous group's
 // stores) was measured slower (14.3 / 30-39 us at N = 256 / 768): every tile's workgroup re-reads the token rows through L2.
-template <int CB, int TT, int EP>
+// training epilogues of the lite kernel (TanteGemm.drop_p / .dact): 0 none, 1 dropout before the residual add, 2 times act'(dact)
+template <int TR>
+__device__ __forceinline__ void epilogue4_train(const TanteGemm& g, const EpiRow& e, long row, int n0, float (&v)[4]) {
+  if (!e.ok || n0 >= g.N) return;
+  const f32x4 b = *(const f32x4*)(g.bias + n0);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) v[j] += b[j];
+  if constexpr (TR == 1) {
+    const float ks = 1.0f / (1.0f - g.drop_p);
+    const unsigned long long i0 = (unsigned long long)row * g.N + n0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = dropout_keep(g.drop_seed, i0 + j, g.drop_p) ? v[j] * ks : 0.0f;
+    if (g.residual) {
+      const f32x4 r = *(const f32x4*)(g.residual + e.r_base + n0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] += r[j];
+    }
+  } else {
+    float pre[4];
+    if (g.dact_dtype == TANTE_BF16) {
+      const u32x2 u = *(const u32x2*)((const unsigned short*)g.dact + row * g.N + n0);
+      pre[0] = bf16_lo(u[0]); pre[1] = bf16_hi(u[0]); pre[2] = bf16_lo(u[1]); pre[3] = bf16_hi(u[1]);
+    } else {
+      const f32x4 f = *(const f32x4*)((const float*)g.dact + row * g.N + n0);
+      pre[0] = f[0]; pre[1] = f[1]; pre[2] = f[2]; pre[3] = f[3];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] *= act_df(pre[j], g.dact_kind);
+  }
+  store4(g.out, g.out_dtype, e.o_base + n0, v);
+}
+
+template <int CB, int TT, int EP, int TR = 0>
 __global__ __launch_bounds__(256, 4) void gemm_lite_kernel(const TanteGemm g, int n_tiles, int tiles_per_split) {
   constexpr int CPR = CB * 4, NT = nt_for_cb(CB), NSUB = NT / 16, TILE_U = NT * CPR, UPT = TILE_U / 256;
   extern __shared__ __attribute__((aligned(16))) char smem[];  // one tile
@@ -579,12 +611,13 @@ __global__ __launch_bounds__(256, 4) void gemm_lite_kernel(const TanteGemm g, in
 #pragma unroll
       for (int tt = 0; tt < TT; ++tt) {
         float v[4] = {acc[ns][tt][0], acc[ns][tt][1], acc[ns][tt][2], acc[ns][tt][3]};
-        epilogue4_fast<EP, true>(g, er[tt], t * NT + ns * 16 + kk * 4, v);
+        if constexpr (TR == 0) epilogue4_fast<EP, true>(g, er[tt], t * NT + ns * 16 + kk * 4, v);
+        else epilogue4_train<TR>(g, er[tt], row0 + tt * 16 + l15, t * NT + ns * 16 + kk * 4, v);
       }
   }
 }
 
-template <int CB, int EP>
+template <int CB, int EP, int TR = 0>
 void launch_lite(const TanteGemm& g, int n_tiles, hipStream_t s) {
   constexpr int TT = (CB <= 8) ? 2 : 1;
   constexpr int NT = nt_for_cb(CB);
@@ -594,14 +627,20 @@ void launch_lite(const TanteGemm& g, int n_tiles, hipStream_t s) {
   for (int d = 1; d <= n_tiles; ++d)
     if (n_tiles % d == 0) { nsplit = d; if ((long)gx * d >= 768) break; }
   const size_t lds = (size_t)NT * CB * 4 * 16;
-  hipLaunchKernelGGL((gemm_lite_kernel<CB, TT, EP>), dim3(gx, nsplit), dim3(256), lds, s, g, n_tiles, n_tiles / nsplit);
+  hipLaunchKernelGGL((gemm_lite_kernel<CB, TT, EP, TR>), dim3(gx, nsplit), dim3(256), lds, s, g, n_tiles, n_tiles / nsplit);
 }
 
 template <int CB>
 bool try_lite(const TanteGemm& g, int n_tiles, int flags, hipStream_t s) {
   static const bool off = getenv("TANTE_GEMM_NO_LITE") != nullptr;
-  if (off || g.ln || g.a_mode != TANTE_A_LINEAR || g.a_dtype != TANTE_BF16 || (flags & 3) != 3 || g.e_mode != TANTE_E_LINEAR) return false;
+  if ((off && g.drop_p <= 0.0f && !g.dact) || g.ln || g.a_mode != TANTE_A_LINEAR || g.a_dtype != TANTE_BF16 || (flags & 3) != 3 || g.e_mode != TANTE_E_LINEAR) return false;
   if (g.K != CB * 32 || g.M < 4096) return false;   // whole 32-wide k blocks: the raw fragment loads have no K tail
+  if (g.drop_p > 0.0f || g.dact) {
+    if (g.act != TANTE_ACT_NONE || (g.drop_p > 0.0f && g.dact)) return false;
+    if (g.drop_p > 0.0f) launch_lite<CB, EP_LIN_NONE, 1>(g, n_tiles, s);
+    else launch_lite<CB, EP_LIN_NONE, 2>(g, n_tiles, s);
+    return true;
+  }
   switch (g.act) {
     case TANTE_ACT_NONE: launch_lite<CB, EP_LIN_NONE>(g, n_tiles, s); return true;
     case TANTE_ACT_RELU: launch_lite<CB, EP_LIN_RELU>(g, n_tiles, s); return true;
@@ -854,6 +893,12 @@ extern "C" int tante_gemm(const TanteGemm* gp, void* stream) {
       TANTE_FAIL(-1, "tante_gemm: bad e_mode %d", g.e_mode);
   }
   if (((uintptr_t)g.w % 16) || ((uintptr_t)g.bias % 16)) TANTE_FAIL(-1, "tante_gemm: packed weight/bias must be 16-byte aligned");
+  if (g.drop_p < 0.0f || g.drop_p >= 1.0f) TANTE_FAIL(-1, "tante_gemm: dropout probability must be in [0, 1)");
+  const bool train_epi = g.drop_p > 0.0f || g.dact != nullptr;
+  if (train_epi && (g.compute != TANTE_BF16 || g.e_mode != TANTE_E_LINEAR || g.a_mode != TANTE_A_LINEAR || g.a_dtype != TANTE_BF16 || g.ln ||
+                    g.act != TANTE_ACT_NONE || (flags & 3) != 3 || g.M < 4096 || (g.K != 128 && g.K != 256 && g.K != 512) || (g.drop_p > 0.0f && g.dact) ||
+                    (g.dact && (((uintptr_t)g.dact % 16) || g.N % 4))))
+    TANTE_FAIL(-2, "tante_gemm: the dropout / activation-gradient epilogues need dense 16-byte aligned bf16 rows, M >= 4096, K of 128, 256 or 512, no LayerNorm, no activation");
   const int n_tiles = geo.n_pad / geo.nt;
   hipStream_t s = (hipStream_t)stream;
   const bool bf = g.compute == TANTE_BF16;

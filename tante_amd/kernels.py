@@ -90,9 +90,12 @@ def _run(g: L.Gemm):
 def linear(a: torch.Tensor, pw: PackedWeight = None, out: torch.Tensor = None, *, M: Optional[int] = None, act: int = L.ACT_NONE,
            ln: bool = False, ln_eps: float = 1e-5, residual: Optional[torch.Tensor] = None,
            a_n0: Optional[int] = None, a_s1: int = 0, a_s0: Optional[int] = None, a_off: int = 0,
-           out_ld: Optional[int] = None):
+           out_ld: Optional[int] = None, drop_p: float = 0.0, drop_seed: int = 0, dact: Optional[torch.Tensor] = None,
+           dact_kind: int = L.ACT_NONE):
     """out[M, N] = act(norm?(rows(a)) @ W^T + b) (+ residual).  Row r of `a` starts at element
-    (r // a_n0) * a_s1 + (r % a_n0) * a_s0 + a_off  (default: dense rows of length K)."""
+    (r // a_n0) * a_s1 + (r % a_n0) * a_s0 + a_off  (default: dense rows of length K).
+    Training epilogues (see TanteGemm in include/tante_hip.h): drop_p > 0 drops the product before the residual is added;
+    dact multiplies it by act'(dact) (an (M, N) pre-activation tensor)."""
     K = pw.K
     M = (a.numel() // K) if M is None else M
     g = _base(pw, a, M, out, act)
@@ -107,8 +110,18 @@ def linear(a: torch.Tensor, pw: PackedWeight = None, out: torch.Tensor = None, *
         if residual.dtype != torch.float32:
             raise RuntimeError("residual stream is fp32")
         g.residual, g.res_ld = _p(residual), pw.N
+    if drop_p > 0.0:
+        g.drop_p, g.drop_seed = float(drop_p), int(drop_seed)
+    if dact is not None:
+        _dev(dact)
+        g.dact, g.dact_dtype, g.dact_kind = _p(dact), _DT[dact.dtype], dact_kind
     _run(g)
     return out
+
+
+def linear_train_epilogue_ok(a: torch.Tensor, M: int, N: int, Kk: int, compute: int) -> bool:
+    """Shapes for which tante_gemm offers the dropout / activation-gradient epilogues."""
+    return compute == L.BF16 and a.dtype == torch.bfloat16 and M >= 4096 and Kk in (128, 256, 512) and N % 4 == 0
 
 
 def patch_embed(a: torch.Tensor, pw: PackedWeight, out: torch.Tensor, *, n_img: int, Hin: int, Win: int, Cin: int, P: int,

@@ -12,7 +12,7 @@ import torch
 from . import _lib as L
 from . import kernels as K
 from . import stages as S
-from .autograd import (ActFn, AttentionFn, AxisMlpFn, DeconvFn, DropoutAddFn, FilmPosFn, LayerNormFn, LayerNormSkipFn, LinearFn, PatchEmbedFn, RtReduceFn,
+from .autograd import (ActFn, AttentionFn, AxisMlpFn, BranchOutFn, DeconvFn, DropoutAddFn, FilmPosFn, LayerNormFn, LayerNormSkipFn, LinearFn, PatchEmbedFn, RtReduceFn,
                        TaylorFn)
 
 
@@ -57,17 +57,11 @@ def block_train(blk, x: torch.Tensor, seq, causal: bool, compute: int) -> torch.
     xh, x = LayerNormSkipFn.apply(x, blk.ln1.eps, adt)      # x: the same tokens, as the skip operand whose gradient LN's backward adds
     qkv = LinearFn.apply(xh, w_in, b_in, None, compute, adt)
     o = AttentionFn.apply(qkv, seq, blk.embed_dim, blk.n_head, causal, p)
-    if p > 0.0:
-        x = DropoutAddFn.apply(LinearFn.apply(o, a.out_proj.weight, a.out_proj.bias, None, compute, adt), x, p)
-    else:
-        x = LinearFn.apply(o, a.out_proj.weight, a.out_proj.bias, x, compute, torch.float32)
+    x = BranchOutFn.apply(o, a.out_proj.weight, a.out_proj.bias, x, L.ACT_NONE, p, compute)       # x + drop(out_proj(o))
     w1, b1 = _folded(m[0].weight, m[0].bias, blk.ln2)
     xh2, x = LayerNormSkipFn.apply(x, blk.ln2.eps, adt)
     hpre = LinearFn.apply(xh2, w1, b1, None, compute, adt)
-    h = ActFn.apply(hpre, L.ACT_GELU_TANH, adt)
-    if p > 0.0:
-        return DropoutAddFn.apply(LinearFn.apply(h, m[2].weight, m[2].bias, None, compute, adt), x, p)
-    return LinearFn.apply(h, m[2].weight, m[2].bias, x, compute, torch.float32)
+    return BranchOutFn.apply(hpre, m[2].weight, m[2].bias, x, L.ACT_GELU_TANH, p, compute)           # x + drop(fc2(gelu(hpre)))
 
 
 def backbone_train(bb, x: torch.Tensor, B: int, compute: int) -> torch.Tensor:

@@ -806,6 +806,45 @@ def test_axis_wgrad_kernel(dev, outer, n, inner):
     assert float((dW.cpu().double() - ref_w).abs().max()) < 1e-5 * float(ref_w.abs().max())
 
 
+@pytest.mark.parametrize("M,N,K", [(4096, 256, 256), (4500, 200, 512), (8192, 128, 128)])
+def test_gemm_training_epilogues(dev, M, N, K):
+    """TanteGemm.drop_p (dropout of the product before the residual add) and .dact (times act'(pre)) against the separate kernels they
+    replace on the train path: the same mask (seed, element index), the same derivative."""
+    from tante_amd import _lib as L, kernels as Kk
+    g = torch.Generator().manual_seed(M + N)
+    a = torch.randn(M, K, generator=g).to(torch.bfloat16).to(dev)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(dev)
+    b = torch.randn(N, generator=g).to(dev)
+    res = torch.randn(M, N, generator=g).to(dev)
+    pre = torch.randn(M, N, generator=g).to(torch.bfloat16).to(dev)
+    pw = Kk.pack_weight(w, b, L.BF16)
+    s = torch.cuda.current_stream().cuda_stream
+    p, seed = 0.3, 4242
+    # dropout + residual
+    fused = torch.full((M + 1, N), float("nan"), device=dev)
+    Kk.linear(a, pw, fused, M=M, residual=res, drop_p=p, drop_seed=seed)
+    y = torch.empty(M, N, device=dev)
+    Kk.linear(a, pw, y, M=M)
+    ref = torch.empty(M, N, device=dev)
+    L.check(L.lib().tante_dropout_add(y.data_ptr(), L.F32, res.data_ptr(), p, seed, y.numel(), ref.data_ptr(), s))
+    assert torch.isnan(fused[M]).all()
+    assert torch.equal(fused[:M] == res, ref == res)                       # the very same elements were dropped
+    assert float((fused[:M] - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+    # activation derivative
+    for act in (L.ACT_GELU_TANH, L.ACT_GELU_ERF, L.ACT_RELU):
+        d16 = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+        Kk.linear(a, pw, d16, M=M, dact=pre, dact_kind=act)
+        y32 = torch.empty(M, N, device=dev)
+        Kk.linear(a, pw, y32, M=M)
+        ref2 = torch.empty(M, N, device=dev)
+        L.check(L.lib().tante_act_bwd(y32.data_ptr(), L.F32, pre.data_ptr(), L.BF16, ref2.data_ptr(), L.F32, y32.numel(), act, s))
+        assert float((d16.float() - ref2).abs().max()) <= 1e-2 * float(ref2.abs().max())
+    # shapes the epilogues do not cover are refused, not silently computed without them
+    small = torch.empty(64, N, device=dev)
+    with pytest.raises(RuntimeError):
+        Kk.linear(a[:64], pw, small, M=64, residual=res[:64], drop_p=p, drop_seed=seed)
+
+
 def test_train_step_with_dropout_runs(dev):
     import tante_amd
     g, m, md = _g9_model(dev)
