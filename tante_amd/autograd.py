@@ -67,9 +67,13 @@ def _grad_slot(p) -> Optional[torch.Tensor]:
     """The parameter's existing .grad when the weight-gradient kernels may accumulate into it directly.  With BPTT a weight is used
     once per rollout step; letting autograd's AccumulateGrad add the per-use gradients costs an elementwise add (and a zero-filled
     temporary) per use per parameter -- ~800 tiny launches per train step.  Backward then returns None for that input."""
-    if not ACCUMULATE_INTO_GRAD or not isinstance(p, torch.nn.Parameter) or p.grad is None:
+    if not ACCUMULATE_INTO_GRAD or p is None:
         return None
-    g = p.grad
+    g = getattr(p, "_tante_grad", None)      # a derived weight with its own accumulator (FoldFn)
+    if g is None:
+        if not isinstance(p, torch.nn.Parameter) or p.grad is None:
+            return None
+        g = p.grad
     return g if (g.dtype == torch.float32 and g.is_contiguous() and g.shape == p.shape and g.is_cuda) else None
 
 
@@ -113,6 +117,35 @@ class LayerNormFn(Function):
         L.check(L.lib().tante_layernorm_bwd(g.data_ptr(), _DT[g.dtype], x.data_ptr(), st.data_ptr(), None, x.shape[0], x.shape[1],
                                             dx.data_ptr(), _s()), "ln_bwd")
         return dx, None, None
+
+
+class FoldFn(Function):
+    """(W diag(gamma), b + W beta): LayerNorm's affine folded into the consumer's weight, with zero-initialised accumulators that the
+    weight-gradient kernels of every use add into (`_tante_grad`, see _grad_slot).  Those uses then return no gradient for the folded
+    tensors, autograd calls this backward once with nothing, and the accumulated gradient is distributed to W, b, gamma, beta here.
+    Without the accumulators every use of a folded weight produced a fresh dW / db that autograd summed: ~300 tiny launches per step."""
+
+    @staticmethod
+    def forward(ctx, W, b, gamma, beta):
+        We = W * gamma[None, :]
+        be = b + W @ beta
+        gW, gb = torch.zeros_like(We), torch.zeros_like(be)
+        ctx.save_for_backward(W, gamma, beta)
+        ctx.acc = (gW, gb)
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(gW, gb)
+        return We, be, gW, gb
+
+    @staticmethod
+    def backward(ctx, gWe, gbe, _a, _b):
+        W, gamma, beta = ctx.saved_tensors
+        GW, Gb = ctx.acc
+        if gWe is not None:
+            GW = GW + gWe
+        if gbe is not None:
+            Gb = Gb + gbe
+        dW = torch.addcmul(GW * gamma[None, :], Gb[:, None], beta[None, :])
+        return dW, Gb, (GW * W).sum(0), W.t() @ Gb
 
 
 class LayerNormSkipFn(Function):

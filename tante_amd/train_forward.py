@@ -12,7 +12,7 @@ import torch
 from . import _lib as L
 from . import kernels as K
 from . import stages as S
-from .autograd import (ActFn, AttentionFn, AxisMlpFn, BranchOutFn, DeconvFn, DropoutAddFn, FilmPosFn, LayerNormFn, LayerNormSkipFn, LinearFn, PatchEmbedFn, RtReduceFn,
+from .autograd import (ActFn, AttentionFn, AxisMlpFn, BranchOutFn, DeconvFn, DropoutAddFn, FilmPosFn, FoldFn, LayerNormFn, LayerNormSkipFn, LinearFn, PatchEmbedFn, RtReduceFn,
                        TaylorFn)
 
 
@@ -45,7 +45,9 @@ def _folded(lin_w, lin_b, ln):
     key = (id(ln), id(lin_w))
     hit = _FOLDS.get(key)
     if hit is None:
-        hit = _FOLDS[key] = (lin_w * ln.weight[None, :], lin_b + lin_w @ ln.bias)
+        we, be, gw, gb = FoldFn.apply(lin_w, lin_b, ln.weight, ln.bias)
+        we._tante_grad, be._tante_grad = gw, gb       # the weight-gradient kernels of every use accumulate here
+        hit = _FOLDS[key] = (we, be)
     return hit
 
 
