@@ -77,6 +77,60 @@ def _grad_slot(p) -> Optional[torch.Tensor]:
     return g if (g.dtype == torch.float32 and g.is_contiguous() and g.shape == p.shape and g.is_cuda) else None
 
 
+# ---- weight gradients on a side stream -------------------------------------------------------------------------------------------
+# The weight-gradient kernel of a layer and the data-gradient GEMM of the same layer are independent (both read dY), each is bound by
+# latency / lockstep rather than by a saturated unit, and their resources add up to exactly one CU (3 x 32 KB + 64 KB of LDS, 4 x 128
+# VGPRs per lane): issued on two streams they overlap.  Only the accumulate-into-slot form runs there (nothing on the main stream reads
+# the slot before the optimiser); the main stream re-joins at the end of the backward pass through an engine callback.
+SIDE_STREAM_WGRAD = __import__("os").environ.get("TANTE_WGRAD_SIDE_STREAM", "1") != "0"
+_SIDE = {"stream": None, "armed": False}
+
+
+def _join_side():
+    _SIDE["armed"] = False
+    if _SIDE["stream"] is not None:
+        torch.cuda.current_stream().wait_stream(_SIDE["stream"])
+
+
+def join_side_stream():
+    """Make the current stream wait for every weight-gradient kernel issued so far (before reading gradient slots)."""
+    _join_side()
+
+
+class _side_wgrad:
+    """with _side_wgrad(dy, a): wgrad(..., into=...)  -- runs the body on the side stream after everything issued so far."""
+
+    def __init__(self, *tensors):
+        self.tensors = tensors
+
+    def __enter__(self):
+        if not SIDE_STREAM_WGRAD:
+            self.ctxm = None
+            return self
+        if _SIDE["stream"] is None:
+            _SIDE["stream"] = torch.cuda.Stream()
+        side = _SIDE["stream"]
+        side.wait_stream(torch.cuda.current_stream())
+        for t in self.tensors:
+            t.record_stream(side)
+        if not _SIDE["armed"]:
+            _SIDE["armed"] = True
+            try:
+                torch.autograd.Variable._execution_engine.queue_callback(_join_side)
+            except RuntimeError:      # not inside a backward pass
+                _SIDE["armed"] = False
+        self.ctxm = torch.cuda.stream(side)
+        self.ctxm.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.ctxm is not None:
+            self.ctxm.__exit__(*exc)
+            if not _SIDE["armed"]:
+                _join_side()
+        return False
+
+
 def wgrad(U: L.RowMat, V: L.RowMat, R: int, I: int, J: int, out_shape, compute: int, layout: int = L.W_LINEAR, P: int = 0,
           C_other: int = 0, swap: bool = False, device=None, with_bias: bool = False, into: Optional[torch.Tensor] = None,
           db_into: Optional[torch.Tensor] = None):
@@ -140,6 +194,8 @@ class FoldFn(Function):
     def backward(ctx, gWe, gbe, _a, _b):
         W, gamma, beta = ctx.saved_tensors
         GW, Gb = ctx.acc
+        if _SIDE["stream"] is not None:      # the accumulators are written by weight-gradient kernels on the side stream
+            torch.cuda.current_stream().wait_stream(_SIDE["stream"])
         if gWe is not None:
             GW = GW + gWe
         if gbe is not None:
@@ -216,6 +272,13 @@ class LinearFn(Function):
             dyb = torch.empty(dy.shape, dtype=torch.bfloat16, device=dy.device)
             L.check(L.lib().tante_act_fwd(dy.data_ptr(), L.F32, dyb.data_ptr(), L.BF16, dy.numel(), L.ACT_NONE, _s()), "tante_act_fwd")
             dy = dyb
+        side_done = False
+        if ctx.needs_input_grad[1] and ctx.has_bias and ctx.needs_input_grad[2]:
+            gW, gb = _grad_slot(ctx.params[0]), _grad_slot(ctx.params[1])
+            if gW is not None and gb is not None:
+                with _side_wgrad(dy, a):
+                    wgrad(_rm_linear(dy), _rm_linear(a), M, N, Kk, (N, Kk), comp, device=a.device, with_bias=True, into=gW, db_into=gb)
+                side_done = True
         if ctx.needs_input_grad[0]:       # dgrad GEMM: (M, N) x (N, K); the contraction (N) is chunked to the kernel's K limit
             chunks = [(c0, min(512, N - c0)) for c0 in range(0, N, 512)]
             da = torch.empty(M, Kk, dtype=a.dtype, device=a.device)
@@ -226,7 +289,9 @@ class LinearFn(Function):
                 out = da if last else (acc if acc is not None else torch.empty(M, Kk, dtype=torch.float32, device=a.device))
                 K.linear(dy, pw=pwt, out=out, M=M, a_n0=M, a_s0=N, a_off=c0, residual=acc)
                 acc = out
-        if ctx.needs_input_grad[1]:
+        if side_done:
+            pass
+        elif ctx.needs_input_grad[1]:
             gW, gb = _grad_slot(ctx.params[0]), _grad_slot(ctx.params[1])
             if gW is not None and ctx.has_bias and ctx.needs_input_grad[2] and gb is not None:
                 wgrad(_rm_linear(dy), _rm_linear(a), M, N, Kk, (N, Kk), comp, device=a.device, with_bias=True, into=gW, db_into=gb)
@@ -288,6 +353,13 @@ class BranchOutFn(Function):
         else:
             L.check(L.lib().tante_act_fwd(dout.data_ptr(), L.F32, dy.data_ptr(), _DT[adt], dout.numel(), L.ACT_NONE, _s()), "tante_act_fwd")
         dpre = dW = db = None
+        side_done = False
+        if ctx.needs_input_grad[1] and ctx.has_bias and ctx.needs_input_grad[2]:
+            gW, gb = _grad_slot(ctx.params[0]), _grad_slot(ctx.params[1])
+            if gW is not None and gb is not None:
+                with _side_wgrad(dy, a):
+                    wgrad(_rm_linear(dy), _rm_linear(a), M, N, Kk, (N, Kk), comp, device=a.device, with_bias=True, into=gW, db_into=gb)
+                side_done = True
         if ctx.needs_input_grad[0]:
             dpre = torch.empty(M, Kk, dtype=pre.dtype, device=pre.device)
             if N <= 512:
@@ -309,7 +381,9 @@ class BranchOutFn(Function):
                     acc = nxt
                 L.check(L.lib().tante_act_bwd(acc.data_ptr(), L.F32, pre.data_ptr(), _DT[pre.dtype], dpre.data_ptr(), _DT[dpre.dtype], pre.numel(),
                                               ctx.act, _s()), "act_bwd")
-        if ctx.needs_input_grad[1]:
+        if side_done:
+            pass
+        elif ctx.needs_input_grad[1]:
             gW, gb = _grad_slot(ctx.params[0]), _grad_slot(ctx.params[1])
             want_b = ctx.has_bias and ctx.needs_input_grad[2]
             if gW is not None and want_b and gb is not None:
