@@ -82,7 +82,9 @@ def _grad_slot(p) -> Optional[torch.Tensor]:
 # latency / lockstep rather than by a saturated unit, and their resources add up to exactly one CU (3 x 32 KB + 64 KB of LDS, 4 x 128
 # VGPRs per lane): issued on two streams they overlap.  Only the accumulate-into-slot form runs there (nothing on the main stream reads
 # the slot before the optimiser); the main stream re-joins at the end of the backward pass through an engine callback.
-SIDE_STREAM_WGRAD = __import__("os").environ.get("TANTE_WGRAD_SIDE_STREAM", "1") != "0"
+# Measured on the cfg3 train step (alternating runs on one box): 29.5-29.9 ms against 30.0-30.1 ms on one stream, but with outliers at
+# 33-34.6 ms when the two streams' workgroups interleave badly -- a small, unreliable gain, so it is opt-in (TANTE_WGRAD_SIDE_STREAM=1).
+SIDE_STREAM_WGRAD = __import__("os").environ.get("TANTE_WGRAD_SIDE_STREAM", "0") != "0"
 _SIDE = {"stream": None, "armed": False}
 
 
@@ -508,8 +510,13 @@ class AxisMlpFn(Function):
                         "tante_axis_wgrad")
                 return (None, None) if acc else (dW, dB)
             both = all(g is not None for g in slots)
-            dw2, db2 = aw(dy, h, slots[2] if both else None, slots[3] if both else None)
-            dw1, db1 = aw(dpre, x, slots[0] if both else None, slots[1] if both else None)
+            if both:
+                with _side_wgrad(dy, h, dpre, x):
+                    aw(dy, h, slots[2], slots[3])
+                    aw(dpre, x, slots[0], slots[1])
+                return dx, None, None, None, None, None, None, None, None
+            dw2, db2 = aw(dy, h, None, None)
+            dw1, db1 = aw(dpre, x, None, None)
             return dx, dw1, db1, dw2, db2, None, None, None, None
         if all(g is not None for g in slots):
             wgrad(lines(dy), lines(h), R, n, n, (n, n), comp, device=x.device, with_bias=True, into=slots[2], db_into=slots[3])
@@ -570,16 +577,20 @@ class PatchEmbedFn(Function):
             dx = dx.view(x.shape)
         if ctx.needs_input_grad[1]:
             U, V = _rm_linear(d), _rm_patch(x, not nchw, n_img, Hin, Win, Cin, P)
+            keep = [d, x]        # operands the (side-stream) kernel reads: held here and marked in use on that stream
             if comp == L.BF16 and not nchw and x.dtype == torch.bfloat16 and _tr_shape(M, Cout, Kk):
                 # a kernel = stride patch matrix is a permutation of the image: one 2 x 25 MB copy buys the dense-row weight-gradient
                 # kernel (~45 us) instead of the gathering one (~240 us at 24576 x 256 x 512)
                 cols = K.im2col(x, False, n_img, Cin, Hin, Win, P, P, P, P, 0, 0, 1, torch.bfloat16)
-                U, V = _rm_linear(d if d.dtype == torch.bfloat16 else _to_bf16(d)), _rm_linear(cols)
+                d16 = d if d.dtype == torch.bfloat16 else _to_bf16(d)
+                U, V = _rm_linear(d16), _rm_linear(cols)
+                keep = [d16, cols]
             gW, gb = _grad_slot(ctx.params[0]), _grad_slot(ctx.params[1])
             lay = L.W_LINEAR if nchw else L.W_CONV_NHWC
             if gW is not None and gb is not None and ctx.needs_input_grad[2]:
-                wgrad(U, V, M, Cout, Kk, tuple(W.shape), comp, layout=lay, P=P, C_other=Cin, device=x.device, with_bias=True,
-                      into=gW, db_into=gb)
+                with _side_wgrad(*keep):
+                    wgrad(U, V, M, Cout, Kk, tuple(W.shape), comp, layout=lay, P=P, C_other=Cin, device=x.device, with_bias=True,
+                          into=gW, db_into=gb)
             else:
                 dW, db = wgrad(U, V, M, Cout, Kk, tuple(W.shape), comp, layout=lay, P=P, C_other=Cin, device=x.device,
                                with_bias=True)
@@ -636,10 +647,12 @@ class DeconvFn(Function):
             gW = _grad_slot(ctx.params[0])
             if cols is not None and a.dtype != torch.bfloat16:     # the first stage reads the fp32 residual stream
                 a = _to_bf16(a)
-            dW = wgrad(_rm_linear(a), V, M, Cin, N, tuple(W.shape), comp, layout=L.W_DECONV_NCHW if nchw_out else L.W_DECONV_NHWC, P=P,
-                       C_other=Cout, swap=True, device=a.device, into=gW)
+            lay_w = L.W_DECONV_NCHW if nchw_out else L.W_DECONV_NHWC
             if gW is not None:
-                dW = None
+                with _side_wgrad(a, d if cols is None else cols):
+                    wgrad(_rm_linear(a), V, M, Cin, N, tuple(W.shape), comp, layout=lay_w, P=P, C_other=Cout, swap=True, device=a.device, into=gW)
+            else:
+                dW = wgrad(_rm_linear(a), V, M, Cin, N, tuple(W.shape), comp, layout=lay_w, P=P, C_other=Cout, swap=True, device=a.device)
         if ctx.needs_input_grad[2]:
             gb = _grad_slot(ctx.params[1])
             db = colsum(d, n_img, Cout, Hi * P * Wi * P, gb) if nchw_out else colsum(d, n_img * Hi * P * Wi * P, Cout, 1, gb)
