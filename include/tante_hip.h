@@ -156,6 +156,13 @@ int tante_axis_mlp_c(float* x, int64_t outer, int n, int64_t inner, const float*
 int tante_axis_hw(float* x, int64_t BT, int nH, int nW, int C, const float* wh1, const float* bh1, const float* wh2,
                   const float* bh2, const float* ww1, const float* bw1, const float* ww2, const float* bw2, int compute,
                   void* stream);
+/* The same, reading every (b, t) plane from a frame-major cache of encoder outputs taken BEFORE FiLM (src[t][b] at
+ * src + t * src_t_stride + b * src_b_stride, (nH * nW, C) fp32 each) and applying film(t) + s_emb + t_emb while it loads
+ * (tante.py:136-141): x[b, t] = src[t][b] * film_a[t] + film_b[t] + s_emb, then the two propagators; x (B, T, nH, nW, C) is written
+ * only.  Lets a rollout loop encode each frame once instead of once per window that contains it. */
+int tante_axis_hw_film(float* x, const float* src, int64_t src_t_stride, int64_t src_b_stride, const float* film_a, const float* film_b,
+                       const float* s_emb, int T, int64_t BT, int nH, int nW, int C, const float* wh1, const float* bh1, const float* wh2,
+                       const float* bh2, const float* ww1, const float* bw1, const float* ww2, const float* bw2, int compute, void* stream);
 
 /* film tables (tante.py:218-230): a[r][c] = 1 + scale(t[r])[c], b[r][c] = shift(t[r])[c] (+ add[r][c]).
  * scale/shift = Linear(1, C/2) -> ReLU -> Linear(C/2, C).  rows = len(t). */

@@ -52,6 +52,7 @@ SIGNATURES = {
     "tante_axis_mlp": ([c_vp, c_i64, c_i32, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp], c_i32),
     "tante_axis_mlp_c": ([c_vp, c_i64, c_i32, c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp], c_i32),
     "tante_axis_hw": ([c_vp, c_i64, c_i32, c_i32, c_i32] + [c_vp] * 8 + [c_i32, c_vp], c_i32),
+    "tante_axis_hw_film": ([c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_i32, c_i32] + [c_vp] * 8 + [c_i32, c_vp], c_i32),
     "tante_film_table": ([c_vp, c_i32, c_i32] + [c_vp] * 8 + [c_vp, c_vp, c_vp, c_vp], c_i32),
     "tante_film_apply": ([c_vp, c_i64, c_vp, c_i64, c_i32, c_i64, c_vp, c_vp, c_vp], c_i32),
     "tante_taylor": ([c_vp, c_i64, C.POINTER(c_vp), c_i32, C.c_double, c_i32, c_vp, c_i64, c_i64, c_i64, c_vp], c_i32),

@@ -181,11 +181,16 @@ class Attn_Backbone(nn.Module):
                     for cb in self.channel_blocks]
         return self._cache.get(compute, params, build)
 
-    def forward_tokens(self, x: torch.Tensor, B: int, compute: int) -> torch.Tensor:
-        """In place on x = (B,T,H,W,C) fp32 contiguous."""
+    def forward_tokens(self, x: torch.Tensor, B: int, compute: int, film_src: Optional[tuple] = None) -> torch.Tensor:
+        """In place on x = (B,T,H,W,C) fp32 contiguous.  film_src = (z, t_stride, b_stride, film): x is not read but produced from the
+        frame-major pre-FiLM encoder cache z while the first propagator kernel loads its planes (TANTE.forward(enc_cache=...))."""
         T, H, W, C_ = self.T, self.H, self.W, self.C
         vp, hp, tp = self.vertical_propagator, self.horizontal_propagator, self.temporal_propagator
-        if K.axis_hw_supported(H, W, C_):      # both axes in one pass over x, contractions on MFMA     l.140-143
+        if film_src is not None:
+            z, ts, bs, film = film_src
+            K.axis_hw_film(x, z, ts, bs, film, B * T, H, W, C_, (vp[0].weight, vp[0].bias, vp[2].weight, vp[2].bias),
+                           (hp[0].weight, hp[0].bias, hp[2].weight, hp[2].bias), compute)
+        elif K.axis_hw_supported(H, W, C_):      # both axes in one pass over x, contractions on MFMA     l.140-143
             K.axis_hw(x, B * T, H, W, C_, (vp[0].weight, vp[0].bias, vp[2].weight, vp[2].bias),
                       (hp[0].weight, hp[0].bias, hp[2].weight, hp[2].bias), compute)
         else:

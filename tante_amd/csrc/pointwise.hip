@@ -317,8 +317,17 @@ __device__ __forceinline__ void axis_phase(float* plane, float* wst_raw, const f
   __syncthreads();
 }
 
+// optional source of the plane: the encoder's per-frame output before FiLM (a frame-major cache kept by the rollout loop), with
+// FiLM(t) + positional embeddings applied while the plane is loaded -- x[b, t] = src[t][b] * a[t] + b[t] + s_emb  (tante.py:136-141)
+struct AxisSrc {
+  const float* src;          // nullptr: read x in place
+  long t_stride, b_stride;   // elements between frames / batch items of src
+  const float *fa, *fb, *se; // (T, C), (T, C), (nH * nW, C)
+  int T;
+};
+
 template <bool BF16, int MT>
-__global__ __launch_bounds__(AXT) void axis_hw_kernel(float* __restrict__ x, int nH, int nW, int C, const float* __restrict__ wh1,
+__global__ __launch_bounds__(AXT) void axis_hw_kernel(float* __restrict__ x, AxisSrc S, int nH, int nW, int C, const float* __restrict__ wh1,
                                                       const float* __restrict__ bh1, const float* __restrict__ wh2,
                                                       const float* __restrict__ bh2, const float* __restrict__ ww1,
                                                       const float* __restrict__ bw1, const float* __restrict__ ww2,
@@ -332,10 +341,22 @@ __global__ __launch_bounds__(AXT) void axis_hw_kernel(float* __restrict__ x, int
   const int rs = axis_row_stride(nW);
   float* wst = plane + nH * rs;
   // ---- load the plane: 4 threads x 16 B per token ---------------------------------------------------------
+  const float* lsrc = gx;
+  const float *fa = nullptr, *fb = nullptr;
+  if (S.src) {
+    const long b = bt / S.T, t = bt - b * S.T;
+    lsrc = S.src + t * S.t_stride + b * S.b_stride + c0;
+    fa = S.fa + t * C + c0;
+    fb = S.fb + t * C + c0;
+  }
   if (!(dbg & 1))
   for (int i = tid; i < nH * nW * 4; i += AXT) {
     const int tokn = i >> 2, q = i & 3, h = tokn / nW, w = tokn - h * nW;
-    const f32x4 v = *(const f32x4*)(gx + (long)tokn * C + q * 4);
+    f32x4 v = *(const f32x4*)(lsrc + (long)tokn * C + q * 4);
+    if (S.src) {
+      const f32x4 a = *(const f32x4*)(fa + q * 4), b = *(const f32x4*)(fb + q * 4), sv = *(const f32x4*)(S.se + (long)tokn * C + c0 + q * 4);
+      v = v * a + b + sv;      // the encoder epilogue's expression, term for term
+    }
     float2* d = (float2*)(plane + h * rs + w * AXWS + q * 4);   // 8-byte aligned: rs, AXWS even
     d[0] = make_float2(v[0], v[1]);
     d[1] = make_float2(v[2], v[3]);
@@ -484,7 +505,7 @@ extern "C" int tante_axis_mlp(float* x, int64_t outer, int n, int64_t inner, con
 }
 
 template <bool BF16, int MT>
-static void launch_axis_hw(float* x, long BT, int nH, int nW, int C, const float* wh1, const float* bh1, const float* wh2,
+static void launch_axis_hw(float* x, const AxisSrc& S, long BT, int nH, int nW, int C, const float* wh1, const float* bh1, const float* wh2,
                            const float* bh2, const float* ww1, const float* bw1, const float* ww2, const float* bw2, size_t lds,
                            hipStream_t s) {
   static size_t attr = 0;
@@ -492,13 +513,33 @@ static void launch_axis_hw(float* x, long BT, int nH, int nW, int C, const float
     hipFuncSetAttribute((const void*)axis_hw_kernel<BF16, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr = lds;
   }
-  hipLaunchKernelGGL((axis_hw_kernel<BF16, MT>), dim3((unsigned)(BT * (C / 16))), dim3(AXT), lds, s, x, nH, nW, C, wh1, bh1, wh2, bh2,
+  hipLaunchKernelGGL((axis_hw_kernel<BF16, MT>), dim3((unsigned)(BT * (C / 16))), dim3(AXT), lds, s, x, S, nH, nW, C, wh1, bh1, wh2, bh2,
                      ww1, bw1, ww2, bw2, getenv("TANTE_AXIS_DEBUG") ? atoi(getenv("TANTE_AXIS_DEBUG")) : 0);
 }
+
+static int axis_hw_impl(float* x, const AxisSrc& S, int64_t BT, int nH, int nW, int C, const float* wh1, const float* bh1, const float* wh2,
+                        const float* bh2, const float* ww1, const float* bw1, const float* ww2, const float* bw2, int compute, void* stream);
 
 extern "C" int tante_axis_hw(float* x, int64_t BT, int nH, int nW, int C, const float* wh1, const float* bh1, const float* wh2,
                              const float* bh2, const float* ww1, const float* bw1, const float* ww2, const float* bw2,
                              int compute, void* stream) {
+  const AxisSrc none = {nullptr, 0, 0, nullptr, nullptr, nullptr, 1};
+  return axis_hw_impl(x, none, BT, nH, nW, C, wh1, bh1, wh2, bh2, ww1, bw1, ww2, bw2, compute, stream);
+}
+
+extern "C" int tante_axis_hw_film(float* x, const float* src, int64_t src_t_stride, int64_t src_b_stride, const float* film_a,
+                                  const float* film_b, const float* s_emb, int T, int64_t BT, int nH, int nW, int C, const float* wh1,
+                                  const float* bh1, const float* wh2, const float* bh2, const float* ww1, const float* bw1, const float* ww2,
+                                  const float* bw2, int compute, void* stream) {
+  if (!src || !film_a || !film_b || !s_emb || T <= 0 || BT % T) TANTE_FAIL(-1, "tante_axis_hw_film: bad argument");
+  if (((uintptr_t)src | (uintptr_t)film_a | (uintptr_t)film_b | (uintptr_t)s_emb) % 16 || src_t_stride % 4 || src_b_stride % 4)
+    TANTE_FAIL(-1, "tante_axis_hw_film: 16-byte alignment");
+  const AxisSrc S = {src, (long)src_t_stride, (long)src_b_stride, film_a, film_b, s_emb, T};
+  return axis_hw_impl(x, S, BT, nH, nW, C, wh1, bh1, wh2, bh2, ww1, bw1, ww2, bw2, compute, stream);
+}
+
+static int axis_hw_impl(float* x, const AxisSrc& S, int64_t BT, int nH, int nW, int C, const float* wh1, const float* bh1, const float* wh2,
+                        const float* bh2, const float* ww1, const float* bw1, const float* ww2, const float* bw2, int compute, void* stream) {
   if (!x || !wh1 || !bh1 || !wh2 || !bh2 || !ww1 || !bw1 || !ww2 || !bw2) TANTE_FAIL(-1, "tante_axis_hw: null pointer");
   if (BT <= 0 || nH <= 0 || nW <= 0 || C <= 0) TANTE_FAIL(-1, "tante_axis_hw: bad shape");
   const int nmax = nH > nW ? nH : nW;
@@ -508,7 +549,7 @@ extern "C" int tante_axis_hw(float* x, int64_t BT, int nH, int nW, int C, const 
     TANTE_FAIL(-2, "tante_axis_hw: needs nH, nW <= 64, C %% 16 == 0 and the plane to fit LDS (use tante_axis_mlp)");
   hipStream_t s = (hipStream_t)stream;
   const int mt = (nmax + 15) / 16;
-#define TANTE_AHW(BF, MTV) launch_axis_hw<BF, MTV>(x, (long)BT, nH, nW, C, wh1, bh1, wh2, bh2, ww1, bw1, ww2, bw2, lds, s)
+#define TANTE_AHW(BF, MTV) launch_axis_hw<BF, MTV>(x, S, (long)BT, nH, nW, C, wh1, bh1, wh2, bh2, ww1, bw1, ww2, bw2, lds, s)
   if (compute == TANTE_BF16) {
     switch (mt) { case 1: TANTE_AHW(true, 1); break; case 2: TANTE_AHW(true, 2); break; case 3: TANTE_AHW(true, 3); break; default: TANTE_AHW(true, 4); }
   } else {

@@ -229,6 +229,19 @@ def axis_hw(x: torch.Tensor, BT: int, nH: int, nW: int, C_: int, vp, hp, compute
     return x
 
 
+def axis_hw_film(x: torch.Tensor, src: torch.Tensor, src_t_stride: int, src_b_stride: int, film: tuple, BT: int, nH: int, nW: int, C_: int,
+                 vp, hp, compute: int):
+    """axis_hw with the planes read from a frame-major pre-FiLM encoder cache; film = (a, b, s_emb, T, HW)."""
+    fa, fb, se, T, HW = film
+    ws = [p.detach() for p in (*vp, *hp)]
+    _dev(x, src, fa, fb, se, *ws)
+    if HW != nH * nW or src.dtype != torch.float32 or x.dtype != torch.float32:
+        raise RuntimeError("axis_hw_film: fp32 planes of nH * nW tokens expected")
+    L.check(L.lib().tante_axis_hw_film(_p(x), _p(src), src_t_stride, src_b_stride, _p(fa), _p(fb), _p(se), T, BT, nH, nW, C_,
+                                       *[_p(w) for w in ws], compute, _stream()), "tante_axis_hw_film")
+    return x
+
+
 def film_table(t: torch.Tensor, film_params: Sequence[torch.Tensor], C_: int, add: Optional[torch.Tensor]):
     """film_params = (scale.0.weight, scale.0.bias, scale.2.weight, scale.2.bias, shift.0.weight, ...)."""
     _dev(t, add, *film_params)

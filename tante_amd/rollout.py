@@ -6,6 +6,7 @@ DefaultChannelsFirstFormatter / ...LastFormatter   (data/datamodule.py:184-202)
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, Tuple
 
 import torch
@@ -46,6 +47,17 @@ def _rollout_in_place(model, x: torch.Tensor, n_steps: int) -> torch.Tensor:
     n_calls = -(-n_steps // ol)
     buf = torch.empty(B, T + n_calls * ol, *x.shape[2:], dtype=torch.float32, device=x.device)
     buf[:, :T].copy_(x)           # the formatter's 'b t h w c -> b t c h w' is materialised here, once
+    if model.enc_cache_supported() and not os.environ.get("TANTE_NO_ENC_CACHE"):
+        # every frame (input or predicted) is encoded once, when it first enters a window; the windows read the frame-major cache
+        HW, C_ = model.H_p * model.W_p, model.C
+        z = torch.empty(T + n_calls * ol, B, HW, C_, dtype=torch.float32, device=x.device)
+        encoded = 0
+        for s in range(n_calls):
+            for f in range(encoded, s * ol + T):
+                model.encode_frame(buf[:, f: f + 1], z[f])
+            encoded = s * ol + T
+            model(buf[:, s * ol: s * ol + T], out=buf[:, T + s * ol: T + (s + 1) * ol], enc_cache=(z[s * ol:], B * HW * C_, HW * C_))
+        return buf[:, T: T + n_steps]
     for s in range(n_calls):
         model(buf[:, s * ol: s * ol + T], out=buf[:, T + s * ol: T + (s + 1) * ol])
     return buf[:, T: T + n_steps]

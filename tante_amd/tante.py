@@ -120,10 +120,14 @@ class enc_CNN(nn.Module):
         s_, p_ = S.stride_pad(self.P[i], self.overlap)
         return s_ != self.P[i] or p_ != 0 or self.chans[i] * self.P[i] ** 2 > S.KMAX
 
-    def forward_tokens(self, inp: torch.Tensor, compute: int, film: Optional[tuple], item_stride: Optional[int] = None) -> torch.Tensor:
+    def fuses_23(self, compute: int) -> bool:
+        return (compute == L.BF16 and self.fused and self.P == (2, 2, 2) and self.overlap == 0.0 and K.enc23_supported(self.embed_dim))
+
+    def forward_tokens(self, inp: torch.Tensor, compute: int, film: Optional[tuple], item_stride: Optional[int] = None,
+                       out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """inp (B,T,D,H,W) fp32 -> tokens (B*T*Hp*Wp, C) fp32; `film` = (a, b, s_emb, T, HW) is applied in the
         last stage's epilogue (None: plain encoder output).  inp may be a window view of a longer rollout buffer:
-        frames contiguous, `item_stride` elements between batch items."""
+        frames contiguous, `item_stride` elements between batch items.  `out` (fused stages 2 + 3 only): destination rows."""
         B, T, D, H, W = inp.shape
         if (H, W) != (self.H, self.W) or D != self.chans[0]:
             raise ValueError(f"encoder built for {self.chans[0]} fields at {(self.H, self.W)}, got {tuple(inp.shape)}")
@@ -131,8 +135,10 @@ class enc_CNN(nn.Module):
         adt = K.act_torch_dtype(compute)
         n_img, h, w = B * T, H, W
         x = inp
-        fuse23 = (compute == L.BF16 and self.fused and film is not None and self.P == (2, 2, 2) and self.overlap == 0.0
-                  and K.enc23_supported(self.embed_dim))
+        fuse23 = film is not None and self.fuses_23(compute)
+        dst = out
+        if dst is not None and not fuse23:
+            raise ValueError("out= needs the fused stage 2 + 3 path")
         for i in range(3):
             p, ci, co = self.P[i], self.chans[i], self.chans[i + 1]
             last = i == 2
@@ -140,8 +146,9 @@ class enc_CNN(nn.Module):
                 convs = [self.enc_conv_2.conv, self.enc_conv_3.conv]
                 params = [q for c in convs for q in (c.weight, c.bias)]
                 st = self._cache.get(-3, params, lambda: K.pack_enc23(params, self.embed_dim))
-                out = torch.empty(n_img * (h // 4) * (w // 4), self.embed_dim, dtype=torch.float32, device=inp.device)
-                return K.enc23_fused(x, n_img, h // 4, w // 4, self.embed_dim, st, film, out)
+                if dst is None:
+                    dst = torch.empty(n_img * (h // 4) * (w // 4), self.embed_dim, dtype=torch.float32, device=inp.device)
+                return K.enc23_fused(x, n_img, h // 4, w // 4, self.embed_dim, st, film, dst)
             if self._general(i):
                 if i == 0:
                     x = x.contiguous().view(n_img, D, H, W)
@@ -414,9 +421,32 @@ class TANTE(nn.Module):
         return self._film_cache.get(0, params, lambda: te.tables(self.t_seq.to(self.t_emb.device, torch.float32).contiguous(),
                                                                  self.t_emb.view(self.T, self.C)))
 
-    def forward(self, input: torch.Tensor, out_T=1, out: Optional[torch.Tensor] = None):
+    # ---- frame-encoding cache (rollout loops) -------------------------------------------------------------------------------------
+    # The encoder is per frame and FiLM(t) / the positional embeddings are applied after it, so a frame's encoding before FiLM does not
+    # depend on the window it is read in: a sliding-window rollout needs each frame encoded ONCE, not once per window containing it
+    # (T times).  encode_frame() writes that pre-FiLM encoding; forward(enc_cache=...) skips the encoder and lets the first propagator
+    # kernel apply FiLM while it loads the planes.  Same arithmetic per token, term for term.
+    def enc_cache_supported(self) -> bool:
+        compute = resolve_compute(self.compute)
+        return bool(self.deg and type(self.encoder).__name__ == "enc_CNN" and self.encoder.fuses_23(compute)
+                    and K.axis_hw_supported(self.H_p, self.W_p, self.C))
+
+    def encode_frame(self, frame: torch.Tensor, z: torch.Tensor) -> torch.Tensor:
+        """frame: (B, 1, D, H, W) fp32 view (contiguous frame, any batch stride) -> z (B, Hp*Wp, C) fp32, the encoder output before FiLM."""
+        compute = resolve_compute(self.compute)
+        HW, C_ = self.H_p * self.W_p, self.C
+        ident = getattr(self, "_ident_film", None)
+        if ident is None or ident[0].device != frame.device:
+            ident = (torch.ones(1, C_, device=frame.device), torch.zeros(1, C_, device=frame.device), torch.zeros(HW, C_, device=frame.device), 1, HW)
+            self._ident_film = ident
+        self.encoder.forward_tokens(frame, compute, ident, frame.stride(0), out=z.view(-1, C_))
+        return z
+
+    def forward(self, input: torch.Tensor, out_T=1, out: Optional[torch.Tensor] = None, enc_cache: Optional[tuple] = None):
         """`out` (optional, deg=True only): a (B, output_length, D, H, W) fp32 view with contiguous frames (e.g. the next
         slots of a rollout buffer) that receives the prediction instead of a fresh tensor.
+        `enc_cache` = (z, t_stride, b_stride): the window's frames already encoded by encode_frame (frame t of item b at
+        z + t * t_stride + b * b_stride); see enc_cache_supported().
         With autograd enabled the differentiable path (train_forward.py: HIP forward + HIP backward kernels) runs."""
         if not input.is_cuda:
             raise RuntimeError("tante_amd.TANTE runs on the GPU only (no CPU fallback); move the input to cuda")
@@ -437,7 +467,13 @@ class TANTE(nn.Module):
         Hp, Wp, C_ = self.H_p, self.W_p, self.C
         HW = Hp * Wp
         fa, fb = self._time_tables()
-        x = self.encoder.forward_tokens(inp, compute, (fa, fb, self.s_emb.view(HW, C_), T, HW), bstride)   # tante.py:132-141
+        film = (fa, fb, self.s_emb.view(HW, C_), T, HW)
+        if enc_cache is not None:
+            if not self.enc_cache_supported():
+                raise RuntimeError("enc_cache: this model / compute mode has no frame-encoding cache path")
+            x = torch.empty(B * T * HW, C_, dtype=torch.float32, device=inp.device)
+        else:
+            x = self.encoder.forward_tokens(inp, compute, film, bstride)                               # tante.py:132-141
         last_slot = dict(a_n0=HW, a_s1=T * HW * C_, a_s0=C_, a_off=(T - 1) * HW * C_)               # x[:, -1:] by stride
         fused_head = (compute == L.BF16 and self.fused_head and getattr(self.decoders[0], 'P', None) == (2, 2, 2) and self.decoders[0].overlap == 0.0
                       and K.head_fused_supported(C_, D))
@@ -449,7 +485,7 @@ class TANTE(nn.Module):
                 raise ValueError("out must be a (B, output_length, D, H, W) fp32 CUDA view with contiguous frames")
         derivs, r_t, srcs = [], [], []
         for i in range(self.taylor_order):
-            self.blocks[i].forward_tokens(x, B, compute)                                            # l.146 (chained)
+            self.blocks[i].forward_tokens(x, B, compute, film_src=(enc_cache + (film,)) if (enc_cache is not None and i == 0) else None)  # l.146 (chained)
             if self.deg:
                 if fused_head:
                     if out is None:

@@ -441,6 +441,33 @@ def test_cfg2_full_size_against_oracle(dev):
     assert torch.equal(y32[1:], y32_b)
 
 
+def test_cfg2_rollout_frame_cache_is_bit_identical(dev, monkeypatch):
+    """The rollout loop encodes every frame once (pre-FiLM cache + FiLM applied by the first propagator kernel while it loads) instead
+    of once per window: the same arithmetic per token, so the frames must equal the window-by-window encoder's BITWISE, and both must
+    equal the plain `model(window)` loop of the reference's rollout_model."""
+    import tante_amd
+    m = _cfg2_model(dev).set_compute("bf16")
+    assert m.enc_cache_supported()
+    md = tante_amd.TanteMetadata(n_fields=11, spatial_resolution=(256, 256))
+    fmt = tante_amd.DefaultChannelsFirstFormatter(md)
+    g = torch.Generator().manual_seed(5)
+    batch = {"input": torch.randn(2, 4, 256, 256, 11, generator=g).to(dev), "output": torch.randn(2, 3, 256, 256, 11, generator=g).to(dev)}
+    with torch.no_grad():
+        y_cache, _ = tante_amd.rollout_model(m, batch, fmt, 3)
+        monkeypatch.setenv("TANTE_NO_ENC_CACHE", "1")
+        y_plain, _ = tante_amd.rollout_model(m, batch, fmt, 3)
+        moving = fmt.process_input(batch)[0][0]
+        frames = []
+        for _ in range(3):
+            y = m(moving)
+            frames.append(y)
+            moving = torch.cat([moving[:, y.shape[1]:], y], dim=1)
+        y_loop = fmt.process_output(torch.cat(frames, dim=1))
+    assert torch.isfinite(y_cache).all()
+    assert torch.equal(y_cache, y_plain)
+    assert torch.equal(y_cache, y_loop)
+
+
 # ---------------------------------------------------------------------------------------------------
 # fused block kernels (bf16): every supported shape against the oracle and against the unfused path
 # ---------------------------------------------------------------------------------------------------
