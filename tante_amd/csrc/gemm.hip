@@ -779,6 +779,7 @@ void launch_gemm(const TanteGemm& g, int n_tiles, int flags, hipStream_t s) {
 #define TANTE_V(LNV, AMV, EPV) launch_variant<BF16, CB, LNV, AMV, EPV>(g, n_tiles, flags, s)
   if (ln && am == AM_LIN && ep == EP_LIN_NONE) return TANTE_V(true, AM_LIN, EP_LIN_NONE);            // LN + QKV
   if (ln && am == AM_LIN && ep == EP_LIN_GELU_TANH) return TANTE_V(true, AM_LIN, EP_LIN_GELU_TANH);  // LN + fc1 + GELU
+  if (ln && am == AM_LIN && ep == EP_LIN_GELU_ERF) return TANTE_V(true, AM_LIN, EP_LIN_GELU_ERF);    // CViT: LN + fc1 + exact GELU (cvit.py:49-58)
   if (!ln && am == AM_LIN && ep == EP_LIN_NONE) return TANTE_V(false, AM_LIN, EP_LIN_NONE);          // out-proj / fc2 (+res)
   if (!ln && am == AM_LIN && ep == EP_LIN_RELU) return TANTE_V(false, AM_LIN, EP_LIN_RELU);          // interprator
   if (!ln && am == AM_NCHW2 && ep == EP_LIN_GELU_ERF) return TANTE_V(false, AM_NCHW2, EP_LIN_GELU_ERF);  // patch embed 1 (NCHW)
