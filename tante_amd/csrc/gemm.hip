@@ -782,6 +782,8 @@ void launch_gemm(const TanteGemm& g, int n_tiles, int flags, hipStream_t s) {
   if (ln && am == AM_LIN && ep == EP_LIN_GELU_ERF) return TANTE_V(true, AM_LIN, EP_LIN_GELU_ERF);    // CViT: LN + fc1 + exact GELU (cvit.py:49-58)
   if (!ln && am == AM_LIN && ep == EP_LIN_NONE) return TANTE_V(false, AM_LIN, EP_LIN_NONE);          // out-proj / fc2 (+res)
   if (!ln && am == AM_LIN && ep == EP_LIN_RELU) return TANTE_V(false, AM_LIN, EP_LIN_RELU);          // interprator
+  if (!ln && am == AM_LIN && ep == EP_LIN_GELU_ERF) return TANTE_V(false, AM_LIN, EP_LIN_GELU_ERF);  // CViT output MLP: x + gelu(dense(x)) (cvit.py Mlp)
+  if (!ln && am == AM_LIN && ep == EP_LIN_GELU_TANH) return TANTE_V(false, AM_LIN, EP_LIN_GELU_TANH);
   if (!ln && am == AM_NCHW2 && ep == EP_LIN_GELU_ERF) return TANTE_V(false, AM_NCHW2, EP_LIN_GELU_ERF);  // patch embed 1 (NCHW)
   if (am == AM_NCHW2) am = AM_GEN;
   if (!ln && am == AM_NHWC && ep == EP_LIN_GELU_ERF) return TANTE_V(false, AM_NHWC, EP_LIN_GELU_ERF);  // patch embed 2
