@@ -178,7 +178,7 @@ __device__ __forceinline__ EpiRow epi_row(const TanteGemm& g, int row) {
 // tile loop is one short straight-line path: a first version that switched on them at run time inlined
 // every combination 8x per tile (170 KB of code per kernel, instruction-fetch bound at ~5 % of MFMA peak).
 enum { AM_LIN = 0, AM_NHWC = 1, AM_GEN = 2, AM_NCHW2 = 3 };
-enum { EP_LIN_NONE = 0, EP_LIN_RELU, EP_LIN_GELU_TANH, EP_LIN_GELU_ERF, EP_FILM, EP_DNHWC_GELU_ERF, EP_DNCHW_NONE, EP_GEN };
+enum { EP_LIN_NONE = 0, EP_LIN_RELU, EP_LIN_GELU_TANH, EP_LIN_GELU_ERF, EP_FILM, EP_DNHWC_GELU_ERF, EP_DNCHW_NONE, EP_DNHWC_NONE, EP_GEN };
 
 template <bool FAST>
 __device__ __forceinline__ float gelu_tanh_v(float x) {
@@ -324,7 +324,7 @@ __device__ __forceinline__ void epilogue4_fast(const TanteGemm& g, const EpiRow&
 #pragma unroll
     for (int j = 0; j < 4; ++j) v[j] = v[j] * fa[j] + fb[j] + se[j];
     store4(g.out, g.out_dtype, e.o_base + n0, v);
-  } else if constexpr (EP == EP_DNHWC_GELU_ERF) {
+  } else if constexpr (EP == EP_DNHWC_GELU_ERF || EP == EP_DNHWC_NONE) {
     const int khw = n0 / g.Cout, co = n0 - khw * g.Cout;
     const int kh = khw / g.Po, kw = khw - kh * g.Po;
     store4(g.out, g.out_dtype, (e.o_base + (long)kh * (g.Wi * g.Po) + kw) * g.Cout + co, v);
@@ -769,6 +769,8 @@ void launch_gemm(const TanteGemm& g, int n_tiles, int flags, hipStream_t s) {
     ep = EP_FILM;
   } else if (out_vec && g.e_mode == TANTE_E_DECONV_NHWC && g.act == TANTE_ACT_GELU_ERF) {
     ep = EP_DNHWC_GELU_ERF;
+  } else if (out_vec && g.e_mode == TANTE_E_DECONV_NHWC && g.act == TANTE_ACT_NONE) {
+    ep = EP_DNHWC_NONE;
   } else if (g.e_mode == TANTE_E_DECONV_NCHW && g.act == TANTE_ACT_NONE) {
     ep = EP_DNCHW_NONE;
   }
@@ -785,11 +787,15 @@ void launch_gemm(const TanteGemm& g, int n_tiles, int flags, hipStream_t s) {
   if (!ln && am == AM_LIN && ep == EP_LIN_GELU_ERF) return TANTE_V(false, AM_LIN, EP_LIN_GELU_ERF);  // CViT output MLP: x + gelu(dense(x)) (cvit.py Mlp)
   if (!ln && am == AM_LIN && ep == EP_LIN_GELU_TANH) return TANTE_V(false, AM_LIN, EP_LIN_GELU_TANH);
   if (!ln && am == AM_NCHW2 && ep == EP_LIN_GELU_ERF) return TANTE_V(false, AM_NCHW2, EP_LIN_GELU_ERF);  // patch embed 1 (NCHW)
+  if (!ln && am == AM_NCHW2 && ep == EP_LIN_NONE) return TANTE_V(false, AM_NCHW2, EP_LIN_NONE);        // train path: stage 1 pre-activation
   if (am == AM_NCHW2) am = AM_GEN;
   if (!ln && am == AM_NHWC && ep == EP_LIN_GELU_ERF) return TANTE_V(false, AM_NHWC, EP_LIN_GELU_ERF);  // patch embed 2
   if (!ln && am == AM_NHWC && ep == EP_FILM) return TANTE_V(false, AM_NHWC, EP_FILM);                // patch embed 3 + FiLM
   if (!ln && am == AM_LIN && ep == EP_DNHWC_GELU_ERF) return TANTE_V(false, AM_LIN, EP_DNHWC_GELU_ERF);  // heads 1, 2
   if (!ln && am == AM_LIN && ep == EP_DNCHW_NONE) return TANTE_V(false, AM_LIN, EP_DNCHW_NONE);      // head 3
+  // the train path's pre-activation stages and their data gradients (PatchEmbedFn / DeconvFn forward + backward)
+  if (!ln && am == AM_LIN && ep == EP_DNHWC_NONE) return TANTE_V(false, AM_LIN, EP_DNHWC_NONE);
+  if (!ln && am == AM_NHWC && ep == EP_LIN_NONE) return TANTE_V(false, AM_NHWC, EP_LIN_NONE);
   if (ln) return TANTE_V(true, AM_GEN, EP_GEN);
   return TANTE_V(false, AM_GEN, EP_GEN);
 #undef TANTE_V
