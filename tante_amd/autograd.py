@@ -38,8 +38,7 @@ def _packed(W, b, compute, layout=L.W_LINEAR, **kw):
     return hit[0]
 
 
-def _s():
-    return torch.cuda.current_stream().cuda_stream
+_s = K._stream
 
 
 def _rm_linear(t: torch.Tensor, n0: Optional[int] = None, s1: int = 0, s0: Optional[int] = None, off: int = 0, es: int = 1,

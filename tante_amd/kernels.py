@@ -17,7 +17,9 @@ COMPUTE = {"fp32": L.F32, "float32": L.F32, "bf16": L.BF16, "bfloat16": L.BF16}
 
 
 def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+    """Raw handle of torch's current stream on the current device.  torch.cuda.current_stream() builds a Stream object per call
+    (~8 us; 400 launches per train step each way made that 6 ms of a 27 ms host-side step)."""
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
 
 
 def _dev(*ts):
