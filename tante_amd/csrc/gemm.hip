@@ -680,10 +680,21 @@ __device__ __forceinline__ long w_src_index(int layout, int n, int k, int N, int
   }
 }
 
+__device__ __forceinline__ void pack_bias_row(const float* __restrict__ w, const float* __restrict__ bias, const float* __restrict__ beta,
+                                              int layout, int N, int K, int P, int Co, int n, float* __restrict__ out);
+
+// blocks [0, w_blocks) pack the weight; the blocks after them the bias (+ W beta of a folded LayerNorm): one launch per packing --
+// a train step re-packs ~90 weights, and every launch costs 4-5 us of GPU time however little it does
 template <bool BF16>
 __global__ void pack_kernel(const float* __restrict__ w, const float* __restrict__ gamma, int layout, int N, int K, int P,
-                            int Co, int n_pad, int cpr, int nt, u32x4* __restrict__ out) {
+                            int Co, int n_pad, int cpr, int nt, u32x4* __restrict__ out, int w_blocks, const float* __restrict__ bias,
+                            const float* __restrict__ beta, float* __restrict__ bias_out) {
   constexpr int E = BF16 ? 8 : 4;
+  if ((int)blockIdx.x >= w_blocks) {
+    const int n = ((int)blockIdx.x - w_blocks) * blockDim.x + threadIdx.x;
+    if (n < n_pad) pack_bias_row(w, bias, beta, layout, N, K, P, Co, n, bias_out);
+    return;
+  }
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (long)n_pad * cpr) return;
   const int n = (int)(idx / cpr), c = (int)(idx % cpr);
@@ -709,10 +720,8 @@ __global__ void pack_kernel(const float* __restrict__ w, const float* __restrict
   out[((long)tile * nt + r) * cpr + swz_chunk(r, c, cpr)] = o;
 }
 
-__global__ void pack_bias_kernel(const float* __restrict__ w, const float* __restrict__ bias, const float* __restrict__ beta,
-                                 int layout, int N, int K, int P, int Co, int n_pad, float* __restrict__ out) {
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= n_pad) return;
+__device__ __forceinline__ void pack_bias_row(const float* __restrict__ w, const float* __restrict__ bias, const float* __restrict__ beta,
+                                              int layout, int N, int K, int P, int Co, int n, float* __restrict__ out) {
   float b = 0.0f;
   if (n < N) {
     if (bias) {
@@ -836,14 +845,13 @@ extern "C" int tante_pack_weight(const float* w, const float* bias, const float*
   const int cpr = geo.cb * 4;
   const long units = (long)geo.n_pad * cpr;
   const int blocks = (int)((units + 255) / 256);
+  const int b_blocks = (geo.n_pad + 255) / 256;
   if (compute == TANTE_BF16)
-    hipLaunchKernelGGL(pack_kernel<true>, dim3(blocks), dim3(256), 0, s, w, gamma, layout, N, K, P, C_other, geo.n_pad, cpr,
-                       geo.nt, (u32x4*)w_out);
+    hipLaunchKernelGGL(pack_kernel<true>, dim3(blocks + b_blocks), dim3(256), 0, s, w, gamma, layout, N, K, P, C_other, geo.n_pad, cpr,
+                       geo.nt, (u32x4*)w_out, blocks, bias, beta, bias_out);
   else
-    hipLaunchKernelGGL(pack_kernel<false>, dim3(blocks), dim3(256), 0, s, w, gamma, layout, N, K, P, C_other, geo.n_pad, cpr,
-                       geo.nt, (u32x4*)w_out);
-  hipLaunchKernelGGL(pack_bias_kernel, dim3((geo.n_pad + 63) / 64), dim3(64), 0, s, w, bias, beta, layout, N, K, P, C_other,
-                     geo.n_pad, bias_out);
+    hipLaunchKernelGGL(pack_kernel<false>, dim3(blocks + b_blocks), dim3(256), 0, s, w, gamma, layout, N, K, P, C_other, geo.n_pad, cpr,
+                       geo.nt, (u32x4*)w_out, blocks, bias, beta, bias_out);
   TANTE_CHECK_LAUNCH();
   return 0;
 }
