@@ -368,6 +368,12 @@ int tante_axis_mlp_bwd(const float* x, const float* dy, int64_t outer, int n, in
 /* weight / bias gradients of one propagator layer from two (outer, n, inner) fp32 tensors in the residual stream's layout:
  * dW[a][j] (+)= sum_{o,i} U[o][a][i] V[o][j][i], db[a] (+)= sum_{o,i} U[o][a][i] (db may be NULL); n <= 64, inner % 16 == 0.
  * (dW2 = <dy, h>, dW1 = <dpre, x> of attn_backbone.py:111-119's two Linear layers.) */
+/* LayerNorm's affine folded into the consuming Linear on the train path (attn_backbone.py:50-56 with nn.LayerNorm's weight / bias):
+ * fwd: We = W diag(gamma), be = b + W beta (b may be NULL);  bwd, from the accumulated gradients GW (N, K), Gb (N) of (We, be), ADDS
+ * dW += GW diag(gamma) + Gb beta^T, db += Gb (db may be NULL), dgamma[k] += sum_n GW[n][k] W[n][k], dbeta[k] += sum_n W[n][k] Gb[n]. */
+int tante_fold_fwd(const float* W, const float* b, const float* gamma, const float* beta, int N, int K, float* We, float* be, void* stream);
+int tante_fold_bwd(const float* GW, const float* Gb, const float* W, const float* gamma, const float* beta, int N, int K, float* dW, float* db,
+                   float* dgamma, float* dbeta, void* stream);
 int tante_axis_wgrad(const float* U, const float* V, int64_t outer, int n, int64_t inner, float* dW, float* db, int accumulate, void* stream);
 
 /* A gathered row matrix (rows r, `cols` columns): LINEAR rows at (r/n0)*s1 + (r%n0)*s0 + off with element stride es, or the

@@ -107,6 +107,8 @@ SIGNATURES = {
     "tante_dropout_add": ([c_vp, c_i32, c_vp, c_f32, C.c_uint64, c_i64, c_vp, c_vp], c_i32),
     "tante_dropout_bwd": ([c_vp, c_f32, C.c_uint64, c_i64, c_vp, c_i32, c_vp], c_i32),
     "tante_axis_mlp_bwd": ([c_vp, c_vp, c_i64, c_i32, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp], c_i32),
+    "tante_fold_fwd": ([c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp], c_i32),
+    "tante_fold_bwd": ([c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp], c_i32),
     "tante_axis_wgrad": ([c_vp, c_vp, c_i64, c_i32, c_i64, c_vp, c_vp, c_i32, c_vp], c_i32),
     "tante_wgrad": ([C.POINTER(RowMat), C.POINTER(RowMat), c_i64, c_i32, c_i32, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp], c_i32),
     "tante_clip_value": ([c_vp, c_i64, c_f32, c_vp], c_i32),

@@ -177,16 +177,22 @@ class LayerNormFn(Function):
 class FoldFn(Function):
     """(W diag(gamma), b + W beta): LayerNorm's affine folded into the consumer's weight, with zero-initialised accumulators that the
     weight-gradient kernels of every use add into (`_tante_grad`, see _grad_slot).  Those uses then return no gradient for the folded
-    tensors, autograd calls this backward once with nothing, and the accumulated gradient is distributed to W, b, gamma, beta here.
+    tensors, autograd calls this backward once with nothing, and the accumulated gradient is distributed to W, b, gamma, beta here --
+    one HIP launch forward (tante_fold_fwd), one backward (tante_fold_bwd, straight into the parameters' gradient slots).
     Without the accumulators every use of a folded weight produced a fresh dW / db that autograd summed: ~300 tiny launches per step."""
 
     @staticmethod
     def forward(ctx, W, b, gamma, beta):
-        We = W * gamma[None, :]
-        be = b + W @ beta
-        gW, gb = torch.zeros_like(We), torch.zeros_like(be)
+        N, Kk = W.shape
+        We = torch.empty_like(W)
+        be = torch.empty(N, dtype=torch.float32, device=W.device)
+        L.check(L.lib().tante_fold_fwd(W.data_ptr(), None if b is None else b.data_ptr(), gamma.data_ptr(), beta.data_ptr(), N, Kk,
+                                       We.data_ptr(), be.data_ptr(), _s()), "tante_fold_fwd")
+        acc = torch.zeros(N * Kk + N, dtype=torch.float32, device=W.device)      # one fill for both accumulators
+        gW, gb = acc[:N * Kk].view(N, Kk), acc[N * Kk:]
         ctx.save_for_backward(W, gamma, beta)
         ctx.acc = (gW, gb)
+        ctx.params = (W, b, gamma, beta)
         ctx.set_materialize_grads(False)
         ctx.mark_non_differentiable(gW, gb)
         return We, be, gW, gb
@@ -201,8 +207,19 @@ class FoldFn(Function):
             GW = GW + gWe
         if gbe is not None:
             Gb = Gb + gbe
-        dW = torch.addcmul(GW * gamma[None, :], Gb[:, None], beta[None, :])
-        return dW, Gb, (GW * W).sum(0), W.t() @ Gb
+        N, Kk = W.shape
+        slots = [_grad_slot(q) for q in ctx.params]
+        has_b = ctx.params[1] is not None
+        direct = all(g is not None for g, q in zip(slots, ctx.params) if q is not None)
+        if direct:
+            dW, db, dg, dbt = slots
+        else:
+            dW, dg, dbt = torch.zeros_like(W), torch.zeros_like(gamma), torch.zeros_like(beta)
+            db = torch.zeros(N, dtype=torch.float32, device=W.device) if has_b else None
+        GW, Gb = GW.contiguous(), Gb.contiguous()
+        L.check(L.lib().tante_fold_bwd(GW.data_ptr(), Gb.data_ptr(), W.data_ptr(), gamma.data_ptr(), beta.data_ptr(), N, Kk, dW.data_ptr(),
+                                       None if db is None else db.data_ptr(), dg.data_ptr(), dbt.data_ptr(), _s()), "tante_fold_bwd")
+        return (None, None, None, None) if direct else (dW, db, dg, dbt)
 
 
 class LayerNormSkipFn(Function):

@@ -696,6 +696,59 @@ __global__ __launch_bounds__(256) void axis_wgrad_kernel(const float* __restrict
   if (db && tid < n) atomicAdd(&db[tid], red[NP * NP + tid]);
 }
 
+// ---- LayerNorm affine folded into the consumer's weight (train path): We = W diag(gamma), be = b + W beta, and the fold's backward ------
+// One launch each.  fwd: blocks [0, nbe) write We (float4 pieces), the blocks after them one be row per wave.
+__global__ __launch_bounds__(256) void fold_fwd_kernel(const float* __restrict__ W, const float* __restrict__ b, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, int N, int K, float* __restrict__ We,
+                                                       float* __restrict__ be, int nbe) {
+  if ((int)blockIdx.x < nbe) {
+    const long i4 = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i4 * 4 >= (long)N * K) return;
+    const int k = (int)((i4 * 4) % K);
+    const f32x4 w = *(const f32x4*)(W + i4 * 4), g = *(const f32x4*)(gamma + k);
+    *(f32x4*)(We + i4 * 4) = w * g;
+    return;
+  }
+  const int n = ((int)blockIdx.x - nbe) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (n >= N) return;
+  float s = 0.f;
+  for (int k = lane; k < K; k += 64) s += W[(long)n * K + k] * beta[k];
+  s = wave_sum(s);
+  if (lane == 0) be[n] = (b ? b[n] : 0.f) + s;
+}
+// bwd, from the accumulated gradients GW (N, K), Gb (N) of the folded pair:
+//   dW += GW diag(gamma) + Gb beta^T,  db += Gb,  dgamma[k] += sum_n GW[n][k] W[n][k],  dbeta[k] += sum_n W[n][k] Gb[n]
+// blocks [0, nbe): elementwise part (and db by the k = 0 pieces); blocks after: 32-row slabs of the two column reductions (atomics)
+__global__ __launch_bounds__(256) void fold_bwd_kernel(const float* __restrict__ GW, const float* __restrict__ Gb, const float* __restrict__ W,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta, int N, int K,
+                                                       float* __restrict__ dW, float* __restrict__ db, float* __restrict__ dgamma,
+                                                       float* __restrict__ dbeta, int nbe) {
+  if ((int)blockIdx.x < nbe) {
+    const long i4 = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i4 * 4 >= (long)N * K) return;
+    const long n = (i4 * 4) / K;
+    const int k = (int)(i4 * 4 - n * K);
+    const f32x4 gw = *(const f32x4*)(GW + i4 * 4), g = *(const f32x4*)(gamma + k), bt = *(const f32x4*)(beta + k);
+    const float gb = Gb[n];
+    f32x4* d = (f32x4*)(dW + i4 * 4);
+    *d = *d + gw * g + bt * gb;
+    if (k == 0 && db) db[n] += gb;
+    return;
+  }
+  const int kb = K / 256 > 0 ? (K + 255) / 256 : 1;
+  const int slab = ((int)blockIdx.x - nbe) / kb, k = (((int)blockIdx.x - nbe) % kb) * 256 + threadIdx.x;
+  if (k >= K) return;
+  const int n0 = slab * 32, n1 = min(N, n0 + 32);
+  float sg = 0.f, sb = 0.f;
+  for (int n = n0; n < n1; ++n) {
+    const float w = W[(long)n * K + k];
+    sg += GW[(long)n * K + k] * w;
+    sb += w * Gb[n];
+  }
+  atomicAdd(&dgamma[k], sg);
+  atomicAdd(&dbeta[k], sb);
+}
+
 // ---- axis propagator backward: y = x + W2 gelu(W1 x + b1) + b2 along an axis of (outer, n, inner) -----------------------
 // one lane per column; writes dx = dy + W1^T (gelu'(pre) * (W2^T dy)), and materialises h = gelu(pre) and dpre for the
 // weight-gradient GEMMs (same (outer, n, inner) layout, fp32)
@@ -836,6 +889,25 @@ extern "C" int tante_axis_wgrad(const float* U, const float* V, int64_t outer, i
     default: TANTE_AW(4); break;
   }
 #undef TANTE_AW
+  TANTE_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int tante_fold_fwd(const float* W, const float* b, const float* gamma, const float* beta, int N, int K, float* We, float* be,
+                              void* stream) {
+  if (!W || !gamma || !beta || !We || !be || N <= 0 || K <= 0 || K % 4) TANTE_FAIL(-1, "tante_fold_fwd: bad argument (K must be a multiple of 4)");
+  const int nbe = (int)(((long)N * K / 4 + 255) / 256);
+  hipLaunchKernelGGL(fold_fwd_kernel, dim3(nbe + (N + 3) / 4), dim3(256), 0, (hipStream_t)stream, W, b, gamma, beta, N, K, We, be, nbe);
+  TANTE_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int tante_fold_bwd(const float* GW, const float* Gb, const float* W, const float* gamma, const float* beta, int N, int K, float* dW,
+                              float* db, float* dgamma, float* dbeta, void* stream) {
+  if (!GW || !Gb || !W || !gamma || !beta || !dW || !dgamma || !dbeta || N <= 0 || K <= 0 || K % 4)
+    TANTE_FAIL(-1, "tante_fold_bwd: bad argument (K must be a multiple of 4)");
+  const int nbe = (int)(((long)N * K / 4 + 255) / 256);
+  const int kb = (K + 255) / 256;
+  hipLaunchKernelGGL(fold_bwd_kernel, dim3(nbe + ((N + 31) / 32) * kb), dim3(256), 0, (hipStream_t)stream, GW, Gb, W, gamma, beta, N, K, dW, db,
+                     dgamma, dbeta, nbe);
   TANTE_CHECK_LAUNCH();
   return 0;
 }

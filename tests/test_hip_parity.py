@@ -872,6 +872,33 @@ def test_gemm_training_epilogues(dev, M, N, K):
         Kk.linear(a[:64], pw, small, M=64, residual=res[:64], drop_p=p, drop_seed=seed)
 
 
+@pytest.mark.parametrize("N,K,bias", [(768, 256, True), (50, 36, True), (256, 512, False)])
+def test_fold_kernels(dev, N, K, bias):
+    """tante_fold_fwd / tante_fold_bwd (LayerNorm affine folded into the consumer weight on the train path) against the torch expressions
+    W * gamma, b + W @ beta and their autograd."""
+    from tante_amd import _lib as L
+    g = torch.Generator().manual_seed(N + K)
+    W = torch.randn(N, K, generator=g).to(dev).requires_grad_()
+    b = torch.randn(N, generator=g).to(dev).requires_grad_() if bias else None
+    ga = (1 + 0.3 * torch.randn(K, generator=g)).to(dev).requires_grad_()
+    be = (0.3 * torch.randn(K, generator=g)).to(dev).requires_grad_()
+    GW, Gb = torch.randn(N, K, generator=g).to(dev), torch.randn(N, generator=g).to(dev)
+    We_ref = W * ga[None, :]
+    be_ref = (b if bias else 0) + W @ be
+    ((We_ref * GW).sum() + (be_ref * Gb).sum()).backward()
+    s = torch.cuda.current_stream().cuda_stream
+    We, bo = torch.empty(N, K, device=dev), torch.empty(N, device=dev)
+    L.check(L.lib().tante_fold_fwd(W.data_ptr(), b.data_ptr() if bias else None, ga.data_ptr(), be.data_ptr(), N, K, We.data_ptr(), bo.data_ptr(), s))
+    assert torch.allclose(We, We_ref.detach(), rtol=1e-6, atol=1e-6) and torch.allclose(bo, be_ref.detach(), rtol=1e-5, atol=1e-5)
+    dW, db, dg, dbt = torch.ones(N, K, device=dev), torch.ones(N, device=dev), torch.ones(K, device=dev), torch.ones(K, device=dev)
+    L.check(L.lib().tante_fold_bwd(GW.data_ptr(), Gb.data_ptr(), W.data_ptr(), ga.data_ptr(), be.data_ptr(), N, K, dW.data_ptr(),
+                                   db.data_ptr() if bias else None, dg.data_ptr(), dbt.data_ptr(), s))
+    assert torch.allclose(dW - 1, W.grad, rtol=1e-5, atol=1e-5)                      # the kernel ADDS onto what is there
+    assert torch.allclose(dg - 1, ga.grad, rtol=1e-4, atol=1e-3) and torch.allclose(dbt - 1, be.grad, rtol=1e-4, atol=1e-3)
+    if bias:
+        assert torch.allclose(db - 1, b.grad, rtol=1e-6, atol=1e-6)
+
+
 def test_train_step_with_dropout_runs(dev):
     import tante_amd
     g, m, md = _g9_model(dev)
