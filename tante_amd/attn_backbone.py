@@ -101,10 +101,17 @@ class TransformerBlock(nn.Module):
         return self._cache.get(compute, params, build)
 
     def _packed_fused(self):
-        a, m = self.attn, self.mlp
-        params = [self.ln1.weight, self.ln1.bias, a.in_proj_weight, a.in_proj_bias, a.out_proj.weight, a.out_proj.bias,
-                  self.ln2.weight, self.ln2.bias, m[0].weight, m[0].bias, m[2].weight, m[2].bias]
+        params = self.__dict__.get("_fused_params")      # nn.Module attribute walks cost ~20 us per call, 72 calls per rollout
+        if params is None:
+            a, m = self.attn, self.mlp
+            params = [self.ln1.weight, self.ln1.bias, a.in_proj_weight, a.in_proj_bias, a.out_proj.weight, a.out_proj.bias,
+                      self.ln2.weight, self.ln2.bias, m[0].weight, m[0].bias, m[2].weight, m[2].bias]
+            self.__dict__["_fused_params"] = params
         return self._cache.get(-1, params, lambda: K.pack_block(params, self.embed_dim, self.hidden))
+
+    def _apply(self, fn, *a, **kw):      # .to() / .half() may replace Parameter objects: drop the cached list
+        self.__dict__.pop("_fused_params", None)
+        return super()._apply(fn, *a, **kw)
 
     def forward_tokens(self, x: torch.Tensor, seq: L.Seq, causal: bool, compute: int) -> torch.Tensor:
         """In place on the flat fp32 residual stream x (tokens, C); `seq` says which tokens attend to which."""
