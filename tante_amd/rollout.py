@@ -84,12 +84,20 @@ def rollout_model(model, batch: Dict, formatter, n_steps: int, device=None):
     return torch.cat(preds, dim=1)[:, :n_steps], y_ref.to(device)
 
 
-def rollout_adaptive(model, batch: Dict, formatter, n_steps: int, out_T: float, per_sample: bool, device=None):
+def rollout_adaptive(model, batch: Dict, formatter, n_steps: int, out_T: float, per_sample: bool, device=None,
+                     batch_when_equivalent: bool = True):
     """deg=False rollouts: per_sample=True, out_T=1.5 is R_Trainer's loop; per_sample=False,
-    out_T=n_steps_rollout is R_Evaler's.  Returns (y_pred, y_ref, Rts)."""
+    out_T=n_steps_rollout is R_Evaler's.  Returns (y_pred, y_ref, Rts).
+
+    R_Trainer serialises the batch (`for i in range(batch)`, r_trainer.py:118) because `floor(R_t[0])` lets sample 0 decide the frame
+    count of a call.  With out_T < 1.999 the clamp bounds every r_t to [1.001, out_T + 0.001) (tante.py:191-201), so EVERY sample
+    produces exactly one frame per call whatever sample 0 says: the per-sample loop and one batched rollout compute the same frames,
+    and `eval_rt` takes a mean over all R_t (order-free).  Then the batch runs as one."""
     device = device or next(model.parameters()).device
     xs, y_ref = formatter.process_input(batch)
     xs = xs[0].to(device)
+    if per_sample and batch_when_equivalent and float(out_T) < 1.999:
+        per_sample = False
     chunks = [xs[i:i + 1] for i in range(xs.shape[0])] if per_sample else [xs]
     from .train_forward import fold_scope
     rts, outs = [], []

@@ -899,6 +899,25 @@ def test_fold_kernels(dev, N, K, bias):
         assert torch.allclose(db - 1, b.grad, rtol=1e-6, atol=1e-6)
 
 
+def test_adaptive_rollout_batched_equals_per_sample(dev):
+    """R_Trainer's per-sample loop (out_T = 1.5: one frame per call for every sample) against the same rollout run as one batch."""
+    import tante_amd
+    g = load_golden("g13_deg_false")
+    md = tante_amd.TanteMetadata(n_fields=1, spatial_resolution=(32, 32))
+    m = _tante_from(g, dev, in_T=4, dset_metadata=md, taylor_order=2, attn_axes="TH-TW", n_head=2, embed_dim=32, patch_scale=8, dropout=0.0,
+                    deg=False)
+    fmt = tante_amd.DefaultChannelsFirstFormatter(md)
+    gen = torch.Generator().manual_seed(3)
+    batch = {"input": torch.randn(3, 4, 32, 32, 1, generator=gen).to(dev), "output": torch.randn(3, 3, 32, 32, 1, generator=gen).to(dev)}
+    with torch.no_grad():
+        y_b, _, rt_b = tante_amd.rollout_adaptive(m, batch, fmt, 3, 1.5, per_sample=True)
+        y_s, _, rt_s = tante_amd.rollout_adaptive(m, batch, fmt, 3, 1.5, per_sample=True, batch_when_equivalent=False)
+    assert y_b.shape == y_s.shape == (3, 3, 32, 32, 1)
+    close(y_b, y_s.cpu(), "fp32")
+    assert abs(float(rt_b.mean()) - float(rt_s.mean())) < 1e-5 and rt_b.numel() == rt_s.numel()
+    assert float(rt_s.min()) >= 1.0 and float(rt_s.max()) < 2.0
+
+
 def test_train_step_with_dropout_runs(dev):
     import tante_amd
     g, m, md = _g9_model(dev)
