@@ -392,6 +392,11 @@ typedef struct TanteRowMat {
  * the tiles that are staged anyway.  MFMA in `compute`, fp32 atomics across the row split. */
 int tante_wgrad(const TanteRowMat* U, const TanteRowMat* V, int64_t R, int I, int J, float* dW, float* dbias, int layout, int P,
                 int C_other, int swap, int compute, int accumulate, void* stream);
+/* The same for n_seg operand pairs of R rows each, contracted as one row range (dW = sum_g U_g^T V_g): the uses of one weight in a
+ * back-propagation through time share a launch and one atomic epilogue where the shapes allow (dense bf16 rows, I and J multiples of
+ * 128, R % 32 == 0, at most 8 segments per launch); otherwise the segments run one by one. */
+int tante_wgrad_multi(const TanteRowMat* U, const TanteRowMat* V, int n_seg, int64_t R, int I, int J, float* dW, float* dbias, int layout,
+                      int P, int C_other, int swap, int compute, int accumulate, void* stream);
 
 const char* tante_last_error(void);
 int tante_abi_version(void);

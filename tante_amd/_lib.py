@@ -111,6 +111,7 @@ SIGNATURES = {
     "tante_fold_bwd": ([c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp], c_i32),
     "tante_axis_wgrad": ([c_vp, c_vp, c_i64, c_i32, c_i64, c_vp, c_vp, c_i32, c_vp], c_i32),
     "tante_wgrad": ([C.POINTER(RowMat), C.POINTER(RowMat), c_i64, c_i32, c_i32, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp], c_i32),
+    "tante_wgrad_multi": ([c_vp, c_vp, c_i32, c_i64, c_i32, c_i32, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp], c_i32),
     "tante_clip_value": ([c_vp, c_i64, c_f32, c_vp], c_i32),
     "tante_rt_reduce_bwd": ([c_vp, c_i32, c_i32, c_vp, c_vp], c_i32),
     "tante_last_error": ([], C.c_char_p),

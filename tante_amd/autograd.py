@@ -132,6 +132,54 @@ class _side_wgrad:
         return False
 
 
+# ---- deferred weight gradients -------------------------------------------------------------------------------------------------------
+# With BPTT a weight is used once per rollout call, and each use's weight-gradient kernel pays its own launch (4-8 us of GPU time
+# however short), its own pipeline ramp and its own atomic epilogue (64 KiB of fp32 atomics per workgroup, ~11 us per call in situ).
+# The dense bf16 linears therefore only RECORD (dY, A) in backward; when the backward pass ends (engine callback) -- or when a FoldFn
+# needs its accumulators -- the uses of one weight run as ONE tante_wgrad_multi launch over the concatenated row range.  The recorded
+# operands stay alive a little longer (~3 GB at cfg3 on a 288 GB part).
+DEFER_WGRAD = __import__("os").environ.get("TANTE_WGRAD_DEFER", "1") != "0"
+_DEFER = {"pending": {}, "armed": False}
+
+
+def _flush_wgrads(slot: Optional[torch.Tensor] = None):
+    pend = _DEFER["pending"]
+    keys = [k for k in pend if slot is None or k[0] == slot.data_ptr()]
+    for k in keys:
+        gW, gb, M, N, Kk, comp, uses = pend.pop(k)
+        n = len(uses)
+        U = (L.RowMat * n)(*[_rm_linear(dy) for dy, _ in uses])
+        V = (L.RowMat * n)(*[_rm_linear(a) for _, a in uses])
+        L.check(L.lib().tante_wgrad_multi(C.byref(U), C.byref(V), n, M, N, Kk, gW.data_ptr(), gb.data_ptr(), L.W_LINEAR, 0, 0, 0, comp, 1, _s()),
+                "tante_wgrad_multi")
+    if slot is None:
+        _DEFER["armed"] = False
+
+
+def flush_deferred_wgrads():
+    """Run every recorded weight-gradient launch now (called automatically at the end of a backward pass)."""
+    _flush_wgrads(None)
+
+
+def _defer_wgrad(gW, gb, dy, a, M, N, Kk, comp) -> bool:
+    """Record one use; False when this use has to run immediately (feature off, shape / dtype outside the shared-launch kernel)."""
+    if not DEFER_WGRAD or comp != L.BF16 or dy.dtype != torch.bfloat16 or a.dtype != torch.bfloat16 or not _tr_shape(M, N, Kk):
+        return False
+    if not _DEFER["armed"]:
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(flush_deferred_wgrads)
+        except RuntimeError:          # not inside a backward pass: nothing would flush it
+            return False
+        _DEFER["pending"].clear()     # leftovers of a backward pass that died half-way must not leak into this one
+        _DEFER["armed"] = True
+    key = (gW.data_ptr(), M, N, Kk, comp)
+    ent = _DEFER["pending"].get(key)
+    if ent is None:
+        ent = _DEFER["pending"][key] = (gW, gb, M, N, Kk, comp, [])
+    ent[6].append((dy, a))
+    return True
+
+
 def wgrad(U: L.RowMat, V: L.RowMat, R: int, I: int, J: int, out_shape, compute: int, layout: int = L.W_LINEAR, P: int = 0,
           C_other: int = 0, swap: bool = False, device=None, with_bias: bool = False, into: Optional[torch.Tensor] = None,
           db_into: Optional[torch.Tensor] = None):
@@ -201,6 +249,7 @@ class FoldFn(Function):
     def backward(ctx, gWe, gbe, _a, _b):
         W, gamma, beta = ctx.saved_tensors
         GW, Gb = ctx.acc
+        _flush_wgrads(GW)                    # the recorded uses of this folded weight run now, as one launch
         if _SIDE["stream"] is not None:      # the accumulators are written by weight-gradient kernels on the side stream
             torch.cuda.current_stream().wait_stream(_SIDE["stream"])
         if gWe is not None:
@@ -294,8 +343,9 @@ class LinearFn(Function):
         if ctx.needs_input_grad[1] and ctx.has_bias and ctx.needs_input_grad[2]:
             gW, gb = _grad_slot(ctx.params[0]), _grad_slot(ctx.params[1])
             if gW is not None and gb is not None:
-                with _side_wgrad(dy, a):
-                    wgrad(_rm_linear(dy), _rm_linear(a), M, N, Kk, (N, Kk), comp, device=a.device, with_bias=True, into=gW, db_into=gb)
+                if not _defer_wgrad(gW, gb, dy, a, M, N, Kk, comp):
+                    with _side_wgrad(dy, a):
+                        wgrad(_rm_linear(dy), _rm_linear(a), M, N, Kk, (N, Kk), comp, device=a.device, with_bias=True, into=gW, db_into=gb)
                 side_done = True
         if ctx.needs_input_grad[0]:       # dgrad GEMM: (M, N) x (N, K); the contraction (N) is chunked to the kernel's K limit
             chunks = [(c0, min(512, N - c0)) for c0 in range(0, N, 512)]
@@ -375,8 +425,9 @@ class BranchOutFn(Function):
         if ctx.needs_input_grad[1] and ctx.has_bias and ctx.needs_input_grad[2]:
             gW, gb = _grad_slot(ctx.params[0]), _grad_slot(ctx.params[1])
             if gW is not None and gb is not None:
-                with _side_wgrad(dy, a):
-                    wgrad(_rm_linear(dy), _rm_linear(a), M, N, Kk, (N, Kk), comp, device=a.device, with_bias=True, into=gW, db_into=gb)
+                if not _defer_wgrad(gW, gb, dy, a, M, N, Kk, comp):
+                    with _side_wgrad(dy, a):
+                        wgrad(_rm_linear(dy), _rm_linear(a), M, N, Kk, (N, Kk), comp, device=a.device, with_bias=True, into=gW, db_into=gb)
                 side_done = True
         if ctx.needs_input_grad[0]:
             dpre = torch.empty(M, Kk, dtype=pre.dtype, device=pre.device)

@@ -295,8 +295,17 @@ __device__ __forceinline__ u32x2 ds_read_tr16_b64(unsigned addr) {
   return r;
 }
 
+// up to WSEG (U, V) operand pairs of R_seg rows each, contracted as ONE row range of n_seg * R_seg rows: the BPTT uses of a weight share
+// one launch and one atomic epilogue (tante_wgrad_multi).  A split never straddles two segments (rows_per_split divides R_seg).
+constexpr int WSEG = 8;
+struct WgSegs {
+  const unsigned short* U[WSEG];
+  const unsigned short* V[WSEG];
+  long R_seg;
+};
+
 template <int WNBUF>   // ring depth: 4 (64 KB, two workgroups per CU) or 8 (128 KB: a lone workgroup keeps 7 chunks = 112 KB in flight)
-__global__ __launch_bounds__(256, WNBUF == 4 ? 2 : 1) void wgrad_tr_kernel(const unsigned short* __restrict__ U, long ldu, const unsigned short* __restrict__ V,
+__global__ __launch_bounds__(256, WNBUF == 4 ? 2 : 1) void wgrad_tr_kernel(const WgSegs SG, long ldu,
                                                           long ldv, long R, int I, int J, long rows_per_split, float* __restrict__ dW,
                                                           float* __restrict__ dbias, int layout, int P, int Co, int swap, int debug, int n_split) {
   extern __shared__ __attribute__((aligned(16))) char wsm[];   // ring: [buf][U chunk | V chunk]
@@ -311,7 +320,11 @@ __global__ __launch_bounds__(256, WNBUF == 4 ? 2 : 1) void wgrad_tr_kernel(const
   if (bz >= n_split) return;
   const int i0 = (tile % ti) * WT, j0 = (tile / ti) * WT;
   const bool first_j = (tile / ti) == 0;
-  const long r_begin = (long)bz * rows_per_split, r_end = min(R, r_begin + rows_per_split);
+  const long g_begin = (long)bz * rows_per_split;                  // row index in the concatenation of the segments
+  const int seg = (int)(g_begin / SG.R_seg);
+  const long r_begin = g_begin - (long)seg * SG.R_seg, r_end = min(SG.R_seg, r_begin + rows_per_split);
+  const unsigned short* __restrict__ U = SG.U[seg];
+  const unsigned short* __restrict__ V = SG.V[seg];
   const int nchunk = (debug & 2) ? 0 : (int)((r_end - r_begin) / WRC);
   const int wi = wave >> 1, wj = wave & 1;
   // DMA: a wave instruction moves 4 rows (lanes 16 q .. 16 q + 15 = row q); wave w copies rows 8 w .. 8 w + 7 of the chunk
@@ -436,49 +449,57 @@ static int rm_stage_mode(const TanteRowMat& m, int ncols) {
   return ST_GENERIC;
 }
 
-extern "C" int tante_wgrad(const TanteRowMat* U, const TanteRowMat* V, int64_t R, int I, int J, float* dW, float* dbias, int layout, int P,
-                           int C_other, int swap, int compute, int accumulate, void* stream) {
-  if (!U || !V || !dW || R <= 0 || I <= 0 || J <= 0) TANTE_FAIL(-1, "tante_wgrad: bad argument");
-  int rc = check_rowmat(*U, "U");
-  if (rc) return rc;
-  rc = check_rowmat(*V, "V");
-  if (rc) return rc;
-  if (layout < TANTE_W_LINEAR || layout > TANTE_W_DECONV_NCHW) TANTE_FAIL(-1, "tante_wgrad: bad output layout");
-  hipStream_t s = (hipStream_t)stream;
-  if (!accumulate && hipMemsetAsync(dW, 0, (size_t)I * J * sizeof(float), s) != hipSuccess) TANTE_FAIL(-3, "tante_wgrad: memset failed");
-  if (!accumulate && dbias && hipMemsetAsync(dbias, 0, (size_t)I * sizeof(float), s) != hipSuccess) TANTE_FAIL(-3, "tante_wgrad: memset failed");
+// the LDS-DMA / transposed-read path for n_seg operand pairs of R rows each (dense bf16 rows, I and J multiples of 128, R % 32 == 0)
+static bool wgrad_tr_launch(const TanteRowMat* U, const TanteRowMat* V, int n_seg, long R, int I, int J, float* dW, float* dbias, int layout,
+                            int P, int C_other, int swap, hipStream_t s) {
   static const bool no_tr = getenv("TANTE_WGRAD_NO_TR") && atoi(getenv("TANTE_WGRAD_NO_TR"));
-  if (compute == TANTE_BF16 && !no_tr && R % WRC == 0 && wgrad_tr_ok(*U, (long)R, I) && wgrad_tr_ok(*V, (long)R, J)) {
-    const int ti = I / WT, tj = J / WT;
-    // every workgroup ends with 128 x 128 fp32 atomics: with the main loop at memory speed the split count is a trade between
-    // parallelism and atomic traffic (64 KiB per workgroup) -- measured best near 128 workgroups for <= 4 tiles, 256 otherwise
-    static const int wg_env = getenv("TANTE_WGRAD_WGS") ? atoi(getenv("TANTE_WGRAD_WGS")) : 0;
-    const int wg_target = wg_env > 0 ? wg_env : (ti * tj <= 4 ? 128 : 256);
-    long split = wg_target / ((long)ti * tj);
-    if (split < 1) split = 1;
-    const long nch = R / WRC;
-    if (split > nch / 4) split = nch / 4 > 0 ? nch / 4 : 1;
-    if (split > 65535) split = 65535;
-    long per = ((nch + split - 1) / split) * WRC;
-    split = (R + per - 1) / per;
-    static const int wdebug = getenv("TANTE_WGRAD_DEBUG") ? atoi(getenv("TANTE_WGRAD_DEBUG")) : 0;
-    static const int deep_env = getenv("TANTE_WGRAD_DEEP") ? atoi(getenv("TANTE_WGRAD_DEEP")) : -1;
-    static bool set = false;
-    if (!set) {
-      hipFuncSetAttribute((const void*)wgrad_tr_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * WCHUNK);
-      hipFuncSetAttribute((const void*)wgrad_tr_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 2 * WCHUNK);
-      set = true;
-    }
-    const unsigned n_wg = 8u * (unsigned)((split + 7) / 8) * (unsigned)(ti * tj);
-    // the 8-deep ring (one workgroup per CU with 112 KB in flight) is kept for experiments only: measured on the train step it LOSES to
-    // the 4-deep one (33.2 vs 31.0 ms when used for grids of <= 256 workgroups, 32.3 ms when forced everywhere)
-    const bool deep = deep_env > 0;
-    if (deep)
-      hipLaunchKernelGGL(wgrad_tr_kernel<8>, dim3(n_wg), dim3(256), (size_t)8 * 2 * WCHUNK, s, (const unsigned short*)U->p + U->off, (long)U->s0,
-                         (const unsigned short*)V->p + V->off, (long)V->s0, (long)R, I, J, per, dW, dbias, layout, P, C_other, swap, wdebug, (int)split);
-    else
-      hipLaunchKernelGGL(wgrad_tr_kernel<4>, dim3(n_wg), dim3(256), (size_t)4 * 2 * WCHUNK, s, (const unsigned short*)U->p + U->off, (long)U->s0,
-                         (const unsigned short*)V->p + V->off, (long)V->s0, (long)R, I, J, per, dW, dbias, layout, P, C_other, swap, wdebug, (int)split);
+  if (no_tr || n_seg < 1 || n_seg > WSEG || R % WRC) return false;
+  for (int g = 0; g < n_seg; ++g)
+    if (!wgrad_tr_ok(U[g], R, I) || !wgrad_tr_ok(V[g], R, J) || U[g].s0 != U[0].s0 || V[g].s0 != V[0].s0) return false;
+  const int ti = I / WT, tj = J / WT;
+  // every workgroup ends with 128 x 128 fp32 atomics: with the main loop at memory speed the split count is a trade between
+  // parallelism and atomic traffic (64 KiB per workgroup) -- measured best near 128 workgroups for <= 4 tiles, 256 otherwise
+  static const int wg_env = getenv("TANTE_WGRAD_WGS") ? atoi(getenv("TANTE_WGRAD_WGS")) : 0;
+  const int wg_target = wg_env > 0 ? wg_env : (ti * tj <= 4 ? 128 : 256);
+  // splits PER SEGMENT (a split never straddles two segments): the workgroup target is shared by the segments
+  long split = wg_target / ((long)ti * tj * n_seg);
+  if (split < 1) split = 1;
+  const long nch = R / WRC;
+  if (split > nch / 4) split = nch / 4 > 0 ? nch / 4 : 1;
+  long per = ((nch + split - 1) / split) * WRC;
+  while (R % per) per += WRC;                       // rows_per_split must divide the segment
+  split = R / per;
+  const long total = split * n_seg;
+  if (total > 65535) return false;
+  WgSegs SG;
+  for (int g = 0; g < WSEG; ++g) {
+    SG.U[g] = (const unsigned short*)U[g < n_seg ? g : 0].p + U[g < n_seg ? g : 0].off;
+    SG.V[g] = (const unsigned short*)V[g < n_seg ? g : 0].p + V[g < n_seg ? g : 0].off;
+  }
+  SG.R_seg = R;
+  static const int wdebug = getenv("TANTE_WGRAD_DEBUG") ? atoi(getenv("TANTE_WGRAD_DEBUG")) : 0;
+  static const int deep_env = getenv("TANTE_WGRAD_DEEP") ? atoi(getenv("TANTE_WGRAD_DEEP")) : -1;
+  static bool set = false;
+  if (!set) {
+    hipFuncSetAttribute((const void*)wgrad_tr_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * WCHUNK);
+    hipFuncSetAttribute((const void*)wgrad_tr_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 2 * WCHUNK);
+    set = true;
+  }
+  const unsigned n_wg = 8u * (unsigned)((total + 7) / 8) * (unsigned)(ti * tj);
+  // the 8-deep ring (one workgroup per CU with 112 KB in flight) is kept for experiments only: measured on the train step it LOSES to
+  // the 4-deep one (33.2 vs 31.0 ms when used for grids of <= 256 workgroups, 32.3 ms when forced everywhere)
+  if (deep_env > 0)
+    hipLaunchKernelGGL(wgrad_tr_kernel<8>, dim3(n_wg), dim3(256), (size_t)8 * 2 * WCHUNK, s, SG, (long)U[0].s0, (long)V[0].s0, R * n_seg, I, J, per, dW,
+                       dbias, layout, P, C_other, swap, wdebug, (int)total);
+  else
+    hipLaunchKernelGGL(wgrad_tr_kernel<4>, dim3(n_wg), dim3(256), (size_t)4 * 2 * WCHUNK, s, SG, (long)U[0].s0, (long)V[0].s0, R * n_seg, I, J, per, dW,
+                       dbias, layout, P, C_other, swap, wdebug, (int)total);
+  return true;
+}
+
+static int wgrad_one(const TanteRowMat* U, const TanteRowMat* V, int64_t R, int I, int J, float* dW, float* dbias, int layout, int P, int C_other,
+                     int swap, int compute, hipStream_t s) {
+  if (compute == TANTE_BF16 && wgrad_tr_launch(U, V, 1, (long)R, I, J, dW, dbias, layout, P, C_other, swap, s)) {
     TANTE_CHECK_LAUNCH();
     return 0;
   }
@@ -490,5 +511,47 @@ extern "C" int tante_wgrad(const TanteRowMat* U, const TanteRowMat* V, int64_t R
     launch_wgrad<false, 64>(*U, *V, (long)R, I, J, dW, dbias, layout, P, C_other, swap, mu, mv, s);
   }
   TANTE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int tante_wgrad(const TanteRowMat* U, const TanteRowMat* V, int64_t R, int I, int J, float* dW, float* dbias, int layout, int P,
+                           int C_other, int swap, int compute, int accumulate, void* stream) {
+  if (!U || !V || !dW || R <= 0 || I <= 0 || J <= 0) TANTE_FAIL(-1, "tante_wgrad: bad argument");
+  int rc = check_rowmat(*U, "U");
+  if (rc) return rc;
+  rc = check_rowmat(*V, "V");
+  if (rc) return rc;
+  if (layout < TANTE_W_LINEAR || layout > TANTE_W_DECONV_NCHW) TANTE_FAIL(-1, "tante_wgrad: bad output layout");
+  hipStream_t s = (hipStream_t)stream;
+  if (!accumulate && hipMemsetAsync(dW, 0, (size_t)I * J * sizeof(float), s) != hipSuccess) TANTE_FAIL(-3, "tante_wgrad: memset failed");
+  if (!accumulate && dbias && hipMemsetAsync(dbias, 0, (size_t)I * sizeof(float), s) != hipSuccess) TANTE_FAIL(-3, "tante_wgrad: memset failed");
+  return wgrad_one(U, V, R, I, J, dW, dbias, layout, P, C_other, swap, compute, s);
+}
+
+extern "C" int tante_wgrad_multi(const TanteRowMat* U, const TanteRowMat* V, int n_seg, int64_t R, int I, int J, float* dW, float* dbias,
+                                 int layout, int P, int C_other, int swap, int compute, int accumulate, void* stream) {
+  if (!U || !V || !dW || n_seg <= 0 || R <= 0 || I <= 0 || J <= 0) TANTE_FAIL(-1, "tante_wgrad_multi: bad argument");
+  for (int g = 0; g < n_seg; ++g) {
+    int rc = check_rowmat(U[g], "U");
+    if (rc) return rc;
+    rc = check_rowmat(V[g], "V");
+    if (rc) return rc;
+  }
+  if (layout < TANTE_W_LINEAR || layout > TANTE_W_DECONV_NCHW) TANTE_FAIL(-1, "tante_wgrad_multi: bad output layout");
+  hipStream_t s = (hipStream_t)stream;
+  if (!accumulate && hipMemsetAsync(dW, 0, (size_t)I * J * sizeof(float), s) != hipSuccess) TANTE_FAIL(-3, "tante_wgrad_multi: memset failed");
+  if (!accumulate && dbias && hipMemsetAsync(dbias, 0, (size_t)I * sizeof(float), s) != hipSuccess) TANTE_FAIL(-3, "tante_wgrad_multi: memset failed");
+  int g = 0;
+  while (g < n_seg) {                                  // groups of up to WSEG segments share a launch when the shape allows
+    const int n = n_seg - g < WSEG ? n_seg - g : WSEG;
+    if (compute == TANTE_BF16 && n > 1 && wgrad_tr_launch(U + g, V + g, n, (long)R, I, J, dW, dbias, layout, P, C_other, swap, s)) {
+      TANTE_CHECK_LAUNCH();
+      g += n;
+      continue;
+    }
+    const int rc = wgrad_one(U + g, V + g, R, I, J, dW, dbias, layout, P, C_other, swap, compute, s);
+    if (rc) return rc;
+    ++g;
+  }
   return 0;
 }
