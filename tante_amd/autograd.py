@@ -146,12 +146,13 @@ def _flush_wgrads(slot: Optional[torch.Tensor] = None):
     pend = _DEFER["pending"]
     keys = [k for k in pend if slot is None or k[0] == slot.data_ptr()]
     for k in keys:
-        gW, gb, M, N, Kk, comp, uses = pend.pop(k)
+        gW, gb, M, N, Kk, comp, lay, uses = pend.pop(k)
         n = len(uses)
         U = (L.RowMat * n)(*[_rm_linear(dy) for dy, _ in uses])
         V = (L.RowMat * n)(*[_rm_linear(a) for _, a in uses])
-        L.check(L.lib().tante_wgrad_multi(C.byref(U), C.byref(V), n, M, N, Kk, gW.data_ptr(), gb.data_ptr(), L.W_LINEAR, 0, 0, 0, comp, 1, _s()),
-                "tante_wgrad_multi")
+        layout, P, Co, swap = lay
+        L.check(L.lib().tante_wgrad_multi(C.byref(U), C.byref(V), n, M, N, Kk, gW.data_ptr(), None if gb is None else gb.data_ptr(), layout, P, Co,
+                                          int(swap), comp, 1, _s()), "tante_wgrad_multi")
     if slot is None:
         _DEFER["armed"] = False
 
@@ -161,8 +162,9 @@ def flush_deferred_wgrads():
     _flush_wgrads(None)
 
 
-def _defer_wgrad(gW, gb, dy, a, M, N, Kk, comp) -> bool:
-    """Record one use; False when this use has to run immediately (feature off, shape / dtype outside the shared-launch kernel)."""
+def _defer_wgrad(gW, gb, dy, a, M, N, Kk, comp, lay=(L.W_LINEAR, 0, 0, False)) -> bool:
+    """Record one use (dW[N x Kk] += dy^T a over M dense bf16 rows; lay = (output layout, P, C_other, swap) as in tante_wgrad);
+    False when this use has to run immediately (feature off, shape / dtype outside the shared-launch kernel)."""
     if not DEFER_WGRAD or comp != L.BF16 or dy.dtype != torch.bfloat16 or a.dtype != torch.bfloat16 or not _tr_shape(M, N, Kk):
         return False
     if not _DEFER["armed"]:
@@ -172,11 +174,11 @@ def _defer_wgrad(gW, gb, dy, a, M, N, Kk, comp) -> bool:
             return False
         _DEFER["pending"].clear()     # leftovers of a backward pass that died half-way must not leak into this one
         _DEFER["armed"] = True
-    key = (gW.data_ptr(), M, N, Kk, comp)
+    key = (gW.data_ptr(), M, N, Kk, comp, lay)
     ent = _DEFER["pending"].get(key)
     if ent is None:
-        ent = _DEFER["pending"][key] = (gW, gb, M, N, Kk, comp, [])
-    ent[6].append((dy, a))
+        ent = _DEFER["pending"][key] = (gW, gb, M, N, Kk, comp, lay, [])
+    ent[7].append((dy, a))
     return True
 
 
@@ -655,9 +657,12 @@ class PatchEmbedFn(Function):
             gW, gb = _grad_slot(ctx.params[0]), _grad_slot(ctx.params[1])
             lay = L.W_LINEAR if nchw else L.W_CONV_NHWC
             if gW is not None and gb is not None and ctx.needs_input_grad[2]:
-                with _side_wgrad(*keep):
-                    wgrad(U, V, M, Cout, Kk, tuple(W.shape), comp, layout=lay, P=P, C_other=Cin, device=x.device, with_bias=True,
-                          into=gW, db_into=gb)
+                if len(keep) == 2 and keep[1] is not x and _defer_wgrad(gW, gb, keep[0], keep[1], M, Cout, Kk, comp, (lay, P, Cin, False)):
+                    pass                       # dense (dY, patch rows): shares a launch with the other BPTT uses
+                else:
+                    with _side_wgrad(*keep):
+                        wgrad(U, V, M, Cout, Kk, tuple(W.shape), comp, layout=lay, P=P, C_other=Cin, device=x.device, with_bias=True,
+                              into=gW, db_into=gb)
             else:
                 dW, db = wgrad(U, V, M, Cout, Kk, tuple(W.shape), comp, layout=lay, P=P, C_other=Cin, device=x.device,
                                with_bias=True)
@@ -716,8 +721,12 @@ class DeconvFn(Function):
                 a = _to_bf16(a)
             lay_w = L.W_DECONV_NCHW if nchw_out else L.W_DECONV_NHWC
             if gW is not None:
-                with _side_wgrad(a, d if cols is None else cols):
-                    wgrad(_rm_linear(a), V, M, Cin, N, tuple(W.shape), comp, layout=lay_w, P=P, C_other=Cout, swap=True, device=a.device, into=gW)
+                if cols is not None and _defer_wgrad(gW, None, a, cols, M, Cin, N, comp, (lay_w, P, Cout, True)):
+                    pass
+                else:
+                    with _side_wgrad(a, d if cols is None else cols):
+                        wgrad(_rm_linear(a), V, M, Cin, N, tuple(W.shape), comp, layout=lay_w, P=P, C_other=Cout, swap=True, device=a.device,
+                              into=gW)
             else:
                 dW = wgrad(_rm_linear(a), V, M, Cin, N, tuple(W.shape), comp, layout=lay_w, P=P, C_other=Cout, swap=True, device=a.device)
         if ctx.needs_input_grad[2]:
