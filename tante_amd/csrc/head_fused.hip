@@ -120,14 +120,16 @@ __global__ __launch_bounds__(HWAVES * 64, 2) void fused_head_kernel(const HeadAr
     const int y0 = hp * 8 + (p >> 1) * 4 + (q >> 1) * 2, x0 = wp * 8 + (p & 1) * 4 + (q & 1) * 2;
     return ((long)(4 * ns + kk) * (A.Hp * 8) + y0) * Wout + x0;
   };
-  float2 pre[4][2], nxt[4][2];
-  auto prefetch = [&](int q, float2 (&dst)[4][2]) {
+  // The epilogue works on sub-pixel PAIRS (q = 2 j, 2 j + 1 are horizontal neighbours): 4 pixels = 16 bytes per row, so every
+  // read-modify-write instruction moves 16 bytes per lane instead of 8 (half the memory instructions of the kernel's epilogue).
+  f32x4 pre[4][2], nxt[4][2];
+  auto prefetch = [&](int q, f32x4 (&dst)[4][2]) {   // q even: the pair (q, q + 1)
 #pragma unroll
     for (int ns = 0; ns < 4; ++ns)
       if (4 * ns < A.D && live && 4 * ns + kk < A.D && !(A.debug & 1)) {
         const float* lp = rmw_src + pix_of(q, ns);
-        dst[ns][0] = *(const float2*)lp;
-        dst[ns][1] = *(const float2*)(lp + Wout);
+        dst[ns][0] = *(const f32x4*)lp;
+        dst[ns][1] = *(const f32x4*)(lp + Wout);
       }
   };
 
@@ -161,10 +163,11 @@ __global__ __launch_bounds__(HWAVES * 64, 2) void fused_head_kernel(const HeadAr
 
   // ---- stages 2 + 3: sub-pixel tile q of W2 (continuing the ring), W3 resident ------------------------------------------------
   const float* bias3 = (const float*)(w3s + 64 * G::CPR3 * 16);
+  f32x4 dl[4];
   sfor<4>([&](auto qc) {
     constexpr int q = decltype(qc)::value;           // sub-pixel (kh2, kw2) = (q >> 1, q & 1)
     if constexpr (q < 3) { if (!(A.debug & 4)) hglds(w2 + (long)(q + 1) * G::T2, slots + ((q + 1) & 1) * G::SLOT, G::T2, tid); }
-    if constexpr (q < 3) prefetch(q + 1, nxt);
+    if constexpr (q == 0) prefetch(2, nxt);
     const char* wt = slots + (q & 1) * G::SLOT;
     const float* bias2 = (const float*)(wt + G::C2 * G::CPR2 * 16);
     f32x4 acc2[G::NS2];
@@ -185,27 +188,32 @@ __global__ __launch_bounds__(HWAVES * 64, 2) void fused_head_kernel(const HeadAr
 #pragma unroll
         for (int b = 0; b < G::KB3; ++b) d = hmfma(*(const u32x4*)(w3s + (ns * 16 + l15) * G::CPR3 * 16 + xo3[b]), h2[b], d);
         if ((A.debug & 1) && d[0] != 1.2345f) continue;
-        if (live && 4 * ns + kk < A.D) {
-          const long pix = pix_of(q, ns);
+        if constexpr ((q & 1) == 0) {
+          dl[ns] = d;                                  // left half of the pair: kept until its right neighbour exists
+        } else if (live && 4 * ns + kk < A.D) {
+          const long pix = pix_of(q - 1, ns);
           float* o0 = A.out + (long)img * A.out_bstride + pix;
           const float c0 = A.coef[0];
-          *(float2*)o0 = make_float2(pre[ns][0].x + c0 * d[0], pre[ns][0].y + c0 * d[1]);
-          *(float2*)(o0 + Wout) = make_float2(pre[ns][1].x + c0 * d[2], pre[ns][1].y + c0 * d[3]);
+          const f32x4 t0 = f32x4{dl[ns][0], dl[ns][1], d[0], d[1]}, t1 = f32x4{dl[ns][2], dl[ns][3], d[2], d[3]};   // rows y0, y0 + 1
+          *(f32x4*)o0 = pre[ns][0] + t0 * c0;
+          *(f32x4*)(o0 + Wout) = pre[ns][1] + t1 * c0;
 #pragma unroll
           for (int i = 1; i < 8; ++i) {   // further output frames (output_length > 1 / adaptive dt): plain read-modify-write
             if (i >= A.n_out) break;
             float* o = o0 + (long)i * frame;
             const float* bp = A.last ? A.last + (long)img * A.last_bstride + pix : o;
-            const float2 r0 = *(const float2*)bp, r1 = *(const float2*)(bp + Wout);
+            const f32x4 r0 = *(const f32x4*)bp, r1 = *(const f32x4*)(bp + Wout);
             const float c = A.coef[i];
-            *(float2*)o = make_float2(r0.x + c * d[0], r0.y + c * d[1]);
-            *(float2*)(o + Wout) = make_float2(r1.x + c * d[2], r1.y + c * d[3]);
+            *(f32x4*)o = r0 + t0 * c;
+            *(f32x4*)(o + Wout) = r1 + t1 * c;
           }
         }
       }
     }
+    if constexpr (q == 1) {
 #pragma unroll
-    for (int ns = 0; ns < 4; ++ns) { pre[ns][0] = nxt[ns][0]; pre[ns][1] = nxt[ns][1]; }
+      for (int ns = 0; ns < 4; ++ns) { pre[ns][0] = nxt[ns][0]; pre[ns][1] = nxt[ns][1]; }
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   });
