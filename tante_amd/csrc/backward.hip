@@ -36,6 +36,77 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
   if (lane == 0) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
 }
 
+// C = 256 NV: a lane owns NV groups of 4 consecutive channels; the row lives in registers (one 16-byte load per group, one pass)
+template <int NV>
+__global__ __launch_bounds__(256) void ln_fwd_vec_kernel(const float* __restrict__ x, long M, float eps, void* __restrict__ xhat, int out_dtype,
+                                                         float* __restrict__ stats) {
+  constexpr int C = 256 * NV;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= M) return;
+  f32x4 v[NV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    v[i] = *(const f32x4*)(x + row * C + (i * 64 + lane) * 4);
+    s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+  }
+  const float mean = wave_sum(s) / C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const float d = v[i][j] - mean; q += d * d; }
+  const float rstd = rsqrtf(wave_sum(q) / C + eps);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const long o = row * C + (i * 64 + lane) * 4;
+    const f32x4 h = (v[i] - mean) * rstd;
+    if (out_dtype == TANTE_BF16) {
+      u32x2 u;
+      u[0] = pack_bf16x2(h[0], h[1]);
+      u[1] = pack_bf16x2(h[2], h[3]);
+      *(u32x2*)((unsigned short*)xhat + o) = u;
+    } else {
+      *(f32x4*)((float*)xhat + o) = h;
+    }
+  }
+  if (lane == 0) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
+}
+template <int NV>
+__global__ __launch_bounds__(256) void ln_bwd_vec_kernel(const void* __restrict__ g, int g_dtype, const float* __restrict__ x,
+                                                         const float* __restrict__ stats, const float* __restrict__ dskip, long M,
+                                                         float* __restrict__ dx) {
+  constexpr int C = 256 * NV;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= M) return;
+  const float mean = stats[2 * row], rstd = stats[2 * row + 1];
+  f32x4 gv[NV], xh[NV];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const long o = row * C + (i * 64 + lane) * 4;
+    if (g_dtype == TANTE_BF16) {
+      const u32x2 u = *(const u32x2*)((const unsigned short*)g + o);
+      gv[i] = f32x4{bf16_lo(u[0]), bf16_hi(u[0]), bf16_lo(u[1]), bf16_hi(u[1])};
+    } else {
+      gv[i] = *(const f32x4*)((const float*)g + o);
+    }
+    xh[i] = (*(const f32x4*)(x + o) - mean) * rstd;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { s1 += gv[i][j]; s2 += gv[i][j] * xh[i][j]; }
+  }
+  s1 = wave_sum(s1) / C; s2 = wave_sum(s2) / C;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const long o = row * C + (i * 64 + lane) * 4;
+    f32x4 d = (gv[i] - s1 - xh[i] * s2) * rstd;
+    if (dskip) d = d + *(const f32x4*)(dskip + o);
+    *(f32x4*)(dx + o) = d;
+  }
+}
+
 // dx = dskip + rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = d xhat
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const void* __restrict__ g, int g_dtype, const float* __restrict__ x,
                                                      const float* __restrict__ stats, const float* __restrict__ dskip, long M, int C,
@@ -842,14 +913,22 @@ void launch_attn_bwd(const void* qkv, const void* dO, void* dqkv, int dtype, int
 
 extern "C" int tante_layernorm_fwd(const float* x, int64_t M, int C, float eps, void* xhat, int out_dtype, float* stats, void* stream) {
   if (!x || !xhat || !stats || M <= 0 || C <= 0) TANTE_FAIL(-1, "tante_layernorm_fwd: bad argument");
-  hipLaunchKernelGGL(ln_fwd_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, (long)M, C, eps, xhat, out_dtype, stats);
+  const dim3 grid((unsigned)((M + 3) / 4));
+  const bool vec = ((uintptr_t)x % 16) == 0 && ((uintptr_t)xhat % 16) == 0;
+  if (vec && C == 256) hipLaunchKernelGGL(ln_fwd_vec_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, x, (long)M, eps, xhat, out_dtype, stats);
+  else if (vec && C == 512) hipLaunchKernelGGL(ln_fwd_vec_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, x, (long)M, eps, xhat, out_dtype, stats);
+  else hipLaunchKernelGGL(ln_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, (long)M, C, eps, xhat, out_dtype, stats);
   TANTE_CHECK_LAUNCH();
   return 0;
 }
 extern "C" int tante_layernorm_bwd(const void* dxhat, int g_dtype, const float* x, const float* stats, const float* dskip, int64_t M, int C,
                                    float* dx, void* stream) {
   if (!dxhat || !x || !stats || !dx || M <= 0 || C <= 0) TANTE_FAIL(-1, "tante_layernorm_bwd: bad argument");
-  hipLaunchKernelGGL(ln_bwd_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, (hipStream_t)stream, dxhat, g_dtype, x, stats, dskip, (long)M, C, dx);
+  const dim3 grid((unsigned)((M + 3) / 4));
+  const bool vec = (((uintptr_t)x | (uintptr_t)dxhat | (uintptr_t)dx | (uintptr_t)dskip) % 16) == 0;
+  if (vec && C == 256) hipLaunchKernelGGL(ln_bwd_vec_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, dxhat, g_dtype, x, stats, dskip, (long)M, dx);
+  else if (vec && C == 512) hipLaunchKernelGGL(ln_bwd_vec_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, dxhat, g_dtype, x, stats, dskip, (long)M, dx);
+  else hipLaunchKernelGGL(ln_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, dxhat, g_dtype, x, stats, dskip, (long)M, C, dx);
   TANTE_CHECK_LAUNCH();
   return 0;
 }
