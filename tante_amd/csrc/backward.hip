@@ -18,6 +18,26 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// four consecutive elements at once (16 bytes of fp32, 8 of bf16): the streaming elementwise kernels of the train path move
+// 25-50 MB per launch and were issuing one 2- or 4-byte access per thread
+__device__ __forceinline__ f32x4 ld4(const void* p, int dtype, long i) {
+  if (dtype == TANTE_BF16) {
+    const u32x2 u = *(const u32x2*)((const unsigned short*)p + i);
+    return f32x4{bf16_lo(u[0]), bf16_hi(u[0]), bf16_lo(u[1]), bf16_hi(u[1])};
+  }
+  return *(const f32x4*)((const float*)p + i);
+}
+__device__ __forceinline__ void st4(void* p, int dtype, long i, const f32x4& v) {
+  if (dtype == TANTE_BF16) {
+    u32x2 u;
+    u[0] = pack_bf16x2(v[0], v[1]);
+    u[1] = pack_bf16x2(v[2], v[3]);
+    *(u32x2*)((unsigned short*)p + i) = u;
+  } else {
+    *(f32x4*)((float*)p + i) = v;
+  }
+}
+
 // ---- LayerNorm without affine (gamma / beta are folded into the consumer's weight by the host) -------------------
 // one wave per row; stats[row] = {mean, rstd}
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, long M, int C, float eps, void* __restrict__ xhat,
@@ -133,6 +153,24 @@ __device__ __forceinline__ float act_f(float x, int act) { return apply_act(x, a
 __global__ void act_fwd_kernel(const void* __restrict__ pre, int in_dtype, void* __restrict__ post, int out_dtype, long n, int act) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) stx(post, out_dtype, i, act_f(ldx(pre, in_dtype, i), act));
+}
+__global__ void act_fwd_vec_kernel(const void* __restrict__ pre, int in_dtype, void* __restrict__ post, int out_dtype, long n4, int act) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  f32x4 v = ld4(pre, in_dtype, 4 * i);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) v[j] = act_f(v[j], act);
+  st4(post, out_dtype, 4 * i, v);
+}
+__global__ void act_bwd_vec_kernel(const void* __restrict__ dpost, int d_dtype, const void* __restrict__ pre, int pre_dtype,
+                                   void* __restrict__ dpre, int out_dtype, long n4, int act) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  f32x4 g = ld4(dpost, d_dtype, 4 * i);
+  const f32x4 x = ld4(pre, pre_dtype, 4 * i);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) g[j] *= act_df(x[j], act);
+  st4(dpre, out_dtype, 4 * i, g);
 }
 __global__ void act_bwd_kernel(const void* __restrict__ dpost, int d_dtype, const void* __restrict__ pre, int pre_dtype,
                                void* __restrict__ dpre, int out_dtype, long n, int act) {
@@ -882,6 +920,25 @@ __global__ void dropout_bwd_kernel(const float* __restrict__ dout, float p, unsi
   stx(dy, y_dtype, i, dropout_keep(seed, (unsigned long long)i, p) ? dout[i] / (1.0f - p) : 0.0f);
 }
 
+__global__ void dropout_add_vec_kernel(const void* __restrict__ y, int y_dtype, const float* __restrict__ res, float p, unsigned long long seed,
+                                       long n4, float* __restrict__ out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const f32x4 v = ld4(y, y_dtype, 4 * i);
+  f32x4 r = *(const f32x4*)(res + 4 * i);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) r[j] += dropout_keep(seed, (unsigned long long)(4 * i + j), p) ? v[j] / (1.0f - p) : 0.0f;   // the scalar kernel's expression
+  *(f32x4*)(out + 4 * i) = r;
+}
+__global__ void dropout_bwd_vec_kernel(const float* __restrict__ dout, float p, unsigned long long seed, long n4, void* __restrict__ dy, int y_dtype) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  f32x4 g = *(const f32x4*)(dout + 4 * i);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) g[j] = dropout_keep(seed, (unsigned long long)(4 * i + j), p) ? g[j] / (1.0f - p) : 0.0f;
+  st4(dy, y_dtype, 4 * i, g);
+}
+
 template <int N>
 void launch_axis_bwd(const float* x, const float* dy, long outer, int n, long inner, const float* w1, const float* b1, const float* w2,
                      float* dx, float* h, float* dpre, hipStream_t s) {
@@ -934,15 +991,23 @@ extern "C" int tante_layernorm_bwd(const void* dxhat, int g_dtype, const float* 
 }
 extern "C" int tante_act_fwd(const void* pre, int in_dtype, void* post, int out_dtype, int64_t n, int act, void* stream) {
   if (!pre || !post || n <= 0) TANTE_FAIL(-1, "tante_act_fwd: bad argument");
-  hipLaunchKernelGGL(act_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pre, in_dtype, post, out_dtype, (long)n, act);
+  if (n % 4 == 0 && (((uintptr_t)pre | (uintptr_t)post) % 16) == 0)
+    hipLaunchKernelGGL(act_fwd_vec_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pre, in_dtype, post, out_dtype,
+                       (long)(n / 4), act);
+  else
+    hipLaunchKernelGGL(act_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pre, in_dtype, post, out_dtype, (long)n, act);
   TANTE_CHECK_LAUNCH();
   return 0;
 }
 extern "C" int tante_act_bwd(const void* dpost, int d_dtype, const void* pre, int pre_dtype, void* dpre, int out_dtype, int64_t n, int act,
                              void* stream) {
   if (!dpost || !pre || !dpre || n <= 0) TANTE_FAIL(-1, "tante_act_bwd: bad argument");
-  hipLaunchKernelGGL(act_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dpost, d_dtype, pre, pre_dtype, dpre,
-                     out_dtype, (long)n, act);
+  if (n % 4 == 0 && (((uintptr_t)dpost | (uintptr_t)pre | (uintptr_t)dpre) % 16) == 0)
+    hipLaunchKernelGGL(act_bwd_vec_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dpost, d_dtype, pre, pre_dtype,
+                       dpre, out_dtype, (long)(n / 4), act);
+  else
+    hipLaunchKernelGGL(act_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dpost, d_dtype, pre, pre_dtype, dpre,
+                       out_dtype, (long)n, act);
   TANTE_CHECK_LAUNCH();
   return 0;
 }
@@ -1099,15 +1164,23 @@ extern "C" int tante_axis_mlp_bwd(const float* x, const float* dy, int64_t outer
 
 extern "C" int tante_dropout_add(const void* y, int y_dtype, const float* res, float p, uint64_t seed, int64_t n, float* out, void* stream) {
   if (!y || !res || !out || n <= 0 || p < 0.0f || p >= 1.0f) TANTE_FAIL(-1, "tante_dropout_add: bad argument");
-  hipLaunchKernelGGL(dropout_add_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, y, y_dtype, res, p,
-                     (unsigned long long)seed, (long)n, out);
+  if (n % 4 == 0 && (((uintptr_t)y | (uintptr_t)res | (uintptr_t)out) % 16) == 0)
+    hipLaunchKernelGGL(dropout_add_vec_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, y, y_dtype, res, p,
+                       (unsigned long long)seed, (long)(n / 4), out);
+  else
+    hipLaunchKernelGGL(dropout_add_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, y, y_dtype, res, p,
+                       (unsigned long long)seed, (long)n, out);
   TANTE_CHECK_LAUNCH();
   return 0;
 }
 extern "C" int tante_dropout_bwd(const float* dout, float p, uint64_t seed, int64_t n, void* dy, int y_dtype, void* stream) {
   if (!dout || !dy || n <= 0 || p < 0.0f || p >= 1.0f) TANTE_FAIL(-1, "tante_dropout_bwd: bad argument");
-  hipLaunchKernelGGL(dropout_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dout, p, (unsigned long long)seed,
-                     (long)n, dy, y_dtype);
+  if (n % 4 == 0 && (((uintptr_t)dout | (uintptr_t)dy) % 16) == 0)
+    hipLaunchKernelGGL(dropout_bwd_vec_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dout, p,
+                       (unsigned long long)seed, (long)(n / 4), dy, y_dtype);
+  else
+    hipLaunchKernelGGL(dropout_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dout, p, (unsigned long long)seed,
+                       (long)n, dy, y_dtype);
   TANTE_CHECK_LAUNCH();
   return 0;
 }
