@@ -543,8 +543,17 @@ __device__ __forceinline__ void epilogue4_train(const TanteGemm& g, const EpiRow
       const f32x4 f = *(const f32x4*)((const float*)g.dact + row * g.N + n0);
       pre[0] = f[0]; pre[1] = f[1]; pre[2] = f[2]; pre[3] = f[3];
     }
+    if (g.dact_kind == TANTE_ACT_GELU_TANH) {   // bf16 path: tanh through one exp and one reciprocal (libm's tanhf is ~40 instructions)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) v[j] *= act_df(pre[j], g.dact_kind);
+      for (int j = 0; j < 4; ++j) {
+        const float x = pre[j], c = 0.79788456080286535588f, u = c * (x + 0.044715f * x * x * x);
+        const float t = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * u));
+        v[j] *= 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * c * (1.0f + 3.0f * 0.044715f * x * x);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] *= act_df(pre[j], g.dact_kind);
+    }
   }
   store4(g.out, g.out_dtype, e.o_base + n0, v);
 }
