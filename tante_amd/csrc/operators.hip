@@ -165,6 +165,45 @@ __global__ __launch_bounds__(256) void ln_affine_kernel(const void* __restrict__
     stx(y, y_dtype, row * C + c, (ldx(x, x_dtype, row * C + c) - mean) * rstd * (gamma ? gamma[c] : 1.0f) + (beta ? beta[c] : 0.0f));
 }
 
+// fp32 rows of C = 256 NV channels: the row stays in registers (one 16-byte load per lane and 4-channel group)
+template <int NV>
+__global__ __launch_bounds__(256) void ln_affine_vec_kernel(const float* __restrict__ x, long M, float eps, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, void* __restrict__ y, int y_dtype) {
+  constexpr int C = 256 * NV;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= M) return;
+  f32x4 v[NV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    v[i] = *(const f32x4*)(x + row * C + (i * 64 + lane) * 4);
+    s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+  }
+  const float mean = wave_sum(s) / C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const float d = v[i][j] - mean; q += d * d; }
+  const float rstd = rsqrtf(wave_sum(q) / C + eps);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    f32x4 h = (v[i] - mean) * rstd;
+    if (gamma) h = h * *(const f32x4*)(gamma + c);
+    if (beta) h = h + *(const f32x4*)(beta + c);
+    if (y_dtype == TANTE_BF16) {
+      u32x2 u;
+      u[0] = pack_bf16x2(h[0], h[1]);
+      u[1] = pack_bf16x2(h[2], h[3]);
+      *(u32x2*)((unsigned short*)y + row * C + c) = u;
+    } else {
+      *(f32x4*)((float*)y + row * C + c) = h;
+    }
+  }
+}
+
 // ---- spectral layer: low-mode complex contraction (writes the WHOLE spectrum: zeros outside the two bands) --------------------
 // Y[b, o, i, j] = scale * sum_c X[b, c, i, j] * Wt[c, o, wi, j]; top band i < m1 (wi = i), bottom band i >= H - m1
 // (wi = i - (H - m1)); the bottom band wins where they overlap (it is written second at enc_dec_fno.py:207-210).
@@ -982,8 +1021,14 @@ extern "C" int tante_resize_bilinear(const void* in, int in_dtype, int64_t n_img
 extern "C" int tante_layernorm_affine(const void* x, int x_dtype, int64_t M, int C, float eps, const float* gamma, const float* beta, void* y,
                                       int y_dtype, void* stream) {
   if (!x || !y || M <= 0 || C <= 0) TANTE_FAIL(-1, "tante_layernorm_affine: bad argument");
-  hipLaunchKernelGGL(ln_affine_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, x_dtype, (long)M, C, eps, gamma, beta,
-                     y, y_dtype);
+  const dim3 grid((unsigned)((M + 3) / 4));
+  const bool vec = x_dtype == TANTE_F32 && (((uintptr_t)x | (uintptr_t)y | (uintptr_t)gamma | (uintptr_t)beta) % 16) == 0;
+  if (vec && C == 256)
+    hipLaunchKernelGGL(ln_affine_vec_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, (long)M, eps, gamma, beta, y, y_dtype);
+  else if (vec && C == 512)
+    hipLaunchKernelGGL(ln_affine_vec_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, (long)M, eps, gamma, beta, y, y_dtype);
+  else
+    hipLaunchKernelGGL(ln_affine_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, x_dtype, (long)M, C, eps, gamma, beta, y, y_dtype);
   TANTE_CHECK_LAUNCH();
   return 0;
 }
