@@ -55,6 +55,9 @@ template <int N, int D, class AddrF, class UseF>
 __device__ __forceinline__ void mfma_stream(AddrF&& addr, UseF&& use) {
   static_assert(D <= 15 && D % 2 == 0, "lgkmcnt is a 4-bit field; fragments are consumed in pairs");
   u32x4 ring[D];
+#ifdef TANTE_MFMA_SETPRIO
+  __builtin_amdgcn_s_setprio(1);
+#endif
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   static_for<(D < N ? D : N)>([&](auto ic) { ring[decltype(ic)::value] = lds_read128(addr(ic)); });
   // fragments are consumed in pairs behind ONE counted wait: the kernels that use this are bound by instruction issue, and an
@@ -73,6 +76,9 @@ __device__ __forceinline__ void mfma_stream(AddrF&& addr, UseF&& use) {
     lds_wait<0>(c0);
     use(std::integral_constant<int, N - 1>{}, c0);
   }
+#ifdef TANTE_MFMA_SETPRIO
+  __builtin_amdgcn_s_setprio(0);
+#endif
 }
 
 __device__ __forceinline__ u32x4 pack8(const f32x4& a, const f32x4& b) {
