@@ -376,7 +376,10 @@ __global__ __launch_bounds__(512, 2) void fused_block16_kernel(float* __restrict
   constexpr int SLOT = (TILEH > TILE2 ? TILEH : TILE2);
   constexpr int NT = NH + TO + T1 + TO;
   constexpr int MAXB = (HB > CB ? HB : CB);
-  constexpr int RING = 4;  // weight fragments in flight per wave (mfma_stream); 8 measured no faster
+#ifndef TANTE_RING
+#define TANTE_RING 4
+#endif
+  constexpr int RING = TANTE_RING;  // weight fragments in flight per wave (mfma_stream); 8 measured no faster
   extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 weight slots, then 2 mailbox sets of 8 x 2 KiB
   char* mbox = smem + 2 * SLOT;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kk = lane >> 4, l15 = lane & 15;
