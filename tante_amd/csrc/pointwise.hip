@@ -162,21 +162,42 @@ __device__ __forceinline__ void axis_wst(typename AxisStage<BF16>::T* ws, int i,
   else ws[i] = v;
 }
 
-// build the fragments from the weight staged in LDS (ws: n x n, row-major)
+// row stride of the staged n x n weight (elements): bf16 rows are padded by 8 so that the 16-byte fragment reads of 8 consecutive rows
+// land in 8 different bank groups (a 64-byte row stride made them 4-way conflicted: PMC showed 64 % of this kernel's LDS cycles as conflicts)
+template <bool BF16>
+__host__ __device__ __forceinline__ int axis_wstride(int n) { return BF16 ? n + 8 : n; }
+
+// build the fragments from the weight staged in LDS (ws: n rows of axis_wstride(n), row-major)
 template <bool BF16, int MT, bool KPERM>
 __device__ __forceinline__ void load_axis_weight(const typename AxisStage<BF16>::T* ws, int n, int l15, int kk, AxisW<BF16, MT>& aw) {
+  const int NS = axis_wstride<BF16>(n);
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int row = mt * 16 + l15;
 #pragma unroll
     for (int kb = 0; kb < AxisW<BF16, MT>::KB; ++kb) {
+      if constexpr (BF16) {
+        if (n % 8 == 0) {     // whole 16-byte (8-byte when k-permuted) pieces of a row: vector reads
+          u32x4 f = u32x4{0u, 0u, 0u, 0u};
+          if constexpr (!KPERM) {
+            const int k0 = kb * 32 + 8 * kk;
+            if (row < n && k0 + 8 <= n) f = *(const u32x4*)(ws + row * NS + k0);
+          } else {
+            const int ka = kb * 32 + 4 * kk, kb2 = kb * 32 + 16 + 4 * kk;
+            if (row < n && ka + 4 <= n) { const u32x2 a = *(const u32x2*)(ws + row * NS + ka); f[0] = a[0]; f[1] = a[1]; }
+            if (row < n && kb2 + 4 <= n) { const u32x2 b = *(const u32x2*)(ws + row * NS + kb2); f[2] = b[0]; f[3] = b[1]; }
+          }
+          aw.f[mt][kb] = f;
+          continue;
+        }
+      }
       float v[8];
 #pragma unroll
       for (int e = 0; e < (BF16 ? 8 : 4); ++e) {
         int k;
         if constexpr (BF16) k = KPERM ? (kb * 32 + (e < 4 ? 4 * kk + e : 16 + 4 * kk + (e - 4))) : (kb * 32 + 8 * kk + e);
         else k = KPERM ? (kb * 16 + 4 * kk + e) : (kb * 16 + 4 * e + kk);
-        v[e] = (row < n && k < n) ? axis_wld<BF16>(ws, row * n + k) : 0.0f;
+        v[e] = (row < n && k < n) ? axis_wld<BF16>(ws, row * NS + k) : 0.0f;
       }
       if constexpr (BF16) {
         aw.f[mt][kb][0] = pack_bf16x2(v[0], v[1]); aw.f[mt][kb][1] = pack_bf16x2(v[2], v[3]);
@@ -271,12 +292,17 @@ __device__ __forceinline__ void axis_phase(float* plane, float* wst_raw, const f
   // stage this axis' weights in LDS: [b1 | b2] fp32, then w1 | w2 in the staging type
   float* bst = wst_raw;
   ST* wst = (ST*)(wst_raw + 2 * n);
-  for (int i = tid; i < n * n; i += AXT) { axis_wst<BF16>(wst, i, gw1[i]); axis_wst<BF16>(wst, n * n + i, gw2[i]); }
+  const int NS = axis_wstride<BF16>(n);
+  for (int i = tid; i < n * n; i += AXT) {
+    const int r = i / n, c = i - r * n;
+    axis_wst<BF16>(wst, r * NS + c, gw1[i]);
+    axis_wst<BF16>(wst, n * NS + r * NS + c, gw2[i]);
+  }
   if (tid < n) { bst[tid] = gb1[tid]; bst[n + tid] = gb2[tid]; }
   __syncthreads();
   AxisW<BF16, MT> w1, w2;
   load_axis_weight<BF16, MT, false>(wst, n, l15, kk, w1);
-  load_axis_weight<BF16, MT, true>(wst + n * n, n, l15, kk, w2);
+  load_axis_weight<BF16, MT, true>(wst + n * NS, n, l15, kk, w2);
   float b1[MT][4], b2[MT][4];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
@@ -339,7 +365,7 @@ __global__ __launch_bounds__(AXT) void axis_hw_kernel(float* __restrict__ x, Axi
   const int c0 = (blockIdx.x % ctiles) * 16;
   float* gx = x + bt * (long)nH * nW * C + c0;
   const int rs = axis_row_stride(nW);
-  float* wst = plane + nH * rs;
+  float* wst = plane + ((nH * rs + 3) & ~3);     // 16-byte aligned: the weight fragments are read as 16-byte pieces
   // ---- load the plane: 4 threads x 16 B per token ---------------------------------------------------------
   const float* lsrc = gx;
   const float *fa = nullptr, *fb = nullptr;
@@ -543,8 +569,8 @@ static int axis_hw_impl(float* x, const AxisSrc& S, int64_t BT, int nH, int nW, 
   if (!x || !wh1 || !bh1 || !wh2 || !bh2 || !ww1 || !bw1 || !ww2 || !bw2) TANTE_FAIL(-1, "tante_axis_hw: null pointer");
   if (BT <= 0 || nH <= 0 || nW <= 0 || C <= 0) TANTE_FAIL(-1, "tante_axis_hw: bad shape");
   const int nmax = nH > nW ? nH : nW;
-  const size_t lds = (size_t)nH * axis_row_stride(nW) * sizeof(float) + 2 * (size_t)nmax * sizeof(float) +
-                     2 * (size_t)nmax * nmax * (compute == TANTE_BF16 ? 2 : 4);
+  const size_t lds = (((size_t)nH * axis_row_stride(nW) + 3) & ~(size_t)3) * sizeof(float) + 2 * (size_t)nmax * sizeof(float) +
+                     2 * (size_t)nmax * (compute == TANTE_BF16 ? (nmax + 8) * 2 : nmax * 4);
   if (nmax > 64 || C % 16 || lds > 160 * 1024 || ((uintptr_t)x % 16))
     TANTE_FAIL(-2, "tante_axis_hw: needs nH, nW <= 64, C %% 16 == 0 and the plane to fit LDS (use tante_axis_mlp)");
   hipStream_t s = (hipStream_t)stream;

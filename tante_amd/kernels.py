@@ -220,7 +220,7 @@ def axis_hw_supported(nH: int, nW: int, C_: int) -> bool:
     rs = nW * 18
     while rs % 8 != 2:       # axis_row_stride() of pointwise.hip
         rs += 1
-    return n <= 64 and C_ % 16 == 0 and nH * rs * 4 + 8 * n + 8 * n * n <= 160 * 1024
+    return n <= 64 and C_ % 16 == 0 and nH * rs * 4 + 8 * n + 8 * n * n + 32 * n <= 160 * 1024
 
 
 def axis_hw(x: torch.Tensor, BT: int, nH: int, nW: int, C_: int, vp, hp, compute: int):
