@@ -241,7 +241,8 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const unsigned short
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kk = lane >> 4, l15 = lane & 15, qq = l15 >> 2, pp = l15 & 3;
   const int h = blockIdx.y * 4 + wave;
   if (h >= n_head) return;                       // no barriers: each wave owns its slice of LDS
-  unsigned short* Vs = (unsigned short*)(sm_raw + wave * ROWS * 64);
+  constexpr int RS = 48;   // 96-byte LDS rows (64 of data): keeps the transposing reads of the four 16-lane groups off each other's banks
+  unsigned short* Vs = (unsigned short*)(sm_raw + wave * ROWS * RS * 2);
   const int L = sq.L, unit = blockIdx.x;
   const bool big = L >= 16;
   const unsigned rcpL = (65536u + L - 1) / L;    // floor(slot / L) for slot < 16
@@ -269,9 +270,9 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const unsigned short
       kf[t] = *(const u32x4*)(r + C);
       vf = *(const u32x4*)(r + 2 * C);
     }
-    *(u32x4*)(Vs + (t * 16 + l15) * 32 + kk * 8) = vf;   // row-major image (64-byte rows) for the transposing reads
+    *(u32x4*)(Vs + (t * 16 + l15) * RS + kk * 8) = vf;   // row-major image (64-byte rows) for the transposing reads
   }
-  const unsigned troff = lds_addr((const char*)Vs) + (4 * kk + qq) * 64 + pp * 8;
+  const unsigned troff = lds_addr((const char*)Vs) + (4 * kk + qq) * (RS * 2) + pp * 8;
   const float c2 = scale * 1.4426950408889634f;
   const float ksc = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
   const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -327,7 +328,7 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const unsigned short
       const u32x4 pf = pack8(st[j0], (2 * jp + 1 < NT) ? st[j1] : zero4);   // un-normalised: 1 / l scales the 8 outputs instead
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt) {
-        u32x2 lo = afm_tr(troff + dt * 32 + j0 * 1024), hi = afm_tr(troff + dt * 32 + j1 * 1024);
+        u32x2 lo = afm_tr(troff + dt * 32 + j0 * (16 * RS * 2)), hi = afm_tr(troff + dt * 32 + j1 * (16 * RS * 2));
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo), "+v"(hi) : : "memory");
         oa[dt] = mfma_bf16(u32x4{lo[0], lo[1], hi[0], hi[1]}, pf, oa[dt]);
       }
@@ -347,7 +348,7 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const unsigned short
 template <int NT>
 void launch_attn_fwd_mfma(const void* qkv, void* o, int C, int n_head, const TanteSeq& sq, int SPT, int units, int causal, float p_drop,
                           unsigned long long seed, hipStream_t s) {
-  hipLaunchKernelGGL((attn_fwd_mfma_kernel<NT>), dim3(units, (n_head + 3) / 4), dim3(256), 4 * (size_t)NT * 16 * 64, s, (const unsigned short*)qkv,
+  hipLaunchKernelGGL((attn_fwd_mfma_kernel<NT>), dim3(units, (n_head + 3) / 4), dim3(256), 4 * (size_t)NT * 16 * 96, s, (const unsigned short*)qkv,
                      (unsigned short*)o, C, n_head, sq, SPT, causal, 1.0f / sqrtf(32.0f), p_drop, seed);
 }
 bool try_attn_fwd_mfma(const void* qkv, void* o, int dtype, int C, int n_head, const TanteSeq& sq, int causal, float p_drop, unsigned long long seed,

@@ -515,16 +515,19 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const unsigned short
                                                             unsigned short* __restrict__ dqkv, int C, int n_head, TanteSeq sq, int SPT, int causal,
                                                             float scale, float p_drop, unsigned long long seed) {
   constexpr int ROWS = NT * 16, NP = (NT + 1) / 2;
-  constexpr int WAVE_LDS = 3 * ROWS * 64 + 3 * ROWS * 4;
+  // LDS rows are 96 bytes apart (64 of data): with 64-byte rows the transposing reads of the four 16-lane groups hit the same banks
+  // (rows r and r + 4 are 256 bytes apart): PMC showed half of this kernel's LDS cycles as bank conflicts
+  constexpr int RS = 48;   // row stride in bf16 elements
+  constexpr int WAVE_LDS = 3 * ROWS * RS * 2 + 3 * ROWS * 4;
   extern __shared__ __attribute__((aligned(16))) char sm_raw[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kk = lane >> 4, l15 = lane & 15, qq = l15 >> 2, pp = l15 & 3;
   const int h = blockIdx.y * 4 + wave;
   if (h >= n_head) return;                       // waves never meet at a barrier: each owns its slice of LDS
   char* base = sm_raw + wave * WAVE_LDS;
   unsigned short* Qs = (unsigned short*)base;
-  unsigned short* Ks = Qs + ROWS * 32;
-  unsigned short* Gs = Ks + ROWS * 32;
-  float* St = (float*)(Gs + ROWS * 32);          // m [ROWS], 1/l [ROWS], delta [ROWS]
+  unsigned short* Ks = Qs + ROWS * RS;
+  unsigned short* Gs = Ks + ROWS * RS;
+  float* St = (float*)(Gs + ROWS * RS);          // m [ROWS], 1/l [ROWS], delta [ROWS]
   const int L = sq.L, unit = blockIdx.x;
   const bool big = L >= 16;
   const unsigned rcpL = (65536u + L - 1) / L;    // floor(slot / L) for slot < 16
@@ -555,15 +558,15 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const unsigned short
   }
 #pragma unroll
   for (int t = 0; t < NT; ++t) {   // row-major images (64-byte rows) for the transposing reads
-    *(u32x4*)(Qs + (t * 16 + l15) * 32 + kk * 8) = qf[t];
-    *(u32x4*)(Ks + (t * 16 + l15) * 32 + kk * 8) = kf[t];
-    *(u32x4*)(Gs + (t * 16 + l15) * 32 + kk * 8) = gf[t];
+    *(u32x4*)(Qs + (t * 16 + l15) * RS + kk * 8) = qf[t];
+    *(u32x4*)(Ks + (t * 16 + l15) * RS + kk * 8) = kf[t];
+    *(u32x4*)(Gs + (t * 16 + l15) * RS + kk * 8) = gf[t];
   }
   // transposed fragment of X (row tile rt, 16-dim tile dt): lane 4 qq + pp of a 16-lane group supplies row 4 kk + qq, columns 4 pp .. 4 pp + 3
-  const unsigned troff = (4 * kk + qq) * 64 + pp * 8;
+  const unsigned troff = (4 * kk + qq) * (RS * 2) + pp * 8;
   auto tfrag = [&](const unsigned short* X, int rt0, int rt1, int dt) {
     const unsigned a = lds_addr((const char*)X) + troff + dt * 32;
-    u32x2 lo = abm_tr(a + rt0 * 1024), hi = abm_tr(a + rt1 * 1024);
+    u32x2 lo = abm_tr(a + rt0 * (16 * RS * 2)), hi = abm_tr(a + rt1 * (16 * RS * 2));
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo), "+v"(hi) : : "memory");
     return u32x4{lo[0], lo[1], hi[0], hi[1]};
   };
@@ -711,7 +714,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const unsigned short
 template <int NT>
 void launch_attn_bwd_mfma(const void* qkv, const void* dO, void* dqkv, int C, int n_head, const TanteSeq& sq, int SPT, int units, int causal,
                           float p_drop, unsigned long long seed, hipStream_t s) {
-  const size_t lds = 4 * (size_t)(3 * NT * 16 * 64 + 3 * NT * 16 * 4);
+  const size_t lds = 4 * (size_t)(3 * NT * 16 * 96 + 3 * NT * 16 * 4);
   hipLaunchKernelGGL((attn_bwd_mfma_kernel<NT>), dim3(units, (n_head + 3) / 4), dim3(256), lds, s, (const unsigned short*)qkv,
                      (const unsigned short*)dO, (unsigned short*)dqkv, C, n_head, sq, SPT, causal, 1.0f / sqrtf(32.0f), p_drop, seed);
 }
