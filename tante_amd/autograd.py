@@ -242,6 +242,7 @@ class FoldFn(Function):
         gW, gb = acc[:N * Kk].view(N, Kk), acc[N * Kk:]
         ctx.save_for_backward(W, gamma, beta)
         ctx.acc = (gW, gb)
+        ctx.acc_buf = acc
         ctx.params = (W, b, gamma, beta)
         ctx.set_materialize_grads(False)
         ctx.mark_non_differentiable(gW, gb)
@@ -270,6 +271,7 @@ class FoldFn(Function):
         GW, Gb = GW.contiguous(), Gb.contiguous()
         L.check(L.lib().tante_fold_bwd(GW.data_ptr(), Gb.data_ptr(), W.data_ptr(), gamma.data_ptr(), beta.data_ptr(), N, Kk, dW.data_ptr(),
                                        None if db is None else db.data_ptr(), dg.data_ptr(), dbt.data_ptr(), _s()), "tante_fold_bwd")
+        ctx.acc_buf.zero_()       # consumed: a second backward through a retained graph starts from empty accumulators
         return (None, None, None, None) if direct else (dW, db, dg, dbt)
 
 
