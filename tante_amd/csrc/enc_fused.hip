@@ -42,7 +42,10 @@ struct EncArgs {
   int n_img, Hp, Wp, T;
 };
 
-template <int CB>
+// SPLIT > 1 (small inputs, e.g. ONE frame per rollout call = 64 token groups for 256 CUs): the per-wave chain stage 2 -> 8 stage-3
+// tiles is what the launch waits for, so SPLIT workgroups share a token group -- each repeats stage 2 (half of the work) and takes
+// NT3 / SPLIT of the stage-3 tiles: per-wave work 2 -> 1 + 1 / SPLIT at SPLIT x the (idle) CUs.
+template <int CB, int SPLIT>
 __global__ __launch_bounds__(512, 2) void enc23_kernel(const EncArgs A) {
   using G = EncGeom<CB>;
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [header][W2][slot 0][slot 1]
@@ -50,7 +53,9 @@ __global__ __launch_bounds__(512, 2) void enc23_kernel(const EncArgs A) {
   char* slots = smem + EHDR + G::W2B;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kk = lane >> 4, l15 = lane & 15;
   eglds(A.w, smem, EHDR + G::W2B, tid);
-  const char* w3 = A.w + EHDR + G::W2B;
+  constexpr int NT3L = G::NT3 / SPLIT;                       // stage-3 tiles of this workgroup: t_first .. t_first + NT3L - 1
+  const int t_first = (SPLIT > 1) ? (int)blockIdx.y * NT3L : 0;
+  const char* w3 = A.w + EHDR + G::W2B + (long)t_first * G::T3B;
 
   const int HW = A.Hp * A.Wp;
   const long rows = (long)A.n_img * HW;
@@ -120,11 +125,12 @@ __global__ __launch_bounds__(512, 2) void enc23_kernel(const EncArgs A) {
   for (int b = 0; b < G::KB3; ++b) bt3[b] = lds_addr(slots + row3 + (swz_chunk(l15, b * 4 + kk, G::CPR3) << 4));
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  static_for<G::NT3>([&](auto tc) {
-    constexpr int t = decltype(tc)::value;
+  static_for<NT3L>([&](auto tc) {
+    constexpr int t = decltype(tc)::value;             // local tile index (ring slot, prefetch distance); tg = its global index
+    const int tg = t_first + t;
     f32x4 acc[2];
 #pragma unroll
-    for (int ns = 0; ns < 2; ++ns) acc[ns] = *(const f32x4*)(bias3 + t * 32 + ns * 16 + kk * 4);
+    for (int ns = 0; ns < 2; ++ns) acc[ns] = *(const f32x4*)(bias3 + tg * 32 + ns * 16 + kk * 4);
     mfma_stream<2 * G::KB3, 4>(
         [&](auto ic) { constexpr int i = decltype(ic)::value; return LdsAddr<(t & 1) * G::T3B + (i % 2) * 16 * G::CPR3 * 16>{bt3[i / 2]}; },
         [&](auto ic, const u32x4& wf) {
@@ -132,18 +138,18 @@ __global__ __launch_bounds__(512, 2) void enc23_kernel(const EncArgs A) {
           acc[ns] = mfma_bf16(wf, h2[kb], acc[ns]);
         });
     __syncthreads();                                   // every wave is done with slot t & 1
-    if constexpr (t + 2 < G::NT3) eglds(w3 + (long)(t + 2) * G::T3B, slots + (t & 1) * G::T3B, G::T3B, tid);
-    if constexpr (t + 1 < G::NT3) {
+    if constexpr (t + 2 < NT3L) eglds(w3 + (long)(t + 2) * G::T3B, slots + (t & 1) * G::T3B, G::T3B, tid);
+    if constexpr (t + 1 < NT3L) {
       // tile t + 1 was issued one tile ago: all but the pieces just issued for t + 2 must have landed.  (vmcnt counts loads, stores
       // and LDS-DMA together in issue order; the epilogue below comes AFTER this wait so its stores never sit in front of it.)
-      if constexpr (t + 2 < G::NT3) wait_vmcnt<G::T3B / 8192>();
+      if constexpr (t + 2 < NT3L) wait_vmcnt<G::T3B / 8192>();
       else wait_vmcnt<0>();
       __syncthreads();
     }
     if (live) {
 #pragma unroll
       for (int ns = 0; ns < 2; ++ns) {
-        const int n0 = t * 32 + ns * 16 + kk * 4;
+        const int n0 = tg * 32 + ns * 16 + kk * 4;
         const f32x4 a = *(const f32x4*)(fa + n0), b = *(const f32x4*)(fb + n0), sv = *(const f32x4*)(se + n0);
         *(f32x4*)(orow + n0) = acc[ns] * a + b + sv;
       }
@@ -197,16 +203,25 @@ __global__ void pack_enc_stream_kernel(const float* __restrict__ w2, const float
   }
 }
 
-template <int CB>
-void launch_enc23(const EncArgs& A, hipStream_t s) {
+template <int CB, int SPLIT>
+void launch_enc23_s(const EncArgs& A, long rows, hipStream_t s) {
   using G = EncGeom<CB>;
   static bool set = false;
   if (!set) {
-    hipFuncSetAttribute((const void*)enc23_kernel<CB>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
+    hipFuncSetAttribute((const void*)enc23_kernel<CB, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
     set = true;
   }
+  hipLaunchKernelGGL((enc23_kernel<CB, SPLIT>), dim3((unsigned)((rows + 127) / 128), SPLIT), dim3(512), G::LDS, s, A);
+}
+template <int CB>
+void launch_enc23(const EncArgs& A, hipStream_t s) {
   const long rows = (long)A.n_img * A.Hp * A.Wp;
-  hipLaunchKernelGGL(enc23_kernel<CB>, dim3((unsigned)((rows + 127) / 128)), dim3(512), G::LDS, s, A);
+  static const int force = getenv("TANTE_ENC23_SPLIT") ? atoi(getenv("TANTE_ENC23_SPLIT")) : 0;
+  const int groups = (int)((rows + 127) / 128);
+  const int split = force ? force : (groups <= 64 ? 4 : groups <= 128 ? 2 : 1);      // fill the CUs when the input is one frame
+  if (split >= 4) launch_enc23_s<CB, 4>(A, rows, s);
+  else if (split == 2) launch_enc23_s<CB, 2>(A, rows, s);
+  else launch_enc23_s<CB, 1>(A, rows, s);
 }
 
 }  // namespace

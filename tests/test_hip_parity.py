@@ -441,6 +441,23 @@ def test_cfg2_full_size_against_oracle(dev):
     assert torch.equal(y32[1:], y32_b)
 
 
+def test_enc23_stage3_split_is_bit_identical(dev):
+    """The fused stage 2 + 3 encoder kernel spreads the stage-3 tiles of a token group over 4 / 2 / 1 workgroups depending on the
+    input size (enc23_kernel<CB, SPLIT>): the same images encoded alone (4-way split), in a mid-sized batch (2-way) and inside a large
+    batch (no split) must come out bitwise equal."""
+    m = _cfg2_model(dev).set_compute("bf16")
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(10, 4, 11, 256, 256, generator=g).to(dev)          # 40 images: 320 token groups -> SPLIT 1
+    with torch.no_grad():
+        fa, fb = m._time_tables()
+        film = (fa, fb, m.s_emb.view(1024, 256), 4, 1024)
+        big = m.encoder.forward_tokens(x, 1, film).view(10, 4, 1024, 256)          # compute code 1 = bf16
+        mid = m.encoder.forward_tokens(x[:3], 1, film).view(3, 4, 1024, 256)       # 12 images: 96 groups -> SPLIT 2
+        one = m.encoder.forward_tokens(x[:1], 1, film).view(1, 4, 1024, 256)       # 4 images: 32 groups -> SPLIT 4
+    assert torch.isfinite(big).all()
+    assert torch.equal(big[:3], mid) and torch.equal(big[:1], one)
+
+
 def test_cfg2_rollout_frame_cache_is_bit_identical(dev, monkeypatch):
     """The rollout loop encodes every frame once (pre-FiLM cache + FiLM applied by the first propagator kernel while it loads) instead
     of once per window: the same arithmetic per token, so the frames must equal the window-by-window encoder's BITWISE, and both must
