@@ -300,6 +300,10 @@ int64_t tante_enc23_stream_bytes(int C);
 int tante_pack_enc23(const float* w2, const float* b2, const float* w3, const float* b3, int C, void* enc_stream, void* stream);
 int tante_enc23_fused(const void* h1, int n_img, int Hp, int Wp, int C, const void* enc_stream, const float* film_a,
                       const float* film_b, const float* s_emb, int T, float* out, void* stream);
+/* The same two stages WITHOUT the FiLM / positional epilogue, for a rollout loop that encodes every frame once: images are ordered
+ * (b, f) with f < frames, and image (b, f) is written to the frame-major row block (f * (n_img / frames) + b) * Hp * Wp of out
+ * (the cache tante_axis_hw_film reads). */
+int tante_enc23_frames(const void* h1, int n_img, int frames, int Hp, int Wp, int C, const void* enc_stream, float* out, void* stream);
 
 /* ---- losses / metrics / optimiser step of the harness ------------------------------------------------
  * pred is addressed as pred[b*pb + t*pt + s*ps + c*pc] (so the channels-first rollout buffer needs no permute copy),

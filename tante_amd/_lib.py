@@ -70,6 +70,7 @@ SIGNATURES = {
     "tante_enc23_stream_bytes": ([c_i32], c_i64),
     "tante_pack_enc23": ([c_vp] * 4 + [c_i32, c_vp, c_vp], c_i32),
     "tante_enc23_fused": ([c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp], c_i32),
+    "tante_enc23_frames": ([c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp], c_i32),
     "tante_im2col": ([c_vp, c_i32, c_i32, c_i64] + [c_i32] * 10 + [c_vp, c_i32, c_vp], c_i32),
     "tante_avgpool_nhwc": ([c_vp, c_i32, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp], c_i32),
     "tante_col2im_nhwc": ([c_vp, c_i32, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_vp], c_i32),

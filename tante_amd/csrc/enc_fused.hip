@@ -40,6 +40,8 @@ struct EncArgs {
   const float *film_a, *film_b, *s_emb;   // (T, C), (T, C), (Hp*Wp, C)
   float* out;                 // (n_img * Hp * Wp, C) fp32
   int n_img, Hp, Wp, T;
+  int out_frames;             // > 0: no FiLM; images are ordered (b, f), f < out_frames, and image (b, f) is written to the frame-major
+                              // row block (f * (n_img / out_frames) + b) * Hp * Wp  (the rollout's pre-FiLM frame cache)
 };
 
 // SPLIT > 1 (small inputs, e.g. ONE frame per rollout call = 64 token groups for 256 CUs): the per-wave chain stage 2 -> 8 stage-3
@@ -119,7 +121,8 @@ __global__ __launch_bounds__(512, 2) void enc23_kernel(const EncArgs A) {
   const float* fa = A.film_a + (long)t_idx * G::C;
   const float* fb = A.film_b + (long)t_idx * G::C;
   const float* se = A.s_emb + (long)hw * G::C;
-  float* orow = A.out + r * G::C;
+  const int nb = A.out_frames > 0 ? A.n_img / A.out_frames : 1;
+  float* orow = A.out + (A.out_frames > 0 ? ((long)(img % A.out_frames) * nb + img / A.out_frames) * HW + hw : r) * G::C;
   unsigned bt3[G::KB3];   // slot-0 bases; the slot and row-tile offsets are instruction immediates
 #pragma unroll
   for (int b = 0; b < G::KB3; ++b) bt3[b] = lds_addr(slots + row3 + (swz_chunk(l15, b * 4 + kk, G::CPR3) << 4));
@@ -151,7 +154,7 @@ __global__ __launch_bounds__(512, 2) void enc23_kernel(const EncArgs A) {
       for (int ns = 0; ns < 2; ++ns) {
         const int n0 = tg * 32 + ns * 16 + kk * 4;
         const f32x4 a = *(const f32x4*)(fa + n0), b = *(const f32x4*)(fb + n0), sv = *(const f32x4*)(se + n0);
-        *(f32x4*)(orow + n0) = acc[ns] * a + b + sv;
+        *(f32x4*)(orow + n0) = A.out_frames > 0 ? acc[ns] : acc[ns] * a + b + sv;
       }
     }
   });
@@ -250,7 +253,20 @@ extern "C" int tante_enc23_fused(const void* h1, int n_img, int Hp, int Wp, int 
     TANTE_FAIL(-1, "tante_enc23_fused: alignment");
   EncArgs A;
   A.h1 = (const unsigned short*)h1; A.w = (const char*)enc_stream; A.film_a = film_a; A.film_b = film_b; A.s_emb = s_emb; A.out = out;
-  A.n_img = n_img; A.Hp = Hp; A.Wp = Wp; A.T = T;
+  A.n_img = n_img; A.Hp = Hp; A.Wp = Wp; A.T = T; A.out_frames = 0;
+  launch_enc23<8>(A, (hipStream_t)stream);
+  TANTE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int tante_enc23_frames(const void* h1, int n_img, int frames, int Hp, int Wp, int C, const void* enc_stream, float* out, void* stream) {
+  if (!h1 || !enc_stream || !out) TANTE_FAIL(-1, "tante_enc23_frames: null pointer");
+  if (!tante_enc23_supported(C)) TANTE_FAIL(-2, "tante_enc23_frames: unsupported C=%d", C);
+  if (n_img <= 0 || frames <= 0 || n_img % frames || Hp <= 0 || Wp <= 0) TANTE_FAIL(-1, "tante_enc23_frames: bad shape");
+  if (((uintptr_t)h1 % 16) || ((uintptr_t)out % 16)) TANTE_FAIL(-1, "tante_enc23_frames: alignment");
+  EncArgs A;
+  A.h1 = (const unsigned short*)h1; A.w = (const char*)enc_stream; A.film_a = A.film_b = A.s_emb = out; A.out = out;   // tables unused
+  A.n_img = n_img; A.Hp = Hp; A.Wp = Wp; A.T = 1; A.out_frames = frames;
   launch_enc23<8>(A, (hipStream_t)stream);
   TANTE_CHECK_LAUNCH();
   return 0;

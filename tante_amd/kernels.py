@@ -363,6 +363,15 @@ def enc23_fused(h1: torch.Tensor, n_img: int, Hp: int, Wp: int, C_: int, enc_str
     return out
 
 
+def enc23_frames(h1: torch.Tensor, n_img: int, frames: int, Hp: int, Wp: int, C_: int, enc_stream: torch.Tensor, out: torch.Tensor):
+    """Stages 2 + 3 without FiLM into the frame-major pre-FiLM cache: image (b, f) -> out[f, b]."""
+    _dev(h1, enc_stream, out)
+    if h1.dtype != torch.bfloat16 or out.dtype != torch.float32:
+        raise RuntimeError("enc23_frames: bf16 stage-1 image, fp32 cache expected")
+    L.check(L.lib().tante_enc23_frames(_p(h1), n_img, frames, Hp, Wp, C_, _p(enc_stream), _p(out), _stream()), "tante_enc23_frames")
+    return out
+
+
 # ---- general conv stages, spectral layer, CViT operators (operators.hip) ---------------------------------------------------------
 def im2col(x: torch.Tensor, nchw: bool, n_img: int, C_: int, H: int, W: int, kh: int, kw: int, sh: int, sw: int, ph: int, pw: int,
            korder: int, out_dtype: torch.dtype) -> torch.Tensor:

@@ -53,9 +53,10 @@ def _rollout_in_place(model, x: torch.Tensor, n_steps: int) -> torch.Tensor:
         z = torch.empty(T + n_calls * ol, B, HW, C_, dtype=torch.float32, device=x.device)
         encoded = 0
         for s in range(n_calls):
-            for f in range(encoded, s * ol + T):
-                model.encode_frame(buf[:, f: f + 1], z[f])
-            encoded = s * ol + T
+            need = s * ol + T
+            if need > encoded:                       # the first call encodes the whole window, later calls the `ol` new frames
+                model.encode_frames(buf[:, encoded: need], z[encoded: need])
+            encoded = need
             model(buf[:, s * ol: s * ol + T], out=buf[:, T + s * ol: T + (s + 1) * ol], enc_cache=(z[s * ol:], B * HW * C_, HW * C_))
         return buf[:, T: T + n_steps]
     for s in range(n_calls):

@@ -123,6 +123,23 @@ class enc_CNN(nn.Module):
     def fuses_23(self, compute: int) -> bool:
         return (compute == L.BF16 and self.fused and self.P == (2, 2, 2) and self.overlap == 0.0 and K.enc23_supported(self.embed_dim))
 
+    def forward_frames(self, inp: torch.Tensor, compute: int, item_stride: int, z: torch.Tensor) -> torch.Tensor:
+        """inp (B, F, D, H, W) fp32 frames -> z (F, B, Hp*Wp, C) fp32: stages 1-3 WITHOUT FiLM, frame-major (the rollout's frame cache).
+        Fused bf16 path only (fuses_23)."""
+        B, F, D, H, W = inp.shape
+        if not self.fuses_23(compute):
+            raise RuntimeError("forward_frames needs the fused stage 2 + 3 encoder path")
+        pk = self._packed(compute)
+        adt = K.act_torch_dtype(compute)
+        n_img = B * F
+        h1 = torch.empty(n_img * (H // 2) * (W // 2), self.chans[1], dtype=adt, device=inp.device)
+        K.patch_embed(inp, pk[0], h1, n_img=n_img, Hin=H, Win=W, Cin=self.chans[0], P=2, nchw=True, act=L.ACT_GELU_ERF, film=None,
+                      imgs_per_item=F, item_stride=item_stride)
+        convs = [self.enc_conv_2.conv, self.enc_conv_3.conv]
+        params = [q for c in convs for q in (c.weight, c.bias)]
+        st = self._cache.get(-3, params, lambda: K.pack_enc23(params, self.embed_dim))
+        return K.enc23_frames(h1, n_img, F, H // 8, W // 8, self.embed_dim, st, z)
+
     def forward_tokens(self, inp: torch.Tensor, compute: int, film: Optional[tuple], item_stride: Optional[int] = None,
                        out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """inp (B,T,D,H,W) fp32 -> tokens (B*T*Hp*Wp, C) fp32; `film` = (a, b, s_emb, T, HW) is applied in the
@@ -431,16 +448,16 @@ class TANTE(nn.Module):
         return bool(self.deg and type(self.encoder).__name__ == "enc_CNN" and self.encoder.fuses_23(compute)
                     and K.axis_hw_supported(self.H_p, self.W_p, self.C))
 
-    def encode_frame(self, frame: torch.Tensor, z: torch.Tensor) -> torch.Tensor:
-        """frame: (B, 1, D, H, W) fp32 view (contiguous frame, any batch stride) -> z (B, Hp*Wp, C) fp32, the encoder output before FiLM."""
+    def encode_frames(self, frames: torch.Tensor, z: torch.Tensor) -> torch.Tensor:
+        """frames: (B, F, D, H, W) fp32 view (contiguous frames, any batch stride) -> z (F, B, Hp*Wp, C) fp32, the encoder output before
+        FiLM in the frame-major layout forward(enc_cache=...) reads (one launch pair for the F frames)."""
         compute = resolve_compute(self.compute)
-        HW, C_ = self.H_p * self.W_p, self.C
-        ident = getattr(self, "_ident_film", None)
-        if ident is None or ident[0].device != frame.device:
-            ident = (torch.ones(1, C_, device=frame.device), torch.zeros(1, C_, device=frame.device), torch.zeros(HW, C_, device=frame.device), 1, HW)
-            self._ident_film = ident
-        self.encoder.forward_tokens(frame, compute, ident, frame.stride(0), out=z.view(-1, C_))
+        self.encoder.forward_frames(frames, compute, frames.stride(0), z)
         return z
+
+    def encode_frame(self, frame: torch.Tensor, z: torch.Tensor) -> torch.Tensor:
+        """One frame: (B, 1, D, H, W) -> z (B, Hp*Wp, C)."""
+        return self.encode_frames(frame, z.view(1, *z.shape))
 
     def forward(self, input: torch.Tensor, out_T=1, out: Optional[torch.Tensor] = None, enc_cache: Optional[tuple] = None):
         """`out` (optional, deg=True only): a (B, output_length, D, H, W) fp32 view with contiguous frames (e.g. the next
