@@ -178,6 +178,10 @@ int tante_film_apply(const float* x, int64_t x_bstride, float* y, int64_t rows, 
 /* out[i] = z[i * E + E - 1]: the "[..., -1]" of the channel-attention letter 'C' (attn_backbone.py:188). */
 int tante_gather_last(const float* z, int64_t n, int E, float* out, void* stream);
 
+/* DefaultChannelsFirstFormatter.process_input for the model input (data/datamodule.py:184-192): x (n_img, HW, D) channels-last fp32 ->
+ * nan_to_num -> channels-first images, image i = (b, t) at out + b * out_bstride + t * D * HW (e.g. the head of a rollout buffer). */
+int tante_format_input(const float* x, int64_t n_img, int T, int64_t HW, int D, float* out, int64_t out_bstride, void* stream);
+
 /* Taylor sum (tante.py:165-171): out[b][i-1] = last[b] + sum_k derivs[k][b] * (i * dt)^k / k!,
  * i = 1..n_out.  last = input[:, -1] given as base pointer + batch stride (elements);
  * derivs = n_order device pointers, each (B, frame) contiguous; out[b] starts at out + b * out_bstride (elements),

@@ -55,6 +55,7 @@ SIGNATURES = {
     "tante_axis_hw_film": ([c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_i32, c_i32] + [c_vp] * 8 + [c_i32, c_vp], c_i32),
     "tante_film_table": ([c_vp, c_i32, c_i32] + [c_vp] * 8 + [c_vp, c_vp, c_vp, c_vp], c_i32),
     "tante_film_apply": ([c_vp, c_i64, c_vp, c_i64, c_i32, c_i64, c_vp, c_vp, c_vp], c_i32),
+    "tante_format_input": ([c_vp, c_i64, c_i32, c_i64, c_i32, c_vp, c_i64, c_vp], c_i32),
     "tante_taylor": ([c_vp, c_i64, C.POINTER(c_vp), c_i32, C.c_double, c_i32, c_vp, c_i64, c_i64, c_i64, c_vp], c_i32),
     "tante_rt_reduce": ([c_vp, c_i32, c_i32, c_f32, c_f32, c_vp, c_vp], c_i32),
     "tante_gather_last": ([c_vp, c_i64, c_i32, c_vp, c_vp], c_i32),

@@ -439,6 +439,26 @@ __global__ void gather_last_kernel(const float* __restrict__ z, long n, int E, f
   if (i < n) out[i] = z[i * E + (E - 1)];
 }
 
+// ---- formatter input: 'b t h w c -> b t c h w' + nan_to_num in one pass (data/datamodule.py:184-192) --------------------------------
+// x: (n_img, HW, D) channels-last; out image i at out + (i / T) * out_bstride + (i % T) * D * HW, (D, HW) channels-first.
+// A workgroup moves 256 pixels of one image: coalesced reads of 256 * D consecutive floats into LDS, coalesced writes of D rows of 256.
+__device__ __forceinline__ float nan_to_num_f(float v) {
+  if (v != v) return 0.0f;                                   // torch.nan_to_num defaults: nan -> 0, +-inf -> +-FLT_MAX
+  return fminf(fmaxf(v, -3.40282346638528859812e+38f), 3.40282346638528859812e+38f);
+}
+__global__ __launch_bounds__(256) void format_input_kernel(const float* __restrict__ x, long HW, int D, int T, float* __restrict__ out,
+                                                           long out_bstride) {
+  extern __shared__ float fsm[];                             // [256][D + 1]
+  const long img = blockIdx.y, p0 = (long)blockIdx.x * 256;
+  const int np = (int)min(256L, HW - p0), tid = threadIdx.x;
+  const float* src = x + (img * HW + p0) * D;
+  for (int i = tid; i < np * D; i += 256) fsm[(i / D) * (D + 1) + (i % D)] = src[i];
+  __syncthreads();
+  float* dst = out + (img / T) * out_bstride + (img % T) * (long)D * HW + p0;
+  for (int d = 0; d < D; ++d)
+    if (tid < np) dst[(long)d * HW + tid] = nan_to_num_f(fsm[tid * (D + 1) + d]);
+}
+
 // ---- Taylor sum -------------------------------------------------------------------------------------
 struct TaylorArgs {
   const float* d[8];
@@ -613,6 +633,14 @@ extern "C" int tante_film_apply(const float* x, int64_t x_bstride, float* y, int
 extern "C" int tante_gather_last(const float* z, int64_t n, int E, float* out, void* stream) {
   if (!z || !out || n <= 0 || E <= 0) TANTE_FAIL(-1, "tante_gather_last: bad argument");
   hipLaunchKernelGGL(gather_last_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, z, (long)n, E, out);
+  TANTE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int tante_format_input(const float* x, int64_t n_img, int T, int64_t HW, int D, float* out, int64_t out_bstride, void* stream) {
+  if (!x || !out || n_img <= 0 || T <= 0 || n_img % T || HW <= 0 || D <= 0 || D > 255) TANTE_FAIL(-1, "tante_format_input: bad argument");
+  hipLaunchKernelGGL(format_input_kernel, dim3((unsigned)((HW + 255) / 256), (unsigned)n_img), dim3(256), 256 * (D + 1) * sizeof(float),
+                     (hipStream_t)stream, x, (long)HW, D, T, out, (long)out_bstride);
   TANTE_CHECK_LAUNCH();
   return 0;
 }

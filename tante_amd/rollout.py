@@ -38,19 +38,31 @@ class DefaultChannelsLastFormatter:
         return output
 
 
-def _rollout_in_place(model, x: torch.Tensor, n_steps: int) -> torch.Tensor:
+def _rollout_in_place(model, x: torch.Tensor, n_steps: int, raw_input: torch.Tensor = None) -> torch.Tensor:
     """The reference's loop without its copies: one (B, T + frames, D, H, W) buffer holds the input window and every
     predicted frame; each model call reads its window in place (strided view) and writes its prediction into the next
     slots, so `torch.cat([moving[:, k:], y])` and the per-step output concatenation disappear."""
-    B, T = x.shape[:2]
+    if raw_input is not None:     # (B, T, H, W, D) channels-last, as the datamodule yields it
+        B, T = raw_input.shape[:2]
+        frame_shape, dev = (raw_input.shape[4], raw_input.shape[2], raw_input.shape[3]), raw_input.device
+    else:
+        B, T = x.shape[:2]
+        frame_shape, dev = tuple(x.shape[2:]), x.device
     ol = model.output_length
     n_calls = -(-n_steps // ol)
-    buf = torch.empty(B, T + n_calls * ol, *x.shape[2:], dtype=torch.float32, device=x.device)
-    buf[:, :T].copy_(x)           # the formatter's 'b t h w c -> b t c h w' is materialised here, once
+    buf = torch.empty(B, T + n_calls * ol, *frame_shape, dtype=torch.float32, device=dev)
+    if raw_input is not None:     # the default formatter's permute + nan_to_num, fused into the one copy that fills the buffer
+        from . import _lib as L
+        from . import kernels as K
+        Bq, Tq, H, W, D = raw_input.shape
+        L.check(L.lib().tante_format_input(raw_input.data_ptr(), Bq * Tq, Tq, H * W, D, buf.data_ptr(), buf.stride(0), K._stream()),
+                "tante_format_input")
+    else:
+        buf[:, :T].copy_(x)       # the formatter's 'b t h w c -> b t c h w' is materialised here, once
     if model.enc_cache_supported() and not os.environ.get("TANTE_NO_ENC_CACHE"):
         # every frame (input or predicted) is encoded once, when it first enters a window; the windows read the frame-major cache
         HW, C_ = model.H_p * model.W_p, model.C
-        z = torch.empty(T + n_calls * ol, B, HW, C_, dtype=torch.float32, device=x.device)
+        z = torch.empty(T + n_calls * ol, B, HW, C_, dtype=torch.float32, device=dev)
         encoded = 0
         for s in range(n_calls):
             need = s * ol + T
@@ -67,9 +79,15 @@ def _rollout_in_place(model, x: torch.Tensor, n_steps: int) -> torch.Tensor:
 def rollout_model(model, batch: Dict, formatter, n_steps: int, device=None):
     """Sliding-window re-feed until n_steps frames exist; returns (y_pred channels-last [:, :n_steps], y_ref)."""
     device = device or next(model.parameters()).device
+    from .tante import TANTE
+    raw = batch["input"]
+    if (not os.environ.get("TANTE_NO_FUSED_FORMAT") and type(formatter) is DefaultChannelsFirstFormatter and isinstance(model, TANTE) and model.deg and not torch.is_grad_enabled()
+            and raw.dim() == 5 and raw.shape[1] == model.T and raw.dtype == torch.float32 and raw.is_cuda and raw.is_contiguous()):
+        # same result as formatter.process_input + the in-place rollout below, without the two extra passes over the window
+        y_ref = torch.nan_to_num(batch["output"])
+        return formatter.process_output(_rollout_in_place(model, None, n_steps, raw_input=raw)), y_ref.to(device)
     moving, y_ref = formatter.process_input(batch)
     moving = moving[0].to(device)
-    from .tante import TANTE
     if isinstance(model, TANTE) and model.deg and not torch.is_grad_enabled() and moving.shape[1] == model.T \
             and moving.dtype == torch.float32:
         return formatter.process_output(_rollout_in_place(model, moving, n_steps)), y_ref.to(device)

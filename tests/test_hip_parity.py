@@ -458,6 +458,20 @@ def test_enc23_stage3_split_is_bit_identical(dev):
     assert torch.equal(big[:3], mid) and torch.equal(big[:1], one)
 
 
+def test_format_input_kernel(dev):
+    """tante_format_input = DefaultChannelsFirstFormatter.process_input's permute + nan_to_num, written straight into a rollout buffer."""
+    from tante_amd import _lib as L
+    B, T, H, W, D, extra = 2, 3, 20, 13, 11, 2
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(B, T, H, W, D, generator=g)
+    x[0, 1, 3, 4, 5] = float("nan"); x[1, 0, 0, 0, 0] = float("inf"); x[1, 2, 19, 12, 10] = float("-inf")
+    ref = torch.nan_to_num(x.permute(0, 1, 4, 2, 3))
+    buf = torch.full((B, T + extra, D, H, W), 7.0, device=dev)
+    xd = x.to(dev)
+    L.check(L.lib().tante_format_input(xd.data_ptr(), B * T, T, H * W, D, buf.data_ptr(), buf.stride(0), torch.cuda.current_stream().cuda_stream))
+    assert torch.equal(buf[:, :T].cpu(), ref) and bool((buf[:, T:] == 7.0).all())
+
+
 def test_cfg2_rollout_frame_cache_is_bit_identical(dev, monkeypatch):
     """The rollout loop encodes every frame once (pre-FiLM cache + FiLM applied by the first propagator kernel while it loads) instead
     of once per window: the same arithmetic per token, so the frames must equal the window-by-window encoder's BITWISE, and both must
