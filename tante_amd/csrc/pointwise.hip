@@ -283,10 +283,12 @@ __host__ __device__ inline int axis_row_stride(int nW) {   // LDS floats per h r
   return rs;
 }
 
+// gout != nullptr (the LAST phase): the updated lines go straight to global memory (position stride gls, group stride ggs, channel
+// l15) instead of back into the LDS plane -- saves the write-back, the barrier and the LDS -> global pass that would follow
 template <bool BF16, int MT>
 __device__ __forceinline__ void axis_phase(float* plane, float* wst_raw, const float* __restrict__ gw1, const float* __restrict__ gb1,
                                            const float* __restrict__ gw2, const float* __restrict__ gb2, int n, int ngroups, int ls,
-                                           int gs, int tid) {
+                                           int gs, int tid, float* __restrict__ gout = nullptr, long gls = 0, long ggs = 0) {
   using ST = typename AxisStage<BF16>::T;
   const int lane = tid & 63, wave = tid >> 6, kk = lane >> 4, l15 = lane & 15;
   // stage this axis' weights in LDS: [b1 | b2] fp32, then w1 | w2 in the staging type
@@ -335,12 +337,15 @@ __device__ __forceinline__ void axis_phase(float* plane, float* wst_raw, const f
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int p = mt * 16 + kk * 4 + j;
-        if (p < n) base[p * ls] += out[mt][j];   // this line group is owned by this wave
+        if (p < n) {
+          if (gout) gout[(long)g * ggs + (long)p * gls + l15] = base[p * ls] + out[mt][j];
+          else base[p * ls] += out[mt][j];       // this line group is owned by this wave
+        }
       }
 #pragma unroll
     for (int j = 0; j < NX; ++j) xa[j] = xb[j];
   }
-  __syncthreads();
+  if (!gout) __syncthreads();
 }
 
 // optional source of the plane: the encoder's per-frame output before FiLM (a frame-major cache kept by the rollout loop), with
@@ -390,8 +395,12 @@ __global__ __launch_bounds__(AXT) void axis_hw_kernel(float* __restrict__ x, Axi
   __syncthreads();
   // phase H: lines along h (stride rs), one group per w;  phase W: lines along w (stride AXWS), one group per h
   if (!(dbg & 2)) axis_phase<BF16, MT>(plane, wst, wh1, bh1, wh2, bh2, nH, nW, rs, AXWS, tid);
+  if (!(dbg & 4) && !(dbg & 1)) {   // phase W writes its lines (w positions of row h, 16 channels) to global memory itself
+    axis_phase<BF16, MT>(plane, wst, ww1, bw1, ww2, bw2, nW, nH, AXWS, rs, tid, gx, (long)C, (long)nW * C);
+    return;
+  }
   if (!(dbg & 4)) axis_phase<BF16, MT>(plane, wst, ww1, bw1, ww2, bw2, nW, nH, AXWS, rs, tid);
-  // ---- store the plane -----------------------------------------------------------------------------------------
+  // ---- store the plane (ablation builds only: the W phase above normally stores) -------------------------------
   if (!(dbg & 1))
   for (int i = tid; i < nH * nW * 4; i += AXT) {
     const int tokn = i >> 2, q = i & 3, h = tokn / nW, w = tokn - h * nW;
