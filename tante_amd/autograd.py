@@ -139,7 +139,8 @@ class _side_wgrad:
 # needs its accumulators -- the uses of one weight run as ONE tante_wgrad_multi launch over the concatenated row range.  The recorded
 # operands stay alive a little longer (~3 GB at cfg3 on a 288 GB part).
 DEFER_WGRAD = __import__("os").environ.get("TANTE_WGRAD_DEFER", "1") != "0"
-_DEFER = {"pending": {}, "armed": False}
+DEFER_MAX_BYTES = int(float(__import__("os").environ.get("TANTE_WGRAD_DEFER_MAX_GB", "32")) * 2 ** 30)   # recorded operands held at most
+_DEFER = {"pending": {}, "armed": False, "bytes": 0}
 
 
 def _flush_wgrads(slot: Optional[torch.Tensor] = None):
@@ -155,6 +156,7 @@ def _flush_wgrads(slot: Optional[torch.Tensor] = None):
                                           int(swap), comp, 1, _s()), "tante_wgrad_multi")
     if slot is None:
         _DEFER["armed"] = False
+        _DEFER["bytes"] = 0
 
 
 def flush_deferred_wgrads():
@@ -173,12 +175,18 @@ def _defer_wgrad(gW, gb, dy, a, M, N, Kk, comp, lay=(L.W_LINEAR, 0, 0, False)) -
         except RuntimeError:          # not inside a backward pass: nothing would flush it
             return False
         _DEFER["pending"].clear()     # leftovers of a backward pass that died half-way must not leak into this one
+        _DEFER["bytes"] = 0
         _DEFER["armed"] = True
     key = (gW.data_ptr(), M, N, Kk, comp, lay)
     ent = _DEFER["pending"].get(key)
     if ent is None:
         ent = _DEFER["pending"][key] = (gW, gb, M, N, Kk, comp, lay, [])
     ent[7].append((dy, a))
+    _DEFER["bytes"] += dy.numel() * dy.element_size() + a.numel() * a.element_size()
+    if _DEFER["bytes"] > DEFER_MAX_BYTES:      # a very large model / batch: do not sit on more activations than this
+        armed = _DEFER["armed"]
+        _flush_wgrads(None)
+        _DEFER["armed"] = armed                # the engine callback is still queued for the rest of this backward pass
     return True
 
 
