@@ -459,7 +459,7 @@ static bool wgrad_tr_launch(const TanteRowMat* U, const TanteRowMat* V, int n_se
   const int ti = I / WT, tj = J / WT;
   // every workgroup ends with 128 x 128 fp32 atomics: with the main loop at memory speed the split count is a trade between
   // parallelism and atomic traffic (64 KiB per workgroup) -- measured best near 128 workgroups for <= 4 tiles, 256 otherwise
-  static const int wg_env = getenv("TANTE_WGRAD_WGS") ? atoi(getenv("TANTE_WGRAD_WGS")) : 0;
+  static const int wg_env = getenv("TANTE_WGRAD_TR_WGS") ? atoi(getenv("TANTE_WGRAD_TR_WGS")) : (getenv("TANTE_WGRAD_WGS") ? atoi(getenv("TANTE_WGRAD_WGS")) : 0);
   const int wg_target = wg_env > 0 ? wg_env : (ti * tj <= 4 ? 128 : 256);
   // splits PER SEGMENT (a split never straddles two segments): the workgroup target is shared by the segments
   long split = wg_target / ((long)ti * tj * n_seg);
