@@ -1489,3 +1489,27 @@ def test_tante_fno_two_train_steps_match_torch_adamw(dev):
         assert float((a - b).abs().max()) <= 2.2 * 1e-3 * 2, k
         assert rel_err(a, b) < 1e-2, k
     assert losses[1] < losses[0]
+
+
+def test_cfg3_training_overfits_a_fixed_batch(dev):
+    """End-to-end health of the train path at full cfg3 size (bf16, dropout 0.1, 4-step BPTT, clip + AdamW through the flat buckets, every
+    fused epilogue / deferred weight-gradient launch of DESIGN 4.3): 25 steps on one smooth batch must cut the loss at least 4x."""
+    import os
+    import tante_amd
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = tante_amd.load_config(os.path.join(root, "configs", "tante_trl.yaml")); wl = cfg["workload"]
+    md = tante_amd.TanteMetadata(n_fields=wl["n_fields"], spatial_resolution=tuple(wl["spatial_resolution"]))
+    torch.manual_seed(211)
+    m = tante_amd.build_model(cfg, md, dropout=0.1).to(dev).train().set_compute("bf16")
+    opt = tante_amd.FlatAdamW(m.parameters(), lr=1e-3, weight_decay=1e-5, max_norm=1.0)
+    B, n, T = 4, wl["n_steps_output"], wl["n_steps_input"]
+    g = torch.Generator().manual_seed(1)
+    base = torch.randn(B, 1, *wl["spatial_resolution"], wl["n_fields"], generator=g)
+    drift = 0.05 * torch.randn(B, 1, *wl["spatial_resolution"], wl["n_fields"], generator=g)
+    frames = torch.cat([base + k * drift for k in range(T + n)], dim=1)
+    batch = {"input": frames[:, :T].to(dev), "output": frames[:, T:].to(dev)}
+    fmt = tante_amd.DefaultChannelsFirstFormatter(md)
+    losses = [float(tante_amd.train_step(m, opt, batch, fmt, n, 1)) for _ in range(25)]
+    assert all(l == l for l in losses), losses
+    assert losses[-1] < 0.25 * losses[0], (losses[0], losses[-1])
+
