@@ -1513,3 +1513,19 @@ def test_cfg3_training_overfits_a_fixed_batch(dev):
     assert all(l == l for l in losses), losses
     assert losses[-1] < 0.25 * losses[0], (losses[0], losses[-1])
 
+
+def test_cfg2_rollout_bf16_tracks_fp32_over_eight_steps(dev):
+    """The re-fed bf16 rollout (fused kernels, frame-encoding cache) against the fp32 rollout (unfused parity kernels) of the same
+    weights: the relative difference of frame k grows about linearly (2e-4 per step measured) and must stay far inside the 1e-2 bar."""
+    import tante_amd
+    m = _cfg2_model(dev)
+    md = tante_amd.TanteMetadata(n_fields=11, spatial_resolution=(256, 256))
+    fmt = tante_amd.DefaultChannelsFirstFormatter(md)
+    g = torch.Generator().manual_seed(5)
+    batch = {"input": torch.randn(2, 4, 256, 256, 11, generator=g).to(dev), "output": torch.randn(2, 8, 256, 256, 11, generator=g).to(dev)}
+    with torch.no_grad():
+        y32, _ = tante_amd.rollout_model(m.set_compute("fp32"), batch, fmt, 8)
+        y16, _ = tante_amd.rollout_model(m.set_compute("bf16"), batch, fmt, 8)
+    errs = [float((y16[:, t] - y32[:, t]).norm() / y32[:, t].norm()) for t in range(8)]
+    assert all(e == e for e in errs) and errs[-1] < 5e-3 and errs[0] < 1e-3, errs
+
