@@ -312,8 +312,10 @@ int tante_enc23_frames(const void* h1, int n_img, int frames, int Hp, int Wp, in
 /* ---- losses / metrics / optimiser step of the harness ------------------------------------------------
  * pred is addressed as pred[b*pb + t*pt + s*ps + c*pc] (so the channels-first rollout buffer needs no permute copy),
  * ref and grad are contiguous channels-last (B, T, HW, C).
- * tante_metric_sums: sums[(b*T + t)*C + c][0..2] = { sum_s (pred-ref)^2, sum_s ref^2, sum_s ref } -- every metric of
- *   trainer/metrics.py (MSE l.53-60, NMSE l.82-98, L2RE l.100-111, NNMSE l.114-130, VRMSE l.158-164) is a closed form of them.
+ * tante_metric_sums: sums[(b*T + t)*C + c][0..4] = { sum_s (pred-ref)^2, sum_s ref^2, sum_s ref, sum_s (ref-p)^2, sum_s (ref-p) } with
+ *   the pivot p = ref[b, t, first pixel, c] -- every metric of trainer/metrics.py (MSE l.53-60, NMSE l.82-98, L2RE l.100-111,
+ *   NNMSE l.114-130, VRMSE l.158-164) is a closed form of them; the 'std' normalisations use the shifted moments (entries 3, 4),
+ *   which stay well conditioned where sum y^2 - (sum y)^2 / n cancels (torch.std in the reference is a stable two-pass form).
  * tante_mse_grad: grad = scale * (pred - ref), the gradient of  MSE(...).mean()  with scale = 2 / (B*T*HW*C)  (trainer.py:189). */
 int tante_metric_sums(const float* pred, int64_t pb, int64_t pt, int64_t ps, int64_t pc, const float* ref, int B, int T, int64_t HW,
                       int C, float* sums, void* stream);

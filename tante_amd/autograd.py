@@ -84,7 +84,7 @@ def _grad_slot(p) -> Optional[torch.Tensor]:
 # Measured on the cfg3 train step (alternating runs on one box): 29.5-29.9 ms against 30.0-30.1 ms on one stream, but with outliers at
 # 33-34.6 ms when the two streams' workgroups interleave badly -- a small, unreliable gain, so it is opt-in (TANTE_WGRAD_SIDE_STREAM=1).
 SIDE_STREAM_WGRAD = __import__("os").environ.get("TANTE_WGRAD_SIDE_STREAM", "0") != "0"
-_SIDE = {"stream": None, "armed": False}
+_SIDE = {"stream": None, "armed": False, "task": -1}
 
 
 def _join_side():
@@ -114,8 +114,9 @@ class _side_wgrad:
         side.wait_stream(torch.cuda.current_stream())
         for t in self.tensors:
             t.record_stream(side)
-        if not _SIDE["armed"]:
-            _SIDE["armed"] = True
+        task = _graph_task()
+        if not _SIDE["armed"] or _SIDE["task"] != task:   # a callback queued by a backward pass that died is gone with it
+            _SIDE["armed"], _SIDE["task"] = True, task
             try:
                 torch.autograd.Variable._execution_engine.queue_callback(_join_side)
             except RuntimeError:      # not inside a backward pass
@@ -140,7 +141,36 @@ class _side_wgrad:
 # operands stay alive a little longer (~3 GB at cfg3 on a 288 GB part).
 DEFER_WGRAD = __import__("os").environ.get("TANTE_WGRAD_DEFER", "1") != "0"
 DEFER_MAX_BYTES = int(float(__import__("os").environ.get("TANTE_WGRAD_DEFER_MAX_GB", "32")) * 2 ** 30)   # recorded operands held at most
-_DEFER = {"pending": {}, "armed": False, "bytes": 0}
+_DEFER = {"pending": {}, "armed": False, "bytes": 0, "task": -1}
+
+
+def _graph_task() -> int:
+    """Id of the backward pass (autograd graph task) this thread is executing, -1 outside one."""
+    return torch._C._current_graph_task_id()
+
+
+def reset_backward_state():
+    """Forget everything recorded for a backward pass that is not running any more.  'armed' means "the engine's end-of-backward
+    callback of THIS backward pass is queued"; a backward pass that raises (OOM, a kernel error, KeyboardInterrupt) drops its
+    callbacks, so the flag is keyed to the graph task and additionally cleared here: train_step* call this before and -- in a
+    finally -- after every loss.backward(), so operands recorded by a dead pass can never reach a later step's gradient slots."""
+    _DEFER["pending"].clear()
+    _DEFER["bytes"] = 0
+    _DEFER["armed"] = False
+    _DEFER["task"] = -1
+    _SIDE["armed"] = False
+    _SIDE["task"] = -1
+    if _SIDE["stream"] is not None:
+        torch.cuda.current_stream().wait_stream(_SIDE["stream"])
+
+
+def run_backward(loss: torch.Tensor):
+    """loss.backward() with the deferred / side-stream state guaranteed clean on entry and on ANY exit."""
+    reset_backward_state()
+    try:
+        loss.backward()
+    finally:
+        reset_backward_state()
 
 
 def _flush_wgrads(slot: Optional[torch.Tensor] = None):
@@ -156,6 +186,7 @@ def _flush_wgrads(slot: Optional[torch.Tensor] = None):
                                           int(swap), comp, 1, _s()), "tante_wgrad_multi")
     if slot is None:
         _DEFER["armed"] = False
+        _DEFER["task"] = -1
         _DEFER["bytes"] = 0
 
 
@@ -169,14 +200,17 @@ def _defer_wgrad(gW, gb, dy, a, M, N, Kk, comp, lay=(L.W_LINEAR, 0, 0, False)) -
     False when this use has to run immediately (feature off, shape / dtype outside the shared-launch kernel)."""
     if not DEFER_WGRAD or comp != L.BF16 or dy.dtype != torch.bfloat16 or a.dtype != torch.bfloat16 or not _tr_shape(M, N, Kk):
         return False
-    if not _DEFER["armed"]:
+    task = _graph_task()
+    if not _DEFER["armed"] or _DEFER["task"] != task:
+        # first deferred use of THIS backward pass (a different graph task id means the pass that armed the flag is gone, and its
+        # queued callback with it: re-queue, and drop whatever it had recorded)
         try:
             torch.autograd.Variable._execution_engine.queue_callback(flush_deferred_wgrads)
         except RuntimeError:          # not inside a backward pass: nothing would flush it
             return False
         _DEFER["pending"].clear()     # leftovers of a backward pass that died half-way must not leak into this one
         _DEFER["bytes"] = 0
-        _DEFER["armed"] = True
+        _DEFER["armed"], _DEFER["task"] = True, task
     key = (gW.data_ptr(), M, N, Kk, comp, lay)
     ent = _DEFER["pending"].get(key)
     if ent is None:
@@ -184,9 +218,9 @@ def _defer_wgrad(gW, gb, dy, a, M, N, Kk, comp, lay=(L.W_LINEAR, 0, 0, False)) -
     ent[7].append((dy, a))
     _DEFER["bytes"] += dy.numel() * dy.element_size() + a.numel() * a.element_size()
     if _DEFER["bytes"] > DEFER_MAX_BYTES:      # a very large model / batch: do not sit on more activations than this
-        armed = _DEFER["armed"]
+        armed, task = _DEFER["armed"], _DEFER["task"]
         _flush_wgrads(None)
-        _DEFER["armed"] = armed                # the engine callback is still queued for the rest of this backward pass
+        _DEFER["armed"], _DEFER["task"] = armed, task                # the engine callback is still queued for the rest of this backward pass
     return True
 
 
@@ -503,7 +537,9 @@ _SEED = [0]
 def next_seed() -> int:
     """A fresh 64-bit dropout seed per op, derived from torch's seed so that runs are reproducible."""
     _SEED[0] += 1
-    return (torch.initial_seed() * 0x9E3779B97F4A7C15 + _SEED[0] * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+    # the data-parallel rank is mixed in: ranks seed identically (same initial weights), but their dropout masks must differ
+    rank = int(__import__("os").environ.get("RANK", "0"))
+    return (torch.initial_seed() * 0x9E3779B97F4A7C15 + _SEED[0] * 0xD1B54A32D192ED03 + rank * 0xA24BAED4963EE407) & 0xFFFFFFFFFFFFFFFF
 
 
 class AttentionFn(Function):

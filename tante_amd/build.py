@@ -24,15 +24,19 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    os.makedirs(LIBDIR, exist_ok=True)
+def build(force: bool = False, verbose: bool = False, ablate: bool = False) -> str:
+    """ablate=True builds tools/_ab/libtante_ablate.so with -DTANTE_ABLATE: the only build in which the TANTE_*_DEBUG
+    timing-ablation switches (which produce wrong results on purpose) read the environment.  The product library never does."""
+    libdir = os.path.join(os.path.dirname(HERE), "tools", "_ab", "ablate_obj") if ablate else LIBDIR
+    lib = os.path.join(os.path.dirname(HERE), "tools", "_ab", "libtante_ablate.so") if ablate else LIB
+    os.makedirs(libdir, exist_ok=True)
     objs, jobs = [], []
     for src in SOURCES:
         sp = os.path.join(CSRC, src)
-        op = os.path.join(LIBDIR, src.replace(".hip", ".o"))
+        op = os.path.join(libdir, src.replace(".hip", ".o"))
         objs.append(op)
         if force or _stale(op, [sp] + HEADERS):
-            jobs.append([HIPCC, *FLAGS, *EXTRA_FLAGS.get(src, []), "-c", sp, "-o", op])
+            jobs.append([HIPCC, *FLAGS, *(["-DTANTE_ABLATE"] if ablate else []), *EXTRA_FLAGS.get(src, []), "-c", sp, "-o", op])
 
     def run(cmd):
         if verbose:
@@ -44,10 +48,10 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if jobs:
         with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
             list(ex.map(run, jobs))
-    if jobs or force or _stale(LIB, objs):
-        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs, "-L/opt/rocm/lib", "-lhipfft", "-Wl,-rpath,/opt/rocm/lib"])
-    return LIB
+    if jobs or force or _stale(lib, objs):
+        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs, "-L/opt/rocm/lib", "-lhipfft", "-Wl,-rpath,/opt/rocm/lib"])
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, ablate="--ablate" in sys.argv))

@@ -954,11 +954,10 @@ void launch_attn_bwd_t(const void* qkv, const void* dO, void* dqkv, int dtype, i
                        unsigned long long seed, hipStream_t s) {
   const int G = 128 / sq.L;
   const size_t lds = 3 * 128 * sizeof(float) + 4 * 128 * (size_t)(D + (LB16 ? 8 : 4)) * (LB16 ? 2 : 4);
-  static bool set = false;
-  if (!set && lds > 64 * 1024) {
-    hipFuncSetAttribute((const void*)attn_bwd_small_kernel<D, LB16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    set = true;
-  }
+  static TantePerDevice attr;
+  if (lds > 64 * 1024) attr.once([&] {
+    hipFuncSetAttribute((const void*)attn_bwd_small_kernel<D, LB16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  });
   hipLaunchKernelGGL((attn_bwd_small_kernel<D, LB16>), dim3((sq.nseq + G - 1) / G, n_head), dim3(128), lds, s, qkv, dO, dqkv, dtype, C, sq, G,
                      causal, 1.0f / sqrtf((float)D), p_drop, seed);
 }

@@ -708,12 +708,11 @@ void launch_block16(float* x, const char* stream, const TanteSeq& sq, int causal
   constexpr int SLOT = TH > T2 ? TH : T2;
   constexpr int LDS = 2 * SLOT + 2 * 16384;
   const int per_wg = sq.L == 32 ? 4 : 8 * (16 / sq.L);  // sequences per workgroup
-  static bool set = false;
-  if (!set) {
+  static TantePerDevice attr;
+  attr.once([&] {
     hipFuncSetAttribute((const void*)fused_block16_kernel<CB, HB>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    set = true;
-  }
-  static const int dbg = getenv("TANTE_BLOCK_DEBUG") ? atoi(getenv("TANTE_BLOCK_DEBUG")) : 0;  // timing ablations only
+  });
+  static const int dbg = tante_ablate_env("TANTE_BLOCK_DEBUG");  // -DTANTE_ABLATE builds only
   hipLaunchKernelGGL((fused_block16_kernel<CB, HB>), dim3((sq.nseq + per_wg - 1) / per_wg), dim3(512), LDS, s, x, stream, sq, causal, eps, dbg);
 }
 
@@ -725,11 +724,10 @@ void launch_block(float* x, const char* stream, const TanteSeq& sq, int causal, 
   constexpr int SLOT = TH > T2 ? TH : T2;
   const int spw = 32 / sq.L;
   const int waves = (sq.nseq + spw - 1) / spw;
-  static bool set = false;
-  if (!set) {
+  static TantePerDevice attr;
+  attr.once([&] {
     hipFuncSetAttribute((const void*)fused_block_kernel<CB, HB>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * SLOT);
-    set = true;
-  }
+  });
   hipLaunchKernelGGL((fused_block_kernel<CB, HB>), dim3((waves + 3) / 4), dim3(256), 3 * SLOT, s, x, stream, sq, causal, eps);
 }
 

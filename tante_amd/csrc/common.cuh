@@ -4,6 +4,8 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <stdlib.h>
+#include <atomic>
 
 #include "../../include/tante_hip.h"
 
@@ -27,6 +29,37 @@ void tante_set_error(const char* fmt, ...);
     hipError_t e__ = hipGetLastError();                                             \
     if (e__ != hipSuccess) TANTE_FAIL(-3, "%s: %s", __func__, hipGetErrorString(e__)); \
   } while (0)
+
+// ---- once-per-device launch attributes --------------------------------------------------------------
+// hipFuncSetAttribute acts on the CURRENT device, so "already set" is remembered per device (a process that drives several GPUs
+// would otherwise launch with the default 64 KiB LDS limit on every device but the first).  Setting twice is harmless, so two
+// threads racing here only repeat the call.
+struct TantePerDevice {
+  std::atomic<unsigned long long> done{0};
+  template <class F>
+  void once(F&& f) {
+    int d = 0;
+    (void)hipGetDevice(&d);
+    const unsigned long long bit = 1ull << (d & 63);
+    if (!(done.load(std::memory_order_acquire) & bit)) {
+      f();
+      done.fetch_or(bit, std::memory_order_release);
+    }
+  }
+};
+
+// ---- timing-ablation switches ------------------------------------------------------------------
+// TANTE_*_DEBUG skip parts of a kernel to time the rest; the results are WRONG by construction, so the shipped library
+// never reads them: they exist only in a -DTANTE_ABLATE build (tools/ab_lib.sh builds one beside the product library).
+static inline int tante_ablate_env(const char* name) {
+#ifdef TANTE_ABLATE
+  const char* v = getenv(name);
+  return v ? atoi(v) : 0;
+#else
+  (void)name;
+  return 0;
+#endif
+}
 
 // ---- bf16 pack / unpack (round-to-nearest-even via v_cvt_pk_bf16_f32, NaN-preserving) ---------
 __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {

@@ -209,11 +209,10 @@ __global__ void pack_enc_stream_kernel(const float* __restrict__ w2, const float
 template <int CB, int SPLIT>
 void launch_enc23_s(const EncArgs& A, long rows, hipStream_t s) {
   using G = EncGeom<CB>;
-  static bool set = false;
-  if (!set) {
+  static TantePerDevice attr;
+  attr.once([&] {
     hipFuncSetAttribute((const void*)enc23_kernel<CB, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
-    set = true;
-  }
+  });
   hipLaunchKernelGGL((enc23_kernel<CB, SPLIT>), dim3((unsigned)((rows + 127) / 128), SPLIT), dim3(512), G::LDS, s, A);
 }
 template <int CB>

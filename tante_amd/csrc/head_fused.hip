@@ -267,11 +267,10 @@ __global__ void pack_head_stream_kernel(const float* __restrict__ w1, const floa
 template <int CB>
 void launch_head(HeadArgs A, hipStream_t s) {
   using G = HeadGeom<CB>;
-  static bool set = false;
-  if (!set) {
+  static TantePerDevice attr;
+  attr.once([&] {
     hipFuncSetAttribute((const void*)fused_head_kernel<CB>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
-    set = true;
-  }
+  });
   const long rows = (long)A.n_img * A.Hp * A.Wp;
   A.groups = (int)((rows + HWAVES * 16 - 1) / (HWAVES * 16));
   const unsigned grid = (unsigned)((A.groups + 7) / 8) * 32;   // 8 token groups x 4 pixels per 32 consecutive workgroups
@@ -311,7 +310,7 @@ extern "C" int tante_head_fused(const float* x, int32_t a_n0, int64_t a_s1, int6
   A.w = (const char*)head_stream; A.out = out; A.out_bstride = out_bstride; A.n_out = n_out;
   A.last = last; A.last_bstride = last_bstride;
   for (int i = 0; i < 8; ++i) A.coef[i] = i < n_out ? coefs[i] : 0.f;
-  { const char* dbg = getenv("TANTE_HEAD_DEBUG"); A.debug = dbg ? atoi(dbg) : 0; }
+  A.debug = tante_ablate_env("TANTE_HEAD_DEBUG");  // -DTANTE_ABLATE builds only
   if (C == 128) launch_head<4>(A, (hipStream_t)stream);
   else launch_head<8>(A, (hipStream_t)stream);
   TANTE_CHECK_LAUNCH();

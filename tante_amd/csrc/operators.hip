@@ -936,12 +936,14 @@ inline unsigned grid_for(long total, int block = 256) {
   return (unsigned)(g > 1048576 ? 1048576 : (g < 1 ? 1 : g));
 }
 
-// ---- hipFFT plans, cached per (H, W, batch, direction) ------------------------------------------------------------------------
-std::mutex plan_mu;
-std::map<std::tuple<int, int, long, int>, hipfftHandle> plans;
+// ---- hipFFT plans, cached per thread and per (device, H, W, batch, direction) ---------------------------------------------------
+// A plan carries its stream (hipfftSetStream) and its work area, so two host threads must never share one: the cache is
+// thread_local, which also makes it lock-free.  The device is part of the key: a plan belongs to the device it was made on.
 int get_plan(int H, int W, long batch, int inverse, hipfftHandle* out) {
-  std::lock_guard<std::mutex> lk(plan_mu);
-  auto key = std::make_tuple(H, W, batch, inverse);
+  thread_local std::map<std::tuple<int, int, int, long, int>, hipfftHandle> plans;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  auto key = std::make_tuple(dev, H, W, batch, inverse);
   auto it = plans.find(key);
   if (it != plans.end()) { *out = it->second; return 0; }
   hipfftHandle p;

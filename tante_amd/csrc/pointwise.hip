@@ -569,7 +569,7 @@ static void launch_axis_hw(float* x, const AxisSrc& S, long BT, int nH, int nW, 
     attr = lds;
   }
   hipLaunchKernelGGL((axis_hw_kernel<BF16, MT>), dim3((unsigned)(BT * (C / 16))), dim3(AXT), lds, s, x, S, nH, nW, C, wh1, bh1, wh2, bh2,
-                     ww1, bw1, ww2, bw2, getenv("TANTE_AXIS_DEBUG") ? atoi(getenv("TANTE_AXIS_DEBUG")) : 0);
+                     ww1, bw1, ww2, bw2, tante_ablate_env("TANTE_AXIS_DEBUG"));
 }
 
 static int axis_hw_impl(float* x, const AxisSrc& S, int64_t BT, int nH, int nW, int C, const float* wh1, const float* bh1, const float* wh2,

@@ -17,14 +17,16 @@ __device__ __forceinline__ float wave_sum(float v) {
 // pred / ref: (B, T, HW, C) channels-last; pred may be a strided view: element (b,t,s,c) at b*pb + t*pt + s*ps + c*pc.
 // One workgroup per (b, t, spatial chunk): lanes own channels (c = lane % C when C <= 64 ...) -- generic: thread i
 // walks elements i, i+256, ... of its chunk so that consecutive lanes read consecutive (s, c) of the contiguous ref.
-// sums[(b*T + t)*C + c][0..2] += { sum (x-y)^2, sum y^2, sum y }  (fp32 atomics; tiny output)
+// sums[(b*T + t)*C + c][0..4] += { sum (x-y)^2, sum y^2, sum y, sum (y-p)^2, sum (y-p) }  (fp32 atomics; tiny output) with the pivot
+// p = ref[b, t, first pixel, c]: the variance of the 'std' metrics is formed from the SHIFTED moments -- sum y^2 - (sum y)^2 / n
+// cancels catastrophically in fp32 for a field whose mean is large against its spread (near-constant pressure / density frames)
 __global__ __launch_bounds__(256) void metric_sums_kernel(const float* __restrict__ pred, long pb, long pt, long ps, long pc,
                                                           const float* __restrict__ ref, int T, long HW, int C, long chunk,
                                                           float* __restrict__ sums) {
-  extern __shared__ float acc[];  // [C][3]
+  extern __shared__ float acc[];  // [C][5]
   const long bt = blockIdx.y;
   const long b = bt / T, t = bt - b * T;
-  for (int i = threadIdx.x; i < 3 * C; i += 256) acc[i] = 0.0f;
+  for (int i = threadIdx.x; i < 5 * C; i += 256) acc[i] = 0.0f;
   __syncthreads();
   const long s0 = (long)blockIdx.x * chunk, s1 = min(HW, s0 + chunk);
   const float* rp = ref + (bt * HW) * C;
@@ -34,25 +36,28 @@ __global__ __launch_bounds__(256) void metric_sums_kernel(const float* __restric
   const bool fixed_c = (256 % C) == 0;
   if (fixed_c) {
     const int c = threadIdx.x % C;
-    float d2 = 0.f, y2 = 0.f, y1 = 0.f;
+    float d2 = 0.f, y2 = 0.f, y1 = 0.f, z2 = 0.f, z1 = 0.f;
+    const float piv = rp[c];
     for (long e = s0 * C + threadIdx.x; e < s1 * C; e += 256) {
       const long s = e / C;
       const float y = rp[e], xv = pp[s * ps + (long)c * pc];
-      const float d = xv - y;
-      d2 += d * d; y2 += y * y; y1 += y;
+      const float d = xv - y, z = y - piv;
+      d2 += d * d; y2 += y * y; y1 += y; z2 += z * z; z1 += z;
     }
-    atomicAdd(&acc[3 * c], d2); atomicAdd(&acc[3 * c + 1], y2); atomicAdd(&acc[3 * c + 2], y1);
+    atomicAdd(&acc[5 * c], d2); atomicAdd(&acc[5 * c + 1], y2); atomicAdd(&acc[5 * c + 2], y1);
+    atomicAdd(&acc[5 * c + 3], z2); atomicAdd(&acc[5 * c + 4], z1);
   } else {
     for (long e = s0 * C + threadIdx.x; e < s1 * C; e += 256) {
       const long s = e / C;
       const int c = (int)(e - s * C);
       const float y = rp[e], xv = pp[s * ps + (long)c * pc];
-      const float d = xv - y;
-      atomicAdd(&acc[3 * c], d * d); atomicAdd(&acc[3 * c + 1], y * y); atomicAdd(&acc[3 * c + 2], y);
+      const float d = xv - y, z = y - rp[c];
+      atomicAdd(&acc[5 * c], d * d); atomicAdd(&acc[5 * c + 1], y * y); atomicAdd(&acc[5 * c + 2], y);
+      atomicAdd(&acc[5 * c + 3], z * z); atomicAdd(&acc[5 * c + 4], z);
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < 3 * C; i += 256) atomicAdd(&sums[bt * C * 3 + i], acc[i]);
+  for (int i = threadIdx.x; i < 5 * C; i += 256) atomicAdd(&sums[bt * C * 5 + i], acc[i]);
 }
 
 // grad[b,t,s,c] (contiguous channels-last) = scale * (pred - ref)
@@ -133,11 +138,11 @@ extern "C" int tante_metric_sums(const float* pred, int64_t pb, int64_t pt, int6
   if (!pred || !ref || !sums || B <= 0 || T <= 0 || HW <= 0 || C <= 0) TANTE_FAIL(-1, "tante_metric_sums: bad argument");
   if (C > 1024) TANTE_FAIL(-2, "tante_metric_sums: too many channels");
   hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(sums, 0, (size_t)B * T * C * 3 * sizeof(float), s) != hipSuccess) TANTE_FAIL(-3, "tante_metric_sums: memset failed");
+  if (hipMemsetAsync(sums, 0, (size_t)B * T * C * 5 * sizeof(float), s) != hipSuccess) TANTE_FAIL(-3, "tante_metric_sums: memset failed");
   long chunks = (HW * C + 256 * 64 - 1) / (256 * 64);  // ~64 elements per thread
   if (chunks < 1) chunks = 1;
   const long chunk = (HW + chunks - 1) / chunks;
-  hipLaunchKernelGGL(metric_sums_kernel, dim3((unsigned)((HW + chunk - 1) / chunk), (unsigned)(B * T)), dim3(256), 3 * C * sizeof(float), s,
+  hipLaunchKernelGGL(metric_sums_kernel, dim3((unsigned)((HW + chunk - 1) / chunk), (unsigned)(B * T)), dim3(256), 5 * C * sizeof(float), s,
                      pred, (long)pb, (long)pt, (long)ps, (long)pc, ref, T, (long)HW, C, chunk, sums);
   TANTE_CHECK_LAUNCH();
   return 0;

@@ -477,14 +477,13 @@ static bool wgrad_tr_launch(const TanteRowMat* U, const TanteRowMat* V, int n_se
     SG.V[g] = (const unsigned short*)V[g < n_seg ? g : 0].p + V[g < n_seg ? g : 0].off;
   }
   SG.R_seg = R;
-  static const int wdebug = getenv("TANTE_WGRAD_DEBUG") ? atoi(getenv("TANTE_WGRAD_DEBUG")) : 0;
+  static const int wdebug = tante_ablate_env("TANTE_WGRAD_DEBUG");  // -DTANTE_ABLATE builds only
   static const int deep_env = getenv("TANTE_WGRAD_DEEP") ? atoi(getenv("TANTE_WGRAD_DEEP")) : -1;
-  static bool set = false;
-  if (!set) {
+  static TantePerDevice attr;
+  attr.once([&] {
     hipFuncSetAttribute((const void*)wgrad_tr_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * WCHUNK);
     hipFuncSetAttribute((const void*)wgrad_tr_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 2 * WCHUNK);
-    set = true;
-  }
+  });
   const unsigned n_wg = 8u * (unsigned)((total + 7) / 8) * (unsigned)(ti * tj);
   // the 8-deep ring (one workgroup per CU with 112 KB in flight) is kept for experiments only: measured on the train step it LOSES to
   // the 4-deep one (33.2 vs 31.0 ms when used for grids of <= 256 workgroups, 32.3 ms when forced everywhere)

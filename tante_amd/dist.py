@@ -48,6 +48,13 @@ def allreduce_sum_(flat: torch.Tensor) -> torch.Tensor:
     return flat
 
 
+def broadcast_(flat: torch.Tensor, src: int = 0) -> torch.Tensor:
+    """In-place broadcast of one flat bucket from rank `src` (a no-op for a single process)."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.broadcast(flat, src=src)
+    return flat
+
+
 def max_over_ranks(value: float, device=None) -> float:
     """Timing reduction of bench.py: the slowest rank defines the step time."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:

@@ -28,7 +28,7 @@ def _spatial_strides(x: torch.Tensor):
 
 
 def metric_sums(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
-    """-> (B, T, C, 3) = {sum (x-y)^2, sum y^2, sum y} over the spatial axes."""
+    """-> (B, T, C, 5) = {sum (x-y)^2, sum y^2, sum y, sum (y-p)^2, sum (y-p)} over the spatial axes, p = y at the first pixel."""
     if not (x.is_cuda and y.is_cuda):
         raise RuntimeError("tante_amd metrics run on the GPU only (no CPU fallback)")
     if x.shape != y.shape or x.dtype != torch.float32 or y.dtype != torch.float32:
@@ -40,7 +40,7 @@ def metric_sums(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
         st = _spatial_strides(x)
     pb, pt, ps, pc, hw = st
     B, T, Cc = x.shape[0], x.shape[1], x.shape[-1]
-    sums = torch.empty(B, T, Cc, 3, dtype=torch.float32, device=x.device)
+    sums = torch.empty(B, T, Cc, 5, dtype=torch.float32, device=x.device)
     L.check(L.lib().tante_metric_sums(x.data_ptr(), pb, pt, ps, pc, y.data_ptr(), B, T, hw, Cc, sums.data_ptr(),
                                       torch.cuda.current_stream().cuda_stream), "tante_metric_sums")
     return sums
@@ -84,12 +84,18 @@ class MSE(Metric):
         return loss
 
 
+def _m2(s, n):
+    """Centred second moment sum (y - mean)^2 per (b, t, c) from the SHIFTED sums, in float64 (tiny tensors), clamped at 0."""
+    z2, z1 = s[..., 3].double(), s[..., 4].double()
+    return (z2 - z1 * z1 / n).clamp_min(0.0)
+
+
 def _nmse_from(s, n, eps, norm_mode):
     mse = s[..., 0] / n
     if norm_mode == "norm":
         norm = s[..., 1] / n
     elif norm_mode == "std":
-        norm = (s[..., 1] - s[..., 2] ** 2 / n) / (n - 1)                          # torch.std(...)**2 (unbiased)
+        norm = (_m2(s, n) / (n - 1)).float()                                       # torch.std(...)**2 (unbiased)
     else:
         raise ValueError(f"Invalid norm_mode: {norm_mode}")
     return mse / (norm + eps)
@@ -141,8 +147,12 @@ class NNMSE(Metric):
         if norm_mode == "norm":
             norm = s[..., 1].sum(dim=-1) / (n * Cc)
         elif norm_mode == "std":
+            # std over (spatial, C) jointly: combine the per-channel centred moments (Chan et al.) -- mean_c = pivot_c + z1_c / n
             tot = n * Cc
-            norm = (s[..., 1].sum(dim=-1) - s[..., 2].sum(dim=-1) ** 2 / tot) / (tot - 1)
+            piv = y.reshape(y.shape[0], y.shape[1], -1, Cc)[:, :, 0, :].double()
+            mean_c = piv + s[..., 4].double() / n
+            mean = mean_c.mean(dim=-1, keepdim=True)
+            norm = ((_m2(s, n) + n * (mean_c - mean) ** 2).sum(dim=-1) / (tot - 1)).float()
         else:
             raise ValueError(f"Invalid norm_mode: {norm_mode}")
         return mse_c / (norm + eps)                                               # metrics.py:114-130

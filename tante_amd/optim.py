@@ -50,10 +50,40 @@ class FlatAdamW:
                 self.flat_p[o:o + sz].copy_(p.detach().reshape(-1))
                 p.data = self.flat_p[o:o + sz].view(p.shape)          # the parameter now lives in the bucket
                 p.grad = self.flat_g[o:o + sz].view(p.shape)
+        self._offs = offs
         self.step_count = 0
 
-    def zero_grad(self):
+    def zero_grad(self, set_to_none: bool = False):
+        """Zero the gradient bucket.  The parameters' .grad stay views of it whatever set_to_none says: step() reads only the bucket."""
+        self._check_views()
         self.flat_g.zero_()
+
+    def _check_views(self):
+        """step() reads only the flat buckets, so every p.data / p.grad must still alias them.  model.zero_grad() (set_to_none=True by
+        default) leaves .grad None -> re-bound here; a .grad or .data that points elsewhere (model.to(), .float(), a fresh tensor
+        written by autograd after the views were dropped) would make the step apply zeros silently -> raise instead."""
+        base_p, base_g = self.flat_p.data_ptr(), self.flat_g.data_ptr()
+        for p, o in zip(self.params, self._offs):
+            if p.data_ptr() != base_p + 4 * o:
+                raise RuntimeError("FlatAdamW: a parameter no longer lives in the flat bucket (model.to()/.float() after the optimiser "
+                                   "was built?); rebuild the optimiser")
+            if p.grad is None:
+                sz = p.numel() * (2 if p.is_complex() else 1)
+                v = self.flat_g[o:o + sz]
+                p.grad = torch.view_as_complex(v.view(*p.shape, 2)) if p.is_complex() else v.view(p.shape)
+            elif p.grad.data_ptr() != base_g + 4 * o:
+                raise RuntimeError("FlatAdamW: a parameter's .grad is not a view of the flat gradient bucket any more (gradients were "
+                                   "written to a fresh tensor, e.g. after model.zero_grad(set_to_none=True) followed by backward); "
+                                   "use FlatAdamW.zero_grad()")
+
+    def broadcast_parameters(self, src: int = 0):
+        """Data parallel: every rank starts from rank `src`'s weights (one broadcast of the flat parameter bucket)."""
+        from . import dist as D
+        D.broadcast_(self.flat_p, src)
+        from .attn_backbone import bump_weight_epoch
+        from .autograd import clear_pack_cache
+        bump_weight_epoch()
+        clear_pack_cache()
 
     # ---- checkpoint interchange with torch.optim.AdamW (the layout the reference's checkpoints hold, trainer/trainer.py:116-141) --
     def _views(self, flat: torch.Tensor):
@@ -107,6 +137,7 @@ class FlatAdamW:
 
     def step(self, grad_scale: float = 1.0, lr: Optional[float] = None):
         """clip_grad_norm_(max_norm) + AdamW.  grad_scale multiplies the gradients first (1/world after a summed all-reduce)."""
+        self._check_views()
         self.step_count += 1
         s = torch.cuda.current_stream().cuda_stream
         if self.max_norm and self.max_norm > 0:

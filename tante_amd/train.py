@@ -15,7 +15,7 @@ from typing import Dict
 import torch
 
 from . import dist as D
-from .autograd import MseMeanFn
+from .autograd import MseMeanFn, run_backward
 from .optim import FlatAdamW
 from .metrics import MSE
 from .rollout import rollout_adaptive, rollout_model
@@ -26,7 +26,7 @@ def train_step(model, opt: FlatAdamW, batch: Dict[str, torch.Tensor], formatter,
     opt.zero_grad()
     y_pred, y_ref = rollout_model(model, batch, formatter, n_steps_output)
     loss = MseMeanFn.apply(y_pred, y_ref)
-    loss.backward()
+    run_backward(loss)
     if world > 1:
         D.allreduce_sum_(opt.flat_g)
     opt.step(grad_scale=1.0 / world, lr=lr)
@@ -40,7 +40,7 @@ def train_step_adaptive(model, opt: FlatAdamW, batch: Dict[str, torch.Tensor], f
     opt.zero_grad()
     y_pred, y_ref, rts = rollout_adaptive(model, batch, formatter, n_steps_output, 1.5, per_sample=True)
     loss = MseMeanFn.apply(y_pred, y_ref) + MSE.eval_rt(rts, rt_eps, rt_n)
-    loss.backward()
+    run_backward(loss)
     if world > 1:
         D.allreduce_sum_(opt.flat_g)
         opt.flat_g.mul_(1.0 / world)
@@ -71,7 +71,7 @@ def train_step_cvit(model, opt: FlatAdamW, batch: Dict[str, torch.Tensor], forma
     else:
         y_pred = formatter.process_output(model(x))                 # (b, t, h, w, d) view of the prediction
         loss = MseMeanFn.apply(y_pred, y_ref[:, :y_pred.shape[1]].contiguous())
-    loss.backward()
+    run_backward(loss)
     if world > 1:
         D.allreduce_sum_(opt.flat_g)
     opt.step(grad_scale=1.0 / world, lr=lr)

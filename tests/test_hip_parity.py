@@ -10,7 +10,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from conftest import load_golden, split_prefix, rel_err, max_rel
+from conftest import load_golden, split_prefix, rel_err, max_rel, record_parity
 
 pytestmark = pytest.mark.gpu
 
@@ -34,6 +34,7 @@ def close(a, b, mode, scale=1.0):
     assert a.shape == b.shape, (a.shape, b.shape)
     assert torch.isfinite(a).all()
     r, m = rel_err(a, b), max_rel(a, b)
+    record_parity(r, m, TOL[mode] * scale, mode)
     assert r < TOL[mode] * scale and m < TOL[mode] * scale * 2, f"rel={r:.3e} max={m:.3e} (tol {TOL[mode] * scale:.1e})"
 
 
