@@ -7,6 +7,10 @@ Evaler.rollout_model loop (trainer/evaler.py:121-138) with the window already re
 `value` = frames produced by all ranks / wall time of the K timed steps (max over ranks).
 Multi-GPU: the rollout shards over batch (independent samples, no data-path collective) -> weak scaling.
 
+Launch: `python bench.py --gpus N` with WORLD_SIZE unset spawns the N ranks ITSELF (one process per GPU, before this process makes
+any GPU call) and prints rank 0's line; under torchrun (RANK / LOCAL_RANK / WORLD_SIZE set) it is one of the ranks.  It fails loudly
+when --gpus disagrees with WORLD_SIZE or with the number of visible GPUs.
+
 Also reported on the same JSON line:
   roofline      dominant kernel (LayerNorm-fused projection GEMM, bf16 MFMA) algorithmic FLOP/s vs the dense
                 bf16 peak, timed with HIP events around each of its launches in an instrumented pass
@@ -25,6 +29,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}      # dense MFMA peaks, MI355X_MICROARCH.md
+PMC_FILE = "r02_pmc_rollout.json"                    # HBM counters of the dominant kernel (separate --pmc passes, committed)
+
+
+def _sha16(path):
+    import hashlib
+    with open(path, "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
 
 
 def parse():
@@ -39,16 +50,78 @@ def parse():
     p.add_argument("--no-roofline", action="store_true")
     p.add_argument("--no-train", action="store_true", help="skip the train-step leg (configs/tante_trl.yaml)")
     p.add_argument("--train-steps", type=int, default=3)
+    p.add_argument("--no-train-strong", action="store_true", help="skip the strong-scaling train line (global batch 64)")
     return p.parse_args()
+
+
+def launch_ranks(args) -> int:
+    """--gpus N without a launcher: start N copies of this script, one per GPU, with the torchrun environment (RANK, LOCAL_RANK,
+    WORLD_SIZE, MASTER_ADDR = 127.0.0.1, a free MASTER_PORT).  Nothing here touches the GPU (device_count() does not initialise it),
+    so no initialised process is ever replaced or forked; rank 0's stdout (the one JSON line) is passed through."""
+    import socket
+    import subprocess
+    n = args.gpus
+    have = torch.cuda.device_count()
+    if have < n:
+        raise SystemExit(f"bench.py: --gpus {n} but only {have} GPU(s) are visible; refusing to run fewer ranks than asked")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        raise SystemExit(f"bench.py: ranks failed (rank, exit code): {bad}")
+    return 0
+
+
+def train_flops_per_sample(cfg, wl) -> float:
+    """Algorithmic FLOPs of one training sample of the TANTE train step: forward per model call =
+    encoder (3 strided patch convs on T frames) + per Taylor order [3 axis propagators + the order's blocks + one derivative head],
+    blocks = tokens x [2 C (3C + C + 2 hidden) + 4 L C]; a train step is n_steps_output calls, backward = 2 x forward."""
+    mk = cfg["model"]
+    C, T, D = mk.get("embed_dim", 256), mk["in_T"], wl["n_fields"]
+    H, W = wl["spatial_resolution"]
+    P = {4: (1, 2, 2), 8: (2, 2, 2), 16: (2, 2, 4), 32: (2, 4, 4), 64: (4, 4, 4)}[mk.get("patch_scale", 8)]
+    chans = (D, C // 4, C // 2, C)
+    enc = dec = 0.0
+    h, w = H, W
+    for i in range(3):
+        h, w = h // P[i], w // P[i]
+        stage = 2.0 * h * w * chans[i + 1] * chans[i] * P[i] * P[i]
+        enc += T * stage
+        dec += stage
+    Hp, Wp = h, w
+    tokens = T * Hp * Wp
+    hidden = int(C * mk.get("mlp_ratio", 1.0))
+    fwd = enc
+    for order_axes in mk.get("attn_axes", "THWTHWTHW").split("-"):
+        fwd += tokens * C * 4.0 * (Hp + Wp + T) + dec
+        for letter in order_axes:
+            Lq = {"T": T, "H": Hp, "W": Wp, "L": Hp * Wp, "Y": T * Hp, "X": T * Wp, "A": tokens}[letter]
+            fwd += tokens * (2.0 * C * (3 * C + C + 2 * hidden) + 4.0 * Lq * C)
+    return 3.0 * fwd * wl["n_steps_output"]
 
 
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(launch_ranks(args))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: the launcher and the flag must agree")
+    if local >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: LOCAL_RANK {local} but only {torch.cuda.device_count()} GPU(s) are visible")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
@@ -140,53 +213,74 @@ def main():
         # HBM bytes per launch of that kernel from the committed PMC passes (profiles/r01_pmc_rollout.json: separate
         # `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this command, FETCH_SIZE doubled per the gfx950 note of
         # MI355X_MICROARCH.md); bench.py itself cannot run the profiler, so the figure is null when the file is absent.
-        traffic = None
+        traffic = traffic_source = None
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_rollout.json")) as f:
+            with open(os.path.join(ROOT, "profiles", PMC_FILE)) as f:
                 pm = json.load(f)
-            if name.startswith("fused_block") and dtype == "bf16":
-                traffic = pm["fused_block16_kernel"]["hbm_bytes_per_launch"]
+            if name.startswith("fused_block") and dtype == "bf16" and os.path.basename(args.config) == pm.get("config", "tante_am.yaml"):
+                traffic = pm["fused_block_kernel"]["hbm_bytes_per_launch"]
+                # the counters come from a separate rocprofv3 --pmc pass (tools/collect_profiles.sh), not from this run: say which
+                traffic_source = {"file": "profiles/" + PMC_FILE, "kernel_source_sha16": pm.get("kernel_source_sha16"),
+                                  "current_kernel_source_sha16": _sha16(os.path.join(ROOT, "tante_amd", "csrc", "block_fused.hip"))}
+                traffic_source["stale"] = traffic_source["kernel_source_sha16"] != traffic_source["current_kernel_source_sha16"]
         except (OSError, KeyError, ValueError):
             pass
         roofline = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": PEAK_TFLOPS[dtype], "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_TFLOPS[dtype], 4), "traffic": traffic, "launches": n,
+                    "frac": round(ach / PEAK_TFLOPS[dtype], 4), "traffic": traffic, "traffic_source": traffic_source, "launches": n,
                     "avg_launch_us": round(1e3 * ms / max(1, n), 2),
                     "others": {k: {"TFLOP/s": round(v[1] / (v[0] * 1e-3) / 1e12, 2), "avg_launch_us": round(1e3 * v[0] / v[2], 2),
                                    "launches": v[2]} for k, v in tot.items() if k != name}}
 
     train = None
     if not args.no_train:
-        # second leg of the metric: train-step samples/sec on cfg3 (TRL-2D shaped fields, batch 8 per GPU, 4-step BPTT,
-        # MSE + clip + AdamW, one summed gradient all-reduce per step when N > 1)
+        # second leg of the metric: train-step samples/sec on cfg3 (TRL-2D shaped fields, 4-step BPTT, MSE + clip + AdamW, one summed
+        # all-reduce of the flat gradient bucket per step when N > 1), weak (8 samples per GPU) and strong (global batch 64)
         tcfg = tante_amd.load_config(os.path.join(ROOT, "configs", "tante_trl.yaml"))
         twl = tcfg["workload"]
         tmd = tante_amd.TanteMetadata(n_fields=twl["n_fields"], spatial_resolution=tuple(twl["spatial_resolution"]))
-        torch.manual_seed(tcfg.get("seed", 211))
         drop = float(os.environ.get("TANTE_TRAIN_DROPOUT", tcfg["model"].get("dropout", 0.0)))
-        tmodel = tante_amd.build_model(tcfg, tmd, dropout=drop).to(dev).train().set_compute(dtype)
         oc = tcfg["optimizer"]
-        opt = tante_amd.FlatAdamW(tmodel.parameters(), lr=oc["lr"], weight_decay=oc["weight_decay"], max_norm=1.0)
-        tB, tn = twl["batch_size"], twl["n_steps_output"]
-        tgen = torch.Generator().manual_seed(1000 + rank)
-        tbatch = {"input": torch.randn(tB, twl["n_steps_input"], *twl["spatial_resolution"], twl["n_fields"], generator=tgen).to(dev),
-                  "output": torch.randn(tB, tn, *twl["spatial_resolution"], twl["n_fields"], generator=tgen).to(dev)}
+        tn = twl["n_steps_output"]
         tfmt = tante_amd.DefaultChannelsFirstFormatter(tmd)
-        tante_amd.train_step(tmodel, opt, tbatch, tfmt, tn, world)          # warm-up (packs, allocator)
-        sync()
-        t0 = time.perf_counter()
-        for _ in range(args.train_steps):
-            tante_amd.train_step(tmodel, opt, tbatch, tfmt, tn, world)
-        sync()
-        tel = time.perf_counter() - t0
-        if dist is not None:
-            tt = torch.tensor([tel], device=dev, dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            tel = float(tt.item())
-        train = {"metric": "train-step samples/sec, TANTE on 128x384 TRL-2D (4-step BPTT, MSE, clip, AdamW)",
-                 "value": round(tB * world * args.train_steps / tel, 2), "unit": "samples/s", "ms_per_step": round(1e3 * tel / args.train_steps, 2),
-                 "global_batch": tB * world, "dropout": drop, "steps": args.train_steps,
-                 "collective": "one summed all-reduce of the flat fp32 gradient bucket (%d params)" % opt.numel if world > 1 else None}
-        del tmodel, opt, tbatch
+        flops_sample = train_flops_per_sample(tcfg, twl)
+
+        def train_leg(tB, n_timed):
+            torch.manual_seed(tcfg.get("seed", 211))
+            tmodel = tante_amd.build_model(tcfg, tmd, dropout=drop).to(dev).train().set_compute(dtype)
+            opt = tante_amd.FlatAdamW(tmodel.parameters(), lr=oc["lr"], weight_decay=oc["weight_decay"], max_norm=1.0)
+            opt.broadcast_parameters(0)                                         # every rank starts from rank 0's weights
+            tgen = torch.Generator().manual_seed(1000 + rank)
+            tbatch = {"input": torch.randn(tB, twl["n_steps_input"], *twl["spatial_resolution"], twl["n_fields"], generator=tgen).to(dev),
+                      "output": torch.randn(tB, tn, *twl["spatial_resolution"], twl["n_fields"], generator=tgen).to(dev)}
+            tante_amd.train_step(tmodel, opt, tbatch, tfmt, tn, world)          # warm-up (packs, allocator)
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(n_timed):
+                tante_amd.train_step(tmodel, opt, tbatch, tfmt, tn, world)
+            sync()
+            tel = time.perf_counter() - t0
+            if dist is not None:
+                tt = torch.tensor([tel], device=dev, dtype=torch.float64)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                tel = float(tt.item())
+            nbytes = opt.numel * 4
+            del tmodel, opt, tbatch
+            torch.cuda.empty_cache()
+            sps = tB * world * n_timed / tel
+            return {"value": round(sps, 2), "unit": "samples/s", "ms_per_step": round(1e3 * tel / n_timed, 2), "global_batch": tB * world,
+                    "batch_per_gpu": tB, "steps": n_timed,
+                    "roofline": {"bound": "mfma", "achieved": round(sps * flops_sample / world / 1e12, 2), "peak": PEAK_TFLOPS[dtype],
+                                 "unit": "TFLOP/s per GPU", "frac": round(sps * flops_sample / world / 1e12 / PEAK_TFLOPS[dtype], 4),
+                                 "algorithmic_gflop_per_sample": round(flops_sample / 1e9, 1)}}, nbytes
+
+        weak, nbytes = train_leg(twl["batch_size"], args.train_steps)
+        train = {"metric": "train-step samples/sec, TANTE on 128x384 TRL-2D (4-step BPTT, MSE, clip, AdamW)", "scaling": "weak", **weak,
+                 "dropout": drop,
+                 "collective": ("RCCL all-reduce(sum) of the flat fp32 gradient bucket, %d bytes, once per step; 1/world folded into "
+                                "clip + AdamW" % nbytes) if world > 1 else None}
+        if 64 % world == 0 and not args.no_train_strong:
+            strong, _ = train_leg(64 // world, max(1, args.train_steps if world > 1 else 2))
+            train["strong"] = {"scaling": "strong", **strong}
 
     cpu = None
     if not args.no_cpu_baseline and rank == 0 and world == 1:

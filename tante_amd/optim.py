@@ -17,6 +17,17 @@ import torch
 from . import _lib as L
 
 
+def flat_layout(params):
+    """(offsets, total) of the flat fp32 buckets: parameters in order, complex ones as (re, im) pairs, every view 16-byte aligned.
+    The data-parallel all-reduce moves exactly this bucket (tante_amd.dist), so the layout is a function of its own."""
+    sizes = [p.numel() * (2 if p.is_complex() else 1) for p in params]
+    offs, n = [], 0
+    for sz in sizes:
+        offs.append(n)
+        n += (sz + 3) // 4 * 4            # keep every view 16-byte aligned
+    return offs, sizes, n
+
+
 class FlatAdamW:
     def __init__(self, params: Iterable[torch.nn.Parameter], lr: float = 5e-5, weight_decay: float = 1e-5,
                  betas=(0.9, 0.999), eps: float = 1e-8, max_norm: float = 1.0):
@@ -29,11 +40,7 @@ class FlatAdamW:
         self.lr, self.weight_decay, self.betas, self.eps, self.max_norm = lr, weight_decay, betas, eps, max_norm
         # complex parameters (the spectral layers' weights) live in the buckets as (re, im) pairs, which is also how torch.optim.AdamW
         # treats them (view_as_real)
-        sizes = [p.numel() * (2 if p.is_complex() else 1) for p in self.params]
-        offs, n = [], 0
-        for sz in sizes:
-            offs.append(n)
-            n += (sz + 3) // 4 * 4            # keep every view 16-byte aligned
+        offs, sizes, n = flat_layout(self.params)
         self.numel = n
         self.flat_p = torch.zeros(n, dtype=torch.float32, device=dev)
         self.flat_g = torch.zeros(n, dtype=torch.float32, device=dev)

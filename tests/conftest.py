@@ -41,6 +41,38 @@ def max_rel(a, b):
     return float((a - b).abs().max() / (b.abs().max() + 1e-30))
 
 
+G14_KW = dict(in_T=4, taylor_order=1, attn_axes="THWTHWTHW", n_head=8, embed_dim=256, patch_scale=8, dropout=0.0)
+G14_FIELDS, G14_RES = 4, (64, 384)
+
+
+def g14_setup():
+    """The production-shape train-step fixture (tests/golden/make_golden.py:g14) stores no weights and no inputs -- 4.2 M parameters
+    and 6 MB of fields do not fit a small fixture -- only their checksums: both are rebuilt here from the same seeded CPU generators
+    the generator script used with the reference (manual_seed(14) before the constructor; Generator(1414) for the fields), and the
+    checksums prove the rebuilt tensors are the reference's.  -> (model on CPU, batch, golden arrays)"""
+    import tante_amd
+    g = load_golden_raw("g14_trainstep_wide")
+    torch.manual_seed(14)
+    md = tante_amd.TanteMetadata(n_fields=G14_FIELDS, spatial_resolution=G14_RES)
+    m = tante_amd.TANTE(dset_metadata=md, **G14_KW)
+    gen = torch.Generator().manual_seed(1414)
+    batch = {"input": torch.randn(2, 4, 64, 384, 4, generator=gen), "output": torch.randn(2, 4, 64, 384, 4, generator=gen)}
+    names = [str(n) for n in g["param_names"]]
+    params = dict(m.named_parameters())
+    assert names == list(params.keys()), "parameter order differs from the reference's named_parameters()"
+    wn = np.array([float(params[n].detach().double().norm()) for n in names])
+    assert np.allclose(wn, g["w_norm"], rtol=1e-6, atol=1e-12), "same-seed initialisation differs from the reference's"
+    chk = np.array([float(batch["input"].double().sum()), float(batch["input"].double().pow(2).sum()),
+                    float(batch["output"].double().sum()), float(batch["output"].double().pow(2).sum())])
+    assert np.allclose(chk, g["in_sum"], rtol=1e-9), "seeded input fields differ from the generator script's"
+    return m, batch, g, names
+
+
+def load_golden_raw(name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    return {k: z[k] for k in z.files}
+
+
 # ---- parity report: every comparison of the GPU suite leaves {test, rel, max, tol} behind -----------------------------------------
 PARITY = []
 

@@ -25,6 +25,10 @@ Fixture index:
   g11_cvit_*         CViT tiny: grid / fourier / mlp coordinate embeddings, full-grid and query-point modes
   g12_spectral_*     SpectralLayer (modes below / above the spectrum size) and TANTE(enc_dec_type='fno') tiny
   g13_deg_false      adaptive-dt forward composed from the reference's own sub-modules
+  g14_trainstep_wide production-shape train step (C=256, 8 heads x 32, "THWTHWTHW", L in {4, 8, 48}): loss, per-parameter gradient
+                     norms, three full gradient tensors.  Weights (4.2 M) and inputs are NOT stored: both come from seeded CPU
+                     generators (manual_seed(14) before the constructor; Generator(1414) for the fields) and the fixture holds their
+                     checksums, so a test first proves it rebuilt the same tensors.
 """
 import os
 import sys
@@ -379,7 +383,40 @@ def g13():
     save("g13_deg_false", x=x.numpy(), **res, **sd_np(m))
 
 
+G14_FULL = ["blocks.0.blocks.4.attn.in_proj_weight", "blocks.0.blocks.8.mlp.0.weight", "encoder.enc_conv_2.conv.weight"]
+
+
+def g14():
+    torch.manual_seed(14)
+    meta = md(4, (64, 384))
+    m = TANTE(in_T=4, dset_metadata=meta, taylor_order=1, attn_axes="THWTHWTHW", n_head=8, embed_dim=256,
+              patch_scale=8, dropout=0.0).train()
+    gen = torch.Generator().manual_seed(1414)
+    batch = {"input": torch.randn(2, 4, 64, 384, 4, generator=gen), "output": torch.randn(2, 4, 64, 384, 4, generator=gen)}
+    tr = Trainer.__new__(Trainer)
+    tr.n_steps_output = 4
+    tr.n_steps_rollout = 8
+    tr.device = torch.device("cpu")
+    fmt = DefaultChannelsFirstFormatter(meta)
+    y_pred, y_ref = tr.rollout_model(m, batch, fmt, "train")
+    loss = ref_metrics.MSE()(y_pred, y_ref, None).mean()
+    loss.backward()
+    names = [k for k, _ in m.named_parameters()]
+    arrs = {"loss": loss.detach().numpy(), "param_names": np.array(names),
+            "w_norm": np.array([float(p.detach().double().norm()) for _, p in m.named_parameters()]),
+            "g_norm": np.array([float(p.grad.double().norm()) for _, p in m.named_parameters()]),
+            "in_sum": np.array([float(batch["input"].double().sum()), float(batch["input"].double().pow(2).sum()),
+                                float(batch["output"].double().sum()), float(batch["output"].double().pow(2).sum())]),
+            "y_pred_slice": y_pred.detach()[:, :, ::8, ::8, :].numpy().copy(),
+            "y_pred_norm": np.array(float(y_pred.detach().double().norm()))}
+    sdict = dict(m.named_parameters())
+    for k in G14_FULL:
+        arrs["g." + k] = sdict[k].grad.detach().numpy().copy()
+    arrs["gnorm"] = np.array(float(torch.nn.utils.clip_grad_norm_(m.parameters(), max_norm=1.0)))
+    save("g14_trainstep_wide", **arrs)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14"]
     for w in which:
         globals()[w]()

@@ -323,7 +323,7 @@ def test_g4_backbone(dev, name, mode):
     bb.compute = mode
     with torch.no_grad():
         y = bb(g["x"].to(dev))
-    close(y, g["y"], mode, scale=2.0 if mode == "bf16" else 1.0)
+    close(y, g["y"], mode)
 
 
 @pytest.mark.parametrize("name", names("g2_encdec_*"))
@@ -393,8 +393,8 @@ def test_g8_rollout(dev, name):
     with torch.no_grad():
         y, y_ref = tante_amd.rollout_model(m, {"input": g["inp"], "output": g["out"]}, fmt, n_roll)
         yt, _ = tante_amd.rollout_model(m, {"input": g["inp"], "output": g["out"][:, :4]}, fmt, 4)
-    close(y, g["y_eval"], "fp32", scale=3.0)
-    close(yt, g["y_train"], "fp32", scale=3.0)
+    close(y, g["y_eval"], "fp32")
+    close(yt, g["y_train"], "fp32")
     assert torch.equal(y_ref.cpu(), g["y_ref"])
 
 
@@ -581,7 +581,7 @@ def test_metrics_golden_and_strided(dev):
     x, y = g["x"].to(dev), g["y"].to(dev)
     for name in ("MSE", "L2RE", "NNMSE", "VRMSE", "NMSE", "RMSE", "NRMSE", "VMSE"):
         out = getattr(tante_amd, name)()(x, y, None)
-        close(out, g[name], "fp32", scale=3.0)
+        close(out, g[name], "fp32")
     for k in ("below", "inside", "above"):
         v = tante_amd.MSE()(x, y, g["rt_" + k].to(dev), 0.5, 2)
         assert abs(float(v) - float(g["mse_rt_" + k])) < 1e-5
@@ -591,9 +591,9 @@ def test_metrics_golden_and_strided(dev):
     ref = torch.randn(3, 5, 33, 20, 7, generator=gen)
     pred_view = buf.to(dev).permute(0, 1, 3, 4, 2)
     assert not pred_view.is_contiguous()
-    close(tante_amd.MSE.eval(pred_view, ref.to(dev)), O.mse(buf.permute(0, 1, 3, 4, 2), ref), "fp32", scale=3.0)
-    close(tante_amd.L2RE.eval(pred_view, ref.to(dev)), O.l2re(buf.permute(0, 1, 3, 4, 2), ref), "fp32", scale=3.0)
-    close(tante_amd.VRMSE.eval(pred_view, ref.to(dev)), O.vrmse(buf.permute(0, 1, 3, 4, 2), ref), "fp32", scale=30.0)
+    close(tante_amd.MSE.eval(pred_view, ref.to(dev)), O.mse(buf.permute(0, 1, 3, 4, 2), ref), "fp32")
+    close(tante_amd.L2RE.eval(pred_view, ref.to(dev)), O.l2re(buf.permute(0, 1, 3, 4, 2), ref), "fp32")
+    close(tante_amd.VRMSE.eval(pred_view, ref.to(dev)), O.vrmse(buf.permute(0, 1, 3, 4, 2), ref), "fp32", scale=3.0)
     # gradient of the train loss MSE(...).mean()
     xx = buf.permute(0, 1, 3, 4, 2).clone().requires_grad_(True)
     O.mse(xx, ref).mean().backward()
@@ -649,7 +649,7 @@ def test_g9_train_step_gradients(dev, mode):
     loss.backward()
     tol = 2e-4 if mode == "fp32" else 4e-2
     assert abs(float(loss) - float(g["loss0"])) < (1e-5 if mode == "fp32" else 2e-3) * float(g["loss0"])
-    close(y_pred, g["y_pred"], mode, scale=3.0)
+    close(y_pred, g["y_pred"], mode)
     worst = 0.0
     for k, p in m.named_parameters():
         assert p.grad is not None, k
@@ -694,8 +694,8 @@ def test_wgrad_linear_with_bias(dev, mode, R, I, J):
     ref, refb = U.float().t() @ V.float(), U.float().sum(0)
     Ud, Vd = U.to(dev), V.to(dev)
     dW, db = wgrad(_rm_linear(Ud), _rm_linear(Vd), R, I, J, (I, J), Kk.COMPUTE[mode], device=dev, with_bias=True)
-    close(dW, ref, mode, scale=2.0)
-    close(db, refb, mode, scale=2.0)
+    close(dW, ref, mode)
+    close(db, refb, mode)
 
 
 def test_wgrad_lines_and_patches(dev):
@@ -1127,7 +1127,7 @@ def test_cvit_grid_embed_sparse_equals_dense(dev):
         e = torch.exp(-eps * d2)
         ref = (e / e.sum(1, keepdim=True)) @ lat
         out = K.grid_embed(coords.to(dev), grid.to(dev), lat.to(dev), eps)
-        close(out, ref, "fp32", scale=3.0)
+        close(out, ref, "fp32")
 
 
 def test_cvit_cfg4_full_size_properties(dev):
@@ -1159,7 +1159,7 @@ def test_cvit_cfg4_full_size_properties(dev):
     xs = torch.randn(2, 4, 4, 64, 32)
     w = {k: v.detach().cpu() for k, v in ms.state_dict().items()}
     with torch.no_grad():
-        close(ms(xs.to(dev)), OC.cvit_forward(w, OC.CvitCfg(4, 4, (64, 32), **kw), xs), "fp32", scale=2.0)
+        close(ms(xs.to(dev)), OC.cvit_forward(w, OC.CvitCfg(4, 4, (64, 32), **kw), xs), "fp32")
 
 
 @pytest.mark.parametrize("nb,nh,Lq,Lk", [(2, 3, 777, 256), (1, 2, 40, 130), (1, 1, 1000, 512), (3, 2, 5, 4), (1, 8, 2048, 256)])
@@ -1207,7 +1207,7 @@ def test_flat_adamw_state_dict_interchanges_with_torch_adamw(dev):
         mdl(x).square().mean().backward()
         o.step()
     for a, b in zip(net.parameters(), ref.parameters()):
-        close(a, b, "fp32", scale=10.0)
+        close(a, b, "fp32")
 
 
 def test_cvit_chunked_query_rollout_equals_full_grid(dev):
@@ -1227,7 +1227,7 @@ def test_cvit_chunked_query_rollout_equals_full_grid(dev):
         f2 = m(torch.cat([x0[:, 4:], f1], 1)[:, -4:])
     want = fmt.process_output(torch.cat([f1, f2], 1))[:, :6]
     assert y.shape == (2, 6, 16, 24, 2) and y_ref.shape == (2, 6, 16, 24, 2)
-    close(y, want, "fp32", scale=5.0)
+    close(y, want, "fp32")
 
 
 def test_fused_encoder_stages_against_oracle_and_unfused(dev):

@@ -187,6 +187,87 @@ def test_dp_shard_and_allreduce_gloo_world2():
         assert t == 2.0                                                          # slowest rank
 
 
+def _dp_grad_worker(rank, world, port, q):
+    """One data-parallel rank on CPU: real gradients (the oracle's autograd on this rank's batch shard of the g9 model) laid out as
+    FlatAdamW's flat bucket, ONE summed all-reduce, 1/world, global-norm clip + AdamW on the bucket."""
+    import os
+    import torch
+    import torch.distributed as dist
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    from tante_amd import dist as D
+    from tante_amd.optim import flat_layout
+    from oracle import tante_oracle as O
+    from conftest import load_golden, split_prefix
+    r, w, _ = D.init("gloo")
+    g = load_golden("g9_trainstep")
+    cfg = O.TanteCfg(4, 2, (16, 16), taylor_order=2, attn_axes="TH-WL", n_head=2, embed_dim=32, patch_scale=8)
+    wts = split_prefix(g, "w0.")
+    names = list(wts.keys())
+    offs, sizes, n = flat_layout([wts[k] for k in names])
+    flat_p = torch.zeros(n)
+    if r == 0:                                       # only rank 0 holds the real weights: the broadcast must deliver them
+        for k, o, sz in zip(names, offs, sizes):
+            flat_p[o:o + sz] = wts[k].reshape(-1)
+    D.broadcast_(flat_p, 0)
+    pw = {k: flat_p[o:o + sz].view(wts[k].shape).clone().requires_grad_(True) for k, o, sz in zip(names, offs, sizes)}
+    batch = D.shard_batch({"input": g["inp"][:2], "output": g["out"][:2]}, r, w)
+    y, y_ref = O.rollout(pw, cfg, batch, 4)
+    loss = O.mse(y, y_ref).mean()
+    grads = torch.autograd.grad(loss, [pw[k] for k in names])
+    flat_g = torch.zeros(n)
+    for gr, o, sz in zip(grads, offs, sizes):
+        flat_g[o:o + sz] = gr.reshape(-1)
+    D.allreduce_sum_(flat_g)                         # the step's one collective
+    flat_g.mul_(1.0 / w)
+    D.barrier()
+    q.put((r, flat_p, flat_g))
+    dist.destroy_process_group()
+
+
+def test_dp_real_gradients_gloo_world2():
+    """SURVEY 8e on CPU: world-2 averaged gradients of real model gradients (oracle autograd per shard, FlatAdamW's bucket layout,
+    one summed all-reduce) == the single-process gradient of the concatenated batch; the parameter broadcast delivers rank 0's
+    weights; clip + AdamW on the reduced bucket gives the same weights as the single process."""
+    import torch.multiprocessing as mp
+    from tante_amd.optim import flat_layout
+    from oracle import tante_oracle as O
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() + 17) % 1000
+    procs = [ctx.Process(target=_dp_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    g = load_golden("g9_trainstep")
+    cfg = O.TanteCfg(4, 2, (16, 16), taylor_order=2, attn_axes="TH-WL", n_head=2, embed_dim=32, patch_scale=8)
+    wts = split_prefix(g, "w0.")
+    names = list(wts.keys())
+    offs, sizes, n = flat_layout([wts[k] for k in names])
+    pw = {k: v.clone().requires_grad_(True) for k, v in wts.items()}
+    y, y_ref = O.rollout(pw, cfg, {"input": g["inp"][:2], "output": g["out"][:2]}, 4)
+    full = torch.autograd.grad(O.mse(y, y_ref).mean(), [pw[k] for k in names])
+    want = torch.zeros(n)
+    for gr, o, sz in zip(full, offs, sizes):
+        want[o:o + sz] = gr.reshape(-1)
+    for r, flat_p, flat_g in res:
+        for k, o, sz in zip(names, offs, sizes):
+            assert torch.equal(flat_p[o:o + sz].view(wts[k].shape), wts[k]), ("broadcast", r, k)
+        assert float((flat_g - want).abs().max()) < 2e-6 * float(want.abs().max()), r
+    assert torch.equal(res[0][2], res[1][2])         # every rank holds the same reduced bucket -> identical optimiser steps
+    # clip + AdamW on the reduced bucket == on the full-batch gradients
+    lr, wd = 5e-3, 1e-2
+    clipped_a, _ = O.clip_grad_norm([res[0][2]], 1.0)
+    clipped_b, _ = O.clip_grad_norm([want], 1.0)
+    z = torch.zeros(n)
+    pa, _, _ = O.adamw_step(res[0][1], clipped_a[0], z.clone(), z.clone(), 1, lr, wd, 0.9, 0.999, 1e-8)
+    pb, _, _ = O.adamw_step(res[0][1], clipped_b[0], z.clone(), z.clone(), 1, lr, wd, 0.9, 0.999, 1e-8)
+    assert float((pa - pb).abs().max()) < 2e-2 * lr      # Adam's first step is sign-like: compare on the update scale, as for g9
+
+
 # ---- harness periphery (SURVEY 8f rank 4) ------------------------------------------------------------------------------------
 def test_lr_scheduler_object_matches_reference_values():
     """LinearWarmupCosineAnnealingLR driving an optimizer-like object: the 35 per-epoch values of fixture g10."""

@@ -125,6 +125,31 @@ def test_g9_train_step():
             assert float((w[k].detach() - g[f"w{step + 1}." + k]).abs().max()) < 2e-2 * lr, k
 
 
+def test_g14_wide_train_step():
+    """Production shape (C = 256, 8 heads x 32, THWTHWTHW, L in {4, 8, 48}, 4-step BPTT): the oracle's loss, every parameter's gradient
+    norm and three full gradient tensors against the reference's."""
+    from conftest import g14_setup, G14_KW, G14_FIELDS, G14_RES
+    m, batch, g, names = g14_setup()
+    cfg = O.TanteCfg(G14_KW["in_T"], G14_FIELDS, G14_RES, taylor_order=1, attn_axes=G14_KW["attn_axes"], n_head=8, embed_dim=256,
+                     patch_scale=8)
+    w = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    for n in names:
+        w[n].requires_grad_(True)
+    y, y_ref = O.rollout(w, cfg, batch, 4)
+    loss = O.mse(y, y_ref).mean()
+    grads = torch.autograd.grad(loss, [w[n] for n in names])
+    assert abs(float(loss.detach()) - float(g["loss"])) < 1e-5 * abs(float(g["loss"]))
+    assert max_rel(y.detach()[:, :, ::8, ::8, :], torch.from_numpy(g["y_pred_slice"])) < 5 * TOL
+    gn = np.array([float(x.double().norm()) for x in grads])
+    bad = [(n, a, b) for n, a, b in zip(names, gn, g["g_norm"]) if abs(a - b) > 2e-4 * b + 1e-12]
+    assert not bad, bad[:5]
+    for n, gr in zip(names, grads):
+        if "g." + n in g:
+            assert max_rel(gr, torch.from_numpy(g["g." + n])) < 2e-4, n
+    total = float(np.sqrt((gn ** 2).sum()))
+    assert abs(total - float(g["gnorm"])) < 1e-4 * float(g["gnorm"])
+
+
 def test_g10_metrics_and_lr():
     g = load_golden("g10_metrics")
     x, y = g["x"], g["y"]
