@@ -167,7 +167,7 @@ def test_data_parallel_gradients_equal_full_batch(dev):
         assert max_rel(p.grad.cpu() * 0.5, q.grad.cpu()) < 2e-5, k
     o_full.step()
     o_dp.step(grad_scale=0.5)
-    assert float((o_dp.flat_p - o_full.flat_p).abs().max()) < 1e-3 * 1e-3      # Adam's first step is ~lr per weight: 1e-3 of that
+    assert float((o_dp.flat_p - o_full.flat_p).abs().max()) < 2e-2 * 1e-3      # Adam's first step is sign-like (|update| ~ lr = 1e-3): the g9 bar
 
 
 def test_backward_failure_does_not_poison_the_next_step(dev, monkeypatch):
