@@ -27,6 +27,7 @@
 
 #include <stdlib.h>
 #include "fused_common.cuh"
+#include "block_sliced.h"
 
 namespace {
 
@@ -733,7 +734,8 @@ void launch_block(float* x, const char* stream, const TanteSeq& sq, int causal, 
 
 }  // namespace
 
-extern "C" int tante_block_fused_supported(int C, int n_head, int hidden, int L) {
+// the round-1 kernels of this file (token-stationary waves, weights streamed through LDS): C in {64, 128, 256}, L | 32
+static int block_ts_supported(int C, int n_head, int hidden, int L) {
   if (n_head <= 0 || C % n_head || C / n_head != 32) return 0;
   if (C != 64 && C != 128 && C != 256) return 0;
   if (hidden != C && hidden != 2 * C) return 0;
@@ -742,11 +744,26 @@ extern "C" int tante_block_fused_supported(int C, int n_head, int hidden, int L)
   return 1;
 }
 
-extern "C" int64_t tante_block_stream_bytes(int C, int hidden) {
+static int64_t block_ts_stream_bytes(int C, int hidden) {
   const long cpr = C / 8, cprh = hidden / 8;
   return (long)(C / 32) * (96 * cpr * 16 + BIAS_BYTES) + (long)(C / 64 + hidden / 64) * (64 * cpr * 16 + BIAS_BYTES) +
          (long)(C / 64) * (64 * cprh * 16 + BIAS_BYTES);
 }
+
+// which kernel family runs a shape: the feature-sliced kernel (block_sliced.hip) wherever it applies (C = 256, 8 heads, hidden 256,
+// any L <= 128); TANTE_BLOCK_KERNEL=16 / 32 forces the round-1 kernels for A/B timing (both compute the same function)
+static bool use_fs(int C, int n_head, int hidden, int L, int causal) {
+  static const int which = getenv("TANTE_BLOCK_KERNEL") ? atoi(getenv("TANTE_BLOCK_KERNEL")) : 0;
+  if (!tante_fs_supported(C, n_head, hidden, L, causal)) return false;
+  return which == 0 || !block_ts_supported(C, n_head, hidden, L);
+}
+
+extern "C" int tante_block_fused_supported(int C, int n_head, int hidden, int L) {
+  return block_ts_supported(C, n_head, hidden, L) || tante_fs_supported(C, n_head, hidden, L, 0);
+}
+
+// the packed block = [round-1 stream | feature-sliced stream] (the second part only for C = 256, hidden 256)
+extern "C" int64_t tante_block_stream_bytes(int C, int hidden) { return block_ts_stream_bytes(C, hidden) + tante_fs_stream_bytes(C, hidden); }
 
 extern "C" int tante_pack_block(const float* ln1_w, const float* ln1_b, const float* in_w, const float* in_b, const float* out_w,
                                 const float* out_b, const float* ln2_w, const float* ln2_b, const float* fc1_w,
@@ -755,10 +772,15 @@ extern "C" int tante_pack_block(const float* ln1_w, const float* ln1_b, const fl
   if (!ln1_w || !ln1_b || !in_w || !in_b || !out_w || !out_b || !ln2_w || !ln2_b || !fc1_w || !fc1_b || !fc2_w || !fc2_b ||
       !block_stream)
     TANTE_FAIL(-1, "tante_pack_block: null pointer");
-  if (!tante_block_fused_supported(C, C / 32, hidden, 32)) TANTE_FAIL(-2, "tante_pack_block: unsupported C=%d hidden=%d", C, hidden);
+  if (!block_ts_supported(C, C / 32, hidden, 32)) TANTE_FAIL(-2, "tante_pack_block: unsupported C=%d hidden=%d", C, hidden);
   hipLaunchKernelGGL(pack_block_stream_kernel, dim3(C / 32 + 2 * (C / 64) + hidden / 64), dim3(256), 0, (hipStream_t)stream, in_w,
                      in_b, ln1_w, ln1_b, out_w, out_b, fc1_w, fc1_b, ln2_w, ln2_b, fc2_w, fc2_b, C, hidden, (char*)block_stream);
   TANTE_CHECK_LAUNCH();
+  if (tante_fs_stream_bytes(C, hidden) > 0) {
+    tante_fs_pack(ln1_w, ln1_b, in_w, in_b, out_w, out_b, ln2_w, ln2_b, fc1_w, fc1_b, fc2_w, fc2_b,
+                  (char*)block_stream + block_ts_stream_bytes(C, hidden), (hipStream_t)stream);
+    TANTE_CHECK_LAUNCH();
+  }
   return 0;
 }
 
@@ -770,6 +792,12 @@ extern "C" int tante_block_fused(float* x, const void* block_stream, int C, int 
   if (((uintptr_t)x % 16) || ((uintptr_t)block_stream % 16)) TANTE_FAIL(-1, "tante_block_fused: buffers must be 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
   const char* st = (const char*)block_stream;
+  if (use_fs(C, n_head, hidden, seq->L, causal)) {
+    if (tante_fs_launch(x, st + block_ts_stream_bytes(C, hidden), *seq, causal, eps, s) != 0)
+      TANTE_FAIL(-2, "tante_block_fused: too many sequences (%d)", seq->nseq);
+    TANTE_CHECK_LAUNCH();
+    return 0;
+  }
   const int key = (C / 32) * 100 + hidden / 32;
   switch (key) {
     case 202: launch_block<2, 2>(x, st, *seq, causal, eps, s); break;

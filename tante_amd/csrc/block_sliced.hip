@@ -1,0 +1,677 @@
+// Fused TransformerBlock (attn_backbone.py:59-83), bf16 path, C = 256 / 8 heads x 32 / hidden 256 -- "feature-sliced" form.
+//
+//   x <- x + Wo . Attention(LayerNorm1(x)) + bo ;   x <- x + W2 . gelu_tanh(W1 . LayerNorm2(x) + b1) + b2
+//
+// One workgroup = 8 waves = up to 128 tokens (whole sequences).  The round-1 kernel (block_fused.hip) gave every wave 16 tokens and
+// all features: each weight fragment was read from LDS by all 8 waves and fed ONE 16-token MFMA, so LDS reads (1 KiB per MFMA and
+// wave) ran as long as the matrix pipe itself and the vector issue port, busy with both, set the time (0.25 of the bf16 peak).
+// Here the roles are turned around: a wave owns a SLICE OF THE OUTPUT FEATURES for all tokens of the workgroup,
+//
+//     QKV + attention : wave h = head h (q, k, v rows of that head, 96 features)
+//     out-proj, fc1, fc2 : wave w = output features 32 w .. 32 w + 31
+//
+// so a wave's weights are its own: they go global/L2 -> registers directly (pre-packed in consumption order, 1 KiB per coalesced
+// load, no LDS, no barrier) and every weight fragment feeds 8 token tiles.  What the waves share are the ACTIVATIONS, as bf16
+// images [token][256] in LDS (XOR-swizzled 16-byte chunks, conflict-free ds_read_b128 fragments): LayerNorm-ed x, the attention
+// output, LayerNorm2-ed x1, the GELU-ed hidden.  One image fragment feeds 2-4 MFMAs instead of 1, a launch has 5 barriers instead
+// of 21, and there is no weight stream through LDS at all.  The fp32 residual slice of a wave (32 features x 128 tokens) rides the
+// out-proj / fc2 accumulators.  Attention operands chain through registers exactly as in round 1 (accumulator pairs packed to bf16
+// ARE the next MFMA's operands): S^T = K Q^T, softmax over accumulator rows, O^T = V^T P^T.
+//
+// Two algebraic savings on the way (both exact): the key bias never reaches the output (it shifts every score of a query by the
+// same amount, softmax removes it), and the value bias commutes with the attention average (rows of P sum to 1), so it is folded
+// into the out-proj bias at pack time:  bo' = bo + Wo . bv.
+#include "common.cuh"
+#include "fused_common.cuh"
+#include "block_sliced.h"
+
+namespace {
+
+constexpr int FS_C = 256;
+constexpr int FS_FRAG = 1024;                              // one wave-wide MFMA operand fragment: 64 lanes x 16 B
+constexpr int FS_W_BYTES = 6 * FS_C * FS_C * 2;               // 768 KiB: q, k, v, Wo, W1, W2 as bf16 fragments
+constexpr int FS_BIAS_FLOATS = 4 * FS_C;                   // q | out' | fc1 | fc2, by output feature
+constexpr int FS_ROW = 512;                                // bytes per token row of an LDS image
+
+struct FsArgs {
+  float* x;
+  const char* w;
+  TanteSeq sq;
+  int causal;
+  float eps;
+  int spw;          // sequences per workgroup
+  unsigned magic;   // ceil(65536 / L): slot / L == (slot * magic) >> 16 for slot < 128
+  int stagger;      // experiment: workgroups of the second half of the grid start this many 64-clock sleeps late
+  unsigned long long* stamps;   // diagnostic builds (-DTANTE_ABLATE) only: per-wave s_memtime at the phase boundaries, else null
+};
+
+// In-kernel stamps (cdna_hip_programming.md 7): a -DTANTE_ABLATE build records the shader clock at every phase boundary of every wave
+// into a buffer of its own (tools/fs_stamps.py reads the phase SHARES from it); in the product build the macro is empty.
+#ifdef TANTE_ABLATE
+#define FS_STAMP(k)                                                                                        \
+  do {                                                                                                     \
+    if (A.stamps) {                                                                                        \
+      unsigned long long t_;                                                                               \
+      __builtin_amdgcn_sched_barrier(0);                                                                   \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                          \
+      __builtin_amdgcn_sched_barrier(0);                                                                   \
+      if (lane == 0) A.stamps[((long)blockIdx.x * 8 + wave) * 20 + (k)] = t_;                               \
+    }                                                                                                      \
+  } while (0)
+unsigned long long* g_fs_stamps = nullptr;
+#else
+#define FS_STAMP(k)
+#endif
+
+// a / n for 0 <= a < 2^23 by the float reciprocal plus one correction each way (an integer division is ~30 VALU instructions and a
+// lane needs two per token; the host checks nseq < 2^23)
+__device__ __forceinline__ void fs_divmod(int a, int n, float rn, int& q, int& r) {
+  q = (int)((float)a * rn);
+  r = a - q * n;
+  if (r >= n) { ++q; r -= n; }
+  if (r < 0) { --q; r += n; }
+}
+struct FsSeqMap {
+  float rs0, rl0;
+  __device__ __forceinline__ explicit FsSeqMap(const TanteSeq& q) : rs0(__builtin_amdgcn_rcpf((float)q.n_s0)), rl0(__builtin_amdgcn_rcpf((float)q.n_l0)) {}
+  __device__ __forceinline__ long token(const TanteSeq& q, int s, int l) const {
+    int a, b, c, d;
+    fs_divmod(s, q.n_s0, rs0, a, b);
+    fs_divmod(l, q.n_l0, rl0, c, d);
+    return (long)a * q.S1 + (long)b * q.S0 + (long)c * q.P1 + (long)d * q.P0;
+  }
+};
+
+__device__ __forceinline__ u32x4 ldg_frag(const char* p) { return *(const u32x4*)p; }
+
+// ---- cross-lane reductions without LDS traffic -------------------------------------------------------------------------------------
+// over the 16 lanes of a row (lanes that share lane >> 4): DPP quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror
+template <int CTRL>
+__device__ __forceinline__ float fs_dpp(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+  v += fs_dpp<0xB1>(v);
+  v += fs_dpp<0x4E>(v);
+  v += fs_dpp<0x141>(v);
+  return v + fs_dpp<0x140>(v);
+}
+// over the four rows of a wave (lanes l15 + 16 kk, i.e. the accumulator rows of one column): v_permlane16_swap exchanges the odd rows of
+// its first operand with the even rows of its second, v_permlane32_swap the upper half of the first with the lower half of the second;
+// fed the same value twice they return the xor-16 / xor-32 partners side by side
+template <class Op>
+__device__ __forceinline__ float rows_reduce(float v, Op op) {
+#ifdef FS_SHFL
+  v = op(v, __shfl_xor(v, 16));
+  return op(v, __shfl_xor(v, 32));
+#else
+  const unsigned u = __float_as_uint(v);
+  auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  v = op(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  const unsigned w = __float_as_uint(v);
+  auto b = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+  return op(__uint_as_float(b[0]), __uint_as_float(b[1]));
+#endif
+}
+__device__ __forceinline__ float rows_max(float v) { return rows_reduce(v, [](float a, float b) { return fmaxf(a, b); }); }
+__device__ __forceinline__ float rows_sum(float v) { return rows_reduce(v, [](float a, float b) { return a + b; }); }
+
+// acc[j][tt] (+)= W[16-row tile j of the wave's 16 RT-row slice][all 256 k] . image[token tile tt], k-step outermost.
+//
+// Weights: the six matrices of the block (q, k, v, Wo, W1, W2) are ONE stream of 48 k-steps per wave (fragment (g, j) at
+// wq + (16 g + j) KiB, g = 8 m + ks), and the register ring `wb` that prefetches it PF k-steps ahead lives for the whole kernel: while
+// a GEMM runs its last k-steps the first fragments of the NEXT matrix are already on their way, across the barriers and the
+// attention / LayerNorm / GELU phases in between, so no GEMM starts by waiting for L2.  Image fragments come through the explicit
+// LDS read ring of mfma_stream (counted lgkmcnt, reads RING fragments ahead of their MFMAs), each feeding all RT row tiles.  All
+// RT x NTT accumulators are live, a matrix's weights never are: that keeps the kernel inside 256 registers at two waves per SIMD.
+// The inline-asm reads and waits carry memory clobbers, so the compiler cannot sink the prefetch loads towards their use (left alone
+// it loads every fragment right in front of its first MFMA and waits for it there).
+// SWAP = false: D[feature][token] = mfma(W, img);  SWAP = true: D[token][feature] = mfma(img, W)  (the V projection).
+constexpr int FS_KSTEPS = 48;
+template <int RT, int PF>
+__device__ __forceinline__ void fs_wring_prime(const char* wq, u32x4 (&wb)[PF + 1][RT]) {
+#pragma unroll
+  for (int p = 0; p < PF; ++p)
+#pragma unroll
+    for (int j = 0; j < RT; ++j) wb[p][j] = ldg_frag(wq + (16 * p + j) * FS_FRAG);
+}
+template <int M, int NTT, int RT, bool SWAP, int PF>
+__device__ __forceinline__ void fs_slice_gemm(const char* wq, u32x4 (&wb)[PF + 1][RT], const char* img, const int (&rdo)[4],
+                                              f32x4 (&acc)[RT][NTT]) {
+  unsigned ab[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) ab[j] = lds_addr(img + rdo[j]);
+  mfma_stream<8 * NTT, 4>(
+      [&](auto ic) {
+        constexpr int i = decltype(ic)::value, ks = i / NTT, tt = i % NTT;
+        return LdsAddr<tt * 8192 + (ks >> 2) * 256>{ab[ks & 3]};
+      },
+      [&](auto ic, const u32x4& tf) {
+        constexpr int i = decltype(ic)::value, ks = i / NTT, tt = i % NTT, g = 8 * M + ks;
+        if constexpr (tt == 0 && g + PF < FS_KSTEPS) {
+#pragma unroll
+          for (int j = 0; j < RT; ++j) wb[(g + PF) % (PF + 1)][j] = ldg_frag(wq + (16 * (g + PF) + j) * FS_FRAG);
+        }
+#pragma unroll
+        for (int j = 0; j < RT; ++j) {
+          if constexpr (SWAP) acc[j][tt] = mfma_bf16(tf, wb[g % (PF + 1)][j], acc[j][tt]);
+          else acc[j][tt] = mfma_bf16(wb[g % (PF + 1)][j], tf, acc[j][tt]);
+        }
+      });
+}
+
+// TPS = token tiles per sequence when sequences are tile-aligned (L = 16 TPS), 1 also for L | 16 (several sequences per tile,
+// block-diagonal mask), 0 = any L <= 16 NTT (every key tile, element masks).  NTT = token tiles per workgroup.  NW = waves per
+// workgroup: 8 (one workgroup per CU, a wave = one head / 32 output features) or 4 (two independent workgroups per CU, a wave = two
+// heads / 64 output features: while one workgroup is in a VALU or memory phase the other one's MFMAs have the matrix pipes).
+template <int TPS, int NTT, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void block_fs_kernel(FsArgs A) {
+  constexpr int RT = 16 / NW;            // 16-row output tiles per wave
+  constexpr int HPW = RT / 2;            // heads per wave
+  constexpr int PF = NW == 8 ? 3 : 2;    // weight k-steps in flight
+  constexpr int IMG = 16 * NTT * FS_ROW;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const bufA = smem;                 // LayerNorm1(x), later LayerNorm2(x1)
+  char* const bufB = smem + IMG;           // attention output, later the GELU-ed hidden
+  char* const stat = smem + 2 * IMG;       // float2 [16 NTT tokens][NW waves]; before that the slot -> token table
+  const int tid = threadIdx.x, lane = tid & 63, kk = lane >> 4, l15 = lane & 15;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float* const x = A.x;
+  const int L = A.sq.L;
+  const int seq0 = blockIdx.x * A.spw;
+  const int nlive = min(A.spw, A.sq.nseq - seq0) * L;     // live token slots of this workgroup (the rest of spw * L is dead)
+  const int nslot = A.spw * L;                            // slots in use by whole sequences (<= 16 NTT)
+
+  const char* const wq = A.w + (RT * wave) * FS_FRAG + lane * 16;   // this wave's row tiles of (matrix 0, k-step 0), this lane's 16 bytes
+  u32x4 wb[PF + 1][RT];                                             // the weight stream's register ring, alive for the whole kernel
+  fs_wring_prime<RT, PF>(wq, wb);
+  // ---- slot -> token index (-1 = dead), once per workgroup: one lane per slot does the two divisions of the axis regrouping ------
+  FS_STAMP(0);
+#ifdef TANTE_ABLATE
+  if (A.stamps && lane == 0) {   // where this wave runs: HW_REG_HW_ID (id 4) and HW_REG_XCC_ID (id 20), and the 100 MHz wall clock
+    A.stamps[((long)blockIdx.x * 8 + wave) * 20 + 16] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+    A.stamps[((long)blockIdx.x * 8 + wave) * 20 + 17] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+    A.stamps[((long)blockIdx.x * 8 + wave) * 20 + 18] = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
+  int* const tokt = (int*)stat;
+  if (tid < 16 * NTT) {
+    const FsSeqMap smap(A.sq);
+    const int s = (int)(((unsigned)tid * A.magic) >> 16), p = tid - s * L;
+    tokt[tid] = tid < nlive ? (int)smap.token(A.sq, seq0 + s, p) : -1;
+  }
+  __syncthreads();
+  FS_STAMP(1);
+  int tokidx[NTT];   // this lane's token of every tile in accumulator layout (column l15 of tile tt)
+#pragma unroll
+  for (int tt = 0; tt < NTT; ++tt) tokidx[tt] = tokt[16 * tt + l15];
+
+  // ================================ phase 0: LayerNorm1 -> bufA ===================================================================
+  // A wave-instruction reads 4 token rows x 256 contiguous bytes; a row's statistics are reduced over the 16 lanes that share it.
+  {
+    constexpr int GPW = 4 * NTT / NW;      // groups of 4 token rows per wave
+    static_assert(GPW * NW == 4 * NTT, "token rows must split evenly over the waves");
+    f32x4 v[GPW][4];
+    bool lv[GPW];
+#pragma unroll
+    for (int i = 0; i < GPW; ++i) {
+      const int ti = tokt[4 * (wave * GPW + i) + kk];
+      lv[i] = ti >= 0;
+      const float* row = x + (long)(lv[i] ? ti : 0) * FS_C;      // dead slots read token 0's row (valid memory) and are zeroed below
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[i][j] = *(const f32x4*)(row + 4 * (l15 + 16 * j));
+    }
+#pragma unroll
+    for (int i = 0; i < GPW; ++i) {
+      float s = 0.f, q = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          s += v[i][j][e];
+          q = fmaf(v[i][j][e], v[i][j][e], q);
+        }
+      s = row16_sum(s);
+      q = row16_sum(q);
+      const float mean = s * (1.0f / FS_C);
+      const float var = fmaxf(q * (1.0f / FS_C) - mean * mean, 0.0f);
+      const float rstd = lv[i] ? rsqrtf(var + A.eps) : 0.0f;
+      const float sh = lv[i] ? -mean * rstd : 0.0f;
+      const int slot = 4 * (wave * GPW + i) + kk, t15 = slot & 15;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        u32x2 o2;
+        o2[0] = pack_bf16x2(fmaf(v[i][j][0], rstd, sh), fmaf(v[i][j][1], rstd, sh));
+        o2[1] = pack_bf16x2(fmaf(v[i][j][2], rstd, sh), fmaf(v[i][j][3], rstd, sh));
+        const int chunk = (l15 >> 1) + 8 * j;
+        *(u32x2*)(bufA + slot * FS_ROW + ((chunk ^ t15) << 4) + (l15 & 1) * 8) = o2;
+      }
+    }
+  }
+
+  // ---- per-lane LDS addressing ----------------------------------------------------------------------------------------------
+  // fragment (tile tt, k-step ks) of an image: lane -> row 16 tt + l15, chunk 4 ks + kk, swizzled by the row:
+  //   byte = tt * 8192 + l15 * 512 + (ks >> 2) * 256 + rdo[ks & 3],   rdo[j] = ((((j ^ (l15 >> 2)) << 2) | (kk ^ (l15 & 3))) << 4)
+  int rdo[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) rdo[j] = l15 * FS_ROW + ((((j ^ (l15 >> 2)) << 2) | (kk ^ (l15 & 3))) << 4);
+  // accumulator tile rt of this wave (features 16 RT w + 16 rt + 4 kk .. +3 of token column l15) -> 8 bytes of row 16 tt + l15
+  int wro[RT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) wro[rt] = l15 * FS_ROW + (((2 * RT * wave + 2 * rt + (kk >> 1)) ^ l15) << 4) + (kk & 1) * 8;
+
+  const float* const bias = (const float*)(A.w + FS_W_BYTES) + 16 * RT * wave + 4 * kk;   // + 256 m + 16 rt: matrix m, row tile rt
+
+  FS_STAMP(2);
+  __syncthreads();
+  FS_STAMP(3);
+
+  // ================================ phase 1: this wave's heads: q, k, v projections + attention -> bufB ==========================
+  const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+  constexpr int NP = (NTT + 1) / 2;
+  u32x4 qf[HPW][NTT], kf[HPW][NTT];
+  u32x4 vtf[HPW][2][NP];   // V^T operand fragments: [head][d tile][pair of key tiles]
+  {
+    f32x4 aq[RT][NTT];   // D[feature 16 j + 4 kk + r][token]
+#pragma unroll
+    for (int j = 0; j < RT; ++j) {
+      const f32x4 bq = *(const f32x4*)(bias + 16 * j);
+#pragma unroll
+      for (int tt = 0; tt < NTT; ++tt) aq[j][tt] = bq;
+    }
+    fs_slice_gemm<0, NTT, RT, false, PF>(wq, wb, bufA, rdo, aq);
+#pragma unroll
+    for (int hh = 0; hh < HPW; ++hh)
+#pragma unroll
+      for (int tt = 0; tt < NTT; ++tt) qf[hh][tt] = pack8(aq[2 * hh][tt], aq[2 * hh + 1][tt]);
+  }
+  FS_STAMP(4);
+  {
+    f32x4 ak[RT][NTT];
+#pragma unroll
+    for (int j = 0; j < RT; ++j)
+#pragma unroll
+      for (int tt = 0; tt < NTT; ++tt) ak[j][tt] = zero4;      // no key bias: it cancels in the softmax
+    fs_slice_gemm<1, NTT, RT, false, PF>(wq, wb, bufA, rdo, ak);
+#pragma unroll
+    for (int hh = 0; hh < HPW; ++hh)
+#pragma unroll
+      for (int tt = 0; tt < NTT; ++tt) kf[hh][tt] = pack8(ak[2 * hh][tt], ak[2 * hh + 1][tt]);
+  }
+  FS_STAMP(5);
+  {
+    f32x4 av[RT][NTT];   // roles swapped:  D[token][d 16 j + l15]
+#pragma unroll
+    for (int j = 0; j < RT; ++j)
+#pragma unroll
+      for (int tt = 0; tt < NTT; ++tt) av[j][tt] = zero4;      // the value bias is folded into the out-proj bias
+    fs_slice_gemm<2, NTT, RT, true, PF>(wq, wb, bufA, rdo, av);
+#pragma unroll
+    for (int hh = 0; hh < HPW; ++hh)
+#pragma unroll
+      for (int p = 0; p < NP; ++p)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+          vtf[hh][dt][p] = (2 * p + 1 < NTT) ? pack8(av[2 * hh + dt][2 * p], av[2 * hh + dt][2 * p + 1]) : pack8(av[2 * hh + dt][2 * p], zero4);
+  }
+  FS_STAMP(6);
+
+  // ---- attention: per head and query tile, S^T = K Q^T over its key tiles, softmax down the accumulator rows, O^T = V^T P^T ----
+  {
+    // TPS == 1: the block-diagonal (and causal) pattern inside a tile is the same for every tile: bit r <-> key row 4 kk + r
+    unsigned allow1 = 0xfu;
+    bool nomask = true;
+    if constexpr (TPS == 1) {
+      allow1 = 0u;
+      const int si = (int)(((unsigned)l15 * A.magic) >> 16), pi = l15 - si * L;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = 4 * kk + r, sj = (int)(((unsigned)j * A.magic) >> 16), pj = j - sj * L;
+        allow1 |= ((sj == si && (!A.causal || pj <= pi)) ? 1u : 0u) << r;
+      }
+      nomask = (L == 16) && !A.causal;
+    }
+    static_for<HPW * NTT>([&](auto hq_c) {
+      constexpr int hh = decltype(hq_c)::value / NTT, qt = decltype(hq_c)::value % NTT;
+      constexpr int k0 = TPS > 0 ? (qt / TPS) * TPS : 0;            // first key tile this query tile can see
+      constexpr int NK = TPS > 0 ? TPS : NTT;
+      f32x4 sc[NK];
+#pragma unroll
+      for (int j = 0; j < NK; ++j) sc[j] = mfma_bf16(kf[hh][k0 + j], qf[hh][qt], zero4);   // rows = keys, column = query
+      unsigned allow[NK];
+      if constexpr (TPS == 0) {
+        const int qs = 16 * qt + l15, si = (int)(((unsigned)qs * A.magic) >> 16), pi = qs - si * L;
+#pragma unroll
+        for (int j = 0; j < NK; ++j) {
+          allow[j] = 0u;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int ksl = 16 * j + 4 * kk + r, sj = (int)(((unsigned)ksl * A.magic) >> 16), pj = ksl - sj * L;
+            allow[j] |= ((sj == si && ksl < nslot && (!A.causal || pj <= pi)) ? 1u : 0u) << r;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < NK; ++j) allow[j] = allow1;
+      }
+      float m = -INFINITY, sum = 0.0f;
+      if (TPS != 0 && nomask) {
+#pragma unroll
+        for (int j = 0; j < NK; ++j) m = fmaxf(m, fmaxf(fmaxf(sc[j][0], sc[j][1]), fmaxf(sc[j][2], sc[j][3])));
+        m = rows_max(m);
+#pragma unroll
+        for (int j = 0; j < NK; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            sc[j][r] = __builtin_amdgcn_exp2f(sc[j][r] - m);
+            sum += sc[j][r];
+          }
+      } else {
+#pragma unroll
+        for (int j = 0; j < NK; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if ((allow[j] >> r) & 1u) m = fmaxf(m, sc[j][r]);
+        m = rows_max(m);
+#pragma unroll
+        for (int j = 0; j < NK; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            sc[j][r] = ((allow[j] >> r) & 1u) ? __builtin_amdgcn_exp2f(sc[j][r] - m) : 0.0f;
+            sum += sc[j][r];
+          }
+      }
+      sum = rows_sum(sum);
+      const float inv = sum > 0.0f ? __builtin_amdgcn_rcpf(sum) : 0.0f;
+      // O^T[d][query] = sum over key-tile pairs; the pairs are the GLOBAL pairs (2 g, 2 g + 1) the V^T fragments were packed in
+      f32x4 o0 = zero4, o1 = zero4;
+      constexpr int g0 = k0 / 2, g1 = (k0 + NK - 1) / 2;
+      static_for<g1 - g0 + 1>([&](auto g_c) {
+        constexpr int g = g0 + decltype(g_c)::value;
+        constexpr int ja = 2 * g - k0, jb = 2 * g + 1 - k0;     // indices into sc[], possibly outside the visible range
+        f32x4 pa = zero4, pb = zero4;
+        if constexpr (ja >= 0 && ja < NK) pa = sc[ja];
+        if constexpr (jb >= 0 && jb < NK) pb = sc[jb];
+        const u32x4 pf = pack8(pa, pb);
+        o0 = mfma_bf16(vtf[hh][0][g], pf, o0);
+        o1 = mfma_bf16(vtf[hh][1][g], pf, o1);
+      });
+      o0 = o0 * inv;
+      o1 = o1 * inv;
+      // this head's 32 output features of the 16 tokens of tile qt -> attention-output image
+      u32x2 w0, w1;
+      w0[0] = pack_bf16x2(o0[0], o0[1]); w0[1] = pack_bf16x2(o0[2], o0[3]);
+      w1[0] = pack_bf16x2(o1[0], o1[1]); w1[1] = pack_bf16x2(o1[2], o1[3]);
+      *(u32x2*)(bufB + qt * 8192 + wro[2 * hh]) = w0;
+      *(u32x2*)(bufB + qt * 8192 + wro[2 * hh + 1]) = w1;
+    });
+  }
+
+  FS_STAMP(7);
+  asm volatile("" ::: "memory");   // keep the residual loads below the attention (they would double its register pressure)
+  // residual slice of this wave: x[token][16 RT w + 16 rt + 4 kk .. +3]; the loads fly while the out-proj GEMM runs
+  f32x4 xr[RT][NTT];
+#pragma unroll
+  for (int tt = 0; tt < NTT; ++tt) {
+    const float* row = x + (long)(tokidx[tt] < 0 ? 0 : tokidx[tt]) * FS_C + 16 * RT * wave + 4 * kk;   // dead: token 0's row, never stored
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) xr[rt][tt] = *(const f32x4*)(row + 16 * rt);
+  }
+  FS_STAMP(8);
+  __syncthreads();
+  FS_STAMP(9);
+
+  // ================================ phase 2: out-proj slice + residual; LayerNorm2 statistics ===================================
+  f32x4 x1[RT][NTT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+    const f32x4 bo = *(const f32x4*)(bias + 256 + 16 * rt);
+#pragma unroll
+    for (int tt = 0; tt < NTT; ++tt) x1[rt][tt] = bo;
+  }
+  fs_slice_gemm<3, NTT, RT, false, PF>(wq, wb, bufB, rdo, x1);
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int tt = 0; tt < NTT; ++tt) x1[rt][tt] += xr[rt][tt];
+  FS_STAMP(10);
+#pragma unroll
+  for (int tt = 0; tt < NTT; ++tt) {
+    float s = 0.f, q = 0.f;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        s += x1[rt][tt][r];
+        q = fmaf(x1[rt][tt][r], x1[rt][tt][r], q);
+      }
+    s = rows_sum(s);
+    q = rows_sum(q);
+    if (kk == 0) *(float2*)(stat + ((16 * tt + l15) * NW + wave) * 8) = make_float2(s, q);
+  }
+  __syncthreads();
+  FS_STAMP(11);
+  // every wave normalises its own feature slice of every token with the full-row statistics, -> bufA (free since phase 1 ended)
+#pragma unroll
+  for (int tt = 0; tt < NTT; ++tt) {
+    const f32x4* sp = (const f32x4*)(stat + (16 * tt + l15) * NW * 8);
+    float s = 0.f, q = 0.f;
+#pragma unroll
+    for (int j = 0; j < NW / 2; ++j) {
+      const f32x4 a = sp[j];
+      s += a[0] + a[2];
+      q += a[1] + a[3];
+    }
+    const float mean = s * (1.0f / FS_C);
+    const float var = fmaxf(q * (1.0f / FS_C) - mean * mean, 0.0f);
+    const float rstd = rsqrtf(var + A.eps);
+    const float sh = -mean * rstd;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      u32x2 o2;
+      o2[0] = pack_bf16x2(fmaf(x1[rt][tt][0], rstd, sh), fmaf(x1[rt][tt][1], rstd, sh));
+      o2[1] = pack_bf16x2(fmaf(x1[rt][tt][2], rstd, sh), fmaf(x1[rt][tt][3], rstd, sh));
+      *(u32x2*)(bufA + tt * 8192 + wro[rt]) = o2;
+    }
+  }
+  __syncthreads();
+  FS_STAMP(12);
+
+  // ================================ phase 3: fc1 slice + GELU -> bufB ============================================================
+  {
+    f32x4 h[RT][NTT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      const f32x4 b1 = *(const f32x4*)(bias + 512 + 16 * rt);
+#pragma unroll
+      for (int tt = 0; tt < NTT; ++tt) h[rt][tt] = b1;
+    }
+    fs_slice_gemm<4, NTT, RT, false, PF>(wq, wb, bufA, rdo, h);
+    FS_STAMP(13);
+#pragma unroll
+    for (int tt = 0; tt < NTT; ++tt)
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        const f32x4 g = gelu_poly4<true>(h[rt][tt]);
+        u32x2 o2;
+        o2[0] = pack_bf16x2(g[0], g[1]);
+        o2[1] = pack_bf16x2(g[2], g[3]);
+        *(u32x2*)(bufB + tt * 8192 + wro[rt]) = o2;
+      }
+  }
+  __syncthreads();
+  FS_STAMP(14);
+
+  // ================================ phase 4: fc2 slice + residual -> x ============================================================
+  {
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      const f32x4 b2 = *(const f32x4*)(bias + 768 + 16 * rt);
+#pragma unroll
+      for (int tt = 0; tt < NTT; ++tt) x1[rt][tt] += b2;
+    }
+    fs_slice_gemm<5, NTT, RT, false, PF>(wq, wb, bufB, rdo, x1);
+    FS_STAMP(15);
+#ifdef TANTE_ABLATE
+    if (A.stamps && lane == 0) A.stamps[((long)blockIdx.x * 8 + wave) * 20 + 19] = __builtin_amdgcn_s_memrealtime();
+#endif
+#pragma unroll
+    for (int tt = 0; tt < NTT; ++tt)
+      if (tokidx[tt] >= 0) {
+        float* row = x + (long)tokidx[tt] * FS_C + 16 * RT * wave + 4 * kk;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) *(f32x4*)(row + 16 * rt) = x1[rt][tt];
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Packing.  Fragment = 64 lanes x 8 bf16; lane (l15, kk) holds  W[row0 + l15][32 ks + 8 kk + 0..7]  (natural k order: every
+// activation operand comes from an LDS image in natural feature order, or from an accumulator pair whose k index is the head
+// dimension on BOTH sides of the product).
+//   f = (m * 8 + ks) * 16 + g :  matrix m = q | k | v rows of W_in (q scaled by log2(e) / sqrt(32)) | Wo | W1 | W2, k-step ks,
+//   rows 16 g .. 16 g + 15 of it.  A wave that owns RT consecutive row tiles finds the RT fragments of a k-step contiguous, whatever
+//   RT is: the same stream serves the 8-wave and the 4-wave kernels.
+// Biases (fp32, 4 x 256 by output feature): q (scaled) | out' = b_out + W_out (b_v + W_v beta1) | fc1 | fc2.
+// LayerNorm gammas are folded into the columns of W_in / W1, the betas into the biases.
+// ------------------------------------------------------------------------------------------------------------------------------
+__global__ void fs_pack_kernel(const float* __restrict__ w_in, const float* __restrict__ b_in, const float* __restrict__ g1,
+                               const float* __restrict__ be1, const float* __restrict__ w_out, const float* __restrict__ b_out,
+                               const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ g2,
+                               const float* __restrict__ be2, const float* __restrict__ w2, const float* __restrict__ b2,
+                               char* __restrict__ dst) {
+  constexpr int C = FS_C;
+  const float qscale = 0.17677669529663687f * 1.44269504088896340736f;  // log2(e) / sqrt(32): the kernel's softmax is exp2
+  const int nfrag = FS_W_BYTES / FS_FRAG;
+  if ((int)blockIdx.x < nfrag / 4) {
+    const int f = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63, l15 = lane & 15, kk = lane >> 4;
+    const int g = f % 16, ks = (f / 16) % 8, m = f / 128;
+    const int row = (m < 3 ? m * C : 0) + 16 * g + l15;
+    const float* src = m < 3 ? w_in : (m == 3 ? w_out : (m == 4 ? w1 : w2));
+    const float* gamma = m < 3 ? g1 : (m == 4 ? g2 : nullptr);
+    const float scale = m == 0 ? qscale : 1.0f;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int k = 32 * ks + 8 * kk + e;
+      float xv = src[(long)row * C + k];
+      if (gamma) xv *= gamma[k];
+      v[e] = xv * scale;
+    }
+    u32x4 o;
+    o[0] = pack_bf16x2(v[0], v[1]); o[1] = pack_bf16x2(v[2], v[3]); o[2] = pack_bf16x2(v[4], v[5]); o[3] = pack_bf16x2(v[6], v[7]);
+    *(u32x4*)(dst + (long)f * FS_FRAG + lane * 16) = o;
+    return;
+  }
+  // last block: the biases.  bv' = b_v + W_v beta1 (256 values), then bo' = b_out + W_out bv'
+  __shared__ float bv[FS_C];
+  const int n = threadIdx.x;   // 256 threads
+  {
+    float s = b_in[2 * C + n];
+    for (int k = 0; k < C; ++k) s += w_in[(long)(2 * C + n) * C + k] * be1[k];
+    bv[n] = s;
+  }
+  __syncthreads();
+  float* bias = (float*)(dst + FS_W_BYTES);
+  {
+    float s = b_in[n];
+    for (int k = 0; k < C; ++k) s += w_in[(long)n * C + k] * be1[k];
+    bias[n] = s * qscale;
+  }
+  {
+    float s = b_out[n];
+    for (int c = 0; c < C; ++c) s += w_out[(long)n * C + c] * bv[c];
+    bias[256 + n] = s;
+  }
+  {
+    float s = b1[n];
+    for (int k = 0; k < C; ++k) s += w1[(long)n * C + k] * be2[k];
+    bias[512 + n] = s;
+  }
+  bias[768 + n] = b2[n];
+}
+
+template <int TPS, int NTT, int NW>
+void fs_launch_t(const FsArgs& A, int nwg, hipStream_t s) {
+  constexpr int LDS = 2 * 16 * NTT * FS_ROW + 16 * NTT * NW * 8;
+  static TantePerDevice attr;
+  attr.once([&] { (void)hipFuncSetAttribute((const void*)block_fs_kernel<TPS, NTT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); });
+  hipLaunchKernelGGL((block_fs_kernel<TPS, NTT, NW>), dim3(nwg), dim3(64 * NW), LDS, s, A);
+}
+
+// waves per workgroup: 4 = two independent 64-token workgroups per CU (sequences up to 64 tokens), 8 = one 128-token workgroup per
+// CU (any L <= 128).  TANTE_FS_WAVES=8 forces the 8-wave form everywhere (A/B timing; both compute the same function).
+int fs_waves(int L) {
+  static const int force8 = getenv("TANTE_FS_WAVES") && atoi(getenv("TANTE_FS_WAVES")) == 8;
+  return (force8 || L > 64) ? 8 : 4;
+}
+
+}  // namespace
+
+#ifdef TANTE_ABLATE
+extern "C" void tante_fs_set_stamps(void* p) { g_fs_stamps = (unsigned long long*)p; }   // (blocks * 8 waves * 16) u64, diagnostic builds only
+#endif
+
+int tante_fs_supported(int C, int n_head, int hidden, int L, int causal) {
+  (void)causal;
+  return C == FS_C && n_head == 8 && hidden == FS_C && L >= 1 && L <= 128;   // (launch also needs nseq < 2^23)
+}
+
+int64_t tante_fs_stream_bytes(int C, int hidden) { return (C == FS_C && hidden == FS_C) ? FS_W_BYTES + FS_BIAS_FLOATS * 4 : 0; }
+
+void tante_fs_pack(const float* ln1_w, const float* ln1_b, const float* in_w, const float* in_b, const float* out_w, const float* out_b,
+                   const float* ln2_w, const float* ln2_b, const float* fc1_w, const float* fc1_b, const float* fc2_w,
+                   const float* fc2_b, char* dst, hipStream_t s) {
+  hipLaunchKernelGGL(fs_pack_kernel, dim3(FS_W_BYTES / FS_FRAG / 4 + 1), dim3(256), 0, s, in_w, in_b, ln1_w, ln1_b, out_w, out_b, fc1_w,
+                     fc1_b, ln2_w, ln2_b, fc2_w, fc2_b, dst);
+}
+
+int tante_fs_launch(float* x, const char* stream, const TanteSeq& sq, int causal, float eps, hipStream_t s) {
+  if (sq.nseq >= (1 << 23)) return -2;
+  FsArgs A;
+  A.x = x; A.w = stream; A.sq = sq; A.causal = causal; A.eps = eps;
+  A.stamps = nullptr;
+  static const int stagger = getenv("TANTE_FS_STAGGER") ? atoi(getenv("TANTE_FS_STAGGER")) : 0;
+  A.stagger = stagger;
+#ifdef TANTE_ABLATE
+  A.stamps = g_fs_stamps;
+#endif
+  const int L = sq.L, nw = fs_waves(L);
+  A.magic = (65536u + (unsigned)L - 1u) / (unsigned)L;
+  // tile-aligned shapes: L | 16 (several sequences per tile), L = 32 / 48 / 64 (2 / 3 / 4 tiles per sequence, non-causal)
+  int tps = 0;
+  if (16 % L == 0) tps = 1;
+  else if (!causal && (L == 32 || L == 48 || L == 64)) tps = L / 16;
+  // token tiles per workgroup: the full size (8 tiles at 8 waves, 4 at 4 waves) or three quarters of it; take the one that needs
+  // fewer rounds of resident workgroups (256 CUs x 1 or 2), then fewer tiles.  L = 48 only fits the three-quarter form.
+  const int full = nw == 8 ? 8 : 4, tq = nw == 8 ? 6 : 3;
+  const long resident = 256L * (8 / nw);
+  auto rounds = [&](int ntt) {
+    const int spw = 16 * ntt / L;
+    const long nwg = (sq.nseq + spw - 1) / spw;
+    return ((nwg + resident - 1) / resident) * ntt;
+  };
+  int ntt = full;
+  if (tps == 3) ntt = tq;
+  else if (tps >= 1 && (16 * tq) % L == 0 && (16 * tq) / L >= 1 && (tps == 1 || tq % tps == 0) && rounds(tq) < rounds(full)) ntt = tq;
+  A.spw = tps ? 16 * ntt / L : (16 * full) / L;
+  const int nwg = (sq.nseq + A.spw - 1) / A.spw;
+  const int key = nw * 100 + tps * 10 + ntt;
+  switch (key) {
+    case 818: fs_launch_t<1, 8, 8>(A, nwg, s); break;
+    case 816: fs_launch_t<1, 6, 8>(A, nwg, s); break;
+    case 828: fs_launch_t<2, 8, 8>(A, nwg, s); break;
+    case 826: fs_launch_t<2, 6, 8>(A, nwg, s); break;
+    case 836: fs_launch_t<3, 6, 8>(A, nwg, s); break;
+    case 848: fs_launch_t<4, 8, 8>(A, nwg, s); break;
+    case 808: fs_launch_t<0, 8, 8>(A, nwg, s); break;
+    case 414: fs_launch_t<1, 4, 4>(A, nwg, s); break;
+    case 413: fs_launch_t<1, 3, 4>(A, nwg, s); break;
+    case 424: fs_launch_t<2, 4, 4>(A, nwg, s); break;
+    case 433: fs_launch_t<3, 3, 4>(A, nwg, s); break;
+    case 444: fs_launch_t<4, 4, 4>(A, nwg, s); break;
+    case 404: fs_launch_t<0, 4, 4>(A, nwg, s); break;
+    default: return -3;
+  }
+  return 0;
+}

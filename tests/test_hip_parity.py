@@ -506,7 +506,15 @@ def test_cfg2_rollout_frame_cache_is_bit_identical(dev, monkeypatch):
 @pytest.mark.parametrize("C,nh,Lq,Bp,causal,ratio", [(256, 8, 32, 5, False, 1.0), (256, 8, 4, 37, True, 1.0), (256, 8, 16, 3, False, 1.0),
                                                       (256, 8, 8, 9, True, 1.0), (256, 8, 1, 70, False, 1.0), (256, 8, 2, 33, True, 1.0),
                                                       (128, 4, 32, 2, False, 2.0), (64, 2, 4, 50, True, 1.0), (64, 2, 32, 3, False, 2.0),
-                                                      (128, 4, 8, 20, False, 1.0), (256, 8, 32, 130, False, 1.0)])
+                                                      (128, 4, 8, 20, False, 1.0), (256, 8, 32, 130, False, 1.0),
+                                                      # shapes only the feature-sliced kernel (block_sliced.hip) takes: sequences of 3 / 4 /
+                                                      # 8 token tiles, lengths that are no multiple or divisor of a tile (element masks),
+                                                      # causal long sequences, ragged last workgroups, the 96-token workgroup form
+                                                      (256, 8, 48, 5, False, 1.0), (256, 8, 48, 512, False, 1.0), (256, 8, 64, 3, False, 1.0),
+                                                      (256, 8, 128, 2, False, 1.0), (256, 8, 12, 23, False, 1.0), (256, 8, 20, 7, True, 1.0),
+                                                      (256, 8, 100, 3, False, 1.0), (256, 8, 32, 7, True, 1.0), (256, 8, 48, 3, True, 1.0),
+                                                      (256, 8, 16, 1536, False, 1.0), (256, 8, 4, 6144, True, 1.0), (256, 8, 32, 771, False, 1.0),
+                                                      (256, 8, 24, 1, False, 1.0), (256, 8, 5, 300, True, 1.0)])
 def test_fused_block(dev, C, nh, Lq, Bp, causal, ratio):
     import tante_amd
     from oracle import tante_oracle as O
