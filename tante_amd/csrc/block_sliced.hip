@@ -128,14 +128,16 @@ __device__ __forceinline__ float rows_sum(float v) { return rows_reduce(v, [](fl
 // it loads every fragment right in front of its first MFMA and waits for it there).
 // SWAP = false: D[feature][token] = mfma(W, img);  SWAP = true: D[token][feature] = mfma(img, W)  (the V projection).
 constexpr int FS_KSTEPS = 48;
-template <int RT, int PF>
+// first PF k-steps of matrix M into the ring (the stream is primed twice per launch: before LayerNorm1 for q | k | v, after the
+// attention for Wo | W1 | W2; in between the GEMMs keep it running across their own boundaries, GEND = where the run ends)
+template <int M, int RT, int PF>
 __device__ __forceinline__ void fs_wring_prime(const char* wq, u32x4 (&wb)[PF + 1][RT]) {
 #pragma unroll
   for (int p = 0; p < PF; ++p)
 #pragma unroll
-    for (int j = 0; j < RT; ++j) wb[p][j] = ldg_frag(wq + (16 * p + j) * FS_FRAG);
+    for (int j = 0; j < RT; ++j) wb[(8 * M + p) % (PF + 1)][j] = ldg_frag(wq + (16 * (8 * M + p) + j) * FS_FRAG);
 }
-template <int M, int NTT, int RT, bool SWAP, int PF>
+template <int M, int GEND, int NTT, int RT, bool SWAP, int PF>
 __device__ __forceinline__ void fs_slice_gemm(const char* wq, u32x4 (&wb)[PF + 1][RT], const char* img, const int (&rdo)[4],
                                               f32x4 (&acc)[RT][NTT]) {
   unsigned ab[4];
@@ -148,7 +150,7 @@ __device__ __forceinline__ void fs_slice_gemm(const char* wq, u32x4 (&wb)[PF + 1
       },
       [&](auto ic, const u32x4& tf) {
         constexpr int i = decltype(ic)::value, ks = i / NTT, tt = i % NTT, g = 8 * M + ks;
-        if constexpr (tt == 0 && g + PF < FS_KSTEPS) {
+        if constexpr (tt == 0 && g + PF < GEND) {
 #pragma unroll
           for (int j = 0; j < RT; ++j) wb[(g + PF) % (PF + 1)][j] = ldg_frag(wq + (16 * (g + PF) + j) * FS_FRAG);
         }
@@ -160,6 +162,14 @@ __device__ __forceinline__ void fs_slice_gemm(const char* wq, u32x4 (&wb)[PF + 1
       });
 }
 
+// largest divisor of ntt that keeps  group x nk  score tiles within 8 (32 accumulator registers)
+constexpr int fs_group(int ntt, int nk) {
+  int g = 1;
+  for (int d = 1; d <= ntt; ++d)
+    if (ntt % d == 0 && d * nk <= 8) g = d;
+  return g;
+}
+
 // TPS = token tiles per sequence when sequences are tile-aligned (L = 16 TPS), 1 also for L | 16 (several sequences per tile,
 // block-diagonal mask), 0 = any L <= 16 NTT (every key tile, element masks).  NTT = token tiles per workgroup.  NW = waves per
 // workgroup: 8 (one workgroup per CU, a wave = one head / 32 output features) or 4 (two independent workgroups per CU, a wave = two
@@ -168,12 +178,19 @@ template <int TPS, int NTT, int NW>
 __global__ __launch_bounds__(64 * NW, 2) void block_fs_kernel(FsArgs A) {
   constexpr int RT = 16 / NW;            // 16-row output tiles per wave
   constexpr int HPW = RT / 2;            // heads per wave
-  constexpr int PF = NW == 8 ? 3 : 2;    // weight k-steps in flight
+#ifndef FS_PF8
+#define FS_PF8 3
+#endif
+#ifndef FS_PF4
+#define FS_PF4 2
+#endif
+  constexpr int PF = NW == 8 ? FS_PF8 : FS_PF4;    // weight k-steps in flight
   constexpr int IMG = 16 * NTT * FS_ROW;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const bufA = smem;                 // LayerNorm1(x), later LayerNorm2(x1)
   char* const bufB = smem + IMG;           // attention output, later the GELU-ed hidden
   char* const stat = smem + 2 * IMG;       // float2 [16 NTT tokens][NW waves]; before that the slot -> token table
+  float* const lbias = (float*)(stat + 16 * NTT * NW * 8);   // the 4 x 256 biases (a global load per GEMM start would expose its latency)
   const int tid = threadIdx.x, lane = tid & 63, kk = lane >> 4, l15 = lane & 15;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   float* const x = A.x;
@@ -183,8 +200,7 @@ __global__ __launch_bounds__(64 * NW, 2) void block_fs_kernel(FsArgs A) {
   const int nslot = A.spw * L;                            // slots in use by whole sequences (<= 16 NTT)
 
   const char* const wq = A.w + (RT * wave) * FS_FRAG + lane * 16;   // this wave's row tiles of (matrix 0, k-step 0), this lane's 16 bytes
-  u32x4 wb[PF + 1][RT];                                             // the weight stream's register ring, alive for the whole kernel
-  fs_wring_prime<RT, PF>(wq, wb);
+  u32x4 wb[PF + 1][RT];                                             // the weight stream's register ring
   // ---- slot -> token index (-1 = dead), once per workgroup: one lane per slot does the two divisions of the axis regrouping ------
   FS_STAMP(0);
 #ifdef TANTE_ABLATE
@@ -200,6 +216,7 @@ __global__ __launch_bounds__(64 * NW, 2) void block_fs_kernel(FsArgs A) {
     const int s = (int)(((unsigned)tid * A.magic) >> 16), p = tid - s * L;
     tokt[tid] = tid < nlive ? (int)smap.token(A.sq, seq0 + s, p) : -1;
   }
+  if (tid < 256) *(f32x4*)(lbias + 4 * tid) = *(const f32x4*)((const float*)(A.w + FS_W_BYTES) + 4 * tid);
   __syncthreads();
   FS_STAMP(1);
   int tokidx[NTT];   // this lane's token of every tile in accumulator layout (column l15 of tile tt)
@@ -221,6 +238,7 @@ __global__ __launch_bounds__(64 * NW, 2) void block_fs_kernel(FsArgs A) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) v[i][j] = *(const f32x4*)(row + 4 * (l15 + 16 * j));
     }
+    fs_wring_prime<0, RT, PF>(wq, wb);     // behind the x rows in the memory queue: LayerNorm1 does not wait for them
 #pragma unroll
     for (int i = 0; i < GPW; ++i) {
       float s = 0.f, q = 0.f;
@@ -260,7 +278,7 @@ __global__ __launch_bounds__(64 * NW, 2) void block_fs_kernel(FsArgs A) {
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) wro[rt] = l15 * FS_ROW + (((2 * RT * wave + 2 * rt + (kk >> 1)) ^ l15) << 4) + (kk & 1) * 8;
 
-  const float* const bias = (const float*)(A.w + FS_W_BYTES) + 16 * RT * wave + 4 * kk;   // + 256 m + 16 rt: matrix m, row tile rt
+  const float* const bias = lbias + 16 * RT * wave + 4 * kk;   // + 256 m + 16 rt: matrix m, row tile rt (in LDS)
 
   FS_STAMP(2);
   __syncthreads();
@@ -279,7 +297,7 @@ __global__ __launch_bounds__(64 * NW, 2) void block_fs_kernel(FsArgs A) {
 #pragma unroll
       for (int tt = 0; tt < NTT; ++tt) aq[j][tt] = bq;
     }
-    fs_slice_gemm<0, NTT, RT, false, PF>(wq, wb, bufA, rdo, aq);
+    fs_slice_gemm<0, 24, NTT, RT, false, PF>(wq, wb, bufA, rdo, aq);
 #pragma unroll
     for (int hh = 0; hh < HPW; ++hh)
 #pragma unroll
@@ -292,7 +310,7 @@ __global__ __launch_bounds__(64 * NW, 2) void block_fs_kernel(FsArgs A) {
     for (int j = 0; j < RT; ++j)
 #pragma unroll
       for (int tt = 0; tt < NTT; ++tt) ak[j][tt] = zero4;      // no key bias: it cancels in the softmax
-    fs_slice_gemm<1, NTT, RT, false, PF>(wq, wb, bufA, rdo, ak);
+    fs_slice_gemm<1, 24, NTT, RT, false, PF>(wq, wb, bufA, rdo, ak);
 #pragma unroll
     for (int hh = 0; hh < HPW; ++hh)
 #pragma unroll
@@ -305,7 +323,7 @@ __global__ __launch_bounds__(64 * NW, 2) void block_fs_kernel(FsArgs A) {
     for (int j = 0; j < RT; ++j)
 #pragma unroll
       for (int tt = 0; tt < NTT; ++tt) av[j][tt] = zero4;      // the value bias is folded into the out-proj bias
-    fs_slice_gemm<2, NTT, RT, true, PF>(wq, wb, bufA, rdo, av);
+    fs_slice_gemm<2, 24, NTT, RT, true, PF>(wq, wb, bufA, rdo, av);
 #pragma unroll
     for (int hh = 0; hh < HPW; ++hh)
 #pragma unroll
@@ -331,79 +349,118 @@ __global__ __launch_bounds__(64 * NW, 2) void block_fs_kernel(FsArgs A) {
       }
       nomask = (L == 16) && !A.causal;
     }
-    static_for<HPW * NTT>([&](auto hq_c) {
-      constexpr int hh = decltype(hq_c)::value / NTT, qt = decltype(hq_c)::value % NTT;
-      constexpr int k0 = TPS > 0 ? (qt / TPS) * TPS : 0;            // first key tile this query tile can see
-      constexpr int NK = TPS > 0 ? TPS : NTT;
-      f32x4 sc[NK];
+    // Staged over ALL query tiles of a head (scores, maxima, exponentials, sums, P V, scale + store): the steps of one tile form a
+    // long dependent chain (MFMA -> max -> cross-lane -> exp -> sum -> cross-lane -> rcp -> pack -> MFMA -> pack -> store); written
+    // tile by tile the wave sits out every latency of it, written stage by stage the NTT chains interleave.
+    constexpr int NK = TPS > 0 ? TPS : NTT;
+    constexpr int QG = fs_group(NTT, NK);        // query tiles staged together: QG x NK score tiles (<= 8, 32 registers) in flight
+    static_for<HPW * (NTT / QG)>([&](auto hg_c) {
+      constexpr int hh = decltype(hg_c)::value / (NTT / QG), q0 = (decltype(hg_c)::value % (NTT / QG)) * QG;
+      f32x4 sc[QG][NK];
+      unsigned allow[QG];      // bit 4 j + r: key row 4 kk + r of visible tile j may be seen by this lane's query of tile q0 + q
+      float mx[QG], sum[QG];
+      static_for<QG>([&](auto qt_c) {
+        constexpr int q = decltype(qt_c)::value, qt = q0 + q;
+        constexpr int k0 = TPS > 0 ? (qt / TPS) * TPS : 0;            // first key tile this query tile can see
 #pragma unroll
-      for (int j = 0; j < NK; ++j) sc[j] = mfma_bf16(kf[hh][k0 + j], qf[hh][qt], zero4);   // rows = keys, column = query
-      unsigned allow[NK];
-      if constexpr (TPS == 0) {
-        const int qs = 16 * qt + l15, si = (int)(((unsigned)qs * A.magic) >> 16), pi = qs - si * L;
+        for (int j = 0; j < NK; ++j) sc[q][j] = mfma_bf16(kf[hh][k0 + j], qf[hh][qt], zero4);   // rows = keys, column = query
+      });
 #pragma unroll
-        for (int j = 0; j < NK; ++j) {
-          allow[j] = 0u;
+      for (int qt = 0; qt < QG; ++qt) {
+        if constexpr (TPS == 0) {
+          const int qs = 16 * (q0 + qt) + l15, si = (int)(((unsigned)qs * A.magic) >> 16), pi = qs - si * L;
+          allow[qt] = 0u;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int ksl = 16 * j + 4 * kk + r, sj = (int)(((unsigned)ksl * A.magic) >> 16), pj = ksl - sj * L;
-            allow[j] |= ((sj == si && ksl < nslot && (!A.causal || pj <= pi)) ? 1u : 0u) << r;
-          }
+          for (int j = 0; j < NK; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int ksl = 16 * j + 4 * kk + r, sj = (int)(((unsigned)ksl * A.magic) >> 16), pj = ksl - sj * L;
+              allow[qt] |= ((sj == si && ksl < nslot && (!A.causal || pj <= pi)) ? 1u : 0u) << (4 * j + r);
+            }
+        } else {
+          allow[qt] = allow1 * 0x11111111u;
+        }
+      }
+      if (TPS != 0 && nomask) {
+#pragma unroll
+        for (int qt = 0; qt < QG; ++qt) {
+          float m = -INFINITY;
+#pragma unroll
+          for (int j = 0; j < NK; ++j) m = fmaxf(m, fmaxf(fmaxf(sc[qt][j][0], sc[qt][j][1]), fmaxf(sc[qt][j][2], sc[qt][j][3])));
+          mx[qt] = m;
         }
       } else {
 #pragma unroll
-        for (int j = 0; j < NK; ++j) allow[j] = allow1;
+        for (int qt = 0; qt < QG; ++qt) {
+          float m = -INFINITY;
+#pragma unroll
+          for (int j = 0; j < NK; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if ((allow[qt] >> (4 * j + r)) & 1u) m = fmaxf(m, sc[qt][j][r]);
+          mx[qt] = m;
+        }
       }
-      float m = -INFINITY, sum = 0.0f;
+#pragma unroll
+      for (int qt = 0; qt < QG; ++qt) mx[qt] = rows_max(mx[qt]);
       if (TPS != 0 && nomask) {
 #pragma unroll
-        for (int j = 0; j < NK; ++j) m = fmaxf(m, fmaxf(fmaxf(sc[j][0], sc[j][1]), fmaxf(sc[j][2], sc[j][3])));
-        m = rows_max(m);
+        for (int qt = 0; qt < QG; ++qt) {
+          float sm = 0.0f;
 #pragma unroll
-        for (int j = 0; j < NK; ++j)
+          for (int j = 0; j < NK; ++j)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            sc[j][r] = __builtin_amdgcn_exp2f(sc[j][r] - m);
-            sum += sc[j][r];
-          }
+            for (int r = 0; r < 4; ++r) {
+              sc[qt][j][r] = __builtin_amdgcn_exp2f(sc[qt][j][r] - mx[qt]);
+              sm += sc[qt][j][r];
+            }
+          sum[qt] = sm;
+        }
       } else {
 #pragma unroll
-        for (int j = 0; j < NK; ++j)
+        for (int qt = 0; qt < QG; ++qt) {
+          float sm = 0.0f;
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if ((allow[j] >> r) & 1u) m = fmaxf(m, sc[j][r]);
-        m = rows_max(m);
+          for (int j = 0; j < NK; ++j)
 #pragma unroll
-        for (int j = 0; j < NK; ++j)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            sc[j][r] = ((allow[j] >> r) & 1u) ? __builtin_amdgcn_exp2f(sc[j][r] - m) : 0.0f;
-            sum += sc[j][r];
-          }
+            for (int r = 0; r < 4; ++r) {
+              sc[qt][j][r] = ((allow[qt] >> (4 * j + r)) & 1u) ? __builtin_amdgcn_exp2f(sc[qt][j][r] - mx[qt]) : 0.0f;
+              sm += sc[qt][j][r];
+            }
+          sum[qt] = sm;
+        }
       }
-      sum = rows_sum(sum);
-      const float inv = sum > 0.0f ? __builtin_amdgcn_rcpf(sum) : 0.0f;
+#pragma unroll
+      for (int qt = 0; qt < QG; ++qt) sum[qt] = rows_sum(sum[qt]);
       // O^T[d][query] = sum over key-tile pairs; the pairs are the GLOBAL pairs (2 g, 2 g + 1) the V^T fragments were packed in
-      f32x4 o0 = zero4, o1 = zero4;
-      constexpr int g0 = k0 / 2, g1 = (k0 + NK - 1) / 2;
-      static_for<g1 - g0 + 1>([&](auto g_c) {
-        constexpr int g = g0 + decltype(g_c)::value;
-        constexpr int ja = 2 * g - k0, jb = 2 * g + 1 - k0;     // indices into sc[], possibly outside the visible range
-        f32x4 pa = zero4, pb = zero4;
-        if constexpr (ja >= 0 && ja < NK) pa = sc[ja];
-        if constexpr (jb >= 0 && jb < NK) pb = sc[jb];
-        const u32x4 pf = pack8(pa, pb);
-        o0 = mfma_bf16(vtf[hh][0][g], pf, o0);
-        o1 = mfma_bf16(vtf[hh][1][g], pf, o1);
+      f32x4 o[QG][2];
+      static_for<QG>([&](auto qt_c) {
+        constexpr int qt = decltype(qt_c)::value;
+        constexpr int k0 = TPS > 0 ? ((q0 + qt) / TPS) * TPS : 0;
+        constexpr int g0 = k0 / 2, g1 = (k0 + NK - 1) / 2;
+        o[qt][0] = o[qt][1] = zero4;
+        static_for<g1 - g0 + 1>([&](auto g_c) {
+          constexpr int g = g0 + decltype(g_c)::value;
+          constexpr int ja = 2 * g - k0, jb = 2 * g + 1 - k0;     // indices into sc[qt][], possibly outside the visible range
+          f32x4 pa = zero4, pb = zero4;
+          if constexpr (ja >= 0 && ja < NK) pa = sc[qt][ja];
+          if constexpr (jb >= 0 && jb < NK) pb = sc[qt][jb];
+          const u32x4 pf = pack8(pa, pb);
+          o[qt][0] = mfma_bf16(vtf[hh][0][g], pf, o[qt][0]);
+          o[qt][1] = mfma_bf16(vtf[hh][1][g], pf, o[qt][1]);
+        });
       });
-      o0 = o0 * inv;
-      o1 = o1 * inv;
-      // this head's 32 output features of the 16 tokens of tile qt -> attention-output image
-      u32x2 w0, w1;
-      w0[0] = pack_bf16x2(o0[0], o0[1]); w0[1] = pack_bf16x2(o0[2], o0[3]);
-      w1[0] = pack_bf16x2(o1[0], o1[1]); w1[1] = pack_bf16x2(o1[2], o1[3]);
-      *(u32x2*)(bufB + qt * 8192 + wro[2 * hh]) = w0;
-      *(u32x2*)(bufB + qt * 8192 + wro[2 * hh + 1]) = w1;
+      // this head's 32 output features of the 16 tokens of each tile -> attention-output image
+#pragma unroll
+      for (int qt = 0; qt < QG; ++qt) {
+        const float inv = sum[qt] > 0.0f ? __builtin_amdgcn_rcpf(sum[qt]) : 0.0f;
+        const f32x4 o0 = o[qt][0] * inv, o1 = o[qt][1] * inv;
+        u32x2 w0, w1;
+        w0[0] = pack_bf16x2(o0[0], o0[1]); w0[1] = pack_bf16x2(o0[2], o0[3]);
+        w1[0] = pack_bf16x2(o1[0], o1[1]); w1[1] = pack_bf16x2(o1[2], o1[3]);
+        *(u32x2*)(bufB + (q0 + qt) * 8192 + wro[2 * hh]) = w0;
+        *(u32x2*)(bufB + (q0 + qt) * 8192 + wro[2 * hh + 1]) = w1;
+      }
     });
   }
 
@@ -417,6 +474,7 @@ __global__ __launch_bounds__(64 * NW, 2) void block_fs_kernel(FsArgs A) {
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) xr[rt][tt] = *(const f32x4*)(row + 16 * rt);
   }
+  fs_wring_prime<3, RT, PF>(wq, wb);
   FS_STAMP(8);
   __syncthreads();
   FS_STAMP(9);
@@ -429,7 +487,7 @@ __global__ __launch_bounds__(64 * NW, 2) void block_fs_kernel(FsArgs A) {
 #pragma unroll
     for (int tt = 0; tt < NTT; ++tt) x1[rt][tt] = bo;
   }
-  fs_slice_gemm<3, NTT, RT, false, PF>(wq, wb, bufB, rdo, x1);
+  fs_slice_gemm<3, 48, NTT, RT, false, PF>(wq, wb, bufB, rdo, x1);
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -486,7 +544,7 @@ __global__ __launch_bounds__(64 * NW, 2) void block_fs_kernel(FsArgs A) {
 #pragma unroll
       for (int tt = 0; tt < NTT; ++tt) h[rt][tt] = b1;
     }
-    fs_slice_gemm<4, NTT, RT, false, PF>(wq, wb, bufA, rdo, h);
+    fs_slice_gemm<4, 48, NTT, RT, false, PF>(wq, wb, bufA, rdo, h);
     FS_STAMP(13);
 #pragma unroll
     for (int tt = 0; tt < NTT; ++tt)
@@ -510,7 +568,7 @@ __global__ __launch_bounds__(64 * NW, 2) void block_fs_kernel(FsArgs A) {
 #pragma unroll
       for (int tt = 0; tt < NTT; ++tt) x1[rt][tt] += b2;
     }
-    fs_slice_gemm<5, NTT, RT, false, PF>(wq, wb, bufB, rdo, x1);
+    fs_slice_gemm<5, 48, NTT, RT, false, PF>(wq, wb, bufB, rdo, x1);
     FS_STAMP(15);
 #ifdef TANTE_ABLATE
     if (A.stamps && lane == 0) A.stamps[((long)blockIdx.x * 8 + wave) * 20 + 19] = __builtin_amdgcn_s_memrealtime();
@@ -593,7 +651,7 @@ __global__ void fs_pack_kernel(const float* __restrict__ w_in, const float* __re
 
 template <int TPS, int NTT, int NW>
 void fs_launch_t(const FsArgs& A, int nwg, hipStream_t s) {
-  constexpr int LDS = 2 * 16 * NTT * FS_ROW + 16 * NTT * NW * 8;
+  constexpr int LDS = 2 * 16 * NTT * FS_ROW + 16 * NTT * NW * 8 + FS_BIAS_FLOATS * 4;
   static TantePerDevice attr;
   attr.once([&] { (void)hipFuncSetAttribute((const void*)block_fs_kernel<TPS, NTT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); });
   hipLaunchKernelGGL((block_fs_kernel<TPS, NTT, NW>), dim3(nwg), dim3(64 * NW), LDS, s, A);
