@@ -189,7 +189,7 @@ __global__ __launch_bounds__(64 * NW, 2) void block_fs_kernel(FsArgs A) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const bufA = smem;                 // LayerNorm1(x), later LayerNorm2(x1)
   char* const bufB = smem + IMG;           // attention output, later the GELU-ed hidden
-  char* const stat = smem + 2 * IMG;       // float2 [16 NTT tokens][NW waves]; before that the slot -> token table
+  char* const stat = smem + 2 * IMG;       // float2 [16 NTT tokens][NW waves]
   float* const lbias = (float*)(stat + 16 * NTT * NW * 8);   // the 4 x 256 biases (a global load per GEMM start would expose its latency)
   const int tid = threadIdx.x, lane = tid & 63, kk = lane >> 4, l15 = lane & 15;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -201,7 +201,8 @@ __global__ __launch_bounds__(64 * NW, 2) void block_fs_kernel(FsArgs A) {
 
   const char* const wq = A.w + (RT * wave) * FS_FRAG + lane * 16;   // this wave's row tiles of (matrix 0, k-step 0), this lane's 16 bytes
   u32x4 wb[PF + 1][RT];                                             // the weight stream's register ring
-  // ---- slot -> token index (-1 = dead), once per workgroup: one lane per slot does the two divisions of the axis regrouping ------
+  // ---- slot -> token index (-1 = dead): every wave works the table out for itself, one or two slots per lane (the two divisions of
+  // the axis regrouping), and hands the entries around with ds_bpermute -- no LDS table, no barrier in front of the first loads ----
   FS_STAMP(0);
 #ifdef TANTE_ABLATE
   if (A.stamps && lane == 0) {   // where this wave runs: HW_REG_HW_ID (id 4) and HW_REG_XCC_ID (id 20), and the 100 MHz wall clock
@@ -210,18 +211,23 @@ __global__ __launch_bounds__(64 * NW, 2) void block_fs_kernel(FsArgs A) {
     A.stamps[((long)blockIdx.x * 8 + wave) * 20 + 18] = __builtin_amdgcn_s_memrealtime();
   }
 #endif
-  int* const tokt = (int*)stat;
-  if (tid < 16 * NTT) {
+  int tslot[2];
+  {
     const FsSeqMap smap(A.sq);
-    const int s = (int)(((unsigned)tid * A.magic) >> 16), p = tid - s * L;
-    tokt[tid] = tid < nlive ? (int)smap.token(A.sq, seq0 + s, p) : -1;
+#pragma unroll
+    for (int h = 0; h < (16 * NTT > 64 ? 2 : 1); ++h) {
+      const int slot = lane + 64 * h;
+      const int s = (int)(((unsigned)slot * A.magic) >> 16), p = slot - s * L;
+      tslot[h] = slot < nlive ? (int)smap.token(A.sq, seq0 + s, p) : -1;
+    }
   }
+  auto tok_of = [&](int slot) { return __shfl(slot < 64 ? tslot[0] : tslot[16 * NTT > 64 ? 1 : 0], slot & 63); };
+  // the 4 x 256 biases go to LDS here; their first reader sits behind barrier 1
   if (tid < 256) *(f32x4*)(lbias + 4 * tid) = *(const f32x4*)((const float*)(A.w + FS_W_BYTES) + 4 * tid);
-  __syncthreads();
   FS_STAMP(1);
   int tokidx[NTT];   // this lane's token of every tile in accumulator layout (column l15 of tile tt)
 #pragma unroll
-  for (int tt = 0; tt < NTT; ++tt) tokidx[tt] = tokt[16 * tt + l15];
+  for (int tt = 0; tt < NTT; ++tt) tokidx[tt] = tok_of(16 * tt + l15);
 
   // ================================ phase 0: LayerNorm1 -> bufA ===================================================================
   // A wave-instruction reads 4 token rows x 256 contiguous bytes; a row's statistics are reduced over the 16 lanes that share it.
@@ -232,7 +238,7 @@ __global__ __launch_bounds__(64 * NW, 2) void block_fs_kernel(FsArgs A) {
     bool lv[GPW];
 #pragma unroll
     for (int i = 0; i < GPW; ++i) {
-      const int ti = tokt[4 * (wave * GPW + i) + kk];
+      const int ti = tok_of(4 * (wave * GPW + i) + kk);
       lv[i] = ti >= 0;
       const float* row = x + (long)(lv[i] ? ti : 0) * FS_C;      // dead slots read token 0's row (valid memory) and are zeroed below
 #pragma unroll
