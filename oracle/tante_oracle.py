@@ -40,19 +40,40 @@ def sub(w: W, prefix: str) -> W:
 # ----------------------------------------------------------------------------------------
 # elementwise helpers
 # ----------------------------------------------------------------------------------------
+# Two spellings of the same arithmetic.  The default writes every operation out (this is what the parity tests check the HIP path
+# against, in fp32 or fp64, with autograd).  FAST swaps the five hottest helpers for torch's fused CPU ops (F.layer_norm, F.gelu,
+# F.linear, scaled_dot_product_attention): same maths, one pass over the data instead of 6-8 -- the written-out form runs ~2x slower
+# than the reference's nn.Module forward on the same host, which would halve the CPU baseline and flatter the GPU/CPU ratio.
+# bench.py's cpu_baseline leg times the FAST form (tools/cpu_reference_time.py holds it to +-10 % of the real reference's time in
+# the build container); tests/test_oracle_golden.py pins BOTH forms to the reference's golden vectors.
+_FAST = False
+
+
+def set_fast(on: bool) -> bool:
+    global _FAST
+    old, _FAST = _FAST, bool(on)
+    return old
+
+
 def gelu_erf(x: Tensor) -> Tensor:
     """nn.GELU() default (exact/erf form): enc_dec_cnn.py:215,260 ; attn_backbone.py:113,116,119."""
+    if _FAST:
+        return F.gelu(x)
     return 0.5 * x * (1.0 + torch.erf(x * (1.0 / math.sqrt(2.0))))
 
 
 def gelu_tanh(x: Tensor) -> Tensor:
     """nn.GELU(approximate='tanh'): attn_backbone.py:54."""
+    if _FAST:
+        return F.gelu(x, approximate="tanh")
     c = math.sqrt(2.0 / math.pi)
     return 0.5 * x * (1.0 + torch.tanh(c * (x + 0.044715 * x * x * x)))
 
 
 def layer_norm(x: Tensor, g: Tensor, b: Tensor, eps: float = 1e-5) -> Tensor:
     """nn.LayerNorm over the last dim, biased variance (attn_backbone.py:47,50)."""
+    if _FAST:
+        return F.layer_norm(x, (x.shape[-1],), g, b, eps)
     mu = x.mean(-1, keepdim=True)
     xc = x - mu
     var = (xc * xc).mean(-1, keepdim=True)
@@ -60,6 +81,8 @@ def layer_norm(x: Tensor, g: Tensor, b: Tensor, eps: float = 1e-5) -> Tensor:
 
 
 def linear(x: Tensor, w: Tensor, b: Optional[Tensor]) -> Tensor:
+    if _FAST:
+        return F.linear(x, w, b)
     y = x @ w.t()
     return y if b is None else y + b
 
@@ -85,6 +108,8 @@ def real_conv2d(x: Tensor, w: Tensor, b: Tensor, P: int, overlap: float) -> Tens
 def _adaptive_avg_pool(y: Tensor, th: int, tw: int) -> Tensor:
     """adaptive_avg_pool2d: output cell i averages input rows floor(i*H/th) .. ceil((i+1)*H/th)-1."""
     H, Wd = y.shape[-2:]
+    if _FAST:
+        return F.adaptive_avg_pool2d(y, (th, tw))     # the reference runs the pool even when it is an identity (enc_dec_cnn.py:99-103): so does the timed form
     if (H, Wd) == (th, tw):
         return y
     rows = []
@@ -201,6 +226,9 @@ def mha_self(w: W, h: Tensor, n_head: int, causal: bool) -> Tensor:
     d = C // n_head
     qkv = linear(h, w["attn.in_proj_weight"], w["attn.in_proj_bias"])
     q, k, v = (t.reshape(Bp, L, n_head, d).transpose(1, 2) for t in qkv.split(C, dim=-1))
+    if _FAST:
+        o = F.scaled_dot_product_attention(q, k, v, is_causal=causal).transpose(1, 2).reshape(Bp, L, C)
+        return linear(o, w["attn.out_proj.weight"], w["attn.out_proj.bias"])
     s = (q @ k.transpose(-1, -2)) * (1.0 / math.sqrt(d))
     if causal:
         blocked = torch.triu(torch.ones(L, L, dtype=torch.bool), diagonal=1)

@@ -147,3 +147,105 @@ class SyntheticDataModule:
             yield {"input": xs[:, :self.n_in], "output": xs[:, self.n_in:]}
 
     val_dataloader = train_dataloader
+
+
+# ---- epoch-level driver: Trainer.train (trainer/trainer.py:234-255) and the Evaler / R_Evaler validation loops ---------------------------
+def validation_loop(model, dataloader, formatter, n_steps_rollout: int, device=None) -> Dict:
+    """Evaler.validation_loop (trainer/evaler.py:186-230), and R_Evaler's (trainer/r_evaler.py:110-177) for an adaptive-dt model
+    (deg=False): per batch a rollout and the four evaluation metrics in the reference's list order [MSE, NNMSE, L2RE, VRMSE]
+    (eval_loss_fn1, fn3, fn2, fn4), then their means and `statistics.variance` over the batches and the mean forward time per batch.
+    The reference reads the wall clock around the rollout without a device sync (evaler.py:127,134), i.e. it times the launches; here
+    the stream is synchronised on both sides, so `forward_time` is completion time.
+    deg=False adds the mean step size r_t, the mean number of model calls per rollout and the five-number summaries of the per-batch
+    NNMSE and r_t (r_evaler.py:160-177)."""
+    import statistics
+    import time
+    from . import metrics as M
+    from .rollout import rollout_adaptive, rollout_model
+    device = device or next(model.parameters()).device
+    was_training = model.training
+    model.eval()
+    adaptive = not getattr(model, "deg", True)
+    seq = [[], [], [], []]
+    times, rt_list, step_list = [], [], []
+    with torch.inference_mode():
+        for batch in dataloader:
+            batch = {"input": batch["input"].to(device), "output": batch["output"][:, :n_steps_rollout].to(device)}
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            if adaptive:
+                y_pred, y_ref, rts = rollout_adaptive(model, batch, formatter, n_steps_rollout, float(n_steps_rollout), per_sample=False)
+            else:
+                y_pred, y_ref = rollout_model(model, batch, formatter, n_steps_rollout)
+            torch.cuda.synchronize(device)
+            times.append(time.perf_counter() - t0)
+            assert y_ref.shape == y_pred.shape, f"Mismatching shapes between reference {y_ref.shape} and prediction {y_pred.shape}"
+            y_ref = y_ref.contiguous()
+            for lst, fn in zip(seq, (M.MSE, M.NNMSE, M.L2RE, M.VRMSE)):
+                lst.append(float(fn.eval(y_pred, y_ref).mean()))
+            if adaptive:
+                rt_list.append(float(rts.float().mean()))
+                step_list.append(int(rts.shape[0]) if rts.dim() > 0 else 1)
+    model.train(was_training)
+    n = max(1, len(times))
+    out = {"validation_loss": [sum(s) / n for s in seq], "metric_names": ["MSE", "NNMSE", "L2RE", "VRMSE"],
+           "variance": [statistics.variance(s) if len(s) > 1 else 0.0 for s in seq], "forward_time": sum(times) / n, "n_batches": len(times)}
+    if adaptive:
+        def five(d):
+            t = torch.tensor(d, dtype=torch.float64)
+            q = torch.quantile(t, torch.tensor([0.0, 0.25, 0.5, 0.75, 1.0], dtype=torch.float64))
+            return dict(zip(("min", "q1", "median", "q3", "max"), (float(v) for v in q)))
+        out.update({"RT": sum(rt_list) / n, "Step": sum(step_list) / n, "summary_error": five(seq[1]), "summary_rt": five(rt_list)})
+    return out
+
+
+def train_one_epoch(model, optimizer, dataloader, formatter, n_steps_output: int, world: int = 1, rt_eps: float = 0.5,
+                    rt_n: float = 2.0) -> float:
+    """Trainer.train_one_epoch (trainer/trainer.py:174-207; R_Trainer's for deg=False, r_trainer.py:135-179): one optimisation step
+    per batch, returns the mean training loss of the epoch (ONE host read at the end instead of the reference's loss.item() per batch)."""
+    from .train import train_step, train_step_adaptive
+    device = next(model.parameters()).device
+    model.train()
+    losses = []
+    for batch in dataloader:
+        batch = {"input": batch["input"].to(device), "output": batch["output"][:, :n_steps_output].contiguous().to(device)}
+        if getattr(model, "deg", True):
+            losses.append(train_step(model, optimizer, batch, formatter, n_steps_output, world))
+        else:
+            losses.append(train_step_adaptive(model, optimizer, batch, formatter, n_steps_output, rt_eps, rt_n, world)[0])
+    return float(torch.stack(losses).mean()) if losses else float("nan")
+
+
+def fit(model, optimizer, datamodule, formatter, max_epoch: int, n_steps_output: int, n_steps_rollout: int, checkpoint_folder: str,
+        lr_scheduler=None, world: int = 1, log=print) -> Dict:
+    """Trainer.train (trainer/trainer.py:234-255): resume from <folder>/recent.pt when it exists (utils.set_ckpt, utils.py:36-47), then per
+    epoch  sampler.set_epoch -> train_one_epoch -> save recent.pt -> validation_loop -> save best.pt on improvement -> scheduler.step.
+    `best` is compared on L2RE (the Trainer's eval_loss_fn, configs/tante.yaml:52-53) and, unlike Trainer (which never updates best_val_loss, trainer.py:254-255, so
+    best.pt is rewritten every epoch), IS updated -- R_Trainer's behaviour (r_trainer.py:228-230).  Only rank 0 writes checkpoints."""
+    import os
+    os.makedirs(checkpoint_folder, exist_ok=True)
+    recent, best = os.path.join(checkpoint_folder, "recent.pt"), os.path.join(checkpoint_folder, "best.pt")
+    state = {"starting_epoch": 1, "starting_val_loss": None, "best_val_loss": None}
+    if os.path.exists(recent):
+        state = load_checkpoint(recent, model, optimizer, lr_scheduler)
+        log(f"resumed from {recent}: starting at epoch {state['starting_epoch']}")
+    val_loss, best_val = state["starting_val_loss"], state["best_val_loss"]
+    history = []
+    rank0 = getattr(datamodule, "rank", 0) == 0
+    for epoch in range(state["starting_epoch"], max_epoch + 1):
+        datamodule.set_epoch(epoch)
+        train_loss = train_one_epoch(model, optimizer, datamodule.train_dataloader(), formatter, n_steps_output, world)
+        if rank0:
+            save_checkpoint(recent, model, optimizer, epoch, val_loss, best_val)
+        val = validation_loop(model, datamodule.val_dataloader(), formatter, n_steps_rollout)
+        val_loss = val["validation_loss"][2]
+        if best_val is None or val_loss < best_val:
+            best_val = val_loss
+            if rank0:
+                save_checkpoint(best, model, optimizer, epoch, val_loss, best_val)
+        if lr_scheduler is not None:
+            lr_scheduler.step()
+        history.append({"epoch": epoch, "train_loss": train_loss, "lr": getattr(optimizer, "lr", None), **val})
+        log(f"epoch {epoch}/{max_epoch}: train loss {train_loss:.6f}  valid {[round(v, 6) for v in val['validation_loss']]}  "
+            f"forward {val['forward_time'] * 1e3:.2f} ms/batch")
+    return {"history": history, "best_val_loss": best_val}

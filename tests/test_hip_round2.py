@@ -280,3 +280,44 @@ def test_cfg3_full_size_against_oracle(dev):
         record_parity(rel_err(d, dref), max_rel(d, dref), dtol, mode, "cfg3 forward, derivative part")
         assert r < tol and mx < 2 * tol, (mode, r, mx)
         assert rel_err(d, dref) < dtol, (mode, rel_err(d, dref))
+
+
+# ---------------------------------------------------------------------------------------------------
+# epoch-level driver (trainer/trainer.py:234-255, trainer/evaler.py:186-230, trainer/r_evaler.py:160-177)
+# ---------------------------------------------------------------------------------------------------
+def test_fit_two_epochs_then_resume(dev, tmp_path):
+    """train_one_epoch -> recent.pt -> validation_loop -> best.pt for two epochs; a fresh model + optimiser resumed from recent.pt and run
+    for the third epoch lands on the same weights as an uninterrupted three-epoch run (same seeds, dropout 0, fp32 compute)."""
+    import tante_amd
+    from tante_amd import harness as H
+    md = tante_amd.TanteMetadata(n_fields=2, spatial_resolution=(32, 32))
+    fmt = tante_amd.DefaultChannelsFirstFormatter(md)
+
+    def make():
+        torch.manual_seed(11)
+        m = tante_amd.TANTE(in_T=4, dset_metadata=md, taylor_order=1, attn_axes="THW", n_head=2, embed_dim=32, patch_scale=8,
+                            dropout=0.0).to(dev).set_compute("fp32")
+        opt = tante_amd.FlatAdamW(m.parameters(), lr=2e-3, weight_decay=1e-2)
+        sch = H.LinearWarmupCosineAnnealingLR(opt, warmup_epochs=1, max_epochs=3, warmup_start_lr=2e-4, eta_min=2e-4)
+        dm = H.SyntheticDataModule(md, batch_size=4, n_steps_input=4, n_steps_output=4, n_samples=8, seed=5)
+        return m, opt, sch, dm
+    m1, o1, s1, d1 = make()
+    full = H.fit(m1, o1, d1, fmt, 3, 2, 4, str(tmp_path / "full"), s1, log=lambda *_: None)
+    assert len(full["history"]) == 3 and all(len(h["validation_loss"]) == 4 and len(h["variance"]) == 4 for h in full["history"])
+    assert full["history"][-1]["forward_time"] > 0 and full["best_val_loss"] is not None
+    assert full["history"][-1]["train_loss"] < full["history"][0]["train_loss"]          # it learns the fixed synthetic set
+    m2, o2, s2, d2 = make()
+    H.fit(m2, o2, d2, fmt, 2, 2, 4, str(tmp_path / "resumed"), s2, log=lambda *_: None)
+    ck = torch.load(str(tmp_path / "resumed" / "recent.pt"), weights_only=False)
+    assert set(ck) == {"epoch", "model_state_dict", "optimizer_state_dit", "validation_loss", "best_validation_loss"} and ck["epoch"] == 2
+    m3, o3, s3, d3 = make()
+    res = H.fit(m3, o3, d3, fmt, 3, 2, 4, str(tmp_path / "resumed"), s3, log=lambda *_: None)      # finds recent.pt, runs epoch 3 only
+    assert [h["epoch"] for h in res["history"]] == [3]
+    for (k, a), b in zip(m3.state_dict().items(), m1.state_dict().values()):
+        assert float((a - b).abs().max()) < 1e-5 * (1 + float(b.abs().max())), k
+    # adaptive-dt model: the R_Evaler extras
+    torch.manual_seed(12)
+    mr = tante_amd.TANTE(in_T=4, dset_metadata=md, taylor_order=2, attn_axes="TH-TW", n_head=2, embed_dim=32, patch_scale=8,
+                         dropout=0.0, deg=False).to(dev).set_compute("fp32")
+    v = H.validation_loop(mr, d1.val_dataloader(), fmt, 4)
+    assert {"RT", "Step", "summary_error", "summary_rt"} <= set(v) and 1.0 <= v["RT"] <= 4.01 and 1 <= v["Step"] <= 4

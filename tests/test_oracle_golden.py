@@ -125,6 +125,26 @@ def test_g9_train_step():
             assert float((w[k].detach() - g[f"w{step + 1}." + k]).abs().max()) < 2e-2 * lr, k
 
 
+def test_fast_form_of_the_oracle_is_pinned_too():
+    """bench.py's cpu_baseline leg times the oracle with torch's fused CPU ops switched in (O.set_fast: F.layer_norm, F.gelu, F.linear,
+    scaled_dot_product_attention, the always-run adaptive pool) so that it costs what the reference's forward costs; that spelling is
+    held to the same golden vectors: cfg1 end to end, causal and long blocks, the encoder/decoder pair."""
+    old = O.set_fast(True)
+    try:
+        g = load_golden("g1_tante_tiny")
+        cfg = O.TanteCfg(4, 1, (64, 64), taylor_order=2, attn_axes="TL-TL", n_head=4, embed_dim=64, patch_scale=8)
+        assert max_rel(O.tante_forward(split_prefix(g, "w."), cfg, g["x"]), g["y"]) < TOL
+        for name, nh, causal in (("g3_block_c64_L4_causal", 4, True), ("g3_block_c256_L32", 8, False), ("g3_block_c64_L48", 4, False)):
+            g = load_golden(name)
+            assert max_rel(O.transformer_block(split_prefix(g, "w."), g["x"], nh, causal), g["y"]) < TOL, name
+        g = load_golden("g8_rollout_ol1_n8")
+        cfg = O.TanteCfg(4, 2, (16, 16), taylor_order=2, output_length=1, attn_axes="T-L", n_head=2, embed_dim=32, patch_scale=8)
+        y, _ = O.rollout(split_prefix(g, "w."), cfg, {"input": g["inp"], "output": g["out"]}, 8)
+        assert max_rel(y, g["y_eval"]) < 5 * TOL
+    finally:
+        O.set_fast(old)
+
+
 def test_g14_wide_train_step():
     """Production shape (C = 256, 8 heads x 32, THWTHWTHW, L in {4, 8, 48}, 4-step BPTT): the oracle's loss, every parameter's gradient
     norm and three full gradient tensors against the reference's."""
