@@ -319,7 +319,7 @@ def main():
                           attn_axes=mk.get("attn_axes", "THWTHWTHW"), n_head=mk.get("n_head", 8), mlp_ratio=mk.get("mlp_ratio", 1.0),
                           embed_dim=mk.get("embed_dim", 256), patch_scale=mk.get("patch_scale", 32),
                           **({"enc_dec_type": "fno", "modes1": mk.get("modes1", 32), "modes2": mk.get("modes2", 32)} if kind == "tante_fno" else {}))
-        w = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+        w = {k: (v.detach().cpu() if v.is_complex() else v.detach().float().cpu()) for k, v in model.state_dict().items()}
         # the GPU box gives one job a share of the host (16 cores per GPU), whatever os.cpu_count() says
         cores = min(len(os.sched_getaffinity(0)), int(os.environ.get("TANTE_CPU_THREADS", "16")))
         torch.set_num_threads(cores)
