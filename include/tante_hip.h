@@ -210,6 +210,29 @@ int tante_pack_block(const float* ln1_w, const float* ln1_b, const float* in_w, 
 int tante_block_fused(float* x, const void* block_stream, int C, int n_head, int hidden, const TanteSeq* seq, int causal,
                       float eps, void* stream);
 
+/* Training forward of a whole TransformerBlock in ONE launch (C = 256, 8 heads, hidden 256, sequences up to 64 tokens): the same
+ * arithmetic as tante_block_fused with dropout (attn_backbone.py:47-83 in train() mode: attention-probability dropout inside
+ * nn.MultiheadAttention, nn.Dropout on both residual branches) and every tensor the backward pass of the unfused operators reads,
+ * stored in THEIR layouts, so that tante_layernorm_bwd / tante_attention_bwd / the data- and weight-gradient GEMMs run unchanged:
+ *   xh1, xh2 (tokens, 256) bf16  LayerNorm outputs (no affine: gamma / beta are folded into the consumer weights)
+ *   st1, st2 (tokens, 2) fp32    (mean, rstd) per token
+ *   qkv (tokens, 768) bf16       packed projection, q NOT scaled, biases included
+ *   o (tokens, 256) bf16         attention output (after probability dropout)
+ *   x1 (tokens, 256) fp32        x + dropout(out_proj(o))
+ *   hpre, act (tokens, 256) bf16 fc1 pre-activation and its tanh-GELU
+ *   out (tokens, 256) fp32       x1 + dropout(fc2(act))   (x itself is left untouched)
+ * Masks are dropout_keep(seed, index, p) with tante_attention_dropout's index for seed_attn and row * 256 + column (the GEMM
+ * epilogue's, tante_dropout_bwd's) for seed_out / seed_mlp. */
+typedef struct TanteBlockTrain {
+  float* out;
+  void *xh1, *qkv, *o, *xh2, *hpre, *act;
+  float *st1, *x1, *st2;
+  float p_drop;
+  uint64_t seed_attn, seed_out, seed_mlp;
+} TanteBlockTrain;
+int tante_block_fused_train(const float* x, const void* block_stream, int C, int n_head, int hidden, const TanteSeq* seq, int causal,
+                            float eps, const TanteBlockTrain* tr, void* stream);
+
 /* ---- fused derivative head (bf16 MFMA path) ----------------------------------------------------------
  * One launch per Taylor order: rows r = (img, hp, wp) of the token stream (gathered like TANTE_A_LINEAR: the last time slot by
  * stride) -> 3 x [ConvTranspose2d k = s = 2 (+GELU erf)] -> for i < n_out:  out_i (+)= coefs[i] * derivative, where out_i is frame i

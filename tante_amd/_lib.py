@@ -44,6 +44,12 @@ class Seq(C.Structure):
                 ("n_l0", c_i32), ("P1", c_i64), ("P0", c_i64)]
 
 
+class BlockTrain(C.Structure):
+    _fields_ = [("out", c_vp), ("xh1", c_vp), ("qkv", c_vp), ("o", c_vp), ("xh2", c_vp), ("hpre", c_vp), ("act", c_vp),
+                ("st1", c_vp), ("x1", c_vp), ("st2", c_vp), ("p_drop", c_f32), ("seed_attn", C.c_uint64), ("seed_out", C.c_uint64),
+                ("seed_mlp", C.c_uint64)]
+
+
 SIGNATURES = {
     "tante_pack_geom": ([c_i32, c_i32, c_i32, C.POINTER(PackGeom)], c_i32),
     "tante_pack_weight": ([c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp], c_i32),
@@ -63,6 +69,7 @@ SIGNATURES = {
     "tante_block_stream_bytes": ([c_i32, c_i32], c_i64),
     "tante_pack_block": ([c_vp] * 12 + [c_i32, c_i32, c_vp, c_vp], c_i32),
     "tante_block_fused": ([c_vp, c_vp, c_i32, c_i32, c_i32, C.POINTER(Seq), c_i32, c_f32, c_vp], c_i32),
+    "tante_block_fused_train": ([c_vp, c_vp, c_i32, c_i32, c_i32, C.POINTER(Seq), c_i32, c_f32, C.POINTER(BlockTrain), c_vp], c_i32),
     "tante_head_fused_supported": ([c_i32, c_i32], c_i32),
     "tante_head_stream_bytes": ([c_i32], c_i64),
     "tante_pack_head": ([c_vp] * 6 + [c_i32, c_i32, c_vp, c_vp], c_i32),

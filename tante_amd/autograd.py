@@ -323,11 +323,17 @@ class LayerNormSkipFn(Function):
     dx (its `dskip` operand) -- otherwise autograd sums the two with a stand-alone elementwise add over the residual stream per LayerNorm."""
 
     @staticmethod
-    def forward(ctx, x, eps, out_dtype):
+    def forward(ctx, x, eps, out_dtype, pre=None):
+        """pre = (xh, stats) already computed by the fused training-forward kernel (tante_block_fused_train): nothing is launched, the
+        node only records what its backward reads.  The same convention holds for LinearFn / AttentionFn / BranchOutFn below: the fused
+        forward produces every intermediate in one launch and the autograd graph -- hence the whole backward pass -- stays the unfused one."""
         M, Cc = x.shape
-        xh = torch.empty(M, Cc, dtype=out_dtype, device=x.device)
-        st = torch.empty(M, 2, dtype=torch.float32, device=x.device)
-        L.check(L.lib().tante_layernorm_fwd(x.data_ptr(), M, Cc, eps, xh.data_ptr(), _DT[out_dtype], st.data_ptr(), _s()), "ln_fwd")
+        if pre is not None:
+            xh, st = pre
+        else:
+            xh = torch.empty(M, Cc, dtype=out_dtype, device=x.device)
+            st = torch.empty(M, 2, dtype=torch.float32, device=x.device)
+            L.check(L.lib().tante_layernorm_fwd(x.data_ptr(), M, Cc, eps, xh.data_ptr(), _DT[out_dtype], st.data_ptr(), _s()), "ln_fwd")
         ctx.save_for_backward(x, st)
         return xh, x.view(M, Cc)
 
@@ -335,24 +341,26 @@ class LayerNormSkipFn(Function):
     def backward(ctx, g, gskip):
         x, st = ctx.saved_tensors
         if g is None:
-            return gskip, None, None
+            return gskip, None, None, None
         g = g.contiguous()
         if gskip is not None and (gskip.dtype != torch.float32 or not gskip.is_contiguous()):
             gskip = gskip.float().contiguous()
         dx = torch.empty_like(x)
         L.check(L.lib().tante_layernorm_bwd(g.data_ptr(), _DT[g.dtype], x.data_ptr(), st.data_ptr(), None if gskip is None else gskip.data_ptr(),
                                             x.shape[0], x.shape[1], dx.data_ptr(), _s()), "ln_bwd")
-        return dx, None, None
+        return dx, None, None, None
 
 
 class LinearFn(Function):
     """y = a @ W^T + b (+ residual).  a (M, K) fp32 / bf16, W (N, K) fp32 master, y in out_dtype (fp32 when a residual is added)."""
 
     @staticmethod
-    def forward(ctx, a, W, b, residual, compute, out_dtype):
+    def forward(ctx, a, W, b, residual, compute, out_dtype, pre=None):
         M, Kk = a.shape
         N = W.shape[0]
-        if Kk <= 512:
+        if pre is not None:
+            out = pre
+        elif Kk <= 512:
             pw = _packed(W, b, compute)
             out = torch.empty(M, N, dtype=torch.float32 if residual is not None else out_dtype, device=a.device)
             K.linear(a, pw, out, M=M, residual=residual)
@@ -416,7 +424,7 @@ class LinearFn(Function):
                     db = None
         elif ctx.has_bias and ctx.needs_input_grad[2]:
             db = colsum(dy, M, N, 1)
-        return da, dW, db, dres, None, None
+        return da, dW, db, dres, None, None, None
 
 
 class BranchOutFn(Function):
@@ -425,10 +433,17 @@ class BranchOutFn(Function):
     passes over the token matrix: the dropout + skip add forward (tante_dropout_add) and the activation backward (tante_act_bwd)."""
 
     @staticmethod
-    def forward(ctx, pre, W, b, res, act, p, compute):
+    def forward(ctx, pre, W, b, res, act, p, compute, done=None):
         M, Kk = pre.shape
         N = W.shape[0]
         adt = K.act_torch_dtype(compute)
+        if done is not None:                  # (out, act(pre) or None, dropout seed) from the fused training-forward kernel
+            out, a, seed = done
+            a = pre if a is None else a
+            ctx.save_for_backward(pre, a, W)
+            ctx.act, ctx.p, ctx.seed, ctx.compute, ctx.has_bias = act, float(p), seed, compute, b is not None
+            ctx.params = (W, b)
+            return out
         if act != L.ACT_NONE:
             a = torch.empty(M, Kk, dtype=adt, device=pre.device)
             L.check(L.lib().tante_act_fwd(pre.data_ptr(), _DT[pre.dtype], a.data_ptr(), _DT[adt], pre.numel(), act, _s()), "act_fwd")
@@ -509,7 +524,7 @@ class BranchOutFn(Function):
                     db = None
         elif ctx.has_bias and ctx.needs_input_grad[2]:
             db = colsum(dy, M, N, 1)
-        return dpre, dW, db, dout, None, None, None
+        return dpre, dW, db, dout, None, None, None, None
 
 
 class ActFn(Function):
@@ -546,7 +561,12 @@ class AttentionFn(Function):
     """o = dropout_p(softmax(q k^T / sqrt(d) [+causal])) v per (sequence, head) on the packed (tokens, 3C) projection."""
 
     @staticmethod
-    def forward(ctx, qkv, seq, Cc, n_head, causal, p_drop=0.0):
+    def forward(ctx, qkv, seq, Cc, n_head, causal, p_drop=0.0, done=None):
+        if done is not None:                  # (o, dropout seed) from the fused training-forward kernel
+            o, seed = done
+            ctx.save_for_backward(qkv)
+            ctx.seq, ctx.C, ctx.nh, ctx.causal, ctx.p, ctx.seed = seq, Cc, n_head, causal, float(p_drop), seed
+            return o
         o = torch.empty(qkv.shape[0], Cc, dtype=qkv.dtype, device=qkv.device)
         seed = next_seed() if p_drop > 0 else 0
         if p_drop > 0:
@@ -565,7 +585,7 @@ class AttentionFn(Function):
         dqkv = torch.empty_like(qkv)
         L.check(L.lib().tante_attention_bwd(qkv.data_ptr(), do.data_ptr(), dqkv.data_ptr(), _DT[qkv.dtype], ctx.C, ctx.nh, C.byref(ctx.seq),
                                             int(ctx.causal), ctx.p, ctx.seed, _s()), "attention_bwd")
-        return dqkv, None, None, None, None, None
+        return dqkv, None, None, None, None, None, None
 
 
 class DropoutAddFn(Function):

@@ -810,3 +810,18 @@ extern "C" int tante_block_fused(float* x, const void* block_stream, int C, int 
   TANTE_CHECK_LAUNCH();
   return 0;
 }
+
+extern "C" int tante_block_fused_train(const float* x, const void* block_stream, int C, int n_head, int hidden, const TanteSeq* seq, int causal,
+                                       float eps, const TanteBlockTrain* tr, void* stream) {
+  if (!x || !block_stream || !seq || !tr || !tr->out || !tr->xh1 || !tr->qkv || !tr->o || !tr->xh2 || !tr->hpre || !tr->act || !tr->st1 ||
+      !tr->x1 || !tr->st2)
+    TANTE_FAIL(-1, "tante_block_fused_train: null pointer");
+  if (!tante_fs_supported(C, n_head, hidden, seq->L, causal) || seq->L > 64)
+    TANTE_FAIL(-2, "tante_block_fused_train: unsupported shape C=%d heads=%d hidden=%d L=%d", C, n_head, hidden, seq->L);
+  if (tr->p_drop < 0.0f || tr->p_drop >= 1.0f) TANTE_FAIL(-1, "tante_block_fused_train: dropout probability %f", (double)tr->p_drop);
+  const char* st = (const char*)block_stream + block_ts_stream_bytes(C, hidden);
+  if (tante_fs_launch((float*)x, st, *seq, causal, eps, (hipStream_t)stream, tr) != 0)
+    TANTE_FAIL(-2, "tante_block_fused_train: launch refused (L=%d, %d sequences)", seq->L, seq->nseq);
+  TANTE_CHECK_LAUNCH();
+  return 0;
+}

@@ -30,7 +30,7 @@ namespace {
 constexpr int FS_C = 256;
 constexpr int FS_FRAG = 1024;                              // one wave-wide MFMA operand fragment: 64 lanes x 16 B
 constexpr int FS_W_BYTES = 6 * FS_C * FS_C * 2;               // 768 KiB: q, k, v, Wo, W1, W2 as bf16 fragments
-constexpr int FS_BIAS_FLOATS = 4 * FS_C;                   // q | out' | fc1 | fc2, by output feature
+constexpr int FS_BIAS_FLOATS = 7 * FS_C;                   // by output feature: q | out' (folded) | fc1 | fc2 | k | v | out (plain)
 constexpr int FS_ROW = 512;                                // bytes per token row of an LDS image
 
 struct FsArgs {
@@ -41,7 +41,16 @@ struct FsArgs {
   float eps;
   int spw;          // sequences per workgroup
   unsigned magic;   // ceil(65536 / L): slot / L == (slot * magic) >> 16 for slot < 128
-  int stagger;      // experiment: workgroups of the second half of the grid start this many 64-clock sleeps late
+  // training forward (block_fs_kernel<..., TRAIN = true>): the block's output goes to `out` (x stays intact: LayerNorm's backward needs
+  // it) and everything the backward pass reads is stored on the way, dense (tokens, features) rows in the layouts of the unfused ops
+  // (autograd.py): LayerNorm outputs + (mean, rstd), the packed q | k | v projection (q NOT pre-scaled, biases included), the
+  // attention output, the residual after the attention half, fc1's pre-activation and its GELU.  Dropout masks are
+  // dropout_keep(seed, index, p) with the indices of tante_attention_dropout / the GEMM epilogue / tante_dropout_bwd.
+  float* out;
+  unsigned short *xh1, *qkv, *o, *xh2, *hpre, *act;
+  float *st1, *x1, *st2;
+  float p_drop;
+  unsigned long long seed_attn, seed_out, seed_mlp;
   unsigned long long* stamps;   // diagnostic builds (-DTANTE_ABLATE) only: per-wave s_memtime at the phase boundaries, else null
 };
 
@@ -174,7 +183,7 @@ constexpr int fs_group(int ntt, int nk) {
 // block-diagonal mask), 0 = any L <= 16 NTT (every key tile, element masks).  NTT = token tiles per workgroup.  NW = waves per
 // workgroup: 8 (one workgroup per CU, a wave = one head / 32 output features) or 4 (two independent workgroups per CU, a wave = two
 // heads / 64 output features: while one workgroup is in a VALU or memory phase the other one's MFMAs have the matrix pipes).
-template <int TPS, int NTT, int NW>
+template <int TPS, int NTT, int NW, bool TRAIN>
 __global__ __launch_bounds__(64 * NW, 2) void block_fs_kernel(FsArgs A) {
   constexpr int RT = 16 / NW;            // 16-row output tiles per wave
   constexpr int HPW = RT / 2;            // heads per wave
@@ -223,7 +232,7 @@ __global__ __launch_bounds__(64 * NW, 2) void block_fs_kernel(FsArgs A) {
   }
   auto tok_of = [&](int slot) { return __shfl(slot < 64 ? tslot[0] : tslot[16 * NTT > 64 ? 1 : 0], slot & 63); };
   // the 4 x 256 biases go to LDS here; their first reader sits behind barrier 1
-  if (tid < 256) *(f32x4*)(lbias + 4 * tid) = *(const f32x4*)((const float*)(A.w + FS_W_BYTES) + 4 * tid);
+  for (int i = tid; i < FS_BIAS_FLOATS / 4; i += 64 * NW) *(f32x4*)(lbias + 4 * i) = *(const f32x4*)((const float*)(A.w + FS_W_BYTES) + 4 * i);
   FS_STAMP(1);
   int tokidx[NTT];   // this lane's token of every tile in accumulator layout (column l15 of tile tt)
 #pragma unroll
@@ -236,9 +245,10 @@ __global__ __launch_bounds__(64 * NW, 2) void block_fs_kernel(FsArgs A) {
     static_assert(GPW * NW == 4 * NTT, "token rows must split evenly over the waves");
     f32x4 v[GPW][4];
     bool lv[GPW];
+    int tis[GPW];
 #pragma unroll
     for (int i = 0; i < GPW; ++i) {
-      const int ti = tok_of(4 * (wave * GPW + i) + kk);
+      const int ti = tis[i] = tok_of(4 * (wave * GPW + i) + kk);
       lv[i] = ti >= 0;
       const float* row = x + (long)(lv[i] ? ti : 0) * FS_C;      // dead slots read token 0's row (valid memory) and are zeroed below
 #pragma unroll
@@ -269,6 +279,12 @@ __global__ __launch_bounds__(64 * NW, 2) void block_fs_kernel(FsArgs A) {
         o2[1] = pack_bf16x2(fmaf(v[i][j][2], rstd, sh), fmaf(v[i][j][3], rstd, sh));
         const int chunk = (l15 >> 1) + 8 * j;
         *(u32x2*)(bufA + slot * FS_ROW + ((chunk ^ t15) << 4) + (l15 & 1) * 8) = o2;
+        if constexpr (TRAIN) {
+          if (lv[i]) *(u32x2*)(A.xh1 + (long)tis[i] * FS_C + 4 * (l15 + 16 * j)) = o2;
+        }
+      }
+      if constexpr (TRAIN) {
+        if (lv[i] && l15 == 0) *(float2*)(A.st1 + 2 * (long)tis[i]) = make_float2(mean, rstd);
       }
     }
   }
@@ -308,28 +324,76 @@ __global__ __launch_bounds__(64 * NW, 2) void block_fs_kernel(FsArgs A) {
     for (int hh = 0; hh < HPW; ++hh)
 #pragma unroll
       for (int tt = 0; tt < NTT; ++tt) qf[hh][tt] = pack8(aq[2 * hh][tt], aq[2 * hh + 1][tt]);
+    if constexpr (TRAIN) {   // the packed projection the attention backward reads holds q WITHOUT the softmax scale folded into Wq
+      const float unscale = 1.0f / (0.17677669529663687f * 1.44269504088896340736f);
+#pragma unroll
+      for (int tt = 0; tt < NTT; ++tt)
+        if (tokidx[tt] >= 0) {
+#pragma unroll
+          for (int j = 0; j < RT; ++j) {
+            const f32x4 qv = aq[j][tt] * unscale;
+            u32x2 u;
+            u[0] = pack_bf16x2(qv[0], qv[1]); u[1] = pack_bf16x2(qv[2], qv[3]);
+            *(u32x2*)(A.qkv + (long)tokidx[tt] * (3 * FS_C) + 16 * RT * wave + 16 * j + 4 * kk) = u;
+          }
+        }
+    }
   }
   FS_STAMP(4);
   {
     f32x4 ak[RT][NTT];
 #pragma unroll
-    for (int j = 0; j < RT; ++j)
+    for (int j = 0; j < RT; ++j) {
+      // inference: no key bias, it cancels in the softmax; training keeps it so that the saved k is the unfused path's
+      const f32x4 bk = TRAIN ? *(const f32x4*)(bias + 1024 + 16 * j) : zero4;
 #pragma unroll
-      for (int tt = 0; tt < NTT; ++tt) ak[j][tt] = zero4;      // no key bias: it cancels in the softmax
+      for (int tt = 0; tt < NTT; ++tt) ak[j][tt] = bk;
+    }
     fs_slice_gemm<1, 24, NTT, RT, false, PF>(wq, wb, bufA, rdo, ak);
 #pragma unroll
     for (int hh = 0; hh < HPW; ++hh)
 #pragma unroll
       for (int tt = 0; tt < NTT; ++tt) kf[hh][tt] = pack8(ak[2 * hh][tt], ak[2 * hh + 1][tt]);
+    if constexpr (TRAIN) {
+#pragma unroll
+      for (int tt = 0; tt < NTT; ++tt)
+        if (tokidx[tt] >= 0) {
+#pragma unroll
+          for (int j = 0; j < RT; ++j) {
+            u32x2 u;
+            u[0] = pack_bf16x2(ak[j][tt][0], ak[j][tt][1]); u[1] = pack_bf16x2(ak[j][tt][2], ak[j][tt][3]);
+            *(u32x2*)(A.qkv + (long)tokidx[tt] * (3 * FS_C) + FS_C + 16 * RT * wave + 16 * j + 4 * kk) = u;
+          }
+        }
+    }
   }
   FS_STAMP(5);
   {
     f32x4 av[RT][NTT];   // roles swapped:  D[token][d 16 j + l15]
 #pragma unroll
-    for (int j = 0; j < RT; ++j)
+    for (int j = 0; j < RT; ++j) {
+      // inference: the value bias is folded into the out-proj bias (rows of P sum to 1); with attention dropout they do not, so the
+      // training form adds it here (per feature = per lane in this layout) and uses the plain out-proj bias
+      const float bv = TRAIN ? lbias[1280 + 16 * RT * wave + 16 * j + l15] : 0.0f;
 #pragma unroll
-      for (int tt = 0; tt < NTT; ++tt) av[j][tt] = zero4;      // the value bias is folded into the out-proj bias
+      for (int tt = 0; tt < NTT; ++tt) av[j][tt] = f32x4{bv, bv, bv, bv};
+    }
     fs_slice_gemm<2, 24, NTT, RT, true, PF>(wq, wb, bufA, rdo, av);
+    if constexpr (TRAIN) {   // rows of this layout are tokens 4 kk + r, the lane is one feature: 2-byte stores, 32 contiguous bytes per token row
+#pragma unroll
+      for (int tt = 0; tt < NTT; ++tt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int tk = __shfl(tokidx[tt], 4 * kk + r);      // token of row 4 kk + r of tile tt (held by lane l15 = 4 kk + r)
+          if (tk >= 0) {
+#pragma unroll
+            for (int j = 0; j < RT; ++j) {
+              const __bf16 b = (__bf16)av[j][tt][r];
+              A.qkv[(long)tk * (3 * FS_C) + 2 * FS_C + 16 * RT * wave + 16 * j + l15] = __builtin_bit_cast(unsigned short, b);
+            }
+          }
+        }
+    }
 #pragma unroll
     for (int hh = 0; hh < HPW; ++hh)
 #pragma unroll
@@ -438,6 +502,24 @@ __global__ __launch_bounds__(64 * NW, 2) void block_fs_kernel(FsArgs A) {
       }
 #pragma unroll
       for (int qt = 0; qt < QG; ++qt) sum[qt] = rows_sum(sum[qt]);
+      if constexpr (TRAIN) {
+        if (A.p_drop > 0.0f) {   // dropout on the probabilities, the normaliser stays the undropped sum (tante_attention_dropout's order)
+          const float ksc = 1.0f / (1.0f - A.p_drop);
+          static_for<QG>([&](auto qt_c) {
+            constexpr int qt = decltype(qt_c)::value;
+            constexpr int k0 = TPS > 0 ? ((q0 + qt) / TPS) * TPS : 0;
+            const int qs = 16 * (q0 + qt) + l15, si = (int)(((unsigned)qs * A.magic) >> 16), pi = qs - si * L;
+            const unsigned long long mrow = ((((unsigned long long)(seq0 + si)) * 8 + (HPW * wave + hh)) * L + pi) * L;
+#pragma unroll
+            for (int j = 0; j < NK; ++j)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int jpos = 16 * (k0 + j) + 4 * kk + r - si * L;     // key position inside the query's sequence (where visible)
+                sc[qt][j][r] = dropout_keep(A.seed_attn, mrow + (unsigned long long)(jpos < 0 ? 0 : jpos), A.p_drop) ? sc[qt][j][r] * ksc : 0.0f;
+              }
+          });
+        }
+      }
       // O^T[d][query] = sum over key-tile pairs; the pairs are the GLOBAL pairs (2 g, 2 g + 1) the V^T fragments were packed in
       f32x4 o[QG][2];
       static_for<QG>([&](auto qt_c) {
@@ -466,6 +548,13 @@ __global__ __launch_bounds__(64 * NW, 2) void block_fs_kernel(FsArgs A) {
         w1[0] = pack_bf16x2(o1[0], o1[1]); w1[1] = pack_bf16x2(o1[2], o1[3]);
         *(u32x2*)(bufB + (q0 + qt) * 8192 + wro[2 * hh]) = w0;
         *(u32x2*)(bufB + (q0 + qt) * 8192 + wro[2 * hh + 1]) = w1;
+        if constexpr (TRAIN) {
+          if (tokidx[q0 + qt] >= 0) {
+            unsigned short* orow = A.o + (long)tokidx[q0 + qt] * FS_C + 16 * RT * wave + 32 * hh + 4 * kk;
+            *(u32x2*)orow = w0;
+            *(u32x2*)(orow + 16) = w1;
+          }
+        }
       }
     });
   }
@@ -489,15 +578,45 @@ __global__ __launch_bounds__(64 * NW, 2) void block_fs_kernel(FsArgs A) {
   f32x4 x1[RT][NTT];
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) {
-    const f32x4 bo = *(const f32x4*)(bias + 256 + 16 * rt);
+    const f32x4 bo = *(const f32x4*)(bias + (TRAIN ? 1536 : 256) + 16 * rt);
 #pragma unroll
     for (int tt = 0; tt < NTT; ++tt) x1[rt][tt] = bo;
   }
   fs_slice_gemm<3, 48, NTT, RT, false, PF>(wq, wb, bufB, rdo, x1);
+  // x + dropout(branch): index = row * 256 + column, the GEMM epilogue's / tante_dropout_bwd's (four consecutive columns per lane)
+  auto drop_add = [&](f32x4 (&acc)[RT][NTT], f32x4 (&res)[RT][NTT], unsigned long long seed) {
+    if constexpr (TRAIN) {
+      if (A.p_drop > 0.0f) {
+        const float ksc = 1.0f / (1.0f - A.p_drop);
 #pragma unroll
-  for (int rt = 0; rt < RT; ++rt)
+        for (int tt = 0; tt < NTT; ++tt) {
+          const unsigned long long i0 = (unsigned long long)(tokidx[tt] < 0 ? 0 : tokidx[tt]) * FS_C + 16 * RT * wave + 4 * kk;
 #pragma unroll
-    for (int tt = 0; tt < NTT; ++tt) x1[rt][tt] += xr[rt][tt];
+          for (int rt = 0; rt < RT; ++rt) {
+            const unsigned k01 = dropout_keep2(seed, i0 + 16 * rt, A.p_drop), k23 = dropout_keep2(seed, i0 + 16 * rt + 2, A.p_drop);
+            acc[rt][tt][0] = (k01 & 1u) ? acc[rt][tt][0] * ksc : 0.0f;
+            acc[rt][tt][1] = (k01 & 2u) ? acc[rt][tt][1] * ksc : 0.0f;
+            acc[rt][tt][2] = (k23 & 1u) ? acc[rt][tt][2] * ksc : 0.0f;
+            acc[rt][tt][3] = (k23 & 2u) ? acc[rt][tt][3] * ksc : 0.0f;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int tt = 0; tt < NTT; ++tt) acc[rt][tt] += res[rt][tt];
+  };
+  drop_add(x1, xr, A.seed_out);
+  if constexpr (TRAIN) {   // the residual after the attention half: LayerNorm2's backward reads it
+#pragma unroll
+    for (int tt = 0; tt < NTT; ++tt)
+      if (tokidx[tt] >= 0) {
+        float* row = A.x1 + (long)tokidx[tt] * FS_C + 16 * RT * wave + 4 * kk;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) *(f32x4*)(row + 16 * rt) = x1[rt][tt];
+      }
+  }
   FS_STAMP(10);
 #pragma unroll
   for (int tt = 0; tt < NTT; ++tt) {
@@ -536,6 +655,12 @@ __global__ __launch_bounds__(64 * NW, 2) void block_fs_kernel(FsArgs A) {
       o2[0] = pack_bf16x2(fmaf(x1[rt][tt][0], rstd, sh), fmaf(x1[rt][tt][1], rstd, sh));
       o2[1] = pack_bf16x2(fmaf(x1[rt][tt][2], rstd, sh), fmaf(x1[rt][tt][3], rstd, sh));
       *(u32x2*)(bufA + tt * 8192 + wro[rt]) = o2;
+      if constexpr (TRAIN) {
+        if (tokidx[tt] >= 0) *(u32x2*)(A.xh2 + (long)tokidx[tt] * FS_C + 16 * RT * wave + 16 * rt + 4 * kk) = o2;
+      }
+    }
+    if constexpr (TRAIN) {
+      if (wave == 0 && kk == 0 && tokidx[tt] >= 0) *(float2*)(A.st2 + 2 * (long)tokidx[tt]) = make_float2(mean, rstd);
     }
   }
   __syncthreads();
@@ -561,6 +686,16 @@ __global__ __launch_bounds__(64 * NW, 2) void block_fs_kernel(FsArgs A) {
         o2[0] = pack_bf16x2(g[0], g[1]);
         o2[1] = pack_bf16x2(g[2], g[3]);
         *(u32x2*)(bufB + tt * 8192 + wro[rt]) = o2;
+        if constexpr (TRAIN) {
+          if (tokidx[tt] >= 0) {
+            u32x2 hp;
+            hp[0] = pack_bf16x2(h[rt][tt][0], h[rt][tt][1]);
+            hp[1] = pack_bf16x2(h[rt][tt][2], h[rt][tt][3]);
+            const long off = (long)tokidx[tt] * FS_C + 16 * RT * wave + 16 * rt + 4 * kk;
+            *(u32x2*)(A.hpre + off) = hp;
+            *(u32x2*)(A.act + off) = o2;
+          }
+        }
       }
   }
   __syncthreads();
@@ -568,13 +703,29 @@ __global__ __launch_bounds__(64 * NW, 2) void block_fs_kernel(FsArgs A) {
 
   // ================================ phase 4: fc2 slice + residual -> x ============================================================
   {
+    f32x4 y2[TRAIN ? RT : 1][TRAIN ? NTT : 1];
+    if constexpr (TRAIN) {     // the branch is dropped before the residual is added: it needs accumulators of its own
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-      const f32x4 b2 = *(const f32x4*)(bias + 768 + 16 * rt);
+      for (int rt = 0; rt < RT; ++rt) {
+        const f32x4 b2 = *(const f32x4*)(bias + 768 + 16 * rt);
 #pragma unroll
-      for (int tt = 0; tt < NTT; ++tt) x1[rt][tt] += b2;
+        for (int tt = 0; tt < NTT; ++tt) y2[rt][tt] = b2;
+      }
+      fs_slice_gemm<5, 48, NTT, RT, false, PF>(wq, wb, bufB, rdo, y2);
+      drop_add(y2, x1, A.seed_mlp);
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int tt = 0; tt < NTT; ++tt) x1[rt][tt] = y2[rt][tt];
+    } else {
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) {
+        const f32x4 b2 = *(const f32x4*)(bias + 768 + 16 * rt);
+#pragma unroll
+        for (int tt = 0; tt < NTT; ++tt) x1[rt][tt] += b2;
+      }
+      fs_slice_gemm<5, 48, NTT, RT, false, PF>(wq, wb, bufB, rdo, x1);
     }
-    fs_slice_gemm<5, 48, NTT, RT, false, PF>(wq, wb, bufB, rdo, x1);
     FS_STAMP(15);
 #ifdef TANTE_ABLATE
     if (A.stamps && lane == 0) A.stamps[((long)blockIdx.x * 8 + wave) * 20 + 19] = __builtin_amdgcn_s_memrealtime();
@@ -582,7 +733,7 @@ __global__ __launch_bounds__(64 * NW, 2) void block_fs_kernel(FsArgs A) {
 #pragma unroll
     for (int tt = 0; tt < NTT; ++tt)
       if (tokidx[tt] >= 0) {
-        float* row = x + (long)tokidx[tt] * FS_C + 16 * RT * wave + 4 * kk;
+        float* row = (TRAIN ? A.out : x) + (long)tokidx[tt] * FS_C + 16 * RT * wave + 4 * kk;
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) *(f32x4*)(row + 16 * rt) = x1[rt][tt];
       }
@@ -596,7 +747,7 @@ __global__ __launch_bounds__(64 * NW, 2) void block_fs_kernel(FsArgs A) {
 //   f = (m * 8 + ks) * 16 + g :  matrix m = q | k | v rows of W_in (q scaled by log2(e) / sqrt(32)) | Wo | W1 | W2, k-step ks,
 //   rows 16 g .. 16 g + 15 of it.  A wave that owns RT consecutive row tiles finds the RT fragments of a k-step contiguous, whatever
 //   RT is: the same stream serves the 8-wave and the 4-wave kernels.
-// Biases (fp32, 4 x 256 by output feature): q (scaled) | out' = b_out + W_out (b_v + W_v beta1) | fc1 | fc2.
+// Biases (fp32, 7 x 256 by output feature): q (scaled) | out' = b_out + W_out (b_v + W_v beta1) | fc1 | fc2 | k | v | b_out.
 // LayerNorm gammas are folded into the columns of W_in / W1, the betas into the biases.
 // ------------------------------------------------------------------------------------------------------------------------------
 __global__ void fs_pack_kernel(const float* __restrict__ w_in, const float* __restrict__ b_in, const float* __restrict__ g1,
@@ -653,14 +804,29 @@ __global__ void fs_pack_kernel(const float* __restrict__ w_in, const float* __re
     bias[512 + n] = s;
   }
   bias[768 + n] = b2[n];
+  {   // training form: key and value biases (LayerNorm1's beta folded in), and the out-proj bias WITHOUT the value bias folded in
+    float s = b_in[C + n];
+    for (int k = 0; k < C; ++k) s += w_in[(long)(C + n) * C + k] * be1[k];
+    bias[1024 + n] = s;
+  }
+  bias[1280 + n] = bv[n];
+  bias[1536 + n] = b_out[n];
 }
 
-template <int TPS, int NTT, int NW>
-void fs_launch_t(const FsArgs& A, int nwg, hipStream_t s) {
+template <int TPS, int NTT, int NW, bool TRAIN>
+void fs_launch_tt(const FsArgs& A, int nwg, hipStream_t s) {
   constexpr int LDS = 2 * 16 * NTT * FS_ROW + 16 * NTT * NW * 8 + FS_BIAS_FLOATS * 4;
   static TantePerDevice attr;
-  attr.once([&] { (void)hipFuncSetAttribute((const void*)block_fs_kernel<TPS, NTT, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); });
-  hipLaunchKernelGGL((block_fs_kernel<TPS, NTT, NW>), dim3(nwg), dim3(64 * NW), LDS, s, A);
+  attr.once([&] { (void)hipFuncSetAttribute((const void*)block_fs_kernel<TPS, NTT, NW, TRAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); });
+  hipLaunchKernelGGL((block_fs_kernel<TPS, NTT, NW, TRAIN>), dim3(nwg), dim3(64 * NW), LDS, s, A);
+}
+// the training form exists for the 4-wave kernels (sequences up to 64 tokens: every shipped axis letter); longer ones train unfused
+template <int TPS, int NTT, int NW>
+void fs_launch_t(const FsArgs& A, int nwg, hipStream_t s) {
+  if constexpr (NW == 4) {
+    if (A.out) return fs_launch_tt<TPS, NTT, NW, true>(A, nwg, s);
+  }
+  fs_launch_tt<TPS, NTT, NW, false>(A, nwg, s);
 }
 
 // waves per workgroup: 4 = two independent 64-token workgroups per CU (sequences up to 64 tokens), 8 = one 128-token workgroup per
@@ -690,17 +856,22 @@ void tante_fs_pack(const float* ln1_w, const float* ln1_b, const float* in_w, co
                      fc1_b, ln2_w, ln2_b, fc2_w, fc2_b, dst);
 }
 
-int tante_fs_launch(float* x, const char* stream, const TanteSeq& sq, int causal, float eps, hipStream_t s) {
+int tante_fs_launch(float* x, const char* stream, const TanteSeq& sq, int causal, float eps, hipStream_t s, const TanteBlockTrain* tr) {
   if (sq.nseq >= (1 << 23)) return -2;
   FsArgs A;
   A.x = x; A.w = stream; A.sq = sq; A.causal = causal; A.eps = eps;
+  A.out = nullptr;
+  if (tr) {
+    if (sq.L > 64) return -4;
+    A.out = tr->out; A.xh1 = (unsigned short*)tr->xh1; A.st1 = tr->st1; A.qkv = (unsigned short*)tr->qkv; A.o = (unsigned short*)tr->o;
+    A.x1 = tr->x1; A.xh2 = (unsigned short*)tr->xh2; A.st2 = tr->st2; A.hpre = (unsigned short*)tr->hpre; A.act = (unsigned short*)tr->act;
+    A.p_drop = tr->p_drop; A.seed_attn = tr->seed_attn; A.seed_out = tr->seed_out; A.seed_mlp = tr->seed_mlp;
+  }
   A.stamps = nullptr;
-  static const int stagger = getenv("TANTE_FS_STAGGER") ? atoi(getenv("TANTE_FS_STAGGER")) : 0;
-  A.stagger = stagger;
 #ifdef TANTE_ABLATE
   A.stamps = g_fs_stamps;
 #endif
-  const int L = sq.L, nw = fs_waves(L);
+  const int L = sq.L, nw = tr ? 4 : fs_waves(L);
   A.magic = (65536u + (unsigned)L - 1u) / (unsigned)L;
   // tile-aligned shapes: L | 16 (several sequences per tile), L = 32 / 48 / 64 (2 / 3 / 4 tiles per sequence, non-causal)
   int tps = 0;

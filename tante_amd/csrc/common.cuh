@@ -148,10 +148,21 @@ __device__ __forceinline__ float act_df(float x, int act) {
 }
 
 // ---- counter-based dropout mask: keep(seed, idx) is a pure function, so backward regenerates the forward's mask -------
-__device__ __forceinline__ bool dropout_keep(unsigned long long seed, unsigned long long idx, float p) {
-  unsigned long long z = seed + idx * 0x9E3779B97F4A7C15ull;   // splitmix64 finaliser
+// One splitmix64 finaliser serves TWO consecutive elements (idx >> 1 is hashed; the even element takes bits 8..31 of the result, the odd
+// one bits 40..63): the kernels work on runs of 2 or 4 consecutive elements, so they hash half as often.  24 uniform bits per decision.
+__device__ __forceinline__ unsigned long long dropout_hash(unsigned long long seed, unsigned long long pair) {
+  unsigned long long z = seed + pair * 0x9E3779B97F4A7C15ull;
   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
   z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  z ^= z >> 31;
-  return (float)(z >> 40) * (1.0f / 16777216.0f) >= p;       // 24 uniform bits
+  return z ^ (z >> 31);
+}
+__device__ __forceinline__ bool dropout_keep(unsigned long long seed, unsigned long long idx, float p) {
+  const unsigned long long z = dropout_hash(seed, idx >> 1);
+  const unsigned bits = (idx & 1) ? (unsigned)(z >> 40) : ((unsigned)z >> 8);
+  return (float)bits * (1.0f / 16777216.0f) >= p;
+}
+// the two decisions of the pair that starts at the EVEN index idx0 (bit 0: idx0, bit 1: idx0 + 1)
+__device__ __forceinline__ unsigned dropout_keep2(unsigned long long seed, unsigned long long idx0, float p) {
+  const unsigned long long z = dropout_hash(seed, idx0 >> 1);
+  return ((float)((unsigned)z >> 8) * (1.0f / 16777216.0f) >= p ? 1u : 0u) | ((float)(unsigned)(z >> 40) * (1.0f / 16777216.0f) >= p ? 2u : 0u);
 }

@@ -311,6 +311,28 @@ def block_fused(x: torch.Tensor, block_stream: torch.Tensor, C_: int, n_head: in
     return x
 
 
+def block_fused_train_supported(C_: int, n_head: int, hidden: int, Lq: int) -> bool:
+    return C_ == 256 and n_head == 8 and hidden == 256 and 1 <= Lq <= 64
+
+
+def block_fused_train(x: torch.Tensor, block_stream: torch.Tensor, C_: int, n_head: int, hidden: int, seq: L.Seq, causal: bool, eps: float,
+                      p_drop: float, seeds) -> dict:
+    """Training forward of a whole block in one launch (tante_block_fused_train): -> the block output and every saved tensor of the
+    unfused operators (see include/tante_hip.h).  x (tokens, 256) fp32 is left untouched."""
+    _dev(x, block_stream)
+    M = x.numel() // C_
+    dev = x.device
+    bf = lambda n: torch.empty(M, n, dtype=torch.bfloat16, device=dev)      # noqa: E731
+    f32 = lambda n: torch.empty(M, n, dtype=torch.float32, device=dev)      # noqa: E731
+    t = {"out": f32(C_), "xh1": bf(C_), "qkv": bf(3 * C_), "o": bf(C_), "xh2": bf(C_), "hpre": bf(hidden), "act": bf(hidden),
+         "st1": f32(2), "x1": f32(C_), "st2": f32(2)}
+    tr = L.BlockTrain(*[t[k].data_ptr() for k in ("out", "xh1", "qkv", "o", "xh2", "hpre", "act", "st1", "x1", "st2")],
+                      float(p_drop), int(seeds[0]), int(seeds[1]), int(seeds[2]))
+    L.check(L.lib().tante_block_fused_train(_p(x), _p(block_stream), C_, n_head, hidden, C.byref(seq), int(causal), eps, C.byref(tr),
+                                            _stream()), "tante_block_fused_train")
+    return t
+
+
 # ---- fused derivative head (bf16) ---------------------------------------------------------------------------------------
 def head_fused_supported(C_: int, D: int) -> bool:
     return bool(L.lib().tante_head_fused_supported(C_, D))

@@ -51,11 +51,28 @@ def _folded(lin_w, lin_b, ln):
     return hit
 
 
+FUSED_TRAIN_FORWARD = __import__("os").environ.get("TANTE_TRAIN_FUSED", "1") != "0"
+
+
 def block_train(blk, x: torch.Tensor, seq, causal: bool, compute: int) -> torch.Tensor:
     p = blk.p_drop if blk.training else 0.0     # nn.Dropout / MHA dropout are active in train() mode only
     adt = K.act_torch_dtype(compute)
     a, m = blk.attn, blk.mlp
     w_in, b_in = _folded(a.in_proj_weight, a.in_proj_bias, blk.ln1)
+    if (FUSED_TRAIN_FORWARD and compute == L.BF16 and blk.fused and blk.ln1.eps == blk.ln2.eps and x.dtype == torch.float32 and x.is_contiguous()
+            and K.block_fused_train_supported(blk.embed_dim, blk.n_head, blk.hidden, seq.L)):
+        # ONE launch computes the block and stores what the backward pass reads; the autograd nodes below launch nothing in forward
+        from .autograd import next_seed
+        seeds = (next_seed(), next_seed(), next_seed()) if p > 0.0 else (0, 0, 0)
+        t = K.block_fused_train(x.detach(), blk._packed_fused(), blk.embed_dim, blk.n_head, blk.hidden, seq, causal, blk.ln1.eps, p, seeds)
+        w1, b1 = _folded(m[0].weight, m[0].bias, blk.ln2)
+        xh, xs = LayerNormSkipFn.apply(x, blk.ln1.eps, adt, (t["xh1"], t["st1"]))
+        qkv = LinearFn.apply(xh, w_in, b_in, None, compute, adt, t["qkv"])
+        o = AttentionFn.apply(qkv, seq, blk.embed_dim, blk.n_head, causal, p, (t["o"], seeds[0]))
+        x1 = BranchOutFn.apply(o, a.out_proj.weight, a.out_proj.bias, xs, L.ACT_NONE, p, compute, (t["x1"], None, seeds[1]))
+        xh2, x1s = LayerNormSkipFn.apply(x1, blk.ln2.eps, adt, (t["xh2"], t["st2"]))
+        hpre = LinearFn.apply(xh2, w1, b1, None, compute, adt, t["hpre"])
+        return BranchOutFn.apply(hpre, m[2].weight, m[2].bias, x1s, L.ACT_GELU_TANH, p, compute, (t["out"], t["act"], seeds[2]))
     xh, x = LayerNormSkipFn.apply(x, blk.ln1.eps, adt)      # x: the same tokens, as the skip operand whose gradient LN's backward adds
     qkv = LinearFn.apply(xh, w_in, b_in, None, compute, adt)
     o = AttentionFn.apply(qkv, seq, blk.embed_dim, blk.n_head, causal, p)

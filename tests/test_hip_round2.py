@@ -88,9 +88,10 @@ def test_attention_mfma_fwd_bwd_against_float64_sdpa(dev, letter, B, T, H, W, ca
 # ---------------------------------------------------------------------------------------------------
 # g14: the production-shape train step against the REFERENCE's gradients
 # ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("fused_fwd", [True, False])
 @pytest.mark.parametrize("defer", [True, False])
 @pytest.mark.parametrize("mode", ["bf16", "fp32"])
-def test_g14_wide_train_step(dev, mode, defer, monkeypatch):
+def test_g14_wide_train_step(dev, mode, defer, fused_fwd, monkeypatch):
     """C = 256, 8 heads x 32, THWTHWTHW on 64 x 384 x 4 fields (L in {4, 8, 48}), B = 2, 4-step BPTT, dropout 0: the loss, every
     parameter's gradient norm, three full gradient tensors and the global norm against the reference run (fixture g14).  This is the
     shape class of cfg3: head-dim-32 MFMA attention forward / backward, the M >= 4096 GEMM epilogues, the shared multi-segment
@@ -98,7 +99,11 @@ def test_g14_wide_train_step(dev, mode, defer, monkeypatch):
     import tante_amd
     from tante_amd import autograd as A
     from conftest import g14_setup, G14_FIELDS, G14_RES
+    from tante_amd import train_forward as TF
+    if mode == "fp32" and not fused_fwd:
+        pytest.skip("the fused training forward is a bf16 kernel: fp32 has one path")
     monkeypatch.setattr(A, "DEFER_WGRAD", defer)
+    monkeypatch.setattr(TF, "FUSED_TRAIN_FORWARD", fused_fwd)      # one launch per block (tante_block_fused_train) vs one per operator
     m, batch, g, names = g14_setup()
     m = m.to(dev).train().set_compute(mode)
     md = tante_amd.TanteMetadata(n_fields=G14_FIELDS, spatial_resolution=G14_RES)
@@ -321,3 +326,50 @@ def test_fit_two_epochs_then_resume(dev, tmp_path):
                          dropout=0.0, deg=False).to(dev).set_compute("fp32")
     v = H.validation_loop(mr, d1.val_dataloader(), fmt, 4)
     assert {"RT", "Step", "summary_error", "summary_rt"} <= set(v) and 1.0 <= v["RT"] <= 4.01 and 4 <= v["Step"] <= 16   # len(Rts) = calls x batch, as in r_evaler.py:143
+
+
+# ---------------------------------------------------------------------------------------------------
+# fused training forward (tante_block_fused_train) against the operator-by-operator training forward
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("p", [0.0, 0.25])
+@pytest.mark.parametrize("letter,B,T,H,W", [("T", 2, 4, 6, 8), ("H", 2, 2, 16, 6), ("W", 1, 2, 4, 48), ("W", 3, 1, 5, 32), ("L", 2, 1, 5, 4), ("H", 1, 3, 64, 2)])
+def test_fused_training_forward_equals_unfused(dev, letter, B, T, H, W, p, monkeypatch):
+    """One TransformerBlock in train() mode on every axis letter's token pattern: the one-launch training forward must give the unfused
+    operators' output, the tensors it saves for the backward pass must be theirs, and -- with the SAME dropout seeds -- the same masks:
+    attention-probability dropout, both residual-branch dropouts (the mask is a pure function of (seed, index), so any index-convention
+    slip shows as an O(1) difference).  Then the gradients of both graphs agree (the backward kernels are the same, fed by either forward)."""
+    import tante_amd
+    from tante_amd import autograd as A, train_forward as TF, kernels as Kk, _lib as L
+    torch.manual_seed(7)
+    blk = tante_amd.TransformerBlock(256, 8, mlp_ratio=1.0, dropout=p).to(dev).train()
+    with torch.no_grad():
+        for ln in (blk.ln1, blk.ln2):
+            ln.weight.add_(0.2 * torch.randn_like(ln.weight))
+            ln.bias.add_(0.2 * torch.randn_like(ln.bias))
+        blk.attn.in_proj_bias.add_(0.2 * torch.randn_like(blk.attn.in_proj_bias))
+        blk.attn.out_proj.bias.add_(0.2 * torch.randn_like(blk.attn.out_proj.bias))
+    seq = Kk.make_seq(letter, B, T, H, W)
+    n = B * T * H * W
+    x0 = (torch.randn(n, 256, generator=torch.Generator().manual_seed(n)) * 1.3 + 0.2).to(dev)
+    w = torch.randn(n, 256, generator=torch.Generator().manual_seed(n + 1)).to(dev)
+    res = {}
+    for fused in (True, False):
+        monkeypatch.setattr(TF, "FUSED_TRAIN_FORWARD", fused)
+        A._SEED[0] = 1000                                     # both runs draw the same three seeds
+        blk.zero_grad()
+        x = x0.clone().requires_grad_(True)
+        with TF.fold_scope():
+            y = TF.block_train(blk, x, seq, letter == "T", L.BF16)
+            A.run_backward((y * w).sum())
+        res[fused] = (y.detach().cpu(), x.grad.cpu(), {k: v.grad.detach().cpu().clone() for k, v in blk.named_parameters()})
+    (yf, gxf, gpf), (yu, gxu, gpu) = res[True], res[False]
+    e = max_rel(yf, yu)
+    record_parity(rel_err(yf, yu), e, 1e-2, "bf16", f"fused vs unfused training forward, p={p}")
+    assert e < 1e-2 and rel_err(yf - x0.cpu(), yu - x0.cpu()) < 3e-2, (e, rel_err(yf - x0.cpu(), yu - x0.cpu()))
+    assert max_rel(gxf, gxu) < 4e-2, max_rel(gxf, gxu)
+    for k in gpf:
+        if "in_proj_bias" in k:            # its k third is zero up to rounding (a key bias cannot change a softmax): compare q and v parts
+            a_, b_ = torch.cat([gpf[k][:256], gpf[k][512:]]), torch.cat([gpu[k][:256], gpu[k][512:]])
+        else:
+            a_, b_ = gpf[k], gpu[k]
+        assert max_rel(a_, b_) < 4e-2, (k, max_rel(a_, b_))
