@@ -230,6 +230,11 @@ typedef struct TanteBlockTrain {
   float p_drop;
   uint64_t seed_attn, seed_out, seed_mlp;
 } TanteBlockTrain;
+/* Packs ONLY the stream tante_block_fused_train reads (into the buffer tante_block_stream_bytes sizes), from weights whose LayerNorm
+ * affines are already folded in (W diag(gamma), b + W beta: the training path keeps those as differentiable tensors). */
+int tante_pack_block_train(const float* in_w_folded, const float* in_b_folded, const float* out_w, const float* out_b,
+                           const float* fc1_w_folded, const float* fc1_b_folded, const float* fc2_w, const float* fc2_b, int C, int hidden,
+                           void* block_stream, void* stream);
 int tante_block_fused_train(const float* x, const void* block_stream, int C, int n_head, int hidden, const TanteSeq* seq, int causal,
                             float eps, const TanteBlockTrain* tr, void* stream);
 
@@ -430,6 +435,12 @@ int tante_wgrad(const TanteRowMat* U, const TanteRowMat* V, int64_t R, int I, in
  * 128, R % 32 == 0, at most 8 segments per launch); otherwise the segments run one by one. */
 int tante_wgrad_multi(const TanteRowMat* U, const TanteRowMat* V, int n_seg, int64_t R, int I, int J, float* dW, float* dbias, int layout,
                       int P, int C_other, int swap, int compute, int accumulate, void* stream);
+/* The same with a caller-owned scratch buffer (16-byte aligned; any size, 64 MiB covers every TANTE shape): when it is large enough the
+ * split-R partial tiles are STORED there and summed by a second kernel instead of added with fp32 atomics (which run at a fifth of the
+ * store rate and limited the launch to half the CUs); too small or null -> the atomic form.  The buffer is scratch for the duration of
+ * the call's kernels on `stream` only. */
+int tante_wgrad_multi_ws(const TanteRowMat* U, const TanteRowMat* V, int n_seg, int64_t R, int I, int J, float* dW, float* dbias, int layout,
+                         int P, int C_other, int swap, int compute, int accumulate, void* workspace, int64_t workspace_bytes, void* stream);
 
 const char* tante_last_error(void);
 int tante_abi_version(void);

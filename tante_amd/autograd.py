@@ -173,6 +173,16 @@ def run_backward(loss: torch.Tensor):
         reset_backward_state()
 
 
+_WG_WS = {}      # device index -> 64 MiB scratch of the shared weight-gradient launches (split-R partial tiles, summed by a second kernel)
+
+
+def _wgrad_workspace(device) -> torch.Tensor:
+    ws = _WG_WS.get(device.index)
+    if ws is None:
+        ws = _WG_WS[device.index] = torch.empty(64 << 20, dtype=torch.uint8, device=device)
+    return ws
+
+
 def _flush_wgrads(slot: Optional[torch.Tensor] = None):
     pend = _DEFER["pending"]
     keys = [k for k in pend if slot is None or k[0] == slot.data_ptr()]
@@ -182,8 +192,9 @@ def _flush_wgrads(slot: Optional[torch.Tensor] = None):
         U = (L.RowMat * n)(*[_rm_linear(dy) for dy, _ in uses])
         V = (L.RowMat * n)(*[_rm_linear(a) for _, a in uses])
         layout, P, Co, swap = lay
-        L.check(L.lib().tante_wgrad_multi(C.byref(U), C.byref(V), n, M, N, Kk, gW.data_ptr(), None if gb is None else gb.data_ptr(), layout, P, Co,
-                                          int(swap), comp, 1, _s()), "tante_wgrad_multi")
+        ws = _wgrad_workspace(gW.device)
+        L.check(L.lib().tante_wgrad_multi_ws(C.byref(U), C.byref(V), n, M, N, Kk, gW.data_ptr(), None if gb is None else gb.data_ptr(), layout, P,
+                                             Co, int(swap), comp, 1, ws.data_ptr(), ws.numel(), _s()), "tante_wgrad_multi")
     if slot is None:
         _DEFER["armed"] = False
         _DEFER["task"] = -1

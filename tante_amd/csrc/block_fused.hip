@@ -825,3 +825,15 @@ extern "C" int tante_block_fused_train(const float* x, const void* block_stream,
   TANTE_CHECK_LAUNCH();
   return 0;
 }
+
+extern "C" int tante_pack_block_train(const float* in_w_folded, const float* in_b_folded, const float* out_w, const float* out_b,
+                                      const float* fc1_w_folded, const float* fc1_b_folded, const float* fc2_w, const float* fc2_b, int C,
+                                      int hidden, void* block_stream, void* stream) {
+  if (!in_w_folded || !in_b_folded || !out_w || !out_b || !fc1_w_folded || !fc1_b_folded || !fc2_w || !fc2_b || !block_stream)
+    TANTE_FAIL(-1, "tante_pack_block_train: null pointer");
+  if (tante_fs_stream_bytes(C, hidden) == 0) TANTE_FAIL(-2, "tante_pack_block_train: unsupported C=%d hidden=%d", C, hidden);
+  tante_fs_pack_folded(in_w_folded, in_b_folded, out_w, out_b, fc1_w_folded, fc1_b_folded, fc2_w, fc2_b,
+                       (char*)block_stream + block_ts_stream_bytes(C, hidden), (hipStream_t)stream);
+  TANTE_CHECK_LAUNCH();
+  return 0;
+}

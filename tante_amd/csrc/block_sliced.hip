@@ -781,6 +781,17 @@ __global__ void fs_pack_kernel(const float* __restrict__ w_in, const float* __re
   // last block: the biases.  bv' = b_v + W_v beta1 (256 values), then bo' = b_out + W_out bv'
   __shared__ float bv[FS_C];
   const int n = threadIdx.x;   // 256 threads
+  if (!be1) {   // training pack: W_in / W1 and their biases arrive with the LayerNorm affines already folded in (FoldFn); plain copies
+    float* bias = (float*)(dst + FS_W_BYTES);
+    bias[n] = b_in[n] * qscale;
+    bias[256 + n] = b_out[n];          // (the inference-only folded out-proj bias is not used by the training kernel)
+    bias[512 + n] = b1[n];
+    bias[768 + n] = b2[n];
+    bias[1024 + n] = b_in[C + n];
+    bias[1280 + n] = b_in[2 * C + n];
+    bias[1536 + n] = b_out[n];
+    return;
+  }
   {
     float s = b_in[2 * C + n];
     for (int k = 0; k < C; ++k) s += w_in[(long)(2 * C + n) * C + k] * be1[k];
@@ -854,6 +865,13 @@ void tante_fs_pack(const float* ln1_w, const float* ln1_b, const float* in_w, co
                    const float* fc2_b, char* dst, hipStream_t s) {
   hipLaunchKernelGGL(fs_pack_kernel, dim3(FS_W_BYTES / FS_FRAG / 4 + 1), dim3(256), 0, s, in_w, in_b, ln1_w, ln1_b, out_w, out_b, fc1_w,
                      fc1_b, ln2_w, ln2_b, fc2_w, fc2_b, dst);
+}
+
+// training pack: only this kernel's stream, from weights whose LayerNorm affines are already folded in (gamma = beta = null)
+void tante_fs_pack_folded(const float* in_w, const float* in_b, const float* out_w, const float* out_b, const float* fc1_w,
+                          const float* fc1_b, const float* fc2_w, const float* fc2_b, char* dst, hipStream_t s) {
+  hipLaunchKernelGGL(fs_pack_kernel, dim3(FS_W_BYTES / FS_FRAG / 4 + 1), dim3(256), 0, s, in_w, in_b, (const float*)nullptr,
+                     (const float*)nullptr, out_w, out_b, fc1_w, fc1_b, (const float*)nullptr, (const float*)nullptr, fc2_w, fc2_b, dst);
 }
 
 int tante_fs_launch(float* x, const char* stream, const TanteSeq& sq, int causal, float eps, hipStream_t s, const TanteBlockTrain* tr) {

@@ -307,7 +307,8 @@ struct WgSegs {
 template <int WNBUF>   // ring depth: 4 (64 KB, two workgroups per CU) or 8 (128 KB: a lone workgroup keeps 7 chunks = 112 KB in flight)
 __global__ __launch_bounds__(256, WNBUF == 4 ? 2 : 1) void wgrad_tr_kernel(const WgSegs SG, long ldu,
                                                           long ldv, long R, int I, int J, long rows_per_split, float* __restrict__ dW,
-                                                          float* __restrict__ dbias, int layout, int P, int Co, int swap, int debug, int n_split) {
+                                                          float* __restrict__ dbias, int layout, int P, int Co, int swap, int debug, int n_split,
+                                                          float* __restrict__ slab, float* __restrict__ bias_slab) {
   extern __shared__ __attribute__((aligned(16))) char wsm[];   // ring: [buf][U chunk | V chunk]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kk = lane >> 4, l15 = lane & 15;
   // XCD-aware mapping: workgroups are dealt round-robin to the 8 XCDs by linear id, and every output tile of one row range re-reads
@@ -400,6 +401,21 @@ __global__ __launch_bounds__(256, WNBUF == 4 ? 2 : 1) void wgrad_tr_kernel(const
       if (do_bias) bacc[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[a]), __builtin_bit_cast(bf16x8, ones), bacc[a], 0, 0, 0);
     }
   }
+  if (slab) {
+    // two-stage reduction: the partial tile goes out with plain 16-byte stores in REGISTER order ([wave][a][b][lane][4], 1 KiB per wave
+    // instruction) and wgrad_reduce_kernel sums the splits -- fp32 atomics run at ~1.3 TB/s chip-wide, a fifth of the store rate, and
+    // 64 KiB of them per workgroup capped this kernel at 128 workgroups (half the CUs, one per CU)
+    float* t = slab + ((long)bz * ntile + tile) * (WT * WT) + (wave * 16) * 256 + lane * 4;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) *(f32x4*)(t + (a * 4 + b) * 256) = acc[a][b];
+    if (do_bias && l15 == 0) {
+#pragma unroll
+      for (int a = 0; a < 4; ++a) *(f32x4*)(bias_slab + (long)bz * I + i0 + wi * 64 + a * 16 + kk * 4) = bacc[a];
+    }
+    return;
+  }
   // D[row = i][col = j]: lane holds j = l15, i = 4*kk + reg
 #pragma unroll
   for (int a = 0; a < 4; ++a)
@@ -416,6 +432,30 @@ __global__ __launch_bounds__(256, WNBUF == 4 ? 2 : 1) void wgrad_tr_kernel(const
     for (int a = 0; a < 4; ++a)
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) atomicAdd(&dbias[i0 + wi * 64 + a * 16 + kk * 4 + rg], bacc[a][rg]);
+  }
+}
+
+// second stage: dW[i][j] += sum over the splits of a slab chunk (grid.y chunks of splits; one thread per 16-byte piece of a tile in the
+// register order wgrad_tr_kernel stored it in, so consecutive threads read consecutive 16 bytes); dbias likewise from the bias slab
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ bias_slab, int n_split,
+                                                          int ntile, int ti, int I, int J, float* __restrict__ dW, float* __restrict__ dbias,
+                                                          int layout, int P, int Co, int swap) {
+  const int per = (n_split + gridDim.y - 1) / gridDim.y, s0 = blockIdx.y * per, s1 = min(n_split, s0 + per);
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t < ntile * 4096 && s0 < s1) {
+    const int tile = t >> 12, rem = t & 4095, wave = rem >> 10, ab = (rem >> 6) & 15, lane = rem & 63;
+    const float* p = slab + ((long)s0 * ntile + tile) * (WT * WT) + rem * 4;
+    f32x4 sum = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int s = s0; s < s1; ++s, p += (long)ntile * (WT * WT)) sum += *(const f32x4*)p;
+    const int i0 = (tile % ti) * WT, j0 = (tile / ti) * WT, wi = wave >> 1, wj = wave & 1, a = ab >> 2, b = ab & 3, kk = lane >> 4, l15 = lane & 15;
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg)
+      atomicAdd(&dW[out_index(layout, i0 + wi * 64 + a * 16 + kk * 4 + rg, j0 + wj * 64 + b * 16 + l15, I, J, P, Co, swap)], sum[rg]);
+  }
+  if (dbias && blockIdx.y == 0 && t < I) {
+    float sum = 0.f;
+    for (int s = 0; s < n_split; ++s) sum += bias_slab[(long)s * I + t];
+    atomicAdd(&dbias[t], sum);
   }
 }
 
@@ -451,7 +491,7 @@ static int rm_stage_mode(const TanteRowMat& m, int ncols) {
 
 // the LDS-DMA / transposed-read path for n_seg operand pairs of R rows each (dense bf16 rows, I and J multiples of 128, R % 32 == 0)
 static bool wgrad_tr_launch(const TanteRowMat* U, const TanteRowMat* V, int n_seg, long R, int I, int J, float* dW, float* dbias, int layout,
-                            int P, int C_other, int swap, hipStream_t s) {
+                            int P, int C_other, int swap, hipStream_t s, void* ws = nullptr, int64_t ws_bytes = 0) {
   static const bool no_tr = getenv("TANTE_WGRAD_NO_TR") && atoi(getenv("TANTE_WGRAD_NO_TR"));
   if (no_tr || n_seg < 1 || n_seg > WSEG || R % WRC) return false;
   for (int g = 0; g < n_seg; ++g)
@@ -460,7 +500,11 @@ static bool wgrad_tr_launch(const TanteRowMat* U, const TanteRowMat* V, int n_se
   // every workgroup ends with 128 x 128 fp32 atomics: with the main loop at memory speed the split count is a trade between
   // parallelism and atomic traffic (64 KiB per workgroup) -- measured best near 128 workgroups for <= 4 tiles, 256 otherwise
   static const int wg_env = getenv("TANTE_WGRAD_TR_WGS") ? atoi(getenv("TANTE_WGRAD_TR_WGS")) : (getenv("TANTE_WGRAD_WGS") ? atoi(getenv("TANTE_WGRAD_WGS")) : 0);
-  const int wg_target = wg_env > 0 ? wg_env : (ti * tj <= 4 ? 128 : 256);
+  // with a workspace the partial tiles are stored and summed by a second kernel instead of added atomically: the atomic traffic no
+  // longer limits the split count, so the grid fills the chip twice (two 64 KB workgroups per CU)
+  static const bool no_slab = getenv("TANTE_WGRAD_NO_SLAB") && atoi(getenv("TANTE_WGRAD_NO_SLAB"));
+  const bool want_slab = ws != nullptr && !no_slab;
+  const int wg_target = wg_env > 0 ? wg_env : (want_slab ? 512 : (ti * tj <= 4 ? 128 : 256));
   // splits PER SEGMENT (a split never straddles two segments): the workgroup target is shared by the segments
   long split = wg_target / ((long)ti * tj * n_seg);
   if (split < 1) split = 1;
@@ -485,14 +529,23 @@ static bool wgrad_tr_launch(const TanteRowMat* U, const TanteRowMat* V, int n_se
     hipFuncSetAttribute((const void*)wgrad_tr_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 2 * WCHUNK);
   });
   const unsigned n_wg = 8u * (unsigned)((total + 7) / 8) * (unsigned)(ti * tj);
+  const int64_t need = ((int64_t)total * ti * tj * WT * WT + (int64_t)total * I) * (int64_t)sizeof(float);
+  const bool use_slab = want_slab && total > 1 && need <= ws_bytes && ((uintptr_t)ws % 16) == 0;
+  float* slab = use_slab ? (float*)ws : nullptr;
+  float* bias_slab = use_slab ? slab + (int64_t)total * ti * tj * WT * WT : nullptr;
   // the 8-deep ring (one workgroup per CU with 112 KB in flight) is kept for experiments only: measured on the train step it LOSES to
   // the 4-deep one (33.2 vs 31.0 ms when used for grids of <= 256 workgroups, 32.3 ms when forced everywhere)
   if (deep_env > 0)
     hipLaunchKernelGGL(wgrad_tr_kernel<8>, dim3(n_wg), dim3(256), (size_t)8 * 2 * WCHUNK, s, SG, (long)U[0].s0, (long)V[0].s0, R * n_seg, I, J, per, dW,
-                       dbias, layout, P, C_other, swap, wdebug, (int)total);
+                       dbias, layout, P, C_other, swap, wdebug, (int)total, slab, bias_slab);
   else
     hipLaunchKernelGGL(wgrad_tr_kernel<4>, dim3(n_wg), dim3(256), (size_t)4 * 2 * WCHUNK, s, SG, (long)U[0].s0, (long)V[0].s0, R * n_seg, I, J, per, dW,
-                       dbias, layout, P, C_other, swap, wdebug, (int)total);
+                       dbias, layout, P, C_other, swap, wdebug, (int)total, slab, bias_slab);
+  if (use_slab) {
+    const int ntile = ti * tj, ny = total >= 32 ? 4 : 1;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(ntile * 16), (unsigned)ny), dim3(256), 0, s, slab, bias_slab, (int)total, ntile, ti, I, J,
+                       dW, dbias, layout, P, C_other, swap);
+  }
   return true;
 }
 
@@ -529,6 +582,12 @@ extern "C" int tante_wgrad(const TanteRowMat* U, const TanteRowMat* V, int64_t R
 
 extern "C" int tante_wgrad_multi(const TanteRowMat* U, const TanteRowMat* V, int n_seg, int64_t R, int I, int J, float* dW, float* dbias,
                                  int layout, int P, int C_other, int swap, int compute, int accumulate, void* stream) {
+  return tante_wgrad_multi_ws(U, V, n_seg, R, I, J, dW, dbias, layout, P, C_other, swap, compute, accumulate, nullptr, 0, stream);
+}
+
+extern "C" int tante_wgrad_multi_ws(const TanteRowMat* U, const TanteRowMat* V, int n_seg, int64_t R, int I, int J, float* dW, float* dbias,
+                                    int layout, int P, int C_other, int swap, int compute, int accumulate, void* workspace,
+                                    int64_t workspace_bytes, void* stream) {
   if (!U || !V || !dW || n_seg <= 0 || R <= 0 || I <= 0 || J <= 0) TANTE_FAIL(-1, "tante_wgrad_multi: bad argument");
   for (int g = 0; g < n_seg; ++g) {
     int rc = check_rowmat(U[g], "U");
@@ -543,7 +602,7 @@ extern "C" int tante_wgrad_multi(const TanteRowMat* U, const TanteRowMat* V, int
   int g = 0;
   while (g < n_seg) {                                  // groups of up to WSEG segments share a launch when the shape allows
     const int n = n_seg - g < WSEG ? n_seg - g : WSEG;
-    if (compute == TANTE_BF16 && n > 1 && wgrad_tr_launch(U + g, V + g, n, (long)R, I, J, dW, dbias, layout, P, C_other, swap, s)) {
+    if (compute == TANTE_BF16 && n > 1 && wgrad_tr_launch(U + g, V + g, n, (long)R, I, J, dW, dbias, layout, P, C_other, swap, s, workspace, workspace_bytes)) {
       TANTE_CHECK_LAUNCH();
       g += n;
       continue;

@@ -315,6 +315,15 @@ def block_fused_train_supported(C_: int, n_head: int, hidden: int, Lq: int) -> b
     return C_ == 256 and n_head == 8 and hidden == 256 and 1 <= Lq <= 64
 
 
+def pack_block_train(params: Sequence[torch.Tensor], C_: int, hidden: int) -> torch.Tensor:
+    """params = (in_w folded, in_b folded, out_w, out_b, fc1_w folded, fc1_b folded, fc2_w, fc2_b) -> the training kernel's weight stream."""
+    ps = [p.detach() for p in params]
+    _dev(*ps)
+    st = torch.empty(L.lib().tante_block_stream_bytes(C_, hidden), dtype=torch.uint8, device=ps[0].device)
+    L.check(L.lib().tante_pack_block_train(*[_p(p) for p in ps], C_, hidden, _p(st), _stream()), "tante_pack_block_train")
+    return st
+
+
 def block_fused_train(x: torch.Tensor, block_stream: torch.Tensor, C_: int, n_head: int, hidden: int, seq: L.Seq, causal: bool, eps: float,
                       p_drop: float, seeds) -> dict:
     """Training forward of a whole block in one launch (tante_block_fused_train): -> the block output and every saved tensor of the

@@ -64,8 +64,15 @@ def block_train(blk, x: torch.Tensor, seq, causal: bool, compute: int) -> torch.
         # ONE launch computes the block and stores what the backward pass reads; the autograd nodes below launch nothing in forward
         from .autograd import next_seed
         seeds = (next_seed(), next_seed(), next_seed()) if p > 0.0 else (0, 0, 0)
-        t = K.block_fused_train(x.detach(), blk._packed_fused(), blk.embed_dim, blk.n_head, blk.hidden, seq, causal, blk.ln1.eps, p, seeds)
         w1, b1 = _folded(m[0].weight, m[0].bias, blk.ln2)
+        # the kernel's weight stream is packed from the folded tensors, once per fold scope (= once per rollout graph: BPTT calls share it)
+        key = ("fs_stream", id(blk))
+        stream = _FOLDS.get(key) if _FOLDS is not None else None
+        if stream is None:
+            stream = K.pack_block_train((w_in, b_in, a.out_proj.weight, a.out_proj.bias, w1, b1, m[2].weight, m[2].bias), blk.embed_dim, blk.hidden)
+            if _FOLDS is not None:
+                _FOLDS[key] = stream
+        t = K.block_fused_train(x.detach(), stream, blk.embed_dim, blk.n_head, blk.hidden, seq, causal, blk.ln1.eps, p, seeds)
         xh, xs = LayerNormSkipFn.apply(x, blk.ln1.eps, adt, (t["xh1"], t["st1"]))
         qkv = LinearFn.apply(xh, w_in, b_in, None, compute, adt, t["qkv"])
         o = AttentionFn.apply(qkv, seq, blk.embed_dim, blk.n_head, causal, p, (t["o"], seeds[0]))
