@@ -235,7 +235,7 @@ def main():
                 traffic = pm["fused_block_kernel"]["hbm_bytes_per_launch"]
                 # the counters come from a separate rocprofv3 --pmc pass (tools/collect_profiles.sh), not from this run: say which
                 traffic_source = {"file": "profiles/" + PMC_FILE, "kernel_source_sha16": pm.get("kernel_source_sha16"),
-                                  "current_kernel_source_sha16": _sha16(os.path.join(ROOT, "tante_amd", "csrc", "block_fused.hip"))}
+                                  "current_kernel_source_sha16": _sha16(os.path.join(ROOT, "tante_amd", "csrc", "block_sliced.hip"))}
                 traffic_source["stale"] = traffic_source["kernel_source_sha16"] != traffic_source["current_kernel_source_sha16"]
         except (OSError, KeyError, ValueError):
             pass

@@ -1,14 +1,24 @@
 #!/bin/bash
-# Run on the MI355X box (via gpurun): the round's rocprofv3 evidence -> gpurun_out/r01/.  Copy what should be judged into profiles/.
+# Run on the MI355X box (via gpurun): the round's rocprofv3 evidence -> gpurun_out/r02/.  tools/summarize_profiles.py condenses it into
+# the files that are committed under profiles/.   gpurun --timeout 1200 -- 'bash tools/collect_profiles.sh'
 set -o pipefail
 R=$GRAFT_REPO_ROOT
-OUT=$R/gpurun_out/r01
-mkdir -p $OUT
+OUT=$R/gpurun_out/r02
+rm -rf $OUT && mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
+# 1. kernel traces (never combined with counters)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/rollout -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-train > $OUT/rollout_bench.json 2> $OUT/rollout.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/train -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --train-steps 3 > $OUT/train_bench.json 2> $OUT/train.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/cvit -- python3 $R/tools/cvit_time.py > $OUT/cvit_time.txt 2> $OUT/cvit.err
-for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU"; do
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-train > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/train -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --train-steps 3 --no-train-strong > $OUT/train_bench.json 2> $OUT/train.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trl -- python3 $R/bench.py --config $R/configs/tante_trl.yaml --steps 5 --warmup 2 --no-cpu-baseline > $OUT/trl_bench.json 2> $OUT/trl.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/cvit -- python3 $R/bench.py --config $R/configs/cvit_rb.yaml --steps 5 --warmup 2 > $OUT/cvit_bench.json 2> $OUT/cvit.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/fno -- python3 $R/bench.py --config $R/configs/tante_fno.yaml --steps 3 --warmup 1 --no-cpu-baseline > $OUT/fno_bench.json 2> $OUT/fno.err
+# 2. counters of the rollout, one pass per group (8 SQ slots; FETCH_SIZE and WRITE_SIZE cannot share a pass), kernel-trace only
+for c in "FETCH_SIZE" "WRITE_SIZE" \
+         "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU" \
+         "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_VALU_MFMA_COEXEC_CYCLES SQ_WAVES"; do
+  n=$(echo $c | tr ' ' '_' | cut -c1-40)
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc/$n -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-train > /dev/null 2> $OUT/pmc_$n.err
 done
+# 3. un-profiled reference lines of the same commands
+python3 $R/bench.py --steps 10 --warmup 3 > $OUT/bench_full.json 2> $OUT/bench_full.err
 cd $R && python3 tools/summarize_profiles.py $OUT
