@@ -238,6 +238,19 @@ int tante_pack_block_train(const float* in_w_folded, const float* in_b_folded, c
 int tante_block_fused_train(const float* x, const void* block_stream, int C, int n_head, int hidden, const TanteSeq* seq, int causal,
                             float eps, const TanteBlockTrain* tr, void* stream);
 
+/* Backward of the block's tail in ONE launch (C = 256, hidden 256; block_bwd.hip): from the gradient of the block output to the gradient
+ * of the attention output, i.e. the backward of  out = x1 + drop(fc2(gelu_tanh(fc1(LayerNorm2(x1))))),  x1 = xs + drop(out_proj(o))
+ * (attn_backbone.py:81-82; six launches unfused).  Reads dout (M, 256) fp32 and what tante_block_fused_train saved (hpre, xh2, st2) with
+ * its seeds; writes dx1 (M, 256) fp32 = the gradient reaching x1 (skip path + LayerNorm2 path; it is also the gradient of the skip
+ * operand xs), d_o (M, 256) bf16 = the gradient of the attention output, and the bf16 row operands of the three weight gradients:
+ * dy2 (fc2: dW2 = dy2^T act), dhpre (fc1: dW1' = dhpre^T xh2), dy1 (out-proj: dWo = dy1^T o).  The transposed weights come pre-packed:
+ * tante_pack_block_tail_bwd(fc2.weight, folded fc1 weight, out_proj.weight) into tante_block_tail_bwd_stream_bytes bytes. */
+int64_t tante_block_tail_bwd_stream_bytes(int C, int hidden);
+int tante_pack_block_tail_bwd(const float* fc2_w, const float* fc1_w_folded, const float* out_w, int C, int hidden, void* bwd_stream, void* stream);
+int tante_block_tail_bwd(const float* dout, const void* hpre, const void* xh2, const float* st2, const void* bwd_stream, int64_t M, int C,
+                         int hidden, float p_drop, uint64_t seed_out, uint64_t seed_mlp, float* dx1, void* dy2, void* dhpre, void* dy1,
+                         void* d_o, void* stream);
+
 /* ---- fused derivative head (bf16 MFMA path) ----------------------------------------------------------
  * One launch per Taylor order: rows r = (img, hp, wp) of the token stream (gathered like TANTE_A_LINEAR: the last time slot by
  * stride) -> 3 x [ConvTranspose2d k = s = 2 (+GELU erf)] -> for i < n_out:  out_i (+)= coefs[i] * derivative, where out_i is frame i

@@ -538,6 +538,41 @@ class BranchOutFn(Function):
         return dpre, dW, db, dout, None, None, None, None
 
 
+class BlockTailFn(Function):
+    """out = x1 + drop(fc2(gelu(fc1'(LN2(x1))))), x1 = xs + drop(out_proj(o)) -- the tail of a TransformerBlock behind its attention --
+    as ONE node.  Forward is always precomputed (tante_block_fused_train produced `out` and every saved tensor); backward is one launch
+    (tante_block_tail_bwd) that returns the gradients of o and of the skip operand xs and hands the three weight-gradient operand
+    pairs to the deferred shared launches.  w1f / b1f are the LayerNorm-folded fc1 parameters (FoldFn outputs with their accumulators)."""
+
+    @staticmethod
+    def forward(ctx, o, xs, Wo, bo, w1f, b1f, W2, b2, saved, bwd_stream, p, seeds):
+        ctx.save_for_backward(o, saved["hpre"], saved["xh2"], saved["st2"], saved["act"], bwd_stream)
+        ctx.params = (Wo, bo, w1f, b1f, W2, b2)
+        ctx.p, ctx.seed_out, ctx.seed_mlp = float(p), seeds[1], seeds[2]
+        return saved["out"]
+
+    @staticmethod
+    def backward(ctx, dout):
+        o, hpre, xh2, st2, act, bwd_stream = ctx.saved_tensors
+        dout = dout.contiguous()
+        if dout.dtype != torch.float32:
+            dout = dout.float()
+        M, Cc = o.shape
+        t = K.block_tail_bwd(dout, hpre, xh2, st2, bwd_stream, Cc, hpre.shape[1], ctx.p, ctx.seed_out, ctx.seed_mlp)
+        Wo, bo, w1f, b1f, W2, b2 = ctx.params
+        for W, b, dy, a in ((W2, b2, t["dy2"], act), (w1f, b1f, t["dhpre"], xh2), (Wo, bo, t["dy1"], o)):
+            gW, gb = _grad_slot(W), _grad_slot(b)
+            N, Kk = W.shape
+            if not _defer_wgrad(gW, gb, dy, a, M, N, Kk, L.BF16):
+                wgrad(_rm_linear(dy), _rm_linear(a), M, N, Kk, (N, Kk), L.BF16, device=a.device, with_bias=True, into=gW, db_into=gb)
+        return t["do"], t["dx1"], None, None, None, None, None, None, None, None, None, None
+
+
+def block_tail_ready(*params) -> bool:
+    """BlockTailFn adds its weight gradients straight into the parameters' accumulators: every one must have one."""
+    return all(_grad_slot(q) is not None for q in params)
+
+
 class ActFn(Function):
     @staticmethod
     def forward(ctx, pre, act, out_dtype):

@@ -23,15 +23,11 @@
 // into the out-proj bias at pack time:  bo' = bo + Wo . bv.
 #include "common.cuh"
 #include "fused_common.cuh"
+#include "fs_common.cuh"
 #include "block_sliced.h"
 
 namespace {
 
-constexpr int FS_C = 256;
-constexpr int FS_FRAG = 1024;                              // one wave-wide MFMA operand fragment: 64 lanes x 16 B
-constexpr int FS_W_BYTES = 6 * FS_C * FS_C * 2;               // 768 KiB: q, k, v, Wo, W1, W2 as bf16 fragments
-constexpr int FS_BIAS_FLOATS = 7 * FS_C;                   // by output feature: q | out' (folded) | fc1 | fc2 | k | v | out (plain)
-constexpr int FS_ROW = 512;                                // bytes per token row of an LDS image
 
 struct FsArgs {
   float* x;
@@ -91,85 +87,6 @@ struct FsSeqMap {
   }
 };
 
-__device__ __forceinline__ u32x4 ldg_frag(const char* p) { return *(const u32x4*)p; }
-
-// ---- cross-lane reductions without LDS traffic -------------------------------------------------------------------------------------
-// over the 16 lanes of a row (lanes that share lane >> 4): DPP quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror
-template <int CTRL>
-__device__ __forceinline__ float fs_dpp(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
-}
-__device__ __forceinline__ float row16_sum(float v) {
-  v += fs_dpp<0xB1>(v);
-  v += fs_dpp<0x4E>(v);
-  v += fs_dpp<0x141>(v);
-  return v + fs_dpp<0x140>(v);
-}
-// over the four rows of a wave (lanes l15 + 16 kk, i.e. the accumulator rows of one column): v_permlane16_swap exchanges the odd rows of
-// its first operand with the even rows of its second, v_permlane32_swap the upper half of the first with the lower half of the second;
-// fed the same value twice they return the xor-16 / xor-32 partners side by side
-template <class Op>
-__device__ __forceinline__ float rows_reduce(float v, Op op) {
-#ifdef FS_SHFL
-  v = op(v, __shfl_xor(v, 16));
-  return op(v, __shfl_xor(v, 32));
-#else
-  const unsigned u = __float_as_uint(v);
-  auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
-  v = op(__uint_as_float(a[0]), __uint_as_float(a[1]));
-  const unsigned w = __float_as_uint(v);
-  auto b = __builtin_amdgcn_permlane32_swap(w, w, false, false);
-  return op(__uint_as_float(b[0]), __uint_as_float(b[1]));
-#endif
-}
-__device__ __forceinline__ float rows_max(float v) { return rows_reduce(v, [](float a, float b) { return fmaxf(a, b); }); }
-__device__ __forceinline__ float rows_sum(float v) { return rows_reduce(v, [](float a, float b) { return a + b; }); }
-
-// acc[j][tt] (+)= W[16-row tile j of the wave's 16 RT-row slice][all 256 k] . image[token tile tt], k-step outermost.
-//
-// Weights: the six matrices of the block (q, k, v, Wo, W1, W2) are ONE stream of 48 k-steps per wave (fragment (g, j) at
-// wq + (16 g + j) KiB, g = 8 m + ks), and the register ring `wb` that prefetches it PF k-steps ahead lives for the whole kernel: while
-// a GEMM runs its last k-steps the first fragments of the NEXT matrix are already on their way, across the barriers and the
-// attention / LayerNorm / GELU phases in between, so no GEMM starts by waiting for L2.  Image fragments come through the explicit
-// LDS read ring of mfma_stream (counted lgkmcnt, reads RING fragments ahead of their MFMAs), each feeding all RT row tiles.  All
-// RT x NTT accumulators are live, a matrix's weights never are: that keeps the kernel inside 256 registers at two waves per SIMD.
-// The inline-asm reads and waits carry memory clobbers, so the compiler cannot sink the prefetch loads towards their use (left alone
-// it loads every fragment right in front of its first MFMA and waits for it there).
-// SWAP = false: D[feature][token] = mfma(W, img);  SWAP = true: D[token][feature] = mfma(img, W)  (the V projection).
-constexpr int FS_KSTEPS = 48;
-// first PF k-steps of matrix M into the ring (the stream is primed twice per launch: before LayerNorm1 for q | k | v, after the
-// attention for Wo | W1 | W2; in between the GEMMs keep it running across their own boundaries, GEND = where the run ends)
-template <int M, int RT, int PF>
-__device__ __forceinline__ void fs_wring_prime(const char* wq, u32x4 (&wb)[PF + 1][RT]) {
-#pragma unroll
-  for (int p = 0; p < PF; ++p)
-#pragma unroll
-    for (int j = 0; j < RT; ++j) wb[(8 * M + p) % (PF + 1)][j] = ldg_frag(wq + (16 * (8 * M + p) + j) * FS_FRAG);
-}
-template <int M, int GEND, int NTT, int RT, bool SWAP, int PF>
-__device__ __forceinline__ void fs_slice_gemm(const char* wq, u32x4 (&wb)[PF + 1][RT], const char* img, const int (&rdo)[4],
-                                              f32x4 (&acc)[RT][NTT]) {
-  unsigned ab[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) ab[j] = lds_addr(img + rdo[j]);
-  mfma_stream<8 * NTT, 4>(
-      [&](auto ic) {
-        constexpr int i = decltype(ic)::value, ks = i / NTT, tt = i % NTT;
-        return LdsAddr<tt * 8192 + (ks >> 2) * 256>{ab[ks & 3]};
-      },
-      [&](auto ic, const u32x4& tf) {
-        constexpr int i = decltype(ic)::value, ks = i / NTT, tt = i % NTT, g = 8 * M + ks;
-        if constexpr (tt == 0 && g + PF < GEND) {
-#pragma unroll
-          for (int j = 0; j < RT; ++j) wb[(g + PF) % (PF + 1)][j] = ldg_frag(wq + (16 * (g + PF) + j) * FS_FRAG);
-        }
-#pragma unroll
-        for (int j = 0; j < RT; ++j) {
-          if constexpr (SWAP) acc[j][tt] = mfma_bf16(tf, wb[g % (PF + 1)][j], acc[j][tt]);
-          else acc[j][tt] = mfma_bf16(wb[g % (PF + 1)][j], tf, acc[j][tt]);
-        }
-      });
-}
 
 // largest divisor of ntt that keeps  group x nk  score tiles within 8 (32 accumulator registers)
 constexpr int fs_group(int ntt, int nk) {

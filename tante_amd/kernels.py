@@ -324,6 +324,28 @@ def pack_block_train(params: Sequence[torch.Tensor], C_: int, hidden: int) -> to
     return st
 
 
+def pack_block_tail_bwd(fc2_w: torch.Tensor, fc1_w_folded: torch.Tensor, out_w: torch.Tensor, C_: int, hidden: int) -> torch.Tensor:
+    _dev(fc2_w, fc1_w_folded, out_w)
+    st = torch.empty(L.lib().tante_block_tail_bwd_stream_bytes(C_, hidden), dtype=torch.uint8, device=fc2_w.device)
+    L.check(L.lib().tante_pack_block_tail_bwd(_p(fc2_w.detach()), _p(fc1_w_folded.detach()), _p(out_w.detach()), C_, hidden, _p(st), _stream()),
+            "tante_pack_block_tail_bwd")
+    return st
+
+
+def block_tail_bwd(dout: torch.Tensor, hpre, xh2, st2, bwd_stream, C_: int, hidden: int, p_drop: float, seed_out: int, seed_mlp: int) -> dict:
+    """-> {"dx1" fp32, "do", "dy2", "dhpre", "dy1" bf16}, each (M, 256) (tante_block_tail_bwd)."""
+    _dev(dout, hpre, xh2, st2, bwd_stream)
+    M = dout.numel() // C_
+    dev = dout.device
+    t = {"dx1": torch.empty(M, C_, dtype=torch.float32, device=dev)}
+    for k in ("do", "dy2", "dhpre", "dy1"):
+        t[k] = torch.empty(M, C_, dtype=torch.bfloat16, device=dev)
+    L.check(L.lib().tante_block_tail_bwd(_p(dout), _p(hpre), _p(xh2), _p(st2), _p(bwd_stream), M, C_, hidden, float(p_drop), int(seed_out),
+                                         int(seed_mlp), _p(t["dx1"]), _p(t["dy2"]), _p(t["dhpre"]), _p(t["dy1"]), _p(t["do"]), _stream()),
+            "tante_block_tail_bwd")
+    return t
+
+
 def block_fused_train(x: torch.Tensor, block_stream: torch.Tensor, C_: int, n_head: int, hidden: int, seq: L.Seq, causal: bool, eps: float,
                       p_drop: float, seeds) -> dict:
     """Training forward of a whole block in one launch (tante_block_fused_train): -> the block output and every saved tensor of the

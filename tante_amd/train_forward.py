@@ -12,7 +12,7 @@ import torch
 from . import _lib as L
 from . import kernels as K
 from . import stages as S
-from .autograd import (ActFn, AttentionFn, AxisMlpFn, BranchOutFn, DeconvFn, DropoutAddFn, FilmPosFn, FoldFn, LayerNormFn, LayerNormSkipFn, LinearFn, PatchEmbedFn, RtReduceFn,
+from .autograd import (ActFn, AttentionFn, BlockTailFn, block_tail_ready, AxisMlpFn, BranchOutFn, DeconvFn, DropoutAddFn, FilmPosFn, FoldFn, LayerNormFn, LayerNormSkipFn, LinearFn, PatchEmbedFn, RtReduceFn,
                        TaylorFn)
 
 
@@ -52,6 +52,7 @@ def _folded(lin_w, lin_b, ln):
 
 
 FUSED_TRAIN_FORWARD = __import__("os").environ.get("TANTE_TRAIN_FUSED", "1") != "0"
+FUSED_TAIL_BACKWARD = __import__("os").environ.get("TANTE_TRAIN_FUSED_BWD", "1") != "0"
 
 
 def block_train(blk, x: torch.Tensor, seq, causal: bool, compute: int) -> torch.Tensor:
@@ -73,6 +74,18 @@ def block_train(blk, x: torch.Tensor, seq, causal: bool, compute: int) -> torch.
             if _FOLDS is not None:
                 _FOLDS[key] = stream
         t = K.block_fused_train(x.detach(), stream, blk.embed_dim, blk.n_head, blk.hidden, seq, causal, blk.ln1.eps, p, seeds)
+        if FUSED_TAIL_BACKWARD and torch.is_grad_enabled() and block_tail_ready(a.out_proj.weight, a.out_proj.bias, w1, b1, m[2].weight, m[2].bias):
+            # the block behind its attention as ONE autograd node whose backward is ONE launch (tante_block_tail_bwd)
+            key = ("bt_stream", id(blk))
+            bstream = _FOLDS.get(key) if _FOLDS is not None else None
+            if bstream is None:
+                bstream = K.pack_block_tail_bwd(m[2].weight, w1, a.out_proj.weight, blk.embed_dim, blk.hidden)
+                if _FOLDS is not None:
+                    _FOLDS[key] = bstream
+            xh, xs = LayerNormSkipFn.apply(x, blk.ln1.eps, adt, (t["xh1"], t["st1"]))
+            qkv = LinearFn.apply(xh, w_in, b_in, None, compute, adt, t["qkv"])
+            o = AttentionFn.apply(qkv, seq, blk.embed_dim, blk.n_head, causal, p, (t["o"], seeds[0]))
+            return BlockTailFn.apply(o, xs, a.out_proj.weight, a.out_proj.bias, w1, b1, m[2].weight, m[2].bias, t, bstream, p, seeds)
         xh, xs = LayerNormSkipFn.apply(x, blk.ln1.eps, adt, (t["xh1"], t["st1"]))
         qkv = LinearFn.apply(xh, w_in, b_in, None, compute, adt, t["qkv"])
         o = AttentionFn.apply(qkv, seq, blk.embed_dim, blk.n_head, causal, p, (t["o"], seeds[0]))

@@ -88,7 +88,7 @@ def test_attention_mfma_fwd_bwd_against_float64_sdpa(dev, letter, B, T, H, W, ca
 # ---------------------------------------------------------------------------------------------------
 # g14: the production-shape train step against the REFERENCE's gradients
 # ---------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("fused_fwd", [True, False])
+@pytest.mark.parametrize("fused_fwd", ["fwd+tail_bwd", "fwd", "none"])
 @pytest.mark.parametrize("defer", [True, False])
 @pytest.mark.parametrize("mode", ["bf16", "fp32"])
 def test_g14_wide_train_step(dev, mode, defer, fused_fwd, monkeypatch):
@@ -100,12 +100,18 @@ def test_g14_wide_train_step(dev, mode, defer, fused_fwd, monkeypatch):
     from tante_amd import autograd as A
     from conftest import g14_setup, G14_FIELDS, G14_RES
     from tante_amd import train_forward as TF
-    if mode == "fp32" and not fused_fwd:
-        pytest.skip("the fused training forward is a bf16 kernel: fp32 has one path")
+    if mode == "fp32" and fused_fwd != "none":
+        pytest.skip("the fused training kernels are bf16: fp32 has one path")
     monkeypatch.setattr(A, "DEFER_WGRAD", defer)
-    monkeypatch.setattr(TF, "FUSED_TRAIN_FORWARD", fused_fwd)      # one launch per block (tante_block_fused_train) vs one per operator
+    monkeypatch.setattr(TF, "FUSED_TRAIN_FORWARD", fused_fwd != "none")      # one launch per block (tante_block_fused_train) vs one per operator
+    monkeypatch.setattr(TF, "FUSED_TAIL_BACKWARD", fused_fwd == "fwd+tail_bwd")   # + one launch for the block tail's backward
     m, batch, g, names = g14_setup()
     m = m.to(dev).train().set_compute(mode)
+    if fused_fwd == "fwd+tail_bwd":
+        opt = tante_amd.FlatAdamW(m.parameters(), lr=1e-4)      # the one-launch tail backward adds into the parameters' accumulators
+        opt.zero_grad()
+        from tante_amd.autograd import block_tail_ready
+        assert block_tail_ready(*list(m.parameters())[:4])
     md = tante_amd.TanteMetadata(n_fields=G14_FIELDS, spatial_resolution=G14_RES)
     fmt = tante_amd.DefaultChannelsFirstFormatter(md)
     b = {k: v.to(dev) for k, v in batch.items()}
@@ -352,17 +358,28 @@ def test_fused_training_forward_equals_unfused(dev, letter, B, T, H, W, p, monke
     n = B * T * H * W
     x0 = (torch.randn(n, 256, generator=torch.Generator().manual_seed(n)) * 1.3 + 0.2).to(dev)
     w = torch.randn(n, 256, generator=torch.Generator().manual_seed(n + 1)).to(dev)
+    opt = tante_amd.FlatAdamW(blk.parameters(), lr=1e-3)     # gives every parameter its accumulator (the fused tail backward adds into them)
     res = {}
-    for fused in (True, False):
-        monkeypatch.setattr(TF, "FUSED_TRAIN_FORWARD", fused)
-        A._SEED[0] = 1000                                     # both runs draw the same three seeds
-        blk.zero_grad()
+    for fused in ("tail", True, False):
+        monkeypatch.setattr(TF, "FUSED_TRAIN_FORWARD", bool(fused))
+        monkeypatch.setattr(TF, "FUSED_TAIL_BACKWARD", fused == "tail")
+        A._SEED[0] = 1000                                     # every run draws the same three seeds
+        opt.zero_grad()
         x = x0.clone().requires_grad_(True)
         with TF.fold_scope():
             y = TF.block_train(blk, x, seq, letter == "T", L.BF16)
             A.run_backward((y * w).sum())
         res[fused] = (y.detach().cpu(), x.grad.cpu(), {k: v.grad.detach().cpu().clone() for k, v in blk.named_parameters()})
-    (yf, gxf, gpf), (yu, gxu, gpu) = res[True], res[False]
+    (yt, gxt, gpt), (yf, gxf, gpf), (yu, gxu, gpu) = res["tail"], res[True], res[False]
+    assert torch.equal(yt, yf)                                # same forward kernel
+    assert max_rel(gxt, gxu) < 4e-2, max_rel(gxt, gxu)        # one-launch tail backward vs the operator-by-operator backward
+    for k in gpt:
+        if "in_proj_bias" in k:
+            a_, b_ = torch.cat([gpt[k][:256], gpt[k][512:]]), torch.cat([gpu[k][:256], gpu[k][512:]])
+        else:
+            a_, b_ = gpt[k], gpu[k]
+        record_parity(rel_err(a_, b_), max_rel(a_, b_), 4e-2, "bf16", f"fused tail backward vs unfused, {k}, p={p}")
+        assert max_rel(a_, b_) < 4e-2, ("tail", k, max_rel(a_, b_))
     e = max_rel(yf, yu)
     record_parity(rel_err(yf, yu), e, 1e-2, "bf16", f"fused vs unfused training forward, p={p}")
     assert e < 1e-2 and rel_err(yf - x0.cpu(), yu - x0.cpu()) < 3e-2, (e, rel_err(yf - x0.cpu(), yu - x0.cpu()))
