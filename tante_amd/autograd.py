@@ -568,6 +568,37 @@ class BlockTailFn(Function):
         return t["do"], t["dx1"], None, None, None, None, None, None, None, None, None, None
 
 
+class BlockFn(Function):
+    """A whole TransformerBlock as ONE autograd node (training, bf16, fused kernels): forward is tante_block_fused_train's result, backward
+    is tante_block_tail_bwd followed by the three operators in front of it (attention backward, the q | k | v data-gradient GEMM with its
+    deferred weight gradient, LayerNorm1 backward with the skip gradient added in the same pass) -- the SAME code the per-operator nodes
+    run (their static backward methods, called on plain records), minus six trips through the autograd engine per block call: with one
+    launch per block the host, not the GPU, was setting the train step's time."""
+
+    @staticmethod
+    def forward(ctx, x, w_in, b_in, Wo, bo, w1f, b1f, W2, b2, saved, bwd_stream, seq, n_head, causal, p, seeds, compute):
+        ctx.save_for_backward(x, saved["st1"], saved["xh1"], saved["qkv"], saved["o"], saved["hpre"], saved["xh2"], saved["st2"], saved["act"],
+                              bwd_stream, w_in)
+        ctx.params = (w_in, b_in, Wo, bo, w1f, b1f, W2, b2)
+        ctx.meta = (seq, n_head, bool(causal), float(p), tuple(seeds), compute)
+        return saved["out"]
+
+    @staticmethod
+    def backward(ctx, dout):
+        from types import SimpleNamespace as NS
+        x, st1, xh1, qkv, o, hpre, xh2, st2, act, bwd_stream, w_in_s = ctx.saved_tensors
+        w_in, b_in, Wo, bo, w1f, b1f, W2, b2 = ctx.params
+        seq, n_head, causal, p, seeds, compute = ctx.meta
+        tail = NS(saved_tensors=(o, hpre, xh2, st2, act, bwd_stream), params=(Wo, bo, w1f, b1f, W2, b2), p=p, seed_out=seeds[1], seed_mlp=seeds[2])
+        r = BlockTailFn.backward(tail, dout)
+        d_o, dx1 = r[0], r[1]
+        dqkv = AttentionFn.backward(NS(saved_tensors=(qkv,), seq=seq, C=x.shape[1], nh=n_head, causal=causal, p=p, seed=seeds[0]), d_o)[0]
+        dxh = LinearFn.backward(NS(saved_tensors=(xh1, w_in_s), compute=compute, has_bias=True, has_res=False, params=(w_in, b_in),
+                                   needs_input_grad=(True, True, True, False, False, False, False)), dqkv)[0]
+        dx = LayerNormSkipFn.backward(NS(saved_tensors=(x, st1)), dxh, dx1)[0]
+        return (dx,) + (None,) * 16
+
+
 def block_tail_ready(*params) -> bool:
     """BlockTailFn adds its weight gradients straight into the parameters' accumulators: every one must have one."""
     return all(_grad_slot(q) is not None for q in params)

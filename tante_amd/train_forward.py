@@ -12,7 +12,7 @@ import torch
 from . import _lib as L
 from . import kernels as K
 from . import stages as S
-from .autograd import (ActFn, AttentionFn, BlockTailFn, block_tail_ready, AxisMlpFn, BranchOutFn, DeconvFn, DropoutAddFn, FilmPosFn, FoldFn, LayerNormFn, LayerNormSkipFn, LinearFn, PatchEmbedFn, RtReduceFn,
+from .autograd import (ActFn, AttentionFn, BlockFn, BlockTailFn, block_tail_ready, AxisMlpFn, BranchOutFn, DeconvFn, DropoutAddFn, FilmPosFn, FoldFn, LayerNormFn, LayerNormSkipFn, LinearFn, PatchEmbedFn, RtReduceFn,
                        TaylorFn)
 
 
@@ -82,6 +82,9 @@ def block_train(blk, x: torch.Tensor, seq, causal: bool, compute: int) -> torch.
                 bstream = K.pack_block_tail_bwd(m[2].weight, w1, a.out_proj.weight, blk.embed_dim, blk.hidden)
                 if _FOLDS is not None:
                     _FOLDS[key] = bstream
+            if block_tail_ready(w_in, b_in):
+                return BlockFn.apply(x, w_in, b_in, a.out_proj.weight, a.out_proj.bias, w1, b1, m[2].weight, m[2].bias, t, bstream, seq,
+                                     blk.n_head, causal, p, seeds, compute)
             xh, xs = LayerNormSkipFn.apply(x, blk.ln1.eps, adt, (t["xh1"], t["st1"]))
             qkv = LinearFn.apply(xh, w_in, b_in, None, compute, adt, t["qkv"])
             o = AttentionFn.apply(qkv, seq, blk.embed_dim, blk.n_head, causal, p, (t["o"], seeds[0]))
