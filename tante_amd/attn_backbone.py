@@ -197,7 +197,7 @@ class Attn_Backbone(nn.Module):
             z, ts, bs, film = film_src
             K.axis_hw_film(x, z, ts, bs, film, B * T, H, W, C_, (vp[0].weight, vp[0].bias, vp[2].weight, vp[2].bias),
                            (hp[0].weight, hp[0].bias, hp[2].weight, hp[2].bias), compute)
-        elif K.axis_hw_supported(H, W, C_):      # both axes in one pass over x, contractions on MFMA     l.140-143
+        elif K.axis_hw_supported(H, W, C_, compute):      # both axes in one pass over x, contractions on MFMA     l.140-143
             K.axis_hw(x, B * T, H, W, C_, (vp[0].weight, vp[0].bias, vp[2].weight, vp[2].bias),
                       (hp[0].weight, hp[0].bias, hp[2].weight, hp[2].bias), compute)
         else:

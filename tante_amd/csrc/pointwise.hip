@@ -410,6 +410,240 @@ __global__ __launch_bounds__(AXT) void axis_hw_kernel(float* __restrict__ x, Axi
   }
 }
 
+// ---- the same stage for whole 16-row tiles (bf16 compute, nH = 16 MTH, nW = 16 MTW): the shapes the rollouts run ----------
+// Every size is a compile-time constant, so the generic kernel's `p < n` predication (a third of its instructions were EXEC
+// bookkeeping and address arithmetic: 2 000 VALU per wave for 24 MFMAs) disappears, and the plane layout is chosen for WIDE accesses
+// on both sides.  Global side: a workgroup owns CT = 32 channels of a plane when that fits the LDS (whole 128-byte lines per token:
+// in-kernel stamps showed the 64-byte pieces of 16-channel tiles loading at 2.2 - 2.7 TB/s), else 16; the plane arrives by LDS-DMA
+// (`global_load_lds`, lane-linear: one instruction = 1 KiB = 8 / 16 consecutive tokens of a row, no register round trip) and the
+// workgroup id is turned into XCD-major order so that the channel tiles of one plane share an L2.  LDS side: a token's CT channels are
+// contiguous with no padding, rows are padded to RS = 32 (mod 64) floats, and one wave iteration handles 32 lines as two MFMA column
+// sets: lane (l15, kk) owns a channel PAIR (CT = 32: channels 2 l15, + 1 of one line group; CT = 16: channels 2 (l15 & 7), + 1 of
+// group l15 >> 3 of a group pair), so every gather, residual read and write-back is a ds_read_b64 / ds_write_b64 (set 0 takes .x,
+// set 1 takes .y).  The k slot (kk, e) of the 32-wide MFMA chunk ks holds line position 32 ks + 4 e + kk (W1's columns are loaded in
+// that order): with it the 32 lanes of a ds_read_b64 service group cover all 64 banks in both phases (kk moves by one token along
+// w, or by RS = 32 (mod 64) floats along h; the other lane bits fill the 32 floats in between).
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+__host__ __device__ constexpr int axe_rs(int nW, int ct) { return nW * ct + 32; }
+
+template <int MT>
+struct AxeW {   // A-operand fragments of W1 (k = line position) and W2 (k = hidden unit, accumulator order) + this lane's bias rows
+  static constexpr int KB = (MT + 1) / 2;
+  u32x4 a1[MT][KB], a2[MT][KB];
+  f32x4 b1[MT], b2[MT];
+};
+
+// The two n x n weights of a phase reach the lanes through LDS: the workgroup reads them coalesced (every lane gathering its own
+// fragment elements from global memory cost 100 scattered load instructions per wave -- stamps showed them, not the plane, holding
+// the memory pipe for the first third of the kernel) and scatters them as bf16 into FRAGMENT order, so that afterwards a lane's
+// A operand is one conflict-free ds_read_b128 per (row tile, k chunk).  Layout (u16 units): w1 at 0, w2 at MT KB 512, fragment
+// (mt, ks) at (mt KB + ks) 512, lane l at + 8 l, k slot e at + e; then (byte offset axe_wbytes - 8 N) b1 | b2 as floats.
+template <int MT>
+__host__ __device__ constexpr int axe_wbytes() { return 2 * MT * ((MT + 1) / 2) * 1024 + 2 * 16 * MT * 4; }
+
+template <int MT, int NT>
+__device__ __forceinline__ void axe_stage_weights(const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2,
+                                                  const float* __restrict__ b2, char* wst, int tid) {
+  constexpr int N = 16 * MT, KB = (MT + 1) / 2;
+  unsigned short* f = (unsigned short*)wst;
+  for (int i = tid; i < N * N; i += NT) {
+    const int row = i / N, col = i - row * N;          // N is a compile-time constant
+    const int mt = row >> 4, l15 = row & 15;
+    {  // w1[row][col]: col is the line position p = 32 ks + 4 e + kk
+      const int ks = col >> 5, e = (col & 31) >> 2, kk = col & 3;
+      __bf16 v = (__bf16)w1[i];
+      f[(mt * KB + ks) * 512 + (kk * 16 + l15) * 8 + e] = __builtin_bit_cast(unsigned short, v);
+    }
+    {  // w2[row][col]: col is the hidden unit j = (2 ks + (e >> 2)) 16 + 4 kk + (e & 3)
+      const int tile = col >> 4, ks = tile >> 1, kk = (col & 15) >> 2, e = (tile & 1) * 4 + (col & 3);
+      __bf16 v = (__bf16)w2[i];
+      f[(MT * KB + mt * KB + ks) * 512 + (kk * 16 + l15) * 8 + e] = __builtin_bit_cast(unsigned short, v);
+    }
+  }
+  float* bs = (float*)(wst + 2 * MT * KB * 1024);
+  if (tid < N) { bs[tid] = b1[tid]; bs[N + tid] = b2[tid]; }
+}
+
+template <int MT>
+__device__ __forceinline__ void axe_load_weights(const char* wst, int lane, int kk, AxeW<MT>& W) {
+  constexpr int N = 16 * MT, KB = AxeW<MT>::KB;
+  const u32x4* f = (const u32x4*)wst;
+  const float* bs = (const float*)(wst + 2 * MT * KB * 1024);
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+    for (int ks = 0; ks < KB; ++ks) {
+      W.a1[mt][ks] = f[(mt * KB + ks) * 64 + lane];
+      W.a2[mt][ks] = f[(MT * KB + mt * KB + ks) * 64 + lane];
+      if (2 * ks + 1 >= MT) {    // odd MT: the upper half of the last k chunk does not exist (and was never written)
+        W.a1[mt][ks][2] = W.a1[mt][ks][3] = 0u;
+        W.a2[mt][ks][2] = W.a2[mt][ks][3] = 0u;
+      }
+    }
+    W.b1[mt] = *(const f32x4*)(bs + mt * 16 + 4 * kk);
+    W.b2[mt] = *(const f32x4*)(bs + N + mt * 16 + 4 * kk);
+  }
+}
+
+// one phase over the LDS plane: lines of N = 16 MT positions with element stride LS floats; NG line groups GS floats apart.
+// GOUT: the updated lines go to global memory (position stride gls, group stride ggs floats) instead of back into the plane.
+template <int MT, int CT, int NWV, int NG, int LS, int GS, bool GOUT>
+__device__ __forceinline__ void axe_phase(float* plane, const AxeW<MT>& W, int wave, int l15, int kk, float* __restrict__ gout, long gls,
+                                          long ggs) {
+  constexpr int KB = AxeW<MT>::KB, NIT = CT == 32 ? NG : NG / 2, NE = 8 * KB;
+  static_assert(CT == 32 || NG % 2 == 0, "16-channel tiles process line groups in pairs");
+  // this lane's (line group within the iteration, channel pair)
+  const int gsel = CT == 32 ? 0 : (l15 >> 3), cp = CT == 32 ? 2 * l15 : 2 * (l15 & 7);
+  constexpr int GPI = CT == 32 ? 1 : 2;     // line groups per iteration
+  auto gather = [&](int it, f32x2 (&xv)[NE]) {
+    const float* base = plane + (GPI * it + gsel) * GS + cp + kk * LS;
+#pragma unroll
+    for (int ks = 0; ks < KB; ++ks)
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (ks * 32 + 4 * e < 16 * MT) xv[ks * 8 + e] = *(const f32x2*)(base + (ks * 32 + 4 * e) * LS);
+        else xv[ks * 8 + e] = f32x2{0.f, 0.f};
+  };
+  f32x2 xa[NE], xn[NE];
+  if (wave < NIT) gather(wave, xa);
+  for (int it = wave; it < NIT; it += NWV) {
+    if (it + NWV < NIT) gather(it + NWV, xn);
+    f32x4 out[2][MT];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      u32x4 xb[KB];
+#pragma unroll
+      for (int ks = 0; ks < KB; ++ks)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) xb[ks][q] = pack_bf16x2(xa[ks * 8 + 2 * q][a], xa[ks * 8 + 2 * q + 1][a]);
+      f32x4 d1[2 * KB];
+#pragma unroll
+      for (int mt = 0; mt < 2 * KB; ++mt) d1[mt] = mt < MT ? W.b1[mt < MT ? mt : 0] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int ks = 0; ks < KB; ++ks)
+          d1[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, W.a1[mt][ks]), __builtin_bit_cast(bf16x8, xb[ks]), d1[mt], 0, 0, 0);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) d1[mt] = gelu_poly4<false>(d1[mt]);
+      u32x4 hb[KB];
+#pragma unroll
+      for (int ks = 0; ks < KB; ++ks) {
+        const f32x4 lo = d1[2 * ks], hi = d1[2 * ks + 1];
+        hb[ks] = u32x4{pack_bf16x2(lo[0], lo[1]), pack_bf16x2(lo[2], lo[3]), pack_bf16x2(hi[0], hi[1]), pack_bf16x2(hi[2], hi[3])};
+      }
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        out[a][mt] = W.b2[mt];
+#pragma unroll
+        for (int ks = 0; ks < KB; ++ks)
+          out[a][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, W.a2[mt][ks]), __builtin_bit_cast(bf16x8, hb[ks]), out[a][mt], 0, 0, 0);
+      }
+    }
+    float* rbase = plane + (GPI * it + gsel) * GS + cp + 4 * kk * LS;   // this lane's output rows: positions 16 mt + 4 kk + r
+    float* gbase = GOUT ? gout + (long)(GPI * it + gsel) * ggs + cp + 4 * kk * gls : nullptr;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        f32x2 v = *(const f32x2*)(rbase + (16 * mt + r) * LS);
+        v[0] += out[0][mt][r];
+        v[1] += out[1][mt][r];
+        if constexpr (GOUT) *(f32x2*)(gbase + (long)(16 * mt + r) * gls) = v;
+        else *(f32x2*)(rbase + (16 * mt + r) * LS) = v;      // these 32 lines belong to this wave alone
+      }
+#pragma unroll
+    for (int j = 0; j < NE; ++j) xa[j] = xn[j];
+  }
+}
+
+// diagnostic builds (-DTANTE_ABLATE) only: per-wave shader-clock stamps at the stage boundaries (tools/axe_stamps.py); empty otherwise
+#ifdef TANTE_ABLATE
+unsigned long long* g_axe_stamps = nullptr;
+#define AXE_STAMP(k)                                                                  \
+  do {                                                                                \
+    if (stamps) {                                                                     \
+      const unsigned long long t_ = __builtin_amdgcn_s_memtime();                     \
+      if (lane == 0) stamps[((long)blockIdx.x * 16 + wave) * 12 + (k)] = t_;          \
+    }                                                                                 \
+  } while (0)
+#else
+#define AXE_STAMP(k)
+#endif
+
+template <int MTH, int MTW, int CT, int NT>
+__global__ __launch_bounds__(NT) void axis_hw_exact_kernel(float* __restrict__ x, AxisSrc S, int C, const float* __restrict__ wh1,
+                                                           const float* __restrict__ bh1, const float* __restrict__ wh2,
+                                                           const float* __restrict__ bh2, const float* __restrict__ ww1,
+                                                           const float* __restrict__ bw1, const float* __restrict__ ww2,
+                                                           const float* __restrict__ bw2, unsigned long long* stamps) {
+  constexpr int NH = 16 * MTH, NW = 16 * MTW, RS = axe_rs(NW, CT), NWV = NT / 64;
+  constexpr int TPI = 256 / CT, LPT = CT / 4;    // tokens per DMA instruction (1 KiB), lanes per token
+  extern __shared__ __attribute__((aligned(16))) float plane[];  // [NH][RS], token (h, w) at h * RS + w * CT
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kk = lane >> 4, l15 = lane & 15;
+  const int ctiles = C / CT;
+  // workgroup id -> (plane, channel tile): consecutive ids go to consecutive XCDs, so id = 8 slot + xcd is turned into xcd-major order:
+  // the channel tiles of one plane then run on ONE XCD at about the same time and its L2 sees whole token rows
+  unsigned wg = blockIdx.x;
+  if (gridDim.x % 8 == 0) wg = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const long bt = wg / ctiles;
+  const int c0 = (wg % ctiles) * CT;
+  float* gx = x + bt * (long)NH * NW * C + c0;
+  AXE_STAMP(0);
+#ifdef TANTE_ABLATE
+  if (stamps && lane == 0) stamps[((long)blockIdx.x * 16 + wave) * 12 + 8] = __builtin_amdgcn_s_memrealtime();
+#endif
+  // ---- the plane: one instruction = TPI tokens of a row (lanes LPT t .. LPT t + LPT - 1 = the CT channels of token t) ------------
+  constexpr int IPR = NW / TPI;                  // instructions per row
+  if (!S.src) {
+    for (int q = wave; q < NH * IPR; q += NWV) {
+      const int h = q / IPR, j = q - h * IPR;
+      const float* g = gx + ((long)h * NW + j * TPI + lane / LPT) * C + (lane % LPT) * 4;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                       (__attribute__((address_space(3))) void*)(plane + h * RS + j * 256), 16, 0, 0);
+    }
+  } else {     // the frame-major pre-FiLM encoder cache: FiLM(t) + positional embedding while loading (the encoder epilogue's expression)
+    const long b = bt / S.T, t = bt - b * S.T;
+    const float* lsrc = S.src + t * S.t_stride + b * S.b_stride + c0;
+    const int q4 = (lane % LPT) * 4;
+    const f32x4 fa = *(const f32x4*)(S.fa + t * C + c0 + q4), fb = *(const f32x4*)(S.fb + t * C + c0 + q4);
+    for (int q = wave; q < NH * IPR; q += NWV) {
+      const int h = q / IPR, j = q - h * IPR, tokn = h * NW + j * TPI + lane / LPT;
+      const f32x4 v = *(const f32x4*)(lsrc + (long)tokn * C + q4), sv = *(const f32x4*)(S.se + (long)tokn * C + c0 + q4);
+      *(f32x4*)(plane + h * RS + j * 256 + lane * 4) = v * fa + fb + sv;
+    }
+  }
+  char* wstH = (char*)(plane + NH * RS);
+  char* wstW = wstH + axe_wbytes<MTH>();
+  axe_stage_weights<MTH, NT>(wh1, bh1, wh2, bh2, wstH, tid);
+  axe_stage_weights<MTW, NT>(ww1, bw1, ww2, bw2, wstW, tid);
+  AXE_STAMP(1);
+  __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0): this wave's part of the plane has landed
+  AXE_STAMP(2);
+  __syncthreads();
+  AXE_STAMP(3);
+  // phase H: lines along h (stride RS), one group per w (stride CT);  phase W: lines along w (stride CT), one group per h
+  {
+    AxeW<MTH> WH;
+    axe_load_weights<MTH>(wstH, lane, kk, WH);
+    axe_phase<MTH, CT, NWV, NW, RS, CT, false>(plane, WH, wave, l15, kk, nullptr, 0, 0);
+  }
+  AXE_STAMP(4);
+  AxeW<MTW> WW;
+  axe_load_weights<MTW>(wstW, lane, kk, WW);
+  __syncthreads();
+  AXE_STAMP(5);
+  axe_phase<MTW, CT, NWV, NH, CT, RS, true>(plane, WW, wave, l15, kk, gx, (long)C, (long)NW * C);
+  AXE_STAMP(6);
+#ifdef TANTE_ABLATE
+  if (stamps) {
+    __builtin_amdgcn_s_waitcnt(0x0070);
+    AXE_STAMP(7);
+    if (lane == 0) stamps[((long)blockIdx.x * 16 + wave) * 12 + 9] = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
+}
+
 // ---- FiLM tables ------------------------------------------------------------------------------------
 // a[r][c] = 1 + W2s relu(w0s * t[r] + b0s) + b2s ; b[r][c] = W2h relu(w0h * t[r] + b0h) + b2h (+ add[r][c])
 __global__ void film_table_kernel(const float* __restrict__ t, int rows, int C, const float* __restrict__ sc_w0,
@@ -575,6 +809,10 @@ static void launch_axis_hw(float* x, const AxisSrc& S, long BT, int nH, int nW, 
 static int axis_hw_impl(float* x, const AxisSrc& S, int64_t BT, int nH, int nW, int C, const float* wh1, const float* bh1, const float* wh2,
                         const float* bh2, const float* ww1, const float* bw1, const float* ww2, const float* bw2, int compute, void* stream);
 
+#ifdef TANTE_ABLATE
+extern "C" void tante_axe_set_stamps(unsigned long long* p) { g_axe_stamps = p; }
+#endif
+
 extern "C" int tante_axis_hw(float* x, int64_t BT, int nH, int nW, int C, const float* wh1, const float* bh1, const float* wh2,
                              const float* bh2, const float* ww1, const float* bw1, const float* ww2, const float* bw2,
                              int compute, void* stream) {
@@ -597,12 +835,54 @@ static int axis_hw_impl(float* x, const AxisSrc& S, int64_t BT, int nH, int nW, 
                         const float* bh2, const float* ww1, const float* bw1, const float* ww2, const float* bw2, int compute, void* stream) {
   if (!x || !wh1 || !bh1 || !wh2 || !bh2 || !ww1 || !bw1 || !ww2 || !bw2) TANTE_FAIL(-1, "tante_axis_hw: null pointer");
   if (BT <= 0 || nH <= 0 || nW <= 0 || C <= 0) TANTE_FAIL(-1, "tante_axis_hw: bad shape");
+  hipStream_t s = (hipStream_t)stream;
+  auto wbytes = [](int m) { return (size_t)(2 * m * ((m + 1) / 2) * 1024 + 2 * 16 * m * 4); };   // = axe_wbytes<m>()
+  const size_t wst_bytes = wbytes(nH / 16) + wbytes(nW / 16);
+  if (compute == TANTE_BF16 && nH % 16 == 0 && nW % 16 == 0 && nH <= 64 && nW <= 64 && C % 16 == 0 && ((uintptr_t)x % 16) == 0 &&
+      (size_t)nH * axe_rs(nW, 16) * sizeof(float) + wst_bytes <= 160 * 1024 && !getenv("TANTE_AXIS_GENERIC")) {
+    // 32-channel tiles (whole 128-byte lines per token) when the plane fits the LDS that way and still gives every CU a workgroup
+    static const int force_ct = getenv("TANTE_AXIS_CT") ? atoi(getenv("TANTE_AXIS_CT")) : 0;
+    const bool fits32 = C % 32 == 0 && (size_t)nH * axe_rs(nW, 32) * sizeof(float) + wst_bytes <= 160 * 1024;
+    const int ct = force_ct == 16 ? 16 : ((fits32 && (force_ct == 32 || BT * (C / 32) >= 192)) ? 32 : 16);
+    const size_t elds = (size_t)nH * axe_rs(nW, ct) * sizeof(float) + wst_bytes;
+    const unsigned grid = (unsigned)(BT * (C / ct));
+    // 16 waves for the 32-channel tiles when the fragments fit 128 registers (measured 16.2 against 17.2 us at 32 x 32)
+    static const int force_nt = getenv("TANTE_AXIS_NT") ? atoi(getenv("TANTE_AXIS_NT")) : 0;
+    const int nt32 = force_nt ? force_nt : ((nH <= 32 && nW <= 32) ? 1024 : 512);
+#ifdef TANTE_ABLATE
+    unsigned long long* axe_st = g_axe_stamps;
+#else
+    unsigned long long* axe_st = nullptr;
+#endif
+#define TANTE_AXE2(MH, MW, CTV, NTV)                                                                                                    \
+  {                                                                                                                                     \
+    static TantePerDevice attr;                                                                                                         \
+    attr.once([&] { (void)hipFuncSetAttribute((const void*)axis_hw_exact_kernel<MH, MW, CTV, NTV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }); \
+    hipLaunchKernelGGL((axis_hw_exact_kernel<MH, MW, CTV, NTV>), dim3(grid), dim3(NTV), elds, s, x, S, C, wh1, bh1, wh2, bh2, ww1, bw1, ww2, bw2, axe_st); \
+  }
+#define TANTE_AXE(MH, MW)                  \
+  {                                        \
+    if (ct == 32 && nt32 == 1024) TANTE_AXE2(MH, MW, 32, 1024) \
+    else if (ct == 32) TANTE_AXE2(MH, MW, 32, 512) \
+    else TANTE_AXE2(MH, MW, 16, 512)       \
+  }
+    switch ((nH / 16) * 8 + nW / 16) {
+      case 1 * 8 + 1: TANTE_AXE(1, 1); break; case 1 * 8 + 2: TANTE_AXE(1, 2); break; case 1 * 8 + 3: TANTE_AXE(1, 3); break; case 1 * 8 + 4: TANTE_AXE(1, 4); break;
+      case 2 * 8 + 1: TANTE_AXE(2, 1); break; case 2 * 8 + 2: TANTE_AXE(2, 2); break; case 2 * 8 + 3: TANTE_AXE(2, 3); break; case 2 * 8 + 4: TANTE_AXE(2, 4); break;
+      case 3 * 8 + 1: TANTE_AXE(3, 1); break; case 3 * 8 + 2: TANTE_AXE(3, 2); break; case 3 * 8 + 3: TANTE_AXE(3, 3); break;
+      case 4 * 8 + 1: TANTE_AXE(4, 1); break; case 4 * 8 + 2: TANTE_AXE(4, 2); break;
+      default: TANTE_FAIL(-2, "tante_axis_hw: no whole-tile variant for %d x %d", nH, nW);
+    }
+#undef TANTE_AXE
+#undef TANTE_AXE2
+    TANTE_CHECK_LAUNCH();
+    return 0;
+  }
   const int nmax = nH > nW ? nH : nW;
   const size_t lds = (((size_t)nH * axis_row_stride(nW) + 3) & ~(size_t)3) * sizeof(float) + 2 * (size_t)nmax * sizeof(float) +
                      2 * (size_t)nmax * (compute == TANTE_BF16 ? (nmax + 8) * 2 : nmax * 4);
   if (nmax > 64 || C % 16 || lds > 160 * 1024 || ((uintptr_t)x % 16))
     TANTE_FAIL(-2, "tante_axis_hw: needs nH, nW <= 64, C %% 16 == 0 and the plane to fit LDS (use tante_axis_mlp)");
-  hipStream_t s = (hipStream_t)stream;
   const int mt = (nmax + 15) / 16;
 #define TANTE_AHW(BF, MTV) launch_axis_hw<BF, MTV>(x, S, (long)BT, nH, nW, C, wh1, bh1, wh2, bh2, ww1, bw1, ww2, bw2, lds, s)
   if (compute == TANTE_BF16) {

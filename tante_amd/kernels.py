@@ -215,7 +215,14 @@ def axis_mlp(x: torch.Tensor, outer: int, n: int, inner: int, w1, b1, w2, b2, co
     return x
 
 
-def axis_hw_supported(nH: int, nW: int, C_: int) -> bool:
+def axis_hw_supported(nH: int, nW: int, C_: int, compute: Optional[int] = None) -> bool:
+    """Mirror of tante_axis_hw's shape rules.  Without `compute` the answer holds for both compute modes (the generic kernel's fp32
+    staging is the larger one); with compute = BF16 whole-tile planes (nH, nW multiples of 16) may be larger (axis_hw_exact_kernel)."""
+    def wbytes(m):           # axe_wbytes<m>() of pointwise.hip: both weights of an axis in fragment order + its biases
+        return 2 * m * ((m + 1) // 2) * 1024 + 128 * m
+    if (compute == L.BF16 and nH % 16 == 0 and nW % 16 == 0 and C_ % 16 == 0 and max(nH, nW) <= 64
+            and nH * (nW * 16 + 32) * 4 + wbytes(nH // 16) + wbytes(nW // 16) <= 160 * 1024):
+        return True
     n = max(nH, nW)
     rs = nW * 18
     while rs % 8 != 2:       # axis_row_stride() of pointwise.hip

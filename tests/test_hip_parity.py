@@ -559,11 +559,20 @@ def test_fused_backbone_strided_letters(dev):
 
 
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])
-@pytest.mark.parametrize("BT,nH,nW,C", [(3, 32, 32, 64), (2, 16, 48, 32), (5, 4, 6, 16), (1, 64, 16, 48), (2, 33, 7, 16), (1, 8, 64, 16)])
+@pytest.mark.parametrize("BT,nH,nW,C", [(3, 32, 32, 64), (2, 16, 48, 32), (5, 4, 6, 16), (1, 64, 16, 48), (2, 33, 7, 16), (1, 8, 64, 16),
+                                          (2, 48, 32, 32), (3, 16, 16, 16), (1, 32, 64, 16), (1, 48, 48, 32), (2, 64, 32, 16)])
 def test_axis_hw_fused(dev, mode, BT, nH, nW, C):
     """Fused vertical+horizontal propagators (MFMA) against the oracle's two sequential axis MLPs."""
     from oracle import tante_oracle as O
     Kk, L = _ops()
+    if not Kk.axis_hw_supported(nH, nW, C, Kk.COMPUTE[mode]):
+        assert nH * nW >= 32 * 48, "only the large planes may be refused"
+        with pytest.raises(RuntimeError, match="tante_axis_hw"):        # the C side must refuse, not fault
+            z = torch.zeros(BT, nH, nW, C, device=dev)
+            w = [torch.zeros(nH, nH, device=dev), torch.zeros(nH, device=dev)] * 2
+            w2 = [torch.zeros(nW, nW, device=dev), torch.zeros(nW, device=dev)] * 2
+            Kk.axis_hw(z, BT, nH, nW, C, w, w2, Kk.COMPUTE[mode])
+        return
     g = torch.Generator().manual_seed(nH * 100 + nW)
     x = torch.randn(BT, nH, nW, C, generator=g)
 
