@@ -155,6 +155,54 @@ __global__ __launch_bounds__(64 * NW, 2) void block_fs_kernel(FsArgs A) {
 #pragma unroll
   for (int tt = 0; tt < NTT; ++tt) tokidx[tt] = tok_of(16 * tt + l15);
 
+  // ---- this wave's fp32 slice of x ([16 NTT tokens][16 RT features]) between memory and the accumulator layout ----------------------
+  // In accumulator layout lane (l15, kk) holds 16 bytes of token l15: neighbouring lanes are different ROWS, and the memory pipe then
+  // works a 64-lane instruction off lane by lane (tools/ubench/ta_cost.hip: 63 clocks against 17 for row-contiguous lanes; without the
+  // residual loads / the final stores the kernel ran 2.9 / 5.4 us shorter).  So memory is touched in ROW form -- CPR = 4 RT lanes per
+  // token row, 64 / CPR rows per instruction -- and a private piece of bufA (free whenever these run) turns one form into the other:
+  // 16-byte chunk c of row r sits at chunk c ^ (r & (CPR - 1)), conflict-free for the ds_write_b128 and ds_read_b128 of both directions.
+  constexpr int CPR = 4 * RT, RPI = 64 / CPR, ROWB = CPR * 16, TILEB = 16 * ROWB;
+  constexpr int NSUB = (IMG / NW) / TILEB >= 2 ? 2 : 1;
+  static_assert((IMG / NW) >= TILEB, "staging piece too small");
+  char* const stg = bufA + wave * (IMG / NW);
+  const int rrow = lane / CPR, rchunk = lane % CPR;            // row form: this lane's row within an instruction and its chunk
+  auto slice_load = [&](const float* __restrict__ src, f32x4 (&raw)[NTT][RT]) {      // row form, straight from memory
+#pragma unroll
+    for (int tt = 0; tt < NTT; ++tt)
+#pragma unroll
+      for (int j = 0; j < RT; ++j) {
+        const int t = tok_of(16 * tt + RPI * j + rrow);
+        raw[tt][j] = *(const f32x4*)(src + (long)(t < 0 ? 0 : t) * FS_C + 16 * RT * wave + 4 * rchunk);   // dead slots: token 0's row
+      }
+  };
+  auto slice_to_acc = [&](const f32x4 (&raw)[NTT][RT], f32x4 (&acc)[RT][NTT]) {
+#pragma unroll
+    for (int tt = 0; tt < NTT; ++tt) {
+      char* sb = stg + (tt % NSUB) * TILEB;
+#pragma unroll
+      for (int j = 0; j < RT; ++j) {
+        const int r = RPI * j + rrow;
+        *(f32x4*)(sb + r * ROWB + ((rchunk ^ (r & (CPR - 1))) << 4)) = raw[tt][j];
+      }
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) acc[rt][tt] = *(const f32x4*)(sb + l15 * ROWB + (((4 * rt + kk) ^ (l15 & (CPR - 1))) << 4));
+    }
+  };
+  auto slice_store = [&](float* __restrict__ dst, const f32x4 (&acc)[RT][NTT]) {
+#pragma unroll
+    for (int tt = 0; tt < NTT; ++tt) {
+      char* sb = stg + (tt % NSUB) * TILEB;
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) *(f32x4*)(sb + l15 * ROWB + (((4 * rt + kk) ^ (l15 & (CPR - 1))) << 4)) = acc[rt][tt];
+#pragma unroll
+      for (int j = 0; j < RT; ++j) {
+        const int r = RPI * j + rrow, t = tok_of(16 * tt + r);
+        const f32x4 v = *(const f32x4*)(sb + r * ROWB + ((rchunk ^ (r & (CPR - 1))) << 4));
+        if (t >= 0) *(f32x4*)(dst + (long)t * FS_C + 16 * RT * wave + 4 * rchunk) = v;
+      }
+    }
+  };
+
   // ================================ phase 0: LayerNorm1 -> bufA ===================================================================
   // A wave-instruction reads 4 token rows x 256 contiguous bytes; a row's statistics are reduced over the 16 lanes that share it.
   {
@@ -478,14 +526,16 @@ __global__ __launch_bounds__(64 * NW, 2) void block_fs_kernel(FsArgs A) {
 
   FS_STAMP(7);
   asm volatile("" ::: "memory");   // keep the residual loads below the attention (they would double its register pressure)
-  // residual slice of this wave: x[token][16 RT w + 16 rt + 4 kk .. +3]; the loads fly while the out-proj GEMM runs
-  f32x4 xr[RT][NTT];
+  // residual slice of this wave: x[token][16 RT w .. + 16 RT), row form; the loads fly while the out-proj GEMM runs
+  f32x4 xraw[NTT][RT];
+#ifdef FS_EXP_NO_RESID     // timing experiment only (wrong results)
 #pragma unroll
-  for (int tt = 0; tt < NTT; ++tt) {
-    const float* row = x + (long)(tokidx[tt] < 0 ? 0 : tokidx[tt]) * FS_C + 16 * RT * wave + 4 * kk;   // dead: token 0's row, never stored
+  for (int tt = 0; tt < NTT; ++tt)
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) xr[rt][tt] = *(const f32x4*)(row + 16 * rt);
-  }
+    for (int j = 0; j < RT; ++j) xraw[tt][j] = f32x4{(float)tt, 1.f, 2.f, (float)j};
+#else
+  slice_load(x, xraw);
+#endif
   fs_wring_prime<3, RT, PF>(wq, wb);
   FS_STAMP(8);
   __syncthreads();
@@ -524,16 +574,12 @@ __global__ __launch_bounds__(64 * NW, 2) void block_fs_kernel(FsArgs A) {
 #pragma unroll
       for (int tt = 0; tt < NTT; ++tt) acc[rt][tt] += res[rt][tt];
   };
-  drop_add(x1, xr, A.seed_out);
-  if constexpr (TRAIN) {   // the residual after the attention half: LayerNorm2's backward reads it
-#pragma unroll
-    for (int tt = 0; tt < NTT; ++tt)
-      if (tokidx[tt] >= 0) {
-        float* row = A.x1 + (long)tokidx[tt] * FS_C + 16 * RT * wave + 4 * kk;
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) *(f32x4*)(row + 16 * rt) = x1[rt][tt];
-      }
+  {
+    f32x4 xr[RT][NTT];
+    slice_to_acc(xraw, xr);      // bufA: LayerNorm1's image died with the q/k/v GEMMs (barrier 2), LayerNorm2's comes after barrier 3
+    drop_add(x1, xr, A.seed_out);
   }
+  if constexpr (TRAIN) slice_store(A.x1, x1);   // the residual after the attention half: LayerNorm2's backward reads it
   FS_STAMP(10);
 #pragma unroll
   for (int tt = 0; tt < NTT; ++tt) {
@@ -647,13 +693,19 @@ __global__ __launch_bounds__(64 * NW, 2) void block_fs_kernel(FsArgs A) {
 #ifdef TANTE_ABLATE
     if (A.stamps && lane == 0) A.stamps[((long)blockIdx.x * 8 + wave) * 20 + 19] = __builtin_amdgcn_s_memrealtime();
 #endif
+#ifdef FS_EXP_NO_STORE     // timing experiment only (wrong results): one store per tile keeps the accumulators alive
 #pragma unroll
     for (int tt = 0; tt < NTT; ++tt)
       if (tokidx[tt] >= 0) {
         float* row = (TRAIN ? A.out : x) + (long)tokidx[tt] * FS_C + 16 * RT * wave + 4 * kk;
+        f32x4 sacc = x1[0][tt];
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) *(f32x4*)(row + 16 * rt) = x1[rt][tt];
+        for (int rt = 1; rt < RT; ++rt) sacc += x1[rt][tt];
+        if (sacc[0] == 1.2345f) *(f32x4*)row = sacc;
       }
+#else
+    slice_store(TRAIN ? A.out : x, x1);      // bufA: LayerNorm2's image died with the fc1 GEMM (barrier 5)
+#endif
   }
 }
 

@@ -30,10 +30,10 @@ __device__ __forceinline__ f32x4 hmfma(const u32x4& a, const u32x4& b, const f32
 __device__ __forceinline__ f32x4 gelu4(const f32x4& v) {
   return gelu_poly4<false>(v);
 }
-constexpr int HWAVES = 4;   // waves per workgroup (16 tokens each)
+template <int NWV>
 __device__ __forceinline__ void hglds(const char* __restrict__ g, char* l, int bytes, int tid) {   // 1 KiB per wave pass
   const int wave = tid >> 6, lane = tid & 63;
-  for (int off = wave * 1024; off < bytes; off += HWAVES * 1024)
+  for (int off = wave * 1024; off < bytes; off += NWV * 1024)
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + off + lane * 16),
                                      (__attribute__((address_space(3))) void*)(l + off), 16, 0, 0);
 }
@@ -46,53 +46,65 @@ struct HeadArgs {
   float* out; long out_bstride; int n_out;
   const float* last; long last_bstride;   // NULL: accumulate into out; else out_i = last + coef_i * d
   float coef[8];
-  int groups;            // 64-token groups
+  int groups;            // token groups of 16 NWV
   int debug;             // TANTE_HEAD_DEBUG ablation bits (timing only, results are wrong): 1 no epilogue memory, 2 no GELU, 4 no weight stream
+  unsigned long long* stamps;   // -DTANTE_ABLATE builds only (tools/head_stamps.py), else null
 };
 
-constexpr int HB = 4096;   // bias block bytes per tile (whole LDS-DMA passes)
+#ifdef TANTE_ABLATE
+unsigned long long* g_head_stamps = nullptr;
+#define HEAD_STAMP(k)                                                                       \
+  do {                                                                                      \
+    if (A.stamps) {                                                                         \
+      const unsigned long long t_ = __builtin_amdgcn_s_memtime();                           \
+      if (lane == 0) A.stamps[((long)blockIdx.x * 8 + wave) * 12 + (k)] = t_;               \
+    }                                                                                       \
+  } while (0)
+#else
+#define HEAD_STAMP(k)
+#endif
+
+constexpr int HB = 1024;   // bias block bytes per tile (one LDS-DMA pass)
 
 // sizes for C = 32 * CB:  stage 1: K = C, 4 pixel tiles of C/2 rows;  stage 2: K = C/2, 4 tiles of C/4 rows;  stage 3: K = C/4, 64 rows
 template <int CB>
 struct HeadGeom {
   static constexpr int C = 32 * CB, C1 = C / 2, C2 = C / 4;
   static constexpr int CPR1 = CB * 4, CPR2 = CB * 2, CPR3 = CB;          // 16-byte chunks per row (K / 8)
-  static constexpr int NS1 = C1 / 16, NS2 = C2 / 16, NSH = NS1 / 2;      // 16-row sub-tiles (NSH: per half W1 tile)
+  static constexpr int NS1 = C1 / 16, NS2 = C2 / 16;                     // 16-row sub-tiles
   static constexpr int KB2 = C1 / 32, KB3 = C2 / 32;                     // k-blocks of stages 2, 3
   static constexpr int T1 = C1 * CPR1 * 16 + HB, T2 = C2 * CPR2 * 16 + HB, T3 = 64 * CPR3 * 16 + HB;
-  static constexpr int HALF1 = (C1 / 2) * CPR1 * 16;                     // half a W1 pixel tile (rows [0, C1/2) or [C1/2, C1))
-  static constexpr int SLOT = HALF1 > T2 ? HALF1 : T2;
-  static constexpr int B1S = 1024;                                       // stage-1 bias of this workgroup's pixel
-  static constexpr int LDS = T3 + B1S + 2 * SLOT;
+  static constexpr int LDS = T3 + T1 + 4 * T2;                           // C = 256: 9 + 65 + 4 x 17 = 142 KiB
 };
 
-// Work split: a workgroup owns 64 tokens AND one stage-1 pixel p; everything downstream of that pixel (its 4 sub-pixels, their
-// 2 x 2 x D values) depends on nothing else, so the four pixel workgroups of a token group never talk.  That quadruples the number
-// of waves over a token-only split (B = 8 has just 512 token groups of 16 for 1024 SIMDs) and shrinks the per-workgroup stream to
-// W1[p] + W2 + W3, small enough for two workgroups per CU -- the kernel is latency-bound per wave, so co-resident waves are what
-// hides the LDS / MFMA / epilogue-memory latencies.  blockIdx -> (group, p) keeps the four pixels of a group on one XCD (their
-// output sectors interleave, the L2 merges them).
-template <int CB>
-__global__ __launch_bounds__(HWAVES * 64, 2) void fused_head_kernel(const HeadArgs A) {
+// Work split: a workgroup owns 16 NWV tokens AND one stage-1 pixel p; everything downstream of that pixel (its 4 sub-pixels, their
+// 2 x 2 x D values) depends on nothing else, so the four pixel workgroups of a token group never talk.  The workgroup's WHOLE weight
+// stream -- W3, W1[p], the four W2 tiles: 142 KiB at C = 256 -- is resident in LDS: every LDS-DMA pass, the token rows and the
+// epilogue's read-modify-write operands are issued in the first few hundred cycles, ONE wait + barrier follows, and the three stages
+// then run without another barrier.  (Round 1 streamed the tiles through a two-slot ring with a wait + barrier per tile: seven
+// L2 round trips in a row, each ~2.5 us because the compute between them is 16 - 64 MFMAs -- the kernel sat at 22 us for 54 MB of
+// traffic, waves parked 59 % of the time.)  One workgroup per CU; blockIdx -> (group, p) keeps the four pixels of a group on one
+// XCD (their output sectors interleave, the L2 merges them).
+template <int CB, int NWV>
+__global__ __launch_bounds__(NWV * 64, 1) void fused_head_kernel(const HeadArgs A) {
   using G = HeadGeom<CB>;
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // [W3 | bias3][bias1 p][slot 0][slot 1]
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [W3 | bias3][W1 p | bias1 p][W2 q | bias2 q] x 4
   char* w3s = smem;
-  char* b1s = smem + G::T3;
-  char* slots = smem + G::T3 + G::B1S;
+  char* w1s = smem + G::T3;
+  char* w2s = smem + G::T3 + G::T1;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kk = lane >> 4, l15 = lane & 15;
   const int p = (blockIdx.x & 31) >> 3;                          // stage-1 pixel (kh, kw) = (p >> 1, p & 1)
   const int grp = (blockIdx.x >> 5) * 8 + (blockIdx.x & 7);
   if (grp >= A.groups) return;
-  const char* w1p = A.w + G::T3 + (long)p * G::T1;
-  const char* w2 = A.w + G::T3 + 4L * G::T1;
-  hglds(A.w, w3s, G::T3, tid);
-  if (wave == 0)
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w1p + G::C1 * G::CPR1 * 16 + lane * 16),
-                                     (__attribute__((address_space(3))) void*)b1s, 16, 0, 0);
-  hglds(w1p, slots, G::HALF1, tid);
+  HEAD_STAMP(0);
+  if (!(A.debug & 4)) {
+    hglds<NWV>(A.w + G::T3 + (long)p * G::T1, w1s, G::T1, tid);
+    hglds<NWV>(A.w, w3s, G::T3, tid);
+    hglds<NWV>(A.w + G::T3 + 4L * G::T1, w2s, 4 * G::T2, tid);
+  }
 
   const int HW = A.Hp * A.Wp;
-  const long row = ((long)grp * HWAVES + wave) * 16 + l15;
+  const long row = ((long)grp * NWV + wave) * 16 + l15;
   const bool live = row < (long)A.n_img * HW;
   const long r = live ? row : 0;
   const int img = (int)(r / HW), hw = (int)(r % HW), hp = hw / A.Wp, wp = hw % A.Wp;
@@ -112,7 +124,7 @@ __global__ __launch_bounds__(HWAVES * 64, 2) void fused_head_kernel(const HeadAr
   for (int b = 0; b < G::KB3; ++b) xo3[b] = swz_chunk(l15, b * 4 + kk, G::CPR3) << 4;
 
   // epilogue addressing: the values the epilogue adds to (frame 0) are `last` for the first order and `out` itself for the later
-  // ones; they are fetched one sub-pixel step ahead of their use so the read-modify-write never stalls the MFMA stream.
+  // ones; both sub-pixel pairs' operands are fetched here, with everything else that comes from memory.
   const long frame = (long)A.D * (A.Hp * 8) * (A.Wp * 8);
   const int Wout = A.Wp * 8;
   const float* rmw_src = A.last ? A.last + (long)img * A.last_bstride : A.out + (long)img * A.out_bstride;
@@ -122,53 +134,46 @@ __global__ __launch_bounds__(HWAVES * 64, 2) void fused_head_kernel(const HeadAr
   };
   // The epilogue works on sub-pixel PAIRS (q = 2 j, 2 j + 1 are horizontal neighbours): 4 pixels = 16 bytes per row, so every
   // read-modify-write instruction moves 16 bytes per lane instead of 8 (half the memory instructions of the kernel's epilogue).
-  f32x4 pre[4][2], nxt[4][2];
-  auto prefetch = [&](int q, f32x4 (&dst)[4][2]) {   // q even: the pair (q, q + 1)
+  f32x4 pre[2][4][2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
 #pragma unroll
     for (int ns = 0; ns < 4; ++ns)
       if (4 * ns < A.D && live && 4 * ns + kk < A.D && !(A.debug & 1)) {
-        const float* lp = rmw_src + pix_of(q, ns);
-        dst[ns][0] = *(const f32x4*)lp;
-        dst[ns][1] = *(const f32x4*)(lp + Wout);
+        const float* lp = rmw_src + pix_of(2 * j, ns);
+        pre[j][ns][0] = *(const f32x4*)lp;
+        pre[j][ns][1] = *(const f32x4*)(lp + Wout);
       }
-  };
 
+  HEAD_STAMP(1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  HEAD_STAMP(2);
   __syncthreads();
+  HEAD_STAMP(3);
 
-  // ---- stage 1: pixel p in two half tiles; h1[kb] = B-operand k-blocks (C/2 channels) for stage 2 ------------------------------
+  // ---- stage 1: pixel p; h1[kb] = B-operand k-blocks (C/2 channels) for stage 2 ------------------------------------------------
   u32x4 h1[G::KB2];
-  const float* bias1 = (const float*)b1s;
-  sfor<2>([&](auto hc) {
-    constexpr int h = decltype(hc)::value;
-    if (!(A.debug & 4)) {
-      if constexpr (h == 0) hglds(w1p + G::HALF1, slots + G::SLOT, G::HALF1, tid);
-      else hglds(w2, slots, G::T2, tid);
-    }
-    if constexpr (h == 1) prefetch(0, pre);
-    const char* wt = slots + h * G::SLOT;
-    f32x4 acc[G::NSH];
+  {
+    const float* bias1 = (const float*)(w1s + G::C1 * G::CPR1 * 16);
+    f32x4 acc[G::NS1];
 #pragma unroll
-    for (int ns = 0; ns < G::NSH; ++ns) acc[ns] = *(const f32x4*)(bias1 + (h * G::NSH + ns) * 16 + kk * 4);
+    for (int ns = 0; ns < G::NS1; ++ns) acc[ns] = *(const f32x4*)(bias1 + ns * 16 + kk * 4);
 #pragma unroll
     for (int b = 0; b < CB; ++b)
 #pragma unroll
-      for (int ns = 0; ns < G::NSH; ++ns) acc[ns] = hmfma(*(const u32x4*)(wt + (ns * 16 + l15) * G::CPR1 * 16 + xo1[b]), xf[b], acc[ns]);
+      for (int ns = 0; ns < G::NS1; ++ns) acc[ns] = hmfma(*(const u32x4*)(w1s + (ns * 16 + l15) * G::CPR1 * 16 + xo1[b]), xf[b], acc[ns]);
 #pragma unroll
-    for (int b = 0; b < G::NSH / 2; ++b)
-      h1[h * (G::NSH / 2) + b] = (A.debug & 2) ? hpack8(acc[2 * b], acc[2 * b + 1]) : hpack8(gelu4(acc[2 * b]), gelu4(acc[2 * b + 1]));
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-  });
+    for (int b = 0; b < G::KB2; ++b)
+      h1[b] = (A.debug & 2) ? hpack8(acc[2 * b], acc[2 * b + 1]) : hpack8(gelu4(acc[2 * b]), gelu4(acc[2 * b + 1]));
+  }
 
-  // ---- stages 2 + 3: sub-pixel tile q of W2 (continuing the ring), W3 resident ------------------------------------------------
+  HEAD_STAMP(4);
+  // ---- stages 2 + 3: sub-pixel tile q of W2, W3 ----------------------------------------------------------------------------
   const float* bias3 = (const float*)(w3s + 64 * G::CPR3 * 16);
   f32x4 dl[4];
   sfor<4>([&](auto qc) {
     constexpr int q = decltype(qc)::value;           // sub-pixel (kh2, kw2) = (q >> 1, q & 1)
-    if constexpr (q < 3) { if (!(A.debug & 4)) hglds(w2 + (long)(q + 1) * G::T2, slots + ((q + 1) & 1) * G::SLOT, G::T2, tid); }
-    if constexpr (q == 0) prefetch(2, nxt);
-    const char* wt = slots + (q & 1) * G::SLOT;
+    const char* wt = w2s + q * G::T2;
     const float* bias2 = (const float*)(wt + G::C2 * G::CPR2 * 16);
     f32x4 acc2[G::NS2];
 #pragma unroll
@@ -195,8 +200,8 @@ __global__ __launch_bounds__(HWAVES * 64, 2) void fused_head_kernel(const HeadAr
           float* o0 = A.out + (long)img * A.out_bstride + pix;
           const float c0 = A.coef[0];
           const f32x4 t0 = f32x4{dl[ns][0], dl[ns][1], d[0], d[1]}, t1 = f32x4{dl[ns][2], dl[ns][3], d[2], d[3]};   // rows y0, y0 + 1
-          *(f32x4*)o0 = pre[ns][0] + t0 * c0;
-          *(f32x4*)(o0 + Wout) = pre[ns][1] + t1 * c0;
+          *(f32x4*)o0 = pre[q >> 1][ns][0] + t0 * c0;
+          *(f32x4*)(o0 + Wout) = pre[q >> 1][ns][1] + t1 * c0;
 #pragma unroll
           for (int i = 1; i < 8; ++i) {   // further output frames (output_length > 1 / adaptive dt): plain read-modify-write
             if (i >= A.n_out) break;
@@ -210,13 +215,14 @@ __global__ __launch_bounds__(HWAVES * 64, 2) void fused_head_kernel(const HeadAr
         }
       }
     }
-    if constexpr (q == 1) {
-#pragma unroll
-      for (int ns = 0; ns < 4; ++ns) { pre[ns][0] = nxt[ns][0]; pre[ns][1] = nxt[ns][1]; }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    HEAD_STAMP(5 + q);
   });
+#ifdef TANTE_ABLATE
+  if (A.stamps) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    HEAD_STAMP(9);
+  }
+#endif
 }
 
 // ---- stream packing: one thread block per tile -------------------------------------------------------------------------------
@@ -264,26 +270,40 @@ __global__ void pack_head_stream_kernel(const float* __restrict__ w1, const floa
   }
 }
 
-template <int CB>
-void launch_head(HeadArgs A, hipStream_t s) {
+template <int CB, int NWV>
+void launch_head_nw(HeadArgs A, hipStream_t s) {
   using G = HeadGeom<CB>;
   static TantePerDevice attr;
   attr.once([&] {
-    hipFuncSetAttribute((const void*)fused_head_kernel<CB>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
+    (void)hipFuncSetAttribute((const void*)fused_head_kernel<CB, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
   });
   const long rows = (long)A.n_img * A.Hp * A.Wp;
-  A.groups = (int)((rows + HWAVES * 16 - 1) / (HWAVES * 16));
+  A.groups = (int)((rows + NWV * 16 - 1) / (NWV * 16));
   const unsigned grid = (unsigned)((A.groups + 7) / 8) * 32;   // 8 token groups x 4 pixels per 32 consecutive workgroups
-  hipLaunchKernelGGL(fused_head_kernel<CB>, dim3(grid), dim3(HWAVES * 64), G::LDS, s, A);
+  hipLaunchKernelGGL((fused_head_kernel<CB, NWV>), dim3(grid), dim3(NWV * 64), G::LDS, s, A);
+}
+
+template <int CB>
+void launch_head(HeadArgs A, hipStream_t s) {
+  // 128-token groups (8 waves) once they still give every CU a workgroup; 64-token groups for small batches
+  const long rows = (long)A.n_img * A.Hp * A.Wp;
+  static const int force = getenv("TANTE_HEAD_WAVES") ? atoi(getenv("TANTE_HEAD_WAVES")) : 0;
+  const bool wide = force ? force == 8 : rows >= 128 * 56;
+  if (wide) launch_head_nw<CB, 8>(A, s);
+  else launch_head_nw<CB, 4>(A, s);
 }
 
 }  // namespace
+
+#ifdef TANTE_ABLATE
+extern "C" void tante_head_set_stamps(unsigned long long* p) { g_head_stamps = p; }
+#endif
 
 extern "C" int tante_head_fused_supported(int C, int D) { return (C == 128 || C == 256) && D >= 1 && D <= 16; }
 
 extern "C" int64_t tante_head_stream_bytes(int C) {
   const long C1 = C / 2, C2 = C / 4;
-  return (64L * (C2 / 8) * 16 + HB) + 4 * (C1 * (long)(C / 8) * 16 + HB) + 4 * (C2 * (C1 / 8) * 16 + HB);
+  return (64L * (C2 / 8) * 16 + HB) + 4 * (C1 * (long)(C / 8) * 16 + HB) + 4 * (C2 * (C1 / 8) * 16 + HB);   // HB = 1024
 }
 
 extern "C" int tante_pack_head(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3, const float* b3, int C, int D,
@@ -311,6 +331,11 @@ extern "C" int tante_head_fused(const float* x, int32_t a_n0, int64_t a_s1, int6
   A.last = last; A.last_bstride = last_bstride;
   for (int i = 0; i < 8; ++i) A.coef[i] = i < n_out ? coefs[i] : 0.f;
   A.debug = tante_ablate_env("TANTE_HEAD_DEBUG");  // -DTANTE_ABLATE builds only
+#ifdef TANTE_ABLATE
+  A.stamps = g_head_stamps;
+#else
+  A.stamps = nullptr;
+#endif
   if (C == 128) launch_head<4>(A, (hipStream_t)stream);
   else launch_head<8>(A, (hipStream_t)stream);
   TANTE_CHECK_LAUNCH();
