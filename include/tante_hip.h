@@ -218,7 +218,7 @@ int tante_block_fused(float* x, const void* block_stream, int C, int n_head, int
  *   st1, st2 (tokens, 2) fp32    (mean, rstd) per token
  *   qkv (tokens, 768) bf16       packed projection, q NOT scaled, biases included
  *   o (tokens, 256) bf16         attention output (after probability dropout)
- *   x1 (tokens, 256) fp32        x + dropout(out_proj(o))
+ *   x1 (tokens, 256) fp32        x + dropout(out_proj(o))   (may be NULL: tante_block_tail_bwd works from xh2 / st2 and never reads it)
  *   hpre, act (tokens, 256) bf16 fc1 pre-activation and its tanh-GELU
  *   out (tokens, 256) fp32       x1 + dropout(fc2(act))   (x itself is left untouched)
  * Masks are dropout_keep(seed, index, p) with tante_attention_dropout's index for seed_attn and row * 256 + column (the GEMM

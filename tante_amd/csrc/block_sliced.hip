@@ -188,6 +188,20 @@ __global__ __launch_bounds__(64 * NW, 2) void block_fs_kernel(FsArgs A) {
       for (int rt = 0; rt < RT; ++rt) acc[rt][tt] = *(const f32x4*)(sb + l15 * ROWB + (((4 * rt + kk) ^ (l15 & (CPR - 1))) << 4));
     }
   };
+  // bf16 tensors of the training forward (q | k | v, attention output, LayerNorm2's image, fc1's pre-activation and its GELU): the wave's
+  // slice of tile tt sits in its own columns of an activation image (logical chunks CPB w .. CPB w + CPB - 1 of every row, swizzled by the
+  // row) and goes to memory in row form: CPB lanes x 16 bytes per token row, 64 / CPB rows per instruction.  In accumulator layout these
+  // were 8-byte (v: 2-byte) stores to 16 different rows per instruction -- 160 of them per wave, worked off lane by lane by the memory pipe.
+  constexpr int CPB = 2 * RT, RPB = 64 / CPB;
+  const int brow = lane / CPB, bchunk = lane % CPB;
+  auto img_rows_store = [&](const char* img, int tt, unsigned short* __restrict__ dst, long dstride, int dcol) {
+#pragma unroll
+    for (int j = 0; j < 16 / RPB; ++j) {
+      const int r = RPB * j + brow, t = tok_of(16 * tt + r);
+      const u32x4 v = *(const u32x4*)(img + tt * 8192 + r * FS_ROW + (((CPB * wave + bchunk) ^ r) << 4));
+      if (t >= 0) *(u32x4*)(dst + (long)t * dstride + dcol + 16 * RT * wave + 8 * bchunk) = v;
+    }
+  };
   auto slice_store = [&](float* __restrict__ dst, const f32x4 (&acc)[RT][NTT]) {
 #pragma unroll
     for (int tt = 0; tt < NTT; ++tt) {
@@ -292,16 +306,16 @@ __global__ __launch_bounds__(64 * NW, 2) void block_fs_kernel(FsArgs A) {
     if constexpr (TRAIN) {   // the packed projection the attention backward reads holds q WITHOUT the softmax scale folded into Wq
       const float unscale = 1.0f / (0.17677669529663687f * 1.44269504088896340736f);
 #pragma unroll
-      for (int tt = 0; tt < NTT; ++tt)
-        if (tokidx[tt] >= 0) {
+      for (int tt = 0; tt < NTT; ++tt) {      // through this wave's columns of bufB (its attention output goes there later)
 #pragma unroll
-          for (int j = 0; j < RT; ++j) {
-            const f32x4 qv = aq[j][tt] * unscale;
-            u32x2 u;
-            u[0] = pack_bf16x2(qv[0], qv[1]); u[1] = pack_bf16x2(qv[2], qv[3]);
-            *(u32x2*)(A.qkv + (long)tokidx[tt] * (3 * FS_C) + 16 * RT * wave + 16 * j + 4 * kk) = u;
-          }
+        for (int j = 0; j < RT; ++j) {
+          const f32x4 qv = aq[j][tt] * unscale;
+          u32x2 u;
+          u[0] = pack_bf16x2(qv[0], qv[1]); u[1] = pack_bf16x2(qv[2], qv[3]);
+          *(u32x2*)(bufB + tt * 8192 + wro[j]) = u;
         }
+        img_rows_store(bufB, tt, A.qkv, 3 * FS_C, 0);
+      }
     }
   }
   FS_STAMP(4);
@@ -321,15 +335,15 @@ __global__ __launch_bounds__(64 * NW, 2) void block_fs_kernel(FsArgs A) {
       for (int tt = 0; tt < NTT; ++tt) kf[hh][tt] = pack8(ak[2 * hh][tt], ak[2 * hh + 1][tt]);
     if constexpr (TRAIN) {
 #pragma unroll
-      for (int tt = 0; tt < NTT; ++tt)
-        if (tokidx[tt] >= 0) {
+      for (int tt = 0; tt < NTT; ++tt) {
 #pragma unroll
-          for (int j = 0; j < RT; ++j) {
-            u32x2 u;
-            u[0] = pack_bf16x2(ak[j][tt][0], ak[j][tt][1]); u[1] = pack_bf16x2(ak[j][tt][2], ak[j][tt][3]);
-            *(u32x2*)(A.qkv + (long)tokidx[tt] * (3 * FS_C) + FS_C + 16 * RT * wave + 16 * j + 4 * kk) = u;
-          }
+        for (int j = 0; j < RT; ++j) {
+          u32x2 u;
+          u[0] = pack_bf16x2(ak[j][tt][0], ak[j][tt][1]); u[1] = pack_bf16x2(ak[j][tt][2], ak[j][tt][3]);
+          *(u32x2*)(bufB + tt * 8192 + wro[j]) = u;
         }
+        img_rows_store(bufB, tt, A.qkv, 3 * FS_C, FS_C);
+      }
     }
   }
   FS_STAMP(5);
@@ -344,20 +358,21 @@ __global__ __launch_bounds__(64 * NW, 2) void block_fs_kernel(FsArgs A) {
       for (int tt = 0; tt < NTT; ++tt) av[j][tt] = f32x4{bv, bv, bv, bv};
     }
     fs_slice_gemm<2, 24, NTT, RT, true, PF>(wq, wb, bufA, rdo, av);
-    if constexpr (TRAIN) {   // rows of this layout are tokens 4 kk + r, the lane is one feature: 2-byte stores, 32 contiguous bytes per token row
+    if constexpr (TRAIN) {   // rows of this layout are tokens 4 kk + r, the lane is one feature: 2-byte LDS stores into the image rows
 #pragma unroll
-      for (int tt = 0; tt < NTT; ++tt)
+      for (int tt = 0; tt < NTT; ++tt) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int tk = __shfl(tokidx[tt], 4 * kk + r);      // token of row 4 kk + r of tile tt (held by lane l15 = 4 kk + r)
-          if (tk >= 0) {
+          const int row = 4 * kk + r;
 #pragma unroll
-            for (int j = 0; j < RT; ++j) {
-              const __bf16 b = (__bf16)av[j][tt][r];
-              A.qkv[(long)tk * (3 * FS_C) + 2 * FS_C + 16 * RT * wave + 16 * j + l15] = __builtin_bit_cast(unsigned short, b);
-            }
+          for (int j = 0; j < RT; ++j) {
+            const __bf16 b = (__bf16)av[j][tt][r];
+            *(unsigned short*)(bufB + tt * 8192 + row * FS_ROW + (((CPB * wave + 2 * j + (l15 >> 3)) ^ row) << 4) + (l15 & 7) * 2) =
+                __builtin_bit_cast(unsigned short, b);
           }
         }
+        img_rows_store(bufB, tt, A.qkv, 3 * FS_C, 2 * FS_C);
+      }
     }
 #pragma unroll
     for (int hh = 0; hh < HPW; ++hh)
@@ -513,15 +528,12 @@ __global__ __launch_bounds__(64 * NW, 2) void block_fs_kernel(FsArgs A) {
         w1[0] = pack_bf16x2(o1[0], o1[1]); w1[1] = pack_bf16x2(o1[2], o1[3]);
         *(u32x2*)(bufB + (q0 + qt) * 8192 + wro[2 * hh]) = w0;
         *(u32x2*)(bufB + (q0 + qt) * 8192 + wro[2 * hh + 1]) = w1;
-        if constexpr (TRAIN) {
-          if (tokidx[q0 + qt] >= 0) {
-            unsigned short* orow = A.o + (long)tokidx[q0 + qt] * FS_C + 16 * RT * wave + 32 * hh + 4 * kk;
-            *(u32x2*)orow = w0;
-            *(u32x2*)(orow + 16) = w1;
-          }
-        }
       }
     });
+  }
+  if constexpr (TRAIN) {     // the attention output (bf16) as the backward reads it: this wave's columns of the image, row form
+#pragma unroll
+    for (int tt = 0; tt < NTT; ++tt) img_rows_store(bufB, tt, A.o, FS_C, 0);
   }
 
   FS_STAMP(7);
@@ -579,7 +591,9 @@ __global__ __launch_bounds__(64 * NW, 2) void block_fs_kernel(FsArgs A) {
     slice_to_acc(xraw, xr);      // bufA: LayerNorm1's image died with the q/k/v GEMMs (barrier 2), LayerNorm2's comes after barrier 3
     drop_add(x1, xr, A.seed_out);
   }
-  if constexpr (TRAIN) slice_store(A.x1, x1);   // the residual after the attention half: LayerNorm2's backward reads it
+  if constexpr (TRAIN) {   // the residual after the attention half: the per-operator LayerNorm2 backward reads it (null when the fused tail backward runs)
+    if (A.x1) slice_store(A.x1, x1);
+  }
   FS_STAMP(10);
 #pragma unroll
   for (int tt = 0; tt < NTT; ++tt) {
@@ -618,11 +632,9 @@ __global__ __launch_bounds__(64 * NW, 2) void block_fs_kernel(FsArgs A) {
       o2[0] = pack_bf16x2(fmaf(x1[rt][tt][0], rstd, sh), fmaf(x1[rt][tt][1], rstd, sh));
       o2[1] = pack_bf16x2(fmaf(x1[rt][tt][2], rstd, sh), fmaf(x1[rt][tt][3], rstd, sh));
       *(u32x2*)(bufA + tt * 8192 + wro[rt]) = o2;
-      if constexpr (TRAIN) {
-        if (tokidx[tt] >= 0) *(u32x2*)(A.xh2 + (long)tokidx[tt] * FS_C + 16 * RT * wave + 16 * rt + 4 * kk) = o2;
-      }
     }
     if constexpr (TRAIN) {
+      img_rows_store(bufA, tt, A.xh2, FS_C, 0);
       if (wave == 0 && kk == 0 && tokidx[tt] >= 0) *(float2*)(A.st2 + 2 * (long)tokidx[tt]) = make_float2(mean, rstd);
     }
   }
@@ -641,7 +653,17 @@ __global__ __launch_bounds__(64 * NW, 2) void block_fs_kernel(FsArgs A) {
     fs_slice_gemm<4, 48, NTT, RT, false, PF>(wq, wb, bufA, rdo, h);
     FS_STAMP(13);
 #pragma unroll
-    for (int tt = 0; tt < NTT; ++tt)
+    for (int tt = 0; tt < NTT; ++tt) {
+      if constexpr (TRAIN) {     // the pre-activation passes through the image columns the GELU-ed values take next
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          u32x2 hp;
+          hp[0] = pack_bf16x2(h[rt][tt][0], h[rt][tt][1]);
+          hp[1] = pack_bf16x2(h[rt][tt][2], h[rt][tt][3]);
+          *(u32x2*)(bufB + tt * 8192 + wro[rt]) = hp;
+        }
+        img_rows_store(bufB, tt, A.hpre, FS_C, 0);
+      }
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) {
         const f32x4 g = gelu_poly4<true>(h[rt][tt]);
@@ -649,17 +671,9 @@ __global__ __launch_bounds__(64 * NW, 2) void block_fs_kernel(FsArgs A) {
         o2[0] = pack_bf16x2(g[0], g[1]);
         o2[1] = pack_bf16x2(g[2], g[3]);
         *(u32x2*)(bufB + tt * 8192 + wro[rt]) = o2;
-        if constexpr (TRAIN) {
-          if (tokidx[tt] >= 0) {
-            u32x2 hp;
-            hp[0] = pack_bf16x2(h[rt][tt][0], h[rt][tt][1]);
-            hp[1] = pack_bf16x2(h[rt][tt][2], h[rt][tt][3]);
-            const long off = (long)tokidx[tt] * FS_C + 16 * RT * wave + 16 * rt + 4 * kk;
-            *(u32x2*)(A.hpre + off) = hp;
-            *(u32x2*)(A.act + off) = o2;
-          }
-        }
       }
+      if constexpr (TRAIN) img_rows_store(bufB, tt, A.act, FS_C, 0);
+    }
   }
   __syncthreads();
   FS_STAMP(14);

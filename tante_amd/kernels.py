@@ -354,17 +354,18 @@ def block_tail_bwd(dout: torch.Tensor, hpre, xh2, st2, bwd_stream, C_: int, hidd
 
 
 def block_fused_train(x: torch.Tensor, block_stream: torch.Tensor, C_: int, n_head: int, hidden: int, seq: L.Seq, causal: bool, eps: float,
-                      p_drop: float, seeds) -> dict:
+                      p_drop: float, seeds, need_x1: bool = True) -> dict:
     """Training forward of a whole block in one launch (tante_block_fused_train): -> the block output and every saved tensor of the
-    unfused operators (see include/tante_hip.h).  x (tokens, 256) fp32 is left untouched."""
+    unfused operators (see include/tante_hip.h).  x (tokens, 256) fp32 is left untouched.  need_x1=False skips the fp32 residual after
+    the attention half (25 MB per launch at cfg3): the fused tail backward works from LayerNorm2's image and statistics."""
     _dev(x, block_stream)
     M = x.numel() // C_
     dev = x.device
     bf = lambda n: torch.empty(M, n, dtype=torch.bfloat16, device=dev)      # noqa: E731
     f32 = lambda n: torch.empty(M, n, dtype=torch.float32, device=dev)      # noqa: E731
     t = {"out": f32(C_), "xh1": bf(C_), "qkv": bf(3 * C_), "o": bf(C_), "xh2": bf(C_), "hpre": bf(hidden), "act": bf(hidden),
-         "st1": f32(2), "x1": f32(C_), "st2": f32(2)}
-    tr = L.BlockTrain(*[t[k].data_ptr() for k in ("out", "xh1", "qkv", "o", "xh2", "hpre", "act", "st1", "x1", "st2")],
+         "st1": f32(2), "x1": f32(C_) if need_x1 else None, "st2": f32(2)}
+    tr = L.BlockTrain(*[(t[k].data_ptr() if t[k] is not None else None) for k in ("out", "xh1", "qkv", "o", "xh2", "hpre", "act", "st1", "x1", "st2")],
                       float(p_drop), int(seeds[0]), int(seeds[1]), int(seeds[2]))
     L.check(L.lib().tante_block_fused_train(_p(x), _p(block_stream), C_, n_head, hidden, C.byref(seq), int(causal), eps, C.byref(tr),
                                             _stream()), "tante_block_fused_train")

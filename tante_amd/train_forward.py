@@ -73,8 +73,11 @@ def block_train(blk, x: torch.Tensor, seq, causal: bool, compute: int) -> torch.
             stream = K.pack_block_train((w_in, b_in, a.out_proj.weight, a.out_proj.bias, w1, b1, m[2].weight, m[2].bias), blk.embed_dim, blk.hidden)
             if _FOLDS is not None:
                 _FOLDS[key] = stream
-        t = K.block_fused_train(x.detach(), stream, blk.embed_dim, blk.n_head, blk.hidden, seq, causal, blk.ln1.eps, p, seeds)
-        if FUSED_TAIL_BACKWARD and torch.is_grad_enabled() and block_tail_ready(a.out_proj.weight, a.out_proj.bias, w1, b1, m[2].weight, m[2].bias):
+        fused_tail = (FUSED_TAIL_BACKWARD and torch.is_grad_enabled()
+                      and block_tail_ready(a.out_proj.weight, a.out_proj.bias, w1, b1, m[2].weight, m[2].bias))
+        t = K.block_fused_train(x.detach(), stream, blk.embed_dim, blk.n_head, blk.hidden, seq, causal, blk.ln1.eps, p, seeds,
+                                need_x1=not fused_tail)
+        if fused_tail:
             # the block behind its attention as ONE autograd node whose backward is ONE launch (tante_block_tail_bwd)
             key = ("bt_stream", id(blk))
             bstream = _FOLDS.get(key) if _FOLDS is not None else None
