@@ -74,7 +74,8 @@ struct HeadGeom {
   static constexpr int NS1 = C1 / 16, NS2 = C2 / 16;                     // 16-row sub-tiles
   static constexpr int KB2 = C1 / 32, KB3 = C2 / 32;                     // k-blocks of stages 2, 3
   static constexpr int T1 = C1 * CPR1 * 16 + HB, T2 = C2 * CPR2 * 16 + HB, T3 = 64 * CPR3 * 16 + HB;
-  static constexpr int LDS = T3 + T1 + 4 * T2;                           // C = 256: 9 + 65 + 4 x 17 = 142 KiB
+  static constexpr int XS = 8 * 16 * CB * 64;                            // token-row staging of 8 waves (bf16), overlaid on the W2 tiles
+  static constexpr int LDS = T3 + T1 + (4 * T2 > XS ? 4 * T2 : XS);      // C = 256: 9 + 65 + 4 x 17 = 142 KiB
 };
 
 // Work split: a workgroup owns 16 NWV tokens AND one stage-1 pixel p; everything downstream of that pixel (its 4 sub-pixels, their
@@ -100,21 +101,66 @@ __global__ __launch_bounds__(NWV * 64, 1) void fused_head_kernel(const HeadArgs 
   if (!(A.debug & 4)) {
     hglds<NWV>(A.w + G::T3 + (long)p * G::T1, w1s, G::T1, tid);
     hglds<NWV>(A.w, w3s, G::T3, tid);
-    hglds<NWV>(A.w + G::T3 + 4L * G::T1, w2s, 4 * G::T2, tid);
   }
+  HEAD_STAMP(10);
 
+  // Row -> (image, hp, wp) and row -> element offset WITHOUT per-lane integer division: the wave's 16 rows are consecutive, so the three
+  // quotients are taken once on the wave-uniform first row and stepped (64-bit divisions by run-time values, one set per lane and load,
+  // were 6 k of this kernel's 35 k clocks per wave: in-kernel stamps).
   const int HW = A.Hp * A.Wp;
-  const long row = ((long)grp * NWV + wave) * 16 + l15;
-  const bool live = row < (long)A.n_img * HW;
-  const long r = live ? row : 0;
-  const int img = (int)(r / HW), hw = (int)(r % HW), hp = hw / A.Wp, wp = hw % A.Wp;
-  const float* xr = A.x + (r / A.a_n0) * A.a_s1 + (r % A.a_n0) * A.a_s0 + A.a_off;
+  const unsigned n_rows = (unsigned)A.n_img * (unsigned)HW;
+  const unsigned row0 = (unsigned)__builtin_amdgcn_readfirstlane((grp * NWV + wave) * 16);
+  const unsigned img0 = row0 / (unsigned)HW, hw0 = row0 - img0 * (unsigned)HW;
+  const unsigned aq0 = row0 / (unsigned)A.a_n0, ar0 = row0 - aq0 * (unsigned)A.a_n0;
+  auto row_img_hw = [&](int j, int& im, int& hwv) {          // row0 + j -> (image, position in image)
+    im = (int)img0; hwv = (int)hw0 + j;
+    while (hwv >= HW) { hwv -= HW; ++im; }
+  };
+  auto row_offset = [&](int j) {                              // row0 + j -> element offset of its token row
+    long q = aq0; int rem = (int)ar0 + j;
+    while (rem >= A.a_n0) { rem -= A.a_n0; ++q; }
+    return q * A.a_s1 + (long)rem * A.a_s0 + A.a_off;
+  };
+  const bool live = row0 + (unsigned)l15 < n_rows;
+  int img, hw;
+  row_img_hw(live ? l15 : 0, img, hw);
+  if (!live) { img = 0; hw = 0; }
+  const int hp = (int)(((float)hw + 0.5f) * __builtin_amdgcn_rcpf((float)A.Wp)), wp = hw - hp * A.Wp;   // exact: hw < 2^22
+  // ---- the wave's 16 token rows: ROW-form loads (one instruction = the 1 KiB of one token; in B-operand layout an instruction touched
+  // 16 rows x 64 B and the memory pipe worked it off lane by lane: 63 clocks against 17, tools/ubench/ta_cost.hip -- the token rows
+  // alone held the pipe for 10 k of the wave's 35 k clocks), packed to bf16 into a private 8 KiB piece of the W2 region (whose LDS-DMA
+  // is issued behind a barrier below), read back as B-operand fragments: 8-byte chunk c of row j at chunk c ^ (2 j), conflict-free
+  // for the ds_write_b64 (lane = chunk) and the ds_read_b64 (32 lanes = 16 rows x 2 neighbouring chunks) alike.
   u32x4 xf[CB];   // the token as B-operand k-blocks, accumulator (k-permuted) order
+  {
+    static_assert(CB == 8 || CB == 4, "a token row is CB * 128 bytes: one or half a 64-lane instruction");
+    constexpr int LPR = CB * 8;                       // lanes per token row (16 bytes each)
+    constexpr int RPI = 64 / LPR;                     // rows per instruction
+    f32x4 xraw[16 / RPI];
 #pragma unroll
-  for (int b = 0; b < CB; ++b) {
-    const f32x4 lo = *(const f32x4*)(xr + 32 * b + 4 * kk), hi = *(const f32x4*)(xr + 32 * b + 16 + 4 * kk);
-    xf[b] = live ? hpack8(lo, hi) : u32x4{0u, 0u, 0u, 0u};
+    for (int j = 0; j < 16 / RPI; ++j) {
+      const int rj = RPI * j + lane / LPR;
+      const long eo = row0 + (unsigned)rj < n_rows ? row_offset(rj) : A.a_off;      // dead rows read row 0 of the view (valid memory)
+      xraw[j] = *(const f32x4*)(A.x + eo + 4 * (lane % LPR));
+    }
+    HEAD_STAMP(11);
+    char* xs = w2s + wave * (16 * CB * 64);           // 16 rows x (32 CB) bf16
+#pragma unroll
+    for (int j = 0; j < 16 / RPI; ++j) {
+      const int rj = RPI * j + lane / LPR, c = lane % LPR;
+      u32x2 u;
+      u[0] = pack_bf16x2(xraw[j][0], xraw[j][1]); u[1] = pack_bf16x2(xraw[j][2], xraw[j][3]);
+      *(u32x2*)(xs + rj * (CB * 64) + ((c ^ ((2 * rj) & (LPR - 1))) << 3)) = u;
+    }
+#pragma unroll
+    for (int b = 0; b < CB; ++b) {      // k-block b: features 32 b + 4 kk .. + 3 and 32 b + 16 + 4 kk .. + 3  = 8-byte chunks 8 b + kk, 8 b + 4 + kk
+      const u32x2 lo = *(const u32x2*)(xs + l15 * (CB * 64) + (((8 * b + kk) ^ ((2 * l15) & (LPR - 1))) << 3));
+      const u32x2 hi = *(const u32x2*)(xs + l15 * (CB * 64) + (((8 * b + 4 + kk) ^ ((2 * l15) & (LPR - 1))) << 3));
+      xf[b] = live ? u32x4{lo[0], lo[1], hi[0], hi[1]} : u32x4{0u, 0u, 0u, 0u};
+    }
   }
+  __syncthreads();      // every wave has its fragments: the W2 tiles may land on the staging pieces
+  if (!(A.debug & 4)) hglds<NWV>(A.w + G::T3 + 4L * G::T1, w2s, 4 * G::T2, tid);
   int xo1[CB], xo2[G::KB2], xo3[G::KB3];
 #pragma unroll
   for (int b = 0; b < CB; ++b) xo1[b] = swz_chunk(l15, b * 4 + kk, G::CPR1) << 4;
@@ -146,10 +192,8 @@ __global__ __launch_bounds__(NWV * 64, 1) void fused_head_kernel(const HeadArgs 
       }
 
   HEAD_STAMP(1);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  HEAD_STAMP(2);
-  __syncthreads();
-  HEAD_STAMP(3);
+  // W1 and W3 are complete here: every wave waited for its token rows, which it requested AFTER its share of the two tiles, before the
+  // barrier above.  Stage 1 runs while the W2 tiles and the read-modify-write operands arrive.
 
   // ---- stage 1: pixel p; h1[kb] = B-operand k-blocks (C/2 channels) for stage 2 ------------------------------------------------
   u32x4 h1[G::KB2];
@@ -167,6 +211,10 @@ __global__ __launch_bounds__(NWV * 64, 1) void fused_head_kernel(const HeadArgs 
       h1[b] = (A.debug & 2) ? hpack8(acc[2 * b], acc[2 * b + 1]) : hpack8(gelu4(acc[2 * b]), gelu4(acc[2 * b + 1]));
   }
 
+  HEAD_STAMP(2);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  HEAD_STAMP(3);
+  __syncthreads();
   HEAD_STAMP(4);
   // ---- stages 2 + 3: sub-pixel tile q of W2, W3 ----------------------------------------------------------------------------
   const float* bias3 = (const float*)(w3s + 64 * G::CPR3 * 16);

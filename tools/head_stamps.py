@@ -16,8 +16,8 @@ L.LIB_PATH = os.path.join(ROOT, "tools", "_ab", "libtante_ablate.so")
 import tante_amd  # noqa: E402
 from tante_amd import kernels as K  # noqa: E402
 
-NAMES = ["issue DMA + token rows + RMW operands", "wait vmcnt(0)", "barrier", "stage 1", "sub-pixel 0", "sub-pixel 1 (+stores)", "sub-pixel 2",
-         "sub-pixel 3 (+stores)", "stores drained"]
+NAMES = ["W1/W3 DMA, token rows -> fragments, barrier, W2 DMA, RMW operands", "stage 1", "wait vmcnt(0)", "barrier", "sub-pixel 0",
+         "sub-pixel 1 (+stores)", "sub-pixel 2", "sub-pixel 3 (+stores)", "stores drained"]
 
 
 def main():
@@ -58,6 +58,7 @@ def main():
     print(f"{len(raw)} waves; per wave: {tot.mean():.0f} shader-clock ticks start -> stores drained (min {tot.min()}, max {tot.max()})")
     for i, n in enumerate(NAMES):
         print(f"  {n:40s} {d[:, i].mean():9.0f}  ({100 * d[:, i].mean() / tot.mean():5.1f} %)   min {d[:, i].min():7d}  max {d[:, i].max():7d}")
+    print(f"  within the first stage: DMA issued after {(raw[:, 10] - raw[:, 0]).mean():.0f}, token-row loads issued after {(raw[:, 11] - raw[:, 0]).mean():.0f} ticks")
     t0 = raw[:, 0]
     print("span of wave starts (ticks):", t0.max() - t0.min(), " span first start -> last end:", raw[:, 9].max() - t0.min())
 
