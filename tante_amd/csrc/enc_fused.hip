@@ -64,7 +64,8 @@ __global__ __launch_bounds__(512, 2) void enc23_kernel(const EncArgs A) {
   const long row = ((long)blockIdx.x * 8 + wave) * 16 + l15;
   const bool live = row < rows;
   const long r = live ? row : 0;
-  const int img = (int)(r / HW), hw = (int)(r % HW), hp = hw / A.Wp, wp = hw % A.Wp;
+  const unsigned r32 = (unsigned)r;      // rows < 2^31 (a row is 1 KiB of output): 32-bit divisions
+  const int img = (int)(r32 / (unsigned)HW), hw = (int)(r32 - (unsigned)img * (unsigned)HW), hp = hw / A.Wp, wp = hw - hp * A.Wp;
   const int H1 = 4 * A.Hp, W1 = 4 * A.Wp;
   const unsigned short* base = A.h1 + (((long)img * H1 + 4 * hp) * W1 + 4 * wp) * G::C1;   // the token's 4 x 4 pixel block
 

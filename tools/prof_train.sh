@@ -5,7 +5,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/prof_train
 rm -rf $OUT; mkdir -p $OUT
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --train-steps 3 --no-train-strong > $OUT/bench.json 2> $OUT/err.log
-f=$(find $OUT -name "*kernel_stats.csv" | head -1)
+f=$(ls -t $(find $OUT -name "*kernel_stats.csv") | head -1)
 python3 - "$f" <<'PY'
 import csv,sys
 rows=list(csv.DictReader(open(sys.argv[1])))
