@@ -426,6 +426,13 @@ int tante_fold_fwd(const float* W, const float* b, const float* gamma, const flo
 int tante_fold_bwd(const float* GW, const float* Gb, const float* W, const float* gamma, const float* beta, int N, int K, float* dW, float* db,
                    float* dgamma, float* dbeta, void* stream);
 int tante_axis_wgrad(const float* U, const float* V, int64_t outer, int n, int64_t inner, float* dW, float* db, int accumulate, void* stream);
+/* The same with a caller-owned workspace of tante_axis_wgrad_workspace_bytes() bytes (16-byte aligned; its LAST 256 bytes -- the arrival
+ * counters -- zero on first use): every workgroup stores its partial there and the last of each group of 16 to finish adds the group's sum
+ * into dW / db -- a sixteenth of the same-address atomics, no second launch; the counters are back at zero when the kernel ends.  One call
+ * at a time per workspace (calls on one stream are).  Null or too small -> every workgroup adds its partial atomically. */
+int64_t tante_axis_wgrad_workspace_bytes(void);
+int tante_axis_wgrad_ws(const float* U, const float* V, int64_t outer, int n, int64_t inner, float* dW, float* db, int accumulate,
+                        void* workspace, int64_t workspace_bytes, void* stream);
 
 /* A gathered row matrix (rows r, `cols` columns): LINEAR rows at (r/n0)*s1 + (r%n0)*s0 + off with element stride es, or the
  * k = s patches of an image batch exactly as in TanteGemm (n0 images per batch item, s1 elements between items). */

@@ -59,6 +59,18 @@ def _rm_patch(t: torch.Tensor, nhwc: bool, n_img: int, Hin: int, Win: int, Cin: 
     return m
 
 
+_AXIS_WS = {}
+
+
+def _axis_wgrad_workspace(device) -> torch.Tensor:
+    """Per-device slab workspace of tante_axis_wgrad_ws: zero on first use, and every call leaves it zeroed (kernels on one stream)."""
+    key = (device.type, device.index, K._stream())
+    ws = _AXIS_WS.get(key)
+    if ws is None:
+        ws = _AXIS_WS[key] = torch.zeros(L.lib().tante_axis_wgrad_workspace_bytes() // 4, dtype=torch.float32, device=device)
+    return ws
+
+
 ACCUMULATE_INTO_GRAD = True   # weight-gradient kernels add straight into a pre-allocated p.grad (FlatAdamW's bucket views)
 
 
@@ -718,8 +730,9 @@ class AxisMlpFn(Function):
                 acc = gw is not None
                 dW = gw if acc else torch.empty(n, n, dtype=torch.float32, device=x.device)
                 dB = gb if acc else torch.empty(n, dtype=torch.float32, device=x.device)
-                L.check(L.lib().tante_axis_wgrad(U.data_ptr(), V.data_ptr(), outer, n, inner, dW.data_ptr(), dB.data_ptr(), int(acc), _s()),
-                        "tante_axis_wgrad")
+                ws = _axis_wgrad_workspace(x.device)
+                L.check(L.lib().tante_axis_wgrad_ws(U.data_ptr(), V.data_ptr(), outer, n, inner, dW.data_ptr(), dB.data_ptr(), int(acc),
+                                                    ws.data_ptr(), ws.numel() * 4, _s()), "tante_axis_wgrad")
                 return (None, None) if acc else (dW, dB)
             both = all(g is not None for g in slots)
             if both:

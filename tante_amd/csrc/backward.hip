@@ -741,15 +741,31 @@ bool try_attn_bwd_mfma(const void* qkv, const void* dO, void* dqkv, int dtype, i
 // of the four uses element s of every lane, i.e. k slot kk <-> i = i0 + 4 kk + s on both sides).  fp32 MFMA (16x16x4): the propagators
 // stay in fp32 in both compute modes.  The generic weight-gradient kernel gathers these operands element by element with stride
 // `inner` (85 us for 2 x 25 MB); this one streams them.
-template <int NT>
-__global__ __launch_bounds__(256) void axis_wgrad_kernel(const float* __restrict__ U, const float* __restrict__ V, long outer, int n, long inner,
-                                                         float* __restrict__ dW, float* __restrict__ db, long n_chunks) {
-  constexpr int NP = NT * 16;
+// Round 2: (1) three chunks in flight per wave and up to four workgroups per CU (two chunks x eight waves per CU left the kernel
+// latency-bound at 1.1 - 2 TB/s); (2) short axes (n <= 8, the temporal propagator's n = 4) pack G = 16 / npad SEGMENTS of the
+// contraction into the 16 rows of the MFMA tile -- row (s, a) = line a of segment s, both operands alike -- and keep the G diagonal
+// blocks of the product: a quarter of the load instructions, each one whole; (3) the workgroups' n x n partials no longer go to dW by
+// global atomics on the same n^2 addresses from every workgroup (the kernel's time grew linearly with the grid: 24 / 35 / 46 us at
+// 512 / 1024 / 1536 workgroups -- device-scope atomics are served behind the XCDs' L2s): each workgroup STORES its partial to a
+// caller-owned workspace, and the last of every AW_GS workgroups to finish (an arrival counter per group) sums the group's partials
+// and adds ONE n x n to dW: a sixteenth of the atomics, no second launch.
+constexpr int AW_GS = 16;                                 // workgroups per reduction group
+constexpr int AW_MAXWG = 1024;                            // grid cap with a workspace
+constexpr int AW_SLAB = 64 * 64 + 64;                     // floats per partial: dW (n <= 64) then db
+constexpr long AW_WS_FLOATS = (long)AW_MAXWG * AW_SLAB + AW_MAXWG / AW_GS;   // partials + one arrival counter per group
+
+template <int NT, int G>
+__global__ __launch_bounds__(512) void axis_wgrad_kernel(const float* __restrict__ U, const float* __restrict__ V, long outer, int n, long inner,
+                                                         float* __restrict__ dW, float* __restrict__ db, long n_chunks, float* __restrict__ ws) {
+  static_assert(G == 1 || NT == 1, "segments are packed into a single 16-row tile");
+  constexpr int NP = NT * 16, NPAD = 16 / G, CW = 16 * G;      // CW: contraction elements per chunk
   __shared__ float red[NP * NP + NP];
+  __shared__ int s_last;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kk = lane >> 4, l15 = lane & 15;
-  for (int i = tid; i < NP * NP + NP; i += 256) red[i] = 0.f;
+  const int nthr = blockDim.x, nwv = nthr >> 6;      // 4 waves, or 8 for the long axes (fewer, larger partials)
+  for (int i = tid; i < NP * NP + NP; i += nthr) red[i] = 0.f;
   __syncthreads();
-  const long cpo = inner / 16;   // 16-wide chunks of the contraction per outer index
+  const long cpo = inner / CW;   // chunks of the contraction per outer index
   f32x4 acc[NT][NT], accb[NT];
 #pragma unroll
   for (int a = 0; a < NT; ++a) {
@@ -757,16 +773,17 @@ __global__ __launch_bounds__(256) void axis_wgrad_kernel(const float* __restrict
 #pragma unroll
     for (int b = 0; b < NT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
+  // this lane's row of tile t: line (t * 16 + l15) % NPAD-wise -> (segment, line)
   auto load = [&](long c, f32x4 (&a)[NT], f32x4 (&b)[NT]) {
     const long o = c / cpo;
-    const long base = o * n * inner + (c - o * cpo) * 16 + kk * 4;
+    const long base = o * n * inner + (c - o * cpo) * CW + kk * 4;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      const int row = t * 16 + l15;
+      const int row = t * 16 + l15, seg = G > 1 ? row / NPAD : 0, line = G > 1 ? row % NPAD : row;
       a[t] = b[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (row < n) {
-        a[t] = *(const f32x4*)(U + base + (long)row * inner);
-        b[t] = *(const f32x4*)(V + base + (long)row * inner);
+      if (line < n) {
+        a[t] = *(const f32x4*)(U + base + (long)line * inner + 16 * seg);
+        b[t] = *(const f32x4*)(V + base + (long)line * inner + 16 * seg);
       }
     }
   };
@@ -780,32 +797,70 @@ __global__ __launch_bounds__(256) void axis_wgrad_kernel(const float* __restrict
         if (db) accb[at] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[at][s4], 1.0f, accb[at], 0, 0, 0);
       }
   };
-  const long stride = (long)gridDim.x * 4;
-  long c = (long)blockIdx.x * 4 + wave;
-  f32x4 a0[NT], b0[NT], a1[NT], b1[NT];
+  const long stride = (long)gridDim.x * nwv;
+  long c = (long)blockIdx.x * nwv + wave;
+  f32x4 a0[NT], b0[NT], a1[NT], b1[NT], a2[NT], b2[NT];
   if (c < n_chunks) load(c, a0, b0);
-  while (c < n_chunks) {        // two chunks per trip: the next chunk's loads fly under this chunk's MFMAs
-    const long c1 = c + stride, c2 = c1 + stride;
-    if (c1 < n_chunks) load(c1, a1, b1);
+  if (c + stride < n_chunks) load(c + stride, a1, b1);
+  while (c < n_chunks) {        // three chunks per trip: two later chunks' loads fly under this chunk's MFMAs
+    if (c + 2 * stride < n_chunks) load(c + 2 * stride, a2, b2);
     fma_chunk(a0, b0);
-    if (c1 >= n_chunks) break;
-    if (c2 < n_chunks) load(c2, a0, b0);
+    if (c + stride >= n_chunks) break;
+    if (c + 3 * stride < n_chunks) load(c + 3 * stride, a0, b0);
     fma_chunk(a1, b1);
-    c = c2;
+    if (c + 2 * stride >= n_chunks) break;
+    if (c + 4 * stride < n_chunks) load(c + 4 * stride, a1, b1);
+    fma_chunk(a2, b2);
+    c += 3 * stride;
   }
+  // D[row][col]: lane holds col = l15, rows 4 kk + r.  G > 1: row = (s, a), col = (s', j): the diagonal blocks s == s' are the product
 #pragma unroll
   for (int at = 0; at < NT; ++at) {
 #pragma unroll
     for (int jt = 0; jt < NT; ++jt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) atomicAdd(&red[(at * 16 + 4 * kk + r) * NP + jt * 16 + l15], acc[at][jt][r]);
+      for (int r = 0; r < 4; ++r) {
+        if constexpr (G > 1) {
+          const int row = 4 * kk + r;
+          if (row / NPAD == l15 / NPAD) atomicAdd(&red[(row % NPAD) * NP + (l15 % NPAD)], acc[at][jt][r]);
+        } else {
+          atomicAdd(&red[(at * 16 + 4 * kk + r) * NP + jt * 16 + l15], acc[at][jt][r]);
+        }
+      }
     if (db && l15 == 0)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) atomicAdd(&red[NP * NP + at * 16 + 4 * kk + r], accb[at][r]);
+      for (int r = 0; r < 4; ++r) atomicAdd(&red[NP * NP + (G > 1 ? (4 * kk + r) % NPAD : at * 16 + 4 * kk + r)], accb[at][r]);
   }
   __syncthreads();
-  for (int i = tid; i < n * n; i += 256) atomicAdd(&dW[i], red[(i / n) * NP + (i % n)]);
-  if (db && tid < n) atomicAdd(&db[tid], red[NP * NP + tid]);
+  if (!ws) {      // no workspace: every workgroup adds its partial straight into the parameter's gradient
+    for (int i = tid; i < n * n; i += nthr) atomicAdd(&dW[i], red[(i / n) * NP + (i % n)]);
+    if (db && tid < n) atomicAdd(&db[tid], red[NP * NP + tid]);
+    return;
+  }
+  // agent-coherent (write-through) stores + a wait for their acknowledgement instead of a release fence: on this part a device-scope
+  // release writes back the whole L2 (buffer_wbl2), and a thousand workgroups doing that quadrupled the kernel's time
+  float* mine = ws + (long)blockIdx.x * AW_SLAB;
+  for (int i = tid; i < n * n; i += nthr) __hip_atomic_store(mine + i, red[(i / n) * NP + (i % n)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (db && tid < n) __hip_atomic_store(mine + 64 * 64 + tid, red[NP * NP + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __builtin_amdgcn_s_waitcnt(0x0070);      // vmcnt(0): this thread's stores have reached the coherence point
+  __syncthreads();
+  const int grp = blockIdx.x / AW_GS, first = grp * AW_GS, members = min(AW_GS, (int)gridDim.x - first);
+  unsigned* counter = (unsigned*)(ws + (long)AW_MAXWG * AW_SLAB) + grp;
+  if (tid == 0) s_last = atomicAdd(counter, 1u) == (unsigned)(members - 1);
+  __syncthreads();
+  if (!s_last) return;
+  for (int i = tid; i < n * n + (db ? n : 0); i += nthr) {
+    const int off = i < n * n ? i : 64 * 64 + (i - n * n);
+    float v[AW_GS];
+#pragma unroll
+    for (int m = 0; m < AW_GS; ++m)      // agent-scope loads (the partials of other XCDs' workgroups), all in flight at once
+      v[m] = m < members ? __hip_atomic_load(ws + (long)(first + m) * AW_SLAB + off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0f;
+    float sum = 0.f;
+#pragma unroll
+    for (int m = 0; m < AW_GS; ++m) sum += v[m];
+    atomicAdd(i < n * n ? dW + i : db + (i - n * n), sum);
+  }
+  if (tid == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ---- LayerNorm affine folded into the consumer's weight (train path): We = W diag(gamma), be = b + W beta, and the fold's backward ------
@@ -1013,30 +1068,45 @@ extern "C" int tante_act_bwd(const void* dpost, int d_dtype, const void* pre, in
   TANTE_CHECK_LAUNCH();
   return 0;
 }
-extern "C" int tante_axis_wgrad(const float* U, const float* V, int64_t outer, int n, int64_t inner, float* dW, float* db, int accumulate,
-                                void* stream) {
+extern "C" int64_t tante_axis_wgrad_workspace_bytes(void) { return AW_WS_FLOATS * (int64_t)sizeof(float); }
+
+extern "C" int tante_axis_wgrad_ws(const float* U, const float* V, int64_t outer, int n, int64_t inner, float* dW, float* db, int accumulate,
+                                   void* workspace, int64_t workspace_bytes, void* stream) {
   if (!U || !V || !dW || outer <= 0 || n <= 0 || inner <= 0) TANTE_FAIL(-1, "tante_axis_wgrad: bad argument");
   if (n > 64) TANTE_FAIL(-2, "tante_axis_wgrad: axis length %d > 64", n);
   if (inner % 16 || (((uintptr_t)U | (uintptr_t)V) & 15)) TANTE_FAIL(-2, "tante_axis_wgrad: inner must be a multiple of 16 and the operands 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
+  float* ws = (workspace && workspace_bytes >= tante_axis_wgrad_workspace_bytes() && ((uintptr_t)workspace % 16) == 0) ? (float*)workspace : nullptr;
   if (!accumulate) {
     if (hipMemsetAsync(dW, 0, (size_t)n * n * sizeof(float), s) != hipSuccess) TANTE_FAIL(-3, "tante_axis_wgrad: memset failed");
     if (db && hipMemsetAsync(db, 0, (size_t)n * sizeof(float), s) != hipSuccess) TANTE_FAIL(-3, "tante_axis_wgrad: memset failed");
   }
-  const long n_chunks = (long)outer * (inner / 16);
-  long wgs = (n_chunks + 15) / 16;          // at least four chunks per wave
-  if (wgs > 512) wgs = 512;
+  // short axes: G segments of the contraction per MFMA tile (inner must hold whole 16 G chunks)
+  const int g = (n <= 4 && inner % 64 == 0) ? 4 : (n <= 8 && inner % 32 == 0) ? 2 : 1;
+  const long n_chunks = (long)outer * (inner / (16 * g));
+  // long axes (n > 16: partials of up to 16 KB): 8 waves per workgroup and one workgroup per CU -- the epilogue (partial store, group sum,
+  // atomics) is per workgroup and was what the kernel's time followed (n = 48: 39 / 66 / 85 us at 256 / 512 / 683 workgroups of 4 waves)
+  const int nthr = n > 16 ? 512 : 256;
+  long wgs = (n_chunks + 3 * (nthr / 64) - 1) / (3 * (nthr / 64));          // at least three chunks per wave
+  static const long wg_cap = getenv("TANTE_AXIS_WGRAD_WGS") ? atol(getenv("TANTE_AXIS_WGRAD_WGS")) : 0;
+  const long cap = wg_cap ? (wg_cap > AW_MAXWG && ws ? AW_MAXWG : wg_cap) : (n > 16 ? 256 : 512);
+  if (wgs > cap) wgs = cap;
   if (wgs < 1) wgs = 1;
-#define TANTE_AW(NTV) hipLaunchKernelGGL(axis_wgrad_kernel<NTV>, dim3((unsigned)wgs), dim3(256), 0, s, U, V, (long)outer, n, (long)inner, dW, db, n_chunks)
+#define TANTE_AW(NTV, GV) hipLaunchKernelGGL((axis_wgrad_kernel<NTV, GV>), dim3((unsigned)wgs), dim3(nthr), 0, s, U, V, (long)outer, n, (long)inner, dW, db, n_chunks, ws)
   switch ((n + 15) / 16) {
-    case 1: TANTE_AW(1); break;
-    case 2: TANTE_AW(2); break;
-    case 3: TANTE_AW(3); break;
-    default: TANTE_AW(4); break;
+    case 1: if (g == 4) TANTE_AW(1, 4); else if (g == 2) TANTE_AW(1, 2); else TANTE_AW(1, 1); break;
+    case 2: TANTE_AW(2, 1); break;
+    case 3: TANTE_AW(3, 1); break;
+    default: TANTE_AW(4, 1); break;
   }
 #undef TANTE_AW
   TANTE_CHECK_LAUNCH();
   return 0;
+}
+
+extern "C" int tante_axis_wgrad(const float* U, const float* V, int64_t outer, int n, int64_t inner, float* dW, float* db, int accumulate,
+                                void* stream) {
+  return tante_axis_wgrad_ws(U, V, outer, n, inner, dW, db, accumulate, nullptr, 0, stream);
 }
 extern "C" int tante_fold_fwd(const float* W, const float* b, const float* gamma, const float* beta, int N, int K, float* We, float* be,
                               void* stream) {
