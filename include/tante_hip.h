@@ -251,6 +251,16 @@ int tante_block_tail_bwd(const float* dout, const void* hpre, const void* xh2, c
                          int hidden, float p_drop, uint64_t seed_out, uint64_t seed_mlp, float* dx1, void* dy2, void* dhpre, void* dy1,
                          void* d_o, void* stream);
 
+/* The FRONT of the block's backward in one launch: dxh = dqkv W_in' (the q | k | v data gradient, W_in' = the LayerNorm1-folded
+ * in-projection weight (768, 256)) and LayerNorm1's backward with the skip gradient added:
+ *   dx = dx1 + rstd1 (dxh - mean(dxh) - xh1 mean(dxh xh1))     (attn_backbone.py:79-80 backwards; replaces a data-gradient tante_gemm +
+ * tante_layernorm_bwd).  dqkv (M, 768) bf16 = tante_attention_bwd's result, xh1 (M, 256) bf16 and st1 (M, 2) fp32 = the forward's saved
+ * LayerNorm1 image and statistics, dx1 (M, 256) fp32 = the gradient reaching the block input through the skip path (tante_block_tail_bwd's
+ * dx1), dx (M, 256) fp32 = the gradient of the block input.  head_bwd_stream = tante_pack_block_tail_bwd(W_in'[0:256], W_in'[256:512],
+ * W_in'[512:768]): the three row blocks of the folded weight, transposed into fragments like the tail's three weights. */
+int tante_block_head_bwd(const void* dqkv, const void* xh1, const float* st1, const float* dx1, const void* head_bwd_stream, int64_t M, int C,
+                         float* dx, void* stream);
+
 /* ---- fused derivative head (bf16 MFMA path) ----------------------------------------------------------
  * One launch per Taylor order: rows r = (img, hp, wp) of the token stream (gathered like TANTE_A_LINEAR: the last time slot by
  * stride) -> 3 x [ConvTranspose2d k = s = 2 (+GELU erf)] -> for i < n_out:  out_i (+)= coefs[i] * derivative, where out_i is frame i

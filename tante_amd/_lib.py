@@ -72,6 +72,7 @@ SIGNATURES = {
     "tante_block_tail_bwd_stream_bytes": ([c_i32, c_i32], c_i64),
     "tante_pack_block_tail_bwd": ([c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp], c_i32),
     "tante_block_tail_bwd": ([c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_f32, C.c_uint64, C.c_uint64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp], c_i32),
+    "tante_block_head_bwd": ([c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_vp, c_vp], c_i32),
     "tante_pack_block_train": ([c_vp] * 8 + [c_i32, c_i32, c_vp, c_vp], c_i32),
     "tante_block_fused_train": ([c_vp, c_vp, c_i32, c_i32, c_i32, C.POINTER(Seq), c_i32, c_f32, C.POINTER(BlockTrain), c_vp], c_i32),
     "tante_head_fused_supported": ([c_i32, c_i32], c_i32),

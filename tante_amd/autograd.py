@@ -588,9 +588,10 @@ class BlockFn(Function):
     launch per block the host, not the GPU, was setting the train step's time."""
 
     @staticmethod
-    def forward(ctx, x, w_in, b_in, Wo, bo, w1f, b1f, W2, b2, saved, bwd_stream, seq, n_head, causal, p, seeds, compute):
+    def forward(ctx, x, w_in, b_in, Wo, bo, w1f, b1f, W2, b2, saved, bwd_stream, seq, n_head, causal, p, seeds, compute, head_stream=None):
         ctx.save_for_backward(x, saved["st1"], saved["xh1"], saved["qkv"], saved["o"], saved["hpre"], saved["xh2"], saved["st2"], saved["act"],
                               bwd_stream, w_in)
+        ctx.head_stream = head_stream      # fragments of the folded in-projection weight's transpose (tante_block_head_bwd), or None
         ctx.params = (w_in, b_in, Wo, bo, w1f, b1f, W2, b2)
         ctx.meta = (seq, n_head, bool(causal), float(p), tuple(seeds), compute)
         return saved["out"]
@@ -605,10 +606,19 @@ class BlockFn(Function):
         r = BlockTailFn.backward(tail, dout)
         d_o, dx1 = r[0], r[1]
         dqkv = AttentionFn.backward(NS(saved_tensors=(qkv,), seq=seq, C=x.shape[1], nh=n_head, causal=causal, p=p, seed=seeds[0]), d_o)[0]
+        if ctx.head_stream is not None and dqkv.dtype == torch.bfloat16:
+            # q | k | v data gradient + LayerNorm1 backward + skip gradient: ONE launch (two GEMM launches and a LayerNorm backward otherwise)
+            M, N = dqkv.shape
+            gW, gb = _grad_slot(w_in), _grad_slot(b_in)
+            if not _defer_wgrad(gW, gb, dqkv, xh1, M, N, xh1.shape[1], L.BF16):
+                wgrad(_rm_linear(dqkv), _rm_linear(xh1), M, N, xh1.shape[1], (N, xh1.shape[1]), L.BF16, device=xh1.device, with_bias=True,
+                      into=gW, db_into=gb)
+            dx = K.block_head_bwd(dqkv, xh1, st1, dx1.contiguous(), ctx.head_stream, x.shape[1])
+            return (dx,) + (None,) * 17
         dxh = LinearFn.backward(NS(saved_tensors=(xh1, w_in_s), compute=compute, has_bias=True, has_res=False, params=(w_in, b_in),
                                    needs_input_grad=(True, True, True, False, False, False, False)), dqkv)[0]
         dx = LayerNormSkipFn.backward(NS(saved_tensors=(x, st1)), dxh, dx1)[0]
-        return (dx,) + (None,) * 16
+        return (dx,) + (None,) * 17
 
 
 def block_tail_ready(*params) -> bool:

@@ -205,6 +205,143 @@ __global__ __launch_bounds__(256, 2) void block_tail_bwd_kernel(BtArgs A) {
   }
 }
 
+// ---- the front of the block's backward in ONE launch: q | k | v data gradient + LayerNorm1 backward + the skip gradient -----------------
+//
+//     dxh = dqkv W_in'        (M x 768 . 768 x 256; W_in' = the LayerNorm-folded in-projection weight)
+//     dx  = dx1 + rstd1 (dxh - mean(dxh) - xh1 mean(dxh xh1))          (attn_backbone.py:79-80 backwards)
+//
+// Unfused: a 768-deep data-gradient GEMM (18 - 20 us) that writes dxh (bf16) and a LayerNorm backward (16 us) that reads it back with the
+// fp32 skip gradient.  Same scheme as the tail kernel: 4 waves, a wave owns 64 of the 256 output features for the workgroup's 48 / 64
+// tokens; the B operand is the workgroup's dqkv rows as THREE bf16 images (q, k, v parts) filled by LDS-DMA -- it writes lane-linear, so the
+// images' row swizzle is applied to the global SOURCE chunk each lane fetches (chunk c of row r lives at c ^ (r & 15): the four lanes of a
+// quad stay inside one 64-byte piece) --, the weights are the three 256 x 256 row blocks of W_in' transposed, i.e. exactly the tail
+// kernel's fragment stream (tante_pack_block_tail_bwd on the three row blocks).  The fp32 skip gradient and the result move in row form
+// through a private piece of an image once the GEMM's last reader is behind the statistics barrier.
+struct BhArgs {
+  const unsigned short *dqkv, *xh1;
+  const float *st1, *dx1;
+  const char* w;
+  float* dx;
+  long M;
+};
+
+template <int NTT>
+__global__ __launch_bounds__(256, 2) void block_head_bwd_kernel(BhArgs A) {
+  constexpr int RT = 4, NW = 4, PF = 2;
+  constexpr int IMG = 16 * NTT * FS_ROW;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const stat = smem + 3 * IMG;     // float2 [16 NTT tokens][4 waves]
+  const int tid = threadIdx.x, lane = tid & 63, kk = lane >> 4, l15 = lane & 15;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const long tok0 = (long)blockIdx.x * (16 * NTT);
+  int rdo[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) rdo[j] = l15 * FS_ROW + ((((j ^ (l15 >> 2)) << 2) | (kk ^ (l15 & 3))) << 4);
+  const char* const wq = A.w + (RT * wave) * FS_FRAG + lane * 16;
+  u32x4 wb[PF + 1][RT];
+  fs_wring_prime<0, RT, PF>(wq, wb);
+  // ---- dqkv rows -> the three images: one instruction = 2 rows of one image (32 lanes x 16 B per 512-byte row) -------------------------
+  {
+    const int half = lane >> 5, s = lane & 31;           // row within the pair, physical 16-byte slot within the row
+    for (int q = wave; q < 3 * 8 * NTT; q += NW) {       // 8 NTT row pairs per image
+      const int m = q / (8 * NTT), rp = q - m * (8 * NTT), r = 2 * rp + half;
+      long t = tok0 + r;
+      if (t >= A.M) t = A.M - 1;                         // dead rows: any valid row (their results are never stored)
+      const int c = (s & 16) | ((s & 15) ^ (r & 15));    // the logical chunk that belongs in this slot
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A.dqkv + t * (3 * FS_C) + m * FS_C + 8 * c),
+                                       (__attribute__((address_space(3))) void*)(smem + m * IMG + rp * 1024), 16, 0, 0);
+    }
+  }
+  const int col0 = 16 * RT * wave + 4 * kk;
+  bool lv[NTT];
+  long off[NTT];
+  float rstd[NTT];
+  u32x2 xh[RT][NTT];
+#pragma unroll
+  for (int tt = 0; tt < NTT; ++tt) {
+    const long t = tok0 + 16 * tt + l15;
+    lv[tt] = t < A.M;
+    off[tt] = (lv[tt] ? t : 0) * FS_C + col0;
+    rstd[tt] = A.st1[2 * (lv[tt] ? t : 0) + 1];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) xh[rt][tt] = *(const u32x2*)(A.xh1 + off[tt] + 16 * rt);      // in flight under the GEMM
+  }
+  // the skip gradient, row form (16 lanes x 16 B per token row of this wave's 64-feature slice), in flight under the GEMM too
+  constexpr int CPR = 4 * RT, RPI = 64 / CPR, ROWB = CPR * 16, TILEB = 16 * ROWB;
+  static_assert(IMG / NW >= TILEB, "staging piece too small");
+  const int rrow = lane / CPR, rchunk = lane % CPR;
+  f32x4 graw[NTT][RT];
+#pragma unroll
+  for (int tt = 0; tt < NTT; ++tt)
+#pragma unroll
+    for (int j = 0; j < RT; ++j) {
+      const long t = tok0 + 16 * tt + RPI * j + rrow;
+      graw[tt][j] = *(const f32x4*)(A.dx1 + (t < A.M ? t : 0) * FS_C + 16 * RT * wave + 4 * rchunk);
+    }
+  // the images must be complete before the GEMM; the row loads above were requested right behind the DMA passes and land with them
+  // (a counted wait would have to rely on the compiler keeping them behind the DMA instructions)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  f32x4 acc[RT][NTT];
+#pragma unroll
+  for (int tt = 0; tt < NTT; ++tt)
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) acc[rt][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  fs_slice_gemm<0, 24, NTT, RT, false, PF>(wq, wb, smem, rdo, acc);
+  fs_slice_gemm<1, 24, NTT, RT, false, PF>(wq, wb, smem + IMG, rdo, acc);
+  fs_slice_gemm<2, 24, NTT, RT, false, PF>(wq, wb, smem + 2 * IMG, rdo, acc);
+  // per-token sums over ALL 256 features: this wave's 64, then the four waves' partials through LDS
+#pragma unroll
+  for (int tt = 0; tt < NTT; ++tt) {
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      const f32x4 xv = unpack4(xh[rt][tt]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        s1 += acc[rt][tt][e];
+        s2 = fmaf(acc[rt][tt][e], xv[e], s2);
+      }
+    }
+    s1 = rows_sum(s1);
+    s2 = rows_sum(s2);
+    if (kk == 0) *(float2*)(stat + ((16 * tt + l15) * NW + wave) * 8) = make_float2(s1, s2);
+  }
+  __syncthreads();
+  char* const sb = smem + wave * (IMG / NW);      // the images' last readers are behind the barrier: a private staging piece
+#pragma unroll
+  for (int tt = 0; tt < NTT; ++tt) {
+    const f32x4* sp = (const f32x4*)(stat + (16 * tt + l15) * NW * 8);
+    const f32x4 a = sp[0], b = sp[1];
+    const float m1 = ((a[0] + a[2]) + (b[0] + b[2])) * (1.0f / FS_C), m2 = ((a[1] + a[3]) + (b[1] + b[3])) * (1.0f / FS_C);
+    // skip gradient of this tile: row form -> accumulator layout
+#pragma unroll
+    for (int j = 0; j < RT; ++j) {
+      const int r = RPI * j + rrow;
+      *(f32x4*)(sb + r * ROWB + ((rchunk ^ (r & (CPR - 1))) << 4)) = graw[tt][j];
+    }
+    f32x4 d[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      const f32x4 g = *(const f32x4*)(sb + l15 * ROWB + (((4 * rt + kk) ^ (l15 & (CPR - 1))) << 4));
+      const f32x4 xv = unpack4(xh[rt][tt]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) d[rt][e] = g[e] + rstd[tt] * (acc[rt][tt][e] - m1 - xv[e] * m2);
+    }
+    // and the result back: accumulator layout -> row form -> memory
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) *(f32x4*)(sb + l15 * ROWB + (((4 * rt + kk) ^ (l15 & (CPR - 1))) << 4)) = d[rt];
+#pragma unroll
+    for (int j = 0; j < RT; ++j) {
+      const int r = RPI * j + rrow;
+      const long t = tok0 + 16 * tt + r;
+      const f32x4 v = *(const f32x4*)(sb + r * ROWB + ((rchunk ^ (r & (CPR - 1))) << 4));
+      if (t < A.M) *(f32x4*)(A.dx + t * FS_C + 16 * RT * wave + 4 * rchunk) = v;
+    }
+  }
+}
+
 // fragment f = (m * 8 + ks) * 16 + g of the TRANSPOSED matrix m: lane (l15, kk) holds  W_m^T[16 g + l15][32 ks + 8 kk + e] =
 // W_m[32 ks + 8 kk + e][16 g + l15];  m = 0: fc2 weight, 1: the folded fc1 weight (W1 diag(gamma2)), 2: out-proj weight
 __global__ void bt_pack_kernel(const float* __restrict__ w2, const float* __restrict__ w1f, const float* __restrict__ wo, char* __restrict__ dst) {
@@ -228,7 +365,33 @@ void bt_launch(const BtArgs& A, hipStream_t s) {
   hipLaunchKernelGGL((block_tail_bwd_kernel<NTT>), dim3((unsigned)((A.M + per - 1) / per)), dim3(256), LDS, s, A);
 }
 
+template <int NTT>
+void bh_launch(const BhArgs& A, hipStream_t s) {
+  constexpr int LDS = 3 * 16 * NTT * FS_ROW + 16 * NTT * 4 * 8;
+  static TantePerDevice attr;
+  attr.once([&] { (void)hipFuncSetAttribute((const void*)block_head_bwd_kernel<NTT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); });
+  const long per = 16 * NTT;
+  hipLaunchKernelGGL((block_head_bwd_kernel<NTT>), dim3((unsigned)((A.M + per - 1) / per)), dim3(256), LDS, s, A);
+}
+
 }  // namespace
+
+extern "C" int tante_block_head_bwd(const void* dqkv, const void* xh1, const float* st1, const float* dx1, const void* head_bwd_stream, int64_t M,
+                                    int C, float* dx, void* stream) {
+  if (!dqkv || !xh1 || !st1 || !dx1 || !head_bwd_stream || !dx || M <= 0) TANTE_FAIL(-1, "tante_block_head_bwd: bad argument");
+  if (C != FS_C) TANTE_FAIL(-2, "tante_block_head_bwd: unsupported C=%d", C);
+  if ((((uintptr_t)dqkv | (uintptr_t)xh1 | (uintptr_t)dx1 | (uintptr_t)dx | (uintptr_t)head_bwd_stream) & 15) || ((uintptr_t)st1 & 7))
+    TANTE_FAIL(-1, "tante_block_head_bwd: 16-byte alignment");
+  BhArgs A;
+  A.dqkv = (const unsigned short*)dqkv; A.xh1 = (const unsigned short*)xh1; A.st1 = st1; A.dx1 = dx1; A.w = (const char*)head_bwd_stream;
+  A.dx = dx; A.M = M;
+  const long w3 = (M + 47) / 48, w4 = (M + 63) / 64;      // 3 images of 24 / 32 KiB: two 48-token workgroups per CU, one 64-token one
+  const long r3 = ((w3 + 511) / 512) * 3, r4 = ((w4 + 255) / 256) * 4;
+  if (r3 <= r4) bh_launch<3>(A, (hipStream_t)stream);
+  else bh_launch<4>(A, (hipStream_t)stream);
+  TANTE_CHECK_LAUNCH();
+  return 0;
+}
 
 extern "C" int64_t tante_block_tail_bwd_stream_bytes(int C, int hidden) { return (C == FS_C && hidden == FS_C) ? BT_W_BYTES : 0; }
 

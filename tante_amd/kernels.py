@@ -339,6 +339,16 @@ def pack_block_tail_bwd(fc2_w: torch.Tensor, fc1_w_folded: torch.Tensor, out_w: 
     return st
 
 
+def block_head_bwd(dqkv: torch.Tensor, xh1: torch.Tensor, st1: torch.Tensor, dx1: torch.Tensor, head_bwd_stream: torch.Tensor, C_: int) -> torch.Tensor:
+    """-> dx (M, 256) fp32: the q | k | v data gradient + LayerNorm1 backward + the skip gradient in one launch (tante_block_head_bwd);
+    head_bwd_stream = pack_block_tail_bwd on the three 256-row blocks of the folded in-projection weight."""
+    _dev(dqkv, xh1, st1, dx1, head_bwd_stream)
+    M = dx1.numel() // C_
+    dx = torch.empty(M, C_, dtype=torch.float32, device=dx1.device)
+    L.check(L.lib().tante_block_head_bwd(_p(dqkv), _p(xh1), _p(st1), _p(dx1), _p(head_bwd_stream), M, C_, _p(dx), _stream()), "tante_block_head_bwd")
+    return dx
+
+
 def block_tail_bwd(dout: torch.Tensor, hpre, xh2, st2, bwd_stream, C_: int, hidden: int, p_drop: float, seed_out: int, seed_mlp: int) -> dict:
     """-> {"dx1" fp32, "do", "dy2", "dhpre", "dy1" bf16}, each (M, 256) (tante_block_tail_bwd)."""
     _dev(dout, hpre, xh2, st2, bwd_stream)

@@ -53,6 +53,7 @@ def _folded(lin_w, lin_b, ln):
 
 FUSED_TRAIN_FORWARD = __import__("os").environ.get("TANTE_TRAIN_FUSED", "1") != "0"
 FUSED_TAIL_BACKWARD = __import__("os").environ.get("TANTE_TRAIN_FUSED_BWD", "1") != "0"
+FUSED_HEAD_BACKWARD = __import__("os").environ.get("TANTE_TRAIN_FUSED_HEAD_BWD", "1") != "0"   # q|k|v dgrad + LayerNorm1 backward in one launch
 
 
 def block_train(blk, x: torch.Tensor, seq, causal: bool, compute: int) -> torch.Tensor:
@@ -86,8 +87,18 @@ def block_train(blk, x: torch.Tensor, seq, causal: bool, compute: int) -> torch.
                 if _FOLDS is not None:
                     _FOLDS[key] = bstream
             if block_tail_ready(w_in, b_in):
+                hstream = None
+                if FUSED_HEAD_BACKWARD and w_in.shape == (3 * blk.embed_dim, blk.embed_dim) and blk.hidden == blk.embed_dim:
+                    key = ("bh_stream", id(blk))
+                    hstream = _FOLDS.get(key) if _FOLDS is not None else None
+                    if hstream is None:      # the three 256-row blocks of the folded in-projection weight, transposed into fragments
+                        E = blk.embed_dim
+                        wd = w_in.detach()
+                        hstream = K.pack_block_tail_bwd(wd[0:E], wd[E:2 * E], wd[2 * E:3 * E], E, blk.hidden)
+                        if _FOLDS is not None:
+                            _FOLDS[key] = hstream
                 return BlockFn.apply(x, w_in, b_in, a.out_proj.weight, a.out_proj.bias, w1, b1, m[2].weight, m[2].bias, t, bstream, seq,
-                                     blk.n_head, causal, p, seeds, compute)
+                                     blk.n_head, causal, p, seeds, compute, hstream)
             xh, xs = LayerNormSkipFn.apply(x, blk.ln1.eps, adt, (t["xh1"], t["st1"]))
             qkv = LinearFn.apply(xh, w_in, b_in, None, compute, adt, t["qkv"])
             o = AttentionFn.apply(qkv, seq, blk.embed_dim, blk.n_head, causal, p, (t["o"], seeds[0]))

@@ -360,9 +360,10 @@ def test_fused_training_forward_equals_unfused(dev, letter, B, T, H, W, p, monke
     w = torch.randn(n, 256, generator=torch.Generator().manual_seed(n + 1)).to(dev)
     opt = tante_amd.FlatAdamW(blk.parameters(), lr=1e-3)     # gives every parameter its accumulator (the fused tail backward adds into them)
     res = {}
-    for fused in ("tail", True, False):
+    for fused in ("tail", "tail_nohead", True, False):
         monkeypatch.setattr(TF, "FUSED_TRAIN_FORWARD", bool(fused))
-        monkeypatch.setattr(TF, "FUSED_TAIL_BACKWARD", fused == "tail")
+        monkeypatch.setattr(TF, "FUSED_TAIL_BACKWARD", fused in ("tail", "tail_nohead"))
+        monkeypatch.setattr(TF, "FUSED_HEAD_BACKWARD", fused == "tail")      # q | k | v dgrad + LayerNorm1 backward in one launch
         A._SEED[0] = 1000                                     # every run draws the same three seeds
         opt.zero_grad()
         x = x0.clone().requires_grad_(True)
@@ -372,6 +373,11 @@ def test_fused_training_forward_equals_unfused(dev, letter, B, T, H, W, p, monke
         res[fused] = (y.detach().cpu(), x.grad.cpu(), {k: v.grad.detach().cpu().clone() for k, v in blk.named_parameters()})
     (yt, gxt, gpt), (yf, gxf, gpf), (yu, gxu, gpu) = res["tail"], res[True], res[False]
     assert torch.equal(yt, yf)                                # same forward kernel
+    gxn, gpn = res["tail_nohead"][1], res["tail_nohead"][2]   # one-launch front of the backward vs GEMM + LayerNorm backward
+    record_parity(rel_err(gxt, gxn), max_rel(gxt, gxn), 2e-2, "bf16", f"fused head backward vs dgrad GEMM + LayerNorm backward, dx, p={p}")
+    assert max_rel(gxt, gxn) < 2e-2, max_rel(gxt, gxn)
+    for k in gpt:
+        assert max_rel(gpt[k], gpn[k]) < 1e-3 or "in_proj" in k and max_rel(gpt[k], gpn[k]) < 2e-2, (k, max_rel(gpt[k], gpn[k]))
     assert max_rel(gxt, gxu) < 4e-2, max_rel(gxt, gxu)        # one-launch tail backward vs the operator-by-operator backward
     for k in gpt:
         if "in_proj_bias" in k:
@@ -390,3 +396,28 @@ def test_fused_training_forward_equals_unfused(dev, letter, B, T, H, W, p, monke
         else:
             a_, b_ = gpf[k], gpu[k]
         assert max_rel(a_, b_) < 4e-2, (k, max_rel(a_, b_))
+
+
+@pytest.mark.parametrize("M", [48 * 5, 64 * 3 + 17, 4096])
+def test_block_head_bwd_against_float64(dev, M):
+    """tante_block_head_bwd: dx = dx1 + rstd (dxh - mean(dxh) - xh mean(dxh xh)), dxh = dqkv W, against float64 on the bf16-rounded
+    operands (what is left is the bf16 MFMA's fp32 accumulation order); ragged M covers the dead rows of the last workgroup."""
+    from tante_amd import kernels as Kk
+    g = torch.Generator().manual_seed(M)
+    W = torch.randn(768, 256, generator=g) / 16
+    dqkv = torch.randn(M, 768, generator=g).to(torch.bfloat16)
+    x = torch.randn(M, 256, generator=g) * 1.5 + 0.3
+    mean, var = x.mean(1, keepdim=True), x.var(1, unbiased=False, keepdim=True)
+    rstd = (var + 1e-5).rsqrt()
+    xh = ((x - mean) * rstd).to(torch.bfloat16)
+    st = torch.cat([mean, rstd], 1).contiguous()
+    dx1 = torch.randn(M, 256, generator=g)
+    Wd = W.to(dev)
+    stream = Kk.pack_block_tail_bwd(Wd[0:256], Wd[256:512], Wd[512:768], 256, 256)
+    dx = Kk.block_head_bwd(dqkv.to(dev), xh.to(dev), st.to(dev), dx1.to(dev), stream, 256).cpu()
+    dxh = dqkv.double() @ W.to(torch.bfloat16).double()
+    xh64 = xh.double()
+    ref = dx1.double() + rstd.double() * (dxh - dxh.mean(1, keepdim=True) - xh64 * (dxh * xh64).mean(1, keepdim=True))
+    e = max_rel(dx, ref.float())
+    record_parity(rel_err(dx, ref.float()), e, 2e-3, "bf16", f"block_head_bwd vs float64, M={M}")
+    assert e < 2e-3, e
