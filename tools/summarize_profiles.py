@@ -27,7 +27,7 @@ for sub in ("rollout", "train", "trl", "cvit", "fno"):
     stats(sub, f"{TAG}_{sub}_kernel_stats.csv")
 
 SHORT = {"block_fs_kernel<2": "fused_block_kernel", "block_fs_kernel<1": "fused_block_kernel_T_letter", "fused_head_kernel": "fused_head_kernel",
-         "axis_hw_kernel": "axis_hw_kernel", "axis_mlp_vec_kernel": "axis_mlp_vec_kernel"}
+         "axis_hw_": "axis_hw_kernel", "axis_mlp_vec_kernel": "axis_mlp_vec_kernel"}
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 dur = collections.defaultdict(list)
 for f in glob.glob(os.path.join(out, "pmc", "**", "*counter_collection.csv"), recursive=True):
@@ -51,7 +51,7 @@ for k, d in agg.items():
     e = {"launches_sampled": len(next(iter(d.values()))), "avg_ns_under_pmc": round(sum(dur[k]) / max(1, len(dur[k])), 1),
          "counters_avg_per_launch": {c: round(v, 1) for c, v in sorted(m.items())}}
     if "FETCH_SIZE" in m and "WRITE_SIZE" in m:
-        e["hbm_bytes_per_launch"] = round(m["FETCH_SIZE"] * 1024 * (1 if k == "axis_hw_kernel" else 2) + m["WRITE_SIZE"] * 1024)
+        e["hbm_bytes_per_launch"] = round(m["FETCH_SIZE"] * 1024 * 2 + m["WRITE_SIZE"] * 1024)   # every kernel here reads 16 B per lane
     if "SQ_WAVE_CYCLES" in m:
         wc = m["SQ_WAVE_CYCLES"]
         e["wave_cycle_split"] = {"parked_waitcnt_barrier": round(m.get("SQ_WAIT_ANY", 0) / wc, 3), "issue_stall": round(m.get("SQ_WAIT_INST_ANY", 0) / wc, 3),

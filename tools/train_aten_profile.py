@@ -22,5 +22,12 @@ torch.cuda.synchronize()
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
     for _ in range(3): tante_amd.train_step(m, opt, batch, fmt, n, 1)
     torch.cuda.synchronize()
-print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=40, max_name_column_width=50, max_shapes_column_width=60))
-print(prof.key_averages(group_by_stack_n=6).table(sort_by="cuda_time_total", row_limit=30, max_name_column_width=40, max_src_column_width=110))
+rows = [e for e in prof.key_averages() if e.key.startswith("aten::") or "Backward" in e.key or e.key.endswith("Fn")]
+rows.sort(key=lambda e: -e.count)
+print("count/step  self-cuda-us/step  name")
+for e in rows[:45]:
+    print(f"{e.count / 3:9.1f} {e.self_device_time_total / 3:12.1f}   {e.key}")
+for e in sorted(prof.key_averages(group_by_stack_n=8), key=lambda e: -e.count)[:40]:
+    if e.key in ("aten::copy_", "aten::fill_", "aten::add_", "aten::add", "aten::mul", "aten::zeros", "aten::zero_", "aten::clone", "aten::contiguous", "aten::to", "aten::cat", "aten::mm", "aten::sum"):
+        st = [fr for fr in e.stack if "tante_amd" in fr][:3]
+        print(f"{e.count / 3:8.1f}  {e.key:18s} {st}")
