@@ -164,6 +164,13 @@ int tante_axis_hw_film(float* x, const float* src, int64_t src_t_stride, int64_t
                        const float* s_emb, int T, int64_t BT, int nH, int nW, int C, const float* wh1, const float* bh1, const float* wh2,
                        const float* bh2, const float* ww1, const float* bw1, const float* ww2, const float* bw2, int compute, void* stream);
 
+/* The training forward of the two propagators in one launch, out of place: xout = H- then W-propagator of xin (xin stays intact for the
+ * backward pass) and xmid = the planes between the two (the W propagator's input, which tante_axis_mlp_bwd needs).  bf16 compute,
+ * whole 16-row tiles only (nH, nW multiples of 16 and the plane within the LDS): -2 otherwise, and the caller runs tante_axis_mlp twice. */
+int tante_axis_hw_train(const float* xin, float* xout, float* xmid, int64_t BT, int nH, int nW, int C, const float* wh1, const float* bh1,
+                        const float* wh2, const float* bh2, const float* ww1, const float* bw1, const float* ww2, const float* bw2, int compute,
+                        void* stream);
+
 /* film tables (tante.py:218-230): a[r][c] = 1 + scale(t[r])[c], b[r][c] = shift(t[r])[c] (+ add[r][c]).
  * scale/shift = Linear(1, C/2) -> ReLU -> Linear(C/2, C).  rows = len(t). */
 int tante_film_table(const float* t, int rows, int C, const float* sc_w0, const float* sc_b0, const float* sc_w2,

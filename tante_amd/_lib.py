@@ -59,6 +59,7 @@ SIGNATURES = {
     "tante_axis_mlp_c": ([c_vp, c_i64, c_i32, c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp], c_i32),
     "tante_axis_hw": ([c_vp, c_i64, c_i32, c_i32, c_i32] + [c_vp] * 8 + [c_i32, c_vp], c_i32),
     "tante_axis_hw_film": ([c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_i32, c_i32] + [c_vp] * 8 + [c_i32, c_vp], c_i32),
+    "tante_axis_hw_train": ([c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp], c_i32),
     "tante_film_table": ([c_vp, c_i32, c_i32] + [c_vp] * 8 + [c_vp, c_vp, c_vp, c_vp], c_i32),
     "tante_film_apply": ([c_vp, c_i64, c_vp, c_i64, c_i32, c_i64, c_vp, c_vp, c_vp], c_i32),
     "tante_format_input": ([c_vp, c_i64, c_i32, c_i64, c_i32, c_vp, c_i64, c_vp], c_i32),

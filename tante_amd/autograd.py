@@ -762,6 +762,31 @@ class AxisMlpFn(Function):
         return dx, dw1, db1, dw2, db2, None, None, None, None
 
 
+class AxisHWFn(Function):
+    """The vertical and the horizontal propagator of a backbone as one node (bf16 training path): forward is ONE launch
+    (tante_axis_hw_train: both axes on MFMA over an LDS-resident plane, out of place, the intermediate planes saved for the backward),
+    backward is AxisMlpFn's backward twice -- W axis on the saved intermediate, then H axis on the input."""
+
+    @staticmethod
+    def forward(ctx, x, vw1, vb1, vw2, vb2, hw1, hb1, hw2, hb2, BT, H, W, C_, compute):
+        y, xm = K.axis_hw_train(x.detach().contiguous(), BT, H, W, C_, (vw1, vb1, vw2, vb2), (hw1, hb1, hw2, hb2), compute)
+        ctx.save_for_backward(x, xm, vw1, vb1, vw2, hw1, hb1, hw2)
+        ctx.params = (vw1, vb1, vw2, vb2, hw1, hb1, hw2, hb2)
+        ctx.dims = (BT, H, W, C_)
+        ctx.compute = compute
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from types import SimpleNamespace as NS
+        x, xm, vw1, vb1, vw2, hw1, hb1, hw2 = ctx.saved_tensors
+        BT, H, W, C_ = ctx.dims
+        p = ctx.params
+        rw = AxisMlpFn.backward(NS(saved_tensors=(xm, hw1, hb1, hw2), dims=(BT * H, W, C_), compute=ctx.compute, params=p[4:8]), dy)
+        rh = AxisMlpFn.backward(NS(saved_tensors=(x, vw1, vb1, vw2), dims=(BT, H, W * C_), compute=ctx.compute, params=p[0:4]), rw[0])
+        return (rh[0], rh[1], rh[2], rh[3], rh[4], rw[1], rw[2], rw[3], rw[4], None, None, None, None, None)
+
+
 def _tr_shape(M: int, I: int, J: int) -> bool:
     """Shapes the LDS-DMA / transposed-read weight-gradient kernel takes (bf16 dense rows)."""
     return M % 32 == 0 and I % 128 == 0 and J % 128 == 0

@@ -576,7 +576,10 @@ __global__ __launch_bounds__(NT) void axis_hw_exact_kernel(float* __restrict__ x
                                                            const float* __restrict__ bh1, const float* __restrict__ wh2,
                                                            const float* __restrict__ bh2, const float* __restrict__ ww1,
                                                            const float* __restrict__ bw1, const float* __restrict__ ww2,
-                                                           const float* __restrict__ bw2, unsigned long long* stamps) {
+                                                           const float* __restrict__ bw2, unsigned long long* stamps,
+                                                           const float* __restrict__ xin, float* __restrict__ xmid) {
+  // xin (training forward): read the planes from here instead of x (out of place: the input stays intact for the backward pass);
+  // xmid: the planes after the H propagator, i.e. the W propagator's input, which its backward needs
   constexpr int NH = 16 * MTH, NW = 16 * MTW, RS = axe_rs(NW, CT), NWV = NT / 64;
   constexpr int TPI = 256 / CT, LPT = CT / 4;    // tokens per DMA instruction (1 KiB), lanes per token
   extern __shared__ __attribute__((aligned(16))) float plane[];  // [NH][RS], token (h, w) at h * RS + w * CT
@@ -596,9 +599,10 @@ __global__ __launch_bounds__(NT) void axis_hw_exact_kernel(float* __restrict__ x
   // ---- the plane: one instruction = TPI tokens of a row (lanes LPT t .. LPT t + LPT - 1 = the CT channels of token t) ------------
   constexpr int IPR = NW / TPI;                  // instructions per row
   if (!S.src) {
+    const float* gin = xin ? xin + (gx - x) : gx;
     for (int q = wave; q < NH * IPR; q += NWV) {
       const int h = q / IPR, j = q - h * IPR;
-      const float* g = gx + ((long)h * NW + j * TPI + lane / LPT) * C + (lane % LPT) * 4;
+      const float* g = gin + ((long)h * NW + j * TPI + lane / LPT) * C + (lane % LPT) * 4;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                        (__attribute__((address_space(3))) void*)(plane + h * RS + j * 256), 16, 0, 0);
     }
@@ -633,6 +637,13 @@ __global__ __launch_bounds__(NT) void axis_hw_exact_kernel(float* __restrict__ x
   axe_load_weights<MTW>(wstW, lane, kk, WW);
   __syncthreads();
   AXE_STAMP(5);
+  if (xmid) {      // the plane as the H propagator left it, row form (the mirror image of the LDS-DMA pass above)
+    float* gm = xmid + (gx - x);
+    for (int q = wave; q < NH * IPR; q += NWV) {
+      const int h = q / IPR, j = q - h * IPR;
+      *(f32x4*)(gm + ((long)h * NW + j * TPI + lane / LPT) * C + (lane % LPT) * 4) = *(const f32x4*)(plane + h * RS + j * 256 + lane * 4);
+    }
+  }
   axe_phase<MTW, CT, NWV, NH, CT, RS, true>(plane, WW, wave, l15, kk, gx, (long)C, (long)NW * C);
   AXE_STAMP(6);
 #ifdef TANTE_ABLATE
@@ -807,11 +818,20 @@ static void launch_axis_hw(float* x, const AxisSrc& S, long BT, int nH, int nW, 
 }
 
 static int axis_hw_impl(float* x, const AxisSrc& S, int64_t BT, int nH, int nW, int C, const float* wh1, const float* bh1, const float* wh2,
-                        const float* bh2, const float* ww1, const float* bw1, const float* ww2, const float* bw2, int compute, void* stream);
+                        const float* bh2, const float* ww1, const float* bw1, const float* ww2, const float* bw2, int compute, void* stream,
+                        const float* xin = nullptr, float* xmid = nullptr);
 
 #ifdef TANTE_ABLATE
 extern "C" void tante_axe_set_stamps(unsigned long long* p) { g_axe_stamps = p; }
 #endif
+
+extern "C" int tante_axis_hw_train(const float* xin, float* xout, float* xmid, int64_t BT, int nH, int nW, int C, const float* wh1, const float* bh1,
+                                   const float* wh2, const float* bh2, const float* ww1, const float* bw1, const float* ww2, const float* bw2,
+                                   int compute, void* stream) {
+  if (!xin || !xmid || ((uintptr_t)xin % 16) || ((uintptr_t)xmid % 16)) TANTE_FAIL(-1, "tante_axis_hw_train: null or misaligned pointer");
+  const AxisSrc none = {nullptr, 0, 0, nullptr, nullptr, nullptr, 1};
+  return axis_hw_impl(xout, none, BT, nH, nW, C, wh1, bh1, wh2, bh2, ww1, bw1, ww2, bw2, compute, stream, xin, xmid);
+}
 
 extern "C" int tante_axis_hw(float* x, int64_t BT, int nH, int nW, int C, const float* wh1, const float* bh1, const float* wh2,
                              const float* bh2, const float* ww1, const float* bw1, const float* ww2, const float* bw2,
@@ -832,7 +852,8 @@ extern "C" int tante_axis_hw_film(float* x, const float* src, int64_t src_t_stri
 }
 
 static int axis_hw_impl(float* x, const AxisSrc& S, int64_t BT, int nH, int nW, int C, const float* wh1, const float* bh1, const float* wh2,
-                        const float* bh2, const float* ww1, const float* bw1, const float* ww2, const float* bw2, int compute, void* stream) {
+                        const float* bh2, const float* ww1, const float* bw1, const float* ww2, const float* bw2, int compute, void* stream,
+                        const float* xin, float* xmid) {
   if (!x || !wh1 || !bh1 || !wh2 || !bh2 || !ww1 || !bw1 || !ww2 || !bw2) TANTE_FAIL(-1, "tante_axis_hw: null pointer");
   if (BT <= 0 || nH <= 0 || nW <= 0 || C <= 0) TANTE_FAIL(-1, "tante_axis_hw: bad shape");
   hipStream_t s = (hipStream_t)stream;
@@ -858,7 +879,7 @@ static int axis_hw_impl(float* x, const AxisSrc& S, int64_t BT, int nH, int nW, 
   {                                                                                                                                     \
     static TantePerDevice attr;                                                                                                         \
     attr.once([&] { (void)hipFuncSetAttribute((const void*)axis_hw_exact_kernel<MH, MW, CTV, NTV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }); \
-    hipLaunchKernelGGL((axis_hw_exact_kernel<MH, MW, CTV, NTV>), dim3(grid), dim3(NTV), elds, s, x, S, C, wh1, bh1, wh2, bh2, ww1, bw1, ww2, bw2, axe_st); \
+    hipLaunchKernelGGL((axis_hw_exact_kernel<MH, MW, CTV, NTV>), dim3(grid), dim3(NTV), elds, s, x, S, C, wh1, bh1, wh2, bh2, ww1, bw1, ww2, bw2, axe_st, xin, xmid); \
   }
 #define TANTE_AXE(MH, MW)                  \
   {                                        \
@@ -878,6 +899,7 @@ static int axis_hw_impl(float* x, const AxisSrc& S, int64_t BT, int nH, int nW, 
     TANTE_CHECK_LAUNCH();
     return 0;
   }
+  if (xin || xmid) TANTE_FAIL(-2, "tante_axis_hw_train: needs the whole-tile bf16 form (nH, nW multiples of 16, the plane within the LDS)");
   const int nmax = nH > nW ? nH : nW;
   const size_t lds = (((size_t)nH * axis_row_stride(nW) + 3) & ~(size_t)3) * sizeof(float) + 2 * (size_t)nmax * sizeof(float) +
                      2 * (size_t)nmax * (compute == TANTE_BF16 ? (nmax + 8) * 2 : nmax * 4);

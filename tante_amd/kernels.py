@@ -238,6 +238,23 @@ def axis_hw(x: torch.Tensor, BT: int, nH: int, nW: int, C_: int, vp, hp, compute
     return x
 
 
+def axis_hw_train(x: torch.Tensor, BT: int, nH: int, nW: int, C_: int, vp, hp, compute: int):
+    """Training forward of the H and W propagators in one launch, out of place: -> (y, x_mid) with x_mid the planes between the two
+    (the W propagator's input); x is left intact.  Only where axis_hw_supported(..., BF16)'s whole-tile form applies."""
+    ws = [p.detach() for p in (*vp, *hp)]
+    _dev(x, *ws)
+    y, xm = torch.empty_like(x), torch.empty_like(x)
+    L.check(L.lib().tante_axis_hw_train(_p(x), _p(y), _p(xm), BT, nH, nW, C_, *[_p(w) for w in ws], compute, _stream()), "tante_axis_hw_train")
+    return y, xm
+
+
+def axis_hw_train_supported(nH: int, nW: int, C_: int, compute: int) -> bool:
+    def wbytes(m):
+        return 2 * m * ((m + 1) // 2) * 1024 + 128 * m
+    return (compute == L.BF16 and nH % 16 == 0 and nW % 16 == 0 and C_ % 16 == 0 and max(nH, nW) <= 64
+            and nH * (nW * 16 + 32) * 4 + wbytes(nH // 16) + wbytes(nW // 16) <= 160 * 1024)
+
+
 def axis_hw_film(x: torch.Tensor, src: torch.Tensor, src_t_stride: int, src_b_stride: int, film: tuple, BT: int, nH: int, nW: int, C_: int,
                  vp, hp, compute: int):
     """axis_hw with the planes read from a frame-major pre-FiLM encoder cache; film = (a, b, s_emb, T, HW)."""

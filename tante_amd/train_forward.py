@@ -12,7 +12,7 @@ import torch
 from . import _lib as L
 from . import kernels as K
 from . import stages as S
-from .autograd import (ActFn, AttentionFn, BlockFn, BlockTailFn, block_tail_ready, AxisMlpFn, BranchOutFn, DeconvFn, DropoutAddFn, FilmPosFn, FoldFn, LayerNormFn, LayerNormSkipFn, LinearFn, PatchEmbedFn, RtReduceFn,
+from .autograd import (ActFn, AttentionFn, BlockFn, BlockTailFn, block_tail_ready, AxisHWFn, AxisMlpFn, BranchOutFn, DeconvFn, DropoutAddFn, FilmPosFn, FoldFn, LayerNormFn, LayerNormSkipFn, LinearFn, PatchEmbedFn, RtReduceFn,
                        TaylorFn)
 
 
@@ -53,6 +53,7 @@ def _folded(lin_w, lin_b, ln):
 
 FUSED_TRAIN_FORWARD = __import__("os").environ.get("TANTE_TRAIN_FUSED", "1") != "0"
 FUSED_TAIL_BACKWARD = __import__("os").environ.get("TANTE_TRAIN_FUSED_BWD", "1") != "0"
+FUSED_AXIS_HW = __import__("os").environ.get("TANTE_TRAIN_FUSED_AXIS", "1") != "0"     # H + W propagators' training forward in one launch
 FUSED_HEAD_BACKWARD = __import__("os").environ.get("TANTE_TRAIN_FUSED_HEAD_BWD", "1") != "0"   # q|k|v dgrad + LayerNorm1 backward in one launch
 
 
@@ -123,8 +124,12 @@ def block_train(blk, x: torch.Tensor, seq, causal: bool, compute: int) -> torch.
 def backbone_train(bb, x: torch.Tensor, B: int, compute: int) -> torch.Tensor:
     T, H, W, C_ = bb.T, bb.H, bb.W, bb.C
     vp, hp, tp = bb.vertical_propagator, bb.horizontal_propagator, bb.temporal_propagator
-    x = AxisMlpFn.apply(x, vp[0].weight, vp[0].bias, vp[2].weight, vp[2].bias, B * T, H, W * C_, compute)
-    x = AxisMlpFn.apply(x, hp[0].weight, hp[0].bias, hp[2].weight, hp[2].bias, B * T * H, W, C_, compute)
+    if FUSED_AXIS_HW and K.axis_hw_train_supported(H, W, C_, compute) and x.dtype == torch.float32:
+        x = AxisHWFn.apply(x, vp[0].weight, vp[0].bias, vp[2].weight, vp[2].bias, hp[0].weight, hp[0].bias, hp[2].weight, hp[2].bias,
+                           B * T, H, W, C_, compute)
+    else:
+        x = AxisMlpFn.apply(x, vp[0].weight, vp[0].bias, vp[2].weight, vp[2].bias, B * T, H, W * C_, compute)
+        x = AxisMlpFn.apply(x, hp[0].weight, hp[0].bias, hp[2].weight, hp[2].bias, B * T * H, W, C_, compute)
     x = AxisMlpFn.apply(x, tp[0].weight, tp[0].bias, tp[2].weight, tp[2].bias, B, T, H * W * C_, compute)
     for i, axis in enumerate(bb.attn_axes):
         if axis == "C":

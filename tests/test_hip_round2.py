@@ -421,3 +421,38 @@ def test_block_head_bwd_against_float64(dev, M):
     e = max_rel(dx, ref.float())
     record_parity(rel_err(dx, ref.float()), e, 2e-3, "bf16", f"block_head_bwd vs float64, M={M}")
     assert e < 2e-3, e
+
+
+@pytest.mark.parametrize("B,T,H,W", [(2, 2, 16, 48), (1, 3, 32, 32)])
+def test_fused_axis_hw_training_forward_equals_two_axis_mlps(dev, B, T, H, W):
+    """AxisHWFn (one bf16-MFMA launch for the H and W propagators, intermediate saved) against AxisMlpFn twice (fp32 lane-per-line
+    kernels): output at the bf16 bar, and -- the backward being the same two calls -- every gradient with it."""
+    from tante_amd import autograd as A, _lib as L
+    C_ = 256
+    g = torch.Generator().manual_seed(H * 100 + W)
+
+    def mk(n):
+        return [(torch.randn(n, n, generator=g) / math.sqrt(n)).to(dev).requires_grad_(True), (0.3 * torch.randn(n, generator=g)).to(dev).requires_grad_(True),
+                (torch.randn(n, n, generator=g) / math.sqrt(n)).to(dev).requires_grad_(True), (0.3 * torch.randn(n, generator=g)).to(dev).requires_grad_(True)]
+    vp, hp = mk(H), mk(W)
+    x0 = torch.randn(B * T, H, W, C_, generator=g).to(dev)
+    w = torch.randn(B * T, H, W, C_, generator=g).to(dev)
+    res = []
+    for fused in (True, False):
+        for q in vp + hp:
+            q.grad = None
+        x = x0.clone().requires_grad_(True)
+        if fused:
+            y = A.AxisHWFn.apply(x, *vp, *hp, B * T, H, W, C_, L.BF16)
+        else:
+            y = A.AxisMlpFn.apply(x, *vp, B * T, H, W * C_, L.BF16)
+            y = A.AxisMlpFn.apply(y, *hp, B * T * H, W, C_, L.BF16)
+        A.run_backward((y * w).sum())
+        res.append((y.detach().cpu(), x.grad.cpu(), [q.grad.detach().cpu().clone() for q in vp + hp]))
+    (yf, gxf, gpf), (yu, gxu, gpu) = res
+    e = max_rel(yf, yu)
+    record_parity(rel_err(yf, yu), e, 1e-2, "bf16", f"fused H+W propagator training forward vs two axis MLPs, {H}x{W}")
+    assert e < 1e-2, e
+    assert max_rel(gxf, gxu) < 2e-2, max_rel(gxf, gxu)
+    for a_, b_ in zip(gpf, gpu):
+        assert max_rel(a_, b_) < 2e-2, max_rel(a_, b_)
