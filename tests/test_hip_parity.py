@@ -560,7 +560,8 @@ def test_fused_backbone_strided_letters(dev):
 
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])
 @pytest.mark.parametrize("BT,nH,nW,C", [(3, 32, 32, 64), (2, 16, 48, 32), (5, 4, 6, 16), (1, 64, 16, 48), (2, 33, 7, 16), (1, 8, 64, 16),
-                                          (2, 48, 32, 32), (3, 16, 16, 16), (1, 32, 64, 16), (1, 48, 48, 32), (2, 64, 32, 16)])
+                                          (2, 48, 32, 32), (3, 16, 16, 16), (1, 32, 64, 16), (1, 48, 48, 32), (2, 64, 32, 16),
+                                          (24, 32, 32, 256), (12, 16, 48, 512)])      # the last two: 32-channel tiles (16 / 8 waves)
 def test_axis_hw_fused(dev, mode, BT, nH, nW, C):
     """Fused vertical+horizontal propagators (MFMA) against the oracle's two sequential axis MLPs."""
     from oracle import tante_oracle as O
@@ -1038,7 +1039,8 @@ def test_adaptive_train_step_runs(dev):
 # ---------------------------------------------------------------------------------------------------
 # fused derivative head + Taylor accumulation (bf16)
 # ---------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("C,D,B,Hp,Wp,n_out", [(256, 11, 2, 4, 6, 1), (128, 3, 3, 5, 3, 3), (256, 16, 1, 3, 7, 2), (128, 1, 2, 8, 8, 8)])
+@pytest.mark.parametrize("C,D,B,Hp,Wp,n_out", [(256, 11, 2, 4, 6, 1), (128, 3, 3, 5, 3, 3), (256, 16, 1, 3, 7, 2), (128, 1, 2, 8, 8, 8),
+                                                (256, 4, 7, 32, 32, 1), (128, 2, 8, 30, 30, 2)])     # the last two: >= 7168 rows = the 8-wave form, one ragged
 def test_fused_head_against_oracle(dev, C, D, B, Hp, Wp, n_out):
     import tante_amd
     from oracle import tante_oracle as O
