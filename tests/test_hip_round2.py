@@ -456,3 +456,28 @@ def test_fused_axis_hw_training_forward_equals_two_axis_mlps(dev, B, T, H, W):
     assert max_rel(gxf, gxu) < 2e-2, max_rel(gxf, gxu)
     for a_, b_ in zip(gpf, gpu):
         assert max_rel(a_, b_) < 2e-2, max_rel(a_, b_)
+
+
+@pytest.mark.parametrize("outer,n,inner", [(8, 4, 4096), (6, 16, 768), (40, 48, 256), (3, 7, 96), (2, 64, 64), (5, 8, 160)])
+@pytest.mark.parametrize("use_ws", [True, False])
+def test_axis_wgrad_against_float64(dev, outer, n, inner, use_ws):
+    """tante_axis_wgrad(_ws): dW[a][j] = sum_{o,i} U[o][a][i] V[o][j][i], db[a] = sum U -- every tile form (segment-packed n <= 4 / <= 8,
+    1 - 4 row tiles), with the group-sum workspace and with plain atomics, accumulate on and off; the workspace's arrival counters must be
+    back at zero afterwards (the next call relies on it)."""
+    from tante_amd import kernels as Kk, _lib as L
+    g = torch.Generator().manual_seed(outer * 1000 + n)
+    U, V = torch.randn(outer, n, inner, generator=g).to(dev), torch.randn(outer, n, inner, generator=g).to(dev)
+    ref = torch.einsum("oai,oji->aj", U.double().cpu(), V.double().cpu())
+    refb = U.double().cpu().sum((0, 2))
+    ws = torch.zeros(L.lib().tante_axis_wgrad_workspace_bytes() // 4, device=dev) if use_ws else None
+    for acc in (False, True, True):
+        dW = torch.full((n, n), 3.0, device=dev) if acc else torch.full((n, n), float("nan"), device=dev)
+        db = torch.full((n,), -2.0, device=dev) if acc else torch.full((n,), float("nan"), device=dev)
+        L.check(L.lib().tante_axis_wgrad_ws(U.data_ptr(), V.data_ptr(), outer, n, inner, dW.data_ptr(), db.data_ptr(), int(acc),
+                                            ws.data_ptr() if use_ws else None, ws.numel() * 4 if use_ws else 0, Kk._stream()), "tante_axis_wgrad_ws")
+        eW = float((dW.double().cpu() - (3.0 if acc else 0.0) - ref).abs().max() / ref.abs().max())
+        eb = float((db.double().cpu() - (-2.0 if acc else 0.0) - refb).abs().max() / refb.abs().max())
+        record_parity(eW, eW, 2e-5, "fp32", f"axis_wgrad ({outer},{n},{inner}) ws={use_ws} acc={acc}")
+        assert eW < 2e-5 and eb < 2e-5, (eW, eb)
+    if use_ws:
+        assert int(ws[-(1024 // 16):].view(torch.int32).abs().max()) == 0       # arrival counters
