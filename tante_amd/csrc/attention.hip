@@ -313,13 +313,22 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const unsigned short
     const float inv_l = lsum > 0.f ? 1.0f / lsum : 0.f;
     if (p_drop > 0.f) {
 #pragma unroll
-      for (int jt = 0; jt < NT; ++jt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
+      for (int jt = 0; jt < NT; ++jt) {
+        if ((L & 3) == 0) {      // the lane's four keys are one aligned run of mask indices of one sequence
           int jsl, jpos; bool jlive;
-          decode(jt * 16 + 4 * kk + r, jsl, jpos, jlive);
-          st[jt][r] = dropout_keep(seed, mrow + jpos, p_drop) ? st[jt][r] * ksc : 0.f;
+          decode(jt * 16 + 4 * kk, jsl, jpos, jlive);
+          const unsigned m4 = dropout_keep4(seed, mrow + jpos, p_drop);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) st[jt][r] = ((m4 >> r) & 1u) ? st[jt][r] * ksc : 0.f;
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            int jsl, jpos; bool jlive;
+            decode(jt * 16 + 4 * kk + r, jsl, jpos, jlive);
+            st[jt][r] = dropout_keep(seed, mrow + jpos, p_drop) ? st[jt][r] * ksc : 0.f;
+          }
         }
+      }
     }
     f32x4 oa[2] = {zero4, zero4};
 #pragma unroll

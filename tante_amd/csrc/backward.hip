@@ -622,20 +622,31 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const unsigned short
     const float inv_l = lsum > 0.f ? 1.0f / lsum : 0.f;
     float delta = 0.f;
 #pragma unroll
-    for (int jt = 0; jt < NT; ++jt)
+    for (int jt = 0; jt < NT; ++jt) {
+      unsigned m4 = 0xfu;
+      if (p_drop > 0.f && (L & 3) == 0) {      // the lane's four keys are one aligned run of mask indices of one sequence
+        int jsl, jpos; bool jlive;
+        decode(jt * 16 + 4 * kk, jsl, jpos, jlive);
+        m4 = dropout_keep4(seed, mrow + jpos, p_drop);
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float p = st[jt][r] * inv_l;
         float dp = dpt[jt][r];
         if (p_drop > 0.f) {
-          int jsl, jpos; bool jlive;
-          decode(jt * 16 + 4 * kk + r, jsl, jpos, jlive);
-          dp = dropout_keep(seed, mrow + jpos, p_drop) ? dp * ksc : 0.f;   // d(dropped prob) -> d(prob)
+          if ((L & 3) == 0) {
+            dp = ((m4 >> r) & 1u) ? dp * ksc : 0.f;                          // d(dropped prob) -> d(prob)
+          } else {
+            int jsl, jpos; bool jlive;
+            decode(jt * 16 + 4 * kk + r, jsl, jpos, jlive);
+            dp = dropout_keep(seed, mrow + jpos, p_drop) ? dp * ksc : 0.f;
+          }
         }
         st[jt][r] = p;
         dpt[jt][r] = dp;
         delta += p * dp;
       }
+    }
     delta += __shfl_xor(delta, 16);
     delta += __shfl_xor(delta, 32);
     if (kk == 0) {

@@ -491,12 +491,20 @@ __global__ __launch_bounds__(64 * NW, 2) void block_fs_kernel(FsArgs A) {
             const int qs = 16 * (q0 + qt) + l15, si = (int)(((unsigned)qs * A.magic) >> 16), pi = qs - si * L;
             const unsigned long long mrow = ((((unsigned long long)(seq0 + si)) * 8 + (HPW * wave + hh)) * L + pi) * L;
 #pragma unroll
-            for (int j = 0; j < NK; ++j)
+            for (int j = 0; j < NK; ++j) {
+              const int jpos0 = 16 * (k0 + j) + 4 * kk - si * L;          // key position inside the query's sequence (where visible)
+              if ((L & 3) == 0) {      // the lane's four keys are one aligned run of mask indices: two hashes instead of four
+                const unsigned m4 = dropout_keep4(A.seed_attn, mrow + (unsigned long long)(jpos0 < 0 ? 0 : jpos0), A.p_drop);
 #pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                const int jpos = 16 * (k0 + j) + 4 * kk + r - si * L;     // key position inside the query's sequence (where visible)
-                sc[qt][j][r] = dropout_keep(A.seed_attn, mrow + (unsigned long long)(jpos < 0 ? 0 : jpos), A.p_drop) ? sc[qt][j][r] * ksc : 0.0f;
+                for (int r = 0; r < 4; ++r) sc[qt][j][r] = ((m4 >> r) & 1u) ? sc[qt][j][r] * ksc : 0.0f;
+              } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                  const int jpos = jpos0 + r;
+                  sc[qt][j][r] = dropout_keep(A.seed_attn, mrow + (unsigned long long)(jpos < 0 ? 0 : jpos), A.p_drop) ? sc[qt][j][r] * ksc : 0.0f;
+                }
               }
+            }
           });
         }
       }

@@ -148,21 +148,33 @@ __device__ __forceinline__ float act_df(float x, int act) {
 }
 
 // ---- counter-based dropout mask: keep(seed, idx) is a pure function, so backward regenerates the forward's mask -------
-// One splitmix64 finaliser serves TWO consecutive elements (idx >> 1 is hashed; the even element takes bits 8..31 of the result, the odd
-// one bits 40..63): the kernels work on runs of 2 or 4 consecutive elements, so they hash half as often.  24 uniform bits per decision.
-__device__ __forceinline__ unsigned long long dropout_hash(unsigned long long seed, unsigned long long pair) {
-  unsigned long long z = seed + pair * 0x9E3779B97F4A7C15ull;
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  return z ^ (z >> 31);
+// One 32-bit hash serves TWO consecutive elements (idx >> 1 is hashed; the even element takes the low 16 bits, the odd one the high
+// 16): the kernels work on runs of 2 or 4 consecutive elements and hash half / a quarter as often as they decide.  The hash is a Weyl
+// step of the pair index, keyed by both words of the seed, through murmur3's 32-bit finaliser: ~11 VALU instructions per pair.  (Round 1
+// used a splitmix64 finaliser per pair, three 64-bit multiplies = ~40 instructions; with one call per element of the attention
+// probabilities that was 10 - 14 us of the L = 48 attention forward / backward launches.)  16 uniform bits per decision: the keep
+// probability is 1 - floor(65536 p) / 65536.
+__device__ __forceinline__ unsigned dropout_mix32(unsigned h) {
+  h ^= h >> 16; h *= 0x85EBCA6Bu;
+  h ^= h >> 13; h *= 0xC2B2AE35u;
+  return h ^ (h >> 16);
 }
+__device__ __forceinline__ unsigned dropout_hash(unsigned long long seed, unsigned long long pair) {
+  unsigned a = (unsigned)pair * 0x9E3779B1u + (unsigned)seed;
+  a ^= ((unsigned)(pair >> 32) + (unsigned)(seed >> 32)) * 0x7FEB352Du;     // the seed's high word always takes part
+  return dropout_mix32(a);
+}
+__device__ __forceinline__ unsigned dropout_threshold(float p) { return (unsigned)(p * 65536.0f); }
 __device__ __forceinline__ bool dropout_keep(unsigned long long seed, unsigned long long idx, float p) {
-  const unsigned long long z = dropout_hash(seed, idx >> 1);
-  const unsigned bits = (idx & 1) ? (unsigned)(z >> 40) : ((unsigned)z >> 8);
-  return (float)bits * (1.0f / 16777216.0f) >= p;
+  const unsigned h = dropout_hash(seed, idx >> 1);
+  return ((idx & 1) ? (h >> 16) : (h & 0xffffu)) >= dropout_threshold(p);
 }
 // the two decisions of the pair that starts at the EVEN index idx0 (bit 0: idx0, bit 1: idx0 + 1)
 __device__ __forceinline__ unsigned dropout_keep2(unsigned long long seed, unsigned long long idx0, float p) {
-  const unsigned long long z = dropout_hash(seed, idx0 >> 1);
-  return ((float)((unsigned)z >> 8) * (1.0f / 16777216.0f) >= p ? 1u : 0u) | ((float)(unsigned)(z >> 40) * (1.0f / 16777216.0f) >= p ? 2u : 0u);
+  const unsigned h = dropout_hash(seed, idx0 >> 1), thr = dropout_threshold(p);
+  return ((h & 0xffffu) >= thr ? 1u : 0u) | ((h >> 16) >= thr ? 2u : 0u);
+}
+// the four decisions of the run that starts at idx0, a multiple of 4 (bits 0..3)
+__device__ __forceinline__ unsigned dropout_keep4(unsigned long long seed, unsigned long long idx0, float p) {
+  return dropout_keep2(seed, idx0, p) | (dropout_keep2(seed, idx0 + 2, p) << 2);
 }
