@@ -53,12 +53,22 @@ def _folded(lin_w, lin_b, ln):
 
 FUSED_TRAIN_FORWARD = __import__("os").environ.get("TANTE_TRAIN_FUSED", "1") != "0"
 FUSED_TAIL_BACKWARD = __import__("os").environ.get("TANTE_TRAIN_FUSED_BWD", "1") != "0"
+BLOCK_RECORDS = __import__("os").environ.get("TANTE_TRAIN_BLOCK_RECORDS", "1") != "0"   # per-scope prepared record of a block (host time)
 FUSED_AXIS_HW = __import__("os").environ.get("TANTE_TRAIN_FUSED_AXIS", "1") != "0"     # H + W propagators' training forward in one launch
 FUSED_HEAD_BACKWARD = __import__("os").environ.get("TANTE_TRAIN_FUSED_HEAD_BWD", "1") != "0"   # q|k|v dgrad + LayerNorm1 backward in one launch
 
 
 def block_train(blk, x: torch.Tensor, seq, causal: bool, compute: int) -> torch.Tensor:
     p = blk.p_drop if blk.training else 0.0     # nn.Dropout / MHA dropout are active in train() mode only
+    # Every later call of this block inside one rollout graph (the BPTT steps) takes the record its first call left in the fold scope:
+    # folded weights, the three fragment streams, the decision for the one-node path: the module attribute chains, fold / stream look-ups
+    # and accumulator checks below are ~60 us of host time per block call (the step is GPU-bound on the bench box, with ~2 ms of margin).
+    rec = _FOLDS.get(("blk_rec", id(blk), seq.L, compute)) if (_FOLDS is not None and BLOCK_RECORDS and torch.is_grad_enabled()) else None
+    if rec is not None and x.dtype == torch.float32 and x.is_contiguous():
+        from .autograd import next_seed
+        seeds = (next_seed(), next_seed(), next_seed()) if p > 0.0 else (0, 0, 0)
+        t = K.block_fused_train(x.detach(), rec[8], blk.embed_dim, blk.n_head, blk.hidden, seq, causal, rec[11], p, seeds, need_x1=False)
+        return BlockFn.apply(x, *rec[:8], t, rec[9], seq, blk.n_head, causal, p, seeds, compute, rec[10])
     adt = K.act_torch_dtype(compute)
     a, m = blk.attn, blk.mlp
     w_in, b_in = _folded(a.in_proj_weight, a.in_proj_bias, blk.ln1)
@@ -98,6 +108,9 @@ def block_train(blk, x: torch.Tensor, seq, causal: bool, compute: int) -> torch.
                         hstream = K.pack_block_tail_bwd(wd[0:E], wd[E:2 * E], wd[2 * E:3 * E], E, blk.hidden)
                         if _FOLDS is not None:
                             _FOLDS[key] = hstream
+                if _FOLDS is not None:
+                    _FOLDS[("blk_rec", id(blk), seq.L, compute)] = (w_in, b_in, a.out_proj.weight, a.out_proj.bias, w1, b1, m[2].weight, m[2].bias,
+                                                                    stream, bstream, hstream, blk.ln1.eps)
                 return BlockFn.apply(x, w_in, b_in, a.out_proj.weight, a.out_proj.bias, w1, b1, m[2].weight, m[2].bias, t, bstream, seq,
                                      blk.n_head, causal, p, seeds, compute, hstream)
             xh, xs = LayerNormSkipFn.apply(x, blk.ln1.eps, adt, (t["xh1"], t["st1"]))
