@@ -148,6 +148,10 @@ int tante_axis_mlp(float* x, int64_t outer, int n, int64_t inner, const float* w
  * positions with inner % 4 == 0 (the temporal propagator) take a float4-vectorised kernel. */
 int tante_axis_mlp_c(float* x, int64_t outer, int n, int64_t inner, const float* w1, const float* b1, const float* w2,
                      const float* b2, int compute, void* stream);
+/* The same out of place (dst = src + MLP(src) along the axis; src stays intact for the backward pass) for short axes: n <= 8 and
+ * inner % 4 == 0 (the temporal propagator); -2 otherwise. */
+int tante_axis_mlp_oop(const float* src, float* dst, int64_t outer, int n, int64_t inner, const float* w1, const float* b1, const float* w2,
+                       const float* b2, int compute, void* stream);
 
 /* Vertical then horizontal propagator in ONE pass over x (BT, nH, nW, C) fp32, in place (attn_backbone.py:140-143):
  * x += MLP_H(x) along h; x += MLP_W(x) along w.  The n x n contractions run on MFMA in the compute dtype

@@ -57,6 +57,7 @@ SIGNATURES = {
     "tante_attention": ([c_vp, c_vp, c_i32, c_i32, c_i32, C.POINTER(Seq), c_i32, c_vp], c_i32),
     "tante_axis_mlp": ([c_vp, c_i64, c_i32, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp], c_i32),
     "tante_axis_mlp_c": ([c_vp, c_i64, c_i32, c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp], c_i32),
+    "tante_axis_mlp_oop": ([c_vp, c_vp, c_i64, c_i32, c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp], c_i32),
     "tante_axis_hw": ([c_vp, c_i64, c_i32, c_i32, c_i32] + [c_vp] * 8 + [c_i32, c_vp], c_i32),
     "tante_axis_hw_film": ([c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_i32, c_i32] + [c_vp] * 8 + [c_i32, c_vp], c_i32),
     "tante_axis_hw_train": ([c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp], c_i32),

@@ -68,7 +68,8 @@ __global__ __launch_bounds__(256) void axis_mlp_kernel(float* __restrict__ x, lo
 template <int N, bool FAST>
 __global__ __launch_bounds__(256) void axis_mlp_vec_kernel(float* __restrict__ x, long outer, int n, long inner4,
                                                            const float* __restrict__ w1, const float* __restrict__ b1,
-                                                           const float* __restrict__ w2, const float* __restrict__ b2) {
+                                                           const float* __restrict__ w2, const float* __restrict__ b2,
+                                                           const float* __restrict__ src = nullptr) {   // src: out of place (x = result only)
   __shared__ float w1s[N * N], w2s[N * N], b1s[N], b2s[N];
   for (int idx = threadIdx.x; idx < N * N; idx += 256) {
     const int j = idx / N, a = idx % N;
@@ -85,9 +86,10 @@ __global__ __launch_bounds__(256) void axis_mlp_vec_kernel(float* __restrict__ x
   if (col >= outer * inner4) return;
   const long o = col / inner4, i = col - o * inner4;
   f32x4* p = (f32x4*)x + o * (long)n * inner4 + i;
+  const f32x4* q = src ? (const f32x4*)src + o * (long)n * inner4 + i : p;
   f32x4 v[N], h[N];
 #pragma unroll
-  for (int a = 0; a < N; ++a) v[a] = (a < n) ? p[(long)a * inner4] : f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int a = 0; a < N; ++a) v[a] = (a < n) ? q[(long)a * inner4] : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int j = 0; j < N; ++j) {
     f32x4 s = splat4(b1s[j]);
@@ -779,6 +781,23 @@ extern "C" int tante_axis_mlp_c(float* x, int64_t outer, int n, int64_t inner, c
     return 0;
   }
   return tante_axis_mlp(x, outer, n, inner, w1, b1, w2, b2, stream);
+}
+
+extern "C" int tante_axis_mlp_oop(const float* src, float* dst, int64_t outer, int n, int64_t inner, const float* w1, const float* b1,
+                                  const float* w2, const float* b2, int compute, void* stream) {
+  if (!src || !dst || !w1 || !b1 || !w2 || !b2) TANTE_FAIL(-1, "tante_axis_mlp_oop: null pointer");
+  if (outer <= 0 || n <= 0 || inner <= 0) TANTE_FAIL(-1, "tante_axis_mlp_oop: bad shape");
+  if (n > 8 || inner % 4 || ((uintptr_t)src % 16) || ((uintptr_t)dst % 16))
+    TANTE_FAIL(-2, "tante_axis_mlp_oop: short axes (n <= 8) with 16-byte columns only (copy, then tante_axis_mlp_c)");
+  hipStream_t s = (hipStream_t)stream;
+  const long cols = outer * (inner / 4);
+  const dim3 grid((unsigned)((cols + 255) / 256));
+#define TANTE_AVO(NN, FF) hipLaunchKernelGGL((axis_mlp_vec_kernel<NN, FF>), grid, dim3(256), 0, s, dst, (long)outer, n, (long)(inner / 4), w1, b1, w2, b2, src)
+  if (n <= 4) { if (compute == TANTE_BF16) TANTE_AVO(4, true); else TANTE_AVO(4, false); }
+  else { if (compute == TANTE_BF16) TANTE_AVO(8, true); else TANTE_AVO(8, false); }
+#undef TANTE_AVO
+  TANTE_CHECK_LAUNCH();
+  return 0;
 }
 
 extern "C" int tante_axis_mlp(float* x, int64_t outer, int n, int64_t inner, const float* w1, const float* b1,
