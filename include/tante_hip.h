@@ -446,6 +446,10 @@ int tante_axis_mlp_bwd(const float* x, const float* dy, int64_t outer, int n, in
 int tante_fold_fwd(const float* W, const float* b, const float* gamma, const float* beta, int N, int K, float* We, float* be, void* stream);
 int tante_fold_bwd(const float* GW, const float* Gb, const float* W, const float* gamma, const float* beta, int N, int K, float* dW, float* db,
                    float* dgamma, float* dbeta, void* stream);
+/* The same, and GW / Gb are ZEROED as they are read (K <= 256): the accumulators of a folded pair can then live across train steps without a
+ * fill per weight and step. */
+int tante_fold_bwd_clear(float* GW, float* Gb, const float* W, const float* gamma, const float* beta, int N, int K, float* dW, float* db,
+                         float* dgamma, float* dbeta, void* stream);
 int tante_axis_wgrad(const float* U, const float* V, int64_t outer, int n, int64_t inner, float* dW, float* db, int accumulate, void* stream);
 /* The same with a caller-owned workspace of tante_axis_wgrad_workspace_bytes() bytes (16-byte aligned; its LAST 256 bytes -- the arrival
  * counters -- zero on first use): every workgroup stores its partial there and the last of each group of 16 to finish adds the group's sum

@@ -125,6 +125,7 @@ SIGNATURES = {
     "tante_axis_mlp_bwd": ([c_vp, c_vp, c_i64, c_i32, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp], c_i32),
     "tante_fold_fwd": ([c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp], c_i32),
     "tante_fold_bwd": ([c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp], c_i32),
+    "tante_fold_bwd_clear": ([c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp], c_i32),
     "tante_axis_wgrad": ([c_vp, c_vp, c_i64, c_i32, c_i64, c_vp, c_vp, c_i32, c_vp], c_i32),
     "tante_axis_wgrad_workspace_bytes": ([], c_i64),
     "tante_axis_wgrad_ws": ([c_vp, c_vp, c_i64, c_i32, c_i64, c_vp, c_vp, c_i32, c_vp, c_i64, c_vp], c_i32),

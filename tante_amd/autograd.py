@@ -161,7 +161,10 @@ def _graph_task() -> int:
     return torch._C._current_graph_task_id()
 
 
-def reset_backward_state():
+_FOLD_DIRTY = {}     # id -> accumulator buffer of a FoldFn whose backward has not consumed (and thereby zeroed) it yet
+
+
+def reset_backward_state(after: bool = False):
     """Forget everything recorded for a backward pass that is not running any more.  'armed' means "the engine's end-of-backward
     callback of THIS backward pass is queued"; a backward pass that raises (OOM, a kernel error, KeyboardInterrupt) drops its
     callbacks, so the flag is keyed to the graph task and additionally cleared here: train_step* call this before and -- in a
@@ -174,6 +177,12 @@ def reset_backward_state():
     _SIDE["task"] = -1
     if _SIDE["stream"] is not None:
         torch.cuda.current_stream().wait_stream(_SIDE["stream"])
+    if after and _FOLD_DIRTY:
+        # fold accumulators live across steps and are zeroed by the fold's own backward kernel; whatever a dead (or partial) backward
+        # pass left non-empty is cleared here, so the next step starts from zeros in every case
+        for buf in list(_FOLD_DIRTY.values()):
+            buf.zero_()
+        _FOLD_DIRTY.clear()
 
 
 def run_backward(loss: torch.Tensor):
@@ -182,7 +191,7 @@ def run_backward(loss: torch.Tensor):
     try:
         loss.backward()
     finally:
-        reset_backward_state()
+        reset_backward_state(after=True)
 
 
 _WG_WS = {}      # device index -> 64 MiB scratch of the shared weight-gradient launches (split-R partial tiles, summed by a second kernel)
@@ -303,7 +312,13 @@ class FoldFn(Function):
         be = torch.empty(N, dtype=torch.float32, device=W.device)
         L.check(L.lib().tante_fold_fwd(W.data_ptr(), None if b is None else b.data_ptr(), gamma.data_ptr(), beta.data_ptr(), N, Kk,
                                        We.data_ptr(), be.data_ptr(), _s()), "tante_fold_fwd")
-        acc = torch.zeros(N * Kk + N, dtype=torch.float32, device=W.device)      # one fill for both accumulators
+        # both accumulators in one buffer that lives ON the weight across steps: the fold's backward kernel zeroes it while reading
+        # (tante_fold_bwd_clear), so the steady state has no fill per weight and step (there were two: here and after the backward)
+        acc = getattr(W, "_tante_fold_acc", None)
+        if acc is None or acc.numel() != N * Kk + N or acc.device != W.device:
+            acc = torch.zeros(N * Kk + N, dtype=torch.float32, device=W.device)
+            W._tante_fold_acc = acc
+        _FOLD_DIRTY[id(acc)] = acc
         gW, gb = acc[:N * Kk].view(N, Kk), acc[N * Kk:]
         ctx.save_for_backward(W, gamma, beta)
         ctx.acc = (gW, gb)
@@ -334,9 +349,13 @@ class FoldFn(Function):
             dW, dg, dbt = torch.zeros_like(W), torch.zeros_like(gamma), torch.zeros_like(beta)
             db = torch.zeros(N, dtype=torch.float32, device=W.device) if has_b else None
         GW, Gb = GW.contiguous(), Gb.contiguous()
-        L.check(L.lib().tante_fold_bwd(GW.data_ptr(), Gb.data_ptr(), W.data_ptr(), gamma.data_ptr(), beta.data_ptr(), N, Kk, dW.data_ptr(),
-                                       None if db is None else db.data_ptr(), dg.data_ptr(), dbt.data_ptr(), _s()), "tante_fold_bwd")
-        ctx.acc_buf.zero_()       # consumed: a second backward through a retained graph starts from empty accumulators
+        own = GW.data_ptr() == ctx.acc[0].data_ptr() and Gb.data_ptr() == ctx.acc[1].data_ptr() and Kk <= 256
+        fn = L.lib().tante_fold_bwd_clear if own else L.lib().tante_fold_bwd
+        L.check(fn(GW.data_ptr(), Gb.data_ptr(), W.data_ptr(), gamma.data_ptr(), beta.data_ptr(), N, Kk, dW.data_ptr(),
+                   None if db is None else db.data_ptr(), dg.data_ptr(), dbt.data_ptr(), _s()), "tante_fold_bwd")
+        if not own:
+            ctx.acc_buf.zero_()   # consumed: a second backward through a retained graph starts from empty accumulators
+        _FOLD_DIRTY.pop(id(ctx.acc_buf), None)      # the kernel (or the fill above) left it zeroed
         return (None, None, None, None) if direct else (dW, db, dg, dbt)
 
 

@@ -896,32 +896,35 @@ __global__ __launch_bounds__(256) void fold_fwd_kernel(const float* __restrict__
 }
 // bwd, from the accumulated gradients GW (N, K), Gb (N) of the folded pair:
 //   dW += GW diag(gamma) + Gb beta^T,  db += Gb,  dgamma[k] += sum_n GW[n][k] W[n][k],  dbeta[k] += sum_n W[n][k] Gb[n]
-// blocks [0, nbe): elementwise part (and db by the k = 0 pieces); blocks after: 32-row slabs of the two column reductions (atomics)
-__global__ __launch_bounds__(256) void fold_bwd_kernel(const float* __restrict__ GW, const float* __restrict__ Gb, const float* __restrict__ W,
+// One pass: block (slab of FB_ROWS rows, 256-column chunk), thread = column: the elementwise update and the slab's share of the two
+// column reductions (atomics) from the same loads.  CLEAR: the accumulators are zeroed as they are read, so the caller can keep them
+// across steps without a fill per weight and step (GW by its only reader; Gb only when there is a single column chunk, K <= 256).
+constexpr int FB_ROWS = 16;
+__global__ __launch_bounds__(256) void fold_bwd_kernel(float* __restrict__ GW, float* __restrict__ Gb, const float* __restrict__ W,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta, int N, int K,
                                                        float* __restrict__ dW, float* __restrict__ db, float* __restrict__ dgamma,
-                                                       float* __restrict__ dbeta, int nbe) {
-  if ((int)blockIdx.x < nbe) {
-    const long i4 = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i4 * 4 >= (long)N * K) return;
-    const long n = (i4 * 4) / K;
-    const int k = (int)(i4 * 4 - n * K);
-    const f32x4 gw = *(const f32x4*)(GW + i4 * 4), g = *(const f32x4*)(gamma + k), bt = *(const f32x4*)(beta + k);
-    const float gb = Gb[n];
-    f32x4* d = (f32x4*)(dW + i4 * 4);
-    *d = *d + gw * g + bt * gb;
-    if (k == 0 && db) db[n] += gb;
-    return;
+                                                       float* __restrict__ dbeta, int clear) {
+  const int kb = (K + 255) / 256;
+  const int slab = (int)blockIdx.x / kb, kc = (int)blockIdx.x % kb, k = kc * 256 + threadIdx.x;
+  const int n0 = slab * FB_ROWS, n1 = min(N, n0 + FB_ROWS);
+  __shared__ float gbs[FB_ROWS];
+  if (threadIdx.x < n1 - n0) gbs[threadIdx.x] = Gb[n0 + threadIdx.x];
+  __syncthreads();
+  if (kc == 0 && threadIdx.x < n1 - n0) {
+    if (db) db[n0 + threadIdx.x] += gbs[threadIdx.x];
+    if (clear && kb == 1) Gb[n0 + threadIdx.x] = 0.0f;
   }
-  const int kb = K / 256 > 0 ? (K + 255) / 256 : 1;
-  const int slab = ((int)blockIdx.x - nbe) / kb, k = (((int)blockIdx.x - nbe) % kb) * 256 + threadIdx.x;
   if (k >= K) return;
-  const int n0 = slab * 32, n1 = min(N, n0 + 32);
+  const float g = gamma[k], bt = beta[k];
   float sg = 0.f, sb = 0.f;
+#pragma unroll 4
   for (int n = n0; n < n1; ++n) {
-    const float w = W[(long)n * K + k];
-    sg += GW[(long)n * K + k] * w;
-    sb += w * Gb[n];
+    const long i = (long)n * K + k;
+    const float gw = GW[i], w = W[i], gb = gbs[n - n0];
+    dW[i] += gw * g + bt * gb;
+    sg += gw * w;
+    sb += w * gb;
+    if (clear) GW[i] = 0.0f;
   }
   atomicAdd(&dgamma[k], sg);
   atomicAdd(&dbeta[k], sb);
@@ -1127,16 +1130,24 @@ extern "C" int tante_fold_fwd(const float* W, const float* b, const float* gamma
   TANTE_CHECK_LAUNCH();
   return 0;
 }
-extern "C" int tante_fold_bwd(const float* GW, const float* Gb, const float* W, const float* gamma, const float* beta, int N, int K, float* dW,
-                              float* db, float* dgamma, float* dbeta, void* stream) {
+static int fold_bwd_impl(float* GW, float* Gb, const float* W, const float* gamma, const float* beta, int N, int K, float* dW, float* db,
+                         float* dgamma, float* dbeta, int clear, void* stream) {
   if (!GW || !Gb || !W || !gamma || !beta || !dW || !dgamma || !dbeta || N <= 0 || K <= 0 || K % 4)
     TANTE_FAIL(-1, "tante_fold_bwd: bad argument (K must be a multiple of 4)");
-  const int nbe = (int)(((long)N * K / 4 + 255) / 256);
   const int kb = (K + 255) / 256;
-  hipLaunchKernelGGL(fold_bwd_kernel, dim3(nbe + ((N + 31) / 32) * kb), dim3(256), 0, (hipStream_t)stream, GW, Gb, W, gamma, beta, N, K, dW, db,
-                     dgamma, dbeta, nbe);
+  hipLaunchKernelGGL(fold_bwd_kernel, dim3(((N + FB_ROWS - 1) / FB_ROWS) * kb), dim3(256), 0, (hipStream_t)stream, GW, Gb, W, gamma, beta, N, K, dW,
+                     db, dgamma, dbeta, clear);
   TANTE_CHECK_LAUNCH();
   return 0;
+}
+extern "C" int tante_fold_bwd(const float* GW, const float* Gb, const float* W, const float* gamma, const float* beta, int N, int K, float* dW,
+                              float* db, float* dgamma, float* dbeta, void* stream) {
+  return fold_bwd_impl((float*)GW, (float*)Gb, W, gamma, beta, N, K, dW, db, dgamma, dbeta, 0, stream);
+}
+extern "C" int tante_fold_bwd_clear(float* GW, float* Gb, const float* W, const float* gamma, const float* beta, int N, int K, float* dW, float* db,
+                                    float* dgamma, float* dbeta, void* stream) {
+  if (K > 256) TANTE_FAIL(-2, "tante_fold_bwd_clear: K <= 256 (one column chunk reads the bias accumulator)");
+  return fold_bwd_impl(GW, Gb, W, gamma, beta, N, K, dW, db, dgamma, dbeta, 1, stream);
 }
 extern "C" int tante_colsum(const void* x, int dtype, int64_t outer, int C, int64_t inner, float* out, int accumulate, void* stream) {
   if (!x || !out || outer <= 0 || C <= 0 || inner <= 0) TANTE_FAIL(-1, "tante_colsum: bad argument");
