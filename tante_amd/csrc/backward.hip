@@ -518,7 +518,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const unsigned short
   // LDS rows are 96 bytes apart (64 of data): with 64-byte rows the transposing reads of the four 16-lane groups hit the same banks
   // (rows r and r + 4 are 256 bytes apart): PMC showed half of this kernel's LDS cycles as bank conflicts
   constexpr int RS = 48;   // row stride in bf16 elements
-  constexpr int WAVE_LDS = 3 * ROWS * RS * 2 + 3 * ROWS * 4;
+  constexpr int WAVE_LDS = 3 * ROWS * RS * 2 + 16 * RS * 2 + 3 * ROWS * 4;   // Q, K, dO images, one 16-row staging tile, the row statistics
   extern __shared__ __attribute__((aligned(16))) char sm_raw[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kk = lane >> 4, l15 = lane & 15, qq = l15 >> 2, pp = l15 & 3;
   const int h = blockIdx.y * 4 + wave;
@@ -527,7 +527,8 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const unsigned short
   unsigned short* Qs = (unsigned short*)base;
   unsigned short* Ks = Qs + ROWS * RS;
   unsigned short* Gs = Ks + ROWS * RS;
-  float* St = (float*)(Gs + ROWS * RS);          // m [ROWS], 1/l [ROWS], delta [ROWS]
+  unsigned short* Os = Gs + ROWS * RS;           // 16-row staging tile: V on the way in (it needs no image), the results on the way out
+  float* St = (float*)(Os + 16 * RS);            // m [ROWS], 1/l [ROWS], delta [ROWS]
   const int L = sq.L, unit = blockIdx.x;
   const bool big = L >= 16;
   const unsigned rcpL = (65536u + L - 1) / L;    // floor(slot / L) for slot < 16
@@ -547,20 +548,37 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const unsigned short
     const int seq = big ? unit : unit * SPT + csl[t];
     ctok[t] = clive[t] ? (long)(seq / sq.n_s0) * sq.S1 + (long)(seq % sq.n_s0) * sq.S0 + (long)(cpos[t] / sq.n_l0) * sq.P1 +
                              (long)(cpos[t] % sq.n_l0) * sq.P0 : 0;
-    qf[t] = kf[t] = vf[t] = gf[t] = u32x4{0u, 0u, 0u, 0u};
-    if (clive[t]) {
-      const unsigned short* r = qkv + ctok[t] * 3L * C + h * 32 + kk * 8;
-      qf[t] = *(const u32x4*)r;
-      kf[t] = *(const u32x4*)(r + C);
-      vf[t] = *(const u32x4*)(r + 2 * C);
-      gf[t] = *(const u32x4*)(dO + ctok[t] * (long)C + h * 32 + kk * 8);
+  }
+  // Memory is touched in ROW form: lanes 4 r .. 4 r + 3 = the 64 bytes of (token row r, this head) -- in operand layout (lane & 15 = row)
+  // neighbouring lanes are different rows and the memory pipe works the instruction off lane by lane (tools/ubench/ta_cost.hip: 63
+  // clocks against 17); with 4 loads + 6 eight-byte stores per 16 tokens that pipe, not HBM, set this kernel's time.  The rows go
+  // through the LDS images (which the transposing reads need anyway) and come back as operand fragments.
+  const int lr = lane >> 2, lc = lane & 3;
+  long rtok[NT];
+  bool rlive[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    rtok[t] = ((long)__shfl((int)(ctok[t] >> 32), lr) << 32) | (unsigned)__shfl((int)ctok[t], lr);
+    rlive[t] = __shfl((int)clive[t], lr) != 0;
+    u32x4 q4 = u32x4{0u, 0u, 0u, 0u}, k4 = q4, v4 = q4, g4 = q4;
+    if (rlive[t]) {
+      const unsigned short* r = qkv + rtok[t] * 3L * C + h * 32 + lc * 8;
+      q4 = *(const u32x4*)r;
+      k4 = *(const u32x4*)(r + C);
+      v4 = *(const u32x4*)(r + 2 * C);
+      g4 = *(const u32x4*)(dO + rtok[t] * (long)C + h * 32 + lc * 8);
     }
+    *(u32x4*)(Qs + (t * 16 + lr) * RS + lc * 8) = q4;     // row-major images (64 data bytes per 96-byte row)
+    *(u32x4*)(Ks + (t * 16 + lr) * RS + lc * 8) = k4;
+    *(u32x4*)(Gs + (t * 16 + lr) * RS + lc * 8) = g4;
+    *(u32x4*)(Os + lr * RS + lc * 8) = v4;
+    vf[t] = *(const u32x4*)(Os + l15 * RS + kk * 8);
   }
 #pragma unroll
-  for (int t = 0; t < NT; ++t) {   // row-major images (64-byte rows) for the transposing reads
-    *(u32x4*)(Qs + (t * 16 + l15) * RS + kk * 8) = qf[t];
-    *(u32x4*)(Ks + (t * 16 + l15) * RS + kk * 8) = kf[t];
-    *(u32x4*)(Gs + (t * 16 + l15) * RS + kk * 8) = gf[t];
+  for (int t = 0; t < NT; ++t) {   // operand fragments: row l15, dims 8 kk .. 8 kk + 7
+    qf[t] = *(const u32x4*)(Qs + (t * 16 + l15) * RS + kk * 8);
+    kf[t] = *(const u32x4*)(Ks + (t * 16 + l15) * RS + kk * 8);
+    gf[t] = *(const u32x4*)(Gs + (t * 16 + l15) * RS + kk * 8);
   }
   // transposed fragment of X (row tile rt, 16-dim tile dt): lane 4 qq + pp of a 16-lane group supplies row 4 kk + qq, columns 4 pp .. 4 pp + 3
   const unsigned troff = (4 * kk + qq) * (RS * 2) + pp * 8;
@@ -573,12 +591,15 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const unsigned short
   const float c2 = scale * 1.4426950408889634f;
   const float ksc = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
   const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
-  auto store4 = [&](int mat, int t, int dt, const f32x4& v) {
-    if (!clive[t]) return;
-    u32x2 u;
-    u[0] = pack_bf16x2(v[0], v[1]);
-    u[1] = pack_bf16x2(v[2], v[3]);
-    *(u32x2*)(dqkv + ctok[t] * 3L * C + (long)mat * C + h * 32 + dt * 16 + 4 * kk) = u;
+  // one 16-token x 32-dim result tile: accumulator layout (token l15, dims 16 dt + 4 kk ..) -> the staging tile -> row form -> memory
+  auto store_tile = [&](int mat, int t, const f32x4& v0, const f32x4& v1) {
+    u32x2 u0, u1;
+    u0[0] = pack_bf16x2(v0[0], v0[1]); u0[1] = pack_bf16x2(v0[2], v0[3]);
+    u1[0] = pack_bf16x2(v1[0], v1[1]); u1[1] = pack_bf16x2(v1[2], v1[3]);
+    *(u32x2*)(Os + l15 * RS + 4 * kk) = u0;
+    *(u32x2*)(Os + l15 * RS + 16 + 4 * kk) = u1;
+    const u32x4 row = *(const u32x4*)(Os + lr * RS + lc * 8);
+    if (rlive[t]) *(u32x4*)(dqkv + rtok[t] * 3L * C + (long)mat * C + h * 32 + lc * 8) = row;
   };
 
   // ---- pass 1: queries in the columns ------------------------------------------------------------------------------------------
@@ -667,8 +688,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const unsigned short
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt) dq[dt] = mfma_bf16(tfrag(Ks, j0, j1, dt), pf, dq[dt]);
     }
-    store4(0, it, 0, dq[0]);
-    store4(0, it, 1, dq[1]);
+    store_tile(0, it, dq[0], dq[1]);
   }
 
   // ---- pass 2: keys in the columns ---------------------------------------------------------------------------------------------
@@ -715,17 +735,17 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const unsigned short
         dv[dt] = mfma_bf16(tfrag(Gs, i0, i1, dt), pfp, dv[dt]);
       }
     }
-    store4(1, jt, 0, dk[0]);
-    store4(1, jt, 1, dk[1]);
-    store4(2, jt, 0, dv[0]);
-    store4(2, jt, 1, dv[1]);
+    store_tile(1, jt, dk[0], dk[1]);
+    store_tile(2, jt, dv[0], dv[1]);
   }
 }
 
 template <int NT>
 void launch_attn_bwd_mfma(const void* qkv, const void* dO, void* dqkv, int C, int n_head, const TanteSeq& sq, int SPT, int units, int causal,
                           float p_drop, unsigned long long seed, hipStream_t s) {
-  const size_t lds = 4 * (size_t)(3 * NT * 16 * 96 + 3 * NT * 16 * 4);
+  const size_t lds = 4 * (size_t)(3 * NT * 16 * 96 + 16 * 96 + 3 * NT * 16 * 4);      // = 4 waves x WAVE_LDS
+  static TantePerDevice attr;
+  attr.once([&] { (void)hipFuncSetAttribute((const void*)attn_bwd_mfma_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
   hipLaunchKernelGGL((attn_bwd_mfma_kernel<NT>), dim3(units, (n_head + 3) / 4), dim3(256), lds, s, (const unsigned short*)qkv,
                      (const unsigned short*)dO, (unsigned short*)dqkv, C, n_head, sq, SPT, causal, 1.0f / sqrtf(32.0f), p_drop, seed);
 }
