@@ -209,6 +209,26 @@ __global__ __launch_bounds__(256) void colsum_kernel(const void* __restrict__ x,
   }
 }
 
+// dense bf16 rows (inner == 1, C a multiple of 8 with 256 % (C / 8) == 0): 16 bytes = 8 channels per lane and row instead of one 2-byte
+// element (the scalar kernel above read the deconvolution stages' bias gradients at 2.2 TB/s)
+__global__ __launch_bounds__(256) void colsum_bf16_vec_kernel(const unsigned short* __restrict__ x, long outer, int C, long chunk, float* __restrict__ out) {
+  __shared__ float acc[2048];
+  const int gpr = C >> 3, rpp = 256 / gpr, cg = threadIdx.x % gpr, rsub = threadIdx.x / gpr;
+  for (int i = threadIdx.x; i < C; i += 256) acc[i] = 0.f;
+  __syncthreads();
+  const long o0 = (long)blockIdx.x * chunk, o1 = min(outer, o0 + chunk);
+  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (long o = o0 + rsub; o < o1; o += rpp) {
+    const u32x4 v = *(const u32x4*)(x + o * C + 8 * cg);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { s[2 * q] += bf16_lo(v[q]); s[2 * q + 1] += bf16_hi(v[q]); }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) atomicAdd(&acc[8 * cg + e], s[e]);
+  __syncthreads();
+  for (int i = threadIdx.x; i < C; i += 256) atomicAdd(&out[i], acc[i]);
+}
+
 // ---- FiLM + positional epilogue as a stand-alone op (train path): y = v * a[t] + b[t] + s[hw], rows r = (b, t, hw) --
 __global__ void film_pos_fwd_kernel(const float* __restrict__ v, const float* __restrict__ a, const float* __restrict__ b,
                                     const float* __restrict__ s, long rows, int C4, int T, long HW, float* __restrict__ y) {
@@ -1173,7 +1193,13 @@ extern "C" int tante_colsum(const void* x, int dtype, int64_t outer, int C, int6
   if (!x || !out || outer <= 0 || C <= 0 || inner <= 0) TANTE_FAIL(-1, "tante_colsum: bad argument");
   hipStream_t s = (hipStream_t)stream;
   if (!accumulate && hipMemsetAsync(out, 0, (size_t)C * sizeof(float), s) != hipSuccess) TANTE_FAIL(-3, "tante_colsum: memset failed");
-  if (inner == 1) {
+  if (inner == 1 && dtype == TANTE_BF16 && C % 8 == 0 && C <= 2048 && 256 % (C / 8) == 0 && ((uintptr_t)x % 16) == 0) {
+    long chunks = 1024;                                      // four workgroups per CU, at least 256 rows each
+    if (chunks > (outer + 255) / 256) chunks = (outer + 255) / 256;
+    const long chunk = (outer + chunks - 1) / chunks;
+    hipLaunchKernelGGL(colsum_bf16_vec_kernel, dim3((unsigned)((outer + chunk - 1) / chunk)), dim3(256), 0, s, (const unsigned short*)x, (long)outer, C,
+                       chunk, out);
+  } else if (inner == 1) {
     // enough workgroups to fill the chip: (row chunks) x (64-channel groups) ~ 2048, at least 64 rows per chunk
     const long groups = (C + 63) / 64;
     long chunks = 2048 / groups;

@@ -481,3 +481,19 @@ def test_axis_wgrad_against_float64(dev, outer, n, inner, use_ws):
         assert eW < 2e-5 and eb < 2e-5, (eW, eb)
     if use_ws:
         assert int(ws[-(1024 // 16):].view(torch.int32).abs().max()) == 0       # arrival counters
+
+
+@pytest.mark.parametrize("outer,Cc,dtype", [(393216, 64, torch.bfloat16), (98304, 128, torch.bfloat16), (1000, 256, torch.bfloat16), (777, 24, torch.bfloat16),
+                                             (5000, 64, torch.float32)])
+def test_colsum_dense_rows(dev, outer, Cc, dtype):
+    """tante_colsum over dense rows (bias gradients): the 16-byte-per-lane bf16 form and the scalar form, overwrite and accumulate."""
+    from tante_amd import autograd as A
+    g = torch.Generator().manual_seed(outer + Cc)
+    x = torch.randn(outer, Cc, generator=g).to(dtype).to(dev)
+    ref = x.double().sum(0).cpu()
+    out = A.colsum(x, outer, Cc, 1).double().cpu()
+    bar = 2e-5 * float(ref.abs().max() + math.sqrt(outer))
+    assert float((out - ref).abs().max()) < bar, float((out - ref).abs().max())
+    into = torch.full((Cc,), 2.5, device=dev)
+    A.colsum(x, outer, Cc, 1, into=into)
+    assert float((into.double().cpu() - 2.5 - ref).abs().max()) < bar
