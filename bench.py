@@ -49,7 +49,7 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-roofline", action="store_true")
     p.add_argument("--no-train", action="store_true", help="skip the train-step leg (configs/tante_trl.yaml)")
-    p.add_argument("--train-steps", type=int, default=6)
+    p.add_argument("--train-steps", type=int, default=12)
     p.add_argument("--no-train-strong", action="store_true", help="skip the strong-scaling train line (global batch 64)")
     return p.parse_args()
 
@@ -281,7 +281,7 @@ def main():
             tgen = torch.Generator().manual_seed(1000 + rank)
             tbatch = {"input": torch.randn(tB, twl["n_steps_input"], *twl["spatial_resolution"], twl["n_fields"], generator=tgen).to(dev),
                       "output": torch.randn(tB, tn, *twl["spatial_resolution"], twl["n_fields"], generator=tgen).to(dev)}
-            for _ in range(2 if tB <= 16 else 1):                              # warm-up (packs, allocator pools, workspace slabs)
+            for _ in range(3 if tB <= 16 else 1):                              # warm-up (packs, allocator pools, workspace slabs)
                 tante_amd.train_step(tmodel, opt, tbatch, tfmt, tn, world)
             sync()
             t0 = time.perf_counter()
