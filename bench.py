@@ -281,12 +281,23 @@ def main():
             tgen = torch.Generator().manual_seed(1000 + rank)
             tbatch = {"input": torch.randn(tB, twl["n_steps_input"], *twl["spatial_resolution"], twl["n_fields"], generator=tgen).to(dev),
                       "output": torch.randn(tB, tn, *twl["spatial_resolution"], twl["n_fields"], generator=tgen).to(dev)}
+            # zero_grad + rollout + loss + backward replayed as one HIP graph (tante_amd.GraphedTrainStep: fresh dropout masks per step
+            # through a device-resident seed word; all-reduce, clip and AdamW stay ordinary launches); TANTE_TRAIN_GRAPH=0, or a capture
+            # that fails, leaves the eager step
+            step_fn, graph_note = (lambda: tante_amd.train_step(tmodel, opt, tbatch, tfmt, tn, world)), "off"
+            graphed = None
+            if os.environ.get("TANTE_TRAIN_GRAPH", "1") != "0":
+                try:
+                    graphed = tante_amd.GraphedTrainStep(tmodel, opt, tbatch, tfmt, tn, world, seed=tcfg.get("seed", 211) + rank)
+                    step_fn, graph_note = (lambda: graphed(tbatch)), "on"
+                except Exception as e:      # noqa: BLE001
+                    graph_note = f"capture failed ({type(e).__name__}: {e}): eager"
             for _ in range(3 if tB <= 16 else 1):                              # warm-up (packs, allocator pools, workspace slabs)
-                tante_amd.train_step(tmodel, opt, tbatch, tfmt, tn, world)
+                step_fn()
             sync()
             t0 = time.perf_counter()
             for _ in range(n_timed):
-                tante_amd.train_step(tmodel, opt, tbatch, tfmt, tn, world)
+                step_fn()
             sync()
             tel = time.perf_counter() - t0
             if dist is not None:
@@ -294,11 +305,13 @@ def main():
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                 tel = float(tt.item())
             nbytes = opt.numel * 4
-            del tmodel, opt, tbatch
+            if graphed is not None:
+                graphed.close()
+            del graphed, step_fn, tmodel, opt, tbatch
             torch.cuda.empty_cache()
             sps = tB * world * n_timed / tel
             return {"value": round(sps, 2), "unit": "samples/s", "ms_per_step": round(1e3 * tel / n_timed, 2), "global_batch": tB * world,
-                    "batch_per_gpu": tB, "steps": n_timed,
+                    "batch_per_gpu": tB, "steps": n_timed, "hip_graph": graph_note,
                     "roofline": {"bound": "mfma", "achieved": round(sps * flops_sample / world / 1e12, 2), "peak": PEAK_TFLOPS[dtype],
                                  "unit": "TFLOP/s per GPU", "frac": round(sps * flops_sample / world / 1e12 / PEAK_TFLOPS[dtype], 4),
                                  "algorithmic_gflop_per_sample": round(flops_sample / 1e9, 1)}}, nbytes

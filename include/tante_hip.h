@@ -234,6 +234,13 @@ int tante_block_fused(float* x, const void* block_stream, int C, int n_head, int
  *   out (tokens, 256) fp32       x1 + dropout(fc2(act))   (x itself is left untouched)
  * Masks are dropout_keep(seed, index, p) with tante_attention_dropout's index for seed_attn and row * 256 + column (the GEMM
  * epilogue's, tante_dropout_bwd's) for seed_out / seed_mlp. */
+/* A 64-bit word in DEVICE memory that the fused training kernels (tante_block_fused_train, tante_block_tail_bwd, the MFMA form of
+ * tante_attention_bwd) XOR into every dropout seed they are given, read when the kernel runs: a HIP graph of a train step replays its
+ * by-value seeds unchanged, so the host rewrites this word before each replay and the step draws fresh masks.  Per device (the
+ * current one); NULL (the default) switches it off.  The other dropout entry points (tante_dropout_*, tante_attention_dropout, the
+ * tante_gemm epilogue) take their seeds as given. */
+int tante_set_seed_mix(const uint64_t* device_word);
+
 typedef struct TanteBlockTrain {
   float* out;
   void *xh1, *qkv, *o, *xh2, *hpre, *act;

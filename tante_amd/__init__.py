@@ -14,7 +14,7 @@ from .config import instantiate, load_config, build_model  # noqa: F401
 from . import metrics, optim, dist  # noqa: F401
 from .metrics import MSE, NMSE, RMSE, NRMSE, VMSE, VRMSE, L2RE, NNMSE  # noqa: F401
 from .optim import FlatAdamW, warmup_cosine_lr  # noqa: F401
-from .train import train_step, train_step_adaptive, train_step_cvit  # noqa: F401
+from .train import GraphedTrainStep, train_step, train_step_adaptive, train_step_cvit  # noqa: F401
 from . import harness  # noqa: F401
 from .harness import LinearWarmupCosineAnnealingLR, SyntheticDataModule, save_checkpoint, load_checkpoint  # noqa: F401
 

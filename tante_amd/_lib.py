@@ -128,6 +128,7 @@ SIGNATURES = {
     "tante_fold_bwd_clear": ([c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp], c_i32),
     "tante_axis_wgrad": ([c_vp, c_vp, c_i64, c_i32, c_i64, c_vp, c_vp, c_i32, c_vp], c_i32),
     "tante_axis_wgrad_workspace_bytes": ([], c_i64),
+    "tante_set_seed_mix": ([c_vp], c_i32),
     "tante_axis_wgrad_ws": ([c_vp, c_vp, c_i64, c_i32, c_i64, c_vp, c_vp, c_i32, c_vp, c_i64, c_vp], c_i32),
     "tante_wgrad": ([C.POINTER(RowMat), C.POINTER(RowMat), c_i64, c_i32, c_i32, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp], c_i32),
     "tante_wgrad_multi_ws": ([c_vp, c_vp, c_i32, c_i64, c_i32, c_i32, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp], c_i32),

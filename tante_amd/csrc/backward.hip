@@ -533,7 +533,9 @@ __device__ __forceinline__ u32x2 abm_tr(unsigned addr) {
 template <int NT>
 __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const unsigned short* __restrict__ qkv, const unsigned short* __restrict__ dO,
                                                             unsigned short* __restrict__ dqkv, int C, int n_head, TanteSeq sq, int SPT, int causal,
-                                                            float scale, float p_drop, unsigned long long seed) {
+                                                            float scale, float p_drop, unsigned long long seed,
+                                                            const unsigned long long* __restrict__ seed_mix) {
+  if (seed_mix) seed ^= *seed_mix;       // per-step word of a replayed train step (tante_set_seed_mix)
   constexpr int ROWS = NT * 16, NP = (NT + 1) / 2;
   // LDS rows are 96 bytes apart (64 of data): with 64-byte rows the transposing reads of the four 16-lane groups hit the same banks
   // (rows r and r + 4 are 256 bytes apart): PMC showed half of this kernel's LDS cycles as bank conflicts
@@ -767,7 +769,7 @@ void launch_attn_bwd_mfma(const void* qkv, const void* dO, void* dqkv, int C, in
   static TantePerDevice attr;
   attr.once([&] { (void)hipFuncSetAttribute((const void*)attn_bwd_mfma_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
   hipLaunchKernelGGL((attn_bwd_mfma_kernel<NT>), dim3(units, (n_head + 3) / 4), dim3(256), lds, s, (const unsigned short*)qkv,
-                     (const unsigned short*)dO, (unsigned short*)dqkv, C, n_head, sq, SPT, causal, 1.0f / sqrtf(32.0f), p_drop, seed);
+                     (const unsigned short*)dO, (unsigned short*)dqkv, C, n_head, sq, SPT, causal, 1.0f / sqrtf(32.0f), p_drop, seed, tante_seed_mix_ptr());
 }
 bool try_attn_bwd_mfma(const void* qkv, const void* dO, void* dqkv, int dtype, int C, int n_head, const TanteSeq& sq, int causal, float p_drop,
                        unsigned long long seed, hipStream_t s) {

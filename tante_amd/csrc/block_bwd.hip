@@ -33,6 +33,7 @@ struct BtArgs {
   long M;
   float p;
   unsigned long long seed_out, seed_mlp;
+  const unsigned long long* seed_mix;   // see tante_set_seed_mix
 };
 
 // d/dx [ x Phi_tanh(x) ]  =  s (1 + 2 c x (1 - s) (1 + 3 k x^2)),  s = sigmoid(2 c (x + k x^3)),  c = sqrt(2 / pi), k = 0.044715:
@@ -82,6 +83,7 @@ __global__ __launch_bounds__(256, 2) void block_tail_bwd_kernel(BtArgs A) {
     off[tt] = (lv[tt] ? t : 0) * FS_C + col0;
   }
   const float ksc = A.p > 0.0f ? 1.0f / (1.0f - A.p) : 1.0f;
+  const unsigned long long smix = A.seed_mix ? *A.seed_mix : 0ull;
   auto drop4 = [&](const f32x4& v, unsigned long long seed, long i0) {
     if (A.p <= 0.0f) return v;
     const unsigned k01 = dropout_keep2(seed, (unsigned long long)i0, A.p), k23 = dropout_keep2(seed, (unsigned long long)i0 + 2, A.p);
@@ -98,7 +100,7 @@ __global__ __launch_bounds__(256, 2) void block_tail_bwd_kernel(BtArgs A) {
   for (int tt = 0; tt < NTT; ++tt)
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
-      const u32x2 u = pack4(lv[tt] ? drop4(g[rt][tt], A.seed_mlp, off[tt] + 16 * rt) : f32x4{0.f, 0.f, 0.f, 0.f});
+      const u32x2 u = pack4(lv[tt] ? drop4(g[rt][tt], A.seed_mlp ^ smix, off[tt] + 16 * rt) : f32x4{0.f, 0.f, 0.f, 0.f});
       *(u32x2*)(imgA + tt * 8192 + wro[rt]) = u;
       if (lv[tt]) *(u32x2*)(A.dy2 + off[tt] + 16 * rt) = u;
     }
@@ -177,7 +179,7 @@ __global__ __launch_bounds__(256, 2) void block_tail_bwd_kernel(BtArgs A) {
         f32x4 d;
 #pragma unroll
         for (int e = 0; e < 4; ++e) d[e] = g[rt][tt][e] + rstd[tt] * (acc[rt][tt][e] - m1 - xv[e] * m2);
-        const u32x2 u = pack4(lv[tt] ? drop4(d, A.seed_out, off[tt] + 16 * rt) : f32x4{0.f, 0.f, 0.f, 0.f});
+        const u32x2 u = pack4(lv[tt] ? drop4(d, A.seed_out ^ smix, off[tt] + 16 * rt) : f32x4{0.f, 0.f, 0.f, 0.f});
         *(u32x2*)(imgA + tt * 8192 + wro[rt]) = u;      // image A's last readers (P1's GEMM) passed two barriers ago
         if (lv[tt]) {
           *(f32x4*)(A.dx1 + off[tt] + 16 * rt) = d;
@@ -414,7 +416,7 @@ extern "C" int tante_block_tail_bwd(const float* dout, const void* hpre, const v
   BtArgs A;
   A.dout = dout; A.hpre = (const unsigned short*)hpre; A.xh2 = (const unsigned short*)xh2; A.st2 = st2; A.w = (const char*)bwd_stream;
   A.dx1 = dx1; A.dy2 = (unsigned short*)dy2; A.dhpre = (unsigned short*)dhpre; A.dy1 = (unsigned short*)dy1; A.d_o = (unsigned short*)d_o;
-  A.M = M; A.p = p_drop; A.seed_out = seed_out; A.seed_mlp = seed_mlp;
+  A.M = M; A.p = p_drop; A.seed_out = seed_out; A.seed_mlp = seed_mlp; A.seed_mix = tante_seed_mix_ptr();
   // 48-token workgroups when that fills the chip's 512 resident slots better (cfg3: 24 576 tokens = 512 x 48), else 64
   const long w3 = (M + 47) / 48, w4 = (M + 63) / 64;
   const long r3 = ((w3 + 511) / 512) * 3, r4 = ((w4 + 511) / 512) * 4;

@@ -47,6 +47,7 @@ struct FsArgs {
   float *st1, *x1, *st2;
   float p_drop;
   unsigned long long seed_attn, seed_out, seed_mlp;
+  const unsigned long long* seed_mix;   // device word XOR-ed into the three seeds (HIP-graph replays of a train step), or null
   unsigned long long* stamps;   // diagnostic builds (-DTANTE_ABLATE) only: per-wave s_memtime at the phase boundaries, else null
 };
 
@@ -120,6 +121,8 @@ __global__ __launch_bounds__(64 * NW, 2) void block_fs_kernel(FsArgs A) {
   const int tid = threadIdx.x, lane = tid & 63, kk = lane >> 4, l15 = lane & 15;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   float* const x = A.x;
+  const unsigned long long smix = (TRAIN && A.seed_mix) ? *A.seed_mix : 0ull;      // per-step word of a replayed train step
+  const unsigned long long sd_attn = A.seed_attn ^ smix;
   const int L = A.sq.L;
   const int seq0 = blockIdx.x * A.spw;
   const int nlive = min(A.spw, A.sq.nseq - seq0) * L;     // live token slots of this workgroup (the rest of spw * L is dead)
@@ -494,14 +497,14 @@ __global__ __launch_bounds__(64 * NW, 2) void block_fs_kernel(FsArgs A) {
             for (int j = 0; j < NK; ++j) {
               const int jpos0 = 16 * (k0 + j) + 4 * kk - si * L;          // key position inside the query's sequence (where visible)
               if ((L & 3) == 0) {      // the lane's four keys are one aligned run of mask indices: two hashes instead of four
-                const unsigned m4 = dropout_keep4(A.seed_attn, mrow + (unsigned long long)(jpos0 < 0 ? 0 : jpos0), A.p_drop);
+                const unsigned m4 = dropout_keep4(sd_attn, mrow + (unsigned long long)(jpos0 < 0 ? 0 : jpos0), A.p_drop);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) sc[qt][j][r] = ((m4 >> r) & 1u) ? sc[qt][j][r] * ksc : 0.0f;
               } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                   const int jpos = jpos0 + r;
-                  sc[qt][j][r] = dropout_keep(A.seed_attn, mrow + (unsigned long long)(jpos < 0 ? 0 : jpos), A.p_drop) ? sc[qt][j][r] * ksc : 0.0f;
+                  sc[qt][j][r] = dropout_keep(sd_attn, mrow + (unsigned long long)(jpos < 0 ? 0 : jpos), A.p_drop) ? sc[qt][j][r] * ksc : 0.0f;
                 }
               }
             }
@@ -597,7 +600,7 @@ __global__ __launch_bounds__(64 * NW, 2) void block_fs_kernel(FsArgs A) {
   {
     f32x4 xr[RT][NTT];
     slice_to_acc(xraw, xr);      // bufA: LayerNorm1's image died with the q/k/v GEMMs (barrier 2), LayerNorm2's comes after barrier 3
-    drop_add(x1, xr, A.seed_out);
+    drop_add(x1, xr, A.seed_out ^ smix);
   }
   if constexpr (TRAIN) {   // the residual after the attention half: the per-operator LayerNorm2 backward reads it (null when the fused tail backward runs)
     if (A.x1) slice_store(A.x1, x1);
@@ -697,7 +700,7 @@ __global__ __launch_bounds__(64 * NW, 2) void block_fs_kernel(FsArgs A) {
         for (int tt = 0; tt < NTT; ++tt) y2[rt][tt] = b2;
       }
       fs_slice_gemm<5, 48, NTT, RT, false, PF>(wq, wb, bufB, rdo, y2);
-      drop_add(y2, x1, A.seed_mlp);
+      drop_add(y2, x1, A.seed_mlp ^ smix);
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -870,11 +873,13 @@ int tante_fs_launch(float* x, const char* stream, const TanteSeq& sq, int causal
   FsArgs A;
   A.x = x; A.w = stream; A.sq = sq; A.causal = causal; A.eps = eps;
   A.out = nullptr;
+  A.seed_mix = nullptr;
   if (tr) {
     if (sq.L > 64) return -4;
     A.out = tr->out; A.xh1 = (unsigned short*)tr->xh1; A.st1 = tr->st1; A.qkv = (unsigned short*)tr->qkv; A.o = (unsigned short*)tr->o;
     A.x1 = tr->x1; A.xh2 = (unsigned short*)tr->xh2; A.st2 = tr->st2; A.hpre = (unsigned short*)tr->hpre; A.act = (unsigned short*)tr->act;
     A.p_drop = tr->p_drop; A.seed_attn = tr->seed_attn; A.seed_out = tr->seed_out; A.seed_mlp = tr->seed_mlp;
+    A.seed_mix = tante_seed_mix_ptr();
   }
   A.stamps = nullptr;
 #ifdef TANTE_ABLATE

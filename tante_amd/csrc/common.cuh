@@ -147,6 +147,12 @@ __device__ __forceinline__ float act_df(float x, int act) {
   }
 }
 
+// ---- per-step seed word in device memory (tante_set_seed_mix) ---------------------------------------------------------------------
+// The dropout seeds are kernel arguments by value: a HIP graph of a train step replays them unchanged.  The kernels that draw masks
+// therefore XOR every seed with a 64-bit word they READ from device memory when one is registered for the device: the host rewrites
+// the word before each replay (an 8-byte copy) and the captured step draws fresh masks.  Null (the default): seeds are used as given.
+const unsigned long long* tante_seed_mix_ptr();     // the current device's registered word (host side), defined in train.hip
+
 // ---- counter-based dropout mask: keep(seed, idx) is a pure function, so backward regenerates the forward's mask -------
 // One 32-bit hash serves TWO consecutive elements (idx >> 1 is hashed; the even element takes the low 16 bits, the odd one the high
 // 16): the kernels work on runs of 2 or 4 consecutive elements and hash half / a quarter as often as they decide.  The hash is a Weyl

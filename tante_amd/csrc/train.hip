@@ -118,6 +118,19 @@ __global__ void rt_bwd_kernel(const float* __restrict__ drt, int L, long n, floa
 
 }  // namespace
 
+static std::atomic<const unsigned long long*> g_seed_mix[64];
+const unsigned long long* tante_seed_mix_ptr() {
+  int d = 0;
+  (void)hipGetDevice(&d);
+  return g_seed_mix[d & 63].load(std::memory_order_acquire);
+}
+extern "C" int tante_set_seed_mix(const uint64_t* device_word) {
+  int d = 0;
+  (void)hipGetDevice(&d);
+  g_seed_mix[d & 63].store((const unsigned long long*)device_word, std::memory_order_release);
+  return 0;
+}
+
 extern "C" int tante_clip_value(float* g, int64_t n, float clip, void* stream) {
   if (!g || n <= 0 || clip <= 0.0f) TANTE_FAIL(-1, "tante_clip_value: bad argument");
   hipLaunchKernelGGL(clip_value_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g, (long)n, clip);

@@ -33,6 +33,95 @@ def train_step(model, opt: FlatAdamW, batch: Dict[str, torch.Tensor], formatter,
     return loss.detach()
 
 
+def _splitmix64(x: int) -> int:
+    x = (x + 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+    x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+    x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+    return x ^ (x >> 31)
+
+
+class GraphedTrainStep:
+    """train_step with zero_grad + rollout + loss + backward captured ONCE as a HIP graph and replayed: a step costs the host a batch
+    copy, an 8-byte seed word and one graph launch (0.15 ms instead of 10 - 20 ms of Python per step -- on a slow host the eager step
+    is issue-bound: 15 - 21 ms measured where the GPU needs 12.3).  What a replay cannot change are kernel arguments: shapes (static
+    here), and the dropout seeds -- so the fused training kernels XOR a device-resident word into every seed (tante_set_seed_mix) and
+    this class rewrites it before each replay: every step draws fresh masks, as the reference's nn.Dropout does.  The gradient
+    all-reduce and the clip + AdamW launch stay outside the graph (two launches; the learning rate and step count are their arguments).
+
+    Requirements: the fixed-dt model (no host-synchronising floor(R_t)), every TransformerBlock on the fused one-node path (bf16,
+    C = 256; otherwise per-operator dropout kernels would replay frozen masks -- checked at capture), batches of one shape.
+    Construction runs two warm-up steps and rolls parameters and optimizer state back afterwards: it leaves no trace in the training
+    trajectory."""
+
+    def __init__(self, model, opt: FlatAdamW, example_batch: Dict[str, torch.Tensor], formatter, n_steps_output: int, world: int = 1,
+                 seed: int = 0):
+        from . import _lib as L
+        from . import autograd as A
+        from . import train_forward as TF
+        if not getattr(model, "deg", True):
+            raise RuntimeError("GraphedTrainStep: the adaptive-dt model synchronises with the host every call (floor(R_t[0]))")
+        self.model, self.opt, self.fmt, self.n, self.world = model, opt, formatter, n_steps_output, world
+        self.dev = opt.flat_p.device
+        self.batch = {k: v.to(self.dev).clone() for k, v in example_batch.items()}
+        self.mix_dev = torch.zeros(1, dtype=torch.int64, device=self.dev)
+        self.mix_host = torch.zeros(1, dtype=torch.int64).pin_memory()
+        self.seed, self.count = int(seed), 0
+        L.check(L.lib().tante_set_seed_mix(self.mix_dev.data_ptr()), "tante_set_seed_mix")
+        snap = (opt.flat_p.clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone(), opt.step_count, A._SEED[0])
+        side = torch.cuda.Stream(device=self.dev)
+        side.wait_stream(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(side):
+            for _ in range(2):          # allocator pools, packs, workspaces of THIS stream, per-device kernel attributes
+                train_step(model, opt, self.batch, formatter, n_steps_output, 1)
+        torch.cuda.current_stream(self.dev).wait_stream(side)
+        opt.flat_p.copy_(snap[0]); opt.exp_avg.copy_(snap[1]); opt.exp_avg_sq.copy_(snap[2]); opt.step_count = snap[3]
+        self._bump()
+        torch.cuda.synchronize(self.dev)
+        self.graph = torch.cuda.CUDAGraph()
+        TF.BLOCK_CALLS[0] = TF.BLOCK_CALLS[1] = 0
+        A._SEED[0] = snap[4]            # the captured step draws the seeds an eager step would have drawn here
+        try:
+            with torch.cuda.graph(self.graph):
+                opt.zero_grad()
+                y_pred, y_ref = rollout_model(model, self.batch, formatter, n_steps_output)
+                self.loss = MseMeanFn.apply(y_pred, y_ref)
+                run_backward(self.loss)
+        finally:
+            pass
+        calls, fused = TF.BLOCK_CALLS
+        if calls == 0 or fused != calls:
+            raise RuntimeError(f"GraphedTrainStep: {calls - fused} of {calls} block calls are not on the fused one-node path "
+                               "(their dropout seeds would be frozen in the graph)")
+
+    @staticmethod
+    def _bump():
+        from .attn_backbone import bump_weight_epoch
+        from .autograd import clear_pack_cache
+        bump_weight_epoch()
+        clear_pack_cache()
+
+    def set_seed_word(self, word: int):
+        """The word the next step's kernels XOR into their seeds (tests use it to run an eager twin with the same masks)."""
+        w = int(word) & 0xFFFFFFFFFFFFFFFF
+        self.mix_host[0] = w - (1 << 64) if w >= (1 << 63) else w
+        self.mix_dev.copy_(self.mix_host, non_blocking=True)
+
+    def __call__(self, batch: Dict[str, torch.Tensor], lr: float = None) -> torch.Tensor:
+        for k, v in self.batch.items():
+            v.copy_(batch[k], non_blocking=True)
+        self.count += 1
+        self.set_seed_word(_splitmix64(self.seed * 0x100000001B3 + self.count))
+        self.graph.replay()
+        if self.world > 1:
+            D.allreduce_sum_(self.opt.flat_g)
+        self.opt.step(grad_scale=1.0 / self.world, lr=lr)
+        return self.loss.detach()
+
+    def close(self):
+        from . import _lib as L
+        L.check(L.lib().tante_set_seed_mix(None), "tante_set_seed_mix")
+
+
 def train_step_adaptive(model, opt: FlatAdamW, batch: Dict[str, torch.Tensor], formatter, n_steps_output: int, rt_eps: float = 0.5,
                         rt_n: float = 2.0, world: int = 1, lr: float = None):
     """R_Trainer.train_one_epoch's step (trainer/r_trainer.py:135-179) for the adaptive-dt model (deg=False): per-sample rollouts

@@ -58,7 +58,11 @@ FUSED_AXIS_HW = __import__("os").environ.get("TANTE_TRAIN_FUSED_AXIS", "1") != "
 FUSED_HEAD_BACKWARD = __import__("os").environ.get("TANTE_TRAIN_FUSED_HEAD_BWD", "1") != "0"   # q|k|v dgrad + LayerNorm1 backward in one launch
 
 
+BLOCK_CALLS = [0, 0]      # block_train calls / those that took the fused one-node path (GraphedTrainStep checks them at capture)
+
+
 def block_train(blk, x: torch.Tensor, seq, causal: bool, compute: int) -> torch.Tensor:
+    BLOCK_CALLS[0] += 1
     p = blk.p_drop if blk.training else 0.0     # nn.Dropout / MHA dropout are active in train() mode only
     # Every later call of this block inside one rollout graph (the BPTT steps) takes the record its first call left in the fold scope:
     # folded weights, the three fragment streams, the decision for the one-node path: the module attribute chains, fold / stream look-ups
@@ -68,6 +72,7 @@ def block_train(blk, x: torch.Tensor, seq, causal: bool, compute: int) -> torch.
         from .autograd import next_seed
         seeds = (next_seed(), next_seed(), next_seed()) if p > 0.0 else (0, 0, 0)
         t = K.block_fused_train(x.detach(), rec[8], blk.embed_dim, blk.n_head, blk.hidden, seq, causal, rec[11], p, seeds, need_x1=False)
+        BLOCK_CALLS[1] += 1
         return BlockFn.apply(x, *rec[:8], t, rec[9], seq, blk.n_head, causal, p, seeds, compute, rec[10])
     adt = K.act_torch_dtype(compute)
     a, m = blk.attn, blk.mlp
@@ -111,6 +116,7 @@ def block_train(blk, x: torch.Tensor, seq, causal: bool, compute: int) -> torch.
                 if _FOLDS is not None:
                     _FOLDS[("blk_rec", id(blk), seq.L, compute)] = (w_in, b_in, a.out_proj.weight, a.out_proj.bias, w1, b1, m[2].weight, m[2].bias,
                                                                     stream, bstream, hstream, blk.ln1.eps)
+                BLOCK_CALLS[1] += 1
                 return BlockFn.apply(x, w_in, b_in, a.out_proj.weight, a.out_proj.bias, w1, b1, m[2].weight, m[2].bias, t, bstream, seq,
                                      blk.n_head, causal, p, seeds, compute, hstream)
             xh, xs = LayerNormSkipFn.apply(x, blk.ln1.eps, adt, (t["xh1"], t["st1"]))

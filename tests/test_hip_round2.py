@@ -497,3 +497,49 @@ def test_colsum_dense_rows(dev, outer, Cc, dtype):
     into = torch.full((Cc,), 2.5, device=dev)
     A.colsum(x, outer, Cc, 1, into=into)
     assert float((into.double().cpu() - 2.5 - ref).abs().max()) < bar
+
+
+def test_graphed_train_step_matches_eager_twin(dev):
+    """GraphedTrainStep (zero_grad + rollout + loss + backward replayed as one HIP graph, a device-resident word XOR-ed into every
+    dropout seed per step) against an eager twin that runs train_step with the same by-value seeds and the same word: the same losses
+    and parameters over three steps (up to the summation order of the atomically reduced gradients), different masks from step to step,
+    and no trace of the capture's warm-up steps in the trajectory."""
+    import copy
+    import tante_amd
+    from tante_amd import autograd as A
+    from tante_amd.train import GraphedTrainStep, _splitmix64, train_step
+    from conftest import g14_setup, G14_FIELDS, G14_RES
+    m1, batch, _, _ = g14_setup()
+    m1 = m1.to(dev).train().set_compute("bf16")
+    for blk in [b for bb in m1.blocks for b in bb.blocks]:
+        blk.p_drop = 0.1
+        blk.attn.dropout = 0.1
+    m2 = copy.deepcopy(m1)
+    md = tante_amd.TanteMetadata(n_fields=G14_FIELDS, spatial_resolution=G14_RES)
+    fmt = tante_amd.DefaultChannelsFirstFormatter(md)
+    b = {k: v.to(dev) for k, v in batch.items()}
+    o1 = tante_amd.FlatAdamW(m1.parameters(), lr=1e-4, weight_decay=0.01, max_norm=1.0)
+    o2 = tante_amd.FlatAdamW(m2.parameters(), lr=1e-4, weight_decay=0.01, max_norm=1.0)
+    p0 = o1.flat_p.clone()
+    A._SEED[0] = 4321
+    g = GraphedTrainStep(m1, o1, b, fmt, 4, seed=7)
+    try:
+        assert torch.equal(o1.flat_p, p0) and o1.step_count == 0          # the warm-up steps were rolled back
+        losses = []
+        for step in range(1, 4):
+            l1 = float(g(b))
+            A._SEED[0] = 4321                                            # the eager twin draws the seeds the capture drew (from 4321 on)
+            g.set_seed_word(_splitmix64(7 * 0x100000001B3 + step))
+            l2 = float(train_step(m2, o2, b, fmt, 4, 1))
+            losses.append(l1)
+            assert abs(l1 - l2) < 1e-4 * abs(l2), (step, l1, l2)
+            # gradients: equal up to the summation order of the atomically reduced ones; parameters: Adam's first steps move every
+            # element by ~lr whatever the gradient's size, so an element whose gradient is rounding noise may differ by 2 lr -- rarely
+            eg = float((o1.flat_g - o2.flat_g).norm() / o2.flat_g.norm())
+            record_parity(eg, eg, 1e-3, "bf16", f"graphed vs eager train step {step}: flat gradient, relative L2")
+            assert eg < 1e-3, (step, eg)
+            far = float(((o1.flat_p - o2.flat_p).abs() > 2e-2 * 1e-4 * step).float().mean())
+            assert far < 2e-3, (step, far)
+        assert len({round(x, 7) for x in losses}) == 3
+    finally:
+        g.close()
