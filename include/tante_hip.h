@@ -108,7 +108,9 @@ typedef struct TanteGemm {
   /* training epilogues (LINEAR, dense bf16 rows, M >= 4096; zero = off):
    *   drop_p > 0: out = residual + keep(drop_seed, row * N + n) * x / (1 - drop_p), the residual-branch dropout of
    *               attn_backbone.py:57,81-82 applied to the product before the skip is added (same mask as tante_dropout_add);
-   *   dact != NULL: out = x * act'(dact[row * N + n]) with act = dact_kind -- the activation backward folded into the data-gradient GEMM. */
+   *   dact != NULL: out = x * act'(dact[row * N + n]) with act = dact_kind -- the activation backward folded into the data-gradient GEMM.
+ *               Also with e_mode = TANTE_E_DECONV_NHWC (no activation, Cout % 4 == 0, any M / K): dact is indexed like `out`, i.e. the
+ *               scatter writes d(pre) of the activation that fed a k = s patch conv (enc_dec_cnn.py:221-225 backwards). */
   float drop_p;
   uint64_t drop_seed;
   const void* dact;

@@ -828,23 +828,33 @@ class PatchEmbedFn(Function):
     PRE-activation."""
 
     @staticmethod
-    def forward(ctx, x, W, b, n_img, Hin, Win, Cin, P, nchw, compute, out_dtype):
+    def forward(ctx, x, W, b, n_img, Hin, Win, Cin, P, nchw, compute, out_dtype, act_in=L.ACT_NONE):
+        """act_in != ACT_NONE: x is the PRE-activation of the previous stage and this node applies the activation itself (channels-last
+        only) -- its backward then folds act'(x) into the data-gradient scatter instead of a separate pass over three images."""
         Cout = W.shape[0]
         if nchw:
             pw = _packed(W, b, compute, L.W_LINEAR, N=Cout, K=Cin * P * P)
         else:
             pw = _packed(W, b, compute, L.W_CONV_NHWC, N=Cout, K=Cin * P * P, P=P, C_other=Cin)
         M = n_img * (Hin // P) * (Win // P)
+        pre = None
+        if act_in != L.ACT_NONE:
+            if nchw or Cin % 4 or not x.is_contiguous():
+                raise RuntimeError("PatchEmbedFn: act_in needs a contiguous channels-last input with Cin % 4 == 0")
+            pre, x = x, torch.empty_like(x)
+            L.check(L.lib().tante_act_fwd(pre.data_ptr(), _DT[pre.dtype], x.data_ptr(), _DT[x.dtype], pre.numel(), act_in, _s()), "act_fwd")
         out = torch.empty(M, Cout, dtype=out_dtype, device=x.device)
         K.patch_embed(x, pw, out, n_img=n_img, Hin=Hin, Win=Win, Cin=Cin, P=P, nchw=nchw, act=L.ACT_NONE)
-        ctx.save_for_backward(x, W)
+        ctx.save_for_backward(x, W, *([pre] if pre is not None else []))
         ctx.geo, ctx.compute = (n_img, Hin, Win, Cin, P, nchw), compute
         ctx.params = (W, b)
+        ctx.act_in = act_in
         return out
 
     @staticmethod
     def backward(ctx, d):
-        x, W = ctx.saved_tensors
+        x, W = ctx.saved_tensors[:2]
+        pre = ctx.saved_tensors[2] if ctx.act_in != L.ACT_NONE else None
         n_img, Hin, Win, Cin, P, nchw = ctx.geo
         comp = ctx.compute
         d = d.contiguous()
@@ -858,7 +868,8 @@ class PatchEmbedFn(Function):
             else:
                 pwt = _packed(W, None, comp, L.W_CONV_NHWC_T, N=Kk, K=Cout, P=P, C_other=Cin)
                 dx = torch.empty(n_img, Hin, Win, Cin, dtype=x.dtype, device=x.device)
-            K.deconv(d, pwt, dx, n_img=n_img, Hi=Hin // P, Wi=Win // P, P=P, Cout=Cin, nchw_out=nchw, act=L.ACT_NONE)
+            K.deconv(d, pwt, dx, n_img=n_img, Hi=Hin // P, Wi=Win // P, P=P, Cout=Cin, nchw_out=nchw, act=L.ACT_NONE,
+                     dact=pre, dact_kind=ctx.act_in)      # act_in: dx is the gradient of the previous stage's PRE-activation
             dx = dx.view(x.shape)
         if ctx.needs_input_grad[1]:
             U, V = _rm_linear(d), _rm_patch(x, not nchw, n_img, Hin, Win, Cin, P)
@@ -884,7 +895,7 @@ class PatchEmbedFn(Function):
                                with_bias=True)
         elif ctx.needs_input_grad[2]:
             db = colsum(d, M, Cout, 1)
-        return dx, dW, db, None, None, None, None, None, None, None, None
+        return dx, dW, db, None, None, None, None, None, None, None, None, None
 
 
 class DeconvFn(Function):

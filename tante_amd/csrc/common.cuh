@@ -131,6 +131,21 @@ __host__ __device__ __forceinline__ int swz_chunk(int r, int c, int cpr) {
   return (cpr >= 16) ? (c ^ (r & 15)) : (c ^ ((r >> 1) & 7));  // cpr == 8 -> two rows per bank row
 }
 
+// d/dx GELU_erf(x) = Phi(x) + x phi(x) for the bf16 compute path: Phi from the forward's polynomial (|error| <= 8.3e-5), phi from one exp2
+__device__ __forceinline__ float gelu_erf_grad_fast(float x) {
+  const float s = fminf(x * x, 18.0625f);
+  float q = -8.949876396e-10f;
+  q = q * s + 7.897345000e-08f;
+  q = q * s + -3.026334298e-06f;
+  q = q * s + 6.673120515e-05f;
+  q = q * s + -9.494310943e-04f;
+  q = q * s + 9.293001145e-03f;
+  q = q * s + -6.551689655e-02f;
+  q = q * s + 3.984565735e-01f;
+  const float Phi = fminf(fmaxf(fmaf(x, q, 0.5f), 0.0f), 1.0f);
+  return fmaf(x * 0.3989422804f, __builtin_amdgcn_exp2f(-0.72134752f * x * x), Phi);
+}
+
 // derivative of an activation at its pre-activation value (training: act_bwd kernel and the data-gradient GEMM's epilogue)
 __device__ __forceinline__ float act_df(float x, int act) {
   switch (act) {

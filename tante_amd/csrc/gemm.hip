@@ -275,7 +275,12 @@ __device__ __forceinline__ void epilogue4(const TanteGemm& g, const EpiRow& e, i
       if (out_vec) {  // Cout % 4 == 0: the 4 features share (kh, kw)
         const int khw = n0 / g.Cout, co = n0 % g.Cout;
         const int kh = khw / g.Po, kw = khw % g.Po;
-        store4(g.out, g.out_dtype, (e.o_base + (long)kh * Wo + kw) * g.Cout + co, v);
+        const long oi = (e.o_base + (long)kh * Wo + kw) * g.Cout + co;
+        if (g.dact) {     // see epilogue4_fast: act'(pre) folded into the scatter
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] *= act_df(ld_elem(g.dact, g.dact_dtype, oi + j), g.dact_kind);
+        }
+        store4(g.out, g.out_dtype, oi, v);
       } else {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
@@ -327,7 +332,22 @@ __device__ __forceinline__ void epilogue4_fast(const TanteGemm& g, const EpiRow&
   } else if constexpr (EP == EP_DNHWC_GELU_ERF || EP == EP_DNHWC_NONE) {
     const int khw = n0 / g.Cout, co = n0 - khw * g.Cout;
     const int kh = khw / g.Po, kw = khw - kh * g.Po;
-    store4(g.out, g.out_dtype, (e.o_base + (long)kh * (g.Wi * g.Po) + kw) * g.Cout + co, v);
+    const long oi = (e.o_base + (long)kh * (g.Wi * g.Po) + kw) * g.Cout + co;
+    if constexpr (EP == EP_DNHWC_NONE) {
+      if (g.dact) {     // training: this scatter is the data gradient of a patch conv whose INPUT was act(pre): times act'(pre), same index
+        float pre[4];
+        if (g.dact_dtype == TANTE_BF16) {
+          const u32x2 u = *(const u32x2*)((const unsigned short*)g.dact + oi);
+          pre[0] = bf16_lo(u[0]); pre[1] = bf16_hi(u[0]); pre[2] = bf16_lo(u[1]); pre[3] = bf16_hi(u[1]);
+        } else {
+          const f32x4 f = *(const f32x4*)((const float*)g.dact + oi);
+          pre[0] = f[0]; pre[1] = f[1]; pre[2] = f[2]; pre[3] = f[3];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] *= (BF16 && g.dact_kind == TANTE_ACT_GELU_ERF) ? gelu_erf_grad_fast(pre[j]) : act_df(pre[j], g.dact_kind);
+      }
+    }
+    store4(g.out, g.out_dtype, oi, v);
   } else {  // EP_DNCHW_NONE: n = (co, kh, kw); P*P consecutive n are one output pixel block of one channel
     const long Ho = (long)g.Hi * g.Po, Wo = (long)g.Wi * g.Po;
     const int pp = g.Po * g.Po;
@@ -921,7 +941,9 @@ extern "C" int tante_gemm(const TanteGemm* gp, void* stream) {
   if (((uintptr_t)g.w % 16) || ((uintptr_t)g.bias % 16)) TANTE_FAIL(-1, "tante_gemm: packed weight/bias must be 16-byte aligned");
   if (g.drop_p < 0.0f || g.drop_p >= 1.0f) TANTE_FAIL(-1, "tante_gemm: dropout probability must be in [0, 1)");
   const bool train_epi = g.drop_p > 0.0f || g.dact != nullptr;
-  if (train_epi && (g.compute != TANTE_BF16 || g.e_mode != TANTE_E_LINEAR || g.a_mode != TANTE_A_LINEAR || g.a_dtype != TANTE_BF16 || g.ln ||
+  const bool dact_scatter = g.dact != nullptr && g.drop_p <= 0.0f && g.e_mode == TANTE_E_DECONV_NHWC && (flags & 2) && g.act == TANTE_ACT_NONE &&
+                            ((uintptr_t)g.dact % 16) == 0;      // act'(pre) folded into the channels-last pixel-shuffle store
+  if (train_epi && !dact_scatter && (g.compute != TANTE_BF16 || g.e_mode != TANTE_E_LINEAR || g.a_mode != TANTE_A_LINEAR || g.a_dtype != TANTE_BF16 || g.ln ||
                     g.act != TANTE_ACT_NONE || (flags & 3) != 3 || g.M < 4096 || (g.K != 128 && g.K != 256 && g.K != 512) || (g.drop_p > 0.0f && g.dact) ||
                     (g.dact && (((uintptr_t)g.dact % 16) || g.N % 4))))
     TANTE_FAIL(-2, "tante_gemm: the dropout / activation-gradient epilogues need dense 16-byte aligned bf16 rows, M >= 4096, K of 128, 256 or 512, no LayerNorm, no activation");

@@ -154,7 +154,8 @@ def patch_embed(a: torch.Tensor, pw: PackedWeight, out: torch.Tensor, *, n_img: 
 
 
 def deconv(a: torch.Tensor, pw: PackedWeight, out: torch.Tensor, *, n_img: int, Hi: int, Wi: int, P: int, Cout: int,
-           nchw_out: bool, act: int, a_n0: Optional[int] = None, a_s1: int = 0, a_s0: Optional[int] = None, a_off: int = 0):
+           nchw_out: bool, act: int, a_n0: Optional[int] = None, a_s1: int = 0, a_s0: Optional[int] = None, a_off: int = 0,
+           dact: Optional[torch.Tensor] = None, dact_kind: int = L.ACT_NONE):
     """ConvTranspose2d with kernel = stride = P: one GEMM row per input pixel, N = Cout*P*P outputs
     scattered (pixel-shuffle) into (n_img, Hi*P, Wi*P, Cout) [channels-last] or (n_img, Cout, Hi*P, Wi*P)."""
     M = n_img * Hi * Wi
@@ -164,6 +165,9 @@ def deconv(a: torch.Tensor, pw: PackedWeight, out: torch.Tensor, *, n_img: int, 
     g.a_s1, g.a_s0, g.a_off = a_s1, (pw.K if a_s0 is None else a_s0), a_off
     g.e_mode = L.E_DECONV_NCHW if nchw_out else L.E_DECONV_NHWC
     g.Hi, g.Wi, g.Po, g.Cout = Hi, Wi, P, Cout
+    if dact is not None:      # channels-last output only: out = scatter(...) * act'(dact), dact laid out like out
+        _dev(dact)
+        g.dact, g.dact_dtype, g.dact_kind = _p(dact), _DT[dact.dtype], dact_kind
     _run(g)
     return out
 

@@ -54,6 +54,7 @@ def _folded(lin_w, lin_b, ln):
 FUSED_TRAIN_FORWARD = __import__("os").environ.get("TANTE_TRAIN_FUSED", "1") != "0"
 FUSED_TAIL_BACKWARD = __import__("os").environ.get("TANTE_TRAIN_FUSED_BWD", "1") != "0"
 BLOCK_RECORDS = __import__("os").environ.get("TANTE_TRAIN_BLOCK_RECORDS", "1") != "0"   # per-scope prepared record of a block (host time)
+FUSED_ENC_ACT = __import__("os").environ.get("TANTE_TRAIN_FUSED_ENC_ACT", "1") != "0"   # encoder GELUs inside the next stage's node
 FUSED_AXIS_HW = __import__("os").environ.get("TANTE_TRAIN_FUSED_AXIS", "1") != "0"     # H + W propagators' training forward in one launch
 FUSED_HEAD_BACKWARD = __import__("os").environ.get("TANTE_TRAIN_FUSED_HEAD_BWD", "1") != "0"   # q|k|v dgrad + LayerNorm1 backward in one launch
 
@@ -172,8 +173,12 @@ def encoder_train(enc, inp: torch.Tensor, compute: int) -> torch.Tensor:
         conv = getattr(enc, f"enc_conv_{i + 1}").conv
         p, ci = enc.P[i], enc.chans[i]
         last = i == 2
-        z = PatchEmbedFn.apply(z, conv.weight, conv.bias, n_img, h, w, ci, p, i == 0, compute, torch.float32 if last else adt)
-        if not last:
+        # stages 2 and 3 take the previous stage's PRE-activation and apply the GELU themselves (their backward folds GELU' into the
+        # data-gradient scatter: no stand-alone activation backward over the two largest images of the step)
+        fold = FUSED_ENC_ACT and i > 0 and ci % 4 == 0
+        z = PatchEmbedFn.apply(z, conv.weight, conv.bias, n_img, h, w, ci, p, i == 0, compute, torch.float32 if last else adt,
+                               L.ACT_GELU_ERF if fold else L.ACT_NONE)
+        if not last and not (FUSED_ENC_ACT and enc.chans[i + 1] % 4 == 0):
             z = ActFn.apply(z, L.ACT_GELU_ERF, adt)
         h, w = h // p, w // p
     return z                                   # (B*T*Hp*Wp, C) fp32, before FiLM / positional embeddings
