@@ -93,6 +93,27 @@ def rollout_model(model, batch: Dict, formatter, n_steps: int, device=None):
         return formatter.process_output(_rollout_in_place(model, moving, n_steps)), y_ref.to(device)
     from .train_forward import fold_scope
     preds, produced = [], 0
+    if isinstance(model, TANTE) and torch.is_grad_enabled() and moving.shape[1] == model.T and moving.dtype == torch.float32:
+        from .train_forward import encode_frames_train, tante_train_forward, train_enc_cache_ok
+        from .attn_backbone import resolve_compute
+        if train_enc_cache_ok(model) and any(p.requires_grad for p in model.parameters()):
+            # BPTT with every frame encoded ONCE: the windows of consecutive calls share T - output_length frames and the encoder is
+            # frame-wise, so a window is assembled from cached per-frame encodings (autograd sums the gradients a frame's encoding
+            # receives from every window it sits in, and the encoder's backward runs once per frame).  Same values and gradients as
+            # re-encoding every window -- the reference's graph with its common subexpressions shared -- for 7 / 16 of the encoder work.
+            compute = resolve_compute(model.compute)
+            T = model.T
+            with fold_scope():
+                zf = list(encode_frames_train(model, moving, compute).unbind(1))
+                last = moving[:, -1:].contiguous()
+                while produced < n_steps:
+                    y = tante_train_forward(model, last, compute, 1, z_win=torch.stack(zf[-T:], dim=1))
+                    produced += y.shape[1]
+                    preds.append(formatter.process_output(y))
+                    if produced < n_steps:
+                        zf.extend(encode_frames_train(model, y, compute).unbind(1))
+                        last = y[:, -1:].contiguous()
+            return torch.cat(preds, dim=1)[:, :n_steps], y_ref.to(device)
     with fold_scope():      # the re-fed calls of one rollout share one autograd graph (and one folded copy of every LayerNorm affine)
         while produced < n_steps:
             y = model(moving)

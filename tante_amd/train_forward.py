@@ -215,11 +215,31 @@ def interprator_train(it, d3: torch.Tensor, B: int, out_T: float, compute: int) 
     return RtReduceFn.apply(t, B, it.sp_dim, float(out_T), float(it.ep))
 
 
-def tante_train_forward(model, inp: torch.Tensor, compute: int, out_T=1):
-    B, T, D, H, W = inp.shape
+TRAIN_ENC_CACHE = __import__("os").environ.get("TANTE_TRAIN_ENC_CACHE", "1") != "0"
+
+
+def train_enc_cache_ok(model) -> bool:
+    """The BPTT rollout may encode every frame once (see rollout_model): the patch-embed encoder is frame-wise (no time mixing before
+    FiLM), so the encoding of a frame that sits in several windows is the same tensor, and autograd sums its gradients."""
+    return (TRAIN_ENC_CACHE and getattr(model, "deg", False) and type(model.encoder).__name__ == "enc_CNN"
+            and all(S.stride_pad(p, model.encoder.overlap) == (p, 0) for p in model.encoder.P))
+
+
+def encode_frames_train(model, frames: torch.Tensor, compute: int) -> torch.Tensor:
+    """frames (B, k, D, H, W) -> their pre-FiLM token rows (B, k, HW, C) fp32, differentiable (encoder_train on the k frames of every item)."""
+    B, k = frames.shape[:2]
+    z = encoder_train(model.encoder, frames.to(torch.float32).contiguous(), compute)
+    return z.view(B, k, model.H_p * model.W_p, model.C)
+
+
+def tante_train_forward(model, inp: torch.Tensor, compute: int, out_T=1, z_win: torch.Tensor = None):
+    """z_win (optional): the window's frames already encoded, (B, T, HW, C) fp32 contiguous (encode_frames_train); `inp` then only
+    supplies its last frame (the Taylor sum's base) and may be that frame alone, (B, 1, D, H, W)."""
+    B, _, D, H, W = inp.shape
+    T = model.T
     Hp, Wp, C_ = model.H_p, model.W_p, model.C
     HW = Hp * Wp
-    z = encoder_train(model.encoder, inp, compute)
+    z = encoder_train(model.encoder, inp, compute) if z_win is None else z_win.reshape(B * T * HW, C_)
     # film(x, t) = x * (1 + scale(t)) + shift(t) with t = the window's fixed time stamps: the two tables are the same for every call of a
     # rollout graph, so they are built once per fold scope (like the folded LayerNorm weights) -- four tiny torch Linear layers, their
     # activations and their backward were ~150 launches of ~4.5 us per train step when rebuilt in each of the four BPTT calls
