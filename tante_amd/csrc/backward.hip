@@ -1134,8 +1134,8 @@ extern "C" int tante_axis_wgrad_ws(const float* U, const float* V, int64_t outer
   hipStream_t s = (hipStream_t)stream;
   float* ws = (workspace && workspace_bytes >= tante_axis_wgrad_workspace_bytes() && ((uintptr_t)workspace % 16) == 0) ? (float*)workspace : nullptr;
   if (!accumulate) {
-    if (hipMemsetAsync(dW, 0, (size_t)n * n * sizeof(float), s) != hipSuccess) TANTE_FAIL(-3, "tante_axis_wgrad: memset failed");
-    if (db && hipMemsetAsync(db, 0, (size_t)n * sizeof(float), s) != hipSuccess) TANTE_FAIL(-3, "tante_axis_wgrad: memset failed");
+    if (tante_zero_async(dW, (size_t)n * n * sizeof(float), s) != hipSuccess) TANTE_FAIL(-3, "tante_axis_wgrad: memset failed");
+    if (db && tante_zero_async(db, (size_t)n * sizeof(float), s) != hipSuccess) TANTE_FAIL(-3, "tante_axis_wgrad: memset failed");
   }
   // short axes: G segments of the contraction per MFMA tile (inner must hold whole 16 G chunks)
   const int g = (n <= 4 && inner % 64 == 0) ? 4 : (n <= 8 && inner % 32 == 0) ? 2 : 1;
@@ -1194,7 +1194,7 @@ extern "C" int tante_fold_bwd_clear(float* GW, float* Gb, const float* W, const 
 extern "C" int tante_colsum(const void* x, int dtype, int64_t outer, int C, int64_t inner, float* out, int accumulate, void* stream) {
   if (!x || !out || outer <= 0 || C <= 0 || inner <= 0) TANTE_FAIL(-1, "tante_colsum: bad argument");
   hipStream_t s = (hipStream_t)stream;
-  if (!accumulate && hipMemsetAsync(out, 0, (size_t)C * sizeof(float), s) != hipSuccess) TANTE_FAIL(-3, "tante_colsum: memset failed");
+  if (!accumulate && tante_zero_async(out, (size_t)C * sizeof(float), s) != hipSuccess) TANTE_FAIL(-3, "tante_colsum: memset failed");
   if (inner == 1 && dtype == TANTE_BF16 && C % 8 == 0 && C <= 2048 && 256 % (C / 8) == 0 && ((uintptr_t)x % 16) == 0) {
     long chunks = 1024;                                      // four workgroups per CU, at least 256 rows each
     if (chunks > (outer + 255) / 256) chunks = (outer + 255) / 256;
@@ -1232,7 +1232,7 @@ extern "C" int tante_film_pos_bwd(const float* dy, const float* v, const float* 
                                   float* db, float* ds, void* stream) {
   if (!dy || !v || !a || !dv || !da || !db || !ds || BT <= 0 || HW <= 0 || C <= 0 || T <= 0) TANTE_FAIL(-1, "tante_film_pos_bwd: bad argument");
   hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(da, 0, (size_t)T * C * sizeof(float), s) != hipSuccess || hipMemsetAsync(db, 0, (size_t)T * C * sizeof(float), s) != hipSuccess)
+  if (tante_zero_async(da, (size_t)T * C * sizeof(float), s) != hipSuccess || tante_zero_async(db, (size_t)T * C * sizeof(float), s) != hipSuccess)
     TANTE_FAIL(-3, "tante_film_pos_bwd: memset failed");
   const long chunk = 64;
   hipLaunchKernelGGL(film_pos_bwd_kernel, dim3((unsigned)((HW + chunk - 1) / chunk), (unsigned)BT), dim3(256), 0, s, dy, v, a, (long)HW, C, T, chunk,

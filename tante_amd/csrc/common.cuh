@@ -48,6 +48,32 @@ struct TantePerDevice {
   }
 };
 
+// ---- zero fill ------------------------------------------------------------------------------------
+// Accumulators that kernels add into are cleared by a KERNEL on the caller's stream, not by hipMemsetAsync: inside a captured HIP graph
+// (train.GraphedTrainStep) the memset becomes a memset node, and replays of such graphs were seen to run with the buffers NOT cleared
+// once other work (allocations, host copies) had happened between replays -- stale sums from the previous replay in the loss and in the
+// FiLM / colsum / weight gradients.  A kernel node is ordered like every other launch.  bytes must be a multiple of 4.
+static __global__ void tante_zero_kernel(unsigned* __restrict__ p, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = 0u;
+}
+static __global__ void tante_zero16_kernel(uint4* __restrict__ p, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = uint4{0u, 0u, 0u, 0u};
+}
+static inline hipError_t tante_zero_async(void* p, size_t bytes, hipStream_t s) {
+  if (bytes == 0) return hipSuccess;
+  if (bytes % 4) return hipErrorInvalidValue;
+  if (bytes % 16 == 0 && ((uintptr_t)p % 16) == 0) {
+    const long n = (long)(bytes / 16);
+    hipLaunchKernelGGL(tante_zero16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (uint4*)p, n);
+  } else {
+    const long n = (long)(bytes / 4);
+    hipLaunchKernelGGL(tante_zero_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (unsigned*)p, n);
+  }
+  return hipGetLastError();
+}
+
 // ---- timing-ablation switches ------------------------------------------------------------------
 // TANTE_*_DEBUG skip parts of a kernel to time the rest; the results are WRONG by construction, so the shipped library
 // never reads them: they exist only in a -DTANTE_ABLATE build (tools/ab_lib.sh builds one beside the product library).

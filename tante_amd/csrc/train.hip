@@ -151,7 +151,7 @@ extern "C" int tante_metric_sums(const float* pred, int64_t pb, int64_t pt, int6
   if (!pred || !ref || !sums || B <= 0 || T <= 0 || HW <= 0 || C <= 0) TANTE_FAIL(-1, "tante_metric_sums: bad argument");
   if (C > 1024) TANTE_FAIL(-2, "tante_metric_sums: too many channels");
   hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(sums, 0, (size_t)B * T * C * 5 * sizeof(float), s) != hipSuccess) TANTE_FAIL(-3, "tante_metric_sums: memset failed");
+  if (tante_zero_async(sums, (size_t)B * T * C * 5 * sizeof(float), s) != hipSuccess) TANTE_FAIL(-3, "tante_metric_sums: memset failed");
   long chunks = (HW * C + 256 * 64 - 1) / (256 * 64);  // ~64 elements per thread
   if (chunks < 1) chunks = 1;
   const long chunk = (HW + chunks - 1) / chunks;
@@ -174,7 +174,7 @@ extern "C" int tante_mse_grad(const float* pred, int64_t pb, int64_t pt, int64_t
 extern "C" int tante_sumsq(const float* g, int64_t n, double* out, void* stream) {
   if (!g || !out || n <= 0) TANTE_FAIL(-1, "tante_sumsq: bad argument");
   hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(out, 0, sizeof(double), s) != hipSuccess) TANTE_FAIL(-3, "tante_sumsq: memset failed");
+  if (tante_zero_async(out, sizeof(double), s) != hipSuccess) TANTE_FAIL(-3, "tante_sumsq: memset failed");
   long blocks = (n + 256 * 16 - 1) / (256 * 16);
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, s, g, (long)n, out);

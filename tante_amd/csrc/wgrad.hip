@@ -621,8 +621,8 @@ extern "C" int tante_wgrad(const TanteRowMat* U, const TanteRowMat* V, int64_t R
   if (rc) return rc;
   if (layout < TANTE_W_LINEAR || layout > TANTE_W_DECONV_NCHW) TANTE_FAIL(-1, "tante_wgrad: bad output layout");
   hipStream_t s = (hipStream_t)stream;
-  if (!accumulate && hipMemsetAsync(dW, 0, (size_t)I * J * sizeof(float), s) != hipSuccess) TANTE_FAIL(-3, "tante_wgrad: memset failed");
-  if (!accumulate && dbias && hipMemsetAsync(dbias, 0, (size_t)I * sizeof(float), s) != hipSuccess) TANTE_FAIL(-3, "tante_wgrad: memset failed");
+  if (!accumulate && tante_zero_async(dW, (size_t)I * J * sizeof(float), s) != hipSuccess) TANTE_FAIL(-3, "tante_wgrad: memset failed");
+  if (!accumulate && dbias && tante_zero_async(dbias, (size_t)I * sizeof(float), s) != hipSuccess) TANTE_FAIL(-3, "tante_wgrad: memset failed");
   return wgrad_one(U, V, R, I, J, dW, dbias, layout, P, C_other, swap, compute, s);
 }
 
@@ -643,8 +643,8 @@ extern "C" int tante_wgrad_multi_ws(const TanteRowMat* U, const TanteRowMat* V, 
   }
   if (layout < TANTE_W_LINEAR || layout > TANTE_W_DECONV_NCHW) TANTE_FAIL(-1, "tante_wgrad_multi: bad output layout");
   hipStream_t s = (hipStream_t)stream;
-  if (!accumulate && hipMemsetAsync(dW, 0, (size_t)I * J * sizeof(float), s) != hipSuccess) TANTE_FAIL(-3, "tante_wgrad_multi: memset failed");
-  if (!accumulate && dbias && hipMemsetAsync(dbias, 0, (size_t)I * sizeof(float), s) != hipSuccess) TANTE_FAIL(-3, "tante_wgrad_multi: memset failed");
+  if (!accumulate && tante_zero_async(dW, (size_t)I * J * sizeof(float), s) != hipSuccess) TANTE_FAIL(-3, "tante_wgrad_multi: memset failed");
+  if (!accumulate && dbias && tante_zero_async(dbias, (size_t)I * sizeof(float), s) != hipSuccess) TANTE_FAIL(-3, "tante_wgrad_multi: memset failed");
   int g = 0;
   while (g < n_seg) {                                  // groups of up to WSEG segments share a launch when the shape allows
     const int n = n_seg - g < WSEG ? n_seg - g : WSEG;

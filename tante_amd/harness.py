@@ -200,15 +200,31 @@ def validation_loop(model, dataloader, formatter, n_steps_rollout: int, device=N
 
 
 def train_one_epoch(model, optimizer, dataloader, formatter, n_steps_output: int, world: int = 1, rt_eps: float = 0.5,
-                    rt_n: float = 2.0) -> float:
+                    rt_n: float = 2.0, graph: bool = False) -> float:
     """Trainer.train_one_epoch (trainer/trainer.py:174-207; R_Trainer's for deg=False, r_trainer.py:135-179): one optimisation step
-    per batch, returns the mean training loss of the epoch (ONE host read at the end instead of the reference's loss.item() per batch)."""
-    from .train import train_step, train_step_adaptive
+    per batch, returns the mean training loss of the epoch (ONE host read at the end instead of the reference's loss.item() per batch).
+    graph=True (fixed-dt model only): the steps of full-size batches replay one HIP graph (train.GraphedTrainStep, captured on the first
+    such batch and kept on the model); a ragged last batch, or a model the capture refuses, takes the eager step."""
+    from .train import GraphedTrainStep, train_step, train_step_adaptive
     device = next(model.parameters()).device
     model.train()
     losses = []
     for batch in dataloader:
         batch = {"input": batch["input"].to(device), "output": batch["output"][:, :n_steps_output].contiguous().to(device)}
+        if graph and getattr(model, "deg", True):
+            g = getattr(model, "_tante_graphed_step", None)
+            shapes = tuple(tuple(v.shape) for v in batch.values())
+            if g is None or g is False:
+                if g is None:
+                    try:
+                        g = GraphedTrainStep(model, optimizer, batch, formatter, n_steps_output, world)
+                        g.shapes = shapes
+                    except RuntimeError:
+                        g = False
+                    model._tante_graphed_step = g
+            if g and g.shapes == shapes and g.opt is optimizer:
+                losses.append(g(batch).clone())
+                continue
         if getattr(model, "deg", True):
             losses.append(train_step(model, optimizer, batch, formatter, n_steps_output, world))
         else:
@@ -217,7 +233,7 @@ def train_one_epoch(model, optimizer, dataloader, formatter, n_steps_output: int
 
 
 def fit(model, optimizer, datamodule, formatter, max_epoch: int, n_steps_output: int, n_steps_rollout: int, checkpoint_folder: str,
-        lr_scheduler=None, world: int = 1, log=print) -> Dict:
+        lr_scheduler=None, world: int = 1, log=print, graph: bool = False) -> Dict:
     """Trainer.train (trainer/trainer.py:234-255): resume from <folder>/recent.pt when it exists (utils.set_ckpt, utils.py:36-47), then per
     epoch  sampler.set_epoch -> train_one_epoch -> save recent.pt -> validation_loop -> save best.pt on improvement -> scheduler.step.
     `best` is compared on L2RE (the Trainer's eval_loss_fn, configs/tante.yaml:52-53) and, unlike Trainer (which never updates best_val_loss, trainer.py:254-255, so
@@ -234,7 +250,7 @@ def fit(model, optimizer, datamodule, formatter, max_epoch: int, n_steps_output:
     rank0 = getattr(datamodule, "rank", 0) == 0
     for epoch in range(state["starting_epoch"], max_epoch + 1):
         datamodule.set_epoch(epoch)
-        train_loss = train_one_epoch(model, optimizer, datamodule.train_dataloader(), formatter, n_steps_output, world)
+        train_loss = train_one_epoch(model, optimizer, datamodule.train_dataloader(), formatter, n_steps_output, world, graph=graph)
         if rank0:
             save_checkpoint(recent, model, optimizer, epoch, val_loss, best_val)
         val = validation_loop(model, datamodule.val_dataloader(), formatter, n_steps_rollout)

@@ -543,3 +543,34 @@ def test_graphed_train_step_matches_eager_twin(dev):
         assert len({round(x, 7) for x in losses}) == 3
     finally:
         g.close()
+
+
+def test_train_one_epoch_graph_mode(dev):
+    """harness.train_one_epoch(graph=True): full-size batches replay one captured step, a ragged batch takes the eager step, and a model the
+    capture refuses (blocks off the fused path) silently trains eagerly; losses stay finite and fall in line with the eager epoch's."""
+    import copy
+    import tante_amd
+    from tante_amd import harness as H
+    from tante_amd.train import GraphedTrainStep
+    from conftest import g14_setup, G14_FIELDS, G14_RES
+    m, batch, _, _ = g14_setup()
+    m = m.to(dev).train().set_compute("bf16")
+    m2 = copy.deepcopy(m)
+    md = tante_amd.TanteMetadata(n_fields=G14_FIELDS, spatial_resolution=G14_RES)
+    fmt = tante_amd.DefaultChannelsFirstFormatter(md)
+    gen = torch.Generator().manual_seed(5)
+    loader = [{"input": torch.randn(2, 4, 64, 384, 4, generator=gen), "output": torch.randn(2, 4, 64, 384, 4, generator=gen)} for _ in range(3)]
+    loader.append({k: v[:1] for k, v in loader[0].items()})                    # a ragged last batch
+    o1 = tante_amd.FlatAdamW(m.parameters(), lr=1e-4)
+    o2 = tante_amd.FlatAdamW(m2.parameters(), lr=1e-4)
+    l1 = H.train_one_epoch(m, o1, loader, fmt, 4, graph=True)
+    assert isinstance(m._tante_graphed_step, GraphedTrainStep)
+    l2 = H.train_one_epoch(m2, o2, loader, fmt, 4, graph=False)
+    m._tante_graphed_step.close()
+    assert math.isfinite(l1) and abs(l1 - l2) < 1e-3 * abs(l2), (l1, l2)      # dropout 0: the same steps either way
+    small = tante_amd.TANTE(in_T=4, dset_metadata=tante_amd.TanteMetadata(n_fields=2, spatial_resolution=(32, 32)), taylor_order=1, attn_axes="THW",
+                            n_head=2, embed_dim=32, patch_scale=8, dropout=0.0).to(dev).train().set_compute("bf16")
+    os_ = tante_amd.FlatAdamW(small.parameters(), lr=1e-3)
+    sl = [{"input": torch.randn(2, 4, 32, 32, 2, generator=gen), "output": torch.randn(2, 2, 32, 32, 2, generator=gen)} for _ in range(2)]
+    fmt2 = tante_amd.DefaultChannelsFirstFormatter(tante_amd.TanteMetadata(n_fields=2, spatial_resolution=(32, 32)))
+    assert math.isfinite(H.train_one_epoch(small, os_, sl, fmt2, 2, graph=True)) and small._tante_graphed_step is False
