@@ -64,7 +64,6 @@ class GraphedTrainStep:
         self.dev = opt.flat_p.device
         self.batch = {k: v.to(self.dev).clone() for k, v in example_batch.items()}
         self.mix_dev = torch.zeros(1, dtype=torch.int64, device=self.dev)
-        self.mix_host = torch.zeros(1, dtype=torch.int64).pin_memory()
         self.seed, self.count = int(seed), 0
         L.check(L.lib().tante_set_seed_mix(self.mix_dev.data_ptr()), "tante_set_seed_mix")
         snap = (opt.flat_p.clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone(), opt.step_count, A._SEED[0])
@@ -81,17 +80,20 @@ class GraphedTrainStep:
         TF.BLOCK_CALLS[0] = TF.BLOCK_CALLS[1] = 0
         A._SEED[0] = snap[4]            # the captured step draws the seeds an eager step would have drawn here
         try:
-            with torch.cuda.graph(self.graph):
+            # thread-local capture mode: RCCL's proxy / watchdog threads of an initialised process group make HIP calls of their own,
+            # which a global-mode capture would take for violations
+            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
                 opt.zero_grad()
                 y_pred, y_ref = rollout_model(model, self.batch, formatter, n_steps_output)
                 self.loss = MseMeanFn.apply(y_pred, y_ref)
                 run_backward(self.loss)
-        finally:
-            pass
-        calls, fused = TF.BLOCK_CALLS
-        if calls == 0 or fused != calls:
-            raise RuntimeError(f"GraphedTrainStep: {calls - fused} of {calls} block calls are not on the fused one-node path "
-                               "(their dropout seeds would be frozen in the graph)")
+            calls, fused = TF.BLOCK_CALLS
+            if calls == 0 or fused != calls:
+                raise RuntimeError(f"GraphedTrainStep: {calls - fused} of {calls} block calls are not on the fused one-node path "
+                                   "(their dropout seeds would be frozen in the graph)")
+        except BaseException:
+            self.close()            # the kernels must not keep reading a seed word that dies with this object
+            raise
 
     @staticmethod
     def _bump():
@@ -103,8 +105,9 @@ class GraphedTrainStep:
     def set_seed_word(self, word: int):
         """The word the next step's kernels XOR into their seeds (tests use it to run an eager twin with the same masks)."""
         w = int(word) & 0xFFFFFFFFFFFFFFFF
-        self.mix_host[0] = w - (1 << 64) if w >= (1 << 63) else w
-        self.mix_dev.copy_(self.mix_host, non_blocking=True)
+        # a fill kernel carries the value in its own arguments: a host staging word would be overwritten by the next step's before the
+        # queued copy of this one has run (the host issues replays far ahead of the GPU)
+        self.mix_dev.fill_(w - (1 << 64) if w >= (1 << 63) else w)
 
     def __call__(self, batch: Dict[str, torch.Tensor], lr: float = None) -> torch.Tensor:
         for k, v in self.batch.items():
