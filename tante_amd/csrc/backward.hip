@@ -867,6 +867,45 @@ __global__ __launch_bounds__(512) void axis_wgrad_kernel(const float* __restrict
     c += 3 * stride;
   }
   // D[row][col]: lane holds col = l15, rows 4 kk + r.  G > 1: row = (s, a), col = (s', j): the diagonal blocks s == s' are the product
+  if constexpr (G == 1 && NT <= 3) {
+    // the waves' partial tiles are summed pairwise through LDS in register order (one 16-byte piece per lane and tile), and wave 0 writes
+    // the workgroup's tile: 36 LDS float atomics per lane and wave on the SAME 2 304 addresses were most of this kernel's time at n = 48
+    __shared__ f32x4 slab[4][(NT * NT + NT) * 64];
+    for (int half = nwv >> 1; half >= 1; half >>= 1) {
+      if (wave >= half && wave < 2 * half) {
+        f32x4* sl = slab[wave - half];
+#pragma unroll
+        for (int at = 0; at < NT; ++at) {
+#pragma unroll
+          for (int jt = 0; jt < NT; ++jt) sl[(at * NT + jt) * 64 + lane] = acc[at][jt];
+          sl[(NT * NT + at) * 64 + lane] = accb[at];
+        }
+      }
+      __syncthreads();
+      if (wave < half) {
+        const f32x4* sl = slab[wave];
+#pragma unroll
+        for (int at = 0; at < NT; ++at) {
+#pragma unroll
+          for (int jt = 0; jt < NT; ++jt) acc[at][jt] += sl[(at * NT + jt) * 64 + lane];
+          accb[at] += sl[(NT * NT + at) * 64 + lane];
+        }
+      }
+      __syncthreads();
+    }
+    if (wave == 0) {
+#pragma unroll
+      for (int at = 0; at < NT; ++at) {
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) red[(at * 16 + 4 * kk + r) * NP + jt * 16 + l15] = acc[at][jt][r];
+        if (db && l15 == 0)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) red[NP * NP + at * 16 + 4 * kk + r] = accb[at][r];
+      }
+    }
+  } else
 #pragma unroll
   for (int at = 0; at < NT; ++at) {
 #pragma unroll
