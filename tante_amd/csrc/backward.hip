@@ -540,7 +540,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const unsigned short
   // LDS rows are 96 bytes apart (64 of data): with 64-byte rows the transposing reads of the four 16-lane groups hit the same banks
   // (rows r and r + 4 are 256 bytes apart): PMC showed half of this kernel's LDS cycles as bank conflicts
   constexpr int RS = 48;   // row stride in bf16 elements
-  constexpr int WAVE_LDS = 3 * ROWS * RS * 2 + 16 * RS * 2 + 3 * ROWS * 4;   // Q, K, dO images, one 16-row staging tile, the row statistics
+  constexpr int WAVE_LDS = 3 * ROWS * RS * 2 + 16 * RS * 2 + 3 * ROWS * 4 + NT * NT * 64;   // Q, K, dO images, one 16-row staging tile, the row statistics, the keep bits
   extern __shared__ __attribute__((aligned(16))) char sm_raw[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kk = lane >> 4, l15 = lane & 15, qq = l15 >> 2, pp = l15 & 3;
   const int h = blockIdx.y * 4 + wave;
@@ -551,6 +551,10 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const unsigned short
   unsigned short* Gs = Ks + ROWS * RS;
   unsigned short* Os = Gs + ROWS * RS;           // 16-row staging tile: V on the way in (it needs no image), the results on the way out
   float* St = (float*)(Os + 16 * RS);            // m [ROWS], 1/l [ROWS], delta [ROWS]
+  // keep bits of the dropout mask, one byte per (score tile, key group kk, query): pass 1 draws them four keys at a time (one hash per
+  // aligned run of mask indices) and pass 2, whose lanes hold four QUERIES of one key -- mask indices L apart, a hash and a 64-bit index
+  // each: half of that pass's instructions -- reads them back transposed: a 32-bit word = the bytes of its four queries
+  unsigned char* Mb = (unsigned char*)(St + 3 * ROWS);
   const int L = sq.L, unit = blockIdx.x;
   const bool big = L >= 16;
   const unsigned rcpL = (65536u + L - 1) / L;    // floor(slot / L) for slot < 16
@@ -667,24 +671,27 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const unsigned short
 #pragma unroll
     for (int jt = 0; jt < NT; ++jt) {
       unsigned m4 = 0xfu;
-      if (p_drop > 0.f && (L & 3) == 0) {      // the lane's four keys are one aligned run of mask indices of one sequence
-        int jsl, jpos; bool jlive;
-        decode(jt * 16 + 4 * kk, jsl, jpos, jlive);
-        m4 = dropout_keep4(seed, mrow + jpos, p_drop);
+      if (p_drop > 0.f) {
+        if ((L & 3) == 0) {      // the lane's four keys are one aligned run of mask indices of one sequence
+          int jsl, jpos; bool jlive;
+          decode(jt * 16 + 4 * kk, jsl, jpos, jlive);
+          m4 = dropout_keep4(seed, mrow + jpos, p_drop);
+        } else {
+          m4 = 0u;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            int jsl, jpos; bool jlive;
+            decode(jt * 16 + 4 * kk + r, jsl, jpos, jlive);
+            m4 |= (unsigned)dropout_keep(seed, mrow + jpos, p_drop) << r;
+          }
+        }
+        Mb[(it * NT + jt) * 64 + kk * 16 + l15] = (unsigned char)m4;
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float p = st[jt][r] * inv_l;
         float dp = dpt[jt][r];
-        if (p_drop > 0.f) {
-          if ((L & 3) == 0) {
-            dp = ((m4 >> r) & 1u) ? dp * ksc : 0.f;                          // d(dropped prob) -> d(prob)
-          } else {
-            int jsl, jpos; bool jlive;
-            decode(jt * 16 + 4 * kk + r, jsl, jpos, jlive);
-            dp = dropout_keep(seed, mrow + jpos, p_drop) ? dp * ksc : 0.f;
-          }
-        }
+        if (p_drop > 0.f) dp = ((m4 >> r) & 1u) ? dp * ksc : 0.f;             // d(dropped prob) -> d(prob)
         st[jt][r] = p;
         dpt[jt][r] = dp;
         delta += p * dp;
@@ -728,6 +735,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const unsigned short
     for (int it = 0; it < NT; ++it) {
       const f32x4 m4 = *(const f32x4*)(St + it * 16 + 4 * kk), il4 = *(const f32x4*)(St + ROWS + it * 16 + 4 * kk);
       const f32x4 de4 = *(const f32x4*)(St + 2 * ROWS + it * 16 + 4 * kk);
+      const unsigned kw = p_drop > 0.f ? *(const unsigned*)(Mb + (it * NT + jt) * 64 + (l15 >> 2) * 16 + 4 * kk) >> (l15 & 3) : 0u;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         int isl, ipos; bool ilive;
@@ -736,8 +744,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const unsigned short
         const float p = valid ? __builtin_amdgcn_exp2f((sv[it][r] - m4[r]) * c2) * il4[r] : 0.f;
         float d = dp[it][r], pd = p;
         if (p_drop > 0.f) {
-          const unsigned long long idx = ((((unsigned long long)(big ? unit : unit * SPT + isl) * n_head + h) * L + ipos) * L) + jpos;
-          const bool keep = dropout_keep(seed, idx, p_drop);
+          const bool keep = (kw >> (8 * r)) & 1u;          // pass 1's draw for (query 4 kk + r, this key)
           pd = keep ? p * ksc : 0.f;
           d = keep ? d * ksc : 0.f;
         }
@@ -765,7 +772,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const unsigned short
 template <int NT>
 void launch_attn_bwd_mfma(const void* qkv, const void* dO, void* dqkv, int C, int n_head, const TanteSeq& sq, int SPT, int units, int causal,
                           float p_drop, unsigned long long seed, hipStream_t s) {
-  const size_t lds = 4 * (size_t)(3 * NT * 16 * 96 + 16 * 96 + 3 * NT * 16 * 4);      // = 4 waves x WAVE_LDS
+  const size_t lds = 4 * (size_t)(3 * NT * 16 * 96 + 16 * 96 + 3 * NT * 16 * 4 + NT * NT * 64);      // = 4 waves x WAVE_LDS
   static TantePerDevice attr;
   attr.once([&] { (void)hipFuncSetAttribute((const void*)attn_bwd_mfma_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
   hipLaunchKernelGGL((attn_bwd_mfma_kernel<NT>), dim3(units, (n_head + 3) / 4), dim3(256), lds, s, (const unsigned short*)qkv,

@@ -81,7 +81,7 @@ def main():
                 seq = K.make_seq(letter, B, T_, H_, W_)
                 import ctypes as Ct
                 timeit(lambda: L.check(L.lib().tante_attention_bwd(qkv.data_ptr(), do.data_ptr(), dq.data_ptr(), L.BF16, C, 8, Ct.byref(seq),
-                                                                   int(letter == "T"), 0.0, 0, torch.cuda.current_stream().cuda_stream)),
+                                                                   int(letter == "T"), float(os.environ.get("PDROP", "0")), 1234, torch.cuda.current_stream().cuda_stream)),
                        f"attn bwd {letter} L={seq.L}")
         elif a.what in ("enc", "dec", "head", "model"):
             m = tante_amd.TANTE(in_T=4, dset_metadata=md, taylor_order=3, attn_axes="THW-THW-THW", n_head=8, embed_dim=256,
