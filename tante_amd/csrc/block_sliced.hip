@@ -120,6 +120,11 @@ __global__ __launch_bounds__(64 * NW, 2) void block_fs_kernel(FsArgs A) {
   float* const lbias = (float*)(stat + 16 * NTT * NW * 8);   // the 4 x 256 biases (a global load per GEMM start would expose its latency)
   const int tid = threadIdx.x, lane = tid & 63, kk = lane >> 4, l15 = lane & 15;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef FS_PRIO
+  // experiment: the two workgroups of a CU run in lockstep through MFMA-only and VALU-only phases.  Waves in odd hardware slots (HW_ID
+  // bits 3:0) get issue priority for the whole kernel, so that the pair drifts apart instead of sharing every phase
+  if ((__builtin_amdgcn_s_getreg(0x1804) & 1u) == (FS_PRIO & 1)) __builtin_amdgcn_s_setprio(3);
+#endif
   float* const x = A.x;
   const unsigned long long smix = (TRAIN && A.seed_mix) ? *A.seed_mix : 0ull;      // per-step word of a replayed train step
   const unsigned long long sd_attn = A.seed_attn ^ smix;

@@ -9,7 +9,7 @@ base=$(basename $src .hip)
 eflags=""
 case $base in
   block_fused) eflags="-fno-honor-nans -DTANTE_MFMA_SETPRIO -mllvm -amdgpu-sched-strategy=max-ilp";;
-  block_sliced) eflags="-fno-honor-nans -DTANTE_MFMA_SETPRIO";;
+  block_sliced) eflags="-fno-honor-nans -DTANTE_MFMA_SETPRIO -DFS_PRIO=1";;
   head_fused|enc_fused|operators) eflags="-fno-honor-nans";;
 esac
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=fast $eflags $extra -c $R/tante_amd/csrc/$base.hip -o $R/tools/_ab/obj_$name/$base.o
