@@ -459,6 +459,15 @@ int tante_fold_bwd(const float* GW, const float* Gb, const float* W, const float
  * fill per weight and step. */
 int tante_fold_bwd_clear(float* GW, float* Gb, const float* W, const float* gamma, const float* beta, int N, int K, float* dW, float* db,
                          float* dgamma, float* dbeta, void* stream);
+/* n folds' backward in ONE launch (the train step has two per TransformerBlock, each 1 - 3 MB of work that costs 11 us as a launch of its
+ * own); clear != 0: as tante_fold_bwd_clear (every K <= 256).  attn_backbone.py:50-56, as above. */
+typedef struct TanteFold {
+  float* GW; float* Gb;                         /* accumulated gradients of (We, be): (N, K), (N) */
+  const float* W; const float* gamma; const float* beta;
+  float* dW; float* db; float* dgamma; float* dbeta;     /* gradient slots, added into (db may be NULL) */
+  int N, K;
+} TanteFold;
+int tante_fold_bwd_multi(const TanteFold* folds, int n, int clear, void* stream);
 int tante_axis_wgrad(const float* U, const float* V, int64_t outer, int n, int64_t inner, float* dW, float* db, int accumulate, void* stream);
 /* The same with a caller-owned workspace of tante_axis_wgrad_workspace_bytes() bytes (16-byte aligned; its LAST 256 bytes -- the arrival
  * counters -- zero on first use): every workgroup stores its partial there and the last of each group of 16 to finish adds the group's sum

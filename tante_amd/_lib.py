@@ -44,6 +44,11 @@ class Seq(C.Structure):
                 ("n_l0", c_i32), ("P1", c_i64), ("P0", c_i64)]
 
 
+class Fold(C.Structure):      # TanteFold (include/tante_hip.h)
+    _fields_ = [("GW", c_vp), ("Gb", c_vp), ("W", c_vp), ("gamma", c_vp), ("beta", c_vp), ("dW", c_vp), ("db", c_vp), ("dgamma", c_vp),
+                ("dbeta", c_vp), ("N", c_i32), ("K", c_i32)]
+
+
 class BlockTrain(C.Structure):
     _fields_ = [("out", c_vp), ("xh1", c_vp), ("qkv", c_vp), ("o", c_vp), ("xh2", c_vp), ("hpre", c_vp), ("act", c_vp),
                 ("st1", c_vp), ("x1", c_vp), ("st2", c_vp), ("p_drop", c_f32), ("seed_attn", C.c_uint64), ("seed_out", C.c_uint64),
@@ -126,6 +131,7 @@ SIGNATURES = {
     "tante_fold_fwd": ([c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp], c_i32),
     "tante_fold_bwd": ([c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp], c_i32),
     "tante_fold_bwd_clear": ([c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp], c_i32),
+    "tante_fold_bwd_multi": ([c_vp, c_i32, c_i32, c_vp], c_i32),
     "tante_axis_wgrad": ([c_vp, c_vp, c_i64, c_i32, c_i64, c_vp, c_vp, c_i32, c_vp], c_i32),
     "tante_axis_wgrad_workspace_bytes": ([], c_i64),
     "tante_set_seed_mix": ([c_vp], c_i32),

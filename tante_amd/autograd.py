@@ -170,6 +170,7 @@ def reset_backward_state(after: bool = False):
     callbacks, so the flag is keyed to the graph task and additionally cleared here: train_step* call this before and -- in a
     finally -- after every loss.backward(), so operands recorded by a dead pass can never reach a later step's gradient slots."""
     _DEFER["pending"].clear()
+    _FOLD_PENDING.clear()
     _DEFER["bytes"] = 0
     _DEFER["armed"] = False
     _DEFER["task"] = -1
@@ -222,9 +223,31 @@ def _flush_wgrads(slot: Optional[torch.Tensor] = None):
         _DEFER["bytes"] = 0
 
 
+_FOLD_PENDING = []      # folds whose backward waits for the end of the pass: (acc buffer, GW, Gb, W, gamma, beta, dW, db, dgamma, dbeta, N, K)
+
+
+def _flush_folds():
+    """The recorded FoldFn backwards as ONE launch (tante_fold_bwd_multi), after the weight-gradient launches that fill their accumulators."""
+    if not _FOLD_PENDING:
+        return
+    if _SIDE["stream"] is not None:      # the accumulators are written by weight-gradient kernels on the side stream
+        torch.cuda.current_stream().wait_stream(_SIDE["stream"])
+    n = len(_FOLD_PENDING)
+    arr = (L.Fold * n)()
+    for f, (buf, GW, Gb, W, gamma, beta, dW, db, dg, dbt, N, Kk) in zip(arr, _FOLD_PENDING):
+        f.GW, f.Gb, f.W, f.gamma, f.beta = GW.data_ptr(), Gb.data_ptr(), W.data_ptr(), gamma.data_ptr(), beta.data_ptr()
+        f.dW, f.db, f.dgamma, f.dbeta = dW.data_ptr(), None if db is None else db.data_ptr(), dg.data_ptr(), dbt.data_ptr()
+        f.N, f.K = N, Kk
+    L.check(L.lib().tante_fold_bwd_multi(C.byref(arr), n, 1, _s()), "tante_fold_bwd_multi")
+    for ent in _FOLD_PENDING:
+        _FOLD_DIRTY.pop(id(ent[0]), None)      # the kernel left the accumulators zeroed
+    _FOLD_PENDING.clear()
+
+
 def flush_deferred_wgrads():
-    """Run every recorded weight-gradient launch now (called automatically at the end of a backward pass)."""
+    """Run every recorded weight-gradient launch now (called automatically at the end of a backward pass), then the folds that wait for them."""
     _flush_wgrads(None)
+    _flush_folds()
 
 
 def _defer_wgrad(gW, gb, dy, a, M, N, Kk, comp, lay=(L.W_LINEAR, 0, 0, False)) -> bool:
@@ -332,6 +355,15 @@ class FoldFn(Function):
     def backward(ctx, gWe, gbe, _a, _b):
         W, gamma, beta = ctx.saved_tensors
         GW, Gb = ctx.acc
+        N, Kk = W.shape
+        if gWe is None and gbe is None and Kk <= 256 and _DEFER["armed"] and _DEFER["task"] == _graph_task():
+            # the usual case on the train path: every use added into the accumulators (or is recorded to), nothing arrives through
+            # autograd.  The fold joins the others of this backward pass: ONE launch after the recorded weight-gradient launches
+            # (flush_deferred_wgrads, the engine's end-of-pass callback that the recorded uses queued)
+            slots = [_grad_slot(q) for q in ctx.params]
+            if all(g is not None for g, q in zip(slots, ctx.params) if q is not None):
+                _FOLD_PENDING.append((ctx.acc_buf, GW, Gb, W, gamma, beta, slots[0], slots[1], slots[2], slots[3], N, Kk))
+                return None, None, None, None
         _flush_wgrads(GW)                    # the recorded uses of this folded weight run now, as one launch
         if _SIDE["stream"] is not None:      # the accumulators are written by weight-gradient kernels on the side stream
             torch.cuda.current_stream().wait_stream(_SIDE["stream"])

@@ -988,12 +988,12 @@ __global__ __launch_bounds__(256) void fold_fwd_kernel(const float* __restrict__
 // column reductions (atomics) from the same loads.  CLEAR: the accumulators are zeroed as they are read, so the caller can keep them
 // across steps without a fill per weight and step (GW by its only reader; Gb only when there is a single column chunk, K <= 256).
 constexpr int FB_ROWS = 16;
-__global__ __launch_bounds__(256) void fold_bwd_kernel(float* __restrict__ GW, float* __restrict__ Gb, const float* __restrict__ W,
-                                                       const float* __restrict__ gamma, const float* __restrict__ beta, int N, int K,
-                                                       float* __restrict__ dW, float* __restrict__ db, float* __restrict__ dgamma,
-                                                       float* __restrict__ dbeta, int clear) {
+__device__ __forceinline__ void fold_bwd_body(int bid, float* __restrict__ GW, float* __restrict__ Gb, const float* __restrict__ W,
+                                              const float* __restrict__ gamma, const float* __restrict__ beta, int N, int K,
+                                              float* __restrict__ dW, float* __restrict__ db, float* __restrict__ dgamma,
+                                              float* __restrict__ dbeta, int clear) {
   const int kb = (K + 255) / 256;
-  const int slab = (int)blockIdx.x / kb, kc = (int)blockIdx.x % kb, k = kc * 256 + threadIdx.x;
+  const int slab = bid / kb, kc = bid % kb, k = kc * 256 + threadIdx.x;
   const int n0 = slab * FB_ROWS, n1 = min(N, n0 + FB_ROWS);
   __shared__ float gbs[FB_ROWS];
   if (threadIdx.x < n1 - n0) gbs[threadIdx.x] = Gb[n0 + threadIdx.x];
@@ -1016,6 +1016,28 @@ __global__ __launch_bounds__(256) void fold_bwd_kernel(float* __restrict__ GW, f
   }
   atomicAdd(&dgamma[k], sg);
   atomicAdd(&dbeta[k], sb);
+}
+__global__ __launch_bounds__(256) void fold_bwd_kernel(float* __restrict__ GW, float* __restrict__ Gb, const float* __restrict__ W,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta, int N, int K,
+                                                       float* __restrict__ dW, float* __restrict__ db, float* __restrict__ dgamma,
+                                                       float* __restrict__ dbeta, int clear) {
+  fold_bwd_body((int)blockIdx.x, GW, Gb, W, gamma, beta, N, K, dW, db, dgamma, dbeta, clear);
+}
+// every fold of a model in ONE launch (tante_fold_bwd_multi): a fold's backward is 1 - 3 MB of elementwise work that takes 11 us as a launch
+// of its own (its latency chain, not its bytes), and a train step has two per TransformerBlock
+constexpr int FOLD_MAX = 24;
+struct FoldBatch {
+  float* GW[FOLD_MAX]; float* Gb[FOLD_MAX];
+  const float* W[FOLD_MAX]; const float* gamma[FOLD_MAX]; const float* beta[FOLD_MAX];
+  float* dW[FOLD_MAX]; float* db[FOLD_MAX]; float* dgamma[FOLD_MAX]; float* dbeta[FOLD_MAX];
+  int N[FOLD_MAX], K[FOLD_MAX], first[FOLD_MAX + 1];      // first[e]: the first block of entry e
+  int n;
+};
+__global__ __launch_bounds__(256) void fold_bwd_multi_kernel(FoldBatch B, int clear) {
+  int e = 0;
+  while (e + 1 < B.n && (int)blockIdx.x >= B.first[e + 1]) ++e;      // block-uniform
+  fold_bwd_body((int)blockIdx.x - B.first[e], B.GW[e], B.Gb[e], B.W[e], B.gamma[e], B.beta[e], B.N[e], B.K[e], B.dW[e], B.db[e], B.dgamma[e],
+                B.dbeta[e], clear);
 }
 
 // ---- axis propagator backward: y = x + W2 gelu(W1 x + b1) + b2 along an axis of (outer, n, inner) -----------------------
@@ -1236,6 +1258,29 @@ extern "C" int tante_fold_bwd_clear(float* GW, float* Gb, const float* W, const 
                                     float* dgamma, float* dbeta, void* stream) {
   if (K > 256) TANTE_FAIL(-2, "tante_fold_bwd_clear: K <= 256 (one column chunk reads the bias accumulator)");
   return fold_bwd_impl(GW, Gb, W, gamma, beta, N, K, dW, db, dgamma, dbeta, 1, stream);
+}
+extern "C" int tante_fold_bwd_multi(const TanteFold* folds, int n, int clear, void* stream) {
+  if (!folds || n <= 0) TANTE_FAIL(-1, "tante_fold_bwd_multi: bad argument");
+  for (int g = 0; g < n; g += FOLD_MAX) {
+    FoldBatch B;
+    const int m = n - g < FOLD_MAX ? n - g : FOLD_MAX;
+    int blocks = 0;
+    for (int e = 0; e < m; ++e) {
+      const TanteFold& f = folds[g + e];
+      if (!f.GW || !f.Gb || !f.W || !f.gamma || !f.beta || !f.dW || !f.dgamma || !f.dbeta || f.N <= 0 || f.K <= 0 || f.K % 4)
+        TANTE_FAIL(-1, "tante_fold_bwd_multi: bad entry %d (K must be a multiple of 4)", g + e);
+      if (clear && f.K > 256) TANTE_FAIL(-2, "tante_fold_bwd_multi: clear needs K <= 256 (one column chunk reads the bias accumulator)");
+      B.GW[e] = f.GW; B.Gb[e] = f.Gb; B.W[e] = f.W; B.gamma[e] = f.gamma; B.beta[e] = f.beta;
+      B.dW[e] = f.dW; B.db[e] = f.db; B.dgamma[e] = f.dgamma; B.dbeta[e] = f.dbeta;
+      B.N[e] = f.N; B.K[e] = f.K; B.first[e] = blocks;
+      blocks += ((f.N + FB_ROWS - 1) / FB_ROWS) * ((f.K + 255) / 256);
+    }
+    B.first[m] = blocks;
+    B.n = m;
+    hipLaunchKernelGGL(fold_bwd_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, B, clear);
+  }
+  TANTE_CHECK_LAUNCH();
+  return 0;
 }
 extern "C" int tante_colsum(const void* x, int dtype, int64_t outer, int C, int64_t inner, float* out, int accumulate, void* stream) {
   if (!x || !out || outer <= 0 || C <= 0 || inner <= 0) TANTE_FAIL(-1, "tante_colsum: bad argument");

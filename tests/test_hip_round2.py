@@ -574,3 +574,35 @@ def test_train_one_epoch_graph_mode(dev):
     sl = [{"input": torch.randn(2, 4, 32, 32, 2, generator=gen), "output": torch.randn(2, 2, 32, 32, 2, generator=gen)} for _ in range(2)]
     fmt2 = tante_amd.DefaultChannelsFirstFormatter(tante_amd.TanteMetadata(n_fields=2, spatial_resolution=(32, 32)))
     assert math.isfinite(H.train_one_epoch(small, os_, sl, fmt2, 2, graph=True)) and small._tante_graphed_step is False
+
+
+def test_fold_bwd_multi_equals_single_launches(dev):
+    """tante_fold_bwd_multi (every fold of a backward pass in one launch) against one tante_fold_bwd per fold: three folds of different
+    shapes, one without a bias slot; clear = 1 leaves the accumulators zeroed.  Reference: attn_backbone.py:50-56 (LayerNorm affine + Linear)."""
+    import ctypes as C
+    from tante_amd import _lib as L
+    g = torch.Generator().manual_seed(77)
+    s = torch.cuda.current_stream().cuda_stream
+    shapes = [(768, 256, True), (256, 256, True), (48, 64, False)]
+    arr = (L.Fold * len(shapes))()
+    keep, want = [], []
+    for f, (N, K, bias) in zip(arr, shapes):
+        W, GW, Gb = torch.randn(N, K, generator=g).to(dev), torch.randn(N, K, generator=g).to(dev), torch.randn(N, generator=g).to(dev)
+        ga, be = (1 + 0.3 * torch.randn(K, generator=g)).to(dev), (0.3 * torch.randn(K, generator=g)).to(dev)
+        one = [torch.full((N, K), 0.5, device=dev), torch.full((N,), 0.5, device=dev) if bias else None, torch.full((K,), 0.5, device=dev),
+               torch.full((K,), 0.5, device=dev)]
+        ref = [t.clone() if t is not None else None for t in one]
+        L.check(L.lib().tante_fold_bwd(GW.data_ptr(), Gb.data_ptr(), W.data_ptr(), ga.data_ptr(), be.data_ptr(), N, K, ref[0].data_ptr(),
+                                       ref[1].data_ptr() if bias else None, ref[2].data_ptr(), ref[3].data_ptr(), s))
+        f.GW, f.Gb, f.W, f.gamma, f.beta = GW.data_ptr(), Gb.data_ptr(), W.data_ptr(), ga.data_ptr(), be.data_ptr()
+        f.dW, f.db, f.dgamma, f.dbeta = one[0].data_ptr(), one[1].data_ptr() if bias else None, one[2].data_ptr(), one[3].data_ptr()
+        f.N, f.K = N, K
+        keep.append((W, GW, Gb, ga, be, one))
+        want.append(ref)
+    L.check(L.lib().tante_fold_bwd_multi(C.byref(arr), len(shapes), 1, s))
+    torch.cuda.synchronize()
+    for (W, GW, Gb, ga, be, got), ref in zip(keep, want):
+        assert torch.equal(got[0], ref[0]) and (ref[1] is None or torch.equal(got[1], ref[1]))      # elementwise parts: the same expression
+        assert torch.allclose(got[2], ref[2], rtol=1e-5, atol=1e-4) and torch.allclose(got[3], ref[3], rtol=1e-5, atol=1e-4)   # atomics: order
+        assert float(GW.abs().max()) == 0.0 and float(Gb.abs().max()) == 0.0                         # cleared while read
+    assert L.lib().tante_fold_bwd_multi(C.byref(arr), 0, 1, s) != 0                                  # n <= 0 is refused
