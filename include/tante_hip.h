@@ -459,6 +459,19 @@ int tante_fold_bwd(const float* GW, const float* Gb, const float* W, const float
  * fill per weight and step. */
 int tante_fold_bwd_clear(float* GW, float* Gb, const float* W, const float* gamma, const float* beta, int N, int K, float* dW, float* db,
                          float* dgamma, float* dbeta, void* stream);
+/* The propagator's backward WITH its parameter gradients in one launch, bf16 operands on the matrix cores (axis lengths 16 / 32 / 48,
+ * inner % 64 == 0; tante_axis_mlp_bwd_fused_supported says so): dx = dy + W1^T (gelu'(pre) (W2^T dy)) with pre = W1 x + b1, and
+ * dW1 += <dpre, x>, db1 += sum dpre, dW2 += <dy, gelu(pre)>, db2 += sum dy (all four ADDED into).  x, dy, dx: fp32 (outer, n, inner), 16-byte
+ * aligned.  Replaces tante_axis_mlp_bwd + two tante_axis_wgrad on the bf16 train path (attn_backbone.py:111-119, 140-145). */
+int tante_axis_mlp_bwd_fused_supported(int n, int64_t inner);
+int tante_axis_mlp_bwd_fused(const float* x, const float* dy, int64_t outer, int n, int64_t inner, const float* w1, const float* b1, const float* w2,
+                             float* dx, float* dW1, float* db1, float* dW2, float* db2, void* stream);
+/* The same with a caller-owned workspace of tante_axis_wgrad_workspace_bytes() bytes (tante_axis_wgrad_ws's; one call at a time per
+ * workspace): workgroups store their partial gradients there and a second small kernel sums them, instead of every workgroup adding its
+ * partial atomically (512 same-address atomics per value). */
+int tante_axis_mlp_bwd_fused_ws(const float* x, const float* dy, int64_t outer, int n, int64_t inner, const float* w1, const float* b1,
+                                const float* w2, float* dx, float* dW1, float* db1, float* dW2, float* db2, void* workspace,
+                                int64_t workspace_bytes, void* stream);
 /* n folds' backward in ONE launch (the train step has two per TransformerBlock, each 1 - 3 MB of work that costs 11 us as a launch of its
  * own); clear != 0: as tante_fold_bwd_clear (every K <= 256).  attn_backbone.py:50-56, as above. */
 typedef struct TanteFold {

@@ -132,6 +132,9 @@ SIGNATURES = {
     "tante_fold_bwd": ([c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp], c_i32),
     "tante_fold_bwd_clear": ([c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp], c_i32),
     "tante_fold_bwd_multi": ([c_vp, c_i32, c_i32, c_vp], c_i32),
+    "tante_axis_mlp_bwd_fused_supported": ([c_i32, c_i64], c_i32),
+    "tante_axis_mlp_bwd_fused": ([c_vp, c_vp, c_i64, c_i32, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp], c_i32),
+    "tante_axis_mlp_bwd_fused_ws": ([c_vp, c_vp, c_i64, c_i32, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp], c_i32),
     "tante_axis_wgrad": ([c_vp, c_vp, c_i64, c_i32, c_i64, c_vp, c_vp, c_i32, c_vp], c_i32),
     "tante_axis_wgrad_workspace_bytes": ([], c_i64),
     "tante_set_seed_mix": ([c_vp], c_i32),

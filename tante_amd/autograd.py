@@ -757,6 +757,9 @@ class DropoutAddFn(Function):
         return dy, dout, None
 
 
+AXIS_BWD_FUSED = __import__("os").environ.get("TANTE_AXIS_BWD_FUSED", "1") != "0"     # propagator backward + weight gradients in one MFMA launch
+
+
 class AxisMlpFn(Function):
     """y = x + W2 gelu_erf(W1 x + b1) + b2 along one axis of (outer, n, inner)."""
 
@@ -780,6 +783,25 @@ class AxisMlpFn(Function):
         x, w1, b1, w2 = ctx.saved_tensors
         outer, n, inner = ctx.dims
         dy = dy.contiguous()
+        if (AXIS_BWD_FUSED and ctx.compute == L.BF16 and x.dtype == torch.float32 and dy.dtype == torch.float32 and x.is_contiguous()
+                and L.lib().tante_axis_mlp_bwd_fused_supported(n, inner)):
+            # bf16 train path, axis lengths 16 / 32 / 48: dx AND the four parameter gradients in one launch on the matrix cores (x and dy
+            # read once, nothing materialised for separate weight-gradient launches)
+            slots = [_grad_slot(q) for q in ctx.params]
+            direct = all(g is not None for g in slots)
+            if direct:
+                dw1, db1, dw2, db2 = slots
+            else:
+                dw1, dw2 = (torch.zeros(n, n, dtype=torch.float32, device=x.device) for _ in range(2))
+                db1, db2 = (torch.zeros(n, dtype=torch.float32, device=x.device) for _ in range(2))
+            dx = torch.empty_like(x)
+            ws = _axis_wgrad_workspace(x.device)
+            L.check(L.lib().tante_axis_mlp_bwd_fused_ws(x.data_ptr(), dy.data_ptr(), outer, n, inner, w1.data_ptr(), b1.data_ptr(), w2.data_ptr(),
+                                                        dx.data_ptr(), dw1.data_ptr(), db1.data_ptr(), dw2.data_ptr(), db2.data_ptr(),
+                                                        ws.data_ptr(), ws.numel() * 4, _s()), "tante_axis_mlp_bwd_fused")
+            if direct:
+                return dx, None, None, None, None, None, None, None, None
+            return dx, dw1, db1, dw2, db2, None, None, None, None
         dx, h, dpre = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
         L.check(L.lib().tante_axis_mlp_bwd(x.data_ptr(), dy.data_ptr(), outer, n, inner, w1.data_ptr(), b1.data_ptr(), w2.data_ptr(),
                                            dx.data_ptr(), h.data_ptr(), dpre.data_ptr(), _s()), "axis_mlp_bwd")

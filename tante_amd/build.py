@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libtante_hip.so")
-SOURCES = ["gemm.hip", "attention.hip", "pointwise.hip", "block_fused.hip", "block_sliced.hip", "block_bwd.hip", "train.hip", "backward.hip", "wgrad.hip", "head_fused.hip", "operators.hip", "enc_fused.hip"]
+SOURCES = ["gemm.hip", "attention.hip", "pointwise.hip", "block_fused.hip", "block_sliced.hip", "block_bwd.hip", "train.hip", "backward.hip", "wgrad.hip", "head_fused.hip", "operators.hip", "enc_fused.hip", "axis_bwd.hip"]
 HEADERS = [os.path.join(CSRC, "common.cuh"), os.path.join(CSRC, "fused_common.cuh"), os.path.join(CSRC, "fs_common.cuh"), os.path.join(CSRC, "block_sliced.h"), os.path.join(os.path.dirname(HERE), "include", "tante_hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=fast"]

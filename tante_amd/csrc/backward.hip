@@ -809,10 +809,10 @@ bool try_attn_bwd_mfma(const void* qkv, const void* dO, void* dqkv, int dtype, i
 // 512 / 1024 / 1536 workgroups -- device-scope atomics are served behind the XCDs' L2s): each workgroup STORES its partial to a
 // caller-owned workspace, and the last of every AW_GS workgroups to finish (an arrival counter per group) sums the group's partials
 // and adds ONE n x n to dW: a sixteenth of the atomics, no second launch.
-constexpr int AW_GS = 16;                                 // workgroups per reduction group
-constexpr int AW_MAXWG = 1024;                            // grid cap with a workspace
-constexpr int AW_SLAB = 64 * 64 + 64;                     // floats per partial: dW (n <= 64) then db
-constexpr long AW_WS_FLOATS = (long)AW_MAXWG * AW_SLAB + AW_MAXWG / AW_GS;   // partials + one arrival counter per group
+constexpr int AW_GS = TANTE_AW_GS;                        // workgroups per reduction group (common.cuh: axis_bwd.hip shares the workspace)
+constexpr int AW_MAXWG = TANTE_AW_MAXWG;                  // grid cap with a workspace
+constexpr int AW_SLAB = TANTE_AW_SLAB;                    // floats per partial: dW (n <= 64) then db
+constexpr long AW_WS_FLOATS = TANTE_AW_WS_FLOATS;         // partials + one arrival counter per group
 
 template <int NT, int G>
 __global__ __launch_bounds__(512) void axis_wgrad_kernel(const float* __restrict__ U, const float* __restrict__ V, long outer, int n, long inner,

@@ -74,6 +74,13 @@ static inline hipError_t tante_zero_async(void* p, size_t bytes, hipStream_t s) 
   return hipGetLastError();
 }
 
+// ---- workspace of the propagator weight-gradient kernels (tante_axis_wgrad_ws, tante_axis_mlp_bwd_fused_ws) -----------------------------
+// partials of up to TANTE_AW_MAXWG workgroups, TANTE_AW_SLAB floats each, then one arrival counter per group of TANTE_AW_GS workgroups
+constexpr int TANTE_AW_GS = 16;
+constexpr int TANTE_AW_MAXWG = 1024;
+constexpr int TANTE_AW_SLAB = 64 * 64 + 64;
+constexpr long TANTE_AW_WS_FLOATS = (long)TANTE_AW_MAXWG * TANTE_AW_SLAB + TANTE_AW_MAXWG / TANTE_AW_GS;
+
 // ---- timing-ablation switches ------------------------------------------------------------------
 // TANTE_*_DEBUG skip parts of a kernel to time the rest; the results are WRONG by construction, so the shipped library
 // never reads them: they exist only in a -DTANTE_ABLATE build (tools/ab_lib.sh builds one beside the product library).

@@ -606,3 +606,35 @@ def test_fold_bwd_multi_equals_single_launches(dev):
         assert torch.allclose(got[2], ref[2], rtol=1e-5, atol=1e-4) and torch.allclose(got[3], ref[3], rtol=1e-5, atol=1e-4)   # atomics: order
         assert float(GW.abs().max()) == 0.0 and float(Gb.abs().max()) == 0.0                         # cleared while read
     assert L.lib().tante_fold_bwd_multi(C.byref(arr), 0, 1, s) != 0                                  # n <= 0 is refused
+
+
+@pytest.mark.parametrize("outer,n,inner", [(6, 48, 128), (3, 16, 448), (5, 32, 64), (32, 16, 256)])
+def test_axis_mlp_bwd_fused_against_float64(dev, outer, n, inner):
+    """tante_axis_mlp_bwd_fused (the propagator's backward and its four parameter gradients in one MFMA launch, bf16 operands) against
+    float64 autograd of  y = x + W2 gelu(W1 x + b1) + b2  along the middle axis of (outer, n, inner) -- attn_backbone.py:111-119, 140-145.
+    Bars: the bf16 train path's (1e-2 relative L2 on dx, 2e-2 on the parameter gradients); the gradients are ADDED into their slots."""
+    from tante_amd import _lib as L
+    g = torch.Generator().manual_seed(outer * 1000 + n)
+    x = torch.randn(outer, n, inner, generator=g).to(dev)
+    dy = torch.randn(outer, n, inner, generator=g).to(dev)
+    w1, w2 = (torch.randn(n, n, generator=g) / n ** 0.5).to(dev), (torch.randn(n, n, generator=g) / n ** 0.5).to(dev)
+    b1 = (0.3 * torch.randn(n, generator=g)).to(dev)
+    xd, w1d, w2d, b1d = (t.double().cpu().requires_grad_() for t in (x, w1, w2, b1))
+    b2d = torch.zeros(n, dtype=torch.float64, requires_grad=True)
+    xt = xd.transpose(1, 2)                                                             # (outer, inner, n): Linear along n
+    y = xt + torch.nn.functional.gelu(xt @ w1d.T + b1d) @ w2d.T + b2d
+    (y * dy.double().cpu().transpose(1, 2)).sum().backward()
+    assert L.lib().tante_axis_mlp_bwd_fused_supported(n, inner) == 1
+    dx = torch.full_like(x, float("nan"))
+    dW1, dW2 = torch.full((n, n), 0.25, device=dev), torch.full((n, n), 0.25, device=dev)
+    db1, db2 = torch.full((n,), 0.25, device=dev), torch.full((n,), 0.25, device=dev)
+    L.check(L.lib().tante_axis_mlp_bwd_fused(x.data_ptr(), dy.data_ptr(), outer, n, inner, w1.data_ptr(), b1.data_ptr(), w2.data_ptr(),
+                                             dx.data_ptr(), dW1.data_ptr(), db1.data_ptr(), dW2.data_ptr(), db2.data_ptr(),
+                                             torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    errs = {"dx": rel_err(dx.double().cpu(), xd.grad), "dW1": rel_err((dW1 - 0.25).double().cpu(), w1d.grad),
+            "db1": rel_err((db1 - 0.25).double().cpu(), b1d.grad), "dW2": rel_err((dW2 - 0.25).double().cpu(), w2d.grad),
+            "db2": rel_err((db2 - 0.25).double().cpu(), b2d.grad)}
+    record_parity(errs["dx"], max(errs.values()), 2e-2, "bf16", "axis_mlp_bwd_fused")
+    assert errs["dx"] < 1e-2 and max(errs.values()) < 2e-2, errs
+    assert L.lib().tante_axis_mlp_bwd_fused_supported(24, inner) == 0 and L.lib().tante_axis_mlp_bwd_fused_supported(n, 96) == 0
