@@ -459,8 +459,9 @@ int tante_fold_bwd(const float* GW, const float* Gb, const float* W, const float
  * fill per weight and step. */
 int tante_fold_bwd_clear(float* GW, float* Gb, const float* W, const float* gamma, const float* beta, int N, int K, float* dW, float* db,
                          float* dgamma, float* dbeta, void* stream);
-/* The propagator's backward WITH its parameter gradients in one launch, bf16 operands on the matrix cores (axis lengths 16 / 32 / 48,
- * inner % 64 == 0; tante_axis_mlp_bwd_fused_supported says so): dx = dy + W1^T (gelu'(pre) (W2^T dy)) with pre = W1 x + b1, and
+/* The propagator's backward WITH its parameter gradients in one launch: bf16 operands on the matrix cores for axis lengths 16 / 32 / 48
+ * (inner % 64 == 0), fp32 on the vector units -- tante_axis_mlp_bwd's own expressions -- for 4 (inner % 4 == 0);
+ * tante_axis_mlp_bwd_fused_supported says which shapes: dx = dy + W1^T (gelu'(pre) (W2^T dy)) with pre = W1 x + b1, and
  * dW1 += <dpre, x>, db1 += sum dpre, dW2 += <dy, gelu(pre)>, db2 += sum dy (all four ADDED into).  x, dy, dx: fp32 (outer, n, inner), 16-byte
  * aligned.  Replaces tante_axis_mlp_bwd + two tante_axis_wgrad on the bf16 train path (attn_backbone.py:111-119, 140-145). */
 int tante_axis_mlp_bwd_fused_supported(int n, int64_t inner);

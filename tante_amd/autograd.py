@@ -783,10 +783,11 @@ class AxisMlpFn(Function):
         x, w1, b1, w2 = ctx.saved_tensors
         outer, n, inner = ctx.dims
         dy = dy.contiguous()
-        if (AXIS_BWD_FUSED and ctx.compute == L.BF16 and x.dtype == torch.float32 and dy.dtype == torch.float32 and x.is_contiguous()
+        if (AXIS_BWD_FUSED and (ctx.compute == L.BF16 or n == 4) and x.dtype == torch.float32 and dy.dtype == torch.float32 and x.is_contiguous()
                 and L.lib().tante_axis_mlp_bwd_fused_supported(n, inner)):
-            # bf16 train path, axis lengths 16 / 32 / 48: dx AND the four parameter gradients in one launch on the matrix cores (x and dy
-            # read once, nothing materialised for separate weight-gradient launches)
+            # dx AND the four parameter gradients in one launch (x and dy read once, nothing materialised for separate weight-gradient
+            # launches): axis lengths 16 / 32 / 48 on the matrix cores with bf16 operands (bf16 train path only), 4 on the vector
+            # units in fp32 (the expressions of the kernels it replaces: every compute mode)
             slots = [_grad_slot(q) for q in ctx.params]
             direct = all(g is not None for g in slots)
             if direct:

@@ -298,6 +298,88 @@ __global__ __launch_bounds__(256) void ab_reduce_kernel(const float* __restrict_
   atomicAdd(dst, (a0 + a1) + (a2 + a3));
 }
 
+// ---- the temporal propagator (n = 4): the same fusion on the vector units, fp32 throughout -------------------------------------------------
+// (instantiated for N = 4 only: at N = 8 the per-thread state -- two weight matrices, 144 partial sums -- is 477 registers, and that build
+// faulted on the GPU; no configuration has such an axis, so it stays on the three-launch path)
+// A thread owns 4 consecutive inner elements for all n positions (float4 streams of x and dy, stride `inner`); the n x n products are
+// 3 n^2 FMAs per element -- nothing at n = 4 -- and the parameter gradients are per-thread partial sums (2 n^2 + 2 n values), reduced
+// over the wave, the workgroup and then as ab_reduce_kernel's slabs.  Before: tante_axis_mlp_bwd wrote gelu(pre) and dpre (2 x 25 MB)
+// for two tante_axis_wgrad launches: 57 us and 225 MB per call at cfg3 against 75 MB here.  Exact erf GELU (the expression of the
+// kernel it replaces), so it serves the fp32 parity path too.
+template <int N>
+__global__ __launch_bounds__(256) void axis_bwd_small_kernel(const float* __restrict__ x, const float* __restrict__ dy, long outer, long inner4,
+                                                             const float* __restrict__ w1, const float* __restrict__ b1,
+                                                             const float* __restrict__ w2, float* __restrict__ dx, float* __restrict__ dW1,
+                                                             float* __restrict__ db1, float* __restrict__ dW2, float* __restrict__ db2,
+                                                             float* __restrict__ ws) {
+  constexpr int NV = 2 * N * N + 2 * N;
+  __shared__ float part[4][NV];
+  float W1[N][N], W2[N][N], B1[N];
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    B1[j] = b1[j];
+#pragma unroll
+    for (int p = 0; p < N; ++p) { W1[j][p] = w1[j * N + p]; W2[j][p] = w2[j * N + p]; }
+  }
+  float g[NV];          // [dW1 (j, p)][dW2 (p, j)][db1 (j)][db2 (p)]
+#pragma unroll
+  for (int i = 0; i < NV; ++i) g[i] = 0.f;
+  const long total = outer * inner4;
+  for (long col = (long)blockIdx.x * 256 + threadIdx.x; col < total; col += (long)gridDim.x * 256) {
+    const long o = col / inner4, i4 = col - o * inner4;
+    const f32x4* xp = (const f32x4*)x + o * N * inner4 + i4;
+    const f32x4* gp = (const f32x4*)dy + o * N * inner4 + i4;
+    f32x4 xv[N], gy[N], gx[N];
+#pragma unroll
+    for (int p = 0; p < N; ++p) { xv[p] = xp[p * inner4]; gy[p] = gp[p * inner4]; gx[p] = gy[p]; }
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      f32x4 pre = f32x4{B1[j], B1[j], B1[j], B1[j]}, da = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int p = 0; p < N; ++p) { pre += W1[j][p] * xv[p]; da += W2[p][j] * gy[p]; }
+      f32x4 act, dp;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {      // gelu and its derivative share the erf: Phi = (1 + erf(x / sqrt 2)) / 2, gelu = x Phi, gelu' = Phi + x phi(x)
+        const float xe = pre[e], cdf = 0.5f * (1.0f + erff(xe * 0.70710678118654752440f));
+        act[e] = xe * cdf;
+        dp[e] = da[e] * (cdf + xe * 0.39894228040143267794f * expf(-0.5f * xe * xe));
+      }
+#pragma unroll
+      for (int p = 0; p < N; ++p) {
+        gx[p] += W1[j][p] * dp;
+        const f32x4 a = dp * xv[p], b = gy[p] * act;
+        g[j * N + p] += (a[0] + a[1]) + (a[2] + a[3]);                  // dW1[j][p] = <dpre_j, x_p>
+        g[N * N + p * N + j] += (b[0] + b[1]) + (b[2] + b[3]);          // dW2[p][j] = <dy_p, gelu(pre)_j>
+      }
+      g[2 * N * N + j] += (dp[0] + dp[1]) + (dp[2] + dp[3]);
+    }
+#pragma unroll
+    for (int p = 0; p < N; ++p) {
+      g[2 * N * N + N + p] += (gy[p][0] + gy[p][1]) + (gy[p][2] + gy[p][3]);
+      ((f32x4*)dx + o * N * inner4 + i4)[p * inner4] = gx[p];
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    float v = g[i];
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    if (lane == 0) part[wave][i] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < NV) {
+    const int i = threadIdx.x;
+    const float v = (part[0][i] + part[1][i]) + (part[2][i] + part[3][i]);
+    if (ws) {
+      ws[(long)blockIdx.x * NV + i] = v;
+    } else {
+      float* dst = i < N * N ? dW1 + i : (i < 2 * N * N ? dW2 + (i - N * N) : (i < 2 * N * N + N ? db1 + (i - 2 * N * N) : db2 + (i - 2 * N * N - N)));
+      atomicAdd(dst, v);
+    }
+  }
+}
+
 template <int MT>
 void ab_launch(const float* x, const float* dy, long outer, long inner, const float* w1, const float* b1, const float* w2, float* dx, float* dW1,
                float* db1, float* dW2, float* db2, float* ws, hipStream_t s) {
@@ -321,7 +403,23 @@ void ab_launch(const float* x, const float* dy, long outer, long inner, const fl
 }  // namespace
 
 extern "C" int tante_axis_mlp_bwd_fused_supported(int n, int64_t inner) {
+  if (n == 4) return inner > 0 && inner % 4 == 0;      // the temporal axis: the fp32 vector-unit form (exact in every compute mode)
   return (n == 16 || n == 32 || n == 48) && inner > 0 && inner % (AB_CT * AB_NG) == 0;
+}
+
+template <int N>
+static void ab_launch_small(const float* x, const float* dy, long outer, long inner, const float* w1, const float* b1, const float* w2, float* dx,
+                            float* dW1, float* db1, float* dW2, float* db2, float* ws, hipStream_t s) {
+  const long total = outer * (inner / 4);
+  static const long cap_env = getenv("TANTE_AXIS_BWD_SMALL_WGS") ? atol(getenv("TANTE_AXIS_BWD_SMALL_WGS")) : 0;
+  long wgs = (total + 255) / 256;
+  const long cap = cap_env > 0 ? cap_env : 512;      // measured at cfg3 (393 k float4 columns): 37.5 us at 512, 40.6 at 256, 45.5 at 1024, 54 at 2048
+  if (wgs > cap) wgs = cap;
+  const int nv = 2 * N * N + 2 * N;
+  hipLaunchKernelGGL((axis_bwd_small_kernel<N>), dim3((unsigned)wgs), dim3(256), 0, s, x, dy, outer, inner / 4, w1, b1, w2, dx, dW1, db1, dW2, db2, ws);
+  if (ws)
+    hipLaunchKernelGGL(ab_reduce_kernel, dim3((unsigned)((nv + 255) / 256), (unsigned)(wgs >= 64 ? 16 : 1)), dim3(256), 0, s, ws, (int)wgs, nv, N * N, N,
+                       dW1, db1, dW2, db2);
 }
 
 extern "C" int tante_axis_mlp_bwd_fused_ws(const float* x, const float* dy, int64_t outer, int n, int64_t inner, const float* w1, const float* b1,
@@ -335,10 +433,12 @@ extern "C" int tante_axis_mlp_bwd_fused_ws(const float* x, const float* dy, int6
                                            const float* w2, float* dx, float* dW1, float* db1, float* dW2, float* db2, void* workspace,
                                            int64_t workspace_bytes, void* stream) {
   if (!x || !dy || !w1 || !b1 || !w2 || !dx || !dW1 || !db1 || !dW2 || !db2 || outer <= 0) TANTE_FAIL(-1, "tante_axis_mlp_bwd_fused: bad argument");
-  if (!tante_axis_mlp_bwd_fused_supported(n, inner)) TANTE_FAIL(-2, "tante_axis_mlp_bwd_fused: n in {16, 32, 48} and inner %% 64 == 0 (got %d, %ld)", n, (long)inner);
+  if (!tante_axis_mlp_bwd_fused_supported(n, inner))
+    TANTE_FAIL(-2, "tante_axis_mlp_bwd_fused: n = 4 with inner %% 4 == 0, or n in {16, 32, 48} with inner %% 64 == 0 (got %d, %ld)", n, (long)inner);
   if ((((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx) & 15)) TANTE_FAIL(-2, "tante_axis_mlp_bwd_fused: operands must be 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
   float* ws = (workspace && workspace_bytes >= TANTE_AW_WS_FLOATS * (int64_t)sizeof(float) && ((uintptr_t)workspace % 16) == 0) ? (float*)workspace : nullptr;
+  if (n == 4) { ab_launch_small<4>(x, dy, outer, inner, w1, b1, w2, dx, dW1, db1, dW2, db2, ws, s); TANTE_CHECK_LAUNCH(); return 0; }
   switch (n / 16) {
     case 1: ab_launch<1>(x, dy, outer, inner, w1, b1, w2, dx, dW1, db1, dW2, db2, ws, s); break;
     case 2: ab_launch<2>(x, dy, outer, inner, w1, b1, w2, dx, dW1, db1, dW2, db2, ws, s); break;

@@ -608,7 +608,7 @@ def test_fold_bwd_multi_equals_single_launches(dev):
     assert L.lib().tante_fold_bwd_multi(C.byref(arr), 0, 1, s) != 0                                  # n <= 0 is refused
 
 
-@pytest.mark.parametrize("outer,n,inner", [(6, 48, 128), (3, 16, 448), (5, 32, 64), (32, 16, 256)])
+@pytest.mark.parametrize("outer,n,inner", [(6, 48, 128), (3, 16, 448), (5, 32, 64), (32, 16, 256), (3, 4, 1236), (8, 4, 40000)])
 def test_axis_mlp_bwd_fused_against_float64(dev, outer, n, inner):
     """tante_axis_mlp_bwd_fused (the propagator's backward and its four parameter gradients in one MFMA launch, bf16 operands) against
     float64 autograd of  y = x + W2 gelu(W1 x + b1) + b2  along the middle axis of (outer, n, inner) -- attn_backbone.py:111-119, 140-145.
@@ -635,6 +635,11 @@ def test_axis_mlp_bwd_fused_against_float64(dev, outer, n, inner):
     errs = {"dx": rel_err(dx.double().cpu(), xd.grad), "dW1": rel_err((dW1 - 0.25).double().cpu(), w1d.grad),
             "db1": rel_err((db1 - 0.25).double().cpu(), b1d.grad), "dW2": rel_err((dW2 - 0.25).double().cpu(), w2d.grad),
             "db2": rel_err((db2 - 0.25).double().cpu(), b2d.grad)}
-    record_parity(errs["dx"], max(errs.values()), 2e-2, "bf16", "axis_mlp_bwd_fused")
-    assert errs["dx"] < 1e-2 and max(errs.values()) < 2e-2, errs
-    assert L.lib().tante_axis_mlp_bwd_fused_supported(24, inner) == 0 and L.lib().tante_axis_mlp_bwd_fused_supported(n, 96) == 0
+    small = n == 4                     # the temporal axis runs in fp32 on the vector units: fp32 bars
+    record_parity(errs["dx"], max(errs.values()), 1e-5 if small else 2e-2, "fp32" if small else "bf16", "axis_mlp_bwd_fused")
+    if small:
+        assert max(errs.values()) < 1e-5, errs
+    else:
+        assert errs["dx"] < 1e-2 and max(errs.values()) < 2e-2, errs
+    assert L.lib().tante_axis_mlp_bwd_fused_supported(24, inner) == 0 and L.lib().tante_axis_mlp_bwd_fused_supported(48, 96) == 0 \
+        and L.lib().tante_axis_mlp_bwd_fused_supported(8, 64) == 0

@@ -19,7 +19,7 @@ def main():
     dev = torch.device("cuda:0")
     s = torch.cuda.current_stream().cuda_stream
     flush = torch.zeros(128 << 20, dtype=torch.float32, device=dev)
-    for name, outer, n, inner in (("W", 32 * 16, 48, 256), ("H", 32, 16, 48 * 256)):
+    for name, outer, n, inner in (("W", 32 * 16, 48, 256), ("H", 32, 16, 48 * 256), ("T", 8, 4, 16 * 48 * 256)):
         x, dy = torch.randn(outer, n, inner, device=dev), torch.randn(outer, n, inner, device=dev)
         w1, w2, b1 = torch.randn(n, n, device=dev) / n ** 0.5, torch.randn(n, n, device=dev) / n ** 0.5, torch.randn(n, device=dev) * 0.1
         dx, h, dp = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
