@@ -262,6 +262,45 @@ __global__ __launch_bounds__(256) void film_pos_bwd_kernel(const float* __restri
     atomicAdd(&db[t * C + c], sb);
   }
 }
+// the same for C = 256: a thread owns four channels (float4 streams: a row is one 1 KiB access of 64 lanes), four rows in flight per
+// workgroup and eight per thread -- the kernel above reads 4 bytes per lane and 64 rows one after the other (2 TB/s by the counters)
+__global__ __launch_bounds__(256) void film_pos_bwd256_kernel(const float* __restrict__ dy, const float* __restrict__ v, const float* __restrict__ a,
+                                                              long HW, int T, float* __restrict__ dv, float* __restrict__ da,
+                                                              float* __restrict__ db) {
+  constexpr int C4 = 64, ROWS = 32;
+  __shared__ f32x4 red[2][3][C4];
+  const long bt = blockIdx.y;
+  const int t = (int)(bt % T), r = threadIdx.x >> 6, c4 = threadIdx.x & 63;
+  const long h0 = (long)blockIdx.x * ROWS;
+  const f32x4 av = ((const f32x4*)a)[t * C4 + c4];
+  f32x4 sa = f32x4{0.f, 0.f, 0.f, 0.f}, sb = sa;
+  f32x4 g[ROWS / 4], x[ROWS / 4];
+#pragma unroll
+  for (int it = 0; it < ROWS / 4; ++it) {
+    const long hw = h0 + it * 4 + r;
+    const bool in = hw < HW;
+    g[it] = in ? ((const f32x4*)dy)[(bt * HW + hw) * C4 + c4] : f32x4{0.f, 0.f, 0.f, 0.f};
+    x[it] = in ? ((const f32x4*)v)[(bt * HW + hw) * C4 + c4] : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll
+  for (int it = 0; it < ROWS / 4; ++it) {
+    const long hw = h0 + it * 4 + r;
+    if (hw < HW) ((f32x4*)dv)[(bt * HW + hw) * C4 + c4] = g[it] * av;
+    sa += g[it] * x[it];
+    sb += g[it];
+  }
+  if (r) { red[0][r - 1][c4] = sa; red[1][r - 1][c4] = sb; }
+  __syncthreads();
+  if (r == 0) {
+    sa += (red[0][0][c4] + red[0][1][c4]) + red[0][2][c4];
+    sb += (red[1][0][c4] + red[1][1][c4]) + red[1][2][c4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      atomicAdd(&da[t * 256 + 4 * c4 + e], sa[e]);
+      atomicAdd(&db[t * 256 + 4 * c4 + e], sb[e]);
+    }
+  }
+}
 // ds[hw][c] = sum over bt of dy[(bt*HW + hw)*C + c]
 __global__ void film_pos_ds_kernel(const float* __restrict__ dy, long BT, long HW, int C, float* __restrict__ ds) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1326,8 +1365,11 @@ extern "C" int tante_film_pos_bwd(const float* dy, const float* v, const float* 
   if (tante_zero_async(da, (size_t)T * C * sizeof(float), s) != hipSuccess || tante_zero_async(db, (size_t)T * C * sizeof(float), s) != hipSuccess)
     TANTE_FAIL(-3, "tante_film_pos_bwd: memset failed");
   const long chunk = 64;
-  hipLaunchKernelGGL(film_pos_bwd_kernel, dim3((unsigned)((HW + chunk - 1) / chunk), (unsigned)BT), dim3(256), 0, s, dy, v, a, (long)HW, C, T, chunk,
-                     dv, da, db);
+  if (C == 256 && ((((uintptr_t)dy | (uintptr_t)v | (uintptr_t)a | (uintptr_t)dv) & 15) == 0))
+    hipLaunchKernelGGL(film_pos_bwd256_kernel, dim3((unsigned)((HW + 31) / 32), (unsigned)BT), dim3(256), 0, s, dy, v, a, (long)HW, T, dv, da, db);
+  else
+    hipLaunchKernelGGL(film_pos_bwd_kernel, dim3((unsigned)((HW + chunk - 1) / chunk), (unsigned)BT), dim3(256), 0, s, dy, v, a, (long)HW, C, T, chunk,
+                       dv, da, db);
   hipLaunchKernelGGL(film_pos_ds_kernel, dim3((unsigned)((HW * C + 255) / 256)), dim3(256), 0, s, dy, (long)BT, (long)HW, C, ds);
   TANTE_CHECK_LAUNCH();
   return 0;

@@ -643,3 +643,24 @@ def test_axis_mlp_bwd_fused_against_float64(dev, outer, n, inner):
         assert errs["dx"] < 1e-2 and max(errs.values()) < 2e-2, errs
     assert L.lib().tante_axis_mlp_bwd_fused_supported(24, inner) == 0 and L.lib().tante_axis_mlp_bwd_fused_supported(48, 96) == 0 \
         and L.lib().tante_axis_mlp_bwd_fused_supported(8, 64) == 0
+
+
+@pytest.mark.parametrize("B,T,HW,C", [(2, 4, 77, 256), (1, 3, 32, 256), (2, 2, 50, 64)])
+def test_film_pos_backward_against_autograd(dev, B, T, HW, C):
+    """tante_film_pos_bwd (y = v a[t] + b[t] + s[hw]; tante.py:136-141 with t_emb folded into b): dv, da, db, ds against torch autograd;
+    C = 256 takes the float4 kernel (ragged HW: the last workgroup's rows are partly out of range), other widths the scalar one."""
+    from tante_amd import _lib as L
+    g = torch.Generator().manual_seed(B * 100 + HW)
+    v = torch.randn(B * T * HW, C, generator=g).to(dev).requires_grad_()
+    a = torch.randn(T, C, generator=g).to(dev).requires_grad_()
+    b = torch.randn(T, C, generator=g).to(dev).requires_grad_()
+    s = torch.randn(HW, C, generator=g).to(dev).requires_grad_()
+    dy = torch.randn(B * T * HW, C, generator=g).to(dev)
+    y = v.view(B, T, HW, C) * a[None, :, None, :] + b[None, :, None, :] + s[None, None]
+    (y * dy.view(B, T, HW, C)).sum().backward()
+    dv, da, db, ds = torch.empty_like(v), torch.empty(T, C, device=dev), torch.empty(T, C, device=dev), torch.empty(HW, C, device=dev)
+    L.check(L.lib().tante_film_pos_bwd(dy.data_ptr(), v.data_ptr(), a.data_ptr(), B * T, HW, C, T, dv.data_ptr(), da.data_ptr(), db.data_ptr(),
+                                       ds.data_ptr(), torch.cuda.current_stream().cuda_stream))
+    assert torch.allclose(dv, v.grad, rtol=1e-6, atol=1e-6)
+    for got, ref in ((da, a.grad), (db, b.grad), (ds, s.grad)):
+        assert rel_err(got, ref) < 1e-5
