@@ -507,6 +507,11 @@ typedef struct TanteRowMat {
  * the tiles that are staged anyway.  MFMA in `compute`, fp32 atomics across the row split. */
 int tante_wgrad(const TanteRowMat* U, const TanteRowMat* V, int64_t R, int I, int J, float* dW, float* dbias, int layout, int P,
                 int C_other, int swap, int compute, int accumulate, void* stream);
+/* The same with a caller-owned scratch buffer (16-byte aligned; one call at a time per buffer): a gradient that fits ONE output tile (I, J <= 64
+ * -- the skinny gradients of the convolution stages) is then cut into many more row ranges whose partials are stored there and summed by a
+ * second kernel, instead of a few hundred workgroups adding into the same I x J addresses.  Null: tante_wgrad. */
+int tante_wgrad_ws(const TanteRowMat* U, const TanteRowMat* V, int64_t R, int I, int J, float* dW, float* dbias, int layout, int P, int C_other,
+                   int swap, int compute, int accumulate, void* workspace, int64_t workspace_bytes, void* stream);
 /* The same for n_seg operand pairs of R rows each, contracted as one row range (dW = sum_g U_g^T V_g): the uses of one weight in a
  * back-propagation through time share a launch and one atomic epilogue where the shapes allow (dense bf16 rows, I and J multiples of
  * 128, R % 32 == 0, at most 8 segments per launch); otherwise the segments run one by one. */

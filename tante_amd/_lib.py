@@ -140,6 +140,7 @@ SIGNATURES = {
     "tante_set_seed_mix": ([c_vp], c_i32),
     "tante_axis_wgrad_ws": ([c_vp, c_vp, c_i64, c_i32, c_i64, c_vp, c_vp, c_i32, c_vp, c_i64, c_vp], c_i32),
     "tante_wgrad": ([C.POINTER(RowMat), C.POINTER(RowMat), c_i64, c_i32, c_i32, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp], c_i32),
+    "tante_wgrad_ws": ([C.POINTER(RowMat), C.POINTER(RowMat), c_i64, c_i32, c_i32, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp], c_i32),
     "tante_wgrad_multi_ws": ([c_vp, c_vp, c_i32, c_i64, c_i32, c_i32, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp], c_i32),
     "tante_wgrad_multi": ([c_vp, c_vp, c_i32, c_i64, c_i32, c_i32, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp], c_i32),
     "tante_clip_value": ([c_vp, c_i64, c_f32, c_vp], c_i32),

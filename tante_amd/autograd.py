@@ -288,8 +288,12 @@ def wgrad(U: L.RowMat, V: L.RowMat, R: int, I: int, J: int, out_shape, compute: 
     db = None
     if with_bias:
         db = db_into if acc else torch.empty(I, dtype=torch.float32, device=device)
-    L.check(L.lib().tante_wgrad(C.byref(U), C.byref(V), R, I, J, dW.data_ptr(), None if db is None else db.data_ptr(), layout, P,
-                                C_other, int(swap), compute, int(acc), _s()), "tante_wgrad")
+    # the scratch buffer of the shared launches serves the single-tile gradients too (split-R partials summed by a second kernel); not when
+    # weight gradients run on a side stream beside the main stream's users of the same buffer
+    ws = None if (SIDE_STREAM_WGRAD or I > 64 or J > 64 or device is None and into is None) else _wgrad_workspace(dW.device)
+    L.check(L.lib().tante_wgrad_ws(C.byref(U), C.byref(V), R, I, J, dW.data_ptr(), None if db is None else db.data_ptr(), layout, P,
+                                   C_other, int(swap), compute, int(acc), None if ws is None else ws.data_ptr(), 0 if ws is None else ws.numel(),
+                                   _s()), "tante_wgrad")
     return (dW, db) if with_bias else dW
 
 

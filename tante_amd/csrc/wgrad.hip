@@ -205,7 +205,8 @@ struct Stager {
 // parameters: inlining the generic gather (integer divisions) at all 64 element sites made a 125k-instruction kernel.
 template <bool BF16, int T, int MU, int MV>
 __global__ __launch_bounds__(256) void wgrad_kernel(const TanteRowMat U, const TanteRowMat V, long R, int I, int J, long rows_per_split,
-                                                    float* __restrict__ dW, float* __restrict__ dbias, int layout, int P, int Co, int swap) {
+                                                    float* __restrict__ dW, float* __restrict__ dbias, int layout, int P, int Co, int swap,
+                                                    float* __restrict__ slab = nullptr, float* __restrict__ bias_slab = nullptr) {
   using elem_t = typename std::conditional<BF16, unsigned short, float>::type;
   constexpr int STRIDE = RC + (BF16 ? 8 : 4);  // elements per LDS row (one operand column, RC rows + pad; multiple of 16 bytes)
   constexpr int NT = T / 32;                   // 16 x 16 MFMA tiles per wave per side
@@ -269,6 +270,20 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const TanteRowMat U, const T
     }
   }
   // D[row = i][col = j]: lane holds j = l15, i = 4*kk + reg
+  if (slab) {   // single-tile outputs with a workspace: the split's partial (valid entries only, [i][j]) for wgrad_gen_reduce_kernel
+    float* mine = slab + (long)blockIdx.z * I * J;
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+      for (int b = 0; b < NT; ++b)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int i = wi * (T / 2) + a * 16 + kk * 4 + rg, j = wj * (T / 2) + b * 16 + l15;
+          if (i < I && j < J) mine[i * J + j] = acc[a][b][rg];
+        }
+    if (dbias && tid < T && tid < I) bias_slab[(long)blockIdx.z * I + tid] = bsum;
+    return;
+  }
 #pragma unroll
   for (int a = 0; a < NT; ++a)
 #pragma unroll
@@ -281,22 +296,54 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const TanteRowMat U, const T
   if (do_bias && tid < T && i0 + tid < I) atomicAdd(&dbias[i0 + tid], bsum);
 }
 
+// second stage of the single-tile form: entry e of the partials ([i][j], then the bias partials), summed over a chunk of the splits
+__global__ __launch_bounds__(256) void wgrad_gen_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ bias_slab, int n_split, int I, int J,
+                                                               float* __restrict__ dW, float* __restrict__ dbias, int layout, int P, int Co, int swap) {
+  const int e = blockIdx.x * 256 + threadIdx.x, ne = I * J + (dbias ? I : 0);
+  if (e >= ne) return;
+  const int per = (n_split + gridDim.y - 1) / gridDim.y, s0 = blockIdx.y * per, s1 = min(n_split, s0 + per);
+  if (s0 >= s1) return;
+  const bool isb = e >= I * J;
+  const long st = isb ? I : (long)I * J;
+  const float* p = (isb ? bias_slab + (e - I * J) : slab + e) + (long)s0 * st;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int s = s0;
+  for (; s + 8 <= s1; s += 8, p += 8 * st) {
+    const float v0 = p[0], v1 = p[st], v2 = p[2 * st], v3 = p[3 * st], v4 = p[4 * st], v5 = p[5 * st], v6 = p[6 * st], v7 = p[7 * st];
+    a0 += v0 + v4; a1 += v1 + v5; a2 += v2 + v6; a3 += v3 + v7;
+  }
+  for (; s < s1; ++s, p += st) a0 += p[0];
+  const float sum = (a0 + a1) + (a2 + a3);
+  if (isb) atomicAdd(&dbias[e - I * J], sum);
+  else atomicAdd(&dW[out_index(layout, e / J, e % J, I, J, P, Co, swap)], sum);
+}
+
 template <bool BF16, int T>
 void launch_wgrad(const TanteRowMat& U, const TanteRowMat& V, long R, int I, int J, float* dW, float* dbias, int layout, int P, int Co, int swap,
-                  int mu, int mv, hipStream_t s) {
+                  int mu, int mv, hipStream_t s, float* ws = nullptr, int64_t ws_bytes = 0) {
   const int ti = (I + T - 1) / T, tj = (J + T - 1) / T;
   static const int wg_target = getenv("TANTE_WGRAD_WGS") ? atoi(getenv("TANTE_WGRAD_WGS")) : 512;
-  long split = wg_target / ((long)ti * tj);   // two workgroups per CU; fewer splits = less atomic traffic
+  // a single output tile with a workspace (the skinny weight gradients of the convolution stages: 98 k rows into 64 x 16 values): the
+  // kernel is latency-bound -- one staged chunk in flight per workgroup -- and 384 workgroups of 4 chunks each left the chip 1.5
+  // workgroups per CU (0.7 TB/s); with the partials stored and summed by a second kernel (no 384-deep same-address atomics) the row
+  // range is cut into up to 1 536 pieces of at least one chunk
+  static const int slab_target = getenv("TANTE_WGRAD_SLAB_WGS") ? atoi(getenv("TANTE_WGRAD_SLAB_WGS")) : 1536;
+  const bool slab_ok = ws != nullptr && ti == 1 && tj == 1 && slab_target > 0 && R >= 8 * RC;
+  long split = (slab_ok ? slab_target : wg_target) / ((long)ti * tj);   // two workgroups per CU; fewer splits = less atomic traffic
   if (split < 1) split = 1;
-  const long max_split = (R + 4 * RC - 1) / (4 * RC);
+  const long max_split = slab_ok ? (R + RC - 1) / RC : (R + 4 * RC - 1) / (4 * RC);
   if (split > max_split) split = max_split;
+  if (slab_ok && split * ((long)I * J + I) * 4 > ws_bytes) split = ws_bytes / (((long)I * J + I) * 4);
   if (split > 65535) split = 65535;
   long per = (R + split - 1) / split;
   per = (per + RC - 1) / RC * RC;
   split = (R + per - 1) / per;
   const size_t lds = 2 * (size_t)T * (RC + (BF16 ? 8 : 4)) * (BF16 ? 2 : 4);
   const dim3 grid(ti, tj, (unsigned)split);
-#define TANTE_WG(MUV, MVV) hipLaunchKernelGGL((wgrad_kernel<BF16, T, MUV, MVV>), grid, dim3(256), lds, s, U, V, R, I, J, per, dW, dbias, layout, P, Co, swap)
+  const bool use_slab = slab_ok && split > 1;
+  float* slab = use_slab ? ws : nullptr;
+  float* bias_slab = use_slab ? ws + split * (long)I * J : nullptr;
+#define TANTE_WG(MUV, MVV) hipLaunchKernelGGL((wgrad_kernel<BF16, T, MUV, MVV>), grid, dim3(256), lds, s, U, V, R, I, J, per, dW, dbias, layout, P, Co, swap, slab, bias_slab)
   if (mu == ST_ROWMAJOR && mv == ST_ROWMAJOR) TANTE_WG(ST_ROWMAJOR, ST_ROWMAJOR);        // linear layers
   else if (mu == ST_COLMAJOR && mv == ST_COLMAJOR) TANTE_WG(ST_COLMAJOR, ST_COLMAJOR);   // axis propagators
   else if (mu == ST_ROWMAJOR && mv == ST_PATCH_NHWC) TANTE_WG(ST_ROWMAJOR, ST_PATCH_NHWC);   // conv / transposed-conv stages on channels-last images
@@ -304,6 +351,11 @@ void launch_wgrad(const TanteRowMat& U, const TanteRowMat& V, long R, int I, int
   else if (mu == ST_ROWMAJOR) TANTE_WG(ST_ROWMAJOR, ST_GENERIC);                         // V = patches of the channels-first input / output
   else TANTE_WG(ST_GENERIC, ST_GENERIC);
 #undef TANTE_WG
+  if (use_slab) {
+    const int ne = I * J + (dbias ? I : 0);
+    hipLaunchKernelGGL(wgrad_gen_reduce_kernel, dim3((unsigned)((ne + 255) / 256), (unsigned)(split >= 64 ? 16 : 1)), dim3(256), 0, s, slab, bias_slab,
+                       (int)split, I, J, dW, dbias, layout, P, Co, swap);
+  }
 }
 
 // ---- fast path: both operands dense row-major bf16, I and J multiples of 128, R a multiple of 32 -------------------------------
@@ -663,24 +715,30 @@ static bool wgrad_tr_launch(const TanteRowMat* U, const TanteRowMat* V, int n_se
 }
 
 static int wgrad_one(const TanteRowMat* U, const TanteRowMat* V, int64_t R, int I, int J, float* dW, float* dbias, int layout, int P, int C_other,
-                     int swap, int compute, hipStream_t s) {
+                     int swap, int compute, hipStream_t s, float* ws = nullptr, int64_t ws_bytes = 0) {
   if (compute == TANTE_BF16 && wgrad_tr_launch(U, V, 1, (long)R, I, J, dW, dbias, layout, P, C_other, swap, s)) {
     TANTE_CHECK_LAUNCH();
     return 0;
   }
   const int mu = rm_stage_mode(*U, I), mv = rm_stage_mode(*V, J);
   if (compute == TANTE_BF16) {
-    if (I > 64 || J > 64) launch_wgrad<true, 128>(*U, *V, (long)R, I, J, dW, dbias, layout, P, C_other, swap, mu, mv, s);
-    else launch_wgrad<true, 64>(*U, *V, (long)R, I, J, dW, dbias, layout, P, C_other, swap, mu, mv, s);
+    if (I > 64 || J > 64) launch_wgrad<true, 128>(*U, *V, (long)R, I, J, dW, dbias, layout, P, C_other, swap, mu, mv, s, ws, ws_bytes);
+    else launch_wgrad<true, 64>(*U, *V, (long)R, I, J, dW, dbias, layout, P, C_other, swap, mu, mv, s, ws, ws_bytes);
   } else {
-    launch_wgrad<false, 64>(*U, *V, (long)R, I, J, dW, dbias, layout, P, C_other, swap, mu, mv, s);
+    launch_wgrad<false, 64>(*U, *V, (long)R, I, J, dW, dbias, layout, P, C_other, swap, mu, mv, s, ws, ws_bytes);
   }
   TANTE_CHECK_LAUNCH();
   return 0;
 }
 
+extern "C" int tante_wgrad_ws(const TanteRowMat* U, const TanteRowMat* V, int64_t R, int I, int J, float* dW, float* dbias, int layout, int P,
+                              int C_other, int swap, int compute, int accumulate, void* workspace, int64_t workspace_bytes, void* stream);
 extern "C" int tante_wgrad(const TanteRowMat* U, const TanteRowMat* V, int64_t R, int I, int J, float* dW, float* dbias, int layout, int P,
                            int C_other, int swap, int compute, int accumulate, void* stream) {
+  return tante_wgrad_ws(U, V, R, I, J, dW, dbias, layout, P, C_other, swap, compute, accumulate, nullptr, 0, stream);
+}
+extern "C" int tante_wgrad_ws(const TanteRowMat* U, const TanteRowMat* V, int64_t R, int I, int J, float* dW, float* dbias, int layout, int P,
+                              int C_other, int swap, int compute, int accumulate, void* workspace, int64_t workspace_bytes, void* stream) {
   if (!U || !V || !dW || R <= 0 || I <= 0 || J <= 0) TANTE_FAIL(-1, "tante_wgrad: bad argument");
   int rc = check_rowmat(*U, "U");
   if (rc) return rc;
@@ -690,7 +748,8 @@ extern "C" int tante_wgrad(const TanteRowMat* U, const TanteRowMat* V, int64_t R
   hipStream_t s = (hipStream_t)stream;
   if (!accumulate && tante_zero_async(dW, (size_t)I * J * sizeof(float), s) != hipSuccess) TANTE_FAIL(-3, "tante_wgrad: memset failed");
   if (!accumulate && dbias && tante_zero_async(dbias, (size_t)I * sizeof(float), s) != hipSuccess) TANTE_FAIL(-3, "tante_wgrad: memset failed");
-  return wgrad_one(U, V, R, I, J, dW, dbias, layout, P, C_other, swap, compute, s);
+  float* ws = (workspace && workspace_bytes > 0 && ((uintptr_t)workspace % 16) == 0) ? (float*)workspace : nullptr;
+  return wgrad_one(U, V, R, I, J, dW, dbias, layout, P, C_other, swap, compute, s, ws, ws ? workspace_bytes : 0);
 }
 
 extern "C" int tante_wgrad_multi(const TanteRowMat* U, const TanteRowMat* V, int n_seg, int64_t R, int I, int J, float* dW, float* dbias,

@@ -664,3 +664,32 @@ def test_film_pos_backward_against_autograd(dev, B, T, HW, C):
     assert torch.allclose(dv, v.grad, rtol=1e-6, atol=1e-6)
     for got, ref in ((da, a.grad), (db, b.grad), (ds, s.grad)):
         assert rel_err(got, ref) < 1e-5
+
+
+@pytest.mark.parametrize("R,I,J,dt", [(6000, 64, 16, "bf16"), (777, 48, 64, "fp32"), (98304, 64, 16, "bf16")])
+def test_single_tile_wgrad_through_workspace(dev, R, I, J, dt):
+    """tante_wgrad_ws: a weight gradient that fits one output tile, cut into many row ranges whose partials are summed by a second kernel
+    (the skinny gradients of the convolution stages, enc_dec_cnn.py:217-229) -- against float64 and against tante_wgrad (atomics) on the
+    same operands; ragged R (the last chunk is partial), accumulation onto existing values, the bias gradient from the same tiles."""
+    import ctypes as C
+    from tante_amd import _lib as L
+    from tante_amd.autograd import _rm_linear, _wgrad_workspace
+    g = torch.Generator().manual_seed(R + I)
+    tdt = torch.bfloat16 if dt == "bf16" else torch.float32
+    U = torch.randn(R, I, generator=g).to(dev).to(tdt)
+    V = torch.randn(R, J, generator=g).to(dev).to(tdt)
+    ref = U.double().T @ V.double()
+    refb = U.double().sum(0)
+    comp = L.BF16 if dt == "bf16" else L.F32
+    ws = _wgrad_workspace(dev)
+    s = torch.cuda.current_stream().cuda_stream
+    out = {}
+    for name in ("ws", "atomic"):
+        dW, db = torch.full((I, J), 0.5, device=dev), torch.full((I,), 0.5, device=dev)
+        u, v = _rm_linear(U), _rm_linear(V)
+        L.check(L.lib().tante_wgrad_ws(C.byref(u), C.byref(v), R, I, J, dW.data_ptr(), db.data_ptr(), L.W_LINEAR, 0, 0, 0, comp, 1,
+                                       ws.data_ptr() if name == "ws" else None, ws.numel() if name == "ws" else 0, s))
+        out[name] = (dW - 0.5, db - 0.5)
+    tol = 2e-5 if dt == "fp32" else 1e-5          # bf16 operands are exact inputs here: only the accumulation order differs
+    for name, (dW, db) in out.items():
+        assert rel_err(dW, ref) < tol and rel_err(db, refb) < tol, (name, rel_err(dW, ref), rel_err(db, refb))
