@@ -473,6 +473,20 @@ int tante_axis_mlp_bwd_fused(const float* x, const float* dy, int64_t outer, int
 int tante_axis_mlp_bwd_fused_ws(const float* x, const float* dy, int64_t outer, int n, int64_t inner, const float* w1, const float* b1,
                                 const float* w2, float* dx, float* dW1, float* db1, float* dW2, float* db2, void* workspace,
                                 int64_t workspace_bytes, void* stream);
+/* n folds' forward in one launch (tante_fold_fwd's expressions per entry; b may be NULL) -- attn_backbone.py:50-56. */
+typedef struct TanteFoldFwd {
+  const float* W; const float* b; const float* gamma; const float* beta;
+  float* We; float* be;
+  int N, K;
+} TanteFoldFwd;
+int tante_fold_fwd_multi(const TanteFoldFwd* folds, int n, void* stream);
+/* n transposed-fragment streams in one launch: entry e = tante_pack_block_tail_bwd(a, b, c) -> dst (the block-tail stream from
+ * (fc2 weight, folded fc1 weight, out-proj weight), the block-head stream from the three 256-row blocks of the folded in-projection). */
+typedef struct TanteMat3 {
+  const float* a; const float* b; const float* c;
+  void* dst;
+} TanteMat3;
+int tante_pack_block_tail_bwd_multi(const TanteMat3* mats, int n, int C, int hidden, void* stream);
 /* n folds' backward in ONE launch (the train step has two per TransformerBlock, each 1 - 3 MB of work that costs 11 us as a launch of its
  * own); clear != 0: as tante_fold_bwd_clear (every K <= 256).  attn_backbone.py:50-56, as above. */
 typedef struct TanteFold {

@@ -49,6 +49,14 @@ class Fold(C.Structure):      # TanteFold (include/tante_hip.h)
                 ("dbeta", c_vp), ("N", c_i32), ("K", c_i32)]
 
 
+class FoldFwd(C.Structure):      # TanteFoldFwd
+    _fields_ = [("W", c_vp), ("b", c_vp), ("gamma", c_vp), ("beta", c_vp), ("We", c_vp), ("be", c_vp), ("N", c_i32), ("K", c_i32)]
+
+
+class Mat3(C.Structure):         # TanteMat3
+    _fields_ = [("a", c_vp), ("b", c_vp), ("c", c_vp), ("dst", c_vp)]
+
+
 class BlockTrain(C.Structure):
     _fields_ = [("out", c_vp), ("xh1", c_vp), ("qkv", c_vp), ("o", c_vp), ("xh2", c_vp), ("hpre", c_vp), ("act", c_vp),
                 ("st1", c_vp), ("x1", c_vp), ("st2", c_vp), ("p_drop", c_f32), ("seed_attn", C.c_uint64), ("seed_out", C.c_uint64),
@@ -132,6 +140,8 @@ SIGNATURES = {
     "tante_fold_bwd": ([c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp], c_i32),
     "tante_fold_bwd_clear": ([c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp], c_i32),
     "tante_fold_bwd_multi": ([c_vp, c_i32, c_i32, c_vp], c_i32),
+    "tante_fold_fwd_multi": ([c_vp, c_i32, c_vp], c_i32),
+    "tante_pack_block_tail_bwd_multi": ([c_vp, c_i32, c_i32, c_i32, c_vp], c_i32),
     "tante_axis_mlp_bwd_fused_supported": ([c_i32, c_i64], c_i32),
     "tante_axis_mlp_bwd_fused": ([c_vp, c_vp, c_i64, c_i32, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp], c_i32),
     "tante_axis_mlp_bwd_fused_ws": ([c_vp, c_vp, c_i64, c_i32, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp], c_i32),

@@ -333,12 +333,15 @@ class FoldFn(Function):
     Without the accumulators every use of a folded weight produced a fresh dW / db that autograd summed: ~300 tiny launches per step."""
 
     @staticmethod
-    def forward(ctx, W, b, gamma, beta):
+    def forward(ctx, W, b, gamma, beta, pre=None):
         N, Kk = W.shape
-        We = torch.empty_like(W)
-        be = torch.empty(N, dtype=torch.float32, device=W.device)
-        L.check(L.lib().tante_fold_fwd(W.data_ptr(), None if b is None else b.data_ptr(), gamma.data_ptr(), beta.data_ptr(), N, Kk,
-                                       We.data_ptr(), be.data_ptr(), _s()), "tante_fold_fwd")
+        if pre is not None:      # (We, be) already computed -- by tante_fold_fwd_multi, for every fold of the model in one launch
+            We, be = pre
+        else:
+            We = torch.empty_like(W)
+            be = torch.empty(N, dtype=torch.float32, device=W.device)
+            L.check(L.lib().tante_fold_fwd(W.data_ptr(), None if b is None else b.data_ptr(), gamma.data_ptr(), beta.data_ptr(), N, Kk,
+                                           We.data_ptr(), be.data_ptr(), _s()), "tante_fold_fwd")
         # both accumulators in one buffer that lives ON the weight across steps: the fold's backward kernel zeroes it while reading
         # (tante_fold_bwd_clear), so the steady state has no fill per weight and step (there were two: here and after the backward)
         acc = getattr(W, "_tante_fold_acc", None)
@@ -367,7 +370,7 @@ class FoldFn(Function):
             slots = [_grad_slot(q) for q in ctx.params]
             if all(g is not None for g, q in zip(slots, ctx.params) if q is not None):
                 _FOLD_PENDING.append((ctx.acc_buf, GW, Gb, W, gamma, beta, slots[0], slots[1], slots[2], slots[3], N, Kk))
-                return None, None, None, None
+                return None, None, None, None, None
         _flush_wgrads(GW)                    # the recorded uses of this folded weight run now, as one launch
         if _SIDE["stream"] is not None:      # the accumulators are written by weight-gradient kernels on the side stream
             torch.cuda.current_stream().wait_stream(_SIDE["stream"])
@@ -392,7 +395,7 @@ class FoldFn(Function):
         if not own:
             ctx.acc_buf.zero_()   # consumed: a second backward through a retained graph starts from empty accumulators
         _FOLD_DIRTY.pop(id(ctx.acc_buf), None)      # the kernel (or the fill above) left it zeroed
-        return (None, None, None, None) if direct else (dW, db, dg, dbt)
+        return (None, None, None, None, None) if direct else (dW, db, dg, dbt, None)
 
 
 class LayerNormSkipFn(Function):

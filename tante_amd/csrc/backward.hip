@@ -1003,23 +1003,40 @@ __global__ __launch_bounds__(512) void axis_wgrad_kernel(const float* __restrict
 
 // ---- LayerNorm affine folded into the consumer's weight (train path): We = W diag(gamma), be = b + W beta, and the fold's backward ------
 // One launch each.  fwd: blocks [0, nbe) write We (float4 pieces), the blocks after them one be row per wave.
-__global__ __launch_bounds__(256) void fold_fwd_kernel(const float* __restrict__ W, const float* __restrict__ b, const float* __restrict__ gamma,
-                                                       const float* __restrict__ beta, int N, int K, float* __restrict__ We,
-                                                       float* __restrict__ be, int nbe) {
-  if ((int)blockIdx.x < nbe) {
-    const long i4 = (long)blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void fold_fwd_body(int bid, const float* __restrict__ W, const float* __restrict__ b, const float* __restrict__ gamma,
+                                              const float* __restrict__ beta, int N, int K, float* __restrict__ We, float* __restrict__ be, int nbe) {
+  if (bid < nbe) {
+    const long i4 = (long)bid * 256 + threadIdx.x;
     if (i4 * 4 >= (long)N * K) return;
     const int k = (int)((i4 * 4) % K);
     const f32x4 w = *(const f32x4*)(W + i4 * 4), g = *(const f32x4*)(gamma + k);
     *(f32x4*)(We + i4 * 4) = w * g;
     return;
   }
-  const int n = ((int)blockIdx.x - nbe) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int n = (bid - nbe) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (n >= N) return;
   float s = 0.f;
   for (int k = lane; k < K; k += 64) s += W[(long)n * K + k] * beta[k];
   s = wave_sum(s);
   if (lane == 0) be[n] = (b ? b[n] : 0.f) + s;
+}
+__global__ __launch_bounds__(256) void fold_fwd_kernel(const float* __restrict__ W, const float* __restrict__ b, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, int N, int K, float* __restrict__ We,
+                                                       float* __restrict__ be, int nbe) {
+  fold_fwd_body((int)blockIdx.x, W, b, gamma, beta, N, K, We, be, nbe);
+}
+// every fold of a model in one launch (tante_fold_fwd_multi): 18 launches of ~4.7 us per train step otherwise
+constexpr int FOLDF_MAX = 24;
+struct FoldFwdBatch {
+  const float* W[FOLDF_MAX]; const float* b[FOLDF_MAX]; const float* gamma[FOLDF_MAX]; const float* beta[FOLDF_MAX];
+  float* We[FOLDF_MAX]; float* be[FOLDF_MAX];
+  int N[FOLDF_MAX], K[FOLDF_MAX], nbe[FOLDF_MAX], first[FOLDF_MAX + 1];
+  int n;
+};
+__global__ __launch_bounds__(256) void fold_fwd_multi_kernel(FoldFwdBatch B) {
+  int e = 0;
+  while (e + 1 < B.n && (int)blockIdx.x >= B.first[e + 1]) ++e;
+  fold_fwd_body((int)blockIdx.x - B.first[e], B.W[e], B.b[e], B.gamma[e], B.beta[e], B.N[e], B.K[e], B.We[e], B.be[e], B.nbe[e]);
 }
 // bwd, from the accumulated gradients GW (N, K), Gb (N) of the folded pair:
 //   dW += GW diag(gamma) + Gb beta^T,  db += Gb,  dgamma[k] += sum_n GW[n][k] W[n][k],  dbeta[k] += sum_n W[n][k] Gb[n]
@@ -1276,6 +1293,26 @@ extern "C" int tante_fold_fwd(const float* W, const float* b, const float* gamma
   if (!W || !gamma || !beta || !We || !be || N <= 0 || K <= 0 || K % 4) TANTE_FAIL(-1, "tante_fold_fwd: bad argument (K must be a multiple of 4)");
   const int nbe = (int)(((long)N * K / 4 + 255) / 256);
   hipLaunchKernelGGL(fold_fwd_kernel, dim3(nbe + (N + 3) / 4), dim3(256), 0, (hipStream_t)stream, W, b, gamma, beta, N, K, We, be, nbe);
+  TANTE_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int tante_fold_fwd_multi(const TanteFoldFwd* folds, int n, void* stream) {
+  if (!folds || n <= 0) TANTE_FAIL(-1, "tante_fold_fwd_multi: bad argument");
+  for (int g = 0; g < n; g += FOLDF_MAX) {
+    FoldFwdBatch B;
+    const int m = n - g < FOLDF_MAX ? n - g : FOLDF_MAX;
+    int blocks = 0;
+    for (int e = 0; e < m; ++e) {
+      const TanteFoldFwd& f = folds[g + e];
+      if (!f.W || !f.gamma || !f.beta || !f.We || !f.be || f.N <= 0 || f.K <= 0 || f.K % 4) TANTE_FAIL(-1, "tante_fold_fwd_multi: bad entry %d", g + e);
+      B.W[e] = f.W; B.b[e] = f.b; B.gamma[e] = f.gamma; B.beta[e] = f.beta; B.We[e] = f.We; B.be[e] = f.be;
+      B.N[e] = f.N; B.K[e] = f.K; B.nbe[e] = (int)(((long)f.N * f.K / 4 + 255) / 256); B.first[e] = blocks;
+      blocks += B.nbe[e] + (f.N + 3) / 4;
+    }
+    B.first[m] = blocks;
+    B.n = m;
+    hipLaunchKernelGGL(fold_fwd_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, B);
+  }
   TANTE_CHECK_LAUNCH();
   return 0;
 }

@@ -346,8 +346,9 @@ __global__ __launch_bounds__(256, 2) void block_head_bwd_kernel(BhArgs A) {
 
 // fragment f = (m * 8 + ks) * 16 + g of the TRANSPOSED matrix m: lane (l15, kk) holds  W_m^T[16 g + l15][32 ks + 8 kk + e] =
 // W_m[32 ks + 8 kk + e][16 g + l15];  m = 0: fc2 weight, 1: the folded fc1 weight (W1 diag(gamma2)), 2: out-proj weight
-__global__ void bt_pack_kernel(const float* __restrict__ w2, const float* __restrict__ w1f, const float* __restrict__ wo, char* __restrict__ dst) {
-  const int f = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63, l15 = lane & 15, kk = lane >> 4;
+__device__ __forceinline__ void bt_pack_body(int bid, const float* __restrict__ w2, const float* __restrict__ w1f, const float* __restrict__ wo,
+                                             char* __restrict__ dst) {
+  const int f = bid * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63, l15 = lane & 15, kk = lane >> 4;
   const int g = f % 16, ks = (f / 16) % 8, m = f / 128;
   const float* src = m == 0 ? w2 : (m == 1 ? w1f : wo);
   float v[8];
@@ -356,6 +357,19 @@ __global__ void bt_pack_kernel(const float* __restrict__ w2, const float* __rest
   u32x4 o;
   o[0] = pack_bf16x2(v[0], v[1]); o[1] = pack_bf16x2(v[2], v[3]); o[2] = pack_bf16x2(v[4], v[5]); o[3] = pack_bf16x2(v[6], v[7]);
   *(u32x4*)(dst + (long)f * FS_FRAG + lane * 16) = o;
+}
+__global__ void bt_pack_kernel(const float* __restrict__ w2, const float* __restrict__ w1f, const float* __restrict__ wo, char* __restrict__ dst) {
+  bt_pack_body((int)blockIdx.x, w2, w1f, wo, dst);
+}
+// the transposed-fragment streams of every block in one launch (tante_pack_block_tail_bwd_multi): two per block and train step otherwise
+constexpr int BTP_MAX = 24, BTP_BLOCKS = 3 * 128 / 4;
+struct BtPackBatch {
+  const float* a[BTP_MAX]; const float* b[BTP_MAX]; const float* c[BTP_MAX];
+  char* dst[BTP_MAX];
+};
+__global__ void bt_pack_multi_kernel(BtPackBatch B) {
+  const int e = blockIdx.x / BTP_BLOCKS;
+  bt_pack_body((int)blockIdx.x - e * BTP_BLOCKS, B.a[e], B.b[e], B.c[e], B.dst[e]);
 }
 
 template <int NTT>
@@ -402,6 +416,23 @@ extern "C" int tante_pack_block_tail_bwd(const float* fc2_w, const float* fc1_w_
   if (!fc2_w || !fc1_w_folded || !out_w || !bwd_stream) TANTE_FAIL(-1, "tante_pack_block_tail_bwd: null pointer");
   if (C != FS_C || hidden != FS_C) TANTE_FAIL(-2, "tante_pack_block_tail_bwd: unsupported C=%d hidden=%d", C, hidden);
   hipLaunchKernelGGL(bt_pack_kernel, dim3(3 * 128 / 4), dim3(256), 0, (hipStream_t)stream, fc2_w, fc1_w_folded, out_w, (char*)bwd_stream);
+  TANTE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int tante_pack_block_tail_bwd_multi(const TanteMat3* mats, int n, int C, int hidden, void* stream) {
+  if (!mats || n <= 0) TANTE_FAIL(-1, "tante_pack_block_tail_bwd_multi: bad argument");
+  if (C != FS_C || hidden != FS_C) TANTE_FAIL(-2, "tante_pack_block_tail_bwd_multi: unsupported C=%d hidden=%d", C, hidden);
+  for (int g = 0; g < n; g += BTP_MAX) {
+    BtPackBatch B;
+    const int m = n - g < BTP_MAX ? n - g : BTP_MAX;
+    for (int e = 0; e < m; ++e) {
+      const TanteMat3& t = mats[g + e];
+      if (!t.a || !t.b || !t.c || !t.dst) TANTE_FAIL(-1, "tante_pack_block_tail_bwd_multi: null pointer in entry %d", g + e);
+      B.a[e] = t.a; B.b[e] = t.b; B.c[e] = t.c; B.dst[e] = (char*)t.dst;
+    }
+    hipLaunchKernelGGL(bt_pack_multi_kernel, dim3((unsigned)(m * BTP_BLOCKS)), dim3(256), 0, (hipStream_t)stream, B);
+  }
   TANTE_CHECK_LAUNCH();
   return 0;
 }

@@ -37,15 +37,15 @@ class fold_scope:
         return False
 
 
-def _folded(lin_w, lin_b, ln):
+def _folded(lin_w, lin_b, ln, pre=None):
     """LayerNorm affine folded into the consumer: (W diag(gamma), b + W beta) -- parameter-sized torch expressions whose
-    autograd distributes the gradients back to W, b, gamma, beta."""
+    autograd distributes the gradients back to W, b, gamma, beta.  pre: the pair already computed (prepare_blocks)."""
     if _FOLDS is None or not torch.is_grad_enabled():
         return lin_w * ln.weight[None, :], lin_b + lin_w @ ln.bias
     key = (id(ln), id(lin_w))
     hit = _FOLDS.get(key)
     if hit is None:
-        we, be, gw, gb = FoldFn.apply(lin_w, lin_b, ln.weight, ln.bias)
+        we, be, gw, gb = FoldFn.apply(lin_w, lin_b, ln.weight, ln.bias, pre)
         we._tante_grad, be._tante_grad = gw, gb       # the weight-gradient kernels of every use accumulate here
         hit = _FOLDS[key] = (we, be)
     return hit
@@ -60,6 +60,70 @@ FUSED_HEAD_BACKWARD = __import__("os").environ.get("TANTE_TRAIN_FUSED_HEAD_BWD",
 
 
 BLOCK_CALLS = [0, 0]      # block_train calls / those that took the fused one-node path (GraphedTrainStep checks them at capture)
+BATCH_PREP = __import__("os").environ.get("TANTE_TRAIN_BATCH_PREP", "1") != "0"     # folds and backward fragment streams of all blocks in two launches
+
+
+def prepare_blocks(model, compute: int):
+    """Once per fold scope (= per rollout graph), before the first block runs: the LayerNorm folds of EVERY block in one launch
+    (tante_fold_fwd_multi) and their two backward fragment streams in another (tante_pack_block_tail_bwd_multi), left in the scope under the
+    keys block_train looks up -- per block these were four launches of ~4.7 us of latency each, 36 per train step.  Blocks that will not
+    take the fused one-node path are left to block_train."""
+    if _FOLDS is None or not BATCH_PREP or not torch.is_grad_enabled():
+        return
+    key = ("prepared", id(model))
+    if key in _FOLDS:
+        return
+    _FOLDS[key] = True
+    if not (FUSED_TRAIN_FORWARD and FUSED_TAIL_BACKWARD and compute == L.BF16):
+        return
+    todo = []
+    for bb in getattr(model, "blocks", ()):
+        if not hasattr(bb, "attn_axes"):
+            return
+        for i, axis in enumerate(bb.attn_axes):
+            if axis == "C":
+                continue
+            blk = bb.blocks[i]
+            a, m = blk.attn, blk.mlp
+            if (id(blk.ln1), id(a.in_proj_weight)) in _FOLDS or (id(blk.ln2), id(m[0].weight)) in _FOLDS:
+                continue
+            if not (blk.fused and blk.ln1.eps == blk.ln2.eps and blk.hidden == blk.embed_dim and a.in_proj_bias is not None
+                    and K.block_fused_train_supported(blk.embed_dim, blk.n_head, blk.hidden, K.make_seq(axis, 1, bb.T, bb.H, bb.W).L)
+                    and block_tail_ready(a.in_proj_weight, a.in_proj_bias, a.out_proj.weight, a.out_proj.bias, m[0].weight, m[0].bias,
+                                         m[2].weight, m[2].bias, blk.ln1.weight, blk.ln1.bias, blk.ln2.weight, blk.ln2.bias)):
+                continue
+            todo.append(blk)
+    if len(todo) < 2:
+        return
+    import ctypes as C
+    dev = todo[0].attn.in_proj_weight.device
+    pairs = []
+    for blk in todo:
+        pairs.append((blk.attn.in_proj_weight, blk.attn.in_proj_bias, blk.ln1))
+        pairs.append((blk.mlp[0].weight, blk.mlp[0].bias, blk.ln2))
+    arr = (L.FoldFwd * len(pairs))()
+    outs = []
+    for f, (W, b, ln) in zip(arr, pairs):
+        N, Kk = W.shape
+        we, be = torch.empty_like(W), torch.empty(N, dtype=torch.float32, device=dev)
+        f.W, f.b, f.gamma, f.beta, f.We, f.be, f.N, f.K = W.data_ptr(), b.data_ptr(), ln.weight.data_ptr(), ln.bias.data_ptr(), we.data_ptr(), be.data_ptr(), N, Kk
+        outs.append((we, be))
+    L.check(L.lib().tante_fold_fwd_multi(C.byref(arr), len(pairs), K._stream()), "tante_fold_fwd_multi")
+    folded = [_folded(W, b, ln, pre=o) for (W, b, ln), o in zip(pairs, outs)]
+    nbytes = L.lib().tante_block_tail_bwd_stream_bytes(todo[0].embed_dim, todo[0].hidden)
+    mats = (L.Mat3 * (2 * len(todo)))()
+    for i, blk in enumerate(todo):
+        E = blk.embed_dim
+        w_in, w1 = folded[2 * i][0].detach(), folded[2 * i + 1][0].detach()
+        bst = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        hst = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        t, h = mats[2 * i], mats[2 * i + 1]
+        t.a, t.b, t.c, t.dst = blk.mlp[2].weight.data_ptr(), w1.data_ptr(), blk.attn.out_proj.weight.data_ptr(), bst.data_ptr()
+        h.a, h.b, h.c, h.dst = w_in[0:E].data_ptr(), w_in[E:2 * E].data_ptr(), w_in[2 * E:3 * E].data_ptr(), hst.data_ptr()
+        _FOLDS[("bt_stream", id(blk))] = bst
+        _FOLDS[("bh_stream", id(blk))] = hst
+    L.check(L.lib().tante_pack_block_tail_bwd_multi(C.byref(mats), 2 * len(todo), todo[0].embed_dim, todo[0].hidden, K._stream()),
+            "tante_pack_block_tail_bwd_multi")
 
 
 def block_train(blk, x: torch.Tensor, seq, causal: bool, compute: int) -> torch.Tensor:
@@ -239,6 +303,7 @@ def tante_train_forward(model, inp: torch.Tensor, compute: int, out_T=1, z_win: 
     T = model.T
     Hp, Wp, C_ = model.H_p, model.W_p, model.C
     HW = Hp * Wp
+    prepare_blocks(model, compute)
     z = encoder_train(model.encoder, inp, compute) if z_win is None else z_win.reshape(B * T * HW, C_)
     # film(x, t) = x * (1 + scale(t)) + shift(t) with t = the window's fixed time stamps: the two tables are the same for every call of a
     # rollout graph, so they are built once per fold scope (like the folded LayerNorm weights) -- four tiny torch Linear layers, their
