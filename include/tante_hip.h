@@ -473,6 +473,13 @@ int tante_axis_mlp_bwd_fused(const float* x, const float* dy, int64_t outer, int
 int tante_axis_mlp_bwd_fused_ws(const float* x, const float* dy, int64_t outer, int n, int64_t inner, const float* w1, const float* b1,
                                 const float* w2, float* dx, float* dW1, float* db1, float* dW2, float* db2, void* workspace,
                                 int64_t workspace_bytes, void* stream);
+/* tante_pack_block_train for n blocks in one launch (weights with the LayerNorm affines folded in; block_stream of tante_block_stream_bytes). */
+typedef struct TanteBlockWeights {
+  const float* in_w; const float* in_b; const float* out_w; const float* out_b;
+  const float* fc1_w; const float* fc1_b; const float* fc2_w; const float* fc2_b;
+  void* block_stream;
+} TanteBlockWeights;
+int tante_pack_block_train_multi(const TanteBlockWeights* blocks, int n, int C, int hidden, void* stream);
 /* n folds' forward in one launch (tante_fold_fwd's expressions per entry; b may be NULL) -- attn_backbone.py:50-56. */
 typedef struct TanteFoldFwd {
   const float* W; const float* b; const float* gamma; const float* beta;

@@ -53,6 +53,11 @@ class FoldFwd(C.Structure):      # TanteFoldFwd
     _fields_ = [("W", c_vp), ("b", c_vp), ("gamma", c_vp), ("beta", c_vp), ("We", c_vp), ("be", c_vp), ("N", c_i32), ("K", c_i32)]
 
 
+class BlockWeights(C.Structure):  # TanteBlockWeights
+    _fields_ = [("in_w", c_vp), ("in_b", c_vp), ("out_w", c_vp), ("out_b", c_vp), ("fc1_w", c_vp), ("fc1_b", c_vp), ("fc2_w", c_vp), ("fc2_b", c_vp),
+                ("block_stream", c_vp)]
+
+
 class Mat3(C.Structure):         # TanteMat3
     _fields_ = [("a", c_vp), ("b", c_vp), ("c", c_vp), ("dst", c_vp)]
 
@@ -141,6 +146,7 @@ SIGNATURES = {
     "tante_fold_bwd_clear": ([c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp], c_i32),
     "tante_fold_bwd_multi": ([c_vp, c_i32, c_i32, c_vp], c_i32),
     "tante_fold_fwd_multi": ([c_vp, c_i32, c_vp], c_i32),
+    "tante_pack_block_train_multi": ([c_vp, c_i32, c_i32, c_i32, c_vp], c_i32),
     "tante_pack_block_tail_bwd_multi": ([c_vp, c_i32, c_i32, c_i32, c_vp], c_i32),
     "tante_axis_mlp_bwd_fused_supported": ([c_i32, c_i64], c_i32),
     "tante_axis_mlp_bwd_fused": ([c_vp, c_vp, c_i64, c_i32, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp], c_i32),

@@ -826,6 +826,27 @@ extern "C" int tante_block_fused_train(const float* x, const void* block_stream,
   return 0;
 }
 
+extern "C" int tante_pack_block_train_multi(const TanteBlockWeights* blocks, int n, int C, int hidden, void* stream) {
+  if (!blocks || n <= 0) TANTE_FAIL(-1, "tante_pack_block_train_multi: bad argument");
+  if (tante_fs_stream_bytes(C, hidden) == 0) TANTE_FAIL(-2, "tante_pack_block_train_multi: unsupported C=%d hidden=%d", C, hidden);
+  for (int g = 0; g < n; g += TANTE_FSP_MAX) {
+    const int m = n - g < TANTE_FSP_MAX ? n - g : TANTE_FSP_MAX;
+    const float* params[TANTE_FSP_MAX][8];
+    char* dst[TANTE_FSP_MAX];
+    for (int e = 0; e < m; ++e) {
+      const TanteBlockWeights& b = blocks[g + e];
+      if (!b.in_w || !b.in_b || !b.out_w || !b.out_b || !b.fc1_w || !b.fc1_b || !b.fc2_w || !b.fc2_b || !b.block_stream)
+        TANTE_FAIL(-1, "tante_pack_block_train_multi: null pointer in entry %d", g + e);
+      const float* q[8] = {b.in_w, b.in_b, b.out_w, b.out_b, b.fc1_w, b.fc1_b, b.fc2_w, b.fc2_b};
+      for (int k = 0; k < 8; ++k) params[e][k] = q[k];
+      dst[e] = (char*)b.block_stream + block_ts_stream_bytes(C, hidden);
+    }
+    tante_fs_pack_folded_multi(params, dst, m, (hipStream_t)stream);
+  }
+  TANTE_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int tante_pack_block_train(const float* in_w_folded, const float* in_b_folded, const float* out_w, const float* out_b,
                                       const float* fc1_w_folded, const float* fc1_b_folded, const float* fc2_w, const float* fc2_b, int C,
                                       int hidden, void* block_stream, void* stream) {

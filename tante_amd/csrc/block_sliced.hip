@@ -749,16 +749,16 @@ __global__ __launch_bounds__(64 * NW, 2) void block_fs_kernel(FsArgs A) {
 // Biases (fp32, 7 x 256 by output feature): q (scaled) | out' = b_out + W_out (b_v + W_v beta1) | fc1 | fc2 | k | v | b_out.
 // LayerNorm gammas are folded into the columns of W_in / W1, the betas into the biases.
 // ------------------------------------------------------------------------------------------------------------------------------
-__global__ void fs_pack_kernel(const float* __restrict__ w_in, const float* __restrict__ b_in, const float* __restrict__ g1,
-                               const float* __restrict__ be1, const float* __restrict__ w_out, const float* __restrict__ b_out,
-                               const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ g2,
-                               const float* __restrict__ be2, const float* __restrict__ w2, const float* __restrict__ b2,
-                               char* __restrict__ dst) {
+__device__ __forceinline__ void fs_pack_body(int bid, const float* __restrict__ w_in, const float* __restrict__ b_in, const float* __restrict__ g1,
+                                             const float* __restrict__ be1, const float* __restrict__ w_out, const float* __restrict__ b_out,
+                                             const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ g2,
+                                             const float* __restrict__ be2, const float* __restrict__ w2, const float* __restrict__ b2,
+                                             char* __restrict__ dst) {
   constexpr int C = FS_C;
   const float qscale = 0.17677669529663687f * 1.44269504088896340736f;  // log2(e) / sqrt(32): the kernel's softmax is exp2
   const int nfrag = FS_W_BYTES / FS_FRAG;
-  if ((int)blockIdx.x < nfrag / 4) {
-    const int f = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63, l15 = lane & 15, kk = lane >> 4;
+  if (bid < nfrag / 4) {
+    const int f = bid * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63, l15 = lane & 15, kk = lane >> 4;
     const int g = f % 16, ks = (f / 16) % 8, m = f / 128;
     const int row = (m < 3 ? m * C : 0) + 16 * g + l15;
     const float* src = m < 3 ? w_in : (m == 3 ? w_out : (m == 4 ? w1 : w2));
@@ -822,6 +822,24 @@ __global__ void fs_pack_kernel(const float* __restrict__ w_in, const float* __re
   bias[1280 + n] = bv[n];
   bias[1536 + n] = b_out[n];
 }
+__global__ void fs_pack_kernel(const float* __restrict__ w_in, const float* __restrict__ b_in, const float* __restrict__ g1,
+                               const float* __restrict__ be1, const float* __restrict__ w_out, const float* __restrict__ b_out,
+                               const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ g2,
+                               const float* __restrict__ be2, const float* __restrict__ w2, const float* __restrict__ b2,
+                               char* __restrict__ dst) {
+  fs_pack_body((int)blockIdx.x, w_in, b_in, g1, be1, w_out, b_out, w1, b1, g2, be2, w2, b2, dst);
+}
+// the training streams of several blocks in one launch (folded weights: gamma = beta = null)
+constexpr int FSP_BLOCKS = FS_W_BYTES / FS_FRAG / 4 + 1;
+struct FsPackBatch {
+  const float* p[TANTE_FSP_MAX][8];
+  char* dst[TANTE_FSP_MAX];
+};
+__global__ void fs_pack_multi_kernel(FsPackBatch B) {
+  const int e = blockIdx.x / FSP_BLOCKS;
+  const float* const* q = B.p[e];
+  fs_pack_body((int)blockIdx.x - e * FSP_BLOCKS, q[0], q[1], nullptr, nullptr, q[2], q[3], q[4], q[5], nullptr, nullptr, q[6], q[7], B.dst[e]);
+}
 
 template <int TPS, int NTT, int NW, bool TRAIN>
 void fs_launch_tt(const FsArgs& A, int nwg, hipStream_t s) {
@@ -871,6 +889,16 @@ void tante_fs_pack_folded(const float* in_w, const float* in_b, const float* out
                           const float* fc1_b, const float* fc2_w, const float* fc2_b, char* dst, hipStream_t s) {
   hipLaunchKernelGGL(fs_pack_kernel, dim3(FS_W_BYTES / FS_FRAG / 4 + 1), dim3(256), 0, s, in_w, in_b, (const float*)nullptr,
                      (const float*)nullptr, out_w, out_b, fc1_w, fc1_b, (const float*)nullptr, (const float*)nullptr, fc2_w, fc2_b, dst);
+}
+
+// entries: 8 pointers each (in_w, in_b, out_w, out_b, fc1_w, fc1_b, fc2_w, fc2_b, LayerNorm affines folded in), n <= TANTE_FSP_MAX
+void tante_fs_pack_folded_multi(const float* const (*params)[8], char* const* dst, int n, hipStream_t s) {
+  FsPackBatch B;
+  for (int e = 0; e < n; ++e) {
+    for (int k = 0; k < 8; ++k) B.p[e][k] = params[e][k];
+    B.dst[e] = dst[e];
+  }
+  hipLaunchKernelGGL(fs_pack_multi_kernel, dim3((unsigned)(n * FSP_BLOCKS)), dim3(256), 0, s, B);
 }
 
 int tante_fs_launch(float* x, const char* stream, const TanteSeq& sq, int causal, float eps, hipStream_t s, const TanteBlockTrain* tr) {

@@ -65,8 +65,9 @@ BATCH_PREP = __import__("os").environ.get("TANTE_TRAIN_BATCH_PREP", "1") != "0" 
 
 def prepare_blocks(model, compute: int):
     """Once per fold scope (= per rollout graph), before the first block runs: the LayerNorm folds of EVERY block in one launch
-    (tante_fold_fwd_multi) and their two backward fragment streams in another (tante_pack_block_tail_bwd_multi), left in the scope under the
-    keys block_train looks up -- per block these were four launches of ~4.7 us of latency each, 36 per train step.  Blocks that will not
+    (tante_fold_fwd_multi), their two backward fragment streams in another (tante_pack_block_tail_bwd_multi) and the forward kernel's weight
+    streams in a third (tante_pack_block_train_multi), left in the scope under the keys block_train looks up -- per block these were five
+    launches of ~4.7 us of latency each, 45 per train step.  Blocks that will not
     take the fused one-node path are left to block_train."""
     if _FOLDS is None or not BATCH_PREP or not torch.is_grad_enabled():
         return
@@ -124,6 +125,18 @@ def prepare_blocks(model, compute: int):
         _FOLDS[("bh_stream", id(blk))] = hst
     L.check(L.lib().tante_pack_block_tail_bwd_multi(C.byref(mats), 2 * len(todo), todo[0].embed_dim, todo[0].hidden, K._stream()),
             "tante_pack_block_tail_bwd_multi")
+    # ... and the forward kernel's weight streams in a third
+    sbytes = L.lib().tante_block_stream_bytes(todo[0].embed_dim, todo[0].hidden)
+    bw = (L.BlockWeights * len(todo))()
+    for i, blk in enumerate(todo):
+        (w_in, b_in), (w1, b1) = folded[2 * i], folded[2 * i + 1]
+        st = torch.empty(sbytes, dtype=torch.uint8, device=dev)
+        e = bw[i]
+        e.in_w, e.in_b, e.out_w, e.out_b = w_in.data_ptr(), b_in.data_ptr(), blk.attn.out_proj.weight.data_ptr(), blk.attn.out_proj.bias.data_ptr()
+        e.fc1_w, e.fc1_b, e.fc2_w, e.fc2_b = w1.data_ptr(), b1.data_ptr(), blk.mlp[2].weight.data_ptr(), blk.mlp[2].bias.data_ptr()
+        e.block_stream = st.data_ptr()
+        _FOLDS[("fs_stream", id(blk))] = st
+    L.check(L.lib().tante_pack_block_train_multi(C.byref(bw), len(todo), todo[0].embed_dim, todo[0].hidden, K._stream()), "tante_pack_block_train_multi")
 
 
 def block_train(blk, x: torch.Tensor, seq, causal: bool, compute: int) -> torch.Tensor:
