@@ -427,6 +427,17 @@ int tante_film_pos_fwd(const float* v, const float* a, const float* b, const flo
                        float* y, void* stream);
 int tante_film_pos_bwd(const float* dy, const float* v, const float* a, int64_t BT, int64_t HW, int C, int T, float* dv, float* da,
                        float* db, float* ds, void* stream);
+/* The same two with the window given as T <= 8 separate frame tensors (frame t of item b at f[t] + b * bstride[t] floats, rows (hw, c);
+ * 16-byte aligned): a BPTT rollout keeps one encoding per frame and a window is any T of them (tante.py:136-141 applied to
+ * trainer.py:144-159's sliding window).  bwd writes the frames' gradients to dv[t], contiguous (B, HW, C) each; C = 256. */
+typedef struct TanteFrames {
+  const float* f[8];
+  int64_t bstride[8];
+} TanteFrames;
+int tante_film_pos_fwd_frames(const TanteFrames* frames, const float* a, const float* b, const float* s_emb, int64_t B, int T, int64_t HW, int C,
+                              float* y, void* stream);
+int tante_film_pos_bwd_frames(const float* dy, const TanteFrames* frames, const float* a, int64_t B, int64_t HW, int C, int T, float* const* dv,
+                              float* da, float* db, float* ds, void* stream);
 /* Taylor sum backward: dderivs[k] = sum_i (i dt)^k / k! * dout_i,  dlast (+)= sum_i dout_i (dlast may be the last frame of the
  * input-window gradient, addressed by base pointer + batch stride) */
 int tante_taylor_bwd(const float* dout, int64_t dout_bstride, float* const* dderivs, int n_order, double dt, int n_out, float* dlast,

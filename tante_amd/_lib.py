@@ -58,6 +58,10 @@ class BlockWeights(C.Structure):  # TanteBlockWeights
                 ("block_stream", c_vp)]
 
 
+class Frames(C.Structure):       # TanteFrames
+    _fields_ = [("f", c_vp * 8), ("bstride", c_i64 * 8)]
+
+
 class Mat3(C.Structure):         # TanteMat3
     _fields_ = [("a", c_vp), ("b", c_vp), ("c", c_vp), ("dst", c_vp)]
 
@@ -146,6 +150,8 @@ SIGNATURES = {
     "tante_fold_bwd_clear": ([c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp], c_i32),
     "tante_fold_bwd_multi": ([c_vp, c_i32, c_i32, c_vp], c_i32),
     "tante_fold_fwd_multi": ([c_vp, c_i32, c_vp], c_i32),
+    "tante_film_pos_fwd_frames": ([c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i64, c_i32, c_vp, c_vp], c_i32),
+    "tante_film_pos_bwd_frames": ([c_vp, c_vp, c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp], c_i32),
     "tante_pack_block_train_multi": ([c_vp, c_i32, c_i32, c_i32, c_vp], c_i32),
     "tante_pack_block_tail_bwd_multi": ([c_vp, c_i32, c_i32, c_i32, c_vp], c_i32),
     "tante_axis_mlp_bwd_fused_supported": ([c_i32, c_i64], c_i32),

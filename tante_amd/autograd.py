@@ -1054,6 +1054,53 @@ class FilmPosFn(Function):
         return dv, da, db, ds, None, None
 
 
+class FilmPosFramesFn(Function):
+    """FilmPosFn with the window given as T separate frame encodings (each (B, HW, C) fp32, rows contiguous, any batch stride): the BPTT
+    rollout keeps one encoding per frame and a window is the last T of them -- no 25 MB torch.stack per call, and every frame receives its
+    gradient as a contiguous tensor of its own (tante.py:136-141 over trainer.py:144-159's sliding window)."""
+
+    @staticmethod
+    def _arg(frames):
+        fr = L.Frames()
+        for t, f in enumerate(frames):
+            fr.f[t] = f.data_ptr()
+            fr.bstride[t] = f.stride(0)
+        return fr
+
+    @staticmethod
+    def supported(frames, Cc) -> bool:
+        return (Cc == 256 and 1 <= len(frames) <= 8 and all(f.dtype == torch.float32 and f.is_cuda and f.dim() == 3 and f.stride(2) == 1
+                                                             and f.stride(1) == Cc and f.stride(0) % 4 == 0 and f.data_ptr() % 16 == 0
+                                                             for f in frames))
+
+    @staticmethod
+    def forward(ctx, a, b, s_emb, *frames):
+        T = len(frames)
+        B, HW, Cc = frames[0].shape
+        y = torch.empty(B * T * HW, Cc, dtype=torch.float32, device=a.device)
+        fr = FilmPosFramesFn._arg(frames)
+        L.check(L.lib().tante_film_pos_fwd_frames(C.byref(fr), a.data_ptr(), b.data_ptr(), s_emb.data_ptr(), B, T, HW, Cc, y.data_ptr(), _s()),
+                "film_pos_fwd_frames")
+        ctx.save_for_backward(a, *frames)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        a, *frames = ctx.saved_tensors
+        T = len(frames)
+        B, HW, Cc = frames[0].shape
+        dy = dy.contiguous()
+        dvs = [torch.empty(B, HW, Cc, dtype=torch.float32, device=a.device) for _ in range(T)]
+        da = torch.empty(T, Cc, dtype=torch.float32, device=a.device)
+        db = torch.empty(T, Cc, dtype=torch.float32, device=a.device)
+        ds = torch.empty(HW, Cc, dtype=torch.float32, device=a.device)
+        fr = FilmPosFramesFn._arg(frames)
+        ptrs = (C.c_void_p * T)(*[d.data_ptr() for d in dvs])
+        L.check(L.lib().tante_film_pos_bwd_frames(dy.data_ptr(), C.byref(fr), a.data_ptr(), B, HW, Cc, T, ptrs, da.data_ptr(), db.data_ptr(),
+                                                  ds.data_ptr(), _s()), "film_pos_bwd_frames")
+        return (da, db, ds, *dvs)
+
+
 class TaylorFn(Function):
     """out_i = inp[:, -1] + sum_k derivs[k] (i dt)^k / k!   (tante.py:165-171)."""
 

@@ -241,6 +241,25 @@ __global__ void film_pos_fwd_kernel(const float* __restrict__ v, const float* __
   const f32x4 vv = ((const f32x4*)v)[idx];
   ((f32x4*)y)[idx] = vv * ((const f32x4*)a)[t * C4 + c4] + ((const f32x4*)b)[t * C4 + c4] + ((const f32x4*)s)[hw * C4 + c4];
 }
+// the same with the window given as T separate frame tensors (frame t of item b at f[t] + b * bstride[t], rows (hw, c)): the BPTT rollout
+// keeps one encoding per frame and a window is any T of them -- stacking them first was a 25 MB copy per call
+struct FilmFrames {
+  const float* f[8];
+  long bstride[8];
+  float* dv[8];        // backward: the frames' gradients, contiguous (B, HW, C) each
+};
+__global__ void film_pos_fwd_frames_kernel(FilmFrames F, const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ s,
+                                           long rows, int C4, int T, long HW, float* __restrict__ y) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * C4) return;
+  const long r = idx / C4;
+  const int c4 = (int)(idx - r * C4);
+  const long hw = r % HW, bt = r / HW;
+  const int t = (int)(bt % T);
+  const long bi = bt / T;
+  const f32x4 vv = *(const f32x4*)(F.f[t] + bi * F.bstride[t] + (hw * C4 + c4) * 4);
+  ((f32x4*)y)[idx] = vv * ((const f32x4*)a)[t * C4 + c4] + ((const f32x4*)b)[t * C4 + c4] + ((const f32x4*)s)[hw * C4 + c4];
+}
 // dv = dy * a[t];  da[t][c] += sum dy * v;  db[t][c] += sum dy   (one workgroup per (bt, hw chunk); thread = channel)
 __global__ __launch_bounds__(256) void film_pos_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ v,
                                                            const float* __restrict__ a, long HW, int C, int T, long chunk,
@@ -264,13 +283,16 @@ __global__ __launch_bounds__(256) void film_pos_bwd_kernel(const float* __restri
 }
 // the same for C = 256: a thread owns four channels (float4 streams: a row is one 1 KiB access of 64 lanes), four rows in flight per
 // workgroup and eight per thread -- the kernel above reads 4 bytes per lane and 64 rows one after the other (2 TB/s by the counters)
+template <bool FRAMES>
 __global__ __launch_bounds__(256) void film_pos_bwd256_kernel(const float* __restrict__ dy, const float* __restrict__ v, const float* __restrict__ a,
                                                               long HW, int T, float* __restrict__ dv, float* __restrict__ da,
-                                                              float* __restrict__ db) {
+                                                              float* __restrict__ db, FilmFrames F) {
   constexpr int C4 = 64, ROWS = 32;
   __shared__ f32x4 red[2][3][C4];
   const long bt = blockIdx.y;
   const int t = (int)(bt % T), r = threadIdx.x >> 6, c4 = threadIdx.x & 63;
+  const f32x4* vsrc = FRAMES ? (const f32x4*)(F.f[t] + (bt / T) * F.bstride[t]) - bt * HW * C4 : (const f32x4*)v;      // indexed by (bt HW + hw) C4 + c4 below
+  f32x4* vdst = FRAMES ? (f32x4*)F.dv[t] + ((bt / T) * HW - bt * HW) * C4 : (f32x4*)dv;
   const long h0 = (long)blockIdx.x * ROWS;
   const f32x4 av = ((const f32x4*)a)[t * C4 + c4];
   f32x4 sa = f32x4{0.f, 0.f, 0.f, 0.f}, sb = sa;
@@ -280,12 +302,12 @@ __global__ __launch_bounds__(256) void film_pos_bwd256_kernel(const float* __res
     const long hw = h0 + it * 4 + r;
     const bool in = hw < HW;
     g[it] = in ? ((const f32x4*)dy)[(bt * HW + hw) * C4 + c4] : f32x4{0.f, 0.f, 0.f, 0.f};
-    x[it] = in ? ((const f32x4*)v)[(bt * HW + hw) * C4 + c4] : f32x4{0.f, 0.f, 0.f, 0.f};
+    x[it] = in ? vsrc[(bt * HW + hw) * C4 + c4] : f32x4{0.f, 0.f, 0.f, 0.f};
   }
 #pragma unroll
   for (int it = 0; it < ROWS / 4; ++it) {
     const long hw = h0 + it * 4 + r;
-    if (hw < HW) ((f32x4*)dv)[(bt * HW + hw) * C4 + c4] = g[it] * av;
+    if (hw < HW) vdst[(bt * HW + hw) * C4 + c4] = g[it] * av;
     sa += g[it] * x[it];
     sb += g[it];
   }
@@ -1403,11 +1425,49 @@ extern "C" int tante_film_pos_bwd(const float* dy, const float* v, const float* 
     TANTE_FAIL(-3, "tante_film_pos_bwd: memset failed");
   const long chunk = 64;
   if (C == 256 && ((((uintptr_t)dy | (uintptr_t)v | (uintptr_t)a | (uintptr_t)dv) & 15) == 0))
-    hipLaunchKernelGGL(film_pos_bwd256_kernel, dim3((unsigned)((HW + 31) / 32), (unsigned)BT), dim3(256), 0, s, dy, v, a, (long)HW, T, dv, da, db);
+    hipLaunchKernelGGL(film_pos_bwd256_kernel<false>, dim3((unsigned)((HW + 31) / 32), (unsigned)BT), dim3(256), 0, s, dy, v, a, (long)HW, T, dv, da, db,
+                       FilmFrames{});
   else
     hipLaunchKernelGGL(film_pos_bwd_kernel, dim3((unsigned)((HW + chunk - 1) / chunk), (unsigned)BT), dim3(256), 0, s, dy, v, a, (long)HW, C, T, chunk,
                        dv, da, db);
   hipLaunchKernelGGL(film_pos_ds_kernel, dim3((unsigned)((HW * C + 255) / 256)), dim3(256), 0, s, dy, (long)BT, (long)HW, C, ds);
+  TANTE_CHECK_LAUNCH();
+  return 0;
+}
+static int film_frames_arg(const TanteFrames* fr, int T, int C, float* const* dv, FilmFrames& F) {
+  if (!fr || T <= 0 || T > 8) return -1;
+  for (int t = 0; t < 8; ++t) {
+    F.f[t] = t < T ? fr->f[t] : nullptr;
+    F.bstride[t] = t < T ? (long)fr->bstride[t] : 0;
+    F.dv[t] = (dv && t < T) ? dv[t] : nullptr;
+    if (t < T && (!F.f[t] || ((uintptr_t)F.f[t] & 15) || F.bstride[t] % 4 || (dv && (!F.dv[t] || ((uintptr_t)F.dv[t] & 15))))) return -1;
+  }
+  return 0;
+}
+extern "C" int tante_film_pos_fwd_frames(const TanteFrames* frames, const float* a, const float* b, const float* s_emb, int64_t B, int T, int64_t HW,
+                                         int C, float* y, void* stream) {
+  FilmFrames F;
+  if (!a || !b || !s_emb || !y || B <= 0 || HW <= 0 || C <= 0 || C % 4 || film_frames_arg(frames, T, C, nullptr, F))
+    TANTE_FAIL(-1, "tante_film_pos_fwd_frames: bad argument (1 <= T <= 8, C %% 4 == 0, 16-byte aligned frames)");
+  const long rows = B * T * HW, n4 = rows * (C / 4);
+  hipLaunchKernelGGL(film_pos_fwd_frames_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, F, a, b, s_emb, rows, C / 4, T,
+                     (long)HW, y);
+  TANTE_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int tante_film_pos_bwd_frames(const float* dy, const TanteFrames* frames, const float* a, int64_t B, int64_t HW, int C, int T,
+                                         float* const* dv, float* da, float* db, float* ds, void* stream) {
+  FilmFrames F;
+  if (!dy || !a || !dv || !da || !db || !ds || B <= 0 || HW <= 0 || film_frames_arg(frames, T, C, dv, F))
+    TANTE_FAIL(-1, "tante_film_pos_bwd_frames: bad argument");
+  if (C != 256 || ((uintptr_t)dy & 15)) TANTE_FAIL(-2, "tante_film_pos_bwd_frames: C = 256 only (got %d)", C);
+  hipStream_t s = (hipStream_t)stream;
+  if (tante_zero_async(da, (size_t)T * C * sizeof(float), s) != hipSuccess || tante_zero_async(db, (size_t)T * C * sizeof(float), s) != hipSuccess)
+    TANTE_FAIL(-3, "tante_film_pos_bwd_frames: clear failed");
+  const long BT = B * T;
+  hipLaunchKernelGGL(film_pos_bwd256_kernel<true>, dim3((unsigned)((HW + 31) / 32), (unsigned)BT), dim3(256), 0, s, dy, (const float*)nullptr, a, (long)HW, T,
+                     (float*)nullptr, da, db, F);
+  hipLaunchKernelGGL(film_pos_ds_kernel, dim3((unsigned)((HW * C + 255) / 256)), dim3(256), 0, s, dy, BT, (long)HW, C, ds);
   TANTE_CHECK_LAUNCH();
   return 0;
 }

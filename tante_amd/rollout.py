@@ -107,7 +107,7 @@ def rollout_model(model, batch: Dict, formatter, n_steps: int, device=None):
                 zf = list(encode_frames_train(model, moving, compute).unbind(1))
                 last = moving[:, -1:].contiguous()
                 while produced < n_steps:
-                    y = tante_train_forward(model, last, compute, 1, z_win=torch.stack(zf[-T:], dim=1))
+                    y = tante_train_forward(model, last, compute, 1, z_win=zf[-T:])      # the window's frames where they are
                     produced += y.shape[1]
                     preds.append(formatter.process_output(y))
                     if produced < n_steps:

@@ -12,7 +12,7 @@ import torch
 from . import _lib as L
 from . import kernels as K
 from . import stages as S
-from .autograd import (ActFn, AttentionFn, BlockFn, BlockTailFn, block_tail_ready, AxisHWFn, AxisMlpFn, BranchOutFn, DeconvFn, DropoutAddFn, FilmPosFn, FoldFn, LayerNormFn, LayerNormSkipFn, LinearFn, PatchEmbedFn, RtReduceFn,
+from .autograd import (ActFn, AttentionFn, BlockFn, BlockTailFn, block_tail_ready, AxisHWFn, AxisMlpFn, BranchOutFn, DeconvFn, DropoutAddFn, FilmPosFn, FilmPosFramesFn, FoldFn, LayerNormFn, LayerNormSkipFn, LinearFn, PatchEmbedFn, RtReduceFn,
                        TaylorFn)
 
 
@@ -60,6 +60,7 @@ FUSED_HEAD_BACKWARD = __import__("os").environ.get("TANTE_TRAIN_FUSED_HEAD_BWD",
 
 
 BLOCK_CALLS = [0, 0]      # block_train calls / those that took the fused one-node path (GraphedTrainStep checks them at capture)
+FRAME_FILM = __import__("os").environ.get("TANTE_TRAIN_FRAME_FILM", "1") != "0"     # FiLM reads the window's frames where they are (no stack per call)
 BATCH_PREP = __import__("os").environ.get("TANTE_TRAIN_BATCH_PREP", "1") != "0"     # folds and backward fragment streams of all blocks in two launches
 
 
@@ -309,7 +310,7 @@ def encode_frames_train(model, frames: torch.Tensor, compute: int) -> torch.Tens
     return z.view(B, k, model.H_p * model.W_p, model.C)
 
 
-def tante_train_forward(model, inp: torch.Tensor, compute: int, out_T=1, z_win: torch.Tensor = None):
+def tante_train_forward(model, inp: torch.Tensor, compute: int, out_T=1, z_win=None):
     """z_win (optional): the window's frames already encoded, (B, T, HW, C) fp32 contiguous (encode_frames_train); `inp` then only
     supplies its last frame (the Taylor sum's base) and may be that frame alone, (B, 1, D, H, W)."""
     B, _, D, H, W = inp.shape
@@ -317,7 +318,13 @@ def tante_train_forward(model, inp: torch.Tensor, compute: int, out_T=1, z_win: 
     Hp, Wp, C_ = model.H_p, model.W_p, model.C
     HW = Hp * Wp
     prepare_blocks(model, compute)
-    z = encoder_train(model.encoder, inp, compute) if z_win is None else z_win.reshape(B * T * HW, C_)
+    z_frames = None
+    if isinstance(z_win, (list, tuple)):       # the window as T separate frame encodings, each (B, HW, C)
+        if FRAME_FILM and FilmPosFramesFn.supported(z_win, C_):
+            z_frames = z_win
+        else:
+            z_win = torch.stack(list(z_win), dim=1)
+    z = None if z_frames is not None else (encoder_train(model.encoder, inp, compute) if z_win is None else z_win.reshape(B * T * HW, C_))
     # film(x, t) = x * (1 + scale(t)) + shift(t) with t = the window's fixed time stamps: the two tables are the same for every call of a
     # rollout graph, so they are built once per fold scope (like the folded LayerNorm weights) -- four tiny torch Linear layers, their
     # activations and their backward were ~150 launches of ~4.5 us per train step when rebuilt in each of the four BPTT calls
@@ -332,7 +339,10 @@ def tante_train_forward(model, inp: torch.Tensor, compute: int, out_T=1, z_win: 
         if _FOLDS is not None:
             _FOLDS[key] = tabs
     fa, fb = tabs
-    x = FilmPosFn.apply(z, fa, fb, model.s_emb.view(HW, C_), T, HW)
+    if z_frames is not None:
+        x = FilmPosFramesFn.apply(fa, fb, model.s_emb.view(HW, C_), *z_frames)
+    else:
+        x = FilmPosFn.apply(z, fa, fb, model.s_emb.view(HW, C_), T, HW)
     derivs, rts = [], []
     for i in range(model.taylor_order):
         x = backbone_train(model.blocks[i], x, B, compute)

@@ -693,3 +693,30 @@ def test_single_tile_wgrad_through_workspace(dev, R, I, J, dt):
     tol = 2e-5 if dt == "fp32" else 1e-5          # bf16 operands are exact inputs here: only the accumulation order differs
     for name, (dW, db) in out.items():
         assert rel_err(dW, ref) < tol and rel_err(db, refb) < tol, (name, rel_err(dW, ref), rel_err(db, refb))
+
+
+def test_film_over_frames_equals_film_over_the_stacked_window(dev):
+    """FilmPosFramesFn (the window as T separate frame encodings with different batch strides -- views of one (B, 4, HW, C) tensor and
+    stand-alone frames, as the BPTT rollout holds them) against FilmPosFn on torch.stack of the same frames: output bit-equal, gradients of
+    the frames, the two FiLM tables and the positional table equal (tante.py:136-141)."""
+    from tante_amd.autograd import FilmPosFn, FilmPosFramesFn
+    g = torch.Generator().manual_seed(3)
+    B, T, HW, C = 2, 4, 50, 256
+    first = torch.randn(B, 4, HW, C, generator=g).to(dev).requires_grad_()
+    extra = torch.randn(B, HW, C, generator=g).to(dev).requires_grad_()
+    a, b = torch.randn(T, C, generator=g).to(dev).requires_grad_(), torch.randn(T, C, generator=g).to(dev).requires_grad_()
+    s = torch.randn(HW, C, generator=g).to(dev).requires_grad_()
+    dy = torch.randn(B * T * HW, C, generator=g).to(dev)
+    frames = list(first.unbind(1))[1:] + [extra]              # a window that slid by one: three views with batch stride 4 HW C, one own tensor
+    assert FilmPosFramesFn.supported(frames, C)
+    y1 = FilmPosFramesFn.apply(a, b, s, *frames)
+    (y1 * dy).sum().backward()
+    got = [t.grad.clone() for t in (first, extra, a, b, s)]
+    for t in (first, extra, a, b, s):
+        t.grad = None
+    y2 = FilmPosFn.apply(torch.stack(frames, 1).reshape(B * T * HW, C), a, b, s, T, HW)
+    (y2 * dy).sum().backward()
+    assert torch.equal(y1, y2)
+    assert torch.equal(got[0], first.grad) and torch.equal(got[1], extra.grad)
+    for u, v in zip(got[2:], (a.grad, b.grad, s.grad)):
+        assert rel_err(u, v) < 1e-6
