@@ -830,6 +830,214 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const unsigned short
   }
 }
 
+// ---- the same for whole sequences of 2 - 4 tiles (16 < L <= 64), NT waves per (sequence, head) -----------------------------------------------
+// In the kernel above ONE wave walks all NT x NT score tiles of its (sequence, head) twice: at L = 48 that is a 54 k-cycle serial chain at
+// two waves per SIMD (200 registers, 16 KB of LDS per wave) -- 1.7 TB/s by the counters where the L <= 16 form reaches 4.1.  Here the NT
+// waves of a head share the row images in LDS (each loads and later stores ONE 16-row tile): wave ti handles query tile ti in pass 1
+// (row statistics, keep bits, dQ) and key tile ti in pass 2 (dK, dV), with one barrier between the passes for the statistics and keep
+// bits of the other tiles.  A third of the chain per wave, fragments of the other tiles from LDS instead of a register file of their own.
+template <int NT, int HG>   // HG heads per workgroup
+__global__ __launch_bounds__(64 * NT * HG) void attn_bwd_split_kernel(const unsigned short* __restrict__ qkv, const unsigned short* __restrict__ dO,
+                                                                      unsigned short* __restrict__ dqkv, int C, int n_head, TanteSeq sq, int causal,
+                                                                      float scale, float p_drop, unsigned long long seed,
+                                                                      const unsigned long long* __restrict__ seed_mix) {
+  if (seed_mix) seed ^= *seed_mix;
+  constexpr int ROWS = NT * 16, NP = (NT + 1) / 2, RS = 48;
+  constexpr int HEAD_LDS = 4 * ROWS * RS * 2 + NT * 16 * RS * 2 + 3 * ROWS * 4 + NT * NT * 64;   // Q, K, V, dO images, NT staging tiles, statistics, keep bits
+  extern __shared__ __attribute__((aligned(16))) char sm_raw[];
+  const int tid = threadIdx.x, lane = tid & 63, kk = lane >> 4, l15 = lane & 15, qq = l15 >> 2, pp = l15 & 3;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), hg = wave / NT, ti = wave - hg * NT;
+  const int h = blockIdx.y * HG + hg;                      // n_head % HG == 0 (host): every wave has a head, every wave reaches the barriers
+  char* base = sm_raw + hg * HEAD_LDS;
+  unsigned short* Qs = (unsigned short*)base;
+  unsigned short* Ks = Qs + ROWS * RS;
+  unsigned short* Vs = Ks + ROWS * RS;
+  unsigned short* Gs = Vs + ROWS * RS;
+  unsigned short* Os = Gs + ROWS * RS + ti * 16 * RS;      // this wave's staging tile
+  float* St = (float*)(Gs + ROWS * RS + NT * 16 * RS);     // m [ROWS], 1/l [ROWS], delta [ROWS]
+  unsigned char* Mb = (unsigned char*)(St + 3 * ROWS);
+  const int L = sq.L, seq = blockIdx.x;
+  // ---- this wave's 16 rows (tile ti) in row form: lanes 4 r .. 4 r + 3 = the 64 bytes of (token row r, this head) ------------------------
+  const int lr = lane >> 2, lc = lane & 3, rpos = ti * 16 + lr;
+  const bool rlive = rpos < L;
+  const long rtok = rlive ? (long)(seq / sq.n_s0) * sq.S1 + (long)(seq % sq.n_s0) * sq.S0 + (long)(rpos / sq.n_l0) * sq.P1 + (long)(rpos % sq.n_l0) * sq.P0 : 0;
+  {
+    u32x4 q4 = u32x4{0u, 0u, 0u, 0u}, k4 = q4, v4 = q4, g4 = q4;
+    if (rlive) {
+      const unsigned short* r = qkv + rtok * 3L * C + h * 32 + lc * 8;
+      q4 = *(const u32x4*)r;
+      k4 = *(const u32x4*)(r + C);
+      v4 = *(const u32x4*)(r + 2 * C);
+      g4 = *(const u32x4*)(dO + rtok * (long)C + h * 32 + lc * 8);
+    }
+    *(u32x4*)(Qs + rpos * RS + lc * 8) = q4;
+    *(u32x4*)(Ks + rpos * RS + lc * 8) = k4;
+    *(u32x4*)(Vs + rpos * RS + lc * 8) = v4;
+    *(u32x4*)(Gs + rpos * RS + lc * 8) = g4;
+  }
+  __syncthreads();
+  auto rfrag = [&](const unsigned short* X, int t) { return *(const u32x4*)(X + (t * 16 + l15) * RS + kk * 8); };   // row l15 of tile t, dims 8 kk ..
+  const unsigned troff = (4 * kk + qq) * (RS * 2) + pp * 8;
+  auto tfrag = [&](const unsigned short* X, int rt0, int rt1, int dt) {
+    const unsigned a = lds_addr((const char*)X) + troff + dt * 32;
+    u32x2 lo = abm_tr(a + rt0 * (16 * RS * 2)), hi = abm_tr(a + rt1 * (16 * RS * 2));
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo), "+v"(hi) : : "memory");
+    return u32x4{lo[0], lo[1], hi[0], hi[1]};
+  };
+  const float c2 = scale * 1.4426950408889634f;
+  const float ksc = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
+  const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto store_tile = [&](int mat, const f32x4& v0, const f32x4& v1) {      // a 16-token x 32-dim result of tile ti: accumulator layout -> rows
+    u32x2 u0, u1;
+    u0[0] = pack_bf16x2(v0[0], v0[1]); u0[1] = pack_bf16x2(v0[2], v0[3]);
+    u1[0] = pack_bf16x2(v1[0], v1[1]); u1[1] = pack_bf16x2(v1[2], v1[3]);
+    *(u32x2*)(Os + l15 * RS + 4 * kk) = u0;
+    *(u32x2*)(Os + l15 * RS + 16 + 4 * kk) = u1;
+    const u32x4 row = *(const u32x4*)(Os + lr * RS + lc * 8);
+    if (rlive) *(u32x4*)(dqkv + rtok * 3L * C + (long)mat * C + h * 32 + lc * 8) = row;
+  };
+  const int mypos = ti * 16 + l15;                 // pass 1: this lane's query; pass 2: this lane's key
+  const bool mylive = mypos < L;
+
+  // ---- pass 1: the queries of tile ti in the columns ---------------------------------------------------------------------------------------
+  {
+    const u32x4 qf = rfrag(Qs, ti), gf = rfrag(Gs, ti);
+    const unsigned long long mrow = (((unsigned long long)seq * n_head + h) * L + mypos) * L;
+    f32x4 st[NT], dpt[NT];
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt) {
+      st[jt] = mfma_bf16(rfrag(Ks, jt), qf, zero4);
+      dpt[jt] = mfma_bf16(rfrag(Vs, jt), gf, zero4);
+    }
+    unsigned vm = 0;
+    float mx = -INFINITY;
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int jpos = jt * 16 + 4 * kk + r;
+        const bool valid = mylive && jpos < L && (!causal || jpos <= mypos);
+        vm |= (unsigned)valid << (jt * 4 + r);
+        if (valid) mx = fmaxf(mx, st[jt][r]);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float mm = (mx == -INFINITY) ? 0.f : mx;
+    float lsum = 0.f;
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float e = ((vm >> (jt * 4 + r)) & 1) ? __builtin_amdgcn_exp2f((st[jt][r] - mm) * c2) : 0.f;
+        st[jt][r] = e;
+        lsum += e;
+      }
+    lsum += __shfl_xor(lsum, 16);
+    lsum += __shfl_xor(lsum, 32);
+    const float inv_l = lsum > 0.f ? 1.0f / lsum : 0.f;
+    float delta = 0.f;
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt) {
+      unsigned m4 = 0xfu;
+      if (p_drop > 0.f) {
+        if ((L & 3) == 0) {
+          m4 = dropout_keep4(seed, mrow + jt * 16 + 4 * kk, p_drop);
+        } else {
+          m4 = 0u;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) m4 |= (unsigned)dropout_keep(seed, mrow + jt * 16 + 4 * kk + r, p_drop) << r;
+        }
+        Mb[(ti * NT + jt) * 64 + kk * 16 + l15] = (unsigned char)m4;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = st[jt][r] * inv_l;
+        float dp = dpt[jt][r];
+        if (p_drop > 0.f) dp = ((m4 >> r) & 1u) ? dp * ksc : 0.f;
+        st[jt][r] = p;
+        dpt[jt][r] = dp;
+        delta += p * dp;
+      }
+    }
+    delta += __shfl_xor(delta, 16);
+    delta += __shfl_xor(delta, 32);
+    if (kk == 0) {
+      St[mypos] = mm;
+      St[ROWS + mypos] = inv_l;
+      St[2 * ROWS + mypos] = delta;
+    }
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dpt[jt][r] = st[jt][r] * (dpt[jt][r] - delta) * scale;   // dS^T
+    f32x4 dq[2] = {zero4, zero4};
+#pragma unroll
+    for (int jp = 0; jp < NP; ++jp) {
+      const int j0 = 2 * jp, j1 = (2 * jp + 1 < NT) ? 2 * jp + 1 : 2 * jp;
+      const u32x4 pf = pack8(dpt[j0], (2 * jp + 1 < NT) ? dpt[j1] : zero4);
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) dq[dt] = mfma_bf16(tfrag(Ks, j0, j1, dt), pf, dq[dt]);
+    }
+    store_tile(0, dq[0], dq[1]);
+  }
+  __syncthreads();      // every tile's statistics and keep bits are in LDS
+
+  // ---- pass 2: the keys of tile ti in the columns --------------------------------------------------------------------------------------------
+  {
+    const u32x4 kf = rfrag(Ks, ti), vf = rfrag(Vs, ti);
+    f32x4 sv[NT], dp[NT];
+#pragma unroll
+    for (int it = 0; it < NT; ++it) {
+      sv[it] = mfma_bf16(rfrag(Qs, it), kf, zero4);
+      dp[it] = mfma_bf16(rfrag(Gs, it), vf, zero4);
+    }
+#pragma unroll
+    for (int it = 0; it < NT; ++it) {
+      const f32x4 m4 = *(const f32x4*)(St + it * 16 + 4 * kk), il4 = *(const f32x4*)(St + ROWS + it * 16 + 4 * kk);
+      const f32x4 de4 = *(const f32x4*)(St + 2 * ROWS + it * 16 + 4 * kk);
+      const unsigned kw = p_drop > 0.f ? *(const unsigned*)(Mb + (it * NT + ti) * 64 + (l15 >> 2) * 16 + 4 * kk) >> (l15 & 3) : 0u;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ipos = it * 16 + 4 * kk + r;
+        const bool valid = ipos < L && mylive && (!causal || mypos <= ipos);
+        const float p = valid ? __builtin_amdgcn_exp2f((sv[it][r] - m4[r]) * c2) * il4[r] : 0.f;
+        float d = dp[it][r], pd = p;
+        if (p_drop > 0.f) {
+          const bool keep = (kw >> (8 * r)) & 1u;
+          pd = keep ? p * ksc : 0.f;
+          d = keep ? d * ksc : 0.f;
+        }
+        sv[it][r] = pd;
+        dp[it][r] = p * (d - de4[r]) * scale;
+      }
+    }
+    f32x4 dk[2] = {zero4, zero4}, dv[2] = {zero4, zero4};
+#pragma unroll
+    for (int ip = 0; ip < NP; ++ip) {
+      const int i0 = 2 * ip, i1 = (2 * ip + 1 < NT) ? 2 * ip + 1 : 2 * ip;
+      const u32x4 pfs = pack8(dp[i0], (2 * ip + 1 < NT) ? dp[i1] : zero4);
+      const u32x4 pfp = pack8(sv[i0], (2 * ip + 1 < NT) ? sv[i1] : zero4);
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        dk[dt] = mfma_bf16(tfrag(Qs, i0, i1, dt), pfs, dk[dt]);
+        dv[dt] = mfma_bf16(tfrag(Gs, i0, i1, dt), pfp, dv[dt]);
+      }
+    }
+    store_tile(1, dk[0], dk[1]);
+    store_tile(2, dv[0], dv[1]);
+  }
+}
+
+template <int NT, int HG>
+void launch_attn_bwd_split(const void* qkv, const void* dO, void* dqkv, int C, int n_head, const TanteSeq& sq, int causal, float p_drop,
+                           unsigned long long seed, hipStream_t s) {
+  const size_t lds = (size_t)HG * (4 * NT * 16 * 96 + NT * 16 * 96 + 3 * NT * 16 * 4 + NT * NT * 64);
+  static TantePerDevice attr;
+  attr.once([&] { (void)hipFuncSetAttribute((const void*)attn_bwd_split_kernel<NT, HG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
+  hipLaunchKernelGGL((attn_bwd_split_kernel<NT, HG>), dim3(sq.nseq, n_head / HG), dim3(64 * NT * HG), lds, s, (const unsigned short*)qkv,
+                     (const unsigned short*)dO, (unsigned short*)dqkv, C, n_head, sq, causal, 1.0f / sqrtf(32.0f), p_drop, seed, tante_seed_mix_ptr());
+}
+
 template <int NT>
 void launch_attn_bwd_mfma(const void* qkv, const void* dO, void* dqkv, int C, int n_head, const TanteSeq& sq, int SPT, int units, int causal,
                           float p_drop, unsigned long long seed, hipStream_t s) {
@@ -847,6 +1055,25 @@ bool try_attn_bwd_mfma(const void* qkv, const void* dO, void* dqkv, int dtype, i
   const int L = sq.L;
   const int SPT = L >= 16 ? 1 : 16 / L;
   const int units = L >= 16 ? sq.nseq : (sq.nseq + SPT - 1) / SPT;
+  static const bool no_split = getenv("TANTE_ATTN_BWD_NO_SPLIT") != nullptr;
+  if (!no_split && L > 16) {      // whole sequences of 2 - 4 tiles: NT waves per (sequence, head)
+    static const int hg_env = getenv("TANTE_ATTN_BWD_HG") ? atoi(getenv("TANTE_ATTN_BWD_HG")) : 1;      // heads per workgroup: 29.2 / 31.2 / 36.4 us at 1 / 2 / 4 (L = 48, cfg3)
+    const int nt = (L + 15) / 16;
+    if (hg_env == 2 && n_head % 2 == 0) {
+      if (nt == 2) launch_attn_bwd_split<2, 2>(qkv, dO, dqkv, C, n_head, sq, causal, p_drop, seed, s);
+      else if (nt == 3) launch_attn_bwd_split<3, 2>(qkv, dO, dqkv, C, n_head, sq, causal, p_drop, seed, s);
+      else launch_attn_bwd_split<4, 2>(qkv, dO, dqkv, C, n_head, sq, causal, p_drop, seed, s);
+    } else if (hg_env == 4 && n_head % 4 == 0) {
+      if (nt == 2) launch_attn_bwd_split<2, 4>(qkv, dO, dqkv, C, n_head, sq, causal, p_drop, seed, s);
+      else if (nt == 3) launch_attn_bwd_split<3, 4>(qkv, dO, dqkv, C, n_head, sq, causal, p_drop, seed, s);
+      else launch_attn_bwd_split<4, 4>(qkv, dO, dqkv, C, n_head, sq, causal, p_drop, seed, s);
+    } else {
+      if (nt == 2) launch_attn_bwd_split<2, 1>(qkv, dO, dqkv, C, n_head, sq, causal, p_drop, seed, s);
+      else if (nt == 3) launch_attn_bwd_split<3, 1>(qkv, dO, dqkv, C, n_head, sq, causal, p_drop, seed, s);
+      else launch_attn_bwd_split<4, 1>(qkv, dO, dqkv, C, n_head, sq, causal, p_drop, seed, s);
+    }
+    return true;
+  }
   switch (L >= 16 ? (L + 15) / 16 : 1) {
     case 1: launch_attn_bwd_mfma<1>(qkv, dO, dqkv, C, n_head, sq, SPT, units, causal, p_drop, seed, s); break;
     case 2: launch_attn_bwd_mfma<2>(qkv, dO, dqkv, C, n_head, sq, SPT, units, causal, p_drop, seed, s); break;
