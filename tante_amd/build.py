@@ -14,7 +14,7 @@ HEADERS = [os.path.join(CSRC, "common.cuh"), os.path.join(CSRC, "fused_common.cu
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=fast"]
 # the fused bf16 kernels are bound by VALU issue: without NaN-honouring every fmaxf / clamp loses its v_max canonicalisation
-EXTRA_FLAGS = {"block_fused.hip": ["-fno-honor-nans", "-DTANTE_MFMA_SETPRIO", "-mllvm", "-amdgpu-sched-strategy=max-ilp"], "block_sliced.hip": ["-fno-honor-nans", "-DTANTE_MFMA_SETPRIO", "-DFS_PRIO=1"], "block_bwd.hip": ["-fno-honor-nans", "-DTANTE_MFMA_SETPRIO"], "head_fused.hip": ["-fno-honor-nans"], "enc_fused.hip": ["-fno-honor-nans"], "operators.hip": ["-fno-honor-nans"]}
+EXTRA_FLAGS = {"block_fused.hip": ["-fno-honor-nans", "-DTANTE_MFMA_SETPRIO", "-mllvm", "-amdgpu-sched-strategy=max-ilp"], "block_sliced.hip": ["-fno-honor-nans", "-DTANTE_MFMA_SETPRIO", "-DFS_PRIO=1"], "block_bwd.hip": ["-fno-honor-nans", "-DTANTE_MFMA_SETPRIO", "-DBT_PRIO"], "head_fused.hip": ["-fno-honor-nans"], "enc_fused.hip": ["-fno-honor-nans"], "operators.hip": ["-fno-honor-nans"]}
 
 
 def _stale(target, deps):

@@ -56,6 +56,9 @@ __device__ __forceinline__ f32x4 unpack4(const u32x2& u) { return f32x4{bf16_lo(
 
 template <int NTT>
 __global__ __launch_bounds__(256, 2) void block_tail_bwd_kernel(BtArgs A) {
+#ifdef BT_PRIO
+  if ((__builtin_amdgcn_s_getreg(0x1804) & 1u) == 1u) __builtin_amdgcn_s_setprio(3);      // as FS_PRIO in block_sliced.hip: the odd hardware wave slots
+#endif
   constexpr int RT = 4, NW = 4, PF = 2;
   constexpr int IMG = 16 * NTT * FS_ROW;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -229,6 +232,9 @@ struct BhArgs {
 
 template <int NTT>
 __global__ __launch_bounds__(256, 2) void block_head_bwd_kernel(BhArgs A) {
+#ifdef BT_PRIO
+  if ((__builtin_amdgcn_s_getreg(0x1804) & 1u) == 1u) __builtin_amdgcn_s_setprio(3);
+#endif
   constexpr int RT = 4, NW = 4, PF = 2;
   constexpr int IMG = 16 * NTT * FS_ROW;
   extern __shared__ __attribute__((aligned(16))) char smem[];
