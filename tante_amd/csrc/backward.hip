@@ -283,11 +283,11 @@ __global__ __launch_bounds__(256) void film_pos_bwd_kernel(const float* __restri
 }
 // the same for C = 256: a thread owns four channels (float4 streams: a row is one 1 KiB access of 64 lanes), four rows in flight per
 // workgroup and eight per thread -- the kernel above reads 4 bytes per lane and 64 rows one after the other (2 TB/s by the counters)
-template <bool FRAMES>
+template <bool FRAMES, int ROWS>
 __global__ __launch_bounds__(256) void film_pos_bwd256_kernel(const float* __restrict__ dy, const float* __restrict__ v, const float* __restrict__ a,
                                                               long HW, int T, float* __restrict__ dv, float* __restrict__ da,
                                                               float* __restrict__ db, FilmFrames F) {
-  constexpr int C4 = 64, ROWS = 32;
+  constexpr int C4 = 64;
   __shared__ f32x4 red[2][3][C4];
   const long bt = blockIdx.y;
   const int t = (int)(bt % T), r = threadIdx.x >> 6, c4 = threadIdx.x & 63;
@@ -1652,7 +1652,7 @@ extern "C" int tante_film_pos_bwd(const float* dy, const float* v, const float* 
     TANTE_FAIL(-3, "tante_film_pos_bwd: memset failed");
   const long chunk = 64;
   if (C == 256 && ((((uintptr_t)dy | (uintptr_t)v | (uintptr_t)a | (uintptr_t)dv) & 15) == 0))
-    hipLaunchKernelGGL(film_pos_bwd256_kernel<false>, dim3((unsigned)((HW + 31) / 32), (unsigned)BT), dim3(256), 0, s, dy, v, a, (long)HW, T, dv, da, db,
+    hipLaunchKernelGGL((film_pos_bwd256_kernel<false, 32>), dim3((unsigned)((HW + 31) / 32), (unsigned)BT), dim3(256), 0, s, dy, v, a, (long)HW, T, dv, da, db,
                        FilmFrames{});
   else
     hipLaunchKernelGGL(film_pos_bwd_kernel, dim3((unsigned)((HW + chunk - 1) / chunk), (unsigned)BT), dim3(256), 0, s, dy, v, a, (long)HW, C, T, chunk,
@@ -1692,8 +1692,16 @@ extern "C" int tante_film_pos_bwd_frames(const float* dy, const TanteFrames* fra
   if (tante_zero_async(da, (size_t)T * C * sizeof(float), s) != hipSuccess || tante_zero_async(db, (size_t)T * C * sizeof(float), s) != hipSuccess)
     TANTE_FAIL(-3, "tante_film_pos_bwd_frames: clear failed");
   const long BT = B * T;
-  hipLaunchKernelGGL(film_pos_bwd256_kernel<true>, dim3((unsigned)((HW + 31) / 32), (unsigned)BT), dim3(256), 0, s, dy, (const float*)nullptr, a, (long)HW, T,
-                     (float*)nullptr, da, db, F);
+  static const int rows_env = getenv("TANTE_FILM_BWD_ROWS") ? atoi(getenv("TANTE_FILM_BWD_ROWS")) : 32;
+  if (rows_env == 64)
+    hipLaunchKernelGGL((film_pos_bwd256_kernel<true, 64>), dim3((unsigned)((HW + 63) / 64), (unsigned)BT), dim3(256), 0, s, dy, (const float*)nullptr, a, (long)HW, T,
+                       (float*)nullptr, da, db, F);
+  else if (rows_env == 16)
+    hipLaunchKernelGGL((film_pos_bwd256_kernel<true, 16>), dim3((unsigned)((HW + 15) / 16), (unsigned)BT), dim3(256), 0, s, dy, (const float*)nullptr, a, (long)HW, T,
+                       (float*)nullptr, da, db, F);
+  else
+    hipLaunchKernelGGL((film_pos_bwd256_kernel<true, 32>), dim3((unsigned)((HW + 31) / 32), (unsigned)BT), dim3(256), 0, s, dy, (const float*)nullptr, a, (long)HW, T,
+                       (float*)nullptr, da, db, F);
   hipLaunchKernelGGL(film_pos_ds_kernel, dim3((unsigned)((HW * C + 255) / 256)), dim3(256), 0, s, dy, BT, (long)HW, C, ds);
   TANTE_CHECK_LAUNCH();
   return 0;
