@@ -218,7 +218,17 @@ __global__ __launch_bounds__(256) void colsum_bf16_vec_kernel(const unsigned sho
   __syncthreads();
   const long o0 = (long)blockIdx.x * chunk, o1 = min(outer, o0 + chunk);
   float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  for (long o = o0 + rsub; o < o1; o += rpp) {
+  long o = o0 + rsub;
+  for (; o + 3L * rpp < o1; o += 4L * rpp) {      // four rows in flight per lane: one load per trip left the pass latency-bound (0.7 TB/s)
+    const u32x4 v0 = *(const u32x4*)(x + o * C + 8 * cg), v1 = *(const u32x4*)(x + (o + rpp) * C + 8 * cg);
+    const u32x4 v2 = *(const u32x4*)(x + (o + 2L * rpp) * C + 8 * cg), v3 = *(const u32x4*)(x + (o + 3L * rpp) * C + 8 * cg);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      s[2 * q] += (bf16_lo(v0[q]) + bf16_lo(v1[q])) + (bf16_lo(v2[q]) + bf16_lo(v3[q]));
+      s[2 * q + 1] += (bf16_hi(v0[q]) + bf16_hi(v1[q])) + (bf16_hi(v2[q]) + bf16_hi(v3[q]));
+    }
+  }
+  for (; o < o1; o += rpp) {
     const u32x4 v = *(const u32x4*)(x + o * C + 8 * cg);
 #pragma unroll
     for (int q = 0; q < 4; ++q) { s[2 * q] += bf16_lo(v[q]); s[2 * q + 1] += bf16_hi(v[q]); }
@@ -1612,8 +1622,9 @@ extern "C" int tante_colsum(const void* x, int dtype, int64_t outer, int C, int6
   hipStream_t s = (hipStream_t)stream;
   if (!accumulate && tante_zero_async(out, (size_t)C * sizeof(float), s) != hipSuccess) TANTE_FAIL(-3, "tante_colsum: memset failed");
   if (inner == 1 && dtype == TANTE_BF16 && C % 8 == 0 && C <= 2048 && 256 % (C / 8) == 0 && ((uintptr_t)x % 16) == 0) {
-    long chunks = 1024;                                      // four workgroups per CU, at least 256 rows each
-    if (chunks > (outer + 255) / 256) chunks = (outer + 255) / 256;
+    long chunks = 1024;                                      // at least 512 rows per workgroup: every workgroup ends in C same-address atomics (9.4 MB of 256-channel rows: 17.6 / 11.5 / 9.7 / 10.7 / 15.1 us at 128 / 256 / 512 / 1024 / 2048 rows)
+    static const long cs_rows = getenv("TANTE_COLSUM_ROWS") ? atol(getenv("TANTE_COLSUM_ROWS")) : 512;
+    if (chunks > (outer + cs_rows - 1) / cs_rows) chunks = (outer + cs_rows - 1) / cs_rows;
     const long chunk = (outer + chunks - 1) / chunks;
     hipLaunchKernelGGL(colsum_bf16_vec_kernel, dim3((unsigned)((outer + chunk - 1) / chunk)), dim3(256), 0, s, (const unsigned short*)x, (long)outer, C,
                        chunk, out);
