@@ -337,9 +337,14 @@ __global__ __launch_bounds__(256) void film_pos_bwd256_kernel(const float* __res
 __global__ void film_pos_ds_kernel(const float* __restrict__ dy, long BT, long HW, int C, float* __restrict__ ds) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= HW * C) return;
-  float s = 0.f;
-  for (long bt = 0; bt < BT; ++bt) s += dy[bt * HW * C + idx];
-  ds[idx] = s;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;      // four images in flight per thread
+  long bt = 0;
+  for (; bt + 4 <= BT; bt += 4) {
+    const float a = dy[bt * HW * C + idx], b = dy[(bt + 1) * HW * C + idx], c = dy[(bt + 2) * HW * C + idx], d = dy[(bt + 3) * HW * C + idx];
+    s0 += a; s1 += b; s2 += c; s3 += d;
+  }
+  for (; bt < BT; ++bt) s0 += dy[bt * HW * C + idx];
+  ds[idx] = (s0 + s1) + (s2 + s3);
 }
 
 // ---- Taylor sum backward: dd_k = sum_i c_ik dout_i;  dlast (+)= sum_i dout_i -----------------------------------------
