@@ -19,9 +19,10 @@ frames = torch.cat([base + k * drift for k in range(twl["n_steps_input"] + n)], 
 batch = {"input": frames[:, :twl["n_steps_input"]].to(dev), "output": frames[:, twl["n_steps_input"]:].to(dev)}
 fmt = tante_amd.DefaultChannelsFirstFormatter(tmd)
 losses = []
+graphed = tante_amd.GraphedTrainStep(m, opt, batch, fmt, n, 1, seed=211) if os.environ.get("SOAK_GRAPH") else None      # SOAK_GRAPH=1: the replayed step
 t0 = time.time()
 for s in range(N):
-    losses.append(float(tante_amd.train_step(m, opt, batch, fmt, n, 1)))
+    losses.append(float(graphed(batch) if graphed is not None else tante_amd.train_step(m, opt, batch, fmt, n, 1)))
     if s % 10 == 0 or s == N - 1:
         print(f"step {s:3d} loss {losses[-1]:.6f}", flush=True)
 print(f"{N} steps in {time.time() - t0:.1f} s; finite: {all(l == l and l < 1e9 for l in losses)}; first {losses[0]:.5f} last {losses[-1]:.5f} min {min(losses):.5f}")
