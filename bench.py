@@ -196,7 +196,8 @@ def main():
                 return r
             return wrapper
 
-        def fl_block(x, st, C_, nh, hidden, seq, causal, eps):
+        def fl_block(x, st, C_, nh, hidden, seq, causal, eps, tprop=None):
+            # (the temporal propagator a T-letter launch may carry -- tprop -- is 64 flops per element of vector work: not counted)
             n_tok = x.numel() // C_
             attn = 2.0 * (seq.L + 1) * C_ if causal else 4.0 * seq.L * C_
             return n_tok * (2.0 * C_ * 3 * C_ + attn + 2.0 * C_ * C_ + 4.0 * C_ * hidden)

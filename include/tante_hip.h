@@ -222,6 +222,11 @@ int tante_pack_block(const float* ln1_w, const float* ln1_b, const float* in_w, 
                      const float* fc2_w, const float* fc2_b, int C, int hidden, void* block_stream, void* stream);
 int tante_block_fused(float* x, const void* block_stream, int C, int n_head, int hidden, const TanteSeq* seq, int causal,
                       float eps, void* stream);
+/* The same at L = 4 (the T letter) WITH the temporal propagator of attn_backbone.py:144-145 applied to the rows first, inside the launch:
+ * tprop = w1 (4 x 4, row-major), b1 (4), w2 (4 x 4), b2 (4) -- 40 floats in device memory.  Equals tante_axis_mlp_c (bf16 compute) along the
+ * T axis followed by tante_block_fused, bit for bit, in one pass over x. */
+int tante_block_fused_tprop(float* x, const void* block_stream, int C, int n_head, int hidden, const TanteSeq* seq, int causal, float eps,
+                            const float* tprop, void* stream);
 
 /* Training forward of a whole TransformerBlock in ONE launch (C = 256, 8 heads, hidden 256, sequences up to 64 tokens): the same
  * arithmetic as tante_block_fused with dropout (attn_backbone.py:47-83 in train() mode: attention-probability dropout inside

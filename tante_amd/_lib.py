@@ -93,6 +93,7 @@ SIGNATURES = {
     "tante_block_stream_bytes": ([c_i32, c_i32], c_i64),
     "tante_pack_block": ([c_vp] * 12 + [c_i32, c_i32, c_vp, c_vp], c_i32),
     "tante_block_fused": ([c_vp, c_vp, c_i32, c_i32, c_i32, C.POINTER(Seq), c_i32, c_f32, c_vp], c_i32),
+    "tante_block_fused_tprop": ([c_vp, c_vp, c_i32, c_i32, c_i32, C.POINTER(Seq), c_i32, c_f32, c_vp, c_vp], c_i32),
     "tante_block_tail_bwd_stream_bytes": ([c_i32, c_i32], c_i64),
     "tante_pack_block_tail_bwd": ([c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp], c_i32),
     "tante_block_tail_bwd": ([c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_f32, C.c_uint64, C.c_uint64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp], c_i32),

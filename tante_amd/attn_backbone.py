@@ -16,10 +16,16 @@ MI355X-first differences from the reference's execution (results identical to ro
 from __future__ import annotations
 
 import math
+import os
 from typing import Optional
 
 import torch
 import torch.nn as nn
+
+# The temporal propagator inside the first (T-letter) block's launch (tante_block_fused_tprop): bit-identical to the separate launch and
+# measured: the block launch grows by the 12 us the propagator kernel took (15 k shuffles through the LDS crossbar per workgroup), the
+# rollout gains 0.3 % and the dominant kernel's roofline fraction falls from 0.28 to 0.26 -- off unless TANTE_FUSE_TPROP=1.
+FUSE_TPROP = os.environ.get("TANTE_FUSE_TPROP", "0") != "0"
 
 from . import _lib as L
 from . import kernels as K
@@ -113,8 +119,14 @@ class TransformerBlock(nn.Module):
         self.__dict__.pop("_fused_params", None)
         return super()._apply(fn, *a, **kw)
 
-    def forward_tokens(self, x: torch.Tensor, seq: L.Seq, causal: bool, compute: int) -> torch.Tensor:
-        """In place on the flat fp32 residual stream x (tokens, C); `seq` says which tokens attend to which."""
+    def takes_tprop(self, seq_L: int, compute: int) -> bool:
+        """Can this block apply the temporal propagator itself (tante_block_fused_tprop: the feature-sliced kernel at L = 4)?"""
+        return (FUSE_TPROP and compute == L.BF16 and self.fused and self.ln1.eps == self.ln2.eps and seq_L == 4 and self.embed_dim == 256
+                and self.n_head == 8 and self.hidden == 256 and not (self.training and self.p_drop > 0.0))
+
+    def forward_tokens(self, x: torch.Tensor, seq: L.Seq, causal: bool, compute: int, tprop: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """In place on the flat fp32 residual stream x (tokens, C); `seq` says which tokens attend to which.  tprop: the temporal
+        propagator's packed weights, applied to the rows inside the fused launch (only when takes_tprop says so)."""
         if self.training and self.p_drop > 0.0:
             raise NotImplementedError("dropout > 0 in training mode is not implemented on the HIP path yet")
         C_ = self.embed_dim
@@ -122,7 +134,9 @@ class TransformerBlock(nn.Module):
         if (compute == L.BF16 and self.fused and self.ln1.eps == self.ln2.eps
                 and K.block_fused_supported(C_, self.n_head, self.hidden, seq.L)):
             # one launch per block: the residual rows are read once and written once
-            return K.block_fused(x, self._packed_fused(), C_, self.n_head, self.hidden, seq, causal, self.ln1.eps)
+            return K.block_fused(x, self._packed_fused(), C_, self.n_head, self.hidden, seq, causal, self.ln1.eps, tprop)
+        if tprop is not None:
+            raise RuntimeError("TransformerBlock.forward_tokens: tprop needs the fused block kernel (takes_tprop)")
         pk = self._packed(compute)
         adt = K.act_torch_dtype(compute)
         qkv = torch.empty(n_tok, 3 * C_, dtype=adt, device=x.device)
@@ -178,7 +192,14 @@ class Attn_Backbone(nn.Module):
                 raise ValueError(f"invalid axis letter {axis!r}")
             self.blocks.append(TransformerBlock(embed_dim=embed_dim, n_head=n_head, mlp_ratio=mlp_ratio, dropout=dropout))
         self._cache = _PackCache()
+        self._tp_cache = _PackCache()
         self.compute: Optional[str] = None
+
+    def _packed_tprop(self) -> torch.Tensor:
+        """w1 (4 x 4), b1, w2 (4 x 4), b2 of the temporal propagator as 40 contiguous floats (tante_block_fused_tprop)."""
+        tp = self.temporal_propagator
+        params = [tp[0].weight, tp[0].bias, tp[2].weight, tp[2].bias]
+        return self._tp_cache.get(0, params, lambda: torch.cat([p.detach().float().reshape(-1) for p in params]).contiguous())
 
     def _packed_channel(self, compute: int):
         params = [p for cb in self.channel_blocks for p in cb.parameters()]
@@ -203,7 +224,14 @@ class Attn_Backbone(nn.Module):
         else:
             K.axis_mlp(x, B * T, H, W * C_, vp[0].weight, vp[0].bias, vp[2].weight, vp[2].bias, compute)      # l.140-141
             K.axis_mlp(x, B * T * H, W, C_, hp[0].weight, hp[0].bias, hp[2].weight, hp[2].bias, compute)      # l.142-143
-        K.axis_mlp(x, B, T, H * W * C_, tp[0].weight, tp[0].bias, tp[2].weight, tp[2].bias, compute)          # l.144-145
+        # l.144-145: the temporal propagator -- inside the first block's launch when that block is a T letter on the fused kernel (the four
+        # time steps of a sequence are the four lane groups of its row loads), a launch of its own otherwise
+        tprop = None
+        if (T == 4 and len(self.attn_axes) > 0 and self.attn_axes[0] == "T" and not torch.is_grad_enabled()
+                and self.blocks[0].takes_tprop(T, compute)):
+            tprop = self._packed_tprop()
+        else:
+            K.axis_mlp(x, B, T, H * W * C_, tp[0].weight, tp[0].bias, tp[2].weight, tp[2].bias, compute)
         ci = 0
         for i, axis in enumerate(self.attn_axes):
             blk = self.blocks[i]
@@ -220,7 +248,7 @@ class Attn_Backbone(nn.Module):
                 blk.forward_tokens(z, K.dense_seq(n // C_, C_), False, compute)
                 K.gather_last(z, n, E, x)
             else:
-                blk.forward_tokens(x, K.make_seq(axis, B, T, H, W), axis == "T", compute)
+                blk.forward_tokens(x, K.make_seq(axis, B, T, H, W), axis == "T", compute, tprop if i == 0 else None)
         return x
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:

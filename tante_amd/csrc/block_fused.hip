@@ -784,6 +784,18 @@ extern "C" int tante_pack_block(const float* ln1_w, const float* ln1_b, const fl
   return 0;
 }
 
+extern "C" int tante_block_fused_tprop(float* x, const void* block_stream, int C, int n_head, int hidden, const TanteSeq* seq, int causal, float eps,
+                                       const float* tprop, void* stream) {
+  if (!x || !block_stream || !seq || !tprop) TANTE_FAIL(-1, "tante_block_fused_tprop: null pointer");
+  if (seq->L != 4 || !tante_block_fused_supported(C, n_head, hidden, seq->L) || !use_fs(C, n_head, hidden, seq->L, causal))
+    TANTE_FAIL(-2, "tante_block_fused_tprop: the feature-sliced kernel at L = 4 only (C=%d heads=%d hidden=%d L=%d)", C, n_head, hidden, seq->L);
+  if (((uintptr_t)x % 16) || ((uintptr_t)block_stream % 16)) TANTE_FAIL(-1, "tante_block_fused_tprop: buffers must be 16-byte aligned");
+  if (tante_fs_launch(x, (const char*)block_stream + block_ts_stream_bytes(C, hidden), *seq, causal, eps, (hipStream_t)stream, nullptr, tprop) != 0)
+    TANTE_FAIL(-2, "tante_block_fused_tprop: too many sequences (%d)", seq->nseq);
+  TANTE_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int tante_block_fused(float* x, const void* block_stream, int C, int n_head, int hidden, const TanteSeq* seq, int causal,
                                  float eps, void* stream) {
   if (!x || !block_stream || !seq) TANTE_FAIL(-1, "tante_block_fused: null pointer");

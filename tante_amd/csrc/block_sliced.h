@@ -14,4 +14,5 @@ void tante_fs_pack_folded(const float* in_w, const float* in_b, const float* out
                           const float* fc1_b, const float* fc2_w, const float* fc2_b, char* dst, hipStream_t s);
 constexpr int TANTE_FSP_MAX = 12;      // entries per tante_fs_pack_folded_multi launch
 void tante_fs_pack_folded_multi(const float* const (*params)[8], char* const* dst, int n, hipStream_t s);
-int tante_fs_launch(float* x, const char* stream, const TanteSeq& sq, int causal, float eps, hipStream_t s, const TanteBlockTrain* tr = nullptr);
+int tante_fs_launch(float* x, const char* stream, const TanteSeq& sq, int causal, float eps, hipStream_t s, const TanteBlockTrain* tr = nullptr,
+                    const float* tprop = nullptr);

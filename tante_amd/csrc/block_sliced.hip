@@ -49,6 +49,9 @@ struct FsArgs {
   unsigned long long seed_attn, seed_out, seed_mlp;
   const unsigned long long* seed_mix;   // device word XOR-ed into the three seeds (HIP-graph replays of a train step), or null
   unsigned long long* stamps;   // diagnostic builds (-DTANTE_ABLATE) only: per-wave s_memtime at the phase boundaries, else null
+  // inference, L = 4 (the T letter): the temporal propagator y_t = x_t + b2[t] + sum_j w2[t][j] gelu(b1[j] + sum_a w1[j][a] x_a)
+  // (attn_backbone.py:144-145) applied to the rows as they are loaded for LayerNorm1: w1 (4 x 4), b1, w2 (4 x 4), b2 = 40 floats, or null
+  const float* tprop;
 };
 
 // In-kernel stamps (cdna_hip_programming.md 7): a -DTANTE_ABLATE build records the shader clock at every phase boundary of every wave
@@ -242,6 +245,53 @@ __global__ __launch_bounds__(64 * NW, 2) void block_fs_kernel(FsArgs A) {
       for (int j = 0; j < 4; ++j) v[i][j] = *(const f32x4*)(row + 4 * (l15 + 16 * j));
     }
     fs_wring_prime<0, RT, PF>(wq, wb);     // behind the x rows in the memory queue: LayerNorm1 does not wait for them
+    if constexpr (!TRAIN) {
+      if (A.tprop) {
+        // The temporal propagator, fused: with L = 4 the four 16-lane groups of an instruction ARE the four time steps of one sequence
+        // (slot = 4 s + t, kk = t), all with the same channels.  Lane group kk computes hidden unit kk from the four x_t (three values
+        // fetched from the other groups), then its own y_kk from the four hidden units -- the expressions and their order are
+        // axis_mlp_vec_kernel<4, true>'s, so the rows are bit-identical to that kernel's.  The propagated rows go back to x: the
+        // residual slices are re-read from there behind the barriers below (workgroup-scope release / acquire of __syncthreads).
+        const float* tp = A.tprop;
+        float w1r[4], w2r[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) { w1r[a] = tp[4 * kk + a]; w2r[a] = tp[20 + 4 * kk + a]; }
+        const float b1k = tp[16 + kk], b2k = tp[36 + kk];
+        int src[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) src[a] = (l15 + 16 * a) << 2;
+#pragma unroll
+        for (int i = 0; i < GPW; ++i) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const f32x4 vin = v[i][j];
+            const float vx = vin[0], vy = vin[1], vz = vin[2], vw = vin[3];
+            f32x4 sacc = splat4(b1k);
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+              const f32x4 xa = f32x4{__builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src[a], __builtin_bit_cast(int, vx))),
+                                     __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src[a], __builtin_bit_cast(int, vy))),
+                                     __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src[a], __builtin_bit_cast(int, vz))),
+                                     __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src[a], __builtin_bit_cast(int, vw)))};
+              sacc += splat4(w1r[a]) * xa;
+            }
+            const f32x4 hk = gelu_poly4<false>(sacc);
+            const float hx = hk[0], hy = hk[1], hz = hk[2], hw_ = hk[3];
+            f32x4 acc = vin + splat4(b2k);
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+              const f32x4 ha = f32x4{__builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src[a], __builtin_bit_cast(int, hx))),
+                                     __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src[a], __builtin_bit_cast(int, hy))),
+                                     __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src[a], __builtin_bit_cast(int, hz))),
+                                     __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src[a], __builtin_bit_cast(int, hw_)))};
+              acc += splat4(w2r[a]) * ha;
+            }
+            v[i][j] = acc;
+            if (lv[i]) *(f32x4*)(x + (long)tis[i] * FS_C + 4 * (l15 + 16 * j)) = acc;
+          }
+        }
+      }
+    }
 #pragma unroll
     for (int i = 0; i < GPW; ++i) {
       float s = 0.f, q = 0.f;
@@ -901,12 +951,15 @@ void tante_fs_pack_folded_multi(const float* const (*params)[8], char* const* ds
   hipLaunchKernelGGL(fs_pack_multi_kernel, dim3((unsigned)(n * FSP_BLOCKS)), dim3(256), 0, s, B);
 }
 
-int tante_fs_launch(float* x, const char* stream, const TanteSeq& sq, int causal, float eps, hipStream_t s, const TanteBlockTrain* tr) {
+int tante_fs_launch(float* x, const char* stream, const TanteSeq& sq, int causal, float eps, hipStream_t s, const TanteBlockTrain* tr,
+                    const float* tprop) {
   if (sq.nseq >= (1 << 23)) return -2;
+  if (tprop && (tr || sq.L != 4)) return -5;
   FsArgs A;
   A.x = x; A.w = stream; A.sq = sq; A.causal = causal; A.eps = eps;
   A.out = nullptr;
   A.seed_mix = nullptr;
+  A.tprop = tprop;
   if (tr) {
     if (sq.L > 64) return -4;
     A.out = tr->out; A.xh1 = (unsigned short*)tr->xh1; A.st1 = tr->st1; A.qkv = (unsigned short*)tr->qkv; A.o = (unsigned short*)tr->o;

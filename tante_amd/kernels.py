@@ -332,8 +332,14 @@ def pack_block(params: Sequence[torch.Tensor], C_: int, hidden: int) -> torch.Te
 
 
 def block_fused(x: torch.Tensor, block_stream: torch.Tensor, C_: int, n_head: int, hidden: int, seq: L.Seq, causal: bool,
-                eps: float):
+                eps: float, tprop: Optional[torch.Tensor] = None):
+    """tprop (L = 4 only): the temporal propagator's 40 packed floats (w1, b1, w2, b2) -- applied to the rows inside the launch."""
     _dev(x, block_stream)
+    if tprop is not None:
+        _dev(tprop)
+        L.check(L.lib().tante_block_fused_tprop(_p(x), _p(block_stream), C_, n_head, hidden, C.byref(seq), int(causal), eps, _p(tprop), _stream()),
+                "tante_block_fused_tprop")
+        return x
     L.check(L.lib().tante_block_fused(_p(x), _p(block_stream), C_, n_head, hidden, C.byref(seq), int(causal), eps, _stream()),
             "tante_block_fused")
     return x

@@ -720,3 +720,28 @@ def test_film_over_frames_equals_film_over_the_stacked_window(dev):
     assert torch.equal(got[0], first.grad) and torch.equal(got[1], extra.grad)
     for u, v in zip(got[2:], (a.grad, b.grad, s.grad)):
         assert rel_err(u, v) < 1e-6
+
+
+@pytest.mark.parametrize("B,T,H,W", [(2, 4, 8, 8), (1, 4, 6, 10), (3, 4, 16, 4)])
+def test_temporal_propagator_inside_the_block_launch_is_bit_identical(dev, B, T, H, W):
+    """Attn_Backbone.forward_tokens with the temporal propagator applied inside the first (T-letter) block's launch
+    (tante_block_fused_tprop) against the propagator as a launch of its own followed by the same block: the residual stream must be
+    bit-identical after the whole backbone (attn_backbone.py:144-145 followed by l.154-162) -- incl. workgroups with dead slots
+    (B H W not a multiple of 16 sequences)."""
+    import tante_amd
+    from tante_amd import attn_backbone as AB, _lib as L
+    torch.manual_seed(B * 100 + H)
+    bb = tante_amd.Attn_Backbone(tensor_shape=(T, H, W, 256), attn_axes="THW", n_head=8, mlp_ratio=1.0, dropout=0.0).to(dev).eval()
+    x0 = torch.randn(B, T, H, W, 256, device=dev)
+    outs = []
+    for fuse in (True, False):
+        AB.FUSE_TPROP = fuse
+        try:
+            with torch.no_grad():
+                x = x0.clone()
+                assert bb.blocks[0].takes_tprop(T, L.BF16) == fuse
+                bb.forward_tokens(x, B, L.BF16)
+                outs.append(x)
+        finally:
+            AB.FUSE_TPROP = False      # the module default (measured: no gain, DESIGN 8)
+    assert torch.isfinite(outs[0]).all() and torch.equal(outs[0], outs[1])
