@@ -55,3 +55,24 @@ def dec_fno(w: W, x: Tensor, patch_scale: int, overlap: float, modes) -> Tensor:
     z = gelu_erf(real_transconv2d(z, w["dec_conv_2.deconv.weight"], w["dec_conv_2.deconv.bias"], P[0], overlap))
     z = spectral_layer(sub(w, "dec_spectral_2."), z, m1, m2)
     return z.reshape(B, T, -1, z.shape[-2], z.shape[-1])
+
+
+def fno_wrapper(w: W, x: Tensor, modes1: int, modes2: int, n_layers: int = 4) -> Tensor:
+    """`models.FNO.forward` (models/fno.py:102-106): 'b t c h w -> b (t c) h w' -> operator -> 'b c h w -> b 1 c h w'.
+    **PARITY UNPINNED** for the operator in the middle: the reference delegates it to `neuralop.models.FNO` (fno.py:4, 94-100), which is
+    not vendored, not version-pinned and not installed here, and no reference test or fixture touches it.  What is restated is the
+    published operator (Li et al. 2021) that tante_amd/fno.py builds: pointwise lifting MLP (GELU) -> n_layers x [spectral_layer,
+    GELU on all but the last] -> pointwise projection MLP (GELU), over the pinned `spectral_layer` above.  The I/O contract around it
+    IS the reference's."""
+    B, T, C_, H, Wd = x.shape
+    z = x.reshape(B, T * C_, H, Wd).permute(0, 2, 3, 1)
+    z = F.linear(gelu_erf(F.linear(z, w["model.lifting.fc1.weight"], w["model.lifting.fc1.bias"])),
+                 w["model.lifting.fc2.weight"], w["model.lifting.fc2.bias"]).permute(0, 3, 1, 2)
+    for i in range(n_layers):
+        z = spectral_layer(sub(w, f"model.fno_blocks.{i}."), z, modes1, modes2)
+        if i + 1 < n_layers:
+            z = gelu_erf(z)
+    z = z.permute(0, 2, 3, 1)
+    z = F.linear(gelu_erf(F.linear(z, w["model.projection.fc1.weight"], w["model.projection.fc1.bias"])),
+                 w["model.projection.fc2.weight"], w["model.projection.fc2.bias"])
+    return z.permute(0, 3, 1, 2).unsqueeze(1)

@@ -8,6 +8,7 @@ from .tante import TANTE, TanteMetadata, enc_CNN, dec_CNN, film, interprator, t_
 from .attn_backbone import Attn_Backbone, TransformerBlock  # noqa: F401
 from .spectral import SpectralLayer, enc_FNO, dec_FNO  # noqa: F401
 from .cvit import CViT  # noqa: F401
+from .fno import FNO  # noqa: F401
 from .rollout import (DefaultChannelsFirstFormatter, DefaultChannelsLastFormatter, rollout_model,  # noqa: F401
                       rollout_adaptive)
 from .config import instantiate, load_config, build_model  # noqa: F401
@@ -20,4 +21,4 @@ from .harness import LinearWarmupCosineAnnealingLR, SyntheticDataModule, save_ch
 
 __all__ = ["TANTE", "TanteMetadata", "enc_CNN", "dec_CNN", "film", "interprator", "t_series", "Attn_Backbone",
            "TransformerBlock", "DefaultChannelsFirstFormatter", "DefaultChannelsLastFormatter", "rollout_model",
-           "rollout_adaptive", "instantiate", "load_config", "build_model", "CViT", "SpectralLayer", "enc_FNO", "dec_FNO"]
+           "rollout_adaptive", "instantiate", "load_config", "build_model", "CViT", "FNO", "SpectralLayer", "enc_FNO", "dec_FNO"]

@@ -13,6 +13,8 @@ _TARGET_ALIASES = {
     "models.tante.TANTE": "tante_amd.tante.TANTE",
     "models.CViT": "tante_amd.cvit.CViT",
     "models.cvit.CViT": "tante_amd.cvit.CViT",
+    "models.FNO": "tante_amd.fno.FNO",
+    "models.fno.FNO": "tante_amd.fno.FNO",
     "models.enc_dec_fno.SpectralLayer": "tante_amd.spectral.SpectralLayer",
     "models.attn_backbone.Attn_Backbone": "tante_amd.attn_backbone.Attn_Backbone",
     "models.attn_backbone.TransformerBlock": "tante_amd.attn_backbone.TransformerBlock",

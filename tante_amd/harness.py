@@ -264,4 +264,8 @@ def fit(model, optimizer, datamodule, formatter, max_epoch: int, n_steps_output:
         history.append({"epoch": epoch, "train_loss": train_loss, "lr": getattr(optimizer, "lr", None), **val})
         log(f"epoch {epoch}/{max_epoch}: train loss {train_loss:.6f}  valid {[round(v, 6) for v in val['validation_loss']]}  "
             f"forward {val['forward_time'] * 1e3:.2f} ms/batch")
+    g = getattr(model, "_tante_graphed_step", None)
+    if g:                       # training is over: the library must not keep reading the step object's seed word
+        g.close()
+        model._tante_graphed_step = None
     return {"history": history, "best_val_loss": best_val}

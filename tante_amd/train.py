@@ -40,6 +40,9 @@ def _splitmix64(x: int) -> int:
     return x ^ (x >> 31)
 
 
+_ACTIVE_MIX = {}        # device index -> address of the seed word the library currently reads there (tante_set_seed_mix)
+
+
 class GraphedTrainStep:
     """train_step with zero_grad + rollout + loss + backward captured ONCE as a HIP graph and replayed: a step costs the host a batch
     copy, an 8-byte seed word and one graph launch (0.15 ms instead of 10 - 20 ms of Python per step -- on a slow host the eager step
@@ -66,6 +69,7 @@ class GraphedTrainStep:
         self.mix_dev = torch.zeros(1, dtype=torch.int64, device=self.dev)
         self.seed, self.count = int(seed), 0
         L.check(L.lib().tante_set_seed_mix(self.mix_dev.data_ptr()), "tante_set_seed_mix")
+        _ACTIVE_MIX[self.dev.index] = self.mix_dev.data_ptr()
         snap = (opt.flat_p.clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone(), opt.step_count, A._SEED[0])
         side = torch.cuda.Stream(device=self.dev)
         side.wait_stream(torch.cuda.current_stream(self.dev))
@@ -79,6 +83,7 @@ class GraphedTrainStep:
         self.graph = torch.cuda.CUDAGraph()
         TF.BLOCK_CALLS[0] = TF.BLOCK_CALLS[1] = 0
         A._SEED[0] = snap[4]            # the captured step draws the seeds an eager step would have drawn here
+        ws_before = set(A._AXIS_WS)
         try:
             # thread-local capture mode: RCCL's proxy / watchdog threads of an initialised process group make HIP calls of their own,
             # which a global-mode capture would take for violations
@@ -93,7 +98,16 @@ class GraphedTrainStep:
                                    "(their dropout seeds would be frozen in the graph)")
         except BaseException:
             self.close()            # the kernels must not keep reading a seed word that dies with this object
+            A.reset_backward_state(after=True)
             raise
+        finally:
+            # Whatever the capture cached was only RECORDED, never computed: weight packs (autograd._PACKS and the modules' pack caches
+            # hold buffers whose tante_pack_weight launch sits in the graph) and the propagator-gradient workspace keyed to the
+            # capture stream (its zero fill is a graph node).  An eager step after a refused capture -- bench.py's and
+            # harness.train_one_epoch's fallback -- or between capture and first replay must not find them: drop them all.
+            self._bump()
+            for k in set(A._AXIS_WS) - ws_before:
+                del A._AXIS_WS[k]
 
     @staticmethod
     def _bump():
@@ -121,8 +135,31 @@ class GraphedTrainStep:
         return self.loss.detach()
 
     def close(self):
+        """Detach the library from this object's seed word (idempotent).  Called by __del__ / the context manager too: a collected
+        step object returns `mix_dev` to the allocator, and a kernel that still XORed that word into its seeds would draw a forward
+        mask and a backward mask that differ as soon as the memory is reused."""
+        if getattr(self, "_closed", False):
+            return
+        self._closed = True
+        if _ACTIVE_MIX.get(self.dev.index) != self.mix_dev.data_ptr():
+            return                  # a later step object has registered its own word on this device: leave it alone
         from . import _lib as L
-        L.check(L.lib().tante_set_seed_mix(None), "tante_set_seed_mix")
+        with torch.cuda.device(self.dev):
+            L.check(L.lib().tante_set_seed_mix(None), "tante_set_seed_mix")
+        _ACTIVE_MIX.pop(self.dev.index, None)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def train_step_adaptive(model, opt: FlatAdamW, batch: Dict[str, torch.Tensor], formatter, n_steps_output: int, rt_eps: float = 0.5,

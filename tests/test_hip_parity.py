@@ -365,7 +365,7 @@ def test_g1_tiny_end_to_end(dev, mode):
     close(y, g["y"], mode)
     # the derivative part alone (output minus the last input frame) must also agree
     d, dref = y.cpu() - g["x"][:, -1:], g["y"] - g["x"][:, -1:]
-    assert rel_err(d, dref) < (2e-5 if mode == "fp32" else 3e-2)
+    assert rel_err(d, dref) < (2e-5 if mode == "fp32" else 1e-2)
 
 
 @pytest.mark.parametrize("tag,axes", [("o1", "TH"), ("o2", "T-W"), ("o3", "T-H-W")])
@@ -381,20 +381,26 @@ def test_g7_taylor_orders(dev, tag, axes):
     close(y, g["y"], "fp32")
 
 
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
 @pytest.mark.parametrize("name", names("g8_rollout_*"))
-def test_g8_rollout(dev, name):
+def test_g8_rollout(dev, name, mode):
+    """The reference's Trainer / Evaler.rollout_model outputs (trainer/trainer.py:144-159, evaler.py:121-138), re-fed 4 and 8 steps, in
+    BOTH compute modes: every frame of the rollout (per step) and the whole rollout (end) under the stated 1e-5 / 1e-2."""
     import tante_amd
     g = load_golden(name)
     ol, n_roll = int(g["meta"][0]), int(g["meta"][1])
     md = tante_amd.TanteMetadata(n_fields=2, spatial_resolution=(16, 16))
     m = _tante_from(g, dev, in_T=4, dset_metadata=md, taylor_order=2, output_length=ol, attn_axes="T-L", n_head=2,
                     embed_dim=32, patch_scale=8, dropout=0.0)
+    m.set_compute(mode)
     fmt = tante_amd.DefaultChannelsFirstFormatter(md)
     with torch.no_grad():
         y, y_ref = tante_amd.rollout_model(m, {"input": g["inp"], "output": g["out"]}, fmt, n_roll)
         yt, _ = tante_amd.rollout_model(m, {"input": g["inp"], "output": g["out"][:, :4]}, fmt, 4)
-    close(y, g["y_eval"], "fp32")
-    close(yt, g["y_train"], "fp32")
+    close(y, g["y_eval"], mode)
+    close(yt, g["y_train"], mode)
+    for t in range(n_roll):
+        close(y[:, t], g["y_eval"][:, t], mode)
     assert torch.equal(y_ref.cpu(), g["y_ref"])
 
 
@@ -437,7 +443,7 @@ def test_cfg2_full_size_against_oracle(dev):
     close(y16[:1], ref, "bf16")
     # derivative part (what the network actually computes) under the same bars, slightly widened
     d32, d16, dref = y32[:1].cpu() - x[:1, -1:], y16[:1].cpu() - x[:1, -1:], ref - x[:1, -1:]
-    assert rel_err(d32, dref) < 5e-5 and rel_err(d16, dref) < 5e-2
+    assert rel_err(d32, dref) < 5e-5 and rel_err(d16, dref) < 1e-2
     # batch independence: sample 1 computed alone == computed inside the batch (bitwise: same kernels, same tiles)
     assert torch.equal(y32[1:], y32_b)
 

@@ -284,7 +284,7 @@ def test_cfg3_full_size_against_oracle(dev):
     with torch.no_grad():
         y32 = m.set_compute("fp32")(x.to(dev)).cpu()
         y16 = m.set_compute("bf16")(x.to(dev)).cpu()
-    for y, mode, tol, dtol in ((y32, "fp32", 1e-5, 5e-5), (y16, "bf16", 1e-2, 5e-2)):
+    for y, mode, tol, dtol in ((y32, "fp32", 1e-5, 5e-5), (y16, "bf16", 1e-2, 1e-2)):
         r, mx = rel_err(y[:1], ref), max_rel(y[:1], ref)
         d, dref = y[:1] - x[:1, -1:], ref - x[:1, -1:]
         record_parity(r, mx, tol, mode, "cfg3 forward")
