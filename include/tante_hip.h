@@ -9,9 +9,13 @@
  *
  * Conventions
  *  - plain C: pointers are DEVICE pointers owned by the caller (torch tensors' data_ptr()); the
- *    library never allocates, frees or synchronises, and keeps no global state besides a
- *    thread-local last-error string.  All launches go to the caller's hipStream_t (passed as void*),
- *    so the calls are HIP-graph capturable.
+ *    library never allocates device memory, frees or synchronises.  All launches go to the caller's
+ *    hipStream_t (passed as void*), so the calls are HIP-graph capturable.
+ *  - process state, all of it: (1) the thread-local last-error string; (2) one pointer per device set by
+ *    tante_set_seed_mix() (the device word the fused training kernels XOR into their dropout seeds);
+ *    (3) a thread-local cache of hipFFT plans keyed by (device, shape) behind tante_spectral_layer*;
+ *    (4) the table of launch-heuristic overrides written ONLY by tante_set_option() -- the library never
+ *    reads the environment (a -DTANTE_ABLATE diagnostic build, which is not the product, does).
  *  - return value: 0 on success, negative on error (-1 bad argument, -2 unsupported shape,
  *    -3 HIP launch error); tante_last_error() returns a description.  No exceptions cross the ABI.
  *  - dtype codes: TANTE_F32 = 0, TANTE_BF16 = 1.  "compute" selects the matrix-core path:
@@ -563,6 +567,14 @@ int tante_wgrad_multi_ws(const TanteRowMat* U, const TanteRowMat* V, int n_seg, 
 
 const char* tante_last_error(void);
 int tante_abi_version(void);
+
+/* Launch-heuristic overrides (workgroup counts, kernel-variant choices).  Every option switches between forms that compute the same
+ * function; none changes a result beyond the summation order the variant implies.  Names start with "TANTE_" (e.g. "TANTE_FS_GROUPS":
+ * 0 = automatic, 1 = unpaired, 2 = paired form of the fused block kernel; "TANTE_FS_WAVES" = 8 forces its 8-wave form;
+ * "TANTE_WGRAD_WGS", "TANTE_GEMM_WGS", ... = grid sizes).  Process-wide, thread-safe; an option that was never set keeps the built-in
+ * default.  There is no counterpart in the reference (it has no native code to tune). */
+int tante_set_option(const char* name, int value);
+int tante_get_option(const char* name, int dflt);
 
 #ifdef __cplusplus
 }

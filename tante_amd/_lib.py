@@ -4,7 +4,9 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libtante_hip.so")
+# TANTE_LIB: an A/B build of the library (tools/build_variant.sh -> tools/_ab/lib_<name>.so) instead of the product one -- measurement
+# scripts only, so that they never overwrite tante_amd/lib/libtante_hip.so; the file must exist (there is no fallback either way)
+LIB_PATH = os.environ.get("TANTE_LIB") or os.path.join(HERE, "lib", "libtante_hip.so")
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_GELU_ERF, ACT_GELU_TANH, ACT_RELU = 0, 1, 2, 3
@@ -170,6 +172,8 @@ SIGNATURES = {
     "tante_rt_reduce_bwd": ([c_vp, c_i32, c_i32, c_vp, c_vp], c_i32),
     "tante_last_error": ([], C.c_char_p),
     "tante_abi_version": ([], c_i32),
+    "tante_set_option": ([C.c_char_p, c_i32], c_i32),
+    "tante_get_option": ([C.c_char_p, c_i32], c_i32),
 }
 
 _lib = None
@@ -189,7 +193,24 @@ def lib():
             fn.argtypes = argtypes
             fn.restype = restype
         _lib = L
+        # The library never reads the environment; the measurement scripts under tools/ drive its A/B switches through TANTE_*
+        # environment variables, which are forwarded ONCE here (integer-valued ones only; later changes go through set_option).
+        for k, v in os.environ.items():
+            if k.startswith("TANTE_") and len(k) < 48:
+                try:
+                    L.tante_set_option(k.encode(), int(v))
+                except ValueError:
+                    pass
     return _lib
+
+
+def set_option(name: str, value: int) -> None:
+    """Override one launch heuristic of the library (include/tante_hip.h: tante_set_option), e.g. ("TANTE_FS_GROUPS", 1)."""
+    check(lib().tante_set_option(name.encode(), int(value)), "tante_set_option")
+
+
+def get_option(name: str, default: int = 0) -> int:
+    return int(lib().tante_get_option(name.encode(), int(default)))
 
 
 def check(rc: int, what: str = ""):

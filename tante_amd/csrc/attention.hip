@@ -362,7 +362,7 @@ void launch_attn_fwd_mfma(const void* qkv, void* o, int C, int n_head, const Tan
 }
 bool try_attn_fwd_mfma(const void* qkv, void* o, int dtype, int C, int n_head, const TanteSeq& sq, int causal, float p_drop, unsigned long long seed,
                        hipStream_t s) {
-  static const bool off = getenv("TANTE_ATTN_FWD_VALU") != nullptr;
+  const bool off = tante_opt("TANTE_ATTN_FWD_VALU", 0) != 0;
   if (off || dtype != TANTE_BF16 || C != n_head * 32 || sq.L > 64 || sq.L < 1) return false;
   const int L = sq.L;
   const int SPT = L >= 16 ? 1 : 16 / L;

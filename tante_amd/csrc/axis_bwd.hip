@@ -386,7 +386,7 @@ void ab_launch(const float* x, const float* dy, long outer, long inner, const fl
   static TantePerDevice attr;
   attr.once([&] { (void)hipFuncSetAttribute((const void*)axis_bwd_fused_kernel<MT>, hipFuncAttributeMaxDynamicSharedMemorySize, ab_lds(MT)); });
   const long n_tiles = outer * (inner / (AB_CT * AB_NG));
-  static const long cap_env = getenv("TANTE_AXIS_BWD_WGS") ? atol(getenv("TANTE_AXIS_BWD_WGS")) : 0;
+  const long cap_env = tante_opt("TANTE_AXIS_BWD_WGS", 0);
   long wgs = cap_env > 0 ? cap_env : (MT >= 3 ? 512 : 1024);   // as many as are resident (LDS: 2 per CU at n = 48, 4+ below), each walking its share of the tiles
   if (wgs > n_tiles) wgs = n_tiles;
   const long slabf = 2L * (16 * MT) * (16 * MT) + 2 * 16 * MT;
@@ -411,7 +411,7 @@ template <int N>
 static void ab_launch_small(const float* x, const float* dy, long outer, long inner, const float* w1, const float* b1, const float* w2, float* dx,
                             float* dW1, float* db1, float* dW2, float* db2, float* ws, hipStream_t s) {
   const long total = outer * (inner / 4);
-  static const long cap_env = getenv("TANTE_AXIS_BWD_SMALL_WGS") ? atol(getenv("TANTE_AXIS_BWD_SMALL_WGS")) : 0;
+  const long cap_env = tante_opt("TANTE_AXIS_BWD_SMALL_WGS", 0);
   long wgs = (total + 255) / 256;
   const long cap = cap_env > 0 ? cap_env : 512;      // measured at cfg3 (393 k float4 columns): 37.5 us at 512, 40.6 at 256, 45.5 at 1024, 54 at 2048
   if (wgs > cap) wgs = cap;

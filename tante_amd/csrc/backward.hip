@@ -1064,15 +1064,15 @@ void launch_attn_bwd_mfma(const void* qkv, const void* dO, void* dqkv, int C, in
 }
 bool try_attn_bwd_mfma(const void* qkv, const void* dO, void* dqkv, int dtype, int C, int n_head, const TanteSeq& sq, int causal, float p_drop,
                        unsigned long long seed, hipStream_t s) {
-  static const bool off = getenv("TANTE_ATTN_BWD_VALU") != nullptr;
+  const bool off = tante_opt("TANTE_ATTN_BWD_VALU", 0) != 0;
   if (off || dtype != TANTE_BF16 || C != n_head * 32 || sq.L > 64 || sq.L < 1) return false;
   if (((uintptr_t)qkv | (uintptr_t)dO | (uintptr_t)dqkv) & 15) return false;
   const int L = sq.L;
   const int SPT = L >= 16 ? 1 : 16 / L;
   const int units = L >= 16 ? sq.nseq : (sq.nseq + SPT - 1) / SPT;
-  static const bool no_split = getenv("TANTE_ATTN_BWD_NO_SPLIT") != nullptr;
+  const bool no_split = tante_opt("TANTE_ATTN_BWD_NO_SPLIT", 0) != 0;
   if (!no_split && L > 16) {      // whole sequences of 2 - 4 tiles: NT waves per (sequence, head)
-    static const int hg_env = getenv("TANTE_ATTN_BWD_HG") ? atoi(getenv("TANTE_ATTN_BWD_HG")) : 1;      // heads per workgroup: 29.2 / 31.2 / 36.4 us at 1 / 2 / 4 (L = 48, cfg3)
+    const int hg_env = tante_opt("TANTE_ATTN_BWD_HG", 1);      // heads per workgroup: 29.2 / 31.2 / 36.4 us at 1 / 2 / 4 (L = 48, cfg3)
     const int nt = (L + 15) / 16;
     if (hg_env == 2 && n_head % 2 == 0) {
       if (nt == 2) launch_attn_bwd_split<2, 2>(qkv, dO, dqkv, C, n_head, sq, causal, p_drop, seed, s);
@@ -1532,7 +1532,7 @@ extern "C" int tante_axis_wgrad_ws(const float* U, const float* V, int64_t outer
   // atomics) is per workgroup and was what the kernel's time followed (n = 48: 39 / 66 / 85 us at 256 / 512 / 683 workgroups of 4 waves)
   const int nthr = n > 16 ? 512 : 256;
   long wgs = (n_chunks + 3 * (nthr / 64) - 1) / (3 * (nthr / 64));          // at least three chunks per wave
-  static const long wg_cap = getenv("TANTE_AXIS_WGRAD_WGS") ? atol(getenv("TANTE_AXIS_WGRAD_WGS")) : 0;
+  const long wg_cap = tante_opt("TANTE_AXIS_WGRAD_WGS", 0);
   const long cap = wg_cap ? (wg_cap > AW_MAXWG && ws ? AW_MAXWG : wg_cap) : (n > 16 ? 256 : 512);
   if (wgs > cap) wgs = cap;
   if (wgs < 1) wgs = 1;
@@ -1628,7 +1628,7 @@ extern "C" int tante_colsum(const void* x, int dtype, int64_t outer, int C, int6
   if (!accumulate && tante_zero_async(out, (size_t)C * sizeof(float), s) != hipSuccess) TANTE_FAIL(-3, "tante_colsum: memset failed");
   if (inner == 1 && dtype == TANTE_BF16 && C % 8 == 0 && C <= 2048 && 256 % (C / 8) == 0 && ((uintptr_t)x % 16) == 0) {
     long chunks = 1024;                                      // at least 512 rows per workgroup: every workgroup ends in C same-address atomics (9.4 MB of 256-channel rows: 17.6 / 11.5 / 9.7 / 10.7 / 15.1 us at 128 / 256 / 512 / 1024 / 2048 rows)
-    static const long cs_rows = getenv("TANTE_COLSUM_ROWS") ? atol(getenv("TANTE_COLSUM_ROWS")) : 512;
+    const long cs_rows = tante_opt("TANTE_COLSUM_ROWS", 512);
     if (chunks > (outer + cs_rows - 1) / cs_rows) chunks = (outer + cs_rows - 1) / cs_rows;
     const long chunk = (outer + chunks - 1) / chunks;
     hipLaunchKernelGGL(colsum_bf16_vec_kernel, dim3((unsigned)((outer + chunk - 1) / chunk)), dim3(256), 0, s, (const unsigned short*)x, (long)outer, C,
@@ -1708,7 +1708,7 @@ extern "C" int tante_film_pos_bwd_frames(const float* dy, const TanteFrames* fra
   if (tante_zero_async(da, (size_t)T * C * sizeof(float), s) != hipSuccess || tante_zero_async(db, (size_t)T * C * sizeof(float), s) != hipSuccess)
     TANTE_FAIL(-3, "tante_film_pos_bwd_frames: clear failed");
   const long BT = B * T;
-  static const int rows_env = getenv("TANTE_FILM_BWD_ROWS") ? atoi(getenv("TANTE_FILM_BWD_ROWS")) : 64;      // 64 rows per workgroup: 20.7 us against 30.2 at 32 (every workgroup ends in 512 same-address atomics)
+  const int rows_env = tante_opt("TANTE_FILM_BWD_ROWS", 64);      // 64 rows per workgroup: 20.7 us against 30.2 at 32 (every workgroup ends in 512 same-address atomics)
   if (rows_env != 16 && rows_env != 32)
     hipLaunchKernelGGL((film_pos_bwd256_kernel<true, 64>), dim3((unsigned)((HW + 63) / 64), (unsigned)BT), dim3(256), 0, s, dy, (const float*)nullptr, a, (long)HW, T,
                        (float*)nullptr, da, db, F);

@@ -719,7 +719,7 @@ void launch_block16(float* x, const char* stream, const TanteSeq& sq, int causal
 
 template <int CB, int HB>
 void launch_block(float* x, const char* stream, const TanteSeq& sq, int causal, float eps, hipStream_t s) {
-  static const int which = getenv("TANTE_BLOCK_KERNEL") ? atoi(getenv("TANTE_BLOCK_KERNEL")) : 16;
+  const int which = tante_opt("TANTE_BLOCK_KERNEL", 16);
   if (which == 16 && (sq.L == 32 || 16 % sq.L == 0)) return launch_block16<CB, HB>(x, stream, sq, causal, eps, s);
   constexpr int TH = 96 * CB * 4 * 16 + BIAS_BYTES, T2 = 64 * HB * 4 * 16 + BIAS_BYTES;
   constexpr int SLOT = TH > T2 ? TH : T2;
@@ -753,7 +753,7 @@ static int64_t block_ts_stream_bytes(int C, int hidden) {
 // which kernel family runs a shape: the feature-sliced kernel (block_sliced.hip) wherever it applies (C = 256, 8 heads, hidden 256,
 // any L <= 128); TANTE_BLOCK_KERNEL=16 / 32 forces the round-1 kernels for A/B timing (both compute the same function)
 static bool use_fs(int C, int n_head, int hidden, int L, int causal) {
-  static const int which = getenv("TANTE_BLOCK_KERNEL") ? atoi(getenv("TANTE_BLOCK_KERNEL")) : 0;
+  const int which = tante_opt("TANTE_BLOCK_KERNEL", 0);
   if (!tante_fs_supported(C, n_head, hidden, L, causal)) return false;
   return which == 0 || !block_ts_supported(C, n_head, hidden, L);
 }

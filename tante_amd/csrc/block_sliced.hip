@@ -64,7 +64,7 @@ struct FsArgs {
       __builtin_amdgcn_sched_barrier(0);                                                                   \
       asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                          \
       __builtin_amdgcn_sched_barrier(0);                                                                   \
-      if (lane == 0) A.stamps[((long)blockIdx.x * 8 + wave) * 20 + (k)] = t_;                               \
+      if (lane == 0) A.stamps[((long)vblock * 8 + wave) * 20 + (k)] = t_;                               \
     }                                                                                                      \
   } while (0)
 unsigned long long* g_fs_stamps = nullptr;
@@ -104,8 +104,17 @@ constexpr int fs_group(int ntt, int nk) {
 // block-diagonal mask), 0 = any L <= 16 NTT (every key tile, element masks).  NTT = token tiles per workgroup.  NW = waves per
 // workgroup: 8 (one workgroup per CU, a wave = one head / 32 output features) or 4 (two independent workgroups per CU, a wave = two
 // heads / 64 output features: while one workgroup is in a VALU or memory phase the other one's MFMAs have the matrix pipes).
-template <int TPS, int NTT, int NW, bool TRAIN>
-__global__ __launch_bounds__(64 * NW, 2) void block_fs_kernel(FsArgs A) {
+//
+// G = 2 ("paired" form, round 3): ONE 8-wave workgroup per CU made of two independent 4-wave GROUPS, each the 4-wave kernel on its own
+// 64 (48) tokens with its own LDS images -- the same instruction stream, but group 1 runs it ONE BARRIER SEGMENT behind group 0 (it
+// takes one extra workgroup barrier at entry, group 0 one at exit) and two alignment barriers split the mixed segments, so that the
+// segments alternate  LayerNorm1 | q,k,v GEMMs | attention | out-proj | LayerNorm2 | fc1 | GELU | fc2 + store  = vector, MATRIX, vector,
+// MATRIX, ...  Waves w and w + 4 share a SIMD: whenever one group is in a matrix segment its partner on the SIMD is in a vector / memory
+// segment, by construction and for the whole launch (two independent workgroups start together and stay in step: MFMA-only phases
+// beside MFMA-only phases, with the matrix pipe idle through every LayerNorm / softmax / GELU phase -- SQ_VALU_MFMA_COEXEC 11 %).
+template <int TPS, int NTT, int NW, bool TRAIN, int G = 1>
+__global__ __launch_bounds__(64 * NW * G, 2) void block_fs_kernel(FsArgs A) {
+  static_assert(G == 1 || (G == 2 && NW == 4), "the paired form is two 4-wave groups");
   constexpr int RT = 16 / NW;            // 16-row output tiles per wave
   constexpr int HPW = RT / 2;            // heads per wave
 #ifndef FS_PF8
@@ -116,23 +125,35 @@ __global__ __launch_bounds__(64 * NW, 2) void block_fs_kernel(FsArgs A) {
 #endif
   constexpr int PF = NW == 8 ? FS_PF8 : FS_PF4;    // weight k-steps in flight
   constexpr int IMG = 16 * NTT * FS_ROW;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int LDS_G = 2 * IMG + 16 * NTT * NW * 8 + FS_BIAS_FLOATS * 4;      // bytes of LDS per group
+  extern __shared__ __attribute__((aligned(16))) char smem_all[];
+  const int grp = G == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8);      // wave-uniform, provably
+  char* const smem = smem_all + grp * LDS_G;
   char* const bufA = smem;                 // LayerNorm1(x), later LayerNorm2(x1)
   char* const bufB = smem + IMG;           // attention output, later the GELU-ed hidden
   char* const stat = smem + 2 * IMG;       // float2 [16 NTT tokens][NW waves]
   float* const lbias = (float*)(stat + 16 * NTT * NW * 8);   // the 4 x 256 biases (a global load per GEMM start would expose its latency)
-  const int tid = threadIdx.x, lane = tid & 63, kk = lane >> 4, l15 = lane & 15;
+  const int tid = threadIdx.x & (64 * NW - 1), lane = tid & 63, kk = lane >> 4, l15 = lane & 15;      // thread within the group
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int vblock = (int)blockIdx.x * G + grp;      // the group's index = the workgroup index of the unpaired form
+#ifndef FS_SKEW
+#define FS_SKEW 1      // 0: experiment -- the two groups of the paired form in step (same barriers, no offset, no alignment barriers)
+#endif
+  if constexpr (G == 2 && FS_SKEW) {
+    if (grp == 1) __builtin_amdgcn_s_barrier();      // one segment behind group 0 from here on (group 0 takes its extra barrier at exit)
+  }
 #ifdef FS_PRIO
   // experiment: the two workgroups of a CU run in lockstep through MFMA-only and VALU-only phases.  Waves in odd hardware slots (HW_ID
   // bits 3:0) get issue priority for the whole kernel, so that the pair drifts apart instead of sharing every phase
-  if ((__builtin_amdgcn_s_getreg(0x1804) & 1u) == (FS_PRIO & 1)) __builtin_amdgcn_s_setprio(3);
+  if constexpr (G == 1) {
+    if ((__builtin_amdgcn_s_getreg(0x1804) & 1u) == (FS_PRIO & 1)) __builtin_amdgcn_s_setprio(3);
+  }
 #endif
   float* const x = A.x;
   const unsigned long long smix = (TRAIN && A.seed_mix) ? *A.seed_mix : 0ull;      // per-step word of a replayed train step
   const unsigned long long sd_attn = A.seed_attn ^ smix;
   const int L = A.sq.L;
-  const int seq0 = blockIdx.x * A.spw;
+  const int seq0 = vblock * A.spw;
   const int nlive = min(A.spw, A.sq.nseq - seq0) * L;     // live token slots of this workgroup (the rest of spw * L is dead)
   const int nslot = A.spw * L;                            // slots in use by whole sequences (<= 16 NTT)
 
@@ -143,9 +164,9 @@ __global__ __launch_bounds__(64 * NW, 2) void block_fs_kernel(FsArgs A) {
   FS_STAMP(0);
 #ifdef TANTE_ABLATE
   if (A.stamps && lane == 0) {   // where this wave runs: HW_REG_HW_ID (id 4) and HW_REG_XCC_ID (id 20), and the 100 MHz wall clock
-    A.stamps[((long)blockIdx.x * 8 + wave) * 20 + 16] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
-    A.stamps[((long)blockIdx.x * 8 + wave) * 20 + 17] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
-    A.stamps[((long)blockIdx.x * 8 + wave) * 20 + 18] = __builtin_amdgcn_s_memrealtime();
+    A.stamps[((long)vblock * 8 + wave) * 20 + 16] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+    A.stamps[((long)vblock * 8 + wave) * 20 + 17] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+    A.stamps[((long)vblock * 8 + wave) * 20 + 18] = __builtin_amdgcn_s_memrealtime();
   }
 #endif
   int tslot[2];
@@ -441,6 +462,7 @@ __global__ __launch_bounds__(64 * NW, 2) void block_fs_kernel(FsArgs A) {
           vtf[hh][dt][p] = (2 * p + 1 < NTT) ? pack8(av[2 * hh + dt][2 * p], av[2 * hh + dt][2 * p + 1]) : pack8(av[2 * hh + dt][2 * p], zero4);
   }
   FS_STAMP(6);
+  if constexpr (G == 2 && FS_SKEW) __builtin_amdgcn_s_barrier();      // alignment only: MATRIX segment (q, k, v) | vector segment (attention)
 
   // ---- attention: per head and query tile, S^T = K Q^T over its key tiles, softmax down the accumulator rows, O^T = V^T P^T ----
   {
@@ -606,6 +628,9 @@ __global__ __launch_bounds__(64 * NW, 2) void block_fs_kernel(FsArgs A) {
   asm volatile("" ::: "memory");   // keep the residual loads below the attention (they would double its register pressure)
   // residual slice of this wave: x[token][16 RT w .. + 16 RT), row form; the loads fly while the out-proj GEMM runs
   f32x4 xraw[NTT][RT];
+#ifndef FS_RESID_FIRST
+  fs_wring_prime<3, RT, PF>(wq, wb);      // ahead of the residual rows in the wave's (in-order) memory queue: the out-proj GEMM starts on them
+#endif
 #ifdef FS_EXP_NO_RESID     // timing experiment only (wrong results)
 #pragma unroll
   for (int tt = 0; tt < NTT; ++tt)
@@ -614,7 +639,9 @@ __global__ __launch_bounds__(64 * NW, 2) void block_fs_kernel(FsArgs A) {
 #else
   slice_load(x, xraw);
 #endif
-  fs_wring_prime<3, RT, PF>(wq, wb);
+#ifdef FS_RESID_FIRST
+  fs_wring_prime<3, RT, PF>(wq, wb);      // (round-2 order, kept for the A/B)
+#endif
   FS_STAMP(8);
   __syncthreads();
   FS_STAMP(9);
@@ -718,6 +745,7 @@ __global__ __launch_bounds__(64 * NW, 2) void block_fs_kernel(FsArgs A) {
     }
     fs_slice_gemm<4, 48, NTT, RT, false, PF>(wq, wb, bufA, rdo, h);
     FS_STAMP(13);
+    if constexpr (G == 2 && FS_SKEW) __builtin_amdgcn_s_barrier();    // alignment only: MATRIX segment (fc1) | vector segment (GELU)
 #pragma unroll
     for (int tt = 0; tt < NTT; ++tt) {
       if constexpr (TRAIN) {     // the pre-activation passes through the image columns the GELU-ed values take next
@@ -771,7 +799,7 @@ __global__ __launch_bounds__(64 * NW, 2) void block_fs_kernel(FsArgs A) {
     }
     FS_STAMP(15);
 #ifdef TANTE_ABLATE
-    if (A.stamps && lane == 0) A.stamps[((long)blockIdx.x * 8 + wave) * 20 + 19] = __builtin_amdgcn_s_memrealtime();
+    if (A.stamps && lane == 0) A.stamps[((long)vblock * 8 + wave) * 20 + 19] = __builtin_amdgcn_s_memrealtime();
 #endif
 #ifdef FS_EXP_NO_STORE     // timing experiment only (wrong results): one store per tile keeps the accumulators alive
 #pragma unroll
@@ -786,6 +814,9 @@ __global__ __launch_bounds__(64 * NW, 2) void block_fs_kernel(FsArgs A) {
 #else
     slice_store(TRAIN ? A.out : x, x1);      // bufA: LayerNorm2's image died with the fc1 GEMM (barrier 5)
 #endif
+  }
+  if constexpr (G == 2 && FS_SKEW) {
+    if (grp == 0) __builtin_amdgcn_s_barrier();      // pairs with group 1's entry barrier: both groups execute the same number
   }
 }
 
@@ -891,26 +922,34 @@ __global__ void fs_pack_multi_kernel(FsPackBatch B) {
   fs_pack_body((int)blockIdx.x - e * FSP_BLOCKS, q[0], q[1], nullptr, nullptr, q[2], q[3], q[4], q[5], nullptr, nullptr, q[6], q[7], B.dst[e]);
 }
 
-template <int TPS, int NTT, int NW, bool TRAIN>
+template <int TPS, int NTT, int NW, bool TRAIN, int G = 1>
 void fs_launch_tt(const FsArgs& A, int nwg, hipStream_t s) {
-  constexpr int LDS = 2 * 16 * NTT * FS_ROW + 16 * NTT * NW * 8 + FS_BIAS_FLOATS * 4;
+  constexpr int LDS = G * (2 * 16 * NTT * FS_ROW + 16 * NTT * NW * 8 + FS_BIAS_FLOATS * 4);
+  static_assert(LDS <= 160 * 1024, "LDS per workgroup");
   static TantePerDevice attr;
-  attr.once([&] { (void)hipFuncSetAttribute((const void*)block_fs_kernel<TPS, NTT, NW, TRAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); });
-  hipLaunchKernelGGL((block_fs_kernel<TPS, NTT, NW, TRAIN>), dim3(nwg), dim3(64 * NW), LDS, s, A);
+  attr.once([&] { (void)hipFuncSetAttribute((const void*)block_fs_kernel<TPS, NTT, NW, TRAIN, G>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); });
+  hipLaunchKernelGGL((block_fs_kernel<TPS, NTT, NW, TRAIN, G>), dim3((nwg + G - 1) / G), dim3(64 * NW * G), LDS, s, A);
 }
+// TANTE_FS_GROUPS = 2 (tante_set_option) selects the paired form; the default is the unpaired one.  Both compute the same function, bit for
+// bit (tools/fs_ab.py asserts it).  MEASURED (round 3, one box, interleaved rounds, cfg2 B = 8): the paired form is 1.2 - 2.3 us SLOWER per
+// launch (T 36.3 -> 38.1, H 35.3 -> 37.5, W 34.3 -> 36.5 us), also with the weight stream served from L1 and without the x loads / stores
+// (timing builds: 26.0 -> 26.8 us), and with the two groups in step instead of offset (-DFS_SKEW=0: 34.0 -> 35.3 us).  Anti-phase by
+// construction buys nothing: what the launch waits for is not the matrix pipe being idle in vector phases.
 // the training form exists for the 4-wave kernels (sequences up to 64 tokens: every shipped axis letter); longer ones train unfused
 template <int TPS, int NTT, int NW>
 void fs_launch_t(const FsArgs& A, int nwg, hipStream_t s) {
   if constexpr (NW == 4) {
     if (A.out) return fs_launch_tt<TPS, NTT, NW, true>(A, nwg, s);
+    const int groups = tante_opt("TANTE_FS_GROUPS", 0);
+    if (groups == 2) return fs_launch_tt<TPS, NTT, NW, false, 2>(A, nwg, s);
   }
   fs_launch_tt<TPS, NTT, NW, false>(A, nwg, s);
 }
 
 // waves per workgroup: 4 = two independent 64-token workgroups per CU (sequences up to 64 tokens), 8 = one 128-token workgroup per
-// CU (any L <= 128).  TANTE_FS_WAVES=8 forces the 8-wave form everywhere (A/B timing; both compute the same function).
+// CU (any L <= 128).  tante_set_option("TANTE_FS_WAVES", 8) forces the 8-wave form everywhere (A/B timing; both compute the same function).
 int fs_waves(int L) {
-  static const int force8 = getenv("TANTE_FS_WAVES") && atoi(getenv("TANTE_FS_WAVES")) == 8;
+  const int force8 = tante_opt("TANTE_FS_WAVES", 0) == 8;
   return (force8 || L > 64) ? 8 : 4;
 }
 

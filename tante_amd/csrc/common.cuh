@@ -12,6 +12,7 @@
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
@@ -80,6 +81,13 @@ constexpr int TANTE_AW_GS = 16;
 constexpr int TANTE_AW_MAXWG = 1024;
 constexpr int TANTE_AW_SLAB = 64 * 64 + 64;
 constexpr long TANTE_AW_WS_FLOATS = (long)TANTE_AW_MAXWG * TANTE_AW_SLAB + TANTE_AW_MAXWG / TANTE_AW_GS;
+
+// ---- tuning options ------------------------------------------------------------------------------
+// The product library never reads the environment.  Its launch heuristics (workgroup counts, kernel-variant choices: every one an
+// A/B switch between forms that compute the same function) look their overrides up in ONE process-wide table that only
+// tante_set_option() writes (include/tante_hip.h; defined in pointwise.hip).  The Python binding forwards TANTE_* environment
+// variables into it at load time (tante_amd/_lib.py), which is what the measurement scripts under tools/ use.
+int tante_opt(const char* name, int dflt);
 
 // ---- timing-ablation switches ------------------------------------------------------------------
 // TANTE_*_DEBUG skip parts of a kernel to time the rest; the results are WRONG by construction, so the shipped library

@@ -219,7 +219,7 @@ void launch_enc23_s(const EncArgs& A, long rows, hipStream_t s) {
 template <int CB>
 void launch_enc23(const EncArgs& A, hipStream_t s) {
   const long rows = (long)A.n_img * A.Hp * A.Wp;
-  static const int force = getenv("TANTE_ENC23_SPLIT") ? atoi(getenv("TANTE_ENC23_SPLIT")) : 0;
+  const int force = tante_opt("TANTE_ENC23_SPLIT", 0);
   const int groups = (int)((rows + 127) / 128);
   const int split = force ? force : (groups <= 64 ? 4 : groups <= 128 ? 2 : 1);      // fill the CUs when the input is one frame
   if (split >= 4) launch_enc23_s<CB, 4>(A, rows, s);

@@ -14,6 +14,13 @@ constexpr int FS_BIAS_FLOATS = 7 * FS_C;                   // by output feature:
 constexpr int FS_ROW = 512;                                // bytes per token row of an LDS image
 
 __device__ __forceinline__ u32x4 ldg_frag(const char* p) { return *(const u32x4*)p; }
+// timing experiment only (-DFS_EXP_NO_WLOAD, wrong results): every fragment load of the weight stream re-reads the stream's FIRST k-step
+// (16 KiB per workgroup, L1-resident) -- the same instructions and waits, none of the L2 -> L1 traffic.  Prices the weight stream.
+#ifdef FS_EXP_NO_WLOAD
+#define FS_WOFF(f) ((f) % 16)
+#else
+#define FS_WOFF(f) (f)
+#endif
 
 // ---- cross-lane reductions without LDS traffic -------------------------------------------------------------------------------------
 // over the 16 lanes of a row (lanes that share lane >> 4): DPP quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror
@@ -66,7 +73,7 @@ __device__ __forceinline__ void fs_wring_prime(const char* wq, u32x4 (&wb)[PF + 
 #pragma unroll
   for (int p = 0; p < PF; ++p)
 #pragma unroll
-    for (int j = 0; j < RT; ++j) wb[(8 * M + p) % (PF + 1)][j] = ldg_frag(wq + (16 * (8 * M + p) + j) * FS_FRAG);
+    for (int j = 0; j < RT; ++j) wb[(8 * M + p) % (PF + 1)][j] = ldg_frag(wq + FS_WOFF(16 * (8 * M + p) + j) * FS_FRAG);
 }
 template <int M, int GEND, int NTT, int RT, bool SWAP, int PF>
 __device__ __forceinline__ void fs_slice_gemm(const char* wq, u32x4 (&wb)[PF + 1][RT], const char* img, const int (&rdo)[4],
@@ -74,6 +81,9 @@ __device__ __forceinline__ void fs_slice_gemm(const char* wq, u32x4 (&wb)[PF + 1
   unsigned ab[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) ab[j] = lds_addr(img + rdo[j]);
+#ifdef FS_EXP_MFMA32
+  u32x4 fs_prev_tf = u32x4{0u, 0u, 0u, 0u};
+#endif
   mfma_stream<8 * NTT, 4>(
       [&](auto ic) {
         constexpr int i = decltype(ic)::value, ks = i / NTT, tt = i % NTT;
@@ -83,8 +93,32 @@ __device__ __forceinline__ void fs_slice_gemm(const char* wq, u32x4 (&wb)[PF + 1
         constexpr int i = decltype(ic)::value, ks = i / NTT, tt = i % NTT, g = 8 * M + ks;
         if constexpr (tt == 0 && g + PF < GEND) {
 #pragma unroll
-          for (int j = 0; j < RT; ++j) wb[(g + PF) % (PF + 1)][j] = ldg_frag(wq + (16 * (g + PF) + j) * FS_FRAG);
+          for (int j = 0; j < RT; ++j) wb[(g + PF) % (PF + 1)][j] = ldg_frag(wq + FS_WOFF(16 * (g + PF) + j) * FS_FRAG);
         }
+#ifdef FS_EXP_MFMA32
+        // TIMING EXPERIMENT ONLY (wrong results): the same loads, the same operand and accumulator registers, half as many MFMAs of
+        // twice the size -- v_mfma_f32_32x32x16_bf16 on the 2 x 2 groups of this wave's 16 x 16 tiles.  Prices the instruction shape
+        // (8 of 32 issue cycles held instead of 8 of 16) before anyone rewrites the accumulator layout of every epilogue for it.
+        if constexpr (RT % 2 == 0 && NTT % 2 == 0) {
+          if constexpr (tt % 2 == 1) {
+#pragma unroll
+            for (int j = 0; j < RT; j += 2) {
+              f32x16 big = __builtin_shufflevector(__builtin_shufflevector(acc[j][tt - 1], acc[j][tt], 0, 1, 2, 3, 4, 5, 6, 7),
+                                                   __builtin_shufflevector(acc[j + 1][tt - 1], acc[j + 1][tt], 0, 1, 2, 3, 4, 5, 6, 7),
+                                                   0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+              big = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wb[g % (PF + 1)][j]), __builtin_bit_cast(bf16x8, tf), big, 0, 0, 0);
+              big = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wb[g % (PF + 1)][j + 1]), __builtin_bit_cast(bf16x8, fs_prev_tf), big, 0, 0, 0);
+              acc[j][tt - 1] = __builtin_shufflevector(big, big, 0, 1, 2, 3);
+              acc[j][tt] = __builtin_shufflevector(big, big, 4, 5, 6, 7);
+              acc[j + 1][tt - 1] = __builtin_shufflevector(big, big, 8, 9, 10, 11);
+              acc[j + 1][tt] = __builtin_shufflevector(big, big, 12, 13, 14, 15);
+            }
+          } else {
+            fs_prev_tf = tf;
+          }
+          return;
+        }
+#endif
 #pragma unroll
         for (int j = 0; j < RT; ++j) {
           if constexpr (SWAP) acc[j][tt] = mfma_bf16(tf, wb[g % (PF + 1)][j], acc[j][tt]);

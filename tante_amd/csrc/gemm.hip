@@ -661,7 +661,7 @@ void launch_lite(const TanteGemm& g, int n_tiles, hipStream_t s) {
 
 template <int CB>
 bool try_lite(const TanteGemm& g, int n_tiles, int flags, hipStream_t s) {
-  static const bool off = getenv("TANTE_GEMM_NO_LITE") != nullptr;
+  const bool off = tante_opt("TANTE_GEMM_NO_LITE", 0) != 0;
   if ((off && g.drop_p <= 0.0f && !g.dact) || g.ln || g.a_mode != TANTE_A_LINEAR || g.a_dtype != TANTE_BF16 || (flags & 3) != 3 || g.e_mode != TANTE_E_LINEAR) return false;
   if (g.K != CB * 32 || g.M < 4096) return false;   // whole 32-wide k blocks: the raw fragment loads have no K tail
   if (g.drop_p > 0.0f || g.dact) {
@@ -775,7 +775,7 @@ void launch_variant(const TanteGemm& g, int n_tiles, int flags, hipStream_t s) {
   const int rows_per_wg = 4 * TT * 16;
   const int gx = (g.M + rows_per_wg - 1) / rows_per_wg;
   int nsplit = 1;
-  static const int target = getenv("TANTE_GEMM_WGS") ? atoi(getenv("TANTE_GEMM_WGS")) : 512;
+  const int target = tante_opt("TANTE_GEMM_WGS", 512);
   // every N-split re-loads (and re-normalises) the token rows, so split only while the grid is short of WGs
   while (nsplit < n_tiles && (long)gx * nsplit < target && (n_tiles % (nsplit * 2) == 0)) nsplit *= 2;
   const int per = (n_tiles + nsplit - 1) / nsplit;

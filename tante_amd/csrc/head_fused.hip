@@ -335,7 +335,7 @@ template <int CB>
 void launch_head(HeadArgs A, hipStream_t s) {
   // 128-token groups (8 waves) once they still give every CU a workgroup; 64-token groups for small batches
   const long rows = (long)A.n_img * A.Hp * A.Wp;
-  static const int force = getenv("TANTE_HEAD_WAVES") ? atoi(getenv("TANTE_HEAD_WAVES")) : 0;
+  const int force = tante_opt("TANTE_HEAD_WAVES", 0);
   const bool wide = force ? force == 8 : rows >= 128 * 56;
   if (wide) launch_head_nw<CB, 8>(A, s);
   else launch_head_nw<CB, 4>(A, s);

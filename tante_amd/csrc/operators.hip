@@ -1125,7 +1125,7 @@ extern "C" int tante_cross_attention(const void* q, const void* k, const void* v
   if ((Lq + 255) / 256 > 65535 || n_batch * n_head > 2147483647L) TANTE_FAIL(-2, "tante_cross_attention: grid too large");
   const float scale = 1.0f / sqrtf((float)D);
   hipStream_t s = (hipStream_t)stream;
-  static const bool force_valu = getenv("TANTE_XATTN_VALU") && atoi(getenv("TANTE_XATTN_VALU"));
+  const bool force_valu = tante_opt("TANTE_XATTN_VALU", 0) != 0;
   if (dtype == TANTE_BF16 && D == XD && Lk <= 512 && !force_valu && ldq % 8 == 0 && ldkv % 8 == 0 && ldo % 4 == 0 &&
       ((uintptr_t)q % 16) == 0 && ((uintptr_t)k % 16) == 0 && ((uintptr_t)v % 16) == 0 && ((uintptr_t)o % 8) == 0) {
     const int Sp = ((Lk + 127) / 128) * 128;

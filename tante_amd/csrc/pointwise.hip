@@ -1,6 +1,8 @@
 // HBM-bound stages of the TANTE path: axis propagators, FiLM tables, Taylor sum, step-size reduction.
 #include "common.cuh"
 #include <stdlib.h>
+#include <string.h>
+#include <mutex>
 
 namespace {
 
@@ -879,15 +881,15 @@ static int axis_hw_impl(float* x, const AxisSrc& S, int64_t BT, int nH, int nW, 
   auto wbytes = [](int m) { return (size_t)(2 * m * ((m + 1) / 2) * 1024 + 2 * 16 * m * 4); };   // = axe_wbytes<m>()
   const size_t wst_bytes = wbytes(nH / 16) + wbytes(nW / 16);
   if (compute == TANTE_BF16 && nH % 16 == 0 && nW % 16 == 0 && nH <= 64 && nW <= 64 && C % 16 == 0 && ((uintptr_t)x % 16) == 0 &&
-      (size_t)nH * axe_rs(nW, 16) * sizeof(float) + wst_bytes <= 160 * 1024 && !getenv("TANTE_AXIS_GENERIC")) {
+      (size_t)nH * axe_rs(nW, 16) * sizeof(float) + wst_bytes <= 160 * 1024 && !tante_opt("TANTE_AXIS_GENERIC", 0)) {
     // 32-channel tiles (whole 128-byte lines per token) when the plane fits the LDS that way and still gives every CU a workgroup
-    static const int force_ct = getenv("TANTE_AXIS_CT") ? atoi(getenv("TANTE_AXIS_CT")) : 0;
+    const int force_ct = tante_opt("TANTE_AXIS_CT", 0);
     const bool fits32 = C % 32 == 0 && (size_t)nH * axe_rs(nW, 32) * sizeof(float) + wst_bytes <= 160 * 1024;
     const int ct = force_ct == 16 ? 16 : ((fits32 && (force_ct == 32 || BT * (C / 32) >= 192)) ? 32 : 16);
     const size_t elds = (size_t)nH * axe_rs(nW, ct) * sizeof(float) + wst_bytes;
     const unsigned grid = (unsigned)(BT * (C / ct));
     // 16 waves for the 32-channel tiles when the fragments fit 128 registers (measured 16.2 against 17.2 us at 32 x 32)
-    static const int force_nt = getenv("TANTE_AXIS_NT") ? atoi(getenv("TANTE_AXIS_NT")) : 0;
+    const int force_nt = tante_opt("TANTE_AXIS_NT", 0);
     const int nt32 = force_nt ? force_nt : ((nH <= 32 && nW <= 32) ? 1024 : 512);
 #ifdef TANTE_ABLATE
     unsigned long long* axe_st = g_axe_stamps;
@@ -1023,4 +1025,32 @@ void tante_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* tante_last_error(void) { return g_err; }
+
+// ---- tuning options (common.cuh: tante_opt) -------------------------------------------------------------------------------------
+// A small fixed table under a mutex: set rarely (start-up, A/B scripts), read once per launch by the host-side dispatch code.
+namespace {
+struct TanteOptEntry { char name[48]; int value; };
+constexpr int TANTE_OPT_MAX = 64;
+TanteOptEntry g_opts[TANTE_OPT_MAX];
+int g_nopts = 0;
+std::mutex g_opt_mutex;
+}  // namespace
+int tante_opt(const char* name, int dflt) {
+  std::lock_guard<std::mutex> lk(g_opt_mutex);
+  for (int i = 0; i < g_nopts; ++i)
+    if (!strcmp(g_opts[i].name, name)) return g_opts[i].value;
+  return dflt;
+}
+extern "C" int tante_set_option(const char* name, int value) {
+  if (!name || !*name || strlen(name) >= sizeof(g_opts[0].name)) TANTE_FAIL(-1, "tante_set_option: bad option name");
+  if (strncmp(name, "TANTE_", 6)) TANTE_FAIL(-1, "tante_set_option: option names start with TANTE_ (got '%s')", name);
+  std::lock_guard<std::mutex> lk(g_opt_mutex);
+  for (int i = 0; i < g_nopts; ++i)
+    if (!strcmp(g_opts[i].name, name)) { g_opts[i].value = value; return 0; }
+  if (g_nopts == TANTE_OPT_MAX) TANTE_FAIL(-1, "tante_set_option: table full");
+  strcpy(g_opts[g_nopts].name, name);
+  g_opts[g_nopts++].value = value;
+  return 0;
+}
+extern "C" int tante_get_option(const char* name, int dflt) { return name ? tante_opt(name, dflt) : dflt; }
 extern "C" int tante_abi_version(void) { return 1; }

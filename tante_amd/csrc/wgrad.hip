@@ -322,12 +322,12 @@ template <bool BF16, int T>
 void launch_wgrad(const TanteRowMat& U, const TanteRowMat& V, long R, int I, int J, float* dW, float* dbias, int layout, int P, int Co, int swap,
                   int mu, int mv, hipStream_t s, float* ws = nullptr, int64_t ws_bytes = 0) {
   const int ti = (I + T - 1) / T, tj = (J + T - 1) / T;
-  static const int wg_target = getenv("TANTE_WGRAD_WGS") ? atoi(getenv("TANTE_WGRAD_WGS")) : 512;
+  const int wg_target = tante_opt("TANTE_WGRAD_WGS", 512);
   // a single output tile with a workspace (the skinny weight gradients of the convolution stages: 98 k rows into 64 x 16 values): the
   // kernel is latency-bound -- one staged chunk in flight per workgroup -- and 384 workgroups of 4 chunks each left the chip 1.5
   // workgroups per CU (0.7 TB/s); with the partials stored and summed by a second kernel (no 384-deep same-address atomics) the row
   // range is cut into up to 1 536 pieces of at least one chunk
-  static const int slab_target = getenv("TANTE_WGRAD_SLAB_WGS") ? atoi(getenv("TANTE_WGRAD_SLAB_WGS")) : 1536;
+  const int slab_target = tante_opt("TANTE_WGRAD_SLAB_WGS", 1536);
   const bool slab_ok = ws != nullptr && ti == 1 && tj == 1 && slab_target > 0 && R >= 8 * RC;
   long split = (slab_ok ? slab_target : wg_target) / ((long)ti * tj);   // two workgroups per CU; fewer splits = less atomic traffic
   if (split < 1) split = 1;
@@ -645,23 +645,23 @@ static int rm_stage_mode(const TanteRowMat& m, int ncols) {
 // the LDS-DMA / transposed-read path for n_seg operand pairs of R rows each (dense bf16 rows, I and J multiples of 128, R % 32 == 0)
 static bool wgrad_tr_launch(const TanteRowMat* U, const TanteRowMat* V, int n_seg, long R, int I, int J, float* dW, float* dbias, int layout,
                             int P, int C_other, int swap, hipStream_t s, void* ws = nullptr, int64_t ws_bytes = 0) {
-  static const bool no_tr = getenv("TANTE_WGRAD_NO_TR") && atoi(getenv("TANTE_WGRAD_NO_TR"));
+  const bool no_tr = tante_opt("TANTE_WGRAD_NO_TR", 0) != 0;
   if (no_tr || n_seg < 1 || n_seg > WSEG || R % WRC) return false;
   for (int g = 0; g < n_seg; ++g)
     if (!wgrad_tr_ok(U[g], R, I) || !wgrad_tr_ok(V[g], R, J) || U[g].s0 != U[0].s0 || V[g].s0 != V[0].s0) return false;
   const int ti = I / WT, tj = J / WT;
   // every workgroup ends with 128 x 128 fp32 atomics: with the main loop at memory speed the split count is a trade between
   // parallelism and atomic traffic (64 KiB per workgroup) -- measured best near 128 workgroups for <= 4 tiles, 256 otherwise
-  static const int wg_env = getenv("TANTE_WGRAD_TR_WGS") ? atoi(getenv("TANTE_WGRAD_TR_WGS")) : (getenv("TANTE_WGRAD_WGS") ? atoi(getenv("TANTE_WGRAD_WGS")) : 0);
+  const int wg_env = tante_opt("TANTE_WGRAD_TR_WGS", tante_opt("TANTE_WGRAD_WGS", 0));
   // with a workspace the partial tiles are stored and summed by a second kernel instead of added atomically: the atomic traffic no
   // longer limits the split count, so the grid fills the chip twice (two 64 KB workgroups per CU)
-  static const bool no_slab = getenv("TANTE_WGRAD_NO_SLAB") && atoi(getenv("TANTE_WGRAD_NO_SLAB"));
+  const bool no_slab = tante_opt("TANTE_WGRAD_NO_SLAB", 0) != 0;
   const bool want_slab = ws != nullptr && !no_slab;
   // TANTE_WGRAD_RG=2 (experiment): eight-wave workgroups of two row groups, one per CU, which halves the partial-tile traffic -- and
   // LOSES to two independent 4-wave workgroups per CU (tools/wgrad_multi_time.py, 4 x 24 576 rows: 44.5 vs 40.1 us for 256 x 256,
   // 105 vs 90 us for 768 x 256): one barrier per chunk over eight waves keeps the two halves in step, two workgroups drift apart
-  static const int rg_env = getenv("TANTE_WGRAD_RG") ? atoi(getenv("TANTE_WGRAD_RG")) : 1;
-  static const int deep_env = getenv("TANTE_WGRAD_DEEP") ? atoi(getenv("TANTE_WGRAD_DEEP")) : -1;
+  const int rg_env = tante_opt("TANTE_WGRAD_RG", 1);
+  const int deep_env = tante_opt("TANTE_WGRAD_DEEP", -1);
   const int RGv = (want_slab && rg_env == 2 && deep_env <= 0) ? 2 : 1;
   const int wg_target = wg_env > 0 ? wg_env : (want_slab ? 512 / RGv : (ti * tj <= 4 ? 128 : 256));
   // splits PER SEGMENT (a split never straddles two segments): the workgroup target is shared by the segments
@@ -706,7 +706,7 @@ static bool wgrad_tr_launch(const TanteRowMat* U, const TanteRowMat* V, int n_se
     hipLaunchKernelGGL((wgrad_tr_kernel<4, 1>), dim3(n_wg), dim3(256), (size_t)4 * 2 * WCHUNK, s, SG, (long)U[0].s0, (long)V[0].s0, R * n_seg, I, J, per, dW,
                        dbias, layout, P, C_other, swap, wdebug, (int)total, slab, bias_slab);
   if (use_slab) {
-    static const int ny_env = getenv("TANTE_WGRAD_REDUCE_NY") ? atoi(getenv("TANTE_WGRAD_REDUCE_NY")) : 0;
+    const int ny_env = tante_opt("TANTE_WGRAD_REDUCE_NY", 0);
     const int ntile = ti * tj, ny = ny_env > 0 ? ny_env : (total >= 16 ? 4 : 1);   // more chunks = more atomics per output: 16 chunks measured 39 us against 14 us for 4
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(ntile * 16), (unsigned)ny), dim3(256), 0, s, slab, bias_slab, (int)total, ntile, ti, I, J,
                        dW, dbias, layout, P, C_other, swap);

@@ -34,6 +34,8 @@ def main():
     seq = K.dense_seq(ntok // Lq, Lq)
     st = blk._packed_fused()
     lib = L.lib()
+    groups = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+    L.set_option("TANTE_FS_GROUPS", groups)
     nwg = 4096
     stamps = torch.zeros(nwg * 8 * 20, dtype=torch.int64, device=dev)
     lib.tante_fs_set_stamps.argtypes = [C.c_void_p]
@@ -75,6 +77,15 @@ def main():
     print(f"first entry -> last stamp over the whole grid: {s[:, 15].max() - s[:, 0].min()} cycles; entry spread {s[:, 0].max() - s[:, 0].min()}")
     for k in range(15):
         print(f"  {NAMES[k + 1]:<28s} median {np.median(d[:, k]):8.0f}   p90 {np.percentile(d[:, k], 90):8.0f}   share {np.median(d[:, k]) / np.median(tot) * 100:5.1f} %")
+    if groups == 2 or (groups == 0 and ntok // 64 > 256):
+        # paired form: group = virtual block & 1; group 1 runs one barrier segment behind group 0
+        g1 = (wg & 1) == 1
+        print(f"paired form: span median group0 {np.median(tot[~g1]):.0f} group1 {np.median(tot[g1]):.0f}; "
+              f"group-0 entry -> group-1 last stamp (per CU pair, median): {np.median(s[g1, 15]) - np.median(s[~g1, 0]):.0f}")
+        for k in range(15):
+            print(f"  {NAMES[k + 1]:<28s} g0 {np.median(d[~g1, k]):8.0f}   g1 {np.median(d[g1, k]):8.0f}   "
+                  f"start offset g1-g0 {np.median(s[g1, k]) - np.median(s[~g1, k]):8.0f}")
+        return
     # the two workgroups of a CU sit in hardware wave slots of different parity (HW_ID bits 3:0); the product build gives the odd ones
     # issue priority (FS_PRIO): how far apart do the two run?
     odd = (hw & 1) == 1
