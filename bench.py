@@ -54,30 +54,89 @@ def parse():
     return p.parse_args()
 
 
+def visible_gpus():
+    """Number of GPUs this process would see, WITHOUT any torch.cuda / HIP call (the parent must not initialise the GPU before it starts
+    its ranks): the KFD topology (nodes with simd_count > 0), cut down by HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES.  None = unknown
+    (no sysfs): the pre-check is skipped then and every rank still fails loudly on its own (`LOCAL_RANK >= device_count`)."""
+    import glob
+    n = 0
+    nodes = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+    if not nodes:
+        return None
+    for f in nodes:
+        try:
+            with open(f) as fh:
+                props = dict(ln.split(None, 1) for ln in fh.read().splitlines() if " " in ln)
+            n += int(props.get("simd_count", "0")) > 0
+        except (OSError, ValueError):
+            return None
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([t for t in v.split(",") if t.strip() != ""]))
+    return n
+
+
 def launch_ranks(args) -> int:
     """--gpus N without a launcher: start N copies of this script, one per GPU, with the torchrun environment (RANK, LOCAL_RANK,
-    WORLD_SIZE, MASTER_ADDR = 127.0.0.1, a free MASTER_PORT).  Nothing here touches the GPU (device_count() does not initialise it),
-    so no initialised process is ever replaced or forked; rank 0's stdout (the one JSON line) is passed through."""
+    WORLD_SIZE, MASTER_ADDR = 127.0.0.1, a free MASTER_PORT).  Nothing here touches the GPU (the GPUs are counted from sysfs, not through
+    torch.cuda), so no initialised process is ever replaced or forked.  All ranks are polled: when one exits non-zero the others are
+    terminated after a short grace period (they would otherwise sit in the rendezvous or a collective until its timeout) and that exit
+    code is returned; every rank's stderr is passed through with its rank as a prefix, rank 0's stdout (the one JSON line) as it is."""
     import socket
     import subprocess
+    import threading
     n = args.gpus
-    have = torch.cuda.device_count()
-    if have < n:
-        raise SystemExit(f"bench.py: --gpus {n} but only {have} GPU(s) are visible; refusing to run fewer ranks than asked")
+    plumbing = os.environ.get("TANTE_ALL_ON_GPU0") == "1"
+    have = visible_gpus()
+    if not plumbing and have is not None and have < n:
+        raise SystemExit(f"bench.py: --gpus {n} but only {have} GPU(s) are visible; refusing to run fewer ranks than asked "
+                         "(TANTE_DIST_BACKEND=gloo TANTE_ALL_ON_GPU0=1 runs the N-rank code path on one GPU: plumbing, not performance)")
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    procs = []
+    procs, pumps = [], []
+
+    def pump(r, stream):
+        for line in stream:
+            sys.stderr.write(f"[rank {r}] {line}")
+        stream.close()
+
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out)
+        p = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                             stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
+        procs.append(p)
+        t = threading.Thread(target=pump, args=(r, p.stderr), daemon=True)
+        t.start()
+        pumps.append(t)
+    out_lines = []
+    t0 = threading.Thread(target=lambda: out_lines.extend(procs[0].stdout.readlines()), daemon=True)
+    t0.start()
+    failed = None
+    while any(p.poll() is None for p in procs):
+        bad = [(r, p.returncode) for r, p in enumerate(procs) if p.poll() not in (None, 0)]
+        if bad:
+            failed = bad
+            time.sleep(5.0)                                  # grace: let the other ranks notice and report on their own
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            time.sleep(2.0)
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            break
+        time.sleep(0.2)
+    for p in procs:
+        p.wait()
+    t0.join(timeout=5)
+    for t in pumps:
+        t.join(timeout=5)
+    sys.stdout.write("".join(out_lines))
     sys.stdout.flush()
-    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    bad = failed or [(r, p.returncode) for r, p in enumerate(procs) if p.returncode != 0]
     if bad:
         raise SystemExit(f"bench.py: ranks failed (rank, exit code): {bad}")
     return 0
@@ -120,6 +179,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: the launcher and the flag must agree")
+    # TANTE_DIST_BACKEND=gloo TANTE_ALL_ON_GPU0=1: every rank on GPU 0, collectives through gloo -- the N-rank code path (sharding,
+    # broadcast, the all-reduce beside the captured graph, MAX-reduced timing, weak / strong lines) end to end on a 1-GPU box.
+    # PLUMBING, NOT PERFORMANCE: the ranks share one GPU and gloo stages through the host; the line says so.
+    backend = os.environ.get("TANTE_DIST_BACKEND", "nccl")
+    plumbing = os.environ.get("TANTE_ALL_ON_GPU0") == "1"
+    if plumbing and backend == "nccl" and world > 1:
+        raise SystemExit("bench.py: TANTE_ALL_ON_GPU0=1 needs TANTE_DIST_BACKEND=gloo (RCCL cannot put two ranks on one device)")
+    if plumbing:
+        local = 0
     if local >= torch.cuda.device_count():
         raise SystemExit(f"bench.py: LOCAL_RANK {local} but only {torch.cuda.device_count()} GPU(s) are visible")
     torch.cuda.set_device(local)
@@ -128,7 +196,10 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import tante_amd
     from tante_amd import kernels as K
@@ -197,7 +268,7 @@ def main():
             return wrapper
 
         def fl_block(x, st, C_, nh, hidden, seq, causal, eps, tprop=None):
-            # (the temporal propagator a T-letter launch may carry -- tprop -- is 64 flops per element of vector work: not counted)
+            # (the temporal propagator a T-letter launch carries -- tprop, 64 flops per element on fp32 4x4x1 MFMAs -- is not counted)
             n_tok = x.numel() // C_
             attn = 2.0 * (seq.L + 1) * C_ if causal else 4.0 * seq.L * C_
             return n_tok * (2.0 * C_ * 3 * C_ + attn + 2.0 * C_ * C_ + 4.0 * C_ * hidden)
@@ -320,8 +391,8 @@ def main():
         weak, nbytes = train_leg(twl["batch_size"], args.train_steps)
         train = {"metric": "train-step samples/sec, TANTE on 128x384 TRL-2D (4-step BPTT, MSE, clip, AdamW)", "scaling": "weak", **weak,
                  "dropout": drop,
-                 "collective": ("RCCL all-reduce(sum) of the flat fp32 gradient bucket, %d bytes, once per step; 1/world folded into "
-                                "clip + AdamW" % nbytes) if world > 1 else None}
+                 "collective": ("%s all-reduce(sum) of the flat fp32 gradient bucket, %d bytes, once per step; 1/world folded into "
+                                "clip + AdamW" % ("RCCL" if backend == "nccl" else backend, nbytes)) if world > 1 else None}
         if 64 % world == 0 and not args.no_train_strong:
             strong, _ = train_leg(64 // world, max(1, args.train_steps if world > 1 else 2))
             train["strong"] = {"scaling": "strong", **strong}
@@ -336,7 +407,8 @@ def main():
                           **({"enc_dec_type": "fno", "modes1": mk.get("modes1", 32), "modes2": mk.get("modes2", 32)} if kind == "tante_fno" else {}))
         w = {k: (v.detach().cpu() if v.is_complex() else v.detach().float().cpu()) for k, v in model.state_dict().items()}
         # the GPU box gives one job a share of the host (16 cores per GPU), whatever os.cpu_count() says
-        cores = min(len(os.sched_getaffinity(0)), int(os.environ.get("TANTE_CPU_THREADS", "16")))
+        affinity, cap = len(os.sched_getaffinity(0)), int(os.environ.get("TANTE_CPU_THREADS", "16"))
+        cores = min(affinity, cap)
         torch.set_num_threads(cores)
         Bc, nc = B, n_steps          # the full batch and rollout length: ~10-15 s of CPU work on 16 cores
         cb = {"input": batch["input"][:Bc].cpu(), "output": batch["output"][:Bc, :nc].cpu()}
@@ -357,6 +429,7 @@ def main():
         except (OSError, StopIteration):
             pass
         cpu = {"value": round(Bc * nc / tc, 3), "unit": "frames/s", "cores": torch.get_num_threads(), "cpu_model": cpu_name, "kind": "port",
+               "affinity_cores": affinity, "thread_cap": cap, "limited_by": "thread_cap (TANTE_CPU_THREADS; the box gives one GPU job a 16-core share)" if cap < affinity else "affinity",
                "sample": f"oracle rollout (fused-op spelling, within 10 % of the reference's own CPU time: profiles/cpu_reference.json), "
                          f"{Bc} samples x {nc} frames of the same workload, fp32, {tc:.1f} s"}
 
@@ -372,6 +445,10 @@ def main():
                           "n_steps_input": T_in, "n_steps_rollout": n_steps, "taylor_order": cfg["model"].get("taylor_order", 1),
                           "attn_axes": cfg["model"].get("attn_axes"), "parallelism": f"batch-sharded x{world} (no collective)"},
                "roofline": roofline, "cpu_baseline": cpu, "train": train}
+        if plumbing or (world > 1 and backend != "nccl"):
+            out["plumbing"] = (f"NOT A PERFORMANCE NUMBER: {world} ranks share GPU 0 and the collectives go through '{backend}' "
+                               "(TANTE_ALL_ON_GPU0 / TANTE_DIST_BACKEND); run to exercise the multi-rank code path only")
+            out["config"]["parallelism"] = f"batch-sharded x{world} on ONE GPU over {backend} (plumbing run)"
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

@@ -198,6 +198,9 @@ int tante_gather_last(const float* z, int64_t n, int E, float* out, void* stream
 /* DefaultChannelsFirstFormatter.process_input for the model input (data/datamodule.py:184-192): x (n_img, HW, D) channels-last fp32 ->
  * nan_to_num -> channels-first images, image i = (b, t) at out + b * out_bstride + t * D * HW (e.g. the head of a rollout buffer). */
 int tante_format_input(const float* x, int64_t n_img, int T, int64_t HW, int D, float* out, int64_t out_bstride, void* stream);
+/* torch.nan_to_num over a dense fp32 tensor (NaN -> 0, +-inf -> +-FLT_MAX): the formatter's pass over the reference frames
+ * `y_ref` (data/datamodule.py:187, `torch.nan_to_num(data["output"])`).  x, y 16-byte aligned, n elements; y may equal x. */
+int tante_nan_to_num(const float* x, float* y, int64_t n, void* stream);
 
 /* Taylor sum (tante.py:165-171): out[b][i-1] = last[b] + sum_k derivs[k][b] * (i * dt)^k / k!,
  * i = 1..n_out.  last = input[:, -1] given as base pointer + batch stride (elements);

@@ -22,10 +22,12 @@ from typing import Optional
 import torch
 import torch.nn as nn
 
-# The temporal propagator inside the first (T-letter) block's launch (tante_block_fused_tprop): bit-identical to the separate launch and
-# measured: the block launch grows by the 12 us the propagator kernel took (15 k shuffles through the LDS crossbar per workgroup), the
-# rollout gains 0.3 % and the dominant kernel's roofline fraction falls from 0.28 to 0.26 -- off unless TANTE_FUSE_TPROP=1.
-FUSE_TPROP = os.environ.get("TANTE_FUSE_TPROP", "0") != "0"
+# The temporal propagator inside the first (T-letter) block's launch (tante_block_fused_tprop).  Round 2's form exchanged the four time
+# steps between lane groups (32 ds_bpermute per 16 bytes): the block launch grew by the 12 us the propagator kernel took -- no gain, off.
+# Round 3: a lane owns 4 channels of all four time steps and the two 4 x 4 contractions run as fp32 v_mfma_f32_4x4x1 (every lane its own
+# column, no cross-lane traffic) in the kernel's LayerNorm1 phase, where the matrix pipe is idle: ON by default; TANTE_FUSE_TPROP=0
+# brings the separate launch back (A/B timing, tests).
+FUSE_TPROP = os.environ.get("TANTE_FUSE_TPROP", "1") != "0"
 
 from . import _lib as L
 from . import kernels as K

@@ -112,8 +112,9 @@ constexpr int fs_group(int ntt, int nk) {
 // MATRIX, ...  Waves w and w + 4 share a SIMD: whenever one group is in a matrix segment its partner on the SIMD is in a vector / memory
 // segment, by construction and for the whole launch (two independent workgroups start together and stay in step: MFMA-only phases
 // beside MFMA-only phases, with the matrix pipe idle through every LayerNorm / softmax / GELU phase -- SQ_VALU_MFMA_COEXEC 11 %).
-template <int TPS, int NTT, int NW, bool TRAIN, int G = 1>
+template <int TPS, int NTT, int NW, bool TRAIN, int G = 1, bool TPROP = false>
 __global__ __launch_bounds__(64 * NW * G, 2) void block_fs_kernel(FsArgs A) {
+  static_assert(!TPROP || (TPS == 1 && !TRAIN), "the fused temporal propagator: T letter (L = 4), inference");
   static_assert(G == 1 || (G == 2 && NW == 4), "the paired form is two 4-wave groups");
   constexpr int RT = 16 / NW;            // 16-row output tiles per wave
   constexpr int HPW = RT / 2;            // heads per wave
@@ -250,8 +251,78 @@ __global__ __launch_bounds__(64 * NW * G, 2) void block_fs_kernel(FsArgs A) {
   };
 
   // ================================ phase 0: LayerNorm1 -> bufA ===================================================================
+  constexpr bool ln1_done = TPROP;
+  if constexpr (TPROP) {
+    {
+      // ---- T letter (L = 4) with the temporal propagator fused (round 3: on the matrix pipe) ---------------------------------------
+      //   y_t = x_t + b2[t] + sum_j w2[t][j] gelu(b1[j] + sum_a w1[j][a] x_a)        (attn_backbone.py:144-145, per position and channel)
+      // The round-2 form kept the row layout of the plain path (a lane = 4 channels of ONE time step) and fetched the other three time
+      // steps from the other lane groups: 32 ds_bpermute per 16 bytes -- +12 us per launch, what the stand-alone propagator kernel took.
+      // Here a lane owns 4 CHANNELS of ALL FOUR time steps of a sequence (a wave-instruction = one whole 1 KiB token row, four rows per
+      // sequence), and the two 4 x 4 contractions run as v_mfma_f32_4x4x1_16B_f32: 16 blocks of (4 x 1)(1 x 4) outer products per
+      // instruction, lane 4 b + j = column j of block b, i.e. EVERY LANE IS ITS OWN COLUMN (its channel), the four accumulator registers
+      // are the four hidden units / time steps, and lane 4 b + i supplies row i of the 4 x 4 weight (the same for every block).  fp32 in,
+      // fp32 accumulate (an exact k-ordered fma chain), no cross-lane traffic at all; the matrix pipe is idle in this phase anyway.
+      constexpr int GPW = 4 * NTT / NW;      // sequences (groups of 4 token rows) per wave
+      const float* tp = A.tprop;
+      float w1c[4], w2c[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) { w1c[a] = tp[4 * (lane & 3) + a]; w2c[a] = tp[20 + 4 * (lane & 3) + a]; }
+      const f32x4 b1v = f32x4{tp[16], tp[17], tp[18], tp[19]}, b2v = f32x4{tp[36], tp[37], tp[38], tp[39]};
+      f32x4 xv[GPW][4];
+#pragma unroll
+      for (int i = 0; i < GPW; ++i)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int tk = tok_of(4 * (wave * GPW + i) + t);
+          xv[i][t] = *(const f32x4*)(x + (long)(tk < 0 ? 0 : tk) * FS_C + 4 * lane);      // dead slots read token 0's row
+        }
+      fs_wring_prime<0, RT, PF>(wq, wb);
+#pragma unroll
+      for (int i = 0; i < GPW; ++i) {
+        f32x4 hid[4], yy[4];      // [channel component e] -> registers = hidden units / time steps
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          f32x4 h = b1v;
+#pragma unroll
+          for (int a = 0; a < 4; ++a) h = __builtin_amdgcn_mfma_f32_4x4x1f32(w1c[a], xv[i][a][e], h, 0, 0, 0);
+          hid[e] = h;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) hid[e] = gelu_poly4<false>(hid[e]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          f32x4 acc = f32x4{xv[i][0][e], xv[i][1][e], xv[i][2][e], xv[i][3][e]} + b2v;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_4x4x1f32(w2c[j], hid[e][j], acc, 0, 0, 0);
+          yy[e] = acc;
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const f32x4 y = f32x4{yy[0][t], yy[1][t], yy[2][t], yy[3][t]};
+          const int tk = tok_of(4 * (wave * GPW + i) + t);      // (wave-uniform; cheaper to fetch again than to keep 16 of them)
+          const bool live = tk >= 0;
+          // the propagated row goes back to x: the residual slices are re-read from there behind the barriers below
+          if (live) *(f32x4*)(x + (long)tk * FS_C + 4 * lane) = y;
+          float sm = (y[0] + y[1]) + (y[2] + y[3]);
+          float sq = fmaf(y[0], y[0], fmaf(y[1], y[1], fmaf(y[2], y[2], y[3] * y[3])));
+          sm = rows_sum(row16_sum(sm));
+          sq = rows_sum(row16_sum(sq));
+          const float mean = sm * (1.0f / FS_C);
+          const float var = fmaxf(sq * (1.0f / FS_C) - mean * mean, 0.0f);
+          const float rstd = live ? rsqrtf(var + A.eps) : 0.0f;
+          const float sh = live ? -mean * rstd : 0.0f;
+          const int slot = 4 * (wave * GPW + i) + t;
+          u32x2 o2;
+          o2[0] = pack_bf16x2(fmaf(y[0], rstd, sh), fmaf(y[1], rstd, sh));
+          o2[1] = pack_bf16x2(fmaf(y[2], rstd, sh), fmaf(y[3], rstd, sh));
+          *(u32x2*)(bufA + slot * FS_ROW + (((lane >> 1) ^ (slot & 15)) << 4) + (lane & 1) * 8) = o2;
+        }
+      }
+    }
+  }
   // A wave-instruction reads 4 token rows x 256 contiguous bytes; a row's statistics are reduced over the 16 lanes that share it.
-  {
+  if constexpr (!ln1_done) {
     constexpr int GPW = 4 * NTT / NW;      // groups of 4 token rows per wave
     static_assert(GPW * NW == 4 * NTT, "token rows must split evenly over the waves");
     f32x4 v[GPW][4];
@@ -266,53 +337,6 @@ __global__ __launch_bounds__(64 * NW * G, 2) void block_fs_kernel(FsArgs A) {
       for (int j = 0; j < 4; ++j) v[i][j] = *(const f32x4*)(row + 4 * (l15 + 16 * j));
     }
     fs_wring_prime<0, RT, PF>(wq, wb);     // behind the x rows in the memory queue: LayerNorm1 does not wait for them
-    if constexpr (!TRAIN) {
-      if (A.tprop) {
-        // The temporal propagator, fused: with L = 4 the four 16-lane groups of an instruction ARE the four time steps of one sequence
-        // (slot = 4 s + t, kk = t), all with the same channels.  Lane group kk computes hidden unit kk from the four x_t (three values
-        // fetched from the other groups), then its own y_kk from the four hidden units -- the expressions and their order are
-        // axis_mlp_vec_kernel<4, true>'s, so the rows are bit-identical to that kernel's.  The propagated rows go back to x: the
-        // residual slices are re-read from there behind the barriers below (workgroup-scope release / acquire of __syncthreads).
-        const float* tp = A.tprop;
-        float w1r[4], w2r[4];
-#pragma unroll
-        for (int a = 0; a < 4; ++a) { w1r[a] = tp[4 * kk + a]; w2r[a] = tp[20 + 4 * kk + a]; }
-        const float b1k = tp[16 + kk], b2k = tp[36 + kk];
-        int src[4];
-#pragma unroll
-        for (int a = 0; a < 4; ++a) src[a] = (l15 + 16 * a) << 2;
-#pragma unroll
-        for (int i = 0; i < GPW; ++i) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const f32x4 vin = v[i][j];
-            const float vx = vin[0], vy = vin[1], vz = vin[2], vw = vin[3];
-            f32x4 sacc = splat4(b1k);
-#pragma unroll
-            for (int a = 0; a < 4; ++a) {
-              const f32x4 xa = f32x4{__builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src[a], __builtin_bit_cast(int, vx))),
-                                     __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src[a], __builtin_bit_cast(int, vy))),
-                                     __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src[a], __builtin_bit_cast(int, vz))),
-                                     __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src[a], __builtin_bit_cast(int, vw)))};
-              sacc += splat4(w1r[a]) * xa;
-            }
-            const f32x4 hk = gelu_poly4<false>(sacc);
-            const float hx = hk[0], hy = hk[1], hz = hk[2], hw_ = hk[3];
-            f32x4 acc = vin + splat4(b2k);
-#pragma unroll
-            for (int a = 0; a < 4; ++a) {
-              const f32x4 ha = f32x4{__builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src[a], __builtin_bit_cast(int, hx))),
-                                     __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src[a], __builtin_bit_cast(int, hy))),
-                                     __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src[a], __builtin_bit_cast(int, hz))),
-                                     __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src[a], __builtin_bit_cast(int, hw_)))};
-              acc += splat4(w2r[a]) * ha;
-            }
-            v[i][j] = acc;
-            if (lv[i]) *(f32x4*)(x + (long)tis[i] * FS_C + 4 * (l15 + 16 * j)) = acc;
-          }
-        }
-      }
-    }
 #pragma unroll
     for (int i = 0; i < GPW; ++i) {
       float s = 0.f, q = 0.f;
@@ -922,13 +946,13 @@ __global__ void fs_pack_multi_kernel(FsPackBatch B) {
   fs_pack_body((int)blockIdx.x - e * FSP_BLOCKS, q[0], q[1], nullptr, nullptr, q[2], q[3], q[4], q[5], nullptr, nullptr, q[6], q[7], B.dst[e]);
 }
 
-template <int TPS, int NTT, int NW, bool TRAIN, int G = 1>
+template <int TPS, int NTT, int NW, bool TRAIN, int G = 1, bool TPROP = false>
 void fs_launch_tt(const FsArgs& A, int nwg, hipStream_t s) {
   constexpr int LDS = G * (2 * 16 * NTT * FS_ROW + 16 * NTT * NW * 8 + FS_BIAS_FLOATS * 4);
   static_assert(LDS <= 160 * 1024, "LDS per workgroup");
   static TantePerDevice attr;
-  attr.once([&] { (void)hipFuncSetAttribute((const void*)block_fs_kernel<TPS, NTT, NW, TRAIN, G>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); });
-  hipLaunchKernelGGL((block_fs_kernel<TPS, NTT, NW, TRAIN, G>), dim3((nwg + G - 1) / G), dim3(64 * NW * G), LDS, s, A);
+  attr.once([&] { (void)hipFuncSetAttribute((const void*)block_fs_kernel<TPS, NTT, NW, TRAIN, G, TPROP>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); });
+  hipLaunchKernelGGL((block_fs_kernel<TPS, NTT, NW, TRAIN, G, TPROP>), dim3((nwg + G - 1) / G), dim3(64 * NW * G), LDS, s, A);
 }
 // TANTE_FS_GROUPS = 2 (tante_set_option) selects the paired form; the default is the unpaired one.  Both compute the same function, bit for
 // bit (tools/fs_ab.py asserts it).  MEASURED (round 3, one box, interleaved rounds, cfg2 B = 8): the paired form is 1.2 - 2.3 us SLOWER per
@@ -940,6 +964,9 @@ template <int TPS, int NTT, int NW>
 void fs_launch_t(const FsArgs& A, int nwg, hipStream_t s) {
   if constexpr (NW == 4) {
     if (A.out) return fs_launch_tt<TPS, NTT, NW, true>(A, nwg, s);
+    if constexpr (TPS == 1) {
+      if (A.tprop) return fs_launch_tt<TPS, NTT, NW, false, 1, true>(A, nwg, s);
+    }
     const int groups = tante_opt("TANTE_FS_GROUPS", 0);
     if (groups == 2) return fs_launch_tt<TPS, NTT, NW, false, 2>(A, nwg, s);
   }
@@ -1010,7 +1037,7 @@ int tante_fs_launch(float* x, const char* stream, const TanteSeq& sq, int causal
 #ifdef TANTE_ABLATE
   A.stamps = g_fs_stamps;
 #endif
-  const int L = sq.L, nw = tr ? 4 : fs_waves(L);
+  const int L = sq.L, nw = (tr || tprop) ? 4 : fs_waves(L);      // (the training form and the fused propagator exist in the 4-wave kernels)
   A.magic = (65536u + (unsigned)L - 1u) / (unsigned)L;
   // tile-aligned shapes: L | 16 (several sequences per tile), L = 32 / 48 / 64 (2 / 3 / 4 tiles per sequence, non-causal)
   int tps = 0;

@@ -3,6 +3,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <mutex>
+#include <algorithm>
 
 namespace {
 
@@ -717,6 +718,33 @@ __global__ __launch_bounds__(256) void format_input_kernel(const float* __restri
     if (tid < np) dst[(long)d * HW + tid] = nan_to_num_f(fsm[tid * (D + 1) + d]);
 }
 
+// torch.nan_to_num on a dense fp32 tensor (the formatter's pass over the reference frames, data/datamodule.py:187): 16 bytes per lane,
+// four vectors in flight -- the torch elementwise kernel ran this 46 MB pass at 1.7 TB/s (55 us per rollout)
+__global__ __launch_bounds__(256) void nan_to_num_kernel(const float* __restrict__ x, float* __restrict__ y, long n4, long n) {
+  const long stride = (long)gridDim.x * 256;
+  long i = (long)blockIdx.x * 256 + threadIdx.x;
+  for (; i + 3 * stride < n4; i += 4 * stride) {
+    f32x4 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = ((const f32x4*)x)[i + k * stride];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = nan_to_num_f(v[k][e]);
+      ((f32x4*)y)[i + k * stride] = o;
+    }
+  }
+  for (; i < n4; i += stride) {
+    const f32x4 v = ((const f32x4*)x)[i];
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = nan_to_num_f(v[e]);
+    ((f32x4*)y)[i] = o;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (int)(n - 4 * n4)) y[4 * n4 + threadIdx.x] = nan_to_num_f(x[4 * n4 + threadIdx.x]);
+}
+
 // ---- Taylor sum -------------------------------------------------------------------------------------
 struct TaylorArgs {
   const float* d[8];
@@ -973,6 +1001,16 @@ extern "C" int tante_format_input(const float* x, int64_t n_img, int T, int64_t 
   if (!x || !out || n_img <= 0 || T <= 0 || n_img % T || HW <= 0 || D <= 0 || D > 255) TANTE_FAIL(-1, "tante_format_input: bad argument");
   hipLaunchKernelGGL(format_input_kernel, dim3((unsigned)((HW + 255) / 256), (unsigned)n_img), dim3(256), 256 * (D + 1) * sizeof(float),
                      (hipStream_t)stream, x, (long)HW, D, T, out, (long)out_bstride);
+  TANTE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int tante_nan_to_num(const float* x, float* y, int64_t n, void* stream) {
+  if (!x || !y || n <= 0) TANTE_FAIL(-1, "tante_nan_to_num: bad argument");
+  if (((uintptr_t)x % 16) || ((uintptr_t)y % 16)) TANTE_FAIL(-2, "tante_nan_to_num: 16-byte aligned tensors expected");
+  const long n4 = n / 4;
+  const long blocks = std::min<long>(2048, std::max<long>(1, (n4 + 1023) / 1024));
+  hipLaunchKernelGGL(nan_to_num_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, y, n4, (long)n);
   TANTE_CHECK_LAUNCH();
   return 0;
 }

@@ -174,3 +174,54 @@ def test_refused_capture_leaves_no_uncomputed_packs(dev):
     eg = float((oa.flat_g - ob.flat_g).norm() / ob.flat_g.norm())
     ep = float((oa.flat_p - ob.flat_p).norm() / ob.flat_p.norm())
     assert eg < 1e-5 and ep < 1e-6, (eg, ep)
+
+
+@pytest.mark.parametrize("n", [1, 3, 4, 1023, 4096 * 11 + 2, 8 * 8 * 256 * 256 * 11 // 16])
+def test_nan_to_num_kernel_equals_torch(dev, n):
+    """tante_nan_to_num = torch.nan_to_num (data/datamodule.py:187) bit for bit: NaN -> 0, +-inf -> +-FLT_MAX, everything else untouched."""
+    from tante_amd import rollout as R
+    g = torch.Generator().manual_seed(n)
+    x = torch.randn(n, generator=g)
+    x[::7] = float("nan"); x[1::13] = float("inf"); x[2::17] = float("-inf"); x[3::19] = -0.0
+    xd = x.to(dev)
+    y = R._nan_to_num(xd)
+    assert y.data_ptr() != xd.data_ptr()
+    assert torch.equal(y.cpu(), torch.nan_to_num(x))
+    assert torch.equal(y.cpu().view(torch.int32), torch.nan_to_num(x).view(torch.int32))      # signed zeros too
+
+
+@pytest.mark.parametrize("letter,B,T,H,W", [("T", 8, 4, 32, 32), ("H", 8, 4, 32, 32), ("W", 2, 4, 16, 48), ("T", 1, 4, 5, 3), ("H", 3, 2, 16, 7),
+                                            ("W", 1, 3, 7, 64), ("L", 1, 1, 6, 6)])
+def test_block_kernel_paired_form_is_bit_identical(dev, letter, B, T, H, W):
+    """The paired form of the fused block kernel (two 4-wave groups per workgroup, one barrier segment apart: TANTE_FS_GROUPS = 2) against
+    the default unpaired form: the same instruction stream on the same tokens, so the outputs must be bitwise equal -- on full grids,
+    on ragged ones (an odd number of 64-token groups: the last workgroup's second group has no live sequence) and for every layout
+    class (several sequences per tile, tile-aligned, element-masked)."""
+    import tante_amd
+    from tante_amd import _lib as L, kernels as Kk
+    torch.manual_seed(B * 100 + H + W)
+    blk = tante_amd.TransformerBlock(256, 8, mlp_ratio=1.0, dropout=0.0).to(dev).eval()
+    st = blk._packed_fused()
+    seq = Kk.make_seq(letter, B, T, H, W)
+    assert Kk.block_fused_supported(256, 8, 256, seq.L)
+    x0 = torch.randn(B * T * H * W, 256, device=dev) * 1.3 + 0.2
+    outs = []
+    try:
+        for groups in (1, 2):
+            L.set_option("TANTE_FS_GROUPS", groups)
+            y = x0.clone()
+            Kk.block_fused(y, st, 256, 8, 256, seq, letter == "T", 1e-5)
+            torch.cuda.synchronize()
+            outs.append(y)
+    finally:
+        L.set_option("TANTE_FS_GROUPS", 0)
+    assert torch.isfinite(outs[0]).all() and not torch.equal(outs[0], x0)
+    assert torch.equal(outs[0], outs[1])
+
+
+def test_set_option_rejects_bad_names(dev):
+    from tante_amd import _lib as L
+    assert L.lib().tante_set_option(b"FS_GROUPS", 1) != 0           # names start with TANTE_
+    assert L.lib().tante_set_option(b"", 1) != 0
+    L.set_option("TANTE_TEST_OPTION", 7)
+    assert L.get_option("TANTE_TEST_OPTION", 0) == 7 and L.get_option("TANTE_NEVER_SET", 5) == 5
