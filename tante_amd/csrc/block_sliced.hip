@@ -92,6 +92,44 @@ struct FsSeqMap {
 };
 
 
+// ---- the temporal propagator on the matrix pipe (kernels with TPROP) -----------------------------------------------------------------
+//   y_t = x_t + b2[t] + sum_j w2[t][j] gelu(b1[j] + sum_a w1[j][a] x_a)        (attn_backbone.py:144-145; erf GELU, per position and channel)
+// xs[t] = 4 channels of time step t of ONE sequence, all four in the same lane.  v_mfma_f32_4x4x1_16B_f32: 16 blocks of (4 x 1)(1 x 4)
+// outer products, lane 4 b + j = column j of block b -- every lane is its own column, its four accumulator registers are the four
+// hidden units (first product) / time steps (second), and lane 4 b + i supplies row i of the 4 x 4 weight, the same for every block.
+// fp32 in, fp32 accumulate (a k-ordered fma chain from the bias), no cross-lane traffic.  tp = w1 (4 x 4) | b1 | w2 (4 x 4) | b2.
+struct TpropW {
+  float w1c[4], w2c[4];
+  f32x4 b1v, b2v;
+};
+__device__ __forceinline__ void tprop_weights(const float* __restrict__ tp, int lane, TpropW& w) {
+#pragma unroll
+  for (int a = 0; a < 4; ++a) { w.w1c[a] = tp[4 * (lane & 3) + a]; w.w2c[a] = tp[20 + 4 * (lane & 3) + a]; }
+  w.b1v = f32x4{tp[16], tp[17], tp[18], tp[19]};
+  w.b2v = f32x4{tp[36], tp[37], tp[38], tp[39]};
+}
+__device__ __forceinline__ void tprop_apply(const TpropW& w, f32x4 (&xs)[4]) {
+  f32x4 hid[4], yy[4];      // [channel component e] -> registers = hidden units / time steps
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    f32x4 h = w.b1v;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) h = __builtin_amdgcn_mfma_f32_4x4x1f32(w.w1c[a], xs[a][e], h, 0, 0, 0);
+    hid[e] = h;
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) hid[e] = gelu_poly4<false>(hid[e]);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    f32x4 acc = f32x4{xs[0][e], xs[1][e], xs[2][e], xs[3][e]} + w.b2v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_4x4x1f32(w.w2c[j], hid[e][j], acc, 0, 0, 0);
+    yy[e] = acc;
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) xs[t] = f32x4{yy[0][t], yy[1][t], yy[2][t], yy[3][t]};
+}
+
 // largest divisor of ntt that keeps  group x nk  score tiles within 8 (32 accumulator registers)
 constexpr int fs_group(int ntt, int nk) {
   int g = 1;
@@ -199,12 +237,16 @@ __global__ __launch_bounds__(64 * NW * G, 2) void block_fs_kernel(FsArgs A) {
   static_assert((IMG / NW) >= TILEB, "staging piece too small");
   char* const stg = bufA + wave * (IMG / NW);
   const int rrow = lane / CPR, rchunk = lane % CPR;            // row form: this lane's row within an instruction and its chunk
+  // row of a tile that instruction j of a lane's row group touches: 4 consecutive rows per instruction, or -- in the kernels that carry the
+  // temporal propagator (L = 4: rows 4 s .. 4 s + 3 are the four time steps of sequence s) -- row 4 rrow + j, so that a LANE holds the four
+  // time steps of one sequence in its four registers (the propagator then needs no cross-lane traffic)
+  auto srow = [&](int j) { return TPROP ? 4 * rrow + j : RPI * j + rrow; };
   auto slice_load = [&](const float* __restrict__ src, f32x4 (&raw)[NTT][RT]) {      // row form, straight from memory
 #pragma unroll
     for (int tt = 0; tt < NTT; ++tt)
 #pragma unroll
       for (int j = 0; j < RT; ++j) {
-        const int t = tok_of(16 * tt + RPI * j + rrow);
+        const int t = tok_of(16 * tt + srow(j));
         raw[tt][j] = *(const f32x4*)(src + (long)(t < 0 ? 0 : t) * FS_C + 16 * RT * wave + 4 * rchunk);   // dead slots: token 0's row
       }
   };
@@ -214,7 +256,7 @@ __global__ __launch_bounds__(64 * NW * G, 2) void block_fs_kernel(FsArgs A) {
       char* sb = stg + (tt % NSUB) * TILEB;
 #pragma unroll
       for (int j = 0; j < RT; ++j) {
-        const int r = RPI * j + rrow;
+        const int r = srow(j);
         *(f32x4*)(sb + r * ROWB + ((rchunk ^ (r & (CPR - 1))) << 4)) = raw[tt][j];
       }
 #pragma unroll
@@ -264,11 +306,6 @@ __global__ __launch_bounds__(64 * NW * G, 2) void block_fs_kernel(FsArgs A) {
       // are the four hidden units / time steps, and lane 4 b + i supplies row i of the 4 x 4 weight (the same for every block).  fp32 in,
       // fp32 accumulate (an exact k-ordered fma chain), no cross-lane traffic at all; the matrix pipe is idle in this phase anyway.
       constexpr int GPW = 4 * NTT / NW;      // sequences (groups of 4 token rows) per wave
-      const float* tp = A.tprop;
-      float w1c[4], w2c[4];
-#pragma unroll
-      for (int a = 0; a < 4; ++a) { w1c[a] = tp[4 * (lane & 3) + a]; w2c[a] = tp[20 + 4 * (lane & 3) + a]; }
-      const f32x4 b1v = f32x4{tp[16], tp[17], tp[18], tp[19]}, b2v = f32x4{tp[36], tp[37], tp[38], tp[39]};
       f32x4 xv[GPW][4];
 #pragma unroll
       for (int i = 0; i < GPW; ++i)
@@ -278,32 +315,15 @@ __global__ __launch_bounds__(64 * NW * G, 2) void block_fs_kernel(FsArgs A) {
           xv[i][t] = *(const f32x4*)(x + (long)(tk < 0 ? 0 : tk) * FS_C + 4 * lane);      // dead slots read token 0's row
         }
       fs_wring_prime<0, RT, PF>(wq, wb);
+      TpropW tw;
+      tprop_weights(A.tprop, lane, tw);
 #pragma unroll
       for (int i = 0; i < GPW; ++i) {
-        f32x4 hid[4], yy[4];      // [channel component e] -> registers = hidden units / time steps
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          f32x4 h = b1v;
-#pragma unroll
-          for (int a = 0; a < 4; ++a) h = __builtin_amdgcn_mfma_f32_4x4x1f32(w1c[a], xv[i][a][e], h, 0, 0, 0);
-          hid[e] = h;
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) hid[e] = gelu_poly4<false>(hid[e]);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          f32x4 acc = f32x4{xv[i][0][e], xv[i][1][e], xv[i][2][e], xv[i][3][e]} + b2v;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_4x4x1f32(w2c[j], hid[e][j], acc, 0, 0, 0);
-          yy[e] = acc;
-        }
+        tprop_apply(tw, xv[i]);      // x is NOT rewritten: the residual slices below run the same rows through the propagator again
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          const f32x4 y = f32x4{yy[0][t], yy[1][t], yy[2][t], yy[3][t]};
-          const int tk = tok_of(4 * (wave * GPW + i) + t);      // (wave-uniform; cheaper to fetch again than to keep 16 of them)
-          const bool live = tk >= 0;
-          // the propagated row goes back to x: the residual slices are re-read from there behind the barriers below
-          if (live) *(f32x4*)(x + (long)tk * FS_C + 4 * lane) = y;
+          const f32x4 y = xv[i][t];
+          const bool live = tok_of(4 * (wave * GPW + i) + t) >= 0;      // (wave-uniform; cheaper to fetch again than to keep 16 of them)
           float sm = (y[0] + y[1]) + (y[2] + y[3]);
           float sq = fmaf(y[0], y[0], fmaf(y[1], y[1], fmaf(y[2], y[2], y[3] * y[3])));
           sm = rows_sum(row16_sum(sm));
@@ -663,6 +683,13 @@ __global__ __launch_bounds__(64 * NW * G, 2) void block_fs_kernel(FsArgs A) {
 #else
   slice_load(x, xraw);
 #endif
+  if constexpr (TPROP) {      // the residual is the PROPAGATED row: the same contraction on this wave's feature slice (see srow)
+    static_assert(!TPROP || RT == 4, "a lane's row group = the four time steps of a sequence");
+    TpropW tw;
+    tprop_weights(A.tprop, lane, tw);
+#pragma unroll
+    for (int tt = 0; tt < NTT; ++tt) tprop_apply(tw, xraw[tt]);
+  }
 #ifdef FS_RESID_FIRST
   fs_wring_prime<3, RT, PF>(wq, wb);      // (round-2 order, kept for the A/B)
 #endif
