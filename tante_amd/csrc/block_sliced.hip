@@ -240,7 +240,11 @@ __global__ __launch_bounds__(64 * NW * G, 2) void block_fs_kernel(FsArgs A) {
   // row of a tile that instruction j of a lane's row group touches: 4 consecutive rows per instruction, or -- in the kernels that carry the
   // temporal propagator (L = 4: rows 4 s .. 4 s + 3 are the four time steps of sequence s) -- row 4 rrow + j, so that a LANE holds the four
   // time steps of one sequence in its four registers (the propagator then needs no cross-lane traffic)
+#ifdef FS_TPROP_RECOMPUTE      // measured, round 3: the T launch 46 us this way against 41 us with the rows rewritten in phase 0 -- off
   auto srow = [&](int j) { return TPROP ? 4 * rrow + j : RPI * j + rrow; };
+#else
+  auto srow = [&](int j) { return RPI * j + rrow; };
+#endif
   auto slice_load = [&](const float* __restrict__ src, f32x4 (&raw)[NTT][RT]) {      // row form, straight from memory
 #pragma unroll
     for (int tt = 0; tt < NTT; ++tt)
@@ -319,11 +323,19 @@ __global__ __launch_bounds__(64 * NW * G, 2) void block_fs_kernel(FsArgs A) {
       tprop_weights(A.tprop, lane, tw);
 #pragma unroll
       for (int i = 0; i < GPW; ++i) {
-        tprop_apply(tw, xv[i]);      // x is NOT rewritten: the residual slices below run the same rows through the propagator again
+        tprop_apply(tw, xv[i]);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           const f32x4 y = xv[i][t];
-          const bool live = tok_of(4 * (wave * GPW + i) + t) >= 0;      // (wave-uniform; cheaper to fetch again than to keep 16 of them)
+          const int tk = tok_of(4 * (wave * GPW + i) + t);      // (wave-uniform; cheaper to fetch again than to keep 16 of them)
+          const bool live = tk >= 0;
+#ifndef FS_TPROP_RECOMPUTE
+          // The propagated row goes back to x: the residual slices are re-read from there behind the barriers below (workgroup-scope
+          // release / acquire of __syncthreads; the rows of a workgroup are its own).  The alternative -- leave x alone and run the
+          // residual slices through the propagator a second time (-DFS_TPROP_RECOMPUTE) -- costs the contraction + 64 GELUs per lane
+          // once more on the critical path: 46 us per launch against 41 us (the extra 33 MB of stores drain under the q, k, v GEMMs).
+          if (live) *(f32x4*)(x + (long)tk * FS_C + 4 * lane) = y;
+#endif
           float sm = (y[0] + y[1]) + (y[2] + y[3]);
           float sq = fmaf(y[0], y[0], fmaf(y[1], y[1], fmaf(y[2], y[2], y[3] * y[3])));
           sm = rows_sum(row16_sum(sm));
@@ -683,13 +695,6 @@ __global__ __launch_bounds__(64 * NW * G, 2) void block_fs_kernel(FsArgs A) {
 #else
   slice_load(x, xraw);
 #endif
-  if constexpr (TPROP) {      // the residual is the PROPAGATED row: the same contraction on this wave's feature slice (see srow)
-    static_assert(!TPROP || RT == 4, "a lane's row group = the four time steps of a sequence");
-    TpropW tw;
-    tprop_weights(A.tprop, lane, tw);
-#pragma unroll
-    for (int tt = 0; tt < NTT; ++tt) tprop_apply(tw, xraw[tt]);
-  }
 #ifdef FS_RESID_FIRST
   fs_wring_prime<3, RT, PF>(wq, wb);      // (round-2 order, kept for the A/B)
 #endif
@@ -730,6 +735,15 @@ __global__ __launch_bounds__(64 * NW * G, 2) void block_fs_kernel(FsArgs A) {
 #pragma unroll
       for (int tt = 0; tt < NTT; ++tt) acc[rt][tt] += res[rt][tt];
   };
+#ifdef FS_TPROP_RECOMPUTE
+  if constexpr (TPROP) {      // the residual is the PROPAGATED row: the same contraction on this wave's feature slice (see srow) -- here,
+    static_assert(!TPROP || RT == 4, "a lane's row group = the four time steps of a sequence");      // behind the out-proj GEMM the loads flew under
+    TpropW tw;
+    tprop_weights(A.tprop, lane, tw);
+#pragma unroll
+    for (int tt = 0; tt < NTT; ++tt) tprop_apply(tw, xraw[tt]);
+  }
+#endif
   {
     f32x4 xr[RT][NTT];
     slice_to_acc(xraw, xr);      // bufA: LayerNorm1's image died with the q/k/v GEMMs (barrier 2), LayerNorm2's comes after barrier 3
