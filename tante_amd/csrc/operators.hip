@@ -2,6 +2,7 @@
 // convolutions, bilinear-resized transposed convolutions), the spectral operator path (enc_dec_fno.py) and CViT (cvit.py) need.
 // All of them are HBM-bound gather / pointwise / small-contraction kernels: coalesced on the innermost axis, fp32 arithmetic.
 #include "common.cuh"
+#include "spectral_dft.h"
 #include "fused_common.cuh"
 #include <hipfft/hipfft.h>
 #include <stdlib.h>
@@ -1050,6 +1051,14 @@ extern "C" int tante_spectral_layer(const float* x, int64_t n, int Cin, int H, i
   const int m1 = modes1 < H ? modes1 : H, m2 = modes2 < Wf ? modes2 : Wf;
   if (m1 > wm1 || m2 > wm2) TANTE_FAIL(-1, "tante_spectral_layer: weight holds fewer modes (%d, %d) than used (%d, %d)", wm1, wm2, m1, m2);
   hipStream_t s = (hipStream_t)stream;
+  // few kept modes: both transforms as skinny fp32 matrix products, the 1x1 conv in the same output pass (spectral_dft.hip);
+  // TANTE_SPECTRAL_DFT = 0 (tante_set_option) keeps the hipFFT path below for every shape (A/B timing, tests)
+  if (tante_opt("TANTE_SPECTRAL_DFT", 1) && tante_spectral_dft_supported(n, Cin, Cout, H, W, m1, m2) &&
+      tante_spectral_dft_workspace_bytes(n, Cin, Cout, H, m1, m2) <= work_bytes) {
+    const int rc = tante_spectral_dft_forward(x, n, Cin, H, W, w_re, w_im, wm1, wm2, m1, m2, w0, b0, Cout, act, out, work, s);
+    if (rc) TANTE_FAIL(rc, "tante_spectral_layer: truncated-DFT launch failed");
+    return 0;
+  }
   float2* X = (float2*)work;
   float2* Y = X + (long)n * Cin * H * Wf;
   hipfftHandle fwd, inv;

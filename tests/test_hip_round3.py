@@ -225,3 +225,34 @@ def test_set_option_rejects_bad_names(dev):
     assert L.lib().tante_set_option(b"", 1) != 0
     L.set_option("TANTE_TEST_OPTION", 7)
     assert L.get_option("TANTE_TEST_OPTION", 0) == 7 and L.get_option("TANTE_NEVER_SET", 5) == 5
+
+
+@pytest.mark.parametrize("n,cin,cout,H,W,m1,m2,act", [(2, 3, 5, 32, 64, 4, 5, 0), (1, 8, 32, 64, 96, 8, 20, 1), (3, 6, 40, 48, 32, 2, 3, 1),
+                                                      (1, 64, 128, 128, 128, 5, 5, 1), (2, 8, 32, 512, 512, 20, 20, 1), (1, 32, 8, 512, 512, 20, 20, 0)])
+def test_spectral_layer_truncated_dft_against_oracle_and_fft_path(dev, n, cin, cout, H, W, m1, m2, act):
+    """tante_spectral_layer's truncated-DFT path (spectral_dft.hip: both transforms as skinny fp32 MFMA products over the kept modes, the
+    1x1 conv in the output pass) against (a) the CPU oracle's rfft2 / irfft2 restatement of SpectralLayer.forward
+    (models/enc_dec_fno.py:184-222) where that is affordable and (b) this library's own hipFFT path (TANTE_SPECTRAL_DFT = 0), at the fp32
+    bar 1e-5 -- incl. the cfg5 shapes (512 x 512, modes 20 x 20, 8 -> 32 and 32 -> 8 channels; 128 x 128, modes 5 x 5, 64 -> 128)."""
+    from oracle import spectral_oracle as OS
+    from tante_amd import _lib as L, kernels as Kk
+    g = torch.Generator().manual_seed(n * 1000 + H + W)
+    x = torch.randn(n, cin, H, W, generator=g)
+    wre, wim = torch.randn(cin, cout, m1, m2, generator=g) / (cin * cout) ** 0.5, torch.randn(cin, cout, m1, m2, generator=g) / (cin * cout) ** 0.5
+    w0, b0 = torch.randn(cout, cin, generator=g) / cin ** 0.5, torch.randn(cout, generator=g)
+    assert L.lib().tante_get_option(b"TANTE_SPECTRAL_DFT", 1) == 1
+    args = (x.to(dev), wre.to(dev), wim.to(dev), m1, m2, w0.to(dev), b0.to(dev), act)
+    y_dft = Kk.spectral_layer(*args)
+    try:
+        L.set_option("TANTE_SPECTRAL_DFT", 0)
+        y_fft = Kk.spectral_layer(*args)
+    finally:
+        L.set_option("TANTE_SPECTRAL_DFT", 1)
+    torch.cuda.synchronize()
+    close(y_dft, y_fft, "fp32", "truncated DFT vs hipFFT path")
+    if n * cout * H * W <= 4 << 20:
+        w = {"weight": torch.complex(wre, wim), "w0.weight": w0.view(cout, cin, 1, 1), "w0.bias": b0}
+        ref = OS.spectral_layer(w, x, m1, m2)
+        if act == 1:
+            ref = torch.nn.functional.gelu(ref)
+        close(y_dft, ref, "fp32", "truncated DFT vs oracle")
