@@ -44,13 +44,19 @@ __global__ __launch_bounds__(256) void dft_rows_kernel(const float* __restrict__
   constexpr int TS = 16 * NT + 4;
   extern __shared__ __attribute__((aligned(16))) float tw[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, kq = lane >> 4;
+  float2* base = (float2*)(tw + W * TS);     // (cos, sin) of 2 pi m / W, m = 0 .. W - 1: W evaluations, the table is a gather of them
+  for (int m = tid; m < W; m += 256) {
+    float s, c;
+    sincos_frac(m, W, s, c);
+    base[m] = make_float2(c, s);
+  }
+  __syncthreads();
   for (int e = tid; e < W * 16 * NT; e += 256) {
     const int w = e / (16 * NT), k = e % (16 * NT);
     float v = 0.0f;
     if (k < 2 * m2) {
-      float s, c;
-      sincos_frac((long)(k < m2 ? k : k - m2) * w, W, s, c);
-      v = k < m2 ? c : -s;
+      const float2 t = base[(int)(((long)(k < m2 ? k : k - m2) * w) % W)];
+      v = k < m2 ? t.x : -t.y;
     }
     tw[w * TS + k] = v;
   }
@@ -100,33 +106,46 @@ __global__ __launch_bounds__(256) void dft_rows_kernel(const float* __restrict__
   }
 }
 
-// ---- B: column DFT over the kept rows.  block = (kept row i2, a group of images); the 2 H twiddles of the row go to LDS once.
-__global__ __launch_bounds__(256) void dft_cols_kernel(const float* __restrict__ Ar, long NC, int H, int m1, int m2, float2* __restrict__ X) {
-  extern __shared__ float2 cs[];   // [H] (cos, sin) of 2 pi r h / H
-  const int i2 = blockIdx.x, r = dft_row(i2, m1, H);
-  for (int h = threadIdx.x; h < H; h += 256) {
-    float s, c;
-    sincos_frac((long)r * h, H, s, c);
-    cs[h] = make_float2(c, s);
-  }
-  __syncthreads();
-  const int per = 256 / m2;                       // images per block pass
-  const int img_l = threadIdx.x / m2, j = threadIdx.x % m2;
-  if (img_l >= per) return;
-  for (long nc = (long)blockIdx.y * per + img_l; nc < NC; nc += (long)gridDim.y * per) {
-    const float* a = Ar + nc * H * (2 * m2);
-    float xr = 0.f, xi = 0.f;
-    for (int h = 0; h < H; ++h) {
-      const float are = a[(long)h * 2 * m2 + j], aim = a[(long)h * 2 * m2 + m2 + j];
-      const float2 t = cs[h];
-      xr += t.x * are + t.y * aim;                // (cos - i sin)(are + i aim)
-      xi += t.x * aim - t.y * are;
+// ---- B: column DFT over the kept rows.  A WAVE per (image, kept row): lane l sums rows h = l, l + 64, ... for all m2 columns (a row of Ar is
+// 2 m2 contiguous floats), then the 2 m2 partial sums are reduced across the wave.  (A thread per output with a 512-step serial loop
+// over h, the first version, was 35 us of pure latency.)
+template <int M2>
+__global__ __launch_bounds__(256) void dft_cols_kernel(const float* __restrict__ Ar, long NC, int H, int m1, float2* __restrict__ X) {
+  const int lane = threadIdx.x & 63;
+  const long unit = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (unit >= NC * 2 * m1) return;
+  const long nc = unit / (2 * m1);
+  const int i2 = (int)(unit - nc * 2 * m1), r = dft_row(i2, m1, H);
+  const float* a = Ar + nc * H * (2 * M2);
+  float xr[M2], xi[M2];
+#pragma unroll
+  for (int j = 0; j < M2; ++j) xr[j] = xi[j] = 0.0f;
+  for (int h = lane; h < H; h += 64) {
+    float sn, cs;
+    sincos_frac((long)r * h, H, sn, cs);
+    const float* row = a + (long)h * 2 * M2;
+#pragma unroll
+    for (int j = 0; j < M2; ++j) {
+      const float are = row[j], aim = row[M2 + j];
+      xr[j] += cs * are + sn * aim;               // (cos - i sin)(are + i aim)
+      xi[j] += cs * aim - sn * are;
     }
-    X[(nc * 2 * m1 + i2) * m2 + j] = make_float2(xr, xi);
+  }
+#pragma unroll
+  for (int j = 0; j < M2; ++j) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+      xr[j] += __shfl_xor(xr[j], o);
+      xi[j] += __shfl_xor(xi[j], o);
+    }
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int j = 0; j < M2; ++j) X[(nc * 2 * m1 + i2) * M2 + j] = make_float2(xr[j], xi[j]);
   }
 }
 
-// ---- C: channel mixing on the kept modes.  Y[n, o, i2, j] = scale sum_c X[n, c, i2, j] Wt[c, o, wi, j]
+// ---- C: channel mixing on the kept modes.  Y[n, i2, j, o] = scale sum_c X[n, c, i2, j] Wt[c, o, wi, j]
 __global__ void spectral_mix_kernel(const float2* __restrict__ X, const float* __restrict__ w_re, const float* __restrict__ w_im, long n, int Cin,
                                     int Cout, int m1, int m2, int wm1, int wm2, float scale, float2* __restrict__ Y) {
   const long total = n * Cout * 2 * m1 * m2;
@@ -138,6 +157,7 @@ __global__ void spectral_mix_kernel(const float2* __restrict__ X, const float* _
     const long b = q / Cout;
     const int wi = i2 < m1 ? i2 : i2 - m1;
     float ar = 0.f, ai = 0.f;
+#pragma unroll 8
     for (int c = 0; c < Cin; ++c) {
       const float2 xv = X[((b * Cin + c) * 2 * m1 + i2) * m2 + j];
       const long wo = (((long)c * Cout + o) * wm1 + wi) * wm2 + j;
@@ -145,15 +165,15 @@ __global__ void spectral_mix_kernel(const float2* __restrict__ X, const float* _
       ar += xv.x * wr - xv.y * wim;
       ai += xv.x * wim + xv.y * wr;
     }
-    Y[idx] = make_float2(ar * scale, ai * scale);
+    Y[((b * 2 * m1 + i2) * m2 + j) * Cout + o] = make_float2(ar * scale, ai * scale);      // [n][i2][j][o]: kernel D's lanes run over o
   }
 }
 
-// ---- D: inverse column DFT.  block = (image n, 16 rows h); a thread owns (o, j), keeps its 2 m1 coefficients in registers and walks
+// ---- D: inverse column DFT.  block = (image n, 8 rows h); a thread owns (o, j), keeps its 2 m1 coefficients in registers and walks
 // the block's rows.  Z[n][h][k][o] (o innermost: the A operand rows of kernel E are contiguous), k = j (real part) | m2 + j (imaginary).
 template <int M1X2>
 __global__ __launch_bounds__(256) void idft_cols_kernel(const float2* __restrict__ Y, int H, int Cout, int m2, float* __restrict__ Z) {
-  constexpr int HB = 16;
+  constexpr int HB = 8;
   __shared__ float2 cs[HB][M1X2];
   const int m1 = M1X2 / 2;
   const long n = blockIdx.y;
@@ -169,7 +189,7 @@ __global__ __launch_bounds__(256) void idft_cols_kernel(const float2* __restrict
     const int o = p % Cout, j = p / Cout;
     float2 y[M1X2];
 #pragma unroll
-    for (int i2 = 0; i2 < M1X2; ++i2) y[i2] = Y[((n * Cout + o) * M1X2 + i2) * m2 + j];
+    for (int i2 = 0; i2 < M1X2; ++i2) y[i2] = Y[((n * M1X2 + i2) * m2 + j) * Cout + o];
     for (int hh = 0; hh < HB && h0 + hh < H; ++hh) {
       float zr = 0.f, zi = 0.f;
 #pragma unroll
@@ -198,11 +218,19 @@ __device__ __forceinline__ float act_fast(float v, int act) {
     default: return apply_act(v, act);
   }
 }
+template <int M2>
 __global__ __launch_bounds__(1024) void idft_rows_conv_kernel(const float* __restrict__ Z, const float* __restrict__ x, const float* __restrict__ w0,
                                                               const float* __restrict__ b0, long n, int Cin, int Cout, int H, int W, int m2, int act,
                                                               float* __restrict__ out) {
-  extern __shared__ __attribute__((aligned(16))) float G[];   // [2 m2][W]
+  // M2 = m2 when it is a shipped size (a row's coefficients are then loaded ten at a time ahead of their MFMAs), 0 = any.
+  // Measured alternatives (round 3, cfg5, us per launch at 512 x 512 / 128 x 128): this form 139 / 69; 8-wave column blocks with two
+  // output tiles' accumulators live and 192 registers 168 / 64; the same with the next row's coefficients prefetched into a second
+  // register set: > 256 registers, spills.  The floor is the fp32 matrix pipe itself: 24 MFMAs x 64 cycles per 32 x 32 output tile
+  // = 50 us for the 8 -> 32 channel layer at 512 x 512 (157 TFLOP/s), beside 56 us of HBM time for its 335 MB.
+  extern __shared__ __attribute__((aligned(16))) float G[];   // [2 m2][W], then w0 transposed [Cin][CP] (zero-padded to 32 channels)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, kk = lane >> 5;
+  const int CP = (Cout + 31) / 32 * 32;
+  float* wt = G + 2 * m2 * W;
   for (int e = tid; e < 2 * m2 * W; e += blockDim.x) {
     const int k = e / W, w = e % W, j = k < m2 ? k : k - m2;
     float s, c;
@@ -210,43 +238,62 @@ __global__ __launch_bounds__(1024) void idft_rows_conv_kernel(const float* __res
     const float a = j == 0 ? 1.0f : 2.0f;
     G[e] = k < m2 ? a * c : -a * s;
   }
+  for (int e = tid; e < Cin * CP; e += blockDim.x) {
+    const int c = e / CP, o = e % CP;
+    wt[e] = o < Cout ? w0[(long)o * Cin + c] : 0.0f;
+  }
   __syncthreads();
   const int w0c = 32 * wave;
   const long rows = n * H;
-  const int otiles = (Cout + 31) / 32;
+  const long HWl = (long)H * W;
   for (long rho = blockIdx.x; rho < rows; rho += gridDim.x) {
     const long b = rho / H;
     const int h = (int)(rho - b * H);
     const float* zrow = Z + rho * 2 * m2 * Cout;
-    for (int ot = 0; ot < otiles; ++ot) {
-      const int o = 32 * ot + l31;                 // this lane's A-operand row (output channel)
+    const float* xp = x + ((b * Cin) * H + h) * (long)W + w0c + l31;
+    for (int og = 0; og < Cout; og += 32) {
+      const int o = og + l31;                      // this lane's A-operand row (output channel)
       const bool olive = o < Cout;
       f32x16_t acc;
 #pragma unroll
       for (int g = 0; g < 16; ++g) acc[g] = 0.0f;
+      if constexpr (M2 > 0) {
+        constexpr int CH = M2 > 5 ? 5 : M2;        // in chunks of 5: 16 waves per workgroup leave 128 registers per lane (10 spills)
+#pragma unroll
+        for (int s0 = 0; s0 < M2; s0 += CH) {
+          float av[CH];
+#pragma unroll
+          for (int sidx = 0; sidx < CH; ++sidx) av[sidx] = (olive && s0 + sidx < M2) ? zrow[(long)(2 * (s0 + sidx) + kk) * Cout + o] : 0.0f;
+#pragma unroll
+          for (int sidx = 0; sidx < CH; ++sidx)
+            if (s0 + sidx < M2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[sidx], G[(2 * (s0 + sidx) + kk) * W + w0c + l31], acc, 0, 0, 0);
+        }
+      } else {
 #pragma unroll 4
-      for (int s = 0; s < m2; ++s) {
-        const int k = 2 * s + kk;
-        const float a = olive ? zrow[(long)k * Cout + o] : 0.0f;
-        const float bv = G[k * W + w0c + l31];
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc, 0, 0, 0);
+        for (int sidx = 0; sidx < m2; ++sidx) {
+          const int k = 2 * sidx + kk;
+          const float a = olive ? zrow[(long)k * Cout + o] : 0.0f;
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, G[k * W + w0c + l31], acc, 0, 0, 0);
+        }
       }
-      const float* xp = x + ((b * Cin) * H + h) * (long)W + w0c + l31;
-#pragma unroll 4
-      for (int s = 0; s < (Cin + 1) / 2; ++s) {
-        const int c = 2 * s + kk;
-        const bool cl = c < Cin;
-        const float a = (olive && cl) ? w0[(long)o * Cin + c] : 0.0f;
-        const float bv = cl ? xp[(long)c * H * W] : 0.0f;
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc, 0, 0, 0);
+      for (int c0 = 0; c0 < Cin; c0 += 8) {        // 1x1 conv: 8 channels (4 loads of 128 contiguous bytes per half wave) at a time
+        float xv[4];
+#pragma unroll
+        for (int sidx = 0; sidx < 4; ++sidx) {
+          const int c = c0 + 2 * sidx + kk;
+          xv[sidx] = c < Cin ? xp[(long)c * HWl] : 0.0f;
+        }
+#pragma unroll
+        for (int sidx = 0; sidx < 4; ++sidx) {
+          const int c = c0 + 2 * sidx + kk;
+          if (c0 + 2 * sidx < Cin) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(c < Cin ? wt[c * CP + o] : 0.0f, xv[sidx], acc, 0, 0, 0);
+        }
       }
+      float* orow = out + (b * Cout * H + h) * (long)W + w0c + l31;
 #pragma unroll
       for (int g = 0; g < 16; ++g) {
-        const int oo = 32 * ot + (g & 3) + 8 * (g >> 2) + 4 * kk;
-        if (oo < Cout) {
-          const float v = acc[g] + (b0 ? b0[oo] : 0.0f);
-          out[((b * Cout + oo) * H + h) * (long)W + w0c + l31] = act_fast(v, act);
-        }
+        const int oo = og + (g & 3) + 8 * (g >> 2) + 4 * kk;
+        if (oo < Cout) orow[(long)oo * HWl] = act_fast(acc[g] + (b0 ? b0[oo] : 0.0f), act);
       }
     }
   }
@@ -258,10 +305,11 @@ int tante_spectral_dft_supported(int64_t n, int Cin, int Cout, int H, int W, int
   if (n <= 0 || Cin <= 0 || Cout <= 0) return 0;
   if (W % 32 || W < 32 || W > 512 || H % 16) return 0;                  // whole 32-column waves, at most 16 of them; 16-row tiles
   if (m1 < 1 || m2 < 1 || 2 * m1 > H || m2 > W / 2 || m2 > 32) return 0;   // disjoint row bands, no Nyquist column, <= 4 table tiles
+  switch (m2) { case 1: case 2: case 3: case 4: case 5: case 6: case 8: case 10: case 12: case 16: case 20: case 24: case 32: break; default: return 0; }   // dft_cols_kernel
   switch (2 * m1) { case 4: case 8: case 10: case 16: case 20: case 32: case 40: case 64: break; default: return 0; }   // idft_cols_kernel instantiations
   const int NT = (2 * m2 + 15) / 16;
-  if ((size_t)W * (16 * NT + 4) * 4 > 150 * 1024) return 0;             // kernel A's table
-  if ((size_t)2 * m2 * W * 4 > 150 * 1024) return 0;                    // kernel E's table
+  if ((size_t)W * (16 * NT + 4) * 4 + (size_t)W * 8 > 150 * 1024) return 0;   // kernel A's tables
+  if ((size_t)2 * m2 * W * 4 + (size_t)Cin * ((Cout + 31) / 32 * 32) * 4 > 150 * 1024) return 0;   // kernel E's tables
   return 1;
 }
 
@@ -281,10 +329,10 @@ int tante_spectral_dft_forward(const float* x, int64_t n, int Cin, int H, int W,
   float* Z = (float*)p;
   const long R = (long)n * Cin * H;
   const int NT = (2 * m2 + 15) / 16;
-  const size_t ldsA = (size_t)W * (16 * NT + 4) * 4;
+  const size_t ldsA = (size_t)W * (16 * NT + 4) * 4 + (size_t)W * 8;
   const long tiles = (R + 31) / 32;
   const unsigned gridA = (unsigned)std::min<long>(256, (tiles + 3) / 4);
-  static TantePerDevice attrA[4], attrE;
+  static TantePerDevice attrA[4], attrE[9];
 #define TANTE_DFT_A(NTV)                                                                                                          \
   case NTV:                                                                                                                       \
     attrA[NTV - 1].once([&] { (void)hipFuncSetAttribute((const void*)dft_rows_kernel<NTV>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); }); \
@@ -293,24 +341,37 @@ int tante_spectral_dft_forward(const float* x, int64_t n, int Cin, int H, int W,
   switch (NT) { TANTE_DFT_A(1) TANTE_DFT_A(2) TANTE_DFT_A(3) TANTE_DFT_A(4) default: return -2; }
 #undef TANTE_DFT_A
   const long NC = (long)n * Cin;
-  const int per = 256 / m2;
-  hipLaunchKernelGGL(dft_cols_kernel, dim3(2 * m1, (unsigned)std::min<long>(64, (NC + per - 1) / per)), dim3(256), (size_t)H * 8, s, Ar, NC, H, m1, m2, X);
+  const unsigned gridB = (unsigned)((NC * 2 * m1 + 3) / 4);
+  switch (m2) {
+#define TANTE_DFT_B(V) case V: hipLaunchKernelGGL(dft_cols_kernel<V>, dim3(gridB), dim3(256), 0, s, Ar, NC, H, m1, X); break;
+    TANTE_DFT_B(1) TANTE_DFT_B(2) TANTE_DFT_B(3) TANTE_DFT_B(4) TANTE_DFT_B(5) TANTE_DFT_B(6) TANTE_DFT_B(8) TANTE_DFT_B(10) TANTE_DFT_B(12) TANTE_DFT_B(16)
+    TANTE_DFT_B(20) TANTE_DFT_B(24) TANTE_DFT_B(32)
+#undef TANTE_DFT_B
+    default: return -2;
+  }
   const long totalC = (long)n * Cout * 2 * m1 * m2;
   hipLaunchKernelGGL(spectral_mix_kernel, dim3((unsigned)std::min<long>(4096, (totalC + 255) / 256)), dim3(256), 0, s, X, w_re, w_im, (long)n, Cin, Cout,
                      m1, m2, wm1, wm2, 1.0f / ((float)H * (float)W), Y);
-  const dim3 gridD((unsigned)((H + 15) / 16), (unsigned)n);
+  const dim3 gridD((unsigned)((H + 7) / 8), (unsigned)n);
   switch (2 * m1) {
 #define TANTE_DFT_D(V) case V: hipLaunchKernelGGL(idft_cols_kernel<V>, gridD, dim3(256), 0, s, Y, H, Cout, m2, Z); break;
     TANTE_DFT_D(4) TANTE_DFT_D(8) TANTE_DFT_D(10) TANTE_DFT_D(16) TANTE_DFT_D(20) TANTE_DFT_D(32) TANTE_DFT_D(40) TANTE_DFT_D(64)
 #undef TANTE_DFT_D
     default: return -2;
   }
-  const size_t ldsE = (size_t)2 * m2 * W * 4;
-  attrE.once([&] { (void)hipFuncSetAttribute((const void*)idft_rows_conv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); });
+  const int wpb = W / 32;                      // waves per workgroup: one per 32 output columns
+  const size_t ldsE = (size_t)2 * m2 * W * 4 + (size_t)Cin * ((Cout + 31) / 32 * 32) * 4;
   const long rows = (long)n * H;
-  // each workgroup builds the table once (2 m2 W sincos), so it should walk many rows; W / 32 waves per workgroup
-  const int wpb = W / 32;
+  // each workgroup builds the tables once (2 m2 W sincos), so it should walk many rows
   const long wgs = std::min<long>(rows, 256L * std::max(1, 16 / wpb));
-  hipLaunchKernelGGL(idft_rows_conv_kernel, dim3((unsigned)wgs), dim3(64 * wpb), ldsE, s, Z, x, w0, b0, (long)n, Cin, Cout, H, W, m2, act, out);
+#define TANTE_DFT_E(V, IDX)                                                                                                        \
+  {                                                                                                                                \
+    attrE[IDX].once([&] { (void)hipFuncSetAttribute((const void*)idft_rows_conv_kernel<V>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); }); \
+    hipLaunchKernelGGL(idft_rows_conv_kernel<V>, dim3((unsigned)wgs), dim3(64 * wpb), ldsE, s, Z, x, w0, b0, (long)n, Cin, Cout, H, W, m2, act, out); \
+  }
+  if (m2 == 5) TANTE_DFT_E(5, 1)      // (M2 = 20 fully unrolled needs > 128 registers: the unroll-by-4 loop of the generic form serves it)
+  else if (m2 == 8) TANTE_DFT_E(8, 2)
+  else TANTE_DFT_E(0, 3)
+#undef TANTE_DFT_E
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
