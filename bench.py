@@ -29,7 +29,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}      # dense MFMA peaks, MI355X_MICROARCH.md
-PMC_FILE = "r02_pmc_rollout.json"                    # HBM counters of the dominant kernel (separate --pmc passes, committed)
+PMC_FILE = "r03_pmc_rollout.json"                    # HBM counters of the dominant kernel (separate --pmc passes, committed)
 
 
 def _sha16(path):
@@ -292,7 +292,7 @@ def main():
         K.block_fused = timed("fused_block_kernel", K.block_fused, fl_block, block_name)
         K.linear = timed("gemm_kernel (token-stationary projection GEMM)", K.linear, fl_lin)
         K.cross_attention = timed("xattn_mfma_kernel (cross / self attention of CViT)", K.cross_attention, fl_xattn)
-        K.spectral_layer = timed("spectral_layer (hipFFT R2C + low-mode contraction + C2R + 1x1 conv)", K.spectral_layer, by_spectral)
+        K.spectral_layer = timed("spectral_layer (truncated DFT on fp32 MFMA: row DFT, column DFT, mode mixing, inverse column DFT, inverse row DFT + 1x1 conv + act)", K.spectral_layer, by_spectral)
         try:
             step()
             torch.cuda.synchronize()
@@ -317,11 +317,21 @@ def main():
                 traffic_source["stale"] = traffic_source["kernel_source_sha16"] != traffic_source["current_kernel_source_sha16"]
         except (OSError, KeyError, ValueError):
             pass
+        try:      # cfg5: the spectral path's HBM bytes per SpectralLayer call (its five kernels), same rules
+            with open(os.path.join(ROOT, "profiles", "r03_pmc_fno.json")) as f:
+                pf = json.load(f)
+            if name.startswith("spectral") and os.path.basename(args.config) == pf.get("config"):
+                traffic = pf["spectral_layer"]["hbm_bytes_per_call"]
+                traffic_source = {"file": "profiles/r03_pmc_fno.json", "kernel_source_sha16": pf.get("kernel_source_sha16"),
+                                  "current_kernel_source_sha16": _sha16(os.path.join(ROOT, "tante_amd", "csrc", "spectral_dft.hip"))}
+                traffic_source["stale"] = traffic_source["kernel_source_sha16"] != traffic_source["current_kernel_source_sha16"]
+        except (OSError, KeyError, ValueError):
+            pass
         others = {k: {("TB/s" if k.startswith("spectral") else "TFLOP/s"): round(v[1] / (v[0] * 1e-3) / 1e12, 3), "avg_launch_us": round(1e3 * v[0] / v[2], 2),
                       "launches": v[2]} for k, v in tot.items() if k != name}
         if name.startswith("spectral"):              # cfg5: the FFT passes are HBM-bound; `achieved` in algorithmic GB/s against 8 TB/s
             roofline = {"bound": "hbm", "kernel": name, "achieved": round(ach * 1e3, 1), "peak": 8000.0, "unit": "GB/s",
-                        "frac": round(ach * 1e3 / 8000.0, 4), "traffic": None, "traffic_source": None, "launches": n,
+                        "frac": round(ach * 1e3 / 8000.0, 4), "traffic": traffic, "traffic_source": traffic_source, "launches": n,
                         "avg_launch_us": round(1e3 * ms / max(1, n), 2), "others": others}
         else:
             roofline = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": PEAK_TFLOPS[dtype], "unit": "TFLOP/s",

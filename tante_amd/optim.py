@@ -61,8 +61,11 @@ class FlatAdamW:
         self.step_count = 0
 
     def zero_grad(self, set_to_none: bool = False):
-        """Zero the gradient bucket.  The parameters' .grad stay views of it whatever set_to_none says: step() reads only the bucket."""
-        self._check_views()
+        """Zero the gradient bucket.  The parameters' .grad stay views of it whatever set_to_none says: step() reads only the bucket.
+        (The view check runs once per step, in step(); here only a dropped .grad -- model.zero_grad(set_to_none=True) -- is re-bound,
+        which a cheap scan of `p.grad is None` finds.)"""
+        if any(p.grad is None for p in self.params):
+            self._check_views()
         self.flat_g.zero_()
 
     def _check_views(self):

@@ -1,9 +1,9 @@
 #!/bin/bash
-# Run on the MI355X box (via gpurun): the round's rocprofv3 evidence -> gpurun_out/r02/.  tools/summarize_profiles.py condenses it into
+# Run on the MI355X box (via gpurun): the round's rocprofv3 evidence -> gpurun_out/r03/.  tools/summarize_profiles.py condenses it into
 # the files that are committed under profiles/.   gpurun --timeout 1200 -- 'bash tools/collect_profiles.sh'
 set -o pipefail
 R=$GRAFT_REPO_ROOT
-OUT=$R/gpurun_out/r02
+OUT=$R/gpurun_out/r03
 rm -rf $OUT && mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 # 1. kernel traces (never combined with counters)
@@ -19,6 +19,12 @@ for c in "FETCH_SIZE" "WRITE_SIZE" \
   n=$(echo $c | tr ' ' '_' | cut -c1-40)
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc/$n -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-train > /dev/null 2> $OUT/pmc_$n.err
 done
+# 2b. HBM counters of cfg5's spectral path (the truncated-DFT kernels) and of the train step (tools/pmc_train.sh: per-kernel MB and TB/s)
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_fno/$c -- python3 $R/bench.py --config $R/configs/tante_fno.yaml --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > /dev/null 2> $OUT/pmc_fno_$c.err
+done
+bash $R/tools/pmc_train.sh > $OUT/pmc_train.log 2>&1
+cp $R/gpurun_out/pmc_train/summary.txt $OUT/r03_pmc_train.txt 2>/dev/null
 # 3. un-profiled reference lines of the same commands
 python3 $R/bench.py --steps 10 --warmup 3 > $OUT/bench_full.json 2> $OUT/bench_full.err
 cd $R && python3 tools/summarize_profiles.py $OUT

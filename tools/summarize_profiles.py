@@ -1,4 +1,4 @@
-"""Condense the rocprofv3 outputs of tools/collect_profiles.sh (gpurun_out/r02/) into the small files committed under profiles/."""
+"""Condense the rocprofv3 outputs of tools/collect_profiles.sh (gpurun_out/r03/) into the small files committed under profiles/."""
 import collections
 import csv
 import glob
@@ -9,7 +9,7 @@ import sys
 
 out = sys.argv[1]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TAG = "r02"
+TAG = "r03"
 
 
 def stats(sub, dst, top=30):
@@ -60,6 +60,33 @@ for k, d in agg.items():
         e["mfma_busy_over_sq_busy_x32"] = round(m["SQ_VALU_MFMA_BUSY_CYCLES"] / (m["SQ_BUSY_CYCLES"] * 32), 4)
     res[k] = e
 json.dump(res, open(os.path.join(out, f"{TAG}_pmc_rollout.json"), "w"), indent=1)
+
+# cfg5: HBM bytes of the spectral path per SpectralLayer call (its five kernels; one idft_rows_conv launch per call)
+SPEC = ("dft_rows_kernel", "dft_cols_kernel", "spectral_mix_kernel", "idft_cols_kernel", "idft_rows_conv_kernel")
+fno = {"config": "tante_fno.yaml", "kernel_source_sha16": hashlib.sha256(open(os.path.join(ROOT, "tante_amd", "csrc", "spectral_dft.hip"), "rb").read()).hexdigest()[:16],
+       "note": "separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --config configs/tante_fno.yaml --steps 2 --warmup 1 --no-cpu-baseline "
+               "--no-roofline`; KiB; FETCH_SIZE doubled (16 B / lane or 128 B / half-wave streams: an upper bound for the narrower reads)", "kernels": {}}
+tot_bytes, calls = 0.0, 0
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    for f in glob.glob(os.path.join(out, "pmc_fno", c, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] != c:
+                continue
+            for k in SPEC:
+                if k in r["Kernel_Name"]:
+                    e = fno["kernels"].setdefault(k, {"FETCH_SIZE": [], "WRITE_SIZE": []})
+                    e[c].append(float(r["Counter_Value"]))
+for k, e in fno["kernels"].items():
+    fb = sum(e["FETCH_SIZE"]) * 1024 * 2
+    wb = sum(e["WRITE_SIZE"]) * 1024
+    n_ = max(1, len(e["FETCH_SIZE"]))
+    fno["kernels"][k] = {"launches_sampled": n_, "fetch_bytes_per_launch": round(fb / n_), "write_bytes_per_launch": round(wb / max(1, len(e["WRITE_SIZE"])))}
+    tot_bytes += fb / n_ * n_ + wb / max(1, len(e["WRITE_SIZE"])) * n_
+    if k == "idft_rows_conv_kernel":
+        calls = n_
+if calls:
+    fno["spectral_layer"] = {"hbm_bytes_per_call": round(tot_bytes / calls), "calls_sampled": calls}
+    json.dump(fno, open(os.path.join(out, f"{TAG}_pmc_fno.json"), "w"), indent=1)
 for name in ("rollout_bench.json", "train_bench.json", "trl_bench.json", "cvit_bench.json", "fno_bench.json", "bench_full.json"):
     p = os.path.join(out, name)
     if os.path.exists(p):
