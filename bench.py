@@ -205,7 +205,8 @@ def main():
     from tante_amd import kernels as K
     cfg = tante_amd.load_config(args.config)
     wl = cfg["workload"]
-    kind = "cvit" if cfg["model"]["_target_"].endswith("CViT") else ("tante_fno" if cfg["model"].get("enc_dec_type", "cnn") == "fno" else "tante")
+    tgt = cfg["model"]["_target_"]
+    kind = "cvit" if tgt.endswith("CViT") else ("fno" if tgt.endswith("FNO") else ("tante_fno" if cfg["model"].get("enc_dec_type", "cnn") == "fno" else "tante"))
     B = args.batch or wl["batch_size"]
     # CViT predicts all out_steps frames in ONE model call (trainer/trainer.py:161-172, `cvit: False` full-grid mode): a step = one call
     n_steps = cfg["model"]["out_steps"] if kind == "cvit" else wl["n_steps_rollout"]
@@ -215,7 +216,12 @@ def main():
     dtype = args.dtype or {"bfloat16": "bf16", "float32": "fp32"}[wl.get("amp", "bfloat16")]
     md = tante_amd.TanteMetadata(n_fields=D, spatial_resolution=res)
     torch.manual_seed(cfg.get("seed", 211))
-    model = tante_amd.build_model(cfg, md).to(dev).eval().set_compute(dtype)
+    model = tante_amd.build_model(cfg, md).to(dev).eval()
+    if kind == "fno":      # models.FNO has no compute switch: the reference's AMP context selects bf16 (the spectral layers stay fp32 either way)
+        import contextlib
+        amp = (lambda: torch.autocast("cuda", dtype=torch.bfloat16)) if dtype == "bf16" else contextlib.nullcontext
+    else:
+        model.set_compute(dtype)
     gen = torch.Generator().manual_seed(cfg.get("seed", 211) + rank)
     batch = {"input": torch.randn(B, T_in, *res, D, generator=gen).to(dev),          # channels-last, like the dataset
              "output": torch.randn(B, n_steps, *res, D, generator=gen).to(dev)}
@@ -227,6 +233,10 @@ def main():
         with torch.inference_mode():
             if kind == "cvit":
                 return model(x_cvit)
+            if kind == "fno":
+                with amp():
+                    y, _ = tante_amd.rollout_model(model, batch, fmt, n_steps, device=dev)
+                return y
             y, _ = tante_amd.rollout_model(model, batch, fmt, n_steps, device=dev)
         return y
 
@@ -414,7 +424,7 @@ def main():
             train["strong"] = {"scaling": "strong", **strong}
 
     cpu = None
-    if not args.no_cpu_baseline and rank == 0 and world == 1 and kind != "cvit":      # (cfg4 as written needs a 8.6 GB temporary on the host)
+    if not args.no_cpu_baseline and rank == 0 and world == 1 and kind not in ("cvit", "fno"):      # (cfg4 as written needs a 8.6 GB temporary on the host)
         from oracle import tante_oracle as O
         mk = cfg["model"]
         ocfg = O.TanteCfg(mk["in_T"], D, res, taylor_order=mk.get("taylor_order", 1), frame_interval=mk.get("frame_interval", 1.0),
@@ -453,7 +463,8 @@ def main():
         title = {"tante": "rollout frames/sec (fwd), TANTE on 256x256 Active Matter" if os.path.basename(args.config).startswith("tante_am")
                  else "rollout frames/sec (fwd), TANTE (%s)" % os.path.basename(args.config),
                  "cvit": "frames/sec (fwd, full-grid queries), CViT on Rayleigh-Benard 512x128",
-                 "tante_fno": "rollout frames/sec (fwd), TANTE with the spectral encoder/decoder on 512x512x8"}[kind]
+                 "tante_fno": "rollout frames/sec (fwd), TANTE with the spectral encoder/decoder on 512x512x8",
+                 "fno": "rollout frames/sec (fwd), models.FNO (configs/fno.yaml model block) on 512x512x8"}[kind]
         out = {"metric": title, "value": round(value, 2), "unit": "frames/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",

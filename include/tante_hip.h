@@ -306,6 +306,14 @@ int tante_pack_head(const float* w1, const float* b1, const float* w2, const flo
 int tante_head_fused(const float* x, int32_t a_n0, int64_t a_s1, int64_t a_s0, int64_t a_off, int n_img, int Hp, int Wp, int C, int D,
                      const void* head_stream, float* out, int64_t out_bstride, int n_out, const float* coefs, const float* last,
                      int64_t last_bstride, void* stream);
+/* Every Taylor order's derivative head in ONE launch, one prediction frame (tante.py:145-154 + 165-171 with output_length = 1):
+ *   out = last + sum_k coefs[k] * head_k(rows_k),  k < n_ord <= 4.
+ * rows[k], k < n_ord - 1: dense (n_img * Hp * Wp, C) fp32 copies of the last-slot token rows as backbone k left them (the stream is
+ * updated in place by the later backbones); rows[n_ord - 1] is the stream itself, addressed through (a_n0, a_s1, a_s0, a_off) like
+ * tante_head_fused.  head_streams[k]: tante_pack_head of decoder k.  The frame is read (`last`) and written once, not once per order. */
+int tante_head_fused_multi(int n_ord, const float* const* rows, const void* const* head_streams, const float* coefs, int32_t a_n0,
+                           int64_t a_s1, int64_t a_s0, int64_t a_off, int n_img, int Hp, int Wp, int C, int D, float* out,
+                           int64_t out_bstride, const float* last, int64_t last_bstride, void* stream);
 
 /* ---- general encoder / decoder stages, spectral operator path, CViT (operators.hip) ---------------------------------
  * tante_im2col: rows = output positions (img, oh, ow) of a convolution with kernel (kh, kw), stride (sh, sw), zero padding (ph, pw)

@@ -174,6 +174,8 @@ SIGNATURES = {
     "tante_abi_version": ([], c_i32),
     "tante_set_option": ([C.c_char_p, c_i32], c_i32),
     "tante_nan_to_num": ([c_vp, c_vp, c_i64, c_vp], c_i32),
+    "tante_head_fused_multi": ([c_i32, c_vp, c_vp, c_vp, c_i32, c_i64, c_i64, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp, c_i64,
+                               c_vp], c_i32),
     "tante_get_option": ([C.c_char_p, c_i32], c_i32),
 }
 

@@ -46,6 +46,14 @@ struct HeadArgs {
   float* out; long out_bstride; int n_out;
   const float* last; long last_bstride;   // NULL: accumulate into out; else out_i = last + coef_i * d
   float coef[8];
+  // MULTI form (fused_head_kernel<..., true>, one prediction frame): every Taylor order in ONE launch -- order k reads its last-slot token
+  // rows from xk[k] (the rows as backbone k left them: dense (rows, C) copies for all but the last order) and its weight stream from wk[k];
+  // the derivatives are summed in registers, coefficient ck[k] each, and the frame is read and written ONCE.
+  int n_ord;
+  const float *xk0, *xk1, *xk2, *xk3;
+  const char *wk0, *wk1, *wk2, *wk3;
+  float ck0, ck1, ck2, ck3;
+  long m_s1, m_s0, m_off; int m_n0;   // row addressing of xk0 .. xk[n_ord - 2] (the copies); the last order uses a_*
   int groups;            // token groups of 16 NWV
   int debug;             // TANTE_HEAD_DEBUG ablation bits (timing only, results are wrong): 1 no epilogue memory, 2 no GELU, 4 no weight stream
   unsigned long long* stamps;   // -DTANTE_ABLATE builds only (tools/head_stamps.py), else null
@@ -86,7 +94,7 @@ struct HeadGeom {
 // L2 round trips in a row, each ~2.5 us because the compute between them is 16 - 64 MFMAs -- the kernel sat at 22 us for 54 MB of
 // traffic, waves parked 59 % of the time.)  One workgroup per CU; blockIdx -> (group, p) keeps the four pixels of a group on one
 // XCD (their output sectors interleave, the L2 merges them).
-template <int CB, int NWV>
+template <int CB, int NWV, bool MULTI = false>
 __global__ __launch_bounds__(NWV * 64, 1) void fused_head_kernel(const HeadArgs A) {
   using G = HeadGeom<CB>;
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [W3 | bias3][W1 p | bias1 p][W2 q | bias2 q] x 4
@@ -98,9 +106,30 @@ __global__ __launch_bounds__(NWV * 64, 1) void fused_head_kernel(const HeadArgs 
   const int grp = (blockIdx.x >> 5) * 8 + (blockIdx.x & 7);
   if (grp >= A.groups) return;
   HEAD_STAMP(0);
+  f32x4 dsum[MULTI ? 4 : 1][4];      // MULTI: sum over the orders of coefficient x derivative, per sub-pixel q and channel tile ns
+  f32x4 pre[2][4][2];                // the frame values the epilogue adds to (fetched during the first order)
+  if constexpr (MULTI) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int ns = 0; ns < 4; ++ns) dsum[q][ns] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+ // One order.  The LAST order's pass is a second copy of this body (IS_LAST): only there are the frame values the epilogue adds to
+ // fetched -- 64 registers that would otherwise be live through every order's pass.
+ auto run_order = [&](auto is_last_c, const int ord) {
+  constexpr bool IS_LAST = decltype(is_last_c)::value;
+  // this order's token rows, weight stream, coefficient and row addressing (named fields: a run-time index into the kernel arguments
+  // would send the struct to scratch)
+  const bool last_ord = !MULTI || IS_LAST;
+  const float* Xp = !MULTI ? A.x : (ord == 0 ? A.xk0 : ord == 1 ? A.xk1 : ord == 2 ? A.xk2 : A.xk3);
+  const char* Wp = !MULTI ? A.w : (ord == 0 ? A.wk0 : ord == 1 ? A.wk1 : ord == 2 ? A.wk2 : A.wk3);
+  const float cord = !MULTI ? 1.0f : (ord == 0 ? A.ck0 : ord == 1 ? A.ck1 : ord == 2 ? A.ck2 : A.ck3);
+  const long r_s1 = last_ord ? A.a_s1 : A.m_s1, r_s0 = last_ord ? A.a_s0 : A.m_s0, r_off = last_ord ? A.a_off : A.m_off;
+  const int r_n0 = last_ord ? A.a_n0 : A.m_n0;
+  if (MULTI && ord) __syncthreads();      // every wave is done with the previous order's weights before the DMA overwrites them
   if (!(A.debug & 4)) {
-    hglds<NWV>(A.w + G::T3 + (long)p * G::T1, w1s, G::T1, tid);
-    hglds<NWV>(A.w, w3s, G::T3, tid);
+    hglds<NWV>(Wp + G::T3 + (long)p * G::T1, w1s, G::T1, tid);
+    hglds<NWV>(Wp, w3s, G::T3, tid);
   }
   HEAD_STAMP(10);
 
@@ -111,15 +140,15 @@ __global__ __launch_bounds__(NWV * 64, 1) void fused_head_kernel(const HeadArgs 
   const unsigned n_rows = (unsigned)A.n_img * (unsigned)HW;
   const unsigned row0 = (unsigned)__builtin_amdgcn_readfirstlane((grp * NWV + wave) * 16);
   const unsigned img0 = row0 / (unsigned)HW, hw0 = row0 - img0 * (unsigned)HW;
-  const unsigned aq0 = row0 / (unsigned)A.a_n0, ar0 = row0 - aq0 * (unsigned)A.a_n0;
+  const unsigned aq0 = row0 / (unsigned)r_n0, ar0 = row0 - aq0 * (unsigned)r_n0;
   auto row_img_hw = [&](int j, int& im, int& hwv) {          // row0 + j -> (image, position in image)
     im = (int)img0; hwv = (int)hw0 + j;
     while (hwv >= HW) { hwv -= HW; ++im; }
   };
   auto row_offset = [&](int j) {                              // row0 + j -> element offset of its token row
     long q = aq0; int rem = (int)ar0 + j;
-    while (rem >= A.a_n0) { rem -= A.a_n0; ++q; }
-    return q * A.a_s1 + (long)rem * A.a_s0 + A.a_off;
+    while (rem >= r_n0) { rem -= r_n0; ++q; }
+    return q * r_s1 + (long)rem * r_s0 + r_off;
   };
   const bool live = row0 + (unsigned)l15 < n_rows;
   int img, hw;
@@ -140,8 +169,8 @@ __global__ __launch_bounds__(NWV * 64, 1) void fused_head_kernel(const HeadArgs 
 #pragma unroll
     for (int j = 0; j < 16 / RPI; ++j) {
       const int rj = RPI * j + lane / LPR;
-      const long eo = row0 + (unsigned)rj < n_rows ? row_offset(rj) : A.a_off;      // dead rows read row 0 of the view (valid memory)
-      xraw[j] = *(const f32x4*)(A.x + eo + 4 * (lane % LPR));
+      const long eo = row0 + (unsigned)rj < n_rows ? row_offset(rj) : r_off;      // dead rows read row 0 of the view (valid memory)
+      xraw[j] = *(const f32x4*)(Xp + eo + 4 * (lane % LPR));
     }
     HEAD_STAMP(11);
     char* xs = w2s + wave * (16 * CB * 64);           // 16 rows x (32 CB) bf16
@@ -160,7 +189,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void fused_head_kernel(const HeadArgs 
     }
   }
   __syncthreads();      // every wave has its fragments: the W2 tiles may land on the staging pieces
-  if (!(A.debug & 4)) hglds<NWV>(A.w + G::T3 + 4L * G::T1, w2s, 4 * G::T2, tid);
+  if (!(A.debug & 4)) hglds<NWV>(Wp + G::T3 + 4L * G::T1, w2s, 4 * G::T2, tid);
   int xo1[CB], xo2[G::KB2], xo3[G::KB3];
 #pragma unroll
   for (int b = 0; b < CB; ++b) xo1[b] = swz_chunk(l15, b * 4 + kk, G::CPR1) << 4;
@@ -180,7 +209,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void fused_head_kernel(const HeadArgs 
   };
   // The epilogue works on sub-pixel PAIRS (q = 2 j, 2 j + 1 are horizontal neighbours): 4 pixels = 16 bytes per row, so every
   // read-modify-write instruction moves 16 bytes per lane instead of 8 (half the memory instructions of the kernel's epilogue).
-  f32x4 pre[2][4][2];
+  if constexpr (!MULTI || IS_LAST)
 #pragma unroll
   for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -241,7 +270,9 @@ __global__ __launch_bounds__(NWV * 64, 1) void fused_head_kernel(const HeadArgs 
 #pragma unroll
         for (int b = 0; b < G::KB3; ++b) d = hmfma(*(const u32x4*)(w3s + (ns * 16 + l15) * G::CPR3 * 16 + xo3[b]), h2[b], d);
         if ((A.debug & 1) && d[0] != 1.2345f) continue;
-        if constexpr ((q & 1) == 0) {
+        if constexpr (MULTI) {
+          dsum[q][ns] += d * cord;                     // the frame is touched once, after the last order (below)
+        } else if constexpr ((q & 1) == 0) {
           dl[ns] = d;                                  // left half of the pair: kept until its right neighbour exists
         } else if (live && 4 * ns + kk < A.D) {
           const long pix = pix_of(q - 1, ns);
@@ -265,6 +296,37 @@ __global__ __launch_bounds__(NWV * 64, 1) void fused_head_kernel(const HeadArgs 
     }
     HEAD_STAMP(5 + q);
   });
+ };   // run_order
+ if constexpr (MULTI) {
+   for (int ord = 0; ord + 1 < A.n_ord; ++ord) run_order(std::false_type{}, ord);
+   run_order(std::true_type{}, A.n_ord - 1);
+ } else {
+   run_order(std::true_type{}, 0);
+ }
+  if constexpr (MULTI) {
+    const float* bias_unused = nullptr; (void)bias_unused;
+    const long frame = (long)A.D * (A.Hp * 8) * (A.Wp * 8); (void)frame;
+    const int Wout = A.Wp * 8;
+    const int HW = A.Hp * A.Wp;
+    const unsigned n_rows = (unsigned)A.n_img * (unsigned)HW;
+    const unsigned row0 = (unsigned)__builtin_amdgcn_readfirstlane((grp * NWV + wave) * 16);
+    const bool live = row0 + (unsigned)l15 < n_rows;
+    unsigned im = row0 / (unsigned)HW; int hwv = (int)(row0 - im * (unsigned)HW) + (live ? l15 : 0);
+    while (hwv >= HW) { hwv -= HW; ++im; }
+    if (!live) { im = 0; hwv = 0; }
+    const int hp = (int)(((float)hwv + 0.5f) * __builtin_amdgcn_rcpf((float)A.Wp)), wp = hwv - hp * A.Wp;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int ns = 0; ns < 4; ++ns)
+        if (4 * ns < A.D && live && 4 * ns + kk < A.D) {
+          const int y0 = hp * 8 + (p >> 1) * 4 + j * 2, x0 = wp * 8 + (p & 1) * 4;
+          float* o0 = A.out + (long)im * A.out_bstride + ((long)(4 * ns + kk) * (A.Hp * 8) + y0) * Wout + x0;
+          const f32x4 dl_ = dsum[2 * j][ns], dr_ = dsum[2 * j + 1][ns];
+          *(f32x4*)o0 = pre[j][ns][0] + f32x4{dl_[0], dl_[1], dr_[0], dr_[1]};
+          *(f32x4*)(o0 + Wout) = pre[j][ns][1] + f32x4{dl_[2], dl_[3], dr_[2], dr_[3]};
+        }
+  }
 #ifdef TANTE_ABLATE
   if (A.stamps) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -318,27 +380,27 @@ __global__ void pack_head_stream_kernel(const float* __restrict__ w1, const floa
   }
 }
 
-template <int CB, int NWV>
+template <int CB, int NWV, bool MULTI>
 void launch_head_nw(HeadArgs A, hipStream_t s) {
   using G = HeadGeom<CB>;
   static TantePerDevice attr;
   attr.once([&] {
-    (void)hipFuncSetAttribute((const void*)fused_head_kernel<CB, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
+    (void)hipFuncSetAttribute((const void*)fused_head_kernel<CB, NWV, MULTI>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
   });
   const long rows = (long)A.n_img * A.Hp * A.Wp;
   A.groups = (int)((rows + NWV * 16 - 1) / (NWV * 16));
   const unsigned grid = (unsigned)((A.groups + 7) / 8) * 32;   // 8 token groups x 4 pixels per 32 consecutive workgroups
-  hipLaunchKernelGGL((fused_head_kernel<CB, NWV>), dim3(grid), dim3(NWV * 64), G::LDS, s, A);
+  hipLaunchKernelGGL((fused_head_kernel<CB, NWV, MULTI>), dim3(grid), dim3(NWV * 64), G::LDS, s, A);
 }
 
-template <int CB>
+template <int CB, bool MULTI = false>
 void launch_head(HeadArgs A, hipStream_t s) {
   // 128-token groups (8 waves) once they still give every CU a workgroup; 64-token groups for small batches
   const long rows = (long)A.n_img * A.Hp * A.Wp;
   const int force = tante_opt("TANTE_HEAD_WAVES", 0);
   const bool wide = force ? force == 8 : rows >= 128 * 56;
-  if (wide) launch_head_nw<CB, 8>(A, s);
-  else launch_head_nw<CB, 4>(A, s);
+  if (wide) launch_head_nw<CB, 8, MULTI>(A, s);
+  else launch_head_nw<CB, 4, MULTI>(A, s);
 }
 
 }  // namespace
@@ -378,6 +440,9 @@ extern "C" int tante_head_fused(const float* x, int32_t a_n0, int64_t a_s1, int6
   A.w = (const char*)head_stream; A.out = out; A.out_bstride = out_bstride; A.n_out = n_out;
   A.last = last; A.last_bstride = last_bstride;
   for (int i = 0; i < 8; ++i) A.coef[i] = i < n_out ? coefs[i] : 0.f;
+  A.n_ord = 1;
+  A.xk0 = A.xk1 = A.xk2 = A.xk3 = nullptr; A.wk0 = A.wk1 = A.wk2 = A.wk3 = nullptr; A.ck0 = A.ck1 = A.ck2 = A.ck3 = 0.f;
+  A.m_n0 = 1; A.m_s1 = A.m_s0 = A.m_off = 0;
   A.debug = tante_ablate_env("TANTE_HEAD_DEBUG");  // -DTANTE_ABLATE builds only
 #ifdef TANTE_ABLATE
   A.stamps = g_head_stamps;
@@ -386,6 +451,44 @@ extern "C" int tante_head_fused(const float* x, int32_t a_n0, int64_t a_s1, int6
 #endif
   if (C == 128) launch_head<4>(A, (hipStream_t)stream);
   else launch_head<8>(A, (hipStream_t)stream);
+  TANTE_CHECK_LAUNCH();
+  return 0;
+}
+
+/* Every Taylor order's derivative head in ONE launch, one prediction frame:  out = last + sum_k coefs[k] * head_k(rows_k)
+ * (tante.py:145-154, 165-171 with output_length = 1).  rows_k, k < n_ord - 1: dense (n_img Hp Wp, C) fp32 copies of the last-slot token
+ * rows as backbone k left them (the stream is updated in place by the later backbones); the last order reads the stream itself through
+ * (a_n0, a_s1, a_s0, a_off) like tante_head_fused.  The frame is read (from `last`) and written once instead of once per order. */
+extern "C" int tante_head_fused_multi(int n_ord, const float* const* rows, const void* const* head_streams, const float* coefs, int32_t a_n0,
+                                      int64_t a_s1, int64_t a_s0, int64_t a_off, int n_img, int Hp, int Wp, int C, int D, float* out,
+                                      int64_t out_bstride, const float* last, int64_t last_bstride, void* stream) {
+  if (!rows || !head_streams || !coefs || !out || !last) TANTE_FAIL(-1, "tante_head_fused_multi: null pointer");
+  if (n_ord < 1 || n_ord > 4) TANTE_FAIL(-2, "tante_head_fused_multi: 1 .. 4 orders");
+  if (!tante_head_fused_supported(C, D)) TANTE_FAIL(-2, "tante_head_fused_multi: unsupported C=%d D=%d", C, D);
+  if (a_n0 <= 0 || n_img <= 0 || Hp <= 0 || Wp <= 0) TANTE_FAIL(-1, "tante_head_fused_multi: bad shape");
+  if (a_s1 % 4 || a_s0 % 4 || a_off % 4 || out_bstride % 2 || last_bstride % 2 || ((uintptr_t)out % 8) || ((uintptr_t)last % 8))
+    TANTE_FAIL(-1, "tante_head_fused_multi: alignment");
+  for (int k = 0; k < n_ord; ++k)
+    if (!rows[k] || !head_streams[k] || ((uintptr_t)rows[k] % 16)) TANTE_FAIL(-1, "tante_head_fused_multi: order %d: null or misaligned rows / stream", k);
+  HeadArgs A;
+  A.x = rows[n_ord - 1]; A.a_n0 = a_n0; A.a_s1 = a_s1; A.a_s0 = a_s0; A.a_off = a_off;
+  A.n_img = n_img; A.Hp = Hp; A.Wp = Wp; A.D = D;
+  A.w = (const char*)head_streams[n_ord - 1]; A.out = out; A.out_bstride = out_bstride; A.n_out = 1;
+  A.last = last; A.last_bstride = last_bstride;
+  for (int i = 0; i < 8; ++i) A.coef[i] = 0.f;
+  A.n_ord = n_ord;
+  const float* xs[4] = {nullptr, nullptr, nullptr, nullptr};
+  const char* ws[4] = {nullptr, nullptr, nullptr, nullptr};
+  float cs[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int k = 0; k < n_ord; ++k) { xs[k] = rows[k]; ws[k] = (const char*)head_streams[k]; cs[k] = coefs[k]; }
+  A.xk0 = xs[0]; A.xk1 = xs[1]; A.xk2 = xs[2]; A.xk3 = xs[3];
+  A.wk0 = ws[0]; A.wk1 = ws[1]; A.wk2 = ws[2]; A.wk3 = ws[3];
+  A.ck0 = cs[0]; A.ck1 = cs[1]; A.ck2 = cs[2]; A.ck3 = cs[3];
+  A.m_n0 = n_img * Hp * Wp; A.m_s1 = 0; A.m_s0 = C; A.m_off = 0;      // the copies: dense rows
+  A.debug = 0;
+  A.stamps = nullptr;
+  if (C == 128) launch_head<4, true>(A, (hipStream_t)stream);
+  else launch_head<8, true>(A, (hipStream_t)stream);
   TANTE_CHECK_LAUNCH();
   return 0;
 }

@@ -438,6 +438,21 @@ def head_fused(x: torch.Tensor, a_n0: int, a_s1: int, a_s0: int, a_off: int, n_i
     return out
 
 
+def head_fused_multi(rows: Sequence[torch.Tensor], a_n0: int, a_s1: int, a_s0: int, a_off: int, n_img: int, Hp: int, Wp: int, C_: int, D: int,
+                     head_streams: Sequence[torch.Tensor], coefs: Sequence[float], out: torch.Tensor, out_bstride: int, last: torch.Tensor,
+                     last_elem_off: int, last_bstride: int):
+    """out = last + sum_k coefs[k] * head_k(rows[k]) in ONE launch (one prediction frame).  rows[:-1]: dense (n_img * Hp * Wp, C_) fp32 copies of
+    the last-slot token rows after each earlier backbone; rows[-1]: the stream itself, addressed by (a_n0, a_s1, a_s0, a_off)."""
+    n = len(rows)
+    _dev(*rows, *head_streams, out, last)
+    rp = (C.c_void_p * n)(*[r.data_ptr() for r in rows])
+    sp = (C.c_void_p * n)(*[h.data_ptr() for h in head_streams])
+    cf = (C.c_float * n)(*[float(c) for c in coefs])
+    L.check(L.lib().tante_head_fused_multi(n, rp, sp, cf, a_n0, a_s1, a_s0, a_off, n_img, Hp, Wp, C_, D, out.data_ptr(), out_bstride,
+                                           last.data_ptr() + 4 * last_elem_off, last_bstride, _stream()), "tante_head_fused_multi")
+    return out
+
+
 def enc23_supported(C_: int) -> bool:
     return bool(L.lib().tante_enc23_supported(C_))
 

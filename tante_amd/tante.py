@@ -53,6 +53,9 @@ class TanteMetadata:
                 "space_grid": [*self.spatial_resolution, self.n_spatial_dims]}
 
 
+HEAD_MULTI = __import__("os").environ.get("TANTE_HEAD_MULTI", "1") != "0"      # every Taylor order's derivative head in one launch
+
+
 def _check_patch_cfg(patch_scale, overlap_ratio):
     """-> per-stage kernel sizes.  Stages with 'same' padding (4x4 kernels, enc_dec_cnn.py:78-81) or overlap (stride < kernel) take
     the general im2col / crop+resize route of stages.py; 1x1 / 2x2 non-overlapping stages keep the dedicated patch GEMM."""
@@ -501,10 +504,25 @@ class TANTE(nn.Module):
                     or out.stride()[1:] != (frame, H * W, W, 1) or out.stride(0) % 4 or out.data_ptr() % 16:
                 raise ValueError("out must be a (B, output_length, D, H, W) fp32 CUDA view with contiguous frames")
         derivs, r_t, srcs = [], [], []
+        # one prediction frame, several Taylor orders: ONE head launch after the last backbone (tante_head_fused_multi) instead of one per
+        # order -- the frame is read and written once instead of taylor_order times.  The earlier orders' last-slot rows are copied aside
+        # (8 MB each at cfg2) because the later backbones update the stream in place.  TANTE_HEAD_MULTI=0: one launch per order (A/B).
+        multi_head = (self.deg and fused_head and self.output_length == 1 and 2 <= self.taylor_order <= 4 and HEAD_MULTI)
+        saved_rows = []
         for i in range(self.taylor_order):
             self.blocks[i].forward_tokens(x, B, compute, film_src=(enc_cache + (film,)) if (enc_cache is not None and i == 0) else None)  # l.146 (chained)
             if self.deg:
-                if fused_head:
+                if multi_head:
+                    if i + 1 < self.taylor_order:
+                        saved_rows.append(x.view(B, T, HW * C_)[:, T - 1].contiguous().view(B * HW, C_))
+                        continue
+                    if out is None:
+                        out = torch.empty(B, 1, D, H, W, dtype=torch.float32, device=x.device)
+                    coefs = [self.frame_interval ** (k + 1) / math.factorial(k + 1) for k in range(self.taylor_order)]
+                    K.head_fused_multi(saved_rows + [x], HW, T * HW * C_, C_, (T - 1) * HW * C_, B, Hp, Wp, C_, D,
+                                       [self.decoders[k].packed_head() for k in range(self.taylor_order)], coefs, out, out.stride(0),
+                                       inp, (T - 1) * frame, bstride)                                          # l.147,153,165-171
+                elif fused_head:
                     if out is None:
                         out = torch.empty(B, self.output_length, D, H, W, dtype=torch.float32, device=x.device)
                     coefs = [(j * self.frame_interval) ** (i + 1) / math.factorial(i + 1) for j in range(1, self.output_length + 1)]

@@ -256,3 +256,34 @@ def test_spectral_layer_truncated_dft_against_oracle_and_fft_path(dev, n, cin, c
         if act == 1:
             ref = torch.nn.functional.gelu(ref)
         close(y_dft, ref, "fp32", "truncated DFT vs oracle")
+
+
+@pytest.mark.parametrize("order,axes", [(2, "T-W"), (3, "T-H-W"), (3, "THW-THW-THW")])
+def test_multi_order_head_launch_equals_per_order_launches(dev, order, axes):
+    """tante_head_fused_multi (every Taylor order's derivative head in one launch, the frame read and written once) against one
+    tante_head_fused launch per order (tante.py:145-154, 165-171): same heads, same coefficients, the sum over the orders taken in
+    registers instead of through the frame -- agreement to fp32 rounding of the sum order; and against the oracle at the bf16 bar."""
+    import tante_amd
+    from tante_amd import tante as TT
+    from oracle import tante_oracle as O
+    torch.manual_seed(order * 7)
+    md = tante_amd.TanteMetadata(n_fields=5, spatial_resolution=(64, 96))
+    m = tante_amd.TANTE(in_T=4, dset_metadata=md, taylor_order=order, attn_axes=axes, n_head=8, embed_dim=256, patch_scale=8, frame_interval=0.5,
+                        dropout=0.0).to(dev).eval().set_compute("bf16")
+    x = torch.randn(3, 4, 5, 64, 96, generator=torch.Generator().manual_seed(1))
+    outs = []
+    saved = TT.HEAD_MULTI
+    try:
+        for multi in (True, False):
+            TT.HEAD_MULTI = multi
+            with torch.no_grad():
+                outs.append(m(x.to(dev)).cpu())
+    finally:
+        TT.HEAD_MULTI = saved
+    d0, d1 = outs[0] - x[:, -1:], outs[1] - x[:, -1:]
+    r = rel_err(d0, d1)
+    record_parity(r, max_rel(d0, d1), 1e-5, "fp32", f"multi-order head vs per-order launches, derivative part, order {order}")
+    assert r < 1e-5, r
+    cfg = O.TanteCfg(4, 5, (64, 96), taylor_order=order, attn_axes=axes, n_head=8, embed_dim=256, patch_scale=8, frame_interval=0.5)
+    ref = O.tante_forward({k: v.detach().cpu() for k, v in m.state_dict().items()}, cfg, x[:1])
+    close(outs[0][:1], ref, "bf16", f"multi-order head, order {order}, vs oracle")
