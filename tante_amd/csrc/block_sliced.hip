@@ -291,7 +291,11 @@ __global__ __launch_bounds__(64 * NW * G, 2) void block_fs_kernel(FsArgs A) {
       for (int j = 0; j < RT; ++j) {
         const int r = RPI * j + rrow, t = tok_of(16 * tt + r);
         const f32x4 v = *(const f32x4*)(sb + r * ROWB + ((rchunk ^ (r & (CPR - 1))) << 4));
+#ifdef FS_NT_STORE      // experiment: streaming (non-temporal) stores of the block's output rows
+        if (t >= 0) __builtin_nontemporal_store(v, (f32x4*)(dst + (long)t * FS_C + 16 * RT * wave + 4 * rchunk));
+#else
         if (t >= 0) *(f32x4*)(dst + (long)t * FS_C + 16 * RT * wave + 4 * rchunk) = v;
+#endif
       }
     }
   };

@@ -444,7 +444,9 @@ def head_fused_multi(rows: Sequence[torch.Tensor], a_n0: int, a_s1: int, a_s0: i
     """out = last + sum_k coefs[k] * head_k(rows[k]) in ONE launch (one prediction frame).  rows[:-1]: dense (n_img * Hp * Wp, C_) fp32 copies of
     the last-slot token rows after each earlier backbone; rows[-1]: the stream itself, addressed by (a_n0, a_s1, a_s0, a_off)."""
     n = len(rows)
-    _dev(*rows, *head_streams, out, last)
+    _dev(*rows, *head_streams)
+    if not (out.is_cuda and last.is_cuda):      # `out` / `last` are base pointers + strides (views of a rollout buffer): not required dense
+        raise RuntimeError("tante_amd kernels need CUDA/HIP tensors (no CPU fallback)")
     rp = (C.c_void_p * n)(*[r.data_ptr() for r in rows])
     sp = (C.c_void_p * n)(*[h.data_ptr() for h in head_streams])
     cf = (C.c_float * n)(*[float(c) for c in coefs])

@@ -514,7 +514,7 @@ class TANTE(nn.Module):
             if self.deg:
                 if multi_head:
                     if i + 1 < self.taylor_order:
-                        saved_rows.append(x.view(B, T, HW * C_)[:, T - 1].contiguous().view(B * HW, C_))
+                        saved_rows.append(x.view(B, T, HW * C_)[:, T - 1].clone(memory_format=torch.contiguous_format).view(B * HW, C_))      # (a COPY also at B = 1)
                         continue
                     if out is None:
                         out = torch.empty(B, 1, D, H, W, dtype=torch.float32, device=x.device)

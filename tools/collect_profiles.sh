@@ -12,6 +12,10 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/train -- python3 $R
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trl -- python3 $R/bench.py --config $R/configs/tante_trl.yaml --steps 5 --warmup 2 --no-cpu-baseline > $OUT/trl_bench.json 2> $OUT/trl.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/cvit -- python3 $R/bench.py --config $R/configs/cvit_rb.yaml --steps 5 --warmup 2 > $OUT/cvit_bench.json 2> $OUT/cvit.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/fno -- python3 $R/bench.py --config $R/configs/tante_fno.yaml --steps 3 --warmup 1 --no-cpu-baseline > $OUT/fno_bench.json 2> $OUT/fno.err
+python3 $R/bench.py --config $R/configs/fno_vf.yaml --steps 3 --warmup 1 > $OUT/fno_vf_bench.json 2> $OUT/fno_vf.err
+python3 $R/tools/dp_gloo_1gpu.py > $OUT/dp_gloo_1gpu.log 2>&1
+TANTE_DIST_BACKEND=gloo TANTE_ALL_ON_GPU0=1 python3 $R/bench.py --gpus 2 --steps 3 --warmup 1 --train-steps 3 > $OUT/bench_gloo2_plumbing.json 2> $OUT/bench_gloo2_plumbing.err
+python3 $R/bench.py --gpus 2 --steps 1 --warmup 0 > $OUT/bench_gpus2_refused.out 2>&1; echo "exit code $?" >> $OUT/bench_gpus2_refused.out
 # 2. counters of the rollout, one pass per group (8 SQ slots; FETCH_SIZE and WRITE_SIZE cannot share a pass), kernel-trace only
 for c in "FETCH_SIZE" "WRITE_SIZE" \
          "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU" \

@@ -87,11 +87,17 @@ for k, e in fno["kernels"].items():
 if calls:
     fno["spectral_layer"] = {"hbm_bytes_per_call": round(tot_bytes / calls), "calls_sampled": calls}
     json.dump(fno, open(os.path.join(out, f"{TAG}_pmc_fno.json"), "w"), indent=1)
-for name in ("rollout_bench.json", "train_bench.json", "trl_bench.json", "cvit_bench.json", "fno_bench.json", "bench_full.json"):
+for name in ("rollout_bench.json", "train_bench.json", "trl_bench.json", "cvit_bench.json", "fno_bench.json", "fno_vf_bench.json", "bench_gloo2_plumbing.json",
+             "bench_full.json"):
     p = os.path.join(out, name)
     if os.path.exists(p):
         lines = [ln for ln in open(p).read().strip().splitlines() if ln.startswith("{")]
         if lines:
             open(os.path.join(out, f"{TAG}_{name}"), "w").write(lines[-1] + "\n")
+for name in ("dp_gloo_1gpu.log", "bench_gpus2_refused.out"):
+    p = os.path.join(out, name)
+    if os.path.exists(p):
+        keep = [ln for ln in open(p).read().splitlines() if ln.startswith("dp_gloo_1gpu") or "bench.py" in ln or ln.startswith("exit code")]
+        open(os.path.join(out, f"{TAG}_{name}"), "w").write("\n".join(keep) + "\n")
 print(json.dumps({k: (v if not isinstance(v, dict) or "counters_avg_per_launch" not in v else {kk: vv for kk, vv in v.items() if kk != "counters_avg_per_launch"})
                   for k, v in res.items()}, indent=1)[:2500])
