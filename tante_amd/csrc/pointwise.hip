@@ -719,29 +719,23 @@ __global__ __launch_bounds__(256) void format_input_kernel(const float* __restri
 }
 
 // torch.nan_to_num on a dense fp32 tensor (the formatter's pass over the reference frames, data/datamodule.py:187): 16 bytes per lane,
-// four vectors in flight -- the torch elementwise kernel ran this 46 MB pass at 1.7 TB/s (55 us per rollout)
+// four vectors in flight per lane (the torch elementwise kernel ran this pass at 55 us per rollout; a first version of this one with
+// 8 MiB between a lane's vectors was SLOWER, 68 us)
 __global__ __launch_bounds__(256) void nan_to_num_kernel(const float* __restrict__ x, float* __restrict__ y, long n4, long n) {
-  const long stride = (long)gridDim.x * 256;
-  long i = (long)blockIdx.x * 256 + threadIdx.x;
-  for (; i + 3 * stride < n4; i += 4 * stride) {
-    f32x4 v[4];
+  // a workgroup owns 4 consecutive KiB-rows of 256 float4 (16 KiB): four independent 16-byte loads per lane, all issued before the first use
+  const long base = (long)blockIdx.x * 1024 + threadIdx.x;
+  f32x4 v[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) v[k] = ((const f32x4*)x)[i + k * stride];
+  for (int k = 0; k < 4; ++k)
+    if (base + 256 * k < n4) v[k] = ((const f32x4*)x)[base + 256 * k];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+  for (int k = 0; k < 4; ++k)
+    if (base + 256 * k < n4) {
       f32x4 o;
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = nan_to_num_f(v[k][e]);
-      ((f32x4*)y)[i + k * stride] = o;
+      ((f32x4*)y)[base + 256 * k] = o;
     }
-  }
-  for (; i < n4; i += stride) {
-    const f32x4 v = ((const f32x4*)x)[i];
-    f32x4 o;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = nan_to_num_f(v[e]);
-    ((f32x4*)y)[i] = o;
-  }
   if (blockIdx.x == 0 && threadIdx.x < (int)(n - 4 * n4)) y[4 * n4 + threadIdx.x] = nan_to_num_f(x[4 * n4 + threadIdx.x]);
 }
 
@@ -1009,7 +1003,7 @@ extern "C" int tante_nan_to_num(const float* x, float* y, int64_t n, void* strea
   if (!x || !y || n <= 0) TANTE_FAIL(-1, "tante_nan_to_num: bad argument");
   if (((uintptr_t)x % 16) || ((uintptr_t)y % 16)) TANTE_FAIL(-2, "tante_nan_to_num: 16-byte aligned tensors expected");
   const long n4 = n / 4;
-  const long blocks = std::min<long>(2048, std::max<long>(1, (n4 + 1023) / 1024));
+  const long blocks = std::max<long>(1, (n4 + 1023) / 1024);
   hipLaunchKernelGGL(nan_to_num_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, y, n4, (long)n);
   TANTE_CHECK_LAUNCH();
   return 0;
