@@ -162,7 +162,14 @@ __global__ __launch_bounds__(64 * NW * G, 2) void block_fs_kernel(FsArgs A) {
 #ifndef FS_PF4
 #define FS_PF4 2
 #endif
-  constexpr int PF = NW == 8 ? FS_PF8 : FS_PF4;    // weight k-steps in flight
+  // weight k-steps in flight.  The register-heaviest instantiations (training forward at 4 token tiles, the element-masked any-L forms,
+  // the 8-tile 8-wave forms) spilled 20 - 290 bytes per lane at the full depth: they run one k-step shallower (16 RT fewer registers)
+#ifdef FS_NO_TIGHT      // (A/B: every instantiation at the full depth, as in round 2)
+  constexpr bool TIGHT = false;
+#else
+  constexpr bool TIGHT = (NW == 4 && NTT == 4 && (TRAIN || TPS == 0)) || (NW == 8 && NTT == 8);
+#endif
+  constexpr int PF = (NW == 8 ? FS_PF8 : FS_PF4) - (TIGHT ? 1 : 0);
   constexpr int IMG = 16 * NTT * FS_ROW;
   constexpr int LDS_G = 2 * IMG + 16 * NTT * NW * 8 + FS_BIAS_FLOATS * 4;      // bytes of LDS per group
   extern __shared__ __attribute__((aligned(16))) char smem_all[];
