@@ -492,7 +492,10 @@ __device__ __forceinline__ void axe_load_weights(const char* wst, int lane, int 
 
 // one phase over the LDS plane: lines of N = 16 MT positions with element stride LS floats; NG line groups GS floats apart.
 // GOUT: the updated lines go to global memory (position stride gls, group stride ggs floats) instead of back into the plane.
-template <int MT, int CT, int NWV, int NG, int LS, int GS, bool GOUT>
+// IL line groups are worked on at once, stage by stage (gather | pack | first contraction | GELU | pack | second contraction | update):
+// one group is a chain of dependent LDS reads, packs and 4 - 16 MFMAs that a wave sits out latency by latency (stamps: 3 k cycles per
+// group for ~100 instructions); two independent chains interleave.  IL = 2 is used by the 8-wave form (256 registers per lane).
+template <int MT, int CT, int NWV, int NG, int LS, int GS, bool GOUT, int IL = 1>
 __device__ __forceinline__ void axe_phase(float* plane, const AxeW<MT>& W, int wave, int l15, int kk, float* __restrict__ gout, long gls,
                                           long ggs) {
   constexpr int KB = AxeW<MT>::KB, NIT = CT == 32 ? NG : NG / 2, NE = 8 * KB;
@@ -509,56 +512,81 @@ __device__ __forceinline__ void axe_phase(float* plane, const AxeW<MT>& W, int w
         if (ks * 32 + 4 * e < 16 * MT) xv[ks * 8 + e] = *(const f32x2*)(base + (ks * 32 + 4 * e) * LS);
         else xv[ks * 8 + e] = f32x2{0.f, 0.f};
   };
-  f32x2 xa[NE], xn[NE];
-  if (wave < NIT) gather(wave, xa);
-  for (int it = wave; it < NIT; it += NWV) {
-    if (it + NWV < NIT) gather(it + NWV, xn);
-    f32x4 out[2][MT];
+  f32x2 xa[IL][NE], xn[IL][NE];
+#pragma unroll
+  for (int g = 0; g < IL; ++g)
+    if (wave + g * NWV < NIT) gather(wave + g * NWV, xa[g]);
+  for (int it0 = wave; it0 < NIT; it0 += IL * NWV) {
+#pragma unroll
+    for (int g = 0; g < IL; ++g)
+      if (it0 + (IL + g) * NWV < NIT) gather(it0 + (IL + g) * NWV, xn[g]);
+    f32x4 out[IL][2][MT];
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
-      u32x4 xb[KB];
+      u32x4 xb[IL][KB];
 #pragma unroll
-      for (int ks = 0; ks < KB; ++ks)
+      for (int g = 0; g < IL; ++g)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) xb[ks][q] = pack_bf16x2(xa[ks * 8 + 2 * q][a], xa[ks * 8 + 2 * q + 1][a]);
-      f32x4 d1[2 * KB];
+        for (int ks = 0; ks < KB; ++ks)
 #pragma unroll
-      for (int mt = 0; mt < 2 * KB; ++mt) d1[mt] = mt < MT ? W.b1[mt < MT ? mt : 0] : f32x4{0.f, 0.f, 0.f, 0.f};
+          for (int q = 0; q < 4; ++q) xb[g][ks][q] = pack_bf16x2(xa[g][ks * 8 + 2 * q][a], xa[g][ks * 8 + 2 * q + 1][a]);
+      f32x4 d1[IL][2 * KB];
+#pragma unroll
+      for (int g = 0; g < IL; ++g)
+#pragma unroll
+        for (int mt = 0; mt < 2 * KB; ++mt) d1[g][mt] = mt < MT ? W.b1[mt < MT ? mt : 0] : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int ks = 0; ks < KB; ++ks)
-          d1[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, W.a1[mt][ks]), __builtin_bit_cast(bf16x8, xb[ks]), d1[mt], 0, 0, 0);
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) d1[mt] = gelu_poly4<false>(d1[mt]);
-      u32x4 hb[KB];
+          for (int g = 0; g < IL; ++g)
+            d1[g][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, W.a1[mt][ks]), __builtin_bit_cast(bf16x8, xb[g][ks]), d1[g][mt], 0, 0, 0);
 #pragma unroll
-      for (int ks = 0; ks < KB; ++ks) {
-        const f32x4 lo = d1[2 * ks], hi = d1[2 * ks + 1];
-        hb[ks] = u32x4{pack_bf16x2(lo[0], lo[1]), pack_bf16x2(lo[2], lo[3]), pack_bf16x2(hi[0], hi[1]), pack_bf16x2(hi[2], hi[3])};
-      }
+      for (int g = 0; g < IL; ++g)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) d1[g][mt] = gelu_poly4<false>(d1[g][mt]);
+      u32x4 hb[IL][KB];
+#pragma unroll
+      for (int g = 0; g < IL; ++g)
+#pragma unroll
+        for (int ks = 0; ks < KB; ++ks) {
+          const f32x4 lo = d1[g][2 * ks], hi = d1[g][2 * ks + 1];
+          hb[g][ks] = u32x4{pack_bf16x2(lo[0], lo[1]), pack_bf16x2(lo[2], lo[3]), pack_bf16x2(hi[0], hi[1]), pack_bf16x2(hi[2], hi[3])};
+        }
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
-        out[a][mt] = W.b2[mt];
+#pragma unroll
+        for (int g = 0; g < IL; ++g) out[g][a][mt] = W.b2[mt];
 #pragma unroll
         for (int ks = 0; ks < KB; ++ks)
-          out[a][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, W.a2[mt][ks]), __builtin_bit_cast(bf16x8, hb[ks]), out[a][mt], 0, 0, 0);
+#pragma unroll
+          for (int g = 0; g < IL; ++g)
+            out[g][a][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, W.a2[mt][ks]), __builtin_bit_cast(bf16x8, hb[g][ks]), out[g][a][mt], 0, 0, 0);
       }
     }
-    float* rbase = plane + (GPI * it + gsel) * GS + cp + 4 * kk * LS;   // this lane's output rows: positions 16 mt + 4 kk + r
-    float* gbase = GOUT ? gout + (long)(GPI * it + gsel) * ggs + cp + 4 * kk * gls : nullptr;
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    for (int g = 0; g < IL; ++g) {
+      const int it = it0 + g * NWV;
+      if (it < NIT) {
+        float* rbase = plane + (GPI * it + gsel) * GS + cp + 4 * kk * LS;   // this lane's output rows: positions 16 mt + 4 kk + r
+        float* gbase = GOUT ? gout + (long)(GPI * it + gsel) * ggs + cp + 4 * kk * gls : nullptr;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        f32x2 v = *(const f32x2*)(rbase + (16 * mt + r) * LS);
-        v[0] += out[0][mt][r];
-        v[1] += out[1][mt][r];
-        if constexpr (GOUT) *(f32x2*)(gbase + (long)(16 * mt + r) * gls) = v;
-        else *(f32x2*)(rbase + (16 * mt + r) * LS) = v;      // these 32 lines belong to this wave alone
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            f32x2 v = *(const f32x2*)(rbase + (16 * mt + r) * LS);
+            v[0] += out[g][0][mt][r];
+            v[1] += out[g][1][mt][r];
+            if constexpr (GOUT) *(f32x2*)(gbase + (long)(16 * mt + r) * gls) = v;
+            else *(f32x2*)(rbase + (16 * mt + r) * LS) = v;      // these lines belong to this wave alone
+          }
       }
+    }
 #pragma unroll
-    for (int j = 0; j < NE; ++j) xa[j] = xn[j];
+    for (int g = 0; g < IL; ++g)
+#pragma unroll
+      for (int j = 0; j < NE; ++j) xa[g][j] = xn[g][j];
   }
 }
 
@@ -586,6 +614,7 @@ __global__ __launch_bounds__(NT) void axis_hw_exact_kernel(float* __restrict__ x
   // xin (training forward): read the planes from here instead of x (out of place: the input stays intact for the backward pass);
   // xmid: the planes after the H propagator, i.e. the W propagator's input, which its backward needs
   constexpr int NH = 16 * MTH, NW = 16 * MTW, RS = axe_rs(NW, CT), NWV = NT / 64;
+  constexpr int AXE_IL = (NT == 512 && CT == 32 && MTH <= 2 && MTW <= 2) ? 2 : 1;      // two line groups at once where 256 registers allow
   constexpr int TPI = 256 / CT, LPT = CT / 4;    // tokens per DMA instruction (1 KiB), lanes per token
   extern __shared__ __attribute__((aligned(16))) float plane[];  // [NH][RS], token (h, w) at h * RS + w * CT
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kk = lane >> 4, l15 = lane & 15;
@@ -635,7 +664,7 @@ __global__ __launch_bounds__(NT) void axis_hw_exact_kernel(float* __restrict__ x
   {
     AxeW<MTH> WH;
     axe_load_weights<MTH>(wstH, lane, kk, WH);
-    axe_phase<MTH, CT, NWV, NW, RS, CT, false>(plane, WH, wave, l15, kk, nullptr, 0, 0);
+    axe_phase<MTH, CT, NWV, NW, RS, CT, false, AXE_IL>(plane, WH, wave, l15, kk, nullptr, 0, 0);
   }
   AXE_STAMP(4);
   AxeW<MTW> WW;
@@ -649,7 +678,7 @@ __global__ __launch_bounds__(NT) void axis_hw_exact_kernel(float* __restrict__ x
       *(f32x4*)(gm + ((long)h * NW + j * TPI + lane / LPT) * C + (lane % LPT) * 4) = *(const f32x4*)(plane + h * RS + j * 256 + lane * 4);
     }
   }
-  axe_phase<MTW, CT, NWV, NH, CT, RS, true>(plane, WW, wave, l15, kk, gx, (long)C, (long)NW * C);
+  axe_phase<MTW, CT, NWV, NH, CT, RS, true, AXE_IL>(plane, WW, wave, l15, kk, gx, (long)C, (long)NW * C);
   AXE_STAMP(6);
 #ifdef TANTE_ABLATE
   if (stamps) {
