@@ -367,6 +367,25 @@ int tante_resize_bilinear_bwd(const void* dout, int d_dtype, int64_t n_img, int 
  * Rows: q (b, i) at (b*Lq + i)*ldq + h*D, k / v (b, j) at (b*Lk + j)*ldkv + h*D, o at (b*Lq + i)*ldo + h*D (elements). */
 int tante_cross_attention(const void* q, const void* k, const void* v, void* o, int dtype, int64_t n_batch, int n_head, int D, int Lq,
                           int Lk, int64_t ldq, int64_t ldkv, int64_t ldo, void* stream);
+/* CViT blocks at width 512 (8 heads x 64, mlp_ratio 1), bf16: everything behind the attention of a SelfAttnBlock / CrossAttnBlock
+ * (models/cvit.py:112-169) in one launch, 64 tokens per workgroup (cvit_fused.hip).
+ *   mode 0: x1 = out_proj(a) + resid; out (M, 512) fp32 = x1 + fc2(gelu(fc1(LN2(x1))))
+ *   mode 1: ... then the model's tail (cvit.py:459-466, Mlp with one layer, cvit.py:213-242): z = norm2(.), y = z + gelu(dense(z)),
+ *           out (M, out_dim <= 16) fp32 = output_layer(LN(y))
+ * a: (M, 512) bf16 attention output; resid: (resid_period, 512) fp32, token t adds row t % resid_period (the decoder's queries are the
+ * same coordinate embedding for every sample); M and resid_period multiples of 16 (64-token workgroups for long launches, 16-token
+ * ones for short ones: TANTE_CVIT_CHAIN_TOKENS overrides).  w: the matrices as bf16 operand fragments,
+ * 512 KiB each, out_proj | fc1 | fc2 [| dense], fragment (wave, k-step, row tile) at ((wave*16 + ks)*4 + j) KiB holding for lane
+ * (l15, kk) the 8 values W[64*wave + 16*j + l15][32*ks + 8*kk ..]; LN2's affine folded into fc1 (and its bias).  bias: (n_mat, 512).
+ * g2 / b2: norm2's affine.  wout: 16 fragments (wave, pair p), lane (row, kk) = W'[row][64*wave + 32*p + 4*kk + 0..3], then the same
+ * columns + 16 -- the Mlp's LayerNorm folded in, rows >= out_dim zero; bout: 16 floats.  tante_amd/cvit.py builds all of them. */
+int tante_cvit_chain512(const void* a, const float* resid, int64_t resid_period, const void* w, const float* bias, const float* g2,
+                        const float* b2, float eps_ln2, float eps_norm2, float eps_mlp, const void* wout, const float* bout, int out_dim,
+                        int64_t M, int mode, float* out, void* stream);
+/* The same with the query rows of sample b starting at row b * q_batch_rows (q_batch_rows = Lq: tante_cross_attention; 0: every sample
+ * attends with the SAME Lq queries -- the decoder's coordinate queries, cvit.py:452, whose projection is then computed once). */
+int tante_cross_attention_q(const void* q, const void* k, const void* v, void* o, int dtype, int64_t n_batch, int n_head, int D, int Lq,
+                            int Lk, int64_t ldq, int64_t ldkv, int64_t ldo, int64_t q_batch_rows, void* stream);
 /* Backward of tante_cross_attention.  o is the forward output; dq gets the query gradient in the layout of q; the key / value gradients
  * are ADDED (fp32 atomics) to dk / dv, rows (b, j) at (b*Lk + j)*ldg + h*D -- zero them first.  stats: n_batch*n_head*Lq*3 floats of
  * scratch (softmax max, 1 / sum, dO . O per query). */

@@ -126,6 +126,8 @@ SIGNATURES = {
     "tante_resize_bilinear_bwd": ([c_vp, c_i32, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_i64, c_i64, c_i64, c_i64, c_i32, c_i32, c_i64, c_i64,
                                    c_i64, c_i64, c_vp, c_vp], c_i32),
     "tante_cross_attention": ([c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_i32, c_i32, c_i32, c_i64, c_i64, c_i64, c_vp], c_i32),
+    "tante_cvit_chain512": ([c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_f32, c_vp, c_vp, c_i32, c_i64, c_i32, c_vp, c_vp], c_i32),
+    "tante_cross_attention_q": ([c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_i32, c_i32, c_i32, c_i64, c_i64, c_i64, c_i64, c_vp], c_i32),
     "tante_cross_attention_bwd": ([c_vp] * 9 + [c_i32, c_i64, c_i32, c_i32, c_i32, c_i32, c_i64, c_i64, c_i64, c_i64, c_vp], c_i32),
     "tante_layernorm_affine_bwd": ([c_vp, c_i32, c_vp, c_i32, c_vp, c_i64, c_i32, c_f32, c_vp, c_vp, c_vp, c_vp], c_i32),
     "tante_grid_embed_bwd": ([c_vp] * 5 + [c_i64, c_i32, c_i32, c_f32, c_vp, c_vp, c_vp, c_vp], c_i32),

@@ -53,6 +53,52 @@ __global__ void im2col_kernel(const void* __restrict__ x, int x_dtype, int nchw,
   }
 }
 
+// Channels-FIRST fp32 source, (c, kh, kw) columns, stride = kernel (non-overlapping P x P patches, any padding < P): the padded 4 x 4 and
+// 2 x 2 stages of the spectral encoder (enc_dec_fno.py:224-273 through RealConv2d).  The scalar kernel above walks the OUTPUT in order:
+// its reads hop 4 bytes at a time between planes 1 MB apart (2.1 TB/s over 400 MB: 189 us for the 512 x 512 x 32-channel stage, the
+// largest kernel of cfg5 once the spectral layers were fixed).  Here a workgroup owns TW patches of one output row: it reads the
+// C x P input segments of TW P (+ padding shift) contiguous floats -- coalesced, zero outside the image -- into LDS and writes TW
+// whole patch rows of K = C P P contiguous elements.  Row stride TW P + 1 floats: the (c, kh) segments a wave reads back at one kw sit
+// on different banks.
+template <int P, bool BF16OUT>
+__global__ __launch_bounds__(256) void im2col_nchw_tile_kernel(const float* __restrict__ x, int C, int H, int W, int pad, int Ho, int Wo, int TW,
+                                                               void* __restrict__ cols) {
+  extern __shared__ float tile[];                  // [C * P][TW * P + 1]
+  const int S = TW * P + 1, seg = TW * P;
+  const int tiles_w = (Wo + TW - 1) / TW;
+  const int tw = blockIdx.x % tiles_w, oh = (blockIdx.x / tiles_w) % Ho;
+  const long img = blockIdx.x / ((long)tiles_w * Ho);
+  const int wo0 = tw * TW, x0 = wo0 * P - pad, y0 = oh * P - pad;
+  for (int e = threadIdx.x; e < C * P * seg; e += 256) {
+    const int ckh = e / seg, j = e - ckh * seg, c = ckh / P, kh = ckh - c * P;
+    const int y = y0 + kh, xx = x0 + j;
+    tile[ckh * S + j] = (y >= 0 && y < H && xx >= 0 && xx < W) ? x[((img * C + c) * (long)H + y) * W + xx] : 0.0f;
+  }
+  __syncthreads();
+  const int K = C * P * P, nt = min(TW, Wo - wo0);
+  const long row0 = (img * Ho + oh) * (long)Wo + wo0;
+  for (int e = threadIdx.x; e < nt * C * P; e += 256) {      // one (patch, c, kh) = P consecutive columns per thread
+    const int t = e / (C * P), ckh = e - t * (C * P);
+    const float* src = tile + ckh * S + t * P;
+    const long dst = (row0 + t) * K + (long)ckh * P;
+    if constexpr (BF16OUT) {
+      if constexpr (P == 4) {
+        u32x2 u;
+        u[0] = pack_bf16x2(src[0], src[1]); u[1] = pack_bf16x2(src[2], src[3]);
+        *(u32x2*)((unsigned short*)cols + dst) = u;
+      } else if constexpr (P == 2) {
+        *(unsigned*)((unsigned short*)cols + dst) = pack_bf16x2(src[0], src[1]);
+      } else {
+#pragma unroll
+        for (int q = 0; q < P; ++q) ((__bf16*)cols)[dst + q] = (__bf16)src[q];
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < P; ++q) ((float*)cols)[dst + q] = src[q];
+    }
+  }
+}
+
 // channels-last source, (kh, kw, c) columns, one dtype on both sides and whole 16-byte pieces per channel run: a gather of 16-byte
 // pieces (the scalar kernel above moves 2 bytes per thread behind six integer divisions: 67 us for a 2 x 25 MB permutation)
 template <int EB>   // element bytes
@@ -271,14 +317,14 @@ __global__ __launch_bounds__(256) void conv1x1_add_kernel(const float* __restric
 template <int D>
 __global__ __launch_bounds__(256) void cross_attn_kernel(const void* __restrict__ q, const void* __restrict__ k, const void* __restrict__ v,
                                                          void* __restrict__ o, int dtype, int n_head, int Lq, int Lk, long ldq, long ldkv,
-                                                         long ldo, float scale) {
+                                                         long ldo, float scale, long qbr) {
   __shared__ float ks[64][D];
   __shared__ float vs[64][D];
   const int bh = blockIdx.x, b = bh / n_head, h = bh - b * n_head;
   const int i = blockIdx.y * 256 + threadIdx.x;
   const bool live = i < Lq;
   float qr[D], acc[D];
-  const long qoff = ((long)b * Lq + (live ? i : 0)) * ldq + (long)h * D;
+  const long qoff = ((long)b * qbr + (live ? i : 0)) * ldq + (long)h * D;
 #pragma unroll
   for (int d = 0; d < D; ++d) { qr[d] = ldx(q, dtype, qoff + d) * scale; acc[d] = 0.0f; }
   float m = -INFINITY, l = 0.0f;
@@ -332,8 +378,8 @@ __device__ __forceinline__ f32x4 xmfma(const u32x4& a, const u32x4& b, const f32
 constexpr int XD = 64;            // head dim
 constexpr int XQG = 2;            // 16-query groups a wave processes together (2: half the LDS reads per MFMA, but 50 more VGPRs)
 constexpr int XWAVES = 4;         // waves per workgroup (measured: XQG 1 with 6 waves = 3 waves/SIMD is 25 % slower than XQG 2 with 4)
-constexpr int XGPW = 8;           // iterations per wave
-constexpr int XQ_PER_WG = XWAVES * XGPW * 16 * XQG;
+constexpr int XGPW_MAX = 8;       // iterations per wave (32 queries each): 8 where the queries fill the chip anyway (K / V staged once per 1024 queries);
+                                  // fewer -- more, shorter workgroups -- for the encoder's few hundred queries per (sample, head)
 
 template <int OFF>
 __device__ __forceinline__ u32x2 x_tr_read_off(unsigned base) {   // base VGPR + 16-bit immediate offset
@@ -352,7 +398,8 @@ __device__ __forceinline__ int xv_swz(int row) { return ((row >> 1) & 3) << 1; }
 
 __global__ __launch_bounds__(XWAVES * 64, 2) void xattn_mfma_kernel(const unsigned short* __restrict__ q, const unsigned short* __restrict__ k,
                                                             const unsigned short* __restrict__ v, unsigned short* __restrict__ o, int n_head,
-                                                            int Lq, int Lk, int Sp, long ldq, long ldkv, long ldo, float scale_log2e) {
+                                                            int Lq, int Lk, int Sp, long ldq, long ldkv, long ldo, float scale_log2e, long qbr, int XGPW) {
+  const int XQ_PER_WG = XWAVES * XGPW * 16 * XQG;
   extern __shared__ __attribute__((aligned(16))) char xsm[];   // K image [Sp][8 chunks] (row reads), then V image [Sp][8 chunks] (transposed reads)
   char* ks = xsm;
   char* vs = xsm + (size_t)Sp * XD * 2;
@@ -392,7 +439,7 @@ __global__ __launch_bounds__(XWAVES * 64, 2) void xattn_mfma_kernel(const unsign
     for (int g = 0; g < XQG; ++g) {
       const int qi = q0n + g * 16 + l15;
       const bool lv = it < XGPW && qi < Lq;
-      const long qoff = ((long)b * Lq + (lv ? qi : 0)) * ldq + (long)h * XD;
+      const long qoff = ((long)b * qbr + (lv ? qi : 0)) * ldq + (long)h * XD;
 #pragma unroll
       for (int bb = 0; bb < 2; ++bb) dst[g][bb] = lv ? *(const u32x4*)(q + qoff + bb * 32 + kk * 8) : u32x4{0u, 0u, 0u, 0u};
     }
@@ -965,6 +1012,24 @@ extern "C" int tante_im2col(const void* x, int x_dtype, int nchw, int64_t n_img,
   if (Ho <= 0 || Wo <= 0) TANTE_FAIL(-1, "tante_im2col: empty output");
   const long total = (long)n_img * Ho * Wo * C * kh * kw;
   const int eb = x_dtype == TANTE_BF16 ? 2 : 4;
+  if (nchw && korder == 0 && x_dtype == TANTE_F32 && kh == kw && sh == kh && sw == kw && ph == pw && ph < kh && (kh == 2 || kh == 4) &&
+      tante_opt("TANTE_IM2COL_TILED", 1)) {
+    // tile width: the largest of 32, 16, 8 patches whose C x P segments fit 64 KB of LDS
+    int TW = 32;
+    while (TW > 4 && (size_t)C * kh * (TW * kh + 1) * 4 > 64 * 1024) TW /= 2;
+    const size_t lds = (size_t)C * kh * (TW * kh + 1) * 4;
+    if (lds <= 64 * 1024) {
+      const long blocks = (long)n_img * Ho * ((Wo + TW - 1) / TW);
+      const bool bf = cols_dtype == TANTE_BF16;
+      hipStream_t s_ = (hipStream_t)stream;
+      if (kh == 4 && bf) hipLaunchKernelGGL((im2col_nchw_tile_kernel<4, true>), dim3((unsigned)blocks), dim3(256), lds, s_, (const float*)x, C, H, W, ph, Ho, Wo, TW, cols);
+      else if (kh == 4) hipLaunchKernelGGL((im2col_nchw_tile_kernel<4, false>), dim3((unsigned)blocks), dim3(256), lds, s_, (const float*)x, C, H, W, ph, Ho, Wo, TW, cols);
+      else if (bf) hipLaunchKernelGGL((im2col_nchw_tile_kernel<2, true>), dim3((unsigned)blocks), dim3(256), lds, s_, (const float*)x, C, H, W, ph, Ho, Wo, TW, cols);
+      else hipLaunchKernelGGL((im2col_nchw_tile_kernel<2, false>), dim3((unsigned)blocks), dim3(256), lds, s_, (const float*)x, C, H, W, ph, Ho, Wo, TW, cols);
+      TANTE_CHECK_LAUNCH();
+      return 0;
+    }
+  }
   if (!nchw && korder == 1 && x_dtype == cols_dtype && C % (16 / eb) == 0 && (((uintptr_t)x | (uintptr_t)cols) & 15) == 0) {
     const long pieces = total / (16 / eb);
     if (eb == 2) hipLaunchKernelGGL(im2col_vec_kernel<2>, dim3(grid_for(pieces)), dim3(256), 0, (hipStream_t)stream, (const char*)x, (long)n_img, C, H, W,
@@ -1130,7 +1195,14 @@ extern "C" int tante_spectral_layer_bwd(const float* x, const float* dy, int64_t
 
 extern "C" int tante_cross_attention(const void* q, const void* k, const void* v, void* o, int dtype, int64_t n_batch, int n_head, int D, int Lq,
                                      int Lk, int64_t ldq, int64_t ldkv, int64_t ldo, void* stream) {
+  return tante_cross_attention_q(q, k, v, o, dtype, n_batch, n_head, D, Lq, Lk, ldq, ldkv, ldo, Lq, stream);
+}
+
+extern "C" int tante_cross_attention_q(const void* q, const void* k, const void* v, void* o, int dtype, int64_t n_batch, int n_head, int D, int Lq,
+                                       int Lk, int64_t ldq, int64_t ldkv, int64_t ldo, int64_t q_batch_rows, void* stream) {
   if (!q || !k || !v || !o || n_batch <= 0 || n_head <= 0 || Lq <= 0 || Lk <= 0) TANTE_FAIL(-1, "tante_cross_attention: bad argument");
+  if (q_batch_rows != 0 && q_batch_rows < Lq) TANTE_FAIL(-1, "tante_cross_attention_q: q_batch_rows = %lld must be 0 (shared queries) or >= Lq", (long long)q_batch_rows);
+  const long qbr = (long)q_batch_rows;
   if ((Lq + 255) / 256 > 65535 || n_batch * n_head > 2147483647L) TANTE_FAIL(-2, "tante_cross_attention: grid too large");
   const float scale = 1.0f / sqrtf((float)D);
   hipStream_t s = (hipStream_t)stream;
@@ -1144,14 +1216,21 @@ extern "C" int tante_cross_attention(const void* q, const void* k, const void* v
       hipFuncSetAttribute((const void*)xattn_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       attr = lds;
     }
+    // iterations per wave: as many as keep >= 512 workgroups in the launch
+    int gpw = XGPW_MAX;
+    while (gpw > 1 && n_batch * n_head * (long)((Lq + XWAVES * gpw * 16 * XQG - 1) / (XWAVES * gpw * 16 * XQG)) < 512) gpw >>= 1;
+    gpw = tante_opt("TANTE_XATTN_GPW", gpw);
+    if (gpw < 1 || gpw > 64) TANTE_FAIL(-1, "tante_cross_attention: TANTE_XATTN_GPW = %d out of range", gpw);
+    const int XQ_PER_WG = XWAVES * gpw * 16 * XQG;
+    if ((Lq + XQ_PER_WG - 1) / XQ_PER_WG > 65535) TANTE_FAIL(-2, "tante_cross_attention: grid too large");
     const dim3 mgrid((unsigned)(n_batch * n_head), (unsigned)((Lq + XQ_PER_WG - 1) / XQ_PER_WG));
     hipLaunchKernelGGL(xattn_mfma_kernel, mgrid, dim3(XWAVES * 64), lds, s, (const unsigned short*)q, (const unsigned short*)k, (const unsigned short*)v,
-                       (unsigned short*)o, n_head, Lq, Lk, Sp, (long)ldq, (long)ldkv, (long)ldo, scale * 1.44269504088896340736f);
+                       (unsigned short*)o, n_head, Lq, Lk, Sp, (long)ldq, (long)ldkv, (long)ldo, scale * 1.44269504088896340736f, qbr, gpw);
     TANTE_CHECK_LAUNCH();
     return 0;
   }
   const dim3 grid((unsigned)(n_batch * n_head), (unsigned)((Lq + 255) / 256));
-#define TANTE_XA(DD) hipLaunchKernelGGL(cross_attn_kernel<DD>, grid, dim3(256), 0, s, q, k, v, o, dtype, n_head, Lq, Lk, (long)ldq, (long)ldkv, (long)ldo, scale)
+#define TANTE_XA(DD) hipLaunchKernelGGL(cross_attn_kernel<DD>, grid, dim3(256), 0, s, q, k, v, o, dtype, n_head, Lq, Lk, (long)ldq, (long)ldkv, (long)ldo, scale, qbr)
   switch (D) {
     case 4: TANTE_XA(4); break;
     case 8: TANTE_XA(8); break;

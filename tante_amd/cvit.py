@@ -71,10 +71,48 @@ class _AttnBlock(nn.Module):
                 fc2=S.pack_linear_chunks(m.fc2.weight.detach(), m.fc2.bias, compute))
         return self._cache.get(compute, params, build)
 
-    def _tail(self, attn_o: torch.Tensor, resid: torch.Tensor, pk, compute: int) -> torch.Tensor:
-        """x = out_proj(attn) + resid;  return x + fc2(gelu(fc1(LN2(x))))."""
+    def _chain_ok(self, compute: int, M: int, resid_rows: int) -> bool:
+        """The one-launch tail (cvit_fused.hip): bf16, width 512, mlp_ratio 1, whole 16-token tiles."""
+        return (compute == L.BF16 and self.emb_dim == 512 and self.mlp.fc1.out_features == 512 and M % 16 == 0 and resid_rows % 16 == 0
+                and L.get_option("TANTE_CVIT_FUSED", 1) != 0)
+
+    def _chain_packed(self, extra=None):
+        """out_proj | fc1 (LN2 folded) | fc2 [| the Mlp's dense layer] as one fragment stream + biases; extra = (norm2, Mlp) for mode 1."""
+        a, m, n2 = self.attn, self.mlp, self.layer_norm2
+        params = [n2.weight, n2.bias, a.out_proj.weight, a.out_proj.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias]
+        if extra is not None:
+            norm2, mlp = extra
+            ln = mlp.layer_norms[0]
+            params += [norm2.weight, norm2.bias, mlp.dense_layers[0].weight, mlp.dense_layers[0].bias, ln.weight, ln.bias, mlp.output_layer.weight,
+                       mlp.output_layer.bias]
+
+        def build():
+            mats = [K.pack_chain_matrix(a.out_proj.weight, a.out_proj.bias), K.pack_chain_matrix(m.fc1.weight, m.fc1.bias, n2.weight, n2.bias),
+                    K.pack_chain_matrix(m.fc2.weight, m.fc2.bias)]
+            tail = None
+            if extra is not None:
+                mats.append(K.pack_chain_matrix(mlp.dense_layers[0].weight, mlp.dense_layers[0].bias))
+                wout, bout = K.pack_chain_output(mlp.output_layer.weight, mlp.output_layer.bias, ln.weight, ln.bias)
+                tail = (norm2.weight.detach().float().contiguous(), norm2.bias.detach().float().contiguous(), float(norm2.eps), float(ln.eps), wout, bout,
+                        mlp.output_layer.out_features)
+            return torch.cat([f for f, _ in mats]), torch.cat([b for _, b in mats]), tail
+        return self._cache.get(("chain", extra is not None), params, build)
+
+    def _tail(self, attn_o: torch.Tensor, resid: torch.Tensor, pk, compute: int, M: int = None, model_tail=None) -> torch.Tensor:
+        """x = out_proj(attn) + resid;  return x + fc2(gelu(fc1(LN2(x)))).  resid may hold fewer rows than attn_o (row t % rows: the decoder's
+        shared queries).  model_tail = (norm2, Mlp): continue through norm2 -> Mlp -> output layer in the same launch, -> (M, out_dim)."""
         adt = K.act_torch_dtype(compute)
         M = attn_o.shape[0]
+        if self._chain_ok(compute, M, resid.shape[0]) and (model_tail is None or _model_tail_ok(model_tail)):
+            w, bias, tail = self._chain_packed(model_tail)
+            out = torch.empty(M, self.emb_dim if tail is None else tail[6], dtype=torch.float32, device=attn_o.device)
+            return K.cvit_chain512(attn_o, resid, w, bias, float(self.eps), M, out, tail)
+        if resid.shape[0] != M:
+            resid = resid.unsqueeze(0).expand(M // resid.shape[0], -1, -1).reshape(M, self.emb_dim).contiguous()
+        if model_tail is not None:
+            norm2, mlp = model_tail
+            x = self._tail(attn_o, resid, pk, compute)
+            return mlp.run(K.layernorm_affine(x, norm2.weight, norm2.bias, norm2.eps), compute)
         x = torch.empty(M, self.emb_dim, dtype=torch.float32, device=attn_o.device)
         K.linear(attn_o, pk["out"], x, M=M, residual=resid)
         h = torch.empty(M, pk["fc1_ln2"].N, dtype=adt, device=x.device)
@@ -83,6 +121,11 @@ class _AttnBlock(nn.Module):
             y = torch.empty_like(x)
             return K.linear(h, pk["fc2"][0], y, M=M, residual=x)
         return S.linear_chunks(h, pk["fc2"], torch.float32) + x    # hidden > 512: chunked accumulate, then the residual add
+
+
+def _model_tail_ok(model_tail) -> bool:
+    norm2, mlp = model_tail
+    return mlp.num_layers == 1 and mlp.output_layer.out_features <= 16 and mlp.dense_layers[0].in_features == 512 and mlp.dense_layers[0].out_features == 512
 
 
 class SelfAttnBlock(_AttnBlock):
@@ -100,18 +143,21 @@ class SelfAttnBlock(_AttnBlock):
 
 
 class CrossAttnBlock(_AttnBlock):
-    def run(self, q_in: torch.Tensor, kv_in: torch.Tensor, nb: int, Lq: int, Lk: int, compute: int) -> torch.Tensor:
-        """q_in (nb * Lq, C), kv_in (nb * Lk, C) fp32 -> block(q_in, kv_in)   (cvit.py:158-169)."""
+    def run(self, q_in: torch.Tensor, kv_in: torch.Tensor, nb: int, Lq: int, Lk: int, compute: int, model_tail=None) -> torch.Tensor:
+        """q_in (nb * Lq, C) -- or (Lq, C): the SAME queries for every sample, projected once -- and kv_in (nb * Lk, C) fp32
+        -> block(q_in, kv_in)   (cvit.py:158-169)."""
         pk = self._packed(compute)
         adt = K.act_torch_dtype(compute)
         C_, nh = self.emb_dim, self.num_heads
-        q = torch.empty(nb * Lq, C_, dtype=adt, device=q_in.device)
-        K.linear(q_in, pk["q_ln1"], q, M=nb * Lq, ln=True, ln_eps=self.eps)
+        shared = q_in.shape[0] == Lq and nb > 1
+        Mq = q_in.shape[0]
+        q = torch.empty(Mq, C_, dtype=adt, device=q_in.device)
+        K.linear(q_in, pk["q_ln1"], q, M=Mq, ln=True, ln_eps=self.eps)
         kv = torch.empty(nb * Lk, 2 * C_, dtype=adt, device=q_in.device)
         K.linear(kv_in, pk["kv_ln2"], kv, M=nb * Lk, ln=True, ln_eps=self.eps)
         o = torch.empty(nb * Lq, C_, dtype=adt, device=q_in.device)
-        K.cross_attention(q, kv, kv[:, C_:], o, nb, nh, C_ // nh, Lq, Lk, C_, 2 * C_, C_)
-        return self._tail(o, q_in, pk, compute)
+        K.cross_attention(q, kv, kv[:, C_:], o, nb, nh, C_ // nh, Lq, Lk, C_, 2 * C_, C_, shared_q=shared)
+        return self._tail(o, q_in, pk, compute, model_tail=model_tail)
 
 
 class TimeAggregation(nn.Module):
@@ -314,18 +360,18 @@ class CViT(nn.Module):
             q1 = self._embed_coords(input_coords.detach().to(x.device, torch.float32).contiguous(), compute)
         n = q1.shape[0]
         d = self.dec_emb_dim
-        q = q1.unsqueeze(0).expand(b, n, d).reshape(b * n, d).contiguous()                     # 'n d -> b n d'
+        q = q1                                                     # 'n d -> b n d' is never materialised: the blocks take the shared rows
         y, s = self.Encoder.run(x, compute)                                                    # (b * s, emb)
         e2d = self._cache.get((compute, "e2d"), [self.norm1.weight, self.norm1.bias, self.E2D.weight, self.E2D.bias],
                               lambda: K.pack_weight(self.E2D.weight, self.E2D.bias, compute, gamma=self.norm1.weight, beta=self.norm1.bias))
         kv = torch.empty(b * s, d, dtype=torch.float32, device=x.device)
         K.linear(y, e2d, kv, M=b * s, ln=True, ln_eps=self.norm1.eps)                          # E2D(norm1(x))
         Lk = s
-        for blk in self.CrossAttnBlocks:                 # queries stay the coordinate embedding; the output becomes the next keys/values
-            kv = blk.run(q, kv, b, n, Lk, compute)
+        for i, blk in enumerate(self.CrossAttnBlocks):   # queries stay the coordinate embedding; the output becomes the next keys/values
+            last = i == len(self.CrossAttnBlocks) - 1     # the last block carries norm2 -> Mlp -> output layer (one launch where it fuses)
+            kv = blk.run(q, kv, b, n, Lk, compute, model_tail=(self.norm2, self.mlp) if last else None)
             Lk = n
-        z = K.layernorm_affine(kv, self.norm2.weight, self.norm2.bias, self.norm2.eps)
-        o = self.mlp.run(z, compute).view(b, n, self.out_steps, c)
+        o = kv.view(b, n, self.out_steps, c)
         if input_coords is None:
             return o.view(b, h, w, self.out_steps, c).permute(0, 3, 4, 1, 2)                   # 'b (h w) (t d) -> b t d h w'
         return o.permute(0, 2, 1, 3)                                                           # 'b n (t d) -> b t n d'

@@ -551,15 +551,62 @@ def spectral_layer(x: torch.Tensor, w_re: torch.Tensor, w_im: torch.Tensor, mode
 
 
 def cross_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, o: torch.Tensor, n_batch: int, n_head: int, D: int, Lq: int, Lk: int,
-                    ldq: int, ldkv: int, ldo: int):
-    """k and v may be views into one packed (…, 2C) buffer: rows are addressed by data_ptr + strides."""
+                    ldq: int, ldkv: int, ldo: int, shared_q: bool = False):
+    """k and v may be views into one packed (…, 2C) buffer: rows are addressed by data_ptr + strides.  shared_q: q holds Lq rows that every
+    sample attends with (the decoder's coordinate queries)."""
     if not (q.is_cuda and k.is_cuda and v.is_cuda and o.is_cuda):
         raise RuntimeError("tante_amd kernels need CUDA/HIP tensors (no CPU fallback)")
     if not (q.dtype == k.dtype == v.dtype == o.dtype):
         raise RuntimeError("q, k, v, o must share a dtype")
-    L.check(L.lib().tante_cross_attention(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), _DT[q.dtype], n_batch, n_head, D, Lq, Lk, ldq,
-                                          ldkv, ldo, _stream()), "tante_cross_attention")
+    L.check(L.lib().tante_cross_attention_q(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), _DT[q.dtype], n_batch, n_head, D, Lq, Lk, ldq,
+                                            ldkv, ldo, 0 if shared_q else Lq, _stream()), "tante_cross_attention")
     return o
+
+
+# ---- CViT blocks at width 512 in one launch (cvit_fused.hip) ------------------------------------------------------------------------
+def pack_chain_matrix(w: torch.Tensor, b: torch.Tensor, gamma: torch.Tensor = None, beta: torch.Tensor = None):
+    """(512, 512) Linear weight (+ a LayerNorm affine folded into its input side) -> (bf16 operand-fragment stream, fp32 bias)
+    in the order tante_cvit_chain512 reads: [wave 8][k-step 16][row tile 4][kk 4][l15 16][8 values]."""
+    w = w.detach().float()
+    b = b.detach().float()
+    if gamma is not None:
+        b = b + w @ beta.detach().float()
+        w = w * gamma.detach().float()[None, :]
+    f = w.to(torch.bfloat16).view(8, 4, 16, 16, 4, 8).permute(0, 3, 1, 4, 2, 5).contiguous()      # [w][j][l15][ks][kk][e] -> [w][ks][j][kk][l15][e]
+    return f.view(-1), b.contiguous()
+
+
+def pack_chain_output(w: torch.Tensor, b: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor):
+    """(out_dim <= 16, 512) output layer with the preceding LayerNorm's affine folded in -> 16 KiB of fragments in the k order of the
+    accumulator tiles that feed it (lane (row, kk) of fragment (wave, pair): columns 64 wave + 32 pair + 4 kk + 0..3, then the same + 16)."""
+    w = w.detach().float()
+    b = b.detach().float() + w @ beta.detach().float()
+    w = w * gamma.detach().float()[None, :]
+    n = w.shape[0]
+    wp = torch.zeros(16, 512, dtype=torch.float32, device=w.device)
+    wp[:n] = w
+    bp = torch.zeros(16, dtype=torch.float32, device=w.device)
+    bp[:n] = b
+    f = wp.to(torch.bfloat16).view(16, 8, 2, 2, 4, 4).permute(1, 2, 4, 0, 3, 5).contiguous()        # [row][w][p][h][kk][e] -> [w][p][kk][row][h][e]
+    return f.view(-1), bp
+
+
+def cvit_chain512(a: torch.Tensor, resid: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, eps_ln2: float, M: int, out: torch.Tensor,
+                  tail=None) -> torch.Tensor:
+    """tante_cvit_chain512: a (M, 512) bf16, resid (period, 512) fp32 (row t % period), w / bias the packed matrices.  tail = None: mode 0,
+    out (M, 512); tail = (g2, b2, eps_norm2, eps_mlp, wout, bout, out_dim): mode 1, out (M, out_dim)."""
+    for t in (a, resid, w, bias, out):
+        _dev(t)
+    if a.dtype != torch.bfloat16 or resid.dtype != torch.float32 or out.dtype != torch.float32 or not (a.is_contiguous() and resid.is_contiguous() and out.is_contiguous()):
+        raise RuntimeError("cvit_chain512: a bf16, resid / out fp32, all contiguous")
+    if tail is None:
+        L.check(L.lib().tante_cvit_chain512(_p(a), _p(resid), resid.shape[0], _p(w), _p(bias), None, None, eps_ln2, 0.0, 0.0, None, None, 0, M, 0,
+                                            _p(out), _stream()), "tante_cvit_chain512")
+    else:
+        g2, b2, eps_n2, eps_mlp, wout, bout, out_dim = tail
+        L.check(L.lib().tante_cvit_chain512(_p(a), _p(resid), resid.shape[0], _p(w), _p(bias), _p(g2), _p(b2), eps_ln2, eps_n2, eps_mlp, _p(wout),
+                                            _p(bout), out_dim, M, 1, _p(out), _stream()), "tante_cvit_chain512")
+    return out
 
 
 def grid_embed(coords: torch.Tensor, grid: torch.Tensor, latents: torch.Tensor, eps: float) -> torch.Tensor:

@@ -287,3 +287,112 @@ def test_multi_order_head_launch_equals_per_order_launches(dev, order, axes):
     cfg = O.TanteCfg(4, 5, (64, 96), taylor_order=order, attn_axes=axes, n_head=8, embed_dim=256, patch_scale=8, frame_interval=0.5)
     ref = O.tante_forward({k: v.detach().cpu() for k, v in m.state_dict().items()}, cfg, x[:1])
     close(outs[0][:1], ref, "bf16", f"multi-order head, order {order}, vs oracle")
+
+
+@pytest.mark.parametrize("n,C,H,W,P,pad,dt", [(2, 32, 64, 96, 4, 1, "bf16"), (1, 128, 32, 32, 2, 0, "bf16"), (3, 5, 20, 36, 4, 1, "fp32"), (1, 8, 512, 512, 4, 1, "bf16"),
+                                              (2, 7, 18, 10, 2, 1, "fp32"), (1, 300, 16, 16, 4, 3, "bf16")])
+def test_im2col_tiled_nchw_equals_scalar_kernel(dev, n, C, H, W, P, pad, dt):
+    """The tiled channels-first im2col (stride = kernel, padded: the spectral encoder's RealConv2d stages, enc_dec_cnn.py:49-110 as used by
+    enc_dec_fno.py:224-273) against the scalar kernel it replaces (TANTE_IM2COL_TILED = 0): the same patch matrix, bit for bit -- incl. a
+    width that is not a multiple of the tile, many channels (narrower tiles) and zero padding on every side."""
+    from tante_amd import _lib as L, kernels as Kk
+    g = torch.Generator().manual_seed(C + H)
+    x = torch.randn(n, C, H, W, generator=g).to(dev)
+    odt = torch.bfloat16 if dt == "bf16" else torch.float32
+    outs = []
+    try:
+        for tiled in (1, 0):
+            L.set_option("TANTE_IM2COL_TILED", tiled)
+            outs.append(Kk.im2col(x, True, n, C, H, W, P, P, P, P, pad, pad, 0, odt))
+    finally:
+        L.set_option("TANTE_IM2COL_TILED", 1)
+    torch.cuda.synchronize()
+    assert outs[0].shape == outs[1].shape and torch.equal(outs[0], outs[1])
+    ref = torch.nn.functional.unfold(x.float().cpu(), kernel_size=P, stride=P, padding=pad).transpose(1, 2).reshape(outs[0].shape)
+    assert torch.equal(outs[0].float().cpu(), ref.to(odt).float())
+
+
+# ---- CViT at width 512: the one-launch block tail / model tail (cvit_fused.hip) --------------------------------------------------------
+def _chain_reference(a, resid, blk, tail=None):
+    """float64 restatement of what tante_cvit_chain512 fuses (models/cvit.py:133-139 behind the attention; 459-466 + Mlp 213-242)."""
+    import torch.nn.functional as F
+    d = torch.float64
+    A, R = a.to(d), resid.to(d)
+    M = A.shape[0]
+    R = R.repeat(M // R.shape[0], 1)
+    p = {k: v.detach().to(d).cpu() for k, v in blk.state_dict().items()}
+    x1 = A @ p["attn.out_proj.weight"].T + p["attn.out_proj.bias"] + R
+    h = F.gelu(F.layer_norm(x1, (512,), p["layer_norm2.weight"], p["layer_norm2.bias"], blk.eps) @ p["mlp.fc1.weight"].T + p["mlp.fc1.bias"])
+    x2 = x1 + h @ p["mlp.fc2.weight"].T + p["mlp.fc2.bias"]
+    if tail is None:
+        return x2
+    norm2, mlp = tail
+    z = F.layer_norm(x2, (512,), norm2.weight.detach().to(d).cpu(), norm2.bias.detach().to(d).cpu(), norm2.eps)
+    q = {k: v.detach().to(d).cpu() for k, v in mlp.state_dict().items()}
+    y = z + F.gelu(z @ q["dense_layers.0.weight"].T + q["dense_layers.0.bias"])
+    y = F.layer_norm(y, (512,), q["layer_norms.0.weight"], q["layer_norms.0.bias"], mlp.layer_norms[0].eps)
+    return y @ q["output_layer.weight"].T + q["output_layer.bias"]
+
+
+@pytest.mark.parametrize("M,period,out_dim,tokens", [(64, 64, 0, 64), (320, 64, 0, 64), (256, 256, 16, 64), (384, 128, 16, 64), (128, 128, 7, 64),
+                                                     (48, 48, 0, 16), (256, 256, 0, 16), (80, 16, 16, 16), (1024, 256, 5, 16), (33280, 33280, 16, 0)])
+def test_cvit_chain512_against_float64(dev, M, period, out_dim, tokens):
+    """tante_cvit_chain512 (mode 0: out_dim = 0; mode 1 otherwise) against a float64 restatement fed the same bf16 attention rows: random
+    (non-trivial) LayerNorm affines everywhere, residual rows shared with a period, an output layer narrower than the 16-row tile; both
+    workgroup shapes (64 / 16 tokens, forced through TANTE_CVIT_CHAIN_TOKENS; 0 = the launcher's own choice)."""
+    from tante_amd import cvit as CV, kernels as Kk, _lib as L
+    torch.manual_seed(M + out_dim)
+    blk = CV.SelfAttnBlock(8, 512, 1).to(dev)
+    norm2 = torch.nn.LayerNorm(512).to(dev)
+    mlp = CV.Mlp(512, 1, 512, max(out_dim, 1)).to(dev)
+    with torch.no_grad():
+        for ln in (blk.layer_norm2, norm2, mlp.layer_norms[0]):
+            ln.weight.copy_(1.0 + 0.3 * torch.randn(512))
+            ln.bias.copy_(0.2 * torch.randn(512))
+    a = torch.randn(M, 512).to(dev, torch.bfloat16)
+    resid = (torch.randn(period, 512) * 1.5 + 0.3).to(dev)
+    tail = (norm2, mlp) if out_dim else None
+    with torch.no_grad():
+        assert blk._chain_ok(L.BF16, M, period)
+        try:
+            L.set_option("TANTE_CVIT_CHAIN_TOKENS", tokens)
+            got = blk._tail(a, resid, None, L.BF16, model_tail=tail)
+        finally:
+            L.set_option("TANTE_CVIT_CHAIN_TOKENS", 0)
+    ref = _chain_reference(a.float().cpu(), resid.cpu(), blk, tail)
+    assert got.shape == ref.shape
+    close(got, ref.float(), "bf16", f"chain512 M={M} out_dim={out_dim}")
+
+
+def test_cvit_width512_fused_against_oracle_and_unfused(dev):
+    """A cfg4-width CViT (emb 512, 8 x 64 heads, depth 2, 64 x 64 fields, 16 x 16 latent grid) at B = 4: (a) bf16 with the fused tails and
+    the once-projected shared queries against the ORACLE (cvit.py:427-466 restated) at the bf16 bar; (b) the same with
+    TANTE_CVIT_FUSED = 0 (per-op launches); (c) query-point mode (777 points: not a multiple of 64, so the decoder takes the per-op
+    route) against the full grid at those pixels."""
+    import tante_amd
+    from tante_amd import _lib as L
+    from oracle import cvit_oracle as OC
+    torch.manual_seed(12)
+    kw = dict(out_steps=4, patch_size=(1, 16, 16), grid_size=(16, 16), latent_dim=512, emb_dim=512, depth=2, num_heads=8, dec_emb_dim=512,
+              dec_num_heads=8, dec_depth=1, num_mlp_layers=1, mlp_ratio=1, eps=300.0)
+    m = tante_amd.CViT(4, tante_amd.TanteMetadata(n_fields=4, spatial_resolution=(64, 64)), **kw).to(dev).eval().set_compute("bf16")
+    with torch.no_grad():
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.LayerNorm):
+                mod.weight.add_(0.2 * torch.randn_like(mod.weight))
+                mod.bias.add_(0.1 * torch.randn_like(mod.bias))
+    xs = torch.randn(4, 4, 4, 64, 64)
+    w = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    ref = OC.cvit_forward(w, OC.CvitCfg(4, 4, (64, 64), **kw), xs)
+    with torch.no_grad():
+        y = m(xs.to(dev))
+        close(y, ref, "bf16", "width-512 CViT, fused tails")
+        try:
+            L.set_option("TANTE_CVIT_FUSED", 0)
+            y0 = m(xs.to(dev))
+        finally:
+            L.set_option("TANTE_CVIT_FUSED", 1)
+        close(y0, ref, "bf16", "width-512 CViT, per-op launches")
+        idx = torch.randint(0, 64 * 64, (777,), device=dev)
+        yq = m(xs.to(dev), tante_amd.cvit.generate_coords(64, 64, dev)[idx])
+    close(yq, y.permute(0, 1, 3, 4, 2).reshape(4, 4, 64 * 64, -1)[:, :, idx], "bf16", "query points vs full grid")

@@ -50,16 +50,25 @@ def main():
     ref = run(full).clone()
     timeit(lambda: run(full), "eager, one stream")
 
-    def multi_stream(n):
+    # calibrate torch.cuda._sleep (spin kernel, one workgroup): cycles per microsecond
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); torch.cuda._sleep(2_000_000); e1.record(); torch.cuda.synchronize()
+    cyc_per_us = 2_000_000 / (e0.elapsed_time(e1) * 1e3)
+    print(f"_sleep: {cyc_per_us:.1f} cycles per us", flush=True)
+
+    def multi_stream(n, stagger_us=0.0):
         ps = parts(n)
         streams = [torch.cuda.Stream() for _ in range(n)]
 
         def fn():
             cur = torch.cuda.current_stream()
             outs = []
-            for s, p in zip(streams, ps):
+            for i, (s, p) in enumerate(zip(streams, ps)):
                 s.wait_stream(cur)
                 with torch.cuda.stream(s):
+                    if stagger_us and i:
+                        torch.cuda._sleep(int(stagger_us * i * cyc_per_us))
                     outs.append(run(p))
             for s in streams:
                 cur.wait_stream(s)
@@ -89,13 +98,13 @@ def main():
         timeit(g.replay, "captured graph, one branch")
     except Exception as e:      # noqa: BLE001
         print("capture failed:", repr(e))
-    for n in (2, 4):
+    for n, st in ((2, 0), (2, 10), (2, 18), (2, 27), (2, 60), (4, 0), (4, 9), (4, 20)):
         try:
-            g, outs = captured(multi_stream(n))
+            g, outs = captured(multi_stream(n, st))
             g.replay()
             torch.cuda.synchronize()
             print("   graph max |diff|:", float((torch.cat(outs, 0) - ref).abs().max()))
-            timeit(g.replay, f"captured graph, {n} branches x B/{n}")
+            timeit(g.replay, f"captured graph, {n} branches x B/{n}, stagger {st} us")
         except Exception as e:      # noqa: BLE001
             print(f"capture ({n} branches) failed:", repr(e))
 

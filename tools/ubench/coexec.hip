@@ -32,6 +32,24 @@ __device__ __forceinline__ float run_role(int iters, float seed) {
     } else if constexpr (ROLE == 4) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) asm volatile("v_exp_f32 %0, %0" : "+v"(v[i]));
+    } else if constexpr (ROLE >= 6 && ROLE <= 9) {     // 1 MFMA + (ROLE - 5) independent v_fma (6: 1, 7: 2 ... ) -- NV = ROLE - 5 + (ROLE == 9 ? 1 : 0)
+      constexpr int NV = ROLE == 6 ? 1 : ROLE == 7 ? 3 : ROLE == 8 ? 4 : 6;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[i], 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < NV; ++q) asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(v[(i * NV + q) & 15]) : "v"(seed));
+      }
+    } else if constexpr (ROLE == 10) {                 // one dependent v_fma chain
+#pragma unroll
+      for (int i = 0; i < 16; ++i) asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(v[0]) : "v"(seed));
+    } else if constexpr (ROLE == 11) {                 // 1 MFMA + 1 ds_read_b128-free pk_fma + 2 fma
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[i], 0, 0, 0);
+        asm volatile("v_pk_fma_f32 %0, %0, %1, %0" : "+v"(p[i]) : "v"(p[(i + 1) & 7]));
+        asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(v[2 * i]) : "v"(seed));
+      }
     } else if constexpr (ROLE == 5) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
@@ -92,5 +110,19 @@ int main() {
   go<1, 4>("mfma | v_exp", 8, 16);
   go<5, 0>("mixed(1 mfma + 2 fma) | idle", 24, 0);
   go<5, 5>("mixed | mixed", 24, 24);
+  go<10, 0>("dependent v_fma chain | idle", 16, 0);
+  go<10, 10>("dep chain | dep chain", 16, 16);
+  go<1, 10>("mfma | dep chain", 8, 16);
+  go<6, 0>("1 mfma + 1 fma | idle (per group)", 8, 0);
+  go<7, 0>("1 mfma + 3 fma | idle (per group)", 8, 0);
+  go<8, 0>("1 mfma + 4 fma | idle (per group)", 8, 0);
+  go<9, 0>("1 mfma + 6 fma | idle (per group)", 8, 0);
+  go<6, 6>("1 mfma + 1 fma | same (per group)", 8, 8);
+  go<7, 7>("1 mfma + 3 fma | same (per group)", 8, 8);
+  go<8, 8>("1 mfma + 4 fma | same (per group)", 8, 8);
+  go<9, 9>("1 mfma + 6 fma | same (per group)", 8, 8);
+  go<11, 0>("1 mfma + pk_fma + fma | idle (per group)", 8, 0);
+  go<11, 11>("1 mfma + pk_fma + fma | same (per group)", 8, 8);
+  go<2, 7>("v_fma | 1 mfma + 3 fma", 16, 8);
   return 0;
 }
