@@ -61,41 +61,51 @@ __global__ void im2col_kernel(const void* __restrict__ x, int x_dtype, int nchw,
 // whole patch rows of K = C P P contiguous elements.  Row stride TW P + 1 floats: the (c, kh) segments a wave reads back at one kw sit
 // on different banks.
 template <int P, bool BF16OUT>
-__global__ __launch_bounds__(256) void im2col_nchw_tile_kernel(const float* __restrict__ x, int C, int H, int W, int pad, int Ho, int Wo, int TW,
+__global__ __launch_bounds__(256) void im2col_nchw_tile_kernel(const float* __restrict__ x, int C, int H, int W, int pad, int Ho, int Wo, int CC,
                                                                void* __restrict__ cols) {
-  extern __shared__ float tile[];                  // [C * P][TW * P + 1]
-  const int S = TW * P + 1, seg = TW * P;
+  constexpr int SEG = 64, TW = SEG / P, S = SEG + 1;   // a tile = TW patches = 64 input columns; LDS rows padded to 65 floats
+  extern __shared__ float tile[];                        // [CC * P][S]
   const int tiles_w = (Wo + TW - 1) / TW;
   const int tw = blockIdx.x % tiles_w, oh = (blockIdx.x / tiles_w) % Ho;
   const long img = blockIdx.x / ((long)tiles_w * Ho);
   const int wo0 = tw * TW, x0 = wo0 * P - pad, y0 = oh * P - pad;
-  for (int e = threadIdx.x; e < C * P * seg; e += 256) {
-    const int ckh = e / seg, j = e - ckh * seg, c = ckh / P, kh = ckh - c * P;
-    const int y = y0 + kh, xx = x0 + j;
-    tile[ckh * S + j] = (y >= 0 && y < H && xx >= 0 && xx < W) ? x[((img * C + c) * (long)H + y) * W + xx] : 0.0f;
-  }
-  __syncthreads();
   const int K = C * P * P, nt = min(TW, Wo - wo0);
   const long row0 = (img * Ho + oh) * (long)Wo + wo0;
-  for (int e = threadIdx.x; e < nt * C * P; e += 256) {      // one (patch, c, kh) = P consecutive columns per thread
-    const int t = e / (C * P), ckh = e - t * (C * P);
-    const float* src = tile + ckh * S + t * P;
-    const long dst = (row0 + t) * K + (long)ckh * P;
-    if constexpr (BF16OUT) {
-      if constexpr (P == 4) {
-        u32x2 u;
-        u[0] = pack_bf16x2(src[0], src[1]); u[1] = pack_bf16x2(src[2], src[3]);
-        *(u32x2*)((unsigned short*)cols + dst) = u;
-      } else if constexpr (P == 2) {
-        *(unsigned*)((unsigned short*)cols + dst) = pack_bf16x2(src[0], src[1]);
+  const int j = threadIdx.x & 63, r0 = threadIdx.x >> 6;          // a wave reads one 256-byte segment per instruction
+  const int xx = x0 + j;
+  const bool xin = xx >= 0 && xx < W;
+  for (int c0 = 0; c0 < C; c0 += CC) {
+    const int cc = min(CC, C - c0), rows = cc * P;                 // (c, kh) segments of this pass
+    for (int rb = r0; rb < rows; rb += 32) {                       // eight independent loads in flight per thread
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int r = rb + 4 * u, c = r / P, kh = r - c * P, y = y0 + kh;
+        v[u] = (r < rows && xin && y >= 0 && y < H) ? x[((img * C + c0 + c) * (long)H + y) * W + xx] : 0.0f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (rb + 4 * u < rows) tile[(rb + 4 * u) * S + j] = v[u];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < nt * rows; e += 256) {           // one (patch, c, kh) = P consecutive columns per thread
+      const int t = e / rows, ckh = e - t * rows;
+      const float* src = tile + ckh * S + t * P;
+      const long dst = (row0 + t) * K + (long)c0 * P * P + (long)ckh * P;
+      if constexpr (BF16OUT) {
+        if constexpr (P == 4) {
+          u32x2 u;
+          u[0] = pack_bf16x2(src[0], src[1]); u[1] = pack_bf16x2(src[2], src[3]);
+          *(u32x2*)((unsigned short*)cols + dst) = u;
+        } else {
+          *(unsigned*)((unsigned short*)cols + dst) = pack_bf16x2(src[0], src[1]);
+        }
       } else {
 #pragma unroll
-        for (int q = 0; q < P; ++q) ((__bf16*)cols)[dst + q] = (__bf16)src[q];
+        for (int q = 0; q < P; ++q) ((float*)cols)[dst + q] = src[q];
       }
-    } else {
-#pragma unroll
-      for (int q = 0; q < P; ++q) ((float*)cols)[dst + q] = src[q];
     }
+    __syncthreads();
   }
 }
 
@@ -1014,18 +1024,20 @@ extern "C" int tante_im2col(const void* x, int x_dtype, int nchw, int64_t n_img,
   const int eb = x_dtype == TANTE_BF16 ? 2 : 4;
   if (nchw && korder == 0 && x_dtype == TANTE_F32 && kh == kw && sh == kh && sw == kw && ph == pw && ph < kh && (kh == 2 || kh == 4) &&
       tante_opt("TANTE_IM2COL_TILED", 1)) {
-    // tile width: the largest of 32, 16, 8 patches whose C x P segments fit 64 KB of LDS
-    int TW = 32;
-    while (TW > 4 && (size_t)C * kh * (TW * kh + 1) * 4 > 64 * 1024) TW /= 2;
-    const size_t lds = (size_t)C * kh * (TW * kh + 1) * 4;
-    if (lds <= 64 * 1024) {
+    // channels per pass: the C x P segments of 64 floats (+ 1 pad) within 48 KB of LDS (three workgroups per CU and more)
+    {
+      int CC = C;
+      while ((size_t)CC * kh * 65 * 4 > 48 * 1024) CC = (CC + 1) / 2;
+      const size_t lds = (size_t)CC * kh * 65 * 4;
+      const int TW = 64 / kh;
       const long blocks = (long)n_img * Ho * ((Wo + TW - 1) / TW);
+      if (blocks > 2147483647L) TANTE_FAIL(-2, "tante_im2col: grid too large");
       const bool bf = cols_dtype == TANTE_BF16;
       hipStream_t s_ = (hipStream_t)stream;
-      if (kh == 4 && bf) hipLaunchKernelGGL((im2col_nchw_tile_kernel<4, true>), dim3((unsigned)blocks), dim3(256), lds, s_, (const float*)x, C, H, W, ph, Ho, Wo, TW, cols);
-      else if (kh == 4) hipLaunchKernelGGL((im2col_nchw_tile_kernel<4, false>), dim3((unsigned)blocks), dim3(256), lds, s_, (const float*)x, C, H, W, ph, Ho, Wo, TW, cols);
-      else if (bf) hipLaunchKernelGGL((im2col_nchw_tile_kernel<2, true>), dim3((unsigned)blocks), dim3(256), lds, s_, (const float*)x, C, H, W, ph, Ho, Wo, TW, cols);
-      else hipLaunchKernelGGL((im2col_nchw_tile_kernel<2, false>), dim3((unsigned)blocks), dim3(256), lds, s_, (const float*)x, C, H, W, ph, Ho, Wo, TW, cols);
+      if (kh == 4 && bf) hipLaunchKernelGGL((im2col_nchw_tile_kernel<4, true>), dim3((unsigned)blocks), dim3(256), lds, s_, (const float*)x, C, H, W, ph, Ho, Wo, CC, cols);
+      else if (kh == 4) hipLaunchKernelGGL((im2col_nchw_tile_kernel<4, false>), dim3((unsigned)blocks), dim3(256), lds, s_, (const float*)x, C, H, W, ph, Ho, Wo, CC, cols);
+      else if (bf) hipLaunchKernelGGL((im2col_nchw_tile_kernel<2, true>), dim3((unsigned)blocks), dim3(256), lds, s_, (const float*)x, C, H, W, ph, Ho, Wo, CC, cols);
+      else hipLaunchKernelGGL((im2col_nchw_tile_kernel<2, false>), dim3((unsigned)blocks), dim3(256), lds, s_, (const float*)x, C, H, W, ph, Ho, Wo, CC, cols);
       TANTE_CHECK_LAUNCH();
       return 0;
     }
@@ -1075,10 +1087,66 @@ extern "C" int tante_col2im_nhwc(const void* cols, int cols_dtype, int64_t n_img
   return 0;
 }
 
+// The same resize from a channels-LAST source into a channels-FIRST destination (the last stage of a padded decoder, enc_dec_cnn.py:164-184
+// as used by enc_dec_fno.py: (n, 512, 512, 32) bf16 -> (n, 32, 512, 512) fp32): the generic kernel above walks the output, so a wave reads
+// 64 pixels x 2 bytes at a stride of C elements -- a 64-byte segment fetched per value (158 us for 16.8 M outputs).  Here a workgroup owns
+// 64 output columns of one output row: the two source rows' <= 66 pixels x CC channels arrive as contiguous runs (channels fastest)
+// into LDS, and every channel leaves as 64 consecutive values.  Same expression, same order: bit-identical to the generic kernel.
+// Needs a horizontal scale Wi / Wo <= 1 (the 66 source columns).
+template <int CC>
+__global__ __launch_bounds__(256) void resize_cl2cf_kernel(const void* __restrict__ in, int in_dtype, int C, int Hi, int Wi, int cy, int cx, long isn,
+                                                           long ish, long isw, int Ho, int Wo, long osn, long osc, long osh, int act,
+                                                           void* __restrict__ out, int out_dtype) {
+  __shared__ float tile[2][66][CC + 1];
+  const int tiles_w = (Wo + 63) / 64;
+  const int bx = blockIdx.x % tiles_w, oy = (blockIdx.x / tiles_w) % Ho;
+  const long img = blockIdx.x / ((long)tiles_w * Ho);
+  const float sy = (float)Hi / (float)Ho, sx = (float)Wi / (float)Wo;
+  float fy = sy * ((float)oy + 0.5f) - 0.5f;
+  fy = fy < 0.0f ? 0.0f : fy;
+  const int y0 = (int)fy, y1 = y0 + (y0 < Hi - 1 ? 1 : 0);
+  const float ly = fy - (float)y0;
+  const int ox0 = bx * 64;
+  float fx0 = sx * ((float)ox0 + 0.5f) - 0.5f;
+  fx0 = fx0 < 0.0f ? 0.0f : fx0;
+  const int xs0 = (int)fx0, ncol = min(66, Wi - xs0);
+  const int ox = ox0 + (threadIdx.x & 63);
+  float fx = sx * ((float)ox + 0.5f) - 0.5f;
+  fx = fx < 0.0f ? 0.0f : fx;
+  const int x0 = (int)fx, x1 = x0 + (x0 < Wi - 1 ? 1 : 0);
+  const float lx = fx - (float)x0;
+  const int s0 = x0 - xs0, s1 = x1 - xs0;
+  for (int c0 = 0; c0 < C; c0 += CC) {
+    const int cc = min(CC, C - c0);
+    for (int e = threadIdx.x; e < 2 * 66 * CC; e += 256) {
+      const int r = e / (66 * CC), rem = e - r * (66 * CC), sc = rem / CC, c = rem - sc * CC;
+      if (sc < ncol && c < cc) tile[r][sc][c] = ldx(in, in_dtype, img * isn + ((r ? y1 : y0) + cy) * ish + (xs0 + sc + cx) * isw + c0 + c);
+    }
+    __syncthreads();
+    if (ox < Wo) {
+      for (int c = threadIdx.x >> 6; c < cc; c += 4) {
+        const float v00 = tile[0][s0][c], v01 = tile[0][s1][c], v10 = tile[1][s0][c], v11 = tile[1][s1][c];
+        const float v = (1.0f - ly) * ((1.0f - lx) * v00 + lx * v01) + ly * ((1.0f - lx) * v10 + lx * v11);
+        stx(out, out_dtype, img * osn + (c0 + c) * osc + oy * osh + ox, apply_act(v, act));
+      }
+    }
+    __syncthreads();
+  }
+}
+
 extern "C" int tante_resize_bilinear(const void* in, int in_dtype, int64_t n_img, int C, int Hi, int Wi, int crop_y, int crop_x,
                                      int64_t isn, int64_t isc, int64_t ish, int64_t isw, int Ho, int Wo, int64_t osn, int64_t osc,
                                      int64_t osh, int64_t osw, int act, void* out, int out_dtype, void* stream) {
   if (!in || !out || n_img <= 0 || C <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0) TANTE_FAIL(-1, "tante_resize_bilinear: bad argument");
+  if (isc == 1 && osw == 1 && Wi <= Wo && tante_opt("TANTE_RESIZE_TILED", 1)) {
+    const long blocks = (long)n_img * Ho * ((Wo + 63) / 64);
+    if (blocks <= 2147483647L) {
+      hipLaunchKernelGGL((resize_cl2cf_kernel<32>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, in, in_dtype, C, Hi, Wi, crop_y, crop_x,
+                         (long)isn, (long)ish, (long)isw, Ho, Wo, (long)osn, (long)osc, (long)osh, act, out, out_dtype);
+      TANTE_CHECK_LAUNCH();
+      return 0;
+    }
+  }
   hipLaunchKernelGGL(resize_kernel, dim3(grid_for((long)n_img * C * Ho * Wo)), dim3(256), 0, (hipStream_t)stream, in, in_dtype, (long)n_img, C,
                      Hi, Wi, crop_y, crop_x, (long)isn, (long)isc, (long)ish, (long)isw, Ho, Wo, (long)osn, (long)osc, (long)osh, (long)osw, act,
                      out, out_dtype, (int)(osc == 1));

@@ -396,3 +396,29 @@ def test_cvit_width512_fused_against_oracle_and_unfused(dev):
         idx = torch.randint(0, 64 * 64, (777,), device=dev)
         yq = m(xs.to(dev), tante_amd.cvit.generate_coords(64, 64, dev)[idx])
     close(yq, y.permute(0, 1, 3, 4, 2).reshape(4, 4, 64 * 64, -1)[:, :, idx], "bf16", "query points vs full grid")
+
+
+@pytest.mark.parametrize("n,C,H,W,p,idt,odt", [(2, 32, 64, 96, 1, "bf16", "fp32"), (1, 8, 130, 70, 1, "fp32", "fp32"), (3, 40, 20, 200, 2, "bf16", "bf16"),
+                                               (1, 32, 512, 512, 1, "bf16", "fp32"), (2, 5, 33, 65, 0, "fp32", "fp32")])
+def test_resize_channels_last_to_first_equals_generic_kernel(dev, n, C, H, W, p, idt, odt):
+    """The tiled crop + bilinear resize of a channels-last stage into a channels-first tensor (the last padded decoder stage,
+    enc_dec_cnn.py:164-184: crop p pixels per side, resize back to (H, W)) against the generic kernel (TANTE_RESIZE_TILED = 0): bit for
+    bit; and against torch's interpolate of the cropped window (fp32 bar)."""
+    from tante_amd import _lib as L, kernels as Kk
+    g = torch.Generator().manual_seed(C * H)
+    dt = {"bf16": torch.bfloat16, "fp32": torch.float32}
+    full = torch.randn(n, H, W, C, generator=g).to(dev, dt[idt])
+    outs = []
+    try:
+        for tiled in (1, 0):
+            L.set_option("TANTE_RESIZE_TILED", tiled)
+            out = torch.empty(n, C, H, W, dtype=dt[odt], device=dev)
+            Kk.resize_bilinear(full, n, C, H - 2 * p, W - 2 * p, (p, p), (H * W * C, 1, W * C, C), H, W, out, (C * H * W, H * W, W, 1), L.ACT_GELU_ERF)
+            outs.append(out)
+    finally:
+        L.set_option("TANTE_RESIZE_TILED", 1)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1])
+    win = full.float().cpu().permute(0, 3, 1, 2)[:, :, p:H - p, p:W - p]
+    ref = torch.nn.functional.gelu(torch.nn.functional.interpolate(win, size=(H, W), mode="bilinear", align_corners=False))
+    close(outs[0], ref if odt == "fp32" else ref.to(torch.bfloat16).float(), "fp32" if odt == "fp32" else "bf16", "tiled resize vs torch")
