@@ -347,6 +347,12 @@ int64_t tante_spectral_workspace_bytes(int64_t n, int Cin, int Cout, int H, int 
 int tante_spectral_layer(const float* x, int64_t n, int Cin, int H, int W, const float* w_re, const float* w_im, int wm1, int wm2,
                          int modes1, int modes2, const float* w0, const float* b0, int Cout, int act, float* out, void* work,
                          int64_t work_bytes, void* stream);
+/* The same with a compute mode: TANTE_F32 = tante_spectral_layer (exact fp32 matrix products); TANTE_BF16 lets the inverse row transform
+ * + 1x1 conv run as split-operand products on the bf16 matrix pipe (every fp32 operand as hi + lo bf16 parts, three products, fp32
+ * accumulation: ~1e-5 relative to the fp32 result) where the shape allows -- the mode of a bf16 model, whose bar is 1e-2. */
+int tante_spectral_layer_c(const float* x, int64_t n, int Cin, int H, int W, const float* w_re, const float* w_im, int wm1, int wm2,
+                           int modes1, int modes2, const float* w0, const float* b0, int Cout, int act, float* out, void* work,
+                           int64_t work_bytes, int compute, void* stream);
 /* Backward of tante_spectral_layer (act none): dx (n, Cin, H, W) = irfft2(M^H rfft2(dy)) + W0^T dy, and the complex weight gradient
  * dw_re / dw_im (Cin, Cout, wm1, wm2) in PyTorch's convention (dL/dRe + i dL/dIm).  w0t: the 1x1 weight transposed, (Cin, Cout).
  * The 1x1 conv's own weight / bias gradients are ordinary reductions (tante_wgrad lines, tante_colsum). */

@@ -120,6 +120,8 @@ SIGNATURES = {
     "tante_spectral_workspace_bytes": ([c_i64, c_i32, c_i32, c_i32, c_i32], c_i64),
     "tante_spectral_layer": ([c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp,
                               c_i64, c_vp], c_i32),
+    "tante_spectral_layer_c": ([c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp,
+                                c_i64, c_i32, c_vp], c_i32),
     "tante_spectral_layer_bwd": ([c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp,
                                   c_vp, c_i64, c_vp], c_i32),
     "tante_col2im_nhwc_sized": ([c_vp, c_i32, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_i32, c_vp, c_i32, c_vp], c_i32),

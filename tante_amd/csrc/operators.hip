@@ -1177,6 +1177,13 @@ extern "C" int64_t tante_spectral_workspace_bytes(int64_t n, int Cin, int Cout, 
 extern "C" int tante_spectral_layer(const float* x, int64_t n, int Cin, int H, int W, const float* w_re, const float* w_im, int wm1, int wm2,
                                     int modes1, int modes2, const float* w0, const float* b0, int Cout, int act, float* out, void* work,
                                     int64_t work_bytes, void* stream) {
+  return tante_spectral_layer_c(x, n, Cin, H, W, w_re, w_im, wm1, wm2, modes1, modes2, w0, b0, Cout, act, out, work, work_bytes, TANTE_F32, stream);
+}
+
+extern "C" int tante_spectral_layer_c(const float* x, int64_t n, int Cin, int H, int W, const float* w_re, const float* w_im, int wm1, int wm2,
+                                      int modes1, int modes2, const float* w0, const float* b0, int Cout, int act, float* out, void* work,
+                                      int64_t work_bytes, int compute, void* stream) {
+  if (compute != TANTE_F32 && compute != TANTE_BF16) TANTE_FAIL(-1, "tante_spectral_layer_c: compute must be TANTE_F32 or TANTE_BF16");
   if (!x || !w_re || !w_im || !w0 || !out || !work || n <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0)
     TANTE_FAIL(-1, "tante_spectral_layer: bad argument");
   if (work_bytes < tante_spectral_workspace_bytes(n, Cin, Cout, H, W)) TANTE_FAIL(-1, "tante_spectral_layer: workspace too small");
@@ -1188,7 +1195,7 @@ extern "C" int tante_spectral_layer(const float* x, int64_t n, int Cin, int H, i
   // TANTE_SPECTRAL_DFT = 0 (tante_set_option) keeps the hipFFT path below for every shape (A/B timing, tests)
   if (tante_opt("TANTE_SPECTRAL_DFT", 1) && tante_spectral_dft_supported(n, Cin, Cout, H, W, m1, m2) &&
       tante_spectral_dft_workspace_bytes(n, Cin, Cout, H, m1, m2) <= work_bytes) {
-    const int rc = tante_spectral_dft_forward(x, n, Cin, H, W, w_re, w_im, wm1, wm2, m1, m2, w0, b0, Cout, act, out, work, s);
+    const int rc = tante_spectral_dft_forward(x, n, Cin, H, W, w_re, w_im, wm1, wm2, m1, m2, w0, b0, Cout, act, out, work, compute, s);
     if (rc) TANTE_FAIL(rc, "tante_spectral_layer: truncated-DFT launch failed");
     return 0;
   }

@@ -6,4 +6,4 @@
 int tante_spectral_dft_supported(int64_t n, int Cin, int Cout, int H, int W, int m1, int m2);
 int64_t tante_spectral_dft_workspace_bytes(int64_t n, int Cin, int Cout, int H, int m1, int m2);
 int tante_spectral_dft_forward(const float* x, int64_t n, int Cin, int H, int W, const float* w_re, const float* w_im, int wm1, int wm2, int m1,
-                               int m2, const float* w0, const float* b0, int Cout, int act, float* out, void* work, hipStream_t s);
+                               int m2, const float* w0, const float* b0, int Cout, int act, float* out, void* work, int compute, hipStream_t s);

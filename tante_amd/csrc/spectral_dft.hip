@@ -299,6 +299,206 @@ __global__ __launch_bounds__(1024) void idft_rows_conv_kernel(const float* __res
   }
 }
 
+// ---- E in the bf16 compute mode: the same products on the bf16 matrix pipe with SPLIT operands -------------------------------------------
+// Kernel E above sits at the fp32 matrix pipe's own rate (24 v_mfma_f32_32x32x2_f32 of 64 cycles per 32 x 32 output tile: 200 us for the
+// 8 -> 32 channel layer of a 4-frame window at 512 x 512, four times the HBM time of its 335 MB).  The bf16 pipe is 16 x faster per
+// product; with every operand split into two bf16 parts, v = hi + lo (16 mantissa bits kept), and the three products
+//     a . b  ~=  a_hi b_hi + a_lo b_hi + a_hi b_lo                 (a_lo b_lo, 2^-18 relative, dropped; fp32 accumulation)
+// the result differs from the fp32 chain by ~1e-5 relative per term -- a thousandth of the bf16 mode's own bar (1e-2; its convolutions
+// round activations to 8 bits) -- for 9 v_mfma_f32_16x16x32_bf16 of 16 cycles per 16 x 16 tile: 2.7 x fewer matrix cycles, which makes the
+// kernel HBM-bound.  Only the bf16 compute mode uses it (tante_spectral_layer_c); fp32 keeps the exact kernel above.
+// A workgroup = 128 output columns; its G table sits in LDS as ready B-operand fragments (hi and lo).  A wave owns one image row at a
+// time: it gathers and splits the row's Z coefficients once (A fragments), then walks the 8 column tiles, splitting x on the way.
+__device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsigned& lo) {
+  hi = pack_bf16x2(a, b);
+  lo = pack_bf16x2(a - bf16_lo(hi), b - bf16_hi(hi));
+}
+__device__ __forceinline__ void split8(const float (&v)[8], u32x4& hi, u32x4& lo) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    unsigned h, l;
+    split_pair(v[2 * q], v[2 * q + 1], h, l);
+    hi[q] = h;
+    lo[q] = l;
+  }
+}
+__device__ __forceinline__ f32x4 mfma16(const u32x4& a, const u32x4& b, const f32x4& c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+template <int KZS, int KCS>   // k-steps of 32 per term: ceil(2 m2 / 32) spectral, ceil(Cin / 32) conv
+__global__ __launch_bounds__(256) void idft_rows_conv_x3_kernel(const float* __restrict__ Z, const float* __restrict__ x, const float* __restrict__ w0,
+                                                                const float* __restrict__ b0, long n, int Cin, int Cout, int H, int W, int m2,
+                                                                int act, float* __restrict__ out) {
+  // LDS: the G table as operand fragments [hi | lo][KZS][8 column tiles][64 lanes], then per wave a staging area for one image row's
+  // operands in ROW form: zs[2 m2][Cout + 4] (the row's coefficients) and xs[Cin][132] (its 128 pixels of every input channel).
+  // Every global access of the row loop is a 16-byte-per-lane access of whole contiguous runs; the operand (MFMA) layouts are taken
+  // from LDS.  (The first version gathered both operands straight from global memory, 64-byte pieces at a time: 160 such
+  // instructions per row and wave kept the texture-address unit busy for longer than the products and the HBM traffic together.)
+  extern __shared__ __attribute__((aligned(16))) u32x4 tbl[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, kk = lane >> 4;
+  const int ncb = W / 128, cb = blockIdx.x % ncb, rg = blockIdx.x / ncb, nrg = gridDim.x / ncb, col0 = cb * 128;
+  const int ZP = Cout + 4, XP = 132;
+  float* stage = (float*)(tbl + 2 * KZS * 512) + wave * (2 * m2 * ZP + Cin * XP);
+  float* zs = stage;
+  float* xs = stage + 2 * m2 * ZP;
+  {
+    // (cos, sin)(2 pi m / W) once per workgroup (W evaluations, in the staging area, which is not in use yet); the table is a gather of them
+    float2* base = (float2*)((float*)(tbl + 2 * KZS * 512));
+    for (int m = tid; m < W; m += 256) {
+      float sn, cs;
+      sincos_frac(m, W, sn, cs);
+      base[m] = make_float2(cs, sn);
+    }
+    __syncthreads();
+    for (int e = tid; e < KZS * 512; e += 256) {
+      const int s = e >> 9, wt = (e >> 6) & 7, ln = e & 63, w = col0 + 16 * wt + (ln & 15);
+      float v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int k = 32 * s + 8 * (ln >> 4) + q;
+        v[q] = 0.0f;
+        if (k < 2 * m2) {
+          const int j = k < m2 ? k : k - m2;
+          const float2 t = base[(int)(((long)j * w) % W)];
+          const float a = j == 0 ? 1.0f : 2.0f;
+          v[q] = k < m2 ? a * t.x : -a * t.y;
+        }
+      }
+      u32x4 hi, lo;
+      split8(v, hi, lo);
+      tbl[e] = hi;
+      tbl[KZS * 512 + e] = lo;
+    }
+    __syncthreads();
+  }
+  // the 1x1 conv's weights as operand fragments (the same for every row): lane (o = l15 of tile ot, kk) holds channels 32 sc + 8 kk ..
+  u32x4 Wc[2][KCS][2];
+#pragma unroll
+  for (int sc = 0; sc < KCS; ++sc)
+#pragma unroll
+    for (int ot = 0; ot < 2; ++ot) {
+      const int o = 16 * ot + l15;
+      float v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int c = 32 * sc + 8 * kk + q;
+        v[q] = (o < Cout && c < Cin) ? w0[(long)o * Cin + c] : 0.0f;
+      }
+      split8(v, Wc[0][sc][ot], Wc[1][sc][ot]);
+    }
+  float bias[2];
+#pragma unroll
+  for (int ot = 0; ot < 2; ++ot) bias[ot] = (b0 && 16 * ot + l15 < Cout) ? b0[16 * ot + l15] : 0.0f;
+  __syncthreads();
+  const long rows = n * H, HWl = (long)H * W;
+  const bool two = Cout > 16;
+  const int nz4 = 2 * m2 * Cout / 4;              // float4 pieces of a coefficient row (Cout % 4 == 0)
+  for (long rho = (long)rg * 4 + wave; rho < rows; rho += (long)nrg * 4) {
+    const long b = rho / H;
+    const int h = (int)(rho - b * H);
+    // global (16 bytes per lane, whole contiguous runs) -> registers -> the wave's staging area; LDS operations of one wave execute in order
+    {
+      const float* zrow = Z + rho * 2 * m2 * Cout;
+      for (int i0 = 0; 64 * i0 < nz4; i0 += 4) {
+        f32x4 zr[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int idx = lane + 64 * (i0 + u);
+          zr[u] = idx < nz4 ? *(const f32x4*)(zrow + 4 * idx) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int idx = lane + 64 * (i0 + u);
+          if (idx < nz4) { const int k = (4 * idx) / Cout, o = 4 * idx - k * Cout; *(f32x4*)(zs + k * ZP + o) = zr[u]; }
+        }
+      }
+      const float* xp = x + ((b * Cin) * H + h) * (long)W + col0 + 4 * (lane & 31);
+      for (int c0 = 0; c0 < Cin; c0 += 8) {         // two channels (2 x 512 bytes) per wave instruction
+        f32x4 xr4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int c = c0 + 2 * u + (lane >> 5);
+          xr4[u] = c < Cin ? *(const f32x4*)(xp + (long)c * HWl) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int c = c0 + 2 * u + (lane >> 5);
+          if (c < Cin) *(f32x4*)(xs + c * XP + 4 * (lane & 31)) = xr4[u];
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+    u32x4 Zf[2][KZS][2];
+#pragma unroll
+    for (int s = 0; s < KZS; ++s)
+#pragma unroll
+      for (int ot = 0; ot < 2; ++ot) {
+        const int o = 16 * ot + l15;
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int k = 32 * s + 8 * kk + q;
+          v[q] = (o < Cout && k < 2 * m2) ? zs[k * ZP + o] : 0.0f;
+        }
+        split8(v, Zf[0][s][ot], Zf[1][s][ot]);
+      }
+    float* orow = out + (b * Cout * H + h) * (long)W + col0 + 4 * kk;
+#pragma unroll 1
+    for (int wt = 0; wt < 8; ++wt) {
+      u32x4 Xf[2][KCS];
+#pragma unroll
+      for (int sc = 0; sc < KCS; ++sc) {
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int c = 32 * sc + 8 * kk + q;
+          v[q] = c < Cin ? xs[c * XP + 16 * wt + l15] : 0.0f;
+        }
+        split8(v, Xf[0][sc], Xf[1][sc]);
+      }
+      f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};     // D[w][o]: lane (o = l15, kk) holds columns 4 kk .. 4 kk + 3 of the tile
+#pragma unroll
+      for (int s = 0; s < KZS; ++s) {
+        const u32x4 gh = tbl[s * 512 + wt * 64 + lane], gl = tbl[(KZS + s) * 512 + wt * 64 + lane];
+#pragma unroll
+        for (int ot = 0; ot < 2; ++ot) {
+          if (ot == 1 && !two) break;
+          acc[ot] = mfma16(gh, Zf[1][s][ot], acc[ot]);
+          acc[ot] = mfma16(gl, Zf[0][s][ot], acc[ot]);
+          acc[ot] = mfma16(gh, Zf[0][s][ot], acc[ot]);
+        }
+      }
+#pragma unroll
+      for (int sc = 0; sc < KCS; ++sc)
+#pragma unroll
+        for (int ot = 0; ot < 2; ++ot) {
+          if (ot == 1 && !two) break;
+          acc[ot] = mfma16(Xf[0][sc], Wc[1][sc][ot], acc[ot]);
+          acc[ot] = mfma16(Xf[1][sc], Wc[0][sc][ot], acc[ot]);
+          acc[ot] = mfma16(Xf[0][sc], Wc[0][sc][ot], acc[ot]);
+        }
+#pragma unroll
+      for (int ot = 0; ot < 2; ++ot) {
+        const int o = 16 * ot + l15;
+        if (o < Cout) {
+          f32x4 v = acc[ot] + splat4(bias[ot]);
+          // the bf16 mode's GELU (common.cuh: degree-7 fit, |error| <= 8.3e-5, packed fp32 math, no transcendental): with erf + exp + rcp
+          // per output this epilogue, not the products or the memory system, set the kernel's time
+          if (act == TANTE_ACT_GELU_ERF) v = gelu_poly4<false>(v);
+          else if (act != TANTE_ACT_NONE) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], act);
+          }
+          *(f32x4*)(orow + (long)o * HWl + 16 * wt) = v;
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+  }
+}
+
 }  // namespace
 
 int tante_spectral_dft_supported(int64_t n, int Cin, int Cout, int H, int W, int m1, int m2) {
@@ -320,7 +520,7 @@ int64_t tante_spectral_dft_workspace_bytes(int64_t n, int Cin, int Cout, int H, 
 }
 
 int tante_spectral_dft_forward(const float* x, int64_t n, int Cin, int H, int W, const float* w_re, const float* w_im, int wm1, int wm2, int m1,
-                               int m2, const float* w0, const float* b0, int Cout, int act, float* out, void* work, hipStream_t s) {
+                               int m2, const float* w0, const float* b0, int Cout, int act, float* out, void* work, int compute, hipStream_t s) {
   auto up = [](int64_t v) { return (v + 255) / 256 * 256; };
   char* p = (char*)work;
   float* Ar = (float*)p; p += up(n * Cin * H * 2 * m2 * 4);
@@ -358,6 +558,28 @@ int tante_spectral_dft_forward(const float* x, int64_t n, int Cin, int H, int W,
     TANTE_DFT_D(4) TANTE_DFT_D(8) TANTE_DFT_D(10) TANTE_DFT_D(16) TANTE_DFT_D(20) TANTE_DFT_D(32) TANTE_DFT_D(40) TANTE_DFT_D(64)
 #undef TANTE_DFT_D
     default: return -2;
+  }
+  // bf16 compute mode: split-operand products on the bf16 matrix pipe (idft_rows_conv_x3_kernel); TANTE_SPECTRAL_X3 = 0 keeps the fp32 kernel
+  const size_t ldsE3 = (size_t)2 * ((2 * m2 + 31) / 32) * 512 * 16 + (size_t)4 * (2 * m2 * (Cout + 4) + Cin * 132) * 4;     // table + four waves' staging areas
+  if (compute == TANTE_BF16 && W % 128 == 0 && Cout <= 32 && Cout % 4 == 0 && Cin <= 64 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)out % 16) == 0 &&
+      ldsE3 <= 150 * 1024 && (size_t)W * 8 <= ldsE3 - (size_t)2 * ((2 * m2 + 31) / 32) * 512 * 16 && tante_opt("TANTE_SPECTRAL_X3", 1)) {
+    const int kzs = (2 * m2 + 31) / 32, kcs = (Cin + 31) / 32, ncb = W / 128;
+    const long rows4 = ((long)n * H + 3) / 4;
+    const size_t lds = ldsE3;
+    const long per_cu = std::max<long>(1, std::min<long>(4, (150 * 1024) / (long)lds));
+    const long nrg = std::max<long>(1, std::min<long>(rows4, 256 * per_cu / ncb));
+    static TantePerDevice attrE3[4];
+#define TANTE_DFT_E3(A_, B_)                                                                                                                   \
+  {                                                                                                                                            \
+    attrE3[(A_ - 1) * 2 + (B_ - 1)].once([&] { (void)hipFuncSetAttribute((const void*)idft_rows_conv_x3_kernel<A_, B_>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); }); \
+    hipLaunchKernelGGL((idft_rows_conv_x3_kernel<A_, B_>), dim3((unsigned)(nrg * ncb)), dim3(256), lds, s, Z, x, w0, b0, (long)n, Cin, Cout, H, W, m2, act, out); \
+  }
+    if (kzs == 1 && kcs == 1) TANTE_DFT_E3(1, 1)
+    else if (kzs == 1) TANTE_DFT_E3(1, 2)
+    else if (kcs == 1) TANTE_DFT_E3(2, 1)
+    else TANTE_DFT_E3(2, 2)
+#undef TANTE_DFT_E3
+    return hipGetLastError() == hipSuccess ? 0 : -3;
   }
   const int wpb = W / 32;                      // waves per workgroup: one per 32 output columns
   const size_t ldsE = (size_t)2 * m2 * W * 4 + (size_t)Cin * ((Cout + 31) / 32 * 32) * 4;

@@ -74,7 +74,7 @@ class FourierOperator2d(nn.Module):
             rows = rows.detach().contiguous()
             z = self.lifting.run(rows, compute).view(B, H, W, -1).permute(0, 3, 1, 2).contiguous()
             for i, blk in enumerate(self.fno_blocks):
-                z = blk.run(z, L.ACT_GELU_ERF if i + 1 < self.n_layers else L.ACT_NONE)
+                z = blk.run(z, L.ACT_GELU_ERF if i + 1 < self.n_layers else L.ACT_NONE, compute)
             rows = z.permute(0, 2, 3, 1).reshape(B * H * W, self.hidden_channels)
             return self.projection.run(rows, compute).view(B, H, W, -1).permute(0, 3, 1, 2)
         from .autograd import ActFn, SpectralLayerFn

@@ -40,13 +40,13 @@ class SpectralLayer(nn.Module):
     def _planes(self):
         return self._cache.get(0, [self.weight], lambda: (self.weight.detach().real.contiguous(), self.weight.detach().imag.contiguous()))
 
-    def run(self, x: torch.Tensor, act: int = L.ACT_NONE) -> torch.Tensor:
-        """x (n, Cin, H, W) fp32 contiguous -> act(layer(x))."""
+    def run(self, x: torch.Tensor, act: int = L.ACT_NONE, compute: int = L.F32) -> torch.Tensor:
+        """x (n, Cin, H, W) fp32 contiguous -> act(layer(x)); compute: the model's mode (kernels.spectral_layer)."""
         if x.dim() != 4 or x.size(1) != self.in_channels:
             raise AssertionError("SpectralLayer expects (B, Cin, H, W)")
         re, im = self._planes()
         w0 = self.w0.weight.detach().view(self.out_channels, self.in_channels)
-        return K.spectral_layer(x, re, im, self.modes1, self.modes2, w0, self.w0.bias.detach(), act)
+        return K.spectral_layer(x, re, im, self.modes1, self.modes2, w0, self.w0.bias.detach(), act, compute)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         _no_autograd(self)
@@ -96,9 +96,9 @@ class enc_FNO(nn.Module):
         pk = self._packed(compute)
         n = B * T
         z = inp.contiguous().view(n, D, H, W)
-        z = self.enc_spectral_1.run(z, L.ACT_GELU_ERF)
+        z = self.enc_spectral_1.run(z, L.ACT_GELU_ERF, compute)
         y, h, w = S.conv_stage(z, True, n, self.chans[1], H, W, self.P[0], self.overlap, pk[0], compute, L.ACT_GELU_ERF, torch.float32)
-        z = self.enc_spectral_2.run(_to_nchw(y, n, h, w), L.ACT_GELU_ERF)
+        z = self.enc_spectral_2.run(_to_nchw(y, n, h, w), L.ACT_GELU_ERF, compute)
         y, h, w = S.conv_stage(z, True, n, self.chans[3], h, w, self.P[1], self.overlap, pk[1], compute, L.ACT_NONE, torch.float32)
         if film is not None:
             fa, fb, se, Tt, HW = film
@@ -163,10 +163,10 @@ class dec_FNO(nn.Module):
         z = S.deconv_stage(src, n_img, h, w, p1, self.overlap, pk[0], self.chans[1], compute, L.ACT_GELU_ERF, True, torch.float32,
                            a_n0=a_n0, a_s1=a_s1, a_s0=a_s0, a_off=a_off)
         h, w = h * p1, w * p1
-        z = self.dec_spectral_1.run(z, L.ACT_GELU_ERF)                                   # (n, C/4, h, w) channels-first
+        z = self.dec_spectral_1.run(z, L.ACT_GELU_ERF, compute)                                   # (n, C/4, h, w) channels-first
         rows = z.permute(0, 2, 3, 1).contiguous().view(n_img * h * w, self.chans[2])     # layout change for the row GEMM
         z = S.deconv_stage(rows, n_img, h, w, p0, self.overlap, pk[1], self.chans[3], compute, L.ACT_GELU_ERF, True, torch.float32)
-        return self.dec_spectral_2.run(z, L.ACT_NONE)
+        return self.dec_spectral_2.run(z, L.ACT_NONE, compute)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         _no_autograd(self)

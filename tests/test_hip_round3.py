@@ -422,3 +422,30 @@ def test_resize_channels_last_to_first_equals_generic_kernel(dev, n, C, H, W, p,
     win = full.float().cpu().permute(0, 3, 1, 2)[:, :, p:H - p, p:W - p]
     ref = torch.nn.functional.gelu(torch.nn.functional.interpolate(win, size=(H, W), mode="bilinear", align_corners=False))
     close(outs[0], ref if odt == "fp32" else ref.to(torch.bfloat16).float(), "fp32" if odt == "fp32" else "bf16", "tiled resize vs torch")
+
+
+@pytest.mark.parametrize("n,Cin,Cout,H,W,m1,m2", [(2, 8, 32, 64, 128, 5, 5), (1, 32, 32, 32, 256, 8, 20), (3, 40, 16, 48, 128, 4, 3), (1, 8, 8, 512, 512, 20, 20),
+                                                   (2, 64, 24, 16, 128, 2, 32)])
+def test_spectral_layer_split_bf16_inverse_rows(dev, n, Cin, Cout, H, W, m1, m2):
+    """tante_spectral_layer_c in the bf16 mode (inverse row transform + 1x1 conv as three split-operand products on the bf16 matrix pipe,
+    enc_dec_fno.py:184-222) against the fp32 mode of the same entry and against the oracle's rfft2 / irfft2 restatement: the split keeps
+    16 mantissa bits per operand, so the bar here is 1e-4 of the output's scale -- a hundred times tighter than the mode's own 1e-2."""
+    from tante_amd import _lib as L, kernels as Kk
+    from oracle import spectral_oracle as SO
+    torch.manual_seed(Cin * H + m2)
+    x = torch.randn(n, Cin, H, W)
+    wre = torch.randn(Cin, Cout, m1, m2) / (Cin * Cout) ** 0.5
+    wim = torch.randn(Cin, Cout, m1, m2) / (Cin * Cout) ** 0.5
+    w0 = torch.randn(Cout, Cin) / Cin ** 0.5
+    b0 = torch.randn(Cout)
+    args = [t.to(dev) for t in (x, wre, wim)]
+    # without the activation: the split products alone (bar 1e-4); with GELU the bf16 mode's polynomial (|error| <= 8.3e-5) joins in
+    for act, bar in ((L.ACT_NONE, 1e-4), (L.ACT_GELU_ERF, 3e-4)):
+        y32 = Kk.spectral_layer(*args, m1, m2, w0.to(dev), b0.to(dev), act, L.F32)
+        y16 = Kk.spectral_layer(*args, m1, m2, w0.to(dev), b0.to(dev), act, L.BF16)
+        torch.cuda.synchronize()
+        r, m = rel_err(y16.cpu(), y32.cpu()), max_rel(y16.cpu(), y32.cpu())
+        record_parity(r, m, bar, "bf16", f"split-bf16 inverse rows vs fp32 kernel, act {act} ({n},{Cin},{Cout},{H},{W},{m1},{m2})")
+        assert r < bar and m < 2 * bar, (act, r, m)
+    ref = torch.nn.functional.gelu(SO.spectral_layer({"weight": torch.complex(wre, wim), "w0.weight": w0.view(Cout, Cin, 1, 1), "w0.bias": b0}, x, m1, m2))
+    close(y16, ref, "bf16", "split-bf16 spectral layer vs oracle", scale=1e-2)
