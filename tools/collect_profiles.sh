@@ -11,6 +11,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/rollout -- python3 
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/train -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --train-steps 3 --no-train-strong > $OUT/train_bench.json 2> $OUT/train.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trl -- python3 $R/bench.py --config $R/configs/tante_trl.yaml --steps 5 --warmup 2 --no-cpu-baseline > $OUT/trl_bench.json 2> $OUT/trl.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/cvit -- python3 $R/bench.py --config $R/configs/cvit_rb.yaml --steps 5 --warmup 2 > $OUT/cvit_bench.json 2> $OUT/cvit.err
+python3 $R/bench.py --config $R/configs/cvit_rb.yaml --batch 4 --steps 10 --warmup 3 > $OUT/cvit_b4_bench.json 2> $OUT/cvit_b4.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/fno -- python3 $R/bench.py --config $R/configs/tante_fno.yaml --steps 3 --warmup 1 --no-cpu-baseline > $OUT/fno_bench.json 2> $OUT/fno.err
 python3 $R/bench.py --config $R/configs/fno_vf.yaml --steps 3 --warmup 1 > $OUT/fno_vf_bench.json 2> $OUT/fno_vf.err
 python3 $R/tools/dp_gloo_1gpu.py > $OUT/dp_gloo_1gpu.log 2>&1

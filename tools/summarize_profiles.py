@@ -87,7 +87,7 @@ for k, e in fno["kernels"].items():
 if calls:
     fno["spectral_layer"] = {"hbm_bytes_per_call": round(tot_bytes / calls), "calls_sampled": calls}
     json.dump(fno, open(os.path.join(out, f"{TAG}_pmc_fno.json"), "w"), indent=1)
-for name in ("rollout_bench.json", "train_bench.json", "trl_bench.json", "cvit_bench.json", "fno_bench.json", "fno_vf_bench.json", "bench_gloo2_plumbing.json",
+for name in ("rollout_bench.json", "train_bench.json", "trl_bench.json", "cvit_bench.json", "cvit_b4_bench.json", "fno_bench.json", "fno_vf_bench.json", "bench_gloo2_plumbing.json",
              "bench_full.json"):
     p = os.path.join(out, name)
     if os.path.exists(p):
