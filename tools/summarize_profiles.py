@@ -61,8 +61,8 @@ for k, d in agg.items():
     res[k] = e
 json.dump(res, open(os.path.join(out, f"{TAG}_pmc_rollout.json"), "w"), indent=1)
 
-# cfg5: HBM bytes of the spectral path per SpectralLayer call (its five kernels; one idft_rows_conv launch per call)
-SPEC = ("dft_rows_kernel", "dft_cols_kernel", "spectral_mix_kernel", "idft_cols_kernel", "idft_rows_conv_kernel")
+# cfg5: HBM bytes of the spectral path per SpectralLayer call (its five kernels; one idft_rows_conv[_x3] launch per call)
+SPEC = ("dft_rows_kernel", "dft_cols_kernel", "spectral_mix_kernel", "idft_cols_kernel", "idft_rows_conv_kernel", "idft_rows_conv_x3_kernel")
 fno = {"config": "tante_fno.yaml", "kernel_source_sha16": hashlib.sha256(open(os.path.join(ROOT, "tante_amd", "csrc", "spectral_dft.hip"), "rb").read()).hexdigest()[:16],
        "note": "separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --config configs/tante_fno.yaml --steps 2 --warmup 1 --no-cpu-baseline "
                "--no-roofline`; KiB; FETCH_SIZE doubled (16 B / lane or 128 B / half-wave streams: an upper bound for the narrower reads)", "kernels": {}}
@@ -82,8 +82,8 @@ for k, e in fno["kernels"].items():
     n_ = max(1, len(e["FETCH_SIZE"]))
     fno["kernels"][k] = {"launches_sampled": n_, "fetch_bytes_per_launch": round(fb / n_), "write_bytes_per_launch": round(wb / max(1, len(e["WRITE_SIZE"])))}
     tot_bytes += fb / n_ * n_ + wb / max(1, len(e["WRITE_SIZE"])) * n_
-    if k == "idft_rows_conv_kernel":
-        calls = n_
+    if k in ("idft_rows_conv_kernel", "idft_rows_conv_x3_kernel"):      # one of the two per SpectralLayer call (fp32 form / split-bf16 form)
+        calls += n_
 if calls:
     fno["spectral_layer"] = {"hbm_bytes_per_call": round(tot_bytes / calls), "calls_sampled": calls}
     json.dump(fno, open(os.path.join(out, f"{TAG}_pmc_fno.json"), "w"), indent=1)
