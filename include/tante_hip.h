@@ -174,6 +174,11 @@ int tante_axis_hw_film(float* x, const float* src, int64_t src_t_stride, int64_t
                        const float* s_emb, int T, int64_t BT, int nH, int nW, int C, const float* wh1, const float* bh1, const float* wh2,
                        const float* bh2, const float* ww1, const float* bw1, const float* ww2, const float* bw2, int compute, void* stream);
 
+/* tante_axis_hw out of place: xout = H- then W-propagator of xin, xin intact (a rollout keeps every Taylor order's stream for the one
+ * head launch without copying rows aside).  Whole-tile bf16 form only (as tante_axis_hw_train): -2 otherwise, and the caller copies. */
+int tante_axis_hw_oop(const float* xin, float* xout, int64_t BT, int nH, int nW, int C, const float* wh1, const float* bh1, const float* wh2,
+                      const float* bh2, const float* ww1, const float* bw1, const float* ww2, const float* bw2, int compute, void* stream);
+
 /* The training forward of the two propagators in one launch, out of place: xout = H- then W-propagator of xin (xin stays intact for the
  * backward pass) and xmid = the planes between the two (the W propagator's input, which tante_axis_mlp_bwd needs).  bf16 compute,
  * whole 16-row tiles only (nH, nW multiples of 16 and the plane within the LDS): -2 otherwise, and the caller runs tante_axis_mlp twice. */
@@ -312,6 +317,11 @@ int tante_head_fused(const float* x, int32_t a_n0, int64_t a_s1, int64_t a_s0, i
  * updated in place by the later backbones); rows[n_ord - 1] is the stream itself, addressed through (a_n0, a_s1, a_s0, a_off) like
  * tante_head_fused.  head_streams[k]: tante_pack_head of decoder k.  The frame is read (`last`) and written once, not once per order. */
 int tante_head_fused_multi(int n_ord, const float* const* rows, const void* const* head_streams, const float* coefs, int32_t a_n0,
+                           int64_t a_s1, int64_t a_s0, int64_t a_off, int n_img, int Hp, int Wp, int C, int D, float* out,
+                           int64_t out_bstride, const float* last, int64_t last_bstride, void* stream);
+/* The same with every order's rows addressed by (a_n0, a_s1, a_s0, a_off): rows[k] = the whole residual stream as backbone k left it
+ * (each backbone writes a buffer of its own through tante_axis_hw_oop; nothing is copied aside). */
+int tante_head_fused_multi_streams(int n_ord, const float* const* rows, const void* const* head_streams, const float* coefs, int32_t a_n0,
                            int64_t a_s1, int64_t a_s0, int64_t a_off, int n_img, int Hp, int Wp, int C, int D, float* out,
                            int64_t out_bstride, const float* last, int64_t last_bstride, void* stream);
 

@@ -84,6 +84,7 @@ SIGNATURES = {
     "tante_axis_mlp_oop": ([c_vp, c_vp, c_i64, c_i32, c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp], c_i32),
     "tante_axis_hw": ([c_vp, c_i64, c_i32, c_i32, c_i32] + [c_vp] * 8 + [c_i32, c_vp], c_i32),
     "tante_axis_hw_film": ([c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_i32, c_i32] + [c_vp] * 8 + [c_i32, c_vp], c_i32),
+    "tante_axis_hw_oop": ([c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp], c_i32),
     "tante_axis_hw_train": ([c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp], c_i32),
     "tante_film_table": ([c_vp, c_i32, c_i32] + [c_vp] * 8 + [c_vp, c_vp, c_vp, c_vp], c_i32),
     "tante_film_apply": ([c_vp, c_i64, c_vp, c_i64, c_i32, c_i64, c_vp, c_vp, c_vp], c_i32),
@@ -179,6 +180,8 @@ SIGNATURES = {
     "tante_set_option": ([C.c_char_p, c_i32], c_i32),
     "tante_nan_to_num": ([c_vp, c_vp, c_i64, c_vp], c_i32),
     "tante_head_fused_multi": ([c_i32, c_vp, c_vp, c_vp, c_i32, c_i64, c_i64, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp, c_i64,
+                               c_vp], c_i32),
+    "tante_head_fused_multi_streams": ([c_i32, c_vp, c_vp, c_vp, c_i32, c_i64, c_i64, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp, c_i64,
                                c_vp], c_i32),
     "tante_get_option": ([C.c_char_p, c_i32], c_i32),
 }

@@ -211,12 +211,20 @@ class Attn_Backbone(nn.Module):
                     for cb in self.channel_blocks]
         return self._cache.get(compute, params, build)
 
-    def forward_tokens(self, x: torch.Tensor, B: int, compute: int, film_src: Optional[tuple] = None) -> torch.Tensor:
+    def takes_x_in(self, compute: int) -> bool:
+        """forward_tokens(x, ..., x_in=other) can read its input from another buffer (the first propagator launch runs out of place)."""
+        return K.axis_hw_train_supported(self.H, self.W, self.C, compute)
+
+    def forward_tokens(self, x: torch.Tensor, B: int, compute: int, film_src: Optional[tuple] = None, x_in: Optional[torch.Tensor] = None) -> torch.Tensor:
         """In place on x = (B,T,H,W,C) fp32 contiguous.  film_src = (z, t_stride, b_stride, film): x is not read but produced from the
-        frame-major pre-FiLM encoder cache z while the first propagator kernel loads its planes (TANTE.forward(enc_cache=...))."""
+        frame-major pre-FiLM encoder cache z while the first propagator kernel loads its planes (TANTE.forward(enc_cache=...)).
+        x_in (takes_x_in): the input stream, left intact -- x is only written."""
         T, H, W, C_ = self.T, self.H, self.W, self.C
         vp, hp, tp = self.vertical_propagator, self.horizontal_propagator, self.temporal_propagator
-        if film_src is not None:
+        if x_in is not None:
+            K.axis_hw_oop(x_in, x, B * T, H, W, C_, (vp[0].weight, vp[0].bias, vp[2].weight, vp[2].bias),
+                          (hp[0].weight, hp[0].bias, hp[2].weight, hp[2].bias), compute)
+        elif film_src is not None:
             z, ts, bs, film = film_src
             K.axis_hw_film(x, z, ts, bs, film, B * T, H, W, C_, (vp[0].weight, vp[0].bias, vp[2].weight, vp[2].bias),
                            (hp[0].weight, hp[0].bias, hp[2].weight, hp[2].bias), compute)

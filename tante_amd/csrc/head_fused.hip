@@ -459,9 +459,27 @@ extern "C" int tante_head_fused(const float* x, int32_t a_n0, int64_t a_s1, int6
  * (tante.py:145-154, 165-171 with output_length = 1).  rows_k, k < n_ord - 1: dense (n_img Hp Wp, C) fp32 copies of the last-slot token
  * rows as backbone k left them (the stream is updated in place by the later backbones); the last order reads the stream itself through
  * (a_n0, a_s1, a_s0, a_off) like tante_head_fused.  The frame is read (from `last`) and written once instead of once per order. */
+static int head_fused_multi_impl(int n_ord, const float* const* rows, const void* const* head_streams, const float* coefs, int32_t a_n0,
+                                 int64_t a_s1, int64_t a_s0, int64_t a_off, int n_img, int Hp, int Wp, int C, int D, float* out,
+                                 int64_t out_bstride, const float* last, int64_t last_bstride, void* stream, bool dense_copies);
+
 extern "C" int tante_head_fused_multi(int n_ord, const float* const* rows, const void* const* head_streams, const float* coefs, int32_t a_n0,
                                       int64_t a_s1, int64_t a_s0, int64_t a_off, int n_img, int Hp, int Wp, int C, int D, float* out,
                                       int64_t out_bstride, const float* last, int64_t last_bstride, void* stream) {
+  return head_fused_multi_impl(n_ord, rows, head_streams, coefs, a_n0, a_s1, a_s0, a_off, n_img, Hp, Wp, C, D, out, out_bstride, last, last_bstride, stream, true);
+}
+
+/* The same with EVERY order's rows addressed like the last one's, rows[k] = the whole residual stream backbone k left (the backbones
+ * write their streams into buffers of their own, tante_axis_hw_oop: nothing is copied aside). */
+extern "C" int tante_head_fused_multi_streams(int n_ord, const float* const* rows, const void* const* head_streams, const float* coefs, int32_t a_n0,
+                                              int64_t a_s1, int64_t a_s0, int64_t a_off, int n_img, int Hp, int Wp, int C, int D, float* out,
+                                              int64_t out_bstride, const float* last, int64_t last_bstride, void* stream) {
+  return head_fused_multi_impl(n_ord, rows, head_streams, coefs, a_n0, a_s1, a_s0, a_off, n_img, Hp, Wp, C, D, out, out_bstride, last, last_bstride, stream, false);
+}
+
+static int head_fused_multi_impl(int n_ord, const float* const* rows, const void* const* head_streams, const float* coefs, int32_t a_n0,
+                                 int64_t a_s1, int64_t a_s0, int64_t a_off, int n_img, int Hp, int Wp, int C, int D, float* out,
+                                 int64_t out_bstride, const float* last, int64_t last_bstride, void* stream, bool dense_copies) {
   if (!rows || !head_streams || !coefs || !out || !last) TANTE_FAIL(-1, "tante_head_fused_multi: null pointer");
   if (n_ord < 1 || n_ord > 4) TANTE_FAIL(-2, "tante_head_fused_multi: 1 .. 4 orders");
   if (!tante_head_fused_supported(C, D)) TANTE_FAIL(-2, "tante_head_fused_multi: unsupported C=%d D=%d", C, D);
@@ -484,7 +502,8 @@ extern "C" int tante_head_fused_multi(int n_ord, const float* const* rows, const
   A.xk0 = xs[0]; A.xk1 = xs[1]; A.xk2 = xs[2]; A.xk3 = xs[3];
   A.wk0 = ws[0]; A.wk1 = ws[1]; A.wk2 = ws[2]; A.wk3 = ws[3];
   A.ck0 = cs[0]; A.ck1 = cs[1]; A.ck2 = cs[2]; A.ck3 = cs[3];
-  A.m_n0 = n_img * Hp * Wp; A.m_s1 = 0; A.m_s0 = C; A.m_off = 0;      // the copies: dense rows
+  if (dense_copies) { A.m_n0 = n_img * Hp * Wp; A.m_s1 = 0; A.m_s0 = C; A.m_off = 0; }      // the copies: dense rows
+  else { A.m_n0 = a_n0; A.m_s1 = a_s1; A.m_s0 = a_s0; A.m_off = a_off; }                       // whole streams, addressed like the last order's
   A.debug = 0;
   A.stamps = nullptr;
   if (C == 128) launch_head<4, true>(A, (hipStream_t)stream);

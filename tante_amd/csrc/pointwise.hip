@@ -905,6 +905,14 @@ extern "C" int tante_axis_hw_train(const float* xin, float* xout, float* xmid, i
   return axis_hw_impl(xout, none, BT, nH, nW, C, wh1, bh1, wh2, bh2, ww1, bw1, ww2, bw2, compute, stream, xin, xmid);
 }
 
+extern "C" int tante_axis_hw_oop(const float* xin, float* xout, int64_t BT, int nH, int nW, int C, const float* wh1, const float* bh1,
+                                 const float* wh2, const float* bh2, const float* ww1, const float* bw1, const float* ww2, const float* bw2,
+                                 int compute, void* stream) {
+  if (!xin || ((uintptr_t)xin % 16) || xin == xout) TANTE_FAIL(-1, "tante_axis_hw_oop: null or misaligned source (or source == destination: use tante_axis_hw)");
+  const AxisSrc none = {nullptr, 0, 0, nullptr, nullptr, nullptr, 1};
+  return axis_hw_impl(xout, none, BT, nH, nW, C, wh1, bh1, wh2, bh2, ww1, bw1, ww2, bw2, compute, stream, xin, nullptr);
+}
+
 extern "C" int tante_axis_hw(float* x, int64_t BT, int nH, int nW, int C, const float* wh1, const float* bh1, const float* wh2,
                              const float* bh2, const float* ww1, const float* bw1, const float* ww2, const float* bw2,
                              int compute, void* stream) {

@@ -242,6 +242,14 @@ def axis_hw(x: torch.Tensor, BT: int, nH: int, nW: int, C_: int, vp, hp, compute
     return x
 
 
+def axis_hw_oop(xin: torch.Tensor, xout: torch.Tensor, BT: int, nH: int, nW: int, C_: int, vp, hp, compute: int):
+    """axis_hw out of place (xin intact); only where axis_hw_train_supported says so."""
+    ws = [p.detach() for p in (*vp, *hp)]
+    _dev(xin, xout, *ws)
+    L.check(L.lib().tante_axis_hw_oop(_p(xin), _p(xout), BT, nH, nW, C_, *[_p(w) for w in ws], compute, _stream()), "tante_axis_hw_oop")
+    return xout
+
+
 def axis_hw_train(x: torch.Tensor, BT: int, nH: int, nW: int, C_: int, vp, hp, compute: int):
     """Training forward of the H and W propagators in one launch, out of place: -> (y, x_mid) with x_mid the planes between the two
     (the W propagator's input); x is left intact.  Only where axis_hw_supported(..., BF16)'s whole-tile form applies."""
@@ -440,7 +448,7 @@ def head_fused(x: torch.Tensor, a_n0: int, a_s1: int, a_s0: int, a_off: int, n_i
 
 def head_fused_multi(rows: Sequence[torch.Tensor], a_n0: int, a_s1: int, a_s0: int, a_off: int, n_img: int, Hp: int, Wp: int, C_: int, D: int,
                      head_streams: Sequence[torch.Tensor], coefs: Sequence[float], out: torch.Tensor, out_bstride: int, last: torch.Tensor,
-                     last_elem_off: int, last_bstride: int):
+                     last_elem_off: int, last_bstride: int, streams: bool = False):
     """out = last + sum_k coefs[k] * head_k(rows[k]) in ONE launch (one prediction frame).  rows[:-1]: dense (n_img * Hp * Wp, C_) fp32 copies of
     the last-slot token rows after each earlier backbone; rows[-1]: the stream itself, addressed by (a_n0, a_s1, a_s0, a_off)."""
     n = len(rows)
@@ -450,8 +458,9 @@ def head_fused_multi(rows: Sequence[torch.Tensor], a_n0: int, a_s1: int, a_s0: i
     rp = (C.c_void_p * n)(*[r.data_ptr() for r in rows])
     sp = (C.c_void_p * n)(*[h.data_ptr() for h in head_streams])
     cf = (C.c_float * n)(*[float(c) for c in coefs])
-    L.check(L.lib().tante_head_fused_multi(n, rp, sp, cf, a_n0, a_s1, a_s0, a_off, n_img, Hp, Wp, C_, D, out.data_ptr(), out_bstride,
-                                           last.data_ptr() + 4 * last_elem_off, last_bstride, _stream()), "tante_head_fused_multi")
+    fn = L.lib().tante_head_fused_multi_streams if streams else L.lib().tante_head_fused_multi      # streams: every rows[k] is a whole stream
+    L.check(fn(n, rp, sp, cf, a_n0, a_s1, a_s0, a_off, n_img, Hp, Wp, C_, D, out.data_ptr(), out_bstride,
+               last.data_ptr() + 4 * last_elem_off, last_bstride, _stream()), "tante_head_fused_multi")
     return out
 
 

@@ -54,6 +54,7 @@ class TanteMetadata:
 
 
 HEAD_MULTI = __import__("os").environ.get("TANTE_HEAD_MULTI", "1") != "0"      # every Taylor order's derivative head in one launch
+HEAD_STREAMS = __import__("os").environ.get("TANTE_HEAD_STREAMS", "1") != "0"  # ... reading each order's own stream buffer (no row copies)
 
 
 def _check_patch_cfg(patch_scale, overlap_ratio):
@@ -509,19 +510,27 @@ class TANTE(nn.Module):
         # (8 MB each at cfg2) because the later backbones update the stream in place.  TANTE_HEAD_MULTI=0: one launch per order (A/B).
         multi_head = (self.deg and fused_head and self.output_length == 1 and 2 <= self.taylor_order <= 4 and HEAD_MULTI)
         saved_rows = []
+        # ... or not copied at all: every later backbone writes a stream buffer of its own (its first launch, the H + W propagator pass,
+        # runs out of place: tante_axis_hw_oop), so the earlier orders' streams stay intact for the head.  TANTE_HEAD_STREAMS=0: copies.
+        streams = multi_head and HEAD_STREAMS and all(b.takes_x_in(compute) for b in self.blocks[1:self.taylor_order])
         for i in range(self.taylor_order):
-            self.blocks[i].forward_tokens(x, B, compute, film_src=(enc_cache + (film,)) if (enc_cache is not None and i == 0) else None)  # l.146 (chained)
+            if streams and i > 0:
+                x_prev, x = x, torch.empty_like(x)
+                self.blocks[i].forward_tokens(x, B, compute, x_in=x_prev)
+            else:
+                self.blocks[i].forward_tokens(x, B, compute, film_src=(enc_cache + (film,)) if (enc_cache is not None and i == 0) else None)  # l.146 (chained)
             if self.deg:
                 if multi_head:
                     if i + 1 < self.taylor_order:
-                        saved_rows.append(x.view(B, T, HW * C_)[:, T - 1].clone(memory_format=torch.contiguous_format).view(B * HW, C_))      # (a COPY also at B = 1)
+                        saved_rows.append(x if streams else
+                                          x.view(B, T, HW * C_)[:, T - 1].clone(memory_format=torch.contiguous_format).view(B * HW, C_))      # (a COPY also at B = 1)
                         continue
                     if out is None:
                         out = torch.empty(B, 1, D, H, W, dtype=torch.float32, device=x.device)
                     coefs = [self.frame_interval ** (k + 1) / math.factorial(k + 1) for k in range(self.taylor_order)]
                     K.head_fused_multi(saved_rows + [x], HW, T * HW * C_, C_, (T - 1) * HW * C_, B, Hp, Wp, C_, D,
                                        [self.decoders[k].packed_head() for k in range(self.taylor_order)], coefs, out, out.stride(0),
-                                       inp, (T - 1) * frame, bstride)                                          # l.147,153,165-171
+                                       inp, (T - 1) * frame, bstride, streams=streams)                          # l.147,153,165-171
                 elif fused_head:
                     if out is None:
                         out = torch.empty(B, self.output_length, D, H, W, dtype=torch.float32, device=x.device)

@@ -287,6 +287,15 @@ def test_multi_order_head_launch_equals_per_order_launches(dev, order, axes):
     cfg = O.TanteCfg(4, 5, (64, 96), taylor_order=order, attn_axes=axes, n_head=8, embed_dim=256, patch_scale=8, frame_interval=0.5)
     ref = O.tante_forward({k: v.detach().cpu() for k, v in m.state_dict().items()}, cfg, x[:1])
     close(outs[0][:1], ref, "bf16", f"multi-order head, order {order}, vs oracle")
+    # every order's stream in a buffer of its own (tante_axis_hw_oop + tante_head_fused_multi_streams) against the row copies: bit for bit
+    saved_s = TT.HEAD_STREAMS
+    try:
+        TT.HEAD_STREAMS = False
+        with torch.no_grad():
+            copies = m(x.to(dev)).cpu()
+    finally:
+        TT.HEAD_STREAMS = saved_s
+    assert torch.equal(outs[0], copies)
 
 
 @pytest.mark.parametrize("n,C,H,W,P,pad,dt", [(2, 32, 64, 96, 4, 1, "bf16"), (1, 128, 32, 32, 2, 0, "bf16"), (3, 5, 20, 36, 4, 1, "fp32"), (1, 8, 512, 512, 4, 1, "bf16"),
