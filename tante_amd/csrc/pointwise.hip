@@ -5,6 +5,9 @@
 #include <mutex>
 #include <algorithm>
 
+int tante_axis_mlp_mfma_supported(int64_t outer, int n, int64_t inner, const void* x, const void* w1, const void* w2);      // axis_mfma.hip
+int tante_axis_mlp_mfma(float* x, int64_t outer, int n, int64_t inner, const float* w1, const float* b1, const float* w2, const float* b2, hipStream_t s);
+
 namespace {
 
 // ---- axis propagator:  x += W2 gelu_erf(W1 x_line + b1) + b2  along a strided axis -------------------
@@ -822,6 +825,13 @@ extern "C" int tante_axis_mlp_c(float* x, int64_t outer, int n, int64_t inner, c
                                 const float* b2, int compute, void* stream) {
   if (!x || !w1 || !b1 || !w2 || !b2) TANTE_FAIL(-1, "tante_axis_mlp_c: null pointer");
   if (outer <= 0 || n <= 0 || inner <= 0) TANTE_FAIL(-1, "tante_axis_mlp_c: bad shape");
+  // long axes in the bf16 mode: the two n x n products on the matrix pipe (axis_mfma.hip); TANTE_AXIS_MFMA = 0: the fp32 vector kernel
+  if (compute == TANTE_BF16 && tante_axis_mlp_mfma_supported(outer, n, inner, x, w1, w2) && ((uintptr_t)b1 % 16) == 0 && ((uintptr_t)b2 % 16) == 0 &&
+      tante_opt("TANTE_AXIS_MFMA", 1)) {
+    const int rc = tante_axis_mlp_mfma(x, outer, n, inner, w1, b1, w2, b2, (hipStream_t)stream);
+    if (rc) TANTE_FAIL(rc, "tante_axis_mlp_c: matrix-pipe propagator launch failed");
+    return 0;
+  }
   if (n <= 8 && inner % 4 == 0 && ((uintptr_t)x % 16) == 0) {
     hipStream_t s = (hipStream_t)stream;
     const long cols = outer * (inner / 4);

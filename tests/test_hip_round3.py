@@ -458,3 +458,30 @@ def test_spectral_layer_split_bf16_inverse_rows(dev, n, Cin, Cout, H, W, m1, m2)
         assert r < bar and m < 2 * bar, (act, r, m)
     ref = torch.nn.functional.gelu(SO.spectral_layer({"weight": torch.complex(wre, wim), "w0.weight": w0.view(Cout, Cin, 1, 1), "w0.bias": b0}, x, m1, m2))
     close(y16, ref, "bf16", "split-bf16 spectral layer vs oracle", scale=1e-2)
+
+
+@pytest.mark.parametrize("outer,n,inner", [(3, 64, 512), (8, 64, 256 * 64), (5, 16, 256), (2, 48, 768), (7, 32, 256)])
+def test_axis_propagator_on_the_matrix_pipe(dev, outer, n, inner):
+    """tante_axis_mlp_c in the bf16 mode for long axes (n = 16 .. 64, inner a multiple of 256: cfg5's 64 x 64 planes) -- the two n x n
+    products of nn.Sequential(Linear(n, n), GELU, Linear(n, n)) (attn_backbone.py:100-106, 140-143) on bf16 MFMAs, the residual in fp32 --
+    against a float64 restatement at the bf16 bar, and against the fp32 vector kernel it replaces (TANTE_AXIS_MFMA = 0) at the same bar."""
+    from tante_amd import _lib as L, kernels as Kk
+    g = torch.Generator().manual_seed(outer * n)
+    x = torch.randn(outer, n, inner, generator=g)
+    w1, w2 = torch.randn(n, n, generator=g) / n ** 0.5, torch.randn(n, n, generator=g) / n ** 0.5
+    b1, b2 = torch.randn(n, generator=g) * 0.1, torch.randn(n, generator=g) * 0.1
+    xd = x.double()
+    ref = xd + torch.einsum("pq,oqi->opi", w2.double(), torch.nn.functional.gelu(torch.einsum("pq,oqi->opi", w1.double(), xd) + b1.double()[None, :, None])) \
+        + b2.double()[None, :, None]
+    outs = []
+    try:
+        for mf in (1, 0):
+            L.set_option("TANTE_AXIS_MFMA", mf)
+            y = x.clone().to(dev)
+            Kk.axis_mlp(y, outer, n, inner, w1.to(dev), b1.to(dev), w2.to(dev), b2.to(dev), L.BF16)
+            outs.append(y.cpu())
+    finally:
+        L.set_option("TANTE_AXIS_MFMA", 1)
+    # the propagator's own contribution (output minus the residual input) carries the bf16 rounding
+    close(outs[0] - x, (ref - xd).float(), "bf16", f"matrix-pipe propagator n={n} vs float64")
+    close(outs[1] - x, (ref - xd).float(), "fp32", f"vector propagator n={n} vs float64", scale=10)
