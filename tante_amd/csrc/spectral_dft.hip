@@ -147,25 +147,37 @@ __global__ __launch_bounds__(256) void dft_cols_kernel(const float* __restrict__
 
 // ---- C: channel mixing on the kept modes.  Y[n, i2, j, o] = scale sum_c X[n, c, i2, j] Wt[c, o, wi, j]
 __global__ void spectral_mix_kernel(const float2* __restrict__ X, const float* __restrict__ w_re, const float* __restrict__ w_im, long n, int Cin,
-                                    int Cout, int m1, int m2, int wm1, int wm2, float scale, float2* __restrict__ Y) {
+                                    int Cout, int m1, int m2, int wm1, int wm2, float scale, float2* __restrict__ Y, int CS) {
+  // CS (a power of two <= 16) neighbouring lanes share one output and split its sum over the input channels: with few kept modes the
+  // launch has only n Cout 2 m1 m2 outputs (6 400 at 128 x 128 with 5 x 5 modes), and one thread walking all 128 channels of its
+  // output -- three dependent-latency loads per step -- made a 25-workgroup launch of 55 us
   const long total = n * Cout * 2 * m1 * m2;
-  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-    const int j = (int)(idx % m2);
-    long q = idx / m2;
+  const long nthr = (long)gridDim.x * blockDim.x / CS;
+  const int seg = threadIdx.x & (CS - 1);
+  for (long idx = ((long)blockIdx.x * blockDim.x + threadIdx.x) / CS; idx < (total + nthr - 1) / nthr * nthr; idx += nthr) {
+    const bool live = idx < total;
+    const long id = live ? idx : 0;
+    const int j = (int)(id % m2);
+    long q = id / m2;
     const int i2 = (int)(q % (2 * m1)); q /= 2 * m1;
     const int o = (int)(q % Cout);
     const long b = q / Cout;
     const int wi = i2 < m1 ? i2 : i2 - m1;
     float ar = 0.f, ai = 0.f;
 #pragma unroll 8
-    for (int c = 0; c < Cin; ++c) {
+    for (int c = seg; c < Cin; c += CS) {
       const float2 xv = X[((b * Cin + c) * 2 * m1 + i2) * m2 + j];
       const long wo = (((long)c * Cout + o) * wm1 + wi) * wm2 + j;
       const float wr = w_re[wo], wim = w_im[wo];
       ar += xv.x * wr - xv.y * wim;
       ai += xv.x * wim + xv.y * wr;
     }
-    Y[((b * 2 * m1 + i2) * m2 + j) * Cout + o] = make_float2(ar * scale, ai * scale);      // [n][i2][j][o]: kernel D's lanes run over o
+    for (int d = 1; d < CS; d <<= 1) {
+      ar += __shfl_xor(ar, d);
+      ai += __shfl_xor(ai, d);
+    }
+    if (live && seg == 0)
+      Y[((b * 2 * m1 + i2) * m2 + j) * Cout + o] = make_float2(ar * scale, ai * scale);      // [n][i2][j][o]: kernel D's lanes run over o
   }
 }
 
@@ -238,9 +250,15 @@ __global__ __launch_bounds__(1024) void idft_rows_conv_kernel(const float* __res
     const float a = j == 0 ? 1.0f : 2.0f;
     G[e] = k < m2 ? a * c : -a * s;
   }
-  for (int e = tid; e < Cin * CP; e += blockDim.x) {
-    const int c = e / CP, o = e % CP;
-    wt[e] = o < Cout ? w0[(long)o * Cin + c] : 0.0f;
+  // (global side contiguous: with o fastest every lane fetched its own 64-byte segment -- for the 64 -> 128 channel layers that
+  // prologue, repeated by every one-row workgroup, was most of the launch)
+  for (int e = tid; e < Cout * Cin; e += blockDim.x) {
+    const int o = e / Cin, c = e - o * Cin;
+    wt[c * CP + o] = w0[e];
+  }
+  for (int e = tid; e < Cin * (CP - Cout); e += blockDim.x) {
+    const int c = e / (CP - Cout), o = Cout + e - c * (CP - Cout);
+    wt[c * CP + o] = 0.0f;
   }
   __syncthreads();
   const int w0c = 32 * wave;
@@ -550,8 +568,10 @@ int tante_spectral_dft_forward(const float* x, int64_t n, int Cin, int H, int W,
     default: return -2;
   }
   const long totalC = (long)n * Cout * 2 * m1 * m2;
-  hipLaunchKernelGGL(spectral_mix_kernel, dim3((unsigned)std::min<long>(4096, (totalC + 255) / 256)), dim3(256), 0, s, X, w_re, w_im, (long)n, Cin, Cout,
-                     m1, m2, wm1, wm2, 1.0f / ((float)H * (float)W), Y);
+  int cs = 1;
+  while (cs < 16 && 2 * cs <= Cin && totalC * cs < 65536) cs *= 2;
+  hipLaunchKernelGGL(spectral_mix_kernel, dim3((unsigned)std::min<long>(4096, (totalC * cs + 255) / 256)), dim3(256), 0, s, X, w_re, w_im, (long)n, Cin, Cout,
+                     m1, m2, wm1, wm2, 1.0f / ((float)H * (float)W), Y, cs);
   const dim3 gridD((unsigned)((H + 7) / 8), (unsigned)n);
   switch (2 * m1) {
 #define TANTE_DFT_D(V) case V: hipLaunchKernelGGL(idft_cols_kernel<V>, gridD, dim3(256), 0, s, Y, H, Cout, m2, Z); break;
