@@ -611,6 +611,22 @@ int tante_wgrad_multi(const TanteRowMat* U, const TanteRowMat* V, int n_seg, int
 int tante_wgrad_multi_ws(const TanteRowMat* U, const TanteRowMat* V, int n_seg, int64_t R, int I, int J, float* dW, float* dbias, int layout,
                          int P, int C_other, int swap, int compute, int accumulate, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* Several weights' gradients in one launch: each job is a tante_wgrad_multi_ws call with accumulate = 1 (dW += sum_g U_g^T V_g, dbias
+ * likewise).  Up to four jobs of dense bf16 rows (I, J multiples of 128, R % 32 == 0) share the launch's workgroups -- a quarter of the
+ * row splits, partial tiles and ramp each (the four weights of a transformer block: trainer step, one launch per block instead of
+ * four) -- and one reduce launch; anything else runs job by job. */
+typedef struct TanteWgradJob {
+  const TanteRowMat* U;
+  const TanteRowMat* V;
+  int32_t n_seg;
+  int64_t R;
+  int32_t I, J;
+  float* dW;
+  float* dbias;
+  int32_t layout, P, C_other, swap;
+} TanteWgradJob;
+int tante_wgrad_jobs_ws(const TanteWgradJob* jobs, int n_jobs, int compute, void* workspace, int64_t workspace_bytes, void* stream);
+
 const char* tante_last_error(void);
 int tante_abi_version(void);
 

@@ -41,6 +41,11 @@ class RowMat(C.Structure):
                 ("n0", c_i32), ("Hin", c_i32), ("Win", c_i32), ("Cin", c_i32), ("P", c_i32)]
 
 
+class WgradJob(C.Structure):      # TanteWgradJob
+    _fields_ = [("U", C.POINTER(RowMat)), ("V", C.POINTER(RowMat)), ("n_seg", c_i32), ("R", c_i64), ("I", c_i32), ("J", c_i32), ("dW", c_vp), ("dbias", c_vp),
+                ("layout", c_i32), ("P", c_i32), ("C_other", c_i32), ("swap", c_i32)]
+
+
 class Seq(C.Structure):
     _fields_ = [("nseq", c_i32), ("L", c_i32), ("n_s0", c_i32), ("S1", c_i64), ("S0", c_i64),
                 ("n_l0", c_i32), ("P1", c_i64), ("P0", c_i64)]
@@ -121,6 +126,7 @@ SIGNATURES = {
     "tante_spectral_workspace_bytes": ([c_i64, c_i32, c_i32, c_i32, c_i32], c_i64),
     "tante_spectral_layer": ([c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp,
                               c_i64, c_vp], c_i32),
+    "tante_wgrad_jobs_ws": ([C.POINTER(WgradJob), c_i32, c_i32, c_vp, c_i64, c_vp], c_i32),
     "tante_spectral_layer_c": ([c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp,
                                 c_i64, c_i32, c_vp], c_i32),
     "tante_spectral_layer_bwd": ([c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp,

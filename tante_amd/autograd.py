@@ -205,9 +205,35 @@ def _wgrad_workspace(device) -> torch.Tensor:
     return ws
 
 
+WGRAD_JOBS = int(__import__("os").environ.get("TANTE_WGRAD_JOBS_PER_LAUNCH", "4"))      # weights per shared launch (1: one launch per weight)
+
+
 def _flush_wgrads(slot: Optional[torch.Tensor] = None):
     pend = _DEFER["pending"]
     keys = [k for k in pend if slot is None or k[0] == slot.data_ptr()]
+    if slot is None and WGRAD_JOBS > 1 and len(keys) > 1:
+        # the end-of-pass flush: consecutive recorded weights (the four of a block sit next to each other) as the jobs of one launch
+        ents = [pend.pop(k) for k in keys]
+        dev = ents[0][0].device
+        ws = _wgrad_workspace(dev)
+        i = 0
+        while i < len(ents):
+            grp = ents[i: i + WGRAD_JOBS]
+            if any(e[5] != grp[0][5] or e[0].device != dev for e in grp):      # mixed compute modes / devices: one at a time
+                grp = grp[:1]
+            i += len(grp)
+            jobs = (L.WgradJob * len(grp))()
+            keep = []
+            for jb, (gW, gb, M, N, Kk, comp, lay, uses) in zip(jobs, grp):
+                n = len(uses)
+                U = (L.RowMat * n)(*[_rm_linear(dy) for dy, _ in uses])
+                V = (L.RowMat * n)(*[_rm_linear(a) for _, a in uses])
+                keep.append((U, V))
+                jb.U, jb.V, jb.n_seg, jb.R, jb.I, jb.J = U, V, n, M, N, Kk
+                jb.dW, jb.dbias = gW.data_ptr(), None if gb is None else gb.data_ptr()
+                jb.layout, jb.P, jb.C_other, jb.swap = lay[0], lay[1], lay[2], int(lay[3])
+            L.check(L.lib().tante_wgrad_jobs_ws(jobs, len(grp), grp[0][5], ws.data_ptr(), ws.numel(), _s()), "tante_wgrad_jobs")
+        keys = []
     for k in keys:
         gW, gb, M, N, Kk, comp, lay, uses = pend.pop(k)
         n = len(uses)

@@ -391,10 +391,9 @@ struct WgSegs {
 // (a partial tile per row split is 64 KiB out, 64 KiB back into the reduce kernel: at 128 splits of a 256 x 256 weight that is
 // 2 x 33 MB beside 100 MB of operands).
 template <int WNBUF, int RG>   // ring depth: 4 (64 KB per row group) or 8 (128 KB: a lone 4-wave workgroup keeps 7 chunks = 112 KB in flight)
-__global__ __launch_bounds__(256 * RG, (WNBUF == 4 && RG == 1) ? 2 : 1) void wgrad_tr_kernel(const WgSegs SG, long ldu,
-                                                          long ldv, long R, int I, int J, long rows_per_split, float* __restrict__ dW,
-                                                          float* __restrict__ dbias, int layout, int P, int Co, int swap, int debug, int n_split,
-                                                          float* __restrict__ slab, float* __restrict__ bias_slab) {
+__device__ __forceinline__ void wgrad_tr_body(const WgSegs& SG, long ldu, long ldv, long R, int I, int J, long rows_per_split, float* __restrict__ dW,
+                                              float* __restrict__ dbias, int layout, int P, int Co, int swap, int debug, int n_split,
+                                              float* __restrict__ slab, float* __restrict__ bias_slab, const unsigned bid) {
   extern __shared__ __attribute__((aligned(16))) char wsm[];   // ring: [buf][U chunk | V chunk]
   const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3, grp = tid >> 8, kk = lane >> 4, l15 = lane & 15;
   // XCD-aware mapping: workgroups are dealt round-robin to the 8 XCDs by linear id, and every output tile of one row range re-reads
@@ -402,7 +401,7 @@ __global__ __launch_bounds__(256 * RG, (WNBUF == 4 && RG == 1) ? 2 : 1) void wgr
   // ones and every tile pulls its operand rows from HBM again.  id -> (xcd = id % 8, slot = id / 8); the slots of an XCD walk the tiles
   // of split 8 * (slot / ntile) + xcd.
   const int ti = I / WT, ntile = ti * (J / WT);
-  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int xcd = bid & 7, slot = bid >> 3;
   const int bz = (slot / ntile) * 8 + xcd, tile = slot % ntile;
   if (bz >= n_split) return;
   const int i0 = (tile % ti) * WT, j0 = (tile / ti) * WT;
@@ -566,11 +565,46 @@ __global__ __launch_bounds__(256 * RG, (WNBUF == 4 && RG == 1) ? 2 : 1) void wgr
   }
 }
 
+template <int WNBUF, int RG>
+__global__ __launch_bounds__(256 * RG, (WNBUF == 4 && RG == 1) ? 2 : 1) void wgrad_tr_kernel(const WgSegs SG, long ldu,
+                                                          long ldv, long R, int I, int J, long rows_per_split, float* __restrict__ dW,
+                                                          float* __restrict__ dbias, int layout, int P, int Co, int swap, int debug, int n_split,
+                                                          float* __restrict__ slab, float* __restrict__ bias_slab) {
+  wgrad_tr_body<WNBUF, RG>(SG, ldu, ldv, R, I, J, rows_per_split, dW, dbias, layout, P, Co, swap, debug, n_split, slab, bias_slab, blockIdx.x);
+}
+
+// ---- several weights in ONE launch (tante_wgrad_jobs_ws) ------------------------------------------------------------------------------------
+// A launch wants ~512 workgroups whatever the weight; alone, a 256 x 256 weight gets them by cutting its rows into 128 splits, and every
+// split costs a 64 KiB partial tile out and back (2 x 33 MB beside 100 MB of operands) plus the launch's own ramp, tail and reduce pass --
+// about half of the 45 + 8 us per weight.  The four weights of a block are gradients over the SAME number of rows at the same time: as
+// jobs of one launch they share the 512 workgroups (a quarter of the splits each, a quarter of the partial traffic), one ramp and one
+// reduce launch.  Every job keeps its own XCD-aware (split, tile) numbering from a workgroup id that starts at a multiple of 8.
+constexpr int WJOBS = 4;
+struct WgJob {
+  WgSegs SG;
+  long ldu, ldv, R, per;
+  float *dW, *dbias, *slab, *bias_slab;
+  int I, J, layout, P, Co, swap, n_split, wg_begin;
+};
+struct WgJobs {
+  WgJob j[WJOBS];
+  int n;
+};
+__global__ __launch_bounds__(256, 2) void wgrad_tr_jobs_kernel(const WgJobs JB) {
+  int k = 0;
+#pragma unroll
+  for (int q = 1; q < WJOBS; ++q)
+    if (q < JB.n && blockIdx.x >= (unsigned)JB.j[q].wg_begin) k = q;
+  const WgJob& jb = JB.j[k];
+  wgrad_tr_body<4, 1>(jb.SG, jb.ldu, jb.ldv, jb.R, jb.I, jb.J, jb.per, jb.dW, jb.dbias, jb.layout, jb.P, jb.Co, jb.swap, 0, jb.n_split, jb.slab,
+                      jb.bias_slab, blockIdx.x - (unsigned)jb.wg_begin);
+}
+
 // second stage: dW[i][j] += sum over the splits of a slab chunk (grid.y chunks of splits; one thread per 16-byte piece of a tile in the
 // register order wgrad_tr_kernel stored it in, so consecutive threads read consecutive 16 bytes); dbias likewise from the bias slab
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ bias_slab, int n_split,
-                                                          int ntile, int ti, int I, int J, float* __restrict__ dW, float* __restrict__ dbias,
-                                                          int layout, int P, int Co, int swap) {
+__device__ __forceinline__ void wgrad_reduce_body(const float* __restrict__ slab, const float* __restrict__ bias_slab, int n_split,
+                                                  int ntile, int ti, int I, int J, float* __restrict__ dW, float* __restrict__ dbias,
+                                                  int layout, int P, int Co, int swap) {
   const int per = (n_split + gridDim.y - 1) / gridDim.y, s0 = blockIdx.y * per, s1 = min(n_split, s0 + per);
   const int t = blockIdx.x * 256 + threadIdx.x;
   if (t < ntile * 4096 && s0 < s1) {
@@ -606,6 +640,24 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     for (; s < s1; ++s, q += I) b0 += q[0];
     atomicAdd(&dbias[t], ((b0 + b1) + (b2 + b3)) + ((b4 + b5) + (b6 + b7)));
   }
+}
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ bias_slab, int n_split,
+                                                          int ntile, int ti, int I, int J, float* __restrict__ dW, float* __restrict__ dbias,
+                                                          int layout, int P, int Co, int swap) {
+  wgrad_reduce_body(slab, bias_slab, n_split, ntile, ti, I, J, dW, dbias, layout, P, Co, swap);
+}
+struct RdJob {
+  const float *slab, *bias_slab;
+  float *dW, *dbias;
+  int n_split, ntile, ti, I, J, layout, P, Co, swap;
+};
+struct RdJobs {
+  RdJob j[WJOBS];
+};
+__global__ __launch_bounds__(256) void wgrad_reduce_jobs_kernel(const RdJobs JB) {      // grid.z = the job
+  const RdJob& jb = JB.j[blockIdx.z];
+  if ((int)blockIdx.x >= jb.ntile * 16) return;
+  wgrad_reduce_body(jb.slab, jb.bias_slab, jb.n_split, jb.ntile, jb.ti, jb.I, jb.J, jb.dW, jb.dbias, jb.layout, jb.P, jb.Co, jb.swap);
 }
 
 static bool wgrad_tr_ok(const TanteRowMat& m, long R, int ncols) {
@@ -783,5 +835,81 @@ extern "C" int tante_wgrad_multi_ws(const TanteRowMat* U, const TanteRowMat* V, 
     if (rc) return rc;
     ++g;
   }
+  return 0;
+}
+
+/* Up to four weight gradients (each: n_seg operand pairs of R rows, as tante_wgrad_multi_ws with accumulate = 1) as the jobs of ONE
+ * launch + one reduce launch, sharing the chip's workgroups: see wgrad_tr_jobs_kernel.  Jobs outside the dense-bf16 shape rules, a
+ * single job, or a workspace too small: each job runs as tante_wgrad_multi_ws. */
+extern "C" int tante_wgrad_jobs_ws(const TanteWgradJob* jobs, int n_jobs, int compute, void* workspace, int64_t workspace_bytes, void* stream) {
+  if (!jobs || n_jobs <= 0) TANTE_FAIL(-1, "tante_wgrad_jobs_ws: bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  auto one_by_one = [&]() -> int {
+    for (int k = 0; k < n_jobs; ++k) {
+      const TanteWgradJob& jb = jobs[k];
+      const int rc = tante_wgrad_multi_ws(jb.U, jb.V, jb.n_seg, jb.R, jb.I, jb.J, jb.dW, jb.dbias, jb.layout, jb.P, jb.C_other, jb.swap, compute, 1, workspace,
+                                          workspace_bytes, stream);
+      if (rc) return rc;
+    }
+    return 0;
+  };
+  bool ok = compute == TANTE_BF16 && n_jobs >= 2 && n_jobs <= WJOBS && workspace && ((uintptr_t)workspace % 16) == 0 && tante_opt("TANTE_WGRAD_JOBS", 1) &&
+            !tante_opt("TANTE_WGRAD_NO_SLAB", 0) && !tante_opt("TANTE_WGRAD_NO_TR", 0);
+  double work[WJOBS] = {0, 0, 0, 0}, work_sum = 0;
+  for (int k = 0; ok && k < n_jobs; ++k) {
+    const TanteWgradJob& jb = jobs[k];
+    if (!jb.U || !jb.V || !jb.dW || jb.n_seg < 1 || jb.n_seg > WSEG || jb.R <= 0 || jb.R % WRC || jb.I <= 0 || jb.J <= 0 || jb.I % WT || jb.J % WT) { ok = false; break; }
+    if (jb.layout < TANTE_W_LINEAR || jb.layout > TANTE_W_DECONV_NCHW) { ok = false; break; }
+    for (int g = 0; g < jb.n_seg; ++g)
+      if (!jb.U[g].p || !jb.V[g].p || !wgrad_tr_ok(jb.U[g], jb.R, jb.I) || !wgrad_tr_ok(jb.V[g], jb.R, jb.J) || jb.U[g].s0 != jb.U[0].s0 || jb.V[g].s0 != jb.V[0].s0) { ok = false; break; }
+    work[k] = (double)(jb.I / WT) * (jb.J / WT) * jb.n_seg * (double)jb.R;
+    work_sum += work[k];
+  }
+  if (!ok) return one_by_one();
+  WgJobs JB;
+  RdJobs RB;
+  JB.n = n_jobs;
+  const int wg_total = tante_opt("TANTE_WGRAD_JOBS_WGS", 512);
+  unsigned wg_begin = 0, max_red_x = 0;
+  int64_t ws_off = 0;      // floats
+  for (int k = 0; k < n_jobs; ++k) {
+    const TanteWgradJob& jb = jobs[k];
+    const int ti = jb.I / WT, tj = jb.J / WT, ntile = ti * tj;
+    const long nch = jb.R / WRC;
+    long split = (long)((double)wg_total * work[k] / work_sum) / ((long)ntile * jb.n_seg);      // splits per segment
+    if (split < 1) split = 1;
+    if (split > nch / 4) split = nch / 4 > 0 ? nch / 4 : 1;
+    long per = ((nch + split - 1) / split) * WRC;
+    while (jb.R % per && per < jb.R) per += WRC;      // rows_per_split must divide the segment
+    if (jb.R % per) return one_by_one();
+    const long total = (jb.R / per) * jb.n_seg;
+    if (total > 65535) return one_by_one();
+    WgJob& w = JB.j[k];
+    for (int g = 0; g < WSEG; ++g) {
+      const TanteRowMat& u = jb.U[g < jb.n_seg ? g : 0];
+      const TanteRowMat& v = jb.V[g < jb.n_seg ? g : 0];
+      w.SG.U[g] = (const unsigned short*)u.p + u.off;
+      w.SG.V[g] = (const unsigned short*)v.p + v.off;
+    }
+    w.SG.R_seg = (long)jb.R;
+    w.ldu = (long)jb.U[0].s0; w.ldv = (long)jb.V[0].s0; w.R = (long)jb.R * jb.n_seg; w.per = per;
+    w.dW = jb.dW; w.dbias = jb.dbias;
+    w.slab = (float*)workspace + ws_off;
+    w.bias_slab = w.slab + (int64_t)total * ntile * WT * WT;
+    ws_off += ((int64_t)total * ntile * WT * WT + (int64_t)total * jb.I + 3) / 4 * 4;
+    w.I = jb.I; w.J = jb.J; w.layout = jb.layout; w.P = jb.P; w.Co = jb.C_other; w.swap = jb.swap; w.n_split = (int)total; w.wg_begin = (int)wg_begin;
+    wg_begin += 8u * (unsigned)((total + 7) / 8) * (unsigned)ntile;
+    RdJob& r = RB.j[k];
+    r.slab = w.slab; r.bias_slab = w.bias_slab; r.dW = jb.dW; r.dbias = jb.dbias; r.n_split = (int)total; r.ntile = ntile; r.ti = ti; r.I = jb.I; r.J = jb.J;
+    r.layout = jb.layout; r.P = jb.P; r.Co = jb.C_other; r.swap = jb.swap;
+    if ((unsigned)(ntile * 16) > max_red_x) max_red_x = (unsigned)(ntile * 16);
+  }
+  for (int k = n_jobs; k < WJOBS; ++k) { JB.j[k] = JB.j[0]; JB.j[k].wg_begin = 0x7fffffff; RB.j[k] = RB.j[0]; RB.j[k].ntile = 0; }
+  if (ws_off * (int64_t)sizeof(float) > workspace_bytes) return one_by_one();
+  static TantePerDevice attr;
+  attr.once([&] { hipFuncSetAttribute((const void*)wgrad_tr_jobs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * WCHUNK); });
+  hipLaunchKernelGGL(wgrad_tr_jobs_kernel, dim3(wg_begin), dim3(256), (size_t)4 * 2 * WCHUNK, s, JB);
+  hipLaunchKernelGGL(wgrad_reduce_jobs_kernel, dim3(max_red_x, 1, (unsigned)n_jobs), dim3(256), 0, s, RB);
+  TANTE_CHECK_LAUNCH();
   return 0;
 }

@@ -485,3 +485,56 @@ def test_axis_propagator_on_the_matrix_pipe(dev, outer, n, inner):
     # the propagator's own contribution (output minus the residual input) carries the bf16 rounding
     close(outs[0] - x, (ref - xd).float(), "bf16", f"matrix-pipe propagator n={n} vs float64")
     close(outs[1] - x, (ref - xd).float(), "fp32", f"vector propagator n={n} vs float64", scale=10)
+
+
+def test_weight_gradient_jobs_share_a_launch(dev):
+    """tante_wgrad_jobs_ws: the four weight gradients of a block (768 x 256 and three 256 x 256, four BPTT uses of 1 536 rows each, bias
+    gradients on two of them) as the jobs of ONE launch against float64 and against the per-weight launches (tante_wgrad_multi_ws);
+    accumulation into non-zero gradient slots; a job outside the shape rules sends every job down the per-weight path."""
+    import ctypes as C
+    from tante_amd import _lib as L
+    from tante_amd.autograd import _rm_linear, _wgrad_workspace
+    torch.manual_seed(3)
+    R, n = 1536, 4
+    shapes = [(768, 256, True), (256, 256, False), (256, 256, True), (256, 256, False)]
+    ws = _wgrad_workspace(dev)
+    s = torch.cuda.current_stream().cuda_stream
+
+    def build(shapes):
+        ops, jobs, keep = [], (L.WgradJob * len(shapes))(), []
+        for jb, (I, J, bias) in zip(jobs, shapes):
+            dys = [torch.randn(R, I, device=dev).bfloat16() for _ in range(n)]
+            acts = [torch.randn(R, J, device=dev).bfloat16() for _ in range(n)]
+            gW = torch.randn(I, J, device=dev)
+            gb = torch.randn(I, device=dev) if bias else None
+            U = (L.RowMat * n)(*[_rm_linear(t) for t in dys])
+            V = (L.RowMat * n)(*[_rm_linear(t) for t in acts])
+            keep.append((U, V))
+            jb.U, jb.V, jb.n_seg, jb.R, jb.I, jb.J = U, V, n, R, I, J
+            jb.dW, jb.dbias = gW.data_ptr(), None if gb is None else gb.data_ptr()
+            jb.layout, jb.P, jb.C_other, jb.swap = L.W_LINEAR, 0, 0, 0
+            ops.append((dys, acts, gW, gb, gW.clone(), None if gb is None else gb.clone()))
+        return ops, jobs, keep
+
+    ops, jobs, keep = build(shapes)
+    L.check(L.lib().tante_wgrad_jobs_ws(jobs, len(shapes), L.BF16, ws.data_ptr(), ws.numel(), s), "tante_wgrad_jobs")
+    torch.cuda.synchronize()
+    for dys, acts, gW, gb, gW0, gb0 in ops:
+        ref = gW0.double() + sum(d.double().T @ a.double() for d, a in zip(dys, acts))
+        close(gW, ref.float(), "fp32", "wgrad jobs: dW", scale=10)
+        if gb is not None:
+            close(gb, (gb0.double() + sum(d.double().sum(0) for d in dys)).float(), "fp32", "wgrad jobs: dbias", scale=10)
+        # the per-weight launch on the same operands (from the same starting slots): the same sums, another split of the rows
+        g2, b2 = gW0.clone(), None if gb0 is None else gb0.clone()
+        U = (L.RowMat * n)(*[_rm_linear(t) for t in dys])
+        V = (L.RowMat * n)(*[_rm_linear(t) for t in acts])
+        L.check(L.lib().tante_wgrad_multi_ws(C.byref(U), C.byref(V), n, R, gW.shape[0], gW.shape[1], g2.data_ptr(), None if b2 is None else b2.data_ptr(),
+                                             L.W_LINEAR, 0, 0, 0, L.BF16, 1, ws.data_ptr(), ws.numel(), s), "tante_wgrad_multi")
+        close(gW, g2, "fp32", "wgrad jobs vs per-weight launch", scale=10)
+    # a 64-column job is outside the shared kernel's tiles: the call still returns the right sums (job by job)
+    ops, jobs, keep = build([(256, 256, True), (128, 64, False)])
+    L.check(L.lib().tante_wgrad_jobs_ws(jobs, 2, L.BF16, ws.data_ptr(), ws.numel(), s), "tante_wgrad_jobs")
+    torch.cuda.synchronize()
+    for dys, acts, gW, gb, gW0, gb0 in ops:
+        ref = gW0.double() + sum(d.double().T @ a.double() for d, a in zip(dys, acts))
+        close(gW, ref.float(), "fp32", "wgrad jobs (fallback): dW", scale=10)
