@@ -203,7 +203,7 @@ __global__ __launch_bounds__(64 * NW * G, 2) void block_fs_kernel(FsArgs A) {
   const int nlive = min(A.spw, A.sq.nseq - seq0) * L;     // live token slots of this workgroup (the rest of spw * L is dead)
   const int nslot = A.spw * L;                            // slots in use by whole sequences (<= 16 NTT)
 
-  const char* const wq = A.w + (RT * wave) * FS_FRAG + lane * 16;   // this wave's row tiles of (matrix 0, k-step 0), this lane's 16 bytes
+  const FsW wq = fs_wstream(A.w, (unsigned)((RT * wave) * FS_FRAG + lane * 16));   // this wave's row tiles of (matrix 0, k-step 0), this lane's 16 bytes
   u32x4 wb[PF + 1][RT];                                             // the weight stream's register ring
   // ---- slot -> token index (-1 = dead): every wave works the table out for itself, one or two slots per lane (the two divisions of
   // the axis regrouping), and hands the entries around with ds_bpermute -- no LDS table, no barrier in front of the first loads ----

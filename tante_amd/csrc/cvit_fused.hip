@@ -58,7 +58,7 @@ __host__ __device__ constexpr long x_woff(int g, int j) { return (long)(g >> 4) 
 
 // acc[j][tt] += W[row tile j of the wave's slice][all 512 k] . image[token tile tt]; the ring keeps prefetching into the NEXT matrix
 template <int M, int GEND, int NTT>
-__device__ __forceinline__ void x_gemm(const char* wu, unsigned voff, u32x4 (&wb)[x_pf(NTT) + 1][4], const unsigned (&ab)[4], f32x4 (&acc)[4][NTT]) {
+__device__ __forceinline__ void x_gemm(const FsW& wu, u32x4 (&wb)[x_pf(NTT) + 1][4], const unsigned (&ab)[4], f32x4 (&acc)[4][NTT]) {
   constexpr int XPF = x_pf(NTT);
   mfma_stream<16 * NTT, 4>(
       [&](auto ic) {
@@ -69,7 +69,7 @@ __device__ __forceinline__ void x_gemm(const char* wu, unsigned voff, u32x4 (&wb
         constexpr int i = decltype(ic)::value, ks = i / NTT, tt = i % NTT, g = 16 * M + ks;
         if constexpr (tt == 0 && g + XPF < GEND) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) wb[(g + XPF) % (XPF + 1)][j] = ldg_frag(wu + x_woff(g + XPF, j) + voff);
+          for (int j = 0; j < 4; ++j) wb[(g + XPF) % (XPF + 1)][j] = ldg_frag(wu, (int)x_woff(g + XPF, j));
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[j][tt] = mfma_bf16(wb[g % (XPF + 1)][j], tf, acc[j][tt]);
@@ -131,15 +131,14 @@ __global__ __launch_bounds__(512) void chain512_kernel(ChainArgs A) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kk = lane >> 4, l15 = lane & 15;
   const long tok0 = (long)blockIdx.x * XT;
   constexpr int NMAT = MODE == 0 ? 3 : 4, GEND = 16 * NMAT;
-  const unsigned voff = (unsigned)(wave * 65536 + lane * 16);
-  const char* wu = A.w;
+  const FsW wu = fs_wstream(A.w, (unsigned)(wave * 65536 + lane * 16));      // base in SGPRs, one VGPR lane offset, fragment offsets by the scalar unit
   const int f0 = 64 * wave + 4 * kk;      // + 16 j: the lane's four features of row tile j
 
   u32x4 wb[XPF + 1][4];
 #pragma unroll
   for (int p = 0; p < XPF; ++p)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) wb[p][j] = ldg_frag(wu + x_woff(p, j) + voff);
+    for (int j = 0; j < 4; ++j) wb[p][j] = ldg_frag(wu, (int)x_woff(p, j));
 
   // out_proj accumulators start from bias + residual rows
   f32x4 acc[4][NTT];
@@ -168,7 +167,7 @@ __global__ __launch_bounds__(512) void chain512_kernel(ChainArgs A) {
   __syncthreads();
 
   // ---- x1 = out_proj(a) + resid -------------------------------------------------------------------------------------------------
-  x_gemm<0, GEND, NTT>(wu, voff, wb, ab0, acc);
+  x_gemm<0, GEND, NTT>(wu, wb, ab0, acc);
   f32x4 x1[4][NTT];
 #pragma unroll
   for (int j = 0; j < 4; ++j)
@@ -191,7 +190,7 @@ __global__ __launch_bounds__(512) void chain512_kernel(ChainArgs A) {
   __syncthreads();
 
   // ---- h = gelu(fc1'(LN2(x1))) ----------------------------------------------------------------------------------------------------
-  x_gemm<1, GEND, NTT>(wu, voff, wb, ab1, acc);
+  x_gemm<1, GEND, NTT>(wu, wb, ab1, acc);
 #pragma unroll
   for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -205,7 +204,7 @@ __global__ __launch_bounds__(512) void chain512_kernel(ChainArgs A) {
   __syncthreads();
 
   // ---- x2 = x1 + fc2(h) -----------------------------------------------------------------------------------------------------------
-  x_gemm<2, GEND, NTT>(wu, voff, wb, ab0, acc);
+  x_gemm<2, GEND, NTT>(wu, wb, ab0, acc);
   if constexpr (MODE == 0) {
     float* op = A.out + (tok0 + l15) * XC + f0;
 #pragma unroll
@@ -235,7 +234,7 @@ __global__ __launch_bounds__(512) void chain512_kernel(ChainArgs A) {
     }
     __syncthreads();
     // ---- y = z + gelu(dense(z)) ---------------------------------------------------------------------------------------------------
-    x_gemm<3, GEND, NTT>(wu, voff, wb, ab1, acc);
+    x_gemm<3, GEND, NTT>(wu, wb, ab1, acc);
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll

@@ -14,6 +14,33 @@ constexpr int FS_BIAS_FLOATS = 7 * FS_C;                   // by output feature:
 constexpr int FS_ROW = 512;                                // bytes per token row of an LDS image
 
 __device__ __forceinline__ u32x4 ldg_frag(const char* p) { return *(const u32x4*)p; }
+// The weight stream through a buffer resource: address = base (4 SGPRs) + lane offset (ONE 32-bit VGPR for the whole kernel) + fragment
+// offset (an SGPR the scalar unit sets).  As plain global loads every fragment needed its own 64-bit vector address -- v_lshl_add_u64 /
+// v_add_co + v_addc per load, ~250 of the block kernel's 2 600 vector instructions per wave, in a kernel bound by vector issue.
+// (-DFS_NO_BUFW: the plain loads, for A/B.)  The stream is < 2 GiB; num_records is left at the maximum (nothing reads past the stream).
+struct FsW {
+#ifdef FS_NO_BUFW
+  const char* p;
+#else
+  __amdgpu_buffer_rsrc_t r;
+  unsigned voff;
+#endif
+};
+__device__ __forceinline__ FsW fs_wstream(const char* base, unsigned lane_off) {
+#ifdef FS_NO_BUFW
+  return FsW{base + lane_off};
+#else
+  return FsW{__builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000), lane_off};
+#endif
+}
+__device__ __forceinline__ u32x4 ldg_frag(const FsW& w, int byte_off) {
+#ifdef FS_NO_BUFW
+  return *(const u32x4*)(w.p + byte_off);
+#else
+  return __builtin_amdgcn_raw_buffer_load_b128(w.r, (int)w.voff, byte_off, 0);
+#endif
+}
+__device__ __forceinline__ u32x4 ldg_frag(const char* p, int byte_off) { return *(const u32x4*)(p + byte_off); }
 // timing experiment only (-DFS_EXP_NO_WLOAD, wrong results): every fragment load of the weight stream re-reads the stream's FIRST k-step
 // (16 KiB per workgroup, L1-resident) -- the same instructions and waits, none of the L2 -> L1 traffic.  Prices the weight stream.
 #ifdef FS_EXP_NO_WLOAD
@@ -68,15 +95,15 @@ __device__ __forceinline__ float rows_sum(float v) { return rows_reduce(v, [](fl
 constexpr int FS_KSTEPS = 48;
 // first PF k-steps of matrix M into the ring (the stream is primed twice per launch: before LayerNorm1 for q | k | v, after the
 // attention for Wo | W1 | W2; in between the GEMMs keep it running across their own boundaries, GEND = where the run ends)
-template <int M, int RT, int PF>
-__device__ __forceinline__ void fs_wring_prime(const char* wq, u32x4 (&wb)[PF + 1][RT]) {
+template <int M, int RT, int PF, class WP>
+__device__ __forceinline__ void fs_wring_prime(const WP& wq, u32x4 (&wb)[PF + 1][RT]) {
 #pragma unroll
   for (int p = 0; p < PF; ++p)
 #pragma unroll
-    for (int j = 0; j < RT; ++j) wb[(8 * M + p) % (PF + 1)][j] = ldg_frag(wq + FS_WOFF(16 * (8 * M + p) + j) * FS_FRAG);
+    for (int j = 0; j < RT; ++j) wb[(8 * M + p) % (PF + 1)][j] = ldg_frag(wq, FS_WOFF(16 * (8 * M + p) + j) * FS_FRAG);
 }
-template <int M, int GEND, int NTT, int RT, bool SWAP, int PF>
-__device__ __forceinline__ void fs_slice_gemm(const char* wq, u32x4 (&wb)[PF + 1][RT], const char* img, const int (&rdo)[4],
+template <int M, int GEND, int NTT, int RT, bool SWAP, int PF, class WP>
+__device__ __forceinline__ void fs_slice_gemm(const WP& wq, u32x4 (&wb)[PF + 1][RT], const char* img, const int (&rdo)[4],
                                               f32x4 (&acc)[RT][NTT]) {
   unsigned ab[4];
 #pragma unroll
@@ -93,7 +120,7 @@ __device__ __forceinline__ void fs_slice_gemm(const char* wq, u32x4 (&wb)[PF + 1
         constexpr int i = decltype(ic)::value, ks = i / NTT, tt = i % NTT, g = 8 * M + ks;
         if constexpr (tt == 0 && g + PF < GEND) {
 #pragma unroll
-          for (int j = 0; j < RT; ++j) wb[(g + PF) % (PF + 1)][j] = ldg_frag(wq + FS_WOFF(16 * (g + PF) + j) * FS_FRAG);
+          for (int j = 0; j < RT; ++j) wb[(g + PF) % (PF + 1)][j] = ldg_frag(wq, FS_WOFF(16 * (g + PF) + j) * FS_FRAG);
         }
 #ifdef FS_EXP_MFMA32
         // TIMING EXPERIMENT ONLY (wrong results): the same loads, the same operand and accumulator registers, half as many MFMAs of
