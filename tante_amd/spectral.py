@@ -97,8 +97,9 @@ class enc_FNO(nn.Module):
         n = B * T
         z = inp.contiguous().view(n, D, H, W)
         z = self.enc_spectral_1.run(z, L.ACT_GELU_ERF, compute)
-        y, h, w = S.conv_stage(z, True, n, self.chans[1], H, W, self.P[0], self.overlap, pk[0], compute, L.ACT_GELU_ERF, torch.float32, nchw_out=True)
-        z = self.enc_spectral_2.run(y, L.ACT_GELU_ERF, compute)
+        y, h, w = S.conv_stage(z, True, n, self.chans[1], H, W, self.P[0], self.overlap, pk[0], compute, L.ACT_GELU_ERF, torch.float32)
+        # (the GEMM's channels-first epilogue -- conv_stage(nchw_out=True) -- was measured at 96 us against 40 us + this 20 us copy)
+        z = self.enc_spectral_2.run(_to_nchw(y, n, h, w), L.ACT_GELU_ERF, compute)
         y, h, w = S.conv_stage(z, True, n, self.chans[3], h, w, self.P[1], self.overlap, pk[1], compute, L.ACT_NONE, torch.float32)
         if film is not None:
             fa, fb, se, Tt, HW = film
