@@ -27,8 +27,11 @@ namespace {
 
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 
+// (every product this file reduces -- mode index x position, kept row x row -- is below 2^31: a 32-bit unsigned remainder, a mask for the
+// power-of-two sizes.  As a 64-bit signed remainder it was ~80 instructions per table entry, most of kernel A's 40 us at W = 512.)
+__device__ __forceinline__ unsigned mod_u32(unsigned v, unsigned den) { return (den & (den - 1)) == 0 ? (v & (den - 1)) : v % den; }
 __device__ __forceinline__ void sincos_frac(long num, int den, float& s, float& c) {   // angle = 2 pi num / den, num reduced exactly
-  const int m = (int)(num % den);
+  const int m = (int)mod_u32((unsigned)num, (unsigned)den);
   sincospif(2.0f * (float)m / (float)den, &s, &c);
 }
 // kept row i2 in [0, 2 m1) -> spectrum row
@@ -55,7 +58,7 @@ __global__ __launch_bounds__(256) void dft_rows_kernel(const float* __restrict__
     const int w = e / (16 * NT), k = e % (16 * NT);
     float v = 0.0f;
     if (k < 2 * m2) {
-      const float2 t = base[(int)(((long)(k < m2 ? k : k - m2) * w) % W)];
+      const float2 t = base[mod_u32((unsigned)((k < m2 ? k : k - m2) * w), (unsigned)W)];
       v = k < m2 ? t.x : -t.y;
     }
     tw[w * TS + k] = v;
@@ -377,7 +380,7 @@ __global__ __launch_bounds__(256) void idft_rows_conv_x3_kernel(const float* __r
         v[q] = 0.0f;
         if (k < 2 * m2) {
           const int j = k < m2 ? k : k - m2;
-          const float2 t = base[(int)(((long)j * w) % W)];
+          const float2 t = base[mod_u32((unsigned)(j * w), (unsigned)W)];
           const float a = j == 0 ? 1.0f : 2.0f;
           v[q] = k < m2 ? a * t.x : -a * t.y;
         }
