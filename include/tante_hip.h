@@ -398,6 +398,11 @@ int tante_cross_attention(const void* q, const void* k, const void* v, void* o, 
 int tante_cvit_chain512(const void* a, const float* resid, int64_t resid_period, const void* w, const float* bias, const float* g2,
                         const float* b2, float eps_ln2, float eps_norm2, float eps_mlp, const void* wout, const float* bout, int out_dim,
                         int64_t M, int mode, float* out, void* stream);
+/* Mode 0 of tante_cvit_chain512 followed, in the same launch, by the NEXT SelfAttnBlock's input projection (cvit.py:129-134 of the block
+ * that follows): qkv (M, 1536) bf16 = in_proj'(LN1_next(out)), LN1 folded into the weights.  w: six packed matrices
+ * out_proj | fc1 | fc2 | Wq | Wk | Wv (the last three from the next block), bias (6, 512). */
+int tante_cvit_chain512_qkv(const void* a, const float* resid, int64_t resid_period, const void* w, const float* bias, float eps_ln2,
+                            float eps_ln1_next, int64_t M, float* out, void* qkv, void* stream);
 /* The same with the query rows of sample b starting at row b * q_batch_rows (q_batch_rows = Lq: tante_cross_attention; 0: every sample
  * attends with the SAME Lq queries -- the decoder's coordinate queries, cvit.py:452, whose projection is then computed once). */
 int tante_cross_attention_q(const void* q, const void* k, const void* v, void* o, int dtype, int64_t n_batch, int n_head, int D, int Lq,

@@ -136,6 +136,7 @@ SIGNATURES = {
                                    c_i64, c_i64, c_vp, c_vp], c_i32),
     "tante_cross_attention": ([c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_i32, c_i32, c_i32, c_i64, c_i64, c_i64, c_vp], c_i32),
     "tante_cvit_chain512": ([c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_f32, c_vp, c_vp, c_i32, c_i64, c_i32, c_vp, c_vp], c_i32),
+    "tante_cvit_chain512_qkv": ([c_vp, c_vp, c_i64, c_vp, c_vp, c_f32, c_f32, c_i64, c_vp, c_vp, c_vp], c_i32),
     "tante_cross_attention_q": ([c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_i32, c_i32, c_i32, c_i64, c_i64, c_i64, c_i64, c_vp], c_i32),
     "tante_cross_attention_bwd": ([c_vp] * 9 + [c_i32, c_i64, c_i32, c_i32, c_i32, c_i32, c_i64, c_i64, c_i64, c_i64, c_vp], c_i32),
     "tante_layernorm_affine_bwd": ([c_vp, c_i32, c_vp, c_i32, c_vp, c_i64, c_i32, c_f32, c_vp, c_vp, c_vp, c_vp], c_i32),

@@ -51,6 +51,7 @@ struct ChainArgs {
   const float* bout;         // 16 floats
   int out_dim;
   float* out;
+  unsigned short* qkv;       // MODE 2: (M, 1536) bf16, the NEXT block's q | k | v rows
 };
 
 // byte offset of fragment (global k-step g, row tile j) of a wave's stream: matrix g / 16, inside it [wave][ks][j]
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(512) void chain512_kernel(ChainArgs A) {
   float* tab = (float*)(xs + 2 * XIMG);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kk = lane >> 4, l15 = lane & 15;
   const long tok0 = (long)blockIdx.x * XT;
-  constexpr int NMAT = MODE == 0 ? 3 : 4, GEND = 16 * NMAT;
+  constexpr int NMAT = MODE == 0 ? 3 : (MODE == 1 ? 4 : 6), GEND = 16 * NMAT;
   const FsW wu = fs_wstream(A.w, (unsigned)(wave * 65536 + lane * 16));      // base in SGPRs, one VGPR lane offset, fragment offsets by the scalar unit
   const int f0 = 64 * wave + 4 * kk;      // + 16 j: the lane's four features of row tile j
 
@@ -205,13 +206,51 @@ __global__ __launch_bounds__(512) void chain512_kernel(ChainArgs A) {
 
   // ---- x2 = x1 + fc2(h) -----------------------------------------------------------------------------------------------------------
   x_gemm<2, GEND, NTT>(wu, wb, ab0, acc);
-  if constexpr (MODE == 0) {
+  if constexpr (MODE == 0 || MODE == 2) {
     float* op = A.out + (tok0 + l15) * XC + f0;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int tt = 0; tt < NTT; ++tt) *(f32x4*)(op + (long)(16 * tt) * XC + 16 * j) = acc[j][tt];
-  } else {
+  }
+  if constexpr (MODE == 2) {
+    // ---- the NEXT SelfAttnBlock's q | k | v = in_proj'(LN1(x2)) (cvit.py:129-134 of the block that follows; LN1 folded into the weights):
+    // the token rows are here, normalised once, and the three 512 x 512 matrices ride the same weight stream -- instead of a launch
+    // of its own that re-reads x2 and, on the encoder's few hundred tokens, is one more latency chain per block
+    {
+      float mean[NTT], rstd[NTT];
+      x_ln_stats<NTT>(acc, tab, wave, kk, l15, A.eps_norm2, mean, rstd);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int tt = 0; tt < NTT; ++tt) x_img_write(img1, wave, kk, l15, j, tt, (acc[j][tt] - splat4(mean[tt])) * splat4(rstd[tt]));
+    }
+    __syncthreads();
+    auto part = [&](auto pc) {
+      constexpr int P = decltype(pc)::value;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const f32x4 b = *(const f32x4*)(A.bias + (3 + P) * XC + f0 + 16 * j);
+#pragma unroll
+        for (int tt = 0; tt < NTT; ++tt) acc[j][tt] = b;
+      }
+      x_gemm<3 + P, GEND, NTT>(wu, wb, ab1, acc);
+      unsigned short* qp = A.qkv + (tok0 + l15) * (3 * XC) + P * XC + f0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int tt = 0; tt < NTT; ++tt) {
+          u32x2 v;
+          v[0] = pack_bf16x2(acc[j][tt][0], acc[j][tt][1]);
+          v[1] = pack_bf16x2(acc[j][tt][2], acc[j][tt][3]);
+          *(u32x2*)(qp + (long)(16 * tt) * (3 * XC) + 16 * j) = v;
+        }
+    };
+    part(std::integral_constant<int, 0>{});
+    part(std::integral_constant<int, 1>{});
+    part(std::integral_constant<int, 2>{});
+  }
+  if constexpr (MODE == 1) {
     // ---- z = norm2(x2) (affine: z is also the Mlp's residual) ---------------------------------------------------------------------
     {
       float mean[NTT], rstd[NTT];
@@ -271,7 +310,7 @@ __global__ __launch_bounds__(512) void chain512_kernel(ChainArgs A) {
   }
 }
 
-TantePerDevice g_chain_attr[4];
+TantePerDevice g_chain_attr[6];
 
 template <int MODE, int NTT>
 void chain_launch(const ChainArgs& A, long M, hipStream_t s) {
@@ -293,7 +332,7 @@ extern "C" int tante_cvit_chain512(const void* a, const float* resid, int64_t re
     TANTE_FAIL(-1, "tante_cvit_chain512: mode 1 needs norm2, the packed output layer and 1 <= out_dim <= 16 (got %d)", out_dim);
   if (((uintptr_t)a | (uintptr_t)resid | (uintptr_t)w | (uintptr_t)bias | (uintptr_t)out | (uintptr_t)g2 | (uintptr_t)b2 | (uintptr_t)wout | (uintptr_t)bout) & 15)
     TANTE_FAIL(-1, "tante_cvit_chain512: operands must be 16-byte aligned");
-  ChainArgs A{(const unsigned short*)a, resid, (long)resid_period, (const char*)w, bias, g2, b2, eps_ln2, eps_norm2, eps_mlp, (const char*)wout, bout, out_dim, out};
+  ChainArgs A{(const unsigned short*)a, resid, (long)resid_period, (const char*)w, bias, g2, b2, eps_ln2, eps_norm2, eps_mlp, (const char*)wout, bout, out_dim, out, nullptr};
   hipStream_t s = (hipStream_t)stream;
   // 64-token workgroups once they fill the chip twice over (and the shapes allow), 16-token workgroups for the short launches
   const int tw = tante_opt("TANTE_CVIT_CHAIN_TOKENS", 0);
@@ -303,6 +342,25 @@ extern "C" int tante_cvit_chain512(const void* a, const float* resid, int64_t re
   } else {
     if (mode == 0) chain_launch<0, 1>(A, (long)M, s); else chain_launch<1, 1>(A, (long)M, s);
   }
+  TANTE_CHECK_LAUNCH();
+  return 0;
+}
+
+
+/* mode 0 of tante_cvit_chain512 followed, in the same launch, by the NEXT SelfAttnBlock's input projection: qkv (M, 1536) bf16 =
+ * in_proj'(LN1_next(out)) with LN1 folded into the weights.  w: out_proj | fc1 | fc2 | Wq | Wk | Wv (six packed matrices), bias (6, 512). */
+extern "C" int tante_cvit_chain512_qkv(const void* a, const float* resid, int64_t resid_period, const void* w, const float* bias, float eps_ln2,
+                                       float eps_ln1_next, int64_t M, float* out, void* qkv, void* stream) {
+  if (M <= 0 || M % 16) TANTE_FAIL(-1, "tante_cvit_chain512_qkv: M = %lld must be a positive multiple of 16", (long long)M);
+  if (resid_period <= 0 || resid_period % 16) TANTE_FAIL(-1, "tante_cvit_chain512_qkv: resid_period = %lld must be a positive multiple of 16", (long long)resid_period);
+  if (!a || !resid || !w || !bias || !out || !qkv) TANTE_FAIL(-1, "tante_cvit_chain512_qkv: null operand");
+  if (((uintptr_t)a | (uintptr_t)resid | (uintptr_t)w | (uintptr_t)bias | (uintptr_t)out | (uintptr_t)qkv) & 15) TANTE_FAIL(-1, "tante_cvit_chain512_qkv: operands must be 16-byte aligned");
+  ChainArgs A{(const unsigned short*)a, resid, (long)resid_period, (const char*)w, bias, nullptr, nullptr, eps_ln2, eps_ln1_next, 0.0f, nullptr, nullptr, 0, out, (unsigned short*)qkv};
+  hipStream_t s = (hipStream_t)stream;
+  const int tw = tante_opt("TANTE_CVIT_CHAIN_TOKENS", 0);
+  const bool wide = tw ? tw == 64 : (M >= 64 * 512);
+  if (wide && M % 64 == 0 && resid_period % 64 == 0) chain_launch<2, 4>(A, (long)M, s);
+  else chain_launch<2, 1>(A, (long)M, s);
   TANTE_CHECK_LAUNCH();
   return 0;
 }

@@ -98,7 +98,7 @@ class _AttnBlock(nn.Module):
             return torch.cat([f for f, _ in mats]), torch.cat([b for _, b in mats]), tail
         return self._cache.get(("chain", extra is not None), params, build)
 
-    def _tail(self, attn_o: torch.Tensor, resid: torch.Tensor, pk, compute: int, M: int = None, model_tail=None) -> torch.Tensor:
+    def _tail(self, attn_o: torch.Tensor, resid: torch.Tensor, pk, compute: int, model_tail=None) -> torch.Tensor:
         """x = out_proj(attn) + resid;  return x + fc2(gelu(fc1(LN2(x)))).  resid may hold fewer rows than attn_o (row t % rows: the decoder's
         shared queries).  model_tail = (norm2, Mlp): continue through norm2 -> Mlp -> output layer in the same launch, -> (M, out_dim)."""
         adt = K.act_torch_dtype(compute)
@@ -129,17 +129,45 @@ def _model_tail_ok(model_tail) -> bool:
 
 
 class SelfAttnBlock(_AttnBlock):
-    def run(self, x: torch.Tensor, nb: int, Lq: int, compute: int) -> torch.Tensor:
-        """x (nb * Lq, C) fp32 -> block(x)   (cvit.py:129-139)."""
+    def _chain_qkv_packed(self, nxt: "SelfAttnBlock"):
+        """This block's tail matrices + the NEXT block's LN1-folded input projection as one six-matrix fragment stream."""
+        a, m, n2 = self.attn, self.mlp, self.layer_norm2
+        na, n1 = nxt.attn, nxt.layer_norm1
+        params = [n2.weight, n2.bias, a.out_proj.weight, a.out_proj.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias,
+                  n1.weight, n1.bias, na.in_proj_weight, na.in_proj_bias]
+
+        def build():
+            C_ = self.emb_dim
+            Wi, bi = na.in_proj_weight.detach(), na.in_proj_bias.detach()
+            mats = [K.pack_chain_matrix(a.out_proj.weight, a.out_proj.bias), K.pack_chain_matrix(m.fc1.weight, m.fc1.bias, n2.weight, n2.bias),
+                    K.pack_chain_matrix(m.fc2.weight, m.fc2.bias)]
+            mats += [K.pack_chain_matrix(Wi[p * C_:(p + 1) * C_], bi[p * C_:(p + 1) * C_], n1.weight, n1.bias) for p in range(3)]
+            return torch.cat([f for f, _ in mats]), torch.cat([b for _, b in mats])
+        return self._cache.get(("chain_qkv", id(nxt)), params, build)
+
+    def run(self, x: torch.Tensor, nb: int, Lq: int, compute: int, qkv: Optional[torch.Tensor] = None, next_blk: Optional["SelfAttnBlock"] = None):
+        """x (nb * Lq, C) fp32 -> block(x)   (cvit.py:129-139).  qkv: this block's q | k | v rows if the previous block's launch already
+        projected them.  next_blk: -> (block(x), the next block's q | k | v) when the one-launch tail applies, (block(x), None) otherwise."""
         pk = self._packed(compute)
         adt = K.act_torch_dtype(compute)
         C_, nh = self.emb_dim, self.num_heads
         M = nb * Lq
-        qkv = torch.empty(M, 3 * C_, dtype=adt, device=x.device)
-        K.linear(x, pk["qkv_ln1"], qkv, M=M, ln=True, ln_eps=self.eps)
+        if qkv is None:
+            qkv = torch.empty(M, 3 * C_, dtype=adt, device=x.device)
+            K.linear(x, pk["qkv_ln1"], qkv, M=M, ln=True, ln_eps=self.eps)
         o = torch.empty(M, C_, dtype=adt, device=x.device)
         K.cross_attention(qkv, qkv[:, C_:], qkv[:, 2 * C_:], o, nb, nh, C_ // nh, Lq, Lq, 3 * C_, 3 * C_, C_)
-        return self._tail(o, x, pk, compute)
+        if next_blk is None:
+            return self._tail(o, x, pk, compute)
+        if (self._chain_ok(compute, M, M) and next_blk.emb_dim == C_ and next_blk.num_heads * 64 == C_
+                and L.get_option("TANTE_CVIT_CHAIN_QKV", 0) != 0):      # measured SLOWER (B = 1: 1.02 -> 1.11 ms, B = 4: 1.80 -> 1.86): off
+            w, bias = self._chain_qkv_packed(next_blk)
+            out = torch.empty(M, C_, dtype=torch.float32, device=x.device)
+            nqkv = torch.empty(M, 3 * C_, dtype=torch.bfloat16, device=x.device)
+            L.check(L.lib().tante_cvit_chain512_qkv(o.data_ptr(), x.data_ptr(), M, w.data_ptr(), bias.data_ptr(), float(self.eps), float(next_blk.eps), M,
+                                                    out.data_ptr(), nqkv.data_ptr(), K._stream()), "tante_cvit_chain512_qkv")
+            return out, nqkv
+        return self._tail(o, x, pk, compute), None
 
 
 class CrossAttnBlock(_AttnBlock):
@@ -238,8 +266,13 @@ class Encoder(nn.Module):
         if tl != 1:
             lat = lat.view(b, s, tl, d).permute(0, 2, 1, 3).contiguous().view(b * tl * s, d)
         y = K.layernorm_affine(lat, self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps)
-        for blk in self.SelfAttnBlocks:
-            y = blk.run(y, b, tl * s, compute)
+        blocks = list(self.SelfAttnBlocks)
+        qkv = None
+        for i, blk in enumerate(blocks):      # a block's launch also projects the next block's q | k | v where the one-launch tail applies
+            if i + 1 < len(blocks):
+                y, qkv = blk.run(y, b, tl * s, compute, qkv=qkv, next_blk=blocks[i + 1])
+            else:
+                y = blk.run(y, b, tl * s, compute, qkv=qkv)
         return y, tl * s
 
 

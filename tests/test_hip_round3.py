@@ -402,6 +402,12 @@ def test_cvit_width512_fused_against_oracle_and_unfused(dev):
         finally:
             L.set_option("TANTE_CVIT_FUSED", 1)
         close(y0, ref, "bf16", "width-512 CViT, per-op launches")
+        try:      # the opt-in form whose block launch also projects the next block's q | k | v (tante_cvit_chain512_qkv)
+            L.set_option("TANTE_CVIT_CHAIN_QKV", 1)
+            y1 = m(xs.to(dev))
+        finally:
+            L.set_option("TANTE_CVIT_CHAIN_QKV", 0)
+        close(y1, ref, "bf16", "width-512 CViT, next block's projection inside the block launch")
         idx = torch.randint(0, 64 * 64, (777,), device=dev)
         yq = m(xs.to(dev), tante_amd.cvit.generate_coords(64, 64, dev)[idx])
     close(yq, y.permute(0, 1, 3, 4, 2).reshape(4, 4, 64 * 64, -1)[:, :, idx], "bf16", "query points vs full grid")
