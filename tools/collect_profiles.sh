@@ -41,4 +41,8 @@ cd $R && python3 tools/summarize_profiles.py $OUT
 cp $OUT/r03_pmc_rollout.json $OUT/r03_pmc_fno.json $R/profiles/ 2>/dev/null
 python3 $R/bench.py --steps 10 --warmup 3 > $OUT/bench_full.json 2> $OUT/bench_full.err
 python3 $R/bench.py --config $R/configs/tante_fno.yaml --steps 3 --warmup 1 --no-cpu-baseline > $OUT/fno_bench.json 2> $OUT/fno2.err
+# (the bench lines written under the profiler above carry its per-launch host overhead: replace them by un-profiled runs of the same commands)
+python3 $R/bench.py --config $R/configs/tante_trl.yaml --steps 5 --warmup 2 --no-cpu-baseline > $OUT/trl_bench.json 2> $OUT/trl2.err
+python3 $R/bench.py --config $R/configs/cvit_rb.yaml --steps 10 --warmup 3 > $OUT/cvit_bench.json 2> $OUT/cvit2.err
+python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-train > $OUT/rollout_bench.json 2> $OUT/rollout2.err
 cd $R && python3 tools/summarize_profiles.py $OUT
