@@ -321,13 +321,15 @@ __global__ __launch_bounds__(1024) void idft_rows_conv_kernel(const float* __res
 }
 
 // ---- E in the bf16 compute mode: the same products on the bf16 matrix pipe with SPLIT operands -------------------------------------------
-// Kernel E above sits at the fp32 matrix pipe's own rate (24 v_mfma_f32_32x32x2_f32 of 64 cycles per 32 x 32 output tile: 200 us for the
-// 8 -> 32 channel layer of a 4-frame window at 512 x 512, four times the HBM time of its 335 MB).  The bf16 pipe is 16 x faster per
-// product; with every operand split into two bf16 parts, v = hi + lo (16 mantissa bits kept), and the three products
+// Kernel E above does 24 v_mfma_f32_32x32x2_f32 of 64 cycles per 32 x 32 output tile: a matrix floor of ~49 us for the 8 -> 32 channel
+// layer of a 4-frame window at 512 x 512 (n = 8), beside 42 us of HBM time for its 335 MB -- and runs 229 us (one wave per 32 columns,
+// operands fetched right in front of their MFMAs).  The bf16 pipe is 16 x faster per product; with every operand split into two bf16
+// parts, v = hi + lo (16 mantissa bits kept), and the three products
 //     a . b  ~=  a_hi b_hi + a_lo b_hi + a_hi b_lo                 (a_lo b_lo, 2^-18 relative, dropped; fp32 accumulation)
 // the result differs from the fp32 chain by ~1e-5 relative per term -- a thousandth of the bf16 mode's own bar (1e-2; its convolutions
-// round activations to 8 bits) -- for 9 v_mfma_f32_16x16x32_bf16 of 16 cycles per 16 x 16 tile: 2.7 x fewer matrix cycles, which makes the
-// kernel HBM-bound.  Only the bf16 compute mode uses it (tante_spectral_layer_c); fp32 keeps the exact kernel above.
+// round activations to 8 bits) -- for 9 v_mfma_f32_16x16x32_bf16 of 16 cycles per 16 x 16 tile: 2.7 x fewer matrix cycles (18 us at
+// n = 8), so that the data movement is what is left to organise.  Only the bf16 compute mode uses it (tante_spectral_layer_c); fp32
+// keeps the exact kernel above.
 // A workgroup = 128 output columns; its G table sits in LDS as ready B-operand fragments (hi and lo).  A wave owns one image row at a
 // time: it gathers and splits the row's Z coefficients once (A fragments), then walks the 8 column tiles, splitting x on the way.
 __device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsigned& lo) {
