@@ -285,6 +285,8 @@ __global__ __launch_bounds__(64 * NW * G, 2) void block_fs_kernel(FsArgs A) {
     for (int j = 0; j < 16 / RPB; ++j) {
       const int r = RPB * j + brow, t = tok_of(16 * tt + r);
       const u32x4 v = *(const u32x4*)(img + tt * 8192 + r * FS_ROW + (((CPB * wave + bchunk) ^ r) << 4));
+      // (ordinary stores: written through, the saved tensors of a training forward gave NaN losses from the second step on --
+      // write-only lines whose stale copies from the previous step's backward reads survive somewhere -- and no time: 9.62 ms either way)
       if (t >= 0) *(u32x4*)(dst + (long)t * dstride + dcol + 16 * RT * wave + 8 * bchunk) = v;
     }
   };
@@ -300,8 +302,12 @@ __global__ __launch_bounds__(64 * NW * G, 2) void block_fs_kernel(FsArgs A) {
         const f32x4 v = *(const f32x4*)(sb + r * ROWB + ((rchunk ^ (r & (CPR - 1))) << 4));
 #ifdef FS_NT_STORE      // experiment: streaming (non-temporal) stores of the block's output rows
         if (t >= 0) __builtin_nontemporal_store(v, (f32x4*)(dst + (long)t * FS_C + 16 * RT * wave + 4 * rchunk));
-#else
-        if (t >= 0) *(f32x4*)(dst + (long)t * FS_C + 16 * RT * wave + 4 * rchunk) = v;
+#else                   // write-through (common.cuh): 38.4 -> 37.2 us per launch and +2.4 % on the rollout, three interleaved rounds
+        // the inference form only: there the kernel has READ these very lines (the residual rows) before it rewrites them
+        if (t >= 0) {
+          if constexpr (TRAIN) *(f32x4*)(dst + (long)t * FS_C + 16 * RT * wave + 4 * rchunk) = v;
+          else st_wt16(dst + (long)t * FS_C + 16 * RT * wave + 4 * rchunk, v);
+        }
 #endif
       }
     }

@@ -112,6 +112,28 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
 __device__ __forceinline__ float bf16_lo(unsigned u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float bf16_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
 
+// ---- write-through stores -----------------------------------------------------------------------------------------------------
+// A kernel's ordinary stores sit dirty in its XCD's L2 until the kernel-end release writes them back: B bytes cost ~B / 6 TB/s behind ALL
+// of the kernel's compute (MI355X_MICROARCH.md, kernel boundary; measured here: 33.5 MB of block-kernel output = 5.6 us, its timing build
+// without the store).  A store with sc0 sc1 goes to memory as it is issued, so results that are final when they are written -- a kernel's
+// output rows, the saved tensors of a training forward -- stream out under the rest of the kernel and the release finds nothing to do.
+// Only for data no other workgroup of the SAME launch reads back.  (-DTANTE_PLAIN_STORES: ordinary stores, for A/B.)
+__device__ __forceinline__ void st_wt16(void* p, const u32x4& v) {
+#ifdef TANTE_PLAIN_STORES
+  *(u32x4*)p = v;
+#else
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+#endif
+}
+__device__ __forceinline__ void st_wt16(void* p, const f32x4& v) { st_wt16(p, __builtin_bit_cast(u32x4, v)); }
+__device__ __forceinline__ void st_wt8(void* p, const u32x2& v) {
+#ifdef TANTE_PLAIN_STORES
+  *(u32x2*)p = v;
+#else
+  asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+#endif
+}
+
 // ---- activations (always evaluated in fp32) ---------------------------------------------------
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 // erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7): one v_exp, one v_rcp, 6 fma -- a third of ocml erff.
