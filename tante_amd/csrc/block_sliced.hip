@@ -285,8 +285,9 @@ __global__ __launch_bounds__(64 * NW * G, 2) void block_fs_kernel(FsArgs A) {
     for (int j = 0; j < 16 / RPB; ++j) {
       const int r = RPB * j + brow, t = tok_of(16 * tt + r);
       const u32x4 v = *(const u32x4*)(img + tt * 8192 + r * FS_ROW + (((CPB * wave + bchunk) ^ r) << 4));
-      // (ordinary stores: written through, the saved tensors of a training forward gave NaN losses from the second step on --
-      // write-only lines whose stale copies from the previous step's backward reads survive somewhere -- and no time: 9.62 ms either way)
+      // (ordinary stores: written through they buy nothing -- 9.65 ms per train step either way.  The first attempt gave NaN losses: the
+      // write-through store is an asm statement, and a GELU that reused its data registers right behind it hit the store-data hazard the
+      // compiler's recognizer does not see inside asm -- st_wt16 carries the wait states now, common.cuh)
       if (t >= 0) *(u32x4*)(dst + (long)t * dstride + dcol + 16 * RT * wave + 8 * bchunk) = v;
     }
   };
@@ -303,7 +304,7 @@ __global__ __launch_bounds__(64 * NW * G, 2) void block_fs_kernel(FsArgs A) {
 #ifdef FS_NT_STORE      // experiment: streaming (non-temporal) stores of the block's output rows
         if (t >= 0) __builtin_nontemporal_store(v, (f32x4*)(dst + (long)t * FS_C + 16 * RT * wave + 4 * rchunk));
 #else                   // write-through (common.cuh): 38.4 -> 37.2 us per launch and +2.4 % on the rollout, three interleaved rounds
-        // the inference form only: there the kernel has READ these very lines (the residual rows) before it rewrites them
+        // the inference form only (the training form's launches are bound by their saved-tensor traffic, not by the release)
         if (t >= 0) {
           if constexpr (TRAIN) *(f32x4*)(dst + (long)t * FS_C + 16 * RT * wave + 4 * rchunk) = v;
           else st_wt16(dst + (long)t * FS_C + 16 * RT * wave + 4 * rchunk, v);

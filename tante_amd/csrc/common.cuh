@@ -122,7 +122,10 @@ __device__ __forceinline__ void st_wt16(void* p, const u32x4& v) {
 #ifdef TANTE_PLAIN_STORES
   *(u32x4*)p = v;
 #else
-  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+  // (s_nop 1: a VALU write to the data registers of a store wider than 64 bits needs wait states behind it; the compiler's hazard
+  // recognizer covers its own stores, not the inside of an asm statement -- without it a GELU that reused these registers right behind
+  // the store corrupted the saved pre-activations of the training forward)
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 #endif
 }
 __device__ __forceinline__ void st_wt16(void* p, const f32x4& v) { st_wt16(p, __builtin_bit_cast(u32x4, v)); }
