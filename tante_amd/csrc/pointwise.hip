@@ -581,7 +581,11 @@ __device__ __forceinline__ void axe_phase(float* plane, const AxeW<MT>& W, int w
             f32x2 v = *(const f32x2*)(rbase + (16 * mt + r) * LS);
             v[0] += out[g][0][mt][r];
             v[1] += out[g][1][mt][r];
+#ifdef AXE_PLAIN_STORE
             if constexpr (GOUT) *(f32x2*)(gbase + (long)(16 * mt + r) * gls) = v;
+#else       // write-through (common.cuh): the finished plane streams out, nothing dirty is left for the kernel-end release
+            if constexpr (GOUT) st_wt8(gbase + (long)(16 * mt + r) * gls, __builtin_bit_cast(u32x2, v));
+#endif
             else *(f32x2*)(rbase + (16 * mt + r) * LS) = v;      // these lines belong to this wave alone
           }
       }
