@@ -513,7 +513,7 @@ __global__ __launch_bounds__(256) void idft_rows_conv_x3_kernel(const float* __r
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], act);
           }
-          *(f32x4*)(orow + (long)o * HWl + 16 * wt) = v;
+          st_wt16(orow + (long)o * HWl + 16 * wt, v);      // write-through: 268 MB of output never read back by this launch
         }
       }
     }
