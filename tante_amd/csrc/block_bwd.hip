@@ -345,7 +345,11 @@ __global__ __launch_bounds__(256, 2) void block_head_bwd_kernel(BhArgs A) {
       const int r = RPI * j + rrow;
       const long t = tok0 + 16 * tt + r;
       const f32x4 v = *(const f32x4*)(sb + r * ROWB + ((rchunk ^ (r & (CPR - 1))) << 4));
+#ifdef BH_PLAIN_STORE
       if (t < A.M) *(f32x4*)(A.dx + t * FS_C + 16 * RT * wave + 4 * rchunk) = v;
+#else   // write-through (common.cuh): the launch's only output, written at its very end
+      if (t < A.M) st_wt16(A.dx + t * FS_C + 16 * RT * wave + 4 * rchunk, v);
+#endif
     }
   }
 }
