@@ -325,6 +325,28 @@ int tante_head_fused_multi_streams(int n_ord, const float* const* rows, const vo
                            int64_t a_s1, int64_t a_s0, int64_t a_off, int n_img, int Hp, int Wp, int C, int D, float* out,
                            int64_t out_bstride, const float* last, int64_t last_bstride, void* stream);
 
+/* ---- the token-local tail of a rollout call in ONE launch (head_enc.hip; bf16, C = 256, D <= 16, Hp Wp % 16 == 0) -----------------
+ * tante_head_enc_fused: every Taylor order's derivative head + the Taylor sum (as tante_head_fused_multi_streams: rows[k] = the residual
+ * stream backbone k left, addressed by (a_n0, a_s1, a_s0, a_off), a_n0 % 16 == 0) and, when enc_stream != NULL, the RE-ENCODING of the
+ * predicted frame for the next call: with patch_scale 8 the 8 x 8 x D block a token's heads write (enc_dec_cnn.py:263-277,
+ * tante.py:165-171) is exactly the block the three encoder stages reduce back to that token (enc_dec_cnn.py:217-229), so the frame
+ * is stored (it is the output) and encoded from the same registers:  z (n_img Hp Wp, C) fp32 = enc_CNN(frame) before FiLM, the
+ * rollout's frame-cache entry that tante_enc23_frames would otherwise produce from the stored frame (2 launches, 25 MB).
+ * enc_stream = tante_pack_head_enc(conv1.w, conv1.b, conv2.w, conv2.b, conv3.w, conv3.b).  ws: tante_head_enc_ws_bytes(rows) bytes,
+ * ZEROED ONCE by the caller before the first use (fp32 partials of encoder stage 3 -- its K = 512 contraction is split over the four
+ * workgroups of a token group, the last to arrive adds them in a fixed order: deterministic -- followed by one arrival counter per
+ * group, which the kernel leaves at zero).  One workspace per stream of concurrent launches.  enc_stream == NULL: heads + Taylor sum
+ * only (z, ws unused). */
+int tante_head_enc_supported(int C, int D);
+int64_t tante_head_enc_stream_bytes(int C);
+int64_t tante_head_enc_ws_bytes(int64_t rows);
+int tante_pack_head_enc(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3, const float* b3, int C, int D,
+                        void* enc_stream, void* stream);
+int tante_head_enc_fused(int n_ord, const float* const* rows, const void* const* head_streams, const float* coefs, int32_t a_n0,
+                         int64_t a_s1, int64_t a_s0, int64_t a_off, int n_img, int Hp, int Wp, int C, int D, float* out,
+                         int64_t out_bstride, const float* last, int64_t last_bstride, const void* enc_stream, float* z, void* ws,
+                         int64_t ws_bytes, void* stream);
+
 /* ---- general encoder / decoder stages, spectral operator path, CViT (operators.hip) ---------------------------------
  * tante_im2col: rows = output positions (img, oh, ow) of a convolution with kernel (kh, kw), stride (sh, sw), zero padding (ph, pw)
  *   over x (n_img, C, H, W) [nchw = 1] or (n_img, H, W, C) [nchw = 0]; columns ordered (c, kh, kw) [korder 0, the native

@@ -191,6 +191,12 @@ SIGNATURES = {
     "tante_head_fused_multi_streams": ([c_i32, c_vp, c_vp, c_vp, c_i32, c_i64, c_i64, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp, c_i64,
                                c_vp], c_i32),
     "tante_get_option": ([C.c_char_p, c_i32], c_i32),
+    "tante_head_enc_supported": ([c_i32, c_i32], c_i32),
+    "tante_head_enc_stream_bytes": ([c_i32], c_i64),
+    "tante_head_enc_ws_bytes": ([c_i64], c_i64),
+    "tante_pack_head_enc": ([c_vp] * 6 + [c_i32, c_i32, c_vp, c_vp], c_i32),
+    "tante_head_enc_fused": ([c_i32, c_vp, c_vp, c_vp, c_i32, c_i64, c_i64, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp, c_i64,
+                             c_vp, c_vp, c_vp, c_i64, c_vp], c_i32),
 }
 
 _lib = None

@@ -464,6 +464,60 @@ def head_fused_multi(rows: Sequence[torch.Tensor], a_n0: int, a_s1: int, a_s0: i
     return out
 
 
+def head_enc_supported(C_: int, D: int, Hp: int, Wp: int) -> bool:
+    """The one-launch tail of a rollout call (heads + Taylor sum + re-encoding of the predicted frame): C = 256, whole 16-token tiles per image."""
+    return bool(L.lib().tante_head_enc_supported(C_, D)) and (Hp * Wp) % 16 == 0
+
+
+def pack_head_enc(params: Sequence[torch.Tensor], C_: int, D: int) -> torch.Tensor:
+    """params = (conv1.w, conv1.b, conv2.w, conv2.b, conv3.w, conv3.b) of enc_CNN -> the encoder stream of tante_head_enc_fused."""
+    ps = [p.detach() for p in params]
+    _dev(*ps)
+    st = torch.empty(L.lib().tante_head_enc_stream_bytes(C_), dtype=torch.uint8, device=ps[0].device)
+    L.check(L.lib().tante_pack_head_enc(*[_p(p) for p in ps], C_, D, _p(st), _stream()), "tante_pack_head_enc")
+    return st
+
+
+_HE_WS = {}
+
+
+def head_enc_workspace(rows: int, device: torch.device) -> torch.Tensor:
+    """The zeroed workspace of tante_head_enc_fused for `rows` tokens, one per (device, stream, size): the kernel leaves its arrival
+    counters at zero, so it is cleared once."""
+    key = (device.index, _stream(), rows)
+    ws = _HE_WS.get(key)
+    if ws is None:
+        ws = torch.zeros(L.lib().tante_head_enc_ws_bytes(rows), dtype=torch.uint8, device=device)
+        _HE_WS[key] = ws
+    return ws
+
+
+def head_enc_fused(rows: Sequence[torch.Tensor], a_n0: int, a_s1: int, a_s0: int, a_off: int, n_img: int, Hp: int, Wp: int, C_: int, D: int,
+                   head_streams: Sequence[torch.Tensor], coefs: Sequence[float], out: torch.Tensor, out_bstride: int, last: torch.Tensor,
+                   last_elem_off: int, last_bstride: int, enc_stream: Optional[torch.Tensor] = None, z: Optional[torch.Tensor] = None):
+    """out = last + sum_k coefs[k] * head_k(rows[k]) and (enc_stream given) z = enc_CNN(out) before FiLM, in ONE launch.
+    rows[k]: the whole residual stream after backbone k, all addressed by (a_n0, a_s1, a_s0, a_off)."""
+    n = len(rows)
+    _dev(*rows, *head_streams, enc_stream, z)
+    if not (out.is_cuda and last.is_cuda):
+        raise RuntimeError("tante_amd kernels need CUDA/HIP tensors (no CPU fallback)")
+    if a_n0 % 16 or (Hp * Wp) % 16:
+        raise RuntimeError("head_enc_fused: whole 16-token tiles per image expected")
+    rp = (C.c_void_p * n)(*[r.data_ptr() for r in rows])
+    sp = (C.c_void_p * n)(*[h.data_ptr() for h in head_streams])
+    cf = (C.c_float * n)(*[float(c) for c in coefs])
+    ws, wsb = None, 0
+    if enc_stream is not None:
+        if z is None or z.dtype != torch.float32 or z.numel() != n_img * Hp * Wp * C_:
+            raise RuntimeError("head_enc_fused: z must be a contiguous fp32 (n_img * Hp * Wp, C) tensor")
+        wst = head_enc_workspace(n_img * Hp * Wp, out.device)
+        ws, wsb = wst.data_ptr(), wst.numel()
+    L.check(L.lib().tante_head_enc_fused(n, rp, sp, cf, a_n0, a_s1, a_s0, a_off, n_img, Hp, Wp, C_, D, out.data_ptr(), out_bstride,
+                                         last.data_ptr() + 4 * last_elem_off, last_bstride, _p(enc_stream), _p(z), ws, wsb, _stream()),
+            "tante_head_enc_fused")
+    return out
+
+
 def enc23_supported(C_: int) -> bool:
     return bool(L.lib().tante_enc23_supported(C_))
 

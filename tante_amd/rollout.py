@@ -75,12 +75,19 @@ def _rollout_in_place(model, x: torch.Tensor, n_steps: int, raw_input: torch.Ten
         HW, C_ = model.H_p * model.W_p, model.C
         z = torch.empty(T + n_calls * ol, B, HW, C_, dtype=torch.float32, device=dev)
         encoded = 0
+        # one output frame per call: the launch that writes the predicted frame also writes its encoding for the next call's window
+        # (csrc/head_enc.hip) -- only the initial window goes through the encoder kernels
+        tail = ol == 1 and model.tail_fused_supported() and not os.environ.get("TANTE_NO_TAIL_ENC")
         for s in range(n_calls):
             need = s * ol + T
             if need > encoded:                       # the first call encodes the whole window, later calls the `ol` new frames
                 model.encode_frames(buf[:, encoded: need], z[encoded: need])
             encoded = need
-            model(buf[:, s * ol: s * ol + T], out=buf[:, T + s * ol: T + (s + 1) * ol], enc_cache=(z[s * ol:], B * HW * C_, HW * C_))
+            nxt = z[T + s] if (tail and s + 1 < n_calls) else None
+            model(buf[:, s * ol: s * ol + T], out=buf[:, T + s * ol: T + (s + 1) * ol], enc_cache=(z[s * ol:], B * HW * C_, HW * C_),
+                  **({"enc_next": nxt} if nxt is not None else {}))
+            if nxt is not None:
+                encoded = need + 1
         return buf[:, T: T + n_steps]
     for s in range(n_calls):
         model(buf[:, s * ol: s * ol + T], out=buf[:, T + s * ol: T + (s + 1) * ol])

@@ -55,6 +55,7 @@ class TanteMetadata:
 
 HEAD_MULTI = __import__("os").environ.get("TANTE_HEAD_MULTI", "1") != "0"      # every Taylor order's derivative head in one launch
 HEAD_STREAMS = __import__("os").environ.get("TANTE_HEAD_STREAMS", "1") != "0"  # ... reading each order's own stream buffer (no row copies)
+HEAD_ENC = __import__("os").environ.get("TANTE_HEAD_ENC", "1") != "0"          # ... and re-encoding the predicted frame in the same launch (head_enc.hip)
 
 
 def _check_patch_cfg(patch_scale, overlap_ratio):
@@ -126,6 +127,12 @@ class enc_CNN(nn.Module):
 
     def fuses_23(self, compute: int) -> bool:
         return (compute == L.BF16 and self.fused and self.P == (2, 2, 2) and self.overlap == 0.0 and K.enc23_supported(self.embed_dim))
+
+    def packed_head_enc(self):
+        """Encoder stream of the one-launch rollout tail (kernels.head_enc_fused), rebuilt when a conv parameter changes."""
+        convs = [getattr(self, f"enc_conv_{i + 1}").conv for i in range(3)]
+        params = [q for c in convs for q in (c.weight, c.bias)]
+        return self._cache.get(-4, params, lambda: K.pack_head_enc(params, self.embed_dim, self.chans[0]))
 
     def forward_frames(self, inp: torch.Tensor, compute: int, item_stride: int, z: torch.Tensor) -> torch.Tensor:
         """inp (B, F, D, H, W) fp32 frames -> z (F, B, Hp*Wp, C) fp32: stages 1-3 WITHOUT FiLM, frame-major (the rollout's frame cache).
@@ -463,11 +470,23 @@ class TANTE(nn.Module):
         """One frame: (B, 1, D, H, W) -> z (B, Hp*Wp, C)."""
         return self.encode_frames(frame, z.view(1, *z.shape))
 
-    def forward(self, input: torch.Tensor, out_T=1, out: Optional[torch.Tensor] = None, enc_cache: Optional[tuple] = None):
+    def tail_fused_supported(self) -> bool:
+        """The token-local tail of a call -- every order's derivative head, the Taylor sum and (in a rollout) the re-encoding of the
+        predicted frame -- as ONE launch (csrc/head_enc.hip): bf16, C = 256, the three 2 x 2 stages of patch_scale 8, one output frame."""
+        compute = resolve_compute(self.compute)
+        return bool(HEAD_ENC and self.deg and self.output_length == 1 and 1 <= self.taylor_order <= 4 and compute == L.BF16 and self.fused_head
+                    and type(self.encoder).__name__ == "enc_CNN" and getattr(self.decoders[0], 'P', None) == (2, 2, 2)
+                    and self.decoders[0].overlap == 0.0 and K.head_enc_supported(self.C, self.D, self.H_p, self.W_p)
+                    and all(b.takes_x_in(compute) for b in self.blocks[1:self.taylor_order]))
+
+    def forward(self, input: torch.Tensor, out_T=1, out: Optional[torch.Tensor] = None, enc_cache: Optional[tuple] = None,
+                enc_next: Optional[torch.Tensor] = None):
         """`out` (optional, deg=True only): a (B, output_length, D, H, W) fp32 view with contiguous frames (e.g. the next
         slots of a rollout buffer) that receives the prediction instead of a fresh tensor.
         `enc_cache` = (z, t_stride, b_stride): the window's frames already encoded by encode_frame (frame t of item b at
         z + t * t_stride + b * b_stride); see enc_cache_supported().
+        `enc_next` (tail_fused_supported() only): a contiguous (B, Hp*Wp, C) fp32 tensor that receives the pre-FiLM encoding of the
+        PREDICTED frame -- what encode_frame would compute from it -- out of the same launch that writes the frame.
         With autograd enabled the differentiable path (train_forward.py: HIP forward + HIP backward kernels) runs."""
         if not input.is_cuda:
             raise RuntimeError("tante_amd.TANTE runs on the GPU only (no CPU fallback); move the input to cuda")
@@ -508,11 +527,17 @@ class TANTE(nn.Module):
         # one prediction frame, several Taylor orders: ONE head launch after the last backbone (tante_head_fused_multi) instead of one per
         # order -- the frame is read and written once instead of taylor_order times.  The earlier orders' last-slot rows are copied aside
         # (8 MB each at cfg2) because the later backbones update the stream in place.  TANTE_HEAD_MULTI=0: one launch per order (A/B).
-        multi_head = (self.deg and fused_head and self.output_length == 1 and 2 <= self.taylor_order <= 4 and HEAD_MULTI)
+        tail_fused = self.tail_fused_supported()
+        if enc_next is not None:
+            if not tail_fused or not self.encoder.fuses_23(compute):
+                raise RuntimeError("enc_next: this model / compute mode has no fused head + re-encoding path (tail_fused_supported())")
+            if tuple(enc_next.shape) != (B, HW, C_) or enc_next.dtype != torch.float32 or not enc_next.is_cuda or not enc_next.is_contiguous():
+                raise ValueError("enc_next must be a contiguous (B, Hp*Wp, C) fp32 CUDA tensor")
+        multi_head = (self.deg and fused_head and self.output_length == 1 and 2 <= self.taylor_order <= 4 and HEAD_MULTI) or tail_fused
         saved_rows = []
         # ... or not copied at all: every later backbone writes a stream buffer of its own (its first launch, the H + W propagator pass,
         # runs out of place: tante_axis_hw_oop), so the earlier orders' streams stay intact for the head.  TANTE_HEAD_STREAMS=0: copies.
-        streams = multi_head and HEAD_STREAMS and all(b.takes_x_in(compute) for b in self.blocks[1:self.taylor_order])
+        streams = tail_fused or (multi_head and HEAD_STREAMS and all(b.takes_x_in(compute) for b in self.blocks[1:self.taylor_order]))
         for i in range(self.taylor_order):
             if streams and i > 0:
                 x_prev, x = x, torch.empty_like(x)
@@ -528,6 +553,12 @@ class TANTE(nn.Module):
                     if out is None:
                         out = torch.empty(B, 1, D, H, W, dtype=torch.float32, device=x.device)
                     coefs = [self.frame_interval ** (k + 1) / math.factorial(k + 1) for k in range(self.taylor_order)]
+                    if tail_fused:      # heads + Taylor sum (+ the predicted frame's encoding for the next call) in one launch
+                        K.head_enc_fused(saved_rows + [x], HW, T * HW * C_, C_, (T - 1) * HW * C_, B, Hp, Wp, C_, D,
+                                         [self.decoders[k].packed_head() for k in range(self.taylor_order)], coefs, out, out.stride(0),
+                                         inp, (T - 1) * frame, bstride,
+                                         enc_stream=self.encoder.packed_head_enc() if enc_next is not None else None, z=enc_next)
+                        continue
                     K.head_fused_multi(saved_rows + [x], HW, T * HW * C_, C_, (T - 1) * HW * C_, B, Hp, Wp, C_, D,
                                        [self.decoders[k].packed_head() for k in range(self.taylor_order)], coefs, out, out.stride(0),
                                        inp, (T - 1) * frame, bstride, streams=streams)                          # l.147,153,165-171
