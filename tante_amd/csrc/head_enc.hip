@@ -48,9 +48,24 @@ struct HeArgs {
   const char* we;                          // encoder stream (tante_pack_head_enc)
   float* z;                                // (rows, 256) fp32: the new frame's encoding before FiLM
   float* part;                             // (groups, 4, 16 NWV, 256) fp32 partials
-  int* cnt;                                // (groups) arrival counters, zero between launches
+  int* cnt;                                // (groups, 4) {arrivals, starts, XCD mask, -}: zero between launches
   int groups;
+  int same_xcd_ok;                         // 0: always write the partials through (A/B: TANTE_HEAD_L2_HANDOFF=0)
+  unsigned long long* stamps;              // -DTANTE_ABLATE builds only (tools/head_enc_stamps.py), else null
 };
+
+#ifdef TANTE_ABLATE
+unsigned long long* g_he_stamps = nullptr;
+#define HE_STAMP(k)                                                                          \
+  do {                                                                                       \
+    if (A.stamps) {                                                                          \
+      const unsigned long long t_ = __builtin_amdgcn_s_memtime();                            \
+      if (lane == 0) A.stamps[((long)blockIdx.x * 8 + wave) * 40 + (k)] = t_;                \
+    }                                                                                        \
+  } while (0)
+#else
+#define HE_STAMP(k)
+#endif
 
 template <int NWV>
 __device__ __forceinline__ void he_glds(const char* __restrict__ g, char* l, int bytes, int tid) {   // 1 KiB per wave pass
@@ -60,10 +75,15 @@ __device__ __forceinline__ void he_glds(const char* __restrict__ g, char* l, int
                                      (__attribute__((address_space(3))) void*)(l + off), 16, 0, 0);
 }
 __device__ __forceinline__ f32x4 he_gelu(const f32x4& v) { return gelu_poly4<false>(v); }
-__device__ __forceinline__ f32x4 he_ld_sys(const float* p) {      // system-scope load: misses every cache level (partials of other workgroups)
+// agent-scope (sc1) 16-byte accesses to the hand-off buffer: the load misses this CU's L1, the store is written through (and waits the
+// two states a VALU write to the data registers of a >64-bit store needs behind it: common.cuh, st_wt16)
+__device__ __forceinline__ f32x4 he_ld_agent(const float* p) {
   f32x4 r;
-  asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(r) : "v"(p) : "memory");
+  asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(r) : "v"(p) : "memory");
   return r;
+}
+__device__ __forceinline__ void he_st_agent(float* p, const f32x4& v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 }
 
 // Pin a packed fragment / an accumulator where the source computes it.  MFMAs and GELUs are pure values to the optimiser: without a use
@@ -73,10 +93,16 @@ __device__ __forceinline__ void he_pin(u32x4& v) { asm volatile("" : "+v"(v)); }
 __device__ __forceinline__ void he_pin(f32x4& v) { asm volatile("" : "+v"(v)); }
 
 // NDT = 16-row tiles of stage 3 that hold real channels (D <= 4 NDT): the Taylor accumulators, the frame operands and the stage-3 MFMAs of the
-// dead tiles do not exist (D = 11: 48 + 48 registers instead of 64 + 64 -- the kernel lives at two waves per SIMD, 256 registers).
-template <int NWV, bool ENC, int NDT>
+// dead tiles do not exist.  TT = 16-token tiles per wave: every weight fragment read from LDS feeds TT MFMAs.  In-kernel stamps of the
+// TT = 1 form (8 waves x 16 tokens) showed stage 1 and stages 2 + 3 running at 60 - 80 % of the CU's LDS read rate (a ds_read_b128 is
+// 8 cycles of the LDS pipe, the MFMA it feeds 4 cycles of the CU's four matrix pipes): 4 waves x 32 tokens halve the LDS traffic per token.
+template <int NWV, int TT, bool ENC, int NDT>
 __global__ __launch_bounds__(NWV * 64, 1) void head_enc_kernel(const HeArgs A) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifndef HE_RING
+#define HE_RING 4
+#endif
+  constexpr int RD = TT == 2 ? HE_RING : 4;      // fragments in flight per wave in the LDS read ring
   char* w3s = smem;
   char* w1s = smem + HE_T3;
   char* w2s = w1s + HE_T1;
@@ -85,35 +111,63 @@ __global__ __launch_bounds__(NWV * 64, 1) void head_enc_kernel(const HeArgs A) {
   const int p = (blockIdx.x & 31) >> 3;                          // stage-1 pixel (kh, kw) = (p >> 1, p & 1)
   const int grp = (blockIdx.x >> 5) * 8 + (blockIdx.x & 7);      // the four pixels of a group share blockIdx & 7 (one XCD)
   if (grp >= A.groups) return;
+  HE_STAMP(0);
+  if constexpr (ENC) {
+    // Early handshake of the group's four workgroups: which XCD each runs on, and that it has started.  When the partials are stored
+    // (tens of microseconds later) a workgroup that finds all four on ITS XCD keeps them in that XCD's L2 (plain stores; the reducing
+    // workgroup is one of the four, its L1-bypassing loads are served by the same L2); otherwise it writes them through to memory.
+    if (tid == 0) {
+      const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u;      // HW_REG_XCC_ID[3:0]
+      const unsigned m = __hip_atomic_fetch_or((unsigned*)A.cnt + 4 * grp + 2, 1u << xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("" ::"v"(m));       // the mask bit is set before the start count moves
+      (void)__hip_atomic_fetch_add(A.cnt + 4 * grp + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 
-  // ---- rows: the wave's 16 consecutive tokens.  Hp Wp and a_n0 are multiples of 16 (checked by the launcher), so a wave's tile never
-  // straddles an image or an addressing block: one base offset + j a_s0, and the tile is live or dead as a whole (wave-uniform) ---------
+  // ---- rows: the wave's TT tiles of 16 consecutive tokens.  Hp Wp and a_n0 are multiples of 16 (checked by the launcher), so a tile never
+  // straddles an image or an addressing block: one base offset + j a_s0, and a tile is live or dead as a whole (wave-uniform) ---------
   const int HW = A.Hp * A.Wp;
   const unsigned n_rows = (unsigned)A.n_img * (unsigned)HW;
-  const unsigned row0 = (unsigned)__builtin_amdgcn_readfirstlane((grp * NWV + wave) * 16);
-  const bool live = row0 < n_rows;
-  const unsigned rowl = live ? row0 : 0u;                     // dead tiles read tile 0 (valid memory) and store nothing
-  const unsigned aq0 = rowl / (unsigned)A.a_n0, ar0 = rowl - aq0 * (unsigned)A.a_n0;
-  const long row_base = (long)aq0 * A.a_s1 + (long)ar0 * A.a_s0 + A.a_off;
-  const int img = (int)(rowl / (unsigned)HW), hw = (int)(rowl - (unsigned)img * (unsigned)HW) + l15;
-  const int hp = (int)(((float)hw + 0.5f) * __builtin_amdgcn_rcpf((float)A.Wp)), wp = hw - hp * A.Wp;   // exact: hw < 2^22
+  const unsigned row0 = (unsigned)__builtin_amdgcn_readfirstlane((grp * NWV + wave) * (TT * 16));
+  bool live[TT];
+  long row_base[TT];
+  int img[TT], hp[TT], wp[TT];
+#pragma unroll
+  for (int tt = 0; tt < TT; ++tt) {
+    live[tt] = row0 + 16u * tt < n_rows;
+    const unsigned rowl = live[tt] ? row0 + 16u * tt : 0u;                     // dead tiles read tile 0 (valid memory) and store nothing
+    const unsigned aq0 = rowl / (unsigned)A.a_n0, ar0 = rowl - aq0 * (unsigned)A.a_n0;
+    row_base[tt] = (long)aq0 * A.a_s1 + (long)ar0 * A.a_s0 + A.a_off;
+    img[tt] = (int)(rowl / (unsigned)HW);
+    const int hw = (int)(rowl - (unsigned)img[tt] * (unsigned)HW) + l15;
+    hp[tt] = (int)(((float)hw + 0.5f) * __builtin_amdgcn_rcpf((float)A.Wp));   // exact: hw < 2^22
+    wp[tt] = hw - hp[tt] * A.Wp;
+  }
 
   auto xk_of = [&](int o) { return o == 0 ? A.xk0 : o == 1 ? A.xk1 : o == 2 ? A.xk2 : A.xk3; };
   auto wk_of = [&](int o) { return o == 0 ? A.wk0 : o == 1 ? A.wk1 : o == 2 ? A.wk2 : A.wk3; };
   auto ck_of = [&](int o) { return o == 0 ? A.ck0 : o == 1 ? A.ck1 : o == 2 ? A.ck2 : A.ck3; };
 
-  // The wave's 16 token rows in ROW form (one instruction = the 1 KiB of one token), requested one order ahead: order k + 1's rows are
-  // asked for at barrier (A) of order k, arrive under its stage 1, and wait as bf16 pairs (32 registers) through its stages 2 + 3.
-  f32x4 xraw[16];
-  u32x2 xb[16];
+  // The wave's token rows in ROW form (one instruction = the 1 KiB of one token), requested one order ahead: order k + 1's rows are
+  // asked for at barrier (A) of order k, arrive under its stage 1, and wait as bf16 pairs through its stages 2 + 3.
+  f32x4 xraw[TT][16];
+  u32x2 xb[TT][16];
   auto load_rows = [&](const float* Xp) {
-    const float* src = Xp + row_base + 4 * lane;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) xraw[j] = *(const f32x4*)(src + (long)j * A.a_s0);
+    for (int tt = 0; tt < TT; ++tt) {
+      const float* src = Xp + row_base[tt] + 4 * lane;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) xraw[tt][j] = *(const f32x4*)(src + (long)j * A.a_s0);
+    }
   };
   auto pack_rows = [&]() {
 #pragma unroll
-    for (int j = 0; j < 16; ++j) { xb[j][0] = pack_bf16x2(xraw[j][0], xraw[j][1]); xb[j][1] = pack_bf16x2(xraw[j][2], xraw[j][3]); }
+    for (int tt = 0; tt < TT; ++tt)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        xb[tt][j][0] = pack_bf16x2(xraw[tt][j][0], xraw[tt][j][1]);
+        xb[tt][j][1] = pack_bf16x2(xraw[tt][j][2], xraw[tt][j][3]);
+      }
   };
 
   // ---- prologue: order 0's W1[p], W3 and rows (and the resident encoder stage-1 tile) ---------------------------------------------
@@ -125,41 +179,41 @@ __global__ __launch_bounds__(NWV * 64, 1) void head_enc_kernel(const HeArgs A) {
     load_rows(xk_of(0));
     pack_rows();
   }
+  HE_STAMP(1);
 
-  f32x4 dsum[4][NDT];                // sum over the orders of coefficient x derivative, per sub-pixel q and channel tile ns
-  f32x4 pre[2][NDT][2];              // the last input frame's values (fetched during the last order)
+  f32x4 dsum[TT][4][NDT];            // sum over the orders of coefficient x derivative, per sub-pixel q and channel tile ns
+  f32x4 pre[TT][2][NDT][2];          // the last input frame's values (fetched during the last order)
 #pragma unroll
-  for (int q = 0; q < 4; ++q)
+  for (int tt = 0; tt < TT; ++tt)
 #pragma unroll
-    for (int ns = 0; ns < NDT; ++ns) dsum[q][ns] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int ns = 0; ns < NDT; ++ns) dsum[tt][q][ns] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int Wout = A.Wp * 8;
-  auto pix_of = [&](int j, int ns) {   // sub-pixel pair j (q = 2 j, 2 j + 1 are horizontal neighbours), channel 4 ns + kk: first of 2 rows x 4 pixels
-    const int y0 = hp * 8 + (p >> 1) * 4 + j * 2, x0 = wp * 8 + (p & 1) * 4;
-    return ((long)(4 * ns + kk) * (A.Hp * 8) + y0) * Wout + x0;
-  };
 
   auto run_order = [&](auto is_last_c, const int ord) {
     constexpr bool IS_LAST = decltype(is_last_c)::value;
     const float cord = ck_of(ord);
     const char* Wp = wk_of(ord);
     // Every LDS address of the order's body is derived from a lane id the optimiser cannot see through: loop-invariant code motion would
-    // otherwise hoist ~50 address registers (16 staging writes, 16 staging reads, the fragment bases) out of the order loop and keep them
+    // otherwise hoist ~50 address registers (the staging writes and reads, the fragment bases) out of the order loop and keep them
     // live -- or spilled -- through all of it.  Recomputing them is two or three VALU instructions each.
     int ln = lane;
     asm volatile("" : "+v"(ln));
     const int kq = ln >> 4, lr = ln & 15;
-    // ---- bf16 rows -> a private 8 KiB piece of the W2 region -> B-operand fragments (k-permuted = accumulator order) -----------------
-    u32x4 xf[8];
-    {
-      char* xs = w2s + wave * 8192;          // 16 rows x 512 B; 8-byte chunk c of row j at chunk c ^ (2 j): conflict-free both ways
+    // ---- bf16 rows -> a private 8 KiB piece of the W2 region per tile -> B-operand fragments (k-permuted = accumulator order) --------
+    u32x4 xf[TT][8];
 #pragma unroll
-      for (int j = 0; j < 16; ++j) *(u32x2*)(xs + j * 512 + ((ln ^ ((2 * j) & 63)) << 3)) = xb[j];
+    for (int tt = 0; tt < TT; ++tt) {
+      char* xs = w2s + (wave * TT + tt) * 8192;          // 16 rows x 512 B; 8-byte chunk c of row j at chunk c ^ (2 j): conflict-free both ways
+#pragma unroll
+      for (int j = 0; j < 16; ++j) *(u32x2*)(xs + j * 512 + ((ln ^ ((2 * j) & 63)) << 3)) = xb[tt][j];
 #pragma unroll
       for (int b = 0; b < 8; ++b) {          // k-block b: features 32 b + 4 kk .. + 3 and 32 b + 16 + 4 kk .. + 3
         const u32x2 lo = *(const u32x2*)(xs + lr * 512 + (((8 * b + kq) ^ ((2 * lr) & 63)) << 3));
         const u32x2 hi = *(const u32x2*)(xs + lr * 512 + (((8 * b + 4 + kq) ^ ((2 * lr) & 63)) << 3));
-        xf[b] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+        xf[tt][b] = u32x4{lo[0], lo[1], hi[0], hi[1]};
       }
     }
     unsigned a1[8], a2[4], a3[2];
@@ -172,79 +226,109 @@ __global__ __launch_bounds__(NWV * 64, 1) void head_enc_kernel(const HeArgs A) {
     // this wave's pieces of W1 / W3 have landed (order 0: requested before its rows; later orders: long ago)
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();      // (A) every wave has its fragments: the W2 tiles may land on the staging pieces
+    HE_STAMP(2 + 6 * ord);
     he_glds<NWV>(Wp + HE_T3 + 4L * HE_T1, w2s, 4 * HE_T2, tid);
     if constexpr (!IS_LAST) load_rows(xk_of(ord + 1));             // in flight during stage 1
     // ---- stage 1: pixel p, two halves of its 128 channels; h1[kb] = B-operand k-blocks for stage 2 ------------------------------------
-    u32x4 h1[4];
+    u32x4 h1[TT][4];
     {
       const float* bias1 = (const float*)(w1s + 128 * 32 * 16);
       static_for<2>([&](auto hc) {
         constexpr int hh = decltype(hc)::value;
-        f32x4 acc[4];
+        f32x4 acc[TT][4];
 #pragma unroll
-        for (int ns = 0; ns < 4; ++ns) acc[ns] = *(const f32x4*)(bias1 + (4 * hh + ns) * 16 + kq * 4);
-        mfma_stream<32, 4>([&](auto ic) { constexpr int i = decltype(ic)::value; return LdsAddr<(4 * hh + i % 4) * 8192>{a1[i / 4]}; },
+        for (int ns = 0; ns < 4; ++ns) {
+          const f32x4 b = *(const f32x4*)(bias1 + (4 * hh + ns) * 16 + kq * 4);
+#pragma unroll
+          for (int tt = 0; tt < TT; ++tt) acc[tt][ns] = b;
+        }
+        mfma_stream<32, RD>([&](auto ic) { constexpr int i = decltype(ic)::value; return LdsAddr<(4 * hh + i % 4) * 8192>{a1[i / 4]}; },
                            [&](auto ic, const u32x4& wf) {
                              constexpr int i = decltype(ic)::value;
-                             acc[i % 4] = mfma_bf16(wf, xf[i / 4], acc[i % 4]);
+#pragma unroll
+                             for (int tt = 0; tt < TT; ++tt) acc[tt][i % 4] = mfma_bf16(wf, xf[tt][i / 4], acc[tt][i % 4]);
                            });
-        h1[2 * hh] = pack8(he_gelu(acc[0]), he_gelu(acc[1]));
-        h1[2 * hh + 1] = pack8(he_gelu(acc[2]), he_gelu(acc[3]));
-        he_pin(h1[2 * hh]); he_pin(h1[2 * hh + 1]);
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt) {
+          h1[tt][2 * hh] = pack8(he_gelu(acc[tt][0]), he_gelu(acc[tt][1]));
+          h1[tt][2 * hh + 1] = pack8(he_gelu(acc[tt][2]), he_gelu(acc[tt][3]));
+          he_pin(h1[tt][2 * hh]); he_pin(h1[tt][2 * hh + 1]);
+        }
       });
     }
+    HE_STAMP(3 + 6 * ord);
     if constexpr (!IS_LAST) pack_rows();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    HE_STAMP(4 + 6 * ord);
     __syncthreads();      // (B) the W2 tiles are complete; every wave is done with W1
+    HE_STAMP(5 + 6 * ord);
     if constexpr (!IS_LAST) he_glds<NWV>(wk_of(ord + 1) + HE_T3 + (long)p * HE_T1, w1s, HE_T1, tid);     // next order's W1: lands under stages 2 + 3
     else if constexpr (ENC) he_glds<NWV>(A.we + HE_E1, w1s, HE_E2, tid);
     if constexpr (IS_LAST) {
-      // the last input frame's pixels of this quadrant: in flight during stages 2 + 3 (requested here, not before stage 1: 48 registers
-      // less while the token fragments and the stage-1 accumulators are live).  Channels past D read channel D - 1 and are zeroed.
-      const float* src = A.last + (long)img * A.last_bstride;
+      // the last input frame's pixels of this quadrant: in flight during stages 2 + 3.  Channels past D read channel D - 1 and are zeroed.
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int tt = 0; tt < TT; ++tt) {
+        const float* src = A.last + (long)img[tt] * A.last_bstride;
 #pragma unroll
-        for (int ns = 0; ns < NDT; ++ns) {
-          const int ch = 4 * ns + kq;
-          const int y0 = hp * 8 + (p >> 1) * 4 + j * 2, x0 = wp * 8 + (p & 1) * 4;
-          const float* lp = src + ((long)(ch < A.D ? ch : A.D - 1) * (A.Hp * 8) + y0) * Wout + x0;
-          const f32x4 r0 = *(const f32x4*)lp, r1 = *(const f32x4*)(lp + Wout);
-          const bool ok = ch < A.D;
-          pre[j][ns][0] = ok ? r0 : f32x4{0.f, 0.f, 0.f, 0.f};
-          pre[j][ns][1] = ok ? r1 : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int ns = 0; ns < NDT; ++ns) {
+            const int ch = 4 * ns + kq;
+            const int y0 = hp[tt] * 8 + (p >> 1) * 4 + j * 2, x0 = wp[tt] * 8 + (p & 1) * 4;
+            const float* lp = src + ((long)(ch < A.D ? ch : A.D - 1) * (A.Hp * 8) + y0) * Wout + x0;
+            const f32x4 r0 = *(const f32x4*)lp, r1 = *(const f32x4*)(lp + Wout);
+            const bool ok = ch < A.D;
+            pre[tt][j][ns][0] = ok ? r0 : f32x4{0.f, 0.f, 0.f, 0.f};
+            pre[tt][j][ns][1] = ok ? r1 : f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+      }
     }
     // ---- stages 2 + 3: sub-pixel tile q of W2, then W3 ---------------------------------------------------------------------------
     const float* bias3 = (const float*)(w3s + 64 * 8 * 16);
     static_for<4>([&](auto qc) {
       constexpr int q = decltype(qc)::value;           // sub-pixel (kh2, kw2) = (q >> 1, q & 1)
       const float* bias2 = (const float*)(w2s + q * HE_T2 + 64 * 16 * 16);
-      f32x4 acc2[4];
+      f32x4 acc2[TT][4];
 #pragma unroll
-      for (int ns = 0; ns < 4; ++ns) acc2[ns] = *(const f32x4*)(bias2 + ns * 16 + kq * 4);
-      mfma_stream<16, 4>([&](auto ic) { constexpr int i = decltype(ic)::value; return LdsAddr<q * HE_T2 + (i % 4) * 4096>{a2[i / 4]}; },
+      for (int ns = 0; ns < 4; ++ns) {
+        const f32x4 b = *(const f32x4*)(bias2 + ns * 16 + kq * 4);
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt) acc2[tt][ns] = b;
+      }
+      mfma_stream<16, RD>([&](auto ic) { constexpr int i = decltype(ic)::value; return LdsAddr<q * HE_T2 + (i % 4) * 4096>{a2[i / 4]}; },
                          [&](auto ic, const u32x4& wf) {
                            constexpr int i = decltype(ic)::value;
-                           acc2[i % 4] = mfma_bf16(wf, h1[i / 4], acc2[i % 4]);
+#pragma unroll
+                           for (int tt = 0; tt < TT; ++tt) acc2[tt][i % 4] = mfma_bf16(wf, h1[tt][i / 4], acc2[tt][i % 4]);
                          });
-      u32x4 h2[2];
+      u32x4 h2[TT][2];
 #pragma unroll
-      for (int b = 0; b < 2; ++b) { h2[b] = pack8(he_gelu(acc2[2 * b]), he_gelu(acc2[2 * b + 1])); he_pin(h2[b]); }
+      for (int tt = 0; tt < TT; ++tt)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) { h2[tt][b] = pack8(he_gelu(acc2[tt][2 * b]), he_gelu(acc2[tt][2 * b + 1])); he_pin(h2[tt][b]); }
       // stage 3: rows n3 = (co, kh3, kw3) = 16 ns + 4 kk + r -> channel co = 4 ns + kk, r = (kh3, kw3)
-      f32x4 d[NDT];
+      f32x4 d[TT][NDT];
 #pragma unroll
-      for (int ns = 0; ns < NDT; ++ns) d[ns] = *(const f32x4*)(bias3 + ns * 16 + kq * 4);
-      mfma_stream<2 * NDT, 4>([&](auto ic) { constexpr int i = decltype(ic)::value; return LdsAddr<(i % NDT) * 2048>{a3[i / NDT]}; },
+      for (int ns = 0; ns < NDT; ++ns) {
+        const f32x4 b = *(const f32x4*)(bias3 + ns * 16 + kq * 4);
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt) d[tt][ns] = b;
+      }
+      mfma_stream<2 * NDT, RD>([&](auto ic) { constexpr int i = decltype(ic)::value; return LdsAddr<(i % NDT) * 2048>{a3[i / NDT]}; },
                               [&](auto ic, const u32x4& wf) {
                                 constexpr int i = decltype(ic)::value;
-                                d[i % NDT] = mfma_bf16(wf, h2[i / NDT], d[i % NDT]);
+#pragma unroll
+                                for (int tt = 0; tt < TT; ++tt) d[tt][i % NDT] = mfma_bf16(wf, h2[tt][i / NDT], d[tt][i % NDT]);
                               });
 #pragma unroll
-      for (int ns = 0; ns < NDT; ++ns) { dsum[q][ns] += d[ns] * cord; he_pin(dsum[q][ns]); }
+      for (int tt = 0; tt < TT; ++tt)
+#pragma unroll
+        for (int ns = 0; ns < NDT; ++ns) { dsum[tt][q][ns] += d[tt][ns] * cord; he_pin(dsum[tt][q][ns]); }
     });
+    HE_STAMP(6 + 6 * ord);
     if constexpr (!IS_LAST) {
       __syncthreads();    // (C) every wave is done with this order's W2 tiles and W3
+      HE_STAMP(7 + 6 * ord);
       he_glds<NWV>(wk_of(ord + 1), w3s, HE_T3, tid);
     }
   };
@@ -255,25 +339,30 @@ __global__ __launch_bounds__(NWV * 64, 1) void head_enc_kernel(const HeArgs A) {
     // W2e (requested after the last order's stage 1) is complete for this wave; after the barrier for all -- and every wave is done with W2 / W3
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();      // (C')
+    HE_STAMP(26);
     he_glds<NWV>(A.we + HE_E1 + HE_E2 + (long)p * HE_E3, w2s, HE_E3, tid);      // this pixel's tap slice of W3e: lands under the frame stores and stages 1 + 2
   }
   // ---- the frame: out = last + sum_k c_k d_k, in the pair layout of the stores (rows y0, y0 + 1 x 4 pixels) --------------------------
-  f32x4 fv[4][NDT];                  // [q][ns][r]: pixel r = (kh3, kw3) of sub-pixel q, channel 4 ns + kk
+  f32x4 fv[TT][4][NDT];              // [q][ns][r]: pixel r = (kh3, kw3) of sub-pixel q, channel 4 ns + kk
 #pragma unroll
-  for (int j = 0; j < 2; ++j)
+  for (int tt = 0; tt < TT; ++tt)
 #pragma unroll
-    for (int ns = 0; ns < NDT; ++ns) {
-      const f32x4 dl_ = dsum[2 * j][ns], dr_ = dsum[2 * j + 1][ns];
-      const f32x4 t0 = pre[j][ns][0] + f32x4{dl_[0], dl_[1], dr_[0], dr_[1]};
-      const f32x4 t1 = pre[j][ns][1] + f32x4{dl_[2], dl_[3], dr_[2], dr_[3]};
-      if (live && 4 * ns + kk < A.D) {
-        float* o0 = A.out + (long)img * A.out_bstride + pix_of(j, ns);
-        *(f32x4*)o0 = t0;
-        *(f32x4*)(o0 + Wout) = t1;
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int ns = 0; ns < NDT; ++ns) {
+        const f32x4 dl_ = dsum[tt][2 * j][ns], dr_ = dsum[tt][2 * j + 1][ns];
+        const f32x4 t0 = pre[tt][j][ns][0] + f32x4{dl_[0], dl_[1], dr_[0], dr_[1]};
+        const f32x4 t1 = pre[tt][j][ns][1] + f32x4{dl_[2], dl_[3], dr_[2], dr_[3]};
+        if (live[tt] && 4 * ns + kk < A.D) {
+          const int y0 = hp[tt] * 8 + (p >> 1) * 4 + j * 2, x0 = wp[tt] * 8 + (p & 1) * 4;
+          float* o0 = A.out + (long)img[tt] * A.out_bstride + ((long)(4 * ns + kk) * (A.Hp * 8) + y0) * Wout + x0;
+          *(f32x4*)o0 = t0;
+          *(f32x4*)(o0 + Wout) = t1;
+        }
+        fv[tt][2 * j][ns] = f32x4{t0[0], t0[1], t1[0], t1[1]};
+        fv[tt][2 * j + 1][ns] = f32x4{t0[2], t0[3], t1[2], t1[3]};
       }
-      fv[2 * j][ns] = f32x4{t0[0], t0[1], t1[0], t1[1]};
-      fv[2 * j + 1][ns] = f32x4{t0[2], t0[3], t1[2], t1[3]};
-    }
+  HE_STAMP(27);
   if constexpr (!ENC) return;
   if constexpr (ENC) {
     unsigned a1[8], a2[4], ae1[2];       // W2e sits in the W1 tile (512 B rows), the W3e slice on the W2 tiles (256 B rows)
@@ -284,101 +373,167 @@ __global__ __launch_bounds__(NWV * 64, 1) void head_enc_kernel(const HeArgs A) {
 #pragma unroll
     for (int b = 0; b < 2; ++b) ae1[b] = lds_addr(w1es + l15 * 128 + (swz_chunk(l15, b * 4 + kk, 8) << 4));
     // ---- encoder stage 1: the 2 x 2 x D pixels of sub-block q -> 64 channels (k = (ci, kh, kw): lane kk holds ci = kk + 4 ns) ---------
-    u32x4 h1e[4][2];
+    u32x4 h1e[TT][4][2];
     {
       const float* bias1e = (const float*)(w1es + 64 * 8 * 16);
       constexpr int KB1 = NDT > 2 ? 2 : 1;          // k-blocks that hold real channels (ci < 8, ci < 16)
       static_for<4>([&](auto qc) {
         constexpr int q = decltype(qc)::value;
         const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
-        u32x4 xin[2];
-        xin[0] = pack8(fv[q][0], NDT > 1 ? fv[q][NDT > 1 ? 1 : 0] : zero);
-        xin[1] = NDT > 2 ? pack8(fv[q][NDT > 2 ? 2 : 0], NDT > 3 ? fv[q][NDT > 3 ? 3 : 0] : zero) : u32x4{0u, 0u, 0u, 0u};
-        f32x4 acc[4];
+        u32x4 xin[TT][2];
 #pragma unroll
-        for (int ns = 0; ns < 4; ++ns) acc[ns] = *(const f32x4*)(bias1e + ns * 16 + kk * 4);
-        mfma_stream<4 * KB1, 4>([&](auto ic) { constexpr int i = decltype(ic)::value; return LdsAddr<(i % 4) * 2048>{ae1[i / 4]}; },
+        for (int tt = 0; tt < TT; ++tt) {
+          xin[tt][0] = pack8(fv[tt][q][0], NDT > 1 ? fv[tt][q][NDT > 1 ? 1 : 0] : zero);
+          xin[tt][1] = NDT > 2 ? pack8(fv[tt][q][NDT > 2 ? 2 : 0], NDT > 3 ? fv[tt][q][NDT > 3 ? 3 : 0] : zero) : u32x4{0u, 0u, 0u, 0u};
+        }
+        f32x4 acc[TT][4];
+#pragma unroll
+        for (int ns = 0; ns < 4; ++ns) {
+          const f32x4 b = *(const f32x4*)(bias1e + ns * 16 + kk * 4);
+#pragma unroll
+          for (int tt = 0; tt < TT; ++tt) acc[tt][ns] = b;
+        }
+        mfma_stream<4 * KB1, RD>([&](auto ic) { constexpr int i = decltype(ic)::value; return LdsAddr<(i % 4) * 2048>{ae1[i / 4]}; },
                                 [&](auto ic, const u32x4& wf) {
                                   constexpr int i = decltype(ic)::value;
-                                  acc[i % 4] = mfma_bf16(wf, xin[i / 4], acc[i % 4]);
+#pragma unroll
+                                  for (int tt = 0; tt < TT; ++tt) acc[tt][i % 4] = mfma_bf16(wf, xin[tt][i / 4], acc[tt][i % 4]);
                                 });
-        h1e[q][0] = pack8(he_gelu(acc[0]), he_gelu(acc[1]));
-        h1e[q][1] = pack8(he_gelu(acc[2]), he_gelu(acc[3]));
-        he_pin(h1e[q][0]); he_pin(h1e[q][1]);
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt) {
+          h1e[tt][q][0] = pack8(he_gelu(acc[tt][0]), he_gelu(acc[tt][1]));
+          h1e[tt][q][1] = pack8(he_gelu(acc[tt][2]), he_gelu(acc[tt][3]));
+          he_pin(h1e[tt][q][0]); he_pin(h1e[tt][q][1]);
+        }
       });
     }
+    HE_STAMP(28);
     // ---- encoder stage 2: position p, taps q -> 128 channels, two halves -----------------------------------------------------------
-    u32x4 h2e[4];
+    u32x4 h2e[TT][4];
     {
       const float* bias2e = (const float*)(w1s + 128 * 32 * 16);
       static_for<2>([&](auto hc) {
         constexpr int hh = decltype(hc)::value;
-        f32x4 acc[4];
+        f32x4 acc[TT][4];
 #pragma unroll
-        for (int ns = 0; ns < 4; ++ns) acc[ns] = *(const f32x4*)(bias2e + (4 * hh + ns) * 16 + kk * 4);
-        mfma_stream<32, 4>([&](auto ic) { constexpr int i = decltype(ic)::value; return LdsAddr<(4 * hh + i % 4) * 8192>{a1[i / 4]}; },
+        for (int ns = 0; ns < 4; ++ns) {
+          const f32x4 b = *(const f32x4*)(bias2e + (4 * hh + ns) * 16 + kk * 4);
+#pragma unroll
+          for (int tt = 0; tt < TT; ++tt) acc[tt][ns] = b;
+        }
+        mfma_stream<32, RD>([&](auto ic) { constexpr int i = decltype(ic)::value; return LdsAddr<(4 * hh + i % 4) * 8192>{a1[i / 4]}; },
                            [&](auto ic, const u32x4& wf) {
                              constexpr int i = decltype(ic)::value, kb = i / 4;
-                             acc[i % 4] = mfma_bf16(wf, h1e[kb >> 1][kb & 1], acc[i % 4]);
+#pragma unroll
+                             for (int tt = 0; tt < TT; ++tt) acc[tt][i % 4] = mfma_bf16(wf, h1e[tt][kb >> 1][kb & 1], acc[tt][i % 4]);
                            });
-        h2e[2 * hh] = pack8(he_gelu(acc[0]), he_gelu(acc[1]));
-        h2e[2 * hh + 1] = pack8(he_gelu(acc[2]), he_gelu(acc[3]));
-        he_pin(h2e[2 * hh]); he_pin(h2e[2 * hh + 1]);
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt) {
+          h2e[tt][2 * hh] = pack8(he_gelu(acc[tt][0]), he_gelu(acc[tt][1]));
+          h2e[tt][2 * hh + 1] = pack8(he_gelu(acc[tt][2]), he_gelu(acc[tt][3]));
+          he_pin(h2e[tt][2 * hh]); he_pin(h2e[tt][2 * hh + 1]);
+        }
       });
+    }
+    HE_STAMP(29);
+    int* flag = (int*)w3s;               // W3 is dead: [0] the arrival ticket, [1] "all four workgroups of the group share this XCD"
+    if (tid == 0) {
+      const int started = __hip_atomic_load(A.cnt + 4 * grp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned m = __hip_atomic_load((unsigned*)A.cnt + 4 * grp + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      ((volatile int*)flag)[1] = (started == 4 && (m & (m - 1)) == 0 && A.same_xcd_ok) ? 1 : 0;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();      // (D) the W3e slice is complete
-    // ---- encoder stage 3, tap p: a 128-deep slice of the K = 512 contraction -> fp32 partial, written through -------------------------
+    HE_STAMP(30);
+    const bool same_xcd = ((volatile int*)flag)[1] != 0;
+#ifdef TANTE_ABLATE
+    if (A.stamps && lane == 0) {
+      A.stamps[((long)blockIdx.x * 8 + wave) * 40 + 35] = same_xcd ? 1 : 2;
+      A.stamps[((long)blockIdx.x * 8 + wave) * 40 + 36] = 100 + (__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u);
+      A.stamps[((long)blockIdx.x * 8 + wave) * 40 + 37] = 1000 + __hip_atomic_load(A.cnt + 4 * grp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      A.stamps[((long)blockIdx.x * 8 + wave) * 40 + 38] = 10000 + __hip_atomic_load(A.cnt + 4 * grp + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#endif
+    // ---- encoder stage 3, tap p: a 128-deep slice of the K = 512 contraction -> fp32 partial.  Partials are stored fragment-wise --
+    // tile (group, p, wave, tt), feature tile ns, then lane: every store and every load of the reduction is 1 KiB contiguous per wave
+    // -- with agent scope (sc1: written through to memory), as MI355X_MICROARCH.md's hand-off table asks of both sides.
+    float* ptile = A.part + (((long)grp * 4 + p) * NWV + wave) * (TT * 16 * 256) + lane * 4;
     {
-      float* prow = A.part + (((long)grp * 4 + p) * (NWV * 16) + wave * 16 + l15) * 256 + kk * 4;
       static_for<2>([&](auto hc) {
         constexpr int hh = decltype(hc)::value;
-        f32x4 acc[8];
+        f32x4 acc[TT][8];
 #pragma unroll
-        for (int ns = 0; ns < 8; ++ns) acc[ns] = f32x4{0.f, 0.f, 0.f, 0.f};
-        mfma_stream<32, 4>([&](auto ic) { constexpr int i = decltype(ic)::value; return LdsAddr<(8 * hh + i % 8) * 4096>{a2[i / 8]}; },
+        for (int tt = 0; tt < TT; ++tt)
+#pragma unroll
+          for (int ns = 0; ns < 8; ++ns) acc[tt][ns] = f32x4{0.f, 0.f, 0.f, 0.f};
+        mfma_stream<32, RD>([&](auto ic) { constexpr int i = decltype(ic)::value; return LdsAddr<(8 * hh + i % 8) * 4096>{a2[i / 8]}; },
                            [&](auto ic, const u32x4& wf) {
                              constexpr int i = decltype(ic)::value;
-                             acc[i % 8] = mfma_bf16(wf, h2e[i / 8], acc[i % 8]);
-                           });
-        if (live) {
 #pragma unroll
-          for (int ns = 0; ns < 8; ++ns) st_wt16(prow + (8 * hh + ns) * 16, acc[ns]);
-        }
+                             for (int tt = 0; tt < TT; ++tt) acc[tt][i % 8] = mfma_bf16(wf, h2e[tt][i / 8], acc[tt][i % 8]);
+                           });
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt)
+          if (live[tt]) {
+#pragma unroll
+            for (int ns = 0; ns < 8; ++ns) {
+              float* dst = ptile + (tt * 16 + 8 * hh + ns) * 256;
+              if (same_xcd) *(f32x4*)dst = acc[tt][ns];
+              else he_st_agent(dst, acc[tt][ns]);
+            }
+          }
       });
     }
+    HE_STAMP(31);
     // ---- arrival: the partials are in memory (write-through stores, acknowledged) before the counter moves ---------------------------
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    HE_STAMP(32);
     __syncthreads();
-    int* flag = (int*)w3s;               // W3 is dead
-    if (tid == 0) *(volatile int*)flag = __hip_atomic_fetch_add(A.cnt + grp, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) *(volatile int*)flag = __hip_atomic_fetch_add(A.cnt + 4 * grp, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
+    HE_STAMP(33);
     if (*(volatile int*)flag != 3) return;
     // the last of the group's four workgroups: z = ((((bias + P0) + P1) + P2) + P3), whatever the arrival order was
-    if (tid == 0) A.cnt[grp] = 0;        // ready for the next launch
-    if (live) {
+    if (tid == 0) { A.cnt[4 * grp] = 0; A.cnt[4 * grp + 1] = 0; A.cnt[4 * grp + 2] = 0; }      // ready for the next launch
+    {
       const float* bias3e = (const float*)(A.we + HE_E1 + HE_E2 + 4L * HE_E3);
-      const float* p0 = A.part + (((long)grp * 4) * (NWV * 16) + wave * 16 + l15) * 256 + kk * 4;
-      float* zrow = A.z + (long)(row0 + (unsigned)l15) * 256 + kk * 4;
+      const float* p0 = A.part + (((long)grp * 4) * NWV + wave) * (TT * 16 * 256) + lane * 4;
+      constexpr long PSTRIDE = (long)NWV * TT * 16 * 256;           // floats between the partials of consecutive pixels
+      // TR feature tiles of every token tile per round, 4 TR TT loads of 1 KiB in flight per wave: the reducing workgroup pulls the group's
+      // 512 KiB alone (everything else on the chip has finished or is finishing), so the rounds are latency chains -- as few as the
+      // registers allow (stamps: four rounds of 16 loads took 28 k cycles, 7 k each)
+      constexpr int TR = TT == 1 ? 8 : 4;
 #pragma unroll
-      for (int h = 0; h < 4; ++h) {      // four feature tiles at a time: 16 loads in flight
-        f32x4 v[4][4];
+      for (int h = 0; h < 16 / TR; ++h) {
+        f32x4 v[TT][TR][4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+        for (int tt = 0; tt < TT; ++tt)
 #pragma unroll
-          for (int pp = 0; pp < 4; ++pp) v[t][pp] = he_ld_sys(p0 + (long)pp * (NWV * 16) * 256 + (4 * h + t) * 16);
-        asm volatile("s_waitcnt vmcnt(0)"
-                     : "+v"(v[0][0]), "+v"(v[0][1]), "+v"(v[0][2]), "+v"(v[0][3]), "+v"(v[1][0]), "+v"(v[1][1]), "+v"(v[1][2]), "+v"(v[1][3]),
-                       "+v"(v[2][0]), "+v"(v[2][1]), "+v"(v[2][2]), "+v"(v[2][3]), "+v"(v[3][0]), "+v"(v[3][1]), "+v"(v[3][2]), "+v"(v[3][3])
-                     :
-                     : "memory");
+          for (int t = 0; t < TR; ++t)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const f32x4 b = *(const f32x4*)(bias3e + (4 * h + t) * 16 + kk * 4);
-          *(f32x4*)(zrow + (4 * h + t) * 16) = (((b + v[t][0]) + v[t][1]) + v[t][2]) + v[t][3];
-        }
+            for (int pp = 0; pp < 4; ++pp) v[tt][t][pp] = he_ld_agent(p0 + pp * PSTRIDE + (tt * 16 + TR * h + t) * 256);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt)
+#pragma unroll
+          for (int t = 0; t < TR; t += 4)
+            asm volatile(""
+                         : "+v"(v[tt][t][0]), "+v"(v[tt][t][1]), "+v"(v[tt][t][2]), "+v"(v[tt][t][3]), "+v"(v[tt][t + 1][0]), "+v"(v[tt][t + 1][1]),
+                           "+v"(v[tt][t + 1][2]), "+v"(v[tt][t + 1][3]), "+v"(v[tt][t + 2][0]), "+v"(v[tt][t + 2][1]), "+v"(v[tt][t + 2][2]),
+                           "+v"(v[tt][t + 2][3]), "+v"(v[tt][t + 3][0]), "+v"(v[tt][t + 3][1]), "+v"(v[tt][t + 3][2]), "+v"(v[tt][t + 3][3]));
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt)
+          if (live[tt]) {
+            float* zrow = A.z + (long)(row0 + 16u * tt + (unsigned)l15) * 256 + kk * 4;
+#pragma unroll
+            for (int t = 0; t < TR; ++t) {
+              const f32x4 b = *(const f32x4*)(bias3e + (TR * h + t) * 16 + kk * 4);
+              *(f32x4*)(zrow + (TR * h + t) * 16) = (((b + v[tt][t][0]) + v[tt][t][1]) + v[tt][t][2]) + v[tt][t][3];
+            }
+          }
       }
     }
+    HE_STAMP(34);
   }
 }
 
@@ -445,22 +600,22 @@ __global__ void pack_head_enc_kernel(const float* __restrict__ w1, const float* 
   }
 }
 
-template <int NWV, bool ENC, int NDT>
+template <int NWV, int TT, bool ENC, int NDT>
 void launch_head_enc_k(const HeArgs& A, hipStream_t s) {
   static TantePerDevice attr;
   attr.once([&] {
-    (void)hipFuncSetAttribute((const void*)head_enc_kernel<NWV, ENC, NDT>, hipFuncAttributeMaxDynamicSharedMemorySize, HE_LDS);
+    (void)hipFuncSetAttribute((const void*)head_enc_kernel<NWV, TT, ENC, NDT>, hipFuncAttributeMaxDynamicSharedMemorySize, HE_LDS);
   });
   const unsigned grid = (unsigned)((A.groups + 7) / 8) * 32;   // 8 token groups x 4 pixels per 32 consecutive workgroups
-  hipLaunchKernelGGL((head_enc_kernel<NWV, ENC, NDT>), dim3(grid), dim3(NWV * 64), HE_LDS, s, A);
+  hipLaunchKernelGGL((head_enc_kernel<NWV, TT, ENC, NDT>), dim3(grid), dim3(NWV * 64), HE_LDS, s, A);
 }
-template <int NWV, bool ENC>
+template <int NWV, int TT, bool ENC>
 void launch_head_enc_nw(const HeArgs& A, hipStream_t s) {
   switch ((A.D + 3) / 4) {
-    case 1: launch_head_enc_k<NWV, ENC, 1>(A, s); break;
-    case 2: launch_head_enc_k<NWV, ENC, 2>(A, s); break;
-    case 3: launch_head_enc_k<NWV, ENC, 3>(A, s); break;
-    default: launch_head_enc_k<NWV, ENC, 4>(A, s); break;
+    case 1: launch_head_enc_k<NWV, TT, ENC, 1>(A, s); break;
+    case 2: launch_head_enc_k<NWV, TT, ENC, 2>(A, s); break;
+    case 3: launch_head_enc_k<NWV, TT, ENC, 3>(A, s); break;
+    default: launch_head_enc_k<NWV, TT, ENC, 4>(A, s); break;
   }
 }
 
@@ -471,6 +626,10 @@ int he_group_tokens(long rows) {      // 128-token groups (8 waves) once they st
 
 }  // namespace
 
+#ifdef TANTE_ABLATE
+extern "C" void tante_head_enc_set_stamps(unsigned long long* p) { g_he_stamps = p; }
+#endif
+
 extern "C" int tante_head_enc_supported(int C, int D) { return C == 256 && D >= 1 && D <= 16; }
 
 extern "C" int64_t tante_head_enc_stream_bytes(int C) { return C == 256 ? HE_ENC_BYTES : 0; }
@@ -479,7 +638,7 @@ extern "C" int64_t tante_head_enc_stream_bytes(int C) { return C == 256 ? HE_ENC
 extern "C" int64_t tante_head_enc_ws_bytes(int64_t rows) {
   if (rows <= 0) return 0;
   const long gt = he_group_tokens(rows), groups = (rows + gt - 1) / gt;
-  return groups * 4 * gt * 256 * 4 + ((groups * 4 + 255) / 256) * 256;
+  return groups * 4 * gt * 256 * 4 + ((groups * 16 + 255) / 256) * 256;
 }
 
 extern "C" int tante_pack_head_enc(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3, const float* b3, int C, int D,
@@ -528,10 +687,21 @@ extern "C" int tante_head_enc_fused(int n_ord, const float* const* rows, const v
   A.groups = (int)((n_rows + gt - 1) / gt);
   A.we = (const char*)enc_stream; A.z = z;
   A.part = (float*)ws;
+  A.same_xcd_ok = tante_opt("TANTE_HEAD_L2_HANDOFF", 1);
   A.cnt = enc ? (int*)((char*)ws + (long)A.groups * 4 * gt * 256 * 4) : nullptr;
+#ifdef TANTE_ABLATE
+  A.stamps = g_he_stamps;
+#else
+  A.stamps = nullptr;
+#endif
   hipStream_t s = (hipStream_t)stream;
-  if (gt == 128) { if (enc) launch_head_enc_nw<8, true>(A, s); else launch_head_enc_nw<8, false>(A, s); }
-  else { if (enc) launch_head_enc_nw<4, true>(A, s); else launch_head_enc_nw<4, false>(A, s); }
+  // 128-token groups run as 8 waves x 1 tile.  The 4 waves x 2 tiles form (TT = 2: every LDS weight fragment feeds two MFMAs, half the LDS
+  // traffic) was built and measured SLOWER, 78 against 67 us: the kernel is bound by instruction issue (per order and wave ~2 000
+  // instructions for 152 MFMAs; GELU alone is 8 VALU instructions per element and packed fp32 math does not run in an MFMA's shadow),
+  // not by LDS bandwidth or latency (ring depths 4 / 8 / 12: +-0), so one wave per SIMD doing twice the work gains nothing.  Kept as a
+  // template parameter, not instantiated.
+  if (gt == 128) { if (enc) launch_head_enc_nw<8, 1, true>(A, s); else launch_head_enc_nw<8, 1, false>(A, s); }
+  else { if (enc) launch_head_enc_nw<4, 1, true>(A, s); else launch_head_enc_nw<4, 1, false>(A, s); }
   TANTE_CHECK_LAUNCH();
   return 0;
 }

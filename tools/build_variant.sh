@@ -11,7 +11,7 @@ case $base in
   block_fused) eflags="-fno-honor-nans -DTANTE_MFMA_SETPRIO -mllvm -amdgpu-sched-strategy=max-ilp";;
   block_sliced) eflags="-fno-honor-nans -DTANTE_MFMA_SETPRIO -DFS_PRIO=1";;
   block_bwd) eflags="-fno-honor-nans -DTANTE_MFMA_SETPRIO -DBT_PRIO";;
-  head_fused|enc_fused|operators|spectral_dft) eflags="-fno-honor-nans";;
+  head_fused|head_enc|enc_fused|operators|spectral_dft) eflags="-fno-honor-nans";;
   pointwise) eflags="";;
 esac
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=fast $eflags $extra -c $R/tante_amd/csrc/$base.hip -o $R/tools/_ab/obj_$name/$base.o
