@@ -401,6 +401,17 @@ def test_g8_rollout(dev, name, mode):
     close(yt, g["y_train"], mode)
     for t in range(n_roll):
         close(y[:, t], g["y_eval"][:, t], mode)
+    # the derivative part of every model call (its frames minus the call's own last input frame) against the reference's
+    yc, rc = y.cpu(), g["y_eval"]
+    prev_y = torch.cat([g["inp"][:, -1:], yc], dim=1)
+    prev_r = torch.cat([g["inp"][:, -1:], rc], dim=1)
+    bar = 5e-5 if mode == "fp32" else 1e-2
+    for t0 in range(0, n_roll, ol):
+        d = yc[:, t0:t0 + ol] - prev_y[:, t0:t0 + 1]
+        dref = rc[:, t0:t0 + ol] - prev_r[:, t0:t0 + 1]
+        r = rel_err(d, dref)
+        record_parity(r, max_rel(d, dref), bar, mode, f"g8 rollout, call at step {t0 + 1}, derivative part")
+        assert r < bar, (name, mode, t0, r)
     assert torch.equal(y_ref.cpu(), g["y_ref"])
 
 

@@ -728,7 +728,10 @@ def test_temporal_propagator_inside_the_block_launch(dev, B, T, H, W):
     (tante_block_fused_tprop: fp32 v_mfma_f32_4x4x1 contractions in the kernel's LayerNorm1 phase) against the propagator as a launch of
     its own followed by the same block (attn_backbone.py:144-145 followed by l.154-162) -- incl. workgroups with dead slots (B H W not
     a multiple of 16 sequences).  Both evaluate the propagator in fp32 with the same GELU polynomial; the fused form sums in the MFMA's
-    k order: the residual stream after the whole backbone agrees to fp32 rounding (1e-6 relative), far inside the bf16 path's 1e-2."""
+    k order, so the PROPAGATED ROWS agree to fp32 rounding (~1e-7) -- but the comparison is made after the three bf16 blocks behind them,
+    where a last-bit difference of a row flips the bf16 rounding of a LayerNorm output here and there (each flip a 4e-3 step of one
+    element): 1.9e-4 measured on the whole stream, held to 2e-4 / 2e-3 (L2 / max), a fiftieth of the bf16 path's 1e-2.  The fused launch
+    against the ORACLE: tests/test_hip_round4.py::test_temporal_propagator_fused_against_oracle."""
     import tante_amd
     from tante_amd import attn_backbone as AB, _lib as L
     torch.manual_seed(B * 100 + H)
@@ -751,6 +754,6 @@ def test_temporal_propagator_inside_the_block_launch(dev, B, T, H, W):
             AB.FUSE_TPROP = saved
     assert torch.isfinite(outs[0]).all()
     r, mx = rel_err(outs[0], outs[1]), max_rel(outs[0], outs[1])
-    record_parity(r, mx, 1e-6, "fp32", "fused temporal propagator vs its own launch (whole backbone, bf16 blocks)")
+    record_parity(r, mx, 2e-4, "bf16", "fused temporal propagator vs its own launch (whole backbone, bf16 blocks)")
     # bf16 blocks downstream amplify a last-bit difference of the propagated rows where a LayerNorm output rounds to another bf16 value
     assert r < 2e-4 and mx < 2e-3, (r, mx)
