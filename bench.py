@@ -51,6 +51,7 @@ def parse():
     p.add_argument("--no-train", action="store_true", help="skip the train-step leg (configs/tante_trl.yaml)")
     p.add_argument("--train-steps", type=int, default=12)
     p.add_argument("--no-train-strong", action="store_true", help="skip the strong-scaling train line (global batch 64)")
+    p.add_argument("--no-workloads", action="store_true", help="skip the compact cfg2 B=1 / cfg4 / cfg5 legs (the `workloads` object)")
     return p.parse_args()
 
 
@@ -170,37 +171,69 @@ def train_flops_per_sample(cfg, wl) -> float:
     return 3.0 * fwd * wl["n_steps_output"]
 
 
-def main():
-    args = parse()
-    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
-        raise SystemExit(launch_ranks(args))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: the launcher and the flag must agree")
-    # TANTE_DIST_BACKEND=gloo TANTE_ALL_ON_GPU0=1: every rank on GPU 0, collectives through gloo -- the N-rank code path (sharding,
-    # broadcast, the all-reduce beside the captured graph, MAX-reduced timing, weak / strong lines) end to end on a 1-GPU box.
-    # PLUMBING, NOT PERFORMANCE: the ranks share one GPU and gloo stages through the host; the line says so.
-    backend = os.environ.get("TANTE_DIST_BACKEND", "nccl")
-    plumbing = os.environ.get("TANTE_ALL_ON_GPU0") == "1"
-    if plumbing and backend == "nccl" and world > 1:
-        raise SystemExit("bench.py: TANTE_ALL_ON_GPU0=1 needs TANTE_DIST_BACKEND=gloo (RCCL cannot put two ranks on one device)")
-    if plumbing:
-        local = 0
-    if local >= torch.cuda.device_count():
-        raise SystemExit(f"bench.py: LOCAL_RANK {local} but only {torch.cuda.device_count()} GPU(s) are visible")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+def physical_cores():
+    """Physical cores of the host from /proc/cpuinfo (unique (physical id, core id) pairs); None when it cannot be read."""
+    try:
+        seen, phys, core = set(), None, None
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("physical id"):
+                phys = ln.split(":")[1].strip()
+            elif ln.startswith("core id"):
+                core = ln.split(":")[1].strip()
+            elif not ln.strip():
+                if phys is not None and core is not None:
+                    seen.add((phys, core))
+                phys = core = None
+        if phys is not None and core is not None:
+            seen.add((phys, core))
+        return len(seen) or None
+    except OSError:
+        return None
 
+
+def cvit_cpu_leg(lg, gpu_frames_per_s):
+    """cfg4's CPU baseline: the oracle (oracle/cvit_oracle.py, kind "port") on the shipped model with 1 024 and 2 048 random query points
+    -- as written the full 65 536-query grid embedding needs an 8.6 GB temporary -- extrapolated linearly in the query count to the
+    full grid (the encoder is the intercept, the grid embedding + decoder + head are per query)."""
+    import torch
+    from oracle import cvit_oracle as OC
+    cfg, wl, model = lg["cfg"], lg["wl"], lg["model"]
+    H, W = lg["res"]
+    mk = {k: v for k, v in cfg["model"].items() if k not in ("_target_", "in_T")}
+    mk["grid_size"] = tuple(mk["grid_size"])
+    ocfg = OC.CvitCfg(cfg["model"]["in_T"], lg["D"], (H, W), **mk)
+    w = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+    affinity = len(os.sched_getaffinity(0))
+    threads = max(1, min(affinity, physical_cores() or affinity))
+    torch.set_num_threads(threads)
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(1, lg["T_in"], lg["D"], H, W, generator=g)
+    ts = {}
+    with torch.no_grad():
+        OC.cvit_forward(w, ocfg, x, torch.rand(256, 2, generator=g))      # warm-up
+        for n in (1024, 2048):
+            c = torch.rand(n, 2, generator=g)
+            t0 = time.perf_counter()
+            OC.cvit_forward(w, ocfg, x, c)
+            ts[n] = time.perf_counter() - t0
+    per_q = (ts[2048] - ts[1024]) / 1024.0
+    base = max(0.0, ts[1024] - 1024 * per_q)
+    t_full = base + per_q * H * W
+    fps = lg["n_steps"] / t_full
+    return {"value": round(fps, 4), "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": f"oracle CViT forward, B = 1, 1 024 / 2 048 random query points in {ts[1024]:.2f} / {ts[2048]:.2f} s, extrapolated linearly to the "
+                      f"{H * W}-query grid ({t_full:.1f} s per forward: encoder intercept {base:.2f} s + {1e3 * per_q:.3f} ms per query)",
+            "gpu_over_cpu": round(gpu_frames_per_s / fps, 1)}
+
+
+def rollout_leg(config, batch_arg, dtype_arg, steps, warmup, dev, rank, world, dist, want_roofline, graph=False):
+    """One timed leg: `steps` rollouts (CViT: model calls) of `config` at per-GPU batch `batch_arg` (None: workload.batch_size), barrier +
+    synchronize on both sides, MAX over ranks; then (rank 0) the instrumented pass for the roofline entry.  graph=True replays the whole
+    rollout as ONE captured HIP graph (B = 1: the 100-odd launches of a rollout are issue-bound on the host)."""
+    class _A:      # the names the body below was written against
+        pass
+    args = _A()
+    args.config, args.batch, args.dtype, args.steps, args.warmup, args.no_roofline = config, batch_arg, dtype_arg, steps, warmup, not want_roofline
     import tante_amd
     from tante_amd import kernels as K
     cfg = tante_amd.load_config(args.config)
@@ -239,6 +272,29 @@ def main():
                 return y
             y, _ = tante_amd.rollout_model(model, batch, fmt, n_steps, device=dev)
         return y
+
+    graph_note = "off"
+    if graph:
+        eager_step = step
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                eager_step()                      # packs, tables, workspaces and allocator pools exist before the capture
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        try:
+            g_ = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_):
+                g_out = eager_step()
+            graph_note = "on"
+
+            def step():
+                g_.replay()
+                return g_out
+        except Exception as e:      # noqa: BLE001
+            graph_note = f"capture failed ({type(e).__name__}: {e}): eager"
+            step = eager_step
 
     def sync():
         torch.cuda.synchronize()
@@ -304,8 +360,19 @@ def main():
         def chain_name(a, resid, w, bias, eps_ln2, M, out, tail=None):
             return ("chain512_kernel<1> (CViT block tail + model tail: out-proj+res, LN2+fc1+GELU+fc2+res, norm2, dense+GELU+res, LN, output layer)" if tail is not None
                     else "chain512_kernel<0> (CViT block tail: out-proj+res, LN2+fc1+GELU+fc2+res)")
+        def fl_head_enc(rows, a_n0, a_s1, a_s0, a_off, n_img, Hp, Wp, C_, D_, *a, **kw):
+            tok = n_img * Hp * Wp      # per token: n_ord x [4 C (C/2) + 16 (C/2)(C/4) + 64 (C/4) D] heads, + the encoder back: 16 (4 D)(C/4) + 4 C (C/2) + 2 C C
+            head = len(rows) * 2.0 * (4 * C_ * C_ // 2 + 16 * (C_ // 2) * (C_ // 4) + 64 * (C_ // 4) * D_)
+            enc = 2.0 * (16 * 4 * D_ * (C_ // 4) + 4 * C_ * (C_ // 2) + 2 * C_ * C_) if kw.get("enc_stream") is not None else 0.0
+            return tok * (head + enc)
+
+        def head_enc_name(*a, **kw):
+            return ("head_enc_kernel (derivative heads of every order + Taylor sum + re-encoding of the predicted frame)" if kw.get("enc_stream") is not None
+                    else "head_enc_kernel (derivative heads of every order + Taylor sum)")
         saved = (K.block_fused, K.linear, K.cross_attention, K.spectral_layer)
         saved_chain = K.cvit_chain512
+        saved_he = K.head_enc_fused
+        K.head_enc_fused = timed("head_enc_kernel", K.head_enc_fused, fl_head_enc, head_enc_name)
         K.cvit_chain512 = timed("chain512_kernel", K.cvit_chain512, fl_chain, chain_name)
         K.block_fused = timed("fused_block_kernel", K.block_fused, fl_block, block_name)
         K.linear = timed("gemm_kernel (token-stationary projection GEMM)", K.linear, fl_lin)
@@ -317,6 +384,7 @@ def main():
         finally:
             K.block_fused, K.linear, K.cross_attention, K.spectral_layer = saved
             K.cvit_chain512 = saved_chain
+            K.head_enc_fused = saved_he
         tot = {k: (sum(e0.elapsed_time(e1) for e0, e1, _ in v), sum(f for _, _, f in v), len(v)) for k, v in prof.items()}
         name = max(tot, key=lambda k: tot[k][0])
         ms, fl, n = tot[name]
@@ -368,6 +436,47 @@ def main():
                                                  "forward (dense-as-written it would add 1 104 GFLOP per forward), and the decoder's query projection "
                                                  "runs once for the coordinate queries every sample shares (as written: once per sample, +34 GFLOP "
                                                  "per extra sample)"}
+
+    return {"value": value, "elapsed": elapsed, "roofline": roofline, "model": model, "batch": batch, "cfg": cfg, "wl": wl, "kind": kind, "B": B,
+            "n_steps": n_steps, "T_in": T_in, "res": res, "D": D, "dtype": dtype, "graph": graph_note}
+
+
+def main():
+    args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(launch_ranks(args))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: the launcher and the flag must agree")
+    # TANTE_DIST_BACKEND=gloo TANTE_ALL_ON_GPU0=1: every rank on GPU 0, collectives through gloo -- the N-rank code path (sharding,
+    # broadcast, the all-reduce beside the captured graph, MAX-reduced timing, weak / strong lines) end to end on a 1-GPU box.
+    # PLUMBING, NOT PERFORMANCE: the ranks share one GPU and gloo stages through the host; the line says so.
+    backend = os.environ.get("TANTE_DIST_BACKEND", "nccl")
+    plumbing = os.environ.get("TANTE_ALL_ON_GPU0") == "1"
+    if plumbing and backend == "nccl" and world > 1:
+        raise SystemExit("bench.py: TANTE_ALL_ON_GPU0=1 needs TANTE_DIST_BACKEND=gloo (RCCL cannot put two ranks on one device)")
+    if plumbing:
+        local = 0
+    if local >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: LOCAL_RANK {local} but only {torch.cuda.device_count()} GPU(s) are visible")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+
+    leg = rollout_leg(args.config, args.batch, args.dtype, args.steps, args.warmup, dev, rank, world, dist, not args.no_roofline)
+    import tante_amd
+    from tante_amd import kernels as K
+    value, elapsed, roofline, model, batch, cfg, wl, kind = (leg[k] for k in ("value", "elapsed", "roofline", "model", "batch", "cfg", "wl", "kind"))
+    B, n_steps, T_in, res, D, dtype = (leg[k] for k in ("B", "n_steps", "T_in", "res", "D", "dtype"))
 
     train = None
     if not args.no_train and kind == "tante" and os.path.basename(args.config) == "tante_am.yaml":
@@ -429,13 +538,13 @@ def main():
         train = {"metric": "train-step samples/sec, TANTE on 128x384 TRL-2D (4-step BPTT, MSE, clip, AdamW)", "scaling": "weak", **weak,
                  "dropout": drop,
                  "collective": ("%s all-reduce(sum) of the flat fp32 gradient bucket, %d bytes, once per step; 1/world folded into "
-                                "clip + AdamW" % ("RCCL" if backend == "nccl" else backend, nbytes)) if world > 1 else None}
+                                "clip + AdamW [%s]" % ("RCCL" if backend == "nccl" else backend, nbytes, tante_amd.dist.collective_info())) if world > 1 else None}
         if 64 % world == 0 and not args.no_train_strong:
             strong, _ = train_leg(64 // world, max(1, args.train_steps if world > 1 else 2))
             train["strong"] = {"scaling": "strong", **strong}
 
     cpu = None
-    if not args.no_cpu_baseline and rank == 0 and world == 1 and kind not in ("cvit", "fno"):      # (cfg4 as written needs a 8.6 GB temporary on the host)
+    if not args.no_cpu_baseline and rank == 0 and world == 1 and kind not in ("cvit", "fno"):      # (cfg4: the `workloads` object's own CPU leg)
         from oracle import tante_oracle as O
         mk = cfg["model"]
         ocfg = O.TanteCfg(mk["in_T"], D, res, taylor_order=mk.get("taylor_order", 1), frame_interval=mk.get("frame_interval", 1.0),
@@ -443,32 +552,80 @@ def main():
                           embed_dim=mk.get("embed_dim", 256), patch_scale=mk.get("patch_scale", 32),
                           **({"enc_dec_type": "fno", "modes1": mk.get("modes1", 32), "modes2": mk.get("modes2", 32)} if kind == "tante_fno" else {}))
         w = {k: (v.detach().cpu() if v.is_complex() else v.detach().float().cpu()) for k, v in model.state_dict().items()}
-        # the GPU box gives one job a share of the host (16 cores per GPU), whatever os.cpu_count() says
+        # BASELINE.md's protocol: the CPU path on all physical host cores.  The GPU box reports 256 hardware threads in the affinity
+        # mask while one GPU job gets a 16-core share of the host, so BOTH are timed and reported: `value` is the run at
+        # min(affinity, physical cores), `share_16` the run at the 16-thread share (TANTE_CPU_THREADS changes that number).
         affinity, cap = len(os.sched_getaffinity(0)), int(os.environ.get("TANTE_CPU_THREADS", "16"))
-        cores = min(affinity, cap)
-        torch.set_num_threads(cores)
-        Bc, nc = B, n_steps          # the full batch and rollout length: ~10-15 s of CPU work on 16 cores
-        cb = {"input": batch["input"][:Bc].cpu(), "output": batch["output"][:Bc, :nc].cpu()}
-        # the oracle in its fused-op spelling: the form tools/cpu_reference_time.py holds to +-10 % of the REAL reference's time on the
-        # same tensors in the build container (profiles/cpu_reference.json); the written-out spelling the parity tests use runs ~2x slower
-        O.set_fast(True)
-        try:
-            with torch.no_grad():
-                O.rollout(w, ocfg, {"input": cb["input"][:1], "output": cb["output"][:1, :1]}, 1)      # warm-up
-                t0 = time.perf_counter()
-                O.rollout(w, ocfg, cb, nc)
-                tc = time.perf_counter() - t0
-        finally:
-            O.set_fast(False)
+        phys = physical_cores()
+        full = max(1, min(affinity, phys or affinity))
         cpu_name = "unknown"
         try:
             cpu_name = next(ln.split(":", 1)[1].strip() for ln in open("/proc/cpuinfo") if ln.startswith("model name"))
         except (OSError, StopIteration):
             pass
-        cpu = {"value": round(Bc * nc / tc, 3), "unit": "frames/s", "cores": torch.get_num_threads(), "cpu_model": cpu_name, "kind": "port",
-               "affinity_cores": affinity, "thread_cap": cap, "limited_by": "thread_cap (TANTE_CPU_THREADS; the box gives one GPU job a 16-core share)" if cap < affinity else "affinity",
-               "sample": f"oracle rollout (fused-op spelling, within 10 % of the reference's own CPU time: profiles/cpu_reference.json), "
-                         f"{Bc} samples x {nc} frames of the same workload, fp32, {tc:.1f} s"}
+
+        def oracle_leg(threads, Bc, nc):
+            torch.set_num_threads(threads)
+            cb = {"input": batch["input"][:Bc].cpu(), "output": batch["output"][:Bc, :nc].cpu()}
+            # the oracle in its fused-op spelling: the form tools/cpu_reference_time.py checks against the REAL reference's time on the same
+            # tensors in the build container (profiles/cpu_reference.json: the oracle takes 1.09 x the reference's time, i.e. this
+            # baseline is ~9 % SLOWER than the reference would be); the written-out spelling the parity tests use runs ~2x slower
+            O.set_fast(True)
+            try:
+                with torch.no_grad():
+                    O.rollout(w, ocfg, {"input": cb["input"][:1], "output": cb["output"][:1, :1]}, 1)      # warm-up
+                    t0 = time.perf_counter()
+                    O.rollout(w, ocfg, cb, nc)
+                    tc = time.perf_counter() - t0
+            finally:
+                O.set_fast(False)
+            return {"value": round(Bc * nc / tc, 3), "cores": torch.get_num_threads(), "seconds": round(tc, 1),
+                    "sample": f"{Bc} samples x {nc} frames of the same workload, fp32"}
+        legs = {}
+        for th in sorted({full, min(affinity, cap)}, reverse=True):
+            legs[th] = oracle_leg(th, B, n_steps if th == full else max(1, n_steps // 2))
+        main_leg = legs[full]
+        cpu = {"value": main_leg["value"], "unit": "frames/s", "cores": main_leg["cores"], "cpu_model": cpu_name, "kind": "port",
+               "affinity_cores": affinity, "physical_cores": phys,
+               "sample": "oracle rollout (fused-op spelling; it takes 1.09 x the reference's own CPU time on the same tensors: "
+                         f"profiles/cpu_reference.json), {main_leg['sample']}, {main_leg['seconds']} s at min(affinity, physical cores) = {full} threads",
+               "share_16": {k: v for k, v in legs[min(affinity, cap)].items()} if min(affinity, cap) != full else None,
+               "gpu_over_cpu": {"all_physical_cores": round(value / main_leg["value"], 1),
+                                **({"share": round(value / legs[min(affinity, cap)]["value"], 1)} if min(affinity, cap) != full else {})}}
+
+    workloads = None
+    if (not args.no_workloads and rank == 0 and world == 1 and kind == "tante" and os.path.basename(args.config) == "tante_am.yaml"):
+        # The other BASELINE configurations, compact, in the driver's own run (round-3 verdict item 7): cfg2 at B = 1 (eager and as ONE
+        # captured graph), cfg4 at B = 1 / 4 with its whole-forward fraction and a CPU leg, cfg5 with its HBM roofline.  Short legs.
+        del model, batch, leg
+        torch.cuda.empty_cache()
+        workloads = {}
+
+        def compact(lg, steps):
+            r = lg["roofline"] or {}
+            o = {"value": round(lg["value"], 1), "unit": "frames/s", "ms_per_step": round(1e3 * lg["elapsed"] / steps, 3), "batch": lg["B"]}
+            if lg["graph"] != "off":
+                o["hip_graph"] = lg["graph"]
+            if r:
+                o["roofline"] = {k: r[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_us") if k in r}
+                o["roofline"]["kernel"] = r["kernel"].split(" (")[0]
+                if "whole_forward" in r:
+                    o["whole_forward"] = {k: r["whole_forward"][k] for k in ("algorithmic_gflop", "ms", "TFLOP/s", "frac")}
+            return o
+        try:
+            for tag, gr in (("cfg2_b1", False), ("cfg2_b1_graph", True)):
+                lg = rollout_leg(args.config, 1, args.dtype, 20, 4, dev, rank, world, dist, False, graph=gr)
+                workloads[tag] = compact(lg, 20)
+                del lg
+            for tag, cfile, bb, st in (("cfg4_b1", "cvit_rb.yaml", 1, 30), ("cfg4_b4", "cvit_rb.yaml", 4, 12), ("cfg5", "tante_fno.yaml", None, 6)):
+                lg = rollout_leg(os.path.join(ROOT, "configs", cfile), bb, None, st, 3, dev, rank, world, dist, True)
+                workloads[tag] = compact(lg, st)
+                if tag == "cfg4_b1" and not args.no_cpu_baseline:
+                    workloads[tag]["cpu_baseline"] = cvit_cpu_leg(lg, workloads[tag]["value"])
+                del lg
+                torch.cuda.empty_cache()
+        except Exception as e:      # noqa: BLE001 -- a side leg must never cost the headline line
+            workloads["error"] = f"{type(e).__name__}: {e}"
 
     if rank == 0:
         title = {"tante": "rollout frames/sec (fwd), TANTE on 256x256 Active Matter" if os.path.basename(args.config).startswith("tante_am")
@@ -482,7 +639,7 @@ def main():
                "config": {"workload": os.path.basename(args.config), "fields": D, "resolution": list(res), "batch_per_gpu": B,
                           "n_steps_input": T_in, "n_steps_rollout": n_steps, "taylor_order": cfg["model"].get("taylor_order", 1),
                           "attn_axes": cfg["model"].get("attn_axes"), "parallelism": f"batch-sharded x{world} (no collective)"},
-               "roofline": roofline, "cpu_baseline": cpu, "train": train}
+               "roofline": roofline, "cpu_baseline": cpu, "train": train, "workloads": workloads}
         if plumbing or (world > 1 and backend != "nccl"):
             out["plumbing"] = (f"NOT A PERFORMANCE NUMBER: {world} ranks share GPU 0 and the collectives go through '{backend}' "
                                "(TANTE_ALL_ON_GPU0 / TANTE_DIST_BACKEND); run to exercise the multi-rank code path only")

@@ -199,7 +199,18 @@ SIGNATURES = {
                              c_vp, c_vp, c_vp, c_i64, c_vp], c_i32),
 }
 
+# every option name the library looks up (tante_opt in csrc/): tests/test_host_cpu.py checks this list against the sources
+LIB_OPTIONS = ("TANTE_ATTN_BWD_HG", "TANTE_ATTN_BWD_NO_SPLIT", "TANTE_ATTN_BWD_VALU", "TANTE_ATTN_FWD_VALU", "TANTE_AXIS_BWD_SMALL_WGS",
+               "TANTE_AXIS_BWD_WGS", "TANTE_AXIS_CT", "TANTE_AXIS_GENERIC", "TANTE_AXIS_MFMA", "TANTE_AXIS_NT", "TANTE_AXIS_WGRAD_WGS",
+               "TANTE_BLOCK_KERNEL", "TANTE_COLSUM_ROWS", "TANTE_CVIT_CHAIN_TOKENS", "TANTE_ENC23_SPLIT", "TANTE_FILM_BWD_ROWS",
+               "TANTE_FS_GROUPS", "TANTE_FS_WAVES", "TANTE_GEMM_NO_LITE", "TANTE_GEMM_WGS", "TANTE_HEAD_L2_HANDOFF", "TANTE_HEAD_WAVES",
+               "TANTE_IM2COL_TILED", "TANTE_RESIZE_TILED", "TANTE_SPECTRAL_DFT", "TANTE_SPECTRAL_X3", "TANTE_WGRAD_DEEP",
+               "TANTE_WGRAD_JOBS", "TANTE_WGRAD_JOBS_WGS", "TANTE_WGRAD_NO_SLAB", "TANTE_WGRAD_NO_TR", "TANTE_WGRAD_REDUCE_NY",
+               "TANTE_WGRAD_RG", "TANTE_WGRAD_SLAB_WGS", "TANTE_WGRAD_TR_WGS", "TANTE_WGRAD_WGS", "TANTE_XATTN_GPW", "TANTE_XATTN_VALU",)
+
+
 _lib = None
+ABI_VERSION = 4      # include/tante_hip.h: bumped whenever an entry point is added or changes (round 4: tante_head_enc_*)
 
 
 def lib():
@@ -215,15 +226,26 @@ def lib():
             fn = getattr(L, name)      # AttributeError here = header / library mismatch
             fn.argtypes = argtypes
             fn.restype = restype
+        got = int(L.tante_abi_version())
+        if got != ABI_VERSION:
+            raise RuntimeError(f"{LIB_PATH}: library ABI {got}, this binding expects {ABI_VERSION} -- a stale build (or a stale variant under "
+                               "TANTE_LIB); rebuild with `python -m tante_amd.build`")
         _lib = L
         # The library never reads the environment; the measurement scripts under tools/ drive its A/B switches through TANTE_*
-        # environment variables, which are forwarded ONCE here (integer-valued ones only; later changes go through set_option).
-        for k, v in os.environ.items():
-            if k.startswith("TANTE_") and len(k) < 48:
-                try:
-                    L.tante_set_option(k.encode(), int(v))
-                except ValueError:
-                    pass
+        # environment variables, which are forwarded ONCE here -- only the names the LIBRARY looks up (LIB_OPTIONS: the Python-side
+        # switches would only fill its 64-entry table), and a refused name is reported instead of silently measuring the default form.
+        import warnings
+        for k in LIB_OPTIONS:
+            v = os.environ.get(k)
+            if v is None:
+                continue
+            try:
+                rc = L.tante_set_option(k.encode(), int(v))
+            except ValueError:
+                warnings.warn(f"{k}={v!r}: library options are integers; ignored")
+                continue
+            if rc != 0:
+                warnings.warn(f"{k}={v}: tante_set_option refused it ({L.tante_last_error().decode(errors='replace')})")
     return _lib
 
 

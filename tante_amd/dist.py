@@ -41,11 +41,34 @@ def shard_batch(batch: Dict[str, torch.Tensor], rank: int, world: int) -> Dict[s
     return out
 
 
+# True: an initialised process group of ONE rank still issues the collective (the identity there).  tests/rccl_world1_child.py uses it
+# to run RCCL's all-reduce beside the captured train-step graph on the single GPU a test box has.
+FORCE_COLLECTIVE = False
+
+
+def collective_needed(world: int) -> bool:
+    return world > 1 or (FORCE_COLLECTIVE and dist.is_available() and dist.is_initialized())
+
+
 def allreduce_sum_(flat: torch.Tensor) -> torch.Tensor:
-    """In-place summed all-reduce of one flat bucket (a no-op for a single process)."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    """In-place summed all-reduce of one flat bucket (a no-op for a single process unless FORCE_COLLECTIVE)."""
+    if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or FORCE_COLLECTIVE):
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     return flat
+
+
+def collective_info() -> Optional[str]:
+    """What carries the gradient all-reduce in this process: backend, RCCL version, rank count (bench.py prints it)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return None
+    be = dist.get_backend()
+    ver = ""
+    if be == "nccl":
+        try:
+            ver = " RCCL " + ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:      # noqa: BLE001
+            ver = " RCCL (version unavailable)"
+    return f"{be}{ver}, {dist.get_world_size()} rank(s)"
 
 
 def broadcast_(flat: torch.Tensor, src: int = 0) -> torch.Tensor:

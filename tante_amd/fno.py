@@ -8,7 +8,17 @@ that the sliding-window rollout loops re-feed it one frame per call.  The arithm
 requirements.txt) nor installed here: **parity unpinned** at that boundary.  `.model` is therefore the published FNO
 (Li et al. 2021: pointwise lifting MLP -> 4 Fourier layers `act(spectral(x) + W x)` -> pointwise projection MLP) assembled from the
 in-repo HIP `SpectralLayer` (models/enc_dec_fno.py:184-222, pinned by fixture G12) and the MFMA row GEMM; its parameter names are
-this file's own, not neuralop's.  Inference and training (autograd nodes of autograd.py); no CPU fallback."""
+this file's own, not neuralop's.  Inference and training (autograd nodes of autograd.py); no CPU fallback.
+
+**What the reference's own forward does with the blocks.**  `NeuralOpsCheckpointWrapper.forward` (models/fno.py:48-51; tfno.py:46-49)
+calls `self.optional_checkpointing(self.fno_blocks, x, layer_idx, ...)` and DISCARDS the result (no `x =`), and it skips neuralop's
+positional embedding: as shipped, the reference's FNO computes `projection(lifting(x))` -- two pointwise MLPs, no Fourier layer acts on
+the output.  That is evidently a bug of the wrapper, not the model the paper's table reports, so the default here is the PUBLISHED
+operator (the Fourier layers are applied); `FNO(..., reference_as_written=True)` reproduces the shipped behaviour (lifting ->
+projection only; the spectral layers keep their parameters and receive zero gradient, as in the reference).  Numbers quoted for
+`fno.yaml` / `fno_vf.yaml` (bench.py, profiles/) are for the published operator.  Neither form can load a reference checkpoint:
+the parameter names and the internals of `neuralop.models.FNO` are not available here; `load_state_dict` refuses neuralop-named
+state dicts with an explicit error instead of a silent `strict=False` mismatch."""
 from __future__ import annotations
 
 import torch
@@ -50,8 +60,9 @@ class FourierOperator2d(nn.Module):
     """(B, Cin, H, W) -> (B, Cout, H, W): lifting -> n_layers x act(SpectralLayer) (no activation after the last) -> projection."""
 
     def __init__(self, n_modes, in_channels: int, out_channels: int, hidden_channels: int, n_layers: int = 4,
-                 lifting_ratio: int = 2, projection_ratio: int = 2, gradient_checkpointing: bool = False):
+                 lifting_ratio: int = 2, projection_ratio: int = 2, gradient_checkpointing: bool = False, skip_blocks: bool = False):
         super().__init__()
+        self.skip_blocks = skip_blocks                            # models/fno.py:48-51 as written: the blocks' outputs are dropped
         if len(n_modes) != 2:
             raise NotImplementedError("the HIP spectral layer is two-dimensional (rfft2): n_spatial_dims = 3 is not built")
         self.n_modes, self.n_layers = tuple(n_modes), n_layers
@@ -73,13 +84,13 @@ class FourierOperator2d(nn.Module):
         if not train:
             rows = rows.detach().contiguous()
             z = self.lifting.run(rows, compute).view(B, H, W, -1).permute(0, 3, 1, 2).contiguous()
-            for i, blk in enumerate(self.fno_blocks):
+            for i, blk in enumerate(self.fno_blocks if not self.skip_blocks else ()):
                 z = blk.run(z, L.ACT_GELU_ERF if i + 1 < self.n_layers else L.ACT_NONE, compute)
             rows = z.permute(0, 2, 3, 1).reshape(B * H * W, self.hidden_channels)
             return self.projection.run(rows, compute).view(B, H, W, -1).permute(0, 3, 1, 2)
         from .autograd import ActFn, SpectralLayerFn
         z = self.lifting.run_train(rows.contiguous(), compute).view(B, H, W, -1).permute(0, 3, 1, 2).contiguous()
-        for i, blk in enumerate(self.fno_blocks):
+        for i, blk in enumerate(self.fno_blocks if not self.skip_blocks else ()):
             z = SpectralLayerFn.apply(z, blk.weight, blk.w0.weight, blk.w0.bias, blk.modes1, blk.modes2)
             if i + 1 < self.n_layers:
                 z = ActFn.apply(z, L.ACT_GELU_ERF, torch.float32)
@@ -91,8 +102,9 @@ class FNO(nn.Module):
     """models/fno.py:63-106 -- same constructor, same attributes, same forward contract."""
 
     def __init__(self, in_T: int, dset_metadata, modes1: int = 16, modes2: int = 16, modes3: int = 16, hidden_channels: int = 64,
-                 gradient_checkpointing: bool = False):
+                 gradient_checkpointing: bool = False, reference_as_written: bool = False):
         super().__init__()
+        self.reference_as_written = reference_as_written
         n_channel = dset_metadata.n_fields
         self.dim_in = n_channel * in_T
         self.dim_out = n_channel
@@ -108,9 +120,20 @@ class FNO(nn.Module):
         else:
             raise ValueError(f"n_spatial_dims must be 2 or 3, got {self.n_spatial_dims}")
         self.model = FourierOperator2d(self.n_modes, self.dim_in, self.dim_out, hidden_channels,
-                                       gradient_checkpointing=gradient_checkpointing)
+                                       gradient_checkpointing=gradient_checkpointing, skip_blocks=reference_as_written)
         self.in_T = in_T
         self.output_length = 1
+
+    # key fragments only neuralop.models.FNO's state dict has (its spectral weights, channel-MLP convolutions, skip connections)
+    _NEURALOP_KEYS = ("fno_blocks.convs", "fno_blocks.fno_skips", "fno_blocks.channel_mlp", "lifting.fcs", "projection.fcs", "positional_embedding")
+
+    def load_state_dict(self, state_dict, strict: bool = True, **kw):
+        foreign = [k for k in state_dict if any(f in k for f in self._NEURALOP_KEYS)]
+        if foreign:
+            raise RuntimeError("tante_amd.FNO cannot load a neuralop.models.FNO state dict (e.g. %r): the reference delegates this model to the "
+                               "third-party `neuralop` package, whose parameterisation is not reproduced here (tante_amd/fno.py, parity "
+                               "unpinned); train this model with tante_amd instead" % foreign[0])
+        return super().load_state_dict(state_dict, strict=strict, **kw)
 
     def forward(self, input: torch.Tensor) -> torch.Tensor:
         if input.dim() != 5 or input.shape[1] * input.shape[2] != self.dim_in:

@@ -27,7 +27,7 @@ def train_step(model, opt: FlatAdamW, batch: Dict[str, torch.Tensor], formatter,
     y_pred, y_ref = rollout_model(model, batch, formatter, n_steps_output)
     loss = MseMeanFn.apply(y_pred, y_ref)
     run_backward(loss)
-    if world > 1:
+    if D.collective_needed(world):
         D.allreduce_sum_(opt.flat_g)
     opt.step(grad_scale=1.0 / world, lr=lr)
     return loss.detach()
@@ -68,7 +68,8 @@ class GraphedTrainStep:
         self.batch = {k: v.to(self.dev).clone() for k, v in example_batch.items()}
         self.mix_dev = torch.zeros(1, dtype=torch.int64, device=self.dev)
         self.seed, self.count = int(seed), 0
-        L.check(L.lib().tante_set_seed_mix(self.mix_dev.data_ptr()), "tante_set_seed_mix")
+        with torch.cuda.device(self.dev):      # the library keys the word by the CURRENT device: register it where the kernels will run
+            L.check(L.lib().tante_set_seed_mix(self.mix_dev.data_ptr()), "tante_set_seed_mix")
         _ACTIVE_MIX[self.dev.index] = self.mix_dev.data_ptr()
         snap = (opt.flat_p.clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone(), opt.step_count, A._SEED[0])
         side = torch.cuda.Stream(device=self.dev)
@@ -129,7 +130,7 @@ class GraphedTrainStep:
         self.count += 1
         self.set_seed_word(_splitmix64(self.seed * 0x100000001B3 + self.count))
         self.graph.replay()
-        if self.world > 1:
+        if D.collective_needed(self.world):
             D.allreduce_sum_(self.opt.flat_g)
         self.opt.step(grad_scale=1.0 / self.world, lr=lr)
         return self.loss.detach()

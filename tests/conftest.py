@@ -14,6 +14,29 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config._rccl_child = None
+
+
+def pytest_sessionstart(session):
+    """The RCCL world-size-1 check (tests/rccl_world1_child.py) needs a process that initialises its process group BEFORE any other GPU
+    call, and a process that has initialised the GPU must not start programs on this pool: so the child is started HERE, before this
+    process has touched the GPU (torch.cuda.device_count() does not initialise it), when the selection includes the gpu tests; it runs
+    beside the first tests and test_rccl_world1_all_reduce_beside_the_captured_graph collects its verdict."""
+    import subprocess
+    cfg = session.config
+    expr = (cfg.getoption("markexpr") or "").strip()
+    if "gpu" not in expr or "not gpu" in expr or os.environ.get("TANTE_NO_RCCL_CHILD"):
+        return
+    try:
+        if torch.cuda.device_count() < 1:
+            return
+    except Exception:      # noqa: BLE001
+        return
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out_dir, exist_ok=True)
+    log = open(os.path.join(out_dir, "r04_rccl_world1.log"), "w")
+    cfg._rccl_child = (subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "rccl_world1_child.py")], stdout=log,
+                                        stderr=subprocess.STDOUT, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")), log.name)
 
 
 def load_golden(name):

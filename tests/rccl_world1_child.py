@@ -1,0 +1,106 @@
+"""Child process of tests/test_hip_round4.py::test_rccl_world1_all_reduce_beside_the_captured_graph (started by conftest.py at session
+start, BEFORE the pytest process makes any GPU call): RCCL on the ONE GPU a test box has.
+
+    init_process_group("nccl", world_size=1, device_id=cuda:0)
+    (1) the bucket all-reduce over one rank returns its input bit for bit;
+    (2) train_step with the collective forced on (tante_amd.dist.FORCE_COLLECTIVE) against train_step without it;
+    (3) GraphedTrainStep -- zero_grad + rollout + loss + backward captured as ONE HIP graph in thread-local capture mode while RCCL's
+        proxy / watchdog threads are alive -- with the all-reduce issued beside the graph after every replay, against an eager twin.
+Prints NCCL_DEBUG=INFO's lines (RCCL version, rank count) and one `VERDICT {json}` line.  The gradients of two runs agree up to the
+summation order of the atomically reduced ones (tests/test_hip_round2.py::test_graphed_train_step_matches_eager_twin), so (2) and (3)
+are held to that test's bars; (1) is exact.  Reference: data/datamodule.py:96-119, trainer/trainer.py:193 (the reference has the
+sampler plumbing and no collective; the build adds this one)."""
+import copy
+import json
+import os
+import socket
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    os.environ.setdefault("NCCL_DEBUG", "INFO")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    import torch.distributed as dist
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    import tante_amd
+    from tante_amd import autograd as A
+    from tante_amd import dist as D
+    from tante_amd.train import GraphedTrainStep, _splitmix64, train_step
+    out = {"collective": D.collective_info(), "checks": {}}
+    # (1) the collective itself
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(4_229_939, generator=g).to(dev)      # configs/tante.yaml's parameter count: the real bucket size
+    y = x.clone()
+    D.FORCE_COLLECTIVE = True
+    D.allreduce_sum_(y)
+    torch.cuda.synchronize()
+    out["checks"]["all_reduce_identity_bit_equal"] = bool(torch.equal(x, y))
+    # model: the production-shape train-step model of fixture G14 (C = 256, 8 heads, THWTHWTHW, 64 x 384 x 4 fields)
+    torch.manual_seed(14)
+    md = tante_amd.TanteMetadata(n_fields=4, spatial_resolution=(64, 384))
+    m0 = tante_amd.TANTE(in_T=4, dset_metadata=md, taylor_order=1, attn_axes="THWTHWTHW", n_head=8, embed_dim=256, patch_scale=8,
+                         dropout=0.0).to(dev).train().set_compute("bf16")
+    for blk in [b for bb in m0.blocks for b in bb.blocks]:
+        blk.p_drop = 0.1
+        blk.attn.dropout = 0.1
+    fmt = tante_amd.DefaultChannelsFirstFormatter(md)
+    gen = torch.Generator().manual_seed(1414)
+    b = {"input": torch.randn(2, 4, 64, 384, 4, generator=gen).to(dev), "output": torch.randn(2, 4, 64, 384, 4, generator=gen).to(dev)}
+
+    def opt_of(m):
+        return tante_amd.FlatAdamW(m.parameters(), lr=1e-4, weight_decay=0.01, max_norm=1.0)
+    # (2) eager step, collective forced on vs off
+    m1, m2 = copy.deepcopy(m0), copy.deepcopy(m0)
+    o1, o2 = opt_of(m1), opt_of(m2)
+    worst = 0.0
+    for step in range(2):
+        A._SEED[0] = 1000 + step
+        D.FORCE_COLLECTIVE = False
+        l1 = float(train_step(m1, o1, b, fmt, 4, 1))
+        A._SEED[0] = 1000 + step
+        D.FORCE_COLLECTIVE = True
+        l2 = float(train_step(m2, o2, b, fmt, 4, 1))
+        eg = float((o1.flat_g - o2.flat_g).norm() / o1.flat_g.norm())
+        worst = max(worst, eg, abs(l1 - l2) / abs(l1))
+    out["checks"]["eager_forced_collective_vs_none"] = {"worst_rel": worst, "ok": worst < 1e-3}
+    # (3) the captured graph with the all-reduce beside it vs an eager twin (as test_graphed_train_step_matches_eager_twin)
+    m3, m4 = copy.deepcopy(m0), copy.deepcopy(m0)
+    o3, o4 = opt_of(m3), opt_of(m4)
+    A._SEED[0] = 4321
+    D.FORCE_COLLECTIVE = True
+    gs = GraphedTrainStep(m3, o3, b, fmt, 4, world=1, seed=7)
+    worst, losses = 0.0, []
+    try:
+        for step in range(1, 4):
+            l3 = float(gs(b))                                      # replay + RCCL all-reduce + clip/AdamW
+            A._SEED[0] = 4321
+            gs.set_seed_word(_splitmix64(7 * 0x100000001B3 + step))
+            D.FORCE_COLLECTIVE = False
+            l4 = float(train_step(m4, o4, b, fmt, 4, 1))
+            D.FORCE_COLLECTIVE = True
+            eg = float((o3.flat_g - o4.flat_g).norm() / o4.flat_g.norm())
+            worst = max(worst, eg, abs(l3 - l4) / abs(l4))
+            losses.append(l3)
+    finally:
+        gs.close()
+    out["checks"]["graph_replay_plus_all_reduce_vs_eager_twin"] = {"worst_rel": worst, "losses": losses,
+                                                                  "ok": worst < 1e-3 and len({round(v, 7) for v in losses}) == 3}
+    torch.cuda.synchronize()
+    out["ok"] = bool(out["checks"]["all_reduce_identity_bit_equal"] and out["checks"]["eager_forced_collective_vs_none"]["ok"]
+                     and out["checks"]["graph_replay_plus_all_reduce_vs_eager_twin"]["ok"])
+    print("VERDICT " + json.dumps(out), flush=True)
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -253,3 +253,24 @@ def test_cfg2_rollout_per_step_derivative_parts(dev, mode):
         r = rel_err(d, dref)
         record_parity(r, max_rel(d, dref), bar, mode, f"cfg2 rollout step {t + 1}, derivative part")
         assert r < bar, (mode, t, r)
+
+
+def test_rccl_world1_all_reduce_beside_the_captured_graph(request):
+    """RCCL on the one GPU of a test box (tests/rccl_world1_child.py, started by conftest.py before this process touched the GPU):
+    init_process_group("nccl", world_size=1), the bucket all-reduce (bit-exact identity over one rank), train_step with the collective
+    forced on, and GraphedTrainStep with the all-reduce beside the thread-local-captured graph -- what an 8-GPU driver run would
+    otherwise be the first to exercise (data/datamodule.py:96-119, trainer/trainer.py:193)."""
+    import json
+    child = getattr(request.config, "_rccl_child", None)
+    if child is None:
+        pytest.skip("the RCCL child is only started for `-m gpu` sessions on a GPU box")
+    proc, log = child
+    rc = proc.wait(timeout=900)
+    text = open(log).read()
+    verdict = [ln for ln in text.splitlines() if ln.startswith("VERDICT ")]
+    assert rc == 0 and verdict, f"RCCL child failed (rc {rc}):\n{text[-3000:]}"
+    v = json.loads(verdict[-1][len("VERDICT "):])
+    assert v["ok"], v
+    assert "RCCL" in (v["collective"] or ""), v
+    record_parity(v["checks"]["graph_replay_plus_all_reduce_vs_eager_twin"]["worst_rel"], 0.0, 1e-3, "bf16",
+                  "graph replay + RCCL all-reduce (world 1) vs eager twin: loss and flat gradient")

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), f"{name} declared in include/tante_hip.h but not exported"
     assert set(declared) == set(_lib.SIGNATURES), "ctypes binding and header disagree"
-    assert L.tante_abi_version() == 1
+    assert L.tante_abi_version() == _lib.ABI_VERSION
 
 
 def test_pack_geometry_host_only():
@@ -345,7 +345,10 @@ def test_fno_wrapper_surface():
     import inspect
     import tante_amd
     sig = inspect.signature(tante_amd.FNO.__init__)
-    assert list(sig.parameters)[1:] == ["in_T", "dset_metadata", "modes1", "modes2", "modes3", "hidden_channels", "gradient_checkpointing"]
+    # the reference's seven arguments in its order, then this build's one keyword extension (the as-shipped behaviour, tante_amd/fno.py)
+    assert list(sig.parameters)[1:] == ["in_T", "dset_metadata", "modes1", "modes2", "modes3", "hidden_channels", "gradient_checkpointing",
+                                        "reference_as_written"]
+    assert sig.parameters["reference_as_written"].default is False
     assert [sig.parameters[k].default for k in ("modes1", "modes2", "modes3", "hidden_channels", "gradient_checkpointing")] == [16, 16, 16, 64, False]
     md = tante_amd.TanteMetadata(n_fields=11, spatial_resolution=(256, 256))
     for target in ("models.FNO", "models.fno.FNO"):
@@ -378,3 +381,32 @@ def test_fno_oracle_wrapper_contract():
     assert y2.shape == y.shape
     # batch independence
     assert torch.allclose(OS.fno_wrapper(w, x[1:], 3, 2), y[1:], atol=1e-6)
+
+
+def test_library_option_allow_list_matches_the_sources():
+    """tante_amd/_lib.py forwards TANTE_* environment variables into the library's option table by an explicit allow-list
+    (the table has 64 slots; Python-side switches must not fill it): the list is exactly the names csrc/ looks up."""
+    import glob
+    import re
+    from tante_amd import _lib as L
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    found = set()
+    for f in glob.glob(os.path.join(root, "tante_amd", "csrc", "*")):
+        with open(f) as fh:
+            found |= set(re.findall(r'tante_opt\("(TANTE_[A-Z0-9_]*)"', fh.read()))
+    assert found == set(L.LIB_OPTIONS), (sorted(found - set(L.LIB_OPTIONS)), sorted(set(L.LIB_OPTIONS) - found))
+    assert len(L.LIB_OPTIONS) <= 64 and all(len(n) < 48 for n in L.LIB_OPTIONS)
+
+
+def test_fno_refuses_neuralop_state_dicts_and_has_the_as_written_mode():
+    """models.FNO as shipped drops its Fourier blocks' outputs (models/fno.py:48-51); the port documents that, offers
+    `reference_as_written=True`, and refuses neuralop-named checkpoints instead of mis-loading them."""
+    import tante_amd
+    md = tante_amd.TanteMetadata(n_fields=2, spatial_resolution=(16, 16))
+    m = tante_amd.FNO(in_T=4, dset_metadata=md, modes1=4, modes2=4, hidden_channels=8)
+    assert m.reference_as_written is False and m.model.skip_blocks is False
+    m2 = tante_amd.FNO(in_T=4, dset_metadata=md, modes1=4, modes2=4, hidden_channels=8, reference_as_written=True)
+    assert m2.model.skip_blocks is True
+    with pytest.raises(RuntimeError, match="neuralop"):
+        m.load_state_dict({"model.fno_blocks.convs.0.weight": torch.zeros(1)})
+    m.load_state_dict(m.state_dict())
