@@ -478,6 +478,12 @@ def main():
     value, elapsed, roofline, model, batch, cfg, wl, kind = (leg[k] for k in ("value", "elapsed", "roofline", "model", "batch", "cfg", "wl", "kind"))
     B, n_steps, T_in, res, D, dtype = (leg[k] for k in ("B", "n_steps", "T_in", "res", "D", "dtype"))
 
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
     train = None
     if not args.no_train and kind == "tante" and os.path.basename(args.config) == "tante_am.yaml":
         # second leg of the metric: train-step samples/sec on cfg3 (TRL-2D shaped fields, 4-step BPTT, MSE + clip + AdamW, one summed
@@ -582,16 +588,20 @@ def main():
             return {"value": round(Bc * nc / tc, 3), "cores": torch.get_num_threads(), "seconds": round(tc, 1),
                     "sample": f"{Bc} samples x {nc} frames of the same workload, fp32"}
         legs = {}
-        for th in sorted({full, min(affinity, cap)}, reverse=True):
-            legs[th] = oracle_leg(th, B, n_steps if th == full else max(1, n_steps // 2))
-        main_leg = legs[full]
-        cpu = {"value": main_leg["value"], "unit": "frames/s", "cores": main_leg["cores"], "cpu_model": cpu_name, "kind": "port",
+        share = min(affinity, cap)
+        for th in sorted({full, share}, reverse=True):
+            # (the affinity mask of a GPU box lists every hardware thread of the host while the job's cgroup holds a 16-core share:
+            # the all-physical-cores run oversubscribes that share and is the SLOWER one there -- it gets half the frames)
+            legs[th] = oracle_leg(th, B, n_steps if th == share else max(1, n_steps // 2))
+        best = max(legs, key=lambda th: legs[th]["value"])
+        cpu = {"value": legs[best]["value"], "unit": "frames/s", "cores": legs[best]["cores"], "cpu_model": cpu_name, "kind": "port",
                "affinity_cores": affinity, "physical_cores": phys,
                "sample": "oracle rollout (fused-op spelling; it takes 1.09 x the reference's own CPU time on the same tensors: "
-                         f"profiles/cpu_reference.json), {main_leg['sample']}, {main_leg['seconds']} s at min(affinity, physical cores) = {full} threads",
-               "share_16": {k: v for k, v in legs[min(affinity, cap)].items()} if min(affinity, cap) != full else None,
-               "gpu_over_cpu": {"all_physical_cores": round(value / main_leg["value"], 1),
-                                **({"share": round(value / legs[min(affinity, cap)]["value"], 1)} if min(affinity, cap) != full else {})}}
+                         f"profiles/cpu_reference.json), {legs[best]['sample']}, {legs[best]['seconds']} s; `value` is the FASTER of the two thread "
+                         "counts timed (BASELINE.md asks for all physical cores; the box's 16-core share is the other)",
+               "threads_timed": {f"{th}{' = min(affinity, physical cores)' if th == full else ' = the 16-core share (TANTE_CPU_THREADS)'}": legs[th]
+                                 for th in legs},
+               "gpu_over_cpu": round(value / legs[best]["value"], 1)}
 
     workloads = None
     if (not args.no_workloads and rank == 0 and world == 1 and kind == "tante" and os.path.basename(args.config) == "tante_am.yaml"):
