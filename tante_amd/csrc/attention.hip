@@ -10,8 +10,8 @@
 //                     the rows of its own sequence (lanes of one sequence read LDS in broadcast).
 //   LONG  (L  > 256): a workgroup owns 256 consecutive queries of one (sequence, head) and walks the
 //                     keys in chunks of KC through LDS (flash-style), causal chunks skipped.
-#include "common.cuh"
-#include "fused_common.cuh"
+#include "common.hip.h"
+#include "fused_common.hip.h"
 
 namespace {
 

@@ -17,7 +17,7 @@
 // applied on the global SOURCE side (as in wgrad_tr_kernel).  Weight gradients accumulate in registers across the tiles of a persistent
 // workgroup (wave w owns row tile w of dW1 and of dW2, wave 3 the two bias gradients) and leave as one partial per workgroup, summed by a
 // second small kernel (atomics without a workspace).
-#include "common.cuh"
+#include "common.hip.h"
 #include <stdlib.h>
 
 namespace {

@@ -10,8 +10,8 @@
 // held in registers; GELU (the bf16 mode's polynomial) on the accumulators; the accumulator tiles, packed in pairs, ARE the B operand of
 // the second product (W2's fragments are gathered in the matching k order); the result is added to the fp32 tile in place and the tile
 // leaves as whole rows.  x is read and written once.
-#include "common.cuh"
-#include "fused_common.cuh"
+#include "common.hip.h"
+#include "fused_common.hip.h"
 
 namespace {
 

@@ -1,7 +1,7 @@
 // Backward kernels of the TANTE train step (everything that is not a GEMM; the data-gradient GEMMs are tante_gemm with
 // the *_T packings, the weight-gradient GEMM is wgrad.hip).
-#include "common.cuh"
-#include "fused_common.cuh"
+#include "common.hip.h"
+#include "fused_common.hip.h"
 
 namespace {
 
@@ -1112,7 +1112,7 @@ bool try_attn_bwd_mfma(const void* qkv, const void* dO, void* dqkv, int dtype, i
 // 512 / 1024 / 1536 workgroups -- device-scope atomics are served behind the XCDs' L2s): each workgroup STORES its partial to a
 // caller-owned workspace, and the last of every AW_GS workgroups to finish (an arrival counter per group) sums the group's partials
 // and adds ONE n x n to dW: a sixteenth of the atomics, no second launch.
-constexpr int AW_GS = TANTE_AW_GS;                        // workgroups per reduction group (common.cuh: axis_bwd.hip shares the workspace)
+constexpr int AW_GS = TANTE_AW_GS;                        // workgroups per reduction group (common.hip.h: axis_bwd.hip shares the workspace)
 constexpr int AW_MAXWG = TANTE_AW_MAXWG;                  // grid cap with a workspace
 constexpr int AW_SLAB = TANTE_AW_SLAB;                    // floats per partial: dW (n <= 64) then db
 constexpr long AW_WS_FLOATS = TANTE_AW_WS_FLOATS;         // partials + one arrival counter per group

@@ -14,9 +14,9 @@
 // and the five results written once.  Same structure as the forward kernel (block_sliced.hip): 4 waves per workgroup, a wave owns 64
 // output features of every GEMM for the workgroup's 48 / 64 tokens, bf16 operand images in LDS, TRANSPOSED weights streamed from L2
 // as pre-packed fragments.  The block is token-wise here (no sequences): workgroup b takes tokens 16 NTT b ...
-#include "common.cuh"
-#include "fused_common.cuh"
-#include "fs_common.cuh"
+#include "common.hip.h"
+#include "fused_common.hip.h"
+#include "fs_common.hip.h"
 #include "block_sliced.h"
 
 namespace {
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(256, 2) void block_head_bwd_kernel(BhArgs A) {
       const f32x4 v = *(const f32x4*)(sb + r * ROWB + ((rchunk ^ (r & (CPR - 1))) << 4));
 #ifdef BH_PLAIN_STORE
       if (t < A.M) *(f32x4*)(A.dx + t * FS_C + 16 * RT * wave + 4 * rchunk) = v;
-#else   // write-through (common.cuh): the launch's only output, written at its very end
+#else   // write-through (common.hip.h): the launch's only output, written at its very end
       if (t < A.M) st_wt16(A.dx + t * FS_C + 16 * RT * wave + 4 * rchunk, v);
 #endif
     }

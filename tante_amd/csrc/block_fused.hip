@@ -23,10 +23,10 @@
 //     y     = Wo O             (A = Wo tile [k-permuted], B = O)
 // A sequence (L | 32) lives entirely inside one wave, so attention needs no LDS exchange at all; shorter
 // sequences are packed 32/L per wave and separated by the mask (block diagonal, causal inside for 'T').
-#include "common.cuh"
+#include "common.hip.h"
 
 #include <stdlib.h>
-#include "fused_common.cuh"
+#include "fused_common.hip.h"
 #include "block_sliced.h"
 
 namespace {

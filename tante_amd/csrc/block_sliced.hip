@@ -21,9 +21,9 @@
 // Two algebraic savings on the way (both exact): the key bias never reaches the output (it shifts every score of a query by the
 // same amount, softmax removes it), and the value bias commutes with the attention average (rows of P sum to 1), so it is folded
 // into the out-proj bias at pack time:  bo' = bo + Wo . bv.
-#include "common.cuh"
-#include "fused_common.cuh"
-#include "fs_common.cuh"
+#include "common.hip.h"
+#include "fused_common.hip.h"
+#include "fs_common.hip.h"
 #include "block_sliced.h"
 
 namespace {
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(64 * NW * G, 2) void block_fs_kernel(FsArgs A) {
       const u32x4 v = *(const u32x4*)(img + tt * 8192 + r * FS_ROW + (((CPB * wave + bchunk) ^ r) << 4));
       // (ordinary stores: written through they buy nothing -- 9.65 ms per train step either way.  The first attempt gave NaN losses: the
       // write-through store is an asm statement, and a GELU that reused its data registers right behind it hit the store-data hazard the
-      // compiler's recognizer does not see inside asm -- st_wt16 carries the wait states now, common.cuh)
+      // compiler's recognizer does not see inside asm -- st_wt16 carries the wait states now, common.hip.h)
       if (t >= 0) *(u32x4*)(dst + (long)t * dstride + dcol + 16 * RT * wave + 8 * bchunk) = v;
     }
   };
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(64 * NW * G, 2) void block_fs_kernel(FsArgs A) {
         const f32x4 v = *(const f32x4*)(sb + r * ROWB + ((rchunk ^ (r & (CPR - 1))) << 4));
 #ifdef FS_NT_STORE      // experiment: streaming (non-temporal) stores of the block's output rows
         if (t >= 0) __builtin_nontemporal_store(v, (f32x4*)(dst + (long)t * FS_C + 16 * RT * wave + 4 * rchunk));
-#else                   // write-through (common.cuh): 38.4 -> 37.2 us per launch and +2.4 % on the rollout, three interleaved rounds
+#else                   // write-through (common.hip.h): 38.4 -> 37.2 us per launch and +2.4 % on the rollout, three interleaved rounds
         // the inference form only (the training form's launches are bound by their saved-tensor traffic, not by the release)
         if (t >= 0) {
           if constexpr (TRAIN) *(f32x4*)(dst + (long)t * FS_C + 16 * RT * wave + 4 * rchunk) = v;
@@ -352,7 +352,9 @@ __global__ __launch_bounds__(64 * NW * G, 2) void block_fs_kernel(FsArgs A) {
           // release / acquire of __syncthreads; the rows of a workgroup are its own).  The alternative -- leave x alone and run the
           // residual slices through the propagator a second time (-DFS_TPROP_RECOMPUTE) -- costs the contraction + 64 GELUs per lane
           // once more on the critical path: 46 us per launch against 41 us (the extra 33 MB of stores drain under the q, k, v GEMMs).
+#ifndef FS_EXP_TPROP_NO_STORE      // timing experiment only (wrong results): what the propagated rows' store and re-read cost
           if (live) *(f32x4*)(x + (long)tk * FS_C + 4 * lane) = y;
+#endif
 #endif
           float sm = (y[0] + y[1]) + (y[2] + y[3]);
           float sq = fmaf(y[0], y[0], fmaf(y[1], y[1], fmaf(y[2], y[2], y[3] * y[3])));

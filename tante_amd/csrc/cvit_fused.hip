@@ -20,9 +20,9 @@
 //
 // MODE 2 / 3 put the front of a CrossAttnBlock in the same launch (LN1 -> q projection -> attention against K / V that are the same for
 // every query of a sample): see xfront below.
-#include "common.cuh"
-#include "fused_common.cuh"
-#include "fs_common.cuh"
+#include "common.hip.h"
+#include "fused_common.hip.h"
+#include "fs_common.hip.h"
 
 namespace {
 

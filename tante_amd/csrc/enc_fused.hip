@@ -7,7 +7,7 @@
 // k-block of stage 3's B operand (W3's columns are packed in accumulator order).  Stage 3 then streams W3 through a two-slot LDS
 // ring in 32-row tiles and writes tokens with the FiLM + positional epilogue.  Against the two GEMM launches this replaces, the
 // (n_img, H/4, W/4, C/2) intermediate (write + read) and one launch disappear.
-#include "fused_common.cuh"
+#include "fused_common.hip.h"
 #include <stdlib.h>
 
 namespace {

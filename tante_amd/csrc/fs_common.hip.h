@@ -2,8 +2,8 @@
 // backward of the block's MLP half): the weight-fragment stream and its register ring, the slice GEMM over an LDS image, cross-lane
 // reductions without LDS traffic.
 #pragma once
-#include "common.cuh"
-#include "fused_common.cuh"
+#include "common.hip.h"
+#include "fused_common.hip.h"
 
 namespace {
 

@@ -1,7 +1,7 @@
 // Helpers shared by the register-chained fused kernels (block_fused.hip, enc_fused.hip): static loops, the explicit LDS read
 // ring that feeds MFMA A operands, bf16 fragment packing.
 #pragma once
-#include "common.cuh"
+#include "common.hip.h"
 #include <utility>
 
 namespace {

@@ -17,7 +17,7 @@
 // operands -- a fixed permutation of the k order inside each 16-wide block, which a dot product does
 // not care about.  bf16 compute uses v_mfma_f32_16x16x32_bf16 whose natural operand layout is
 // already one 16-byte chunk (8 consecutive k) per lane.
-#include "common.cuh"
+#include "common.hip.h"
 #include <stdlib.h>
 
 namespace {

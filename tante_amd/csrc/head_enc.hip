@@ -15,12 +15,12 @@
 //
 // Pipeline (the round-3 kernel waited three times for 142 KiB of weights and for its token rows, and its compiler-scheduled LDS reads
 // waited lgkmcnt(0) -- a full LDS round trip per MFMA -- whenever an LDS-DMA was in flight): every GEMM stage reads its weight
-// fragments through the explicit read ring of fused_common.cuh (counted lgkmcnt), and everything that comes from memory for order
+// fragments through the explicit read ring of fused_common.hip.h (counted lgkmcnt), and everything that comes from memory for order
 // k + 1 is requested while order k computes:  W1[k+1] and the token rows right after order k's stage 1 (the W1 tile is free then; the
 // rows wait in registers), W3[k+1] after its stage 3; only W2[k+1] (it shares its LDS region with the row staging) arrives under
 // stage 1 of its own order.  The encoder's weights ride the same slots: W1e is resident, W2e lands on W1 during the last order's
 // stages 2 + 3, the W3e slice on W2 during encoder stages 1 + 2.
-#include "fused_common.cuh"
+#include "fused_common.hip.h"
 #include <stdlib.h>
 
 namespace {
@@ -76,7 +76,7 @@ __device__ __forceinline__ void he_glds(const char* __restrict__ g, char* l, int
 }
 __device__ __forceinline__ f32x4 he_gelu(const f32x4& v) { return gelu_poly4<false>(v); }
 // agent-scope (sc1) 16-byte accesses to the hand-off buffer: the load misses this CU's L1, the store is written through (and waits the
-// two states a VALU write to the data registers of a >64-bit store needs behind it: common.cuh, st_wt16)
+// two states a VALU write to the data registers of a >64-bit store needs behind it: common.hip.h, st_wt16)
 __device__ __forceinline__ f32x4 he_ld_agent(const float* p) {
   f32x4 r;
   asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(r) : "v"(p) : "memory");

@@ -8,7 +8,7 @@
 // W3 (resident), W1 in 4 pixel tiles, W2 in 4 sub-pixel tiles.  The epilogue adds  coef_i * derivative  straight into the
 // output frames (out_i = last + sum_k coef_ik d_k: the first order starts from the last input frame, later orders accumulate),
 // so neither the three intermediate images nor the derivative fields nor a separate Taylor pass exist.
-#include "common.cuh"
+#include "common.hip.h"
 #include <stdlib.h>
 #include <utility>
 

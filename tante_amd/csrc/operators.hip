@@ -1,9 +1,9 @@
 // Operator kernels around the GEMM / attention core that the general encoder-decoder stages (padded or overlapping patch
 // convolutions, bilinear-resized transposed convolutions), the spectral operator path (enc_dec_fno.py) and CViT (cvit.py) need.
 // All of them are HBM-bound gather / pointwise / small-contraction kernels: coalesced on the innermost axis, fp32 arithmetic.
-#include "common.cuh"
+#include "common.hip.h"
 #include "spectral_dft.h"
-#include "fused_common.cuh"
+#include "fused_common.hip.h"
 #include <hipfft/hipfft.h>
 #include <stdlib.h>
 #include <map>

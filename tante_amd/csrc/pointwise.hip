@@ -1,5 +1,5 @@
 // HBM-bound stages of the TANTE path: axis propagators, FiLM tables, Taylor sum, step-size reduction.
-#include "common.cuh"
+#include "common.hip.h"
 #include <stdlib.h>
 #include <string.h>
 #include <mutex>
@@ -583,7 +583,7 @@ __device__ __forceinline__ void axe_phase(float* plane, const AxeW<MT>& W, int w
             v[1] += out[g][1][mt][r];
 #ifdef AXE_PLAIN_STORE
             if constexpr (GOUT) *(f32x2*)(gbase + (long)(16 * mt + r) * gls) = v;
-#else       // write-through (common.cuh): the finished plane streams out, nothing dirty is left for the kernel-end release
+#else       // write-through (common.hip.h): the finished plane streams out, nothing dirty is left for the kernel-end release
             if constexpr (GOUT) st_wt8(gbase + (long)(16 * mt + r) * gls, __builtin_bit_cast(u32x2, v));
 #endif
             else *(f32x2*)(rbase + (16 * mt + r) * LS) = v;      // these lines belong to this wave alone
@@ -1109,7 +1109,7 @@ void tante_set_error(const char* fmt, ...) {
 }
 extern "C" const char* tante_last_error(void) { return g_err; }
 
-// ---- tuning options (common.cuh: tante_opt) -------------------------------------------------------------------------------------
+// ---- tuning options (common.hip.h: tante_opt) -------------------------------------------------------------------------------------
 // A small fixed table under a mutex: set rarely (start-up, A/B scripts), read once per launch by the host-side dispatch code.
 namespace {
 struct TanteOptEntry { char name[48]; int value; };

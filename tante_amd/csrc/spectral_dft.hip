@@ -19,7 +19,7 @@
 // reduced integer phase, the sums have 512 terms -- the result agrees with the FFT path to ~1e-6 relative (tests: 1e-5 against the
 // oracle, and against the hipFFT path of this library).  x is read twice (A and E), `out` written once, and the only intermediates
 // are the compact Ar (n Cin H x 2 m2) and Z (n H x 2 m2 x Cout).  The backward pass and shapes outside the rules below stay on hipFFT.
-#include "common.cuh"
+#include "common.hip.h"
 #include "spectral_dft.h"
 #include <algorithm>
 
@@ -506,7 +506,7 @@ __global__ __launch_bounds__(256) void idft_rows_conv_x3_kernel(const float* __r
         const int o = 16 * ot + l15;
         if (o < Cout) {
           f32x4 v = acc[ot] + splat4(bias[ot]);
-          // the bf16 mode's GELU (common.cuh: degree-7 fit, |error| <= 8.3e-5, packed fp32 math, no transcendental): with erf + exp + rcp
+          // the bf16 mode's GELU (common.hip.h: degree-7 fit, |error| <= 8.3e-5, packed fp32 math, no transcendental): with erf + exp + rcp
           // per output this epilogue, not the products or the memory system, set the kernel's time
           if (act == TANTE_ACT_GELU_ERF) v = gelu_poly4<false>(v);
           else if (act != TANTE_ACT_NONE) {

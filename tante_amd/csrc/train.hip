@@ -4,7 +4,7 @@
 //   tante_mse_grad        d mean(MSE) / d pred  (trainer/trainer.py:189: loss = MSE(y_pred, y_ref).mean())
 //   tante_sumsq           sum of squares of a flat fp32 bucket (the global gradient norm of clip_grad_norm_, trainer.py:193)
 //   tante_adamw_step      clip-scale + AdamW update over the flat parameter bucket (torch.optim.AdamW, configs/tante.yaml:38-41)
-#include "common.cuh"
+#include "common.hip.h"
 
 namespace {
 

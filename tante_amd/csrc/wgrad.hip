@@ -9,7 +9,7 @@
 // The contraction runs over r, which is the slow axis of both operands, so tiles are staged through LDS TRANSPOSED
 // ([column][32 rows], r contiguous): one 16-byte ds_read per lane is then an MFMA operand fragment.  The result tile is
 // added with fp32 atomics at the parameter's own index (TANTE_W_* layouts), r is split over workgroups.
-#include "common.cuh"
+#include "common.hip.h"
 #include <stdlib.h>
 
 namespace {
