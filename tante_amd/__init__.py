@@ -17,8 +17,9 @@ from .metrics import MSE, NMSE, RMSE, NRMSE, VMSE, VRMSE, L2RE, NNMSE  # noqa: F
 from .optim import FlatAdamW, warmup_cosine_lr  # noqa: F401
 from .train import GraphedTrainStep, train_step, train_step_adaptive, train_step_cvit  # noqa: F401
 from . import harness  # noqa: F401
+from .options import set_option, get_option  # noqa: F401
 from .harness import LinearWarmupCosineAnnealingLR, SyntheticDataModule, save_checkpoint, load_checkpoint  # noqa: F401
 
 __all__ = ["TANTE", "TanteMetadata", "enc_CNN", "dec_CNN", "film", "interprator", "t_series", "Attn_Backbone",
            "TransformerBlock", "DefaultChannelsFirstFormatter", "DefaultChannelsLastFormatter", "rollout_model",
-           "rollout_adaptive", "instantiate", "load_config", "build_model", "CViT", "FNO", "SpectralLayer", "enc_FNO", "dec_FNO"]
+           "rollout_adaptive", "instantiate", "load_config", "build_model", "CViT", "FNO", "SpectralLayer", "enc_FNO", "dec_FNO", "set_option", "get_option"]

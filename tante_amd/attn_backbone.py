@@ -27,10 +27,11 @@ import torch.nn as nn
 # Round 3: a lane owns 4 channels of all four time steps and the two 4 x 4 contractions run as fp32 v_mfma_f32_4x4x1 (every lane its own
 # column, no cross-lane traffic) in the kernel's LayerNorm1 phase, where the matrix pipe is idle: ON by default; TANTE_FUSE_TPROP=0
 # brings the separate launch back (A/B timing, tests).
-FUSE_TPROP = os.environ.get("TANTE_FUSE_TPROP", "1") != "0"
-
 from . import _lib as L
 from . import kernels as K
+from . import options as _O
+
+FUSE_TPROP = _O.register("TANTE_FUSE_TPROP", True, __name__, "FUSE_TPROP")
 
 
 def resolve_compute(module_default: Optional[str] = None) -> int:

@@ -14,6 +14,7 @@ import torch
 from torch.autograd import Function
 
 from . import _lib as L
+from . import options as _O
 from . import kernels as K
 
 _DT = {torch.float32: L.F32, torch.bfloat16: L.BF16}
@@ -95,7 +96,7 @@ def _grad_slot(p) -> Optional[torch.Tensor]:
 # the slot before the optimiser); the main stream re-joins at the end of the backward pass through an engine callback.
 # Measured on the cfg3 train step (alternating runs on one box): 29.5-29.9 ms against 30.0-30.1 ms on one stream, but with outliers at
 # 33-34.6 ms when the two streams' workgroups interleave badly -- a small, unreliable gain, so it is opt-in (TANTE_WGRAD_SIDE_STREAM=1).
-SIDE_STREAM_WGRAD = __import__("os").environ.get("TANTE_WGRAD_SIDE_STREAM", "0") != "0"
+SIDE_STREAM_WGRAD = _O.register("TANTE_WGRAD_SIDE_STREAM", False, __name__, "SIDE_STREAM_WGRAD")
 _SIDE = {"stream": None, "armed": False, "task": -1}
 
 
@@ -151,8 +152,9 @@ class _side_wgrad:
 # The dense bf16 linears therefore only RECORD (dY, A) in backward; when the backward pass ends (engine callback) -- or when a FoldFn
 # needs its accumulators -- the uses of one weight run as ONE tante_wgrad_multi launch over the concatenated row range.  The recorded
 # operands stay alive a little longer (~3 GB at cfg3 on a 288 GB part).
-DEFER_WGRAD = __import__("os").environ.get("TANTE_WGRAD_DEFER", "1") != "0"
-DEFER_MAX_BYTES = int(float(__import__("os").environ.get("TANTE_WGRAD_DEFER_MAX_GB", "32")) * 2 ** 30)   # recorded operands held at most
+DEFER_WGRAD = _O.register("TANTE_WGRAD_DEFER", True, __name__, "DEFER_WGRAD")
+DEFER_MAX_GB = _O.register("TANTE_WGRAD_DEFER_MAX_GB", 32.0, __name__, "DEFER_MAX_GB")
+# (recorded operands held at most DEFER_MAX_GB GiB)
 _DEFER = {"pending": {}, "armed": False, "bytes": 0, "task": -1}
 
 
@@ -205,7 +207,7 @@ def _wgrad_workspace(device) -> torch.Tensor:
     return ws
 
 
-WGRAD_JOBS = int(__import__("os").environ.get("TANTE_WGRAD_JOBS_PER_LAUNCH", "4"))      # weights per shared launch (1: one launch per weight)
+WGRAD_JOBS = _O.register("TANTE_WGRAD_JOBS_PER_LAUNCH", 4, __name__, "WGRAD_JOBS")      # weights per shared launch (1: one launch per weight)
 
 
 def _flush_wgrads(slot: Optional[torch.Tensor] = None):
@@ -298,7 +300,7 @@ def _defer_wgrad(gW, gb, dy, a, M, N, Kk, comp, lay=(L.W_LINEAR, 0, 0, False)) -
         ent = _DEFER["pending"][key] = (gW, gb, M, N, Kk, comp, lay, [])
     ent[7].append((dy, a))
     _DEFER["bytes"] += dy.numel() * dy.element_size() + a.numel() * a.element_size()
-    if _DEFER["bytes"] > DEFER_MAX_BYTES:      # a very large model / batch: do not sit on more activations than this
+    if _DEFER["bytes"] > int(DEFER_MAX_GB * 2 ** 30):      # a very large model / batch: do not sit on more activations than this
         armed, task = _DEFER["armed"], _DEFER["task"]
         _flush_wgrads(None)
         _DEFER["armed"], _DEFER["task"] = armed, task                # the engine callback is still queued for the rest of this backward pass
@@ -790,7 +792,7 @@ class DropoutAddFn(Function):
         return dy, dout, None
 
 
-AXIS_BWD_FUSED = __import__("os").environ.get("TANTE_AXIS_BWD_FUSED", "1") != "0"     # propagator backward + weight gradients in one MFMA launch
+AXIS_BWD_FUSED = _O.register("TANTE_AXIS_BWD_FUSED", True, __name__, "AXIS_BWD_FUSED")     # propagator backward + weight gradients in one MFMA launch
 
 
 class AxisMlpFn(Function):

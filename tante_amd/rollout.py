@@ -6,10 +6,17 @@ DefaultChannelsFirstFormatter / ...LastFormatter   (data/datamodule.py:184-202)
 """
 from __future__ import annotations
 
-import os
 from typing import Dict, Tuple
 
 import torch
+
+from . import options as _O
+
+# A/B switches (tante_amd.set_option): each falls back to the form the default replaced
+NO_ENC_CACHE = _O.register("TANTE_NO_ENC_CACHE", False, __name__, "NO_ENC_CACHE")          # window-by-window encoder
+NO_TAIL_ENC = _O.register("TANTE_NO_TAIL_ENC", False, __name__, "NO_TAIL_ENC")            # predicted frames re-encoded by the encoder launches
+NO_FUSED_FORMAT = _O.register("TANTE_NO_FUSED_FORMAT", False, __name__, "NO_FUSED_FORMAT")  # formatter.process_input as torch ops
+NO_SIDE_STREAM = _O.register("TANTE_NO_SIDE_STREAM", False, __name__, "NO_SIDE_STREAM")      # reference frames' nan_to_num on the main stream
 
 
 class DefaultChannelsFirstFormatter:
@@ -82,14 +89,14 @@ def _rollout_in_place(model, x: torch.Tensor, n_steps: int, raw_input: torch.Ten
                 "tante_format_input")
     else:
         buf[:, :T].copy_(x)       # the formatter's 'b t h w c -> b t c h w' is materialised here, once
-    if model.enc_cache_supported() and not os.environ.get("TANTE_NO_ENC_CACHE"):
+    if model.enc_cache_supported() and not NO_ENC_CACHE:
         # every frame (input or predicted) is encoded once, when it first enters a window; the windows read the frame-major cache
         HW, C_ = model.H_p * model.W_p, model.C
         z = torch.empty(T + n_calls * ol, B, HW, C_, dtype=torch.float32, device=dev)
         encoded = 0
         # one output frame per call: the launch that writes the predicted frame also writes its encoding for the next call's window
         # (csrc/head_enc.hip) -- only the initial window goes through the encoder kernels
-        tail = ol == 1 and model.tail_fused_supported() and not os.environ.get("TANTE_NO_TAIL_ENC")
+        tail = ol == 1 and model.tail_fused_supported() and not NO_TAIL_ENC
         for s in range(n_calls):
             need = s * ol + T
             if need > encoded:                       # the first call encodes the whole window, later calls the `ol` new frames
@@ -111,11 +118,11 @@ def rollout_model(model, batch: Dict, formatter, n_steps: int, device=None):
     device = device or next(model.parameters()).device
     from .tante import TANTE
     raw = batch["input"]
-    if (not os.environ.get("TANTE_NO_FUSED_FORMAT") and type(formatter) is DefaultChannelsFirstFormatter and isinstance(model, TANTE) and model.deg and not torch.is_grad_enabled()
+    if (not NO_FUSED_FORMAT and type(formatter) is DefaultChannelsFirstFormatter and isinstance(model, TANTE) and model.deg and not torch.is_grad_enabled()
             and raw.dim() == 5 and raw.shape[1] == model.T and raw.dtype == torch.float32 and raw.is_cuda and raw.is_contiguous()):
         # same result as formatter.process_input + the in-place rollout below, without the two extra passes over the window
         out_ref = batch["output"]
-        if out_ref.is_cuda and not os.environ.get("TANTE_NO_SIDE_STREAM") and not torch.cuda.is_current_stream_capturing():
+        if out_ref.is_cuda and not NO_SIDE_STREAM and not torch.cuda.is_current_stream_capturing():
             # the formatter's nan_to_num of the REFERENCE frames (370 MB through HBM at cfg2, 57 us) depends on nothing the rollout
             # computes: it runs on a second stream under the rollout's matrix-bound launches and is joined before returning
             main = torch.cuda.current_stream(out_ref.device)

@@ -24,6 +24,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib as L
+from . import options as _O
 from . import kernels as K
 from . import stages as S
 from .attn_backbone import Attn_Backbone, _PackCache, _no_autograd, resolve_compute
@@ -53,9 +54,9 @@ class TanteMetadata:
                 "space_grid": [*self.spatial_resolution, self.n_spatial_dims]}
 
 
-HEAD_MULTI = __import__("os").environ.get("TANTE_HEAD_MULTI", "1") != "0"      # every Taylor order's derivative head in one launch
-HEAD_STREAMS = __import__("os").environ.get("TANTE_HEAD_STREAMS", "1") != "0"  # ... reading each order's own stream buffer (no row copies)
-HEAD_ENC = __import__("os").environ.get("TANTE_HEAD_ENC", "1") != "0"          # ... and re-encoding the predicted frame in the same launch (head_enc.hip)
+HEAD_MULTI = _O.register("TANTE_HEAD_MULTI", True, __name__, "HEAD_MULTI")      # every Taylor order's derivative head in one launch
+HEAD_STREAMS = _O.register("TANTE_HEAD_STREAMS", True, __name__, "HEAD_STREAMS")  # ... reading each order's own stream buffer (no row copies)
+HEAD_ENC = _O.register("TANTE_HEAD_ENC", True, __name__, "HEAD_ENC")          # ... and re-encoding the predicted frame in the same launch (head_enc.hip)
 
 
 def _check_patch_cfg(patch_scale, overlap_ratio):

@@ -10,6 +10,7 @@ from __future__ import annotations
 import torch
 
 from . import _lib as L
+from . import options as _O
 from . import kernels as K
 from . import stages as S
 from .autograd import (ActFn, AttentionFn, BlockFn, BlockTailFn, block_tail_ready, AxisHWFn, AxisMlpFn, BranchOutFn, DeconvFn, DropoutAddFn, FilmPosFn, FilmPosFramesFn, FoldFn, LayerNormFn, LayerNormSkipFn, LinearFn, PatchEmbedFn, RtReduceFn,
@@ -51,17 +52,17 @@ def _folded(lin_w, lin_b, ln, pre=None):
     return hit
 
 
-FUSED_TRAIN_FORWARD = __import__("os").environ.get("TANTE_TRAIN_FUSED", "1") != "0"
-FUSED_TAIL_BACKWARD = __import__("os").environ.get("TANTE_TRAIN_FUSED_BWD", "1") != "0"
-BLOCK_RECORDS = __import__("os").environ.get("TANTE_TRAIN_BLOCK_RECORDS", "1") != "0"   # per-scope prepared record of a block (host time)
-FUSED_ENC_ACT = __import__("os").environ.get("TANTE_TRAIN_FUSED_ENC_ACT", "1") != "0"   # encoder GELUs inside the next stage's node
-FUSED_AXIS_HW = __import__("os").environ.get("TANTE_TRAIN_FUSED_AXIS", "1") != "0"     # H + W propagators' training forward in one launch
-FUSED_HEAD_BACKWARD = __import__("os").environ.get("TANTE_TRAIN_FUSED_HEAD_BWD", "1") != "0"   # q|k|v dgrad + LayerNorm1 backward in one launch
+FUSED_TRAIN_FORWARD = _O.register("TANTE_TRAIN_FUSED", True, __name__, "FUSED_TRAIN_FORWARD")
+FUSED_TAIL_BACKWARD = _O.register("TANTE_TRAIN_FUSED_BWD", True, __name__, "FUSED_TAIL_BACKWARD")
+BLOCK_RECORDS = _O.register("TANTE_TRAIN_BLOCK_RECORDS", True, __name__, "BLOCK_RECORDS")   # per-scope prepared record of a block (host time)
+FUSED_ENC_ACT = _O.register("TANTE_TRAIN_FUSED_ENC_ACT", True, __name__, "FUSED_ENC_ACT")   # encoder GELUs inside the next stage's node
+FUSED_AXIS_HW = _O.register("TANTE_TRAIN_FUSED_AXIS", True, __name__, "FUSED_AXIS_HW")     # H + W propagators' training forward in one launch
+FUSED_HEAD_BACKWARD = _O.register("TANTE_TRAIN_FUSED_HEAD_BWD", True, __name__, "FUSED_HEAD_BACKWARD")   # q|k|v dgrad + LayerNorm1 backward in one launch
 
 
 BLOCK_CALLS = [0, 0]      # block_train calls / those that took the fused one-node path (GraphedTrainStep checks them at capture)
-FRAME_FILM = __import__("os").environ.get("TANTE_TRAIN_FRAME_FILM", "1") != "0"     # FiLM reads the window's frames where they are (no stack per call)
-BATCH_PREP = __import__("os").environ.get("TANTE_TRAIN_BATCH_PREP", "1") != "0"     # folds and backward fragment streams of all blocks in two launches
+FRAME_FILM = _O.register("TANTE_TRAIN_FRAME_FILM", True, __name__, "FRAME_FILM")     # FiLM reads the window's frames where they are (no stack per call)
+BATCH_PREP = _O.register("TANTE_TRAIN_BATCH_PREP", True, __name__, "BATCH_PREP")     # folds and backward fragment streams of all blocks in two launches
 
 
 def prepare_blocks(model, compute: int):
@@ -293,7 +294,7 @@ def interprator_train(it, d3: torch.Tensor, B: int, out_T: float, compute: int) 
     return RtReduceFn.apply(t, B, it.sp_dim, float(out_T), float(it.ep))
 
 
-TRAIN_ENC_CACHE = __import__("os").environ.get("TANTE_TRAIN_ENC_CACHE", "1") != "0"
+TRAIN_ENC_CACHE = _O.register("TANTE_TRAIN_ENC_CACHE", True, __name__, "TRAIN_ENC_CACHE")
 
 
 def train_enc_cache_ok(model) -> bool:

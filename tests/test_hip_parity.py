@@ -495,7 +495,7 @@ def test_cfg2_rollout_frame_cache_is_bit_identical(dev, monkeypatch):
     of once per window: the same arithmetic per token, so the frames must equal the window-by-window encoder's BITWISE, and both must
     equal the plain `model(window)` loop of the reference's rollout_model."""
     import tante_amd
-    monkeypatch.setenv("TANTE_NO_TAIL_ENC", "1")      # (round 4's fused tail re-encodes predicted frames with another sum order: test_hip_round4.py)
+    monkeypatch.setattr(tante_amd.rollout, "NO_TAIL_ENC", True)      # (round 4's fused tail re-encodes predicted frames with another sum order: test_hip_round4.py)
     m = _cfg2_model(dev).set_compute("bf16")
     assert m.enc_cache_supported()
     md = tante_amd.TanteMetadata(n_fields=11, spatial_resolution=(256, 256))
@@ -504,7 +504,7 @@ def test_cfg2_rollout_frame_cache_is_bit_identical(dev, monkeypatch):
     batch = {"input": torch.randn(2, 4, 256, 256, 11, generator=g).to(dev), "output": torch.randn(2, 3, 256, 256, 11, generator=g).to(dev)}
     with torch.no_grad():
         y_cache, _ = tante_amd.rollout_model(m, batch, fmt, 3)
-        monkeypatch.setenv("TANTE_NO_ENC_CACHE", "1")
+        monkeypatch.setattr(tante_amd.rollout, "NO_ENC_CACHE", True)
         y_plain, _ = tante_amd.rollout_model(m, batch, fmt, 3)
         moving = fmt.process_input(batch)[0][0]
         frames = []

@@ -117,7 +117,7 @@ def test_cfg2_rollout_fused_tail_against_plain_loop(dev, monkeypatch):
     with torch.no_grad():
         y_tail, _ = tante_amd.rollout_model(m, batch, fmt, 5)
         y_tail2, _ = tante_amd.rollout_model(m, batch, fmt, 5)
-        monkeypatch.setenv("TANTE_NO_TAIL_ENC", "1")
+        monkeypatch.setattr(tante_amd.rollout, "NO_TAIL_ENC", True)
         y_plain, _ = tante_amd.rollout_model(m, batch, fmt, 5)
     assert torch.isfinite(y_tail).all()
     assert torch.equal(y_tail, y_tail2), "the fused-tail rollout is not reproducible"

@@ -410,3 +410,31 @@ def test_fno_refuses_neuralop_state_dicts_and_has_the_as_written_mode():
     with pytest.raises(RuntimeError, match="neuralop"):
         m.load_state_dict({"model.fno_blocks.convs.0.weight": torch.zeros(1)})
     m.load_state_dict(m.state_dict())
+
+
+def test_set_option_reaches_host_and_library_switches():
+    """tante_amd.set_option: one entry point for the package's own A/B flags (module attributes registered in tante_amd/options.py --
+    the only file that reads TANTE_* variables for behaviour) and for the library's launch heuristics."""
+    import tante_amd
+    from tante_amd import options as O
+    names = O.host_options()
+    assert "TANTE_HEAD_ENC" in names and "TANTE_TRAIN_FUSED" in names and "TANTE_NO_TAIL_ENC" in names
+    assert tante_amd.get_option("TANTE_HEAD_ENC") is True
+    tante_amd.set_option("TANTE_HEAD_ENC", 0)
+    try:
+        assert tante_amd.tante.HEAD_ENC is False
+    finally:
+        tante_amd.set_option("TANTE_HEAD_ENC", 1)
+    tante_amd.set_option("TANTE_WGRAD_JOBS_PER_LAUNCH", 2)
+    assert tante_amd.autograd.WGRAD_JOBS == 2
+    tante_amd.set_option("TANTE_WGRAD_JOBS_PER_LAUNCH", 4)
+    with pytest.raises(KeyError):
+        tante_amd.set_option("TANTE_NO_SUCH_SWITCH", 1)
+    # nothing but options.py (switches), dist.py (torchrun rank variables), build.py (HIPCC) and _lib.py (the allow-list) reads the environment
+    import glob
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for f in glob.glob(os.path.join(root, "tante_amd", "*.py")):
+        if os.path.basename(f) in ("options.py", "dist.py", "build.py", "_lib.py"):
+            continue
+        src = open(f).read()
+        assert "environ" not in src.replace('environ.get("RANK"', ""), f
