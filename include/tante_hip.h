@@ -325,6 +325,13 @@ int tante_head_fused_multi_streams(int n_ord, const float* const* rows, const vo
                            int64_t a_s1, int64_t a_s0, int64_t a_off, int n_img, int Hp, int Wp, int C, int D, float* out,
                            int64_t out_bstride, const float* last, int64_t last_bstride, void* stream);
 
+/* Attention over DENSE sequences (token b * L + l) with nn.MultiheadAttention's masks as additive fp32 tensors: attn_mask (L, L) shared
+ * (mask_bstride 0) or (Bp * n_head, L, L) (mask_bstride L * L), key_padding_mask (Bp, L); either may be NULL; -inf blocks a key.
+ * qkv / o layouts as tante_attention.  The reference's TransformerBlock.forward(x, key_padding_mask, attn_mask, causal) signature
+ * (attn_backbone.py:59-72); the TANTE path passes `causal` only, so this is a completeness kernel (one lane per query). */
+int tante_attention_masked(const void* qkv, void* o, int dtype, int C, int n_head, int Bp, int L, int causal, const float* attn_mask,
+                           int64_t mask_bstride, const float* key_padding_mask, void* stream);
+
 /* ---- the token-local tail of a rollout call in ONE launch (head_enc.hip; bf16, C = 256, D <= 16, Hp Wp % 16 == 0) -----------------
  * tante_head_enc_fused: every Taylor order's derivative head + the Taylor sum (as tante_head_fused_multi_streams: rows[k] = the residual
  * stream backbone k left, addressed by (a_n0, a_s1, a_s0, a_off), a_n0 % 16 == 0) and, when enc_stream != NULL, the RE-ENCODING of the

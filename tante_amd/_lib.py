@@ -191,6 +191,7 @@ SIGNATURES = {
     "tante_head_fused_multi_streams": ([c_i32, c_vp, c_vp, c_vp, c_i32, c_i64, c_i64, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp, c_i64,
                                c_vp], c_i32),
     "tante_get_option": ([C.c_char_p, c_i32], c_i32),
+    "tante_attention_masked": ([c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp, c_vp], c_i32),
     "tante_head_enc_supported": ([c_i32, c_i32], c_i32),
     "tante_head_enc_stream_bytes": ([c_i32], c_i64),
     "tante_head_enc_ws_bytes": ([c_i64], c_i64),
@@ -210,7 +211,7 @@ LIB_OPTIONS = ("TANTE_ATTN_BWD_HG", "TANTE_ATTN_BWD_NO_SPLIT", "TANTE_ATTN_BWD_V
 
 
 _lib = None
-ABI_VERSION = 4      # include/tante_hip.h: bumped whenever an entry point is added or changes (round 4: tante_head_enc_*)
+ABI_VERSION = 5      # include/tante_hip.h: bumped whenever an entry point is added or changes (round 4: tante_head_enc_*)
 
 
 def lib():

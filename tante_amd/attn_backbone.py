@@ -48,10 +48,24 @@ def resolve_compute(module_default: Optional[str] = None) -> int:
 
 
 def _no_autograd(module: nn.Module):
+    """Sub-modules that have no differentiable path of their own yet (the spectral enc/dec and CViT's internals: their models train through
+    TANTE.forward / CViT.forward / FNO.forward)."""
     if torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters()):
         raise NotImplementedError(
-            "tante_amd forward kernels do not record an autograd graph yet: call under torch.no_grad() / "
-            "inference_mode (rollout path).")
+            "this sub-module has no stand-alone differentiable path: call it under torch.no_grad(), or train through the model's forward()")
+
+
+def _gpu_only(x: torch.Tensor):
+    if not x.is_cuda:
+        raise RuntimeError("tante_amd modules run on the GPU only (no CPU fallback); move the module and its input to cuda")
+
+
+def _wants_grad(module: nn.Module, *inputs) -> bool:
+    """The reference's modules are differentiable anywhere (attn_backbone.py:59-83, 134-191; enc_dec_cnn.py:217-229, 263-277): under
+    autograd a sub-module's forward() takes the differentiable path (train_forward.py: HIP forward that saves what the HIP backward
+    kernels read), exactly like TANTE.forward; without it the inference kernels run."""
+    return torch.is_grad_enabled() and (any(p.requires_grad for p in module.parameters())
+                                        or any(isinstance(t, torch.Tensor) and t.requires_grad for t in inputs))
 
 
 _WEIGHT_EPOCH = [0]
@@ -154,13 +168,61 @@ class TransformerBlock(nn.Module):
         return x
 
     def forward(self, x: torch.Tensor, key_padding_mask=None, attn_mask=None, causal: bool = False) -> torch.Tensor:
-        if key_padding_mask is not None or attn_mask is not None:
-            raise NotImplementedError("only the causal flag is used on the TANTE path (attn_backbone.py:148-189)")
-        _no_autograd(self)
+        """attn_backbone.py:59-83.  `causal` is what the TANTE path uses (l.148-189); `attn_mask` (bool: True = blocked, or additive float;
+        (L, L) or (B * n_head, L, L)) and `key_padding_mask` ((B, L) bool: True = ignored, or additive float) follow
+        nn.MultiheadAttention's semantics and run the masked attention kernel of the unfused path (inference only)."""
+        _gpu_only(x)
         Bp, Lq, C_ = x.shape
+        compute = resolve_compute(self.compute)
+        if key_padding_mask is not None or attn_mask is not None:
+            if _wants_grad(self, x):
+                raise NotImplementedError("attn_mask / key_padding_mask are implemented on the inference path (the TANTE path uses `causal` only)")
+            y = x.detach().to(torch.float32).contiguous().clone()
+            self._forward_masked(y.view(Bp * Lq, C_), Bp, Lq, causal, compute, key_padding_mask, attn_mask)
+            return y
+        if _wants_grad(self, x):
+            from .train_forward import block_train
+            y = block_train(self, x.to(torch.float32).reshape(Bp * Lq, C_).contiguous(), K.dense_seq(Bp, Lq), causal, compute)
+            return y.view(Bp, Lq, C_)
         y = x.detach().to(torch.float32).contiguous().clone()
-        self.forward_tokens(y.view(Bp * Lq, C_), K.dense_seq(Bp, Lq), causal, resolve_compute(self.compute))
+        self.forward_tokens(y.view(Bp * Lq, C_), K.dense_seq(Bp, Lq), causal, compute)
         return y
+
+    def _forward_masked(self, x: torch.Tensor, Bp: int, Lq: int, causal: bool, compute: int, key_padding_mask, attn_mask) -> torch.Tensor:
+        """The unfused block with the masked attention kernel (tante_attention_masked): masks as ONE additive fp32 tensor pair."""
+        C_, nh = self.embed_dim, self.n_head
+        dev = x.device
+        ninf = float("-inf")
+        am = None
+        if attn_mask is not None:
+            am = attn_mask.to(dev)
+            if am.dtype == torch.bool:
+                am = torch.zeros(am.shape, dtype=torch.float32, device=dev).masked_fill_(am, ninf)
+            am = am.to(torch.float32).contiguous()
+            if am.dim() == 2 and tuple(am.shape) == (Lq, Lq):
+                am = am.view(1, Lq, Lq)
+            elif not (am.dim() == 3 and tuple(am.shape) == (Bp * nh, Lq, Lq)):
+                raise ValueError(f"attn_mask must be (L, L) or (B * n_head, L, L) = ({Lq}, {Lq}) / ({Bp * nh}, {Lq}, {Lq}), got {tuple(attn_mask.shape)}")
+        kp = None
+        if key_padding_mask is not None:
+            kp = key_padding_mask.to(dev)
+            if tuple(kp.shape) != (Bp, Lq):
+                raise ValueError(f"key_padding_mask must be (B, L) = ({Bp}, {Lq}), got {tuple(key_padding_mask.shape)}")
+            if kp.dtype == torch.bool:
+                kp = torch.zeros(kp.shape, dtype=torch.float32, device=dev).masked_fill_(kp, ninf)
+            kp = kp.to(torch.float32).contiguous()
+        pk = self._packed(compute)
+        adt = K.act_torch_dtype(compute)
+        n_tok = Bp * Lq
+        qkv = torch.empty(n_tok, 3 * C_, dtype=adt, device=dev)
+        K.linear(x, pk["qkv"], qkv, M=n_tok, ln=True, ln_eps=self.ln1.eps)
+        o = torch.empty(n_tok, C_, dtype=adt, device=dev)
+        K.attention_masked(qkv, o, C_, nh, Bp, Lq, causal, am, kp)
+        K.linear(o, pk["out"], x, M=n_tok, residual=x)
+        h = torch.empty(n_tok, self.hidden, dtype=adt, device=dev)
+        K.linear(x, pk["fc1"], h, M=n_tok, ln=True, ln_eps=self.ln2.eps, act=L.ACT_GELU_TANH)
+        K.linear(h, pk["fc2"], x, M=n_tok, residual=x)
+        return x
 
 
 class Attn_Backbone(nn.Module):
@@ -263,9 +325,13 @@ class Attn_Backbone(nn.Module):
         return x
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        _no_autograd(self)
+        _gpu_only(x)
         B, T, H, W, C_ = x.shape
         if (T, H, W, C_) != (self.T, self.H, self.W, self.C):
             raise ValueError(f"expected (B,{self.T},{self.H},{self.W},{self.C}), got {tuple(x.shape)}")
+        if _wants_grad(self, x):
+            from .train_forward import backbone_train
+            y = backbone_train(self, x.to(torch.float32).reshape(B * T * H * W, C_).contiguous(), B, resolve_compute(self.compute))
+            return y.view(B, T, H, W, C_)
         y = x.detach().to(torch.float32).contiguous().clone()
         return self.forward_tokens(y, B, resolve_compute(self.compute))

@@ -414,3 +414,73 @@ extern "C" int tante_attention_dropout(const void* qkv, void* o, int dtype, int 
                                        float p_drop, uint64_t seed, void* stream) {
   return attention_impl(qkv, o, dtype, C, n_head, seq, causal, p_drop, (unsigned long long)seed, stream);
 }
+
+// ---- masked attention over dense (batch, L) sequences: nn.MultiheadAttention's attn_mask / key_padding_mask --------------------------
+// TransformerBlock.forward(x, key_padding_mask, attn_mask, causal) is the reference's documented operator signature
+// (attn_backbone.py:59-72); the TANTE path itself only ever passes `causal`, so this is the boundary's completeness, not a hot kernel:
+// one lane per (batch, head, query) walks the keys from global memory with an online softmax; the masks arrive as ADDITIVE fp32 tensors
+// (the host turns bool masks into 0 / -inf): attn_mask (L, L) shared or (B n_head, L, L) by mask_bstride, key_padding_mask (B, L).
+// A key whose score is -inf contributes nothing; a row with every key blocked yields NaN, as torch's softmax does.
+namespace {
+template <int D>
+__global__ __launch_bounds__(256) void attn_masked_kernel(const void* __restrict__ qkv, void* __restrict__ o, int dtype, int C, int n_head, int Bp,
+                                                          int L, int causal, float scale, const float* __restrict__ amask, long mask_bstride,
+                                                          const float* __restrict__ kpm) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;      // (b, h, l)
+  if (idx >= (long)Bp * n_head * L) return;
+  const int l = (int)(idx % L), h = (int)((idx / L) % n_head), b = (int)(idx / ((long)L * n_head));
+  float q[D], acc[D];
+  load_row<D>(qkv, dtype, ((long)b * L + l) * 3 * C + h * D, q);
+#pragma unroll
+  for (int i = 0; i < D; ++i) { q[i] *= scale; acc[i] = 0.f; }
+  float m = -INFINITY, ssum = 0.f;
+  const float* am = amask ? amask + ((long)b * n_head + h) * mask_bstride + (long)l * L : nullptr;
+  const float* kp = kpm ? kpm + (long)b * L : nullptr;
+  const int jmax = causal ? l + 1 : L;
+  for (int j = 0; j < jmax; ++j) {
+    float k[D], v[D];
+    load_row<D>(qkv, dtype, ((long)b * L + j) * 3 * C + C + h * D, k);
+    float sc = 0.f;
+#pragma unroll
+    for (int i = 0; i < D; ++i) sc += q[i] * k[i];
+    if (am) sc += am[j];
+    if (kp) sc += kp[j];
+    if (sc == -INFINITY) continue;
+    load_row<D>(qkv, dtype, ((long)b * L + j) * 3 * C + 2 * C + h * D, v);
+    const float mn = fmaxf(m, sc);
+    const float corr = expf(m - mn), p = expf(sc - mn);      // m = -inf before the first live key: corr = 0
+    ssum = ssum * corr + p;
+#pragma unroll
+    for (int i = 0; i < D; ++i) acc[i] = acc[i] * corr + p * v[i];
+    m = mn;
+  }
+  const float inv = 1.0f / ssum;      // ssum = 0 (every key blocked): inf * 0 = NaN, torch's result for such a row
+#pragma unroll
+  for (int i = 0; i < D; ++i) acc[i] *= inv;
+  store_row<D>(o, dtype, ((long)b * L + l) * C + h * D, acc);
+}
+}  // namespace
+
+extern "C" int tante_attention_masked(const void* qkv, void* o, int dtype, int C, int n_head, int Bp, int L, int causal, const float* attn_mask,
+                                      int64_t mask_bstride, const float* key_padding_mask, void* stream) {
+  if (!qkv || !o) TANTE_FAIL(-1, "tante_attention_masked: null pointer");
+  if (dtype != TANTE_F32 && dtype != TANTE_BF16) TANTE_FAIL(-2, "tante_attention_masked: dtype");
+  if (C <= 0 || n_head <= 0 || C % n_head || Bp <= 0 || L <= 0) TANTE_FAIL(-1, "tante_attention_masked: bad shape");
+  if (attn_mask && mask_bstride != 0 && mask_bstride != (int64_t)L * L) TANTE_FAIL(-1, "tante_attention_masked: mask stride must be 0 (shared) or L * L");
+  const int D = C / n_head;
+  const float scale = 1.0f / sqrtf((float)D);
+  const long n = (long)Bp * n_head * L;
+  const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+  hipStream_t s = (hipStream_t)stream;
+#define TANTE_AM(DD) hipLaunchKernelGGL(attn_masked_kernel<DD>, grid, block, 0, s, qkv, o, dtype, C, n_head, Bp, L, causal, scale, attn_mask, (long)mask_bstride, key_padding_mask)
+  switch (D) {
+    case 8: TANTE_AM(8); break;
+    case 16: TANTE_AM(16); break;
+    case 32: TANTE_AM(32); break;
+    case 64: TANTE_AM(64); break;
+    default: TANTE_FAIL(-2, "tante_attention_masked: head dim %d (8, 16, 32, 64)", D);
+  }
+#undef TANTE_AM
+  TANTE_CHECK_LAUNCH();
+  return 0;
+}

@@ -325,6 +325,16 @@ def gather_last(z: torch.Tensor, n: int, E: int, out: torch.Tensor):
 
 
 # ---- fused TransformerBlock halves (bf16) ----------------------------------------------------------------
+def attention_masked(qkv: torch.Tensor, o: torch.Tensor, C_: int, n_head: int, Bp: int, Lq: int, causal: bool, attn_mask: Optional[torch.Tensor],
+                     key_padding_mask: Optional[torch.Tensor]):
+    """Dense-sequence attention with additive fp32 masks: attn_mask (1, L, L) or (Bp * n_head, L, L), key_padding_mask (Bp, L)."""
+    _dev(qkv, o, attn_mask, key_padding_mask)
+    stride = 0 if attn_mask is None or attn_mask.shape[0] == 1 else Lq * Lq
+    L.check(L.lib().tante_attention_masked(_p(qkv), _p(o), _DT[qkv.dtype], C_, n_head, Bp, Lq, int(causal), _p(attn_mask), stride,
+                                           _p(key_padding_mask), _stream()), "tante_attention_masked")
+    return o
+
+
 def block_fused_supported(C_: int, n_head: int, hidden: int, Lq: int) -> bool:
     return bool(L.lib().tante_block_fused_supported(C_, n_head, hidden, Lq))
 

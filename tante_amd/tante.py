@@ -27,7 +27,7 @@ from . import _lib as L
 from . import options as _O
 from . import kernels as K
 from . import stages as S
-from .attn_backbone import Attn_Backbone, _PackCache, _no_autograd, resolve_compute
+from .attn_backbone import Attn_Backbone, _PackCache, _gpu_only, _no_autograd, _wants_grad, resolve_compute
 
 # models/enc_dec_cnn.py:39-46
 Patch_map = {64: (4, 4, 4), 32: (4, 4, 2), 16: (4, 2, 2), 8: (2, 2, 2), 4: (2, 2, 1), 2: (2, 1, 1)}
@@ -195,8 +195,12 @@ class enc_CNN(nn.Module):
         return x
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        _no_autograd(self)
+        _gpu_only(x)
         B, T = x.shape[:2]
+        if _wants_grad(self, x):      # enc_dec_cnn.py:217-229 is differentiable: HIP forward + HIP backward (train_forward.encoder_train)
+            from .train_forward import encoder_train
+            tok = encoder_train(self, x.to(torch.float32).contiguous(), resolve_compute(None))
+            return tok.view(B, T, self.patch_shape[0], self.patch_shape[1], self.embed_dim)
         tok = self.forward_tokens(x.detach().float().contiguous(), resolve_compute(None), None)
         return tok.view(B, T, self.patch_shape[0], self.patch_shape[1], self.embed_dim)
 
@@ -276,8 +280,12 @@ class dec_CNN(nn.Module):
         return x
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        _no_autograd(self)
+        _gpu_only(x)
         B, T, Hp, Wp, C_ = x.shape
+        if _wants_grad(self, x):      # enc_dec_cnn.py:263-277
+            from .train_forward import decoder_train
+            y = decoder_train(self, x.to(torch.float32).reshape(B * T * Hp * Wp, C_).contiguous(), B * T, resolve_compute(None))
+            return y.view(B, T, *y.shape[1:])
         src = x.detach().float().contiguous()
         y = self.forward_tokens(src, B * T, resolve_compute(None), B * T * Hp * Wp, 0, C_, 0)
         return y.view(B, T, *y.shape[1:])
@@ -299,7 +307,24 @@ class film(nn.Module):
                             self.h_dim, add)
 
     def forward(self, x: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
-        _no_autograd(self)
+        _gpu_only(x)
+        if _wants_grad(self, x, t):   # tante.py:218-230: x + (x * scale(t) + shift(t)); the two small MLPs are torch (parameter-sized), the
+            from .autograd import FilmPosFn      # broadcast multiply-add over the tokens and its backward are HIP (FilmPosFn)
+            tt = t.to(x.device, torch.float32).reshape(-1, 1)
+            fa = (1.0 + self.condition_to_scale(tt)).float().contiguous()
+            fb = self.condition_to_shift(tt).float().contiguous()
+            C_ = x.shape[-1]
+            if x.dim() == 5:          # (B,T,H,W,C), t (T,): table row = time slot
+                B, T, H, W = x.shape[:4]
+                zero = torch.zeros(H * W, C_, dtype=torch.float32, device=x.device)
+                y = FilmPosFn.apply(x.to(torch.float32).reshape(B * T * H * W, C_).contiguous(), fa, fb, zero, T, H * W)
+            elif x.dim() == 3:        # (B,L,C), t (B,): table row = batch item
+                B, Lq = x.shape[:2]
+                zero = torch.zeros(Lq, C_, dtype=torch.float32, device=x.device)
+                y = FilmPosFn.apply(x.to(torch.float32).reshape(B * Lq, C_).contiguous(), fa, fb, zero, B, Lq)
+            else:
+                raise ValueError("film expects a 3-D or 5-D tensor")
+            return y.view(x.shape)
         x = x.detach().float().contiguous()
         a, b = self.tables(t.detach().float().contiguous().to(x.device))
         C_ = x.shape[-1]
@@ -345,8 +370,11 @@ class interprator(nn.Module):
         return K.rt_reduce(t, B, self.sp_dim, out_T, self.ep)
 
     def forward(self, x: torch.Tensor, out_T) -> torch.Tensor:
-        _no_autograd(self)
+        _gpu_only(x)
         B, Lq, C_ = x.shape
+        if _wants_grad(self, x):      # tante.py:191-201 incl. the straight-through clamp's gradient (RtReduceFn)
+            from .train_forward import interprator_train
+            return interprator_train(self, x.to(torch.float32).reshape(B * Lq, C_).contiguous(), B, out_T, resolve_compute(None))
         src = x.detach().float().contiguous()
         return self.forward_tokens(src, B, out_T, resolve_compute(None), B * Lq, 0, C_, 0)
 

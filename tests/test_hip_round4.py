@@ -274,3 +274,111 @@ def test_rccl_world1_all_reduce_beside_the_captured_graph(request):
     assert "RCCL" in (v["collective"] or ""), v
     record_parity(v["checks"]["graph_replay_plus_all_reduce_vs_eager_twin"]["worst_rel"], 0.0, 1e-3, "bf16",
                   "graph replay + RCCL all-reduce (world 1) vs eager twin: loss and flat gradient")
+
+
+# ---- boundary completeness (round-3 verdict, item 9 / "what's missing" 4 and 5) -------------------------------------------------------
+def _grads_against_oracle(mod, oracle_fn, inputs, mode, note, grad_tol=None):
+    """Run mod(*inputs) under autograd on the GPU and oracle_fn(w, *inputs) under torch autograd on the CPU with the same weights and
+    the same random cotangent; compare the output, every parameter's gradient and the first input's gradient."""
+    import contextlib
+    dev = next(mod.parameters()).device
+    w = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in mod.state_dict().items() if v.is_floating_point()}
+    xc = [t.detach().clone().requires_grad_(True) if (torch.is_tensor(t) and t.is_floating_point()) else t for t in inputs]
+    ref = oracle_fn(w, *xc)
+    r = torch.randn(ref.shape, generator=torch.Generator().manual_seed(99))
+    (ref * r).sum().backward()
+    xg = [t.detach().to(dev).clone().requires_grad_(True) if (torch.is_tensor(t) and t.is_floating_point()) else t for t in inputs]
+    ctx = torch.autocast("cuda", dtype=torch.bfloat16) if mode == "bf16" else contextlib.nullcontext()
+    for p in mod.parameters():
+        p.grad = None
+    with ctx:
+        y = mod(*xg)
+    (y.float() * r.to(dev)).sum().backward()
+    close(y, ref, mode, f"{note}: output")
+    gt = grad_tol or (2e-4 if mode == "fp32" else 4e-2)
+    worst = 0.0
+    for name, p in mod.named_parameters():
+        if name not in w or w[name].grad is None:
+            continue
+        assert p.grad is not None, f"{note}: no gradient for {name}"
+        e = rel_err(p.grad.cpu(), w[name].grad)
+        worst = max(worst, e)
+        assert e < gt, f"{note}: grad {name}: {e:.3e} (tol {gt:.0e})"
+    e = rel_err(xg[0].grad.cpu(), xc[0].grad)
+    worst = max(worst, e)
+    assert e < gt, f"{note}: input gradient: {e:.3e}"
+    record_parity(worst, worst, gt, mode, f"{note}: worst gradient (parameters and input)")
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_submodules_are_differentiable_standalone(dev, mode):
+    """The reference's sub-modules are differentiable wherever they are called (attn_backbone.py:59-83, 134-191;
+    enc_dec_cnn.py:217-229, 263-277; tante.py:191-201, 218-230).  Round 3 raised under autograd for everything but TANTE / CViT / FNO
+    .forward: now TransformerBlock, Attn_Backbone, enc_CNN, dec_CNN, film (5-D and 3-D) and interprator take the differentiable HIP
+    path on their own -- output, every parameter's gradient and the input's gradient against torch autograd through the CPU oracle."""
+    import tante_amd
+    from oracle import tante_oracle as O
+    g = torch.Generator().manual_seed(31)
+    torch.manual_seed(31)
+    blk = tante_amd.TransformerBlock(256, 8, mlp_ratio=1.0, dropout=0.0).to(dev)
+    x = torch.randn(6, 16, 256, generator=g)
+    _grads_against_oracle(blk, lambda w, a: O.transformer_block(w, a, 8, False), [x], mode, "TransformerBlock")
+    bb = tante_amd.Attn_Backbone(tensor_shape=(4, 16, 16, 256), attn_axes="THW", n_head=8, mlp_ratio=1.0, dropout=0.0).to(dev)
+    xb = torch.randn(2, 4, 16, 16, 256, generator=g)
+    _grads_against_oracle(bb, lambda w, a: O.attn_backbone(w, a, "THW", 8), [xb], mode, "Attn_Backbone THW")
+    md = tante_amd.TanteMetadata(n_fields=3, spatial_resolution=(32, 48))
+    enc = tante_amd.enc_CNN(dset_metadata=md, embed_dim=64, patch_scale=8, overlap_ratio=0.0).to(dev)
+    xi = torch.randn(2, 3, 3, 32, 48, generator=g)
+    _grads_against_oracle(enc, lambda w, a: O.enc_cnn(w, a, 8), [xi], mode, "enc_CNN")
+    dec = tante_amd.dec_CNN(dset_metadata=md, embed_dim=64, patch_scale=8, overlap_ratio=0.0).to(dev)
+    xt = torch.randn(2, 2, 4, 6, 64, generator=g)
+    _grads_against_oracle(dec, lambda w, a: O.dec_cnn(w, a, 8), [xt], mode, "dec_CNN")
+    if mode == "fp32":
+        fl = tante_amd.film(64, in_dim=1).to(dev)
+        _grads_against_oracle(fl, O.film, [torch.randn(2, 4, 3, 5, 64, generator=g), torch.tensor([-2.0, -1.0, 0.0, 0.0])], mode, "film 5-D")
+        _grads_against_oracle(fl, O.film, [torch.randn(3, 10, 64, generator=g), torch.tensor([1.1, 1.4, 1.25])], mode, "film 3-D")
+        it = tante_amd.interprator(64, sp_dim=12).to(dev)
+        _grads_against_oracle(it, lambda w, a: O.interprator(w, a, 6.0), [torch.randn(3, 12, 64, generator=g), 6.0], mode, "interprator")
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_transformer_block_masks(dev, mode):
+    """TransformerBlock.forward(x, key_padding_mask, attn_mask, causal) -- the reference's documented signature (attn_backbone.py:59-72;
+    the TANTE path passes `causal` only) -- against torch's own nn.MultiheadAttention on the CPU with the same parameters: bool and
+    additive float attn_mask, (L, L) and per-(batch x head) masks, bool key_padding_mask, and causal combined with padding."""
+    import copy
+    import tante_amd
+    torch.manual_seed(17)
+    blk = tante_amd.TransformerBlock(64, 4, mlp_ratio=2.0, dropout=0.0).to(dev).eval()
+    blk.compute = mode
+    ref_blk = copy.deepcopy(blk).cpu()
+    Bp, Lq = 3, 10
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(Bp, Lq, 64, generator=g)
+
+    def reference(kp, am, causal):
+        with torch.no_grad():
+            h = ref_blk.ln1(x)
+            mask = am
+            if causal:
+                tri = torch.triu(torch.ones(Lq, Lq, dtype=torch.bool), diagonal=1)
+                mask = tri if am is None else (am | tri if am.dtype == torch.bool else am.masked_fill(tri, float("-inf")))
+            y, _ = ref_blk.attn(h, h, h, key_padding_mask=kp, attn_mask=mask, need_weights=False)
+            x1 = x + y
+            return x1 + ref_blk.mlp(ref_blk.ln2(x1))
+    am_bool = torch.rand(Lq, Lq, generator=g) < 0.3
+    am_bool.fill_diagonal_(False)                          # every query keeps itself: no fully blocked row
+    am_float = torch.randn(Lq, Lq, generator=g)
+    am_heads = torch.randn(Bp * 4, Lq, Lq, generator=g)
+    kp = torch.zeros(Bp, Lq, dtype=torch.bool)
+    kp[0, 7:] = True
+    kp[2, 0] = True
+    cases = [("bool attn_mask", None, am_bool, False), ("float attn_mask", None, am_float, False), ("per-head float attn_mask", None, am_heads, False),
+             ("key_padding_mask", kp, None, False), ("key_padding_mask + bool attn_mask", kp, am_bool, False)]
+    kp_c = torch.zeros(Bp, Lq, dtype=torch.bool)
+    kp_c[1, 6:] = True
+    cases.append(("causal + key_padding_mask", kp_c, None, True))
+    for name, kpm, am, causal in cases:
+        with torch.no_grad():
+            y = blk(x.to(dev), None if kpm is None else kpm.to(dev), None if am is None else am.to(dev), causal)
+        close(y, reference(kpm, am, causal), mode, f"TransformerBlock masks: {name}")

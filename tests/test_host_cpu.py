@@ -59,8 +59,10 @@ def test_cpu_tensors_are_rejected():
     with pytest.raises(RuntimeError, match="no CPU fallback"):     # the differentiable path is GPU-only as well
         m(torch.zeros(1, 2, 1, 16, 16))
     blk = tante_amd.TransformerBlock(16, 2)
-    with pytest.raises(NotImplementedError):     # stand-alone modules do not record a graph: refuse instead of silently detaching
+    with pytest.raises(RuntimeError, match="no CPU fallback"):     # stand-alone modules are differentiable on the GPU, and GPU-only too
         blk(torch.zeros(1, 2, 16))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m.encoder(torch.zeros(1, 2, 1, 16, 16))
 
 
 @pytest.mark.parametrize("letter", list("THWLYXA"))
