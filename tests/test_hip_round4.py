@@ -338,7 +338,7 @@ def test_submodules_are_differentiable_standalone(dev, mode):
         _grads_against_oracle(fl, O.film, [torch.randn(2, 4, 3, 5, 64, generator=g), torch.tensor([-2.0, -1.0, 0.0, 0.0])], mode, "film 5-D")
         _grads_against_oracle(fl, O.film, [torch.randn(3, 10, 64, generator=g), torch.tensor([1.1, 1.4, 1.25])], mode, "film 3-D")
         it = tante_amd.interprator(64, sp_dim=12).to(dev)
-        _grads_against_oracle(it, lambda w, a: O.interprator(w, a, 6.0), [torch.randn(3, 12, 64, generator=g), 6.0], mode, "interprator")
+        _grads_against_oracle(it, lambda w, a, oT: O.interprator(w, a, oT), [torch.randn(3, 12, 64, generator=g), 6.0], mode, "interprator")
 
 
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])
