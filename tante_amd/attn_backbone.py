@@ -43,8 +43,23 @@ def resolve_compute(module_default: Optional[str] = None) -> int:
         dt = torch.get_autocast_dtype("cuda")
         if dt == torch.bfloat16:
             return L.BF16
-        raise NotImplementedError(f"autocast dtype {dt} has no MFMA path here (use bfloat16 or fp32)")
+        if dt == torch.float16:
+            # The reference Trainer's default amp_type is "float16" with a GradScaler (trainer/trainer.py:86-104).  There is one 16-bit
+            # MFMA path here and its operand format is bf16: the same operand width and matrix rate as v_mfma_f32_16x16x32_f16, 8 instead
+            # of 11 mantissa bits, and fp32's exponent range -- nothing overflows, so the scaler's loss scaling is accepted and is
+            # arithmetically a power-of-two no-op (train.train_step(scaler=...), FlatAdamW.param_groups).  Said once, not silently.
+            global _FP16_NOTED
+            if not _FP16_NOTED:
+                _FP16_NOTED = True
+                import warnings
+                warnings.warn("tante_amd: torch.autocast(float16) runs the bf16 MFMA kernels (16-bit operands rounded to bfloat16, fp32 "
+                              "accumulation); results meet the same 1e-2 bar, GradScaler is supported but never has to skip a step")
+            return L.BF16
+        raise NotImplementedError(f"autocast dtype {dt} has no MFMA path here (use bfloat16, float16 or fp32)")
     return L.F32
+
+
+_FP16_NOTED = False
 
 
 def _no_autograd(module: nn.Module):

@@ -200,7 +200,7 @@ def validation_loop(model, dataloader, formatter, n_steps_rollout: int, device=N
 
 
 def train_one_epoch(model, optimizer, dataloader, formatter, n_steps_output: int, world: int = 1, rt_eps: float = 0.5,
-                    rt_n: float = 2.0, graph: bool = False) -> float:
+                    rt_n: float = 2.0, graph: bool = False, enable_amp: bool = False, amp_type: str = "bfloat16", scaler=None) -> float:
     """Trainer.train_one_epoch (trainer/trainer.py:174-207; R_Trainer's for deg=False, r_trainer.py:135-179): one optimisation step
     per batch, returns the mean training loss of the epoch (ONE host read at the end instead of the reference's loss.item() per batch).
     graph=True (fixed-dt model only): the steps of full-size batches replay one HIP graph (train.GraphedTrainStep, captured on the first
@@ -209,6 +209,22 @@ def train_one_epoch(model, optimizer, dataloader, formatter, n_steps_output: int
     device = next(model.parameters()).device
     model.train()
     losses = []
+    if enable_amp:
+        # Trainer.__init__ / train_one_epoch (trainer/trainer.py:86-104, 183-196): autocast(amp_type) around the forward and, for float16
+        # only, a GradScaler around backward / step.  Both 16-bit types select the bf16 MFMA kernels (attn_backbone.resolve_compute).
+        import contextlib
+        dt = {"float16": torch.float16, "bfloat16": torch.bfloat16}[amp_type]
+        if scaler is None and dt == torch.float16:
+            scaler = getattr(model, "_tante_grad_scaler", None) or torch.amp.GradScaler("cuda", enabled=True)
+            model._tante_grad_scaler = scaler
+        for batch in dataloader:
+            batch = {"input": batch["input"].to(device), "output": batch["output"][:, :n_steps_output].contiguous().to(device)}
+            with torch.autocast("cuda", dtype=dt):
+                if getattr(model, "deg", True):
+                    losses.append(train_step(model, optimizer, batch, formatter, n_steps_output, world, scaler=scaler))
+                else:
+                    losses.append(train_step_adaptive(model, optimizer, batch, formatter, n_steps_output, rt_eps, rt_n, world)[0])
+        return float(torch.stack(losses).mean()) if losses else float("nan")
     for batch in dataloader:
         batch = {"input": batch["input"].to(device), "output": batch["output"][:, :n_steps_output].contiguous().to(device)}
         if graph and getattr(model, "deg", True):

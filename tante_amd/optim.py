@@ -60,6 +60,14 @@ class FlatAdamW:
         self._offs = offs
         self.step_count = 0
 
+    @property
+    def param_groups(self):
+        """torch.optim's view of this optimiser: ONE group holding the parameters (whose .grad are views of the flat gradient bucket).
+        It is what torch.amp.GradScaler walks in unscale_() -- its in-place foreach unscale + inf check act directly on the bucket --
+        so the reference's AMP sequence works unchanged:  scaler.scale(loss).backward(); scaler.unscale_(opt); scaler.step(opt);
+        scaler.update()   (trainer/trainer.py:191-195; the norm clip lives inside step())."""
+        return [{"params": self.params, "lr": self.lr, "betas": self.betas, "eps": self.eps, "weight_decay": self.weight_decay}]
+
     def zero_grad(self, set_to_none: bool = False):
         """Zero the gradient bucket.  The parameters' .grad stay views of it whatever set_to_none says: step() reads only the bucket.
         (The view check runs once per step, in step(); here only a dropped .grad -- model.zero_grad(set_to_none=True) -- is re-bound,

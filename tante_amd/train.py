@@ -22,10 +22,20 @@ from .rollout import rollout_adaptive, rollout_model
 
 
 def train_step(model, opt: FlatAdamW, batch: Dict[str, torch.Tensor], formatter, n_steps_output: int, world: int = 1,
-               lr: float = None) -> torch.Tensor:
+               lr: float = None, scaler=None) -> torch.Tensor:
+    """scaler: a torch.amp.GradScaler -- the reference's fp16 AMP sequence (trainer/trainer.py:191-195):
+    scale(loss).backward(); unscale_(opt); [clip, inside step()]; step(opt) -- skipped when a gradient is not finite --; update()."""
     opt.zero_grad()
     y_pred, y_ref = rollout_model(model, batch, formatter, n_steps_output)
     loss = MseMeanFn.apply(y_pred, y_ref)
+    if scaler is not None and scaler.is_enabled():
+        run_backward(scaler.scale(loss))
+        if D.collective_needed(world):
+            D.allreduce_sum_(opt.flat_g)
+        scaler.unscale_(opt)
+        scaler.step(opt, grad_scale=1.0 / world, lr=lr)
+        scaler.update()
+        return loss.detach()
     run_backward(loss)
     if D.collective_needed(world):
         D.allreduce_sum_(opt.flat_g)

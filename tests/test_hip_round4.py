@@ -382,3 +382,52 @@ def test_transformer_block_masks(dev, mode):
         with torch.no_grad():
             y = blk(x.to(dev), None if kpm is None else kpm.to(dev), None if am is None else am.to(dev), causal)
         close(y, reference(kpm, am, causal), mode, f"TransformerBlock masks: {name}")
+
+
+def test_fp16_autocast_and_grad_scaler(dev):
+    """The reference Trainer's DEFAULT mixed-precision setting: amp_type "float16" with a GradScaler (trainer/trainer.py:86-104, 183-196).
+    torch.autocast(float16) selects the 16-bit MFMA path (bf16 operands: tante_amd/attn_backbone.py) and torch.amp.GradScaler drives
+    FlatAdamW through its param_groups: (1) two scaled steps land where two unscaled bf16 steps land (the scale is a power of two);
+    (2) a non-finite gradient makes the scaler skip the step and halve its scale, the parameters untouched."""
+    import copy
+    import warnings
+    import tante_amd
+    from tante_amd import autograd as A
+    from tante_amd.train import train_step
+    torch.manual_seed(3)
+    md = tante_amd.TanteMetadata(n_fields=2, spatial_resolution=(64, 64))
+    m1 = tante_amd.TANTE(in_T=4, dset_metadata=md, taylor_order=1, attn_axes="THW", n_head=8, embed_dim=256, patch_scale=8, dropout=0.0).to(dev).train()
+    m2 = copy.deepcopy(m1)
+    fmt = tante_amd.DefaultChannelsFirstFormatter(md)
+    g = torch.Generator().manual_seed(8)
+    b = {"input": torch.randn(2, 4, 64, 64, 2, generator=g).to(dev), "output": torch.randn(2, 2, 64, 64, 2, generator=g).to(dev)}
+    o1 = tante_amd.FlatAdamW(m1.parameters(), lr=1e-4, weight_decay=0.01, max_norm=1.0)
+    o2 = tante_amd.FlatAdamW(m2.parameters(), lr=1e-4, weight_decay=0.01, max_norm=1.0)
+    scaler = torch.amp.GradScaler("cuda", init_scale=2.0 ** 12, enabled=True)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for step in range(2):
+            A._SEED[0] = 50 + step
+            with torch.autocast("cuda", dtype=torch.float16):
+                l1 = float(train_step(m1, o1, b, fmt, 2, 1, scaler=scaler))
+            A._SEED[0] = 50 + step
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                l2 = float(train_step(m2, o2, b, fmt, 2, 1))
+            assert abs(l1 - l2) < 1e-4 * abs(l2), (step, l1, l2)
+            eg = float((o1.flat_g - o2.flat_g).norm() / o2.flat_g.norm())      # o1's bucket is unscaled in place by scaler.unscale_
+            record_parity(eg, eg, 1e-3, "bf16", f"fp16 autocast + GradScaler vs bf16 autocast, step {step + 1}: flat gradient")
+            assert eg < 1e-3, (step, eg)
+        assert o1.step_count == 2 and scaler.get_scale() == 2.0 ** 12
+        # (2) a non-finite gradient: the step is skipped, the scale backs off
+        p_before = o1.flat_p.clone()
+        o1.zero_grad()
+        with torch.autocast("cuda", dtype=torch.float16):
+            y_pred, y_ref = tante_amd.rollout_model(m1, b, fmt, 2)
+            loss = tante_amd.autograd.MseMeanFn.apply(y_pred, y_ref)
+        A.run_backward(scaler.scale(loss))
+        o1.flat_g[123] = float("inf")
+        scaler.unscale_(o1)
+        scaler.step(o1)
+        scaler.update()
+        assert torch.equal(o1.flat_p, p_before) and o1.step_count == 2
+        assert scaler.get_scale() == 2.0 ** 11
