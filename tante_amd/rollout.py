@@ -182,12 +182,16 @@ def rollout_adaptive(model, batch: Dict, formatter, n_steps: int, out_T: float, 
     R_Trainer serialises the batch (`for i in range(batch)`, r_trainer.py:118) because `floor(R_t[0])` lets sample 0 decide the frame
     count of a call.  With out_T < 1.999 the clamp bounds every r_t to [1.001, out_T + 0.001) (tante.py:191-201), so EVERY sample
     produces exactly one frame per call whatever sample 0 says: the per-sample loop and one batched rollout compute the same frames,
-    and `eval_rt` takes a mean over all R_t (order-free).  Then the batch runs as one."""
+    and `eval_rt` takes a mean over all R_t (order-free).  Then the batch runs as one.
+    For larger out_T the samples advance at their OWN rates (floor(R_t[i]) frames per call): _rollout_adaptive_batched keeps them in one
+    batch all the same (batch_when_equivalent=False brings the reference's serial loop back)."""
     device = device or next(model.parameters()).device
     xs, y_ref = formatter.process_input(batch)
     xs = xs[0].to(device)
     if per_sample and batch_when_equivalent and float(out_T) < 1.999:
         per_sample = False
+    if per_sample and batch_when_equivalent and xs.shape[0] > 1:
+        return _rollout_adaptive_batched(model, xs, y_ref.to(device), formatter, n_steps, out_T)
     chunks = [xs[i:i + 1] for i in range(xs.shape[0])] if per_sample else [xs]
     from .train_forward import fold_scope
     rts, outs = [], []
@@ -203,3 +207,36 @@ def rollout_adaptive(model, batch: Dict, formatter, n_steps: int, out_T: float, 
                 rts.append(rt)
             outs.append(torch.cat(preds, dim=1)[:, :n_steps])
     return torch.cat(outs, dim=0), y_ref.to(device), torch.cat(rts, dim=0)
+
+
+def _rollout_adaptive_batched(model, xs: torch.Tensor, y_ref: torch.Tensor, formatter, n_steps: int, out_T: float):
+    """R_Trainer.rollout_model's per-sample loop (r_trainer.py:112-133) WITHOUT its serialisation, for any out_T: every call runs all
+    samples that still need frames as one batch with per_sample_counts (TANTE.forward); sample i keeps floor(R_t[i]) frames of the call,
+    shifts ITS window by that many, and leaves the batch when it has n_steps frames.  Every operator of the path is per sample, so the
+    frames are those of the serial loop, and R_t comes back in that loop's order (all calls of sample 0, then sample 1, ...).
+    Differentiable: slicing and re-stacking are torch views / copies that autograd tracks."""
+    from .train_forward import fold_scope
+    B, T = xs.shape[0], model.T
+    win = [xs[i, -T:] for i in range(B)]                     # (T, D, H, W) each
+    preds = [[] for _ in range(B)]
+    rts = [[] for _ in range(B)]
+    produced = [0] * B
+    with fold_scope():
+        while True:
+            active = [i for i in range(B) if produced[i] < n_steps]
+            if not active:
+                break
+            y, rt = model(torch.stack([win[i] for i in active], dim=0), out_T, per_sample_counts=True)
+            counts = torch.floor(rt.detach()).to(torch.int64).tolist()          # one host read per call (the reference: one per sample)
+            for j, i in enumerate(active):
+                n = int(counts[j])
+                rts[i].append(rt[j:j + 1])
+                if n < 1:
+                    continue
+                yi = y[j, :n]
+                preds[i].append(yi)
+                produced[i] += n
+                if produced[i] < n_steps:
+                    win[i] = torch.cat([win[i][n:], yi], dim=0)[-T:]
+    out = torch.stack([formatter.process_output(torch.cat(p, dim=0)[:n_steps].unsqueeze(0))[0] for p in preds], dim=0)
+    return out, y_ref, torch.cat([torch.cat(r, dim=0) for r in rts], dim=0)

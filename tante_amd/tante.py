@@ -509,13 +509,17 @@ class TANTE(nn.Module):
                     and all(b.takes_x_in(compute) for b in self.blocks[1:self.taylor_order]))
 
     def forward(self, input: torch.Tensor, out_T=1, out: Optional[torch.Tensor] = None, enc_cache: Optional[tuple] = None,
-                enc_next: Optional[torch.Tensor] = None):
+                enc_next: Optional[torch.Tensor] = None, per_sample_counts: bool = False):
         """`out` (optional, deg=True only): a (B, output_length, D, H, W) fp32 view with contiguous frames (e.g. the next
         slots of a rollout buffer) that receives the prediction instead of a fresh tensor.
         `enc_cache` = (z, t_stride, b_stride): the window's frames already encoded by encode_frame (frame t of item b at
         z + t * t_stride + b * b_stride); see enc_cache_supported().
         `enc_next` (tail_fused_supported() only): a contiguous (B, Hp*Wp, C) fp32 tensor that receives the pre-FiLM encoding of the
         PREDICTED frame -- what encode_frame would compute from it -- out of the same launch that writes the frame.
+        `per_sample_counts` (deg=False): the reference lets sample 0's floor(R_t[0]) decide the frame count of the whole batch
+        (tante.py:163), which is why R_Trainer loops over the samples one at a time (r_trainer.py:118-119).  With this flag the call
+        produces max_i floor(R_t[i]) frames; frame j of sample i is what a single-sample call would give for j < floor(R_t[i]) (every op
+        of the path is per sample), and the caller keeps floor(R_t[i]) frames of sample i (rollout.rollout_adaptive).
         With autograd enabled the differentiable path (train_forward.py: HIP forward + HIP backward kernels) runs."""
         if not input.is_cuda:
             raise RuntimeError("tante_amd.TANTE runs on the GPU only (no CPU fallback); move the input to cuda")
@@ -525,7 +529,8 @@ class TANTE(nn.Module):
             from .train_forward import tante_train_forward
             if out is not None:
                 raise ValueError("out= is an inference-path option")
-            return tante_train_forward(self, input.to(torch.float32).contiguous(), resolve_compute(self.compute), out_T)
+            return tante_train_forward(self, input.to(torch.float32).contiguous(), resolve_compute(self.compute), out_T,
+                                       per_sample_counts=per_sample_counts)
         inp = input.detach().to(torch.float32)
         B, T, D, H, W = inp.shape
         frame = D * H * W
@@ -614,7 +619,8 @@ class TANTE(nn.Module):
                 return out
         else:
             R_t = torch.stack(r_t, dim=1).mean(dim=1)
-            n_out = math.floor(float(R_t[0]))         # l.163: sample 0 decides for the batch (host sync, as in the reference)
+            # l.163: sample 0 decides for the batch (host sync, as in the reference); per_sample_counts: enough frames for every sample
+            n_out = int(torch.floor(R_t).max()) if per_sample_counts else math.floor(float(R_t[0]))
             if n_out >= 1 and fused_head and n_out <= 8:
                 out = torch.empty(B, n_out, D, H, W, dtype=torch.float32, device=x.device)
                 for i, d3 in enumerate(srcs):

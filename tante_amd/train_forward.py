@@ -311,7 +311,7 @@ def encode_frames_train(model, frames: torch.Tensor, compute: int) -> torch.Tens
     return z.view(B, k, model.H_p * model.W_p, model.C)
 
 
-def tante_train_forward(model, inp: torch.Tensor, compute: int, out_T=1, z_win=None):
+def tante_train_forward(model, inp: torch.Tensor, compute: int, out_T=1, z_win=None, per_sample_counts: bool = False):
     """z_win (optional): the window's frames already encoded, (B, T, HW, C) fp32 contiguous (encode_frames_train); `inp` then only
     supplies its last frame (the Taylor sum's base) and may be that frame alone, (B, 1, D, H, W)."""
     B, _, D, H, W = inp.shape
@@ -362,7 +362,8 @@ def tante_train_forward(model, inp: torch.Tensor, compute: int, out_T=1, z_win=N
     if model.deg:
         return TaylorFn.apply(inp, model.frame_interval, model.output_length, *derivs)
     R_t = torch.stack(rts, dim=1).mean(dim=1)
-    n_out = int(torch.floor(R_t[0].detach()))          # tante.py:163 -- sample 0 decides (host sync, as in the reference)
+    # tante.py:163 -- sample 0 decides (host sync, as in the reference); per_sample_counts: frames for the largest count (TANTE.forward)
+    n_out = int(torch.floor(R_t.detach()).max()) if per_sample_counts else int(torch.floor(R_t[0].detach()))
     if n_out < 1:
         return torch.empty(B, 0, D, H, W, dtype=torch.float32, device=inp.device), R_t
     return TaylorFn.apply(inp, model.frame_interval, n_out, *derivs), R_t

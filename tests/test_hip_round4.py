@@ -387,7 +387,8 @@ def test_transformer_block_masks(dev, mode):
 def test_fp16_autocast_and_grad_scaler(dev):
     """The reference Trainer's DEFAULT mixed-precision setting: amp_type "float16" with a GradScaler (trainer/trainer.py:86-104, 183-196).
     torch.autocast(float16) selects the 16-bit MFMA path (bf16 operands: tante_amd/attn_backbone.py) and torch.amp.GradScaler drives
-    FlatAdamW through its param_groups: (1) two scaled steps land where two unscaled bf16 steps land (the scale is a power of two);
+    FlatAdamW through its param_groups: (1) two scaled steps land where two unscaled bf16-autocast steps land -- the scale is a power of
+    two; what differs is torch's own FiLM-table MLPs, which autocast runs in fp16 here and in bf16 there: the bf16 gradient bar 4e-2;
     (2) a non-finite gradient makes the scaler skip the step and halve its scale, the parameters untouched."""
     import copy
     import warnings
@@ -413,10 +414,10 @@ def test_fp16_autocast_and_grad_scaler(dev):
             A._SEED[0] = 50 + step
             with torch.autocast("cuda", dtype=torch.bfloat16):
                 l2 = float(train_step(m2, o2, b, fmt, 2, 1))
-            assert abs(l1 - l2) < 1e-4 * abs(l2), (step, l1, l2)
+            assert abs(l1 - l2) < 2e-3 * abs(l2), (step, l1, l2)
             eg = float((o1.flat_g - o2.flat_g).norm() / o2.flat_g.norm())      # o1's bucket is unscaled in place by scaler.unscale_
-            record_parity(eg, eg, 1e-3, "bf16", f"fp16 autocast + GradScaler vs bf16 autocast, step {step + 1}: flat gradient")
-            assert eg < 1e-3, (step, eg)
+            record_parity(eg, eg, 4e-2, "bf16", f"fp16 autocast + GradScaler vs bf16 autocast, step {step + 1}: flat gradient")
+            assert eg < 4e-2, (step, eg)
         assert o1.step_count == 2 and scaler.get_scale() == 2.0 ** 12
         # (2) a non-finite gradient: the step is skipped, the scale backs off
         p_before = o1.flat_p.clone()
@@ -431,3 +432,55 @@ def test_fp16_autocast_and_grad_scaler(dev):
         scaler.update()
         assert torch.equal(o1.flat_p, p_before) and o1.step_count == 2
         assert scaler.get_scale() == 2.0 ** 11
+
+
+@pytest.mark.parametrize("grad", [False, True])
+def test_adaptive_rollout_batched_with_per_sample_frame_counts(dev, grad):
+    """R_Trainer's per-sample loop for an out_T where the samples advance at DIFFERENT rates (floor(R_t[i]) frames per call,
+    r_trainer.py:112-133, tante.py:163) against the batched form that keeps them in one batch (rollout._rollout_adaptive_batched):
+    the same frames, the same R_t in the same order -- without autograd and, with it, the same parameter gradients."""
+    import tante_amd
+    from test_hip_parity import _tante_from
+    from conftest import load_golden
+    g = load_golden("g13_deg_false")
+    md = tante_amd.TanteMetadata(n_fields=1, spatial_resolution=(32, 32))
+    m = _tante_from(g, dev, in_T=4, dset_metadata=md, taylor_order=2, attn_axes="TH-TW", n_head=2, embed_dim=32, patch_scale=8, dropout=0.0,
+                    deg=False)
+    with torch.no_grad():      # step sizes that depend on the sample: a steep last layer around the middle of the clamp range
+        for it in m.interprators:
+            it.interprete[4].weight.mul_(60.0)
+            it.interprete[4].bias.add_(2.2)
+    fmt = tante_amd.DefaultChannelsFirstFormatter(md)
+    gen = torch.Generator().manual_seed(11)
+    amp = torch.tensor([0.05, 0.4, 1.0, 2.0, 5.0, 12.0]).view(6, 1, 1, 1, 1)
+    batch = {"input": (torch.randn(6, 4, 32, 32, 1, generator=gen) * amp).to(dev), "output": torch.randn(6, 7, 32, 32, 1, generator=gen).to(dev)}
+    if grad:
+        m.train()
+        for p in m.parameters():
+            p.grad = None
+        y_b, _, rt_b = tante_amd.rollout_adaptive(m, batch, fmt, 7, 6.0, per_sample=True)
+        (y_b.square().mean() + rt_b.mean()).backward()
+        gb = {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}
+        for p in m.parameters():
+            p.grad = None
+        y_s, _, rt_s = tante_amd.rollout_adaptive(m, batch, fmt, 7, 6.0, per_sample=True, batch_when_equivalent=False)
+        (y_s.square().mean() + rt_s.mean()).backward()
+        worst = 0.0
+        for n, p in m.named_parameters():
+            if p.grad is None:
+                continue
+            e = rel_err(gb[n], p.grad)
+            worst = max(worst, e)
+            assert e < 2e-4, (n, e)
+        record_parity(worst, worst, 2e-4, "fp32", "batched adaptive rollout with per-sample counts vs serial loop: worst parameter gradient")
+    else:
+        m.eval()
+        with torch.no_grad():
+            y_b, _, rt_b = tante_amd.rollout_adaptive(m, batch, fmt, 7, 6.0, per_sample=True)
+            y_s, _, rt_s = tante_amd.rollout_adaptive(m, batch, fmt, 7, 6.0, per_sample=True, batch_when_equivalent=False)
+    assert y_b.shape == y_s.shape == (6, 7, 32, 32, 1)
+    assert rt_b.shape == rt_s.shape
+    counts = torch.floor(rt_s.detach()).cpu()
+    assert counts.min() >= 1 and len(set(counts.tolist())) > 1, f"the fixture must give the samples different frame counts: {counts.tolist()}"
+    close(y_b, y_s.detach().cpu(), "fp32", "batched adaptive rollout (per-sample counts) vs serial loop: frames")
+    close(rt_b, rt_s.detach().cpu(), "fp32", "batched adaptive rollout (per-sample counts) vs serial loop: R_t, in order")
