@@ -192,6 +192,13 @@ int tante_film_table(const float* t, int rows, int C, const float* sc_w0, const 
                      const float* sc_b2, const float* sh_w0, const float* sh_b0, const float* sh_w2,
                      const float* sh_b2, const float* add, float* a_out, float* b_out, void* stream);
 
+/* Backward of tante_film_table: dA, dB (rows, C) -> the gradients of the eight MLP parameters, written or (accumulate) added onto
+ * existing buffers; d(add) = dB is the caller's.  One launch instead of torch's ten small GEMMs + their glue per train step. */
+int tante_film_table_bwd(const float* t, int rows, int C, const float* sc_w0, const float* sc_b0, const float* sc_w2, const float* sh_w0,
+                         const float* sh_b0, const float* sh_w2, const float* dA, const float* dB, float* g_sc_w0, float* g_sc_b0,
+                         float* g_sc_w2, float* g_sc_b2, float* g_sh_w0, float* g_sh_b0, float* g_sh_w2, float* g_sh_b2, int accumulate,
+                         void* stream);
+
 /* y[r][c] = x_row(r)[c] * a[g][c] + b[g][c], g = r / rows_per, x_row(r) = x + g * x_bstride + (r % rows_per) * C
  * (film on (B, L, C) tokens, tante.py:222-224,229-230; tables hold 1+scale and shift). */
 int tante_film_apply(const float* x, int64_t x_bstride, float* y, int64_t rows, int C, int64_t rows_per, const float* a,
@@ -527,6 +534,11 @@ int tante_film_pos_fwd_frames(const TanteFrames* frames, const float* a, const f
                               float* y, void* stream);
 int tante_film_pos_bwd_frames(const float* dy, const TanteFrames* frames, const float* a, int64_t B, int64_t HW, int C, int T, float* const* dv,
                               float* da, float* db, float* ds, void* stream);
+/* The same with accumulation, for a BPTT rollout: bit t of dv_acc_mask -- dv[t] is ADDED to (a frame encoding that sits in several
+ * windows receives one gradient per window; the uses add in place instead of autograd summing fresh tensors); acc_flags bit 0: da / db
+ * are added to (the FiLM tables are shared by every call of the rollout), bit 1: ds is added to (the parameter's gradient slot). */
+int tante_film_pos_bwd_frames_acc(const float* dy, const TanteFrames* frames, const float* a, int64_t B, int64_t HW, int C, int T,
+                                  float* const* dv, int dv_acc_mask, float* da, float* db, float* ds, int acc_flags, void* stream);
 /* Taylor sum backward: dderivs[k] = sum_i (i dt)^k / k! * dout_i,  dlast (+)= sum_i dout_i (dlast may be the last frame of the
  * input-window gradient, addressed by base pointer + batch stride) */
 int tante_taylor_bwd(const float* dout, int64_t dout_bstride, float* const* dderivs, int n_order, double dt, int n_out, float* dlast,

@@ -167,6 +167,8 @@ SIGNATURES = {
     "tante_fold_fwd_multi": ([c_vp, c_i32, c_vp], c_i32),
     "tante_film_pos_fwd_frames": ([c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i64, c_i32, c_vp, c_vp], c_i32),
     "tante_film_pos_bwd_frames": ([c_vp, c_vp, c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp], c_i32),
+    "tante_film_pos_bwd_frames_acc": ([c_vp, c_vp, c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp], c_i32),
+    "tante_film_table_bwd": ([c_vp, c_i32, c_i32] + [c_vp] * 6 + [c_vp, c_vp] + [c_vp] * 8 + [c_i32, c_vp], c_i32),
     "tante_pack_block_train_multi": ([c_vp, c_i32, c_i32, c_i32, c_vp], c_i32),
     "tante_pack_block_tail_bwd_multi": ([c_vp, c_i32, c_i32, c_i32, c_vp], c_i32),
     "tante_axis_mlp_bwd_fused_supported": ([c_i32, c_i64], c_i32),
@@ -211,7 +213,7 @@ LIB_OPTIONS = ("TANTE_ATTN_BWD_HG", "TANTE_ATTN_BWD_NO_SPLIT", "TANTE_ATTN_BWD_V
 
 
 _lib = None
-ABI_VERSION = 5      # include/tante_hip.h: bumped whenever an entry point is added or changes (round 4: tante_head_enc_*)
+ABI_VERSION = 6      # include/tante_hip.h: bumped whenever an entry point is added or changes (round 4: tante_head_enc_*)
 
 
 def lib():

@@ -1110,6 +1110,15 @@ class FilmPosFramesFn(Function):
         L.check(L.lib().tante_film_pos_fwd_frames(C.byref(fr), a.data_ptr(), b.data_ptr(), s_emb.data_ptr(), B, T, HW, Cc, y.data_ptr(), _s()),
                 "film_pos_fwd_frames")
         ctx.save_for_backward(a, *frames)
+        # the Python objects (saved_tensors hands back fresh wrappers): the per-frame window counts and the accumulators live on them
+        ctx.frame_objs, ctx.a_obj, ctx.b_obj, ctx.s_obj = frames, a, b, s_emb
+        for f in frames:
+            if f.requires_grad:
+                st = getattr(f, "_tante_fwin", None)
+                if st is None:
+                    f._tante_fwin = [1, 0, None]          # [windows that hold the frame, contributions so far, accumulator]
+                else:
+                    st[0] += 1
         return y
 
     @staticmethod
@@ -1118,15 +1127,96 @@ class FilmPosFramesFn(Function):
         T = len(frames)
         B, HW, Cc = frames[0].shape
         dy = dy.contiguous()
-        dvs = [torch.empty(B, HW, Cc, dtype=torch.float32, device=a.device) for _ in range(T)]
-        da = torch.empty(T, Cc, dtype=torch.float32, device=a.device)
-        db = torch.empty(T, Cc, dtype=torch.float32, device=a.device)
-        ds = torch.empty(HW, Cc, dtype=torch.float32, device=a.device)
+        dev = a.device
+        # Gradients that several calls of a BPTT rollout contribute to are accumulated IN PLACE by the kernel instead of returned as fresh
+        # tensors for autograd to sum (one elementwise add + one temporary per use: 9 adds of 6 MB for the frame encodings, 6 for the
+        # tables, 3 for s_emb per train step):
+        #   * a frame encoding sits in up to T windows; the windows' nodes run in reverse call order (call k + 1 depends on call k), so
+        #     the first node to run allocates the frame's accumulator, later ones add, and the node that completes the count returns it;
+        #   * the FiLM tables come from ONE FilmTableFn node per rollout and carry accumulators (`_tante_grad`) that node reads;
+        #   * s_emb is a parameter: its .grad slot is added to directly.
+        objs = ctx.frame_objs
+        mask, dvs, rets = 0, [], []
+        for t, f in enumerate(objs):
+            st = getattr(f, "_tante_fwin", None)
+            if st is None or st[0] <= 1:              # used by this window only: an ordinary gradient
+                g = torch.empty(B, HW, Cc, dtype=torch.float32, device=dev)
+                dvs.append(g)
+                rets.append(g)
+                continue
+            if st[2] is None:                         # first contribution (the LAST window that holds the frame): write
+                st[2] = torch.empty(B, HW, Cc, dtype=torch.float32, device=dev)
+            else:
+                mask |= 1 << t
+            st[1] += 1
+            dvs.append(st[2])
+            if st[1] == st[0]:                        # every window has contributed: the sum flows on to the frame's encoder node
+                rets.append(st[2])
+                f._tante_fwin = None
+            else:
+                rets.append(None)
+        ga, gb, gs = _grad_slot(ctx.a_obj), _grad_slot(ctx.b_obj), _grad_slot(ctx.s_obj)
+        flags = 0
+        if ga is not None and gb is not None:
+            da, db, flags = ga, gb, 1
+        else:
+            da = torch.empty(T, Cc, dtype=torch.float32, device=dev)
+            db = torch.empty(T, Cc, dtype=torch.float32, device=dev)
+        if gs is not None:
+            ds, flags = gs.view(HW, Cc), flags | 2
+        else:
+            ds = torch.empty(HW, Cc, dtype=torch.float32, device=dev)
         fr = FilmPosFramesFn._arg(frames)
         ptrs = (C.c_void_p * T)(*[d.data_ptr() for d in dvs])
-        L.check(L.lib().tante_film_pos_bwd_frames(dy.data_ptr(), C.byref(fr), a.data_ptr(), B, HW, Cc, T, ptrs, da.data_ptr(), db.data_ptr(),
-                                                  ds.data_ptr(), _s()), "film_pos_bwd_frames")
-        return (da, db, ds, *dvs)
+        L.check(L.lib().tante_film_pos_bwd_frames_acc(dy.data_ptr(), C.byref(fr), a.data_ptr(), B, HW, Cc, T, ptrs, mask, da.data_ptr(),
+                                                      db.data_ptr(), ds.data_ptr(), flags, _s()), "film_pos_bwd_frames_acc")
+        ctx.frame_objs = ctx.a_obj = ctx.b_obj = ctx.s_obj = None
+        return (None if flags & 1 else da, None if flags & 1 else db, None if flags & 2 else ds, *rets)
+
+
+class FilmTableFn(Function):
+    """(a, b) = (1 + scale(t), shift(t) + add): the FiLM tables of a rollout (tante.py:203-230 with t_emb folded into the shift) in ONE
+    launch, differentiable: the outputs carry zeroed accumulators (`_tante_grad`) that every FilmPos*Fn use adds its da / db into, autograd
+    then calls this backward once with nothing, and ONE launch (tante_film_table_bwd) turns the accumulated (T, C) gradients into the eight
+    MLP parameters' gradients, straight into their slots.  (As torch modules the two MLPs were ten hipBLASLt GEMMs plus their glue per
+    train step -- 0.14 ms of 4-row launches -- and their tables' gradients six more adds.)"""
+
+    @staticmethod
+    def forward(ctx, t, add, *params):
+        rows, Cc = t.numel(), params[3].numel()
+        dev = t.device
+        a = torch.empty(rows, Cc, dtype=torch.float32, device=dev)
+        b = torch.empty(rows, Cc, dtype=torch.float32, device=dev)
+        L.check(L.lib().tante_film_table(t.data_ptr(), rows, Cc, *[p.data_ptr() for p in params], None if add is None else add.data_ptr(),
+                                         a.data_ptr(), b.data_ptr(), _s()), "tante_film_table")
+        acc = torch.zeros(2, rows, Cc, dtype=torch.float32, device=dev)
+        ctx.save_for_backward(t, *params)
+        ctx.acc, ctx.params, ctx.add = acc, params, add
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(acc)
+        return a, b, acc
+
+    @staticmethod
+    def backward(ctx, ga, gb, _acc):
+        t, *params = ctx.saved_tensors
+        rows, Cc = t.numel(), params[3].numel()
+        dA, dB = ctx.acc[0], ctx.acc[1]
+        if ga is not None:
+            dA = dA + ga
+        if gb is not None:
+            dB = dB + gb
+        dA, dB = dA.contiguous(), dB.contiguous()
+        slots = [_grad_slot(p) for p in ctx.params]
+        direct = all(g is not None for g in slots)
+        outs = slots if direct else [torch.empty_like(p) for p in params]
+        sc_w0, sc_b0, sc_w2, sc_b2, sh_w0, sh_b0, sh_w2, sh_b2 = params
+        L.check(L.lib().tante_film_table_bwd(t.data_ptr(), rows, Cc, sc_w0.data_ptr(), sc_b0.data_ptr(), sc_w2.data_ptr(), sh_w0.data_ptr(),
+                                             sh_b0.data_ptr(), sh_w2.data_ptr(), dA.data_ptr(), dB.data_ptr(), *[o.data_ptr() for o in outs],
+                                             1 if direct else 0, _s()), "tante_film_table_bwd")
+        d_add = None
+        if ctx.add is not None and ctx.add.requires_grad:
+            d_add = dB.view(ctx.add.shape).clone() if dB.numel() == ctx.add.numel() else None
+        return (None, d_add) + ((None,) * 8 if direct else tuple(outs))
 
 
 class TaylorFn(Function):
@@ -1145,7 +1235,8 @@ class TaylorFn(Function):
     def backward(ctx, dout):
         B, T, frame, dt, n_out, n_order, ishape = ctx.dims
         dout = dout.contiguous()
-        dinp = torch.zeros(ishape, dtype=torch.float32, device=dout.device)
+        # (the kernel writes the last frame's gradient in full; only the earlier frames of a longer window need the zero fill)
+        dinp = (torch.empty if T == 1 else torch.zeros)(ishape, dtype=torch.float32, device=dout.device)
         dds = [torch.empty(B, frame, dtype=torch.float32, device=dout.device) for _ in range(n_order)]
         arr = (C.c_void_p * n_order)(*[d.data_ptr() for d in dds])
         L.check(L.lib().tante_taylor_bwd(dout.data_ptr(), n_out * frame, arr, n_order, float(dt), n_out,

@@ -257,6 +257,7 @@ struct FilmFrames {
   const float* f[8];
   long bstride[8];
   float* dv[8];        // backward: the frames' gradients, contiguous (B, HW, C) each
+  int acc = 0;         // backward: bit t -- dv[t] is added to, not written
 };
 __global__ void film_pos_fwd_frames_kernel(FilmFrames F, const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ s,
                                            long rows, int C4, int T, long HW, float* __restrict__ y) {
@@ -317,7 +318,11 @@ __global__ __launch_bounds__(256) void film_pos_bwd256_kernel(const float* __res
 #pragma unroll
   for (int it = 0; it < ROWS / 4; ++it) {
     const long hw = h0 + it * 4 + r;
-    if (hw < HW) vdst[(bt * HW + hw) * C4 + c4] = g[it] * av;
+    if (hw < HW) {
+      f32x4 o = g[it] * av;
+      if (FRAMES && ((F.acc >> t) & 1)) o += vdst[(bt * HW + hw) * C4 + c4];      // a frame that sits in several windows: the later uses add
+      vdst[(bt * HW + hw) * C4 + c4] = o;
+    }
     sa += g[it] * x[it];
     sb += g[it];
   }
@@ -334,7 +339,7 @@ __global__ __launch_bounds__(256) void film_pos_bwd256_kernel(const float* __res
   }
 }
 // ds[hw][c] = sum over bt of dy[(bt*HW + hw)*C + c]
-__global__ void film_pos_ds_kernel(const float* __restrict__ dy, long BT, long HW, int C, float* __restrict__ ds) {
+__global__ void film_pos_ds_kernel(const float* __restrict__ dy, long BT, long HW, int C, float* __restrict__ ds, int accumulate = 0) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= HW * C) return;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;      // four images in flight per thread
@@ -344,7 +349,7 @@ __global__ void film_pos_ds_kernel(const float* __restrict__ dy, long BT, long H
     s0 += a; s1 += b; s2 += c; s3 += d;
   }
   for (; bt < BT; ++bt) s0 += dy[bt * HW * C + idx];
-  ds[idx] = (s0 + s1) + (s2 + s3);
+  ds[idx] = (accumulate ? ds[idx] : 0.0f) + ((s0 + s1) + (s2 + s3));
 }
 
 // ---- Taylor sum backward: dd_k = sum_i c_ik dout_i;  dlast (+)= sum_i dout_i -----------------------------------------
@@ -1679,6 +1684,7 @@ extern "C" int tante_film_pos_bwd(const float* dy, const float* v, const float* 
 }
 static int film_frames_arg(const TanteFrames* fr, int T, int C, float* const* dv, FilmFrames& F) {
   if (!fr || T <= 0 || T > 8) return -1;
+  F.acc = 0;
   for (int t = 0; t < 8; ++t) {
     F.f[t] = t < T ? fr->f[t] : nullptr;
     F.bstride[t] = t < T ? (long)fr->bstride[t] : 0;
@@ -1719,6 +1725,26 @@ extern "C" int tante_film_pos_bwd_frames(const float* dy, const TanteFrames* fra
     hipLaunchKernelGGL((film_pos_bwd256_kernel<true, 32>), dim3((unsigned)((HW + 31) / 32), (unsigned)BT), dim3(256), 0, s, dy, (const float*)nullptr, a, (long)HW, T,
                        (float*)nullptr, da, db, F);
   hipLaunchKernelGGL(film_pos_ds_kernel, dim3((unsigned)((HW * C + 255) / 256)), dim3(256), 0, s, dy, BT, (long)HW, C, ds);
+  TANTE_CHECK_LAUNCH();
+  return 0;
+}
+/* tante_film_pos_bwd_frames with accumulation: bit t of dv_acc_mask -- dv[t] is ADDED to (a frame encoding that sits in several windows of
+ * a BPTT rollout receives one gradient per window: the uses accumulate in place instead of autograd summing fresh tensors);
+ * acc_flags bit 0: da / db are added to (the FiLM tables are shared by every call of the rollout), bit 1: ds is added to. */
+extern "C" int tante_film_pos_bwd_frames_acc(const float* dy, const TanteFrames* frames, const float* a, int64_t B, int64_t HW, int C, int T,
+                                             float* const* dv, int dv_acc_mask, float* da, float* db, float* ds, int acc_flags, void* stream) {
+  FilmFrames F;
+  if (!dy || !a || !dv || !da || !db || !ds || B <= 0 || HW <= 0 || film_frames_arg(frames, T, C, dv, F))
+    TANTE_FAIL(-1, "tante_film_pos_bwd_frames_acc: bad argument");
+  if (C != 256 || ((uintptr_t)dy & 15)) TANTE_FAIL(-2, "tante_film_pos_bwd_frames_acc: C = 256 only (got %d)", C);
+  F.acc = dv_acc_mask;
+  hipStream_t s = (hipStream_t)stream;
+  if (!(acc_flags & 1) && (tante_zero_async(da, (size_t)T * C * sizeof(float), s) != hipSuccess || tante_zero_async(db, (size_t)T * C * sizeof(float), s) != hipSuccess))
+    TANTE_FAIL(-3, "tante_film_pos_bwd_frames_acc: clear failed");
+  const long BT = B * T;
+  hipLaunchKernelGGL((film_pos_bwd256_kernel<true, 64>), dim3((unsigned)((HW + 63) / 64), (unsigned)BT), dim3(256), 0, s, dy, (const float*)nullptr, a, (long)HW, T,
+                     (float*)nullptr, da, db, F);
+  hipLaunchKernelGGL(film_pos_ds_kernel, dim3((unsigned)((HW * C + 255) / 256)), dim3(256), 0, s, dy, BT, (long)HW, C, ds, (acc_flags >> 1) & 1);
   TANTE_CHECK_LAUNCH();
   return 0;
 }

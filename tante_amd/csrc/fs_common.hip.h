@@ -41,6 +41,16 @@ __device__ __forceinline__ u32x4 ldg_frag(const FsW& w, int byte_off) {
 #endif
 }
 __device__ __forceinline__ u32x4 ldg_frag(const char* p, int byte_off) { return *(const u32x4*)(p + byte_off); }
+// TIMING EXPERIMENT ONLY (-DFS_EXP_ROT, wrong results): every workgroup reads the k-steps of a matrix in an order rotated by a per-workgroup
+// amount (fs_exp_rot, wave-uniform), the MFMAs consume them as if nothing had happened.  Prices the hot-spot hypothesis: all 512
+// workgroups ask the L2 for the SAME 16 KiB of weight fragments at the same moment (the q and k GEMMs, right behind LayerNorm1, take
+// 6 k cycles in the stamps where the v / fc1 / fc2 GEMMs take 3 k).
+#ifdef FS_EXP_ROT
+__device__ int fs_exp_rot_of() { return (int)((blockIdx.x >> 3) & 7); }
+#define FS_GROT(g) (8 * ((g) >> 3) + ((((g) & 7) + fs_exp_rot_of()) & 7))
+#else
+#define FS_GROT(g) (g)
+#endif
 // timing experiment only (-DFS_EXP_NO_WLOAD, wrong results): every fragment load of the weight stream re-reads the stream's FIRST k-step
 // (16 KiB per workgroup, L1-resident) -- the same instructions and waits, none of the L2 -> L1 traffic.  Prices the weight stream.
 #ifdef FS_EXP_NO_WLOAD
@@ -100,7 +110,7 @@ __device__ __forceinline__ void fs_wring_prime(const WP& wq, u32x4 (&wb)[PF + 1]
 #pragma unroll
   for (int p = 0; p < PF; ++p)
 #pragma unroll
-    for (int j = 0; j < RT; ++j) wb[(8 * M + p) % (PF + 1)][j] = ldg_frag(wq, FS_WOFF(16 * (8 * M + p) + j) * FS_FRAG);
+    for (int j = 0; j < RT; ++j) wb[(8 * M + p) % (PF + 1)][j] = ldg_frag(wq, FS_WOFF(16 * FS_GROT(8 * M + p) + j) * FS_FRAG);
 }
 template <int M, int GEND, int NTT, int RT, bool SWAP, int PF, class WP>
 __device__ __forceinline__ void fs_slice_gemm(const WP& wq, u32x4 (&wb)[PF + 1][RT], const char* img, const int (&rdo)[4],
@@ -120,7 +130,7 @@ __device__ __forceinline__ void fs_slice_gemm(const WP& wq, u32x4 (&wb)[PF + 1][
         constexpr int i = decltype(ic)::value, ks = i / NTT, tt = i % NTT, g = 8 * M + ks;
         if constexpr (tt == 0 && g + PF < GEND) {
 #pragma unroll
-          for (int j = 0; j < RT; ++j) wb[(g + PF) % (PF + 1)][j] = ldg_frag(wq, FS_WOFF(16 * (g + PF) + j) * FS_FRAG);
+          for (int j = 0; j < RT; ++j) wb[(g + PF) % (PF + 1)][j] = ldg_frag(wq, FS_WOFF(16 * FS_GROT(g + PF) + j) * FS_FRAG);
         }
 #ifdef FS_EXP_MFMA32
         // TIMING EXPERIMENT ONLY (wrong results): the same loads, the same operand and accumulator registers, half as many MFMAs of

@@ -716,6 +716,61 @@ __global__ void film_table_kernel(const float* __restrict__ t, int rows, int C, 
   b_out[idx] = sb + (add ? add[idx] : 0.0f);
 }
 
+// Backward of the tables: per MLP  out[r][c] = b2[c] + sum_j w2[c][j] relu(w0[j] t[r] + b0[j]);  dOut = dA (scale) / dB (shift), (rows, C).
+// One workgroup does both MLPs (rows <= 8, C <= 512: a few hundred kFLOP); results are ADDED onto the gradient buffers when `acc`
+// (the parameters' .grad slots, zeroed by the optimiser's zero_grad) and written otherwise.
+__global__ __launch_bounds__(256) void film_table_bwd_kernel(const float* __restrict__ t, int rows, int C, const float* __restrict__ sc_w0,
+                                                            const float* __restrict__ sc_b0, const float* __restrict__ sc_w2,
+                                                            const float* __restrict__ sh_w0, const float* __restrict__ sh_b0,
+                                                            const float* __restrict__ sh_w2, const float* __restrict__ dA,
+                                                            const float* __restrict__ dB, float* g_sc_w0, float* g_sc_b0, float* g_sc_w2,
+                                                            float* g_sc_b2, float* g_sh_w0, float* g_sh_b0, float* g_sh_w2, float* g_sh_b2,
+                                                            int acc) {
+  extern __shared__ float fsm[];      // h[rows][Hd], dh[rows][Hd], dO[rows][C]
+  const int Hd = C / 2, tid = threadIdx.x;
+  float* h = fsm;
+  float* dh = fsm + rows * Hd;
+  float* dO = dh + rows * Hd;
+  for (int m = 0; m < 2; ++m) {
+    const float* w0 = m ? sh_w0 : sc_w0;
+    const float* b0 = m ? sh_b0 : sc_b0;
+    const float* w2 = m ? sh_w2 : sc_w2;
+    const float* dOut = m ? dB : dA;
+    float* gw0 = m ? g_sh_w0 : g_sc_w0;
+    float* gb0 = m ? g_sh_b0 : g_sc_b0;
+    float* gw2 = m ? g_sh_w2 : g_sc_w2;
+    float* gb2 = m ? g_sh_b2 : g_sc_b2;
+    __syncthreads();
+    for (int i = tid; i < rows * Hd; i += 256) { const int r = i / Hd, j = i % Hd; h[i] = fmaxf(w0[j] * t[r] + b0[j], 0.0f); }
+    for (int i = tid; i < rows * C; i += 256) dO[i] = dOut[i];
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+      float sb = 0.f;
+      for (int r = 0; r < rows; ++r) sb += dO[r * C + c];
+      gb2[c] = (acc ? gb2[c] : 0.f) + sb;
+    }
+    for (int i = tid; i < C * Hd; i += 256) {
+      const int c = i / Hd, j = i % Hd;
+      float sw = 0.f;
+      for (int r = 0; r < rows; ++r) sw += dO[r * C + c] * h[r * Hd + j];
+      gw2[i] = (acc ? gw2[i] : 0.f) + sw;
+    }
+    for (int i = tid; i < rows * Hd; i += 256) {
+      const int r = i / Hd, j = i % Hd;
+      float sd = 0.f;
+      for (int c = 0; c < C; ++c) sd += dO[r * C + c] * w2[c * Hd + j];
+      dh[i] = h[i] > 0.0f ? sd : 0.0f;      // relu'(pre) = [pre > 0] = [h > 0]
+    }
+    __syncthreads();
+    for (int j = tid; j < Hd; j += 256) {
+      float s0 = 0.f, s1 = 0.f;
+      for (int r = 0; r < rows; ++r) { s0 += dh[r * Hd + j] * t[r]; s1 += dh[r * Hd + j]; }
+      gw0[j] = (acc ? gw0[j] : 0.f) + s0;
+      gb0[j] = (acc ? gb0[j] : 0.f) + s1;
+    }
+  }
+}
+
 __global__ void film_apply_kernel(const float* __restrict__ x, long x_bstride, float* __restrict__ y, long rows, int C4,
                                   long rows_per, const float* __restrict__ a, const float* __restrict__ b) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;  // one float4 per thread
@@ -1023,6 +1078,22 @@ extern "C" int tante_film_table(const float* t, int rows, int C, const float* sc
   return 0;
 }
 
+extern "C" int tante_film_table_bwd(const float* t, int rows, int C, const float* sc_w0, const float* sc_b0, const float* sc_w2, const float* sh_w0,
+                                    const float* sh_b0, const float* sh_w2, const float* dA, const float* dB, float* g_sc_w0, float* g_sc_b0,
+                                    float* g_sc_w2, float* g_sc_b2, float* g_sh_w0, float* g_sh_b0, float* g_sh_w2, float* g_sh_b2,
+                                    int accumulate, void* stream) {
+  if (!t || !sc_w0 || !sc_b0 || !sc_w2 || !sh_w0 || !sh_b0 || !sh_w2 || !dA || !dB || !g_sc_w0 || !g_sc_b0 || !g_sc_w2 || !g_sc_b2 || !g_sh_w0 ||
+      !g_sh_b0 || !g_sh_w2 || !g_sh_b2)
+    TANTE_FAIL(-1, "tante_film_table_bwd: null pointer");
+  if (rows <= 0 || rows > 64 || C <= 0 || C % 2) TANTE_FAIL(-1, "tante_film_table_bwd: bad shape");
+  const size_t lds = ((size_t)2 * rows * (C / 2) + (size_t)rows * C) * sizeof(float);
+  if (lds > 60 * 1024) TANTE_FAIL(-2, "tante_film_table_bwd: rows x C too large for one workgroup (%d x %d)", rows, C);
+  hipLaunchKernelGGL(film_table_bwd_kernel, dim3(1), dim3(256), lds, (hipStream_t)stream, t, rows, C, sc_w0, sc_b0, sc_w2, sh_w0, sh_b0, sh_w2, dA,
+                     dB, g_sc_w0, g_sc_b0, g_sc_w2, g_sc_b2, g_sh_w0, g_sh_b0, g_sh_w2, g_sh_b2, accumulate);
+  TANTE_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int tante_film_apply(const float* x, int64_t x_bstride, float* y, int64_t rows, int C, int64_t rows_per,
                                 const float* a, const float* b, void* stream) {
   if (!x || !y || !a || !b) TANTE_FAIL(-1, "tante_film_apply: null pointer");
@@ -1136,4 +1207,4 @@ extern "C" int tante_set_option(const char* name, int value) {
   return 0;
 }
 extern "C" int tante_get_option(const char* name, int dflt) { return name ? tante_opt(name, dflt) : dflt; }
-extern "C" int tante_abi_version(void) { return 5; }      // = tante_amd/_lib.py ABI_VERSION; bumped with every added / changed entry point
+extern "C" int tante_abi_version(void) { return 6; }      // = tante_amd/_lib.py ABI_VERSION; bumped with every added / changed entry point

@@ -13,7 +13,7 @@ from . import _lib as L
 from . import options as _O
 from . import kernels as K
 from . import stages as S
-from .autograd import (ActFn, AttentionFn, BlockFn, BlockTailFn, block_tail_ready, AxisHWFn, AxisMlpFn, BranchOutFn, DeconvFn, DropoutAddFn, FilmPosFn, FilmPosFramesFn, FoldFn, LayerNormFn, LayerNormSkipFn, LinearFn, PatchEmbedFn, RtReduceFn,
+from .autograd import (FilmTableFn, ActFn, AttentionFn, BlockFn, BlockTailFn, block_tail_ready, AxisHWFn, AxisMlpFn, BranchOutFn, DeconvFn, DropoutAddFn, FilmPosFn, FilmPosFramesFn, FoldFn, LayerNormFn, LayerNormSkipFn, LinearFn, PatchEmbedFn, RtReduceFn,
                        TaylorFn)
 
 
@@ -62,7 +62,8 @@ FUSED_HEAD_BACKWARD = _O.register("TANTE_TRAIN_FUSED_HEAD_BWD", True, __name__, 
 
 BLOCK_CALLS = [0, 0]      # block_train calls / those that took the fused one-node path (GraphedTrainStep checks them at capture)
 FRAME_FILM = _O.register("TANTE_TRAIN_FRAME_FILM", True, __name__, "FRAME_FILM")     # FiLM reads the window's frames where they are (no stack per call)
-BATCH_PREP = _O.register("TANTE_TRAIN_BATCH_PREP", True, __name__, "BATCH_PREP")     # folds and backward fragment streams of all blocks in two launches
+BATCH_PREP = _O.register("TANTE_TRAIN_BATCH_PREP", True, __name__, "BATCH_PREP")
+FILM_TABLE_HIP = _O.register("TANTE_TRAIN_FILM_TABLE_HIP", True, __name__, "FILM_TABLE_HIP")   # FiLM tables + their backward as two HIP launches     # folds and backward fragment streams of all blocks in two launches
 
 
 def prepare_blocks(model, compute: int):
@@ -333,17 +334,31 @@ def tante_train_forward(model, inp: torch.Tensor, compute: int, out_T=1, z_win=N
     tabs = _FOLDS.get(key) if _FOLDS is not None else None
     if tabs is None:
         te = model.t_encode
-        t = model.t_seq.to(inp.device, torch.float32)[:, None]
-        fa = (1.0 + te.condition_to_scale(t)).contiguous()                     # (T, C)
-        fb = (te.condition_to_shift(t) + model.t_emb.view(T, C_)).contiguous()
+        sc, sh = te.condition_to_scale, te.condition_to_shift
+        if FILM_TABLE_HIP:
+            # one launch forward, one backward (autograd.FilmTableFn); the tables' gradients of the rollout's calls accumulate on the node
+            tsec = model.t_seq.to(inp.device, torch.float32).contiguous()
+            fa, fb, acc = FilmTableFn.apply(tsec, model.t_emb.view(T, C_), sc[0].weight, sc[0].bias, sc[2].weight, sc[2].bias,
+                                            sh[0].weight, sh[0].bias, sh[2].weight, sh[2].bias)
+            fa._tante_grad, fb._tante_grad = acc[0], acc[1]
+        else:
+            t = model.t_seq.to(inp.device, torch.float32)[:, None]
+            fa = (1.0 + sc(t)).contiguous()                     # (T, C)
+            fb = (sh(t) + model.t_emb.view(T, C_)).contiguous()
         tabs = (fa, fb)
         if _FOLDS is not None:
             _FOLDS[key] = tabs
     fa, fb = tabs
+    s_view = model.s_emb.view(HW, C_)
+    if FILM_TABLE_HIP:      # s_emb's gradient slot, for the kernel to add into (the rollout's calls share the parameter)
+        from .autograd import _grad_slot
+        gs = _grad_slot(model.s_emb)
+        if gs is not None:
+            s_view._tante_grad = gs.view(HW, C_)
     if z_frames is not None:
-        x = FilmPosFramesFn.apply(fa, fb, model.s_emb.view(HW, C_), *z_frames)
+        x = FilmPosFramesFn.apply(fa, fb, s_view, *z_frames)
     else:
-        x = FilmPosFn.apply(z, fa, fb, model.s_emb.view(HW, C_), T, HW)
+        x = FilmPosFn.apply(z, fa, fb, s_view, T, HW)
     derivs, rts = [], []
     for i in range(model.taylor_order):
         x = backbone_train(model.blocks[i], x, B, compute)
