@@ -1174,6 +1174,26 @@ class FilmPosFramesFn(Function):
         return (None if flags & 1 else da, None if flags & 1 else db, None if flags & 2 else ds, *rets)
 
 
+class SplitFramesFn(Function):
+    """(B, k, HW, C) frame encodings -> k contiguous (B, HW, C) tensors.  torch's unbind would do, but its backward builds the window's
+    gradient with a zero fill + a copy per frame and autograd then sums those k full-size tensors; here the forward is one transposing
+    copy and the backward one stack of the k frame gradients (a frame no window used contributes zeros)."""
+
+    @staticmethod
+    def forward(ctx, z):
+        B, k, HW, Cc = z.shape
+        zc = z.permute(1, 0, 2, 3).contiguous()          # (k, B, HW, C): one copy kernel
+        ctx.dims = (B, k, HW, Cc)
+        return tuple(zc[f] for f in range(k))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        B, k, HW, Cc = ctx.dims
+        ref = next(g for g in gs if g is not None)
+        gs = [g if g is not None else torch.zeros_like(ref) for g in gs]
+        return torch.stack(gs, dim=1)
+
+
 class FilmTableFn(Function):
     """(a, b) = (1 + scale(t), shift(t) + add): the FiLM tables of a rollout (tante.py:203-230 with t_emb folded into the shift) in ONE
     launch, differentiable: the outputs carry zeroed accumulators (`_tante_grad`) that every FilmPos*Fn use adds its da / db into, autograd

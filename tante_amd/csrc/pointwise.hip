@@ -717,8 +717,11 @@ __global__ void film_table_kernel(const float* __restrict__ t, int rows, int C, 
 }
 
 // Backward of the tables: per MLP  out[r][c] = b2[c] + sum_j w2[c][j] relu(w0[j] t[r] + b0[j]);  dOut = dA (scale) / dB (shift), (rows, C).
-// One workgroup does both MLPs (rows <= 8, C <= 512: a few hundred kFLOP); results are ADDED onto the gradient buffers when `acc`
-// (the parameters' .grad slots, zeroed by the optimiser's zero_grad) and written otherwise.
+// grid = (Hd / 8, 2 MLPs): a workgroup owns 8 hidden units j of one MLP; thread c owns output channel c (C <= 256 per pass):
+//   gw2[c][j] = sum_r dO[r][c] h[r][j]                      (8 consecutive floats per thread)
+//   dh[r][j]  = sum_c dO[r][c] w2[c][j]  -> [h > 0]        (a sum over the workgroup's threads: wave DPP + LDS)
+//   gw0[j] = sum_r dh[r][j] t[r],  gb0[j] = sum_r dh[r][j];  gb2[c] = sum_r dO[r][c]  (by the j = 0 workgroup)
+// Results are ADDED onto the gradient buffers when `acc` (the parameters' .grad slots) and written otherwise.  rows <= 8.
 __global__ __launch_bounds__(256) void film_table_bwd_kernel(const float* __restrict__ t, int rows, int C, const float* __restrict__ sc_w0,
                                                             const float* __restrict__ sc_b0, const float* __restrict__ sc_w2,
                                                             const float* __restrict__ sh_w0, const float* __restrict__ sh_b0,
@@ -726,48 +729,77 @@ __global__ __launch_bounds__(256) void film_table_bwd_kernel(const float* __rest
                                                             const float* __restrict__ dB, float* g_sc_w0, float* g_sc_b0, float* g_sc_w2,
                                                             float* g_sc_b2, float* g_sh_w0, float* g_sh_b0, float* g_sh_w2, float* g_sh_b2,
                                                             int acc) {
-  extern __shared__ float fsm[];      // h[rows][Hd], dh[rows][Hd], dO[rows][C]
-  const int Hd = C / 2, tid = threadIdx.x;
-  float* h = fsm;
-  float* dh = fsm + rows * Hd;
-  float* dO = dh + rows * Hd;
-  for (int m = 0; m < 2; ++m) {
-    const float* w0 = m ? sh_w0 : sc_w0;
-    const float* b0 = m ? sh_b0 : sc_b0;
-    const float* w2 = m ? sh_w2 : sc_w2;
-    const float* dOut = m ? dB : dA;
-    float* gw0 = m ? g_sh_w0 : g_sc_w0;
-    float* gb0 = m ? g_sh_b0 : g_sc_b0;
-    float* gw2 = m ? g_sh_w2 : g_sc_w2;
-    float* gb2 = m ? g_sh_b2 : g_sc_b2;
-    __syncthreads();
-    for (int i = tid; i < rows * Hd; i += 256) { const int r = i / Hd, j = i % Hd; h[i] = fmaxf(w0[j] * t[r] + b0[j], 0.0f); }
-    for (int i = tid; i < rows * C; i += 256) dO[i] = dOut[i];
-    __syncthreads();
-    for (int c = tid; c < C; c += 256) {
-      float sb = 0.f;
-      for (int r = 0; r < rows; ++r) sb += dO[r * C + c];
-      gb2[c] = (acc ? gb2[c] : 0.f) + sb;
+  __shared__ float red[4][8][8];      // [wave][row][j]
+  const int Hd = C / 2, tid = threadIdx.x, m = blockIdx.y, j0 = blockIdx.x * 8;
+  const float* w0 = m ? sh_w0 : sc_w0;
+  const float* b0 = m ? sh_b0 : sc_b0;
+  const float* w2 = m ? sh_w2 : sc_w2;
+  const float* dOut = m ? dB : dA;
+  float* gw0 = m ? g_sh_w0 : g_sc_w0;
+  float* gb0 = m ? g_sh_b0 : g_sc_b0;
+  float* gw2 = m ? g_sh_w2 : g_sc_w2;
+  float* gb2 = m ? g_sh_b2 : g_sc_b2;
+  float tv[8], h[8][8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    tv[r] = r < rows ? t[r] : 0.0f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) h[r][j] = r < rows ? fmaxf(w0[j0 + j] * tv[r] + b0[j0 + j], 0.0f) : 0.0f;
+  }
+  float part[8][8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) part[r][j] = 0.0f;
+  for (int c = tid; c < C; c += 256) {
+    float d[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) d[r] = r < rows ? dOut[r * C + c] : 0.0f;
+    float w[8];
+    const f32x4 wa = *(const f32x4*)(w2 + (long)c * Hd + j0), wb = *(const f32x4*)(w2 + (long)c * Hd + j0 + 4);
+    w[0] = wa[0]; w[1] = wa[1]; w[2] = wa[2]; w[3] = wa[3]; w[4] = wb[0]; w[5] = wb[1]; w[6] = wb[2]; w[7] = wb[3];
+    float g[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float sw = 0.0f;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) { sw += d[r] * h[r][j]; part[r][j] += d[r] * w[j]; }
+      g[j] = sw;
     }
-    for (int i = tid; i < C * Hd; i += 256) {
-      const int c = i / Hd, j = i % Hd;
-      float sw = 0.f;
-      for (int r = 0; r < rows; ++r) sw += dO[r * C + c] * h[r * Hd + j];
-      gw2[i] = (acc ? gw2[i] : 0.f) + sw;
+    float* o = gw2 + (long)c * Hd + j0;
+    f32x4 oa = f32x4{g[0], g[1], g[2], g[3]}, ob = f32x4{g[4], g[5], g[6], g[7]};
+    if (acc) { oa += *(const f32x4*)o; ob += *(const f32x4*)(o + 4); }
+    *(f32x4*)o = oa; *(f32x4*)(o + 4) = ob;
+    if (blockIdx.x == 0) {
+      float sb = 0.0f;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) sb += d[r];
+      gb2[c] = (acc ? gb2[c] : 0.0f) + sb;
     }
-    for (int i = tid; i < rows * Hd; i += 256) {
-      const int r = i / Hd, j = i % Hd;
-      float sd = 0.f;
-      for (int c = 0; c < C; ++c) sd += dO[r * C + c] * w2[c * Hd + j];
-      dh[i] = h[i] > 0.0f ? sd : 0.0f;      // relu'(pre) = [pre > 0] = [h > 0]
+  }
+  // dh[r][j]: sum of part over the workgroup's threads
+#pragma unroll
+  for (int r = 0; r < 8; ++r)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float v = part[r][j];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+      if ((tid & 63) == 0) red[tid >> 6][r][j] = v;
     }
-    __syncthreads();
-    for (int j = tid; j < Hd; j += 256) {
-      float s0 = 0.f, s1 = 0.f;
-      for (int r = 0; r < rows; ++r) { s0 += dh[r * Hd + j] * t[r]; s1 += dh[r * Hd + j]; }
-      gw0[j] = (acc ? gw0[j] : 0.f) + s0;
-      gb0[j] = (acc ? gb0[j] : 0.f) + s1;
+  __syncthreads();
+  if (tid < 8) {
+    const int j = tid;
+    float s0 = 0.0f, s1 = 0.0f;
+    for (int r = 0; r < rows; ++r) {
+      const float dh = (red[0][r][j] + red[1][r][j]) + (red[2][r][j] + red[3][r][j]);
+      const float hv = fmaxf(w0[j0 + j] * t[r] + b0[j0 + j], 0.0f);
+      const float dp = hv > 0.0f ? dh : 0.0f;      // relu'(pre) = [pre > 0] = [h > 0]
+      s0 += dp * t[r];
+      s1 += dp;
     }
+    gw0[j0 + j] = (acc ? gw0[j0 + j] : 0.0f) + s0;
+    gb0[j0 + j] = (acc ? gb0[j0 + j] : 0.0f) + s1;
   }
 }
 
@@ -1085,11 +1117,9 @@ extern "C" int tante_film_table_bwd(const float* t, int rows, int C, const float
   if (!t || !sc_w0 || !sc_b0 || !sc_w2 || !sh_w0 || !sh_b0 || !sh_w2 || !dA || !dB || !g_sc_w0 || !g_sc_b0 || !g_sc_w2 || !g_sc_b2 || !g_sh_w0 ||
       !g_sh_b0 || !g_sh_w2 || !g_sh_b2)
     TANTE_FAIL(-1, "tante_film_table_bwd: null pointer");
-  if (rows <= 0 || rows > 64 || C <= 0 || C % 2) TANTE_FAIL(-1, "tante_film_table_bwd: bad shape");
-  const size_t lds = ((size_t)2 * rows * (C / 2) + (size_t)rows * C) * sizeof(float);
-  if (lds > 60 * 1024) TANTE_FAIL(-2, "tante_film_table_bwd: rows x C too large for one workgroup (%d x %d)", rows, C);
-  hipLaunchKernelGGL(film_table_bwd_kernel, dim3(1), dim3(256), lds, (hipStream_t)stream, t, rows, C, sc_w0, sc_b0, sc_w2, sh_w0, sh_b0, sh_w2, dA,
-                     dB, g_sc_w0, g_sc_b0, g_sc_w2, g_sc_b2, g_sh_w0, g_sh_b0, g_sh_w2, g_sh_b2, accumulate);
+  if (rows <= 0 || rows > 8 || C <= 0 || C % 16) TANTE_FAIL(-2, "tante_film_table_bwd: rows <= 8 and C %% 16 == 0 expected (got %d x %d)", rows, C);
+  hipLaunchKernelGGL(film_table_bwd_kernel, dim3((unsigned)(C / 16), 2), dim3(256), 0, (hipStream_t)stream, t, rows, C, sc_w0, sc_b0, sc_w2, sh_w0,
+                     sh_b0, sh_w2, dA, dB, g_sc_w0, g_sc_b0, g_sc_w2, g_sc_b2, g_sh_w0, g_sh_b0, g_sh_w2, g_sh_b2, accumulate);
   TANTE_CHECK_LAUNCH();
   return 0;
 }

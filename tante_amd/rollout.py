@@ -136,8 +136,19 @@ def rollout_model(model, batch: Dict, formatter, n_steps: int, device=None):
             return formatter.process_output(y), y_ref.to(device)
         y_ref = _nan_to_num(out_ref)
         return formatter.process_output(_rollout_in_place(model, None, n_steps, raw_input=raw)), y_ref.to(device)
-    moving, y_ref = formatter.process_input(batch)
-    moving = moving[0].to(device)
+    if (not NO_FUSED_FORMAT and type(formatter) is DefaultChannelsFirstFormatter and raw.dim() == 5 and raw.dtype == torch.float32 and raw.is_cuda
+            and raw.is_contiguous() and raw.data_ptr() % 16 == 0 and not raw.requires_grad and not batch["output"].requires_grad):
+        # the default formatter's 'b t h w c -> b t c h w' + nan_to_num as ONE HIP pass, also on the training path (as torch ops: a
+        # permute, two nan_to_num kernels and the copy that makes the window contiguous)
+        from . import _lib as L
+        from . import kernels as K
+        Bq, Tq, H, W, D = raw.shape
+        moving = torch.empty(Bq, Tq, D, H, W, dtype=torch.float32, device=raw.device)
+        L.check(L.lib().tante_format_input(raw.data_ptr(), Bq * Tq, Tq, H * W, D, moving.data_ptr(), moving.stride(0), K._stream()), "tante_format_input")
+        y_ref = _nan_to_num(batch["output"])
+    else:
+        moving, y_ref = formatter.process_input(batch)
+        moving = moving[0].to(device)
     if isinstance(model, TANTE) and model.deg and not torch.is_grad_enabled() and moving.shape[1] == model.T \
             and moving.dtype == torch.float32:
         return formatter.process_output(_rollout_in_place(model, moving, n_steps)), y_ref.to(device)
@@ -153,15 +164,20 @@ def rollout_model(model, batch: Dict, formatter, n_steps: int, device=None):
             # re-encoding every window -- the reference's graph with its common subexpressions shared -- for 7 / 16 of the encoder work.
             compute = resolve_compute(model.compute)
             T = model.T
+            def frames_of(z):      # (B, k, HW, C) -> k frame tensors without unbind's zero-fill + copy + sum backward
+                if z.shape[1] == 1:
+                    return [z.view(z.shape[0], z.shape[2], z.shape[3])]
+                from .autograd import SplitFramesFn
+                return list(SplitFramesFn.apply(z))
             with fold_scope():
-                zf = list(encode_frames_train(model, moving, compute).unbind(1))
+                zf = frames_of(encode_frames_train(model, moving, compute))
                 last = moving[:, -1:].contiguous()
                 while produced < n_steps:
                     y = tante_train_forward(model, last, compute, 1, z_win=zf[-T:])      # the window's frames where they are
                     produced += y.shape[1]
                     preds.append(formatter.process_output(y))
                     if produced < n_steps:
-                        zf.extend(encode_frames_train(model, y, compute).unbind(1))
+                        zf.extend(frames_of(encode_frames_train(model, y, compute)))
                         last = y[:, -1:].contiguous()
             return torch.cat(preds, dim=1)[:, :n_steps], y_ref.to(device)
     with fold_scope():      # the re-fed calls of one rollout share one autograd graph (and one folded copy of every LayerNorm affine)

@@ -335,7 +335,7 @@ def tante_train_forward(model, inp: torch.Tensor, compute: int, out_T=1, z_win=N
     if tabs is None:
         te = model.t_encode
         sc, sh = te.condition_to_scale, te.condition_to_shift
-        if FILM_TABLE_HIP:
+        if FILM_TABLE_HIP and T <= 8 and C_ % 16 == 0:
             # one launch forward, one backward (autograd.FilmTableFn); the tables' gradients of the rollout's calls accumulate on the node
             tsec = model.t_seq.to(inp.device, torch.float32).contiguous()
             fa, fb, acc = FilmTableFn.apply(tsec, model.t_emb.view(T, C_), sc[0].weight, sc[0].bias, sc[2].weight, sc[2].bias,

@@ -484,3 +484,37 @@ def test_adaptive_rollout_batched_with_per_sample_frame_counts(dev, grad):
     assert counts.min() >= 1 and len(set(counts.tolist())) > 1, f"the fixture must give the samples different frame counts: {counts.tolist()}"
     close(y_b, y_s.detach().cpu(), "fp32", "batched adaptive rollout (per-sample counts) vs serial loop: frames")
     close(rt_b, rt_s.detach().cpu(), "fp32", "batched adaptive rollout (per-sample counts) vs serial loop: R_t, in order")
+
+
+@pytest.mark.parametrize("T,C_", [(4, 256), (8, 64), (1, 32)])
+def test_film_table_fn_gradients(dev, T, C_):
+    """autograd.FilmTableFn (the FiLM tables of a rollout and their backward as two HIP launches, tante.py:203-230) against torch autograd
+    through the same two MLPs: the tables, and every parameter's gradient from accumulated table gradients."""
+    import tante_amd
+    from tante_amd.autograd import FilmTableFn
+    torch.manual_seed(T * 10 + C_)
+    fl = tante_amd.film(C_, in_dim=1).to(dev)
+    sc, sh = fl.condition_to_scale, fl.condition_to_shift
+    t = torch.linspace(-2.0, 0.5, T, device=dev)
+    add = torch.randn(T, C_, device=dev, requires_grad=True)
+    ga, gb = torch.randn(T, C_, device=dev), torch.randn(T, C_, device=dev)
+    a_ref = 1.0 + sc(t[:, None])
+    b_ref = sh(t[:, None]) + add
+    (a_ref * ga).sum().backward(retain_graph=True)
+    (b_ref * gb).sum().backward()
+    ref = {n: p.grad.clone() for n, p in fl.named_parameters()}
+    ref_add = add.grad.clone()
+    for p in fl.parameters():
+        p.grad = None
+    add.grad = None
+    a, b, acc = FilmTableFn.apply(t, add, sc[0].weight, sc[0].bias, sc[2].weight, sc[2].bias, sh[0].weight, sh[0].bias, sh[2].weight, sh[2].bias)
+    close(a, a_ref, "fp32", "FilmTableFn: scale table")
+    close(b, b_ref, "fp32", "FilmTableFn: shift table")
+    with torch.no_grad():      # the uses' contributions, as FilmPos*Fn adds them: two halves
+        acc[0] += 0.25 * ga; acc[0] += 0.75 * ga
+        acc[1] += gb
+    (a.sum() * 0.0 + b.sum() * 0.0).backward()      # nothing arrives through autograd but zeros: the accumulators carry the gradient
+    for n, p in fl.named_parameters():
+        e = rel_err(p.grad, ref[n])
+        assert e < 1e-5, (n, e)
+    assert rel_err(add.grad, ref_add) < 1e-5
