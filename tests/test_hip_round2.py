@@ -325,7 +325,9 @@ def test_fit_two_epochs_then_resume(dev, tmp_path):
     res = H.fit(m3, o3, d3, fmt, 3, 2, 4, str(tmp_path / "resumed"), s3, log=lambda *_: None)      # finds recent.pt, runs epoch 3 only
     assert [h["epoch"] for h in res["history"]] == [3]
     for (k, a), b in zip(m3.state_dict().items(), m1.state_dict().values()):
-        assert float((a - b).abs().max()) < 1e-5 * (1 + float(b.abs().max())), k
+        # (3e-5: the gradients' atomic reductions sum in a run-dependent order, and Adam's early steps move an element by ~lr whatever the
+        # size of its gradient, so a last-bit difference in a near-zero gradient shows up at 1e-5 here and there -- 1.2e-5 measured)
+        assert float((a - b).abs().max()) < 3e-5 * (1 + float(b.abs().max())), k
     # adaptive-dt model: the R_Evaler extras
     torch.manual_seed(12)
     mr = tante_amd.TANTE(in_T=4, dset_metadata=md, taylor_order=2, attn_axes="TH-TW", n_head=2, embed_dim=32, patch_scale=8,
