@@ -521,6 +521,10 @@ int tante_colsum(const void* x, int dtype, int64_t outer, int C, int64_t inner, 
  * dv = dy * a[t], da / db (T, C) and ds (HW, C) reduced over the other indices */
 int tante_film_pos_fwd(const float* v, const float* a, const float* b, const float* s_emb, int64_t rows, int C, int T, int64_t HW,
                        float* y, void* stream);
+/* CViT's encoder (models/cvit.py:291-297): y[(b, hw), t] = v[(b, t), hw] + t_emb[t] + s_emb[hw] -- the two positional sums and the
+ * 'b t s d -> (b s) t d' regrouping in one pass.  v (B * T * HW, C) rows (b, t, hw); y (B * HW * T, C) rows (b, hw, t); C % 4 == 0. */
+int tante_pos_embed_tmajor(const float* v, const float* t_emb, const float* s_emb, int64_t B, int T, int64_t HW, int C, float* y,
+                           void* stream);
 int tante_film_pos_bwd(const float* dy, const float* v, const float* a, int64_t BT, int64_t HW, int C, int T, float* dv, float* da,
                        float* db, float* ds, void* stream);
 /* The same two with the window given as T <= 8 separate frame tensors (frame t of item b at f[t] + b * bstride[t] floats, rows (hw, c);

@@ -153,6 +153,7 @@ SIGNATURES = {
     "tante_act_bwd": ([c_vp, c_i32, c_vp, c_i32, c_vp, c_i32, c_i64, c_i32, c_vp], c_i32),
     "tante_colsum": ([c_vp, c_i32, c_i64, c_i32, c_i64, c_vp, c_i32, c_vp], c_i32),
     "tante_film_pos_fwd": ([c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i64, c_vp, c_vp], c_i32),
+    "tante_pos_embed_tmajor": ([c_vp, c_vp, c_vp, c_i64, c_i32, c_i64, c_i32, c_vp, c_vp], c_i32),
     "tante_film_pos_bwd": ([c_vp, c_vp, c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp], c_i32),
     "tante_taylor_bwd": ([c_vp, c_i64, C.POINTER(c_vp), c_i32, C.c_double, c_i32, c_vp, c_i64, c_i32, c_i64, c_i64, c_vp], c_i32),
     "tante_attention_bwd": ([c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, C.POINTER(Seq), c_i32, c_f32, C.c_uint64, c_vp], c_i32),

@@ -251,6 +251,19 @@ __global__ void film_pos_fwd_kernel(const float* __restrict__ v, const float* __
   const f32x4 vv = ((const f32x4*)v)[idx];
   ((f32x4*)y)[idx] = vv * ((const f32x4*)a)[t * C4 + c4] + ((const f32x4*)b)[t * C4 + c4] + ((const f32x4*)s)[hw * C4 + c4];
 }
+// CViT's encoder: y[(b, hw), t] = v[(b, t), hw] + t_emb[t] + s_emb[hw]: the positional sums and the 'b t s d -> (b s) t d' regrouping that the
+// time-aggregation attention reads, in one pass (one output row per thread quad group; reads stride HW rows, writes are consecutive)
+__global__ void pos_embed_tmajor_kernel(const float* __restrict__ v, const float* __restrict__ te, const float* __restrict__ se, long rows,
+                                        int C4, int T, long HW, float* __restrict__ y) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;     // output element: row (b, hw, t)
+  if (idx >= rows * C4) return;
+  const long r = idx / C4;
+  const int c4 = (int)(idx - r * C4);
+  const int t = (int)(r % T);
+  const long bh = r / T, hw = bh % HW, b = bh / HW;
+  const f32x4 vv = ((const f32x4*)v)[((b * T + t) * HW + hw) * C4 + c4];
+  ((f32x4*)y)[idx] = vv + ((const f32x4*)te)[t * C4 + c4] + ((const f32x4*)se)[hw * C4 + c4];
+}
 // the same with the window given as T separate frame tensors (frame t of item b at f[t] + b * bstride[t], rows (hw, c)): the BPTT rollout
 // keeps one encoding per frame and a window is any T of them -- stacking them first was a 25 MB copy per call
 struct FilmFrames {
@@ -1662,6 +1675,15 @@ extern "C" int tante_film_pos_fwd(const float* v, const float* a, const float* b
   const long n4 = rows * (C / 4);
   hipLaunchKernelGGL(film_pos_fwd_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, v, a, b, s_emb, (long)rows, C / 4,
                      T, (long)HW, y);
+  TANTE_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int tante_pos_embed_tmajor(const float* v, const float* t_emb, const float* s_emb, int64_t B, int T, int64_t HW, int C, float* y,
+                                      void* stream) {
+  if (!v || !t_emb || !s_emb || !y || B <= 0 || C <= 0 || C % 4 || T <= 0 || HW <= 0) TANTE_FAIL(-1, "tante_pos_embed_tmajor: bad argument");
+  const long rows = (long)B * T * HW, n4 = rows * (C / 4);
+  hipLaunchKernelGGL(pos_embed_tmajor_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, v, t_emb, s_emb, rows, C / 4, T,
+                     (long)HW, y);
   TANTE_CHECK_LAUNCH();
   return 0;
 }

@@ -196,10 +196,14 @@ class TimeAggregation(nn.Module):
         self.emb_dim, self.depth, self.num_latents = emb_dim, depth, num_latents
         self.latents = nn.Parameter(torch.randn(num_latents, emb_dim))
         self.CrossAttnBlocks = nn.ModuleList([CrossAttnBlock(num_heads, emb_dim, mlp_ratio, layer_norm_eps) for _ in range(depth)])
+        self._rep = _PackCache()
 
     def run(self, x_bs_t: torch.Tensor, nbs: int, T: int, compute: int) -> torch.Tensor:
         """x ((b s) t, d) fp32 -> latents ((b s) t', d)."""
-        lat = self.latents.detach().unsqueeze(0).expand(nbs, -1, -1).reshape(nbs * self.num_latents, self.emb_dim).contiguous()
+        # the latents repeated per (b, s) token: input independent, so built once per weight version (the fused block tail reads its
+        # residual rows one per query row)
+        lat = self._rep.get(nbs, [self.latents], lambda: self.latents.detach().unsqueeze(0).expand(nbs, -1, -1)
+                            .reshape(nbs * self.num_latents, self.emb_dim).contiguous())
         for blk in self.CrossAttnBlocks:
             lat = blk.run(lat, x_bs_t, nbs, self.num_latents, T, compute)
         return lat
@@ -218,14 +222,15 @@ class PatchEmbed(nn.Module):
             self.layer_norm = nn.LayerNorm(emb_dim, eps=layer_norm_eps)
         self._cache = _PackCache()
 
-    def run(self, x: torch.Tensor, compute: int) -> torch.Tensor:
-        """x (b, t, c, h, w) fp32 contiguous -> (b * t * s, emb) fp32, s = (h / ph)(w / pw) row-major."""
+    def run(self, x: torch.Tensor, compute: int, nhwc: bool = False) -> torch.Tensor:
+        """x (b, t, c, h, w) fp32 contiguous -- or, with nhwc, the channels-first VIEW of a contiguous (b, t, h, w, c) tensor, which is what
+        the formatter hands over -> (b * t * s, emb) fp32, s = (h / ph)(w / pw) row-major."""
         b, t, c, h, w = x.shape
         _, ph, pw = self.patch_size
         chunks = self._cache.get(compute, [self.conv.weight, self.conv.bias],
                                  lambda: S.pack_linear_chunks(self.conv.weight.detach().reshape(self.conv.weight.shape[0], -1),
                                                               self.conv.bias, compute))
-        cols = K.im2col(x.view(b * t, c, h, w), True, b * t, c, h, w, ph, pw, ph, pw, 0, 0, 0, K.act_torch_dtype(compute))
+        cols = K.im2col(x.permute(0, 1, 3, 4, 2) if nhwc else x, not nhwc, b * t, c, h, w, ph, pw, ph, pw, 0, 0, 0, K.act_torch_dtype(compute))
         y = S.linear_chunks(cols, chunks, torch.float32)
         if self.use_norm:
             y = K.layernorm_affine(y, self.layer_norm.weight, self.layer_norm.bias, self.layer_norm.eps)
@@ -248,19 +253,17 @@ class Encoder(nn.Module):
         self.s_emb = nn.Parameter(s_emb_init(emb_dim, (h // patch_size[1], w // patch_size[2]), flatten=True))   # (1, S, D)
         self.SelfAttnBlocks = nn.ModuleList([SelfAttnBlock(num_heads, emb_dim, mlp_ratio, layer_norm_eps) for _ in range(depth)])
 
-    def run(self, x: torch.Tensor, compute: int):
-        """x (b, t, c, h, w) -> tokens (b * t' * s, d) fp32, (t' * s)."""
+    def run(self, x: torch.Tensor, compute: int, nhwc: bool = False):
+        """x (b, t, c, h, w) -> tokens (b * t' * s, d) fp32, (t' * s).  nhwc: see PatchEmbed.run."""
         b, t = x.shape[:2]
         d = self.emb_dim
-        y = self.patch_embed.run(x, compute)                       # rows (b, t, s)
+        y = self.patch_embed.run(x, compute, nhwc)                 # rows (b, t, s)
         s = y.shape[0] // (b * t)
-        # + t_emb[t] + s_emb[s]: the FiLM/positional kernel with scale 1 (a = 1, b = t_emb)
-        ones = torch.ones(t, d, dtype=torch.float32, device=y.device)
-        z = torch.empty_like(y)
-        L.check(L.lib().tante_film_pos_fwd(y.data_ptr(), ones.data_ptr(), self.t_emb.detach().view(t, d).contiguous().data_ptr(),
-                                           self.s_emb.detach().view(s, d).contiguous().data_ptr(), y.shape[0], d, t, s, z.data_ptr(),
-                                           K._stream()), "tante_film_pos_fwd")
-        kv = z.view(b, t, s, d).permute(0, 2, 1, 3).contiguous().view(b * s * t, d)     # 'b t s d -> (b s) t d' (layout change)
+        # + t_emb[t] + s_emb[s] and 'b t s d -> (b s) t d' (the layout the time aggregation attends over) in one pass
+        kv = torch.empty_like(y)
+        L.check(L.lib().tante_pos_embed_tmajor(y.data_ptr(), self.t_emb.detach().view(t, d).contiguous().data_ptr(),
+                                               self.s_emb.detach().view(s, d).contiguous().data_ptr(), b, t, s, d, kv.data_ptr(), K._stream()),
+                "tante_pos_embed_tmajor")
         lat = self.time_agg.run(kv, b * s, t, compute)                                   # ((b s) t', d), t' = 1
         tl = self.time_agg.num_latents
         if tl != 1:
@@ -384,7 +387,11 @@ class CViT(nn.Module):
         compute = resolve_compute(self.compute)
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             return cvit_train_forward(self, x.detach().to(torch.float32).contiguous(), input_coords, compute)
-        x = x.detach().to(torch.float32).contiguous()
+        x = x.detach()
+        # the formatter's 'b t h w c -> b t c h w' view of a channels-last batch is read in place by the patch gather (no copy)
+        nhwc = x.dtype == torch.float32 and x.dim() == 5 and not x.is_contiguous() and x.permute(0, 1, 3, 4, 2).is_contiguous()
+        if not nhwc:
+            x = x.to(torch.float32).contiguous()
         b, t, c, h, w = x.shape
         if input_coords is None:
             params = [p for p in self.parameters()]
@@ -394,7 +401,7 @@ class CViT(nn.Module):
         n = q1.shape[0]
         d = self.dec_emb_dim
         q = q1                                                     # 'n d -> b n d' is never materialised: the blocks take the shared rows
-        y, s = self.Encoder.run(x, compute)                                                    # (b * s, emb)
+        y, s = self.Encoder.run(x, compute, nhwc)                                              # (b * s, emb)
         e2d = self._cache.get((compute, "e2d"), [self.norm1.weight, self.norm1.bias, self.E2D.weight, self.E2D.bias],
                               lambda: K.pack_weight(self.E2D.weight, self.E2D.bias, compute, gamma=self.norm1.weight, beta=self.norm1.bias))
         kv = torch.empty(b * s, d, dtype=torch.float32, device=x.device)

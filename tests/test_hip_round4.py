@@ -157,6 +157,10 @@ def test_cfg4_shipped_model_query_subset_against_oracle(dev):
             y = m.set_compute(mode)(x.to(dev), coords.to(dev))
             assert y.shape == ref.shape
             close(y, ref, mode, f"cfg4 as shipped, 2 048 query points, {mode}")
+            # the formatter's channels-first VIEW of a channels-last batch is gathered in place (no input copy): the same bits
+            x_cl = x.permute(0, 1, 3, 4, 2).contiguous().to(dev).permute(0, 1, 4, 2, 3)
+            assert not x_cl.is_contiguous()
+            assert torch.equal(m(x_cl, coords.to(dev)), y), f"cfg4 {mode}: channels-last view input differs from the contiguous input"
 
 
 def test_cfg5_one_sample_full_size_against_oracle(dev):
