@@ -8,10 +8,12 @@
 //
 // Work split as in head_fused.hip: a workgroup owns 16 NWV tokens and ONE stage-1 pixel p (a 4 x 4 pixel quadrant of every token's
 // block).  Head stages chain through MFMA accumulators; the encoder runs the other way through the same quadrant: stage 1 on the four
-// 2 x 2 sub-blocks q, stage 2 on the quadrant (tap q), and stage 3 needs all four quadrants -- each workgroup contracts its own tap p
-// (a 128-deep slice of K = 512), writes the fp32 partial through to memory, and the LAST of a group's four workgroups to arrive (one
-// agent-scope counter per group, no spinning) adds the four partials in the fixed order p = 0..3 onto the bias: deterministic whatever
-// the arrival order.
+// 2 x 2 sub-blocks q, stage 2 on the quadrant (tap q), and stage 3 needs all four quadrants -- each workgroup writes its stage-2 output
+// (bf16 operand fragments, 32 KiB) through to memory, and the LAST of a group's four workgroups to arrive (one agent-scope counter per
+// group, no spinning) reads the four back and runs stage 3 over the whole K = 512 as ONE accumulation chain in the fixed tap order
+// 0..3: deterministic whatever the arrival order.  (The first form exchanged fp32 stage-3 partials, 128 KiB per workgroup: 67 MB written
+// and read back by the whole chip at the same moment, 13 us of the launch; the operand fragments are a quarter of that and three of
+// four workgroups skip stage 3.)
 //
 // Pipeline (the round-3 kernel waited three times for 142 KiB of weights and for its token rows, and its compiler-scheduled LDS reads
 // waited lgkmcnt(0) -- a full LDS round trip per MFMA -- whenever an LDS-DMA was in flight): every GEMM stage reads its weight
@@ -19,7 +21,7 @@
 // k + 1 is requested while order k computes:  W1[k+1] and the token rows right after order k's stage 1 (the W1 tile is free then; the
 // rows wait in registers), W3[k+1] after its stage 3; only W2[k+1] (it shares its LDS region with the row staging) arrives under
 // stage 1 of its own order.  The encoder's weights ride the same slots: W1e is resident, W2e lands on W1 during the last order's
-// stages 2 + 3, the W3e slice on W2 during encoder stages 1 + 2.
+// stages 2 + 3, tap 0 of W3e on W2 during encoder stages 1 + 2; the reducing workgroup streams taps 1..3 through the two regions in turn.
 #include "fused_common.hip.h"
 #include <stdlib.h>
 
@@ -47,10 +49,9 @@ struct HeArgs {
   const float* last; long last_bstride;
   const char* we;                          // encoder stream (tante_pack_head_enc)
   float* z;                                // (rows, 256) fp32: the new frame's encoding before FiLM
-  float* part;                             // (groups, 4, 16 NWV, 256) fp32 partials
-  int* cnt;                                // (groups, 4) {arrivals, starts, XCD mask, -}: zero between launches
+  void* part;                              // (groups, 4 pixels, 4 TT fragments, threads) 16-byte words: stage 2's output as stage 3 reads it
+  int* cnt;                                // (groups, 4) {arrivals, -, -, -}: zero between launches
   int groups;
-  int same_xcd_ok;                         // 0: always write the partials through (A/B: TANTE_HEAD_L2_HANDOFF=0)
   unsigned long long* stamps;              // -DTANTE_ABLATE builds only (tools/head_enc_stamps.py), else null
 };
 
@@ -77,12 +78,12 @@ __device__ __forceinline__ void he_glds(const char* __restrict__ g, char* l, int
 __device__ __forceinline__ f32x4 he_gelu(const f32x4& v) { return gelu_poly4<false>(v); }
 // agent-scope (sc1) 16-byte accesses to the hand-off buffer: the load misses this CU's L1, the store is written through (and waits the
 // two states a VALU write to the data registers of a >64-bit store needs behind it: common.hip.h, st_wt16)
-__device__ __forceinline__ f32x4 he_ld_agent(const float* p) {
-  f32x4 r;
+__device__ __forceinline__ u32x4 he_ld_agent(const u32x4* p) {
+  u32x4 r;
   asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(r) : "v"(p) : "memory");
   return r;
 }
-__device__ __forceinline__ void he_st_agent(float* p, const f32x4& v) {
+__device__ __forceinline__ void he_st_agent(u32x4* p, const u32x4& v) {
   asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 }
 
@@ -112,17 +113,6 @@ __global__ __launch_bounds__(NWV * 64, 1) void head_enc_kernel(const HeArgs A) {
   const int grp = (blockIdx.x >> 5) * 8 + (blockIdx.x & 7);      // the four pixels of a group share blockIdx & 7 (one XCD)
   if (grp >= A.groups) return;
   HE_STAMP(0);
-  if constexpr (ENC) {
-    // Early handshake of the group's four workgroups: which XCD each runs on, and that it has started.  When the partials are stored
-    // (tens of microseconds later) a workgroup that finds all four on ITS XCD keeps them in that XCD's L2 (plain stores; the reducing
-    // workgroup is one of the four, its L1-bypassing loads are served by the same L2); otherwise it writes them through to memory.
-    if (tid == 0) {
-      const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u;      // HW_REG_XCC_ID[3:0]
-      const unsigned m = __hip_atomic_fetch_or((unsigned*)A.cnt + 4 * grp + 2, 1u << xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      asm volatile("" ::"v"(m));       // the mask bit is set before the start count moves
-      (void)__hip_atomic_fetch_add(A.cnt + 4 * grp + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
 
   // ---- rows: the wave's TT tiles of 16 consecutive tokens.  Hp Wp and a_n0 are multiples of 16 (checked by the launcher), so a tile never
   // straddles an image or an addressing block: one base offset + j a_s0, and a tile is live or dead as a whole (wave-uniform) ---------
@@ -340,7 +330,7 @@ __global__ __launch_bounds__(NWV * 64, 1) void head_enc_kernel(const HeArgs A) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();      // (C')
     HE_STAMP(26);
-    he_glds<NWV>(A.we + HE_E1 + HE_E2 + (long)p * HE_E3, w2s, HE_E3, tid);      // this pixel's tap slice of W3e: lands under the frame stores and stages 1 + 2
+    he_glds<NWV>(A.we + HE_E1 + HE_E2, w2s, HE_E3, tid);      // tap 0 of W3e for whichever workgroup reduces: lands under the frame stores and stages 1 + 2
   }
   // ---- the frame: out = last + sum_k c_k d_k, in the pair layout of the stores (rows y0, y0 + 1 x 4 pixels) --------------------------
   f32x4 fv[TT][4][NDT];              // [q][ns][r]: pixel r = (kh3, kw3) of sub-pixel q, channel 4 ns + kk
@@ -436,103 +426,84 @@ __global__ __launch_bounds__(NWV * 64, 1) void head_enc_kernel(const HeArgs A) {
       });
     }
     HE_STAMP(29);
-    int* flag = (int*)w3s;               // W3 is dead: [0] the arrival ticket, [1] "all four workgroups of the group share this XCD"
-    if (tid == 0) {
-      const int started = __hip_atomic_load(A.cnt + 4 * grp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const unsigned m = __hip_atomic_load((unsigned*)A.cnt + 4 * grp + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      ((volatile int*)flag)[1] = (started == 4 && (m & (m - 1)) == 0 && A.same_xcd_ok) ? 1 : 0;
-    }
+    // ---- hand-off: this pixel's stage-2 output, fragment-wise (every store and every load is 1 KiB contiguous per wave), written
+    // through to memory with agent scope (sc1) as MI355X_MICROARCH.md's hand-off table asks of both sides -----------------------------
+    u32x4* hslot = (u32x4*)A.part + (long)grp * 4 * (4 * TT * NWV * 64) + tid;
+    constexpr long HSTRIDE = 4L * TT * NWV * 64;           // 16-byte words between the slots of consecutive pixels
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) he_st_agent(hslot + p * HSTRIDE + (tt * 4 + b) * (NWV * 64), h2e[tt][b]);
+    // ---- arrival: the fragments are in memory (write-through stores, acknowledged) before the counter moves; the barrier also says every
+    // wave is done with W2e on the W1 tile --------------------------------------------------------------------------------------------
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();      // (D) the W3e slice is complete
     HE_STAMP(30);
-    const bool same_xcd = ((volatile int*)flag)[1] != 0;
-#ifdef TANTE_ABLATE
-    if (A.stamps && lane == 0) {
-      A.stamps[((long)blockIdx.x * 8 + wave) * 40 + 35] = same_xcd ? 1 : 2;
-      A.stamps[((long)blockIdx.x * 8 + wave) * 40 + 36] = 100 + (__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u);
-      A.stamps[((long)blockIdx.x * 8 + wave) * 40 + 37] = 1000 + __hip_atomic_load(A.cnt + 4 * grp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      A.stamps[((long)blockIdx.x * 8 + wave) * 40 + 38] = 10000 + __hip_atomic_load(A.cnt + 4 * grp + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    int* flag = (int*)w3s;               // W3 is dead: the arrival ticket
+    if (tid == 0) *(volatile int*)flag = __hip_atomic_fetch_add(A.cnt + 4 * grp, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    HE_STAMP(31);
+    if (*(volatile int*)flag != 3) return;
+    // ---- the last of the group's four workgroups: encoder stage 3 over K = 512, taps in the order 0..3 whatever the arrival order was.
+    // Tap 0 has been on the W2 region since (C'); the taps alternate between the two big regions, each requested as soon as every wave
+    // is done with the slice before it.
+    if (tid == 0) A.cnt[4 * grp] = 0;    // ready for the next launch
+    constexpr int TAPI = HE_E3 / (NWV * 1024);       // LDS-DMA instructions per wave and tap slice
+    u32x4 hs[4][TT][4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int tt = 0; tt < TT; ++tt)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) hs[t][tt][b] = he_ld_agent(hslot + t * HSTRIDE + (tt * 4 + b) * (NWV * 64));
+    he_glds<NWV>(A.we + HE_E1 + HE_E2 + 1L * HE_E3, w1s, HE_E3, tid);
+    unsigned a3e[2][4];                  // tap slices: 256 B rows on the W2 region (even taps) / the W1 tile (odd taps)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      a3e[0][b] = a2[b];
+      a3e[1][b] = lds_addr(w1s + l15 * 256 + (swz_chunk(l15, b * 4 + kk, 16) << 4));
     }
-#endif
-    // ---- encoder stage 3, tap p: a 128-deep slice of the K = 512 contraction -> fp32 partial.  Partials are stored fragment-wise --
-    // tile (group, p, wave, tt), feature tile ns, then lane: every store and every load of the reduction is 1 KiB contiguous per wave
-    // -- with agent scope (sc1: written through to memory), as MI355X_MICROARCH.md's hand-off table asks of both sides.
-    float* ptile = A.part + (((long)grp * 4 + p) * NWV + wave) * (TT * 16 * 256) + lane * 4;
+    f32x4 acc3[TT][16];
     {
+      const float* bias3e = (const float*)(A.we + HE_E1 + HE_E2 + 4L * HE_E3);
+#pragma unroll
+      for (int ns = 0; ns < 16; ++ns) {
+        const f32x4 b = *(const f32x4*)(bias3e + ns * 16 + kk * 4);
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt) acc3[tt][ns] = b;
+      }
+    }
+    static_for<4>([&](auto tc) {
+      constexpr int t = decltype(tc)::value;
+      // tap t's pieces of this wave (and the fragments) have landed -- tap t + 1 may still be in flight behind them
+      if constexpr (t == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TAPI) : "memory");
+      else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                 // tap t is complete, and every wave is done with tap t - 1's region
+        if constexpr (t + 1 < 4) he_glds<NWV>(A.we + HE_E1 + HE_E2 + (long)(t + 1) * HE_E3, (t + 1) % 2 ? w1s : w2s, HE_E3, tid);
+      }
+#pragma unroll
+      for (int tt = 0; tt < TT; ++tt)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) he_pin(hs[t][tt][b]);          // (asm-volatile loads: the optimiser must see them defined here)
       static_for<2>([&](auto hc) {
         constexpr int hh = decltype(hc)::value;
-        f32x4 acc[TT][8];
-#pragma unroll
-        for (int tt = 0; tt < TT; ++tt)
-#pragma unroll
-          for (int ns = 0; ns < 8; ++ns) acc[tt][ns] = f32x4{0.f, 0.f, 0.f, 0.f};
-        mfma_stream<32, RD>([&](auto ic) { constexpr int i = decltype(ic)::value; return LdsAddr<(8 * hh + i % 8) * 4096>{a2[i / 8]}; },
+        mfma_stream<32, RD>([&](auto ic) { constexpr int i = decltype(ic)::value; return LdsAddr<(8 * hh + i % 8) * 4096>{a3e[t % 2][i / 8]}; },
                            [&](auto ic, const u32x4& wf) {
                              constexpr int i = decltype(ic)::value;
 #pragma unroll
-                             for (int tt = 0; tt < TT; ++tt) acc[tt][i % 8] = mfma_bf16(wf, h2e[tt][i / 8], acc[tt][i % 8]);
+                             for (int tt = 0; tt < TT; ++tt) acc3[tt][8 * hh + i % 8] = mfma_bf16(wf, hs[t][tt][i / 8], acc3[tt][8 * hh + i % 8]);
                            });
-#pragma unroll
-        for (int tt = 0; tt < TT; ++tt)
-          if (live[tt]) {
-#pragma unroll
-            for (int ns = 0; ns < 8; ++ns) {
-              float* dst = ptile + (tt * 16 + 8 * hh + ns) * 256;
-              if (same_xcd) *(f32x4*)dst = acc[tt][ns];
-              else he_st_agent(dst, acc[tt][ns]);
-            }
-          }
       });
-    }
-    HE_STAMP(31);
-    // ---- arrival: the partials are in memory (write-through stores, acknowledged) before the counter moves ---------------------------
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    HE_STAMP(32);
-    __syncthreads();
-    if (tid == 0) *(volatile int*)flag = __hip_atomic_fetch_add(A.cnt + 4 * grp, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
+    });
     HE_STAMP(33);
-    if (*(volatile int*)flag != 3) return;
-    // the last of the group's four workgroups: z = ((((bias + P0) + P1) + P2) + P3), whatever the arrival order was
-    if (tid == 0) { A.cnt[4 * grp] = 0; A.cnt[4 * grp + 1] = 0; A.cnt[4 * grp + 2] = 0; }      // ready for the next launch
-    {
-      const float* bias3e = (const float*)(A.we + HE_E1 + HE_E2 + 4L * HE_E3);
-      const float* p0 = A.part + (((long)grp * 4) * NWV + wave) * (TT * 16 * 256) + lane * 4;
-      constexpr long PSTRIDE = (long)NWV * TT * 16 * 256;           // floats between the partials of consecutive pixels
-      // TR feature tiles of every token tile per round, 4 TR TT loads of 1 KiB in flight per wave: the reducing workgroup pulls the group's
-      // 512 KiB alone (everything else on the chip has finished or is finishing), so the rounds are latency chains -- as few as the
-      // registers allow (stamps: four rounds of 16 loads took 28 k cycles, 7 k each)
-      constexpr int TR = TT == 1 ? 8 : 4;
 #pragma unroll
-      for (int h = 0; h < 16 / TR; ++h) {
-        f32x4 v[TT][TR][4];
+    for (int tt = 0; tt < TT; ++tt)
+      if (live[tt]) {
+        float* zrow = A.z + (long)(row0 + 16u * tt + (unsigned)l15) * 256 + kk * 4;
 #pragma unroll
-        for (int tt = 0; tt < TT; ++tt)
-#pragma unroll
-          for (int t = 0; t < TR; ++t)
-#pragma unroll
-            for (int pp = 0; pp < 4; ++pp) v[tt][t][pp] = he_ld_agent(p0 + pp * PSTRIDE + (tt * 16 + TR * h + t) * 256);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int tt = 0; tt < TT; ++tt)
-#pragma unroll
-          for (int t = 0; t < TR; t += 4)
-            asm volatile(""
-                         : "+v"(v[tt][t][0]), "+v"(v[tt][t][1]), "+v"(v[tt][t][2]), "+v"(v[tt][t][3]), "+v"(v[tt][t + 1][0]), "+v"(v[tt][t + 1][1]),
-                           "+v"(v[tt][t + 1][2]), "+v"(v[tt][t + 1][3]), "+v"(v[tt][t + 2][0]), "+v"(v[tt][t + 2][1]), "+v"(v[tt][t + 2][2]),
-                           "+v"(v[tt][t + 2][3]), "+v"(v[tt][t + 3][0]), "+v"(v[tt][t + 3][1]), "+v"(v[tt][t + 3][2]), "+v"(v[tt][t + 3][3]));
-#pragma unroll
-        for (int tt = 0; tt < TT; ++tt)
-          if (live[tt]) {
-            float* zrow = A.z + (long)(row0 + 16u * tt + (unsigned)l15) * 256 + kk * 4;
-#pragma unroll
-            for (int t = 0; t < TR; ++t) {
-              const f32x4 b = *(const f32x4*)(bias3e + (TR * h + t) * 16 + kk * 4);
-              *(f32x4*)(zrow + (TR * h + t) * 16) = (((b + v[tt][t][0]) + v[tt][t][1]) + v[tt][t][2]) + v[tt][t][3];
-            }
-          }
+        for (int ns = 0; ns < 16; ++ns) *(f32x4*)(zrow + ns * 16) = acc3[tt][ns];
       }
-    }
     HE_STAMP(34);
   }
 }
@@ -634,11 +605,13 @@ extern "C" int tante_head_enc_supported(int C, int D) { return C == 256 && D >= 
 
 extern "C" int64_t tante_head_enc_stream_bytes(int C) { return C == 256 ? HE_ENC_BYTES : 0; }
 
-/* workspace of tante_head_enc_fused for `rows` tokens: fp32 partials (4 per token row), then one arrival counter per token group */
+/* workspace of tante_head_enc_fused for `rows` tokens: the four pixels' stage-2 fragments of every token group (128 bf16 per token and
+ * pixel), then one arrival counter per token group */
+static long he_frag_bytes(long groups, long gt) { return groups * 4 * gt * 128 * 2; }
 extern "C" int64_t tante_head_enc_ws_bytes(int64_t rows) {
   if (rows <= 0) return 0;
   const long gt = he_group_tokens(rows), groups = (rows + gt - 1) / gt;
-  return groups * 4 * gt * 256 * 4 + ((groups * 16 + 255) / 256) * 256;
+  return he_frag_bytes(groups, gt) + ((groups * 16 + 255) / 256) * 256;
 }
 
 extern "C" int tante_pack_head_enc(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3, const float* b3, int C, int D,
@@ -686,9 +659,8 @@ extern "C" int tante_head_enc_fused(int n_ord, const float* const* rows, const v
   const int gt = he_group_tokens(n_rows);
   A.groups = (int)((n_rows + gt - 1) / gt);
   A.we = (const char*)enc_stream; A.z = z;
-  A.part = (float*)ws;
-  A.same_xcd_ok = tante_opt("TANTE_HEAD_L2_HANDOFF", 1);
-  A.cnt = enc ? (int*)((char*)ws + (long)A.groups * 4 * gt * 256 * 4) : nullptr;
+  A.part = ws;
+  A.cnt = enc ? (int*)((char*)ws + he_frag_bytes(A.groups, gt)) : nullptr;
 #ifdef TANTE_ABLATE
   A.stamps = g_he_stamps;
 #else

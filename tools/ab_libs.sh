@@ -8,7 +8,7 @@ for i in 1 2 3; do
   for v in "$@"; do
     if [ "$v" == "product" ]; then lib=$R/tante_amd/lib/libtante_hip.so; else lib=$R/tools/_ab/lib_$v.so; fi
     [ -f "$lib" ] || { echo "missing $lib" >&2; exit 1; }
-    TANTE_LIB=$lib timeout -k 10 200 python $R/bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-train 2>/dev/null | python3 -c "
+    TANTE_LIB=$lib timeout -k 10 200 python $R/bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-train --no-workloads 2>/dev/null | python3 -c "
 import sys,json
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$v', 'frames/s', d['value'], 'ms', d['ms_per_step'], 'block us', d['roofline']['avg_launch_us'], 'frac', d['roofline']['frac'])"
   done

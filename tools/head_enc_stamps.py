@@ -21,9 +21,8 @@ for o in range(3):
     b = 2 + 6 * o
     NAMES.update({b: f"o{o} staging + barrier A", b + 1: f"o{o} stage 1", b + 2: f"o{o} pack rows + vmcnt(0)", b + 3: f"o{o} barrier B",
                   b + 4: f"o{o} stages 2+3", b + 5: f"o{o} barrier C"})
-NAMES.update({26: "vmcnt + barrier C'", 27: "frame sum + stores", 28: "enc stage 1", 29: "enc stage 2", 30: "vmcnt + barrier D", 31: "enc stage 3 + partial stores",
-              32: "vmcnt(0) (partials acknowledged)", 33: "barrier + counter", 34: "last arriver: reduce"})
-
+NAMES.update({26: "vmcnt + barrier C'", 27: "frame sum + stores", 28: "enc stage 1", 29: "enc stage 2", 30: "fragment stores + vmcnt(0) (acknowledged)",
+              31: "barrier + counter", 33: "last arriver: fragments back + stage 3 over K = 512 (taps 1..3 streamed)", 34: "last arriver: z stores"})
 
 def main():
     dev = torch.device("cuda:0")
@@ -79,11 +78,6 @@ def main():
         d = (col - raw[:, pk])[both]
         print(f"  [{k:2d}] {NAMES[k]:45s} {d.mean():8.1f} ticks  (min {d.min():6d} max {d.max():6d})   reached at {(col[ok] - t0).mean():8.1f} (max {(col[ok] - t0).max()}) by {ok.sum()} waves")
         prev = k
-    for k, nm in ((35, "same_xcd flag (1 yes, 2 no)"), (36, "100 + xcc id"), (37, "1000 + started"), (38, "10000 + mask")):
-        vals, cnts = np.unique(raw[:, k], return_counts=True)
-        print(f"  [{k}] {nm}: " + ", ".join(f"{v}x{c}" for v, c in zip(vals, cnts)))
-    blk = stamps.cpu().numpy().reshape(nwg, 8, 40)[:64, 0, 36]
-    print("  xcc id of blocks 0..63:", " ".join(str(int(v) - 100) for v in blk))
 
 
 if __name__ == "__main__":

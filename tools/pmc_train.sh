@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/pmc_train
 rm -rf $OUT; mkdir -p $OUT
 for c in FETCH_SIZE WRITE_SIZE; do
-  TANTE_TRAIN_GRAPH=0 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/$c -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --train-steps 2 --no-train-strong > /dev/null 2> $OUT/$c.err
+  TANTE_TRAIN_GRAPH=0 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/$c -- python3 $R/bench.py --no-workloads --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --train-steps 2 --no-train-strong > /dev/null 2> $OUT/$c.err
 done
 python3 - $OUT <<'PY'
 import csv, glob, sys, collections, re

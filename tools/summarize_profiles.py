@@ -1,4 +1,4 @@
-"""Condense the rocprofv3 outputs of tools/collect_profiles.sh (gpurun_out/r03/) into the small files committed under profiles/."""
+"""Condense the rocprofv3 outputs of tools/collect_profiles.sh (gpurun_out/r04/) into the small files committed under profiles/."""
 import collections
 import csv
 import glob
@@ -9,7 +9,7 @@ import sys
 
 out = sys.argv[1]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TAG = "r03"
+TAG = "r04"
 
 
 def stats(sub, dst, top=30):
@@ -26,7 +26,7 @@ def stats(sub, dst, top=30):
 for sub in ("rollout", "train", "trl", "cvit", "fno"):
     stats(sub, f"{TAG}_{sub}_kernel_stats.csv")
 
-SHORT = {"block_fs_kernel<2": "fused_block_kernel", "block_fs_kernel<1": "fused_block_kernel_T_letter", "fused_head_kernel": "fused_head_kernel",
+SHORT = {"block_fs_kernel<2": "fused_block_kernel", "block_fs_kernel<1": "fused_block_kernel_T_letter", "fused_head_kernel": "fused_head_kernel", "head_enc_kernel": "head_enc_kernel",
          "axis_hw_": "axis_hw_kernel", "axis_mlp_vec_kernel": "axis_mlp_vec_kernel"}
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 dur = collections.defaultdict(list)
@@ -43,7 +43,7 @@ for f in glob.glob(os.path.join(out, "pmc", "**", "*kernel_trace.csv"), recursiv
 res = {"config": "tante_am.yaml",
        "kernel_source_sha16": hashlib.sha256(open(os.path.join(ROOT, "tante_amd", "csrc", "block_sliced.hip"), "rb").read()).hexdigest()[:16],
        "kernel_sources": {n: hashlib.sha256(open(os.path.join(ROOT, "tante_amd", "csrc", n), "rb").read()).hexdigest()[:16]
-                          for n in ("block_fused.hip", "block_sliced.hip")},
+                          for n in ("block_fused.hip", "block_sliced.hip", "head_enc.hip")},
        "note": "separate rocprofv3 --pmc passes of `bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-train`; FETCH_SIZE / WRITE_SIZE "
                "in KiB, FETCH_SIZE doubled for the 16 B/lane streams (MI355X_MICROARCH.md, HBM); SQ_* wave-cycle counters count quad-cycles"}
 for k, d in agg.items():
