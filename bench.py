@@ -433,9 +433,9 @@ def rollout_leg(config, batch_arg, dtype_arg, steps, warmup, dev, rank, world, d
                                          "TFLOP/s": round(alg / (elapsed / args.steps) / 1e12, 2),
                                          "frac": round(alg / (elapsed / args.steps) / 1e12 / PEAK_TFLOPS[dtype], 4),
                                          "note": "FLOPs of the launches as executed: the grid embedding (input-independent) is cached outside the timed "
-                                                 "forward (dense-as-written it would add 1 104 GFLOP per forward), and the decoder's query projection "
-                                                 "runs once for the coordinate queries every sample shares (as written: once per sample, +34 GFLOP "
-                                                 "per extra sample)"}
+                                                 "forward (dense-as-written it would add 1 104 GFLOP per forward), and so is the decoder's LayerNorm1 + "
+                                                 "query projection of those coordinate queries (as written: once per sample, 34 GFLOP each); both "
+                                                 "are rebuilt when a weight changes"}
 
     return {"value": value, "elapsed": elapsed, "roofline": roofline, "model": model, "batch": batch, "cfg": cfg, "wl": wl, "kind": kind, "B": B,
             "n_steps": n_steps, "T_in": T_in, "res": res, "D": D, "dtype": dtype, "graph": graph_note}

@@ -778,6 +778,11 @@ void launch_variant(const TanteGemm& g, int n_tiles, int flags, hipStream_t s) {
   const int target = tante_opt("TANTE_GEMM_WGS", 512);
   // every N-split re-loads (and re-normalises) the token rows, so split only while the grid is short of WGs
   while (nsplit < n_tiles && (long)gx * nsplit < target && (n_tiles % (nsplit * 2) == 0)) nsplit *= 2;
+  // a few hundred rows (CViT's encoder at B = 1: 256 tokens, gx = 4, 24 tiles): doubling stops at 8 splits = 32 workgroups with three
+  // tiles each in a row; any divisor will do -- every output tile is one workgroup's either way
+  if ((long)gx * nsplit * 2 <= target)
+    for (int d = nsplit + 1; d <= n_tiles; ++d)
+      if (n_tiles % d == 0) { nsplit = d; if ((long)gx * d >= target) break; }
   const int per = (n_tiles + nsplit - 1) / nsplit;
   const size_t lds = 2 * (size_t)NT * CB * 4 * 16;
   auto kern = gemm_kernel<BF16, CB, TT, LN, AM, EP>;

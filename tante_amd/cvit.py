@@ -171,16 +171,20 @@ class SelfAttnBlock(_AttnBlock):
 
 
 class CrossAttnBlock(_AttnBlock):
-    def run(self, q_in: torch.Tensor, kv_in: torch.Tensor, nb: int, Lq: int, Lk: int, compute: int, model_tail=None) -> torch.Tensor:
+    def project_queries(self, q_in: torch.Tensor, compute: int) -> torch.Tensor:
+        """LN1 + the query projection of q_in (rows, C) fp32 -> (rows, C) in the activation dtype."""
+        pk = self._packed(compute)
+        q = torch.empty(q_in.shape[0], self.emb_dim, dtype=K.act_torch_dtype(compute), device=q_in.device)
+        return K.linear(q_in, pk["q_ln1"], q, M=q_in.shape[0], ln=True, ln_eps=self.eps)
+
+    def run(self, q_in: torch.Tensor, kv_in: torch.Tensor, nb: int, Lq: int, Lk: int, compute: int, model_tail=None, q_proj=None) -> torch.Tensor:
         """q_in (nb * Lq, C) -- or (Lq, C): the SAME queries for every sample, projected once -- and kv_in (nb * Lk, C) fp32
-        -> block(q_in, kv_in)   (cvit.py:158-169)."""
+        -> block(q_in, kv_in)   (cvit.py:158-169).  q_proj: project_queries(q_in) computed earlier (input-independent queries)."""
         pk = self._packed(compute)
         adt = K.act_torch_dtype(compute)
         C_, nh = self.emb_dim, self.num_heads
         shared = q_in.shape[0] == Lq and nb > 1
-        Mq = q_in.shape[0]
-        q = torch.empty(Mq, C_, dtype=adt, device=q_in.device)
-        K.linear(q_in, pk["q_ln1"], q, M=Mq, ln=True, ln_eps=self.eps)
+        q = q_proj if q_proj is not None else self.project_queries(q_in, compute)
         kv = torch.empty(nb * Lk, 2 * C_, dtype=adt, device=q_in.device)
         K.linear(kv_in, pk["kv_ln2"], kv, M=nb * Lk, ln=True, ln_eps=self.eps)
         o = torch.empty(nb * Lq, C_, dtype=adt, device=q_in.device)
@@ -409,7 +413,10 @@ class CViT(nn.Module):
         Lk = s
         for i, blk in enumerate(self.CrossAttnBlocks):   # queries stay the coordinate embedding; the output becomes the next keys/values
             last = i == len(self.CrossAttnBlocks) - 1     # the last block carries norm2 -> Mlp -> output layer (one launch where it fuses)
-            kv = blk.run(q, kv, b, n, Lk, compute, model_tail=(self.norm2, self.mlp) if last else None)
+            # the default full-grid queries are input-independent, and so is every block's LayerNorm1 + query projection of them: cached
+            # with the embedding, per weight version (34 GFLOP and ~100 us per forward at 65 536 queries)
+            qp = self._coord_cache.get((compute, h, w, "qproj", i), params, lambda: blk.project_queries(q, compute)) if input_coords is None else None
+            kv = blk.run(q, kv, b, n, Lk, compute, model_tail=(self.norm2, self.mlp) if last else None, q_proj=qp)
             Lk = n
         o = kv.view(b, n, self.out_steps, c)
         if input_coords is None:
