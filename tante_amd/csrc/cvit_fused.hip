@@ -35,7 +35,10 @@ __host__ __device__ constexpr int x_img(int ntt) { return 16 * ntt * XROW; }
 __host__ __device__ constexpr int x_lds(int ntt) { return 2 * x_img(ntt) + 8 * 16 * ntt * 2 * 4 + (ntt < 4 ? 8 * ntt * 1024 : 0); }
 // weight ring, k-steps ahead: 2 where a k-step is 16 MFMAs per wave (64 tokens); 6 for the 16-token form, whose k-step is 4 MFMAs = 64
 // clocks against an L2 round trip of many hundred (its 129 registers leave the room)
-__host__ __device__ constexpr int x_pf(int ntt) { return ntt >= 4 ? 2 : 6; }
+#ifndef X_PF_SMALL
+#define X_PF_SMALL 6
+#endif
+__host__ __device__ constexpr int x_pf(int ntt) { return ntt >= 4 ? 2 : X_PF_SMALL; }
 constexpr int XMAT = XC * XC * 2;    // one packed matrix: 512 KiB
 
 struct ChainArgs {
