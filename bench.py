@@ -51,6 +51,7 @@ def parse():
     p.add_argument("--no-train", action="store_true", help="skip the train-step leg (configs/tante_trl.yaml)")
     p.add_argument("--train-steps", type=int, default=12)
     p.add_argument("--no-train-strong", action="store_true", help="skip the strong-scaling train line (global batch 64)")
+    p.add_argument("--graph", action="store_true", help="replay each rollout as one captured HIP graph (small batches are launch-bound on the host)")
     p.add_argument("--no-workloads", action="store_true", help="skip the compact cfg2 B=1 / cfg4 / cfg5 legs (the `workloads` object)")
     return p.parse_args()
 
@@ -276,22 +277,28 @@ def rollout_leg(config, batch_arg, dtype_arg, steps, warmup, dev, rank, world, d
     graph_note = "off"
     if graph:
         eager_step = step
-        side = torch.cuda.Stream(device=dev)
-        side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):
-            for _ in range(2):
-                eager_step()                      # packs, tables, workspaces and allocator pools exist before the capture
-        torch.cuda.current_stream(dev).wait_stream(side)
-        torch.cuda.synchronize(dev)
         try:
-            g_ = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g_):
-                g_out = eager_step()
-            graph_note = "on"
+            if kind in ("tante", "tante_fno"):       # the product's own captured rollout (tante_amd.GraphedRollout)
+                roll = tante_amd.GraphedRollout(model, batch, fmt, n_steps, device=dev)
 
-            def step():
-                g_.replay()
-                return g_out
+                def step():
+                    return roll(batch)[0]
+            else:
+                side = torch.cuda.Stream(device=dev)
+                side.wait_stream(torch.cuda.current_stream(dev))
+                with torch.cuda.stream(side):
+                    for _ in range(2):
+                        eager_step()                      # packs, tables, workspaces and allocator pools exist before the capture
+                torch.cuda.current_stream(dev).wait_stream(side)
+                torch.cuda.synchronize(dev)
+                g_ = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g_):
+                    g_out = eager_step()
+
+                def step():
+                    g_.replay()
+                    return g_out
+            graph_note = "on"
         except Exception as e:      # noqa: BLE001
             graph_note = f"capture failed ({type(e).__name__}: {e}): eager"
             step = eager_step
@@ -472,7 +479,7 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    leg = rollout_leg(args.config, args.batch, args.dtype, args.steps, args.warmup, dev, rank, world, dist, not args.no_roofline)
+    leg = rollout_leg(args.config, args.batch, args.dtype, args.steps, args.warmup, dev, rank, world, dist, not args.no_roofline, graph=args.graph)
     import tante_amd
     from tante_amd import kernels as K
     value, elapsed, roofline, model, batch, cfg, wl, kind = (leg[k] for k in ("value", "elapsed", "roofline", "model", "batch", "cfg", "wl", "kind"))
@@ -634,6 +641,11 @@ def main():
                     workloads[tag]["cpu_baseline"] = cvit_cpu_leg(lg, workloads[tag]["value"])
                 del lg
                 torch.cuda.empty_cache()
+                if tag == "cfg4_b1":      # 47 launches of 10-30 us each: near the host's issue rate on a busy box; as one captured graph
+                    lg = rollout_leg(os.path.join(ROOT, "configs", cfile), bb, None, st, 3, dev, rank, world, dist, False, graph=True)
+                    workloads["cfg4_b1_graph"] = compact(lg, st)
+                    del lg
+                    torch.cuda.empty_cache()
         except Exception as e:      # noqa: BLE001 -- a side leg must never cost the headline line
             workloads["error"] = f"{type(e).__name__}: {e}"
 

@@ -10,7 +10,7 @@ from .spectral import SpectralLayer, enc_FNO, dec_FNO  # noqa: F401
 from .cvit import CViT  # noqa: F401
 from .fno import FNO  # noqa: F401
 from .rollout import (DefaultChannelsFirstFormatter, DefaultChannelsLastFormatter, rollout_model,  # noqa: F401
-                      rollout_adaptive)
+                      rollout_adaptive, GraphedRollout)
 from .config import instantiate, load_config, build_model  # noqa: F401
 from . import metrics, optim, dist  # noqa: F401
 from .metrics import MSE, NMSE, RMSE, NRMSE, VMSE, VRMSE, L2RE, NNMSE  # noqa: F401
@@ -22,4 +22,4 @@ from .harness import LinearWarmupCosineAnnealingLR, SyntheticDataModule, save_ch
 
 __all__ = ["TANTE", "TanteMetadata", "enc_CNN", "dec_CNN", "film", "interprator", "t_series", "Attn_Backbone",
            "TransformerBlock", "DefaultChannelsFirstFormatter", "DefaultChannelsLastFormatter", "rollout_model",
-           "rollout_adaptive", "instantiate", "load_config", "build_model", "CViT", "FNO", "SpectralLayer", "enc_FNO", "dec_FNO", "set_option", "get_option"]
+           "rollout_adaptive", "GraphedRollout", "instantiate", "load_config", "build_model", "CViT", "FNO", "SpectralLayer", "enc_FNO", "dec_FNO", "set_option", "get_option"]

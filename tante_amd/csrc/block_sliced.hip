@@ -181,7 +181,12 @@ __global__ __launch_bounds__(64 * NW * G, 2) void block_fs_kernel(FsArgs A) {
   float* const lbias = (float*)(stat + 16 * NTT * NW * 8);   // the 4 x 256 biases (a global load per GEMM start would expose its latency)
   const int tid = threadIdx.x & (64 * NW - 1), lane = tid & 63, kk = lane >> 4, l15 = lane & 15;      // thread within the group
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef FS_XCD_SAMPLE   // experiment: consecutive workgroup ids go to consecutive XCDs; give XCD k a CONTIGUOUS eighth of the sequences (at B = 8:
+  // sample k, in every letter's launch and in the propagator pass), so that a launch finds the rows the previous one wrote in its own L2
+  const int vblock = (G == 1 && gridDim.x % 8 == 0) ? (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) : (int)blockIdx.x * G + grp;
+#else
   const int vblock = (int)blockIdx.x * G + grp;      // the group's index = the workgroup index of the unpaired form
+#endif
 #ifndef FS_SKEW
 #define FS_SKEW 1      // 0: experiment -- the two groups of the paired form in step (same barriers, no offset, no alignment barriers)
 #endif
@@ -1116,10 +1121,23 @@ int tante_fs_launch(float* x, const char* stream, const TanteSeq& sq, int causal
   int ntt = full;
   if (tps == 3) ntt = tq;
   else if (tps >= 1 && (16 * tq) % L == 0 && (16 * tq) / L >= 1 && (tps == 1 || tq % tps == 0) && rounds(tq) < rounds(full)) ntt = tq;
+  // small batches (inference, 4 waves, L | 16 or L = 32): HALF-size workgroups (2 tiles = 32 tokens) while the full-size grid fills at most
+  // a quarter of the resident slots -- cfg2 at B = 1 is 64 full-size workgroups for 256 CUs, each the whole serial chain of a block; 128
+  // half-size ones run it on half the tokens.  Measured as captured graphs (tools/_r4_half.sh, same box): B = 1 3 920 -> 4 432 frames/s,
+  // B = 2 7 232 -> 7 898; B = 4 (256 full-size workgroups) 12 480 -> 12 150 and B = 6 -0.6 %: not there.  Bit-identical either way.
+  if (!tr && nw == 4 && (tps == 1 || tps == 2) && 32 % L == 0 && tante_opt("TANTE_FS_HALF", 1)) {
+    const int spw_full = 16 * ntt / L;
+    if (((long)sq.nseq + spw_full - 1) / spw_full * 4 <= resident) ntt = 2;
+  }
   A.spw = tps ? 16 * ntt / L : (16 * full) / L;
   const int nwg = (sq.nseq + A.spw - 1) / A.spw;
   const int key = nw * 100 + tps * 10 + ntt;
   switch (key) {
+    case 412:
+      if (A.tprop) fs_launch_tt<1, 2, 4, false, 1, true>(A, nwg, s);
+      else fs_launch_tt<1, 2, 4, false>(A, nwg, s);
+      break;
+    case 422: fs_launch_tt<2, 2, 4, false>(A, nwg, s); break;
     case 818: fs_launch_t<1, 8, 8>(A, nwg, s); break;
     case 816: fs_launch_t<1, 6, 8>(A, nwg, s); break;
     case 828: fs_launch_t<2, 8, 8>(A, nwg, s); break;

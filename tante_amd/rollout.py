@@ -190,6 +190,64 @@ def rollout_model(model, batch: Dict, formatter, n_steps: int, device=None):
     return torch.cat(preds, dim=1)[:, :n_steps], y_ref.to(device)
 
 
+class GraphedRollout:
+    """rollout_model(model, batch, formatter, n_steps) replayed as ONE captured HIP graph -- for small batches, where the hundred-odd
+    launches of a rollout are issue-bound on the host (cfg2, B = 1: 3.3 k -> 4.4 k frames/s).  Same kernels, same bits as the eager call.
+
+        roll = tante_amd.GraphedRollout(model, batch, formatter, n_steps)     # warms up, captures on `batch`'s shapes
+        y_pred, y_ref = roll(batch)                                            # copies the batch in, replays
+
+    The returned tensors are the graph's own output buffers: they are overwritten by the next call (clone what must be kept).  The
+    graph holds the packed weights by address, so it is re-captured when a parameter changed (optimizer step, load_state_dict, .to()).
+    Inference only (the model must be in eval mode; no autograd)."""
+
+    def __init__(self, model, batch: Dict, formatter, n_steps: int, device=None):
+        self.model, self.formatter, self.n_steps = model, formatter, n_steps
+        self.device = device or next(model.parameters()).device
+        if self.device.type != "cuda":
+            raise RuntimeError("GraphedRollout needs the model on the GPU (no CPU fallback)")
+        if model.training:
+            raise RuntimeError("GraphedRollout replays an inference rollout: call model.eval() first")
+        self._in = {k: batch[k].to(self.device).clone() for k in ("input", "output")}
+        self._graph = self._out = self._key = None
+        self._capture()
+
+    def _weights_key(self):
+        from .attn_backbone import _WEIGHT_EPOCH
+        return (_WEIGHT_EPOCH[0],) + tuple((p.data_ptr(), p._version) for p in self.model.parameters())
+
+    def _run(self):
+        with torch.inference_mode():
+            return rollout_model(self.model, self._in, self.formatter, self.n_steps, device=self.device)
+
+    def _capture(self):
+        dev = self.device
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                self._run()                      # packs, tables, workspaces and allocator pools exist before the capture
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = self._run()
+        self._graph, self._out, self._key = g, out, self._weights_key()
+
+    def __call__(self, batch: Dict):
+        for k in ("input", "output"):
+            src = batch[k]
+            if src.shape != self._in[k].shape or src.dtype != self._in[k].dtype:
+                raise ValueError(f"GraphedRollout was captured for batch[{k!r}] of shape {tuple(self._in[k].shape)} {self._in[k].dtype}, got "
+                                 f"{tuple(src.shape)} {src.dtype}")
+            if src.data_ptr() != self._in[k].data_ptr():
+                self._in[k].copy_(src, non_blocking=True)
+        if self._weights_key() != self._key:
+            self._capture()
+        self._graph.replay()
+        return self._out
+
+
 def rollout_adaptive(model, batch: Dict, formatter, n_steps: int, out_T: float, per_sample: bool, device=None,
                      batch_when_equivalent: bool = True):
     """deg=False rollouts: per_sample=True, out_T=1.5 is R_Trainer's loop; per_sample=False,

@@ -522,3 +522,54 @@ def test_film_table_fn_gradients(dev, T, C_):
         e = rel_err(p.grad, ref[n])
         assert e < 1e-5, (n, e)
     assert rel_err(add.grad, ref_add) < 1e-5
+
+
+@pytest.mark.parametrize("B,res,axes", [(1, (256, 256), "THW"), (2, (256, 256), "THW"), (3, (128, 256), "TW"), (1, (128, 128), "HT")])
+def test_half_size_block_workgroups_bit_identical(dev, B, res, axes):
+    """Small batches run the fused block kernel on 32-token workgroups (block_fs_kernel<TPS, 2, 4>: twice the workgroups, half the serial
+    chain each) where that needs fewer resident rounds; TANTE_FS_HALF = 0 keeps the 64-token form.  A token's arithmetic does not depend
+    on the tiling: the two must agree bit for bit (both are held to the oracle by test_fused_block / the G fixtures)."""
+    from tante_amd import _lib as L
+    m = _model(dev, 11, res, 1, axes, seed=7)
+    x = torch.randn(B, 4, 11, *res, generator=torch.Generator().manual_seed(B)).to(dev)
+    try:
+        with torch.no_grad():
+            L.set_option("TANTE_FS_HALF", 0)
+            y_full = m(x).clone()
+            L.set_option("TANTE_FS_HALF", 1)
+            y_half = m(x).clone()
+    finally:
+        L.set_option("TANTE_FS_HALF", 1)
+    assert torch.isfinite(y_half).all()
+    assert torch.equal(y_full, y_half), "half-size block workgroups changed the result"
+
+
+def test_graphed_rollout_equals_eager_and_follows_weight_updates(dev):
+    """tante_amd.GraphedRollout: the rollout as one captured HIP graph gives the eager rollout's bits, on the batch it was captured with
+    and on a new one; after a parameter changed the graph is re-captured (its packed weights are referenced by address)."""
+    import tante_amd
+    torch.manual_seed(3)
+    md = tante_amd.TanteMetadata(n_fields=4, spatial_resolution=(64, 96))
+    m = tante_amd.TANTE(in_T=4, dset_metadata=md, n_head=8, embed_dim=256, patch_scale=8, taylor_order=2, attn_axes="TH-W",
+                        dropout=0.0).to(dev).eval().set_compute("bf16")
+    fmt = tante_amd.DefaultChannelsFirstFormatter(md)
+    g = torch.Generator().manual_seed(9)
+
+    def mk():
+        return {"input": torch.randn(2, 4, 64, 96, 4, generator=g).to(dev), "output": torch.randn(2, 5, 64, 96, 4, generator=g).to(dev)}
+    b1, b2 = mk(), mk()
+    b2["output"][0, 0, 0, 0, 0] = float("nan")          # the formatter's nan_to_num runs inside the graph too
+    roll = tante_amd.GraphedRollout(m, b1, fmt, 5)
+    with torch.no_grad():
+        for b in (b1, b2, b1):
+            y, ref = roll(b)
+            y, ref = y.clone(), ref.clone()
+            ye, refe = tante_amd.rollout_model(m, b, fmt, 5)
+            assert torch.equal(y, ye) and torch.equal(ref, refe)
+        with torch.no_grad():
+            m.decoders[0].dec_conv_3.deconv.bias.add_(0.25)
+        y = roll(b2)[0].clone()
+        ye = tante_amd.rollout_model(m, b2, fmt, 5)[0]
+        assert torch.equal(y, ye), "GraphedRollout did not follow a parameter update"
+    with pytest.raises(ValueError):
+        roll({"input": b1["input"][:1], "output": b1["output"][:1]})
