@@ -399,6 +399,14 @@ int tante_spectral_layer(const float* x, int64_t n, int Cin, int H, int W, const
 int tante_spectral_layer_c(const float* x, int64_t n, int Cin, int H, int W, const float* w_re, const float* w_im, int wm1, int wm2,
                            int modes1, int modes2, const float* w0, const float* b0, int Cout, int act, float* out, void* work,
                            int64_t work_bytes, int compute, void* stream);
+/* tante_spectral_layer_c in TANTE_BF16 mode writing act(layer(x)) as a bf16 (n, Cout, H, W) image (round to nearest even): for a layer whose
+ * output only feeds a bf16 patch gather (enc_FNO: spectral -> GELU -> conv, enc_dec_fno.py:224-273) -- tante_im2col reads bf16 images --
+ * with the same final bits and half the bytes both ways.  tante_spectral_bf16out_supported: the shape has this form (truncated-DFT
+ * path, W % 128 == 0, Cout <= 32, Cout % 4 == 0, Cin <= 64).  work as tante_spectral_layer. */
+int tante_spectral_bf16out_supported(int64_t n, int Cin, int Cout, int H, int W, int modes1, int modes2);
+int tante_spectral_layer_bf16out(const float* x, int64_t n, int Cin, int H, int W, const float* w_re, const float* w_im, int wm1, int wm2,
+                                 int modes1, int modes2, const float* w0, const float* b0, int Cout, int act, void* out, void* work,
+                                 int64_t work_bytes, void* stream);
 /* Backward of tante_spectral_layer (act none): dx (n, Cin, H, W) = irfft2(M^H rfft2(dy)) + W0^T dy, and the complex weight gradient
  * dw_re / dw_im (Cin, Cout, wm1, wm2) in PyTorch's convention (dL/dRe + i dL/dIm).  w0t: the 1x1 weight transposed, (Cin, Cout).
  * The 1x1 conv's own weight / bias gradients are ordinary reductions (tante_wgrad lines, tante_colsum). */

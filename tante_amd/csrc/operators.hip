@@ -60,9 +60,11 @@ __global__ void im2col_kernel(const void* __restrict__ x, int x_dtype, int nchw,
 // C x P input segments of TW P (+ padding shift) contiguous floats -- coalesced, zero outside the image -- into LDS and writes TW
 // whole patch rows of K = C P P contiguous elements.  Row stride TW P + 1 floats: the (c, kh) segments a wave reads back at one kw sit
 // on different banks.
-template <int P, bool BF16OUT>
-__global__ __launch_bounds__(256) void im2col_nchw_tile_kernel(const float* __restrict__ x, int C, int H, int W, int pad, int Ho, int Wo, int CC,
+template <int P, bool BF16OUT, bool XB16 = false>      // XB16: the source image is bf16 (a producer that rounded for this gather already)
+__global__ __launch_bounds__(256) void im2col_nchw_tile_kernel(const void* __restrict__ xv, int C, int H, int W, int pad, int Ho, int Wo, int CC,
                                                                void* __restrict__ cols) {
+  const float* const x = (const float*)xv;
+  const unsigned short* const xh = (const unsigned short*)xv;
   constexpr int SEG = 64, TW = SEG / P, S = SEG + 1;   // a tile = TW patches = 64 input columns; LDS rows padded to 65 floats
   extern __shared__ float tile[];                        // [CC * P][S]
   const int tiles_w = (Wo + TW - 1) / TW;
@@ -76,15 +78,19 @@ __global__ __launch_bounds__(256) void im2col_nchw_tile_kernel(const float* __re
   const bool xin = xx >= 0 && xx < W;
   for (int c0 = 0; c0 < C; c0 += CC) {
     const int cc = min(CC, C - c0), rows = cc * P;                 // (c, kh) segments of this pass
-    for (int rb = r0; rb < rows; rb += 32) {                       // eight independent loads in flight per thread
-      float v[8];
+    constexpr int NLD = 8;                                         // independent loads in flight per thread (16: +-0, 32: -9 % on cfg5)
+    for (int rb = r0; rb < rows; rb += 4 * NLD) {
+      float v[NLD];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < NLD; ++u) {
         const int r = rb + 4 * u, c = r / P, kh = r - c * P, y = y0 + kh;
-        v[u] = (r < rows && xin && y >= 0 && y < H) ? x[((img * C + c0 + c) * (long)H + y) * W + xx] : 0.0f;
+        const bool ok = r < rows && xin && y >= 0 && y < H;
+        const long src = ((img * C + c0 + c) * (long)H + y) * W + xx;
+        if constexpr (XB16) v[u] = ok ? __uint_as_float((unsigned)xh[src] << 16) : 0.0f;
+        else v[u] = ok ? x[src] : 0.0f;
       }
 #pragma unroll
-      for (int u = 0; u < 8; ++u)
+      for (int u = 0; u < NLD; ++u)
         if (rb + 4 * u < rows) tile[(rb + 4 * u) * S + j] = v[u];
     }
     __syncthreads();
@@ -1022,8 +1028,8 @@ extern "C" int tante_im2col(const void* x, int x_dtype, int nchw, int64_t n_img,
   if (Ho <= 0 || Wo <= 0) TANTE_FAIL(-1, "tante_im2col: empty output");
   const long total = (long)n_img * Ho * Wo * C * kh * kw;
   const int eb = x_dtype == TANTE_BF16 ? 2 : 4;
-  if (nchw && korder == 0 && x_dtype == TANTE_F32 && kh == kw && sh == kh && sw == kw && ph == pw && ph < kh && (kh == 2 || kh == 4) &&
-      tante_opt("TANTE_IM2COL_TILED", 1)) {
+  if (nchw && korder == 0 && (x_dtype == TANTE_F32 || (x_dtype == TANTE_BF16 && cols_dtype == TANTE_BF16)) && kh == kw && sh == kh && sw == kw &&
+      ph == pw && ph < kh && (kh == 2 || kh == 4) && tante_opt("TANTE_IM2COL_TILED", 1)) {
     // channels per pass: the C x P segments of 64 floats (+ 1 pad) within 48 KB of LDS (three workgroups per CU and more)
     {
       int CC = C;
@@ -1034,7 +1040,10 @@ extern "C" int tante_im2col(const void* x, int x_dtype, int nchw, int64_t n_img,
       if (blocks > 2147483647L) TANTE_FAIL(-2, "tante_im2col: grid too large");
       const bool bf = cols_dtype == TANTE_BF16;
       hipStream_t s_ = (hipStream_t)stream;
-      if (kh == 4 && bf) hipLaunchKernelGGL((im2col_nchw_tile_kernel<4, true>), dim3((unsigned)blocks), dim3(256), lds, s_, (const float*)x, C, H, W, ph, Ho, Wo, CC, cols);
+      if (x_dtype == TANTE_BF16) {
+        if (kh == 4) hipLaunchKernelGGL((im2col_nchw_tile_kernel<4, true, true>), dim3((unsigned)blocks), dim3(256), lds, s_, x, C, H, W, ph, Ho, Wo, CC, cols);
+        else hipLaunchKernelGGL((im2col_nchw_tile_kernel<2, true, true>), dim3((unsigned)blocks), dim3(256), lds, s_, x, C, H, W, ph, Ho, Wo, CC, cols);
+      } else if (kh == 4 && bf) hipLaunchKernelGGL((im2col_nchw_tile_kernel<4, true>), dim3((unsigned)blocks), dim3(256), lds, s_, (const float*)x, C, H, W, ph, Ho, Wo, CC, cols);
       else if (kh == 4) hipLaunchKernelGGL((im2col_nchw_tile_kernel<4, false>), dim3((unsigned)blocks), dim3(256), lds, s_, (const float*)x, C, H, W, ph, Ho, Wo, CC, cols);
       else if (bf) hipLaunchKernelGGL((im2col_nchw_tile_kernel<2, true>), dim3((unsigned)blocks), dim3(256), lds, s_, (const float*)x, C, H, W, ph, Ho, Wo, CC, cols);
       else hipLaunchKernelGGL((im2col_nchw_tile_kernel<2, false>), dim3((unsigned)blocks), dim3(256), lds, s_, (const float*)x, C, H, W, ph, Ho, Wo, CC, cols);
@@ -1216,6 +1225,30 @@ extern "C" int tante_spectral_layer_c(const float* x, int64_t n, int Cin, int H,
   const long HW = (long)H * W;
   hipLaunchKernelGGL(conv1x1_add_kernel, dim3((unsigned)((HW + 63) / 64), (unsigned)n), dim3(256), lds, s, x, w0, b0, out, HW, Cin, Cout, act, out);
   TANTE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int tante_spectral_bf16out_supported(int64_t n, int Cin, int Cout, int H, int W, int modes1, int modes2) {
+  if (n <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return 0;
+  const int Wf = W / 2 + 1;
+  const int m1 = modes1 < H ? modes1 : H, m2 = modes2 < Wf ? modes2 : Wf;
+  return tante_opt("TANTE_SPECTRAL_DFT", 1) && tante_opt("TANTE_SPECTRAL_BF16OUT", 1) && tante_spectral_dft_bf16out_supported(n, Cin, Cout, H, W, m1, m2);
+}
+
+extern "C" int tante_spectral_layer_bf16out(const float* x, int64_t n, int Cin, int H, int W, const float* w_re, const float* w_im, int wm1, int wm2,
+                                            int modes1, int modes2, const float* w0, const float* b0, int Cout, int act, void* out, void* work,
+                                            int64_t work_bytes, void* stream) {
+  if (!x || !w_re || !w_im || !w0 || !out || !work || n <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0)
+    TANTE_FAIL(-1, "tante_spectral_layer_bf16out: bad argument");
+  if (!tante_spectral_bf16out_supported(n, Cin, Cout, H, W, modes1, modes2)) TANTE_FAIL(-2, "tante_spectral_layer_bf16out: shape without the bf16-output form");
+  if (((uintptr_t)x % 16) || ((uintptr_t)out % 16)) TANTE_FAIL(-1, "tante_spectral_layer_bf16out: x and out must be 16-byte aligned");
+  const int Wf = W / 2 + 1;
+  const int m1 = modes1 < H ? modes1 : H, m2 = modes2 < Wf ? modes2 : Wf;
+  if (m1 > wm1 || m2 > wm2) TANTE_FAIL(-1, "tante_spectral_layer_bf16out: weight holds fewer modes (%d, %d) than used (%d, %d)", wm1, wm2, m1, m2);
+  if (work_bytes < tante_spectral_dft_workspace_bytes(n, Cin, Cout, H, m1, m2)) TANTE_FAIL(-1, "tante_spectral_layer_bf16out: workspace too small");
+  const int rc = tante_spectral_dft_forward(x, n, Cin, H, W, w_re, w_im, wm1, wm2, m1, m2, w0, b0, Cout, act, (float*)out, work, TANTE_BF16,
+                                            (hipStream_t)stream, 1);
+  if (rc) TANTE_FAIL(rc, "tante_spectral_layer_bf16out: truncated-DFT launch failed");
   return 0;
 }
 

@@ -5,5 +5,8 @@
 
 int tante_spectral_dft_supported(int64_t n, int Cin, int Cout, int H, int W, int m1, int m2);
 int64_t tante_spectral_dft_workspace_bytes(int64_t n, int Cin, int Cout, int H, int m1, int m2);
+// out_bf16: `out` is a bf16 (n, Cout, H, W) image (tante_spectral_dft_bf16out_supported: the shape runs the split-bf16 last kernel)
+int tante_spectral_dft_bf16out_supported(int64_t n, int Cin, int Cout, int H, int W, int m1, int m2);
 int tante_spectral_dft_forward(const float* x, int64_t n, int Cin, int H, int W, const float* w_re, const float* w_im, int wm1, int wm2, int m1,
-                               int m2, const float* w0, const float* b0, int Cout, int act, float* out, void* work, int compute, hipStream_t s);
+                               int m2, const float* w0, const float* b0, int Cout, int act, float* out, void* work, int compute, hipStream_t s,
+                               int out_bf16 = 0);

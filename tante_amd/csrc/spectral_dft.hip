@@ -348,7 +348,10 @@ __device__ __forceinline__ void split8(const float (&v)[8], u32x4& hi, u32x4& lo
 __device__ __forceinline__ f32x4 mfma16(const u32x4& a, const u32x4& b, const f32x4& c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
-template <int KZS, int KCS>   // k-steps of 32 per term: ceil(2 m2 / 32) spectral, ceil(Cin / 32) conv
+// OUT16: the (n, Cout, H, W) image is written as bf16 (round to nearest even, what the consumer's own conversion would do): for a layer whose
+// output only feeds the bf16 patch gather of the convolution behind it (enc_FNO's first stage: 268 MB of fp32 written here and read
+// back by tante_im2col at cfg5) both passes move half the bytes and the result is the same bit for bit.
+template <int KZS, int KCS, bool OUT16 = false>   // k-steps of 32 per term: ceil(2 m2 / 32) spectral, ceil(Cin / 32) conv
 __global__ __launch_bounds__(256) void idft_rows_conv_x3_kernel(const float* __restrict__ Z, const float* __restrict__ x, const float* __restrict__ w0,
                                                                 const float* __restrict__ b0, long n, int Cin, int Cout, int H, int W, int m2,
                                                                 int act, float* __restrict__ out) {
@@ -513,7 +516,13 @@ __global__ __launch_bounds__(256) void idft_rows_conv_x3_kernel(const float* __r
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], act);
           }
-          st_wt16(orow + (long)o * HWl + 16 * wt, v);      // write-through: 268 MB of output never read back by this launch
+          if constexpr (OUT16) {
+            u32x2 pk;
+            pk[0] = pack_bf16x2(v[0], v[1]);
+            pk[1] = pack_bf16x2(v[2], v[3]);
+            st_wt8((unsigned short*)out + (orow - out) + (long)o * HWl + 16 * wt, pk);
+          } else
+            st_wt16(orow + (long)o * HWl + 16 * wt, v);      // write-through: 268 MB of output never read back by this launch
         }
       }
     }
@@ -542,8 +551,19 @@ int64_t tante_spectral_dft_workspace_bytes(int64_t n, int Cin, int Cout, int H, 
   return up(ar) + up(xx) + up(yy) + up(zz);
 }
 
+// the split-bf16 inverse row transform's conditions (kernel E3)
+static bool dft_x3_ok(int Cin, int Cout, int W, int m2, size_t* lds_out) {
+  const size_t ldsE3 = (size_t)2 * ((2 * m2 + 31) / 32) * 512 * 16 + (size_t)4 * (2 * m2 * (Cout + 4) + Cin * 132) * 4;     // table + four waves' staging areas
+  if (lds_out) *lds_out = ldsE3;
+  return W % 128 == 0 && Cout <= 32 && Cout % 4 == 0 && Cin <= 64 && ldsE3 <= 150 * 1024 && (size_t)W * 8 <= ldsE3 - (size_t)2 * ((2 * m2 + 31) / 32) * 512 * 16;
+}
+int tante_spectral_dft_bf16out_supported(int64_t n, int Cin, int Cout, int H, int W, int m1, int m2) {
+  return tante_spectral_dft_supported(n, Cin, Cout, H, W, m1, m2) && dft_x3_ok(Cin, Cout, W, m2, nullptr);
+}
+
 int tante_spectral_dft_forward(const float* x, int64_t n, int Cin, int H, int W, const float* w_re, const float* w_im, int wm1, int wm2, int m1,
-                               int m2, const float* w0, const float* b0, int Cout, int act, float* out, void* work, int compute, hipStream_t s) {
+                               int m2, const float* w0, const float* b0, int Cout, int act, float* out, void* work, int compute, hipStream_t s,
+                               int out_bf16) {
   auto up = [](int64_t v) { return (v + 255) / 256 * 256; };
   char* p = (char*)work;
   float* Ar = (float*)p; p += up(n * Cin * H * 2 * m2 * 4);
@@ -585,19 +605,25 @@ int tante_spectral_dft_forward(const float* x, int64_t n, int Cin, int H, int W,
     default: return -2;
   }
   // bf16 compute mode: split-operand products on the bf16 matrix pipe (idft_rows_conv_x3_kernel); TANTE_SPECTRAL_X3 = 0 keeps the fp32 kernel
-  const size_t ldsE3 = (size_t)2 * ((2 * m2 + 31) / 32) * 512 * 16 + (size_t)4 * (2 * m2 * (Cout + 4) + Cin * 132) * 4;     // table + four waves' staging areas
-  if (compute == TANTE_BF16 && W % 128 == 0 && Cout <= 32 && Cout % 4 == 0 && Cin <= 64 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)out % 16) == 0 &&
-      ldsE3 <= 150 * 1024 && (size_t)W * 8 <= ldsE3 - (size_t)2 * ((2 * m2 + 31) / 32) * 512 * 16 && tante_opt("TANTE_SPECTRAL_X3", 1)) {
+  size_t ldsE3 = 0;
+  const bool x3 = dft_x3_ok(Cin, Cout, W, m2, &ldsE3) && ((uintptr_t)x % 16) == 0 && ((uintptr_t)out % 16) == 0;
+  if (out_bf16 && !x3) return -2;      // (the caller asked tante_spectral_dft_bf16out_supported first)
+  if (out_bf16 || (compute == TANTE_BF16 && x3 && tante_opt("TANTE_SPECTRAL_X3", 1))) {
     const int kzs = (2 * m2 + 31) / 32, kcs = (Cin + 31) / 32, ncb = W / 128;
     const long rows4 = ((long)n * H + 3) / 4;
     const size_t lds = ldsE3;
     const long per_cu = std::max<long>(1, std::min<long>(4, (150 * 1024) / (long)lds));
     const long nrg = std::max<long>(1, std::min<long>(rows4, 256 * per_cu / ncb));
-    static TantePerDevice attrE3[4];
+    static TantePerDevice attrE3[8];
 #define TANTE_DFT_E3(A_, B_)                                                                                                                   \
   {                                                                                                                                            \
-    attrE3[(A_ - 1) * 2 + (B_ - 1)].once([&] { (void)hipFuncSetAttribute((const void*)idft_rows_conv_x3_kernel<A_, B_>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); }); \
-    hipLaunchKernelGGL((idft_rows_conv_x3_kernel<A_, B_>), dim3((unsigned)(nrg * ncb)), dim3(256), lds, s, Z, x, w0, b0, (long)n, Cin, Cout, H, W, m2, act, out); \
+    if (out_bf16) {                                                                                                                            \
+      attrE3[4 + (A_ - 1) * 2 + (B_ - 1)].once([&] { (void)hipFuncSetAttribute((const void*)idft_rows_conv_x3_kernel<A_, B_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); }); \
+      hipLaunchKernelGGL((idft_rows_conv_x3_kernel<A_, B_, true>), dim3((unsigned)(nrg * ncb)), dim3(256), lds, s, Z, x, w0, b0, (long)n, Cin, Cout, H, W, m2, act, out); \
+    } else {                                                                                                                                   \
+      attrE3[(A_ - 1) * 2 + (B_ - 1)].once([&] { (void)hipFuncSetAttribute((const void*)idft_rows_conv_x3_kernel<A_, B_>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); }); \
+      hipLaunchKernelGGL((idft_rows_conv_x3_kernel<A_, B_>), dim3((unsigned)(nrg * ncb)), dim3(256), lds, s, Z, x, w0, b0, (long)n, Cin, Cout, H, W, m2, act, out); \
+    }                                                                                                                                          \
   }
     if (kzs == 1 && kcs == 1) TANTE_DFT_E3(1, 1)
     else if (kzs == 1) TANTE_DFT_E3(1, 2)

@@ -610,15 +610,21 @@ def layernorm_affine(x: torch.Tensor, gamma: Optional[torch.Tensor], beta: Optio
 
 
 def spectral_layer(x: torch.Tensor, w_re: torch.Tensor, w_im: torch.Tensor, modes1: int, modes2: int, w0: torch.Tensor, b0: torch.Tensor,
-                   act: int, compute: int = L.F32) -> torch.Tensor:
+                   act: int, compute: int = L.F32, bf16_out: bool = False) -> torch.Tensor:
     """x (n, Cin, H, W) fp32 -> act(SpectralLayer(x)) (n, Cout, H, W) fp32.  compute = L.BF16 (a bf16 model): the inverse row transform may
-    use split-operand products on the bf16 matrix pipe (~1e-5 relative to the fp32 result)."""
+    use split-operand products on the bf16 matrix pipe (~1e-5 relative to the fp32 result).  bf16_out (bf16 mode, a consumer that rounds to
+    bf16 anyway): the image is written as bf16 where the shape has that form (tante_spectral_layer_bf16out), fp32 otherwise."""
     _dev(x, w_re, w_im, w0, b0)
     n, Cin, H, W = x.shape
     Cout = w_re.shape[1]
-    out = torch.empty(n, Cout, H, W, dtype=torch.float32, device=x.device)
     nbytes = L.lib().tante_spectral_workspace_bytes(n, Cin, Cout, H, W)
     work = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    if bf16_out and compute == L.BF16 and L.lib().tante_spectral_bf16out_supported(n, Cin, Cout, H, W, modes1, modes2):
+        out = torch.empty(n, Cout, H, W, dtype=torch.bfloat16, device=x.device)
+        L.check(L.lib().tante_spectral_layer_bf16out(_p(x), n, Cin, H, W, _p(w_re), _p(w_im), w_re.shape[2], w_re.shape[3], modes1, modes2, _p(w0),
+                                                     _p(b0), Cout, act, _p(out), _p(work), nbytes, _stream()), "tante_spectral_layer_bf16out")
+        return out
+    out = torch.empty(n, Cout, H, W, dtype=torch.float32, device=x.device)
     L.check(L.lib().tante_spectral_layer_c(_p(x), n, Cin, H, W, _p(w_re), _p(w_im), w_re.shape[2], w_re.shape[3], modes1, modes2, _p(w0), _p(b0),
                                            Cout, act, _p(out), _p(work), nbytes, compute, _stream()), "tante_spectral_layer")
     return out

@@ -40,13 +40,14 @@ class SpectralLayer(nn.Module):
     def _planes(self):
         return self._cache.get(0, [self.weight], lambda: (self.weight.detach().real.contiguous(), self.weight.detach().imag.contiguous()))
 
-    def run(self, x: torch.Tensor, act: int = L.ACT_NONE, compute: int = L.F32) -> torch.Tensor:
-        """x (n, Cin, H, W) fp32 contiguous -> act(layer(x)); compute: the model's mode (kernels.spectral_layer)."""
+    def run(self, x: torch.Tensor, act: int = L.ACT_NONE, compute: int = L.F32, bf16_out: bool = False) -> torch.Tensor:
+        """x (n, Cin, H, W) fp32 contiguous -> act(layer(x)); compute: the model's mode; bf16_out: the consumer rounds to bf16 anyway
+        (kernels.spectral_layer)."""
         if x.dim() != 4 or x.size(1) != self.in_channels:
             raise AssertionError("SpectralLayer expects (B, Cin, H, W)")
         re, im = self._planes()
         w0 = self.w0.weight.detach().view(self.out_channels, self.in_channels)
-        return K.spectral_layer(x, re, im, self.modes1, self.modes2, w0, self.w0.bias.detach(), act, compute)
+        return K.spectral_layer(x, re, im, self.modes1, self.modes2, w0, self.w0.bias.detach(), act, compute, bf16_out)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         _no_autograd(self)
@@ -96,7 +97,8 @@ class enc_FNO(nn.Module):
         pk = self._packed(compute)
         n = B * T
         z = inp.contiguous().view(n, D, H, W)
-        z = self.enc_spectral_1.run(z, L.ACT_GELU_ERF, compute)
+        # (bf16 mode: the conv's patch gather rounds the image to bf16 anyway -- the spectral layer's last kernel does it while storing)
+        z = self.enc_spectral_1.run(z, L.ACT_GELU_ERF, compute, bf16_out=True)
         y, h, w = S.conv_stage(z, True, n, self.chans[1], H, W, self.P[0], self.overlap, pk[0], compute, L.ACT_GELU_ERF, torch.float32)
         # (the GEMM's channels-first epilogue -- conv_stage(nchw_out=True) -- was measured at 96 us against 40 us + this 20 us copy)
         z = self.enc_spectral_2.run(_to_nchw(y, n, h, w), L.ACT_GELU_ERF, compute)

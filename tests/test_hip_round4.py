@@ -573,3 +573,27 @@ def test_graphed_rollout_equals_eager_and_follows_weight_updates(dev):
         assert torch.equal(y, ye), "GraphedRollout did not follow a parameter update"
     with pytest.raises(ValueError):
         roll({"input": b1["input"][:1], "output": b1["output"][:1]})
+
+
+def test_spectral_bf16_output_feeds_the_patch_gather_bit_identically(dev):
+    """enc_FNO in bf16 mode: the first spectral layer writes its (GELU'd) image as bf16 and tante_im2col gathers the conv's patches from
+    the bf16 image (tante_spectral_layer_bf16out) -- the rounding the gather did anyway, done once at the store: the encoder's tokens
+    must be the same bits as with the fp32 image in between (TANTE_SPECTRAL_BF16OUT = 0), at half the traffic both ways."""
+    import tante_amd
+    from tante_amd import _lib as L
+    torch.manual_seed(17)
+    md = tante_amd.TanteMetadata(n_fields=8, spatial_resolution=(256, 128))
+    m = tante_amd.TANTE(in_T=4, dset_metadata=md, n_head=8, embed_dim=256, patch_scale=8, taylor_order=1, attn_axes="THW", enc_dec_type="fno",
+                        modes1=10, modes2=10, overlap_ratio=0.0, dropout=0.0).to(dev).eval().set_compute("bf16")
+    x = torch.randn(2, 4, 8, 256, 128, generator=torch.Generator().manual_seed(2)).to(dev)
+    assert L.lib().tante_spectral_bf16out_supported(8, 8, 32, 256, 128, 10, 10)
+    try:
+        with torch.no_grad():
+            L.set_option("TANTE_SPECTRAL_BF16OUT", 0)
+            y0 = m(x).clone()
+            L.set_option("TANTE_SPECTRAL_BF16OUT", 1)
+            y1 = m(x).clone()
+    finally:
+        L.set_option("TANTE_SPECTRAL_BF16OUT", 1)
+    assert torch.isfinite(y1).all()
+    assert torch.equal(y0, y1), "the bf16 image changed the encoder's result"
