@@ -217,7 +217,7 @@ LIB_OPTIONS = ("TANTE_ATTN_BWD_HG", "TANTE_ATTN_BWD_NO_SPLIT", "TANTE_ATTN_BWD_V
 
 
 _lib = None
-ABI_VERSION = 6      # include/tante_hip.h: bumped whenever an entry point is added or changes (round 4: tante_head_enc_*)
+ABI_VERSION = 7      # include/tante_hip.h: bumped whenever an entry point is added or changes (round 4: 6 tante_head_enc_*, 7 tante_pos_embed_tmajor + tante_spectral_*bf16out*)
 
 
 def lib():
