@@ -100,7 +100,7 @@ class enc_FNO(nn.Module):
         # (bf16 mode: the conv's patch gather rounds the image to bf16 anyway -- the spectral layer's last kernel does it while storing)
         z = self.enc_spectral_1.run(z, L.ACT_GELU_ERF, compute, bf16_out=True)
         y, h, w = S.conv_stage(z, True, n, self.chans[1], H, W, self.P[0], self.overlap, pk[0], compute, L.ACT_GELU_ERF, torch.float32)
-        # (the GEMM's channels-first epilogue -- conv_stage(nchw_out=True) -- was measured at 96 us against 40 us + this 20 us copy)
+        # (a channels-first epilogue of the conv GEMM was measured at 96 us against 40 us + this 20 us copy: stages.conv_stage)
         z = self.enc_spectral_2.run(_to_nchw(y, n, h, w), L.ACT_GELU_ERF, compute)
         y, h, w = S.conv_stage(z, True, n, self.chans[3], h, w, self.P[1], self.overlap, pk[1], compute, L.ACT_NONE, torch.float32)
         if film is not None:

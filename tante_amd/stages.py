@@ -59,10 +59,11 @@ def conv_weight_2d(w: torch.Tensor, korder: int) -> torch.Tensor:
 
 
 def conv_stage(x: torch.Tensor, nchw: bool, n_img: int, Cin: int, H: int, W: int, P: int, overlap: float, chunks: List[K.PackedWeight],
-               compute: int, act: int, out_dtype: torch.dtype, nchw_out: bool = False) -> Tuple[torch.Tensor, int, int]:
+               compute: int, act: int, out_dtype: torch.dtype) -> Tuple[torch.Tensor, int, int]:
     """RealConv2d.forward (enc_dec_cnn.py:97-110): conv(kernel P, stride / padding from overlap) -> adaptive_avg_pool2d to
-    (H // P, W // P) -> act.  Returns the channels-last (n_img * Ht * Wt, Cout) matrix and (Ht, Wt); with nchw_out the
-    (n_img, Cout, Ht, Wt) tensor instead (the GEMM's channels-first epilogue where one chunk and no pooling allow it, a copy otherwise)."""
+    (H // P, W // P) -> act.  Returns the channels-last (n_img * Ht * Wt, Cout) matrix and (Ht, Wt).  x may be a bf16 image (a producer
+    that rounded for the bf16 patch gather already).  (A channels-first output through the GEMM's pixel-shuffle epilogue was measured
+    slower than the caller's layout copy -- 96 against 40 + 20 us at cfg5 -- and removed.)"""
     if H % P or W % P:
         raise ValueError("To enforce (H//P, W//P), input H and W must be divisible by patch_size.")
     s, p = stride_pad(P, overlap)
@@ -71,16 +72,9 @@ def conv_stage(x: torch.Tensor, nchw: bool, n_img: int, Cin: int, H: int, W: int
     adt = K.act_torch_dtype(compute)
     cols = K.im2col(x, nchw, n_img, Cin, H, W, P, P, s, s, p, p, 0 if nchw else 1, adt)
     same = (Hc, Wc) == (Ht, Wt)
-    if nchw_out and same and len(chunks) == 1:      # one output pixel per row: the pixel-shuffle epilogue with P = 1 IS a channels-first store
-        Cout = chunks[0].N
-        out = torch.empty(n_img, Cout, Ht, Wt, dtype=out_dtype, device=x.device)
-        K.deconv(cols, chunks[0], out, n_img=n_img, Hi=Ht, Wi=Wt, P=1, Cout=Cout, nchw_out=True, act=act)
-        return out, Ht, Wt
     y = linear_chunks(cols, chunks, out_dtype if same else adt, act if same else L.ACT_NONE)
     if not same:
         y = K.avgpool_nhwc(y, n_img, Hc, Wc, chunks[0].N, Ht, Wt, act, out_dtype)
-    if nchw_out:
-        y = y.view(n_img, Ht, Wt, -1).permute(0, 3, 1, 2).to(out_dtype).contiguous()
     return y, Ht, Wt
 
 
