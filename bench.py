@@ -52,6 +52,7 @@ def parse():
     p.add_argument("--train-steps", type=int, default=12)
     p.add_argument("--no-train-strong", action="store_true", help="skip the strong-scaling train line (global batch 64)")
     p.add_argument("--graph", action="store_true", help="replay each rollout as one captured HIP graph (small batches are launch-bound on the host)")
+    p.add_argument("--no-graph", action="store_true", help="the eager loop only (default: decided in the warm-up, eager unless the captured rollout is > 2 %% faster)")
     p.add_argument("--no-workloads", action="store_true", help="skip the compact cfg2 B=1 / cfg4 / cfg5 legs (the `workloads` object)")
     return p.parse_args()
 
@@ -274,14 +275,18 @@ def rollout_leg(config, batch_arg, dtype_arg, steps, warmup, dev, rank, world, d
             y, _ = tante_amd.rollout_model(model, batch, fmt, n_steps, device=dev)
         return y
 
+    # graph: False = the eager loop, True = tante_amd.GraphedRollout (one captured HIP graph per rollout), "auto" = decided in the warm-up:
+    # the eager loop unless the captured rollout is clearly (> 2 %) faster -- small batches and busy hosts, where the host's ~100 launches
+    # per rollout are the bottleneck, not the device
     graph_note = "off"
+    eager_step = step
+    graph_step = None
     if graph:
-        eager_step = step
         try:
             if kind in ("tante", "tante_fno"):       # the product's own captured rollout (tante_amd.GraphedRollout)
                 roll = tante_amd.GraphedRollout(model, batch, fmt, n_steps, device=dev)
 
-                def step():
+                def graph_step():
                     return roll(batch)[0]
             else:
                 side = torch.cuda.Stream(device=dev)
@@ -295,13 +300,26 @@ def rollout_leg(config, batch_arg, dtype_arg, steps, warmup, dev, rank, world, d
                 with torch.cuda.graph(g_):
                     g_out = eager_step()
 
-                def step():
+                def graph_step():
                     g_.replay()
                     return g_out
             graph_note = "on"
+            step = graph_step
         except Exception as e:      # noqa: BLE001
             graph_note = f"capture failed ({type(e).__name__}: {e}): eager"
-            step = eager_step
+            step, graph_step = eager_step, None
+    if graph == "auto" and graph_step is not None:
+        def pair_ms(fn):
+            fn()
+            torch.cuda.synchronize(dev)
+            t_ = time.perf_counter()
+            fn(); fn()
+            torch.cuda.synchronize(dev)
+            return (time.perf_counter() - t_) * 500.0
+        te, tg = pair_ms(eager_step), pair_ms(graph_step)
+        te = min(te, pair_ms(eager_step))      # (the first pair also pays the clock ramp: eager is timed on both sides of the captured pair)
+        step = graph_step if tg < 0.98 * te else eager_step
+        graph_note = f"auto: eager {te:.3f} ms, captured {tg:.3f} ms per rollout in the warm-up -> {'captured' if step is graph_step else 'eager'}"
 
     def sync():
         torch.cuda.synchronize()
@@ -386,7 +404,7 @@ def rollout_leg(config, batch_arg, dtype_arg, steps, warmup, dev, rank, world, d
         K.cross_attention = timed("xattn_mfma_kernel (cross / self attention of CViT)", K.cross_attention, fl_xattn)
         K.spectral_layer = timed("spectral_layer (truncated DFT on fp32 MFMA: row DFT, column DFT, mode mixing, inverse column DFT, inverse row DFT + 1x1 conv + act)", K.spectral_layer, by_spectral)
         try:
-            step()
+            eager_step()      # (a captured rollout replays without passing through the wrappers)
             torch.cuda.synchronize()
         finally:
             K.block_fused, K.linear, K.cross_attention, K.spectral_layer = saved
@@ -479,11 +497,13 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    leg = rollout_leg(args.config, args.batch, args.dtype, args.steps, args.warmup, dev, rank, world, dist, not args.no_roofline, graph=args.graph)
+    leg = rollout_leg(args.config, args.batch, args.dtype, args.steps, args.warmup, dev, rank, world, dist, not args.no_roofline,
+                      graph=True if args.graph else (False if args.no_graph else "auto"))
     import tante_amd
     from tante_amd import kernels as K
     value, elapsed, roofline, model, batch, cfg, wl, kind = (leg[k] for k in ("value", "elapsed", "roofline", "model", "batch", "cfg", "wl", "kind"))
     B, n_steps, T_in, res, D, dtype = (leg[k] for k in ("B", "n_steps", "T_in", "res", "D", "dtype"))
+    graph_mode = leg["graph"]
 
     def sync():
         torch.cuda.synchronize()
@@ -660,7 +680,8 @@ def main():
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
                "config": {"workload": os.path.basename(args.config), "fields": D, "resolution": list(res), "batch_per_gpu": B,
                           "n_steps_input": T_in, "n_steps_rollout": n_steps, "taylor_order": cfg["model"].get("taylor_order", 1),
-                          "attn_axes": cfg["model"].get("attn_axes"), "parallelism": f"batch-sharded x{world} (no collective)"},
+                          "attn_axes": cfg["model"].get("attn_axes"), "parallelism": f"batch-sharded x{world} (no collective)",
+                          "hip_graph": graph_mode},
                "roofline": roofline, "cpu_baseline": cpu, "train": train, "workloads": workloads}
         if plumbing or (world > 1 and backend != "nccl"):
             out["plumbing"] = (f"NOT A PERFORMANCE NUMBER: {world} ranks share GPU 0 and the collectives go through '{backend}' "

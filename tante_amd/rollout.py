@@ -122,15 +122,17 @@ def rollout_model(model, batch: Dict, formatter, n_steps: int, device=None):
             and raw.dim() == 5 and raw.shape[1] == model.T and raw.dtype == torch.float32 and raw.is_cuda and raw.is_contiguous()):
         # same result as formatter.process_input + the in-place rollout below, without the two extra passes over the window
         out_ref = batch["output"]
-        if out_ref.is_cuda and not NO_SIDE_STREAM and not torch.cuda.is_current_stream_capturing():
+        if out_ref.is_cuda and not NO_SIDE_STREAM:
             # the formatter's nan_to_num of the REFERENCE frames (370 MB through HBM at cfg2, 57 us) depends on nothing the rollout
-            # computes: it runs on a second stream under the rollout's matrix-bound launches and is joined before returning
+            # computes: it runs on a second stream under the rollout's matrix-bound launches and is joined before returning (inside a
+            # graph capture the fork and the join are captured with it; the capture's private pool needs no record_stream)
             main = torch.cuda.current_stream(out_ref.device)
             side = _side_stream(out_ref.device)
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 y_ref = _nan_to_num(out_ref)
-            y_ref.record_stream(main)
+            if not torch.cuda.is_current_stream_capturing():
+                y_ref.record_stream(main)
             y = _rollout_in_place(model, None, n_steps, raw_input=raw)
             main.wait_stream(side)
             return formatter.process_output(y), y_ref.to(device)
@@ -194,8 +196,8 @@ class GraphedRollout:
     """rollout_model(model, batch, formatter, n_steps) replayed as ONE captured HIP graph -- for small batches, where the hundred-odd
     launches of a rollout are issue-bound on the host (cfg2, B = 1: 3.3 k -> 4.4 k frames/s).  Same kernels, same bits as the eager call.
 
-        roll = tante_amd.GraphedRollout(model, batch, formatter, n_steps)     # warms up, captures on `batch`'s shapes
-        y_pred, y_ref = roll(batch)                                            # copies the batch in, replays
+        roll = tante_amd.GraphedRollout(model, batch, formatter, n_steps)     # warms up, captures; `batch`'s tensors become its inputs
+        y_pred, y_ref = roll(other_batch)                                      # copies the batch in (nothing if it IS `batch`), replays
 
     The returned tensors are the graph's own output buffers: they are overwritten by the next call (clone what must be kept).  The
     graph holds the packed weights by address, so it is re-captured when a parameter changed (optimizer step, load_state_dict, .to()).
@@ -208,7 +210,9 @@ class GraphedRollout:
             raise RuntimeError("GraphedRollout needs the model on the GPU (no CPU fallback)")
         if model.training:
             raise RuntimeError("GraphedRollout replays an inference rollout: call model.eval() first")
-        self._in = {k: batch[k].to(self.device).clone() for k in ("input", "output")}
+        # the graph reads THESE tensors: the batch given here is adopted as its input buffers (a call with the same tensors copies nothing;
+        # any other batch is copied into them first)
+        self._in = {k: batch[k].to(self.device) for k in ("input", "output")}
         self._graph = self._out = self._key = None
         self._capture()
 
