@@ -347,10 +347,10 @@ int tante_attention_masked(const void* qkv, void* o, int dtype, int C, int n_hea
  * is stored (it is the output) and encoded from the same registers:  z (n_img Hp Wp, C) fp32 = enc_CNN(frame) before FiLM, the
  * rollout's frame-cache entry that tante_enc23_frames would otherwise produce from the stored frame (2 launches, 25 MB).
  * enc_stream = tante_pack_head_enc(conv1.w, conv1.b, conv2.w, conv2.b, conv3.w, conv3.b).  ws: tante_head_enc_ws_bytes(rows) bytes,
- * ZEROED ONCE by the caller before the first use (fp32 partials of encoder stage 3 -- its K = 512 contraction is split over the four
- * workgroups of a token group, the last to arrive adds them in a fixed order: deterministic -- followed by one arrival counter per
- * group, which the kernel leaves at zero).  One workspace per stream of concurrent launches.  enc_stream == NULL: heads + Taylor sum
- * only (z, ws unused). */
+ * ZEROED ONCE by the caller before the first use (the four pixel workgroups of a token group hand their encoder stage-2 outputs over
+ * through it as bf16 operand fragments; the last to arrive runs stage 3 over the whole K = 512 in a fixed tap order: deterministic --
+ * followed by one arrival counter per group, which the kernel leaves at zero).  One workspace per stream of concurrent launches.
+ * enc_stream == NULL: heads + Taylor sum only (z, ws unused). */
 int tante_head_enc_supported(int C, int D);
 int64_t tante_head_enc_stream_bytes(int C);
 int64_t tante_head_enc_ws_bytes(int64_t rows);

@@ -56,10 +56,11 @@ def test_fused_tail_frames_and_encoding(dev, D, res, B, order, axes):
     """tante_head_enc_fused against the launches it replaces.
     (1) the predicted frame is BIT-IDENTICAL to tante_head_fused_multi_streams' (same head arithmetic, same sum order);
     (2) the encoding z of that frame against the encoder launches (stage-1 GEMM + enc23_kernel) on the stored frame: the same bf16
-        operands and fp32 accumulation, but stage 3's K = 512 is summed as four 128-deep partials instead of one chain and stage 1's
-        k order differs -- fp32 rounding of the sum order, and a bf16 re-rounding of an intermediate where that flips it: 2e-4;
+        operands and fp32 accumulation, but the k orders of stages 1 and 3 differ (stage 3 runs tap by tap over K = 512) -- fp32
+        rounding of the sum order, and a bf16 re-rounding of an intermediate where that flips it: 2e-4;
     (3) z against the ORACLE's encoder (fp32 CPU, enc_dec_cnn.py:217-229) on the same frame at the bf16 bar;
-    (4) two launches give the same bits (the partials are added in a fixed order whatever the arrival order of the workgroups)."""
+    (4) two launches give the same bits (stage 3 is one accumulation chain in a fixed tap order whatever the arrival order of the
+        four pixel workgroups that hand their stage-2 outputs to the last one)."""
     import tante_amd
     from tante_amd import tante as TT
     from oracle import tante_oracle as O

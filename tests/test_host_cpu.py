@@ -63,6 +63,9 @@ def test_cpu_tensors_are_rejected():
         blk(torch.zeros(1, 2, 16))
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         m.encoder(torch.zeros(1, 2, 1, 16, 16))
+    fmt = tante_amd.DefaultChannelsFirstFormatter(md)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):     # the captured rollout refuses a CPU model before it touches a graph
+        tante_amd.GraphedRollout(m, {"input": torch.zeros(1, 2, 16, 16, 1), "output": torch.zeros(1, 1, 16, 16, 1)}, fmt, 1)
 
 
 @pytest.mark.parametrize("letter", list("THWLYXA"))
