@@ -498,7 +498,7 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     leg = rollout_leg(args.config, args.batch, args.dtype, args.steps, args.warmup, dev, rank, world, dist, not args.no_roofline,
-                      graph=True if args.graph else (False if args.no_graph else "auto"))
+                      graph=True if args.graph else (False if (args.no_graph or world > 1) else "auto"))      # (multi-rank runs: eager unless asked)
     import tante_amd
     from tante_amd import kernels as K
     value, elapsed, roofline, model, batch, cfg, wl, kind = (leg[k] for k in ("value", "elapsed", "roofline", "model", "batch", "cfg", "wl", "kind"))

@@ -234,7 +234,8 @@ class GraphedRollout:
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        # thread-local capture: another thread's HIP calls (RCCL's watchdog / proxy threads in a data-parallel job) must not invalidate it
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
             out = self._run()
         self._graph, self._out, self._key = g, out, self._weights_key()
 
