@@ -16,7 +16,11 @@ from . import options as _O
 NO_ENC_CACHE = _O.register("TANTE_NO_ENC_CACHE", False, __name__, "NO_ENC_CACHE")          # window-by-window encoder
 NO_TAIL_ENC = _O.register("TANTE_NO_TAIL_ENC", False, __name__, "NO_TAIL_ENC")            # predicted frames re-encoded by the encoder launches
 NO_FUSED_FORMAT = _O.register("TANTE_NO_FUSED_FORMAT", False, __name__, "NO_FUSED_FORMAT")  # formatter.process_input as torch ops
-NO_SIDE_STREAM = _O.register("TANTE_NO_SIDE_STREAM", False, __name__, "NO_SIDE_STREAM")      # reference frames' nan_to_num on the main stream
+# the reference frames' nan_to_num on a SECOND stream under the rollout: the default of round 3, when it hid 57 us; measured again at the
+# end of round 4 (tools/_r4_side.sh, same box, three rounds) it COSTS 3.4 % at B = 8 (16.79 -> 17.36 k frames/s without it), 4.1 % at
+# B = 4 and 8 % at B = 1 -- its workgroups take CU slots from block launches that need the whole chip for their one resident round, and
+# the fork / join is tens of microseconds of a small-batch rollout.  Opt-in now.
+SIDE_STREAM = _O.register("TANTE_SIDE_STREAM", False, __name__, "SIDE_STREAM")
 
 
 class DefaultChannelsFirstFormatter:
@@ -122,10 +126,10 @@ def rollout_model(model, batch: Dict, formatter, n_steps: int, device=None):
             and raw.dim() == 5 and raw.shape[1] == model.T and raw.dtype == torch.float32 and raw.is_cuda and raw.is_contiguous()):
         # same result as formatter.process_input + the in-place rollout below, without the two extra passes over the window
         out_ref = batch["output"]
-        if out_ref.is_cuda and not NO_SIDE_STREAM:
-            # the formatter's nan_to_num of the REFERENCE frames (370 MB through HBM at cfg2, 57 us) depends on nothing the rollout
-            # computes: it runs on a second stream under the rollout's matrix-bound launches and is joined before returning (inside a
-            # graph capture the fork and the join are captured with it; the capture's private pool needs no record_stream)
+        if out_ref.is_cuda and SIDE_STREAM:
+            # (opt-in, see SIDE_STREAM) the formatter's nan_to_num of the REFERENCE frames (370 MB through HBM at cfg2, 57 us) depends on
+            # nothing the rollout computes: on a second stream, joined before returning (inside a graph capture the fork and the join
+            # are captured with it; the capture's private pool needs no record_stream)
             main = torch.cuda.current_stream(out_ref.device)
             side = _side_stream(out_ref.device)
             side.wait_stream(main)
