@@ -194,7 +194,7 @@ def physical_cores():
 
 
 def cvit_cpu_leg(lg, gpu_frames_per_s):
-    """cfg4's CPU baseline: the oracle (oracle/cvit_oracle.py, kind "port") on the shipped model with 1 024 and 2 048 random query points
+    """cfg4's CPU baseline: the oracle (oracle/cvit_oracle.py, kind "port") on the shipped model with 1 024 and 4 096 random query points
     -- as written the full 65 536-query grid embedding needs an 8.6 GB temporary -- extrapolated linearly in the query count to the
     full grid (the encoder is the intercept, the grid embedding + decoder + head are per query)."""
     import torch
@@ -205,25 +205,34 @@ def cvit_cpu_leg(lg, gpu_frames_per_s):
     mk["grid_size"] = tuple(mk["grid_size"])
     ocfg = OC.CvitCfg(cfg["model"]["in_T"], lg["D"], (H, W), **mk)
     w = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+    # the box's 16-core share (TANTE_CPU_THREADS), the faster of the two thread counts the cfg2 leg times: all 128 physical cores
+    # oversubscribe the cgroup and made this short measurement noisy enough to extrapolate a NEGATIVE time once
     affinity = len(os.sched_getaffinity(0))
-    threads = max(1, min(affinity, physical_cores() or affinity))
+    threads = max(1, min(affinity, physical_cores() or affinity, int(os.environ.get("TANTE_CPU_THREADS", "16"))))
     torch.set_num_threads(threads)
     g = torch.Generator().manual_seed(4)
     x = torch.randn(1, lg["T_in"], lg["D"], H, W, generator=g)
     ts = {}
+    n_lo, n_hi = 1024, 4096
     with torch.no_grad():
         OC.cvit_forward(w, ocfg, x, torch.rand(256, 2, generator=g))      # warm-up
-        for n in (1024, 2048):
+        for n in (n_lo, n_hi):
             c = torch.rand(n, 2, generator=g)
-            t0 = time.perf_counter()
-            OC.cvit_forward(w, ocfg, x, c)
-            ts[n] = time.perf_counter() - t0
-    per_q = (ts[2048] - ts[1024]) / 1024.0
-    base = max(0.0, ts[1024] - 1024 * per_q)
+            best = float("inf")
+            for _ in range(2):                                             # the better of two
+                t0 = time.perf_counter()
+                OC.cvit_forward(w, ocfg, x, c)
+                best = min(best, time.perf_counter() - t0)
+            ts[n] = best
+    per_q = (ts[n_hi] - ts[n_lo]) / float(n_hi - n_lo)
+    if per_q <= 0.0:      # still noise-dominated: no intercept, the larger sample's time per query (an upper bound of the CPU's speed)
+        per_q, base = ts[n_hi] / n_hi, 0.0
+    else:
+        base = max(0.0, ts[n_lo] - n_lo * per_q)
     t_full = base + per_q * H * W
     fps = lg["n_steps"] / t_full
     return {"value": round(fps, 4), "unit": "frames/s", "cores": threads, "kind": "port",
-            "sample": f"oracle CViT forward, B = 1, 1 024 / 2 048 random query points in {ts[1024]:.2f} / {ts[2048]:.2f} s, extrapolated linearly to the "
+            "sample": f"oracle CViT forward, B = 1, {n_lo} / {n_hi} random query points in {ts[n_lo]:.2f} / {ts[n_hi]:.2f} s (the better of two runs each), extrapolated linearly to the "
                       f"{H * W}-query grid ({t_full:.1f} s per forward: encoder intercept {base:.2f} s + {1e3 * per_q:.3f} ms per query)",
             "gpu_over_cpu": round(gpu_frames_per_s / fps, 1)}
 
