@@ -311,12 +311,8 @@ __global__ __launch_bounds__(64 * NW * G, 2) void block_fs_kernel(FsArgs A) {
 #else                   // write-through (common.hip.h): 38.4 -> 37.2 us per launch and +2.4 % on the rollout, three interleaved rounds
         // the inference form only (the training form's launches are bound by their saved-tensor traffic, not by the release)
         if (t >= 0) {
-#ifdef FS_EXP_PLAIN_STORE      // A/B: ordinary stores in the inference form too
-          *(f32x4*)(dst + (long)t * FS_C + 16 * RT * wave + 4 * rchunk) = v;
-#else
           if constexpr (TRAIN) *(f32x4*)(dst + (long)t * FS_C + 16 * RT * wave + 4 * rchunk) = v;
           else st_wt16(dst + (long)t * FS_C + 16 * RT * wave + 4 * rchunk, v);
-#endif
         }
 #endif
       }
