@@ -208,8 +208,14 @@ class TimeAggregation(nn.Module):
         # residual rows one per query row)
         lat = self._rep.get(nbs, [self.latents], lambda: self.latents.detach().unsqueeze(0).expand(nbs, -1, -1)
                             .reshape(nbs * self.num_latents, self.emb_dim).contiguous())
-        for blk in self.CrossAttnBlocks:
-            lat = blk.run(lat, x_bs_t, nbs, self.num_latents, T, compute)
+        for i, blk in enumerate(self.CrossAttnBlocks):
+            # the first block's queries ARE the (repeated) latents: their LayerNorm1 + projection is input-independent too
+            qp = None
+            if i == 0:
+                a = blk.attn
+                qp = self._rep.get(("qproj", nbs, compute), [self.latents, blk.layer_norm1.weight, blk.layer_norm1.bias, a.in_proj_weight, a.in_proj_bias],
+                                   lambda: blk.project_queries(lat, compute))
+            lat = blk.run(lat, x_bs_t, nbs, self.num_latents, T, compute, q_proj=qp)
         return lat
 
 
