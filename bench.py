@@ -54,6 +54,8 @@ def parse():
     p.add_argument("--graph", action="store_true", help="replay each rollout as one captured HIP graph (small batches are launch-bound on the host)")
     p.add_argument("--no-graph", action="store_true", help="the eager loop only (default: decided in the warm-up, eager unless the captured rollout is > 2 %% faster)")
     p.add_argument("--no-workloads", action="store_true", help="skip the compact cfg2 B=1 / cfg4 / cfg5 legs (the `workloads` object)")
+    p.add_argument("--reps", type=int, default=7, help="the timed region of exactly --steps steps is repeated this many times behind a >= 0.5 s "
+                                                       "ramp; `value` / `ms_per_step` are the MEDIAN region (min / max / reps in config.timing)")
     return p.parse_args()
 
 
@@ -193,6 +195,55 @@ def physical_cores():
         return None
 
 
+def shader_clock_mhz(local=0):
+    """The shader clock the card reports right now (the starred line of sysfs pp_dpm_sclk of the local-th amdgpu card), or None when sysfs does
+    not show it to this user.  Read before and after the timed regions: two readings that differ say the regions ran in different DVFS states."""
+    import glob
+    try:
+        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/pp_dpm_sclk"))
+        with open(cards[min(local, len(cards) - 1)]) as f:
+            for ln in f:
+                if "*" in ln:
+                    return int(re_mhz(ln))
+    except (OSError, IndexError, ValueError):
+        pass
+    return None
+
+
+def re_mhz(ln):
+    import re
+    return re.search(r"(\d+)\s*[Mm][Hh]z", ln).group(1)
+
+
+def timed_regions(step, steps, reps, sync, dist, dev, ramp_s=0.5):
+    """`reps` timed regions of EXACTLY `steps` steps each, every one bracketed by barrier + synchronize on both sides (MAX over ranks per
+    region), behind a ramp of untimed steps lasting >= ramp_s: the clock state of a 75 ms region on a freshly woken card is one DVFS
+    state, and a box-to-box +- 4 % hid a round's kernel work in round 4.  -> (median seconds per region, sorted list of all regions)."""
+    sync()
+    t_ramp = time.perf_counter()
+    n_ramp = 0
+    while time.perf_counter() - t_ramp < ramp_s:
+        step()
+        n_ramp += 1
+        if n_ramp % 4 == 0:
+            torch.cuda.synchronize()
+    regions = []
+    for _ in range(max(1, reps)):
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        sync()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        regions.append(el)
+    regions.sort()
+    return regions[len(regions) // 2], regions, n_ramp
+
+
 def cvit_cpu_leg(lg, gpu_frames_per_s):
     """cfg4's CPU baseline: the oracle (oracle/cvit_oracle.py, kind "port") on the shipped model with 1 024 and 4 096 random query points
     -- as written the full 65 536-query grid embedding needs an 8.6 GB temporary -- extrapolated linearly in the query count to the
@@ -237,7 +288,7 @@ def cvit_cpu_leg(lg, gpu_frames_per_s):
             "gpu_over_cpu": round(gpu_frames_per_s / fps, 1)}
 
 
-def rollout_leg(config, batch_arg, dtype_arg, steps, warmup, dev, rank, world, dist, want_roofline, graph=False):
+def rollout_leg(config, batch_arg, dtype_arg, steps, warmup, dev, rank, world, dist, want_roofline, graph=False, reps=1):
     """One timed leg: `steps` rollouts (CViT: model calls) of `config` at per-GPU batch `batch_arg` (None: workload.batch_size), barrier +
     synchronize on both sides, MAX over ranks; then (rank 0) the instrumented pass for the roofline entry.  graph=True replays the whole
     rollout as ONE captured HIP graph (B = 1: the 100-odd launches of a rollout are issue-bound on the host)."""
@@ -338,18 +389,14 @@ def rollout_leg(config, batch_arg, dtype_arg, steps, warmup, dev, rank, world, d
 
     for _ in range(args.warmup):
         step()
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    sync()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    clk0 = shader_clock_mhz(dev.index or 0)
+    elapsed, regions, n_ramp = timed_regions(step, args.steps, reps, sync, dist, dev, ramp_s=0.5 if reps > 1 else 0.0)
+    clk1 = shader_clock_mhz(dev.index or 0)
     frames = B * n_steps * args.steps * world
     value = frames / elapsed
+    timing = {"reps": len(regions), "statistic": "median region" if len(regions) > 1 else "single region", "ramp_steps_untimed": n_ramp,
+              "ms_per_step_min": round(1e3 * regions[0] / args.steps, 4), "ms_per_step_max": round(1e3 * regions[-1] / args.steps, 4),
+              "spread_pct": round(100.0 * (regions[-1] - regions[0]) / elapsed, 2), "sclk_mhz_before": clk0, "sclk_mhz_after": clk1}
 
     roofline = None
     if not args.no_roofline and rank == 0:
@@ -472,7 +519,7 @@ def rollout_leg(config, batch_arg, dtype_arg, steps, warmup, dev, rank, world, d
                                                  "are rebuilt when a weight changes"}
 
     return {"value": value, "elapsed": elapsed, "roofline": roofline, "model": model, "batch": batch, "cfg": cfg, "wl": wl, "kind": kind, "B": B,
-            "n_steps": n_steps, "T_in": T_in, "res": res, "D": D, "dtype": dtype, "graph": graph_note}
+            "n_steps": n_steps, "T_in": T_in, "res": res, "D": D, "dtype": dtype, "graph": graph_note, "timing": timing}
 
 
 def main():
@@ -507,12 +554,13 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     leg = rollout_leg(args.config, args.batch, args.dtype, args.steps, args.warmup, dev, rank, world, dist, not args.no_roofline,
-                      graph=True if args.graph else (False if (args.no_graph or world > 1) else "auto"))      # (multi-rank runs: eager unless asked)
+                      graph=True if args.graph else (False if (args.no_graph or world > 1) else "auto"),      # (multi-rank runs: eager unless asked)
+                      reps=args.reps)
     import tante_amd
     from tante_amd import kernels as K
     value, elapsed, roofline, model, batch, cfg, wl, kind = (leg[k] for k in ("value", "elapsed", "roofline", "model", "batch", "cfg", "wl", "kind"))
     B, n_steps, T_in, res, D, dtype = (leg[k] for k in ("B", "n_steps", "T_in", "res", "D", "dtype"))
-    graph_mode = leg["graph"]
+    graph_mode, timing_main = leg["graph"], leg["timing"]
 
     def sync():
         torch.cuda.synchronize()
@@ -554,16 +602,9 @@ def main():
                     graph_note = f"capture failed ({type(e).__name__}: {e}): eager"
             for _ in range(3 if tB <= 16 else 1):                              # warm-up (packs, allocator pools, workspace slabs)
                 step_fn()
-            sync()
-            t0 = time.perf_counter()
-            for _ in range(n_timed):
-                step_fn()
-            sync()
-            tel = time.perf_counter() - t0
-            if dist is not None:
-                tt = torch.tensor([tel], device=dev, dtype=torch.float64)
-                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                tel = float(tt.item())
+            # the same protocol as the rollout leg: median of `reps` regions of exactly n_timed steps behind a ramp
+            t_reps = max(1, min(args.reps, 5)) if tB <= 16 else 1
+            tel, tregions, _ = timed_regions(step_fn, n_timed, t_reps, sync, dist, dev, ramp_s=0.3 if t_reps > 1 else 0.0)
             nbytes = opt.numel * 4
             if graphed is not None:
                 graphed.close()
@@ -572,6 +613,8 @@ def main():
             sps = tB * world * n_timed / tel
             return {"value": round(sps, 2), "unit": "samples/s", "ms_per_step": round(1e3 * tel / n_timed, 2), "global_batch": tB * world,
                     "batch_per_gpu": tB, "steps": n_timed, "hip_graph": graph_note,
+                    "timing": {"reps": len(tregions), "statistic": "median region" if len(tregions) > 1 else "single region",
+                               "ms_per_step_min": round(1e3 * tregions[0] / n_timed, 3), "ms_per_step_max": round(1e3 * tregions[-1] / n_timed, 3)},
                     "roofline": {"bound": "mfma", "achieved": round(sps * flops_sample / world / 1e12, 2), "peak": PEAK_TFLOPS[dtype],
                                  "unit": "TFLOP/s per GPU", "frac": round(sps * flops_sample / world / 1e12 / PEAK_TFLOPS[dtype], 4),
                                  "algorithmic_gflop_per_sample": round(flops_sample / 1e9, 1)}}, nbytes
@@ -659,6 +702,14 @@ def main():
                     o["whole_forward"] = {k: r["whole_forward"][k] for k in ("algorithmic_gflop", "ms", "TFLOP/s", "frac")}
             return o
         try:
+            # cfg2 at two and four resident rounds of the fused block kernel (B = 8 is exactly one round of 512 workgroups): the same model,
+            # the same kernels, the block kernel's own roofline entry -- the curve DESIGN 4.1 reads the "one resident round" explanation from
+            for tag, bb in (("cfg2_b16", 16), ("cfg2_b32", 32)):
+                lg = rollout_leg(args.config, bb, args.dtype, 6 if bb == 16 else 4, 2, dev, rank, world, dist, True, graph=False, reps=3)
+                workloads[tag] = compact(lg, 6 if bb == 16 else 4)
+                workloads[tag]["timing"] = lg["timing"]
+                del lg
+                torch.cuda.empty_cache()
             for tag, gr in (("cfg2_b1", False), ("cfg2_b1_graph", True)):
                 lg = rollout_leg(args.config, 1, args.dtype, 20, 4, dev, rank, world, dist, False, graph=gr)
                 workloads[tag] = compact(lg, 20)
@@ -690,7 +741,11 @@ def main():
                "config": {"workload": os.path.basename(args.config), "fields": D, "resolution": list(res), "batch_per_gpu": B,
                           "n_steps_input": T_in, "n_steps_rollout": n_steps, "taylor_order": cfg["model"].get("taylor_order", 1),
                           "attn_axes": cfg["model"].get("attn_axes"), "parallelism": f"batch-sharded x{world} (no collective)",
-                          "hip_graph": graph_mode},
+                          "hip_graph": graph_mode, "timing": timing_main,
+                          "h2d": "excluded (the window is resident in HBM when the timed region starts); PCIe-inclusive, a host-resident window of "
+                                 "%.1f MB per sample over PCIe Gen5 x16 (63 GB/s): ~%.0f frames/s" % (
+                                     T_in * D * res[0] * res[1] * 4 / 1e6,
+                                     B * n_steps / (1e-3 * 1e3 * elapsed / args.steps + B * T_in * D * res[0] * res[1] * 4 / 63e9))},
                "roofline": roofline, "cpu_baseline": cpu, "train": train, "workloads": workloads}
         if plumbing or (world > 1 and backend != "nccl"):
             out["plumbing"] = (f"NOT A PERFORMANCE NUMBER: {world} ranks share GPU 0 and the collectives go through '{backend}' "

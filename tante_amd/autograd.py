@@ -165,6 +165,30 @@ def _graph_task() -> int:
 
 _FOLD_DIRTY = {}     # id -> accumulator buffer of a FoldFn whose backward has not consumed (and thereby zeroed) it yet
 
+# id(frame encoding) -> the gradient accumulator FilmPosFramesFn nodes of ONE backward pass share (see its backward)
+_FRAME_ACC = {"task": -1, "acc": {}}
+
+
+def _drop_frame_accumulators():
+    _FRAME_ACC["task"] = -1
+    _FRAME_ACC["acc"] = {}
+
+
+def _frame_accumulators():
+    """The table of the backward pass this thread is executing (created on its first use, dropped by an engine callback when the pass
+    ends and by reset_backward_state); None outside a backward pass: nothing is shared then, every node returns its own gradient."""
+    task = _graph_task()
+    if task < 0:
+        return None
+    if _FRAME_ACC["task"] != task:
+        _FRAME_ACC["task"], _FRAME_ACC["acc"] = task, {}
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(_drop_frame_accumulators)
+        except RuntimeError:
+            _drop_frame_accumulators()
+            return None
+    return _FRAME_ACC["acc"]
+
 
 def reset_backward_state(after: bool = False):
     """Forget everything recorded for a backward pass that is not running any more.  'armed' means "the engine's end-of-backward
@@ -173,6 +197,7 @@ def reset_backward_state(after: bool = False):
     finally -- after every loss.backward(), so operands recorded by a dead pass can never reach a later step's gradient slots."""
     _DEFER["pending"].clear()
     _FOLD_PENDING.clear()
+    _drop_frame_accumulators()
     _DEFER["bytes"] = 0
     _DEFER["armed"] = False
     _DEFER["task"] = -1
@@ -1110,15 +1135,8 @@ class FilmPosFramesFn(Function):
         L.check(L.lib().tante_film_pos_fwd_frames(C.byref(fr), a.data_ptr(), b.data_ptr(), s_emb.data_ptr(), B, T, HW, Cc, y.data_ptr(), _s()),
                 "film_pos_fwd_frames")
         ctx.save_for_backward(a, *frames)
-        # the Python objects (saved_tensors hands back fresh wrappers): the per-frame window counts and the accumulators live on them
+        # the Python objects (saved_tensors hands back fresh wrappers): their identity keys the per-backward-pass accumulators below
         ctx.frame_objs, ctx.a_obj, ctx.b_obj, ctx.s_obj = frames, a, b, s_emb
-        for f in frames:
-            if f.requires_grad:
-                st = getattr(f, "_tante_fwin", None)
-                if st is None:
-                    f._tante_fwin = [1, 0, None]          # [windows that hold the frame, contributions so far, accumulator]
-                else:
-                    st[0] += 1
         return y
 
     @staticmethod
@@ -1131,30 +1149,30 @@ class FilmPosFramesFn(Function):
         # Gradients that several calls of a BPTT rollout contribute to are accumulated IN PLACE by the kernel instead of returned as fresh
         # tensors for autograd to sum (one elementwise add + one temporary per use: 9 adds of 6 MB for the frame encodings, 6 for the
         # tables, 3 for s_emb per train step):
-        #   * a frame encoding sits in up to T windows; the windows' nodes run in reverse call order (call k + 1 depends on call k), so
-        #     the first node to run allocates the frame's accumulator, later ones add, and the node that completes the count returns it;
+        #   * a frame encoding sits in up to T windows.  The FIRST of their nodes to run in a backward pass allocates the frame's
+        #     accumulator, has the kernel WRITE it and RETURNS it: the engine keeps that tensor (by reference) as the pending gradient of
+        #     the frame's producer.  Every later node of the same pass has the kernel ADD into the same storage and returns None.  The
+        #     producer runs once all of the pass's consumers of the frame have run (the engine's own dependency count), so it sees the
+        #     sum of exactly the windows that took part -- whichever they are: a loss on some calls only, torch.autograd.grad with an
+        #     inputs subset, a second pass over a retained graph (the table is keyed to the graph task and dropped when it ends);
         #   * the FiLM tables come from ONE FilmTableFn node per rollout and carry accumulators (`_tante_grad`) that node reads;
         #   * s_emb is a parameter: its .grad slot is added to directly.
         objs = ctx.frame_objs
+        if objs is None:
+            raise RuntimeError("FilmPosFramesFn.backward: the node's frame records are gone (backward through a freed graph?)")
+        acc = _frame_accumulators()
         mask, dvs, rets = 0, [], []
         for t, f in enumerate(objs):
-            st = getattr(f, "_tante_fwin", None)
-            if st is None or st[0] <= 1:              # used by this window only: an ordinary gradient
+            g = None if acc is None else acc.get(id(f))
+            if g is None:                             # first contribution of this pass: write, and hand the tensor to the engine
                 g = torch.empty(B, HW, Cc, dtype=torch.float32, device=dev)
-                dvs.append(g)
+                if acc is not None:
+                    acc[id(f)] = g
                 rets.append(g)
-                continue
-            if st[2] is None:                         # first contribution (the LAST window that holds the frame): write
-                st[2] = torch.empty(B, HW, Cc, dtype=torch.float32, device=dev)
-            else:
+            else:                                     # the engine already holds g for the frame's producer: add in place
                 mask |= 1 << t
-            st[1] += 1
-            dvs.append(st[2])
-            if st[1] == st[0]:                        # every window has contributed: the sum flows on to the frame's encoder node
-                rets.append(st[2])
-                f._tante_fwin = None
-            else:
                 rets.append(None)
+            dvs.append(g)
         ga, gb, gs = _grad_slot(ctx.a_obj), _grad_slot(ctx.b_obj), _grad_slot(ctx.s_obj)
         flags = 0
         if ga is not None and gb is not None:
@@ -1170,7 +1188,6 @@ class FilmPosFramesFn(Function):
         ptrs = (C.c_void_p * T)(*[d.data_ptr() for d in dvs])
         L.check(L.lib().tante_film_pos_bwd_frames_acc(dy.data_ptr(), C.byref(fr), a.data_ptr(), B, HW, Cc, T, ptrs, mask, da.data_ptr(),
                                                       db.data_ptr(), ds.data_ptr(), flags, _s()), "film_pos_bwd_frames_acc")
-        ctx.frame_objs = ctx.a_obj = ctx.b_obj = ctx.s_obj = None
         return (None if flags & 1 else da, None if flags & 1 else db, None if flags & 2 else ds, *rets)
 
 
@@ -1233,6 +1250,7 @@ class FilmTableFn(Function):
         L.check(L.lib().tante_film_table_bwd(t.data_ptr(), rows, Cc, sc_w0.data_ptr(), sc_b0.data_ptr(), sc_w2.data_ptr(), sh_w0.data_ptr(),
                                              sh_b0.data_ptr(), sh_w2.data_ptr(), dA.data_ptr(), dB.data_ptr(), *[o.data_ptr() for o in outs],
                                              1 if direct else 0, _s()), "tante_film_table_bwd")
+        ctx.acc.zero_()      # consumed: a second pass over a retained graph starts from zeros again
         d_add = None
         if ctx.add is not None and ctx.add.requires_grad:
             d_add = dB.view(ctx.add.shape).clone() if dB.numel() == ctx.add.numel() else None
