@@ -253,7 +253,7 @@ int tante_block_fused_tprop(float* x, const void* block_stream, int C, int n_hea
  * stored in THEIR layouts, so that tante_layernorm_bwd / tante_attention_bwd / the data- and weight-gradient GEMMs run unchanged:
  *   xh1, xh2 (tokens, 256) bf16  LayerNorm outputs (no affine: gamma / beta are folded into the consumer weights)
  *   st1, st2 (tokens, 2) fp32    (mean, rstd) per token
- *   qkv (tokens, 768) bf16       packed projection, q NOT scaled, biases included
+ *   qkv (tokens, 768) bf16       packed projection, q NOT scaled, biases included (may be NULL: tante_block_bwd_fused recomputes it)
  *   o (tokens, 256) bf16         attention output (after probability dropout)
  *   x1 (tokens, 256) fp32        x + dropout(out_proj(o))   (may be NULL: tante_block_tail_bwd works from xh2 / st2 and never reads it)
  *   hpre, act (tokens, 256) bf16 fc1 pre-activation and its tanh-GELU
@@ -304,6 +304,22 @@ int tante_block_tail_bwd(const float* dout, const void* hpre, const void* xh2, c
  * W_in'[512:768]): the three row blocks of the folded weight, transposed into fragments like the tail's three weights. */
 int tante_block_head_bwd(const void* dqkv, const void* xh1, const float* st1, const float* dx1, const void* head_bwd_stream, int64_t M, int C,
                          float* dx, void* stream);
+
+/* The WHOLE backward of a TransformerBlock in ONE launch (block_bwd_fs.hip; attn_backbone.py:59-83 backwards, trainer/trainer.py:191):
+ * tante_block_tail_bwd + tante_attention_bwd + tante_block_head_bwd with nothing but LDS and registers in between, on the forward
+ * kernel's partition (a workgroup owns whole sequences of `seq`).  Reads dout (tokens, 256) fp32 and what tante_block_fused_train saved:
+ * xh1, xh2, hpre (tokens, 256) bf16 and st1, st2 (tokens, 2) fp32 -- NOT the packed projection: q | k | v are recomputed from xh1 with the
+ * forward's own weights (block_stream = the buffer tante_pack_block_train filled), so the training forward may be called with qkv = NULL.
+ * tail_bwd_stream = tante_pack_block_tail_bwd(fc2, folded fc1, out_proj), head_bwd_stream = the same packing of the three 256-row blocks
+ * of the folded in-projection weight.  Dropout masks are regenerated from (p_drop, seeds) as the forward drew them.  Writes dx (tokens,
+ * 256) fp32 and the bf16 row operands of the four weight gradients: dy2 (fc2: dW2 = dy2^T act), dhpre (fc1: dW1' = dhpre^T xh2), dy1
+ * (out-proj: dWo = dy1^T o), dqkv (tokens, 768) (in-proj: dW_in' = dqkv^T xh1).  Shapes: C = 256, 8 heads, hidden 256, L | 16 (any
+ * mask) or L in {32, 48, 64} non-causal (tante_block_bwd_fused_supported); others take the three launches above. */
+int tante_block_bwd_fused_supported(int C, int n_head, int hidden, int L, int causal);
+int tante_block_bwd_fused(const float* dout, const void* xh1, const float* st1, const void* hpre, const void* xh2, const float* st2,
+                          const void* tail_bwd_stream, const void* block_stream, const void* head_bwd_stream, int C, int n_head, int hidden,
+                          const TanteSeq* seq, int causal, float p_drop, uint64_t seed_attn, uint64_t seed_out, uint64_t seed_mlp, float* dx,
+                          void* dy2, void* dhpre, void* dy1, void* dqkv, void* stream);
 
 /* ---- fused derivative head (bf16 MFMA path) ----------------------------------------------------------
  * One launch per Taylor order: rows r = (img, hp, wp) of the token stream (gathered like TANTE_A_LINEAR: the last time slot by

@@ -106,6 +106,8 @@ SIGNATURES = {
     "tante_pack_block_tail_bwd": ([c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp], c_i32),
     "tante_block_tail_bwd": ([c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_f32, C.c_uint64, C.c_uint64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp], c_i32),
     "tante_block_head_bwd": ([c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_vp, c_vp], c_i32),
+    "tante_block_bwd_fused_supported": ([c_i32, c_i32, c_i32, c_i32, c_i32], c_i32),
+    "tante_block_bwd_fused": ([c_vp] * 9 + [c_i32, c_i32, c_i32, C.POINTER(Seq), c_i32, c_f32, C.c_uint64, C.c_uint64, C.c_uint64] + [c_vp] * 6, c_i32),
     "tante_pack_block_train": ([c_vp] * 8 + [c_i32, c_i32, c_vp, c_vp], c_i32),
     "tante_block_fused_train": ([c_vp, c_vp, c_i32, c_i32, c_i32, C.POINTER(Seq), c_i32, c_f32, C.POINTER(BlockTrain), c_vp], c_i32),
     "tante_head_fused_supported": ([c_i32, c_i32], c_i32),
@@ -217,7 +219,7 @@ LIB_OPTIONS = ("TANTE_ATTN_BWD_HG", "TANTE_ATTN_BWD_NO_SPLIT", "TANTE_ATTN_BWD_V
 
 
 _lib = None
-ABI_VERSION = 7      # include/tante_hip.h: bumped whenever an entry point is added or changes (round 4: 6 tante_head_enc_*, 7 tante_pos_embed_tmajor + tante_spectral_*bf16out*)
+ABI_VERSION = 8      # include/tante_hip.h: bumped whenever an entry point is added or changes (round 4: 6 tante_head_enc_*, 7 tante_pos_embed_tmajor + tante_spectral_*bf16out*; round 5: 8 tante_block_bwd_fused)
 
 
 def lib():

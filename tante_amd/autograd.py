@@ -699,10 +699,14 @@ class BlockFn(Function):
     launch per block the host, not the GPU, was setting the train step's time."""
 
     @staticmethod
-    def forward(ctx, x, w_in, b_in, Wo, bo, w1f, b1f, W2, b2, saved, bwd_stream, seq, n_head, causal, p, seeds, compute, head_stream=None):
+    def forward(ctx, x, w_in, b_in, Wo, bo, w1f, b1f, W2, b2, saved, bwd_stream, seq, n_head, causal, p, seeds, compute, head_stream=None,
+                fwd_stream=None):
         ctx.save_for_backward(x, saved["st1"], saved["xh1"], saved["qkv"], saved["o"], saved["hpre"], saved["xh2"], saved["st2"], saved["act"],
                               bwd_stream, w_in)
         ctx.head_stream = head_stream      # fragments of the folded in-projection weight's transpose (tante_block_head_bwd), or None
+        # the forward kernel's own weight stream: given = the backward is ONE launch (tante_block_bwd_fused) that recomputes q | k | v with
+        # it (saved["qkv"] is None then: the forward did not store the packed projection)
+        ctx.fwd_stream = fwd_stream
         ctx.params = (w_in, b_in, Wo, bo, w1f, b1f, W2, b2)
         ctx.meta = (seq, n_head, bool(causal), float(p), tuple(seeds), compute)
         return saved["out"]
@@ -713,6 +717,19 @@ class BlockFn(Function):
         x, st1, xh1, qkv, o, hpre, xh2, st2, act, bwd_stream, w_in_s = ctx.saved_tensors
         w_in, b_in, Wo, bo, w1f, b1f, W2, b2 = ctx.params
         seq, n_head, causal, p, seeds, compute = ctx.meta
+        if ctx.fwd_stream is not None:
+            dout = dout.contiguous()
+            if dout.dtype != torch.float32:
+                dout = dout.float()
+            M, Cc = xh1.shape
+            t = K.block_bwd_fused(dout, xh1, st1, hpre, xh2, st2, bwd_stream, ctx.fwd_stream, ctx.head_stream, Cc, n_head, hpre.shape[1], seq,
+                                  causal, p, seeds)
+            for W, b, dy, a in ((W2, b2, t["dy2"], act), (w1f, b1f, t["dhpre"], xh2), (Wo, bo, t["dy1"], o), (w_in, b_in, t["dqkv"], xh1)):
+                gW, gb = _grad_slot(W), _grad_slot(b)
+                N, Kk = W.shape
+                if not _defer_wgrad(gW, gb, dy, a, M, N, Kk, L.BF16):
+                    wgrad(_rm_linear(dy), _rm_linear(a), M, N, Kk, (N, Kk), L.BF16, device=a.device, with_bias=True, into=gW, db_into=gb)
+            return (t["dx"],) + (None,) * 18
         tail = NS(saved_tensors=(o, hpre, xh2, st2, act, bwd_stream), params=(Wo, bo, w1f, b1f, W2, b2), p=p, seed_out=seeds[1], seed_mlp=seeds[2])
         r = BlockTailFn.backward(tail, dout)
         d_o, dx1 = r[0], r[1]
@@ -725,11 +742,11 @@ class BlockFn(Function):
                 wgrad(_rm_linear(dqkv), _rm_linear(xh1), M, N, xh1.shape[1], (N, xh1.shape[1]), L.BF16, device=xh1.device, with_bias=True,
                       into=gW, db_into=gb)
             dx = K.block_head_bwd(dqkv, xh1, st1, dx1.contiguous(), ctx.head_stream, x.shape[1])
-            return (dx,) + (None,) * 17
+            return (dx,) + (None,) * 18
         dxh = LinearFn.backward(NS(saved_tensors=(xh1, w_in_s), compute=compute, has_bias=True, has_res=False, params=(w_in, b_in),
                                    needs_input_grad=(True, True, True, False, False, False, False)), dqkv)[0]
         dx = LayerNormSkipFn.backward(NS(saved_tensors=(x, st1)), dxh, dx1)[0]
-        return (dx,) + (None,) * 17
+        return (dx,) + (None,) * 18
 
 
 def block_tail_ready(*params) -> bool:
@@ -1250,10 +1267,10 @@ class FilmTableFn(Function):
         L.check(L.lib().tante_film_table_bwd(t.data_ptr(), rows, Cc, sc_w0.data_ptr(), sc_b0.data_ptr(), sc_w2.data_ptr(), sh_w0.data_ptr(),
                                              sh_b0.data_ptr(), sh_w2.data_ptr(), dA.data_ptr(), dB.data_ptr(), *[o.data_ptr() for o in outs],
                                              1 if direct else 0, _s()), "tante_film_table_bwd")
-        ctx.acc.zero_()      # consumed: a second pass over a retained graph starts from zeros again
         d_add = None
         if ctx.add is not None and ctx.add.requires_grad:
             d_add = dB.view(ctx.add.shape).clone() if dB.numel() == ctx.add.numel() else None
+        ctx.acc.zero_()      # consumed: a second pass over a retained graph starts from zeros again
         return (None, d_add) + ((None,) * 8 if direct else tuple(outs))
 
 

@@ -825,8 +825,8 @@ extern "C" int tante_block_fused(float* x, const void* block_stream, int C, int 
 
 extern "C" int tante_block_fused_train(const float* x, const void* block_stream, int C, int n_head, int hidden, const TanteSeq* seq, int causal,
                                        float eps, const TanteBlockTrain* tr, void* stream) {
-  if (!x || !block_stream || !seq || !tr || !tr->out || !tr->xh1 || !tr->qkv || !tr->o || !tr->xh2 || !tr->hpre || !tr->act || !tr->st1 ||
-      !tr->st2)      // x1 may be null: only the per-operator backward (LayerNorm2 from its input) reads it
+  if (!x || !block_stream || !seq || !tr || !tr->out || !tr->xh1 || !tr->o || !tr->xh2 || !tr->hpre || !tr->act || !tr->st1 ||
+      !tr->st2)      // x1 may be null: only the per-operator backward (LayerNorm2 from its input) reads it; qkv may be null: tante_block_bwd_fused recomputes it
     TANTE_FAIL(-1, "tante_block_fused_train: null pointer");
   if (!tante_fs_supported(C, n_head, hidden, seq->L, causal) || seq->L > 64)
     TANTE_FAIL(-2, "tante_block_fused_train: unsupported shape C=%d heads=%d hidden=%d L=%d", C, n_head, hidden, seq->L);

@@ -463,7 +463,7 @@ __global__ __launch_bounds__(64 * NW * G, 2) void block_fs_kernel(FsArgs A) {
     for (int hh = 0; hh < HPW; ++hh)
 #pragma unroll
       for (int tt = 0; tt < NTT; ++tt) qf[hh][tt] = pack8(aq[2 * hh][tt], aq[2 * hh + 1][tt]);
-    if constexpr (TRAIN) {   // the packed projection the attention backward reads holds q WITHOUT the softmax scale folded into Wq
+    if (TRAIN && A.qkv) {   // the packed projection the three-launch attention backward reads holds q WITHOUT the softmax scale folded into Wq
       const float unscale = 1.0f / (0.17677669529663687f * 1.44269504088896340736f);
 #pragma unroll
       for (int tt = 0; tt < NTT; ++tt) {      // through this wave's columns of bufB (its attention output goes there later)
@@ -493,7 +493,7 @@ __global__ __launch_bounds__(64 * NW * G, 2) void block_fs_kernel(FsArgs A) {
     for (int hh = 0; hh < HPW; ++hh)
 #pragma unroll
       for (int tt = 0; tt < NTT; ++tt) kf[hh][tt] = pack8(ak[2 * hh][tt], ak[2 * hh + 1][tt]);
-    if constexpr (TRAIN) {
+    if (TRAIN && A.qkv) {
 #pragma unroll
       for (int tt = 0; tt < NTT; ++tt) {
 #pragma unroll
@@ -518,7 +518,7 @@ __global__ __launch_bounds__(64 * NW * G, 2) void block_fs_kernel(FsArgs A) {
       for (int tt = 0; tt < NTT; ++tt) av[j][tt] = f32x4{bv, bv, bv, bv};
     }
     fs_slice_gemm<2, 24, NTT, RT, true, PF>(wq, wb, bufA, rdo, av);
-    if constexpr (TRAIN) {   // rows of this layout are tokens 4 kk + r, the lane is one feature: 2-byte LDS stores into the image rows
+    if (TRAIN && A.qkv) {   // rows of this layout are tokens 4 kk + r, the lane is one feature: 2-byte LDS stores into the image rows
 #pragma unroll
       for (int tt = 0; tt < NTT; ++tt) {
 #pragma unroll

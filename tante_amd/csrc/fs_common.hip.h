@@ -112,9 +112,15 @@ __device__ __forceinline__ void fs_wring_prime(const WP& wq, u32x4 (&wb)[PF + 1]
 #pragma unroll
     for (int j = 0; j < RT; ++j) wb[(8 * M + p) % (PF + 1)][j] = ldg_frag(wq, FS_WOFF(16 * FS_GROT(8 * M + p) + j) * FS_FRAG);
 }
-template <int M, int GEND, int NTT, int RT, bool SWAP, int PF, class WP>
+// HOOK (optional): called once per k-step with std::integral_constant<int, ks>, in front of the k-step's MFMAs -- work that should ride
+// the matrix phase instead of forming a burst of its own behind it (block_bwd_fs.hip spreads its row stores over the GEMMs this way)
+struct FsNoHook {
+  template <class KC>
+  __device__ __forceinline__ void operator()(KC) const {}
+};
+template <int M, int GEND, int NTT, int RT, bool SWAP, int PF, class WP, class HOOK = FsNoHook>
 __device__ __forceinline__ void fs_slice_gemm(const WP& wq, u32x4 (&wb)[PF + 1][RT], const char* img, const int (&rdo)[4],
-                                              f32x4 (&acc)[RT][NTT]) {
+                                              f32x4 (&acc)[RT][NTT], HOOK&& hook = FsNoHook{}) {
   unsigned ab[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) ab[j] = lds_addr(img + rdo[j]);
@@ -132,6 +138,7 @@ __device__ __forceinline__ void fs_slice_gemm(const WP& wq, u32x4 (&wb)[PF + 1][
 #pragma unroll
           for (int j = 0; j < RT; ++j) wb[(g + PF) % (PF + 1)][j] = ldg_frag(wq, FS_WOFF(16 * FS_GROT(g + PF) + j) * FS_FRAG);
         }
+        if constexpr (tt == 0) hook(std::integral_constant<int, ks>{});
 #ifdef FS_EXP_MFMA32
         // TIMING EXPERIMENT ONLY (wrong results): the same loads, the same operand and accumulator registers, half as many MFMAs of
         // twice the size -- v_mfma_f32_32x32x16_bf16 on the 2 x 2 groups of this wave's 16 x 16 tiles.  Prices the instruction shape

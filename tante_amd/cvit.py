@@ -25,6 +25,11 @@ from . import kernels as K
 from . import stages as S
 from .attn_backbone import _PackCache, _no_autograd, resolve_compute
 from .tante import TanteMetadata, s_emb_init, t_emb_init
+from . import options as _O
+
+# host switches of this module (options.set_option, or TANTE_<NAME>=<int> when the package is imported)
+CVIT_FUSED = _O.register("TANTE_CVIT_FUSED", True, __name__, "CVIT_FUSED")                # the block tail as one chain512 launch
+CVIT_CHAIN_QKV = _O.register("TANTE_CVIT_CHAIN_QKV", False, __name__, "CVIT_CHAIN_QKV")   # measured SLOWER (B = 1: 1.02 -> 1.11 ms): off
 
 
 class MlpBlock(nn.Module):
@@ -74,7 +79,7 @@ class _AttnBlock(nn.Module):
     def _chain_ok(self, compute: int, M: int, resid_rows: int) -> bool:
         """The one-launch tail (cvit_fused.hip): bf16, width 512, mlp_ratio 1, whole 16-token tiles."""
         return (compute == L.BF16 and self.emb_dim == 512 and self.mlp.fc1.out_features == 512 and M % 16 == 0 and resid_rows % 16 == 0
-                and L.get_option("TANTE_CVIT_FUSED", 1) != 0)
+                and CVIT_FUSED)
 
     def _chain_packed(self, extra=None):
         """out_proj | fc1 (LN2 folded) | fc2 [| the Mlp's dense layer] as one fragment stream + biases; extra = (norm2, Mlp) for mode 1."""
@@ -160,7 +165,7 @@ class SelfAttnBlock(_AttnBlock):
         if next_blk is None:
             return self._tail(o, x, pk, compute)
         if (self._chain_ok(compute, M, M) and next_blk.emb_dim == C_ and next_blk.num_heads * 64 == C_
-                and L.get_option("TANTE_CVIT_CHAIN_QKV", 0) != 0):      # measured SLOWER (B = 1: 1.02 -> 1.11 ms, B = 4: 1.80 -> 1.86): off
+                and CVIT_CHAIN_QKV):      # measured SLOWER (B = 1: 1.02 -> 1.11 ms, B = 4: 1.80 -> 1.86): off
             w, bias = self._chain_qkv_packed(next_blk)
             out = torch.empty(M, C_, dtype=torch.float32, device=x.device)
             nqkv = torch.empty(M, 3 * C_, dtype=torch.bfloat16, device=x.device)

@@ -408,17 +408,39 @@ def block_tail_bwd(dout: torch.Tensor, hpre, xh2, st2, bwd_stream, C_: int, hidd
     return t
 
 
+def block_bwd_fused_supported(C_: int, n_head: int, hidden: int, Lq: int, causal: bool) -> bool:
+    return bool(L.lib().tante_block_bwd_fused_supported(C_, n_head, hidden, Lq, int(causal)))
+
+
+def block_bwd_fused(dout: torch.Tensor, xh1, st1, hpre, xh2, st2, tail_bwd_stream, block_stream, head_bwd_stream, C_: int, n_head: int,
+                    hidden: int, seq: L.Seq, causal: bool, p_drop: float, seeds) -> dict:
+    """The whole backward of a block in ONE launch (tante_block_bwd_fused) -> {"dx" fp32 (M, 256); "dy2", "dhpre", "dy1" (M, 256) and
+    "dqkv" (M, 768) bf16: the row operands of the four weight gradients}.  seeds = (attention, out-proj, mlp) as the forward drew them."""
+    _dev(dout, xh1, st1, hpre, xh2, st2, tail_bwd_stream, block_stream, head_bwd_stream)
+    M = dout.numel() // C_
+    dev = dout.device
+    t = {"dx": torch.empty(M, C_, dtype=torch.float32, device=dev), "dqkv": torch.empty(M, 3 * C_, dtype=torch.bfloat16, device=dev)}
+    for k in ("dy2", "dhpre", "dy1"):
+        t[k] = torch.empty(M, C_, dtype=torch.bfloat16, device=dev)
+    L.check(L.lib().tante_block_bwd_fused(_p(dout), _p(xh1), _p(st1), _p(hpre), _p(xh2), _p(st2), _p(tail_bwd_stream), _p(block_stream),
+                                          _p(head_bwd_stream), C_, n_head, hidden, C.byref(seq), int(causal), float(p_drop), int(seeds[0]),
+                                          int(seeds[1]), int(seeds[2]), _p(t["dx"]), _p(t["dy2"]), _p(t["dhpre"]), _p(t["dy1"]), _p(t["dqkv"]),
+                                          _stream()), "tante_block_bwd_fused")
+    return t
+
+
 def block_fused_train(x: torch.Tensor, block_stream: torch.Tensor, C_: int, n_head: int, hidden: int, seq: L.Seq, causal: bool, eps: float,
-                      p_drop: float, seeds, need_x1: bool = True) -> dict:
+                      p_drop: float, seeds, need_x1: bool = True, need_qkv: bool = True) -> dict:
     """Training forward of a whole block in one launch (tante_block_fused_train): -> the block output and every saved tensor of the
     unfused operators (see include/tante_hip.h).  x (tokens, 256) fp32 is left untouched.  need_x1=False skips the fp32 residual after
-    the attention half (25 MB per launch at cfg3): the fused tail backward works from LayerNorm2's image and statistics."""
+    the attention half (25 MB per launch at cfg3): the fused tail backward works from LayerNorm2's image and statistics.  need_qkv=False
+    skips the packed projection (37.8 MB): the one-launch backward (block_bwd_fused) recomputes q | k | v from LayerNorm1's image."""
     _dev(x, block_stream)
     M = x.numel() // C_
     dev = x.device
     bf = lambda n: torch.empty(M, n, dtype=torch.bfloat16, device=dev)      # noqa: E731
     f32 = lambda n: torch.empty(M, n, dtype=torch.float32, device=dev)      # noqa: E731
-    t = {"out": f32(C_), "xh1": bf(C_), "qkv": bf(3 * C_), "o": bf(C_), "xh2": bf(C_), "hpre": bf(hidden), "act": bf(hidden),
+    t = {"out": f32(C_), "xh1": bf(C_), "qkv": bf(3 * C_) if need_qkv else None, "o": bf(C_), "xh2": bf(C_), "hpre": bf(hidden), "act": bf(hidden),
          "st1": f32(2), "x1": f32(C_) if need_x1 else None, "st2": f32(2)}
     tr = L.BlockTrain(*[(t[k].data_ptr() if t[k] is not None else None) for k in ("out", "xh1", "qkv", "o", "xh2", "hpre", "act", "st1", "x1", "st2")],
                       float(p_drop), int(seeds[0]), int(seeds[1]), int(seeds[2]))

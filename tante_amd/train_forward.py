@@ -58,6 +58,8 @@ BLOCK_RECORDS = _O.register("TANTE_TRAIN_BLOCK_RECORDS", True, __name__, "BLOCK_
 FUSED_ENC_ACT = _O.register("TANTE_TRAIN_FUSED_ENC_ACT", True, __name__, "FUSED_ENC_ACT")   # encoder GELUs inside the next stage's node
 FUSED_AXIS_HW = _O.register("TANTE_TRAIN_FUSED_AXIS", True, __name__, "FUSED_AXIS_HW")     # H + W propagators' training forward in one launch
 FUSED_HEAD_BACKWARD = _O.register("TANTE_TRAIN_FUSED_HEAD_BWD", True, __name__, "FUSED_HEAD_BACKWARD")   # q|k|v dgrad + LayerNorm1 backward in one launch
+# the WHOLE backward of a block in one launch (tante_block_bwd_fused: tail + attention backward + head, q | k | v recomputed); off: three launches
+FUSED_BLOCK_BACKWARD = _O.register("TANTE_TRAIN_FUSED_BLOCK_BWD", True, __name__, "FUSED_BLOCK_BACKWARD")
 
 
 BLOCK_CALLS = [0, 0]      # block_train calls / those that took the fused one-node path (GraphedTrainStep checks them at capture)
@@ -152,9 +154,10 @@ def block_train(blk, x: torch.Tensor, seq, causal: bool, compute: int) -> torch.
     if rec is not None and x.dtype == torch.float32 and x.is_contiguous():
         from .autograd import next_seed
         seeds = (next_seed(), next_seed(), next_seed()) if p > 0.0 else (0, 0, 0)
-        t = K.block_fused_train(x.detach(), rec[8], blk.embed_dim, blk.n_head, blk.hidden, seq, causal, rec[11], p, seeds, need_x1=False)
+        t = K.block_fused_train(x.detach(), rec[8], blk.embed_dim, blk.n_head, blk.hidden, seq, causal, rec[11], p, seeds, need_x1=False,
+                                need_qkv=not rec[12])
         BLOCK_CALLS[1] += 1
-        return BlockFn.apply(x, *rec[:8], t, rec[9], seq, blk.n_head, causal, p, seeds, compute, rec[10])
+        return BlockFn.apply(x, *rec[:8], t, rec[9], seq, blk.n_head, causal, p, seeds, compute, rec[10], rec[8] if rec[12] else None)
     adt = K.act_torch_dtype(compute)
     a, m = blk.attn, blk.mlp
     w_in, b_in = _folded(a.in_proj_weight, a.in_proj_bias, blk.ln1)
@@ -173,8 +176,13 @@ def block_train(blk, x: torch.Tensor, seq, causal: bool, compute: int) -> torch.
                 _FOLDS[key] = stream
         fused_tail = (FUSED_TAIL_BACKWARD and torch.is_grad_enabled()
                       and block_tail_ready(a.out_proj.weight, a.out_proj.bias, w1, b1, m[2].weight, m[2].bias))
+        # the whole backward in one launch: needs both transposed-fragment streams and every gradient slot (decided here: the forward then
+        # skips the packed projection, which only the three-launch attention backward reads)
+        fused_bwd = (fused_tail and FUSED_BLOCK_BACKWARD and FUSED_HEAD_BACKWARD and _FOLDS is not None and block_tail_ready(w_in, b_in)
+                     and w_in.shape == (3 * blk.embed_dim, blk.embed_dim)
+                     and K.block_bwd_fused_supported(blk.embed_dim, blk.n_head, blk.hidden, seq.L, causal))
         t = K.block_fused_train(x.detach(), stream, blk.embed_dim, blk.n_head, blk.hidden, seq, causal, blk.ln1.eps, p, seeds,
-                                need_x1=not fused_tail)
+                                need_x1=not fused_tail, need_qkv=not fused_bwd)
         if fused_tail:
             # the block behind its attention as ONE autograd node whose backward is ONE launch (tante_block_tail_bwd)
             key = ("bt_stream", id(blk))
@@ -196,10 +204,10 @@ def block_train(blk, x: torch.Tensor, seq, causal: bool, compute: int) -> torch.
                             _FOLDS[key] = hstream
                 if _FOLDS is not None:
                     _FOLDS[("blk_rec", id(blk), seq.L, compute)] = (w_in, b_in, a.out_proj.weight, a.out_proj.bias, w1, b1, m[2].weight, m[2].bias,
-                                                                    stream, bstream, hstream, blk.ln1.eps)
+                                                                    stream, bstream, hstream, blk.ln1.eps, fused_bwd and hstream is not None)
                 BLOCK_CALLS[1] += 1
                 return BlockFn.apply(x, w_in, b_in, a.out_proj.weight, a.out_proj.bias, w1, b1, m[2].weight, m[2].bias, t, bstream, seq,
-                                     blk.n_head, causal, p, seeds, compute, hstream)
+                                     blk.n_head, causal, p, seeds, compute, hstream, stream if (fused_bwd and hstream is not None) else None)
             xh, xs = LayerNormSkipFn.apply(x, blk.ln1.eps, adt, (t["xh1"], t["st1"]))
             qkv = LinearFn.apply(xh, w_in, b_in, None, compute, adt, t["qkv"])
             o = AttentionFn.apply(qkv, seq, blk.embed_dim, blk.n_head, causal, p, (t["o"], seeds[0]))

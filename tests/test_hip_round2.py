@@ -88,7 +88,7 @@ def test_attention_mfma_fwd_bwd_against_float64_sdpa(dev, letter, B, T, H, W, ca
 # ---------------------------------------------------------------------------------------------------
 # g14: the production-shape train step against the REFERENCE's gradients
 # ---------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("fused_fwd", ["fwd+tail_bwd", "fwd", "none"])
+@pytest.mark.parametrize("fused_fwd", ["fwd+block_bwd", "fwd+tail_bwd", "fwd", "none"])
 @pytest.mark.parametrize("defer", [True, False])
 @pytest.mark.parametrize("mode", ["bf16", "fp32"])
 def test_g14_wide_train_step(dev, mode, defer, fused_fwd, monkeypatch):
@@ -104,10 +104,11 @@ def test_g14_wide_train_step(dev, mode, defer, fused_fwd, monkeypatch):
         pytest.skip("the fused training kernels are bf16: fp32 has one path")
     monkeypatch.setattr(A, "DEFER_WGRAD", defer)
     monkeypatch.setattr(TF, "FUSED_TRAIN_FORWARD", fused_fwd != "none")      # one launch per block (tante_block_fused_train) vs one per operator
-    monkeypatch.setattr(TF, "FUSED_TAIL_BACKWARD", fused_fwd == "fwd+tail_bwd")   # + one launch for the block tail's backward
+    monkeypatch.setattr(TF, "FUSED_TAIL_BACKWARD", fused_fwd in ("fwd+tail_bwd", "fwd+block_bwd"))   # + one launch for the block tail's backward
+    monkeypatch.setattr(TF, "FUSED_BLOCK_BACKWARD", fused_fwd == "fwd+block_bwd")   # round 5: ONE launch for the whole block's backward
     m, batch, g, names = g14_setup()
     m = m.to(dev).train().set_compute(mode)
-    if fused_fwd == "fwd+tail_bwd":
+    if fused_fwd in ("fwd+tail_bwd", "fwd+block_bwd"):
         opt = tante_amd.FlatAdamW(m.parameters(), lr=1e-4)      # the one-launch tail backward adds into the parameters' accumulators
         opt.zero_grad()
         from tante_amd.autograd import block_tail_ready
@@ -362,10 +363,11 @@ def test_fused_training_forward_equals_unfused(dev, letter, B, T, H, W, p, monke
     w = torch.randn(n, 256, generator=torch.Generator().manual_seed(n + 1)).to(dev)
     opt = tante_amd.FlatAdamW(blk.parameters(), lr=1e-3)     # gives every parameter its accumulator (the fused tail backward adds into them)
     res = {}
-    for fused in ("tail", "tail_nohead", True, False):
+    for fused in ("block", "tail", "tail_nohead", True, False):
         monkeypatch.setattr(TF, "FUSED_TRAIN_FORWARD", bool(fused))
-        monkeypatch.setattr(TF, "FUSED_TAIL_BACKWARD", fused in ("tail", "tail_nohead"))
-        monkeypatch.setattr(TF, "FUSED_HEAD_BACKWARD", fused == "tail")      # q | k | v dgrad + LayerNorm1 backward in one launch
+        monkeypatch.setattr(TF, "FUSED_TAIL_BACKWARD", fused in ("block", "tail", "tail_nohead"))
+        monkeypatch.setattr(TF, "FUSED_HEAD_BACKWARD", fused in ("block", "tail"))      # q | k | v dgrad + LayerNorm1 backward in one launch
+        monkeypatch.setattr(TF, "FUSED_BLOCK_BACKWARD", fused == "block")     # round 5: the whole backward in ONE launch (where the shape has one)
         A._SEED[0] = 1000                                     # every run draws the same three seeds
         opt.zero_grad()
         x = x0.clone().requires_grad_(True)
@@ -375,6 +377,21 @@ def test_fused_training_forward_equals_unfused(dev, letter, B, T, H, W, p, monke
         res[fused] = (y.detach().cpu(), x.grad.cpu(), {k: v.grad.detach().cpu().clone() for k, v in blk.named_parameters()})
     (yt, gxt, gpt), (yf, gxf, gpf), (yu, gxu, gpu) = res["tail"], res[True], res[False]
     assert torch.equal(yt, yf)                                # same forward kernel
+    # round 5: tante_block_bwd_fused (tail + attention backward + head in one launch, q | k | v recomputed; the forward then stores no packed
+    # projection) against the three launches and against the operator-by-operator backward, same seeds = same masks
+    yb, gxb, gpb = res["block"]
+    assert torch.equal(yb, yt)
+    e = max_rel(gxb, gxt)
+    record_parity(rel_err(gxb, gxt), e, 2e-2, "bf16", f"one-launch block backward vs three launches, dx, {letter} L={seq.L}, p={p}")
+    assert e < 2e-2, e
+    assert max_rel(gxb, gxu) < 4e-2, max_rel(gxb, gxu)
+    for k in gpb:
+        if "in_proj_bias" in k:
+            a_, b_ = torch.cat([gpb[k][:256], gpb[k][512:]]), torch.cat([gpu[k][:256], gpu[k][512:]])
+        else:
+            a_, b_ = gpb[k], gpu[k]
+        record_parity(rel_err(a_, b_), max_rel(a_, b_), 4e-2, "bf16", f"one-launch block backward vs unfused, {k}, p={p}")
+        assert max_rel(a_, b_) < 4e-2, ("block", k, max_rel(a_, b_))
     gxn, gpn = res["tail_nohead"][1], res["tail_nohead"][2]   # one-launch front of the backward vs GEMM + LayerNorm backward
     record_parity(rel_err(gxt, gxn), max_rel(gxt, gxn), 2e-2, "bf16", f"fused head backward vs dgrad GEMM + LayerNorm backward, dx, p={p}")
     assert max_rel(gxt, gxn) < 2e-2, max_rel(gxt, gxn)

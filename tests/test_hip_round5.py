@@ -82,3 +82,127 @@ def test_frame_gradients_second_pass_over_a_retained_graph(dev, monkeypatch):
         worst = max(worst, e)
         assert e < 2e-5, (k, e)
     record_parity(worst, worst, 2e-5, "fp32", "FilmPosFramesFn: two passes over a retained graph = 2 x one pass")
+
+
+# ---------------------------------------------------------------------------------------------------
+# tante_block_bwd_fused: the whole backward of a TransformerBlock in one launch
+# ---------------------------------------------------------------------------------------------------
+def _block64(x, blk, idx, causal):
+    """The block in float64 on the CPU from the module's own parameters (attn_backbone.py:59-83, eval-mode arithmetic)."""
+    import torch.nn.functional as F
+    from test_hip_round2 import _sdpa64
+    P = {k: v.detach().double().cpu().requires_grad_(True) for k, v in blk.named_parameters()}
+    h = F.layer_norm(x, (256,), P["ln1.weight"], P["ln1.bias"], blk.ln1.eps)
+    qkv = h @ P["attn.in_proj_weight"].T + P["attn.in_proj_bias"]
+    o = _sdpa64(qkv, idx, 8, causal)
+    x1 = x + o @ P["attn.out_proj.weight"].T + P["attn.out_proj.bias"]
+    h2 = F.layer_norm(x1, (256,), P["ln2.weight"], P["ln2.bias"], blk.ln2.eps)
+    hp = h2 @ P["mlp.0.weight"].T + P["mlp.0.bias"]
+    return x1 + F.gelu(hp, approximate="tanh") @ P["mlp.2.weight"].T + P["mlp.2.bias"], P
+
+
+BWD_SHAPES = [("T", 1, 4, 16, 48), ("H", 1, 4, 16, 48), ("W", 1, 4, 16, 48),      # cfg3's three letters: L = 4 (causal), 16, 48
+              ("T", 1, 4, 5, 7),          # 35 sequences of 4: the last workgroup (12 per workgroup) has one live sequence
+              ("H", 1, 2, 8, 5),          # L = 8: 10 sequences, 6 per workgroup
+              ("T", 2, 2, 4, 4),          # L = 2, causal
+              ("W", 2, 1, 3, 32),         # L = 32: two tiles per sequence, 32-token workgroups
+              ("W", 1, 1, 3, 64),         # L = 64: four tiles per sequence, one workgroup per CU
+              ("H", 3, 1, 1, 2)]          # L = 1: attention is the identity on v
+
+
+@pytest.mark.parametrize("letter,B,T,H,W", BWD_SHAPES)
+def test_block_backward_in_one_launch_against_float64(dev, letter, B, T, H, W, monkeypatch):
+    """One TransformerBlock (C = 256, 8 heads, train() mode, dropout 0) through the one-launch training forward and the ONE-LAUNCH
+    backward (tante_block_bwd_fused: q | k | v recomputed, the attention's backward between the two token-wise halves in LDS): the
+    gradient of the input and of every parameter against float64 autograd of the same block on the CPU.  Bar: bf16 gradients, 4e-2 of
+    each tensor's largest entry (measured: see the parity report).  Also: the forward really stored no packed projection."""
+    import tante_amd
+    from tante_amd import autograd as A, train_forward as TF, kernels as Kk, _lib as L
+    from test_hip_round2 import _seq_tokens
+    torch.manual_seed(17)
+    blk = tante_amd.TransformerBlock(256, 8, mlp_ratio=1.0, dropout=0.0).to(dev).train()
+    with torch.no_grad():
+        for ln in (blk.ln1, blk.ln2):
+            ln.weight.add_(0.2 * torch.randn_like(ln.weight))
+            ln.bias.add_(0.2 * torch.randn_like(ln.bias))
+        blk.attn.in_proj_bias.add_(0.2 * torch.randn_like(blk.attn.in_proj_bias))
+        blk.attn.out_proj.bias.add_(0.2 * torch.randn_like(blk.attn.out_proj.bias))
+    causal = letter == "T"
+    seq = Kk.make_seq(letter, B, T, H, W)
+    assert Kk.block_bwd_fused_supported(256, 8, 256, seq.L, causal)
+    n = B * T * H * W
+    x0 = torch.randn(n, 256, generator=torch.Generator().manual_seed(n)) * 1.3 + 0.2
+    w = torch.randn(n, 256, generator=torch.Generator().manual_seed(n + 1))
+    opt = tante_amd.FlatAdamW(blk.parameters(), lr=1e-3)
+    opt.zero_grad()
+    calls = []
+    real = Kk.block_bwd_fused
+    monkeypatch.setattr(Kk, "block_bwd_fused", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    x = x0.to(dev).requires_grad_(True)
+    with TF.fold_scope():
+        y = TF.block_train(blk, x, seq, causal, L.BF16)
+        assert y.grad_fn.saved_tensors[3] is None, "the forward stored the packed projection although the backward recomputes it"
+        A.run_backward((y * w.to(dev)).sum())
+    assert calls == [1], "the one-launch backward did not run"
+    x64 = x0.double().requires_grad_(True)
+    y64, P = _block64(x64, blk, _seq_tokens(seq), causal)
+    (y64 * w.double()).sum().backward()
+    e = max_rel(y.detach().cpu(), y64.detach())
+    record_parity(rel_err(y.detach().cpu(), y64.detach()), e, 1e-2, "bf16", f"block training forward vs float64, {letter} L={seq.L}")
+    assert e < 1e-2, e
+    e = max_rel(x.grad.cpu(), x64.grad)
+    record_parity(rel_err(x.grad.cpu(), x64.grad), e, 4e-2, "bf16", f"one-launch block backward vs float64, dx, {letter} L={seq.L}")
+    assert e < 4e-2 and rel_err(x.grad.cpu(), x64.grad) < 1e-2, (e, rel_err(x.grad.cpu(), x64.grad))
+    for k, p in blk.named_parameters():
+        a_, b_ = p.grad.detach().cpu(), P[k].grad
+        if k == "attn.in_proj_bias":      # its k third is zero up to rounding (a key bias cannot change a softmax)
+            a_, b_ = torch.cat([a_[:256], a_[512:]]), torch.cat([b_[:256], b_[512:]])
+        if seq.L == 1 and k in ("attn.in_proj_weight", "attn.in_proj_bias"):      # L = 1: q and k gradients vanish identically; compare v
+            a_, b_ = a_[-256:], b_[-256:]
+        e = max_rel(a_, b_)
+        record_parity(rel_err(a_, b_), e, 4e-2, "bf16", f"one-launch block backward vs float64, {k}, {letter} L={seq.L}")
+        assert e < 4e-2, (k, e)
+
+
+@pytest.mark.parametrize("letter,B,T,H,W", [("T", 1, 4, 16, 48), ("H", 1, 4, 16, 48), ("W", 1, 4, 16, 48), ("H", 1, 2, 8, 5), ("W", 2, 1, 3, 32)])
+def test_block_backward_in_one_launch_row_operands(dev, letter, B, T, H, W):
+    """tante_block_bwd_fused against the three launches it replaces (tante_block_tail_bwd, tante_attention_bwd, tante_block_head_bwd) on the
+    tensors ONE training forward saved, with dropout 0.1 and the same seeds: the row operands of the fc2 / fc1 / out-proj weight gradients
+    are BIT-IDENTICAL (same arithmetic, same masks); dq | dk | dv and dx differ by the q | k | v recompute (q' rounded with the softmax
+    scale folded in, exp2 domain) -- bf16 bar."""
+    import tante_amd
+    from tante_amd import kernels as Kk, _lib as L, train_forward as TF
+    torch.manual_seed(23)
+    blk = tante_amd.TransformerBlock(256, 8, mlp_ratio=1.0, dropout=0.1).to(dev).train()
+    causal = letter == "T"
+    seq = Kk.make_seq(letter, B, T, H, W)
+    n = B * T * H * W
+    x = (torch.randn(n, 256, generator=torch.Generator().manual_seed(n)) * 1.3 + 0.2).to(dev)
+    dout = torch.randn(n, 256, generator=torch.Generator().manual_seed(n + 2)).to(dev)
+    a, m = blk.attn, blk.mlp
+    with torch.no_grad(), TF.fold_scope():
+        w_in, b_in = TF._folded(a.in_proj_weight, a.in_proj_bias, blk.ln1)
+        w1, b1 = TF._folded(m[0].weight, m[0].bias, blk.ln2)
+        w_in, b_in, w1, b1 = w_in.detach(), b_in.detach(), w1.detach(), b1.detach()
+        fs = Kk.pack_block_train((w_in, b_in, a.out_proj.weight, a.out_proj.bias, w1, b1, m[2].weight, m[2].bias), 256, 256)
+        bst = Kk.pack_block_tail_bwd(m[2].weight, w1, a.out_proj.weight, 256, 256)
+        hst = Kk.pack_block_tail_bwd(w_in[0:256], w_in[256:512], w_in[512:768], 256, 256)
+    seeds = (0x1234567890ABCDEF, 0x0FEDCBA987654321, 0x55AA55AA12345678)
+    t = Kk.block_fused_train(x, fs, 256, 8, 256, seq, causal, blk.ln1.eps, 0.1, seeds, need_x1=False)
+    r = Kk.block_tail_bwd(dout, t["hpre"], t["xh2"], t["st2"], bst, 256, 256, 0.1, seeds[1], seeds[2])
+    dqkv = torch.empty_like(t["qkv"])
+    s = torch.cuda.current_stream().cuda_stream
+    L.check(L.lib().tante_attention_bwd(t["qkv"].data_ptr(), r["do"].data_ptr(), dqkv.data_ptr(), L.BF16, 256, 8, Ct.byref(seq), int(causal), 0.1,
+                                        seeds[0], s), "attention_bwd")
+    dx3 = Kk.block_head_bwd(dqkv, t["xh1"], t["st1"], r["dx1"], hst, 256)
+    f = Kk.block_bwd_fused(dout, t["xh1"], t["st1"], t["hpre"], t["xh2"], t["st2"], bst, fs, hst, 256, 8, 256, seq, causal, 0.1, seeds)
+    for k in ("dy2", "dhpre", "dy1"):
+        assert torch.equal(f[k], r[k]), k
+    for i, name in enumerate(("dq", "dk", "dv")):
+        a_, b_ = f["dqkv"][:, 256 * i:256 * (i + 1)].float().cpu(), dqkv[:, 256 * i:256 * (i + 1)].float().cpu()
+        e = max_rel(a_, b_)
+        record_parity(rel_err(a_, b_), e, 2e-2, "bf16", f"one-launch block backward vs tante_attention_bwd, {name}, {letter} L={seq.L}, p=0.1")
+        assert e < 2e-2 and rel_err(a_, b_) < 1e-2, (name, e, rel_err(a_, b_))
+    e = max_rel(f["dx"].cpu(), dx3.cpu())
+    record_parity(rel_err(f["dx"].cpu(), dx3.cpu()), e, 2e-2, "bf16", f"one-launch block backward vs three launches, dx, {letter} L={seq.L}, p=0.1")
+    assert e < 2e-2 and rel_err(f["dx"].cpu(), dx3.cpu()) < 5e-3, (e, rel_err(f["dx"].cpu(), dx3.cpu()))

@@ -401,6 +401,15 @@ def test_library_option_allow_list_matches_the_sources():
             found |= set(re.findall(r'tante_opt\("(TANTE_[A-Z0-9_]*)"', fh.read()))
     assert found == set(L.LIB_OPTIONS), (sorted(found - set(L.LIB_OPTIONS)), sorted(set(L.LIB_OPTIONS) - found))
     assert len(L.LIB_OPTIONS) <= 64 and all(len(n) < 48 for n in L.LIB_OPTIONS)
+    # ... and every switch the Python package itself reads through get_option is one set_option can reach (two CViT
+    # switches were read from the library table but neither registered nor on the allow-list: TANTE_CVIT_FUSED=0 measured the default)
+    from tante_amd import options as O
+    host = set(O.host_options())
+    for f in glob.glob(os.path.join(root, "tante_amd", "*.py")):
+        with open(f) as fh:
+            for name in re.findall(r'get_option\("(TANTE_[A-Z0-9_]*)"', fh.read()):
+                assert name in host or name in L.LIB_OPTIONS, (os.path.basename(f), name)
+    assert "TANTE_CVIT_FUSED" in host and "TANTE_CVIT_CHAIN_QKV" in host and "TANTE_TRAIN_FUSED_BLOCK_BWD" in host
 
 
 def test_fno_refuses_neuralop_state_dicts_and_has_the_as_written_mode():

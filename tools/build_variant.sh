@@ -10,7 +10,7 @@ eflags=""
 case $base in
   block_fused) eflags="-fno-honor-nans -DTANTE_MFMA_SETPRIO -mllvm -amdgpu-sched-strategy=max-ilp";;
   block_sliced) eflags="-fno-honor-nans -DTANTE_MFMA_SETPRIO -DFS_PRIO=1";;
-  block_bwd) eflags="-fno-honor-nans -DTANTE_MFMA_SETPRIO -DBT_PRIO";;
+  block_bwd|block_bwd_fs) eflags="-fno-honor-nans -DTANTE_MFMA_SETPRIO -DBT_PRIO";;
   head_fused|head_enc|enc_fused|operators|spectral_dft) eflags="-fno-honor-nans";;
   pointwise) eflags="";;
 esac
