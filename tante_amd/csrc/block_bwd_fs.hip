@@ -39,6 +39,20 @@
 #include "fs_common.hip.h"
 #include "block_sliced.h"
 
+// Structure switches (each pair computes the same function; tools/build_variant.sh builds the other forms, tools/ab_train.sh times them on
+// the cfg3 train step on ONE box).  Measured, round 5, B = 8, ms per train step, two interleaved rounds (gpurun_out/r05_ab_train_1.log ->
+// profiles/r05_block_bwd_ab.log): three launches 9.45 / 9.45; DMA rows + burst stores + dx1 in registers 9.34 / 9.40 (the default);
+// everything off (the first form of the round) 9.39 / 9.40; + stores riding the GEMMs 9.38 / 9.48; + dx1 parked in memory 9.71 / 9.67.
+#ifndef BF_DMA_ROWS
+#define BF_DMA_ROWS 1      // 1: hpre / xh2 / xh1 rows take turns in image C by LDS-DMA; 0: accumulator-layout global loads (xh1's image by DMA at the start)
+#endif
+#ifndef BF_HOOK_STORES
+#define BF_HOOK_STORES 0   // 1: bf16 row stores ride the k-steps of the following GEMM; 0: issued together behind the phase that wrote the image
+#endif
+#ifndef BF_PARK_DX1
+#define BF_PARK_DX1 0      // 1: dx1 waits in the output buffer between LayerNorm2's backward and the end (+50 MB per launch); 0: in 48 registers
+#endif
+
 namespace {
 
 struct BfArgs {
@@ -120,7 +134,8 @@ struct BfSeqMap {
 
 // TPS = token tiles per sequence (L = 16 TPS), 1 also for L | 16 (several sequences per tile, block-diagonal mask).  NTT = token tiles per
 // workgroup (a multiple of TPS).  Two workgroups per CU at NTT <= 3 (3 x 24 KiB of images each).
-template <int TPS, int NTT>
+// DROP: dropout compiled in (p > 0) or out -- the mask arithmetic is a third of the attention phase's instructions
+template <int TPS, int NTT, bool DROP>
 __global__ __launch_bounds__(256, NTT <= 3 ? 2 : 1) void block_bwd_fs_kernel(BfArgs A) {
 #ifdef BT_PRIO
   if ((__builtin_amdgcn_s_getreg(0x1804) & 1u) == 1u) __builtin_amdgcn_s_setprio(3);      // as FS_PRIO in block_sliced.hip: the odd hardware wave slots
@@ -140,7 +155,7 @@ __global__ __launch_bounds__(256, NTT <= 3 ? 2 : 1) void block_bwd_fs_kernel(BfA
   const int L = A.sq.L;
   const int seq0 = (int)blockIdx.x * A.spw;
   const int nlive = min(A.spw, A.sq.nseq - seq0) * L;
-  const float ksc = A.p > 0.0f ? 1.0f / (1.0f - A.p) : 1.0f;
+  const float ksc = DROP ? 1.0f / (1.0f - A.p) : 1.0f;
 
   const FsW wqt = fs_wstream(A.wt, (unsigned)((RT * wave) * FS_FRAG + lane * 16));
   const FsW wqf = fs_wstream(A.wf, (unsigned)((RT * wave) * FS_FRAG + lane * 16));
@@ -265,6 +280,19 @@ __global__ __launch_bounds__(256, NTT <= 3 ? 2 : 1) void block_bwd_fs_kernel(BfA
     };
   };
   static_assert(16 / RPB == 2 && 2 * NTT <= 8, "a tensor's row stores fit the k-steps of one GEMM");
+  auto rows_burst = [&](const char* img, unsigned short* __restrict__ dst, long dstride, int dcol) {      // BF_HOOK_STORES == 0: all at once
+    static_for<2 * NTT>([&](auto i_c) {
+      constexpr int i = decltype(i_c)::value;
+      img_rows_store1(img, std::integral_constant<int, i / 2>{}, std::integral_constant<int, i % 2>{}, dst, dstride, dcol);
+    });
+  };
+#if BF_HOOK_STORES
+#define BF_HOOK(img, dst, stride, col) rows_hook(img, dst, stride, col)
+#define BF_BURST(img, dst, stride, col)
+#else
+#define BF_HOOK(img, dst, stride, col) FsNoHook{}
+#define BF_BURST(img, dst, stride, col) rows_burst(img, dst, stride, col)
+#endif
 
   // ---- per-lane LDS addressing (block_sliced.hip) ----------------------------------------------------------------------------------------
   int rdo[4], wro[RT];
@@ -281,7 +309,7 @@ __global__ __launch_bounds__(256, NTT <= 3 ? 2 : 1) void block_bwd_fs_kernel(BfA
     off[tt] = (long)(lv[tt] ? tokidx[tt] : 0) * FS_C + col0;
   }
   auto drop4 = [&](const f32x4& v, unsigned long long seed, long i0) {
-    if (A.p <= 0.0f) return v;
+    if constexpr (!DROP) return v;
     const unsigned k01 = dropout_keep2(seed, (unsigned long long)i0, A.p), k23 = dropout_keep2(seed, (unsigned long long)i0 + 2, A.p);
     return f32x4{(k01 & 1u) ? v[0] * ksc : 0.0f, (k01 & 2u) ? v[1] * ksc : 0.0f, (k23 & 1u) ? v[2] * ksc : 0.0f, (k23 & 2u) ? v[3] * ksc : 0.0f};
   };
@@ -294,7 +322,11 @@ __global__ __launch_bounds__(256, NTT <= 3 ? 2 : 1) void block_bwd_fs_kernel(BfA
     f32x4 raw[NTT][RT];
     slice_load(A.dout, raw);      // the rows everything waits for: first in the memory queue
     asm volatile("" ::: "memory");
+#if BF_DMA_ROWS
     dma_rows(A.hpre);
+#else
+    dma_rows(A.xh1);
+#endif
     slice_to_acc(imgB + wave * (IMG / NW), raw, g);      // image B: first written behind barrier 1
   }
 #pragma unroll
@@ -302,6 +334,7 @@ __global__ __launch_bounds__(256, NTT <= 3 ? 2 : 1) void block_bwd_fs_kernel(BfA
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) *(u32x2*)(imgA + tt * 8192 + wro[rt]) = bf_pack4(drop4(g[rt][tt], A.seed_mlp ^ smix, off[tt] + 16 * rt));
   }
+  BF_BURST(imgA, A.dy2, FS_C, 0);
   if (tid < 3 * FS_C / 4) *(f32x4*)(lbias + 4 * tid) = bias_in;
   BF_STAMP(2);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's share of the pre-activation rows has landed in image C (the barrier publishes it)
@@ -315,13 +348,23 @@ __global__ __launch_bounds__(256, NTT <= 3 ? 2 : 1) void block_bwd_fs_kernel(BfA
     for (int tt = 0; tt < NTT; ++tt)
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) acc[rt][tt] = zero4;
-    fs_slice_gemm<0, 24, NTT, RT, false, PF>(wqt, wb, imgA, rdo, acc, rows_hook(imgA, A.dy2, FS_C, 0));
+#if BF_DMA_ROWS
+    fs_slice_gemm<0, 24, NTT, RT, false, PF>(wqt, wb, imgA, rdo, acc, BF_HOOK(imgA, A.dy2, FS_C, 0));
     BF_STAMP(4);
     u32x2 hp[RT][NTT];      // (read together: the compiler cannot move an LDS read over the image writes below)
 #pragma unroll
     for (int tt = 0; tt < NTT; ++tt)
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) hp[rt][tt] = *(const u32x2*)(imgC + tt * 8192 + wro[rt]);
+#else
+    u32x2 hp[RT][NTT];
+#pragma unroll
+    for (int tt = 0; tt < NTT; ++tt)
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) hp[rt][tt] = *(const u32x2*)(A.hpre + off[tt] + 16 * rt);      // in flight under the GEMM
+    fs_slice_gemm<0, 24, NTT, RT, false, PF>(wqt, wb, imgA, rdo, acc, BF_HOOK(imgA, A.dy2, FS_C, 0));
+    BF_STAMP(4);
+#endif
 #pragma unroll
     for (int tt = 0; tt < NTT; ++tt) {
 #pragma unroll
@@ -335,8 +378,11 @@ __global__ __launch_bounds__(256, NTT <= 3 ? 2 : 1) void block_bwd_fs_kernel(BfA
       rstd2[tt] = A.st2[2 * (long)(lv[tt] ? tokidx[tt] : 0) + 1];
     }
   }
+  BF_BURST(imgB, A.dhpre, FS_C, 0);
   __syncthreads();      // 2: every wave has read its pre-activations; image C takes LayerNorm2's rows (they land under P2's GEMM)
+#if BF_DMA_ROWS
   dma_rows(A.xh2);
+#endif
   BF_STAMP(5);
 
   // ================================ P2: dxh2 = W1'^T dhpre ; LayerNorm2 backward + skip -> dx1 (registers) ; dy1 -> image A and memory ====
@@ -346,7 +392,8 @@ __global__ __launch_bounds__(256, NTT <= 3 ? 2 : 1) void block_bwd_fs_kernel(BfA
     for (int tt = 0; tt < NTT; ++tt)
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) acc[rt][tt] = zero4;
-    fs_slice_gemm<1, 24, NTT, RT, false, PF>(wqt, wb, imgB, rdo, acc, rows_hook(imgB, A.dhpre, FS_C, 0));
+#if BF_DMA_ROWS
+    fs_slice_gemm<1, 24, NTT, RT, false, PF>(wqt, wb, imgB, rdo, acc, BF_HOOK(imgB, A.dhpre, FS_C, 0));
     BF_STAMP(6);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();      // 2b: LayerNorm2's rows are in image C
@@ -355,6 +402,15 @@ __global__ __launch_bounds__(256, NTT <= 3 ? 2 : 1) void block_bwd_fs_kernel(BfA
     for (int tt = 0; tt < NTT; ++tt)
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) xh[rt][tt] = *(const u32x2*)(imgC + tt * 8192 + wro[rt]);
+#else
+    u32x2 xh[RT][NTT];
+#pragma unroll
+    for (int tt = 0; tt < NTT; ++tt)
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) xh[rt][tt] = *(const u32x2*)(A.xh2 + off[tt] + 16 * rt);      // in flight under the GEMM
+    fs_slice_gemm<1, 24, NTT, RT, false, PF>(wqt, wb, imgB, rdo, acc, BF_HOOK(imgB, A.dhpre, FS_C, 0));
+    BF_STAMP(6);
+#endif
 #pragma unroll
     for (int tt = 0; tt < NTT; ++tt) {
       float s1 = 0.f, s2 = 0.f;
@@ -396,10 +452,15 @@ __global__ __launch_bounds__(256, NTT <= 3 ? 2 : 1) void block_bwd_fs_kernel(BfA
     // dx1 waits in the OUTPUT buffer for the end of the launch (this wave's own rows, read back by itself: no other workgroup touches them).
     // Held in 48 registers through the recompute and the attention it pushed the launch into scratch: the compiler spilled half of it
     // anyway, and every scratch reload in between -- a vector-memory wait in an in-order queue -- drained the row stores and DMAs in flight.
+#if BF_PARK_DX1
     slice_store(imgB + wave * (IMG / NW), A.dx, g, std::false_type{});      // image B: its readers (P2's GEMM) are behind barrier 3
+#endif
   }
+  BF_BURST(imgA, A.dy1, FS_C, 0);
   __syncthreads();      // 4: every wave has read LayerNorm2's rows; image C takes LayerNorm1's (they land under P3's GEMM)
+#if BF_DMA_ROWS
   dma_rows(A.xh1);
+#endif
   BF_STAMP(7);
 
   // ================================ P3: do = Wo^T dy1 -> operand fragments (registers) and image B ========================================
@@ -409,7 +470,7 @@ __global__ __launch_bounds__(256, NTT <= 3 ? 2 : 1) void block_bwd_fs_kernel(BfA
     for (int tt = 0; tt < NTT; ++tt)
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) acc[rt][tt] = zero4;
-    fs_slice_gemm<2, 24, NTT, RT, false, PF>(wqt, wb, imgA, rdo, acc, rows_hook(imgA, A.dy1, FS_C, 0));
+    fs_slice_gemm<2, 24, NTT, RT, false, PF>(wqt, wb, imgA, rdo, acc, BF_HOOK(imgA, A.dy1, FS_C, 0));
     BF_STAMP(8);
     fs_wring_prime<0, RT, PF>(wqf, wb);      // the forward stream's q rows, under the epilogue and the barrier
     // image B (dhpre) died with P2's GEMM (barriers 3, 4): d_o in row-major form, for the plain and the transposing fragment reads
@@ -418,7 +479,9 @@ __global__ __launch_bounds__(256, NTT <= 3 ? 2 : 1) void block_bwd_fs_kernel(BfA
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) *(u32x2*)(imgB + tt * 8192 + wro[rt]) = bf_pack4(acc[rt][tt]);
   }
+#if BF_DMA_ROWS
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
   __syncthreads();      // 5: image A's readers (P3's GEMM) are done, LayerNorm1's rows are in image C
   BF_STAMP(9);
 
@@ -488,7 +551,7 @@ __global__ __launch_bounds__(256, NTT <= 3 ? 2 : 1) void block_bwd_fs_kernel(BfA
     // TPS == 1: the block-diagonal (and causal) pattern inside a tile; bit r of allow1: key row 4 kk + r may be seen by query l15,
     // bit r of allow2: query row 4 kk + r sees key l15
     unsigned allow1 = 0xfu, allow2 = 0xfu;
-    bool nomask = true;
+    bool nomask = true;      // (TPS > 1: every key of the group's sequence is visible; constant-folded)
     const int si15 = (int)(((unsigned)l15 * A.magic) >> 16), pi15 = l15 - si15 * L;      // TPS == 1: sequence / position of slot l15 in its tile
     if constexpr (TPS == 1) {
       allow1 = allow2 = 0u;
@@ -580,7 +643,7 @@ __global__ __launch_bounds__(256, NTT <= 3 ? 2 : 1) void block_bwd_fs_kernel(BfA
 #pragma unroll
         for (int j = 0; j < NK; ++j) {
           unsigned m4 = 0xfu;
-          if (A.p > 0.0f) {
+          if constexpr (DROP) {
             const int jpos0 = 16 * (k0 + j) + 4 * kk - si * L;
             if ((L & 3) == 0) {
               m4 = dropout_keep4(sd_attn, mrow + (unsigned long long)(jpos0 < 0 ? 0 : jpos0), A.p);
@@ -598,7 +661,7 @@ __global__ __launch_bounds__(256, NTT <= 3 ? 2 : 1) void block_bwd_fs_kernel(BfA
           for (int r = 0; r < 4; ++r) {
             const float pr = st[j][r] * il;
             float dp = dpt[j][r];
-            if (A.p > 0.0f) dp = ((m4 >> r) & 1u) ? dp * ksc : 0.0f;      // d(dropped probability) -> d(probability)
+            if constexpr (DROP) dp = ((m4 >> r) & 1u) ? dp * ksc : 0.0f;      // d(dropped probability) -> d(probability)
             st[j][r] = pr;
             dpt[j][r] = dp;
             delta = fmaf(pr, dp, delta);
@@ -672,7 +735,7 @@ __global__ __launch_bounds__(256, NTT <= 3 ? 2 : 1) void block_bwd_fs_kernel(BfA
             const bool valid = nomask || ((allow2 >> r) & 1u);
             const float pr = valid ? __builtin_amdgcn_exp2f(sv[i][r] - cq[i][r]) : 0.0f;
             float d = dp[i][r], pd = pr;
-            if (A.p > 0.0f) {
+            if constexpr (DROP) {
               // pass 1 drew the keep bits of (query 4 kk + r of tile k0 + i, keys 4 (l15 >> 2) .. + 3 of this tile) in lane
               // (l15 = that query, kk = l15 >> 2 of THIS lane): one ds_bpermute instead of a 64-bit index and a hash per element
               // (544 quarter-rate integer multiplies per head at L = 48 before)
@@ -730,8 +793,22 @@ __global__ __launch_bounds__(256, NTT <= 3 ? 2 : 1) void block_bwd_fs_kernel(BfA
   float rstd1[NTT];
 #pragma unroll
   for (int tt = 0; tt < NTT; ++tt) rstd1[tt] = A.st1[2 * (long)(lv[tt] ? tokidx[tt] : 0) + 1];
+#if BF_PARK_DX1
   f32x4 dx1raw[NTT][RT];      // dx1 back from the output buffer (row form), in flight under the closing GEMMs
   slice_load(A.dx, dx1raw);
+#endif
+#if !BF_HOOK_STORES
+  BF_BURST(imgC, A.dqkv, 3 * FS_C, 0);
+  BF_BURST(imgA, A.dqkv, 3 * FS_C, FS_C);
+  BF_BURST(imgB, A.dqkv, 3 * FS_C, 2 * FS_C);
+#endif
+#if !BF_DMA_ROWS
+  u32x2 xh1r[RT][NTT];      // in flight under the closing GEMMs
+#pragma unroll
+  for (int tt = 0; tt < NTT; ++tt)
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) xh1r[rt][tt] = *(const u32x2*)(A.xh1 + off[tt] + 16 * rt);
+#endif
   __syncthreads();      // 7
   BF_STAMP(16);
 
@@ -743,11 +820,14 @@ __global__ __launch_bounds__(256, NTT <= 3 ? 2 : 1) void block_bwd_fs_kernel(BfA
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) acc[rt][tt] = zero4;
     // dq | dk | dv rows -> memory (the in-projection's weight gradient reads them) under the three GEMMs that read the same images
-    fs_slice_gemm<0, 24, NTT, RT, false, PF>(wqh, wb, imgC, rdo, acc, rows_hook(imgC, A.dqkv, 3 * FS_C, 0));
+    fs_slice_gemm<0, 24, NTT, RT, false, PF>(wqh, wb, imgC, rdo, acc, BF_HOOK(imgC, A.dqkv, 3 * FS_C, 0));
+#if BF_DMA_ROWS
     __syncthreads();      // 7b: image C (dq) has no reader left: LayerNorm1's rows come back into it under the other two GEMMs (held in
     dma_rows(A.xh1);      // registers through the attention they pushed the launch into scratch)
-    fs_slice_gemm<1, 24, NTT, RT, false, PF>(wqh, wb, imgA, rdo, acc, rows_hook(imgA, A.dqkv, 3 * FS_C, FS_C));
-    fs_slice_gemm<2, 24, NTT, RT, false, PF>(wqh, wb, imgB, rdo, acc, rows_hook(imgB, A.dqkv, 3 * FS_C, 2 * FS_C));
+#endif
+    fs_slice_gemm<1, 24, NTT, RT, false, PF>(wqh, wb, imgA, rdo, acc, BF_HOOK(imgA, A.dqkv, 3 * FS_C, FS_C));
+    fs_slice_gemm<2, 24, NTT, RT, false, PF>(wqh, wb, imgB, rdo, acc, BF_HOOK(imgB, A.dqkv, 3 * FS_C, 2 * FS_C));
+#if BF_DMA_ROWS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();      // 8a
     u32x2 xh1r[RT][NTT];
@@ -755,6 +835,7 @@ __global__ __launch_bounds__(256, NTT <= 3 ? 2 : 1) void block_bwd_fs_kernel(BfA
     for (int tt = 0; tt < NTT; ++tt)
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) xh1r[rt][tt] = *(const u32x2*)(imgC + tt * 8192 + wro[rt]);
+#endif
     BF_STAMP(17);
 #pragma unroll
     for (int tt = 0; tt < NTT; ++tt) {
@@ -795,6 +876,7 @@ __global__ __launch_bounds__(256, NTT <= 3 ? 2 : 1) void block_bwd_fs_kernel(BfA
     char* const stg = imgA + wave * (IMG / NW);
 #pragma unroll
     for (int tt = 0; tt < NTT; ++tt) {
+#if BF_PARK_DX1
 #pragma unroll
       for (int j = 0; j < RT; ++j) {
         const int r = RPI * j + rrow;
@@ -806,6 +888,10 @@ __global__ __launch_bounds__(256, NTT <= 3 ? 2 : 1) void block_bwd_fs_kernel(BfA
         const f32x4 d = *(const f32x4*)(stg + o) + acc[rt][tt];
         *(f32x4*)(stg + o) = d;      // (the same lane reads and rewrites its own 16 bytes)
       }
+#else
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) *(f32x4*)(stg + l15 * ROWB + (((4 * rt + kk) ^ (l15 & (CPR - 1))) << 4)) = g[rt][tt] + acc[rt][tt];
+#endif
 #pragma unroll
       for (int j = 0; j < RT; ++j) {
         const int r = RPI * j + rrow, t = tok_of(16 * tt + r);
@@ -821,12 +907,19 @@ __global__ __launch_bounds__(256, NTT <= 3 ? 2 : 1) void block_bwd_fs_kernel(BfA
 }
 
 template <int TPS, int NTT>
+void bf_launch_d(const BfArgs& A, int nwg, hipStream_t s);
+template <int TPS, int NTT, bool DROP>
 void bf_launch(const BfArgs& A, int nwg, hipStream_t s) {
   constexpr int LDS = 3 * 16 * NTT * FS_ROW + 16 * NTT * 4 * 8 + 3 * FS_C * 4;
   static_assert(LDS <= 160 * 1024, "LDS per workgroup");
   static TantePerDevice attr;
-  attr.once([&] { (void)hipFuncSetAttribute((const void*)block_bwd_fs_kernel<TPS, NTT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); });
-  hipLaunchKernelGGL((block_bwd_fs_kernel<TPS, NTT>), dim3((unsigned)nwg), dim3(256), LDS, s, A);
+  attr.once([&] { (void)hipFuncSetAttribute((const void*)block_bwd_fs_kernel<TPS, NTT, DROP>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); });
+  hipLaunchKernelGGL((block_bwd_fs_kernel<TPS, NTT, DROP>), dim3((unsigned)nwg), dim3(256), LDS, s, A);
+}
+template <int TPS, int NTT>
+void bf_launch_d(const BfArgs& A, int nwg, hipStream_t s) {
+  if (A.p > 0.0f) bf_launch<TPS, NTT, true>(A, nwg, s);
+  else bf_launch<TPS, NTT, false>(A, nwg, s);
 }
 
 // (TPS, NTT) for a sequence length, 0 = no instantiation (the three-launch path serves it)
@@ -885,10 +978,10 @@ extern "C" int tante_block_bwd_fused(const float* dout, const void* xh1, const f
   hipStream_t s = (hipStream_t)stream;
   const int key = tps * 10 + ntt;
   switch (key) {
-    case 13: bf_launch<1, 3>(A, nwg, s); break;
-    case 22: bf_launch<2, 2>(A, nwg, s); break;
-    case 33: bf_launch<3, 3>(A, nwg, s); break;
-    case 44: bf_launch<4, 4>(A, nwg, s); break;
+    case 13: bf_launch_d<1, 3>(A, nwg, s); break;
+    case 22: bf_launch_d<2, 2>(A, nwg, s); break;
+    case 33: bf_launch_d<3, 3>(A, nwg, s); break;
+    case 44: bf_launch_d<4, 4>(A, nwg, s); break;
     default: TANTE_FAIL(-2, "tante_block_bwd_fused: no instantiation for L=%d", seq->L);
   }
   TANTE_CHECK_LAUNCH();
