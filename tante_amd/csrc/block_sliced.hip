@@ -812,8 +812,13 @@ __global__ __launch_bounds__(64 * NW * G, 2) void block_fs_kernel(FsArgs A) {
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
       u32x2 o2;
+#ifdef FS_EXP_LN_ID        // timing experiment only (wrong results): the price of LayerNorm2's normalise pass
+      o2[0] = pack_bf16x2(x1[rt][tt][0], x1[rt][tt][1]);
+      o2[1] = pack_bf16x2(x1[rt][tt][2], x1[rt][tt][3]);
+#else
       o2[0] = pack_bf16x2(fmaf(x1[rt][tt][0], rstd, sh), fmaf(x1[rt][tt][1], rstd, sh));
       o2[1] = pack_bf16x2(fmaf(x1[rt][tt][2], rstd, sh), fmaf(x1[rt][tt][3], rstd, sh));
+#endif
       *(u32x2*)(bufA + tt * 8192 + wro[rt]) = o2;
     }
     if constexpr (TRAIN) {
@@ -850,7 +855,11 @@ __global__ __launch_bounds__(64 * NW * G, 2) void block_fs_kernel(FsArgs A) {
       }
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) {
+#ifdef FS_EXP_GELU_ID      // timing experiment only (wrong results): the whole price of the GELU arithmetic (round-5 verdict item 4)
+        const f32x4 g = h[rt][tt];
+#else
         const f32x4 g = gelu_poly4<true>(h[rt][tt]);
+#endif
         u32x2 o2;
         o2[0] = pack_bf16x2(g[0], g[1]);
         o2[1] = pack_bf16x2(g[2], g[3]);

@@ -75,7 +75,11 @@ __device__ __forceinline__ void he_glds(const char* __restrict__ g, char* l, int
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + off + lane * 16),
                                      (__attribute__((address_space(3))) void*)(l + off), 16, 0, 0);
 }
+#ifdef HE_EXP_GELU_ID      // timing experiment only (wrong results): the whole price of the GELU arithmetic (round-5 verdict item 4)
+__device__ __forceinline__ f32x4 he_gelu(const f32x4& v) { return v; }
+#else
 __device__ __forceinline__ f32x4 he_gelu(const f32x4& v) { return gelu_poly4<false>(v); }
+#endif
 // agent-scope (sc1) 16-byte accesses to the hand-off buffer: the load misses this CU's L1, the store is written through (and waits the
 // two states a VALU write to the data registers of a >64-bit store needs behind it: common.hip.h, st_wt16)
 __device__ __forceinline__ u32x4 he_ld_agent(const u32x4* p) {

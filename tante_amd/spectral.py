@@ -180,30 +180,33 @@ class dec_FNO(nn.Module):
 
 
 # ---- differentiable (training) forward of the spectral encoder / decoder ---------------------------------------------------------------
-def _conv_stage_train(z_nchw: torch.Tensor, conv: nn.Conv2d, P: int, overlap: float, compute: int, out_dtype: torch.dtype):
-    """RealConv2d on the train path: channels-last im2col (its backward is the gather-sum col2im) + LinearFn; -> (rows, Cout), (h, w)."""
+def _conv_stage_train(z_nchw: torch.Tensor, conv: nn.Conv2d, P: int, overlap: float, compute: int, out_dtype: torch.dtype, nhwc=None):
+    """RealConv2d on the train path: channels-last im2col (its backward is the gather-sum col2im) + LinearFn; -> (rows, Cout), (h, w).
+    nhwc = (n, C, H, W): z_nchw is already the channels-last image (n, H, W, C) (the CNN encoder's stage outputs are token rows)."""
     from .autograd import Im2colFn, LinearFn
-    n, C_, H, W = z_nchw.shape
+    n, C_, H, W = nhwc if nhwc is not None else z_nchw.shape
     st, pd = S.stride_pad(P, overlap)
     Ho, Wo = (H + 2 * pd - P) // st + 1, (W + 2 * pd - P) // st + 1
     if (Ho, Wo) != (H // P, W // P):
         raise NotImplementedError("the differentiable path has no adaptive-average-pool backward (overlap_ratio > 0): inference path only")
-    cols = Im2colFn.apply(z_nchw.permute(0, 2, 3, 1).contiguous(), n, C_, H, W, P, st, pd, K.act_torch_dtype(compute))
+    img = z_nchw.reshape(n, H, W, C_) if nhwc is not None else z_nchw.permute(0, 2, 3, 1)
+    cols = Im2colFn.apply(img.contiguous(), n, C_, H, W, P, st, pd, K.act_torch_dtype(compute))
     w2d = conv.weight.permute(0, 2, 3, 1).reshape(conv.weight.shape[0], -1)           # columns (kh, kw, c), a parameter-sized re-layout
     return LinearFn.apply(cols, w2d, conv.bias, None, compute, out_dtype), Ho, Wo
 
 
-def _deconv_stage_train(rows: torch.Tensor, dc: nn.ConvTranspose2d, n_img: int, h: int, w: int, P: int, overlap: float, compute: int):
-    """RealTransConv2d on the train path -> (n_img, Cout, h P, w P) fp32 pre-activation."""
+def _deconv_stage_train(rows: torch.Tensor, dc: nn.ConvTranspose2d, n_img: int, h: int, w: int, P: int, overlap: float, compute: int,
+                        nchw_out: bool = True, out_dtype: torch.dtype = torch.float32):
+    """RealTransConv2d on the train path -> (n_img, Cout, h P, w P) (or channels-last (n_img, h P, w P, Cout)) pre-activation."""
     from .autograd import CropResizeFn, DeconvFn
     st, pd = S.stride_pad(P, overlap)
     if st != P:
         raise NotImplementedError("overlapping transposed convolutions run on the inference path only")
     if pd == 0:
-        return DeconvFn.apply(rows, dc.weight, dc.bias, n_img, h, w, P, True, compute, torch.float32)
+        return DeconvFn.apply(rows, dc.weight, dc.bias, n_img, h, w, P, nchw_out, compute, out_dtype)
     full = DeconvFn.apply(rows, dc.weight, dc.bias, n_img, h, w, P, False, compute, K.act_torch_dtype(compute))   # (n, hP, wP, Cout)
     Cout = dc.weight.shape[1]
-    return CropResizeFn.apply(full, n_img, Cout, h * P - 2 * pd, w * P - 2 * pd, (pd, pd), h * P, w * P, True, torch.float32)
+    return CropResizeFn.apply(full, n_img, Cout, h * P - 2 * pd, w * P - 2 * pd, (pd, pd), h * P, w * P, nchw_out, out_dtype)
 
 
 def enc_fno_train(enc: enc_FNO, inp: torch.Tensor, compute: int) -> torch.Tensor:

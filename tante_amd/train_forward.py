@@ -239,9 +239,21 @@ def backbone_train(bb, x: torch.Tensor, B: int, compute: int) -> torch.Tensor:
         x = AxisMlpFn.apply(x, vp[0].weight, vp[0].bias, vp[2].weight, vp[2].bias, B * T, H, W * C_, compute)
         x = AxisMlpFn.apply(x, hp[0].weight, hp[0].bias, hp[2].weight, hp[2].bias, B * T * H, W, C_, compute)
     x = AxisMlpFn.apply(x, tp[0].weight, tp[0].bias, tp[2].weight, tp[2].bias, B, T, H * W * C_, compute)
+    ci = 0
     for i, axis in enumerate(bb.attn_axes):
         if axis == "C":
-            raise NotImplementedError("the channel-attention letter 'C' is not on the HIP train path yet")
+            # attn_backbone.py:184-189: every scalar channel value is lifted 1 -> E/4 -> E (channel_blocks), the block attends over the C
+            # axis of each token (sequences of C "tokens" of width E), and feature E - 1 comes back as the channel's new value
+            cb = bb.channel_blocks[ci]
+            ci += 1
+            n, E = x.shape[0], bb.expanded_channel
+            adt = K.act_torch_dtype(compute)
+            # the first lift is an outer product with a (E/4, 1) weight, not a contraction: an elementwise torch expression
+            z1 = ActFn.apply((x.reshape(n * C_, 1) * cb[0].weight.view(1, -1) + cb[0].bias).contiguous(), L.ACT_GELU_ERF, adt)
+            z = LinearFn.apply(z1, cb[2].weight, cb[2].bias, None, compute, torch.float32)
+            z = block_train(bb.blocks[i], z, K.dense_seq(n, C_), False, compute)
+            x = z.view(n, C_, E)[:, :, -1].contiguous()
+            continue
         x = block_train(bb.blocks[i], x, K.make_seq(axis, B, T, H, W), axis == "T", compute)
     return x
 
@@ -250,13 +262,25 @@ def encoder_train(enc, inp: torch.Tensor, compute: int) -> torch.Tensor:
     if type(enc).__name__ == "enc_FNO":
         from .spectral import enc_fno_train
         return enc_fno_train(enc, inp, compute)
-    if any(S.stride_pad(p, enc.overlap) != (p, 0) for p in enc.P):
-        raise NotImplementedError("the differentiable path covers non-overlapping, unpadded stages (patch_scale 2, 4, 8); padded / "
-                                  "overlapping stages run on the inference path only")
+    if any(S.stride_pad(p, enc.overlap)[0] != p for p in enc.P):
+        raise NotImplementedError("the differentiable path covers non-overlapping stages (overlap_ratio 0, every patch_scale); "
+                                  "overlapping stages (adaptive average pool) run on the inference path only")
     B, T, D, H, W = inp.shape
     adt = K.act_torch_dtype(compute)
     n_img, h, w = B * T, H, W
     z = inp.reshape(n_img, D, H, W)
+    if any(S.stride_pad(p, enc.overlap)[1] for p in enc.P):
+        # 'same'-padded stages (kernel 4: patch_scale 16 / 32 / 64, enc_dec_cnn.py:66-81): the general route, stage by stage -- im2col with the
+        # padding (its backward: the gather-sum col2im) + the dense GEMM, GELU between the stages as an op of its own
+        from .spectral import _conv_stage_train
+        for i in range(3):
+            conv = getattr(enc, f"enc_conv_{i + 1}").conv
+            p, ci = enc.P[i], enc.chans[i]
+            last = i == 2
+            z, h, w = _conv_stage_train(z, conv, p, enc.overlap, compute, torch.float32 if last else adt, None if i == 0 else (n_img, ci, h, w))
+            if not last:
+                z = ActFn.apply(z, L.ACT_GELU_ERF, adt)
+        return z
     for i in range(3):
         conv = getattr(enc, f"enc_conv_{i + 1}").conv
         p, ci = enc.P[i], enc.chans[i]
@@ -276,12 +300,25 @@ def decoder_train(dec, a: torch.Tensor, n_img: int, compute: int) -> torch.Tenso
     if type(dec).__name__ == "dec_FNO":
         from .spectral import dec_fno_train
         return dec_fno_train(dec, a.reshape(-1, dec.chans[0]), n_img, compute)
-    if any(S.stride_pad(p, dec.overlap) != (p, 0) for p in dec.P):
-        raise NotImplementedError("the differentiable path covers non-overlapping, unpadded stages (patch_scale 2, 4, 8); padded / "
-                                  "overlapping stages run on the inference path only")
+    if any(S.stride_pad(p, dec.overlap)[0] != p for p in dec.P):
+        raise NotImplementedError("the differentiable path covers non-overlapping stages (overlap_ratio 0, every patch_scale); "
+                                  "overlapping transposed convolutions run on the inference path only")
     adt = K.act_torch_dtype(compute)
     h, w = dec.patch_shape
     x = a
+    if any(S.stride_pad(p, dec.overlap)[1] for p in dec.P):
+        # 'same'-padded stages (enc_dec_cnn.py:128-143, 164-184): the padding crops the transposed convolution's result and the reference
+        # resizes it back (bilinear) -- DeconvFn + CropResizeFn per stage, channels-last rows between the stages
+        from .spectral import _deconv_stage_train
+        for i in range(3):
+            dc = getattr(dec, f"dec_conv_{i + 1}").deconv
+            p = dec.P[i]
+            last = i == 2
+            x = _deconv_stage_train(x.reshape(-1, dec.chans[i]), dc, n_img, h, w, p, dec.overlap, compute, last, torch.float32 if last else adt)
+            if not last:
+                x = ActFn.apply(x, L.ACT_GELU_ERF, adt)
+            h, w = h * p, w * p
+        return x
     for i in range(3):
         dc = getattr(dec, f"dec_conv_{i + 1}").deconv
         p, co = dec.P[i], dec.chans[i + 1]

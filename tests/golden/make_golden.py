@@ -25,6 +25,7 @@ Fixture index:
   g11_cvit_*         CViT tiny: grid / fourier / mlp coordinate embeddings, full-grid and query-point modes
   g12_spectral_*     SpectralLayer (modes below / above the spectrum size) and TANTE(enc_dec_type='fno') tiny
   g13_deg_false      adaptive-dt forward composed from the reference's own sub-modules
+  g15_*              gradients of 'same'-padded encoder / decoder stages (patch_scale 16 / 32 / 64) and of the channel-attention letter 'C'
   g14_trainstep_wide production-shape train step (C=256, 8 heads x 32, "THWTHWTHW", L in {4, 8, 48}): loss, per-parameter gradient
                      norms, three full gradient tensors.  Weights (4.2 M) and inputs are NOT stored: both come from seeded CPU
                      generators (manual_seed(14) before the constructor; Generator(1414) for the fields) and the fixture holds their
@@ -416,7 +417,44 @@ def g14():
     save("g14_trainstep_wide", **arrs)
 
 
+def g15():
+    """Round 5: GRADIENTS of the training-surface cases the HIP path did not cover before -- 'same'-padded conv / deconv stages
+    (patch_scale 16 / 32 / 64: kernel-4 stages; 32 is the constructor default) and the channel-attention letter 'C' -- from the
+    reference's own backward(): loss = sum(output * w) with a seeded w, gradients of the input and of every parameter."""
+    for ps, res, nf, C in [(16, (32, 64), 2, 32), (32, (64, 64), 2, 16), (64, (64, 128), 1, 16)]:
+        torch.manual_seed(1500 + ps)
+        e = enc_CNN(md(nf, res), embed_dim=C, patch_scale=ps, overlap_ratio=0.0).train()
+        d = dec_CNN(md(nf, res), embed_dim=C, patch_scale=ps, overlap_ratio=0.0).train()
+        x = torch.randn(2, 3, nf, *res, requires_grad=True)
+        z = e(x)
+        wz = torch.randn_like(z)
+        (z * wz).sum().backward()
+        zz = torch.randn(2, 1, *z.shape[2:], requires_grad=True)
+        r = d(zz)
+        wr = torch.randn_like(r)
+        (r * wr).sum().backward()
+        arrs = {"x": x.detach().numpy(), "z": z.detach().numpy(), "wz": wz.numpy(), "dx": x.grad.numpy(), "zz": zz.detach().numpy(),
+                "r": r.detach().numpy(), "wr": wr.numpy(), "dzz": zz.grad.numpy(), "meta": np.array([ps, 0, res[0], res[1], nf, C])}
+        for k, q in e.named_parameters():
+            arrs["genc." + k] = q.grad.numpy().copy()
+        for k, q in d.named_parameters():
+            arrs["gdec." + k] = q.grad.numpy().copy()
+        save(f"g15_encdec_grad_ps{ps}", **arrs, **sd_np(e, "enc."), **sd_np(d, "dec."))
+    T, H, W, C = 3, 4, 6, 32
+    for axes in ["C", "LTCAXY"]:
+        torch.manual_seed(1515 + len(axes))
+        bb = Attn_Backbone((T, H, W, C), axes, expanded_channel=16, n_head=4, mlp_ratio=1.0, dropout=0.0).train()
+        x = torch.randn(2, T, H, W, C, requires_grad=True)
+        y = bb(x)
+        w = torch.randn_like(y)
+        (y * w).sum().backward()
+        arrs = {"x": x.detach().numpy(), "y": y.detach().numpy(), "w": w.numpy(), "dx": x.grad.numpy(), "meta": np.array([T, H, W, C, 16, 4])}
+        for k, q in bb.named_parameters():
+            arrs["g." + k] = q.grad.numpy().copy()
+        save(f"g15_backbone_grad_{axes}", **arrs, **sd_np(bb))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15"]
     for w in which:
         globals()[w]()

@@ -206,3 +206,134 @@ def test_block_backward_in_one_launch_row_operands(dev, letter, B, T, H, W):
     e = max_rel(f["dx"].cpu(), dx3.cpu())
     record_parity(rel_err(f["dx"].cpu(), dx3.cpu()), e, 2e-2, "bf16", f"one-launch block backward vs three launches, dx, {letter} L={seq.L}, p=0.1")
     assert e < 2e-2 and rel_err(f["dx"].cpu(), dx3.cpu()) < 5e-3, (e, rel_err(f["dx"].cpu(), dx3.cpu()))
+
+
+# ---------------------------------------------------------------------------------------------------
+# g15: training-surface cases closed in round 5, against the REFERENCE's gradients
+# ---------------------------------------------------------------------------------------------------
+def _names(pattern):
+    import glob
+    import os
+    from conftest import GOLDEN
+    return sorted(os.path.basename(q)[:-4] for q in glob.glob(os.path.join(GOLDEN, pattern + ".npz")))
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+@pytest.mark.parametrize("name", _names("g15_encdec_grad_*"))
+def test_g15_padded_stages_train(dev, name, mode):
+    """enc_CNN / dec_CNN with 'same'-padded kernel-4 stages (patch_scale 16 / 32 / 64; 32 is the constructor default,
+    enc_dec_cnn.py:39-46, 66-81, 128-143) under autograd: round 4 raised NotImplementedError on the train path.  Output, input gradient
+    and every parameter's gradient against the reference's backward() (fixture g15).  Bars: fp32 1e-5 / 2e-4, bf16 1e-2 / 4e-2."""
+    import contextlib
+    import tante_amd
+    from conftest import load_golden, split_prefix
+    g = load_golden(name)
+    ps, _, H, W, nf, C = (int(v) for v in g["meta"])
+    md = tante_amd.TanteMetadata(n_fields=nf, spatial_resolution=(H, W))
+    e = tante_amd.enc_CNN(md, embed_dim=C, patch_scale=ps, overlap_ratio=0.0).to(dev).train()
+    d = tante_amd.dec_CNN(md, embed_dim=C, patch_scale=ps, overlap_ratio=0.0).to(dev).train()
+    e.load_state_dict(split_prefix(g, "enc."))
+    d.load_state_dict(split_prefix(g, "dec."))
+    amp = (lambda: torch.autocast("cuda", dtype=torch.bfloat16)) if mode == "bf16" else contextlib.nullcontext
+    ft, gt = (1e-5, 2e-4) if mode == "fp32" else (1e-2, 4e-2)
+    x = g["x"].to(dev).requires_grad_(True)
+    with amp():
+        z = e(x)
+    (z.float() * g["wz"].to(dev)).sum().backward()
+    assert max_rel(z.detach().float().cpu(), g["z"]) < ft
+    worst = max_rel(x.grad.cpu(), g["dx"])
+    assert worst < gt, ("dx", worst)
+    for k, q in e.named_parameters():
+        err = max_rel(q.grad.cpu(), g["genc." + k])
+        worst = max(worst, err)
+        assert err < gt, (k, err)
+    record_parity(worst, worst, gt, mode, f"{name}: enc_CNN gradients (input and parameters) vs the reference")
+    zz = g["zz"].to(dev).requires_grad_(True)
+    with amp():
+        r = d(zz)
+    (r.float() * g["wr"].to(dev)).sum().backward()
+    assert max_rel(r.detach().float().cpu(), g["r"]) < ft
+    worst = max_rel(zz.grad.cpu(), g["dzz"])
+    assert worst < gt, ("dzz", worst)
+    for k, q in d.named_parameters():
+        err = max_rel(q.grad.cpu(), g["gdec." + k])
+        worst = max(worst, err)
+        assert err < gt, (k, err)
+    record_parity(worst, worst, gt, mode, f"{name}: dec_CNN gradients (input and parameters) vs the reference")
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+@pytest.mark.parametrize("name", _names("g15_backbone_grad_*"))
+def test_g15_channel_letter_train(dev, name, mode):
+    """Attn_Backbone with the channel-attention letter 'C' (attn_backbone.py:184-189) under autograd -- alone and inside "LTCAXY":
+    round 4 raised on the train path.  Output, input gradient and every parameter's gradient against the reference's backward()."""
+    import tante_amd
+    from conftest import load_golden, split_prefix
+    g = load_golden(name)
+    axes = name.split("_")[-1]
+    T, H, W, C, E, nh = (int(v) for v in g["meta"])
+    bb = tante_amd.Attn_Backbone((T, H, W, C), axes, expanded_channel=E, n_head=nh, mlp_ratio=1.0, dropout=0.0).to(dev).train()
+    bb.load_state_dict(split_prefix(g, "w."))
+    bb.compute = mode
+    ft, gt = (1e-5, 2e-4) if mode == "fp32" else (1e-2, 4e-2)
+    x = g["x"].to(dev).requires_grad_(True)
+    y = bb(x)
+    (y.float() * g["w"].to(dev)).sum().backward()
+    assert max_rel(y.detach().float().cpu(), g["y"]) < ft * (3 if len(axes) > 1 else 1)
+    worst = max_rel(x.grad.cpu(), g["dx"])
+    assert worst < gt, ("dx", worst)
+    ours, refs = [], []
+    for k, q in bb.named_parameters():
+        ref = g["g." + k]
+        ours.append(q.grad.cpu().reshape(-1))
+        refs.append(ref.reshape(-1))
+        if float(ref.abs().max()) == 0.0:
+            assert float(q.grad.abs().max()) == 0.0, k
+            continue
+        if mode == "fp32":
+            err = max_rel(q.grad.cpu(), ref)
+            assert err < gt, (k, err)
+        else:
+            # bf16: relative L2 per tensor (as test_submodules_are_differentiable_standalone).  A bias gradient is a sum over 4 608 rows of
+            # entries rounded to bf16; where the reference's sum is a cancellation -- the C block's fc2 bias: 1.55 against entries of
+            # magnitude ~2.4, i.e. 2 % of a random walk's length -- the rounding noise of the terms (~0.15) is 10 % of the VALUE while it
+            # is 2e-3 of the terms.  Vectors therefore get 3.5 x the bar, and the whole gradient (all tensors concatenated) the bar itself.
+            err = rel_err(q.grad.cpu(), ref)
+            assert err < (gt if ref.dim() > 1 else 3.5 * gt), (k, err)
+        worst = max(worst, err)
+    err = rel_err(torch.cat(ours), torch.cat(refs))
+    assert err < gt, ("all parameters", err)
+    record_parity(max(worst, err), max(worst, err), gt if mode == "fp32" else 3.5 * gt, mode,
+                  f"{name}: Attn_Backbone gradients (input and parameters) vs the reference; all parameters concatenated: {err:.2e}")
+
+
+def test_constructor_default_patch_scale_trains(dev):
+    """TANTE's constructor default is patch_scale = 32 (tante.py:38-60: Patch_map[32] = (2, 4, 4), two 'same'-padded kernel-4 stages):
+    a forward + backward through the whole model on the HIP train path against torch autograd through the CPU oracle (fp32 compute;
+    output 1e-5, gradients 2e-4 of each tensor's largest entry).  Round 4 raised NotImplementedError here."""
+    import tante_amd
+    from oracle import tante_oracle as O
+    torch.manual_seed(77)
+    md = tante_amd.TanteMetadata(n_fields=2, spatial_resolution=(64, 64))
+    m = tante_amd.TANTE(in_T=4, dset_metadata=md, taylor_order=2, attn_axes="TH-WL", n_head=4, embed_dim=64, dropout=0.0).to(dev).train().set_compute("fp32")
+    assert sorted(m.encoder.P) == [2, 4, 4]
+    g = torch.Generator().manual_seed(78)
+    x = torch.randn(2, 4, 2, 64, 64, generator=g)
+    w = torch.randn(2, 1, 2, 64, 64, generator=g)
+    y = m(x.to(dev))
+    (y * w.to(dev)).sum().backward()
+    wo = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    cfg = O.TanteCfg(4, 2, (64, 64), taylor_order=2, attn_axes="TH-WL", n_head=4, embed_dim=64, patch_scale=32)
+    yo = O.tante_forward(wo, cfg, x)
+    (yo * w).sum().backward()
+    e = max_rel(y.detach().cpu(), yo.detach())
+    record_parity(rel_err(y.detach().cpu(), yo.detach()), e, 1e-5, "fp32", "TANTE(patch_scale=32) training forward vs oracle")
+    assert e < 1e-5, e
+    worst = 0.0
+    for k, q in m.named_parameters():
+        if wo[k].grad is None:
+            continue
+        err = max_rel(q.grad.cpu(), wo[k].grad)
+        worst = max(worst, err)
+        assert err < 2e-4, (k, err)
+    record_parity(worst, worst, 2e-4, "fp32", "TANTE(patch_scale=32) parameter gradients vs oracle autograd")

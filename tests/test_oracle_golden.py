@@ -241,3 +241,42 @@ def test_g12_tante_fno():
                      modes1=8, modes2=8)
     y = O.tante_forward(split_prefix(g, "w."), cfg, g["x"])
     assert y.shape == g["y"].shape and max_rel(y, g["y"]) < 5 * TOL
+
+
+# ---- g15 (round 5): the reference's GRADIENTS through padded conv / deconv stages and the channel-attention letter ------------------
+@pytest.mark.parametrize("name", names("g15_encdec_grad_*"))
+def test_g15_encdec_gradients(name):
+    """torch autograd through the oracle's enc_cnn / dec_cnn ('same'-padded kernel-4 stages: patch_scale 16 / 32 / 64) reproduces the
+    reference's backward(): input gradient and every parameter's gradient."""
+    g = load_golden(name)
+    ps = int(g["meta"][0])
+    we = {k: v.clone().requires_grad_(True) for k, v in split_prefix(g, "enc.").items()}
+    x = g["x"].clone().requires_grad_(True)
+    z = O.enc_cnn(we, x, ps, 0.0)
+    assert max_rel(z.detach(), g["z"]) < TOL
+    (z * g["wz"]).sum().backward()
+    assert max_rel(x.grad, g["dx"]) < 1e-5
+    for k, v in we.items():
+        assert max_rel(v.grad, g["genc." + k]) < 1e-5, k
+    wd = {k: v.clone().requires_grad_(True) for k, v in split_prefix(g, "dec.").items()}
+    zz = g["zz"].clone().requires_grad_(True)
+    r = O.dec_cnn(wd, zz, ps, 0.0)
+    assert max_rel(r.detach(), g["r"]) < TOL
+    (r * g["wr"]).sum().backward()
+    assert max_rel(zz.grad, g["dzz"]) < 1e-5
+    for k, v in wd.items():
+        assert max_rel(v.grad, g["gdec." + k]) < 1e-5, k
+
+
+@pytest.mark.parametrize("name", names("g15_backbone_grad_*"))
+def test_g15_backbone_gradients(name):
+    g = load_golden(name)
+    axes = name.split("_")[-1]
+    w = {k: v.clone().requires_grad_(True) for k, v in split_prefix(g, "w.").items()}
+    x = g["x"].clone().requires_grad_(True)
+    y = O.attn_backbone(w, x, axes, int(g["meta"][5]))
+    assert max_rel(y.detach(), g["y"]) < TOL
+    (y * g["w"]).sum().backward()
+    assert max_rel(x.grad, g["dx"]) < 1e-5
+    for k, v in w.items():      # (six blocks deep in "LTCAXY": fp32 re-association between two CPU evaluation orders reaches 2.2e-5)
+        assert max_rel(v.grad, g["g." + k]) < 5e-5, k
