@@ -297,8 +297,43 @@ def _flush_folds():
     _FOLD_PENDING.clear()
 
 
-def flush_deferred_wgrads():
+PRE_FLUSH_HOOK = [None]      # callable() run before the end-of-pass flush (train.py: the early part of the gradient all-reduce)
+HOLD_FLUSH = [False]         # True: the engine callback leaves the recorded work alone (train.GraphedTrainStep flushes in a graph of its own)
+
+
+def flush_write_range(bucket: torch.Tensor):
+    """(first element, end element) of `bucket` (a flat gradient buffer) that the pending flush will write: the deferred linears' weight /
+    bias slots and the folds' four outputs, as far as they are views of the bucket (the folded weights' own accumulators are private
+    buffers).  None when the flush writes nothing inside it."""
+    base, esz = bucket.data_ptr(), bucket.element_size()
+    end = base + bucket.numel() * esz
+    lo, hi = None, 0
+
+    def add(t):
+        nonlocal lo, hi
+        if t is None:
+            return
+        a = t.data_ptr()
+        if a < base or a >= end:
+            return
+        lo = a if lo is None else min(lo, a)
+        hi = max(hi, a + t.numel() * t.element_size())
+    for ent in _DEFER["pending"].values():
+        add(ent[0])
+        add(ent[1])
+    for ent in _FOLD_PENDING:
+        for t in ent[6:10]:
+            add(t)
+    return None if lo is None else ((lo - base) // esz, (min(hi, end) - base) // esz)
+
+
+def flush_deferred_wgrads(force: bool = False):
     """Run every recorded weight-gradient launch now (called automatically at the end of a backward pass), then the folds that wait for them."""
+    if HOLD_FLUSH[0] and not force:
+        return
+    if PRE_FLUSH_HOOK[0] is not None:
+        _join_side()                     # (weight gradients issued on the side stream, when that option is on, are part of "final")
+        PRE_FLUSH_HOOK[0]()
     _flush_wgrads(None)
     _flush_folds()
 

@@ -57,6 +57,66 @@ def allreduce_sum_(flat: torch.Tensor) -> torch.Tensor:
     return flat
 
 
+# The gradient collective in TWO calls (round 5; SURVEY 8e "overlapped with the tail of backward").  With BPTT every weight is used in every
+# rollout call, so no gradient is final before the last call's backward has passed its layer -- but the dense linears of the blocks (85 % of
+# the bucket) only RECORD their operands there: their weight gradients run as shared launches when the backward pass ends
+# (autograd.flush_deferred_wgrads: ~1.5 ms of the 9.4 ms step at cfg3), followed by the LayerNorm folds.  Everything else -- encoder, decoders,
+# propagators, FiLM, embeddings -- is final when that flush STARTS.  So: `early(lo, hi)` (called by the flush, with the element range its
+# launches will write) all-reduces flat[:lo] and flat[hi:] on a side stream while the weight-gradient launches run, `finish()` all-reduces
+# flat[lo:hi] behind them and joins.  Every element goes through exactly one summed all-reduce; over two ranks the result is bit-identical
+# to one call (a + b commutes), over more ranks it is the same sum in RCCL's ring order for that message.
+SPLIT_ALLREDUCE = True
+
+
+class GradAllReduce:
+    def __init__(self, flat: torch.Tensor):
+        self.flat, self.range, self.side, self.calls = flat, None, None, []
+
+    def active(self) -> bool:
+        return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or FORCE_COLLECTIVE)
+
+    def early(self, lo: int, hi: int):
+        """All-reduce what lies OUTSIDE [lo, hi) now, beside whatever the caller's stream does next."""
+        if not (self.active() and SPLIT_ALLREDUCE) or self.range is not None:
+            return
+        n = self.flat.numel()
+        lo, hi = max(0, min(lo, n)), max(0, min(hi, n))
+        if lo >= hi or (lo == 0 and hi == n):
+            return
+        self.range = (lo, hi)
+        parts = [q for q in (self.flat[:lo], self.flat[hi:]) if q.numel()]
+        if self.flat.is_cuda:
+            if self.side is None:
+                self.side = torch.cuda.Stream(device=self.flat.device)
+            self.side.wait_stream(torch.cuda.current_stream(self.flat.device))
+            with torch.cuda.stream(self.side):
+                for q in parts:
+                    dist.all_reduce(q, op=dist.ReduceOp.SUM)
+        else:
+            for q in parts:
+                dist.all_reduce(q, op=dist.ReduceOp.SUM)
+        self.calls += [int(q.numel()) for q in parts]
+
+    def finish(self) -> torch.Tensor:
+        """The rest (everything when early() did not run), then the caller's stream waits for the side stream."""
+        if not self.active():
+            return self.flat
+        if self.range is None:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+            self.calls = [int(self.flat.numel())]
+        else:
+            lo, hi = self.range
+            dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM)
+            self.calls.append(hi - lo)
+            if self.side is not None:
+                torch.cuda.current_stream(self.flat.device).wait_stream(self.side)
+        self.range = None
+        return self.flat
+
+
+LAST_CALLS: list = []      # element counts of the last step's all-reduce calls (bench.py prints them in `collective`)
+
+
 def collective_info() -> Optional[str]:
     """What carries the gradient all-reduce in this process: backend, RCCL version, rank count (bench.py prints it)."""
     if not (dist.is_available() and dist.is_initialized()):

@@ -29,18 +29,36 @@ def train_step(model, opt: FlatAdamW, batch: Dict[str, torch.Tensor], formatter,
     y_pred, y_ref = rollout_model(model, batch, formatter, n_steps_output)
     loss = MseMeanFn.apply(y_pred, y_ref)
     if scaler is not None and scaler.is_enabled():
-        run_backward(scaler.scale(loss))
-        if D.collective_needed(world):
-            D.allreduce_sum_(opt.flat_g)
+        _backward_and_allreduce(scaler.scale(loss), opt, world)
         scaler.unscale_(opt)
         scaler.step(opt, grad_scale=1.0 / world, lr=lr)
         scaler.update()
         return loss.detach()
-    run_backward(loss)
-    if D.collective_needed(world):
-        D.allreduce_sum_(opt.flat_g)
+    _backward_and_allreduce(loss, opt, world)
     opt.step(grad_scale=1.0 / world, lr=lr)
     return loss.detach()
+
+
+def _backward_and_allreduce(loss, opt: FlatAdamW, world: int):
+    """loss.backward() and the summed all-reduce of the flat gradient bucket, the collective in two calls when the backward pass ends in a
+    deferred weight-gradient flush (dist.GradAllReduce: what the flush does not write is reduced on a side stream WHILE it runs)."""
+    from . import autograd as A
+    if not D.collective_needed(world):
+        run_backward(loss)
+        return
+    ar = D.GradAllReduce(opt.flat_g)
+
+    def hook():
+        rng = A.flush_write_range(opt.flat_g)
+        if rng is not None:
+            ar.early(*rng)
+    A.PRE_FLUSH_HOOK[0] = hook
+    try:
+        run_backward(loss)
+    finally:
+        A.PRE_FLUSH_HOOK[0] = None
+    ar.finish()
+    D.LAST_CALLS[:] = ar.calls
 
 
 def _splitmix64(x: int) -> int:
@@ -92,6 +110,10 @@ class GraphedTrainStep:
         self._bump()
         torch.cuda.synchronize(self.dev)
         self.graph = torch.cuda.CUDAGraph()
+        # a data-parallel step is captured as TWO graphs: everything up to the end-of-pass weight-gradient flush, and the flush -- between
+        # their replays the part of the bucket the flush does not write is handed to RCCL on a side stream (dist.GradAllReduce)
+        self.split = bool(D.collective_needed(world) and D.SPLIT_ALLREDUCE)
+        self.graph2, self.flush_range = None, None
         TF.BLOCK_CALLS[0] = TF.BLOCK_CALLS[1] = 0
         A._SEED[0] = snap[4]            # the captured step draws the seeds an eager step would have drawn here
         ws_before = set(A._AXIS_WS)
@@ -102,7 +124,21 @@ class GraphedTrainStep:
                 opt.zero_grad()
                 y_pred, y_ref = rollout_model(model, self.batch, formatter, n_steps_output)
                 self.loss = MseMeanFn.apply(y_pred, y_ref)
-                run_backward(self.loss)
+                if self.split:
+                    A.reset_backward_state()
+                    A.HOLD_FLUSH[0] = True          # the engine's end-of-pass callback leaves the recorded weight gradients alone
+                    try:
+                        self.loss.backward()
+                    finally:
+                        A.HOLD_FLUSH[0] = False
+                else:
+                    run_backward(self.loss)
+            if self.split:
+                self.flush_range = A.flush_write_range(opt.flat_g)
+                self.graph2 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph2, pool=self.graph.pool(), capture_error_mode="thread_local"):
+                    A.flush_deferred_wgrads(force=True)
+                A.reset_backward_state(after=True)
             calls, fused = TF.BLOCK_CALLS
             if calls == 0 or fused != calls:
                 raise RuntimeError(f"GraphedTrainStep: {calls - fused} of {calls} block calls are not on the fused one-node path "
@@ -140,7 +176,14 @@ class GraphedTrainStep:
         self.count += 1
         self.set_seed_word(_splitmix64(self.seed * 0x100000001B3 + self.count))
         self.graph.replay()
-        if D.collective_needed(self.world):
+        if self.split:
+            ar = D.GradAllReduce(self.opt.flat_g)
+            if self.flush_range is not None:
+                ar.early(*self.flush_range)          # encoder / decoders / propagators / FiLM / embeddings: on a side stream ...
+            self.graph2.replay()                     # ... while the blocks' weight gradients and the LayerNorm folds run
+            ar.finish()
+            D.LAST_CALLS[:] = ar.calls
+        elif D.collective_needed(self.world):
             D.allreduce_sum_(self.opt.flat_g)
         self.opt.step(grad_scale=1.0 / self.world, lr=lr)
         return self.loss.detach()
