@@ -200,8 +200,13 @@ __global__ __launch_bounds__(256, NTT <= 3 ? 2 : 1) void block_bwd_fs_kernel(BfA
   // writes lane-linear, so the image's row swizzle is applied to the global SOURCE chunk each lane fetches (chunk c of row r lives at
   // c ^ (r & 15)).  (Round 5, first form: these rows were loaded in ACCUMULATOR layout -- 8 bytes per lane, 16 different rows per
   // instruction, every 64-byte line fetched twice -- and cost the launch 13-22 us: tools/build_variant.sh + -DBF_EXP_NO_ACCLOADS.)
+  auto fresh_lane = [&]() {
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    return ln;
+  };
   auto dma_rows = [&](const unsigned short* __restrict__ src) {
-    const int half = lane >> 5, sl = lane & 31;
+    const int ln_ = fresh_lane(), half = ln_ >> 5, sl = ln_ & 31;
 #pragma unroll
     for (int i = 0; i < 2 * NTT; ++i) {
       const int rp = wave + NW * i, r = 2 * rp + half;
@@ -218,8 +223,13 @@ __global__ __launch_bounds__(256, NTT <= 3 ? 2 : 1) void block_bwd_fs_kernel(BfA
   // ---- fp32 rows between memory (row form: 16 lanes x 16 B per token row of this wave's 64 features) and the accumulator layout ----------
   constexpr int CPR = 4 * RT, RPI = 64 / CPR, ROWB = CPR * 16, TILEB = 16 * ROWB;
   static_assert(IMG / NW >= TILEB, "staging piece too small");
-  const int rrow = lane / CPR, rchunk = lane % CPR;
+  // Every helper below derives its row / chunk indices from a LAUNDERED copy of the lane id: left alone, loop-invariant code motion computes
+  // the ~40 per-lane addresses of all their call sites once, keeps them alive across the launch and spills them -- and a scratch reload is a
+  // vector-memory wait in a queue that returns in order (it drains every row store and DMA in flight).  Recomputing them is a few VALU each.
+#define BF_RLANE const int ln_ = fresh_lane(), rrow = ln_ / CPR, rchunk = ln_ % CPR
+#define BF_BLANE const int ln_ = fresh_lane(), brow = ln_ / CPB, bchunk = ln_ % CPB
   auto slice_load = [&](const float* __restrict__ src, f32x4 (&raw)[NTT][RT]) {
+    BF_RLANE;
 #pragma unroll
     for (int tt = 0; tt < NTT; ++tt)
 #pragma unroll
@@ -229,6 +239,7 @@ __global__ __launch_bounds__(256, NTT <= 3 ? 2 : 1) void block_bwd_fs_kernel(BfA
       }
   };
   auto slice_to_acc = [&](char* stg, const f32x4 (&raw)[NTT][RT], f32x4 (&acc)[RT][NTT]) {      // stg: a private IMG / NW piece of a free image
+    BF_RLANE;
 #pragma unroll
     for (int tt = 0; tt < NTT; ++tt) {
 #pragma unroll
@@ -241,6 +252,7 @@ __global__ __launch_bounds__(256, NTT <= 3 ? 2 : 1) void block_bwd_fs_kernel(BfA
     }
   };
   auto slice_store = [&](char* stg, float* __restrict__ dst, const f32x4 (&acc)[RT][NTT], auto wt_c) {
+    BF_RLANE;
 #pragma unroll
     for (int tt = 0; tt < NTT; ++tt) {
 #pragma unroll
@@ -258,12 +270,12 @@ __global__ __launch_bounds__(256, NTT <= 3 ? 2 : 1) void block_bwd_fs_kernel(BfA
   };
   // bf16 rows: this wave's columns of image tile tt -> memory in row form (8 lanes x 16 B per token row, 8 rows per instruction)
   constexpr int CPB = 2 * RT, RPB = 64 / CPB;
-  const int brow = lane / CPB, bchunk = lane % CPB;
   // one sub-step = one instruction = 8 rows; a tensor's 2 NTT sub-steps ride the k-steps of the GEMM that FOLLOWS the phase that wrote the
   // image (rows_hook): issued together behind their phase, the 36 row stores of a wave (100 MB per launch at cfg3) formed bursts that the
   // next GEMM's weight loads queued behind (the wave's memory queue returns in order) -- 15-20 us of the launch (-DBF_EXP_NO_ROWSTORES)
   auto img_rows_store1 = [&](const char* img, auto tt_c, auto j_c, unsigned short* __restrict__ dst, long dstride, int dcol) {
     constexpr int tt = decltype(tt_c)::value, j = decltype(j_c)::value;
+    BF_BLANE;
     const int r = RPB * j + brow;
     const int t = tok_of(16 * tt + r);
     const u32x4 v = *(const u32x4*)(img + tt * 8192 + r * FS_ROW + (((CPB * wave + bchunk) ^ r) << 4));
@@ -310,6 +322,9 @@ __global__ __launch_bounds__(256, NTT <= 3 ? 2 : 1) void block_bwd_fs_kernel(BfA
   }
   auto drop4 = [&](const f32x4& v, unsigned long long seed, long i0) {
     if constexpr (!DROP) return v;
+    // (laundered: the mask depends on indices only, and left alone the compiler hashes LayerNorm2's masks in P0, two barriers early, and
+    // spills them -- every scratch reload then drains the wave's memory queue)
+    asm volatile("" : "+v"(i0));
     const unsigned k01 = dropout_keep2(seed, (unsigned long long)i0, A.p), k23 = dropout_keep2(seed, (unsigned long long)i0 + 2, A.p);
     return f32x4{(k01 & 1u) ? v[0] * ksc : 0.0f, (k01 & 2u) ? v[1] * ksc : 0.0f, (k23 & 1u) ? v[2] * ksc : 0.0f, (k23 & 2u) ? v[3] * ksc : 0.0f};
   };
@@ -393,7 +408,7 @@ __global__ __launch_bounds__(256, NTT <= 3 ? 2 : 1) void block_bwd_fs_kernel(BfA
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) acc[rt][tt] = zero4;
 #if BF_DMA_ROWS
-    fs_slice_gemm<1, 24, NTT, RT, false, PF>(wqt, wb, imgB, rdo, acc, BF_HOOK(imgB, A.dhpre, FS_C, 0));
+    fs_slice_gemm<1, 16, NTT, RT, false, PF>(wqt, wb, imgB, rdo, acc, BF_HOOK(imgB, A.dhpre, FS_C, 0));
     BF_STAMP(6);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();      // 2b: LayerNorm2's rows are in image C
@@ -408,7 +423,7 @@ __global__ __launch_bounds__(256, NTT <= 3 ? 2 : 1) void block_bwd_fs_kernel(BfA
     for (int tt = 0; tt < NTT; ++tt)
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) xh[rt][tt] = *(const u32x2*)(A.xh2 + off[tt] + 16 * rt);      // in flight under the GEMM
-    fs_slice_gemm<1, 24, NTT, RT, false, PF>(wqt, wb, imgB, rdo, acc, BF_HOOK(imgB, A.dhpre, FS_C, 0));
+    fs_slice_gemm<1, 16, NTT, RT, false, PF>(wqt, wb, imgB, rdo, acc, BF_HOOK(imgB, A.dhpre, FS_C, 0));
     BF_STAMP(6);
 #endif
 #pragma unroll
@@ -456,6 +471,9 @@ __global__ __launch_bounds__(256, NTT <= 3 ? 2 : 1) void block_bwd_fs_kernel(BfA
     slice_store(imgB + wave * (IMG / NW), A.dx, g, std::false_type{});      // image B: its readers (P2's GEMM) are behind barrier 3
 #endif
   }
+  // (Wo^T's first k-steps are requested HERE, not inside P2's GEMM: alive across LayerNorm2's backward, those 32 registers were what pushed
+  // the phase into scratch -- and a scratch reload drains the wave's whole memory queue, row stores and DMAs included)
+  fs_wring_prime<2, RT, PF>(wqt, wb);
   BF_BURST(imgA, A.dy1, FS_C, 0);
   __syncthreads();      // 4: every wave has read LayerNorm2's rows; image C takes LayerNorm1's (they land under P3's GEMM)
 #if BF_DMA_ROWS
@@ -676,30 +694,25 @@ __global__ __launch_bounds__(256, NTT <= 3 ? 2 : 1) void block_bwd_fs_kernel(BfA
         for (int j = 0; j < NK; ++j)
 #pragma unroll
           for (int r = 0; r < 4; ++r) dpt[j][r] = st[j][r] * (dpt[j][r] - delta) * scale;      // dS^T / sqrt(32)
-        u32x2 ktl[NP][2], kth[NP][2];      // K^T fragments for dQ (requested this late: every set of fragments alive at once does not fit)
-#pragma unroll
-        for (int g = 0; g < NP; ++g)
+        f32x4 dq[2] = {zero4, zero4};
+        static_for<NP>([&](auto g_c) {      // K^T fragments pair by pair (every pair's fragments alive at once does not fit the register file)
+          constexpr int g = decltype(g_c)::value, ja = 2 * g, jb = ja + 1;
+          u32x2 ktl[2], kth[2];
 #pragma unroll
           for (int dt = 0; dt < 2; ++dt) {
-            ktl[g][dt] = bf_tr(aC + to[dt] + (unsigned)(k0 + 2 * g) * 8192u);
-            kth[g][dt] = bf_tr(aC + to[dt] + (unsigned)(k0 + (2 * g + 1 < NK ? 2 * g + 1 : 2 * g)) * 8192u);
+            ktl[dt] = bf_tr(aC + to[dt] + (unsigned)(k0 + ja) * 8192u);
+            kth[dt] = bf_tr(aC + to[dt] + (unsigned)(k0 + (jb < NK ? jb : ja)) * 8192u);
           }
-        wait0();
-#pragma unroll
-        for (int g = 0; g < NP; ++g)
-#pragma unroll
-          for (int dt = 0; dt < 2; ++dt) { tie2(ktl[g][dt]); tie2(kth[g][dt]); }
-        f32x4 dq[2] = {zero4, zero4};
-        static_for<NP>([&](auto g_c) {
-          constexpr int g = decltype(g_c)::value, ja = 2 * g, jb = ja + 1;
           const u32x4 pf = pack8(dpt[ja], jb < NK ? dpt[jb < NK ? jb : ja] : zero4);
+          wait0();
+          tie2(ktl[0]); tie2(ktl[1]); tie2(kth[0]); tie2(kth[1]);
 #pragma unroll
-          for (int dt = 0; dt < 2; ++dt)
-            dq[dt] = mfma_bf16(u32x4{ktl[g][dt][0], ktl[g][dt][1], kth[g][dt][0], kth[g][dt][1]}, pf, dq[dt]);
+          for (int dt = 0; dt < 2; ++dt) dq[dt] = mfma_bf16(u32x4{ktl[dt][0], ktl[dt][1], kth[dt][0], kth[dt][1]}, pf, dq[dt]);
         });
         dqp[qt][0] = bf_pack4(dq[0]);
         dqp[qt][1] = bf_pack4(dq[1]);
-      });
+        __builtin_amdgcn_sched_barrier(0);      // tile after tile: interleaved (the mask hashes depend on indices only and float to the top), the
+      });                                       // tiles' temporaries do not fit the register file
       // ---- pass 2: keys in the columns ------------------------------------------------------------------------------------------------
       u32x2 dkp[NTT][2], dvp[NTT][2];
       static_for<NTT>([&](auto jt_c) {
@@ -722,18 +735,14 @@ __global__ __launch_bounds__(256, NTT <= 3 ? 2 : 1) void block_bwd_fs_kernel(BfA
           sv[i] = mfma_bf16(u32x4{q0r[i][0], q0r[i][1], q1r[i][0], q1r[i][1]}, kfj, zero4);      // rows = queries 4 kk + r, column = key l15
           dp[i] = mfma_bf16(u32x4{g0r[i][0], g0r[i][1], g1r[i][0], g1r[i][1]}, vf[hh][jt], zero4);
         }
-        f32x4 cq[NK], dq_[NK];      // the statistics of queries 4 kk .. 4 kk + 3 of every visible query tile
 #pragma unroll
         for (int i = 0; i < NK; ++i) {
-          cq[i] = *(const f32x4*)(wst + 16 * (k0 + i) + 4 * kk);
-          dq_[i] = *(const f32x4*)(wst + 16 * NTT + 16 * (k0 + i) + 4 * kk);
-        }
-#pragma unroll
-        for (int i = 0; i < NK; ++i) {
+          // the statistics of queries 4 kk .. 4 kk + 3 of this query tile
+          const f32x4 cqi = *(const f32x4*)(wst + 16 * (k0 + i) + 4 * kk), dqi = *(const f32x4*)(wst + 16 * NTT + 16 * (k0 + i) + 4 * kk);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const bool valid = nomask || ((allow2 >> r) & 1u);
-            const float pr = valid ? __builtin_amdgcn_exp2f(sv[i][r] - cq[i][r]) : 0.0f;
+            const float pr = valid ? __builtin_amdgcn_exp2f(sv[i][r] - cqi[r]) : 0.0f;
             float d = dp[i][r], pd = pr;
             if constexpr (DROP) {
               // pass 1 drew the keep bits of (query 4 kk + r of tile k0 + i, keys 4 (l15 >> 2) .. + 3 of this tile) in lane
@@ -745,36 +754,33 @@ __global__ __launch_bounds__(256, NTT <= 3 ? 2 : 1) void block_bwd_fs_kernel(BfA
               d = keep ? d * ksc : 0.0f;
             }
             sv[i][r] = pd;                                  // dropped probabilities (dV)
-            dp[i][r] = pr * (d - dq_[i][r]) * ln2;          // dS ln 2 (dK, against q')
+            dp[i][r] = pr * (d - dqi[r]) * ln2;             // dS ln 2 (dK, against q')
           }
         }
-        u32x2 qtl[NP][2], qth[NP][2], gtl[NP][2], gth[NP][2];      // Q^T and dO^T fragments for dK, dV
-#pragma unroll
-        for (int g = 0; g < NP; ++g)
+        f32x4 dk[2] = {zero4, zero4}, dv[2] = {zero4, zero4};
+        static_for<NP>([&](auto g_c) {      // Q^T and dO^T fragments for dK, dV, pair by pair
+          constexpr int g = decltype(g_c)::value, ia = 2 * g, ib = ia + 1;
+          u32x2 qtl[2], qth[2], gtl[2], gth[2];
 #pragma unroll
           for (int dt = 0; dt < 2; ++dt) {
-            const unsigned ta = to[dt] + (unsigned)(k0 + 2 * g) * 8192u, tb = to[dt] + (unsigned)(k0 + (2 * g + 1 < NK ? 2 * g + 1 : 2 * g)) * 8192u;
-            qtl[g][dt] = bf_tr(aA + ta); qth[g][dt] = bf_tr(aA + tb);
-            gtl[g][dt] = bf_tr(aB + ta); gth[g][dt] = bf_tr(aB + tb);
+            const unsigned ta = to[dt] + (unsigned)(k0 + ia) * 8192u, tb = to[dt] + (unsigned)(k0 + (ib < NK ? ib : ia)) * 8192u;
+            qtl[dt] = bf_tr(aA + ta); qth[dt] = bf_tr(aA + tb);
+            gtl[dt] = bf_tr(aB + ta); gth[dt] = bf_tr(aB + tb);
           }
-        wait0();
-#pragma unroll
-        for (int g = 0; g < NP; ++g)
-#pragma unroll
-          for (int dt = 0; dt < 2; ++dt) { tie2(qtl[g][dt]); tie2(qth[g][dt]); tie2(gtl[g][dt]); tie2(gth[g][dt]); }
-        f32x4 dk[2] = {zero4, zero4}, dv[2] = {zero4, zero4};
-        static_for<NP>([&](auto g_c) {
-          constexpr int g = decltype(g_c)::value, ia = 2 * g, ib = ia + 1;
           const u32x4 pfs = pack8(dp[ia], ib < NK ? dp[ib < NK ? ib : ia] : zero4);
           const u32x4 pfp = pack8(sv[ia], ib < NK ? sv[ib < NK ? ib : ia] : zero4);
+          wait0();
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt) { tie2(qtl[dt]); tie2(qth[dt]); tie2(gtl[dt]); tie2(gth[dt]); }
 #pragma unroll
           for (int dt = 0; dt < 2; ++dt) {
-            dk[dt] = mfma_bf16(u32x4{qtl[g][dt][0], qtl[g][dt][1], qth[g][dt][0], qth[g][dt][1]}, pfs, dk[dt]);
-            dv[dt] = mfma_bf16(u32x4{gtl[g][dt][0], gtl[g][dt][1], gth[g][dt][0], gth[g][dt][1]}, pfp, dv[dt]);
+            dk[dt] = mfma_bf16(u32x4{qtl[dt][0], qtl[dt][1], qth[dt][0], qth[dt][1]}, pfs, dk[dt]);
+            dv[dt] = mfma_bf16(u32x4{gtl[dt][0], gtl[dt][1], gth[dt][0], gth[dt][1]}, pfp, dv[dt]);
           }
         });
         dkp[jt][0] = bf_pack4(dk[0]); dkp[jt][1] = bf_pack4(dk[1]);
         dvp[jt][0] = bf_pack4(dv[0]); dvp[jt][1] = bf_pack4(dv[1]);
+        __builtin_amdgcn_sched_barrier(0);
       });
       // the head's results over its operands' columns (every read of them is behind us in this wave's in-order LDS queue)
 #pragma unroll
@@ -874,6 +880,7 @@ __global__ __launch_bounds__(256, NTT <= 3 ? 2 : 1) void block_bwd_fs_kernel(BfA
     // tile by tile through a private staging piece (every image is dead behind barrier 8): dx1's rows -> accumulator layout, the sum back
     // to row form, out (write-through: the launch's last output, at its very end)
     char* const stg = imgA + wave * (IMG / NW);
+    BF_RLANE;
 #pragma unroll
     for (int tt = 0; tt < NTT; ++tt) {
 #if BF_PARK_DX1
