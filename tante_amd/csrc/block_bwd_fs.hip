@@ -371,6 +371,12 @@ __global__ __launch_bounds__(256, NTT <= 3 ? 2 : 1) void block_bwd_fs_kernel(BfA
     for (int tt = 0; tt < NTT; ++tt)
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) hp[rt][tt] = *(const u32x2*)(imgC + tt * 8192 + wro[rt]);
+    // image C is free as soon as every wave holds its pre-activations: LayerNorm2's rows are requested NOW and land under this epilogue.
+    // (Requested behind barrier 2 they sat in front of P2's weight fragments in the wave's in-order memory queue: stamps, P2's GEMM
+    // 10.5 k cycles against 2.5 k for P1's.)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();      // 1b
+    dma_rows(A.xh2);
 #else
     u32x2 hp[RT][NTT];
 #pragma unroll
@@ -394,10 +400,7 @@ __global__ __launch_bounds__(256, NTT <= 3 ? 2 : 1) void block_bwd_fs_kernel(BfA
     }
   }
   BF_BURST(imgB, A.dhpre, FS_C, 0);
-  __syncthreads();      // 2: every wave has read its pre-activations; image C takes LayerNorm2's rows (they land under P2's GEMM)
-#if BF_DMA_ROWS
-  dma_rows(A.xh2);
-#endif
+  __syncthreads();      // 2
   BF_STAMP(5);
 
   // ================================ P2: dxh2 = W1'^T dhpre ; LayerNorm2 backward + skip -> dx1 (registers) ; dy1 -> image A and memory ====
@@ -417,6 +420,9 @@ __global__ __launch_bounds__(256, NTT <= 3 ? 2 : 1) void block_bwd_fs_kernel(BfA
     for (int tt = 0; tt < NTT; ++tt)
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) xh[rt][tt] = *(const u32x2*)(imgC + tt * 8192 + wro[rt]);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();      // 2c: every wave holds LayerNorm2's rows: LayerNorm1's are requested now and land under this epilogue
+    dma_rows(A.xh1);
 #else
     u32x2 xh[RT][NTT];
 #pragma unroll
@@ -475,10 +481,7 @@ __global__ __launch_bounds__(256, NTT <= 3 ? 2 : 1) void block_bwd_fs_kernel(BfA
   // the phase into scratch -- and a scratch reload drains the wave's whole memory queue, row stores and DMAs included)
   fs_wring_prime<2, RT, PF>(wqt, wb);
   BF_BURST(imgA, A.dy1, FS_C, 0);
-  __syncthreads();      // 4: every wave has read LayerNorm2's rows; image C takes LayerNorm1's (they land under P3's GEMM)
-#if BF_DMA_ROWS
-  dma_rows(A.xh1);
-#endif
+  __syncthreads();      // 4
   BF_STAMP(7);
 
   // ================================ P3: do = Wo^T dy1 -> operand fragments (registers) and image B ========================================
@@ -804,6 +807,8 @@ __global__ __launch_bounds__(256, NTT <= 3 ? 2 : 1) void block_bwd_fs_kernel(BfA
   slice_load(A.dx, dx1raw);
 #endif
 #if !BF_HOOK_STORES
+  // (issued per head, right behind each head's image writes, so that head 0's drain under head 1: measured, same box, no gain -- 8.94 ms
+  // per train step either way; what the closing GEMMs wait for is not these stores' place in the queue)
   BF_BURST(imgC, A.dqkv, 3 * FS_C, 0);
   BF_BURST(imgA, A.dqkv, 3 * FS_C, FS_C);
   BF_BURST(imgB, A.dqkv, 3 * FS_C, 2 * FS_C);

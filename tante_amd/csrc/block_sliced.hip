@@ -293,7 +293,11 @@ __global__ __launch_bounds__(64 * NW * G, 2) void block_fs_kernel(FsArgs A) {
       // (ordinary stores: written through they buy nothing -- 9.65 ms per train step either way.  The first attempt gave NaN losses: the
       // write-through store is an asm statement, and a GELU that reused its data registers right behind it hit the store-data hazard the
       // compiler's recognizer does not see inside asm -- st_wt16 carries the wait states now, common.hip.h)
+#ifdef FS_EXP_NO_SAVE      // timing experiment only (wrong results): what the saved tensors' row stores cost the training forward
+      if (t >= 0 && v[0] == 0x12345u) *(u32x4*)(dst + (long)t * dstride + dcol + 16 * RT * wave + 8 * bchunk) = v;
+#else
       if (t >= 0) *(u32x4*)(dst + (long)t * dstride + dcol + 16 * RT * wave + 8 * bchunk) = v;
+#endif
     }
   };
   auto slice_store = [&](float* __restrict__ dst, const f32x4 (&acc)[RT][NTT]) {
@@ -419,7 +423,11 @@ __global__ __launch_bounds__(64 * NW * G, 2) void block_fs_kernel(FsArgs A) {
         const int chunk = (l15 >> 1) + 8 * j;
         *(u32x2*)(bufA + slot * FS_ROW + ((chunk ^ t15) << 4) + (l15 & 1) * 8) = o2;
         if constexpr (TRAIN) {
+#ifdef FS_EXP_NO_SAVE
+          if (lv[i] && o2[0] == 0x12345u) *(u32x2*)(A.xh1 + (long)tis[i] * FS_C + 4 * (l15 + 16 * j)) = o2;
+#else
           if (lv[i]) *(u32x2*)(A.xh1 + (long)tis[i] * FS_C + 4 * (l15 + 16 * j)) = o2;
+#endif
         }
       }
       if constexpr (TRAIN) {
