@@ -516,7 +516,9 @@ _HE_WS = {}
 def head_enc_workspace(rows: int, device: torch.device) -> torch.Tensor:
     """The zeroed workspace of tante_head_enc_fused for `rows` tokens, one per (device, stream, size): the kernel leaves its arrival
     counters at zero, so it is cleared once."""
-    key = (device.index, _stream(), rows)
+    # (the group size is part of the key: the arrival counters sit behind the fragments, whose size depends on it -- flipping
+    # TANTE_HEAD_WAVES between calls would otherwise move the counters onto bytes that held fragments: ADVICE round 4)
+    key = (device.index, _stream(), rows, L.get_option("TANTE_HEAD_WAVES", 0))
     ws = _HE_WS.get(key)
     if ws is None:
         ws = torch.zeros(L.lib().tante_head_enc_ws_bytes(rows), dtype=torch.uint8, device=device)

@@ -42,9 +42,13 @@ def host_options():
     return sorted(_REGISTRY)
 
 
+EPOCH = [0]      # bumped by every set_option: captured graphs (rollout.GraphedRollout) re-capture when a switch changed under them
+
+
 def set_option(name: str, value) -> None:
     """Set a host option (a registered module flag) or a library option (tante_set_option) by its TANTE_* name."""
     from . import _lib
+    EPOCH[0] += 1
     if name not in _REGISTRY:
         _load_owners()
     if name in _REGISTRY:

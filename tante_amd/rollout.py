@@ -221,8 +221,13 @@ class GraphedRollout:
         self._capture()
 
     def _weights_key(self):
-        from .attn_backbone import _WEIGHT_EPOCH
-        return (_WEIGHT_EPOCH[0],) + tuple((p.data_ptr(), p._version) for p in self.model.parameters())
+        # what the captured launches depend on besides the batch: the parameters (by address and version), the compute mode the model
+        # resolves to (set_compute / an enclosing autocast) and the A/B switches (options.EPOCH): any change re-captures (ADVICE round 4:
+        # set_compute or a set_option flip kept replaying the stale graph)
+        from .attn_backbone import _WEIGHT_EPOCH, resolve_compute
+        from .options import EPOCH
+        return (_WEIGHT_EPOCH[0], EPOCH[0], resolve_compute(getattr(self.model, "compute", None))) + tuple(
+            (p.data_ptr(), p._version) for p in self.model.parameters())
 
     def _run(self):
         with torch.inference_mode():
@@ -230,7 +235,9 @@ class GraphedRollout:
 
     def _capture(self):
         dev = self.device
-        side = torch.cuda.Stream(device=dev)
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=dev)      # one warm-up stream for every (re-)capture: per-stream workspaces are keyed to it
+        side = self._side
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
             for _ in range(2):
