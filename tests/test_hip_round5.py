@@ -337,3 +337,32 @@ def test_constructor_default_patch_scale_trains(dev):
         worst = max(worst, err)
         assert err < 2e-4, (k, err)
     record_parity(worst, worst, 2e-4, "fp32", "TANTE(patch_scale=32) parameter gradients vs oracle autograd")
+
+
+def test_graphed_rollout_follows_compute_and_option_changes(dev):
+    """GraphedRollout keyed its capture on the parameters only and kept replaying a stale graph after
+    `model.set_compute(...)` or a `set_option` flip.  The key now carries the resolved compute mode and the options epoch."""
+    import tante_amd
+    torch.manual_seed(3)
+    md = tante_amd.TanteMetadata(n_fields=2, spatial_resolution=(64, 64))
+    m = tante_amd.TANTE(in_T=4, dset_metadata=md, taylor_order=1, attn_axes="THW", n_head=8, embed_dim=256, patch_scale=8, dropout=0.0).to(dev).eval()
+    m.set_compute("bf16")
+    fmt = tante_amd.DefaultChannelsFirstFormatter(md)
+    g = torch.Generator().manual_seed(4)
+    batch = {"input": torch.randn(2, 4, 64, 64, 2, generator=g).to(dev), "output": torch.randn(2, 3, 64, 64, 2, generator=g).to(dev)}
+    roll = tante_amd.GraphedRollout(m, batch, fmt, 3)
+    y16 = roll(batch)[0].clone()
+    with torch.inference_mode():
+        e16 = tante_amd.rollout_model(m, batch, fmt, 3, device=dev)[0]
+    assert torch.equal(y16, e16)
+    k0 = roll._key
+    m.set_compute("fp32")
+    y32 = roll(batch)[0].clone()
+    assert roll._key != k0, "no re-capture after set_compute"
+    with torch.inference_mode():
+        e32 = tante_amd.rollout_model(m, batch, fmt, 3, device=dev)[0]
+    assert torch.equal(y32, e32) and not torch.equal(y32, y16)
+    k1 = roll._key
+    tante_amd.set_option("TANTE_HEAD_ENC", 1)      # any set_option bumps the options epoch
+    roll(batch)
+    assert roll._key != k1, "no re-capture after set_option"
