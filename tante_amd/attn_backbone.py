@@ -211,6 +211,10 @@ class TransformerBlock(nn.Module):
         am = None
         if attn_mask is not None:
             am = attn_mask.to(dev)
+            if causal and am.dtype != torch.bool:
+                # attn_backbone.py:70-72: under `causal` the reference combines `attn_mask.bool() | causal_mask`, i.e. ANY non-zero entry of a
+                # float mask blocks (it is not added); without `causal` a float mask stays additive, as nn.MultiheadAttention takes it
+                am = am != 0
             if am.dtype == torch.bool:
                 am = torch.zeros(am.shape, dtype=torch.float32, device=dev).masked_fill_(am, ninf)
             am = am.to(torch.float32).contiguous()

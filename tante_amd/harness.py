@@ -217,13 +217,29 @@ def train_one_epoch(model, optimizer, dataloader, formatter, n_steps_output: int
         if scaler is None and dt == torch.float16:
             scaler = getattr(model, "_tante_grad_scaler", None) or torch.amp.GradScaler("cuda", enabled=True)
             model._tante_grad_scaler = scaler
+        if graph:
+            import warnings
+            warnings.warn("tante_amd.harness.train_one_epoch: graph=True is ignored with enable_amp (the captured step resolves its compute mode "
+                          "at capture; call model.set_compute('bf16') and pass enable_amp=False to replay the step as a HIP graph)")
+        # The reference leaves the autocast context BEFORE scaler.scale(loss).backward() (trainer/trainer.py:183-196).  Here the context only
+        # SELECTS the kernels (attn_backbone.resolve_compute reads it during the forward; the backward nodes carry the mode they were built
+        # with, and clip + AdamW run on fp32 buckets whatever the context), so the forward alone is what must sit inside it: the model is
+        # switched for the step instead of wrapping backward and step in the context.
+        mode = "bf16"
+        prev = getattr(model, "compute", None)
         for batch in dataloader:
             batch = {"input": batch["input"].to(device), "output": batch["output"][:, :n_steps_output].contiguous().to(device)}
-            with torch.autocast("cuda", dtype=dt):
+            model.set_compute(mode)
+            try:
                 if getattr(model, "deg", True):
                     losses.append(train_step(model, optimizer, batch, formatter, n_steps_output, world, scaler=scaler))
                 else:
+                    if scaler is not None and scaler.is_enabled():
+                        raise NotImplementedError("the adaptive-dt trainer (R_Trainer, r_trainer.py:135-179) clips by VALUE between backward and step; "
+                                                  "a float16 GradScaler is not wired through train_step_adaptive: use amp_type='bfloat16'")
                     losses.append(train_step_adaptive(model, optimizer, batch, formatter, n_steps_output, rt_eps, rt_n, world)[0])
+            finally:
+                model.set_compute(prev)
         return float(torch.stack(losses).mean()) if losses else float("nan")
     for batch in dataloader:
         batch = {"input": batch["input"].to(device), "output": batch["output"][:, :n_steps_output].contiguous().to(device)}

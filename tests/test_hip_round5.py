@@ -366,3 +366,43 @@ def test_graphed_rollout_follows_compute_and_option_changes(dev):
     tante_amd.set_option("TANTE_HEAD_ENC", 1)      # any set_option bumps the options epoch
     roll(batch)
     assert roll._key != k1, "no re-capture after set_option"
+
+
+def test_epoch_with_amp_equals_the_bf16_compute_mode_and_float_masks_block_under_causal(dev):
+    """ADVICE round 4, harness.py: train_one_epoch(enable_amp=True) wrapped backward and the optimizer step in the autocast context (the
+    reference leaves it before backward, trainer/trainer.py:183-196).  It now switches the model's compute mode for the forward only: two
+    steps land exactly where two `set_compute("bf16")` steps land, and the model's own setting is restored.  And TransformerBlock.forward
+    with a FLOAT attn_mask plus causal=True blocks every non-zero entry (attn_backbone.py:70-72: `attn_mask.bool() | causal_mask`)."""
+    import copy
+    import tante_amd
+    from tante_amd import autograd as A, harness as H
+    from tante_amd.train import train_step
+    torch.manual_seed(5)
+    md = tante_amd.TanteMetadata(n_fields=2, spatial_resolution=(64, 64))
+    m1 = tante_amd.TANTE(in_T=4, dset_metadata=md, taylor_order=1, attn_axes="THW", n_head=8, embed_dim=256, patch_scale=8, dropout=0.0).to(dev).train()
+    m2 = copy.deepcopy(m1)
+    fmt = tante_amd.DefaultChannelsFirstFormatter(md)
+    g = torch.Generator().manual_seed(9)
+    batches = [{"input": torch.randn(2, 4, 64, 64, 2, generator=g), "output": torch.randn(2, 2, 64, 64, 2, generator=g)} for _ in range(2)]
+    o1 = tante_amd.FlatAdamW(m1.parameters(), lr=1e-4, weight_decay=0.01, max_norm=1.0)
+    o2 = tante_amd.FlatAdamW(m2.parameters(), lr=1e-4, weight_decay=0.01, max_norm=1.0)
+    A._SEED[0] = 77
+    l1 = H.train_one_epoch(m1, o1, batches, fmt, 2, enable_amp=True, amp_type="bfloat16")
+    assert m1.compute is None
+    A._SEED[0] = 77
+    m2.set_compute("bf16")
+    l2 = [float(train_step(m2, o2, {k: v.to(dev) for k, v in b.items()}, fmt, 2, 1)) for b in batches]
+    assert abs(l1 - sum(l2) / 2) < 1e-6 * abs(l1)
+    assert float((o1.flat_p - o2.flat_p).abs().max()) < 1e-7
+    # float mask + causal
+    torch.manual_seed(6)
+    blk = tante_amd.TransformerBlock(64, 4, mlp_ratio=1.0, dropout=0.0).to(dev).eval()
+    x = torch.randn(3, 8, 64, device=dev)
+    fm = torch.zeros(8, 8)
+    fm[5, 2] = 0.5          # a float entry that an ADDITIVE mask would merely nudge; under causal it must block (5 -> 2)
+    fm[1, 0] = -3.0
+    with torch.no_grad():
+        y_f = blk(x, attn_mask=fm.to(dev), causal=True)
+        y_b = blk(x, attn_mask=(fm != 0).to(dev), causal=True)
+        y_c = blk(x, causal=True)
+    assert torch.equal(y_f, y_b) and not torch.equal(y_f, y_c)
