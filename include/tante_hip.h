@@ -119,6 +119,10 @@ typedef struct TanteGemm {
   uint64_t drop_seed;
   const void* dact;
   int32_t dact_dtype, dact_kind;
+  /* PATCH_NCHW only (ABI 9): 'same' padding of a kernel-P stride-P conv (enc_dec_cnn.py:66-81: (P - 1) / 2): patch (ho, wo) starts at pixel
+   * (ho P - a_pad, wo P - a_pad), zero outside the image.  0, or 1 with P = 4 on the bf16 register-stationary path (K = 256 / 512,
+   * M >= 4096, linear epilogue, act none / exact GELU); anything else is refused (-2). */
+  int32_t a_pad;
 } TanteGemm;
 
 /* out = epilogue(gather(a) @ W^T).  Replaces, depending on the descriptor:

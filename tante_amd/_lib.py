@@ -33,6 +33,7 @@ class Gemm(C.Structure):
         ("film_a", c_vp), ("film_b", c_vp), ("s_emb", c_vp), ("T", c_i32), ("HW", c_i32),
         ("Hi", c_i32), ("Wi", c_i32), ("Po", c_i32), ("Cout", c_i32),
         ("drop_p", c_f32), ("drop_seed", C.c_uint64), ("dact", c_vp), ("dact_dtype", c_i32), ("dact_kind", c_i32),
+        ("a_pad", c_i32),
     ]
 
 
@@ -219,7 +220,7 @@ LIB_OPTIONS = ("TANTE_ATTN_BWD_HG", "TANTE_ATTN_BWD_NO_SPLIT", "TANTE_ATTN_BWD_V
 
 
 _lib = None
-ABI_VERSION = 8      # include/tante_hip.h: bumped whenever an entry point is added or changes (round 4: 6 tante_head_enc_*, 7 tante_pos_embed_tmajor + tante_spectral_*bf16out*; round 5: 8 tante_block_bwd_fused)
+ABI_VERSION = 9      # include/tante_hip.h: bumped whenever an entry point is added or changes (round 4: 6 tante_head_enc_*, 7 tante_pos_embed_tmajor + tante_spectral_*bf16out*; round 5: 8 tante_block_bwd_fused, 9 TanteGemm.a_pad)
 
 
 def lib():

@@ -22,6 +22,8 @@
 
 namespace {
 
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
 constexpr int nt_for_cb(int CB) { return (512 / CB) < 64 ? (512 / CB) : 64; }
 
 struct RowInfo {
@@ -578,7 +580,92 @@ __device__ __forceinline__ void epilogue4_train(const TanteGemm& g, const EpiRow
   store4(g.out, g.out_dtype, e.o_base + n0, v);
 }
 
-template <int CB, int TT, int EP, int TR = 0>
+// Token fragments straight from a channels-FIRST image (TANTE_A_PATCH_NCHW, kernel P, stride P, padding a_pad = 0 or -- P = 4 only -- the
+// 'same' padding 1 of enc_dec_cnn.py:66-81, under which the conv still has H / P x W / P outputs and only the top row / left column of
+// the patch grid reach outside the image): lane (token l15, k-chunk q) needs 8 consecutive k = (ci, kh, kw) of its patch -- at P = 4 two
+// image rows of four pixels of channel q / 2, at P = 2 two rows of two pixels of channels 2 q and 2 q + 1 -- and the 16 tokens of a wave
+// are 16 neighbouring patches, so every load instruction covers whole 128-byte (bf16, P = 4) runs of four image rows.  With the padding
+// the four pixels start one to the left of an aligned quad: the lane loads its own quad and the quad before it (the neighbour lane's,
+// an L1 hit) and funnel-shifts.  Values are rounded to bf16 exactly as tante_im2col's gather rounds them, and the k order is the packed
+// weight's, so the product is bit-identical to im2col + the dense kernel -- without the (M, K) matrix, which at cfg5's first conv stage
+// (8 images x 32 ch x 512 x 512 -> 131072 x 512) was a 134 MB write and a 134 MB read around a 118 us gather.
+// AM: 1 / 2 = P 4 from bf16 / fp32, 3 / 4 = P 2 from bf16 / fp32.
+struct PatchRow {
+  long org;          // element offset of pixel (ho P, wo P) of channel 0
+  bool ok, top, left;
+};
+
+__device__ __forceinline__ PatchRow patch_row(const TanteGemm& g, int row) {
+  PatchRow pr;
+  pr.ok = row < g.M;
+  const int r = pr.ok ? row : 0;
+  const int Wo = g.Win / g.P, Ho = g.Hin / g.P;
+  const int img = r / (Ho * Wo), rem = r % (Ho * Wo);
+  const int ho = rem / Wo, wo = rem % Wo;
+  pr.org = (long)(img / g.a_n0) * g.a_s1 + (long)(img % g.a_n0) * g.Cin * g.Hin * g.Win + g.a_off + ((long)ho * g.P) * g.Win + (long)wo * g.P;
+  pr.top = g.a_pad != 0 && ho == 0;
+  pr.left = g.a_pad != 0 && wo == 0;
+  return pr;
+}
+
+template <int AM>
+__device__ __forceinline__ u32x4 patch_frag(const TanteGemm& g, const PatchRow& pr, int q) {
+  const long plane = (long)g.Hin * g.Win;
+  if constexpr (AM == 1 || AM == 2) {
+    const int kh0 = (q & 1) * 2;
+    const long o = pr.org + (long)(q >> 1) * plane + (long)(kh0 - g.a_pad) * g.Win;
+    const bool skip0 = pr.top && kh0 == 0;      // image row -1
+    if constexpr (AM == 1) {
+      const unsigned short* p = (const unsigned short*)g.a + o;
+      u32x2 r0 = {0u, 0u}, r1;
+      if (!skip0) r0 = *(const u32x2*)p;
+      r1 = *(const u32x2*)(p + g.Win);
+      if (g.a_pad) {
+        u32x2 l0 = {0u, 0u}, l1 = {0u, 0u};
+        if (!pr.left) {
+          if (!skip0) l0 = *(const u32x2*)(p - 4);
+          l1 = *(const u32x2*)(p + g.Win - 4);
+        }
+        return u32x4{(l0[1] >> 16) | (r0[0] << 16), (r0[0] >> 16) | (r0[1] << 16), (l1[1] >> 16) | (r1[0] << 16), (r1[0] >> 16) | (r1[1] << 16)};
+      }
+      return u32x4{r0[0], r0[1], r1[0], r1[1]};
+    } else {
+      const float* p = (const float*)g.a + o;
+      f32x4 r0 = {0.f, 0.f, 0.f, 0.f}, r1;
+      if (!skip0) r0 = *(const f32x4*)p;
+      r1 = *(const f32x4*)(p + g.Win);
+      if (g.a_pad) {
+        float l0 = 0.0f, l1 = 0.0f;
+        if (!pr.left) {
+          if (!skip0) l0 = p[-1];
+          l1 = p[g.Win - 1];
+        }
+        return u32x4{pack_bf16x2(l0, r0[0]), pack_bf16x2(r0[1], r0[2]), pack_bf16x2(l1, r1[0]), pack_bf16x2(r1[1], r1[2])};
+      }
+      return u32x4{pack_bf16x2(r0[0], r0[1]), pack_bf16x2(r0[2], r0[3]), pack_bf16x2(r1[0], r1[1]), pack_bf16x2(r1[2], r1[3])};
+    }
+  } else {
+    const long o = pr.org + (long)(q * 2) * plane;
+    if constexpr (AM == 3) {
+      const unsigned short* p = (const unsigned short*)g.a + o;
+      return u32x4{*(const unsigned*)p, *(const unsigned*)(p + g.Win), *(const unsigned*)(p + plane), *(const unsigned*)(p + plane + g.Win)};
+    } else {
+      const float* p = (const float*)g.a + o;
+      const f32x2 a = *(const f32x2*)p, b = *(const f32x2*)(p + g.Win), c = *(const f32x2*)(p + plane), d = *(const f32x2*)(p + plane + g.Win);
+      return u32x4{pack_bf16x2(a[0], a[1]), pack_bf16x2(b[0], b[1]), pack_bf16x2(c[0], c[1]), pack_bf16x2(d[0], d[1])};
+    }
+  }
+}
+
+// what the fragment-load form needs (tante_gemm refuses a_pad != 0 elsewhere: no other path implements the padding)
+inline bool patch_lite_ok(const TanteGemm& g, int flags, int cb) {
+  return g.a_mode == TANTE_A_PATCH_NCHW && g.compute == TANTE_BF16 && !g.ln && g.drop_p <= 0.0f && !g.dact && (flags & 2) && g.e_mode == TANTE_E_LINEAR &&
+         (cb == 8 || cb == 16) && g.K == cb * 32 && g.M >= 4096 && (g.P == 2 || g.P == 4) && ((uintptr_t)g.a % 16) == 0 &&
+         (g.a_dtype == TANTE_BF16 || g.a_dtype == TANTE_F32) && (g.a_pad == 0 || (g.a_pad == 1 && g.P == 4)) &&
+         (g.act == TANTE_ACT_NONE || g.act == TANTE_ACT_GELU_ERF);
+}
+
+template <int CB, int TT, int EP, int TR = 0, int AM = 0>
 __global__ __launch_bounds__(256, 4) void gemm_lite_kernel(const TanteGemm g, int n_tiles, int tiles_per_split) {
   constexpr int CPR = CB * 4, NT = nt_for_cb(CB), NSUB = NT / 16, TILE_U = NT * CPR, UPT = TILE_U / 256;
   extern __shared__ __attribute__((aligned(16))) char smem[];  // one tile
@@ -600,11 +687,20 @@ __global__ __launch_bounds__(256, 4) void gemm_lite_kernel(const TanteGemm g, in
   u32x4 xf[TT][CB];
 #pragma unroll
   for (int tt = 0; tt < TT; ++tt) {
-    const RowInfo ri = row_info(g, row0 + tt * 16 + l15);
+    if constexpr (AM == 0) {
+      const RowInfo ri = row_info(g, row0 + tt * 16 + l15);
 #pragma unroll
-    for (int cb = 0; cb < CB; ++cb) {
-      xf[tt][cb] = u32x4{0u, 0u, 0u, 0u};
-      if (ri.ok) xf[tt][cb] = *(const u32x4*)((const unsigned short*)g.a + ri.a_base + (cb * 4 + kk) * 8);
+      for (int cb = 0; cb < CB; ++cb) {
+        xf[tt][cb] = u32x4{0u, 0u, 0u, 0u};
+        if (ri.ok) xf[tt][cb] = *(const u32x4*)((const unsigned short*)g.a + ri.a_base + (cb * 4 + kk) * 8);
+      }
+    } else {
+      const PatchRow pr = patch_row(g, row0 + tt * 16 + l15);
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) {
+        xf[tt][cb] = u32x4{0u, 0u, 0u, 0u};
+        if (pr.ok) xf[tt][cb] = patch_frag<AM>(g, pr, cb * 4 + kk);
+      }
     }
   }
   EpiRow er[TT];
@@ -646,7 +742,7 @@ __global__ __launch_bounds__(256, 4) void gemm_lite_kernel(const TanteGemm g, in
   }
 }
 
-template <int CB, int EP, int TR = 0>
+template <int CB, int EP, int TR = 0, int AM = 0>
 void launch_lite(const TanteGemm& g, int n_tiles, hipStream_t s) {
   constexpr int TT = (CB <= 8) ? 2 : 1;
   constexpr int NT = nt_for_cb(CB);
@@ -656,12 +752,30 @@ void launch_lite(const TanteGemm& g, int n_tiles, hipStream_t s) {
   for (int d = 1; d <= n_tiles; ++d)
     if (n_tiles % d == 0) { nsplit = d; if ((long)gx * d >= 768) break; }
   const size_t lds = (size_t)NT * CB * 4 * 16;
-  hipLaunchKernelGGL((gemm_lite_kernel<CB, TT, EP, TR>), dim3(gx, nsplit), dim3(256), lds, s, g, n_tiles, n_tiles / nsplit);
+  hipLaunchKernelGGL((gemm_lite_kernel<CB, TT, EP, TR, AM>), dim3(gx, nsplit), dim3(256), lds, s, g, n_tiles, n_tiles / nsplit);
+}
+
+template <int CB, int AM>
+bool lite_patch(const TanteGemm& g, int n_tiles, hipStream_t s) {
+  switch (g.act) {
+    case TANTE_ACT_NONE: launch_lite<CB, EP_LIN_NONE, 0, AM>(g, n_tiles, s); return true;
+    case TANTE_ACT_GELU_ERF: launch_lite<CB, EP_LIN_GELU_ERF, 0, AM>(g, n_tiles, s); return true;
+    default: return false;
+  }
 }
 
 template <int CB>
 bool try_lite(const TanteGemm& g, int n_tiles, int flags, hipStream_t s) {
   const bool off = tante_opt("TANTE_GEMM_NO_LITE", 0) != 0;
+  if (g.a_mode == TANTE_A_PATCH_NCHW) {     // the patch gather of a channels-first image as the fragment load (patch_frag)
+    if ((off && !g.a_pad) || !patch_lite_ok(g, flags, CB)) return false;
+    if constexpr (CB >= 8) {
+      const bool b16 = g.a_dtype == TANTE_BF16;
+      if (g.P == 4) return b16 ? lite_patch<CB, 1>(g, n_tiles, s) : lite_patch<CB, 2>(g, n_tiles, s);
+      return b16 ? lite_patch<CB, 3>(g, n_tiles, s) : lite_patch<CB, 4>(g, n_tiles, s);
+    }
+    return false;
+  }
   if ((off && g.drop_p <= 0.0f && !g.dact) || g.ln || g.a_mode != TANTE_A_LINEAR || g.a_dtype != TANTE_BF16 || (flags & 3) != 3 || g.e_mode != TANTE_E_LINEAR) return false;
   if (g.K != CB * 32 || g.M < 4096) return false;   // whole 32-wide k blocks: the raw fragment loads have no K tail
   if (g.drop_p > 0.0f || g.dact) {
@@ -952,6 +1066,8 @@ extern "C" int tante_gemm(const TanteGemm* gp, void* stream) {
                     g.act != TANTE_ACT_NONE || (flags & 3) != 3 || g.M < 4096 || (g.K != 128 && g.K != 256 && g.K != 512) || (g.drop_p > 0.0f && g.dact) ||
                     (g.dact && (((uintptr_t)g.dact % 16) || g.N % 4))))
     TANTE_FAIL(-2, "tante_gemm: the dropout / activation-gradient epilogues need dense 16-byte aligned bf16 rows, M >= 4096, K of 128, 256 or 512, no LayerNorm, no activation");
+  if (g.a_pad < 0 || (g.a_pad != 0 && !patch_lite_ok(g, flags, geo.cb)))
+    TANTE_FAIL(-2, "tante_gemm: a_pad needs a channels-first bf16-compute patch stage with P = 4, a_pad = 1, K of 256 or 512, M >= 4096, a linear epilogue");
   const int n_tiles = geo.n_pad / geo.nt;
   hipStream_t s = (hipStream_t)stream;
   const bool bf = g.compute == TANTE_BF16;

@@ -128,17 +128,18 @@ def linear_train_epilogue_ok(a: torch.Tensor, M: int, N: int, Kk: int, compute: 
 
 def patch_embed(a: torch.Tensor, pw: PackedWeight, out: torch.Tensor, *, n_img: int, Hin: int, Win: int, Cin: int, P: int,
                 nchw: bool, act: int, film: Optional[tuple] = None, imgs_per_item: Optional[int] = None, item_stride: int = 0,
-                elem_off: int = 0):
+                elem_off: int = 0, pad: int = 0):
     """Patch conv with kernel = stride = P as a GEMM over non-overlapping patches.  `a` is
     (n_img, Cin, Hin, Win) when nchw else (n_img, Hin, Win, Cin); out is channels-last
-    (n_img, Hin/P, Win/P, N).  film = (film_a, film_b, s_emb, T, HW) selects the FiLM + positional epilogue."""
+    (n_img, Hin/P, Win/P, N).  film = (film_a, film_b, s_emb, T, HW) selects the FiLM + positional epilogue.  pad: TanteGemm.a_pad (the
+    'same' padding 1 of a P = 4 stage, channels-first bf16-compute only -- the library refuses what it cannot serve)."""
     M = n_img * (Hin // P) * (Win // P)
     if not a.is_cuda:
         raise RuntimeError("tante_amd kernels need CUDA/HIP tensors (no CPU fallback)")
     g = _base(pw, a if a.is_contiguous() else a.new_empty(0), M, out, act)
     g.a = a.data_ptr()        # may be a strided window view: addressing is explicit below
     g.a_mode = L.A_PATCH_NCHW if nchw else L.A_PATCH_NHWC
-    g.Hin, g.Win, g.Cin, g.P = Hin, Win, Cin, P
+    g.Hin, g.Win, g.Cin, g.P, g.a_pad = Hin, Win, Cin, P, pad
     g.a_n0 = n_img if imgs_per_item is None else imgs_per_item
     g.a_s1, g.a_off = item_stride, elem_off
     g.out_ld = pw.N

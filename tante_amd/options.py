@@ -33,7 +33,7 @@ def register(name: str, default, module: str, attr: str):
 def _load_owners():
     """The modules that own switches register them when they are imported; make sure all of them have been."""
     import importlib
-    for m in ("attn_backbone", "autograd", "tante", "train_forward", "rollout", "cvit"):
+    for m in ("attn_backbone", "autograd", "tante", "train_forward", "rollout", "cvit", "stages"):
         importlib.import_module("tante_amd." + m)
 
 

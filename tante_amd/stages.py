@@ -12,6 +12,7 @@ import torch
 
 from . import _lib as L
 from . import kernels as K
+from . import options as _O
 
 KMAX = 512   # register-stationary K limit of tante_gemm
 
@@ -50,6 +51,10 @@ def linear_chunks(a: torch.Tensor, chunks: List[K.PackedWeight], out_dtype: torc
     return acc
 
 
+# False: non-overlapping channels-first conv stages always run as tante_im2col + the dense GEMM (the A/B and parity reference of the fused route)
+PATCH_GEMM = _O.register("TANTE_CONV_PATCH_GEMM", True, __name__, "PATCH_GEMM")
+
+
 def conv_weight_2d(w: torch.Tensor, korder: int) -> torch.Tensor:
     """Conv weight (Cout, Cin, kh, kw[, ...]) -> (Cout, K) in the im2col column order."""
     w = w.detach()
@@ -70,6 +75,14 @@ def conv_stage(x: torch.Tensor, nchw: bool, n_img: int, Cin: int, H: int, W: int
     Hc, Wc = (H + 2 * p - P) // s + 1, (W + 2 * p - P) // s + 1
     Ht, Wt = H // P, W // P
     adt = K.act_torch_dtype(compute)
+    if (PATCH_GEMM and nchw and s == P and (Hc, Wc) == (Ht, Wt) and ((P == 2 and p == 0) or (P == 4 and p == 1)) and len(chunks) == 1
+            and compute == L.BF16 and chunks[0].K == Cin * P * P and chunks[0].K in (256, 512) and chunks[0].N % 4 == 0 and n_img * Ht * Wt >= 4096
+            and x.is_contiguous() and x.dtype in (torch.bfloat16, torch.float32) and x.data_ptr() % 16 == 0
+            and act in (L.ACT_NONE, L.ACT_GELU_ERF)):
+        # the gather IS the GEMM's fragment load (gemm.hip patch_frag): no (M, K) matrix in HBM; bit-identical to the two launches below
+        y = torch.empty(n_img * Ht * Wt, chunks[0].N, dtype=out_dtype, device=x.device)
+        K.patch_embed(x, chunks[0], y, n_img=n_img, Hin=H, Win=W, Cin=Cin, P=P, nchw=True, act=act, pad=p)
+        return y, Ht, Wt
     cols = K.im2col(x, nchw, n_img, Cin, H, W, P, P, s, s, p, p, 0 if nchw else 1, adt)
     same = (Hc, Wc) == (Ht, Wt)
     y = linear_chunks(cols, chunks, out_dtype if same else adt, act if same else L.ACT_NONE)

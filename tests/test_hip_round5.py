@@ -406,3 +406,37 @@ def test_epoch_with_amp_equals_the_bf16_compute_mode_and_float_masks_block_under
         y_b = blk(x, attn_mask=(fm != 0).to(dev), causal=True)
         y_c = blk(x, causal=True)
     assert torch.equal(y_f, y_b) and not torch.equal(y_f, y_c)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("P,Cin,src", [(4, 32, torch.bfloat16), (4, 16, torch.float32), (2, 128, torch.float32), (2, 64, torch.bfloat16)])
+def test_conv_stage_gathers_patches_inside_the_gemm(dev, P, Cin, src):
+    """stages.conv_stage on a channels-first image without overlap (enc_dec_fno.py:224-273's two conv stages at cfg5): the patch gather as
+    the dense GEMM's fragment load (gemm.hip patch_frag) -- bit-identical to tante_im2col + the dense GEMM it replaces, and equal to
+    torch's conv2d on the bf16-rounded operands within fp32 accumulation order."""
+    import tante_amd
+    from tante_amd import stages as S, _lib as L
+    torch.manual_seed(P * 100 + Cin)
+    n, H, W, Cout = 3, 24 * P, 32 * P, 48          # 3 * 24 * 32 = 2304 patches < 4096: falls back; 6 images -> 4608 use the fused route
+    pad = (P - 1) // 2                             # enc_dec_cnn.py:66-81: P = 4 reaches one pixel over the top / left edge
+    conv = torch.nn.Conv2d(Cin, Cout, (P, P), stride=(P, P), padding=(pad, pad)).to(dev)
+    chunks = S.pack_linear_chunks(S.conv_weight_2d(conv.weight, 0), conv.bias, L.BF16)
+    for n_img in (n, 2 * n):
+        x = torch.randn(n_img, Cin, H, W, device=dev).to(src).contiguous()
+        outs = {}
+        for on in (1, 0):
+            tante_amd.set_option("TANTE_CONV_PATCH_GEMM", on)
+            try:
+                for act in (L.ACT_NONE, L.ACT_GELU_ERF):
+                    y, ht, wt = S.conv_stage(x, True, n_img, Cin, H, W, P, 0.0, chunks, L.BF16, act, torch.float32)
+                    assert (ht, wt) == (H // P, W // P)
+                    outs[(on, act)] = y
+            finally:
+                tante_amd.set_option("TANTE_CONV_PATCH_GEMM", 1)
+        for act in (L.ACT_NONE, L.ACT_GELU_ERF):
+            assert torch.equal(outs[(1, act)], outs[(0, act)]), (n_img, act, (outs[(1, act)] - outs[(0, act)]).abs().max().item())
+        wq = conv.weight.detach().bfloat16().float()
+        ref = torch.nn.functional.conv2d(x.bfloat16().float(), wq, conv.bias.detach(), stride=P, padding=pad).permute(0, 2, 3, 1).reshape(-1, Cout)
+        e = rel_err(outs[(1, L.ACT_NONE)], ref)
+        record_parity(e, e, 1e-5, "bf16", f"conv stage with the patch gather inside the GEMM vs conv2d on bf16-rounded operands, P={P} Cin={Cin} n={n_img}")
+        assert e < 1e-5, e
