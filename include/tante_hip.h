@@ -391,6 +391,10 @@ int tante_im2col(const void* x, int x_dtype, int nchw, int64_t n_img, int C, int
 /* F.adaptive_avg_pool2d to (Ht, Wt) on a channels-last image, then `act` (RealConv2d.forward, enc_dec_cnn.py:104-110). */
 int tante_avgpool_nhwc(const void* x, int x_dtype, int64_t n_img, int H, int W, int C, int Ht, int Wt, int act, void* y, int y_dtype,
                        void* stream);
+/* Its backward without the activation (autograd of enc_dec_cnn.py:104-110 on the train path): dx (n_img, H, W, C) from dy (n_img, Ht, Wt, C);
+ * every input pixel gathers dy / window area from the one or two cells per axis whose adaptive windows contain it. */
+int tante_avgpool_nhwc_bwd(const void* dy, int dy_dtype, int64_t n_img, int H, int W, int C, int Ht, int Wt, void* dx, int dx_dtype,
+                           void* stream);
 /* Gather half of a ConvTranspose2d whose taps overlap (stride < kernel P, padding `pad`; RealTransConv2d with overlap_ratio > 0,
  * enc_dec_cnn.py:128-166): cols (n_img*Hi*Wi, P*P*Cout) with columns (kh, kw, co) is the tap matrix from one GEMM; out
  * (n_img, Hf, Wf, Cout) channels-last, Hf = (Hi - 1) stride - 2 pad + P, gets the overlapping taps summed plus the bias. */

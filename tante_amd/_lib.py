@@ -122,6 +122,7 @@ SIGNATURES = {
     "tante_enc23_frames": ([c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp], c_i32),
     "tante_im2col": ([c_vp, c_i32, c_i32, c_i64] + [c_i32] * 10 + [c_vp, c_i32, c_vp], c_i32),
     "tante_avgpool_nhwc": ([c_vp, c_i32, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp], c_i32),
+    "tante_avgpool_nhwc_bwd": ([c_vp, c_i32, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp], c_i32),
     "tante_col2im_nhwc": ([c_vp, c_i32, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_vp], c_i32),
     "tante_resize_bilinear": ([c_vp, c_i32, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_i64, c_i64, c_i64, c_i64, c_i32, c_i32, c_i64, c_i64,
                                c_i64, c_i64, c_i32, c_vp, c_i32, c_vp], c_i32),

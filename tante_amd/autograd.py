@@ -1537,6 +1537,51 @@ class Im2colFn(Function):
         return dx, None, None, None, None, None, None, None, None
 
 
+class AvgPoolFn(Function):
+    """F.adaptive_avg_pool2d to (Ht, Wt) on channels-last rows (n_img * H * W, C) -> (n_img * Ht * Wt, C): what follows an OVERLAPPING conv
+    (stride < kernel) in RealConv2d.forward (enc_dec_cnn.py:104-110)."""
+
+    @staticmethod
+    def forward(ctx, x, n_img, H, W, C_, Ht, Wt, out_dtype):
+        ctx.geo = (n_img, H, W, C_, Ht, Wt, x.dtype)
+        return K.avgpool_nhwc(x.contiguous(), n_img, H, W, C_, Ht, Wt, L.ACT_NONE, out_dtype)
+
+    @staticmethod
+    def backward(ctx, dy):
+        n_img, H, W, C_, Ht, Wt, xdt = ctx.geo
+        dy = dy.contiguous()
+        dx = torch.empty(n_img * H * W, C_, dtype=xdt, device=dy.device)
+        L.check(L.lib().tante_avgpool_nhwc_bwd(dy.data_ptr(), _DT[dy.dtype], n_img, H, W, C_, Ht, Wt, dx.data_ptr(), _DT[xdt], _s()),
+                "tante_avgpool_nhwc_bwd")
+        return dx, None, None, None, None, None, None, None
+
+
+class Col2imFn(Function):
+    """The gather half of a ConvTranspose2d with OVERLAPPING taps (stride < kernel P; enc_dec_cnn.py:128-166): tap matrix (n_img * Hi * Wi,
+    P * P * Cout), columns (kh, kw, co) -> channels-last (n_img, Hf, Wf, Cout) = summed taps + bias.  Backward: the tap matrix's gradient is
+    the patch matrix of d(out) (tante_im2col with the same kernel / stride / padding), the bias's its column sum."""
+
+    @staticmethod
+    def forward(ctx, cols, bias, n_img, Hi, Wi, P, stride, pad, Cout, out_dtype):
+        ctx.geo = (n_img, Hi, Wi, P, stride, pad, Cout, cols.dtype, bias is not None)
+        return K.col2im_nhwc(cols.contiguous(), n_img, Hi, Wi, P, stride, pad, Cout, None if bias is None else bias.detach().float().contiguous(),
+                             out_dtype)
+
+    @staticmethod
+    def backward(ctx, dout):
+        n_img, Hi, Wi, P, stride, pad, Cout, cdt, has_bias = ctx.geo
+        dout = dout.contiguous()
+        Hf, Wf = dout.shape[1], dout.shape[2]
+        dcols = db = None
+        if ctx.needs_input_grad[0]:
+            dcols = K.im2col(dout, False, n_img, Cout, Hf, Wf, P, P, stride, stride, pad, pad, 1, cdt)
+            if dcols.shape[0] != n_img * Hi * Wi:
+                raise RuntimeError("Col2imFn: geometry mismatch")
+        if has_bias and ctx.needs_input_grad[1]:
+            db = colsum(dout, n_img * Hf * Wf, Cout, 1)
+        return dcols, db, None, None, None, None, None, None, None, None
+
+
 class CropResizeFn(Function):
     """Bilinear resize (align_corners=False) of the window (crop, Hi x Wi) of a channels-last image to (Ho, Wo), channels-last or -first out."""
 

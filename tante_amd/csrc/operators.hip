@@ -154,6 +154,31 @@ __global__ void avgpool_kernel(const void* __restrict__ x, int x_dtype, long n_i
   }
 }
 
+// backward of the pooling above (no activation), gather form: input pixel (yy, xx) lies in the cells oh = floor(yy Ht / H) .. ceil((yy + 1) Ht / H) - 1
+// (one cell when H divides evenly, two where the adaptive windows overlap) and takes dy / area from each.
+__global__ void avgpool_bwd_kernel(const void* __restrict__ dy, int dy_dtype, long n_img, int H, int W, int C, int Ht, int Wt,
+                                   void* __restrict__ dx, int dx_dtype) {
+  const long total = n_img * H * W * C;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % C);
+    long r = idx / C;
+    const int xx = (int)(r % W); r /= W;
+    const int yy = (int)(r % H);
+    const long img = r / H;
+    const int oh0 = (int)(((long)yy * Ht) / H), oh1 = (int)((((long)yy + 1) * Ht + H - 1) / H);
+    const int ow0 = (int)(((long)xx * Wt) / W), ow1 = (int)((((long)xx + 1) * Wt + W - 1) / W);
+    float s = 0.0f;
+    for (int oh = oh0; oh < oh1; ++oh) {
+      const int y0 = (oh * H) / Ht, y1 = ((oh + 1) * H + Ht - 1) / Ht;
+      for (int ow = ow0; ow < ow1; ++ow) {
+        const int x0 = (ow * W) / Wt, x1 = ((ow + 1) * W + Wt - 1) / Wt;
+        s += ldx(dy, dy_dtype, ((img * Ht + oh) * Wt + ow) * C + c) / (float)((y1 - y0) * (x1 - x0));
+      }
+    }
+    stx(dx, dx_dtype, idx, s);
+  }
+}
+
 // ---- col2im for a transposed convolution with overlapping taps (stride < kernel): gather form, no atomics ----------------------
 // cols[(img, ih, iw)][(kh, kw, co)] = sum_ci x[img, ih, iw, ci] W[ci, co, kh, kw] (one GEMM); output pixel (y, x) sums the taps with
 // ih * s - p + kh = y, iw * s - p + kw = x, plus the bias; out is channels-last (img, Hf, Wf, Cout), Hf = (Hi - 1) s - 2 p + P.
@@ -1071,6 +1096,15 @@ extern "C" int tante_avgpool_nhwc(const void* x, int x_dtype, int64_t n_img, int
   if (!x || !y || n_img <= 0 || H <= 0 || W <= 0 || C <= 0 || Ht <= 0 || Wt <= 0) TANTE_FAIL(-1, "tante_avgpool_nhwc: bad argument");
   hipLaunchKernelGGL(avgpool_kernel, dim3(grid_for((long)n_img * Ht * Wt * C)), dim3(256), 0, (hipStream_t)stream, x, x_dtype, (long)n_img, H, W,
                      C, Ht, Wt, act, y, y_dtype);
+  TANTE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int tante_avgpool_nhwc_bwd(const void* dy, int dy_dtype, int64_t n_img, int H, int W, int C, int Ht, int Wt, void* dx, int dx_dtype,
+                                      void* stream) {
+  if (!dy || !dx || n_img <= 0 || H <= 0 || W <= 0 || C <= 0 || Ht <= 0 || Wt <= 0 || Ht > H || Wt > W) TANTE_FAIL(-1, "tante_avgpool_nhwc_bwd: bad argument");
+  hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(grid_for((long)n_img * H * W * C)), dim3(256), 0, (hipStream_t)stream, dy, dy_dtype, (long)n_img, H, W,
+                     C, Ht, Wt, dx, dx_dtype);
   TANTE_CHECK_LAUNCH();
   return 0;
 }

@@ -183,29 +183,40 @@ class dec_FNO(nn.Module):
 def _conv_stage_train(z_nchw: torch.Tensor, conv: nn.Conv2d, P: int, overlap: float, compute: int, out_dtype: torch.dtype, nhwc=None):
     """RealConv2d on the train path: channels-last im2col (its backward is the gather-sum col2im) + LinearFn; -> (rows, Cout), (h, w).
     nhwc = (n, C, H, W): z_nchw is already the channels-last image (n, H, W, C) (the CNN encoder's stage outputs are token rows)."""
-    from .autograd import Im2colFn, LinearFn
+    from .autograd import AvgPoolFn, Im2colFn, LinearFn
     n, C_, H, W = nhwc if nhwc is not None else z_nchw.shape
     st, pd = S.stride_pad(P, overlap)
     Ho, Wo = (H + 2 * pd - P) // st + 1, (W + 2 * pd - P) // st + 1
-    if (Ho, Wo) != (H // P, W // P):
-        raise NotImplementedError("the differentiable path has no adaptive-average-pool backward (overlap_ratio > 0): inference path only")
+    if H % P or W % P:
+        raise ValueError("To enforce (H//P, W//P), input H and W must be divisible by patch_size.")
     img = z_nchw.reshape(n, H, W, C_) if nhwc is not None else z_nchw.permute(0, 2, 3, 1)
     cols = Im2colFn.apply(img.contiguous(), n, C_, H, W, P, st, pd, K.act_torch_dtype(compute))
-    w2d = conv.weight.permute(0, 2, 3, 1).reshape(conv.weight.shape[0], -1)           # columns (kh, kw, c), a parameter-sized re-layout
-    return LinearFn.apply(cols, w2d, conv.bias, None, compute, out_dtype), Ho, Wo
+    w2d = conv.weight.permute(0, 2, 3, 1).reshape(conv.weight.shape[0], -1).contiguous()   # columns (kh, kw, c), a parameter-sized re-layout
+    if (Ho, Wo) == (H // P, W // P):
+        return LinearFn.apply(cols, w2d, conv.bias, None, compute, out_dtype), Ho, Wo
+    # overlapping stage (stride < kernel): the conv's (Ho, Wo) grid is adaptive-average-pooled to (H // P, W // P) before the activation
+    y = LinearFn.apply(cols, w2d, conv.bias, None, compute, K.act_torch_dtype(compute))
+    return AvgPoolFn.apply(y, n, Ho, Wo, conv.weight.shape[0], H // P, W // P, out_dtype), H // P, W // P
 
 
 def _deconv_stage_train(rows: torch.Tensor, dc: nn.ConvTranspose2d, n_img: int, h: int, w: int, P: int, overlap: float, compute: int,
                         nchw_out: bool = True, out_dtype: torch.dtype = torch.float32):
     """RealTransConv2d on the train path -> (n_img, Cout, h P, w P) (or channels-last (n_img, h P, w P, Cout)) pre-activation."""
-    from .autograd import CropResizeFn, DeconvFn
+    from .autograd import Col2imFn, CropResizeFn, DeconvFn, LinearFn
     st, pd = S.stride_pad(P, overlap)
+    Cout = dc.weight.shape[1]
+    adt = K.act_torch_dtype(compute)
     if st != P:
-        raise NotImplementedError("overlapping transposed convolutions run on the inference path only")
+        # overlapping taps (enc_dec_cnn.py:128-184): tap matrix by one GEMM -> gather-sum + bias -> bilinear resize to (h P, w P)
+        if dc.weight.shape[0] > S.KMAX:
+            raise NotImplementedError("overlapping transposed conv with more than 512 input channels")
+        w2 = dc.weight.permute(2, 3, 1, 0).reshape(-1, dc.weight.shape[0]).contiguous()   # rows (kh, kw, co), a parameter-sized re-layout
+        taps = LinearFn.apply(rows, w2, None, None, compute, adt)
+        full = Col2imFn.apply(taps, dc.bias, n_img, h, w, P, st, pd, Cout, adt)      # (n, Hf, Wf, Cout)
+        return CropResizeFn.apply(full, n_img, Cout, full.shape[1], full.shape[2], (0, 0), h * P, w * P, nchw_out, out_dtype)
     if pd == 0:
         return DeconvFn.apply(rows, dc.weight, dc.bias, n_img, h, w, P, nchw_out, compute, out_dtype)
-    full = DeconvFn.apply(rows, dc.weight, dc.bias, n_img, h, w, P, False, compute, K.act_torch_dtype(compute))   # (n, hP, wP, Cout)
-    Cout = dc.weight.shape[1]
+    full = DeconvFn.apply(rows, dc.weight, dc.bias, n_img, h, w, P, False, compute, adt)   # (n, hP, wP, Cout)
     return CropResizeFn.apply(full, n_img, Cout, h * P - 2 * pd, w * P - 2 * pd, (pd, pd), h * P, w * P, nchw_out, out_dtype)
 
 

@@ -262,16 +262,14 @@ def encoder_train(enc, inp: torch.Tensor, compute: int) -> torch.Tensor:
     if type(enc).__name__ == "enc_FNO":
         from .spectral import enc_fno_train
         return enc_fno_train(enc, inp, compute)
-    if any(S.stride_pad(p, enc.overlap)[0] != p for p in enc.P):
-        raise NotImplementedError("the differentiable path covers non-overlapping stages (overlap_ratio 0, every patch_scale); "
-                                  "overlapping stages (adaptive average pool) run on the inference path only")
     B, T, D, H, W = inp.shape
     adt = K.act_torch_dtype(compute)
     n_img, h, w = B * T, H, W
     z = inp.reshape(n_img, D, H, W)
-    if any(S.stride_pad(p, enc.overlap)[1] for p in enc.P):
-        # 'same'-padded stages (kernel 4: patch_scale 16 / 32 / 64, enc_dec_cnn.py:66-81): the general route, stage by stage -- im2col with the
-        # padding (its backward: the gather-sum col2im) + the dense GEMM, GELU between the stages as an op of its own
+    if any(S.stride_pad(p, enc.overlap) != (p, 0) for p in enc.P):
+        # 'same'-padded stages (kernel 4: patch_scale 16 / 32 / 64, enc_dec_cnn.py:66-81) and overlapping ones (overlap_ratio > 0: stride <
+        # kernel, adaptive average pool behind the conv, enc_dec_cnn.py:97-110): the general route, stage by stage -- im2col with the padding /
+        # stride (its backward: the gather-sum col2im) + the dense GEMM (+ AvgPoolFn), GELU between the stages as an op of its own
         from .spectral import _conv_stage_train
         for i in range(3):
             conv = getattr(enc, f"enc_conv_{i + 1}").conv
@@ -300,15 +298,13 @@ def decoder_train(dec, a: torch.Tensor, n_img: int, compute: int) -> torch.Tenso
     if type(dec).__name__ == "dec_FNO":
         from .spectral import dec_fno_train
         return dec_fno_train(dec, a.reshape(-1, dec.chans[0]), n_img, compute)
-    if any(S.stride_pad(p, dec.overlap)[0] != p for p in dec.P):
-        raise NotImplementedError("the differentiable path covers non-overlapping stages (overlap_ratio 0, every patch_scale); "
-                                  "overlapping transposed convolutions run on the inference path only")
     adt = K.act_torch_dtype(compute)
     h, w = dec.patch_shape
     x = a
-    if any(S.stride_pad(p, dec.overlap)[1] for p in dec.P):
+    if any(S.stride_pad(p, dec.overlap) != (p, 0) for p in dec.P):
         # 'same'-padded stages (enc_dec_cnn.py:128-143, 164-184): the padding crops the transposed convolution's result and the reference
-        # resizes it back (bilinear) -- DeconvFn + CropResizeFn per stage, channels-last rows between the stages
+        # resizes it back (bilinear) -- DeconvFn + CropResizeFn per stage, channels-last rows between the stages; overlapping stages
+        # (overlap_ratio > 0): tap GEMM + Col2imFn (summed taps) + CropResizeFn
         from .spectral import _deconv_stage_train
         for i in range(3):
             dc = getattr(dec, f"dec_conv_{i + 1}").deconv

@@ -454,7 +454,34 @@ def g15():
         save(f"g15_backbone_grad_{axes}", **arrs, **sd_np(bb))
 
 
+def g16():
+    """Round 5: GRADIENTS through OVERLAPPING stages (overlap_ratio > 0; 0.5 is the constructor default, enc_dec_cnn.py:39-46): the conv
+    has stride round(P (1 - overlap)) < P and its output is adaptive-average-pooled back to H / P x W / P (enc_dec_cnn.py:97-110); the
+    transposed conv's overlapping taps are summed and the result resized (bilinear) to H P x W P (enc_dec_cnn.py:164-184).  Same recipe as
+    g15: loss = sum(output * w), gradients of the input and of every parameter from the reference's backward().  0.25 gives stride 3 under
+    kernel 4: uneven pooling windows."""
+    for ps, ov, res, nf, C in [(8, 0.5, (16, 32), 2, 32), (32, 0.5, (64, 64), 2, 16), (16, 0.25, (32, 48), 1, 16)]:
+        torch.manual_seed(1600 + ps)
+        e = enc_CNN(md(nf, res), embed_dim=C, patch_scale=ps, overlap_ratio=ov).train()
+        d = dec_CNN(md(nf, res), embed_dim=C, patch_scale=ps, overlap_ratio=ov).train()
+        x = torch.randn(2, 3, nf, *res, requires_grad=True)
+        z = e(x)
+        wz = torch.randn_like(z)
+        (z * wz).sum().backward()
+        zz = torch.randn(2, 1, *z.shape[2:], requires_grad=True)
+        r = d(zz)
+        wr = torch.randn_like(r)
+        (r * wr).sum().backward()
+        arrs = {"x": x.detach().numpy(), "z": z.detach().numpy(), "wz": wz.numpy(), "dx": x.grad.numpy(), "zz": zz.detach().numpy(),
+                "r": r.detach().numpy(), "wr": wr.numpy(), "dzz": zz.grad.numpy(), "meta": np.array([ps, int(round(ov * 100)), res[0], res[1], nf, C])}
+        for k, q in e.named_parameters():
+            arrs["genc." + k] = q.grad.numpy().copy()
+        for k, q in d.named_parameters():
+            arrs["gdec." + k] = q.grad.numpy().copy()
+        save(f"g16_encdec_grad_ps{ps}_ov{int(round(ov * 100))}", **arrs, **sd_np(e, "enc."), **sd_np(d, "dec."))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16"]
     for w in which:
         globals()[w]()

@@ -440,3 +440,91 @@ def test_conv_stage_gathers_patches_inside_the_gemm(dev, P, Cin, src):
         e = rel_err(outs[(1, L.ACT_NONE)], ref)
         record_parity(e, e, 1e-5, "bf16", f"conv stage with the patch gather inside the GEMM vs conv2d on bf16-rounded operands, P={P} Cin={Cin} n={n_img}")
         assert e < 1e-5, e
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+@pytest.mark.parametrize("name", _names("g16_encdec_grad_*"))
+def test_g16_overlapping_stages_train(dev, name, mode):
+    """enc_CNN / dec_CNN with OVERLAPPING stages (overlap_ratio 0.5 is their constructor default, enc_dec_cnn.py:39-46; 0.25 gives stride 3
+    under kernel 4 = uneven pooling windows) under autograd: conv with stride < kernel -> adaptive average pool (AvgPoolFn, new
+    tante_avgpool_nhwc_bwd) / tap GEMM -> summed taps (Col2imFn) -> bilinear resize.  Until round 5 the train path raised
+    NotImplementedError.  Output, input gradient and every parameter's gradient against the reference's backward() (fixture g16)."""
+    import contextlib
+    import tante_amd
+    from conftest import load_golden, split_prefix
+    g = load_golden(name)
+    ps, ov, H, W, nf, C = (int(v) for v in g["meta"])
+    ov = ov / 100.0
+    md = tante_amd.TanteMetadata(n_fields=nf, spatial_resolution=(H, W))
+    e = tante_amd.enc_CNN(md, embed_dim=C, patch_scale=ps, overlap_ratio=ov).to(dev).train()
+    d = tante_amd.dec_CNN(md, embed_dim=C, patch_scale=ps, overlap_ratio=ov).to(dev).train()
+    e.load_state_dict(split_prefix(g, "enc."))
+    d.load_state_dict(split_prefix(g, "dec."))
+    amp = (lambda: torch.autocast("cuda", dtype=torch.bfloat16)) if mode == "bf16" else contextlib.nullcontext
+    ft, gt = (1e-5, 2e-4) if mode == "fp32" else (1e-2, 4e-2)
+    x = g["x"].to(dev).requires_grad_(True)
+    with amp():
+        z = e(x)
+    (z.float() * g["wz"].to(dev)).sum().backward()
+    assert max_rel(z.detach().float().cpu(), g["z"]) < ft
+    worst = max_rel(x.grad.cpu(), g["dx"])
+    assert worst < gt, ("dx", worst)
+    for k, q in e.named_parameters():
+        err = max_rel(q.grad.cpu(), g["genc." + k])
+        worst = max(worst, err)
+        assert err < gt, (k, err)
+    record_parity(worst, worst, gt, mode, f"{name}: enc_CNN gradients (input and parameters) vs the reference")
+    zz = g["zz"].to(dev).requires_grad_(True)
+    with amp():
+        r = d(zz)
+    (r.float() * g["wr"].to(dev)).sum().backward()
+    assert max_rel(r.detach().float().cpu(), g["r"]) < ft
+    worst = max_rel(zz.grad.cpu(), g["dzz"])
+    assert worst < gt, ("dzz", worst)
+    for k, q in d.named_parameters():
+        err = max_rel(q.grad.cpu(), g["gdec." + k])
+        worst = max(worst, err)
+        assert err < gt, (k, err)
+    record_parity(worst, worst, gt, mode, f"{name}: dec_CNN gradients (input and parameters) vs the reference")
+
+
+@pytest.mark.gpu
+def test_overlapping_model_trains(dev):
+    """A whole TANTE with overlap_ratio = 0.5 (tante.py:58 passes it to both enc_CNN and dec_CNN) on the HIP train path: forward + backward
+    against torch autograd through the CPU oracle, fp32 compute (output 1e-5, gradients 2e-4 of each tensor's largest entry), then one
+    train_step in bf16 that must move the loss."""
+    import tante_amd
+    from oracle import tante_oracle as O
+    torch.manual_seed(81)
+    md = tante_amd.TanteMetadata(n_fields=2, spatial_resolution=(32, 64))
+    kw = dict(taylor_order=2, attn_axes="TH-WL", n_head=4, embed_dim=64, patch_scale=16, overlap_ratio=0.5)
+    m = tante_amd.TANTE(in_T=4, dset_metadata=md, dropout=0.0, **kw).to(dev).train().set_compute("fp32")
+    g = torch.Generator().manual_seed(82)
+    x = torch.randn(2, 4, 2, 32, 64, generator=g)
+    w = torch.randn(2, 1, 2, 32, 64, generator=g)
+    y = m(x.to(dev))
+    (y * w.to(dev)).sum().backward()
+    wo = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    cfg = O.TanteCfg(4, 2, (32, 64), **kw)
+    yo = O.tante_forward(wo, cfg, x)
+    (yo * w).sum().backward()
+    e = max_rel(y.detach().cpu(), yo.detach())
+    record_parity(rel_err(y.detach().cpu(), yo.detach()), e, 1e-5, "fp32", "TANTE(overlap_ratio=0.5) training forward vs oracle")
+    assert e < 1e-5, e
+    worst = 0.0
+    for k, q in m.named_parameters():
+        if wo[k].grad is None:
+            continue
+        err = max_rel(q.grad.cpu(), wo[k].grad)
+        worst = max(worst, err)
+        assert err < 2e-4, (k, err)
+    record_parity(worst, worst, 2e-4, "fp32", "TANTE(overlap_ratio=0.5) parameter gradients vs oracle autograd")
+    m.set_compute("bf16")
+    opt = tante_amd.FlatAdamW(m.parameters(), lr=1e-3, weight_decay=0.0, max_norm=1.0)
+    fmt = tante_amd.DefaultChannelsFirstFormatter(md)
+    batch = {"input": torch.randn(2, 4, 32, 64, 2, generator=g).to(dev), "output": torch.randn(2, 2, 32, 64, 2, generator=g).to(dev)}
+    l0 = float(tante_amd.train_step(m, opt, batch, fmt, 2, 1))
+    for _ in range(5):
+        l1 = float(tante_amd.train_step(m, opt, batch, fmt, 2, 1))
+    assert l1 < l0, (l0, l1)

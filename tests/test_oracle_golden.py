@@ -268,6 +268,30 @@ def test_g15_encdec_gradients(name):
         assert max_rel(v.grad, g["gdec." + k]) < 1e-5, k
 
 
+@pytest.mark.parametrize("name", names("g16_encdec_grad_*"))
+def test_g16_overlapping_stage_gradients(name):
+    """The same through OVERLAPPING stages (overlap_ratio 0.5 -- the constructor default -- and 0.25: stride < kernel, adaptive average
+    pool after the conv, summed taps + bilinear resize after the transposed conv; enc_dec_cnn.py:97-110, 164-184)."""
+    g = load_golden(name)
+    ps, ov = int(g["meta"][0]), int(g["meta"][1]) / 100.0
+    we = {k: v.clone().requires_grad_(True) for k, v in split_prefix(g, "enc.").items()}
+    x = g["x"].clone().requires_grad_(True)
+    z = O.enc_cnn(we, x, ps, ov)
+    assert max_rel(z.detach(), g["z"]) < TOL
+    (z * g["wz"]).sum().backward()
+    assert max_rel(x.grad, g["dx"]) < 1e-5
+    for k, v in we.items():
+        assert max_rel(v.grad, g["genc." + k]) < 1e-5, k
+    wd = {k: v.clone().requires_grad_(True) for k, v in split_prefix(g, "dec.").items()}
+    zz = g["zz"].clone().requires_grad_(True)
+    r = O.dec_cnn(wd, zz, ps, ov)
+    assert max_rel(r.detach(), g["r"]) < TOL
+    (r * g["wr"]).sum().backward()
+    assert max_rel(zz.grad, g["dzz"]) < 1e-5
+    for k, v in wd.items():
+        assert max_rel(v.grad, g["gdec." + k]) < 1e-5, k
+
+
 @pytest.mark.parametrize("name", names("g15_backbone_grad_*"))
 def test_g15_backbone_gradients(name):
     g = load_golden(name)

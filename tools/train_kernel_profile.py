@@ -28,3 +28,12 @@ print(f"total kernel time per step {tot:.0f} us")
 print("count/step  us/step   avg us   name")
 for e in rows[:60]:
     print(f"{e.count / 3:9.1f} {e.self_device_time_total / 3:9.1f} {e.self_device_time_total / max(1, e.count):8.1f}   {e.key[:150]}")
+if "--sequence" in sys.argv:      # the launches of the LAST profiled step in start order (what runs between the block kernels)
+    evs = sorted((e for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA), key=lambda e: e.time_range.start)
+    per = len(evs) // 3
+    step = evs[2 * per:]
+    t0 = step[0].time_range.start
+    print(f"--- one step: {len(step)} device events")
+    short = lambda k: k.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:70]
+    for e in step:
+        print(f"{e.time_range.start - t0:9.1f} {e.time_range.end - e.time_range.start:7.1f}  {short(e.name)}")
