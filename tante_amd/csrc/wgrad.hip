@@ -393,7 +393,8 @@ struct WgSegs {
 template <int WNBUF, int RG>   // ring depth: 4 (64 KB per row group) or 8 (128 KB: a lone 4-wave workgroup keeps 7 chunks = 112 KB in flight)
 __device__ __forceinline__ void wgrad_tr_body(const WgSegs& SG, long ldu, long ldv, long R, int I, int J, long rows_per_split, float* __restrict__ dW,
                                               float* __restrict__ dbias, int layout, int P, int Co, int swap, int debug, int n_split,
-                                              float* __restrict__ slab, float* __restrict__ bias_slab, const unsigned bid) {
+                                              float* __restrict__ slab, float* __restrict__ bias_slab, const unsigned bid, const int seg_splits = 0,
+                                              const int xcd_rot = 0) {
   extern __shared__ __attribute__((aligned(16))) char wsm[];   // ring: [buf][U chunk | V chunk]
   const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3, grp = tid >> 8, kk = lane >> 4, l15 = lane & 15;
   // XCD-aware mapping: workgroups are dealt round-robin to the 8 XCDs by linear id, and every output tile of one row range re-reads
@@ -402,14 +403,27 @@ __device__ __forceinline__ void wgrad_tr_body(const WgSegs& SG, long ldu, long l
   // of split 8 * (slot / ntile) + xcd.
   const int ti = I / WT, ntile = ti * (J / WT);
   const int xcd = bid & 7, slot = bid >> 3;
-  const int bz = (slot / ntile) * 8 + xcd, tile = slot % ntile;
+  // (xcd_rot: the jobs launch starts each job's splits on the XCD where the previous job's ended, so that split counts that are not
+  // multiples of 8 still load the eight XCDs evenly)
+  const int bz = (slot / ntile) * 8 + ((xcd - xcd_rot) & 7), tile = slot % ntile;
   if (bz >= n_split) return;
   const int i0 = (tile % ti) * WT, j0 = (tile / ti) * WT;
   const bool first_j = (tile / ti) == 0;
-  const long g_begin = (long)bz * rows_per_split;                  // row index in the concatenation of the segments
-  const int seg = (int)(g_begin / SG.R_seg);
-  const long r_begin = g_begin - (long)seg * SG.R_seg + (long)grp * (rows_per_split / RG);      // rows_per_split is a multiple of RG * WRC
-  const long r_end = min(SG.R_seg, r_begin + rows_per_split / RG);
+  // seg_splits > 0 (the jobs launch): every segment is cut into seg_splits ranges of whole chunks whose lengths differ by at most one
+  // chunk -- any split count fits any segment, so the grid can be sized to the chip instead of to the divisors of R_seg
+  int seg;
+  long r_begin, r_end;
+  if (seg_splits > 0) {
+    seg = bz / seg_splits;
+    const long sp = bz - seg * seg_splits, nch_seg = SG.R_seg / WRC;
+    r_begin = (sp * nch_seg / seg_splits) * WRC;
+    r_end = ((sp + 1) * nch_seg / seg_splits) * WRC;
+  } else {
+    const long g_begin = (long)bz * rows_per_split;                  // row index in the concatenation of the segments
+    seg = (int)(g_begin / SG.R_seg);
+    r_begin = g_begin - (long)seg * SG.R_seg + (long)grp * (rows_per_split / RG);      // rows_per_split is a multiple of RG * WRC
+    r_end = min(SG.R_seg, r_begin + rows_per_split / RG);
+  }
   char* const ring = wsm + grp * (WNBUF * 2 * WCHUNK);
   const unsigned short* __restrict__ U = SG.U[seg];
   const unsigned short* __restrict__ V = SG.V[seg];
@@ -584,7 +598,7 @@ struct WgJob {
   WgSegs SG;
   long ldu, ldv, R, per;
   float *dW, *dbias, *slab, *bias_slab;
-  int I, J, layout, P, Co, swap, n_split, wg_begin;
+  int I, J, layout, P, Co, swap, n_split, wg_begin, seg_splits, xcd_rot;
 };
 struct WgJobs {
   WgJob j[WJOBS];
@@ -597,7 +611,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_tr_jobs_kernel(const WgJobs JB) 
     if (q < JB.n && blockIdx.x >= (unsigned)JB.j[q].wg_begin) k = q;
   const WgJob& jb = JB.j[k];
   wgrad_tr_body<4, 1>(jb.SG, jb.ldu, jb.ldv, jb.R, jb.I, jb.J, jb.per, jb.dW, jb.dbias, jb.layout, jb.P, jb.Co, jb.swap, 0, jb.n_split, jb.slab,
-                      jb.bias_slab, blockIdx.x - (unsigned)jb.wg_begin);
+                      jb.bias_slab, blockIdx.x - (unsigned)jb.wg_begin, jb.seg_splits, jb.xcd_rot);
 }
 
 // second stage: dW[i][j] += sum over the splits of a slab chunk (grid.y chunks of splits; one thread per 16-byte piece of a tile in the
@@ -869,20 +883,50 @@ extern "C" int tante_wgrad_jobs_ws(const TanteWgradJob* jobs, int n_jobs, int co
   WgJobs JB;
   RdJobs RB;
   JB.n = n_jobs;
+  // Two 64 KB workgroups fit a CU -- 64 per XCD -- and each should cover the same number of row chunks: the smallest chunk count c per
+  // workgroup for which no XCD gets more than its 64 (splits are dealt to the XCDs round-robin, every job starting where the last one
+  // ended).  (Row ranges used to be divisors of the segment length: at cfg3, 512 chunks per segment, that meant 384 workgroups of 128
+  // chunks -- half the CUs with two workgroups, half with one -- or 768 of 64 in one and a half rounds; 480 of 102 / 103 now.)
   const int wg_total = tante_opt("TANTE_WGRAD_JOBS_WGS", 512);
+  long cper = 4;
+  int rot[WJOBS] = {0, 0, 0, 0};
+  {
+    // workgroups on the busiest XCD when every workgroup covers at most c chunks; split b of a job runs on XCD (b + rot) % 8
+    auto busiest = [&](long c) {
+      long load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      int r = 0;
+      for (int k = 0; k < n_jobs; ++k) {
+        const long nch = jobs[k].R / WRC, ntile = (long)(jobs[k].I / WT) * (jobs[k].J / WT);
+        const long total = ((nch + c - 1) / c) * jobs[k].n_seg;
+        rot[k] = r;
+        for (int x = 0; x < 8; ++x) load[(x + r) & 7] += (total / 8 + (x < total % 8 ? 1 : 0)) * ntile;
+        r = (int)((r + total) & 7);
+      }
+      long m = 0;
+      for (int x = 0; x < 8; ++x) m = std::max(m, load[x]);
+      return m;
+    };
+    long lo = 4, hi = 4;
+    for (int k = 0; k < n_jobs; ++k) hi = std::max<long>(hi, jobs[k].R / WRC);
+    while (lo < hi) {      // (close to monotone in c; the final check below settles it)
+      const long mid = (lo + hi) / 2;
+      if (busiest(mid) * 8 <= wg_total) hi = mid; else lo = mid + 1;
+    }
+    cper = lo;
+    while (busiest(cper) * 8 > wg_total && cper < hi) ++cper;
+    (void)busiest(cper);      // rot[] of the chosen c
+  }
   unsigned wg_begin = 0, max_red_x = 0;
   int64_t ws_off = 0;      // floats
   for (int k = 0; k < n_jobs; ++k) {
     const TanteWgradJob& jb = jobs[k];
     const int ti = jb.I / WT, tj = jb.J / WT, ntile = ti * tj;
     const long nch = jb.R / WRC;
-    long split = (long)((double)wg_total * work[k] / work_sum) / ((long)ntile * jb.n_seg);      // splits per segment
+    long split = (nch + cper - 1) / cper;      // splits per segment
     if (split < 1) split = 1;
-    if (split > nch / 4) split = nch / 4 > 0 ? nch / 4 : 1;
-    long per = ((nch + split - 1) / split) * WRC;
-    while (jb.R % per && per < jb.R) per += WRC;      // rows_per_split must divide the segment
-    if (jb.R % per) return one_by_one();
-    const long total = (jb.R / per) * jb.n_seg;
+    if (split > nch) split = nch;
+    const long per = 0;
+    const long total = split * jb.n_seg;
     if (total > 65535) return one_by_one();
     WgJob& w = JB.j[k];
     for (int g = 0; g < WSEG; ++g) {
@@ -897,7 +941,7 @@ extern "C" int tante_wgrad_jobs_ws(const TanteWgradJob* jobs, int n_jobs, int co
     w.slab = (float*)workspace + ws_off;
     w.bias_slab = w.slab + (int64_t)total * ntile * WT * WT;
     ws_off += ((int64_t)total * ntile * WT * WT + (int64_t)total * jb.I + 3) / 4 * 4;
-    w.I = jb.I; w.J = jb.J; w.layout = jb.layout; w.P = jb.P; w.Co = jb.C_other; w.swap = jb.swap; w.n_split = (int)total; w.wg_begin = (int)wg_begin;
+    w.I = jb.I; w.J = jb.J; w.layout = jb.layout; w.P = jb.P; w.Co = jb.C_other; w.swap = jb.swap; w.n_split = (int)total; w.wg_begin = (int)wg_begin; w.seg_splits = (int)split; w.xcd_rot = rot[k];
     wg_begin += 8u * (unsigned)((total + 7) / 8) * (unsigned)ntile;
     RdJob& r = RB.j[k];
     r.slab = w.slab; r.bias_slab = w.bias_slab; r.dW = jb.dW; r.dbias = jb.dbias; r.n_split = (int)total; r.ntile = ntile; r.ti = ti; r.I = jb.I; r.J = jb.J;
