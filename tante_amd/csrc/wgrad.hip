@@ -604,13 +604,17 @@ struct WgJobs {
   WgJob j[WJOBS];
   int n;
 };
-__global__ __launch_bounds__(256, 2) void wgrad_tr_jobs_kernel(const WgJobs JB) {
+#ifndef WGJ_NBUF
+#define WGJ_NBUF 4      // ring depth of the jobs kernel (x 16 KB) ...
+#define WGJ_OCC 2       // ... and the workgroups per CU it is sized for (192 VGPRs; 3 / 3 and 2 / 4 spill: train step 10.8 / 18.4 against 8.58 ms)
+#endif
+__global__ __launch_bounds__(256, WGJ_OCC) void wgrad_tr_jobs_kernel(const WgJobs JB) {
   int k = 0;
 #pragma unroll
   for (int q = 1; q < WJOBS; ++q)
     if (q < JB.n && blockIdx.x >= (unsigned)JB.j[q].wg_begin) k = q;
   const WgJob& jb = JB.j[k];
-  wgrad_tr_body<4, 1>(jb.SG, jb.ldu, jb.ldv, jb.R, jb.I, jb.J, jb.per, jb.dW, jb.dbias, jb.layout, jb.P, jb.Co, jb.swap, 0, jb.n_split, jb.slab,
+  wgrad_tr_body<WGJ_NBUF, 1>(jb.SG, jb.ldu, jb.ldv, jb.R, jb.I, jb.J, jb.per, jb.dW, jb.dbias, jb.layout, jb.P, jb.Co, jb.swap, 0, jb.n_split, jb.slab,
                       jb.bias_slab, blockIdx.x - (unsigned)jb.wg_begin, jb.seg_splits, jb.xcd_rot);
 }
 
@@ -887,7 +891,7 @@ extern "C" int tante_wgrad_jobs_ws(const TanteWgradJob* jobs, int n_jobs, int co
   // workgroup for which no XCD gets more than its 64 (splits are dealt to the XCDs round-robin, every job starting where the last one
   // ended).  (Row ranges used to be divisors of the segment length: at cfg3, 512 chunks per segment, that meant 384 workgroups of 128
   // chunks -- half the CUs with two workgroups, half with one -- or 768 of 64 in one and a half rounds; 480 of 102 / 103 now.)
-  const int wg_total = tante_opt("TANTE_WGRAD_JOBS_WGS", 512);
+  const int wg_total = tante_opt("TANTE_WGRAD_JOBS_WGS", 256 * WGJ_OCC);
   long cper = 4;
   int rot[WJOBS] = {0, 0, 0, 0};
   {
@@ -951,8 +955,8 @@ extern "C" int tante_wgrad_jobs_ws(const TanteWgradJob* jobs, int n_jobs, int co
   for (int k = n_jobs; k < WJOBS; ++k) { JB.j[k] = JB.j[0]; JB.j[k].wg_begin = 0x7fffffff; RB.j[k] = RB.j[0]; RB.j[k].ntile = 0; }
   if (ws_off * (int64_t)sizeof(float) > workspace_bytes) return one_by_one();
   static TantePerDevice attr;
-  attr.once([&] { hipFuncSetAttribute((const void*)wgrad_tr_jobs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * WCHUNK); });
-  hipLaunchKernelGGL(wgrad_tr_jobs_kernel, dim3(wg_begin), dim3(256), (size_t)4 * 2 * WCHUNK, s, JB);
+  attr.once([&] { hipFuncSetAttribute((const void*)wgrad_tr_jobs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WGJ_NBUF * 2 * WCHUNK); });
+  hipLaunchKernelGGL(wgrad_tr_jobs_kernel, dim3(wg_begin), dim3(256), (size_t)WGJ_NBUF * 2 * WCHUNK, s, JB);
   hipLaunchKernelGGL(wgrad_reduce_jobs_kernel, dim3(max_red_x, 1, (unsigned)n_jobs), dim3(256), 0, s, RB);
   TANTE_CHECK_LAUNCH();
   return 0;
