@@ -344,11 +344,13 @@ __global__ __launch_bounds__(256, NTT <= 3 ? 2 : 1) void block_bwd_fs_kernel(BfA
 #endif
     slice_to_acc(imgB + wave * (IMG / NW), raw, g);      // image B: first written behind barrier 1
   }
+  BF_STAMP(20);
 #pragma unroll
   for (int tt = 0; tt < NTT; ++tt) {
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) *(u32x2*)(imgA + tt * 8192 + wro[rt]) = bf_pack4(drop4(g[rt][tt], A.seed_mlp ^ smix, off[tt] + 16 * rt));
   }
+  BF_STAMP(21);
   BF_BURST(imgA, A.dy2, FS_C, 0);
   if (tid < 3 * FS_C / 4) *(f32x4*)(lbias + 4 * tid) = bias_in;
   BF_STAMP(2);

@@ -92,6 +92,13 @@ def main():
     print(f"{s.shape[0]} waves; shader clock {np.median(clk) / 1e9:.3f} GHz; stamped span per wave: median {np.median(tot):.0f} cycles "
           f"({np.median(tot) / np.median(clk) * 1e6:.1f} us), max {tot.max()}; grid first entry -> last exit {s[:, 19].max() - s[:, 0].min()} cycles; "
           f"entry spread {s[:, 0].max() - s[:, 0].min()}")
+    if (raw[:, 20] != 0).all():      # P0 in three parts (stamps 20, 21)
+        for name, a, b in (("  P0a dout rows -> accumulators", raw[:, 20] - s[:, 1]), ("  P0b dropout mask + image A", raw[:, 21] - raw[:, 20]),
+                           ("  P0c dy2 row stores + biases", s[:, 2] - raw[:, 21])) if False else ():
+            pass
+        for name, v in (("P0a dout rows -> accumulators", raw[:, 20] - s[:, 1]), ("P0b dropout mask + image A", raw[:, 21] - raw[:, 20]),
+                        ("P0c dy2 row stores + biases", s[:, 2] - raw[:, 21])):
+            print(f"    {name:<38s} median {np.median(v):8.0f}   p90 {np.percentile(v, 90):8.0f}")
     for k in range(19):
         print(f"  {NAMES[k]:<40s} median {np.median(d[:, k]):8.0f}   p90 {np.percentile(d[:, k], 90):8.0f}   share {np.median(d[:, k]) / np.median(tot) * 100:5.1f} %")
 

@@ -12,7 +12,7 @@ torch.manual_seed(211)
 m = tante_amd.build_model(tcfg, tmd, dropout=float(tcfg["model"].get("dropout", 0.0))).to(dev).train().set_compute("bf16")
 oc = tcfg["optimizer"]
 opt = tante_amd.FlatAdamW(m.parameters(), lr=oc["lr"], weight_decay=oc["weight_decay"], max_norm=1.0)
-B, n = twl["batch_size"], twl["n_steps_output"]
+B, n = int(os.environ.get("TRAIN_B", twl["batch_size"])), twl["n_steps_output"]
 g = torch.Generator().manual_seed(1)
 batch = {"input": torch.randn(B, twl["n_steps_input"], *twl["spatial_resolution"], twl["n_fields"], generator=g).to(dev),
          "output": torch.randn(B, n, *twl["spatial_resolution"], twl["n_fields"], generator=g).to(dev)}
