@@ -49,6 +49,9 @@
 #ifndef BF_HOOK_STORES
 #define BF_HOOK_STORES 0   // 1: bf16 row stores ride the k-steps of the following GEMM; 0: issued together behind the phase that wrote the image
 #endif
+#ifndef BF_LATE_HPRE
+#define BF_LATE_HPRE 1     // 1: the first saved rows (fc1's pre-activation) are requested behind the arrival of the gradient rows; 0: with them
+#endif
 #ifndef BF_PARK_DX1
 #define BF_PARK_DX1 0      // 1: dx1 waits in the output buffer between LayerNorm2's backward and the end (+50 MB per launch); 0: in 48 registers
 #endif
@@ -337,12 +340,24 @@ __global__ __launch_bounds__(256, NTT <= 3 ? 2 : 1) void block_bwd_fs_kernel(BfA
     f32x4 raw[NTT][RT];
     slice_load(A.dout, raw);      // the rows everything waits for: first in the memory queue
     asm volatile("" ::: "memory");
+#if !BF_LATE_HPRE
 #if BF_DMA_ROWS
     dma_rows(A.hpre);
 #else
     dma_rows(A.xh1);
 #endif
+#endif
     slice_to_acc(imgB + wave * (IMG / NW), raw, g);      // image B: first written behind barrier 1
+#if BF_LATE_HPRE
+    // the saved rows are requested only now: the single resident round starts in step, and every workgroup asking for its gradient rows AND
+    // its saved rows at once made a 37 MB burst that the gradient rows -- the only thing P0 needs -- waited out (stamps: 17.6 k cycles)
+    asm volatile("" ::: "memory");
+#if BF_DMA_ROWS
+    dma_rows(A.hpre);
+#else
+    dma_rows(A.xh1);
+#endif
+#endif
   }
   BF_STAMP(20);
 #pragma unroll
