@@ -659,10 +659,29 @@ __device__ __forceinline__ u32x4 patch_frag(const TanteGemm& g, const PatchRow& 
 
 // what the fragment-load form needs (tante_gemm refuses a_pad != 0 elsewhere: no other path implements the padding)
 inline bool patch_lite_ok(const TanteGemm& g, int flags, int cb) {
-  return g.a_mode == TANTE_A_PATCH_NCHW && g.compute == TANTE_BF16 && !g.ln && g.drop_p <= 0.0f && !g.dact && (flags & 2) && g.e_mode == TANTE_E_LINEAR &&
+  const bool e_lin = (flags & 2) && g.e_mode == TANTE_E_LINEAR;
+  const bool e_cf = g.e_mode == TANTE_E_DECONV_NCHW && g.Po == 1 && g.out_dtype == TANTE_F32 && g.N % 4 == 0 && ((uintptr_t)g.out % 4) == 0;
+  return g.a_mode == TANTE_A_PATCH_NCHW && g.compute == TANTE_BF16 && !g.ln && g.drop_p <= 0.0f && !g.dact && (e_lin || e_cf) &&
          (cb == 8 || cb == 16) && g.K == cb * 32 && g.M >= 4096 && (g.P == 2 || g.P == 4) && ((uintptr_t)g.a % 16) == 0 &&
          (g.a_dtype == TANTE_BF16 || g.a_dtype == TANTE_F32) && (g.a_pad == 0 || (g.a_pad == 1 && g.P == 4)) &&
          (g.act == TANTE_ACT_NONE || g.act == TANTE_ACT_GELU_ERF);
+}
+
+// channels-FIRST output of a patch stage (e_mode DECONV_NCHW with Po = 1: out[img][n][ho][wo], fp32): a lane holds 4 channels of one token and
+// the 16 lanes of a group hold 16 neighbouring tokens, so every store instruction writes four 64-byte runs; the four waves of the workgroup
+// own the next 16 tokens each and L2 merges their runs before they leave for HBM.  (TR = 3: no activation, TR = 4: exact GELU.)
+template <int TR>
+__device__ __forceinline__ void epilogue4_nchw(const TanteGemm& g, const EpiRow& e, int n0, float (&v)[4]) {
+  if (!e.ok || n0 >= g.N) return;
+  const f32x4 b = *(const f32x4*)(g.bias + n0);
+  const long hw = (long)g.Hi * g.Wi;
+  float* o = (float*)g.out + e.o_base + (long)n0 * hw;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float x = v[j] + b[j];
+    if constexpr (TR == 4) x = gelu_poly1<false>(x);
+    o[j * hw] = x;
+  }
 }
 
 template <int CB, int TT, int EP, int TR = 0, int AM = 0>
@@ -737,6 +756,7 @@ __global__ __launch_bounds__(256, 4) void gemm_lite_kernel(const TanteGemm g, in
       for (int tt = 0; tt < TT; ++tt) {
         float v[4] = {acc[ns][tt][0], acc[ns][tt][1], acc[ns][tt][2], acc[ns][tt][3]};
         if constexpr (TR == 0) epilogue4_fast<EP, true>(g, er[tt], t * NT + ns * 16 + kk * 4, v);
+        else if constexpr (TR >= 3) epilogue4_nchw<TR>(g, er[tt], t * NT + ns * 16 + kk * 4, v);
         else epilogue4_train<TR>(g, er[tt], row0 + tt * 16 + l15, t * NT + ns * 16 + kk * 4, v);
       }
   }
@@ -757,6 +777,11 @@ void launch_lite(const TanteGemm& g, int n_tiles, hipStream_t s) {
 
 template <int CB, int AM>
 bool lite_patch(const TanteGemm& g, int n_tiles, hipStream_t s) {
+  if (g.e_mode == TANTE_E_DECONV_NCHW) {      // channels-first output (Po = 1)
+    if (g.act == TANTE_ACT_NONE) launch_lite<CB, EP_LIN_NONE, 3, AM>(g, n_tiles, s);
+    else launch_lite<CB, EP_LIN_NONE, 4, AM>(g, n_tiles, s);
+    return true;
+  }
   switch (g.act) {
     case TANTE_ACT_NONE: launch_lite<CB, EP_LIN_NONE, 0, AM>(g, n_tiles, s); return true;
     case TANTE_ACT_GELU_ERF: launch_lite<CB, EP_LIN_GELU_ERF, 0, AM>(g, n_tiles, s); return true;

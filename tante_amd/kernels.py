@@ -128,11 +128,12 @@ def linear_train_epilogue_ok(a: torch.Tensor, M: int, N: int, Kk: int, compute: 
 
 def patch_embed(a: torch.Tensor, pw: PackedWeight, out: torch.Tensor, *, n_img: int, Hin: int, Win: int, Cin: int, P: int,
                 nchw: bool, act: int, film: Optional[tuple] = None, imgs_per_item: Optional[int] = None, item_stride: int = 0,
-                elem_off: int = 0, pad: int = 0):
+                elem_off: int = 0, pad: int = 0, nchw_out: bool = False):
     """Patch conv with kernel = stride = P as a GEMM over non-overlapping patches.  `a` is
     (n_img, Cin, Hin, Win) when nchw else (n_img, Hin, Win, Cin); out is channels-last
     (n_img, Hin/P, Win/P, N).  film = (film_a, film_b, s_emb, T, HW) selects the FiLM + positional epilogue.  pad: TanteGemm.a_pad (the
-    'same' padding 1 of a P = 4 stage, channels-first bf16-compute only -- the library refuses what it cannot serve)."""
+    'same' padding 1 of a P = 4 stage, channels-first bf16-compute only -- the library refuses what it cannot serve).  nchw_out: `out` is
+    (n_img, N, Hin/P, Win/P) fp32, channels first (TANTE_E_DECONV_NCHW with Po = 1)."""
     M = n_img * (Hin // P) * (Win // P)
     if not a.is_cuda:
         raise RuntimeError("tante_amd kernels need CUDA/HIP tensors (no CPU fallback)")
@@ -143,7 +144,12 @@ def patch_embed(a: torch.Tensor, pw: PackedWeight, out: torch.Tensor, *, n_img: 
     g.a_n0 = n_img if imgs_per_item is None else imgs_per_item
     g.a_s1, g.a_off = item_stride, elem_off
     g.out_ld = pw.N
-    if film is None:
+    if nchw_out:
+        if film is not None:
+            raise ValueError("the FiLM epilogue writes channels-last rows")
+        g.e_mode = L.E_DECONV_NCHW
+        g.Hi, g.Wi, g.Po, g.Cout = Hin // P, Win // P, 1, pw.N
+    elif film is None:
         g.e_mode = L.E_LINEAR
     else:
         fa, fb, se, T, HW = film

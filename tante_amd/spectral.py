@@ -54,11 +54,6 @@ class SpectralLayer(nn.Module):
         return self.run(x.detach().float().contiguous())
 
 
-def _to_nchw(y2d: torch.Tensor, n: int, h: int, w: int) -> torch.Tensor:
-    """channels-last rows (n*h*w, C) -> (n, C, h, w) fp32 (layout change only)."""
-    return y2d.view(n, h, w, -1).permute(0, 3, 1, 2).float().contiguous()
-
-
 class enc_FNO(nn.Module):
     """(B,T,D,H,W) -> (B,T,Hp,Wp,C): spectral -> GELU -> conv(P0) -> GELU -> spectral -> GELU -> conv(P1)  (enc_dec_fno.py:224-273)."""
 
@@ -99,9 +94,9 @@ class enc_FNO(nn.Module):
         z = inp.contiguous().view(n, D, H, W)
         # (bf16 mode: the conv's patch gather rounds the image to bf16 anyway -- the spectral layer's last kernel does it while storing)
         z = self.enc_spectral_1.run(z, L.ACT_GELU_ERF, compute, bf16_out=True)
-        y, h, w = S.conv_stage(z, True, n, self.chans[1], H, W, self.P[0], self.overlap, pk[0], compute, L.ACT_GELU_ERF, torch.float32)
-        # (a channels-first epilogue of the conv GEMM was measured at 96 us against 40 us + this 20 us copy: stages.conv_stage)
-        z = self.enc_spectral_2.run(_to_nchw(y, n, h, w), L.ACT_GELU_ERF, compute)
+        # (channels-first for the spectral layer: written by the patch GEMM's epilogue, stages.conv_stage)
+        y, h, w = S.conv_stage(z, True, n, self.chans[1], H, W, self.P[0], self.overlap, pk[0], compute, L.ACT_GELU_ERF, torch.float32, nchw_out=True)
+        z = self.enc_spectral_2.run(y, L.ACT_GELU_ERF, compute)
         y, h, w = S.conv_stage(z, True, n, self.chans[3], h, w, self.P[1], self.overlap, pk[1], compute, L.ACT_NONE, torch.float32)
         if film is not None:
             fa, fb, se, Tt, HW = film

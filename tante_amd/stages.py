@@ -64,11 +64,12 @@ def conv_weight_2d(w: torch.Tensor, korder: int) -> torch.Tensor:
 
 
 def conv_stage(x: torch.Tensor, nchw: bool, n_img: int, Cin: int, H: int, W: int, P: int, overlap: float, chunks: List[K.PackedWeight],
-               compute: int, act: int, out_dtype: torch.dtype) -> Tuple[torch.Tensor, int, int]:
+               compute: int, act: int, out_dtype: torch.dtype, nchw_out: bool = False) -> Tuple[torch.Tensor, int, int]:
     """RealConv2d.forward (enc_dec_cnn.py:97-110): conv(kernel P, stride / padding from overlap) -> adaptive_avg_pool2d to
     (H // P, W // P) -> act.  Returns the channels-last (n_img * Ht * Wt, Cout) matrix and (Ht, Wt).  x may be a bf16 image (a producer
-    that rounded for the bf16 patch gather already).  (A channels-first output through the GEMM's pixel-shuffle epilogue was measured
-    slower than the caller's layout copy -- 96 against 40 + 20 us at cfg5 -- and removed.)"""
+    that rounded for the bf16 patch gather already).  nchw_out: the (n_img, Cout, Ht, Wt) fp32 image instead (a spectral layer follows):
+    written by the patch GEMM's own epilogue where that route applies (round 5; the generic kernel's pixel-shuffle epilogue had been
+    measured slower than a layout copy -- 96 against 40 + 20 us at cfg5), by a layout copy of the rows otherwise."""
     if H % P or W % P:
         raise ValueError("To enforce (H//P, W//P), input H and W must be divisible by patch_size.")
     s, p = stride_pad(P, overlap)
@@ -80,15 +81,24 @@ def conv_stage(x: torch.Tensor, nchw: bool, n_img: int, Cin: int, H: int, W: int
             and x.is_contiguous() and x.dtype in (torch.bfloat16, torch.float32) and x.data_ptr() % 16 == 0
             and act in (L.ACT_NONE, L.ACT_GELU_ERF)):
         # the gather IS the GEMM's fragment load (gemm.hip patch_frag): no (M, K) matrix in HBM; bit-identical to the two launches below
+        if nchw_out and out_dtype == torch.float32:
+            y = torch.empty(n_img, chunks[0].N, Ht, Wt, dtype=torch.float32, device=x.device)
+            K.patch_embed(x, chunks[0], y, n_img=n_img, Hin=H, Win=W, Cin=Cin, P=P, nchw=True, act=act, pad=p, nchw_out=True)
+            return y, Ht, Wt
         y = torch.empty(n_img * Ht * Wt, chunks[0].N, dtype=out_dtype, device=x.device)
         K.patch_embed(x, chunks[0], y, n_img=n_img, Hin=H, Win=W, Cin=Cin, P=P, nchw=True, act=act, pad=p)
-        return y, Ht, Wt
+        return (_rows_to_nchw(y, n_img, Ht, Wt) if nchw_out else y), Ht, Wt
     cols = K.im2col(x, nchw, n_img, Cin, H, W, P, P, s, s, p, p, 0 if nchw else 1, adt)
     same = (Hc, Wc) == (Ht, Wt)
     y = linear_chunks(cols, chunks, out_dtype if same else adt, act if same else L.ACT_NONE)
     if not same:
         y = K.avgpool_nhwc(y, n_img, Hc, Wc, chunks[0].N, Ht, Wt, act, out_dtype)
-    return y, Ht, Wt
+    return (_rows_to_nchw(y, n_img, Ht, Wt) if nchw_out else y), Ht, Wt
+
+
+def _rows_to_nchw(y2d: torch.Tensor, n: int, h: int, w: int) -> torch.Tensor:
+    """channels-last rows (n*h*w, C) -> (n, C, h, w) fp32 (layout change only)."""
+    return y2d.view(n, h, w, -1).permute(0, 3, 1, 2).float().contiguous()
 
 
 def deconv_taps_pack(weight: torch.Tensor, bias: Optional[torch.Tensor], compute: int):

@@ -435,6 +435,10 @@ def test_conv_stage_gathers_patches_inside_the_gemm(dev, P, Cin, src):
                 tante_amd.set_option("TANTE_CONV_PATCH_GEMM", 1)
         for act in (L.ACT_NONE, L.ACT_GELU_ERF):
             assert torch.equal(outs[(1, act)], outs[(0, act)]), (n_img, act, (outs[(1, act)] - outs[(0, act)]).abs().max().item())
+            # channels-first output (the GEMM's own epilogue on the fused route, a layout copy otherwise): the same numbers, transposed
+            ycf, _, _ = S.conv_stage(x, True, n_img, Cin, H, W, P, 0.0, chunks, L.BF16, act, torch.float32, nchw_out=True)
+            assert ycf.shape == (n_img, Cout, H // P, W // P)
+            assert torch.equal(ycf.permute(0, 2, 3, 1).reshape(-1, Cout), outs[(1, act)]), (n_img, act)
         wq = conv.weight.detach().bfloat16().float()
         ref = torch.nn.functional.conv2d(x.bfloat16().float(), wq, conv.bias.detach(), stride=P, padding=pad).permute(0, 2, 3, 1).reshape(-1, Cout)
         e = rel_err(outs[(1, L.ACT_NONE)], ref)
