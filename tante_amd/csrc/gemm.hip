@@ -684,6 +684,25 @@ __device__ __forceinline__ void epilogue4_nchw(const TanteGemm& g, const EpiRow&
   }
 }
 
+// pixel-shuffle output of a kernel-2 stride-2 transposed conv, channels first (e_mode DECONV_NCHW, Po = 2; fp32): the lane's four
+// consecutive n are one channel's 2 x 2 output block of its token -- two 8-byte stores, and the 16 tokens of a lane group are 16
+// neighbouring input pixels, so each store instruction writes 128-byte runs.  (TR = 5: no activation, TR = 6: exact GELU.)  The generic
+// kernel's scalar scatter took 44.6 us for cfg5's first decoder stage (32768 x 256 -> 512, 67 MB out).
+template <int TR>
+__device__ __forceinline__ void epilogue4_dnchw2(const TanteGemm& g, const EpiRow& e, int n0, float (&v)[4]) {
+  if (!e.ok || n0 >= g.N) return;
+  const f32x4 b = *(const f32x4*)(g.bias + n0);
+  const long Wo = 2L * g.Wi, plane = 2L * g.Hi * Wo;
+  float* o = (float*)g.out + e.o_base + (long)(n0 >> 2) * plane;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    v[j] += b[j];
+    if constexpr (TR == 6) v[j] = gelu_erf_fast(v[j]);      // |error| <= 1.5e-7 against erff (the generic epilogue's): the output is an fp32 image
+  }
+  *(f32x2*)o = f32x2{v[0], v[1]};
+  *(f32x2*)(o + Wo) = f32x2{v[2], v[3]};
+}
+
 template <int CB, int TT, int EP, int TR = 0, int AM = 0>
 __global__ __launch_bounds__(256, 4) void gemm_lite_kernel(const TanteGemm g, int n_tiles, int tiles_per_split) {
   constexpr int CPR = CB * 4, NT = nt_for_cb(CB), NSUB = NT / 16, TILE_U = NT * CPR, UPT = TILE_U / 256;
@@ -706,12 +725,20 @@ __global__ __launch_bounds__(256, 4) void gemm_lite_kernel(const TanteGemm g, in
   u32x4 xf[TT][CB];
 #pragma unroll
   for (int tt = 0; tt < TT; ++tt) {
-    if constexpr (AM == 0) {
+    if constexpr (AM == 0 || AM == 5) {
       const RowInfo ri = row_info(g, row0 + tt * 16 + l15);
 #pragma unroll
       for (int cb = 0; cb < CB; ++cb) {
         xf[tt][cb] = u32x4{0u, 0u, 0u, 0u};
-        if (ri.ok) xf[tt][cb] = *(const u32x4*)((const unsigned short*)g.a + ri.a_base + (cb * 4 + kk) * 8);
+        if (ri.ok) {
+          if constexpr (AM == 0) {
+            xf[tt][cb] = *(const u32x4*)((const unsigned short*)g.a + ri.a_base + (cb * 4 + kk) * 8);
+          } else {      // fp32 rows (the residual stream), rounded to bf16 as the staged kernels round them
+            const float* p = (const float*)g.a + ri.a_base + (cb * 4 + kk) * 8;
+            const f32x4 lo = *(const f32x4*)p, hi = *(const f32x4*)(p + 4);
+            xf[tt][cb] = u32x4{pack_bf16x2(lo[0], lo[1]), pack_bf16x2(lo[2], lo[3]), pack_bf16x2(hi[0], hi[1]), pack_bf16x2(hi[2], hi[3])};
+          }
+        }
       }
     } else {
       const PatchRow pr = patch_row(g, row0 + tt * 16 + l15);
@@ -756,6 +783,7 @@ __global__ __launch_bounds__(256, 4) void gemm_lite_kernel(const TanteGemm g, in
       for (int tt = 0; tt < TT; ++tt) {
         float v[4] = {acc[ns][tt][0], acc[ns][tt][1], acc[ns][tt][2], acc[ns][tt][3]};
         if constexpr (TR == 0) epilogue4_fast<EP, true>(g, er[tt], t * NT + ns * 16 + kk * 4, v);
+        else if constexpr (TR >= 5) epilogue4_dnchw2<TR>(g, er[tt], t * NT + ns * 16 + kk * 4, v);
         else if constexpr (TR >= 3) epilogue4_nchw<TR>(g, er[tt], t * NT + ns * 16 + kk * 4, v);
         else epilogue4_train<TR>(g, er[tt], row0 + tt * 16 + l15, t * NT + ns * 16 + kk * 4, v);
       }
@@ -800,6 +828,15 @@ bool try_lite(const TanteGemm& g, int n_tiles, int flags, hipStream_t s) {
       return b16 ? lite_patch<CB, 3>(g, n_tiles, s) : lite_patch<CB, 4>(g, n_tiles, s);
     }
     return false;
+  }
+  if (g.a_mode == TANTE_A_LINEAR && g.e_mode == TANTE_E_DECONV_NCHW) {      // kernel-2 transposed conv, channels-first pixel shuffle (epilogue4_dnchw2)
+    if (off || g.ln || g.drop_p > 0.0f || g.dact || g.Po != 2 || g.out_dtype != TANTE_F32 || !(flags & 1) || g.K != CB * 32 || g.M < 4096 ||
+        ((uintptr_t)g.out % 8) != 0 || (g.act != TANTE_ACT_NONE && g.act != TANTE_ACT_GELU_ERF) || (g.a_dtype != TANTE_BF16 && g.a_dtype != TANTE_F32))
+      return false;
+    const bool gelu = g.act == TANTE_ACT_GELU_ERF;
+    if (g.a_dtype == TANTE_BF16) { if (gelu) launch_lite<CB, EP_LIN_NONE, 6, 0>(g, n_tiles, s); else launch_lite<CB, EP_LIN_NONE, 5, 0>(g, n_tiles, s); }
+    else { if (gelu) launch_lite<CB, EP_LIN_NONE, 6, 5>(g, n_tiles, s); else launch_lite<CB, EP_LIN_NONE, 5, 5>(g, n_tiles, s); }
+    return true;
   }
   if ((off && g.drop_p <= 0.0f && !g.dact) || g.ln || g.a_mode != TANTE_A_LINEAR || g.a_dtype != TANTE_BF16 || (flags & 3) != 3 || g.e_mode != TANTE_E_LINEAR) return false;
   if (g.K != CB * 32 || g.M < 4096) return false;   // whole 32-wide k blocks: the raw fragment loads have no K tail

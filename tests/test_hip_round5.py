@@ -532,3 +532,35 @@ def test_overlapping_model_trains(dev):
     for _ in range(5):
         l1 = float(tante_amd.train_step(m, opt, batch, fmt, 2, 1))
     assert l1 < l0, (l0, l1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("src", [torch.float32, torch.bfloat16])
+def test_deconv2_channels_first_in_the_register_stationary_kernel(dev, src):
+    """stages.deconv_stage with kernel = stride = 2 and a channels-first fp32 output (enc_dec_fno.py:276-323's first decoder stage at cfg5:
+    32768 x 256 -> 128 x 2 x 2): the register-stationary GEMM with the pixel shuffle as its epilogue (gemm.hip epilogue4_dnchw2) against
+    the generic kernel it replaces (TANTE_GEMM_NO_LITE) and against torch's conv_transpose2d on bf16-rounded operands."""
+    import tante_amd
+    from tante_amd import stages as S, kernels as K, _lib as L
+    torch.manual_seed(5)
+    n, h, w, Cin, Cout = 2, 48, 64, 256, 40          # 6144 rows
+    dc = torch.nn.ConvTranspose2d(Cin, Cout, (2, 2), stride=(2, 2)).to(dev)
+    pw = K.pack_weight(dc.weight, dc.bias, L.BF16, L.W_DECONV_NCHW, N=Cout * 4, K=Cin, P=2, C_other=Cout)
+    rows = torch.randn(n * h * w, Cin, device=dev).to(src).contiguous()
+    for act in (L.ACT_NONE, L.ACT_GELU_ERF):
+        y = S.deconv_stage(rows, n, h, w, 2, 0.0, pw, Cout, L.BF16, act, True, torch.float32)
+        tante_amd.set_option("TANTE_GEMM_NO_LITE", 1)
+        try:
+            y0 = S.deconv_stage(rows, n, h, w, 2, 0.0, pw, Cout, L.BF16, act, True, torch.float32)
+        finally:
+            tante_amd.set_option("TANTE_GEMM_NO_LITE", 0)
+        assert y.shape == (n, Cout, 2 * h, 2 * w)
+        e0 = rel_err(y, y0)
+        assert e0 < 1e-6, (act, e0)
+        x4 = rows.float().bfloat16().float().view(n, h, w, Cin).permute(0, 3, 1, 2)
+        ref = torch.nn.functional.conv_transpose2d(x4, dc.weight.detach().bfloat16().float(), dc.bias.detach(), stride=2)
+        if act == L.ACT_GELU_ERF:
+            ref = torch.nn.functional.gelu(ref)
+        e = rel_err(y, ref)
+        record_parity(e, e, 2e-5, "bf16", f"kernel-2 transposed conv, channels-first epilogue, act {act}, rows {str(src).split('.')[-1]}")
+        assert e < 2e-5, (act, e)
