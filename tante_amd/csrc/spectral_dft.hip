@@ -531,6 +531,149 @@ __global__ __launch_bounds__(256) void idft_rows_conv_x3_kernel(const float* __r
   }
 }
 
+// ---- E3 for the WIDE layers (64 -> 128 and 128 -> 64 channels at W = 128: enc_FNO's second and dec_FNO's first spectral layer at cfg5) -----
+// The kernel above keeps a wave's image row in a staging area of its own (Cin x 132 floats) and both output tiles' conv weights in
+// registers: Cin <= 64, Cout <= 32.  The wide layers ran on the fp32 kernel E (v_mfma_f32_32x32x2_f32, 64 cycles each): 81 / 41 us per
+// call at cfg5 against a matrix floor of ~20 us, every one-row workgroup rebuilding the table and transposing w0.  Here the WORKGROUP owns
+// one image row at a time (W = 128 = its 8 column tiles): the four waves stage the row's coefficients zs[2 m2][Cout + 4] and its pixels
+// xs[Cin][132] together (16 bytes per lane, whole contiguous runs), then wave w computes output channels 16 OTW w .. 16 OTW (w + 1) - 1
+// for every column tile with the same split-operand products (a . b ~= a_hi b_hi + a_lo b_hi + a_hi b_lo on v_mfma_f32_16x16x32_bf16);
+// its conv weights (OTW tiles x KCS k-steps, hi and lo) stay in registers across rows.  Every wave splits the row's pixels itself (the
+// split is VALU work of the order of its MFMAs; sharing it would cost a second LDS round trip).
+template <int KCS, int OTW>   // Cin = 32 KCS, Cout = 64 OTW; 2 m2 <= 32; W = 128
+__global__ __launch_bounds__(256) void idft_rows_conv_x3w_kernel(const float* __restrict__ Z, const float* __restrict__ x, const float* __restrict__ w0,
+                                                                 const float* __restrict__ b0, long n, int H, int m2, int act, float* __restrict__ out) {
+  constexpr int Cin = 32 * KCS, Cout = 64 * OTW, W = 128, ZP = Cout + 4, XP = 132;
+  extern __shared__ __attribute__((aligned(16))) u32x4 tblw[];      // G fragments [hi | lo][8 column tiles][64 lanes], then zs, then xs
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, kk = lane >> 4;
+  float* zs = (float*)(tblw + 2 * 512);
+  float* xs = zs + 32 * ZP;
+  {
+    float2* base = (float2*)xs;      // (cos, sin)(2 pi m / W), in the pixel area, which is not in use yet
+    for (int m = tid; m < W; m += 256) {
+      float sn, cs;
+      sincos_frac(m, W, sn, cs);
+      base[m] = make_float2(cs, sn);
+    }
+    __syncthreads();
+    for (int e = tid; e < 512; e += 256) {
+      const int wt = (e >> 6) & 7, ln = e & 63, w = 16 * wt + (ln & 15);
+      float v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int k = 8 * (ln >> 4) + q;
+        v[q] = 0.0f;
+        if (k < 2 * m2) {
+          const int j = k < m2 ? k : k - m2;
+          const float2 t = base[mod_u32((unsigned)(j * w), (unsigned)W)];
+          const float a = j == 0 ? 1.0f : 2.0f;
+          v[q] = k < m2 ? a * t.x : -a * t.y;
+        }
+      }
+      u32x4 hi, lo;
+      split8(v, hi, lo);
+      tblw[e] = hi;
+      tblw[512 + e] = lo;
+    }
+    __syncthreads();
+  }
+  const int o_base = 16 * OTW * wave;      // this wave's first output channel
+  u32x4 Wc[2][KCS][OTW];
+#pragma unroll
+  for (int sc = 0; sc < KCS; ++sc)
+#pragma unroll
+    for (int ot = 0; ot < OTW; ++ot) {
+      const int o = o_base + 16 * ot + l15;
+      const float* wp = w0 + (long)o * Cin + 32 * sc + 8 * kk;
+      const f32x4 a = *(const f32x4*)wp, b = *(const f32x4*)(wp + 4);
+      const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+      split8(v, Wc[0][sc][ot], Wc[1][sc][ot]);
+    }
+  float bias[OTW];
+#pragma unroll
+  for (int ot = 0; ot < OTW; ++ot) bias[ot] = b0 ? b0[o_base + 16 * ot + l15] : 0.0f;
+  const long rows = n * H, HWl = (long)H * W;
+  const int nz4 = 2 * m2 * Cout / 4;
+  for (long rho = blockIdx.x; rho < rows; rho += gridDim.x) {
+    const long b = rho / H;
+    const int h = (int)(rho - b * H);
+    __syncthreads();      // the previous row's operands have been read by every wave
+    {
+      const float* zrow = Z + rho * 2 * m2 * Cout;
+      for (int idx = tid; idx < nz4; idx += 256) {
+        const f32x4 zr = *(const f32x4*)(zrow + 4 * idx);
+        const int k = (4 * idx) / Cout, o = 4 * idx - k * Cout;
+        *(f32x4*)(zs + k * ZP + o) = zr;
+      }
+      const float* xp = x + ((b * Cin) * H + h) * (long)W;
+      constexpr int NX = Cin * 32 / 256;      // 16-byte pieces per thread
+      f32x4 xr[NX];
+#pragma unroll
+      for (int u = 0; u < NX; ++u) {
+        const int piece = tid + 256 * u, c = piece >> 5, c4 = piece & 31;
+        xr[u] = *(const f32x4*)(xp + (long)c * HWl + 4 * c4);
+      }
+#pragma unroll
+      for (int u = 0; u < NX; ++u) {
+        const int piece = tid + 256 * u, c = piece >> 5, c4 = piece & 31;
+        *(f32x4*)(xs + c * XP + 4 * c4) = xr[u];
+      }
+    }
+    __syncthreads();
+    u32x4 Zf[2][OTW];
+#pragma unroll
+    for (int ot = 0; ot < OTW; ++ot) {
+      const int o = o_base + 16 * ot + l15;
+      float v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int k = 8 * kk + q;
+        v[q] = k < 2 * m2 ? zs[k * ZP + o] : 0.0f;
+      }
+      split8(v, Zf[0][ot], Zf[1][ot]);
+    }
+    float* orow = out + ((b * Cout + o_base) * H + h) * (long)W + 4 * kk;
+#pragma unroll 1
+    for (int wt = 0; wt < 8; ++wt) {
+      u32x4 Xf[2][KCS];
+#pragma unroll
+      for (int sc = 0; sc < KCS; ++sc) {
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = xs[(32 * sc + 8 * kk + q) * XP + 16 * wt + l15];
+        split8(v, Xf[0][sc], Xf[1][sc]);
+      }
+      const u32x4 gh = tblw[wt * 64 + lane], gl = tblw[512 + wt * 64 + lane];
+      f32x4 acc[OTW];
+#pragma unroll
+      for (int ot = 0; ot < OTW; ++ot) {
+        acc[ot] = f32x4{0.f, 0.f, 0.f, 0.f};
+        acc[ot] = mfma16(gh, Zf[1][ot], acc[ot]);
+        acc[ot] = mfma16(gl, Zf[0][ot], acc[ot]);
+        acc[ot] = mfma16(gh, Zf[0][ot], acc[ot]);
+      }
+#pragma unroll
+      for (int sc = 0; sc < KCS; ++sc)
+#pragma unroll
+        for (int ot = 0; ot < OTW; ++ot) {
+          acc[ot] = mfma16(Xf[0][sc], Wc[1][sc][ot], acc[ot]);
+          acc[ot] = mfma16(Xf[1][sc], Wc[0][sc][ot], acc[ot]);
+          acc[ot] = mfma16(Xf[0][sc], Wc[0][sc][ot], acc[ot]);
+        }
+#pragma unroll
+      for (int ot = 0; ot < OTW; ++ot) {
+        f32x4 v = acc[ot] + splat4(bias[ot]);
+        if (act == TANTE_ACT_GELU_ERF) v = gelu_poly4<false>(v);
+        else if (act != TANTE_ACT_NONE) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], act);
+        }
+        st_wt16(orow + (long)(16 * ot + l15) * HWl + 16 * wt, v);
+      }
+    }
+  }
+}
+
 }  // namespace
 
 int tante_spectral_dft_supported(int64_t n, int Cin, int Cout, int H, int W, int m1, int m2) {
@@ -608,6 +751,21 @@ int tante_spectral_dft_forward(const float* x, int64_t n, int Cin, int H, int W,
   size_t ldsE3 = 0;
   const bool x3 = dft_x3_ok(Cin, Cout, W, m2, &ldsE3) && ((uintptr_t)x % 16) == 0 && ((uintptr_t)out % 16) == 0;
   if (out_bf16 && !x3) return -2;      // (the caller asked tante_spectral_dft_bf16out_supported first)
+  // the wide layers (idft_rows_conv_x3w_kernel): 64 -> 128 and 128 -> 64 channels at W = 128
+  if (!x3 && !out_bf16 && compute == TANTE_BF16 && tante_opt("TANTE_SPECTRAL_X3", 1) && W == 128 && 2 * m2 <= 32 && ((uintptr_t)x % 16) == 0 &&
+      ((uintptr_t)out % 16) == 0 && ((uintptr_t)w0 % 16) == 0 && ((Cin == 64 && Cout == 128) || (Cin == 128 && Cout == 64))) {
+    const size_t ldsW = (size_t)2 * 512 * 16 + (size_t)(32 * (Cout + 4) + Cin * 132) * 4;
+    const long rowsW = (long)n * H;
+    static TantePerDevice attrW[2];
+    if (Cin == 64) {
+      attrW[0].once([&] { (void)hipFuncSetAttribute((const void*)idft_rows_conv_x3w_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); });
+      hipLaunchKernelGGL((idft_rows_conv_x3w_kernel<2, 2>), dim3((unsigned)std::min<long>(rowsW, 512)), dim3(256), ldsW, s, Z, x, w0, b0, (long)n, H, m2, act, out);
+    } else {
+      attrW[1].once([&] { (void)hipFuncSetAttribute((const void*)idft_rows_conv_x3w_kernel<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); });
+      hipLaunchKernelGGL((idft_rows_conv_x3w_kernel<4, 1>), dim3((unsigned)std::min<long>(rowsW, 256)), dim3(256), ldsW, s, Z, x, w0, b0, (long)n, H, m2, act, out);
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+  }
   if (out_bf16 || (compute == TANTE_BF16 && x3 && tante_opt("TANTE_SPECTRAL_X3", 1))) {
     const int kzs = (2 * m2 + 31) / 32, kcs = (Cin + 31) / 32, ncb = W / 128;
     const long rows4 = ((long)n * H + 3) / 4;

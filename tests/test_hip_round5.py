@@ -564,3 +564,34 @@ def test_deconv2_channels_first_in_the_register_stationary_kernel(dev, src):
         e = rel_err(y, ref)
         record_parity(e, e, 2e-5, "bf16", f"kernel-2 transposed conv, channels-first epilogue, act {act}, rows {str(src).split('.')[-1]}")
         assert e < 2e-5, (act, e)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("Cin,Cout", [(64, 128), (128, 64)])
+def test_wide_spectral_layers_on_the_bf16_matrix_pipe(dev, Cin, Cout):
+    """SpectralLayer (enc_dec_fno.py:184-222) at cfg5's two wide shapes (64 -> 128 and 128 -> 64 channels on 128 x 128, modes 10 x 10) in the
+    bf16 compute mode: the inverse row transform + 1 x 1 conv with split-operand products on the bf16 matrix pipe
+    (idft_rows_conv_x3w_kernel, a . b ~= a_hi b_hi + a_lo b_hi + a_hi b_lo) against the fp32-MFMA kernel it replaces there
+    (TANTE_SPECTRAL_X3 = 0) and against the torch.fft restatement of the layer; 5 images, so that workgroups walk several rows."""
+    import tante_amd
+    from tante_amd import _lib as L
+    from oracle import spectral_oracle as SO
+    torch.manual_seed(Cin)
+    layer = tante_amd.SpectralLayer(Cin, Cout, 10, 10).to(dev)
+    x = torch.randn(5, Cin, 128, 128, device=dev)
+    for act in (L.ACT_NONE, L.ACT_GELU_ERF):
+        y = layer.run(x, act, L.BF16)
+        tante_amd.set_option("TANTE_SPECTRAL_X3", 0)
+        try:
+            y0 = layer.run(x, act, L.BF16)
+        finally:
+            tante_amd.set_option("TANTE_SPECTRAL_X3", 1)
+        e0 = max_rel(y, y0)
+        assert e0 < 2e-4, (act, e0)
+        sd = {k: v.detach().cpu() for k, v in layer.state_dict().items()}
+        ref = SO.spectral_layer(sd, x.cpu(), 10, 10)
+        if act == L.ACT_GELU_ERF:
+            ref = torch.nn.functional.gelu(ref)
+        e = max_rel(y.cpu(), ref)
+        record_parity(rel_err(y.cpu(), ref), e, 2e-4, "bf16", f"wide spectral layer {Cin}->{Cout}, split-bf16 inverse rows, act {act}")
+        assert e < 2e-4, (act, e)
