@@ -16,6 +16,7 @@ arithmetic runs in libtante_hip.so:
 """
 from __future__ import annotations
 
+import ctypes as C
 import math
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Tuple
@@ -484,14 +485,30 @@ class TANTE(nn.Module):
     # (T times).  encode_frame() writes that pre-FiLM encoding; forward(enc_cache=...) skips the encoder and lets the first propagator
     # kernel apply FiLM while it loads the planes.  Same arithmetic per token, term for term.
     def enc_cache_supported(self) -> bool:
+        return self._enc_cache_fused() or self._enc_cache_frames()
+
+    def _enc_cache_fused(self) -> bool:
+        """enc_CNN with the fused stages: the first propagator launch applies FiLM while it loads the cached planes."""
         compute = resolve_compute(self.compute)
         return bool(self.deg and type(self.encoder).__name__ == "enc_CNN" and self.encoder.fuses_23(compute)
                     and K.axis_hw_supported(self.H_p, self.W_p, self.C))
+
+    def _enc_cache_frames(self) -> bool:
+        """The spectral encoder (round 5): enc_FNO is per frame too (enc_dec_fno.py:224-273: every layer acts on (B T) images), so the
+        rollout encodes each frame once and a window is T cached encodings + one FiLM / positional pass over them
+        (tante_film_pos_fwd_frames: the same expression per token as the dense pass).  At cfg5 the encoder was 42 % of a model call and
+        three of its four frames had been encoded by the previous calls."""
+        return bool(self.deg and type(self.encoder).__name__ == "enc_FNO" and self.C == 256 and 1 <= self.T <= 8)
 
     def encode_frames(self, frames: torch.Tensor, z: torch.Tensor) -> torch.Tensor:
         """frames: (B, F, D, H, W) fp32 view (contiguous frames, any batch stride) -> z (F, B, Hp*Wp, C) fp32, the encoder output before
         FiLM in the frame-major layout forward(enc_cache=...) reads (one launch pair for the F frames)."""
         compute = resolve_compute(self.compute)
+        if self._enc_cache_frames() and not self._enc_cache_fused():
+            B, F = frames.shape[:2]
+            y = self.encoder.forward_tokens(frames.detach().to(torch.float32), compute, None)        # rows (b, f, hw)
+            z.copy_(y.view(B, F, self.H_p * self.W_p, self.C).transpose(0, 1))
+            return z
         self.encoder.forward_frames(frames, compute, frames.stride(0), z)
         return z
 
@@ -546,6 +563,17 @@ class TANTE(nn.Module):
             if not self.enc_cache_supported():
                 raise RuntimeError("enc_cache: this model / compute mode has no frame-encoding cache path")
             x = torch.empty(B * T * HW, C_, dtype=torch.float32, device=inp.device)
+            if not self._enc_cache_fused():      # cached frames + FiLM / positional terms in one pass (tante.py:136-141 over the window)
+                zc = enc_cache[0]
+                fr = L.Frames()
+                for t in range(T):
+                    f = zc[t]
+                    if tuple(f.shape) != (B, HW, C_) or f.dtype != torch.float32 or f.stride(2) != 1 or f.stride(1) != C_ or f.data_ptr() % 16:
+                        raise ValueError("enc_cache: frames must be (B, Hp*Wp, C) fp32 with contiguous rows")
+                    fr.f[t], fr.bstride[t] = f.data_ptr(), f.stride(0)
+                L.check(L.lib().tante_film_pos_fwd_frames(C.byref(fr), fa.data_ptr(), fb.data_ptr(), self.s_emb.view(HW, C_).data_ptr(), B, T, HW, C_,
+                                                          x.data_ptr(), K._stream()), "tante_film_pos_fwd_frames")
+                enc_cache = None
         else:
             x = self.encoder.forward_tokens(inp, compute, film, bstride)                               # tante.py:132-141
         last_slot = dict(a_n0=HW, a_s1=T * HW * C_, a_s0=C_, a_off=(T - 1) * HW * C_)               # x[:, -1:] by stride

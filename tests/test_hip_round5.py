@@ -595,3 +595,31 @@ def test_wide_spectral_layers_on_the_bf16_matrix_pipe(dev, Cin, Cout):
         e = max_rel(y.cpu(), ref)
         record_parity(rel_err(y.cpu(), ref), e, 2e-4, "bf16", f"wide spectral layer {Cin}->{Cout}, split-bf16 inverse rows, act {act}")
         assert e < 2e-4, (act, e)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,tol", [("fp32", 1e-5), ("bf16", 1e-2)])
+def test_spectral_encoder_frame_cache_in_the_rollout(dev, mode, tol):
+    """rollout._rollout_in_place with the spectral encoder: every frame encoded once and a window assembled from the cached per-frame
+    encodings + tante_film_pos_fwd_frames (TANTE._enc_cache_frames; enc_dec_fno.py:224-273 is per frame, tante.py:136-141 applies FiLM(t)
+    and the positional terms behind it) against the window-by-window path (TANTE_NO_ENC_CACHE = 1) -- the same function; the mode mixing's
+    channel split depends on the image count, so fp32 agrees to rounding and bf16 to its own bar."""
+    import tante_amd
+    from tante_amd import rollout as R
+    torch.manual_seed(31)
+    md = tante_amd.TanteMetadata(n_fields=3, spatial_resolution=(64, 64))
+    m = tante_amd.TANTE(in_T=4, dset_metadata=md, taylor_order=1, attn_axes="THW", n_head=8, embed_dim=256, patch_scale=8, overlap_ratio=0.0,
+                        enc_dec_type="fno", modes1=8, modes2=8).to(dev).eval().set_compute(mode)
+    assert m.enc_cache_supported() and m._enc_cache_frames() and not m._enc_cache_fused()
+    x = torch.randn(2, 4, 3, 64, 64, device=dev)
+    with torch.no_grad():
+        y1 = R._rollout_in_place(m, x, 5).clone()
+        tante_amd.set_option("TANTE_NO_ENC_CACHE", 1)
+        try:
+            y0 = R._rollout_in_place(m, x, 5).clone()
+        finally:
+            tante_amd.set_option("TANTE_NO_ENC_CACHE", 0)
+    assert y1.shape == (2, 5, 3, 64, 64) and torch.isfinite(y1).all()
+    e = rel_err(y1, y0)
+    record_parity(e, max_rel(y1, y0), tol, mode, "rollout with the spectral encoder's frame cache vs window-by-window encoding")
+    assert e < tol, e
