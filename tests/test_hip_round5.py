@@ -623,3 +623,42 @@ def test_spectral_encoder_frame_cache_in_the_rollout(dev, mode, tol):
     e = rel_err(y1, y0)
     record_parity(e, max_rel(y1, y0), tol, mode, "rollout with the spectral encoder's frame cache vs window-by-window encoding")
     assert e < tol, e
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("H,W,Ht,Wt", [(7, 10, 3, 4), (15, 9, 5, 3), (12, 12, 6, 6), (5, 5, 5, 5), (9, 4, 2, 1)])
+def test_adaptive_average_pool_backward_against_torch(dev, H, W, Ht, Wt):
+    """tante_avgpool_nhwc / tante_avgpool_nhwc_bwd (AvgPoolFn: F.adaptive_avg_pool2d behind an overlapping conv, enc_dec_cnn.py:104-110) on
+    window geometries where cells overlap (H % Ht != 0), against torch's own forward and backward."""
+    from tante_amd.autograd import AvgPoolFn
+    torch.manual_seed(H * 100 + W)
+    n, C_ = 3, 12
+    x = torch.randn(n, H, W, C_, device=dev, requires_grad=True)
+    y = AvgPoolFn.apply(x.reshape(n * H * W, C_), n, H, W, C_, Ht, Wt, torch.float32)
+    w = torch.randn_like(y)
+    (y * w).sum().backward()
+    xr = x.detach().clone().requires_grad_(True)
+    yr = torch.nn.functional.adaptive_avg_pool2d(xr.permute(0, 3, 1, 2), (Ht, Wt)).permute(0, 2, 3, 1).reshape(n * Ht * Wt, C_)
+    (yr * w).sum().backward()
+    assert rel_err(y, yr) < 1e-6
+    e = rel_err(x.grad, xr.grad)
+    record_parity(e, e, 1e-6, "fp32", f"adaptive average pool backward {H}x{W} -> {Ht}x{Wt}")
+    assert e < 1e-6, e
+
+
+@pytest.mark.gpu
+def test_gemm_refuses_padding_it_cannot_serve(dev):
+    """TanteGemm.a_pad is implemented by the register-stationary bf16 patch path only (P = 4, pad 1, K = 256 / 512, M >= 4096): anything else
+    must fail loudly (-2), not run unpadded."""
+    from tante_amd import kernels as K, stages as S, _lib as L
+    conv = torch.nn.Conv2d(64, 32, (2, 2), stride=(2, 2)).to(dev)
+    pw = S.pack_linear_chunks(S.conv_weight_2d(conv.weight, 0), conv.bias, L.BF16)[0]
+    x = torch.randn(8, 64, 64, 64, device=dev)
+    y = torch.empty(8 * 32 * 32, 32, device=dev)
+    with pytest.raises(RuntimeError, match="a_pad"):
+        K.patch_embed(x, pw, y, n_img=8, Hin=64, Win=64, Cin=64, P=2, nchw=True, act=L.ACT_NONE, pad=1)
+    conv4 = torch.nn.Conv2d(16, 32, (4, 4), stride=(4, 4), padding=1).to(dev)
+    pw4 = S.pack_linear_chunks(S.conv_weight_2d(conv4.weight, 0), conv4.bias, L.BF16)[0]
+    xs = torch.randn(1, 16, 64, 64, device=dev)      # 256 patches: below the path's M >= 4096
+    with pytest.raises(RuntimeError, match="a_pad"):
+        K.patch_embed(xs, pw4, torch.empty(256, 32, device=dev), n_img=1, Hin=64, Win=64, Cin=16, P=4, nchw=True, act=L.ACT_NONE, pad=1)
