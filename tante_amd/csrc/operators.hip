@@ -1159,11 +1159,25 @@ __global__ __launch_bounds__(256) void resize_cl2cf_kernel(const void* __restric
   const int x0 = (int)fx, x1 = x0 + (x0 < Wi - 1 ? 1 : 0);
   const float lx = fx - (float)x0;
   const int s0 = x0 - xs0, s1 = x1 - xs0;
+  const bool vec16 = in_dtype == TANTE_BF16 && C % 8 == 0 && ((uintptr_t)in % 16) == 0 && isn % 8 == 0 && ish % 8 == 0 && isw % 8 == 0;
   for (int c0 = 0; c0 < C; c0 += CC) {
     const int cc = min(CC, C - c0);
-    for (int e = threadIdx.x; e < 2 * 66 * CC; e += 256) {
-      const int r = e / (66 * CC), rem = e - r * (66 * CC), sc = rem / CC, c = rem - sc * CC;
-      if (sc < ncol && c < cc) tile[r][sc][c] = ldx(in, in_dtype, img * isn + ((r ? y1 : y0) + cy) * ish + (xs0 + sc + cx) * isw + c0 + c);
+    if (vec16) {      // bf16 pixels of whole 16-byte pieces: one load per 8 channels (the scalar form below: 16 two-byte loads per thread)
+      constexpr int PCS = CC / 8;
+      for (int e = threadIdx.x; e < 2 * 66 * PCS; e += 256) {
+        const int r = e / (66 * PCS), rem = e - r * (66 * PCS), sc = rem / PCS, pc = rem - sc * PCS;
+        if (sc < ncol && 8 * pc < cc) {
+          const u32x4 u = *(const u32x4*)((const unsigned short*)in + img * isn + ((r ? y1 : y0) + cy) * ish + (xs0 + sc + cx) * isw + c0 + 8 * pc);
+          float* t = &tile[r][sc][8 * pc];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { t[2 * q] = bf16_lo(u[q]); t[2 * q + 1] = bf16_hi(u[q]); }
+        }
+      }
+    } else {
+      for (int e = threadIdx.x; e < 2 * 66 * CC; e += 256) {
+        const int r = e / (66 * CC), rem = e - r * (66 * CC), sc = rem / CC, c = rem - sc * CC;
+        if (sc < ncol && c < cc) tile[r][sc][c] = ldx(in, in_dtype, img * isn + ((r ? y1 : y0) + cy) * ish + (xs0 + sc + cx) * isw + c0 + c);
+      }
     }
     __syncthreads();
     if (ox < Wo) {
