@@ -531,6 +531,122 @@ __global__ __launch_bounds__(256) void idft_rows_conv_x3_kernel(const float* __r
   }
 }
 
+// ---- A in the bf16 compute mode: the row DFT with split operands on the bf16 matrix pipe (the products of kernel E3) ------------------------
+// Kernel A above feeds v_mfma_f32_16x16x4_f32 (32 cycles per 16 x 16 x 4) from one float per lane and one LDS word per table operand: a
+// 512-wide image costs 768 such MFMAs per 32-row wave tile, one wave per SIMD (110 KB of tables), and ran 35-38 us per launch at cfg5
+// whatever the grid or the load depth (profiles/r05_ab_fno_dft_unroll.log) -- the wave's LDS-read -> MFMA chain.  Here x and the table are
+// split into bf16 hi + lo parts and x . T ~= x_hi T_hi + x_lo T_hi + x_hi T_lo runs as v_mfma_f32_16x16x32_bf16: 18 MFMAs of 16 cycles per
+// 32 columns instead of 48 of 32, the table as ready operand fragments (one ds_read_b128 per fragment), and every global access is 32
+// contiguous bytes per lane = whole 128-byte runs per image row.  ~1e-5 relative to the fp32 chain; bf16 compute mode only.
+template <int NT>
+__global__ __launch_bounds__(256) void dft_rows_x3_kernel(const float* __restrict__ x, long R, int W, int m2, float* __restrict__ Ar) {
+  extern __shared__ __attribute__((aligned(16))) u32x4 tfr[];      // [hi | lo][k-step s][column tile nt][64 lanes]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, kk = lane >> 4;
+  const int KS = W / 32, NF = KS * NT * 64;
+  {
+    float2* base = (float2*)(tfr + 2 * NF);      // (cos, sin)(2 pi m / W)
+    for (int m = tid; m < W; m += 256) {
+      float sn, cs;
+      sincos_frac(m, W, sn, cs);
+      base[m] = make_float2(cs, sn);
+    }
+    __syncthreads();
+    for (int e = tid; e < NF; e += 256) {
+      const int ln = e & 63, nt = (e >> 6) % NT, sk = (e >> 6) / NT;
+      const int ncol = 16 * nt + (ln & 15), j = ncol < m2 ? ncol : ncol - m2;
+      float v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int w = 32 * sk + 8 * (ln >> 4) + q;
+        v[q] = 0.0f;
+        if (ncol < 2 * m2) {
+          const float2 t = base[mod_u32((unsigned)(j * w), (unsigned)W)];
+          v[q] = ncol < m2 ? t.x : -t.y;
+        }
+      }
+      u32x4 hi, lo;
+      split8(v, hi, lo);
+      tfr[e] = hi;
+      tfr[NF + e] = lo;
+    }
+    __syncthreads();
+  }
+  const long ntile = (R + 31) / 32;
+  for (long t = (long)blockIdx.x * 4 + wave; t < ntile; t += (long)gridDim.x * 4) {
+    const long row0 = t * 32;
+    f32x4 acc[2][NT];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* xr[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      long r = row0 + 16 * mt + l15;
+      if (r >= R) r = R - 1;                      // clamped rows are computed and never stored
+      xr[mt] = x + r * W + 8 * kk;
+    }
+    auto kstep = [&](int sk, const f32x4 (&c)[2][2]) {
+      u32x4 xh[2], xl[2];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        const float v[8] = {c[mt][0][0], c[mt][0][1], c[mt][0][2], c[mt][0][3], c[mt][1][0], c[mt][1][1], c[mt][1][2], c[mt][1][3]};
+        split8(v, xh[mt], xl[mt]);
+      }
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const u32x4 th = tfr[(sk * NT + nt) * 64 + lane], tl = tfr[NF + (sk * NT + nt) * 64 + lane];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          acc[mt][nt] = mfma16(xl[mt], th, acc[mt][nt]);
+          acc[mt][nt] = mfma16(xh[mt], tl, acc[mt][nt]);
+          acc[mt][nt] = mfma16(xh[mt], th, acc[mt][nt]);
+        }
+      }
+    };
+    auto fetch = [&](int sk, f32x4 (&c)[2][2]) {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) { c[mt][0] = *(const f32x4*)(xr[mt] + 32 * sk); c[mt][1] = *(const f32x4*)(xr[mt] + 32 * sk + 4); }
+    };
+    if ((KS & 3) == 0) {      // a ring of four k-steps in flight (16 loads of 16 bytes per lane): the rows come cold from HBM
+      f32x4 ring[4][2][2];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) fetch(u, ring[u]);
+      for (int s0 = 0; s0 < KS; s0 += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          f32x4 c[2][2];
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt) { c[mt][0] = ring[u][mt][0]; c[mt][1] = ring[u][mt][1]; }
+          if (s0 + 4 + u < KS) fetch(s0 + 4 + u, ring[u]);
+          kstep(s0 + u, c);
+        }
+      }
+    } else {
+      f32x4 cur[2][2], nxt[2][2];
+      fetch(0, cur);
+      for (int sk = 0; sk < KS; ++sk) {
+        if (sk + 1 < KS) fetch(sk + 1, nxt);
+        kstep(sk, cur);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) { cur[mt][0] = nxt[mt][0]; cur[mt][1] = nxt[mt][1]; }
+      }
+    }
+    // D: column l15 = table column 16 nt + l15, rows 4 kk + r
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int k = 16 * nt + l15;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const long row = row0 + 16 * mt + 4 * kk + r;
+          if (k < 2 * m2 && row < R) Ar[row * (2 * m2) + k] = acc[mt][nt][r];
+        }
+      }
+  }
+}
+
 // ---- E3 for the WIDE layers (64 -> 128 and 128 -> 64 channels at W = 128: enc_FNO's second and dec_FNO's first spectral layer at cfg5) -----
 // The kernel above keeps a wave's image row in a staging area of its own (Cin x 132 floats) and both output tiles' conv weights in
 // registers: Cin <= 64, Cout <= 32.  The wide layers ran on the fp32 kernel E (v_mfma_f32_32x32x2_f32, 64 cycles each): 81 / 41 us per
@@ -724,7 +840,19 @@ int tante_spectral_dft_forward(const float* x, int64_t n, int Cin, int H, int W,
     attrA[NTV - 1].once([&] { (void)hipFuncSetAttribute((const void*)dft_rows_kernel<NTV>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); }); \
     hipLaunchKernelGGL(dft_rows_kernel<NTV>, dim3(gridA), dim3(256), ldsA, s, x, R, W, m2, Ar);                                  \
     break;
-  switch (NT) { TANTE_DFT_A(1) TANTE_DFT_A(2) TANTE_DFT_A(3) TANTE_DFT_A(4) default: return -2; }
+  const size_t ldsA3 = (size_t)2 * (W / 32) * NT * 1024 + (size_t)W * 8;
+  if (compute == TANTE_BF16 && tante_opt("TANTE_SPECTRAL_X3", 1) && ldsA3 <= 150 * 1024 && ((uintptr_t)x % 16) == 0) {      // split-bf16 row transform
+    static TantePerDevice attrA3[4];
+#define TANTE_DFT_A3(NTV)                                                                                                         \
+  case NTV:                                                                                                                       \
+    attrA3[NTV - 1].once([&] { (void)hipFuncSetAttribute((const void*)dft_rows_x3_kernel<NTV>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); }); \
+    hipLaunchKernelGGL(dft_rows_x3_kernel<NTV>, dim3(gridA), dim3(256), ldsA3, s, x, R, W, m2, Ar);                                \
+    break;
+    switch (NT) { TANTE_DFT_A3(1) TANTE_DFT_A3(2) TANTE_DFT_A3(3) TANTE_DFT_A3(4) default: return -2; }
+#undef TANTE_DFT_A3
+  } else {
+    switch (NT) { TANTE_DFT_A(1) TANTE_DFT_A(2) TANTE_DFT_A(3) TANTE_DFT_A(4) default: return -2; }
+  }
 #undef TANTE_DFT_A
   const long NC = (long)n * Cin;
   const unsigned gridB = (unsigned)((NC * 2 * m1 + 3) / 4);

@@ -662,3 +662,28 @@ def test_gemm_refuses_padding_it_cannot_serve(dev):
     xs = torch.randn(1, 16, 64, 64, device=dev)      # 256 patches: below the path's M >= 4096
     with pytest.raises(RuntimeError, match="a_pad"):
         K.patch_embed(xs, pw4, torch.empty(256, 32, device=dev), n_img=1, Hin=64, Win=64, Cin=16, P=4, nchw=True, act=L.ACT_NONE, pad=1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("Cin,Cout,H,W,m", [(8, 32, 64, 512, 20), (32, 8, 48, 256, 12), (3, 5, 32, 96, 6)])
+def test_row_transform_with_split_operands(dev, Cin, Cout, H, W, m):
+    """SpectralLayer (enc_dec_fno.py:184-222) in the bf16 compute mode: the forward row DFT as split-bf16 products on the bf16 matrix pipe
+    (dft_rows_x3_kernel) against the fp32-MFMA kernels (TANTE_SPECTRAL_X3 = 0) and the torch.fft restatement -- 2e-4 of the largest entry
+    (the bf16 mode's own bar is 1e-2); ragged row counts (n Cin H not a multiple of 32) and a width that is not a multiple of 64."""
+    import tante_amd
+    from tante_amd import _lib as L
+    from oracle import spectral_oracle as SO
+    torch.manual_seed(W + Cin)
+    layer = tante_amd.SpectralLayer(Cin, Cout, m, m).to(dev)
+    x = torch.randn(3, Cin, H, W, device=dev)
+    y = layer.run(x, L.ACT_NONE, L.BF16)
+    tante_amd.set_option("TANTE_SPECTRAL_X3", 0)
+    try:
+        y0 = layer.run(x, L.ACT_NONE, L.BF16)
+    finally:
+        tante_amd.set_option("TANTE_SPECTRAL_X3", 1)
+    assert max_rel(y, y0) < 2e-4, max_rel(y, y0)
+    ref = SO.spectral_layer({k: v.detach().cpu() for k, v in layer.state_dict().items()}, x.cpu(), m, m)
+    e = max_rel(y.cpu(), ref)
+    record_parity(rel_err(y.cpu(), ref), e, 2e-4, "bf16", f"spectral layer {Cin}->{Cout} at {H}x{W}, split-bf16 row transform")
+    assert e < 2e-4, e
