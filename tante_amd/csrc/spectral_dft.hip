@@ -593,16 +593,23 @@ __global__ __launch_bounds__(256) void dft_rows_x3_kernel(const float* __restric
         const float v[8] = {c[mt][0][0], c[mt][0][1], c[mt][0][2], c[mt][0][3], c[mt][1][0], c[mt][1][1], c[mt][1][2], c[mt][1][3]};
         split8(v, xh[mt], xl[mt]);
       }
+      // (the three products of one accumulator are issued 2 NT MFMAs apart: back to back each would wait for the one before it, and with
+      // one or two waves per SIMD nothing else fills the matrix pipe)
+      u32x4 th[NT], tl[NT];
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const u32x4 th = tfr[(sk * NT + nt) * 64 + lane], tl = tfr[NF + (sk * NT + nt) * 64 + lane];
+      for (int nt = 0; nt < NT; ++nt) { th[nt] = tfr[(sk * NT + nt) * 64 + lane]; tl[nt] = tfr[NF + (sk * NT + nt) * 64 + lane]; }
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-          acc[mt][nt] = mfma16(xl[mt], th, acc[mt][nt]);
-          acc[mt][nt] = mfma16(xh[mt], tl, acc[mt][nt]);
-          acc[mt][nt] = mfma16(xh[mt], th, acc[mt][nt]);
-        }
-      }
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) acc[mt][nt] = mfma16(xl[mt], th[nt], acc[mt][nt]);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) acc[mt][nt] = mfma16(xh[mt], tl[nt], acc[mt][nt]);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) acc[mt][nt] = mfma16(xh[mt], th[nt], acc[mt][nt]);
     };
     auto fetch = [&](int sk, f32x4 (&c)[2][2]) {
 #pragma unroll
