@@ -395,12 +395,22 @@ class CViT(nn.Module):
         c = S.linear_chunks(h, pk[1], torch.float32)
         return K.layernorm_affine(c, ln.weight, ln.bias, ln.eps)
 
-    def forward(self, x: torch.Tensor, input_coords: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """x (b, t, c, h, w) -> (b, out_steps, c, h, w); with input_coords (n, 2): (b, out_steps, n, c)   (cvit.py:427-466)."""
+    def encode(self, x: torch.Tensor):
+        """The input-dependent half of forward that does NOT depend on the query points: Encoder -> norm1 -> E2D (cvit.py:437-448) ->
+        the decoder's first keys / values.  Evaler.rollout_cvit (trainer/evaler.py:140-165) evaluates the full field in query chunks and
+        the reference runs the whole model per chunk; `forward(x, coords, encoded=model.encode(x))` runs this half once per window
+        (harness.rollout_cvit_eval) -- the same launches on the same data, so the same bits."""
+        return self.forward(x, None, _encode_only=True)
+
+    def forward(self, x: torch.Tensor, input_coords: Optional[torch.Tensor] = None, encoded=None, _encode_only: bool = False) -> torch.Tensor:
+        """x (b, t, c, h, w) -> (b, out_steps, c, h, w); with input_coords (n, 2): (b, out_steps, n, c)   (cvit.py:427-466).
+        encoded: the result of encode(x) for this x (inference only)."""
         if not x.is_cuda:
             raise RuntimeError("tante_amd.CViT runs on the GPU only (no CPU fallback); move the input to cuda")
         compute = resolve_compute(self.compute)
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            if encoded is not None or _encode_only:
+                raise ValueError("encode() / encoded= are inference-path options")
             return cvit_train_forward(self, x.detach().to(torch.float32).contiguous(), input_coords, compute)
         x = x.detach()
         # the formatter's 'b t h w c -> b t c h w' view of a channels-last batch is read in place by the patch gather (no copy)
@@ -408,6 +418,13 @@ class CViT(nn.Module):
         if not nhwc:
             x = x.to(torch.float32).contiguous()
         b, t, c, h, w = x.shape
+        if _encode_only:
+            y, s = self.Encoder.run(x, compute, nhwc)
+            e2d = self._cache.get((compute, "e2d"), [self.norm1.weight, self.norm1.bias, self.E2D.weight, self.E2D.bias],
+                                  lambda: K.pack_weight(self.E2D.weight, self.E2D.bias, compute, gamma=self.norm1.weight, beta=self.norm1.bias))
+            kv = torch.empty(b * s, self.dec_emb_dim, dtype=torch.float32, device=x.device)
+            K.linear(y, e2d, kv, M=b * s, ln=True, ln_eps=self.norm1.eps)
+            return (kv, s, compute, (b, t, c, h, w))
         if input_coords is None:
             params = [p for p in self.parameters()]
             q1 = self._coord_cache.get((compute, h, w), params, lambda: self._embed_coords(generate_coords(h, w, x.device), compute))
@@ -416,11 +433,17 @@ class CViT(nn.Module):
         n = q1.shape[0]
         d = self.dec_emb_dim
         q = q1                                                     # 'n d -> b n d' is never materialised: the blocks take the shared rows
-        y, s = self.Encoder.run(x, compute, nhwc)                                              # (b * s, emb)
-        e2d = self._cache.get((compute, "e2d"), [self.norm1.weight, self.norm1.bias, self.E2D.weight, self.E2D.bias],
-                              lambda: K.pack_weight(self.E2D.weight, self.E2D.bias, compute, gamma=self.norm1.weight, beta=self.norm1.bias))
-        kv = torch.empty(b * s, d, dtype=torch.float32, device=x.device)
-        K.linear(y, e2d, kv, M=b * s, ln=True, ln_eps=self.norm1.eps)                          # E2D(norm1(x))
+        if encoded is not None:
+            kv0, s, ecompute, eshape = encoded
+            if ecompute != compute or tuple(eshape) != (b, t, c, h, w):
+                raise ValueError("encoded= was computed for another input shape or compute mode")
+            kv = kv0      # (the blocks write fresh tensors: the cached rows stay intact for the next chunk)
+        else:
+            y, s = self.Encoder.run(x, compute, nhwc)                                          # (b * s, emb)
+            e2d = self._cache.get((compute, "e2d"), [self.norm1.weight, self.norm1.bias, self.E2D.weight, self.E2D.bias],
+                                  lambda: K.pack_weight(self.E2D.weight, self.E2D.bias, compute, gamma=self.norm1.weight, beta=self.norm1.bias))
+            kv = torch.empty(b * s, d, dtype=torch.float32, device=x.device)
+            K.linear(y, e2d, kv, M=b * s, ln=True, ln_eps=self.norm1.eps)                      # E2D(norm1(x))
         Lk = s
         for i, blk in enumerate(self.CrossAttnBlocks):   # queries stay the coordinate embedding; the output becomes the next keys/values
             last = i == len(self.CrossAttnBlocks) - 1     # the last block carries norm2 -> Mlp -> output layer (one launch where it fuses)

@@ -106,7 +106,9 @@ def rollout_cvit_eval(model, batch: Dict, formatter, n_steps: int, num_query_poi
     preds, produced = [], 0
     while produced < n_steps:
         cc, ii = generate_chunked_coords_with_indices(H, W, num_query_points, device)
-        y = reconstruct_full_field([model(moving, c) for c in cc], ii, H, W)
+        # (the reference runs the whole model per chunk; the encoder half does not depend on the query points: once per window)
+        enc = model.encode(moving) if (hasattr(model, "encode") and not torch.is_grad_enabled()) else None
+        y = reconstruct_full_field([model(moving, c, encoded=enc) if enc is not None else model(moving, c) for c in cc], ii, H, W)
         produced += y.shape[1]
         if produced < n_steps:
             moving = torch.cat([moving[:, y.shape[1]:], y], dim=1)

@@ -687,3 +687,35 @@ def test_row_transform_with_split_operands(dev, Cin, Cout, H, W, m):
     e = max_rel(y.cpu(), ref)
     record_parity(rel_err(y.cpu(), ref), e, 2e-4, "bf16", f"spectral layer {Cin}->{Cout} at {H}x{W}, split-bf16 row transform")
     assert e < 2e-4, e
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_cvit_query_chunks_share_one_encoding(dev, mode):
+    """Evaler.rollout_cvit (trainer/evaler.py:140-165) runs the whole model per query chunk; the encoder half (cvit.py:437-448) does not
+    depend on the query points: `CViT.encode(x)` once per window + `forward(x, coords, encoded=...)` per chunk gives the same bits as
+    the per-chunk full forward, and harness.rollout_cvit_eval (which now does that) the same as a loop of plain calls."""
+    import tante_amd
+    from tante_amd import harness as Hn
+    torch.manual_seed(4)
+    md = tante_amd.TanteMetadata(n_fields=2, spatial_resolution=(16, 24))
+    m = tante_amd.CViT(4, md, out_steps=2, patch_size=(1, 8, 8), grid_size=(16, 24), latent_dim=24, emb_dim=32, depth=2, num_heads=4,
+                       dec_emb_dim=32, dec_num_heads=4, dec_depth=2).to(dev).eval().set_compute(mode)
+    x = torch.randn(2, 4, 2, 16, 24, device=dev)
+    cc, ii = Hn.generate_chunked_coords_with_indices(16, 24, 100, dev)
+    with torch.no_grad():
+        enc = m.encode(x)
+        for c in cc:
+            assert torch.equal(m(x, c, encoded=enc), m(x, c))
+        with pytest.raises(ValueError):
+            m(x[:1], cc[0], encoded=enc)
+        fmt = tante_amd.DefaultChannelsFirstFormatter(md)
+        batch = {"input": torch.randn(2, 4, 16, 24, 2), "output": torch.randn(2, 4, 16, 24, 2)}
+        y, _ = Hn.rollout_cvit_eval(m, batch, fmt, n_steps=4, num_query_points=100, device=dev)
+        mov = fmt.process_input(batch)[0][0].to(dev)
+        outs = []
+        for _ in range(2):
+            f = Hn.reconstruct_full_field([m(mov, c) for c in cc], ii, 16, 24)
+            outs.append(fmt.process_output(f))
+            mov = torch.cat([mov[:, f.shape[1]:], f], dim=1)
+        assert torch.equal(y, torch.cat(outs, dim=1)[:, :4])
