@@ -184,11 +184,14 @@ __global__ void spectral_mix_kernel(const float2* __restrict__ X, const float* _
   }
 }
 
-// ---- D: inverse column DFT.  block = (image n, 8 rows h); a thread owns (o, j), keeps its 2 m1 coefficients in registers and walks
+// ---- D: inverse column DFT.  block = (image n, DFT_D_HB rows h); a thread owns (o, j), keeps its 2 m1 coefficients in registers and walks
 // the block's rows.  Z[n][h][k][o] (o innermost: the A operand rows of kernel E are contiguous), k = j (real part) | m2 + j (imaginary).
 template <int M1X2>
 __global__ __launch_bounds__(256) void idft_cols_kernel(const float2* __restrict__ Y, int H, int Cout, int m2, float* __restrict__ Z) {
-  constexpr int HB = 8;
+#ifndef DFT_D_HB
+#define DFT_D_HB 2      // rows per workgroup: a thread's pass is a serial chain over its rows (8 rows: 31 us per launch at cfg5 on 128 workgroups;
+#endif                  // 4 / 2 / 1 rows: cfg5 3 080 -> 3 124 / 3 150 / 3 137 frames/s, profiles/r05_ab_fno_idft_cols_rows.log)
+  constexpr int HB = DFT_D_HB;
   __shared__ float2 cs[HB][M1X2];
   const int m1 = M1X2 / 2;
   const long n = blockIdx.y;
@@ -875,7 +878,7 @@ int tante_spectral_dft_forward(const float* x, int64_t n, int Cin, int H, int W,
   while (cs < 16 && 2 * cs <= Cin && totalC * cs < 65536) cs *= 2;
   hipLaunchKernelGGL(spectral_mix_kernel, dim3((unsigned)std::min<long>(4096, (totalC * cs + 255) / 256)), dim3(256), 0, s, X, w_re, w_im, (long)n, Cin, Cout,
                      m1, m2, wm1, wm2, 1.0f / ((float)H * (float)W), Y, cs);
-  const dim3 gridD((unsigned)((H + 7) / 8), (unsigned)n);
+  const dim3 gridD((unsigned)((H + DFT_D_HB - 1) / DFT_D_HB), (unsigned)n);
   switch (2 * m1) {
 #define TANTE_DFT_D(V) case V: hipLaunchKernelGGL(idft_cols_kernel<V>, gridD, dim3(256), 0, s, Y, H, Cout, m2, Z); break;
     TANTE_DFT_D(4) TANTE_DFT_D(8) TANTE_DFT_D(10) TANTE_DFT_D(16) TANTE_DFT_D(20) TANTE_DFT_D(32) TANTE_DFT_D(40) TANTE_DFT_D(64)
