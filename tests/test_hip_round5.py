@@ -719,3 +719,22 @@ def test_cvit_query_chunks_share_one_encoding(dev, mode):
             outs.append(fmt.process_output(f))
             mov = torch.cat([mov[:, f.shape[1]:], f], dim=1)
         assert torch.equal(y, torch.cat(outs, dim=1)[:, :4])
+
+
+@pytest.mark.gpu
+def test_graphed_rollout_with_the_spectral_frame_cache(dev):
+    """GraphedRollout (one captured HIP graph per rollout) over a TANTE with the spectral encoder: the frame cache's copies and the
+    per-window FiLM pass are captured with the rest -- the replay gives the eager rollout's bits, twice."""
+    import tante_amd
+    torch.manual_seed(33)
+    md = tante_amd.TanteMetadata(n_fields=3, spatial_resolution=(64, 64))
+    m = tante_amd.TANTE(in_T=4, dset_metadata=md, taylor_order=1, attn_axes="THW", n_head=8, embed_dim=256, patch_scale=8, overlap_ratio=0.0,
+                        enc_dec_type="fno", modes1=8, modes2=8).to(dev).eval().set_compute("bf16")
+    fmt = tante_amd.DefaultChannelsFirstFormatter(md)
+    batch = {"input": torch.randn(2, 4, 64, 64, 3, device=dev), "output": torch.randn(2, 3, 64, 64, 3, device=dev)}
+    with torch.no_grad():
+        y0, _ = tante_amd.rollout_model(m, batch, fmt, 3)
+        roll = tante_amd.GraphedRollout(m, batch, fmt, 3)
+        y1 = roll(batch)[0].clone()
+        y2 = roll(batch)[0].clone()
+    assert torch.equal(y0, y1) and torch.equal(y1, y2)
