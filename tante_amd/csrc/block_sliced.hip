@@ -52,6 +52,9 @@ struct FsArgs {
   // inference, L = 4 (the T letter): the temporal propagator y_t = x_t + b2[t] + sum_j w2[t][j] gelu(b1[j] + sum_a w1[j][a] x_a)
   // (attn_backbone.py:144-145) applied to the rows as they are loaded for LayerNorm1: w1 (4 x 4), b1, w2 (4 x 4), b2 = 40 floats, or null
   const float* tprop;
+  // entry skew (inference, one resident round of two workgroups per CU): the workgroups of the second half of the grid -- the second
+  // resident of every CU -- sleep `skew` x 512 cycles before their first load, so that the two residents of a CU stop sharing every phase
+  int skew;
 };
 
 // In-kernel stamps (cdna_hip_programming.md 7): a -DTANTE_ABLATE build records the shader clock at every phase boundary of every wave
@@ -200,6 +203,11 @@ __global__ __launch_bounds__(64 * NW * G, 2) void block_fs_kernel(FsArgs A) {
     if ((__builtin_amdgcn_s_getreg(0x1804) & 1u) == (FS_PRIO & 1)) __builtin_amdgcn_s_setprio(3);
   }
 #endif
+  if constexpr (!TRAIN && G == 1) {
+    if (A.skew > 0 && blockIdx.x >= (gridDim.x >> 1)) {
+      for (int i = 0; i < A.skew; ++i) __builtin_amdgcn_s_sleep(8);
+    }
+  }
   float* const x = A.x;
   const unsigned long long smix = (TRAIN && A.seed_mix) ? *A.seed_mix : 0ull;      // per-step word of a replayed train step
   const unsigned long long sd_attn = A.seed_attn ^ smix;
@@ -1148,6 +1156,8 @@ int tante_fs_launch(float* x, const char* stream, const TanteSeq& sq, int causal
   }
   A.spw = tps ? 16 * ntt / L : (16 * full) / L;
   const int nwg = (sq.nseq + A.spw - 1) / A.spw;
+  // one resident round of two workgroups per CU (cfg2 / cfg3 at B = 8): the second residents start late (FsArgs.skew)
+  A.skew = (!tr && nw == 4 && nwg > 256 && nwg <= 512) ? tante_opt("TANTE_FS_SKEW", 0) : 0;
   const int key = nw * 100 + tps * 10 + ntt;
   switch (key) {
     case 412:
