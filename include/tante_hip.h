@@ -709,6 +709,70 @@ typedef struct TanteWgradJob {
 } TanteWgradJob;
 int tante_wgrad_jobs_ws(const TanteWgradJob* jobs, int n_jobs, int compute, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* ---- the TRAINING form of the token-local tail of a rollout call (tail_chain.hip; bf16, C = 256, patch_scale 8, D <= 12, Wp % 16 == 0) ----
+ * Replaces, on the differentiable path, the per-stage launches of dec_CNN.forward (enc_dec_cnn.py:263-277: three kernel = stride = 2
+ * transposed convolutions with erf-GELU between them), the Taylor sum (tante.py:165-171), enc_CNN.forward on the predicted frame
+ * (enc_dec_cnn.py:217-229) and the whole backward of that chain (~13 + ~33 launches per rollout call) by ONE forward and ONE backward launch.
+ * All "rows" tensors are token-major dense bf16 matrices: a token's 8 x 8 pixel block in hierarchical order, pixel index
+ * (kh1, kw1, kh2, kw2[, kh3, kw3]) = the taps of the three stages, so every weight gradient is dW = U^T V of two of them with NO gather:
+ *   xl16 (T, 256) | pre1 / act1 (4T, 128) | pre2 / act2 (16T, 64) | f16 (16T, 64: (kh3, kw3, d) at k = sub * D + d, zero beyond 4 D)
+ *   pre1e / act1e (16T, 64) | pre2e / act2e (4T, 128) | z (T, 256) fp32             (T = n_img * Hp * Wp tokens, 16 per workgroup)
+ * Weights come pre-packed (tante_tail_pack_dec / _enc: conv weights in the reference layouts, (Cin, Cout, 2, 2) / (Cout, Cin, 2, 2)) into
+ * buffers of tante_tail_stream_bytes(0 dec fwd | 1 dec bwd | 2 enc fwd | 3 enc bwd) bytes.  Token rows of the residual stream are
+ * addressed like tante_head_fused: row r at (r / a_n0) * a_s1 + (r % a_n0) * a_s0 + a_off (elements; a_n0 % 16 == 0). */
+#define TANTE_TAIL_MAX_ORD 3
+typedef struct TanteTailOrdF {
+  const float* x;        /* this order's residual stream */
+  const void* w;         /* decoder forward stream */
+  float coef;            /* Taylor coefficient (i dt)^k / k! */
+  void *xl16, *pre1, *act1, *pre2, *act2;
+} TanteTailOrdF;
+typedef struct TanteTailFwd {
+  TanteTailOrdF o[TANTE_TAIL_MAX_ORD];
+  int32_t n_ord;
+  int64_t a_s1, a_s0, a_off;
+  int32_t a_n0;
+  int32_t n_img, Hp, Wp, D;
+  const float* base;     /* the window's last frame (D, H, W) per image */
+  int64_t base_bstride;
+  float* out;            /* the predicted frame */
+  int64_t out_bstride;
+  const void* we;        /* encoder forward stream, or NULL: no re-encoding (the rollout's last call) */
+  void *f16, *pre1e, *act1e, *pre2e, *act2e;
+  float* z;
+} TanteTailFwd;
+typedef struct TanteTailOrdB {
+  const void* w;         /* decoder backward stream */
+  float coef;
+  const void *pre1, *pre2;
+  void *dpre1, *dpre2, *dder;      /* (T, 512) | (4T, 256) | (16T, 64): the V operands of the three decoder weight gradients */
+  float* dx;             /* gradient of this order's residual stream (rows addressed by a_*) */
+  float *db1, *db2, *db3;          /* bias gradients, ADDED (fp32 atomics); may be NULL */
+} TanteTailOrdB;
+typedef struct TanteTailBwd {
+  TanteTailOrdB o[TANTE_TAIL_MAX_ORD];
+  int32_t n_ord;
+  int64_t a_s1, a_s0, a_off;
+  int32_t a_n0;
+  int32_t n_img, Hp, Wp, D;
+  const float* dext;     /* gradient reaching the predicted frame from outside the chain (loss, the next call's Taylor base), or NULL */
+  int64_t dext_bstride;
+  float* dbase;          /* out: gradient of the window's last frame (= the frame's total gradient), or NULL */
+  int64_t dbase_bstride;
+  const float* dz;       /* gradient of the frame's encoding (T, 256), or NULL: the encoder part is skipped */
+  const void* we;        /* encoder backward stream */
+  const void *pre1e, *pre2e;
+  void *dz16, *dpre2e, *dpre1e;    /* (T, 256) | (4T, 128) | (16T, 64): the U operands of the three encoder weight gradients */
+} TanteTailBwd;
+int tante_tail_supported(int C, int D, int Hp, int Wp);
+int64_t tante_tail_stream_bytes(int which);
+int tante_tail_pack_dec(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3, const float* b3, int D,
+                        void* fwd_stream, void* bwd_stream, void* stream);
+int tante_tail_pack_enc(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3, const float* b3, int D,
+                        void* fwd_stream, void* bwd_stream, void* stream);
+int tante_tail_fwd(const TanteTailFwd* args, void* stream);
+int tante_tail_bwd(const TanteTailBwd* args, void* stream);
+
 const char* tante_last_error(void);
 int tante_abi_version(void);
 

@@ -80,7 +80,36 @@ class BlockTrain(C.Structure):
                 ("seed_mlp", C.c_uint64)]
 
 
+class TailOrdF(C.Structure):      # TanteTailOrdF
+    _fields_ = [("x", c_vp), ("w", c_vp), ("coef", c_f32), ("xl16", c_vp), ("pre1", c_vp), ("act1", c_vp), ("pre2", c_vp), ("act2", c_vp)]
+
+
+class TailFwd(C.Structure):       # TanteTailFwd
+    _fields_ = [("o", TailOrdF * 3), ("n_ord", c_i32), ("a_s1", c_i64), ("a_s0", c_i64), ("a_off", c_i64), ("a_n0", c_i32),
+                ("n_img", c_i32), ("Hp", c_i32), ("Wp", c_i32), ("D", c_i32), ("base", c_vp), ("base_bstride", c_i64),
+                ("out", c_vp), ("out_bstride", c_i64), ("we", c_vp), ("f16", c_vp), ("pre1e", c_vp), ("act1e", c_vp),
+                ("pre2e", c_vp), ("act2e", c_vp), ("z", c_vp)]
+
+
+class TailOrdB(C.Structure):      # TanteTailOrdB
+    _fields_ = [("w", c_vp), ("coef", c_f32), ("pre1", c_vp), ("pre2", c_vp), ("dpre1", c_vp), ("dpre2", c_vp), ("dder", c_vp),
+                ("dx", c_vp), ("db1", c_vp), ("db2", c_vp), ("db3", c_vp)]
+
+
+class TailBwd(C.Structure):       # TanteTailBwd
+    _fields_ = [("o", TailOrdB * 3), ("n_ord", c_i32), ("a_s1", c_i64), ("a_s0", c_i64), ("a_off", c_i64), ("a_n0", c_i32),
+                ("n_img", c_i32), ("Hp", c_i32), ("Wp", c_i32), ("D", c_i32), ("dext", c_vp), ("dext_bstride", c_i64),
+                ("dbase", c_vp), ("dbase_bstride", c_i64), ("dz", c_vp), ("we", c_vp), ("pre1e", c_vp), ("pre2e", c_vp),
+                ("dz16", c_vp), ("dpre2e", c_vp), ("dpre1e", c_vp)]
+
+
 SIGNATURES = {
+    "tante_tail_supported": ([c_i32, c_i32, c_i32, c_i32], c_i32),
+    "tante_tail_stream_bytes": ([c_i32], c_i64),
+    "tante_tail_pack_dec": ([c_vp] * 6 + [c_i32, c_vp, c_vp, c_vp], c_i32),
+    "tante_tail_pack_enc": ([c_vp] * 6 + [c_i32, c_vp, c_vp, c_vp], c_i32),
+    "tante_tail_fwd": ([C.POINTER(TailFwd), c_vp], c_i32),
+    "tante_tail_bwd": ([C.POINTER(TailBwd), c_vp], c_i32),
     "tante_pack_geom": ([c_i32, c_i32, c_i32, C.POINTER(PackGeom)], c_i32),
     "tante_pack_weight": ([c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp], c_i32),
     "tante_gemm": ([C.POINTER(Gemm), c_vp], c_i32),
@@ -221,7 +250,7 @@ LIB_OPTIONS = ("TANTE_ATTN_BWD_HG", "TANTE_ATTN_BWD_NO_SPLIT", "TANTE_ATTN_BWD_V
 
 
 _lib = None
-ABI_VERSION = 9      # include/tante_hip.h: bumped whenever an entry point is added or changes (round 4: 6 tante_head_enc_*, 7 tante_pos_embed_tmajor + tante_spectral_*bf16out*; round 5: 8 tante_block_bwd_fused, 9 TanteGemm.a_pad)
+ABI_VERSION = 10     # include/tante_hip.h: bumped whenever an entry point is added or changes (round 4: 6 tante_head_enc_*, 7 tante_pos_embed_tmajor + tante_spectral_*bf16out*; round 5: 8 tante_block_bwd_fused, 9 TanteGemm.a_pad; round 6: 10 tante_tail_*)
 
 
 def lib():

@@ -1334,6 +1334,139 @@ class TaylorFn(Function):
         return (dinp, None, None) + tuple(d.view(B, 1, *ishape[2:]) for d in dds)
 
 
+class TailFn(Function):
+    """The token-local tail of a rollout call as ONE autograd node, one launch forward and one backward (csrc/tail_chain.hip):
+    every order's derivative head (dec_CNN, enc_dec_cnn.py:263-277) -> Taylor sum (tante.py:165-171) -> predicted frame -> its
+    re-encoding for the next call's window (enc_CNN, enc_dec_cnn.py:217-229).  Inputs: base (B, 1, D, H, W) = the window's last frame,
+    cfg = TailCfg, xs[k] = order k's residual stream (B * T * HW, C) fp32 (its last time slot is read).  Outputs: the predicted frame
+    (B, 1, D, H, W) and its pre-FiLM encoding (B, HW, C) (None when cfg.want_z is False: the rollout's last call).
+    Parameter gradients go straight into the parameters' gradient slots (cfg checked that every one exists): the four wide weight
+    gradients as recorded uses of the shared end-of-pass launches, the two pixel-level ones (J = 4 D columns) immediately."""
+
+    @staticmethod
+    def forward(ctx, base, cfg, *xs):
+        B, T, HW, D, Hp, Wp = cfg.B, cfg.T, cfg.HW, cfg.D, cfg.Hp, cfg.Wp
+        dev = base.device
+        Tk = B * HW
+        bf = torch.bfloat16
+        a = L.TailFwd()
+        a.n_ord = len(xs)
+        a.a_n0, a.a_s1, a.a_s0, a.a_off = HW, T * HW * cfg.C, cfg.C, (T - 1) * HW * cfg.C
+        a.n_img, a.Hp, a.Wp, a.D = B, Hp, Wp, D
+        base = base.contiguous()
+        out = torch.empty(B, 1, D, 8 * Hp, 8 * Wp, dtype=torch.float32, device=dev)
+        a.base, a.base_bstride, a.out, a.out_bstride = base.data_ptr(), base.stride(0), out.data_ptr(), out.stride(0)
+        saved = []
+        keep = [base]
+        for k, x in enumerate(xs):
+            x = x.contiguous()
+            keep.append(x)
+            o = a.o[k]
+            t = {"xl16": torch.empty(Tk, 256, dtype=bf, device=dev), "pre1": torch.empty(4 * Tk, 128, dtype=bf, device=dev),
+                 "act1": torch.empty(4 * Tk, 128, dtype=bf, device=dev), "pre2": torch.empty(16 * Tk, 64, dtype=bf, device=dev),
+                 "act2": torch.empty(16 * Tk, 64, dtype=bf, device=dev)}
+            o.x, o.w, o.coef = x.data_ptr(), cfg.dec_streams[k][0].data_ptr(), cfg.coefs[k]
+            o.xl16, o.pre1, o.act1, o.pre2, o.act2 = (t[n].data_ptr() for n in ("xl16", "pre1", "act1", "pre2", "act2"))
+            saved.append(t)
+        enc = None
+        z = None
+        if cfg.want_z:
+            enc = {"f16": torch.empty(16 * Tk, 64, dtype=bf, device=dev), "pre1e": torch.empty(16 * Tk, 64, dtype=bf, device=dev),
+                   "act1e": torch.empty(16 * Tk, 64, dtype=bf, device=dev), "pre2e": torch.empty(4 * Tk, 128, dtype=bf, device=dev),
+                   "act2e": torch.empty(4 * Tk, 128, dtype=bf, device=dev)}
+            z = torch.empty(B, HW, cfg.C, dtype=torch.float32, device=dev)
+            a.we = cfg.enc_streams[0].data_ptr()
+            a.f16, a.pre1e, a.act1e, a.pre2e, a.act2e = (enc[n].data_ptr() for n in ("f16", "pre1e", "act1e", "pre2e", "act2e"))
+            a.z = z.data_ptr()
+        L.check(L.lib().tante_tail_fwd(C.byref(a), _s()), "tante_tail_fwd")
+        ctx.cfg, ctx.saved, ctx.enc, ctx.xshapes = cfg, saved, enc, [tuple(x.shape) for x in xs]
+        ctx.set_materialize_grads(False)
+        return out, z
+
+    @staticmethod
+    def backward(ctx, d_out, d_z):
+        cfg, saved, enc = ctx.cfg, ctx.saved, ctx.enc
+        B, T, HW, D, Hp, Wp = cfg.B, cfg.T, cfg.HW, cfg.D, cfg.Hp, cfg.Wp
+        Tk = B * HW
+        n_ord = len(saved)
+        if d_out is None and d_z is None:
+            return (None, None) + (None,) * n_ord
+        dev = saved[0]["xl16"].device
+        bf = torch.bfloat16
+        a = L.TailBwd()
+        a.n_ord = n_ord
+        a.a_n0, a.a_s1, a.a_s0, a.a_off = HW, T * HW * cfg.C, cfg.C, (T - 1) * HW * cfg.C
+        a.n_img, a.Hp, a.Wp, a.D = B, Hp, Wp, D
+        keep = []
+        if d_out is not None:
+            d_out = d_out.contiguous()
+            keep.append(d_out)
+            a.dext, a.dext_bstride = d_out.data_ptr(), d_out.stride(0)
+        dbase = torch.empty(B, 1, D, 8 * Hp, 8 * Wp, dtype=torch.float32, device=dev)
+        a.dbase, a.dbase_bstride = dbase.data_ptr(), dbase.stride(0)
+        outs, dxs = [], []
+        for k in range(n_ord):
+            t = saved[k]
+            o = a.o[k]
+            # (the other time slots of the stream receive no gradient from this node: the zero fill the slice's backward used to do)
+            dx = torch.zeros(ctx.xshapes[k], dtype=torch.float32, device=dev)
+            g = {"dpre1": torch.empty(Tk, 512, dtype=bf, device=dev), "dpre2": torch.empty(4 * Tk, 256, dtype=bf, device=dev),
+                 "dder": torch.empty(16 * Tk, 64, dtype=bf, device=dev)}
+            dc = cfg.dec_params[k]
+            slots = [_grad_slot(q) for q in dc]
+            o.w, o.coef, o.pre1, o.pre2 = cfg.dec_streams[k][1].data_ptr(), cfg.coefs[k], t["pre1"].data_ptr(), t["pre2"].data_ptr()
+            o.dpre1, o.dpre2, o.dder, o.dx = g["dpre1"].data_ptr(), g["dpre2"].data_ptr(), g["dder"].data_ptr(), dx.data_ptr()
+            o.db1, o.db2, o.db3 = slots[1].data_ptr(), slots[3].data_ptr(), slots[5].data_ptr()
+            outs.append((g, slots))
+            dxs.append(dx)
+        ge = None
+        if d_z is not None and enc is not None:
+            d_z = d_z.contiguous()
+            keep.append(d_z)
+            ge = {"dz16": torch.empty(Tk, 256, dtype=bf, device=dev), "dpre2e": torch.empty(4 * Tk, 128, dtype=bf, device=dev),
+                  "dpre1e": torch.empty(16 * Tk, 64, dtype=bf, device=dev)}
+            a.dz, a.we = d_z.data_ptr(), cfg.enc_streams[1].data_ptr()
+            a.pre1e, a.pre2e = enc["pre1e"].data_ptr(), enc["pre2e"].data_ptr()
+            a.dz16, a.dpre2e, a.dpre1e = ge["dz16"].data_ptr(), ge["dpre2e"].data_ptr(), ge["dpre1e"].data_ptr()
+        L.check(L.lib().tante_tail_bwd(C.byref(a), _s()), "tante_tail_bwd")
+        comp = L.BF16
+        for k in range(n_ord):
+            t, (g, slots), dc = saved[k], outs[k], cfg.dec_params[k]
+            # decoder weights (Cin, Cout, 2, 2): U = the stage's input pixels, V = the output-gradient patches, n = (kh, kw, co)
+            if not _defer_wgrad(slots[0], None, t["xl16"], g["dpre1"], Tk, 256, 512, comp, (L.W_DECONV_NHWC, 2, 128, True)):
+                wgrad(_rm_linear(t["xl16"]), _rm_linear(g["dpre1"]), Tk, 256, 512, tuple(dc[0].shape), comp, layout=L.W_DECONV_NHWC, P=2,
+                      C_other=128, swap=True, device=dev, into=slots[0])
+            if not _defer_wgrad(slots[2], None, t["act1"], g["dpre2"], 4 * Tk, 128, 256, comp, (L.W_DECONV_NHWC, 2, 64, True)):
+                wgrad(_rm_linear(t["act1"]), _rm_linear(g["dpre2"]), 4 * Tk, 128, 256, tuple(dc[2].shape), comp, layout=L.W_DECONV_NHWC, P=2,
+                      C_other=64, swap=True, device=dev, into=slots[2])
+            wgrad(_rm_linear(t["act2"]), _rm_linear(g["dder"], s0=64, rows=16 * Tk, cols=4 * D), 16 * Tk, 64, 4 * D, tuple(dc[4].shape), comp,
+                  layout=L.W_DECONV_NHWC, P=2, C_other=D, swap=True, device=dev, into=slots[4])
+        if ge is not None:
+            ec = cfg.enc_params
+            es = [_grad_slot(q) for q in ec]
+            # encoder weights (Cout, Cin, 2, 2): U = the stage's output gradient (bias gradient = its column sums), V = input patches, k = (kh, kw, ci)
+            if not _defer_wgrad(es[4], es[5], ge["dz16"], enc["act2e"].view(Tk, 512), Tk, 256, 512, comp, (L.W_CONV_NHWC, 2, 128, False)):
+                wgrad(_rm_linear(ge["dz16"]), _rm_linear(enc["act2e"].view(Tk, 512)), Tk, 256, 512, tuple(ec[4].shape), comp, layout=L.W_CONV_NHWC,
+                      P=2, C_other=128, device=dev, with_bias=True, into=es[4], db_into=es[5])
+            if not _defer_wgrad(es[2], es[3], ge["dpre2e"], enc["act1e"].view(4 * Tk, 256), 4 * Tk, 128, 256, comp, (L.W_CONV_NHWC, 2, 64, False)):
+                wgrad(_rm_linear(ge["dpre2e"]), _rm_linear(enc["act1e"].view(4 * Tk, 256)), 4 * Tk, 128, 256, tuple(ec[2].shape), comp,
+                      layout=L.W_CONV_NHWC, P=2, C_other=64, device=dev, with_bias=True, into=es[2], db_into=es[3])
+            wgrad(_rm_linear(ge["dpre1e"]), _rm_linear(enc["f16"], s0=64, rows=16 * Tk, cols=4 * D), 16 * Tk, 64, 4 * D, tuple(ec[0].shape), comp,
+                  layout=L.W_CONV_NHWC, P=2, C_other=D, device=dev, with_bias=True, into=es[0], db_into=es[1])
+        ctx.saved = ctx.enc = None
+        return (dbase, None) + tuple(dxs)
+
+
+class TailCfg:
+    """What TailFn needs besides tensors: geometry, Taylor coefficients, the packed weight streams (one set per rollout graph) and the
+    parameters whose gradient slots its backward adds into."""
+
+    def __init__(self, B, T, Hp, Wp, C_, D, coefs, dec_params, dec_streams, enc_params, enc_streams, want_z):
+        self.B, self.T, self.Hp, self.Wp, self.HW, self.C, self.D = B, T, Hp, Wp, Hp * Wp, C_, D
+        self.coefs, self.dec_params, self.dec_streams = coefs, dec_params, dec_streams
+        self.enc_params, self.enc_streams, self.want_z = enc_params, enc_streams, want_z
+
+
 class MseMeanFn(Function):
     """MSE(pred, ref).mean() of channels-last tensors (trainer/trainer.py:189)."""
 

@@ -9,12 +9,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libtante_hip.so")
-SOURCES = ["gemm.hip", "attention.hip", "pointwise.hip", "block_fused.hip", "block_sliced.hip", "block_bwd.hip", "block_bwd_fs.hip", "train.hip", "backward.hip", "wgrad.hip", "head_fused.hip", "head_enc.hip", "operators.hip", "enc_fused.hip", "axis_bwd.hip", "spectral_dft.hip", "cvit_fused.hip", "axis_mfma.hip"]
+SOURCES = ["gemm.hip", "attention.hip", "pointwise.hip", "block_fused.hip", "block_sliced.hip", "block_bwd.hip", "block_bwd_fs.hip", "train.hip", "backward.hip", "wgrad.hip", "head_fused.hip", "head_enc.hip", "operators.hip", "enc_fused.hip", "axis_bwd.hip", "spectral_dft.hip", "cvit_fused.hip", "axis_mfma.hip", "tail_chain.hip"]
 HEADERS = [os.path.join(CSRC, "common.hip.h"), os.path.join(CSRC, "fused_common.hip.h"), os.path.join(CSRC, "fs_common.hip.h"), os.path.join(CSRC, "block_sliced.h"), os.path.join(CSRC, "spectral_dft.h"), os.path.join(os.path.dirname(HERE), "include", "tante_hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=fast"]
 # the fused bf16 kernels are bound by VALU issue: without NaN-honouring every fmaxf / clamp loses its v_max canonicalisation
-EXTRA_FLAGS = {"block_fused.hip": ["-fno-honor-nans", "-DTANTE_MFMA_SETPRIO", "-mllvm", "-amdgpu-sched-strategy=max-ilp"], "block_sliced.hip": ["-fno-honor-nans", "-DTANTE_MFMA_SETPRIO", "-DFS_PRIO=1"], "block_bwd.hip": ["-fno-honor-nans", "-DTANTE_MFMA_SETPRIO", "-DBT_PRIO"], "block_bwd_fs.hip": ["-fno-honor-nans", "-DTANTE_MFMA_SETPRIO", "-DBT_PRIO"], "head_fused.hip": ["-fno-honor-nans"], "head_enc.hip": ["-fno-honor-nans"], "enc_fused.hip": ["-fno-honor-nans"], "operators.hip": ["-fno-honor-nans"], "spectral_dft.hip": ["-fno-honor-nans"], "cvit_fused.hip": ["-fno-honor-nans", "-DTANTE_MFMA_SETPRIO"], "axis_mfma.hip": ["-fno-honor-nans"]}
+EXTRA_FLAGS = {"block_fused.hip": ["-fno-honor-nans", "-DTANTE_MFMA_SETPRIO", "-mllvm", "-amdgpu-sched-strategy=max-ilp"], "block_sliced.hip": ["-fno-honor-nans", "-DTANTE_MFMA_SETPRIO", "-DFS_PRIO=1"], "block_bwd.hip": ["-fno-honor-nans", "-DTANTE_MFMA_SETPRIO", "-DBT_PRIO"], "block_bwd_fs.hip": ["-fno-honor-nans", "-DTANTE_MFMA_SETPRIO", "-DBT_PRIO"], "head_fused.hip": ["-fno-honor-nans"], "head_enc.hip": ["-fno-honor-nans"], "enc_fused.hip": ["-fno-honor-nans"], "operators.hip": ["-fno-honor-nans"], "spectral_dft.hip": ["-fno-honor-nans"], "cvit_fused.hip": ["-fno-honor-nans", "-DTANTE_MFMA_SETPRIO"], "axis_mfma.hip": ["-fno-honor-nans"], "tail_chain.hip": ["-fno-honor-nans"]}
 
 
 def _stale(target, deps):

@@ -1,0 +1,692 @@
+// Training form of the token-local tail of a rollout call (bf16, C = 256, patch_scale 8: three 2 x 2 stages, no overlap):
+//
+//   forward  (tante_tail_fwd):  derivative head of every Taylor order (enc_dec_cnn.py:263-277) -> Taylor sum (tante.py:165-171) ->
+//                               predicted frame -> its re-encoding for the next call's window (enc_dec_cnn.py:217-229), with every
+//                               pre-activation / activation the backward pass reads stored on the way;
+//   backward (tante_tail_bwd):  encoder stages backwards -> + the frame's other gradients -> Taylor backwards -> every order's decoder
+//                               stages backwards -> gradient of the residual stream's last time slot, with the row operands of all six
+//                               weight gradients written as dense bf16 matrices (the shared weight-gradient launches read them).
+//
+// The inference path has had the forward as one launch since round 4 (head_enc.hip).  The training path ran it as 13 launches per call
+// and its backward as ~33 (GEMM, activation, im2col, column sum, small weight gradient + reduce, Taylor, slice copies: 5 - 25 us each,
+// ~4.5 us of which is the launch floor) -- 0.3 ms per call, 1.2 ms of the 8.5 ms train step at cfg3, for 7 GFLOP and 150 MB.
+//
+// Everything is local to a token: the 8 x 8 x D pixel block a token's heads write is the block the three encoder stages reduce back to
+// that token.  A workgroup owns 16 consecutive tokens (one MFMA column tile) and walks the levels
+//     level 0: 16 tokens x 256 ch | level 1: 64 pixels x 128 ch | level 2: 256 pixels x 64 ch | level 3: 1024 pixels x D fields
+// with the data of a level as a bf16 image in LDS, columns in HIERARCHICAL pixel order (col = 4 * parent + (kh, kw)): a kernel = stride
+// = 2 (transposed) convolution is then a plain GEMM between neighbouring levels and its "im2col" is a reinterpretation of the image --
+// level l + 1 as [cols][C] IS level l as [cols / 4][4 C] with k = (kh, kw, c).  Two kinds of step:
+//     expanding   (l -> l + 1: decoder forward, encoder backward):  D[(sub, c')][col] = W[(sub, c')][c] . img[col][c]  -> img'[4 col + sub][c']
+//     contracting (l + 1 -> l: encoder forward, decoder backward):  D[c][col] = W[c][(sub, c')] . img'[col][(sub, c')] -> img[col][c]
+// Waves own output-feature slices (weights come L2 -> registers as packed fragments, tante_tail_pack_*) or, at the pixel level where the
+// matrix has one to three row tiles, column slices.  All saved / row-operand tensors are TOKEN-MAJOR (a workgroup's tile of every one of
+// them is one contiguous chunk: coalesced 16-byte copies between LDS and memory), so the patch matrices of the weight gradients
+// (dW = dY^T patches) need no gather either; frames (nchw fp32) go through an fp32 tile in LDS, 512-byte runs per (field, row).
+#include "fused_common.hip.h"
+#include "fs_common.hip.h"
+
+namespace {
+
+constexpr int TC_A = 0, TC_B = 32768, TC_C = 65536, TC_LDS = 65536 + 49152;      // LDS regions: 32 + 32 + 48 KiB
+
+// decoder forward stream | decoder backward | encoder forward | encoder backward (bytes; fragments of 1 KiB, (row tile, k-step) order)
+constexpr int DF_X01 = 0, DF_X12 = 262144, DF_X23 = 327680, DF_BIAS = 335872, DF_BYTES = 336896;      // biases: b1[128] | b2[64] | b3[16]
+constexpr int DB_C32 = 0, DB_C21 = 8192, DB_C10 = 73728, DB_BYTES = 335872;
+constexpr int EF_C32 = 0, EF_C21 = 8192, EF_C10 = 73728, EF_BIAS = 335872, EF_BYTES = 337920;         // biases: b1[64] | b2[128] | b3[256]
+constexpr int EB_X01 = 0, EB_X12 = 262144, EB_X23 = 327680, EB_BYTES = 335872;
+
+template <int CPR>
+__device__ __forceinline__ int tc_off(int r, int c) {      // byte offset of 16-byte chunk c of row r in an image of CPR chunks per row
+  if constexpr (CPR >= 16) return r * (CPR * 16) + ((c ^ (r & 15)) << 4);
+  else return r * (CPR * 16) + ((c ^ ((r >> 1) & 7)) << 4);      // CPR == 8: two rows per 256-byte bank row
+}
+template <int CPR>
+__device__ __forceinline__ void tc_put4(char* img, int R, int ch0, const u32x2& v) {      // 4 bf16 at channels ch0 .. ch0 + 3 (ch0 % 4 == 0)
+  *(u32x2*)(img + tc_off<CPR>(R, ch0 >> 3) + (ch0 & 4) * 2) = v;
+}
+template <int CPR>
+__device__ __forceinline__ f32x4 tc_get4(const char* img, int R, int ch0) {
+  const u32x2 v = *(const u32x2*)(img + tc_off<CPR>(R, ch0 >> 3) + (ch0 & 4) * 2);
+  return f32x4{bf16_lo(v[0]), bf16_hi(v[0]), bf16_lo(v[1]), bf16_hi(v[1])};
+}
+__device__ __forceinline__ u32x2 tc_pack4(const f32x4& v) { return u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])}; }
+__device__ __forceinline__ f32x4 tc_unpack4(const u32x2& v) { return f32x4{bf16_lo(v[0]), bf16_hi(v[0]), bf16_lo(v[1]), bf16_hi(v[1])}; }
+
+// image <-> its token-major tile in memory (rows of CPR x 16 bytes, linear), 16 bytes per thread and pass
+template <int CPR>
+__device__ __forceinline__ void tc_img_out(const char* img, void* dst, int rows, int tid) {
+  for (int i = tid; i < rows * CPR; i += 256) {
+    const int r = i / CPR, c = i % CPR;
+    *(u32x4*)((char*)dst + (long)i * 16) = *(const u32x4*)(img + tc_off<CPR>(r, c));
+  }
+}
+template <int CPR>
+__device__ __forceinline__ void tc_img_in(char* img, const void* src, int rows, int tid) {
+  for (int i = tid; i < rows * CPR; i += 256) {
+    const int r = i / CPR, c = i % CPR;
+    *(u32x4*)(img + tc_off<CPR>(r, c)) = *(const u32x4*)((const char*)src + (long)i * 16);
+  }
+}
+
+// acc[j][c] += W[row tile rt0 + j][all k] . img[col tile ct0 + c]; wfr = this lane's 16 bytes of fragment (rt0, k-step 0) of the matrix
+// VIEW4: the image was written one level finer ([4 rows][CPR / 4 chunks] per row of this view); same bytes, the finer image's swizzle
+template <int KS, int CPR, int RTW, int CTW, bool VIEW4 = false>
+__device__ __forceinline__ void tc_gemm(const char* __restrict__ wfr, const char* img, int ct0, int lane, f32x4 (&acc)[RTW][CTW]) {
+  const int l15 = lane & 15, kk = lane >> 4;
+  u32x4 a_cur[RTW], a_nxt[RTW];
+#pragma unroll
+  for (int j = 0; j < RTW; ++j) a_cur[j] = *(const u32x4*)(wfr + (long)(j * KS) * 1024);
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    if (ks + 1 < KS) {
+#pragma unroll
+      for (int j = 0; j < RTW; ++j) a_nxt[j] = *(const u32x4*)(wfr + (long)(j * KS + ks + 1) * 1024);
+    }
+    u32x4 b[CTW];
+#pragma unroll
+    for (int c = 0; c < CTW; ++c) {
+      const int r = 16 * (ct0 + c) + l15, ch = 4 * ks + kk;
+      if constexpr (VIEW4) b[c] = *(const u32x4*)(img + tc_off<CPR / 4>(4 * r + ch / (CPR / 4), ch % (CPR / 4)));
+      else b[c] = *(const u32x4*)(img + tc_off<CPR>(r, ch));
+    }
+#pragma unroll
+    for (int j = 0; j < RTW; ++j)
+#pragma unroll
+      for (int c = 0; c < CTW; ++c) acc[j][c] = mfma_bf16(a_cur[j], b[c], acc[j][c]);
+    if (ks + 1 < KS) {
+#pragma unroll
+      for (int j = 0; j < RTW; ++j) a_cur[j] = a_nxt[j];
+    }
+  }
+}
+template <int RTW, int CTW>
+__device__ __forceinline__ void tc_zero(f32x4 (&acc)[RTW][CTW]) {
+#pragma unroll
+  for (int j = 0; j < RTW; ++j)
+#pragma unroll
+    for (int c = 0; c < CTW; ++c) acc[j][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+__device__ __forceinline__ f32x4 tc_gelu_grad4(const f32x4& p) {
+  return f32x4{gelu_erf_grad_fast(p[0]), gelu_erf_grad_fast(p[1]), gelu_erf_grad_fast(p[2]), gelu_erf_grad_fast(p[3])};
+}
+
+// a frame tile (D fields x 8 rows x 128 pixels of 16 tokens in one patch row) between memory and the fp32 tile [(d, y)][128]
+__device__ __forceinline__ void tc_ftile_in(float* ft, const float* g, int D, int H, int W, int y0, int x0, int tid) {
+  for (int i = tid; i < D * 8 * 32; i += 256) {
+    const int row = i >> 5, c = i & 31, d = row >> 3, y = row & 7;
+    *(f32x4*)(ft + row * 128 + 4 * c) = *(const f32x4*)(g + ((long)d * H + y0 + y) * W + x0 + 4 * c);
+  }
+}
+__device__ __forceinline__ void tc_ftile_out(const float* ft, float* g, int D, int H, int W, int y0, int x0, int tid) {
+  for (int i = tid; i < D * 8 * 32; i += 256) {
+    const int row = i >> 5, c = i & 31, d = row >> 3, y = row & 7;
+    *(f32x4*)(g + ((long)d * H + y0 + y) * W + x0 + 4 * c) = *(const f32x4*)(ft + row * 128 + 4 * c);
+  }
+}
+// position of level-3 element (sub3 = (kh3, kw3), field d) of pixel px16 = (kh1, kw1, kh2, kw2) of tile token tok in the fp32 tile
+__device__ __forceinline__ int tc_fpos(int tok, int px16, int sub3, int d) {
+  const int y = ((px16 >> 3) & 1) * 4 + ((px16 >> 1) & 1) * 2 + (sub3 >> 1);
+  const int x = ((px16 >> 2) & 1) * 4 + (px16 & 1) * 2 + (sub3 & 1);
+  return (d * 8 + y) * 128 + tok * 8 + x;
+}
+
+// ================================================================ forward ==============================================================
+template <int RT3>
+__global__ __launch_bounds__(256, 1) void tail_fwd_kernel(const TanteTailFwd A) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const rA = smem + TC_A;
+  char* const rB = smem + TC_B;
+  char* const rC = smem + TC_C;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, kk = lane >> 4;
+  const int tile = blockIdx.x;
+  const int D = A.D, H = 8 * A.Hp, W = 8 * A.Wp, HW = A.Hp * A.Wp;
+  const long tok0 = 16L * tile;
+  const int img = (int)(tok0 / HW), hw0 = (int)(tok0 - (long)img * HW), hp = hw0 / A.Wp, wp0 = hw0 - hp * A.Wp;
+
+  // level-3 element of accumulator row 16 j + 4 kk + r: (sub3, d) and whether it is a real one
+  int e_sub[RT3][4], e_d[RT3][4];
+#pragma unroll
+  for (int j = 0; j < RT3; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int idx = 16 * j + 4 * kk + r;
+      e_sub[j][r] = idx < 4 * D ? idx / D : -1;
+      e_d[j][r] = idx - (idx / D) * D;
+    }
+  f32x4 facc[RT3][4];      // the Taylor sum's derivative part: rows (sub3, d), columns (token 4 w + c, pixel l15)
+  tc_zero(facc);
+
+  for (int k = 0; k < A.n_ord; ++k) {
+    const TanteTailOrdF& O = A.o[k];
+    const char* const wf = (const char*)O.w;
+    char* const L0 = rC;                 // [16][256]   8 KiB
+    char* const L1 = rC + 8192;          // [64][128]  16 KiB (activation)
+    char* const P1 = rC + 24576;         // [64][128]  16 KiB (pre-activation)
+    // ---- the tokens' rows (fp32, the last time slot of the residual stream) -> bf16 image ----
+    for (int i = tid; i < 16 * 64; i += 256) {
+      const int r = i >> 6, c4 = i & 63;
+      const long t = tok0 + r;
+      const float* row = (const float*)O.x + (t / A.a_n0) * A.a_s1 + (t % A.a_n0) * A.a_s0 + A.a_off;
+      const f32x4 v = *(const f32x4*)(row + 4 * c4);
+      *(u32x2*)(L0 + tc_off<32>(r, c4 >> 1) + (c4 & 1) * 8) = tc_pack4(v);
+    }
+    __syncthreads();
+    if (O.xl16) tc_img_out<32>(L0, (char*)O.xl16 + tok0 * 512, 16, tid);
+    // ---- stage 1: 256 -> (sub, 128) ----
+    {
+      f32x4 acc[8][1];
+      tc_zero(acc);
+      tc_gemm<8, 32, 8, 1>(wf + DF_X01 + (long)(8 * wave) * 8 * 1024 + lane * 16, L0, 0, lane, acc);
+      const float* b1 = (const float*)(wf + DF_BIAS);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int rt = 8 * wave + j, sub = rt >> 3, ch0 = (rt & 7) * 16 + 4 * kk, R = 4 * l15 + sub;
+        const f32x4 v = acc[j][0] + *(const f32x4*)(b1 + ch0);
+        const u32x2 pb = tc_pack4(v);
+        tc_put4<16>(P1, R, ch0, pb);
+        tc_put4<16>(L1, R, ch0, tc_pack4(gelu_poly4<false>(tc_unpack4(pb))));
+      }
+    }
+    __syncthreads();
+    tc_img_out<16>(P1, (char*)O.pre1 + tok0 * 1024, 64, tid);
+    tc_img_out<16>(L1, (char*)O.act1 + tok0 * 1024, 64, tid);
+    // ---- stage 2: 128 -> (sub, 64);  activation -> region A, pre-activation -> region B ----
+    {
+      f32x4 acc[4][4];
+      tc_zero(acc);
+      tc_gemm<4, 16, 4, 4>(wf + DF_X12 + (long)(4 * wave) * 4 * 1024 + lane * 16, L1, 0, lane, acc);
+      const float* b2 = (const float*)(wf + DF_BIAS) + 128;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int rt = 4 * wave + j, sub = rt >> 2, ch0 = (rt & 3) * 16 + 4 * kk;
+        const f32x4 bb = *(const f32x4*)(b2 + ch0);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int R = 4 * (16 * c + l15) + sub;
+          const u32x2 pb = tc_pack4(acc[j][c] + bb);
+          tc_put4<8>(rB, R, ch0, pb);
+          tc_put4<8>(rA, R, ch0, tc_pack4(gelu_poly4<false>(tc_unpack4(pb))));
+        }
+      }
+    }
+    __syncthreads();
+    tc_img_out<8>(rB, (char*)O.pre2 + tok0 * 2048, 256, tid);
+    tc_img_out<8>(rA, (char*)O.act2 + tok0 * 2048, 256, tid);
+    // ---- stage 3: 64 -> (sub3, d): this order's derivative, times its Taylor coefficient ----
+    {
+      f32x4 acc[RT3][4];
+      tc_zero(acc);
+      tc_gemm<2, 8, RT3, 4>(wf + DF_X23 + lane * 16, rA, 4 * wave, lane, acc);
+      const float* b3 = (const float*)(wf + DF_BIAS) + 192;
+#pragma unroll
+      for (int j = 0; j < RT3; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float bb = e_sub[j][r] >= 0 ? b3[e_d[j][r]] : 0.0f;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) facc[j][c][r] += O.coef * (acc[j][c][r] + bb);
+        }
+    }
+    __syncthreads();      // the next order's rows overwrite region C, its stage 2 regions A and B
+  }
+
+  // ---- Taylor sum: + the window's last frame; the predicted frame goes out (fp32) and into the level-3 patch image (bf16) ----
+  float* const ft = (float*)rC;
+  char* const L3 = rB;      // [256 (token, px16)][64]: (sub3, d) at 2-byte position sub3 * D + d, zero beyond 4 D
+  const int y0 = 8 * hp, x0 = 8 * wp0;
+  tc_ftile_in(ft, A.base + (long)img * A.base_bstride, D, H, W, y0, x0, tid);
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int tok = 4 * wave + c;
+#pragma unroll
+    for (int j = 0; j < RT3; ++j) {
+      f32x4 f = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (e_sub[j][r] >= 0) {
+          const int p = tc_fpos(tok, l15, e_sub[j][r], e_d[j][r]);
+          f[r] = facc[j][c][r] + ft[p];
+          ft[p] = f[r];
+        }
+      tc_put4<8>(L3, 16 * tok + l15, 16 * j + 4 * kk, tc_pack4(f));
+    }
+#pragma unroll
+    for (int j = RT3; j < 4; ++j) tc_put4<8>(L3, 16 * tok + l15, 16 * j + 4 * kk, u32x2{0u, 0u});
+  }
+  __syncthreads();
+  tc_ftile_out(ft, A.out + (long)img * A.out_bstride, D, H, W, y0, x0, tid);
+  if (!A.we) return;
+  tc_img_out<8>(L3, (char*)A.f16 + tok0 * 2048, 256, tid);
+  __syncthreads();      // the frame tile has left region C
+
+  // =========================================================== re-encoding ===========================================================
+  const char* const we = (const char*)A.we;
+  {   // ---- stage 1: (sub3, d) -> 64 at the 256 level-2 pixels; activation -> region A, pre-activation -> region C ----
+    f32x4 acc[4][4];
+    tc_zero(acc);
+    tc_gemm<2, 8, 4, 4>(we + EF_C32 + lane * 16, L3, 4 * wave, lane, acc);
+    const float* b1 = (const float*)(we + EF_BIAS);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int ch0 = 16 * j + 4 * kk;
+      const f32x4 bb = *(const f32x4*)(b1 + ch0);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int R = 16 * (4 * wave + c) + l15;
+        const u32x2 pb = tc_pack4(acc[j][c] + bb);
+        tc_put4<8>(rC, R, ch0, pb);
+        tc_put4<8>(rA, R, ch0, tc_pack4(gelu_poly4<false>(tc_unpack4(pb))));
+      }
+    }
+  }
+  __syncthreads();
+  tc_img_out<8>(rC, (char*)A.pre1e + tok0 * 2048, 256, tid);
+  tc_img_out<8>(rA, (char*)A.act1e + tok0 * 2048, 256, tid);
+  {   // ---- stage 2: region A as [64][(sub, 64)] -> 128; activation -> B[0 : 16K], pre-activation -> B[16K : 32K] ----
+    f32x4 acc[2][4];
+    tc_zero(acc);
+    tc_gemm<8, 32, 2, 4, true>(we + EF_C21 + (long)(2 * wave) * 8 * 1024 + lane * 16, rA, 0, lane, acc);
+    const float* b2 = (const float*)(we + EF_BIAS) + 64;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int ch0 = 16 * (2 * wave + j) + 4 * kk;
+      const f32x4 bb = *(const f32x4*)(b2 + ch0);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int R = 16 * c + l15;
+        const u32x2 pb = tc_pack4(acc[j][c] + bb);
+        tc_put4<16>(rB + 16384, R, ch0, pb);
+        tc_put4<16>(rB, R, ch0, tc_pack4(gelu_poly4<false>(tc_unpack4(pb))));
+      }
+    }
+  }
+  __syncthreads();
+  tc_img_out<16>(rB + 16384, (char*)A.pre2e + tok0 * 1024, 64, tid);
+  tc_img_out<16>(rB, (char*)A.act2e + tok0 * 1024, 64, tid);
+  {   // ---- stage 3: B[0 : 16K] as [16][(sub, 128)] -> 256: the frame's encoding before FiLM (fp32 rows, through region C) ----
+    f32x4 acc[4][1];
+    tc_zero(acc);
+    tc_gemm<16, 64, 4, 1, true>(we + EF_C10 + (long)(4 * wave) * 16 * 1024 + lane * 16, rB, 0, lane, acc);
+    const float* b3 = (const float*)(we + EF_BIAS) + 192;
+    __syncthreads();      // (region C: the pre-activation copy above has finished)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int ch0 = 16 * (4 * wave + j) + 4 * kk;
+      *(f32x4*)(rC + (l15 * 256 + ch0) * 4) = acc[j][0] + *(const f32x4*)(b3 + ch0);
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < 16 * 64; i += 256) *(f32x4*)(A.z + tok0 * 256 + 4 * i) = *(const f32x4*)(rC + 16 * i);
+}
+
+// ================================================================ backward =============================================================
+// column sums of the wave's accumulators (rows = channels 16 (rt0 + j) + 4 kk + r, over the wave's columns) added to db
+template <int RTW, int CTW>
+__device__ __forceinline__ void tc_bias_grad(const f32x4 (&g)[RTW][CTW], float* db, int rt0, int lane) {
+  const int l15 = lane & 15, kk = lane >> 4;
+#pragma unroll
+  for (int j = 0; j < RTW; ++j) {
+    f32x4 s = g[j][0];
+#pragma unroll
+    for (int c = 1; c < CTW; ++c) s += g[j][c];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float t = row16_sum(s[r]);
+      if (l15 == 0) atomicAdd(db + 16 * (rt0 + j) + 4 * kk + r, t);
+    }
+  }
+}
+
+template <int RT3>
+__global__ __launch_bounds__(256, 1) void tail_bwd_kernel(const TanteTailBwd A) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const rA = smem + TC_A;
+  char* const rB = smem + TC_B;
+  char* const rC = smem + TC_C;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, kk = lane >> 4;
+  const int tile = blockIdx.x;
+  const int D = A.D, H = 8 * A.Hp, W = 8 * A.Wp, HW = A.Hp * A.Wp;
+  const long tok0 = 16L * tile;
+  const int img = (int)(tok0 / HW), hw0 = (int)(tok0 - (long)img * HW), hp = hw0 / A.Wp, wp0 = hw0 - hp * A.Wp;
+  const int y0 = 8 * hp, x0 = 8 * wp0;
+  int e_sub[RT3][4], e_d[RT3][4];
+#pragma unroll
+  for (int j = 0; j < RT3; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int idx = 16 * j + 4 * kk + r;
+      e_sub[j][r] = idx < 4 * D ? idx / D : -1;
+      e_d[j][r] = idx - (idx / D) * D;
+    }
+  f32x4 dfr[RT3][4];      // gradient of the predicted frame: rows (sub3, d), columns (token 4 w + c, pixel l15)
+  tc_zero(dfr);
+  float* const ft = (float*)rC;
+
+  if (A.dz) {
+    // =================================================== encoder stages, backwards ===================================================
+    const char* const we = (const char*)A.we;
+    char* const L0 = rC;      // dz as bf16 [16][256]
+    for (int i = tid; i < 16 * 64; i += 256) {
+      const int r = i >> 6, c4 = i & 63;
+      const f32x4 v = *(const f32x4*)(A.dz + (tok0 + r) * 256 + 4 * c4);
+      *(u32x2*)(L0 + tc_off<32>(r, c4 >> 1) + (c4 & 1) * 8) = tc_pack4(v);
+    }
+    tc_img_in<16>(rB + 16384, (const char*)A.pre2e + tok0 * 1024, 64, tid);
+    __syncthreads();
+    tc_img_out<32>(L0, (char*)A.dz16 + tok0 * 512, 16, tid);
+    {   // stage 3 backwards: 256 -> (sub, 128), times GELU'(pre2e) -> B[0 : 16K]
+      f32x4 acc[8][1];
+      tc_zero(acc);
+      tc_gemm<8, 32, 8, 1>(we + EB_X01 + (long)(8 * wave) * 8 * 1024 + lane * 16, L0, 0, lane, acc);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int rt = 8 * wave + j, sub = rt >> 3, ch0 = (rt & 7) * 16 + 4 * kk, R = 4 * l15 + sub;
+        tc_put4<16>(rB, R, ch0, tc_pack4(acc[j][0] * tc_gelu_grad4(tc_get4<16>(rB + 16384, R, ch0))));
+      }
+    }
+    __syncthreads();
+    tc_img_out<16>(rB, (char*)A.dpre2e + tok0 * 1024, 64, tid);
+    tc_img_in<8>(rC, (const char*)A.pre1e + tok0 * 2048, 256, tid);
+    __syncthreads();
+    {   // stage 2 backwards: 128 -> (sub, 64), times GELU'(pre1e) -> region A
+      f32x4 acc[4][4];
+      tc_zero(acc);
+      tc_gemm<4, 16, 4, 4>(we + EB_X12 + (long)(4 * wave) * 4 * 1024 + lane * 16, rB, 0, lane, acc);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int rt = 4 * wave + j, sub = rt >> 2, ch0 = (rt & 3) * 16 + 4 * kk;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int R = 4 * (16 * c + l15) + sub;
+          tc_put4<8>(rA, R, ch0, tc_pack4(acc[j][c] * tc_gelu_grad4(tc_get4<8>(rC, R, ch0))));
+        }
+      }
+    }
+    __syncthreads();
+    tc_img_out<8>(rA, (char*)A.dpre1e + tok0 * 2048, 256, tid);
+    // stage 1 backwards: 64 -> (sub3, d): the encoder's share of the frame's gradient
+    tc_gemm<2, 8, RT3, 4>(we + EB_X23 + lane * 16, rA, 4 * wave, lane, dfr);
+    __syncthreads();      // region C (pre1e) is free for the frame tile
+  }
+
+  // ---- + the frame's other gradients (loss, the next call's Taylor base); the total is the gradient of this call's base frame too ----
+  if (A.dext) tc_ftile_in(ft, A.dext + (long)img * A.dext_bstride, D, H, W, y0, x0, tid);
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int tok = 4 * wave + c;
+#pragma unroll
+    for (int j = 0; j < RT3; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (e_sub[j][r] >= 0) {
+          const int p = tc_fpos(tok, l15, e_sub[j][r], e_d[j][r]);
+          if (A.dext) dfr[j][c][r] += ft[p];
+          ft[p] = dfr[j][c][r];
+        } else {
+          dfr[j][c][r] = 0.0f;
+        }
+  }
+  __syncthreads();
+  if (A.dbase) tc_ftile_out(ft, A.dbase + (long)img * A.dbase_bstride, D, H, W, y0, x0, tid);
+  // per-field sums of the tile (the last decoder stage's bias gradient, up to the Taylor coefficient)
+  float fsum = 0.0f;
+  {
+    const int d = tid >> 4, part = tid & 15;      // 16 threads per field (D <= 16)
+    if (d < D) {
+      for (int i = part; i < 256; i += 16) {
+        const f32x4 v = *(const f32x4*)(ft + d * 1024 + 4 * i);
+        fsum += (v[0] + v[1]) + (v[2] + v[3]);
+      }
+    }
+    fsum = row16_sum(fsum);
+  }
+  __syncthreads();      // the frame tile has left region C
+
+  // ===================================================== decoder stages, backwards ===================================================
+  for (int k = 0; k < A.n_ord; ++k) {
+    const TanteTailOrdB& O = A.o[k];
+    const char* const wb = (const char*)O.w;
+    if (O.db3 && (tid & 15) == 0 && (tid >> 4) < D) atomicAdd(O.db3 + (tid >> 4), O.coef * fsum);
+    char* const L3 = rB;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int tok = 4 * wave + c;
+#pragma unroll
+      for (int j = 0; j < RT3; ++j) tc_put4<8>(L3, 16 * tok + l15, 16 * j + 4 * kk, tc_pack4(dfr[j][c] * O.coef));
+#pragma unroll
+      for (int j = RT3; j < 4; ++j) tc_put4<8>(L3, 16 * tok + l15, 16 * j + 4 * kk, u32x2{0u, 0u});
+    }
+    tc_img_in<8>(rC, (const char*)O.pre2 + tok0 * 2048, 256, tid);
+    __syncthreads();
+    tc_img_out<8>(L3, (char*)O.dder + tok0 * 2048, 256, tid);
+    {   // stage 3 backwards: (sub3, d) -> 64, times GELU'(pre2) -> region A
+      f32x4 acc[4][4];
+      tc_zero(acc);
+      tc_gemm<2, 8, 4, 4>(wb + DB_C32 + lane * 16, L3, 4 * wave, lane, acc);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int ch0 = 16 * j + 4 * kk;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int R = 16 * (4 * wave + c) + l15;
+          acc[j][c] = acc[j][c] * tc_gelu_grad4(tc_get4<8>(rC, R, ch0));
+          tc_put4<8>(rA, R, ch0, tc_pack4(acc[j][c]));
+        }
+      }
+      if (O.db2) tc_bias_grad<4, 4>(acc, O.db2, 0, lane);
+    }
+    __syncthreads();
+    tc_img_out<8>(rA, (char*)O.dpre2 + tok0 * 2048, 256, tid);
+    tc_img_in<16>(rB + 16384, (const char*)O.pre1 + tok0 * 1024, 64, tid);
+    __syncthreads();
+    {   // stage 2 backwards: region A as [64][(sub, 64)] -> 128, times GELU'(pre1) -> B[0 : 16K]
+      f32x4 acc[2][4];
+      tc_zero(acc);
+      tc_gemm<8, 32, 2, 4, true>(wb + DB_C21 + (long)(2 * wave) * 8 * 1024 + lane * 16, rA, 0, lane, acc);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int ch0 = 16 * (2 * wave + j) + 4 * kk;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int R = 16 * c + l15;
+          acc[j][c] = acc[j][c] * tc_gelu_grad4(tc_get4<16>(rB + 16384, R, ch0));
+          tc_put4<16>(rB, R, ch0, tc_pack4(acc[j][c]));
+        }
+      }
+      if (O.db1) tc_bias_grad<2, 4>(acc, O.db1, 2 * wave, lane);
+    }
+    __syncthreads();
+    tc_img_out<16>(rB, (char*)O.dpre1 + tok0 * 1024, 64, tid);
+    {   // stage 1 backwards: B[0 : 16K] as [16][(sub, 128)] -> 256: the gradient of the residual stream's rows (fp32, through region C)
+      f32x4 acc[4][1];
+      tc_zero(acc);
+      tc_gemm<16, 64, 4, 1, true>(wb + DB_C10 + (long)(4 * wave) * 16 * 1024 + lane * 16, rB, 0, lane, acc);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) *(f32x4*)(rC + (l15 * 256 + 16 * (4 * wave + j) + 4 * kk) * 4) = acc[j][0];
+    }
+    __syncthreads();
+    for (int i = tid; i < 16 * 64; i += 256) {
+      const int r = i >> 6, c4 = i & 63;
+      const long t = tok0 + r;
+      float* row = O.dx + (t / A.a_n0) * A.a_s1 + (t % A.a_n0) * A.a_s0 + A.a_off;
+      *(f32x4*)(row + 4 * c4) = *(const f32x4*)(rC + (r * 256 + 4 * c4) * 4);
+    }
+    __syncthreads();
+  }
+}
+
+// ================================================================= packing =============================================================
+// One conv / transposed-conv weight src[a][b][kh][kw] (na x nb x 2 x 2) as MFMA A-operand fragments of the matrix
+//   orient 0:  Wm[a][(sub, b)]      (rows a, k = sub * nb + b)        orient 1:  Wm[(sub, b)][a]      (rows sub * nb + b, k = a)
+// fragment (rt, ks) at dst + (rt * n_ks + ks) KiB: lane (l15, kk) holds Wm[16 rt + l15][32 ks + 8 kk .. + 7]; zero outside the matrix.
+struct TcPackJob {
+  const float* src;
+  char* dst;
+  int na, nb, orient, n_rt, n_ks, frag0;
+};
+struct TcPack {
+  TcPackJob j[6];
+  const float* bias[3];
+  float* bias_dst[3];
+  int bias_n[3];
+  int n_frag;
+};
+__global__ void tail_pack_kernel(const TcPack P) {
+  const int f = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63, l15 = lane & 15, kk = lane >> 4;
+  if (f >= P.n_frag) {
+    if (blockIdx.x == gridDim.x - 1 && (threadIdx.x >> 6) == 3) {      // (the last wave of the grid never holds a fragment) the biases
+      for (int q = 0; q < 3; ++q)
+        for (int i = lane; i < P.bias_n[q]; i += 64) P.bias_dst[q][i] = P.bias[q] ? P.bias[q][i] : 0.0f;
+    }
+    return;
+  }
+  int q = 0;
+#pragma unroll
+  for (int t = 1; t < 6; ++t)
+    if (f >= P.j[t].frag0) q = t;
+  const TcPackJob& J = P.j[q];
+  const int fl = f - J.frag0, rt = fl / J.n_ks, ks = fl % J.n_ks;
+  const int row = 16 * rt + l15;
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int k = 32 * ks + 8 * kk + e;
+    int a, sb;
+    if (J.orient == 0) { a = row; sb = k; } else { a = k; sb = row; }
+    const int sub = sb / J.nb, b = sb - sub * J.nb;
+    v[e] = (a < J.na && sb < 4 * J.nb) ? J.src[((long)a * J.nb + b) * 4 + sub] : 0.0f;
+  }
+  u32x4 o;
+  o[0] = pack_bf16x2(v[0], v[1]); o[1] = pack_bf16x2(v[2], v[3]); o[2] = pack_bf16x2(v[4], v[5]); o[3] = pack_bf16x2(v[6], v[7]);
+  *(u32x4*)(J.dst + (long)fl * 1024 + lane * 16) = o;
+}
+
+int tc_pack(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3, const float* b3, int D, int dec,
+            char* dstF, char* dstB, hipStream_t s) {
+  if (!w1 || !w2 || !w3 || !dstF || !dstB || D < 1 || D > 12) return -1;
+  TcPack P;
+  // decoder: W1 (256, 128, 2, 2), W2 (128, 64, 2, 2), W3 (64, D, 2, 2) = src[ci][co][kh][kw]: forward rows (sub, co), k = ci (orient 1);
+  //          backward rows ci, k = (sub, co) (orient 0)
+  // encoder: W1 (64, D, 2, 2), W2 (128, 64, 2, 2), W3 (256, 128, 2, 2) = src[co][ci][kh][kw]: forward rows co, k = (sub, ci) (orient 0);
+  //          backward rows (sub, ci), k = co (orient 1)
+  const int rt3 = (4 * D + 15) / 16;
+  int f0 = 0;
+  auto job = [&](int i, const float* src, char* dst, int na, int nb, int orient, int n_rt, int n_ks) {
+    P.j[i] = TcPackJob{src, dst, na, nb, orient, n_rt, n_ks, f0};
+    f0 += n_rt * n_ks;
+  };
+  if (dec) {
+    job(0, w1, dstF + DF_X01, 256, 128, 1, 32, 8);
+    job(1, w2, dstF + DF_X12, 128, 64, 1, 16, 4);
+    job(2, w3, dstF + DF_X23, 64, D, 1, rt3, 2);
+    job(3, w3, dstB + DB_C32, 64, D, 0, 4, 2);
+    job(4, w2, dstB + DB_C21, 128, 64, 0, 8, 8);
+    job(5, w1, dstB + DB_C10, 256, 128, 0, 16, 16);
+    float* bd = (float*)(dstF + DF_BIAS);
+    P.bias[0] = b1; P.bias_dst[0] = bd; P.bias_n[0] = 128;
+    P.bias[1] = b2; P.bias_dst[1] = bd + 128; P.bias_n[1] = 64;
+    P.bias[2] = b3; P.bias_dst[2] = bd + 192; P.bias_n[2] = D;
+  } else {
+    job(0, w1, dstF + EF_C32, 64, D, 0, 4, 2);
+    job(1, w2, dstF + EF_C21, 128, 64, 0, 8, 8);
+    job(2, w3, dstF + EF_C10, 256, 128, 0, 16, 16);
+    job(3, w3, dstB + EB_X01, 256, 128, 1, 32, 8);
+    job(4, w2, dstB + EB_X12, 128, 64, 1, 16, 4);
+    job(5, w1, dstB + EB_X23, 64, D, 1, rt3, 2);
+    float* bd = (float*)(dstF + EF_BIAS);
+    P.bias[0] = b1; P.bias_dst[0] = bd; P.bias_n[0] = 64;
+    P.bias[1] = b2; P.bias_dst[1] = bd + 64; P.bias_n[1] = 128;
+    P.bias[2] = b3; P.bias_dst[2] = bd + 192; P.bias_n[2] = 256;
+  }
+  P.n_frag = f0;
+  hipLaunchKernelGGL(tail_pack_kernel, dim3((unsigned)(f0 / 4 + 1)), dim3(256), 0, s, P);
+  return 0;
+}
+
+template <class KERN>
+void tc_attr(KERN k) {
+  (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, TC_LDS);
+}
+
+}  // namespace
+
+extern "C" int tante_tail_supported(int C, int D, int Hp, int Wp) { return C == 256 && D >= 1 && D <= 12 && Hp >= 1 && Wp >= 16 && Wp % 16 == 0; }
+
+extern "C" int64_t tante_tail_stream_bytes(int which) {
+  switch (which) {
+    case 0: return DF_BYTES;
+    case 1: return DB_BYTES;
+    case 2: return EF_BYTES;
+    case 3: return EB_BYTES;
+    default: return 0;
+  }
+}
+
+extern "C" int tante_tail_pack_dec(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3, const float* b3, int D,
+                                   void* fwd_stream, void* bwd_stream, void* stream) {
+  if (tc_pack(w1, b1, w2, b2, w3, b3, D, 1, (char*)fwd_stream, (char*)bwd_stream, (hipStream_t)stream)) TANTE_FAIL(-1, "tante_tail_pack_dec: bad argument");
+  TANTE_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int tante_tail_pack_enc(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3, const float* b3, int D,
+                                   void* fwd_stream, void* bwd_stream, void* stream) {
+  if (tc_pack(w1, b1, w2, b2, w3, b3, D, 0, (char*)fwd_stream, (char*)bwd_stream, (hipStream_t)stream)) TANTE_FAIL(-1, "tante_tail_pack_enc: bad argument");
+  TANTE_CHECK_LAUNCH();
+  return 0;
+}
+
+static int tc_check_geom(int n_ord, int n_img, int Hp, int Wp, int D, int a_n0, const char* who) {
+  if (n_ord < 1 || n_ord > TANTE_TAIL_MAX_ORD) TANTE_FAIL(-1, "%s: 1 .. %d Taylor orders (got %d)", who, TANTE_TAIL_MAX_ORD, n_ord);
+  if (!tante_tail_supported(256, D, Hp, Wp)) TANTE_FAIL(-2, "%s: unsupported shape (D = %d, Hp = %d, Wp = %d: D <= 12, Wp %% 16 == 0)", who, D, Hp, Wp);
+  if (n_img < 1 || a_n0 < 16 || a_n0 % 16) TANTE_FAIL(-1, "%s: rows are addressed in blocks of a multiple of 16 tokens (a_n0 = %d)", who, a_n0);
+  return 0;
+}
+
+extern "C" int tante_tail_fwd(const TanteTailFwd* a, void* stream) {
+  if (!a) TANTE_FAIL(-1, "tante_tail_fwd: null");
+  if (int rc = tc_check_geom(a->n_ord, a->n_img, a->Hp, a->Wp, a->D, a->a_n0, "tante_tail_fwd")) return rc;
+  for (int k = 0; k < a->n_ord; ++k) {
+    const TanteTailOrdF& o = a->o[k];
+    if (!o.x || !o.w || !o.pre1 || !o.act1 || !o.pre2 || !o.act2) TANTE_FAIL(-1, "tante_tail_fwd: order %d: null pointer", k);
+  }
+  if (!a->base || !a->out) TANTE_FAIL(-1, "tante_tail_fwd: null frame pointer");
+  if (a->we && (!a->f16 || !a->pre1e || !a->act1e || !a->pre2e || !a->act2e || !a->z)) TANTE_FAIL(-1, "tante_tail_fwd: encoder outputs missing");
+  const long tiles = (long)a->n_img * a->Hp * a->Wp / 16;
+  const int rt3 = (4 * a->D + 15) / 16;
+  static TantePerDevice attr;
+  attr.once([&] { tc_attr(tail_fwd_kernel<1>); tc_attr(tail_fwd_kernel<2>); tc_attr(tail_fwd_kernel<3>); });
+  hipStream_t s = (hipStream_t)stream;
+  switch (rt3) {
+    case 1: hipLaunchKernelGGL(tail_fwd_kernel<1>, dim3((unsigned)tiles), dim3(256), TC_LDS, s, *a); break;
+    case 2: hipLaunchKernelGGL(tail_fwd_kernel<2>, dim3((unsigned)tiles), dim3(256), TC_LDS, s, *a); break;
+    default: hipLaunchKernelGGL(tail_fwd_kernel<3>, dim3((unsigned)tiles), dim3(256), TC_LDS, s, *a); break;
+  }
+  TANTE_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int tante_tail_bwd(const TanteTailBwd* a, void* stream) {
+  if (!a) TANTE_FAIL(-1, "tante_tail_bwd: null");
+  if (int rc = tc_check_geom(a->n_ord, a->n_img, a->Hp, a->Wp, a->D, a->a_n0, "tante_tail_bwd")) return rc;
+  for (int k = 0; k < a->n_ord; ++k) {
+    const TanteTailOrdB& o = a->o[k];
+    if (!o.w || !o.pre1 || !o.pre2 || !o.dpre1 || !o.dpre2 || !o.dder || !o.dx) TANTE_FAIL(-1, "tante_tail_bwd: order %d: null pointer", k);
+  }
+  if (!a->dz && !a->dext) TANTE_FAIL(-1, "tante_tail_bwd: no gradient arrives (dz and dext are both null)");
+  if (a->dz && (!a->we || !a->pre1e || !a->pre2e || !a->dz16 || !a->dpre2e || !a->dpre1e)) TANTE_FAIL(-1, "tante_tail_bwd: encoder operands missing");
+  const long tiles = (long)a->n_img * a->Hp * a->Wp / 16;
+  const int rt3 = (4 * a->D + 15) / 16;
+  static TantePerDevice attr;
+  attr.once([&] { tc_attr(tail_bwd_kernel<1>); tc_attr(tail_bwd_kernel<2>); tc_attr(tail_bwd_kernel<3>); });
+  hipStream_t s = (hipStream_t)stream;
+  switch (rt3) {
+    case 1: hipLaunchKernelGGL(tail_bwd_kernel<1>, dim3((unsigned)tiles), dim3(256), TC_LDS, s, *a); break;
+    case 2: hipLaunchKernelGGL(tail_bwd_kernel<2>, dim3((unsigned)tiles), dim3(256), TC_LDS, s, *a); break;
+    default: hipLaunchKernelGGL(tail_bwd_kernel<3>, dim3((unsigned)tiles), dim3(256), TC_LDS, s, *a); break;
+  }
+  TANTE_CHECK_LAUNCH();
+  return 0;
+}

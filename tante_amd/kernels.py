@@ -734,3 +734,20 @@ def fourier_embed(coords: torch.Tensor, kernel: torch.Tensor) -> torch.Tensor:
     out = torch.empty(N, E, dtype=torch.float32, device=coords.device)
     L.check(L.lib().tante_fourier_embed(_p(coords), _p(kernel), N, E, _p(out), _stream()), "tante_fourier_embed")
     return out
+
+
+# ---- the training form of the rollout tail (csrc/tail_chain.hip): decoder stages -> Taylor sum -> re-encoding, forward and backward --------
+def tail_supported(C_: int, D: int, Hp: int, Wp: int) -> bool:
+    return bool(L.lib().tante_tail_supported(C_, D, Hp, Wp))
+
+
+def pack_tail(params: Sequence[torch.Tensor], D: int, decoder: bool) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(forward stream, backward stream) of one decoder (conv-transpose weights (Cin, Cout, 2, 2)) or of the encoder (conv weights
+    (Cout, Cin, 2, 2)); params = (w1, b1, w2, b2, w3, b3) in stage order."""
+    _dev(*params)
+    dev = params[0].device
+    fwd = torch.empty(L.lib().tante_tail_stream_bytes(0 if decoder else 2), dtype=torch.uint8, device=dev)
+    bwd = torch.empty(L.lib().tante_tail_stream_bytes(1 if decoder else 3), dtype=torch.uint8, device=dev)
+    fn = L.lib().tante_tail_pack_dec if decoder else L.lib().tante_tail_pack_enc
+    L.check(fn(*[_p(q.detach()) for q in params], D, fwd.data_ptr(), bwd.data_ptr(), _stream()), "tante_tail_pack")
+    return fwd, bwd

@@ -179,11 +179,16 @@ def rollout_model(model, batch: Dict, formatter, n_steps: int, device=None):
                 zf = frames_of(encode_frames_train(model, moving, compute))
                 last = moving[:, -1:].contiguous()
                 while produced < n_steps:
-                    y = tante_train_forward(model, last, compute, 1, z_win=zf[-T:])      # the window's frames where they are
+                    # (the one-launch tail, where it applies, also returns the predicted frame's encoding: train_forward.tail_train_cfg)
+                    nz = [produced + model.output_length < n_steps]
+                    y = tante_train_forward(model, last, compute, 1, z_win=zf[-T:], next_z=nz)      # the window's frames where they are
                     produced += y.shape[1]
                     preds.append(formatter.process_output(y))
                     if produced < n_steps:
-                        zf.extend(frames_of(encode_frames_train(model, y, compute)))
+                        if len(nz) > 1:
+                            zf.append(nz[0])
+                        else:
+                            zf.extend(frames_of(encode_frames_train(model, y, compute)))
                         last = y[:, -1:].contiguous()
             return torch.cat(preds, dim=1)[:, :n_steps], y_ref.to(device)
     with fold_scope():      # the re-fed calls of one rollout share one autograd graph (and one folded copy of every LayerNorm affine)

@@ -13,7 +13,7 @@ from . import _lib as L
 from . import options as _O
 from . import kernels as K
 from . import stages as S
-from .autograd import (FilmTableFn, ActFn, AttentionFn, BlockFn, BlockTailFn, block_tail_ready, AxisHWFn, AxisMlpFn, BranchOutFn, DeconvFn, DropoutAddFn, FilmPosFn, FilmPosFramesFn, FoldFn, LayerNormFn, LayerNormSkipFn, LinearFn, PatchEmbedFn, RtReduceFn,
+from .autograd import (TailCfg, TailFn, FilmTableFn, ActFn, AttentionFn, BlockFn, BlockTailFn, block_tail_ready, AxisHWFn, AxisMlpFn, BranchOutFn, DeconvFn, DropoutAddFn, FilmPosFn, FilmPosFramesFn, FoldFn, LayerNormFn, LayerNormSkipFn, LinearFn, PatchEmbedFn, RtReduceFn,
                        TaylorFn)
 
 
@@ -60,6 +60,40 @@ FUSED_AXIS_HW = _O.register("TANTE_TRAIN_FUSED_AXIS", True, __name__, "FUSED_AXI
 FUSED_HEAD_BACKWARD = _O.register("TANTE_TRAIN_FUSED_HEAD_BWD", True, __name__, "FUSED_HEAD_BACKWARD")   # q|k|v dgrad + LayerNorm1 backward in one launch
 # the WHOLE backward of a block in one launch (tante_block_bwd_fused: tail + attention backward + head, q | k | v recomputed); off: three launches
 FUSED_BLOCK_BACKWARD = _O.register("TANTE_TRAIN_FUSED_BLOCK_BWD", True, __name__, "FUSED_BLOCK_BACKWARD")
+
+
+# decoder stages -> Taylor sum -> re-encoding of the predicted frame, forward and backward, as one launch each (csrc/tail_chain.hip)
+FUSED_TAIL = _O.register("TANTE_TRAIN_FUSED_TAIL", True, __name__, "FUSED_TAIL")
+
+
+def tail_train_cfg(model, B: int, compute: int, want_z: bool):
+    """TailCfg for this model and batch when the one-launch training tail applies (shipped shapes: C = 256, three 2 x 2 stages without
+    overlap, D <= 12, Wp % 16 == 0, bf16 compute, fixed dt with one output frame, every conv parameter with a gradient slot), else None.
+    The packed streams live in the fold scope: one set per rollout graph."""
+    if not (FUSED_TAIL and compute == L.BF16 and torch.is_grad_enabled() and _FOLDS is not None and model.deg and model.output_length == 1
+            and 1 <= model.taylor_order <= 3 and type(model.encoder).__name__ == "enc_CNN" and model.C == 256):
+        return None
+    enc, decs = model.encoder, list(model.decoders)
+    D = enc.chans[0]
+    if any(type(d).__name__ != "dec_CNN" or tuple(d.P) != (2, 2, 2) or d.overlap != 0.0 or list(d.chans) != [256, 128, 64, D] for d in decs):
+        return None
+    if tuple(enc.P) != (2, 2, 2) or enc.overlap != 0.0 or list(enc.chans) != [D, 64, 128, 256] or not K.tail_supported(model.C, D, model.H_p, model.W_p):
+        return None
+    key = ("tail", id(model))
+    rec = _FOLDS.get(key)
+    if rec is None:
+        from .autograd import _grad_slot
+        ep = [q for i in range(3) for q in (getattr(enc, f"enc_conv_{i + 1}").conv.weight, getattr(enc, f"enc_conv_{i + 1}").conv.bias)]
+        dps = [[q for i in range(3) for q in (getattr(d, f"dec_conv_{i + 1}").deconv.weight, getattr(d, f"dec_conv_{i + 1}").deconv.bias)]
+               for d in decs]
+        ok = all(q is not None and q.requires_grad and _grad_slot(q) is not None for q in ep + [q for dp in dps for q in dp])
+        rec = _FOLDS[key] = (ep, dps, K.pack_tail(ep, D, False), [K.pack_tail(dp, D, True) for dp in dps]) if ok else False
+    if rec is False:
+        return None
+    ep, dps, es, dss = rec
+    import math
+    coefs = [float(model.frame_interval) ** (k + 1) / math.factorial(k + 1) for k in range(model.taylor_order)]
+    return TailCfg(B, model.T, model.H_p, model.W_p, model.C, D, coefs, dps, dss, ep, es, want_z)
 
 
 BLOCK_CALLS = [0, 0]      # block_train calls / those that took the fused one-node path (GraphedTrainStep checks them at capture)
@@ -353,9 +387,12 @@ def encode_frames_train(model, frames: torch.Tensor, compute: int) -> torch.Tens
     return z.view(B, k, model.H_p * model.W_p, model.C)
 
 
-def tante_train_forward(model, inp: torch.Tensor, compute: int, out_T=1, z_win=None, per_sample_counts: bool = False):
+def tante_train_forward(model, inp: torch.Tensor, compute: int, out_T=1, z_win=None, per_sample_counts: bool = False, next_z=None):
     """z_win (optional): the window's frames already encoded, (B, T, HW, C) fp32 contiguous (encode_frames_train); `inp` then only
-    supplies its last frame (the Taylor sum's base) and may be that frame alone, (B, 1, D, H, W)."""
+    supplies its last frame (the Taylor sum's base) and may be that frame alone, (B, 1, D, H, W).
+    next_z (optional): a list; True / False in next_z[0] on entry = whether the caller wants the predicted frame's encoding for the
+    next call's window.  When the one-launch tail runs (tail_train_cfg), next_z[0] is that encoding (B, HW, C) -- or None for False --
+    on return; when it does not, next_z is left alone and the caller encodes the frame itself."""
     B, _, D, H, W = inp.shape
     T = model.T
     Hp, Wp, C_ = model.H_p, model.W_p, model.C
@@ -401,6 +438,18 @@ def tante_train_forward(model, inp: torch.Tensor, compute: int, out_T=1, z_win=N
     else:
         x = FilmPosFn.apply(z, fa, fb, s_view, T, HW)
     derivs, rts = [], []
+    tail = None
+    if next_z is not None and inp.shape[1] >= 1 and inp.dtype == torch.float32:
+        tail = tail_train_cfg(model, B, compute, bool(next_z[0]))
+    if tail is not None:
+        xs = []
+        for i in range(model.taylor_order):
+            x = backbone_train(model.blocks[i], x, B, compute)
+            xs.append(x)
+        y, zn = TailFn.apply(inp[:, -1:], tail, *xs)
+        next_z[0] = zn
+        next_z.append("tail")
+        return y
     for i in range(model.taylor_order):
         x = backbone_train(model.blocks[i], x, B, compute)
         last = x.view(B, T, HW, C_)[:, -1].reshape(B * HW, C_)

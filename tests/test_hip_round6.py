@@ -1,0 +1,126 @@
+"""GPU parity, round 6.
+
+* csrc/tail_chain.hip -- the training form of a rollout call's token-local tail (dec_CNN stages, enc_dec_cnn.py:263-277 -> Taylor sum,
+  tante.py:165-171 -> enc_CNN stages on the predicted frame, enc_dec_cnn.py:217-229) as one launch forward and one backward: against the
+  per-operator nodes it replaces (same bf16 compute mode; values and every gradient), at the production shape (fixture g14: D = 4) and
+  on a two-order model with D = 11 (three row tiles at the pixel level, two decoders).  Against the REFERENCE's gradients the fused
+  tail is what test_g14_wide_train_step[bf16-...] runs since this round (tests/test_hip_round2.py).
+
+Bars: fp32 compute 1e-5 / gradients 2e-4, bf16 compute 1e-2 / gradients 4e-2, relative to the reference's fp32 CPU result.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err, max_rel, record_parity
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+def _train_grads(dev, monkeypatch, model, batch, md, fused_tail, n_steps=4, n_loss=None):
+    import tante_amd
+    from tante_amd import autograd as A
+    from tante_amd import train_forward as TF
+    monkeypatch.setattr(TF, "FUSED_TAIL", fused_tail)
+    m = model.to(dev).train().set_compute("bf16")
+    opt = tante_amd.FlatAdamW(m.parameters(), lr=1e-4)
+    opt.zero_grad()
+    fmt = tante_amd.DefaultChannelsFirstFormatter(md)
+    b = {k: v.to(dev) for k, v in batch.items()}
+    y_pred, y_ref = tante_amd.rollout_model(m, b, fmt, n_steps)
+    n_loss = n_steps if n_loss is None else n_loss
+    loss = A.MseMeanFn.apply(y_pred[:, :n_loss].contiguous(), y_ref[:, :n_loss].contiguous())
+    A.run_backward(loss)
+    torch.cuda.synchronize()
+    return y_pred.detach().float().cpu(), {k: p.grad.detach().clone().cpu() for k, p in m.named_parameters()}, float(loss)
+
+
+def _compare(ya, ga, yb, gb, what, tol_y=2e-3, tol_g=2e-2):
+    e = rel_err(ya, yb)
+    record_parity(e, max_rel(ya, yb), tol_y, "bf16", what + ": predicted frames, fused tail vs per-operator nodes")
+    assert e < tol_y, e
+    worst, wk = 0.0, None
+    for k in gb:
+        if float(gb[k].abs().max()) == 0.0:
+            assert float(ga[k].abs().max()) == 0.0, k
+            continue
+        e = rel_err(ga[k], gb[k])
+        if e > worst:
+            worst, wk = e, k
+        assert e < tol_g, (k, e)
+    record_parity(worst, worst, tol_g, "bf16", what + ": every parameter gradient, worst " + str(wk))
+    return worst
+
+
+def test_training_tail_in_one_launch_production_shape(dev, monkeypatch):
+    """g14's model (C = 256, THWTHWTHW, 64 x 384 x 4 fields, B = 2, 4-step BPTT): the fused tail (three of its four calls re-encode the
+    predicted frame, the last does not) against the per-operator path in the same compute mode.  Both are bf16 paths that round at
+    slightly different places (the fused forward's GELU is the polynomial of the inference kernels): 2e-3 on the frames, 2e-2 on every
+    gradient tensor (relative L2) -- the bar against the reference is test_g14_wide_train_step's 4e-2."""
+    import tante_amd
+    from conftest import g14_setup, G14_FIELDS, G14_RES
+    md = tante_amd.TanteMetadata(n_fields=G14_FIELDS, spatial_resolution=G14_RES)
+    m, batch, _, _ = g14_setup()
+    yf, gf, lf = _train_grads(dev, monkeypatch, m, batch, md, True)
+    m2, batch2, _, _ = g14_setup()
+    yu, gu, lu = _train_grads(dev, monkeypatch, m2, batch2, md, False)
+    assert abs(lf - lu) < 2e-3 * abs(lu)
+    _compare(yf, gf, yu, gu, "g14")
+    enc = [k for k in gf if k.startswith("encoder.")]
+    dec = [k for k in gf if k.startswith("decoders.")]
+    assert enc and dec and all(float(gf[k].abs().max()) > 0.0 for k in enc + dec)
+
+
+@pytest.mark.parametrize("n_loss", [3, 1])
+def test_training_tail_two_orders_eleven_fields(dev, monkeypatch, n_loss):
+    """Two Taylor orders (two decoders, two residual streams), D = 11 (4 D = 44: three row tiles, zero-padded k), Hp x Wp = 4 x 16, a loss
+    on the first `n_loss` of three frames (n_loss = 1: the later calls' nodes never run; the first call's frame still receives the
+    gradient of its encoding's consumers only where they are part of the graph)."""
+    import tante_amd
+    md = tante_amd.TanteMetadata(n_fields=11, spatial_resolution=(32, 128))
+    kw = dict(in_T=4, taylor_order=2, attn_axes="TH-W", n_head=8, embed_dim=256, patch_scale=8, dropout=0.0, frame_interval=0.5)
+
+    def build():
+        torch.manual_seed(7)
+        m = tante_amd.TANTE(dset_metadata=md, **kw)
+        gen = torch.Generator().manual_seed(77)
+        batch = {"input": torch.randn(2, 4, 32, 128, 11, generator=gen), "output": torch.randn(2, 3, 32, 128, 11, generator=gen)}
+        return m, batch
+    m, batch = build()
+    yf, gf, lf = _train_grads(dev, monkeypatch, m, batch, md, True, n_steps=3, n_loss=n_loss)
+    m2, batch2 = build()
+    yu, gu, lu = _train_grads(dev, monkeypatch, m2, batch2, md, False, n_steps=3, n_loss=n_loss)
+    assert abs(lf - lu) < 2e-3 * abs(lu)
+    _compare(yf, gf, yu, gu, f"two orders, D = 11, loss on {n_loss} of 3 frames")
+
+
+def test_training_tail_is_taken_and_counts_launches(dev, monkeypatch):
+    """The fused tail is the path the shipped training configuration takes (tail_train_cfg returns a configuration for cfg3's model), and a
+    train step with it issues fewer launches than without (the point of the fusion: ~45 fewer per rollout call)."""
+    import tante_amd
+    from tante_amd import train_forward as TF
+    from conftest import g14_setup, G14_FIELDS, G14_RES
+    md = tante_amd.TanteMetadata(n_fields=G14_FIELDS, spatial_resolution=G14_RES)
+    counts = {}
+    for fused in (True, False):
+        monkeypatch.setattr(TF, "FUSED_TAIL", fused)
+        m, batch, _, _ = g14_setup()
+        m = m.to(dev).train().set_compute("bf16")
+        opt = tante_amd.FlatAdamW(m.parameters(), lr=1e-4)
+        fmt = tante_amd.DefaultChannelsFirstFormatter(md)
+        b = {k: v.to(dev) for k, v in batch.items()}
+        tante_amd.train_step(m, opt, b, fmt, 4)      # warm-up: packs, workspaces
+        torch.cuda.synchronize()
+        with torch.profiler.profile(activities=[torch.profiler.ProfilerActivity.CUDA]) as prof:
+            tante_amd.train_step(m, opt, b, fmt, 4)
+            torch.cuda.synchronize()
+        counts[fused] = sum(1 for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA)
+    assert counts[True] < counts[False] - 100, counts
+    record_parity(0.0, 0.0, 1.0, "bf16", f"launches per train step: {counts[True]} with the fused tail, {counts[False]} without")
