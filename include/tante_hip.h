@@ -718,7 +718,7 @@ int tante_wgrad_jobs_ws(const TanteWgradJob* jobs, int n_jobs, int compute, void
  *   xl16 (T, 256) | pre1 / act1 (4T, 128) | pre2 / act2 (16T, 64) | f16 (16T, 64: (kh3, kw3, d) at k = sub * D + d, zero beyond 4 D)
  *   pre1e / act1e (16T, 64) | pre2e / act2e (4T, 128) | z (T, 256) fp32             (T = n_img * Hp * Wp tokens, 16 per workgroup)
  * Weights come pre-packed (tante_tail_pack_dec / _enc: conv weights in the reference layouts, (Cin, Cout, 2, 2) / (Cout, Cin, 2, 2)) into
- * buffers of tante_tail_stream_bytes(0 dec fwd | 1 dec bwd | 2 enc fwd | 3 enc bwd) bytes.  Token rows of the residual stream are
+ * buffers of tante_tail_stream_bytes(0 dec fwd | 1 dec bwd | 2 enc fwd | 3 enc bwd) bytes (4: see TanteTailBwd.bias_ws).  Token rows of the residual stream are
  * addressed like tante_head_fused: row r at (r / a_n0) * a_s1 + (r % a_n0) * a_s0 + a_off (elements; a_n0 % 16 == 0). */
 #define TANTE_TAIL_MAX_ORD 3
 typedef struct TanteTailOrdF {
@@ -747,7 +747,7 @@ typedef struct TanteTailOrdB {
   const void *pre1, *pre2;
   void *dpre1, *dpre2, *dder;      /* (T, 512) | (4T, 256) | (16T, 64): the V operands of the three decoder weight gradients */
   float* dx;             /* gradient of this order's residual stream (rows addressed by a_*) */
-  float *db1, *db2, *db3;          /* bias gradients, ADDED (fp32 atomics); may be NULL */
+  float *db1, *db2, *db3;          /* bias gradients, ADDED (through bias_ws); may be NULL */
 } TanteTailOrdB;
 typedef struct TanteTailBwd {
   TanteTailOrdB o[TANTE_TAIL_MAX_ORD];
@@ -763,6 +763,8 @@ typedef struct TanteTailBwd {
   const void* we;        /* encoder backward stream */
   const void *pre1e, *pre2e;
   void *dz16, *dpre2e, *dpre1e;    /* (T, 256) | (4T, 128) | (16T, 64): the U operands of the three encoder weight gradients */
+  float* bias_ws;        /* scratch, (T / 16) * n_ord * tante_tail_stream_bytes(4) bytes: per-workgroup partial sums of the decoder bias
+                            gradients, summed into db1 / db2 / db3 by a second small launch; NULL: no bias gradients */
 } TanteTailBwd;
 int tante_tail_supported(int C, int D, int Hp, int Wp);
 int64_t tante_tail_stream_bytes(int which);

@@ -100,7 +100,7 @@ class TailBwd(C.Structure):       # TanteTailBwd
     _fields_ = [("o", TailOrdB * 3), ("n_ord", c_i32), ("a_s1", c_i64), ("a_s0", c_i64), ("a_off", c_i64), ("a_n0", c_i32),
                 ("n_img", c_i32), ("Hp", c_i32), ("Wp", c_i32), ("D", c_i32), ("dext", c_vp), ("dext_bstride", c_i64),
                 ("dbase", c_vp), ("dbase_bstride", c_i64), ("dz", c_vp), ("we", c_vp), ("pre1e", c_vp), ("pre2e", c_vp),
-                ("dz16", c_vp), ("dpre2e", c_vp), ("dpre1e", c_vp)]
+                ("dz16", c_vp), ("dpre2e", c_vp), ("dpre1e", c_vp), ("bias_ws", c_vp)]
 
 
 SIGNATURES = {

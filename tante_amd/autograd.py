@@ -1428,6 +1428,8 @@ class TailFn(Function):
             a.dz, a.we = d_z.data_ptr(), cfg.enc_streams[1].data_ptr()
             a.pre1e, a.pre2e = enc["pre1e"].data_ptr(), enc["pre2e"].data_ptr()
             a.dz16, a.dpre2e, a.dpre1e = ge["dz16"].data_ptr(), ge["dpre2e"].data_ptr(), ge["dpre1e"].data_ptr()
+        bias_ws = torch.empty((Tk // 16) * n_ord * (L.lib().tante_tail_stream_bytes(4) // 4), dtype=torch.float32, device=dev)
+        a.bias_ws = bias_ws.data_ptr()
         L.check(L.lib().tante_tail_bwd(C.byref(a), _s()), "tante_tail_bwd")
         comp = L.BF16
         for k in range(n_ord):

@@ -28,7 +28,7 @@
 
 namespace {
 
-constexpr int TC_A = 0, TC_B = 32768, TC_C = 65536, TC_LDS = 65536 + 49152;      // LDS regions: 32 + 32 + 48 KiB
+constexpr int TC_X = 0, TC_Y = 32768, TC_LDS = 32768 + 49152;      // LDS regions: 32 + 48 KiB -- two workgroups per CU
 
 // decoder forward stream | decoder backward | encoder forward | encoder backward (bytes; fragments of 1 KiB, (row tile, k-step) order)
 constexpr int DF_X01 = 0, DF_X12 = 262144, DF_X23 = 327680, DF_BIAS = 335872, DF_BYTES = 336896;      // biases: b1[128] | b2[64] | b3[16]
@@ -53,35 +53,48 @@ __device__ __forceinline__ f32x4 tc_get4(const char* img, int R, int ch0) {
 __device__ __forceinline__ u32x2 tc_pack4(const f32x4& v) { return u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])}; }
 __device__ __forceinline__ f32x4 tc_unpack4(const u32x2& v) { return f32x4{bf16_lo(v[0]), bf16_hi(v[0]), bf16_lo(v[1]), bf16_hi(v[1])}; }
 
+// Global accesses of the accumulator-layout epilogues and the tile copies go through buffer resources: address = tile base (4 SGPRs) +
+// ONE lane offset per layout (a VGPR) + a wave-uniform offset (an SGPR or an immediate).  As plain pointers every access had a 64-bit
+// vector address of its own, computed ahead and kept alive across the phase: the kernels filled 256 registers and spilled.
+struct TcBuf {
+  __amdgpu_buffer_rsrc_t r;
+};
+__device__ __forceinline__ TcBuf tc_buf(const void* p) { return TcBuf{__builtin_amdgcn_make_buffer_rsrc((void*)p, 0, 0x7fffffff, 0x00020000)}; }
+__device__ __forceinline__ u32x2 tc_ld8(const TcBuf& b, int voff, int soff) { return __builtin_amdgcn_raw_buffer_load_b64(b.r, voff, soff, 0); }
+__device__ __forceinline__ void tc_st8(const TcBuf& b, int voff, int soff, const u32x2& v) { __builtin_amdgcn_raw_buffer_store_b64(v, b.r, voff, soff, 0); }
+__device__ __forceinline__ void tc_st16(const TcBuf& b, int voff, int soff, const u32x4& v) { __builtin_amdgcn_raw_buffer_store_b128(v, b.r, voff, soff, 0); }
+
 // image <-> its token-major tile in memory (rows of CPR x 16 bytes, linear), 16 bytes per thread and pass
-template <int CPR>
-__device__ __forceinline__ void tc_img_out(const char* img, void* dst, int rows, int tid) {
-  for (int i = tid; i < rows * CPR; i += 256) {
-    const int r = i / CPR, c = i % CPR;
-    *(u32x4*)((char*)dst + (long)i * 16) = *(const u32x4*)(img + tc_off<CPR>(r, c));
+template <int CPR, int ROWS>
+__device__ __forceinline__ void tc_img_out(const char* img, void* dst, int tid) {
+  static_assert(ROWS * CPR % 256 == 0, "whole passes");
+  u32x4 v[ROWS * CPR / 256];
+#pragma unroll
+  for (int q = 0; q < ROWS * CPR / 256; ++q) {
+    const int i = tid + 256 * q;
+    v[q] = *(const u32x4*)(img + tc_off<CPR>(i / CPR, i % CPR));
   }
-}
-template <int CPR>
-__device__ __forceinline__ void tc_img_in(char* img, const void* src, int rows, int tid) {
-  for (int i = tid; i < rows * CPR; i += 256) {
-    const int r = i / CPR, c = i % CPR;
-    *(u32x4*)(img + tc_off<CPR>(r, c)) = *(const u32x4*)((const char*)src + (long)i * 16);
-  }
+  const TcBuf b = tc_buf(dst);
+#pragma unroll
+  for (int q = 0; q < ROWS * CPR / 256; ++q) tc_st16(b, tid * 16, 4096 * q, v[q]);
 }
 
-// acc[j][c] += W[row tile rt0 + j][all k] . img[col tile ct0 + c]; wfr = this lane's 16 bytes of fragment (rt0, k-step 0) of the matrix
-// VIEW4: the image was written one level finer ([4 rows][CPR / 4 chunks] per row of this view); same bytes, the finer image's swizzle
+// acc[j][c] += W[row tile rt0 + j][all k] . img[col tile ct0 + c].  w = the weight stream as a buffer resource (fs_common.hip.h: one
+// 32-bit lane offset for the whole kernel, fragment offsets in SGPRs), woff = byte offset of fragment (rt0, k-step 0) of the matrix.
+// VIEW4: the image was written one level finer ([4 rows][CPR / 4 chunks] per row of this view); same bytes, the finer image's swizzle.
+// The k loop is a real loop (one k-step's fragments in flight ahead of the MFMAs): unrolled, the scheduler hoists every k-step's
+// loads and address arithmetic to the top of the phase -- 256 registers and scratch.
 template <int KS, int CPR, int RTW, int CTW, bool VIEW4 = false>
-__device__ __forceinline__ void tc_gemm(const char* __restrict__ wfr, const char* img, int ct0, int lane, f32x4 (&acc)[RTW][CTW]) {
+__device__ __forceinline__ void tc_gemm(const FsW& w, int woff, const char* img, int ct0, int lane, f32x4 (&acc)[RTW][CTW]) {
   const int l15 = lane & 15, kk = lane >> 4;
   u32x4 a_cur[RTW], a_nxt[RTW];
 #pragma unroll
-  for (int j = 0; j < RTW; ++j) a_cur[j] = *(const u32x4*)(wfr + (long)(j * KS) * 1024);
-#pragma unroll
+  for (int j = 0; j < RTW; ++j) a_cur[j] = ldg_frag(w, woff + (j * KS) * 1024);
+#pragma unroll 1
   for (int ks = 0; ks < KS; ++ks) {
     if (ks + 1 < KS) {
 #pragma unroll
-      for (int j = 0; j < RTW; ++j) a_nxt[j] = *(const u32x4*)(wfr + (long)(j * KS + ks + 1) * 1024);
+      for (int j = 0; j < RTW; ++j) a_nxt[j] = ldg_frag(w, woff + (j * KS + ks + 1) * 1024);
     }
     u32x4 b[CTW];
 #pragma unroll
@@ -94,10 +107,8 @@ __device__ __forceinline__ void tc_gemm(const char* __restrict__ wfr, const char
     for (int j = 0; j < RTW; ++j)
 #pragma unroll
       for (int c = 0; c < CTW; ++c) acc[j][c] = mfma_bf16(a_cur[j], b[c], acc[j][c]);
-    if (ks + 1 < KS) {
 #pragma unroll
-      for (int j = 0; j < RTW; ++j) a_cur[j] = a_nxt[j];
-    }
+    for (int j = 0; j < RTW; ++j) a_cur[j] = a_nxt[j];
   }
 }
 template <int RTW, int CTW>
@@ -113,12 +124,14 @@ __device__ __forceinline__ f32x4 tc_gelu_grad4(const f32x4& p) {
 
 // a frame tile (D fields x 8 rows x 128 pixels of 16 tokens in one patch row) between memory and the fp32 tile [(d, y)][128]
 __device__ __forceinline__ void tc_ftile_in(float* ft, const float* g, int D, int H, int W, int y0, int x0, int tid) {
+#pragma unroll 4
   for (int i = tid; i < D * 8 * 32; i += 256) {
     const int row = i >> 5, c = i & 31, d = row >> 3, y = row & 7;
     *(f32x4*)(ft + row * 128 + 4 * c) = *(const f32x4*)(g + ((long)d * H + y0 + y) * W + x0 + 4 * c);
   }
 }
 __device__ __forceinline__ void tc_ftile_out(const float* ft, float* g, int D, int H, int W, int y0, int x0, int tid) {
+#pragma unroll 4
   for (int i = tid; i < D * 8 * 32; i += 256) {
     const int row = i >> 5, c = i & 31, d = row >> 3, y = row & 7;
     *(f32x4*)(g + ((long)d * H + y0 + y) * W + x0 + 4 * c) = *(const f32x4*)(ft + row * 128 + 4 * c);
@@ -132,12 +145,13 @@ __device__ __forceinline__ int tc_fpos(int tok, int px16, int sub3, int d) {
 }
 
 // ================================================================ forward ==============================================================
+// LDS: region X (32 KiB) + region Y (48 KiB) = 80 KiB, two workgroups per CU.  Pre-activations never pass through LDS: the forward stores
+// them from the accumulator layout (8 bytes per lane; small tensors), the backward loads them the same way ahead of the GEMM they scale.
 template <int RT3>
-__global__ __launch_bounds__(256, 1) void tail_fwd_kernel(const TanteTailFwd A) {
+__global__ __launch_bounds__(256, 2) void tail_fwd_kernel(const TanteTailFwd A) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* const rA = smem + TC_A;
-  char* const rB = smem + TC_B;
-  char* const rC = smem + TC_C;
+  char* const rX = smem + TC_X;
+  char* const rY = smem + TC_Y;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, kk = lane >> 4;
   const int tile = blockIdx.x;
   const int D = A.D, H = 8 * A.Hp, W = 8 * A.Wp, HW = A.Hp * A.Wp;
@@ -160,43 +174,45 @@ __global__ __launch_bounds__(256, 1) void tail_fwd_kernel(const TanteTailFwd A) 
   for (int k = 0; k < A.n_ord; ++k) {
     const TanteTailOrdF& O = A.o[k];
     const char* const wf = (const char*)O.w;
-    char* const L0 = rC;                 // [16][256]   8 KiB
-    char* const L1 = rC + 8192;          // [64][128]  16 KiB (activation)
-    char* const P1 = rC + 24576;         // [64][128]  16 KiB (pre-activation)
+    const FsW w_wf = fs_wstream(wf, (unsigned)(lane * 16));
+    char* const L0 = rY;                 // [16][256]   8 KiB
+    char* const L1 = rY + 8192;          // [64][128]  16 KiB
     // ---- the tokens' rows (fp32, the last time slot of the residual stream) -> bf16 image ----
-    for (int i = tid; i < 16 * 64; i += 256) {
-      const int r = i >> 6, c4 = i & 63;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = tid + 256 * q, r = i >> 6, c4 = i & 63;
       const long t = tok0 + r;
       const float* row = (const float*)O.x + (t / A.a_n0) * A.a_s1 + (t % A.a_n0) * A.a_s0 + A.a_off;
       const f32x4 v = *(const f32x4*)(row + 4 * c4);
       *(u32x2*)(L0 + tc_off<32>(r, c4 >> 1) + (c4 & 1) * 8) = tc_pack4(v);
     }
     __syncthreads();
-    if (O.xl16) tc_img_out<32>(L0, (char*)O.xl16 + tok0 * 512, 16, tid);
+    if (O.xl16) tc_img_out<32, 16>(L0, (char*)O.xl16 + tok0 * 512, tid);
     // ---- stage 1: 256 -> (sub, 128) ----
     {
       f32x4 acc[8][1];
       tc_zero(acc);
-      tc_gemm<8, 32, 8, 1>(wf + DF_X01 + (long)(8 * wave) * 8 * 1024 + lane * 16, L0, 0, lane, acc);
+      tc_gemm<8, 32, 8, 1>(w_wf, DF_X01 + (long)(8 * wave) * 8 * 1024, L0, 0, lane, acc);
       const float* b1 = (const float*)(wf + DF_BIAS);
+      const TcBuf gpre = tc_buf((char*)O.pre1 + tok0 * 1024);      // [(token, sub)][128]: lane part l15 * 1024 + kk * 8
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int rt = 8 * wave + j, sub = rt >> 3, ch0 = (rt & 7) * 16 + 4 * kk, R = 4 * l15 + sub;
         const f32x4 v = acc[j][0] + *(const f32x4*)(b1 + ch0);
         const u32x2 pb = tc_pack4(v);
-        tc_put4<16>(P1, R, ch0, pb);
+        tc_st8(gpre, l15 * 1024 + kk * 8, sub * 256 + (rt & 7) * 32, pb);
         tc_put4<16>(L1, R, ch0, tc_pack4(gelu_poly4<false>(tc_unpack4(pb))));
       }
     }
     __syncthreads();
-    tc_img_out<16>(P1, (char*)O.pre1 + tok0 * 1024, 64, tid);
-    tc_img_out<16>(L1, (char*)O.act1 + tok0 * 1024, 64, tid);
-    // ---- stage 2: 128 -> (sub, 64);  activation -> region A, pre-activation -> region B ----
+    tc_img_out<16, 64>(L1, (char*)O.act1 + tok0 * 1024, tid);
+    // ---- stage 2: 128 -> (sub, 64): activation -> region X ----
     {
       f32x4 acc[4][4];
       tc_zero(acc);
-      tc_gemm<4, 16, 4, 4>(wf + DF_X12 + (long)(4 * wave) * 4 * 1024 + lane * 16, L1, 0, lane, acc);
+      tc_gemm<4, 16, 4, 4>(w_wf, DF_X12 + (long)(4 * wave) * 4 * 1024, L1, 0, lane, acc);
       const float* b2 = (const float*)(wf + DF_BIAS) + 128;
+      const TcBuf gpre = tc_buf((char*)O.pre2 + tok0 * 2048);      // [(token, sub1, sub)][64]: lane part l15 * 512 + kk * 8
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int rt = 4 * wave + j, sub = rt >> 2, ch0 = (rt & 3) * 16 + 4 * kk;
@@ -205,19 +221,18 @@ __global__ __launch_bounds__(256, 1) void tail_fwd_kernel(const TanteTailFwd A) 
         for (int c = 0; c < 4; ++c) {
           const int R = 4 * (16 * c + l15) + sub;
           const u32x2 pb = tc_pack4(acc[j][c] + bb);
-          tc_put4<8>(rB, R, ch0, pb);
-          tc_put4<8>(rA, R, ch0, tc_pack4(gelu_poly4<false>(tc_unpack4(pb))));
+          tc_st8(gpre, l15 * 512 + kk * 8, c * 8192 + sub * 128 + (rt & 3) * 32, pb);
+          tc_put4<8>(rX, R, ch0, tc_pack4(gelu_poly4<false>(tc_unpack4(pb))));
         }
       }
     }
     __syncthreads();
-    tc_img_out<8>(rB, (char*)O.pre2 + tok0 * 2048, 256, tid);
-    tc_img_out<8>(rA, (char*)O.act2 + tok0 * 2048, 256, tid);
+    tc_img_out<8, 256>(rX, (char*)O.act2 + tok0 * 2048, tid);
     // ---- stage 3: 64 -> (sub3, d): this order's derivative, times its Taylor coefficient ----
     {
       f32x4 acc[RT3][4];
       tc_zero(acc);
-      tc_gemm<2, 8, RT3, 4>(wf + DF_X23 + lane * 16, rA, 4 * wave, lane, acc);
+      tc_gemm<2, 8, RT3, 4>(w_wf, DF_X23, rX, 4 * wave, lane, acc);
       const float* b3 = (const float*)(wf + DF_BIAS) + 192;
 #pragma unroll
       for (int j = 0; j < RT3; ++j)
@@ -228,12 +243,12 @@ __global__ __launch_bounds__(256, 1) void tail_fwd_kernel(const TanteTailFwd A) 
           for (int c = 0; c < 4; ++c) facc[j][c][r] += O.coef * (acc[j][c][r] + bb);
         }
     }
-    __syncthreads();      // the next order's rows overwrite region C, its stage 2 regions A and B
+    __syncthreads();      // the next order's rows overwrite region Y, its stage 2 region X
   }
 
   // ---- Taylor sum: + the window's last frame; the predicted frame goes out (fp32) and into the level-3 patch image (bf16) ----
-  float* const ft = (float*)rC;
-  char* const L3 = rB;      // [256 (token, px16)][64]: (sub3, d) at 2-byte position sub3 * D + d, zero beyond 4 D
+  float* const ft = (float*)rY;
+  char* const L3 = rX;      // [256 (token, px16)][64]: (sub3, d) at 2-byte position sub3 * D + d, zero beyond 4 D
   const int y0 = 8 * hp, x0 = 8 * wp0;
   tc_ftile_in(ft, A.base + (long)img * A.base_bstride, D, H, W, y0, x0, tid);
   __syncthreads();
@@ -258,16 +273,18 @@ __global__ __launch_bounds__(256, 1) void tail_fwd_kernel(const TanteTailFwd A) 
   __syncthreads();
   tc_ftile_out(ft, A.out + (long)img * A.out_bstride, D, H, W, y0, x0, tid);
   if (!A.we) return;
-  tc_img_out<8>(L3, (char*)A.f16 + tok0 * 2048, 256, tid);
-  __syncthreads();      // the frame tile has left region C
+  tc_img_out<8, 256>(L3, (char*)A.f16 + tok0 * 2048, tid);
+  __syncthreads();      // the frame tile has left region Y
 
   // =========================================================== re-encoding ===========================================================
   const char* const we = (const char*)A.we;
-  {   // ---- stage 1: (sub3, d) -> 64 at the 256 level-2 pixels; activation -> region A, pre-activation -> region C ----
+  const FsW w_we = fs_wstream(we, (unsigned)(lane * 16));
+  {   // ---- stage 1: (sub3, d) -> 64 at the 256 level-2 pixels; activation -> region Y ----
     f32x4 acc[4][4];
     tc_zero(acc);
-    tc_gemm<2, 8, 4, 4>(we + EF_C32 + lane * 16, L3, 4 * wave, lane, acc);
+    tc_gemm<2, 8, 4, 4>(w_we, EF_C32, L3, 4 * wave, lane, acc);
     const float* b1 = (const float*)(we + EF_BIAS);
+    const TcBuf gpre = tc_buf((char*)A.pre1e + tok0 * 2048);      // [(token, px16)][64]: lane part l15 * 128 + kk * 8
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int ch0 = 16 * j + 4 * kk;
@@ -276,19 +293,19 @@ __global__ __launch_bounds__(256, 1) void tail_fwd_kernel(const TanteTailFwd A) 
       for (int c = 0; c < 4; ++c) {
         const int R = 16 * (4 * wave + c) + l15;
         const u32x2 pb = tc_pack4(acc[j][c] + bb);
-        tc_put4<8>(rC, R, ch0, pb);
-        tc_put4<8>(rA, R, ch0, tc_pack4(gelu_poly4<false>(tc_unpack4(pb))));
+        tc_st8(gpre, l15 * 128 + kk * 8, (4 * wave + c) * 2048 + j * 32, pb);
+        tc_put4<8>(rY, R, ch0, tc_pack4(gelu_poly4<false>(tc_unpack4(pb))));
       }
     }
   }
   __syncthreads();
-  tc_img_out<8>(rC, (char*)A.pre1e + tok0 * 2048, 256, tid);
-  tc_img_out<8>(rA, (char*)A.act1e + tok0 * 2048, 256, tid);
-  {   // ---- stage 2: region A as [64][(sub, 64)] -> 128; activation -> B[0 : 16K], pre-activation -> B[16K : 32K] ----
+  tc_img_out<8, 256>(rY, (char*)A.act1e + tok0 * 2048, tid);
+  {   // ---- stage 2: region Y as [64][(sub, 64)] -> 128; activation -> X[0 : 16K] ----
     f32x4 acc[2][4];
     tc_zero(acc);
-    tc_gemm<8, 32, 2, 4, true>(we + EF_C21 + (long)(2 * wave) * 8 * 1024 + lane * 16, rA, 0, lane, acc);
+    tc_gemm<8, 32, 2, 4, true>(w_we, EF_C21 + (long)(2 * wave) * 8 * 1024, rY, 0, lane, acc);
     const float* b2 = (const float*)(we + EF_BIAS) + 64;
+    const TcBuf gpre = tc_buf((char*)A.pre2e + tok0 * 1024);      // [(token, px4)][128]: lane part l15 * 256 + kk * 8
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int ch0 = 16 * (2 * wave + j) + 4 * kk;
@@ -297,54 +314,88 @@ __global__ __launch_bounds__(256, 1) void tail_fwd_kernel(const TanteTailFwd A) 
       for (int c = 0; c < 4; ++c) {
         const int R = 16 * c + l15;
         const u32x2 pb = tc_pack4(acc[j][c] + bb);
-        tc_put4<16>(rB + 16384, R, ch0, pb);
-        tc_put4<16>(rB, R, ch0, tc_pack4(gelu_poly4<false>(tc_unpack4(pb))));
+        tc_st8(gpre, l15 * 256 + kk * 8, c * 4096 + (2 * wave + j) * 32, pb);
+        tc_put4<16>(rX, R, ch0, tc_pack4(gelu_poly4<false>(tc_unpack4(pb))));
       }
     }
   }
   __syncthreads();
-  tc_img_out<16>(rB + 16384, (char*)A.pre2e + tok0 * 1024, 64, tid);
-  tc_img_out<16>(rB, (char*)A.act2e + tok0 * 1024, 64, tid);
-  {   // ---- stage 3: B[0 : 16K] as [16][(sub, 128)] -> 256: the frame's encoding before FiLM (fp32 rows, through region C) ----
+  tc_img_out<16, 64>(rX, (char*)A.act2e + tok0 * 1024, tid);
+  {   // ---- stage 3: X[0 : 16K] as [16][(sub, 128)] -> 256: the frame's encoding before FiLM (fp32 rows, through region Y) ----
     f32x4 acc[4][1];
     tc_zero(acc);
-    tc_gemm<16, 64, 4, 1, true>(we + EF_C10 + (long)(4 * wave) * 16 * 1024 + lane * 16, rB, 0, lane, acc);
+    tc_gemm<16, 64, 4, 1, true>(w_we, EF_C10 + (long)(4 * wave) * 16 * 1024, rX, 0, lane, acc);
     const float* b3 = (const float*)(we + EF_BIAS) + 192;
-    __syncthreads();      // (region C: the pre-activation copy above has finished)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int ch0 = 16 * (4 * wave + j) + 4 * kk;
-      *(f32x4*)(rC + (l15 * 256 + ch0) * 4) = acc[j][0] + *(const f32x4*)(b3 + ch0);
+      *(f32x4*)(rY + (l15 * 256 + ch0) * 4) = acc[j][0] + *(const f32x4*)(b3 + ch0);      // (region Y: its copy-out ended before the stage-2 barrier)
     }
   }
   __syncthreads();
-  for (int i = tid; i < 16 * 64; i += 256) *(f32x4*)(A.z + tok0 * 256 + 4 * i) = *(const f32x4*)(rC + 16 * i);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int i = tid + 256 * q;
+    *(f32x4*)(A.z + tok0 * 256 + 4 * i) = *(const f32x4*)(rY + 16 * i);
+  }
 }
 
 // ================================================================ backward =============================================================
-// column sums of the wave's accumulators (rows = channels 16 (rt0 + j) + 4 kk + r, over the wave's columns) added to db
+// Bias gradients of the decoder stages (column sums of the V operands folded over the taps).  Adding them from every workgroup with
+// atomics took 150 us of the first form's 210 us launch: 1 536 same-address adds per bias element, and device-scope atomics to one address
+// are served one behind the other at the memory side.  Each wave STORES the column sums of its accumulators into the workgroup's row of a
+// scratch matrix (TC_WS floats per workgroup and order: [wave][64] stage-3 sums | [128] stage-2 sums | [16] field sums) and a small second
+// kernel (tail_bias_reduce_kernel, launched by tante_tail_bwd) adds the column sums of that matrix to the gradients.
+constexpr int TC_WS = 512;
 template <int RTW, int CTW>
-__device__ __forceinline__ void tc_bias_grad(const f32x4 (&g)[RTW][CTW], float* db, int rt0, int lane) {
+__device__ __forceinline__ void tc_bias_part(const f32x4 (&g)[RTW][CTW], float* dst, int lane) {
   const int l15 = lane & 15, kk = lane >> 4;
 #pragma unroll
   for (int j = 0; j < RTW; ++j) {
     f32x4 s = g[j][0];
 #pragma unroll
     for (int c = 1; c < CTW; ++c) s += g[j][c];
+    f32x4 t;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float t = row16_sum(s[r]);
-      if (l15 == 0) atomicAdd(db + 16 * (rt0 + j) + 4 * kk + r, t);
-    }
+    for (int r = 0; r < 4; ++r) t[r] = row16_sum(s[r]);
+    if (l15 == 0) *(f32x4*)(dst + 16 * j + 4 * kk) = t;
   }
+}
+struct TcRed {
+  const float* ws;
+  float* db1[TANTE_TAIL_MAX_ORD];
+  float* db2[TANTE_TAIL_MAX_ORD];
+  float* db3[TANTE_TAIL_MAX_ORD];
+  int n_ord, tiles, D;
+};
+// grid (8 column blocks of 64, n_ord, 16 row slices), 256 threads = 64 columns x 4 sub-slices
+__global__ __launch_bounds__(256) void tail_bias_reduce_kernel(const TcRed R) {
+  __shared__ float part[4][64];
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63), sub = threadIdx.x >> 6, k = blockIdx.y;
+  float s0 = 0.f, s1 = 0.f;
+  const int stride = 4 * gridDim.z;
+  int row = blockIdx.z * 4 + sub;
+  for (; row + stride < R.tiles; row += 2 * stride) {
+    s0 += R.ws[((long)row * R.n_ord + k) * TC_WS + col];
+    s1 += R.ws[((long)(row + stride) * R.n_ord + k) * TC_WS + col];
+  }
+  if (row < R.tiles) s0 += R.ws[((long)row * R.n_ord + k) * TC_WS + col];
+  part[sub][threadIdx.x & 63] = s0 + s1;
+  __syncthreads();
+  if (sub != 0) return;
+  const float v = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+  float* dst = nullptr;
+  if (col < 256) dst = R.db2[k] ? R.db2[k] + (col & 63) : nullptr;
+  else if (col < 384) dst = R.db1[k] ? R.db1[k] + (col - 256) : nullptr;
+  else if (col < 384 + R.D) dst = R.db3[k] ? R.db3[k] + (col - 384) : nullptr;
+  if (dst) atomicAdd(dst, v);
 }
 
 template <int RT3>
-__global__ __launch_bounds__(256, 1) void tail_bwd_kernel(const TanteTailBwd A) {
+__global__ __launch_bounds__(256, 2) void tail_bwd_kernel(const TanteTailBwd A) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* const rA = smem + TC_A;
-  char* const rB = smem + TC_B;
-  char* const rC = smem + TC_C;
+  char* const rX = smem + TC_X;
+  char* const rY = smem + TC_Y;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l15 = lane & 15, kk = lane >> 4;
   const int tile = blockIdx.x;
   const int D = A.D, H = 8 * A.Hp, W = 8 * A.Wp, HW = A.Hp * A.Wp;
@@ -362,53 +413,67 @@ __global__ __launch_bounds__(256, 1) void tail_bwd_kernel(const TanteTailBwd A) 
     }
   f32x4 dfr[RT3][4];      // gradient of the predicted frame: rows (sub3, d), columns (token 4 w + c, pixel l15)
   tc_zero(dfr);
-  float* const ft = (float*)rC;
+  float* const ft = (float*)rY;
 
   if (A.dz) {
     // =================================================== encoder stages, backwards ===================================================
-    const char* const we = (const char*)A.we;
-    char* const L0 = rC;      // dz as bf16 [16][256]
-    for (int i = tid; i < 16 * 64; i += 256) {
-      const int r = i >> 6, c4 = i & 63;
+    const FsW w_we = fs_wstream((const char*)A.we, (unsigned)(lane * 16));
+    char* const L0 = rY;      // dz as bf16 [16][256]
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = tid + 256 * q, r = i >> 6, c4 = i & 63;
       const f32x4 v = *(const f32x4*)(A.dz + (tok0 + r) * 256 + 4 * c4);
       *(u32x2*)(L0 + tc_off<32>(r, c4 >> 1) + (c4 & 1) * 8) = tc_pack4(v);
     }
-    tc_img_in<16>(rB + 16384, (const char*)A.pre2e + tok0 * 1024, 64, tid);
-    __syncthreads();
-    tc_img_out<32>(L0, (char*)A.dz16 + tok0 * 512, 16, tid);
-    {   // stage 3 backwards: 256 -> (sub, 128), times GELU'(pre2e) -> B[0 : 16K]
-      f32x4 acc[8][1];
-      tc_zero(acc);
-      tc_gemm<8, 32, 8, 1>(we + EB_X01 + (long)(8 * wave) * 8 * 1024 + lane * 16, L0, 0, lane, acc);
+    u32x2 p2[8];      // pre2e at this lane's accumulator positions of stage 3
+    {
+      const TcBuf gpre = tc_buf((const char*)A.pre2e + tok0 * 1024);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const int rt = 8 * wave + j, sub = rt >> 3, ch0 = (rt & 7) * 16 + 4 * kk, R = 4 * l15 + sub;
-        tc_put4<16>(rB, R, ch0, tc_pack4(acc[j][0] * tc_gelu_grad4(tc_get4<16>(rB + 16384, R, ch0))));
+        const int rt = 8 * wave + j, sub = rt >> 3;
+        p2[j] = tc_ld8(gpre, l15 * 1024 + kk * 8, sub * 256 + (rt & 7) * 32);
       }
     }
     __syncthreads();
-    tc_img_out<16>(rB, (char*)A.dpre2e + tok0 * 1024, 64, tid);
-    tc_img_in<8>(rC, (const char*)A.pre1e + tok0 * 2048, 256, tid);
+    tc_img_out<32, 16>(L0, (char*)A.dz16 + tok0 * 512, tid);
+    {   // stage 3 backwards: 256 -> (sub, 128), times GELU'(pre2e) -> X[0 : 16K]
+      f32x4 acc[8][1];
+      tc_zero(acc);
+      tc_gemm<8, 32, 8, 1>(w_we, EB_X01 + (long)(8 * wave) * 8 * 1024, L0, 0, lane, acc);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int rt = 8 * wave + j, sub = rt >> 3, ch0 = (rt & 7) * 16 + 4 * kk, R = 4 * l15 + sub;
+        tc_put4<16>(rX, R, ch0, tc_pack4(acc[j][0] * tc_gelu_grad4(tc_unpack4(p2[j]))));
+      }
+    }
+    u32x2 p1[4][4];   // pre1e at the accumulator positions of stage 2
+    {
+      const TcBuf gpre = tc_buf((const char*)A.pre1e + tok0 * 2048);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int rt = 4 * wave + j, sub = rt >> 2;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) p1[j][c] = tc_ld8(gpre, l15 * 512 + kk * 8, c * 8192 + sub * 128 + (rt & 3) * 32);
+      }
+    }
     __syncthreads();
-    {   // stage 2 backwards: 128 -> (sub, 64), times GELU'(pre1e) -> region A
+    tc_img_out<16, 64>(rX, (char*)A.dpre2e + tok0 * 1024, tid);
+    {   // stage 2 backwards: 128 -> (sub, 64), times GELU'(pre1e) -> Y[0 : 32K]
       f32x4 acc[4][4];
       tc_zero(acc);
-      tc_gemm<4, 16, 4, 4>(we + EB_X12 + (long)(4 * wave) * 4 * 1024 + lane * 16, rB, 0, lane, acc);
+      tc_gemm<4, 16, 4, 4>(w_we, EB_X12 + (long)(4 * wave) * 4 * 1024, rX, 0, lane, acc);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int rt = 4 * wave + j, sub = rt >> 2, ch0 = (rt & 3) * 16 + 4 * kk;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const int R = 4 * (16 * c + l15) + sub;
-          tc_put4<8>(rA, R, ch0, tc_pack4(acc[j][c] * tc_gelu_grad4(tc_get4<8>(rC, R, ch0))));
-        }
+        for (int c = 0; c < 4; ++c) tc_put4<8>(rY, 4 * (16 * c + l15) + sub, ch0, tc_pack4(acc[j][c] * tc_gelu_grad4(tc_unpack4(p1[j][c]))));
       }
     }
     __syncthreads();
-    tc_img_out<8>(rA, (char*)A.dpre1e + tok0 * 2048, 256, tid);
+    tc_img_out<8, 256>(rY, (char*)A.dpre1e + tok0 * 2048, tid);
     // stage 1 backwards: 64 -> (sub3, d): the encoder's share of the frame's gradient
-    tc_gemm<2, 8, RT3, 4>(we + EB_X23 + lane * 16, rA, 4 * wave, lane, dfr);
-    __syncthreads();      // region C (pre1e) is free for the frame tile
+    tc_gemm<2, 8, RT3, 4>(w_we, EB_X23, rY, 4 * wave, lane, dfr);
+    __syncthreads();      // region Y is free for the frame tile
   }
 
   // ---- + the frame's other gradients (loss, the next call's Taylor base); the total is the gradient of this call's base frame too ----
@@ -443,14 +508,15 @@ __global__ __launch_bounds__(256, 1) void tail_bwd_kernel(const TanteTailBwd A) 
     }
     fsum = row16_sum(fsum);
   }
-  __syncthreads();      // the frame tile has left region C
+  __syncthreads();      // the frame tile has left region Y
 
   // ===================================================== decoder stages, backwards ===================================================
   for (int k = 0; k < A.n_ord; ++k) {
     const TanteTailOrdB& O = A.o[k];
-    const char* const wb = (const char*)O.w;
-    if (O.db3 && (tid & 15) == 0 && (tid >> 4) < D) atomicAdd(O.db3 + (tid >> 4), O.coef * fsum);
-    char* const L3 = rB;
+    const FsW w_wb = fs_wstream((const char*)O.w, (unsigned)(lane * 16));
+    float* const wsrow = A.bias_ws ? A.bias_ws + ((long)tile * A.n_ord + k) * TC_WS : nullptr;
+    if (wsrow && (tid & 15) == 0 && (tid >> 4) < 16) wsrow[384 + (tid >> 4)] = (tid >> 4) < D ? O.coef * fsum : 0.0f;
+    char* const L3 = rX;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const int tok = 4 * wave + c;
@@ -459,60 +525,68 @@ __global__ __launch_bounds__(256, 1) void tail_bwd_kernel(const TanteTailBwd A) 
 #pragma unroll
       for (int j = RT3; j < 4; ++j) tc_put4<8>(L3, 16 * tok + l15, 16 * j + 4 * kk, u32x2{0u, 0u});
     }
-    tc_img_in<8>(rC, (const char*)O.pre2 + tok0 * 2048, 256, tid);
+    u32x2 q2[4][4];   // pre2 at the accumulator positions of stage 3 backwards
+    {
+      const TcBuf gpre = tc_buf((const char*)O.pre2 + tok0 * 2048);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) q2[j][c] = tc_ld8(gpre, l15 * 128 + kk * 8, (4 * wave + c) * 2048 + j * 32);
+    }
     __syncthreads();
-    tc_img_out<8>(L3, (char*)O.dder + tok0 * 2048, 256, tid);
-    {   // stage 3 backwards: (sub3, d) -> 64, times GELU'(pre2) -> region A
+    tc_img_out<8, 256>(L3, (char*)O.dder + tok0 * 2048, tid);
+    {   // stage 3 backwards: (sub3, d) -> 64, times GELU'(pre2) -> Y[0 : 32K]
       f32x4 acc[4][4];
       tc_zero(acc);
-      tc_gemm<2, 8, 4, 4>(wb + DB_C32 + lane * 16, L3, 4 * wave, lane, acc);
+      tc_gemm<2, 8, 4, 4>(w_wb, DB_C32, L3, 4 * wave, lane, acc);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int ch0 = 16 * j + 4 * kk;
+      for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          const int R = 16 * (4 * wave + c) + l15;
-          acc[j][c] = acc[j][c] * tc_gelu_grad4(tc_get4<8>(rC, R, ch0));
-          tc_put4<8>(rA, R, ch0, tc_pack4(acc[j][c]));
+          acc[j][c] = acc[j][c] * tc_gelu_grad4(tc_unpack4(q2[j][c]));
+          tc_put4<8>(rY, 16 * (4 * wave + c) + l15, 16 * j + 4 * kk, tc_pack4(acc[j][c]));
         }
-      }
-      if (O.db2) tc_bias_grad<4, 4>(acc, O.db2, 0, lane);
+      if (wsrow) tc_bias_part<4, 4>(acc, wsrow + 64 * wave, lane);
+    }
+    u32x2 q1[2][4];   // pre1 at the accumulator positions of stage 2 backwards
+    {
+      const TcBuf gpre = tc_buf((const char*)O.pre1 + tok0 * 1024);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) q1[j][c] = tc_ld8(gpre, l15 * 256 + kk * 8, c * 4096 + (2 * wave + j) * 32);
     }
     __syncthreads();
-    tc_img_out<8>(rA, (char*)O.dpre2 + tok0 * 2048, 256, tid);
-    tc_img_in<16>(rB + 16384, (const char*)O.pre1 + tok0 * 1024, 64, tid);
-    __syncthreads();
-    {   // stage 2 backwards: region A as [64][(sub, 64)] -> 128, times GELU'(pre1) -> B[0 : 16K]
+    tc_img_out<8, 256>(rY, (char*)O.dpre2 + tok0 * 2048, tid);
+    {   // stage 2 backwards: region Y as [64][(sub, 64)] -> 128, times GELU'(pre1) -> X[0 : 16K]
       f32x4 acc[2][4];
       tc_zero(acc);
-      tc_gemm<8, 32, 2, 4, true>(wb + DB_C21 + (long)(2 * wave) * 8 * 1024 + lane * 16, rA, 0, lane, acc);
+      tc_gemm<8, 32, 2, 4, true>(w_wb, DB_C21 + (long)(2 * wave) * 8 * 1024, rY, 0, lane, acc);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int ch0 = 16 * (2 * wave + j) + 4 * kk;
+      for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          const int R = 16 * c + l15;
-          acc[j][c] = acc[j][c] * tc_gelu_grad4(tc_get4<16>(rB + 16384, R, ch0));
-          tc_put4<16>(rB, R, ch0, tc_pack4(acc[j][c]));
+          acc[j][c] = acc[j][c] * tc_gelu_grad4(tc_unpack4(q1[j][c]));
+          tc_put4<16>(rX, 16 * c + l15, 16 * (2 * wave + j) + 4 * kk, tc_pack4(acc[j][c]));
         }
-      }
-      if (O.db1) tc_bias_grad<2, 4>(acc, O.db1, 2 * wave, lane);
+      if (wsrow) tc_bias_part<2, 4>(acc, wsrow + 256 + 32 * wave, lane);
     }
     __syncthreads();
-    tc_img_out<16>(rB, (char*)O.dpre1 + tok0 * 1024, 64, tid);
-    {   // stage 1 backwards: B[0 : 16K] as [16][(sub, 128)] -> 256: the gradient of the residual stream's rows (fp32, through region C)
+    tc_img_out<16, 64>(rX, (char*)O.dpre1 + tok0 * 1024, tid);
+    {   // stage 1 backwards: X[0 : 16K] as [16][(sub, 128)] -> 256: the gradient of the residual stream's rows (fp32, through region Y)
       f32x4 acc[4][1];
       tc_zero(acc);
-      tc_gemm<16, 64, 4, 1, true>(wb + DB_C10 + (long)(4 * wave) * 16 * 1024 + lane * 16, rB, 0, lane, acc);
+      tc_gemm<16, 64, 4, 1, true>(w_wb, DB_C10 + (long)(4 * wave) * 16 * 1024, rX, 0, lane, acc);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) *(f32x4*)(rC + (l15 * 256 + 16 * (4 * wave + j) + 4 * kk) * 4) = acc[j][0];
+      for (int j = 0; j < 4; ++j) *(f32x4*)(rY + (l15 * 256 + 16 * (4 * wave + j) + 4 * kk) * 4) = acc[j][0];      // (Y's copy-out ended before the last barrier)
     }
     __syncthreads();
-    for (int i = tid; i < 16 * 64; i += 256) {
-      const int r = i >> 6, c4 = i & 63;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = tid + 256 * q, r = i >> 6, c4 = i & 63;
       const long t = tok0 + r;
       float* row = O.dx + (t / A.a_n0) * A.a_s1 + (t % A.a_n0) * A.a_s0 + A.a_off;
-      *(f32x4*)(row + 4 * c4) = *(const f32x4*)(rC + (r * 256 + 4 * c4) * 4);
+      *(f32x4*)(row + 4 * c4) = *(const f32x4*)(rY + (r * 256 + 4 * c4) * 4);
     }
     __syncthreads();
   }
@@ -617,6 +691,7 @@ extern "C" int tante_tail_supported(int C, int D, int Hp, int Wp) { return C == 
 
 extern "C" int64_t tante_tail_stream_bytes(int which) {
   switch (which) {
+    case 4: return (int64_t)TC_WS * 4;      // bias-gradient scratch: bytes per workgroup (16 tokens) and Taylor order
     case 0: return DF_BYTES;
     case 1: return DB_BYTES;
     case 2: return EF_BYTES;
@@ -686,6 +761,16 @@ extern "C" int tante_tail_bwd(const TanteTailBwd* a, void* stream) {
     case 1: hipLaunchKernelGGL(tail_bwd_kernel<1>, dim3((unsigned)tiles), dim3(256), TC_LDS, s, *a); break;
     case 2: hipLaunchKernelGGL(tail_bwd_kernel<2>, dim3((unsigned)tiles), dim3(256), TC_LDS, s, *a); break;
     default: hipLaunchKernelGGL(tail_bwd_kernel<3>, dim3((unsigned)tiles), dim3(256), TC_LDS, s, *a); break;
+  }
+  if (a->bias_ws) {
+    TcRed R;
+    R.ws = a->bias_ws; R.n_ord = a->n_ord; R.tiles = (int)tiles; R.D = a->D;
+    for (int k = 0; k < TANTE_TAIL_MAX_ORD; ++k) {
+      R.db1[k] = k < a->n_ord ? a->o[k].db1 : nullptr;
+      R.db2[k] = k < a->n_ord ? a->o[k].db2 : nullptr;
+      R.db3[k] = k < a->n_ord ? a->o[k].db3 : nullptr;
+    }
+    hipLaunchKernelGGL(tail_bias_reduce_kernel, dim3(8, (unsigned)a->n_ord, 16), dim3(256), 0, s, R);
   }
   TANTE_CHECK_LAUNCH();
   return 0;
