@@ -84,31 +84,36 @@ __device__ __forceinline__ void tc_img_out(const char* img, void* dst, int tid) 
 // VIEW4: the image was written one level finer ([4 rows][CPR / 4 chunks] per row of this view); same bytes, the finer image's swizzle.
 // The k loop is a real loop (one k-step's fragments in flight ahead of the MFMAs): unrolled, the scheduler hoists every k-step's
 // loads and address arithmetic to the top of the phase -- 256 registers and scratch.
-template <int KS, int CPR, int RTW, int CTW, bool VIEW4 = false>
+template <int KS, int CPR, int RTW, int CTW, bool VIEW4 = false, int RING = 2>
 __device__ __forceinline__ void tc_gemm(const FsW& w, int woff, const char* img, int ct0, int lane, f32x4 (&acc)[RTW][CTW]) {
+  static_assert(KS % RING == 0, "the ring divides the k-steps");
   const int l15 = lane & 15, kk = lane >> 4;
-  u32x4 a_cur[RTW], a_nxt[RTW];
+  u32x4 a[RING][RTW];      // RING k-steps of weight fragments in flight: every phase starts cold and its k loop is short
 #pragma unroll
-  for (int j = 0; j < RTW; ++j) a_cur[j] = ldg_frag(w, woff + (j * KS) * 1024);
+  for (int u = 0; u < RING; ++u)
+#pragma unroll
+    for (int j = 0; j < RTW; ++j) a[u][j] = ldg_frag(w, woff + (j * KS + u) * 1024);
 #pragma unroll 1
-  for (int ks = 0; ks < KS; ++ks) {
-    if (ks + 1 < KS) {
+  for (int ks0 = 0; ks0 < KS; ks0 += RING) {
+    static_for<RING>([&](auto uc) {
+      constexpr int u = decltype(uc)::value;
+      const int ks = ks0 + u;
+      u32x4 b[CTW];
 #pragma unroll
-      for (int j = 0; j < RTW; ++j) a_nxt[j] = ldg_frag(w, woff + (j * KS + ks + 1) * 1024);
-    }
-    u32x4 b[CTW];
+      for (int c = 0; c < CTW; ++c) {
+        const int r = 16 * (ct0 + c) + l15, ch = 4 * ks + kk;
+        if constexpr (VIEW4) b[c] = *(const u32x4*)(img + tc_off<CPR / 4>(4 * r + ch / (CPR / 4), ch % (CPR / 4)));
+        else b[c] = *(const u32x4*)(img + tc_off<CPR>(r, ch));
+      }
 #pragma unroll
-    for (int c = 0; c < CTW; ++c) {
-      const int r = 16 * (ct0 + c) + l15, ch = 4 * ks + kk;
-      if constexpr (VIEW4) b[c] = *(const u32x4*)(img + tc_off<CPR / 4>(4 * r + ch / (CPR / 4), ch % (CPR / 4)));
-      else b[c] = *(const u32x4*)(img + tc_off<CPR>(r, ch));
-    }
+      for (int j = 0; j < RTW; ++j)
 #pragma unroll
-    for (int j = 0; j < RTW; ++j)
+        for (int c = 0; c < CTW; ++c) acc[j][c] = mfma_bf16(a[u][j], b[c], acc[j][c]);
+      if (ks + RING < KS) {
 #pragma unroll
-      for (int c = 0; c < CTW; ++c) acc[j][c] = mfma_bf16(a_cur[j], b[c], acc[j][c]);
-#pragma unroll
-    for (int j = 0; j < RTW; ++j) a_cur[j] = a_nxt[j];
+        for (int j = 0; j < RTW; ++j) a[u][j] = ldg_frag(w, woff + (j * KS + ks + RING) * 1024);
+      }
+    });
   }
 }
 template <int RTW, int CTW>
@@ -210,7 +215,7 @@ __global__ __launch_bounds__(256, 2) void tail_fwd_kernel(const TanteTailFwd A) 
     {
       f32x4 acc[4][4];
       tc_zero(acc);
-      tc_gemm<4, 16, 4, 4>(w_wf, DF_X12 + (long)(4 * wave) * 4 * 1024, L1, 0, lane, acc);
+      tc_gemm<4, 16, 4, 4, false, 4>(w_wf, DF_X12 + (long)(4 * wave) * 4 * 1024, L1, 0, lane, acc);
       const float* b2 = (const float*)(wf + DF_BIAS) + 128;
       const TcBuf gpre = tc_buf((char*)O.pre2 + tok0 * 2048);      // [(token, sub1, sub)][64]: lane part l15 * 512 + kk * 8
 #pragma unroll
@@ -303,7 +308,7 @@ __global__ __launch_bounds__(256, 2) void tail_fwd_kernel(const TanteTailFwd A) 
   {   // ---- stage 2: region Y as [64][(sub, 64)] -> 128; activation -> X[0 : 16K] ----
     f32x4 acc[2][4];
     tc_zero(acc);
-    tc_gemm<8, 32, 2, 4, true>(w_we, EF_C21 + (long)(2 * wave) * 8 * 1024, rY, 0, lane, acc);
+    tc_gemm<8, 32, 2, 4, true, 4>(w_we, EF_C21 + (long)(2 * wave) * 8 * 1024, rY, 0, lane, acc);
     const float* b2 = (const float*)(we + EF_BIAS) + 64;
     const TcBuf gpre = tc_buf((char*)A.pre2e + tok0 * 1024);      // [(token, px4)][128]: lane part l15 * 256 + kk * 8
 #pragma unroll
@@ -324,7 +329,7 @@ __global__ __launch_bounds__(256, 2) void tail_fwd_kernel(const TanteTailFwd A) 
   {   // ---- stage 3: X[0 : 16K] as [16][(sub, 128)] -> 256: the frame's encoding before FiLM (fp32 rows, through region Y) ----
     f32x4 acc[4][1];
     tc_zero(acc);
-    tc_gemm<16, 64, 4, 1, true>(w_we, EF_C10 + (long)(4 * wave) * 16 * 1024, rX, 0, lane, acc);
+    tc_gemm<16, 64, 4, 1, true, 4>(w_we, EF_C10 + (long)(4 * wave) * 16 * 1024, rX, 0, lane, acc);
     const float* b3 = (const float*)(we + EF_BIAS) + 192;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -461,7 +466,7 @@ __global__ __launch_bounds__(256, 2) void tail_bwd_kernel(const TanteTailBwd A) 
     {   // stage 2 backwards: 128 -> (sub, 64), times GELU'(pre1e) -> Y[0 : 32K]
       f32x4 acc[4][4];
       tc_zero(acc);
-      tc_gemm<4, 16, 4, 4>(w_we, EB_X12 + (long)(4 * wave) * 4 * 1024, rX, 0, lane, acc);
+      tc_gemm<4, 16, 4, 4, false, 4>(w_we, EB_X12 + (long)(4 * wave) * 4 * 1024, rX, 0, lane, acc);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int rt = 4 * wave + j, sub = rt >> 2, ch0 = (rt & 3) * 16 + 4 * kk;
@@ -561,7 +566,7 @@ __global__ __launch_bounds__(256, 2) void tail_bwd_kernel(const TanteTailBwd A) 
     {   // stage 2 backwards: region Y as [64][(sub, 64)] -> 128, times GELU'(pre1) -> X[0 : 16K]
       f32x4 acc[2][4];
       tc_zero(acc);
-      tc_gemm<8, 32, 2, 4, true>(w_wb, DB_C21 + (long)(2 * wave) * 8 * 1024, rY, 0, lane, acc);
+      tc_gemm<8, 32, 2, 4, true, 4>(w_wb, DB_C21 + (long)(2 * wave) * 8 * 1024, rY, 0, lane, acc);
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -576,7 +581,7 @@ __global__ __launch_bounds__(256, 2) void tail_bwd_kernel(const TanteTailBwd A) 
     {   // stage 1 backwards: X[0 : 16K] as [16][(sub, 128)] -> 256: the gradient of the residual stream's rows (fp32, through region Y)
       f32x4 acc[4][1];
       tc_zero(acc);
-      tc_gemm<16, 64, 4, 1, true>(w_wb, DB_C10 + (long)(4 * wave) * 16 * 1024, rX, 0, lane, acc);
+      tc_gemm<16, 64, 4, 1, true, 4>(w_wb, DB_C10 + (long)(4 * wave) * 16 * 1024, rX, 0, lane, acc);
 #pragma unroll
       for (int j = 0; j < 4; ++j) *(f32x4*)(rY + (l15 * 256 + 16 * (4 * wave + j) + 4 * kk) * 4) = acc[j][0];      // (Y's copy-out ended before the last barrier)
     }
