@@ -327,9 +327,177 @@ def flush_write_range(bucket: torch.Tensor):
     return None if lo is None else ((lo - base) // esz, (min(hi, end) - base) // esz)
 
 
+# ---- the end-of-pass flush in SEGMENTS (round 6: the data-parallel all-reduce pipelined against it, dist.GradAllReduce) ------------------
+# The flush is ~11 shared weight-gradient launches (one per block: its four weights) followed by the LayerNorm folds, which distribute the
+# folded in-projection / fc1 gradients to W, b, gamma, beta -- 58 % of the bucket, final only at the very end when the folds run as ONE
+# launch.  In segments, every fold runs right behind the launch group that fills its accumulator, so a block's whole span of the bucket is
+# final when its group is: the spans of the first segments travel while the later segments still compute.
+def _pending_groups():
+    ents = list(_DEFER["pending"].values())
+    groups = []
+    if WGRAD_JOBS > 1 and len(ents) > 1:
+        i = 0
+        while i < len(ents):
+            grp = ents[i: i + WGRAD_JOBS]
+            if any(e[5] != grp[0][5] or e[0].device != grp[0][0].device for e in grp):
+                grp = grp[:1]
+            i += len(grp)
+            groups.append(grp)
+    else:
+        groups = [[e] for e in ents]
+    # fold f is ready behind the last group that writes its accumulator (group -1: nothing pending writes it)
+    ready = {}
+    for fi, f in enumerate(_FOLD_PENDING):
+        last = -1
+        for gi, grp in enumerate(groups):
+            if any(e[0].data_ptr() == f[1].data_ptr() for e in grp):
+                last = gi
+        ready.setdefault(max(last, 0), []).append(fi)
+    return groups, ready
+
+
+def _segment_bounds(n_groups: int, segments: int):
+    segments = max(1, min(int(segments), max(1, n_groups)))
+    return [round(s * n_groups / segments) for s in range(segments + 1)]
+
+
+def flush_plan(bucket: torch.Tensor, segments: int):
+    """What the pending flush will finalise, by segment, WITHOUT launching: (early, [seg_0, seg_1, ...]) -- each a list of disjoint
+    (first element, end element) ranges of `bucket`.  `early` = what no segment writes (final already); every element of the bucket is in
+    exactly one list.  None when nothing is pending."""
+    groups, ready = _pending_groups()
+    if not groups and not _FOLD_PENDING:
+        return None
+    fold_acc = {f[1].data_ptr() for f in _FOLD_PENDING}
+    base, esz, n = bucket.data_ptr(), bucket.element_size(), bucket.numel()
+    owner = {}      # (lo, hi) -> the LAST segment that writes it
+    bounds = _segment_bounds(len(groups), segments)
+    seg_of = lambda gi: max(s for s in range(len(bounds) - 1) if bounds[s] <= gi) if groups else 0
+
+    def add(t, seg):
+        if t is None:
+            return
+        a = t.data_ptr()
+        if a < base or a >= base + n * esz:
+            return
+        lo = (a - base) // esz
+        owner[(lo, min(n, lo + t.numel()))] = seg
+    for gi, grp in enumerate(groups):
+        for e in grp:
+            if e[0].data_ptr() not in fold_acc:
+                add(e[0], seg_of(gi))
+                add(e[1], seg_of(gi))
+        for fi in ready.get(gi, ()):
+            for t in _FOLD_PENDING[fi][6:10]:
+                add(t, seg_of(gi))
+    if not groups:
+        for f in _FOLD_PENDING:
+            for t in f[6:10]:
+                add(t, 0)
+    n_seg = len(bounds) - 1
+    segs = [[] for _ in range(n_seg)]
+    for (lo, hi), sg in sorted(owner.items()):
+        lst = segs[sg]
+        if lst and lst[-1][1] == lo:
+            lst[-1] = (lst[-1][0], hi)
+        else:
+            lst.append((lo, hi))
+    taken = sorted(r for lst in segs for r in lst)
+    early, pos = [], 0
+    for lo, hi in taken:
+        if lo < pos:
+            raise RuntimeError("flush_plan: overlapping gradient slots in the bucket")
+        if lo > pos:
+            early.append((pos, lo))
+        pos = hi
+    if pos < n:
+        early.append((pos, n))
+    return early, segs
+
+
+def flush_steps(segments: int):
+    """Generator form of the flush: every next() launches one segment (its launch groups, each followed by the folds it completes) and
+    yields the segment's index; exhausting it resets the recorded state.  (train.GraphedTrainStep captures each next() as a graph.)"""
+    groups, ready = _pending_groups()
+    bounds = _segment_bounds(len(groups), segments)
+    n_seg = len(bounds) - 1
+    eager = n_seg > 1
+    for s in range(n_seg):
+        for gi in range(bounds[s], bounds[s + 1]):
+            _launch_group(groups[gi])
+            if eager and ready.get(gi):
+                _launch_folds([_FOLD_PENDING[fi] for fi in ready[gi]])
+        if s == n_seg - 1:      # the last segment also resets the recorded state (before its yield: the caller may never come back)
+            _DEFER["pending"].clear()
+            _DEFER["armed"], _DEFER["task"], _DEFER["bytes"] = False, -1, 0
+            if eager:
+                if not groups:
+                    _launch_folds(list(_FOLD_PENDING))
+                _FOLD_PENDING.clear()
+            else:
+                _flush_folds()
+        yield s
+
+
+def flush_run(segments: int, on_segment=None):
+    """Run the pending flush in `segments` segments (flush_plan's partition), calling on_segment(s) behind each.  One segment is the plain
+    flush: the folds as ONE launch at the end."""
+    for s in flush_steps(segments):
+        if on_segment is not None:
+            on_segment(s)
+
+
+def _launch_group(grp):
+    dev = grp[0][0].device
+    ws = _wgrad_workspace(dev)
+    if WGRAD_JOBS > 1 and len(_DEFER["pending"]) > 1:
+        jobs = (L.WgradJob * len(grp))()
+        keep = []
+        for jb, (gW, gb, M, N, Kk, comp, lay, uses) in zip(jobs, grp):
+            n = len(uses)
+            U = (L.RowMat * n)(*[_rm_linear(dy) for dy, _ in uses])
+            V = (L.RowMat * n)(*[_rm_linear(a) for _, a in uses])
+            keep.append((U, V))
+            jb.U, jb.V, jb.n_seg, jb.R, jb.I, jb.J = U, V, n, M, N, Kk
+            jb.dW, jb.dbias = gW.data_ptr(), None if gb is None else gb.data_ptr()
+            jb.layout, jb.P, jb.C_other, jb.swap = lay[0], lay[1], lay[2], int(lay[3])
+        L.check(L.lib().tante_wgrad_jobs_ws(jobs, len(grp), grp[0][5], ws.data_ptr(), ws.numel(), _s()), "tante_wgrad_jobs")
+        return
+    for gW, gb, M, N, Kk, comp, lay, uses in grp:
+        n = len(uses)
+        U = (L.RowMat * n)(*[_rm_linear(dy) for dy, _ in uses])
+        V = (L.RowMat * n)(*[_rm_linear(a) for _, a in uses])
+        layout, P, Co, swap = lay
+        L.check(L.lib().tante_wgrad_multi_ws(C.byref(U), C.byref(V), n, M, N, Kk, gW.data_ptr(), None if gb is None else gb.data_ptr(), layout, P,
+                                             Co, int(swap), comp, 1, ws.data_ptr(), ws.numel(), _s()), "tante_wgrad_multi")
+
+
+def _launch_folds(folds):
+    if not folds:
+        return
+    if _SIDE["stream"] is not None:
+        torch.cuda.current_stream().wait_stream(_SIDE["stream"])
+    n = len(folds)
+    arr = (L.Fold * n)()
+    for f, (buf, GW, Gb, W, gamma, beta, dW, db, dg, dbt, N, Kk) in zip(arr, folds):
+        f.GW, f.Gb, f.W, f.gamma, f.beta = GW.data_ptr(), Gb.data_ptr(), W.data_ptr(), gamma.data_ptr(), beta.data_ptr()
+        f.dW, f.db, f.dgamma, f.dbeta = dW.data_ptr(), None if db is None else db.data_ptr(), dg.data_ptr(), dbt.data_ptr()
+        f.N, f.K = N, Kk
+    L.check(L.lib().tante_fold_bwd_multi(C.byref(arr), n, 1, _s()), "tante_fold_bwd_multi")
+    for ent in folds:
+        _FOLD_DIRTY.pop(id(ent[0]), None)
+
+
+FLUSH_DRIVER = [None]        # callable() that runs the end-of-pass flush itself (train.py: flush_plan + flush_run around the all-reduce calls)
+
+
 def flush_deferred_wgrads(force: bool = False):
     """Run every recorded weight-gradient launch now (called automatically at the end of a backward pass), then the folds that wait for them."""
     if HOLD_FLUSH[0] and not force:
+        return
+    if FLUSH_DRIVER[0] is not None:
+        _join_side()
+        FLUSH_DRIVER[0]()
         return
     if PRE_FLUSH_HOOK[0] is not None:
         _join_side()                     # (weight gradients issued on the side stream, when that option is on, are part of "final")

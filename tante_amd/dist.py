@@ -57,63 +57,125 @@ def allreduce_sum_(flat: torch.Tensor) -> torch.Tensor:
     return flat
 
 
-# The gradient collective in TWO calls (round 5; SURVEY 8e "overlapped with the tail of backward").  With BPTT every weight is used in every
-# rollout call, so no gradient is final before the last call's backward has passed its layer -- but the dense linears of the blocks (85 % of
-# the bucket) only RECORD their operands there: their weight gradients run as shared launches when the backward pass ends
-# (autograd.flush_deferred_wgrads: ~1.5 ms of the 9.4 ms step at cfg3), followed by the LayerNorm folds.  Everything else -- encoder, decoders,
-# propagators, FiLM, embeddings -- is final when that flush STARTS.  So: `early(lo, hi)` (called by the flush, with the element range its
-# launches will write) all-reduces flat[:lo] and flat[hi:] on a side stream while the weight-gradient launches run, `finish()` all-reduces
-# flat[lo:hi] behind them and joins.  Every element goes through exactly one summed all-reduce; over two ranks the result is bit-identical
-# to one call (a + b commutes), over more ranks it is the same sum in RCCL's ring order for that message.
+# The gradient collective PIPELINED against the end-of-pass weight-gradient flush (round 5: two calls; round 6: segments).  With BPTT every
+# weight is used in every rollout call, so no gradient is final before the last call's backward has passed its layer -- but the dense
+# linears of the blocks (85 % of the bucket) only RECORD their operands there: their weight gradients run as shared launches when the
+# backward pass ends (autograd.flush_run: ~1.5 ms of the step at cfg3, one launch group per block, each followed by the LayerNorm folds it
+# completes).  So: what no flush launch writes (encoder, decoders, propagators, FiLM, embeddings) is all-reduced on a side stream when the
+# flush STARTS, the spans of flush segment s while segment s + 1 computes, the last segment's behind it.  Every element goes through exactly
+# one summed all-reduce; over two ranks the result is bit-identical to one call (a + b commutes), over more ranks it is the same sum in
+# RCCL's ring order for that message.
+# The call list must be the same on every rank.  It is derived from run-time state (which linears were recorded), so the ranks AGREE on it
+# once (agree(): a MIN all-reduce of the plan's signature and of its negation) and fall back to ONE call, all of them, when they differ; a
+# rank whose plan later changes raises instead of issuing a different list.
 SPLIT_ALLREDUCE = True
+FLUSH_SEGMENTS = 3      # the flush in this many segments: the early part + two thirds of the flush's spans travel under compute
+
+_SIDE_STREAMS = {}      # device index -> the one side stream the collectives of this process are issued under
+_AGREED = {}            # bucket numel -> (signature, agreed?)
+
+
+def _side_stream(device):
+    st = _SIDE_STREAMS.get(device.index)
+    if st is None:
+        st = _SIDE_STREAMS[device.index] = torch.cuda.Stream(device=device)
+    return st
+
+
+def plan_signature(plan) -> tuple:
+    if plan is None:
+        return (-1,)
+    early, segs = plan
+    flat = [len(early)] + [v for r in early for v in r] + [len(segs)]
+    for sg in segs:
+        flat += [len(sg)] + [v for r in sg for v in r]
+    return tuple(int(v) for v in flat)
+
+
+def agree(flat: torch.Tensor, plan) -> bool:
+    """True when every rank holds this same plan (a collective the first time a bucket is seen; afterwards a local look-up).  A plan that
+    differs from the one agreed earlier raises: the other ranks will not be asking again."""
+    sig = plan_signature(plan)
+    hit = _AGREED.get(flat.numel())
+    if hit is not None:
+        if hit[0] != sig:
+            raise RuntimeError("the gradient all-reduce plan of this rank changed after the ranks agreed on it (a different set of "
+                               "recorded weight gradients: ragged local batch or an option flipped on one rank?)")
+        return hit[1]
+    h = hash(sig)
+    v = [len(sig), h & 0x7FFFFFFF, (h >> 31) & 0x7FFFFFFF]
+    dev = flat.device if (dist.get_backend() == "nccl") else "cpu"
+    t = torch.tensor(v + [-q for q in v], dtype=torch.int64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    t = t.tolist()
+    same = all(t[i] == -t[i + 3] for i in range(3))
+    _AGREED[flat.numel()] = (sig, same)
+    return same
 
 
 class GradAllReduce:
     def __init__(self, flat: torch.Tensor):
-        self.flat, self.range, self.side, self.calls = flat, None, None, []
+        self.flat, self.done, self.calls, self.used_side = flat, [], [], False
 
     def active(self) -> bool:
         return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or FORCE_COLLECTIVE)
 
+    def ranges(self, rs):
+        """All-reduce these disjoint (lo, hi) element ranges now -- on the side stream, behind whatever the caller's stream has issued so
+        far, beside whatever it issues next."""
+        rs = [(int(lo), int(hi)) for lo, hi in rs if hi > lo]
+        if not rs or not self.active():
+            return
+        for lo, hi in rs:
+            if any(lo < h and l < hi for l, h in self.done):
+                raise RuntimeError("GradAllReduce: an element would pass through two all-reduces")
+            self.done.append((lo, hi))
+        if self.flat.is_cuda:
+            side = _side_stream(self.flat.device)
+            side.wait_stream(torch.cuda.current_stream(self.flat.device))
+            self.used_side = True
+            with torch.cuda.stream(side):
+                for lo, hi in rs:
+                    dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM)
+        else:
+            for lo, hi in rs:
+                dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM)
+        self.calls += [hi - lo for lo, hi in rs]
+
     def early(self, lo: int, hi: int):
-        """All-reduce what lies OUTSIDE [lo, hi) now, beside whatever the caller's stream does next."""
-        if not (self.active() and SPLIT_ALLREDUCE) or self.range is not None:
+        """All-reduce what lies OUTSIDE [lo, hi) now (the two-call form of round 5)."""
+        if not (self.active() and SPLIT_ALLREDUCE) or self.done:
             return
         n = self.flat.numel()
         lo, hi = max(0, min(lo, n)), max(0, min(hi, n))
         if lo >= hi or (lo == 0 and hi == n):
             return
-        self.range = (lo, hi)
-        parts = [q for q in (self.flat[:lo], self.flat[hi:]) if q.numel()]
-        if self.flat.is_cuda:
-            if self.side is None:
-                self.side = torch.cuda.Stream(device=self.flat.device)
-            self.side.wait_stream(torch.cuda.current_stream(self.flat.device))
-            with torch.cuda.stream(self.side):
-                for q in parts:
-                    dist.all_reduce(q, op=dist.ReduceOp.SUM)
-        else:
-            for q in parts:
-                dist.all_reduce(q, op=dist.ReduceOp.SUM)
-        self.calls += [int(q.numel()) for q in parts]
+        self.ranges([(0, lo), (hi, n)])
 
     def finish(self) -> torch.Tensor:
-        """The rest (everything when early() did not run), then the caller's stream waits for the side stream."""
+        """Whatever has not travelled yet (everything when nothing has), then the caller's stream waits for the side stream."""
         if not self.active():
             return self.flat
-        if self.range is None:
+        n, pos, rest = self.flat.numel(), 0, []
+        LAST_OVERLAPPED[0] = sum(self.calls) / max(1, n)      # the share that travelled beside compute (before this call)
+        for lo, hi in sorted(self.done):
+            if lo > pos:
+                rest.append((pos, lo))
+            pos = max(pos, hi)
+        if pos < n:
+            rest.append((pos, n))
+        if not self.done:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
-            self.calls = [int(self.flat.numel())]
+            self.calls = [n]
         else:
-            lo, hi = self.range
-            dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM)
-            self.calls.append(hi - lo)
-            if self.side is not None:
-                torch.cuda.current_stream(self.flat.device).wait_stream(self.side)
-        self.range = None
+            self.ranges(rest)
+        if self.used_side:
+            torch.cuda.current_stream(self.flat.device).wait_stream(_side_stream(self.flat.device))
+        self.done = []
         return self.flat
 
 
+LAST_OVERLAPPED = [0.0]  # share of the bucket's elements all-reduced BEFORE finish() in the last step (issued beside the flush)
 LAST_CALLS: list = []      # element counts of the last step's all-reduce calls (bench.py prints them in `collective`)
 
 

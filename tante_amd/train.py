@@ -48,15 +48,19 @@ def _backward_and_allreduce(loss, opt: FlatAdamW, world: int):
         return
     ar = D.GradAllReduce(opt.flat_g)
 
-    def hook():
-        rng = A.flush_write_range(opt.flat_g)
-        if rng is not None:
-            ar.early(*rng)
-    A.PRE_FLUSH_HOOK[0] = hook
+    def driver():      # the end-of-pass flush, run by the autograd engine's callback: segments of it under the all-reduce of the previous ones
+        plan = A.flush_plan(opt.flat_g, D.FLUSH_SEGMENTS) if D.SPLIT_ALLREDUCE else None
+        if plan is None or not D.agree(opt.flat_g, plan):
+            A.flush_run(1)
+            return
+        early, segs = plan
+        ar.ranges(early)
+        A.flush_run(len(segs), on_segment=lambda sg: ar.ranges(segs[sg]) if sg + 1 < len(segs) else None)
+    A.FLUSH_DRIVER[0] = driver
     try:
         run_backward(loss)
     finally:
-        A.PRE_FLUSH_HOOK[0] = None
+        A.FLUSH_DRIVER[0] = None
     ar.finish()
     D.LAST_CALLS[:] = ar.calls
 
@@ -113,7 +117,7 @@ class GraphedTrainStep:
         # a data-parallel step is captured as TWO graphs: everything up to the end-of-pass weight-gradient flush, and the flush -- between
         # their replays the part of the bucket the flush does not write is handed to RCCL on a side stream (dist.GradAllReduce)
         self.split = bool(D.collective_needed(world) and D.SPLIT_ALLREDUCE)
-        self.graph2, self.flush_range = None, None
+        self.graph2, self.plan = None, None
         TF.BLOCK_CALLS[0] = TF.BLOCK_CALLS[1] = 0
         A._SEED[0] = snap[4]            # the captured step draws the seeds an eager step would have drawn here
         ws_before = set(A._AXIS_WS)
@@ -134,10 +138,18 @@ class GraphedTrainStep:
                 else:
                     run_backward(self.loss)
             if self.split:
-                self.flush_range = A.flush_write_range(opt.flat_g)
-                self.graph2 = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self.graph2, pool=self.graph.pool(), capture_error_mode="thread_local"):
-                    A.flush_deferred_wgrads(force=True)
+                # the flush as one graph per segment (autograd.flush_plan's partition, agreed between the ranks once): between their
+                # replays the spans a segment has finalised go to RCCL on the side stream
+                plan = A.flush_plan(opt.flat_g, D.FLUSH_SEGMENTS)
+                self.plan = plan if (plan is not None and D.agree(opt.flat_g, plan)) else None
+                gen = A.flush_steps(len(plan[1]) if self.plan is not None else 1)
+                self.graph2 = []
+                for _ in range(len(plan[1]) if self.plan is not None else 1):
+                    g2 = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g2, pool=self.graph.pool(), capture_error_mode="thread_local"):
+                        next(gen)
+                    self.graph2.append(g2)
+                next(gen, None)
                 A.reset_backward_state(after=True)
             calls, fused = TF.BLOCK_CALLS
             if calls == 0 or fused != calls:
@@ -178,9 +190,16 @@ class GraphedTrainStep:
         self.graph.replay()
         if self.split:
             ar = D.GradAllReduce(self.opt.flat_g)
-            if self.flush_range is not None:
-                ar.early(*self.flush_range)          # encoder / decoders / propagators / FiLM / embeddings: on a side stream ...
-            self.graph2.replay()                     # ... while the blocks' weight gradients and the LayerNorm folds run
+            if self.plan is not None:
+                early, segs = self.plan
+                ar.ranges(early)                     # encoder / decoders / propagators / FiLM / embeddings: on a side stream ...
+                for sg, g2 in enumerate(self.graph2):
+                    g2.replay()                      # ... while the blocks' weight gradients and the LayerNorm folds run, segment by segment,
+                    if sg + 1 < len(segs):
+                        ar.ranges(segs[sg])          # each segment's spans travelling under the next one
+            else:
+                for g2 in self.graph2:
+                    g2.replay()
             ar.finish()
             D.LAST_CALLS[:] = ar.calls
         elif D.collective_needed(self.world):

@@ -34,7 +34,7 @@ def pytest_sessionstart(session):
         return
     out_dir = os.path.join(ROOT, "gpurun_out")
     os.makedirs(out_dir, exist_ok=True)
-    log = open(os.path.join(out_dir, "r05_rccl_world1.log"), "w")
+    log = open(os.path.join(out_dir, "r06_rccl_world1.log"), "w")
     cfg._rccl_child = (subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "rccl_world1_child.py")], stdout=log,
                                         stderr=subprocess.STDOUT, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")), log.name)
 

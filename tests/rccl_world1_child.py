@@ -98,10 +98,13 @@ def main():
     finally:
         gs.close()
     calls_graph = list(D.LAST_CALLS)
+    overlapped = float(D.LAST_OVERLAPPED[0])      # round 6: the flush in segments -- the share of the bucket that travels beside compute
     out["checks"]["graph_replay_plus_all_reduce_vs_eager_twin"] = {"worst_rel": worst, "losses": losses, "all_reduce_calls_elements": calls_graph,
-                                                                  "two_graphs": gs.graph2 is not None,
+                                                                  "two_graphs": gs.graph2 is not None, "flush_graphs": len(gs.graph2 or []),
+                                                                  "share_beside_compute": overlapped,
                                                                   "ok": worst < 1e-3 and len({round(v, 7) for v in losses}) == 3
-                                                                  and gs.graph2 is not None and len(calls_graph) >= 2
+                                                                  and gs.graph2 is not None and len(gs.graph2) >= 2 and overlapped >= 0.5
+                                                                  and len(calls_graph) >= 2
                                                                   and sum(calls_graph) == o3.flat_g.numel()}
     torch.cuda.synchronize()
     out["ok"] = bool(out["checks"]["all_reduce_identity_bit_equal"] and out["checks"]["eager_forced_collective_vs_none"]["ok"]

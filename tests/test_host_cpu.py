@@ -476,6 +476,35 @@ def _split_allreduce_worker(rank, world, port, q):
     ar = D.GradAllReduce(t)          # early() never called (no deferred flush): one call over everything
     ar.finish()
     outs["none"] = (bool(torch.equal(t, one)), list(ar.calls))
+    # round 6: a flush plan (autograd.flush_plan's shape): what no segment writes first, then the segments' spans one after the other, the
+    # last one in finish() -- every element exactly once, bit-identical to the single call; the ranks agree on the plan once
+    plan = ([(0, 100), (4000, 4100), (9000, 10_007)], [[(100, 2000)], [(2000, 3000), (3000, 4000)], [(4100, 9000)]])
+    same_plan = D.agree(flat, plan)
+    t = flat.clone()
+    ar = D.GradAllReduce(t)
+    ar.ranges(plan[0])
+    for sg in plan[1][:-1]:
+        ar.ranges(sg)
+    ar.finish()
+    outs["plan"] = (bool(torch.equal(t, one)) and same_plan, list(ar.calls))
+    overlapped = D.LAST_OVERLAPPED[0]
+    try:                              # an element twice: refused
+        ar2 = D.GradAllReduce(flat.clone())
+        ar2.ranges([(0, 10)])
+        ar2.ranges([(5, 20)])
+        twice = False
+    except RuntimeError:
+        twice = True
+    ar2.done = []
+    # ranks that hold DIFFERENT plans: agree() is False on both (they fall back to the single call together)
+    other = torch.zeros(777)
+    differ = D.agree(other, ([(0, 10 + rank)], [[(10 + rank, 777)]]))
+    try:                              # ... and a rank whose plan changes after the agreement raises instead of issuing another call list
+        D.agree(flat, ([(0, 1)], [[(1, 10_007)]]))
+        changed = False
+    except RuntimeError:
+        changed = True
+    outs["plan_checks"] = (twice and (not differ) and changed and abs(overlapped - (10_007 - 4900) / 10_007) < 1e-9, [10_007])
     D.barrier()
     q.put((rank, one.numpy().tobytes(), outs))      # (plain bytes: a tensor would travel as a shared-memory handle that dies with this process)
     dist.destroy_process_group()
@@ -500,4 +529,5 @@ def test_split_gradient_allreduce_equals_one_call_gloo_world2():
             assert same, (r, key)
             assert sum(calls) == 10_007, (key, calls)
         assert outs[(1234, 9000)][1] == [1234, 1007, 7766] and outs["none"][1] == [10_007] and outs[(0, 10_007)][1] == [10_007]
+        assert outs["plan"][1] == [100, 100, 1007, 1900, 1000, 1000, 4900], outs["plan"][1]
     assert res[0][1] == res[1][1]
