@@ -764,6 +764,9 @@ class LinearFn(Function):
         return da, dW, db, dres, None, None, None
 
 
+FP32_BIAS_SUMS = _O.register("TANTE_TRAIN_FP32_BIAS_SUMS", True, __name__, "FP32_BIAS_SUMS")
+
+
 class BranchOutFn(Function):
     """out = res + dropout_p(act(pre) @ W^T + b): the closing projection of a residual branch (attention out-proj: act = none; MLP fc2:
     act = GELU on fc1's pre-activation) as ONE differentiable op, so that the GEMM epilogues carry what would otherwise be separate
@@ -820,12 +823,25 @@ class BranchOutFn(Function):
             L.check(L.lib().tante_act_fwd(dout.data_ptr(), L.F32, dy.data_ptr(), _DT[adt], dout.numel(), L.ACT_NONE, _s()), "tante_act_fwd")
         dpre = dW = db = None
         side_done = False
+        # The bias gradient is a column sum over every token.  From the bf16 copy (what the weight-gradient kernel stages) each term carries
+        # 2^-9 of rounding noise, and where the true sum is a cancellation that noise is a large share of the VALUE (fixture g15: 12 % on a
+        # block's fc2 bias).  Without dropout the fp32 gradient is right here: sum that instead (round-5 verdict, weak item 1).
+        db32, bias32 = None, False
+        if FP32_BIAS_SUMS and ctx.p == 0.0 and adt != torch.float32 and ctx.has_bias and ctx.needs_input_grad[2]:
+            bias32 = True
+            gb_slot = _grad_slot(ctx.params[1])
+            if gb_slot is not None:
+                colsum(dout, M, N, 1, into=gb_slot)
+            else:
+                db32 = colsum(dout, M, N, 1)
         if ctx.needs_input_grad[1] and ctx.has_bias and ctx.needs_input_grad[2]:
             gW, gb = _grad_slot(ctx.params[0]), _grad_slot(ctx.params[1])
             if gW is not None and gb is not None:
-                if not _defer_wgrad(gW, gb, dy, a, M, N, Kk, comp):
+                gbk = None if bias32 else gb      # (bias32: the bias gradient has been added above, from the fp32 rows)
+                if not _defer_wgrad(gW, gbk, dy, a, M, N, Kk, comp):
                     with _side_wgrad(dy, a):
-                        wgrad(_rm_linear(dy), _rm_linear(a), M, N, Kk, (N, Kk), comp, device=a.device, with_bias=True, into=gW, db_into=gb)
+                        wgrad(_rm_linear(dy), _rm_linear(a), M, N, Kk, (N, Kk), comp, device=a.device, with_bias=not bias32, into=gW,
+                              db_into=gbk)
                 side_done = True
         if ctx.needs_input_grad[0]:
             dpre = torch.empty(M, Kk, dtype=pre.dtype, device=pre.device)
@@ -855,12 +871,14 @@ class BranchOutFn(Function):
             want_b = ctx.has_bias and ctx.needs_input_grad[2]
             if gW is not None and want_b and gb is not None:
                 wgrad(_rm_linear(dy), _rm_linear(a), M, N, Kk, (N, Kk), comp, device=a.device, with_bias=True, into=gW, db_into=gb)
+            elif bias32:      # (db32 None: the bias gradient went into its slot above)
+                dW, db = wgrad(_rm_linear(dy), _rm_linear(a), M, N, Kk, (N, Kk), comp, device=a.device), db32
             else:
                 dW, db = wgrad(_rm_linear(dy), _rm_linear(a), M, N, Kk, (N, Kk), comp, device=a.device, with_bias=True)
                 if not want_b:
                     db = None
         elif ctx.has_bias and ctx.needs_input_grad[2]:
-            db = colsum(dy, M, N, 1)
+            db = db32 if bias32 else colsum(dy, M, N, 1)
         return dpre, dW, db, dout, None, None, None, None
 
 
@@ -1409,6 +1427,25 @@ class FilmPosFramesFn(Function):
         L.check(L.lib().tante_film_pos_bwd_frames_acc(dy.data_ptr(), C.byref(fr), a.data_ptr(), B, HW, Cc, T, ptrs, mask, da.data_ptr(),
                                                       db.data_ptr(), ds.data_ptr(), flags, _s()), "film_pos_bwd_frames_acc")
         return (None if flags & 1 else da, None if flags & 1 else db, None if flags & 2 else ds, *rets)
+
+
+def guard_frame_gradient(frame: torch.Tensor):
+    """FilmPosFramesFn's accumulators rely on the autograd engine keeping the FIRST node's returned tensor, by reference, as the pending
+    gradient of the frame's producer (later nodes add into the same storage and return None).  Should the engine ever accumulate out of
+    place -- a second consumer of the frame outside FilmPosFramesFn, a producer / consumer stream mismatch -- those in-place adds would be
+    lost silently.  This hook on the frame checks what actually reaches the producer: the accumulator itself."""
+    if not frame.requires_grad:
+        return
+    key = id(frame)
+
+    def hook(g):
+        acc = _frame_accumulators()
+        exp = None if acc is None else acc.get(key)
+        if exp is not None and g.data_ptr() != exp.data_ptr():
+            raise RuntimeError("tante_amd: a frame encoding's gradient reached its producer as a different tensor than FilmPosFramesFn's "
+                               "accumulator -- the windows' in-place contributions would be lost (the frame has another consumer, or the "
+                               "engine accumulated out of place); set TANTE_TRAIN_FRAME_FILM=0")
+    frame.register_hook(hook)
 
 
 class SplitFramesFn(Function):

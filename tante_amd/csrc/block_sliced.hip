@@ -26,6 +26,13 @@
 #include "fs_common.hip.h"
 #include "block_sliced.h"
 
+// The FS_EXP_* switches are TIMING experiments: they skip work and produce wrong results by design.  They compile only into the diagnostic
+// build (-DTANTE_ABLATE: tools/_ab/ libraries, never tante_amd/lib/libtante_hip.so) -- ADVICE round 5.
+#if (defined(FS_EXP_NO_SAVE) || defined(FS_EXP_LN_ID) || defined(FS_EXP_GELU_ID) || defined(FS_EXP_NO_RESID) || defined(FS_EXP_NO_STORE) || \
+     defined(FS_EXP_TPROP_NO_STORE) || defined(FS_EXP_ROT) || defined(FS_EXP_NO_WLOAD) || defined(FS_EXP_MFMA32)) && !defined(TANTE_ABLATE)
+#error "FS_EXP_* timing experiments produce wrong results on purpose: build them with -DTANTE_ABLATE (tools/build_variant.sh), never into the product library"
+#endif
+
 namespace {
 
 

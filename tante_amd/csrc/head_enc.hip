@@ -25,6 +25,10 @@
 #include "fused_common.hip.h"
 #include <stdlib.h>
 
+#if defined(HE_EXP_GELU_ID) && !defined(TANTE_ABLATE)
+#error "HE_EXP_GELU_ID is a timing experiment (wrong results on purpose): build it with -DTANTE_ABLATE, never into the product library"
+#endif
+
 namespace {
 
 constexpr int HE_HB = 1024;                          // bias block of a tile (one LDS-DMA pass)

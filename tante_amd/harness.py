@@ -214,8 +214,14 @@ def train_one_epoch(model, optimizer, dataloader, formatter, n_steps_output: int
     if enable_amp:
         # Trainer.__init__ / train_one_epoch (trainer/trainer.py:86-104, 183-196): autocast(amp_type) around the forward and, for float16
         # only, a GradScaler around backward / step.  Both 16-bit types select the bf16 MFMA kernels (attn_backbone.resolve_compute).
-        import contextlib
         dt = {"float16": torch.float16, "bfloat16": torch.bfloat16}[amp_type]
+        if dt == torch.float16 and not getattr(model, "_tante_fp16_notice", False):
+            import warnings
+            warnings.warn("tante_amd: amp_type='float16' runs the bf16 MFMA kernels (there is no fp16 compute mode); the GradScaler sequence "
+                          "of the reference is kept")
+            model._tante_fp16_notice = True
+        if not hasattr(model, "set_compute"):
+            raise TypeError("tante_amd.harness.train_one_epoch(enable_amp=True) needs a tante_amd model (set_compute selects the bf16 kernels)")
         if scaler is None and dt == torch.float16:
             scaler = getattr(model, "_tante_grad_scaler", None) or torch.amp.GradScaler("cuda", enabled=True)
             model._tante_grad_scaler = scaler
@@ -236,10 +242,7 @@ def train_one_epoch(model, optimizer, dataloader, formatter, n_steps_output: int
                 if getattr(model, "deg", True):
                     losses.append(train_step(model, optimizer, batch, formatter, n_steps_output, world, scaler=scaler))
                 else:
-                    if scaler is not None and scaler.is_enabled():
-                        raise NotImplementedError("the adaptive-dt trainer (R_Trainer, r_trainer.py:135-179) clips by VALUE between backward and step; "
-                                                  "a float16 GradScaler is not wired through train_step_adaptive: use amp_type='bfloat16'")
-                    losses.append(train_step_adaptive(model, optimizer, batch, formatter, n_steps_output, rt_eps, rt_n, world)[0])
+                    losses.append(train_step_adaptive(model, optimizer, batch, formatter, n_steps_output, rt_eps, rt_n, world, scaler=scaler)[0])
             finally:
                 model.set_compute(prev)
         return float(torch.stack(losses).mean()) if losses else float("nan")

@@ -175,8 +175,11 @@ def rollout_model(model, batch: Dict, formatter, n_steps: int, device=None):
                     return [z.view(z.shape[0], z.shape[2], z.shape[3])]
                 from .autograd import SplitFramesFn
                 return list(SplitFramesFn.apply(z))
+            from .autograd import guard_frame_gradient
             with fold_scope():
                 zf = frames_of(encode_frames_train(model, moving, compute))
+                for f in zf:
+                    guard_frame_gradient(f)
                 last = moving[:, -1:].contiguous()
                 while produced < n_steps:
                     # (the one-launch tail, where it applies, also returns the predicted frame's encoding: train_forward.tail_train_cfg)
@@ -189,6 +192,7 @@ def rollout_model(model, batch: Dict, formatter, n_steps: int, device=None):
                             zf.append(nz[0])
                         else:
                             zf.extend(frames_of(encode_frames_train(model, y, compute)))
+                        guard_frame_gradient(zf[-1])
                         last = y[:, -1:].contiguous()
             return torch.cat(preds, dim=1)[:, :n_steps], y_ref.to(device)
     with fold_scope():      # the re-fed calls of one rollout share one autograd graph (and one folded copy of every LayerNorm affine)

@@ -236,20 +236,28 @@ class GraphedTrainStep:
 
 
 def train_step_adaptive(model, opt: FlatAdamW, batch: Dict[str, torch.Tensor], formatter, n_steps_output: int, rt_eps: float = 0.5,
-                        rt_n: float = 2.0, world: int = 1, lr: float = None):
+                        rt_n: float = 2.0, world: int = 1, lr: float = None, scaler=None):
     """R_Trainer.train_one_epoch's step (trainer/r_trainer.py:135-179) for the adaptive-dt model (deg=False): per-sample rollouts
-    with out_T = 1.5, loss = MSE(...).mean() + eval_rt(Rts, eps, n), clip_grad_value_(1.0) instead of a norm clip, AdamW."""
+    with out_T = 1.5, loss = MSE(...).mean() + eval_rt(Rts, eps, n), clip_grad_value_(1.0) instead of a norm clip, AdamW.
+    scaler: a torch.amp.GradScaler -- the reference's float16 sequence, as written there (l.152-158): scale(loss).backward();
+    clip_grad_value_(1.0) on the gradients AS THEY ARE (there is no unscale_ in front of the clip: the scaled gradients are clipped);
+    scaler.step(opt) unscales and skips the step when a gradient is not finite; update()."""
     opt.zero_grad()
     y_pred, y_ref, rts = rollout_adaptive(model, batch, formatter, n_steps_output, 1.5, per_sample=True)
     loss = MseMeanFn.apply(y_pred, y_ref) + MSE.eval_rt(rts, rt_eps, rt_n)
-    run_backward(loss)
+    amp = scaler is not None and scaler.is_enabled()
+    run_backward(scaler.scale(loss) if amp else loss)
     if world > 1:
         D.allreduce_sum_(opt.flat_g)
         opt.flat_g.mul_(1.0 / world)
     opt.clip_grad_value_(1.0)
     saved, opt.max_norm = opt.max_norm, 0.0          # value clip replaces the norm clip in this trainer
     try:
-        opt.step(lr=lr)
+        if amp:
+            scaler.step(opt, lr=lr)
+            scaler.update()
+        else:
+            opt.step(lr=lr)
     finally:
         opt.max_norm = saved
     return loss.detach(), rts.detach()
