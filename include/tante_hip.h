@@ -719,7 +719,9 @@ int tante_wgrad_jobs_ws(const TanteWgradJob* jobs, int n_jobs, int compute, void
  *   pre1e / act1e (16T, 64) | pre2e / act2e (4T, 128) | z (T, 256) fp32             (T = n_img * Hp * Wp tokens, 16 per workgroup)
  * Weights come pre-packed (tante_tail_pack_dec / _enc: conv weights in the reference layouts, (Cin, Cout, 2, 2) / (Cout, Cin, 2, 2)) into
  * buffers of tante_tail_stream_bytes(0 dec fwd | 1 dec bwd | 2 enc fwd | 3 enc bwd) bytes (4: see TanteTailBwd.bias_ws).  Token rows of the residual stream are
- * addressed like tante_head_fused: row r at (r / a_n0) * a_s1 + (r % a_n0) * a_s0 + a_off (elements; a_n0 % 16 == 0). */
+ * addressed like tante_head_fused: row r at (r / a_n0) * a_s1 + (r % a_n0) * a_s0 + a_off (elements; a_n0 % 16 == 0).
+ * n_ord = 0 is the encoder alone on given frames (`base`; `out` may be NULL): the initial window of a rollout -- enc_CNN.forward with its
+ * saves, and in tante_tail_bwd (dbase NULL) the two wide encoder stages backwards for the weight-gradient operands. */
 #define TANTE_TAIL_MAX_ORD 3
 typedef struct TanteTailOrdF {
   const float* x;        /* this order's residual stream */

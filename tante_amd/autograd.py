@@ -1649,19 +1649,73 @@ class TailFn(Function):
             wgrad(_rm_linear(t["act2"]), _rm_linear(g["dder"], s0=64, rows=16 * Tk, cols=4 * D), 16 * Tk, 64, 4 * D, tuple(dc[4].shape), comp,
                   layout=L.W_DECONV_NHWC, P=2, C_other=D, swap=True, device=dev, into=slots[4])
         if ge is not None:
-            ec = cfg.enc_params
-            es = [_grad_slot(q) for q in ec]
-            # encoder weights (Cout, Cin, 2, 2): U = the stage's output gradient (bias gradient = its column sums), V = input patches, k = (kh, kw, ci)
-            if not _defer_wgrad(es[4], es[5], ge["dz16"], enc["act2e"].view(Tk, 512), Tk, 256, 512, comp, (L.W_CONV_NHWC, 2, 128, False)):
-                wgrad(_rm_linear(ge["dz16"]), _rm_linear(enc["act2e"].view(Tk, 512)), Tk, 256, 512, tuple(ec[4].shape), comp, layout=L.W_CONV_NHWC,
-                      P=2, C_other=128, device=dev, with_bias=True, into=es[4], db_into=es[5])
-            if not _defer_wgrad(es[2], es[3], ge["dpre2e"], enc["act1e"].view(4 * Tk, 256), 4 * Tk, 128, 256, comp, (L.W_CONV_NHWC, 2, 64, False)):
-                wgrad(_rm_linear(ge["dpre2e"]), _rm_linear(enc["act1e"].view(4 * Tk, 256)), 4 * Tk, 128, 256, tuple(ec[2].shape), comp,
-                      layout=L.W_CONV_NHWC, P=2, C_other=64, device=dev, with_bias=True, into=es[2], db_into=es[3])
-            wgrad(_rm_linear(ge["dpre1e"]), _rm_linear(enc["f16"], s0=64, rows=16 * Tk, cols=4 * D), 16 * Tk, 64, 4 * D, tuple(ec[0].shape), comp,
-                  layout=L.W_CONV_NHWC, P=2, C_other=D, device=dev, with_bias=True, into=es[0], db_into=es[1])
+            _tail_enc_wgrads(cfg, enc, ge, Tk, dev)
         ctx.saved = ctx.enc = None
         return (dbase, None) + tuple(dxs)
+
+
+class EncTailFn(Function):
+    """enc_CNN.forward on INPUT frames (the rollout's initial window) through the tail kernels' encoder half (csrc/tail_chain.hip with no
+    decoder): frames (n_img, D, H, W) fp32, no gradient -> their pre-FiLM encodings (n_img * HW, C) fp32.  One launch forward (with the
+    activations the weight gradients read, token-major), one backward (the two wide stages backwards: the weight-gradient operands)."""
+
+    @staticmethod
+    def forward(ctx, frames, cfg, *enc_params):      # (the parameters are inputs so that the node takes part in the backward pass)
+        n_img, D, Hp, Wp, HW = frames.shape[0], cfg.D, cfg.Hp, cfg.Wp, cfg.HW
+        dev, bf = frames.device, torch.bfloat16
+        Tk = n_img * HW
+        frames = frames.contiguous()
+        a = L.TailFwd()
+        a.n_ord, a.a_n0 = 0, HW
+        a.n_img, a.Hp, a.Wp, a.D = n_img, Hp, Wp, D
+        a.base, a.base_bstride = frames.data_ptr(), frames.stride(0)
+        enc = {"f16": torch.empty(16 * Tk, 64, dtype=bf, device=dev), "pre1e": torch.empty(16 * Tk, 64, dtype=bf, device=dev),
+               "act1e": torch.empty(16 * Tk, 64, dtype=bf, device=dev), "pre2e": torch.empty(4 * Tk, 128, dtype=bf, device=dev),
+               "act2e": torch.empty(4 * Tk, 128, dtype=bf, device=dev)}
+        z = torch.empty(Tk, cfg.C, dtype=torch.float32, device=dev)
+        a.we = cfg.enc_streams[0].data_ptr()
+        a.f16, a.pre1e, a.act1e, a.pre2e, a.act2e = (enc[n].data_ptr() for n in ("f16", "pre1e", "act1e", "pre2e", "act2e"))
+        a.z = z.data_ptr()
+        L.check(L.lib().tante_tail_fwd(C.byref(a), _s()), "tante_tail_fwd")
+        ctx.cfg, ctx.enc, ctx.geo = cfg, enc, (n_img, Tk)
+        return z
+
+    @staticmethod
+    def backward(ctx, d_z):
+        cfg, enc = ctx.cfg, ctx.enc
+        n_img, Tk = ctx.geo
+        D = cfg.D
+        dev, bf = d_z.device, torch.bfloat16
+        d_z = d_z.contiguous()
+        a = L.TailBwd()
+        a.n_ord, a.a_n0 = 0, cfg.HW
+        a.n_img, a.Hp, a.Wp, a.D = n_img, cfg.Hp, cfg.Wp, D
+        ge = {"dz16": torch.empty(Tk, 256, dtype=bf, device=dev), "dpre2e": torch.empty(4 * Tk, 128, dtype=bf, device=dev),
+              "dpre1e": torch.empty(16 * Tk, 64, dtype=bf, device=dev)}
+        a.dz, a.we = d_z.data_ptr(), cfg.enc_streams[1].data_ptr()
+        a.pre1e, a.pre2e = enc["pre1e"].data_ptr(), enc["pre2e"].data_ptr()
+        a.dz16, a.dpre2e, a.dpre1e = ge["dz16"].data_ptr(), ge["dpre2e"].data_ptr(), ge["dpre1e"].data_ptr()
+        L.check(L.lib().tante_tail_bwd(C.byref(a), _s()), "tante_tail_bwd")
+        _tail_enc_wgrads(cfg, enc, ge, Tk, dev)
+        ctx.enc = None
+        return (None, None) + (None,) * len(cfg.enc_params)
+
+
+def _tail_enc_wgrads(cfg, enc, ge, Tk, dev):
+    """The three encoder weight gradients from the tail kernels' token-major operands: (Cout, Cin, 2, 2) weights, U = the stage's output
+    gradient (the bias gradient = its column sums), V = input patches with k = (kh, kw, ci); the two wide ones as recorded uses of the
+    shared end-of-pass launches, the pixel-level one (J = 4 D columns) immediately."""
+    comp, D = L.BF16, cfg.D
+    ec = cfg.enc_params
+    es = [_grad_slot(q) for q in ec]
+    if not _defer_wgrad(es[4], es[5], ge["dz16"], enc["act2e"].view(Tk, 512), Tk, 256, 512, comp, (L.W_CONV_NHWC, 2, 128, False)):
+        wgrad(_rm_linear(ge["dz16"]), _rm_linear(enc["act2e"].view(Tk, 512)), Tk, 256, 512, tuple(ec[4].shape), comp, layout=L.W_CONV_NHWC,
+              P=2, C_other=128, device=dev, with_bias=True, into=es[4], db_into=es[5])
+    if not _defer_wgrad(es[2], es[3], ge["dpre2e"], enc["act1e"].view(4 * Tk, 256), 4 * Tk, 128, 256, comp, (L.W_CONV_NHWC, 2, 64, False)):
+        wgrad(_rm_linear(ge["dpre2e"]), _rm_linear(enc["act1e"].view(4 * Tk, 256)), 4 * Tk, 128, 256, tuple(ec[2].shape), comp,
+              layout=L.W_CONV_NHWC, P=2, C_other=64, device=dev, with_bias=True, into=es[2], db_into=es[3])
+    wgrad(_rm_linear(ge["dpre1e"]), _rm_linear(enc["f16"], s0=64, rows=16 * Tk, cols=4 * D), 16 * Tk, 64, 4 * D, tuple(ec[0].shape), comp,
+          layout=L.W_CONV_NHWC, P=2, C_other=D, device=dev, with_bias=True, into=es[0], db_into=es[1])
 
 
 class TailCfg:

@@ -276,7 +276,7 @@ __global__ __launch_bounds__(256, 2) void tail_fwd_kernel(const TanteTailFwd A) 
     for (int j = RT3; j < 4; ++j) tc_put4<8>(L3, 16 * tok + l15, 16 * j + 4 * kk, u32x2{0u, 0u});
   }
   __syncthreads();
-  tc_ftile_out(ft, A.out + (long)img * A.out_bstride, D, H, W, y0, x0, tid);
+  if (A.out) tc_ftile_out(ft, A.out + (long)img * A.out_bstride, D, H, W, y0, x0, tid);
   if (!A.we) return;
   tc_img_out<8, 256>(L3, (char*)A.f16 + tok0 * 2048, tid);
   __syncthreads();      // the frame tile has left region Y
@@ -476,6 +476,7 @@ __global__ __launch_bounds__(256, 2) void tail_bwd_kernel(const TanteTailBwd A) 
     }
     __syncthreads();
     tc_img_out<8, 256>(rY, (char*)A.dpre1e + tok0 * 2048, tid);
+    if (A.n_ord == 0 && !A.dbase) return;      // encoder of INPUT frames: the weight-gradient operands are all that is asked for
     // stage 1 backwards: 64 -> (sub3, d): the encoder's share of the frame's gradient
     tc_gemm<2, 8, RT3, 4>(w_we, EB_X23, rY, 4 * wave, lane, dfr);
     __syncthreads();      // region Y is free for the frame tile
@@ -719,9 +720,9 @@ extern "C" int tante_tail_pack_enc(const float* w1, const float* b1, const float
 }
 
 static int tc_check_geom(int n_ord, int n_img, int Hp, int Wp, int D, int a_n0, const char* who) {
-  if (n_ord < 1 || n_ord > TANTE_TAIL_MAX_ORD) TANTE_FAIL(-1, "%s: 1 .. %d Taylor orders (got %d)", who, TANTE_TAIL_MAX_ORD, n_ord);
+  if (n_ord < 0 || n_ord > TANTE_TAIL_MAX_ORD) TANTE_FAIL(-1, "%s: 0 .. %d Taylor orders (got %d)", who, TANTE_TAIL_MAX_ORD, n_ord);
   if (!tante_tail_supported(256, D, Hp, Wp)) TANTE_FAIL(-2, "%s: unsupported shape (D = %d, Hp = %d, Wp = %d: D <= 12, Wp %% 16 == 0)", who, D, Hp, Wp);
-  if (n_img < 1 || a_n0 < 16 || a_n0 % 16) TANTE_FAIL(-1, "%s: rows are addressed in blocks of a multiple of 16 tokens (a_n0 = %d)", who, a_n0);
+  if (n_img < 1 || (n_ord > 0 && (a_n0 < 16 || a_n0 % 16))) TANTE_FAIL(-1, "%s: rows are addressed in blocks of a multiple of 16 tokens (a_n0 = %d)", who, a_n0);
   return 0;
 }
 
@@ -732,7 +733,8 @@ extern "C" int tante_tail_fwd(const TanteTailFwd* a, void* stream) {
     const TanteTailOrdF& o = a->o[k];
     if (!o.x || !o.w || !o.pre1 || !o.act1 || !o.pre2 || !o.act2) TANTE_FAIL(-1, "tante_tail_fwd: order %d: null pointer", k);
   }
-  if (!a->base || !a->out) TANTE_FAIL(-1, "tante_tail_fwd: null frame pointer");
+  if (!a->base || (!a->out && a->n_ord > 0)) TANTE_FAIL(-1, "tante_tail_fwd: null frame pointer");
+  if (a->n_ord == 0 && !a->we) TANTE_FAIL(-1, "tante_tail_fwd: neither a decoder nor the encoder to run");
   if (a->we && (!a->f16 || !a->pre1e || !a->act1e || !a->pre2e || !a->act2e || !a->z)) TANTE_FAIL(-1, "tante_tail_fwd: encoder outputs missing");
   const long tiles = (long)a->n_img * a->Hp * a->Wp / 16;
   const int rt3 = (4 * a->D + 15) / 16;
@@ -756,6 +758,7 @@ extern "C" int tante_tail_bwd(const TanteTailBwd* a, void* stream) {
     if (!o.w || !o.pre1 || !o.pre2 || !o.dpre1 || !o.dpre2 || !o.dder || !o.dx) TANTE_FAIL(-1, "tante_tail_bwd: order %d: null pointer", k);
   }
   if (!a->dz && !a->dext) TANTE_FAIL(-1, "tante_tail_bwd: no gradient arrives (dz and dext are both null)");
+  if (a->n_ord == 0 && !a->dz) TANTE_FAIL(-1, "tante_tail_bwd: neither a decoder nor the encoder to run");
   if (a->dz && (!a->we || !a->pre1e || !a->pre2e || !a->dz16 || !a->dpre2e || !a->dpre1e)) TANTE_FAIL(-1, "tante_tail_bwd: encoder operands missing");
   const long tiles = (long)a->n_img * a->Hp * a->Wp / 16;
   const int rt3 = (4 * a->D + 15) / 16;

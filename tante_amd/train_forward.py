@@ -13,7 +13,7 @@ from . import _lib as L
 from . import options as _O
 from . import kernels as K
 from . import stages as S
-from .autograd import (TailCfg, TailFn, FilmTableFn, ActFn, AttentionFn, BlockFn, BlockTailFn, block_tail_ready, AxisHWFn, AxisMlpFn, BranchOutFn, DeconvFn, DropoutAddFn, FilmPosFn, FilmPosFramesFn, FoldFn, LayerNormFn, LayerNormSkipFn, LinearFn, PatchEmbedFn, RtReduceFn,
+from .autograd import (EncTailFn, TailCfg, TailFn, FilmTableFn, ActFn, AttentionFn, BlockFn, BlockTailFn, block_tail_ready, AxisHWFn, AxisMlpFn, BranchOutFn, DeconvFn, DropoutAddFn, FilmPosFn, FilmPosFramesFn, FoldFn, LayerNormFn, LayerNormSkipFn, LinearFn, PatchEmbedFn, RtReduceFn,
                        TaylorFn)
 
 
@@ -383,6 +383,11 @@ def train_enc_cache_ok(model) -> bool:
 def encode_frames_train(model, frames: torch.Tensor, compute: int) -> torch.Tensor:
     """frames (B, k, D, H, W) -> their pre-FiLM token rows (B, k, HW, C) fp32, differentiable (encoder_train on the k frames of every item)."""
     B, k = frames.shape[:2]
+    if not frames.requires_grad and frames.dtype == torch.float32:
+        tail = tail_train_cfg(model, B, compute, True)       # input frames: the tail kernels' encoder half, one launch each way
+        if tail is not None:
+            z = EncTailFn.apply(frames.reshape(B * k, *frames.shape[2:]), tail, *tail.enc_params)
+            return z.view(B, k, model.H_p * model.W_p, model.C)
     z = encoder_train(model.encoder, frames.to(torch.float32).contiguous(), compute)
     return z.view(B, k, model.H_p * model.W_p, model.C)
 

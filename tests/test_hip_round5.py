@@ -294,16 +294,17 @@ def test_g15_channel_letter_train(dev, name, mode):
             err = max_rel(q.grad.cpu(), ref)
             assert err < gt, (k, err)
         else:
-            # bf16: relative L2 per tensor (as test_submodules_are_differentiable_standalone).  A bias gradient is a sum over 4 608 rows of
-            # entries rounded to bf16; where the reference's sum is a cancellation -- the C block's fc2 bias: 1.55 against entries of
-            # magnitude ~2.4, i.e. 2 % of a random walk's length -- the rounding noise of the terms (~0.15) is 10 % of the VALUE while it
-            # is 2e-3 of the terms.  Vectors therefore get 3.5 x the bar, and the whole gradient (all tensors concatenated) the bar itself.
+            # bf16: relative L2 per tensor (as test_submodules_are_differentiable_standalone).  A bias gradient is a sum over 4 608 rows; where
+            # the reference's sum is a cancellation (the C block's fc2 bias: 1.55 against entries of magnitude ~2.4) the rounding noise of
+            # bf16 TERMS was 12 % of the value (round 5: vectors got 3.5 x the bar).  Round 6: the closing projections of a branch sum their
+            # fp32 rows (autograd.BranchOutFn, FP32_BIAS_SUMS): that vector is at 2.3e-2 now and the worst vector (LayerNorm1's bias, whose
+            # gradient comes through the bf16 q | k | v gradient rows) at 4.0e-2: vectors 1.25 x the bar, matrices and the whole gradient the bar.
             err = rel_err(q.grad.cpu(), ref)
-            assert err < (gt if ref.dim() > 1 else 3.5 * gt), (k, err)
+            assert err < (gt if ref.dim() > 1 else 1.25 * gt), (k, err)
         worst = max(worst, err)
     err = rel_err(torch.cat(ours), torch.cat(refs))
     assert err < gt, ("all parameters", err)
-    record_parity(max(worst, err), max(worst, err), gt if mode == "fp32" else 3.5 * gt, mode,
+    record_parity(max(worst, err), max(worst, err), gt if mode == "fp32" else 1.25 * gt, mode,
                   f"{name}: Attn_Backbone gradients (input and parameters) vs the reference; all parameters concatenated: {err:.2e}")
 
 
