@@ -29,7 +29,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}      # dense MFMA peaks, MI355X_MICROARCH.md
-PMC_FILE = "r05_pmc_rollout.json"                    # HBM counters of the dominant kernel (separate --pmc passes, committed)
+PMC_FILE = "r06_pmc_rollout.json"                    # HBM counters of the dominant kernel (separate --pmc passes, committed)
 
 
 def _sha16(path):
@@ -486,11 +486,11 @@ def rollout_leg(config, batch_arg, dtype_arg, steps, warmup, dev, rank, world, d
         except (OSError, KeyError, ValueError):
             pass
         try:      # cfg5: the spectral path's HBM bytes per SpectralLayer call (its five kernels), same rules
-            with open(os.path.join(ROOT, "profiles", "r05_pmc_fno.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r06_pmc_fno.json")) as f:
                 pf = json.load(f)
             if name.startswith("spectral") and os.path.basename(args.config) == pf.get("config"):
                 traffic = pf["spectral_layer"]["hbm_bytes_per_call"]
-                traffic_source = {"file": "profiles/r05_pmc_fno.json", "kernel_source_sha16": pf.get("kernel_source_sha16"),
+                traffic_source = {"file": "profiles/r06_pmc_fno.json", "kernel_source_sha16": pf.get("kernel_source_sha16"),
                                   "current_kernel_source_sha16": _sha16(os.path.join(ROOT, "tante_amd", "csrc", "spectral_dft.hip"))}
                 traffic_source["stale"] = traffic_source["kernel_source_sha16"] != traffic_source["current_kernel_source_sha16"]
         except (OSError, KeyError, ValueError):

@@ -1,9 +1,9 @@
 #!/bin/bash
-# Run on the MI355X box (via gpurun): the round's rocprofv3 evidence -> gpurun_out/r05/.  tools/summarize_profiles.py condenses it into
+# Run on the MI355X box (via gpurun): the round's rocprofv3 evidence -> gpurun_out/r06/.  tools/summarize_profiles.py condenses it into
 # the files that are committed under profiles/.   gpurun --timeout 1200 -- 'bash tools/collect_profiles.sh'
 set -o pipefail
 R=$GRAFT_REPO_ROOT
-OUT=$R/gpurun_out/r05
+OUT=$R/gpurun_out/r06
 rm -rf $OUT && mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 # 1. kernel traces (never combined with counters)
@@ -29,16 +29,16 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_fno/$c -- python3 $R/bench.py --config $R/configs/tante_fno.yaml --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > /dev/null 2> $OUT/pmc_fno_$c.err
 done
 bash $R/tools/pmc_train.sh > $OUT/pmc_train.log 2>&1
-cp $R/gpurun_out/pmc_train/summary.txt $OUT/r05_pmc_train.txt 2>/dev/null
+cp $R/gpurun_out/pmc_train/summary.txt $OUT/r06_pmc_train.txt 2>/dev/null
 # 2c. cfg4 at B = 4 and cfg5: per-kernel HBM bytes, TB/s and matrix-pipe occupancy (tools/pmc_bench.sh)
 bash $R/tools/pmc_bench.sh cvit_b4 --config configs/cvit_rb.yaml --batch 4 --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > $OUT/pmc_cvit_b4.log 2>&1
-cp $R/gpurun_out/pmc_cvit_b4/summary.txt $OUT/r05_pmc_cvit_b4.txt 2>/dev/null
+cp $R/gpurun_out/pmc_cvit_b4/summary.txt $OUT/r06_pmc_cvit_b4.txt 2>/dev/null
 bash $R/tools/pmc_bench.sh fno --config configs/tante_fno.yaml --steps 2 --warmup 1 --no-cpu-baseline --no-roofline > $OUT/pmc_fno_all.log 2>&1
-cp $R/gpurun_out/pmc_fno/summary.txt $OUT/r05_pmc_fno_kernels.txt 2>/dev/null
+cp $R/gpurun_out/pmc_fno/summary.txt $OUT/r06_pmc_fno_kernels.txt 2>/dev/null
 # 3. the counters condensed, put where bench.py reads them (this box's copy of profiles/), then the un-profiled reference line: its
 #    roofline.traffic then cites counters taken from the same source tree (traffic_source.stale = false)
 cd $R && python3 tools/summarize_profiles.py $OUT
-cp $OUT/r05_pmc_rollout.json $OUT/r05_pmc_fno.json $R/profiles/ 2>/dev/null
+cp $OUT/r06_pmc_rollout.json $OUT/r06_pmc_fno.json $R/profiles/ 2>/dev/null
 python3 $R/bench.py --steps 10 --warmup 3 > $OUT/bench_full.json 2> $OUT/bench_full.err
 python3 $R/bench.py --config $R/configs/tante_fno.yaml --steps 3 --warmup 1 --no-cpu-baseline > $OUT/fno_bench.json 2> $OUT/fno2.err
 # (the bench lines written under the profiler above carry its per-launch host overhead: replace them by un-profiled runs of the same commands)

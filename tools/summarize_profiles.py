@@ -1,4 +1,4 @@
-"""Condense the rocprofv3 outputs of tools/collect_profiles.sh (gpurun_out/r05/) into the small files committed under profiles/."""
+"""Condense the rocprofv3 outputs of tools/collect_profiles.sh (gpurun_out/r06/) into the small files committed under profiles/."""
 import collections
 import csv
 import glob
@@ -9,7 +9,7 @@ import sys
 
 out = sys.argv[1]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TAG = "r05"
+TAG = "r06"
 
 
 def stats(sub, dst, top=30):
