@@ -162,7 +162,12 @@ __global__ void adamw_kernel(float* __restrict__ p, float* __restrict__ m, float
 
 __global__ void clip_value_kernel(float* __restrict__ g, long n, float c) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) g[i] = fminf(fmaxf(g[i], -c), c);
+  // torch.clamp_'s semantics (clip_grad_value_, r_trainer.py:155): +-inf clamps to +-c, NaN STAYS NaN (fminf / fmaxf would turn it into
+  // a finite value, and a GradScaler behind the clip would no longer see the overflow and skip the step)
+  if (i < n) {
+    const float v = g[i];
+    g[i] = v != v ? v : fminf(fmaxf(v, -c), c);
+  }
 }
 
 // dt[b][l] = drt[b] / L : backward of  rt[b] = mean_l clamp_ST(t[b][l]) + ep  (the clamp is straight-through, tante.py:195-198)

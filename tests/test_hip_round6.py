@@ -124,3 +124,46 @@ def test_training_tail_is_taken_and_counts_launches(dev, monkeypatch):
         counts[fused] = sum(1 for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA)
     assert counts[True] < counts[False] - 100, counts
     record_parity(0.0, 0.0, 1.0, "bf16", f"launches per train step: {counts[True]} with the fused tail, {counts[False]} without")
+
+
+def test_adaptive_trainer_step_with_the_float16_grad_scaler(dev):
+    """R_Trainer.train_one_epoch's float16 sequence (trainer/r_trainer.py:152-158) through train_step_adaptive(scaler=): scale(loss).backward(),
+    clip_grad_value_(1.0) on the gradients AS THEY ARE -- the reference has no unscale_ in front of the clip, so the SCALED gradients are
+    clipped --, scaler.step (unscales, skips on a non-finite gradient), update.  (1) scale 1: the same step as without a scaler; (2) scale 2^10: after the step the bucket holds clip(2^10 g, 1) / 2^10, i.e. nothing above 2^-10; (3) a non-finite gradient:
+    the step is skipped, the scale halves."""
+    import math
+    import tante_amd
+    from conftest import load_golden, split_prefix
+    g = load_golden("g13_deg_false")
+    md = tante_amd.TanteMetadata(n_fields=1, spatial_resolution=(32, 32))
+    fmt = tante_amd.DefaultChannelsFirstFormatter(md)
+    gen = torch.Generator().manual_seed(0)
+    batch = {"input": torch.randn(2, 4, 32, 32, 1, generator=gen).to(dev), "output": torch.randn(2, 3, 32, 32, 1, generator=gen).to(dev)}
+
+    def build():
+        m = tante_amd.TANTE(in_T=4, dset_metadata=md, taylor_order=2, attn_axes="TH-TW", n_head=2, embed_dim=32, patch_scale=8,
+                            dropout=0.0, deg=False).to(dev).train()
+        m.load_state_dict(split_prefix(g, "w."))
+        return m, tante_amd.FlatAdamW(m.parameters(), lr=1e-3)
+    m0, o0 = build()
+    l0, _ = tante_amd.train_step_adaptive(m0, o0, batch, fmt, 3)
+    m1, o1 = build()
+    s1 = torch.amp.GradScaler("cuda", init_scale=1.0, enabled=True)
+    l1, _ = tante_amd.train_step_adaptive(m1, o1, batch, fmt, 3, scaler=s1)
+    # (two runs of the same step differ in the last bits: the loss reduction and some parameter gradients add with atomics)
+    assert abs(float(l0) - float(l1)) < 1e-5 * abs(float(l0)) and float((o0.flat_p - o1.flat_p).abs().max()) < 1e-6, "scale 1 must be the plain step"
+    m2, o2 = build()
+    s2 = torch.amp.GradScaler("cuda", init_scale=2.0 ** 10, enabled=True)
+    w_before = o2.flat_p.clone()
+    l2, _ = tante_amd.train_step_adaptive(m2, o2, batch, fmt, 3, scaler=s2)
+    assert math.isfinite(float(l2)) and float((o2.flat_p - w_before).abs().max()) > 0
+    assert float(o2.flat_g.abs().max()) <= 2.0 ** -10 * (1 + 1e-6)          # the clip acted on the scaled gradients
+    assert float(o0.flat_g.abs().max()) > 2.0 ** -10                         # ... which the unscaled step's gradients exceed
+    m3, o3 = build()
+    s3 = torch.amp.GradScaler("cuda", init_scale=2.0 ** 10, enabled=True)
+    with torch.no_grad():
+        next(m3.parameters()).view(-1)[0] = float("inf")                      # a non-finite weight -> non-finite loss and gradients
+    w_before = o3.flat_p.clone()
+    tante_amd.train_step_adaptive(m3, o3, batch, fmt, 3, scaler=s3)
+    fin = torch.isfinite(w_before)
+    assert torch.equal(o3.flat_p[fin], w_before[fin]) and o3.step_count == 0 and s3.get_scale() == 2.0 ** 9
