@@ -750,6 +750,8 @@ typedef struct TanteTailOrdB {
   void *dpre1, *dpre2, *dder;      /* (T, 512) | (4T, 256) | (16T, 64): the V operands of the three decoder weight gradients */
   float* dx;             /* gradient of this order's residual stream (rows addressed by a_*) */
   float *db1, *db2, *db3;          /* bias gradients, ADDED (through bias_ws); may be NULL */
+  const void* act2;      /* with dw3 and bias_ws: the last stage's weight gradient (64, D, 2, 2) is computed inside the launch (per-workgroup */
+  float* dw3;            /*   partials in bias_ws, ADDED by the reduce launch) and dder may be NULL */
 } TanteTailOrdB;
 typedef struct TanteTailBwd {
   TanteTailOrdB o[TANTE_TAIL_MAX_ORD];
@@ -765,8 +767,11 @@ typedef struct TanteTailBwd {
   const void* we;        /* encoder backward stream */
   const void *pre1e, *pre2e;
   void *dz16, *dpre2e, *dpre1e;    /* (T, 256) | (4T, 128) | (16T, 64): the U operands of the three encoder weight gradients */
-  float* bias_ws;        /* scratch, (T / 16) * n_ord * tante_tail_stream_bytes(4) bytes: per-workgroup partial sums of the decoder bias
-                            gradients, summed into db1 / db2 / db3 by a second small launch; NULL: no bias gradients */
+  float* bias_ws;        /* scratch, (T / 16) * (n_ord + 1) * tante_tail_stream_bytes(4) bytes: per-workgroup partial sums of the decoder bias
+                            gradients and of the two pixel-level weight gradients, summed into their destinations by a second small launch;
+                            NULL: none of them */
+  const void* f16;       /* with dwe1 (+ dbe1) and bias_ws: the first encoder stage's weight (64, D, 2, 2) and bias gradients are computed */
+  float *dwe1, *dbe1;    /*   inside the launch (ADDED) and dpre1e may be NULL */
 } TanteTailBwd;
 int tante_tail_supported(int C, int D, int Hp, int Wp);
 int64_t tante_tail_stream_bytes(int which);

@@ -93,14 +93,14 @@ class TailFwd(C.Structure):       # TanteTailFwd
 
 class TailOrdB(C.Structure):      # TanteTailOrdB
     _fields_ = [("w", c_vp), ("coef", c_f32), ("pre1", c_vp), ("pre2", c_vp), ("dpre1", c_vp), ("dpre2", c_vp), ("dder", c_vp),
-                ("dx", c_vp), ("db1", c_vp), ("db2", c_vp), ("db3", c_vp)]
+                ("dx", c_vp), ("db1", c_vp), ("db2", c_vp), ("db3", c_vp), ("act2", c_vp), ("dw3", c_vp)]
 
 
 class TailBwd(C.Structure):       # TanteTailBwd
     _fields_ = [("o", TailOrdB * 3), ("n_ord", c_i32), ("a_s1", c_i64), ("a_s0", c_i64), ("a_off", c_i64), ("a_n0", c_i32),
                 ("n_img", c_i32), ("Hp", c_i32), ("Wp", c_i32), ("D", c_i32), ("dext", c_vp), ("dext_bstride", c_i64),
                 ("dbase", c_vp), ("dbase_bstride", c_i64), ("dz", c_vp), ("we", c_vp), ("pre1e", c_vp), ("pre2e", c_vp),
-                ("dz16", c_vp), ("dpre2e", c_vp), ("dpre1e", c_vp), ("bias_ws", c_vp)]
+                ("dz16", c_vp), ("dpre2e", c_vp), ("dpre1e", c_vp), ("bias_ws", c_vp), ("f16", c_vp), ("dwe1", c_vp), ("dbe1", c_vp)]
 
 
 SIGNATURES = {

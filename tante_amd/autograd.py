@@ -1615,25 +1615,29 @@ class TailFn(Function):
             o = a.o[k]
             # (the other time slots of the stream receive no gradient from this node: the zero fill the slice's backward used to do)
             dx = torch.zeros(ctx.xshapes[k], dtype=torch.float32, device=dev)
-            g = {"dpre1": torch.empty(Tk, 512, dtype=bf, device=dev), "dpre2": torch.empty(4 * Tk, 256, dtype=bf, device=dev),
-                 "dder": torch.empty(16 * Tk, 64, dtype=bf, device=dev)}
+            g = {"dpre1": torch.empty(Tk, 512, dtype=bf, device=dev), "dpre2": torch.empty(4 * Tk, 256, dtype=bf, device=dev)}
             dc = cfg.dec_params[k]
             slots = [_grad_slot(q) for q in dc]
             o.w, o.coef, o.pre1, o.pre2 = cfg.dec_streams[k][1].data_ptr(), cfg.coefs[k], t["pre1"].data_ptr(), t["pre2"].data_ptr()
-            o.dpre1, o.dpre2, o.dder, o.dx = g["dpre1"].data_ptr(), g["dpre2"].data_ptr(), g["dder"].data_ptr(), dx.data_ptr()
+            o.dpre1, o.dpre2, o.dx = g["dpre1"].data_ptr(), g["dpre2"].data_ptr(), dx.data_ptr()
             o.db1, o.db2, o.db3 = slots[1].data_ptr(), slots[3].data_ptr(), slots[5].data_ptr()
+            if PIXEL_WGRAD_IN_KERNEL:      # the last stage's weight gradient inside the launch (per-workgroup partials + the reduce launch)
+                o.act2, o.dw3 = t["act2"].data_ptr(), slots[4].data_ptr()
+            else:
+                g["dder"] = torch.empty(16 * Tk, 64, dtype=bf, device=dev)
+                o.dder = g["dder"].data_ptr()
             outs.append((g, slots))
             dxs.append(dx)
         ge = None
         if d_z is not None and enc is not None:
             d_z = d_z.contiguous()
             keep.append(d_z)
-            ge = {"dz16": torch.empty(Tk, 256, dtype=bf, device=dev), "dpre2e": torch.empty(4 * Tk, 128, dtype=bf, device=dev),
-                  "dpre1e": torch.empty(16 * Tk, 64, dtype=bf, device=dev)}
+            ge = {"dz16": torch.empty(Tk, 256, dtype=bf, device=dev), "dpre2e": torch.empty(4 * Tk, 128, dtype=bf, device=dev)}
             a.dz, a.we = d_z.data_ptr(), cfg.enc_streams[1].data_ptr()
             a.pre1e, a.pre2e = enc["pre1e"].data_ptr(), enc["pre2e"].data_ptr()
-            a.dz16, a.dpre2e, a.dpre1e = ge["dz16"].data_ptr(), ge["dpre2e"].data_ptr(), ge["dpre1e"].data_ptr()
-        bias_ws = torch.empty((Tk // 16) * n_ord * (L.lib().tante_tail_stream_bytes(4) // 4), dtype=torch.float32, device=dev)
+            a.dz16, a.dpre2e = ge["dz16"].data_ptr(), ge["dpre2e"].data_ptr()
+            _tail_enc_first_stage(a, cfg, enc, ge, Tk, dev)
+        bias_ws = torch.empty((Tk // 16) * (n_ord + 1) * (L.lib().tante_tail_stream_bytes(4) // 4), dtype=torch.float32, device=dev)
         a.bias_ws = bias_ws.data_ptr()
         L.check(L.lib().tante_tail_bwd(C.byref(a), _s()), "tante_tail_bwd")
         comp = L.BF16
@@ -1646,8 +1650,9 @@ class TailFn(Function):
             if not _defer_wgrad(slots[2], None, t["act1"], g["dpre2"], 4 * Tk, 128, 256, comp, (L.W_DECONV_NHWC, 2, 64, True)):
                 wgrad(_rm_linear(t["act1"]), _rm_linear(g["dpre2"]), 4 * Tk, 128, 256, tuple(dc[2].shape), comp, layout=L.W_DECONV_NHWC, P=2,
                       C_other=64, swap=True, device=dev, into=slots[2])
-            wgrad(_rm_linear(t["act2"]), _rm_linear(g["dder"], s0=64, rows=16 * Tk, cols=4 * D), 16 * Tk, 64, 4 * D, tuple(dc[4].shape), comp,
-                  layout=L.W_DECONV_NHWC, P=2, C_other=D, swap=True, device=dev, into=slots[4])
+            if "dder" in g:
+                wgrad(_rm_linear(t["act2"]), _rm_linear(g["dder"], s0=64, rows=16 * Tk, cols=4 * D), 16 * Tk, 64, 4 * D, tuple(dc[4].shape), comp,
+                      layout=L.W_DECONV_NHWC, P=2, C_other=D, swap=True, device=dev, into=slots[4])
         if ge is not None:
             _tail_enc_wgrads(cfg, enc, ge, Tk, dev)
         ctx.saved = ctx.enc = None
@@ -1690,15 +1695,33 @@ class EncTailFn(Function):
         a = L.TailBwd()
         a.n_ord, a.a_n0 = 0, cfg.HW
         a.n_img, a.Hp, a.Wp, a.D = n_img, cfg.Hp, cfg.Wp, D
-        ge = {"dz16": torch.empty(Tk, 256, dtype=bf, device=dev), "dpre2e": torch.empty(4 * Tk, 128, dtype=bf, device=dev),
-              "dpre1e": torch.empty(16 * Tk, 64, dtype=bf, device=dev)}
+        ge = {"dz16": torch.empty(Tk, 256, dtype=bf, device=dev), "dpre2e": torch.empty(4 * Tk, 128, dtype=bf, device=dev)}
         a.dz, a.we = d_z.data_ptr(), cfg.enc_streams[1].data_ptr()
         a.pre1e, a.pre2e = enc["pre1e"].data_ptr(), enc["pre2e"].data_ptr()
-        a.dz16, a.dpre2e, a.dpre1e = ge["dz16"].data_ptr(), ge["dpre2e"].data_ptr(), ge["dpre1e"].data_ptr()
+        a.dz16, a.dpre2e = ge["dz16"].data_ptr(), ge["dpre2e"].data_ptr()
+        _tail_enc_first_stage(a, cfg, enc, ge, Tk, dev)
+        if a.dwe1:
+            bias_ws = torch.empty((Tk // 16) * (L.lib().tante_tail_stream_bytes(4) // 4), dtype=torch.float32, device=dev)
+            a.bias_ws = bias_ws.data_ptr()
         L.check(L.lib().tante_tail_bwd(C.byref(a), _s()), "tante_tail_bwd")
         _tail_enc_wgrads(cfg, enc, ge, Tk, dev)
         ctx.enc = None
         return (None, None) + (None,) * len(cfg.enc_params)
+
+
+# the two pixel-level weight gradients (64 x 4 D each) inside the tail's backward launch instead of a gathering launch + a reduce each
+PIXEL_WGRAD_IN_KERNEL = _O.register("TANTE_TAIL_PIXEL_WGRAD", True, __name__, "PIXEL_WGRAD_IN_KERNEL")
+
+
+def _tail_enc_first_stage(a, cfg, enc, ge, Tk, dev):
+    """How the first encoder stage's weight / bias gradients are produced: inside the launch (partials + the reduce launch), or from the
+    dpre1e rows by an immediate weight-gradient launch (_tail_enc_wgrads)."""
+    if PIXEL_WGRAD_IN_KERNEL:
+        es = [_grad_slot(q) for q in cfg.enc_params]
+        a.f16, a.dwe1, a.dbe1 = enc["f16"].data_ptr(), es[0].data_ptr(), es[1].data_ptr()
+    else:
+        ge["dpre1e"] = torch.empty(16 * Tk, 64, dtype=torch.bfloat16, device=dev)
+        a.dpre1e = ge["dpre1e"].data_ptr()
 
 
 def _tail_enc_wgrads(cfg, enc, ge, Tk, dev):
@@ -1714,8 +1737,9 @@ def _tail_enc_wgrads(cfg, enc, ge, Tk, dev):
     if not _defer_wgrad(es[2], es[3], ge["dpre2e"], enc["act1e"].view(4 * Tk, 256), 4 * Tk, 128, 256, comp, (L.W_CONV_NHWC, 2, 64, False)):
         wgrad(_rm_linear(ge["dpre2e"]), _rm_linear(enc["act1e"].view(4 * Tk, 256)), 4 * Tk, 128, 256, tuple(ec[2].shape), comp,
               layout=L.W_CONV_NHWC, P=2, C_other=64, device=dev, with_bias=True, into=es[2], db_into=es[3])
-    wgrad(_rm_linear(ge["dpre1e"]), _rm_linear(enc["f16"], s0=64, rows=16 * Tk, cols=4 * D), 16 * Tk, 64, 4 * D, tuple(ec[0].shape), comp,
-          layout=L.W_CONV_NHWC, P=2, C_other=D, device=dev, with_bias=True, into=es[0], db_into=es[1])
+    if "dpre1e" in ge:
+        wgrad(_rm_linear(ge["dpre1e"]), _rm_linear(enc["f16"], s0=64, rows=16 * Tk, cols=4 * D), 16 * Tk, 64, 4 * D, tuple(ec[0].shape), comp,
+              layout=L.W_CONV_NHWC, P=2, C_other=D, device=dev, with_bias=True, into=es[0], db_into=es[1])
 
 
 class TailCfg:

@@ -79,6 +79,58 @@ __device__ __forceinline__ void tc_img_out(const char* img, void* dst, int tid) 
   for (int q = 0; q < ROWS * CPR / 256; ++q) tc_st16(b, tid * 16, 4096 * q, v[q]);
 }
 
+template <int CPR, int ROWS>
+__device__ __forceinline__ void tc_img_in(char* img, const void* src, int tid) {
+  static_assert(ROWS * CPR % 256 == 0, "whole passes");
+  u32x4 v[ROWS * CPR / 256];
+#pragma unroll
+  for (int q = 0; q < ROWS * CPR / 256; ++q) v[q] = *(const u32x4*)((const char*)src + (long)(tid + 256 * q) * 16);
+#pragma unroll
+  for (int q = 0; q < ROWS * CPR / 256; ++q) {
+    const int i = tid + 256 * q;
+    *(u32x4*)(img + tc_off<CPR>(i / CPR, i % CPR)) = v[q];
+  }
+}
+
+// The two pixel-level weight gradients (64 x 4 D: dW = sum over the tile's 256 level-2 pixels of  U[row][i] V[row][j]) inside the kernel:
+// the contraction index is the ROW of both [256][64] images, so the MFMA fragments (8 consecutive rows of one column) are gfx950's
+// transposing LDS reads (cdna_hip_programming.md T10: per 16-lane group lane 4 q + p supplies the address of row q, columns 4 p .. 4 p + 3
+// of a 4-row x 16-column block; lane i receives column i).  acc[t] += U[:, 16 mt .. + 15]^T V[:, 16 t .. + 15].
+// (Both reads of a fragment and their wait are ONE asm statement: a transposing read delivers its registers when the LDS answers, not
+// when the instruction issues, and the compiler does not know -- with the wait in a later statement it was free to spill the "result"
+// in between: the D = 11 instantiation, the only one under register pressure here, summed stale registers into the gradient.)
+__device__ __forceinline__ u32x4 tc_tr_frag(const char* p0, const char* p1) {
+  u32x2 lo, hi;
+  asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %3\n\ts_waitcnt lgkmcnt(0)"
+               : "=&v"(lo), "=&v"(hi)
+               : "v"(lds_addr(p0)), "v"(lds_addr(p1))
+               : "memory");
+  return u32x4{lo[0], lo[1], hi[0], hi[1]};
+}
+template <int NT>
+__device__ __forceinline__ void tc_rows_outer(const char* U, int mt, const char* V, int lane, f32x4 (&acc)[NT]) {
+  const int l15 = lane & 15, kk = lane >> 4, q = l15 >> 2, p = l15 & 3;
+#pragma unroll 2
+  for (int ks = 0; ks < 8; ++ks) {
+    const int r0 = 32 * ks + 8 * kk + q;
+    const u32x4 a = tc_tr_frag(U + tc_off<8>(r0, 2 * mt + (p >> 1)) + 8 * (p & 1), U + tc_off<8>(r0 + 4, 2 * mt + (p >> 1)) + 8 * (p & 1));
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const u32x4 b = tc_tr_frag(V + tc_off<8>(r0, 2 * t + (p >> 1)) + 8 * (p & 1), V + tc_off<8>(r0 + 4, 2 * t + (p >> 1)) + 8 * (p & 1));
+      acc[t] = mfma_bf16(a, b, acc[t]);
+    }
+  }
+}
+// ... and out to the workgroup's slot of the scratch matrix: [64 rows][16 NT] floats behind the bias partials
+template <int NT>
+__device__ __forceinline__ void tc_dw_part(const f32x4 (&acc)[NT], float* dst, int mt, int lane) {
+  const int l15 = lane & 15, kk = lane >> 4;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dst[(16 * mt + 4 * kk + r) * (16 * NT) + 16 * t + l15] = acc[t][r];
+}
+
 // acc[j][c] += W[row tile rt0 + j][all k] . img[col tile ct0 + c].  w = the weight stream as a buffer resource (fs_common.hip.h: one
 // 32-bit lane offset for the whole kernel, fragment offsets in SGPRs), woff = byte offset of fragment (rt0, k-step 0) of the matrix.
 // VIEW4: the image was written one level finer ([4 rows][CPR / 4 chunks] per row of this view); same bytes, the finer image's swizzle.
@@ -349,9 +401,10 @@ __global__ __launch_bounds__(256, 2) void tail_fwd_kernel(const TanteTailFwd A) 
 // Bias gradients of the decoder stages (column sums of the V operands folded over the taps).  Adding them from every workgroup with
 // atomics took 150 us of the first form's 210 us launch: 1 536 same-address adds per bias element, and device-scope atomics to one address
 // are served one behind the other at the memory side.  Each wave STORES the column sums of its accumulators into the workgroup's row of a
-// scratch matrix (TC_WS floats per workgroup and order: [wave][64] stage-3 sums | [128] stage-2 sums | [16] field sums) and a small second
+// scratch matrix (per workgroup one slot per order and one for the encoder: [wave][64] stage-3 sums | [128] stage-2 sums | [16] field sums |
+// the pixel-level weight gradient's partial) and a small second
 // kernel (tail_bias_reduce_kernel, launched by tante_tail_bwd) adds the column sums of that matrix to the gradients.
-constexpr int TC_WS = 512;
+constexpr int TC_WS = 512 + 64 * 48;      // per workgroup and slot: 512 bias partials | the pixel-level weight gradient's partial, [64][16 RT3]
 template <int RTW, int CTW>
 __device__ __forceinline__ void tc_bias_part(const f32x4 (&g)[RTW][CTW], float* dst, int lane) {
   const int l15 = lane & 15, kk = lane >> 4;
@@ -368,12 +421,13 @@ __device__ __forceinline__ void tc_bias_part(const f32x4 (&g)[RTW][CTW], float* 
 }
 struct TcRed {
   const float* ws;
-  float* db1[TANTE_TAIL_MAX_ORD];
-  float* db2[TANTE_TAIL_MAX_ORD];
-  float* db3[TANTE_TAIL_MAX_ORD];
-  int n_ord, tiles, D;
+  float* db1[TANTE_TAIL_MAX_ORD + 1];
+  float* db2[TANTE_TAIL_MAX_ORD + 1];
+  float* db3[TANTE_TAIL_MAX_ORD + 1];
+  float* dw[TANTE_TAIL_MAX_ORD + 1];      // (64, D, 2, 2) weight: element (row, (sub, d)) at ((row D + d) 4 + sub)
+  int n_slot, tiles, D, ncol;
 };
-// grid (8 column blocks of 64, n_ord, 16 row slices), 256 threads = 64 columns x 4 sub-slices
+// grid (ncol / 64 column blocks, n_slot, 16 row slices), 256 threads = 64 columns x 4 sub-slices
 __global__ __launch_bounds__(256) void tail_bias_reduce_kernel(const TcRed R) {
   __shared__ float part[4][64];
   const int col = blockIdx.x * 64 + (threadIdx.x & 63), sub = threadIdx.x >> 6, k = blockIdx.y;
@@ -381,10 +435,10 @@ __global__ __launch_bounds__(256) void tail_bias_reduce_kernel(const TcRed R) {
   const int stride = 4 * gridDim.z;
   int row = blockIdx.z * 4 + sub;
   for (; row + stride < R.tiles; row += 2 * stride) {
-    s0 += R.ws[((long)row * R.n_ord + k) * TC_WS + col];
-    s1 += R.ws[((long)(row + stride) * R.n_ord + k) * TC_WS + col];
+    s0 += R.ws[((long)row * R.n_slot + k) * TC_WS + col];
+    s1 += R.ws[((long)(row + stride) * R.n_slot + k) * TC_WS + col];
   }
-  if (row < R.tiles) s0 += R.ws[((long)row * R.n_ord + k) * TC_WS + col];
+  if (row < R.tiles) s0 += R.ws[((long)row * R.n_slot + k) * TC_WS + col];
   part[sub][threadIdx.x & 63] = s0 + s1;
   __syncthreads();
   if (sub != 0) return;
@@ -392,7 +446,14 @@ __global__ __launch_bounds__(256) void tail_bias_reduce_kernel(const TcRed R) {
   float* dst = nullptr;
   if (col < 256) dst = R.db2[k] ? R.db2[k] + (col & 63) : nullptr;
   else if (col < 384) dst = R.db1[k] ? R.db1[k] + (col - 256) : nullptr;
-  else if (col < 384 + R.D) dst = R.db3[k] ? R.db3[k] + (col - 384) : nullptr;
+  else if (col < 512) dst = (R.db3[k] && col < 384 + R.D) ? R.db3[k] + (col - 384) : nullptr;
+  else if (R.dw[k]) {
+    const int w = (R.ncol - 512) / 64, q = col - 512, r = q / w, n = q - r * w;      // w = 16 RT3 columns per row
+    if (n < 4 * R.D) {
+      const int sb = n / R.D, d = n - sb * R.D;
+      dst = R.dw[k] + ((long)r * R.D + d) * 4 + sb;
+    }
+  }
   if (dst) atomicAdd(dst, v);
 }
 
@@ -471,11 +532,25 @@ __global__ __launch_bounds__(256, 2) void tail_bwd_kernel(const TanteTailBwd A) 
       for (int j = 0; j < 4; ++j) {
         const int rt = 4 * wave + j, sub = rt >> 2, ch0 = (rt & 3) * 16 + 4 * kk;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) tc_put4<8>(rY, 4 * (16 * c + l15) + sub, ch0, tc_pack4(acc[j][c] * tc_gelu_grad4(tc_unpack4(p1[j][c]))));
+        for (int c = 0; c < 4; ++c) {
+          acc[j][c] = acc[j][c] * tc_gelu_grad4(tc_unpack4(p1[j][c]));
+          tc_put4<8>(rY, 4 * (16 * c + l15) + sub, ch0, tc_pack4(acc[j][c]));
+        }
       }
+      // the first stage's bias gradient: column sums of these values (wave w holds tap w of all 64 channels)
+      if (A.bias_ws && A.dwe1) tc_bias_part<4, 4>(acc, A.bias_ws + ((long)tile * (A.n_ord + 1) + A.n_ord) * TC_WS + 64 * wave, lane);
     }
-    __syncthreads();
-    tc_img_out<8, 256>(rY, (char*)A.dpre1e + tok0 * 2048, tid);
+    __syncthreads();      // region X (stage 2's input) is consumed, region Y holds dpre1e
+    if (A.dpre1e) tc_img_out<8, 256>(rY, (char*)A.dpre1e + tok0 * 2048, tid);
+    if (A.dwe1 && A.bias_ws) {      // the first stage's weight gradient of this tile: dpre1e^T . frame patches
+      tc_img_in<8, 256>(rX, (const char*)A.f16 + tok0 * 2048, tid);
+      __syncthreads();
+      f32x4 dwp[RT3];
+#pragma unroll
+      for (int t = 0; t < RT3; ++t) dwp[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      tc_rows_outer<RT3>(rY, wave, rX, lane, dwp);
+      tc_dw_part<RT3>(dwp, A.bias_ws + ((long)tile * (A.n_ord + 1) + A.n_ord) * TC_WS + 512, wave, lane);
+    }
     if (A.n_ord == 0 && !A.dbase) return;      // encoder of INPUT frames: the weight-gradient operands are all that is asked for
     // stage 1 backwards: 64 -> (sub3, d): the encoder's share of the frame's gradient
     tc_gemm<2, 8, RT3, 4>(w_we, EB_X23, rY, 4 * wave, lane, dfr);
@@ -520,7 +595,9 @@ __global__ __launch_bounds__(256, 2) void tail_bwd_kernel(const TanteTailBwd A) 
   for (int k = 0; k < A.n_ord; ++k) {
     const TanteTailOrdB& O = A.o[k];
     const FsW w_wb = fs_wstream((const char*)O.w, (unsigned)(lane * 16));
-    float* const wsrow = A.bias_ws ? A.bias_ws + ((long)tile * A.n_ord + k) * TC_WS : nullptr;
+    float* const wsrow = A.bias_ws ? A.bias_ws + ((long)tile * (A.n_ord + 1) + k) * TC_WS : nullptr;
+    const bool dw_here = wsrow && O.dw3 && O.act2;
+    if (dw_here) tc_img_in<8, 256>(rY, (const char*)O.act2 + tok0 * 2048, tid);      // (region Y is free: the frame tile / the last order's rows have left)
     if (wsrow && (tid & 15) == 0 && (tid >> 4) < 16) wsrow[384 + (tid >> 4)] = (tid >> 4) < D ? O.coef * fsum : 0.0f;
     char* const L3 = rX;
 #pragma unroll
@@ -540,7 +617,15 @@ __global__ __launch_bounds__(256, 2) void tail_bwd_kernel(const TanteTailBwd A) 
         for (int c = 0; c < 4; ++c) q2[j][c] = tc_ld8(gpre, l15 * 128 + kk * 8, (4 * wave + c) * 2048 + j * 32);
     }
     __syncthreads();
-    tc_img_out<8, 256>(L3, (char*)O.dder + tok0 * 2048, tid);
+    if (O.dder) tc_img_out<8, 256>(L3, (char*)O.dder + tok0 * 2048, tid);
+    if (dw_here) {      // the last stage's weight gradient of this tile: act2^T . derivative-gradient patches
+      f32x4 dwp[RT3];
+#pragma unroll
+      for (int t = 0; t < RT3; ++t) dwp[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      tc_rows_outer<RT3>(rY, wave, L3, lane, dwp);
+      tc_dw_part<RT3>(dwp, wsrow + 512, wave, lane);
+      __syncthreads();      // region Y is written by the epilogue below
+    }
     {   // stage 3 backwards: (sub3, d) -> 64, times GELU'(pre2) -> Y[0 : 32K]
       f32x4 acc[4][4];
       tc_zero(acc);
@@ -697,7 +782,7 @@ extern "C" int tante_tail_supported(int C, int D, int Hp, int Wp) { return C == 
 
 extern "C" int64_t tante_tail_stream_bytes(int which) {
   switch (which) {
-    case 4: return (int64_t)TC_WS * 4;      // bias-gradient scratch: bytes per workgroup (16 tokens) and Taylor order
+    case 4: return (int64_t)TC_WS * 4;      // gradient scratch: bytes per workgroup (16 tokens) and slot (one per Taylor order + one for the encoder)
     case 0: return DF_BYTES;
     case 1: return DB_BYTES;
     case 2: return EF_BYTES;
@@ -755,11 +840,13 @@ extern "C" int tante_tail_bwd(const TanteTailBwd* a, void* stream) {
   if (int rc = tc_check_geom(a->n_ord, a->n_img, a->Hp, a->Wp, a->D, a->a_n0, "tante_tail_bwd")) return rc;
   for (int k = 0; k < a->n_ord; ++k) {
     const TanteTailOrdB& o = a->o[k];
-    if (!o.w || !o.pre1 || !o.pre2 || !o.dpre1 || !o.dpre2 || !o.dder || !o.dx) TANTE_FAIL(-1, "tante_tail_bwd: order %d: null pointer", k);
+    if (!o.w || !o.pre1 || !o.pre2 || !o.dpre1 || !o.dpre2 || !o.dx) TANTE_FAIL(-1, "tante_tail_bwd: order %d: null pointer", k);
+    if (!o.dder && !(o.dw3 && o.act2 && a->bias_ws)) TANTE_FAIL(-1, "tante_tail_bwd: order %d: the last stage's weight gradient needs dder, or dw3 + act2 + bias_ws", k);
   }
   if (!a->dz && !a->dext) TANTE_FAIL(-1, "tante_tail_bwd: no gradient arrives (dz and dext are both null)");
   if (a->n_ord == 0 && !a->dz) TANTE_FAIL(-1, "tante_tail_bwd: neither a decoder nor the encoder to run");
-  if (a->dz && (!a->we || !a->pre1e || !a->pre2e || !a->dz16 || !a->dpre2e || !a->dpre1e)) TANTE_FAIL(-1, "tante_tail_bwd: encoder operands missing");
+  if (a->dz && (!a->we || !a->pre1e || !a->pre2e || !a->dz16 || !a->dpre2e)) TANTE_FAIL(-1, "tante_tail_bwd: encoder operands missing");
+  if (a->dz && !a->dpre1e && !(a->dwe1 && a->f16 && a->bias_ws)) TANTE_FAIL(-1, "tante_tail_bwd: the first encoder stage's weight gradient needs dpre1e, or dwe1 + f16 + bias_ws");
   const long tiles = (long)a->n_img * a->Hp * a->Wp / 16;
   const int rt3 = (4 * a->D + 15) / 16;
   static TantePerDevice attr;
@@ -772,13 +859,15 @@ extern "C" int tante_tail_bwd(const TanteTailBwd* a, void* stream) {
   }
   if (a->bias_ws) {
     TcRed R;
-    R.ws = a->bias_ws; R.n_ord = a->n_ord; R.tiles = (int)tiles; R.D = a->D;
-    for (int k = 0; k < TANTE_TAIL_MAX_ORD; ++k) {
-      R.db1[k] = k < a->n_ord ? a->o[k].db1 : nullptr;
-      R.db2[k] = k < a->n_ord ? a->o[k].db2 : nullptr;
-      R.db3[k] = k < a->n_ord ? a->o[k].db3 : nullptr;
+    R.ws = a->bias_ws; R.n_slot = a->n_ord + 1; R.tiles = (int)tiles; R.D = a->D; R.ncol = 512 + 64 * 16 * rt3;
+    for (int k = 0; k <= TANTE_TAIL_MAX_ORD; ++k) {
+      const bool ord = k < a->n_ord, enc = k == a->n_ord && a->dz && a->dwe1;
+      R.db1[k] = ord ? a->o[k].db1 : nullptr;
+      R.db2[k] = ord ? a->o[k].db2 : (enc ? a->dbe1 : nullptr);
+      R.db3[k] = ord ? a->o[k].db3 : nullptr;
+      R.dw[k] = ord ? (a->o[k].act2 ? a->o[k].dw3 : nullptr) : (enc ? a->dwe1 : nullptr);
     }
-    hipLaunchKernelGGL(tail_bias_reduce_kernel, dim3(8, (unsigned)a->n_ord, 16), dim3(256), 0, s, R);
+    hipLaunchKernelGGL(tail_bias_reduce_kernel, dim3((unsigned)(R.ncol / 64), (unsigned)R.n_slot, 16), dim3(256), 0, s, R);
   }
   TANTE_CHECK_LAUNCH();
   return 0;
