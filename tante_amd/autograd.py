@@ -1546,7 +1546,8 @@ class TailFn(Function):
     cfg = TailCfg, xs[k] = order k's residual stream (B * T * HW, C) fp32 (its last time slot is read).  Outputs: the predicted frame
     (B, 1, D, H, W) and its pre-FiLM encoding (B, HW, C) (None when cfg.want_z is False: the rollout's last call).
     Parameter gradients go straight into the parameters' gradient slots (cfg checked that every one exists): the four wide weight
-    gradients as recorded uses of the shared end-of-pass launches, the two pixel-level ones (J = 4 D columns) immediately."""
+    gradients as recorded uses of the shared end-of-pass launches, the two pixel-level ones (64 x 4 D) and the decoder biases inside the
+    backward launch (per-workgroup partials + a small reduce launch; PIXEL_WGRAD_IN_KERNEL off: from row operands, immediately)."""
 
     @staticmethod
     def forward(ctx, base, cfg, *xs):
@@ -1562,10 +1563,8 @@ class TailFn(Function):
         out = torch.empty(B, 1, D, 8 * Hp, 8 * Wp, dtype=torch.float32, device=dev)
         a.base, a.base_bstride, a.out, a.out_bstride = base.data_ptr(), base.stride(0), out.data_ptr(), out.stride(0)
         saved = []
-        keep = [base]
         for k, x in enumerate(xs):
-            x = x.contiguous()
-            keep.append(x)
+            x = x.contiguous()      # (kernels on one stream: the caching allocator does not hand a temporary's memory out before they have run)
             o = a.o[k]
             t = {"xl16": torch.empty(Tk, 256, dtype=bf, device=dev), "pre1": torch.empty(4 * Tk, 128, dtype=bf, device=dev),
                  "act1": torch.empty(4 * Tk, 128, dtype=bf, device=dev), "pre2": torch.empty(16 * Tk, 64, dtype=bf, device=dev),

@@ -4,8 +4,9 @@
 //                               predicted frame -> its re-encoding for the next call's window (enc_dec_cnn.py:217-229), with every
 //                               pre-activation / activation the backward pass reads stored on the way;
 //   backward (tante_tail_bwd):  encoder stages backwards -> + the frame's other gradients -> Taylor backwards -> every order's decoder
-//                               stages backwards -> gradient of the residual stream's last time slot, with the row operands of all six
-//                               weight gradients written as dense bf16 matrices (the shared weight-gradient launches read them).
+//                               stages backwards -> gradient of the residual stream's last time slot, with the row operands of the four
+//                               wide weight gradients written as dense bf16 matrices (the shared weight-gradient launches read them) and
+//                               the two pixel-level weight gradients + the decoder biases' as per-workgroup partials (a reduce launch).
 //
 // The inference path has had the forward as one launch since round 4 (head_enc.hip).  The training path ran it as 13 launches per call
 // and its backward as ~33 (GEMM, activation, im2col, column sum, small weight gradient + reduce, Taylor, slice copies: 5 - 25 us each,
