@@ -622,11 +622,12 @@ def main():
         weak, nbytes = train_leg(twl["batch_size"], args.train_steps)
         train = {"metric": "train-step samples/sec, TANTE on 128x384 TRL-2D (4-step BPTT, MSE, clip, AdamW)", "scaling": "weak", **weak,
                  "dropout": drop,
-                 "collective": ("%s all-reduce(sum) of the flat fp32 gradient bucket, %d bytes per step in %d call(s) of %s elements (the part "
-                                "the end-of-pass weight-gradient flush does not write goes out on a side stream while the flush runs, the rest "
-                                "behind it: dist.GradAllReduce); 1/world folded into clip + AdamW [%s]; UNMEASURED on more than one GPU in this round"
+                 "collective": ("%s all-reduce(sum) of the flat fp32 gradient bucket, %d bytes per step in %d call(s) of %s elements, %.2f of them issued "
+                                "beside compute (dist.GradAllReduce: what the end-of-pass weight-gradient flush does not write when the flush starts, "
+                                "the spans of each flush segment while the next one runs, the last segment's behind it; the ranks agreed on the call "
+                                "list once); 1/world folded into clip + AdamW [%s]; UNMEASURED on more than one GPU in this round"
                                 % ("RCCL" if backend == "nccl" else backend, nbytes, len(tante_amd.dist.LAST_CALLS), list(tante_amd.dist.LAST_CALLS),
-                                   tante_amd.dist.collective_info())) if world > 1 else None}
+                                   tante_amd.dist.LAST_OVERLAPPED[0], tante_amd.dist.collective_info())) if world > 1 else None}
         if 64 % world == 0 and not args.no_train_strong:
             strong, _ = train_leg(64 // world, max(1, args.train_steps if world > 1 else 2))
             train["strong"] = {"scaling": "strong", **strong}
