@@ -160,7 +160,15 @@ class TransformerBlock(nn.Module):
         """In place on the flat fp32 residual stream x (tokens, C); `seq` says which tokens attend to which.  tprop: the temporal
         propagator's packed weights, applied to the rows inside the fused launch (only when takes_tprop says so)."""
         if self.training and self.p_drop > 0.0:
-            raise NotImplementedError("dropout > 0 in training mode is not implemented on the HIP path yet")
+            # train() mode without autograd (a validation pass that forgot eval(), MC dropout): nn.Dropout and the attention's dropout are
+            # active whatever the grad mode (attn_backbone.py:47,56,81-82) -- the training forward's kernels, their saved tensors dropped
+            if tprop is not None:
+                raise RuntimeError("TransformerBlock.forward_tokens: tprop is an inference-path fusion (takes_tprop is False under dropout)")
+            from .train_forward import block_train
+            with torch.no_grad():
+                y = block_train(self, x.view(-1, self.embed_dim), seq, causal, compute)
+            x.view(-1, self.embed_dim).copy_(y)
+            return x
         C_ = self.embed_dim
         n_tok = x.numel() // C_
         if (compute == L.BF16 and self.fused and self.ln1.eps == self.ln2.eps

@@ -231,7 +231,10 @@ class PatchEmbed(nn.Module):
         super().__init__()
         self.patch_size, self.use_norm = tuple(patch_size), use_norm
         if self.patch_size[0] != 1:
-            raise NotImplementedError("temporal patches (patch_size[0] > 1) are not on the HIP path; every shipped config uses 1")
+            # (the reference itself cannot run them: Encoder.forward repeats s_emb over the INPUT's t while the patch-embedded sequence has
+            # t / patch_size[0] steps, cvit.py:293-296 -> a shape error in `x + t_emb + s_emb`; verified with patch_size (2, 8, 8))
+            raise NotImplementedError("temporal patches (patch_size[0] > 1): the reference's Encoder.forward raises for them (cvit.py:293-296); "
+                                      "every shipped config uses 1")
         self.conv = nn.Conv3d(n_channel, emb_dim, kernel_size=self.patch_size, stride=self.patch_size)
         if use_norm:
             self.layer_norm = nn.LayerNorm(emb_dim, eps=layer_norm_eps)
