@@ -358,6 +358,12 @@ int tante_head_fused_multi_streams(int n_ord, const float* const* rows, const vo
  * (attn_backbone.py:59-72); the TANTE path passes `causal` only, so this is a completeness kernel (one lane per query). */
 int tante_attention_masked(const void* qkv, void* o, int dtype, int C, int n_head, int Bp, int L, int causal, const float* attn_mask,
                            int64_t mask_bstride, const float* key_padding_mask, void* stream);
+/* Its backward: dqkv (tokens, 3C) = (dq | dk | dv) from dO (tokens, C), probabilities recomputed from qkv under the same masks (no
+ * attention dropout on this path).  stats: Bp * n_head * L * 3 floats of scratch (row max, 1 / row sum, dO . O).  Also the train
+ * path's fallback for dense sequences longer than tante_attention_bwd takes (L > 128: the channel letter 'C' over 256 channels,
+ * attn_backbone.py:176-184).  Head dims 4, 8, 16, 32, 64.  Deterministic (fixed-order sums, no atomics). */
+int tante_attention_masked_bwd(const void* qkv, const void* dO, void* dqkv, int dtype, int C, int n_head, int Bp, int L, int causal,
+                               const float* attn_mask, int64_t mask_bstride, const float* key_padding_mask, float* stats, void* stream);
 
 /* ---- the token-local tail of a rollout call in ONE launch (head_enc.hip; bf16, C = 256, D <= 16, Hp Wp % 16 == 0) -----------------
  * tante_head_enc_fused: every Taylor order's derivative head + the Taylor sum (as tante_head_fused_multi_streams: rows[k] = the residual

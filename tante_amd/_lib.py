@@ -231,6 +231,7 @@ SIGNATURES = {
                                      c_i64, c_vp], c_i32),
     "tante_get_option": ([C.c_char_p, c_i32], c_i32),
     "tante_attention_masked": ([c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp, c_vp], c_i32),
+    "tante_attention_masked_bwd": ([c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i64, c_vp, c_vp, c_vp], c_i32),
     "tante_head_enc_supported": ([c_i32, c_i32], c_i32),
     "tante_head_enc_stream_bytes": ([c_i32], c_i64),
     "tante_head_enc_ws_bytes": ([c_i64], c_i64),
@@ -250,7 +251,7 @@ LIB_OPTIONS = ("TANTE_ATTN_BWD_HG", "TANTE_ATTN_BWD_NO_SPLIT", "TANTE_ATTN_BWD_V
 
 
 _lib = None
-ABI_VERSION = 10     # include/tante_hip.h: bumped whenever an entry point is added or changes (round 4: 6 tante_head_enc_*, 7 tante_pos_embed_tmajor + tante_spectral_*bf16out*; round 5: 8 tante_block_bwd_fused, 9 TanteGemm.a_pad; round 6: 10 tante_tail_*)
+ABI_VERSION = 11     # include/tante_hip.h: bumped whenever an entry point is added or changes (round 4: 6 tante_head_enc_*, 7 tante_pos_embed_tmajor + tante_spectral_*bf16out*; round 5: 8 tante_block_bwd_fused, 9 TanteGemm.a_pad; round 6: 10 tante_tail_*, 11 tante_attention_masked_bwd)
 
 
 def lib():

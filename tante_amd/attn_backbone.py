@@ -193,13 +193,25 @@ class TransformerBlock(nn.Module):
     def forward(self, x: torch.Tensor, key_padding_mask=None, attn_mask=None, causal: bool = False) -> torch.Tensor:
         """attn_backbone.py:59-83.  `causal` is what the TANTE path uses (l.148-189); `attn_mask` (bool: True = blocked, or additive float;
         (L, L) or (B * n_head, L, L)) and `key_padding_mask` ((B, L) bool: True = ignored, or additive float) follow
-        nn.MultiheadAttention's semantics and run the masked attention kernel of the unfused path (inference only)."""
+        nn.MultiheadAttention's semantics and run the masked attention kernels of the unfused path (forward, and the recomputing backward
+        under autograd; no attention dropout there).  `causal` next to an attn_mask follows what the reference's call computes, which
+        depends on the mode (see below)."""
         _gpu_only(x)
         Bp, Lq, C_ = x.shape
         compute = resolve_compute(self.compute)
+        if causal and attn_mask is not None and key_padding_mask is None and (self.training or _wants_grad(self, x)):
+            # What the reference computes here is PLAIN causal attention: it hands nn.MultiheadAttention `attn_mask.bool() | causal_mask`
+            # together with is_causal=True, need_weights=False (attn_backbone.py:70-80), and torch's multi_head_attention_forward -- the path
+            # taken in train() mode or when anything requires grad -- treats is_causal without a key_padding_mask as "the mask IS the causal
+            # mask" and drops the tensor.  Only eval() without autograd (torch's fused fast path) applies the combined mask.  Fixture
+            # g17_block_masked_grad_ambool_causal pins the reference's actual output and gradients.
+            attn_mask = None
         if key_padding_mask is not None or attn_mask is not None:
             if _wants_grad(self, x):
-                raise NotImplementedError("attn_mask / key_padding_mask are implemented on the inference path (the TANTE path uses `causal` only)")
+                from .train_forward import block_train
+                masks = self._masks(x.device, Bp, Lq, causal, key_padding_mask, attn_mask)
+                y = block_train(self, x.to(torch.float32).reshape(Bp * Lq, C_).contiguous(), K.dense_seq(Bp, Lq), causal, compute, masks)
+                return y.view(Bp, Lq, C_)
             y = x.detach().to(torch.float32).contiguous().clone()
             self._forward_masked(y.view(Bp * Lq, C_), Bp, Lq, causal, compute, key_padding_mask, attn_mask)
             return y
@@ -211,10 +223,9 @@ class TransformerBlock(nn.Module):
         self.forward_tokens(y.view(Bp * Lq, C_), K.dense_seq(Bp, Lq), causal, compute)
         return y
 
-    def _forward_masked(self, x: torch.Tensor, Bp: int, Lq: int, causal: bool, compute: int, key_padding_mask, attn_mask) -> torch.Tensor:
-        """The unfused block with the masked attention kernel (tante_attention_masked): masks as ONE additive fp32 tensor pair."""
-        C_, nh = self.embed_dim, self.n_head
-        dev = x.device
+    def _masks(self, dev, Bp: int, Lq: int, causal: bool, key_padding_mask, attn_mask):
+        """nn.MultiheadAttention's masks as ONE additive fp32 tensor pair (attn_mask (1, L, L) | (Bp n_head, L, L) | None, kpm (Bp, L) | None)."""
+        nh = self.n_head
         ninf = float("-inf")
         am = None
         if attn_mask is not None:
@@ -238,13 +249,20 @@ class TransformerBlock(nn.Module):
             if kp.dtype == torch.bool:
                 kp = torch.zeros(kp.shape, dtype=torch.float32, device=dev).masked_fill_(kp, ninf)
             kp = kp.to(torch.float32).contiguous()
+        return am, kp
+
+    def _forward_masked(self, x: torch.Tensor, Bp: int, Lq: int, causal: bool, compute: int, key_padding_mask, attn_mask) -> torch.Tensor:
+        """The unfused block with the masked attention kernel (tante_attention_masked)."""
+        C_ = self.embed_dim
+        dev = x.device
+        am, kp = self._masks(dev, Bp, Lq, causal, key_padding_mask, attn_mask)
         pk = self._packed(compute)
         adt = K.act_torch_dtype(compute)
         n_tok = Bp * Lq
         qkv = torch.empty(n_tok, 3 * C_, dtype=adt, device=dev)
         K.linear(x, pk["qkv"], qkv, M=n_tok, ln=True, ln_eps=self.ln1.eps)
         o = torch.empty(n_tok, C_, dtype=adt, device=dev)
-        K.attention_masked(qkv, o, C_, nh, Bp, Lq, causal, am, kp)
+        K.attention_masked(qkv, o, C_, self.n_head, Bp, Lq, causal, am, kp)
         K.linear(o, pk["out"], x, M=n_tok, residual=x)
         h = torch.empty(n_tok, self.hidden, dtype=adt, device=dev)
         K.linear(x, pk["fc1"], h, M=n_tok, ln=True, ln_eps=self.ln2.eps, act=L.ACT_GELU_TANH)

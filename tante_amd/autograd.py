@@ -1031,9 +1031,45 @@ class AttentionFn(Function):
         (qkv,) = ctx.saved_tensors
         do = do.contiguous().to(qkv.dtype)
         dqkv = torch.empty_like(qkv)
+        q = ctx.seq
+        if q.L > 128 and ctx.p == 0.0 and q.n_s0 == 1 and q.S1 == q.L and q.n_l0 >= q.L and q.P0 == 1:
+            # dense sequences past the MFMA backward's length (the channel letter 'C' over 256 channels, 'L' over a 16 x 16 patch grid):
+            # the lane-per-row recomputing backward (tante_attention_masked_bwd with no masks)
+            stats = torch.empty(q.nseq * ctx.nh * q.L * 3, dtype=torch.float32, device=qkv.device)
+            L.check(L.lib().tante_attention_masked_bwd(qkv.data_ptr(), do.data_ptr(), dqkv.data_ptr(), _DT[qkv.dtype], ctx.C, ctx.nh, q.nseq, q.L,
+                                                       int(ctx.causal), None, 0, None, stats.data_ptr(), _s()), "attention_masked_bwd")
+            return dqkv, None, None, None, None, None, None
         L.check(L.lib().tante_attention_bwd(qkv.data_ptr(), do.data_ptr(), dqkv.data_ptr(), _DT[qkv.dtype], ctx.C, ctx.nh, C.byref(ctx.seq),
                                             int(ctx.causal), ctx.p, ctx.seed, _s()), "attention_bwd")
         return dqkv, None, None, None, None, None, None
+
+
+class MaskedAttentionFn(Function):
+    """AttentionFn over dense (Bp, L) sequences with nn.MultiheadAttention's masks as additive fp32 tensors (attn_backbone.py:59-72):
+    attn_mask (1, L, L) or (Bp * n_head, L, L), key_padding_mask (Bp, L), either None.  No attention dropout on this path."""
+
+    @staticmethod
+    def forward(ctx, qkv, Cc, n_head, Bp, Lq, causal, attn_mask, key_padding_mask):
+        o = torch.empty(qkv.shape[0], Cc, dtype=qkv.dtype, device=qkv.device)
+        K.attention_masked(qkv, o, Cc, n_head, Bp, Lq, causal, attn_mask, key_padding_mask)
+        ctx.save_for_backward(qkv)
+        ctx.a = (Cc, n_head, Bp, Lq, int(causal))
+        ctx.masks = (attn_mask, key_padding_mask)      # constants (no gradient): kept alive for the backward launch
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        (qkv,) = ctx.saved_tensors
+        Cc, nh, Bp, Lq, causal = ctx.a
+        am, kp = ctx.masks
+        do = do.contiguous().to(qkv.dtype)
+        dqkv = torch.empty_like(qkv)
+        stats = torch.empty(Bp * nh * Lq * 3, dtype=torch.float32, device=qkv.device)
+        stride = 0 if am is None or am.shape[0] == 1 else Lq * Lq
+        L.check(L.lib().tante_attention_masked_bwd(qkv.data_ptr(), do.data_ptr(), dqkv.data_ptr(), _DT[qkv.dtype], Cc, nh, Bp, Lq, causal,
+                                                   am.data_ptr() if am is not None else None, stride,
+                                                   kp.data_ptr() if kp is not None else None, stats.data_ptr(), _s()), "attention_masked_bwd")
+        return dqkv, None, None, None, None, None, None, None
 
 
 class DropoutAddFn(Function):

@@ -474,13 +474,159 @@ extern "C" int tante_attention_masked(const void* qkv, void* o, int dtype, int C
   hipStream_t s = (hipStream_t)stream;
 #define TANTE_AM(DD) hipLaunchKernelGGL(attn_masked_kernel<DD>, grid, block, 0, s, qkv, o, dtype, C, n_head, Bp, L, causal, scale, attn_mask, (long)mask_bstride, key_padding_mask)
   switch (D) {
+    case 4: TANTE_AM(4); break;
     case 8: TANTE_AM(8); break;
     case 16: TANTE_AM(16); break;
     case 32: TANTE_AM(32); break;
     case 64: TANTE_AM(64); break;
-    default: TANTE_FAIL(-2, "tante_attention_masked: head dim %d (8, 16, 32, 64)", D);
+    default: TANTE_FAIL(-2, "tante_attention_masked: head dim %d (4, 8, 16, 32, 64)", D);
   }
 #undef TANTE_AM
+  TANTE_CHECK_LAUNCH();
+  return 0;
+}
+
+// The masked attention's BACKWARD, and the train path's fallback for sequences the MFMA backward does not take (L > 128: the channel
+// letter 'C' over 256 channels).  Two lane-per-row passes over the same additive masks, recomputing the probabilities from q, k:
+//   pass Q (one lane per (b, h, query)):  m, 1/sum and delta = dO . O by the forward's online recurrence, then
+//                                          dq = scale * sum_j p_j (dO . v_j - delta) k_j;  (m, 1/sum, delta) go to `stats`
+//   pass K (one lane per (b, h, key)):    dv = sum_i p_ij dO_i,  dk = scale * sum_i p_ij (dO_i . v_j - delta_i) q_i
+// Plain sums in a fixed order: deterministic, no atomics.  A completeness kernel like the forward (VALU, global-memory operands).
+namespace {
+template <int D>
+__global__ __launch_bounds__(256) void attn_masked_bwd_q_kernel(const void* __restrict__ qkv, const void* __restrict__ dO, void* __restrict__ dqkv,
+                                                                int dtype, int C, int n_head, int Bp, int L, int causal, float scale,
+                                                                const float* __restrict__ amask, long mask_bstride,
+                                                                const float* __restrict__ kpm, float* __restrict__ stats) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;      // (b, h, l)
+  if (idx >= (long)Bp * n_head * L) return;
+  const int l = (int)(idx % L), h = (int)((idx / L) % n_head), b = (int)(idx / ((long)L * n_head));
+  float q[D], g[D], acc[D];
+  load_row<D>(qkv, dtype, ((long)b * L + l) * 3 * C + h * D, q);
+  load_row<D>(dO, dtype, ((long)b * L + l) * C + h * D, g);
+#pragma unroll
+  for (int i = 0; i < D; ++i) { q[i] *= scale; acc[i] = 0.f; }
+  float m = -INFINITY, ssum = 0.f;
+  const float* am = amask ? amask + ((long)b * n_head + h) * mask_bstride + (long)l * L : nullptr;
+  const float* kp = kpm ? kpm + (long)b * L : nullptr;
+  const int jmax = causal ? l + 1 : L;
+  for (int j = 0; j < jmax; ++j) {
+    float k[D], v[D];
+    load_row<D>(qkv, dtype, ((long)b * L + j) * 3 * C + C + h * D, k);
+    float sc = 0.f;
+#pragma unroll
+    for (int i = 0; i < D; ++i) sc += q[i] * k[i];
+    if (am) sc += am[j];
+    if (kp) sc += kp[j];
+    if (sc == -INFINITY) continue;
+    load_row<D>(qkv, dtype, ((long)b * L + j) * 3 * C + 2 * C + h * D, v);
+    const float mn = fmaxf(m, sc);
+    const float corr = expf(m - mn), p = expf(sc - mn);
+    ssum = ssum * corr + p;
+#pragma unroll
+    for (int i = 0; i < D; ++i) acc[i] = acc[i] * corr + p * v[i];
+    m = mn;
+  }
+  const float inv = 1.0f / ssum;
+  float delta = 0.f;
+#pragma unroll
+  for (int i = 0; i < D; ++i) delta += g[i] * acc[i];
+  delta *= inv;
+  stats[idx * 3 + 0] = m;
+  stats[idx * 3 + 1] = inv;
+  stats[idx * 3 + 2] = delta;
+#pragma unroll
+  for (int i = 0; i < D; ++i) acc[i] = 0.f;      // now dq
+  for (int j = 0; j < jmax; ++j) {
+    float k[D], v[D];
+    load_row<D>(qkv, dtype, ((long)b * L + j) * 3 * C + C + h * D, k);
+    float sc = 0.f;
+#pragma unroll
+    for (int i = 0; i < D; ++i) sc += q[i] * k[i];
+    if (am) sc += am[j];
+    if (kp) sc += kp[j];
+    if (sc == -INFINITY) continue;
+    load_row<D>(qkv, dtype, ((long)b * L + j) * 3 * C + 2 * C + h * D, v);
+    float dp = 0.f;
+#pragma unroll
+    for (int i = 0; i < D; ++i) dp += g[i] * v[i];
+    const float ds = expf(sc - m) * inv * (dp - delta) * scale;
+#pragma unroll
+    for (int i = 0; i < D; ++i) acc[i] += ds * k[i];
+  }
+  store_row<D>(dqkv, dtype, ((long)b * L + l) * 3 * C + h * D, acc);
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void attn_masked_bwd_kv_kernel(const void* __restrict__ qkv, const void* __restrict__ dO, void* __restrict__ dqkv,
+                                                                 int dtype, int C, int n_head, int Bp, int L, int causal, float scale,
+                                                                 const float* __restrict__ amask, long mask_bstride,
+                                                                 const float* __restrict__ kpm, const float* __restrict__ stats) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;      // (b, h, key j)
+  if (idx >= (long)Bp * n_head * L) return;
+  const int j = (int)(idx % L), h = (int)((idx / L) % n_head), b = (int)(idx / ((long)L * n_head));
+  float k[D], v[D], dk[D], dv[D];
+  load_row<D>(qkv, dtype, ((long)b * L + j) * 3 * C + C + h * D, k);
+  load_row<D>(qkv, dtype, ((long)b * L + j) * 3 * C + 2 * C + h * D, v);
+#pragma unroll
+  for (int i = 0; i < D; ++i) { dk[i] = 0.f; dv[i] = 0.f; }
+  const float kpj = kpm ? kpm[(long)b * L + j] : 0.f;
+  const float* am = amask ? amask + ((long)b * n_head + h) * mask_bstride + j : nullptr;
+  const float* st = stats + ((long)b * n_head + h) * L * 3;
+  if (kpj != -INFINITY) {
+    for (int l = causal ? j : 0; l < L; ++l) {
+      float q[D], g[D];
+      load_row<D>(qkv, dtype, ((long)b * L + l) * 3 * C + h * D, q);
+      float sc = 0.f;
+#pragma unroll
+      for (int i = 0; i < D; ++i) { q[i] *= scale; sc += q[i] * k[i]; }
+      if (am) sc += am[(long)l * L];
+      sc += kpj;
+      if (sc == -INFINITY) continue;
+      load_row<D>(dO, dtype, ((long)b * L + l) * C + h * D, g);
+      const float p = expf(sc - st[l * 3 + 0]) * st[l * 3 + 1];
+      float dp = 0.f;
+#pragma unroll
+      for (int i = 0; i < D; ++i) { dv[i] += p * g[i]; dp += g[i] * v[i]; }
+      const float ds = p * (dp - st[l * 3 + 2]);
+#pragma unroll
+      for (int i = 0; i < D; ++i) dk[i] += ds * q[i];
+    }
+  }
+  store_row<D>(dqkv, dtype, ((long)b * L + j) * 3 * C + C + h * D, dk);
+  store_row<D>(dqkv, dtype, ((long)b * L + j) * 3 * C + 2 * C + h * D, dv);
+}
+}  // namespace
+
+extern "C" int tante_attention_masked_bwd(const void* qkv, const void* dO, void* dqkv, int dtype, int C, int n_head, int Bp, int L, int causal,
+                                          const float* attn_mask, int64_t mask_bstride, const float* key_padding_mask, float* stats,
+                                          void* stream) {
+  if (!qkv || !dO || !dqkv || !stats) TANTE_FAIL(-1, "tante_attention_masked_bwd: null pointer");
+  if (dtype != TANTE_F32 && dtype != TANTE_BF16) TANTE_FAIL(-2, "tante_attention_masked_bwd: dtype");
+  if (C <= 0 || n_head <= 0 || C % n_head || Bp <= 0 || L <= 0) TANTE_FAIL(-1, "tante_attention_masked_bwd: bad shape");
+  if (attn_mask && mask_bstride != 0 && mask_bstride != (int64_t)L * L)
+    TANTE_FAIL(-1, "tante_attention_masked_bwd: mask stride must be 0 (shared) or L * L");
+  const int D = C / n_head;
+  const float scale = 1.0f / sqrtf((float)D);
+  const long n = (long)Bp * n_head * L;
+  const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+  hipStream_t s = (hipStream_t)stream;
+#define TANTE_AMB(DD)                                                                                                                          \
+  do {                                                                                                                                          \
+    hipLaunchKernelGGL(attn_masked_bwd_q_kernel<DD>, grid, block, 0, s, qkv, dO, dqkv, dtype, C, n_head, Bp, L, causal, scale, attn_mask,       \
+                       (long)mask_bstride, key_padding_mask, stats);                                                                          \
+    hipLaunchKernelGGL(attn_masked_bwd_kv_kernel<DD>, grid, block, 0, s, qkv, dO, dqkv, dtype, C, n_head, Bp, L, causal, scale, attn_mask,      \
+                       (long)mask_bstride, key_padding_mask, (const float*)stats);                                                            \
+  } while (0)
+  switch (D) {
+    case 4: TANTE_AMB(4); break;
+    case 8: TANTE_AMB(8); break;
+    case 16: TANTE_AMB(16); break;
+    case 32: TANTE_AMB(32); break;
+    case 64: TANTE_AMB(64); break;
+    default: TANTE_FAIL(-2, "tante_attention_masked_bwd: head dim %d (4, 8, 16, 32, 64)", D);
+  }
+#undef TANTE_AMB
   TANTE_CHECK_LAUNCH();
   return 0;
 }

@@ -178,9 +178,27 @@ def prepare_blocks(model, compute: int):
     L.check(L.lib().tante_pack_block_train_multi(C.byref(bw), len(todo), todo[0].embed_dim, todo[0].hidden, K._stream()), "tante_pack_block_train_multi")
 
 
-def block_train(blk, x: torch.Tensor, seq, causal: bool, compute: int) -> torch.Tensor:
+def block_train(blk, x: torch.Tensor, seq, causal: bool, compute: int, masks=None) -> torch.Tensor:
+    """masks: None, or (attn_mask, key_padding_mask) as the additive fp32 tensors TransformerBlock._masks builds (dense sequences only):
+    the per-operator chain with the masked attention node."""
     BLOCK_CALLS[0] += 1
     p = blk.p_drop if blk.training else 0.0     # nn.Dropout / MHA dropout are active in train() mode only
+    if masks is not None:
+        if p > 0.0:
+            raise NotImplementedError("attn_mask / key_padding_mask under autograd with dropout > 0 in train() mode: the masked attention "
+                                      "kernels have no attention-probability dropout (the TANTE path passes `causal` only)")
+        from .autograd import MaskedAttentionFn
+        adt = K.act_torch_dtype(compute)
+        a, m = blk.attn, blk.mlp
+        w_in, b_in = _folded(a.in_proj_weight, a.in_proj_bias, blk.ln1)
+        xh, x = LayerNormSkipFn.apply(x, blk.ln1.eps, adt)
+        qkv = LinearFn.apply(xh, w_in, b_in, None, compute, adt)
+        o = MaskedAttentionFn.apply(qkv, blk.embed_dim, blk.n_head, seq.nseq, seq.L, causal, masks[0], masks[1])
+        x = BranchOutFn.apply(o, a.out_proj.weight, a.out_proj.bias, x, L.ACT_NONE, 0.0, compute)
+        w1, b1 = _folded(m[0].weight, m[0].bias, blk.ln2)
+        xh2, x = LayerNormSkipFn.apply(x, blk.ln2.eps, adt)
+        hpre = LinearFn.apply(xh2, w1, b1, None, compute, adt)
+        return BranchOutFn.apply(hpre, m[2].weight, m[2].bias, x, L.ACT_GELU_TANH, 0.0, compute)
     # Every later call of this block inside one rollout graph (the BPTT steps) takes the record its first call left in the fold scope:
     # folded weights, the three fragment streams, the decision for the one-node path: the module attribute chains, fold / stream look-ups
     # and accumulator checks below are ~60 us of host time per block call (the step is GPU-bound on the bench box, with ~2 ms of margin).

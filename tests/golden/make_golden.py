@@ -26,6 +26,7 @@ Fixture index:
   g12_spectral_*     SpectralLayer (modes below / above the spectrum size) and TANTE(enc_dec_type='fno') tiny
   g13_deg_false      adaptive-dt forward composed from the reference's own sub-modules
   g15_*              gradients of 'same'-padded encoder / decoder stages (patch_scale 16 / 32 / 64) and of the channel-attention letter 'C'
+  g17_*              gradients through TransformerBlock's attn_mask / key_padding_mask forms, and the letter 'C' over 256 channels
   g14_trainstep_wide production-shape train step (C=256, 8 heads x 32, "THWTHWTHW", L in {4, 8, 48}): loss, per-parameter gradient
                      norms, three full gradient tensors.  Weights (4.2 M) and inputs are NOT stored: both come from seeded CPU
                      generators (manual_seed(14) before the constructor; Generator(1414) for the fields) and the fixture holds their
@@ -481,7 +482,55 @@ def g16():
         save(f"g16_encdec_grad_ps{ps}_ov{int(round(ov * 100))}", **arrs, **sd_np(e, "enc."), **sd_np(d, "dec."))
 
 
+def g17():
+    """Round 6: GRADIENTS through TransformerBlock.forward(x, key_padding_mask, attn_mask, causal) (attn_backbone.py:59-83) with masks --
+    a bool (L, L) attn_mask, a float additive one, a per-(batch, head) one, a bool key_padding_mask, and bool mask | causal -- and through
+    the channel letter 'C' over 256 channels (sequences of 256: past the length the block backward kernels take).  Recipe of g15."""
+    L_, C = 12, 64
+    cases = {}
+    gen = torch.Generator().manual_seed(1717)
+    am_bool = torch.rand(L_, L_, generator=gen) < 0.3
+    am_bool[torch.arange(L_), torch.arange(L_)] = False                      # every query keeps its own key: no all-blocked row
+    am_float = torch.randn(L_, L_, generator=gen)
+    am_bh = torch.randn(3 * 4, L_, L_, generator=gen)
+    am_bh[torch.rand(3 * 4, L_, L_, generator=gen) < 0.2] = float("-inf")
+    am_bh[:, torch.arange(L_), torch.arange(L_)] = 0.0
+    kp = torch.zeros(3, L_, dtype=torch.bool)
+    kp[0, -3:] = True
+    kp[2, 1] = True
+    cases["ambool"] = dict(attn_mask=am_bool)
+    cases["amfloat"] = dict(attn_mask=am_float)
+    cases["ambh_kp"] = dict(attn_mask=am_bh, key_padding_mask=kp)
+    cases["kp"] = dict(key_padding_mask=kp)
+    cases["ambool_causal"] = dict(attn_mask=am_bool, causal=True)
+    for name, kw in cases.items():
+        torch.manual_seed(1700 + len(name))
+        blk = TransformerBlock(C, 4, mlp_ratio=2.0, dropout=0.0).train()
+        x = torch.randn(3, L_, C, requires_grad=True)
+        y = blk(x, **kw)
+        w = torch.randn_like(y)
+        (y * w).sum().backward()
+        arrs = {"x": x.detach().numpy(), "y": y.detach().numpy(), "w": w.numpy(), "dx": x.grad.numpy(), "meta": np.array([L_, C, 4, int(kw.get("causal", False))])}
+        for k, v in kw.items():
+            if k != "causal":
+                arrs[k] = v.numpy()
+        for k, q in blk.named_parameters():
+            arrs["g." + k] = q.grad.numpy().copy()
+        save(f"g17_block_masked_grad_{name}", **arrs, **sd_np(blk))
+    T, H, W, C = 2, 2, 3, 256
+    torch.manual_seed(1790)
+    bb = Attn_Backbone((T, H, W, C), "C", expanded_channel=16, n_head=4, mlp_ratio=1.0, dropout=0.0).train()
+    x = torch.randn(1, T, H, W, C, requires_grad=True)
+    y = bb(x)
+    w = torch.randn_like(y)
+    (y * w).sum().backward()
+    arrs = {"x": x.detach().numpy(), "y": y.detach().numpy(), "w": w.numpy(), "dx": x.grad.numpy(), "meta": np.array([T, H, W, C, 16, 4])}
+    for k, q in bb.named_parameters():
+        arrs["g." + k] = q.grad.numpy().copy()
+    save("g17_backbone_grad_C256", **arrs, **sd_np(bb))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17"]
     for w in which:
         globals()[w]()
