@@ -841,6 +841,20 @@ __global__ __launch_bounds__(256) void format_input_kernel(const float* __restri
     if (tid < np) dst[(long)d * HW + tid] = nan_to_num_f(fsm[tid * (D + 1) + d]);
 }
 
+// D = 4 (cfg2 / cfg3: four fields): a lane takes FOUR consecutive pixels -- four 16-byte loads of 64 contiguous bytes, a 4 x 4 transpose in
+// registers, one 16-byte store per channel row.  The generic kernel above moves 4 bytes per lane and instruction through LDS: 39.7 us per
+// rollout at cfg2 for 12.6 MB (r06_rollout_kernel_stats.csv).  Needs HW % 4 == 0 and 16-byte aligned rows.
+__global__ __launch_bounds__(256) void format_input_d4_kernel(const float* __restrict__ x, long HW, int T, float* __restrict__ out, long out_bstride) {
+  const long img = blockIdx.y, q = (long)blockIdx.x * 256 + threadIdx.x;      // q: group of 4 pixels
+  if (4 * q >= HW) return;
+  const f32x4* src = (const f32x4*)(x + (img * HW + 4 * q) * 4);
+  const f32x4 a = src[0], b = src[1], c = src[2], d = src[3];
+  float* dst = out + (img / T) * out_bstride + (img % T) * 4 * HW + 4 * q;
+#pragma unroll
+  for (int ch = 0; ch < 4; ++ch)
+    *(f32x4*)(dst + (long)ch * HW) = f32x4{nan_to_num_f(a[ch]), nan_to_num_f(b[ch]), nan_to_num_f(c[ch]), nan_to_num_f(d[ch])};
+}
+
 // torch.nan_to_num on a dense fp32 tensor (the formatter's pass over the reference frames, data/datamodule.py:187): 16 bytes per lane,
 // four vectors in flight per lane (the torch elementwise kernel ran this pass at 55 us per rollout; a first version of this one with
 // 8 MiB between a lane's vectors was SLOWER, 68 us)
@@ -1145,8 +1159,12 @@ extern "C" int tante_gather_last(const float* z, int64_t n, int E, float* out, v
 
 extern "C" int tante_format_input(const float* x, int64_t n_img, int T, int64_t HW, int D, float* out, int64_t out_bstride, void* stream) {
   if (!x || !out || n_img <= 0 || T <= 0 || n_img % T || HW <= 0 || D <= 0 || D > 255) TANTE_FAIL(-1, "tante_format_input: bad argument");
-  hipLaunchKernelGGL(format_input_kernel, dim3((unsigned)((HW + 255) / 256), (unsigned)n_img), dim3(256), 256 * (D + 1) * sizeof(float),
-                     (hipStream_t)stream, x, (long)HW, D, T, out, (long)out_bstride);
+  if (D == 4 && HW % 4 == 0 && out_bstride % 4 == 0 && (((uintptr_t)x | (uintptr_t)out) % 16) == 0)
+    hipLaunchKernelGGL(format_input_d4_kernel, dim3((unsigned)((HW / 4 + 255) / 256), (unsigned)n_img), dim3(256), 0, (hipStream_t)stream, x,
+                       (long)HW, T, out, (long)out_bstride);
+  else
+    hipLaunchKernelGGL(format_input_kernel, dim3((unsigned)((HW + 255) / 256), (unsigned)n_img), dim3(256), 256 * (D + 1) * sizeof(float),
+                       (hipStream_t)stream, x, (long)HW, D, T, out, (long)out_bstride);
   TANTE_CHECK_LAUNCH();
   return 0;
 }

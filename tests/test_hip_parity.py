@@ -476,13 +476,16 @@ def test_enc23_stage3_split_is_bit_identical(dev):
     assert torch.equal(big[:3], mid) and torch.equal(big[:1], one)
 
 
-def test_format_input_kernel(dev):
-    """tante_format_input = DefaultChannelsFirstFormatter.process_input's permute + nan_to_num, written straight into a rollout buffer."""
+@pytest.mark.parametrize("shape", [(20, 13, 11), (20, 13, 4), (20, 12, 4), (64, 96, 4)])
+def test_format_input_kernel(dev, shape):
+    """tante_format_input = DefaultChannelsFirstFormatter.process_input's permute + nan_to_num, written straight into a rollout buffer.
+    D = 4 with H W % 4 == 0 takes the register-transpose kernel (four pixels per lane), everything else the generic LDS one."""
     from tante_amd import _lib as L
-    B, T, H, W, D, extra = 2, 3, 20, 13, 11, 2
+    B, T, extra = 2, 3, 2
+    H, W, D = shape
     g = torch.Generator().manual_seed(4)
     x = torch.randn(B, T, H, W, D, generator=g)
-    x[0, 1, 3, 4, 5] = float("nan"); x[1, 0, 0, 0, 0] = float("inf"); x[1, 2, 19, 12, 10] = float("-inf")
+    x[0, 1, 3, 4, D // 2] = float("nan"); x[1, 0, 0, 0, 0] = float("inf"); x[1, 2, H - 1, W - 1, D - 1] = float("-inf")
     ref = torch.nan_to_num(x.permute(0, 1, 4, 2, 3))
     buf = torch.full((B, T + extra, D, H, W), 7.0, device=dev)
     xd = x.to(dev)
