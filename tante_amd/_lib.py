@@ -244,7 +244,7 @@ SIGNATURES = {
 LIB_OPTIONS = ("TANTE_ATTN_BWD_HG", "TANTE_ATTN_BWD_NO_SPLIT", "TANTE_ATTN_BWD_VALU", "TANTE_ATTN_FWD_VALU", "TANTE_AXIS_BWD_SMALL_WGS",
                "TANTE_AXIS_BWD_WGS", "TANTE_AXIS_CT", "TANTE_AXIS_GENERIC", "TANTE_AXIS_MFMA", "TANTE_AXIS_NT", "TANTE_AXIS_WGRAD_WGS",
                "TANTE_BLOCK_KERNEL", "TANTE_COLSUM_ROWS", "TANTE_CVIT_CHAIN_TOKENS", "TANTE_ENC23_SPLIT", "TANTE_FILM_BWD_ROWS",
-               "TANTE_FS_GROUPS", "TANTE_FS_HALF", "TANTE_FS_SKEW", "TANTE_FS_WAVES", "TANTE_GEMM_NO_LITE", "TANTE_GEMM_WGS", "TANTE_HEAD_WAVES",
+               "TANTE_FS_GROUPS", "TANTE_FS_HALF", "TANTE_FS_SKEW", "TANTE_FS_WAVES", "TANTE_GEMM_NO_LITE", "TANTE_GEMM_SMALLM", "TANTE_GEMM_WGS", "TANTE_HEAD_WAVES",
                "TANTE_IM2COL_TILED", "TANTE_RESIZE_TILED", "TANTE_SPECTRAL_BF16OUT", "TANTE_SPECTRAL_DFT", "TANTE_SPECTRAL_X3", "TANTE_WGRAD_DEEP",
                "TANTE_WGRAD_JOBS", "TANTE_WGRAD_JOBS_WGS", "TANTE_WGRAD_NO_SLAB", "TANTE_WGRAD_NO_TR", "TANTE_WGRAD_REDUCE_NY",
                "TANTE_WGRAD_RG", "TANTE_WGRAD_SLAB_WGS", "TANTE_WGRAD_TR_WGS", "TANTE_WGRAD_WGS", "TANTE_XATTN_GPW", "TANTE_XATTN_VALU",)

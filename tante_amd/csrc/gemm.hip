@@ -530,6 +530,118 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const TanteGemm g, int n_t
   }
 }
 
+// ---- a few hundred rows (CViT's encoder at B = 1: 256 tokens x 512) ------------------------------------------------------------------
+// gemm_kernel gives such a GEMM 4 workgroups' worth of rows; split over N (launch_variant) every workgroup re-loads and re-normalises
+// its 64 rows (128 KB of fp32) for ONE 32-row weight tile and then walks load -> LDS -> barrier -> MFMA -> store: 10.8 us per launch for
+// 0.4 GFLOP, and the one-launch block tail (cvit_fused.hip, 16 workgroups) pulls 1.5 MB of weights through each of 16 CUs: 26 us.
+// Here ONE WAVE owns a (16-row tile, 32-feature weight tile) pair and nothing is shared, staged or waited for twice: its 32 weight
+// fragments (straight from the packed tile image in L2: the swizzle is an address function) and its 16 rows are all requested up front,
+// the rows are normalised in registers, 32 MFMAs, the epilogue.  One memory round trip deep; M / 16 x N / 32 waves (256 - 768 at
+// cfg4) spread the weight stream over every CU.  bf16 compute, K = 512, linear rows / linear epilogue only.
+template <bool LN, int EP>
+__global__ __launch_bounds__(64) void gemm_small_kernel(const TanteGemm g) {
+  constexpr int CB = 16, CPR = 64, NT = 32, E = 8;
+  const int lane = threadIdx.x, kk = lane >> 4, l15 = lane & 15;
+  const int row0 = blockIdx.x * 16, t = blockIdx.y;
+  // (the same fragments from a fragment-ordered copy of the weight -- whole-KiB loads instead of 16 rows x 64 bytes per instruction --
+  // measured: 6.94 against 7.14 us per launch, nothing on the forward; not kept: the launch is latency, not address work)
+  const char* wt = (const char*)g.w + (size_t)t * (NT * CPR * 16);
+  u32x4 wf[2][CB];
+#pragma unroll
+  for (int ns = 0; ns < 2; ++ns) {
+    const int r = ns * 16 + l15;
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) wf[ns][cb] = *(const u32x4*)(wt + ((r * CPR + swz_chunk(r, cb * 4 + kk, CPR)) << 4));
+  }
+  const RowInfo ri = row_info(g, row0 + l15);
+  const EpiRow er = epi_row(g, row0 + l15);
+  // the epilogue's operands ride the same round trip: bias, and the residual rows (behind the MFMAs they were a second, dependent one)
+  f32x4 bq[2], rq[2];
+#pragma unroll
+  for (int ns = 0; ns < 2; ++ns) {
+    const int n0 = t * NT + ns * 16 + kk * 4;
+    bq[ns] = n0 < g.N ? *(const f32x4*)(g.bias + n0) : f32x4{0.f, 0.f, 0.f, 0.f};
+    rq[ns] = (g.residual && er.ok && n0 < g.N) ? *(const f32x4*)(g.residual + er.r_base + n0) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  u32x4 xf[CB];
+  if constexpr (LN) {
+    float v[CB][E];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) load_chunk_fast_lin<E>(g, ri, (cb * 4 + kk) * E, v[cb]);
+    float s = 0.0f;
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+      for (int i = 0; i < E; ++i) s += v[cb][i];
+    s += __shfl_xor(s, 16);
+    s += __shfl_xor(s, 32);
+    const float mean = s / (float)g.K;
+    float q = 0.0f;
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+      for (int i = 0; i < E; ++i) {
+        const float d = v[cb][i] - mean;
+        v[cb][i] = d;
+        q += d * d;
+      }
+    q += __shfl_xor(q, 16);
+    q += __shfl_xor(q, 32);
+    const float rstd = rsqrtf(q / (float)g.K + g.ln_eps);
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) {
+#pragma unroll
+      for (int i = 0; i < E; ++i) v[cb][i] *= rstd;
+      xf[cb] = to_frag<true>(v[cb]);
+    }
+  } else {
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) {
+      float v[E];
+      load_chunk_fast_lin<E>(g, ri, (cb * 4 + kk) * E, v);
+      xf[cb] = to_frag<true>(v);
+    }
+  }
+  f32x4 acc[2][2];      // [row tile][even / odd k-step]: four independent MFMA chains
+#pragma unroll
+  for (int ns = 0; ns < 2; ++ns) acc[ns][0] = acc[ns][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+    for (int ns = 0; ns < 2; ++ns)
+      acc[ns][cb & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[ns][cb]), __builtin_bit_cast(bf16x8, xf[cb]),
+                                                                acc[ns][cb & 1], 0, 0, 0);
+#pragma unroll
+  for (int ns = 0; ns < 2; ++ns) {
+    const int n0 = t * NT + ns * 16 + kk * 4;
+    if (!er.ok || n0 >= g.N) continue;
+    const f32x4 a = acc[ns][0] + acc[ns][1] + bq[ns];
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {       // = epilogue4_fast<EP, true>: the same activation forms, the same order (act, then the residual)
+      float x = a[j];
+      if constexpr (EP == EP_LIN_GELU_ERF) x = gelu_poly1<false>(x);
+      v[j] = x + rq[ns][j];
+    }
+    store4(g.out, g.out_dtype, er.o_base + n0, v);
+  }
+}
+
+// -> launched?  (bf16 compute, K = 512 dense rows, vector epilogue, at most TANTE_GEMM_SMALLM rows; 0 turns the path off)
+inline bool try_small(const TanteGemm& g, int n_tiles, int flags, int am, int ep, hipStream_t s) {
+  const int lim = tante_opt("TANTE_GEMM_SMALLM", 1024);
+  if (g.M > lim || g.K != 512 || am != AM_LIN || (flags & 3) != 3 || g.e_mode != TANTE_E_LINEAR || g.drop_p > 0.0f || g.dact) return false;
+  const dim3 grid((unsigned)((g.M + 15) / 16), (unsigned)n_tiles);
+  const bool ln = g.ln != 0;
+#define TANTE_SM(LNV, EPV) do { hipLaunchKernelGGL((gemm_small_kernel<LNV, EPV>), grid, dim3(64), 0, s, g); return true; } while (0)
+  if (ln && ep == EP_LIN_NONE) TANTE_SM(true, EP_LIN_NONE);
+  if (ln && ep == EP_LIN_GELU_ERF) TANTE_SM(true, EP_LIN_GELU_ERF);
+  if (!ln && ep == EP_LIN_NONE) TANTE_SM(false, EP_LIN_NONE);
+  if (!ln && ep == EP_LIN_GELU_ERF) TANTE_SM(false, EP_LIN_GELU_ERF);
+#undef TANTE_SM
+  return false;
+}
+
 // ---- dense bf16 GEMM for the training path (M = every token of the batch) ---------------------------------------------------------
 // At M ~ 16-32 k tokens and K, N of a few hundred the job is a 25 MB stream with < 2 us of MFMA work, and gemm_kernel's 186 VGPRs +
 // 64 KB of LDS hold two workgroups per CU: a grid of several hundred workgroups then runs as 1.5 serial load -> MFMA -> store rounds.
@@ -994,6 +1106,9 @@ void launch_gemm(const TanteGemm& g, int n_tiles, int flags, hipStream_t s) {
     ep = EP_DNCHW_NONE;
   }
   const bool ln = g.ln != 0;
+  if constexpr (BF16 && CB == 16) {
+    if (try_small(g, n_tiles, flags, am, ep, s)) return;
+  }
   if constexpr (BF16 && CB >= 4 && CB <= 16) {
     if (try_lite<CB>(g, n_tiles, flags, s)) return;
   }

@@ -30,6 +30,11 @@ from . import options as _O
 # host switches of this module (options.set_option, or TANTE_<NAME>=<int> when the package is imported)
 CVIT_FUSED = _O.register("TANTE_CVIT_FUSED", True, __name__, "CVIT_FUSED")                # the block tail as one chain512 launch
 CVIT_CHAIN_QKV = _O.register("TANTE_CVIT_CHAIN_QKV", False, __name__, "CVIT_CHAIN_QKV")   # measured SLOWER (B = 1: 1.02 -> 1.11 ms): off
+# Block tails of at most this many token rows run as three wave-per-tile GEMM launches (gemm.hip: gemm_small_kernel, every CU takes part)
+# instead of the one-launch chain, whose 16-token workgroups pull all 1.5 MB of weights through 16 CUs at B = 1.  Measured at cfg4 B = 1
+# (profiles/r06_cvit_small_probe.log): 7.1 + 5.9 + 7.1 us of kernels + two boundaries against the chain's 22.8 us -- 0.717-0.722 against
+# 0.717-0.741 ms per forward: a wash, so the chain (24 launches fewer) stays the default.  0: always the chain.
+CVIT_SMALL_ROWS = _O.register("TANTE_CVIT_SMALL_ROWS", 0, __name__, "CVIT_SMALL_ROWS")
 
 
 class MlpBlock(nn.Module):
@@ -108,7 +113,8 @@ class _AttnBlock(nn.Module):
         shared queries).  model_tail = (norm2, Mlp): continue through norm2 -> Mlp -> output layer in the same launch, -> (M, out_dim)."""
         adt = K.act_torch_dtype(compute)
         M = attn_o.shape[0]
-        if self._chain_ok(compute, M, resid.shape[0]) and (model_tail is None or _model_tail_ok(model_tail)):
+        small = model_tail is None and M <= CVIT_SMALL_ROWS and resid.shape[0] == M
+        if not small and self._chain_ok(compute, M, resid.shape[0]) and (model_tail is None or _model_tail_ok(model_tail)):
             w, bias, tail = self._chain_packed(model_tail)
             out = torch.empty(M, self.emb_dim if tail is None else tail[6], dtype=torch.float32, device=attn_o.device)
             return K.cvit_chain512(attn_o, resid, w, bias, float(self.eps), M, out, tail)

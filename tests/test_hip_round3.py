@@ -345,11 +345,12 @@ def _chain_reference(a, resid, blk, tail=None):
 
 @pytest.mark.parametrize("M,period,out_dim,tokens", [(64, 64, 0, 64), (320, 64, 0, 64), (256, 256, 16, 64), (384, 128, 16, 64), (128, 128, 7, 64),
                                                      (48, 48, 0, 16), (256, 256, 0, 16), (80, 16, 16, 16), (1024, 256, 5, 16), (33280, 33280, 16, 0)])
-def test_cvit_chain512_against_float64(dev, M, period, out_dim, tokens):
+def test_cvit_chain512_against_float64(dev, M, period, out_dim, tokens, monkeypatch):
     """tante_cvit_chain512 (mode 0: out_dim = 0; mode 1 otherwise) against a float64 restatement fed the same bf16 attention rows: random
     (non-trivial) LayerNorm affines everywhere, residual rows shared with a period, an output layer narrower than the 16-row tile; both
     workgroup shapes (64 / 16 tokens, forced through TANTE_CVIT_CHAIN_TOKENS; 0 = the launcher's own choice)."""
     from tante_amd import cvit as CV, kernels as Kk, _lib as L
+    monkeypatch.setattr(CV, "CVIT_SMALL_ROWS", 0)      # (round 6: short tails run as three wave-per-tile GEMMs by default; this is the chain's test)
     torch.manual_seed(M + out_dim)
     blk = CV.SelfAttnBlock(8, 512, 1).to(dev)
     norm2 = torch.nn.LayerNorm(512).to(dev)

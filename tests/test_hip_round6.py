@@ -333,3 +333,53 @@ def test_masked_attention_backward_against_torch(dev, D, dtype):
         tol = 2e-5 if dtype == torch.float32 else 1.5e-2
         assert rel_err(o.detach().float().cpu(), o_ref.detach()) < tol
         assert rel_err(x.grad.float().cpu(), q32.grad) < tol, (D, causal)
+
+
+@pytest.mark.parametrize("M", [16, 200, 256, 1024])
+@pytest.mark.parametrize("case", ["ln_qkv", "out_res", "ln_fc1_gelu", "dense_gelu_res"])
+def test_small_row_gemm_against_float64(dev, M, case):
+    """gemm.hip gemm_small_kernel (bf16 compute, K = 512, at most TANTE_GEMM_SMALLM rows: one wave per (16 rows, 32 features), CViT's
+    encoder blocks at B = 1, cvit.py:112-139): every epilogue it serves against float64 on bf16-rounded operands, and against the
+    token-stationary kernel it replaces (TANTE_GEMM_SMALLM = 0) within rounding.  M = 200: a ragged last row tile."""
+    import tante_amd
+    from tante_amd import kernels as K, _lib as L
+    gen = torch.Generator().manual_seed(600 + M)
+    Kd = 512
+    N = 1536 if case == "ln_qkv" else 512
+    w = (torch.randn(N, Kd, generator=gen) / Kd ** 0.5).to(dev)
+    b = (0.1 * torch.randn(N, generator=gen)).to(dev)
+    ln = case.startswith("ln_")
+    gamma = (1 + 0.1 * torch.randn(Kd, generator=gen)).to(dev) if ln else None
+    beta = (0.1 * torch.randn(Kd, generator=gen)).to(dev) if ln else None
+    a_bf16 = case == "out_res"
+    x = torch.randn(M, Kd, generator=gen).to(dev) * 1.5 + 0.3
+    xa = x.to(torch.bfloat16) if a_bf16 else x
+    res = torch.randn(M, N, generator=gen).to(dev) if case in ("out_res", "dense_gelu_res") else None
+    act = L.ACT_GELU_ERF if "gelu" in case else L.ACT_NONE
+    odt = torch.bfloat16 if case in ("ln_qkv", "ln_fc1_gelu") else torch.float32
+    pk = K.pack_weight(w, b, L.BF16, gamma=gamma, beta=beta)
+
+    def run():
+        out = torch.empty(M, N, dtype=odt, device=dev)
+        K.linear(xa, pk, out, M=M, ln=ln, ln_eps=1e-5, act=act, residual=res)
+        return out.float()
+    y_small = run()
+    tante_amd.set_option("TANTE_GEMM_SMALLM", 0)
+    try:
+        y_old = run()
+    finally:
+        tante_amd.set_option("TANTE_GEMM_SMALLM", 1024)
+    xr = xa.double()
+    if ln:
+        xr = torch.nn.functional.layer_norm(xr, (Kd,), gamma.double(), beta.double(), 1e-5)
+    ref = xr @ w.double().t() + b.double()
+    if act == L.ACT_GELU_ERF:
+        ref = torch.nn.functional.gelu(ref)
+    if res is not None:
+        ref = ref + res.double()
+    tol = 1.2e-2
+    assert rel_err(y_small.cpu(), ref.float().cpu()) < tol
+    assert rel_err(y_small.cpu(), y_old.cpu()) < 6e-3
+    if M in (200, 256) and case == "ln_qkv":
+        record_parity(rel_err(y_small.cpu(), ref.float().cpu()), max_rel(y_small.cpu(), ref.float().cpu()), tol, "bf16",
+                      f"gemm_small_kernel {case} M={M} vs float64")
