@@ -437,6 +437,16 @@ int tante_spectral_bf16out_supported(int64_t n, int Cin, int Cout, int H, int W,
 int tante_spectral_layer_bf16out(const float* x, int64_t n, int Cin, int H, int W, const float* w_re, const float* w_im, int wm1, int wm2,
                                  int modes1, int modes2, const float* w0, const float* b0, int Cout, int act, void* out, void* work,
                                  int64_t work_bytes, void* stream);
+/* (ABI 12) tante_spectral_layer_c in TANTE_BF16 mode with the images of x `x_istride` elements apart (>= Cin H W: one frame of every batch
+ * item inside a rollout buffer, trainer/trainer.py:144-159's window without the copy) and the output layout chosen by out_mode:
+ * 0 = fp32 (n, Cout, H, W), 1 = bf16 (n, Cout, H, W), 2 = fp32 channels-last rows ((n h w), Cout) -- what the transposed-conv GEMM behind
+ * dec_FNO's first spectral layer reads (enc_dec_fno.py:276-323).  Served by the split-bf16 kernels of the truncated-DFT path only:
+ * _supported says whether (shape, strided, out_mode) is; -2 otherwise.  x, out, w0, b0 16-byte aligned; work as tante_spectral_layer. */
+int tante_spectral_layer_x_supported(int64_t n, int Cin, int Cout, int H, int W, int modes1, int modes2, int strided, int out_mode);
+int tante_spectral_layer_x(const float* x, int64_t x_istride, int64_t n, int Cin, int H, int W, const float* w_re, const float* w_im, int wm1,
+                           int wm2, int modes1, int modes2, const float* w0, const float* b0, int Cout, int act, void* out, int out_mode,
+                           void* work, int64_t work_bytes, void* stream);
+
 /* Backward of tante_spectral_layer (act none): dx (n, Cin, H, W) = irfft2(M^H rfft2(dy)) + W0^T dy, and the complex weight gradient
  * dw_re / dw_im (Cin, Cout, wm1, wm2) in PyTorch's convention (dL/dRe + i dL/dIm).  w0t: the 1x1 weight transposed, (Cin, Cout).
  * The 1x1 conv's own weight / bias gradients are ordinary reductions (tante_wgrad lines, tante_colsum). */

@@ -162,6 +162,9 @@ SIGNATURES = {
     "tante_wgrad_jobs_ws": ([C.POINTER(WgradJob), c_i32, c_i32, c_vp, c_i64, c_vp], c_i32),
     "tante_spectral_layer_c": ([c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp,
                                 c_i64, c_i32, c_vp], c_i32),
+    "tante_spectral_layer_x_supported": ([c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32], c_i32),
+    "tante_spectral_layer_x": ([c_vp, c_i64, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_i32, c_vp,
+                               c_i32, c_vp, c_i64, c_vp], c_i32),
     "tante_spectral_layer_bwd": ([c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp,
                                   c_vp, c_i64, c_vp], c_i32),
     "tante_col2im_nhwc_sized": ([c_vp, c_i32, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_i32, c_vp, c_i32, c_vp], c_i32),
@@ -251,7 +254,7 @@ LIB_OPTIONS = ("TANTE_ATTN_BWD_HG", "TANTE_ATTN_BWD_NO_SPLIT", "TANTE_ATTN_BWD_V
 
 
 _lib = None
-ABI_VERSION = 11     # include/tante_hip.h: bumped whenever an entry point is added or changes (round 4: 6 tante_head_enc_*, 7 tante_pos_embed_tmajor + tante_spectral_*bf16out*; round 5: 8 tante_block_bwd_fused, 9 TanteGemm.a_pad; round 6: 10 tante_tail_*, 11 tante_attention_masked_bwd)
+ABI_VERSION = 12     # include/tante_hip.h: bumped whenever an entry point is added or changes (round 4: 6 tante_head_enc_*, 7 tante_pos_embed_tmajor + tante_spectral_*bf16out*; round 5: 8 tante_block_bwd_fused, 9 TanteGemm.a_pad; round 6: 10 tante_tail_*, 11 tante_attention_masked_bwd, 12 tante_spectral_layer_x)
 
 
 def lib():

@@ -1300,6 +1300,38 @@ extern "C" int tante_spectral_layer_bf16out(const float* x, int64_t n, int Cin, 
   return 0;
 }
 
+// tante_spectral_layer_c with (a) images of x `x_istride` elements apart (a frame of every batch item inside a rollout buffer) and (b) the
+// output layout chosen: 0 fp32 (n, Cout, H, W), 1 bf16 (n, Cout, H, W), 2 fp32 channels-last rows ((n h w), Cout).  bf16 compute mode, shapes
+// of the truncated-DFT path's split-bf16 kernels only: ask tante_spectral_layer_x_supported first (-2 otherwise).
+extern "C" int tante_spectral_layer_x_supported(int64_t n, int Cin, int Cout, int H, int W, int modes1, int modes2, int strided, int out_mode) {
+  if (n <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || out_mode < 0 || out_mode > 2) return 0;
+  const int Wf = W / 2 + 1;
+  const int m1 = modes1 < H ? modes1 : H, m2 = modes2 < Wf ? modes2 : Wf;
+  if (!tante_opt("TANTE_SPECTRAL_DFT", 1) || (out_mode == 1 && !tante_opt("TANTE_SPECTRAL_BF16OUT", 1))) return 0;
+  return tante_spectral_dft_x_supported(n, Cin, Cout, H, W, m1, m2, strided, out_mode == 1, out_mode == 2);
+}
+
+extern "C" int tante_spectral_layer_x(const float* x, int64_t x_istride, int64_t n, int Cin, int H, int W, const float* w_re, const float* w_im,
+                                      int wm1, int wm2, int modes1, int modes2, const float* w0, const float* b0, int Cout, int act, void* out,
+                                      int out_mode, void* work, int64_t work_bytes, void* stream) {
+  if (!x || !w_re || !w_im || !w0 || !out || !work || n <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0)
+    TANTE_FAIL(-1, "tante_spectral_layer_x: bad argument");
+  if (x_istride < (int64_t)Cin * H * W || x_istride % 4) TANTE_FAIL(-1, "tante_spectral_layer_x: image stride must be >= Cin H W and a multiple of 4");
+  const int strided = x_istride != (int64_t)Cin * H * W;
+  if (!tante_spectral_layer_x_supported(n, Cin, Cout, H, W, modes1, modes2, strided, out_mode))
+    TANTE_FAIL(-2, "tante_spectral_layer_x: shape / layout without a split-bf16 kernel (use tante_spectral_layer_c on a dense copy)");
+  if (((uintptr_t)x % 16) || ((uintptr_t)out % 16) || ((uintptr_t)w0 % 16) || (b0 && ((uintptr_t)b0 % 16)))
+    TANTE_FAIL(-1, "tante_spectral_layer_x: x, out, w0 and b0 must be 16-byte aligned");
+  const int Wf = W / 2 + 1;
+  const int m1 = modes1 < H ? modes1 : H, m2 = modes2 < Wf ? modes2 : Wf;
+  if (m1 > wm1 || m2 > wm2) TANTE_FAIL(-1, "tante_spectral_layer_x: weight holds fewer modes (%d, %d) than used (%d, %d)", wm1, wm2, m1, m2);
+  if (work_bytes < tante_spectral_dft_workspace_bytes(n, Cin, Cout, H, m1, m2)) TANTE_FAIL(-1, "tante_spectral_layer_x: workspace too small");
+  const int rc = tante_spectral_dft_forward(x, n, Cin, H, W, w_re, w_im, wm1, wm2, m1, m2, w0, b0, Cout, act, (float*)out, work, TANTE_BF16,
+                                            (hipStream_t)stream, out_mode == 1, (long)x_istride, out_mode == 2);
+  if (rc) TANTE_FAIL(rc, "tante_spectral_layer_x: truncated-DFT launch failed");
+  return 0;
+}
+
 extern "C" int tante_resize_bilinear_bwd(const void* dout, int d_dtype, int64_t n_img, int C, int Hi, int Wi, int crop_y, int crop_x, int64_t isn,
                                          int64_t isc, int64_t ish, int64_t isw, int Ho, int Wo, int64_t osn, int64_t osc, int64_t osh,
                                          int64_t osw, float* din, void* stream) {

@@ -1255,4 +1255,4 @@ extern "C" int tante_set_option(const char* name, int value) {
   return 0;
 }
 extern "C" int tante_get_option(const char* name, int dflt) { return name ? tante_opt(name, dflt) : dflt; }
-extern "C" int tante_abi_version(void) { return 11; }      // = tante_amd/_lib.py ABI_VERSION; bumped with every added / changed entry point
+extern "C" int tante_abi_version(void) { return 12; }      // = tante_amd/_lib.py ABI_VERSION; bumped with every added / changed entry point

@@ -357,7 +357,7 @@ __device__ __forceinline__ f32x4 mfma16(const u32x4& a, const u32x4& b, const f3
 template <int KZS, int KCS, bool OUT16 = false>   // k-steps of 32 per term: ceil(2 m2 / 32) spectral, ceil(Cin / 32) conv
 __global__ __launch_bounds__(256) void idft_rows_conv_x3_kernel(const float* __restrict__ Z, const float* __restrict__ x, const float* __restrict__ w0,
                                                                 const float* __restrict__ b0, long n, int Cin, int Cout, int H, int W, int m2,
-                                                                int act, float* __restrict__ out) {
+                                                                int act, float* __restrict__ out, long x_istride) {
   // LDS: the G table as operand fragments [hi | lo][KZS][8 column tiles][64 lanes], then per wave a staging area for one image row's
   // operands in ROW form: zs[2 m2][Cout + 4] (the row's coefficients) and xs[Cin][132] (its 128 pixels of every input channel).
   // Every global access of the row loop is a 16-byte-per-lane access of whole contiguous runs; the operand (MFMA) layouts are taken
@@ -441,7 +441,7 @@ __global__ __launch_bounds__(256) void idft_rows_conv_x3_kernel(const float* __r
           if (idx < nz4) { const int k = (4 * idx) / Cout, o = 4 * idx - k * Cout; *(f32x4*)(zs + k * ZP + o) = zr[u]; }
         }
       }
-      const float* xp = x + ((b * Cin) * H + h) * (long)W + col0 + 4 * (lane & 31);
+      const float* xp = x + b * x_istride + (long)h * W + col0 + 4 * (lane & 31);
       for (int c0 = 0; c0 < Cin; c0 += 8) {         // two channels (2 x 512 bytes) per wave instruction
         f32x4 xr4[4];
 #pragma unroll
@@ -541,8 +541,11 @@ __global__ __launch_bounds__(256) void idft_rows_conv_x3_kernel(const float* __r
 // split into bf16 hi + lo parts and x . T ~= x_hi T_hi + x_lo T_hi + x_hi T_lo runs as v_mfma_f32_16x16x32_bf16: 18 MFMAs of 16 cycles per
 // 32 columns instead of 48 of 32, the table as ready operand fragments (one ds_read_b128 per fragment), and every global access is 32
 // contiguous bytes per lane = whole 128-byte runs per image row.  ~1e-5 relative to the fp32 chain; bf16 compute mode only.
+// (rows_img, img_gap: x may be n images of rows_img rows each with img_gap extra elements between consecutive images -- a frame of
+// every batch item inside a longer rollout buffer; 0 gap = dense)
 template <int NT>
-__global__ __launch_bounds__(256) void dft_rows_x3_kernel(const float* __restrict__ x, long R, int W, int m2, float* __restrict__ Ar) {
+__global__ __launch_bounds__(256) void dft_rows_x3_kernel(const float* __restrict__ x, long R, int W, int m2, float* __restrict__ Ar, long rows_img,
+                                                          long img_gap) {
   extern __shared__ __attribute__((aligned(16))) u32x4 tfr[];      // [hi | lo][k-step s][column tile nt][64 lanes]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, kk = lane >> 4;
   const int KS = W / 32, NF = KS * NT * 64;
@@ -587,7 +590,7 @@ __global__ __launch_bounds__(256) void dft_rows_x3_kernel(const float* __restric
     for (int mt = 0; mt < 2; ++mt) {
       long r = row0 + 16 * mt + l15;
       if (r >= R) r = R - 1;                      // clamped rows are computed and never stored
-      xr[mt] = x + r * W + 8 * kk;
+      xr[mt] = x + r * W + 8 * kk + (img_gap ? (r / rows_img) * img_gap : 0);
     }
     auto kstep = [&](int sk, const f32x4 (&c)[2][2]) {
       u32x4 xh[2], xl[2];
@@ -666,7 +669,10 @@ __global__ __launch_bounds__(256) void dft_rows_x3_kernel(const float* __restric
 // for every column tile with the same split-operand products (a . b ~= a_hi b_hi + a_lo b_hi + a_hi b_lo on v_mfma_f32_16x16x32_bf16);
 // its conv weights (OTW tiles x KCS k-steps, hi and lo) stay in registers across rows.  Every wave splits the row's pixels itself (the
 // split is VALU work of the order of its MFMAs; sharing it would cost a second LDS round trip).
-template <int KCS, int OTW>   // Cin = 32 KCS, Cout = 64 OTW; 2 m2 <= 32; W = 128
+// NHWC: the output as channels-last rows ((n h w), Cout) -- what the transposed-conv GEMM behind dec_FNO's first spectral layer reads
+// (enc_dec_fno.py:276-323; a 12 us layout copy per call before).  The same fragments with the MFMA operands exchanged give the tile as
+// D[o][w]: a lane holds four consecutive CHANNELS of one pixel, 16 bytes of its row.
+template <int KCS, int OTW, bool NHWC = false>   // Cin = 32 KCS, Cout = 64 OTW; 2 m2 <= 32; W = 128
 __global__ __launch_bounds__(256) void idft_rows_conv_x3w_kernel(const float* __restrict__ Z, const float* __restrict__ x, const float* __restrict__ w0,
                                                                  const float* __restrict__ b0, long n, int H, int m2, int act, float* __restrict__ out) {
   constexpr int Cin = 32 * KCS, Cout = 64 * OTW, W = 128, ZP = Cout + 4, XP = 132;
@@ -716,8 +722,12 @@ __global__ __launch_bounds__(256) void idft_rows_conv_x3w_kernel(const float* __
       split8(v, Wc[0][sc][ot], Wc[1][sc][ot]);
     }
   float bias[OTW];
+  f32x4 bias4[OTW];      // NHWC: the lane's four channels 4 kk .. 4 kk + 3 of tile ot
 #pragma unroll
-  for (int ot = 0; ot < OTW; ++ot) bias[ot] = b0 ? b0[o_base + 16 * ot + l15] : 0.0f;
+  for (int ot = 0; ot < OTW; ++ot) {
+    bias[ot] = b0 ? b0[o_base + 16 * ot + l15] : 0.0f;
+    bias4[ot] = b0 ? *(const f32x4*)(b0 + o_base + 16 * ot + 4 * kk) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
   const long rows = n * H, HWl = (long)H * W;
   const int nz4 = 2 * m2 * Cout / 4;
   for (long rho = blockIdx.x; rho < rows; rho += gridDim.x) {
@@ -774,27 +784,40 @@ __global__ __launch_bounds__(256) void idft_rows_conv_x3w_kernel(const float* __
 #pragma unroll
       for (int ot = 0; ot < OTW; ++ot) {
         acc[ot] = f32x4{0.f, 0.f, 0.f, 0.f};
-        acc[ot] = mfma16(gh, Zf[1][ot], acc[ot]);
-        acc[ot] = mfma16(gl, Zf[0][ot], acc[ot]);
-        acc[ot] = mfma16(gh, Zf[0][ot], acc[ot]);
+        if constexpr (NHWC) {      // the same three products, operands exchanged: D[o][w]
+          acc[ot] = mfma16(Zf[1][ot], gh, acc[ot]);
+          acc[ot] = mfma16(Zf[0][ot], gl, acc[ot]);
+          acc[ot] = mfma16(Zf[0][ot], gh, acc[ot]);
+        } else {
+          acc[ot] = mfma16(gh, Zf[1][ot], acc[ot]);
+          acc[ot] = mfma16(gl, Zf[0][ot], acc[ot]);
+          acc[ot] = mfma16(gh, Zf[0][ot], acc[ot]);
+        }
       }
 #pragma unroll
       for (int sc = 0; sc < KCS; ++sc)
 #pragma unroll
         for (int ot = 0; ot < OTW; ++ot) {
-          acc[ot] = mfma16(Xf[0][sc], Wc[1][sc][ot], acc[ot]);
-          acc[ot] = mfma16(Xf[1][sc], Wc[0][sc][ot], acc[ot]);
-          acc[ot] = mfma16(Xf[0][sc], Wc[0][sc][ot], acc[ot]);
+          if constexpr (NHWC) {
+            acc[ot] = mfma16(Wc[1][sc][ot], Xf[0][sc], acc[ot]);
+            acc[ot] = mfma16(Wc[0][sc][ot], Xf[1][sc], acc[ot]);
+            acc[ot] = mfma16(Wc[0][sc][ot], Xf[0][sc], acc[ot]);
+          } else {
+            acc[ot] = mfma16(Xf[0][sc], Wc[1][sc][ot], acc[ot]);
+            acc[ot] = mfma16(Xf[1][sc], Wc[0][sc][ot], acc[ot]);
+            acc[ot] = mfma16(Xf[0][sc], Wc[0][sc][ot], acc[ot]);
+          }
         }
 #pragma unroll
       for (int ot = 0; ot < OTW; ++ot) {
-        f32x4 v = acc[ot] + splat4(bias[ot]);
+        f32x4 v = acc[ot] + (NHWC ? bias4[ot] : splat4(bias[ot]));
         if (act == TANTE_ACT_GELU_ERF) v = gelu_poly4<false>(v);
         else if (act != TANTE_ACT_NONE) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], act);
         }
-        st_wt16(orow + (long)(16 * ot + l15) * HWl + 16 * wt, v);
+        if constexpr (NHWC) st_wt16(out + ((b * H + h) * (long)W + 16 * wt + l15) * Cout + o_base + 16 * ot + 4 * kk, v);
+        else st_wt16(orow + (long)(16 * ot + l15) * HWl + 16 * wt, v);
       }
     }
   }
@@ -830,9 +853,27 @@ int tante_spectral_dft_bf16out_supported(int64_t n, int Cin, int Cout, int H, in
   return tante_spectral_dft_supported(n, Cin, Cout, H, W, m1, m2) && dft_x3_ok(Cin, Cout, W, m2, nullptr);
 }
 
+static bool dft_x3w_ok(int Cin, int Cout, int W, int m2) {
+  return W == 128 && 2 * m2 <= 32 && ((Cin == 64 && Cout == 128) || (Cin == 128 && Cout == 64));
+}
+int tante_spectral_dft_x_supported(int64_t n, int Cin, int Cout, int H, int W, int m1, int m2, int strided, int out_bf16, int out_nhwc) {
+  if (!tante_spectral_dft_supported(n, Cin, Cout, H, W, m1, m2) || !tante_opt("TANTE_SPECTRAL_X3", 1)) return 0;
+  const int NT = (2 * m2 + 15) / 16;
+  if ((size_t)2 * (W / 32) * NT * 1024 + (size_t)W * 8 > 150 * 1024) return 0;      // the split-bf16 row transform (the one that takes a stride)
+  const bool x3 = dft_x3_ok(Cin, Cout, W, m2, nullptr), x3w = !x3 && dft_x3w_ok(Cin, Cout, W, m2);
+  if (out_bf16 && (!x3 || out_nhwc)) return 0;
+  if (out_nhwc && !x3w) return 0;
+  if (strided && !x3) return 0;      // (the wide layers' last kernel reads dense images)
+  return (x3 || x3w) ? 1 : 0;
+}
+
 int tante_spectral_dft_forward(const float* x, int64_t n, int Cin, int H, int W, const float* w_re, const float* w_im, int wm1, int wm2, int m1,
                                int m2, const float* w0, const float* b0, int Cout, int act, float* out, void* work, int compute, hipStream_t s,
-                               int out_bf16) {
+                               int out_bf16, long x_istride, int out_nhwc) {
+  const bool strided = x_istride != 0 && x_istride != (long)Cin * H * W;
+  if (x_istride == 0) x_istride = (long)Cin * H * W;
+  if ((strided || out_nhwc) && (compute != TANTE_BF16 || !tante_spectral_dft_x_supported(n, Cin, Cout, H, W, m1, m2, strided, out_bf16, out_nhwc)))
+    return -2;
   auto up = [](int64_t v) { return (v + 255) / 256 * 256; };
   char* p = (char*)work;
   float* Ar = (float*)p; p += up(n * Cin * H * 2 * m2 * 4);
@@ -856,11 +897,13 @@ int tante_spectral_dft_forward(const float* x, int64_t n, int Cin, int H, int W,
 #define TANTE_DFT_A3(NTV)                                                                                                         \
   case NTV:                                                                                                                       \
     attrA3[NTV - 1].once([&] { (void)hipFuncSetAttribute((const void*)dft_rows_x3_kernel<NTV>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); }); \
-    hipLaunchKernelGGL(dft_rows_x3_kernel<NTV>, dim3(gridA), dim3(256), ldsA3, s, x, R, W, m2, Ar);                                \
+    hipLaunchKernelGGL(dft_rows_x3_kernel<NTV>, dim3(gridA), dim3(256), ldsA3, s, x, R, W, m2, Ar, (long)Cin * H,                  \
+                       strided ? x_istride - (long)Cin * H * W : 0L);                                                              \
     break;
     switch (NT) { TANTE_DFT_A3(1) TANTE_DFT_A3(2) TANTE_DFT_A3(3) TANTE_DFT_A3(4) default: return -2; }
 #undef TANTE_DFT_A3
   } else {
+    if (strided) return -2;      // (the fp32 row transform reads dense images)
     switch (NT) { TANTE_DFT_A(1) TANTE_DFT_A(2) TANTE_DFT_A(3) TANTE_DFT_A(4) default: return -2; }
   }
 #undef TANTE_DFT_A
@@ -890,20 +933,25 @@ int tante_spectral_dft_forward(const float* x, int64_t n, int Cin, int H, int W,
   const bool x3 = dft_x3_ok(Cin, Cout, W, m2, &ldsE3) && ((uintptr_t)x % 16) == 0 && ((uintptr_t)out % 16) == 0;
   if (out_bf16 && !x3) return -2;      // (the caller asked tante_spectral_dft_bf16out_supported first)
   // the wide layers (idft_rows_conv_x3w_kernel): 64 -> 128 and 128 -> 64 channels at W = 128
-  if (!x3 && !out_bf16 && compute == TANTE_BF16 && tante_opt("TANTE_SPECTRAL_X3", 1) && W == 128 && 2 * m2 <= 32 && ((uintptr_t)x % 16) == 0 &&
-      ((uintptr_t)out % 16) == 0 && ((uintptr_t)w0 % 16) == 0 && ((Cin == 64 && Cout == 128) || (Cin == 128 && Cout == 64))) {
+  if (!x3 && !out_bf16 && compute == TANTE_BF16 && tante_opt("TANTE_SPECTRAL_X3", 1) && dft_x3w_ok(Cin, Cout, W, m2) && ((uintptr_t)x % 16) == 0 &&
+      ((uintptr_t)out % 16) == 0 && ((uintptr_t)w0 % 16) == 0 && (!b0 || ((uintptr_t)b0 % 16) == 0 || !out_nhwc)) {
     const size_t ldsW = (size_t)2 * 512 * 16 + (size_t)(32 * (Cout + 4) + Cin * 132) * 4;
     const long rowsW = (long)n * H;
-    static TantePerDevice attrW[2];
+    static TantePerDevice attrW[4];
+#define TANTE_DFT_W(IDX, A_, B_, NH, GR)                                                                                                   \
+  {                                                                                                                                        \
+    attrW[IDX].once([&] { (void)hipFuncSetAttribute((const void*)idft_rows_conv_x3w_kernel<A_, B_, NH>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); }); \
+    hipLaunchKernelGGL((idft_rows_conv_x3w_kernel<A_, B_, NH>), dim3((unsigned)std::min<long>(rowsW, GR)), dim3(256), ldsW, s, Z, x, w0, b0, (long)n, H, m2, act, out); \
+  }
     if (Cin == 64) {
-      attrW[0].once([&] { (void)hipFuncSetAttribute((const void*)idft_rows_conv_x3w_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); });
-      hipLaunchKernelGGL((idft_rows_conv_x3w_kernel<2, 2>), dim3((unsigned)std::min<long>(rowsW, 512)), dim3(256), ldsW, s, Z, x, w0, b0, (long)n, H, m2, act, out);
+      if (out_nhwc) TANTE_DFT_W(2, 2, 2, true, 512) else TANTE_DFT_W(0, 2, 2, false, 512)
     } else {
-      attrW[1].once([&] { (void)hipFuncSetAttribute((const void*)idft_rows_conv_x3w_kernel<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); });
-      hipLaunchKernelGGL((idft_rows_conv_x3w_kernel<4, 1>), dim3((unsigned)std::min<long>(rowsW, 256)), dim3(256), ldsW, s, Z, x, w0, b0, (long)n, H, m2, act, out);
+      if (out_nhwc) TANTE_DFT_W(3, 4, 1, true, 256) else TANTE_DFT_W(1, 4, 1, false, 256)
     }
+#undef TANTE_DFT_W
     return hipGetLastError() == hipSuccess ? 0 : -3;
   }
+  if (out_nhwc) return -2;
   if (out_bf16 || (compute == TANTE_BF16 && x3 && tante_opt("TANTE_SPECTRAL_X3", 1))) {
     const int kzs = (2 * m2 + 31) / 32, kcs = (Cin + 31) / 32, ncb = W / 128;
     const long rows4 = ((long)n * H + 3) / 4;
@@ -915,10 +963,10 @@ int tante_spectral_dft_forward(const float* x, int64_t n, int Cin, int H, int W,
   {                                                                                                                                            \
     if (out_bf16) {                                                                                                                            \
       attrE3[4 + (A_ - 1) * 2 + (B_ - 1)].once([&] { (void)hipFuncSetAttribute((const void*)idft_rows_conv_x3_kernel<A_, B_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); }); \
-      hipLaunchKernelGGL((idft_rows_conv_x3_kernel<A_, B_, true>), dim3((unsigned)(nrg * ncb)), dim3(256), lds, s, Z, x, w0, b0, (long)n, Cin, Cout, H, W, m2, act, out); \
+      hipLaunchKernelGGL((idft_rows_conv_x3_kernel<A_, B_, true>), dim3((unsigned)(nrg * ncb)), dim3(256), lds, s, Z, x, w0, b0, (long)n, Cin, Cout, H, W, m2, act, out, x_istride); \
     } else {                                                                                                                                   \
       attrE3[(A_ - 1) * 2 + (B_ - 1)].once([&] { (void)hipFuncSetAttribute((const void*)idft_rows_conv_x3_kernel<A_, B_>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); }); \
-      hipLaunchKernelGGL((idft_rows_conv_x3_kernel<A_, B_>), dim3((unsigned)(nrg * ncb)), dim3(256), lds, s, Z, x, w0, b0, (long)n, Cin, Cout, H, W, m2, act, out); \
+      hipLaunchKernelGGL((idft_rows_conv_x3_kernel<A_, B_>), dim3((unsigned)(nrg * ncb)), dim3(256), lds, s, Z, x, w0, b0, (long)n, Cin, Cout, H, W, m2, act, out, x_istride); \
     }                                                                                                                                          \
   }
     if (kzs == 1 && kcs == 1) TANTE_DFT_E3(1, 1)
@@ -928,6 +976,7 @@ int tante_spectral_dft_forward(const float* x, int64_t n, int Cin, int H, int W,
 #undef TANTE_DFT_E3
     return hipGetLastError() == hipSuccess ? 0 : -3;
   }
+  if (strided) return -2;                      // (the fp32 kernels read dense images)
   const int wpb = W / 32;                      // waves per workgroup: one per 32 output columns
   const size_t ldsE = (size_t)2 * m2 * W * 4 + (size_t)Cin * ((Cout + 31) / 32 * 32) * 4;
   const long rows = (long)n * H;

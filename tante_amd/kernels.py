@@ -641,13 +641,35 @@ def layernorm_affine(x: torch.Tensor, gamma: Optional[torch.Tensor], beta: Optio
 
 
 def spectral_layer(x: torch.Tensor, w_re: torch.Tensor, w_im: torch.Tensor, modes1: int, modes2: int, w0: torch.Tensor, b0: torch.Tensor,
-                   act: int, compute: int = L.F32, bf16_out: bool = False) -> torch.Tensor:
+                   act: int, compute: int = L.F32, bf16_out: bool = False, nhwc_out: bool = False) -> torch.Tensor:
     """x (n, Cin, H, W) fp32 -> act(SpectralLayer(x)) (n, Cout, H, W) fp32.  compute = L.BF16 (a bf16 model): the inverse row transform may
     use split-operand products on the bf16 matrix pipe (~1e-5 relative to the fp32 result).  bf16_out (bf16 mode, a consumer that rounds to
-    bf16 anyway): the image is written as bf16 where the shape has that form (tante_spectral_layer_bf16out), fp32 otherwise."""
-    _dev(x, w_re, w_im, w0, b0)
+    bf16 anyway): the image is written as bf16 where the shape has that form (tante_spectral_layer_bf16out), fp32 otherwise.
+    x may be a batch-strided view of contiguous images (a frame of every item of a rollout buffer): read in place where
+    tante_spectral_layer_x serves the shape, copied otherwise.  nhwc_out: -> channels-last rows (n * H * W, Cout) fp32 (a row GEMM follows):
+    written that way by the layer's last kernel where it can, by a layout copy otherwise."""
     n, Cin, H, W = x.shape
     Cout = w_re.shape[1]
+    dense = x.is_contiguous()
+    img_ok = x.is_cuda and x.dtype == torch.float32 and x[0].is_contiguous() and x.stride(0) >= Cin * H * W and x.stride(0) % 4 == 0
+    if (compute == L.BF16 and img_ok and (not dense or nhwc_out)
+            and L.lib().tante_spectral_layer_x_supported(n, Cin, Cout, H, W, modes1, modes2, int(not dense), 2 if nhwc_out else int(bool(bf16_out)))
+            and x.data_ptr() % 16 == 0 and w0.data_ptr() % 16 == 0 and (b0 is None or b0.data_ptr() % 16 == 0)):
+        _dev(w_re, w_im, w0, b0)
+        mode = 2 if nhwc_out else int(bool(bf16_out))
+        nbytes = L.lib().tante_spectral_workspace_bytes(n, Cin, Cout, H, W)
+        work = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        out = (torch.empty(n * H * W, Cout, dtype=torch.float32, device=x.device) if nhwc_out
+               else torch.empty(n, Cout, H, W, dtype=torch.bfloat16 if bf16_out else torch.float32, device=x.device))
+        L.check(L.lib().tante_spectral_layer_x(x.data_ptr(), x.stride(0), n, Cin, H, W, _p(w_re), _p(w_im), w_re.shape[2], w_re.shape[3], modes1, modes2,
+                                               _p(w0), _p(b0), Cout, act, _p(out), mode, _p(work), nbytes, _stream()), "tante_spectral_layer_x")
+        return out
+    if not dense:
+        x = x.contiguous()
+    if nhwc_out:
+        y = spectral_layer(x, w_re, w_im, modes1, modes2, w0, b0, act, compute)
+        return y.permute(0, 2, 3, 1).contiguous().view(n * H * W, Cout)
+    _dev(x, w_re, w_im, w0, b0)
     nbytes = L.lib().tante_spectral_workspace_bytes(n, Cin, Cout, H, W)
     work = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
     if bf16_out and compute == L.BF16 and L.lib().tante_spectral_bf16out_supported(n, Cin, Cout, H, W, modes1, modes2):

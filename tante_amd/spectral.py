@@ -40,14 +40,14 @@ class SpectralLayer(nn.Module):
     def _planes(self):
         return self._cache.get(0, [self.weight], lambda: (self.weight.detach().real.contiguous(), self.weight.detach().imag.contiguous()))
 
-    def run(self, x: torch.Tensor, act: int = L.ACT_NONE, compute: int = L.F32, bf16_out: bool = False) -> torch.Tensor:
-        """x (n, Cin, H, W) fp32 contiguous -> act(layer(x)); compute: the model's mode; bf16_out: the consumer rounds to bf16 anyway
-        (kernels.spectral_layer)."""
+    def run(self, x: torch.Tensor, act: int = L.ACT_NONE, compute: int = L.F32, bf16_out: bool = False, nhwc_out: bool = False) -> torch.Tensor:
+        """x (n, Cin, H, W) fp32 (contiguous, or contiguous images with a batch stride) -> act(layer(x)); compute: the model's mode;
+        bf16_out: the consumer rounds to bf16 anyway; nhwc_out: channels-last rows (n H W, Cout) instead of the image (kernels.spectral_layer)."""
         if x.dim() != 4 or x.size(1) != self.in_channels:
             raise AssertionError("SpectralLayer expects (B, Cin, H, W)")
         re, im = self._planes()
         w0 = self.w0.weight.detach().view(self.out_channels, self.in_channels)
-        return K.spectral_layer(x, re, im, self.modes1, self.modes2, w0, self.w0.bias.detach(), act, compute, bf16_out)
+        return K.spectral_layer(x, re, im, self.modes1, self.modes2, w0, self.w0.bias.detach(), act, compute, bf16_out, nhwc_out)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         _no_autograd(self)
@@ -85,19 +85,23 @@ class enc_FNO(nn.Module):
         return self._cache.get(compute, params,
                                lambda: [S.pack_linear_chunks(S.conv_weight_2d(c.weight, 0), c.bias, compute) for c in convs])
 
-    def forward_tokens(self, inp: torch.Tensor, compute: int, film: Optional[tuple], item_stride: Optional[int] = None) -> torch.Tensor:
+    def forward_tokens(self, inp: torch.Tensor, compute: int, film: Optional[tuple], item_stride: Optional[int] = None,
+                       out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """out (no FiLM): a contiguous (B T Hp Wp, C) fp32 tensor that receives the token rows (the rollout's frame cache)."""
         B, T, D, H, W = inp.shape
         if (H, W) != (self.H, self.W) or D != self.chans[0]:
             raise ValueError(f"encoder built for {self.chans[0]} fields at {(self.H, self.W)}, got {tuple(inp.shape)}")
         pk = self._packed(compute)
         n = B * T
-        z = inp.contiguous().view(n, D, H, W)
+        # one frame of every batch item out of a longer buffer (the rollout's re-encoding of a predicted frame): read in place
+        z = inp[:, 0] if (T == 1 and not inp.is_contiguous() and inp[0].is_contiguous()) else inp.contiguous().view(n, D, H, W)
         # (bf16 mode: the conv's patch gather rounds the image to bf16 anyway -- the spectral layer's last kernel does it while storing)
         z = self.enc_spectral_1.run(z, L.ACT_GELU_ERF, compute, bf16_out=True)
         # (channels-first for the spectral layer: written by the patch GEMM's epilogue, stages.conv_stage)
         y, h, w = S.conv_stage(z, True, n, self.chans[1], H, W, self.P[0], self.overlap, pk[0], compute, L.ACT_GELU_ERF, torch.float32, nchw_out=True)
         z = self.enc_spectral_2.run(y, L.ACT_GELU_ERF, compute)
-        y, h, w = S.conv_stage(z, True, n, self.chans[3], h, w, self.P[1], self.overlap, pk[1], compute, L.ACT_NONE, torch.float32)
+        y, h, w = S.conv_stage(z, True, n, self.chans[3], h, w, self.P[1], self.overlap, pk[1], compute, L.ACT_NONE, torch.float32,
+                               out=out if film is None else None)
         if film is not None:
             fa, fb, se, Tt, HW = film
             out = torch.empty_like(y)
@@ -161,8 +165,8 @@ class dec_FNO(nn.Module):
         z = S.deconv_stage(src, n_img, h, w, p1, self.overlap, pk[0], self.chans[1], compute, L.ACT_GELU_ERF, True, torch.float32,
                            a_n0=a_n0, a_s1=a_s1, a_s0=a_s0, a_off=a_off)
         h, w = h * p1, w * p1
-        z = self.dec_spectral_1.run(z, L.ACT_GELU_ERF, compute)                                   # (n, C/4, h, w) channels-first
-        rows = z.permute(0, 2, 3, 1).contiguous().view(n_img * h * w, self.chans[2])     # layout change for the row GEMM
+        # channels-last rows for the row GEMM behind it: written that way by the layer's last kernel (bf16 mode), by a layout copy otherwise
+        rows = self.dec_spectral_1.run(z, L.ACT_GELU_ERF, compute, nhwc_out=True)
         z = S.deconv_stage(rows, n_img, h, w, p0, self.overlap, pk[1], self.chans[3], compute, L.ACT_GELU_ERF, True, torch.float32)
         return self.dec_spectral_2.run(z, L.ACT_NONE, compute)
 

@@ -64,12 +64,14 @@ def conv_weight_2d(w: torch.Tensor, korder: int) -> torch.Tensor:
 
 
 def conv_stage(x: torch.Tensor, nchw: bool, n_img: int, Cin: int, H: int, W: int, P: int, overlap: float, chunks: List[K.PackedWeight],
-               compute: int, act: int, out_dtype: torch.dtype, nchw_out: bool = False) -> Tuple[torch.Tensor, int, int]:
+               compute: int, act: int, out_dtype: torch.dtype, nchw_out: bool = False,
+               out: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, int, int]:
     """RealConv2d.forward (enc_dec_cnn.py:97-110): conv(kernel P, stride / padding from overlap) -> adaptive_avg_pool2d to
     (H // P, W // P) -> act.  Returns the channels-last (n_img * Ht * Wt, Cout) matrix and (Ht, Wt).  x may be a bf16 image (a producer
     that rounded for the bf16 patch gather already).  nchw_out: the (n_img, Cout, Ht, Wt) fp32 image instead (a spectral layer follows):
     written by the patch GEMM's own epilogue where that route applies (round 5; the generic kernel's pixel-shuffle epilogue had been
-    measured slower than a layout copy -- 96 against 40 + 20 us at cfg5), by a layout copy of the rows otherwise."""
+    measured slower than a layout copy -- 96 against 40 + 20 us at cfg5), by a layout copy of the rows otherwise.
+    out: where the rows may be written (used when the patch-gather GEMM runs and the shape / dtype match; the caller checks identity)."""
     if H % P or W % P:
         raise ValueError("To enforce (H//P, W//P), input H and W must be divisible by patch_size.")
     s, p = stride_pad(P, overlap)
@@ -85,7 +87,8 @@ def conv_stage(x: torch.Tensor, nchw: bool, n_img: int, Cin: int, H: int, W: int
             y = torch.empty(n_img, chunks[0].N, Ht, Wt, dtype=torch.float32, device=x.device)
             K.patch_embed(x, chunks[0], y, n_img=n_img, Hin=H, Win=W, Cin=Cin, P=P, nchw=True, act=act, pad=p, nchw_out=True)
             return y, Ht, Wt
-        y = torch.empty(n_img * Ht * Wt, chunks[0].N, dtype=out_dtype, device=x.device)
+        take = (out is not None and not nchw_out and out.dtype == out_dtype and out.is_contiguous() and tuple(out.shape) == (n_img * Ht * Wt, chunks[0].N))
+        y = out if take else torch.empty(n_img * Ht * Wt, chunks[0].N, dtype=out_dtype, device=x.device)
         K.patch_embed(x, chunks[0], y, n_img=n_img, Hin=H, Win=W, Cin=Cin, P=P, nchw=True, act=act, pad=p)
         return (_rows_to_nchw(y, n_img, Ht, Wt) if nchw_out else y), Ht, Wt
     cols = K.im2col(x, nchw, n_img, Cin, H, W, P, P, s, s, p, p, 0 if nchw else 1, adt)

@@ -506,8 +506,11 @@ class TANTE(nn.Module):
         compute = resolve_compute(self.compute)
         if self._enc_cache_frames() and not self._enc_cache_fused():
             B, F = frames.shape[:2]
-            y = self.encoder.forward_tokens(frames.detach().to(torch.float32), compute, None)        # rows (b, f, hw)
-            z.copy_(y.view(B, F, self.H_p * self.W_p, self.C).transpose(0, 1))
+            # one frame: the rows (b, hw) ARE the cache entry -- the encoder's last GEMM writes them there
+            want = z.view(B * self.H_p * self.W_p, self.C) if (F == 1 and z.is_contiguous()) else None
+            y = self.encoder.forward_tokens(frames.detach().to(torch.float32), compute, None, out=want)        # rows (b, f, hw)
+            if want is None or y.data_ptr() != want.data_ptr():
+                z.copy_(y.view(B, F, self.H_p * self.W_p, self.C).transpose(0, 1))
             return z
         self.encoder.forward_frames(frames, compute, frames.stride(0), z)
         return z

@@ -383,3 +383,36 @@ def test_small_row_gemm_against_float64(dev, M, case):
     if M in (200, 256) and case == "ln_qkv":
         record_parity(rel_err(y_small.cpu(), ref.float().cpu()), max_rel(y_small.cpu(), ref.float().cpu()), tol, "bf16",
                       f"gemm_small_kernel {case} M={M} vs float64")
+
+
+def test_spectral_layer_reads_strided_frames_and_writes_rows(dev):
+    """tante_spectral_layer_x (round 6): the spectral layer on one frame of every item of a rollout buffer read IN PLACE (images a batch
+    stride apart; enc_FNO's first layer, enc_dec_fno.py:224-273) and its output as channels-last rows for the row GEMM behind dec_FNO's first
+    layer (enc_dec_fno.py:276-323) -- the same kernels with a pointer stride / the MFMA operands exchanged: bit-identical to the dense
+    call and to a layout copy of the image."""
+    import tante_amd
+    from tante_amd import _lib as L
+    torch.manual_seed(66)
+    # (a) strided frames: cfg5's first encoder layer, 8 -> 32 channels at 512 x 512, 20 x 20 modes, bf16 and fp32 output
+    lay = tante_amd.SpectralLayer(8, 32, 20, 20).to(dev)
+    buf = torch.randn(2, 3, 8, 512, 512, device=dev)
+    frame = buf[:, 1]                                     # (2, 8, 512, 512), batch stride 3 frames
+    assert not frame.is_contiguous()
+    assert L.lib().tante_spectral_layer_x_supported(2, 8, 32, 512, 512, 20, 20, 1, 1)
+    for bf16_out in (True, False):
+        y_str = lay.run(frame, L.ACT_GELU_ERF, L.BF16, bf16_out=bf16_out)
+        y_den = lay.run(frame.contiguous(), L.ACT_GELU_ERF, L.BF16, bf16_out=bf16_out)
+        assert y_str.dtype == y_den.dtype and torch.equal(y_str, y_den)
+    # (b) rows out: cfg5's first decoder layer, 128 -> 64 channels at 128 x 128, 5 x 5 modes
+    lay2 = tante_amd.SpectralLayer(128, 64, 5, 5).to(dev)
+    x = torch.randn(2, 128, 128, 128, device=dev)
+    assert L.lib().tante_spectral_layer_x_supported(2, 128, 64, 128, 128, 5, 5, 0, 2)
+    rows = lay2.run(x, L.ACT_GELU_ERF, L.BF16, nhwc_out=True)
+    img = lay2.run(x, L.ACT_GELU_ERF, L.BF16)
+    assert rows.shape == (2 * 128 * 128, 64) and torch.equal(rows.view(2, 128, 128, 64), img.permute(0, 2, 3, 1))
+    # the fp32 mode and unsupported shapes take the copy route with the same result
+    rows32 = lay2.run(x, L.ACT_NONE, L.F32, nhwc_out=True)
+    assert torch.equal(rows32.view(2, 128, 128, 64), lay2.run(x, L.ACT_NONE, L.F32).permute(0, 2, 3, 1))
+    small = tante_amd.SpectralLayer(4, 8, 3, 3).to(dev)
+    xs = torch.randn(3, 2, 4, 32, 32, device=dev)[:, 0]
+    assert torch.equal(small.run(xs, L.ACT_NONE, L.BF16), small.run(xs.contiguous(), L.ACT_NONE, L.BF16))
