@@ -584,6 +584,12 @@ typedef struct TanteFrames {
 } TanteFrames;
 int tante_film_pos_fwd_frames(const TanteFrames* frames, const float* a, const float* b, const float* s_emb, int64_t B, int T, int64_t HW, int C,
                               float* y, void* stream);
+/* (round 6) tante_film_pos_fwd_frames + the vertical propagator (tante_axis_mlp_c over (B T, n = Hp, inner = Wp C)) in ONE launch: the
+ * propagator's tile load applies a[t] v + b[t] + s_emb[hw] to the cached frames; x (B T, Hp Wp, C) is written, not read.  bf16
+ * matrix-pipe propagator shapes with C = 256 only (tante_axis_mlp_film_supported).  attn_backbone.py:140-141 on tante.py:136-141's result. */
+int tante_axis_mlp_film_supported(int64_t B, int T, int n, int64_t inner, int C);
+int tante_axis_mlp_film(float* x, const TanteFrames* frames, const float* a, const float* b, const float* s_emb, int64_t B, int T, int n,
+                        int64_t inner, int C, const float* w1, const float* b1, const float* w2, const float* b2, void* stream);
 int tante_film_pos_bwd_frames(const float* dy, const TanteFrames* frames, const float* a, int64_t B, int64_t HW, int C, int T, float* const* dv,
                               float* da, float* db, float* ds, void* stream);
 /* The same with accumulation, for a BPTT rollout: bit t of dv_acc_mask -- dv[t] is ADDED to (a frame encoding that sits in several

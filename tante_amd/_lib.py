@@ -202,6 +202,8 @@ SIGNATURES = {
     "tante_fold_bwd_clear": ([c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp], c_i32),
     "tante_fold_bwd_multi": ([c_vp, c_i32, c_i32, c_vp], c_i32),
     "tante_fold_fwd_multi": ([c_vp, c_i32, c_vp], c_i32),
+    "tante_axis_mlp_film_supported": ([c_i64, c_i32, c_i32, c_i64, c_i32], c_i32),
+    "tante_axis_mlp_film": ([c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp], c_i32),
     "tante_film_pos_fwd_frames": ([c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i64, c_i32, c_vp, c_vp], c_i32),
     "tante_film_pos_bwd_frames": ([c_vp, c_vp, c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp], c_i32),
     "tante_film_pos_bwd_frames_acc": ([c_vp, c_vp, c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp], c_i32),
@@ -245,7 +247,7 @@ SIGNATURES = {
 
 # every option name the library looks up (tante_opt in csrc/): tests/test_host_cpu.py checks this list against the sources
 LIB_OPTIONS = ("TANTE_ATTN_BWD_HG", "TANTE_ATTN_BWD_NO_SPLIT", "TANTE_ATTN_BWD_VALU", "TANTE_ATTN_FWD_VALU", "TANTE_AXIS_BWD_SMALL_WGS",
-               "TANTE_AXIS_BWD_WGS", "TANTE_AXIS_CT", "TANTE_AXIS_GENERIC", "TANTE_AXIS_MFMA", "TANTE_AXIS_NT", "TANTE_AXIS_WGRAD_WGS",
+               "TANTE_AXIS_BWD_WGS", "TANTE_AXIS_CT", "TANTE_AXIS_FILM", "TANTE_AXIS_GENERIC", "TANTE_AXIS_MFMA", "TANTE_AXIS_NT", "TANTE_AXIS_WGRAD_WGS",
                "TANTE_BLOCK_KERNEL", "TANTE_COLSUM_ROWS", "TANTE_CVIT_CHAIN_TOKENS", "TANTE_ENC23_SPLIT", "TANTE_FILM_BWD_ROWS",
                "TANTE_FS_GROUPS", "TANTE_FS_HALF", "TANTE_FS_SKEW", "TANTE_FS_WAVES", "TANTE_GEMM_NO_LITE", "TANTE_GEMM_SMALLM", "TANTE_GEMM_WGS", "TANTE_HEAD_WAVES",
                "TANTE_IM2COL_TILED", "TANTE_RESIZE_TILED", "TANTE_SPECTRAL_BF16OUT", "TANTE_SPECTRAL_DFT", "TANTE_SPECTRAL_X3", "TANTE_WGRAD_DEEP",
@@ -254,7 +256,7 @@ LIB_OPTIONS = ("TANTE_ATTN_BWD_HG", "TANTE_ATTN_BWD_NO_SPLIT", "TANTE_ATTN_BWD_V
 
 
 _lib = None
-ABI_VERSION = 12     # include/tante_hip.h: bumped whenever an entry point is added or changes (round 4: 6 tante_head_enc_*, 7 tante_pos_embed_tmajor + tante_spectral_*bf16out*; round 5: 8 tante_block_bwd_fused, 9 TanteGemm.a_pad; round 6: 10 tante_tail_*, 11 tante_attention_masked_bwd, 12 tante_spectral_layer_x)
+ABI_VERSION = 12     # include/tante_hip.h: bumped whenever an entry point is added or changes (round 4: 6 tante_head_enc_*, 7 tante_pos_embed_tmajor + tante_spectral_*bf16out*; round 5: 8 tante_block_bwd_fused, 9 TanteGemm.a_pad; round 6: 10 tante_tail_*, 11 tante_attention_masked_bwd, 12 tante_spectral_layer_x, tante_axis_mlp_film)
 
 
 def lib():

@@ -323,13 +323,23 @@ class Attn_Backbone(nn.Module):
         """forward_tokens(x, ..., x_in=other) can read its input from another buffer (the first propagator launch runs out of place)."""
         return K.axis_hw_train_supported(self.H, self.W, self.C, compute)
 
-    def forward_tokens(self, x: torch.Tensor, B: int, compute: int, film_src: Optional[tuple] = None, x_in: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def forward_tokens(self, x: torch.Tensor, B: int, compute: int, film_src: Optional[tuple] = None, x_in: Optional[torch.Tensor] = None,
+                       film_frames: Optional[tuple] = None) -> torch.Tensor:
         """In place on x = (B,T,H,W,C) fp32 contiguous.  film_src = (z, t_stride, b_stride, film): x is not read but produced from the
         frame-major pre-FiLM encoder cache z while the first propagator kernel loads its planes (TANTE.forward(enc_cache=...)).
-        x_in (takes_x_in): the input stream, left intact -- x is only written."""
+        x_in (takes_x_in): the input stream, left intact -- x is only written.
+        film_frames = (TanteFrames, the frame tensors, a, b, s_emb) (planes too large for the whole-plane kernel: the spectral path at
+        512 x 512): the same, by the vertical propagator's launch (tante_axis_mlp_film); the caller asked _supported."""
         T, H, W, C_ = self.T, self.H, self.W, self.C
         vp, hp, tp = self.vertical_propagator, self.horizontal_propagator, self.temporal_propagator
-        if x_in is not None:
+        if film_frames is not None:
+            import ctypes as C
+            fr, _keep, fa, fb, se = film_frames
+            L.check(L.lib().tante_axis_mlp_film(x.data_ptr(), C.byref(fr), fa.data_ptr(), fb.data_ptr(), se.data_ptr(), B, T, H, W * C_, C_,
+                                                vp[0].weight.data_ptr(), vp[0].bias.data_ptr(), vp[2].weight.data_ptr(), vp[2].bias.data_ptr(),
+                                                K._stream()), "tante_axis_mlp_film")
+            K.axis_mlp(x, B * T * H, W, C_, hp[0].weight, hp[0].bias, hp[2].weight, hp[2].bias, compute)      # l.142-143
+        elif x_in is not None:
             K.axis_hw_oop(x_in, x, B * T, H, W, C_, (vp[0].weight, vp[0].bias, vp[2].weight, vp[2].bias),
                           (hp[0].weight, hp[0].bias, hp[2].weight, hp[2].bias), compute)
         elif film_src is not None:

@@ -562,6 +562,7 @@ class TANTE(nn.Module):
         HW = Hp * Wp
         fa, fb = self._time_tables()
         film = (fa, fb, self.s_emb.view(HW, C_), T, HW)
+        film_frames = None
         if enc_cache is not None:
             if not self.enc_cache_supported():
                 raise RuntimeError("enc_cache: this model / compute mode has no frame-encoding cache path")
@@ -574,8 +575,16 @@ class TANTE(nn.Module):
                     if tuple(f.shape) != (B, HW, C_) or f.dtype != torch.float32 or f.stride(2) != 1 or f.stride(1) != C_ or f.data_ptr() % 16:
                         raise ValueError("enc_cache: frames must be (B, Hp*Wp, C) fp32 with contiguous rows")
                     fr.f[t], fr.bstride[t] = f.data_ptr(), f.stride(0)
-                L.check(L.lib().tante_film_pos_fwd_frames(C.byref(fr), fa.data_ptr(), fb.data_ptr(), self.s_emb.view(HW, C_).data_ptr(), B, T, HW, C_,
-                                                          x.data_ptr(), K._stream()), "tante_film_pos_fwd_frames")
+                vp0 = self.blocks[0].vertical_propagator
+                if (compute == L.BF16 and not K.axis_hw_supported(Hp, Wp, C_, compute)
+                        and L.lib().tante_axis_mlp_film_supported(B, T, Hp, Wp * C_, C_)
+                        and all(q.data_ptr() % 16 == 0 for q in (vp0[0].weight, vp0[0].bias, vp0[2].weight, vp0[2].bias, fa, fb, self.s_emb))):
+                    # the first backbone's vertical propagator applies FiLM + the positional terms while it loads its tiles
+                    # (tante_axis_mlp_film): x is produced by that launch, the pass below is not run
+                    film_frames = (fr, zc, fa, fb, self.s_emb.view(HW, C_))
+                else:
+                    L.check(L.lib().tante_film_pos_fwd_frames(C.byref(fr), fa.data_ptr(), fb.data_ptr(), self.s_emb.view(HW, C_).data_ptr(), B, T, HW, C_,
+                                                              x.data_ptr(), K._stream()), "tante_film_pos_fwd_frames")
                 enc_cache = None
         else:
             x = self.encoder.forward_tokens(inp, compute, film, bstride)                               # tante.py:132-141
@@ -608,7 +617,8 @@ class TANTE(nn.Module):
                 x_prev, x = x, torch.empty_like(x)
                 self.blocks[i].forward_tokens(x, B, compute, x_in=x_prev)
             else:
-                self.blocks[i].forward_tokens(x, B, compute, film_src=(enc_cache + (film,)) if (enc_cache is not None and i == 0) else None)  # l.146 (chained)
+                self.blocks[i].forward_tokens(x, B, compute, film_src=(enc_cache + (film,)) if (enc_cache is not None and i == 0) else None,
+                                              film_frames=film_frames if i == 0 else None)  # l.146 (chained)
             if self.deg:
                 if multi_head:
                     if i + 1 < self.taylor_order:

@@ -416,3 +416,34 @@ def test_spectral_layer_reads_strided_frames_and_writes_rows(dev):
     small = tante_amd.SpectralLayer(4, 8, 3, 3).to(dev)
     xs = torch.randn(3, 2, 4, 32, 32, device=dev)[:, 0]
     assert torch.equal(small.run(xs, L.ACT_NONE, L.BF16), small.run(xs.contiguous(), L.ACT_NONE, L.BF16))
+
+
+def test_vertical_propagator_applies_film_while_loading(dev):
+    """tante_axis_mlp_film (round 6): FiLM(t) + positional terms (tante.py:136-141) applied by the vertical propagator's tile load
+    (attn_backbone.py:140-141) to a window of cached frame encodings -- against the two launches it replaces (tante_film_pos_fwd_frames,
+    then tante_axis_mlp_c in place): the same expression per token and the same kernel behind it, bit for bit.  Frames a batch stride
+    apart and in any order (a sliding window of a frame-major cache)."""
+    import ctypes as C
+    from tante_amd import _lib as L, kernels as K
+    torch.manual_seed(67)
+    B, T, Hp, Wp, Cc = 2, 4, 64, 64, 256
+    HW = Hp * Wp
+    assert L.lib().tante_axis_mlp_film_supported(B, T, Hp, Wp * Cc, Cc)
+    cache = torch.randn(T + 2, B, HW, Cc, device=dev)
+    fa, fb = torch.randn(T, Cc, device=dev), torch.randn(T, Cc, device=dev)
+    se = torch.randn(HW, Cc, device=dev)
+    w1, w2 = torch.randn(Hp, Hp, device=dev) / 8, torch.randn(Hp, Hp, device=dev) / 8
+    b1, b2 = torch.randn(Hp, device=dev), torch.randn(Hp, device=dev)
+    fr = L.Frames()
+    for t in range(T):
+        f = cache[t + 1]
+        fr.f[t], fr.bstride[t] = f.data_ptr(), f.stride(0)
+    st = torch.cuda.current_stream().cuda_stream
+    x2 = torch.empty(B * T * HW, Cc, device=dev)
+    L.check(L.lib().tante_film_pos_fwd_frames(C.byref(fr), fa.data_ptr(), fb.data_ptr(), se.data_ptr(), B, T, HW, Cc, x2.data_ptr(), st))
+    K.axis_mlp(x2, B * T, Hp, Wp * Cc, w1, b1, w2, b2, L.BF16)
+    x1 = torch.full((B * T * HW, Cc), float("nan"), device=dev)
+    L.check(L.lib().tante_axis_mlp_film(x1.data_ptr(), C.byref(fr), fa.data_ptr(), fb.data_ptr(), se.data_ptr(), B, T, Hp, Wp * Cc, Cc,
+                                        w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), st))
+    assert torch.equal(x1, x2)
+    assert not L.lib().tante_axis_mlp_film_supported(B, T, Hp, Wp * 128, 128)
